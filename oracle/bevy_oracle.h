@@ -1,0 +1,239 @@
+/*
+ * bevy_oracle.h -- CPU ORACLE for the propagate -> cull -> cluster render-prep path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it, and only as the checker / reported
+ * baseline.  The product (bevy_amd/, include/) never links, imports or calls it.
+ *
+ * It is a plain-C restatement of the reference's CPU systems (bevyengine/bevy @ v0.20.0-dev,
+ * paths relative to /root/reference) and of the glam 0.33.2 SSE2 arithmetic they call
+ * (glam is a crates.io dependency, crates/bevy_math/Cargo.toml:13, NOT present under
+ * /root/reference; its published algorithm is restated, see the per-function notes).
+ *
+ * PARITY PINNING STATUS
+ *   - Frustum/sphere/OBB/half-space tests: pinned against every known-answer vector in
+ *     crates/bevy_camera/src/primitives.rs:462-857 and benches/benches/bevy_camera/primitives.rs:41-52
+ *     (tests/test_oracle_golden.py).
+ *   - Transform propagation: pinned against the exact-equality tests in
+ *     crates/bevy_transform/src/systems.rs:827-1221 and helper.rs:97-146.
+ *   - ViewVisibility bit protocol: pinned against visibility/mod.rs:1313-1448.
+ *   - Cluster tiling: pinned against crates/bevy_light/src/cluster/test.rs.
+ *   - assign_objects_to_clusters: PARITY UNPINNED by the reference (it has no test that
+ *     exercises it); the restatement below is the spec, cross-checked by invariants.
+ *   - Last-ulp order of glam's SSE2 lanes: PARITY UNPINNED here (no Rust toolchain, glam
+ *     source absent); the operation order is restated from glam's published source.
+ *
+ * Data conventions (shared with include/bevy_mi355x.h):
+ *   translation f32[3n], rotation f32[4n] (x,y,z,w), scale f32[3n]
+ *   global transform f32[12n] = Affine3A::to_cols_array(): x_axis, y_axis, z_axis, translation
+ *   aabb center f32[3n], half extents f32[3n]; sphere = (center, half.x as radius)
+ *   frusta f32[V*24]: six half-spaces (nx,ny,nz,d), order left,right,top,bottom,near,far
+ */
+#ifndef BEVY_ORACLE_H
+#define BEVY_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* entity flag bits (same values as MI_FLAG_* in include/bevy_mi355x.h) */
+#define ORC_FLAG_INHERITED_VISIBLE   0x01u
+#define ORC_FLAG_NO_FRUSTUM_CULLING  0x02u
+#define ORC_FLAG_HAS_AABB            0x04u
+#define ORC_FLAG_HAS_SPHERE          0x08u
+#define ORC_FLAG_NO_CPU_CULLING      0x10u
+#define ORC_FLAG_HAS_VISIBILITY_RANGE 0x20u
+
+#define ORC_VIEW_FLAG_NO_CPU_CULLING 0x01u
+
+#define ORC_NO_PARENT 0xFFFFFFFFu
+
+/* ---- glam / bevy_math primitives ------------------------------------------------------- */
+
+/* Transform::compute_affine, crates/bevy_transform/src/components/transform.rs:273-275 */
+void orc_transform_to_affine(const float t[3], const float r[4], const float s[3], float out[12]);
+/* Affine3A * Affine3A (GlobalTransform::mul_transform is a * affine(T)), global_transform.rs:315-317 */
+void orc_affine_mul(const float a[12], const float b[12], float out[12]);
+/* Affine3A::inverse */
+void orc_affine_inverse(const float a[12], float out[12]);
+/* Affine3A::transform_point3a */
+void orc_affine_transform_point(const float a[12], const float p[3], float out[3]);
+/* GlobalTransform::radius_vec3a, global_transform.rs:252-254 */
+float orc_radius_vec3a(const float a[12], const float extents[3]);
+/* HalfSpace::new, crates/bevy_math/src/primitives/half_space.rs:53-57 */
+void orc_half_space_new(const float normal_d[4], float out[4]);
+/* Mat4::inverse (col-major 16) */
+void orc_mat4_inverse(const float m[16], float out[16]);
+void orc_mat4_mul(const float a[16], const float b[16], float out[16]);
+void orc_mat4_mul_vec4(const float m[16], const float v[4], float out[4]);
+/* glam::camera::rh::proj::directx::perspective_infinite_reverse (bevy_math/src/lib.rs:57) */
+void orc_perspective_infinite_reverse(float fov, float aspect, float near, float out[16]);
+/* CameraProjection::compute_frustum for PerspectiveProjection,
+ * crates/bevy_camera/src/projection.rs:72-80,339-343; view_frustum.rs:43-108 */
+void orc_compute_frustum_perspective(float fov, float aspect, float near, float far,
+                                     const float camera_affine[12], float out_frustum[24]);
+/* ViewFrustum::from_clip_from_world (far = row 2), view_frustum.rs:43-47 */
+void orc_frustum_from_clip_from_world(const float clip_from_world[16], float out_frustum[24]);
+
+/* Frustum::intersects_sphere, crates/bevy_camera/src/primitives.rs:255-268 */
+int orc_frustum_intersects_sphere(const float frustum[24], const float center[3], float radius,
+                                  int intersect_far);
+/* Frustum::intersects_obb, primitives.rs:272-294 */
+int orc_frustum_intersects_obb(const float frustum[24], const float aabb_center[3],
+                               const float aabb_half[3], const float world_from_local[12],
+                               int intersect_near, int intersect_far);
+/* Frustum::intersects_obb_identity, primitives.rs:299-309 */
+int orc_frustum_intersects_obb_identity(const float frustum[24], const float aabb_center[3],
+                                        const float aabb_half[3]);
+/* Frustum::contains_aabb / Aabb::is_in_half_space, primitives.rs:134-143,314-321 */
+int orc_frustum_contains_aabb(const float frustum[24], const float aabb_center[3],
+                              const float aabb_half[3], const float world_from_local[12]);
+int orc_aabb_is_in_half_space(const float aabb_center[3], const float aabb_half[3],
+                              const float half_space[4], const float world_from_local[12]);
+int orc_aabb_is_in_half_space_identity(const float aabb_center[3], const float aabb_half[3],
+                                       const float half_space[4]);
+/* Sphere::intersects_obb, primitives.rs:219-226 */
+int orc_sphere_intersects_obb(const float sphere_center[3], float sphere_radius,
+                              const float aabb_center[3], const float aabb_half[3],
+                              const float world_from_local[12]);
+
+/* ---- transform propagation -------------------------------------------------------------- */
+
+/* sync_simple_transforms, crates/bevy_transform/src/systems.rs:42-79.
+ * Rows with dirty==NULL or dirty[i]!=0 get G = From(T).  Rows are assumed flat (no ChildOf,
+ * no Children).  changed_out (optional, u8 per row) is set for every written row. */
+void orc_sync_simple_transforms(uint32_t n, const float* translation, const float* rotation,
+                                const float* scale, const uint8_t* dirty, float* global,
+                                uint8_t* changed_out);
+
+/* mark_dirty_trees, systems.rs:111-306: tree_changed |= ancestors-or-self of every changed row. */
+void orc_mark_dirty_trees(uint32_t n, const uint32_t* parent, const uint8_t* changed,
+                          uint8_t* tree_changed);
+
+/* mark_dirty_trees + sync_simple_transforms + propagate_parent_transforms (parallel flavour,
+ * systems.rs:506-748) over rows in ARBITRARY order.  parent[i] = row of the ChildOf target or
+ * ORC_NO_PARENT.  static_opt != 0 -> StaticTransformOptimizations::Enabled.
+ *   tree_changed (u8[n] or NULL = all changed): TransformTreeChanged.is_changed()
+ *   transform_changed (u8[n] or NULL = all): Changed<Transform> || Added<GlobalTransform>
+ *       (only consulted for flat rows -- those with neither parent nor children)
+ *   global: in/out (old values are needed by set_if_neq, systems.rs:719)
+ *   changed_out (u8[n], optional): 1 where GlobalTransform's change tick would be bumped.
+ * Returns 0, or -1 if the parent array contains a cycle / out-of-range parent
+ * (the reference panics, systems.rs:715). */
+int orc_propagate_transforms(uint32_t n, const uint32_t* parent, const float* translation,
+                             const float* rotation, const float* scale, int static_opt,
+                             const uint8_t* tree_changed, const uint8_t* transform_changed,
+                             float* global, uint8_t* changed_out);
+
+/* TransformHelper::compute_global_transform, crates/bevy_transform/src/helper.rs:28-50:
+ * independent definition (leaf affine, left-multiplied by each ancestor's Transform). */
+int orc_compute_global_transform(uint32_t n, const uint32_t* parent, const float* translation,
+                                 const float* rotation, const float* scale, uint32_t row,
+                                 float out[12]);
+
+/* ---- visibility ------------------------------------------------------------------------- */
+
+/* reset_view_visibility, crates/bevy_camera/src/visibility/mod.rs:733-737 (+ :270-274) */
+void orc_reset_view_visibility(uint32_t n, const uint8_t* flags, uint8_t* view_visibility);
+/* check_visibility_cpu_culling, visibility/mod.rs:748-876.
+ *   in_range: optional u8[n_views*n] (VisibleEntityRanges::entity_is_in_range_of_view), NULL = all in range
+ *   visible_out: u8[n_views*n], 1 where the entity reached set_visible() for that view
+ *   vv_changed_out: optional u8[n], 1 where set_visible() bumped the change tick (:290-306) */
+void orc_check_visibility(uint32_t n, const float* global, const float* aabb_center,
+                          const float* aabb_half, const uint8_t* flags, const uint32_t* layer_mask,
+                          const uint8_t* in_range, uint8_t* view_visibility, const float* frusta,
+                          const uint32_t* view_layer_masks, const uint8_t* view_flags,
+                          uint32_t n_views, uint8_t* visible_out, uint8_t* vv_changed_out);
+/* check_visibility_gpu_culling, visibility/mod.rs:884-903 (applied to every NoCpuCulling row) */
+void orc_check_visibility_gpu_culling(uint32_t n, const uint8_t* flags, uint8_t* view_visibility,
+                                      uint8_t* vv_changed_out);
+/* mark_newly_hidden_entities_invisible, visibility/mod.rs:908-918 */
+void orc_mark_newly_hidden(uint32_t n, const uint8_t* flags, uint8_t* view_visibility,
+                           uint8_t* vv_changed_out);
+/* VisibleEntities for one (view, class): sorted Entity::to_bits keys (mod.rs:852-874).
+ * visible: u8[n] for this view; class_mask: u32[n]; returns count written to out_keys/out_rows. */
+uint32_t orc_visible_entities_sorted(uint32_t n, const uint8_t* visible, const uint32_t* class_mask,
+                                     uint32_t class_bit, const uint64_t* entity_keys,
+                                     uint64_t* out_keys, uint32_t* out_rows);
+
+/* ---- light clustering ------------------------------------------------------------------- */
+
+#define ORC_OBJ_POINT_LIGHT 0
+#define ORC_OBJ_SPOT_LIGHT 1
+#define ORC_OBJ_RECT_LIGHT 2
+#define ORC_OBJ_REFLECTION_PROBE 3
+#define ORC_OBJ_IRRADIANCE_VOLUME 4
+#define ORC_OBJ_DECAL 5
+
+#define ORC_MAX_CLUSTER_DIM 4096
+
+typedef struct orc_cluster_view {
+    uint32_t dims[3];
+    uint32_t tile_size[2];
+    uint32_t screen_size[2];
+    uint32_t is_orthographic;
+    uint32_t view_layer_mask;
+    float near_; /* clusters.near = first_slice_depth (scaled) */
+    float far_;  /* clusters.far */
+    float cluster_factors[2];
+    float view_from_world[16]; /* col-major Mat4 */
+    float clip_from_view[16];
+    float view_from_clip[16];
+    float view_from_world_scale[3];
+    float view_from_world_scale_max;
+    float frustum[24];
+    uint32_t n_x_planes, n_y_planes, n_z_planes;
+    float x_planes[(ORC_MAX_CLUSTER_DIM + 1) * 4];
+    float y_planes[(ORC_MAX_CLUSTER_DIM + 1) * 4];
+    float z_planes[(ORC_MAX_CLUSTER_DIM + 1) * 4];
+} orc_cluster_view;
+
+/* ClusterConfig::dimensions_for_screen_size (FixedZ), crates/bevy_light/src/cluster/mod.rs:311-347 */
+void orc_cluster_dimensions_fixed_z(uint32_t total, uint32_t z_slices, uint32_t screen_w,
+                                    uint32_t screen_h, uint32_t out_dims[3]);
+/* Clusters::update, cluster/mod.rs:398-416 */
+void orc_clusters_update(uint32_t screen_w, uint32_t screen_h, const uint32_t requested[3],
+                         uint32_t out_tile_size[2], uint32_t out_dims[3]);
+/* Per-view setup of assign_objects_to_clusters, cluster/assign.rs:342-485.
+ * far_z: the value selected by ClusterFarZMode (:350-355); first_slice_depth_cfg: config value. */
+void orc_cluster_view_setup(const float camera_affine[12], const float clip_from_view[16],
+                            const float frustum[24], uint32_t screen_w, uint32_t screen_h,
+                            const uint32_t requested_dims[3], float first_slice_depth_cfg,
+                            float far_z, uint32_t view_layer_mask, orc_cluster_view* out);
+/* compute_aabb_for_cluster -> bounding sphere, assign.rs:693-707,834-900.  out[4] = center, radius */
+void orc_cluster_aabb_sphere(const orc_cluster_view* view, uint32_t x, uint32_t y, uint32_t z,
+                             float out[4]);
+
+/* Per-object loop of assign_objects_to_clusters, assign.rs:487-811.
+ * Objects are given in gather order (:190-296).  For spot lights spot_dir = transform.back()
+ * (world space, unnormalised input is fine: it is re-normalised in view space :567-569) and
+ * spot_sin_cos = sin_cos(outer_angle).
+ * Output is the per-cluster Vec<Entity> in push order, flattened CSR:
+ *   offsets u32[C+1], indices (object index) u32[capacity], counts u32[6*C] by object type.
+ * Returns total_cluster_index_count (may exceed capacity: then only counts/offsets are valid). */
+uint64_t orc_assign_objects_to_clusters(const orc_cluster_view* view, uint32_t n_objects,
+                                        const float* pos_range /*4n*/, const uint8_t* obj_type,
+                                        const uint32_t* obj_layer_mask /*NULL = all default*/,
+                                        const float* spot_dir /*3n or NULL*/,
+                                        const float* spot_sin_cos /*2n or NULL*/,
+                                        uint32_t* offsets, uint32_t* indices, uint64_t capacity,
+                                        uint32_t* counts, float* farthest_z_out);
+
+/* ---- CPU baseline drivers (Bevy-shaped: ceil(n/threads) batches, batching.rs:95-106) ---- */
+
+/* One frame of the flat path on `threads` pthreads: sync_simple_transforms (all dirty) +
+ * reset + check_visibility (n_views) + mark_newly_hidden.  Returns seconds for `iters` frames. */
+double orc_bench_flat_frame(uint32_t n, const float* translation, const float* rotation,
+                            const float* scale, const float* aabb_center, const float* aabb_half,
+                            const uint8_t* flags, const uint32_t* layer_mask, float* global,
+                            uint8_t* view_visibility, uint8_t* visible_out, const float* frusta,
+                            const uint32_t* view_layer_masks, const uint8_t* view_flags,
+                            uint32_t n_views, int threads, int iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,319 @@
+"""ctypes binding of the CPU oracle (oracle/libbevy_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (bevy_amd) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_SO = os.path.join(ORACLE_DIR, "libbevy_oracle.so")
+
+FLAG_INHERITED_VISIBLE = 0x01
+FLAG_NO_FRUSTUM_CULLING = 0x02
+FLAG_HAS_AABB = 0x04
+FLAG_HAS_SPHERE = 0x08
+FLAG_NO_CPU_CULLING = 0x10
+FLAG_HAS_VISIBILITY_RANGE = 0x20
+NO_PARENT = 0xFFFFFFFF
+MAX_CLUSTER_DIM = 4096
+
+
+def build():
+    """(Re)build the oracle .so if it is missing or older than its sources."""
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("bevy_oracle.c", "bevy_oracle.h", "Makefile")]
+    if os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs):
+        return _SO
+    subprocess.run(["make", "-C", ORACLE_DIR], check=True, capture_output=True)
+    return _SO
+
+
+class ClusterView(C.Structure):
+    _fields_ = [
+        ("dims", C.c_uint32 * 3),
+        ("tile_size", C.c_uint32 * 2),
+        ("screen_size", C.c_uint32 * 2),
+        ("is_orthographic", C.c_uint32),
+        ("view_layer_mask", C.c_uint32),
+        ("near_", C.c_float),
+        ("far_", C.c_float),
+        ("cluster_factors", C.c_float * 2),
+        ("view_from_world", C.c_float * 16),
+        ("clip_from_view", C.c_float * 16),
+        ("view_from_clip", C.c_float * 16),
+        ("view_from_world_scale", C.c_float * 3),
+        ("view_from_world_scale_max", C.c_float),
+        ("frustum", C.c_float * 24),
+        ("n_x_planes", C.c_uint32),
+        ("n_y_planes", C.c_uint32),
+        ("n_z_planes", C.c_uint32),
+        ("x_planes", C.c_float * ((MAX_CLUSTER_DIM + 1) * 4)),
+        ("y_planes", C.c_float * ((MAX_CLUSTER_DIM + 1) * 4)),
+        ("z_planes", C.c_float * ((MAX_CLUSTER_DIM + 1) * 4)),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.orc_radius_vec3a.restype = C.c_float
+        _lib.orc_bench_flat_frame.restype = C.c_double
+        _lib.orc_assign_objects_to_clusters.restype = C.c_uint64
+        _lib.orc_visible_entities_sorted.restype = C.c_uint32
+    return _lib
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _p(a, ty):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(ty))
+
+
+def fp(a):
+    return _p(a, C.c_float)
+
+
+def u8p(a):
+    return _p(a, C.c_uint8)
+
+
+def u32p(a):
+    return _p(a, C.c_uint32)
+
+
+def u64p(a):
+    return _p(a, C.c_uint64)
+
+
+# ---- primitive wrappers ------------------------------------------------------------------
+
+def transform_to_affine(t, r, s):
+    t, tp = _f(t); r, rp = _f(r); s, sp = _f(s)
+    out = np.zeros(12, np.float32)
+    lib().orc_transform_to_affine(tp, rp, sp, fp(out))
+    return out
+
+
+def affine_mul(a, b):
+    a, ap = _f(a); b, bp = _f(b)
+    out = np.zeros(12, np.float32)
+    lib().orc_affine_mul(ap, bp, fp(out))
+    return out
+
+
+def half_space_new(nd):
+    nd, p = _f(nd)
+    out = np.zeros(4, np.float32)
+    lib().orc_half_space_new(p, fp(out))
+    return out
+
+
+def frustum_from_planes(planes):
+    """HalfSpace::new applied to six raw Vec4s (the form the reference tests use)."""
+    return np.concatenate([half_space_new(p) for p in planes]).astype(np.float32)
+
+
+def compute_frustum_perspective(fov, aspect, near, far, camera_affine):
+    cam, cp = _f(camera_affine)
+    out = np.zeros(24, np.float32)
+    lib().orc_compute_frustum_perspective(C.c_float(fov), C.c_float(aspect), C.c_float(near), C.c_float(far), cp, fp(out))
+    return out
+
+
+def perspective_infinite_reverse(fov, aspect, near):
+    out = np.zeros(16, np.float32)
+    lib().orc_perspective_infinite_reverse(C.c_float(fov), C.c_float(aspect), C.c_float(near), fp(out))
+    return out
+
+
+def intersects_sphere(frustum, center, radius, intersect_far):
+    fr, frp = _f(frustum); c, cp = _f(center)
+    return bool(lib().orc_frustum_intersects_sphere(frp, cp, C.c_float(radius), int(intersect_far)))
+
+
+def intersects_obb(frustum, center, half, wfl, near, far):
+    fr, frp = _f(frustum); c, cp = _f(center); h, hp = _f(half); w, wp = _f(wfl)
+    return bool(lib().orc_frustum_intersects_obb(frp, cp, hp, wp, int(near), int(far)))
+
+
+def intersects_obb_identity(frustum, center, half):
+    fr, frp = _f(frustum); c, cp = _f(center); h, hp = _f(half)
+    return bool(lib().orc_frustum_intersects_obb_identity(frp, cp, hp))
+
+
+def contains_aabb(frustum, center, half, wfl):
+    fr, frp = _f(frustum); c, cp = _f(center); h, hp = _f(half); w, wp = _f(wfl)
+    return bool(lib().orc_frustum_contains_aabb(frp, cp, hp, wp))
+
+
+def is_in_half_space(center, half, hs, wfl):
+    c, cp = _f(center); h, hp = _f(half); s, sp = _f(hs); w, wp = _f(wfl)
+    return bool(lib().orc_aabb_is_in_half_space(cp, hp, sp, wp))
+
+
+def is_in_half_space_identity(center, half, hs):
+    c, cp = _f(center); h, hp = _f(half); s, sp = _f(hs)
+    return bool(lib().orc_aabb_is_in_half_space_identity(cp, hp, sp))
+
+
+def sphere_intersects_obb(sc, sr, center, half, wfl):
+    s, sp = _f(sc); c, cp = _f(center); h, hp = _f(half); w, wp = _f(wfl)
+    return bool(lib().orc_sphere_intersects_obb(sp, C.c_float(sr), cp, hp, wp))
+
+
+# ---- systems -------------------------------------------------------------------------------
+
+def sync_simple_transforms(t, r, s, dirty=None, global_in=None):
+    n = len(t) // 3
+    g = np.zeros(12 * n, np.float32) if global_in is None else global_in.copy()
+    changed = np.zeros(n, np.uint8)
+    lib().orc_sync_simple_transforms(n, fp(t), fp(r), fp(s), u8p(dirty), fp(g), u8p(changed))
+    return g, changed
+
+
+def mark_dirty_trees(parent, changed):
+    n = len(parent)
+    tc = np.zeros(n, np.uint8)
+    lib().orc_mark_dirty_trees(n, u32p(parent), u8p(changed), u8p(tc))
+    return tc
+
+
+def propagate_transforms(parent, t, r, s, global_in=None, static_opt=False, tree_changed=None,
+                         transform_changed=None):
+    n = len(parent)
+    g = np.zeros(12 * n, np.float32) if global_in is None else global_in.copy()
+    changed = np.zeros(n, np.uint8)
+    rc = lib().orc_propagate_transforms(n, u32p(parent), fp(t), fp(r), fp(s), int(static_opt),
+                                        u8p(tree_changed), u8p(transform_changed), fp(g), u8p(changed))
+    return rc, g, changed
+
+
+def compute_global_transform(parent, t, r, s, row):
+    out = np.zeros(12, np.float32)
+    rc = lib().orc_compute_global_transform(len(parent), u32p(parent), fp(t), fp(r), fp(s), int(row), fp(out))
+    assert rc == 0
+    return out
+
+
+def reset_view_visibility(flags, vv):
+    vv = vv.copy()
+    lib().orc_reset_view_visibility(len(vv), u8p(flags), u8p(vv))
+    return vv
+
+
+def check_visibility(g, c, h, flags, layers, vv, frusta, view_masks=None, view_flags=None, in_range=None):
+    n = len(flags)
+    nv = len(frusta) // 24
+    vv = vv.copy()
+    vis = np.zeros(nv * n, np.uint8)
+    chg = np.zeros(n, np.uint8)
+    lib().orc_check_visibility(n, fp(g), fp(c), fp(h), u8p(flags), u32p(layers), u8p(in_range), u8p(vv),
+                               fp(frusta), u32p(view_masks), u8p(view_flags), nv, u8p(vis), u8p(chg))
+    return vv, vis.reshape(nv, n), chg
+
+
+def check_visibility_gpu_culling(flags, vv):
+    vv = vv.copy()
+    chg = np.zeros(len(vv), np.uint8)
+    lib().orc_check_visibility_gpu_culling(len(vv), u8p(flags), u8p(vv), u8p(chg))
+    return vv, chg
+
+
+def mark_newly_hidden(flags, vv):
+    vv = vv.copy()
+    chg = np.zeros(len(vv), np.uint8)
+    lib().orc_mark_newly_hidden(len(vv), u8p(flags), u8p(vv), u8p(chg))
+    return vv, chg
+
+
+def visible_entities_sorted(visible, class_mask, class_bit, entity_keys):
+    n = len(visible)
+    keys = np.zeros(n, np.uint64)
+    rows = np.zeros(n, np.uint32)
+    m = lib().orc_visible_entities_sorted(n, u8p(visible), u32p(class_mask), int(class_bit), u64p(entity_keys),
+                                          u64p(keys), u32p(rows))
+    return keys[:m].copy(), rows[:m].copy()
+
+
+def full_frame(t, r, s, c, h, flags, layers, vv, frusta, view_masks=None, view_flags=None):
+    """reset -> sync_simple (all dirty) -> check_visibility -> gpu_culling rows -> mark_newly_hidden."""
+    g, _ = sync_simple_transforms(t, r, s)
+    vv1 = reset_view_visibility(flags, vv)
+    vv2, vis, chg = check_visibility(g, c, h, flags, layers, vv1, frusta, view_masks, view_flags)
+    vv3, chg2 = check_visibility_gpu_culling(flags, vv2)
+    vv4, chg3 = mark_newly_hidden(flags, vv3)
+    return g, vv4, vis, (chg | chg2 | chg3)
+
+
+# ---- clustering ------------------------------------------------------------------------------
+
+def cluster_dimensions_fixed_z(total, z_slices, w, h):
+    out = (C.c_uint32 * 3)()
+    lib().orc_cluster_dimensions_fixed_z(total, z_slices, w, h, out)
+    return tuple(out)
+
+
+def clusters_update(w, h, req):
+    tile = (C.c_uint32 * 2)()
+    dims = (C.c_uint32 * 3)()
+    lib().orc_clusters_update(w, h, (C.c_uint32 * 3)(*req), tile, dims)
+    return tuple(tile), tuple(dims)
+
+
+def cluster_view_setup(camera_affine, clip_from_view, frustum, w, h, requested_dims, first_slice_depth, far_z,
+                       view_layer_mask=1):
+    view = ClusterView()
+    cam, camp = _f(camera_affine); cfv, cfvp = _f(clip_from_view); fr, frp = _f(frustum)
+    lib().orc_cluster_view_setup(camp, cfvp, frp, w, h, (C.c_uint32 * 3)(*requested_dims),
+                                 C.c_float(first_slice_depth), C.c_float(far_z), view_layer_mask, C.byref(view))
+    return view
+
+
+def cluster_aabb_sphere(view, x, y, z):
+    out = np.zeros(4, np.float32)
+    lib().orc_cluster_aabb_sphere(C.byref(view), x, y, z, fp(out))
+    return out
+
+
+def assign_objects_to_clusters(view, pos_range, obj_type=None, layer_mask=None, spot_dir=None, spot_sin_cos=None,
+                               capacity=None):
+    n = len(pos_range) // 4
+    ncl = view.dims[0] * view.dims[1] * view.dims[2]
+    offsets = np.zeros(ncl + 1, np.uint32)
+    counts = np.zeros(6 * ncl, np.uint32)
+    far = C.c_float(0)
+    if capacity is None:
+        total = lib().orc_assign_objects_to_clusters(C.byref(view), n, fp(pos_range), u8p(obj_type), u32p(layer_mask),
+                                                     fp(spot_dir), fp(spot_sin_cos), u32p(offsets), None,
+                                                     C.c_uint64(0), u32p(counts), C.byref(far))
+        capacity = int(total)
+    indices = np.zeros(max(capacity, 1), np.uint32)
+    total = lib().orc_assign_objects_to_clusters(C.byref(view), n, fp(pos_range), u8p(obj_type), u32p(layer_mask),
+                                                 fp(spot_dir), fp(spot_sin_cos), u32p(offsets), u32p(indices),
+                                                 C.c_uint64(capacity), u32p(counts), C.byref(far))
+    return offsets, indices[:min(int(total), capacity)], counts.reshape(ncl, 6), float(far.value), int(total)
+
+
+def bench_flat_frame(t, r, s, c, h, flags, layers, frusta, threads, iters):
+    n = len(flags)
+    nv = len(frusta) // 24
+    g = np.zeros(12 * n, np.float32)
+    vv = np.zeros(n, np.uint8)
+    vis = np.zeros(nv * n, np.uint8)
+    secs = lib().orc_bench_flat_frame(n, fp(t), fp(r), fp(s), fp(c), fp(h), u8p(flags), u32p(layers), fp(g), u8p(vv),
+                                      u8p(vis), fp(frusta), None, None, nv, int(threads), int(iters))
+    return float(secs), g, vv, vis.reshape(nv, n)

@@ -1,0 +1,31 @@
+"""bevy_amd -- MI355X-native render-prep path for Bevy (transform propagate -> frustum cull ->
+light-cluster assign) as hand-written HIP kernels behind a C ABI (include/bevy_mi355x.h).
+
+The product is `libbevy_mi355x.so` (csrc/); this package is only the plumbing that tests and
+bench.py use to reach the C ABI from Python (ctypes).  There is NO CPU fallback: every compute entry
+point needs a gfx950 device and raises `MiError` otherwise.
+"""
+from .api import (  # noqa: F401
+    ClusterView,
+    Context,
+    MiError,
+    cluster_dimensions_fixed_z,
+    cluster_view_build,
+    compute_frustum,
+    hierarchy_sort,
+    lib_path,
+    load_library,
+    perspective_clip_from_view,
+)
+from . import workloads  # noqa: F401
+
+FLAG_INHERITED_VISIBLE = 0x01
+FLAG_NO_FRUSTUM_CULLING = 0x02
+FLAG_HAS_AABB = 0x04
+FLAG_HAS_SPHERE = 0x08
+FLAG_NO_CPU_CULLING = 0x10
+FLAG_HAS_VISIBILITY_RANGE = 0x20
+VIEW_FLAG_NO_CPU_CULLING = 0x01
+PROPAGATE_ALL_DIRTY = 0x1
+PROPAGATE_STATIC_OPT = 0x2
+NO_PARENT = 0xFFFFFFFF

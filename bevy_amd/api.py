@@ -1,0 +1,422 @@
+"""ctypes binding of include/bevy_mi355x.h.  Thin by design: one Python method per C entry point,
+numpy arrays in / out, status codes turned into MiError.  No compute happens in Python."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libbevy_mi355x.so")
+
+MI_OK = 0
+MI_ERR_INVALID_ARG = -1
+MI_ERR_DEVICE = -2
+MI_ERR_OUT_OF_MEMORY = -3
+MI_ERR_MALFORMED_HIERARCHY = -4
+MI_ERR_NOT_READY = -5
+MI_ERR_CAPACITY = -6
+
+
+class MiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"bevy_mi355x error {code}: {msg}")
+        self.code = code
+
+
+class ClusterView(C.Structure):
+    """mi_cluster_view"""
+    _fields_ = [
+        ("dims", C.c_uint32 * 3),
+        ("tile_size", C.c_uint32 * 2),
+        ("screen_size", C.c_uint32 * 2),
+        ("is_orthographic", C.c_uint32),
+        ("view_layer_mask", C.c_uint32),
+        ("near_", C.c_float),
+        ("far_", C.c_float),
+        ("cluster_factors", C.c_float * 2),
+        ("view_from_world", C.c_float * 16),
+        ("clip_from_view", C.c_float * 16),
+        ("view_from_clip", C.c_float * 16),
+        ("view_from_world_scale", C.c_float * 3),
+        ("view_from_world_scale_max", C.c_float),
+        ("frustum", C.c_float * 24),
+        ("x_planes", C.POINTER(C.c_float)),
+        ("y_planes", C.POINTER(C.c_float)),
+        ("z_planes", C.POINTER(C.c_float)),
+        ("cluster_spheres", C.POINTER(C.c_float)),
+    ]
+
+    @property
+    def n_clusters(self):
+        return self.dims[0] * self.dims[1] * self.dims[2]
+
+
+_lib = None
+
+# every symbol include/bevy_mi355x.h declares (tests/test_abi.py checks header <-> library <-> this list)
+ABI_SYMBOLS = [
+    "mi_abi_version", "mi_ctx_create", "mi_ctx_destroy", "mi_last_error_string", "mi_synchronize",
+    "mi_columns_resize", "mi_upload_transforms", "mi_upload_global_transforms", "mi_upload_bounds",
+    "mi_upload_view_visibility", "mi_upload_visibility_classes", "mi_upload_entity_keys", "mi_upload_changed",
+    "mi_upload_view_ranges", "mi_upload_hierarchy", "mi_hierarchy_sort", "mi_propagate",
+    "mi_visibility_begin_frame", "mi_cull", "mi_propagate_and_cull", "mi_visibility_end_frame",
+    "mi_download_global_transforms", "mi_download_visibility", "mi_download_view_visibility",
+    "mi_download_visible_entities", "mi_cluster_view_dims", "mi_cluster_view_build",
+    "mi_cluster_dimensions_fixed_z", "mi_cluster_assign", "mi_cluster_upload_objects", "mi_cluster_upload_view",
+    "mi_cluster_assign_resident", "mi_cluster_download", "mi_perspective_clip_from_view", "mi_compute_frustum",
+    "mi_bind_visibility_output", "mi_device_buffer", "mi_timer_begin", "mi_timer_end", "mi_profile_enable",
+    "mi_profile_filter", "mi_profile_read", "mi_profile_kernel_name",
+]
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """Loads libbevy_mi355x.so.  Fails loudly if it has not been built (python -m bevy_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise MiError(MI_ERR_DEVICE, f"{_LIB_PATH} is missing: build it with `python -m bevy_amd.build` "
+                                     "(there is no CPU fallback)")
+    lib = C.CDLL(_LIB_PATH)
+    lib.mi_last_error_string.restype = C.c_char_p
+    lib.mi_last_error_string.argtypes = [C.c_void_p]
+    lib.mi_profile_kernel_name.restype = C.c_char_p
+    for name in ABI_SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("mi_last_error_string", "mi_profile_kernel_name"):
+            fn.restype = C.c_int32
+    _lib = lib
+    return lib
+
+
+def _ptr(a, ty):
+    if a is None:
+        return None
+    assert isinstance(a, np.ndarray) and a.flags["C_CONTIGUOUS"], "need a C-contiguous numpy array"
+    return a.ctypes.data_as(C.POINTER(ty))
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _u8(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def _u32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _u64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def _host_check(rc, what):
+    if rc != MI_OK:
+        raise MiError(rc, f"{what} failed")
+
+
+# ---- pure host helpers -------------------------------------------------------------------------
+
+def perspective_clip_from_view(fov, aspect, near):
+    out = np.zeros(16, np.float32)
+    _host_check(load_library().mi_perspective_clip_from_view(C.c_float(fov), C.c_float(aspect), C.c_float(near),
+                                                             _ptr(out, C.c_float)), "mi_perspective_clip_from_view")
+    return out
+
+
+def compute_frustum(clip_from_view, camera_affine, far):
+    cfv, cam = _f32(clip_from_view), _f32(camera_affine)
+    out = np.zeros(24, np.float32)
+    _host_check(load_library().mi_compute_frustum(_ptr(cfv, C.c_float), _ptr(cam, C.c_float), C.c_float(far),
+                                                  _ptr(out, C.c_float)), "mi_compute_frustum")
+    return out
+
+
+def cluster_dimensions_fixed_z(total, z_slices, w, h):
+    out = (C.c_uint32 * 3)()
+    _host_check(load_library().mi_cluster_dimensions_fixed_z(total, z_slices, w, h, out), "mi_cluster_dimensions_fixed_z")
+    return tuple(out)
+
+
+def cluster_view_build(camera_affine, clip_from_view, frustum, w, h, requested_dims, first_slice_depth, far_z,
+                       view_layer_mask=1, with_spheres=True):
+    """Returns (ClusterView, keepalive) -- keepalive owns the plane / sphere storage the view points into."""
+    lib = load_library()
+    req = (C.c_uint32 * 3)(*requested_dims)
+    tile = (C.c_uint32 * 2)()
+    dims = (C.c_uint32 * 3)()
+    _host_check(lib.mi_cluster_view_dims(w, h, req, tile, dims), "mi_cluster_view_dims")
+    planes = np.zeros((dims[0] + dims[1] + dims[2] + 3) * 4, np.float32)
+    spheres = np.zeros(dims[0] * dims[1] * dims[2] * 4, np.float32) if with_spheres else None
+    cam, cfv, fr = _f32(camera_affine), _f32(clip_from_view), _f32(frustum)
+    view = ClusterView()
+    _host_check(lib.mi_cluster_view_build(_ptr(cam, C.c_float), _ptr(cfv, C.c_float), _ptr(fr, C.c_float), w, h, req,
+                                          C.c_float(first_slice_depth), C.c_float(far_z), view_layer_mask,
+                                          _ptr(planes, C.c_float), _ptr(spheres, C.c_float), C.byref(view)),
+                "mi_cluster_view_build")
+    return view, (planes, spheres)
+
+
+def hierarchy_sort(parent):
+    """-> (new_to_old, parent_idx_new, level_offsets)"""
+    parent = _u32(parent)
+    n = len(parent)
+    new_to_old = np.zeros(max(n, 1), np.uint32)
+    pidx = np.zeros(max(n, 1), np.uint32)
+    cap = n + 2
+    offs = np.zeros(cap, np.uint32)
+    nl = C.c_uint32(0)
+    rc = load_library().mi_hierarchy_sort(n, _ptr(parent, C.c_uint32), _ptr(new_to_old, C.c_uint32),
+                                          _ptr(pidx, C.c_uint32), _ptr(offs, C.c_uint32), cap, C.byref(nl))
+    if rc != MI_OK:
+        raise MiError(rc, "mi_hierarchy_sort: malformed hierarchy" if rc == MI_ERR_MALFORMED_HIERARCHY else "mi_hierarchy_sort")
+    return new_to_old[:n], pidx[:n], offs[:nl.value + 1].copy()
+
+
+# ---- device context ------------------------------------------------------------------------------
+
+class Context:
+    """One mi_ctx: device-resident component columns + the systems of the render-prep path."""
+
+    def __init__(self, device=0, stream=None):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        rc = self._lib.mi_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self._h))
+        if rc != MI_OK:
+            msg = self._lib.mi_last_error_string(None).decode()
+            self._h = None
+            raise MiError(rc, msg)
+        self.n = 0
+        self.n_views = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mi_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, rc):
+        if rc != MI_OK:
+            raise MiError(rc, self._lib.mi_last_error_string(self._h).decode())
+
+    # columns
+    def resize(self, n):
+        self._ck(self._lib.mi_columns_resize(self._h, int(n)))
+        self.n = int(n)
+
+    def upload_transforms(self, translation, rotation, scale, first_row=0):
+        t, r, s = _f32(translation), _f32(rotation), _f32(scale)
+        n = len(t) // 3
+        self._ck(self._lib.mi_upload_transforms(self._h, first_row, n, _ptr(t, C.c_float), _ptr(r, C.c_float),
+                                                _ptr(s, C.c_float)))
+
+    def upload_global_transforms(self, g, first_row=0):
+        g = _f32(g)
+        self._ck(self._lib.mi_upload_global_transforms(self._h, first_row, len(g) // 12, _ptr(g, C.c_float)))
+
+    def upload_bounds(self, center, half, flags=None, layer_mask=None, first_row=0):
+        c, h, f, l = _f32(center), _f32(half), _u8(flags), _u32(layer_mask)
+        self._ck(self._lib.mi_upload_bounds(self._h, first_row, len(c) // 3, _ptr(c, C.c_float), _ptr(h, C.c_float),
+                                            _ptr(f, C.c_uint8), _ptr(l, C.c_uint32)))
+
+    def upload_view_visibility(self, vv, first_row=0):
+        vv = _u8(vv)
+        self._ck(self._lib.mi_upload_view_visibility(self._h, first_row, len(vv), _ptr(vv, C.c_uint8)))
+
+    def upload_visibility_classes(self, class_mask, first_row=0):
+        cm = _u32(class_mask)
+        self._ck(self._lib.mi_upload_visibility_classes(self._h, first_row, len(cm), _ptr(cm, C.c_uint32)))
+
+    def upload_entity_keys(self, keys, first_row=0):
+        k = _u64(keys)
+        self._ck(self._lib.mi_upload_entity_keys(self._h, first_row, len(k), _ptr(k, C.c_uint64)))
+
+    def upload_changed(self, changed, first_row=0):
+        ch = _u8(changed)
+        self._ck(self._lib.mi_upload_changed(self._h, first_row, len(ch), _ptr(ch, C.c_uint8)))
+
+    def upload_view_ranges(self, in_range):
+        if in_range is None:
+            self._ck(self._lib.mi_upload_view_ranges(self._h, 0, None))
+            return
+        a = _u8(in_range)
+        self._ck(self._lib.mi_upload_view_ranges(self._h, a.shape[0], _ptr(a, C.c_uint8)))
+
+    def upload_hierarchy(self, parent_idx, level_offsets):
+        if parent_idx is None:
+            self._ck(self._lib.mi_upload_hierarchy(self._h, self.n, None, None, 1))
+            return
+        p, lo = _u32(parent_idx), _u32(level_offsets)
+        self._ck(self._lib.mi_upload_hierarchy(self._h, len(p), _ptr(p, C.c_uint32), _ptr(lo, C.c_uint32), len(lo) - 1))
+
+    # systems
+    def propagate(self, flags=0x1):
+        self._ck(self._lib.mi_propagate(self._h, int(flags)))
+
+    def visibility_begin_frame(self):
+        self._ck(self._lib.mi_visibility_begin_frame(self._h))
+
+    def visibility_end_frame(self):
+        self._ck(self._lib.mi_visibility_end_frame(self._h))
+
+    def _views(self, frusta, view_masks, view_flags):
+        fr = _f32(frusta).reshape(-1)
+        nv = len(fr) // 24
+        self.n_views = nv
+        return fr, _u32(view_masks), _u8(view_flags), nv
+
+    def cull(self, frusta, view_masks=None, view_flags=None):
+        fr, vm, vf, nv = self._views(frusta, view_masks, view_flags)
+        self._ck(self._lib.mi_cull(self._h, _ptr(fr, C.c_float), _ptr(vm, C.c_uint32), _ptr(vf, C.c_uint8), nv))
+
+    def propagate_and_cull(self, frusta, view_masks=None, view_flags=None):
+        fr, vm, vf, nv = self._views(frusta, view_masks, view_flags)
+        self._ck(self._lib.mi_propagate_and_cull(self._h, _ptr(fr, C.c_float), _ptr(vm, C.c_uint32),
+                                                 _ptr(vf, C.c_uint8), nv))
+
+    # results
+    def download_global_transforms(self, first_row=0, n=None, want_changed=True):
+        n = self.n - first_row if n is None else n
+        g = np.zeros(12 * n, np.float32)
+        chg = np.zeros((n + 31) // 32, np.uint32) if want_changed else None
+        self._ck(self._lib.mi_download_global_transforms(self._h, first_row, n, _ptr(g, C.c_float), _ptr(chg, C.c_uint32)))
+        return (g, unpack_bits(chg, n)) if want_changed else g
+
+    def download_visibility(self, view=0):
+        bm = np.zeros((self.n + 31) // 32, np.uint32)
+        self._ck(self._lib.mi_download_visibility(self._h, view, _ptr(bm, C.c_uint32)))
+        return unpack_bits(bm, self.n)
+
+    def download_view_visibility(self, first_row=0, n=None):
+        n = self.n - first_row if n is None else n
+        vv = np.zeros(n, np.uint8)
+        chg = np.zeros((n + 31) // 32, np.uint32)
+        self._ck(self._lib.mi_download_view_visibility(self._h, first_row, n, _ptr(vv, C.c_uint8), _ptr(chg, C.c_uint32)))
+        return vv, unpack_bits(chg, n)
+
+    def download_visible_entities(self, view=0, class_bit=0):
+        cnt = C.c_uint32(0)
+        rc = self._lib.mi_download_visible_entities(self._h, view, class_bit, None, None, 0, C.byref(cnt))
+        if rc not in (MI_OK, MI_ERR_CAPACITY):
+            self._ck(rc)
+        m = cnt.value
+        keys = np.zeros(max(m, 1), np.uint64)
+        rows = np.zeros(max(m, 1), np.uint32)
+        self._ck(self._lib.mi_download_visible_entities(self._h, view, class_bit, _ptr(keys, C.c_uint64),
+                                                        _ptr(rows, C.c_uint32), m, C.byref(cnt)))
+        return keys[:m], rows[:m]
+
+    # clustering
+    def cluster_assign(self, view, pos_range, obj_type=None, layer_mask=None, spot_dir=None, spot_sin_cos=None):
+        self.cluster_upload_objects(pos_range, obj_type, layer_mask, spot_dir, spot_sin_cos)
+        self.cluster_upload_view(view)
+        self.cluster_assign_resident(want_total=True)
+        return self.cluster_download(view.n_clusters)
+
+    def cluster_upload_objects(self, pos_range, obj_type=None, layer_mask=None, spot_dir=None, spot_sin_cos=None):
+        pr, ty, lm, sd, sc = _f32(pos_range), _u8(obj_type), _u32(layer_mask), _f32(spot_dir), _f32(spot_sin_cos)
+        self._ck(self._lib.mi_cluster_upload_objects(self._h, len(pr) // 4, _ptr(pr, C.c_float), _ptr(ty, C.c_uint8),
+                                                     _ptr(lm, C.c_uint32), _ptr(sd, C.c_float), _ptr(sc, C.c_float)))
+
+    def cluster_upload_view(self, view):
+        self._ck(self._lib.mi_cluster_upload_view(self._h, C.byref(view)))
+
+    def cluster_assign_resident(self, want_total=False):
+        tot = C.c_uint64(0)
+        self._ck(self._lib.mi_cluster_assign_resident(self._h, C.byref(tot) if want_total else None))
+        return tot.value
+
+    def cluster_download(self, n_clusters):
+        tot = C.c_uint64(0)
+        far = C.c_float(0)
+        offsets = np.zeros(n_clusters + 1, np.uint32)
+        counts = np.zeros(6 * n_clusters, np.uint32)
+        self._ck(self._lib.mi_cluster_download(self._h, _ptr(offsets, C.c_uint32), None, C.c_uint64(0),
+                                               _ptr(counts, C.c_uint32), C.byref(tot), C.byref(far)))
+        indices = np.zeros(max(tot.value, 1), np.uint32)
+        self._ck(self._lib.mi_cluster_download(self._h, None, _ptr(indices, C.c_uint32), C.c_uint64(len(indices)), None,
+                                               C.byref(tot), None))
+        return offsets, indices[:tot.value], counts.reshape(n_clusters, 6), float(far.value), int(tot.value)
+
+    # interop / timing
+    def bind_visibility_output(self, device_ptr, words_per_view, word_offset):
+        self._ck(self._lib.mi_bind_visibility_output(self._h, C.c_void_p(device_ptr), C.c_uint64(words_per_view),
+                                                     C.c_uint64(word_offset)))
+
+    def device_buffer(self, which):
+        p = C.c_void_p()
+        nbytes = C.c_uint64(0)
+        self._ck(self._lib.mi_device_buffer(self._h, which, C.byref(p), C.byref(nbytes)))
+        return p.value, nbytes.value
+
+    def synchronize(self):
+        self._ck(self._lib.mi_synchronize(self._h))
+
+    def timer_begin(self):
+        self._ck(self._lib.mi_timer_begin(self._h))
+
+    def timer_end(self):
+        ms = C.c_float(0)
+        self._ck(self._lib.mi_timer_end(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def profile_enable(self, on=True):
+        self._ck(self._lib.mi_profile_enable(self._h, 1 if on else 0))
+
+    def profile_filter(self, kernel_names=None):
+        """Only bracket the named kernels (None = all)."""
+        mask = 0
+        if kernel_names:
+            k = 0
+            while True:
+                name = self._lib.mi_profile_kernel_name(k)
+                if not name:
+                    break
+                if name.decode() in kernel_names:
+                    mask |= 1 << k
+                k += 1
+        self._ck(self._lib.mi_profile_filter(self._h, C.c_uint64(mask)))
+
+    def profile_read(self):
+        n = C.c_uint32(64)
+        launches = (C.c_uint64 * 64)()
+        ms = (C.c_double * 64)()
+        self._ck(self._lib.mi_profile_read(self._h, C.byref(n), launches, ms))
+        out = {}
+        for k in range(n.value):
+            name = self._lib.mi_profile_kernel_name(k)
+            if name and launches[k]:
+                out[name.decode()] = {"launches": int(launches[k]), "total_ms": float(ms[k]),
+                                      "avg_us": 1e3 * float(ms[k]) / int(launches[k])}
+        return out
+
+    def debug_logf(self, x):
+        x = _f32(x)
+        out = np.zeros_like(x)
+        self._ck(self._lib.mi_debug_logf(self._h, _ptr(x, C.c_float), _ptr(out, C.c_float), len(x)))
+        return out
+
+
+def unpack_bits(words, n):
+    """u32 little-endian bit words -> uint8[n] of 0/1"""
+    if words is None:
+        return None
+    b = np.unpackbits(words.view(np.uint8), bitorder="little")
+    return b[:n].copy()

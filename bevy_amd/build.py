@@ -1,0 +1,53 @@
+"""Builds libbevy_mi355x.so (HIP kernels + C ABI) for gfx950, in-tree, with hipcc.
+
+    python -m bevy_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels with the gpurun snapshot.
+-ffp-contract=off is REQUIRED: bit-exact parity with the reference's SSE2 arithmetic depends on
+every multiply and add being rounded separately (see csrc/glam_math.h).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libbevy_mi355x.so")
+SOURCES = ["kernels_flat.hip", "kernels_tree.hip", "kernels_cluster.hip", "context.cpp", "host_helpers.cpp"]
+HEADERS = ["kernels.h", "glam_math.h", os.path.join("..", "..", "include", "bevy_mi355x.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
+         "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def up_to_date():
+    if not os.path.exists(LIB):
+        return False
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and up_to_date():
+        return LIB
+    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        sys.stderr.write(res.stdout + res.stderr)
+        raise RuntimeError("hipcc failed building libbevy_mi355x.so")
+    if verbose and res.stderr:
+        sys.stderr.write(res.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,1151 @@
+// context.cpp -- implementation of the C ABI in include/bevy_mi355x.h on top of the gfx950 kernels.
+//
+// Owns: the device-resident component columns (SoA across components, packed within a component),
+// a pinned staging arena for host->device copies, the hierarchy tile plan, the per-view constants,
+// the visibility bitmasks / VisibleEntities lists, the clustering scratch, and HIP-event timing.
+// Everything is enqueued on one HIP stream per context; the only host synchronisations are in the
+// download / timer-read entry points.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/bevy_mi355x.h"
+#include "kernels.h"
+
+namespace mi {
+hipError_t set_cluster_lds_limit();
+hipError_t launch_logf_probe(const float* in, float* out, uint32_t n, hipStream_t stream);
+}  // namespace mi
+
+using namespace mi;
+
+namespace {
+
+std::mutex g_err_mutex;
+std::string g_create_error = "no error";
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct ProfSpan {
+    uint32_t kernel;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct mi_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err = "no error";
+
+    // ---- columns ----
+    uint32_t n = 0, cap = 0;
+    float *t = nullptr, *r = nullptr, *s = nullptr, *g = nullptr, *c = nullptr, *h = nullptr;
+    uint8_t *flags = nullptr, *vv = nullptr, *changed = nullptr, *g_changed_bytes = nullptr;
+    uint32_t *layers = nullptr, *class_mask = nullptr;
+    uint64_t *keys = nullptr, *g_chg_bits = nullptr, *vv_chg_bits = nullptr;
+    uint32_t* tree_bits = nullptr;
+    bool have_class_mask = false, have_keys = false, have_changed = false;
+    uint32_t classes_present = 1u;
+    std::vector<uint64_t> h_keys;
+    bool order_dirty = false, order_identity = true;
+    DevBuf order;
+    DevBuf in_range;
+    uint32_t in_range_views = 0;
+
+    // ---- staging ----
+    void* stage = nullptr;
+    size_t stage_bytes = 0, stage_used = 0;
+
+    // ---- hierarchy ----
+    uint32_t n_levels = 1;
+    std::vector<uint32_t> level_offsets;  // n_levels + 1
+    DevBuf parent_idx, node_flags, tiles;
+    std::vector<std::pair<uint32_t, uint32_t>> passes;  // (first tile, n tiles)
+    bool have_hierarchy = false;
+
+    // ---- views / visibility ----
+    DevBuf views;
+    uint32_t n_views = 0;
+    DevBuf bitmask;
+    uint64_t words_per_view = 0;
+    void* ext_bitmask = nullptr;
+    uint64_t ext_words_per_view = 0, ext_word_offset = 0;
+    bool culled = false;
+    // compaction
+    DevBuf block_counts, seg_totals, seg_bases, out_rows, out_keys;
+    uint32_t compact_views = 0, compact_classes = 0;
+    uint32_t class_bits[32] = {0};
+
+    // ---- clustering ----
+    DevBuf cl_pos, cl_type, cl_layers, cl_dir, cl_sincos, cl_planes, cl_spheres;
+    DevBuf cl_block_counts, cl_block_bases, cl_offsets, cl_counts, cl_indices, cl_scalars;
+    uint32_t cl_n = 0;
+    bool cl_have_type = false, cl_have_layers = false, cl_have_spot = false, cl_any_spot = false;
+    ClusterViewDev cl_view{};
+    bool cl_have_view = false, cl_assigned = false;
+
+    // ---- timing ----
+    hipEvent_t timer_a = nullptr, timer_b = nullptr;
+    bool profiling = false;
+    uint64_t prof_mask = ~0ull;
+    std::vector<ProfSpan> spans;
+    bool span_open = false;
+    uint64_t prof_launches[K_NUM_KERNELS] = {0};
+    double prof_ms[K_NUM_KERNELS] = {0};
+};
+
+namespace {
+
+int32_t fail(mi_ctx* ctx, int32_t code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else {
+        std::lock_guard<std::mutex> lk(g_err_mutex);
+        g_create_error = buf;
+    }
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                                   \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? MI_ERR_OUT_OF_MEMORY : MI_ERR_DEVICE, "%s: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                          \
+    } while (0)
+
+#define ENTER(ctx)                                                       \
+    do {                                                                 \
+        if (!(ctx)) return fail(nullptr, MI_ERR_INVALID_ARG, "ctx is NULL"); \
+        HIP_TRY(ctx, hipSetDevice((ctx)->device));                       \
+    } while (0)
+
+inline uint64_t words64(uint32_t n) { return ((uint64_t)n + 63u) / 64u; }
+// bitmask words written by a launch of ceil(n/256) workgroups x 4 waves
+inline uint64_t padded_words(uint32_t n) { return (((uint64_t)n + 255u) / 256u) * 4u; }
+
+int32_t ensure(mi_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes && b.p) return MI_OK;
+    if (b.p) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    size_t want = std::max<size_t>(bytes, 256);
+    HIP_TRY(ctx, hipMalloc(&b.p, want));
+    b.bytes = want;
+    return MI_OK;
+}
+
+template <typename T>
+int32_t grow_column(mi_ctx* ctx, T*& col, size_t elems_per_row, uint32_t old_rows, uint32_t new_cap, int fill_byte) {
+    T* np = nullptr;
+    const size_t bytes = (size_t)new_cap * elems_per_row * sizeof(T) + 256;
+    HIP_TRY(ctx, hipMalloc((void**)&np, bytes));
+    HIP_TRY(ctx, hipMemsetAsync(np, fill_byte, bytes, ctx->stream));
+    if (col && old_rows)
+        HIP_TRY(ctx, hipMemcpyAsync(np, col, (size_t)old_rows * elems_per_row * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+    if (col) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(col));
+    }
+    col = np;
+    return MI_OK;
+}
+
+// Pinned staging arena: host slices are copied here (the ECS owns them only for the call) and the
+// H2D copy runs asynchronously on the context's stream.
+int32_t stage_alloc(mi_ctx* ctx, size_t bytes, void** out) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (ctx->stage_used + bytes > ctx->stage_bytes) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // everything staged so far has been consumed
+        ctx->stage_used = 0;
+        if (bytes > ctx->stage_bytes) {
+            if (ctx->stage) HIP_TRY(ctx, hipHostFree(ctx->stage));
+            ctx->stage = nullptr;
+            size_t want = std::max<size_t>(bytes, (size_t)64 << 20);
+            HIP_TRY(ctx, hipHostMalloc(&ctx->stage, want, hipHostMallocDefault));
+            ctx->stage_bytes = want;
+        }
+    }
+    *out = (char*)ctx->stage + ctx->stage_used;
+    ctx->stage_used += bytes;
+    return MI_OK;
+}
+
+int32_t upload(mi_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!bytes) return MI_OK;
+    void* st = nullptr;
+    int32_t rc = stage_alloc(ctx, bytes, &st);
+    if (rc) return rc;
+    memcpy(st, src, bytes);
+    HIP_TRY(ctx, hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return MI_OK;
+}
+
+int32_t download(mi_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!bytes) return MI_OK;
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MI_OK;
+}
+
+int32_t check_rows(mi_ctx* ctx, uint32_t first, uint32_t n, const char* what) {
+    if ((uint64_t)first + n > ctx->n) return fail(ctx, MI_ERR_INVALID_ARG, "%s: rows [%u,%u) exceed %u live rows", what, first, first + n, ctx->n);
+    return MI_OK;
+}
+
+// ---- profiling ------------------------------------------------------------------------------
+void prof_close(mi_ctx* ctx) {
+    if (ctx->span_open) {
+        hipEventRecord(ctx->spans.back().b, ctx->stream);
+        ctx->span_open = false;
+    }
+}
+void prof_mark(void* vctx, uint32_t kernel) {
+    mi_ctx* ctx = (mi_ctx*)vctx;
+    if (!ctx->profiling) return;
+    prof_close(ctx);
+    if (kernel >= K_NUM_KERNELS || !((ctx->prof_mask >> kernel) & 1ull)) return;
+    ProfSpan sp;
+    sp.kernel = kernel;
+    hipEventCreate(&sp.a);
+    hipEventCreate(&sp.b);
+    hipEventRecord(sp.a, ctx->stream);
+    ctx->spans.push_back(sp);
+    ctx->span_open = true;
+}
+struct ProfScope {
+    mi_ctx* ctx;
+    ProfScope(mi_ctx* c, uint32_t k) : ctx(c) { prof_mark(c, k); }
+    ~ProfScope() { prof_mark(ctx, K_NUM_KERNELS); }
+};
+void prof_collect(mi_ctx* ctx) {
+    prof_close(ctx);
+    hipStreamSynchronize(ctx->stream);
+    for (auto& sp : ctx->spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+            ctx->prof_ms[sp.kernel] += ms;
+            ctx->prof_launches[sp.kernel] += 1;
+        }
+        hipEventDestroy(sp.a);
+        hipEventDestroy(sp.b);
+    }
+    ctx->spans.clear();
+}
+
+Columns columns_of(mi_ctx* ctx) {
+    Columns c;
+    c.n = ctx->n;
+    c.translation = ctx->t;
+    c.rotation = ctx->r;
+    c.scale = ctx->s;
+    c.global = ctx->g;
+    c.aabb_center = ctx->c;
+    c.aabb_half = ctx->h;
+    c.flags = ctx->flags;
+    c.layer_mask = ctx->layers;
+    c.view_visibility = ctx->vv;
+    c.in_range = nullptr;
+    c.g_changed_bits = ctx->g_chg_bits;
+    c.vv_changed_bits = ctx->vv_chg_bits;
+    return c;
+}
+
+int32_t prepare_views(mi_ctx* ctx, const float* frusta, const uint32_t* masks, const uint8_t* vflags, uint32_t n_views,
+                      VisibilityOut* out) {
+    if (!frusta || n_views == 0) return fail(ctx, MI_ERR_INVALID_ARG, "mi_cull: frusta NULL or n_views == 0");
+    std::vector<ViewParams> vp(n_views);
+    for (uint32_t v = 0; v < n_views; ++v) {
+        memcpy(vp[v].planes, frusta + 24 * (size_t)v, sizeof vp[v].planes);
+        vp[v].layer_mask = masks ? masks[v] : 1u;
+        vp[v].flags = vflags ? vflags[v] : 0u;
+        vp[v].pad[0] = vp[v].pad[1] = 0;
+    }
+    int32_t rc = ensure(ctx, ctx->views, sizeof(ViewParams) * n_views);
+    if (rc) return rc;
+    rc = upload(ctx, ctx->views.p, vp.data(), sizeof(ViewParams) * n_views);
+    if (rc) return rc;
+    ctx->n_views = n_views;
+    if (ctx->ext_bitmask) {
+        out->bitmask = (uint64_t*)ctx->ext_bitmask;
+        out->words_per_view = ctx->ext_words_per_view;
+        out->word_offset = ctx->ext_word_offset;
+    } else {
+        ctx->words_per_view = padded_words(ctx->cap);
+        rc = ensure(ctx, ctx->bitmask, ctx->words_per_view * 8 * n_views);
+        if (rc) return rc;
+        out->bitmask = (uint64_t*)ctx->bitmask.p;
+        out->words_per_view = ctx->words_per_view;
+        out->word_offset = 0;
+    }
+    return MI_OK;
+}
+
+int32_t rebuild_order(mi_ctx* ctx) {
+    if (!ctx->order_dirty) return MI_OK;
+    ctx->order_dirty = false;
+    const uint32_t n = ctx->n;
+    ctx->order_identity = true;
+    if (!ctx->have_keys || n == 0) return MI_OK;
+    const uint64_t* k = ctx->h_keys.data();
+    bool sorted = true;
+    for (uint32_t i = 1; i < n; ++i)
+        if (k[i] < k[i - 1]) { sorted = false; break; }
+    if (sorted) return MI_OK;
+    std::vector<uint32_t> ord(n);
+    std::iota(ord.begin(), ord.end(), 0u);
+    std::stable_sort(ord.begin(), ord.end(), [k](uint32_t a, uint32_t b) { return k[a] < k[b]; });
+    int32_t rc = ensure(ctx, ctx->order, (size_t)n * 4);
+    if (rc) return rc;
+    rc = upload(ctx, ctx->order.p, ord.data(), (size_t)n * 4);
+    if (rc) return rc;
+    ctx->order_identity = false;
+    return MI_OK;
+}
+
+int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo) {
+    int32_t rc = rebuild_order(ctx);
+    if (rc) return rc;
+    CompactArgs a{};
+    a.n = ctx->n;
+    a.n_views = ctx->n_views;
+    uint32_t k = 0;
+    const uint32_t present = ctx->have_class_mask ? ctx->classes_present : 1u;
+    for (uint32_t b = 0; b < 32; ++b)
+        if (present & (1u << b)) { a.class_bits[k] = b; ctx->class_bits[k] = b; ++k; }
+    if (k == 0) { a.class_bits[0] = 0; ctx->class_bits[0] = 0; k = 1; }
+    a.n_classes = k;
+    a.order = ctx->order_identity ? nullptr : (const uint32_t*)ctx->order.p;
+    a.class_mask = ctx->have_class_mask ? ctx->class_mask : nullptr;
+    a.entity_keys = ctx->have_keys ? ctx->keys : nullptr;
+    a.bitmask = vo.bitmask;
+    a.words_per_view = vo.words_per_view;
+    a.word_offset = vo.word_offset;
+    a.n_blocks = (ctx->n + COMPACT_BLOCK_ROWS - 1) / COMPACT_BLOCK_ROWS;
+    const size_t segs = (size_t)a.n_views * a.n_classes;
+    if ((rc = ensure(ctx, ctx->block_counts, segs * a.n_blocks * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->seg_totals, segs * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->seg_bases, segs * 8))) return rc;
+    // worst case: every row of every view in every class it belongs to
+    const size_t max_entries = (size_t)a.n_views * ctx->cap * (ctx->have_class_mask ? a.n_classes : 1);
+    if ((rc = ensure(ctx, ctx->out_rows, max_entries * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->out_keys, max_entries * 8))) return rc;
+    a.block_counts = (uint32_t*)ctx->block_counts.p;
+    a.seg_totals = (uint32_t*)ctx->seg_totals.p;
+    a.seg_bases = (uint64_t*)ctx->seg_bases.p;
+    a.out_rows = (uint32_t*)ctx->out_rows.p;
+    a.out_keys = (uint64_t*)ctx->out_keys.p;
+    ctx->compact_views = a.n_views;
+    ctx->compact_classes = a.n_classes;
+    HIP_TRY(ctx, launch_compact(a, ctx->stream, prof_mark, ctx));
+    return MI_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+// lifecycle
+// =============================================================================================
+extern "C" {
+
+int32_t mi_abi_version(void) { return MI_ABI_VERSION; }
+
+int32_t mi_ctx_create(int32_t device, void* hip_stream, mi_ctx** out_ctx) {
+    if (!out_ctx) return fail(nullptr, MI_ERR_INVALID_ARG, "out_ctx is NULL");
+    *out_ctx = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, MI_ERR_DEVICE, "no HIP device available (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(nullptr, MI_ERR_INVALID_ARG, "device %d out of range [0,%d)", device, count);
+    mi_ctx* ctx = new (std::nothrow) mi_ctx();
+    if (!ctx) return fail(nullptr, MI_ERR_OUT_OF_MEMORY, "host allocation failed");
+    ctx->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, MI_ERR_DEVICE, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            std::string arch = prop.gcnArchName;
+            delete ctx;
+            return fail(nullptr, MI_ERR_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", device,
+                        arch.c_str());
+        }
+    }
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+    } else {
+        if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+            delete ctx;
+            return fail(nullptr, MI_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e));
+        }
+        ctx->own_stream = true;
+    }
+    hipEventCreate(&ctx->timer_a);
+    hipEventCreate(&ctx->timer_b);
+    set_cluster_lds_limit();
+    ctx->level_offsets = {0, 0};
+    *out_ctx = ctx;
+    return MI_OK;
+}
+
+int32_t mi_ctx_destroy(mi_ctx* ctx) {
+    if (!ctx) return MI_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    prof_collect(ctx);
+    void* cols[] = {ctx->t, ctx->r, ctx->s, ctx->g, ctx->c, ctx->h, ctx->flags, ctx->vv, ctx->changed, ctx->g_changed_bytes,
+                    ctx->layers, ctx->class_mask, ctx->keys, ctx->g_chg_bits, ctx->vv_chg_bits, ctx->tree_bits};
+    for (void* p : cols)
+        if (p) hipFree(p);
+    DevBuf* bufs[] = {&ctx->order, &ctx->in_range, &ctx->parent_idx, &ctx->node_flags, &ctx->tiles, &ctx->views, &ctx->bitmask,
+                      &ctx->block_counts, &ctx->seg_totals, &ctx->seg_bases, &ctx->out_rows, &ctx->out_keys, &ctx->cl_pos,
+                      &ctx->cl_type, &ctx->cl_layers, &ctx->cl_dir, &ctx->cl_sincos, &ctx->cl_planes, &ctx->cl_spheres,
+                      &ctx->cl_block_counts, &ctx->cl_block_bases, &ctx->cl_offsets, &ctx->cl_counts, &ctx->cl_indices,
+                      &ctx->cl_scalars};
+    for (DevBuf* b : bufs)
+        if (b->p) hipFree(b->p);
+    if (ctx->stage) hipHostFree(ctx->stage);
+    if (ctx->timer_a) hipEventDestroy(ctx->timer_a);
+    if (ctx->timer_b) hipEventDestroy(ctx->timer_b);
+    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return MI_OK;
+}
+
+const char* mi_last_error_string(mi_ctx* ctx) {
+    if (ctx) return ctx->err.c_str();
+    std::lock_guard<std::mutex> lk(g_err_mutex);
+    static thread_local std::string copy;
+    copy = g_create_error;
+    return copy.c_str();
+}
+
+int32_t mi_synchronize(mi_ctx* ctx) {
+    ENTER(ctx);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MI_OK;
+}
+
+// =============================================================================================
+// columns
+// =============================================================================================
+int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
+    ENTER(ctx);
+    if (n_rows > ctx->cap) {
+        uint32_t new_cap = std::max<uint64_t>(n_rows, std::min<uint64_t>((uint64_t)ctx->cap * 3 / 2, 0xFFFFFF00ull));
+        new_cap = (uint32_t)(((uint64_t)new_cap + 255u) / 256u * 256u);  // whole workgroups
+        const uint32_t old = ctx->n;
+        int32_t rc;
+        if ((rc = grow_column(ctx, ctx->t, 3, old, new_cap, 0))) return rc;
+        if ((rc = grow_column(ctx, ctx->r, 4, old, new_cap, 0))) return rc;
+        if ((rc = grow_column(ctx, ctx->s, 3, old, new_cap, 0))) return rc;
+        if ((rc = grow_column(ctx, ctx->g, 12, old, new_cap, 0))) return rc;
+        if ((rc = grow_column(ctx, ctx->c, 3, old, new_cap, 0))) return rc;
+        if ((rc = grow_column(ctx, ctx->h, 3, old, new_cap, 0))) return rc;
+        if ((rc = grow_column(ctx, ctx->flags, 1, old, new_cap, MI_FLAG_INHERITED_VISIBLE))) return rc;
+        if ((rc = grow_column(ctx, ctx->vv, 1, old, new_cap, 0))) return rc;
+        if ((rc = grow_column(ctx, ctx->changed, 1, old, new_cap, 1))) return rc;
+        if ((rc = grow_column(ctx, ctx->g_changed_bytes, 1, old, new_cap, 0))) return rc;
+        if ((rc = grow_column(ctx, ctx->layers, 1, old, new_cap, 0))) return rc;
+        if ((rc = grow_column(ctx, ctx->class_mask, 1, old, new_cap, 0))) return rc;
+        if ((rc = grow_column(ctx, ctx->keys, 1, old, new_cap, 0))) return rc;
+        // default RenderLayers = layer 0 (mask 1) for rows never uploaded
+        {
+            std::vector<uint32_t> ones(new_cap - old, 1u);
+            if ((rc = upload(ctx, ctx->layers + old, ones.data(), ones.size() * 4))) return rc;
+        }
+        uint64_t* nb = nullptr;
+        const size_t wbytes = padded_words(new_cap) * 8 + 256;
+        for (uint64_t** bits : {&ctx->g_chg_bits, &ctx->vv_chg_bits}) {
+            HIP_TRY(ctx, hipMalloc((void**)&nb, wbytes));
+            HIP_TRY(ctx, hipMemsetAsync(nb, 0, wbytes, ctx->stream));
+            if (*bits) {
+                HIP_TRY(ctx, hipMemcpyAsync(nb, *bits, words64(old) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                HIP_TRY(ctx, hipFree(*bits));
+            }
+            *bits = nb;
+        }
+        if (ctx->tree_bits) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, hipFree(ctx->tree_bits));
+        }
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->tree_bits, padded_words(new_cap) * 8 + 256));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->tree_bits, 0, padded_words(new_cap) * 8 + 256, ctx->stream));
+        ctx->cap = new_cap;
+    }
+    if (n_rows != ctx->n) {
+        // a different row count invalidates the hierarchy and any cull result
+        ctx->have_hierarchy = false;
+        ctx->n_levels = 1;
+        ctx->culled = false;
+        ctx->h_keys.resize(n_rows, 0);
+        ctx->order_dirty = true;
+        ctx->level_offsets = {0, n_rows};
+        ctx->passes.clear();
+    }
+    ctx->n = n_rows;
+    return MI_OK;
+}
+
+int32_t mi_upload_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t n, const float* translation, const float* rotation,
+                             const float* scale) {
+    ENTER(ctx);
+    if (!translation || !rotation || !scale) return fail(ctx, MI_ERR_INVALID_ARG, "mi_upload_transforms: NULL column");
+    int32_t rc = check_rows(ctx, first_row, n, "mi_upload_transforms");
+    if (rc) return rc;
+    if ((rc = upload(ctx, ctx->t + 3 * (size_t)first_row, translation, (size_t)n * 12))) return rc;
+    if ((rc = upload(ctx, ctx->r + 4 * (size_t)first_row, rotation, (size_t)n * 16))) return rc;
+    if ((rc = upload(ctx, ctx->s + 3 * (size_t)first_row, scale, (size_t)n * 12))) return rc;
+    return MI_OK;
+}
+
+int32_t mi_upload_global_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t n, const float* global12) {
+    ENTER(ctx);
+    if (!global12) return fail(ctx, MI_ERR_INVALID_ARG, "mi_upload_global_transforms: NULL");
+    int32_t rc = check_rows(ctx, first_row, n, "mi_upload_global_transforms");
+    if (rc) return rc;
+    return upload(ctx, ctx->g + 12 * (size_t)first_row, global12, (size_t)n * 48);
+}
+
+int32_t mi_upload_bounds(mi_ctx* ctx, uint32_t first_row, uint32_t n, const float* aabb_center, const float* aabb_half,
+                         const uint8_t* flags, const uint32_t* layer_mask) {
+    ENTER(ctx);
+    if (!aabb_center || !aabb_half) return fail(ctx, MI_ERR_INVALID_ARG, "mi_upload_bounds: NULL column");
+    int32_t rc = check_rows(ctx, first_row, n, "mi_upload_bounds");
+    if (rc) return rc;
+    if ((rc = upload(ctx, ctx->c + 3 * (size_t)first_row, aabb_center, (size_t)n * 12))) return rc;
+    if ((rc = upload(ctx, ctx->h + 3 * (size_t)first_row, aabb_half, (size_t)n * 12))) return rc;
+    if (flags) {
+        if ((rc = upload(ctx, ctx->flags + first_row, flags, n))) return rc;
+    } else {
+        std::vector<uint8_t> def(n, (uint8_t)(MI_FLAG_INHERITED_VISIBLE | MI_FLAG_HAS_AABB));
+        if ((rc = upload(ctx, ctx->flags + first_row, def.data(), n))) return rc;
+    }
+    if (layer_mask) {
+        if ((rc = upload(ctx, ctx->layers + first_row, layer_mask, (size_t)n * 4))) return rc;
+    } else {
+        std::vector<uint32_t> def(n, 1u);
+        if ((rc = upload(ctx, ctx->layers + first_row, def.data(), (size_t)n * 4))) return rc;
+    }
+    return MI_OK;
+}
+
+int32_t mi_upload_view_visibility(mi_ctx* ctx, uint32_t first_row, uint32_t n, const uint8_t* vv) {
+    ENTER(ctx);
+    if (!vv) return fail(ctx, MI_ERR_INVALID_ARG, "mi_upload_view_visibility: NULL");
+    int32_t rc = check_rows(ctx, first_row, n, "mi_upload_view_visibility");
+    if (rc) return rc;
+    return upload(ctx, ctx->vv + first_row, vv, n);
+}
+
+int32_t mi_upload_visibility_classes(mi_ctx* ctx, uint32_t first_row, uint32_t n, const uint32_t* class_mask) {
+    ENTER(ctx);
+    if (!class_mask) return fail(ctx, MI_ERR_INVALID_ARG, "mi_upload_visibility_classes: NULL");
+    int32_t rc = check_rows(ctx, first_row, n, "mi_upload_visibility_classes");
+    if (rc) return rc;
+    uint32_t present = 0;
+    for (uint32_t i = 0; i < n; ++i) present |= class_mask[i];
+    if (!ctx->have_class_mask) ctx->classes_present = 0;
+    ctx->classes_present |= present;
+    ctx->have_class_mask = true;
+    return upload(ctx, ctx->class_mask + first_row, class_mask, (size_t)n * 4);
+}
+
+int32_t mi_upload_entity_keys(mi_ctx* ctx, uint32_t first_row, uint32_t n, const uint64_t* entity_bits) {
+    ENTER(ctx);
+    if (!entity_bits) return fail(ctx, MI_ERR_INVALID_ARG, "mi_upload_entity_keys: NULL");
+    int32_t rc = check_rows(ctx, first_row, n, "mi_upload_entity_keys");
+    if (rc) return rc;
+    ctx->h_keys.resize(ctx->n, 0);
+    memcpy(ctx->h_keys.data() + first_row, entity_bits, (size_t)n * 8);
+    ctx->have_keys = true;
+    ctx->order_dirty = true;
+    return upload(ctx, ctx->keys + first_row, entity_bits, (size_t)n * 8);
+}
+
+int32_t mi_upload_changed(mi_ctx* ctx, uint32_t first_row, uint32_t n, const uint8_t* changed) {
+    ENTER(ctx);
+    if (!changed) return fail(ctx, MI_ERR_INVALID_ARG, "mi_upload_changed: NULL");
+    int32_t rc = check_rows(ctx, first_row, n, "mi_upload_changed");
+    if (rc) return rc;
+    ctx->have_changed = true;
+    return upload(ctx, ctx->changed + first_row, changed, n);
+}
+
+int32_t mi_upload_view_ranges(mi_ctx* ctx, uint32_t n_views, const uint8_t* in_range) {
+    ENTER(ctx);
+    if (!in_range || n_views == 0) {
+        ctx->in_range_views = 0;
+        return MI_OK;
+    }
+    int32_t rc = ensure(ctx, ctx->in_range, (size_t)n_views * ctx->n);
+    if (rc) return rc;
+    ctx->in_range_views = n_views;
+    return upload(ctx, ctx->in_range.p, in_range, (size_t)n_views * ctx->n);
+}
+
+// ---------------------------------------------------------------------------------------------
+// hierarchy: validation + subtree-tile planning (host), see kernels_tree.hip for the consumer.
+// ---------------------------------------------------------------------------------------------
+int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx, const uint32_t* level_offsets,
+                            uint32_t n_levels) {
+    ENTER(ctx);
+    if (n != ctx->n) return fail(ctx, MI_ERR_INVALID_ARG, "mi_upload_hierarchy: n (%u) != live rows (%u)", n, ctx->n);
+    if (!parent_idx || n_levels <= 1) {
+        ctx->have_hierarchy = false;
+        ctx->n_levels = 1;
+        ctx->level_offsets = {0, n};
+        ctx->passes.clear();
+        return MI_OK;
+    }
+    if (!level_offsets) return fail(ctx, MI_ERR_INVALID_ARG, "mi_upload_hierarchy: level_offsets NULL");
+    if (level_offsets[0] != 0 || level_offsets[n_levels] != n)
+        return fail(ctx, MI_ERR_MALFORMED_HIERARCHY, "level_offsets must start at 0 and end at n");
+    for (uint32_t l = 0; l < n_levels; ++l)
+        if (level_offsets[l + 1] < level_offsets[l]) return fail(ctx, MI_ERR_MALFORMED_HIERARCHY, "level_offsets not monotone");
+    // level 0: roots; level l>0: parent in level l-1, parents non-decreasing (BFS order)
+    for (uint32_t i = level_offsets[0]; i < level_offsets[1]; ++i)
+        if (parent_idx[i] != MI_NO_PARENT)
+            return fail(ctx, MI_ERR_MALFORMED_HIERARCHY, "row %u in level 0 has a parent", i);
+    for (uint32_t l = 1; l < n_levels; ++l) {
+        const uint32_t plo = level_offsets[l - 1], phi = level_offsets[l];
+        uint32_t prev = plo;
+        for (uint32_t i = level_offsets[l]; i < level_offsets[l + 1]; ++i) {
+            const uint32_t p = parent_idx[i];
+            if (p < plo || p >= phi)
+                return fail(ctx, MI_ERR_MALFORMED_HIERARCHY, "row %u (level %u): parent %u is not in level %u", i, l, p, l - 1);
+            if (p < prev)
+                return fail(ctx, MI_ERR_MALFORMED_HIERARCHY, "row %u: rows of a level must be ordered by parent (use mi_hierarchy_sort)", i);
+            prev = p;
+        }
+    }
+    // node flags + first-child table
+    std::vector<uint8_t> nflags(n, 0);
+    std::vector<uint32_t> first_child((size_t)n + 1, 0);
+    for (uint32_t l = 0; l + 1 < n_levels; ++l) {
+        uint32_t ch = level_offsets[l + 1];
+        const uint32_t chi = level_offsets[l + 2];
+        for (uint32_t p = level_offsets[l]; p < level_offsets[l + 1]; ++p) {
+            first_child[p] = ch;
+            while (ch < chi && parent_idx[ch] == p) { ++ch; nflags[p] |= 1; }
+        }
+    }
+    for (uint32_t p = level_offsets[n_levels - 1]; p <= n; ++p) first_child[p] = n;
+    // first_child[level end] of level l must read as "end of level l+1": patch boundaries
+    auto child_begin = [&](uint32_t l, uint32_t row) -> uint32_t {
+        // first row of level l+1 whose parent >= row (row in level l, or == end of level l)
+        if (row >= level_offsets[l + 1]) return level_offsets[l + 2];
+        return first_child[row];
+    };
+
+    // ---- tile plan ----
+    const char* env_levels = getenv("MI_TILE_LEVELS");
+    const uint32_t band_pref = env_levels ? std::max(1, std::min((int)TILE_MAX_LEVELS, atoi(env_levels))) : 3u;
+    std::vector<TileDesc> tiles;
+    ctx->passes.clear();
+    uint32_t l = 1;
+    while (l < n_levels) {
+        uint32_t d = 1;
+        uint64_t cum = level_offsets[l + 1] - level_offsets[l];
+        while (d < TILE_MAX_LEVELS && l + d < n_levels) {
+            const uint64_t next = level_offsets[l + d + 1] - level_offsets[l + d];
+            if (d >= band_pref && cum + next > 2048) break;
+            cum += next;
+            ++d;
+        }
+        const uint32_t first_tile = (uint32_t)tiles.size();
+        // tile roots live in level l-1; extend the root range while every level of the band fits in LDS
+        const uint32_t rlo = level_offsets[l - 1], rhi = level_offsets[l];
+        uint32_t a = rlo;
+        while (a < rhi) {
+            auto ranges = [&](uint32_t lo, uint32_t hi, TileDesc& td) -> bool {
+                bool fits = true;
+                uint32_t clo = lo, chi2 = hi;
+                td.n_levels = 0;
+                for (uint32_t k = 0; k < d; ++k) {
+                    const uint32_t nlo = child_begin(l - 1 + k, clo), nhi = child_begin(l - 1 + k, chi2);
+                    td.start[k] = nlo;
+                    td.count[k] = nhi - nlo;
+                    if (nhi - nlo > TILE_LDS_ROWS) fits = false;
+                    clo = nlo; chi2 = nhi;
+                    if (nhi > nlo) td.n_levels = k + 1;
+                }
+                return fits;
+            };
+            TileDesc best{};
+            uint32_t b = a + 1;
+            ranges(a, b, best);
+            // galloping extension
+            uint32_t step = 1;
+            while (b < rhi) {
+                const uint32_t nb = std::min<uint64_t>((uint64_t)b + step, rhi);
+                TileDesc cand{};
+                if (ranges(a, nb, cand)) { best = cand; b = nb; step *= 2; }
+                else if (step > 1) step = 1;
+                else break;
+            }
+            if (best.n_levels) tiles.push_back(best);
+            a = b;
+        }
+        ctx->passes.emplace_back(first_tile, (uint32_t)tiles.size() - first_tile);
+        l += d;
+    }
+    int32_t rc;
+    if ((rc = ensure(ctx, ctx->parent_idx, (size_t)n * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->node_flags, n))) return rc;
+    if ((rc = ensure(ctx, ctx->tiles, std::max<size_t>(tiles.size(), 1) * sizeof(TileDesc)))) return rc;
+    if ((rc = upload(ctx, ctx->parent_idx.p, parent_idx, (size_t)n * 4))) return rc;
+    if ((rc = upload(ctx, ctx->node_flags.p, nflags.data(), n))) return rc;
+    if ((rc = upload(ctx, ctx->tiles.p, tiles.data(), tiles.size() * sizeof(TileDesc)))) return rc;
+    ctx->level_offsets.assign(level_offsets, level_offsets + n_levels + 1);
+    ctx->n_levels = n_levels;
+    ctx->have_hierarchy = true;
+    return MI_OK;
+}
+
+// =============================================================================================
+// systems
+// =============================================================================================
+int32_t mi_propagate(mi_ctx* ctx, uint32_t flags) {
+    ENTER(ctx);
+    if (ctx->n == 0) return MI_OK;
+    const bool all_dirty = (flags & MI_PROPAGATE_ALL_DIRTY) != 0 || !ctx->have_changed;
+    const bool static_opt = (flags & MI_PROPAGATE_STATIC_OPT) != 0;
+    Columns c = columns_of(ctx);
+    const uint32_t n0 = ctx->have_hierarchy ? ctx->level_offsets[1] : ctx->n;
+    const uint32_t* tree_bits = nullptr;
+    // mark_dirty_trees returns early unless the static optimisation is enabled (systems.rs:131-133)
+    if (ctx->have_hierarchy && static_opt && !all_dirty) {
+        {
+            ProfScope ps(ctx, K_CLEAR);
+            HIP_TRY(ctx, launch_clear_u32(ctx->tree_bits, padded_words(ctx->n) * 2, ctx->stream));
+        }
+        ProfScope ps(ctx, K_MARK_DIRTY);
+        HIP_TRY(ctx, launch_mark_dirty(ctx->n, ctx->changed, (const uint32_t*)ctx->parent_idx.p, ctx->tree_bits, ctx->stream));
+        tree_bits = ctx->tree_bits;
+    }
+    {
+        ProfScope ps(ctx, K_LEVEL0_PROPAGATE);
+        HIP_TRY(ctx, launch_level0_propagate(c, n0, ctx->have_hierarchy ? (const uint8_t*)ctx->node_flags.p : nullptr,
+                                             ctx->changed, tree_bits, all_dirty, static_opt, ctx->stream));
+    }
+    if (ctx->have_hierarchy) {
+        HIP_TRY(ctx, launch_level0_bytes(ctx->g_chg_bits, n0, ctx->g_changed_bytes, ctx->stream));
+        for (auto& ps : ctx->passes) {
+            ProfScope sc(ctx, K_PROPAGATE_TILES);
+            HIP_TRY(ctx, launch_propagate_tiles(c, (const uint32_t*)ctx->parent_idx.p, (const TileDesc*)ctx->tiles.p + ps.first,
+                                                ps.second, tree_bits, ctx->g_changed_bytes, all_dirty, static_opt, ctx->stream));
+        }
+        HIP_TRY(ctx, launch_bytes_to_bits(ctx->g_changed_bytes, ctx->n, ctx->g_chg_bits, ctx->stream));
+    }
+    if (ctx->have_changed) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, ctx->n, ctx->stream));  // change flags are consumed
+    }
+    return MI_OK;
+}
+
+int32_t mi_visibility_begin_frame(mi_ctx* ctx) {
+    ENTER(ctx);
+    ProfScope ps(ctx, K_VIS_BEGIN);
+    HIP_TRY(ctx, launch_vis_begin(columns_of(ctx), ctx->stream));
+    return MI_OK;
+}
+
+int32_t mi_visibility_end_frame(mi_ctx* ctx) {
+    ENTER(ctx);
+    ProfScope ps(ctx, K_VIS_END);
+    HIP_TRY(ctx, launch_vis_end(columns_of(ctx), ctx->stream));
+    return MI_OK;
+}
+
+int32_t mi_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_masks, const uint8_t* view_flags,
+                uint32_t n_views) {
+    ENTER(ctx);
+    VisibilityOut vo{};
+    int32_t rc = prepare_views(ctx, frusta, view_layer_masks, view_flags, n_views, &vo);
+    if (rc) return rc;
+    Columns c = columns_of(ctx);
+    if (ctx->in_range_views >= n_views) c.in_range = (const uint8_t*)ctx->in_range.p;
+    {
+        ProfScope ps(ctx, K_CULL);
+        HIP_TRY(ctx, launch_cull(c, (const ViewParams*)ctx->views.p, n_views, vo, ctx->stream));
+    }
+    if ((rc = run_compaction(ctx, vo))) return rc;
+    ctx->culled = true;
+    return MI_OK;
+}
+
+int32_t mi_propagate_and_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_masks, const uint8_t* view_flags,
+                              uint32_t n_views) {
+    ENTER(ctx);
+    if (ctx->have_hierarchy)
+        return fail(ctx, MI_ERR_NOT_READY, "mi_propagate_and_cull is the flat fast path; a hierarchy is uploaded -- use mi_propagate + mi_cull");
+    VisibilityOut vo{};
+    int32_t rc = prepare_views(ctx, frusta, view_layer_masks, view_flags, n_views, &vo);
+    if (rc) return rc;
+    Columns c = columns_of(ctx);
+    if (ctx->in_range_views >= n_views) c.in_range = (const uint8_t*)ctx->in_range.p;
+    {
+        ProfScope ps(ctx, K_FLAT_PROPAGATE_CULL);
+        HIP_TRY(ctx, launch_flat_propagate_cull(c, (const ViewParams*)ctx->views.p, n_views, vo, ctx->stream));
+    }
+    if ((rc = run_compaction(ctx, vo))) return rc;
+    if (ctx->have_changed) HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, ctx->n, ctx->stream));
+    ctx->culled = true;
+    return MI_OK;
+}
+
+// =============================================================================================
+// results
+// =============================================================================================
+int32_t mi_download_global_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t n, float* out, uint32_t* changed_bitmask) {
+    ENTER(ctx);
+    int32_t rc = check_rows(ctx, first_row, n, "mi_download_global_transforms");
+    if (rc) return rc;
+    if (changed_bitmask && (first_row & 31u)) return fail(ctx, MI_ERR_INVALID_ARG, "first_row must be a multiple of 32 for the change bitmask");
+    if (out && (rc = download(ctx, out, ctx->g + 12 * (size_t)first_row, (size_t)n * 48))) return rc;
+    if (changed_bitmask) {
+        const size_t words32 = ((size_t)n + 31) / 32;
+        if ((rc = download(ctx, changed_bitmask, (const uint32_t*)ctx->g_chg_bits + first_row / 32, words32 * 4))) return rc;
+        if (n & 31u) changed_bitmask[words32 - 1] &= (1u << (n & 31u)) - 1u;
+    }
+    return MI_OK;
+}
+
+int32_t mi_download_visibility(mi_ctx* ctx, uint32_t view, uint32_t* bitmask) {
+    ENTER(ctx);
+    if (!ctx->culled) return fail(ctx, MI_ERR_NOT_READY, "mi_download_visibility before mi_cull");
+    if (view >= ctx->n_views || !bitmask) return fail(ctx, MI_ERR_INVALID_ARG, "mi_download_visibility: bad view or NULL");
+    const uint64_t* base;
+    if (ctx->ext_bitmask) base = (const uint64_t*)ctx->ext_bitmask + view * ctx->ext_words_per_view + ctx->ext_word_offset;
+    else base = (const uint64_t*)ctx->bitmask.p + view * ctx->words_per_view;
+    const size_t words32 = ((size_t)ctx->n + 31) / 32;
+    int32_t rc = download(ctx, bitmask, base, words32 * 4);
+    if (rc) return rc;
+    if (ctx->n & 31u) bitmask[words32 - 1] &= (1u << (ctx->n & 31u)) - 1u;
+    return MI_OK;
+}
+
+int32_t mi_download_view_visibility(mi_ctx* ctx, uint32_t first_row, uint32_t n, uint8_t* out_vv, uint32_t* changed_bitmask) {
+    ENTER(ctx);
+    int32_t rc = check_rows(ctx, first_row, n, "mi_download_view_visibility");
+    if (rc) return rc;
+    if (changed_bitmask && (first_row & 31u)) return fail(ctx, MI_ERR_INVALID_ARG, "first_row must be a multiple of 32 for the change bitmask");
+    if (out_vv && (rc = download(ctx, out_vv, ctx->vv + first_row, n))) return rc;
+    if (changed_bitmask) {
+        const size_t words32 = ((size_t)n + 31) / 32;
+        if ((rc = download(ctx, changed_bitmask, (const uint32_t*)ctx->vv_chg_bits + first_row / 32, words32 * 4))) return rc;
+        if (n & 31u) changed_bitmask[words32 - 1] &= (1u << (n & 31u)) - 1u;
+    }
+    return MI_OK;
+}
+
+int32_t mi_download_visible_entities(mi_ctx* ctx, uint32_t view, uint32_t class_bit, uint64_t* out_keys, uint32_t* out_rows,
+                                     uint32_t capacity, uint32_t* out_count) {
+    ENTER(ctx);
+    if (!ctx->culled) return fail(ctx, MI_ERR_NOT_READY, "mi_download_visible_entities before mi_cull");
+    if (view >= ctx->compact_views || !out_count) return fail(ctx, MI_ERR_INVALID_ARG, "mi_download_visible_entities: bad view or NULL out_count");
+    uint32_t slot = 0xFFFFFFFFu;
+    for (uint32_t k = 0; k < ctx->compact_classes; ++k)
+        if (ctx->class_bits[k] == class_bit) slot = k;
+    if (slot == 0xFFFFFFFFu) {  // no row carries this class: VisibleEntities::get() returns &[]
+        *out_count = 0;
+        return MI_OK;
+    }
+    const uint32_t seg = view * ctx->compact_classes + slot;
+    uint32_t total = 0;
+    uint64_t base = 0;
+    int32_t rc;
+    if ((rc = download(ctx, &total, (const uint32_t*)ctx->seg_totals.p + seg, 4))) return rc;
+    if ((rc = download(ctx, &base, (const uint64_t*)ctx->seg_bases.p + seg, 8))) return rc;
+    *out_count = total;
+    if (total > capacity) return fail(ctx, MI_ERR_CAPACITY, "visible list has %u entries, capacity %u", total, capacity);
+    if (out_keys && (rc = download(ctx, out_keys, (const uint64_t*)ctx->out_keys.p + base, (size_t)total * 8))) return rc;
+    if (out_rows && (rc = download(ctx, out_rows, (const uint32_t*)ctx->out_rows.p + base, (size_t)total * 4))) return rc;
+    return MI_OK;
+}
+
+// =============================================================================================
+// clustering
+// =============================================================================================
+int32_t mi_cluster_upload_objects(mi_ctx* ctx, uint32_t n, const float* pos_range, const uint8_t* obj_type,
+                                  const uint32_t* layer_mask, const float* spot_dir, const float* spot_sin_cos) {
+    ENTER(ctx);
+    if (n && !pos_range) return fail(ctx, MI_ERR_INVALID_ARG, "mi_cluster_upload_objects: pos_range NULL");
+    bool any_spot = false;
+    if (obj_type)
+        for (uint32_t i = 0; i < n; ++i) {
+            if (obj_type[i] > MI_OBJ_DECAL) return fail(ctx, MI_ERR_INVALID_ARG, "object %u: unknown type %u", i, obj_type[i]);
+            any_spot |= obj_type[i] == MI_OBJ_SPOT_LIGHT;
+        }
+    if (any_spot && (!spot_dir || !spot_sin_cos)) return fail(ctx, MI_ERR_INVALID_ARG, "spot lights need spot_dir and spot_sin_cos");
+    int32_t rc;
+    if ((rc = ensure(ctx, ctx->cl_pos, (size_t)n * 16))) return rc;
+    if ((rc = upload(ctx, ctx->cl_pos.p, pos_range, (size_t)n * 16))) return rc;
+    ctx->cl_have_type = obj_type != nullptr;
+    if (obj_type) {
+        if ((rc = ensure(ctx, ctx->cl_type, n))) return rc;
+        if ((rc = upload(ctx, ctx->cl_type.p, obj_type, n))) return rc;
+    }
+    ctx->cl_have_layers = layer_mask != nullptr;
+    if (layer_mask) {
+        if ((rc = ensure(ctx, ctx->cl_layers, (size_t)n * 4))) return rc;
+        if ((rc = upload(ctx, ctx->cl_layers.p, layer_mask, (size_t)n * 4))) return rc;
+    }
+    ctx->cl_have_spot = spot_dir && spot_sin_cos;
+    if (ctx->cl_have_spot) {
+        if ((rc = ensure(ctx, ctx->cl_dir, (size_t)n * 12))) return rc;
+        if ((rc = upload(ctx, ctx->cl_dir.p, spot_dir, (size_t)n * 12))) return rc;
+        if ((rc = ensure(ctx, ctx->cl_sincos, (size_t)n * 8))) return rc;
+        if ((rc = upload(ctx, ctx->cl_sincos.p, spot_sin_cos, (size_t)n * 8))) return rc;
+    }
+    ctx->cl_any_spot = any_spot;
+    ctx->cl_n = n;
+    ctx->cl_assigned = false;
+    return MI_OK;
+}
+
+int32_t mi_cluster_upload_view(mi_ctx* ctx, const mi_cluster_view* view) {
+    ENTER(ctx);
+    if (!view || !view->x_planes || !view->y_planes || !view->z_planes) return fail(ctx, MI_ERR_INVALID_ARG, "mi_cluster_upload_view: NULL");
+    const uint64_t C = (uint64_t)view->dims[0] * view->dims[1] * view->dims[2];
+    if (C == 0 || C > 4096) return fail(ctx, MI_ERR_INVALID_ARG, "cluster count %llu outside 1..4096 (assign.rs:410-413)", (unsigned long long)C);
+    const uint32_t nx = view->dims[0] + 1, ny = view->dims[1] + 1, nz = view->dims[2] + 1;
+    int32_t rc;
+    if ((rc = ensure(ctx, ctx->cl_planes, (size_t)(nx + ny + nz) * 16))) return rc;
+    float* base = (float*)ctx->cl_planes.p;
+    if ((rc = upload(ctx, base, view->x_planes, (size_t)nx * 16))) return rc;
+    if ((rc = upload(ctx, base + 4 * (size_t)nx, view->y_planes, (size_t)ny * 16))) return rc;
+    if ((rc = upload(ctx, base + 4 * (size_t)(nx + ny), view->z_planes, (size_t)nz * 16))) return rc;
+    ClusterViewDev& d = ctx->cl_view;
+    memcpy(d.dims, view->dims, sizeof d.dims);
+    d.is_orthographic = view->is_orthographic;
+    d.view_layer_mask = view->view_layer_mask;
+    d.n_clusters = (uint32_t)C;
+    memcpy(d.cluster_factors, view->cluster_factors, sizeof d.cluster_factors);
+    memcpy(d.view_from_world, view->view_from_world, sizeof d.view_from_world);
+    memcpy(d.clip_from_view, view->clip_from_view, sizeof d.clip_from_view);
+    memcpy(d.view_from_world_scale, view->view_from_world_scale, sizeof d.view_from_world_scale);
+    d.view_from_world_scale_max = view->view_from_world_scale_max;
+    memcpy(d.frustum, view->frustum, sizeof d.frustum);
+    d.x_planes = base;
+    d.y_planes = base + 4 * (size_t)nx;
+    d.z_planes = base + 4 * (size_t)(nx + ny);
+    d.cluster_spheres = nullptr;
+    if (view->cluster_spheres) {
+        if ((rc = ensure(ctx, ctx->cl_spheres, (size_t)C * 16))) return rc;
+        if ((rc = upload(ctx, ctx->cl_spheres.p, view->cluster_spheres, (size_t)C * 16))) return rc;
+        d.cluster_spheres = (const float*)ctx->cl_spheres.p;
+    }
+    ctx->cl_have_view = true;
+    ctx->cl_assigned = false;
+    return MI_OK;
+}
+
+int32_t mi_cluster_assign_resident(mi_ctx* ctx, uint64_t* out_total) {
+    ENTER(ctx);
+    if (!ctx->cl_have_view) return fail(ctx, MI_ERR_NOT_READY, "mi_cluster_assign_resident: no view uploaded");
+    if (ctx->cl_any_spot && !ctx->cl_view.cluster_spheres)
+        return fail(ctx, MI_ERR_INVALID_ARG, "spot lights present but mi_cluster_view.cluster_spheres is NULL");
+    const uint32_t C = ctx->cl_view.n_clusters;
+    ClusterObjects o{};
+    o.n = ctx->cl_n;
+    o.pos_range = (const float*)ctx->cl_pos.p;
+    o.obj_type = ctx->cl_have_type ? (const uint8_t*)ctx->cl_type.p : nullptr;
+    o.layer_mask = ctx->cl_have_layers ? (const uint32_t*)ctx->cl_layers.p : nullptr;
+    o.spot_dir = ctx->cl_have_spot ? (const float*)ctx->cl_dir.p : nullptr;
+    o.spot_sin_cos = ctx->cl_have_spot ? (const float*)ctx->cl_sincos.p : nullptr;
+    ClusterWork w{};
+    w.n_blocks = std::max(1u, (o.n + CLUSTER_BLOCK - 1) / CLUSTER_BLOCK);
+    int32_t rc;
+    if ((rc = ensure(ctx, ctx->cl_block_counts, (size_t)w.n_blocks * C * 2))) return rc;
+    if ((rc = ensure(ctx, ctx->cl_block_bases, (size_t)w.n_blocks * C * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->cl_offsets, ((size_t)C + 1) * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->cl_counts, (size_t)C * 6 * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->cl_scalars, 16))) return rc;
+    if (!ctx->cl_indices.p && (rc = ensure(ctx, ctx->cl_indices, (size_t)1 << 20))) return rc;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        w.block_counts = (uint16_t*)ctx->cl_block_counts.p;
+        w.block_bases = (uint32_t*)ctx->cl_block_bases.p;
+        w.offsets = (uint32_t*)ctx->cl_offsets.p;
+        w.counts = (uint32_t*)ctx->cl_counts.p;
+        w.indices = (uint32_t*)ctx->cl_indices.p;
+        w.capacity = ctx->cl_indices.bytes / 4;
+        w.total = (uint64_t*)ctx->cl_scalars.p;
+        w.farthest_z = (float*)((char*)ctx->cl_scalars.p + 8);
+        HIP_TRY(ctx, hipMemsetAsync(ctx->cl_offsets.p, 0, ((size_t)C + 1) * 4, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->cl_counts.p, 0, (size_t)C * 6 * 4, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->cl_scalars.p, 0, 16, ctx->stream));
+        HIP_TRY(ctx, launch_cluster_assign(ctx->cl_view, o, w, ctx->stream, prof_mark, ctx));
+        if (!out_total && attempt == 0) break;  // fire and forget: capacity is re-checked at download
+        uint64_t total = 0;
+        if ((rc = download(ctx, &total, w.total, 8))) return rc;
+        if (out_total) *out_total = total;
+        if (total <= w.capacity) break;
+        // index list overflowed the device buffer: grow and redo (the reference's Vecs grow the same way)
+        if ((rc = ensure(ctx, ctx->cl_indices, (size_t)total * 4 * 5 / 4))) return rc;
+    }
+    ctx->cl_assigned = true;
+    return MI_OK;
+}
+
+int32_t mi_cluster_download(mi_ctx* ctx, uint32_t* out_offsets, uint32_t* out_indices, uint64_t capacity, uint32_t* out_counts,
+                            uint64_t* out_total, float* out_farthest_z) {
+    ENTER(ctx);
+    if (!ctx->cl_assigned) return fail(ctx, MI_ERR_NOT_READY, "mi_cluster_download before mi_cluster_assign_resident");
+    const uint32_t C = ctx->cl_view.n_clusters;
+    uint64_t total = 0;
+    int32_t rc;
+    if ((rc = download(ctx, &total, ctx->cl_scalars.p, 8))) return rc;
+    if (total > ctx->cl_indices.bytes / 4) {
+        // fire-and-forget assign overflowed: redo with a big enough buffer
+        uint64_t t2 = 0;
+        if ((rc = mi_cluster_assign_resident(ctx, &t2))) return rc;
+        total = t2;
+    }
+    if (out_total) *out_total = total;
+    if (out_farthest_z && (rc = download(ctx, out_farthest_z, (char*)ctx->cl_scalars.p + 8, 4))) return rc;
+    if (out_offsets && (rc = download(ctx, out_offsets, ctx->cl_offsets.p, ((size_t)C + 1) * 4))) return rc;
+    if (out_counts && (rc = download(ctx, out_counts, ctx->cl_counts.p, (size_t)C * 6 * 4))) return rc;
+    if (out_indices) {
+        if (total > capacity) return fail(ctx, MI_ERR_CAPACITY, "cluster index list has %llu entries, capacity %llu", (unsigned long long)total, (unsigned long long)capacity);
+        if ((rc = download(ctx, out_indices, ctx->cl_indices.p, (size_t)total * 4))) return rc;
+    }
+    return MI_OK;
+}
+
+int32_t mi_cluster_assign(mi_ctx* ctx, const mi_cluster_view* view, uint32_t n_objects, const float* pos_range,
+                          const uint8_t* obj_type, const uint32_t* layer_mask, const float* spot_dir, const float* spot_sin_cos,
+                          uint32_t* out_offsets, uint32_t* out_indices, uint64_t capacity, uint32_t* out_counts,
+                          uint64_t* out_total, float* out_farthest_z) {
+    int32_t rc;
+    if ((rc = mi_cluster_upload_objects(ctx, n_objects, pos_range, obj_type, layer_mask, spot_dir, spot_sin_cos))) return rc;
+    if ((rc = mi_cluster_upload_view(ctx, view))) return rc;
+    uint64_t total = 0;
+    if ((rc = mi_cluster_assign_resident(ctx, &total))) return rc;
+    return mi_cluster_download(ctx, out_offsets, out_indices, capacity, out_counts, out_total, out_farthest_z);
+}
+
+// =============================================================================================
+// interop, timing
+// =============================================================================================
+int32_t mi_bind_visibility_output(mi_ctx* ctx, void* device_ptr, uint64_t words_per_view, uint64_t word_offset) {
+    ENTER(ctx);
+    ctx->ext_bitmask = device_ptr;
+    ctx->ext_words_per_view = words_per_view;
+    ctx->ext_word_offset = word_offset;
+    ctx->culled = false;
+    return MI_OK;
+}
+
+int32_t mi_device_buffer(mi_ctx* ctx, uint32_t which, void** out_ptr, uint64_t* out_bytes) {
+    ENTER(ctx);
+    if (!out_ptr) return fail(ctx, MI_ERR_INVALID_ARG, "mi_device_buffer: NULL");
+    void* p = nullptr;
+    uint64_t bytes = 0;
+    switch (which) {
+    case MI_BUF_GLOBAL_TRANSFORM: p = ctx->g; bytes = (uint64_t)ctx->n * 48; break;
+    case MI_BUF_VISIBILITY_BITMASK:
+        if (ctx->ext_bitmask) { p = ctx->ext_bitmask; bytes = ctx->ext_words_per_view * 8 * ctx->n_views; }
+        else { p = ctx->bitmask.p; bytes = ctx->words_per_view * 8 * ctx->n_views; }
+        break;
+    case MI_BUF_VIEW_VISIBILITY: p = ctx->vv; bytes = ctx->n; break;
+    case MI_BUF_VISIBLE_ROWS: p = ctx->out_rows.p; bytes = ctx->out_rows.bytes; break;
+    default: return fail(ctx, MI_ERR_INVALID_ARG, "mi_device_buffer: unknown buffer %u", which);
+    }
+    *out_ptr = p;
+    if (out_bytes) *out_bytes = bytes;
+    return MI_OK;
+}
+
+int32_t mi_timer_begin(mi_ctx* ctx) {
+    ENTER(ctx);
+    HIP_TRY(ctx, hipEventRecord(ctx->timer_a, ctx->stream));
+    return MI_OK;
+}
+int32_t mi_timer_end(mi_ctx* ctx, float* out_ms) {
+    ENTER(ctx);
+    HIP_TRY(ctx, hipEventRecord(ctx->timer_b, ctx->stream));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->timer_b));
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->timer_a, ctx->timer_b));
+    if (out_ms) *out_ms = ms;
+    return MI_OK;
+}
+
+int32_t mi_profile_enable(mi_ctx* ctx, int32_t enabled) {
+    ENTER(ctx);
+    if (!enabled) prof_collect(ctx);
+    else {
+        prof_collect(ctx);
+        memset(ctx->prof_launches, 0, sizeof ctx->prof_launches);
+        memset(ctx->prof_ms, 0, sizeof ctx->prof_ms);
+    }
+    ctx->profiling = enabled != 0;
+    return MI_OK;
+}
+int32_t mi_profile_filter(mi_ctx* ctx, uint64_t kernel_mask) {
+    ENTER(ctx);
+    ctx->prof_mask = kernel_mask ? kernel_mask : ~0ull;
+    return MI_OK;
+}
+int32_t mi_profile_read(mi_ctx* ctx, uint32_t* inout_n, uint64_t* launches, double* total_ms) {
+    ENTER(ctx);
+    if (!inout_n) return fail(ctx, MI_ERR_INVALID_ARG, "mi_profile_read: NULL");
+    prof_collect(ctx);
+    const uint32_t n = std::min<uint32_t>(*inout_n, K_NUM_KERNELS);
+    for (uint32_t k = 0; k < n; ++k) {
+        if (launches) launches[k] = ctx->prof_launches[k];
+        if (total_ms) total_ms[k] = ctx->prof_ms[k];
+    }
+    *inout_n = K_NUM_KERNELS;
+    return MI_OK;
+}
+const char* mi_profile_kernel_name(uint32_t k) {
+    static const char* names[K_NUM_KERNELS] = {"k_flat_propagate_cull", "k_level0_propagate", "k_cull", "k_vis_begin",
+                                               "k_vis_end", "k_compact_count", "k_compact_scan", "k_compact_scatter",
+                                               "k_mark_dirty", "k_propagate_tiles", "k_cluster_count", "k_cluster_scan",
+                                               "k_cluster_fill", "k_clear_u32"};
+    return k < K_NUM_KERNELS ? names[k] : nullptr;
+}
+
+// test hook: device logf probe (not part of the public header; used by tests/test_logf.py)
+int32_t mi_debug_logf(mi_ctx* ctx, const float* in, float* out, uint32_t n) {
+    ENTER(ctx);
+    DevBuf a, b;
+    int32_t rc;
+    if ((rc = ensure(ctx, a, (size_t)n * 4))) return rc;
+    if ((rc = ensure(ctx, b, (size_t)n * 4))) return rc;
+    if ((rc = upload(ctx, a.p, in, (size_t)n * 4))) return rc;
+    HIP_TRY(ctx, launch_logf_probe((const float*)a.p, (float*)b.p, n, ctx->stream));
+    rc = download(ctx, out, b.p, (size_t)n * 4);
+    hipFree(a.p);
+    hipFree(b.p);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,153 @@
+// kernels.h -- launch wrappers of the gfx950 kernels (implemented in kernels_*.hip).
+// Host-callable; every wrapper only enqueues on `stream` and returns the hipError_t of the launch.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mi {
+
+// One view's constants, read through scalar loads (uniform across the wave).
+struct ViewParams {
+    float planes[24];     // 6 x (nx,ny,nz,d)
+    uint32_t layer_mask;  // RenderLayers bits of the view
+    uint32_t flags;       // MI_VIEW_FLAG_*
+    uint32_t pad[2];
+};
+static_assert(sizeof(ViewParams) == 112, "ViewParams layout");
+
+// Device-resident component columns of one context (all pointers device memory).
+struct Columns {
+    uint32_t n;                 // live rows
+    const float* translation;   // 3n
+    const float* rotation;      // 4n
+    const float* scale;         // 3n
+    float* global;              // 12n
+    const float* aabb_center;   // 3n
+    const float* aabb_half;     // 3n
+    const uint8_t* flags;       // n
+    const uint32_t* layer_mask; // n
+    uint8_t* view_visibility;   // n
+    const uint8_t* in_range;    // n_views*n or nullptr
+    uint64_t* g_changed_bits;   // ceil(n/64) words: GlobalTransform change tick bumped
+    uint64_t* vv_changed_bits;  // ceil(n/64) words: ViewVisibility change tick bumped
+};
+
+struct VisibilityOut {
+    uint64_t* bitmask;        // base of per-view bitmasks
+    uint64_t words_per_view;  // stride between views, in 64-bit words
+    uint64_t word_offset;     // this shard's first word inside a view's mask
+};
+
+enum KernelId : uint32_t {
+    K_FLAT_PROPAGATE_CULL = 0,
+    K_LEVEL0_PROPAGATE,
+    K_CULL,
+    K_VIS_BEGIN,
+    K_VIS_END,
+    K_COMPACT_COUNT,
+    K_COMPACT_SCAN,
+    K_COMPACT_SCATTER,
+    K_MARK_DIRTY,
+    K_PROPAGATE_TILES,
+    K_CLUSTER_COUNT,
+    K_CLUSTER_SCAN,
+    K_CLUSTER_FILL,
+    K_CLEAR,
+    K_NUM_KERNELS
+};
+
+// ---- flat path ------------------------------------------------------------------------------
+hipError_t launch_flat_propagate_cull(const Columns& c, const ViewParams* d_views, uint32_t n_views,
+                                      const VisibilityOut& out, hipStream_t stream);
+// Level 0 of the hierarchy (roots + flat rows).  node_flags: bit0 = has children (nullptr = none do).
+// changed: per-row Changed<Transform>|... byte (nullptr or all_dirty => every row recomputed).
+// tree_bits: TransformTreeChanged bitset (only read when static_opt).
+hipError_t launch_level0_propagate(const Columns& c, uint32_t n_level0, const uint8_t* node_flags,
+                                   const uint8_t* changed, const uint32_t* tree_bits, bool all_dirty,
+                                   bool static_opt, hipStream_t stream);
+hipError_t launch_cull(const Columns& c, const ViewParams* d_views, uint32_t n_views, const VisibilityOut& out,
+                       hipStream_t stream);
+hipError_t launch_vis_begin(const Columns& c, hipStream_t stream);
+hipError_t launch_vis_end(const Columns& c, hipStream_t stream);
+
+// ---- VisibleEntities compaction -----------------------------------------------------------
+struct CompactArgs {
+    uint32_t n;                  // rows
+    uint32_t n_views, n_classes; // segments = n_views * n_classes (segment = view * n_classes + class_slot)
+    uint32_t class_bits[32];     // class bit of each class slot
+    const uint32_t* order;       // rows in ascending Entity-key order, nullptr = identity
+    const uint32_t* class_mask;  // nullptr = every row in class bit 0
+    const uint64_t* entity_keys; // nullptr = key == row
+    const uint64_t* bitmask;     // per-view masks (local words only)
+    uint64_t words_per_view, word_offset;
+    uint32_t* block_counts;      // [segments * n_blocks] -> turned into exclusive bases by the scan
+    uint32_t* seg_totals;        // [segments]
+    uint64_t* seg_bases;         // [segments] start of each segment in out_rows/out_keys
+    uint32_t* out_rows;          // packed lists
+    uint64_t* out_keys;
+    uint32_t n_blocks;
+};
+constexpr uint32_t COMPACT_BLOCK_ROWS = 4096;
+hipError_t launch_compact(const CompactArgs& a, hipStream_t stream, void (*mark)(void*, uint32_t), void* mark_ctx);
+
+// ---- hierarchy ---------------------------------------------------------------------------------
+constexpr uint32_t TILE_MAX_LEVELS = 6;
+constexpr uint32_t TILE_LDS_ROWS = 512;  // rows of one level kept in LDS (x2 buffers x 48 B)
+struct TileDesc {
+    uint32_t n_levels;
+    uint32_t start[TILE_MAX_LEVELS];
+    uint32_t count[TILE_MAX_LEVELS];
+    uint32_t pad;
+};
+hipError_t launch_mark_dirty(uint32_t n, const uint8_t* changed, const uint32_t* parent_idx, uint32_t* tree_bits,
+                             hipStream_t stream);
+hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, const TileDesc* d_tiles,
+                                  uint32_t n_tiles, const uint32_t* tree_bits, uint8_t* g_changed_bytes,
+                                  bool all_dirty, bool static_opt, hipStream_t stream);
+hipError_t launch_level0_bytes(const uint64_t* g_changed_bits, uint32_t n_level0, uint8_t* g_changed_bytes,
+                               hipStream_t stream);
+hipError_t launch_clear_u32(uint32_t* p, uint64_t n_words, hipStream_t stream);
+hipError_t launch_bytes_to_bits(const uint8_t* bytes, uint32_t n, uint64_t* bits, hipStream_t stream);
+
+// ---- clustering ------------------------------------------------------------------------------
+struct ClusterViewDev {
+    uint32_t dims[3];
+    uint32_t is_orthographic;
+    uint32_t view_layer_mask;
+    uint32_t n_clusters;
+    float cluster_factors[2];
+    float view_from_world[16];
+    float clip_from_view[16];
+    float view_from_world_scale[3];
+    float view_from_world_scale_max;
+    float frustum[24];
+    const float* x_planes;
+    const float* y_planes;
+    const float* z_planes;
+    const float* cluster_spheres;
+};
+struct ClusterObjects {
+    uint32_t n;
+    const float* pos_range;      // 4n
+    const uint8_t* obj_type;     // n or nullptr
+    const uint32_t* layer_mask;  // n or nullptr
+    const float* spot_dir;       // 3n or nullptr
+    const float* spot_sin_cos;   // 2n or nullptr
+};
+constexpr uint32_t CLUSTER_BLOCK = 256;  // objects per workgroup (= bits per cluster row in LDS)
+struct ClusterWork {
+    uint32_t n_blocks;
+    uint16_t* block_counts;  // [n_blocks * n_clusters] objects of block b in cluster c
+    uint32_t* block_bases;   // [n_blocks * n_clusters] exclusive base inside the cluster's segment
+    uint32_t* offsets;       // [n_clusters + 1]
+    uint32_t* counts;        // [6 * n_clusters]
+    uint32_t* indices;       // [capacity]
+    uint64_t capacity;
+    uint64_t* total;         // [1]
+    float* farthest_z;       // [1] (as uint bits for atomicMax of non-negative floats)
+};
+hipError_t launch_cluster_assign(const ClusterViewDev& view, const ClusterObjects& objs, const ClusterWork& w,
+                                 hipStream_t stream, void (*mark)(void*, uint32_t), void* mark_ctx);
+
+}  // namespace mi

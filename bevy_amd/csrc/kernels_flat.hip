@@ -1,0 +1,395 @@
+// kernels_flat.hip -- gfx950 kernels for the flat (non-hierarchical) render-prep path:
+//   sync_simple_transforms          crates/bevy_transform/src/systems.rs:42-79
+//   reset_view_visibility           crates/bevy_camera/src/visibility/mod.rs:733-737
+//   check_visibility_cpu_culling    crates/bevy_camera/src/visibility/mod.rs:748-876
+//   check_visibility_gpu_culling    crates/bevy_camera/src/visibility/mod.rs:884-903
+//   mark_newly_hidden_entities_...  crates/bevy_camera/src/visibility/mod.rs:908-918
+//
+// All of it is HBM-bound streaming work (roofline: DESIGN.md "Kernels").  One row per lane,
+// 256-thread workgroups (4 wave64 per group, grid >> 256 CUs), component columns read as
+// 12/16-byte lane-contiguous chunks, per-view visibility packed with a wave64 ballot: lane 0
+// of every wave stores one 64-bit mask word per view, so the bitmask is written coalesced and
+// needs no atomics.  Compiled with -ffp-contract=off (see glam_math.h).
+#include "glam_math.h"
+#include "kernels.h"
+
+namespace mi {
+
+struct F3 {
+    float x, y, z;
+};
+
+__device__ __forceinline__ V3 ld3(const float* base, uint32_t row) {
+    const F3 v = reinterpret_cast<const F3*>(base)[row];
+    return V3{v.x, v.y, v.z};
+}
+__device__ __forceinline__ V4 ld4(const float* base, uint32_t row) {
+    const float4 v = reinterpret_cast<const float4*>(base)[row];
+    return V4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ Affine ld_affine(const float* g, uint32_t row) {
+    const float4* p = reinterpret_cast<const float4*>(g) + 3ull * row;
+    const float4 a = p[0], b = p[1], c = p[2];
+    Affine r;
+    r.m.x_axis = V3{a.x, a.y, a.z};
+    r.m.y_axis = V3{a.w, b.x, b.y};
+    r.m.z_axis = V3{b.z, b.w, c.x};
+    r.t = V3{c.y, c.z, c.w};
+    return r;
+}
+__device__ __forceinline__ void st_affine(float* g, uint32_t row, const Affine& a) {
+    float4* p = reinterpret_cast<float4*>(g) + 3ull * row;
+    p[0] = make_float4(a.m.x_axis.x, a.m.x_axis.y, a.m.x_axis.z, a.m.y_axis.x);
+    p[1] = make_float4(a.m.y_axis.y, a.m.y_axis.z, a.m.z_axis.x, a.m.z_axis.y);
+    p[2] = make_float4(a.m.z_axis.z, a.t.x, a.t.y, a.t.z);
+}
+
+// The closure body of check_visibility_cpu_culling (visibility/mod.rs:788-858) for one row and
+// one view.  The sphere pre-test and the OBB test share the world-space centre and the plane
+// dot products (bit-identical values in the reference: both call transform_point3a on the same
+// inputs, mod.rs:827 and primitives.rs:279), so they are computed once.  Far plane never tested
+// on this path (intersect_far = false in both calls, mod.rs:831,835).
+__device__ __forceinline__ bool row_visible_in_view(const Affine& g, V3 center, V3 half, uint32_t fl,
+                                                    uint32_t entity_mask, bool in_range, const ViewParams& vp) {
+    bool vis = (fl & 0x01u) != 0;                          // InheritedVisibility
+    vis = vis && (vp.layer_mask & entity_mask) != 0;       // RenderLayers::intersects
+    vis = vis && (!(fl & 0x20u) || in_range);              // VisibilityRange
+    const bool cull = !(fl & 0x02u) && !(vp.flags & 0x01u); // !NoFrustumCulling && !camera NoCpuCulling
+    if (cull && (fl & (0x04u | 0x08u))) {
+        const bool has_aabb = (fl & 0x04u) != 0;
+        // world-space sphere: Aabb -> (affine*center, |M3*half|) ; Sphere component used as is
+        const V3 cw = has_aabb ? transform_point(g, center) : center;
+        const float sr = has_aabb ? length3(mul(g.m, half)) : half.x;
+        const V4 c4 = extend(cw, 1.0f);
+        bool inside = true;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const V4 pl = V4{vp.planes[4 * i], vp.planes[4 * i + 1], vp.planes[4 * i + 2], vp.planes[4 * i + 3]};
+            const float d = dot4(pl, c4);
+            inside = inside && !(d + sr <= 0.0f);
+            if (has_aabb) {
+                const float rr = aabb_relative_radius(half, xyz(pl), g.m);
+                inside = inside && !(d + rr <= 0.0f);
+            }
+        }
+        vis = vis && inside;
+    }
+    return vis;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused: G = From(T) for every row  +  reset_view_visibility  +  cull against all views.
+// Algorithmic bytes per row (V views): read 40 (T) + 24 (Aabb) + 1 (flags) + 4 (layers) + 1 (vv),
+// write 48 (G) + 1 (vv) + (V+2)/8 bits.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_flat_propagate_cull(Columns c, const ViewParams* __restrict__ views,
+                                                              uint32_t n_views, VisibilityOut out) {
+    const uint32_t row = blockIdx.x * 256u + threadIdx.x;
+    const bool live = row < c.n;
+    const uint32_t wave = row >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+
+    Affine g = {};
+    V3 center = {}, half = {};
+    uint32_t fl = 0, emask = 0, old_vv = 0;
+    if (live) {
+        const V3 t = ld3(c.translation, row);
+        const V4 q = ld4(c.rotation, row);
+        const V3 s = ld3(c.scale, row);
+        center = ld3(c.aabb_center, row);
+        half = ld3(c.aabb_half, row);
+        fl = c.flags[row];
+        emask = c.layer_mask[row];
+        old_vv = c.view_visibility[row];
+        g = affine_from_srt(s, q, t);
+        st_affine(c.global, row, g);
+    }
+    const bool ncc = (fl & 0x10u) != 0;  // NoCpuCulling rows are not in the cull query (mod.rs:771)
+    const unsigned long long lv = __ballot(live);  // waves past the last row must not touch the mask
+    bool any = false;
+    for (uint32_t v = 0; v < n_views; ++v) {
+        const bool in_range = (c.in_range && live) ? c.in_range[(size_t)v * c.n + row] != 0 : true;
+        const bool vis = live && !ncc && row_visible_in_view(g, center, half, fl, emask, in_range, views[v]);
+        any = any || vis;
+        const unsigned long long m = __ballot(vis);
+        if (lane == 0 && lv) out.bitmask[v * out.words_per_view + out.word_offset + wave] = m;
+    }
+    // reset (mod.rs:270-274) then set_visible (mod.rs:290-306)
+    bool vv_changed = false;
+    if (live && !ncc) {
+        const uint32_t prev = old_vv & 1u;
+        c.view_visibility[row] = (uint8_t)((prev << 1) | (any ? 1u : 0u));
+        vv_changed = any && !prev;
+    }
+    const unsigned long long chg = __ballot(vv_changed);
+    if (lane == 0 && lv) {
+        c.vv_changed_bits[wave] = chg;
+        c.g_changed_bits[wave] = lv;  // plain assignment bumps the tick of every written row (systems.rs:62)
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Level 0 of propagation: flat rows (sync_simple_transforms) and tree roots
+// (propagate_parent_transforms, systems.rs:522-530).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_level0_propagate(Columns c, uint32_t n_level0,
+                                                           const uint8_t* __restrict__ node_flags,
+                                                           const uint8_t* __restrict__ changed,
+                                                           const uint32_t* __restrict__ tree_bits, bool all_dirty,
+                                                           bool static_opt) {
+    const uint32_t row = blockIdx.x * 256u + threadIdx.x;
+    const bool live = row < n_level0;
+    bool write = false;
+    if (live) {
+        const bool has_children = node_flags ? (node_flags[row] & 1u) != 0 : false;
+        if (has_children) {
+            // roots: skipped only when the static optimisation is on and the tree is clean
+            const bool tree_changed = all_dirty || !tree_bits || ((tree_bits[row >> 5] >> (row & 31u)) & 1u);
+            write = !static_opt || tree_changed;
+        } else {
+            // flat rows: Changed<Transform> || Added<GlobalTransform> (systems.rs:45-50)
+            write = all_dirty || !changed || changed[row] != 0;
+        }
+        if (write) {
+            const V3 t = ld3(c.translation, row);
+            const V4 q = ld4(c.rotation, row);
+            const V3 s = ld3(c.scale, row);
+            st_affine(c.global, row, affine_from_srt(s, q, t));
+        }
+    }
+    const unsigned long long w = __ballot(write);
+    const unsigned long long lv = __ballot(live);
+    if ((threadIdx.x & 63u) == 0 && lv) c.g_changed_bits[row >> 6] = w;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cull against resident GlobalTransform (unfused path; also used after hierarchy propagation).
+// Algorithmic bytes per row: read 48 (G) + 24 + 1 + 4 + 1, write 1 + bits.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_cull(Columns c, const ViewParams* __restrict__ views, uint32_t n_views,
+                                               VisibilityOut out) {
+    const uint32_t row = blockIdx.x * 256u + threadIdx.x;
+    const bool live = row < c.n;
+    const uint32_t wave = row >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    Affine g = {};
+    V3 center = {}, half = {};
+    uint32_t fl = 0, emask = 0, cur = 0;
+    if (live) {
+        g = ld_affine(c.global, row);
+        center = ld3(c.aabb_center, row);
+        half = ld3(c.aabb_half, row);
+        fl = c.flags[row];
+        emask = c.layer_mask[row];
+        cur = c.view_visibility[row];
+    }
+    const bool ncc = (fl & 0x10u) != 0;
+    const unsigned long long lv = __ballot(live);
+    bool any = false;
+    for (uint32_t v = 0; v < n_views; ++v) {
+        const bool in_range = (c.in_range && live) ? c.in_range[(size_t)v * c.n + row] != 0 : true;
+        const bool vis = live && !ncc && row_visible_in_view(g, center, half, fl, emask, in_range, views[v]);
+        any = any || vis;
+        const unsigned long long m = __ballot(vis);
+        if (lane == 0 && lv) out.bitmask[v * out.words_per_view + out.word_offset + wave] = m;
+    }
+    bool vv_changed = false;
+    if (any && !(cur & 1u)) {  // set_visible, mod.rs:290-306
+        vv_changed = !(cur & 2u);
+        c.view_visibility[row] = (uint8_t)(cur | 1u);
+    }
+    const unsigned long long chg = __ballot(vv_changed);
+    if (lane == 0 && chg) atomicOr(reinterpret_cast<unsigned long long*>(&c.vv_changed_bits[wave]), chg);
+}
+
+// reset_view_visibility: bits = (bits & 1) << 1 for rows without NoCpuCulling; clears the change mask.
+__global__ void __launch_bounds__(256) k_vis_begin(Columns c) {
+    const uint32_t row = blockIdx.x * 256u + threadIdx.x;
+    const bool live = row < c.n;
+    if (live) {
+        const uint32_t fl = c.flags[row];
+        if (!(fl & 0x10u)) c.view_visibility[row] = (uint8_t)((c.view_visibility[row] & 1u) << 1);
+    }
+    if ((threadIdx.x & 63u) == 0 && live) c.vv_changed_bits[row >> 6] = 0ull;
+}
+
+// check_visibility_gpu_culling for NoCpuCulling rows, then mark_newly_hidden_entities_invisible.
+__global__ void __launch_bounds__(256) k_vis_end(Columns c) {
+    const uint32_t row = blockIdx.x * 256u + threadIdx.x;
+    const bool live = row < c.n;
+    bool changed = false;
+    if (live) {
+        const uint32_t fl = c.flags[row];
+        const uint32_t cur = c.view_visibility[row];
+        if (fl & 0x10u) {
+            const uint32_t nv = (fl & 0x01u) ? 3u : 0u;  // ViewVisibility::VISIBLE / HIDDEN, set_if_neq
+            if (nv != cur) { c.view_visibility[row] = (uint8_t)nv; changed = true; }
+        } else if ((cur & 3u) == 2u) {  // was_visible_now_hidden, mod.rs:264-267
+            c.view_visibility[row] = 0;
+            changed = true;
+        }
+    }
+    const unsigned long long chg = __ballot(changed);
+    if ((threadIdx.x & 63u) == 0 && chg)
+        atomicOr(reinterpret_cast<unsigned long long*>(&c.vv_changed_bits[row >> 6]), chg);
+}
+
+static inline uint32_t blocks_for(uint32_t n) { return (n + 255u) / 256u; }
+
+hipError_t launch_flat_propagate_cull(const Columns& c, const ViewParams* d_views, uint32_t n_views,
+                                      const VisibilityOut& out, hipStream_t stream) {
+    if (c.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_flat_propagate_cull, dim3(blocks_for(c.n)), dim3(256), 0, stream, c, d_views, n_views, out);
+    return hipGetLastError();
+}
+hipError_t launch_level0_propagate(const Columns& c, uint32_t n_level0, const uint8_t* node_flags,
+                                   const uint8_t* changed, const uint32_t* tree_bits, bool all_dirty,
+                                   bool static_opt, hipStream_t stream) {
+    if (n_level0 == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_level0_propagate, dim3(blocks_for(n_level0)), dim3(256), 0, stream, c, n_level0, node_flags,
+                       changed, tree_bits, all_dirty, static_opt);
+    return hipGetLastError();
+}
+hipError_t launch_cull(const Columns& c, const ViewParams* d_views, uint32_t n_views, const VisibilityOut& out,
+                       hipStream_t stream) {
+    if (c.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_cull, dim3(blocks_for(c.n)), dim3(256), 0, stream, c, d_views, n_views, out);
+    return hipGetLastError();
+}
+hipError_t launch_vis_begin(const Columns& c, hipStream_t stream) {
+    if (c.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_vis_begin, dim3(blocks_for(c.n)), dim3(256), 0, stream, c);
+    return hipGetLastError();
+}
+hipError_t launch_vis_end(const Columns& c, hipStream_t stream) {
+    if (c.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_vis_end, dim3(blocks_for(c.n)), dim3(256), 0, stream, c);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// VisibleEntities compaction (visibility/mod.rs:852-874): stable stream compaction of rows in
+// ascending Entity-key order, so the emitted list is already sorted like sort_unstable() leaves it.
+// count -> scan -> scatter; grid.y enumerates (view, class) segments.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool compact_pred(const CompactArgs& a, uint32_t pos, uint32_t view, uint32_t class_bit,
+                                             uint32_t* row_out) {
+    if (pos >= a.n) return false;
+    const uint32_t row = a.order ? a.order[pos] : pos;
+    *row_out = row;
+    const uint64_t word = a.bitmask[view * a.words_per_view + a.word_offset + (row >> 6)];
+    if (!((word >> (row & 63u)) & 1ull)) return false;
+    const uint32_t cm = a.class_mask ? a.class_mask[row] : 1u;
+    return ((cm >> class_bit) & 1u) != 0;
+}
+
+__global__ void __launch_bounds__(256) k_compact_count(CompactArgs a) {
+    const uint32_t seg = blockIdx.y, view = seg / a.n_classes, class_bit = a.class_bits[seg % a.n_classes];
+    const uint32_t base = blockIdx.x * COMPACT_BLOCK_ROWS;
+    uint32_t cnt = 0;
+    for (uint32_t j = 0; j < COMPACT_BLOCK_ROWS; j += 256u) {
+        uint32_t row;
+        const bool p = compact_pred(a, base + j + threadIdx.x, view, class_bit, &row);
+        cnt += __popcll(__ballot(p));
+    }
+    __shared__ uint32_t wsum[4];
+    if ((threadIdx.x & 63u) == 0) wsum[threadIdx.x >> 6] = cnt;  // cnt is wave-uniform
+    __syncthreads();
+    if (threadIdx.x == 0) a.block_counts[(size_t)seg * a.n_blocks + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// One workgroup: exclusive scan of block_counts in segment-major order; per-segment totals and bases.
+__global__ void __launch_bounds__(1024) k_compact_scan(CompactArgs a) {
+    __shared__ uint32_t part[1024];
+    __shared__ uint64_t carry;
+    const uint32_t segments = a.n_views * a.n_classes;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t seg = 0; seg < segments; ++seg) {
+        uint32_t* bc = a.block_counts + (size_t)seg * a.n_blocks;
+        uint32_t seg_running = 0;
+        for (uint32_t b0 = 0; b0 < a.n_blocks; b0 += 1024u) {
+            const uint32_t b = b0 + threadIdx.x;
+            const uint32_t v = b < a.n_blocks ? bc[b] : 0u;
+            part[threadIdx.x] = v;
+            __syncthreads();
+            for (uint32_t off = 1; off < 1024u; off <<= 1) {  // Hillis-Steele inclusive scan
+                uint32_t add = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+                __syncthreads();
+                part[threadIdx.x] += add;
+                __syncthreads();
+            }
+            if (b < a.n_blocks) bc[b] = seg_running + part[threadIdx.x] - v;  // exclusive, within the segment
+            seg_running += part[1023];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            a.seg_totals[seg] = seg_running;
+            a.seg_bases[seg] = carry;
+            carry += seg_running;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) k_compact_scatter(CompactArgs a) {
+    const uint32_t seg = blockIdx.y, view = seg / a.n_classes, class_bit = a.class_bits[seg % a.n_classes];
+    const uint32_t base = blockIdx.x * COMPACT_BLOCK_ROWS;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    __shared__ uint32_t wcnt[4];
+    uint64_t out_base = a.seg_bases[seg] + a.block_counts[(size_t)seg * a.n_blocks + blockIdx.x];
+    for (uint32_t j = 0; j < COMPACT_BLOCK_ROWS; j += 256u) {
+        uint32_t row = 0;
+        const bool p = compact_pred(a, base + j + threadIdx.x, view, class_bit, &row);
+        const unsigned long long m = __ballot(p);
+        if (lane == 0) wcnt[wv] = __popcll(m);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) { const uint32_t cw = wcnt[k]; before += k < wv ? cw : 0u; total += cw; }
+        if (p) {
+            const uint64_t dst = out_base + before + __popcll(m & ((1ull << lane) - 1ull));
+            a.out_rows[dst] = row;
+            a.out_keys[dst] = a.entity_keys ? a.entity_keys[row] : (uint64_t)row;
+        }
+        out_base += total;
+        __syncthreads();
+    }
+}
+
+hipError_t launch_compact(const CompactArgs& a, hipStream_t stream, void (*mark)(void*, uint32_t), void* mctx) {
+    if (a.n == 0) return hipSuccess;
+    const dim3 grid(a.n_blocks, a.n_views * a.n_classes);
+    if (mark) mark(mctx, K_COMPACT_COUNT);
+    hipLaunchKernelGGL(k_compact_count, grid, dim3(256), 0, stream, a);
+    if (mark) mark(mctx, K_COMPACT_SCAN);
+    hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, stream, a);
+    if (mark) mark(mctx, K_COMPACT_SCATTER);
+    hipLaunchKernelGGL(k_compact_scatter, grid, dim3(256), 0, stream, a);
+    if (mark) mark(mctx, K_NUM_KERNELS);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_clear_u32(uint32_t* p, uint64_t n_words) {
+    for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * 256ull) p[i] = 0u;
+}
+hipError_t launch_clear_u32(uint32_t* p, uint64_t n_words, hipStream_t stream) {
+    if (n_words == 0) return hipSuccess;
+    const uint32_t blocks = (uint32_t)((n_words + 255ull) / 256ull > 2048ull ? 2048ull : (n_words + 255ull) / 256ull);
+    hipLaunchKernelGGL(k_clear_u32, dim3(blocks), dim3(256), 0, stream, p, n_words);
+    return hipGetLastError();
+}
+__global__ void __launch_bounds__(256) k_bytes_to_bits(const uint8_t* __restrict__ bytes, uint32_t n, uint64_t* bits) {
+    const uint32_t row = blockIdx.x * 256u + threadIdx.x;
+    const bool b = row < n && bytes[row] != 0;
+    const unsigned long long m = __ballot(b);
+    if ((threadIdx.x & 63u) == 0 && (row & ~63u) < n) bits[row >> 6] = m;
+}
+hipError_t launch_bytes_to_bits(const uint8_t* bytes, uint32_t n, uint64_t* bits, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_bytes_to_bits, dim3(blocks_for(n)), dim3(256), 0, stream, bytes, n, bits);
+    return hipGetLastError();
+}
+
+}  // namespace mi

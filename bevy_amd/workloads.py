@@ -1,0 +1,156 @@
+"""Synthetic inputs shaped like the reference's stress tests.  Pure numpy, seeded,
+no reference files are read.  These only GENERATE columns; all computation on them happens in the
+HIP library (or, in tests, in the oracle).
+
+  many_cubes    examples/stress_tests/many_cubes.rs:192-212,574-587   Fibonacci sphere of unit cubes
+  many_lights   examples/stress_tests/many_lights.rs:48-51,71-126     100k point lights on a shell
+  gen_tree      examples/stress_tests/transform_hierarchy.rs:440-453  uniform b-ary tree, BFS parents
+"""
+import math
+
+import numpy as np
+
+F = np.float32
+NO_PARENT = 0xFFFFFFFF
+EPSILON = 0.36
+
+
+def splitmix64(seed, n, start=0):
+    """pseudo-random uint64 number start..start+n of the splitmix64(seed) sequence (vectorised, so any
+    slice of a big scene can be generated on its own)."""
+    idx = (np.arange(start + 1, start + n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed))
+    z = idx
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def uniform01(seed, n, start=0):
+    return (splitmix64(seed, n, start) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+
+
+def random_unit_quats(seed, n, start=0):
+    """Uniform on S^3 (Marsaglia / Shoemake), normalised in f64 then cast -> from_quat's precondition holds."""
+    u1, u2, u3 = uniform01(seed, n, start), uniform01(seed + 1, n, start), uniform01(seed + 2, n, start)
+    q = np.stack([np.sqrt(1 - u1) * np.sin(2 * np.pi * u2), np.sqrt(1 - u1) * np.cos(2 * np.pi * u2),
+                  np.sqrt(u1) * np.sin(2 * np.pi * u3), np.sqrt(u1) * np.cos(2 * np.pi * u3)], axis=1)
+    return q.astype(F)
+
+
+def fibonacci_sphere(n, radius, f32_acos=False, start=0, count=None):
+    """many_cubes.rs:574-587 (f64) / many_lights.rs:120-126 (acos evaluated in f32).  Points start..start+count
+    of the n-point spiral."""
+    count = n - start if count is None else count
+    i = np.arange(start, start + count, dtype=np.float64)
+    golden = 0.5 * (1.0 + math.sqrt(5.0))
+    theta = 2.0 * np.pi * (i / golden)
+    arg = 1.0 - 2.0 * (i + EPSILON) / (n - 1.0 + 2.0 * EPSILON)
+    phi = np.arccos(arg.astype(F)).astype(np.float64) if f32_acos else np.arccos(arg)
+    p = np.stack([np.cos(theta) * np.sin(phi), np.sin(theta) * np.sin(phi), np.cos(phi)], axis=1)
+    return (radius * p).astype(F)
+
+
+def many_cubes(n, radius=500.0, seed=42, ragged_flags=False, start=0, count=None):
+    """Flat scene: n unit cubes on a sphere (rows start..start+count of it).  Returns a dict of contiguous columns."""
+    total = n
+    count = total - start if count is None else count
+    t = fibonacci_sphere(total, radius, start=start, count=count)
+    r = random_unit_quats(seed, count, start)
+    n = count
+    s = np.ones((n, 3), F)
+    c = np.zeros((n, 3), F)
+    h = np.full((n, 3), 0.5, F)
+    flags = np.full(n, 0x01 | 0x04, np.uint8)  # InheritedVisibility | HAS_AABB
+    layers = np.ones(n, np.uint32)
+    if ragged_flags:  # exercise every branch of the visibility closure
+        rnd = splitmix64(seed + 7, n)
+        flags[(rnd % np.uint64(17)) == 0] &= ~np.uint8(0x01)              # hidden by inheritance
+        flags[(rnd % np.uint64(19)) == 1] |= np.uint8(0x02)               # NoFrustumCulling
+        sph = (rnd % np.uint64(23)) == 2
+        flags[sph] = (flags[sph] & ~np.uint8(0x04)) | np.uint8(0x08)      # Sphere instead of Aabb
+        c[sph] = t[sph]
+        h[sph, 0] = 0.75
+        flags[(rnd % np.uint64(29)) == 3] &= ~np.uint8(0x04)              # neither Aabb nor Sphere
+        flags[(rnd % np.uint64(31)) == 4] |= np.uint8(0x10)               # NoCpuCulling
+        layers[(rnd % np.uint64(13)) == 5] = 2                            # on render layer 1 only
+        layers[(rnd % np.uint64(37)) == 6] = 3
+        s[:, :] = (0.5 + uniform01(seed + 9, 3 * n).reshape(n, 3)).astype(F)
+        c[~sph] = (uniform01(seed + 11, 3 * n).reshape(n, 3)[~sph] - 0.5).astype(F)
+    return dict(n=n, translation=np.ascontiguousarray(t).reshape(-1), rotation=np.ascontiguousarray(r).reshape(-1),
+                scale=np.ascontiguousarray(s).reshape(-1), aabb_center=np.ascontiguousarray(c).reshape(-1),
+                aabb_half=np.ascontiguousarray(h).reshape(-1), flags=flags, layers=layers)
+
+
+def quat_mul(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz], np.float64)
+
+
+def quat_axis(axis, angle):
+    q = np.zeros(4, np.float64)
+    q["xyz".index(axis)] = math.sin(angle * 0.5)
+    q[3] = math.cos(angle * 0.5)
+    return q
+
+
+def affine_from_quat_translation(q, t):
+    """col-major 3x4 (x_axis,y_axis,z_axis,translation) of a rotation+translation, f32."""
+    x, y, z, w = [float(v) for v in q]
+    m = np.array([1 - 2 * (y * y + z * z), 2 * (x * y + w * z), 2 * (x * z - w * y),
+                  2 * (x * y - w * z), 1 - 2 * (x * x + z * z), 2 * (y * z + w * x),
+                  2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y),
+                  t[0], t[1], t[2]], np.float64)
+    return m.astype(F)
+
+
+def many_cubes_camera(frame=0, yaw=0.0, position=(0.0, 0.0, 0.0)):
+    """Camera of many_cubes.rs:590-603: at the origin, rotate_z(d) then rotate_x(d) every frame (d = 0.15/60),
+    plus an optional yaw (config 4: four cameras at 0/90/180/270 deg)."""
+    d = 0.15 / 60.0
+    q = quat_axis("y", yaw)
+    for _ in range(frame):
+        q = quat_mul(quat_axis("z", d), q)
+        q = quat_mul(quat_axis("x", d), q)
+    q = q / np.linalg.norm(q)
+    return affine_from_quat_translation(q, position)
+
+
+CAMERA_FOV = math.pi / 4.0
+CAMERA_ASPECT = 16.0 / 9.0
+CAMERA_NEAR = 0.1
+CAMERA_FAR = 1000.0
+
+
+def many_lights(n=100_000, radius=50.0, light_range=0.3):
+    p = fibonacci_sphere(n, radius, f32_acos=True)
+    pos_range = np.concatenate([p, np.full((n, 1), light_range, F)], axis=1)
+    return np.ascontiguousarray(pos_range).reshape(-1)
+
+
+def gen_tree(depth, branch, max_nodes=None, seed=42):
+    """Uniform tree (transform_hierarchy.rs:440-453): node i>0 has parent (i-1)//branch; rows are already in
+    level (BFS) order.  Local transforms: translation on a radius-32 circle (:266-269,416-422) plus a seeded
+    small rotation and a uniform scale in [0.9,1.1] so the chain product is non-trivial."""
+    total = sum(branch ** i for i in range(depth))
+    n = total if max_nodes is None else min(total, max_nodes)
+    idx = np.arange(n, dtype=np.int64)
+    parent = np.where(idx == 0, NO_PARENT, (idx - 1) // branch).astype(np.uint32)
+    level_offsets = [0]
+    acc, k = 0, 0
+    while acc < n:
+        acc = min(n, acc + branch ** k)
+        level_offsets.append(acc)
+        k += 1
+    slot = np.where(idx == 0, 0, (idx - 1) % branch).astype(np.float64)
+    a = slot / branch
+    t = np.stack([32.0 * np.cos(a), 32.0 * np.sin(a), np.zeros(n)], axis=1).astype(F)
+    small = (uniform01(seed, 3 * n).reshape(n, 3) - 0.5) * 0.4
+    q = np.concatenate([small, np.ones((n, 1))], axis=1)
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(F)
+    sc = (0.9 + 0.2 * uniform01(seed + 5, n)).astype(F)
+    s = np.repeat(sc[:, None], 3, axis=1)
+    return dict(n=n, parent=parent, level_offsets=np.array(level_offsets, np.uint32),
+                translation=np.ascontiguousarray(t).reshape(-1), rotation=np.ascontiguousarray(q).reshape(-1),
+                scale=np.ascontiguousarray(s).reshape(-1))

@@ -1,0 +1,322 @@
+/*
+ * bevy_mi355x.h -- C ABI of the MI355X-native render-prep path for Bevy
+ *                  (transform propagate -> frustum cull -> light-cluster assign).
+ *
+ * This is the drop-in boundary: exactly the entry points a Rust `bevy_mi355x` plugin crate
+ * binds with `#[link(name = "bevy_mi355x")] unsafe extern "C" { ... }` to replace the stock
+ * CPU systems (INTEGRATION.md shows the binding and the Plugin that registers it).  Plain
+ * pointers and sizes only -- no C++/torch types.  All reference citations are relative to
+ * the Bevy checkout (v0.20.0-dev).
+ *
+ * Conventions
+ *   - Every function returns an int32 status: MI_OK (0) or a negative MI_ERR_*.  Nothing
+ *     throws or aborts.  MI_ERR_MALFORMED_HIERARCHY is what the shim turns into the
+ *     reference's panic (crates/bevy_transform/src/systems.rs:715); any MI_ERR_DEVICE means
+ *     "run the stock CPU system this frame".
+ *   - Host slices are owned by the caller (the ECS) and only borrowed for the duration of the
+ *     call: the library copies in to pinned staging it owns and copies out into caller
+ *     buffers.  Device memory is library-owned and persists across frames.
+ *   - A context may be used from any thread, one call at a time (Bevy systems have no thread
+ *     affinity: crates/bevy_ecs/src/schedule/executor/multi_threaded.rs:241); every entry
+ *     point selects the context's device itself.
+ *   - Rows are dense indices 0..n chosen by the shim.  When a hierarchy is uploaded rows must
+ *     be in level (BFS) order -- mi_hierarchy_sort() computes that order from an arbitrary
+ *     ChildOf array.
+ *   - Layouts (f32 unless noted): translation[3n], rotation[4n] (x,y,z,w), scale[3n];
+ *     GlobalTransform[12n] = Affine3A::to_cols_array() (x_axis,y_axis,z_axis,translation);
+ *     Aabb center[3n], half_extents[3n]; a Sphere component is (center, half_extents.x = radius);
+ *     Frustum = 6 x (nx,ny,nz,d) in ViewFrustum order left,right,top,bottom,near,far
+ *     (crates/bevy_math/src/primitives/view_frustum.rs:25-34).
+ */
+#ifndef BEVY_MI355X_H
+#define BEVY_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_ABI_VERSION 1
+
+/* ---- status codes ---------------------------------------------------------------------- */
+#define MI_OK 0
+#define MI_ERR_INVALID_ARG (-1)
+#define MI_ERR_DEVICE (-2)
+#define MI_ERR_OUT_OF_MEMORY (-3)
+#define MI_ERR_MALFORMED_HIERARCHY (-4) /* systems.rs:715 assert_eq!(child_of.parent(), parent) */
+#define MI_ERR_NOT_READY (-5)           /* a required column / hierarchy / cull result is missing */
+#define MI_ERR_CAPACITY (-6)            /* caller buffer too small; required size is reported */
+
+/* ---- per-entity flag byte (mi_upload_bounds) ------------------------------------------- */
+#define MI_FLAG_INHERITED_VISIBLE 0x01u  /* InheritedVisibility::get(), visibility/mod.rs:804 */
+#define MI_FLAG_NO_FRUSTUM_CULLING 0x02u /* Has<NoFrustumCulling>, visibility/mod.rs:768,823 */
+#define MI_FLAG_HAS_AABB 0x04u           /* Option<&Aabb> is Some, visibility/mod.rs:824 */
+#define MI_FLAG_HAS_SPHERE 0x08u         /* Option<&Sphere> is Some (Aabb takes precedence), :838 */
+#define MI_FLAG_NO_CPU_CULLING 0x10u     /* With<NoCpuCulling>: excluded from a11/a12, handled by :884-903 */
+#define MI_FLAG_HAS_VISIBILITY_RANGE 0x20u /* Has<VisibilityRange>, :814-820 (needs mi_upload_view_ranges) */
+
+/* ---- per-view flag byte (mi_cull) ------------------------------------------------------- */
+#define MI_VIEW_FLAG_NO_CPU_CULLING 0x01u /* camera Has<NoCpuCulling>: skip frustum tests, :756,823 */
+
+/* ---- mi_propagate flags ----------------------------------------------------------------- */
+#define MI_PROPAGATE_ALL_DIRTY 0x1u  /* every Transform counts as changed (worst case / first frame) */
+#define MI_PROPAGATE_STATIC_OPT 0x2u /* StaticTransformOptimizations::Enabled, systems.rs:87-103 */
+
+#define MI_NO_PARENT 0xFFFFFFFFu
+
+/* ---- clusterable object types (gather order of assign.rs:190-296) ---------------------- */
+#define MI_OBJ_POINT_LIGHT 0
+#define MI_OBJ_SPOT_LIGHT 1
+#define MI_OBJ_RECT_LIGHT 2
+#define MI_OBJ_REFLECTION_PROBE 3
+#define MI_OBJ_IRRADIANCE_VOLUME 4
+#define MI_OBJ_DECAL 5
+
+typedef struct mi_ctx mi_ctx;
+
+/* ======================================================================================= */
+/* lifecycle                                                                                 */
+/* ======================================================================================= */
+
+/* Creates a context on HIP device `device`.  `hip_stream` is an existing hipStream_t to enqueue
+ * on (e.g. the host framework's current stream) or NULL to let the library create its own.
+ * Replaces: nothing in Bevy -- this is the Plugin::build-time setup (crates/bevy_app/src/plugin.rs:57-92). */
+int32_t mi_ctx_create(int32_t device, void* hip_stream, mi_ctx** out_ctx);
+int32_t mi_ctx_destroy(mi_ctx* ctx);
+/* Human-readable description of the last error on this context (or of the last failed
+ * mi_ctx_create when ctx == NULL).  Never NULL. */
+const char* mi_last_error_string(mi_ctx* ctx);
+/* Blocks until everything enqueued on the context's stream has finished. */
+int32_t mi_synchronize(mi_ctx* ctx);
+int32_t mi_abi_version(void);
+
+/* ======================================================================================= */
+/* component columns (ECS table columns -> device-resident SoA)                              */
+/* Bulk source on the Bevy side: Query::contiguous_iter() per-table slices                   */
+/* (crates/bevy_ecs/src/system/query.rs:1509-1560)                                           */
+/* ======================================================================================= */
+
+/* Sets the number of live rows (grows device columns geometrically; contents of existing rows are kept). */
+int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows);
+
+/* Transform { translation: Vec3, rotation: Quat, scale: Vec3 },
+ * crates/bevy_transform/src/components/transform.rs:86-106.  Rows [first_row, first_row+n). */
+int32_t mi_upload_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t n, const float* translation,
+                             const float* rotation, const float* scale);
+
+/* Existing GlobalTransform values (global_transform.rs:60).  Only needed when the previous values
+ * matter: set_if_neq change detection (systems.rs:719) and MI_PROPAGATE_STATIC_OPT skipping. */
+int32_t mi_upload_global_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t n, const float* global12);
+
+/* Aabb (crates/bevy_camera/src/primitives.rs:63-68) or Sphere (:197-211), the MI_FLAG_* byte and the
+ * first 32 RenderLayers bits (crates/bevy_camera/src/visibility/render_layers.rs:20; default layer 0 = mask 1).
+ * flags / layer_mask may be NULL (= MI_FLAG_INHERITED_VISIBLE|MI_FLAG_HAS_AABB, mask 1). */
+int32_t mi_upload_bounds(mi_ctx* ctx, uint32_t first_row, uint32_t n, const float* aabb_center,
+                         const float* aabb_half_extents, const uint8_t* flags, const uint32_t* layer_mask);
+
+/* ViewVisibility's packed byte (bit0 current, bit1 previous; visibility/mod.rs:226-275). */
+int32_t mi_upload_view_visibility(mi_ctx* ctx, uint32_t first_row, uint32_t n, const uint8_t* view_visibility);
+
+/* VisibilityClass (visibility/mod.rs:208-211) mapped by the shim to a bit set of small class ids,
+ * and Entity::to_bits() (crates/bevy_ecs/src/entity/mod.rs:566-568), the VisibleEntities sort key. */
+int32_t mi_upload_visibility_classes(mi_ctx* ctx, uint32_t first_row, uint32_t n, const uint32_t* class_mask);
+int32_t mi_upload_entity_keys(mi_ctx* ctx, uint32_t first_row, uint32_t n, const uint64_t* entity_bits);
+
+/* Per-row "Changed<Transform> || Changed<ChildOf> || Added<GlobalTransform> || orphaned" byte:
+ * the `changed` query + RemovedComponents of mark_dirty_trees / sync_simple_transforms
+ * (systems.rs:42-55,111-116).  Consumed (cleared) by the next mi_propagate. */
+int32_t mi_upload_changed(mi_ctx* ctx, uint32_t first_row, uint32_t n, const uint8_t* changed);
+
+/* VisibleEntityRanges::entity_is_in_range_of_view (visibility/range.rs), one byte per (view,row);
+ * only consulted for rows with MI_FLAG_HAS_VISIBILITY_RANGE.  NULL clears it (= all in range). */
+int32_t mi_upload_view_ranges(mi_ctx* ctx, uint32_t n_views, const uint8_t* in_range);
+
+/* ChildOf as a row index (MI_NO_PARENT for roots), rows in level order: level l occupies rows
+ * [level_offsets[l], level_offsets[l+1]); level 0 holds every root and every flat entity;
+ * parent_idx[row] must lie in the previous level.  Validates and returns
+ * MI_ERR_MALFORMED_HIERARCHY otherwise.  n_levels == 1 / parent_idx == NULL means "all rows flat".
+ * Replaces the Children/ChildOf walk of propagate_descendants_unchecked (systems.rs:679-748). */
+int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx, const uint32_t* level_offsets,
+                            uint32_t n_levels);
+
+/* Host helper: computes the level order for an arbitrary ChildOf array.
+ *   parent[n]            : row of each row's parent in the CALLER's order (MI_NO_PARENT = root)
+ *   out_new_to_old[n]    : permutation, new row -> old row (stable: siblings keep caller order)
+ *   out_parent_idx[n]    : parent in NEW row numbering, ready for mi_upload_hierarchy
+ *   out_level_offsets    : capacity level_capacity entries; *out_n_levels + 1 are written
+ * Returns MI_ERR_MALFORMED_HIERARCHY for cycles / out-of-range parents, MI_ERR_CAPACITY if
+ * level_capacity is too small.  Pure host code (no ctx). */
+int32_t mi_hierarchy_sort(uint32_t n, const uint32_t* parent, uint32_t* out_new_to_old, uint32_t* out_parent_idx,
+                          uint32_t* out_level_offsets, uint32_t level_capacity, uint32_t* out_n_levels);
+
+/* ======================================================================================= */
+/* systems                                                                                   */
+/* ======================================================================================= */
+
+/* mark_dirty_trees + sync_simple_transforms + propagate_parent_transforms
+ * (crates/bevy_transform/src/systems.rs:111-306, 42-79, 506-748) in one call.
+ * Writes GlobalTransform and the per-row "change tick bumped" bit. */
+int32_t mi_propagate(mi_ctx* ctx, uint32_t flags);
+
+/* reset_view_visibility (visibility/mod.rs:733-737) -- call once per frame before mi_cull. */
+int32_t mi_visibility_begin_frame(mi_ctx* ctx);
+
+/* check_visibility_cpu_culling (visibility/mod.rs:748-876) for n_views ACTIVE cameras in one pass over
+ * the columns: sets ViewVisibility bit0 (set_visible, :290-306), writes one packed visibility bitmask
+ * per view, and builds the per-view, per-class VisibleEntities lists sorted by Entity bits (:861-874).
+ *   frusta[24*n_views]; view_layer_masks[n_views] (NULL = layer 0); view_flags[n_views] (NULL = 0). */
+int32_t mi_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_masks, const uint8_t* view_flags,
+                uint32_t n_views);
+
+/* Fused fast path for flat rows (no hierarchy uploaded): sync_simple_transforms with every Transform
+ * dirty + reset_view_visibility + check_visibility_cpu_culling in ONE pass (Transform is read once,
+ * GlobalTransform is written once and never re-read).  Results are identical to
+ * mi_propagate(MI_PROPAGATE_ALL_DIRTY); mi_visibility_begin_frame(); mi_cull(...). */
+int32_t mi_propagate_and_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_masks,
+                              const uint8_t* view_flags, uint32_t n_views);
+
+/* check_visibility_gpu_culling for NoCpuCulling rows (visibility/mod.rs:884-903) followed by
+ * mark_newly_hidden_entities_invisible (:908-918). */
+int32_t mi_visibility_end_frame(mi_ctx* ctx);
+
+/* ======================================================================================= */
+/* results                                                                                   */
+/* ======================================================================================= */
+
+/* GlobalTransform rows [first_row, first_row+n) and (optional) bitmask, bit (row-first_row) set where
+ * the reference would have bumped GlobalTransform's change tick.  first_row must be a multiple of 32
+ * when changed_bitmask != NULL.  changed_bitmask has ceil(n/32) words. */
+int32_t mi_download_global_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t n, float* out_global12,
+                                      uint32_t* changed_bitmask);
+
+/* Packed per-view visibility of the last mi_cull: bit r of word r/32 = row r reached set_visible()
+ * for that view.  bitmask has ceil(n_rows/32) words. */
+int32_t mi_download_visibility(mi_ctx* ctx, uint32_t view, uint32_t* bitmask);
+
+/* ViewVisibility bytes and (optional) bitmask of rows whose change tick the reference would bump
+ * (set_visible hidden->visible, set_if_neq, mark_newly_hidden) since mi_visibility_begin_frame. */
+int32_t mi_download_view_visibility(mi_ctx* ctx, uint32_t first_row, uint32_t n, uint8_t* out_view_visibility,
+                                    uint32_t* changed_bitmask);
+
+/* VisibleEntities::get(class) of one view (visibility/mod.rs:342-402): entity keys ascending
+ * (= sort_unstable on Entity) and the matching rows.  Either output may be NULL.
+ * *out_count receives the list length; MI_ERR_CAPACITY if it exceeds `capacity`. */
+int32_t mi_download_visible_entities(mi_ctx* ctx, uint32_t view, uint32_t class_bit, uint64_t* out_entity_keys,
+                                     uint32_t* out_rows, uint32_t capacity, uint32_t* out_count);
+
+/* ======================================================================================= */
+/* light clustering -- assign_objects_to_clusters, crates/bevy_light/src/cluster/assign.rs:137-813 */
+/* ======================================================================================= */
+
+/* Per-view constants of assign.rs:342-485, computed by the shim with glam (or mi_cluster_view_build). */
+typedef struct mi_cluster_view {
+    uint32_t dims[3];        /* Clusters::dimensions */
+    uint32_t tile_size[2];   /* Clusters::tile_size */
+    uint32_t screen_size[2]; /* Camera::physical_viewport_size */
+    uint32_t is_orthographic;
+    uint32_t view_layer_mask;
+    float near_; /* Clusters::near (first_slice_depth * view_from_world_scale.z) */
+    float far_;  /* Clusters::far */
+    float cluster_factors[2];
+    float view_from_world[16]; /* column-major Mat4 */
+    float clip_from_view[16];
+    float view_from_clip[16];
+    float view_from_world_scale[3];
+    float view_from_world_scale_max;
+    float frustum[24];
+    const float* x_planes; /* (dims[0]+1) x 4, view space, assign.rs:434-476 */
+    const float* y_planes; /* (dims[1]+1) x 4 */
+    const float* z_planes; /* (dims[2]+1) x 4, assign.rs:478-485 */
+    /* Bounding spheres of every cluster AABB (compute_aabb_for_cluster, assign.rs:693-707,834-900),
+     * dims[0]*dims[1]*dims[2] x (cx,cy,cz,r), index (y*dims[0]+x)*dims[2]+z.  Only read for spot lights;
+     * may be NULL when there are none. */
+    const float* cluster_spheres;
+} mi_cluster_view;
+
+/* Host helper (pure host code): fills *out from the camera's GlobalTransform, clip_from_view, Frustum,
+ * viewport and the already-resolved ClusterConfig values (requested dims, first_slice_depth, far_z of
+ * ClusterFarZMode).  plane_storage must hold (dx+dy+dz+3)*4 floats and sphere_storage dx*dy*dz*4 floats
+ * (NULL = skip spheres) for the dims this call computes; query them first with mi_cluster_view_dims. */
+int32_t mi_cluster_view_dims(uint32_t screen_w, uint32_t screen_h, const uint32_t requested_dims[3],
+                             uint32_t out_tile_size[2], uint32_t out_dims[3]);
+int32_t mi_cluster_view_build(const float camera_affine[12], const float clip_from_view[16], const float frustum[24],
+                              uint32_t screen_w, uint32_t screen_h, const uint32_t requested_dims[3],
+                              float first_slice_depth, float far_z, uint32_t view_layer_mask, float* plane_storage,
+                              float* sphere_storage, mi_cluster_view* out);
+/* ClusterConfig::dimensions_for_screen_size for FixedZ (cluster/mod.rs:311-347). */
+int32_t mi_cluster_dimensions_fixed_z(uint32_t total, uint32_t z_slices, uint32_t screen_w, uint32_t screen_h,
+                                      uint32_t out_dims[3]);
+
+/* The per-object loop (assign.rs:487-811) over n_objects clusterable objects given in gather order
+ * (point, spot, rect, reflection probes, irradiance volumes, decals; :190-296):
+ *   pos_range[4n]   world translation + range (ClusterableObjectAssignmentData::sphere, :52-59)
+ *   obj_type[n]     MI_OBJ_* (NULL = all point lights)
+ *   layer_mask[n]   RenderLayers bits (NULL = default layer)
+ *   spot_dir[3n]    GlobalTransform::back() of spot lights, spot_sin_cos[2n] = sin_cos(outer_angle) (:563-573)
+ * Output = every cluster's Vec<Entity> in push order, flattened:
+ *   out_offsets[C+1], out_indices[capacity] (object index), out_counts[6*C] (ClusterableObjectCounts order),
+ *   out_total = last_frame_total_cluster_index_count, out_farthest_z = last_frame_farthest_z (:810-811).
+ * Returns MI_ERR_CAPACITY (with out_total/out_offsets/out_counts valid) when capacity < total. */
+int32_t mi_cluster_assign(mi_ctx* ctx, const mi_cluster_view* view, uint32_t n_objects, const float* pos_range,
+                          const uint8_t* obj_type, const uint32_t* layer_mask, const float* spot_dir,
+                          const float* spot_sin_cos, uint32_t* out_offsets, uint32_t* out_indices, uint64_t capacity,
+                          uint32_t* out_counts, uint64_t* out_total, float* out_farthest_z);
+
+/* Device-resident variant for steady-state frames: objects are uploaded once and re-assigned per frame. */
+int32_t mi_cluster_upload_objects(mi_ctx* ctx, uint32_t n_objects, const float* pos_range, const uint8_t* obj_type,
+                                  const uint32_t* layer_mask, const float* spot_dir, const float* spot_sin_cos);
+int32_t mi_cluster_upload_view(mi_ctx* ctx, const mi_cluster_view* view);
+int32_t mi_cluster_assign_resident(mi_ctx* ctx, uint64_t* out_total);
+int32_t mi_cluster_download(mi_ctx* ctx, uint32_t* out_offsets, uint32_t* out_indices, uint64_t capacity,
+                            uint32_t* out_counts, uint64_t* out_total, float* out_farthest_z);
+
+/* ======================================================================================= */
+/* camera helpers (pure host code; what update_frusta computes, visibility/mod.rs:627-636)   */
+/* ======================================================================================= */
+
+/* PerspectiveProjection::get_clip_from_view without a custom near plane (projection.rs:339-343). */
+int32_t mi_perspective_clip_from_view(float fov, float aspect_ratio, float near, float out_clip_from_view[16]);
+/* CameraProjection::compute_frustum (projection.rs:72-80) for any clip_from_view. */
+int32_t mi_compute_frustum(const float clip_from_view[16], const float camera_affine[12], float far,
+                           float out_frustum[24]);
+
+/* ======================================================================================= */
+/* device interop, multi-GPU plumbing, timing                                                */
+/* ======================================================================================= */
+
+/* Row-range sharding over GPUs (one context per GPU/process): this context owns global rows
+ * [first_global_row, first_global_row + n_rows).  Visibility bitmasks can be written straight into a
+ * caller-provided device buffer shared by an RCCL all-gather: view v's words for this shard land at
+ * device_ptr + (v * words_per_view + word_offset) * 8 bytes (any layout expressible that way, e.g.
+ * [gpu][view][words] for an in-place all-gather); the shard's first global row must be a multiple of 64
+ * and the caller guarantees the buffer covers every view's words.
+ * Pass device_ptr = NULL to go back to the internal buffer. */
+int32_t mi_bind_visibility_output(mi_ctx* ctx, void* device_ptr, uint64_t words_per_view, uint64_t word_offset);
+
+/* Raw device pointers of library-owned columns, for zero-copy consumers on the same device
+ * (e.g. the render world's mesh-uniform builder).  Valid until the next mi_columns_resize. */
+#define MI_BUF_GLOBAL_TRANSFORM 0
+#define MI_BUF_VISIBILITY_BITMASK 1
+#define MI_BUF_VIEW_VISIBILITY 2
+#define MI_BUF_VISIBLE_ROWS 3
+int32_t mi_device_buffer(mi_ctx* ctx, uint32_t which, void** out_device_ptr, uint64_t* out_bytes);
+
+/* HIP-event timing on the context's stream (torch.cuda.Event only sees torch's stream). */
+int32_t mi_timer_begin(mi_ctx* ctx);
+int32_t mi_timer_end(mi_ctx* ctx, float* out_ms); /* synchronises */
+
+/* Per-kernel HIP-event profile: while enabled every launch is bracketed by events.
+ * mi_profile_read synchronises and returns, for kernel id k < *inout_n: launches[k], total_ms[k].
+ * mi_profile_kernel_name(k) names the ids (NULL past the end). */
+int32_t mi_profile_enable(mi_ctx* ctx, int32_t enabled);
+/* Restricts the profile to the kernels whose id bit is set in kernel_mask (default: all).  Bracketing only
+ * the dominant kernel keeps the event overhead out of a timed region. */
+int32_t mi_profile_filter(mi_ctx* ctx, uint64_t kernel_mask);
+int32_t mi_profile_read(mi_ctx* ctx, uint32_t* inout_n, uint64_t* launches, double* total_ms);
+const char* mi_profile_kernel_name(uint32_t k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEVY_MI355X_H */

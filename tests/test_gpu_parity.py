@@ -1,0 +1,403 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same seeded
+inputs.  Bit-exact everywhere: GlobalTransform matrices (stronger than the 1e-5 the north star asks),
+ViewVisibility flags, per-view bitmasks, VisibleEntities lists, change-tick masks."""
+import math
+
+import numpy as np
+import pytest
+
+import bevy_amd as B
+from bevy_amd import api, workloads as W
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+@pytest.fixture(scope="module")
+def ctx_factory():
+    made = []
+
+    def make():
+        c = api.Context(0)
+        made.append(c)
+        return c
+    yield make
+    for c in made:
+        c.close()
+
+
+def frusta_for(cams):
+    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+    return np.concatenate([api.compute_frustum(cfv, cam, W.CAMERA_FAR) for cam in cams])
+
+
+def upload_scene(ctx, sc, vv0=None):
+    ctx.resize(sc["n"])
+    if sc["n"] == 0:
+        return
+    ctx.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
+    ctx.upload_bounds(sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"])
+    if vv0 is not None:
+        ctx.upload_view_visibility(vv0)
+
+
+def oracle_frame(sc, vv, frusta, vmasks, vflags):
+    return O.full_frame(sc["translation"], sc["rotation"], sc["scale"], sc["aabb_center"], sc["aabb_half"],
+                        sc["flags"], sc["layers"], vv, frusta, vmasks, vflags)
+
+
+def assert_bits(a, b, what):
+    bad = np.nonzero(np.asarray(a) != np.asarray(b))[0]
+    assert bad.size == 0, f"{what}: {bad.size} mismatches, first rows {bad[:8].tolist()}"
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 257, 4096, 50_003])
+def test_flat_fused_frame_matches_oracle(ctx_factory, n):
+    sc = W.many_cubes(n, radius=500.0 if n > 1000 else 5.0, ragged_flags=True)
+    cams = [W.many_cubes_camera(0), W.many_cubes_camera(5, yaw=math.pi / 2), W.many_cubes_camera(9, yaw=math.pi)]
+    frusta = frusta_for(cams)
+    vmasks = np.array([1, 3, 2], np.uint32)
+    vflags = np.array([0, 0, B.VIEW_FLAG_NO_CPU_CULLING], np.uint8)
+    vv0 = (W.splitmix64(3, n) % np.uint64(2)).astype(np.uint8)  # some rows visible last frame
+    ctx = ctx_factory()
+    upload_scene(ctx, sc, vv0)
+    ctx.propagate_and_cull(frusta, vmasks, vflags)
+    ctx.visibility_end_frame()
+    g_exp, vv_exp, vis_exp, chg_exp = oracle_frame(sc, vv0, frusta, vmasks, vflags)
+    g, g_chg = ctx.download_global_transforms()
+    assert g.tobytes() == g_exp.tobytes(), "GlobalTransform not bit-exact"
+    assert_bits(g_chg, np.ones(n, np.uint8), "GlobalTransform change mask")
+    for v in range(3):
+        assert_bits(ctx.download_visibility(v), vis_exp[v], f"view {v} visibility")
+    vv, vv_chg = ctx.download_view_visibility()
+    assert_bits(vv, vv_exp, "ViewVisibility bytes")
+    assert_bits(vv_chg, chg_exp, "ViewVisibility change mask")
+
+
+def test_unfused_equals_fused_and_oracle(ctx_factory):
+    n = 20_011
+    sc = W.many_cubes(n, ragged_flags=True)
+    frusta = frusta_for([W.many_cubes_camera(3), W.many_cubes_camera(3, yaw=2.0)])
+    vv0 = (W.splitmix64(5, n) % np.uint64(2)).astype(np.uint8)
+    a, b = ctx_factory(), ctx_factory()
+    upload_scene(a, sc, vv0)
+    upload_scene(b, sc, vv0)
+    a.propagate_and_cull(frusta)
+    a.visibility_end_frame()
+    b.propagate(B.PROPAGATE_ALL_DIRTY)
+    b.visibility_begin_frame()
+    b.cull(frusta)
+    b.visibility_end_frame()
+    g_exp, vv_exp, vis_exp, chg_exp = oracle_frame(sc, vv0, frusta, None, None)
+    for c in (a, b):
+        assert c.download_global_transforms(want_changed=False).tobytes() == g_exp.tobytes()
+        for v in range(2):
+            assert_bits(c.download_visibility(v), vis_exp[v], "visibility")
+        vv, chg = c.download_view_visibility()
+        assert_bits(vv, vv_exp, "vv")
+        assert_bits(chg, chg_exp, "vv changed")
+
+
+def test_view_visibility_lifecycle_over_frames(ctx_factory):
+    """visibility/mod.rs:1313-1448 at scale: the 2-bit protocol and change ticks over 6 frames of a moving camera."""
+    n = 30_000
+    sc = W.many_cubes(n, ragged_flags=True)
+    ctx = ctx_factory()
+    upload_scene(ctx, sc)
+    vv = np.zeros(n, np.uint8)
+    for frame in range(6):
+        frusta = frusta_for([W.many_cubes_camera(frame * 40)])
+        ctx.propagate_and_cull(frusta)
+        ctx.visibility_end_frame()
+        _, vv, _, chg = oracle_frame(sc, vv, frusta, None, None)
+        got_vv, got_chg = ctx.download_view_visibility()
+        assert_bits(got_vv, vv, f"frame {frame} vv")
+        assert_bits(got_chg, chg, f"frame {frame} change ticks")
+
+
+def test_partial_dirty_flat_rows(ctx_factory):
+    """sync_simple_transforms only rewrites rows whose Transform changed (systems.rs:45-50)."""
+    n = 10_000
+    sc = W.many_cubes(n)
+    ctx = ctx_factory()
+    upload_scene(ctx, sc)
+    ctx.propagate(B.PROPAGATE_ALL_DIRTY)
+    g0 = ctx.download_global_transforms(want_changed=False)
+    t2 = sc["translation"].copy()
+    t2[::2] += F(1.0)
+    changed = np.zeros(n, np.uint8)
+    changed[::7] = 1
+    ctx.upload_transforms(t2, sc["rotation"], sc["scale"])
+    ctx.upload_changed(changed)
+    ctx.propagate(0)
+    g1, chg = ctx.download_global_transforms()
+    exp, exp_chg = O.sync_simple_transforms(t2, sc["rotation"], sc["scale"], changed, g0)
+    assert g1.tobytes() == exp.tobytes()
+    assert_bits(chg, exp_chg, "changed rows")
+    ctx.propagate(0)  # change flags were consumed: nothing is rewritten
+    g2, chg2 = ctx.download_global_transforms()
+    assert g2.tobytes() == exp.tobytes() and not chg2.any()
+
+
+def test_visible_entities_sorted_lists(ctx_factory):
+    n = 40_000
+    sc = W.many_cubes(n, ragged_flags=True)
+    frusta = frusta_for([W.many_cubes_camera(0), W.many_cubes_camera(0, yaw=1.0)])
+    rnd = W.splitmix64(99, n)
+    # Entity::to_bits: generation << 32 | !index  -> arbitrary order relative to rows
+    keys = ((rnd % np.uint64(3)) << np.uint64(32)) | (np.uint64(0xFFFFFFFF) - np.random.default_rng(1).permutation(n).astype(np.uint64))
+    class_mask = np.where(rnd % np.uint64(5) == 0, 0b101, np.where(rnd % np.uint64(5) == 1, 0b100, 0b001)).astype(np.uint32)
+    class_mask[rnd % np.uint64(41) == 0] = 0  # no VisibilityClass: set_visible but in no list (mod.rs:848-857)
+    ctx = ctx_factory()
+    upload_scene(ctx, sc)
+    ctx.upload_entity_keys(keys)
+    ctx.upload_visibility_classes(class_mask)
+    ctx.propagate_and_cull(frusta)
+    _, _, vis_exp, _ = oracle_frame(sc, np.zeros(n, np.uint8), frusta, None, None)
+    for v in range(2):
+        for cb in (0, 2, 1):
+            k, rows = ctx.download_visible_entities(v, cb)
+            ek, er = O.visible_entities_sorted(vis_exp[v], class_mask, cb, keys)
+            assert np.array_equal(k, ek) and np.array_equal(rows, er), (v, cb, len(k), len(ek))
+            assert np.all(k[1:] >= k[:-1])
+    # identity order fast path: no keys uploaded -> key == row
+    ctx2 = ctx_factory()
+    upload_scene(ctx2, sc)
+    ctx2.propagate_and_cull(frusta)
+    k, rows = ctx2.download_visible_entities(0, 0)
+    assert np.array_equal(rows, np.nonzero(vis_exp[0])[0].astype(np.uint32)) and np.array_equal(k, rows.astype(np.uint64))
+
+
+# ---- hierarchy -----------------------------------------------------------------------------------
+
+def upload_tree(ctx, tr, g_init=None):
+    ctx.resize(tr["n"])
+    ctx.upload_transforms(tr["translation"], tr["rotation"], tr["scale"])
+    ctx.upload_hierarchy(tr["parent"], tr["level_offsets"])
+    if g_init is not None:
+        ctx.upload_global_transforms(g_init)
+
+
+def test_reference_propagate_scenarios_on_gpu(ctx_factory):
+    """systems.rs:888-925 did_propagate and :1048-1097 correct_transforms_when_no_children, through the GPU path."""
+    ident_q = [0, 0, 0, 1]
+    t = np.array([1, 0, 0, 1, 0, 0, 0, 2, 0, 0, 0, 3], F)  # flat root, parent, two children
+    r = np.array(ident_q * 4, F)
+    s = np.ones(12, F)
+    parent = np.array([B.NO_PARENT, B.NO_PARENT, 1, 1], np.uint32)
+    ctx = ctx_factory()
+    ctx.resize(4)
+    ctx.upload_transforms(t, r, s)
+    ctx.upload_hierarchy(parent, np.array([0, 2, 4], np.uint32))
+    ctx.propagate(B.PROPAGATE_ALL_DIRTY | B.PROPAGATE_STATIC_OPT)
+    g = ctx.download_global_transforms(want_changed=False).reshape(4, 12)
+    assert g[2][9:].tolist() == [1.0, 2.0, 0.0] and g[3][9:].tolist() == [1.0, 0.0, 3.0]
+    assert g[2][:9].tolist() == [1, 0, 0, 0, 1, 0, 0, 0, 1]
+    # chain of three: parent(1,0,0) <- identity <- identity
+    t = np.array([1, 0, 0, 0, 0, 0, 0, 0, 0], F)
+    ctx.resize(3)
+    ctx.upload_transforms(t, np.array(ident_q * 3, F), np.ones(9, F))
+    ctx.upload_hierarchy(np.array([B.NO_PARENT, 0, 1], np.uint32), np.array([0, 1, 2, 3], np.uint32))
+    ctx.propagate(B.PROPAGATE_ALL_DIRTY)
+    g = ctx.download_global_transforms(want_changed=False).reshape(3, 12)
+    for row in g:
+        assert row.tolist() == [1, 0, 0, 0, 1, 0, 0, 0, 1, 1, 0, 0]
+
+
+def test_malformed_hierarchy_is_reported(ctx_factory):
+    ctx = ctx_factory()
+    ctx.resize(3)
+    with pytest.raises(api.MiError) as e:  # row 2's parent is not in the previous level
+        ctx.upload_hierarchy(np.array([B.NO_PARENT, 0, 0], np.uint32), np.array([0, 1, 2, 3], np.uint32))
+    assert e.value.code == api.MI_ERR_MALFORMED_HIERARCHY
+
+
+@pytest.mark.parametrize("depth,branch,cap", [(5, 4, None), (8, 4, None), (11, 2, None), (9, 4, 60_000), (4, 40, None)])
+def test_tree_propagation_all_dirty(ctx_factory, depth, branch, cap):
+    tr = W.gen_tree(depth, branch, cap)
+    ctx = ctx_factory()
+    upload_tree(ctx, tr)
+    ctx.propagate(B.PROPAGATE_ALL_DIRTY)
+    g, chg = ctx.download_global_transforms()
+    rc, g_exp, chg_exp = O.propagate_transforms(tr["parent"], tr["translation"], tr["rotation"], tr["scale"])
+    assert rc == 0
+    bad = np.nonzero((g.view(np.uint32) != g_exp.view(np.uint32)).reshape(-1, 12).any(axis=1))[0]
+    assert bad.size == 0, f"{bad.size} rows differ, first {bad[:5].tolist()}"
+    assert_bits(chg, chg_exp, "changed")
+    # independent second oracle: TransformHelper chain product on a few leaves
+    for row in (tr["n"] - 1, tr["n"] // 2, 1 % tr["n"]):
+        assert np.allclose(g.reshape(-1, 12)[row], O.compute_global_transform(tr["parent"], tr["translation"],
+                                                                              tr["rotation"], tr["scale"], row),
+                           rtol=1e-5, atol=1e-3)
+    # second run with unchanged inputs: set_if_neq sees equal values everywhere except re-assigned roots
+    ctx.propagate(B.PROPAGATE_ALL_DIRTY)
+    g2, chg2 = ctx.download_global_transforms()
+    rc, g_exp2, chg_exp2 = O.propagate_transforms(tr["parent"], tr["translation"], tr["rotation"], tr["scale"], global_in=g_exp)
+    assert g2.tobytes() == g_exp2.tobytes()
+    assert_bits(chg2, chg_exp2, "changed (2nd run)")
+
+
+def random_forest(n, seed, flat_fraction=0.3, max_children=6):
+    rng = np.random.default_rng(seed)
+    parent = np.full(n, B.NO_PARENT, np.uint32)
+    n_flat = int(n * flat_fraction)
+    order = rng.permutation(n)
+    nodes = order[n_flat:]
+    for k in range(1, len(nodes)):
+        if rng.random() < 0.01:
+            continue
+        lo = max(0, k - 1 - int(rng.integers(0, 50 * max_children)))
+        parent[nodes[k]] = nodes[rng.integers(lo, k)]
+    return parent
+
+
+@pytest.mark.parametrize("static_opt", [False, True])
+def test_random_forest_with_static_optimisation(ctx_factory, static_opt):
+    n = 30_000
+    parent_old = random_forest(n, 7)
+    new_to_old, parent, offs = api.hierarchy_sort(parent_old)
+    rng = np.random.default_rng(11)
+    t = rng.normal(size=(n, 3)).astype(F).reshape(-1)
+    q = rng.normal(size=(n, 4)); q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(F).reshape(-1)
+    s = rng.uniform(0.8, 1.25, size=(n, 3)).astype(F).reshape(-1)
+    flags = B.PROPAGATE_STATIC_OPT if static_opt else 0
+    ctx = ctx_factory()
+    ctx.resize(n)
+    ctx.upload_transforms(t, q, s)
+    ctx.upload_hierarchy(parent, offs)
+    ctx.propagate(B.PROPAGATE_ALL_DIRTY | flags)
+    g0 = ctx.download_global_transforms(want_changed=False)
+    rc, g0_exp, _ = O.propagate_transforms(parent, t, q, s, static_opt=static_opt)
+    assert rc == 0 and g0.tobytes() == g0_exp.tobytes()
+    # frame 2: 1% of the transforms change
+    changed = (rng.random(n) < 0.01).astype(np.uint8)
+    t2 = t.copy().reshape(n, 3); t2[changed == 1] += F(0.5); t2 = t2.reshape(-1)
+    ctx.upload_transforms(t2, q, s)
+    ctx.upload_changed(changed)
+    ctx.propagate(flags)
+    g1, chg = ctx.download_global_transforms()
+    tree_changed = O.mark_dirty_trees(parent, changed)
+    rc, g1_exp, chg_exp = O.propagate_transforms(parent, t2, q, s, global_in=g0_exp, static_opt=static_opt,
+                                                 tree_changed=tree_changed, transform_changed=changed)
+    assert rc == 0
+    bad = np.nonzero((g1.view(np.uint32) != g1_exp.view(np.uint32)).reshape(-1, 12).any(axis=1))[0]
+    assert bad.size == 0, f"{bad.size} rows differ, first {bad[:5].tolist()}"
+    assert_bits(chg, chg_exp, "changed")
+
+
+def test_cull_after_tree_propagation(ctx_factory):
+    tr = W.gen_tree(8, 4)
+    n = tr["n"]
+    ctx = ctx_factory()
+    upload_tree(ctx, tr)
+    c = np.zeros(3 * n, F); h = np.full(3 * n, 0.5, F)
+    ctx.upload_bounds(c, h)
+    frusta = frusta_for([W.many_cubes_camera(0, position=(0.0, 0.0, 150.0))])
+    ctx.propagate(B.PROPAGATE_ALL_DIRTY)
+    ctx.visibility_begin_frame()
+    ctx.cull(frusta)
+    ctx.visibility_end_frame()
+    rc, g_exp, _ = O.propagate_transforms(tr["parent"], tr["translation"], tr["rotation"], tr["scale"])
+    flags = np.full(n, 0x05, np.uint8)
+    vv = O.reset_view_visibility(flags, np.zeros(n, np.uint8))
+    vv, vis, _ = O.check_visibility(g_exp, c, h, flags, np.ones(n, np.uint32), vv, frusta)
+    assert_bits(ctx.download_visibility(0), vis[0], "tree visibility")
+    assert 0 < vis[0].sum() < n
+
+
+# ---- clustering -----------------------------------------------------------------------------------
+
+def cluster_case(ctx, cam, pos_range, obj_type=None, layers=None, spot_dir=None, spot_sin_cos=None,
+                 req=(16, 9, 24), far_z=1000.0, ortho=False, view_mask=1):
+    if ortho:
+        from test_abi_and_host import ortho_clip_from_view
+        cfv = ortho_clip_from_view(-60.0, 60.0, -33.75, 33.75, 0.1, 1000.0)
+    else:
+        cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+    fr = api.compute_frustum(cfv, cam, W.CAMERA_FAR)
+    view, keep = api.cluster_view_build(cam, cfv, fr, 1920, 1080, req, 5.0, far_z, view_mask)
+    ov = O.cluster_view_setup(cam, cfv, fr, 1920, 1080, req, 5.0, far_z, view_mask)
+    off, idx, counts, far, total = ctx.cluster_assign(view, pos_range, obj_type, layers, spot_dir, spot_sin_cos)
+    eoff, eidx, ecounts, efar, etotal = O.assign_objects_to_clusters(ov, pos_range, obj_type, layers, spot_dir, spot_sin_cos)
+    assert total == etotal, (total, etotal)
+    assert np.array_equal(off, eoff), "cluster offsets"
+    assert np.array_equal(idx, eidx), "cluster index lists (push order)"
+    assert np.array_equal(counts, ecounts), "per-type counts"
+    assert np.float32(far).tobytes() == np.float32(efar).tobytes(), (far, efar)
+    return total
+
+
+def test_cluster_many_lights_shape(ctx_factory):
+    ctx = ctx_factory()
+    pr = W.many_lights(20_000, 50.0, 0.3)
+    total = cluster_case(ctx, W.many_cubes_camera(0), pr)
+    assert total > 0
+    cluster_case(ctx, W.many_cubes_camera(30, yaw=0.4), pr)
+    cluster_case(ctx, W.many_cubes_camera(0), pr, ortho=True)
+
+
+def test_cluster_mixed_objects(ctx_factory):
+    rng = np.random.default_rng(5)
+    n = 3000
+    pos = rng.uniform(-60, 60, size=(n, 3)).astype(F)
+    rng_r = np.where(rng.random(n) < 0.1, rng.uniform(20, 200, n), rng.uniform(0.5, 12, n)).astype(F)
+    pr = np.concatenate([pos, rng_r[:, None]], axis=1).astype(F).reshape(-1)
+    types = np.sort(rng.integers(0, 6, n)).astype(np.uint8)  # gather order: grouped by type
+    layers = np.where(rng.random(n) < 0.1, 2, 1).astype(np.uint32)
+    d = rng.normal(size=(n, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(F).reshape(-1)
+    ang = rng.uniform(0.1, 1.4, n).astype(F)
+    sc = np.stack([np.sin(ang), np.cos(ang)], axis=1).astype(F).reshape(-1)
+    ctx = ctx_factory()
+    for cam in (W.many_cubes_camera(0), W.many_cubes_camera(12, yaw=2.2, position=(5.0, 1.0, -3.0))):
+        cluster_case(ctx, cam, pr, types, layers, d, sc)
+        cluster_case(ctx, cam, pr, types, layers, d, sc, req=(17, 9, 24), far_z=120.0)
+        cluster_case(ctx, cam, pr, types, layers, d, sc, req=(5, 3, 1))
+        cluster_case(ctx, cam, pr, types, layers, d, sc, ortho=True)
+
+
+def test_cluster_edge_cases(ctx_factory):
+    ctx = ctx_factory()
+    cam = W.many_cubes_camera(0)
+    assert cluster_case(ctx, cam, np.zeros(0, F)) == 0                                  # no objects
+    assert cluster_case(ctx, cam, np.array([0, 0, 500, 1.0], F)) == 0                   # behind the camera
+    assert cluster_case(ctx, cam, np.array([0, 0, -20, 1e6], F)) == 16 * 9 * 24         # covers every cluster
+    cluster_case(ctx, cam, np.array([0, 0, 0, 3.0, 0, 0, -5.0, 0.0, 0.2, 0.1, -0.1, 0.05], F))  # at the eye / zero range
+    cluster_case(ctx, cam, np.array([0, 0, -20, 5.0], F), view_mask=2)                  # layer mismatch
+
+
+def test_device_logf_matches_libm(ctx_factory):
+    ctx = ctx_factory()
+    rng = np.random.default_rng(3)
+    bits = rng.integers(0, 0x7F800000, 2_000_000, dtype=np.uint32)
+    x = np.concatenate([bits.view(F), np.array([0.0, 1.0, np.inf, 1e-45, 1.17549435e-38, -1.0, np.nan], F)])
+    got = ctx.debug_logf(x)
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.logf.restype = ctypes.c_float
+    libm.logf.argtypes = [ctypes.c_float]
+    sample = np.concatenate([np.arange(0, len(x), 37), np.arange(len(x) - 7, len(x))])
+    for i in sample:
+        e = F(libm.logf(float(x[i])))
+        assert (np.isnan(e) and np.isnan(got[i])) or e.tobytes() == got[i].tobytes(), (x[i], e, got[i])
+
+
+# ---- BASELINE-size run -------------------------------------------------------------------------
+
+def test_one_million_flat_entities(ctx_factory):
+    """configs[1]: 1M flat entities, 1 frustum -- compared row-for-row with the oracle (a few seconds of CPU)."""
+    n = 1_000_000
+    sc = W.many_cubes(n)
+    frusta = frusta_for([W.many_cubes_camera(1)])
+    ctx = ctx_factory()
+    upload_scene(ctx, sc)
+    ctx.propagate_and_cull(frusta)
+    ctx.visibility_end_frame()
+    g_exp, vv_exp, vis_exp, chg_exp = oracle_frame(sc, np.zeros(n, np.uint8), frusta, None, None)
+    assert ctx.download_global_transforms(want_changed=False).tobytes() == g_exp.tobytes()
+    vis = ctx.download_visibility(0)
+    assert_bits(vis, vis_exp[0], "visibility @1M")
+    frac = vis.mean()
+    assert 0.01 < frac < 0.15, frac
+    k, rows = ctx.download_visible_entities(0, 0)
+    assert np.array_equal(rows, np.nonzero(vis_exp[0])[0].astype(np.uint32))

@@ -1,0 +1,93 @@
+"""N>1 path on CPU: world_size-2 gloo run of the entity-range shard + in-place all-gather of the packed
+ViewVisibility bitmask (bevy_amd/sharding.py).  The kernels need a GPU, so each rank fills its block of the
+gathered buffer from the oracle's per-row visibility (the oracle is the checker here, never the product);
+what is under test is the row partition, the [gpu][view][words] layout and the collective."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from bevy_amd import api, sharding, workloads as W
+import oracle_lib as O
+
+N_ROWS = 10_000 + 37
+N_VIEWS = 3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _scene_and_frusta():
+    sc = W.many_cubes(N_ROWS, radius=120.0, ragged_flags=True)
+    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+    frusta = np.concatenate([api.compute_frustum(cfv, W.many_cubes_camera(0, yaw=v * 1.1), W.CAMERA_FAR) for v in range(N_VIEWS)])
+    return sc, frusta
+
+
+def _visible(sc, frusta, lo, hi):
+    s3, s4 = slice(3 * lo, 3 * hi), slice(4 * lo, 4 * hi)
+    n = hi - lo
+    _, _, vis, _ = O.full_frame(sc["translation"][s3], sc["rotation"][s4], sc["scale"][s3], sc["aabb_center"][s3],
+                                sc["aabb_half"][s3], sc["flags"][lo:hi], sc["layers"][lo:hi], np.zeros(n, np.uint8), frusta)
+    return vis
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sc, frusta = _scene_and_frusta()
+        lo, hi = sharding.shard_rows(N_ROWS, world, rank)
+        w = sharding.words_per_shard(N_ROWS, world)
+        full = torch.zeros(sharding.gathered_words(N_ROWS, world, N_VIEWS), dtype=torch.int64)
+        wpv, woff = sharding.block_offset_words(N_ROWS, world, N_VIEWS, rank)
+        assert wpv == w and woff == rank * N_VIEWS * w
+        vis = _visible(sc, frusta, lo, hi)
+        mine = np.zeros((N_VIEWS, w), np.uint64)
+        for v in range(N_VIEWS):
+            bits = np.zeros(w * 64, np.uint8)
+            bits[:hi - lo] = vis[v]
+            mine[v] = np.packbits(bits, bitorder="little").view(np.uint64)
+        full[woff:woff + N_VIEWS * w] = torch.from_numpy(mine.reshape(-1).view(np.int64))
+        sharding.all_gather_visibility(full, N_ROWS, world, N_VIEWS, rank)
+        ret[rank] = full.numpy().copy()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_rows_partition():
+    for n in (0, 1, 255, 256, 257, 10_000, 1_000_000, 10_000_000):
+        for world in (1, 2, 3, 8):
+            spans = [sharding.shard_rows(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c and a <= b
+            assert all(lo % sharding.ROW_ALIGN == 0 for lo, hi in spans if hi > lo)
+            assert all(hi - lo <= sharding.words_per_shard(n, world) * 64 for lo, hi in spans)
+
+
+def test_all_gather_visibility_world2():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    assert np.array_equal(ret[0], ret[1]), "ranks disagree after the all-gather"
+    sc, frusta = _scene_and_frusta()
+    expect = _visible(sc, frusta, 0, N_ROWS)
+    for v in range(N_VIEWS):
+        got = sharding.unpack_view(ret[0], N_ROWS, world, N_VIEWS, v)
+        assert np.array_equal(got, expect[v]), f"view {v}"
+    assert expect.sum() > 0

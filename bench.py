@@ -112,11 +112,9 @@ def main():
         def step(f):
             if args.unfused:
                 ctx.propagate(B.PROPAGATE_ALL_DIRTY)
-                ctx.visibility_begin_frame()
-                ctx.cull(frames[f])
+                ctx.cull(frames[f], flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME)
             else:
-                ctx.propagate_and_cull(frames[f])
-            ctx.visibility_end_frame()
+                ctx.propagate_and_cull(frames[f], flags=B.CULL_END_FRAME)
             if world > 1:
                 sharding.all_gather_visibility(full, n_global, world, n_views, rank)
         config = {"workload": f"many_cubes-shaped flat scene, {n_local} entities/GPU ({n_global} total), {n_views} camera "

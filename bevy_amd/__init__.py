@@ -26,6 +26,8 @@ FLAG_HAS_SPHERE = 0x08
 FLAG_NO_CPU_CULLING = 0x10
 FLAG_HAS_VISIBILITY_RANGE = 0x20
 VIEW_FLAG_NO_CPU_CULLING = 0x01
+CULL_BEGIN_FRAME = 0x1
+CULL_END_FRAME = 0x2
 PROPAGATE_ALL_DIRTY = 0x1
 PROPAGATE_STATIC_OPT = 0x2
 NO_PARENT = 0xFFFFFFFF

@@ -282,14 +282,15 @@ class Context:
         self.n_views = nv
         return fr, _u32(view_masks), _u8(view_flags), nv
 
-    def cull(self, frusta, view_masks=None, view_flags=None):
+    def cull(self, frusta, view_masks=None, view_flags=None, flags=0):
         fr, vm, vf, nv = self._views(frusta, view_masks, view_flags)
-        self._ck(self._lib.mi_cull(self._h, _ptr(fr, C.c_float), _ptr(vm, C.c_uint32), _ptr(vf, C.c_uint8), nv))
+        self._ck(self._lib.mi_cull(self._h, _ptr(fr, C.c_float), _ptr(vm, C.c_uint32), _ptr(vf, C.c_uint8), nv,
+                                   int(flags)))
 
-    def propagate_and_cull(self, frusta, view_masks=None, view_flags=None):
+    def propagate_and_cull(self, frusta, view_masks=None, view_flags=None, flags=0):
         fr, vm, vf, nv = self._views(frusta, view_masks, view_flags)
         self._ck(self._lib.mi_propagate_and_cull(self._h, _ptr(fr, C.c_float), _ptr(vm, C.c_uint32),
-                                                 _ptr(vf, C.c_uint8), nv))
+                                                 _ptr(vf, C.c_uint8), nv, int(flags)))
 
     # results
     def download_global_transforms(self, first_row=0, n=None, want_changed=True):

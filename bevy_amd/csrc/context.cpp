@@ -27,6 +27,8 @@ hipError_t launch_logf_probe(const float* in, float* out, uint32_t n, hipStream_
 
 using namespace mi;
 
+thread_local const mi::LaunchTimer* mi::g_launch_timer = nullptr;
+
 namespace {
 
 std::mutex g_err_mutex;
@@ -73,8 +75,9 @@ struct mi_ctx {
     uint32_t n_levels = 1;
     std::vector<uint32_t> level_offsets;  // n_levels + 1
     DevBuf parent_idx, node_flags, tiles;
-    std::vector<std::pair<uint32_t, uint32_t>> passes;  // (first tile, n tiles)
+    std::vector<std::pair<uint32_t, uint32_t>> passes;  // (first tile, n tiles); pass 0 starts at level 0 (roots)
     bool have_hierarchy = false;
+    bool g_chg_in_bytes = false;  // the GlobalTransform change mask currently lives in g_changed_bytes (tree path)
 
     // ---- views / visibility ----
     DevBuf views;
@@ -84,10 +87,14 @@ struct mi_ctx {
     void* ext_bitmask = nullptr;
     uint64_t ext_words_per_view = 0, ext_word_offset = 0;
     bool culled = false;
+    ViewSet view_set{};      // views passed by value when n_views <= MAX_INLINE_VIEWS
+    bool views_inline = false;
     // compaction
-    DevBuf block_counts, seg_totals, seg_bases, out_rows, out_keys;
+    DevBuf block_counts, seg_totals, seg_bases, out_rows, out_keys, wave_cnt, seg_mask;
     uint32_t compact_views = 0, compact_classes = 0;
     uint32_t class_bits[32] = {0};
+    bool compact_fast = false;   // last compaction used the single-launch path (out_rows strided per segment)
+    uint64_t seg_stride = 0;
 
     // ---- clustering ----
     DevBuf cl_pos, cl_type, cl_layers, cl_dir, cl_sincos, cl_planes, cl_spheres;
@@ -182,7 +189,7 @@ int32_t stage_alloc(mi_ctx* ctx, size_t bytes, void** out) {
             if (ctx->stage) HIP_TRY(ctx, hipHostFree(ctx->stage));
             ctx->stage = nullptr;
             size_t want = std::max<size_t>(bytes, (size_t)64 << 20);
-            HIP_TRY(ctx, hipHostMalloc(&ctx->stage, want, hipHostMallocDefault));
+            HIP_TRY(ctx, hipHostMalloc(&ctx->stage, want, hipHostMallocMapped));
             ctx->stage_bytes = want;
         }
     }
@@ -233,10 +240,32 @@ void prof_mark(void* vctx, uint32_t kernel) {
     ctx->spans.push_back(sp);
     ctx->span_open = true;
 }
+// Times exactly one launch (the next MI_LAUNCH on this thread) with its dispatch timestamps.
 struct ProfScope {
     mi_ctx* ctx;
-    ProfScope(mi_ctx* c, uint32_t k) : ctx(c) { prof_mark(c, k); }
-    ~ProfScope() { prof_mark(ctx, K_NUM_KERNELS); }
+    LaunchTimer lt{};
+    bool armed = false;
+    ProfScope(mi_ctx* c, uint32_t k) : ctx(c) {
+        if (!c->profiling || k >= K_NUM_KERNELS || !((c->prof_mask >> k) & 1ull)) return;
+        prof_close(c);
+        ProfSpan sp;
+        sp.kernel = k;
+        hipEventCreate(&sp.a);
+        hipEventCreate(&sp.b);
+        c->spans.push_back(sp);
+        lt.start = sp.a;
+        lt.stop = sp.b;
+        g_launch_timer = &lt;
+        armed = true;
+    }
+    ~ProfScope() {
+        if (armed && g_launch_timer == &lt) {  // nothing was launched inside the scope
+            g_launch_timer = nullptr;
+            hipEventDestroy(ctx->spans.back().a);
+            hipEventDestroy(ctx->spans.back().b);
+            ctx->spans.pop_back();
+        }
+    }
 };
 void prof_collect(mi_ctx* ctx) {
     prof_close(ctx);
@@ -281,10 +310,16 @@ int32_t prepare_views(mi_ctx* ctx, const float* frusta, const uint32_t* masks, c
         vp[v].flags = vflags ? vflags[v] : 0u;
         vp[v].pad[0] = vp[v].pad[1] = 0;
     }
-    int32_t rc = ensure(ctx, ctx->views, sizeof(ViewParams) * n_views);
-    if (rc) return rc;
-    rc = upload(ctx, ctx->views.p, vp.data(), sizeof(ViewParams) * n_views);
-    if (rc) return rc;
+    int32_t rc = MI_OK;
+    ctx->views_inline = n_views <= MAX_INLINE_VIEWS;
+    if (ctx->views_inline) {
+        memcpy(ctx->view_set.v, vp.data(), sizeof(ViewParams) * n_views);  // travels in the kernarg segment
+    } else {
+        rc = ensure(ctx, ctx->views, sizeof(ViewParams) * n_views);
+        if (rc) return rc;
+        rc = upload(ctx, ctx->views.p, vp.data(), sizeof(ViewParams) * n_views);
+        if (rc) return rc;
+    }
     ctx->n_views = n_views;
     if (ctx->ext_bitmask) {
         out->bitmask = (uint64_t*)ctx->ext_bitmask;
@@ -323,18 +358,72 @@ int32_t rebuild_order(mi_ctx* ctx) {
     return MI_OK;
 }
 
-int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo) {
+// Class slots present + the by-product buffers of the cull pass.  Decides between the single-launch
+// compaction (rows already in Entity-key order) and the general count/scan/scatter path.
+int32_t prepare_segments(mi_ctx* ctx, uint32_t n_views, SegOut* seg) {
     int32_t rc = rebuild_order(ctx);
     if (rc) return rc;
-    CompactArgs a{};
-    a.n = ctx->n;
-    a.n_views = ctx->n_views;
     uint32_t k = 0;
     const uint32_t present = ctx->have_class_mask ? ctx->classes_present : 1u;
     for (uint32_t b = 0; b < 32; ++b)
-        if (present & (1u << b)) { a.class_bits[k] = b; ctx->class_bits[k] = b; ++k; }
-    if (k == 0) { a.class_bits[0] = 0; ctx->class_bits[0] = 0; k = 1; }
-    a.n_classes = k;
+        if (present & (1u << b)) { ctx->class_bits[k] = b; ++k; }
+    if (k == 0) { ctx->class_bits[0] = 0; k = 1; }
+    ctx->compact_views = n_views;
+    ctx->compact_classes = k;
+    ctx->compact_fast = ctx->order_identity;
+    memset(seg, 0, sizeof *seg);
+    seg->n_classes = k;
+    for (uint32_t i = 0; i < k; ++i) seg->class_bits[i] = (uint8_t)ctx->class_bits[i];
+    seg->class_mask = nullptr;
+    if (!ctx->compact_fast) return MI_OK;  // general path reads class_mask itself
+    const size_t segs = (size_t)n_views * k;
+    seg->n_waves = (uint32_t)((padded_words(ctx->cap) + 63u) / 64u * 64u);
+    if ((rc = ensure(ctx, ctx->wave_cnt, segs * seg->n_waves))) return rc;
+    seg->wave_cnt = (uint8_t*)ctx->wave_cnt.p;
+    if (ctx->have_class_mask) {
+        seg->class_mask = ctx->class_mask;
+        seg->seg_words = padded_words(ctx->cap);
+        if ((rc = ensure(ctx, ctx->seg_mask, segs * seg->seg_words * 8))) return rc;
+        seg->seg_mask = (uint64_t*)ctx->seg_mask.p;
+    }
+    return MI_OK;
+}
+
+int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg) {
+    int32_t rc;
+    const uint32_t n_classes = ctx->compact_classes;
+    const size_t segs = (size_t)ctx->n_views * n_classes;
+    if ((rc = ensure(ctx, ctx->seg_totals, segs * 4))) return rc;
+    if (ctx->n == 0) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->seg_totals.p, 0, segs * 4, ctx->stream));
+        return MI_OK;
+    }
+    if (ctx->compact_fast) {
+        CompactFastArgs f{};
+        f.n = ctx->n;
+        f.n_segments = (uint32_t)segs;
+        f.n_classes = n_classes;
+        f.n_waves = seg.n_waves;
+        f.wave_cnt = seg.wave_cnt;
+        f.seg_mask = seg.seg_mask;
+        f.seg_words = seg.seg_words;
+        f.bitmask = vo.bitmask;
+        f.words_per_view = vo.words_per_view;
+        f.word_offset = vo.word_offset;
+        ctx->seg_stride = ctx->cap;
+        if ((rc = ensure(ctx, ctx->out_rows, segs * ctx->seg_stride * 4))) return rc;
+        f.out_rows = (uint32_t*)ctx->out_rows.p;
+        f.seg_stride = ctx->seg_stride;
+        f.seg_totals = (uint32_t*)ctx->seg_totals.p;
+        ProfScope ps(ctx, K_COMPACT_FAST);
+        HIP_TRY(ctx, launch_compact_fast(f, ctx->stream));
+        return MI_OK;
+    }
+    CompactArgs a{};
+    a.n = ctx->n;
+    a.n_views = ctx->n_views;
+    for (uint32_t i = 0; i < n_classes; ++i) a.class_bits[i] = ctx->class_bits[i];
+    a.n_classes = n_classes;
     a.order = ctx->order_identity ? nullptr : (const uint32_t*)ctx->order.p;
     a.class_mask = ctx->have_class_mask ? ctx->class_mask : nullptr;
     a.entity_keys = ctx->have_keys ? ctx->keys : nullptr;
@@ -342,9 +431,7 @@ int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo) {
     a.words_per_view = vo.words_per_view;
     a.word_offset = vo.word_offset;
     a.n_blocks = (ctx->n + COMPACT_BLOCK_ROWS - 1) / COMPACT_BLOCK_ROWS;
-    const size_t segs = (size_t)a.n_views * a.n_classes;
     if ((rc = ensure(ctx, ctx->block_counts, segs * a.n_blocks * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->seg_totals, segs * 4))) return rc;
     if ((rc = ensure(ctx, ctx->seg_bases, segs * 8))) return rc;
     // worst case: every row of every view in every class it belongs to
     const size_t max_entries = (size_t)a.n_views * ctx->cap * (ctx->have_class_mask ? a.n_classes : 1);
@@ -355,8 +442,6 @@ int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo) {
     a.seg_bases = (uint64_t*)ctx->seg_bases.p;
     a.out_rows = (uint32_t*)ctx->out_rows.p;
     a.out_keys = (uint64_t*)ctx->out_keys.p;
-    ctx->compact_views = a.n_views;
-    ctx->compact_classes = a.n_classes;
     HIP_TRY(ctx, launch_compact(a, ctx->stream, prof_mark, ctx));
     return MI_OK;
 }
@@ -421,7 +506,7 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
     for (void* p : cols)
         if (p) hipFree(p);
     DevBuf* bufs[] = {&ctx->order, &ctx->in_range, &ctx->parent_idx, &ctx->node_flags, &ctx->tiles, &ctx->views, &ctx->bitmask,
-                      &ctx->block_counts, &ctx->seg_totals, &ctx->seg_bases, &ctx->out_rows, &ctx->out_keys, &ctx->cl_pos,
+                      &ctx->block_counts, &ctx->seg_totals, &ctx->seg_bases, &ctx->out_rows, &ctx->out_keys, &ctx->wave_cnt, &ctx->seg_mask, &ctx->cl_pos,
                       &ctx->cl_type, &ctx->cl_layers, &ctx->cl_dir, &ctx->cl_sincos, &ctx->cl_planes, &ctx->cl_spheres,
                       &ctx->cl_block_counts, &ctx->cl_block_bases, &ctx->cl_offsets, &ctx->cl_counts, &ctx->cl_indices,
                       &ctx->cl_scalars};
@@ -517,6 +602,18 @@ int32_t mi_upload_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t n, const 
     if (!translation || !rotation || !scale) return fail(ctx, MI_ERR_INVALID_ARG, "mi_upload_transforms: NULL column");
     int32_t rc = check_rows(ctx, first_row, n, "mi_upload_transforms");
     if (rc) return rc;
+    if (n && n <= SMALL_UPLOAD_ROWS) {  // dirty-row sized: one staging block, one scatter kernel
+        void* st = nullptr;
+        if ((rc = stage_alloc(ctx, (size_t)n * 40, &st))) return rc;
+        float* f = (float*)st;
+        memcpy(f, translation, (size_t)n * 12);
+        memcpy(f + 3 * (size_t)n, rotation, (size_t)n * 16);
+        memcpy(f + 7 * (size_t)n, scale, (size_t)n * 12);
+        void* dev = nullptr;
+        HIP_TRY(ctx, hipHostGetDevicePointer(&dev, st, 0));
+        HIP_TRY(ctx, launch_upload_trs((const float*)dev, ctx->t, ctx->r, ctx->s, first_row, n, ctx->stream));
+        return MI_OK;
+    }
     if ((rc = upload(ctx, ctx->t + 3 * (size_t)first_row, translation, (size_t)n * 12))) return rc;
     if ((rc = upload(ctx, ctx->r + 4 * (size_t)first_row, rotation, (size_t)n * 16))) return rc;
     if ((rc = upload(ctx, ctx->s + 3 * (size_t)first_row, scale, (size_t)n * 12))) return rc;
@@ -663,48 +760,61 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
     };
 
     // ---- tile plan ----
+    // A pass = one launch covering `d` consecutive levels; its tiles partition the rows of the level the pass is
+    // rooted in.  Pass 0 is rooted in level 0 itself (tile level 0 = a range of roots / flat rows); later passes
+    // are rooted in the last level of the previous pass (tile level 0 = the children of a range of its rows).
+    // A tile "fits" when all its levels but the last together hold <= TILE_UCAP rows (they live in LDS).
     const char* env_levels = getenv("MI_TILE_LEVELS");
-    const uint32_t band_pref = env_levels ? std::max(1, std::min((int)TILE_MAX_LEVELS, atoi(env_levels))) : 3u;
+    const uint32_t max_d = env_levels ? std::max(1, std::min((int)TILE_MAX_LEVELS, atoi(env_levels))) : TILE_MAX_LEVELS;
     std::vector<TileDesc> tiles;
     ctx->passes.clear();
-    uint32_t l = 1;
+    auto level_size = [&](uint32_t lv) -> uint64_t { return lv < n_levels ? level_offsets[lv + 1] - level_offsets[lv] : 0; };
+    uint32_t l = 0;  // first level this pass computes
     while (l < n_levels) {
+        const bool roots = l == 0;
+        // band depth: as deep as possible while an average root range of one row still fits in LDS
+        const uint64_t n_roots = std::max<uint64_t>(1, roots ? level_size(0) : level_size(l - 1));
         uint32_t d = 1;
-        uint64_t cum = level_offsets[l + 1] - level_offsets[l];
-        while (d < TILE_MAX_LEVELS && l + d < n_levels) {
-            const uint64_t next = level_offsets[l + d + 1] - level_offsets[l + d];
-            if (d >= band_pref && cum + next > 2048) break;
-            cum += next;
+        uint64_t upper = level_size(l);  // rows of the levels that would be non-last if we add one more level
+        while (d < max_d && l + d < n_levels && upper <= (uint64_t)TILE_UCAP * n_roots) {
             ++d;
+            upper += level_size(l + d - 1);
         }
+        // [lo,hi) is a row range of the rooting level; returns the tile and whether it fits
+        auto build = [&](uint32_t lo, uint32_t hi, TileDesc& td) -> bool {
+            uint32_t clo = lo, chi2 = hi;
+            td = TileDesc{};
+            for (uint32_t k = 0; k < d; ++k) {
+                uint32_t nlo, nhi;
+                if (roots && k == 0) { nlo = lo; nhi = hi; }
+                else {
+                    const uint32_t plevel = roots ? k - 1 : l - 1 + k;
+                    nlo = child_begin(plevel, clo);
+                    nhi = child_begin(plevel, chi2);
+                }
+                td.start[k] = nlo;
+                td.count[k] = nhi - nlo;
+                clo = nlo; chi2 = nhi;
+                if (nhi > nlo) td.n_levels = k + 1;
+            }
+            uint64_t up = 0;
+            for (uint32_t k = 0; k + 1 < td.n_levels; ++k) up += td.count[k];
+            return up <= TILE_UCAP;
+        };
         const uint32_t first_tile = (uint32_t)tiles.size();
-        // tile roots live in level l-1; extend the root range while every level of the band fits in LDS
-        const uint32_t rlo = level_offsets[l - 1], rhi = level_offsets[l];
+        const uint32_t rl = roots ? 0 : l - 1;
+        const uint32_t rlo = level_offsets[rl], rhi = level_offsets[rl + 1];
         uint32_t a = rlo;
         while (a < rhi) {
-            auto ranges = [&](uint32_t lo, uint32_t hi, TileDesc& td) -> bool {
-                bool fits = true;
-                uint32_t clo = lo, chi2 = hi;
-                td.n_levels = 0;
-                for (uint32_t k = 0; k < d; ++k) {
-                    const uint32_t nlo = child_begin(l - 1 + k, clo), nhi = child_begin(l - 1 + k, chi2);
-                    td.start[k] = nlo;
-                    td.count[k] = nhi - nlo;
-                    if (nhi - nlo > TILE_LDS_ROWS) fits = false;
-                    clo = nlo; chi2 = nhi;
-                    if (nhi > nlo) td.n_levels = k + 1;
-                }
-                return fits;
-            };
             TileDesc best{};
             uint32_t b = a + 1;
-            ranges(a, b, best);
-            // galloping extension
-            uint32_t step = 1;
+            build(a, b, best);
+            uint32_t step = 1;  // galloping extension of the root range
             while (b < rhi) {
-                const uint32_t nb = std::min<uint64_t>((uint64_t)b + step, rhi);
+                const uint32_t nb = (uint32_t)std::min<uint64_t>((uint64_t)b + step, rhi);
                 TileDesc cand{};
-                if (ranges(a, nb, cand)) { best = cand; b = nb; step *= 2; }
+                // keep tiles small enough to spread over the chip: at most 4 x TILE_UCAP rows in the streamed last level
+                if (build(a, nb, cand) && (cand.n_levels == 0 || cand.count[cand.n_levels - 1] <= 4 * TILE_UCAP || nb == a + 1)) { best = cand; b = nb; step *= 2; }
                 else if (step > 1) step = 1;
                 else break;
             }
@@ -748,19 +858,20 @@ int32_t mi_propagate(mi_ctx* ctx, uint32_t flags) {
         HIP_TRY(ctx, launch_mark_dirty(ctx->n, ctx->changed, (const uint32_t*)ctx->parent_idx.p, ctx->tree_bits, ctx->stream));
         tree_bits = ctx->tree_bits;
     }
-    {
+    if (!ctx->have_hierarchy) {
         ProfScope ps(ctx, K_LEVEL0_PROPAGATE);
-        HIP_TRY(ctx, launch_level0_propagate(c, n0, ctx->have_hierarchy ? (const uint8_t*)ctx->node_flags.p : nullptr,
-                                             ctx->changed, tree_bits, all_dirty, static_opt, ctx->stream));
-    }
-    if (ctx->have_hierarchy) {
-        HIP_TRY(ctx, launch_level0_bytes(ctx->g_chg_bits, n0, ctx->g_changed_bytes, ctx->stream));
+        HIP_TRY(ctx, launch_level0_propagate(c, n0, nullptr, ctx->changed, tree_bits, all_dirty, static_opt, ctx->stream));
+        ctx->g_chg_in_bytes = false;
+    } else {
+        bool first = true;
         for (auto& ps : ctx->passes) {
             ProfScope sc(ctx, K_PROPAGATE_TILES);
             HIP_TRY(ctx, launch_propagate_tiles(c, (const uint32_t*)ctx->parent_idx.p, (const TileDesc*)ctx->tiles.p + ps.first,
-                                                ps.second, tree_bits, ctx->g_changed_bytes, all_dirty, static_opt, ctx->stream));
+                                                ps.second, first, (const uint8_t*)ctx->node_flags.p, ctx->changed, tree_bits,
+                                                ctx->g_changed_bytes, all_dirty, static_opt, ctx->stream));
+            first = false;
         }
-        HIP_TRY(ctx, launch_bytes_to_bits(ctx->g_changed_bytes, ctx->n, ctx->g_chg_bits, ctx->stream));
+        ctx->g_chg_in_bytes = true;
     }
     if (ctx->have_changed) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, ctx->n, ctx->stream));  // change flags are consumed
@@ -783,37 +894,43 @@ int32_t mi_visibility_end_frame(mi_ctx* ctx) {
 }
 
 int32_t mi_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_masks, const uint8_t* view_flags,
-                uint32_t n_views) {
+                uint32_t n_views, uint32_t flags) {
     ENTER(ctx);
     VisibilityOut vo{};
     int32_t rc = prepare_views(ctx, frusta, view_layer_masks, view_flags, n_views, &vo);
     if (rc) return rc;
+    SegOut seg;
+    if ((rc = prepare_segments(ctx, n_views, &seg))) return rc;
     Columns c = columns_of(ctx);
     if (ctx->in_range_views >= n_views) c.in_range = (const uint8_t*)ctx->in_range.p;
     {
         ProfScope ps(ctx, K_CULL);
-        HIP_TRY(ctx, launch_cull(c, (const ViewParams*)ctx->views.p, n_views, vo, ctx->stream));
+        HIP_TRY(ctx, launch_cull(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p, n_views, vo,
+                                 seg, flags & (MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME), ctx->stream));
     }
-    if ((rc = run_compaction(ctx, vo))) return rc;
+    if ((rc = run_compaction(ctx, vo, seg))) return rc;
     ctx->culled = true;
     return MI_OK;
 }
 
 int32_t mi_propagate_and_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_masks, const uint8_t* view_flags,
-                              uint32_t n_views) {
+                              uint32_t n_views, uint32_t flags) {
     ENTER(ctx);
     if (ctx->have_hierarchy)
         return fail(ctx, MI_ERR_NOT_READY, "mi_propagate_and_cull is the flat fast path; a hierarchy is uploaded -- use mi_propagate + mi_cull");
     VisibilityOut vo{};
     int32_t rc = prepare_views(ctx, frusta, view_layer_masks, view_flags, n_views, &vo);
     if (rc) return rc;
+    SegOut seg;
+    if ((rc = prepare_segments(ctx, n_views, &seg))) return rc;
     Columns c = columns_of(ctx);
     if (ctx->in_range_views >= n_views) c.in_range = (const uint8_t*)ctx->in_range.p;
     {
         ProfScope ps(ctx, K_FLAT_PROPAGATE_CULL);
-        HIP_TRY(ctx, launch_flat_propagate_cull(c, (const ViewParams*)ctx->views.p, n_views, vo, ctx->stream));
+        HIP_TRY(ctx, launch_flat_propagate_cull(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p,
+                                                n_views, vo, seg, flags & MI_CULL_END_FRAME, ctx->stream));
     }
-    if ((rc = run_compaction(ctx, vo))) return rc;
+    if ((rc = run_compaction(ctx, vo, seg))) return rc;
     if (ctx->have_changed) HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, ctx->n, ctx->stream));
     ctx->culled = true;
     return MI_OK;
@@ -829,6 +946,10 @@ int32_t mi_download_global_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t 
     if (changed_bitmask && (first_row & 31u)) return fail(ctx, MI_ERR_INVALID_ARG, "first_row must be a multiple of 32 for the change bitmask");
     if (out && (rc = download(ctx, out, ctx->g + 12 * (size_t)first_row, (size_t)n * 48))) return rc;
     if (changed_bitmask) {
+        if (ctx->g_chg_in_bytes) {  // the tree path records one byte per row; pack on demand
+            HIP_TRY(ctx, launch_bytes_to_bits(ctx->g_changed_bytes, ctx->n, ctx->g_chg_bits, ctx->stream));
+            ctx->g_chg_in_bytes = false;
+        }
         const size_t words32 = ((size_t)n + 31) / 32;
         if ((rc = download(ctx, changed_bitmask, (const uint32_t*)ctx->g_chg_bits + first_row / 32, words32 * 4))) return rc;
         if (n & 31u) changed_bitmask[words32 - 1] &= (1u << (n & 31u)) - 1u;
@@ -881,9 +1002,20 @@ int32_t mi_download_visible_entities(mi_ctx* ctx, uint32_t view, uint32_t class_
     uint64_t base = 0;
     int32_t rc;
     if ((rc = download(ctx, &total, (const uint32_t*)ctx->seg_totals.p + seg, 4))) return rc;
-    if ((rc = download(ctx, &base, (const uint64_t*)ctx->seg_bases.p + seg, 8))) return rc;
     *out_count = total;
     if (total > capacity) return fail(ctx, MI_ERR_CAPACITY, "visible list has %u entries, capacity %u", total, capacity);
+    if (ctx->compact_fast) {
+        // rows are in key order already; keys are looked up in the host copy of the key column
+        base = (uint64_t)seg * ctx->seg_stride;
+        std::vector<uint32_t> tmp;
+        uint32_t* rows = out_rows;
+        if (!rows && out_keys) { tmp.resize(total); rows = tmp.data(); }
+        if (rows && (rc = download(ctx, rows, (const uint32_t*)ctx->out_rows.p + base, (size_t)total * 4))) return rc;
+        if (out_keys)
+            for (uint32_t i = 0; i < total; ++i) out_keys[i] = ctx->have_keys ? ctx->h_keys[rows[i]] : (uint64_t)rows[i];
+        return MI_OK;
+    }
+    if ((rc = download(ctx, &base, (const uint64_t*)ctx->seg_bases.p + seg, 8))) return rc;
     if (out_keys && (rc = download(ctx, out_keys, (const uint64_t*)ctx->out_keys.p + base, (size_t)total * 8))) return rc;
     if (out_rows && (rc = download(ctx, out_rows, (const uint32_t*)ctx->out_rows.p + base, (size_t)total * 4))) return rc;
     return MI_OK;
@@ -1128,7 +1260,7 @@ int32_t mi_profile_read(mi_ctx* ctx, uint32_t* inout_n, uint64_t* launches, doub
 const char* mi_profile_kernel_name(uint32_t k) {
     static const char* names[K_NUM_KERNELS] = {"k_flat_propagate_cull", "k_level0_propagate", "k_cull", "k_vis_begin",
                                                "k_vis_end", "k_compact_count", "k_compact_scan", "k_compact_scatter",
-                                               "k_mark_dirty", "k_propagate_tiles", "k_cluster_count", "k_cluster_scan",
+                                               "k_compact_fast", "k_mark_dirty", "k_propagate_tiles", "k_cluster_count", "k_cluster_scan",
                                                "k_cluster_fill", "k_clear_u32"};
     return k < K_NUM_KERNELS ? names[k] : nullptr;
 }

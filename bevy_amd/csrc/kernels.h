@@ -3,9 +3,34 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 namespace mi {
+
+// Kernel timing with the dispatch packet's own timestamps (what rocprofv3 --kernel-trace reports): when the
+// context arms g_launch_timer, the next MI_LAUNCH goes through hipExtLaunchKernelGGL with (start, stop) events
+// bound to that one dispatch; hipEventElapsedTime(start, stop) is then the kernel's duration without the
+// marker-packet and inter-dispatch gaps a hipEventRecord bracket would add.
+struct LaunchTimer {
+    hipEvent_t start, stop;
+};
+extern thread_local const LaunchTimer* g_launch_timer;
+// Orders one wave's own LDS traffic (cross-lane exchange through a wave-private LDS region): waits for the
+// wave's outstanding LDS operations and stops the compiler from moving LDS accesses across it.
+#define MI_WAVE_LDS_SYNC()                                    \
+    do {                                                      \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
+        __builtin_amdgcn_wave_barrier();                      \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
+    } while (0)
+#define MI_LAUNCH(kernel, grid, block, lds, stream, ...)                                                        \
+    do {                                                                                                        \
+        const ::mi::LaunchTimer* lt_ = ::mi::g_launch_timer;                                                    \
+        ::mi::g_launch_timer = nullptr;                                                                         \
+        if (lt_) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, lt_->start, lt_->stop, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                 \
+    } while (0)
 
 // One view's constants, read through scalar loads (uniform across the wave).
 struct ViewParams {
@@ -39,6 +64,32 @@ struct VisibilityOut {
     uint64_t word_offset;     // this shard's first word inside a view's mask
 };
 
+// Views are passed BY VALUE in the kernarg segment (scalar loads, no per-frame H2D copy) when there are
+// at most MAX_INLINE_VIEWS of them; more views go through a device array.
+constexpr uint32_t MAX_INLINE_VIEWS = 8;
+struct ViewSet {
+    ViewParams v[MAX_INLINE_VIEWS];
+};
+
+// Per-(view, class) by-products of the cull pass that feed the single-launch VisibleEntities compaction:
+// segment s = view * n_classes + class_slot.
+//   wave_cnt[s * n_waves + wave]    number of rows of that wave (64 rows) visible in view AND in the class (u8, <= 64)
+//   seg_mask[s * seg_words + wave]  their bitmask -- only written when class_mask != nullptr; without classes the
+//                                   segment mask IS the view mask.
+struct SegOut {
+    uint32_t n_classes;          // >= 1
+    uint32_t n_waves;            // padded wave count (stride of wave_cnt)
+    const uint32_t* class_mask;  // nullptr = every row is in class slot 0
+    uint8_t* wave_cnt;           // nullptr = compaction by-products not wanted
+    uint64_t* seg_mask;
+    uint64_t seg_words;
+    uint8_t class_bits[32];      // class bit of each class slot
+};
+
+// mi_cull / mi_propagate_and_cull flags (MI_CULL_* in the public header)
+constexpr uint32_t CULL_BEGIN_FRAME = 1u;  // fuse reset_view_visibility
+constexpr uint32_t CULL_END_FRAME = 2u;    // fuse check_visibility_gpu_culling + mark_newly_hidden_entities_invisible
+
 enum KernelId : uint32_t {
     K_FLAT_PROPAGATE_CULL = 0,
     K_LEVEL0_PROPAGATE,
@@ -48,6 +99,7 @@ enum KernelId : uint32_t {
     K_COMPACT_COUNT,
     K_COMPACT_SCAN,
     K_COMPACT_SCATTER,
+    K_COMPACT_FAST,
     K_MARK_DIRTY,
     K_PROPAGATE_TILES,
     K_CLUSTER_COUNT,
@@ -58,16 +110,21 @@ enum KernelId : uint32_t {
 };
 
 // ---- flat path ------------------------------------------------------------------------------
-hipError_t launch_flat_propagate_cull(const Columns& c, const ViewParams* d_views, uint32_t n_views,
-                                      const VisibilityOut& out, hipStream_t stream);
+// views_inline is used when n_views <= MAX_INLINE_VIEWS (d_views may then be nullptr).
+hipError_t launch_flat_propagate_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views,
+                                      uint32_t n_views, const VisibilityOut& out, const SegOut& seg, uint32_t flags,
+                                      hipStream_t stream);
 // Level 0 of the hierarchy (roots + flat rows).  node_flags: bit0 = has children (nullptr = none do).
 // changed: per-row Changed<Transform>|... byte (nullptr or all_dirty => every row recomputed).
 // tree_bits: TransformTreeChanged bitset (only read when static_opt).
 hipError_t launch_level0_propagate(const Columns& c, uint32_t n_level0, const uint8_t* node_flags,
                                    const uint8_t* changed, const uint32_t* tree_bits, bool all_dirty,
                                    bool static_opt, hipStream_t stream);
-hipError_t launch_cull(const Columns& c, const ViewParams* d_views, uint32_t n_views, const VisibilityOut& out,
-                       hipStream_t stream);
+hipError_t launch_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views,
+                       const VisibilityOut& out, const SegOut& seg, uint32_t flags, hipStream_t stream);
+hipError_t launch_upload_trs(const float* pinned_src, float* t, float* r, float* s, uint32_t first_row, uint32_t n,
+                             hipStream_t stream);
+constexpr uint32_t SMALL_UPLOAD_ROWS = 4096;  // at or below this, Transform uploads take the one-kernel path
 hipError_t launch_vis_begin(const Columns& c, hipStream_t stream);
 hipError_t launch_vis_end(const Columns& c, hipStream_t stream);
 
@@ -91,9 +148,30 @@ struct CompactArgs {
 constexpr uint32_t COMPACT_BLOCK_ROWS = 4096;
 hipError_t launch_compact(const CompactArgs& a, hipStream_t stream, void (*mark)(void*, uint32_t), void* mark_ctx);
 
+// Single-launch compaction for rows already in ascending Entity-key order (the common case: the shim numbers
+// rows by key).  Consumes the per-wave counts + segment masks the cull pass left behind; every workgroup
+// derives its base from the preceding wave counts (L2-resident bytes), so no scan kernel and no atomics.
+// Segment s writes out_rows[s * seg_stride ...] and seg_totals[s].
+struct CompactFastArgs {
+    uint32_t n;               // rows
+    uint32_t n_segments;
+    uint32_t n_classes;
+    uint32_t n_waves;         // stride of wave_cnt per segment
+    const uint8_t* wave_cnt;
+    const uint64_t* seg_mask; // segment masks (class-filtered), or nullptr -> use the view masks below
+    uint64_t seg_words;
+    const uint64_t* bitmask;  // per-view masks
+    uint64_t words_per_view, word_offset;
+    uint32_t* out_rows;
+    uint64_t seg_stride;      // entries reserved per segment in out_rows
+    uint32_t* seg_totals;
+};
+hipError_t launch_compact_fast(const CompactFastArgs& a, hipStream_t stream);
+
 // ---- hierarchy ---------------------------------------------------------------------------------
 constexpr uint32_t TILE_MAX_LEVELS = 6;
-constexpr uint32_t TILE_LDS_ROWS = 512;  // rows of one level kept in LDS (x2 buffers x 48 B)
+constexpr uint32_t TILE_UCAP = 512;            // LDS slots of one tile: rows of all its levels but the last
+constexpr uint32_t TILE_R = TILE_UCAP / 256;   // LDS-resident rows per thread
 struct TileDesc {
     uint32_t n_levels;
     uint32_t start[TILE_MAX_LEVELS];
@@ -102,11 +180,10 @@ struct TileDesc {
 };
 hipError_t launch_mark_dirty(uint32_t n, const uint8_t* changed, const uint32_t* parent_idx, uint32_t* tree_bits,
                              hipStream_t stream);
-hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, const TileDesc* d_tiles,
-                                  uint32_t n_tiles, const uint32_t* tree_bits, uint8_t* g_changed_bytes,
-                                  bool all_dirty, bool static_opt, hipStream_t stream);
-hipError_t launch_level0_bytes(const uint64_t* g_changed_bits, uint32_t n_level0, uint8_t* g_changed_bytes,
-                               hipStream_t stream);
+// roots = true: the tiles' first level is level 0 of the forest (roots + flat rows, no parents).
+hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, const TileDesc* d_tiles, uint32_t n_tiles,
+                                  bool roots, const uint8_t* node_flags, const uint8_t* changed, const uint32_t* tree_bits,
+                                  uint8_t* g_changed_bytes, bool all_dirty, bool static_opt, hipStream_t stream);
 hipError_t launch_clear_u32(uint32_t* p, uint64_t n_words, hipStream_t stream);
 hipError_t launch_bytes_to_bits(const uint8_t* bytes, uint32_t n, uint64_t* bits, hipStream_t stream);
 

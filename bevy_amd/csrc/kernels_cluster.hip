@@ -62,7 +62,7 @@ __global__ void k_logf_probe(const float* __restrict__ in, float* out, uint32_t 
 }
 hipError_t launch_logf_probe(const float* in, float* out, uint32_t n, hipStream_t stream) {
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(k_logf_probe, dim3((n + 255u) / 256u), dim3(256), 0, stream, in, out, n);
+    MI_LAUNCH(k_logf_probe, dim3((n + 255u) / 256u), dim3(256), 0, stream, in, out, n);
     return hipGetLastError();
 }
 
@@ -375,17 +375,17 @@ hipError_t launch_cluster_assign(const ClusterViewDev& view, const ClusterObject
     // w.counts, w.total, w.farthest_z and the scratch were cleared by the caller on this stream.
     if (objs.n) {
         if (mark) mark(mctx, K_CLUSTER_COUNT);
-        hipLaunchKernelGGL(k_cluster_count, dim3(w.n_blocks), dim3(CLUSTER_BLOCK), lds, stream, view, objs, w);
+        MI_LAUNCH(k_cluster_count, dim3(w.n_blocks), dim3(CLUSTER_BLOCK), lds, stream, view, objs, w);
     }
     if (mark) mark(mctx, K_CLUSTER_SCAN);
     uint32_t* cluster_totals = w.offsets;  // reuse: totals are consumed into offsets in place
     if (objs.n) {
-        hipLaunchKernelGGL(k_cluster_scan_rows, dim3((C + 3u) / 4u), dim3(256), 0, stream, w, C, cluster_totals);
+        MI_LAUNCH(k_cluster_scan_rows, dim3((C + 3u) / 4u), dim3(256), 0, stream, w, C, cluster_totals);
     }
-    hipLaunchKernelGGL(k_cluster_scan_offsets, dim3(1), dim3(1024), 0, stream, w, C, cluster_totals);
+    MI_LAUNCH(k_cluster_scan_offsets, dim3(1), dim3(1024), 0, stream, w, C, cluster_totals);
     if (objs.n) {
         if (mark) mark(mctx, K_CLUSTER_FILL);
-        hipLaunchKernelGGL(k_cluster_fill, dim3(w.n_blocks), dim3(CLUSTER_BLOCK), lds, stream, view, objs, w);
+        MI_LAUNCH(k_cluster_fill, dim3(w.n_blocks), dim3(CLUSTER_BLOCK), lds, stream, view, objs, w);
     }
     if (mark) mark(mctx, K_NUM_KERNELS);
     return hipGetLastError();

@@ -78,53 +78,143 @@ __device__ __forceinline__ bool row_visible_in_view(const Affine& g, V3 center, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused: G = From(T) for every row  +  reset_view_visibility  +  cull against all views.
-// Algorithmic bytes per row (V views): read 40 (T) + 24 (Aabb) + 1 (flags) + 4 (layers) + 1 (vv),
-// write 48 (G) + 1 (vv) + (V+2)/8 bits.
+// Wave-local transposes through LDS.  A row's GlobalTransform is 48 bytes; one lane per row means
+// a lane-major float4 access touches a 3 KB span per wave-instruction and uses a third of every
+// cache line it opens.  Staging the wave's 64 x 48 B = 3 KB in LDS turns the global side into three
+// fully contiguous 1 KB wave-instructions (lane i <-> float4 i).  LDS side: ds_write_b128 at a 48-byte
+// lane stride and ds_read_b128 at a 16-byte lane stride are both bank-conflict free (8-lane groups cover
+// 32 distinct banks).  Each wave only touches its own 3 KB, but a workgroup barrier is used for
+// ordering (4 waves, negligible next to the HBM time).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_flat_propagate_cull(Columns c, const ViewParams* __restrict__ views,
-                                                              uint32_t n_views, VisibilityOut out) {
+__device__ __forceinline__ void store_affine_coalesced(float4* lds_wave, float* g, uint32_t wave_row0, uint32_t n,
+                                                       uint32_t lane, const Affine& a) {
+    lds_wave[lane * 3u + 0u] = make_float4(a.m.x_axis.x, a.m.x_axis.y, a.m.x_axis.z, a.m.y_axis.x);
+    lds_wave[lane * 3u + 1u] = make_float4(a.m.y_axis.y, a.m.y_axis.z, a.m.z_axis.x, a.m.z_axis.y);
+    lds_wave[lane * 3u + 2u] = make_float4(a.m.z_axis.z, a.t.x, a.t.y, a.t.z);
+    __syncthreads();
+    float4* dst = reinterpret_cast<float4*>(g) + 3ull * wave_row0;
+    const uint32_t lim = (n - wave_row0 < 64u ? n - wave_row0 : 64u) * 3u;  // float4s of live rows in this wave
+#pragma unroll
+    for (uint32_t k = 0; k < 3u; ++k) {
+        const uint32_t i = k * 64u + lane;
+        if (i < lim) dst[i] = lds_wave[i];
+    }
+}
+__device__ __forceinline__ Affine load_affine_coalesced(float4* lds_wave, const float* g, uint32_t wave_row0, uint32_t n,
+                                                        uint32_t lane) {
+    const float4* src = reinterpret_cast<const float4*>(g) + 3ull * wave_row0;
+    const uint32_t lim = wave_row0 < n ? (n - wave_row0 < 64u ? n - wave_row0 : 64u) * 3u : 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < 3u; ++k) {
+        const uint32_t i = k * 64u + lane;
+        lds_wave[i] = i < lim ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    const float4 a = lds_wave[lane * 3u], b = lds_wave[lane * 3u + 1u], c = lds_wave[lane * 3u + 2u];
+    Affine r;
+    r.m.x_axis = V3{a.x, a.y, a.z};
+    r.m.y_axis = V3{a.w, b.x, b.y};
+    r.m.z_axis = V3{b.z, b.w, c.x};
+    r.t = V3{c.y, c.z, c.w};
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The frame kernel.  PROPAGATE = true : G = From(T) for every row (sync_simple_transforms, all dirty),
+//                                       written once and never re-read (fused flat path);
+//                    PROPAGATE = false: G is read from the resident column (after mi_propagate).
+// Both: optional reset_view_visibility (CULL_BEGIN_FRAME), check_visibility_cpu_culling against all views,
+// optional check_visibility_gpu_culling + mark_newly_hidden_entities_invisible (CULL_END_FRAME), the packed
+// per-view bitmasks (one wave64 ballot = one 64-bit word, no atomics) and the per-(view,class) wave counts /
+// segment masks the VisibleEntities compaction consumes.
+// Algorithmic bytes per row, fused, V views: read 40 (T) + 24 (Aabb) + 1 (flags) + 4 (layers) + 1 (vv),
+// write 48 (G) + 1 (vv) + (V + 2 change masks) / 8 + V / 64 (wave counts).
+// ---------------------------------------------------------------------------------------------
+template <bool PROPAGATE, bool INLINE_VIEWS>
+__global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const ViewParams* __restrict__ dviews,
+                                                uint32_t n_views, VisibilityOut out, SegOut seg, uint32_t fl_frame) {
+    __shared__ float4 lds_g[4][192];
     const uint32_t row = blockIdx.x * 256u + threadIdx.x;
     const bool live = row < c.n;
     const uint32_t wave = row >> 6;
     const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t wave_row0 = row & ~63u;
 
     Affine g = {};
     V3 center = {}, half = {};
-    uint32_t fl = 0, emask = 0, old_vv = 0;
+    uint32_t fl = 0, emask = 0, vv0 = 0, cmask = 1u;
     if (live) {
-        const V3 t = ld3(c.translation, row);
-        const V4 q = ld4(c.rotation, row);
-        const V3 s = ld3(c.scale, row);
         center = ld3(c.aabb_center, row);
         half = ld3(c.aabb_half, row);
         fl = c.flags[row];
         emask = c.layer_mask[row];
-        old_vv = c.view_visibility[row];
-        g = affine_from_srt(s, q, t);
-        st_affine(c.global, row, g);
+        vv0 = c.view_visibility[row];
+        if (seg.class_mask) cmask = seg.class_mask[row];
+    }
+    if (PROPAGATE) {
+        if (live) {
+            const V3 t = ld3(c.translation, row);
+            const V4 q = ld4(c.rotation, row);
+            const V3 s = ld3(c.scale, row);
+            g = affine_from_srt(s, q, t);
+        }
+        store_affine_coalesced(lds_g[wv], c.global, wave_row0, c.n, lane, g);
+    } else {
+        g = load_affine_coalesced(lds_g[wv], c.global, wave_row0, c.n, lane);
     }
     const bool ncc = (fl & 0x10u) != 0;  // NoCpuCulling rows are not in the cull query (mod.rs:771)
-    const unsigned long long lv = __ballot(live);  // waves past the last row must not touch the mask
+    const bool any_live = wave_row0 < c.n;  // waves past the last row must not touch the masks
     bool any = false;
     for (uint32_t v = 0; v < n_views; ++v) {
+        const ViewParams& vp = INLINE_VIEWS ? vs.v[v] : dviews[v];
         const bool in_range = (c.in_range && live) ? c.in_range[(size_t)v * c.n + row] != 0 : true;
-        const bool vis = live && !ncc && row_visible_in_view(g, center, half, fl, emask, in_range, views[v]);
+        const bool vis = live && !ncc && row_visible_in_view(g, center, half, fl, emask, in_range, vp);
         any = any || vis;
         const unsigned long long m = __ballot(vis);
-        if (lane == 0 && lv) out.bitmask[v * out.words_per_view + out.word_offset + wave] = m;
+        if (lane == 0 && any_live) out.bitmask[v * out.words_per_view + out.word_offset + wave] = m;
+        if (seg.wave_cnt) {
+            if (!seg.class_mask) {
+                if (lane == 0 && any_live) seg.wave_cnt[(size_t)v * seg.n_waves + wave] = (uint8_t)__popcll(m);
+            } else {
+                for (uint32_t k = 0; k < seg.n_classes; ++k) {
+                    const unsigned long long mk = __ballot(vis && ((cmask >> seg.class_bits[k]) & 1u));
+                    if (lane == 0 && any_live) {
+                        const size_t s = (size_t)v * seg.n_classes + k;
+                        seg.seg_mask[s * seg.seg_words + wave] = mk;
+                        seg.wave_cnt[s * seg.n_waves + wave] = (uint8_t)__popcll(mk);
+                    }
+                }
+            }
+        }
     }
-    // reset (mod.rs:270-274) then set_visible (mod.rs:290-306)
+    // ViewVisibility byte: reset (mod.rs:270-274), set_visible (:290-306), gpu-culling rows (:884-903),
+    // mark_newly_hidden (:908-918)
+    uint32_t cur = vv0;
     bool vv_changed = false;
-    if (live && !ncc) {
-        const uint32_t prev = old_vv & 1u;
-        c.view_visibility[row] = (uint8_t)((prev << 1) | (any ? 1u : 0u));
-        vv_changed = any && !prev;
+    if (live) {
+        if ((fl_frame & CULL_BEGIN_FRAME) && !ncc) cur = (cur & 1u) << 1;
+        if (any && !(cur & 1u)) {
+            vv_changed = !(cur & 2u);
+            cur |= 1u;
+        }
+        if (fl_frame & CULL_END_FRAME) {
+            if (ncc) {
+                const uint32_t nv = (fl & 0x01u) ? 3u : 0u;
+                if (nv != cur) { cur = nv; vv_changed = true; }
+            } else if ((cur & 3u) == 2u) {
+                cur = 0u;
+                vv_changed = true;
+            }
+        }
+        if (cur != vv0) c.view_visibility[row] = (uint8_t)cur;
     }
     const unsigned long long chg = __ballot(vv_changed);
-    if (lane == 0 && lv) {
-        c.vv_changed_bits[wave] = chg;
-        c.g_changed_bits[wave] = lv;  // plain assignment bumps the tick of every written row (systems.rs:62)
+    const unsigned long long lv = __ballot(live);
+    if (lane == 0 && any_live) {
+        if (fl_frame & CULL_BEGIN_FRAME) c.vv_changed_bits[wave] = chg;
+        else if (chg) atomicOr(reinterpret_cast<unsigned long long*>(&c.vv_changed_bits[wave]), chg);
+        if (PROPAGATE) c.g_changed_bits[wave] = lv;  // plain assignment bumps every written row's tick (systems.rs:62)
     }
 }
 
@@ -162,46 +252,6 @@ __global__ void __launch_bounds__(256) k_level0_propagate(Columns c, uint32_t n_
     if ((threadIdx.x & 63u) == 0 && lv) c.g_changed_bits[row >> 6] = w;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Cull against resident GlobalTransform (unfused path; also used after hierarchy propagation).
-// Algorithmic bytes per row: read 48 (G) + 24 + 1 + 4 + 1, write 1 + bits.
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_cull(Columns c, const ViewParams* __restrict__ views, uint32_t n_views,
-                                               VisibilityOut out) {
-    const uint32_t row = blockIdx.x * 256u + threadIdx.x;
-    const bool live = row < c.n;
-    const uint32_t wave = row >> 6;
-    const uint32_t lane = threadIdx.x & 63u;
-    Affine g = {};
-    V3 center = {}, half = {};
-    uint32_t fl = 0, emask = 0, cur = 0;
-    if (live) {
-        g = ld_affine(c.global, row);
-        center = ld3(c.aabb_center, row);
-        half = ld3(c.aabb_half, row);
-        fl = c.flags[row];
-        emask = c.layer_mask[row];
-        cur = c.view_visibility[row];
-    }
-    const bool ncc = (fl & 0x10u) != 0;
-    const unsigned long long lv = __ballot(live);
-    bool any = false;
-    for (uint32_t v = 0; v < n_views; ++v) {
-        const bool in_range = (c.in_range && live) ? c.in_range[(size_t)v * c.n + row] != 0 : true;
-        const bool vis = live && !ncc && row_visible_in_view(g, center, half, fl, emask, in_range, views[v]);
-        any = any || vis;
-        const unsigned long long m = __ballot(vis);
-        if (lane == 0 && lv) out.bitmask[v * out.words_per_view + out.word_offset + wave] = m;
-    }
-    bool vv_changed = false;
-    if (any && !(cur & 1u)) {  // set_visible, mod.rs:290-306
-        vv_changed = !(cur & 2u);
-        c.view_visibility[row] = (uint8_t)(cur | 1u);
-    }
-    const unsigned long long chg = __ballot(vv_changed);
-    if (lane == 0 && chg) atomicOr(reinterpret_cast<unsigned long long*>(&c.vv_changed_bits[wave]), chg);
-}
-
 // reset_view_visibility: bits = (bits & 1) << 1 for rows without NoCpuCulling; clears the change mask.
 __global__ void __launch_bounds__(256) k_vis_begin(Columns c) {
     const uint32_t row = blockIdx.x * 256u + threadIdx.x;
@@ -236,34 +286,64 @@ __global__ void __launch_bounds__(256) k_vis_end(Columns c) {
 
 static inline uint32_t blocks_for(uint32_t n) { return (n + 255u) / 256u; }
 
-hipError_t launch_flat_propagate_cull(const Columns& c, const ViewParams* d_views, uint32_t n_views,
-                                      const VisibilityOut& out, hipStream_t stream) {
-    if (c.n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_flat_propagate_cull, dim3(blocks_for(c.n)), dim3(256), 0, stream, c, d_views, n_views, out);
+// Small dirty-row uploads: the three Transform columns of a few rows are staged back to back in pinned host
+// memory and scattered by ONE kernel that reads the staging buffer over PCIe, instead of three DMA copies
+// (each a separate ~4 us engine submission).  src = translation[3n] | rotation[4n] | scale[3n].
+__global__ void __launch_bounds__(256) k_upload_trs(const float* __restrict__ src, float* t, float* r, float* s,
+                                                     uint32_t first_row, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < 3u * n) {
+        t[3ull * first_row + i] = src[i];
+        s[3ull * first_row + i] = src[7ull * n + i];
+    }
+    if (i < 4u * n) r[4ull * first_row + i] = src[3ull * n + i];
+}
+hipError_t launch_upload_trs(const float* pinned_src, float* t, float* r, float* s, uint32_t first_row, uint32_t n,
+                             hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    MI_LAUNCH(k_upload_trs, dim3(blocks_for(4u * n)), dim3(256), 0, stream, pinned_src, t, r, s, first_row, n);
     return hipGetLastError();
+}
+
+template <bool PROPAGATE>
+static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views,
+                               const VisibilityOut& out, const SegOut& seg, uint32_t flags, hipStream_t stream) {
+    if (c.n == 0) return hipSuccess;
+    if (n_views <= MAX_INLINE_VIEWS && views_inline) {
+        MI_LAUNCH((k_frame<PROPAGATE, true>), dim3(blocks_for(c.n)), dim3(256), 0, stream, c, *views_inline,
+                           (const ViewParams*)nullptr, n_views, out, seg, flags);
+    } else {
+        ViewSet dummy = {};
+        MI_LAUNCH((k_frame<PROPAGATE, false>), dim3(blocks_for(c.n)), dim3(256), 0, stream, c, dummy, d_views,
+                           n_views, out, seg, flags);
+    }
+    return hipGetLastError();
+}
+hipError_t launch_flat_propagate_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views,
+                                      uint32_t n_views, const VisibilityOut& out, const SegOut& seg, uint32_t flags,
+                                      hipStream_t stream) {
+    return launch_frame<true>(c, views_inline, d_views, n_views, out, seg, flags | CULL_BEGIN_FRAME, stream);
+}
+hipError_t launch_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views,
+                       const VisibilityOut& out, const SegOut& seg, uint32_t flags, hipStream_t stream) {
+    return launch_frame<false>(c, views_inline, d_views, n_views, out, seg, flags, stream);
 }
 hipError_t launch_level0_propagate(const Columns& c, uint32_t n_level0, const uint8_t* node_flags,
                                    const uint8_t* changed, const uint32_t* tree_bits, bool all_dirty,
                                    bool static_opt, hipStream_t stream) {
     if (n_level0 == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_level0_propagate, dim3(blocks_for(n_level0)), dim3(256), 0, stream, c, n_level0, node_flags,
+    MI_LAUNCH(k_level0_propagate, dim3(blocks_for(n_level0)), dim3(256), 0, stream, c, n_level0, node_flags,
                        changed, tree_bits, all_dirty, static_opt);
-    return hipGetLastError();
-}
-hipError_t launch_cull(const Columns& c, const ViewParams* d_views, uint32_t n_views, const VisibilityOut& out,
-                       hipStream_t stream) {
-    if (c.n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_cull, dim3(blocks_for(c.n)), dim3(256), 0, stream, c, d_views, n_views, out);
     return hipGetLastError();
 }
 hipError_t launch_vis_begin(const Columns& c, hipStream_t stream) {
     if (c.n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_vis_begin, dim3(blocks_for(c.n)), dim3(256), 0, stream, c);
+    MI_LAUNCH(k_vis_begin, dim3(blocks_for(c.n)), dim3(256), 0, stream, c);
     return hipGetLastError();
 }
 hipError_t launch_vis_end(const Columns& c, hipStream_t stream) {
     if (c.n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_vis_end, dim3(blocks_for(c.n)), dim3(256), 0, stream, c);
+    MI_LAUNCH(k_vis_end, dim3(blocks_for(c.n)), dim3(256), 0, stream, c);
     return hipGetLastError();
 }
 
@@ -361,12 +441,80 @@ hipError_t launch_compact(const CompactArgs& a, hipStream_t stream, void (*mark)
     if (a.n == 0) return hipSuccess;
     const dim3 grid(a.n_blocks, a.n_views * a.n_classes);
     if (mark) mark(mctx, K_COMPACT_COUNT);
-    hipLaunchKernelGGL(k_compact_count, grid, dim3(256), 0, stream, a);
+    MI_LAUNCH(k_compact_count, grid, dim3(256), 0, stream, a);
     if (mark) mark(mctx, K_COMPACT_SCAN);
-    hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, stream, a);
+    MI_LAUNCH(k_compact_scan, dim3(1), dim3(1024), 0, stream, a);
     if (mark) mark(mctx, K_COMPACT_SCATTER);
-    hipLaunchKernelGGL(k_compact_scatter, grid, dim3(256), 0, stream, a);
+    MI_LAUNCH(k_compact_scatter, grid, dim3(256), 0, stream, a);
     if (mark) mark(mctx, K_NUM_KERNELS);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Single-launch compaction (rows already in ascending Entity-key order).  grid = (ceil(words/64), segments).
+// A workgroup owns 64 mask words (4096 rows).  Its base is the sum of the u8 wave counts of all preceding
+// words of the segment (<= n/64 bytes, L2 resident, read as 16-byte vectors and summed with v_sad_u8), so
+// there is no scan kernel, no look-back chain and no atomics; the list order is the row order.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t sum_bytes(uint32_t x, uint32_t acc) { return __builtin_amdgcn_sad_u8(x, 0u, acc); }
+
+__global__ void __launch_bounds__(256) k_compact_fast(CompactFastArgs a) {
+    const uint32_t seg = blockIdx.y;
+    const uint32_t view = seg / a.n_classes;
+    const uint8_t* cnt = a.wave_cnt + (size_t)seg * a.n_waves;
+    const uint64_t* mask = a.seg_mask ? a.seg_mask + (size_t)seg * a.seg_words
+                                      : a.bitmask + view * a.words_per_view + a.word_offset;
+    const uint32_t n_words = (a.n + 63u) >> 6;
+    const uint32_t w0 = blockIdx.x * 64u;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    __shared__ uint32_t red[4], wtot[4];
+
+    // phase 1: base = sum of cnt[0 .. w0)
+    uint32_t partial = 0;
+    const uint4* c4 = reinterpret_cast<const uint4*>(cnt);
+    for (uint32_t i = threadIdx.x; i < (w0 >> 4); i += 256u) {
+        const uint4 q = c4[i];
+        partial = sum_bytes(q.x, partial);
+        partial = sum_bytes(q.y, partial);
+        partial = sum_bytes(q.z, partial);
+        partial = sum_bytes(q.w, partial);
+    }
+#pragma unroll
+    for (uint32_t off = 32u; off; off >>= 1) partial += __shfl_xor(partial, off, 64);
+    if (lane == 0) red[wv] = partial;
+
+    // phase 2: this wave's 16 words
+    const uint32_t my_word = w0 + wv * 16u + lane;
+    const unsigned long long m = (lane < 16u && my_word < n_words) ? mask[my_word] : 0ull;
+    const uint32_t pc = __popcll(m);
+    uint32_t incl = pc;
+#pragma unroll
+    for (uint32_t off = 1; off < 16u; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    const uint32_t excl = incl - pc;
+    if (lane == 15u) wtot[wv] = incl;
+    __syncthreads();
+    uint32_t base = red[0] + red[1] + red[2] + red[3];
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) base += k < wv ? wtot[k] : 0u;
+    uint32_t* out = a.out_rows + (size_t)seg * a.seg_stride;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll 4
+    for (uint32_t j = 0; j < 16u; ++j) {
+        const unsigned long long mj = __shfl(m, (int)j, 64);
+        const uint32_t oj = __shfl(excl, (int)j, 64);
+        if ((mj >> lane) & 1ull) out[base + oj + __popcll(mj & lt)] = (w0 + wv * 16u + j) * 64u + lane;
+    }
+    if (blockIdx.x == gridDim.x - 1u && threadIdx.x == 0)
+        a.seg_totals[seg] = red[0] + red[1] + red[2] + red[3] + wtot[0] + wtot[1] + wtot[2] + wtot[3];
+}
+
+hipError_t launch_compact_fast(const CompactFastArgs& a, hipStream_t stream) {
+    if (a.n == 0 || a.n_segments == 0) return hipSuccess;
+    const uint32_t n_words = (a.n + 63u) >> 6;
+    MI_LAUNCH(k_compact_fast, dim3((n_words + 63u) / 64u, a.n_segments), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -377,7 +525,7 @@ __global__ void __launch_bounds__(256) k_clear_u32(uint32_t* p, uint64_t n_words
 hipError_t launch_clear_u32(uint32_t* p, uint64_t n_words, hipStream_t stream) {
     if (n_words == 0) return hipSuccess;
     const uint32_t blocks = (uint32_t)((n_words + 255ull) / 256ull > 2048ull ? 2048ull : (n_words + 255ull) / 256ull);
-    hipLaunchKernelGGL(k_clear_u32, dim3(blocks), dim3(256), 0, stream, p, n_words);
+    MI_LAUNCH(k_clear_u32, dim3(blocks), dim3(256), 0, stream, p, n_words);
     return hipGetLastError();
 }
 __global__ void __launch_bounds__(256) k_bytes_to_bits(const uint8_t* __restrict__ bytes, uint32_t n, uint64_t* bits) {
@@ -388,7 +536,7 @@ __global__ void __launch_bounds__(256) k_bytes_to_bits(const uint8_t* __restrict
 }
 hipError_t launch_bytes_to_bits(const uint8_t* bytes, uint32_t n, uint64_t* bits, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_bytes_to_bits, dim3(blocks_for(n)), dim3(256), 0, stream, bytes, n, bits);
+    MI_LAUNCH(k_bytes_to_bits, dim3(blocks_for(n)), dim3(256), 0, stream, bytes, n, bits);
     return hipGetLastError();
 }
 

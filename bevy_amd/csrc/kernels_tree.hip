@@ -1,19 +1,30 @@
 // kernels_tree.hip -- hierarchy propagation on gfx950:
 //   mark_dirty_trees              crates/bevy_transform/src/systems.rs:111-306
-//   propagate_parent_transforms   crates/bevy_transform/src/systems.rs:506-748 (levels >= 1)
+//   propagate_parent_transforms   crates/bevy_transform/src/systems.rs:506-748 (roots :522-530, descendants :679-748)
+//   sync_simple_transforms        crates/bevy_transform/src/systems.rs:42-79 (flat rows sharing level 0 with the roots)
 //
 // Rows are in level (BFS) order, so the descendants of a contiguous range of nodes form one
-// contiguous range per level.  A workgroup owns a *subtree tile*: a contiguous range of nodes
-// at the band's first level plus all their descendants for the next few levels.  It walks the
-// tile level by level with a workgroup barrier in between, keeping the GlobalTransforms of the
-// level it just produced in LDS (2 x 512 rows x 48 B ping-pong), so a child reads its parent's
-// matrix with three ds_read_b128 instead of going back to L2/HBM, and one launch covers several
-// levels (the reference's mpsc work queue, systems.rs:767-813, becomes the tile list).
-// A level wider than the LDS budget inside a tile falls back to reading parents from global
-// memory, so any plan is correct; the host planner (context.cpp) only chooses the fast one.
+// contiguous range per level.  A workgroup owns a *subtree tile*: a contiguous range of nodes at the
+// tile's first level plus all their descendants for the next few levels (the reference's mpsc work
+// queue of 512-entity chunks, systems.rs:767-813, becomes the tile list).  The tile is walked in
+// three steps:
+//   step 0  every row of the tile's upper levels (all but the last; <= TILE_UCAP rows together) gets
+//           its local affine computed from T/R/S into an LDS slot, and its old GlobalTransform and
+//           parent slot fetched into registers -- ALL upper levels at once, so the HBM latency is
+//           paid once per tile, not once per level;
+//   step 1  level by level (workgroup barrier in between) G = G_parent * local, both operands read
+//           from LDS (three ds_read_b128 each); the result overwrites the local affine in place;
+//   step 2  the tile's last level -- usually ~3/4 of its rows -- is streamed: coalesced T/R/S and
+//           old-G loads (wave-local LDS transpose), parent G from LDS, coalesced G stores.
+// One launch therefore covers up to TILE_MAX_LEVELS levels with one HBM round trip of latency plus
+// the streaming time.  A level wider than the LDS budget inside a tile falls back to reading its
+// parents from global memory, so any plan is correct; the host planner (context.cpp) only chooses
+// the fast one.
 //
 // Algorithmic bytes per node: read T 40 + parent_idx 4 + old G 48 (set_if_neq, systems.rs:719),
-// write G 48 + changed 1; parent G comes from LDS (first level of a tile: from L2).
+// write G 48 + changed 1; parent G comes from LDS (first level of a non-root tile: from L2).
+#include <stdlib.h>
+
 #include "glam_math.h"
 #include "kernels.h"
 
@@ -47,6 +58,24 @@ __device__ __forceinline__ void pack(const Affine& a, float4& o0, float4& o1, fl
     o1 = make_float4(a.m.y_axis.y, a.m.y_axis.z, a.m.z_axis.x, a.m.z_axis.y);
     o2 = make_float4(a.m.z_axis.z, a.t.x, a.t.y, a.t.z);
 }
+__device__ __forceinline__ void st_affine(float* g, uint32_t row, const Affine& a) {
+    float4 o0, o1, o2;
+    pack(a, o0, o1, o2);
+    float4* dst = reinterpret_cast<float4*>(g) + 3ull * row;
+    dst[0] = o0;
+    dst[1] = o1;
+    dst[2] = o2;
+}
+__device__ __forceinline__ Affine lds_affine(const float4* slots, uint32_t slot) {
+    return unpack(slots[slot * 3u], slots[slot * 3u + 1u], slots[slot * 3u + 2u]);
+}
+__device__ __forceinline__ void lds_put(float4* slots, uint32_t slot, const Affine& a) {
+    float4 o0, o1, o2;
+    pack(a, o0, o1, o2);
+    slots[slot * 3u] = o0;
+    slots[slot * 3u + 1u] = o1;
+    slots[slot * 3u + 2u] = o2;
+}
 
 // mark_dirty_trees: climb from every changed row to its root, OR-ing the TransformTreeChanged bit;
 // a climber stops at the first node somebody already marked (the shared atomic bitset of
@@ -65,92 +94,312 @@ __global__ void __launch_bounds__(256) k_mark_dirty(uint32_t n, const uint8_t* _
     }
 }
 
-__global__ void __launch_bounds__(256) k_propagate_tiles(Columns c, const uint32_t* __restrict__ parent_idx,
-                                                          const TileDesc* __restrict__ tiles,
-                                                          const uint32_t* __restrict__ tree_bits,
-                                                          uint8_t* g_changed_bytes, bool all_dirty, bool static_opt) {
-    __shared__ float4 lds_g[2][TILE_LDS_ROWS * 3];
-    __shared__ uint8_t lds_chg[2][TILE_LDS_ROWS];
-    const TileDesc& td = tiles[blockIdx.x];
-    const uint32_t n_levels = td.n_levels;
-    for (uint32_t l = 0; l < n_levels; ++l) {
-        const uint32_t start = td.start[l], count = td.count[l];
-        const uint32_t prev_start = l ? td.start[l - 1] : 0u;
-        const uint32_t prev_count = l ? td.count[l - 1] : 0u;
-        const bool prev_in_lds = l && prev_count <= TILE_LDS_ROWS;
-        const bool cur_to_lds = (l + 1 < n_levels) && count <= TILE_LDS_ROWS;
-        const uint32_t rb = (l + 1u) & 1u, wb = l & 1u;
-        for (uint32_t i = threadIdx.x; i < count; i += 256u) {
-            const uint32_t row = start + i;
-            const uint32_t p = parent_idx[row];
-            Affine gp;
-            bool p_changed;
-            if (prev_in_lds) {
-                const uint32_t slot = p - prev_start;
-                gp = unpack(lds_g[rb][slot * 3], lds_g[rb][slot * 3 + 1], lds_g[rb][slot * 3 + 2]);
-                p_changed = lds_chg[rb][slot] != 0;
-            } else {
-                gp = ld_affine(c.global, p);
-                p_changed = g_changed_bytes[p] != 0;
-            }
-            const bool tree_changed = all_dirty || !tree_bits || ((tree_bits[row >> 5] >> (row & 31u)) & 1u);
-            // static scene optimisation, systems.rs:708-714
-            const bool skip = static_opt && !tree_changed && !p_changed;
-            const Affine old = ld_affine(c.global, row);
-            Affine cur = old;
-            bool changed = false;
-            if (!skip) {
-                const Affine local = affine_from_srt(ld3(c.scale, row), ld4(c.rotation, row), ld3(c.translation, row));
-                const Affine nw = mul(gp, local);  // p_global_transform.mul_transform(*transform)
-                if (!affine_eq(nw, old)) {         // set_if_neq, systems.rs:719
-                    float4 o0, o1, o2;
-                    pack(nw, o0, o1, o2);
-                    float4* dst = reinterpret_cast<float4*>(c.global) + 3ull * row;
-                    dst[0] = o0; dst[1] = o1; dst[2] = o2;
-                    cur = nw;
-                    changed = true;
-                }
-            }
-            g_changed_bytes[row] = changed ? 1 : 0;
-            if (cur_to_lds) {
-                float4 o0, o1, o2;
-                pack(cur, o0, o1, o2);
-                lds_g[wb][i * 3] = o0; lds_g[wb][i * 3 + 1] = o1; lds_g[wb][i * 3 + 2] = o2;
-                lds_chg[wb][i] = changed ? 1 : 0;
-            }
-        }
-        __syncthreads();  // also orders this level's global stores before the next level's fallback loads
+struct TreeArgs {
+    const uint32_t* parent_idx;
+    const TileDesc* tiles;
+    const uint8_t* node_flags;  // bit0 = has children (only level-0 rows consult it)
+    const uint8_t* changed;     // per-row Changed<Transform>|Added<GlobalTransform> byte, nullptr = all
+    const uint32_t* tree_bits;  // TransformTreeChanged bitset, nullptr = all changed
+    uint8_t* g_changed_bytes;   // out: GlobalTransform change tick bumped
+    uint32_t all_dirty;
+    uint32_t static_opt;
+};
+
+// The per-node rule.  Level-0 rows: roots (systems.rs:522-530) and flat rows (systems.rs:58-63) are plain
+// assignments; every other node is set_if_neq(parent * local) unless the static-scene rule skips it
+// (systems.rs:708-719).  *cur = the row's GlobalTransform after the system; returns "tick bumped".
+template <bool IS_ROOT_LEVEL>
+__device__ __forceinline__ bool node_update(const TreeArgs& a, uint32_t row, const Affine& gp, bool p_changed,
+                                            const Affine& local, const Affine& old, Affine* cur) {
+    const bool tree_changed = a.all_dirty || !a.tree_bits || ((a.tree_bits[row >> 5] >> (row & 31u)) & 1u);
+    if (IS_ROOT_LEVEL) {
+        const bool has_children = a.node_flags && (a.node_flags[row] & 1u);
+        const bool write =
+            has_children ? (!a.static_opt || tree_changed) : (a.all_dirty || !a.changed || a.changed[row] != 0);
+        *cur = write ? local : old;
+        return write;
     }
+    const bool skip = a.static_opt && !tree_changed && !p_changed;
+    if (!skip) {
+        const Affine nw = mul(gp, local);  // p_global_transform.mul_transform(*transform)
+        if (!affine_eq(nw, old)) {         // set_if_neq
+            *cur = nw;
+            return true;
+        }
+    }
+    *cur = old;
+    return false;
 }
 
-// Level-0 variant that also records the per-row changed byte (children look it up).
-__global__ void __launch_bounds__(256) k_level0_bytes(const uint64_t* __restrict__ g_changed_bits, uint32_t n_level0,
-                                                       uint8_t* g_changed_bytes) {
-    const uint32_t row = blockIdx.x * 256u + threadIdx.x;
-    if (row < n_level0) g_changed_bytes[row] = (uint8_t)((g_changed_bits[row >> 6] >> (row & 63u)) & 1ull);
+// One streamed row's inputs, fetched one loop iteration ahead of their use (software pipelining: the loads of
+// iteration i+1 are in flight while iteration i is multiplied and stored).
+struct RowFetch {
+    V3 t, s;
+    V4 q;
+    uint32_t p;
+    float4 g0, g1, g2;  // this lane's share of the wave's coalesced old-G rows
+};
+
+__device__ __forceinline__ RowFetch fetch_row(const Columns& c, const uint32_t* __restrict__ parent_idx, uint32_t start,
+                                              uint32_t count, uint32_t base, uint32_t tid, uint32_t lane, uint32_t wv,
+                                              bool root_level) {
+    RowFetch f;
+    const uint32_t i = base + tid;
+    const uint32_t wbase = base + wv * 64u;
+    const uint32_t lim = wbase < count ? (count - wbase < 64u ? count - wbase : 64u) * 3u : 0u;
+    const float4* src = reinterpret_cast<const float4*>(c.global) + 3ull * (start + wbase);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    f.g0 = lane < lim ? src[lane] : z;
+    f.g1 = 64u + lane < lim ? src[64u + lane] : z;
+    f.g2 = 128u + lane < lim ? src[128u + lane] : z;
+    f.t = V3{0.f, 0.f, 0.f};
+    f.s = V3{0.f, 0.f, 0.f};
+    f.q = V4{0.f, 0.f, 0.f, 0.f};
+    f.p = 0;
+    if (i < count) {
+        const uint32_t row = start + i;
+        f.t = ld3(c.translation, row);
+        f.q = ld4(c.rotation, row);
+        f.s = ld3(c.scale, row);
+        if (!root_level) f.p = parent_idx[row];
+    }
+    return f;
+}
+
+// ROOTS = true: the tile's first level is level 0 of the forest (no parents).
+// BLOCK = 256 normally; 1024 for passes with so few tiles that one workgroup's loop length is the critical path.
+template <bool ROOTS, uint32_t BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_propagate_tiles(Columns c, TreeArgs a) {
+    constexpr uint32_t R = (TILE_UCAP + BLOCK - 1) / BLOCK;  // LDS-resident rows per thread
+    __shared__ float4 lds_g[TILE_UCAP * 3];  // upper-level rows: local affine, then GlobalTransform (in place)
+    __shared__ uint8_t lds_chg[TILE_UCAP];
+    __shared__ float4 lds_stage[BLOCK / 64][192];  // wave-private transpose rows for the streamed level
+    const TileDesc& td = a.tiles[blockIdx.x];
+    const uint32_t L = td.n_levels;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+
+    // Leading levels resident in LDS: every level but the last, while the running row total fits.
+    uint32_t ubase[TILE_MAX_LEVELS + 1];
+    ubase[0] = 0;
+    uint32_t n_lds = 0, U = 0;
+#pragma unroll
+    for (uint32_t l = 0; l < TILE_MAX_LEVELS; ++l) {
+        const uint32_t cnt = l < L ? td.count[l] : 0u;
+        ubase[l + 1] = ubase[l] + cnt;
+        if (l + 1 < L && n_lds == l && ubase[l + 1] <= TILE_UCAP) {
+            n_lds = l + 1;
+            U = ubase[l + 1];
+        }
+    }
+
+    // ---- step 0: fetch everything the LDS-resident levels need, all levels at once -------------------
+    Affine old_g[R];
+    uint32_t my_row[R], my_level[R], my_pslot[R];
+#pragma unroll
+    for (uint32_t k = 0; k < R; ++k) {
+        const uint32_t u = tid + BLOCK * k;
+        my_level[k] = 0xFFFFFFFFu;
+        my_row[k] = 0;
+        my_pslot[k] = 0;
+        old_g[k] = Affine{};
+        if (u < U) {
+            uint32_t l = 0;
+#pragma unroll
+            for (uint32_t j = 1; j < TILE_MAX_LEVELS; ++j)
+                if (j < n_lds && u >= ubase[j]) l = j;
+            uint32_t lstart = td.start[0], lbase = 0, pstart = 0, pbase = 0;
+#pragma unroll
+            for (uint32_t j = 1; j < TILE_MAX_LEVELS; ++j)
+                if (j == l) {
+                    lstart = td.start[j];
+                    lbase = ubase[j];
+                    pstart = td.start[j - 1];
+                    pbase = ubase[j - 1];
+                }
+            const uint32_t row = lstart + (u - lbase);
+            my_level[k] = l;
+            my_row[k] = row;
+            const Affine local = affine_from_srt(ld3(c.scale, row), ld4(c.rotation, row), ld3(c.translation, row));
+            lds_put(lds_g, u, local);
+            old_g[k] = ld_affine(c.global, row);
+            if (!(ROOTS && l == 0)) {
+                const uint32_t p = a.parent_idx[row];
+                // parent's LDS slot (levels >= 1 of the tile) or its global row (level 0 of a non-root tile)
+                my_pslot[k] = l ? pbase + (p - pstart) : p;
+            }
+        }
+    }
+    // The first streamed level's inputs do not depend on step 1 either: put its loads in flight now.
+    uint32_t s_start = td.start[0], s_count = L ? td.count[0] : 0u;
+#pragma unroll
+    for (uint32_t j = 1; j < TILE_MAX_LEVELS; ++j)
+        if (j == n_lds) {
+            s_start = td.start[j];
+            s_count = j < L ? td.count[j] : 0u;
+        }
+    RowFetch cur_f = fetch_row(c, a.parent_idx, s_start, s_count, 0u, tid, lane, wv, ROOTS && n_lds == 0);
+    __syncthreads();
+
+    // ---- step 1: LDS-resident levels ---------------------------------------------------------------
+    bool any_chg = false;
+    for (uint32_t l = 0; l < n_lds; ++l) {
+#pragma unroll
+        for (uint32_t k = 0; k < R; ++k) {
+            if (my_level[k] == l) {
+                const uint32_t u = tid + BLOCK * k, row = my_row[k];
+                const Affine local = lds_affine(lds_g, u);
+                Affine cur;
+                bool chg;
+                if (ROOTS && l == 0) {
+                    chg = node_update<true>(a, row, local, false, local, old_g[k], &cur);
+                } else {
+                    Affine gp;
+                    bool p_changed;
+                    if (l) {
+                        gp = lds_affine(lds_g, my_pslot[k]);
+                        p_changed = lds_chg[my_pslot[k]] != 0;
+                    } else {
+                        gp = ld_affine(c.global, my_pslot[k]);
+                        p_changed = a.g_changed_bytes[my_pslot[k]] != 0;
+                    }
+                    chg = node_update<false>(a, row, gp, p_changed, local, old_g[k], &cur);
+                }
+                any_chg = any_chg || chg;
+                a.g_changed_bytes[row] = chg ? 1 : 0;
+                lds_put(lds_g, u, cur);
+                lds_chg[u] = chg ? 1 : 0;
+            }
+        }
+        __syncthreads();
+    }
+    // Flush the LDS-resident levels: slots and rows are both contiguous per level, so the write-back is a
+    // straight float4 copy (fully coalesced) instead of one 48-byte scatter per lane.  Unchanged rows hold
+    // their old bytes, so rewriting them is value-neutral; a tile in which nothing changed writes nothing.
+    if (__syncthreads_or(any_chg ? 1 : 0)) {
+#pragma unroll
+        for (uint32_t j = 0; j < TILE_MAX_LEVELS - 1; ++j) {
+            if (j < n_lds) {
+                float4* dst = reinterpret_cast<float4*>(c.global) + 3ull * td.start[j];
+                const float4* src = lds_g + 3u * ubase[j];
+                const uint32_t n4 = 3u * td.count[j];
+                for (uint32_t i = tid; i < n4; i += BLOCK) dst[i] = src[i];
+            }
+        }
+    }
+
+    // ---- step 2: streamed levels (normally just the last one) ---------------------------------------
+    for (uint32_t l = n_lds; l < L; ++l) {
+        uint32_t start = td.start[0], count = td.count[0], pbase = 0, pstart = 0;
+#pragma unroll
+        for (uint32_t j = 1; j < TILE_MAX_LEVELS; ++j)
+            if (j == l) {
+                start = td.start[j];
+                count = td.count[j];
+                pbase = ubase[j - 1];
+                pstart = td.start[j - 1];
+            }
+        const bool parents_in_lds = l > 0 && l - 1 < n_lds;
+        const bool root_level = ROOTS && l == 0;
+        float4* stage = lds_stage[wv];
+
+        if (l != n_lds) cur_f = fetch_row(c, a.parent_idx, start, count, 0u, tid, lane, wv, root_level);
+        for (uint32_t base = 0; base < count; base += BLOCK) {
+            // next iteration's loads go out before this one's math (past the end: every load is predicated off)
+            const RowFetch nxt_f = fetch_row(c, a.parent_idx, start, count, base + BLOCK, tid, lane, wv, root_level);
+            const uint32_t i = base + tid;
+            const bool live = i < count;
+            const uint32_t row = start + i;
+            const uint32_t wbase = base + wv * 64u;
+            const uint32_t wave_row0 = start + wbase;
+            const uint32_t wave_lim = wbase < count ? (count - wbase < 64u ? count - wbase : 64u) * 3u : 0u;
+            stage[lane] = cur_f.g0;
+            stage[64u + lane] = cur_f.g1;
+            stage[128u + lane] = cur_f.g2;
+            Affine local = {}, gp = {};
+            bool p_changed = false;
+            if (live) {
+                local = affine_from_srt(cur_f.s, cur_f.q, cur_f.t);
+                if (!root_level) {
+                    if (parents_in_lds) {
+                        const uint32_t slot = pbase + (cur_f.p - pstart);
+                        gp = lds_affine(lds_g, slot);
+                        p_changed = lds_chg[slot] != 0;
+                    } else {
+                        gp = ld_affine(c.global, cur_f.p);
+                        p_changed = a.g_changed_bytes[cur_f.p] != 0;
+                    }
+                }
+            }
+            MI_WAVE_LDS_SYNC();
+            const Affine old = lds_affine(stage, lane);
+            Affine cur = old;
+            bool chg = false;
+            if (live) {
+                if (root_level) chg = node_update<true>(a, row, local, false, local, old, &cur);
+                else chg = node_update<false>(a, row, gp, p_changed, local, old, &cur);
+                a.g_changed_bytes[row] = chg ? 1 : 0;
+            }
+            // store: whole wave changed (the dirty-tree case) -> transpose back and write 3 x 1 KB rows;
+            // otherwise only the changed lanes write their own 48 bytes.
+            const unsigned long long cm = __ballot(chg), lm = __ballot(live);
+            if (cm == lm) {
+                MI_WAVE_LDS_SYNC();
+                lds_put(stage, lane, cur);
+                MI_WAVE_LDS_SYNC();
+                float4* dst = reinterpret_cast<float4*>(c.global) + 3ull * wave_row0;
+#pragma unroll
+                for (uint32_t k = 0; k < 3u; ++k) {
+                    const uint32_t j = k * 64u + lane;
+                    if (j < wave_lim) dst[j] = stage[j];
+                }
+            } else if (chg) {
+                st_affine(c.global, row, cur);
+            }
+            MI_WAVE_LDS_SYNC();
+            cur_f = nxt_f;
+        }
+        if (l + 1 < L) {
+            // fallback only (a non-last level too wide for LDS): the next level reads these rows back from
+            // global memory, possibly through lines this CU cached before rewriting them
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    }
 }
 
 hipError_t launch_mark_dirty(uint32_t n, const uint8_t* changed, const uint32_t* parent_idx, uint32_t* tree_bits,
                              hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_mark_dirty, dim3((n + 255u) / 256u), dim3(256), 0, stream, n, changed, parent_idx, tree_bits);
+    MI_LAUNCH(k_mark_dirty, dim3((n + 255u) / 256u), dim3(256), 0, stream, n, changed, parent_idx, tree_bits);
     return hipGetLastError();
 }
 
-hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, const TileDesc* d_tiles,
-                                  uint32_t n_tiles, const uint32_t* tree_bits, uint8_t* g_changed_bytes,
-                                  bool all_dirty, bool static_opt, hipStream_t stream) {
+hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, const TileDesc* d_tiles, uint32_t n_tiles,
+                                  bool roots, const uint8_t* node_flags, const uint8_t* changed, const uint32_t* tree_bits,
+                                  uint8_t* g_changed_bytes, bool all_dirty, bool static_opt, hipStream_t stream) {
     if (n_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_propagate_tiles, dim3(n_tiles), dim3(256), 0, stream, c, parent_idx, d_tiles, tree_bits,
-                       g_changed_bytes, all_dirty, static_opt);
-    return hipGetLastError();
-}
-
-hipError_t launch_level0_bytes(const uint64_t* g_changed_bits, uint32_t n_level0, uint8_t* g_changed_bytes,
-                               hipStream_t stream) {
-    if (n_level0 == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_level0_bytes, dim3((n_level0 + 255u) / 256u), dim3(256), 0, stream, g_changed_bits, n_level0,
-                       g_changed_bytes);
+    TreeArgs a;
+    a.parent_idx = parent_idx;
+    a.tiles = d_tiles;
+    a.node_flags = node_flags;
+    a.changed = changed;
+    a.tree_bits = tree_bits;
+    a.g_changed_bytes = g_changed_bytes;
+    a.all_dirty = all_dirty ? 1u : 0u;
+    a.static_opt = static_opt ? 1u : 0u;
+    // few tiles: one workgroup's streamed-level loop is the critical path -> 1024 threads shorten it 4x
+    static const int forced = getenv("MI_TILE_BLOCK") ? atoi(getenv("MI_TILE_BLOCK")) : 0;
+    const uint32_t block = forced ? (uint32_t)forced : (n_tiles < 128u ? 1024u : 256u);
+    if (roots) {
+        if (block == 1024u) MI_LAUNCH((k_propagate_tiles<true, 1024>), dim3(n_tiles), dim3(1024), 0, stream, c, a);
+        else if (block == 512u) MI_LAUNCH((k_propagate_tiles<true, 512>), dim3(n_tiles), dim3(512), 0, stream, c, a);
+        else MI_LAUNCH((k_propagate_tiles<true, 256>), dim3(n_tiles), dim3(256), 0, stream, c, a);
+    } else {
+        if (block == 1024u) MI_LAUNCH((k_propagate_tiles<false, 1024>), dim3(n_tiles), dim3(1024), 0, stream, c, a);
+        else if (block == 512u) MI_LAUNCH((k_propagate_tiles<false, 512>), dim3(n_tiles), dim3(512), 0, stream, c, a);
+        else MI_LAUNCH((k_propagate_tiles<false, 256>), dim3(n_tiles), dim3(256), 0, stream, c, a);
+    }
     return hipGetLastError();
 }
 

@@ -59,6 +59,12 @@ extern "C" {
 /* ---- per-view flag byte (mi_cull) ------------------------------------------------------- */
 #define MI_VIEW_FLAG_NO_CPU_CULLING 0x01u /* camera Has<NoCpuCulling>: skip frustum tests, :756,823 */
 
+/* ---- mi_cull / mi_propagate_and_cull flags ------------------------------------------------- */
+#define MI_CULL_BEGIN_FRAME 0x1u /* also apply reset_view_visibility (mod.rs:733-737) in the same pass */
+#define MI_CULL_END_FRAME 0x2u   /* also apply check_visibility_gpu_culling + mark_newly_hidden_entities_invisible
+                                    (mod.rs:884-918) in the same pass: valid when nothing else (e.g. shadow-view
+                                    culling, bevy_light/src/lib.rs:499-510) ORs into ViewVisibility this frame */
+
 /* ---- mi_propagate flags ----------------------------------------------------------------- */
 #define MI_PROPAGATE_ALL_DIRTY 0x1u  /* every Transform counts as changed (worst case / first frame) */
 #define MI_PROPAGATE_STATIC_OPT 0x2u /* StaticTransformOptimizations::Enabled, systems.rs:87-103 */
@@ -159,7 +165,8 @@ int32_t mi_hierarchy_sort(uint32_t n, const uint32_t* parent, uint32_t* out_new_
  * Writes GlobalTransform and the per-row "change tick bumped" bit. */
 int32_t mi_propagate(mi_ctx* ctx, uint32_t flags);
 
-/* reset_view_visibility (visibility/mod.rs:733-737) -- call once per frame before mi_cull. */
+/* reset_view_visibility (visibility/mod.rs:733-737) -- call once per frame before mi_cull
+ * (or pass MI_CULL_BEGIN_FRAME to mi_cull and skip this call). */
 int32_t mi_visibility_begin_frame(mi_ctx* ctx);
 
 /* check_visibility_cpu_culling (visibility/mod.rs:748-876) for n_views ACTIVE cameras in one pass over
@@ -167,14 +174,15 @@ int32_t mi_visibility_begin_frame(mi_ctx* ctx);
  * per view, and builds the per-view, per-class VisibleEntities lists sorted by Entity bits (:861-874).
  *   frusta[24*n_views]; view_layer_masks[n_views] (NULL = layer 0); view_flags[n_views] (NULL = 0). */
 int32_t mi_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_masks, const uint8_t* view_flags,
-                uint32_t n_views);
+                uint32_t n_views, uint32_t flags /* MI_CULL_* */);
 
 /* Fused fast path for flat rows (no hierarchy uploaded): sync_simple_transforms with every Transform
  * dirty + reset_view_visibility + check_visibility_cpu_culling in ONE pass (Transform is read once,
  * GlobalTransform is written once and never re-read).  Results are identical to
- * mi_propagate(MI_PROPAGATE_ALL_DIRTY); mi_visibility_begin_frame(); mi_cull(...). */
+ * mi_propagate(MI_PROPAGATE_ALL_DIRTY); mi_visibility_begin_frame(); mi_cull(...) [; mi_visibility_end_frame()
+ * when flags has MI_CULL_END_FRAME].  MI_CULL_BEGIN_FRAME is implied. */
 int32_t mi_propagate_and_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_masks,
-                              const uint8_t* view_flags, uint32_t n_views);
+                              const uint8_t* view_flags, uint32_t n_views, uint32_t flags /* MI_CULL_* */);
 
 /* check_visibility_gpu_culling for NoCpuCulling rows (visibility/mod.rs:884-903) followed by
  * mark_newly_hidden_entities_invisible (:908-918). */

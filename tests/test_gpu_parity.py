@@ -99,6 +99,76 @@ def test_unfused_equals_fused_and_oracle(ctx_factory):
         assert_bits(chg, chg_exp, "vv changed")
 
 
+@pytest.mark.parametrize("n", [1, 64, 1000, 33_333])
+def test_fused_begin_end_flags_equal_separate_passes(ctx_factory, n):
+    """MI_CULL_BEGIN_FRAME / MI_CULL_END_FRAME fold reset_view_visibility and check_visibility_gpu_culling +
+    mark_newly_hidden into the cull pass: same bytes and change ticks as the separate systems (and the oracle)."""
+    sc = W.many_cubes(n, radius=500.0 if n > 1000 else 5.0, ragged_flags=True)
+    frusta = frusta_for([W.many_cubes_camera(2), W.many_cubes_camera(2, yaw=1.5)])
+    vv0 = (W.splitmix64(11, n) % np.uint64(4)).astype(np.uint8)  # all four 2-bit states
+    g_exp, vv_exp, vis_exp, chg_exp = oracle_frame(sc, vv0, frusta, None, None)
+    a, b = ctx_factory(), ctx_factory()
+    upload_scene(a, sc, vv0)
+    a.propagate_and_cull(frusta, flags=B.CULL_END_FRAME)
+    upload_scene(b, sc, vv0)
+    b.propagate(B.PROPAGATE_ALL_DIRTY)
+    b.cull(frusta, flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME)
+    for c in (a, b):
+        assert c.download_global_transforms(want_changed=False).tobytes() == g_exp.tobytes()
+        for v in range(2):
+            assert_bits(c.download_visibility(v), vis_exp[v], "visibility")
+        vv, chg = c.download_view_visibility()
+        assert_bits(vv, vv_exp, "vv")
+        assert_bits(chg, chg_exp, "vv changed")
+
+
+def test_many_views_use_the_device_view_table(ctx_factory):
+    """More than MAX_INLINE_VIEWS (8) cameras: views come from a device array instead of the kernarg segment."""
+    n = 9_001
+    sc = W.many_cubes(n, ragged_flags=True)
+    cams = [W.many_cubes_camera(k, yaw=0.6 * k) for k in range(11)]
+    frusta = frusta_for(cams)
+    vmasks = np.array([1, 3, 2, 1, 1, 3, 1, 2, 1, 1, 3], np.uint32)
+    ctx = ctx_factory()
+    upload_scene(ctx, sc)
+    ctx.propagate_and_cull(frusta, vmasks, flags=B.CULL_END_FRAME)
+    _, vv_exp, vis_exp, chg_exp = oracle_frame(sc, np.zeros(n, np.uint8), frusta, vmasks, None)
+    for v in range(11):
+        assert_bits(ctx.download_visibility(v), vis_exp[v], f"view {v}")
+        k, rows = ctx.download_visible_entities(v, 0)
+        assert np.array_equal(rows, np.nonzero(vis_exp[v])[0].astype(np.uint32))
+    vv, chg = ctx.download_view_visibility()
+    assert_bits(vv, vv_exp, "vv")
+    assert_bits(chg, chg_exp, "vv changed")
+
+
+@pytest.mark.parametrize("n", [5, 4096, 4097, 70_001])
+def test_visible_entities_fast_path_with_classes(ctx_factory, n):
+    """Rows already in Entity-key order (the shim's numbering): single-launch compaction from the per-wave counts
+    and class-filtered segment masks, fused and unfused."""
+    sc = W.many_cubes(n, radius=500.0 if n > 1000 else 5.0, ragged_flags=True)
+    frusta = frusta_for([W.many_cubes_camera(0), W.many_cubes_camera(0, yaw=1.0), W.many_cubes_camera(7, yaw=2.5)])
+    rnd = W.splitmix64(7, n)
+    keys = (np.arange(n, dtype=np.uint64) * np.uint64(3)) + np.uint64(1 << 32)  # ascending with the row
+    class_mask = np.where(rnd % np.uint64(4) == 0, 0b1010, np.where(rnd % np.uint64(4) == 1, 0b1000, 0b0010)).astype(np.uint32)
+    class_mask[rnd % np.uint64(29) == 0] = 0
+    _, _, vis_exp, _ = oracle_frame(sc, np.zeros(n, np.uint8), frusta, None, None)
+    a, b = ctx_factory(), ctx_factory()
+    for c in (a, b):
+        upload_scene(c, sc)
+        c.upload_entity_keys(keys)
+        c.upload_visibility_classes(class_mask)
+    a.propagate_and_cull(frusta)
+    b.propagate(B.PROPAGATE_ALL_DIRTY)
+    b.cull(frusta, flags=B.CULL_BEGIN_FRAME)
+    for c in (a, b):
+        for v in range(3):
+            for cb in (1, 3, 0):
+                k, rows = c.download_visible_entities(v, cb)
+                ek, er = O.visible_entities_sorted(vis_exp[v], class_mask, cb, keys)
+                assert np.array_equal(k, ek) and np.array_equal(rows, er), (v, cb, len(k), len(ek))
+
+
 def test_view_visibility_lifecycle_over_frames(ctx_factory):
     """visibility/mod.rs:1313-1448 at scale: the 2-bit protocol and change ticks over 6 frames of a moving camera."""
     n = 30_000

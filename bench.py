@@ -6,14 +6,15 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one frame of the hot path over device-resident columns with every Transform dirty:
-  flat (default, BASELINE.json configs[1]): 1M flat entities per GPU, 1 camera frustum:
-        fused sync_simple_transforms + reset_view_visibility + check_visibility_cpu_culling (one kernel),
-        VisibleEntities compaction, check_visibility_gpu_culling + mark_newly_hidden_entities_invisible.
+  flat (default, BASELINE.json configs[1]): 1M flat entities per GPU, 1 camera frustum: ONE frame kernel
+        (sync_simple_transforms + reset_view_visibility + check_visibility_cpu_culling + check_visibility_gpu_culling
+        + mark_newly_hidden_entities_invisible) and ONE VisibleEntities compaction kernel.
         With N > 1 GPUs every rank owns a 1M-row range of an N x 1M scene (weak scaling) and the packed
         ViewVisibility bitmasks are exchanged with ONE RCCL all-gather per frame.
-  tree  (configs[4]): depth-12/branch-4 tree truncated to 1M nodes, propagate only.
+  tree  (configs[4]): depth-12/branch-4 tree truncated to 1M nodes, root moved every frame, propagate only.
   lights (configs[2]): 100k point lights, 16x9x24 clusters, assign_objects_to_clusters only.
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for the byte accounting behind `roofline`).
+Rank 0 prints ONE JSON line (DESIGN.md section 5 explains the byte accounting behind `roofline`); at N=1 the
+default run also measures tree and lights briefly and reports them under `other_workloads`.
 """
 import argparse
 import json
@@ -41,21 +42,168 @@ def parse():
     ap.add_argument("--lights", type=int, default=100_000)
     ap.add_argument("--unfused", action="store_true", help="flat: mi_propagate + mi_cull instead of the fused kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget")
-    ap.add_argument("--profile-all", action="store_true", help="bracket every kernel with HIP events (perturbs `value`)")
+    ap.add_argument("--profile-all", action="store_true", help="time every kernel, not only the dominant one")
     return ap.parse_args()
 
 
-def flat_bytes_per_entity(n_views):
-    # fused kernel: read T 40 + Aabb 24 + flags 1 + layers 4 + vv 1; write G 48 + vv 1 + (V + 2 change masks)/8
-    return 70.0 + 49.0 + (n_views + 2) / 8.0
+def flat_bytes_per_entity(n_views, fused=True):
+    # frame kernel: read Aabb 24 + flags 1 + layers 4 + vv 1 and T 40 (fused) or resident G 48 (unfused);
+    # write vv 1 + (V view masks + vv change mask)/8 bits + V/64 wave counts, and G 48 + its change mask (fused)
+    rd = 30.0 + (40.0 if fused else 48.0)
+    wr = 1.0 + (n_views + 1) / 8.0 + n_views / 64.0 + ((48.0 + 1.0 / 8.0) if fused else 0.0)
+    return rd + wr
+
+
+class Workload:
+    """step(f) enqueues one frame; units = work items per frame on this rank."""
+
+    def __init__(self, name, step, units, bytes_per_unit, dominant, config, metric, unit):
+        self.name, self.step, self.units, self.bytes_per_unit = name, step, units, bytes_per_unit
+        self.dominant, self.config, self.metric, self.unit = dominant, config, metric, unit
+
+
+def build_flat(ctx, args, rank, world, total_frames, full_holder):
+    import torch
+    import bevy_amd as B
+    from bevy_amd import api, sharding, workloads as W
+    n_views = args.views
+    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+
+    def frusta_of_frame(f):
+        return np.concatenate([api.compute_frustum(cfv, W.many_cubes_camera(f, yaw=v * np.pi / 2), W.CAMERA_FAR)
+                               for v in range(n_views)])
+
+    n_local = args.entities
+    n_global = n_local * world
+    lo = rank * n_local
+    radius = 500.0 * (n_global / 1_000_000.0) ** (1.0 / 3.0)
+    scene = W.many_cubes(n_global, radius=radius, start=lo, count=n_local)
+    ctx.resize(n_local)
+    ctx.upload_transforms(scene["translation"], scene["rotation"], scene["scale"])
+    ctx.upload_bounds(scene["aabb_center"], scene["aabb_half"], scene["flags"], scene["layers"])
+    frames = [frusta_of_frame(f) for f in range(total_frames)]
+    if world > 1:
+        words = sharding.gathered_words(n_global, world, n_views)
+        full = torch.zeros(words, dtype=torch.int64, device="cuda")
+        wpv, woff = sharding.block_offset_words(n_global, world, n_views, rank)
+        ctx.bind_visibility_output(full.data_ptr(), wpv, woff)
+        full_holder.append(full)
+
+    def step(f):
+        if args.unfused:
+            ctx.propagate(B.PROPAGATE_ALL_DIRTY)
+            ctx.cull(frames[f], flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME)
+        else:
+            ctx.propagate_and_cull(frames[f], flags=B.CULL_END_FRAME)
+        if world > 1:
+            sharding.all_gather_visibility(full_holder[0], n_global, world, n_views, rank)
+
+    config = {"workload": f"many_cubes-shaped flat scene, {n_local} entities/GPU ({n_global} total), {n_views} camera "
+                          f"frustum(s), all Transforms dirty, columns resident in HBM: "
+                          f"{'mi_propagate + mi_cull' if args.unfused else 'fused frame kernel'} (propagate + reset + frustum "
+                          "cull + mark-newly-hidden) + VisibleEntities compaction"
+                          + (f" + RCCL all-gather of the visibility bitmask over {world} GPUs" if world > 1 else ""),
+              "entities_per_gpu": n_local, "views": n_views, "parallelism": f"row-range shard x{world}"}
+    wl = Workload("flat", step, n_local, flat_bytes_per_entity(n_views, not args.unfused),
+                  "k_cull" if args.unfused else "k_flat_propagate_cull", config, "entities/sec through propagate+cull",
+                  "entities/s")
+    wl.scene, wl.frusta_of_frame, wl.n_views = scene, frusta_of_frame, n_views
+    return wl
+
+
+def build_tree(ctx, args):
+    import bevy_amd as B
+    from bevy_amd import workloads as W
+    tr = W.gen_tree(12, 4, args.entities)
+    ctx.resize(tr["n"])
+    ctx.upload_transforms(tr["translation"], tr["rotation"], tr["scale"])
+    ctx.upload_hierarchy(tr["parent"], tr["level_offsets"])
+    # the root moves every frame (a 40-byte dirty-row upload), so set_if_neq really rewrites every descendant
+    root_t = [tr["translation"][:3].copy(), tr["translation"][:3] + np.float32(1.0)]
+
+    def step(f):
+        ctx.upload_transforms(root_t[f & 1], tr["rotation"][:4], tr["scale"][:3], first_row=0)
+        ctx.propagate(B.PROPAGATE_ALL_DIRTY)
+    config = {"workload": f"gen_tree(12,4) truncated to {tr['n']} nodes ({len(tr['level_offsets']) - 1} levels), root moved "
+                          "every frame (dirty-row upload), LDS subtree-tile propagation (replicas per GPU)", "nodes": tr["n"]}
+    # T 40, parent_idx 4, old G 48 (set_if_neq), G 48, changed byte 1
+    return Workload("tree", step, tr["n"], 141.0, "k_propagate_tiles", config, "nodes/sec through hierarchy propagate", "nodes/s")
+
+
+def build_lights(ctx, args):
+    from bevy_amd import api, workloads as W
+    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+    lights = W.many_lights(args.lights, 50.0, 0.3)
+    cam = W.many_cubes_camera(0)
+    fr = api.compute_frustum(cfv, cam, W.CAMERA_FAR)
+    view, keep = api.cluster_view_build(cam, cfv, fr, 1920, 1080, (16, 9, 24), 5.0, 1000.0)
+    ctx.cluster_upload_objects(lights)
+    ctx.cluster_upload_view(view)
+
+    def step(f):
+        ctx.cluster_assign_resident()
+    config = {"workload": f"many_lights-shaped: {args.lights} point lights (range 0.3, shell R=50), 16x9x24 clusters, "
+                          "assign_objects_to_clusters, objects resident (replicas per GPU)", "lights": args.lights}
+    wl = Workload("lights", step, args.lights, 17.0, "k_cluster_walk", config,
+                  "lights/sec through assign_objects_to_clusters", "lights/s")
+    wl.keep = (view, keep, lights)
+    return wl
+
+
+def measure(ctx, wl, steps, warmup, profile_all, sync_extra=None):
+    """warmup untimed frames, then exactly `steps` frames between barrier+synchronize pairs.  Returns
+    (elapsed_s, per-kernel profile)."""
+    import torch
+
+    def sync_all():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if sync_extra:
+            sync_extra()
+
+    for f in range(warmup):
+        wl.step(f)
+    sync_all()
+    ctx.profile_filter(None if profile_all else [wl.dominant])
+    ctx.profile_enable(True)
+    sync_all()
+    t0 = time.perf_counter()
+    for f in range(warmup, warmup + steps):
+        wl.step(f)
+    sync_all()
+    t1 = time.perf_counter()
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    return t1 - t0, prof
+
+
+def roofline_of(wl, prof, steps):
+    dk = prof.get(wl.dominant)
+    if not dk:
+        return None
+    avg_s = dk["avg_us"] * 1e-6
+    launches_per_step = dk["launches"] / steps
+    alg_bytes = wl.bytes_per_unit * wl.units / launches_per_step
+    achieved = alg_bytes / avg_s / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # HBM bytes per launch from the separate --pmc passes
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get(wl.dominant, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    return {"bound": "hbm", "kernel": wl.dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "avg_kernel_us": round(dk["avg_us"], 3),
+            "launches": dk["launches"], "algorithmic_bytes_per_launch": int(alg_bytes),
+            "timing": "per-dispatch start/stop events (hipExtLaunchKernelGGL) inside the timed region"}
 
 
 def main():
     args = parse()
     import torch
-    import bevy_amd as B
-    from bevy_amd import api, sharding, workloads as W
+    from bevy_amd import api
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -74,111 +222,17 @@ def main():
 
     stream = torch.cuda.Stream()
     ctx = api.Context(local_rank, stream.cuda_stream)
-    n_views = args.views
     total_frames = args.steps + args.warmup
-    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
-
-    def frusta_of_frame(f):
-        return np.concatenate([api.compute_frustum(cfv, W.many_cubes_camera(f, yaw=v * np.pi / 2), W.CAMERA_FAR)
-                               for v in range(n_views)])
-
-    dominant = None
-    units_per_rank = 0
-    bytes_per_unit = 0.0
-    step = None
-    config = {}
-    scene = None
-    full = None
-
-    if args.workload == "flat":
-        n_local = args.entities
-        n_global = n_local * world
-        lo = rank * n_local
-        radius = 500.0 * (n_global / 1_000_000.0) ** (1.0 / 3.0)
-        scene = W.many_cubes(n_global, radius=radius, start=lo, count=n_local)
-        ctx.resize(n_local)
-        ctx.upload_transforms(scene["translation"], scene["rotation"], scene["scale"])
-        ctx.upload_bounds(scene["aabb_center"], scene["aabb_half"], scene["flags"], scene["layers"])
-        frames = [frusta_of_frame(f) for f in range(total_frames)]
-        if world > 1:
-            words = sharding.gathered_words(n_global, world, n_views)
-            full = torch.zeros(words, dtype=torch.int64, device="cuda")
-            wpv, woff = sharding.block_offset_words(n_global, world, n_views, rank)
-            ctx.bind_visibility_output(full.data_ptr(), wpv, woff)
-        units_per_rank = n_local
-        bytes_per_unit = flat_bytes_per_entity(n_views) if not args.unfused else flat_bytes_per_entity(n_views) + 48.0
-        dominant = "k_cull" if args.unfused else "k_flat_propagate_cull"
-
-        def step(f):
-            if args.unfused:
-                ctx.propagate(B.PROPAGATE_ALL_DIRTY)
-                ctx.cull(frames[f], flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME)
-            else:
-                ctx.propagate_and_cull(frames[f], flags=B.CULL_END_FRAME)
-            if world > 1:
-                sharding.all_gather_visibility(full, n_global, world, n_views, rank)
-        config = {"workload": f"many_cubes-shaped flat scene, {n_local} entities/GPU ({n_global} total), {n_views} camera "
-                              f"frustum(s), all Transforms dirty: {'unfused' if args.unfused else 'fused'} propagate + frustum cull "
-                              "+ VisibleEntities compaction + mark-newly-hidden"
-                              + (f" + RCCL all-gather of the visibility bitmask over {world} GPUs" if world > 1 else ""),
-                  "entities_per_gpu": n_local, "views": n_views, "parallelism": f"row-range shard x{world}"}
-    elif args.workload == "tree":
-        tr = W.gen_tree(12, 4, args.entities)
-        ctx.resize(tr["n"])
-        ctx.upload_transforms(tr["translation"], tr["rotation"], tr["scale"])
-        ctx.upload_hierarchy(tr["parent"], tr["level_offsets"])
-        units_per_rank = tr["n"]
-        bytes_per_unit = 40.0 + 4.0 + 48.0 + 48.0 + 1.0  # T, parent_idx, old G (set_if_neq), G, changed byte
-        dominant = "k_propagate_tiles"
-        # the root moves every frame (a 40-byte upload), so set_if_neq really rewrites every descendant
-        root_t = [tr["translation"][:3].copy(), tr["translation"][:3] + np.float32(1.0)]
-
-        def step(f):
-            ctx.upload_transforms(root_t[f & 1], tr["rotation"][:4], tr["scale"][:3], first_row=0)
-            ctx.propagate(B.PROPAGATE_ALL_DIRTY)
-        config = {"workload": f"gen_tree(12,4) truncated to {tr['n']} nodes ({len(tr['level_offsets']) - 1} levels), "
-                              "all dirty, LDS subtree-tile propagation (replicas per GPU)", "nodes": tr["n"]}
-    else:
-        lights = W.many_lights(args.lights, 50.0, 0.3)
-        cam = W.many_cubes_camera(0)
-        fr = api.compute_frustum(cfv, cam, W.CAMERA_FAR)
-        view, keep = api.cluster_view_build(cam, cfv, fr, 1920, 1080, (16, 9, 24), 5.0, 1000.0)
-        ctx.cluster_upload_objects(lights)
-        ctx.cluster_upload_view(view)
-        units_per_rank = args.lights
-        bytes_per_unit = 17.0
-        dominant = "k_cluster_count"
-
-        def step(f):
-            ctx.cluster_assign_resident()
-        config = {"workload": f"many_lights-shaped: {args.lights} point lights (range 0.3, shell R=50), 16x9x24 clusters, "
-                              "assign_objects_to_clusters (replicas per GPU)", "lights": args.lights}
-
-    def sync_all():
-        ctx.synchronize()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-
+    full_holder = []
     with torch.cuda.stream(stream):
-        for f in range(args.warmup):
-            step(f)
-        sync_all()
-        ctx.profile_filter(None if args.profile_all else [dominant])
-        ctx.profile_enable(True)
-        sync_all()
-        t0 = time.perf_counter()
-        for f in range(args.warmup, total_frames):
-            step(f)
-        ctx.synchronize()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t1 = time.perf_counter()
-        prof = ctx.profile_read()
-        ctx.profile_enable(False)
-
-    elapsed = t1 - t0
+        if args.workload == "flat":
+            wl = build_flat(ctx, args, rank, world, total_frames, full_holder)
+        elif args.workload == "tree":
+            wl = build_tree(ctx, args)
+        else:
+            wl = build_lights(ctx, args)
+        barrier = (lambda: dist.barrier()) if world > 1 else None
+        elapsed, prof = measure(ctx, wl, args.steps, args.warmup, args.profile_all, barrier)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -186,53 +240,41 @@ def main():
 
     out = None
     if rank == 0:
-        units_total = units_per_rank * world
-        value = units_total * args.steps / elapsed
-        dk = prof.get(dominant)
-        roofline = None
-        if dk:
-            avg_s = dk["avg_us"] * 1e-6
-            launches_per_step = dk["launches"] / args.steps
-            alg_bytes = bytes_per_unit * units_per_rank / launches_per_step
-            achieved = alg_bytes / avg_s / 1e9
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-            if os.path.exists(pmc):
-                try:
-                    traffic = json.load(open(pmc)).get(dominant, {}).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                        "avg_kernel_us": round(dk["avg_us"], 3), "launches": dk["launches"],
-                        "algorithmic_bytes_per_launch": int(alg_bytes)}
-        cpu_baseline = None
+        value = wl.units * world * args.steps / elapsed
+        out = {"metric": wl.metric, "value": round(value, 1), "unit": wl.unit, "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 5), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": wl.config,
+               "roofline": roofline_of(wl, prof, args.steps), "cpu_baseline": None,
+               "kernels": {k: round(v["avg_us"], 3) for k, v in prof.items()}}
         if not args.no_cpu_baseline and args.workload == "flat":
             import oracle_lib as O  # the oracle doubles as the reported CPU baseline ("port"), never as the product
+            from bevy_amd import workloads as W
             cores = os.cpu_count() or 1
-            n_cpu = min(units_per_rank, 1_000_000)
-            sc = scene if n_cpu == units_per_rank else W.many_cubes(n_cpu)
-            fr0 = frusta_of_frame(args.warmup)
-            secs, _, _, _ = O.bench_flat_frame(sc["translation"], sc["rotation"], sc["scale"], sc["aabb_center"],
-                                               sc["aabb_half"], sc["flags"], sc["layers"], fr0, cores, 1)
+            n_cpu = min(wl.units, 1_000_000)
+            sc = wl.scene if n_cpu == wl.units else W.many_cubes(n_cpu)
+            fr0 = wl.frusta_of_frame(args.warmup)
+            a = (sc["translation"], sc["rotation"], sc["scale"], sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"], fr0)
+            secs, _, _, _ = O.bench_flat_frame(*a, cores, 1)
             iters = int(max(1, min(400, args.cpu_seconds / max(secs, 1e-4))))
-            secs, _, _, _ = O.bench_flat_frame(sc["translation"], sc["rotation"], sc["scale"], sc["aabb_center"],
-                                               sc["aabb_half"], sc["flags"], sc["layers"], fr0, cores, iters)
-            cpu_baseline = {"value": round(n_cpu * iters / secs, 1), "unit": "entities/s", "cores": cores, "kind": "port",
-                            "sample": f"{iters} frames of {n_cpu} entities x {n_views} view(s): oracle C port of sync_simple_transforms + "
-                                      "reset + check_visibility + mark_newly_hidden, one ceil(n/threads) batch per thread "
-                                      f"(Bevy's par_iter batching), {secs:.2f}s"}
-        out = {"metric": "entities/sec through propagate+cull", "value": round(value, 1), "unit": "entities/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 5),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": config, "roofline": roofline, "cpu_baseline": cpu_baseline,
-               "kernels": {k: round(v["avg_us"], 3) for k, v in prof.items()}}
-        if args.workload == "tree":
-            out["metric"] = "nodes/sec through hierarchy propagate"
-            out["unit"] = "nodes/s"
-        if args.workload == "lights":
-            out["metric"] = "lights/sec through assign_objects_to_clusters"
-            out["unit"] = "lights/s"
+            secs, _, _, _ = O.bench_flat_frame(*a, cores, iters)
+            out["cpu_baseline"] = {
+                "value": round(n_cpu * iters / secs, 1), "unit": "entities/s", "cores": cores, "kind": "port",
+                "sample": f"{iters} frames of {n_cpu} entities x {wl.n_views} view(s): oracle C port of sync_simple_transforms + "
+                          "reset + check_visibility + mark_newly_hidden, one ceil(n/threads) batch per thread "
+                          f"(Bevy's par_iter batching), {secs:.2f}s"}
+        if world == 1 and args.workload == "flat" and not args.no_other_workloads:
+            # configs[4] and configs[2], measured briefly on fresh contexts so the one line carries every stage
+            others = {}
+            for name, builder in (("tree", build_tree), ("lights", build_lights)):
+                c2 = api.Context(local_rank, stream.cuda_stream)
+                with torch.cuda.stream(stream):
+                    w2 = builder(c2, args)
+                    e2, p2 = measure(c2, w2, 100, 10, False)
+                others[name] = {"metric": w2.metric, "value": round(w2.units * 100 / e2, 1), "unit": w2.unit,
+                                "ms_per_step": round(1e3 * e2 / 100, 5), "config": w2.config,
+                                "roofline": roofline_of(w2, p2, 100)}
+                c2.close()
+            out["other_workloads"] = others
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:

@@ -98,7 +98,8 @@ struct mi_ctx {
 
     // ---- clustering ----
     DevBuf cl_pos, cl_type, cl_layers, cl_dir, cl_sincos, cl_planes, cl_spheres;
-    DevBuf cl_block_counts, cl_block_bases, cl_offsets, cl_counts, cl_indices, cl_scalars;
+    DevBuf cl_block_counts, cl_pair_cb, cl_pair_mask, cl_acc, cl_offsets, cl_indices, cl_scalars;
+    uint32_t cl_parity = 0, cl_acc_clusters = 0, cl_acc_blocks = 0;  // cl_acc = 2 x [counts 6C | totals C | farthest_z + pad]
     uint32_t cl_n = 0;
     bool cl_have_type = false, cl_have_layers = false, cl_have_spot = false, cl_any_spot = false;
     ClusterViewDev cl_view{};
@@ -227,18 +228,28 @@ void prof_close(mi_ctx* ctx) {
         ctx->span_open = false;
     }
 }
+// Callback form used by the multi-kernel launch wrappers: arms dispatch-timestamp timing for the NEXT launch
+// (kernel id K_NUM_KERNELS = disarm).
+thread_local LaunchTimer g_cb_timer;
 void prof_mark(void* vctx, uint32_t kernel) {
     mi_ctx* ctx = (mi_ctx*)vctx;
     if (!ctx->profiling) return;
     prof_close(ctx);
+    if (g_launch_timer == &g_cb_timer) {  // previous arm was never consumed
+        g_launch_timer = nullptr;
+        hipEventDestroy(ctx->spans.back().a);
+        hipEventDestroy(ctx->spans.back().b);
+        ctx->spans.pop_back();
+    }
     if (kernel >= K_NUM_KERNELS || !((ctx->prof_mask >> kernel) & 1ull)) return;
     ProfSpan sp;
     sp.kernel = kernel;
     hipEventCreate(&sp.a);
     hipEventCreate(&sp.b);
-    hipEventRecord(sp.a, ctx->stream);
     ctx->spans.push_back(sp);
-    ctx->span_open = true;
+    g_cb_timer.start = sp.a;
+    g_cb_timer.stop = sp.b;
+    g_launch_timer = &g_cb_timer;
 }
 // Times exactly one launch (the next MI_LAUNCH on this thread) with its dispatch timestamps.
 struct ProfScope {
@@ -490,7 +501,11 @@ int32_t mi_ctx_create(int32_t device, void* hip_stream, mi_ctx** out_ctx) {
     }
     hipEventCreate(&ctx->timer_a);
     hipEventCreate(&ctx->timer_b);
-    set_cluster_lds_limit();
+    if ((e = set_cluster_lds_limit()) != hipSuccess) {
+        std::string msg = hipGetErrorString(e);
+        mi_ctx_destroy(ctx);
+        return fail(nullptr, MI_ERR_DEVICE, "raising the LDS limit of the clustering kernel failed: %s", msg.c_str());
+    }
     ctx->level_offsets = {0, 0};
     *out_ctx = ctx;
     return MI_OK;
@@ -508,8 +523,8 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->order, &ctx->in_range, &ctx->parent_idx, &ctx->node_flags, &ctx->tiles, &ctx->views, &ctx->bitmask,
                       &ctx->block_counts, &ctx->seg_totals, &ctx->seg_bases, &ctx->out_rows, &ctx->out_keys, &ctx->wave_cnt, &ctx->seg_mask, &ctx->cl_pos,
                       &ctx->cl_type, &ctx->cl_layers, &ctx->cl_dir, &ctx->cl_sincos, &ctx->cl_planes, &ctx->cl_spheres,
-                      &ctx->cl_block_counts, &ctx->cl_block_bases, &ctx->cl_offsets, &ctx->cl_counts, &ctx->cl_indices,
-                      &ctx->cl_scalars};
+                      &ctx->cl_block_counts, &ctx->cl_pair_cb, &ctx->cl_pair_mask, &ctx->cl_acc,
+                      &ctx->cl_offsets, &ctx->cl_indices, &ctx->cl_scalars};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (ctx->stage) hipHostFree(ctx->stage);
@@ -1114,24 +1129,43 @@ int32_t mi_cluster_assign_resident(mi_ctx* ctx, uint64_t* out_total) {
     ClusterWork w{};
     w.n_blocks = std::max(1u, (o.n + CLUSTER_BLOCK - 1) / CLUSTER_BLOCK);
     int32_t rc;
-    if ((rc = ensure(ctx, ctx->cl_block_counts, (size_t)w.n_blocks * C * 2))) return rc;
-    if ((rc = ensure(ctx, ctx->cl_block_bases, (size_t)w.n_blocks * C * 4))) return rc;
+    const size_t off_totals = (6 * (size_t)C + 3) & ~(size_t)3, off_misc = off_totals + (((size_t)C + 3) & ~(size_t)3);
+    const size_t acc_words = off_misc + 4;  // per parity; 16-byte aligned sections: counts | totals | misc
+    w.row_stride = (w.n_blocks + 7u) & ~7u;
+    const size_t mat_bytes = (size_t)C * w.row_stride * 2;  // per parity
+    if ((rc = ensure(ctx, ctx->cl_pair_cb, (size_t)w.n_blocks * C * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->cl_pair_mask, (size_t)w.n_blocks * C * 32))) return rc;
     if ((rc = ensure(ctx, ctx->cl_offsets, ((size_t)C + 1) * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->cl_counts, (size_t)C * 6 * 4))) return rc;
     if ((rc = ensure(ctx, ctx->cl_scalars, 16))) return rc;
+    if (!ctx->cl_acc.p || ctx->cl_acc_clusters != C || ctx->cl_acc_blocks != w.n_blocks) {
+        // (re)shaped accumulators / count matrix start zeroed in both parities; afterwards the fill kernel keeps
+        // the idle parity zeroed
+        if ((rc = ensure(ctx, ctx->cl_acc, 2 * acc_words * 4))) return rc;
+        if ((rc = ensure(ctx, ctx->cl_block_counts, 2 * mat_bytes))) return rc;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->cl_acc.p, 0, 2 * acc_words * 4, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->cl_block_counts.p, 0, 2 * mat_bytes, ctx->stream));
+        ctx->cl_acc_clusters = C;
+        ctx->cl_acc_blocks = w.n_blocks;
+    }
     if (!ctx->cl_indices.p && (rc = ensure(ctx, ctx->cl_indices, (size_t)1 << 20))) return rc;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        w.block_counts = (uint16_t*)ctx->cl_block_counts.p;
-        w.block_bases = (uint32_t*)ctx->cl_block_bases.p;
+        ctx->cl_parity ^= 1u;
+        const uint32_t par = ctx->cl_parity;
+        uint32_t* acc = (uint32_t*)ctx->cl_acc.p + par * acc_words;
+        w.block_counts = (uint16_t*)((char*)ctx->cl_block_counts.p + par * mat_bytes);
+        w.block_counts_next = (uint16_t*)((char*)ctx->cl_block_counts.p + (par ^ 1u) * mat_bytes);
+        w.counts = acc;
+        w.totals = acc + off_totals;
+        w.farthest_z = (float*)(acc + off_misc);
+        w.pair_total = acc + off_misc + 1;
+        w.acc_words = (uint32_t)acc_words;
+        w.acc_next = (uint32_t*)ctx->cl_acc.p + (par ^ 1u) * acc_words;
+        w.pair_cb = (uint32_t*)ctx->cl_pair_cb.p;
+        w.pair_mask = (uint32_t*)ctx->cl_pair_mask.p;
         w.offsets = (uint32_t*)ctx->cl_offsets.p;
-        w.counts = (uint32_t*)ctx->cl_counts.p;
         w.indices = (uint32_t*)ctx->cl_indices.p;
         w.capacity = ctx->cl_indices.bytes / 4;
         w.total = (uint64_t*)ctx->cl_scalars.p;
-        w.farthest_z = (float*)((char*)ctx->cl_scalars.p + 8);
-        HIP_TRY(ctx, hipMemsetAsync(ctx->cl_offsets.p, 0, ((size_t)C + 1) * 4, ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->cl_counts.p, 0, (size_t)C * 6 * 4, ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->cl_scalars.p, 0, 16, ctx->stream));
         HIP_TRY(ctx, launch_cluster_assign(ctx->cl_view, o, w, ctx->stream, prof_mark, ctx));
         if (!out_total && attempt == 0) break;  // fire and forget: capacity is re-checked at download
         uint64_t total = 0;
@@ -1160,9 +1194,11 @@ int32_t mi_cluster_download(mi_ctx* ctx, uint32_t* out_offsets, uint32_t* out_in
         total = t2;
     }
     if (out_total) *out_total = total;
-    if (out_farthest_z && (rc = download(ctx, out_farthest_z, (char*)ctx->cl_scalars.p + 8, 4))) return rc;
+    const size_t off_totals = (6 * (size_t)C + 3) & ~(size_t)3, off_misc = off_totals + (((size_t)C + 3) & ~(size_t)3);
+    const uint32_t* acc = (const uint32_t*)ctx->cl_acc.p + ctx->cl_parity * (off_misc + 4);
+    if (out_farthest_z && (rc = download(ctx, out_farthest_z, acc + off_misc, 4))) return rc;
     if (out_offsets && (rc = download(ctx, out_offsets, ctx->cl_offsets.p, ((size_t)C + 1) * 4))) return rc;
-    if (out_counts && (rc = download(ctx, out_counts, ctx->cl_counts.p, (size_t)C * 6 * 4))) return rc;
+    if (out_counts && (rc = download(ctx, out_counts, acc, (size_t)C * 6 * 4))) return rc;
     if (out_indices) {
         if (total > capacity) return fail(ctx, MI_ERR_CAPACITY, "cluster index list has %llu entries, capacity %llu", (unsigned long long)total, (unsigned long long)capacity);
         if ((rc = download(ctx, out_indices, ctx->cl_indices.p, (size_t)total * 4))) return rc;
@@ -1260,8 +1296,8 @@ int32_t mi_profile_read(mi_ctx* ctx, uint32_t* inout_n, uint64_t* launches, doub
 const char* mi_profile_kernel_name(uint32_t k) {
     static const char* names[K_NUM_KERNELS] = {"k_flat_propagate_cull", "k_level0_propagate", "k_cull", "k_vis_begin",
                                                "k_vis_end", "k_compact_count", "k_compact_scan", "k_compact_scatter",
-                                               "k_compact_fast", "k_mark_dirty", "k_propagate_tiles", "k_cluster_count", "k_cluster_scan",
-                                               "k_cluster_fill", "k_clear_u32"};
+                                               "k_compact_fast", "k_mark_dirty", "k_propagate_tiles", "k_cluster_walk", "k_cluster_fill",
+                                               "k_clear_u32"};
     return k < K_NUM_KERNELS ? names[k] : nullptr;
 }
 

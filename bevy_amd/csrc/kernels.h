@@ -102,8 +102,7 @@ enum KernelId : uint32_t {
     K_COMPACT_FAST,
     K_MARK_DIRTY,
     K_PROPAGATE_TILES,
-    K_CLUSTER_COUNT,
-    K_CLUSTER_SCAN,
+    K_CLUSTER_WALK,
     K_CLUSTER_FILL,
     K_CLEAR,
     K_NUM_KERNELS
@@ -215,14 +214,24 @@ struct ClusterObjects {
 constexpr uint32_t CLUSTER_BLOCK = 256;  // objects per workgroup (= bits per cluster row in LDS)
 struct ClusterWork {
     uint32_t n_blocks;
-    uint16_t* block_counts;  // [n_blocks * n_clusters] objects of block b in cluster c
-    uint32_t* block_bases;   // [n_blocks * n_clusters] exclusive base inside the cluster's segment
-    uint32_t* offsets;       // [n_clusters + 1]
-    uint32_t* counts;        // [6 * n_clusters]
-    uint32_t* indices;       // [capacity]
+    uint32_t row_stride;          // entries per cluster row of block_counts: n_blocks rounded up to 8
+    // Everything the walk kernel accumulates into is double-buffered by frame parity: the fill kernel of frame f
+    // zeroes the buffers frame f+1 will use, so no memset sits in the stream.
+    uint16_t* block_counts;       // [n_clusters * n_blocks] objects of block b in cluster c (cluster-major; only
+                                  //  non-empty entries are written)
+    uint16_t* block_counts_next;
+    uint32_t* counts;             // accumulator block, 16-byte aligned sections: [6 * n_clusters] ClusterableObjectCounts
+    uint32_t* totals;             //   [n_clusters]
+    float* farthest_z;            //   (uint bits for atomicMax of non-negative floats)
+    uint32_t* pair_total;         //   number of (cluster, block) pairs
+    uint32_t* acc_next;           // the other parity's accumulator block
+    uint32_t acc_words;           // its size in 32-bit words
+    uint32_t* pair_cb;            // [n_blocks * n_clusters] (block << 12) | cluster of every non-empty row
+    uint32_t* pair_mask;          // [n_blocks * n_clusters * 8] its 256-bit object mask
+    uint32_t* offsets;            // [n_clusters + 1] out
+    uint32_t* indices;            // [capacity] out
     uint64_t capacity;
-    uint64_t* total;         // [1]
-    float* farthest_z;       // [1] (as uint bits for atomicMax of non-negative floats)
+    uint64_t* total;              // [1] out
 };
 hipError_t launch_cluster_assign(const ClusterViewDev& view, const ClusterObjects& objs, const ClusterWork& w,
                                  hipStream_t stream, void (*mark)(void*, uint32_t), void* mark_ctx);

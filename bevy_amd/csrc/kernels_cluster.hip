@@ -2,17 +2,21 @@
 //   crates/bevy_light/src/cluster/assign.rs:487-811 (per-object loop) and its helpers :903-1134.
 //
 // The reference is one serial triple loop pushing Entities into per-cluster Vecs; the order of
-// every cluster's list is the object iteration order.  Here:
-//   count : one object per lane walks the same z -> y -> x-range refinement and sets ITS bit in a
-//           per-cluster 256-bit row held in LDS (clusters x 32 B, 108 KB for 16x9x24); after a
-//           barrier the workgroup popcounts every row -> per-(cluster, block) counts, per-type counts.
-//   scan  : one wave per cluster prefix-sums its row of block counts (cluster-major matrix), then one
-//           workgroup prefix-sums the cluster totals -> CSR offsets.
-//   fill  : the walk again, bits again, then every cluster row is expanded in bit order: the rank of
-//           an object inside its block is the popcount of the lower bits, so each cluster's segment
-//           is written in ascending object order == the reference's push order, with no sort and no
-//           order-dependent atomics.
-// HBM traffic is tiny (17 B/object + 4 B/entry); the path is latency/launch bound, see DESIGN.md.
+// every cluster's list is the object iteration order.  Here (two launches, no memsets, no scan kernel):
+//   walk : one object per lane walks the same z -> y -> x-range refinement ONCE -- the view's cluster planes
+//          are staged in LDS, so the data-dependent plane reads of the refinement loops cost an LDS
+//          round trip, not an L2 one -- and sets ITS bit in a per-cluster 256-bit row held in LDS
+//          (clusters x 32 B, 108 KB for 16x9x24).  After a barrier the workgroup popcounts every row:
+//          per-(cluster, block) counts (cluster-major u16 matrix), cluster totals and per-type counts
+//          (atomics into the frame-parity buffer), and the non-empty rows themselves as
+//          (cluster, 256-bit mask) pairs in the block's scratch list.
+//   fill : every workgroup prefix-sums the 4096-max cluster totals in LDS (-> CSR offsets), then one wave
+//          per pair adds the counts of the lower-numbered blocks of that cluster (a contiguous u16 row)
+//          and expands the mask in bit order: the rank of an object inside its block is the popcount of
+//          the lower bits, so each cluster's segment is written in ascending object order == the
+//          reference's push order, with no sort and no order-dependent atomics.  It also zeroes the
+//          other parity's atomic buffers for the next frame.
+// HBM traffic is tiny (17 B/object + 4 B/entry); the stage is latency-bound, see DESIGN.md.
 #include "glam_math.h"
 #include "kernels.h"
 
@@ -123,21 +127,29 @@ __device__ __forceinline__ float get_distance_x(V4 plane, V3 p, bool ortho) {
 
 // The body of `for clusterable_object in &clusterable_objects` (assign.rs:487-804) for one object.
 // emit(cluster_index) is called for every cluster the reference would push this object into.
+// The two early-outs at the top of the per-object loop (assign.rs:489 RenderLayers, :496 frustum vs light sphere).
+__device__ __forceinline__ bool object_in_view(const ClusterViewDev& v, const ClusterObjects& o, uint32_t obj) {
+    const float4 pr = reinterpret_cast<const float4*>(o.pos_range)[obj];
+    const uint32_t layers = o.layer_mask ? o.layer_mask[obj] : 1u;
+    if (!(v.view_layer_mask & layers)) return false;  // :489
+    V4 fr[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) fr[i] = V4{v.frustum[4 * i], v.frustum[4 * i + 1], v.frustum[4 * i + 2], v.frustum[4 * i + 3]};
+    return frustum_intersects_sphere(fr, V3{pr.x, pr.y, pr.z}, pr.w, true);  // :496
+}
+
+// The rest of the body for an object that passed object_in_view.
+// xp / yp / zp: the view's x, y, z cluster planes (LDS copies in the kernels below).
 template <typename Emit>
 __device__ __forceinline__ void assign_one_object(const ClusterViewDev& v, const ClusterObjects& o, uint32_t obj,
+                                                  const float* xp, const float* yp, const float* zp,
                                                   float* far_z_out, bool* counted, Emit emit) {
     *counted = false;
     const float4 pr = reinterpret_cast<const float4*>(o.pos_range)[obj];
     const V3 center = V3{pr.x, pr.y, pr.z};
     const float range = pr.w;
     const uint32_t type = o.obj_type ? o.obj_type[obj] : 0u;
-    const uint32_t layers = o.layer_mask ? o.layer_mask[obj] : 1u;
     const bool ortho = v.is_orthographic != 0;
-    if (!(v.view_layer_mask & layers)) return;  // :489
-    V4 fr[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) fr[i] = V4{v.frustum[4 * i], v.frustum[4 * i + 1], v.frustum[4 * i + 2], v.frustum[4 * i + 3]};
-    if (!frustum_intersects_sphere(fr, center, range, true)) return;  // :496
 
     const M4 view_from_world = load_m4(v.view_from_world);
     const M4 clip_from_view = load_m4(v.clip_from_view);
@@ -197,26 +209,26 @@ __device__ __forceinline__ void assign_one_object(const ClusterViewDev& v, const
     for (uint32_t z = minc[2]; z <= maxc[2]; ++z) {
         Sphere z_object = vs;
         if (!z_center_some || z != z_center) {
-            const V4 z_plane = (z_center_some && z < z_center) ? ldp(v.z_planes, z + 1u) : ldp(v.z_planes, z);
+            const V4 z_plane = (z_center_some && z < z_center) ? ldp(zp, z + 1u) : ldp(zp, z);
             if (!project_to_plane_z(z_object, z_plane)) continue;
         }
         for (uint32_t y = minc[1]; y <= maxc[1]; ++y) {
             Sphere y_object = z_object;
             if (!y_center_some || y != y_center) {
-                const V4 y_plane = (y_center_some && y < y_center) ? ldp(v.y_planes, y + 1u) : ldp(v.y_planes, y);
+                const V4 y_plane = (y_center_some && y < y_center) ? ldp(yp, y + 1u) : ldp(yp, y);
                 if (!project_to_plane_y(y_object, y_plane, ortho)) continue;
             }
             uint32_t min_x = minc[0];
             for (;;) {
                 if (min_x >= maxc[0] ||
-                    -get_distance_x(ldp(v.x_planes, min_x + 1u), y_object.center, ortho) + y_object.radius > 0.0f)
+                    -get_distance_x(ldp(xp, min_x + 1u), y_object.center, ortho) + y_object.radius > 0.0f)
                     break;
                 min_x += 1u;
             }
             uint32_t max_x = maxc[0];
             for (;;) {
                 if (max_x <= min_x ||
-                    get_distance_x(ldp(v.x_planes, max_x), y_object.center, ortho) + y_object.radius > 0.0f)
+                    get_distance_x(ldp(xp, max_x), y_object.center, ortho) + y_object.radius > 0.0f)
                     break;
                 max_x -= 1u;
             }
@@ -244,126 +256,191 @@ __device__ __forceinline__ void assign_one_object(const ClusterViewDev& v, const
     }
 }
 
-// Dynamic LDS: n_clusters x 8 words (one 256-bit row per cluster) + 6 x 8 words of type masks.
+// Dynamic LDS of k_cluster_walk: n_clusters x 8 words (one 256-bit row per cluster) + 6 x 8 words of type
+// masks + the view's planes + the pair counter.
 extern __shared__ __attribute__((aligned(16))) uint32_t cluster_lds[];
+constexpr size_t CLUSTER_MAX_DYN_LDS = 160u * 1024u - 2048u;  // 160 KB per workgroup minus the kernel's static LDS
 
-__device__ __forceinline__ void walk_block_into_lds(const ClusterViewDev& v, const ClusterObjects& o, uint32_t* rows,
-                                                    uint32_t* type_rows, float* farthest_z_bits_out) {
+// PLANES_IN_LDS = false only for degenerate grids whose plane tables do not fit next to the bit rows.
+template <bool PLANES_IN_LDS>
+__global__ void __launch_bounds__(CLUSTER_BLOCK) k_cluster_walk(ClusterViewDev v, ClusterObjects o, ClusterWork w) {
     const uint32_t C = v.n_clusters;
-    for (uint32_t i = threadIdx.x; i < C * 8u + 48u; i += CLUSTER_BLOCK) cluster_lds[i] = 0u;
-    __syncthreads();
+    uint32_t* rows = cluster_lds;
+    uint32_t* type_rows = rows + C * 8u;
+    float* planes = reinterpret_cast<float*>(type_rows + 48u);
+    const uint32_t nx = v.dims[0] + 1u, ny = v.dims[1] + 1u, nz = v.dims[2] + 1u;
+    const float* xp = PLANES_IN_LDS ? planes : v.x_planes;
+    const float* yp = PLANES_IN_LDS ? planes + 4u * nx : v.y_planes;
+    const float* zp = PLANES_IN_LDS ? planes + 4u * (nx + ny) : v.z_planes;
+
+    // Most blocks of a big light set see nothing of it in this view: test first, and leave before touching LDS.
     const uint32_t obj = blockIdx.x * CLUSTER_BLOCK + threadIdx.x;
-    if (obj < o.n) {
+    const bool in_view = obj < o.n && object_in_view(v, o, obj);
+    if (!__syncthreads_or(in_view ? 1 : 0)) return;
+
+    {
+        uint4* z4 = reinterpret_cast<uint4*>(cluster_lds);
+        for (uint32_t i = threadIdx.x; i < C * 2u + 12u; i += CLUSTER_BLOCK) z4[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    // the three plane tables are contiguous in device memory (x | y | z)
+    if (PLANES_IN_LDS)
+        for (uint32_t i = threadIdx.x; i < 4u * (nx + ny + nz); i += CLUSTER_BLOCK) planes[i] = v.x_planes[i];
+    __syncthreads();
+
+    if (in_view) {
         const uint32_t word = threadIdx.x >> 5, bit = 1u << (threadIdx.x & 31u);
         float far_z = 0.0f;
         bool counted = false;
-        assign_one_object(v, o, obj, &far_z, &counted, [&](uint32_t cluster) { atomicOr(&rows[cluster * 8u + word], bit); });
+        assign_one_object(v, o, obj, xp, yp, zp, &far_z, &counted,
+                          [&](uint32_t cluster) { atomicOr(&rows[cluster * 8u + word], bit); });
         const uint32_t type = o.obj_type ? o.obj_type[obj] : 0u;
         atomicOr(&type_rows[(type < 6u ? type : 5u) * 8u + word], bit);
         // farthest_z = farthest_z.max(this_object_far_z), starting from 0.0 (assign.rs:421,561):
         // only positive values can raise it, and positive floats order like their bit patterns.
-        if (farthest_z_bits_out && counted && far_z > 0.0f)
-            atomicMax(reinterpret_cast<unsigned int*>(farthest_z_bits_out), __float_as_uint(far_z));
+        if (counted && far_z > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(w.farthest_z), __float_as_uint(far_z));
     }
     __syncthreads();
-}
 
-__global__ void __launch_bounds__(CLUSTER_BLOCK) k_cluster_count(ClusterViewDev v, ClusterObjects o, ClusterWork w) {
-    uint32_t* rows = cluster_lds;
-    uint32_t* type_rows = cluster_lds + v.n_clusters * 8u;
-    walk_block_into_lds(v, o, rows, type_rows, w.farthest_z);
-    const uint32_t C = v.n_clusters;
+    // Sweep: popcount every cluster row.  Non-empty rows become (cluster, block, 256-bit mask) pairs in ONE global
+    // list; the block reserves its slots with a single atomic (per-thread counts -> block scan -> base), so the
+    // fill kernel can spread pairs evenly over the chip no matter how unevenly the objects are distributed.
+    // Only non-empty entries of the (cluster, block) count matrix are written (it is kept zeroed otherwise).
+    __shared__ uint32_t scan_part[CLUSTER_BLOCK];
+    __shared__ uint32_t scan_base;
+    uint32_t mine = 0;
     for (uint32_t c = threadIdx.x; c < C; c += CLUSTER_BLOCK) {
+        const uint4 lo = reinterpret_cast<const uint4*>(rows)[c * 2u], hi = reinterpret_cast<const uint4*>(rows)[c * 2u + 1u];
+        mine += ((lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) != 0u) ? 1u : 0u;
+    }
+    scan_part[threadIdx.x] = mine;
+    __syncthreads();
+    for (uint32_t off = 1; off < CLUSTER_BLOCK; off <<= 1) {
+        const uint32_t add = threadIdx.x >= off ? scan_part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        scan_part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    if (threadIdx.x == CLUSTER_BLOCK - 1u) scan_base = scan_part[threadIdx.x] ? atomicAdd(w.pair_total, scan_part[threadIdx.x]) : 0u;
+    __syncthreads();
+    uint32_t slot = scan_base + scan_part[threadIdx.x] - mine;
+    for (uint32_t c = threadIdx.x; c < C; c += CLUSTER_BLOCK) {
+        const uint4 lo = reinterpret_cast<const uint4*>(rows)[c * 2u], hi = reinterpret_cast<const uint4*>(rows)[c * 2u + 1u];
+        const uint32_t m[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         uint32_t cnt = 0;
-        uint32_t tc[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) {
-            const uint32_t m = rows[c * 8u + k];
-            cnt += __popc(m);
-            if (m) {
-#pragma unroll
-                for (uint32_t t = 0; t < 6; ++t) tc[t] += __popc(m & type_rows[t * 8u + k]);
-            }
-        }
-        w.block_counts[(size_t)c * w.n_blocks + blockIdx.x] = (uint16_t)cnt;  // cluster-major
+        for (uint32_t k = 0; k < 8; ++k) cnt += __popc(m[k]);
         if (cnt) {
+            w.block_counts[(size_t)c * w.row_stride + blockIdx.x] = (uint16_t)cnt;  // cluster-major
+            atomicAdd(&w.totals[c], cnt);
 #pragma unroll
-            for (uint32_t t = 0; t < 6; ++t)
-                if (tc[t]) atomicAdd(&w.counts[6u * c + t], tc[t]);
-        }
-    }
-}
-
-// One wave per cluster: exclusive prefix sum over its row of per-block counts.
-__global__ void __launch_bounds__(256) k_cluster_scan_rows(ClusterWork w, uint32_t n_clusters, uint32_t* cluster_totals) {
-    const uint32_t c = blockIdx.x * 4u + (threadIdx.x >> 6);
-    const uint32_t lane = threadIdx.x & 63u;
-    if (c >= n_clusters) return;
-    const uint16_t* src = w.block_counts + (size_t)c * w.n_blocks;
-    uint32_t* dst = w.block_bases + (size_t)c * w.n_blocks;
-    uint32_t running = 0;
-    for (uint32_t b0 = 0; b0 < w.n_blocks; b0 += 64u) {
-        const uint32_t b = b0 + lane;
-        const uint32_t val = b < w.n_blocks ? (uint32_t)src[b] : 0u;
-        uint32_t incl = val;
+            for (uint32_t t = 0; t < 6; ++t) {
+                uint32_t tc = 0;
 #pragma unroll
-        for (uint32_t off = 1; off < 64u; off <<= 1) {
-            const uint32_t up = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += up;
-        }
-        if (b < w.n_blocks) dst[b] = running + incl - val;
-        running += __shfl(incl, 63, 64);
-    }
-    if (lane == 0) cluster_totals[c] = running;
-}
-
-// One workgroup: CSR offsets over clusters (n_clusters <= 4096) and the grand total.
-__global__ void __launch_bounds__(1024) k_cluster_scan_offsets(ClusterWork w, uint32_t n_clusters,
-                                                                const uint32_t* __restrict__ cluster_totals) {
-    __shared__ uint32_t part[1024];
-    __shared__ uint32_t carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (uint32_t c0 = 0; c0 < n_clusters; c0 += 1024u) {
-        const uint32_t c = c0 + threadIdx.x;
-        const uint32_t val = c < n_clusters ? cluster_totals[c] : 0u;
-        part[threadIdx.x] = val;
-        __syncthreads();
-        for (uint32_t off = 1; off < 1024u; off <<= 1) {
-            const uint32_t add = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
-            __syncthreads();
-            part[threadIdx.x] += add;
-            __syncthreads();
-        }
-        const uint32_t carry = carry_s;
-        if (c < n_clusters) w.offsets[c] = carry + part[threadIdx.x] - val;
-        __syncthreads();
-        if (threadIdx.x == 0) carry_s = carry + part[1023];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        w.offsets[n_clusters] = carry_s;
-        *w.total = (uint64_t)carry_s;
-    }
-}
-
-__global__ void __launch_bounds__(CLUSTER_BLOCK) k_cluster_fill(ClusterViewDev v, ClusterObjects o, ClusterWork w) {
-    uint32_t* rows = cluster_lds;
-    uint32_t* type_rows = cluster_lds + v.n_clusters * 8u;
-    walk_block_into_lds(v, o, rows, type_rows, nullptr);
-    const uint32_t C = v.n_clusters;
-    const uint32_t obj_base = blockIdx.x * CLUSTER_BLOCK;
-    for (uint32_t c = threadIdx.x; c < C; c += CLUSTER_BLOCK) {
-        uint64_t dst = (uint64_t)w.offsets[c] + w.block_bases[(size_t)c * w.n_blocks + blockIdx.x];
-#pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) {
-            uint32_t m = rows[c * 8u + k];
-            while (m) {
-                const uint32_t b = __ffs(m) - 1u;
-                m &= m - 1u;
-                if (dst < w.capacity) w.indices[dst] = obj_base + k * 32u + b;
-                ++dst;
+                for (uint32_t k = 0; k < 8; ++k) tc += __popc(m[k] & type_rows[t * 8u + k]);
+                if (tc) atomicAdd(&w.counts[6u * c + t], tc);
             }
+            w.pair_cb[slot] = (blockIdx.x << 12) | c;
+            reinterpret_cast<uint4*>(w.pair_mask)[(size_t)slot * 2u] = lo;
+            reinterpret_cast<uint4*>(w.pair_mask)[(size_t)slot * 2u + 1u] = hi;
+            ++slot;
+        }
+    }
+}
+
+constexpr uint32_t CLUSTER_FILL_BLOCKS = 2048;
+
+
+__global__ void __launch_bounds__(256) k_cluster_fill(ClusterWork w, uint32_t C, uint32_t n_objects) {
+    __shared__ uint32_t offs[4096];
+    __shared__ uint32_t part[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t n_pairs = n_objects ? *w.pair_total : 0u;
+
+    // zero the other parity's buffers for the next frame (this frame's buffers are only read from here on)
+    {
+        for (size_t i = blockIdx.x * 256u + tid; i < w.acc_words; i += (size_t)gridDim.x * 256u) w.acc_next[i] = 0u;
+        uint4* m4 = reinterpret_cast<uint4*>(w.block_counts_next);
+        const size_t n4 = (size_t)C * w.row_stride / 8u;
+        for (size_t i = blockIdx.x * 256u + tid; i < n4; i += (size_t)gridDim.x * 256u) m4[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    const uint32_t first_wave = blockIdx.x * 4u;
+    if (first_wave >= n_pairs && blockIdx.x != 0) return;
+
+    // CSR offsets = exclusive prefix of the cluster totals (C <= 4096: 16 per thread, wave scan, 4 wave totals)
+    uint32_t loc[16];
+    uint32_t sum = 0;
+    {
+        const uint4* t4 = reinterpret_cast<const uint4*>(w.totals) + tid * 4u;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t c0 = tid * 16u + q * 4u;
+            uint4 v4 = c0 + 3u < C ? t4[q] : make_uint4(c0 < C ? w.totals[c0] : 0u, c0 + 1u < C ? w.totals[c0 + 1u] : 0u,
+                                                       c0 + 2u < C ? w.totals[c0 + 2u] : 0u, 0u);
+            loc[q * 4u] = sum; sum += v4.x;
+            loc[q * 4u + 1u] = sum; sum += v4.y;
+            loc[q * 4u + 2u] = sum; sum += v4.z;
+            loc[q * 4u + 3u] = sum; sum += v4.w;
+        }
+    }
+    uint32_t incl = sum;
+#pragma unroll
+    for (uint32_t off = 1; off < 64u; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63u) part[wv] = incl;
+    __syncthreads();
+    uint32_t before = incl - sum;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) before += k < wv ? part[k] : 0u;
+    const uint32_t grand = part[0] + part[1] + part[2] + part[3];
+#pragma unroll
+    for (uint32_t k = 0; k < 16; ++k) offs[tid * 16u + k] = before + loc[k];
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (uint32_t c = tid; c < C; c += 256u) w.offsets[c] = offs[c];
+        if (tid == 0) {
+            w.offsets[C] = grand;
+            *w.total = (uint64_t)grand;
+        }
+    }
+
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (uint32_t p = first_wave + wv; p < n_pairs; p += gridDim.x * 4u) {
+        const uint32_t cb = w.pair_cb[p];
+        const uint32_t c = cb & 4095u, b = cb >> 12;
+        // entries of lower-numbered blocks in this cluster: a contiguous u16 row prefix
+        // (rows are padded to 8 entries: one 16-byte load covers 8 blocks, 512 blocks per wave pass)
+        const uint4* row4 = reinterpret_cast<const uint4*>(w.block_counts + (size_t)c * w.row_stride);
+        uint32_t lower = 0;
+        for (uint32_t i = lane; i * 8u < b; i += 64u) {
+            uint4 q = row4[i];
+            const uint32_t keep = b - i * 8u;  // entries of this vector that belong to blocks < b (>= 1)
+            if (keep < 8u) {
+                uint32_t wds[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) {
+                    if (2u * k >= keep) wds[k] = 0u;
+                    else if (2u * k + 1u >= keep) wds[k] &= 0xFFFFu;
+                }
+                q = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+            }
+            lower += (q.x & 0xFFFFu) + (q.x >> 16) + (q.y & 0xFFFFu) + (q.y >> 16) + (q.z & 0xFFFFu) + (q.z >> 16) +
+                     (q.w & 0xFFFFu) + (q.w >> 16);
+        }
+#pragma unroll
+        for (uint32_t off = 32u; off; off >>= 1) lower += __shfl_xor(lower, off, 64);
+        const uint32_t mw = lane < 8u ? w.pair_mask[(size_t)p * 8u + lane] : 0u;
+        uint64_t dst = (uint64_t)offs[c] + lower;
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const unsigned long long m64 = (unsigned long long)__shfl(mw, (int)(2u * j), 64) |
+                                           ((unsigned long long)__shfl(mw, (int)(2u * j + 1u), 64) << 32);
+            if ((m64 >> lane) & 1ull) {
+                const uint64_t d = dst + __popcll(m64 & lt);
+                if (d < w.capacity) w.indices[d] = b * CLUSTER_BLOCK + j * 64u + lane;
+            }
+            dst += __popcll(m64);
         }
     }
 }
@@ -371,32 +448,28 @@ __global__ void __launch_bounds__(CLUSTER_BLOCK) k_cluster_fill(ClusterViewDev v
 hipError_t launch_cluster_assign(const ClusterViewDev& view, const ClusterObjects& objs, const ClusterWork& w,
                                  hipStream_t stream, void (*mark)(void*, uint32_t), void* mctx) {
     const uint32_t C = view.n_clusters;
-    const size_t lds = ((size_t)C * 8u + 48u) * sizeof(uint32_t);
-    // w.counts, w.total, w.farthest_z and the scratch were cleared by the caller on this stream.
+    const uint32_t n_planes = view.dims[0] + view.dims[1] + view.dims[2] + 3u;
+    const size_t lds_rows = ((size_t)C * 8u + 48u) * sizeof(uint32_t);
+    const bool planes_in_lds = lds_rows + (size_t)n_planes * 16u <= CLUSTER_MAX_DYN_LDS;
+    const size_t lds = lds_rows + (planes_in_lds ? (size_t)n_planes * 16u : 0u);
+    // this frame's parity of the accumulators and of the count matrix was zeroed by the previous frame's fill kernel
     if (objs.n) {
-        if (mark) mark(mctx, K_CLUSTER_COUNT);
-        MI_LAUNCH(k_cluster_count, dim3(w.n_blocks), dim3(CLUSTER_BLOCK), lds, stream, view, objs, w);
+        if (mark) mark(mctx, K_CLUSTER_WALK);
+        if (planes_in_lds) MI_LAUNCH(k_cluster_walk<true>, dim3(w.n_blocks), dim3(CLUSTER_BLOCK), lds, stream, view, objs, w);
+        else MI_LAUNCH(k_cluster_walk<false>, dim3(w.n_blocks), dim3(CLUSTER_BLOCK), lds, stream, view, objs, w);
     }
-    if (mark) mark(mctx, K_CLUSTER_SCAN);
-    uint32_t* cluster_totals = w.offsets;  // reuse: totals are consumed into offsets in place
-    if (objs.n) {
-        MI_LAUNCH(k_cluster_scan_rows, dim3((C + 3u) / 4u), dim3(256), 0, stream, w, C, cluster_totals);
-    }
-    MI_LAUNCH(k_cluster_scan_offsets, dim3(1), dim3(1024), 0, stream, w, C, cluster_totals);
-    if (objs.n) {
-        if (mark) mark(mctx, K_CLUSTER_FILL);
-        MI_LAUNCH(k_cluster_fill, dim3(w.n_blocks), dim3(CLUSTER_BLOCK), lds, stream, view, objs, w);
-    }
+    if (mark) mark(mctx, K_CLUSTER_FILL);
+    MI_LAUNCH(k_cluster_fill, dim3(CLUSTER_FILL_BLOCKS), dim3(256), 0, stream, w, C, objs.n);
     if (mark) mark(mctx, K_NUM_KERNELS);
     return hipGetLastError();
 }
 
 hipError_t set_cluster_lds_limit() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_cluster_count),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_cluster_walk<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)CLUSTER_MAX_DYN_LDS);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_cluster_fill),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_cluster_walk<false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)CLUSTER_MAX_DYN_LDS);
 }
 
 }  // namespace mi

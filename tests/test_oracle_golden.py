@@ -40,39 +40,30 @@ def affine_t(t):
 
 # ---------------------------------------------------------------- primitives.rs:462-611
 
+import json
+import os
+
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "primitives_known_answers.json")) as _f:
+    GOLDEN = json.load(_f)  # literals of the reference's tests, see the file's _provenance
+
+
+def _golden_frustum(name):
+    return O.frustum_from_planes([tuple(p) for p in GOLDEN["frusta"][name]["planes"]])
+
+
 def big_frustum():
-    return O.frustum_from_planes([
-        (-0.9701, -0.2425, -0.0000, 7.7611), (-0.0000, 1.0000, -0.0000, 4.0000),
-        (-0.0000, -0.2425, -0.9701, 2.9104), (-0.0000, -1.0000, -0.0000, 4.0000),
-        (-0.0000, -0.2425, 0.9701, 2.9104), (0.9701, -0.2425, -0.0000, -1.9403)])
+    return _golden_frustum("big_frustum")
 
 
 def frustum():
-    return O.frustum_from_planes([
-        (-0.9701, -0.2425, -0.0000, 0.7276), (-0.0000, 1.0000, -0.0000, 1.0000),
-        (-0.0000, -0.2425, -0.9701, 0.7276), (-0.0000, -1.0000, -0.0000, 1.0000),
-        (-0.0000, -0.2425, 0.9701, 0.7276), (0.9701, -0.2425, -0.0000, 0.7276)])
+    return _golden_frustum("frustum")
 
 
 def long_frustum():
-    return O.frustum_from_planes([
-        (-0.9998, -0.0222, -0.0000, -1.9543), (-0.0000, 1.0000, -0.0000, 45.1249),
-        (-0.0000, -0.0168, -0.9999, 2.2718), (-0.0000, -1.0000, -0.0000, 45.1249),
-        (-0.0000, -0.0168, 0.9999, 2.2718), (0.9998, -0.0222, -0.0000, 7.9528)])
+    return _golden_frustum("long_frustum")
 
 
-SPHERE_CASES = [
-    ("big_outside", big_frustum, (0.9167, 0.0, 0.0), 0.75, False),
-    ("big_intersect", big_frustum, (7.9288, 0.0, 2.9728), 2.0, True),
-    ("surrounding", frustum, (0.0, 0.0, 0.0), 3.0, True),
-    ("contained", frustum, (0.0, 0.0, 0.0), 0.7, True),
-    ("intersects_plane", frustum, (0.0, 0.0, 0.9695), 0.7, True),
-    ("intersects_2_planes", frustum, (1.2037, 0.0, 0.9695), 0.7, True),
-    ("intersects_3_planes", frustum, (1.2037, -1.0988, 0.9695), 0.7, True),
-    ("dodges_1_plane", frustum, (-1.7020, 0.0, 0.0), 0.7, False),
-    ("long_outside", long_frustum, (-4.4889, 46.9021, 0.0), 0.75, False),
-    ("long_intersect", long_frustum, (-4.9957, 0.0, -0.7396), 4.4094, True),
-]
+SPHERE_CASES = [(n, globals()[f], tuple(c), r, e) for n, f, c, r, e in GOLDEN["intersects_sphere"]["cases"]]
 
 
 @pytest.mark.parametrize("name,fr,center,radius,expect", SPHERE_CASES, ids=[c[0] for c in SPHERE_CASES])

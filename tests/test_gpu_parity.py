@@ -379,15 +379,15 @@ def test_cull_after_tree_propagation(ctx_factory):
 # ---- clustering -----------------------------------------------------------------------------------
 
 def cluster_case(ctx, cam, pos_range, obj_type=None, layers=None, spot_dir=None, spot_sin_cos=None,
-                 req=(16, 9, 24), far_z=1000.0, ortho=False, view_mask=1):
+                 req=(16, 9, 24), far_z=1000.0, ortho=False, view_mask=1, screen=(1920, 1080)):
     if ortho:
         from test_abi_and_host import ortho_clip_from_view
         cfv = ortho_clip_from_view(-60.0, 60.0, -33.75, 33.75, 0.1, 1000.0)
     else:
         cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
     fr = api.compute_frustum(cfv, cam, W.CAMERA_FAR)
-    view, keep = api.cluster_view_build(cam, cfv, fr, 1920, 1080, req, 5.0, far_z, view_mask)
-    ov = O.cluster_view_setup(cam, cfv, fr, 1920, 1080, req, 5.0, far_z, view_mask)
+    view, keep = api.cluster_view_build(cam, cfv, fr, screen[0], screen[1], req, 5.0, far_z, view_mask)
+    ov = O.cluster_view_setup(cam, cfv, fr, screen[0], screen[1], req, 5.0, far_z, view_mask)
     off, idx, counts, far, total = ctx.cluster_assign(view, pos_range, obj_type, layers, spot_dir, spot_sin_cos)
     eoff, eidx, ecounts, efar, etotal = O.assign_objects_to_clusters(ov, pos_range, obj_type, layers, spot_dir, spot_sin_cos)
     assert total == etotal, (total, etotal)
@@ -434,6 +434,31 @@ def test_cluster_edge_cases(ctx_factory):
     assert cluster_case(ctx, cam, np.array([0, 0, -20, 1e6], F)) == 16 * 9 * 24         # covers every cluster
     cluster_case(ctx, cam, np.array([0, 0, 0, 3.0, 0, 0, -5.0, 0.0, 0.2, 0.1, -0.1, 0.05], F))  # at the eye / zero range
     cluster_case(ctx, cam, np.array([0, 0, -20, 5.0], F), view_mask=2)                  # layer mismatch
+
+
+def test_cluster_degenerate_grids(ctx_factory):
+    """Grids whose plane tables do not fit in LDS next to the bit rows (4096 x 1 x 1), a single cluster, and an
+    odd cluster count (unaligned accumulator sections)."""
+    ctx = ctx_factory()
+    cam = W.many_cubes_camera(0)
+    pr = W.many_lights(6_000, 50.0, 3.0)
+    assert cluster_case(ctx, cam, pr, req=(4096, 1, 1), screen=(4096, 8)) > 0
+    assert cluster_case(ctx, cam, pr, req=(1, 1, 1)) > 0
+    assert cluster_case(ctx, cam, pr, req=(3, 3, 3)) > 0
+    assert cluster_case(ctx, cam, pr, req=(5, 7, 11)) > 0
+
+
+def test_cluster_many_blocks_and_growth(ctx_factory):
+    """More (cluster, block) pairs than fill waves, an index list that outgrows the initial device buffer, and
+    repeated assignment on one context (frame-parity accumulators)."""
+    ctx = ctx_factory()
+    cam = W.many_cubes_camera(0)
+    pr = W.many_lights(150_000, 50.0, 10.0)
+    t1 = cluster_case(ctx, cam, pr)
+    assert t1 > (1 << 18)  # outgrows the initial 2^18-entry device index buffer
+    assert cluster_case(ctx, cam, pr[-4 * 70_001:]) > 0  # a different block count on the same context
+    assert cluster_case(ctx, W.many_cubes_camera(30, yaw=1.0), pr) > 0
+    assert cluster_case(ctx, cam, pr) == t1
 
 
 def test_device_logf_matches_libm(ctx_factory):

@@ -25,7 +25,18 @@ FLAG_HAS_AABB = 0x04
 FLAG_HAS_SPHERE = 0x08
 FLAG_NO_CPU_CULLING = 0x10
 FLAG_HAS_VISIBILITY_RANGE = 0x20
+FLAG_RANGE_USE_AABB = 0x40
+FLAG_SHADOW_CASTER = 0x80
 VIEW_FLAG_NO_CPU_CULLING = 0x01
+VIEW_FLAG_SHADOW = 0x02
+VIEW_FLAG_SKIP_NEAR = 0x04
+VIEW_FLAG_TEST_FAR = 0x08
+VIEW_FLAG_LIGHT_SPHERE = 0x10
+VIEW_FLAG_RANGES = 0x20
+VIEW_FLAG_RANGES_NO_ORIGIN = 0x40
+VIEW_KIND_CASCADE = 0x02 | 0x04 | 0x08
+VIEW_KIND_CUBE_FACE_OR_SPOT = 0x02 | 0x08 | 0x10
+VISIBILITY_INHERITED, VISIBILITY_HIDDEN, VISIBILITY_VISIBLE, VISIBILITY_NONE = 0, 1, 2, 0x80
 CULL_BEGIN_FRAME = 0x1
 CULL_END_FRAME = 0x2
 PROPAGATE_ALL_DIRTY = 0x1

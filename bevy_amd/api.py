@@ -51,6 +51,30 @@ class ClusterView(C.Structure):
         return self.dims[0] * self.dims[1] * self.dims[2]
 
 
+class View(C.Structure):
+    """mi_view"""
+    _fields_ = [("frustum", C.c_float * 24), ("layer_mask", C.c_uint32), ("flags", C.c_uint32),
+                ("position", C.c_float * 3), ("light_sphere", C.c_float * 4), ("reserved", C.c_uint32 * 3)]
+
+
+def make_views(frusta, layer_masks=None, flags=None, positions=None, light_spheres=None):
+    """Per-view numpy columns -> ctypes array of mi_view."""
+    fr = np.ascontiguousarray(frusta, np.float32).reshape(-1, 24)
+    nv = len(fr)
+    arr = (View * nv)()
+    pos = None if positions is None else np.asarray(positions, np.float32).reshape(-1, 3)
+    sph = None if light_spheres is None else np.asarray(light_spheres, np.float32).reshape(-1, 4)
+    for v in range(nv):
+        arr[v].frustum[:] = fr[v].tolist()
+        arr[v].layer_mask = int(layer_masks[v]) if layer_masks is not None else 1
+        arr[v].flags = int(flags[v]) if flags is not None else 0
+        if pos is not None:
+            arr[v].position[:] = pos[v].tolist()
+        if sph is not None:
+            arr[v].light_sphere[:] = sph[v].tolist()
+    return arr
+
+
 _lib = None
 
 # every symbol include/bevy_mi355x.h declares (tests/test_abi.py checks header <-> library <-> this list)
@@ -58,8 +82,10 @@ ABI_SYMBOLS = [
     "mi_abi_version", "mi_ctx_create", "mi_ctx_destroy", "mi_last_error_string", "mi_synchronize",
     "mi_columns_resize", "mi_upload_transforms", "mi_upload_global_transforms", "mi_upload_bounds",
     "mi_upload_view_visibility", "mi_upload_visibility_classes", "mi_upload_entity_keys", "mi_upload_changed",
-    "mi_upload_view_ranges", "mi_upload_hierarchy", "mi_hierarchy_sort", "mi_propagate",
-    "mi_visibility_begin_frame", "mi_cull", "mi_propagate_and_cull", "mi_visibility_end_frame",
+    "mi_upload_visibility_ranges", "mi_upload_visibility", "mi_upload_hierarchy", "mi_hierarchy_sort", "mi_propagate",
+    "mi_visibility_propagate", "mi_download_inherited_visibility",
+    "mi_visibility_begin_frame", "mi_cull", "mi_cull_views", "mi_propagate_and_cull", "mi_propagate_and_cull_views",
+    "mi_visibility_end_frame",
     "mi_download_global_transforms", "mi_download_visibility", "mi_download_view_visibility",
     "mi_download_visible_entities", "mi_cluster_view_dims", "mi_cluster_view_build",
     "mi_cluster_dimensions_fixed_z", "mi_cluster_assign", "mi_cluster_upload_objects", "mi_cluster_upload_view",
@@ -252,12 +278,27 @@ class Context:
         ch = _u8(changed)
         self._ck(self._lib.mi_upload_changed(self._h, first_row, len(ch), _ptr(ch, C.c_uint8)))
 
-    def upload_view_ranges(self, in_range):
-        if in_range is None:
-            self._ck(self._lib.mi_upload_view_ranges(self._h, 0, None))
+    def upload_visibility_ranges(self, start_end, first_row=0):
+        """start_end: f32[2n] (start_margin.start, end_margin.end); None = no VisibleEntityRanges resource."""
+        if start_end is None:
+            self._ck(self._lib.mi_upload_visibility_ranges(self._h, 0, 0, None))
             return
-        a = _u8(in_range)
-        self._ck(self._lib.mi_upload_view_ranges(self._h, a.shape[0], _ptr(a, C.c_uint8)))
+        a = _f32(start_end)
+        self._ck(self._lib.mi_upload_visibility_ranges(self._h, first_row, len(a) // 2, _ptr(a, C.c_float)))
+
+    def upload_visibility(self, visibility, first_row=0):
+        v = _u8(visibility)
+        self._ck(self._lib.mi_upload_visibility(self._h, first_row, len(v), _ptr(v, C.c_uint8)))
+
+    def visibility_propagate(self):
+        self._ck(self._lib.mi_visibility_propagate(self._h))
+
+    def download_inherited_visibility(self, first_row=0, n=None):
+        n = self.n - first_row if n is None else n
+        out = np.zeros(n, np.uint8)
+        chg = np.zeros((n + 31) // 32, np.uint32)
+        self._ck(self._lib.mi_download_inherited_visibility(self._h, first_row, n, _ptr(out, C.c_uint8), _ptr(chg, C.c_uint32)))
+        return out, unpack_bits(chg, n)
 
     def upload_hierarchy(self, parent_idx, level_offsets):
         if parent_idx is None:
@@ -286,6 +327,15 @@ class Context:
         fr, vm, vf, nv = self._views(frusta, view_masks, view_flags)
         self._ck(self._lib.mi_cull(self._h, _ptr(fr, C.c_float), _ptr(vm, C.c_uint32), _ptr(vf, C.c_uint8), nv,
                                    int(flags)))
+
+    def cull_views(self, views, flags=0):
+        """views: ctypes array from make_views()."""
+        self.n_views = len(views)
+        self._ck(self._lib.mi_cull_views(self._h, views, len(views), int(flags)))
+
+    def propagate_and_cull_views(self, views, flags=0):
+        self.n_views = len(views)
+        self._ck(self._lib.mi_propagate_and_cull_views(self._h, views, len(views), int(flags)))
 
     def propagate_and_cull(self, frusta, view_masks=None, view_flags=None, flags=0):
         fr, vm, vf, nv = self._views(frusta, view_masks, view_flags)

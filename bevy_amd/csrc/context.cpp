@@ -64,8 +64,11 @@ struct mi_ctx {
     std::vector<uint64_t> h_keys;
     bool order_dirty = false, order_identity = true;
     DevBuf order;
-    DevBuf in_range;
-    uint32_t in_range_views = 0;
+    float* range = nullptr;        // VisibilityRange (start_margin.start, end_margin.end) per row
+    bool have_ranges = false;      // a VisibleEntityRanges resource exists (mi_upload_visibility_ranges was called)
+    uint8_t* visibility = nullptr; // Visibility component: 0 Inherited, 1 Hidden, 2 Visible, 0x80 none
+    uint8_t* inh_changed = nullptr;  // InheritedVisibility assigned by the last mi_visibility_propagate (bytes)
+    DevBuf inh_bits;
 
     // ---- staging ----
     void* stage = nullptr;
@@ -305,22 +308,19 @@ Columns columns_of(mi_ctx* ctx) {
     c.flags = ctx->flags;
     c.layer_mask = ctx->layers;
     c.view_visibility = ctx->vv;
-    c.in_range = nullptr;
+    c.range_start_end = ctx->have_ranges ? ctx->range : nullptr;
     c.g_changed_bits = ctx->g_chg_bits;
     c.vv_changed_bits = ctx->vv_chg_bits;
     return c;
 }
 
-int32_t prepare_views(mi_ctx* ctx, const float* frusta, const uint32_t* masks, const uint8_t* vflags, uint32_t n_views,
-                      VisibilityOut* out) {
-    if (!frusta || n_views == 0) return fail(ctx, MI_ERR_INVALID_ARG, "mi_cull: frusta NULL or n_views == 0");
+static_assert(sizeof(mi_view) == sizeof(ViewParams), "mi_view and ViewParams share one layout");
+
+int32_t prepare_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, VisibilityOut* out) {
+    if (!views || n_views == 0) return fail(ctx, MI_ERR_INVALID_ARG, "mi_cull: views NULL or n_views == 0");
     std::vector<ViewParams> vp(n_views);
-    for (uint32_t v = 0; v < n_views; ++v) {
-        memcpy(vp[v].planes, frusta + 24 * (size_t)v, sizeof vp[v].planes);
-        vp[v].layer_mask = masks ? masks[v] : 1u;
-        vp[v].flags = vflags ? vflags[v] : 0u;
-        vp[v].pad[0] = vp[v].pad[1] = 0;
-    }
+    memcpy(vp.data(), views, sizeof(ViewParams) * n_views);
+    for (auto& v : vp) v.pad[0] = v.pad[1] = v.pad[2] = 0;
     int32_t rc = MI_OK;
     ctx->views_inline = n_views <= MAX_INLINE_VIEWS;
     if (ctx->views_inline) {
@@ -517,10 +517,11 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
     hipStreamSynchronize(ctx->stream);
     prof_collect(ctx);
     void* cols[] = {ctx->t, ctx->r, ctx->s, ctx->g, ctx->c, ctx->h, ctx->flags, ctx->vv, ctx->changed, ctx->g_changed_bytes,
-                    ctx->layers, ctx->class_mask, ctx->keys, ctx->g_chg_bits, ctx->vv_chg_bits, ctx->tree_bits};
+                    ctx->layers, ctx->class_mask, ctx->keys, ctx->g_chg_bits, ctx->vv_chg_bits, ctx->tree_bits,
+                    ctx->range, ctx->visibility, ctx->inh_changed};
     for (void* p : cols)
         if (p) hipFree(p);
-    DevBuf* bufs[] = {&ctx->order, &ctx->in_range, &ctx->parent_idx, &ctx->node_flags, &ctx->tiles, &ctx->views, &ctx->bitmask,
+    DevBuf* bufs[] = {&ctx->order, &ctx->inh_bits, &ctx->parent_idx, &ctx->node_flags, &ctx->tiles, &ctx->views, &ctx->bitmask,
                       &ctx->block_counts, &ctx->seg_totals, &ctx->seg_bases, &ctx->out_rows, &ctx->out_keys, &ctx->wave_cnt, &ctx->seg_mask, &ctx->cl_pos,
                       &ctx->cl_type, &ctx->cl_layers, &ctx->cl_dir, &ctx->cl_sincos, &ctx->cl_planes, &ctx->cl_spheres,
                       &ctx->cl_block_counts, &ctx->cl_pair_cb, &ctx->cl_pair_mask, &ctx->cl_acc,
@@ -572,6 +573,9 @@ int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
         if ((rc = grow_column(ctx, ctx->layers, 1, old, new_cap, 0))) return rc;
         if ((rc = grow_column(ctx, ctx->class_mask, 1, old, new_cap, 0))) return rc;
         if ((rc = grow_column(ctx, ctx->keys, 1, old, new_cap, 0))) return rc;
+        if ((rc = grow_column(ctx, ctx->range, 2, old, new_cap, 0))) return rc;
+        if ((rc = grow_column(ctx, ctx->visibility, 1, old, new_cap, 0))) return rc;
+        if ((rc = grow_column(ctx, ctx->inh_changed, 1, old, new_cap, 0))) return rc;
         // default RenderLayers = layer 0 (mask 1) for rows never uploaded
         {
             std::vector<uint32_t> ones(new_cap - old, 1u);
@@ -708,16 +712,24 @@ int32_t mi_upload_changed(mi_ctx* ctx, uint32_t first_row, uint32_t n, const uin
     return upload(ctx, ctx->changed + first_row, changed, n);
 }
 
-int32_t mi_upload_view_ranges(mi_ctx* ctx, uint32_t n_views, const uint8_t* in_range) {
+int32_t mi_upload_visibility_ranges(mi_ctx* ctx, uint32_t first_row, uint32_t n, const float* start_end) {
     ENTER(ctx);
-    if (!in_range || n_views == 0) {
-        ctx->in_range_views = 0;
+    if (!start_end) {  // no VisibleEntityRanges resource: ranged rows are not range-culled
+        ctx->have_ranges = false;
         return MI_OK;
     }
-    int32_t rc = ensure(ctx, ctx->in_range, (size_t)n_views * ctx->n);
+    int32_t rc = check_rows(ctx, first_row, n, "mi_upload_visibility_ranges");
     if (rc) return rc;
-    ctx->in_range_views = n_views;
-    return upload(ctx, ctx->in_range.p, in_range, (size_t)n_views * ctx->n);
+    ctx->have_ranges = true;
+    return upload(ctx, ctx->range + 2 * (size_t)first_row, start_end, (size_t)n * 8);
+}
+
+int32_t mi_upload_visibility(mi_ctx* ctx, uint32_t first_row, uint32_t n, const uint8_t* visibility) {
+    ENTER(ctx);
+    if (!visibility) return fail(ctx, MI_ERR_INVALID_ARG, "mi_upload_visibility: NULL");
+    int32_t rc = check_rows(ctx, first_row, n, "mi_upload_visibility");
+    if (rc) return rc;
+    return upload(ctx, ctx->visibility + first_row, visibility, n);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -908,16 +920,26 @@ int32_t mi_visibility_end_frame(mi_ctx* ctx) {
     return MI_OK;
 }
 
-int32_t mi_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_masks, const uint8_t* view_flags,
-                uint32_t n_views, uint32_t flags) {
+namespace {
+void simple_views(std::vector<mi_view>& v, const float* frusta, const uint32_t* masks, const uint8_t* vflags, uint32_t n_views) {
+    v.resize(frusta ? n_views : 0);
+    for (uint32_t i = 0; i < v.size(); ++i) {
+        memset(&v[i], 0, sizeof(mi_view));
+        memcpy(v[i].frustum, frusta + 24 * (size_t)i, sizeof v[i].frustum);
+        v[i].layer_mask = masks ? masks[i] : 1u;
+        v[i].flags = vflags ? vflags[i] : 0u;
+    }
+}
+}  // namespace
+
+int32_t mi_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint32_t flags) {
     ENTER(ctx);
     VisibilityOut vo{};
-    int32_t rc = prepare_views(ctx, frusta, view_layer_masks, view_flags, n_views, &vo);
+    int32_t rc = prepare_views(ctx, views, n_views, &vo);
     if (rc) return rc;
     SegOut seg;
     if ((rc = prepare_segments(ctx, n_views, &seg))) return rc;
     Columns c = columns_of(ctx);
-    if (ctx->in_range_views >= n_views) c.in_range = (const uint8_t*)ctx->in_range.p;
     {
         ProfScope ps(ctx, K_CULL);
         HIP_TRY(ctx, launch_cull(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p, n_views, vo,
@@ -928,18 +950,23 @@ int32_t mi_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_mas
     return MI_OK;
 }
 
-int32_t mi_propagate_and_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_masks, const uint8_t* view_flags,
-                              uint32_t n_views, uint32_t flags) {
+int32_t mi_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_masks, const uint8_t* view_flags,
+                uint32_t n_views, uint32_t flags) {
+    std::vector<mi_view> v;
+    simple_views(v, frusta, view_layer_masks, view_flags, n_views);
+    return mi_cull_views(ctx, v.empty() ? nullptr : v.data(), n_views, flags);
+}
+
+int32_t mi_propagate_and_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint32_t flags) {
     ENTER(ctx);
     if (ctx->have_hierarchy)
         return fail(ctx, MI_ERR_NOT_READY, "mi_propagate_and_cull is the flat fast path; a hierarchy is uploaded -- use mi_propagate + mi_cull");
     VisibilityOut vo{};
-    int32_t rc = prepare_views(ctx, frusta, view_layer_masks, view_flags, n_views, &vo);
+    int32_t rc = prepare_views(ctx, views, n_views, &vo);
     if (rc) return rc;
     SegOut seg;
     if ((rc = prepare_segments(ctx, n_views, &seg))) return rc;
     Columns c = columns_of(ctx);
-    if (ctx->in_range_views >= n_views) c.in_range = (const uint8_t*)ctx->in_range.p;
     {
         ProfScope ps(ctx, K_FLAT_PROPAGATE_CULL);
         HIP_TRY(ctx, launch_flat_propagate_cull(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p,
@@ -947,7 +974,54 @@ int32_t mi_propagate_and_cull(mi_ctx* ctx, const float* frusta, const uint32_t* 
     }
     if ((rc = run_compaction(ctx, vo, seg))) return rc;
     if (ctx->have_changed) HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, ctx->n, ctx->stream));
+    ctx->g_chg_in_bytes = false;
     ctx->culled = true;
+    return MI_OK;
+}
+
+int32_t mi_propagate_and_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_masks, const uint8_t* view_flags,
+                              uint32_t n_views, uint32_t flags) {
+    std::vector<mi_view> v;
+    simple_views(v, frusta, view_layer_masks, view_flags, n_views);
+    return mi_propagate_and_cull_views(ctx, v.empty() ? nullptr : v.data(), n_views, flags);
+}
+
+// visibility_propagate_system (crates/bevy_camera/src/visibility/mod.rs:638-729) over the uploaded hierarchy
+int32_t mi_visibility_propagate(mi_ctx* ctx) {
+    ENTER(ctx);
+    if (ctx->n == 0) return MI_OK;
+    if (!ctx->have_hierarchy) {
+        ProfScope ps(ctx, K_INHERIT);
+        HIP_TRY(ctx, launch_inherit_flat(ctx->n, ctx->visibility, ctx->flags, ctx->inh_changed, ctx->stream));
+        return MI_OK;
+    }
+    bool first = true;
+    for (auto& ps : ctx->passes) {
+        ProfScope sc(ctx, K_INHERIT);
+        HIP_TRY(ctx, launch_inherit_tiles((const uint32_t*)ctx->parent_idx.p, (const TileDesc*)ctx->tiles.p + ps.first, ps.second,
+                                          first, ctx->visibility, ctx->flags, ctx->inh_changed, ctx->stream));
+        first = false;
+    }
+    return MI_OK;
+}
+
+int32_t mi_download_inherited_visibility(mi_ctx* ctx, uint32_t first_row, uint32_t n, uint8_t* out_inherited,
+                                         uint32_t* changed_bitmask) {
+    ENTER(ctx);
+    int32_t rc = check_rows(ctx, first_row, n, "mi_download_inherited_visibility");
+    if (rc) return rc;
+    if (changed_bitmask && (first_row & 31u)) return fail(ctx, MI_ERR_INVALID_ARG, "first_row must be a multiple of 32 for the change bitmask");
+    if (out_inherited) {
+        if ((rc = download(ctx, out_inherited, ctx->flags + first_row, n))) return rc;
+        for (uint32_t i = 0; i < n; ++i) out_inherited[i] &= 1u;
+    }
+    if (changed_bitmask) {
+        if ((rc = ensure(ctx, ctx->inh_bits, padded_words(ctx->cap) * 8 + 256))) return rc;
+        HIP_TRY(ctx, launch_bytes_to_bits(ctx->inh_changed, ctx->n, (uint64_t*)ctx->inh_bits.p, ctx->stream));
+        const size_t words32 = ((size_t)n + 31) / 32;
+        if ((rc = download(ctx, changed_bitmask, (const uint32_t*)ctx->inh_bits.p + first_row / 32, words32 * 4))) return rc;
+        if (n & 31u) changed_bitmask[words32 - 1] &= (1u << (n & 31u)) - 1u;
+    }
     return MI_OK;
 }
 
@@ -1297,7 +1371,7 @@ const char* mi_profile_kernel_name(uint32_t k) {
     static const char* names[K_NUM_KERNELS] = {"k_flat_propagate_cull", "k_level0_propagate", "k_cull", "k_vis_begin",
                                                "k_vis_end", "k_compact_count", "k_compact_scan", "k_compact_scatter",
                                                "k_compact_fast", "k_mark_dirty", "k_propagate_tiles", "k_cluster_walk", "k_cluster_fill",
-                                               "k_clear_u32"};
+                                               "k_clear_u32", "k_inherit"};
     return k < K_NUM_KERNELS ? names[k] : nullptr;
 }
 

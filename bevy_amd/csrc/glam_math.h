@@ -222,6 +222,16 @@ MI_HD bool frustum_intersects_obb(const V4* planes, V3 center, V3 half_extents, 
     return inside;
 }
 
+// Sphere::intersects_obb (bevy_camera/src/primitives.rs:219-226)
+MI_HD bool sphere_intersects_obb(V3 sphere_center, float sphere_radius, V3 aabb_center_world, V3 half_extents,
+                                 const M3& world_from_local) {
+    const V3 v = aabb_center_world - sphere_center;
+    const float d_sq = dot3(v, v);
+    const float d = f_sqrt(d_sq);
+    const float rr = aabb_relative_radius(half_extents, v, world_from_local);
+    return d_sq <= sphere_radius * d + rr;
+}
+
 // Rust `f32 as u32` (saturating, NaN -> 0)
 MI_HD uint32_t f32_as_u32(float f) {
     if (!(f > 0.0f)) return 0u;

@@ -32,14 +32,19 @@ extern thread_local const LaunchTimer* g_launch_timer;
         else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                 \
     } while (0)
 
-// One view's constants, read through scalar loads (uniform across the wave).
+// One view's constants, read through scalar loads (uniform across the wave).  Same layout as mi_view.
 struct ViewParams {
-    float planes[24];     // 6 x (nx,ny,nz,d)
-    uint32_t layer_mask;  // RenderLayers bits of the view
-    uint32_t flags;       // MI_VIEW_FLAG_*
-    uint32_t pad[2];
+    float planes[24];       // 6 x (nx,ny,nz,d)
+    uint32_t layer_mask;    // RenderLayers bits of the view
+    uint32_t flags;         // MI_VIEW_FLAG_*
+    float position[3];      // origin for VisibilityRange distances
+    float light_sphere[4];  // point / spot light (translation, range)
+    uint32_t pad[3];
 };
-static_assert(sizeof(ViewParams) == 112, "ViewParams layout");
+static_assert(sizeof(ViewParams) == 144, "ViewParams layout");
+// MI_VIEW_FLAG_* (public header)
+constexpr uint32_t VIEW_NO_CPU_CULLING = 0x01u, VIEW_SHADOW = 0x02u, VIEW_SKIP_NEAR = 0x04u, VIEW_TEST_FAR = 0x08u,
+                   VIEW_LIGHT_SPHERE = 0x10u, VIEW_RANGES = 0x20u, VIEW_RANGES_NO_ORIGIN = 0x40u;
 
 // Device-resident component columns of one context (all pointers device memory).
 struct Columns {
@@ -53,7 +58,8 @@ struct Columns {
     const uint8_t* flags;       // n
     const uint32_t* layer_mask; // n
     uint8_t* view_visibility;   // n
-    const uint8_t* in_range;    // n_views*n or nullptr
+    const float* range_start_end;  // 2n (VisibilityRange start_margin.start, end_margin.end) or nullptr = no
+                                   // VisibleEntityRanges resource
     uint64_t* g_changed_bits;   // ceil(n/64) words: GlobalTransform change tick bumped
     uint64_t* vv_changed_bits;  // ceil(n/64) words: ViewVisibility change tick bumped
 };
@@ -105,6 +111,7 @@ enum KernelId : uint32_t {
     K_CLUSTER_WALK,
     K_CLUSTER_FILL,
     K_CLEAR,
+    K_INHERIT,
     K_NUM_KERNELS
 };
 
@@ -183,6 +190,10 @@ hipError_t launch_mark_dirty(uint32_t n, const uint8_t* changed, const uint32_t*
 hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, const TileDesc* d_tiles, uint32_t n_tiles,
                                   bool roots, const uint8_t* node_flags, const uint8_t* changed, const uint32_t* tree_bits,
                                   uint8_t* g_changed_bytes, bool all_dirty, bool static_opt, hipStream_t stream);
+// InheritedVisibility propagation (visibility_propagate_system): writes bit0 of flags[] and changed bytes.
+hipError_t launch_inherit_flat(uint32_t n, const uint8_t* visibility, uint8_t* flags, uint8_t* inh_changed, hipStream_t stream);
+hipError_t launch_inherit_tiles(const uint32_t* parent_idx, const TileDesc* d_tiles, uint32_t n_tiles, bool roots,
+                                const uint8_t* visibility, uint8_t* flags, uint8_t* inh_changed, hipStream_t stream);
 hipError_t launch_clear_u32(uint32_t* p, uint64_t n_words, hipStream_t stream);
 hipError_t launch_bytes_to_bits(const uint8_t* bytes, uint32_t n, uint64_t* bits, hipStream_t stream);
 

@@ -368,6 +368,107 @@ __global__ void __launch_bounds__(BLOCK) k_propagate_tiles(Columns c, TreeArgs a
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// visibility_propagate_system + propagate_recursive (crates/bevy_camera/src/visibility/mod.rs:638-729) as the
+// fixpoint they maintain, swept over the same subtree tiles as the transforms:
+//   Visible -> true, Hidden -> false, Inherited -> parent's InheritedVisibility (true without a parent or when
+//   the parent lacks the visibility components, mod.rs:656-659).  InheritedVisibility is bit0 of flags[]; it is
+//   assigned (and the change byte set) only where the value differs (mod.rs:667-669,717-718).
+// LDS holds one byte per upper-level row: 0/1 = InheritedVisibility, 2 = "no components" (children fall back to true).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t inherit_rule(uint32_t vis, uint32_t parent_state /*0,1,2; 2 = none*/) {
+    return vis == 2u ? 1u : vis == 1u ? 0u : (parent_state == 0u ? 0u : 1u);
+}
+// returns the state children see: 2 when the row has no components, else its (possibly updated) InheritedVisibility
+__device__ __forceinline__ uint32_t inherit_update(uint32_t row, uint32_t vis, uint32_t parent_state, uint8_t* flags,
+                                                   uint8_t* inh_changed) {
+    if (vis & 0x80u) {
+        inh_changed[row] = 0;
+        return 2u;
+    }
+    const uint32_t fl = flags[row];
+    const uint32_t nv = inherit_rule(vis, parent_state);
+    const bool chg = (fl & 1u) != nv;
+    if (chg) flags[row] = (uint8_t)((fl & ~1u) | nv);
+    inh_changed[row] = chg ? 1 : 0;
+    return nv;
+}
+
+__global__ void __launch_bounds__(256) k_inherit_flat(uint32_t n, const uint8_t* __restrict__ visibility, uint8_t* flags,
+                                                       uint8_t* inh_changed) {
+    const uint32_t row = blockIdx.x * 256u + threadIdx.x;
+    if (row < n) inherit_update(row, visibility[row], 2u, flags, inh_changed);  // no parent -> Inherited means visible
+}
+
+template <bool ROOTS>
+__global__ void __launch_bounds__(256) k_inherit_tiles(const uint32_t* __restrict__ parent_idx,
+                                                        const TileDesc* __restrict__ tiles,
+                                                        const uint8_t* __restrict__ visibility, uint8_t* flags,
+                                                        uint8_t* inh_changed) {
+    __shared__ uint8_t lds_state[TILE_UCAP];
+    const TileDesc& td = tiles[blockIdx.x];
+    const uint32_t L = td.n_levels;
+    const uint32_t tid = threadIdx.x;
+    uint32_t ubase[TILE_MAX_LEVELS + 1];
+    ubase[0] = 0;
+    uint32_t n_lds = 0;
+#pragma unroll
+    for (uint32_t l = 0; l < TILE_MAX_LEVELS; ++l) {
+        const uint32_t cnt = l < L ? td.count[l] : 0u;
+        ubase[l + 1] = ubase[l] + cnt;
+        if (l + 1 < L && n_lds == l && ubase[l + 1] <= TILE_UCAP) n_lds = l + 1;
+    }
+    // parent state of a row whose parent is NOT in LDS (first level of a non-root tile, or the LDS fallback)
+    auto parent_state_global = [&](uint32_t p) -> uint32_t {
+        return (visibility[p] & 0x80u) ? 2u : (uint32_t)(flags[p] & 1u);
+    };
+    for (uint32_t l = 0; l < L; ++l) {
+        uint32_t start = td.start[0], count = td.count[0], lbase = 0, pbase = 0, pstart = 0;
+#pragma unroll
+        for (uint32_t j = 1; j < TILE_MAX_LEVELS; ++j)
+            if (j == l) {
+                start = td.start[j];
+                count = td.count[j];
+                lbase = ubase[j];
+                pbase = ubase[j - 1];
+                pstart = td.start[j - 1];
+            }
+        const bool to_lds = l < n_lds;
+        const bool parents_in_lds = l > 0 && l - 1 < n_lds;
+        for (uint32_t i = tid; i < count; i += 256u) {
+            const uint32_t row = start + i;
+            uint32_t ps = 2u;
+            if (!(ROOTS && l == 0)) {
+                const uint32_t p = parent_idx[row];
+                ps = parents_in_lds ? (uint32_t)lds_state[pbase + (p - pstart)] : parent_state_global(p);
+            }
+            const uint32_t st = inherit_update(row, visibility[row], ps, flags, inh_changed);
+            if (to_lds) lds_state[lbase + i] = (uint8_t)st;
+        }
+        if (l + 1 < L && !to_lds) {  // fallback: the next level reads this level's flags back from global memory
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        } else {
+            __syncthreads();
+        }
+    }
+}
+
+hipError_t launch_inherit_flat(uint32_t n, const uint8_t* visibility, uint8_t* flags, uint8_t* inh_changed,
+                               hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    MI_LAUNCH(k_inherit_flat, dim3((n + 255u) / 256u), dim3(256), 0, stream, n, visibility, flags, inh_changed);
+    return hipGetLastError();
+}
+hipError_t launch_inherit_tiles(const uint32_t* parent_idx, const TileDesc* d_tiles, uint32_t n_tiles, bool roots,
+                                const uint8_t* visibility, uint8_t* flags, uint8_t* inh_changed, hipStream_t stream) {
+    if (n_tiles == 0) return hipSuccess;
+    if (roots) MI_LAUNCH(k_inherit_tiles<true>, dim3(n_tiles), dim3(256), 0, stream, parent_idx, d_tiles, visibility, flags, inh_changed);
+    else MI_LAUNCH(k_inherit_tiles<false>, dim3(n_tiles), dim3(256), 0, stream, parent_idx, d_tiles, visibility, flags, inh_changed);
+    return hipGetLastError();
+}
+
 hipError_t launch_mark_dirty(uint32_t n, const uint8_t* changed, const uint32_t* parent_idx, uint32_t* tree_bits,
                              hipStream_t stream) {
     if (n == 0) return hipSuccess;

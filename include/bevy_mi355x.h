@@ -54,10 +54,31 @@ extern "C" {
 #define MI_FLAG_HAS_AABB 0x04u           /* Option<&Aabb> is Some, visibility/mod.rs:824 */
 #define MI_FLAG_HAS_SPHERE 0x08u         /* Option<&Sphere> is Some (Aabb takes precedence), :838 */
 #define MI_FLAG_NO_CPU_CULLING 0x10u     /* With<NoCpuCulling>: excluded from a11/a12, handled by :884-903 */
-#define MI_FLAG_HAS_VISIBILITY_RANGE 0x20u /* Has<VisibilityRange>, :814-820 (needs mi_upload_view_ranges) */
+#define MI_FLAG_HAS_VISIBILITY_RANGE 0x20u /* Has<VisibilityRange>, :814-820 (see mi_upload_visibility_ranges) */
+#define MI_FLAG_RANGE_USE_AABB 0x40u     /* VisibilityRange::use_aabb, visibility/range.rs:255-263 */
+#define MI_FLAG_SHADOW_CASTER 0x80u      /* With<Mesh3d>, Without<NotShadowCaster>, Without<DirectionalLight>:
+                                            matched by the shadow-view queries, crates/bevy_light/src/lib.rs:355-372 */
 
-/* ---- per-view flag byte (mi_cull) ------------------------------------------------------- */
+/* ---- per-view flags (mi_view.flags; mi_cull's view_flags byte carries the low bits) ------ */
 #define MI_VIEW_FLAG_NO_CPU_CULLING 0x01u /* camera Has<NoCpuCulling>: skip frustum tests, :756,823 */
+#define MI_VIEW_FLAG_SHADOW 0x02u         /* shadow view (cascade / cube face / spot): only MI_FLAG_SHADOW_CASTER rows,
+                                             OBB test only; crates/bevy_light/src/lib.rs:342-757 */
+#define MI_VIEW_FLAG_SKIP_NEAR 0x04u      /* intersects_obb(.., intersect_near = false, ..): cascades, lib.rs:455-458 */
+#define MI_VIEW_FLAG_TEST_FAR 0x08u       /* intersects_obb(.., .., intersect_far = true): every shadow view */
+#define MI_VIEW_FLAG_LIGHT_SPHERE 0x10u   /* point / spot: light_sphere.intersects_obb pre-test, lib.rs:617-623 */
+#define MI_VIEW_FLAG_RANGES 0x20u         /* this view has an index in VisibleEntityRanges (range.rs:238-243):
+                                             ranged rows are tested against mi_view.position */
+#define MI_VIEW_FLAG_RANGES_NO_ORIGIN 0x40u /* point / spot shadow view without a shadow LOD origin
+                                             (lib.rs:601-611): ranged rows are culled */
+/* typical combinations */
+#define MI_VIEW_KIND_CASCADE (MI_VIEW_FLAG_SHADOW | MI_VIEW_FLAG_SKIP_NEAR | MI_VIEW_FLAG_TEST_FAR)
+#define MI_VIEW_KIND_CUBE_FACE_OR_SPOT (MI_VIEW_FLAG_SHADOW | MI_VIEW_FLAG_TEST_FAR | MI_VIEW_FLAG_LIGHT_SPHERE)
+
+/* ---- Visibility component values (mi_upload_visibility) ----------------------------------- */
+#define MI_VISIBILITY_INHERITED 0u
+#define MI_VISIBILITY_HIDDEN 1u
+#define MI_VISIBILITY_VISIBLE 2u
+#define MI_VISIBILITY_NONE 0x80u /* the entity has no Visibility / InheritedVisibility components */
 
 /* ---- mi_cull / mi_propagate_and_cull flags ------------------------------------------------- */
 #define MI_CULL_BEGIN_FRAME 0x1u /* also apply reset_view_visibility (mod.rs:733-737) in the same pass */
@@ -134,9 +155,15 @@ int32_t mi_upload_entity_keys(mi_ctx* ctx, uint32_t first_row, uint32_t n, const
  * (systems.rs:42-55,111-116).  Consumed (cleared) by the next mi_propagate. */
 int32_t mi_upload_changed(mi_ctx* ctx, uint32_t first_row, uint32_t n, const uint8_t* changed);
 
-/* VisibleEntityRanges::entity_is_in_range_of_view (visibility/range.rs), one byte per (view,row);
- * only consulted for rows with MI_FLAG_HAS_VISIBILITY_RANGE.  NULL clears it (= all in range). */
-int32_t mi_upload_view_ranges(mi_ctx* ctx, uint32_t n_views, const uint8_t* in_range);
+/* VisibilityRange (crates/bevy_camera/src/visibility/range.rs:78-103): start_end[2n] =
+ * (start_margin.start, end_margin.end), the two bounds is_visible_at_all reads (:159-161); only consulted for
+ * rows with MI_FLAG_HAS_VISIBILITY_RANGE.  check_visibility_ranges (:225-284) is then evaluated on the device
+ * inside mi_cull, per view, from mi_view.position.  start_end == NULL = no VisibleEntityRanges resource (ranged
+ * rows are not range-culled, visibility/mod.rs:814-816 `is_some_and`). */
+int32_t mi_upload_visibility_ranges(mi_ctx* ctx, uint32_t first_row, uint32_t n, const float* start_end);
+
+/* Visibility component per row (MI_VISIBILITY_*), input of mi_visibility_propagate. */
+int32_t mi_upload_visibility(mi_ctx* ctx, uint32_t first_row, uint32_t n, const uint8_t* visibility);
 
 /* ChildOf as a row index (MI_NO_PARENT for roots), rows in level order: level l occupies rows
  * [level_offsets[l], level_offsets[l+1]); level 0 holds every root and every flat entity;
@@ -165,6 +192,14 @@ int32_t mi_hierarchy_sort(uint32_t n, const uint32_t* parent, uint32_t* out_new_
  * Writes GlobalTransform and the per-row "change tick bumped" bit. */
 int32_t mi_propagate(mi_ctx* ctx, uint32_t flags);
 
+/* visibility_propagate_system (visibility/mod.rs:638-729): recomputes InheritedVisibility (bit
+ * MI_FLAG_INHERITED_VISIBLE of the flag byte) from the Visibility column over the uploaded hierarchy
+ * (flat rows: Hidden -> false, otherwise true); assigns only where the value differs. */
+int32_t mi_visibility_propagate(mi_ctx* ctx);
+/* InheritedVisibility::get() per row (0/1) and the bitmask of rows the system assigned (change ticks). */
+int32_t mi_download_inherited_visibility(mi_ctx* ctx, uint32_t first_row, uint32_t n, uint8_t* out_inherited,
+                                         uint32_t* changed_bitmask);
+
 /* reset_view_visibility (visibility/mod.rs:733-737) -- call once per frame before mi_cull
  * (or pass MI_CULL_BEGIN_FRAME to mi_cull and skip this call). */
 int32_t mi_visibility_begin_frame(mi_ctx* ctx);
@@ -175,6 +210,23 @@ int32_t mi_visibility_begin_frame(mi_ctx* ctx);
  *   frusta[24*n_views]; view_layer_masks[n_views] (NULL = layer 0); view_flags[n_views] (NULL = 0). */
 int32_t mi_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_masks, const uint8_t* view_flags,
                 uint32_t n_views, uint32_t flags /* MI_CULL_* */);
+
+/* One view of any kind the main-world visibility systems test entities against: a camera
+ * (check_visibility_cpu_culling), a directional-light cascade (check_dir_light_mesh_visibility,
+ * crates/bevy_light/src/lib.rs:342-515) or a point-light cube face / spot-light frustum
+ * (check_point_light_mesh_visibility, lib.rs:517-757).  Every kind ORs into ViewVisibility (set_visible) and gets
+ * its own bitmask / VisibleEntities (VisibleMeshEntities) lists, indexed by its position in the array. */
+typedef struct mi_view {
+    float frustum[24];     /* Frustum::half_spaces */
+    uint32_t layer_mask;   /* RenderLayers of the camera / light */
+    uint32_t flags;        /* MI_VIEW_FLAG_* */
+    float position[3];     /* GlobalTransform::translation of the view for VisibilityRange distances: the camera,
+                              the cascade's camera (lib.rs:437-443) or the shadow LOD origin (lib.rs:601-611) */
+    float light_sphere[4]; /* point / spot light: (translation, range) */
+    uint32_t reserved[3];  /* 0 */
+} mi_view;
+int32_t mi_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint32_t flags /* MI_CULL_* */);
+int32_t mi_propagate_and_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint32_t flags);
 
 /* Fused fast path for flat rows (no hierarchy uploaded): sync_simple_transforms with every Transform
  * dirty + reset_view_visibility + check_visibility_cpu_culling in ONE pass (Transform is read once,

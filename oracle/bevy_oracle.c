@@ -597,6 +597,129 @@ void orc_check_visibility(uint32_t n, const float* global, const float* aabb_cen
     }
 }
 
+/* VisibilityRange::is_visible_at_all(distance), range.rs:159-161, with the model position rule of :255-263 */
+static inline int entity_in_range_of(const float* g, const float* c, uint8_t fl, const float* start_end,
+                                     const float* view_pos) {
+    aff wfl = aff_load(g);
+    v3 model = ((fl & ORC_FLAG_RANGE_USE_AABB) && (fl & ORC_FLAG_HAS_AABB)) ? aff_point(&wfl, V3(c[0], c[1], c[2]))
+                                                                           : wfl.t;
+    float d = v3_length(v3_sub(V3(view_pos[0], view_pos[1], view_pos[2]), model));
+    return d >= start_end[0] && d < start_end[1];
+}
+
+void orc_check_visibility_ranges(uint32_t n, const float* global, const float* aabb_center,
+                                 const uint8_t* flags, const float* range_start_end,
+                                 const float* view_positions, uint32_t n_views, uint8_t* in_range_out) {
+    if (n_views > 32) n_views = 32; /* .take(32), range.rs:240 */
+    for (uint32_t v = 0; v < n_views; ++v)
+        for (uint32_t i = 0; i < n; ++i) {
+            uint8_t fl = flags[i];
+            int in = 0;
+            if ((fl & ORC_FLAG_HAS_VISIBILITY_RANGE) && !(fl & ORC_FLAG_NO_CPU_CULLING))
+                in = entity_in_range_of(global + 12 * (size_t)i, aabb_center + 3 * (size_t)i, fl,
+                                        range_start_end + 2 * (size_t)i, view_positions + 3 * (size_t)v);
+            in_range_out[(size_t)v * n + i] = (uint8_t)in;
+        }
+}
+
+/* shadow-view closures: bevy_light/src/lib.rs:425-475 (cascades), :592-650 (cube faces), :694-738 (spot) */
+static inline int entity_visible_in_shadow_view(const float* g, const float* c, const float* h, uint8_t fl,
+                                                uint32_t entity_mask, int in_range, const orc_view* view) {
+    if (!(fl & ORC_FLAG_SHADOW_CASTER)) return 0; /* not matched by visible_entity_query */
+    if (!(fl & ORC_FLAG_INHERITED_VISIBLE)) return 0;
+    if (!(view->layer_mask & entity_mask)) return 0;
+    if ((fl & ORC_FLAG_HAS_VISIBILITY_RANGE) && !in_range) return 0;
+    if (fl & ORC_FLAG_HAS_AABB) { /* (Some(aabb), Some(transform)) */
+        aff wfl = aff_load(g);
+        v3 center = V3(c[0], c[1], c[2]), half = V3(h[0], h[1], h[2]);
+        if (!(fl & ORC_FLAG_NO_FRUSTUM_CULLING)) {
+            if ((view->flags & ORC_VIEW_FLAG_LIGHT_SPHERE) &&
+                !orc_sphere_intersects_obb(view->light_sphere, view->light_sphere[3], c, h, g))
+                return 0;
+            if (!frustum_intersects_obb(view->frustum, center, half, &wfl, !(view->flags & ORC_VIEW_FLAG_SKIP_NEAR),
+                                        (view->flags & ORC_VIEW_FLAG_TEST_FAR) != 0))
+                return 0;
+        }
+    }
+    return 1;
+}
+
+void orc_check_visibility_views(uint32_t n, const float* global, const float* aabb_center,
+                                const float* aabb_half, const uint8_t* flags, const uint32_t* layer_mask,
+                                const float* range_start_end, uint8_t* vv, const orc_view* views,
+                                uint32_t n_views, uint8_t* visible_out, uint8_t* vv_changed_out) {
+    for (uint32_t v = 0; v < n_views; ++v) {
+        const orc_view* view = &views[v];
+        for (uint32_t i = 0; i < n; ++i) {
+            uint8_t fl = flags[i];
+            uint8_t vis = 0;
+            if (!(fl & ORC_FLAG_NO_CPU_CULLING)) {
+                uint32_t em = layer_mask ? layer_mask[i] : 1u;
+                const float* g = global + 12 * (size_t)i;
+                const float* c = aabb_center + 3 * (size_t)i;
+                /* has_visibility_range && visible_entity_ranges.is_some_and(|r| !r.entity_is_in_range_of_view(..)) */
+                int in_range = 1;
+                if ((fl & ORC_FLAG_HAS_VISIBILITY_RANGE) && range_start_end) {
+                    if (view->flags & ORC_VIEW_FLAG_RANGES_NO_ORIGIN) in_range = 0;
+                    else if (view->flags & ORC_VIEW_FLAG_RANGES)
+                        in_range = entity_in_range_of(g, c, fl, range_start_end + 2 * (size_t)i, view->position);
+                    else in_range = 0; /* the view has no index in VisibleEntityRanges::views */
+                }
+                if (view->flags & ORC_VIEW_FLAG_SHADOW)
+                    vis = (uint8_t)entity_visible_in_shadow_view(g, c, aabb_half + 3 * (size_t)i, fl, em, in_range, view);
+                else
+                    vis = (uint8_t)entity_visible_in_view(g, c, aabb_half + 3 * (size_t)i, fl, em, in_range, view->frustum,
+                                                          view->layer_mask,
+                                                          (view->flags & ORC_VIEW_FLAG_NO_CPU_CULLING) != 0);
+                if (vis) set_visible(&vv[i], vv_changed_out ? &vv_changed_out[i] : NULL);
+            }
+            if (visible_out) visible_out[(size_t)v * n + i] = vis;
+        }
+    }
+}
+
+int orc_visibility_propagate(uint32_t n, const uint32_t* parent, const uint8_t* visibility,
+                             uint8_t* inherited, uint8_t* changed_out) {
+    /* resolve in root-to-leaf order: depth of every row first (also detects cycles) */
+    uint32_t* depth = (uint32_t*)malloc((size_t)(n ? n : 1) * sizeof(uint32_t));
+    uint32_t* order = (uint32_t*)malloc((size_t)(n ? n : 1) * sizeof(uint32_t));
+    uint32_t maxd = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t d = 0, cur = i;
+        while (parent && parent[cur] != ORC_NO_PARENT) {
+            cur = parent[cur];
+            if (cur >= n || ++d > n) { free(depth); free(order); return -1; }
+        }
+        depth[i] = d;
+        if (d > maxd) maxd = d;
+    }
+    /* counting sort by depth */
+    uint32_t* start = (uint32_t*)calloc((size_t)maxd + 2, sizeof(uint32_t));
+    for (uint32_t i = 0; i < n; ++i) start[depth[i] + 1]++;
+    for (uint32_t d = 0; d <= maxd; ++d) start[d + 1] += start[d];
+    for (uint32_t i = 0; i < n; ++i) order[start[depth[i]]++] = i;
+    for (uint32_t k = 0; k < n; ++k) {
+        uint32_t i = order[k];
+        if (changed_out) changed_out[i] = 0;
+        uint8_t vis = visibility[i];
+        if (vis & 0x80u) continue; /* no Visibility / InheritedVisibility: never touched */
+        uint8_t is_visible;
+        if (vis == 2u) is_visible = 1;
+        else if (vis == 1u) is_visible = 0;
+        else {
+            uint32_t p = parent ? parent[i] : ORC_NO_PARENT;
+            /* "fall back to true if no parent is found or parent lacks components" (mod.rs:656-659) */
+            is_visible = (p == ORC_NO_PARENT || (visibility[p] & 0x80u)) ? 1 : (inherited[p] & 1u);
+        }
+        if ((inherited[i] & 1u) != is_visible) {
+            inherited[i] = is_visible;
+            if (changed_out) changed_out[i] = 1;
+        }
+    }
+    free(depth); free(order); free(start);
+    return 0;
+}
+
 void orc_check_visibility_gpu_culling(uint32_t n, const uint8_t* flags, uint8_t* vv, uint8_t* vv_changed_out) {
     for (uint32_t i = 0; i < n; ++i) {
         if (!(flags[i] & ORC_FLAG_NO_CPU_CULLING)) continue;

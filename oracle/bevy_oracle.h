@@ -46,8 +46,17 @@ extern "C" {
 #define ORC_FLAG_HAS_SPHERE          0x08u
 #define ORC_FLAG_NO_CPU_CULLING      0x10u
 #define ORC_FLAG_HAS_VISIBILITY_RANGE 0x20u
+#define ORC_FLAG_RANGE_USE_AABB      0x40u /* VisibilityRange::use_aabb */
+#define ORC_FLAG_SHADOW_CASTER       0x80u /* With<Mesh3d>, Without<NotShadowCaster>, Without<DirectionalLight> */
 
-#define ORC_VIEW_FLAG_NO_CPU_CULLING 0x01u
+/* per-view flags (same values as MI_VIEW_FLAG_*) */
+#define ORC_VIEW_FLAG_NO_CPU_CULLING 0x01u /* camera Has<NoCpuCulling> */
+#define ORC_VIEW_FLAG_SHADOW         0x02u /* a shadow view (cascade / cube face / spot), bevy_light/src/lib.rs:342-757 */
+#define ORC_VIEW_FLAG_SKIP_NEAR      0x04u /* intersects_obb(.., intersect_near = false, ..) */
+#define ORC_VIEW_FLAG_TEST_FAR       0x08u /* intersects_obb(.., .., intersect_far = true) */
+#define ORC_VIEW_FLAG_LIGHT_SPHERE   0x10u /* point/spot: light_sphere.intersects_obb pre-test */
+#define ORC_VIEW_FLAG_RANGES         0x20u /* VisibleEntityRanges exists and this view has an index in it */
+#define ORC_VIEW_FLAG_RANGES_NO_ORIGIN 0x40u /* point/spot with no shadow LOD origin: ranged entities are culled */
 
 #define ORC_NO_PARENT 0xFFFFFFFFu
 
@@ -147,6 +156,42 @@ void orc_check_visibility(uint32_t n, const float* global, const float* aabb_cen
                           const uint8_t* in_range, uint8_t* view_visibility, const float* frusta,
                           const uint32_t* view_layer_masks, const uint8_t* view_flags,
                           uint32_t n_views, uint8_t* visible_out, uint8_t* vv_changed_out);
+/* One view of any kind the main-world visibility systems test entities against. */
+typedef struct orc_view {
+    float frustum[24];
+    uint32_t layer_mask;
+    uint32_t flags;        /* ORC_VIEW_FLAG_* */
+    float position[3];     /* GlobalTransform::translation of the view used for VisibilityRange distances */
+    float light_sphere[4]; /* point/spot light: (translation, range) */
+} orc_view;
+
+/* check_visibility_ranges, crates/bevy_camera/src/visibility/range.rs:225-284.
+ *   range_start_end f32[2n]: (start_margin.start, end_margin.end) -- all is_visible_at_all (:159-161) reads
+ *   in_range_out u8[n_views*n]: VisibleEntityRanges::entity_is_in_range_of_view (0 for rows without a range) */
+void orc_check_visibility_ranges(uint32_t n, const float* global, const float* aabb_center,
+                                 const uint8_t* flags, const float* range_start_end,
+                                 const float* view_positions, uint32_t n_views, uint8_t* in_range_out);
+
+/* The per-entity closures of check_visibility_cpu_culling (visibility/mod.rs:788-858),
+ * check_dir_light_mesh_visibility (bevy_light/src/lib.rs:425-475) and check_point_light_mesh_visibility
+ * (lib.rs:592-650 cube faces, :694-738 spot), selected per view by orc_view.flags; every survivor calls
+ * set_visible().  Visibility ranges are evaluated from range_start_end and each view's position
+ * (range_start_end == NULL: no VisibleEntityRanges resource). */
+void orc_check_visibility_views(uint32_t n, const float* global, const float* aabb_center,
+                                const float* aabb_half, const uint8_t* flags, const uint32_t* layer_mask,
+                                const float* range_start_end, uint8_t* view_visibility,
+                                const orc_view* views, uint32_t n_views, uint8_t* visible_out,
+                                uint8_t* vv_changed_out);
+
+/* visibility_propagate_system + propagate_recursive, visibility/mod.rs:638-729, as the fixpoint they
+ * maintain: Visible -> true, Hidden -> false, Inherited -> the parent's InheritedVisibility (true without a
+ * parent or when the parent lacks the visibility components).
+ *   visibility u8[n]: 0 Inherited, 1 Hidden, 2 Visible, 0x80 = entity has no Visibility/InheritedVisibility
+ *   inherited  u8[n] in/out; changed_out u8[n] optional (1 where InheritedVisibility was assigned).
+ * Returns -1 on a cycle / out-of-range parent. */
+int orc_visibility_propagate(uint32_t n, const uint32_t* parent, const uint8_t* visibility,
+                             uint8_t* inherited, uint8_t* changed_out);
+
 /* check_visibility_gpu_culling, visibility/mod.rs:884-903 (applied to every NoCpuCulling row) */
 void orc_check_visibility_gpu_culling(uint32_t n, const uint8_t* flags, uint8_t* view_visibility,
                                       uint8_t* vv_changed_out);

@@ -19,6 +19,15 @@ FLAG_HAS_AABB = 0x04
 FLAG_HAS_SPHERE = 0x08
 FLAG_NO_CPU_CULLING = 0x10
 FLAG_HAS_VISIBILITY_RANGE = 0x20
+FLAG_RANGE_USE_AABB = 0x40
+FLAG_SHADOW_CASTER = 0x80
+VIEW_FLAG_NO_CPU_CULLING = 0x01
+VIEW_FLAG_SHADOW = 0x02
+VIEW_FLAG_SKIP_NEAR = 0x04
+VIEW_FLAG_TEST_FAR = 0x08
+VIEW_FLAG_LIGHT_SPHERE = 0x10
+VIEW_FLAG_RANGES = 0x20
+VIEW_FLAG_RANGES_NO_ORIGIN = 0x40
 NO_PARENT = 0xFFFFFFFF
 MAX_CLUSTER_DIM = 4096
 
@@ -55,6 +64,28 @@ class ClusterView(C.Structure):
         ("y_planes", C.c_float * ((MAX_CLUSTER_DIM + 1) * 4)),
         ("z_planes", C.c_float * ((MAX_CLUSTER_DIM + 1) * 4)),
     ]
+
+
+class View(C.Structure):
+    """orc_view"""
+    _fields_ = [("frustum", C.c_float * 24), ("layer_mask", C.c_uint32), ("flags", C.c_uint32),
+                ("position", C.c_float * 3), ("light_sphere", C.c_float * 4)]
+
+
+def make_views(frusta, layer_masks=None, flags=None, positions=None, light_spheres=None):
+    """-> ctypes array of orc_view from per-view numpy columns."""
+    fr = np.ascontiguousarray(frusta, np.float32).reshape(-1, 24)
+    nv = len(fr)
+    arr = (View * nv)()
+    for v in range(nv):
+        arr[v].frustum[:] = fr[v].tolist()
+        arr[v].layer_mask = int(layer_masks[v]) if layer_masks is not None else 1
+        arr[v].flags = int(flags[v]) if flags is not None else 0
+        if positions is not None:
+            arr[v].position[:] = np.asarray(positions, np.float32).reshape(-1, 3)[v].tolist()
+        if light_spheres is not None:
+            arr[v].light_sphere[:] = np.asarray(light_spheres, np.float32).reshape(-1, 4)[v].tolist()
+    return arr
 
 
 _lib = None
@@ -224,6 +255,37 @@ def check_visibility(g, c, h, flags, layers, vv, frusta, view_masks=None, view_f
     lib().orc_check_visibility(n, fp(g), fp(c), fp(h), u8p(flags), u32p(layers), u8p(in_range), u8p(vv),
                                fp(frusta), u32p(view_masks), u8p(view_flags), nv, u8p(vis), u8p(chg))
     return vv, vis.reshape(nv, n), chg
+
+
+def check_visibility_ranges(g, c, flags, range_start_end, view_positions):
+    n = len(flags)
+    vp = np.ascontiguousarray(view_positions, np.float32).reshape(-1)
+    nv = len(vp) // 3
+    out = np.zeros(nv * n, np.uint8)
+    lib().orc_check_visibility_ranges(n, fp(g), fp(c), u8p(flags), fp(range_start_end), fp(vp), nv, u8p(out))
+    return out.reshape(nv, n)
+
+
+def check_visibility_views(g, c, h, flags, layers, range_start_end, vv, views):
+    """views: ctypes array from make_views()."""
+    n = len(flags)
+    nv = len(views)
+    vv = vv.copy()
+    vis = np.zeros(nv * n, np.uint8)
+    chg = np.zeros(n, np.uint8)
+    lib().orc_check_visibility_views(n, fp(g), fp(c), fp(h), u8p(flags), u32p(layers), fp(range_start_end), u8p(vv),
+                                     views, nv, u8p(vis), u8p(chg))
+    return vv, vis.reshape(nv, n), chg
+
+
+def visibility_propagate(parent, visibility, inherited):
+    """-> (rc, inherited_after, changed)"""
+    n = len(visibility)
+    inh = np.ascontiguousarray(inherited, np.uint8).copy()
+    chg = np.zeros(n, np.uint8)
+    rc = lib().orc_visibility_propagate(n, u32p(np.ascontiguousarray(parent, np.uint32)) if parent is not None else None,
+                                        u8p(np.ascontiguousarray(visibility, np.uint8)), u8p(inh), u8p(chg))
+    return rc, inh, chg
 
 
 def check_visibility_gpu_culling(flags, vv):

@@ -315,3 +315,91 @@ def test_default_cluster_dims_1080p():
     assert O.cluster_dimensions_fixed_z(4096, 24, 1920, 1080) == (17, 9, 24)
     tile, dims = O.clusters_update(1920, 1080, (16, 9, 24))
     assert tile == (120, 120) and dims == (16, 9, 24)
+
+
+# ---------------------------------------------------------------- visibility/mod.rs:950-1282
+# visibility_propagate_system scenarios (Visibility: 0 Inherited, 1 Hidden, 2 Visible; 0x80 no components)
+INH, HID, VIS, NONE = 0, 1, 2, 0x80
+NP = O.NO_PARENT
+
+
+def _propagate(parent, vis, inherited=None):
+    inherited = np.zeros(len(vis), np.uint8) if inherited is None else inherited  # InheritedVisibility::default() = HIDDEN
+    rc, inh, chg = O.visibility_propagate(np.array(parent, np.uint32), np.array(vis, np.uint8), inherited)
+    assert rc == 0
+    return inh, chg
+
+
+def test_visibility_propagation_reference_tree():
+    # mod.rs:950-1037: root1 Hidden {child1 {gc}, child2 Hidden {gc}}, root2 Inherited {child1 {gc}, child2 Hidden {gc}}
+    parent = [NP, 0, 0, 1, 2, NP, 5, 5, 6, 7]
+    vis = [HID, INH, HID, INH, INH, INH, INH, HID, INH, INH]
+    inh, _ = _propagate(parent, vis)
+    assert inh.tolist() == [0, 0, 0, 0, 0, 1, 1, 0, 1, 0]
+
+
+def test_visibility_propagation_parent_change_and_removal():
+    # mod.rs:1040-1092: child2 re-parented from a Hidden to a Visible parent
+    vis = [HID, VIS, INH, INH]
+    inh, _ = _propagate([NP, NP, 0, 0], vis)
+    assert inh.tolist() == [0, 1, 0, 0]
+    inh, _ = _propagate([NP, NP, 0, 1], vis, inh)
+    assert inh.tolist() == [0, 1, 0, 1]
+    # mod.rs:1094-1125: ChildOf removed -> an inheriting entity without a parent is visible
+    inh, _ = _propagate([NP, 0], [HID, INH])
+    assert inh.tolist() == [0, 0]
+    inh, _ = _propagate([NP, NP], [HID, INH], inh)
+    assert inh.tolist() == [0, 1]
+
+
+def test_visibility_propagation_unconditional_visible():
+    # mod.rs:1127-1187
+    parent = [NP, 0, 0, 1, 2, NP, NP]
+    vis = [VIS, INH, HID, VIS, VIS, INH, HID]
+    inh, _ = _propagate(parent, vis)
+    assert inh.tolist() == [1, 1, 0, 1, 1, 1, 0]
+
+
+def test_visibility_propagation_change_detection():
+    # mod.rs:1189-1262: chain id1 -> id2 -> id3(Hidden) -> id4
+    parent = [NP, 0, 1, 2]
+    vis = [INH, INH, HID, INH]
+    inh, _ = _propagate(parent, vis)
+    assert inh.tolist() == [1, 1, 0, 0]
+    vis[0] = HID
+    inh, chg = _propagate(parent, vis, inh)
+    assert chg.tolist() == [1, 1, 0, 0]
+    inh, chg = _propagate(parent, vis, inh)
+    assert chg.tolist() == [0, 0, 0, 0]
+    vis[2] = INH
+    inh, chg = _propagate(parent, vis, inh)
+    assert chg.tolist() == [0, 0, 0, 0]
+    vis[1] = VIS
+    inh, chg = _propagate(parent, vis, inh)
+    assert chg.tolist() == [0, 1, 1, 1] and inh.tolist() == [0, 1, 1, 1]
+    inh, chg = _propagate(parent, vis, inh)
+    assert chg.tolist() == [0, 0, 0, 0]
+
+
+def test_visibility_propagation_with_invalid_parent():
+    # mod.rs:1264-1279: the parent has no visibility components
+    inh, _ = _propagate([NP, 0], [NONE, INH])
+    assert inh[1] == 1
+
+
+# ---------------------------------------------------------------- visibility/range.rs:159-161,225-284
+def test_visibility_range_is_visible_at_all():
+    g = np.tile(IDENT, 4)
+    g[9::12] = [0.0, 20.0, 24.999, 25.0]          # translations along x
+    c = np.zeros(12, F)
+    c[0::3] = 100.0                                # aabb centers far away (only used with use_aabb)
+    flags = np.array([O.FLAG_HAS_VISIBILITY_RANGE] * 4, np.uint8)
+    rng = np.tile(np.array([20.0, 25.0], F), 4)    # start_margin.start = 20, end_margin.end = 25
+    r = O.check_visibility_ranges(g, c, flags, rng, np.zeros(3, F))
+    assert r[0].tolist() == [0, 1, 1, 0]           # distance >= start && distance < end
+    flags2 = flags | np.uint8(O.FLAG_RANGE_USE_AABB | O.FLAG_HAS_AABB)
+    rng2 = np.tile(np.array([100.0, 126.0], F), 4)
+    r = O.check_visibility_ranges(g, c, flags2, rng2, np.zeros(3, F))
+    assert r[0].tolist() == [1, 1, 1, 1]           # model position = affine * aabb.center = 100 + tx
+    no_range = np.array([0, 0, 0, 0], np.uint8)
+    assert not O.check_visibility_ranges(g, c, no_range, rng, np.zeros(3, F)).any()

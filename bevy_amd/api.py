@@ -90,8 +90,8 @@ ABI_SYMBOLS = [
     "mi_download_visible_entities", "mi_cluster_view_dims", "mi_cluster_view_build",
     "mi_cluster_dimensions_fixed_z", "mi_cluster_assign", "mi_cluster_upload_objects", "mi_cluster_upload_view",
     "mi_cluster_assign_resident", "mi_cluster_download", "mi_perspective_clip_from_view", "mi_compute_frustum",
-    "mi_bind_visibility_output", "mi_device_buffer", "mi_timer_begin", "mi_timer_end", "mi_profile_enable",
-    "mi_profile_filter", "mi_profile_read", "mi_profile_kernel_name",
+    "mi_bind_visibility_output", "mi_exchange_configure", "mi_exchange_last", "mi_device_buffer", "mi_timer_begin", "mi_timer_end", "mi_profile_enable",
+    "mi_profile_filter", "mi_profile_sample", "mi_profile_read", "mi_profile_kernel_name",
 ]
 
 
@@ -119,9 +119,20 @@ def load_library():
     return lib
 
 
+class PreparedFrusta:
+    """A frusta array converted once (contiguous f32 + its ctypes pointer) for per-frame calls."""
+
+    def __init__(self, frusta):
+        self.array = np.ascontiguousarray(frusta, dtype=np.float32).reshape(-1)
+        self.n_views = len(self.array) // 24
+        self.pointer = self.array.ctypes.data_as(C.POINTER(C.c_float))
+
+
 def _ptr(a, ty):
     if a is None:
         return None
+    if isinstance(a, PreparedFrusta):
+        return a.pointer
     assert isinstance(a, np.ndarray) and a.flags["C_CONTIGUOUS"], "need a C-contiguous numpy array"
     return a.ctypes.data_as(C.POINTER(ty))
 
@@ -318,6 +329,9 @@ class Context:
         self._ck(self._lib.mi_visibility_end_frame(self._h))
 
     def _views(self, frusta, view_masks, view_flags):
+        if isinstance(frusta, PreparedFrusta):  # per-frame hot path: no numpy work
+            self.n_views = frusta.n_views
+            return frusta, _u32(view_masks), _u8(view_flags), frusta.n_views
         fr = _f32(frusta).reshape(-1)
         nv = len(fr) // 24
         self.n_views = nv
@@ -411,6 +425,19 @@ class Context:
         self._ck(self._lib.mi_bind_visibility_output(self._h, C.c_void_p(device_ptr), C.c_uint64(words_per_view),
                                                      C.c_uint64(word_offset)))
 
+    def exchange_configure(self, comm, fn_all_gather, bufs, words_per_view, word_offset, block_bytes, rank):
+        """bufs: list of device pointers of the gathered buffers (None / empty with comm=None switches it off)."""
+        bufs = list(bufs or [])
+        arr = (C.c_void_p * max(len(bufs), 1))(*bufs)
+        self._ck(self._lib.mi_exchange_configure(self._h, C.c_void_p(comm), C.c_void_p(fn_all_gather), arr, len(bufs),
+                                                 C.c_uint64(words_per_view), C.c_uint64(word_offset),
+                                                 C.c_uint64(block_bytes), C.c_uint32(rank)))
+
+    def exchange_last(self, wait=True):
+        p = C.c_void_p()
+        self._ck(self._lib.mi_exchange_last(self._h, C.byref(p), 1 if wait else 0))
+        return p.value
+
     def device_buffer(self, which):
         p = C.c_void_p()
         nbytes = C.c_uint64(0)
@@ -444,6 +471,9 @@ class Context:
                     mask |= 1 << k
                 k += 1
         self._ck(self._lib.mi_profile_filter(self._h, C.c_uint64(mask)))
+
+    def profile_sample(self, every_n=1):
+        self._ck(self._lib.mi_profile_sample(self._h, int(every_n)))
 
     def profile_read(self):
         n = C.c_uint32(64)

@@ -12,8 +12,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <numeric>
+#include <chrono>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -87,6 +92,33 @@ struct mi_ctx {
     uint32_t n_views = 0;
     DevBuf bitmask;
     uint64_t words_per_view = 0;
+    // multi-GPU exchange (mi_exchange_configure): in-place all-gather of the masks after every cull
+    struct Exchange {
+        bool on = false;
+        int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;  // ncclAllGather
+        void* comm = nullptr;
+        static constexpr uint32_t MAX_BUFS = 8;
+        uint32_t n_bufs = 0;
+        void* buf[MAX_BUFS] = {nullptr};
+        uint64_t words_per_view = 0, word_offset = 0, block_bytes = 0;
+        uint32_t rank = 0;
+        uint64_t frame = 0;
+        hipStream_t comm_stream = nullptr;
+        hipEvent_t ev_kernels[MAX_BUFS] = {nullptr}, ev_gathered[MAX_BUFS] = {nullptr};
+        // The collective is enqueued by a library-owned host thread: RCCL's enqueue path costs tens of
+        // microseconds of CPU per call, which would otherwise sit in the frame's critical path on the caller's
+        // thread.  The caller's thread never runs more than two frames ahead of it.
+        std::thread worker;
+        std::mutex m;
+        std::condition_variable cv;
+        std::deque<uint32_t> queue;
+        bool stop = false;
+        uint64_t submitted = 0, issued = 0;  // guarded by m
+        uint64_t worker_frames = 0;          // exchange thread only
+        int worker_error = 0;
+        volatile uint32_t* done_flag = nullptr;  // pinned host word: number of frames whose all-gather has completed
+        double dbg_wait_ns = 0, dbg_begin_ns = 0, dbg_end_ns = 0, dbg_worker_ns = 0;  // MI_XCH_DEBUG
+    } xch;
     void* ext_bitmask = nullptr;
     uint64_t ext_words_per_view = 0, ext_word_offset = 0;
     bool culled = false;
@@ -112,6 +144,7 @@ struct mi_ctx {
     hipEvent_t timer_a = nullptr, timer_b = nullptr;
     bool profiling = false;
     uint64_t prof_mask = ~0ull;
+    uint32_t prof_every = 1, prof_tick[K_NUM_KERNELS] = {0};  // time every n-th launch of a kernel
     std::vector<ProfSpan> spans;
     bool span_open = false;
     uint64_t prof_launches[K_NUM_KERNELS] = {0};
@@ -261,6 +294,7 @@ struct ProfScope {
     bool armed = false;
     ProfScope(mi_ctx* c, uint32_t k) : ctx(c) {
         if (!c->profiling || k >= K_NUM_KERNELS || !((c->prof_mask >> k) & 1ull)) return;
+        if (c->prof_every > 1 && (c->prof_tick[k]++ % c->prof_every) != 0) return;
         prof_close(c);
         ProfSpan sp;
         sp.kernel = k;
@@ -457,6 +491,110 @@ int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg) 
     return MI_OK;
 }
 
+// Multi-GPU exchange around a cull: bind this frame's gathered buffer (after its previous all-gather drained),
+// and afterwards hand the in-place all-gather to the exchange thread, which enqueues it on the communication
+// stream behind the kernels.
+void exchange_worker(mi_ctx* ctx) {
+    auto& x = ctx->xch;
+    hipSetDevice(ctx->device);
+    for (;;) {
+        uint32_t slot;
+        {
+            std::unique_lock<std::mutex> lk(x.m);
+            x.cv.wait(lk, [&] { return x.stop || !x.queue.empty(); });
+            if (x.queue.empty()) return;  // stop requested and drained
+            slot = x.queue.front();
+            x.queue.pop_front();
+        }
+        int err = 0;
+        const auto tw0 = std::chrono::steady_clock::now();
+        if (hipStreamWaitEvent(x.comm_stream, x.ev_kernels[slot], 0) != hipSuccess) err = -1;
+        char* base = (char*)x.buf[slot];
+        if (!err) err = x.all_gather(base + (size_t)x.rank * x.block_bytes, base, (size_t)x.block_bytes, 1 /* ncclUint8 */, x.comm,
+                                     x.comm_stream);
+        if (hipEventRecord(x.ev_gathered[slot], x.comm_stream) != hipSuccess && !err) err = -2;
+        // completion counter the caller's thread can read without a driver call
+        if (hipStreamWriteValue32(x.comm_stream, (void*)x.done_flag, (uint32_t)(x.worker_frames + 1), 0) != hipSuccess && !err) err = -3;
+        ++x.worker_frames;
+        x.dbg_worker_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tw0).count();
+        {
+            std::lock_guard<std::mutex> lk(x.m);
+            if (err && !x.worker_error) x.worker_error = err;
+            ++x.issued;
+        }
+        x.cv.notify_all();
+    }
+}
+// blocks until the exchange thread has enqueued the collectives of frames < upto
+int32_t exchange_wait_issued(mi_ctx* ctx, uint64_t upto) {
+    auto& x = ctx->xch;
+    std::unique_lock<std::mutex> lk(x.m);
+    x.cv.wait(lk, [&] { return x.issued >= upto || x.worker_error; });
+    if (x.worker_error) return fail(ctx, MI_ERR_DEVICE, "exchange thread: ncclAllGather / HIP call failed (%d)", x.worker_error);
+    return MI_OK;
+}
+void exchange_stop(mi_ctx* ctx) {
+    auto& x = ctx->xch;
+    if (x.worker.joinable()) {
+        {
+            std::lock_guard<std::mutex> lk(x.m);
+            x.stop = true;
+        }
+        x.cv.notify_all();
+        x.worker.join();
+    }
+    x.stop = false;
+}
+int32_t exchange_begin(mi_ctx* ctx) {
+    auto& x = ctx->xch;
+    if (!x.on) return MI_OK;
+    const uint32_t slot = (uint32_t)(x.frame % x.n_bufs);
+    const auto tb0 = std::chrono::steady_clock::now();
+    struct Acc { double& d; std::chrono::steady_clock::time_point t; ~Acc() { d += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t).count(); } } acc{x.dbg_begin_ns, tb0};
+    if (x.frame >= x.n_bufs) {
+        // This buffer was last used n_bufs frames ago and its all-gather must have completed before the kernels
+        // overwrite it.  The dependency is enforced on the HOST (the communication stream bumps a pinned counter
+        // behind every all-gather), not with a cross-stream wait: a barrier packet on the compute queue costs
+        // ~6 us of GPU time per frame, while pacing the caller n_bufs - 1 frames ahead of the exchange costs
+        // nothing as long as the next frame is already queued.
+        const uint64_t need = x.frame - x.n_bufs + 1;
+        uint32_t spins = 0;
+        while ((uint64_t)*x.done_flag < need) {
+            if ((++spins & 1023u) == 0) {
+                {
+                    std::lock_guard<std::mutex> lk(x.m);
+                    if (x.worker_error) return fail(ctx, MI_ERR_DEVICE, "exchange thread: ncclAllGather / HIP call failed (%d)", x.worker_error);
+                }
+                if (std::chrono::steady_clock::now() - tb0 > std::chrono::seconds(30))
+                    return fail(ctx, MI_ERR_DEVICE, "exchange: the all-gather of frame %llu did not complete within 30 s",
+                                (unsigned long long)(need - 1));
+                std::this_thread::yield();
+            }
+        }
+        x.dbg_wait_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tb0).count();
+    }
+    ctx->ext_bitmask = x.buf[slot];
+    ctx->ext_words_per_view = x.words_per_view;
+    ctx->ext_word_offset = x.word_offset;
+    return MI_OK;
+}
+int32_t exchange_end(mi_ctx* ctx) {
+    auto& x = ctx->xch;
+    if (!x.on) return MI_OK;
+    const uint32_t slot = (uint32_t)(x.frame % x.n_bufs);
+    const auto te0 = std::chrono::steady_clock::now();
+    HIP_TRY(ctx, hipEventRecord(x.ev_kernels[slot], ctx->stream));
+    {
+        std::lock_guard<std::mutex> lk(x.m);
+        x.queue.push_back(slot);
+        ++x.submitted;
+    }
+    x.cv.notify_all();
+    ++x.frame;
+    x.dbg_end_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - te0).count();
+    return MI_OK;
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -531,6 +669,20 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
     if (ctx->stage) hipHostFree(ctx->stage);
     if (ctx->timer_a) hipEventDestroy(ctx->timer_a);
     if (ctx->timer_b) hipEventDestroy(ctx->timer_b);
+    exchange_stop(ctx);
+    if (getenv("MI_XCH_DEBUG") && ctx->xch.frame)
+        fprintf(stderr, "[mi exchange] frames %llu: begin %.2f us (wait-issued %.2f us), end %.2f us, worker %.2f us per frame\n",
+                (unsigned long long)ctx->xch.frame, ctx->xch.dbg_begin_ns / ctx->xch.frame / 1e3, ctx->xch.dbg_wait_ns / ctx->xch.frame / 1e3,
+                ctx->xch.dbg_end_ns / ctx->xch.frame / 1e3, ctx->xch.dbg_worker_ns / ctx->xch.frame / 1e3);
+    if (ctx->xch.comm_stream) {
+        hipStreamSynchronize(ctx->xch.comm_stream);
+        for (uint32_t i = 0; i < mi_ctx::Exchange::MAX_BUFS; ++i) {
+            if (ctx->xch.ev_kernels[i]) hipEventDestroy(ctx->xch.ev_kernels[i]);
+            if (ctx->xch.ev_gathered[i]) hipEventDestroy(ctx->xch.ev_gathered[i]);
+        }
+        hipStreamDestroy(ctx->xch.comm_stream);
+        if (ctx->xch.done_flag) hipHostFree((void*)ctx->xch.done_flag);
+    }
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return MI_OK;
@@ -547,6 +699,11 @@ const char* mi_last_error_string(mi_ctx* ctx) {
 int32_t mi_synchronize(mi_ctx* ctx) {
     ENTER(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->xch.on) {
+        int32_t rc = exchange_wait_issued(ctx, ctx->xch.frame);
+        if (rc) return rc;
+    }
+    if (ctx->xch.comm_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->xch.comm_stream));
     return MI_OK;
 }
 
@@ -935,8 +1092,9 @@ void simple_views(std::vector<mi_view>& v, const float* frusta, const uint32_t* 
 int32_t mi_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint32_t flags) {
     ENTER(ctx);
     VisibilityOut vo{};
-    int32_t rc = prepare_views(ctx, views, n_views, &vo);
+    int32_t rc = exchange_begin(ctx);
     if (rc) return rc;
+    if ((rc = prepare_views(ctx, views, n_views, &vo))) return rc;
     SegOut seg;
     if ((rc = prepare_segments(ctx, n_views, &seg))) return rc;
     Columns c = columns_of(ctx);
@@ -947,7 +1105,7 @@ int32_t mi_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint3
     }
     if ((rc = run_compaction(ctx, vo, seg))) return rc;
     ctx->culled = true;
-    return MI_OK;
+    return exchange_end(ctx);
 }
 
 int32_t mi_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_masks, const uint8_t* view_flags,
@@ -962,8 +1120,9 @@ int32_t mi_propagate_and_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t 
     if (ctx->have_hierarchy)
         return fail(ctx, MI_ERR_NOT_READY, "mi_propagate_and_cull is the flat fast path; a hierarchy is uploaded -- use mi_propagate + mi_cull");
     VisibilityOut vo{};
-    int32_t rc = prepare_views(ctx, views, n_views, &vo);
+    int32_t rc = exchange_begin(ctx);
     if (rc) return rc;
+    if ((rc = prepare_views(ctx, views, n_views, &vo))) return rc;
     SegOut seg;
     if ((rc = prepare_segments(ctx, n_views, &seg))) return rc;
     Columns c = columns_of(ctx);
@@ -976,7 +1135,7 @@ int32_t mi_propagate_and_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t 
     if (ctx->have_changed) HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, ctx->n, ctx->stream));
     ctx->g_chg_in_bytes = false;
     ctx->culled = true;
-    return MI_OK;
+    return exchange_end(ctx);
 }
 
 int32_t mi_propagate_and_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_masks, const uint8_t* view_flags,
@@ -1304,6 +1463,67 @@ int32_t mi_bind_visibility_output(mi_ctx* ctx, void* device_ptr, uint64_t words_
     return MI_OK;
 }
 
+int32_t mi_exchange_configure(mi_ctx* ctx, void* nccl_comm, void* fn_nccl_all_gather, void* const* device_bufs, uint32_t n_bufs,
+                              uint64_t words_per_view, uint64_t word_offset, uint64_t block_bytes, uint32_t rank) {
+    ENTER(ctx);
+    auto& x = ctx->xch;
+    if (x.on) {  // drain whatever is in flight before changing anything
+        int32_t rc0 = exchange_wait_issued(ctx, x.frame);
+        exchange_stop(ctx);
+        if (x.comm_stream) HIP_TRY(ctx, hipStreamSynchronize(x.comm_stream));
+        x.on = false;
+        if (rc0) return rc0;
+    }
+    if (!nccl_comm) {  // off: back to the internal mask buffer
+        x.on = false;
+        ctx->ext_bitmask = nullptr;
+        ctx->culled = false;
+        return MI_OK;
+    }
+    if (!fn_nccl_all_gather || !device_bufs || n_bufs < 2 || n_bufs > mi_ctx::Exchange::MAX_BUFS || block_bytes == 0)
+        return fail(ctx, MI_ERR_INVALID_ARG, "mi_exchange_configure: NULL function / buffers, n_bufs outside 2..8, or empty block");
+    for (uint32_t i = 0; i < n_bufs; ++i)
+        if (!device_bufs[i]) return fail(ctx, MI_ERR_INVALID_ARG, "mi_exchange_configure: buffer %u is NULL", i);
+    if (!x.comm_stream) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&x.comm_stream, hipStreamNonBlocking));
+        for (uint32_t i = 0; i < mi_ctx::Exchange::MAX_BUFS; ++i) {
+            HIP_TRY(ctx, hipEventCreateWithFlags(&x.ev_kernels[i], hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&x.ev_gathered[i], hipEventDisableTiming));
+        }
+    }
+    x.all_gather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))fn_nccl_all_gather;
+    x.comm = nccl_comm;
+    x.n_bufs = n_bufs;
+    for (uint32_t i = 0; i < n_bufs; ++i) x.buf[i] = device_bufs[i];
+    x.words_per_view = words_per_view;
+    x.word_offset = word_offset;
+    x.block_bytes = block_bytes;
+    x.rank = rank;
+    if (!x.done_flag) HIP_TRY(ctx, hipHostMalloc((void**)&x.done_flag, 64, hipHostMallocMapped));
+    *x.done_flag = 0;
+    x.worker_frames = 0;
+    x.frame = 0;
+    x.submitted = x.issued = 0;
+    x.worker_error = 0;
+    x.queue.clear();
+    x.worker = std::thread(exchange_worker, ctx);
+    x.on = true;
+    ctx->culled = false;
+    return MI_OK;
+}
+
+int32_t mi_exchange_last(mi_ctx* ctx, void** out_device_buf, int32_t wait) {
+    ENTER(ctx);
+    auto& x = ctx->xch;
+    if (!x.on || x.frame == 0) return fail(ctx, MI_ERR_NOT_READY, "mi_exchange_last: no exchanged frame yet");
+    const uint32_t slot = (uint32_t)((x.frame - 1) % x.n_bufs);
+    int32_t rc = exchange_wait_issued(ctx, x.frame);
+    if (rc) return rc;
+    if (wait) HIP_TRY(ctx, hipEventSynchronize(x.ev_gathered[slot]));
+    if (out_device_buf) *out_device_buf = x.buf[slot];
+    return MI_OK;
+}
+
 int32_t mi_device_buffer(mi_ctx* ctx, uint32_t which, void** out_ptr, uint64_t* out_bytes) {
     ENTER(ctx);
     if (!out_ptr) return fail(ctx, MI_ERR_INVALID_ARG, "mi_device_buffer: NULL");
@@ -1353,6 +1573,12 @@ int32_t mi_profile_enable(mi_ctx* ctx, int32_t enabled) {
 int32_t mi_profile_filter(mi_ctx* ctx, uint64_t kernel_mask) {
     ENTER(ctx);
     ctx->prof_mask = kernel_mask ? kernel_mask : ~0ull;
+    return MI_OK;
+}
+int32_t mi_profile_sample(mi_ctx* ctx, uint32_t every_n) {
+    ENTER(ctx);
+    ctx->prof_every = every_n ? every_n : 1;
+    memset(ctx->prof_tick, 0, sizeof ctx->prof_tick);
     return MI_OK;
 }
 int32_t mi_profile_read(mi_ctx* ctx, uint32_t* inout_n, uint64_t* launches, double* total_ms) {

@@ -7,6 +7,8 @@ all_gather_into_tensor on an in-place layout, no bucketing.
 Layout of the gathered buffer (uint64 words): [world][n_views][words_per_shard]; rank r's kernels write
 straight into block r (mi_bind_visibility_output), so the collective is in place and needs no packing pass.
 """
+import os
+
 import numpy as np
 
 ROW_ALIGN = 256  # one workgroup; keeps every shard's first row on a 64-bit mask word boundary
@@ -47,6 +49,167 @@ def all_gather_visibility(full, n_rows, world, n_views, rank, group=None):
         return full
     dist.all_gather_into_tensor(full, full[rank * blk:(rank + 1) * blk], group=group)
     return full
+
+
+class MaskGatherer:
+    """The per-frame exchange, pipelined: frame f's all-gather runs on its own HIP stream while the kernels of the
+    following frames run on the compute stream (n_bufs gathered buffers rotate), so a step costs
+    max(kernels, collective), not their sum.  The collective is ONE in-place all-gather per frame.
+
+    On GPUs it is issued by calling RCCL directly (ncclAllGather through ctypes on the library torch already
+    loaded): the masks are ~125 KB per GPU, so the exchange is latency-bound and torch.distributed's Python
+    dispatch (tens of microseconds per call) would otherwise be the longest thing in the frame.  The communicator
+    is bootstrapped with torch.distributed (the ncclUniqueId is broadcast from rank 0) and checked once against a
+    known pattern; if anything in that path fails the gatherer falls back to dist.all_gather_into_tensor.
+    On CPU tensors (gloo tests) it always uses torch.distributed.
+    """
+
+    def __init__(self, n_rows, world, n_views, rank, device=None, direct=True, group=None, n_bufs=4):
+        import torch
+        self.torch = torch
+        self.world, self.rank, self.n_views, self.n_rows, self.group = world, rank, n_views, n_rows, group
+        self.w = words_per_shard(n_rows, world)
+        self.block = n_views * self.w                       # int64 words per rank
+        self.on_gpu = device is not None and torch.device(device).type == "cuda"
+        dev = device if device is not None else "cpu"
+        self.n_bufs = n_bufs
+        self.bufs = [torch.zeros(world * self.block, dtype=torch.int64, device=dev) for _ in range(n_bufs)]
+        self.comm_stream = torch.cuda.Stream() if self.on_gpu else None
+        self.ev_kernels = [torch.cuda.Event() for _ in range(n_bufs)] if self.on_gpu else None
+        self.ev_gathered = [torch.cuda.Event() for _ in range(n_bufs)] if self.on_gpu else None
+        self.rccl = None
+        self.native = False
+        self.mode = "torch.distributed"
+        self.fallback_reason = None
+        if self.on_gpu and direct and os.environ.get("MI_DIRECT_RCCL", "1") != "0":
+            ok = 1
+            try:
+                self._init_rccl()
+                self._self_check()
+            except Exception as e:  # noqa: BLE001 -- any failure here means "use the portable path"
+                ok = 0
+                self.fallback_reason = repr(e)
+            if world > 1:  # every rank must take the same path
+                import torch.distributed as dist
+                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                ok = int(flag.item())
+            if ok:
+                self.mode = "rccl-direct"
+            else:
+                self.rccl = None
+                self.fallback_reason = self.fallback_reason or "another rank failed to set up direct RCCL"
+
+    def attach(self, ctx):
+        """Hands the per-frame exchange to the library (mi_exchange_configure): one FFI call per frame then does
+        bind + kernels + events + ncclAllGather natively.  Only in rccl-direct mode; returns whether it did."""
+        if self.rccl is None:
+            return False
+        import ctypes as C
+        fn = C.cast(self.rccl.ncclAllGather, C.c_void_p).value
+        ctx.exchange_configure(self.comm.value, fn, [b.data_ptr() for b in self.bufs], self.w, self.rank * self.block,
+                               self.block * 8, self.rank)
+        self.mode = "rccl-native"
+        self.native = True
+        return True
+
+    # -- layout -------------------------------------------------------------------------------------
+    def bind_args(self, frame):
+        """(device_ptr, words_per_view, word_offset) for mi_bind_visibility_output of this frame's buffer."""
+        return self.bufs[frame % self.n_bufs].data_ptr(), self.w, self.rank * self.block
+
+    def buffer(self, frame):
+        return self.bufs[frame % self.n_bufs]
+
+    # -- direct RCCL ----------------------------------------------------------------------------------
+    def _init_rccl(self):
+        import ctypes as C
+        torch = self.torch
+        import torch.distributed as dist
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        lib = C.CDLL(path if os.path.exists(path) else "librccl.so")
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+        lib.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+        lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+        lib.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        lib.ncclCommDestroy.argtypes = [C.c_void_p]
+        lib.ncclGetErrorString.restype = C.c_char_p
+        uid = UniqueId()
+        t = torch.zeros(129, dtype=torch.uint8, device=self.bufs[0].device)  # 128 id bytes + "rank 0 has an id"
+        if self.rank == 0 and lib.ncclGetUniqueId(C.byref(uid)) == 0:
+            t[:128].copy_(torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8))
+            t[128] = 1
+        if self.world > 1:
+            dist.broadcast(t, 0, group=self.group)  # always reached by every rank
+        host = t.cpu().numpy()
+        if host[128] != 1:
+            raise RuntimeError("ncclGetUniqueId failed on rank 0")
+        C.memmove(C.byref(uid), host[:128].tobytes(), 128)
+        comm = C.c_void_p()
+        rc = lib.ncclCommInitRank(C.byref(comm), self.world, uid, self.rank)
+        if rc:
+            raise RuntimeError(f"ncclCommInitRank: {lib.ncclGetErrorString(rc)}")
+        self.rccl, self.comm = lib, comm
+
+    def _rccl_all_gather(self, buf, stream_handle):
+        nbytes = self.block * 8
+        base = buf.data_ptr()
+        rc = self.rccl.ncclAllGather(base + self.rank * nbytes, base, nbytes, 1, self.comm, stream_handle)  # 1 = ncclUint8
+        if rc:
+            raise RuntimeError(f"ncclAllGather: {self.rccl.ncclGetErrorString(rc)}")
+
+    def _self_check(self):
+        torch = self.torch
+        buf = self.bufs[0]
+        buf.zero_()
+        buf[self.rank * self.block:(self.rank + 1) * self.block] = self.rank + 1
+        torch.cuda.current_stream().synchronize()
+        self._rccl_all_gather(buf, self.comm_stream.cuda_stream)
+        self.comm_stream.synchronize()
+        expect = torch.arange(1, self.world + 1, dtype=torch.int64, device=buf.device).repeat_interleave(self.block)
+        if not torch.equal(buf, expect):
+            raise RuntimeError("direct RCCL all-gather self-check mismatch")
+        buf.zero_()
+        torch.cuda.current_stream().synchronize()
+
+    # -- per frame ------------------------------------------------------------------------------------
+    def before_kernels(self, frame, compute_stream=None):
+        """The buffer of this frame was last used two frames ago: its all-gather must have drained."""
+        if self.on_gpu:
+            (compute_stream or self.torch.cuda.current_stream()).wait_event(self.ev_gathered[frame % self.n_bufs])
+
+    def after_kernels(self, frame, compute_stream=None):
+        """Enqueue this frame's all-gather behind its kernels, on the communication stream."""
+        i = frame % self.n_bufs
+        buf = self.bufs[i]
+        if not self.on_gpu:
+            if self.world > 1:
+                import torch.distributed as dist
+                dist.all_gather_into_tensor(buf, buf[self.rank * self.block:(self.rank + 1) * self.block].clone(), group=self.group)
+            return buf
+        cs = compute_stream or self.torch.cuda.current_stream()
+        self.ev_kernels[i].record(cs)
+        self.comm_stream.wait_event(self.ev_kernels[i])
+        if self.rccl is not None:
+            self._rccl_all_gather(buf, self.comm_stream.cuda_stream)
+        elif self.world > 1:
+            import torch.distributed as dist
+            with self.torch.cuda.stream(self.comm_stream):
+                dist.all_gather_into_tensor(buf, buf[self.rank * self.block:(self.rank + 1) * self.block], group=self.group)
+        self.ev_gathered[i].record(self.comm_stream)
+        return buf
+
+    def synchronize(self):
+        if self.on_gpu:
+            self.comm_stream.synchronize()
+
+    def close(self):
+        if self.rccl is not None:
+            self.synchronize()
+            self.rccl.ncclCommDestroy(self.comm)
+            self.rccl = None
 
 
 def unpack_view(full_words, n_rows, world, n_views, view):

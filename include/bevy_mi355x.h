@@ -354,6 +354,24 @@ int32_t mi_compute_frustum(const float clip_from_view[16], const float camera_af
  * Pass device_ptr = NULL to go back to the internal buffer. */
 int32_t mi_bind_visibility_output(mi_ctx* ctx, void* device_ptr, uint64_t words_per_view, uint64_t word_offset);
 
+/* The exchange itself, issued by the library: after every mi_cull / mi_propagate_and_cull the packed masks are
+ * all-gathered IN PLACE across the ranks of an RCCL communicator.  The kernels write frame f's masks straight into
+ * gathered buffer f % n_bufs; a library-owned host thread enqueues ncclAllGather on a library-owned communication
+ * stream behind them (RCCL's enqueue costs tens of microseconds of CPU, kept off the caller's thread), so frame f's
+ * collective overlaps the kernels of the following frames.  A buffer is reused n_bufs frames later; that dependency
+ * is enforced by pacing the CALLER (it blocks until the all-gather of frame f - n_bufs has completed, normally
+ * never), not by a cross-stream wait in the compute stream.  One FFI call per frame does everything.
+ *   nccl_comm            ncclComm_t of this rank (created by the host: ncclCommInitRank); NULL switches it off
+ *   fn_nccl_all_gather   address of ncclAllGather in the RCCL library the communicator belongs to
+ *   device_bufs[n_bufs]  2..8 [world][n_views][words_per_view] uint64 buffers on this device (3+ recommended)
+ *   word_offset          rank * n_views * words_per_view;  block_bytes = n_views * words_per_view * 8
+ * The reference has no counterpart (single process); this replaces nothing and adds the only collective. */
+int32_t mi_exchange_configure(mi_ctx* ctx, void* nccl_comm, void* fn_nccl_all_gather, void* const* device_bufs,
+                              uint32_t n_bufs, uint64_t words_per_view, uint64_t word_offset, uint64_t block_bytes,
+                              uint32_t rank);
+/* The gathered buffer of the most recent frame (optionally after waiting for its collective). */
+int32_t mi_exchange_last(mi_ctx* ctx, void** out_device_buf, int32_t wait);
+
 /* Raw device pointers of library-owned columns, for zero-copy consumers on the same device
  * (e.g. the render world's mesh-uniform builder).  Valid until the next mi_columns_resize. */
 #define MI_BUF_GLOBAL_TRANSFORM 0
@@ -373,6 +391,8 @@ int32_t mi_profile_enable(mi_ctx* ctx, int32_t enabled);
 /* Restricts the profile to the kernels whose id bit is set in kernel_mask (default: all).  Bracketing only
  * the dominant kernel keeps the event overhead out of a timed region. */
 int32_t mi_profile_filter(mi_ctx* ctx, uint64_t kernel_mask);
+/* Times only every n-th launch of each selected kernel (a timed launch costs several microseconds of host time). */
+int32_t mi_profile_sample(mi_ctx* ctx, uint32_t every_n);
 int32_t mi_profile_read(mi_ctx* ctx, uint32_t* inout_n, uint64_t* launches, double* total_ms);
 const char* mi_profile_kernel_name(uint32_t k);
 

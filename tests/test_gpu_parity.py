@@ -496,3 +496,56 @@ def test_one_million_flat_entities(ctx_factory):
     assert 0.01 < frac < 0.15, frac
     k, rows = ctx.download_visible_entities(0, 0)
     assert np.array_equal(rows, np.nonzero(vis_exp[0])[0].astype(np.uint32))
+
+
+def test_mask_gatherer_single_rank_pipeline(ctx_factory):
+    """The pipelined exchange bench.py uses for N > 1, on one rank: kernels write their masks in place into the
+    gatherer's alternating buffers and the (1-rank) all-gather runs on the communication stream -- through RCCL
+    directly when the library can be set up on this box, else through torch.distributed."""
+    import torch
+    from bevy_amd import sharding
+    n, n_views = 20_000, 2
+    sc = W.many_cubes(n, ragged_flags=True)
+    ctx = ctx_factory()
+    upload_scene(ctx, sc)
+    g = sharding.MaskGatherer(n, 1, n_views, 0, device=torch.device("cuda", 0))
+    assert g.mode in ("rccl-direct", "torch.distributed"), g.mode
+    vv = np.zeros(n, np.uint8)
+    outs = []
+    for frame in range(4):
+        frusta = frusta_for([W.many_cubes_camera(frame * 30), W.many_cubes_camera(frame * 30, yaw=1.3)])
+        g.before_kernels(frame)
+        ctx.bind_visibility_output(*g.bind_args(frame))
+        ctx.propagate_and_cull(frusta, flags=B.CULL_END_FRAME)
+        ctx.synchronize()                      # the context runs on its own stream in this test
+        buf = g.after_kernels(frame)
+        _, vv, vis_exp, _ = oracle_frame(sc, vv, frusta, None, None)
+        outs.append((buf, vis_exp))
+        for v in range(n_views):
+            assert_bits(ctx.download_visibility(v), vis_exp[v], f"frame {frame} view {v}")
+    g.synchronize()
+    for frame in (2, 3):                       # recent frames are still resident in the rotating buffers
+        buf, vis_exp = outs[frame]
+        words = buf.cpu().numpy()
+        for v in range(n_views):
+            assert_bits(sharding.unpack_view(words, n, 1, n_views, v), vis_exp[v], f"gathered frame {frame} view {v}")
+    # the same exchange issued natively by the library (mi_exchange_configure), when RCCL could be set up
+    ctx2 = ctx_factory()
+    upload_scene(ctx2, sc)
+    if g.attach(ctx2):
+        assert g.mode == "rccl-native"
+        vv = np.zeros(n, np.uint8)
+        for frame in range(5):
+            frusta = frusta_for([W.many_cubes_camera(frame * 30), W.many_cubes_camera(frame * 30, yaw=1.3)])
+            ctx2.propagate_and_cull(frusta, flags=B.CULL_END_FRAME)
+            _, vv, vis_exp, _ = oracle_frame(sc, vv, frusta, None, None)
+            ptr = ctx2.exchange_last(wait=True)
+            assert ptr == g.buffer(frame).data_ptr()
+            words = g.buffer(frame).cpu().numpy()
+            for v in range(n_views):
+                assert_bits(sharding.unpack_view(words, n, 1, n_views, v), vis_exp[v], f"native exchange frame {frame} view {v}")
+                assert_bits(ctx2.download_visibility(v), vis_exp[v], f"native exchange download frame {frame} view {v}")
+        ctx2.exchange_configure(None, None, None, 0, 0, 0, 0)
+        ctx2.propagate_and_cull(frusta, flags=B.CULL_END_FRAME)
+        assert_bits(ctx2.download_visibility(0), vis_exp[0], "after switching the exchange off")
+    g.close()

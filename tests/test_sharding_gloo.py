@@ -62,6 +62,17 @@ def _worker(rank, world, port, ret):
         full[woff:woff + N_VIEWS * w] = torch.from_numpy(mine.reshape(-1).view(np.int64))
         sharding.all_gather_visibility(full, N_ROWS, world, N_VIEWS, rank)
         ret[rank] = full.numpy().copy()
+        # the pipelined gatherer bench.py uses (two alternating buffers); on CPU tensors it goes through gloo
+        g = sharding.MaskGatherer(N_ROWS, world, N_VIEWS, rank, device=None)
+        assert g.mode == "torch.distributed" and g.bind_args(0)[1:] == (wpv, woff)
+        for frame in range(3):
+            g.before_kernels(frame)
+            buf = g.buffer(frame)
+            buf.zero_()
+            buf[woff:woff + N_VIEWS * w] = torch.from_numpy((mine.reshape(-1) + np.uint64(frame)).view(np.int64))
+            out = g.after_kernels(frame)
+            ret[(rank, frame)] = out.numpy().copy()
+        g.close()
     finally:
         dist.destroy_process_group()
 
@@ -83,8 +94,12 @@ def test_all_gather_visibility_world2():
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
-    assert len(ret) == world
+    assert len(ret) == world + 3 * world
     assert np.array_equal(ret[0], ret[1]), "ranks disagree after the all-gather"
+    for frame in range(3):
+        assert np.array_equal(ret[(0, frame)], ret[(1, frame)]), f"pipelined gatherer: ranks disagree at frame {frame}"
+    assert np.array_equal(ret[(0, 0)], ret[0]), "pipelined gatherer differs from the plain all-gather"
+    assert not np.array_equal(ret[(0, 1)], ret[(0, 0)])
     sc, frusta = _scene_and_frusta()
     expect = _visible(sc, frusta, 0, N_ROWS)
     for v in range(N_VIEWS):

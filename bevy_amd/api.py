@@ -80,13 +80,13 @@ _lib = None
 # every symbol include/bevy_mi355x.h declares (tests/test_abi.py checks header <-> library <-> this list)
 ABI_SYMBOLS = [
     "mi_abi_version", "mi_ctx_create", "mi_ctx_destroy", "mi_last_error_string", "mi_synchronize",
-    "mi_columns_resize", "mi_upload_transforms", "mi_upload_global_transforms", "mi_upload_bounds",
+    "mi_columns_resize", "mi_upload_transforms", "mi_upload_transforms_indexed", "mi_upload_global_transforms", "mi_upload_bounds",
     "mi_upload_view_visibility", "mi_upload_visibility_classes", "mi_upload_entity_keys", "mi_upload_changed",
     "mi_upload_visibility_ranges", "mi_upload_visibility", "mi_upload_hierarchy", "mi_hierarchy_sort", "mi_propagate",
     "mi_visibility_propagate", "mi_download_inherited_visibility",
     "mi_visibility_begin_frame", "mi_cull", "mi_cull_views", "mi_propagate_and_cull", "mi_propagate_and_cull_views",
     "mi_visibility_end_frame",
-    "mi_download_global_transforms", "mi_download_visibility", "mi_download_view_visibility",
+    "mi_download_global_transforms", "mi_download_changed_global_transforms", "mi_download_visibility", "mi_download_view_visibility",
     "mi_download_visible_entities", "mi_cluster_view_dims", "mi_cluster_view_build",
     "mi_cluster_dimensions_fixed_z", "mi_cluster_assign", "mi_cluster_upload_objects", "mi_cluster_upload_view",
     "mi_cluster_assign_resident", "mi_cluster_download", "mi_perspective_clip_from_view", "mi_compute_frustum",
@@ -264,6 +264,11 @@ class Context:
         self._ck(self._lib.mi_upload_transforms(self._h, first_row, n, _ptr(t, C.c_float), _ptr(r, C.c_float),
                                                 _ptr(s, C.c_float)))
 
+    def upload_transforms_indexed(self, rows, translation, rotation, scale):
+        rw, t, r, s = _u32(rows), _f32(translation), _f32(rotation), _f32(scale)
+        self._ck(self._lib.mi_upload_transforms_indexed(self._h, len(rw), _ptr(rw, C.c_uint32), _ptr(t, C.c_float),
+                                                        _ptr(r, C.c_float), _ptr(s, C.c_float)))
+
     def upload_global_transforms(self, g, first_row=0):
         g = _f32(g)
         self._ck(self._lib.mi_upload_global_transforms(self._h, first_row, len(g) // 12, _ptr(g, C.c_float)))
@@ -363,6 +368,18 @@ class Context:
         chg = np.zeros((n + 31) // 32, np.uint32) if want_changed else None
         self._ck(self._lib.mi_download_global_transforms(self._h, first_row, n, _ptr(g, C.c_float), _ptr(chg, C.c_uint32)))
         return (g, unpack_bits(chg, n)) if want_changed else g
+
+    def download_changed_global_transforms(self):
+        """-> (rows ascending, G[12 * len(rows)]) of the rows whose GlobalTransform changed in the last propagate."""
+        cnt = C.c_uint32(0)
+        rc = self._lib.mi_download_changed_global_transforms(self._h, None, None, 0, C.byref(cnt))
+        if rc not in (MI_OK, MI_ERR_CAPACITY):
+            self._ck(rc)
+        m = cnt.value
+        rows = np.zeros(max(m, 1), np.uint32)
+        g = np.zeros(12 * max(m, 1), np.float32)
+        self._ck(self._lib.mi_download_changed_global_transforms(self._h, _ptr(rows, C.c_uint32), _ptr(g, C.c_float), m, C.byref(cnt)))
+        return rows[:m], g[:12 * m]
 
     def download_visibility(self, view=0):
         bm = np.zeros((self.n + 31) // 32, np.uint32)

@@ -73,7 +73,7 @@ struct mi_ctx {
     bool have_ranges = false;      // a VisibleEntityRanges resource exists (mi_upload_visibility_ranges was called)
     uint8_t* visibility = nullptr; // Visibility component: 0 Inherited, 1 Hidden, 2 Visible, 0x80 none
     uint8_t* inh_changed = nullptr;  // InheritedVisibility assigned by the last mi_visibility_propagate (bytes)
-    DevBuf inh_bits;
+    DevBuf inh_bits, sparse_cnt, sparse_rows, sparse_total, sparse_g;
 
     // ---- staging ----
     void* stage = nullptr;
@@ -659,7 +659,7 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
                     ctx->range, ctx->visibility, ctx->inh_changed};
     for (void* p : cols)
         if (p) hipFree(p);
-    DevBuf* bufs[] = {&ctx->order, &ctx->inh_bits, &ctx->parent_idx, &ctx->node_flags, &ctx->tiles, &ctx->views, &ctx->bitmask,
+    DevBuf* bufs[] = {&ctx->order, &ctx->inh_bits, &ctx->sparse_cnt, &ctx->sparse_rows, &ctx->sparse_total, &ctx->sparse_g, &ctx->parent_idx, &ctx->node_flags, &ctx->tiles, &ctx->views, &ctx->bitmask,
                       &ctx->block_counts, &ctx->seg_totals, &ctx->seg_bases, &ctx->out_rows, &ctx->out_keys, &ctx->wave_cnt, &ctx->seg_mask, &ctx->cl_pos,
                       &ctx->cl_type, &ctx->cl_layers, &ctx->cl_dir, &ctx->cl_sincos, &ctx->cl_planes, &ctx->cl_spheres,
                       &ctx->cl_block_counts, &ctx->cl_pair_cb, &ctx->cl_pair_mask, &ctx->cl_acc,
@@ -793,6 +793,33 @@ int32_t mi_upload_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t n, const 
     if ((rc = upload(ctx, ctx->t + 3 * (size_t)first_row, translation, (size_t)n * 12))) return rc;
     if ((rc = upload(ctx, ctx->r + 4 * (size_t)first_row, rotation, (size_t)n * 16))) return rc;
     if ((rc = upload(ctx, ctx->s + 3 * (size_t)first_row, scale, (size_t)n * 12))) return rc;
+    return MI_OK;
+}
+
+int32_t mi_upload_transforms_indexed(mi_ctx* ctx, uint32_t n, const uint32_t* rows, const float* translation,
+                                     const float* rotation, const float* scale) {
+    ENTER(ctx);
+    if (n == 0) return MI_OK;
+    if (!rows || !translation || !rotation || !scale) return fail(ctx, MI_ERR_INVALID_ARG, "mi_upload_transforms_indexed: NULL");
+    for (uint32_t i = 0; i < n; ++i)
+        if (rows[i] >= ctx->n) return fail(ctx, MI_ERR_INVALID_ARG, "mi_upload_transforms_indexed: row %u >= %u live rows", rows[i], ctx->n);
+    void* st = nullptr;
+    int32_t rc = stage_alloc(ctx, (size_t)n * 44, &st);
+    if (rc) return rc;
+    uint32_t* u = (uint32_t*)st;
+    float* f = (float*)(u + n);
+    memcpy(u, rows, (size_t)n * 4);
+    memcpy(f, translation, (size_t)n * 12);
+    memcpy(f + 3 * (size_t)n, rotation, (size_t)n * 16);
+    memcpy(f + 7 * (size_t)n, scale, (size_t)n * 12);
+    void* dev = nullptr;
+    HIP_TRY(ctx, hipHostGetDevicePointer(&dev, st, 0));
+    if (!ctx->have_changed) {
+        // first use of the change column: rows never marked count as unchanged from here on
+        HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, ctx->n, ctx->stream));
+        ctx->have_changed = true;
+    }
+    HIP_TRY(ctx, launch_upload_trs_indexed((const uint32_t*)dev, n, ctx->t, ctx->r, ctx->s, ctx->changed, ctx->stream));
     return MI_OK;
 }
 
@@ -1201,6 +1228,50 @@ int32_t mi_download_global_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t 
         const size_t words32 = ((size_t)n + 31) / 32;
         if ((rc = download(ctx, changed_bitmask, (const uint32_t*)ctx->g_chg_bits + first_row / 32, words32 * 4))) return rc;
         if (n & 31u) changed_bitmask[words32 - 1] &= (1u << (n & 31u)) - 1u;
+    }
+    return MI_OK;
+}
+
+int32_t mi_download_changed_global_transforms(mi_ctx* ctx, uint32_t* out_rows, float* out_global12, uint32_t capacity,
+                                              uint32_t* out_count) {
+    ENTER(ctx);
+    if (!out_count) return fail(ctx, MI_ERR_INVALID_ARG, "mi_download_changed_global_transforms: out_count NULL");
+    *out_count = 0;
+    if (ctx->n == 0) return MI_OK;
+    int32_t rc;
+    if (ctx->g_chg_in_bytes) {
+        HIP_TRY(ctx, launch_bytes_to_bits(ctx->g_changed_bytes, ctx->n, ctx->g_chg_bits, ctx->stream));
+        ctx->g_chg_in_bytes = false;
+    }
+    // compact the change mask into an ascending row list on the device, gather those rows' matrices, copy both out
+    const uint32_t n_waves = (uint32_t)((padded_words(ctx->cap) + 63u) / 64u * 64u);
+    if ((rc = ensure(ctx, ctx->sparse_cnt, n_waves))) return rc;
+    if ((rc = ensure(ctx, ctx->sparse_rows, (size_t)ctx->cap * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->sparse_total, 16))) return rc;
+    HIP_TRY(ctx, launch_popcount_words(ctx->g_chg_bits, ctx->n, (uint8_t*)ctx->sparse_cnt.p, ctx->stream));
+    CompactFastArgs f{};
+    f.n = ctx->n;
+    f.n_segments = 1;
+    f.n_classes = 1;
+    f.n_waves = n_waves;
+    f.wave_cnt = (const uint8_t*)ctx->sparse_cnt.p;
+    f.seg_mask = ctx->g_chg_bits;
+    f.seg_words = padded_words(ctx->cap);
+    f.out_rows = (uint32_t*)ctx->sparse_rows.p;
+    f.seg_stride = ctx->cap;
+    f.seg_totals = (uint32_t*)ctx->sparse_total.p;
+    HIP_TRY(ctx, launch_compact_fast(f, ctx->stream));
+    uint32_t total = 0;
+    if ((rc = download(ctx, &total, ctx->sparse_total.p, 4))) return rc;
+    *out_count = total;
+    if (total > capacity) return fail(ctx, MI_ERR_CAPACITY, "%u GlobalTransforms changed, capacity %u", total, capacity);
+    if (total == 0) return MI_OK;
+    if (out_rows && (rc = download(ctx, out_rows, ctx->sparse_rows.p, (size_t)total * 4))) return rc;
+    if (out_global12) {
+        if ((rc = ensure(ctx, ctx->sparse_g, (size_t)total * 48))) return rc;
+        HIP_TRY(ctx, launch_gather_global((const uint32_t*)ctx->sparse_rows.p, (const uint32_t*)ctx->sparse_total.p, total, ctx->g,
+                                          (float*)ctx->sparse_g.p, ctx->stream));
+        if ((rc = download(ctx, out_global12, ctx->sparse_g.p, (size_t)total * 48))) return rc;
     }
     return MI_OK;
 }

@@ -130,6 +130,11 @@ hipError_t launch_cull(const Columns& c, const ViewSet* views_inline, const View
                        const VisibilityOut& out, const SegOut& seg, uint32_t flags, hipStream_t stream);
 hipError_t launch_upload_trs(const float* pinned_src, float* t, float* r, float* s, uint32_t first_row, uint32_t n,
                              hipStream_t stream);
+hipError_t launch_upload_trs_indexed(const uint32_t* pinned_src, uint32_t n, float* t, float* r, float* s, uint8_t* changed,
+                                     hipStream_t stream);
+hipError_t launch_popcount_words(const uint64_t* bits, uint32_t n_rows, uint8_t* cnt, hipStream_t stream);
+hipError_t launch_gather_global(const uint32_t* rows, const uint32_t* total, uint32_t capacity, const float* g, float* out,
+                                hipStream_t stream);
 constexpr uint32_t SMALL_UPLOAD_ROWS = 4096;  // at or below this, Transform uploads take the one-kernel path
 hipError_t launch_vis_begin(const Columns& c, hipStream_t stream);
 hipError_t launch_vis_end(const Columns& c, hipStream_t stream);

@@ -10,6 +10,8 @@
 // 12/16-byte lane-contiguous chunks, per-view visibility packed with a wave64 ballot: lane 0
 // of every wave stores one 64-bit mask word per view, so the bitmask is written coalesced and
 // needs no atomics.  Compiled with -ffp-contract=off (see glam_math.h).
+#include <algorithm>
+
 #include "glam_math.h"
 #include "kernels.h"
 
@@ -339,6 +341,65 @@ __global__ void __launch_bounds__(256) k_upload_trs(const float* __restrict__ sr
     }
     if (i < 4u * n) r[4ull * first_row + i] = src[3ull * n + i];
 }
+// Sparse dirty-row upload (the rows a Changed<Transform> query yields): src = rows[n] | t[3n] | r[4n] | s[3n] in
+// pinned host memory; one thread per row scatters its Transform and raises the row's changed byte.
+__global__ void __launch_bounds__(256) k_upload_trs_indexed(const uint32_t* __restrict__ src, uint32_t n, float* t, float* r,
+                                                             float* s, uint8_t* changed) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t row = src[i];
+    const float* ft = reinterpret_cast<const float*>(src + n);
+    const float* fr = ft + 3ull * n;
+    const float* fs = fr + 4ull * n;
+#pragma unroll
+    for (uint32_t k = 0; k < 3u; ++k) {
+        t[3ull * row + k] = ft[3ull * i + k];
+        s[3ull * row + k] = fs[3ull * i + k];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) r[4ull * row + k] = fr[4ull * i + k];
+    changed[row] = 1;
+}
+hipError_t launch_upload_trs_indexed(const uint32_t* pinned_src, uint32_t n, float* t, float* r, float* s, uint8_t* changed,
+                                     hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    MI_LAUNCH(k_upload_trs_indexed, dim3(blocks_for(n)), dim3(256), 0, stream, pinned_src, n, t, r, s, changed);
+    return hipGetLastError();
+}
+
+// Sparse read-back helpers: u8 popcount of every 64-bit mask word (the wave counts k_compact_fast consumes), and
+// a gather of the listed rows' GlobalTransforms into a dense array.
+__global__ void __launch_bounds__(256) k_popcount_words(const uint64_t* __restrict__ bits, uint32_t n_words, uint32_t n_rows,
+                                                         uint8_t* cnt) {
+    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+    if (w >= n_words) return;
+    uint64_t m = bits[w];
+    const uint32_t tail = n_rows - w * 64u;
+    if (tail < 64u) m &= (1ull << tail) - 1ull;
+    cnt[w] = (uint8_t)__popcll(m);
+}
+__global__ void __launch_bounds__(256) k_gather_global(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ total,
+                                                        uint32_t capacity, const float* __restrict__ g, float* out) {
+    const uint32_t m = *total < capacity ? *total : capacity;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < m * 3u; i += gridDim.x * 256u) {
+        const uint32_t row = rows[i / 3u];
+        reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(g)[3ull * row + (i % 3u)];
+    }
+}
+hipError_t launch_popcount_words(const uint64_t* bits, uint32_t n_rows, uint8_t* cnt, hipStream_t stream) {
+    const uint32_t n_words = (n_rows + 63u) / 64u;
+    if (n_words == 0) return hipSuccess;
+    MI_LAUNCH(k_popcount_words, dim3(blocks_for(n_words)), dim3(256), 0, stream, bits, n_words, n_rows, cnt);
+    return hipGetLastError();
+}
+hipError_t launch_gather_global(const uint32_t* rows, const uint32_t* total, uint32_t capacity, const float* g, float* out,
+                                hipStream_t stream) {
+    if (capacity == 0) return hipSuccess;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(2048, ((uint64_t)capacity * 3 + 255) / 256);
+    MI_LAUNCH(k_gather_global, dim3(blocks), dim3(256), 0, stream, rows, total, capacity, g, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_upload_trs(const float* pinned_src, float* t, float* r, float* s, uint32_t first_row, uint32_t n,
                              hipStream_t stream) {
     if (n == 0) return hipSuccess;

@@ -132,6 +132,12 @@ int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows);
 int32_t mi_upload_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t n, const float* translation,
                              const float* rotation, const float* scale);
 
+/* Sparse form for the steady state: exactly the rows a `Changed<Transform>` query yields this frame
+ * (crates/bevy_transform/src/systems.rs:45-50,111-116), in any order.  One staging block, one scatter kernel;
+ * also raises the rows' "changed" byte, so a following mi_propagate(0) treats precisely these rows as dirty. */
+int32_t mi_upload_transforms_indexed(mi_ctx* ctx, uint32_t n, const uint32_t* rows, const float* translation,
+                                     const float* rotation, const float* scale);
+
 /* Existing GlobalTransform values (global_transform.rs:60).  Only needed when the previous values
  * matter: set_if_neq change detection (systems.rs:719) and MI_PROPAGATE_STATIC_OPT skipping. */
 int32_t mi_upload_global_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t n, const float* global12);
@@ -249,6 +255,13 @@ int32_t mi_visibility_end_frame(mi_ctx* ctx);
  * when changed_bitmask != NULL.  changed_bitmask has ceil(n/32) words. */
 int32_t mi_download_global_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t n, float* out_global12,
                                       uint32_t* changed_bitmask);
+
+/* Sparse form for the steady state: only the rows whose GlobalTransform change tick the reference would have
+ * bumped in the last propagate (ascending rows + their matrices, compacted and gathered on the device), so the
+ * write-back through `Mut<GlobalTransform>` touches -- and the PCIe copy carries -- only what changed.
+ * *out_count receives the number of changed rows; MI_ERR_CAPACITY if it exceeds `capacity`. */
+int32_t mi_download_changed_global_transforms(mi_ctx* ctx, uint32_t* out_rows, float* out_global12, uint32_t capacity,
+                                              uint32_t* out_count);
 
 /* Packed per-view visibility of the last mi_cull: bit r of word r/32 = row r reached set_visible()
  * for that view.  bitmask has ceil(n_rows/32) words. */

@@ -549,3 +549,53 @@ def test_mask_gatherer_single_rank_pipeline(ctx_factory):
         ctx2.propagate_and_cull(frusta, flags=B.CULL_END_FRAME)
         assert_bits(ctx2.download_visibility(0), vis_exp[0], "after switching the exchange off")
     g.close()
+
+
+@pytest.mark.parametrize("static_opt", [False, True])
+def test_sparse_dirty_upload_and_changed_readback(ctx_factory, static_opt):
+    """The steady-state PCIe path: upload only the Changed<Transform> rows (indexed), propagate, read back only the
+    rows whose GlobalTransform tick was bumped.  Same result as the dense upload + full download."""
+    n = 40_000
+    parent_old = random_forest(n, 17)
+    new_to_old, parent, offs = api.hierarchy_sort(parent_old)
+    rng = np.random.default_rng(23)
+    t = rng.normal(size=(n, 3)).astype(F)
+    q = rng.normal(size=(n, 4)); q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(F)
+    s = rng.uniform(0.8, 1.25, size=(n, 3)).astype(F)
+    flags = B.PROPAGATE_STATIC_OPT if static_opt else 0
+    ctx = ctx_factory()
+    ctx.resize(n)
+    ctx.upload_transforms(t.reshape(-1), q.reshape(-1), s.reshape(-1))
+    ctx.upload_hierarchy(parent, offs)
+    ctx.propagate(B.PROPAGATE_ALL_DIRTY | flags)
+    rows0, g0s = ctx.download_changed_global_transforms()
+    g0 = ctx.download_global_transforms(want_changed=False)
+    assert np.array_equal(rows0, np.arange(n, dtype=np.uint32)) and g0s.tobytes() == g0.tobytes()   # first frame: all
+    for frame in range(3):
+        dirty = np.nonzero(rng.random(n) < 0.003)[0].astype(np.uint32)
+        rng.shuffle(dirty)
+        t[dirty] += F(0.25)
+        q2 = q[dirty] + rng.normal(scale=0.05, size=(len(dirty), 4)).astype(F)
+        q[dirty] = (q2 / np.linalg.norm(q2, axis=1, keepdims=True)).astype(F)
+        ctx.upload_transforms_indexed(dirty, t[dirty].reshape(-1), q[dirty].reshape(-1), s[dirty].reshape(-1))
+        ctx.propagate(flags)
+        changed = np.zeros(n, np.uint8); changed[dirty] = 1
+        tree_changed = O.mark_dirty_trees(parent, changed)
+        rc, g1, chg = O.propagate_transforms(parent, t.reshape(-1), q.reshape(-1), s.reshape(-1), global_in=g0,
+                                             static_opt=static_opt, tree_changed=tree_changed, transform_changed=changed)
+        assert rc == 0
+        rows, gs = ctx.download_changed_global_transforms()
+        exp_rows = np.nonzero(chg)[0].astype(np.uint32)
+        assert np.array_equal(rows, exp_rows), (frame, len(rows), len(exp_rows))
+        assert gs.tobytes() == g1.reshape(n, 12)[exp_rows].tobytes()
+        assert ctx.download_global_transforms(want_changed=False).tobytes() == g1.tobytes()
+        g0 = g1
+    # nothing dirty: nothing changes, nothing comes back
+    ctx.upload_transforms_indexed(np.zeros(0, np.uint32), np.zeros(0, F), np.zeros(0, F), np.zeros(0, F))
+    ctx.propagate(flags)
+    rows, gs = ctx.download_changed_global_transforms()
+    none = np.zeros(n, np.uint8)
+    rc, g2, chg = O.propagate_transforms(parent, t.reshape(-1), q.reshape(-1), s.reshape(-1), global_in=g0, static_opt=static_opt,
+                                         tree_changed=O.mark_dirty_trees(parent, none), transform_changed=none)
+    # without the static-scene optimisation every root with children is re-assigned each frame (systems.rs:522-530)
+    assert np.array_equal(rows, np.nonzero(chg)[0].astype(np.uint32)) and (static_opt and len(rows) == 0 or not static_opt)

@@ -84,6 +84,11 @@ struct mi_ctx {
     std::vector<uint32_t> level_offsets;  // n_levels + 1
     DevBuf parent_idx, node_flags, tiles;
     std::vector<std::pair<uint32_t, uint32_t>> passes;  // (first tile, n tiles); pass 0 starts at level 0 (roots)
+    struct TileGroup { uint32_t first, count, n_chain, owner_rows; };
+    std::vector<TileGroup> groups;  // launches of mi_propagate: an owner pass + at most one pass of chain tiles
+    DevBuf chains, snap;            // snap: 2 x snap_rows x 48 B, pre-frame GlobalTransforms of the owner rows (see kernels_tree.hip)
+    uint32_t snap_rows = 0, snap_parity = 0;
+    bool snap_valid = false;
     bool have_hierarchy = false;
     bool g_chg_in_bytes = false;  // the GlobalTransform change mask currently lives in g_changed_bytes (tree path)
 
@@ -659,7 +664,7 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
                     ctx->range, ctx->visibility, ctx->inh_changed};
     for (void* p : cols)
         if (p) hipFree(p);
-    DevBuf* bufs[] = {&ctx->order, &ctx->inh_bits, &ctx->sparse_cnt, &ctx->sparse_rows, &ctx->sparse_total, &ctx->sparse_g, &ctx->parent_idx, &ctx->node_flags, &ctx->tiles, &ctx->views, &ctx->bitmask,
+    DevBuf* bufs[] = {&ctx->order, &ctx->chains, &ctx->snap, &ctx->inh_bits, &ctx->sparse_cnt, &ctx->sparse_rows, &ctx->sparse_total, &ctx->sparse_g, &ctx->parent_idx, &ctx->node_flags, &ctx->tiles, &ctx->views, &ctx->bitmask,
                       &ctx->block_counts, &ctx->seg_totals, &ctx->seg_bases, &ctx->out_rows, &ctx->out_keys, &ctx->wave_cnt, &ctx->seg_mask, &ctx->cl_pos,
                       &ctx->cl_type, &ctx->cl_layers, &ctx->cl_dir, &ctx->cl_sincos, &ctx->cl_planes, &ctx->cl_spheres,
                       &ctx->cl_block_counts, &ctx->cl_pair_cb, &ctx->cl_pair_mask, &ctx->cl_acc,
@@ -767,6 +772,7 @@ int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
         ctx->order_dirty = true;
         ctx->level_offsets = {0, n_rows};
         ctx->passes.clear();
+        ctx->groups.clear();
     }
     ctx->n = n_rows;
     return MI_OK;
@@ -828,6 +834,7 @@ int32_t mi_upload_global_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t n,
     if (!global12) return fail(ctx, MI_ERR_INVALID_ARG, "mi_upload_global_transforms: NULL");
     int32_t rc = check_rows(ctx, first_row, n, "mi_upload_global_transforms");
     if (rc) return rc;
+    ctx->snap_valid = false;  // externally supplied values: the tree path re-snapshots its owner rows
     return upload(ctx, ctx->g + 12 * (size_t)first_row, global12, (size_t)n * 48);
 }
 
@@ -928,6 +935,7 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
         ctx->n_levels = 1;
         ctx->level_offsets = {0, n};
         ctx->passes.clear();
+        ctx->groups.clear();
         return MI_OK;
     }
     if (!level_offsets) return fail(ctx, MI_ERR_INVALID_ARG, "mi_upload_hierarchy: level_offsets NULL");
@@ -978,7 +986,9 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
     const char* env_levels = getenv("MI_TILE_LEVELS");
     const uint32_t max_d = env_levels ? std::max(1, std::min((int)TILE_MAX_LEVELS, atoi(env_levels))) : TILE_MAX_LEVELS;
     std::vector<TileDesc> tiles;
+    std::vector<uint32_t> chains;
     ctx->passes.clear();
+    ctx->groups.clear();
     auto level_size = [&](uint32_t lv) -> uint64_t { return lv < n_levels ? level_offsets[lv + 1] - level_offsets[lv] : 0; };
     uint32_t l = 0;  // first level this pass computes
     while (l < n_levels) {
@@ -1012,6 +1022,13 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
             for (uint32_t k = 0; k + 1 < td.n_levels; ++k) up += td.count[k];
             return up <= TILE_UCAP;
         };
+        // Chain candidate (see "Tile kinds" below): then every tile hangs below exactly one node, as long as that
+        // still gives tiles of a decent size.
+        uint64_t pass_rows = 0;
+        for (uint32_t k = 0; k < d; ++k) pass_rows += level_size(l + k);
+        const bool chain_candidate = !roots && l <= TILE_MAX_CHAIN && !ctx->groups.empty() && ctx->groups.back().n_chain == 0 &&
+                                     ctx->groups.back().count <= 64 && getenv("MI_TILE_NO_CHAIN") == nullptr &&
+                                     n_roots <= 16384 && pass_rows >= 128 * n_roots;
         const uint32_t first_tile = (uint32_t)tiles.size();
         const uint32_t rl = roots ? 0 : l - 1;
         const uint32_t rlo = level_offsets[rl], rhi = level_offsets[rl + 1];
@@ -1021,7 +1038,7 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
             uint32_t b = a + 1;
             build(a, b, best);
             uint32_t step = 1;  // galloping extension of the root range
-            while (b < rhi) {
+            while (b < rhi && !chain_candidate) {
                 const uint32_t nb = (uint32_t)std::min<uint64_t>((uint64_t)b + step, rhi);
                 TileDesc cand{};
                 // keep tiles small enough to spread over the chip: at most 4 x TILE_UCAP rows in the streamed last level
@@ -1032,7 +1049,40 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
             if (best.n_levels) tiles.push_back(best);
             a = b;
         }
-        ctx->passes.emplace_back(first_tile, (uint32_t)tiles.size() - first_tile);
+        const uint32_t n_pass_tiles = (uint32_t)tiles.size() - first_tile;
+        ctx->passes.emplace_back(first_tile, n_pass_tiles);
+        // Tile kinds.  Pass 0: roots.  A later pass whose every tile hangs below ONE node of a short enough ancestor
+        // chain lets each tile re-evaluate that chain itself (kernels_tree.hip), which makes the pass independent of
+        // the one above it: it joins the previous launch.  Otherwise its tiles read their parents from global memory
+        // and the pass needs its own launch behind the previous one.
+        // (the owners wait for the chain tiles to start, so there must be few of them and only one chained pass per launch)
+        bool chainable = chain_candidate;
+        for (uint32_t ti = first_tile; chainable && ti < tiles.size(); ++ti) {
+            const TileDesc& td = tiles[ti];
+            if (td.n_levels == 0) continue;
+            const uint32_t p0 = parent_idx[td.start[0]];
+            if (parent_idx[td.start[0] + td.count[0] - 1] != p0) chainable = false;  // level 0 of the tile spans several parents
+        }
+        chains.resize(tiles.size() * (size_t)TILE_MAX_CHAIN, 0u);
+        for (uint32_t ti = first_tile; ti < tiles.size(); ++ti) {
+            TileDesc& td = tiles[ti];
+            td.kind = roots ? TILE_ROOTS : 0u;
+            if (chainable && td.n_levels) {
+                uint32_t row = parent_idx[td.start[0]], len = 0;
+                while (row != MI_NO_PARENT && len < TILE_MAX_CHAIN) {
+                    chains[(size_t)ti * TILE_MAX_CHAIN + len++] = row;
+                    row = parent_idx[row];
+                }
+                td.kind = len;
+            }
+        }
+        if (chainable) {
+            ctx->groups.back().count += n_pass_tiles;
+            ctx->groups.back().n_chain = n_pass_tiles;
+            ctx->groups.back().owner_rows = level_offsets[l];  // the owners' rows are the prefix [0, first row of level l)
+        } else {
+            ctx->groups.push_back({first_tile, n_pass_tiles, 0u, 0u});
+        }
         l += d;
     }
     int32_t rc;
@@ -1042,6 +1092,12 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
     if ((rc = upload(ctx, ctx->parent_idx.p, parent_idx, (size_t)n * 4))) return rc;
     if ((rc = upload(ctx, ctx->node_flags.p, nflags.data(), n))) return rc;
     if ((rc = upload(ctx, ctx->tiles.p, tiles.data(), tiles.size() * sizeof(TileDesc)))) return rc;
+    ctx->snap_rows = 0;
+    for (auto& gr : ctx->groups) ctx->snap_rows = std::max(ctx->snap_rows, gr.owner_rows);
+    ctx->snap_valid = false;
+    if (ctx->snap_rows && (rc = ensure(ctx, ctx->snap, 2 * (size_t)ctx->snap_rows * 48))) return rc;
+    if ((rc = ensure(ctx, ctx->chains, std::max<size_t>(chains.size(), 1) * 4))) return rc;
+    if ((rc = upload(ctx, ctx->chains.p, chains.data(), chains.size() * 4))) return rc;
     ctx->level_offsets.assign(level_offsets, level_offsets + n_levels + 1);
     ctx->n_levels = n_levels;
     ctx->have_hierarchy = true;
@@ -1074,13 +1130,24 @@ int32_t mi_propagate(mi_ctx* ctx, uint32_t flags) {
         HIP_TRY(ctx, launch_level0_propagate(c, n0, nullptr, ctx->changed, tree_bits, all_dirty, static_opt, ctx->stream));
         ctx->g_chg_in_bytes = false;
     } else {
-        bool first = true;
-        for (auto& ps : ctx->passes) {
+        float* snap_r = nullptr;
+        float* snap_w = nullptr;
+        if (ctx->snap_rows) {
+            snap_r = (float*)ctx->snap.p + (size_t)ctx->snap_parity * ctx->snap_rows * 12;
+            snap_w = (float*)ctx->snap.p + (size_t)(ctx->snap_parity ^ 1u) * ctx->snap_rows * 12;
+            if (!ctx->snap_valid) {  // first frame after a (re)plan or an external GlobalTransform upload
+                HIP_TRY(ctx, hipMemcpyAsync(snap_r, ctx->g, (size_t)ctx->snap_rows * 48, hipMemcpyDeviceToDevice, ctx->stream));
+                ctx->snap_valid = true;
+            }
+            ctx->snap_parity ^= 1u;
+        }
+        for (auto& gr : ctx->groups) {
             ProfScope sc(ctx, K_PROPAGATE_TILES);
-            HIP_TRY(ctx, launch_propagate_tiles(c, (const uint32_t*)ctx->parent_idx.p, (const TileDesc*)ctx->tiles.p + ps.first,
-                                                ps.second, first, (const uint8_t*)ctx->node_flags.p, ctx->changed, tree_bits,
-                                                ctx->g_changed_bytes, all_dirty, static_opt, ctx->stream));
-            first = false;
+            HIP_TRY(ctx, launch_propagate_tiles(c, (const uint32_t*)ctx->parent_idx.p, (const TileDesc*)ctx->tiles.p + gr.first,
+                                                (const uint32_t*)ctx->chains.p + (size_t)gr.first * TILE_MAX_CHAIN, gr.count,
+                                                (const uint8_t*)ctx->node_flags.p, ctx->changed, tree_bits, ctx->g_changed_bytes,
+                                                gr.n_chain ? snap_r : nullptr, gr.n_chain ? snap_w : nullptr, all_dirty, static_opt,
+                                                ctx->stream));
         }
         ctx->g_chg_in_bytes = true;
     }

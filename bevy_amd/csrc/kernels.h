@@ -183,18 +183,22 @@ hipError_t launch_compact_fast(const CompactFastArgs& a, hipStream_t stream);
 constexpr uint32_t TILE_MAX_LEVELS = 6;
 constexpr uint32_t TILE_UCAP = 512;            // LDS slots of one tile: rows of all its levels but the last
 constexpr uint32_t TILE_R = TILE_UCAP / 256;   // LDS-resident rows per thread
+constexpr uint32_t TILE_MAX_CHAIN = 24;       // ancestors a chain tile re-evaluates (levels above its first level)
+constexpr uint32_t TILE_ROOTS = 0x80000000u;   // TileDesc::kind: first level = level 0 of the forest
+constexpr uint32_t TILE_CHAIN_MASK = 0xFFu;    // TileDesc::kind: chain length (0 = parents come from global memory)
 struct TileDesc {
     uint32_t n_levels;
     uint32_t start[TILE_MAX_LEVELS];
     uint32_t count[TILE_MAX_LEVELS];
-    uint32_t pad;
+    uint32_t kind;
 };
 hipError_t launch_mark_dirty(uint32_t n, const uint8_t* changed, const uint32_t* parent_idx, uint32_t* tree_bits,
                              hipStream_t stream);
-// roots = true: the tiles' first level is level 0 of the forest (roots + flat rows, no parents).
-hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, const TileDesc* d_tiles, uint32_t n_tiles,
-                                  bool roots, const uint8_t* node_flags, const uint8_t* changed, const uint32_t* tree_bits,
-                                  uint8_t* g_changed_bytes, bool all_dirty, bool static_opt, hipStream_t stream);
+// One launch over a group of mutually independent tiles (TileDesc::kind tells roots / chain / dependent apart).
+hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, const TileDesc* d_tiles, const uint32_t* d_chains,
+                                  uint32_t n_tiles, const uint8_t* node_flags, const uint8_t* changed, const uint32_t* tree_bits,
+                                  uint8_t* g_changed_bytes, const float* snap_read, float* snap_write, bool all_dirty, bool static_opt,
+                                  hipStream_t stream);
 // InheritedVisibility propagation (visibility_propagate_system): writes bit0 of flags[] and changed bytes.
 hipError_t launch_inherit_flat(uint32_t n, const uint8_t* visibility, uint8_t* flags, uint8_t* inh_changed, hipStream_t stream);
 hipError_t launch_inherit_tiles(const uint32_t* parent_idx, const TileDesc* d_tiles, uint32_t n_tiles, bool roots,

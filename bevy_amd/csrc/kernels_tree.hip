@@ -101,25 +101,42 @@ struct TreeArgs {
     const uint8_t* changed;     // per-row Changed<Transform>|Added<GlobalTransform> byte, nullptr = all
     const uint32_t* tree_bits;  // TransformTreeChanged bitset, nullptr = all changed
     uint8_t* g_changed_bytes;   // out: GlobalTransform change tick bumped
+    const uint32_t* chains;     // [n_tiles * TILE_MAX_CHAIN] ancestor rows of chain tiles (tile root first, forest root last)
+    // Chain tiles need the PRE-frame GlobalTransforms of their ancestors while the tiles that own those ancestors
+    // rewrite them in the same launch.  The owners therefore keep a snapshot of their rows (a prefix of the row
+    // space), double-buffered by frame: this frame's chain tiles read snap_read (written by the previous frame's
+    // launch), this frame's owners write snap_write for the next one.  No tile ever waits for another.
+    const float* snap_read;
+    float* snap_write;
     uint32_t all_dirty;
     uint32_t static_opt;
 };
 
 // The per-node rule.  Level-0 rows: roots (systems.rs:522-530) and flat rows (systems.rs:58-63) are plain
 // assignments; every other node is set_if_neq(parent * local) unless the static-scene rule skips it
-// (systems.rs:708-719).  *cur = the row's GlobalTransform after the system; returns "tick bumped".
-template <bool IS_ROOT_LEVEL>
-__device__ __forceinline__ bool node_update(const TreeArgs& a, uint32_t row, const Affine& gp, bool p_changed,
-                                            const Affine& local, const Affine& old, Affine* cur) {
-    const bool tree_changed = a.all_dirty || !a.tree_bits || ((a.tree_bits[row >> 5] >> (row & 31u)) & 1u);
-    if (IS_ROOT_LEVEL) {
+// (systems.rs:708-719).  node_inputs gathers what the rule reads from the per-row side tables, node_apply is the
+// pure rule: *cur = the row's GlobalTransform after the system; returns "tick bumped".
+struct NodeIn {
+    bool tree_changed;  // TransformTreeChanged.is_changed()
+    bool root_write;    // level-0 rows only: the assignment happens
+};
+__device__ __forceinline__ NodeIn node_inputs(const TreeArgs& a, uint32_t row, bool is_root_level) {
+    NodeIn in;
+    in.tree_changed = a.all_dirty || !a.tree_bits || ((a.tree_bits[row >> 5] >> (row & 31u)) & 1u);
+    in.root_write = false;
+    if (is_root_level) {
         const bool has_children = a.node_flags && (a.node_flags[row] & 1u);
-        const bool write =
-            has_children ? (!a.static_opt || tree_changed) : (a.all_dirty || !a.changed || a.changed[row] != 0);
-        *cur = write ? local : old;
-        return write;
+        in.root_write = has_children ? (!a.static_opt || in.tree_changed) : (a.all_dirty || !a.changed || a.changed[row] != 0);
     }
-    const bool skip = a.static_opt && !tree_changed && !p_changed;
+    return in;
+}
+__device__ __forceinline__ bool node_apply(bool is_root_level, bool static_opt, NodeIn in, const Affine& gp, bool p_changed,
+                                           const Affine& local, const Affine& old, Affine* cur) {
+    if (is_root_level) {
+        *cur = in.root_write ? local : old;
+        return in.root_write;
+    }
+    const bool skip = static_opt && !in.tree_changed && !p_changed;
     if (!skip) {
         const Affine nw = mul(gp, local);  // p_global_transform.mul_transform(*transform)
         if (!affine_eq(nw, old)) {         // set_if_neq
@@ -129,6 +146,10 @@ __device__ __forceinline__ bool node_update(const TreeArgs& a, uint32_t row, con
     }
     *cur = old;
     return false;
+}
+__device__ __forceinline__ bool node_update(const TreeArgs& a, bool is_root_level, uint32_t row, const Affine& gp,
+                                            bool p_changed, const Affine& local, const Affine& old, Affine* cur) {
+    return node_apply(is_root_level, a.static_opt != 0, node_inputs(a, row, is_root_level), gp, p_changed, local, old, cur);
 }
 
 // One streamed row's inputs, fetched one loop iteration ahead of their use (software pipelining: the loads of
@@ -166,16 +187,32 @@ __device__ __forceinline__ RowFetch fetch_row(const Columns& c, const uint32_t* 
     return f;
 }
 
-// ROOTS = true: the tile's first level is level 0 of the forest (no parents).
-// BLOCK = 256 normally; 1024 for passes with so few tiles that one workgroup's loop length is the critical path.
-template <bool ROOTS, uint32_t BLOCK>
-__global__ void __launch_bounds__(BLOCK) k_propagate_tiles(Columns c, TreeArgs a) {
+template <uint32_t BLOCK>
+struct TileLds {
+    float4* g;            // [TILE_UCAP * 3] upper-level rows: local affine, then GlobalTransform (in place)
+    uint8_t* chg;         // [TILE_UCAP]
+    float4 (*stage)[192]; // [BLOCK / 64][192] wave-private transpose rows for the streamed level
+    float4* chain;        // [TILE_MAX_CHAIN * 6] per chain node: local affine (3) + old GlobalTransform (3)
+    uint8_t* chain_in;    // [TILE_MAX_CHAIN] bit0 tree_changed, bit1 root_write
+    float4* chain_g;      // [3] the tile root's GlobalTransform ...
+    uint32_t* chain_chg;  // ... and whether its tick was bumped
+};
+
+template <uint32_t BLOCK>
+__device__ __forceinline__ void process_tile(const Columns& c, const TreeArgs& a, uint32_t tile, const TileLds<BLOCK>& lds) {
     constexpr uint32_t R = (TILE_UCAP + BLOCK - 1) / BLOCK;  // LDS-resident rows per thread
-    __shared__ float4 lds_g[TILE_UCAP * 3];  // upper-level rows: local affine, then GlobalTransform (in place)
-    __shared__ uint8_t lds_chg[TILE_UCAP];
-    __shared__ float4 lds_stage[BLOCK / 64][192];  // wave-private transpose rows for the streamed level
-    const TileDesc& td = a.tiles[blockIdx.x];
+    float4* const lds_g = lds.g;
+    uint8_t* const lds_chg = lds.chg;
+    float4 (*const lds_stage)[192] = lds.stage;
+    float4* const lds_chain = lds.chain;
+    uint8_t* const lds_chain_in = lds.chain_in;
+    float4* const lds_chain_g = lds.chain_g;
+    uint32_t& lds_chain_chg = *lds.chain_chg;
+    const TileDesc& td = a.tiles[tile];
     const uint32_t L = td.n_levels;
+    const bool ROOTS = (td.kind & TILE_ROOTS) != 0;
+    const uint32_t chain_len = td.kind & TILE_CHAIN_MASK;
+    float* const snap_out = chain_len ? nullptr : a.snap_write;  // owner tiles of a launch with chain tiles
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
 
     // Leading levels resident in LDS: every level but the last, while the running row total fits.
@@ -229,6 +266,14 @@ __global__ void __launch_bounds__(BLOCK) k_propagate_tiles(Columns c, TreeArgs a
             }
         }
     }
+    if (tid < chain_len) {  // chain tiles: one thread per ancestor fetches what the rule needs
+        const uint32_t row = a.chains[(size_t)tile * TILE_MAX_CHAIN + tid];
+        const bool is_root = tid + 1u == chain_len;
+        lds_put(lds_chain, 2u * tid, affine_from_srt(ld3(c.scale, row), ld4(c.rotation, row), ld3(c.translation, row)));
+        lds_put(lds_chain, 2u * tid + 1u, ld_affine(a.snap_read, row));  // pre-frame value (see TreeArgs)
+        const NodeIn in = node_inputs(a, row, is_root);
+        lds_chain_in[tid] = (uint8_t)((in.tree_changed ? 1u : 0u) | (in.root_write ? 2u : 0u));
+    }
     // The first streamed level's inputs do not depend on step 1 either: put its loads in flight now.
     uint32_t s_start = td.start[0], s_count = L ? td.count[0] : 0u;
 #pragma unroll
@@ -239,6 +284,25 @@ __global__ void __launch_bounds__(BLOCK) k_propagate_tiles(Columns c, TreeArgs a
         }
     RowFetch cur_f = fetch_row(c, a.parent_idx, s_start, s_count, 0u, tid, lane, wv, ROOTS && n_lds == 0);
     __syncthreads();
+    if (chain_len) {
+        if (tid == 0) {  // forest root first, down to the tile's root: the same products the owning tiles compute
+            Affine g = {};
+            bool chg = false;
+            for (uint32_t k = chain_len; k-- > 0;) {
+                const bool is_root = k + 1u == chain_len;
+                NodeIn in;
+                in.tree_changed = (lds_chain_in[k] & 1u) != 0;
+                in.root_write = (lds_chain_in[k] & 2u) != 0;
+                const Affine local = lds_affine(lds_chain, 2u * k), old = lds_affine(lds_chain, 2u * k + 1u);
+                Affine cur;
+                chg = node_apply(is_root, a.static_opt != 0, in, g, chg, local, old, &cur);
+                g = cur;
+            }
+            lds_put(lds_chain_g, 0, g);
+            lds_chain_chg = chg ? 1u : 0u;
+        }
+        __syncthreads();
+    }
 
     // ---- step 1: LDS-resident levels ---------------------------------------------------------------
     bool any_chg = false;
@@ -251,18 +315,21 @@ __global__ void __launch_bounds__(BLOCK) k_propagate_tiles(Columns c, TreeArgs a
                 Affine cur;
                 bool chg;
                 if (ROOTS && l == 0) {
-                    chg = node_update<true>(a, row, local, false, local, old_g[k], &cur);
+                    chg = node_update(a, true, row, local, false, local, old_g[k], &cur);
                 } else {
                     Affine gp;
                     bool p_changed;
                     if (l) {
                         gp = lds_affine(lds_g, my_pslot[k]);
                         p_changed = lds_chg[my_pslot[k]] != 0;
+                    } else if (chain_len) {
+                        gp = lds_affine(lds_chain_g, 0);
+                        p_changed = lds_chain_chg != 0;
                     } else {
                         gp = ld_affine(c.global, my_pslot[k]);
                         p_changed = a.g_changed_bytes[my_pslot[k]] != 0;
                     }
-                    chg = node_update<false>(a, row, gp, p_changed, local, old_g[k], &cur);
+                    chg = node_update(a, false, row, gp, p_changed, local, old_g[k], &cur);
                 }
                 any_chg = any_chg || chg;
                 a.g_changed_bytes[row] = chg ? 1 : 0;
@@ -275,14 +342,20 @@ __global__ void __launch_bounds__(BLOCK) k_propagate_tiles(Columns c, TreeArgs a
     // Flush the LDS-resident levels: slots and rows are both contiguous per level, so the write-back is a
     // straight float4 copy (fully coalesced) instead of one 48-byte scatter per lane.  Unchanged rows hold
     // their old bytes, so rewriting them is value-neutral; a tile in which nothing changed writes nothing.
-    if (__syncthreads_or(any_chg ? 1 : 0)) {
+    const bool flush_live = __syncthreads_or(any_chg ? 1 : 0) != 0;
+    if (flush_live || snap_out) {
 #pragma unroll
         for (uint32_t j = 0; j < TILE_MAX_LEVELS - 1; ++j) {
             if (j < n_lds) {
                 float4* dst = reinterpret_cast<float4*>(c.global) + 3ull * td.start[j];
+                float4* snp = snap_out ? reinterpret_cast<float4*>(snap_out) + 3ull * td.start[j] : nullptr;
                 const float4* src = lds_g + 3u * ubase[j];
                 const uint32_t n4 = 3u * td.count[j];
-                for (uint32_t i = tid; i < n4; i += BLOCK) dst[i] = src[i];
+                for (uint32_t i = tid; i < n4; i += BLOCK) {
+                    const float4 v = src[i];
+                    if (flush_live) dst[i] = v;
+                    if (snp) snp[i] = v;  // the snapshot always tracks the row's current value
+                }
             }
         }
     }
@@ -324,6 +397,9 @@ __global__ void __launch_bounds__(BLOCK) k_propagate_tiles(Columns c, TreeArgs a
                         const uint32_t slot = pbase + (cur_f.p - pstart);
                         gp = lds_affine(lds_g, slot);
                         p_changed = lds_chg[slot] != 0;
+                    } else if (chain_len && l == 0) {
+                        gp = lds_affine(lds_chain_g, 0);
+                        p_changed = lds_chain_chg != 0;
                     } else {
                         gp = ld_affine(c.global, cur_f.p);
                         p_changed = a.g_changed_bytes[cur_f.p] != 0;
@@ -335,9 +411,9 @@ __global__ void __launch_bounds__(BLOCK) k_propagate_tiles(Columns c, TreeArgs a
             Affine cur = old;
             bool chg = false;
             if (live) {
-                if (root_level) chg = node_update<true>(a, row, local, false, local, old, &cur);
-                else chg = node_update<false>(a, row, gp, p_changed, local, old, &cur);
+                chg = node_update(a, root_level, row, gp, p_changed, local, old, &cur);
                 a.g_changed_bytes[row] = chg ? 1 : 0;
+                if (snap_out) st_affine(snap_out, row, cur);
             }
             // store: whole wave changed (the dirty-tree case) -> transpose back and write 3 x 1 KB rows;
             // otherwise only the changed lanes write their own 48 bytes.
@@ -366,6 +442,29 @@ __global__ void __launch_bounds__(BLOCK) k_propagate_tiles(Columns c, TreeArgs a
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
     }
+}
+
+// Tile kinds (TileDesc::kind):
+//   TILE_ROOTS   the tile's first level is level 0 of the forest (no parents);
+//   chain tile   (kind & TILE_CHAIN_MASK) = n > 0: the tile hangs below ONE node whose n-node ancestor chain
+//                (a.chains) it re-evaluates itself -- same operations, same order, hence the same bits as the tile
+//                that owns those ancestors writes -- so it depends on nothing another workgroup produces and can
+//                share a launch with the tiles above it (a deep narrow tree becomes ONE launch);
+//   otherwise    the parents of its first level are read from global memory (written by an earlier launch).
+// (Letting a chain tile's workgroup also process an owner tile was measured slower: 42 us against 34.5 us for the
+// 1 M-node tree, the owner's latency chain simply adds to that workgroup's time.)
+// BLOCK = 256 normally; 1024 for launches with so few tiles that one workgroup's loop length is the critical path.
+template <uint32_t BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_propagate_tiles(Columns c, TreeArgs a) {
+    __shared__ float4 lds_g[TILE_UCAP * 3];
+    __shared__ uint8_t lds_chg[TILE_UCAP];
+    __shared__ float4 lds_stage[BLOCK / 64][192];
+    __shared__ float4 lds_chain[TILE_MAX_CHAIN * 6];
+    __shared__ uint8_t lds_chain_in[TILE_MAX_CHAIN];
+    __shared__ float4 lds_chain_g[3];
+    __shared__ uint32_t lds_chain_chg;
+    const TileLds<BLOCK> lds{lds_g, lds_chg, lds_stage, lds_chain, lds_chain_in, lds_chain_g, &lds_chain_chg};
+    process_tile<BLOCK>(c, a, blockIdx.x, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -476,31 +575,30 @@ hipError_t launch_mark_dirty(uint32_t n, const uint8_t* changed, const uint32_t*
     return hipGetLastError();
 }
 
-hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, const TileDesc* d_tiles, uint32_t n_tiles,
-                                  bool roots, const uint8_t* node_flags, const uint8_t* changed, const uint32_t* tree_bits,
-                                  uint8_t* g_changed_bytes, bool all_dirty, bool static_opt, hipStream_t stream) {
+hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, const TileDesc* d_tiles, const uint32_t* d_chains,
+                                  uint32_t n_tiles, const uint8_t* node_flags, const uint8_t* changed, const uint32_t* tree_bits,
+                                  uint8_t* g_changed_bytes, const float* snap_read, float* snap_write, bool all_dirty, bool static_opt,
+                                  hipStream_t stream) {
     if (n_tiles == 0) return hipSuccess;
     TreeArgs a;
+    a.snap_read = snap_read;
+    a.snap_write = snap_write;
     a.parent_idx = parent_idx;
     a.tiles = d_tiles;
     a.node_flags = node_flags;
     a.changed = changed;
     a.tree_bits = tree_bits;
     a.g_changed_bytes = g_changed_bytes;
+    a.chains = d_chains;
     a.all_dirty = all_dirty ? 1u : 0u;
     a.static_opt = static_opt ? 1u : 0u;
     // few tiles: one workgroup's streamed-level loop is the critical path -> 1024 threads shorten it 4x
     static const int forced = getenv("MI_TILE_BLOCK") ? atoi(getenv("MI_TILE_BLOCK")) : 0;
     const uint32_t block = forced ? (uint32_t)forced : (n_tiles < 128u ? 1024u : 256u);
-    if (roots) {
-        if (block == 1024u) MI_LAUNCH((k_propagate_tiles<true, 1024>), dim3(n_tiles), dim3(1024), 0, stream, c, a);
-        else if (block == 512u) MI_LAUNCH((k_propagate_tiles<true, 512>), dim3(n_tiles), dim3(512), 0, stream, c, a);
-        else MI_LAUNCH((k_propagate_tiles<true, 256>), dim3(n_tiles), dim3(256), 0, stream, c, a);
-    } else {
-        if (block == 1024u) MI_LAUNCH((k_propagate_tiles<false, 1024>), dim3(n_tiles), dim3(1024), 0, stream, c, a);
-        else if (block == 512u) MI_LAUNCH((k_propagate_tiles<false, 512>), dim3(n_tiles), dim3(512), 0, stream, c, a);
-        else MI_LAUNCH((k_propagate_tiles<false, 256>), dim3(n_tiles), dim3(256), 0, stream, c, a);
-    }
+    const uint32_t grid = n_tiles;
+    if (block == 1024u) MI_LAUNCH((k_propagate_tiles<1024>), dim3(grid), dim3(1024), 0, stream, c, a);
+    else if (block == 512u) MI_LAUNCH((k_propagate_tiles<512>), dim3(grid), dim3(512), 0, stream, c, a);
+    else MI_LAUNCH((k_propagate_tiles<256>), dim3(grid), dim3(256), 0, stream, c, a);
     return hipGetLastError();
 }
 

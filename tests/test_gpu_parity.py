@@ -283,7 +283,8 @@ def test_malformed_hierarchy_is_reported(ctx_factory):
     assert e.value.code == api.MI_ERR_MALFORMED_HIERARCHY
 
 
-@pytest.mark.parametrize("depth,branch,cap", [(5, 4, None), (8, 4, None), (11, 2, None), (9, 4, 60_000), (4, 40, None)])
+@pytest.mark.parametrize("depth,branch,cap", [(5, 4, None), (8, 4, None), (11, 2, None), (9, 4, 60_000), (4, 40, None),
+                                              (10, 4, None), (12, 4, 400_000), (9, 7, None), (20, 2, 300_000)])
 def test_tree_propagation_all_dirty(ctx_factory, depth, branch, cap):
     tr = W.gen_tree(depth, branch, cap)
     ctx = ctx_factory()
@@ -306,6 +307,40 @@ def test_tree_propagation_all_dirty(ctx_factory, depth, branch, cap):
     rc, g_exp2, chg_exp2 = O.propagate_transforms(tr["parent"], tr["translation"], tr["rotation"], tr["scale"], global_in=g_exp)
     assert g2.tobytes() == g_exp2.tobytes()
     assert_bits(chg2, chg_exp2, "changed (2nd run)")
+
+
+@pytest.mark.parametrize("static_opt", [False, True])
+def test_deep_tree_partial_dirty_through_chain_tiles(ctx_factory, static_opt):
+    """A deep narrow-topped tree runs as ONE launch: the tiles below level 5 re-evaluate their ancestor chain instead
+    of waiting for the tile that owns it.  Dirty nodes high in the tree (owned by the top tile), in the chain and
+    inside the chain tiles must give the oracle's GlobalTransforms and change ticks, frame after frame."""
+    tr = W.gen_tree(10, 4)
+    n, parent = tr["n"], tr["parent"]
+    t = tr["translation"].reshape(n, 3).copy()
+    flags = B.PROPAGATE_STATIC_OPT if static_opt else 0
+    ctx = ctx_factory()
+    upload_tree(ctx, tr)
+    ctx.propagate(B.PROPAGATE_ALL_DIRTY | flags)
+    rc, g0, _ = O.propagate_transforms(parent, tr["translation"], tr["rotation"], tr["scale"], static_opt=static_opt)
+    assert rc == 0 and ctx.download_global_transforms(want_changed=False).tobytes() == g0.tobytes()
+    rng = np.random.default_rng(5)
+    picks = [np.array([0]), np.array([3, 17]), np.array([300, 1200]), np.array([1365 + 7, 5461 + 100, 90_000]),
+             np.zeros(0, np.int64), rng.integers(0, n, 40)]
+    for frame, dirty in enumerate(picks):
+        dirty = np.unique(dirty).astype(np.uint32)
+        t[dirty] += F(0.5)
+        ctx.upload_transforms_indexed(dirty, t[dirty].reshape(-1), tr["rotation"].reshape(n, 4)[dirty].reshape(-1),
+                                      tr["scale"].reshape(n, 3)[dirty].reshape(-1))
+        ctx.propagate(flags)
+        changed = np.zeros(n, np.uint8); changed[dirty] = 1
+        rc, g1, chg = O.propagate_transforms(parent, t.reshape(-1), tr["rotation"], tr["scale"], global_in=g0, static_opt=static_opt,
+                                             tree_changed=O.mark_dirty_trees(parent, changed), transform_changed=changed)
+        assert rc == 0
+        g, got_chg = ctx.download_global_transforms()
+        bad = np.nonzero((g.view(np.uint32) != g1.view(np.uint32)).reshape(-1, 12).any(axis=1))[0]
+        assert bad.size == 0, f"frame {frame}: {bad.size} rows differ, first {bad[:5].tolist()}"
+        assert_bits(got_chg, chg, f"frame {frame} change ticks")
+        g0 = g1
 
 
 def random_forest(n, seed, flat_fraction=0.3, max_children=6):

@@ -85,7 +85,7 @@ def build_flat(ctx, args, rank, world, total_frames, full_holder):
     ctx.upload_bounds(scene["aabb_center"], scene["aabb_half"], scene["flags"], scene["layers"])
     frames = [api.PreparedFrusta(frusta_of_frame(f)) for f in range(total_frames)]
     gather = None
-    if world > 1 or os.environ.get("MI_FORCE_GATHER") == "1":
+    if world > 1 or os.environ.get("MI_FORCE_GATHER") == "1" or os.environ.get("MI_FORCE_DIST") == "1":
         # frame f's all-gather overlaps frame f+1's kernels (two gathered buffers, own stream)
         gather = sharding.MaskGatherer(n_global, world, n_views, rank, device=torch.device("cuda", torch.cuda.current_device()))
         full_holder.append(gather)
@@ -227,7 +227,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("MI_FORCE_DIST") == "1"  # MI_FORCE_DIST: exercise the N > 1 code on one GPU
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -242,9 +243,9 @@ def main():
             wl = build_tree(ctx, args)
         else:
             wl = build_lights(ctx, args)
-        barrier = (lambda: dist.barrier()) if world > 1 else None
+        barrier = (lambda: dist.barrier()) if use_dist else None
         elapsed, prof = measure(ctx, wl, args.steps, args.warmup, args.profile_all, barrier)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -294,8 +295,10 @@ def main():
         except Exception:
             pass
         print(json.dumps(out), flush=True)
+    for g in full_holder:
+        g.close()
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     return out
 

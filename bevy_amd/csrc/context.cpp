@@ -1622,12 +1622,53 @@ int32_t mi_exchange_configure(mi_ctx* ctx, void* nccl_comm, void* fn_nccl_all_ga
         return fail(ctx, MI_ERR_INVALID_ARG, "mi_exchange_configure: NULL function / buffers, n_bufs outside 2..8, or empty block");
     for (uint32_t i = 0; i < n_bufs; ++i)
         if (!device_bufs[i]) return fail(ctx, MI_ERR_INVALID_ARG, "mi_exchange_configure: buffer %u is NULL", i);
+    if (!x.done_flag) HIP_TRY(ctx, hipHostMalloc((void**)&x.done_flag, 64, hipHostMallocMapped));
     if (!x.comm_stream) {
-        HIP_TRY(ctx, hipStreamCreateWithFlags(&x.comm_stream, hipStreamNonBlocking));
         for (uint32_t i = 0; i < mi_ctx::Exchange::MAX_BUFS; ++i) {
             HIP_TRY(ctx, hipEventCreateWithFlags(&x.ev_kernels[i], hipEventDisableTiming));
             HIP_TRY(ctx, hipEventCreateWithFlags(&x.ev_gathered[i], hipEventDisableTiming));
         }
+        // Pick the communication stream empirically.  HIP maps streams onto a small pool of hardware queues; if the
+        // communication stream lands on the compute stream's queue, its wait / record / write packets serialise with
+        // the frame kernels (measured: 32 us -> 48 us per frame), and which stream collides depends on how many
+        // streams the process created before.  So: make a few candidates (normal and high priority), drive each with
+        // the per-frame pattern over a stand-in kernel, keep the fastest.
+        int prio_lo = 0, prio_hi = 0;
+        HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        constexpr int N_CAND = 6;
+        hipStream_t cand[N_CAND] = {nullptr};
+        for (int i = 0; i < N_CAND; ++i) {
+            if (i == N_CAND - 1) HIP_TRY(ctx, hipStreamCreateWithPriority(&cand[i], hipStreamNonBlocking, prio_hi));
+            else HIP_TRY(ctx, hipStreamCreateWithFlags(&cand[i], hipStreamNonBlocking));
+        }
+        const size_t probe_words = (size_t)16 << 20;  // 64 MB clear: a stand-in for one frame of kernels
+        uint32_t* probe = nullptr;
+        HIP_TRY(ctx, hipMalloc((void**)&probe, probe_words * 4));
+        double best_t = 1e30;
+        int best = 0;
+        for (int rep = 0; rep < 2; ++rep)
+            for (int i = 0; i < N_CAND; ++i) {
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                HIP_TRY(ctx, hipStreamSynchronize(cand[i]));
+                const auto t0 = std::chrono::steady_clock::now();
+                for (uint32_t it = 0; it < 24; ++it) {
+                    HIP_TRY(ctx, launch_clear_u32(probe, probe_words, ctx->stream));
+                    HIP_TRY(ctx, hipEventRecord(x.ev_kernels[it & 1u], ctx->stream));
+                    HIP_TRY(ctx, hipStreamWaitEvent(cand[i], x.ev_kernels[it & 1u], 0));
+                    HIP_TRY(ctx, hipEventRecord(x.ev_gathered[it & 1u], cand[i]));
+                    HIP_TRY(ctx, hipStreamWriteValue32(cand[i], (void*)x.done_flag, it + 1, 0));
+                }
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                HIP_TRY(ctx, hipStreamSynchronize(cand[i]));
+                const double t = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+                if (rep == 1 && t < best_t) { best_t = t; best = i; }
+                if (getenv("MI_XCH_DEBUG")) fprintf(stderr, "[mi exchange] comm stream candidate %d%s: %.1f us / frame\n", i,
+                                                    i == N_CAND - 1 ? " (high priority)" : "", t / 24.0);
+            }
+        HIP_TRY(ctx, hipFree(probe));
+        for (int i = 0; i < N_CAND; ++i)
+            if (i != best) HIP_TRY(ctx, hipStreamDestroy(cand[i]));
+        x.comm_stream = cand[best];
     }
     x.all_gather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))fn_nccl_all_gather;
     x.comm = nccl_comm;
@@ -1637,7 +1678,6 @@ int32_t mi_exchange_configure(mi_ctx* ctx, void* nccl_comm, void* fn_nccl_all_ga
     x.word_offset = word_offset;
     x.block_bytes = block_bytes;
     x.rank = rank;
-    if (!x.done_flag) HIP_TRY(ctx, hipHostMalloc((void**)&x.done_flag, 64, hipHostMallocMapped));
     *x.done_flag = 0;
     x.worker_frames = 0;
     x.frame = 0;

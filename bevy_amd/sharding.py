@@ -51,6 +51,14 @@ def all_gather_visibility(full, n_rows, world, n_views, rank, group=None):
     return full
 
 
+def _dist_on():
+    try:
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized()
+    except Exception:  # noqa: BLE001
+        return False
+
+
 class MaskGatherer:
     """The per-frame exchange, pipelined: frame f's all-gather runs on its own HIP stream while the kernels of the
     following frames run on the compute stream (n_bufs gathered buffers rotate), so a step costs
@@ -89,7 +97,7 @@ class MaskGatherer:
             except Exception as e:  # noqa: BLE001 -- any failure here means "use the portable path"
                 ok = 0
                 self.fallback_reason = repr(e)
-            if world > 1:  # every rank must take the same path
+            if _dist_on():  # every rank must take the same path
                 import torch.distributed as dist
                 flag = torch.tensor([ok], dtype=torch.int32, device=dev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
@@ -141,7 +149,7 @@ class MaskGatherer:
         if self.rank == 0 and lib.ncclGetUniqueId(C.byref(uid)) == 0:
             t[:128].copy_(torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8))
             t[128] = 1
-        if self.world > 1:
+        if _dist_on():
             dist.broadcast(t, 0, group=self.group)  # always reached by every rank
         host = t.cpu().numpy()
         if host[128] != 1:

@@ -634,3 +634,56 @@ def test_sparse_dirty_upload_and_changed_readback(ctx_factory, static_opt):
                                          tree_changed=O.mark_dirty_trees(parent, none), transform_changed=none)
     # without the static-scene optimisation every root with children is re-assigned each frame (systems.rs:522-530)
     assert np.array_equal(rows, np.nonzero(chg)[0].astype(np.uint32)) and (static_opt and len(rows) == 0 or not static_opt)
+
+
+def test_columns_grow_and_shrink_keep_rows(ctx_factory):
+    """mi_columns_resize: growing reallocates the columns (contents of existing rows kept), shrinking keeps them."""
+    n0, n1 = 5_000, 70_000
+    sc = W.many_cubes(n1, ragged_flags=True)
+    frusta = frusta_for([W.many_cubes_camera(1)])
+    ctx = ctx_factory()
+    ctx.resize(n0)
+    ctx.upload_transforms(sc["translation"][:3 * n0], sc["rotation"][:4 * n0], sc["scale"][:3 * n0])
+    ctx.upload_bounds(sc["aabb_center"][:3 * n0], sc["aabb_half"][:3 * n0], sc["flags"][:n0], sc["layers"][:n0])
+    ctx.resize(n1)   # grows: rows [0, n0) must survive the reallocation
+    ctx.upload_transforms(sc["translation"][3 * n0:], sc["rotation"][4 * n0:], sc["scale"][3 * n0:], first_row=n0)
+    ctx.upload_bounds(sc["aabb_center"][3 * n0:], sc["aabb_half"][3 * n0:], sc["flags"][n0:], sc["layers"][n0:], first_row=n0)
+    ctx.propagate_and_cull(frusta, flags=B.CULL_END_FRAME)
+    g_exp, vv_exp, vis_exp, _ = oracle_frame(sc, np.zeros(n1, np.uint8), frusta, None, None)
+    assert ctx.download_global_transforms(want_changed=False).tobytes() == g_exp.tobytes()
+    assert_bits(ctx.download_visibility(0), vis_exp[0], "after growth")
+    ctx.resize(n0)   # shrink: the first rows are still there
+    ctx.propagate_and_cull(frusta, flags=B.CULL_END_FRAME)
+    assert ctx.download_global_transforms(want_changed=False).tobytes() == g_exp[:12 * n0].tobytes()
+    assert_bits(ctx.download_visibility(0), vis_exp[0][:n0], "after shrink")
+    ctx.resize(0)
+    ctx.propagate_and_cull(frusta, flags=B.CULL_END_FRAME)
+    assert len(ctx.download_visibility(0)) == 0
+
+
+def test_error_codes(ctx_factory):
+    ctx = ctx_factory()
+    ctx.resize(100)
+    with pytest.raises(api.MiError) as e:
+        ctx.upload_transforms(np.zeros(3 * 200, F), np.zeros(4 * 200, F), np.zeros(3 * 200, F))
+    assert e.value.code == api.MI_ERR_INVALID_ARG
+    with pytest.raises(api.MiError) as e:
+        ctx.upload_transforms_indexed(np.array([5, 100], np.uint32), np.zeros(6, F), np.zeros(8, F), np.zeros(6, F))
+    assert e.value.code == api.MI_ERR_INVALID_ARG
+    with pytest.raises(api.MiError) as e:
+        ctx.download_visibility(0)                      # nothing culled yet
+    assert e.value.code == api.MI_ERR_NOT_READY
+    with pytest.raises(api.MiError) as e:               # a child whose parent is not in the previous level
+        ctx.upload_hierarchy(np.array([B.NO_PARENT] + [0] * 98 + [50], np.uint32), np.array([0, 1, 100], np.uint32))
+    assert e.value.code == api.MI_ERR_MALFORMED_HIERARCHY
+    with pytest.raises(api.MiError) as e:
+        api.hierarchy_sort(np.array([1, 0], np.uint32))  # a 2-cycle
+    assert e.value.code == api.MI_ERR_MALFORMED_HIERARCHY
+    frusta = frusta_for([W.many_cubes_camera(0)])
+    ctx.upload_hierarchy(np.array([B.NO_PARENT] + [0] * 99, np.uint32), np.array([0, 1, 100], np.uint32))
+    with pytest.raises(api.MiError) as e:
+        ctx.propagate_and_cull(frusta)                   # flat fast path refuses a context with a hierarchy
+    assert e.value.code == api.MI_ERR_NOT_READY
+    with pytest.raises(api.MiError) as e:
+        api.Context(device=4096)
+    assert e.value.code == api.MI_ERR_INVALID_ARG

@@ -89,7 +89,7 @@ ABI_SYMBOLS = [
     "mi_download_global_transforms", "mi_download_changed_global_transforms", "mi_download_visibility", "mi_download_view_visibility",
     "mi_download_visible_entities", "mi_cluster_view_dims", "mi_cluster_view_build",
     "mi_cluster_dimensions_fixed_z", "mi_cluster_assign", "mi_cluster_upload_objects", "mi_cluster_upload_view",
-    "mi_cluster_assign_resident", "mi_cluster_download", "mi_perspective_clip_from_view", "mi_compute_frustum",
+    "mi_cluster_assign_resident", "mi_cluster_download", "mi_cluster_download_bindings", "mi_perspective_clip_from_view", "mi_compute_frustum",
     "mi_bind_visibility_output", "mi_exchange_configure", "mi_exchange_last", "mi_device_buffer", "mi_timer_begin", "mi_timer_end", "mi_profile_enable",
     "mi_profile_filter", "mi_profile_sample", "mi_profile_read", "mi_profile_kernel_name",
 ]
@@ -436,6 +436,18 @@ class Context:
         self._ck(self._lib.mi_cluster_download(self._h, None, _ptr(indices, C.c_uint32), C.c_uint64(len(indices)), None,
                                                C.byref(tot), None))
         return offsets, indices[:tot.value], counts.reshape(n_clusters, 6), float(far.value), int(tot.value)
+
+    def cluster_download_bindings(self, n_clusters, remap=None):
+        """-> (offsets_and_counts u32[C, 8], index_list u32[total]) in the storage-buffer wire format."""
+        rm = _u32(remap)
+        tot = C.c_uint64(0)
+        oc = np.zeros(8 * n_clusters, np.uint32)
+        self._ck(self._lib.mi_cluster_download_bindings(self._h, _ptr(rm, C.c_uint32), 0 if rm is None else len(rm),
+                                                        _ptr(oc, C.c_uint32), None, C.c_uint64(0), C.byref(tot)))
+        idx = np.zeros(max(tot.value, 1), np.uint32)
+        self._ck(self._lib.mi_cluster_download_bindings(self._h, _ptr(rm, C.c_uint32), 0 if rm is None else len(rm), None,
+                                                        _ptr(idx, C.c_uint32), C.c_uint64(len(idx)), C.byref(tot)))
+        return oc.reshape(n_clusters, 8), idx[:tot.value]
 
     # interop / timing
     def bind_visibility_output(self, device_ptr, words_per_view, word_offset):

@@ -138,7 +138,7 @@ struct mi_ctx {
 
     // ---- clustering ----
     DevBuf cl_pos, cl_type, cl_layers, cl_dir, cl_sincos, cl_planes, cl_spheres;
-    DevBuf cl_block_counts, cl_pair_cb, cl_pair_mask, cl_acc, cl_offsets, cl_indices, cl_scalars;
+    DevBuf cl_remap, cl_bind_oc, cl_bind_idx, cl_block_counts, cl_pair_cb, cl_pair_mask, cl_acc, cl_offsets, cl_indices, cl_scalars;
     uint32_t cl_parity = 0, cl_acc_clusters = 0, cl_acc_blocks = 0;  // cl_acc = 2 x [counts 6C | totals C | farthest_z + pad]
     uint32_t cl_n = 0;
     bool cl_have_type = false, cl_have_layers = false, cl_have_spot = false, cl_any_spot = false;
@@ -667,7 +667,7 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->order, &ctx->chains, &ctx->snap, &ctx->inh_bits, &ctx->sparse_cnt, &ctx->sparse_rows, &ctx->sparse_total, &ctx->sparse_g, &ctx->parent_idx, &ctx->node_flags, &ctx->tiles, &ctx->views, &ctx->bitmask,
                       &ctx->block_counts, &ctx->seg_totals, &ctx->seg_bases, &ctx->out_rows, &ctx->out_keys, &ctx->wave_cnt, &ctx->seg_mask, &ctx->cl_pos,
                       &ctx->cl_type, &ctx->cl_layers, &ctx->cl_dir, &ctx->cl_sincos, &ctx->cl_planes, &ctx->cl_spheres,
-                      &ctx->cl_block_counts, &ctx->cl_pair_cb, &ctx->cl_pair_mask, &ctx->cl_acc,
+                      &ctx->cl_remap, &ctx->cl_bind_oc, &ctx->cl_bind_idx, &ctx->cl_block_counts, &ctx->cl_pair_cb, &ctx->cl_pair_mask, &ctx->cl_acc,
                       &ctx->cl_offsets, &ctx->cl_indices, &ctx->cl_scalars};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
@@ -1577,6 +1577,40 @@ int32_t mi_cluster_download(mi_ctx* ctx, uint32_t* out_offsets, uint32_t* out_in
     return MI_OK;
 }
 
+int32_t mi_cluster_download_bindings(mi_ctx* ctx, const uint32_t* remap, uint32_t n_remap, uint32_t* out_offsets_and_counts,
+                                     uint32_t* out_index_list, uint64_t capacity, uint64_t* out_total) {
+    ENTER(ctx);
+    if (!ctx->cl_assigned) return fail(ctx, MI_ERR_NOT_READY, "mi_cluster_download_bindings before mi_cluster_assign_resident");
+    const uint32_t C = ctx->cl_view.n_clusters;
+    uint64_t total = 0;
+    int32_t rc;
+    if ((rc = download(ctx, &total, ctx->cl_scalars.p, 8))) return rc;
+    if (total > ctx->cl_indices.bytes / 4) {  // fire-and-forget assign overflowed: redo with a big enough buffer
+        uint64_t t2 = 0;
+        if ((rc = mi_cluster_assign_resident(ctx, &t2))) return rc;
+        total = t2;
+    }
+    if (out_total) *out_total = total;
+    const size_t off_totals = (6 * (size_t)C + 3) & ~(size_t)3, off_misc = off_totals + (((size_t)C + 3) & ~(size_t)3);
+    const uint32_t* acc = (const uint32_t*)ctx->cl_acc.p + ctx->cl_parity * (off_misc + 4);
+    if ((rc = ensure(ctx, ctx->cl_bind_oc, (size_t)C * 32))) return rc;
+    if ((rc = ensure(ctx, ctx->cl_bind_idx, std::max<size_t>(total, 1) * 4))) return rc;
+    const uint32_t* d_remap = nullptr;
+    if (remap) {
+        if ((rc = ensure(ctx, ctx->cl_remap, std::max<size_t>(n_remap, 1) * 4))) return rc;
+        if ((rc = upload(ctx, ctx->cl_remap.p, remap, (size_t)n_remap * 4))) return rc;
+        d_remap = (const uint32_t*)ctx->cl_remap.p;
+    }
+    HIP_TRY(ctx, launch_cluster_bindings(C, (const uint32_t*)ctx->cl_offsets.p, acc, (const uint32_t*)ctx->cl_indices.p, d_remap, n_remap,
+                                         total, (uint32_t*)ctx->cl_bind_oc.p, (uint32_t*)ctx->cl_bind_idx.p, ctx->stream));
+    if (out_offsets_and_counts && (rc = download(ctx, out_offsets_and_counts, ctx->cl_bind_oc.p, (size_t)C * 32))) return rc;
+    if (out_index_list) {
+        if (total > capacity) return fail(ctx, MI_ERR_CAPACITY, "cluster index list has %llu entries, capacity %llu", (unsigned long long)total, (unsigned long long)capacity);
+        if ((rc = download(ctx, out_index_list, ctx->cl_bind_idx.p, (size_t)total * 4))) return rc;
+    }
+    return MI_OK;
+}
+
 int32_t mi_cluster_assign(mi_ctx* ctx, const mi_cluster_view* view, uint32_t n_objects, const float* pos_range,
                           const uint8_t* obj_type, const uint32_t* layer_mask, const float* spot_dir, const float* spot_sin_cos,
                           uint32_t* out_offsets, uint32_t* out_indices, uint64_t capacity, uint32_t* out_counts,
@@ -1715,6 +1749,8 @@ int32_t mi_device_buffer(mi_ctx* ctx, uint32_t which, void** out_ptr, uint64_t* 
         break;
     case MI_BUF_VIEW_VISIBILITY: p = ctx->vv; bytes = ctx->n; break;
     case MI_BUF_VISIBLE_ROWS: p = ctx->out_rows.p; bytes = ctx->out_rows.bytes; break;
+    case MI_BUF_CLUSTER_OFFSETS_AND_COUNTS: p = ctx->cl_bind_oc.p; bytes = ctx->cl_bind_oc.bytes; break;
+    case MI_BUF_CLUSTER_INDEX_LIST: p = ctx->cl_bind_idx.p; bytes = ctx->cl_bind_idx.bytes; break;
     default: return fail(ctx, MI_ERR_INVALID_ARG, "mi_device_buffer: unknown buffer %u", which);
     }
     *out_ptr = p;

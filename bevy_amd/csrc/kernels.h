@@ -253,6 +253,9 @@ struct ClusterWork {
     uint64_t capacity;
     uint64_t* total;              // [1] out
 };
+hipError_t launch_cluster_bindings(uint32_t n_clusters, const uint32_t* offsets, const uint32_t* counts, const uint32_t* indices,
+                                   const uint32_t* remap, uint32_t n_remap, uint64_t capacity, uint32_t* out_oc,
+                                   uint32_t* out_idx, hipStream_t stream);
 hipError_t launch_cluster_assign(const ClusterViewDev& view, const ClusterObjects& objs, const ClusterWork& w,
                                  hipStream_t stream, void (*mark)(void*, uint32_t), void* mark_ctx);
 

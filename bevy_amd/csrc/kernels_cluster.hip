@@ -445,6 +445,33 @@ __global__ void __launch_bounds__(256) k_cluster_fill(ClusterWork w, uint32_t C,
     }
 }
 
+// The storage-buffer wire format of a view's clusters (crates/bevy_pbr/src/cluster/mod.rs:478-582,634-650): per
+// cluster [uvec4(offset, point, spot, rect), uvec4(reflection probes, irradiance volumes, decals, 0)] and the flat index
+// list with object indices replaced by their render-world indices.
+__global__ void __launch_bounds__(256) k_cluster_bindings(uint32_t n_clusters, const uint32_t* __restrict__ offsets,
+                                                           const uint32_t* __restrict__ counts,
+                                                           const uint32_t* __restrict__ indices,
+                                                           const uint32_t* __restrict__ remap, uint32_t n_remap,
+                                                           uint64_t capacity, uint4* out_oc, uint32_t* out_idx) {
+    const uint32_t total = offsets[n_clusters];
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_clusters; i += gridDim.x * 256u) {
+        out_oc[2u * i] = make_uint4(offsets[i], counts[6u * i], counts[6u * i + 1u], counts[6u * i + 2u]);
+        out_oc[2u * i + 1u] = make_uint4(counts[6u * i + 3u], counts[6u * i + 4u], counts[6u * i + 5u], 0u);
+    }
+    const uint64_t lim = total < capacity ? total : capacity;
+    for (uint64_t i = blockIdx.x * 256u + threadIdx.x; i < lim; i += (uint64_t)gridDim.x * 256u) {
+        const uint32_t obj = indices[i];
+        out_idx[i] = remap ? (obj < n_remap ? remap[obj] : 0xFFFFFFFFu) : obj;
+    }
+}
+hipError_t launch_cluster_bindings(uint32_t n_clusters, const uint32_t* offsets, const uint32_t* counts, const uint32_t* indices,
+                                   const uint32_t* remap, uint32_t n_remap, uint64_t capacity, uint32_t* out_oc,
+                                   uint32_t* out_idx, hipStream_t stream) {
+    MI_LAUNCH(k_cluster_bindings, dim3(1024), dim3(256), 0, stream, n_clusters, offsets, counts, indices, remap, n_remap, capacity,
+              reinterpret_cast<uint4*>(out_oc), out_idx);
+    return hipGetLastError();
+}
+
 hipError_t launch_cluster_assign(const ClusterViewDev& view, const ClusterObjects& objs, const ClusterWork& w,
                                  hipStream_t stream, void (*mark)(void*, uint32_t), void* mctx) {
     const uint32_t C = view.n_clusters;

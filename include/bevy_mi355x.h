@@ -344,6 +344,18 @@ int32_t mi_cluster_assign_resident(mi_ctx* ctx, uint64_t* out_total);
 int32_t mi_cluster_download(mi_ctx* ctx, uint32_t* out_offsets, uint32_t* out_indices, uint64_t capacity,
                             uint32_t* out_counts, uint64_t* out_total, float* out_farthest_z);
 
+/* The GPU wire format of the view's clusters, storage-buffer flavour, built on the device from the last
+ * assignment: what extract_clusters_for_cpu_clustering + prepare_clusters_for_cpu_clustering assemble element by
+ * element on the CPU (crates/bevy_pbr/src/cluster/mod.rs:394-476,478-582; push_offset_and_counts :634-650):
+ *   out_offsets_and_counts[8*C]  per cluster uvec4(offset, point, spot, rect), uvec4(reflection probes, irradiance
+ *                                volumes, decals, 0)
+ *   out_index_list[total]        remap[object] for every entry in cluster order; remap = the shim's table
+ *                                object -> GlobalClusterableObjectMeta::entity_to_index / render light-probe index
+ *                                (0xFFFFFFFF = push_dummy_index, :698-700); NULL = the object index itself.
+ * The same arrays stay on the device as MI_BUF_CLUSTER_OFFSETS_AND_COUNTS / MI_BUF_CLUSTER_INDEX_LIST. */
+int32_t mi_cluster_download_bindings(mi_ctx* ctx, const uint32_t* remap, uint32_t n_remap, uint32_t* out_offsets_and_counts,
+                                     uint32_t* out_index_list, uint64_t capacity, uint64_t* out_total);
+
 /* ======================================================================================= */
 /* camera helpers (pure host code; what update_frusta computes, visibility/mod.rs:627-636)   */
 /* ======================================================================================= */
@@ -391,6 +403,8 @@ int32_t mi_exchange_last(mi_ctx* ctx, void** out_device_buf, int32_t wait);
 #define MI_BUF_VISIBILITY_BITMASK 1
 #define MI_BUF_VIEW_VISIBILITY 2
 #define MI_BUF_VISIBLE_ROWS 3
+#define MI_BUF_CLUSTER_OFFSETS_AND_COUNTS 4
+#define MI_BUF_CLUSTER_INDEX_LIST 5
 int32_t mi_device_buffer(mi_ctx* ctx, uint32_t which, void** out_device_ptr, uint64_t* out_bytes);
 
 /* HIP-event timing on the context's stream (torch.cuda.Event only sees torch's stream). */

@@ -1216,6 +1216,27 @@ uint64_t orc_assign_objects_to_clusters(const orc_cluster_view* view, uint32_t n
     return cc.total;
 }
 
+void orc_cluster_bindings_storage(uint32_t n_clusters, const uint32_t* offsets, const uint32_t* counts,
+                                  const uint32_t* indices, const uint32_t* remap,
+                                  uint32_t* out_oc, uint32_t* out_idx) {
+    uint32_t n_indices = 0; /* ViewClusterBindings::n_indices */
+    for (uint32_t c = 0; c < n_clusters; ++c) {
+        /* ClusterHeader -> push_offset_and_counts(n_indices, counts) */
+        out_oc[8 * c + 0] = n_indices;
+        out_oc[8 * c + 1] = counts[6 * c + 0]; /* point_lights */
+        out_oc[8 * c + 2] = counts[6 * c + 1]; /* spot_lights */
+        out_oc[8 * c + 3] = counts[6 * c + 2]; /* rect_lights */
+        out_oc[8 * c + 4] = counts[6 * c + 3]; /* reflection_probes */
+        out_oc[8 * c + 5] = counts[6 * c + 4]; /* irradiance_volumes */
+        out_oc[8 * c + 6] = counts[6 * c + 5]; /* decals */
+        out_oc[8 * c + 7] = 0;
+        for (uint32_t i = offsets[c]; i < offsets[c + 1]; ++i) {
+            uint32_t obj = indices[i];
+            out_idx[n_indices++] = remap ? remap[obj] : obj; /* push_index / push_dummy_index (!0) */
+        }
+    }
+}
+
 /* ======================================================================================= */
 /* CPU baseline driver: Bevy-shaped par_iter (one batch of ceil(n/threads) rows per thread,  */
 /* crates/bevy_ecs/src/batching.rs:95-106), systems run back-to-back with a join in between  */

@@ -267,6 +267,17 @@ uint64_t orc_assign_objects_to_clusters(const orc_cluster_view* view, uint32_t n
                                         uint32_t* offsets, uint32_t* indices, uint64_t capacity,
                                         uint32_t* counts, float* farthest_z_out);
 
+/* The GPU wire format of one view's clusters, storage-buffer flavour: extract_clusters_for_cpu_clustering +
+ * prepare_clusters_for_cpu_clustering, crates/bevy_pbr/src/cluster/mod.rs:394-476,478-582, push_offset_and_counts
+ * :634-650, push_index / push_dummy_index :690-700.  Input = the per-cluster lists (CSR) and counts the assignment
+ * produced; remap[object] = GlobalClusterableObjectMeta::entity_to_index / render light-probe index (0xFFFFFFFF =
+ * not loaded yet -> push_dummy_index); NULL = identity.
+ *   out_offsets_and_counts u32[8*C]: uvec4(offset, point, spot, rect), uvec4(refl probes, irradiance vols, decals, 0)
+ *   out_index_list u32[total] */
+void orc_cluster_bindings_storage(uint32_t n_clusters, const uint32_t* offsets, const uint32_t* counts,
+                                  const uint32_t* indices, const uint32_t* remap,
+                                  uint32_t* out_offsets_and_counts, uint32_t* out_index_list);
+
 /* ---- CPU baseline drivers (Bevy-shaped: ceil(n/threads) batches, batching.rs:95-106) ---- */
 
 /* One frame of the flat path on `threads` pthreads: sync_simple_transforms (all dirty) +

@@ -370,6 +370,18 @@ def assign_objects_to_clusters(view, pos_range, obj_type=None, layer_mask=None, 
     return offsets, indices[:min(int(total), capacity)], counts.reshape(ncl, 6), float(far.value), int(total)
 
 
+def cluster_bindings_storage(offsets, counts, indices, remap=None):
+    ncl = len(offsets) - 1
+    oc = np.zeros(8 * ncl, np.uint32)
+    idx = np.zeros(max(len(indices), 1), np.uint32)
+    lib().orc_cluster_bindings_storage(ncl, u32p(np.ascontiguousarray(offsets, np.uint32)),
+                                       u32p(np.ascontiguousarray(counts, np.uint32).reshape(-1)),
+                                       u32p(np.ascontiguousarray(indices, np.uint32)),
+                                       u32p(np.ascontiguousarray(remap, np.uint32)) if remap is not None else None,
+                                       u32p(oc), u32p(idx))
+    return oc, idx[:len(indices)]
+
+
 def bench_flat_frame(t, r, s, c, h, flags, layers, frusta, threads, iters):
     n = len(flags)
     nv = len(frusta) // 24

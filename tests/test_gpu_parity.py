@@ -496,6 +496,30 @@ def test_cluster_many_blocks_and_growth(ctx_factory):
     assert cluster_case(ctx, cam, pr) == t1
 
 
+def test_cluster_wire_format_bindings(ctx_factory):
+    """The storage-buffer bindings (cluster_offsets_and_counts + clusterable_object_index_lists) built on the device
+    equal the element-by-element CPU assembly of prepare_clusters_for_cpu_clustering, with and without a remap."""
+    ctx = ctx_factory()
+    cam = W.many_cubes_camera(0)
+    rng = np.random.default_rng(4)
+    n = 3_000
+    pr = W.many_lights(n, 50.0, 3.0).reshape(n, 4)[::-1].copy()   # visible ones first
+    types = np.sort(rng.integers(0, 6, n)).astype(np.uint8)        # gather order: grouped by type
+    types[types == 1] = 0                                          # (no spot lights: they need cone inputs)
+    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+    fr = api.compute_frustum(cfv, cam, W.CAMERA_FAR)
+    view, keep = api.cluster_view_build(cam, cfv, fr, 1920, 1080, (16, 9, 24), 5.0, 1000.0)
+    off, idx, counts, far, total = ctx.cluster_assign(view, pr.reshape(-1), types)
+    assert total > 0
+    remap = rng.permutation(n).astype(np.uint32)
+    remap[rng.random(n) < 0.05] = 0xFFFFFFFF                       # probes that have not loaded yet
+    for rm in (None, remap):
+        oc, il = ctx.cluster_download_bindings(view.n_clusters, rm)
+        eoc, eil = O.cluster_bindings_storage(off, counts, idx, rm)
+        assert np.array_equal(oc.reshape(-1), eoc) and np.array_equal(il, eil)
+    assert np.array_equal(oc[:, 0], off[:-1]) and np.array_equal(oc[:, 1:4], counts[:, 0:3]) and np.array_equal(oc[:, 4:7], counts[:, 3:6])
+
+
 def test_device_logf_matches_libm(ctx_factory):
     ctx = ctx_factory()
     rng = np.random.default_rng(3)

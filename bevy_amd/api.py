@@ -86,7 +86,7 @@ ABI_SYMBOLS = [
     "mi_visibility_propagate", "mi_download_inherited_visibility",
     "mi_visibility_begin_frame", "mi_cull", "mi_cull_views", "mi_propagate_and_cull", "mi_propagate_and_cull_views",
     "mi_visibility_end_frame",
-    "mi_download_global_transforms", "mi_download_changed_global_transforms", "mi_download_visibility", "mi_download_view_visibility",
+    "mi_download_global_transforms", "mi_download_changed_global_transforms", "mi_download_changed_mesh_inputs", "mi_download_visibility", "mi_download_view_visibility",
     "mi_download_visible_entities", "mi_cluster_view_dims", "mi_cluster_view_build",
     "mi_cluster_dimensions_fixed_z", "mi_cluster_assign", "mi_cluster_upload_objects", "mi_cluster_upload_view",
     "mi_cluster_assign_resident", "mi_cluster_download", "mi_cluster_download_bindings", "mi_perspective_clip_from_view", "mi_compute_frustum",
@@ -380,6 +380,20 @@ class Context:
         g = np.zeros(12 * max(m, 1), np.float32)
         self._ck(self._lib.mi_download_changed_global_transforms(self._h, _ptr(rows, C.c_uint32), _ptr(g, C.c_float), m, C.byref(cnt)))
         return rows[:m], g[:12 * m]
+
+    def download_changed_mesh_inputs(self):
+        """-> (rows, world_from_local f32[12m] transposed 3x4, culling f32[8m]) for rows whose GlobalTransform changed."""
+        cnt = C.c_uint32(0)
+        rc = self._lib.mi_download_changed_mesh_inputs(self._h, None, None, None, 0, C.byref(cnt))
+        if rc not in (MI_OK, MI_ERR_CAPACITY):
+            self._ck(rc)
+        m = cnt.value
+        rows = np.zeros(max(m, 1), np.uint32)
+        wfl = np.zeros(12 * max(m, 1), np.float32)
+        cull = np.zeros(8 * max(m, 1), np.float32)
+        self._ck(self._lib.mi_download_changed_mesh_inputs(self._h, _ptr(rows, C.c_uint32), _ptr(wfl, C.c_float),
+                                                           _ptr(cull, C.c_float), m, C.byref(cnt)))
+        return rows[:m], wfl[:12 * m], cull[:8 * m]
 
     def download_visibility(self, view=0):
         bm = np.zeros((self.n + 31) // 32, np.uint32)

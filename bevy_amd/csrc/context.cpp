@@ -1299,18 +1299,13 @@ int32_t mi_download_global_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t 
     return MI_OK;
 }
 
-int32_t mi_download_changed_global_transforms(mi_ctx* ctx, uint32_t* out_rows, float* out_global12, uint32_t capacity,
-                                              uint32_t* out_count) {
-    ENTER(ctx);
-    if (!out_count) return fail(ctx, MI_ERR_INVALID_ARG, "mi_download_changed_global_transforms: out_count NULL");
-    *out_count = 0;
-    if (ctx->n == 0) return MI_OK;
+// Compacts the GlobalTransform change mask into an ascending row list on the device; *total = its length.
+static int32_t changed_rows_on_device(mi_ctx* ctx, uint32_t* total) {
     int32_t rc;
     if (ctx->g_chg_in_bytes) {
         HIP_TRY(ctx, launch_bytes_to_bits(ctx->g_changed_bytes, ctx->n, ctx->g_chg_bits, ctx->stream));
         ctx->g_chg_in_bytes = false;
     }
-    // compact the change mask into an ascending row list on the device, gather those rows' matrices, copy both out
     const uint32_t n_waves = (uint32_t)((padded_words(ctx->cap) + 63u) / 64u * 64u);
     if ((rc = ensure(ctx, ctx->sparse_cnt, n_waves))) return rc;
     if ((rc = ensure(ctx, ctx->sparse_rows, (size_t)ctx->cap * 4))) return rc;
@@ -1328,8 +1323,18 @@ int32_t mi_download_changed_global_transforms(mi_ctx* ctx, uint32_t* out_rows, f
     f.seg_stride = ctx->cap;
     f.seg_totals = (uint32_t*)ctx->sparse_total.p;
     HIP_TRY(ctx, launch_compact_fast(f, ctx->stream));
+    return download(ctx, total, ctx->sparse_total.p, 4);
+}
+
+int32_t mi_download_changed_global_transforms(mi_ctx* ctx, uint32_t* out_rows, float* out_global12, uint32_t capacity,
+                                              uint32_t* out_count) {
+    ENTER(ctx);
+    if (!out_count) return fail(ctx, MI_ERR_INVALID_ARG, "mi_download_changed_global_transforms: out_count NULL");
+    *out_count = 0;
+    if (ctx->n == 0) return MI_OK;
+    int32_t rc;
     uint32_t total = 0;
-    if ((rc = download(ctx, &total, ctx->sparse_total.p, 4))) return rc;
+    if ((rc = changed_rows_on_device(ctx, &total))) return rc;
     *out_count = total;
     if (total > capacity) return fail(ctx, MI_ERR_CAPACITY, "%u GlobalTransforms changed, capacity %u", total, capacity);
     if (total == 0) return MI_OK;
@@ -1339,6 +1344,31 @@ int32_t mi_download_changed_global_transforms(mi_ctx* ctx, uint32_t* out_rows, f
         HIP_TRY(ctx, launch_gather_global((const uint32_t*)ctx->sparse_rows.p, (const uint32_t*)ctx->sparse_total.p, total, ctx->g,
                                           (float*)ctx->sparse_g.p, ctx->stream));
         if ((rc = download(ctx, out_global12, ctx->sparse_g.p, (size_t)total * 48))) return rc;
+    }
+    return MI_OK;
+}
+
+int32_t mi_download_changed_mesh_inputs(mi_ctx* ctx, uint32_t* out_rows, float* out_world_from_local12, float* out_culling8,
+                                        uint32_t capacity, uint32_t* out_count) {
+    ENTER(ctx);
+    if (!out_count) return fail(ctx, MI_ERR_INVALID_ARG, "mi_download_changed_mesh_inputs: out_count NULL");
+    *out_count = 0;
+    if (ctx->n == 0) return MI_OK;
+    int32_t rc;
+    uint32_t total = 0;
+    if ((rc = changed_rows_on_device(ctx, &total))) return rc;
+    *out_count = total;
+    if (total > capacity) return fail(ctx, MI_ERR_CAPACITY, "%u GlobalTransforms changed, capacity %u", total, capacity);
+    if (total == 0) return MI_OK;
+    if (out_rows && (rc = download(ctx, out_rows, ctx->sparse_rows.p, (size_t)total * 4))) return rc;
+    if (out_world_from_local12 || out_culling8) {
+        if ((rc = ensure(ctx, ctx->sparse_g, (size_t)total * 80))) return rc;
+        float* wfl = (float*)ctx->sparse_g.p;
+        float* cull = wfl + 12 * (size_t)total;
+        HIP_TRY(ctx, launch_gather_mesh_inputs((const uint32_t*)ctx->sparse_rows.p, (const uint32_t*)ctx->sparse_total.p, total,
+                                               columns_of(ctx), wfl, cull, ctx->stream));
+        if (out_world_from_local12 && (rc = download(ctx, out_world_from_local12, wfl, (size_t)total * 48))) return rc;
+        if (out_culling8 && (rc = download(ctx, out_culling8, cull, (size_t)total * 32))) return rc;
     }
     return MI_OK;
 }

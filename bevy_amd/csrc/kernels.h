@@ -135,6 +135,8 @@ hipError_t launch_upload_trs_indexed(const uint32_t* pinned_src, uint32_t n, flo
 hipError_t launch_popcount_words(const uint64_t* bits, uint32_t n_rows, uint8_t* cnt, hipStream_t stream);
 hipError_t launch_gather_global(const uint32_t* rows, const uint32_t* total, uint32_t capacity, const float* g, float* out,
                                 hipStream_t stream);
+hipError_t launch_gather_mesh_inputs(const uint32_t* rows, const uint32_t* total, uint32_t capacity, const Columns& c, float* out_wfl,
+                                     float* out_cull, hipStream_t stream);
 constexpr uint32_t SMALL_UPLOAD_ROWS = 4096;  // at or below this, Transform uploads take the one-kernel path
 hipError_t launch_vis_begin(const Columns& c, hipStream_t stream);
 hipError_t launch_vis_end(const Columns& c, hipStream_t stream);

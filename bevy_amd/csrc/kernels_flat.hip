@@ -386,6 +386,37 @@ __global__ void __launch_bounds__(256) k_gather_global(const uint32_t* __restric
         reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(g)[3ull * row + (i % 3u)];
     }
 }
+// Mesh-instance wire format for the listed rows: MeshInputUniform::world_from_local (the affine transposed to three
+// Vec4 rows, bevy_math/src/affine3.rs:27-34) and MeshCullingData (center / half extents as Vec4, infinite half
+// extents without an Aabb, bevy_pbr/src/render/mesh.rs:1646-1657).
+__global__ void __launch_bounds__(256) k_gather_mesh_inputs(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ total,
+                                                             uint32_t capacity, Columns c, float4* out_wfl, float4* out_cull) {
+    const uint32_t m = *total < capacity ? *total : capacity;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < m; i += gridDim.x * 256u) {
+        const uint32_t row = rows[i];
+        const Affine g = ld_affine(c.global, row);
+        out_wfl[3u * i] = make_float4(g.m.x_axis.x, g.m.y_axis.x, g.m.z_axis.x, g.t.x);
+        out_wfl[3u * i + 1u] = make_float4(g.m.x_axis.y, g.m.y_axis.y, g.m.z_axis.y, g.t.y);
+        out_wfl[3u * i + 2u] = make_float4(g.m.x_axis.z, g.m.y_axis.z, g.m.z_axis.z, g.t.z);
+        if (c.flags[row] & 0x04u) {
+            const V3 ce = ld3(c.aabb_center, row), he = ld3(c.aabb_half, row);
+            out_cull[2u * i] = make_float4(ce.x, ce.y, ce.z, 0.0f);
+            out_cull[2u * i + 1u] = make_float4(he.x, he.y, he.z, 0.0f);
+        } else {
+            out_cull[2u * i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            out_cull[2u * i + 1u] = make_float4(INFINITY, INFINITY, INFINITY, 0.0f);
+        }
+    }
+}
+hipError_t launch_gather_mesh_inputs(const uint32_t* rows, const uint32_t* total, uint32_t capacity, const Columns& c, float* out_wfl,
+                                     float* out_cull, hipStream_t stream) {
+    if (capacity == 0) return hipSuccess;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(2048, ((uint64_t)capacity + 255) / 256);
+    MI_LAUNCH(k_gather_mesh_inputs, dim3(blocks), dim3(256), 0, stream, rows, total, capacity, c, reinterpret_cast<float4*>(out_wfl),
+              reinterpret_cast<float4*>(out_cull));
+    return hipGetLastError();
+}
+
 hipError_t launch_popcount_words(const uint64_t* bits, uint32_t n_rows, uint8_t* cnt, hipStream_t stream) {
     const uint32_t n_words = (n_rows + 63u) / 64u;
     if (n_words == 0) return hipSuccess;

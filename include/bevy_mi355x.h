@@ -263,6 +263,14 @@ int32_t mi_download_global_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t 
 int32_t mi_download_changed_global_transforms(mi_ctx* ctx, uint32_t* out_rows, float* out_global12, uint32_t capacity,
                                               uint32_t* out_count);
 
+/* The same rows in the render world's mesh-instance wire format (next row 8f-3 i): MeshInputUniform::world_from_local
+ * = the affine transposed to three Vec4 rows (crates/bevy_math/src/affine3.rs:27-34, crates/bevy_pbr/src/render/
+ * mesh.rs:568-571) and MeshCullingData (aabb center / half extents as Vec4; infinite half extents without an Aabb,
+ * mesh.rs:1646-1657), i.e. the transform / bounds part of what extract_meshes_for_gpu_building (mesh.rs:1933-2262)
+ * rebuilds per changed mesh on the CPU.  The remaining MeshInputUniform fields are renderer bookkeeping. */
+int32_t mi_download_changed_mesh_inputs(mi_ctx* ctx, uint32_t* out_rows, float* out_world_from_local12, float* out_culling8,
+                                        uint32_t capacity, uint32_t* out_count);
+
 /* Packed per-view visibility of the last mi_cull: bit r of word r/32 = row r reached set_visible()
  * for that view.  bitmask has ceil(n_rows/32) words. */
 int32_t mi_download_visibility(mi_ctx* ctx, uint32_t view, uint32_t* bitmask);

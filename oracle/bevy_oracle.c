@@ -1216,6 +1216,23 @@ uint64_t orc_assign_objects_to_clusters(const orc_cluster_view* view, uint32_t n
     return cc.total;
 }
 
+void orc_mesh_inputs(const float g[12], const float c[3], const float h[3], int has_aabb, float wfl[12], float cull[8]) {
+    /* transpose_3x3.{x,y,z}_axis.extend(translation.{x,y,z}) */
+    for (int r = 0; r < 3; ++r) {
+        wfl[4 * r + 0] = g[0 + r];
+        wfl[4 * r + 1] = g[3 + r];
+        wfl[4 * r + 2] = g[6 + r];
+        wfl[4 * r + 3] = g[9 + r];
+    }
+    if (has_aabb) {
+        cull[0] = c[0]; cull[1] = c[1]; cull[2] = c[2]; cull[3] = 0.0f;
+        cull[4] = h[0]; cull[5] = h[1]; cull[6] = h[2]; cull[7] = 0.0f;
+    } else {
+        cull[0] = cull[1] = cull[2] = cull[3] = 0.0f;
+        cull[4] = cull[5] = cull[6] = INFINITY; cull[7] = 0.0f;
+    }
+}
+
 void orc_cluster_bindings_storage(uint32_t n_clusters, const uint32_t* offsets, const uint32_t* counts,
                                   const uint32_t* indices, const uint32_t* remap,
                                   uint32_t* out_oc, uint32_t* out_idx) {

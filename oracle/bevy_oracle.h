@@ -278,6 +278,12 @@ void orc_cluster_bindings_storage(uint32_t n_clusters, const uint32_t* offsets, 
                                   const uint32_t* indices, const uint32_t* remap,
                                   uint32_t* out_offsets_and_counts, uint32_t* out_index_list);
 
+/* The transform / bounds part of the mesh-instance wire format: MeshInputUniform::world_from_local =
+ * Affine3::to_transpose() (crates/bevy_math/src/affine3.rs:27-34; crates/bevy_pbr/src/render/mesh.rs:568-571) and
+ * MeshCullingData::new (mesh.rs:1646-1657).  out_world_from_local f32[12] = three Vec4 rows, out_culling f32[8]. */
+void orc_mesh_inputs(const float global[12], const float aabb_center[3], const float aabb_half[3], int has_aabb,
+                     float out_world_from_local[12], float out_culling[8]);
+
 /* ---- CPU baseline drivers (Bevy-shaped: ceil(n/threads) batches, batching.rs:95-106) ---- */
 
 /* One frame of the flat path on `threads` pthreads: sync_simple_transforms (all dirty) +

@@ -370,6 +370,19 @@ def assign_objects_to_clusters(view, pos_range, obj_type=None, layer_mask=None, 
     return offsets, indices[:min(int(total), capacity)], counts.reshape(ncl, 6), float(far.value), int(total)
 
 
+def mesh_inputs(g, c, h, flags, rows):
+    """-> (world_from_local f32[len(rows)*12], culling f32[len(rows)*8]) for the listed rows."""
+    m = len(rows)
+    wfl = np.zeros(12 * max(m, 1), np.float32)
+    cull = np.zeros(8 * max(m, 1), np.float32)
+    g = np.ascontiguousarray(g, np.float32); c = np.ascontiguousarray(c, np.float32); h = np.ascontiguousarray(h, np.float32)
+    for k, r in enumerate(rows):
+        r = int(r)
+        lib().orc_mesh_inputs(fp(g[12 * r:12 * r + 12].copy()), fp(c[3 * r:3 * r + 3].copy()), fp(h[3 * r:3 * r + 3].copy()),
+                              int(flags[r] & FLAG_HAS_AABB != 0), fp(wfl[12 * k:12 * k + 12]), fp(cull[8 * k:8 * k + 8]))
+    return wfl[:12 * m], cull[:8 * m]
+
+
 def cluster_bindings_storage(offsets, counts, indices, remap=None):
     ncl = len(offsets) - 1
     oc = np.zeros(8 * ncl, np.uint32)

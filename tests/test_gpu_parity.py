@@ -711,3 +711,26 @@ def test_error_codes(ctx_factory):
     with pytest.raises(api.MiError) as e:
         api.Context(device=4096)
     assert e.value.code == api.MI_ERR_INVALID_ARG
+
+
+def test_changed_mesh_inputs_wire_format(ctx_factory):
+    """MeshInputUniform::world_from_local (transposed affine) + MeshCullingData for exactly the rows whose
+    GlobalTransform changed (flat scene: the dirty rows), bit for bit against the restated to_transpose / new()."""
+    n = 20_000
+    sc = W.many_cubes(n, ragged_flags=True)
+    ctx = ctx_factory()
+    upload_scene(ctx, sc)
+    ctx.propagate(B.PROPAGATE_ALL_DIRTY)
+    rng = np.random.default_rng(8)
+    dirty = np.sort(rng.choice(n, 300, replace=False)).astype(np.uint32)
+    t = sc["translation"].reshape(n, 3).copy()
+    t[dirty] += F(2.0)
+    ctx.upload_transforms_indexed(dirty, t[dirty].reshape(-1), sc["rotation"].reshape(n, 4)[dirty].reshape(-1),
+                                  sc["scale"].reshape(n, 3)[dirty].reshape(-1))
+    ctx.propagate(0)
+    rows, wfl, cull = ctx.download_changed_mesh_inputs()
+    assert np.array_equal(rows, dirty)
+    g, _ = O.sync_simple_transforms(t.reshape(-1), sc["rotation"], sc["scale"])
+    ewfl, ecull = O.mesh_inputs(g, sc["aabb_center"], sc["aabb_half"], sc["flags"], dirty)
+    assert wfl.tobytes() == ewfl.tobytes() and cull.tobytes() == ecull.tobytes()
+    assert np.isinf(cull.reshape(-1, 8)[:, 4]).any() and not np.isinf(cull.reshape(-1, 8)[:, 4]).all()

@@ -295,9 +295,9 @@ def main():
         except Exception:
             pass
         print(json.dumps(out), flush=True)
+    ctx.close()          # stops the library's exchange thread before the communicator goes away
     for g in full_holder:
         g.close()
-    ctx.close()
     if use_dist:
         dist.destroy_process_group()
     return out

@@ -10,6 +10,8 @@
 // 12/16-byte lane-contiguous chunks, per-view visibility packed with a wave64 ballot: lane 0
 // of every wave stores one 64-bit mask word per view, so the bitmask is written coalesced and
 // needs no atomics.  Compiled with -ffp-contract=off (see glam_math.h).
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "glam_math.h"
@@ -123,8 +125,9 @@ __device__ __forceinline__ bool row_visible_in_view(const Affine& g, V3 center, 
 // 32 distinct banks).  Each wave only touches its own 3 KB, but a workgroup barrier is used for
 // ordering (4 waves, negligible next to the HBM time).
 // ---------------------------------------------------------------------------------------------
+typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_affine_coalesced(float4* lds_wave, float* g, uint32_t wave_row0, uint32_t n,
-                                                       uint32_t lane, const Affine& a) {
+                                                       uint32_t lane, const Affine& a, bool nt = false) {
     lds_wave[lane * 3u + 0u] = make_float4(a.m.x_axis.x, a.m.x_axis.y, a.m.x_axis.z, a.m.y_axis.x);
     lds_wave[lane * 3u + 1u] = make_float4(a.m.y_axis.y, a.m.y_axis.z, a.m.z_axis.x, a.m.z_axis.y);
     lds_wave[lane * 3u + 2u] = make_float4(a.m.z_axis.z, a.t.x, a.t.y, a.t.z);
@@ -134,7 +137,11 @@ __device__ __forceinline__ void store_affine_coalesced(float4* lds_wave, float* 
 #pragma unroll
     for (uint32_t k = 0; k < 3u; ++k) {
         const uint32_t i = k * 64u + lane;
-        if (i < lim) dst[i] = lds_wave[i];
+        if (i < lim) {
+            const float4 v = lds_wave[i];
+            if (nt) __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f*>(dst) + i);
+            else dst[i] = v;
+        }
     }
 }
 __device__ __forceinline__ Affine load_affine_coalesced(float4* lds_wave, const float* g, uint32_t wave_row0, uint32_t n,
@@ -202,7 +209,8 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
             const V3 s = ld3(c.scale, row);
             g = affine_from_srt(s, q, t);
         }
-        store_affine_coalesced(lds_g[wv], c.global, wave_row0, c.n, lane, g);
+        // nontemporal: the fused path never reads G back (measured +3..16 % at 4 M - 10 M rows, neutral at 1 M)
+        store_affine_coalesced(lds_g[wv], c.global, wave_row0, c.n, lane, g, true);
     } else {
         g = load_affine_coalesced(lds_g[wv], c.global, wave_row0, c.n, lane);
     }

@@ -734,3 +734,51 @@ def test_changed_mesh_inputs_wire_format(ctx_factory):
     ewfl, ecull = O.mesh_inputs(g, sc["aabb_center"], sc["aabb_half"], sc["flags"], dirty)
     assert wfl.tobytes() == ewfl.tobytes() and cull.tobytes() == ecull.tobytes()
     assert np.isinf(cull.reshape(-1, 8)[:, 4]).any() and not np.isinf(cull.reshape(-1, 8)[:, 4]).all()
+
+
+def test_non_finite_and_denormal_inputs_match_oracle(ctx_factory):
+    """NaN / Inf / zero / denormal components in Transform and Aabb: the comparisons of the reference are written so
+    that NaN never culls (`<= 0.0` is false) and GlobalTransform's PartialEq treats NaN as changed; denormals must not
+    be flushed.  Whatever the CPU arithmetic does, the device must do bit for bit."""
+    n = 4_096
+    sc = W.many_cubes(n, radius=30.0, ragged_flags=True)
+    rng = np.random.default_rng(12)
+    t = sc["translation"].reshape(n, 3); s = sc["scale"].reshape(n, 3); h = sc["aabb_half"].reshape(n, 3)
+    q = sc["rotation"].reshape(n, 4); c = sc["aabb_center"].reshape(n, 3)
+    special = np.array([np.nan, np.inf, -np.inf, 0.0, -0.0, 1e-42, -3e-45, 3.4e38, 1.17549435e-38], F)
+    for arr in (t, s, h, q, c):
+        rows = rng.choice(n, 200, replace=False)
+        arr[rows, rng.integers(0, arr.shape[1], 200)] = special[rng.integers(0, len(special), 200)]
+    frusta = frusta_for([W.many_cubes_camera(0), W.many_cubes_camera(4, yaw=2.0)])
+    vv0 = (W.splitmix64(4, n) % np.uint64(4)).astype(np.uint8)
+    ctx = ctx_factory()
+    upload_scene(ctx, sc, vv0)
+    ctx.propagate_and_cull(frusta, flags=B.CULL_END_FRAME)
+    g_exp, vv_exp, vis_exp, chg_exp = oracle_frame(sc, vv0, frusta, None, None)
+    g = ctx.download_global_transforms(want_changed=False)
+    diff = (g.view(np.uint32) != g_exp.view(np.uint32)) & ~(np.isnan(g) & np.isnan(g_exp))   # NaN payload / sign is not specified
+    bad = np.nonzero(diff.reshape(-1, 12).any(axis=1))[0]
+    detail = [(int(r), g.reshape(-1, 12)[r].view(np.uint32).tolist(), g_exp.reshape(-1, 12)[r].view(np.uint32).tolist()) for r in bad[:3]]
+    assert bad.size == 0, f"{bad.size} GlobalTransforms differ, e.g. {detail}"
+    for v in range(2):
+        assert_bits(ctx.download_visibility(v), vis_exp[v], f"view {v}")
+    vv, chg = ctx.download_view_visibility()
+    assert_bits(vv, vv_exp, "vv")
+    assert_bits(chg, chg_exp, "vv changed")
+    # the same rows as a (flat-level + one level) hierarchy: set_if_neq with NaN is always "changed"
+    parent = np.full(n, B.NO_PARENT, np.uint32)
+    parent[n // 2:] = np.arange(n // 2, dtype=np.uint32)
+    new_to_old, pidx, offs = api.hierarchy_sort(parent)
+    ctx2 = ctx_factory()
+    ctx2.resize(n)
+    ctx2.upload_transforms(t[new_to_old].reshape(-1), q[new_to_old].reshape(-1), s[new_to_old].reshape(-1))
+    ctx2.upload_hierarchy(pidx, offs)
+    for frame in range(2):
+        ctx2.propagate(B.PROPAGATE_ALL_DIRTY)
+    g2, chg2 = ctx2.download_global_transforms()
+    rc, e1, _ = O.propagate_transforms(pidx, t[new_to_old].reshape(-1), q[new_to_old].reshape(-1), s[new_to_old].reshape(-1))
+    rc, e2, echg = O.propagate_transforms(pidx, t[new_to_old].reshape(-1), q[new_to_old].reshape(-1), s[new_to_old].reshape(-1), global_in=e1)
+    diff = (g2.view(np.uint32) != e2.view(np.uint32)) & ~(np.isnan(g2) & np.isnan(e2))
+    bad = np.nonzero(diff.reshape(-1, 12).any(axis=1))[0]
+    assert bad.size == 0, f"tree: {bad.size} rows differ, first {bad[:5].tolist()}"
+    assert_bits(chg2, echg, "tree change ticks with NaN")

@@ -269,6 +269,10 @@ __global__ void __launch_bounds__(CLUSTER_BLOCK) k_cluster_walk(ClusterViewDev v
     uint32_t* type_rows = rows + C * 8u;
     float* planes = reinterpret_cast<float*>(type_rows + 48u);
     const uint32_t nx = v.dims[0] + 1u, ny = v.dims[1] + 1u, nz = v.dims[2] + 1u;
+    // after the planes: one "touched" bit per cluster, the list of touched clusters (u16) and its length
+    uint32_t* touched_bits = reinterpret_cast<uint32_t*>(planes + (PLANES_IN_LDS ? 4u * (nx + ny + nz) : 0u));
+    uint32_t* n_touched = touched_bits + ((C + 31u) >> 5);
+    uint16_t* touched_list = reinterpret_cast<uint16_t*>(n_touched + 1);
     const float* xp = PLANES_IN_LDS ? planes : v.x_planes;
     const float* yp = PLANES_IN_LDS ? planes + 4u * nx : v.y_planes;
     const float* zp = PLANES_IN_LDS ? planes + 4u * (nx + ny) : v.z_planes;
@@ -281,6 +285,7 @@ __global__ void __launch_bounds__(CLUSTER_BLOCK) k_cluster_walk(ClusterViewDev v
     {
         uint4* z4 = reinterpret_cast<uint4*>(cluster_lds);
         for (uint32_t i = threadIdx.x; i < C * 2u + 12u; i += CLUSTER_BLOCK) z4[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (uint32_t i = threadIdx.x; i <= ((C + 31u) >> 5); i += CLUSTER_BLOCK) touched_bits[i] = 0u;  // bits + counter
     }
     // the three plane tables are contiguous in device memory (x | y | z)
     if (PLANES_IN_LDS)
@@ -291,8 +296,12 @@ __global__ void __launch_bounds__(CLUSTER_BLOCK) k_cluster_walk(ClusterViewDev v
         const uint32_t word = threadIdx.x >> 5, bit = 1u << (threadIdx.x & 31u);
         float far_z = 0.0f;
         bool counted = false;
-        assign_one_object(v, o, obj, xp, yp, zp, &far_z, &counted,
-                          [&](uint32_t cluster) { atomicOr(&rows[cluster * 8u + word], bit); });
+        assign_one_object(v, o, obj, xp, yp, zp, &far_z, &counted, [&](uint32_t cluster) {
+            atomicOr(&rows[cluster * 8u + word], bit);
+            const uint32_t tb = 1u << (cluster & 31u);
+            if (!(touched_bits[cluster >> 5] & tb) && !(atomicOr(&touched_bits[cluster >> 5], tb) & tb))
+                touched_list[atomicAdd(n_touched, 1u)] = (uint16_t)cluster;  // first toucher records the cluster
+        });
         const uint32_t type = o.obj_type ? o.obj_type[obj] : 0u;
         atomicOr(&type_rows[(type < 6u ? type : 5u) * 8u + word], bit);
         // farthest_z = farthest_z.max(this_object_far_z), starting from 0.0 (assign.rs:421,561):
@@ -301,49 +310,34 @@ __global__ void __launch_bounds__(CLUSTER_BLOCK) k_cluster_walk(ClusterViewDev v
     }
     __syncthreads();
 
-    // Sweep: popcount every cluster row.  Non-empty rows become (cluster, block, 256-bit mask) pairs in ONE global
-    // list; the block reserves its slots with a single atomic (per-thread counts -> block scan -> base), so the
-    // fill kernel can spread pairs evenly over the chip no matter how unevenly the objects are distributed.
-    // Only non-empty entries of the (cluster, block) count matrix are written (it is kept zeroed otherwise).
-    __shared__ uint32_t scan_part[CLUSTER_BLOCK];
-    __shared__ uint32_t scan_base;
-    uint32_t mine = 0;
-    for (uint32_t c = threadIdx.x; c < C; c += CLUSTER_BLOCK) {
-        const uint4 lo = reinterpret_cast<const uint4*>(rows)[c * 2u], hi = reinterpret_cast<const uint4*>(rows)[c * 2u + 1u];
-        mine += ((lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) != 0u) ? 1u : 0u;
-    }
-    scan_part[threadIdx.x] = mine;
+    // Epilogue over the clusters this workgroup touched (a list kept next to the bit rows, so nothing is swept):
+    // every touched row becomes a (cluster, block, 256-bit mask) pair in ONE global list -- the group reserves its
+    // slots with a single atomic -- so the fill kernel can spread pairs evenly over the chip no matter how unevenly
+    // the objects are distributed.  Only non-empty entries of the (cluster, block) count matrix are written.
+    __shared__ uint32_t pair_base;
+    const uint32_t nt = *n_touched;
+    if (threadIdx.x == 0) pair_base = nt ? atomicAdd(w.pair_total, nt) : 0u;
     __syncthreads();
-    for (uint32_t off = 1; off < CLUSTER_BLOCK; off <<= 1) {
-        const uint32_t add = threadIdx.x >= off ? scan_part[threadIdx.x - off] : 0u;
-        __syncthreads();
-        scan_part[threadIdx.x] += add;
-        __syncthreads();
-    }
-    if (threadIdx.x == CLUSTER_BLOCK - 1u) scan_base = scan_part[threadIdx.x] ? atomicAdd(w.pair_total, scan_part[threadIdx.x]) : 0u;
-    __syncthreads();
-    uint32_t slot = scan_base + scan_part[threadIdx.x] - mine;
-    for (uint32_t c = threadIdx.x; c < C; c += CLUSTER_BLOCK) {
+    for (uint32_t i = threadIdx.x; i < nt; i += CLUSTER_BLOCK) {
+        const uint32_t c = touched_list[i];
         const uint4 lo = reinterpret_cast<const uint4*>(rows)[c * 2u], hi = reinterpret_cast<const uint4*>(rows)[c * 2u + 1u];
         const uint32_t m[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         uint32_t cnt = 0;
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k) cnt += __popc(m[k]);
-        if (cnt) {
-            w.block_counts[(size_t)c * w.row_stride + blockIdx.x] = (uint16_t)cnt;  // cluster-major
-            atomicAdd(&w.totals[c], cnt);
+        w.block_counts[(size_t)c * w.row_stride + blockIdx.x] = (uint16_t)cnt;  // cluster-major
+        atomicAdd(&w.totals[c], cnt);
 #pragma unroll
-            for (uint32_t t = 0; t < 6; ++t) {
-                uint32_t tc = 0;
+        for (uint32_t t = 0; t < 6; ++t) {
+            uint32_t tc = 0;
 #pragma unroll
-                for (uint32_t k = 0; k < 8; ++k) tc += __popc(m[k] & type_rows[t * 8u + k]);
-                if (tc) atomicAdd(&w.counts[6u * c + t], tc);
-            }
-            w.pair_cb[slot] = (blockIdx.x << 12) | c;
-            reinterpret_cast<uint4*>(w.pair_mask)[(size_t)slot * 2u] = lo;
-            reinterpret_cast<uint4*>(w.pair_mask)[(size_t)slot * 2u + 1u] = hi;
-            ++slot;
+            for (uint32_t k = 0; k < 8; ++k) tc += __popc(m[k] & type_rows[t * 8u + k]);
+            if (tc) atomicAdd(&w.counts[6u * c + t], tc);
         }
+        const uint32_t slot = pair_base + i;
+        w.pair_cb[slot] = (blockIdx.x << 12) | c;
+        reinterpret_cast<uint4*>(w.pair_mask)[(size_t)slot * 2u] = lo;
+        reinterpret_cast<uint4*>(w.pair_mask)[(size_t)slot * 2u + 1u] = hi;
     }
 }
 
@@ -477,8 +471,9 @@ hipError_t launch_cluster_assign(const ClusterViewDev& view, const ClusterObject
     const uint32_t C = view.n_clusters;
     const uint32_t n_planes = view.dims[0] + view.dims[1] + view.dims[2] + 3u;
     const size_t lds_rows = ((size_t)C * 8u + 48u) * sizeof(uint32_t);
-    const bool planes_in_lds = lds_rows + (size_t)n_planes * 16u <= CLUSTER_MAX_DYN_LDS;
-    const size_t lds = lds_rows + (planes_in_lds ? (size_t)n_planes * 16u : 0u);
+    const size_t lds_touched = (((size_t)C + 31u) / 32u + 1u) * 4u + (size_t)C * 2u + 16u;
+    const bool planes_in_lds = lds_rows + lds_touched + (size_t)n_planes * 16u <= CLUSTER_MAX_DYN_LDS;
+    const size_t lds = lds_rows + lds_touched + (planes_in_lds ? (size_t)n_planes * 16u : 0u);
     // this frame's parity of the accumulators and of the count matrix was zeroed by the previous frame's fill kernel
     if (objs.n) {
         if (mark) mark(mctx, K_CLUSTER_WALK);

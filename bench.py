@@ -138,7 +138,9 @@ def build_tree(ctx, args):
     config = {"workload": f"gen_tree(12,4) truncated to {tr['n']} nodes ({len(tr['level_offsets']) - 1} levels), root moved "
                           "every frame (dirty-row upload), LDS subtree-tile propagation (replicas per GPU)", "nodes": tr["n"]}
     # T 40, parent_idx 4, old G 48 (set_if_neq), G 48, changed byte 1
-    return Workload("tree", step, tr["n"], 141.0, "k_propagate_tiles", config, "nodes/sec through hierarchy propagate", "nodes/s")
+    wl = Workload("tree", step, tr["n"], 141.0, "k_propagate_tiles", config, "nodes/sec through hierarchy propagate", "nodes/s")
+    wl.tree = tr
+    return wl
 
 
 def build_lights(ctx, args):
@@ -158,7 +160,40 @@ def build_lights(ctx, args):
     wl = Workload("lights", step, args.lights, 17.0, "k_cluster_walk", config,
                   "lights/sec through assign_objects_to_clusters", "lights/s")
     wl.keep = (view, keep, lights)
+    wl.oracle_args = (cam, cfv, fr)
     return wl
+
+
+def cpu_baseline_other(name, wl):
+    """The oracle's scalar C port of the same stage on ONE host core (assign_objects_to_clusters is single-threaded in
+    the reference; the propagate port is not parallelised), a few seconds' worth of frames."""
+    import oracle_lib as O
+    if name == "tree":
+        tr = wl.tree
+        t0 = time.perf_counter()
+        rc, g, _ = O.propagate_transforms(tr["parent"], tr["translation"], tr["rotation"], tr["scale"])
+        one = time.perf_counter() - t0
+        iters = int(max(1, min(50, 3.0 / max(one, 1e-4))))
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            rc, g, _ = O.propagate_transforms(tr["parent"], tr["translation"], tr["rotation"], tr["scale"], global_in=g)
+        secs = time.perf_counter() - t0
+        return {"value": round(tr["n"] * iters / secs, 1), "unit": "nodes/s", "cores": 1, "kind": "port",
+                "sample": f"{iters} frames of {tr['n']} nodes: oracle C port of propagate_parent_transforms (set_if_neq), {secs:.2f}s"}
+    cam, cfv, fr = wl.oracle_args
+    view, lights = O.cluster_view_setup(cam, cfv, fr, 1920, 1080, (16, 9, 24), 5.0, 1000.0), wl.keep[2]
+    t0 = time.perf_counter()
+    O.assign_objects_to_clusters(view, lights)
+    one = time.perf_counter() - t0
+    iters = int(max(1, min(200, 3.0 / max(one, 1e-4))))
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        O.assign_objects_to_clusters(view, lights)
+    secs = time.perf_counter() - t0
+    n = len(lights) // 4
+    return {"value": round(n * iters / secs, 1), "unit": "lights/s", "cores": 1, "kind": "port",
+            "sample": f"{iters} frames of {n} lights: oracle C port of assign_objects_to_clusters (two passes per frame: size, then "
+                      f"fill), {secs:.2f}s"}
 
 
 def measure(ctx, wl, steps, warmup, profile_all, sync_extra=None):
@@ -172,6 +207,13 @@ def measure(ctx, wl, steps, warmup, profile_all, sync_extra=None):
         if sync_extra:
             sync_extra()
 
+    # A generation-2 pass of Python's cyclic GC over everything torch imported takes ~50 ms -- a thousand frames of
+    # this workload -- and fires after a fixed number of allocations, i.e. at a random frame: collect now, and keep the
+    # collector off while frames are being enqueued (what timeit does).
+    import gc
+    gc.collect()
+    gc_was_enabled = gc.isenabled()
+    gc.disable()
     for f in range(warmup):
         wl.step(f)
     sync_all()
@@ -185,6 +227,8 @@ def measure(ctx, wl, steps, warmup, profile_all, sync_extra=None):
     wl.host_enqueue_s = time.perf_counter() - t0  # host time to enqueue the frames (GPU-bound if well below elapsed)
     sync_all()
     t1 = time.perf_counter()
+    if gc_was_enabled:
+        gc.enable()
     prof = ctx.profile_read()
     ctx.profile_enable(False)
     return t1 - t0, prof
@@ -287,6 +331,8 @@ def main():
                                 "ms_per_step": round(1e3 * e2 / 100, 5), "config": w2.config,
                                 "roofline": roofline_of(w2, p2, 100)}
                 c2.close()
+                if not args.no_cpu_baseline:
+                    others[name]["cpu_baseline"] = cpu_baseline_other(name, w2)
             out["other_workloads"] = others
         sys.stdout.flush()
         try:  # anything native code left in C stdio buffers (e.g. RCCL's version banner) goes out BEFORE the result line

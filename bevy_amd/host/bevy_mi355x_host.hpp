@@ -1,0 +1,389 @@
+// bevy_mi355x_host.hpp -- C++ host side of the drop-in, above the C ABI (include/bevy_mi355x.h).
+//
+// The reference's host language is Rust and this image has no Rust toolchain, so the host layer a Bevy maintainer
+// would write as a `bevy_mi355x` plugin crate is written here in C++ with the same shape: a World
+// holding the components of the path (Transform, GlobalTransform, ChildOf / Children, Visibility, InheritedVisibility,
+// ViewVisibility, Aabb), change detection flags the systems consume, and a plugin whose systems have the names, the
+// ordering and the observable behaviour of the stock ones they replace:
+//     propagate_transforms()    = (mark_dirty_trees, sync_simple_transforms, propagate_parent_transforms).chain()
+//                                 crates/bevy_transform/src/systems.rs:42-79,111-306,506-748, plugins.rs:36-47
+//     visibility_propagate()    = visibility_propagate_system, crates/bevy_camera/src/visibility/mod.rs:638-729
+//     check_visibility()        = reset_view_visibility + check_visibility_cpu_culling + mark_newly_hidden_entities_invisible
+//                                 crates/bevy_camera/src/visibility/mod.rs:733-737,748-876,908-918
+// No arithmetic of the path happens here: every system copies the changed rows in, calls the library, and writes the
+// changed rows back with the reference's change-tick behaviour.  A malformed hierarchy throws (the reference panics,
+// systems.rs:715).  tests/cpp/host_systems_test.cpp restates the reference's own system tests against this layer.
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/bevy_mi355x.h"
+#include "../csrc/glam_math.h"  // host build of the glam op order: used only to construct values (from_xyz, operator*)
+
+namespace bevy_mi355x {
+
+struct Vec3 {
+    float x = 0, y = 0, z = 0;
+};
+struct Quat {
+    float x = 0, y = 0, z = 0, w = 1;
+};
+
+// Transform, crates/bevy_transform/src/components/transform.rs:86-106
+struct Transform {
+    Vec3 translation;
+    Quat rotation;
+    Vec3 scale{1, 1, 1};
+    static Transform from_xyz(float x, float y, float z) { Transform t; t.translation = {x, y, z}; return t; }
+    static Transform from_translation(Vec3 v) { Transform t; t.translation = v; return t; }
+    static Transform identity() { return Transform{}; }
+};
+
+// GlobalTransform(Affine3A), components/global_transform.rs:60 -- cols = Affine3A::to_cols_array()
+struct GlobalTransform {
+    float cols[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+    static GlobalTransform from(const Transform& t) {  // global_transform.rs:326-330
+        const mi::Affine a = mi::affine_from_srt(mi::V3{t.scale.x, t.scale.y, t.scale.z},
+                                                 mi::V4{t.rotation.x, t.rotation.y, t.rotation.z, t.rotation.w},
+                                                 mi::V3{t.translation.x, t.translation.y, t.translation.z});
+        GlobalTransform g;
+        mi::store_affine(a, g.cols);
+        return g;
+    }
+    static GlobalTransform from_xyz(float x, float y, float z) { return from(Transform::from_xyz(x, y, z)); }
+    static GlobalTransform from_translation(Vec3 v) { return from(Transform::from_translation(v)); }
+    // GlobalTransform * Transform = mul_transform, global_transform.rs:315-317
+    GlobalTransform operator*(const Transform& t) const {
+        const mi::Affine r = mi::mul(mi::load_affine(cols), mi::load_affine(from(t).cols));
+        GlobalTransform g;
+        mi::store_affine(r, g.cols);
+        return g;
+    }
+    Vec3 translation() const { return {cols[9], cols[10], cols[11]}; }
+    bool operator==(const GlobalTransform& o) const {  // PartialEq: 12 float compares
+        for (int i = 0; i < 12; ++i)
+            if (!(cols[i] == o.cols[i])) return false;
+        return true;
+    }
+    bool operator!=(const GlobalTransform& o) const { return !(*this == o); }
+};
+
+struct Aabb {  // crates/bevy_camera/src/primitives.rs:63-68
+    Vec3 center, half_extents;
+};
+enum class Visibility : uint8_t { Inherited = MI_VISIBILITY_INHERITED, Hidden = MI_VISIBILITY_HIDDEN, Visible = MI_VISIBILITY_VISIBLE };
+
+// Entity, crates/bevy_ecs/src/entity/mod.rs:424; to_bits orders by generation then by the NonMax-encoded (inverted) index
+struct Entity {
+    uint32_t index = 0xFFFFFFFFu, generation = 0;
+    uint64_t to_bits() const { return ((uint64_t)generation << 32) | (uint64_t)(index ^ 0xFFFFFFFFu); }
+    bool operator==(const Entity& o) const { return index == o.index && generation == o.generation; }
+    bool operator!=(const Entity& o) const { return !(*this == o); }
+};
+
+// The slice of the ECS the path touches: dense per-entity columns plus the change flags the systems read.
+class World {
+  public:
+    Entity spawn(const Transform& t = Transform{}) {
+        uint32_t i;
+        if (!free_.empty()) { i = free_.back(); free_.pop_back(); }
+        else { i = (uint32_t)rec_.size(); rec_.emplace_back(); }
+        Rec& r = rec_[i];
+        const uint32_t gen = r.generation;
+        r = Rec{};
+        r.generation = gen;
+        r.alive = true;
+        r.transform = t;
+        r.transform_changed = r.added = true;
+        ++structure_version_;
+        return Entity{i, gen};
+    }
+    Entity spawn_child(Entity parent, const Transform& t = Transform{}) { Entity c = spawn(t); add_child(parent, c); return c; }
+    // despawn: ChildOf is a linked_spawn relationship -- descendants go too (crates/bevy_ecs/src/hierarchy.rs:107)
+    bool despawn(Entity e) {
+        if (!contains(e)) return false;
+        const std::vector<Entity> kids = rec(e).children;
+        for (Entity c : kids) despawn(c);
+        remove_parent(e);
+        Rec& r = rec(e);
+        r.alive = false;
+        ++r.generation;
+        free_.push_back(e.index);
+        ++structure_version_;
+        return true;
+    }
+    bool contains(Entity e) const { return e.index < rec_.size() && rec_[e.index].alive && rec_[e.index].generation == e.generation; }
+
+    // entity.insert(ChildOf(parent)) / parent.add_child(child)
+    void add_child(Entity parent, Entity child) {
+        remove_parent(child);
+        rec(child).parent = parent;
+        rec(child).parent_changed = true;
+        rec(parent).children.push_back(child);
+        ++structure_version_;
+    }
+    void add_children(Entity parent, const std::vector<Entity>& kids) { for (Entity c : kids) add_child(parent, c); }
+    // entity.remove::<ChildOf>()
+    void remove_parent(Entity child) {
+        Rec& r = rec(child);
+        if (!r.parent) return;
+        auto& sib = rec(*r.parent).children;
+        sib.erase(std::remove(sib.begin(), sib.end(), child), sib.end());
+        r.parent.reset();
+        r.orphaned = true;
+        ++structure_version_;
+    }
+    // test-only: corrupt ChildOf without touching Children (systems.rs:1127-1147 does the same with unsafe code)
+    void set_child_of_unchecked(Entity child, Entity parent) { rec(child).parent = parent; ++structure_version_; }
+
+    const Transform& transform(Entity e) const { return rec(e).transform; }
+    Transform& transform_mut(Entity e) { rec(e).transform_changed = true; return rec(e).transform; }  // DerefMut bumps the tick
+    const GlobalTransform& global_transform(Entity e) const { return rec(e).global; }
+    bool global_transform_changed(Entity e) const { return rec(e).global_changed; }
+    std::optional<Entity> parent(Entity e) const { return rec(e).parent; }
+    const std::vector<Entity>& children(Entity e) const { return rec(e).children; }
+
+    void insert_visibility(Entity e, Visibility v) { rec(e).visibility = v; rec(e).has_visibility = true; rec(e).visibility_changed = true; }
+    bool inherited_visibility(Entity e) const { return rec(e).inherited; }
+    bool inherited_visibility_changed(Entity e) const { return rec(e).inherited_changed; }
+    void insert_aabb(Entity e, Aabb a) { rec(e).aabb = a; rec(e).bounds_changed = true; }
+    bool view_visibility(Entity e) const { return (rec(e).view_visibility & 1u) != 0; }  // ViewVisibility::get
+    bool view_visibility_changed(Entity e) const { return rec(e).view_visibility_changed; }
+
+    // World::clear_trackers(): change flags older than this frame are no longer "changed"
+    void clear_trackers() {
+        for (Rec& r : rec_) {
+            r.transform_changed = r.added = r.parent_changed = r.orphaned = false;
+            r.global_changed = r.inherited_changed = r.view_visibility_changed = false;
+            r.visibility_changed = r.bounds_changed = false;
+        }
+    }
+    std::vector<Entity> entities() const {
+        std::vector<Entity> out;
+        for (uint32_t i = 0; i < rec_.size(); ++i)
+            if (rec_[i].alive) out.push_back(Entity{i, rec_[i].generation});
+        return out;
+    }
+    bool static_transform_optimizations = false;  // Res<StaticTransformOptimizations>, systems.rs:87-103
+
+  private:
+    friend class Mi355xPlugin;
+    struct Rec {
+        bool alive = false;
+        uint32_t generation = 0;
+        Transform transform;
+        GlobalTransform global;
+        std::optional<Entity> parent;
+        std::vector<Entity> children;
+        Visibility visibility = Visibility::Inherited;
+        bool has_visibility = false;
+        bool inherited = false;  // InheritedVisibility::default() == HIDDEN
+        uint8_t view_visibility = 0;
+        std::optional<Aabb> aabb;
+        bool transform_changed = false, added = false, parent_changed = false, orphaned = false;
+        bool global_changed = false, inherited_changed = false, view_visibility_changed = false;
+        bool visibility_changed = false, bounds_changed = false;
+    };
+    Rec& rec(Entity e) {
+        if (!contains(e)) throw std::out_of_range("no such entity");
+        return rec_[e.index];
+    }
+    const Rec& rec(Entity e) const {
+        if (!contains(e)) throw std::out_of_range("no such entity");
+        return rec_[e.index];
+    }
+    std::vector<Rec> rec_;
+    std::vector<uint32_t> free_;
+    uint64_t structure_version_ = 1;
+};
+
+struct View {  // an active camera: Frustum + RenderLayers (crates/bevy_camera/src/visibility/mod.rs:756-781)
+    float frustum[24];
+    uint32_t layer_mask = 1;
+};
+
+class Mi355xPlugin {
+  public:
+    explicit Mi355xPlugin(int device = 0) {
+        if (mi_ctx_create(device, nullptr, &ctx_) != MI_OK) throw std::runtime_error(std::string("mi_ctx_create: ") + mi_last_error_string(nullptr));
+    }
+    ~Mi355xPlugin() { mi_ctx_destroy(ctx_); }
+    Mi355xPlugin(const Mi355xPlugin&) = delete;
+    Mi355xPlugin& operator=(const Mi355xPlugin&) = delete;
+
+    // TransformSystems::Propagate
+    void propagate_transforms(World& w) {
+        sync_structure(w);
+        const uint32_t n = (uint32_t)entity_of_row_.size();
+        if (n == 0) return;
+        // Changed<Transform> rows: sparse upload (also raises their "changed" byte)
+        std::vector<uint32_t> rows;
+        std::vector<float> t, r, s;
+        for (uint32_t row = 0; row < n; ++row) {
+            const World::Rec& e = w.rec_[entity_of_row_[row].index];
+            if (!(e.transform_changed || e.added || e.parent_changed || e.orphaned)) continue;
+            rows.push_back(row);
+            t.insert(t.end(), {e.transform.translation.x, e.transform.translation.y, e.transform.translation.z});
+            r.insert(r.end(), {e.transform.rotation.x, e.transform.rotation.y, e.transform.rotation.z, e.transform.rotation.w});
+            s.insert(s.end(), {e.transform.scale.x, e.transform.scale.y, e.transform.scale.z});
+        }
+        check(mi_upload_transforms_indexed(ctx_, (uint32_t)rows.size(), rows.data(), t.data(), r.data(), s.data()));
+        if (rows.empty()) {  // keep "nothing changed" distinct from "no change information" (= all dirty)
+            const uint8_t zero = 0;
+            check(mi_upload_changed(ctx_, 0, 1, &zero));
+        }
+        check(mi_propagate(ctx_, w.static_transform_optimizations ? MI_PROPAGATE_STATIC_OPT : 0u));
+        // write back exactly the rows whose tick the reference would bump
+        uint32_t count = 0;
+        std::vector<uint32_t> crow(n);
+        std::vector<float> cg(12 * (size_t)n);
+        check(mi_download_changed_global_transforms(ctx_, crow.data(), cg.data(), n, &count));
+        for (uint32_t k = 0; k < count; ++k) {
+            World::Rec& e = w.rec_[entity_of_row_[crow[k]].index];
+            std::memcpy(e.global.cols, &cg[12 * (size_t)k], 48);
+            e.global_changed = true;
+        }
+    }
+
+    // VisibilitySystems::VisibilityPropagate
+    void visibility_propagate(World& w) {
+        sync_structure(w);
+        const uint32_t n = (uint32_t)entity_of_row_.size();
+        if (n == 0) return;
+        std::vector<uint8_t> vis(n);
+        for (uint32_t row = 0; row < n; ++row) {
+            const World::Rec& e = w.rec_[entity_of_row_[row].index];
+            vis[row] = e.has_visibility ? (uint8_t)e.visibility : (uint8_t)MI_VISIBILITY_NONE;
+        }
+        check(mi_upload_visibility(ctx_, 0, n, vis.data()));
+        check(mi_visibility_propagate(ctx_));
+        std::vector<uint8_t> inh(n);
+        std::vector<uint32_t> chg((n + 31) / 32);
+        check(mi_download_inherited_visibility(ctx_, 0, n, inh.data(), chg.data()));
+        for (uint32_t row = 0; row < n; ++row) {
+            World::Rec& e = w.rec_[entity_of_row_[row].index];
+            if ((chg[row >> 5] >> (row & 31)) & 1u) { e.inherited = inh[row] != 0; e.inherited_changed = true; }
+        }
+    }
+
+    // VisibilitySystems::CheckVisibility .. MarkNewlyHiddenEntitiesInvisible
+    void check_visibility(World& w, const std::vector<View>& views) {
+        sync_structure(w);
+        const uint32_t n = (uint32_t)entity_of_row_.size();
+        if (n == 0 || views.empty()) return;
+        upload_bounds(w);
+        std::vector<float> fr;
+        std::vector<uint32_t> masks;
+        for (const View& v : views) { fr.insert(fr.end(), v.frustum, v.frustum + 24); masks.push_back(v.layer_mask); }
+        check(mi_cull(ctx_, fr.data(), masks.data(), nullptr, (uint32_t)views.size(), MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME));
+        std::vector<uint8_t> vv(n);
+        std::vector<uint32_t> chg((n + 31) / 32);
+        check(mi_download_view_visibility(ctx_, 0, n, vv.data(), chg.data()));
+        for (uint32_t row = 0; row < n; ++row) {
+            World::Rec& e = w.rec_[entity_of_row_[row].index];
+            e.view_visibility = vv[row];
+            if ((chg[row >> 5] >> (row & 31)) & 1u) e.view_visibility_changed = true;
+        }
+    }
+    // VisibleEntities::get(class) of one view: entities in ascending Entity order (visibility/mod.rs:861-874)
+    std::vector<Entity> visible_entities(uint32_t view) {
+        const uint32_t n = (uint32_t)entity_of_row_.size();
+        std::vector<uint32_t> rows(n);
+        uint32_t count = 0;
+        check(mi_download_visible_entities(ctx_, view, 0, nullptr, rows.data(), n, &count));
+        std::vector<Entity> out;
+        for (uint32_t k = 0; k < count; ++k) out.push_back(entity_of_row_[rows[k]]);
+        return out;
+    }
+
+  private:
+    void check(int32_t rc) {
+        if (rc == MI_OK) return;
+        const std::string msg = mi_last_error_string(ctx_);
+        if (rc == MI_ERR_MALFORMED_HIERARCHY) throw std::logic_error("malformed hierarchy (the reference panics here): " + msg);
+        throw std::runtime_error("bevy_mi355x error " + std::to_string(rc) + ": " + msg);
+    }
+    // Entity -> row table.  Rebuilt (level order via mi_hierarchy_sort, full column upload) whenever entities were
+    // spawned / despawned or a ChildOf changed; otherwise only dirty rows travel.
+    void sync_structure(World& w) {
+        if (seen_version_ == w.structure_version_) return;
+        std::vector<Entity> ents = w.entities();
+        // rows in Entity::to_bits order first, so sibling order and VisibleEntities order follow the key
+        std::sort(ents.begin(), ents.end(), [](Entity a, Entity b) { return a.to_bits() < b.to_bits(); });
+        const uint32_t n = (uint32_t)ents.size();
+        std::vector<uint32_t> slot_of_index(w.rec_.size(), MI_NO_PARENT);
+        for (uint32_t i = 0; i < n; ++i) slot_of_index[ents[i].index] = i;
+        std::vector<uint32_t> parent(n, MI_NO_PARENT);
+        for (uint32_t i = 0; i < n; ++i) {
+            const auto& p = w.rec_[ents[i].index].parent;
+            if (p) {
+                if (!w.contains(*p)) throw std::logic_error("ChildOf points at a despawned entity");
+                parent[i] = slot_of_index[p->index];
+            }
+        }
+        std::vector<uint32_t> new_to_old(std::max(n, 1u)), pidx(std::max(n, 1u)), offs((size_t)n + 2);
+        uint32_t n_levels = 0;
+        int32_t rc = mi_hierarchy_sort(n, parent.data(), new_to_old.data(), pidx.data(), offs.data(), n + 2, &n_levels);
+        if (rc == MI_ERR_MALFORMED_HIERARCHY) throw std::logic_error("malformed hierarchy (the reference panics here): cycle in ChildOf");
+        if (rc != MI_OK) throw std::runtime_error("mi_hierarchy_sort failed");
+        entity_of_row_.resize(n);
+        for (uint32_t row = 0; row < n; ++row) entity_of_row_[row] = ents[new_to_old[row]];
+        check(mi_columns_resize(ctx_, n));
+        if (n) {
+            std::vector<float> t(3 * (size_t)n), r(4 * (size_t)n), s(3 * (size_t)n), g(12 * (size_t)n);
+            std::vector<uint8_t> changed(n), vv(n);
+            std::vector<uint64_t> keys(n);
+            for (uint32_t row = 0; row < n; ++row) {
+                const World::Rec& e = w.rec_[entity_of_row_[row].index];
+                std::memcpy(&t[3 * (size_t)row], &e.transform.translation, 12);
+                std::memcpy(&r[4 * (size_t)row], &e.transform.rotation, 16);
+                std::memcpy(&s[3 * (size_t)row], &e.transform.scale, 12);
+                std::memcpy(&g[12 * (size_t)row], e.global.cols, 48);
+                changed[row] = (e.transform_changed || e.added || e.parent_changed || e.orphaned) ? 1 : 0;
+                vv[row] = e.view_visibility;
+                keys[row] = entity_of_row_[row].to_bits();
+            }
+            check(mi_upload_transforms(ctx_, 0, n, t.data(), r.data(), s.data()));
+            check(mi_upload_global_transforms(ctx_, 0, n, g.data()));
+            check(mi_upload_view_visibility(ctx_, 0, n, vv.data()));
+            check(mi_upload_entity_keys(ctx_, 0, n, keys.data()));
+            check(mi_upload_hierarchy(ctx_, n, n_levels > 1 ? pidx.data() : nullptr, offs.data(), n_levels));
+            check(mi_upload_changed(ctx_, 0, n, changed.data()));
+            bounds_dirty_ = true;
+        }
+        seen_version_ = w.structure_version_;
+        upload_bounds(w);  // the flag byte carries InheritedVisibility: the device must start from the World's values
+    }
+    void upload_bounds(World& w) {
+        const uint32_t n = (uint32_t)entity_of_row_.size();
+        bool any = bounds_dirty_;
+        for (uint32_t row = 0; row < n && !any; ++row) {
+            const World::Rec& e = w.rec_[entity_of_row_[row].index];
+            any = e.bounds_changed || e.inherited_changed || e.visibility_changed;
+        }
+        if (!any) return;
+        std::vector<float> c(3 * (size_t)n, 0.f), h(3 * (size_t)n, 0.f);
+        std::vector<uint8_t> flags(n);
+        for (uint32_t row = 0; row < n; ++row) {
+            const World::Rec& e = w.rec_[entity_of_row_[row].index];
+            // entities without the visibility components never enter the query; without Visibility they default visible
+            flags[row] = (uint8_t)(((!e.has_visibility || e.inherited) ? MI_FLAG_INHERITED_VISIBLE : 0u) | (e.aabb ? MI_FLAG_HAS_AABB : 0u));
+            if (e.aabb) { std::memcpy(&c[3 * (size_t)row], &e.aabb->center, 12); std::memcpy(&h[3 * (size_t)row], &e.aabb->half_extents, 12); }
+        }
+        check(mi_upload_bounds(ctx_, 0, n, c.data(), h.data(), flags.data(), nullptr));
+        bounds_dirty_ = false;
+    }
+
+    mi_ctx* ctx_ = nullptr;
+    std::vector<Entity> entity_of_row_;
+    uint64_t seen_version_ = 0;
+    bool bounds_dirty_ = true;
+};
+
+}  // namespace bevy_mi355x

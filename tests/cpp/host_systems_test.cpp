@@ -1,0 +1,297 @@
+// host_systems_test.cpp -- the reference's own system tests, restated against the C++ host layer
+// (bevy_amd/host/bevy_mi355x_host.hpp) that sits on the C ABI.  Each test names the reference test it follows:
+//   crates/bevy_transform/src/systems.rs:826-1221          propagate semantics (exact assert_eq! on GlobalTransform)
+//   crates/bevy_camera/src/visibility/mod.rs:950-1279       InheritedVisibility propagation + change detection
+//   crates/bevy_camera/src/visibility/mod.rs:1313-1448      ViewVisibility 2-bit lifecycle over frames
+//   benches/benches/bevy_camera/primitives.rs:41-52         an OBB inside a perspective frustum is visible
+// Needs an MI355X (the systems run on the device).  Exit code 0 = all passed.
+#include <cmath>
+#include <cstdio>
+#include <functional>
+
+#include "../../bevy_amd/host/bevy_mi355x_host.hpp"
+
+using namespace bevy_mi355x;
+
+static int g_failed = 0, g_checks = 0;
+#define CHECK(cond, msg)                                                                     \
+    do {                                                                                     \
+        ++g_checks;                                                                          \
+        if (!(cond)) { ++g_failed; std::printf("  FAILED %s:%d: %s -- %s\n", __FILE__, __LINE__, #cond, msg); } \
+    } while (0)
+
+// the chained transform systems of one schedule.run()
+static void run(Mi355xPlugin& p, World& w) {
+    p.propagate_transforms(w);
+    w.clear_trackers();
+}
+
+// systems.rs:826-886
+static void correct_parent_removed() {
+    World world;
+    Mi355xPlugin plugin;
+    auto offset_global_transform = [](float o) { return GlobalTransform::from(Transform::from_xyz(o, o, o)); };
+    auto offset_transform = [](float o) { return Transform::from_xyz(o, o, o); };
+    Entity root = world.spawn(offset_transform(3.3f));
+    Entity parent = world.spawn(offset_transform(4.4f));
+    Entity child = world.spawn(offset_transform(5.5f));
+    world.add_child(root, parent);
+    world.add_child(parent, child);
+    run(plugin, world);
+    CHECK(world.global_transform(parent) == offset_global_transform(4.4f + 3.3f), "GlobalTransform wasn't updated");
+    world.remove_parent(parent);
+    run(plugin, world);
+    CHECK(world.global_transform(parent) == offset_global_transform(4.4f), "orphaned entity wasn't updated properly");
+    world.remove_parent(child);
+    run(plugin, world);
+    CHECK(world.global_transform(child) == offset_global_transform(5.5f), "orphaned entity wasn't updated properly");
+}
+
+// systems.rs:888-925 (and :928-965, the command-buffer variant: same world after apply)
+static void did_propagate() {
+    World world;
+    Mi355xPlugin plugin;
+    world.spawn(Transform::from_xyz(1.0f, 0.0f, 0.0f));  // root entity without children
+    Entity parent = world.spawn(Transform::from_xyz(1.0f, 0.0f, 0.0f));
+    Entity c0 = world.spawn_child(parent, Transform::from_xyz(0.0f, 2.0f, 0.0f));
+    Entity c1 = world.spawn_child(parent, Transform::from_xyz(0.0f, 0.0f, 3.0f));
+    run(plugin, world);
+    CHECK(world.global_transform(c0) == GlobalTransform::from_xyz(1.0f, 0.0f, 0.0f) * Transform::from_xyz(0.0f, 2.0f, 0.0f), "child 0");
+    CHECK(world.global_transform(c1) == GlobalTransform::from_xyz(1.0f, 0.0f, 0.0f) * Transform::from_xyz(0.0f, 0.0f, 3.0f), "child 1");
+}
+
+// systems.rs:967-1046
+static void correct_children() {
+    World world;
+    Mi355xPlugin plugin;
+    Entity parent = world.spawn(Transform::from_xyz(1.0f, 0.0f, 0.0f));
+    std::vector<Entity> children = {world.spawn_child(parent, Transform::from_xyz(0.0f, 2.0f, 0.0f)),
+                                    world.spawn_child(parent, Transform::from_xyz(0.0f, 3.0f, 0.0f))};
+    run(plugin, world);
+    CHECK(world.children(parent) == children, "Children of parent");
+    world.add_child(children[1], children[0]);
+    run(plugin, world);
+    CHECK(world.children(parent) == std::vector<Entity>{children[1]}, "Children of parent after re-parenting");
+    CHECK(world.children(children[1]) == std::vector<Entity>{children[0]}, "Children of child 1");
+    // and the values follow the new hierarchy: child0 = parent * child1 * child0
+    CHECK(world.global_transform(children[0]) ==
+              (GlobalTransform::from_xyz(1.0f, 0.0f, 0.0f) * Transform::from_xyz(0.0f, 3.0f, 0.0f)) * Transform::from_xyz(0.0f, 2.0f, 0.0f),
+          "re-parented child follows its new parent");
+    CHECK(world.despawn(children[0]), "despawn");
+    run(plugin, world);
+    CHECK(world.children(parent) == std::vector<Entity>{children[1]}, "Children of parent after despawn");
+}
+
+// systems.rs:1048-1097
+static void correct_transforms_when_no_children() {
+    World world;
+    Mi355xPlugin plugin;
+    const Vec3 translation{1.0f, 0.0f, 0.0f};
+    Entity parent = world.spawn(Transform::from_translation(translation));
+    Entity child = world.spawn_child(parent, Transform::identity());
+    Entity grandchild = world.spawn_child(child, Transform::identity());
+    run(plugin, world);
+    CHECK(world.children(parent) == std::vector<Entity>{child}, "children of parent");
+    CHECK(world.children(child) == std::vector<Entity>{grandchild}, "children of child");
+    run(plugin, world);
+    for (Entity e : world.entities()) CHECK(world.global_transform(e) == GlobalTransform::from_translation(translation), "every GlobalTransform");
+}
+
+// systems.rs:1099-1165 (#[should_panic])
+static void panic_when_hierarchy_cycle() {
+    World world;
+    Mi355xPlugin plugin;
+    Entity child = world.spawn(Transform::identity());
+    Entity grandchild = world.spawn_child(child, Transform::identity());
+    Entity top = world.spawn(Transform::identity());
+    world.add_child(top, child);
+    world.set_child_of_unchecked(child, grandchild);  // ChildOf of child and grandchild now point at each other
+    bool panicked = false;
+    try {
+        run(plugin, world);
+    } catch (const std::logic_error&) {
+        panicked = true;
+    }
+    CHECK(panicked, "a hierarchy cycle must be reported (the reference panics)");
+}
+
+// systems.rs:1167-1221
+static void global_transform_should_not_be_overwritten_after_reparenting() {
+    World world;
+    Mi355xPlugin plugin;
+    const Vec3 translation{1.0f, 1.0f, 1.0f};
+    Entity parent = world.spawn(Transform::from_translation(translation));
+    Entity child = world.spawn(Transform::from_translation(translation));
+    world.add_child(parent, child);
+    run(plugin, world);
+    const GlobalTransform pg = world.global_transform(parent), cg = world.global_transform(child);
+    CHECK(std::fabs(pg.translation().x - 1.0f) < 0.1f && std::fabs(pg.translation().y - 1.0f) < 0.1f, "parent translation");
+    CHECK(std::fabs(cg.translation().x - 2.0f) < 0.1f && std::fabs(cg.translation().z - 2.0f) < 0.1f, "child translation");
+    world.remove_parent(child);
+    world.add_child(parent, child);
+    run(plugin, world);
+    CHECK(pg == world.global_transform(parent), "parent GlobalTransform unchanged");
+    CHECK(cg == world.global_transform(child), "child GlobalTransform unchanged");
+}
+
+// change ticks: set_if_neq leaves unchanged descendants untouched (systems.rs:719) but roots with children are
+// re-assigned every run unless StaticTransformOptimizations is enabled (systems.rs:522-530)
+static void change_ticks_follow_set_if_neq() {
+    World world;
+    Mi355xPlugin plugin;
+    Entity root = world.spawn(Transform::from_xyz(1, 0, 0));
+    Entity a = world.spawn_child(root, Transform::from_xyz(0, 1, 0));
+    Entity b = world.spawn_child(a, Transform::from_xyz(0, 0, 1));
+    Entity flat = world.spawn(Transform::from_xyz(5, 5, 5));
+    run(plugin, world);
+    plugin.propagate_transforms(world);  // nothing changed
+    CHECK(world.global_transform_changed(root), "root is re-assigned each run");
+    CHECK(!world.global_transform_changed(a) && !world.global_transform_changed(b), "set_if_neq: equal value, no tick");
+    CHECK(!world.global_transform_changed(flat), "flat entity without Changed<Transform> is not touched");
+    world.clear_trackers();
+    world.transform_mut(a).translation.y = 2.0f;
+    plugin.propagate_transforms(world);
+    CHECK(world.global_transform_changed(a) && world.global_transform_changed(b), "moved subtree");
+    CHECK(world.global_transform(b) == (GlobalTransform::from_xyz(1, 0, 0) * Transform::from_xyz(0, 2, 0)) * Transform::from_xyz(0, 0, 1), "value");
+    world.clear_trackers();
+    world.static_transform_optimizations = true;
+    plugin.propagate_transforms(world);
+    CHECK(!world.global_transform_changed(root), "static scene optimisation: clean tree is skipped");
+}
+
+// visibility/mod.rs:950-1037
+static void visibility_propagation() {
+    World w;
+    Mi355xPlugin plugin;
+    auto spawn = [&](Visibility v) { Entity e = w.spawn(); w.insert_visibility(e, v); return e; };
+    Entity root1 = spawn(Visibility::Hidden), root1_child1 = spawn(Visibility::Inherited), root1_child2 = spawn(Visibility::Hidden);
+    Entity r1c1g = spawn(Visibility::Inherited), r1c2g = spawn(Visibility::Inherited);
+    w.add_children(root1, {root1_child1, root1_child2});
+    w.add_child(root1_child1, r1c1g);
+    w.add_child(root1_child2, r1c2g);
+    Entity root2 = spawn(Visibility::Inherited), root2_child1 = spawn(Visibility::Inherited), root2_child2 = spawn(Visibility::Hidden);
+    Entity r2c1g = spawn(Visibility::Inherited), r2c2g = spawn(Visibility::Inherited);
+    w.add_children(root2, {root2_child1, root2_child2});
+    w.add_child(root2_child1, r2c1g);
+    w.add_child(root2_child2, r2c2g);
+    plugin.visibility_propagate(w);
+    for (Entity e : {root1, root1_child1, root1_child2, r1c1g, r1c2g}) CHECK(!w.inherited_visibility(e), "invisibility propagates down tree from root");
+    CHECK(w.inherited_visibility(root2) && w.inherited_visibility(root2_child1) && w.inherited_visibility(r2c1g), "visibility propagates down tree from root");
+    CHECK(!w.inherited_visibility(root2_child2), "local invisibility is preserved");
+    CHECK(!w.inherited_visibility(r2c2g), "child's invisibility propagates down to grandchild");
+}
+
+// visibility/mod.rs:1189-1262
+static void visibility_propagation_change_detection() {
+    World w;
+    Mi355xPlugin plugin;
+    auto spawn = [&](Visibility v) { Entity e = w.spawn(); w.insert_visibility(e, v); return e; };
+    Entity id1 = spawn(Visibility::Inherited), id2 = spawn(Visibility::Inherited), id3 = spawn(Visibility::Hidden), id4 = spawn(Visibility::Inherited);
+    w.add_child(id1, id2);
+    w.add_child(id2, id3);
+    w.add_child(id3, id4);
+    auto step = [&](std::function<void()> edit, bool c1, bool c2, bool c3, bool c4, const char* what) {
+        w.clear_trackers();
+        if (edit) edit();
+        plugin.visibility_propagate(w);
+        CHECK(w.inherited_visibility_changed(id1) == c1 && w.inherited_visibility_changed(id2) == c2 &&
+                  w.inherited_visibility_changed(id3) == c3 && w.inherited_visibility_changed(id4) == c4, what);
+    };
+    plugin.visibility_propagate(w);
+    step(nullptr, false, false, false, false, "nothing changed");
+    step([&] { w.insert_visibility(id1, Visibility::Hidden); }, true, true, false, false, "id1 hidden");
+    step(nullptr, false, false, false, false, "stable");
+    step([&] { w.insert_visibility(id3, Visibility::Inherited); }, false, false, false, false, "id3 inherits a hidden parent");
+    step([&] { w.insert_visibility(id2, Visibility::Visible); }, false, true, true, true, "id2 visible");
+    step(nullptr, false, false, false, false, "stable again");
+}
+
+static View camera_looking_down_neg_z() {
+    View v;
+    float cfv[16], cam[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+    mi_perspective_clip_from_view(1.0f, 1.0f, 0.1f, cfv);
+    mi_compute_frustum(cfv, cam, 1000.0f, v.frustum);
+    return v;
+}
+
+// visibility/mod.rs:1313-1448 (the "manual mark" is a camera the entity is inside / outside of)
+static void view_visibility_lifecycle() {
+    World w;
+    Mi355xPlugin plugin;
+    Entity e = w.spawn(Transform::from_xyz(0, 0, 50));  // behind the camera: hidden
+    w.insert_aabb(e, Aabb{{0, 0, 0}, {0.5f, 0.5f, 0.5f}});
+    const std::vector<View> views = {camera_looking_down_neg_z()};
+    bool first = true;
+    auto update = [&](std::function<void()> edit) {  // App::update(): trackers are cleared at the END of a frame
+        if (!first) w.clear_trackers();
+        first = false;
+        if (edit) edit();
+        plugin.propagate_transforms(w);
+        plugin.visibility_propagate(w);
+        plugin.check_visibility(w, views);
+    };
+    update(nullptr);
+    update(nullptr);
+    CHECK(!w.view_visibility(e), "Frame 1: should be hidden");
+    CHECK(!w.view_visibility_changed(e), "Frame 1: should not be changed");
+    update([&] { w.transform_mut(e).translation.z = -50.0f; });
+    CHECK(w.view_visibility(e), "Frame 2: should be visible");
+    CHECK(w.view_visibility_changed(e), "Frame 2: should be changed");
+    update(nullptr);
+    CHECK(w.view_visibility(e), "Frame 3: should be visible");
+    CHECK(!w.view_visibility_changed(e), "Frame 3: should NOT be changed");
+    update([&] { w.transform_mut(e).translation.z = 50.0f; });
+    CHECK(!w.view_visibility(e), "Frame 4: should be hidden");
+    CHECK(w.view_visibility_changed(e), "Frame 4: should be changed");
+    update(nullptr);
+    CHECK(!w.view_visibility(e), "Frame 5: should be hidden");
+    CHECK(!w.view_visibility_changed(e), "Frame 5: should NOT be changed");
+}
+
+// benches/benches/bevy_camera/primitives.rs:41-52 + VisibleEntities ordering (visibility/mod.rs:861-874)
+static void visible_entities_are_sorted_by_entity() {
+    World w;
+    Mi355xPlugin plugin;
+    std::vector<Entity> inside;
+    for (int i = 0; i < 40; ++i) {
+        const bool in = (i % 3) != 0;
+        Entity e = w.spawn(Transform::from_xyz((float)(i % 5) - 2.0f, 0.0f, in ? -20.0f : 20.0f));
+        w.insert_aabb(e, Aabb{{0, 0, 0}, {0.5f, 0.5f, 0.5f}});
+        if (in) inside.push_back(e);
+    }
+    plugin.propagate_transforms(w);
+    plugin.check_visibility(w, {camera_looking_down_neg_z()});
+    std::vector<Entity> got = plugin.visible_entities(0);
+    std::sort(inside.begin(), inside.end(), [](Entity a, Entity b) { return a.to_bits() < b.to_bits(); });
+    CHECK(got == inside, "VisibleEntities = the entities in view, ascending by Entity::to_bits");
+    for (Entity e : w.entities()) CHECK(w.view_visibility(e) == (std::find(inside.begin(), inside.end(), e) != inside.end()), "ViewVisibility");
+}
+
+int main() {
+    struct T { const char* name; void (*fn)(); };
+    const T tests[] = {{"correct_parent_removed", correct_parent_removed},
+                       {"did_propagate", did_propagate},
+                       {"correct_children", correct_children},
+                       {"correct_transforms_when_no_children", correct_transforms_when_no_children},
+                       {"panic_when_hierarchy_cycle", panic_when_hierarchy_cycle},
+                       {"global_transform_should_not_be_overwritten_after_reparenting", global_transform_should_not_be_overwritten_after_reparenting},
+                       {"change_ticks_follow_set_if_neq", change_ticks_follow_set_if_neq},
+                       {"visibility_propagation", visibility_propagation},
+                       {"visibility_propagation_change_detection", visibility_propagation_change_detection},
+                       {"view_visibility_lifecycle", view_visibility_lifecycle},
+                       {"visible_entities_are_sorted_by_entity", visible_entities_are_sorted_by_entity}};
+    int n_failed_tests = 0;
+    for (const T& t : tests) {
+        const int before = g_failed;
+        try {
+            t.fn();
+        } catch (const std::exception& e) {
+            ++g_failed;
+            std::printf("  EXCEPTION in %s: %s\n", t.name, e.what());
+        }
+        std::printf("%s %s\n", g_failed == before ? "ok    " : "FAILED", t.name);
+        if (g_failed != before) ++n_failed_tests;
+    }
+    std::printf("%d tests, %d failed (%d checks)\n", (int)(sizeof tests / sizeof tests[0]), n_failed_tests, g_checks);
+    return n_failed_tests ? 1 : 0;
+}

@@ -153,6 +153,7 @@ class World {
     bool inherited_visibility(Entity e) const { return rec(e).inherited; }
     bool inherited_visibility_changed(Entity e) const { return rec(e).inherited_changed; }
     void insert_aabb(Entity e, Aabb a) { rec(e).aabb = a; rec(e).bounds_changed = true; }
+    void insert_point_light(Entity e, float range) { rec(e).point_light_range = range; }  // PointLight { range, .. }
     bool view_visibility(Entity e) const { return (rec(e).view_visibility & 1u) != 0; }  // ViewVisibility::get
     bool view_visibility_changed(Entity e) const { return rec(e).view_visibility_changed; }
 
@@ -186,6 +187,7 @@ class World {
         bool inherited = false;  // InheritedVisibility::default() == HIDDEN
         uint8_t view_visibility = 0;
         std::optional<Aabb> aabb;
+        std::optional<float> point_light_range;
         bool transform_changed = false, added = false, parent_changed = false, orphaned = false;
         bool global_changed = false, inherited_changed = false, view_visibility_changed = false;
         bool visibility_changed = false, bounds_changed = false;
@@ -201,6 +203,27 @@ class World {
     std::vector<Rec> rec_;
     std::vector<uint32_t> free_;
     uint64_t structure_version_ = 1;
+};
+
+// Clusters + ObjectsInClusterCpu, crates/bevy_light/src/cluster/mod.rs:143-213
+struct ObjectsInCluster {
+    std::vector<Entity> entities;  // push order of assign_objects_to_clusters
+    uint32_t counts[6] = {0, 0, 0, 0, 0, 0};  // ClusterableObjectCounts: point, spot, rect, reflection probes, irradiance volumes, decals
+};
+struct Clusters {
+    uint32_t dimensions[3] = {0, 0, 0};
+    std::vector<ObjectsInCluster> clusterable_objects;  // index (y * dims.x + x) * dims.z + z
+    float farthest_z = 0.0f;
+    uint64_t total_index_count = 0;
+};
+struct ClusterCamera {  // what the per-view setup of assign.rs:342-485 reads
+    float camera_affine[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+    float clip_from_view[16];
+    float frustum[24];
+    uint32_t screen_width = 1920, screen_height = 1080;
+    uint32_t requested_dimensions[3] = {16, 9, 24};  // ClusterConfig::XYZ
+    float first_slice_depth = 5.0f, far_z = 1000.0f; // ClusterFarZMode::Constant
+    uint32_t layer_mask = 1;
 };
 
 struct View {  // an active camera: Frustum + RenderLayers (crates/bevy_camera/src/visibility/mod.rs:756-781)
@@ -299,6 +322,48 @@ class Mi355xPlugin {
         check(mi_download_visible_entities(ctx_, view, 0, nullptr, rows.data(), n, &count));
         std::vector<Entity> out;
         for (uint32_t k = 0; k < count; ++k) out.push_back(entity_of_row_[rows[k]]);
+        return out;
+    }
+
+    // SimulationLightSystems::AssignLightsToClusters: gathers the clusterable objects in query order (point lights;
+    // assign.rs:190-296, clustered with GlobalTransform::from_translation(translation), :198) and fills Clusters.
+    Clusters assign_objects_to_clusters(World& w, const ClusterCamera& cam) {
+        std::vector<Entity> lights;
+        std::vector<float> pos_range;
+        for (Entity e : w.entities()) {
+            const World::Rec& r = w.rec_[e.index];
+            if (!r.point_light_range) continue;
+            lights.push_back(e);
+            pos_range.insert(pos_range.end(), {r.global.cols[9], r.global.cols[10], r.global.cols[11], *r.point_light_range});
+        }
+        uint32_t tile[2], dims[3];
+        if (mi_cluster_view_dims(cam.screen_width, cam.screen_height, cam.requested_dimensions, tile, dims) != MI_OK)
+            throw std::runtime_error("mi_cluster_view_dims failed");
+        const size_t C = (size_t)dims[0] * dims[1] * dims[2];
+        std::vector<float> planes((size_t)(dims[0] + dims[1] + dims[2] + 3) * 4);
+        mi_cluster_view view;
+        if (mi_cluster_view_build(cam.camera_affine, cam.clip_from_view, cam.frustum, cam.screen_width, cam.screen_height,
+                                  cam.requested_dimensions, cam.first_slice_depth, cam.far_z, cam.layer_mask, planes.data(),
+                                  nullptr, &view) != MI_OK)
+            throw std::runtime_error("mi_cluster_view_build failed");
+        std::vector<uint32_t> offsets(C + 1), counts(6 * C), indices(1);
+        uint64_t total = 0;
+        float farthest = 0.0f;
+        int32_t rc = mi_cluster_assign(ctx_, &view, (uint32_t)lights.size(), pos_range.data(), nullptr, nullptr, nullptr, nullptr,
+                                       offsets.data(), nullptr, 0, counts.data(), &total, &farthest);
+        check(rc);
+        indices.resize(std::max<uint64_t>(total, 1));
+        check(mi_cluster_download(ctx_, nullptr, indices.data(), indices.size(), nullptr, &total, nullptr));
+        Clusters out;
+        std::memcpy(out.dimensions, dims, sizeof dims);
+        out.farthest_z = farthest;
+        out.total_index_count = total;
+        out.clusterable_objects.resize(C);
+        for (size_t c = 0; c < C; ++c) {
+            ObjectsInCluster& o = out.clusterable_objects[c];
+            for (uint32_t i = offsets[c]; i < offsets[c + 1]; ++i) o.entities.push_back(lights[indices[i]]);
+            std::memcpy(o.counts, &counts[6 * c], sizeof o.counts);
+        }
         return out;
     }
 

@@ -267,6 +267,53 @@ static void visible_entities_are_sorted_by_entity() {
     for (Entity e : w.entities()) CHECK(w.view_visibility(e) == (std::find(inside.begin(), inside.end(), e) != inside.end()), "ViewVisibility");
 }
 
+// crates/bevy_light/src/cluster/test.rs (tiling) + the structural invariants of assign_objects_to_clusters
+// (assign.rs:487-804): the reference has no known-answer test for the assignment itself.
+static void lights_are_assigned_to_clusters() {
+    World w;
+    Mi355xPlugin plugin;
+    Entity in_front = w.spawn(Transform::from_xyz(0.0f, 0.0f, -20.0f));
+    Entity behind = w.spawn(Transform::from_xyz(0.0f, 0.0f, 30.0f));
+    Entity off_right = w.spawn(Transform::from_xyz(6.0f, 0.0f, -20.0f));
+    Entity huge = w.spawn(Transform::from_xyz(0.0f, 0.0f, -50.0f));
+    w.insert_point_light(in_front, 1.0f);
+    w.insert_point_light(behind, 1.0f);
+    w.insert_point_light(off_right, 1.0f);
+    w.insert_point_light(huge, 1.0e6f);
+    w.spawn(Transform::from_xyz(1, 2, 3));  // not a light
+    plugin.propagate_transforms(w);
+    ClusterCamera cam;
+    mi_perspective_clip_from_view(3.14159265f / 4.0f, 16.0f / 9.0f, 0.1f, cam.clip_from_view);
+    mi_compute_frustum(cam.clip_from_view, cam.camera_affine, 1000.0f, cam.frustum);
+    const Clusters cl = plugin.assign_objects_to_clusters(w, cam);
+    CHECK(cl.dimensions[0] == 16 && cl.dimensions[1] == 9 && cl.dimensions[2] == 24, "1920x1080 with 16x9x24 requested");
+    CHECK(cl.dimensions[0] * cl.dimensions[1] * cl.dimensions[2] <= 4096, "at most 4096 clusters (test.rs)");
+    size_t n_front = 0, n_behind = 0, n_right = 0, n_huge = 0, total = 0;
+    bool ordered = true, counts_ok = true;
+    for (const ObjectsInCluster& c : cl.clusterable_objects) {
+        total += c.entities.size();
+        counts_ok = counts_ok && c.counts[0] == c.entities.size();
+        for (size_t i = 0; i < c.entities.size(); ++i) {
+            const Entity e = c.entities[i];
+            n_front += e == in_front; n_behind += e == behind; n_right += e == off_right; n_huge += e == huge;
+            if (i && !(c.entities[i - 1].index < e.index)) ordered = false;  // push order = gather (query) order
+        }
+    }
+    CHECK(n_front >= 1 && n_front <= 24, "a small light straight ahead touches a handful of clusters");
+    CHECK(n_behind == 0, "a light behind the camera is culled by the frustum test (assign.rs:496)");
+    CHECK(n_right >= 1, "a light off to the right but in view is assigned");
+    CHECK(n_huge == cl.clusterable_objects.size(), "a light that swallows the frustum is in every cluster");
+    CHECK(ordered, "per-cluster lists keep the gather order");
+    CHECK(counts_ok && total == cl.total_index_count, "counts and total agree with the lists");
+    // the small light's clusters are central in x/y: cluster index (y * dims.x + x) * dims.z + z
+    for (size_t c = 0; c < cl.clusterable_objects.size(); ++c)
+        for (Entity e : cl.clusterable_objects[c].entities)
+            if (e == in_front) {
+                const uint32_t xy = (uint32_t)(c / cl.dimensions[2]), x = xy % cl.dimensions[0], y = xy / cl.dimensions[0];
+                CHECK(x >= 6 && x <= 9 && y >= 3 && y <= 5, "cluster of the centred light is central");
+            }
+}
+
 int main() {
     struct T { const char* name; void (*fn)(); };
     const T tests[] = {{"correct_parent_removed", correct_parent_removed},
@@ -279,7 +326,8 @@ int main() {
                        {"visibility_propagation", visibility_propagation},
                        {"visibility_propagation_change_detection", visibility_propagation_change_detection},
                        {"view_visibility_lifecycle", view_visibility_lifecycle},
-                       {"visible_entities_are_sorted_by_entity", visible_entities_are_sorted_by_entity}};
+                       {"visible_entities_are_sorted_by_entity", visible_entities_are_sorted_by_entity},
+                       {"lights_are_assigned_to_clusters", lights_are_assigned_to_clusters}};
     int n_failed_tests = 0;
     for (const T& t : tests) {
         const int before = g_failed;

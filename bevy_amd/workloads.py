@@ -154,3 +154,50 @@ def gen_tree(depth, branch, max_nodes=None, seed=42):
     return dict(n=n, parent=parent, level_offsets=np.array(level_offsets, np.uint32),
                 translation=np.ascontiguousarray(t).reshape(-1), rotation=np.ascontiguousarray(q).reshape(-1),
                 scale=np.ascontiguousarray(s).reshape(-1))
+
+
+def batching_scene(n_rows, n_sets=7, max_bins=40, seed=42, unbatched_fraction=0.05):
+    """Synthetic render-phase binning for `n_rows` mesh rows: every row names a batch set (or
+    NO_BATCH_SET = not multidrawable), a RenderBinIndex inside it and an InputUniformIndex; every set has a
+    RenderBinIndex -> metadata-index table with holes and a GpuBinMetadata array whose indirect_parameters_offset is a
+    permutation (bins are created and destroyed over time in the reference, render_phase/mod.rs:268-400)."""
+    r = splitmix64(seed, 3 * n_rows + 4 * n_sets + 16)
+    rng = np.random.default_rng(int(r[0] & 0xFFFFFFFF))
+    bins_per_set = 1 + (r[1:1 + n_sets] % np.uint64(max_bins)).astype(np.int64)
+    if n_sets > 2:
+        bins_per_set[1] = max(1, max_bins * 8)  # one set with more than 256 bins: the two-level scan
+    set_indexed = ((r[1 + n_sets:1 + 2 * n_sets] >> np.uint64(7)) & np.uint64(1)).astype(np.uint8)
+    bin_table_offset = np.zeros(n_sets + 1, np.uint32)
+    meta_offset = np.zeros(n_sets + 1, np.uint32)
+    tables, metas = [], []
+    for s in range(n_sets):
+        b = int(bins_per_set[s])
+        slots = b + int(rng.integers(0, 4))  # holes in the RenderBinIndex space
+        live = np.sort(rng.choice(slots, b, replace=False)).astype(np.uint32)
+        table = np.full(slots, 0xFFFFFFFF, np.uint32)
+        meta_of_bin = rng.permutation(b).astype(np.uint32)
+        table[live] = meta_of_bin
+        meta = np.zeros((b, 3), np.uint32)
+        meta[meta_of_bin, 1] = live                      # bin_index: the reverse map
+        meta[:, 0] = rng.permutation(b).astype(np.uint32)  # indirect_parameters_offset, relative to the set
+        meta[:, 2] = 0xABCD                               # stale instance_count: must be overwritten
+        tables.append(table)
+        metas.append(meta)
+        bin_table_offset[s + 1] = bin_table_offset[s] + slots
+        meta_offset[s + 1] = meta_offset[s] + b
+    row_set = (r[16 + 2 * n_sets:16 + 2 * n_sets + n_rows] % np.uint64(max(n_sets, 1))).astype(np.uint32)
+    pick = r[16 + 2 * n_sets + n_rows:16 + 2 * n_sets + 2 * n_rows]
+    row_bin = np.zeros(n_rows, np.uint32)
+    for s in range(n_sets):
+        live = np.nonzero(tables[s] != 0xFFFFFFFF)[0].astype(np.uint32)
+        m = row_set == s
+        # skewed: most rows of a set share a few bins (instances of the same mesh + material)
+        k = (pick[m] % np.uint64(len(live))).astype(np.int64)
+        k = np.minimum(k, (pick[m] >> np.uint64(32)) % np.uint64(len(live))).astype(np.int64)
+        row_bin[m] = live[k]
+    unb = uniform01(seed + 1, n_rows) < unbatched_fraction
+    row_set[unb] = 0xFFFFFFFF
+    row_input = rng.permutation(n_rows).astype(np.uint32)
+    return dict(row_set=row_set, row_bin=row_bin, row_input=row_input, set_indexed=set_indexed,
+                bin_table_offset=bin_table_offset, bin_table=np.concatenate(tables) if tables else np.zeros(0, np.uint32),
+                meta_offset=meta_offset, bin_metadata=np.concatenate(metas) if metas else np.zeros((0, 3), np.uint32))

@@ -295,6 +295,39 @@ double orc_bench_flat_frame(uint32_t n, const float* translation, const float* r
                             const uint32_t* view_layer_masks, const uint8_t* view_flags,
                             uint32_t n_views, int threads, int iters);
 
+/* ---- batching work-item build (batching_oracle.c) ---------------------------------------- */
+#define ORC_NO_BATCH_SET 0xFFFFFFFFu
+typedef struct orc_binned_mesh_instance { uint32_t input_uniform_index, bin_index; } orc_binned_mesh_instance; /* render_phase/mod.rs:777 */
+typedef struct orc_bin_metadata { uint32_t indirect_parameters_offset, bin_index, instance_count; } orc_bin_metadata; /* mesh_preprocess_types.wesl:130-149 */
+typedef struct orc_preprocess_work_item { uint32_t input_index, output_or_indirect_parameters_index; } orc_preprocess_work_item; /* gpu_preprocessing.rs:783-799 */
+typedef struct orc_indirect_parameters_metadata {  /* gpu_preprocessing.rs:898-934 */
+    uint32_t base_output_index, batch_set_index, mesh_index, early_instance_count, late_instance_count;
+} orc_indirect_parameters_metadata;
+typedef struct orc_indirect_batch_set { uint32_t indirect_parameters_count, indirect_parameters_base; } orc_indirect_batch_set; /* :946-965 */
+typedef struct orc_batch_set_record {  /* what BinnedRenderPhaseBatchSet keeps, gpu_preprocessing.rs:2560-2577 */
+    uint32_t set, indexed, index, first_work_item_index, instance_count, first_indirect_parameters_index, batch_count,
+        first_output_mesh_uniform_index;
+} orc_batch_set_record;
+typedef struct orc_batch_initial {  /* lengths of the phase's buffers before the multidrawable pass, [0] non-indexed [1] indexed */
+    uint32_t work_item_index[2], indirect_parameters_index[2], batch_set_index[2], output_mesh_uniform_index;
+} orc_batch_initial;
+typedef struct orc_batch_totals {
+    uint32_t work_item_len[2], indirect_parameters_len[2], batch_set_len[2], data_buffer_len, n_records;
+} orc_batch_totals;
+void orc_unpack_bins(uint32_t base_output_work_item_index, uint32_t base_indirect_parameters_index,
+                     uint32_t binned_mesh_instance_count, const orc_binned_mesh_instance* binned_mesh_instances,
+                     const orc_bin_metadata* bin_metadata, const uint32_t* bin_index_to_bin_metadata_index,
+                     orc_preprocess_work_item* preprocess_work_items);
+void orc_allocate_uniforms(uint32_t batch_set_index, uint32_t bin_count, uint32_t first_indirect_parameters_index,
+                           uint32_t first_output_mesh_uniform_index, const orc_bin_metadata* bin_metadata,
+                           orc_indirect_parameters_metadata* indirect_parameters_metadata, uint32_t* fan_buffer);
+uint32_t orc_batch_build(uint32_t n_list, const uint32_t* rows, const uint32_t* row_batch_set, const uint32_t* row_bin_index,
+                         const uint32_t* row_input_uniform_index, uint32_t n_sets, const uint8_t* set_indexed,
+                         const uint32_t* bin_table_offset, const uint32_t* bin_table, const uint32_t* meta_offset,
+                         orc_bin_metadata* bin_metadata, const orc_batch_initial* initial,
+                         orc_preprocess_work_item* work_items[2], orc_indirect_parameters_metadata* metadata[2],
+                         orc_indirect_batch_set* batch_sets[2], orc_batch_set_record* records, orc_batch_totals* totals);
+
 #ifdef __cplusplus
 }
 #endif

@@ -404,3 +404,68 @@ def bench_flat_frame(t, r, s, c, h, flags, layers, frusta, threads, iters):
     secs = lib().orc_bench_flat_frame(n, fp(t), fp(r), fp(s), fp(c), fp(h), u8p(flags), u32p(layers), fp(g), u8p(vv),
                                       u8p(vis), fp(frusta), None, None, nv, int(threads), int(iters))
     return float(secs), g, vv, vis.reshape(nv, n)
+
+
+# ---- batching work-item build (oracle/batching_oracle.c) -----------------------------------------------------------
+NO_BATCH_SET = 0xFFFFFFFF
+
+
+class BatchInitial(C.Structure):
+    _fields_ = [("work_item_index", C.c_uint32 * 2), ("indirect_parameters_index", C.c_uint32 * 2),
+                ("batch_set_index", C.c_uint32 * 2), ("output_mesh_uniform_index", C.c_uint32)]
+
+
+class BatchTotals(C.Structure):
+    _fields_ = [("work_item_len", C.c_uint32 * 2), ("indirect_parameters_len", C.c_uint32 * 2),
+                ("batch_set_len", C.c_uint32 * 2), ("data_buffer_len", C.c_uint32), ("n_records", C.c_uint32)]
+
+
+def unpack_bins(base_work_item, base_indirect, instances, bin_metadata, bin_table, n_out):
+    """instances u32[k,2] (input_uniform_index, bin_index); bin_metadata u32[m,3]; -> work items u32[n_out,2]"""
+    inst = np.ascontiguousarray(instances, np.uint32).reshape(-1, 2)
+    out = np.zeros((n_out, 2), np.uint32)
+    lib().orc_unpack_bins(C.c_uint32(base_work_item), C.c_uint32(base_indirect), C.c_uint32(len(inst)),
+                          inst.ctypes.data_as(C.c_void_p), np.ascontiguousarray(bin_metadata, np.uint32).ctypes.data_as(C.c_void_p),
+                          u32p(np.ascontiguousarray(bin_table, np.uint32)), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def allocate_uniforms(batch_set_index, first_indirect, first_output, bin_metadata, n_out):
+    meta = np.ascontiguousarray(bin_metadata, np.uint32).reshape(-1, 3)
+    out = np.full((n_out, 5), 0xDEADBEEF, np.uint32)
+    fan = np.zeros(len(meta) // 256 + 2, np.uint32)
+    lib().orc_allocate_uniforms(C.c_uint32(batch_set_index), C.c_uint32(len(meta)), C.c_uint32(first_indirect), C.c_uint32(first_output),
+                                meta.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), u32p(fan))
+    return out
+
+
+def batch_build(rows, row_set, row_bin, row_input, set_indexed, bin_table_offset, bin_table, meta_offset, bin_metadata,
+                initial=None):
+    """-> dict(work_items=[ni, ix], metadata=[ni, ix], batch_sets=[ni, ix], records u32[k,8], totals, bin_metadata u32[m,3])"""
+    rows = np.ascontiguousarray(rows, np.uint32)
+    n_sets = len(set_indexed)
+    meta = np.ascontiguousarray(bin_metadata, np.uint32).reshape(-1, 3).copy()
+    ini = initial if initial is not None else BatchInitial()
+    cap_items = [int(ini.work_item_index[c]) + len(rows) + 1 for c in range(2)]
+    cap_meta = [int(ini.indirect_parameters_index[c]) + len(meta) + 1 for c in range(2)]
+    cap_sets = [int(ini.batch_set_index[c]) + n_sets + 1 for c in range(2)]
+    wi = [np.zeros((cap_items[c], 2), np.uint32) for c in range(2)]
+    md = [np.zeros((cap_meta[c], 5), np.uint32) for c in range(2)]
+    bs = [np.zeros((cap_sets[c], 2), np.uint32) for c in range(2)]
+    rec = np.zeros((n_sets + 1, 8), np.uint32)
+    tot = BatchTotals()
+    P2 = C.c_void_p * 2
+    lib().orc_batch_build.restype = C.c_uint32
+    lib().orc_batch_build(C.c_uint32(len(rows)), u32p(rows), u32p(np.ascontiguousarray(row_set, np.uint32)),
+                          u32p(np.ascontiguousarray(row_bin, np.uint32)), u32p(np.ascontiguousarray(row_input, np.uint32)),
+                          C.c_uint32(n_sets), u8p(np.ascontiguousarray(set_indexed, np.uint8)),
+                          u32p(np.ascontiguousarray(bin_table_offset, np.uint32)), u32p(np.ascontiguousarray(bin_table, np.uint32)),
+                          u32p(np.ascontiguousarray(meta_offset, np.uint32)), meta.ctypes.data_as(C.c_void_p), C.byref(ini),
+                          P2(wi[0].ctypes.data, wi[1].ctypes.data), P2(md[0].ctypes.data, md[1].ctypes.data),
+                          P2(bs[0].ctypes.data, bs[1].ctypes.data), rec.ctypes.data_as(C.c_void_p), C.byref(tot))
+    return dict(work_items=[wi[c][:tot.work_item_len[c]] for c in range(2)],
+                metadata=[md[c][:tot.indirect_parameters_len[c]] for c in range(2)],
+                batch_sets=[bs[c][:tot.batch_set_len[c]] for c in range(2)], records=rec[:tot.n_records],
+                totals=dict(work_item_len=list(tot.work_item_len), indirect_parameters_len=list(tot.indirect_parameters_len),
+                            batch_set_len=list(tot.batch_set_len), data_buffer_len=int(tot.data_buffer_len)),
+                bin_metadata=meta)

@@ -89,7 +89,8 @@ ABI_SYMBOLS = [
     "mi_download_global_transforms", "mi_download_changed_global_transforms", "mi_download_changed_mesh_inputs", "mi_download_visibility", "mi_download_view_visibility",
     "mi_download_visible_entities", "mi_cluster_view_dims", "mi_cluster_view_build",
     "mi_cluster_dimensions_fixed_z", "mi_cluster_assign", "mi_cluster_upload_objects", "mi_cluster_upload_view",
-    "mi_cluster_assign_resident", "mi_cluster_download", "mi_cluster_download_bindings", "mi_perspective_clip_from_view", "mi_compute_frustum",
+    "mi_cluster_assign_resident", "mi_cluster_download", "mi_cluster_download_bindings",
+    "mi_batch_upload_rows", "mi_batch_upload_sets", "mi_batch_build", "mi_batch_download_totals", "mi_batch_download", "mi_perspective_clip_from_view", "mi_compute_frustum",
     "mi_bind_visibility_output", "mi_exchange_configure", "mi_exchange_last", "mi_device_buffer", "mi_timer_begin", "mi_timer_end", "mi_profile_enable",
     "mi_profile_filter", "mi_profile_sample", "mi_profile_read", "mi_profile_kernel_name",
 ]
@@ -462,6 +463,41 @@ class Context:
         self._ck(self._lib.mi_cluster_download_bindings(self._h, _ptr(rm, C.c_uint32), 0 if rm is None else len(rm), None,
                                                         _ptr(idx, C.c_uint32), C.c_uint64(len(idx)), C.byref(tot)))
         return oc.reshape(n_clusters, 8), idx[:tot.value]
+
+    # batching work-item build
+    def batch_upload_rows(self, batch_set, bin_index, input_uniform_index, first_row=0):
+        bs, bi, iu = _u32(batch_set), _u32(bin_index), _u32(input_uniform_index)
+        self._ck(self._lib.mi_batch_upload_rows(self._h, first_row, len(bs), _ptr(bs, C.c_uint32), _ptr(bi, C.c_uint32),
+                                                _ptr(iu, C.c_uint32)))
+
+    def batch_upload_sets(self, set_indexed, bin_table_offset, bin_table, meta_offset, bin_metadata):
+        si = np.ascontiguousarray(set_indexed, np.uint8)
+        bto, bt, mo = _u32(bin_table_offset), _u32(bin_table), _u32(meta_offset)
+        bm = np.ascontiguousarray(bin_metadata, np.uint32).reshape(-1)
+        self._ck(self._lib.mi_batch_upload_sets(self._h, len(si), _ptr(si, C.c_uint8), _ptr(bto, C.c_uint32), _ptr(bt, C.c_uint32),
+                                                _ptr(mo, C.c_uint32), bm.ctypes.data_as(C.c_void_p) if bm.size else None))
+
+    def batch_build(self, view=0, class_bit=0, initial=None):
+        """initial: 7 ints (work_item_index[2], indirect_parameters_index[2], batch_set_index[2], output_mesh_uniform_index)."""
+        ini = None if initial is None else (C.c_uint32 * 7)(*[int(x) for x in initial])
+        self._ck(self._lib.mi_batch_build(self._h, view, class_bit, ini))
+
+    def batch_download(self):
+        """-> dict: work_items / metadata / batch_sets (lists indexed by mesh class, u32 arrays), records u32[k, 8], totals,
+        bin_metadata."""
+        tot = (C.c_uint32 * 8)()
+        self._ck(self._lib.mi_batch_download_totals(self._h, tot))
+
+        def get(what, cls, words):
+            cnt = C.c_uint32(0)
+            self._lib.mi_batch_download(self._h, what, cls, None, 0, C.byref(cnt))  # length only (capacity error expected)
+            out = np.zeros((max(cnt.value, 1), words), np.uint32)
+            self._ck(self._lib.mi_batch_download(self._h, what, cls, out.ctypes.data_as(C.c_void_p), len(out), C.byref(cnt)))
+            return out[:cnt.value]
+        return dict(work_items=[get(0, c, 2) for c in range(2)], metadata=[get(1, c, 5) for c in range(2)],
+                    batch_sets=[get(2, c, 2) for c in range(2)], records=get(3, 0, 8), bin_metadata=get(4, 0, 3),
+                    totals=dict(work_item_len=[tot[0], tot[1]], indirect_parameters_len=[tot[2], tot[3]],
+                                batch_set_len=[tot[4], tot[5]], data_buffer_len=int(tot[6])))
 
     # interop / timing
     def bind_visibility_output(self, device_ptr, words_per_view, word_offset):

@@ -261,4 +261,49 @@ hipError_t launch_cluster_bindings(uint32_t n_clusters, const uint32_t* offsets,
 hipError_t launch_cluster_assign(const ClusterViewDev& view, const ClusterObjects& objs, const ClusterWork& w,
                                  hipStream_t stream, void (*mark)(void*, uint32_t), void* mark_ctx);
 
+// ---------------------------------------------------------------------------------------------
+// Batching work-item build (kernels_batch.hip).
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t BATCH_TILE = 2048;       // list items per workgroup in the partition passes
+constexpr uint32_t BATCH_NO_SET = 0xFFFFFFFFu;
+struct BatchInitial {
+    uint32_t work_item_index[2], indirect_parameters_index[2], batch_set_index[2], output_mesh_uniform_index;
+};
+struct BatchArgs {
+    // the view's VisibleEntities list of one class (device), its length and -- general compaction path -- its base
+    const uint32_t* list;
+    const uint32_t* list_count;
+    const uint64_t* list_base;  // nullptr: `list` already points at the first entry
+    // per-row render-world columns
+    const uint32_t* row_set;
+    const uint32_t* row_bin;
+    const uint32_t* row_input;
+    // the phase's batch sets
+    uint32_t n_sets, n_meta;
+    const uint8_t* set_indexed;
+    const uint32_t* bin_table_offset;
+    const uint32_t* bin_table;
+    const uint32_t* meta_offset;
+    uint32_t* bin_metadata;  // 3 words per bin: indirect_parameters_offset, bin_index, instance_count
+    // scratch
+    uint32_t* rows_a;
+    uint32_t* rows_b;
+    uint32_t* tile_hist;     // [256][n_tiles]
+    uint32_t n_tiles;
+    uint32_t* set_count;     // [n_sets]
+    uint32_t* set_scan;      // [5][n_sets]: start in the partitioned list, first work item, first indirect parameters,
+                             //              batch set index, first MeshUniform slot
+    uint32_t* counters;      // [0] batched entries of the list
+    // outputs, [0] non-indexed [1] indexed
+    uint32_t* work_items[2];   // 2 words each
+    uint32_t* metadata[2];     // 5 words each
+    uint32_t* batch_sets[2];   // 2 words each
+    uint32_t* records;         // 8 words per non-empty batch set
+    uint32_t* totals;          // 8 words (mi_batch_totals)
+    BatchInitial initial;
+};
+// enqueues the whole build (clear, stable partition of the list by batch set, set bookkeeping, allocate_uniforms,
+// unpack_bins); `mark` is called before each kernel for profiling
+hipError_t launch_batch_build(const BatchArgs& a, hipStream_t stream);
+
 }  // namespace mi

@@ -365,6 +365,74 @@ int32_t mi_cluster_download_bindings(mi_ctx* ctx, const uint32_t* remap, uint32_
                                      uint32_t* out_index_list, uint64_t capacity, uint64_t* out_total);
 
 /* ======================================================================================= */
+/* batching work-item build                                                 */
+/* ======================================================================================= */
+/* The multidrawable part of batch_and_prepare_binned_render_phase
+ * (crates/bevy_render/src/batching/gpu_preprocessing.rs:2360-2447, MultidrawableBatchSetPreparer::
+ * prepare_multidrawable_binned_batch_set :2497-2580) together with the two compute passes it feeds --
+ * allocate_uniforms.wesl and unpack_bins.wesl (crates/bevy_pbr/src/render/) -- built on the device straight from a
+ * view's VisibleEntities list, which the cull pass left in HBM: no D2H of the list, no CPU bin hash maps
+ * (render_phase/mod.rs:268-400), no H2D of GpuRenderBinnedMeshInstance arrays.
+ *
+ * The render world uploads, per row, which batch set the mesh instance belongs to (MI_NO_BATCH_SET = unbatchable /
+ * batchable-only: stays on the reference's CPU path), its RenderBinIndex inside that set and its InputUniformIndex;
+ * and per phase the batch sets in the order phase.multidrawable_meshes iterates them: mesh class (indexed or not),
+ * the RenderBinIndex -> bin-metadata-index table (holes allowed) and the GpuBinMetadata array of every set, both
+ * concatenated with offset arrays of n_sets + 1 entries.  instance_count of the metadata is an output.
+ *
+ * mi_batch_build(view, class_bit) then produces, for that view's list of that visibility class:
+ *   work items      PreprocessWorkItem {input_index, output_or_indirect_parameters_index} per mesh class; a set's run
+ *                   starts at its first_work_item_index and lists its visible instances in VisibleEntities order
+ *   metadata        IndirectParametersMetadata {base_output_index, batch_set_index, 0, 0, 0} per bin, at
+ *                   first_indirect_parameters_index + GpuBinMetadata.indirect_parameters_offset
+ *   batch sets      IndirectBatchSet {indirect_parameters_count = 0, indirect_parameters_base}
+ *   records         one mi_batch_set_record per non-empty set = what BinnedRenderPhaseBatchSet records (:2560-2577)
+ *   totals          the lengths of the phase's buffers after the pass
+ * A set none of whose instances is visible is skipped, like a batch set without bins (:2520-2524).  All indices start
+ * at `initial` (the buffer lengths the unbatchable / batchable passes left, :2431-2447); entries below them are zero.
+ * Mesh class index everywhere: 0 = non-indexed, 1 = indexed. */
+#define MI_NO_BATCH_SET 0xFFFFFFFFu
+typedef struct mi_bin_metadata {  /* GpuBinMetadata, mesh_preprocess_types.wesl:130-149 */
+    uint32_t indirect_parameters_offset, bin_index, instance_count;
+} mi_bin_metadata;
+typedef struct mi_preprocess_work_item {  /* gpu_preprocessing.rs:783-799 */
+    uint32_t input_index, output_or_indirect_parameters_index;
+} mi_preprocess_work_item;
+typedef struct mi_indirect_parameters_metadata {  /* gpu_preprocessing.rs:898-934 */
+    uint32_t base_output_index, batch_set_index, mesh_index, early_instance_count, late_instance_count;
+} mi_indirect_parameters_metadata;
+typedef struct mi_indirect_batch_set {  /* gpu_preprocessing.rs:946-965 */
+    uint32_t indirect_parameters_count, indirect_parameters_base;
+} mi_indirect_batch_set;
+typedef struct mi_batch_set_record {
+    uint32_t set, indexed, index, first_work_item_index, instance_count, first_indirect_parameters_index, batch_count,
+        first_output_mesh_uniform_index;
+} mi_batch_set_record;
+typedef struct mi_batch_initial {
+    uint32_t work_item_index[2], indirect_parameters_index[2], batch_set_index[2], output_mesh_uniform_index;
+} mi_batch_initial;
+typedef struct mi_batch_totals {
+    uint32_t work_item_len[2], indirect_parameters_len[2], batch_set_len[2], data_buffer_len, n_records;
+} mi_batch_totals;
+
+int32_t mi_batch_upload_rows(mi_ctx* ctx, uint32_t first_row, uint32_t n, const uint32_t* batch_set, const uint32_t* bin_index,
+                             const uint32_t* input_uniform_index);
+/* n_sets <= 65536.  Replaces the previous tables. */
+int32_t mi_batch_upload_sets(mi_ctx* ctx, uint32_t n_sets, const uint8_t* set_indexed, const uint32_t* bin_table_offset,
+                             const uint32_t* bin_index_to_bin_metadata_index, const uint32_t* meta_offset,
+                             const mi_bin_metadata* bin_metadata);
+/* After mi_cull / mi_propagate_and_cull of the same frame.  initial = NULL: all zero.  Enqueues only. */
+int32_t mi_batch_build(mi_ctx* ctx, uint32_t view, uint32_t class_bit, const mi_batch_initial* initial);
+int32_t mi_batch_download_totals(mi_ctx* ctx, mi_batch_totals* out);
+/* Element [0, len) of one output array, indices absolute (the region below `initial` reads as zeros). */
+#define MI_BATCH_WORK_ITEMS 0                   /* mi_preprocess_work_item */
+#define MI_BATCH_INDIRECT_PARAMETERS_METADATA 1 /* mi_indirect_parameters_metadata */
+#define MI_BATCH_SETS 2                         /* mi_indirect_batch_set */
+#define MI_BATCH_RECORDS 3                      /* mi_batch_set_record; mesh_class ignored */
+#define MI_BATCH_BIN_METADATA 4                 /* mi_bin_metadata with instance_count filled in; mesh_class ignored */
+int32_t mi_batch_download(mi_ctx* ctx, uint32_t what, uint32_t mesh_class, void* out, uint32_t capacity_elems, uint32_t* out_count);
+
+/* ======================================================================================= */
 /* camera helpers (pure host code; what update_frusta computes, visibility/mod.rs:627-636)   */
 /* ======================================================================================= */
 
@@ -413,6 +481,12 @@ int32_t mi_exchange_last(mi_ctx* ctx, void** out_device_buf, int32_t wait);
 #define MI_BUF_VISIBLE_ROWS 3
 #define MI_BUF_CLUSTER_OFFSETS_AND_COUNTS 4
 #define MI_BUF_CLUSTER_INDEX_LIST 5
+#define MI_BUF_BATCH_WORK_ITEMS_NON_INDEXED 6
+#define MI_BUF_BATCH_WORK_ITEMS_INDEXED 7
+#define MI_BUF_BATCH_METADATA_NON_INDEXED 8
+#define MI_BUF_BATCH_METADATA_INDEXED 9
+#define MI_BUF_BATCH_SETS_NON_INDEXED 10
+#define MI_BUF_BATCH_SETS_INDEXED 11
 int32_t mi_device_buffer(mi_ctx* ctx, uint32_t which, void** out_device_ptr, uint64_t* out_bytes);
 
 /* HIP-event timing on the context's stream (torch.cuda.Event only sees torch's stream). */

@@ -1,0 +1,136 @@
+"""GPU parity of the batching work-item build (mi_batch_build) against oracle/batching_oracle.c:
+every output array bit-exact (u32), from the VisibleEntities list the cull pass left on the device."""
+import numpy as np
+import pytest
+
+import bevy_amd as B
+from bevy_amd import api, workloads as W
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def ctx_factory():
+    made = []
+
+    def make():
+        c = api.Context()
+        made.append(c)
+        return c
+    yield make
+    for c in made:
+        c.close()
+
+
+def frusta_for(cams):
+    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+    return np.concatenate([api.compute_frustum(cfv, cam, W.CAMERA_FAR) for cam in cams])
+
+
+def upload_scene(ctx, sc):
+    n = len(sc["flags"])
+    ctx.resize(n)
+    ctx.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
+    ctx.upload_bounds(sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"])
+
+
+def assert_same(got, exp):
+    assert got["totals"] == exp["totals"]
+    assert np.array_equal(got["records"], exp["records"])
+    assert np.array_equal(got["bin_metadata"], exp["bin_metadata"])
+    for c in range(2):
+        for key in ("work_items", "metadata", "batch_sets"):
+            assert got[key][c].shape == exp[key][c].shape, (key, c)
+            assert np.array_equal(got[key][c], exp[key][c]), (key, c)
+
+
+INITIAL = (3, 10, 2, 7, 1, 4, 13)
+
+
+def oracle_initial(ini):
+    o = O.BatchInitial()
+    if ini is not None:
+        o.work_item_index[0], o.work_item_index[1] = ini[0], ini[1]
+        o.indirect_parameters_index[0], o.indirect_parameters_index[1] = ini[2], ini[3]
+        o.batch_set_index[0], o.batch_set_index[1] = ini[4], ini[5]
+        o.output_mesh_uniform_index = ini[6]
+    return o
+
+
+@pytest.mark.parametrize("n,n_sets,radius,initial", [(1, 1, 5.0, None), (5000, 7, 30.0, INITIAL), (70_001, 40, 60.0, None),
+                                                      (300_000, 300, 40.0, INITIAL), (300_000, 1, 40.0, None),
+                                                      (40_000, 65536, 20.0, None)])
+def test_batch_build_matches_oracle(ctx_factory, n, n_sets, radius, initial):
+    sc = W.many_cubes(n, radius=radius, ragged_flags=True)
+    bs = W.batching_scene(n, n_sets=n_sets, max_bins=40 if n_sets < 1000 else 3, seed=n + n_sets)
+    ctx = ctx_factory()
+    upload_scene(ctx, sc)
+    ctx.batch_upload_rows(bs["row_set"], bs["row_bin"], bs["row_input"])
+    ctx.batch_upload_sets(bs["set_indexed"], bs["bin_table_offset"], bs["bin_table"], bs["meta_offset"], bs["bin_metadata"])
+    views = frusta_for([W.many_cubes_camera(0), W.many_cubes_camera(0, yaw=2.5)])
+    for frame in range(2):  # second frame: scratch and counters are reused
+        ctx.propagate_and_cull(views, flags=B.CULL_END_FRAME)
+        for v in range(2):
+            ctx.batch_build(v, 0, initial)
+            got = ctx.batch_download()
+            rows = ctx.download_visible_entities(v, 0)[1]
+            exp = O.batch_build(rows, bs["row_set"], bs["row_bin"], bs["row_input"], bs["set_indexed"], bs["bin_table_offset"],
+                                bs["bin_table"], bs["meta_offset"], bs["bin_metadata"], oracle_initial(initial))
+            assert_same(got, exp)
+            if n >= 5000 and v == 0:
+                assert len(rows) > 0 and len(exp["records"]) >= 1
+        views = frusta_for([W.many_cubes_camera(7), W.many_cubes_camera(7, yaw=2.5)])
+
+
+def test_batch_build_classes_and_key_order(ctx_factory):
+    """A second visibility class, and Entity keys that are not in row order (general compaction path: the list is in key
+    order, the work items follow it)."""
+    n = 20_000
+    sc = W.many_cubes(n, radius=25.0)
+    bs = W.batching_scene(n, n_sets=9, seed=5)
+    cm = (1 + (np.arange(n) % 3 == 0) * 4).astype(np.uint32)
+    keys = np.random.default_rng(1).permutation(n).astype(np.uint64) + np.uint64(1 << 32)
+    for use_keys in (False, True):
+        ctx = ctx_factory()
+        upload_scene(ctx, sc)
+        ctx.upload_visibility_classes(cm)
+        if use_keys:
+            ctx.upload_entity_keys(keys)
+        ctx.batch_upload_rows(bs["row_set"], bs["row_bin"], bs["row_input"])
+        ctx.batch_upload_sets(bs["set_indexed"], bs["bin_table_offset"], bs["bin_table"], bs["meta_offset"], bs["bin_metadata"])
+        ctx.propagate_and_cull(frusta_for([W.many_cubes_camera(0)]), flags=B.CULL_END_FRAME)
+        for class_bit in (0, 2, 5):  # 5: no row carries it
+            ctx.batch_build(0, class_bit, INITIAL)
+            got = ctx.batch_download()
+            rows = ctx.download_visible_entities(0, class_bit)[1]
+            exp = O.batch_build(rows, bs["row_set"], bs["row_bin"], bs["row_input"], bs["set_indexed"], bs["bin_table_offset"],
+                                bs["bin_table"], bs["meta_offset"], bs["bin_metadata"], oracle_initial(INITIAL))
+            assert_same(got, exp)
+            if class_bit == 2:
+                assert 0 < len(rows) < n and np.all(cm[rows] & 4)
+        if use_keys:
+            assert not np.all(np.diff(rows.astype(np.int64)) > 0) or len(rows) < 2
+
+
+def test_batch_build_errors(ctx_factory):
+    ctx = ctx_factory()
+    sc = W.many_cubes(100, radius=5.0)
+    upload_scene(ctx, sc)
+    with pytest.raises(api.MiError):
+        ctx.batch_build(0, 0)  # before a cull
+    ctx.propagate_and_cull(frusta_for([W.many_cubes_camera(0)]), flags=B.CULL_END_FRAME)
+    with pytest.raises(api.MiError):
+        ctx.batch_build(0, 0)  # before the uploads
+    bs = W.batching_scene(100, n_sets=2, seed=1)
+    bad = bs["bin_metadata"].copy()
+    bad[0, 0] = 10_000
+    with pytest.raises(api.MiError):
+        ctx.batch_upload_sets(bs["set_indexed"], bs["bin_table_offset"], bs["bin_table"], bs["meta_offset"], bad)
+    ctx.batch_upload_sets(np.zeros(0, np.uint8), np.zeros(1, np.uint32), np.zeros(0, np.uint32), np.zeros(1, np.uint32), np.zeros((0, 3), np.uint32))
+    ctx.batch_upload_rows(bs["row_set"], bs["row_bin"], bs["row_input"])
+    ctx.batch_build(0, 0)  # no batch sets at all: nothing appended
+    got = ctx.batch_download()
+    assert got["totals"]["data_buffer_len"] == 0 and len(got["records"]) == 0
+    with pytest.raises(api.MiError):
+        ctx.batch_build(3, 0)  # no such view

@@ -164,10 +164,82 @@ def build_lights(ctx, args):
     return wl
 
 
+def build_flat_static(ctx, args):
+    """configs[1], second run: 0 % dirty -- mi_propagate finds nothing changed, mi_cull reads the resident G."""
+    import bevy_amd as B
+    from bevy_amd import api, workloads as W
+    n = args.entities
+    sc = W.many_cubes(n)
+    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+    ctx.resize(n)
+    ctx.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
+    ctx.upload_bounds(sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"])
+    ctx.propagate(B.PROPAGATE_ALL_DIRTY)
+    frames = [api.PreparedFrusta(api.compute_frustum(cfv, W.many_cubes_camera(f), W.CAMERA_FAR)) for f in range(128)]
+
+    def step(f):
+        ctx.propagate(0)
+        ctx.cull(frames[f & 127], flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME)
+    config = {"workload": f"many_cubes-shaped flat scene, {n} entities, 1 frustum, 0 % of the Transforms dirty: mi_propagate "
+                          "(nothing to do) + mi_cull (G resident) + VisibleEntities compaction", "entities": n}
+    # cull with G resident: read G 48 + Aabb 24 + flags 1 + layers 4 + vv 1, write vv 1 + masks
+    return Workload("flat_static", step, n, flat_bytes_per_entity(1, False), "k_cull", config,
+                    "entities/sec through propagate+cull", "entities/s")
+
+
+def build_batching(ctx, args):
+    """the flat frame followed by the batching work-item build of the camera's list."""
+    import bevy_amd as B
+    from bevy_amd import api, workloads as W
+    n = args.entities
+    sc = W.many_cubes(n)
+    bs = W.batching_scene(n, n_sets=64, max_bins=40, seed=7)
+    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+    ctx.resize(n)
+    ctx.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
+    ctx.upload_bounds(sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"])
+    ctx.batch_upload_rows(bs["row_set"], bs["row_bin"], bs["row_input"])
+    ctx.batch_upload_sets(bs["set_indexed"], bs["bin_table_offset"], bs["bin_table"], bs["meta_offset"], bs["bin_metadata"])
+    frames = [api.PreparedFrusta(api.compute_frustum(cfv, W.many_cubes_camera(f), W.CAMERA_FAR)) for f in range(128)]
+
+    def step(f):
+        ctx.propagate_and_cull(frames[f & 127], flags=B.CULL_END_FRAME)
+        ctx.batch_build(0, 0)
+    step(0)
+    ctx.synchronize()
+    rows = ctx.download_visible_entities(0, 0)[1]
+    items = int(np.count_nonzero(bs["row_set"][rows] != 0xFFFFFFFF))
+    config = {"workload": f"flat frame of {n} entities + batching work-item build of the camera's VisibleEntities list: "
+                          f"{len(rows)} visible rows -> {items} PreprocessWorkItems in {len(bs['set_indexed'])} batch sets / "
+                          f"{len(bs['bin_metadata'])} bins (stable partition by set, allocate_uniforms, unpack_bins)",
+              "entities": n, "work_items_per_frame": items}
+    wl = Workload("batching", step, n, flat_bytes_per_entity(1, True), "k_flat_propagate_cull", config,
+                  "entities/sec through propagate+cull+batch build", "entities/s")
+    wl.batch = (bs, rows)
+    return wl
+
+
 def cpu_baseline_other(name, wl):
     """The oracle's scalar C port of the same stage on ONE host core (assign_objects_to_clusters is single-threaded in
     the reference; the propagate port is not parallelised), a few seconds' worth of frames."""
     import oracle_lib as O
+    if name == "flat_static":
+        return None  # the flat line's CPU baseline is the same stage with the propagate included
+    if name == "batching":
+        bs, rows = wl.batch
+        a = (rows, bs["row_set"], bs["row_bin"], bs["row_input"], bs["set_indexed"], bs["bin_table_offset"], bs["bin_table"],
+             bs["meta_offset"], bs["bin_metadata"])
+        t0 = time.perf_counter()
+        O.batch_build(*a)
+        one = time.perf_counter() - t0
+        iters = int(max(1, min(200, 2.0 / max(one, 1e-4))))
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            O.batch_build(*a)
+        secs = time.perf_counter() - t0
+        return {"value": round(len(rows) * iters / secs, 1), "unit": "visible rows/s (batch build only)", "cores": 1, "kind": "port",
+                "sample": f"{iters} builds over {len(rows)} visible rows: oracle C restatement of the bin bookkeeping + "
+                          f"allocate_uniforms + unpack_bins, {secs:.2f}s"}
     if name == "tree":
         tr = wl.tree
         t0 = time.perf_counter()
@@ -322,7 +394,8 @@ def main():
         if world == 1 and args.workload == "flat" and not args.no_other_workloads:
             # configs[4] and configs[2], measured briefly on fresh contexts so the one line carries every stage
             others = {}
-            for name, builder in (("tree", build_tree), ("lights", build_lights)):
+            for name, builder in (("tree", build_tree), ("lights", build_lights), ("flat_static", build_flat_static),
+                                  ("batching", build_batching)):
                 c2 = api.Context(local_rank, stream.cuda_stream)
                 with torch.cuda.stream(stream):
                     w2 = builder(c2, args)
@@ -330,9 +403,14 @@ def main():
                 others[name] = {"metric": w2.metric, "value": round(w2.units * 100 / e2, 1), "unit": w2.unit,
                                 "ms_per_step": round(1e3 * e2 / 100, 5), "config": w2.config,
                                 "roofline": roofline_of(w2, p2, 100)}
-                c2.close()
+                if name == "batching":
+                    others[name]["batch_build_us_per_frame"] = round(1e6 * e2 / 100 - 1e3 * out["ms_per_step"], 2)
+                    with torch.cuda.stream(stream):
+                        _, p3 = measure(c2, w2, 20, 2, True)  # per-kernel breakdown, every launch timed (not the rate above)
+                    others[name]["kernels_us"] = {k: round(v["avg_us"], 2) for k, v in p3.items()}
                 if not args.no_cpu_baseline:
                     others[name]["cpu_baseline"] = cpu_baseline_other(name, w2)
+                c2.close()
             out["other_workloads"] = others
         sys.stdout.flush()
         try:  # anything native code left in C stdio buffers (e.g. RCCL's version banner) goes out BEFORE the result line

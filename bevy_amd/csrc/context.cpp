@@ -139,7 +139,8 @@ struct mi_ctx {
     // ---- clustering ----
     DevBuf cl_pos, cl_type, cl_layers, cl_dir, cl_sincos, cl_planes, cl_spheres;
     // batching work-item build (kernels_batch.hip)
-    uint32_t *bt_set = nullptr, *bt_bin = nullptr, *bt_input = nullptr;  // per-row columns
+    uint32_t *bt_set = nullptr, *bt_bin = nullptr, *bt_input = nullptr, *bt_row_meta = nullptr;  // per-row columns
+    bool bt_resolve = true;  // rows or tables changed: bt_row_meta must be recomputed
     DevBuf bt_set_indexed, bt_table_off, bt_table, bt_meta_off, bt_meta, bt_rows_a, bt_rows_b, bt_hist, bt_set_count, bt_set_scan,
         bt_counters, bt_wi[2], bt_md[2], bt_bs[2], bt_records, bt_totals;
     uint32_t bt_n_sets = 0, bt_n_meta = 0;
@@ -667,7 +668,7 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
     prof_collect(ctx);
     void* cols[] = {ctx->t, ctx->r, ctx->s, ctx->g, ctx->c, ctx->h, ctx->flags, ctx->vv, ctx->changed, ctx->g_changed_bytes,
                     ctx->layers, ctx->class_mask, ctx->keys, ctx->g_chg_bits, ctx->vv_chg_bits, ctx->tree_bits,
-                    ctx->range, ctx->visibility, ctx->inh_changed, ctx->bt_set, ctx->bt_bin, ctx->bt_input};
+                    ctx->range, ctx->visibility, ctx->inh_changed, ctx->bt_set, ctx->bt_bin, ctx->bt_input, ctx->bt_row_meta};
     for (void* p : cols)
         if (p) hipFree(p);
     DevBuf* bufs[] = {&ctx->order, &ctx->chains, &ctx->snap, &ctx->inh_bits, &ctx->sparse_cnt, &ctx->sparse_rows, &ctx->sparse_total, &ctx->sparse_g, &ctx->parent_idx, &ctx->node_flags, &ctx->tiles, &ctx->views, &ctx->bitmask,
@@ -726,6 +727,7 @@ int32_t mi_synchronize(mi_ctx* ctx) {
 // =============================================================================================
 int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
     ENTER(ctx);
+    ctx->bt_resolve = true;
     if (n_rows > ctx->cap) {
         uint32_t new_cap = std::max<uint64_t>(n_rows, std::min<uint64_t>((uint64_t)ctx->cap * 3 / 2, 0xFFFFFF00ull));
         new_cap = (uint32_t)(((uint64_t)new_cap + 255u) / 256u * 256u);  // whole workgroups
@@ -750,6 +752,7 @@ int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
         if ((rc = grow_column(ctx, ctx->bt_set, 1, old, new_cap, 0xFF))) return rc;  // MI_NO_BATCH_SET until uploaded
         if ((rc = grow_column(ctx, ctx->bt_bin, 1, old, new_cap, 0))) return rc;
         if ((rc = grow_column(ctx, ctx->bt_input, 1, old, new_cap, 0))) return rc;
+        if ((rc = grow_column(ctx, ctx->bt_row_meta, 1, old, new_cap, 0xFF))) return rc;
         // default RenderLayers = layer 0 (mask 1) for rows never uploaded
         {
             std::vector<uint32_t> ones(new_cap - old, 1u);
@@ -1463,6 +1466,7 @@ int32_t mi_batch_upload_rows(mi_ctx* ctx, uint32_t first_row, uint32_t n, const 
     if ((rc = upload(ctx, ctx->bt_bin + first_row, bin_index, (size_t)n * 4))) return rc;
     if ((rc = upload(ctx, ctx->bt_input + first_row, input_uniform_index, (size_t)n * 4))) return rc;
     ctx->bt_have_rows = true;
+    ctx->bt_resolve = true;
     return MI_OK;
 }
 
@@ -1500,6 +1504,7 @@ int32_t mi_batch_upload_sets(mi_ctx* ctx, uint32_t n_sets, const uint8_t* set_in
     ctx->bt_n_sets = n_sets;
     ctx->bt_n_meta = n_meta;
     ctx->bt_have_sets = true;
+    ctx->bt_resolve = true;
     ctx->bt_built = false;
     return MI_OK;
 }
@@ -1523,7 +1528,7 @@ int32_t mi_batch_build(mi_ctx* ctx, uint32_t view, uint32_t class_bit, const mi_
     if ((rc = ensure(ctx, ctx->bt_rows_a, cap_rows * 4))) return rc;
     if (n_sets > 256u && (rc = ensure(ctx, ctx->bt_rows_b, cap_rows * 4))) return rc;
     if ((rc = ensure(ctx, ctx->bt_hist, (size_t)256 * n_tiles * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->bt_set_count, std::max<size_t>(n_sets, 1) * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->bt_set_count, std::max<size_t>(n_sets, 1) * 2 * 4))) return rc;
     if ((rc = ensure(ctx, ctx->bt_set_scan, std::max<size_t>(n_sets, 1) * 5 * 4))) return rc;
     if ((rc = ensure(ctx, ctx->bt_counters, 64))) return rc;
     if ((rc = ensure(ctx, ctx->bt_records, std::max<size_t>(n_sets, 1) * 32))) return rc;
@@ -1575,6 +1580,13 @@ int32_t mi_batch_build(mi_ctx* ctx, uint32_t view, uint32_t class_bit, const mi_
     a.row_set = ctx->bt_set;
     a.row_bin = ctx->bt_bin;
     a.row_input = ctx->bt_input;
+    a.row_meta = ctx->bt_row_meta;
+    if (ctx->bt_resolve) {
+        HIP_TRY(ctx, launch_batch_resolve_rows(ctx->n, n_sets, ctx->bt_set, ctx->bt_bin, (const uint32_t*)ctx->bt_table_off.p,
+                                               (const uint32_t*)ctx->bt_table.p, (const uint32_t*)ctx->bt_meta_off.p, ctx->bt_row_meta,
+                                               ctx->stream));
+        ctx->bt_resolve = false;
+    }
     a.n_sets = n_sets;
     a.n_meta = ctx->bt_n_meta;
     a.set_indexed = (const uint8_t*)ctx->bt_set_indexed.p;
@@ -1591,7 +1603,7 @@ int32_t mi_batch_build(mi_ctx* ctx, uint32_t view, uint32_t class_bit, const mi_
     a.counters = (uint32_t*)ctx->bt_counters.p;
     a.records = (uint32_t*)ctx->bt_records.p;
     a.totals = (uint32_t*)ctx->bt_totals.p;
-    HIP_TRY(ctx, launch_batch_build(a, ctx->stream));
+    HIP_TRY(ctx, launch_batch_build(a, ctx->stream, prof_mark, ctx));
     ctx->bt_built = true;
     return MI_OK;
 }
@@ -2038,7 +2050,8 @@ const char* mi_profile_kernel_name(uint32_t k) {
     static const char* names[K_NUM_KERNELS] = {"k_flat_propagate_cull", "k_level0_propagate", "k_cull", "k_vis_begin",
                                                "k_vis_end", "k_compact_count", "k_compact_scan", "k_compact_scatter",
                                                "k_compact_fast", "k_mark_dirty", "k_propagate_tiles", "k_cluster_walk", "k_cluster_fill",
-                                               "k_clear_u32", "k_inherit"};
+                                               "k_clear_u32", "k_inherit", "k_batch_clear", "k_batch_hist", "k_batch_scan",
+                                               "k_batch_scatter", "k_batch_bounds", "k_batch_sets", "k_batch_allocate", "k_batch_unpack"};
     return k < K_NUM_KERNELS ? names[k] : nullptr;
 }
 

@@ -112,6 +112,14 @@ enum KernelId : uint32_t {
     K_CLUSTER_FILL,
     K_CLEAR,
     K_INHERIT,
+    K_BATCH_CLEAR,
+    K_BATCH_HIST,
+    K_BATCH_SCAN,
+    K_BATCH_SCATTER,
+    K_BATCH_BOUNDS,
+    K_BATCH_SETS,
+    K_BATCH_ALLOCATE,
+    K_BATCH_UNPACK,
     K_NUM_KERNELS
 };
 
@@ -278,6 +286,7 @@ struct BatchArgs {
     const uint32_t* row_set;
     const uint32_t* row_bin;
     const uint32_t* row_input;
+    const uint32_t* row_meta;  // row -> index of its bin's metadata (k_batch_resolve_rows), 0xFFFFFFFF = names no bin
     // the phase's batch sets
     uint32_t n_sets, n_meta;
     const uint8_t* set_indexed;
@@ -290,7 +299,7 @@ struct BatchArgs {
     uint32_t* rows_b;
     uint32_t* tile_hist;     // [256][n_tiles]
     uint32_t n_tiles;
-    uint32_t* set_count;     // [n_sets]
+    uint32_t* set_count;     // [2][n_sets]: start and end of the set's run in the partitioned list
     uint32_t* set_scan;      // [5][n_sets]: start in the partitioned list, first work item, first indirect parameters,
                              //              batch set index, first MeshUniform slot
     uint32_t* counters;      // [0] batched entries of the list
@@ -304,6 +313,9 @@ struct BatchArgs {
 };
 // enqueues the whole build (clear, stable partition of the list by batch set, set bookkeeping, allocate_uniforms,
 // unpack_bins); `mark` is called before each kernel for profiling
-hipError_t launch_batch_build(const BatchArgs& a, hipStream_t stream);
+hipError_t launch_batch_resolve_rows(uint32_t n, uint32_t n_sets, const uint32_t* row_set, const uint32_t* row_bin,
+                                     const uint32_t* bin_table_offset, const uint32_t* bin_table, const uint32_t* meta_offset,
+                                     uint32_t* row_meta, hipStream_t stream);
+hipError_t launch_batch_build(const BatchArgs& a, hipStream_t stream, void (*mark)(void*, uint32_t), void* mark_ctx);
 
 }  // namespace mi

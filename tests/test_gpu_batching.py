@@ -58,6 +58,26 @@ def oracle_initial(ini):
     return o
 
 
+def test_batch_build_one_bin(ctx_factory):
+    """many_cubes itself: one mesh, one material -> one batch set with one bin holding every visible instance."""
+    n = 200_000
+    sc = W.many_cubes(n, radius=30.0)
+    bs = W.batching_scene(n, n_sets=1, max_bins=1, seed=3, unbatched_fraction=0.0)
+    assert len(bs["bin_metadata"]) == 1
+    ctx = ctx_factory()
+    upload_scene(ctx, sc)
+    ctx.batch_upload_rows(bs["row_set"], bs["row_bin"], bs["row_input"])
+    ctx.batch_upload_sets(bs["set_indexed"], bs["bin_table_offset"], bs["bin_table"], bs["meta_offset"], bs["bin_metadata"])
+    ctx.propagate_and_cull(frusta_for([W.many_cubes_camera(0)]), flags=B.CULL_END_FRAME)
+    ctx.batch_build(0, 0)
+    got = ctx.batch_download()
+    rows = ctx.download_visible_entities(0, 0)[1]
+    exp = O.batch_build(rows, bs["row_set"], bs["row_bin"], bs["row_input"], bs["set_indexed"], bs["bin_table_offset"],
+                        bs["bin_table"], bs["meta_offset"], bs["bin_metadata"])
+    assert_same(got, exp)
+    assert got["bin_metadata"][0, 2] == len(rows) > 1000
+
+
 @pytest.mark.parametrize("n,n_sets,radius,initial", [(1, 1, 5.0, None), (5000, 7, 30.0, INITIAL), (70_001, 40, 60.0, None),
                                                       (300_000, 300, 40.0, INITIAL), (300_000, 1, 40.0, None),
                                                       (40_000, 65536, 20.0, None)])

@@ -14,7 +14,8 @@ A "step" is one frame of the hot path over device-resident columns with every Tr
   tree  (configs[4]): depth-12/branch-4 tree truncated to 1M nodes, root moved every frame, propagate only.
   lights (configs[2]): 100k point lights, 16x9x24 clusters, assign_objects_to_clusters only.
 Rank 0 prints ONE JSON line (DESIGN.md section 5 explains the byte accounting behind `roofline`); at N=1 the
-default run also measures tree and lights briefly and reports them under `other_workloads`.
+default run also measures tree, lights, the 0 %-dirty flat frame and the batching work-item build briefly and reports
+them under `other_workloads`.
 """
 import argparse
 import json
@@ -24,6 +25,7 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs between processes on this driver
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -76,8 +78,11 @@ def build_flat(ctx, args, rank, world, total_frames, full_holder):
                                for v in range(n_views)])
 
     n_local = args.entities
+    if world > 1:  # shards start on a workgroup (256-row) boundary: sharding.shard_rows(n_global, world, rank) is then exactly
+        n_local = -(-n_local // sharding.ROW_ALIGN) * sharding.ROW_ALIGN  # [rank * n_local, (rank + 1) * n_local)
     n_global = n_local * world
-    lo = rank * n_local
+    lo, hi = sharding.shard_rows(n_global, world, rank)
+    assert (lo, hi) == (rank * n_local, (rank + 1) * n_local)
     radius = 500.0 * (n_global / 1_000_000.0) ** (1.0 / 3.0)
     scene = W.many_cubes(n_global, radius=radius, start=lo, count=n_local)
     ctx.resize(n_local)

@@ -127,10 +127,19 @@ def build_flat(ctx, args, rank, world, total_frames, full_holder):
     return wl
 
 
-def build_tree(ctx, args):
+def build_tree(ctx, args, rank=0, world=1):
     import bevy_amd as B
-    from bevy_amd import workloads as W
-    tr = W.gen_tree(12, 4, args.entities)
+    from bevy_amd import sharding, workloads as W
+    tr = W.gen_tree(12, 4, args.entities * world)
+    n_global = tr["n"]
+    if world > 1:
+        # shard by root subtree -- the one giant tree is opened up, its top rows are replicated and the
+        # subtrees below are bin-packed on the GPUs; no collective (a rank's rows never read another rank's)
+        sh = sharding.shard_hierarchy(tr["parent"], tr["level_offsets"], world, rank)
+        rows = sh["rows"].astype(np.int64)
+        tr = dict(n=len(rows), parent=sh["parent"], level_offsets=sh["level_offsets"],
+                  translation=tr["translation"].reshape(-1, 3)[rows].reshape(-1), rotation=tr["rotation"].reshape(-1, 4)[rows].reshape(-1),
+                  scale=tr["scale"].reshape(-1, 3)[rows].reshape(-1), owned=int(sh["owned"].sum()))
     ctx.resize(tr["n"])
     ctx.upload_transforms(tr["translation"], tr["rotation"], tr["scale"])
     ctx.upload_hierarchy(tr["parent"], tr["level_offsets"])
@@ -140,11 +149,14 @@ def build_tree(ctx, args):
     def step(f):
         ctx.upload_transforms(root_t[f & 1], tr["rotation"][:4], tr["scale"][:3], first_row=0)
         ctx.propagate(B.PROPAGATE_ALL_DIRTY)
-    config = {"workload": f"gen_tree(12,4) truncated to {tr['n']} nodes ({len(tr['level_offsets']) - 1} levels), root moved "
-                          "every frame (dirty-row upload), LDS subtree-tile propagation (replicas per GPU)", "nodes": tr["n"]}
+    config = {"workload": f"gen_tree(12,4) truncated to {n_global} nodes ({len(tr['level_offsets']) - 1} levels), root moved "
+                          "every frame (dirty-row upload), LDS subtree-tile propagation"
+                          + (f", sharded by root subtree over {world} GPUs (this rank holds {tr['n']} rows, no collective)" if world > 1 else ""),
+              "nodes": n_global, "parallelism": f"root-subtree shard x{world}"}
     # T 40, parent_idx 4, old G 48 (set_if_neq), G 48, changed byte 1
     wl = Workload("tree", step, tr["n"], 141.0, "k_propagate_tiles", config, "nodes/sec through hierarchy propagate", "nodes/s")
     wl.tree = tr
+    wl.global_units = n_global  # every node is owned by exactly one rank (replicated top rows are recomputed, not counted)
     return wl
 
 
@@ -361,7 +373,7 @@ def main():
         if args.workload == "flat":
             wl = build_flat(ctx, args, rank, world, total_frames, full_holder)
         elif args.workload == "tree":
-            wl = build_tree(ctx, args)
+            wl = build_tree(ctx, args, rank, world)
         else:
             wl = build_lights(ctx, args)
         barrier = (lambda: dist.barrier()) if use_dist else None
@@ -373,7 +385,7 @@ def main():
 
     out = None
     if rank == 0:
-        value = wl.units * world * args.steps / elapsed
+        value = getattr(wl, "global_units", wl.units * world) * args.steps / elapsed
         out = {"metric": wl.metric, "value": round(value, 1), "unit": wl.unit, "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 5), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": wl.config,

@@ -232,3 +232,113 @@ def unpack_view(full_words, n_rows, world, n_views, view):
         bits = np.unpackbits(full_words[r, view].view(np.uint8), bitorder="little")
         out[lo:hi] = bits[:hi - lo]
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Hierarchies: shard by root subtree.  Forest roots are independent
+# (propagate_parent_transforms, systems.rs:522), so whole trees go to GPUs; a tree bigger than a GPU's fair share
+# is opened up: its root is replicated (every rank that owns something below it recomputes it -- a handful of
+# rows) and its child subtrees are distributed instead.  No collective: a rank's rows never read another rank's.
+# ---------------------------------------------------------------------------------------------------------------------
+NO_PARENT = 0xFFFFFFFF
+
+
+def shard_hierarchy(parent, level_offsets, world, rank=None, slack=1.10):
+    """parent[i] (NO_PARENT for roots) with rows in level (BFS) order, level_offsets as mi_upload_hierarchy takes them.
+    Returns for `rank` (or a list for every rank if rank is None) a dict:
+      rows           global row ids this rank holds, ascending (level order is kept, parents precede children)
+      owned          bool per local row: this rank is responsible for the row's GlobalTransform (every global row is
+                     owned by exactly one rank; replicated ancestors are owned by the lowest rank holding them)
+      parent         local parent indices (NO_PARENT for roots)
+      level_offsets  local level offsets
+    Greedy: units start as the forest's trees and are placed biggest first on the least loaded rank; while the fullest
+    rank exceeds slack x (nodes / world), the biggest unit that has children is replaced by its child subtrees (its
+    root becomes a replicated row) and the placement is redone."""
+    parent = np.asarray(parent, np.uint32)
+    lv = np.asarray(level_offsets, np.int64)
+    n = len(parent)
+    is_root = parent == NO_PARENT
+    # subtree sizes, deepest level first
+    size = np.ones(n, np.int64)
+    for l in range(len(lv) - 2, 0, -1):
+        lo, hi = lv[l], lv[l + 1]
+        np.add.at(size, parent[lo:hi].astype(np.int64), size[lo:hi])
+    children_start = None  # children of a node are found by scanning its level's successor: build an index once
+    order = np.argsort(np.where(is_root, -1, parent.astype(np.int64)), kind="stable")
+    sorted_parent = np.where(is_root, -1, parent.astype(np.int64))[order]
+    first = np.searchsorted(sorted_parent, np.arange(n), "left")
+    last = np.searchsorted(sorted_parent, np.arange(n), "right")
+
+    def children(i):
+        return order[first[i]:last[i]]
+
+    # units: (size, root).  Pack biggest-first on the least loaded rank; while the fullest rank exceeds
+    # slack x (nodes / world), open the biggest unit that still has children and pack again.
+    units = [(int(size[i]), int(i)) for i in np.nonzero(is_root)[0]]
+    replicated = []
+    ideal = n / max(world, 1)
+
+    def pack(us):
+        load = [0] * world
+        where = {}
+        for sz, i in sorted(us, key=lambda u: (-u[0], u[1])):
+            r = min(range(world), key=lambda k: (load[k], k))
+            load[r] += sz
+            where[i] = r
+        return load, where
+
+    load, unit_rank = pack(units)
+    for _ in range(64 * max(world, 1)):
+        if world == 1 or max(load) <= slack * ideal:
+            break
+        splittable = [u for u in units if last[u[1]] > first[u[1]]]
+        if not splittable:
+            break
+        big = max(splittable, key=lambda u: (u[0], -u[1]))
+        units.remove(big)
+        replicated.append(big[1])
+        units.extend((int(size[c]), int(c)) for c in children(big[1]))
+        load, unit_rank = pack(units)
+    # rank of every node: the unit it lies in (replicated nodes: -1), level by level
+    node_rank = np.full(n, -2, np.int64)
+    rep = np.zeros(n, bool)
+    rep[replicated] = True
+    unit_root_rank = np.full(n, -2, np.int64)
+    for i, r in unit_rank.items():
+        unit_root_rank[i] = r
+    for l in range(len(lv) - 1):
+        lo, hi = lv[l], lv[l + 1]
+        idx = np.arange(lo, hi)
+        inherit = np.where(is_root[lo:hi], -2, node_rank[np.where(is_root[lo:hi], 0, parent[lo:hi]).astype(np.int64)])
+        node_rank[lo:hi] = np.where(rep[idx], -1, np.where(unit_root_rank[idx] >= 0, unit_root_rank[idx], inherit))
+    assert np.all(node_rank >= -1), "every row is in a unit or replicated"
+    # which ranks need each replicated node: those owning something below it
+    need = np.zeros((world, n), bool)
+    for r in range(world):
+        need[r] = node_rank == r
+    for l in range(len(lv) - 2, 0, -1):
+        lo, hi = lv[l], lv[l + 1]
+        p = parent[lo:hi].astype(np.int64)
+        for r in range(world):
+            np.logical_or.at(need[r], p, need[r, lo:hi])
+    out = []
+    rep_owner = np.full(n, -1, np.int64)
+    for i in replicated:
+        holders = [r for r in range(world) if need[r, i]]
+        rep_owner[i] = holders[0] if holders else 0
+        if not holders:
+            need[0, i] = True
+    for r in range(world):
+        rows = np.nonzero(need[r])[0].astype(np.uint32)
+        local_of = np.full(n, NO_PARENT, np.uint32)
+        local_of[rows] = np.arange(len(rows), dtype=np.uint32)
+        p = parent[rows]
+        lp = np.where(p == NO_PARENT, NO_PARENT, local_of[np.where(p == NO_PARENT, 0, p)]).astype(np.uint32)
+        assert not np.any((p != NO_PARENT) & (lp == NO_PARENT)), "a held row's parent must be held"
+        lvl = np.searchsorted(rows, lv.astype(np.uint32), "left").astype(np.uint32)
+        lvl = np.unique(lvl) if len(rows) else np.zeros(1, np.uint32)  # drop empty levels
+        if lvl[0] != 0:
+            lvl = np.concatenate([[0], lvl]).astype(np.uint32)
+        owned = (node_rank[rows] == r) | (rep_owner[rows] == r)
+        out.append(dict(rows=rows, owned=owned, parent=lp, level_offsets=lvl.astype(np.uint32)))
+    return out if rank is None else out[rank]

@@ -782,3 +782,35 @@ def test_non_finite_and_denormal_inputs_match_oracle(ctx_factory):
     bad = np.nonzero(diff.reshape(-1, 12).any(axis=1))[0]
     assert bad.size == 0, f"tree: {bad.size} rows differ, first {bad[:5].tolist()}"
     assert_bits(chg2, echg, "tree change ticks with NaN")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 5])
+def test_hierarchy_shards_reproduce_the_whole_tree(ctx_factory, world):
+    """SURVEY 8e, hierarchy: shard by root subtree (sharding.shard_hierarchy), one context per shard as the ranks of an
+    N-GPU run would hold them; the owned rows of all shards together are the unsharded GlobalTransforms, bit for bit."""
+    from bevy_amd import sharding
+    tr = W.gen_tree(9, 4, 60_000)
+    n = tr["n"]
+    full = ctx_factory()
+    full.resize(n)
+    full.upload_transforms(tr["translation"], tr["rotation"], tr["scale"])
+    full.upload_hierarchy(tr["parent"], tr["level_offsets"])
+    full.propagate(B.PROPAGATE_ALL_DIRTY)
+    g_full = full.download_global_transforms(want_changed=False).reshape(n, 12)
+    _, g_orc, _ = O.propagate_transforms(tr["parent"], tr["translation"], tr["rotation"], tr["scale"])
+    assert g_full.tobytes() == g_orc.tobytes()
+    got = np.zeros_like(g_full)
+    seen = np.zeros(n, np.int64)
+    for sh in sharding.shard_hierarchy(tr["parent"], tr["level_offsets"], world):
+        rows = sh["rows"].astype(np.int64)
+        c = ctx_factory()
+        c.resize(len(rows))
+        c.upload_transforms(*(tr[k].reshape(n, -1)[rows].reshape(-1) for k in ("translation", "rotation", "scale")))
+        c.upload_hierarchy(sh["parent"], sh["level_offsets"])
+        c.propagate(B.PROPAGATE_ALL_DIRTY)
+        g = c.download_global_transforms(want_changed=False).reshape(-1, 12)
+        got[rows[sh["owned"]]] = g[sh["owned"]]
+        seen[rows[sh["owned"]]] += 1
+    assert np.all(seen == 1)
+    assert got.tobytes() == g_full.tobytes()

@@ -106,3 +106,67 @@ def test_all_gather_visibility_world2():
         got = sharding.unpack_view(ret[0], N_ROWS, world, N_VIEWS, v)
         assert np.array_equal(got, expect[v]), f"view {v}"
     assert expect.sum() > 0
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("shape", ["one_tree", "forest", "chain"])
+def test_shard_hierarchy_partition(world, shape):
+    """Hierarchy sharding by root subtree: every row owned exactly once, every held row's ancestors held,
+    level order kept, loads balanced; and propagating each shard on its own reproduces the unsharded result bit for
+    bit (checked with the oracle on CPU -- no collective is involved)."""
+    if shape == "one_tree":
+        tr = W.gen_tree(7, 4)                      # 5461 nodes, one root: must be opened up
+    elif shape == "forest":
+        tr = W.gen_tree(6, 3)
+        # 9 copies of a small tree -> a forest (roots first, then level by level)
+        parts, n1 = [], tr["n"]
+        lv1 = tr["level_offsets"].astype(np.int64)
+        k = 9
+        parent = np.zeros(k * n1, np.uint32)
+        t, r, s = (np.zeros((k * n1, d), np.float32) for d in (3, 4, 3))
+        lv = [0]
+        pos = 0
+        new_index = np.zeros((k, n1), np.int64)
+        for l in range(len(lv1) - 1):
+            for c in range(k):
+                cnt = lv1[l + 1] - lv1[l]
+                new_index[c, lv1[l]:lv1[l + 1]] = np.arange(pos, pos + cnt)
+                pos += cnt
+            lv.append(pos)
+        for c in range(k):
+            p1 = tr["parent"]
+            parent[new_index[c]] = np.where(p1 == W.NO_PARENT, W.NO_PARENT, new_index[c][np.where(p1 == W.NO_PARENT, 0, p1)])
+            t[new_index[c]] = tr["translation"].reshape(-1, 3) * (1 + 0.1 * c)
+            r[new_index[c]] = tr["rotation"].reshape(-1, 4)
+            s[new_index[c]] = tr["scale"].reshape(-1, 3)
+        tr = dict(n=k * n1, parent=parent, level_offsets=np.array(lv, np.uint32), translation=t.reshape(-1), rotation=r.reshape(-1),
+                  scale=s.reshape(-1))
+    else:
+        n = 40
+        tr = W.gen_tree(n, 1)
+    n = tr["n"]
+    shards = sharding.shard_hierarchy(tr["parent"], tr["level_offsets"], world)
+    owners = np.zeros(n, np.int64)
+    _, g_full, _ = O.propagate_transforms(tr["parent"], tr["translation"], tr["rotation"], tr["scale"])
+    g_full = g_full.reshape(n, 12)
+    got = np.zeros_like(g_full)
+    for r, sh in enumerate(shards):
+        rows = sh["rows"].astype(np.int64)
+        owners[rows[sh["owned"]]] += 1
+        assert np.all(np.diff(rows) > 0)
+        lp = sh["parent"]
+        assert np.all((lp == W.NO_PARENT) | (lp < np.arange(len(rows))))          # parents precede children
+        assert np.array_equal(tr["parent"][rows] == W.NO_PARENT, lp == W.NO_PARENT)
+        ok = lp != W.NO_PARENT
+        assert np.array_equal(rows[lp[ok]], tr["parent"][rows][ok])             # and are the same nodes
+        lv = sh["level_offsets"].astype(np.int64)
+        assert lv[0] == 0 and lv[-1] == len(rows) and np.all(np.diff(lv) > 0) or len(rows) == 0
+        if len(rows):
+            t3, r4, s3 = (tr[k].reshape(n, -1)[rows].reshape(-1) for k in ("translation", "rotation", "scale"))
+            _, g, _ = O.propagate_transforms(lp, t3, r4, s3)
+            got[rows[sh["owned"]]] = g.reshape(-1, 12)[sh["owned"]]
+    assert np.all(owners == 1)
+    assert got.tobytes() == g_full.tobytes()
+    held = [len(sh["rows"]) for sh in shards]
+    if shape != "chain" and world > 1:
+        assert max(held) <= 1.35 * n / world + 64, held

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <map>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -88,6 +89,30 @@ struct Entity {
 };
 
 // The slice of the ECS the path touches: dense per-entity columns plus the change flags the systems read.
+struct MeshBinning {
+    uint64_t batch_set_key = 0;  // BinnedPhaseItem::BatchSetKey, ordered (phase.multidrawable_meshes is an IndexMap sorted by key)
+    bool indexed = true;         // PhaseItemBatchSetKey::indexed()
+    uint64_t bin_key = 0;        // BinnedPhaseItem::BinKey
+    uint32_t input_uniform_index = 0;
+};
+struct BatchSetRecord {  // BinnedRenderPhaseBatchSet, gpu_preprocessing.rs:2560-2577
+    uint64_t batch_set_key;
+    bool indexed;
+    uint32_t index, first_work_item_index, instance_count, first_indirect_parameters_index, batch_count, first_output_mesh_uniform_index;
+};
+struct BatchBin {  // one bin of a batch set, with the metadata the device filled in
+    uint64_t batch_set_key, bin_key;
+    mi_bin_metadata metadata;
+};
+struct PhaseBatches {  // what the multidrawable pass of batch_and_prepare_binned_render_phase leaves behind for one view
+    std::vector<mi_preprocess_work_item> work_items[2];               // [0] non-indexed, [1] indexed
+    std::vector<mi_indirect_parameters_metadata> metadata[2];
+    std::vector<mi_indirect_batch_set> batch_sets[2];
+    std::vector<BatchSetRecord> records;
+    std::vector<BatchBin> bins;
+    mi_batch_totals totals{};
+};
+
 class World {
   public:
     Entity spawn(const Transform& t = Transform{}) {
@@ -154,6 +179,10 @@ class World {
     bool inherited_visibility_changed(Entity e) const { return rec(e).inherited_changed; }
     void insert_aabb(Entity e, Aabb a) { rec(e).aabb = a; rec(e).bounds_changed = true; }
     void insert_point_light(Entity e, float range) { rec(e).point_light_range = range; }  // PointLight { range, .. }
+    // What queue_material_meshes decides for a multidrawable mesh instance: the batch set key (pipeline + bind groups +
+    // slabs), the bin key (mesh asset) and its slot in the MeshInputUniform buffer (render_phase/mod.rs:1086-1180)
+    void insert_mesh_binning(Entity e, MeshBinning b) { rec(e).binning = b; ++binning_version_; }
+    void remove_mesh_binning(Entity e) { rec(e).binning.reset(); ++binning_version_; }
     bool view_visibility(Entity e) const { return (rec(e).view_visibility & 1u) != 0; }  // ViewVisibility::get
     bool view_visibility_changed(Entity e) const { return rec(e).view_visibility_changed; }
 
@@ -188,6 +217,7 @@ class World {
         uint8_t view_visibility = 0;
         std::optional<Aabb> aabb;
         std::optional<float> point_light_range;
+        std::optional<MeshBinning> binning;
         bool transform_changed = false, added = false, parent_changed = false, orphaned = false;
         bool global_changed = false, inherited_changed = false, view_visibility_changed = false;
         bool visibility_changed = false, bounds_changed = false;
@@ -203,6 +233,7 @@ class World {
     std::vector<Rec> rec_;
     std::vector<uint32_t> free_;
     uint64_t structure_version_ = 1;
+    uint64_t binning_version_ = 1;
 };
 
 // Clusters + ObjectsInClusterCpu, crates/bevy_light/src/cluster/mod.rs:143-213
@@ -322,6 +353,37 @@ class Mi355xPlugin {
         check(mi_download_visible_entities(ctx_, view, 0, nullptr, rows.data(), n, &count));
         std::vector<Entity> out;
         for (uint32_t k = 0; k < count; ++k) out.push_back(entity_of_row_[rows[k]]);
+        return out;
+    }
+
+    // RenderSystems::PrepareResources, multidrawable part of batch_and_prepare_binned_render_phase
+    // (gpu_preprocessing.rs:2360-2447): the view's visible mesh instances -> PreprocessWorkItems, per-bin
+    // IndirectParametersMetadata and batch-set records, built on the device from the VisibleEntities list.
+    // Batch sets and bins are visited in key order.  Call after check_visibility.
+    PhaseBatches batch_multidrawables(World& w, uint32_t view, const mi_batch_initial* initial = nullptr) {
+        sync_structure(w);
+        sync_binning(w);
+        PhaseBatches out;
+        check(mi_batch_build(ctx_, view, 0, initial));
+        check(mi_batch_download_totals(ctx_, &out.totals));
+        for (uint32_t c = 0; c < 2; ++c) {
+            uint32_t k = 0;
+            out.work_items[c].resize(out.totals.work_item_len[c]);
+            check(mi_batch_download(ctx_, MI_BATCH_WORK_ITEMS, c, out.work_items[c].data(), (uint32_t)out.work_items[c].size(), &k));
+            out.metadata[c].resize(out.totals.indirect_parameters_len[c]);
+            check(mi_batch_download(ctx_, MI_BATCH_INDIRECT_PARAMETERS_METADATA, c, out.metadata[c].data(), (uint32_t)out.metadata[c].size(), &k));
+            out.batch_sets[c].resize(out.totals.batch_set_len[c]);
+            check(mi_batch_download(ctx_, MI_BATCH_SETS, c, out.batch_sets[c].data(), (uint32_t)out.batch_sets[c].size(), &k));
+        }
+        std::vector<mi_batch_set_record> recs(out.totals.n_records);
+        uint32_t k = 0;
+        check(mi_batch_download(ctx_, MI_BATCH_RECORDS, 0, recs.data(), (uint32_t)recs.size(), &k));
+        for (const auto& r : recs)
+            out.records.push_back(BatchSetRecord{set_keys_[r.set].first, r.indexed != 0, r.index, r.first_work_item_index, r.instance_count,
+                                                 r.first_indirect_parameters_index, r.batch_count, r.first_output_mesh_uniform_index});
+        std::vector<mi_bin_metadata> meta(bin_keys_.size());
+        check(mi_batch_download(ctx_, MI_BATCH_BIN_METADATA, 0, meta.data(), (uint32_t)meta.size(), &k));
+        for (size_t i = 0; i < meta.size(); ++i) out.bins.push_back(BatchBin{bin_keys_[i].first, bin_keys_[i].second, meta[i]});
         return out;
     }
 
@@ -445,7 +507,56 @@ class Mi355xPlugin {
         bounds_dirty_ = false;
     }
 
+    // Flattens the World's MeshBinning components into the row columns and bin tables mi_batch_* take: batch sets in key
+    // order, a set's bins in bin-key order (RenderBinIndex = rank of the bin key, metadata in the same order).
+    void sync_binning(World& w) {
+        if (seen_binning_ == w.binning_version_ && seen_binning_structure_ == w.structure_version_) return;
+        const uint32_t n = (uint32_t)entity_of_row_.size();
+        std::map<std::pair<uint64_t, bool>, std::map<uint64_t, uint32_t>> sets;  // (set key, indexed) -> bin key -> RenderBinIndex
+        for (uint32_t row = 0; row < n; ++row) {
+            const auto& b = w.rec_[entity_of_row_[row].index].binning;
+            if (b) sets[{b->batch_set_key, b->indexed}][b->bin_key] = 0;
+        }
+        set_keys_.clear();
+        bin_keys_.clear();
+        std::vector<uint8_t> indexed;
+        std::vector<uint32_t> table_off{0}, meta_off{0}, table;
+        std::vector<mi_bin_metadata> meta;
+        std::map<std::pair<uint64_t, bool>, uint32_t> set_id;
+        for (auto& [key, bins] : sets) {
+            set_id[key] = (uint32_t)set_keys_.size();
+            set_keys_.push_back(key);
+            indexed.push_back(key.second ? 1 : 0);
+            uint32_t k = 0;
+            for (auto& [bin_key, idx] : bins) {
+                idx = k;
+                table.push_back(k);
+                meta.push_back(mi_bin_metadata{k, k, 0});
+                bin_keys_.push_back({key.first, bin_key});
+                ++k;
+            }
+            table_off.push_back((uint32_t)table.size());
+            meta_off.push_back((uint32_t)meta.size());
+        }
+        std::vector<uint32_t> rs(n, MI_NO_BATCH_SET), rb(n, 0), ri(n, 0);
+        for (uint32_t row = 0; row < n; ++row) {
+            const auto& b = w.rec_[entity_of_row_[row].index].binning;
+            if (!b) continue;
+            rs[row] = set_id[{b->batch_set_key, b->indexed}];
+            rb[row] = sets[{b->batch_set_key, b->indexed}][b->bin_key];
+            ri[row] = b->input_uniform_index;
+        }
+        if (n) check(mi_batch_upload_rows(ctx_, 0, n, rs.data(), rb.data(), ri.data()));
+        else check(mi_batch_upload_rows(ctx_, 0, 0, nullptr, nullptr, nullptr));
+        check(mi_batch_upload_sets(ctx_, (uint32_t)set_keys_.size(), indexed.data(), table_off.data(), table.data(), meta_off.data(), meta.data()));
+        seen_binning_ = w.binning_version_;
+        seen_binning_structure_ = w.structure_version_;
+    }
+
     mi_ctx* ctx_ = nullptr;
+    std::vector<std::pair<uint64_t, bool>> set_keys_;
+    std::vector<std::pair<uint64_t, uint64_t>> bin_keys_;  // per metadata entry: (batch set key, bin key)
+    uint64_t seen_binning_ = 0, seen_binning_structure_ = 0;
     std::vector<Entity> entity_of_row_;
     uint64_t seen_version_ = 0;
     bool bounds_dirty_ = true;

@@ -314,6 +314,109 @@ static void lights_are_assigned_to_clusters() {
             }
 }
 
+// crates/bevy_render/src/render_phase/mod.rs:2356-2700 (proptest render_multidrawable_batch_set): random Add / Remove
+// of mock mesh instances (entity 0..32, bin 0..8, distinct input uniform indices), then the invariants -- a bin's
+// instance_count is the number of entities in it, every binned instance appears exactly once with its input uniform
+// index -- here for the instances the camera sees, plus what prepare_multidrawable_binned_batch_set promises
+// (gpu_preprocessing.rs:2511-2579): contiguous work-item, MeshUniform and indirect-parameter ranges per batch set.
+static void render_multidrawable_batch_set() {
+    World w;
+    Mi355xPlugin plugin;
+    std::vector<Entity> ents;
+    for (int i = 0; i < 32; ++i) {
+        // two out of three in front of the camera, the rest behind it
+        Entity e = w.spawn(Transform::from_xyz((float)(i % 7) - 3.0f, (float)(i % 3) - 1.0f, (i % 3) ? -25.0f : 25.0f));
+        w.insert_aabb(e, Aabb{{0, 0, 0}, {0.5f, 0.5f, 0.5f}});
+        ents.push_back(e);
+    }
+    plugin.propagate_transforms(w);
+    uint64_t rng = 0x9E3779B97F4A7C15ull;
+    auto next = [&rng]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+    std::map<uint32_t, MeshBinning> binned;  // entity index -> control copy
+    uint32_t next_input = 0;
+    const mi_batch_initial initial = {{2, 5}, {1, 3}, {1, 2}, 7};
+    for (int round = 0; round < 6; ++round) {
+        for (int op = 0; op < 40; ++op) {
+            const uint32_t id = (uint32_t)(next() % 32);
+            if (next() % 3) {  // Add (skipped when already binned, like the proptest)
+                if (binned.count(id)) continue;
+                MeshBinning b;
+                b.batch_set_key = 100 + next() % 3;
+                b.indexed = (b.batch_set_key & 1) != 0;
+                b.bin_key = next() % 8;
+                b.input_uniform_index = next_input++;
+                binned[id] = b;
+                w.insert_mesh_binning(ents[id], b);
+            } else if (binned.count(id)) {  // Remove
+                binned.erase(id);
+                w.remove_mesh_binning(ents[id]);
+            }
+        }
+        plugin.check_visibility(w, {camera_looking_down_neg_z()});
+        const std::vector<Entity> visible = plugin.visible_entities(0);
+        const PhaseBatches pb = plugin.batch_multidrawables(w, 0, &initial);
+        // control: visible binned instances per (set, bin)
+        std::map<std::pair<uint64_t, uint64_t>, std::vector<uint32_t>> expect;  // -> input uniform indices, VisibleEntities order
+        std::map<uint64_t, uint32_t> per_set;
+        for (Entity e : visible) {
+            auto it = binned.find(e.index);
+            if (it == binned.end()) continue;
+            expect[{it->second.batch_set_key, it->second.bin_key}].push_back(it->second.input_uniform_index);
+            per_set[it->second.batch_set_key] += 1;
+        }
+        for (const BatchBin& b : pb.bins) {
+            auto it = expect.find({b.batch_set_key, b.bin_key});
+            CHECK(b.metadata.instance_count == (it == expect.end() ? 0u : (uint32_t)it->second.size()), "instance_count == visible entities in the bin");
+        }
+        CHECK(pb.records.size() == per_set.size(), "one record per batch set with a visible instance");
+        uint32_t wi_cursor[2] = {initial.work_item_index[0], initial.work_item_index[1]};
+        uint32_t ip_cursor[2] = {initial.indirect_parameters_index[0], initial.indirect_parameters_index[1]};
+        uint32_t bs_cursor[2] = {initial.batch_set_index[0], initial.batch_set_index[1]};
+        uint32_t out_cursor = initial.output_mesh_uniform_index;
+        uint64_t prev_key = 0;
+        for (const BatchSetRecord& r : pb.records) {
+            const uint32_t c = r.indexed ? 1u : 0u;
+            CHECK(r.batch_set_key > prev_key, "batch sets in key order");
+            prev_key = r.batch_set_key;
+            CHECK(r.instance_count == per_set[r.batch_set_key], "record.instance_count");
+            CHECK(r.first_work_item_index == wi_cursor[c] && r.first_indirect_parameters_index == ip_cursor[c] && r.index == bs_cursor[c] &&
+                      r.first_output_mesh_uniform_index == out_cursor,
+                  "ranges are allocated back to back (prepare_multidrawable_binned_batch_set)");
+            CHECK(pb.batch_sets[c][r.index].indirect_parameters_base == r.first_indirect_parameters_index &&
+                      pb.batch_sets[c][r.index].indirect_parameters_count == 0,
+                  "IndirectBatchSet");
+            // work items of the set: every visible instance once, pointing at its bin's indirect parameters
+            std::map<uint32_t, std::vector<uint32_t>> by_slot;
+            for (uint32_t k = 0; k < r.instance_count; ++k) {
+                const mi_preprocess_work_item& wi = pb.work_items[c][r.first_work_item_index + k];
+                by_slot[wi.output_or_indirect_parameters_index].push_back(wi.input_index);
+            }
+            uint32_t expect_base = r.first_output_mesh_uniform_index, bins_of_set = 0;
+            for (const BatchBin& b : pb.bins) {
+                if (b.batch_set_key != r.batch_set_key) continue;
+                ++bins_of_set;
+                const uint32_t slot = r.first_indirect_parameters_index + b.metadata.indirect_parameters_offset;
+                const auto it = expect.find({b.batch_set_key, b.bin_key});
+                const std::vector<uint32_t> none;
+                CHECK(by_slot[slot] == (it == expect.end() ? none : it->second), "a bin's work items = its visible instances, in VisibleEntities order");
+                const mi_indirect_parameters_metadata& md = pb.metadata[c][slot];
+                CHECK(md.base_output_index == expect_base && md.batch_set_index == r.index && md.mesh_index == 0 && md.early_instance_count == 0 &&
+                          md.late_instance_count == 0,
+                      "allocate_uniforms: MeshUniform ranges of the bins tile the set's range");
+                expect_base += b.metadata.instance_count;
+            }
+            CHECK(bins_of_set == r.batch_count, "batch_count = bins of the set");
+            wi_cursor[c] += r.instance_count;
+            ip_cursor[c] += r.batch_count;
+            bs_cursor[c] += 1;
+            out_cursor += r.instance_count;
+        }
+        CHECK(pb.totals.data_buffer_len == out_cursor && pb.totals.work_item_len[0] == wi_cursor[0] && pb.totals.work_item_len[1] == wi_cursor[1], "totals");
+        w.clear_trackers();
+    }
+    CHECK(!binned.empty(), "the random walk left instances binned");
+}
+
 int main() {
     struct T { const char* name; void (*fn)(); };
     const T tests[] = {{"correct_parent_removed", correct_parent_removed},
@@ -327,7 +430,8 @@ int main() {
                        {"visibility_propagation_change_detection", visibility_propagation_change_detection},
                        {"view_visibility_lifecycle", view_visibility_lifecycle},
                        {"visible_entities_are_sorted_by_entity", visible_entities_are_sorted_by_entity},
-                       {"lights_are_assigned_to_clusters", lights_are_assigned_to_clusters}};
+                       {"lights_are_assigned_to_clusters", lights_are_assigned_to_clusters},
+                       {"render_multidrawable_batch_set", render_multidrawable_batch_set}};
     int n_failed_tests = 0;
     for (const T& t : tests) {
         const int before = g_failed;

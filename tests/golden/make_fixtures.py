@@ -56,7 +56,31 @@ def cluster_case(n=3000):
                 farthest_z=np.float32(far), total=np.uint64(total))
 
 
+def batching_case(n=777):
+    """The flat fixture's view 0 list -> batching work items (oracle/batching_oracle.c)."""
+    fx = flat_case(n)
+    rows = np.nonzero(fx["visible"][0])[0].astype(np.uint32)
+    bs = W.batching_scene(n, n_sets=5, max_bins=6, seed=11)
+    ini = O.BatchInitial()
+    ini.work_item_index[0], ini.work_item_index[1] = 3, 10
+    ini.indirect_parameters_index[0], ini.indirect_parameters_index[1] = 2, 7
+    ini.batch_set_index[0], ini.batch_set_index[1] = 1, 4
+    ini.output_mesh_uniform_index = 13
+    res = O.batch_build(rows, bs["row_set"], bs["row_bin"], bs["row_input"], bs["set_indexed"], bs["bin_table_offset"],
+                        bs["bin_table"], bs["meta_offset"], bs["bin_metadata"], ini)
+    out = dict(rows=rows, initial=np.array([3, 10, 2, 7, 1, 4, 13], np.uint32), records=res["records"],
+               bin_metadata_out=res["bin_metadata"], totals=np.array(res["totals"]["work_item_len"] + res["totals"]["indirect_parameters_len"]
+                                                                     + res["totals"]["batch_set_len"] + [res["totals"]["data_buffer_len"]], np.uint32))
+    for c in range(2):
+        out[f"work_items_{c}"] = res["work_items"][c]
+        out[f"metadata_{c}"] = res["metadata"][c]
+        out[f"batch_sets_{c}"] = res["batch_sets"][c]
+    out.update({k: v for k, v in bs.items()})
+    return out
+
+
 def main():
+    np.savez_compressed(os.path.join(HERE, "batching_777.npz"), **batching_case())
     np.savez_compressed(os.path.join(HERE, "flat_frame_777.npz"), **flat_case())
     np.savez_compressed(os.path.join(HERE, "tree_6x3.npz"), **tree_case())
     np.savez_compressed(os.path.join(HERE, "cluster_3000.npz"), **cluster_case())

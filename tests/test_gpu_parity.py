@@ -814,3 +814,46 @@ def test_hierarchy_shards_reproduce_the_whole_tree(ctx_factory, world):
         seen[rows[sh["owned"]]] += 1
     assert np.all(seen == 1)
     assert got.tobytes() == g_full.tobytes()
+
+
+@pytest.mark.gpu
+def test_ten_million_entities_four_views_properties(ctx_factory):
+    """configs[3] at full size on one GPU (the 8-GPU run holds an eighth of it per rank): 10 M entities, 4 cameras at
+    yaw 0/90/180/270.  The oracle needs minutes for the whole scene, so the full-size run is checked through
+    size-independent properties -- rows are independent, so any window of rows culled on its own (fresh context) must
+    give the same bits; three windows are compared with the oracle bit for bit (GlobalTransform included); per view the
+    sorted list is exactly the set bits of the mask; ViewVisibility is the OR over the views."""
+    n = 10_000_000
+    radius = 500.0 * 10.0 ** (1.0 / 3.0)
+    sc = W.many_cubes(n, radius=radius)
+    frusta = frusta_for([W.many_cubes_camera(3, yaw=k * math.pi / 2) for k in range(4)])
+    ctx = ctx_factory()
+    upload_scene(ctx, sc)
+    ctx.propagate_and_cull(frusta, flags=B.CULL_END_FRAME)
+    vis = [ctx.download_visibility(v) for v in range(4)]
+    vv, _ = ctx.download_view_visibility()
+    any_vis = np.zeros(n, bool)
+    total = 0
+    for v in range(4):
+        rows = ctx.download_visible_entities(v, 0)[1]
+        assert np.array_equal(rows, np.nonzero(vis[v])[0].astype(np.uint32)), f"view {v}: list != set bits of the mask"
+        any_vis |= vis[v].astype(bool)
+        total += len(rows)
+    assert 0.02 * n < total < 0.4 * n
+    assert np.array_equal((vv & 1).astype(bool), any_vis), "ViewVisibility = OR over the views"
+    assert np.all((vv & 2) == 0), "after MarkNewlyHidden only bit 0 survives"
+    g = ctx.download_global_transforms(want_changed=False).reshape(n, 12)
+    for lo in (0, 4_999_936, n - 65_536):  # windows on 256-row boundaries, 64 k rows each
+        hi = lo + 65_536
+        sub = {k: (sc[k].reshape(n, -1)[lo:hi].reshape(-1) if k != "n" else hi - lo) for k in sc}
+        g_exp, vv_exp, vis_exp, _ = oracle_frame(sub, np.zeros(hi - lo, np.uint8), frusta, None, None)
+        assert g[lo:hi].tobytes() == g_exp.tobytes(), f"GlobalTransform window at {lo}"
+        for v in range(4):
+            assert_bits(vis[v][lo:hi], vis_exp[v], f"window at {lo}, view {v}")
+        assert_bits(vv[lo:hi], vv_exp, f"ViewVisibility window at {lo}")
+        c2 = ctx_factory()
+        upload_scene(c2, sub)
+        c2.propagate_and_cull(frusta, flags=B.CULL_END_FRAME)
+        for v in range(4):
+            assert_bits(c2.download_visibility(v), vis[v][lo:hi], f"window at {lo} culled on its own, view {v}")
+        c2.close()

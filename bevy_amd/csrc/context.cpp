@@ -91,6 +91,10 @@ struct mi_ctx {
     bool snap_valid = false;
     bool have_hierarchy = false;
     bool g_chg_in_bytes = false;  // the GlobalTransform change mask currently lives in g_changed_bytes (tree path)
+    // host-side knowledge that lets a frame with no dirty Transform skip its launches: some byte of `changed` may be
+    // non-zero (set by the uploads that mark rows, cleared when mi_propagate consumes the column); the change masks of
+    // the last propagate may hold set bits
+    bool changed_maybe = true, g_chg_maybe = true;
 
     // ---- views / visibility ----
     DevBuf views;
@@ -728,6 +732,7 @@ int32_t mi_synchronize(mi_ctx* ctx) {
 int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
     ENTER(ctx);
     ctx->bt_resolve = true;
+    ctx->changed_maybe = true;
     if (n_rows > ctx->cap) {
         uint32_t new_cap = std::max<uint64_t>(n_rows, std::min<uint64_t>((uint64_t)ctx->cap * 3 / 2, 0xFFFFFF00ull));
         new_cap = (uint32_t)(((uint64_t)new_cap + 255u) / 256u * 256u);  // whole workgroups
@@ -742,6 +747,7 @@ int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
         if ((rc = grow_column(ctx, ctx->flags, 1, old, new_cap, MI_FLAG_INHERITED_VISIBLE))) return rc;
         if ((rc = grow_column(ctx, ctx->vv, 1, old, new_cap, 0))) return rc;
         if ((rc = grow_column(ctx, ctx->changed, 1, old, new_cap, 1))) return rc;
+        ctx->changed_maybe = true;
         if ((rc = grow_column(ctx, ctx->g_changed_bytes, 1, old, new_cap, 0))) return rc;
         if ((rc = grow_column(ctx, ctx->layers, 1, old, new_cap, 0))) return rc;
         if ((rc = grow_column(ctx, ctx->class_mask, 1, old, new_cap, 0))) return rc;
@@ -841,6 +847,7 @@ int32_t mi_upload_transforms_indexed(mi_ctx* ctx, uint32_t n, const uint32_t* ro
         ctx->have_changed = true;
     }
     HIP_TRY(ctx, launch_upload_trs_indexed((const uint32_t*)dev, n, ctx->t, ctx->r, ctx->s, ctx->changed, ctx->stream));
+    ctx->changed_maybe = true;
     return MI_OK;
 }
 
@@ -915,6 +922,7 @@ int32_t mi_upload_changed(mi_ctx* ctx, uint32_t first_row, uint32_t n, const uin
     int32_t rc = check_rows(ctx, first_row, n, "mi_upload_changed");
     if (rc) return rc;
     ctx->have_changed = true;
+    ctx->changed_maybe = true;
     return upload(ctx, ctx->changed + first_row, changed, n);
 }
 
@@ -945,6 +953,7 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
                             uint32_t n_levels) {
     ENTER(ctx);
     if (n != ctx->n) return fail(ctx, MI_ERR_INVALID_ARG, "mi_upload_hierarchy: n (%u) != live rows (%u)", n, ctx->n);
+    ctx->changed_maybe = true;  // conservative: the next propagate looks at the rows again
     if (!parent_idx || n_levels <= 1) {
         ctx->have_hierarchy = false;
         ctx->n_levels = 1;
@@ -1127,6 +1136,20 @@ int32_t mi_propagate(mi_ctx* ctx, uint32_t flags) {
     if (ctx->n == 0) return MI_OK;
     const bool all_dirty = (flags & MI_PROPAGATE_ALL_DIRTY) != 0 || !ctx->have_changed;
     const bool static_opt = (flags & MI_PROPAGATE_STATIC_OPT) != 0;
+    if (!all_dirty && !ctx->changed_maybe && (!ctx->have_hierarchy || static_opt)) {
+        // No Transform was marked since the last propagate consumed the change column: every row keeps its
+        // GlobalTransform (set_if_neq would compare equal, systems.rs:719) and no change tick moves.  Only the change
+        // masks of the previous frame have to read as empty.  (Not with a hierarchy and the static optimisation off:
+        // there the reference re-assigns every root each frame, which bumps the roots' ticks, systems.rs:522-530.)
+        if (ctx->g_chg_maybe) {
+            HIP_TRY(ctx, hipMemsetAsync(ctx->g_chg_bits, 0, padded_words(ctx->n) * 8, ctx->stream));
+            if (ctx->g_changed_bytes) HIP_TRY(ctx, hipMemsetAsync(ctx->g_changed_bytes, 0, ctx->n, ctx->stream));
+            ctx->g_chg_in_bytes = false;
+            ctx->g_chg_maybe = false;
+        }
+        return MI_OK;
+    }
+    ctx->g_chg_maybe = true;
     Columns c = columns_of(ctx);
     const uint32_t n0 = ctx->have_hierarchy ? ctx->level_offsets[1] : ctx->n;
     const uint32_t* tree_bits = nullptr;
@@ -1168,6 +1191,7 @@ int32_t mi_propagate(mi_ctx* ctx, uint32_t flags) {
     }
     if (ctx->have_changed) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, ctx->n, ctx->stream));  // change flags are consumed
+        ctx->changed_maybe = false;
     }
     return MI_OK;
 }
@@ -1241,7 +1265,11 @@ int32_t mi_propagate_and_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t 
                                                 n_views, vo, seg, flags & MI_CULL_END_FRAME, ctx->stream));
     }
     if ((rc = run_compaction(ctx, vo, seg))) return rc;
-    if (ctx->have_changed) HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, ctx->n, ctx->stream));
+    if (ctx->have_changed) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, ctx->n, ctx->stream));
+        ctx->changed_maybe = false;
+    }
+    ctx->g_chg_maybe = true;
     ctx->g_chg_in_bytes = false;
     ctx->culled = true;
     return exchange_end(ctx);

@@ -857,3 +857,51 @@ def test_ten_million_entities_four_views_properties(ctx_factory):
         for v in range(4):
             assert_bits(c2.download_visibility(v), vis[v][lo:hi], f"window at {lo} culled on its own, view {v}")
         c2.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tree", [False, True])
+def test_static_frames_change_nothing_and_report_nothing(ctx_factory, tree):
+    """0 % dirty frames (configs[1], second run): after the change column was consumed and nothing was marked again,
+    mi_propagate returns without launching; GlobalTransforms stay bit-identical and the changed masks read empty --
+    what the reference's Changed<Transform> filter + set_if_neq give (systems.rs:45-50, :719).  A later dirty row is
+    picked up as usual."""
+    if tree:
+        tr = W.gen_tree(7, 4)
+        n = tr["n"]
+        t, r, s = tr["translation"], tr["rotation"], tr["scale"]
+    else:
+        sc = W.many_cubes(20_000, radius=30.0)
+        n = sc["n"]
+        t, r, s = sc["translation"], sc["rotation"], sc["scale"]
+    ctx = ctx_factory()
+    ctx.resize(n)
+    ctx.upload_transforms(t, r, s)
+    if tree:
+        ctx.upload_hierarchy(tr["parent"], tr["level_offsets"])
+    flags = B.PROPAGATE_STATIC_OPT if tree else 0  # without it the reference re-assigns (and ticks) every root each frame
+    ctx.upload_changed(np.ones(n, np.uint8))
+    ctx.propagate(flags)
+    g0, chg0 = ctx.download_global_transforms()
+    assert chg0.all()
+    for _ in range(3):
+        ctx.propagate(flags)
+        g1, chg1 = ctx.download_global_transforms()
+        assert g1.tobytes() == g0.tobytes() and not chg1.any()
+    # one row moves
+    row = n // 2
+    t2 = t.reshape(n, 3)[row].copy() + np.float32(1.5)
+    ctx.upload_transforms_indexed(np.array([row], np.uint32), t2, r.reshape(n, 4)[row], s.reshape(n, 3)[row])
+    ctx.propagate(flags)
+    g2, chg2 = ctx.download_global_transforms()
+    tt = t.copy().reshape(n, 3)
+    tt[row] = t2
+    if tree:
+        _, g_exp, _ = O.propagate_transforms(tr["parent"], tt.reshape(-1), r, s)
+    else:
+        g_exp = O.full_frame(tt.reshape(-1), r, s, sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"], np.zeros(n, np.uint8),
+                             frusta_for([W.many_cubes_camera(0)]), None, None)[0]
+    assert g2.tobytes() == g_exp.tobytes()
+    assert chg2[row] and 1 <= chg2.sum() < n
+    ctx.propagate(flags)
+    assert not ctx.download_global_transforms()[1].any()

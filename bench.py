@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["flat", "tree", "lights"], default="flat")
+    ap.add_argument("--workload", choices=["flat", "tree", "lights", "flat_static", "batching"], default="flat")
     ap.add_argument("--entities", type=int, default=1_000_000, help="rows per GPU (flat) / nodes (tree)")
     ap.add_argument("--views", type=int, default=1)
     ap.add_argument("--lights", type=int, default=100_000)
@@ -65,9 +65,11 @@ class Workload:
     def __init__(self, name, step, units, bytes_per_unit, dominant, config, metric, unit):
         self.name, self.step, self.units, self.bytes_per_unit = name, step, units, bytes_per_unit
         self.dominant, self.config, self.metric, self.unit = dominant, config, metric, unit
-        # The dominant kernel is timed on every 8th launch: binding start/stop events to a dispatch costs ~5 us of GPU time
-        # per launch on this stack (30.5 -> 25.5 us per flat frame when sampled), which would tax `value` itself.
-        self.profile_every = 8
+        # The dominant kernel is timed on the first eighth of the timed region's launches only: binding start/stop events to
+        # a dispatch fences it off from its neighbours (as rocprofv3's kernel trace does) and costs ~5 us of GPU time per
+        # launch on this stack (30.5 vs 25.5 us per flat frame), which would otherwise tax `value` itself.
+        self.profile_every = 1
+        self.profile_fraction = 8
 
 
 def build_flat(ctx, args, rank, world, total_frames, full_holder):
@@ -312,6 +314,8 @@ def measure(ctx, wl, steps, warmup, profile_all, sync_extra=None):
     sync_all()
     ctx.profile_filter(None if profile_all else [wl.dominant])
     ctx.profile_sample(getattr(wl, "profile_every", 1))
+    wl.timed_launches = max(8, steps // getattr(wl, "profile_fraction", 1)) if getattr(wl, "profile_fraction", 1) > 1 else 0
+    ctx.profile_burst(wl.timed_launches)
     ctx.profile_enable(True)
     sync_all()
     t0 = time.perf_counter()
@@ -332,7 +336,7 @@ def roofline_of(wl, prof, steps):
     if not dk:
         return None
     avg_s = dk["avg_us"] * 1e-6
-    launches_per_step = dk["launches"] * getattr(wl, "profile_every", 1) / steps
+    launches_per_step = 1.0 if getattr(wl, "timed_launches", 0) else dk["launches"] * getattr(wl, "profile_every", 1) / steps
     alg_bytes = wl.bytes_per_unit * wl.units / launches_per_step
     achieved = alg_bytes / avg_s / 1e9
     traffic = None
@@ -345,8 +349,8 @@ def roofline_of(wl, prof, steps):
     return {"bound": "hbm", "kernel": wl.dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "avg_kernel_us": round(dk["avg_us"], 3),
             "launches": dk["launches"], "algorithmic_bytes_per_launch": int(alg_bytes),
-            "timing": f"per-dispatch start/stop events (hipExtLaunchKernelGGL) on every {getattr(wl, 'profile_every', 1)}th launch "
-                      "inside the timed region"}
+            "timing": "per-dispatch start/stop events (hipExtLaunchKernelGGL) on the first "
+                      f"{dk['launches']} launches inside the timed region of {steps} steps"}
 
 
 def main():
@@ -379,10 +383,14 @@ def main():
             wl = build_flat(ctx, args, rank, world, total_frames, full_holder)
         elif args.workload == "tree":
             wl = build_tree(ctx, args, rank, world)
+        elif args.workload == "flat_static":
+            wl = build_flat_static(ctx, args)
+        elif args.workload == "batching":
+            wl = build_batching(ctx, args)
         else:
             wl = build_lights(ctx, args)
         if args.profile_every > 0:
-            wl.profile_every = args.profile_every
+            wl.profile_every, wl.profile_fraction = args.profile_every, 1
         barrier = (lambda: dist.barrier()) if use_dist else None
         elapsed, prof = measure(ctx, wl, args.steps, args.warmup, args.profile_all, barrier)
     if use_dist:

@@ -92,7 +92,7 @@ ABI_SYMBOLS = [
     "mi_cluster_assign_resident", "mi_cluster_download", "mi_cluster_download_bindings",
     "mi_batch_upload_rows", "mi_batch_upload_sets", "mi_batch_build", "mi_batch_download_totals", "mi_batch_download", "mi_perspective_clip_from_view", "mi_compute_frustum",
     "mi_bind_visibility_output", "mi_exchange_configure", "mi_exchange_last", "mi_device_buffer", "mi_timer_begin", "mi_timer_end", "mi_profile_enable",
-    "mi_profile_filter", "mi_profile_sample", "mi_profile_read", "mi_profile_kernel_name",
+    "mi_profile_filter", "mi_profile_sample", "mi_profile_burst", "mi_profile_read", "mi_profile_kernel_name",
 ]
 
 
@@ -553,6 +553,9 @@ class Context:
 
     def profile_sample(self, every_n=1):
         self._ck(self._lib.mi_profile_sample(self._h, int(every_n)))
+
+    def profile_burst(self, first_n=0):
+        self._ck(self._lib.mi_profile_burst(self._h, int(first_n)))
 
     def profile_read(self):
         n = C.c_uint32(64)

@@ -161,6 +161,7 @@ struct mi_ctx {
     bool profiling = false;
     uint64_t prof_mask = ~0ull;
     uint32_t prof_every = 1, prof_tick[K_NUM_KERNELS] = {0};  // time every n-th launch of a kernel
+    uint32_t prof_burst = 0, prof_timed[K_NUM_KERNELS] = {0};  // ... and at most the first prof_burst of them (0 = no limit)
     std::vector<ProfSpan> spans;
     bool span_open = false;
     uint64_t prof_launches[K_NUM_KERNELS] = {0};
@@ -311,6 +312,8 @@ struct ProfScope {
     ProfScope(mi_ctx* c, uint32_t k) : ctx(c) {
         if (!c->profiling || k >= K_NUM_KERNELS || !((c->prof_mask >> k) & 1ull)) return;
         if (c->prof_every > 1 && (c->prof_tick[k]++ % c->prof_every) != 0) return;
+        if (c->prof_burst && c->prof_timed[k] >= c->prof_burst) return;
+        ++c->prof_timed[k];
         prof_close(c);
         ProfSpan sp;
         sp.kernel = k;
@@ -2047,6 +2050,7 @@ int32_t mi_profile_enable(mi_ctx* ctx, int32_t enabled) {
         prof_collect(ctx);
         memset(ctx->prof_launches, 0, sizeof ctx->prof_launches);
         memset(ctx->prof_ms, 0, sizeof ctx->prof_ms);
+        memset(ctx->prof_timed, 0, sizeof ctx->prof_timed);
     }
     ctx->profiling = enabled != 0;
     return MI_OK;
@@ -2060,6 +2064,12 @@ int32_t mi_profile_sample(mi_ctx* ctx, uint32_t every_n) {
     ENTER(ctx);
     ctx->prof_every = every_n ? every_n : 1;
     memset(ctx->prof_tick, 0, sizeof ctx->prof_tick);
+    return MI_OK;
+}
+int32_t mi_profile_burst(mi_ctx* ctx, uint32_t first_n) {
+    ENTER(ctx);
+    ctx->prof_burst = first_n;
+    memset(ctx->prof_timed, 0, sizeof ctx->prof_timed);
     return MI_OK;
 }
 int32_t mi_profile_read(mi_ctx* ctx, uint32_t* inout_n, uint64_t* launches, double* total_ms) {

@@ -502,6 +502,10 @@ int32_t mi_profile_enable(mi_ctx* ctx, int32_t enabled);
 int32_t mi_profile_filter(mi_ctx* ctx, uint64_t kernel_mask);
 /* Times only every n-th launch of each selected kernel (a timed launch costs several microseconds of host time). */
 int32_t mi_profile_sample(mi_ctx* ctx, uint32_t every_n);
+/* Times at most the first first_n launches of each selected kernel after mi_profile_enable(1) (0 = no limit): a
+ * timed dispatch is fenced off from its neighbours by its timestamp packets (the same isolation rocprofv3's kernel
+ * trace imposes), which costs ~5 us of GPU time per launch -- a burst keeps that out of the rest of a timed region. */
+int32_t mi_profile_burst(mi_ctx* ctx, uint32_t first_n);
 int32_t mi_profile_read(mi_ctx* ctx, uint32_t* inout_n, uint64_t* launches, double* total_ms);
 const char* mi_profile_kernel_name(uint32_t k);
 

@@ -25,7 +25,7 @@ def short(name):
 
 
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
-for wl in ("flat", "tree", "lights"):
+for wl in ("flat", "tree", "lights", "flat_static", "batching"):
     stats = os.path.join(src, wl, f"{wl}_kernel_stats.csv")
     if os.path.exists(stats):
         shutil.copy(stats, os.path.join(dst, f"{wl}_kernel_stats.csv"))

@@ -121,11 +121,19 @@ struct mi_ctx {
         std::mutex m;
         std::condition_variable cv;
         std::deque<uint32_t> queue;
+        std::atomic<uint64_t> submitted_fast{0};  // == submitted, readable without the lock (the thread polls it)
+        std::atomic<bool> sleeping{false}, stop_fast{false};
         bool stop = false;
         uint64_t submitted = 0, issued = 0;  // guarded by m
         uint64_t worker_frames = 0;          // exchange thread only
         int worker_error = 0;
         volatile uint32_t* done_flag = nullptr;  // pinned host word: number of frames whose all-gather has completed
+        // device word: number of frames whose masks are complete.  Written by the compaction kernel itself (see
+        // CompactFastArgs::signal) or, when that kernel is not the one running, by a write-value packet behind the
+        // frame's kernels; the communication stream waits on it with hipStreamWaitValue32.
+        uint32_t* kernels_flag = nullptr;
+        bool kernel_signal = true;      // MI_XCH_NO_KERNEL_SIGNAL forces the packet
+        bool signalled = false;         // this frame's compaction launch carries the signal
         double dbg_wait_ns = 0, dbg_begin_ns = 0, dbg_end_ns = 0, dbg_worker_ns = 0;  // MI_XCH_DEBUG
     } xch;
     void* ext_bitmask = nullptr;
@@ -479,6 +487,11 @@ int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg) 
         f.out_rows = (uint32_t*)ctx->out_rows.p;
         f.seg_stride = ctx->seg_stride;
         f.seg_totals = (uint32_t*)ctx->seg_totals.p;
+        if (ctx->xch.on && ctx->xch.kernel_signal) {
+            f.signal = ctx->xch.kernels_flag;
+            f.signal_value = (uint32_t)(ctx->xch.frame + 1);
+            ctx->xch.signalled = true;
+        }
         ProfScope ps(ctx, K_COMPACT_FAST);
         HIP_TRY(ctx, launch_compact_fast(f, ctx->stream));
         return MI_OK;
@@ -518,19 +531,32 @@ void exchange_worker(mi_ctx* ctx) {
     hipSetDevice(ctx->device);
     for (;;) {
         uint32_t slot;
+        // While frames are flowing the thread must not go to sleep between them: waking a thread through a futex
+        // takes tens of microseconds, more than a frame.  Poll the submission counter for a while first.
+        if (x.submitted_fast.load(std::memory_order_acquire) == x.worker_frames) {
+            const auto spin0 = std::chrono::steady_clock::now();
+            uint32_t spins = 0;
+            while (x.submitted_fast.load(std::memory_order_acquire) == x.worker_frames && !x.stop_fast.load(std::memory_order_relaxed)) {
+                __builtin_ia32_pause();
+                if ((++spins & 255u) == 0 && std::chrono::steady_clock::now() - spin0 > std::chrono::microseconds(500)) break;
+            }
+        }
         {
             std::unique_lock<std::mutex> lk(x.m);
-            x.cv.wait(lk, [&] { return x.stop || !x.queue.empty(); });
+            if (x.queue.empty() && !x.stop) {
+                x.sleeping.store(true, std::memory_order_seq_cst);
+                x.cv.wait(lk, [&] { return x.stop || !x.queue.empty(); });
+                x.sleeping.store(false, std::memory_order_relaxed);
+            }
             if (x.queue.empty()) return;  // stop requested and drained
             slot = x.queue.front();
             x.queue.pop_front();
         }
         int err = 0;
         const auto tw0 = std::chrono::steady_clock::now();
-        if (hipStreamWaitEvent(x.comm_stream, x.ev_kernels[slot], 0) != hipSuccess) err = -1;
+        if (hipStreamWaitValue32(x.comm_stream, x.kernels_flag, (uint32_t)(x.worker_frames + 1), hipStreamWaitValueGte, 0xFFFFFFFFu) != hipSuccess) err = -1;
         char* base = (char*)x.buf[slot];
-        if (!err) err = x.all_gather(base + (size_t)x.rank * x.block_bytes, base, (size_t)x.block_bytes, 1 /* ncclUint8 */, x.comm,
-                                     x.comm_stream);
+        if (!err) err = x.all_gather(base + (size_t)x.rank * x.block_bytes, base, (size_t)x.block_bytes, 1 /* ncclUint8 */, x.comm, x.comm_stream);
         if (hipEventRecord(x.ev_gathered[slot], x.comm_stream) != hipSuccess && !err) err = -2;
         // completion counter the caller's thread can read without a driver call
         if (hipStreamWriteValue32(x.comm_stream, (void*)x.done_flag, (uint32_t)(x.worker_frames + 1), 0) != hipSuccess && !err) err = -3;
@@ -559,10 +585,12 @@ void exchange_stop(mi_ctx* ctx) {
             std::lock_guard<std::mutex> lk(x.m);
             x.stop = true;
         }
+        x.stop_fast.store(true);
         x.cv.notify_all();
         x.worker.join();
     }
     x.stop = false;
+    x.stop_fast.store(false);
 }
 int32_t exchange_begin(mi_ctx* ctx) {
     auto& x = ctx->xch;
@@ -578,6 +606,7 @@ int32_t exchange_begin(mi_ctx* ctx) {
         // nothing as long as the next frame is already queued.
         const uint64_t need = x.frame - x.n_bufs + 1;
         uint32_t spins = 0;
+
         while ((uint64_t)*x.done_flag < need) {
             if ((++spins & 1023u) == 0) {
                 {
@@ -602,13 +631,15 @@ int32_t exchange_end(mi_ctx* ctx) {
     if (!x.on) return MI_OK;
     const uint32_t slot = (uint32_t)(x.frame % x.n_bufs);
     const auto te0 = std::chrono::steady_clock::now();
-    HIP_TRY(ctx, hipEventRecord(x.ev_kernels[slot], ctx->stream));
+    if (!x.signalled) HIP_TRY(ctx, hipStreamWriteValue32(ctx->stream, x.kernels_flag, (uint32_t)(x.frame + 1), 0));
+    x.signalled = false;
     {
         std::lock_guard<std::mutex> lk(x.m);
         x.queue.push_back(slot);
         ++x.submitted;
     }
-    x.cv.notify_all();
+    x.submitted_fast.fetch_add(1, std::memory_order_seq_cst);
+    if (x.sleeping.load(std::memory_order_seq_cst)) x.cv.notify_all();  // no futex call while the thread is polling
     ++x.frame;
     x.dbg_end_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - te0).count();
     return MI_OK;
@@ -1921,6 +1952,11 @@ int32_t mi_exchange_configure(mi_ctx* ctx, void* nccl_comm, void* fn_nccl_all_ga
     for (uint32_t i = 0; i < n_bufs; ++i)
         if (!device_bufs[i]) return fail(ctx, MI_ERR_INVALID_ARG, "mi_exchange_configure: buffer %u is NULL", i);
     if (!x.done_flag) HIP_TRY(ctx, hipHostMalloc((void**)&x.done_flag, 64, hipHostMallocMapped));
+    if (!x.kernels_flag) HIP_TRY(ctx, hipMalloc((void**)&x.kernels_flag, 64));
+    HIP_TRY(ctx, hipMemsetAsync(x.kernels_flag, 0, 64, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    x.kernel_signal = getenv("MI_XCH_NO_KERNEL_SIGNAL") == nullptr;
+    x.signalled = false;
     if (!x.comm_stream) {
         for (uint32_t i = 0; i < mi_ctx::Exchange::MAX_BUFS; ++i) {
             HIP_TRY(ctx, hipEventCreateWithFlags(&x.ev_kernels[i], hipEventDisableTiming));
@@ -1980,6 +2016,7 @@ int32_t mi_exchange_configure(mi_ctx* ctx, void* nccl_comm, void* fn_nccl_all_ga
     x.worker_frames = 0;
     x.frame = 0;
     x.submitted = x.issued = 0;
+    x.submitted_fast.store(0);
     x.worker_error = 0;
     x.queue.clear();
     x.worker = std::thread(exchange_worker, ctx);

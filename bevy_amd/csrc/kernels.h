@@ -186,6 +186,13 @@ struct CompactFastArgs {
     uint32_t* out_rows;
     uint64_t seg_stride;      // entries reserved per segment in out_rows
     uint32_t* seg_totals;
+    // Multi-GPU exchange: workgroup (0, 0) publishes `signal_value` at its start.  Any workgroup of this kernel running
+    // means the frame kernel before it in the stream has completed and its masks are visible, which is all the
+    // all-gather on the communication stream (hipStreamWaitValue32 on this word) needs -- and no signalling packet
+    // has to sit between the frames in the compute queue (an event record or write-value packet there costs ~6 us
+    // per frame: it keeps the next frame kernel from starting behind the compaction).
+    uint32_t* signal;
+    uint32_t signal_value;
 };
 hipError_t launch_compact_fast(const CompactFastArgs& a, hipStream_t stream);
 

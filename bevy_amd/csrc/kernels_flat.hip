@@ -600,6 +600,8 @@ hipError_t launch_compact(const CompactArgs& a, hipStream_t stream, void (*mark)
 __device__ __forceinline__ uint32_t sum_bytes(uint32_t x, uint32_t acc) { return __builtin_amdgcn_sad_u8(x, 0u, acc); }
 
 __global__ void __launch_bounds__(256) k_compact_fast(CompactFastArgs a) {
+    if (a.signal && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        __hip_atomic_store(a.signal, a.signal_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const uint32_t seg = blockIdx.y;
     const uint32_t view = seg / a.n_classes;
     const uint8_t* cnt = a.wave_cnt + (size_t)seg * a.n_waves;

@@ -91,7 +91,7 @@ ABI_SYMBOLS = [
     "mi_cluster_dimensions_fixed_z", "mi_cluster_assign", "mi_cluster_upload_objects", "mi_cluster_upload_view",
     "mi_cluster_assign_resident", "mi_cluster_download", "mi_cluster_download_bindings",
     "mi_batch_upload_rows", "mi_batch_upload_sets", "mi_batch_build", "mi_batch_download_totals", "mi_batch_download", "mi_perspective_clip_from_view", "mi_compute_frustum",
-    "mi_bind_visibility_output", "mi_exchange_configure", "mi_exchange_last", "mi_device_buffer", "mi_timer_begin", "mi_timer_end", "mi_profile_enable",
+    "mi_bind_visibility_output", "mi_exchange_configure", "mi_exchange_configure_multi", "mi_exchange_last", "mi_device_buffer", "mi_timer_begin", "mi_timer_end", "mi_profile_enable",
     "mi_profile_filter", "mi_profile_sample", "mi_profile_burst", "mi_profile_read", "mi_profile_kernel_name",
 ]
 
@@ -504,13 +504,20 @@ class Context:
         self._ck(self._lib.mi_bind_visibility_output(self._h, C.c_void_p(device_ptr), C.c_uint64(words_per_view),
                                                      C.c_uint64(word_offset)))
 
-    def exchange_configure(self, comm, fn_all_gather, bufs, words_per_view, word_offset, block_bytes, rank):
-        """bufs: list of device pointers of the gathered buffers (None / empty with comm=None switches it off)."""
+    def exchange_configure(self, comms, fn_all_gather, bufs, words_per_view, word_offset, block_bytes, rank):
+        """comms: one ncclComm_t handle or a list of them (used round-robin by frame); None / empty switches the exchange
+        off.  bufs: list of device pointers of the gathered buffers."""
+        if comms is None:
+            comms = []
+        elif not isinstance(comms, (list, tuple)):
+            comms = [comms]
+        comms = [c for c in comms if c]
         bufs = list(bufs or [])
         arr = (C.c_void_p * max(len(bufs), 1))(*bufs)
-        self._ck(self._lib.mi_exchange_configure(self._h, C.c_void_p(comm), C.c_void_p(fn_all_gather), arr, len(bufs),
-                                                 C.c_uint64(words_per_view), C.c_uint64(word_offset),
-                                                 C.c_uint64(block_bytes), C.c_uint32(rank)))
+        carr = (C.c_void_p * max(len(comms), 1))(*comms)
+        self._ck(self._lib.mi_exchange_configure_multi(self._h, carr, len(comms), C.c_void_p(fn_all_gather), arr, len(bufs),
+                                                       C.c_uint64(words_per_view), C.c_uint64(word_offset),
+                                                       C.c_uint64(block_bytes), C.c_uint32(rank)))
 
     def exchange_last(self, wait=True):
         p = C.c_void_p()

@@ -105,14 +105,19 @@ struct mi_ctx {
     struct Exchange {
         bool on = false;
         int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;  // ncclAllGather
-        void* comm = nullptr;
+        // Up to MAX_COMMS communicators, used round-robin by frame, each on its own stream: the all-gathers of
+        // consecutive frames are then in flight together (a ~125 KB all-gather over 8 GPUs is pure latency, and one
+        // communicator runs its collectives strictly one after the other).  Every rank issues them in frame order.
+        static constexpr uint32_t MAX_COMMS = 4;
+        uint32_t n_comms = 0;
+        void* comm[MAX_COMMS] = {nullptr};
         static constexpr uint32_t MAX_BUFS = 8;
         uint32_t n_bufs = 0;
         void* buf[MAX_BUFS] = {nullptr};
         uint64_t words_per_view = 0, word_offset = 0, block_bytes = 0;
         uint32_t rank = 0;
         uint64_t frame = 0;
-        hipStream_t comm_stream = nullptr;
+        hipStream_t comm_stream[MAX_COMMS] = {nullptr};
         hipEvent_t ev_kernels[MAX_BUFS] = {nullptr}, ev_gathered[MAX_BUFS] = {nullptr};
         // The collective is enqueued by a library-owned host thread: RCCL's enqueue path costs tens of
         // microseconds of CPU per call, which would otherwise sit in the frame's critical path on the caller's
@@ -127,7 +132,7 @@ struct mi_ctx {
         uint64_t submitted = 0, issued = 0;  // guarded by m
         uint64_t worker_frames = 0;          // exchange thread only
         int worker_error = 0;
-        volatile uint32_t* done_flag = nullptr;  // pinned host word: number of frames whose all-gather has completed
+        volatile uint32_t* done_flag = nullptr;  // pinned host words [MAX_COMMS]: all-gathers completed on each communicator
         // device word: number of frames whose masks are complete.  Written by the compaction kernel itself (see
         // CompactFastArgs::signal) or, when that kernel is not the one running, by a write-value packet behind the
         // frame's kernels; the communication stream waits on it with hipStreamWaitValue32.
@@ -554,12 +559,14 @@ void exchange_worker(mi_ctx* ctx) {
         }
         int err = 0;
         const auto tw0 = std::chrono::steady_clock::now();
-        if (hipStreamWaitValue32(x.comm_stream, x.kernels_flag, (uint32_t)(x.worker_frames + 1), hipStreamWaitValueGte, 0xFFFFFFFFu) != hipSuccess) err = -1;
+        const uint32_t k = (uint32_t)(x.worker_frames % x.n_comms);  // frame f travels on communicator f % n_comms
+        hipStream_t cs = x.comm_stream[k];
+        if (hipStreamWaitValue32(cs, x.kernels_flag, (uint32_t)(x.worker_frames + 1), hipStreamWaitValueGte, 0xFFFFFFFFu) != hipSuccess) err = -1;
         char* base = (char*)x.buf[slot];
-        if (!err) err = x.all_gather(base + (size_t)x.rank * x.block_bytes, base, (size_t)x.block_bytes, 1 /* ncclUint8 */, x.comm, x.comm_stream);
-        if (hipEventRecord(x.ev_gathered[slot], x.comm_stream) != hipSuccess && !err) err = -2;
+        if (!err) err = x.all_gather(base + (size_t)x.rank * x.block_bytes, base, (size_t)x.block_bytes, 1 /* ncclUint8 */, x.comm[k], cs);
+        if (hipEventRecord(x.ev_gathered[slot], cs) != hipSuccess && !err) err = -2;
         // completion counter the caller's thread can read without a driver call
-        if (hipStreamWriteValue32(x.comm_stream, (void*)x.done_flag, (uint32_t)(x.worker_frames + 1), 0) != hipSuccess && !err) err = -3;
+        if (hipStreamWriteValue32(cs, (void*)(x.done_flag + k), (uint32_t)(x.worker_frames / x.n_comms + 1), 0) != hipSuccess && !err) err = -3;
         ++x.worker_frames;
         x.dbg_worker_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tw0).count();
         {
@@ -607,7 +614,13 @@ int32_t exchange_begin(mi_ctx* ctx) {
         const uint64_t need = x.frame - x.n_bufs + 1;
         uint32_t spins = 0;
 
-        while ((uint64_t)*x.done_flag < need) {
+        // frames 0 .. need-1 complete <=> every communicator k has finished its ceil((need - k) / n_comms) of them
+        auto drained = [&]() {
+            for (uint32_t k = 0; k < x.n_comms; ++k)
+                if ((uint64_t)x.done_flag[k] < (need + x.n_comms - 1 - k) / x.n_comms) return false;
+            return true;
+        };
+        while (!drained()) {
             if ((++spins & 1023u) == 0) {
                 {
                     std::lock_guard<std::mutex> lk(x.m);
@@ -727,13 +740,15 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
         fprintf(stderr, "[mi exchange] frames %llu: begin %.2f us (wait-issued %.2f us), end %.2f us, worker %.2f us per frame\n",
                 (unsigned long long)ctx->xch.frame, ctx->xch.dbg_begin_ns / ctx->xch.frame / 1e3, ctx->xch.dbg_wait_ns / ctx->xch.frame / 1e3,
                 ctx->xch.dbg_end_ns / ctx->xch.frame / 1e3, ctx->xch.dbg_worker_ns / ctx->xch.frame / 1e3);
-    if (ctx->xch.comm_stream) {
-        hipStreamSynchronize(ctx->xch.comm_stream);
+    if (ctx->xch.comm_stream[0]) {
+        for (hipStream_t cs : ctx->xch.comm_stream)
+            if (cs) hipStreamSynchronize(cs);
         for (uint32_t i = 0; i < mi_ctx::Exchange::MAX_BUFS; ++i) {
             if (ctx->xch.ev_kernels[i]) hipEventDestroy(ctx->xch.ev_kernels[i]);
             if (ctx->xch.ev_gathered[i]) hipEventDestroy(ctx->xch.ev_gathered[i]);
         }
-        hipStreamDestroy(ctx->xch.comm_stream);
+        for (hipStream_t cs : ctx->xch.comm_stream)
+            if (cs) hipStreamDestroy(cs);
         if (ctx->xch.done_flag) hipHostFree((void*)ctx->xch.done_flag);
     }
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
@@ -756,7 +771,8 @@ int32_t mi_synchronize(mi_ctx* ctx) {
         int32_t rc = exchange_wait_issued(ctx, ctx->xch.frame);
         if (rc) return rc;
     }
-    if (ctx->xch.comm_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->xch.comm_stream));
+    for (hipStream_t cs : ctx->xch.comm_stream)
+        if (cs) HIP_TRY(ctx, hipStreamSynchronize(cs));
     return MI_OK;
 }
 
@@ -1223,7 +1239,7 @@ int32_t mi_propagate(mi_ctx* ctx, uint32_t flags) {
         }
         ctx->g_chg_in_bytes = true;
     }
-    if (ctx->have_changed) {
+    if (ctx->have_changed && ctx->changed_maybe) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, ctx->n, ctx->stream));  // change flags are consumed
         ctx->changed_maybe = false;
     }
@@ -1299,7 +1315,7 @@ int32_t mi_propagate_and_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t 
                                                 n_views, vo, seg, flags & MI_CULL_END_FRAME, ctx->stream));
     }
     if ((rc = run_compaction(ctx, vo, seg))) return rc;
-    if (ctx->have_changed) {
+    if (ctx->have_changed && ctx->changed_maybe) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, ctx->n, ctx->stream));
         ctx->changed_maybe = false;
     }
@@ -1932,12 +1948,25 @@ int32_t mi_bind_visibility_output(mi_ctx* ctx, void* device_ptr, uint64_t words_
 
 int32_t mi_exchange_configure(mi_ctx* ctx, void* nccl_comm, void* fn_nccl_all_gather, void* const* device_bufs, uint32_t n_bufs,
                               uint64_t words_per_view, uint64_t word_offset, uint64_t block_bytes, uint32_t rank) {
+    void* comms[1] = {nccl_comm};
+    return mi_exchange_configure_multi(ctx, nccl_comm ? comms : nullptr, nccl_comm ? 1u : 0u, fn_nccl_all_gather, device_bufs, n_bufs,
+                                       words_per_view, word_offset, block_bytes, rank);
+}
+
+int32_t mi_exchange_configure_multi(mi_ctx* ctx, void* const* nccl_comms, uint32_t n_comms, void* fn_nccl_all_gather,
+                                    void* const* device_bufs, uint32_t n_bufs, uint64_t words_per_view, uint64_t word_offset,
+                                    uint64_t block_bytes, uint32_t rank) {
     ENTER(ctx);
     auto& x = ctx->xch;
+    void* const nccl_comm = (nccl_comms && n_comms) ? nccl_comms[0] : nullptr;
+    if (n_comms > mi_ctx::Exchange::MAX_COMMS) return fail(ctx, MI_ERR_INVALID_ARG, "mi_exchange_configure: at most %u communicators", mi_ctx::Exchange::MAX_COMMS);
+    for (uint32_t k = 0; k < n_comms; ++k)
+        if (!nccl_comms[k]) return fail(ctx, MI_ERR_INVALID_ARG, "mi_exchange_configure: communicator %u is NULL", k);
     if (x.on) {  // drain whatever is in flight before changing anything
         int32_t rc0 = exchange_wait_issued(ctx, x.frame);
         exchange_stop(ctx);
-        if (x.comm_stream) HIP_TRY(ctx, hipStreamSynchronize(x.comm_stream));
+        for (hipStream_t cs : x.comm_stream)
+            if (cs) HIP_TRY(ctx, hipStreamSynchronize(cs));
         x.on = false;
         if (rc0) return rc0;
     }
@@ -1957,7 +1986,7 @@ int32_t mi_exchange_configure(mi_ctx* ctx, void* nccl_comm, void* fn_nccl_all_ga
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     x.kernel_signal = getenv("MI_XCH_NO_KERNEL_SIGNAL") == nullptr;
     x.signalled = false;
-    if (!x.comm_stream) {
+    if (!x.comm_stream[0]) {
         for (uint32_t i = 0; i < mi_ctx::Exchange::MAX_BUFS; ++i) {
             HIP_TRY(ctx, hipEventCreateWithFlags(&x.ev_kernels[i], hipEventDisableTiming));
             HIP_TRY(ctx, hipEventCreateWithFlags(&x.ev_gathered[i], hipEventDisableTiming));
@@ -1978,8 +2007,7 @@ int32_t mi_exchange_configure(mi_ctx* ctx, void* nccl_comm, void* fn_nccl_all_ga
         const size_t probe_words = (size_t)16 << 20;  // 64 MB clear: a stand-in for one frame of kernels
         uint32_t* probe = nullptr;
         HIP_TRY(ctx, hipMalloc((void**)&probe, probe_words * 4));
-        double best_t = 1e30;
-        int best = 0;
+        double cand_t[N_CAND];
         for (int rep = 0; rep < 2; ++rep)
             for (int i = 0; i < N_CAND; ++i) {
                 HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1995,24 +2023,29 @@ int32_t mi_exchange_configure(mi_ctx* ctx, void* nccl_comm, void* fn_nccl_all_ga
                 HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
                 HIP_TRY(ctx, hipStreamSynchronize(cand[i]));
                 const double t = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-                if (rep == 1 && t < best_t) { best_t = t; best = i; }
+                if (rep == 1) cand_t[i] = t;
                 if (getenv("MI_XCH_DEBUG")) fprintf(stderr, "[mi exchange] comm stream candidate %d%s: %.1f us / frame\n", i,
                                                     i == N_CAND - 1 ? " (high priority)" : "", t / 24.0);
             }
         HIP_TRY(ctx, hipFree(probe));
-        for (int i = 0; i < N_CAND; ++i)
-            if (i != best) HIP_TRY(ctx, hipStreamDestroy(cand[i]));
-        x.comm_stream = cand[best];
+        int order[N_CAND];
+        std::iota(order, order + N_CAND, 0);
+        std::sort(order, order + N_CAND, [&](int a, int b) { return cand_t[a] < cand_t[b]; });
+        for (int i = 0; i < N_CAND; ++i) {  // keep the MAX_COMMS fastest, fastest first
+            if (i < (int)mi_ctx::Exchange::MAX_COMMS) x.comm_stream[i] = cand[order[i]];
+            else HIP_TRY(ctx, hipStreamDestroy(cand[order[i]]));
+        }
     }
     x.all_gather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))fn_nccl_all_gather;
-    x.comm = nccl_comm;
+    x.n_comms = n_comms;
+    for (uint32_t k = 0; k < n_comms; ++k) x.comm[k] = nccl_comms[k];
     x.n_bufs = n_bufs;
     for (uint32_t i = 0; i < n_bufs; ++i) x.buf[i] = device_bufs[i];
     x.words_per_view = words_per_view;
     x.word_offset = word_offset;
     x.block_bytes = block_bytes;
     x.rank = rank;
-    *x.done_flag = 0;
+    for (uint32_t k = 0; k < mi_ctx::Exchange::MAX_COMMS; ++k) x.done_flag[k] = 0;
     x.worker_frames = 0;
     x.frame = 0;
     x.submitted = x.issued = 0;

@@ -72,7 +72,7 @@ class MaskGatherer:
     On CPU tensors (gloo tests) it always uses torch.distributed.
     """
 
-    def __init__(self, n_rows, world, n_views, rank, device=None, direct=True, group=None, n_bufs=4):
+    def __init__(self, n_rows, world, n_views, rank, device=None, direct=True, group=None, n_bufs=4, n_comms=None):
         import torch
         self.torch = torch
         self.world, self.rank, self.n_views, self.n_rows, self.group = world, rank, n_views, n_rows, group
@@ -86,6 +86,10 @@ class MaskGatherer:
         self.ev_kernels = [torch.cuda.Event() for _ in range(n_bufs)] if self.on_gpu else None
         self.ev_gathered = [torch.cuda.Event() for _ in range(n_bufs)] if self.on_gpu else None
         self.rccl = None
+        self.comms = []
+        # two communicators, used alternately by frame: consecutive all-gathers are in flight together (MI_XCH_COMMS=1..4)
+        self.n_comms = int(os.environ.get("MI_XCH_COMMS", "2")) if n_comms is None else n_comms
+        self.n_comms = max(1, min(4, self.n_comms))
         self.native = False
         self.mode = "torch.distributed"
         self.fallback_reason = None
@@ -115,7 +119,7 @@ class MaskGatherer:
             return False
         import ctypes as C
         fn = C.cast(self.rccl.ncclAllGather, C.c_void_p).value
-        ctx.exchange_configure(self.comm.value, fn, [b.data_ptr() for b in self.bufs], self.w, self.rank * self.block,
+        ctx.exchange_configure([c.value for c in self.comms], fn, [b.data_ptr() for b in self.bufs], self.w, self.rank * self.block,
                                self.block * 8, self.rank)
         self.mode = "rccl-native"
         self.native = True
@@ -144,41 +148,47 @@ class MaskGatherer:
         lib.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
         lib.ncclCommDestroy.argtypes = [C.c_void_p]
         lib.ncclGetErrorString.restype = C.c_char_p
-        uid = UniqueId()
-        t = torch.zeros(129, dtype=torch.uint8, device=self.bufs[0].device)  # 128 id bytes + "rank 0 has an id"
-        if self.rank == 0 and lib.ncclGetUniqueId(C.byref(uid)) == 0:
-            t[:128].copy_(torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8))
-            t[128] = 1
-        if _dist_on():
-            dist.broadcast(t, 0, group=self.group)  # always reached by every rank
-        host = t.cpu().numpy()
-        if host[128] != 1:
-            raise RuntimeError("ncclGetUniqueId failed on rank 0")
-        C.memmove(C.byref(uid), host[:128].tobytes(), 128)
-        comm = C.c_void_p()
-        rc = lib.ncclCommInitRank(C.byref(comm), self.world, uid, self.rank)
-        if rc:
-            raise RuntimeError(f"ncclCommInitRank: {lib.ncclGetErrorString(rc)}")
+        comms = []
+        for _ in range(self.n_comms):  # every rank creates them in the same order
+            uid = UniqueId()
+            t = torch.zeros(129, dtype=torch.uint8, device=self.bufs[0].device)  # 128 id bytes + "rank 0 has an id"
+            if self.rank == 0 and lib.ncclGetUniqueId(C.byref(uid)) == 0:
+                t[:128].copy_(torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8))
+                t[128] = 1
+            if _dist_on():
+                dist.broadcast(t, 0, group=self.group)  # always reached by every rank
+            host = t.cpu().numpy()
+            if host[128] != 1:
+                raise RuntimeError("ncclGetUniqueId failed on rank 0")
+            C.memmove(C.byref(uid), host[:128].tobytes(), 128)
+            comm = C.c_void_p()
+            rc = lib.ncclCommInitRank(C.byref(comm), self.world, uid, self.rank)
+            if rc:
+                raise RuntimeError(f"ncclCommInitRank: {lib.ncclGetErrorString(rc)}")
+            comms.append(comm)
+        self.comms = comms
+        comm = comms[0]
         self.rccl, self.comm = lib, comm
 
-    def _rccl_all_gather(self, buf, stream_handle):
+    def _rccl_all_gather(self, buf, stream_handle, comm=None):
         nbytes = self.block * 8
         base = buf.data_ptr()
-        rc = self.rccl.ncclAllGather(base + self.rank * nbytes, base, nbytes, 1, self.comm, stream_handle)  # 1 = ncclUint8
+        rc = self.rccl.ncclAllGather(base + self.rank * nbytes, base, nbytes, 1, comm or self.comm, stream_handle)  # 1 = ncclUint8
         if rc:
             raise RuntimeError(f"ncclAllGather: {self.rccl.ncclGetErrorString(rc)}")
 
     def _self_check(self):
         torch = self.torch
         buf = self.bufs[0]
-        buf.zero_()
-        buf[self.rank * self.block:(self.rank + 1) * self.block] = self.rank + 1
-        torch.cuda.current_stream().synchronize()
-        self._rccl_all_gather(buf, self.comm_stream.cuda_stream)
-        self.comm_stream.synchronize()
-        expect = torch.arange(1, self.world + 1, dtype=torch.int64, device=buf.device).repeat_interleave(self.block)
-        if not torch.equal(buf, expect):
-            raise RuntimeError("direct RCCL all-gather self-check mismatch")
+        for k, comm in enumerate(self.comms):  # every communicator, in order
+            buf.zero_()
+            buf[self.rank * self.block:(self.rank + 1) * self.block] = self.rank + 1 + 100 * k
+            torch.cuda.current_stream().synchronize()
+            self._rccl_all_gather(buf, self.comm_stream.cuda_stream, comm)
+            self.comm_stream.synchronize()
+            expect = (torch.arange(1, self.world + 1, dtype=torch.int64, device=buf.device) + 100 * k).repeat_interleave(self.block)
+            if not torch.equal(buf, expect):
+                raise RuntimeError(f"direct RCCL all-gather self-check mismatch (communicator {k})")
         buf.zero_()
         torch.cuda.current_stream().synchronize()
 
@@ -216,7 +226,9 @@ class MaskGatherer:
     def close(self):
         if self.rccl is not None:
             self.synchronize()
-            self.rccl.ncclCommDestroy(self.comm)
+            for c in self.comms:
+                self.rccl.ncclCommDestroy(c)
+            self.comms = []
             self.rccl = None
 
 

@@ -470,6 +470,13 @@ int32_t mi_bind_visibility_output(mi_ctx* ctx, void* device_ptr, uint64_t words_
 int32_t mi_exchange_configure(mi_ctx* ctx, void* nccl_comm, void* fn_nccl_all_gather, void* const* device_bufs,
                               uint32_t n_bufs, uint64_t words_per_view, uint64_t word_offset, uint64_t block_bytes,
                               uint32_t rank);
+/* The same with up to 4 communicators over the same ranks, used round-robin by frame (frame f travels on communicator
+ * f % n_comms, each on its own library stream): one communicator runs its collectives strictly one after the other,
+ * and a ~125 KB all-gather over 8 GPUs is pure latency -- with two, the all-gathers of consecutive frames are in
+ * flight together.  Every rank must pass its communicators in the same order.  n_comms = 0 switches the exchange off. */
+int32_t mi_exchange_configure_multi(mi_ctx* ctx, void* const* nccl_comms, uint32_t n_comms, void* fn_nccl_all_gather,
+                                    void* const* device_bufs, uint32_t n_bufs, uint64_t words_per_view, uint64_t word_offset,
+                                    uint64_t block_bytes, uint32_t rank);
 /* The gathered buffer of the most recent frame (optionally after waiting for its collective). */
 int32_t mi_exchange_last(mi_ctx* ctx, void** out_device_buf, int32_t wait);
 

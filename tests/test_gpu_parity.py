@@ -557,7 +557,8 @@ def test_one_million_flat_entities(ctx_factory):
     assert np.array_equal(rows, np.nonzero(vis_exp[0])[0].astype(np.uint32))
 
 
-def test_mask_gatherer_single_rank_pipeline(ctx_factory):
+@pytest.mark.parametrize("n_comms", [1, 2, 3])
+def test_mask_gatherer_single_rank_pipeline(ctx_factory, n_comms):
     """The pipelined exchange bench.py uses for N > 1, on one rank: kernels write their masks in place into the
     gatherer's alternating buffers and the (1-rank) all-gather runs on the communication stream -- through RCCL
     directly when the library can be set up on this box, else through torch.distributed."""
@@ -567,8 +568,9 @@ def test_mask_gatherer_single_rank_pipeline(ctx_factory):
     sc = W.many_cubes(n, ragged_flags=True)
     ctx = ctx_factory()
     upload_scene(ctx, sc)
-    g = sharding.MaskGatherer(n, 1, n_views, 0, device=torch.device("cuda", 0))
+    g = sharding.MaskGatherer(n, 1, n_views, 0, device=torch.device("cuda", 0), n_comms=n_comms)
     assert g.mode in ("rccl-direct", "torch.distributed"), g.mode
+    assert g.mode != "rccl-direct" or len(g.comms) == n_comms
     vv = np.zeros(n, np.uint8)
     outs = []
     for frame in range(4):
@@ -604,6 +606,16 @@ def test_mask_gatherer_single_rank_pipeline(ctx_factory):
             for v in range(n_views):
                 assert_bits(sharding.unpack_view(words, n, 1, n_views, v), vis_exp[v], f"native exchange frame {frame} view {v}")
                 assert_bits(ctx2.download_visibility(v), vis_exp[v], f"native exchange download frame {frame} view {v}")
+        # a burst with nothing read in between: the caller's thread is paced by the per-communicator counters
+        for frame in range(5, 5 + 23):
+            frusta = frusta_for([W.many_cubes_camera(frame * 30), W.many_cubes_camera(frame * 30, yaw=1.3)])
+            ctx2.propagate_and_cull(frusta, flags=B.CULL_END_FRAME)
+            _, vv, vis_exp, _ = oracle_frame(sc, vv, frusta, None, None)
+        assert ctx2.exchange_last(wait=True) == g.buffer(frame).data_ptr()
+        ctx2.synchronize()
+        words = g.buffer(frame).cpu().numpy()
+        for v in range(n_views):
+            assert_bits(sharding.unpack_view(words, n, 1, n_views, v), vis_exp[v], f"native exchange after the burst, view {v}")
         ctx2.exchange_configure(None, None, None, 0, 0, 0, 0)
         ctx2.propagate_and_cull(frusta, flags=B.CULL_END_FRAME)
         assert_bits(ctx2.download_visibility(0), vis_exp[0], "after switching the exchange off")

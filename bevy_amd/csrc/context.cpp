@@ -5,183 +5,19 @@
 // the visibility bitmasks / VisibleEntities lists, the clustering scratch, and HIP-event timing.
 // Everything is enqueued on one HIP stream per context; the only host synchronisations are in the
 // download / timer-read entry points.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <atomic>
-#include <condition_variable>
-#include <deque>
-#include <mutex>
-#include <numeric>
-#include <chrono>
-#include <thread>
-#include <string>
-#include <vector>
-
-#include "../../include/bevy_mi355x.h"
-#include "kernels.h"
-
-namespace mi {
-hipError_t set_cluster_lds_limit();
-hipError_t launch_logf_probe(const float* in, float* out, uint32_t n, hipStream_t stream);
-}  // namespace mi
+#include "ctx.h"
 
 using namespace mi;
+using namespace mi_detail;
 
 thread_local const mi::LaunchTimer* mi::g_launch_timer = nullptr;
 
 namespace {
-
 std::mutex g_err_mutex;
 std::string g_create_error = "no error";
-
-struct DevBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-};
-
-struct ProfSpan {
-    uint32_t kernel;
-    hipEvent_t a, b;
-};
-
 }  // namespace
 
-struct mi_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    std::string err = "no error";
-
-    // ---- columns ----
-    uint32_t n = 0, cap = 0;
-    float *t = nullptr, *r = nullptr, *s = nullptr, *g = nullptr, *c = nullptr, *h = nullptr;
-    uint8_t *flags = nullptr, *vv = nullptr, *changed = nullptr, *g_changed_bytes = nullptr;
-    uint32_t *layers = nullptr, *class_mask = nullptr;
-    uint64_t *keys = nullptr, *g_chg_bits = nullptr, *vv_chg_bits = nullptr;
-    uint32_t* tree_bits = nullptr;
-    bool have_class_mask = false, have_keys = false, have_changed = false;
-    uint32_t classes_present = 1u;
-    std::vector<uint64_t> h_keys;
-    bool order_dirty = false, order_identity = true;
-    DevBuf order;
-    float* range = nullptr;        // VisibilityRange (start_margin.start, end_margin.end) per row
-    bool have_ranges = false;      // a VisibleEntityRanges resource exists (mi_upload_visibility_ranges was called)
-    uint8_t* visibility = nullptr; // Visibility component: 0 Inherited, 1 Hidden, 2 Visible, 0x80 none
-    uint8_t* inh_changed = nullptr;  // InheritedVisibility assigned by the last mi_visibility_propagate (bytes)
-    DevBuf inh_bits, sparse_cnt, sparse_rows, sparse_total, sparse_g;
-
-    // ---- staging ----
-    void* stage = nullptr;
-    size_t stage_bytes = 0, stage_used = 0;
-
-    // ---- hierarchy ----
-    uint32_t n_levels = 1;
-    std::vector<uint32_t> level_offsets;  // n_levels + 1
-    DevBuf parent_idx, node_flags, tiles;
-    std::vector<std::pair<uint32_t, uint32_t>> passes;  // (first tile, n tiles); pass 0 starts at level 0 (roots)
-    struct TileGroup { uint32_t first, count, n_chain, owner_rows; };
-    std::vector<TileGroup> groups;  // launches of mi_propagate: an owner pass + at most one pass of chain tiles
-    DevBuf chains, snap;            // snap: 2 x snap_rows x 48 B, pre-frame GlobalTransforms of the owner rows (see kernels_tree.hip)
-    uint32_t snap_rows = 0, snap_parity = 0;
-    bool snap_valid = false;
-    bool have_hierarchy = false;
-    bool g_chg_in_bytes = false;  // the GlobalTransform change mask currently lives in g_changed_bytes (tree path)
-    // host-side knowledge that lets a frame with no dirty Transform skip its launches: some byte of `changed` may be
-    // non-zero (set by the uploads that mark rows, cleared when mi_propagate consumes the column); the change masks of
-    // the last propagate may hold set bits
-    bool changed_maybe = true, g_chg_maybe = true;
-
-    // ---- views / visibility ----
-    DevBuf views;
-    uint32_t n_views = 0;
-    DevBuf bitmask;
-    uint64_t words_per_view = 0;
-    // multi-GPU exchange (mi_exchange_configure): in-place all-gather of the masks after every cull
-    struct Exchange {
-        bool on = false;
-        int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;  // ncclAllGather
-        // Up to MAX_COMMS communicators, used round-robin by frame, each on its own stream: the all-gathers of
-        // consecutive frames are then in flight together (a ~125 KB all-gather over 8 GPUs is pure latency, and one
-        // communicator runs its collectives strictly one after the other).  Every rank issues them in frame order.
-        static constexpr uint32_t MAX_COMMS = 4;
-        uint32_t n_comms = 0;
-        void* comm[MAX_COMMS] = {nullptr};
-        static constexpr uint32_t MAX_BUFS = 8;
-        uint32_t n_bufs = 0;
-        void* buf[MAX_BUFS] = {nullptr};
-        uint64_t words_per_view = 0, word_offset = 0, block_bytes = 0;
-        uint32_t rank = 0;
-        uint64_t frame = 0;
-        hipStream_t comm_stream[MAX_COMMS] = {nullptr};
-        hipEvent_t ev_kernels[MAX_BUFS] = {nullptr}, ev_gathered[MAX_BUFS] = {nullptr};
-        // The collective is enqueued by a library-owned host thread: RCCL's enqueue path costs tens of
-        // microseconds of CPU per call, which would otherwise sit in the frame's critical path on the caller's
-        // thread.  The caller's thread never runs more than two frames ahead of it.
-        std::thread worker;
-        std::mutex m;
-        std::condition_variable cv;
-        std::deque<uint32_t> queue;
-        std::atomic<uint64_t> submitted_fast{0};  // == submitted, readable without the lock (the thread polls it)
-        std::atomic<bool> sleeping{false}, stop_fast{false};
-        bool stop = false;
-        uint64_t submitted = 0, issued = 0;  // guarded by m
-        uint64_t worker_frames = 0;          // exchange thread only
-        int worker_error = 0;
-        volatile uint32_t* done_flag = nullptr;  // pinned host words [MAX_COMMS]: all-gathers completed on each communicator
-        // device word: number of frames whose masks are complete.  Written by the compaction kernel itself (see
-        // CompactFastArgs::signal) or, when that kernel is not the one running, by a write-value packet behind the
-        // frame's kernels; the communication stream waits on it with hipStreamWaitValue32.
-        uint32_t* kernels_flag = nullptr;
-        bool kernel_signal = true;      // MI_XCH_NO_KERNEL_SIGNAL forces the packet
-        bool signalled = false;         // this frame's compaction launch carries the signal
-        double dbg_wait_ns = 0, dbg_begin_ns = 0, dbg_end_ns = 0, dbg_worker_ns = 0;  // MI_XCH_DEBUG
-    } xch;
-    void* ext_bitmask = nullptr;
-    uint64_t ext_words_per_view = 0, ext_word_offset = 0;
-    bool culled = false;
-    ViewSet view_set{};      // views passed by value when n_views <= MAX_INLINE_VIEWS
-    bool views_inline = false;
-    // compaction
-    DevBuf block_counts, seg_totals, seg_bases, out_rows, out_keys, wave_cnt, seg_mask;
-    uint32_t compact_views = 0, compact_classes = 0;
-    uint32_t class_bits[32] = {0};
-    bool compact_fast = false;   // last compaction used the single-launch path (out_rows strided per segment)
-    uint64_t seg_stride = 0;
-
-    // ---- clustering ----
-    DevBuf cl_pos, cl_type, cl_layers, cl_dir, cl_sincos, cl_planes, cl_spheres;
-    // batching work-item build (kernels_batch.hip)
-    uint32_t *bt_set = nullptr, *bt_bin = nullptr, *bt_input = nullptr, *bt_row_meta = nullptr;  // per-row columns
-    bool bt_resolve = true;  // rows or tables changed: bt_row_meta must be recomputed
-    DevBuf bt_set_indexed, bt_table_off, bt_table, bt_meta_off, bt_meta, bt_rows_a, bt_rows_b, bt_hist, bt_set_count, bt_set_scan,
-        bt_counters, bt_wi[2], bt_md[2], bt_bs[2], bt_records, bt_totals;
-    uint32_t bt_n_sets = 0, bt_n_meta = 0;
-    bool bt_have_rows = false, bt_have_sets = false, bt_built = false;
-    DevBuf cl_remap, cl_bind_oc, cl_bind_idx, cl_block_counts, cl_pair_cb, cl_pair_mask, cl_acc, cl_offsets, cl_indices, cl_scalars;
-    uint32_t cl_parity = 0, cl_acc_clusters = 0, cl_acc_blocks = 0;  // cl_acc = 2 x [counts 6C | totals C | farthest_z + pad]
-    uint32_t cl_n = 0;
-    bool cl_have_type = false, cl_have_layers = false, cl_have_spot = false, cl_any_spot = false;
-    ClusterViewDev cl_view{};
-    bool cl_have_view = false, cl_assigned = false;
-
-    // ---- timing ----
-    hipEvent_t timer_a = nullptr, timer_b = nullptr;
-    bool profiling = false;
-    uint64_t prof_mask = ~0ull;
-    uint32_t prof_every = 1, prof_tick[K_NUM_KERNELS] = {0};  // time every n-th launch of a kernel
-    uint32_t prof_burst = 0, prof_timed[K_NUM_KERNELS] = {0};  // ... and at most the first prof_burst of them (0 = no limit)
-    std::vector<ProfSpan> spans;
-    bool span_open = false;
-    uint64_t prof_launches[K_NUM_KERNELS] = {0};
-    double prof_ms[K_NUM_KERNELS] = {0};
-};
-
-namespace {
+namespace mi_detail {
 
 int32_t fail(mi_ctx* ctx, int32_t code, const char* fmt, ...) {
     char buf[512];
@@ -197,24 +33,6 @@ int32_t fail(mi_ctx* ctx, int32_t code, const char* fmt, ...) {
     return code;
 }
 
-#define HIP_TRY(ctx, expr)                                                                                   \
-    do {                                                                                                     \
-        hipError_t e_ = (expr);                                                                              \
-        if (e_ != hipSuccess)                                                                                \
-            return fail(ctx, e_ == hipErrorOutOfMemory ? MI_ERR_OUT_OF_MEMORY : MI_ERR_DEVICE, "%s: %s (%s:%d)", #expr, \
-                        hipGetErrorString(e_), __FILE__, __LINE__);                                          \
-    } while (0)
-
-#define ENTER(ctx)                                                       \
-    do {                                                                 \
-        if (!(ctx)) return fail(nullptr, MI_ERR_INVALID_ARG, "ctx is NULL"); \
-        HIP_TRY(ctx, hipSetDevice((ctx)->device));                       \
-    } while (0)
-
-inline uint64_t words64(uint32_t n) { return ((uint64_t)n + 63u) / 64u; }
-// bitmask words written by a launch of ceil(n/256) workgroups x 4 waves
-inline uint64_t padded_words(uint32_t n) { return (((uint64_t)n + 255u) / 256u) * 4u; }
-
 int32_t ensure(mi_ctx* ctx, DevBuf& b, size_t bytes) {
     if (b.bytes >= bytes && b.p) return MI_OK;
     if (b.p) {
@@ -229,24 +47,6 @@ int32_t ensure(mi_ctx* ctx, DevBuf& b, size_t bytes) {
     return MI_OK;
 }
 
-template <typename T>
-int32_t grow_column(mi_ctx* ctx, T*& col, size_t elems_per_row, uint32_t old_rows, uint32_t new_cap, int fill_byte) {
-    T* np = nullptr;
-    const size_t bytes = (size_t)new_cap * elems_per_row * sizeof(T) + 256;
-    HIP_TRY(ctx, hipMalloc((void**)&np, bytes));
-    HIP_TRY(ctx, hipMemsetAsync(np, fill_byte, bytes, ctx->stream));
-    if (col && old_rows)
-        HIP_TRY(ctx, hipMemcpyAsync(np, col, (size_t)old_rows * elems_per_row * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
-    if (col) {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipFree(col));
-    }
-    col = np;
-    return MI_OK;
-}
-
-// Pinned staging arena: host slices are copied here (the ECS owns them only for the call) and the
-// H2D copy runs asynchronously on the context's stream.
 int32_t stage_alloc(mi_ctx* ctx, size_t bytes, void** out) {
     bytes = (bytes + 255) & ~(size_t)255;
     if (ctx->stage_used + bytes > ctx->stage_bytes) {
@@ -317,36 +117,6 @@ void prof_mark(void* vctx, uint32_t kernel) {
     g_cb_timer.stop = sp.b;
     g_launch_timer = &g_cb_timer;
 }
-// Times exactly one launch (the next MI_LAUNCH on this thread) with its dispatch timestamps.
-struct ProfScope {
-    mi_ctx* ctx;
-    LaunchTimer lt{};
-    bool armed = false;
-    ProfScope(mi_ctx* c, uint32_t k) : ctx(c) {
-        if (!c->profiling || k >= K_NUM_KERNELS || !((c->prof_mask >> k) & 1ull)) return;
-        if (c->prof_every > 1 && (c->prof_tick[k]++ % c->prof_every) != 0) return;
-        if (c->prof_burst && c->prof_timed[k] >= c->prof_burst) return;
-        ++c->prof_timed[k];
-        prof_close(c);
-        ProfSpan sp;
-        sp.kernel = k;
-        hipEventCreate(&sp.a);
-        hipEventCreate(&sp.b);
-        c->spans.push_back(sp);
-        lt.start = sp.a;
-        lt.stop = sp.b;
-        g_launch_timer = &lt;
-        armed = true;
-    }
-    ~ProfScope() {
-        if (armed && g_launch_timer == &lt) {  // nothing was launched inside the scope
-            g_launch_timer = nullptr;
-            hipEventDestroy(ctx->spans.back().a);
-            hipEventDestroy(ctx->spans.back().b);
-            ctx->spans.pop_back();
-        }
-    }
-};
 void prof_collect(mi_ctx* ctx) {
     prof_close(ctx);
     hipStreamSynchronize(ctx->stream);
@@ -528,137 +298,7 @@ int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg) 
     return MI_OK;
 }
 
-// Multi-GPU exchange around a cull: bind this frame's gathered buffer (after its previous all-gather drained),
-// and afterwards hand the in-place all-gather to the exchange thread, which enqueues it on the communication
-// stream behind the kernels.
-void exchange_worker(mi_ctx* ctx) {
-    auto& x = ctx->xch;
-    hipSetDevice(ctx->device);
-    for (;;) {
-        uint32_t slot;
-        // While frames are flowing the thread must not go to sleep between them: waking a thread through a futex
-        // takes tens of microseconds, more than a frame.  Poll the submission counter for a while first.
-        if (x.submitted_fast.load(std::memory_order_acquire) == x.worker_frames) {
-            const auto spin0 = std::chrono::steady_clock::now();
-            uint32_t spins = 0;
-            while (x.submitted_fast.load(std::memory_order_acquire) == x.worker_frames && !x.stop_fast.load(std::memory_order_relaxed)) {
-                __builtin_ia32_pause();
-                if ((++spins & 255u) == 0 && std::chrono::steady_clock::now() - spin0 > std::chrono::microseconds(500)) break;
-            }
-        }
-        {
-            std::unique_lock<std::mutex> lk(x.m);
-            if (x.queue.empty() && !x.stop) {
-                x.sleeping.store(true, std::memory_order_seq_cst);
-                x.cv.wait(lk, [&] { return x.stop || !x.queue.empty(); });
-                x.sleeping.store(false, std::memory_order_relaxed);
-            }
-            if (x.queue.empty()) return;  // stop requested and drained
-            slot = x.queue.front();
-            x.queue.pop_front();
-        }
-        int err = 0;
-        const auto tw0 = std::chrono::steady_clock::now();
-        const uint32_t k = (uint32_t)(x.worker_frames % x.n_comms);  // frame f travels on communicator f % n_comms
-        hipStream_t cs = x.comm_stream[k];
-        if (hipStreamWaitValue32(cs, x.kernels_flag, (uint32_t)(x.worker_frames + 1), hipStreamWaitValueGte, 0xFFFFFFFFu) != hipSuccess) err = -1;
-        char* base = (char*)x.buf[slot];
-        if (!err) err = x.all_gather(base + (size_t)x.rank * x.block_bytes, base, (size_t)x.block_bytes, 1 /* ncclUint8 */, x.comm[k], cs);
-        if (hipEventRecord(x.ev_gathered[slot], cs) != hipSuccess && !err) err = -2;
-        // completion counter the caller's thread can read without a driver call
-        if (hipStreamWriteValue32(cs, (void*)(x.done_flag + k), (uint32_t)(x.worker_frames / x.n_comms + 1), 0) != hipSuccess && !err) err = -3;
-        ++x.worker_frames;
-        x.dbg_worker_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tw0).count();
-        {
-            std::lock_guard<std::mutex> lk(x.m);
-            if (err && !x.worker_error) x.worker_error = err;
-            ++x.issued;
-        }
-        x.cv.notify_all();
-    }
-}
-// blocks until the exchange thread has enqueued the collectives of frames < upto
-int32_t exchange_wait_issued(mi_ctx* ctx, uint64_t upto) {
-    auto& x = ctx->xch;
-    std::unique_lock<std::mutex> lk(x.m);
-    x.cv.wait(lk, [&] { return x.issued >= upto || x.worker_error; });
-    if (x.worker_error) return fail(ctx, MI_ERR_DEVICE, "exchange thread: ncclAllGather / HIP call failed (%d)", x.worker_error);
-    return MI_OK;
-}
-void exchange_stop(mi_ctx* ctx) {
-    auto& x = ctx->xch;
-    if (x.worker.joinable()) {
-        {
-            std::lock_guard<std::mutex> lk(x.m);
-            x.stop = true;
-        }
-        x.stop_fast.store(true);
-        x.cv.notify_all();
-        x.worker.join();
-    }
-    x.stop = false;
-    x.stop_fast.store(false);
-}
-int32_t exchange_begin(mi_ctx* ctx) {
-    auto& x = ctx->xch;
-    if (!x.on) return MI_OK;
-    const uint32_t slot = (uint32_t)(x.frame % x.n_bufs);
-    const auto tb0 = std::chrono::steady_clock::now();
-    struct Acc { double& d; std::chrono::steady_clock::time_point t; ~Acc() { d += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t).count(); } } acc{x.dbg_begin_ns, tb0};
-    if (x.frame >= x.n_bufs) {
-        // This buffer was last used n_bufs frames ago and its all-gather must have completed before the kernels
-        // overwrite it.  The dependency is enforced on the HOST (the communication stream bumps a pinned counter
-        // behind every all-gather), not with a cross-stream wait: a barrier packet on the compute queue costs
-        // ~6 us of GPU time per frame, while pacing the caller n_bufs - 1 frames ahead of the exchange costs
-        // nothing as long as the next frame is already queued.
-        const uint64_t need = x.frame - x.n_bufs + 1;
-        uint32_t spins = 0;
-
-        // frames 0 .. need-1 complete <=> every communicator k has finished its ceil((need - k) / n_comms) of them
-        auto drained = [&]() {
-            for (uint32_t k = 0; k < x.n_comms; ++k)
-                if ((uint64_t)x.done_flag[k] < (need + x.n_comms - 1 - k) / x.n_comms) return false;
-            return true;
-        };
-        while (!drained()) {
-            if ((++spins & 1023u) == 0) {
-                {
-                    std::lock_guard<std::mutex> lk(x.m);
-                    if (x.worker_error) return fail(ctx, MI_ERR_DEVICE, "exchange thread: ncclAllGather / HIP call failed (%d)", x.worker_error);
-                }
-                if (std::chrono::steady_clock::now() - tb0 > std::chrono::seconds(30))
-                    return fail(ctx, MI_ERR_DEVICE, "exchange: the all-gather of frame %llu did not complete within 30 s",
-                                (unsigned long long)(need - 1));
-                std::this_thread::yield();
-            }
-        }
-        x.dbg_wait_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tb0).count();
-    }
-    ctx->ext_bitmask = x.buf[slot];
-    ctx->ext_words_per_view = x.words_per_view;
-    ctx->ext_word_offset = x.word_offset;
-    return MI_OK;
-}
-int32_t exchange_end(mi_ctx* ctx) {
-    auto& x = ctx->xch;
-    if (!x.on) return MI_OK;
-    const uint32_t slot = (uint32_t)(x.frame % x.n_bufs);
-    const auto te0 = std::chrono::steady_clock::now();
-    if (!x.signalled) HIP_TRY(ctx, hipStreamWriteValue32(ctx->stream, x.kernels_flag, (uint32_t)(x.frame + 1), 0));
-    x.signalled = false;
-    {
-        std::lock_guard<std::mutex> lk(x.m);
-        x.queue.push_back(slot);
-        ++x.submitted;
-    }
-    x.submitted_fast.fetch_add(1, std::memory_order_seq_cst);
-    if (x.sleeping.load(std::memory_order_seq_cst)) x.cv.notify_all();  // no futex call while the thread is polling
-    ++x.frame;
-    x.dbg_end_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - te0).count();
-    return MI_OK;
-}
-
-}  // namespace
+}  // namespace mi_detail
 
 // =============================================================================================
 // lifecycle
@@ -999,185 +639,6 @@ int32_t mi_upload_visibility(mi_ctx* ctx, uint32_t first_row, uint32_t n, const 
 // ---------------------------------------------------------------------------------------------
 // hierarchy: validation + subtree-tile planning (host), see kernels_tree.hip for the consumer.
 // ---------------------------------------------------------------------------------------------
-int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx, const uint32_t* level_offsets,
-                            uint32_t n_levels) {
-    ENTER(ctx);
-    if (n != ctx->n) return fail(ctx, MI_ERR_INVALID_ARG, "mi_upload_hierarchy: n (%u) != live rows (%u)", n, ctx->n);
-    ctx->changed_maybe = true;  // conservative: the next propagate looks at the rows again
-    if (!parent_idx || n_levels <= 1) {
-        ctx->have_hierarchy = false;
-        ctx->n_levels = 1;
-        ctx->level_offsets = {0, n};
-        ctx->passes.clear();
-        ctx->groups.clear();
-        return MI_OK;
-    }
-    if (!level_offsets) return fail(ctx, MI_ERR_INVALID_ARG, "mi_upload_hierarchy: level_offsets NULL");
-    if (level_offsets[0] != 0 || level_offsets[n_levels] != n)
-        return fail(ctx, MI_ERR_MALFORMED_HIERARCHY, "level_offsets must start at 0 and end at n");
-    for (uint32_t l = 0; l < n_levels; ++l)
-        if (level_offsets[l + 1] < level_offsets[l]) return fail(ctx, MI_ERR_MALFORMED_HIERARCHY, "level_offsets not monotone");
-    // level 0: roots; level l>0: parent in level l-1, parents non-decreasing (BFS order)
-    for (uint32_t i = level_offsets[0]; i < level_offsets[1]; ++i)
-        if (parent_idx[i] != MI_NO_PARENT)
-            return fail(ctx, MI_ERR_MALFORMED_HIERARCHY, "row %u in level 0 has a parent", i);
-    for (uint32_t l = 1; l < n_levels; ++l) {
-        const uint32_t plo = level_offsets[l - 1], phi = level_offsets[l];
-        uint32_t prev = plo;
-        for (uint32_t i = level_offsets[l]; i < level_offsets[l + 1]; ++i) {
-            const uint32_t p = parent_idx[i];
-            if (p < plo || p >= phi)
-                return fail(ctx, MI_ERR_MALFORMED_HIERARCHY, "row %u (level %u): parent %u is not in level %u", i, l, p, l - 1);
-            if (p < prev)
-                return fail(ctx, MI_ERR_MALFORMED_HIERARCHY, "row %u: rows of a level must be ordered by parent (use mi_hierarchy_sort)", i);
-            prev = p;
-        }
-    }
-    // node flags + first-child table
-    std::vector<uint8_t> nflags(n, 0);
-    std::vector<uint32_t> first_child((size_t)n + 1, 0);
-    for (uint32_t l = 0; l + 1 < n_levels; ++l) {
-        uint32_t ch = level_offsets[l + 1];
-        const uint32_t chi = level_offsets[l + 2];
-        for (uint32_t p = level_offsets[l]; p < level_offsets[l + 1]; ++p) {
-            first_child[p] = ch;
-            while (ch < chi && parent_idx[ch] == p) { ++ch; nflags[p] |= 1; }
-        }
-    }
-    for (uint32_t p = level_offsets[n_levels - 1]; p <= n; ++p) first_child[p] = n;
-    // first_child[level end] of level l must read as "end of level l+1": patch boundaries
-    auto child_begin = [&](uint32_t l, uint32_t row) -> uint32_t {
-        // first row of level l+1 whose parent >= row (row in level l, or == end of level l)
-        if (row >= level_offsets[l + 1]) return level_offsets[l + 2];
-        return first_child[row];
-    };
-
-    // ---- tile plan ----
-    // A pass = one launch covering `d` consecutive levels; its tiles partition the rows of the level the pass is
-    // rooted in.  Pass 0 is rooted in level 0 itself (tile level 0 = a range of roots / flat rows); later passes
-    // are rooted in the last level of the previous pass (tile level 0 = the children of a range of its rows).
-    // A tile "fits" when all its levels but the last together hold <= TILE_UCAP rows (they live in LDS).
-    const char* env_levels = getenv("MI_TILE_LEVELS");
-    const uint32_t max_d = env_levels ? std::max(1, std::min((int)TILE_MAX_LEVELS, atoi(env_levels))) : TILE_MAX_LEVELS;
-    std::vector<TileDesc> tiles;
-    std::vector<uint32_t> chains;
-    ctx->passes.clear();
-    ctx->groups.clear();
-    auto level_size = [&](uint32_t lv) -> uint64_t { return lv < n_levels ? level_offsets[lv + 1] - level_offsets[lv] : 0; };
-    uint32_t l = 0;  // first level this pass computes
-    while (l < n_levels) {
-        const bool roots = l == 0;
-        // band depth: as deep as possible while an average root range of one row still fits in LDS
-        const uint64_t n_roots = std::max<uint64_t>(1, roots ? level_size(0) : level_size(l - 1));
-        uint32_t d = 1;
-        uint64_t upper = level_size(l);  // rows of the levels that would be non-last if we add one more level
-        while (d < max_d && l + d < n_levels && upper <= (uint64_t)TILE_UCAP * n_roots) {
-            ++d;
-            upper += level_size(l + d - 1);
-        }
-        // [lo,hi) is a row range of the rooting level; returns the tile and whether it fits
-        auto build = [&](uint32_t lo, uint32_t hi, TileDesc& td) -> bool {
-            uint32_t clo = lo, chi2 = hi;
-            td = TileDesc{};
-            for (uint32_t k = 0; k < d; ++k) {
-                uint32_t nlo, nhi;
-                if (roots && k == 0) { nlo = lo; nhi = hi; }
-                else {
-                    const uint32_t plevel = roots ? k - 1 : l - 1 + k;
-                    nlo = child_begin(plevel, clo);
-                    nhi = child_begin(plevel, chi2);
-                }
-                td.start[k] = nlo;
-                td.count[k] = nhi - nlo;
-                clo = nlo; chi2 = nhi;
-                if (nhi > nlo) td.n_levels = k + 1;
-            }
-            uint64_t up = 0;
-            for (uint32_t k = 0; k + 1 < td.n_levels; ++k) up += td.count[k];
-            return up <= TILE_UCAP;
-        };
-        // Chain candidate (see "Tile kinds" below): then every tile hangs below exactly one node, as long as that
-        // still gives tiles of a decent size.
-        uint64_t pass_rows = 0;
-        for (uint32_t k = 0; k < d; ++k) pass_rows += level_size(l + k);
-        const bool chain_candidate = !roots && l <= TILE_MAX_CHAIN && !ctx->groups.empty() && ctx->groups.back().n_chain == 0 &&
-                                     ctx->groups.back().count <= 64 && getenv("MI_TILE_NO_CHAIN") == nullptr &&
-                                     n_roots <= 16384 && pass_rows >= 128 * n_roots;
-        const uint32_t first_tile = (uint32_t)tiles.size();
-        const uint32_t rl = roots ? 0 : l - 1;
-        const uint32_t rlo = level_offsets[rl], rhi = level_offsets[rl + 1];
-        uint32_t a = rlo;
-        while (a < rhi) {
-            TileDesc best{};
-            uint32_t b = a + 1;
-            build(a, b, best);
-            uint32_t step = 1;  // galloping extension of the root range
-            while (b < rhi && !chain_candidate) {
-                const uint32_t nb = (uint32_t)std::min<uint64_t>((uint64_t)b + step, rhi);
-                TileDesc cand{};
-                // keep tiles small enough to spread over the chip: at most 4 x TILE_UCAP rows in the streamed last level
-                if (build(a, nb, cand) && (cand.n_levels == 0 || cand.count[cand.n_levels - 1] <= 4 * TILE_UCAP || nb == a + 1)) { best = cand; b = nb; step *= 2; }
-                else if (step > 1) step = 1;
-                else break;
-            }
-            if (best.n_levels) tiles.push_back(best);
-            a = b;
-        }
-        const uint32_t n_pass_tiles = (uint32_t)tiles.size() - first_tile;
-        ctx->passes.emplace_back(first_tile, n_pass_tiles);
-        // Tile kinds.  Pass 0: roots.  A later pass whose every tile hangs below ONE node of a short enough ancestor
-        // chain lets each tile re-evaluate that chain itself (kernels_tree.hip), which makes the pass independent of
-        // the one above it: it joins the previous launch.  Otherwise its tiles read their parents from global memory
-        // and the pass needs its own launch behind the previous one.
-        // (the owners wait for the chain tiles to start, so there must be few of them and only one chained pass per launch)
-        bool chainable = chain_candidate;
-        for (uint32_t ti = first_tile; chainable && ti < tiles.size(); ++ti) {
-            const TileDesc& td = tiles[ti];
-            if (td.n_levels == 0) continue;
-            const uint32_t p0 = parent_idx[td.start[0]];
-            if (parent_idx[td.start[0] + td.count[0] - 1] != p0) chainable = false;  // level 0 of the tile spans several parents
-        }
-        chains.resize(tiles.size() * (size_t)TILE_MAX_CHAIN, 0u);
-        for (uint32_t ti = first_tile; ti < tiles.size(); ++ti) {
-            TileDesc& td = tiles[ti];
-            td.kind = roots ? TILE_ROOTS : 0u;
-            if (chainable && td.n_levels) {
-                uint32_t row = parent_idx[td.start[0]], len = 0;
-                while (row != MI_NO_PARENT && len < TILE_MAX_CHAIN) {
-                    chains[(size_t)ti * TILE_MAX_CHAIN + len++] = row;
-                    row = parent_idx[row];
-                }
-                td.kind = len;
-            }
-        }
-        if (chainable) {
-            ctx->groups.back().count += n_pass_tiles;
-            ctx->groups.back().n_chain = n_pass_tiles;
-            ctx->groups.back().owner_rows = level_offsets[l];  // the owners' rows are the prefix [0, first row of level l)
-        } else {
-            ctx->groups.push_back({first_tile, n_pass_tiles, 0u, 0u});
-        }
-        l += d;
-    }
-    int32_t rc;
-    if ((rc = ensure(ctx, ctx->parent_idx, (size_t)n * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->node_flags, n))) return rc;
-    if ((rc = ensure(ctx, ctx->tiles, std::max<size_t>(tiles.size(), 1) * sizeof(TileDesc)))) return rc;
-    if ((rc = upload(ctx, ctx->parent_idx.p, parent_idx, (size_t)n * 4))) return rc;
-    if ((rc = upload(ctx, ctx->node_flags.p, nflags.data(), n))) return rc;
-    if ((rc = upload(ctx, ctx->tiles.p, tiles.data(), tiles.size() * sizeof(TileDesc)))) return rc;
-    ctx->snap_rows = 0;
-    for (auto& gr : ctx->groups) ctx->snap_rows = std::max(ctx->snap_rows, gr.owner_rows);
-    ctx->snap_valid = false;
-    if (ctx->snap_rows && (rc = ensure(ctx, ctx->snap, 2 * (size_t)ctx->snap_rows * 48))) return rc;
-    if ((rc = ensure(ctx, ctx->chains, std::max<size_t>(chains.size(), 1) * 4))) return rc;
-    if ((rc = upload(ctx, ctx->chains.p, chains.data(), chains.size() * 4))) return rc;
-    ctx->level_offsets.assign(level_offsets, level_offsets + n_levels + 1);
-    ctx->n_levels = n_levels;
-    ctx->have_hierarchy = true;
-    return MI_OK;
-}
-
 // =============================================================================================
 // systems
 // =============================================================================================
@@ -1527,546 +988,6 @@ int32_t mi_download_visible_entities(mi_ctx* ctx, uint32_t view, uint32_t class_
     if ((rc = download(ctx, &base, (const uint64_t*)ctx->seg_bases.p + seg, 8))) return rc;
     if (out_keys && (rc = download(ctx, out_keys, (const uint64_t*)ctx->out_keys.p + base, (size_t)total * 8))) return rc;
     if (out_rows && (rc = download(ctx, out_rows, (const uint32_t*)ctx->out_rows.p + base, (size_t)total * 4))) return rc;
-    return MI_OK;
-}
-
-// =============================================================================================
-// batching work-item build
-// =============================================================================================
-int32_t mi_batch_upload_rows(mi_ctx* ctx, uint32_t first_row, uint32_t n, const uint32_t* batch_set, const uint32_t* bin_index,
-                             const uint32_t* input_uniform_index) {
-    ENTER(ctx);
-    if (n && (!batch_set || !bin_index || !input_uniform_index)) return fail(ctx, MI_ERR_INVALID_ARG, "mi_batch_upload_rows: NULL column");
-    int32_t rc = check_rows(ctx, first_row, n, "mi_batch_upload_rows");
-    if (rc) return rc;
-    if (n == 0) return MI_OK;
-    if ((rc = upload(ctx, ctx->bt_set + first_row, batch_set, (size_t)n * 4))) return rc;
-    if ((rc = upload(ctx, ctx->bt_bin + first_row, bin_index, (size_t)n * 4))) return rc;
-    if ((rc = upload(ctx, ctx->bt_input + first_row, input_uniform_index, (size_t)n * 4))) return rc;
-    ctx->bt_have_rows = true;
-    ctx->bt_resolve = true;
-    return MI_OK;
-}
-
-int32_t mi_batch_upload_sets(mi_ctx* ctx, uint32_t n_sets, const uint8_t* set_indexed, const uint32_t* bin_table_offset,
-                             const uint32_t* bin_index_to_bin_metadata_index, const uint32_t* meta_offset,
-                             const mi_bin_metadata* bin_metadata) {
-    ENTER(ctx);
-    if (n_sets > 65536u) return fail(ctx, MI_ERR_INVALID_ARG, "mi_batch_upload_sets: %u batch sets, at most 65536", n_sets);
-    if (n_sets && (!set_indexed || !bin_table_offset || !bin_index_to_bin_metadata_index || !meta_offset || !bin_metadata))
-        return fail(ctx, MI_ERR_INVALID_ARG, "mi_batch_upload_sets: NULL table");
-    static const uint32_t zero_offsets[1] = {0};
-    if (n_sets == 0) bin_table_offset = meta_offset = zero_offsets;
-    for (uint32_t s = 0; s < n_sets; ++s) {
-        if (bin_table_offset[s + 1] < bin_table_offset[s] || meta_offset[s + 1] < meta_offset[s])
-            return fail(ctx, MI_ERR_INVALID_ARG, "mi_batch_upload_sets: offsets of set %u decrease", s);
-        const uint32_t bins = meta_offset[s + 1] - meta_offset[s];
-        for (uint32_t k = 0; k < bins; ++k)
-            if (bin_metadata[meta_offset[s] + k].indirect_parameters_offset >= bins)
-                return fail(ctx, MI_ERR_INVALID_ARG, "mi_batch_upload_sets: set %u bin %u: indirect_parameters_offset %u >= %u bins", s, k,
-                            bin_metadata[meta_offset[s] + k].indirect_parameters_offset, bins);
-    }
-    if (bin_table_offset[0] != 0 || meta_offset[0] != 0) return fail(ctx, MI_ERR_INVALID_ARG, "mi_batch_upload_sets: offsets must start at 0");
-    const uint32_t n_table = bin_table_offset[n_sets], n_meta = meta_offset[n_sets];
-    int32_t rc;
-    if ((rc = ensure(ctx, ctx->bt_set_indexed, std::max<size_t>(n_sets, 1)))) return rc;
-    if ((rc = ensure(ctx, ctx->bt_table_off, ((size_t)n_sets + 1) * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->bt_meta_off, ((size_t)n_sets + 1) * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->bt_table, std::max<size_t>(n_table, 1) * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->bt_meta, std::max<size_t>(n_meta, 1) * 12))) return rc;
-    if (n_sets && (rc = upload(ctx, ctx->bt_set_indexed.p, set_indexed, n_sets))) return rc;
-    if ((rc = upload(ctx, ctx->bt_table_off.p, bin_table_offset, ((size_t)n_sets + 1) * 4))) return rc;
-    if ((rc = upload(ctx, ctx->bt_meta_off.p, meta_offset, ((size_t)n_sets + 1) * 4))) return rc;
-    if (n_table && (rc = upload(ctx, ctx->bt_table.p, bin_index_to_bin_metadata_index, (size_t)n_table * 4))) return rc;
-    if (n_meta && (rc = upload(ctx, ctx->bt_meta.p, bin_metadata, (size_t)n_meta * 12))) return rc;
-    ctx->bt_n_sets = n_sets;
-    ctx->bt_n_meta = n_meta;
-    ctx->bt_have_sets = true;
-    ctx->bt_resolve = true;
-    ctx->bt_built = false;
-    return MI_OK;
-}
-
-int32_t mi_batch_build(mi_ctx* ctx, uint32_t view, uint32_t class_bit, const mi_batch_initial* initial) {
-    ENTER(ctx);
-    if (!ctx->culled) return fail(ctx, MI_ERR_NOT_READY, "mi_batch_build before mi_cull");
-    if (!ctx->bt_have_sets || !ctx->bt_have_rows) return fail(ctx, MI_ERR_NOT_READY, "mi_batch_build before mi_batch_upload_rows / mi_batch_upload_sets");
-    if (view >= ctx->compact_views) return fail(ctx, MI_ERR_INVALID_ARG, "mi_batch_build: view %u of %u", view, ctx->compact_views);
-    static_assert(sizeof(mi_batch_initial) == sizeof(BatchInitial), "mi_batch_initial layout");
-    BatchArgs a{};
-    if (initial) memcpy(&a.initial, initial, sizeof a.initial);
-    uint32_t slot = 0xFFFFFFFFu;
-    for (uint32_t k = 0; k < ctx->compact_classes; ++k)
-        if (ctx->class_bits[k] == class_bit) slot = k;
-    int32_t rc;
-    const uint32_t n_sets = ctx->bt_n_sets;
-    // capacities: every row of the list could be a work item of either class; every bin gets a metadata entry
-    const uint32_t n_tiles = std::max<uint32_t>(1u, (ctx->n + BATCH_TILE - 1u) / BATCH_TILE);
-    const size_t cap_rows = (size_t)n_tiles * BATCH_TILE;
-    if ((rc = ensure(ctx, ctx->bt_rows_a, cap_rows * 4))) return rc;
-    if (n_sets > 256u && (rc = ensure(ctx, ctx->bt_rows_b, cap_rows * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->bt_hist, (size_t)256 * n_tiles * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->bt_set_count, std::max<size_t>(n_sets, 1) * 2 * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->bt_set_scan, std::max<size_t>(n_sets, 1) * 5 * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->bt_counters, 64))) return rc;
-    if ((rc = ensure(ctx, ctx->bt_records, std::max<size_t>(n_sets, 1) * 32))) return rc;
-    if ((rc = ensure(ctx, ctx->bt_totals, 32))) return rc;
-    for (int c = 0; c < 2; ++c) {
-        const size_t wi = ((size_t)a.initial.work_item_index[c] + ctx->n + 1) * 8;
-        const size_t md = ((size_t)a.initial.indirect_parameters_index[c] + ctx->bt_n_meta + 1) * 20;
-        const size_t bs = ((size_t)a.initial.batch_set_index[c] + n_sets + 1) * 8;
-        if ((rc = ensure(ctx, ctx->bt_wi[c], wi))) return rc;
-        if ((rc = ensure(ctx, ctx->bt_md[c], md))) return rc;
-        if ((rc = ensure(ctx, ctx->bt_bs[c], bs))) return rc;
-        // entries below `initial` belong to the CPU-built part of the phase: they read as zeros here
-        if (a.initial.work_item_index[c]) HIP_TRY(ctx, hipMemsetAsync(ctx->bt_wi[c].p, 0, (size_t)a.initial.work_item_index[c] * 8, ctx->stream));
-        if (a.initial.indirect_parameters_index[c])
-            HIP_TRY(ctx, hipMemsetAsync(ctx->bt_md[c].p, 0, (size_t)a.initial.indirect_parameters_index[c] * 20, ctx->stream));
-        if (a.initial.batch_set_index[c]) HIP_TRY(ctx, hipMemsetAsync(ctx->bt_bs[c].p, 0, (size_t)a.initial.batch_set_index[c] * 8, ctx->stream));
-        a.work_items[c] = (uint32_t*)ctx->bt_wi[c].p;
-        a.metadata[c] = (uint32_t*)ctx->bt_md[c].p;
-        a.batch_sets[c] = (uint32_t*)ctx->bt_bs[c].p;
-    }
-    if (slot == 0xFFFFFFFFu || ctx->n == 0) {
-        // no row carries this class: VisibleEntities::get() is empty -> nothing is appended
-        mi_batch_totals t{};
-        for (int c = 0; c < 2; ++c) {
-            t.work_item_len[c] = a.initial.work_item_index[c];
-            t.indirect_parameters_len[c] = a.initial.indirect_parameters_index[c];
-            t.batch_set_len[c] = a.initial.batch_set_index[c];
-        }
-        t.data_buffer_len = a.initial.output_mesh_uniform_index;
-        if ((rc = upload(ctx, ctx->bt_totals.p, &t, sizeof t))) return rc;
-        if (ctx->bt_n_meta) {  // instance counts of an empty build are all zero
-            std::vector<mi_bin_metadata> m(ctx->bt_n_meta);
-            if ((rc = download(ctx, m.data(), ctx->bt_meta.p, m.size() * 12))) return rc;
-            for (auto& e : m) e.instance_count = 0;
-            if ((rc = upload(ctx, ctx->bt_meta.p, m.data(), m.size() * 12))) return rc;
-        }
-        ctx->bt_built = true;
-        return MI_OK;
-    }
-    const uint32_t seg = view * ctx->compact_classes + slot;
-    a.list_count = (const uint32_t*)ctx->seg_totals.p + seg;
-    if (ctx->compact_fast) {
-        a.list = (const uint32_t*)ctx->out_rows.p + (size_t)seg * ctx->seg_stride;
-        a.list_base = nullptr;
-    } else {
-        a.list = (const uint32_t*)ctx->out_rows.p;
-        a.list_base = (const uint64_t*)ctx->seg_bases.p + seg;
-    }
-    a.row_set = ctx->bt_set;
-    a.row_bin = ctx->bt_bin;
-    a.row_input = ctx->bt_input;
-    a.row_meta = ctx->bt_row_meta;
-    if (ctx->bt_resolve) {
-        HIP_TRY(ctx, launch_batch_resolve_rows(ctx->n, n_sets, ctx->bt_set, ctx->bt_bin, (const uint32_t*)ctx->bt_table_off.p,
-                                               (const uint32_t*)ctx->bt_table.p, (const uint32_t*)ctx->bt_meta_off.p, ctx->bt_row_meta,
-                                               ctx->stream));
-        ctx->bt_resolve = false;
-    }
-    a.n_sets = n_sets;
-    a.n_meta = ctx->bt_n_meta;
-    a.set_indexed = (const uint8_t*)ctx->bt_set_indexed.p;
-    a.bin_table_offset = (const uint32_t*)ctx->bt_table_off.p;
-    a.bin_table = (const uint32_t*)ctx->bt_table.p;
-    a.meta_offset = (const uint32_t*)ctx->bt_meta_off.p;
-    a.bin_metadata = (uint32_t*)ctx->bt_meta.p;
-    a.rows_a = (uint32_t*)ctx->bt_rows_a.p;
-    a.rows_b = (uint32_t*)ctx->bt_rows_b.p;
-    a.tile_hist = (uint32_t*)ctx->bt_hist.p;
-    a.n_tiles = n_tiles;
-    a.set_count = (uint32_t*)ctx->bt_set_count.p;
-    a.set_scan = (uint32_t*)ctx->bt_set_scan.p;
-    a.counters = (uint32_t*)ctx->bt_counters.p;
-    a.records = (uint32_t*)ctx->bt_records.p;
-    a.totals = (uint32_t*)ctx->bt_totals.p;
-    HIP_TRY(ctx, launch_batch_build(a, ctx->stream, prof_mark, ctx));
-    ctx->bt_built = true;
-    return MI_OK;
-}
-
-int32_t mi_batch_download_totals(mi_ctx* ctx, mi_batch_totals* out) {
-    ENTER(ctx);
-    if (!out) return fail(ctx, MI_ERR_INVALID_ARG, "mi_batch_download_totals: NULL");
-    if (!ctx->bt_built) return fail(ctx, MI_ERR_NOT_READY, "mi_batch_download_totals before mi_batch_build");
-    return download(ctx, out, ctx->bt_totals.p, sizeof *out);
-}
-
-int32_t mi_batch_download(mi_ctx* ctx, uint32_t what, uint32_t mesh_class, void* out, uint32_t capacity_elems, uint32_t* out_count) {
-    ENTER(ctx);
-    if (!out_count) return fail(ctx, MI_ERR_INVALID_ARG, "mi_batch_download: NULL out_count");
-    if (!ctx->bt_built) return fail(ctx, MI_ERR_NOT_READY, "mi_batch_download before mi_batch_build");
-    if (mesh_class > 1u && what <= MI_BATCH_SETS) return fail(ctx, MI_ERR_INVALID_ARG, "mi_batch_download: mesh class %u", mesh_class);
-    mi_batch_totals t{};
-    int32_t rc = download(ctx, &t, ctx->bt_totals.p, sizeof t);
-    if (rc) return rc;
-    const void* src = nullptr;
-    uint32_t count = 0, elem = 0;
-    switch (what) {
-    case MI_BATCH_WORK_ITEMS: src = ctx->bt_wi[mesh_class].p; count = t.work_item_len[mesh_class]; elem = 8; break;
-    case MI_BATCH_INDIRECT_PARAMETERS_METADATA: src = ctx->bt_md[mesh_class].p; count = t.indirect_parameters_len[mesh_class]; elem = 20; break;
-    case MI_BATCH_SETS: src = ctx->bt_bs[mesh_class].p; count = t.batch_set_len[mesh_class]; elem = 8; break;
-    case MI_BATCH_RECORDS: src = ctx->bt_records.p; count = t.n_records; elem = 32; break;
-    case MI_BATCH_BIN_METADATA: src = ctx->bt_meta.p; count = ctx->bt_n_meta; elem = 12; break;
-    default: return fail(ctx, MI_ERR_INVALID_ARG, "mi_batch_download: unknown array %u", what);
-    }
-    *out_count = count;
-    if (count > capacity_elems) return fail(ctx, MI_ERR_CAPACITY, "mi_batch_download: %u elements, capacity %u", count, capacity_elems);
-    if (count && !out) return fail(ctx, MI_ERR_INVALID_ARG, "mi_batch_download: NULL out");
-    if (count) return download(ctx, out, src, (size_t)count * elem);
-    return MI_OK;
-}
-
-// =============================================================================================
-// clustering
-// =============================================================================================
-int32_t mi_cluster_upload_objects(mi_ctx* ctx, uint32_t n, const float* pos_range, const uint8_t* obj_type,
-                                  const uint32_t* layer_mask, const float* spot_dir, const float* spot_sin_cos) {
-    ENTER(ctx);
-    if (n && !pos_range) return fail(ctx, MI_ERR_INVALID_ARG, "mi_cluster_upload_objects: pos_range NULL");
-    bool any_spot = false;
-    if (obj_type)
-        for (uint32_t i = 0; i < n; ++i) {
-            if (obj_type[i] > MI_OBJ_DECAL) return fail(ctx, MI_ERR_INVALID_ARG, "object %u: unknown type %u", i, obj_type[i]);
-            any_spot |= obj_type[i] == MI_OBJ_SPOT_LIGHT;
-        }
-    if (any_spot && (!spot_dir || !spot_sin_cos)) return fail(ctx, MI_ERR_INVALID_ARG, "spot lights need spot_dir and spot_sin_cos");
-    int32_t rc;
-    if ((rc = ensure(ctx, ctx->cl_pos, (size_t)n * 16))) return rc;
-    if ((rc = upload(ctx, ctx->cl_pos.p, pos_range, (size_t)n * 16))) return rc;
-    ctx->cl_have_type = obj_type != nullptr;
-    if (obj_type) {
-        if ((rc = ensure(ctx, ctx->cl_type, n))) return rc;
-        if ((rc = upload(ctx, ctx->cl_type.p, obj_type, n))) return rc;
-    }
-    ctx->cl_have_layers = layer_mask != nullptr;
-    if (layer_mask) {
-        if ((rc = ensure(ctx, ctx->cl_layers, (size_t)n * 4))) return rc;
-        if ((rc = upload(ctx, ctx->cl_layers.p, layer_mask, (size_t)n * 4))) return rc;
-    }
-    ctx->cl_have_spot = spot_dir && spot_sin_cos;
-    if (ctx->cl_have_spot) {
-        if ((rc = ensure(ctx, ctx->cl_dir, (size_t)n * 12))) return rc;
-        if ((rc = upload(ctx, ctx->cl_dir.p, spot_dir, (size_t)n * 12))) return rc;
-        if ((rc = ensure(ctx, ctx->cl_sincos, (size_t)n * 8))) return rc;
-        if ((rc = upload(ctx, ctx->cl_sincos.p, spot_sin_cos, (size_t)n * 8))) return rc;
-    }
-    ctx->cl_any_spot = any_spot;
-    ctx->cl_n = n;
-    ctx->cl_assigned = false;
-    return MI_OK;
-}
-
-int32_t mi_cluster_upload_view(mi_ctx* ctx, const mi_cluster_view* view) {
-    ENTER(ctx);
-    if (!view || !view->x_planes || !view->y_planes || !view->z_planes) return fail(ctx, MI_ERR_INVALID_ARG, "mi_cluster_upload_view: NULL");
-    const uint64_t C = (uint64_t)view->dims[0] * view->dims[1] * view->dims[2];
-    if (C == 0 || C > 4096) return fail(ctx, MI_ERR_INVALID_ARG, "cluster count %llu outside 1..4096 (assign.rs:410-413)", (unsigned long long)C);
-    const uint32_t nx = view->dims[0] + 1, ny = view->dims[1] + 1, nz = view->dims[2] + 1;
-    int32_t rc;
-    if ((rc = ensure(ctx, ctx->cl_planes, (size_t)(nx + ny + nz) * 16))) return rc;
-    float* base = (float*)ctx->cl_planes.p;
-    if ((rc = upload(ctx, base, view->x_planes, (size_t)nx * 16))) return rc;
-    if ((rc = upload(ctx, base + 4 * (size_t)nx, view->y_planes, (size_t)ny * 16))) return rc;
-    if ((rc = upload(ctx, base + 4 * (size_t)(nx + ny), view->z_planes, (size_t)nz * 16))) return rc;
-    ClusterViewDev& d = ctx->cl_view;
-    memcpy(d.dims, view->dims, sizeof d.dims);
-    d.is_orthographic = view->is_orthographic;
-    d.view_layer_mask = view->view_layer_mask;
-    d.n_clusters = (uint32_t)C;
-    memcpy(d.cluster_factors, view->cluster_factors, sizeof d.cluster_factors);
-    memcpy(d.view_from_world, view->view_from_world, sizeof d.view_from_world);
-    memcpy(d.clip_from_view, view->clip_from_view, sizeof d.clip_from_view);
-    memcpy(d.view_from_world_scale, view->view_from_world_scale, sizeof d.view_from_world_scale);
-    d.view_from_world_scale_max = view->view_from_world_scale_max;
-    memcpy(d.frustum, view->frustum, sizeof d.frustum);
-    d.x_planes = base;
-    d.y_planes = base + 4 * (size_t)nx;
-    d.z_planes = base + 4 * (size_t)(nx + ny);
-    d.cluster_spheres = nullptr;
-    if (view->cluster_spheres) {
-        if ((rc = ensure(ctx, ctx->cl_spheres, (size_t)C * 16))) return rc;
-        if ((rc = upload(ctx, ctx->cl_spheres.p, view->cluster_spheres, (size_t)C * 16))) return rc;
-        d.cluster_spheres = (const float*)ctx->cl_spheres.p;
-    }
-    ctx->cl_have_view = true;
-    ctx->cl_assigned = false;
-    return MI_OK;
-}
-
-int32_t mi_cluster_assign_resident(mi_ctx* ctx, uint64_t* out_total) {
-    ENTER(ctx);
-    if (!ctx->cl_have_view) return fail(ctx, MI_ERR_NOT_READY, "mi_cluster_assign_resident: no view uploaded");
-    if (ctx->cl_any_spot && !ctx->cl_view.cluster_spheres)
-        return fail(ctx, MI_ERR_INVALID_ARG, "spot lights present but mi_cluster_view.cluster_spheres is NULL");
-    const uint32_t C = ctx->cl_view.n_clusters;
-    ClusterObjects o{};
-    o.n = ctx->cl_n;
-    o.pos_range = (const float*)ctx->cl_pos.p;
-    o.obj_type = ctx->cl_have_type ? (const uint8_t*)ctx->cl_type.p : nullptr;
-    o.layer_mask = ctx->cl_have_layers ? (const uint32_t*)ctx->cl_layers.p : nullptr;
-    o.spot_dir = ctx->cl_have_spot ? (const float*)ctx->cl_dir.p : nullptr;
-    o.spot_sin_cos = ctx->cl_have_spot ? (const float*)ctx->cl_sincos.p : nullptr;
-    ClusterWork w{};
-    w.n_blocks = std::max(1u, (o.n + CLUSTER_BLOCK - 1) / CLUSTER_BLOCK);
-    int32_t rc;
-    const size_t off_totals = (6 * (size_t)C + 3) & ~(size_t)3, off_misc = off_totals + (((size_t)C + 3) & ~(size_t)3);
-    const size_t acc_words = off_misc + 4;  // per parity; 16-byte aligned sections: counts | totals | misc
-    w.row_stride = (w.n_blocks + 7u) & ~7u;
-    const size_t mat_bytes = (size_t)C * w.row_stride * 2;  // per parity
-    if ((rc = ensure(ctx, ctx->cl_pair_cb, (size_t)w.n_blocks * C * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->cl_pair_mask, (size_t)w.n_blocks * C * 32))) return rc;
-    if ((rc = ensure(ctx, ctx->cl_offsets, ((size_t)C + 1) * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->cl_scalars, 16))) return rc;
-    if (!ctx->cl_acc.p || ctx->cl_acc_clusters != C || ctx->cl_acc_blocks != w.n_blocks) {
-        // (re)shaped accumulators / count matrix start zeroed in both parities; afterwards the fill kernel keeps
-        // the idle parity zeroed
-        if ((rc = ensure(ctx, ctx->cl_acc, 2 * acc_words * 4))) return rc;
-        if ((rc = ensure(ctx, ctx->cl_block_counts, 2 * mat_bytes))) return rc;
-        HIP_TRY(ctx, hipMemsetAsync(ctx->cl_acc.p, 0, 2 * acc_words * 4, ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->cl_block_counts.p, 0, 2 * mat_bytes, ctx->stream));
-        ctx->cl_acc_clusters = C;
-        ctx->cl_acc_blocks = w.n_blocks;
-    }
-    if (!ctx->cl_indices.p && (rc = ensure(ctx, ctx->cl_indices, (size_t)1 << 20))) return rc;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        ctx->cl_parity ^= 1u;
-        const uint32_t par = ctx->cl_parity;
-        uint32_t* acc = (uint32_t*)ctx->cl_acc.p + par * acc_words;
-        w.block_counts = (uint16_t*)((char*)ctx->cl_block_counts.p + par * mat_bytes);
-        w.block_counts_next = (uint16_t*)((char*)ctx->cl_block_counts.p + (par ^ 1u) * mat_bytes);
-        w.counts = acc;
-        w.totals = acc + off_totals;
-        w.farthest_z = (float*)(acc + off_misc);
-        w.pair_total = acc + off_misc + 1;
-        w.acc_words = (uint32_t)acc_words;
-        w.acc_next = (uint32_t*)ctx->cl_acc.p + (par ^ 1u) * acc_words;
-        w.pair_cb = (uint32_t*)ctx->cl_pair_cb.p;
-        w.pair_mask = (uint32_t*)ctx->cl_pair_mask.p;
-        w.offsets = (uint32_t*)ctx->cl_offsets.p;
-        w.indices = (uint32_t*)ctx->cl_indices.p;
-        w.capacity = ctx->cl_indices.bytes / 4;
-        w.total = (uint64_t*)ctx->cl_scalars.p;
-        HIP_TRY(ctx, launch_cluster_assign(ctx->cl_view, o, w, ctx->stream, prof_mark, ctx));
-        if (!out_total && attempt == 0) break;  // fire and forget: capacity is re-checked at download
-        uint64_t total = 0;
-        if ((rc = download(ctx, &total, w.total, 8))) return rc;
-        if (out_total) *out_total = total;
-        if (total <= w.capacity) break;
-        // index list overflowed the device buffer: grow and redo (the reference's Vecs grow the same way)
-        if ((rc = ensure(ctx, ctx->cl_indices, (size_t)total * 4 * 5 / 4))) return rc;
-    }
-    ctx->cl_assigned = true;
-    return MI_OK;
-}
-
-int32_t mi_cluster_download(mi_ctx* ctx, uint32_t* out_offsets, uint32_t* out_indices, uint64_t capacity, uint32_t* out_counts,
-                            uint64_t* out_total, float* out_farthest_z) {
-    ENTER(ctx);
-    if (!ctx->cl_assigned) return fail(ctx, MI_ERR_NOT_READY, "mi_cluster_download before mi_cluster_assign_resident");
-    const uint32_t C = ctx->cl_view.n_clusters;
-    uint64_t total = 0;
-    int32_t rc;
-    if ((rc = download(ctx, &total, ctx->cl_scalars.p, 8))) return rc;
-    if (total > ctx->cl_indices.bytes / 4) {
-        // fire-and-forget assign overflowed: redo with a big enough buffer
-        uint64_t t2 = 0;
-        if ((rc = mi_cluster_assign_resident(ctx, &t2))) return rc;
-        total = t2;
-    }
-    if (out_total) *out_total = total;
-    const size_t off_totals = (6 * (size_t)C + 3) & ~(size_t)3, off_misc = off_totals + (((size_t)C + 3) & ~(size_t)3);
-    const uint32_t* acc = (const uint32_t*)ctx->cl_acc.p + ctx->cl_parity * (off_misc + 4);
-    if (out_farthest_z && (rc = download(ctx, out_farthest_z, acc + off_misc, 4))) return rc;
-    if (out_offsets && (rc = download(ctx, out_offsets, ctx->cl_offsets.p, ((size_t)C + 1) * 4))) return rc;
-    if (out_counts && (rc = download(ctx, out_counts, acc, (size_t)C * 6 * 4))) return rc;
-    if (out_indices) {
-        if (total > capacity) return fail(ctx, MI_ERR_CAPACITY, "cluster index list has %llu entries, capacity %llu", (unsigned long long)total, (unsigned long long)capacity);
-        if ((rc = download(ctx, out_indices, ctx->cl_indices.p, (size_t)total * 4))) return rc;
-    }
-    return MI_OK;
-}
-
-int32_t mi_cluster_download_bindings(mi_ctx* ctx, const uint32_t* remap, uint32_t n_remap, uint32_t* out_offsets_and_counts,
-                                     uint32_t* out_index_list, uint64_t capacity, uint64_t* out_total) {
-    ENTER(ctx);
-    if (!ctx->cl_assigned) return fail(ctx, MI_ERR_NOT_READY, "mi_cluster_download_bindings before mi_cluster_assign_resident");
-    const uint32_t C = ctx->cl_view.n_clusters;
-    uint64_t total = 0;
-    int32_t rc;
-    if ((rc = download(ctx, &total, ctx->cl_scalars.p, 8))) return rc;
-    if (total > ctx->cl_indices.bytes / 4) {  // fire-and-forget assign overflowed: redo with a big enough buffer
-        uint64_t t2 = 0;
-        if ((rc = mi_cluster_assign_resident(ctx, &t2))) return rc;
-        total = t2;
-    }
-    if (out_total) *out_total = total;
-    const size_t off_totals = (6 * (size_t)C + 3) & ~(size_t)3, off_misc = off_totals + (((size_t)C + 3) & ~(size_t)3);
-    const uint32_t* acc = (const uint32_t*)ctx->cl_acc.p + ctx->cl_parity * (off_misc + 4);
-    if ((rc = ensure(ctx, ctx->cl_bind_oc, (size_t)C * 32))) return rc;
-    if ((rc = ensure(ctx, ctx->cl_bind_idx, std::max<size_t>(total, 1) * 4))) return rc;
-    const uint32_t* d_remap = nullptr;
-    if (remap) {
-        if ((rc = ensure(ctx, ctx->cl_remap, std::max<size_t>(n_remap, 1) * 4))) return rc;
-        if ((rc = upload(ctx, ctx->cl_remap.p, remap, (size_t)n_remap * 4))) return rc;
-        d_remap = (const uint32_t*)ctx->cl_remap.p;
-    }
-    HIP_TRY(ctx, launch_cluster_bindings(C, (const uint32_t*)ctx->cl_offsets.p, acc, (const uint32_t*)ctx->cl_indices.p, d_remap, n_remap,
-                                         total, (uint32_t*)ctx->cl_bind_oc.p, (uint32_t*)ctx->cl_bind_idx.p, ctx->stream));
-    if (out_offsets_and_counts && (rc = download(ctx, out_offsets_and_counts, ctx->cl_bind_oc.p, (size_t)C * 32))) return rc;
-    if (out_index_list) {
-        if (total > capacity) return fail(ctx, MI_ERR_CAPACITY, "cluster index list has %llu entries, capacity %llu", (unsigned long long)total, (unsigned long long)capacity);
-        if ((rc = download(ctx, out_index_list, ctx->cl_bind_idx.p, (size_t)total * 4))) return rc;
-    }
-    return MI_OK;
-}
-
-int32_t mi_cluster_assign(mi_ctx* ctx, const mi_cluster_view* view, uint32_t n_objects, const float* pos_range,
-                          const uint8_t* obj_type, const uint32_t* layer_mask, const float* spot_dir, const float* spot_sin_cos,
-                          uint32_t* out_offsets, uint32_t* out_indices, uint64_t capacity, uint32_t* out_counts,
-                          uint64_t* out_total, float* out_farthest_z) {
-    int32_t rc;
-    if ((rc = mi_cluster_upload_objects(ctx, n_objects, pos_range, obj_type, layer_mask, spot_dir, spot_sin_cos))) return rc;
-    if ((rc = mi_cluster_upload_view(ctx, view))) return rc;
-    uint64_t total = 0;
-    if ((rc = mi_cluster_assign_resident(ctx, &total))) return rc;
-    return mi_cluster_download(ctx, out_offsets, out_indices, capacity, out_counts, out_total, out_farthest_z);
-}
-
-// =============================================================================================
-// interop, timing
-// =============================================================================================
-int32_t mi_bind_visibility_output(mi_ctx* ctx, void* device_ptr, uint64_t words_per_view, uint64_t word_offset) {
-    ENTER(ctx);
-    ctx->ext_bitmask = device_ptr;
-    ctx->ext_words_per_view = words_per_view;
-    ctx->ext_word_offset = word_offset;
-    ctx->culled = false;
-    return MI_OK;
-}
-
-int32_t mi_exchange_configure(mi_ctx* ctx, void* nccl_comm, void* fn_nccl_all_gather, void* const* device_bufs, uint32_t n_bufs,
-                              uint64_t words_per_view, uint64_t word_offset, uint64_t block_bytes, uint32_t rank) {
-    void* comms[1] = {nccl_comm};
-    return mi_exchange_configure_multi(ctx, nccl_comm ? comms : nullptr, nccl_comm ? 1u : 0u, fn_nccl_all_gather, device_bufs, n_bufs,
-                                       words_per_view, word_offset, block_bytes, rank);
-}
-
-int32_t mi_exchange_configure_multi(mi_ctx* ctx, void* const* nccl_comms, uint32_t n_comms, void* fn_nccl_all_gather,
-                                    void* const* device_bufs, uint32_t n_bufs, uint64_t words_per_view, uint64_t word_offset,
-                                    uint64_t block_bytes, uint32_t rank) {
-    ENTER(ctx);
-    auto& x = ctx->xch;
-    void* const nccl_comm = (nccl_comms && n_comms) ? nccl_comms[0] : nullptr;
-    if (n_comms > mi_ctx::Exchange::MAX_COMMS) return fail(ctx, MI_ERR_INVALID_ARG, "mi_exchange_configure: at most %u communicators", mi_ctx::Exchange::MAX_COMMS);
-    for (uint32_t k = 0; k < n_comms; ++k)
-        if (!nccl_comms[k]) return fail(ctx, MI_ERR_INVALID_ARG, "mi_exchange_configure: communicator %u is NULL", k);
-    if (x.on) {  // drain whatever is in flight before changing anything
-        int32_t rc0 = exchange_wait_issued(ctx, x.frame);
-        exchange_stop(ctx);
-        for (hipStream_t cs : x.comm_stream)
-            if (cs) HIP_TRY(ctx, hipStreamSynchronize(cs));
-        x.on = false;
-        if (rc0) return rc0;
-    }
-    if (!nccl_comm) {  // off: back to the internal mask buffer
-        x.on = false;
-        ctx->ext_bitmask = nullptr;
-        ctx->culled = false;
-        return MI_OK;
-    }
-    if (!fn_nccl_all_gather || !device_bufs || n_bufs < 2 || n_bufs > mi_ctx::Exchange::MAX_BUFS || block_bytes == 0)
-        return fail(ctx, MI_ERR_INVALID_ARG, "mi_exchange_configure: NULL function / buffers, n_bufs outside 2..8, or empty block");
-    for (uint32_t i = 0; i < n_bufs; ++i)
-        if (!device_bufs[i]) return fail(ctx, MI_ERR_INVALID_ARG, "mi_exchange_configure: buffer %u is NULL", i);
-    if (!x.done_flag) HIP_TRY(ctx, hipHostMalloc((void**)&x.done_flag, 64, hipHostMallocMapped));
-    if (!x.kernels_flag) HIP_TRY(ctx, hipMalloc((void**)&x.kernels_flag, 64));
-    HIP_TRY(ctx, hipMemsetAsync(x.kernels_flag, 0, 64, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    x.kernel_signal = getenv("MI_XCH_NO_KERNEL_SIGNAL") == nullptr;
-    x.signalled = false;
-    if (!x.comm_stream[0]) {
-        for (uint32_t i = 0; i < mi_ctx::Exchange::MAX_BUFS; ++i) {
-            HIP_TRY(ctx, hipEventCreateWithFlags(&x.ev_kernels[i], hipEventDisableTiming));
-            HIP_TRY(ctx, hipEventCreateWithFlags(&x.ev_gathered[i], hipEventDisableTiming));
-        }
-        // Pick the communication stream empirically.  HIP maps streams onto a small pool of hardware queues; if the
-        // communication stream lands on the compute stream's queue, its wait / record / write packets serialise with
-        // the frame kernels (measured: 32 us -> 48 us per frame), and which stream collides depends on how many
-        // streams the process created before.  So: make a few candidates (normal and high priority), drive each with
-        // the per-frame pattern over a stand-in kernel, keep the fastest.
-        int prio_lo = 0, prio_hi = 0;
-        HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        constexpr int N_CAND = 6;
-        hipStream_t cand[N_CAND] = {nullptr};
-        for (int i = 0; i < N_CAND; ++i) {
-            if (i == N_CAND - 1) HIP_TRY(ctx, hipStreamCreateWithPriority(&cand[i], hipStreamNonBlocking, prio_hi));
-            else HIP_TRY(ctx, hipStreamCreateWithFlags(&cand[i], hipStreamNonBlocking));
-        }
-        const size_t probe_words = (size_t)16 << 20;  // 64 MB clear: a stand-in for one frame of kernels
-        uint32_t* probe = nullptr;
-        HIP_TRY(ctx, hipMalloc((void**)&probe, probe_words * 4));
-        double cand_t[N_CAND];
-        for (int rep = 0; rep < 2; ++rep)
-            for (int i = 0; i < N_CAND; ++i) {
-                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-                HIP_TRY(ctx, hipStreamSynchronize(cand[i]));
-                const auto t0 = std::chrono::steady_clock::now();
-                for (uint32_t it = 0; it < 24; ++it) {
-                    HIP_TRY(ctx, launch_clear_u32(probe, probe_words, ctx->stream));
-                    HIP_TRY(ctx, hipEventRecord(x.ev_kernels[it & 1u], ctx->stream));
-                    HIP_TRY(ctx, hipStreamWaitEvent(cand[i], x.ev_kernels[it & 1u], 0));
-                    HIP_TRY(ctx, hipEventRecord(x.ev_gathered[it & 1u], cand[i]));
-                    HIP_TRY(ctx, hipStreamWriteValue32(cand[i], (void*)x.done_flag, it + 1, 0));
-                }
-                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-                HIP_TRY(ctx, hipStreamSynchronize(cand[i]));
-                const double t = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-                if (rep == 1) cand_t[i] = t;
-                if (getenv("MI_XCH_DEBUG")) fprintf(stderr, "[mi exchange] comm stream candidate %d%s: %.1f us / frame\n", i,
-                                                    i == N_CAND - 1 ? " (high priority)" : "", t / 24.0);
-            }
-        HIP_TRY(ctx, hipFree(probe));
-        int order[N_CAND];
-        std::iota(order, order + N_CAND, 0);
-        std::sort(order, order + N_CAND, [&](int a, int b) { return cand_t[a] < cand_t[b]; });
-        for (int i = 0; i < N_CAND; ++i) {  // keep the MAX_COMMS fastest, fastest first
-            if (i < (int)mi_ctx::Exchange::MAX_COMMS) x.comm_stream[i] = cand[order[i]];
-            else HIP_TRY(ctx, hipStreamDestroy(cand[order[i]]));
-        }
-    }
-    x.all_gather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))fn_nccl_all_gather;
-    x.n_comms = n_comms;
-    for (uint32_t k = 0; k < n_comms; ++k) x.comm[k] = nccl_comms[k];
-    x.n_bufs = n_bufs;
-    for (uint32_t i = 0; i < n_bufs; ++i) x.buf[i] = device_bufs[i];
-    x.words_per_view = words_per_view;
-    x.word_offset = word_offset;
-    x.block_bytes = block_bytes;
-    x.rank = rank;
-    for (uint32_t k = 0; k < mi_ctx::Exchange::MAX_COMMS; ++k) x.done_flag[k] = 0;
-    x.worker_frames = 0;
-    x.frame = 0;
-    x.submitted = x.issued = 0;
-    x.submitted_fast.store(0);
-    x.worker_error = 0;
-    x.queue.clear();
-    x.worker = std::thread(exchange_worker, ctx);
-    x.on = true;
-    ctx->culled = false;
-    return MI_OK;
-}
-
-int32_t mi_exchange_last(mi_ctx* ctx, void** out_device_buf, int32_t wait) {
-    ENTER(ctx);
-    auto& x = ctx->xch;
-    if (!x.on || x.frame == 0) return fail(ctx, MI_ERR_NOT_READY, "mi_exchange_last: no exchanged frame yet");
-    const uint32_t slot = (uint32_t)((x.frame - 1) % x.n_bufs);
-    int32_t rc = exchange_wait_issued(ctx, x.frame);
-    if (rc) return rc;
-    if (wait) HIP_TRY(ctx, hipEventSynchronize(x.ev_gathered[slot]));
-    if (out_device_buf) *out_device_buf = x.buf[slot];
     return MI_OK;
 }
 

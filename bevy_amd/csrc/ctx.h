@@ -1,0 +1,259 @@
+// ctx.h -- internal to the library: the context object behind the opaque mi_ctx handle and the helpers the
+// entry-point files (context.cpp, ctx_hierarchy.cpp, ctx_exchange.cpp, ctx_batch.cpp, ctx_cluster.cpp) share.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <numeric>
+#include <chrono>
+#include <thread>
+#include <string>
+#include <vector>
+
+#include "../../include/bevy_mi355x.h"
+#include "kernels.h"
+
+namespace mi {
+hipError_t set_cluster_lds_limit();
+hipError_t launch_logf_probe(const float* in, float* out, uint32_t n, hipStream_t stream);
+}  // namespace mi
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct ProfSpan {
+    uint32_t kernel;
+    hipEvent_t a, b;
+};
+
+struct mi_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err = "no error";
+
+    // ---- columns ----
+    uint32_t n = 0, cap = 0;
+    float *t = nullptr, *r = nullptr, *s = nullptr, *g = nullptr, *c = nullptr, *h = nullptr;
+    uint8_t *flags = nullptr, *vv = nullptr, *changed = nullptr, *g_changed_bytes = nullptr;
+    uint32_t *layers = nullptr, *class_mask = nullptr;
+    uint64_t *keys = nullptr, *g_chg_bits = nullptr, *vv_chg_bits = nullptr;
+    uint32_t* tree_bits = nullptr;
+    bool have_class_mask = false, have_keys = false, have_changed = false;
+    uint32_t classes_present = 1u;
+    std::vector<uint64_t> h_keys;
+    bool order_dirty = false, order_identity = true;
+    DevBuf order;
+    float* range = nullptr;        // VisibilityRange (start_margin.start, end_margin.end) per row
+    bool have_ranges = false;      // a VisibleEntityRanges resource exists (mi_upload_visibility_ranges was called)
+    uint8_t* visibility = nullptr; // Visibility component: 0 Inherited, 1 Hidden, 2 Visible, 0x80 none
+    uint8_t* inh_changed = nullptr;  // InheritedVisibility assigned by the last mi_visibility_propagate (bytes)
+    DevBuf inh_bits, sparse_cnt, sparse_rows, sparse_total, sparse_g;
+
+    // ---- staging ----
+    void* stage = nullptr;
+    size_t stage_bytes = 0, stage_used = 0;
+
+    // ---- hierarchy ----
+    uint32_t n_levels = 1;
+    std::vector<uint32_t> level_offsets;  // n_levels + 1
+    DevBuf parent_idx, node_flags, tiles;
+    std::vector<std::pair<uint32_t, uint32_t>> passes;  // (first tile, n tiles); pass 0 starts at level 0 (roots)
+    struct TileGroup { uint32_t first, count, n_chain, owner_rows; };
+    std::vector<TileGroup> groups;  // launches of mi_propagate: an owner pass + at most one pass of chain tiles
+    DevBuf chains, snap;            // snap: 2 x snap_rows x 48 B, pre-frame GlobalTransforms of the owner rows (see kernels_tree.hip)
+    uint32_t snap_rows = 0, snap_parity = 0;
+    bool snap_valid = false;
+    bool have_hierarchy = false;
+    bool g_chg_in_bytes = false;  // the GlobalTransform change mask currently lives in g_changed_bytes (tree path)
+    // host-side knowledge that lets a frame with no dirty Transform skip its launches: some byte of `changed` may be
+    // non-zero (set by the uploads that mark rows, cleared when mi_propagate consumes the column); the change masks of
+    // the last propagate may hold set bits
+    bool changed_maybe = true, g_chg_maybe = true;
+
+    // ---- views / visibility ----
+    DevBuf views;
+    uint32_t n_views = 0;
+    DevBuf bitmask;
+    uint64_t words_per_view = 0;
+    // multi-GPU exchange (mi_exchange_configure): in-place all-gather of the masks after every cull
+    struct Exchange {
+        bool on = false;
+        int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;  // ncclAllGather
+        // Up to MAX_COMMS communicators, used round-robin by frame, each on its own stream: the all-gathers of
+        // consecutive frames are then in flight together (a ~125 KB all-gather over 8 GPUs is pure latency, and one
+        // communicator runs its collectives strictly one after the other).  Every rank issues them in frame order.
+        static constexpr uint32_t MAX_COMMS = 4;
+        uint32_t n_comms = 0;
+        void* comm[MAX_COMMS] = {nullptr};
+        static constexpr uint32_t MAX_BUFS = 8;
+        uint32_t n_bufs = 0;
+        void* buf[MAX_BUFS] = {nullptr};
+        uint64_t words_per_view = 0, word_offset = 0, block_bytes = 0;
+        uint32_t rank = 0;
+        uint64_t frame = 0;
+        hipStream_t comm_stream[MAX_COMMS] = {nullptr};
+        hipEvent_t ev_kernels[MAX_BUFS] = {nullptr}, ev_gathered[MAX_BUFS] = {nullptr};
+        // The collective is enqueued by a library-owned host thread: RCCL's enqueue path costs tens of
+        // microseconds of CPU per call, which would otherwise sit in the frame's critical path on the caller's
+        // thread.  The caller's thread never runs more than two frames ahead of it.
+        std::thread worker;
+        std::mutex m;
+        std::condition_variable cv;
+        std::deque<uint32_t> queue;
+        std::atomic<uint64_t> submitted_fast{0};  // == submitted, readable without the lock (the thread polls it)
+        std::atomic<bool> sleeping{false}, stop_fast{false};
+        bool stop = false;
+        uint64_t submitted = 0, issued = 0;  // guarded by m
+        uint64_t worker_frames = 0;          // exchange thread only
+        int worker_error = 0;
+        volatile uint32_t* done_flag = nullptr;  // pinned host words [MAX_COMMS]: all-gathers completed on each communicator
+        // device word: number of frames whose masks are complete.  Written by the compaction kernel itself (see
+        // CompactFastArgs::signal) or, when that kernel is not the one running, by a write-value packet behind the
+        // frame's kernels; the communication stream waits on it with hipStreamWaitValue32.
+        uint32_t* kernels_flag = nullptr;
+        bool kernel_signal = true;      // MI_XCH_NO_KERNEL_SIGNAL forces the packet
+        bool signalled = false;         // this frame's compaction launch carries the signal
+        double dbg_wait_ns = 0, dbg_begin_ns = 0, dbg_end_ns = 0, dbg_worker_ns = 0;  // MI_XCH_DEBUG
+    } xch;
+    void* ext_bitmask = nullptr;
+    uint64_t ext_words_per_view = 0, ext_word_offset = 0;
+    bool culled = false;
+    mi::ViewSet view_set{};      // views passed by value when n_views <= mi::MAX_INLINE_VIEWS
+    bool views_inline = false;
+    // compaction
+    DevBuf block_counts, seg_totals, seg_bases, out_rows, out_keys, wave_cnt, seg_mask;
+    uint32_t compact_views = 0, compact_classes = 0;
+    uint32_t class_bits[32] = {0};
+    bool compact_fast = false;   // last compaction used the single-launch path (out_rows strided per segment)
+    uint64_t seg_stride = 0;
+
+    // ---- clustering ----
+    DevBuf cl_pos, cl_type, cl_layers, cl_dir, cl_sincos, cl_planes, cl_spheres;
+    // batching work-item build (kernels_batch.hip)
+    uint32_t *bt_set = nullptr, *bt_bin = nullptr, *bt_input = nullptr, *bt_row_meta = nullptr;  // per-row columns
+    bool bt_resolve = true;  // rows or tables changed: bt_row_meta must be recomputed
+    DevBuf bt_set_indexed, bt_table_off, bt_table, bt_meta_off, bt_meta, bt_rows_a, bt_rows_b, bt_hist, bt_set_count, bt_set_scan,
+        bt_counters, bt_wi[2], bt_md[2], bt_bs[2], bt_records, bt_totals;
+    uint32_t bt_n_sets = 0, bt_n_meta = 0;
+    bool bt_have_rows = false, bt_have_sets = false, bt_built = false;
+    DevBuf cl_remap, cl_bind_oc, cl_bind_idx, cl_block_counts, cl_pair_cb, cl_pair_mask, cl_acc, cl_offsets, cl_indices, cl_scalars;
+    uint32_t cl_parity = 0, cl_acc_clusters = 0, cl_acc_blocks = 0;  // cl_acc = 2 x [counts 6C | totals C | farthest_z + pad]
+    uint32_t cl_n = 0;
+    bool cl_have_type = false, cl_have_layers = false, cl_have_spot = false, cl_any_spot = false;
+    mi::ClusterViewDev cl_view{};
+    bool cl_have_view = false, cl_assigned = false;
+
+    // ---- timing ----
+    hipEvent_t timer_a = nullptr, timer_b = nullptr;
+    bool profiling = false;
+    uint64_t prof_mask = ~0ull;
+    uint32_t prof_every = 1, prof_tick[mi::K_NUM_KERNELS] = {0};  // time every n-th launch of a kernel
+    uint32_t prof_burst = 0, prof_timed[mi::K_NUM_KERNELS] = {0};  // ... and at most the first prof_burst of them (0 = no limit)
+    std::vector<ProfSpan> spans;
+    bool span_open = false;
+    uint64_t prof_launches[mi::K_NUM_KERNELS] = {0};
+    double prof_ms[mi::K_NUM_KERNELS] = {0};
+};
+
+
+namespace mi_detail {
+using namespace mi;
+
+int32_t fail(mi_ctx* ctx, int32_t code, const char* fmt, ...);
+
+#define HIP_TRY(ctx, expr)                                                                                   \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? MI_ERR_OUT_OF_MEMORY : MI_ERR_DEVICE, "%s: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                          \
+    } while (0)
+
+#define ENTER(ctx)                                                       \
+    do {                                                                 \
+        if (!(ctx)) return fail(nullptr, MI_ERR_INVALID_ARG, "ctx is NULL"); \
+        HIP_TRY(ctx, hipSetDevice((ctx)->device));                       \
+    } while (0)
+
+inline uint64_t words64(uint32_t n) { return ((uint64_t)n + 63u) / 64u; }
+// bitmask words written by a launch of ceil(n/256) workgroups x 4 waves
+inline uint64_t padded_words(uint32_t n) { return (((uint64_t)n + 255u) / 256u) * 4u; }
+
+int32_t ensure(mi_ctx* ctx, DevBuf& b, size_t bytes);
+template <typename T>
+int32_t grow_column(mi_ctx* ctx, T*& col, size_t elems_per_row, uint32_t old_rows, uint32_t new_cap, int fill_byte) {
+    T* np = nullptr;
+    const size_t bytes = (size_t)new_cap * elems_per_row * sizeof(T) + 256;
+    HIP_TRY(ctx, hipMalloc((void**)&np, bytes));
+    HIP_TRY(ctx, hipMemsetAsync(np, fill_byte, bytes, ctx->stream));
+    if (col && old_rows)
+        HIP_TRY(ctx, hipMemcpyAsync(np, col, (size_t)old_rows * elems_per_row * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+    if (col) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(col));
+    }
+    col = np;
+    return MI_OK;
+}
+
+// Pinned staging arena: host slices are copied here (the ECS owns them only for the call) and the
+// H2D copy runs asynchronously on the context's stream.
+int32_t stage_alloc(mi_ctx* ctx, size_t bytes, void** out);
+int32_t upload(mi_ctx* ctx, void* dst, const void* src, size_t bytes);
+int32_t download(mi_ctx* ctx, void* dst, const void* src, size_t bytes);
+int32_t check_rows(mi_ctx* ctx, uint32_t first, uint32_t n, const char* what);
+void prof_close(mi_ctx* ctx);
+void prof_mark(void* vctx, uint32_t kernel);
+void prof_collect(mi_ctx* ctx);
+// Times exactly one launch (the next MI_LAUNCH on this thread) with its dispatch timestamps.
+struct ProfScope {
+    mi_ctx* ctx;
+    LaunchTimer lt{};
+    bool armed = false;
+    ProfScope(mi_ctx* c, uint32_t k) : ctx(c) {
+        if (!c->profiling || k >= K_NUM_KERNELS || !((c->prof_mask >> k) & 1ull)) return;
+        if (c->prof_every > 1 && (c->prof_tick[k]++ % c->prof_every) != 0) return;
+        if (c->prof_burst && c->prof_timed[k] >= c->prof_burst) return;
+        ++c->prof_timed[k];
+        prof_close(c);
+        ProfSpan sp;
+        sp.kernel = k;
+        hipEventCreate(&sp.a);
+        hipEventCreate(&sp.b);
+        c->spans.push_back(sp);
+        lt.start = sp.a;
+        lt.stop = sp.b;
+        g_launch_timer = &lt;
+        armed = true;
+    }
+    ~ProfScope() {
+        if (armed && g_launch_timer == &lt) {  // nothing was launched inside the scope
+            g_launch_timer = nullptr;
+            hipEventDestroy(ctx->spans.back().a);
+            hipEventDestroy(ctx->spans.back().b);
+            ctx->spans.pop_back();
+        }
+    }
+};
+Columns columns_of(mi_ctx* ctx);
+int32_t prepare_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, VisibilityOut* out);
+int32_t prepare_segments(mi_ctx* ctx, uint32_t n_views, SegOut* seg);
+int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg);
+// ctx_exchange.cpp
+int32_t exchange_begin(mi_ctx* ctx);
+int32_t exchange_end(mi_ctx* ctx);
+int32_t exchange_wait_issued(mi_ctx* ctx, uint64_t upto);
+void exchange_stop(mi_ctx* ctx);
+
+}  // namespace mi_detail

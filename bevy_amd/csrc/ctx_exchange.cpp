@@ -1,0 +1,279 @@
+// ctx_exchange.cpp -- the multi-GPU exchange: in-place all-gather of the visibility masks behind every cull.
+#include "ctx.h"
+
+using namespace mi;
+using namespace mi_detail;
+
+namespace mi_detail {
+
+// Multi-GPU exchange around a cull: bind this frame's gathered buffer (after its previous all-gather drained),
+// and afterwards hand the in-place all-gather to the exchange thread, which enqueues it on the communication
+// stream behind the kernels.
+void exchange_worker(mi_ctx* ctx) {
+    auto& x = ctx->xch;
+    hipSetDevice(ctx->device);
+    for (;;) {
+        uint32_t slot;
+        // While frames are flowing the thread must not go to sleep between them: waking a thread through a futex
+        // takes tens of microseconds, more than a frame.  Poll the submission counter for a while first.
+        if (x.submitted_fast.load(std::memory_order_acquire) == x.worker_frames) {
+            const auto spin0 = std::chrono::steady_clock::now();
+            uint32_t spins = 0;
+            while (x.submitted_fast.load(std::memory_order_acquire) == x.worker_frames && !x.stop_fast.load(std::memory_order_relaxed)) {
+                __builtin_ia32_pause();
+                if ((++spins & 255u) == 0 && std::chrono::steady_clock::now() - spin0 > std::chrono::microseconds(500)) break;
+            }
+        }
+        {
+            std::unique_lock<std::mutex> lk(x.m);
+            if (x.queue.empty() && !x.stop) {
+                x.sleeping.store(true, std::memory_order_seq_cst);
+                x.cv.wait(lk, [&] { return x.stop || !x.queue.empty(); });
+                x.sleeping.store(false, std::memory_order_relaxed);
+            }
+            if (x.queue.empty()) return;  // stop requested and drained
+            slot = x.queue.front();
+            x.queue.pop_front();
+        }
+        int err = 0;
+        const auto tw0 = std::chrono::steady_clock::now();
+        const uint32_t k = (uint32_t)(x.worker_frames % x.n_comms);  // frame f travels on communicator f % n_comms
+        hipStream_t cs = x.comm_stream[k];
+        if (hipStreamWaitValue32(cs, x.kernels_flag, (uint32_t)(x.worker_frames + 1), hipStreamWaitValueGte, 0xFFFFFFFFu) != hipSuccess) err = -1;
+        char* base = (char*)x.buf[slot];
+        if (!err) err = x.all_gather(base + (size_t)x.rank * x.block_bytes, base, (size_t)x.block_bytes, 1 /* ncclUint8 */, x.comm[k], cs);
+        if (hipEventRecord(x.ev_gathered[slot], cs) != hipSuccess && !err) err = -2;
+        // completion counter the caller's thread can read without a driver call
+        if (hipStreamWriteValue32(cs, (void*)(x.done_flag + k), (uint32_t)(x.worker_frames / x.n_comms + 1), 0) != hipSuccess && !err) err = -3;
+        ++x.worker_frames;
+        x.dbg_worker_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tw0).count();
+        {
+            std::lock_guard<std::mutex> lk(x.m);
+            if (err && !x.worker_error) x.worker_error = err;
+            ++x.issued;
+        }
+        x.cv.notify_all();
+    }
+}
+// blocks until the exchange thread has enqueued the collectives of frames < upto
+int32_t exchange_wait_issued(mi_ctx* ctx, uint64_t upto) {
+    auto& x = ctx->xch;
+    std::unique_lock<std::mutex> lk(x.m);
+    x.cv.wait(lk, [&] { return x.issued >= upto || x.worker_error; });
+    if (x.worker_error) return fail(ctx, MI_ERR_DEVICE, "exchange thread: ncclAllGather / HIP call failed (%d)", x.worker_error);
+    return MI_OK;
+}
+void exchange_stop(mi_ctx* ctx) {
+    auto& x = ctx->xch;
+    if (x.worker.joinable()) {
+        {
+            std::lock_guard<std::mutex> lk(x.m);
+            x.stop = true;
+        }
+        x.stop_fast.store(true);
+        x.cv.notify_all();
+        x.worker.join();
+    }
+    x.stop = false;
+    x.stop_fast.store(false);
+}
+int32_t exchange_begin(mi_ctx* ctx) {
+    auto& x = ctx->xch;
+    if (!x.on) return MI_OK;
+    const uint32_t slot = (uint32_t)(x.frame % x.n_bufs);
+    const auto tb0 = std::chrono::steady_clock::now();
+    struct Acc { double& d; std::chrono::steady_clock::time_point t; ~Acc() { d += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t).count(); } } acc{x.dbg_begin_ns, tb0};
+    if (x.frame >= x.n_bufs) {
+        // This buffer was last used n_bufs frames ago and its all-gather must have completed before the kernels
+        // overwrite it.  The dependency is enforced on the HOST (the communication stream bumps a pinned counter
+        // behind every all-gather), not with a cross-stream wait: a barrier packet on the compute queue costs
+        // ~6 us of GPU time per frame, while pacing the caller n_bufs - 1 frames ahead of the exchange costs
+        // nothing as long as the next frame is already queued.
+        const uint64_t need = x.frame - x.n_bufs + 1;
+        uint32_t spins = 0;
+
+        // frames 0 .. need-1 complete <=> every communicator k has finished its ceil((need - k) / n_comms) of them
+        auto drained = [&]() {
+            for (uint32_t k = 0; k < x.n_comms; ++k)
+                if ((uint64_t)x.done_flag[k] < (need + x.n_comms - 1 - k) / x.n_comms) return false;
+            return true;
+        };
+        while (!drained()) {
+            if ((++spins & 1023u) == 0) {
+                {
+                    std::lock_guard<std::mutex> lk(x.m);
+                    if (x.worker_error) return fail(ctx, MI_ERR_DEVICE, "exchange thread: ncclAllGather / HIP call failed (%d)", x.worker_error);
+                }
+                if (std::chrono::steady_clock::now() - tb0 > std::chrono::seconds(30))
+                    return fail(ctx, MI_ERR_DEVICE, "exchange: the all-gather of frame %llu did not complete within 30 s",
+                                (unsigned long long)(need - 1));
+                std::this_thread::yield();
+            }
+        }
+        x.dbg_wait_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tb0).count();
+    }
+    ctx->ext_bitmask = x.buf[slot];
+    ctx->ext_words_per_view = x.words_per_view;
+    ctx->ext_word_offset = x.word_offset;
+    return MI_OK;
+}
+int32_t exchange_end(mi_ctx* ctx) {
+    auto& x = ctx->xch;
+    if (!x.on) return MI_OK;
+    const uint32_t slot = (uint32_t)(x.frame % x.n_bufs);
+    const auto te0 = std::chrono::steady_clock::now();
+    if (!x.signalled) HIP_TRY(ctx, hipStreamWriteValue32(ctx->stream, x.kernels_flag, (uint32_t)(x.frame + 1), 0));
+    x.signalled = false;
+    {
+        std::lock_guard<std::mutex> lk(x.m);
+        x.queue.push_back(slot);
+        ++x.submitted;
+    }
+    x.submitted_fast.fetch_add(1, std::memory_order_seq_cst);
+    if (x.sleeping.load(std::memory_order_seq_cst)) x.cv.notify_all();  // no futex call while the thread is polling
+    ++x.frame;
+    x.dbg_end_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - te0).count();
+    return MI_OK;
+}
+
+}  // namespace mi_detail
+
+extern "C" {
+
+// =============================================================================================
+// interop, timing
+// =============================================================================================
+int32_t mi_bind_visibility_output(mi_ctx* ctx, void* device_ptr, uint64_t words_per_view, uint64_t word_offset) {
+    ENTER(ctx);
+    ctx->ext_bitmask = device_ptr;
+    ctx->ext_words_per_view = words_per_view;
+    ctx->ext_word_offset = word_offset;
+    ctx->culled = false;
+    return MI_OK;
+}
+
+int32_t mi_exchange_configure(mi_ctx* ctx, void* nccl_comm, void* fn_nccl_all_gather, void* const* device_bufs, uint32_t n_bufs,
+                              uint64_t words_per_view, uint64_t word_offset, uint64_t block_bytes, uint32_t rank) {
+    void* comms[1] = {nccl_comm};
+    return mi_exchange_configure_multi(ctx, nccl_comm ? comms : nullptr, nccl_comm ? 1u : 0u, fn_nccl_all_gather, device_bufs, n_bufs,
+                                       words_per_view, word_offset, block_bytes, rank);
+}
+
+int32_t mi_exchange_configure_multi(mi_ctx* ctx, void* const* nccl_comms, uint32_t n_comms, void* fn_nccl_all_gather,
+                                    void* const* device_bufs, uint32_t n_bufs, uint64_t words_per_view, uint64_t word_offset,
+                                    uint64_t block_bytes, uint32_t rank) {
+    ENTER(ctx);
+    auto& x = ctx->xch;
+    void* const nccl_comm = (nccl_comms && n_comms) ? nccl_comms[0] : nullptr;
+    if (n_comms > mi_ctx::Exchange::MAX_COMMS) return fail(ctx, MI_ERR_INVALID_ARG, "mi_exchange_configure: at most %u communicators", mi_ctx::Exchange::MAX_COMMS);
+    for (uint32_t k = 0; k < n_comms; ++k)
+        if (!nccl_comms[k]) return fail(ctx, MI_ERR_INVALID_ARG, "mi_exchange_configure: communicator %u is NULL", k);
+    if (x.on) {  // drain whatever is in flight before changing anything
+        int32_t rc0 = exchange_wait_issued(ctx, x.frame);
+        exchange_stop(ctx);
+        for (hipStream_t cs : x.comm_stream)
+            if (cs) HIP_TRY(ctx, hipStreamSynchronize(cs));
+        x.on = false;
+        if (rc0) return rc0;
+    }
+    if (!nccl_comm) {  // off: back to the internal mask buffer
+        x.on = false;
+        ctx->ext_bitmask = nullptr;
+        ctx->culled = false;
+        return MI_OK;
+    }
+    if (!fn_nccl_all_gather || !device_bufs || n_bufs < 2 || n_bufs > mi_ctx::Exchange::MAX_BUFS || block_bytes == 0)
+        return fail(ctx, MI_ERR_INVALID_ARG, "mi_exchange_configure: NULL function / buffers, n_bufs outside 2..8, or empty block");
+    for (uint32_t i = 0; i < n_bufs; ++i)
+        if (!device_bufs[i]) return fail(ctx, MI_ERR_INVALID_ARG, "mi_exchange_configure: buffer %u is NULL", i);
+    if (!x.done_flag) HIP_TRY(ctx, hipHostMalloc((void**)&x.done_flag, 64, hipHostMallocMapped));
+    if (!x.kernels_flag) HIP_TRY(ctx, hipMalloc((void**)&x.kernels_flag, 64));
+    HIP_TRY(ctx, hipMemsetAsync(x.kernels_flag, 0, 64, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    x.kernel_signal = getenv("MI_XCH_NO_KERNEL_SIGNAL") == nullptr;
+    x.signalled = false;
+    if (!x.comm_stream[0]) {
+        for (uint32_t i = 0; i < mi_ctx::Exchange::MAX_BUFS; ++i) {
+            HIP_TRY(ctx, hipEventCreateWithFlags(&x.ev_kernels[i], hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&x.ev_gathered[i], hipEventDisableTiming));
+        }
+        // Pick the communication stream empirically.  HIP maps streams onto a small pool of hardware queues; if the
+        // communication stream lands on the compute stream's queue, its wait / record / write packets serialise with
+        // the frame kernels (measured: 32 us -> 48 us per frame), and which stream collides depends on how many
+        // streams the process created before.  So: make a few candidates (normal and high priority), drive each with
+        // the per-frame pattern over a stand-in kernel, keep the fastest.
+        int prio_lo = 0, prio_hi = 0;
+        HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        constexpr int N_CAND = 6;
+        hipStream_t cand[N_CAND] = {nullptr};
+        for (int i = 0; i < N_CAND; ++i) {
+            if (i == N_CAND - 1) HIP_TRY(ctx, hipStreamCreateWithPriority(&cand[i], hipStreamNonBlocking, prio_hi));
+            else HIP_TRY(ctx, hipStreamCreateWithFlags(&cand[i], hipStreamNonBlocking));
+        }
+        const size_t probe_words = (size_t)16 << 20;  // 64 MB clear: a stand-in for one frame of kernels
+        uint32_t* probe = nullptr;
+        HIP_TRY(ctx, hipMalloc((void**)&probe, probe_words * 4));
+        double cand_t[N_CAND];
+        for (int rep = 0; rep < 2; ++rep)
+            for (int i = 0; i < N_CAND; ++i) {
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                HIP_TRY(ctx, hipStreamSynchronize(cand[i]));
+                const auto t0 = std::chrono::steady_clock::now();
+                for (uint32_t it = 0; it < 24; ++it) {
+                    HIP_TRY(ctx, launch_clear_u32(probe, probe_words, ctx->stream));
+                    HIP_TRY(ctx, hipEventRecord(x.ev_kernels[it & 1u], ctx->stream));
+                    HIP_TRY(ctx, hipStreamWaitEvent(cand[i], x.ev_kernels[it & 1u], 0));
+                    HIP_TRY(ctx, hipEventRecord(x.ev_gathered[it & 1u], cand[i]));
+                    HIP_TRY(ctx, hipStreamWriteValue32(cand[i], (void*)x.done_flag, it + 1, 0));
+                }
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                HIP_TRY(ctx, hipStreamSynchronize(cand[i]));
+                const double t = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+                if (rep == 1) cand_t[i] = t;
+                if (getenv("MI_XCH_DEBUG")) fprintf(stderr, "[mi exchange] comm stream candidate %d%s: %.1f us / frame\n", i,
+                                                    i == N_CAND - 1 ? " (high priority)" : "", t / 24.0);
+            }
+        HIP_TRY(ctx, hipFree(probe));
+        int order[N_CAND];
+        std::iota(order, order + N_CAND, 0);
+        std::sort(order, order + N_CAND, [&](int a, int b) { return cand_t[a] < cand_t[b]; });
+        for (int i = 0; i < N_CAND; ++i) {  // keep the MAX_COMMS fastest, fastest first
+            if (i < (int)mi_ctx::Exchange::MAX_COMMS) x.comm_stream[i] = cand[order[i]];
+            else HIP_TRY(ctx, hipStreamDestroy(cand[order[i]]));
+        }
+    }
+    x.all_gather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))fn_nccl_all_gather;
+    x.n_comms = n_comms;
+    for (uint32_t k = 0; k < n_comms; ++k) x.comm[k] = nccl_comms[k];
+    x.n_bufs = n_bufs;
+    for (uint32_t i = 0; i < n_bufs; ++i) x.buf[i] = device_bufs[i];
+    x.words_per_view = words_per_view;
+    x.word_offset = word_offset;
+    x.block_bytes = block_bytes;
+    x.rank = rank;
+    for (uint32_t k = 0; k < mi_ctx::Exchange::MAX_COMMS; ++k) x.done_flag[k] = 0;
+    x.worker_frames = 0;
+    x.frame = 0;
+    x.submitted = x.issued = 0;
+    x.submitted_fast.store(0);
+    x.worker_error = 0;
+    x.queue.clear();
+    x.worker = std::thread(exchange_worker, ctx);
+    x.on = true;
+    ctx->culled = false;
+    return MI_OK;
+}
+
+int32_t mi_exchange_last(mi_ctx* ctx, void** out_device_buf, int32_t wait) {
+    ENTER(ctx);
+    auto& x = ctx->xch;
+    if (!x.on || x.frame == 0) return fail(ctx, MI_ERR_NOT_READY, "mi_exchange_last: no exchanged frame yet");
+    const uint32_t slot = (uint32_t)((x.frame - 1) % x.n_bufs);
+    int32_t rc = exchange_wait_issued(ctx, x.frame);
+    if (rc) return rc;
+    if (wait) HIP_TRY(ctx, hipEventSynchronize(x.ev_gathered[slot]));
+    if (out_device_buf) *out_device_buf = x.buf[slot];
+    return MI_OK;
+}
+
+}  // extern "C"

@@ -8,7 +8,8 @@
 A "step" is one frame of the hot path over device-resident columns with every Transform dirty:
   flat (default, BASELINE.json configs[1]): 1M flat entities per GPU, 1 camera frustum: ONE frame kernel
         (sync_simple_transforms + reset_view_visibility + check_visibility_cpu_culling + check_visibility_gpu_culling
-        + mark_newly_hidden_entities_invisible) and ONE VisibleEntities compaction kernel.
+        + mark_newly_hidden_entities_invisible) and ONE VisibleEntities compaction kernel (at N = 1 on the library's side
+        stream, overlapping the next frame's kernel; --inline-compaction keeps it on the caller's stream).
         With N > 1 GPUs every rank owns a 1M-row range of an N x 1M scene (weak scaling) and the packed
         ViewVisibility bitmasks are exchanged with ONE RCCL all-gather per frame.
   tree  (configs[4]): depth-12/branch-4 tree truncated to 1M nodes, root moved every frame, propagate only.
@@ -43,6 +44,9 @@ def parse():
     ap.add_argument("--views", type=int, default=1)
     ap.add_argument("--lights", type=int, default=100_000)
     ap.add_argument("--unfused", action="store_true", help="flat: mi_propagate + mi_cull instead of the fused kernel")
+    ap.add_argument("--inline-compaction", action="store_true",
+                    help="flat: keep the VisibleEntities compaction on the caller's stream (default at N=1: the library's side "
+                         "stream, overlapping the next frame's kernel; mi_set_async_compaction)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget")
@@ -102,6 +106,13 @@ def build_flat(ctx, args, rank, world, total_frames, full_holder):
         full_holder.append(gather)
         gather.attach(ctx)  # direct RCCL available: the library issues the exchange itself, one FFI call per frame
     py_exchange = gather is not None and not gather.native
+    async_compaction = False
+    if not args.inline_compaction and gather is None:
+        try:
+            ctx.set_async_compaction(True)
+            async_compaction = True
+        except api.MiError as e:  # stay on the inline path, say so in the result line
+            async_compaction = repr(e)
 
     def step(f):
         if py_exchange:
@@ -119,9 +130,11 @@ def build_flat(ctx, args, rank, world, total_frames, full_holder):
                           f"frustum(s), all Transforms dirty, columns resident in HBM: "
                           f"{'mi_propagate + mi_cull' if args.unfused else 'fused frame kernel'} (propagate + reset + frustum "
                           "cull + mark-newly-hidden) + VisibleEntities compaction"
+                          + (" (compaction of frame f on the library's side stream while frame f+1's kernel runs; every "
+                             "frame's lists are complete when the timed region ends)" if async_compaction is True else "")
                           + (f" + one in-place RCCL all-gather of the visibility bitmask per frame over {world} GPUs "
                              f"({gather.mode}, pipelined one frame deep on its own stream)" if gather is not None else ""),
-              "entities_per_gpu": n_local, "views": n_views, "parallelism": f"row-range shard x{world}"}
+              "entities_per_gpu": n_local, "views": n_views, "async_compaction": async_compaction, "parallelism": f"row-range shard x{world}"}
     if gather is not None and gather.fallback_reason:
         config["rccl_direct_fallback"] = gather.fallback_reason
     wl = Workload("flat", step, n_local, flat_bytes_per_entity(n_views, not args.unfused),

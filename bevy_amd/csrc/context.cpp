@@ -120,6 +120,7 @@ void prof_mark(void* vctx, uint32_t kernel) {
 void prof_collect(mi_ctx* ctx) {
     prof_close(ctx);
     hipStreamSynchronize(ctx->stream);
+    if (ctx->ac.stream && ctx->ac.released >= ctx->ac.frames) hipStreamSynchronize(ctx->ac.stream);  // (a pending frame is not waited for)
     for (auto& sp : ctx->spans) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
@@ -174,9 +175,9 @@ int32_t prepare_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, Visib
         out->word_offset = ctx->ext_word_offset;
     } else {
         ctx->words_per_view = padded_words(ctx->cap);
-        rc = ensure(ctx, ctx->bitmask, ctx->words_per_view * 8 * n_views);
+        rc = ensure(ctx, ctx->fb[ctx->cur].bitmask, ctx->words_per_view * 8 * n_views);
         if (rc) return rc;
-        out->bitmask = (uint64_t*)ctx->bitmask.p;
+        out->bitmask = (uint64_t*)ctx->fb[ctx->cur].bitmask.p;
         out->words_per_view = ctx->words_per_view;
         out->word_offset = 0;
     }
@@ -219,19 +220,24 @@ int32_t prepare_segments(mi_ctx* ctx, uint32_t n_views, SegOut* seg) {
     ctx->compact_classes = k;
     ctx->compact_fast = ctx->order_identity;
     memset(seg, 0, sizeof *seg);
+    if (ctx->ac.on && !ctx->xch.on && ctx->n > 0) {  // every frame kernel releases the side-stream compactions of the frames before it
+        seg->start_signal = ctx->ac.started;
+        seg->start_value = (uint32_t)ctx->ac.frames;
+        ctx->ac.released = ctx->ac.frames;
+    }
     seg->n_classes = k;
     for (uint32_t i = 0; i < k; ++i) seg->class_bits[i] = (uint8_t)ctx->class_bits[i];
     seg->class_mask = nullptr;
     if (!ctx->compact_fast) return MI_OK;  // general path reads class_mask itself
     const size_t segs = (size_t)n_views * k;
     seg->n_waves = (uint32_t)((padded_words(ctx->cap) + 63u) / 64u * 64u);
-    if ((rc = ensure(ctx, ctx->wave_cnt, segs * seg->n_waves))) return rc;
-    seg->wave_cnt = (uint8_t*)ctx->wave_cnt.p;
+    if ((rc = ensure(ctx, ctx->fb[ctx->cur].wave_cnt, segs * seg->n_waves))) return rc;
+    seg->wave_cnt = (uint8_t*)ctx->fb[ctx->cur].wave_cnt.p;
     if (ctx->have_class_mask) {
         seg->class_mask = ctx->class_mask;
         seg->seg_words = padded_words(ctx->cap);
-        if ((rc = ensure(ctx, ctx->seg_mask, segs * seg->seg_words * 8))) return rc;
-        seg->seg_mask = (uint64_t*)ctx->seg_mask.p;
+        if ((rc = ensure(ctx, ctx->fb[ctx->cur].seg_mask, segs * seg->seg_words * 8))) return rc;
+        seg->seg_mask = (uint64_t*)ctx->fb[ctx->cur].seg_mask.p;
     }
     return MI_OK;
 }
@@ -240,9 +246,9 @@ int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg) 
     int32_t rc;
     const uint32_t n_classes = ctx->compact_classes;
     const size_t segs = (size_t)ctx->n_views * n_classes;
-    if ((rc = ensure(ctx, ctx->seg_totals, segs * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->fb[ctx->cur].seg_totals, segs * 4))) return rc;
     if (ctx->n == 0) {
-        HIP_TRY(ctx, hipMemsetAsync(ctx->seg_totals.p, 0, segs * 4, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->fb[ctx->cur].seg_totals.p, 0, segs * 4, ctx->stream));
         return MI_OK;
     }
     if (ctx->compact_fast) {
@@ -258,14 +264,29 @@ int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg) 
         f.words_per_view = vo.words_per_view;
         f.word_offset = vo.word_offset;
         ctx->seg_stride = ctx->cap;
-        if ((rc = ensure(ctx, ctx->out_rows, segs * ctx->seg_stride * 4))) return rc;
-        f.out_rows = (uint32_t*)ctx->out_rows.p;
+        if ((rc = ensure(ctx, ctx->fb[ctx->cur].out_rows, segs * ctx->seg_stride * 4))) return rc;
+        f.out_rows = (uint32_t*)ctx->fb[ctx->cur].out_rows.p;
         f.seg_stride = ctx->seg_stride;
-        f.seg_totals = (uint32_t*)ctx->seg_totals.p;
+        f.seg_totals = (uint32_t*)ctx->fb[ctx->cur].seg_totals.p;
         if (ctx->xch.on && ctx->xch.kernel_signal) {
             f.signal = ctx->xch.kernels_flag;
             f.signal_value = (uint32_t)(ctx->xch.frame + 1);
             ctx->xch.signalled = true;
+        }
+        if (ctx->ac.on && !ctx->xch.on) {
+            // Asynchronous compaction: frame F's lists are built on the side stream once "frame kernel F has completed"
+            // is published -- by the next frame kernel's first workgroup, or by compaction_join's write-value packet --
+            // so the caller's stream goes straight on to the next frame.
+            auto& ac = ctx->ac;
+            const uint32_t want = (uint32_t)(ac.frames + 1);
+            HIP_TRY(ctx, hipStreamWaitValue32(ac.stream, ac.started, want, hipStreamWaitValueGte, 0xFFFFFFFFu));
+            {
+                ProfScope ps(ctx, K_COMPACT_FAST);
+                HIP_TRY(ctx, launch_compact_fast(f, ac.stream));
+            }
+            HIP_TRY(ctx, hipStreamWriteValue32(ac.stream, (void*)ac.done, want, 0));
+            ++ac.frames;
+            return MI_OK;
         }
         ProfScope ps(ctx, K_COMPACT_FAST);
         HIP_TRY(ctx, launch_compact_fast(f, ctx->stream));
@@ -287,14 +308,50 @@ int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg) 
     if ((rc = ensure(ctx, ctx->seg_bases, segs * 8))) return rc;
     // worst case: every row of every view in every class it belongs to
     const size_t max_entries = (size_t)a.n_views * ctx->cap * (ctx->have_class_mask ? a.n_classes : 1);
-    if ((rc = ensure(ctx, ctx->out_rows, max_entries * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->fb[ctx->cur].out_rows, max_entries * 4))) return rc;
     if ((rc = ensure(ctx, ctx->out_keys, max_entries * 8))) return rc;
     a.block_counts = (uint32_t*)ctx->block_counts.p;
-    a.seg_totals = (uint32_t*)ctx->seg_totals.p;
+    a.seg_totals = (uint32_t*)ctx->fb[ctx->cur].seg_totals.p;
     a.seg_bases = (uint64_t*)ctx->seg_bases.p;
-    a.out_rows = (uint32_t*)ctx->out_rows.p;
+    a.out_rows = (uint32_t*)ctx->fb[ctx->cur].out_rows.p;
     a.out_keys = (uint64_t*)ctx->out_keys.p;
     HIP_TRY(ctx, launch_compact(a, ctx->stream, prof_mark, ctx));
+    return MI_OK;
+}
+
+// Start of a cull frame.  With asynchronous compaction the frame takes the next buffer set of the ring, after the
+// compaction that last used it (N_FB frames ago) has completed -- checked on the host, on the pinned counter the side
+// stream bumps; the packet that released that compaction was enqueued N_FB - 1 frames ago, so this cannot deadlock.
+int32_t frame_begin(mi_ctx* ctx) {
+    auto& ac = ctx->ac;
+    if (!ac.on || ctx->xch.on) return MI_OK;
+    ctx->cur = (uint32_t)(ac.frames % mi_ctx::N_FB);
+    if (ac.frames >= mi_ctx::N_FB) {
+        const uint64_t need = ac.frames - mi_ctx::N_FB + 1;
+        const auto t0 = std::chrono::steady_clock::now();
+        uint32_t spins = 0;
+        while ((uint64_t)*ac.done < need) {
+            if ((++spins & 4095u) == 0) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
+                    return fail(ctx, MI_ERR_DEVICE, "asynchronous compaction of frame %llu did not complete within 30 s", (unsigned long long)(need - 1));
+                std::this_thread::yield();
+            }
+        }
+    }
+    return MI_OK;
+}
+
+// Everything that exposes VisibleEntities (downloads, the batching build, MI_BUF_VISIBLE_ROWS, mi_synchronize) joins
+// first: the last frame's compaction is released with a write-value packet behind its frame kernel if no later frame
+// kernel has done so, then the side stream is drained.
+int32_t compaction_join(mi_ctx* ctx) {
+    auto& ac = ctx->ac;
+    if (!ac.stream || ac.frames == 0) return MI_OK;
+    if (ac.released < ac.frames) {
+        HIP_TRY(ctx, hipStreamWriteValue32(ctx->stream, ac.started, (uint32_t)ac.frames, 0));
+        ac.released = ac.frames;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ac.stream));
     return MI_OK;
 }
 
@@ -355,6 +412,7 @@ int32_t mi_ctx_create(int32_t device, void* hip_stream, mi_ctx** out_ctx) {
 int32_t mi_ctx_destroy(mi_ctx* ctx) {
     if (!ctx) return MI_OK;
     hipSetDevice(ctx->device);
+    compaction_join(ctx);
     hipStreamSynchronize(ctx->stream);
     prof_collect(ctx);
     void* cols[] = {ctx->t, ctx->r, ctx->s, ctx->g, ctx->c, ctx->h, ctx->flags, ctx->vv, ctx->changed, ctx->g_changed_bytes,
@@ -362,8 +420,8 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
                     ctx->range, ctx->visibility, ctx->inh_changed, ctx->bt_set, ctx->bt_bin, ctx->bt_input, ctx->bt_row_meta};
     for (void* p : cols)
         if (p) hipFree(p);
-    DevBuf* bufs[] = {&ctx->order, &ctx->chains, &ctx->snap, &ctx->inh_bits, &ctx->sparse_cnt, &ctx->sparse_rows, &ctx->sparse_total, &ctx->sparse_g, &ctx->parent_idx, &ctx->node_flags, &ctx->tiles, &ctx->views, &ctx->bitmask,
-                      &ctx->block_counts, &ctx->seg_totals, &ctx->seg_bases, &ctx->out_rows, &ctx->out_keys, &ctx->wave_cnt, &ctx->seg_mask, &ctx->cl_pos,
+    DevBuf* bufs[] = {&ctx->order, &ctx->chains, &ctx->snap, &ctx->inh_bits, &ctx->sparse_cnt, &ctx->sparse_rows, &ctx->sparse_total, &ctx->sparse_g, &ctx->parent_idx, &ctx->node_flags, &ctx->tiles, &ctx->views,
+                      &ctx->block_counts, &ctx->seg_bases, &ctx->out_keys, &ctx->cl_pos,
                       &ctx->cl_type, &ctx->cl_layers, &ctx->cl_dir, &ctx->cl_sincos, &ctx->cl_planes, &ctx->cl_spheres,
                       &ctx->bt_set_indexed, &ctx->bt_table_off, &ctx->bt_table, &ctx->bt_meta_off, &ctx->bt_meta, &ctx->bt_rows_a, &ctx->bt_rows_b,
                       &ctx->bt_hist, &ctx->bt_set_count, &ctx->bt_set_scan, &ctx->bt_counters, &ctx->bt_wi[0], &ctx->bt_wi[1], &ctx->bt_md[0],
@@ -372,6 +430,15 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
                       &ctx->cl_offsets, &ctx->cl_indices, &ctx->cl_scalars};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
+    if (ctx->ac.stream) {
+        hipStreamSynchronize(ctx->ac.stream);
+        hipStreamDestroy(ctx->ac.stream);
+    }
+    if (ctx->ac.started) hipFree(ctx->ac.started);
+    if (ctx->ac.done) hipHostFree((void*)ctx->ac.done);
+    for (auto& f : ctx->fb)
+        for (DevBuf* b : {&f.bitmask, &f.wave_cnt, &f.seg_mask, &f.out_rows, &f.seg_totals})
+            if (b->p) hipFree(b->p);
     if (ctx->stage) hipHostFree(ctx->stage);
     if (ctx->timer_a) hipEventDestroy(ctx->timer_a);
     if (ctx->timer_b) hipEventDestroy(ctx->timer_b);
@@ -406,6 +473,10 @@ const char* mi_last_error_string(mi_ctx* ctx) {
 
 int32_t mi_synchronize(mi_ctx* ctx) {
     ENTER(ctx);
+    {
+        int32_t rcj = compaction_join(ctx);
+        if (rcj) return rcj;
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->xch.on) {
         int32_t rc = exchange_wait_issued(ctx, ctx->xch.frame);
@@ -421,6 +492,10 @@ int32_t mi_synchronize(mi_ctx* ctx) {
 // =============================================================================================
 int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
     ENTER(ctx);
+    {
+        int32_t rcj = compaction_join(ctx);  // buffers may move
+        if (rcj) return rcj;
+    }
     ctx->bt_resolve = true;
     ctx->changed_maybe = true;
     if (n_rows > ctx->cap) {
@@ -736,8 +811,9 @@ void simple_views(std::vector<mi_view>& v, const float* frusta, const uint32_t* 
 int32_t mi_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint32_t flags) {
     ENTER(ctx);
     VisibilityOut vo{};
-    int32_t rc = exchange_begin(ctx);
+    int32_t rc = frame_begin(ctx);
     if (rc) return rc;
+    if ((rc = exchange_begin(ctx))) return rc;
     if ((rc = prepare_views(ctx, views, n_views, &vo))) return rc;
     SegOut seg;
     if ((rc = prepare_segments(ctx, n_views, &seg))) return rc;
@@ -764,8 +840,9 @@ int32_t mi_propagate_and_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t 
     if (ctx->have_hierarchy)
         return fail(ctx, MI_ERR_NOT_READY, "mi_propagate_and_cull is the flat fast path; a hierarchy is uploaded -- use mi_propagate + mi_cull");
     VisibilityOut vo{};
-    int32_t rc = exchange_begin(ctx);
+    int32_t rc = frame_begin(ctx);
     if (rc) return rc;
+    if ((rc = exchange_begin(ctx))) return rc;
     if ((rc = prepare_views(ctx, views, n_views, &vo))) return rc;
     SegOut seg;
     if ((rc = prepare_segments(ctx, n_views, &seg))) return rc;
@@ -933,7 +1010,7 @@ int32_t mi_download_visibility(mi_ctx* ctx, uint32_t view, uint32_t* bitmask) {
     if (view >= ctx->n_views || !bitmask) return fail(ctx, MI_ERR_INVALID_ARG, "mi_download_visibility: bad view or NULL");
     const uint64_t* base;
     if (ctx->ext_bitmask) base = (const uint64_t*)ctx->ext_bitmask + view * ctx->ext_words_per_view + ctx->ext_word_offset;
-    else base = (const uint64_t*)ctx->bitmask.p + view * ctx->words_per_view;
+    else base = (const uint64_t*)ctx->fb[ctx->cur].bitmask.p + view * ctx->words_per_view;
     const size_t words32 = ((size_t)ctx->n + 31) / 32;
     int32_t rc = download(ctx, bitmask, base, words32 * 4);
     if (rc) return rc;
@@ -959,6 +1036,10 @@ int32_t mi_download_visible_entities(mi_ctx* ctx, uint32_t view, uint32_t class_
                                      uint32_t capacity, uint32_t* out_count) {
     ENTER(ctx);
     if (!ctx->culled) return fail(ctx, MI_ERR_NOT_READY, "mi_download_visible_entities before mi_cull");
+    {
+        int32_t rcj = compaction_join(ctx);
+        if (rcj) return rcj;
+    }
     if (view >= ctx->compact_views || !out_count) return fail(ctx, MI_ERR_INVALID_ARG, "mi_download_visible_entities: bad view or NULL out_count");
     uint32_t slot = 0xFFFFFFFFu;
     for (uint32_t k = 0; k < ctx->compact_classes; ++k)
@@ -971,7 +1052,7 @@ int32_t mi_download_visible_entities(mi_ctx* ctx, uint32_t view, uint32_t class_
     uint32_t total = 0;
     uint64_t base = 0;
     int32_t rc;
-    if ((rc = download(ctx, &total, (const uint32_t*)ctx->seg_totals.p + seg, 4))) return rc;
+    if ((rc = download(ctx, &total, (const uint32_t*)ctx->fb[ctx->cur].seg_totals.p + seg, 4))) return rc;
     *out_count = total;
     if (total > capacity) return fail(ctx, MI_ERR_CAPACITY, "visible list has %u entries, capacity %u", total, capacity);
     if (ctx->compact_fast) {
@@ -980,14 +1061,37 @@ int32_t mi_download_visible_entities(mi_ctx* ctx, uint32_t view, uint32_t class_
         std::vector<uint32_t> tmp;
         uint32_t* rows = out_rows;
         if (!rows && out_keys) { tmp.resize(total); rows = tmp.data(); }
-        if (rows && (rc = download(ctx, rows, (const uint32_t*)ctx->out_rows.p + base, (size_t)total * 4))) return rc;
+        if (rows && (rc = download(ctx, rows, (const uint32_t*)ctx->fb[ctx->cur].out_rows.p + base, (size_t)total * 4))) return rc;
         if (out_keys)
             for (uint32_t i = 0; i < total; ++i) out_keys[i] = ctx->have_keys ? ctx->h_keys[rows[i]] : (uint64_t)rows[i];
         return MI_OK;
     }
     if ((rc = download(ctx, &base, (const uint64_t*)ctx->seg_bases.p + seg, 8))) return rc;
     if (out_keys && (rc = download(ctx, out_keys, (const uint64_t*)ctx->out_keys.p + base, (size_t)total * 8))) return rc;
-    if (out_rows && (rc = download(ctx, out_rows, (const uint32_t*)ctx->out_rows.p + base, (size_t)total * 4))) return rc;
+    if (out_rows && (rc = download(ctx, out_rows, (const uint32_t*)ctx->fb[ctx->cur].out_rows.p + base, (size_t)total * 4))) return rc;
+    return MI_OK;
+}
+
+int32_t mi_set_async_compaction(mi_ctx* ctx, int32_t enabled) {
+    ENTER(ctx);
+    auto& ac = ctx->ac;
+    int32_t rc = compaction_join(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (enabled && !ac.stream) {
+        if ((rc = pick_side_streams(ctx, &ac.stream, 1))) return rc;
+        HIP_TRY(ctx, hipMalloc((void**)&ac.started, 64));
+        HIP_TRY(ctx, hipHostMalloc((void**)&ac.done, 64, hipHostMallocMapped));
+    }
+    if (ac.started) {
+        HIP_TRY(ctx, hipMemsetAsync(ac.started, 0, 64, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        *ac.done = 0;
+    }
+    ac.frames = ac.released = 0;
+    ac.on = enabled != 0;
+    if (!ac.on) ctx->cur = 0;
+    ctx->culled = false;
     return MI_OK;
 }
 
@@ -1000,10 +1104,16 @@ int32_t mi_device_buffer(mi_ctx* ctx, uint32_t which, void** out_ptr, uint64_t* 
     case MI_BUF_GLOBAL_TRANSFORM: p = ctx->g; bytes = (uint64_t)ctx->n * 48; break;
     case MI_BUF_VISIBILITY_BITMASK:
         if (ctx->ext_bitmask) { p = ctx->ext_bitmask; bytes = ctx->ext_words_per_view * 8 * ctx->n_views; }
-        else { p = ctx->bitmask.p; bytes = ctx->words_per_view * 8 * ctx->n_views; }
+        else { p = ctx->fb[ctx->cur].bitmask.p; bytes = ctx->words_per_view * 8 * ctx->n_views; }
         break;
     case MI_BUF_VIEW_VISIBILITY: p = ctx->vv; bytes = ctx->n; break;
-    case MI_BUF_VISIBLE_ROWS: p = ctx->out_rows.p; bytes = ctx->out_rows.bytes; break;
+    case MI_BUF_VISIBLE_ROWS: {
+        int32_t rcj = compaction_join(ctx);  // asynchronous compaction: the lists are complete when this returns
+        if (rcj) return rcj;
+        p = ctx->fb[ctx->cur].out_rows.p;
+        bytes = ctx->fb[ctx->cur].out_rows.bytes;
+        break;
+    }
     case MI_BUF_CLUSTER_OFFSETS_AND_COUNTS: p = ctx->cl_bind_oc.p; bytes = ctx->cl_bind_oc.bytes; break;
     case MI_BUF_CLUSTER_INDEX_LIST: p = ctx->cl_bind_idx.p; bytes = ctx->cl_bind_idx.bytes; break;
     case MI_BUF_BATCH_WORK_ITEMS_NON_INDEXED: p = ctx->bt_wi[0].p; bytes = ctx->bt_wi[0].bytes; break;

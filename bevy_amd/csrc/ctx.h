@@ -84,7 +84,6 @@ struct mi_ctx {
     // ---- views / visibility ----
     DevBuf views;
     uint32_t n_views = 0;
-    DevBuf bitmask;
     uint64_t words_per_view = 0;
     // multi-GPU exchange (mi_exchange_configure): in-place all-gather of the masks after every cull
     struct Exchange {
@@ -132,7 +131,24 @@ struct mi_ctx {
     mi::ViewSet view_set{};      // views passed by value when n_views <= mi::MAX_INLINE_VIEWS
     bool views_inline = false;
     // compaction
-    DevBuf block_counts, seg_totals, seg_bases, out_rows, out_keys, wave_cnt, seg_mask;
+    DevBuf block_counts, seg_bases, out_keys;
+    // What one cull frame leaves behind: the view masks (unless bound elsewhere), the by-products the compaction
+    // consumes and the lists it writes.  One set normally; with asynchronous compaction (mi_set_async_compaction) a
+    // ring of N_FB sets, frame f using set f % N_FB, because the compaction of frame f runs on a side stream while the
+    // frame kernels of the following frames run on the caller's.
+    static constexpr uint32_t N_FB = 4;
+    struct FrameBufs {
+        DevBuf bitmask, wave_cnt, seg_mask, out_rows, seg_totals;
+    } fb[N_FB];
+    uint32_t cur = 0;  // set of the current / last frame
+    struct AsyncCompaction {
+        bool on = false;
+        hipStream_t stream = nullptr;
+        uint32_t* started = nullptr;          // device word: k_frame of async frame F stores F at its start ("frames < F are complete")
+        volatile uint32_t* done = nullptr;    // pinned host word: async frames whose compaction has completed
+        uint64_t frames = 0;                  // async cull frames issued
+        uint64_t released = 0;                // ... of which this many have had their "complete" signal enqueued or implied
+    } ac;
     uint32_t compact_views = 0, compact_classes = 0;
     uint32_t class_bits[32] = {0};
     bool compact_fast = false;   // last compaction used the single-launch path (out_rows strided per segment)
@@ -250,7 +266,10 @@ Columns columns_of(mi_ctx* ctx);
 int32_t prepare_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, VisibilityOut* out);
 int32_t prepare_segments(mi_ctx* ctx, uint32_t n_views, SegOut* seg);
 int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg);
+int32_t frame_begin(mi_ctx* ctx);       // picks the frame's buffer set (asynchronous compaction: ring + pacing)
+int32_t compaction_join(mi_ctx* ctx);   // makes every issued frame's VisibleEntities lists complete (host-side wait)
 // ctx_exchange.cpp
+int32_t pick_side_streams(mi_ctx* ctx, hipStream_t* out, uint32_t n_keep);
 int32_t exchange_begin(mi_ctx* ctx);
 int32_t exchange_end(mi_ctx* ctx);
 int32_t exchange_wait_issued(mi_ctx* ctx, uint64_t upto);

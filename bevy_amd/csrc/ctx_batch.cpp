@@ -66,6 +66,10 @@ int32_t mi_batch_upload_sets(mi_ctx* ctx, uint32_t n_sets, const uint8_t* set_in
 int32_t mi_batch_build(mi_ctx* ctx, uint32_t view, uint32_t class_bit, const mi_batch_initial* initial) {
     ENTER(ctx);
     if (!ctx->culled) return fail(ctx, MI_ERR_NOT_READY, "mi_batch_build before mi_cull");
+    {
+        int32_t rcj = compaction_join(ctx);  // asynchronous compaction: the list this build reads must be complete
+        if (rcj) return rcj;
+    }
     if (!ctx->bt_have_sets || !ctx->bt_have_rows) return fail(ctx, MI_ERR_NOT_READY, "mi_batch_build before mi_batch_upload_rows / mi_batch_upload_sets");
     if (view >= ctx->compact_views) return fail(ctx, MI_ERR_INVALID_ARG, "mi_batch_build: view %u of %u", view, ctx->compact_views);
     static_assert(sizeof(mi_batch_initial) == sizeof(BatchInitial), "mi_batch_initial layout");
@@ -123,12 +127,12 @@ int32_t mi_batch_build(mi_ctx* ctx, uint32_t view, uint32_t class_bit, const mi_
         return MI_OK;
     }
     const uint32_t seg = view * ctx->compact_classes + slot;
-    a.list_count = (const uint32_t*)ctx->seg_totals.p + seg;
+    a.list_count = (const uint32_t*)ctx->fb[ctx->cur].seg_totals.p + seg;
     if (ctx->compact_fast) {
-        a.list = (const uint32_t*)ctx->out_rows.p + (size_t)seg * ctx->seg_stride;
+        a.list = (const uint32_t*)ctx->fb[ctx->cur].out_rows.p + (size_t)seg * ctx->seg_stride;
         a.list_base = nullptr;
     } else {
-        a.list = (const uint32_t*)ctx->out_rows.p;
+        a.list = (const uint32_t*)ctx->fb[ctx->cur].out_rows.p;
         a.list_base = (const uint64_t*)ctx->seg_bases.p + seg;
     }
     a.row_set = ctx->bt_set;

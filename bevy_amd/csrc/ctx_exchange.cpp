@@ -6,6 +6,66 @@ using namespace mi_detail;
 
 namespace mi_detail {
 
+// Side streams are picked empirically.  HIP maps streams onto a small pool of hardware queues; if a side stream lands
+// on the compute stream's queue, its wait / record / write packets serialise with the frame kernels (measured: 32 us
+// -> 48 us per frame), and which stream collides depends on how many streams the process created before.  So: make a
+// few candidates (normal and high priority), drive each with the per-frame pattern over a stand-in kernel, and keep
+// the n_keep fastest, fastest first.
+int32_t pick_side_streams(mi_ctx* ctx, hipStream_t* out, uint32_t n_keep) {
+    int prio_lo = 0, prio_hi = 0;
+    HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    constexpr int N_CAND = 6;
+    hipStream_t cand[N_CAND] = {nullptr};
+    for (int i = 0; i < N_CAND; ++i) {
+        if (i == N_CAND - 1) HIP_TRY(ctx, hipStreamCreateWithPriority(&cand[i], hipStreamNonBlocking, prio_hi));
+        else HIP_TRY(ctx, hipStreamCreateWithFlags(&cand[i], hipStreamNonBlocking));
+    }
+    hipEvent_t ev_a[2], ev_b[2];
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ev_a[i], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ev_b[i], hipEventDisableTiming));
+    }
+    uint32_t* flag = nullptr;
+    HIP_TRY(ctx, hipHostMalloc((void**)&flag, 64, hipHostMallocMapped));
+    const size_t probe_words = (size_t)16 << 20;  // 64 MB clear: a stand-in for one frame of kernels
+    uint32_t* probe = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&probe, probe_words * 4));
+    double cand_t[N_CAND];
+    for (int rep = 0; rep < 2; ++rep)
+        for (int i = 0; i < N_CAND; ++i) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(cand[i]));
+            const auto t0 = std::chrono::steady_clock::now();
+            for (uint32_t it = 0; it < 24; ++it) {
+                HIP_TRY(ctx, launch_clear_u32(probe, probe_words, ctx->stream));
+                HIP_TRY(ctx, hipEventRecord(ev_a[it & 1u], ctx->stream));
+                HIP_TRY(ctx, hipStreamWaitEvent(cand[i], ev_a[it & 1u], 0));
+                HIP_TRY(ctx, hipEventRecord(ev_b[it & 1u], cand[i]));
+                HIP_TRY(ctx, hipStreamWriteValue32(cand[i], (void*)flag, it + 1, 0));
+            }
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(cand[i]));
+            const double t = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            if (rep == 1) cand_t[i] = t;
+            if (getenv("MI_XCH_DEBUG")) fprintf(stderr, "[mi side stream] candidate %d%s: %.1f us / frame\n", i,
+                                                i == N_CAND - 1 ? " (high priority)" : "", t / 24.0);
+        }
+    HIP_TRY(ctx, hipFree(probe));
+    HIP_TRY(ctx, hipHostFree(flag));
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(ctx, hipEventDestroy(ev_a[i]));
+        HIP_TRY(ctx, hipEventDestroy(ev_b[i]));
+    }
+    int order[N_CAND];
+    std::iota(order, order + N_CAND, 0);
+    std::sort(order, order + N_CAND, [&](int a, int b) { return cand_t[a] < cand_t[b]; });
+    for (int i = 0; i < N_CAND; ++i) {
+        if (i < (int)n_keep) out[i] = cand[order[i]];
+        else HIP_TRY(ctx, hipStreamDestroy(cand[order[i]]));
+    }
+    return MI_OK;
+}
+
 // Multi-GPU exchange around a cull: bind this frame's gathered buffer (after its previous all-gather drained),
 // and afterwards hand the in-place all-gather to the exchange thread, which enqueues it on the communication
 // stream behind the kernels.
@@ -197,50 +257,8 @@ int32_t mi_exchange_configure_multi(mi_ctx* ctx, void* const* nccl_comms, uint32
             HIP_TRY(ctx, hipEventCreateWithFlags(&x.ev_kernels[i], hipEventDisableTiming));
             HIP_TRY(ctx, hipEventCreateWithFlags(&x.ev_gathered[i], hipEventDisableTiming));
         }
-        // Pick the communication stream empirically.  HIP maps streams onto a small pool of hardware queues; if the
-        // communication stream lands on the compute stream's queue, its wait / record / write packets serialise with
-        // the frame kernels (measured: 32 us -> 48 us per frame), and which stream collides depends on how many
-        // streams the process created before.  So: make a few candidates (normal and high priority), drive each with
-        // the per-frame pattern over a stand-in kernel, keep the fastest.
-        int prio_lo = 0, prio_hi = 0;
-        HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        constexpr int N_CAND = 6;
-        hipStream_t cand[N_CAND] = {nullptr};
-        for (int i = 0; i < N_CAND; ++i) {
-            if (i == N_CAND - 1) HIP_TRY(ctx, hipStreamCreateWithPriority(&cand[i], hipStreamNonBlocking, prio_hi));
-            else HIP_TRY(ctx, hipStreamCreateWithFlags(&cand[i], hipStreamNonBlocking));
-        }
-        const size_t probe_words = (size_t)16 << 20;  // 64 MB clear: a stand-in for one frame of kernels
-        uint32_t* probe = nullptr;
-        HIP_TRY(ctx, hipMalloc((void**)&probe, probe_words * 4));
-        double cand_t[N_CAND];
-        for (int rep = 0; rep < 2; ++rep)
-            for (int i = 0; i < N_CAND; ++i) {
-                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-                HIP_TRY(ctx, hipStreamSynchronize(cand[i]));
-                const auto t0 = std::chrono::steady_clock::now();
-                for (uint32_t it = 0; it < 24; ++it) {
-                    HIP_TRY(ctx, launch_clear_u32(probe, probe_words, ctx->stream));
-                    HIP_TRY(ctx, hipEventRecord(x.ev_kernels[it & 1u], ctx->stream));
-                    HIP_TRY(ctx, hipStreamWaitEvent(cand[i], x.ev_kernels[it & 1u], 0));
-                    HIP_TRY(ctx, hipEventRecord(x.ev_gathered[it & 1u], cand[i]));
-                    HIP_TRY(ctx, hipStreamWriteValue32(cand[i], (void*)x.done_flag, it + 1, 0));
-                }
-                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-                HIP_TRY(ctx, hipStreamSynchronize(cand[i]));
-                const double t = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-                if (rep == 1) cand_t[i] = t;
-                if (getenv("MI_XCH_DEBUG")) fprintf(stderr, "[mi exchange] comm stream candidate %d%s: %.1f us / frame\n", i,
-                                                    i == N_CAND - 1 ? " (high priority)" : "", t / 24.0);
-            }
-        HIP_TRY(ctx, hipFree(probe));
-        int order[N_CAND];
-        std::iota(order, order + N_CAND, 0);
-        std::sort(order, order + N_CAND, [&](int a, int b) { return cand_t[a] < cand_t[b]; });
-        for (int i = 0; i < N_CAND; ++i) {  // keep the MAX_COMMS fastest, fastest first
-            if (i < (int)mi_ctx::Exchange::MAX_COMMS) x.comm_stream[i] = cand[order[i]];
-            else HIP_TRY(ctx, hipStreamDestroy(cand[order[i]]));
-        }
+        int32_t rcp = pick_side_streams(ctx, x.comm_stream, mi_ctx::Exchange::MAX_COMMS);
+        if (rcp) return rcp;
     }
     x.all_gather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))fn_nccl_all_gather;
     x.n_comms = n_comms;

@@ -90,6 +90,10 @@ struct SegOut {
     uint64_t* seg_mask;
     uint64_t seg_words;
     uint8_t class_bits[32];      // class bit of each class slot
+    // Asynchronous compaction: workgroup 0 of the frame kernel publishes `start_value` at its start -- "every frame
+    // kernel enqueued before this one has completed" -- which releases the side-stream compaction of the previous frame.
+    uint32_t* start_signal;
+    uint32_t start_value;
 };
 
 // mi_cull / mi_propagate_and_cull flags (MI_CULL_* in the public header)

@@ -178,6 +178,8 @@ template <bool PROPAGATE, bool INLINE_VIEWS>
 __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const ViewParams* __restrict__ dviews,
                                                 uint32_t n_views, VisibilityOut out, SegOut seg, uint32_t fl_frame) {
     __shared__ float4 lds_g[4][192];
+    if (seg.start_signal && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(seg.start_signal, seg.start_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const uint32_t row = blockIdx.x * 256u + threadIdx.x;
     const bool live = row < c.n;
     const uint32_t wave = row >> 6;

@@ -455,6 +455,16 @@ int32_t mi_compute_frustum(const float clip_from_view[16], const float camera_af
  * Pass device_ptr = NULL to go back to the internal buffer. */
 int32_t mi_bind_visibility_output(mi_ctx* ctx, void* device_ptr, uint64_t words_per_view, uint64_t word_offset);
 
+/* Asynchronous VisibleEntities compaction (off by default).  The compaction of frame f then runs on a library-owned
+ * side stream as soon as f's frame kernel has completed, while the caller's stream goes straight on to whatever comes
+ * next -- in a loop of frames, the next frame kernel, whose first workgroup is also what tells the side stream that
+ * frame f is complete (no event or marker packet between the frames).  The frame's outputs rotate through a ring of
+ * four buffer sets.  Every entry point that exposes the lists joins first -- mi_download_visible_entities,
+ * mi_batch_build, mi_device_buffer(MI_BUF_VISIBLE_ROWS), mi_synchronize, mi_columns_resize -- so results are the
+ * same as with the compaction inline; only when they become available changes.  Masks and ViewVisibility are
+ * unaffected (complete in stream order).  Ignored while the multi-GPU exchange is on. */
+int32_t mi_set_async_compaction(mi_ctx* ctx, int32_t enabled);
+
 /* The exchange itself, issued by the library: after every mi_cull / mi_propagate_and_cull the packed masks are
  * all-gathered IN PLACE across the ranks of an RCCL communicator.  The kernels write frame f's masks straight into
  * gathered buffer f % n_bufs; a library-owned host thread enqueues ncclAllGather on a library-owned communication

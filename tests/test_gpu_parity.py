@@ -917,3 +917,55 @@ def test_static_frames_change_nothing_and_report_nothing(ctx_factory, tree):
     assert chg2[row] and 1 <= chg2.sum() < n
     ctx.propagate(flags)
     assert not ctx.download_global_transforms()[1].any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_classes", [False, True])
+def test_async_compaction_matches_inline(ctx_factory, with_classes):
+    """mi_set_async_compaction: frame f's lists are built on a side stream while the caller's stream runs the next
+    frames (released by the next frame kernel's first workgroup, or by the join).  Whatever is read -- after every
+    frame, after a burst of frames with nothing read in between, through the batching build, after switching back --
+    must be what the inline compaction gives."""
+    n = 300_000 + 77
+    sc = W.many_cubes(n, radius=300.0, ragged_flags=True)
+    cams = [frusta_for([W.many_cubes_camera(f, yaw=0.0), W.many_cubes_camera(f, yaw=2.0)]) for f in range(16)]
+    cm = (1 + (np.arange(n) % 3 == 0) * 2 + (np.arange(n) % 5 == 0) * 4).astype(np.uint32)
+    bs = W.batching_scene(n, n_sets=5, seed=9)
+    classes = (0, 1, 2) if with_classes else (0,)
+
+    def lists(ctx):
+        return [ctx.download_visible_entities(v, c)[1].copy() for v in range(2) for c in classes]
+
+    def run(async_on):
+        ctx = ctx_factory()
+        upload_scene(ctx, sc)
+        if with_classes:
+            ctx.upload_visibility_classes(cm)
+        ctx.batch_upload_rows(bs["row_set"], bs["row_bin"], bs["row_input"])
+        ctx.batch_upload_sets(bs["set_indexed"], bs["bin_table_offset"], bs["bin_table"], bs["meta_offset"], bs["bin_metadata"])
+        ctx.set_async_compaction(async_on)
+        outs = []
+        for f in range(3):  # read after every frame (join releases the pending compaction)
+            ctx.propagate_and_cull(cams[f], flags=B.CULL_END_FRAME)
+            outs.append(lists(ctx) + [ctx.download_visibility(v).copy() for v in range(2)] + [ctx.download_view_visibility()[0].copy()])
+        for f in range(3, 14):  # burst: more frames than the ring holds, released by the following frame kernels
+            ctx.propagate_and_cull(cams[f], flags=B.CULL_END_FRAME)
+        outs.append(lists(ctx))
+        ctx.propagate(B.PROPAGATE_ALL_DIRTY)  # unfused calls
+        ctx.cull(cams[14], flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME)
+        ctx.batch_build(1, 0)                  # joins, then reads the list on the caller's stream
+        got = ctx.batch_download()
+        outs.append([got["work_items"][0], got["work_items"][1], got["records"]] + lists(ctx))
+        ctx.synchronize()
+        ctx.set_async_compaction(False)        # and back: inline again
+        ctx.propagate_and_cull(cams[15], flags=B.CULL_END_FRAME)
+        outs.append(lists(ctx))
+        return outs
+
+    a, b = run(True), run(False)
+    assert len(a) == len(b)
+    for k, (fa, fb) in enumerate(zip(a, b)):
+        assert len(fa) == len(fb)
+        for x, y in zip(fa, fb):
+            assert x.shape == y.shape and np.array_equal(x, y), f"step {k}"
+    assert a[0][0].size > 0 and a[3][0].size > 0

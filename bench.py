@@ -107,12 +107,14 @@ def build_flat(ctx, args, rank, world, total_frames, full_holder):
         gather.attach(ctx)  # direct RCCL available: the library issues the exchange itself, one FFI call per frame
     py_exchange = gather is not None and not gather.native
     async_compaction = False
-    if not args.inline_compaction and gather is None:
+    if not args.inline_compaction and gather is None:  # with the exchange on the compaction stays inline (it carries the signal)
         try:
             ctx.set_async_compaction(True)
             async_compaction = True
         except api.MiError as e:  # stay on the inline path, say so in the result line
             async_compaction = repr(e)
+
+    more = B.CULL_MORE_FRAMES if async_compaction is True else 0  # frames follow back to back; measure()'s synchronize joins
 
     def step(f):
         if py_exchange:
@@ -120,9 +122,9 @@ def build_flat(ctx, args, rank, world, total_frames, full_holder):
             ctx.bind_visibility_output(*gather.bind_args(f))
         if args.unfused:
             ctx.propagate(B.PROPAGATE_ALL_DIRTY)
-            ctx.cull(frames[f], flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME)
+            ctx.cull(frames[f], flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME | more)
         else:
-            ctx.propagate_and_cull(frames[f], flags=B.CULL_END_FRAME)
+            ctx.propagate_and_cull(frames[f], flags=B.CULL_END_FRAME | more)
         if py_exchange:
             gather.after_kernels(f)
 
@@ -130,8 +132,9 @@ def build_flat(ctx, args, rank, world, total_frames, full_holder):
                           f"frustum(s), all Transforms dirty, columns resident in HBM: "
                           f"{'mi_propagate + mi_cull' if args.unfused else 'fused frame kernel'} (propagate + reset + frustum "
                           "cull + mark-newly-hidden) + VisibleEntities compaction"
-                          + (" (compaction of frame f on the library's side stream while frame f+1's kernel runs; every "
-                             "frame's lists are complete when the timed region ends)" if async_compaction is True else "")
+                          + (" (compaction of frame f on the library's side stream while frame f+1's kernel runs -- whose "
+                             "first workgroup is also what releases it; every frame's lists are complete when the timed region ends)"
+                             if async_compaction is True else "")
                           + (f" + one in-place RCCL all-gather of the visibility bitmask per frame over {world} GPUs "
                              f"({gather.mode}, pipelined one frame deep on its own stream)" if gather is not None else ""),
               "entities_per_gpu": n_local, "views": n_views, "async_compaction": async_compaction, "parallelism": f"row-range shard x{world}"}

@@ -36,6 +36,8 @@ int32_t fail(mi_ctx* ctx, int32_t code, const char* fmt, ...) {
 int32_t ensure(mi_ctx* ctx, DevBuf& b, size_t bytes) {
     if (b.bytes >= bytes && b.p) return MI_OK;
     if (b.p) {
+        int32_t rcj = compaction_join(ctx);  // hipFree waits for the whole device
+        if (rcj) return rcj;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         HIP_TRY(ctx, hipFree(b.p));
         b.p = nullptr;
@@ -77,6 +79,10 @@ int32_t upload(mi_ctx* ctx, void* dst, const void* src, size_t bytes) {
 
 int32_t download(mi_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!bytes) return MI_OK;
+    // A copy into pageable host memory may wait for the whole device: nothing on a side stream may still be waiting
+    // for a frame kernel that has not been submitted (asynchronous compaction with MI_CULL_MORE_FRAMES).
+    int32_t rcr = compaction_release(ctx);
+    if (rcr) return rcr;
     HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return MI_OK;
@@ -220,7 +226,7 @@ int32_t prepare_segments(mi_ctx* ctx, uint32_t n_views, SegOut* seg) {
     ctx->compact_classes = k;
     ctx->compact_fast = ctx->order_identity;
     memset(seg, 0, sizeof *seg);
-    if (ctx->ac.on && !ctx->xch.on && ctx->n > 0) {  // every frame kernel releases the side-stream compactions of the frames before it
+    if (async_now(ctx) && ctx->n > 0) {  // every frame kernel releases the side-stream compactions of the frames before it
         seg->start_signal = ctx->ac.started;
         seg->start_value = (uint32_t)ctx->ac.frames;
         ctx->ac.released = ctx->ac.frames;
@@ -268,12 +274,15 @@ int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg) 
         f.out_rows = (uint32_t*)ctx->fb[ctx->cur].out_rows.p;
         f.seg_stride = ctx->seg_stride;
         f.seg_totals = (uint32_t*)ctx->fb[ctx->cur].seg_totals.p;
+        const bool async = async_now(ctx);
         if (ctx->xch.on && ctx->xch.kernel_signal) {
             f.signal = ctx->xch.kernels_flag;
             f.signal_value = (uint32_t)(ctx->xch.frame + 1);
+            ctx->xch.wait_flag = f.signal;
+            ctx->xch.wait_value = f.signal_value;
             ctx->xch.signalled = true;
         }
-        if (ctx->ac.on && !ctx->xch.on) {
+        if (async) {
             // Asynchronous compaction: frame F's lists are built on the side stream once "frame kernel F has completed"
             // is published -- by the next frame kernel's first workgroup, or by compaction_join's write-value packet --
             // so the caller's stream goes straight on to the next frame.
@@ -324,7 +333,7 @@ int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg) 
 // stream bumps; the packet that released that compaction was enqueued N_FB - 1 frames ago, so this cannot deadlock.
 int32_t frame_begin(mi_ctx* ctx) {
     auto& ac = ctx->ac;
-    if (!ac.on || ctx->xch.on) return MI_OK;
+    if (!async_now(ctx)) return MI_OK;
     ctx->cur = (uint32_t)(ac.frames % mi_ctx::N_FB);
     if (ac.frames >= mi_ctx::N_FB) {
         const uint64_t need = ac.frames - mi_ctx::N_FB + 1;
@@ -344,13 +353,18 @@ int32_t frame_begin(mi_ctx* ctx) {
 // Everything that exposes VisibleEntities (downloads, the batching build, MI_BUF_VISIBLE_ROWS, mi_synchronize) joins
 // first: the last frame's compaction is released with a write-value packet behind its frame kernel if no later frame
 // kernel has done so, then the side stream is drained.
+int32_t compaction_release(mi_ctx* ctx) {
+    auto& ac = ctx->ac;
+    if (!ac.stream || ac.released >= ac.frames) return MI_OK;
+    HIP_TRY(ctx, hipStreamWriteValue32(ctx->stream, ac.started, (uint32_t)ac.frames, 0));
+    ac.released = ac.frames;
+    return MI_OK;
+}
 int32_t compaction_join(mi_ctx* ctx) {
     auto& ac = ctx->ac;
     if (!ac.stream || ac.frames == 0) return MI_OK;
-    if (ac.released < ac.frames) {
-        HIP_TRY(ctx, hipStreamWriteValue32(ctx->stream, ac.started, (uint32_t)ac.frames, 0));
-        ac.released = ac.frames;
-    }
+    int32_t rc = compaction_release(ctx);
+    if (rc) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ac.stream));
     return MI_OK;
 }
@@ -825,7 +839,8 @@ int32_t mi_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint3
     }
     if ((rc = run_compaction(ctx, vo, seg))) return rc;
     ctx->culled = true;
-    return exchange_end(ctx);
+    if ((rc = exchange_end(ctx))) return rc;
+    return (flags & MI_CULL_MORE_FRAMES) ? MI_OK : compaction_release(ctx);
 }
 
 int32_t mi_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_masks, const uint8_t* view_flags,
@@ -860,7 +875,8 @@ int32_t mi_propagate_and_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t 
     ctx->g_chg_maybe = true;
     ctx->g_chg_in_bytes = false;
     ctx->culled = true;
-    return exchange_end(ctx);
+    if ((rc = exchange_end(ctx))) return rc;
+    return (flags & MI_CULL_MORE_FRAMES) ? MI_OK : compaction_release(ctx);
 }
 
 int32_t mi_propagate_and_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_masks, const uint8_t* view_flags,
@@ -1079,7 +1095,14 @@ int32_t mi_set_async_compaction(mi_ctx* ctx, int32_t enabled) {
     if (rc) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (enabled && !ac.stream) {
-        if ((rc = pick_side_streams(ctx, &ac.stream, 1))) return rc;
+        bool shares = false;
+        if ((rc = pick_side_streams(ctx, &ac.stream, 1, &shares))) return rc;
+        if (shares) {
+            hipStreamDestroy(ac.stream);
+            ac.stream = nullptr;
+            return fail(ctx, MI_ERR_NOT_READY, "mi_set_async_compaction: every candidate side stream shares the compute stream's hardware queue "
+                                               "(too many streams in this process); staying with the inline compaction");
+        }
         HIP_TRY(ctx, hipMalloc((void**)&ac.started, 64));
         HIP_TRY(ctx, hipHostMalloc((void**)&ac.done, 64, hipHostMallocMapped));
     }

@@ -102,6 +102,7 @@ struct mi_ctx {
         uint32_t rank = 0;
         uint64_t frame = 0;
         hipStream_t comm_stream[MAX_COMMS] = {nullptr};
+        bool comm_shares_queue[MAX_COMMS] = {false};  // shares the compute stream's hardware queue (pick_side_streams)
         hipEvent_t ev_kernels[MAX_BUFS] = {nullptr}, ev_gathered[MAX_BUFS] = {nullptr};
         // The collective is enqueued by a library-owned host thread: RCCL's enqueue path costs tens of
         // microseconds of CPU per call, which would otherwise sit in the frame's critical path on the caller's
@@ -109,7 +110,14 @@ struct mi_ctx {
         std::thread worker;
         std::mutex m;
         std::condition_variable cv;
-        std::deque<uint32_t> queue;
+        struct Job {
+            uint32_t slot;     // gathered buffer of the frame
+            uint32_t* flag;    // device word to wait on ...
+            uint32_t value;    // ... until it is >= value: "this frame's masks are complete"
+        };
+        std::deque<Job> queue;
+        uint32_t* wait_flag = nullptr;  // how the current frame announces its masks (set while the frame is enqueued)
+        uint32_t wait_value = 0;
         std::atomic<uint64_t> submitted_fast{0};  // == submitted, readable without the lock (the thread polls it)
         std::atomic<bool> sleeping{false}, stop_fast{false};
         bool stop = false;
@@ -143,6 +151,7 @@ struct mi_ctx {
     uint32_t cur = 0;  // set of the current / last frame
     struct AsyncCompaction {
         bool on = false;
+        bool with_exchange = false;           // the communication streams in use may wait for a later frame kernel too
         hipStream_t stream = nullptr;
         uint32_t* started = nullptr;          // device word: k_frame of async frame F stores F at its start ("frames < F are complete")
         volatile uint32_t* done = nullptr;    // pinned host word: async frames whose compaction has completed
@@ -199,8 +208,14 @@ int32_t fail(mi_ctx* ctx, int32_t code, const char* fmt, ...);
 #define ENTER(ctx)                                                       \
     do {                                                                 \
         if (!(ctx)) return fail(nullptr, MI_ERR_INVALID_ARG, "ctx is NULL"); \
+        if (mi_detail::trace_on()) fprintf(stderr, "[mi] %s\n", __func__); \
         HIP_TRY(ctx, hipSetDevice((ctx)->device));                       \
     } while (0)
+
+inline bool trace_on() {
+    static const bool on = getenv("MI_TRACE") != nullptr;  // every entry point announces itself on stderr
+    return on;
+}
 
 inline uint64_t words64(uint32_t n) { return ((uint64_t)n + 63u) / 64u; }
 // bitmask words written by a launch of ceil(n/256) workgroups x 4 waves
@@ -266,10 +281,17 @@ Columns columns_of(mi_ctx* ctx);
 int32_t prepare_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, VisibilityOut* out);
 int32_t prepare_segments(mi_ctx* ctx, uint32_t n_views, SegOut* seg);
 int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg);
+// Asynchronous compaction applies to this frame: on, and the multi-GPU exchange off.  (Releasing the all-gather with
+// the same "next frame kernel has started" word was tried: it measured 23.6 us per frame against 26.1 us with the
+// in-kernel signal of the inline compaction, but hung intermittently with RCCL's enqueue path in the loop -- a
+// collective that waits for work not yet submitted is one device-wide wait away from a deadlock -- so the exchange
+// keeps the inline compaction.)
+inline bool async_now(mi_ctx* ctx) { return ctx->ac.on && !ctx->xch.on; }
 int32_t frame_begin(mi_ctx* ctx);       // picks the frame's buffer set (asynchronous compaction: ring + pacing)
+int32_t compaction_release(mi_ctx* ctx);  // the last frame's compaction (and all-gather) may start as soon as its frame kernel is done
 int32_t compaction_join(mi_ctx* ctx);   // makes every issued frame's VisibleEntities lists complete (host-side wait)
 // ctx_exchange.cpp
-int32_t pick_side_streams(mi_ctx* ctx, hipStream_t* out, uint32_t n_keep);
+int32_t pick_side_streams(mi_ctx* ctx, hipStream_t* out, uint32_t n_keep, bool* out_shares_queue);
 int32_t exchange_begin(mi_ctx* ctx);
 int32_t exchange_end(mi_ctx* ctx);
 int32_t exchange_wait_issued(mi_ctx* ctx, uint64_t upto);

@@ -11,7 +11,13 @@ namespace mi_detail {
 // -> 48 us per frame), and which stream collides depends on how many streams the process created before.  So: make a
 // few candidates (normal and high priority), drive each with the per-frame pattern over a stand-in kernel, and keep
 // the n_keep fastest, fastest first.
-int32_t pick_side_streams(mi_ctx* ctx, hipStream_t* out, uint32_t n_keep) {
+// A side stream that shares the compute stream's hardware queue is worse than slow when it waits (hipStreamWaitValue32)
+// for something the compute stream has yet to submit -- the released-by-the-next-frame-kernel scheme of the
+// asynchronous compaction: the wait packet would sit in front of the very kernel that satisfies it.  That is probed
+// explicitly: candidate waits on a pinned word, the compute stream is asked to write it; if the candidate does not get
+// through within 20 ms the host writes the word itself (so the probe cannot hang) and the candidate is marked as
+// sharing the queue.  Candidates that do not share it are preferred; out_shares_queue[i] reports the rest.
+int32_t pick_side_streams(mi_ctx* ctx, hipStream_t* out, uint32_t n_keep, bool* out_shares_queue) {
     int prio_lo = 0, prio_hi = 0;
     HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     constexpr int N_CAND = 6;
@@ -51,6 +57,25 @@ int32_t pick_side_streams(mi_ctx* ctx, hipStream_t* out, uint32_t n_keep) {
                                                 i == N_CAND - 1 ? " (high priority)" : "", t / 24.0);
         }
     HIP_TRY(ctx, hipFree(probe));
+    bool shares[N_CAND];
+    volatile uint32_t* w = flag;  // [0] the word the candidate waits on, [8] what it writes once through
+    for (int i = 0; i < N_CAND; ++i) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(cand[i]));
+        w[0] = 0;
+        w[8] = 0;
+        HIP_TRY(ctx, hipStreamWaitValue32(cand[i], (void*)&w[0], 1u, hipStreamWaitValueGte, 0xFFFFFFFFu));
+        HIP_TRY(ctx, hipStreamWriteValue32(cand[i], (void*)&w[8], 1u, 0));
+        HIP_TRY(ctx, hipStreamWriteValue32(ctx->stream, (void*)&w[0], 1u, 0));
+        const auto t0 = std::chrono::steady_clock::now();
+        while (w[8] == 0 && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(20)) std::this_thread::yield();
+        shares[i] = w[8] == 0;
+        if (shares[i]) w[0] = 1;  // release the wait from the host: the compute stream's write is stuck behind it
+        HIP_TRY(ctx, hipStreamSynchronize(cand[i]));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (getenv("MI_XCH_DEBUG")) fprintf(stderr, "[mi side stream] candidate %d %s the compute stream's hardware queue\n", i,
+                                            shares[i] ? "SHARES" : "does not share");
+    }
     HIP_TRY(ctx, hipHostFree(flag));
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(ctx, hipEventDestroy(ev_a[i]));
@@ -58,10 +83,14 @@ int32_t pick_side_streams(mi_ctx* ctx, hipStream_t* out, uint32_t n_keep) {
     }
     int order[N_CAND];
     std::iota(order, order + N_CAND, 0);
-    std::sort(order, order + N_CAND, [&](int a, int b) { return cand_t[a] < cand_t[b]; });
+    std::sort(order, order + N_CAND, [&](int a, int b) { return shares[a] != shares[b] ? !shares[a] : cand_t[a] < cand_t[b]; });
     for (int i = 0; i < N_CAND; ++i) {
-        if (i < (int)n_keep) out[i] = cand[order[i]];
-        else HIP_TRY(ctx, hipStreamDestroy(cand[order[i]]));
+        if (i < (int)n_keep) {
+            out[i] = cand[order[i]];
+            if (out_shares_queue) out_shares_queue[i] = shares[order[i]];
+        } else {
+            HIP_TRY(ctx, hipStreamDestroy(cand[order[i]]));
+        }
     }
     return MI_OK;
 }
@@ -73,7 +102,7 @@ void exchange_worker(mi_ctx* ctx) {
     auto& x = ctx->xch;
     hipSetDevice(ctx->device);
     for (;;) {
-        uint32_t slot;
+        mi_ctx::Exchange::Job job{};
         // While frames are flowing the thread must not go to sleep between them: waking a thread through a futex
         // takes tens of microseconds, more than a frame.  Poll the submission counter for a while first.
         if (x.submitted_fast.load(std::memory_order_acquire) == x.worker_frames) {
@@ -92,14 +121,15 @@ void exchange_worker(mi_ctx* ctx) {
                 x.sleeping.store(false, std::memory_order_relaxed);
             }
             if (x.queue.empty()) return;  // stop requested and drained
-            slot = x.queue.front();
+            job = x.queue.front();
             x.queue.pop_front();
         }
+        const uint32_t slot = job.slot;
         int err = 0;
         const auto tw0 = std::chrono::steady_clock::now();
         const uint32_t k = (uint32_t)(x.worker_frames % x.n_comms);  // frame f travels on communicator f % n_comms
         hipStream_t cs = x.comm_stream[k];
-        if (hipStreamWaitValue32(cs, x.kernels_flag, (uint32_t)(x.worker_frames + 1), hipStreamWaitValueGte, 0xFFFFFFFFu) != hipSuccess) err = -1;
+        if (hipStreamWaitValue32(cs, job.flag, job.value, hipStreamWaitValueGte, 0xFFFFFFFFu) != hipSuccess) err = -1;
         char* base = (char*)x.buf[slot];
         if (!err) err = x.all_gather(base + (size_t)x.rank * x.block_bytes, base, (size_t)x.block_bytes, 1 /* ncclUint8 */, x.comm[k], cs);
         if (hipEventRecord(x.ev_gathered[slot], cs) != hipSuccess && !err) err = -2;
@@ -182,11 +212,15 @@ int32_t exchange_end(mi_ctx* ctx) {
     if (!x.on) return MI_OK;
     const uint32_t slot = (uint32_t)(x.frame % x.n_bufs);
     const auto te0 = std::chrono::steady_clock::now();
-    if (!x.signalled) HIP_TRY(ctx, hipStreamWriteValue32(ctx->stream, x.kernels_flag, (uint32_t)(x.frame + 1), 0));
+    if (!x.signalled) {  // nobody announces this frame's masks in-kernel: a write-value packet behind its kernels does
+        x.wait_flag = x.kernels_flag;
+        x.wait_value = (uint32_t)(x.frame + 1);
+        HIP_TRY(ctx, hipStreamWriteValue32(ctx->stream, x.kernels_flag, x.wait_value, 0));
+    }
     x.signalled = false;
     {
         std::lock_guard<std::mutex> lk(x.m);
-        x.queue.push_back(slot);
+        x.queue.push_back(mi_ctx::Exchange::Job{slot, x.wait_flag, x.wait_value});
         ++x.submitted;
     }
     x.submitted_fast.fetch_add(1, std::memory_order_seq_cst);
@@ -224,6 +258,10 @@ int32_t mi_exchange_configure_multi(mi_ctx* ctx, void* const* nccl_comms, uint32
                                     uint64_t block_bytes, uint32_t rank) {
     ENTER(ctx);
     auto& x = ctx->xch;
+    {
+        int32_t rcj = compaction_join(ctx);  // releases a pending last frame (asynchronous compaction) before draining
+        if (rcj) return rcj;
+    }
     void* const nccl_comm = (nccl_comms && n_comms) ? nccl_comms[0] : nullptr;
     if (n_comms > mi_ctx::Exchange::MAX_COMMS) return fail(ctx, MI_ERR_INVALID_ARG, "mi_exchange_configure: at most %u communicators", mi_ctx::Exchange::MAX_COMMS);
     for (uint32_t k = 0; k < n_comms; ++k)
@@ -257,7 +295,7 @@ int32_t mi_exchange_configure_multi(mi_ctx* ctx, void* const* nccl_comms, uint32
             HIP_TRY(ctx, hipEventCreateWithFlags(&x.ev_kernels[i], hipEventDisableTiming));
             HIP_TRY(ctx, hipEventCreateWithFlags(&x.ev_gathered[i], hipEventDisableTiming));
         }
-        int32_t rcp = pick_side_streams(ctx, x.comm_stream, mi_ctx::Exchange::MAX_COMMS);
+        int32_t rcp = pick_side_streams(ctx, x.comm_stream, mi_ctx::Exchange::MAX_COMMS, x.comm_shares_queue);
         if (rcp) return rcp;
     }
     x.all_gather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))fn_nccl_all_gather;
@@ -287,8 +325,9 @@ int32_t mi_exchange_last(mi_ctx* ctx, void** out_device_buf, int32_t wait) {
     auto& x = ctx->xch;
     if (!x.on || x.frame == 0) return fail(ctx, MI_ERR_NOT_READY, "mi_exchange_last: no exchanged frame yet");
     const uint32_t slot = (uint32_t)((x.frame - 1) % x.n_bufs);
-    int32_t rc = exchange_wait_issued(ctx, x.frame);
+    int32_t rc = compaction_join(ctx);  // asynchronous compaction: also what releases the last frame's all-gather
     if (rc) return rc;
+    if ((rc = exchange_wait_issued(ctx, x.frame))) return rc;
     if (wait) HIP_TRY(ctx, hipEventSynchronize(x.ev_gathered[slot]));
     if (out_device_buf) *out_device_buf = x.buf[slot];
     return MI_OK;

@@ -8,11 +8,11 @@ export TMPDIR=/tmp
 P=gpurun_out/prof_$TAG
 mkdir -p $P
 for wl in flat tree lights flat_static batching; do
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $P/$wl -o $wl -- \
+  timeout -k 5 120 rocprofv3 --kernel-trace --stats --output-format csv -d $P/$wl -o $wl -- \
       python bench.py --workload $wl --steps 100 --warmup 10 --no-cpu-baseline --no-other-workloads > $P/$wl.log 2>&1
   if [ $wl = flat_static ] || [ $wl = batching ]; then continue; fi
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $P/${wl}_$ctr -o $wl -- \
+    timeout -k 5 120 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $P/${wl}_$ctr -o $wl -- \
         python bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline --no-other-workloads > $P/${wl}_$ctr.log 2>&1
   done
 done

@@ -151,7 +151,6 @@ struct mi_ctx {
     uint32_t cur = 0;  // set of the current / last frame
     struct AsyncCompaction {
         bool on = false;
-        bool with_exchange = false;           // the communication streams in use may wait for a later frame kernel too
         hipStream_t stream = nullptr;
         uint32_t* started = nullptr;          // device word: k_frame of async frame F stores F at its start ("frames < F are complete")
         volatile uint32_t* done = nullptr;    // pinned host word: async frames whose compaction has completed

@@ -214,13 +214,20 @@ def build_flat_static(ctx, args):
     ctx.upload_changed(np.zeros(n, np.uint8))  # the change column exists from here on: only marked rows are recomputed
     ctx.propagate(B.PROPAGATE_ALL_DIRTY)
     frames = [api.PreparedFrusta(api.compute_frustum(cfv, W.many_cubes_camera(f), W.CAMERA_FAR)) for f in range(128)]
+    more = 0
+    if not args.inline_compaction:
+        try:
+            ctx.set_async_compaction(True)  # as in the flat workload: compaction on the side stream, frames back to back
+            more = B.CULL_MORE_FRAMES
+        except api.MiError:
+            pass
 
     def step(f):
         ctx.propagate(0)
-        ctx.cull(frames[f & 127], flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME)
+        ctx.cull(frames[f & 127], flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME | more)
     config = {"workload": f"many_cubes-shaped flat scene, {n} entities, 1 frustum, 0 % of the Transforms dirty: mi_propagate "
                           "(no row was marked since the last one: returns without a launch) + mi_cull (G resident) + VisibleEntities "
-                          "compaction", "entities": n}
+                          "compaction" + (" on the side stream" if more else ""), "entities": n, "async_compaction": bool(more)}
     # cull with G resident: read G 48 + Aabb 24 + flags 1 + layers 4 + vv 1, write vv 1 + masks
     return Workload("flat_static", step, n, flat_bytes_per_entity(1, False), "k_cull", config,
                     "entities/sec through propagate+cull", "entities/s")

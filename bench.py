@@ -8,8 +8,8 @@
 A "step" is one frame of the hot path over device-resident columns with every Transform dirty:
   flat (default, BASELINE.json configs[1]): 1M flat entities per GPU, 1 camera frustum: ONE frame kernel
         (sync_simple_transforms + reset_view_visibility + check_visibility_cpu_culling + check_visibility_gpu_culling
-        + mark_newly_hidden_entities_invisible) and ONE VisibleEntities compaction kernel (at N = 1 on the library's side
-        stream, overlapping the next frame's kernel; --inline-compaction keeps it on the caller's stream).
+        + mark_newly_hidden_entities_invisible) and ONE VisibleEntities compaction kernel (at N = 1 the compaction of frame f rides in
+        the tail workgroups of frame f+1's launch, MI_CULL_MORE_FRAMES; --inline-compaction launches it on its own).
         With N > 1 GPUs every rank owns a 1M-row range of an N x 1M scene (weak scaling) and the packed
         ViewVisibility bitmasks are exchanged with ONE RCCL all-gather per frame.
   tree  (configs[4]): depth-12/branch-4 tree truncated to 1M nodes, root moved every frame, propagate only.
@@ -45,8 +45,8 @@ def parse():
     ap.add_argument("--lights", type=int, default=100_000)
     ap.add_argument("--unfused", action="store_true", help="flat: mi_propagate + mi_cull instead of the fused kernel")
     ap.add_argument("--inline-compaction", action="store_true",
-                    help="flat: keep the VisibleEntities compaction on the caller's stream (default at N=1: the library's side "
-                         "stream, overlapping the next frame's kernel; mi_set_async_compaction)")
+                    help="flat: launch the VisibleEntities compaction as its own kernel every frame (default at N=1: "
+                         "MI_CULL_MORE_FRAMES, the compaction of frame f rides in frame f+1's launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget")
@@ -106,14 +106,9 @@ def build_flat(ctx, args, rank, world, total_frames, full_holder):
         full_holder.append(gather)
         gather.attach(ctx)  # direct RCCL available: the library issues the exchange itself, one FFI call per frame
     py_exchange = gather is not None and not gather.native
-    async_compaction = False
-    if not args.inline_compaction and gather is None:  # with the exchange on the compaction stays inline (it carries the signal)
-        try:
-            ctx.set_async_compaction(True)
-            async_compaction = True
-        except api.MiError as e:  # stay on the inline path, say so in the result line
-            async_compaction = repr(e)
-
+    # frames follow back to back: each frame's compaction is deferred into the next frame's launch (MI_CULL_MORE_FRAMES);
+    # measure()'s final mi_synchronize enqueues the last one.  With the exchange on the flag is ignored by the library.
+    async_compaction = not args.inline_compaction and gather is None
     more = B.CULL_MORE_FRAMES if async_compaction is True else 0  # frames follow back to back; measure()'s synchronize joins
 
     def step(f):
@@ -132,12 +127,12 @@ def build_flat(ctx, args, rank, world, total_frames, full_holder):
                           f"frustum(s), all Transforms dirty, columns resident in HBM: "
                           f"{'mi_propagate + mi_cull' if args.unfused else 'fused frame kernel'} (propagate + reset + frustum "
                           "cull + mark-newly-hidden) + VisibleEntities compaction"
-                          + (" (compaction of frame f on the library's side stream while frame f+1's kernel runs -- whose "
-                             "first workgroup is also what releases it; every frame's lists are complete when the timed region ends)"
+                          + (" (MI_CULL_MORE_FRAMES: the compaction of frame f rides in the tail workgroups of frame f+1's "
+                             "kernel, the last one is enqueued by the final mi_synchronize inside the timed region)"
                              if async_compaction is True else "")
                           + (f" + one in-place RCCL all-gather of the visibility bitmask per frame over {world} GPUs "
                              f"({gather.mode}, pipelined one frame deep on its own stream)" if gather is not None else ""),
-              "entities_per_gpu": n_local, "views": n_views, "async_compaction": async_compaction, "parallelism": f"row-range shard x{world}"}
+              "entities_per_gpu": n_local, "views": n_views, "deferred_compaction": async_compaction, "parallelism": f"row-range shard x{world}"}
     if gather is not None and gather.fallback_reason:
         config["rccl_direct_fallback"] = gather.fallback_reason
     wl = Workload("flat", step, n_local, flat_bytes_per_entity(n_views, not args.unfused),
@@ -214,20 +209,14 @@ def build_flat_static(ctx, args):
     ctx.upload_changed(np.zeros(n, np.uint8))  # the change column exists from here on: only marked rows are recomputed
     ctx.propagate(B.PROPAGATE_ALL_DIRTY)
     frames = [api.PreparedFrusta(api.compute_frustum(cfv, W.many_cubes_camera(f), W.CAMERA_FAR)) for f in range(128)]
-    more = 0
-    if not args.inline_compaction:
-        try:
-            ctx.set_async_compaction(True)  # as in the flat workload: compaction on the side stream, frames back to back
-            more = B.CULL_MORE_FRAMES
-        except api.MiError:
-            pass
+    more = 0 if args.inline_compaction else B.CULL_MORE_FRAMES  # as in the flat workload: frames back to back
 
     def step(f):
         ctx.propagate(0)
         ctx.cull(frames[f & 127], flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME | more)
     config = {"workload": f"many_cubes-shaped flat scene, {n} entities, 1 frustum, 0 % of the Transforms dirty: mi_propagate "
                           "(no row was marked since the last one: returns without a launch) + mi_cull (G resident) + VisibleEntities "
-                          "compaction" + (" on the side stream" if more else ""), "entities": n, "async_compaction": bool(more)}
+                          "compaction" + (" deferred into the next frame's launch" if more else ""), "entities": n, "deferred_compaction": bool(more)}
     # cull with G resident: read G 48 + Aabb 24 + flags 1 + layers 4 + vv 1, write vv 1 + masks
     return Workload("flat_static", step, n, flat_bytes_per_entity(1, False), "k_cull", config,
                     "entities/sec through propagate+cull", "entities/s")

@@ -39,7 +39,7 @@ VIEW_KIND_CUBE_FACE_OR_SPOT = 0x02 | 0x08 | 0x10
 VISIBILITY_INHERITED, VISIBILITY_HIDDEN, VISIBILITY_VISIBLE, VISIBILITY_NONE = 0, 1, 2, 0x80
 CULL_BEGIN_FRAME = 0x1
 CULL_END_FRAME = 0x2
-CULL_MORE_FRAMES = 0x4  # asynchronous compaction: another frame follows at once (see MI_CULL_MORE_FRAMES)
+CULL_MORE_FRAMES = 0x4  # another cull frame follows at once: defer the compaction into its launch (MI_CULL_MORE_FRAMES)
 PROPAGATE_ALL_DIRTY = 0x1
 PROPAGATE_STATIC_OPT = 0x2
 NO_PARENT = 0xFFFFFFFF

@@ -91,7 +91,7 @@ ABI_SYMBOLS = [
     "mi_cluster_dimensions_fixed_z", "mi_cluster_assign", "mi_cluster_upload_objects", "mi_cluster_upload_view",
     "mi_cluster_assign_resident", "mi_cluster_download", "mi_cluster_download_bindings",
     "mi_batch_upload_rows", "mi_batch_upload_sets", "mi_batch_build", "mi_batch_download_totals", "mi_batch_download", "mi_perspective_clip_from_view", "mi_compute_frustum",
-    "mi_bind_visibility_output", "mi_set_async_compaction", "mi_exchange_configure", "mi_exchange_configure_multi", "mi_exchange_last", "mi_device_buffer", "mi_timer_begin", "mi_timer_end", "mi_profile_enable",
+    "mi_bind_visibility_output", "mi_exchange_configure", "mi_exchange_configure_multi", "mi_exchange_last", "mi_device_buffer", "mi_timer_begin", "mi_timer_end", "mi_profile_enable",
     "mi_profile_filter", "mi_profile_sample", "mi_profile_burst", "mi_profile_read", "mi_profile_kernel_name",
 ]
 
@@ -518,9 +518,6 @@ class Context:
         self._ck(self._lib.mi_exchange_configure_multi(self._h, carr, len(comms), C.c_void_p(fn_all_gather), arr, len(bufs),
                                                        C.c_uint64(words_per_view), C.c_uint64(word_offset),
                                                        C.c_uint64(block_bytes), C.c_uint32(rank)))
-
-    def set_async_compaction(self, on=True):
-        self._ck(self._lib.mi_set_async_compaction(self._h, 1 if on else 0))
 
     def exchange_last(self, wait=True):
         p = C.c_void_p()

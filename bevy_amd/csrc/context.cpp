@@ -36,8 +36,6 @@ int32_t fail(mi_ctx* ctx, int32_t code, const char* fmt, ...) {
 int32_t ensure(mi_ctx* ctx, DevBuf& b, size_t bytes) {
     if (b.bytes >= bytes && b.p) return MI_OK;
     if (b.p) {
-        int32_t rcj = compaction_join(ctx);  // hipFree waits for the whole device
-        if (rcj) return rcj;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         HIP_TRY(ctx, hipFree(b.p));
         b.p = nullptr;
@@ -79,10 +77,6 @@ int32_t upload(mi_ctx* ctx, void* dst, const void* src, size_t bytes) {
 
 int32_t download(mi_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!bytes) return MI_OK;
-    // A copy into pageable host memory may wait for the whole device: nothing on a side stream may still be waiting
-    // for a frame kernel that has not been submitted (asynchronous compaction with MI_CULL_MORE_FRAMES).
-    int32_t rcr = compaction_release(ctx);
-    if (rcr) return rcr;
     HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return MI_OK;
@@ -126,7 +120,6 @@ void prof_mark(void* vctx, uint32_t kernel) {
 void prof_collect(mi_ctx* ctx) {
     prof_close(ctx);
     hipStreamSynchronize(ctx->stream);
-    if (ctx->ac.stream && ctx->ac.released >= ctx->ac.frames) hipStreamSynchronize(ctx->ac.stream);  // (a pending frame is not waited for)
     for (auto& sp : ctx->spans) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
@@ -226,11 +219,6 @@ int32_t prepare_segments(mi_ctx* ctx, uint32_t n_views, SegOut* seg) {
     ctx->compact_classes = k;
     ctx->compact_fast = ctx->order_identity;
     memset(seg, 0, sizeof *seg);
-    if (async_now(ctx) && ctx->n > 0) {  // every frame kernel releases the side-stream compactions of the frames before it
-        seg->start_signal = ctx->ac.started;
-        seg->start_value = (uint32_t)ctx->ac.frames;
-        ctx->ac.released = ctx->ac.frames;
-    }
     seg->n_classes = k;
     for (uint32_t i = 0; i < k; ++i) seg->class_bits[i] = (uint8_t)ctx->class_bits[i];
     seg->class_mask = nullptr;
@@ -248,7 +236,7 @@ int32_t prepare_segments(mi_ctx* ctx, uint32_t n_views, SegOut* seg) {
     return MI_OK;
 }
 
-int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg) {
+int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg, uint32_t flags) {
     int32_t rc;
     const uint32_t n_classes = ctx->compact_classes;
     const size_t segs = (size_t)ctx->n_views * n_classes;
@@ -274,28 +262,19 @@ int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg) 
         f.out_rows = (uint32_t*)ctx->fb[ctx->cur].out_rows.p;
         f.seg_stride = ctx->seg_stride;
         f.seg_totals = (uint32_t*)ctx->fb[ctx->cur].seg_totals.p;
-        const bool async = async_now(ctx);
+        if ((flags & MI_CULL_MORE_FRAMES) && !ctx->xch.on) {
+            // Another frame follows at once: this frame's compaction rides in the tail workgroups of that frame's kernel
+            // (one launch per frame instead of two); compaction_join launches it on its own if something else comes first.
+            ctx->defer.args = f;
+            ctx->defer.pending = true;
+            return MI_OK;
+        }
         if (ctx->xch.on && ctx->xch.kernel_signal) {
             f.signal = ctx->xch.kernels_flag;
             f.signal_value = (uint32_t)(ctx->xch.frame + 1);
             ctx->xch.wait_flag = f.signal;
             ctx->xch.wait_value = f.signal_value;
             ctx->xch.signalled = true;
-        }
-        if (async) {
-            // Asynchronous compaction: frame F's lists are built on the side stream once "frame kernel F has completed"
-            // is published -- by the next frame kernel's first workgroup, or by compaction_join's write-value packet --
-            // so the caller's stream goes straight on to the next frame.
-            auto& ac = ctx->ac;
-            const uint32_t want = (uint32_t)(ac.frames + 1);
-            HIP_TRY(ctx, hipStreamWaitValue32(ac.stream, ac.started, want, hipStreamWaitValueGte, 0xFFFFFFFFu));
-            {
-                ProfScope ps(ctx, K_COMPACT_FAST);
-                HIP_TRY(ctx, launch_compact_fast(f, ac.stream));
-            }
-            HIP_TRY(ctx, hipStreamWriteValue32(ac.stream, (void*)ac.done, want, 0));
-            ++ac.frames;
-            return MI_OK;
         }
         ProfScope ps(ctx, K_COMPACT_FAST);
         HIP_TRY(ctx, launch_compact_fast(f, ctx->stream));
@@ -328,44 +307,21 @@ int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg) 
     return MI_OK;
 }
 
-// Start of a cull frame.  With asynchronous compaction the frame takes the next buffer set of the ring, after the
-// compaction that last used it (N_FB frames ago) has completed -- checked on the host, on the pinned counter the side
-// stream bumps; the packet that released that compaction was enqueued N_FB - 1 frames ago, so this cannot deadlock.
-int32_t frame_begin(mi_ctx* ctx) {
-    auto& ac = ctx->ac;
-    if (!async_now(ctx)) return MI_OK;
-    ctx->cur = (uint32_t)(ac.frames % mi_ctx::N_FB);
-    if (ac.frames >= mi_ctx::N_FB) {
-        const uint64_t need = ac.frames - mi_ctx::N_FB + 1;
-        const auto t0 = std::chrono::steady_clock::now();
-        uint32_t spins = 0;
-        while ((uint64_t)*ac.done < need) {
-            if ((++spins & 4095u) == 0) {
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
-                    return fail(ctx, MI_ERR_DEVICE, "asynchronous compaction of frame %llu did not complete within 30 s", (unsigned long long)(need - 1));
-                std::this_thread::yield();
-            }
-        }
-    }
-    return MI_OK;
+bool frame_begin(mi_ctx* ctx, CompactFastArgs* prev) {
+    const bool have = ctx->defer.pending;
+    if (have) *prev = ctx->defer.args;
+    ctx->defer.pending = false;
+    ctx->cur ^= 1u;
+    return have;
 }
 
 // Everything that exposes VisibleEntities (downloads, the batching build, MI_BUF_VISIBLE_ROWS, mi_synchronize) joins
-// first: the last frame's compaction is released with a write-value packet behind its frame kernel if no later frame
-// kernel has done so, then the side stream is drained.
-int32_t compaction_release(mi_ctx* ctx) {
-    auto& ac = ctx->ac;
-    if (!ac.stream || ac.released >= ac.frames) return MI_OK;
-    HIP_TRY(ctx, hipStreamWriteValue32(ctx->stream, ac.started, (uint32_t)ac.frames, 0));
-    ac.released = ac.frames;
-    return MI_OK;
-}
+// first; the join only enqueues, so device-side consumers on the context's stream are ordered behind it.
 int32_t compaction_join(mi_ctx* ctx) {
-    auto& ac = ctx->ac;
-    if (!ac.stream || ac.frames == 0) return MI_OK;
-    int32_t rc = compaction_release(ctx);
-    if (rc) return rc;
-    HIP_TRY(ctx, hipStreamSynchronize(ac.stream));
+    if (!ctx->defer.pending) return MI_OK;
+    ctx->defer.pending = false;
+    ProfScope ps(ctx, K_COMPACT_FAST);
+    HIP_TRY(ctx, launch_compact_fast(ctx->defer.args, ctx->stream));
     return MI_OK;
 }
 
@@ -444,12 +400,6 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
                       &ctx->cl_offsets, &ctx->cl_indices, &ctx->cl_scalars};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
-    if (ctx->ac.stream) {
-        hipStreamSynchronize(ctx->ac.stream);
-        hipStreamDestroy(ctx->ac.stream);
-    }
-    if (ctx->ac.started) hipFree(ctx->ac.started);
-    if (ctx->ac.done) hipHostFree((void*)ctx->ac.done);
     for (auto& f : ctx->fb)
         for (DevBuf* b : {&f.bitmask, &f.wave_cnt, &f.seg_mask, &f.out_rows, &f.seg_totals})
             if (b->p) hipFree(b->p);
@@ -825,9 +775,10 @@ void simple_views(std::vector<mi_view>& v, const float* frusta, const uint32_t* 
 int32_t mi_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint32_t flags) {
     ENTER(ctx);
     VisibilityOut vo{};
-    int32_t rc = frame_begin(ctx);
+    CompactFastArgs prev_args{};
+    const CompactFastArgs* prev = frame_begin(ctx, &prev_args) ? &prev_args : nullptr;
+    int32_t rc = exchange_begin(ctx);
     if (rc) return rc;
-    if ((rc = exchange_begin(ctx))) return rc;
     if ((rc = prepare_views(ctx, views, n_views, &vo))) return rc;
     SegOut seg;
     if ((rc = prepare_segments(ctx, n_views, &seg))) return rc;
@@ -835,12 +786,12 @@ int32_t mi_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint3
     {
         ProfScope ps(ctx, K_CULL);
         HIP_TRY(ctx, launch_cull(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p, n_views, vo,
-                                 seg, flags & (MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME), ctx->stream));
+                                 seg, flags & (MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME), prev, ctx->stream));
     }
-    if ((rc = run_compaction(ctx, vo, seg))) return rc;
+    if (prev && ctx->n == 0) HIP_TRY(ctx, launch_compact_fast(*prev, ctx->stream));  // no frame kernel to ride in
+    if ((rc = run_compaction(ctx, vo, seg, flags))) return rc;
     ctx->culled = true;
-    if ((rc = exchange_end(ctx))) return rc;
-    return (flags & MI_CULL_MORE_FRAMES) ? MI_OK : compaction_release(ctx);
+    return exchange_end(ctx);
 }
 
 int32_t mi_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_masks, const uint8_t* view_flags,
@@ -855,9 +806,10 @@ int32_t mi_propagate_and_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t 
     if (ctx->have_hierarchy)
         return fail(ctx, MI_ERR_NOT_READY, "mi_propagate_and_cull is the flat fast path; a hierarchy is uploaded -- use mi_propagate + mi_cull");
     VisibilityOut vo{};
-    int32_t rc = frame_begin(ctx);
+    CompactFastArgs prev_args{};
+    const CompactFastArgs* prev = frame_begin(ctx, &prev_args) ? &prev_args : nullptr;
+    int32_t rc = exchange_begin(ctx);
     if (rc) return rc;
-    if ((rc = exchange_begin(ctx))) return rc;
     if ((rc = prepare_views(ctx, views, n_views, &vo))) return rc;
     SegOut seg;
     if ((rc = prepare_segments(ctx, n_views, &seg))) return rc;
@@ -865,9 +817,10 @@ int32_t mi_propagate_and_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t 
     {
         ProfScope ps(ctx, K_FLAT_PROPAGATE_CULL);
         HIP_TRY(ctx, launch_flat_propagate_cull(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p,
-                                                n_views, vo, seg, flags & MI_CULL_END_FRAME, ctx->stream));
+                                                n_views, vo, seg, flags & MI_CULL_END_FRAME, prev, ctx->stream));
     }
-    if ((rc = run_compaction(ctx, vo, seg))) return rc;
+    if (prev && ctx->n == 0) HIP_TRY(ctx, launch_compact_fast(*prev, ctx->stream));  // no frame kernel to ride in
+    if ((rc = run_compaction(ctx, vo, seg, flags))) return rc;
     if (ctx->have_changed && ctx->changed_maybe) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, ctx->n, ctx->stream));
         ctx->changed_maybe = false;
@@ -875,8 +828,7 @@ int32_t mi_propagate_and_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t 
     ctx->g_chg_maybe = true;
     ctx->g_chg_in_bytes = false;
     ctx->culled = true;
-    if ((rc = exchange_end(ctx))) return rc;
-    return (flags & MI_CULL_MORE_FRAMES) ? MI_OK : compaction_release(ctx);
+    return exchange_end(ctx);
 }
 
 int32_t mi_propagate_and_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_masks, const uint8_t* view_flags,
@@ -1088,36 +1040,6 @@ int32_t mi_download_visible_entities(mi_ctx* ctx, uint32_t view, uint32_t class_
     return MI_OK;
 }
 
-int32_t mi_set_async_compaction(mi_ctx* ctx, int32_t enabled) {
-    ENTER(ctx);
-    auto& ac = ctx->ac;
-    int32_t rc = compaction_join(ctx);
-    if (rc) return rc;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (enabled && !ac.stream) {
-        bool shares = false;
-        if ((rc = pick_side_streams(ctx, &ac.stream, 1, &shares))) return rc;
-        if (shares) {
-            hipStreamDestroy(ac.stream);
-            ac.stream = nullptr;
-            return fail(ctx, MI_ERR_NOT_READY, "mi_set_async_compaction: every candidate side stream shares the compute stream's hardware queue "
-                                               "(too many streams in this process); staying with the inline compaction");
-        }
-        HIP_TRY(ctx, hipMalloc((void**)&ac.started, 64));
-        HIP_TRY(ctx, hipHostMalloc((void**)&ac.done, 64, hipHostMallocMapped));
-    }
-    if (ac.started) {
-        HIP_TRY(ctx, hipMemsetAsync(ac.started, 0, 64, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        *ac.done = 0;
-    }
-    ac.frames = ac.released = 0;
-    ac.on = enabled != 0;
-    if (!ac.on) ctx->cur = 0;
-    ctx->culled = false;
-    return MI_OK;
-}
-
 int32_t mi_device_buffer(mi_ctx* ctx, uint32_t which, void** out_ptr, uint64_t* out_bytes) {
     ENTER(ctx);
     if (!out_ptr) return fail(ctx, MI_ERR_INVALID_ARG, "mi_device_buffer: NULL");
@@ -1131,7 +1053,7 @@ int32_t mi_device_buffer(mi_ctx* ctx, uint32_t which, void** out_ptr, uint64_t* 
         break;
     case MI_BUF_VIEW_VISIBILITY: p = ctx->vv; bytes = ctx->n; break;
     case MI_BUF_VISIBLE_ROWS: {
-        int32_t rcj = compaction_join(ctx);  // asynchronous compaction: the lists are complete when this returns
+        int32_t rcj = compaction_join(ctx);  // a deferred compaction is enqueued now: complete in stream order
         if (rcj) return rcj;
         p = ctx->fb[ctx->cur].out_rows.p;
         bytes = ctx->fb[ctx->cur].out_rows.bytes;

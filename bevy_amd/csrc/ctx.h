@@ -141,22 +141,18 @@ struct mi_ctx {
     // compaction
     DevBuf block_counts, seg_bases, out_keys;
     // What one cull frame leaves behind: the view masks (unless bound elsewhere), the by-products the compaction
-    // consumes and the lists it writes.  One set normally; with asynchronous compaction (mi_set_async_compaction) a
-    // ring of N_FB sets, frame f using set f % N_FB, because the compaction of frame f runs on a side stream while the
-    // frame kernels of the following frames run on the caller's.
-    static constexpr uint32_t N_FB = 4;
+    // consumes and the lists it writes.  Two sets, alternating by frame: a frame culled with MI_CULL_MORE_FRAMES defers
+    // its compaction into the tail workgroups of the NEXT frame's kernel (or into a launch of its own at the first
+    // entry point that exposes the lists), which reads set f while that kernel writes set f + 1.
+    static constexpr uint32_t N_FB = 2;
     struct FrameBufs {
         DevBuf bitmask, wave_cnt, seg_mask, out_rows, seg_totals;
     } fb[N_FB];
     uint32_t cur = 0;  // set of the current / last frame
-    struct AsyncCompaction {
-        bool on = false;
-        hipStream_t stream = nullptr;
-        uint32_t* started = nullptr;          // device word: k_frame of async frame F stores F at its start ("frames < F are complete")
-        volatile uint32_t* done = nullptr;    // pinned host word: async frames whose compaction has completed
-        uint64_t frames = 0;                  // async cull frames issued
-        uint64_t released = 0;                // ... of which this many have had their "complete" signal enqueued or implied
-    } ac;
+    struct DeferredCompaction {
+        bool pending = false;
+        mi::CompactFastArgs args{};  // everything the compaction of the last frame needs
+    } defer;
     uint32_t compact_views = 0, compact_classes = 0;
     uint32_t class_bits[32] = {0};
     bool compact_fast = false;   // last compaction used the single-launch path (out_rows strided per segment)
@@ -279,16 +275,11 @@ struct ProfScope {
 Columns columns_of(mi_ctx* ctx);
 int32_t prepare_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, VisibilityOut* out);
 int32_t prepare_segments(mi_ctx* ctx, uint32_t n_views, SegOut* seg);
-int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg);
-// Asynchronous compaction applies to this frame: on, and the multi-GPU exchange off.  (Releasing the all-gather with
-// the same "next frame kernel has started" word was tried: it measured 23.6 us per frame against 26.1 us with the
-// in-kernel signal of the inline compaction, but hung intermittently with RCCL's enqueue path in the loop -- a
-// collective that waits for work not yet submitted is one device-wide wait away from a deadlock -- so the exchange
-// keeps the inline compaction.)
-inline bool async_now(mi_ctx* ctx) { return ctx->ac.on && !ctx->xch.on; }
-int32_t frame_begin(mi_ctx* ctx);       // picks the frame's buffer set (asynchronous compaction: ring + pacing)
-int32_t compaction_release(mi_ctx* ctx);  // the last frame's compaction (and all-gather) may start as soon as its frame kernel is done
-int32_t compaction_join(mi_ctx* ctx);   // makes every issued frame's VisibleEntities lists complete (host-side wait)
+int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg, uint32_t flags = 0);
+// start of a cull frame: switches to the other buffer set and hands out the previous frame's deferred compaction (to
+// ride in this frame's launch); returns whether there is one
+bool frame_begin(mi_ctx* ctx, mi::CompactFastArgs* prev);
+int32_t compaction_join(mi_ctx* ctx);   // enqueues a deferred compaction now: the lists are complete in stream order afterwards
 // ctx_exchange.cpp
 int32_t pick_side_streams(mi_ctx* ctx, hipStream_t* out, uint32_t n_keep, bool* out_shares_queue);
 int32_t exchange_begin(mi_ctx* ctx);

@@ -90,10 +90,6 @@ struct SegOut {
     uint64_t* seg_mask;
     uint64_t seg_words;
     uint8_t class_bits[32];      // class bit of each class slot
-    // Asynchronous compaction: workgroup 0 of the frame kernel publishes `start_value` at its start -- "every frame
-    // kernel enqueued before this one has completed" -- which releases the side-stream compaction of the previous frame.
-    uint32_t* start_signal;
-    uint32_t start_value;
 };
 
 // mi_cull / mi_propagate_and_cull flags (MI_CULL_* in the public header)
@@ -129,9 +125,30 @@ enum KernelId : uint32_t {
 
 // ---- flat path ------------------------------------------------------------------------------
 // views_inline is used when n_views <= MAX_INLINE_VIEWS (d_views may then be nullptr).
+struct CompactFastArgs {
+    uint32_t n;               // rows
+    uint32_t n_segments;
+    uint32_t n_classes;
+    uint32_t n_waves;         // stride of wave_cnt per segment
+    const uint8_t* wave_cnt;
+    const uint64_t* seg_mask; // segment masks (class-filtered), or nullptr -> use the view masks below
+    uint64_t seg_words;
+    const uint64_t* bitmask;  // per-view masks
+    uint64_t words_per_view, word_offset;
+    uint32_t* out_rows;
+    uint64_t seg_stride;      // entries reserved per segment in out_rows
+    uint32_t* seg_totals;
+    // Multi-GPU exchange: workgroup (0, 0) publishes `signal_value` at its start.  Any workgroup of this kernel running
+    // means the frame kernel before it in the stream has completed and its masks are visible, which is all the
+    // all-gather on the communication stream (hipStreamWaitValue32 on this word) needs -- and no signalling packet
+    // has to sit between the frames in the compute queue (an event record or write-value packet there costs ~6 us
+    // per frame: it keeps the next frame kernel from starting behind the compaction).
+    uint32_t* signal;
+    uint32_t signal_value;
+};
 hipError_t launch_flat_propagate_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views,
                                       uint32_t n_views, const VisibilityOut& out, const SegOut& seg, uint32_t flags,
-                                      hipStream_t stream);
+                                      const CompactFastArgs* prev, hipStream_t stream);
 // Level 0 of the hierarchy (roots + flat rows).  node_flags: bit0 = has children (nullptr = none do).
 // changed: per-row Changed<Transform>|... byte (nullptr or all_dirty => every row recomputed).
 // tree_bits: TransformTreeChanged bitset (only read when static_opt).
@@ -139,7 +156,7 @@ hipError_t launch_level0_propagate(const Columns& c, uint32_t n_level0, const ui
                                    const uint8_t* changed, const uint32_t* tree_bits, bool all_dirty,
                                    bool static_opt, hipStream_t stream);
 hipError_t launch_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views,
-                       const VisibilityOut& out, const SegOut& seg, uint32_t flags, hipStream_t stream);
+                       const VisibilityOut& out, const SegOut& seg, uint32_t flags, const CompactFastArgs* prev, hipStream_t stream);
 hipError_t launch_upload_trs(const float* pinned_src, float* t, float* r, float* s, uint32_t first_row, uint32_t n,
                              hipStream_t stream);
 hipError_t launch_upload_trs_indexed(const uint32_t* pinned_src, uint32_t n, float* t, float* r, float* s, uint8_t* changed,
@@ -177,27 +194,6 @@ hipError_t launch_compact(const CompactArgs& a, hipStream_t stream, void (*mark)
 // rows by key).  Consumes the per-wave counts + segment masks the cull pass left behind; every workgroup
 // derives its base from the preceding wave counts (L2-resident bytes), so no scan kernel and no atomics.
 // Segment s writes out_rows[s * seg_stride ...] and seg_totals[s].
-struct CompactFastArgs {
-    uint32_t n;               // rows
-    uint32_t n_segments;
-    uint32_t n_classes;
-    uint32_t n_waves;         // stride of wave_cnt per segment
-    const uint8_t* wave_cnt;
-    const uint64_t* seg_mask; // segment masks (class-filtered), or nullptr -> use the view masks below
-    uint64_t seg_words;
-    const uint64_t* bitmask;  // per-view masks
-    uint64_t words_per_view, word_offset;
-    uint32_t* out_rows;
-    uint64_t seg_stride;      // entries reserved per segment in out_rows
-    uint32_t* seg_totals;
-    // Multi-GPU exchange: workgroup (0, 0) publishes `signal_value` at its start.  Any workgroup of this kernel running
-    // means the frame kernel before it in the stream has completed and its masks are visible, which is all the
-    // all-gather on the communication stream (hipStreamWaitValue32 on this word) needs -- and no signalling packet
-    // has to sit between the frames in the compute queue (an event record or write-value packet there costs ~6 us
-    // per frame: it keeps the next frame kernel from starting behind the compaction).
-    uint32_t* signal;
-    uint32_t signal_value;
-};
 hipError_t launch_compact_fast(const CompactFastArgs& a, hipStream_t stream);
 
 // ---- hierarchy ---------------------------------------------------------------------------------

@@ -163,6 +163,63 @@ __device__ __forceinline__ Affine load_affine_coalesced(float4* lds_wave, const 
     return r;
 }
 
+__device__ __forceinline__ uint32_t sum_bytes(uint32_t x, uint32_t acc) { return __builtin_amdgcn_sad_u8(x, 0u, acc); }
+
+// One workgroup of the single-launch compaction: block (bx of gx, segment by).  Called from k_compact_fast and from the
+// tail workgroups of the frame kernels (deferred compaction of the previous frame).
+__device__ __forceinline__ void compact_fast_block(const CompactFastArgs& a, uint32_t bx, uint32_t by, uint32_t gx) {
+    const uint32_t seg = by;
+    const uint32_t view = seg / a.n_classes;
+    const uint8_t* cnt = a.wave_cnt + (size_t)seg * a.n_waves;
+    const uint64_t* mask = a.seg_mask ? a.seg_mask + (size_t)seg * a.seg_words
+                                      : a.bitmask + view * a.words_per_view + a.word_offset;
+    const uint32_t n_words = (a.n + 63u) >> 6;
+    const uint32_t w0 = bx * 64u;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    __shared__ uint32_t red[4], wtot[4];
+
+    // phase 1: base = sum of cnt[0 .. w0)
+    uint32_t partial = 0;
+    const uint4* c4 = reinterpret_cast<const uint4*>(cnt);
+    for (uint32_t i = threadIdx.x; i < (w0 >> 4); i += 256u) {
+        const uint4 q = c4[i];
+        partial = sum_bytes(q.x, partial);
+        partial = sum_bytes(q.y, partial);
+        partial = sum_bytes(q.z, partial);
+        partial = sum_bytes(q.w, partial);
+    }
+#pragma unroll
+    for (uint32_t off = 32u; off; off >>= 1) partial += __shfl_xor(partial, off, 64);
+    if (lane == 0) red[wv] = partial;
+
+    // phase 2: this wave's 16 words
+    const uint32_t my_word = w0 + wv * 16u + lane;
+    const unsigned long long m = (lane < 16u && my_word < n_words) ? mask[my_word] : 0ull;
+    const uint32_t pc = __popcll(m);
+    uint32_t incl = pc;
+#pragma unroll
+    for (uint32_t off = 1; off < 16u; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    const uint32_t excl = incl - pc;
+    if (lane == 15u) wtot[wv] = incl;
+    __syncthreads();
+    uint32_t base = red[0] + red[1] + red[2] + red[3];
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) base += k < wv ? wtot[k] : 0u;
+    uint32_t* out = a.out_rows + (size_t)seg * a.seg_stride;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll 4
+    for (uint32_t j = 0; j < 16u; ++j) {
+        const unsigned long long mj = __shfl(m, (int)j, 64);
+        const uint32_t oj = __shfl(excl, (int)j, 64);
+        if ((mj >> lane) & 1ull) out[base + oj + __popcll(mj & lt)] = (w0 + wv * 16u + j) * 64u + lane;
+    }
+    if (bx == gx - 1u && threadIdx.x == 0)
+        a.seg_totals[seg] = red[0] + red[1] + red[2] + red[3] + wtot[0] + wtot[1] + wtot[2] + wtot[3];
+}
+
 // ---------------------------------------------------------------------------------------------
 // The frame kernel.  PROPAGATE = true : G = From(T) for every row (sync_simple_transforms, all dirty),
 //                                       written once and never re-read (fused flat path);
@@ -176,10 +233,14 @@ __device__ __forceinline__ Affine load_affine_coalesced(float4* lds_wave, const 
 // ---------------------------------------------------------------------------------------------
 template <bool PROPAGATE, bool INLINE_VIEWS>
 __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const ViewParams* __restrict__ dviews,
-                                                uint32_t n_views, VisibilityOut out, SegOut seg, uint32_t fl_frame) {
+                                                uint32_t n_views, VisibilityOut out, SegOut seg, uint32_t fl_frame, uint32_t n_tiles,
+                                                CompactFastArgs prev, uint32_t prev_gx) {
     __shared__ float4 lds_g[4][192];
-    if (seg.start_signal && blockIdx.x == 0 && threadIdx.x == 0)
-        __hip_atomic_store(seg.start_signal, seg.start_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (blockIdx.x >= n_tiles) {  // tail workgroups: the deferred VisibleEntities compaction of the previous frame
+        const uint32_t id = blockIdx.x - n_tiles;
+        compact_fast_block(prev, id % prev_gx, id / prev_gx, prev_gx);
+        return;
+    }
     const uint32_t row = blockIdx.x * 256u + threadIdx.x;
     const bool live = row < c.n;
     const uint32_t wave = row >> 6;
@@ -448,28 +509,38 @@ hipError_t launch_upload_trs(const float* pinned_src, float* t, float* r, float*
     return hipGetLastError();
 }
 
+// prev != nullptr: the previous frame's deferred compaction rides in the tail workgroups of this launch
 template <bool PROPAGATE>
 static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views,
-                               const VisibilityOut& out, const SegOut& seg, uint32_t flags, hipStream_t stream) {
+                               const VisibilityOut& out, const SegOut& seg, uint32_t flags, const CompactFastArgs* prev,
+                               hipStream_t stream) {
     if (c.n == 0) return hipSuccess;
+    const uint32_t n_tiles = blocks_for(c.n);
+    CompactFastArgs pa{};
+    uint32_t prev_gx = 1, prev_blocks = 0;
+    if (prev && prev->n && prev->n_segments) {
+        pa = *prev;
+        prev_gx = (((pa.n + 63u) >> 6) + 63u) / 64u;
+        prev_blocks = prev_gx * pa.n_segments;
+    }
     if (n_views <= MAX_INLINE_VIEWS && views_inline) {
-        MI_LAUNCH((k_frame<PROPAGATE, true>), dim3(blocks_for(c.n)), dim3(256), 0, stream, c, *views_inline,
-                           (const ViewParams*)nullptr, n_views, out, seg, flags);
+        MI_LAUNCH((k_frame<PROPAGATE, true>), dim3(n_tiles + prev_blocks), dim3(256), 0, stream, c, *views_inline,
+                  (const ViewParams*)nullptr, n_views, out, seg, flags, n_tiles, pa, prev_gx);
     } else {
         ViewSet dummy = {};
-        MI_LAUNCH((k_frame<PROPAGATE, false>), dim3(blocks_for(c.n)), dim3(256), 0, stream, c, dummy, d_views,
-                           n_views, out, seg, flags);
+        MI_LAUNCH((k_frame<PROPAGATE, false>), dim3(n_tiles + prev_blocks), dim3(256), 0, stream, c, dummy, d_views, n_views, out, seg,
+                  flags, n_tiles, pa, prev_gx);
     }
     return hipGetLastError();
 }
 hipError_t launch_flat_propagate_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views,
                                       uint32_t n_views, const VisibilityOut& out, const SegOut& seg, uint32_t flags,
-                                      hipStream_t stream) {
-    return launch_frame<true>(c, views_inline, d_views, n_views, out, seg, flags | CULL_BEGIN_FRAME, stream);
+                                      const CompactFastArgs* prev, hipStream_t stream) {
+    return launch_frame<true>(c, views_inline, d_views, n_views, out, seg, flags | CULL_BEGIN_FRAME, prev, stream);
 }
 hipError_t launch_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views,
-                       const VisibilityOut& out, const SegOut& seg, uint32_t flags, hipStream_t stream) {
-    return launch_frame<false>(c, views_inline, d_views, n_views, out, seg, flags, stream);
+                       const VisibilityOut& out, const SegOut& seg, uint32_t flags, const CompactFastArgs* prev, hipStream_t stream) {
+    return launch_frame<false>(c, views_inline, d_views, n_views, out, seg, flags, prev, stream);
 }
 hipError_t launch_level0_propagate(const Columns& c, uint32_t n_level0, const uint8_t* node_flags,
                                    const uint8_t* changed, const uint32_t* tree_bits, bool all_dirty,
@@ -599,61 +670,10 @@ hipError_t launch_compact(const CompactArgs& a, hipStream_t stream, void (*mark)
 // words of the segment (<= n/64 bytes, L2 resident, read as 16-byte vectors and summed with v_sad_u8), so
 // there is no scan kernel, no look-back chain and no atomics; the list order is the row order.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t sum_bytes(uint32_t x, uint32_t acc) { return __builtin_amdgcn_sad_u8(x, 0u, acc); }
-
 __global__ void __launch_bounds__(256) k_compact_fast(CompactFastArgs a) {
     if (a.signal && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
         __hip_atomic_store(a.signal, a.signal_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    const uint32_t seg = blockIdx.y;
-    const uint32_t view = seg / a.n_classes;
-    const uint8_t* cnt = a.wave_cnt + (size_t)seg * a.n_waves;
-    const uint64_t* mask = a.seg_mask ? a.seg_mask + (size_t)seg * a.seg_words
-                                      : a.bitmask + view * a.words_per_view + a.word_offset;
-    const uint32_t n_words = (a.n + 63u) >> 6;
-    const uint32_t w0 = blockIdx.x * 64u;
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    __shared__ uint32_t red[4], wtot[4];
-
-    // phase 1: base = sum of cnt[0 .. w0)
-    uint32_t partial = 0;
-    const uint4* c4 = reinterpret_cast<const uint4*>(cnt);
-    for (uint32_t i = threadIdx.x; i < (w0 >> 4); i += 256u) {
-        const uint4 q = c4[i];
-        partial = sum_bytes(q.x, partial);
-        partial = sum_bytes(q.y, partial);
-        partial = sum_bytes(q.z, partial);
-        partial = sum_bytes(q.w, partial);
-    }
-#pragma unroll
-    for (uint32_t off = 32u; off; off >>= 1) partial += __shfl_xor(partial, off, 64);
-    if (lane == 0) red[wv] = partial;
-
-    // phase 2: this wave's 16 words
-    const uint32_t my_word = w0 + wv * 16u + lane;
-    const unsigned long long m = (lane < 16u && my_word < n_words) ? mask[my_word] : 0ull;
-    const uint32_t pc = __popcll(m);
-    uint32_t incl = pc;
-#pragma unroll
-    for (uint32_t off = 1; off < 16u; off <<= 1) {
-        const uint32_t up = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += up;
-    }
-    const uint32_t excl = incl - pc;
-    if (lane == 15u) wtot[wv] = incl;
-    __syncthreads();
-    uint32_t base = red[0] + red[1] + red[2] + red[3];
-#pragma unroll
-    for (uint32_t k = 0; k < 4u; ++k) base += k < wv ? wtot[k] : 0u;
-    uint32_t* out = a.out_rows + (size_t)seg * a.seg_stride;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-#pragma unroll 4
-    for (uint32_t j = 0; j < 16u; ++j) {
-        const unsigned long long mj = __shfl(m, (int)j, 64);
-        const uint32_t oj = __shfl(excl, (int)j, 64);
-        if ((mj >> lane) & 1ull) out[base + oj + __popcll(mj & lt)] = (w0 + wv * 16u + j) * 64u + lane;
-    }
-    if (blockIdx.x == gridDim.x - 1u && threadIdx.x == 0)
-        a.seg_totals[seg] = red[0] + red[1] + red[2] + red[3] + wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    compact_fast_block(a, blockIdx.x, blockIdx.y, gridDim.x);
 }
 
 hipError_t launch_compact_fast(const CompactFastArgs& a, hipStream_t stream) {

@@ -85,11 +85,13 @@ extern "C" {
 #define MI_CULL_END_FRAME 0x2u   /* also apply check_visibility_gpu_culling + mark_newly_hidden_entities_invisible
                                     (mod.rs:884-918) in the same pass: valid when nothing else (e.g. shadow-view
                                     culling, bevy_light/src/lib.rs:499-510) ORs into ViewVisibility this frame */
-#define MI_CULL_MORE_FRAMES 0x4u /* asynchronous compaction only (mi_set_async_compaction): another cull frame follows at
-                                   * once, so this frame's side-stream work is released by that frame's kernel instead of by a
-                                   * packet behind this one.  Until then -- or until an entry point that joins -- something on
-                                   * the device is waiting for work that has not been submitted: do not call anything that
-                                   * waits for the whole device (hipDeviceSynchronize, hipFree, pageable copies) in between. */
+#define MI_CULL_MORE_FRAMES 0x4u /* another cull frame follows at once: this frame's VisibleEntities compaction is deferred into
+                                   * the tail workgroups of that frame's kernel -- one launch per frame instead of two (any
+                                   * dispatch costs >= 4.3 us on this part).  If something else comes first, the entry points
+                                   * that expose the lists (mi_download_visible_entities, mi_batch_build,
+                                   * mi_device_buffer(MI_BUF_VISIBLE_ROWS), mi_synchronize, mi_columns_resize) enqueue the
+                                   * compaction themselves, so results never depend on the flag; masks and ViewVisibility
+                                   * are unaffected.  Ignored while the multi-GPU exchange is on. */
 
 /* ---- mi_propagate flags ----------------------------------------------------------------- */
 #define MI_PROPAGATE_ALL_DIRTY 0x1u  /* every Transform counts as changed (worst case / first frame) */
@@ -459,18 +461,6 @@ int32_t mi_compute_frustum(const float clip_from_view[16], const float camera_af
  * and the caller guarantees the buffer covers every view's words.
  * Pass device_ptr = NULL to go back to the internal buffer. */
 int32_t mi_bind_visibility_output(mi_ctx* ctx, void* device_ptr, uint64_t words_per_view, uint64_t word_offset);
-
-/* Asynchronous VisibleEntities compaction (off by default).  The compaction of frame f then runs on a library-owned
- * side stream as soon as f's frame kernel has completed, while the caller's stream goes straight on to whatever comes
- * next -- in a loop of frames, the next frame kernel, whose first workgroup is also what tells the side stream that
- * frame f is complete (no event or marker packet between the frames).  The frame's outputs rotate through a ring of
- * four buffer sets (pass MI_CULL_MORE_FRAMES in such a loop; without it every frame is released by a packet of its
- * own).  Every entry point that exposes the lists joins first -- mi_download_visible_entities,
- * mi_batch_build, mi_device_buffer(MI_BUF_VISIBLE_ROWS), mi_synchronize, mi_columns_resize -- so results are the
- * same as with the compaction inline; only when they become available changes.  Masks and ViewVisibility are
- * unaffected (complete in stream order).  While the multi-GPU exchange is on the compaction stays inline (it is what
- * tells the communication stream that the masks are complete). */
-int32_t mi_set_async_compaction(mi_ctx* ctx, int32_t enabled);
 
 /* The exchange itself, issued by the library: after every mi_cull / mi_propagate_and_cull the packed masks are
  * all-gathered IN PLACE across the ranks of an RCCL communicator.  The kernels write frame f's masks straight into

@@ -557,8 +557,8 @@ def test_one_million_flat_entities(ctx_factory):
     assert np.array_equal(rows, np.nonzero(vis_exp[0])[0].astype(np.uint32))
 
 
-@pytest.mark.parametrize("n_comms,async_compaction", [(1, False), (2, False), (2, True), (3, True)])
-def test_mask_gatherer_single_rank_pipeline(ctx_factory, n_comms, async_compaction):
+@pytest.mark.parametrize("n_comms,more", [(1, 0), (2, 0), (2, 4), (3, 4)])
+def test_mask_gatherer_single_rank_pipeline(ctx_factory, n_comms, more):
     """The pipelined exchange bench.py uses for N > 1, on one rank: kernels write their masks in place into the
     gatherer's alternating buffers and the (1-rank) all-gather runs on the communication stream -- through RCCL
     directly when the library can be set up on this box, else through torch.distributed."""
@@ -595,14 +595,11 @@ def test_mask_gatherer_single_rank_pipeline(ctx_factory, n_comms, async_compacti
     upload_scene(ctx2, sc)
     if g.attach(ctx2):
         assert g.mode == "rccl-native"
-        try:
-            ctx2.set_async_compaction(async_compaction)  # then the next frame kernel's first workgroup releases the all-gather
-        except api.MiError as e:  # no side stream with a hardware queue of its own in this process: inline compaction stays
-            assert "hardware queue" in str(e)
+        # more = MI_CULL_MORE_FRAMES: ignored while the exchange is on (the inline compaction carries its signal)
         vv = np.zeros(n, np.uint8)
         for frame in range(5):
             frusta = frusta_for([W.many_cubes_camera(frame * 30), W.many_cubes_camera(frame * 30, yaw=1.3)])
-            ctx2.propagate_and_cull(frusta, flags=B.CULL_END_FRAME)
+            ctx2.propagate_and_cull(frusta, flags=B.CULL_END_FRAME | more)
             _, vv, vis_exp, _ = oracle_frame(sc, vv, frusta, None, None)
             ptr = ctx2.exchange_last(wait=True)
             assert ptr == g.buffer(frame).data_ptr()
@@ -613,7 +610,7 @@ def test_mask_gatherer_single_rank_pipeline(ctx_factory, n_comms, async_compacti
         # a burst with nothing read in between: the caller's thread is paced by the per-communicator counters
         for frame in range(5, 5 + 23):
             frusta = frusta_for([W.many_cubes_camera(frame * 30), W.many_cubes_camera(frame * 30, yaw=1.3)])
-            ctx2.propagate_and_cull(frusta, flags=B.CULL_END_FRAME | (B.CULL_MORE_FRAMES if frame < 27 else 0))
+            ctx2.propagate_and_cull(frusta, flags=B.CULL_END_FRAME | more)
             _, vv, vis_exp, _ = oracle_frame(sc, vv, frusta, None, None)
         assert ctx2.exchange_last(wait=True) == g.buffer(frame).data_ptr()
         ctx2.synchronize()
@@ -926,14 +923,14 @@ def test_static_frames_change_nothing_and_report_nothing(ctx_factory, tree):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("with_classes", [False, True])
-def test_async_compaction_matches_inline(ctx_factory, with_classes):
-    """mi_set_async_compaction: frame f's lists are built on a side stream while the caller's stream runs the next
-    frames (released by the next frame kernel's first workgroup, or by the join).  Whatever is read -- after every
-    frame, after a burst of frames with nothing read in between, through the batching build, after switching back --
-    must be what the inline compaction gives."""
+def test_deferred_compaction_matches_inline(ctx_factory, with_classes):
+    """MI_CULL_MORE_FRAMES: frame f's lists are built by the tail workgroups of frame f+1's kernel, or by a launch of
+    their own at the first entry point that exposes them.  Whatever is read -- after every frame, after a burst of
+    frames with nothing read in between, through the batching build, through mi_cull after mi_propagate, after a
+    resize -- must be what the inline compaction gives."""
     n = 300_000 + 77
     sc = W.many_cubes(n, radius=300.0, ragged_flags=True)
-    cams = [frusta_for([W.many_cubes_camera(f, yaw=0.0), W.many_cubes_camera(f, yaw=2.0)]) for f in range(16)]
+    cams = [frusta_for([W.many_cubes_camera(f, yaw=0.0), W.many_cubes_camera(f, yaw=2.0)]) for f in range(18)]
     cm = (1 + (np.arange(n) % 3 == 0) * 2 + (np.arange(n) % 5 == 0) * 4).astype(np.uint32)
     bs = W.batching_scene(n, n_sets=5, seed=9)
     classes = (0, 1, 2) if with_classes else (0,)
@@ -941,36 +938,34 @@ def test_async_compaction_matches_inline(ctx_factory, with_classes):
     def lists(ctx):
         return [ctx.download_visible_entities(v, c)[1].copy() for v in range(2) for c in classes]
 
-    def run(async_on):
+    def run(more):
         ctx = ctx_factory()
         upload_scene(ctx, sc)
         if with_classes:
             ctx.upload_visibility_classes(cm)
         ctx.batch_upload_rows(bs["row_set"], bs["row_bin"], bs["row_input"])
         ctx.batch_upload_sets(bs["set_indexed"], bs["bin_table_offset"], bs["bin_table"], bs["meta_offset"], bs["bin_metadata"])
-        try:
-            ctx.set_async_compaction(async_on)
-        except api.MiError as e:
-            pytest.skip(f"asynchronous compaction unavailable here: {e}")
         outs = []
-        for f in range(3):  # read after every frame (join releases the pending compaction)
-            ctx.propagate_and_cull(cams[f], flags=B.CULL_END_FRAME)
+        for f in range(3):  # read after every frame: the join launches the deferred compaction on its own
+            ctx.propagate_and_cull(cams[f], flags=B.CULL_END_FRAME | more)
             outs.append(lists(ctx) + [ctx.download_visibility(v).copy() for v in range(2)] + [ctx.download_view_visibility()[0].copy()])
-        for f in range(3, 14):  # burst: more frames than the ring holds, released by the following frame kernels
-            ctx.propagate_and_cull(cams[f], flags=B.CULL_END_FRAME | (B.CULL_MORE_FRAMES if f % 3 else 0))
+        for f in range(3, 14):  # burst: every compaction rides in the next frame's launch
+            ctx.propagate_and_cull(cams[f], flags=B.CULL_END_FRAME | more)
         outs.append(lists(ctx))
-        ctx.propagate(B.PROPAGATE_ALL_DIRTY)  # unfused calls
-        ctx.cull(cams[14], flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME)
-        ctx.batch_build(1, 0)                  # joins, then reads the list on the caller's stream
+        ctx.propagate(B.PROPAGATE_ALL_DIRTY)  # unfused calls, a different number of views in between
+        ctx.cull(cams[14][:24], flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME | more)
+        ctx.cull(cams[15], flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME | more)
+        ctx.batch_build(1, 0)                  # enqueues the pending compaction, then reads the list on the same stream
         got = ctx.batch_download()
         outs.append([got["work_items"][0], got["work_items"][1], got["records"]] + lists(ctx))
+        ctx.propagate_and_cull(cams[16], flags=B.CULL_END_FRAME | more)
+        ctx.resize(n - 1000)                   # joins first (buffers may move), then fewer rows
+        ctx.propagate_and_cull(cams[17], flags=B.CULL_END_FRAME | more)
         ctx.synchronize()
-        ctx.set_async_compaction(False)        # and back: inline again
-        ctx.propagate_and_cull(cams[15], flags=B.CULL_END_FRAME)
         outs.append(lists(ctx))
         return outs
 
-    a, b = run(True), run(False)
+    a, b = run(B.CULL_MORE_FRAMES), run(0)
     assert len(a) == len(b)
     for k, (fa, fb) in enumerate(zip(a, b)):
         assert len(fa) == len(fb)

@@ -108,8 +108,8 @@ def build_flat(ctx, args, rank, world, total_frames, full_holder):
     py_exchange = gather is not None and not gather.native
     # frames follow back to back: each frame's compaction is deferred into the next frame's launch (MI_CULL_MORE_FRAMES);
     # measure()'s final mi_synchronize enqueues the last one.  With the exchange on the flag is ignored by the library.
-    async_compaction = not args.inline_compaction and gather is None
-    more = B.CULL_MORE_FRAMES if async_compaction is True else 0  # frames follow back to back; measure()'s synchronize joins
+    deferred_compaction = not args.inline_compaction and gather is None
+    more = B.CULL_MORE_FRAMES if deferred_compaction is True else 0  # frames follow back to back; measure()'s synchronize joins
 
     def step(f):
         if py_exchange:
@@ -129,10 +129,10 @@ def build_flat(ctx, args, rank, world, total_frames, full_holder):
                           "cull + mark-newly-hidden) + VisibleEntities compaction"
                           + (" (MI_CULL_MORE_FRAMES: the compaction of frame f rides in the tail workgroups of frame f+1's "
                              "kernel, the last one is enqueued by the final mi_synchronize inside the timed region)"
-                             if async_compaction is True else "")
+                             if deferred_compaction is True else "")
                           + (f" + one in-place RCCL all-gather of the visibility bitmask per frame over {world} GPUs "
                              f"({gather.mode}, pipelined one frame deep on its own stream)" if gather is not None else ""),
-              "entities_per_gpu": n_local, "views": n_views, "deferred_compaction": async_compaction, "parallelism": f"row-range shard x{world}"}
+              "entities_per_gpu": n_local, "views": n_views, "deferred_compaction": deferred_compaction, "parallelism": f"row-range shard x{world}"}
     if gather is not None and gather.fallback_reason:
         config["rccl_direct_fallback"] = gather.fallback_reason
     wl = Workload("flat", step, n_local, flat_bytes_per_entity(n_views, not args.unfused),

@@ -234,14 +234,18 @@ __device__ __forceinline__ void compact_fast_block(const CompactFastArgs& a, uin
 template <bool PROPAGATE, bool INLINE_VIEWS>
 __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const ViewParams* __restrict__ dviews,
                                                 uint32_t n_views, VisibilityOut out, SegOut seg, uint32_t fl_frame, uint32_t n_tiles,
-                                                CompactFastArgs prev, uint32_t prev_gx) {
+                                                CompactFastArgs prev, uint32_t prev_gx, uint32_t prev_first) {
     __shared__ float4 lds_g[4][192];
-    if (blockIdx.x >= n_tiles) {  // tail workgroups: the deferred VisibleEntities compaction of the previous frame
-        const uint32_t id = blockIdx.x - n_tiles;
+    // extra workgroups: the deferred VisibleEntities compaction of the previous frame.  prev_first != 0 puts them at the
+    // head of the grid (they overlap the ramp-up instead of lengthening the tail)
+    const uint32_t n_extra = gridDim.x - n_tiles;
+    const bool extra = prev_first ? blockIdx.x < n_extra : blockIdx.x >= n_tiles;
+    if (extra) {
+        const uint32_t id = prev_first ? blockIdx.x : blockIdx.x - n_tiles;
         compact_fast_block(prev, id % prev_gx, id / prev_gx, prev_gx);
         return;
     }
-    const uint32_t row = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t row = (blockIdx.x - (prev_first ? n_extra : 0u)) * 256u + threadIdx.x;
     const bool live = row < c.n;
     const uint32_t wave = row >> 6;
     const uint32_t lane = threadIdx.x & 63u;
@@ -518,6 +522,7 @@ static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, co
     const uint32_t n_tiles = blocks_for(c.n);
     CompactFastArgs pa{};
     uint32_t prev_gx = 1, prev_blocks = 0;
+    static const uint32_t prev_first = getenv("MI_DEFERRED_LAST") ? 0u : 1u;
     if (prev && prev->n && prev->n_segments) {
         pa = *prev;
         prev_gx = (((pa.n + 63u) >> 6) + 63u) / 64u;
@@ -525,11 +530,11 @@ static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, co
     }
     if (n_views <= MAX_INLINE_VIEWS && views_inline) {
         MI_LAUNCH((k_frame<PROPAGATE, true>), dim3(n_tiles + prev_blocks), dim3(256), 0, stream, c, *views_inline,
-                  (const ViewParams*)nullptr, n_views, out, seg, flags, n_tiles, pa, prev_gx);
+                  (const ViewParams*)nullptr, n_views, out, seg, flags, n_tiles, pa, prev_gx, prev_first);
     } else {
         ViewSet dummy = {};
         MI_LAUNCH((k_frame<PROPAGATE, false>), dim3(n_tiles + prev_blocks), dim3(256), 0, stream, c, dummy, d_views, n_views, out, seg,
-                  flags, n_tiles, pa, prev_gx);
+                  flags, n_tiles, pa, prev_gx, prev_first);
     }
     return hipGetLastError();
 }

@@ -108,7 +108,7 @@ def build_flat(ctx, args, rank, world, total_frames, full_holder):
     py_exchange = gather is not None and not gather.native
     # frames follow back to back: each frame's compaction is deferred into the next frame's launch (MI_CULL_MORE_FRAMES);
     # measure()'s final mi_synchronize enqueues the last one.  With the exchange on the flag is ignored by the library.
-    deferred_compaction = not args.inline_compaction and gather is None
+    deferred_compaction = not args.inline_compaction and not py_exchange
     more = B.CULL_MORE_FRAMES if deferred_compaction is True else 0  # frames follow back to back; measure()'s synchronize joins
 
     def step(f):

@@ -262,9 +262,21 @@ int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg, 
         f.out_rows = (uint32_t*)ctx->fb[ctx->cur].out_rows.p;
         f.seg_stride = ctx->seg_stride;
         f.seg_totals = (uint32_t*)ctx->fb[ctx->cur].seg_totals.p;
-        if ((flags & MI_CULL_MORE_FRAMES) && !ctx->xch.on) {
-            // Another frame follows at once: this frame's compaction rides in the tail workgroups of that frame's kernel
-            // (one launch per frame instead of two); compaction_join launches it on its own if something else comes first.
+        if ((flags & MI_CULL_MORE_FRAMES) && (!ctx->xch.on || ctx->xch.kernel_signal)) {
+            // Another frame follows at once: this frame's compaction rides in extra workgroups of that frame's kernel (one
+            // launch per frame instead of two); compaction_join launches it on its own if something else comes first.
+            // With the exchange on it still publishes "this frame's masks are complete", and the frame's all-gather is
+            // queued when that launch is submitted.
+            ctx->defer.has_job = false;
+            if (ctx->xch.on) {
+                auto& x = ctx->xch;
+                f.signal = x.kernels_flag;
+                f.signal_value = (uint32_t)(x.frame + 1);
+                ctx->defer.has_job = true;
+                ctx->defer.job = mi_ctx::Exchange::Job{(uint32_t)(x.frame % x.n_bufs), f.signal, f.signal_value};
+                x.signalled = true;
+                x.job_deferred = true;
+            }
             ctx->defer.args = f;
             ctx->defer.pending = true;
             return MI_OK;
@@ -307,10 +319,16 @@ int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg, 
     return MI_OK;
 }
 
-bool frame_begin(mi_ctx* ctx, CompactFastArgs* prev) {
+bool frame_begin(mi_ctx* ctx, CompactFastArgs* prev, bool* prev_has_job, mi_ctx::Exchange::Job* prev_job) {
     const bool have = ctx->defer.pending;
-    if (have) *prev = ctx->defer.args;
+    *prev_has_job = false;
+    if (have) {
+        *prev = ctx->defer.args;
+        *prev_has_job = ctx->defer.has_job;
+        *prev_job = ctx->defer.job;
+    }
     ctx->defer.pending = false;
+    ctx->defer.has_job = false;
     ctx->cur ^= 1u;
     return have;
 }
@@ -320,8 +338,12 @@ bool frame_begin(mi_ctx* ctx, CompactFastArgs* prev) {
 int32_t compaction_join(mi_ctx* ctx) {
     if (!ctx->defer.pending) return MI_OK;
     ctx->defer.pending = false;
-    ProfScope ps(ctx, K_COMPACT_FAST);
-    HIP_TRY(ctx, launch_compact_fast(ctx->defer.args, ctx->stream));
+    {
+        ProfScope ps(ctx, K_COMPACT_FAST);
+        HIP_TRY(ctx, launch_compact_fast(ctx->defer.args, ctx->stream));
+    }
+    if (ctx->defer.has_job) exchange_push(ctx, ctx->defer.job);  // the kernel that publishes its signal is submitted now
+    ctx->defer.has_job = false;
     return MI_OK;
 }
 
@@ -776,7 +798,9 @@ int32_t mi_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint3
     ENTER(ctx);
     VisibilityOut vo{};
     CompactFastArgs prev_args{};
-    const CompactFastArgs* prev = frame_begin(ctx, &prev_args) ? &prev_args : nullptr;
+    bool prev_has_job = false;
+    mi_ctx::Exchange::Job prev_job{};
+    const CompactFastArgs* prev = frame_begin(ctx, &prev_args, &prev_has_job, &prev_job) ? &prev_args : nullptr;
     int32_t rc = exchange_begin(ctx);
     if (rc) return rc;
     if ((rc = prepare_views(ctx, views, n_views, &vo))) return rc;
@@ -789,6 +813,7 @@ int32_t mi_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint3
                                  seg, flags & (MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME), prev, ctx->stream));
     }
     if (prev && ctx->n == 0) HIP_TRY(ctx, launch_compact_fast(*prev, ctx->stream));  // no frame kernel to ride in
+    if (prev_has_job) exchange_push(ctx, prev_job);  // the launch that publishes the previous frame's signal is submitted
     if ((rc = run_compaction(ctx, vo, seg, flags))) return rc;
     ctx->culled = true;
     return exchange_end(ctx);
@@ -807,7 +832,9 @@ int32_t mi_propagate_and_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t 
         return fail(ctx, MI_ERR_NOT_READY, "mi_propagate_and_cull is the flat fast path; a hierarchy is uploaded -- use mi_propagate + mi_cull");
     VisibilityOut vo{};
     CompactFastArgs prev_args{};
-    const CompactFastArgs* prev = frame_begin(ctx, &prev_args) ? &prev_args : nullptr;
+    bool prev_has_job = false;
+    mi_ctx::Exchange::Job prev_job{};
+    const CompactFastArgs* prev = frame_begin(ctx, &prev_args, &prev_has_job, &prev_job) ? &prev_args : nullptr;
     int32_t rc = exchange_begin(ctx);
     if (rc) return rc;
     if ((rc = prepare_views(ctx, views, n_views, &vo))) return rc;
@@ -820,6 +847,7 @@ int32_t mi_propagate_and_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t 
                                                 n_views, vo, seg, flags & MI_CULL_END_FRAME, prev, ctx->stream));
     }
     if (prev && ctx->n == 0) HIP_TRY(ctx, launch_compact_fast(*prev, ctx->stream));  // no frame kernel to ride in
+    if (prev_has_job) exchange_push(ctx, prev_job);  // the launch that publishes the previous frame's signal is submitted
     if ((rc = run_compaction(ctx, vo, seg, flags))) return rc;
     if (ctx->have_changed && ctx->changed_maybe) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, ctx->n, ctx->stream));

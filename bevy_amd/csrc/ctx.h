@@ -118,6 +118,7 @@ struct mi_ctx {
         std::deque<Job> queue;
         uint32_t* wait_flag = nullptr;  // how the current frame announces its masks (set while the frame is enqueued)
         uint32_t wait_value = 0;
+        bool job_deferred = false;      // ... in the next frame's launch: exchange_end must not queue the all-gather yet
         std::atomic<uint64_t> submitted_fast{0};  // == submitted, readable without the lock (the thread polls it)
         std::atomic<bool> sleeping{false}, stop_fast{false};
         bool stop = false;
@@ -152,6 +153,8 @@ struct mi_ctx {
     struct DeferredCompaction {
         bool pending = false;
         mi::CompactFastArgs args{};  // everything the compaction of the last frame needs
+        bool has_job = false;        // with the exchange on: the frame's all-gather, queued once the compaction is submitted
+        Exchange::Job job{};
     } defer;
     uint32_t compact_views = 0, compact_classes = 0;
     uint32_t class_bits[32] = {0};
@@ -278,12 +281,13 @@ int32_t prepare_segments(mi_ctx* ctx, uint32_t n_views, SegOut* seg);
 int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg, uint32_t flags = 0);
 // start of a cull frame: switches to the other buffer set and hands out the previous frame's deferred compaction (to
 // ride in this frame's launch); returns whether there is one
-bool frame_begin(mi_ctx* ctx, mi::CompactFastArgs* prev);
+bool frame_begin(mi_ctx* ctx, mi::CompactFastArgs* prev, bool* prev_has_job, mi_ctx::Exchange::Job* prev_job);
 int32_t compaction_join(mi_ctx* ctx);   // enqueues a deferred compaction now: the lists are complete in stream order afterwards
 // ctx_exchange.cpp
 int32_t pick_side_streams(mi_ctx* ctx, hipStream_t* out, uint32_t n_keep, bool* out_shares_queue);
 int32_t exchange_begin(mi_ctx* ctx);
 int32_t exchange_end(mi_ctx* ctx);
+void exchange_push(mi_ctx* ctx, const mi_ctx::Exchange::Job& job);  // hands one frame's all-gather to the exchange thread
 int32_t exchange_wait_issued(mi_ctx* ctx, uint64_t upto);
 void exchange_stop(mi_ctx* ctx);
 

@@ -207,6 +207,17 @@ int32_t exchange_begin(mi_ctx* ctx) {
     ctx->ext_word_offset = x.word_offset;
     return MI_OK;
 }
+void exchange_push(mi_ctx* ctx, const mi_ctx::Exchange::Job& job) {
+    auto& x = ctx->xch;
+    {
+        std::lock_guard<std::mutex> lk(x.m);
+        x.queue.push_back(job);
+        ++x.submitted;
+    }
+    x.submitted_fast.fetch_add(1, std::memory_order_seq_cst);
+    if (x.sleeping.load(std::memory_order_seq_cst)) x.cv.notify_all();  // no futex call while the thread is polling
+}
+
 int32_t exchange_end(mi_ctx* ctx) {
     auto& x = ctx->xch;
     if (!x.on) return MI_OK;
@@ -218,13 +229,14 @@ int32_t exchange_end(mi_ctx* ctx) {
         HIP_TRY(ctx, hipStreamWriteValue32(ctx->stream, x.kernels_flag, x.wait_value, 0));
     }
     x.signalled = false;
-    {
-        std::lock_guard<std::mutex> lk(x.m);
-        x.queue.push_back(mi_ctx::Exchange::Job{slot, x.wait_flag, x.wait_value});
-        ++x.submitted;
+    if (x.job_deferred) {
+        // this frame's compaction -- and with it the "masks complete" signal -- rides in the next frame's launch: its
+        // all-gather is handed to the exchange thread there (or by compaction_join), once that launch is submitted, so
+        // the communication stream never waits for work that has not been submitted
+        x.job_deferred = false;
+    } else {
+        exchange_push(ctx, mi_ctx::Exchange::Job{slot, x.wait_flag, x.wait_value});
     }
-    x.submitted_fast.fetch_add(1, std::memory_order_seq_cst);
-    if (x.sleeping.load(std::memory_order_seq_cst)) x.cv.notify_all();  // no futex call while the thread is polling
     ++x.frame;
     x.dbg_end_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - te0).count();
     return MI_OK;

@@ -242,6 +242,8 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
     const bool extra = prev_first ? blockIdx.x < n_extra : blockIdx.x >= n_tiles;
     if (extra) {
         const uint32_t id = prev_first ? blockIdx.x : blockIdx.x - n_tiles;
+        if (prev.signal && id == 0 && threadIdx.x == 0)  // multi-GPU exchange: the previous frame's masks are complete
+            __hip_atomic_store(prev.signal, prev.signal_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         compact_fast_block(prev, id % prev_gx, id / prev_gx, prev_gx);
         return;
     }

@@ -91,7 +91,8 @@ extern "C" {
                                    * that expose the lists (mi_download_visible_entities, mi_batch_build,
                                    * mi_device_buffer(MI_BUF_VISIBLE_ROWS), mi_synchronize, mi_columns_resize) enqueue the
                                    * compaction themselves, so results never depend on the flag; masks and ViewVisibility
-                                   * are unaffected.  Ignored while the multi-GPU exchange is on. */
+                                   * are unaffected.  With the multi-GPU exchange on, the frame's all-gather is issued together
+                                   * with its compaction, i.e. one call later (mi_exchange_last joins first). */
 
 /* ---- mi_propagate flags ----------------------------------------------------------------- */
 #define MI_PROPAGATE_ALL_DIRTY 0x1u  /* every Transform counts as changed (worst case / first frame) */

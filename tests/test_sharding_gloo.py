@@ -170,3 +170,19 @@ def test_shard_hierarchy_partition(world, shape):
     held = [len(sh["rows"]) for sh in shards]
     if shape != "chain" and world > 1:
         assert max(held) <= 1.35 * n / world + 64, held
+
+
+def test_shard_hierarchy_degenerate_inputs():
+    """Nothing to shard, one node, fewer trees than ranks: every row still owned exactly once, empty ranks are empty."""
+    cases = [(np.zeros(0, np.uint32), np.array([0], np.uint32)),
+             (np.array([W.NO_PARENT], np.uint32), np.array([0, 1], np.uint32)),
+             (np.full(5, W.NO_PARENT, np.uint32), np.array([0, 5], np.uint32))]
+    for parent, lv in cases:
+        for world in (1, 2, 8):
+            shards = sharding.shard_hierarchy(parent, lv, world)
+            assert len(shards) == world
+            owned = np.zeros(len(parent), np.int64)
+            for sh in shards:
+                owned[sh["rows"][sh["owned"]].astype(np.int64)] += 1
+                assert sh["level_offsets"][0] == 0 and sh["level_offsets"][-1] == len(sh["rows"])
+            assert np.all(owned == 1)

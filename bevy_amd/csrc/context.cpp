@@ -437,7 +437,6 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
         for (hipStream_t cs : ctx->xch.comm_stream)
             if (cs) hipStreamSynchronize(cs);
         for (uint32_t i = 0; i < mi_ctx::Exchange::MAX_BUFS; ++i) {
-            if (ctx->xch.ev_kernels[i]) hipEventDestroy(ctx->xch.ev_kernels[i]);
             if (ctx->xch.ev_gathered[i]) hipEventDestroy(ctx->xch.ev_gathered[i]);
         }
         for (hipStream_t cs : ctx->xch.comm_stream)

@@ -103,7 +103,7 @@ struct mi_ctx {
         uint64_t frame = 0;
         hipStream_t comm_stream[MAX_COMMS] = {nullptr};
         bool comm_shares_queue[MAX_COMMS] = {false};  // shares the compute stream's hardware queue (pick_side_streams)
-        hipEvent_t ev_kernels[MAX_BUFS] = {nullptr}, ev_gathered[MAX_BUFS] = {nullptr};
+        hipEvent_t ev_gathered[MAX_BUFS] = {nullptr};  // recorded behind each buffer's all-gather (mi_exchange_last waits on it)
         // The collective is enqueued by a library-owned host thread: RCCL's enqueue path costs tens of
         // microseconds of CPU per call, which would otherwise sit in the frame's critical path on the caller's
         // thread.  The caller's thread never runs more than two frames ahead of it.

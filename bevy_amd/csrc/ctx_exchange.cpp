@@ -304,7 +304,6 @@ int32_t mi_exchange_configure_multi(mi_ctx* ctx, void* const* nccl_comms, uint32
     x.signalled = false;
     if (!x.comm_stream[0]) {
         for (uint32_t i = 0; i < mi_ctx::Exchange::MAX_BUFS; ++i) {
-            HIP_TRY(ctx, hipEventCreateWithFlags(&x.ev_kernels[i], hipEventDisableTiming));
             HIP_TRY(ctx, hipEventCreateWithFlags(&x.ev_gathered[i], hipEventDisableTiming));
         }
         int32_t rcp = pick_side_streams(ctx, x.comm_stream, mi_ctx::Exchange::MAX_COMMS, x.comm_shares_queue);

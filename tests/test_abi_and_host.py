@@ -169,3 +169,21 @@ def test_gen_tree_is_level_ordered():
     n2o, pidx, offs = api.hierarchy_sort(tr["parent"])
     assert np.array_equal(n2o, np.arange(tr["n"])) and np.array_equal(pidx, tr["parent"])
     assert np.array_equal(offs, tr["level_offsets"])
+
+
+def test_header_is_plain_c_and_wire_structs_have_the_reference_sizes(tmp_path):
+    """include/bevy_mi355x.h compiles as C99 on its own (no torch / HIP / C++ types at the boundary) and the structs that
+    are GPU wire formats in the reference have the sizes of their #[repr(C)] originals: PreprocessWorkItem 8 B,
+    IndirectParametersMetadata 20 B, IndirectBatchSet 8 B (gpu_preprocessing.rs:783-965), GpuBinMetadata 12 B
+    (mesh_preprocess_types.wesl:130-149); mi_view is the 144-byte block the kernels read."""
+    import subprocess
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "bevy_mi355x.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", '
+                   'sizeof(mi_view), sizeof(mi_preprocess_work_item), sizeof(mi_indirect_parameters_metadata), '
+                   'sizeof(mi_indirect_batch_set), sizeof(mi_bin_metadata), sizeof(mi_batch_set_record), sizeof(mi_batch_initial), '
+                   'sizeof(mi_batch_totals)); return 0; }\n')
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                   check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert [int(x) for x in out] == [144, 8, 20, 8, 12, 32, 28, 32]

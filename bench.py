@@ -428,13 +428,13 @@ def main():
             fr0 = wl.frusta_of_frame(args.warmup)
             a = (sc["translation"], sc["rotation"], sc["scale"], sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"], fr0)
             secs, _, _, _ = O.bench_flat_frame(*a, cores, 1)
-            iters = int(max(1, min(400, args.cpu_seconds / max(secs, 1e-4))))
+            iters = int(max(1, min(5000, args.cpu_seconds / max(secs, 1e-4))))
             secs, _, _, _ = O.bench_flat_frame(*a, cores, iters)
             out["cpu_baseline"] = {
                 "value": round(n_cpu * iters / secs, 1), "unit": "entities/s", "cores": cores, "kind": "port",
                 "sample": f"{iters} frames of {n_cpu} entities x {wl.n_views} view(s): oracle C port of sync_simple_transforms + "
-                          "reset + check_visibility + mark_newly_hidden, one ceil(n/threads) batch per thread "
-                          f"(Bevy's par_iter batching), {secs:.2f}s"}
+                          "reset + check_visibility + mark_newly_hidden on a persistent thread pool, one ceil(n/threads) batch per "
+                          f"thread and system (Bevy's par_iter batching), {secs:.2f}s"}
         if world == 1 and args.workload == "flat" and not args.no_other_workloads:
             # configs[4] and configs[2], measured briefly on fresh contexts so the one line carries every stage
             others = {}

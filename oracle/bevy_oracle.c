@@ -1305,10 +1305,30 @@ static void* job_run(void* p) {
     return NULL;
 }
 
-static void run_phase(job_t* jobs, pthread_t* th, int threads) {
-    for (int k = 1; k < threads; ++k) pthread_create(&th[k], NULL, job_run, &jobs[k]);
-    job_run(&jobs[0]);
-    for (int k = 1; k < threads; ++k) pthread_join(th[k], NULL);
+/* A persistent pool, like Bevy's ComputeTaskPool (threads are not created per system run): the workers park on a
+ * barrier, run their batch of the current phase, and meet the caller on a second barrier. */
+typedef struct pool_t {
+    job_t* jobs;
+    int threads;
+    volatile int stop;
+    pthread_barrier_t start, done;
+} pool_t;
+typedef struct worker_arg_t { pool_t* pool; int k; } worker_arg_t;
+
+static void* pool_worker(void* p) {
+    worker_arg_t* wa = (worker_arg_t*)p;
+    for (;;) {
+        pthread_barrier_wait(&wa->pool->start);
+        if (wa->pool->stop) return NULL;
+        job_run(&wa->pool->jobs[wa->k]);
+        pthread_barrier_wait(&wa->pool->done);
+    }
+}
+
+static void run_phase(pool_t* pool) {
+    pthread_barrier_wait(&pool->start);
+    job_run(&pool->jobs[0]);
+    pthread_barrier_wait(&pool->done);
 }
 
 double orc_bench_flat_frame(uint32_t n, const float* t, const float* r, const float* s, const float* c,
@@ -1318,6 +1338,13 @@ double orc_bench_flat_frame(uint32_t n, const float* t, const float* r, const fl
     if (threads < 1) threads = 1;
     job_t* jobs = (job_t*)calloc((size_t)threads, sizeof(job_t));
     pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+    worker_arg_t* wargs = (worker_arg_t*)calloc((size_t)threads, sizeof(worker_arg_t));
+    pool_t pool;
+    pool.jobs = jobs;
+    pool.threads = threads;
+    pool.stop = 0;
+    pthread_barrier_init(&pool.start, NULL, (unsigned)threads);
+    pthread_barrier_init(&pool.done, NULL, (unsigned)threads);
     uint32_t batch = (n + (uint32_t)threads - 1) / (uint32_t)threads;
     for (int k = 0; k < threads; ++k) {
         job_t* j = &jobs[k];
@@ -1326,21 +1353,31 @@ double orc_bench_flat_frame(uint32_t n, const float* t, const float* r, const fl
         j->t = t; j->r = r; j->s = s; j->c = c; j->h = h; j->flags = flags; j->layers = layers;
         j->g = g; j->vv = vv; j->vis = vis; j->frusta = frusta; j->vmasks = vmasks; j->vflags = vflags;
     }
+    for (int k = 1; k < threads; ++k) {
+        wargs[k].pool = &pool;
+        wargs[k].k = k;
+        pthread_create(&th[k], NULL, pool_worker, &wargs[k]);
+    }
     struct timespec a, b;
     clock_gettime(CLOCK_MONOTONIC, &a);
     for (int it = 0; it < iters; ++it) {
         for (int k = 0; k < threads; ++k) jobs[k].phase = 0;
-        run_phase(jobs, th, threads);
+        run_phase(&pool);
         for (int k = 0; k < threads; ++k) jobs[k].phase = 1;
-        run_phase(jobs, th, threads);
+        run_phase(&pool);
         for (uint32_t v = 0; v < n_views; ++v) {
             for (int k = 0; k < threads; ++k) { jobs[k].phase = 2; jobs[k].view = v; }
-            run_phase(jobs, th, threads);
+            run_phase(&pool);
         }
         for (int k = 0; k < threads; ++k) jobs[k].phase = 3;
-        run_phase(jobs, th, threads);
+        run_phase(&pool);
     }
     clock_gettime(CLOCK_MONOTONIC, &b);
-    free(jobs); free(th);
+    pool.stop = 1;
+    pthread_barrier_wait(&pool.start);
+    for (int k = 1; k < threads; ++k) pthread_join(th[k], NULL);
+    pthread_barrier_destroy(&pool.start);
+    pthread_barrier_destroy(&pool.done);
+    free(jobs); free(th); free(wargs);
     return (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
 }

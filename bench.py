@@ -255,8 +255,9 @@ def build_batching(ctx, args):
 
 
 def cpu_baseline_other(name, wl):
-    """The oracle's scalar C port of the same stage on ONE host core (assign_objects_to_clusters is single-threaded in
-    the reference; the propagate port is not parallelised), a few seconds' worth of frames."""
+    """The oracle's C port of the same stage on the host: the hierarchy on all cores (rows of a level in parallel, levels in
+    order -- the parallelism propagate_parent_transforms gets from the task pool), assign_objects_to_clusters and the batch
+    bookkeeping on ONE core (single-threaded in the reference); a few seconds' worth of frames."""
     import oracle_lib as O
     if name == "flat_static":
         return None  # the flat line's CPU baseline is the same stage with the propagate included
@@ -277,16 +278,14 @@ def cpu_baseline_other(name, wl):
                           f"allocate_uniforms + unpack_bins, {secs:.2f}s"}
     if name == "tree":
         tr = wl.tree
-        t0 = time.perf_counter()
-        rc, g, _ = O.propagate_transforms(tr["parent"], tr["translation"], tr["rotation"], tr["scale"])
-        one = time.perf_counter() - t0
-        iters = int(max(1, min(50, 3.0 / max(one, 1e-4))))
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            rc, g, _ = O.propagate_transforms(tr["parent"], tr["translation"], tr["rotation"], tr["scale"], global_in=g)
-        secs = time.perf_counter() - t0
-        return {"value": round(tr["n"] * iters / secs, 1), "unit": "nodes/s", "cores": 1, "kind": "port",
-                "sample": f"{iters} frames of {tr['n']} nodes: oracle C port of propagate_parent_transforms (set_if_neq), {secs:.2f}s"}
+        cores = os.cpu_count() or 1
+        a = (tr["parent"], tr["level_offsets"], tr["translation"], tr["rotation"], tr["scale"])
+        one, _ = O.bench_tree_frame(*a, cores, 1)
+        iters = int(max(1, min(2000, 3.0 / max(one, 1e-4))))
+        secs, _ = O.bench_tree_frame(*a, cores, iters)
+        return {"value": round(tr["n"] * iters / secs, 1), "unit": "nodes/s", "cores": cores, "kind": "port",
+                "sample": f"{iters} frames of {tr['n']} nodes, every Transform changed: oracle C port of propagate_parent_transforms "
+                          f"(set_if_neq), rows of a level split over a persistent pool of {cores} threads, levels in order, {secs:.2f}s"}
     cam, cfv, fr = wl.oracle_args
     view, lights = O.cluster_view_setup(cam, cfv, fr, 1920, 1080, (16, 9, 24), 5.0, 1000.0), wl.keep[2]
     t0 = time.perf_counter()

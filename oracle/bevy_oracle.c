@@ -1381,3 +1381,89 @@ double orc_bench_flat_frame(uint32_t n, const float* t, const float* r, const fl
     free(jobs); free(th); free(wargs);
     return (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
 }
+
+/* ---- parallel CPU baseline for the hierarchy (bench.py only) ---------------------------------------------------
+ * propagate_parent_transforms fans out over the task pool (par_iter over roots, then a work queue of subtrees,
+ * systems.rs:506-640).  Rows here are in level (BFS) order, so the same parallelism is available as "all rows of a
+ * level in parallel, levels in order" on the persistent pool above; every node does exactly what
+ * orc_propagate_transforms does for it with every Transform changed (aff_from_srt, parent * local, set_if_neq). */
+typedef struct tree_job_t {
+    uint32_t lo, hi, root_level;
+    const uint32_t* parent;
+    const float *t, *r, *s;
+    float* g;
+} tree_job_t;
+typedef struct tree_pool_t {
+    tree_job_t* jobs;
+    volatile int stop;
+    pthread_barrier_t start, done;
+} tree_pool_t;
+typedef struct tree_arg_t { tree_pool_t* pool; int k; } tree_arg_t;
+
+static void tree_job_run(const tree_job_t* j) {
+    for (uint32_t i = j->lo; i < j->hi; ++i) {
+        aff local = aff_from_srt(j->s + 3 * (size_t)i, j->r + 4 * (size_t)i, j->t + 3 * (size_t)i);
+        if (j->root_level || j->parent[i] == ORC_NO_PARENT) {
+            aff_store(&local, j->g + 12 * (size_t)i);
+            continue;
+        }
+        aff gp = aff_load(j->g + 12 * (size_t)j->parent[i]);
+        aff gc = aff_mul(&gp, &local);
+        float tmp[12];
+        aff_store(&gc, tmp);
+        if (!aff_eq(tmp, j->g + 12 * (size_t)i)) memcpy(j->g + 12 * (size_t)i, tmp, sizeof tmp);
+    }
+}
+static void* tree_worker(void* p) {
+    tree_arg_t* a = (tree_arg_t*)p;
+    for (;;) {
+        pthread_barrier_wait(&a->pool->start);
+        if (a->pool->stop) return NULL;
+        tree_job_run(&a->pool->jobs[a->k]);
+        pthread_barrier_wait(&a->pool->done);
+    }
+}
+
+double orc_bench_tree_frame(uint32_t n, const uint32_t* parent, const uint32_t* level_offsets, uint32_t n_levels, const float* t,
+                            const float* r, const float* s, float* g, int threads, int iters) {
+    if (threads < 1) threads = 1;
+    tree_job_t* jobs = (tree_job_t*)calloc((size_t)threads, sizeof(tree_job_t));
+    pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+    tree_arg_t* args = (tree_arg_t*)calloc((size_t)threads, sizeof(tree_arg_t));
+    tree_pool_t pool;
+    pool.jobs = jobs;
+    pool.stop = 0;
+    pthread_barrier_init(&pool.start, NULL, (unsigned)threads);
+    pthread_barrier_init(&pool.done, NULL, (unsigned)threads);
+    for (int k = 0; k < threads; ++k) { jobs[k].parent = parent; jobs[k].t = t; jobs[k].r = r; jobs[k].s = s; jobs[k].g = g; }
+    for (int k = 1; k < threads; ++k) {
+        args[k].pool = &pool;
+        args[k].k = k;
+        pthread_create(&th[k], NULL, tree_worker, &args[k]);
+    }
+    (void)n;
+    struct timespec a, b;
+    clock_gettime(CLOCK_MONOTONIC, &a);
+    for (int it = 0; it < iters; ++it)
+        for (uint32_t l = 0; l < n_levels; ++l) {
+            const uint32_t lo = level_offsets[l], cnt = level_offsets[l + 1] - lo;
+            const uint32_t batch = (cnt + (uint32_t)threads - 1) / (uint32_t)threads;
+            for (int k = 0; k < threads; ++k) {
+                uint64_t a0 = (uint64_t)batch * (uint64_t)k, a1 = a0 + batch;
+                jobs[k].lo = lo + (uint32_t)(a0 > cnt ? cnt : a0);
+                jobs[k].hi = lo + (uint32_t)(a1 > cnt ? cnt : a1);
+                jobs[k].root_level = l == 0;
+            }
+            pthread_barrier_wait(&pool.start);
+            tree_job_run(&jobs[0]);
+            pthread_barrier_wait(&pool.done);
+        }
+    clock_gettime(CLOCK_MONOTONIC, &b);
+    pool.stop = 1;
+    pthread_barrier_wait(&pool.start);
+    for (int k = 1; k < threads; ++k) pthread_join(th[k], NULL);
+    pthread_barrier_destroy(&pool.start);
+    pthread_barrier_destroy(&pool.done);
+    free(jobs); free(th); free(args);
+    return (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
+}

@@ -295,6 +295,9 @@ double orc_bench_flat_frame(uint32_t n, const float* translation, const float* r
                             const uint32_t* view_layer_masks, const uint8_t* view_flags,
                             uint32_t n_views, int threads, int iters);
 
+double orc_bench_tree_frame(uint32_t n, const uint32_t* parent, const uint32_t* level_offsets, uint32_t n_levels, const float* t,
+                            const float* r, const float* s, float* g, int threads, int iters);
+
 /* ---- batching work-item build (batching_oracle.c) ---------------------------------------- */
 #define ORC_NO_BATCH_SET 0xFFFFFFFFu
 typedef struct orc_binned_mesh_instance { uint32_t input_uniform_index, bin_index; } orc_binned_mesh_instance; /* render_phase/mod.rs:777 */

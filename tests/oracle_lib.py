@@ -469,3 +469,14 @@ def batch_build(rows, row_set, row_bin, row_input, set_indexed, bin_table_offset
                 totals=dict(work_item_len=list(tot.work_item_len), indirect_parameters_len=list(tot.indirect_parameters_len),
                             batch_set_len=list(tot.batch_set_len), data_buffer_len=int(tot.data_buffer_len)),
                 bin_metadata=meta)
+
+
+def bench_tree_frame(parent, level_offsets, t, r, s, threads, iters):
+    """Level-parallel propagate (all Transforms changed) on a persistent pool; -> (seconds, G)."""
+    n = len(parent)
+    g = np.zeros(12 * n, np.float32)
+    lo = np.ascontiguousarray(level_offsets, np.uint32)
+    lib().orc_bench_tree_frame.restype = C.c_double
+    secs = lib().orc_bench_tree_frame(C.c_uint32(n), u32p(np.ascontiguousarray(parent, np.uint32)), u32p(lo), C.c_uint32(len(lo) - 1),
+                                      fp(t), fp(r), fp(s), fp(g), int(threads), int(iters))
+    return float(secs), g

@@ -755,7 +755,7 @@ int32_t mi_propagate(mi_ctx* ctx, uint32_t flags) {
             HIP_TRY(ctx, launch_propagate_tiles(c, (const uint32_t*)ctx->parent_idx.p, (const TileDesc*)ctx->tiles.p + gr.first,
                                                 (const uint32_t*)ctx->chains.p + (size_t)gr.first * TILE_MAX_CHAIN, gr.count,
                                                 (const uint8_t*)ctx->node_flags.p, ctx->changed, tree_bits, ctx->g_changed_bytes,
-                                                gr.n_chain ? snap_r : nullptr, gr.n_chain ? snap_w : nullptr, all_dirty, static_opt,
+                                                gr.n_chain ? snap_r : nullptr, gr.n_chain ? snap_w : nullptr, gr.owner_rows, all_dirty, static_opt,
                                                 ctx->stream));
         }
         ctx->g_chg_in_bytes = true;

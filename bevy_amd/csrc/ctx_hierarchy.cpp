@@ -71,6 +71,16 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
     ctx->passes.clear();
     ctx->groups.clear();
     auto level_size = [&](uint32_t lv) -> uint64_t { return lv < n_levels ? level_offsets[lv + 1] - level_offsets[lv] : 0; };
+    // MI_TILE_PLAN="2,5,4": explicit band depths (experiments)
+    std::vector<uint32_t> plan;
+    if (const char* pe = getenv("MI_TILE_PLAN")) {
+        for (const char* q = pe; *q;) {
+            plan.push_back((uint32_t)std::max(1, atoi(q)));
+            while (*q && *q != ',') ++q;
+            if (*q == ',') ++q;
+        }
+    }
+    uint32_t band = 0;
     uint32_t l = 0;  // first level this pass computes
     while (l < n_levels) {
         const bool roots = l == 0;
@@ -82,6 +92,8 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
             ++d;
             upper += level_size(l + d - 1);
         }
+        if (band < plan.size()) d = std::min<uint32_t>(std::min<uint32_t>(plan[band], TILE_MAX_LEVELS), n_levels - l);
+        ++band;
         // [lo,hi) is a row range of the rooting level; returns the tile and whether it fits
         auto build = [&](uint32_t lo, uint32_t hi, TileDesc& td) -> bool {
             uint32_t clo = lo, chi2 = hi;
@@ -107,9 +119,10 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
         // still gives tiles of a decent size.
         uint64_t pass_rows = 0;
         for (uint32_t k = 0; k < d; ++k) pass_rows += level_size(l + k);
-        const bool chain_candidate = !roots && l <= TILE_MAX_CHAIN && !ctx->groups.empty() && ctx->groups.back().n_chain == 0 &&
-                                     ctx->groups.back().count <= 64 && getenv("MI_TILE_NO_CHAIN") == nullptr &&
-                                     n_roots <= 16384 && pass_rows >= 128 * n_roots;
+        // (several chained passes may share a launch: chain tiles read the pre-frame snapshot, nobody waits for anybody)
+        const bool chain_candidate = !roots && l <= TILE_MAX_CHAIN && !ctx->groups.empty() &&
+                                     (!plan.empty() || (ctx->groups.back().n_chain == 0 && ctx->groups.back().count <= 64)) &&
+                                     getenv("MI_TILE_NO_CHAIN") == nullptr && n_roots <= 16384 && pass_rows >= 128 * n_roots;
         const uint32_t first_tile = (uint32_t)tiles.size();
         const uint32_t rl = roots ? 0 : l - 1;
         const uint32_t rlo = level_offsets[rl], rhi = level_offsets[rl + 1];
@@ -159,8 +172,8 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
         }
         if (chainable) {
             ctx->groups.back().count += n_pass_tiles;
-            ctx->groups.back().n_chain = n_pass_tiles;
-            ctx->groups.back().owner_rows = level_offsets[l];  // the owners' rows are the prefix [0, first row of level l)
+            ctx->groups.back().n_chain += n_pass_tiles;
+            ctx->groups.back().owner_rows = level_offsets[l];  // the snapshot prefix: every row above the deepest chained pass
         } else {
             ctx->groups.push_back({first_tile, n_pass_tiles, 0u, 0u});
         }

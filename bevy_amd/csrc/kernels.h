@@ -214,7 +214,8 @@ hipError_t launch_mark_dirty(uint32_t n, const uint8_t* changed, const uint32_t*
 // One launch over a group of mutually independent tiles (TileDesc::kind tells roots / chain / dependent apart).
 hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, const TileDesc* d_tiles, const uint32_t* d_chains,
                                   uint32_t n_tiles, const uint8_t* node_flags, const uint8_t* changed, const uint32_t* tree_bits,
-                                  uint8_t* g_changed_bytes, const float* snap_read, float* snap_write, bool all_dirty, bool static_opt,
+                                  uint8_t* g_changed_bytes, const float* snap_read, float* snap_write, uint32_t snap_rows, bool all_dirty,
+                                  bool static_opt,
                                   hipStream_t stream);
 // InheritedVisibility propagation (visibility_propagate_system): writes bit0 of flags[] and changed bytes.
 hipError_t launch_inherit_flat(uint32_t n, const uint8_t* visibility, uint8_t* flags, uint8_t* inh_changed, hipStream_t stream);

@@ -108,6 +108,7 @@ struct TreeArgs {
     // launch), this frame's owners write snap_write for the next one.  No tile ever waits for another.
     const float* snap_read;
     float* snap_write;
+    uint32_t snap_rows;  // the snapshot covers rows [0, snap_rows): whoever computes one of them also writes its snapshot
     uint32_t all_dirty;
     uint32_t static_opt;
 };
@@ -212,7 +213,7 @@ __device__ __forceinline__ void process_tile(const Columns& c, const TreeArgs& a
     const uint32_t L = td.n_levels;
     const bool ROOTS = (td.kind & TILE_ROOTS) != 0;
     const uint32_t chain_len = td.kind & TILE_CHAIN_MASK;
-    float* const snap_out = chain_len ? nullptr : a.snap_write;  // owner tiles of a launch with chain tiles
+    float* const snap_out = a.snap_write;  // launches with chain tiles: rows below snap_rows are mirrored for the next frame
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
 
     // Leading levels resident in LDS: every level but the last, while the running row total fits.
@@ -348,7 +349,7 @@ __device__ __forceinline__ void process_tile(const Columns& c, const TreeArgs& a
         for (uint32_t j = 0; j < TILE_MAX_LEVELS - 1; ++j) {
             if (j < n_lds) {
                 float4* dst = reinterpret_cast<float4*>(c.global) + 3ull * td.start[j];
-                float4* snp = snap_out ? reinterpret_cast<float4*>(snap_out) + 3ull * td.start[j] : nullptr;
+                float4* snp = (snap_out && td.start[j] < a.snap_rows) ? reinterpret_cast<float4*>(snap_out) + 3ull * td.start[j] : nullptr;
                 const float4* src = lds_g + 3u * ubase[j];
                 const uint32_t n4 = 3u * td.count[j];
                 for (uint32_t i = tid; i < n4; i += BLOCK) {
@@ -413,7 +414,7 @@ __device__ __forceinline__ void process_tile(const Columns& c, const TreeArgs& a
             if (live) {
                 chg = node_update(a, root_level, row, gp, p_changed, local, old, &cur);
                 a.g_changed_bytes[row] = chg ? 1 : 0;
-                if (snap_out) st_affine(snap_out, row, cur);
+                if (snap_out && row < a.snap_rows) st_affine(snap_out, row, cur);
             }
             // store: whole wave changed (the dirty-tree case) -> transpose back and write 3 x 1 KB rows;
             // otherwise only the changed lanes write their own 48 bytes.
@@ -577,12 +578,14 @@ hipError_t launch_mark_dirty(uint32_t n, const uint8_t* changed, const uint32_t*
 
 hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, const TileDesc* d_tiles, const uint32_t* d_chains,
                                   uint32_t n_tiles, const uint8_t* node_flags, const uint8_t* changed, const uint32_t* tree_bits,
-                                  uint8_t* g_changed_bytes, const float* snap_read, float* snap_write, bool all_dirty, bool static_opt,
+                                  uint8_t* g_changed_bytes, const float* snap_read, float* snap_write, uint32_t snap_rows, bool all_dirty,
+                                  bool static_opt,
                                   hipStream_t stream) {
     if (n_tiles == 0) return hipSuccess;
     TreeArgs a;
     a.snap_read = snap_read;
     a.snap_write = snap_write;
+    a.snap_rows = snap_rows;
     a.parent_idx = parent_idx;
     a.tiles = d_tiles;
     a.node_flags = node_flags;

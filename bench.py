@@ -132,6 +132,8 @@ def build_flat(ctx, args, rank, world, total_frames, full_holder):
                              if deferred_compaction is True else "")
                           + (f" + one in-place RCCL all-gather of the visibility bitmask per frame over {world} GPUs "
                              f"({gather.mode}, pipelined one frame deep on its own stream)" if gather is not None else ""),
+              "baseline_config": "BASELINE.json configs[1] (propagate + frustum-cull; the cluster stage of the metric's name is "
+                                 "configs[2], reported under other_workloads.lights)",
               "entities_per_gpu": n_local, "views": n_views, "deferred_compaction": deferred_compaction, "parallelism": f"row-range shard x{world}"}
     if gather is not None and gather.fallback_reason:
         config["rccl_direct_fallback"] = gather.fallback_reason

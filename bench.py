@@ -420,7 +420,7 @@ def main():
                "host_enqueue_ms_per_step": round(1e3 * wl.host_enqueue_s / args.steps, 5),
                "roofline": roofline_of(wl, prof, args.steps), "cpu_baseline": None,
                "kernels": {k: round(v["avg_us"], 3) for k, v in prof.items()}}
-        if not args.no_cpu_baseline and args.workload == "flat":
+        if not args.no_cpu_baseline and args.workload == "flat" and world == 1:  # reported at N = 1 only
             import oracle_lib as O  # the oracle doubles as the reported CPU baseline ("port"), never as the product
             from bevy_amd import workloads as W
             cores = os.cpu_count() or 1

@@ -51,6 +51,30 @@ class ClusterView(C.Structure):
         return self.dims[0] * self.dims[1] * self.dims[2]
 
 
+class ClusterConfig(C.Structure):
+    """mi_cluster_config"""
+    _fields_ = [("kind", C.c_uint32), ("dimensions", C.c_uint32 * 3), ("total", C.c_uint32), ("z_slices", C.c_uint32),
+                ("first_slice_depth", C.c_float), ("far_z_mode", C.c_uint32), ("far_z_constant", C.c_float),
+                ("dynamic_resizing", C.c_uint32)]
+
+
+class ClusterHistory(C.Structure):
+    """mi_cluster_history"""
+    _fields_ = [("has_farthest_z", C.c_uint32), ("farthest_z", C.c_float), ("has_total_cluster_index_count", C.c_uint32),
+                ("reserved", C.c_uint32), ("total_cluster_index_count", C.c_uint64)]
+
+
+class ClusterResolved(C.Structure):
+    """mi_cluster_resolved"""
+    _fields_ = [("active", C.c_uint32), ("requested_dims", C.c_uint32 * 3), ("first_slice_depth", C.c_float), ("far_z", C.c_float)]
+
+
+CLUSTER_CONFIG_NONE, CLUSTER_CONFIG_SINGLE, CLUSTER_CONFIG_XYZ, CLUSTER_CONFIG_FIXED_Z = 0, 1, 2, 3
+CLUSTER_FAR_Z_MAX_CLUSTERABLE_OBJECT_RANGE, CLUSTER_FAR_Z_CONSTANT = 0, 1
+VIEW_CLUSTER_BINDINGS_MAX_INDICES = 16384
+MAX_UNIFORM_BUFFER_CLUSTERABLE_OBJECTS = 204
+
+
 class View(C.Structure):
     """mi_view"""
     _fields_ = [("frustum", C.c_float * 24), ("layer_mask", C.c_uint32), ("flags", C.c_uint32),
@@ -90,6 +114,8 @@ ABI_SYMBOLS = [
     "mi_download_visible_entities", "mi_cluster_view_dims", "mi_cluster_view_build",
     "mi_cluster_dimensions_fixed_z", "mi_cluster_assign", "mi_cluster_upload_objects", "mi_cluster_upload_view",
     "mi_cluster_assign_resident", "mi_cluster_download", "mi_cluster_download_bindings",
+    "mi_cluster_config_default", "mi_cluster_config_resolve", "mi_cluster_sort_truncate", "mi_cluster_bind_objects_to_rows",
+    "mi_cluster_assign_frame",
     "mi_batch_upload_rows", "mi_batch_upload_sets", "mi_batch_build", "mi_batch_download_totals", "mi_batch_download", "mi_perspective_clip_from_view", "mi_compute_frustum",
     "mi_bind_visibility_output", "mi_exchange_configure", "mi_exchange_configure_multi", "mi_exchange_last", "mi_device_buffer", "mi_timer_begin", "mi_timer_end", "mi_profile_enable",
     "mi_profile_filter", "mi_profile_sample", "mi_profile_burst", "mi_profile_read", "mi_profile_kernel_name",
@@ -180,6 +206,30 @@ def cluster_dimensions_fixed_z(total, z_slices, w, h):
     out = (C.c_uint32 * 3)()
     _host_check(load_library().mi_cluster_dimensions_fixed_z(total, z_slices, w, h, out), "mi_cluster_dimensions_fixed_z")
     return tuple(out)
+
+
+def cluster_config_default():
+    cfg = ClusterConfig()
+    _host_check(load_library().mi_cluster_config_default(C.byref(cfg)), "mi_cluster_config_default")
+    return cfg
+
+
+def cluster_config_resolve(config, history, w, h, max_indices=VIEW_CLUSTER_BINDINGS_MAX_INDICES):
+    out = ClusterResolved()
+    _host_check(load_library().mi_cluster_config_resolve(C.byref(config), C.byref(history) if history is not None else None, w, h,
+                                                         C.c_uint64(max_indices), C.byref(out)), "mi_cluster_config_resolve")
+    return out
+
+
+def cluster_sort_truncate(obj_type, shadow_maps_enabled, volumetric, entity_bits, max_objects, supports_storage_buffers):
+    ty, sh, vo, en = _u8(obj_type), _u8(shadow_maps_enabled), _u8(volumetric), _u64(entity_bits)
+    n = len(en)
+    order = np.zeros(max(n, 1), np.uint32)
+    out_n = C.c_uint32(0)
+    _host_check(load_library().mi_cluster_sort_truncate(n, _ptr(ty, C.c_uint8), _ptr(sh, C.c_uint8), _ptr(vo, C.c_uint8),
+                                                        _ptr(en, C.c_uint64), max_objects, int(bool(supports_storage_buffers)),
+                                                        _ptr(order, C.c_uint32), C.byref(out_n)), "mi_cluster_sort_truncate")
+    return order[:out_n.value]
 
 
 def cluster_view_build(camera_affine, clip_from_view, frustum, w, h, requested_dims, first_slice_depth, far_z,
@@ -434,6 +484,20 @@ class Context:
 
     def cluster_upload_view(self, view):
         self._ck(self._lib.mi_cluster_upload_view(self._h, C.byref(view)))
+
+    def cluster_bind_objects_to_rows(self, first_row, n_objects):
+        self._ck(self._lib.mi_cluster_bind_objects_to_rows(self._h, first_row, n_objects))
+
+    def cluster_assign_frame(self, config, history, camera_affine, clip_from_view, frustum, w, h, view_layer_mask=1,
+                             max_indices=VIEW_CLUSTER_BINDINGS_MAX_INDICES):
+        """-> (ClusterView used, active).  `history` (ClusterHistory) is updated in place."""
+        cam, cfv, fr = _f32(camera_affine), _f32(clip_from_view), _f32(frustum)
+        view = ClusterView()
+        active = C.c_uint32(0)
+        self._ck(self._lib.mi_cluster_assign_frame(self._h, C.byref(config), C.byref(history), _ptr(cam, C.c_float), _ptr(cfv, C.c_float),
+                                                   _ptr(fr, C.c_float), w, h, view_layer_mask, C.c_uint64(max_indices), C.byref(view),
+                                                   C.byref(active)))
+        return view, bool(active.value)
 
     def cluster_assign_resident(self, want_total=False):
         tot = C.c_uint64(0)

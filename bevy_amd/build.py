@@ -27,26 +27,56 @@ def hipcc():
     return "hipcc"
 
 
+OBJ_DIR = os.path.join(HERE, "build")
+CFLAGS = [f for f in FLAGS if f != "-shared"]
+
+
+def _deps():
+    return [os.path.join(CSRC, f) for f in HEADERS] + [os.path.abspath(__file__)]
+
+
 def up_to_date():
     if not os.path.exists(LIB):
         return False
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, f) for f in SOURCES] + _deps()
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
 def build(force=False, verbose=False):
+    """One object per translation unit (only the stale ones are recompiled, all of them in parallel), then one link."""
     if not force and up_to_date():
         return LIB
-    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hdr_t = max(os.path.getmtime(d) for d in _deps())
+    procs, objs = [], []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(OBJ_DIR, src + ".o")
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(sp), hdr_t):
+            continue
+        cmd = [hipcc()] + CFLAGS + ["-x", "hip", "-c", sp, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = False
+    for src, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            failed = True
+            sys.stderr.write(out)
+        elif verbose and out:
+            sys.stderr.write(out)
+    if failed:
+        raise RuntimeError("hipcc failed building libbevy_mi355x.so")
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         sys.stderr.write(res.stdout + res.stderr)
-        raise RuntimeError("hipcc failed building libbevy_mi355x.so")
-    if verbose and res.stderr:
-        sys.stderr.write(res.stderr)
+        raise RuntimeError("hipcc failed linking libbevy_mi355x.so")
     return LIB
 
 

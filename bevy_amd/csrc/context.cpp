@@ -262,7 +262,12 @@ int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg, 
         f.out_rows = (uint32_t*)ctx->fb[ctx->cur].out_rows.p;
         f.seg_stride = ctx->seg_stride;
         f.seg_totals = (uint32_t*)ctx->fb[ctx->cur].seg_totals.p;
-        if ((flags & MI_CULL_MORE_FRAMES) && (!ctx->xch.on || ctx->xch.kernel_signal)) {
+        // A deferred compaction reads this frame's masks while the next frame's kernel writes its own: that needs the
+        // masks in alternating buffers.  The internal sets alternate, the exchange's gathered buffers rotate and the
+        // per-class segment masks live in the frame set; a single caller-bound buffer (mi_bind_visibility_output
+        // without the exchange) read as the segment mask does not -- compact inline then.
+        const bool masks_alternate = !ctx->ext_bitmask || ctx->xch.on || seg.seg_mask != nullptr;
+        if ((flags & MI_CULL_MORE_FRAMES) && masks_alternate && (!ctx->xch.on || ctx->xch.kernel_signal)) {
             // Another frame follows at once: this frame's compaction rides in extra workgroups of that frame's kernel (one
             // launch per frame instead of two); compaction_join launches it on its own if something else comes first.
             // With the exchange on it still publishes "this frame's masks are complete", and the frame's all-gather is
@@ -333,6 +338,16 @@ bool frame_begin(mi_ctx* ctx, CompactFastArgs* prev, bool* prev_has_job, mi_ctx:
     return have;
 }
 
+// A cull frame failed after frame_begin took the previous frame's deferred compaction out of the context: launch it on
+// its own and hand its all-gather to the exchange thread (what compaction_join would have done), so that nothing waits
+// for a launch that will never be submitted.  Returns `rc` for `return frame_abort(...)`.
+int32_t frame_abort(mi_ctx* ctx, int32_t rc, const CompactFastArgs* prev, bool prev_has_job, const mi_ctx::Exchange::Job& prev_job) {
+    if (prev) launch_compact_fast(*prev, ctx->stream);
+    if (prev_has_job) exchange_push(ctx, prev_job);
+    ctx->cur ^= 1u;  // the failed frame wrote nothing: the previous frame's set stays the current one
+    return rc;
+}
+
 // Everything that exposes VisibleEntities (downloads, the batching build, MI_BUF_VISIBLE_ROWS, mi_synchronize) joins
 // first; the join only enqueues, so device-side consumers on the context's stream are ordered behind it.
 int32_t compaction_join(mi_ctx* ctx) {
@@ -348,6 +363,51 @@ int32_t compaction_join(mi_ctx* ctx) {
 }
 
 }  // namespace mi_detail
+
+// The frame entry points share one body: PROPAGATE selects the fused flat kernel (mi_propagate_and_cull).
+template <bool PROPAGATE>
+static int32_t cull_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint32_t flags) {
+    // validate before anything changes: a failed call must leave the previous frame's deferred compaction in place
+    if (!views || n_views == 0) return fail(ctx, MI_ERR_INVALID_ARG, "mi_cull: views NULL or n_views == 0");
+    if (PROPAGATE && ctx->have_hierarchy)
+        return fail(ctx, MI_ERR_NOT_READY, "mi_propagate_and_cull is the flat fast path; a hierarchy is uploaded -- use mi_propagate + mi_cull");
+    VisibilityOut vo{};
+    CompactFastArgs prev_args{};
+    bool prev_has_job = false;
+    mi_ctx::Exchange::Job prev_job{};
+    const CompactFastArgs* prev = frame_begin(ctx, &prev_args, &prev_has_job, &prev_job) ? &prev_args : nullptr;
+    int32_t rc = exchange_begin(ctx);
+    if (rc) return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
+    if ((rc = prepare_views(ctx, views, n_views, &vo))) return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
+    SegOut seg;
+    if ((rc = prepare_segments(ctx, n_views, &seg))) return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
+    Columns c = columns_of(ctx);
+    {
+        ProfScope ps(ctx, PROPAGATE ? K_FLAT_PROPAGATE_CULL : K_CULL);
+        const hipError_t e = PROPAGATE ? launch_flat_propagate_cull(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p,
+                                                                    n_views, vo, seg, flags & MI_CULL_END_FRAME, prev, ctx->stream)
+                                       : launch_cull(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p, n_views, vo,
+                                                     seg, flags & (MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME), prev, ctx->stream);
+        if (e != hipSuccess) {
+            fail(ctx, MI_ERR_DEVICE, "frame kernel launch: %s", hipGetErrorString(e));
+            return frame_abort(ctx, MI_ERR_DEVICE, prev, prev_has_job, prev_job);
+        }
+    }
+    if (prev && ctx->n == 0) HIP_TRY(ctx, launch_compact_fast(*prev, ctx->stream));  // no frame kernel to ride in
+    if (prev_has_job) exchange_push(ctx, prev_job);  // the launch that publishes the previous frame's signal is submitted
+    if ((rc = run_compaction(ctx, vo, seg, flags))) return rc;
+    if (PROPAGATE) {
+        if (ctx->have_changed && ctx->changed_maybe) {
+            HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, ctx->n, ctx->stream));
+            ctx->changed_maybe = false;
+        }
+        ctx->g_chg_maybe = true;
+        ctx->g_chg_in_bytes = false;
+        ctx->propagated_rows = ctx->n;
+    }
+    ctx->culled = true;
+    return exchange_end(ctx);
+}
 
 // =============================================================================================
 // lifecycle
@@ -483,6 +543,7 @@ int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
     }
     ctx->bt_resolve = true;
     ctx->changed_maybe = true;
+    const uint32_t old_cap_rows = ctx->cap;
     if (n_rows > ctx->cap) {
         uint32_t new_cap = std::max<uint64_t>(n_rows, std::min<uint64_t>((uint64_t)ctx->cap * 3 / 2, 0xFFFFFF00ull));
         new_cap = (uint32_t)(((uint64_t)new_cap + 255u) / 256u * 256u);  // whole workgroups
@@ -534,6 +595,22 @@ int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->tree_bits, 0, padded_words(new_cap) * 8 + 256, ctx->stream));
         ctx->cap = new_cap;
     }
+    if (n_rows > ctx->n && ctx->n < old_cap_rows) {
+        // Rows [n, min(n_rows, old capacity)) come (back) to life inside the existing allocation: they may hold a previous
+        // occupant's values (shrink, then regrow).  Give them what a freshly allocated row has -- in particular
+        // changed = 1: they are Added<GlobalTransform> rows and the next propagate must compute them.
+        const uint32_t lo = ctx->n, cnt = std::min(n_rows, old_cap_rows) - lo;
+        struct { void* p; size_t elem; int fill; } cols[] = {
+            {ctx->t, 12, 0}, {ctx->r, 16, 0}, {ctx->s, 12, 0}, {ctx->g, 48, 0}, {ctx->c, 12, 0}, {ctx->h, 12, 0},
+            {ctx->flags, 1, MI_FLAG_INHERITED_VISIBLE}, {ctx->vv, 1, 0}, {ctx->changed, 1, 1}, {ctx->g_changed_bytes, 1, 0},
+            {ctx->class_mask, 4, 0}, {ctx->keys, 8, 0}, {ctx->range, 8, 0}, {ctx->visibility, 1, 0}, {ctx->inh_changed, 1, 0},
+            {ctx->bt_set, 4, 0xFF}, {ctx->bt_bin, 4, 0}, {ctx->bt_input, 4, 0}, {ctx->bt_row_meta, 4, 0xFF}};
+        for (auto& cdesc : cols)
+            if (cdesc.p) HIP_TRY(ctx, hipMemsetAsync((char*)cdesc.p + (size_t)lo * cdesc.elem, cdesc.fill, (size_t)cnt * cdesc.elem, ctx->stream));
+        HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->layers + lo), 1, cnt, ctx->stream));  // default RenderLayers = layer 0
+        ctx->propagated_rows = std::min(ctx->propagated_rows, lo);
+    }
+    if (n_rows < ctx->propagated_rows) ctx->propagated_rows = n_rows;
     if (n_rows != ctx->n) {
         // a different row count invalidates the hierarchy and any cull result
         ctx->have_hierarchy = false;
@@ -592,8 +669,10 @@ int32_t mi_upload_transforms_indexed(mi_ctx* ctx, uint32_t n, const uint32_t* ro
     void* dev = nullptr;
     HIP_TRY(ctx, hipHostGetDevicePointer(&dev, st, 0));
     if (!ctx->have_changed) {
-        // first use of the change column: rows never marked count as unchanged from here on
-        HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, ctx->n, ctx->stream));
+        // First use of the change column: rows a propagate has already consumed count as unchanged from here on.  Rows
+        // that have not been through one yet are still Added<GlobalTransform> (systems.rs:45-50) and keep their mark.
+        if (ctx->propagated_rows)
+            HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, std::min(ctx->propagated_rows, ctx->n), ctx->stream));
         ctx->have_changed = true;
     }
     HIP_TRY(ctx, launch_upload_trs_indexed((const uint32_t*)dev, n, ctx->t, ctx->r, ctx->s, ctx->changed, ctx->stream));
@@ -750,12 +829,15 @@ int32_t mi_propagate(mi_ctx* ctx, uint32_t flags) {
             }
             ctx->snap_parity ^= 1u;
         }
+        // EVERY launch mirrors the rows it owns below snap_rows into next frame's snapshot -- not only the launch the
+        // chain tiles ride in: a chain runs up through rows owned by earlier launches too, and under the static-scene
+        // rule the chain tiles compare against (and fall back to) the snapshot's value.
         for (auto& gr : ctx->groups) {
             ProfScope sc(ctx, K_PROPAGATE_TILES);
             HIP_TRY(ctx, launch_propagate_tiles(c, (const uint32_t*)ctx->parent_idx.p, (const TileDesc*)ctx->tiles.p + gr.first,
                                                 (const uint32_t*)ctx->chains.p + (size_t)gr.first * TILE_MAX_CHAIN, gr.count,
                                                 (const uint8_t*)ctx->node_flags.p, ctx->changed, tree_bits, ctx->g_changed_bytes,
-                                                gr.n_chain ? snap_r : nullptr, gr.n_chain ? snap_w : nullptr, gr.owner_rows, all_dirty, static_opt,
+                                                gr.n_chain ? snap_r : nullptr, snap_w, ctx->snap_rows, all_dirty, static_opt,
                                                 ctx->stream));
         }
         ctx->g_chg_in_bytes = true;
@@ -764,6 +846,7 @@ int32_t mi_propagate(mi_ctx* ctx, uint32_t flags) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, ctx->n, ctx->stream));  // change flags are consumed
         ctx->changed_maybe = false;
     }
+    ctx->propagated_rows = ctx->n;
     return MI_OK;
 }
 
@@ -795,27 +878,7 @@ void simple_views(std::vector<mi_view>& v, const float* frusta, const uint32_t* 
 
 int32_t mi_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint32_t flags) {
     ENTER(ctx);
-    VisibilityOut vo{};
-    CompactFastArgs prev_args{};
-    bool prev_has_job = false;
-    mi_ctx::Exchange::Job prev_job{};
-    const CompactFastArgs* prev = frame_begin(ctx, &prev_args, &prev_has_job, &prev_job) ? &prev_args : nullptr;
-    int32_t rc = exchange_begin(ctx);
-    if (rc) return rc;
-    if ((rc = prepare_views(ctx, views, n_views, &vo))) return rc;
-    SegOut seg;
-    if ((rc = prepare_segments(ctx, n_views, &seg))) return rc;
-    Columns c = columns_of(ctx);
-    {
-        ProfScope ps(ctx, K_CULL);
-        HIP_TRY(ctx, launch_cull(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p, n_views, vo,
-                                 seg, flags & (MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME), prev, ctx->stream));
-    }
-    if (prev && ctx->n == 0) HIP_TRY(ctx, launch_compact_fast(*prev, ctx->stream));  // no frame kernel to ride in
-    if (prev_has_job) exchange_push(ctx, prev_job);  // the launch that publishes the previous frame's signal is submitted
-    if ((rc = run_compaction(ctx, vo, seg, flags))) return rc;
-    ctx->culled = true;
-    return exchange_end(ctx);
+    return cull_frame<false>(ctx, views, n_views, flags);
 }
 
 int32_t mi_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_masks, const uint8_t* view_flags,
@@ -827,35 +890,7 @@ int32_t mi_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_mas
 
 int32_t mi_propagate_and_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint32_t flags) {
     ENTER(ctx);
-    if (ctx->have_hierarchy)
-        return fail(ctx, MI_ERR_NOT_READY, "mi_propagate_and_cull is the flat fast path; a hierarchy is uploaded -- use mi_propagate + mi_cull");
-    VisibilityOut vo{};
-    CompactFastArgs prev_args{};
-    bool prev_has_job = false;
-    mi_ctx::Exchange::Job prev_job{};
-    const CompactFastArgs* prev = frame_begin(ctx, &prev_args, &prev_has_job, &prev_job) ? &prev_args : nullptr;
-    int32_t rc = exchange_begin(ctx);
-    if (rc) return rc;
-    if ((rc = prepare_views(ctx, views, n_views, &vo))) return rc;
-    SegOut seg;
-    if ((rc = prepare_segments(ctx, n_views, &seg))) return rc;
-    Columns c = columns_of(ctx);
-    {
-        ProfScope ps(ctx, K_FLAT_PROPAGATE_CULL);
-        HIP_TRY(ctx, launch_flat_propagate_cull(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p,
-                                                n_views, vo, seg, flags & MI_CULL_END_FRAME, prev, ctx->stream));
-    }
-    if (prev && ctx->n == 0) HIP_TRY(ctx, launch_compact_fast(*prev, ctx->stream));  // no frame kernel to ride in
-    if (prev_has_job) exchange_push(ctx, prev_job);  // the launch that publishes the previous frame's signal is submitted
-    if ((rc = run_compaction(ctx, vo, seg, flags))) return rc;
-    if (ctx->have_changed && ctx->changed_maybe) {
-        HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, ctx->n, ctx->stream));
-        ctx->changed_maybe = false;
-    }
-    ctx->g_chg_maybe = true;
-    ctx->g_chg_in_bytes = false;
-    ctx->culled = true;
-    return exchange_end(ctx);
+    return cull_frame<true>(ctx, views, n_views, flags);
 }
 
 int32_t mi_propagate_and_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_masks, const uint8_t* view_flags,

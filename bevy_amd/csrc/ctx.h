@@ -50,6 +50,7 @@ struct mi_ctx {
     uint64_t *keys = nullptr, *g_chg_bits = nullptr, *vv_chg_bits = nullptr;
     uint32_t* tree_bits = nullptr;
     bool have_class_mask = false, have_keys = false, have_changed = false;
+    uint32_t propagated_rows = 0;  // rows [0, propagated_rows) have been through a propagate (their Added<GlobalTransform> is consumed)
     uint32_t classes_present = 1u;
     std::vector<uint64_t> h_keys;
     bool order_dirty = false, order_identity = true;
@@ -173,7 +174,11 @@ struct mi_ctx {
     DevBuf cl_remap, cl_bind_oc, cl_bind_idx, cl_block_counts, cl_pair_cb, cl_pair_mask, cl_acc, cl_offsets, cl_indices, cl_scalars;
     uint32_t cl_parity = 0, cl_acc_clusters = 0, cl_acc_blocks = 0;  // cl_acc = 2 x [counts 6C | totals C | farthest_z + pad]
     uint32_t cl_n = 0;
-    bool cl_have_type = false, cl_have_layers = false, cl_have_spot = false, cl_any_spot = false;
+    bool cl_have_type = false, cl_have_layers = false, cl_have_spot = false, cl_have_spot_dir = false, cl_any_spot = false;
+    bool cl_rows_bound = false;      // mi_cluster_bind_objects_to_rows: object i is row cl_first_row + i
+    uint32_t cl_first_row = 0;
+    std::vector<float> cl_host_planes, cl_host_spheres;  // storage of the view mi_cluster_assign_frame builds
+    std::vector<float> cl_planes_sent, cl_spheres_sent;  // what the device copies currently hold (re-sent only when they change)
     mi::ClusterViewDev cl_view{};
     bool cl_have_view = false, cl_assigned = false;
 

@@ -133,6 +133,83 @@ int32_t mi_cluster_dimensions_fixed_z(uint32_t total, uint32_t z_slices, uint32_
     return MI_OK;
 }
 
+int32_t mi_cluster_config_default(mi_cluster_config* out) {
+    if (!out) return MI_ERR_INVALID_ARG;
+    // ClusterConfig::default() + ClusterZConfig::default(), crates/bevy_light/src/cluster/mod.rs:288-308
+    memset(out, 0, sizeof *out);
+    out->kind = MI_CLUSTER_CONFIG_FIXED_Z;
+    out->total = 4096;
+    out->z_slices = 24;
+    out->first_slice_depth = 5.0f;
+    out->far_z_mode = MI_CLUSTER_FAR_Z_MAX_CLUSTERABLE_OBJECT_RANGE;
+    out->dynamic_resizing = 1;
+    return MI_OK;
+}
+
+int32_t mi_cluster_config_resolve(const mi_cluster_config* config, const mi_cluster_history* last, uint32_t sw, uint32_t sh,
+                                  uint64_t max_indices, mi_cluster_resolved* out) {
+    if (!config || !out || config->kind > MI_CLUSTER_CONFIG_FIXED_Z) return MI_ERR_INVALID_ARG;
+    memset(out, 0, sizeof *out);
+    // assign.rs:328-339: ClusterConfig::None, or a viewport without pixels -> Clusters::clear()
+    if (config->kind == MI_CLUSTER_CONFIG_NONE || sw == 0 || sh == 0) return MI_OK;
+    // ClusterConfig::dimensions_for_screen_size, cluster/mod.rs:311-347
+    uint32_t dims[3] = {1, 1, 1};
+    if (config->kind == MI_CLUSTER_CONFIG_XYZ) {
+        memcpy(dims, config->dimensions, sizeof dims);
+    } else if (config->kind == MI_CLUSTER_CONFIG_FIXED_Z) {
+        if (config->total == 0 || config->z_slices == 0) return MI_ERR_INVALID_ARG;
+        int32_t rc = mi_cluster_dimensions_fixed_z(config->total, config->z_slices, sw, sh, dims);
+        if (rc) return rc;
+    }
+    if (dims[0] == 0 || dims[1] == 0 || dims[2] == 0) return MI_ERR_INVALID_ARG;  // Clusters::update debug_assert, mod.rs:399-401
+    const bool has_z_config = config->kind == MI_CLUSTER_CONFIG_XYZ || config->kind == MI_CLUSTER_CONFIG_FIXED_Z;
+    // first_slice_depth() / far_z_mode() / dynamic_resizing(), mod.rs:349-382: Single = (0.0, MaxClusterableObjectRange, false)
+    out->first_slice_depth = has_z_config ? config->first_slice_depth : 0.0f;
+    const bool constant_far = has_z_config && config->far_z_mode == MI_CLUSTER_FAR_Z_CONSTANT;
+    // assign.rs:350-355 (DEFAULT_FAR_DEPTH :37)
+    out->far_z = constant_far ? config->far_z_constant : ((last && last->has_farthest_z) ? last->farthest_z : 1000.0f);
+    // assign.rs:384-404
+    if (has_z_config && config->dynamic_resizing && last && last->has_total_cluster_index_count &&
+        last->total_cluster_index_count > max_indices) {
+        const float index_ratio = (float)max_indices / (float)last->total_cluster_index_count;  // usize as f32
+        const float xy_ratio = sqrtf(index_ratio);
+        dims[0] = std::max(f32_as_u32(floorf((float)dims[0] * xy_ratio)), 1u);
+        dims[1] = std::max(f32_as_u32(floorf((float)dims[1] * xy_ratio)), 1u);
+    }
+    memcpy(out->requested_dims, dims, sizeof dims);
+    out->active = 1;
+    return MI_OK;
+}
+
+int32_t mi_cluster_sort_truncate(uint32_t n, const uint8_t* obj_type, const uint8_t* shadow_maps_enabled, const uint8_t* volumetric,
+                                 const uint64_t* entity_bits, uint32_t max_objects, uint32_t supports_storage_buffers,
+                                 uint32_t* out_order, uint32_t* out_n) {
+    if ((n && !out_order) || !out_n) return MI_ERR_INVALID_ARG;
+    for (uint32_t i = 0; i < n; ++i) out_order[i] = i;
+    *out_n = n;
+    if (n <= max_objects || supports_storage_buffers) return MI_OK;  // assign.rs:297-300
+    if (!entity_bits) return MI_ERR_INVALID_ARG;
+    // sort_by_cached_key(|o| (o.object_type.ordering(), o.entity)), assign.rs:301-306; ordering() :108-128.
+    // Tuple order: type, then the two negated bools (false < true), then Entity (= to_bits, entity/mod.rs:566-568).
+    auto key = [&](uint32_t i, uint32_t k[3]) {
+        const uint32_t t = obj_type ? obj_type[i] : (uint32_t)MI_OBJ_POINT_LIGHT;
+        const bool light = t == MI_OBJ_POINT_LIGHT || t == MI_OBJ_SPOT_LIGHT;
+        k[0] = t;
+        k[1] = light ? !(shadow_maps_enabled && shadow_maps_enabled[i]) : 0u;
+        k[2] = light ? !(volumetric && volumetric[i]) : 0u;
+    };
+    std::stable_sort(out_order, out_order + n, [&](uint32_t a, uint32_t b) {
+        uint32_t ka[3], kb[3];
+        key(a, ka);
+        key(b, kb);
+        for (int j = 0; j < 3; ++j)
+            if (ka[j] != kb[j]) return ka[j] < kb[j];
+        return entity_bits[a] < entity_bits[b];
+    });
+    *out_n = max_objects;  // truncate, :319-320
+    return MI_OK;
+}
+
 int32_t mi_cluster_view_dims(uint32_t sw, uint32_t sh, const uint32_t req[3], uint32_t tile[2], uint32_t dims[3]) {
     if (!req || !tile || !dims || sw == 0 || sh == 0 || req[0] == 0 || req[1] == 0 || req[2] == 0) return MI_ERR_INVALID_ARG;
     // Clusters::update, cluster/mod.rs:398-416

@@ -248,6 +248,12 @@ struct ClusterObjects {
     const uint32_t* layer_mask;  // n or nullptr
     const float* spot_dir;       // 3n or nullptr
     const float* spot_sin_cos;   // 2n or nullptr
+    // mi_cluster_bind_objects_to_rows: object i is row first_row + i of the context's columns.  It takes part only if
+    // ViewVisibility::get() (bit0 of row_vv), its centre is the row's GlobalTransform translation and a spot light's
+    // direction the row's GlobalTransform::back() -- the gather of assign.rs:190-296 done on the device.
+    const float* row_global;     // 12 floats per row, or nullptr = objects are not rows
+    const uint8_t* row_vv;
+    uint32_t first_row;
 };
 constexpr uint32_t CLUSTER_BLOCK = 256;  // objects per workgroup (= bits per cluster row in LDS)
 struct ClusterWork {

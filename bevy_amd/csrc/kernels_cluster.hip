@@ -128,8 +128,21 @@ __device__ __forceinline__ float get_distance_x(V4 plane, V3 p, bool ortho) {
 // The body of `for clusterable_object in &clusterable_objects` (assign.rs:487-804) for one object.
 // emit(cluster_index) is called for every cluster the reference would push this object into.
 // The two early-outs at the top of the per-object loop (assign.rs:489 RenderLayers, :496 frustum vs light sphere).
+// ClusterableObjectAssignmentData::sphere (assign.rs:52-59): (x, y, z, range).  Row-bound objects take the centre from
+// their row's GlobalTransform (point lights: GlobalTransform::from_translation(transform.translation()), :198).
+__device__ __forceinline__ float4 object_sphere(const ClusterObjects& o, uint32_t obj) {
+    float4 pr = reinterpret_cast<const float4*>(o.pos_range)[obj];
+    if (o.row_global) {
+        const float* g = o.row_global + 12ull * (o.first_row + obj);
+        pr.x = g[9];
+        pr.y = g[10];
+        pr.z = g[11];
+    }
+    return pr;
+}
 __device__ __forceinline__ bool object_in_view(const ClusterViewDev& v, const ClusterObjects& o, uint32_t obj) {
-    const float4 pr = reinterpret_cast<const float4*>(o.pos_range)[obj];
+    if (o.row_vv && !(o.row_vv[o.first_row + obj] & 1u)) return false;  // the gather's `if view_visibility.get()`, :194
+    const float4 pr = object_sphere(o, obj);
     const uint32_t layers = o.layer_mask ? o.layer_mask[obj] : 1u;
     if (!(v.view_layer_mask & layers)) return false;  // :489
     V4 fr[6];
@@ -145,7 +158,7 @@ __device__ __forceinline__ void assign_one_object(const ClusterViewDev& v, const
                                                   const float* xp, const float* yp, const float* zp,
                                                   float* far_z_out, bool* counted, Emit emit) {
     *counted = false;
-    const float4 pr = reinterpret_cast<const float4*>(o.pos_range)[obj];
+    const float4 pr = object_sphere(o, obj);
     const V3 center = V3{pr.x, pr.y, pr.z};
     const float range = pr.w;
     const uint32_t type = o.obj_type ? o.obj_type[obj] : 0u;
@@ -187,7 +200,18 @@ __device__ __forceinline__ void assign_one_object(const ClusterViewDev& v, const
     V3 light_dir = V3{0.0f, 0.0f, 0.0f};
     float angle_sin = 0.0f, angle_cos = 0.0f;
     if (type == 1u) {  // spot light, :563-573
-        const V3 d = V3{o.spot_dir[3 * obj], o.spot_dir[3 * obj + 1], o.spot_dir[3 * obj + 2]};
+        V3 d;
+        if (o.row_global) {  // GlobalTransform::back() = (matrix3 * Vec3::Z).normalize(), global_transform.rs:62-68,206
+            const float* g = o.row_global + 12ull * (o.first_row + obj);
+            M3 m3;
+            m3.x_axis = V3{g[0], g[1], g[2]};
+            m3.y_axis = V3{g[3], g[4], g[5]};
+            m3.z_axis = V3{g[6], g[7], g[8]};
+            const V3 z = mul(m3, V3{0.0f, 0.0f, 1.0f});
+            d = z * f_div(1.0f, f_sqrt((z.x * z.x + z.y * z.y) + z.z * z.z));
+        } else {
+            d = V3{o.spot_dir[3 * obj], o.spot_dir[3 * obj + 1], o.spot_dir[3 * obj + 2]};
+        }
         const V3 dv = xyz(mul(view_from_world, extend(d, 0.0f)));
         light_dir = dv * f_div(1.0f, f_sqrt(dot3(dv, dv)));
         angle_sin = o.spot_sin_cos[2 * obj];

@@ -133,7 +133,8 @@ __device__ __forceinline__ void store_affine_coalesced(float4* lds_wave, float* 
     lds_wave[lane * 3u + 2u] = make_float4(a.m.z_axis.z, a.t.x, a.t.y, a.t.z);
     __syncthreads();
     float4* dst = reinterpret_cast<float4*>(g) + 3ull * wave_row0;
-    const uint32_t lim = (n - wave_row0 < 64u ? n - wave_row0 : 64u) * 3u;  // float4s of live rows in this wave
+    // float4s of live rows in this wave (none for the dead waves of the last workgroup)
+    const uint32_t lim = wave_row0 < n ? (n - wave_row0 < 64u ? n - wave_row0 : 64u) * 3u : 0u;
 #pragma unroll
     for (uint32_t k = 0; k < 3u; ++k) {
         const uint32_t i = k * 64u + lane;
@@ -234,20 +235,19 @@ __device__ __forceinline__ void compact_fast_block(const CompactFastArgs& a, uin
 template <bool PROPAGATE, bool INLINE_VIEWS>
 __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const ViewParams* __restrict__ dviews,
                                                 uint32_t n_views, VisibilityOut out, SegOut seg, uint32_t fl_frame, uint32_t n_tiles,
-                                                CompactFastArgs prev, uint32_t prev_gx, uint32_t prev_first) {
+                                                CompactFastArgs prev, uint32_t prev_gx) {
     __shared__ float4 lds_g[4][192];
-    // extra workgroups: the deferred VisibleEntities compaction of the previous frame.  prev_first != 0 puts them at the
-    // head of the grid (they overlap the ramp-up instead of lengthening the tail)
+    // extra workgroups: the deferred VisibleEntities compaction of the previous frame, at the head of the grid (they
+    // overlap the ramp-up instead of lengthening the tail: 0.5 us per frame at 1 M rows)
     const uint32_t n_extra = gridDim.x - n_tiles;
-    const bool extra = prev_first ? blockIdx.x < n_extra : blockIdx.x >= n_tiles;
-    if (extra) {
-        const uint32_t id = prev_first ? blockIdx.x : blockIdx.x - n_tiles;
+    if (blockIdx.x < n_extra) {
+        const uint32_t id = blockIdx.x;
         if (prev.signal && id == 0 && threadIdx.x == 0)  // multi-GPU exchange: the previous frame's masks are complete
             __hip_atomic_store(prev.signal, prev.signal_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         compact_fast_block(prev, id % prev_gx, id / prev_gx, prev_gx);
         return;
     }
-    const uint32_t row = (blockIdx.x - (prev_first ? n_extra : 0u)) * 256u + threadIdx.x;
+    const uint32_t row = (blockIdx.x - n_extra) * 256u + threadIdx.x;
     const bool live = row < c.n;
     const uint32_t wave = row >> 6;
     const uint32_t lane = threadIdx.x & 63u;
@@ -524,7 +524,6 @@ static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, co
     const uint32_t n_tiles = blocks_for(c.n);
     CompactFastArgs pa{};
     uint32_t prev_gx = 1, prev_blocks = 0;
-    static const uint32_t prev_first = getenv("MI_DEFERRED_LAST") ? 0u : 1u;
     if (prev && prev->n && prev->n_segments) {
         pa = *prev;
         prev_gx = (((pa.n + 63u) >> 6) + 63u) / 64u;
@@ -532,11 +531,11 @@ static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, co
     }
     if (n_views <= MAX_INLINE_VIEWS && views_inline) {
         MI_LAUNCH((k_frame<PROPAGATE, true>), dim3(n_tiles + prev_blocks), dim3(256), 0, stream, c, *views_inline,
-                  (const ViewParams*)nullptr, n_views, out, seg, flags, n_tiles, pa, prev_gx, prev_first);
+                  (const ViewParams*)nullptr, n_views, out, seg, flags, n_tiles, pa, prev_gx);
     } else {
         ViewSet dummy = {};
         MI_LAUNCH((k_frame<PROPAGATE, false>), dim3(n_tiles + prev_blocks), dim3(256), 0, stream, c, dummy, d_views, n_views, out, seg,
-                  flags, n_tiles, pa, prev_gx, prev_first);
+                  flags, n_tiles, pa, prev_gx);
     }
     return hipGetLastError();
 }

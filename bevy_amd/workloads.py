@@ -129,6 +129,42 @@ def many_lights(n=100_000, radius=50.0, light_range=0.3):
     return np.ascontiguousarray(pos_range).reshape(-1)
 
 
+def concat_scenes(*scenes):
+    """Row-wise concatenation of scene dicts (same columns as many_cubes)."""
+    out = dict(n=sum(sc["n"] for sc in scenes))
+    for k in ("translation", "rotation", "scale", "aabb_center", "aabb_half", "flags", "layers"):
+        out[k] = np.ascontiguousarray(np.concatenate([sc[k] for sc in scenes]))
+    return out
+
+
+def light_rows(pos_range, seed=77):
+    """Point lights as ROWS of a scene: every light is an entity with a Transform, a world-space bounding Sphere
+    (update_point_light_bounding_spheres, crates/bevy_light/src/point_light.rs:195-208: centre = translation, radius =
+    range) and a ViewVisibility like any other entity; check_visibility culls it through the Sphere branch
+    (visibility/mod.rs:838-843) and assign_objects_to_clusters gathers the visible ones (assign.rs:190-215)."""
+    pr = np.asarray(pos_range, F).reshape(-1, 4)
+    n = len(pr)
+    h = np.zeros((n, 3), F)
+    h[:, 0] = pr[:, 3]
+    return dict(n=n, translation=np.ascontiguousarray(pr[:, :3]).reshape(-1), rotation=np.ascontiguousarray(random_unit_quats(seed, n)).reshape(-1),
+                scale=np.ones(3 * n, F), aabb_center=np.ascontiguousarray(pr[:, :3]).reshape(-1), aabb_half=h.reshape(-1),
+                flags=np.full(n, 0x01 | 0x08, np.uint8), layers=np.ones(n, np.uint32))
+
+
+def frame_scene(n_entities=1_000_000, n_lights=100_000, n_meshes=10_000, light_range=0.3, ragged_flags=False):
+    """The scene of BASELINE.json's metric -- "propagate + cull + cluster at 1M entities" -- in ONE context: configs[1]'s
+    many_cubes sphere (n_entities unit cubes, R = 500) followed by configs[2]'s many_lights set (n_meshes cubes on
+    R = 40, n_lights point lights on R = 50, range 0.3).  All three share the camera at the origin.  Returns
+    (scene, first_light_row, pos_range of the lights)."""
+    cubes = many_cubes(n_entities, ragged_flags=ragged_flags)
+    meshes = many_cubes(max(n_meshes, 1), radius=40.0, seed=43)
+    if n_meshes == 0:
+        meshes = {k: (v[:0] if k != "n" else 0) for k, v in meshes.items()}
+    pr = many_lights(n_lights, 50.0, light_range)
+    sc = concat_scenes(cubes, meshes, light_rows(pr))
+    return sc, n_entities + n_meshes, pr
+
+
 def gen_tree(depth, branch, max_nodes=None, seed=42):
     """Uniform tree (transform_hierarchy.rs:440-453): node i>0 has parent (i-1)//branch; rows are already in
     level (BFS) order.  Local transforms: translation on a radius-32 circle (:266-269,416-422) plus a seeded

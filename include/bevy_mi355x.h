@@ -337,6 +337,60 @@ int32_t mi_cluster_view_build(const float camera_affine[12], const float clip_fr
 int32_t mi_cluster_dimensions_fixed_z(uint32_t total, uint32_t z_slices, uint32_t screen_w, uint32_t screen_h,
                                       uint32_t out_dims[3]);
 
+/* ---- ClusterConfig and the per-frame feedback of assign_objects_to_clusters ------------------------------------
+ * ClusterConfig (crates/bevy_light/src/cluster/mod.rs:107-139; Default = FixedZ{4096, 24, first_slice_depth 5.0,
+ * MaxClusterableObjectRange, dynamic_resizing} :288-308), the two statistics a frame leaves for the next one
+ * (Clusters::last_frame_farthest_z / last_frame_total_cluster_index_count, cluster/mod.rs:152-164, written at
+ * assign.rs:810-811) and what assign.rs:324-404 derives from them before Clusters::update: the requested grid
+ * (dimensions_for_screen_size :311-347, then dynamic_resizing against view_cluster_bindings_max_indices =
+ * ViewClusterBindings::MAX_INDICES, crates/bevy_pbr/src/cluster/mod.rs:587, assign.rs:384-404), the configured first
+ * slice depth (:349-365 finishes it inside mi_cluster_view_build) and the far_z chosen by ClusterFarZMode (:350-355,
+ * DEFAULT_FAR_DEPTH = 1000 on the first frame, :37). */
+#define MI_CLUSTER_CONFIG_NONE 0u
+#define MI_CLUSTER_CONFIG_SINGLE 1u
+#define MI_CLUSTER_CONFIG_XYZ 2u
+#define MI_CLUSTER_CONFIG_FIXED_Z 3u
+#define MI_CLUSTER_FAR_Z_MAX_CLUSTERABLE_OBJECT_RANGE 0u
+#define MI_CLUSTER_FAR_Z_CONSTANT 1u
+#define MI_VIEW_CLUSTER_BINDINGS_MAX_INDICES 16384u /* ViewClusterBindings::MAX_INDICES */
+#define MI_MAX_UNIFORM_BUFFER_CLUSTERABLE_OBJECTS 204u /* crates/bevy_pbr/src/cluster/mod.rs:31 */
+typedef struct mi_cluster_config {
+    uint32_t kind;            /* MI_CLUSTER_CONFIG_* */
+    uint32_t dimensions[3];   /* XYZ */
+    uint32_t total, z_slices; /* FixedZ */
+    float first_slice_depth;  /* ClusterZConfig::first_slice_depth (XYZ, FixedZ) */
+    uint32_t far_z_mode;      /* MI_CLUSTER_FAR_Z_* (XYZ, FixedZ) */
+    float far_z_constant;     /* ClusterFarZMode::Constant */
+    uint32_t dynamic_resizing;
+} mi_cluster_config;
+typedef struct mi_cluster_history {
+    uint32_t has_farthest_z;  /* Option::is_some */
+    float farthest_z;
+    uint32_t has_total_cluster_index_count;
+    uint32_t reserved;
+    uint64_t total_cluster_index_count;
+} mi_cluster_history;
+typedef struct mi_cluster_resolved {
+    uint32_t active;            /* 0 = Clusters::clear(): ClusterConfig::None or an empty viewport (assign.rs:328-339) */
+    uint32_t requested_dims[3]; /* after dynamic resizing: what Clusters::update receives */
+    float first_slice_depth;    /* ClusterConfig::first_slice_depth() */
+    float far_z;                /* the value ClusterFarZMode selects */
+} mi_cluster_resolved;
+/* ClusterConfig::default() */
+int32_t mi_cluster_config_default(mi_cluster_config* out);
+/* Pure host code.  last == NULL = first frame (both statistics None). */
+int32_t mi_cluster_config_resolve(const mi_cluster_config* config, const mi_cluster_history* last, uint32_t screen_w,
+                                  uint32_t screen_h, uint64_t view_cluster_bindings_max_indices, mi_cluster_resolved* out);
+/* The UBO fallback of the gather (assign.rs:297-321): when storage buffers are unsupported and more than max_objects
+ * objects were gathered, they are sorted (stable, sort_by_cached_key) by (ClusterableObjectType::ordering(), Entity) --
+ * ordering() = (type, !shadow_maps_enabled, !volumetric) for point / spot lights, (type, false, false) otherwise
+ * (:108-128) -- and truncated.  out_order[0 .. *out_n) = the surviving objects as indices into the gathered arrays, in
+ * the order the per-object loop then visits them; identity when nothing has to be dropped.  shadow_maps_enabled /
+ * volumetric may be NULL (= false).  Pure host code. */
+int32_t mi_cluster_sort_truncate(uint32_t n, const uint8_t* obj_type, const uint8_t* shadow_maps_enabled, const uint8_t* volumetric,
+                                 const uint64_t* entity_bits, uint32_t max_objects, uint32_t supports_storage_buffers,
+                                 uint32_t* out_order, uint32_t* out_n);
+
 /* The per-object loop (assign.rs:487-811) over n_objects clusterable objects given in gather order
  * (point, spot, rect, reflection probes, irradiance volumes, decals; :190-296):
  *   pos_range[4n]   world translation + range (ClusterableObjectAssignmentData::sphere, :52-59)
@@ -356,7 +410,26 @@ int32_t mi_cluster_assign(mi_ctx* ctx, const mi_cluster_view* view, uint32_t n_o
 int32_t mi_cluster_upload_objects(mi_ctx* ctx, uint32_t n_objects, const float* pos_range, const uint8_t* obj_type,
                                   const uint32_t* layer_mask, const float* spot_dir, const float* spot_sin_cos);
 int32_t mi_cluster_upload_view(mi_ctx* ctx, const mi_cluster_view* view);
+/* Lights that are rows of this context (they have a Transform, a bounding Sphere and a ViewVisibility like every other
+ * entity: update_point_light_bounding_spheres, crates/bevy_light/src/point_light.rs:195-208): object i of the uploaded
+ * object arrays IS row first_row + i.  The assignment then applies the gather of assign.rs:190-296 on the device --
+ * an object takes part only if its row's ViewVisibility::get() is true (the cull of the same frame decided that), its
+ * sphere centre is the row's GlobalTransform translation (:198, :52-59) and a spot light's direction the row's
+ * GlobalTransform::back() (:567) -- so nothing about the lights crosses PCIe per frame; pos_range[4i+3] (range),
+ * obj_type, layer_mask and spot_sin_cos stay as uploaded.  Object indices in the output are positions in the
+ * uploaded arrays (= row - first_row); objects that are not visible simply appear in no cluster, exactly like
+ * entities the reference never gathered.  n_objects must equal the uploaded object count; n_objects = 0 unbinds. */
+int32_t mi_cluster_bind_objects_to_rows(mi_ctx* ctx, uint32_t first_row, uint32_t n_objects);
 int32_t mi_cluster_assign_resident(mi_ctx* ctx, uint64_t* out_total);
+/* One view of one frame exactly as the system runs it (assign.rs:324-811): resolve the config against `history`,
+ * build and upload the view constants, assign the resident objects, and store this frame's
+ * total_cluster_index_count / farthest_z back into `history` (:810-811).  out_view (optional) receives the view
+ * constants that were used (plane / sphere pointers are library-owned and valid until the next call).
+ * *out_active = 0 when the config resolved to Clusters::clear() (nothing assigned, history untouched). */
+int32_t mi_cluster_assign_frame(mi_ctx* ctx, const mi_cluster_config* config, mi_cluster_history* history,
+                                const float camera_affine[12], const float clip_from_view[16], const float frustum[24],
+                                uint32_t screen_w, uint32_t screen_h, uint32_t view_layer_mask,
+                                uint64_t view_cluster_bindings_max_indices, mi_cluster_view* out_view, uint32_t* out_active);
 int32_t mi_cluster_download(mi_ctx* ctx, uint32_t* out_offsets, uint32_t* out_indices, uint64_t capacity,
                             uint32_t* out_counts, uint64_t* out_total, float* out_farthest_z);
 

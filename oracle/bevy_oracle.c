@@ -805,6 +805,85 @@ void orc_clusters_update(uint32_t sw, uint32_t sh, const uint32_t req[3], uint32
     dims[2] = req[2] < 1 ? 1 : req[2];
 }
 
+/* ClusterConfig::default(), cluster/mod.rs:297-308 (ClusterZConfig::default :288-295) */
+void orc_cluster_config_default(orc_cluster_config* out) {
+    memset(out, 0, sizeof *out);
+    out->kind = 3; /* FixedZ */
+    out->total = 4096;
+    out->z_slices = 24;
+    out->first_slice_depth = 5.0f;
+    out->far_z_mode = 0; /* MaxClusterableObjectRange */
+    out->dynamic_resizing = 1;
+}
+
+/* assign.rs:324-404 up to (not including) clusters.update() */
+int orc_cluster_config_resolve(const orc_cluster_config* config, const float* last_farthest_z, const uint64_t* last_total,
+                               uint32_t sw, uint32_t sh, uint64_t max_indices, uint32_t req[3],
+                               float* out_first_slice_depth, float* out_far_z) {
+    /* :328-331 */
+    if (config->kind == 0) return 0;
+    /* :333-339: physical_viewport_size() must be Some and non-zero */
+    if (sw == 0 || sh == 0) return 0;
+    /* :342 config.dimensions_for_screen_size(screen_size), mod.rs:311-347 */
+    switch (config->kind) {
+    case 1: req[0] = req[1] = req[2] = 1; break;                       /* Single => UVec3::ONE */
+    case 2: memcpy(req, config->dimensions, 3 * sizeof(uint32_t)); break; /* XYZ => *dimensions */
+    default: orc_cluster_dimensions_fixed_z(config->total, config->z_slices, sw, sh, req); break;
+    }
+    /* mod.rs:349-382 */
+    float first_slice_depth = (config->kind == 2 || config->kind == 3) ? config->first_slice_depth : 0.0f;
+    int far_constant = (config->kind == 2 || config->kind == 3) && config->far_z_mode == 1;
+    int dynamic_resizing = (config->kind == 2 || config->kind == 3) && config->dynamic_resizing != 0;
+    /* :350-355 */
+    float far_z;
+    if (far_constant) far_z = config->far_z_constant;
+    else far_z = last_farthest_z ? *last_farthest_z : 1000.0f; /* unwrap_or(DEFAULT_FAR_DEPTH) */
+    /* :384-404 */
+    if (dynamic_resizing && last_total && *last_total > max_indices) {
+        float index_ratio = (float)max_indices / (float)*last_total;
+        float xy_ratio = sqrtf(index_ratio);
+        uint32_t x = f32_as_u32(floorf((float)req[0] * xy_ratio));
+        uint32_t y = f32_as_u32(floorf((float)req[1] * xy_ratio));
+        req[0] = x > 1 ? x : 1;
+        req[1] = y > 1 ? y : 1;
+    }
+    *out_first_slice_depth = first_slice_depth;
+    *out_far_z = far_z;
+    return 1;
+}
+
+/* ClusterableObjectType::ordering(), assign.rs:108-128, followed by the Entity: the sort key of :301-306 */
+typedef struct { uint8_t type, not_shadow, not_volumetric; uint64_t entity; uint32_t index; } sort_key_t;
+static int sort_key_cmp(const void* pa, const void* pb) {
+    const sort_key_t* a = (const sort_key_t*)pa;
+    const sort_key_t* b = (const sort_key_t*)pb;
+    if (a->type != b->type) return a->type < b->type ? -1 : 1;
+    if (a->not_shadow != b->not_shadow) return a->not_shadow < b->not_shadow ? -1 : 1;
+    if (a->not_volumetric != b->not_volumetric) return a->not_volumetric < b->not_volumetric ? -1 : 1;
+    if (a->entity != b->entity) return a->entity < b->entity ? -1 : 1;
+    return a->index < b->index ? -1 : (a->index > b->index ? 1 : 0); /* stable (sort_by_cached_key is) */
+}
+uint32_t orc_cluster_sort_truncate(uint32_t n, const uint8_t* obj_type, const uint8_t* shadow_maps_enabled,
+                                   const uint8_t* volumetric, const uint64_t* entity_bits, uint32_t max_objects,
+                                   int supports_storage_buffers, uint32_t* order) {
+    for (uint32_t i = 0; i < n; ++i) order[i] = i;
+    if (!(n > max_objects && !supports_storage_buffers)) return n; /* :297-300 */
+    sort_key_t* keys = (sort_key_t*)malloc((size_t)n * sizeof *keys);
+    for (uint32_t i = 0; i < n; ++i) {
+        uint8_t t = obj_type ? obj_type[i] : ORC_OBJ_POINT_LIGHT;
+        int light = t == ORC_OBJ_POINT_LIGHT || t == ORC_OBJ_SPOT_LIGHT;
+        keys[i].type = t;
+        keys[i].not_shadow = light ? (uint8_t)!(shadow_maps_enabled && shadow_maps_enabled[i]) : 0;
+        keys[i].not_volumetric = light ? (uint8_t)!(volumetric && volumetric[i]) : 0;
+        keys[i].entity = entity_bits[i];
+        keys[i].index = i;
+    }
+    qsort(keys, n, sizeof *keys, sort_key_cmp);
+    for (uint32_t i = 0; i < n; ++i) order[i] = keys[i].index;
+    free(keys);
+    return max_objects; /* truncate, :319-320 */
+}
+
 /* calculate_cluster_factors, assign.rs:817-832 */
 static void calculate_cluster_factors(float near, float far, float z_slices, int ortho, float out[2]) {
     if (ortho) {

@@ -242,6 +242,33 @@ void orc_cluster_dimensions_fixed_z(uint32_t total, uint32_t z_slices, uint32_t 
 /* Clusters::update, cluster/mod.rs:398-416 */
 void orc_clusters_update(uint32_t screen_w, uint32_t screen_h, const uint32_t requested[3],
                          uint32_t out_tile_size[2], uint32_t out_dims[3]);
+/* ClusterConfig (cluster/mod.rs:107-139) and the part of assign_objects_to_clusters that turns it, the viewport and
+ * last frame's statistics into what Clusters::update and the per-view setup consume (assign.rs:324-404):
+ *   kind 0 None, 1 Single, 2 XYZ, 3 FixedZ;  far_z_mode 0 MaxClusterableObjectRange, 1 Constant.
+ *   last_farthest_z / last_total: Clusters::last_frame_* (NULL = None).
+ * Returns 0 when the view is cleared (ClusterConfig::None or an empty viewport, :328-339), else 1 with
+ *   out_requested_dims (dimensions_for_screen_size + dynamic_resizing :384-404), out_first_slice_depth
+ *   (config.first_slice_depth()), out_far_z (:350-355). */
+typedef struct orc_cluster_config {
+    uint32_t kind;
+    uint32_t dimensions[3];
+    uint32_t total, z_slices;
+    float first_slice_depth;
+    uint32_t far_z_mode;
+    float far_z_constant;
+    uint32_t dynamic_resizing;
+} orc_cluster_config;
+void orc_cluster_config_default(orc_cluster_config* out);
+int orc_cluster_config_resolve(const orc_cluster_config* config, const float* last_farthest_z, const uint64_t* last_total,
+                               uint32_t screen_w, uint32_t screen_h, uint64_t view_cluster_bindings_max_indices,
+                               uint32_t out_requested_dims[3], float* out_first_slice_depth, float* out_far_z);
+/* assign.rs:297-321: sort_by_cached_key((object_type.ordering(), entity)) + truncate when the gathered objects exceed
+ * max_uniform_buffer_clusterable_objects on a platform without storage buffers.  order[n] receives the surviving
+ * objects (indices into the gathered arrays); returns how many survive. */
+uint32_t orc_cluster_sort_truncate(uint32_t n, const uint8_t* obj_type, const uint8_t* shadow_maps_enabled,
+                                   const uint8_t* volumetric, const uint64_t* entity_bits, uint32_t max_objects,
+                                   int supports_storage_buffers, uint32_t* order);
+
 /* Per-view setup of assign_objects_to_clusters, cluster/assign.rs:342-485.
  * far_z: the value selected by ClusterFarZMode (:350-355); first_slice_depth_cfg: config value. */
 void orc_cluster_view_setup(const float camera_affine[12], const float clip_from_view[16],

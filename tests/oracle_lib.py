@@ -66,6 +66,13 @@ class ClusterView(C.Structure):
     ]
 
 
+class ClusterConfig(C.Structure):
+    """orc_cluster_config"""
+    _fields_ = [("kind", C.c_uint32), ("dimensions", C.c_uint32 * 3), ("total", C.c_uint32), ("z_slices", C.c_uint32),
+                ("first_slice_depth", C.c_float), ("far_z_mode", C.c_uint32), ("far_z_constant", C.c_float),
+                ("dynamic_resizing", C.c_uint32)]
+
+
 class View(C.Structure):
     """orc_view"""
     _fields_ = [("frustum", C.c_float * 24), ("layer_mask", C.c_uint32), ("flags", C.c_uint32),
@@ -334,6 +341,31 @@ def clusters_update(w, h, req):
     dims = (C.c_uint32 * 3)()
     lib().orc_clusters_update(w, h, (C.c_uint32 * 3)(*req), tile, dims)
     return tuple(tile), tuple(dims)
+
+
+def cluster_config_default():
+    cfg = ClusterConfig()
+    lib().orc_cluster_config_default(C.byref(cfg))
+    return cfg
+
+
+def cluster_config_resolve(config, last_farthest_z, last_total, w, h, max_indices=16384):
+    """-> None (view cleared) or (requested_dims, first_slice_depth, far_z); last_* = None for Option::None."""
+    req = (C.c_uint32 * 3)()
+    fsd, far = C.c_float(0), C.c_float(0)
+    lf = C.byref(C.c_float(last_farthest_z)) if last_farthest_z is not None else None
+    lt = C.byref(C.c_uint64(last_total)) if last_total is not None else None
+    active = lib().orc_cluster_config_resolve(C.byref(config), lf, lt, w, h, C.c_uint64(max_indices), req, C.byref(fsd), C.byref(far))
+    return (tuple(req), float(fsd.value), float(far.value)) if active else None
+
+
+def cluster_sort_truncate(obj_type, shadow_maps_enabled, volumetric, entity_bits, max_objects, supports_storage_buffers):
+    n = len(entity_bits)
+    order = np.zeros(max(n, 1), np.uint32)
+    lib().orc_cluster_sort_truncate.restype = C.c_uint32
+    m = lib().orc_cluster_sort_truncate(n, u8p(obj_type), u8p(shadow_maps_enabled), u8p(volumetric), u64p(entity_bits), max_objects,
+                                        int(bool(supports_storage_buffers)), u32p(order))
+    return order[:m]
 
 
 def cluster_view_setup(camera_affine, clip_from_view, frustum, w, h, requested_dims, first_slice_depth, far_z,

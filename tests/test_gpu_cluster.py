@@ -1,0 +1,209 @@
+"""GPU tests of the cluster stage beyond bit-parity with the oracle (tests/test_gpu_parity.py has those):
+
+* the oracle-independent invariants of tests/cluster_invariants.py over the HIP library's own output;
+* the default ClusterConfig feedback loop through mi_cluster_assign_frame (assign.rs:324-404,810-811);
+* lights as rows of the frame context (mi_cluster_bind_objects_to_rows): propagate + cull + gather-visible + assign in one
+  context, against the reference's sequence check_visibility -> gather -> assign restated with the oracle;
+* the BASELINE.json shapes at full size: 100 k lights / range 0.3 / R = 50 with the bench's camera, and the 1 M-node tree.
+"""
+import numpy as np
+import pytest
+
+import bevy_amd as B
+from bevy_amd import api, workloads as W
+import oracle_lib as O
+import cluster_invariants as CI
+from test_gpu_parity import ctx_factory, frusta_for, upload_scene, upload_tree, assert_bits  # noqa: F401
+from test_cluster_invariants import CASES, PERSP, rand_lights, two_frames
+from test_abi_and_host import ortho_clip_from_view
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def both_views(cam, dims=(16, 9, 24), far=1000.0, fsd=5.0, ortho=False, screen=(1920, 1080), view_mask=1):
+    cfv = ortho_clip_from_view(-60.0, 60.0, -33.75, 33.75, 0.1, 1000.0) if ortho else api.perspective_clip_from_view(
+        W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+    fr = api.compute_frustum(cfv, cam, W.CAMERA_FAR)
+    view, keep = api.cluster_view_build(cam, cfv, fr, screen[0], screen[1], dims, fsd, far, view_mask)
+    ov = O.cluster_view_setup(cam, cfv, fr, screen[0], screen[1], dims, fsd, far, view_mask)
+    return view, keep, ov
+
+
+def assert_same_assignment(got, want):
+    off, idx, counts, far, total = got
+    eoff, eidx, ecounts, efar, etotal = want
+    assert total == etotal, (total, etotal)
+    assert np.array_equal(off, eoff), "cluster offsets"
+    assert np.array_equal(idx, eidx), "cluster index lists (push order)"
+    assert np.array_equal(counts, ecounts), "per-type counts"
+    assert np.float32(far).tobytes() == np.float32(efar).tobytes(), (far, efar)
+
+
+@pytest.mark.parametrize("name,case", CASES, ids=[c[0] for c in CASES])
+def test_invariants_hold_for_the_hip_output(ctx_factory, name, case):
+    case = dict(case)
+    lights = case.pop("lights")
+    view, keep, ov = both_views(case.pop("cam", W.many_cubes_camera(0)), **case)
+    ctx = ctx_factory()
+    got = ctx.cluster_assign(view, lights)
+    CI.check_all(view, lights, None, None, *got)          # the HIP output on its own, against the float64 definitions
+    assert_same_assignment(got, O.assign_objects_to_clusters(ov, lights))
+
+
+def test_assign_frame_default_config_feedback(ctx_factory):
+    """mi_cluster_assign_frame = one view of one frame of the system, default ClusterConfig: frame 0 runs on far_z = 1000,
+    frame 1 on last frame's farthest_z; with big lights frame 0 overflows MAX_INDICES and frame 1 runs on a coarser grid."""
+    cam = W.many_cubes_camera(0)
+    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+    fr = api.compute_frustum(cfv, cam, W.CAMERA_FAR)
+    for lights in (W.many_lights(100_000, 50.0, 0.3), W.many_lights(20_000, 50.0, 6.0)):
+        want = two_frames(lights, cam)
+        ctx = ctx_factory()
+        ctx.cluster_upload_objects(lights)
+        cfg, hist = api.cluster_config_default(), api.ClusterHistory()
+        for f, (req, far, oview, eoff, eidx, ecounts, efar, etotal) in enumerate(want):
+            view, active = ctx.cluster_assign_frame(cfg, hist, cam, cfv, fr, 1920, 1080)
+            assert active and tuple(view.dims) == tuple(oview.dims), (f, tuple(view.dims), tuple(oview.dims))
+            assert F(view.far_).tobytes() == F(oview.far_).tobytes() and F(view.near_).tobytes() == F(oview.near_).tobytes()
+            got = ctx.cluster_download(view.n_clusters)
+            assert_same_assignment(got, (eoff, eidx, ecounts, efar, etotal))
+            assert hist.has_farthest_z and hist.has_total_cluster_index_count
+            assert hist.total_cluster_index_count == etotal and F(hist.farthest_z).tobytes() == F(efar).tobytes()
+            CI.check_all(view, lights, None, None, *got, superset=False)
+    # ClusterConfig::None clears the view and leaves the statistics alone
+    none = api.cluster_config_default()
+    none.kind = api.CLUSTER_CONFIG_NONE
+    before = (hist.farthest_z, hist.total_cluster_index_count)
+    _, active = ctx.cluster_assign_frame(none, hist, cam, cfv, fr, 1920, 1080)
+    assert not active and (hist.farthest_z, hist.total_cluster_index_count) == before
+
+
+def reference_sequence(sc, first_light, pr, frusta, cam, types=None, layers=None, sc_sincos=None):
+    """check_visibility over every row, then the gather of the visible lights (assign.rs:190-215) and the assignment of the
+    gathered list -- with the oracle.  Returns the assignment in terms of LIGHT indices (row - first_light)."""
+    n = sc["n"]
+    g, vv, vis, _ = O.full_frame(sc["translation"], sc["rotation"], sc["scale"], sc["aabb_center"], sc["aabb_half"], sc["flags"],
+                                 sc["layers"], np.zeros(n, np.uint8), frusta)
+    n_l = len(pr) // 4
+    visible = (vv[first_light:first_light + n_l] & 1) != 0
+    keep = np.nonzero(visible)[0]
+    pr_g = np.asarray(pr, F).reshape(-1, 4)[keep].copy()
+    pr_g[:, :3] = g.reshape(-1, 12)[first_light + keep, 9:12]   # GlobalTransform::from_translation(transform.translation())
+    spot_dir = None
+    if types is not None and (types == 1).any():               # transform.back() = (matrix3 * Vec3::Z).normalize()
+        z = g.reshape(-1, 12)[first_light + keep, 6:9].astype(F)
+        ln = np.sqrt((z[:, 0] * z[:, 0] + z[:, 1] * z[:, 1]) + z[:, 2] * z[:, 2]).astype(F)
+        spot_dir = (z * (F(1.0) / ln)[:, None]).astype(F).reshape(-1)
+    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+    ov = O.cluster_view_setup(cam, cfv, frusta[:24], 1920, 1080, (16, 9, 24), 5.0, 1000.0)
+    off, idx, counts, far, total = O.assign_objects_to_clusters(
+        ov, pr_g.reshape(-1), None if types is None else types[keep].copy(), None if layers is None else layers[keep].copy(), spot_dir,
+        None if sc_sincos is None else sc_sincos.reshape(-1, 2)[keep].copy().reshape(-1))
+    return off, keep[idx].astype(np.uint32), counts, far, total, visible, vv, g
+
+
+@pytest.mark.parametrize("spots", [False, True])
+def test_lights_as_rows_of_the_frame_context(ctx_factory, spots):
+    """The whole metric frame in one context: rows = cubes + meshes + lights; mi_propagate_and_cull decides every row's
+    ViewVisibility (lights through their bounding Sphere), mi_cluster_assign_resident gathers the visible lights ON THE
+    DEVICE and assigns them.  Equal, list for list, to the reference's sequence restated with the oracle."""
+    sc, first_light, pr = W.frame_scene(60_000, 30_000, 3_000, light_range=1.5, ragged_flags=True)
+    n_l = len(pr) // 4
+    rng = np.random.default_rng(3)
+    types = layers = sincos = None
+    if spots:
+        types = np.sort(rng.integers(0, 3, n_l)).astype(np.uint8)   # points, spots, rect lights in gather order
+        layers = np.where(rng.random(n_l) < 0.1, 2, 1).astype(np.uint32)
+        ang = rng.uniform(0.1, 1.2, n_l).astype(F)
+        sincos = np.stack([np.sin(ang), np.cos(ang)], axis=1).astype(F).reshape(-1)
+        hidden = first_light + rng.integers(0, n_l, 500)             # some lights are hidden by inheritance
+        sc["flags"][hidden] &= ~np.uint8(0x01)
+    ctx = ctx_factory()
+    upload_scene(ctx, sc)
+    ctx.cluster_upload_objects(pr, types, layers, None, sincos)
+    ctx.cluster_bind_objects_to_rows(first_light, n_l)
+    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+    for f in (0, 40):
+        cam = W.many_cubes_camera(f, yaw=0.3 * f)
+        frusta = frusta_for([cam])
+        view, keep = api.cluster_view_build(cam, cfv, frusta, 1920, 1080, (16, 9, 24), 5.0, 1000.0)
+        ctx.cluster_upload_view(view)
+        ctx.upload_view_visibility(np.zeros(sc["n"], np.uint8))
+        ctx.propagate_and_cull(frusta, flags=B.CULL_END_FRAME | B.CULL_MORE_FRAMES)
+        ctx.cluster_assign_resident()
+        got = ctx.cluster_download(view.n_clusters)
+        eoff, eidx, ecounts, efar, etotal, visible, vv, g = reference_sequence(sc, first_light, pr, frusta, cam, types, layers, sincos)
+        assert 0 < visible.sum() < n_l and etotal > 0
+        assert_same_assignment(got, (eoff, eidx, ecounts, efar, etotal))
+        assert_bits(ctx.download_view_visibility()[0], vv, "ViewVisibility of every row (cubes, meshes, lights)")
+        pr_rows = np.asarray(pr, F).reshape(-1, 4).copy()
+        pr_rows[:, :3] = g.reshape(-1, 12)[first_light:first_light + n_l, 9:12]
+        CI.check_all(view, pr_rows.reshape(-1), types, layers, *got, visible=visible, superset=not spots)
+    ctx.synchronize()
+
+
+def test_baseline_lights_config_at_full_size(ctx_factory):
+    """BASELINE.json configs[2] exactly as bench.py runs it: 100 000 point lights (range 0.3, shell R = 50) + 10 000 meshes,
+    16 x 9 x 24 clusters, the bench's camera; plus the 1 M cubes of configs[1] in the same context."""
+    sc, first_light, pr = W.frame_scene(1_000_000, 100_000, 10_000)
+    ctx = ctx_factory()
+    upload_scene(ctx, sc)
+    ctx.cluster_upload_objects(pr)
+    ctx.cluster_bind_objects_to_rows(first_light, 100_000)
+    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+    cam = W.many_cubes_camera(7)
+    frusta = frusta_for([cam])
+    view, keep = api.cluster_view_build(cam, cfv, frusta, 1920, 1080, (16, 9, 24), 5.0, 1000.0)
+    ctx.cluster_upload_view(view)
+    ctx.propagate_and_cull(frusta, flags=B.CULL_END_FRAME)
+    ctx.cluster_assign_resident()
+    got = ctx.cluster_download(view.n_clusters)
+    eoff, eidx, ecounts, efar, etotal, visible, vv, g = reference_sequence(sc, first_light, pr, frusta, cam)
+    assert_same_assignment(got, (eoff, eidx, ecounts, efar, etotal))
+    assert_bits(ctx.download_view_visibility()[0], vv, "ViewVisibility")
+    assert ctx.download_global_transforms(want_changed=False).tobytes() == g.tobytes()
+    assert 3000 < visible.sum() < 8000 and etotal >= visible.sum()
+    CI.check_all(view, pr, None, None, *got, visible=visible, superset=False)
+    # the standalone object-list form of the same configuration (what bench.py --workload lights times)
+    ctx2 = ctx_factory()
+    assert_same_assignment(ctx2.cluster_assign(view, pr), O.assign_objects_to_clusters(
+        O.cluster_view_setup(cam, cfv, frusta, 1920, 1080, (16, 9, 24), 5.0, 1000.0), pr))
+
+
+def test_baseline_tree_config_at_full_size(ctx_factory):
+    """BASELINE.json configs[4]: gen_tree(12, 4) truncated to 1 000 000 nodes, bit-exact against the oracle, then a
+    partially dirty frame and a static frame."""
+    tr = W.gen_tree(12, 4, 1_000_000)
+    assert tr["n"] == 1_000_000
+    ctx = ctx_factory()
+    upload_tree(ctx, tr)
+    ctx.propagate(B.PROPAGATE_ALL_DIRTY)
+    g, chg = ctx.download_global_transforms()
+    rc, g0, chg0 = O.propagate_transforms(tr["parent"], tr["translation"], tr["rotation"], tr["scale"])
+    assert rc == 0
+    bad = np.nonzero((g.view(np.uint32) != g0.view(np.uint32)).reshape(-1, 12).any(axis=1))[0]
+    assert bad.size == 0, f"{bad.size} of 1 000 000 rows differ, first {bad[:5].tolist()}"
+    assert_bits(chg, chg0, "change ticks")
+    # the root moves (what bench.py does every frame): every descendant is rewritten
+    t = tr["translation"].copy()
+    t[:3] += F(1.0)
+    ctx.upload_transforms(t[:3], tr["rotation"][:4], tr["scale"][:3], first_row=0)
+    ctx.propagate(B.PROPAGATE_ALL_DIRTY)
+    g, chg = ctx.download_global_transforms()
+    rc, g1, chg1 = O.propagate_transforms(tr["parent"], t, tr["rotation"], tr["scale"], global_in=g0)
+    assert g.tobytes() == g1.tobytes() and chg1.all()
+    assert_bits(chg, chg1, "change ticks after the root moved")
+    # a few dirty nodes deep in the tree under the static-scene rule
+    rows = np.array([5, 1400, 349_530, 999_999], np.uint32)
+    t3 = t.reshape(-1, 3).copy()
+    t3[rows] += F(0.5)
+    ctx.upload_transforms_indexed(rows, t3[rows].reshape(-1), tr["rotation"].reshape(-1, 4)[rows].reshape(-1), tr["scale"].reshape(-1, 3)[rows].reshape(-1))
+    ctx.propagate(B.PROPAGATE_STATIC_OPT)
+    changed = np.zeros(tr["n"], np.uint8)
+    changed[rows] = 1
+    rc, g2, chg2 = O.propagate_transforms(tr["parent"], t3.reshape(-1), tr["rotation"], tr["scale"], global_in=g1, static_opt=True,
+                                          tree_changed=O.mark_dirty_trees(tr["parent"], changed), transform_changed=changed)
+    g, chg = ctx.download_global_transforms()
+    assert g.tobytes() == g2.tobytes()
+    assert_bits(chg, chg2, "change ticks of the sparse frame")

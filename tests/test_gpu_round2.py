@@ -1,0 +1,193 @@
+"""GPU regression tests for the round-1 advisor findings: every scenario is driven through the C ABI and
+checked against the oracle (or against the inline path of the library where the finding is about a fast path)."""
+import numpy as np
+import pytest
+
+import bevy_amd as B
+from bevy_amd import api, workloads as W
+import oracle_lib as O
+from test_gpu_parity import ctx_factory, frusta_for, upload_scene, upload_tree, assert_bits  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def flat_rows_plus_deep_tree(n_flat=45_000, chain=11, fan_levels=6, seed=3):
+    """Level 0 = n_flat flat rows + ONE root; below the root a chain of `chain` single nodes, then a 4-ary fan.  The
+    tile planner cuts this into three launches' worth of passes -- pass 0 (> 64 root tiles) on its own, pass 1 (the
+    chain) on its own, pass 2 (the fan: chain tiles) riding in pass 1's launch -- so the chain tiles' ancestor chain
+    runs up through rows owned by TWO earlier launches."""
+    rng = np.random.default_rng(seed)
+    parent = [B.NO_PARENT] * (n_flat + 1)
+    level_offsets = [0, n_flat + 1]
+    prev = [n_flat]  # the root is the last row of level 0
+    for _ in range(chain):
+        row = len(parent)
+        parent.append(prev[0])
+        prev = [row]
+        level_offsets.append(len(parent))
+    for _ in range(fan_levels):
+        nxt = []
+        for p in prev:
+            for _k in range(4):
+                nxt.append(len(parent))
+                parent.append(p)
+        prev = nxt
+        level_offsets.append(len(parent))
+    n = len(parent)
+    q = rng.normal(size=(n, 4)).astype(F)
+    q /= np.linalg.norm(q, axis=1, keepdims=True).astype(F)
+    return dict(n=n, parent=np.array(parent, np.uint32), level_offsets=np.array(level_offsets, np.uint32),
+                translation=rng.uniform(-3, 3, size=3 * n).astype(F), rotation=q.reshape(-1).astype(F),
+                scale=rng.uniform(0.9, 1.1, size=3 * n).astype(F), root=n_flat, n_flat=n_flat)
+
+
+@pytest.mark.parametrize("static_opt", [True, False])
+def test_chain_tiles_below_two_owner_launches(ctx_factory, static_opt):
+    """every launch mirrors the rows it owns into the pre-frame snapshot the chain tiles read.  The frames
+    below move the root away and back while a local in the chain changes in between -- with a stale snapshot the chain
+    tiles would compare against (and, under the static-scene rule, fall back to) values from the first frame."""
+    tr = flat_rows_plus_deep_tree()
+    n, parent, root = tr["n"], tr["parent"], tr["root"]
+    t = tr["translation"].reshape(n, 3).copy()
+    flags = B.PROPAGATE_STATIC_OPT if static_opt else 0
+    ctx = ctx_factory()
+    upload_tree(ctx, tr)
+    ctx.propagate(B.PROPAGATE_ALL_DIRTY | flags)
+    rc, g0, _ = O.propagate_transforms(parent, tr["translation"], tr["rotation"], tr["scale"], static_opt=static_opt)
+    assert rc == 0 and ctx.download_global_transforms(want_changed=False).tobytes() == g0.tobytes()
+    chain3, chain8 = root + 3, root + 8  # rows of the chain: level 3 is owned by pass 0, level 8 by pass 1
+    fan = n - 5
+    t_root0 = t[root].copy()
+    frames = [
+        {root: t_root0 + F(2.0)},                     # root moves away
+        {chain3: t[chain3] + F(0.25)},                # an intermediate local changes ...
+        {root: t_root0},                              # ... and the root moves back
+        {},                                           # nothing changed
+        {chain8: t[chain8] - F(0.5), fan: t[fan] + F(1.0)},
+        {root: t_root0 + F(2.0), 5: t[5] + F(1.0)},   # root again + a flat row
+        {root: t_root0},
+    ]
+    for f, upd in enumerate(frames):
+        rows = np.array(sorted(upd), np.uint32)
+        for r_, v in upd.items():
+            t[r_] = v
+        if rows.size:
+            ctx.upload_transforms_indexed(rows, t[rows].reshape(-1), tr["rotation"].reshape(n, 4)[rows].reshape(-1),
+                                          tr["scale"].reshape(n, 3)[rows].reshape(-1))
+        ctx.propagate(flags)
+        changed = np.zeros(n, np.uint8)
+        changed[rows] = 1
+        rc, g1, chg = O.propagate_transforms(parent, t.reshape(-1), tr["rotation"], tr["scale"], global_in=g0, static_opt=static_opt,
+                                             tree_changed=O.mark_dirty_trees(parent, changed), transform_changed=changed)
+        assert rc == 0
+        g, got_chg = ctx.download_global_transforms()
+        bad = np.nonzero((g.view(np.uint32) != g1.view(np.uint32)).reshape(-1, 12).any(axis=1))[0]
+        assert bad.size == 0, f"frame {f}: {bad.size} rows differ, first {bad[:5].tolist()}"
+        assert_bits(got_chg, chg, f"frame {f} change ticks")
+        g0 = g1
+
+
+def test_deferred_compaction_with_a_caller_bound_mask_buffer(ctx_factory):
+    """mi_bind_visibility_output + MI_CULL_MORE_FRAMES without the exchange and without class masks: the one
+    bound buffer is overwritten by the next frame, so the library must not defer the compaction into that frame."""
+    import torch
+    n = 200_000 + 13
+    sc = W.many_cubes(n, radius=260.0)
+    cams = [frusta_for([W.many_cubes_camera(f, yaw=0.7 * f)]) for f in range(6)]
+    words = (n + 255) // 256 * 4
+
+    def run(more, bind):
+        ctx = ctx_factory()
+        upload_scene(ctx, sc)
+        buf = torch.zeros(words, dtype=torch.int64, device="cuda")
+        if bind:
+            ctx.bind_visibility_output(buf.data_ptr(), words, 0)
+        outs = []
+        for f in range(5):
+            ctx.propagate_and_cull(cams[f], flags=B.CULL_END_FRAME | more)
+        ctx.propagate_and_cull(cams[5], flags=B.CULL_END_FRAME | more)
+        outs.append(ctx.download_visible_entities(0, 0)[1].copy())
+        # the frame before the last one: re-run 4 then 5, read the lists of 4 through a deferred join
+        ctx.propagate_and_cull(cams[4], flags=B.CULL_END_FRAME | more)
+        outs.append(ctx.download_visible_entities(0, 0)[1].copy())
+        ctx.synchronize()
+        del buf
+        return outs
+
+    ref = run(0, False)
+    for more, bind in ((B.CULL_MORE_FRAMES, True), (0, True), (B.CULL_MORE_FRAMES, False)):
+        got = run(more, bind)
+        for a, b in zip(ref, got):
+            assert a.size > 0 and np.array_equal(a, b), f"more={more} bind={bind}"
+
+
+def test_failed_frame_keeps_the_previous_frames_lists(ctx_factory):
+    """a cull call that fails validation must not swallow the deferred compaction of the frame before it."""
+    n = 120_000
+    sc = W.many_cubes(n, radius=240.0)
+    fr = frusta_for([W.many_cubes_camera(0)])
+    ctx = ctx_factory()
+    upload_scene(ctx, sc)
+    ctx.propagate_and_cull(fr, flags=B.CULL_END_FRAME)
+    want = ctx.download_visible_entities(0, 0)[1].copy()
+    vis = ctx.download_visibility(0).copy()
+    ctx.propagate_and_cull(fr, flags=B.CULL_END_FRAME | B.CULL_MORE_FRAMES)
+    with pytest.raises(api.MiError) as e:
+        ctx.cull(np.zeros(0, F), flags=B.CULL_MORE_FRAMES)  # no views
+    assert e.value.code == api.MI_ERR_INVALID_ARG
+    got = ctx.download_visible_entities(0, 0)[1]
+    assert want.size > 0 and np.array_equal(got, want)
+    assert_bits(ctx.download_visibility(0), vis, "masks after the failed call")
+    ctx.synchronize()
+
+
+def test_rows_regrown_inside_the_capacity_are_fresh(ctx_factory):
+    """shrink, then regrow within the allocation: the rows that come back are new entities -- default flags /
+    layers / ViewVisibility, no batch set, and Added<GlobalTransform> (computed by the next mi_propagate(0))."""
+    n = 40_000
+    half = n // 2
+    sc = W.many_cubes(n, ragged_flags=True)
+    fr = frusta_for([W.many_cubes_camera(0)])
+    ctx = ctx_factory()
+    upload_scene(ctx, sc)
+    ctx.upload_changed(np.zeros(n, np.uint8))  # the change column is in use
+    ctx.propagate(B.PROPAGATE_ALL_DIRTY)
+    ctx.cull(fr, flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME)
+    ctx.resize(half)
+    ctx.resize(n)  # no reallocation
+    sc2 = W.many_cubes(n, radius=333.0)
+    ctx.upload_transforms(sc2["translation"][3 * half:], sc2["rotation"][4 * half:], sc2["scale"][3 * half:], first_row=half)
+    # bounds / flags deliberately NOT uploaded for the regrown rows: they must read as the defaults of a fresh row
+    ctx.propagate(0)
+    g, chg = ctx.download_global_transforms()
+    g_new, _, _, _ = O.full_frame(sc2["translation"], sc2["rotation"], sc2["scale"], sc2["aabb_center"], sc2["aabb_half"],
+                                  sc2["flags"], sc2["layers"], np.zeros(n, np.uint8), fr)
+    g_old, _, _, _ = O.full_frame(sc["translation"], sc["rotation"], sc["scale"], sc["aabb_center"], sc["aabb_half"],
+                                  sc["flags"], sc["layers"], np.zeros(n, np.uint8), fr)
+    assert g[:12 * half].tobytes() == g_old[:12 * half].tobytes()
+    assert g[12 * half:].tobytes() == g_new[12 * half:].tobytes(), "regrown rows were not recomputed as Added<GlobalTransform>"
+    assert not chg[:half].any() and chg[half:].all()
+    vv, _ = ctx.download_view_visibility()
+    assert not vv[half:].any(), "regrown rows kept a previous occupant's ViewVisibility"
+    # default flags = InheritedVisibility only (no Aabb): such a row is visible in every view that shares layer 0
+    ctx.cull(fr, flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME)
+    assert ctx.download_visibility(0)[half:].all()
+
+
+def test_first_indexed_upload_keeps_rows_that_were_never_propagated(ctx_factory):
+    """ADVICE 5 (second half): the first mi_upload_transforms_indexed starts the change column; rows no propagate has
+    consumed yet are still Added<GlobalTransform> and must be computed by the following mi_propagate(0)."""
+    n = 10_000
+    sc = W.many_cubes(n)
+    ctx = ctx_factory()
+    upload_scene(ctx, sc)
+    rows = np.array([7, 4000], np.uint32)
+    t = sc["translation"].reshape(n, 3).copy()
+    t[rows] += F(1.0)
+    ctx.upload_transforms_indexed(rows, t[rows].reshape(-1), sc["rotation"].reshape(n, 4)[rows].reshape(-1),
+                                  sc["scale"].reshape(n, 3)[rows].reshape(-1))
+    ctx.propagate(0)
+    g, chg = ctx.download_global_transforms()
+    g_exp, _ = O.sync_simple_transforms(t.reshape(-1), sc["rotation"], sc["scale"])
+    assert g.tobytes() == g_exp.tobytes() and chg.all()

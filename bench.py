@@ -5,18 +5,27 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one frame of the hot path over device-resident columns with every Transform dirty:
-  flat (default, BASELINE.json configs[1]): 1M flat entities per GPU, 1 camera frustum: ONE frame kernel
-        (sync_simple_transforms + reset_view_visibility + check_visibility_cpu_culling + check_visibility_gpu_culling
-        + mark_newly_hidden_entities_invisible) and ONE VisibleEntities compaction kernel (at N = 1 the compaction of frame f rides in
-        the tail workgroups of frame f+1's launch, MI_CULL_MORE_FRAMES; --inline-compaction launches it on its own).
-        With N > 1 GPUs every rank owns a 1M-row range of an N x 1M scene (weak scaling) and the packed
-        ViewVisibility bitmasks are exchanged with ONE RCCL all-gather per frame.
-  tree  (configs[4]): depth-12/branch-4 tree truncated to 1M nodes, root moved every frame, propagate only.
-  lights (configs[2]): 100k point lights, 16x9x24 clusters, assign_objects_to_clusters only.
-Rank 0 prints ONE JSON line (DESIGN.md section 5 explains the byte accounting behind `roofline`); at N=1 the
-default run also measures tree, lights, the 0 %-dirty flat frame and the batching work-item build briefly and reports
-them under `other_workloads`.
+A "step" is one frame of the hot path over device-resident columns with every Transform dirty.
+
+N = 1 (default workload `frame`) is BASELINE.json's metric as worded -- "entities/sec through propagate+cull+cluster at 1M
+entities" -- in ONE context on ONE stream: configs[1]'s 1 000 000 many_cubes entities plus configs[2]'s many_lights set
+(10 000 meshes + 100 000 point lights, which are rows like everything else), 1 camera:
+    mi_propagate_and_cull      sync_simple_transforms + reset_view_visibility + check_visibility_cpu_culling (meshes through
+                               their Aabb, lights through their bounding Sphere) + mark_newly_hidden + VisibleEntities lists
+    mi_cluster_upload_view     this frame's camera (host constants; the view-space planes are cached on the device)
+    mi_cluster_assign_resident gather of the visible lights + assign_objects_to_clusters, 16x9x24 clusters
+`value` counts the 1 000 000 entities of the metric's name only (the 110 000 rows of configs[2] are processed, not counted).
+
+N > 1 (default workload `sharded`) is configs[3]: 10 000 000 entities x 4 camera frusta, STRONG scaling -- the row range is
+split over the N ranks, every rank runs the fused frame kernel on its rows and the packed ViewVisibility bitmasks are
+exchanged with ONE in-place RCCL all-gather per frame (--scaling weak: --entities rows per rank instead).  Rank 0 also times
+the whole scene alone on its GPU (outside the timed region) and reports it as `single_gpu_same_workload`.
+
+Timing: W warm-up steps, then B blocks of exactly K steps, each bracketed by barrier + synchronize pairs; per block the MAX
+over ranks; `ms_per_step` / `value` come from the MEDIAN block (p10 / p90 / min / max under `blocks`).  B is chosen so that the
+timed blocks cover ~0.4 s (at least 15).  Three further blocks run with per-dispatch HIP events on the kernels (`kernels`,
+`roofline`) and are kept out of the statistics -- binding events to a dispatch fences it off from its neighbours.
+Rank 0 prints ONE JSON line; DESIGN.md section 5 explains the byte accounting behind `roofline`.
 """
 import argparse
 import json
@@ -32,26 +41,32 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+PROFILED_BLOCKS = 3
+N_FRAMES = 256          # distinct prepared camera frames, cycled
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["flat", "tree", "lights", "flat_static", "batching"], default="flat")
-    ap.add_argument("--entities", type=int, default=1_000_000, help="rows per GPU (flat) / nodes (tree)")
-    ap.add_argument("--views", type=int, default=1)
+    ap.add_argument("--workload", choices=["auto", "frame", "sharded", "flat", "tree", "lights", "flat_static", "batching"], default="auto",
+                    help="auto = frame at N=1 (the BASELINE metric), sharded (configs[3]) at N>1")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong", help="sharded workload: total rows fixed / rows per GPU fixed")
+    ap.add_argument("--entities", type=int, default=0, help="frame/flat/tree: entities (default 1M); sharded: total (strong, default 10M) or per GPU (weak, default 1M)")
+    ap.add_argument("--views", type=int, default=0, help="camera frusta (default 1; sharded: 4)")
     ap.add_argument("--lights", type=int, default=100_000)
+    ap.add_argument("--meshes", type=int, default=10_000)
+    ap.add_argument("--blocks", type=int, default=0, help="timed blocks of --steps steps (0 = enough for ~0.4 s, at least 15)")
     ap.add_argument("--unfused", action="store_true", help="flat: mi_propagate + mi_cull instead of the fused kernel")
     ap.add_argument("--inline-compaction", action="store_true",
-                    help="flat: launch the VisibleEntities compaction as its own kernel every frame (default at N=1: "
-                         "MI_CULL_MORE_FRAMES, the compaction of frame f rides in frame f+1's launch)")
+                    help="launch the VisibleEntities compaction as its own kernel every frame (default: MI_CULL_MORE_FRAMES, the "
+                         "compaction of frame f rides in frame f+1's launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget")
-    ap.add_argument("--profile-all", action="store_true", help="time every kernel, not only the dominant one")
-    ap.add_argument("--profile-every", type=int, default=0, help="time every Nth launch of the dominant kernel (0 = workload default)")
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget")
+    ap.add_argument("--profile-all", action="store_true", help="profiled blocks time every kernel, not only the workload's own")
     return ap.parse_args()
 
 
@@ -64,90 +79,134 @@ def flat_bytes_per_entity(n_views, fused=True):
 
 
 class Workload:
-    """step(f) enqueues one frame; units = work items per frame on this rank."""
+    """step(f) enqueues one frame; units = work items per frame on this rank; rows = rows the dominant kernel streams."""
 
-    def __init__(self, name, step, units, bytes_per_unit, dominant, config, metric, unit):
-        self.name, self.step, self.units, self.bytes_per_unit = name, step, units, bytes_per_unit
+    def __init__(self, name, step, units, bytes_per_row, dominant, config, metric, unit, rows=None, kernels=None):
+        self.name, self.step, self.units, self.bytes_per_row = name, step, units, bytes_per_row
         self.dominant, self.config, self.metric, self.unit = dominant, config, metric, unit
-        # The dominant kernel is timed on the first eighth of the timed region's launches only: binding start/stop events to
-        # a dispatch fences it off from its neighbours (as rocprofv3's kernel trace does) and costs ~5 us of GPU time per
-        # launch on this stack (30.5 vs 25.5 us per flat frame), which would otherwise tax `value` itself.
-        self.profile_every = 1
-        self.profile_fraction = 8
+        self.rows = units if rows is None else rows
+        self.kernels = kernels or [dominant]   # what the profiled blocks time
 
 
-def build_flat(ctx, args, rank, world, total_frames, full_holder):
+def camera_frusta(n_views, frame):
+    from bevy_amd import api, workloads as W
+    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+    return np.concatenate([api.compute_frustum(cfv, W.many_cubes_camera(frame, yaw=v * np.pi / 2), W.CAMERA_FAR) for v in range(n_views)])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the BASELINE metric: propagate + cull + cluster in one frame (N = 1)
+# ---------------------------------------------------------------------------------------------------------------------
+def build_frame(ctx, args):
+    import bevy_amd as B
+    from bevy_amd import api, workloads as W
+    n_ent = args.entities or 1_000_000
+    sc, first_light, pr = W.frame_scene(n_ent, args.lights, args.meshes)
+    n_rows = sc["n"]
+    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+    ctx.resize(n_rows)
+    ctx.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
+    ctx.upload_bounds(sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"])
+    ctx.cluster_upload_objects(pr)
+    ctx.cluster_bind_objects_to_rows(first_light, args.lights)
+    frames, views, keep = [], [], []
+    for f in range(N_FRAMES):
+        cam = W.many_cubes_camera(f)
+        fr = api.compute_frustum(cfv, cam, W.CAMERA_FAR)
+        frames.append(api.PreparedFrusta(fr))
+        # ClusterConfig::XYZ{(16,9,24), first_slice_depth 5.0, Constant(1000.0), dynamic_resizing: false} (SURVEY 8d config 3)
+        v, k = api.cluster_view_build(cam, cfv, fr, 1920, 1080, (16, 9, 24), 5.0, 1000.0, with_spheres=False)
+        views.append(v)
+        keep.append(k)
+    more = 0 if args.inline_compaction else B.CULL_MORE_FRAMES
+
+    def step(f):
+        i = f % N_FRAMES
+        ctx.propagate_and_cull(frames[i], flags=B.CULL_END_FRAME | more)
+        ctx.cluster_upload_view(views[i])
+        ctx.cluster_assign_resident()
+
+    config = {"workload": f"BASELINE.json metric, one frame in one context: {n_ent} many_cubes entities (configs[1]) + {args.meshes} meshes "
+                          f"and {args.lights} point lights of the many_lights shape (configs[2]; range 0.3, shell R = 50; lights are rows with a "
+                          f"bounding Sphere) = {n_rows} rows, 1 camera, all Transforms dirty, columns resident in HBM: fused frame kernel "
+                          "(propagate + reset + frustum cull + mark-newly-hidden) + VisibleEntities compaction"
+                          + (" (deferred into the next frame's launch)" if more else "")
+                          + " + device-side gather of the visible lights + assign_objects_to_clusters on 16x9x24 clusters "
+                            "(ClusterConfig::XYZ, first slice 5.0, far Constant(1000))",
+              "baseline_config": "BASELINE.json configs[1] + configs[2] in one frame; value counts the entities of configs[1] only",
+              "entities": n_ent, "rows_per_frame": n_rows, "lights": args.lights, "meshes": args.meshes, "views": 1,
+              "deferred_compaction": bool(more), "parallelism": "1 GPU"}
+    wl = Workload("frame", step, n_ent, flat_bytes_per_entity(1, True), "k_flat_propagate_cull", config,
+                  "entities/sec through propagate+cull+cluster at 1M entities", "entities/s", rows=n_rows,
+                  kernels=["k_flat_propagate_cull", "k_compact_fast", "k_cluster_walk", "k_cluster_fill"])
+    wl.scene, wl.first_light, wl.pos_range, wl.frusta0, wl.keep = sc, first_light, pr, frames[0].array, (views, keep)
+    return wl
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# flat rows, optionally sharded over ranks (configs[1] at N = 1, configs[3] at N > 1)
+# ---------------------------------------------------------------------------------------------------------------------
+def build_flat(ctx, args, rank, world, full_holder, n_global, n_views, name):
     import torch
     import bevy_amd as B
     from bevy_amd import api, sharding, workloads as W
-    n_views = args.views
-    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
-
-    def frusta_of_frame(f):
-        return np.concatenate([api.compute_frustum(cfv, W.many_cubes_camera(f, yaw=v * np.pi / 2), W.CAMERA_FAR)
-                               for v in range(n_views)])
-
-    n_local = args.entities
-    if world > 1:  # shards start on a workgroup (256-row) boundary: sharding.shard_rows(n_global, world, rank) is then exactly
-        n_local = -(-n_local // sharding.ROW_ALIGN) * sharding.ROW_ALIGN  # [rank * n_local, (rank + 1) * n_local)
-    n_global = n_local * world
     lo, hi = sharding.shard_rows(n_global, world, rank)
-    assert (lo, hi) == (rank * n_local, (rank + 1) * n_local)
+    n_local = hi - lo
     radius = 500.0 * (n_global / 1_000_000.0) ** (1.0 / 3.0)
     scene = W.many_cubes(n_global, radius=radius, start=lo, count=n_local)
     ctx.resize(n_local)
     ctx.upload_transforms(scene["translation"], scene["rotation"], scene["scale"])
     ctx.upload_bounds(scene["aabb_center"], scene["aabb_half"], scene["flags"], scene["layers"])
-    frames = [api.PreparedFrusta(frusta_of_frame(f)) for f in range(total_frames)]
+    frames = [api.PreparedFrusta(camera_frusta(n_views, f)) for f in range(N_FRAMES)]
     gather = None
     if world > 1 or os.environ.get("MI_FORCE_GATHER") == "1" or os.environ.get("MI_FORCE_DIST") == "1":
-        # frame f's all-gather overlaps frame f+1's kernels (two gathered buffers, own stream)
         gather = sharding.MaskGatherer(n_global, world, n_views, rank, device=torch.device("cuda", torch.cuda.current_device()))
         full_holder.append(gather)
         gather.attach(ctx)  # direct RCCL available: the library issues the exchange itself, one FFI call per frame
     py_exchange = gather is not None and not gather.native
-    # frames follow back to back: each frame's compaction is deferred into the next frame's launch (MI_CULL_MORE_FRAMES);
-    # measure()'s final mi_synchronize enqueues the last one.  With the exchange on the flag is ignored by the library.
-    deferred_compaction = not args.inline_compaction and not py_exchange
-    more = B.CULL_MORE_FRAMES if deferred_compaction is True else 0  # frames follow back to back; measure()'s synchronize joins
+    deferred = not args.inline_compaction and not py_exchange
+    more = B.CULL_MORE_FRAMES if deferred else 0
+    fcount = [0]
 
     def step(f):
+        i = f % N_FRAMES
+        k = fcount[0]
+        fcount[0] += 1
         if py_exchange:
-            gather.before_kernels(f)
-            ctx.bind_visibility_output(*gather.bind_args(f))
+            gather.before_kernels(k)
+            ctx.bind_visibility_output(*gather.bind_args(k))
         if args.unfused:
             ctx.propagate(B.PROPAGATE_ALL_DIRTY)
-            ctx.cull(frames[f], flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME | more)
+            ctx.cull(frames[i], flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME | more)
         else:
-            ctx.propagate_and_cull(frames[f], flags=B.CULL_END_FRAME | more)
+            ctx.propagate_and_cull(frames[i], flags=B.CULL_END_FRAME | more)
         if py_exchange:
-            gather.after_kernels(f)
+            gather.after_kernels(k)
 
-    config = {"workload": f"many_cubes-shaped flat scene, {n_local} entities/GPU ({n_global} total), {n_views} camera "
-                          f"frustum(s), all Transforms dirty, columns resident in HBM: "
-                          f"{'mi_propagate + mi_cull' if args.unfused else 'fused frame kernel'} (propagate + reset + frustum "
-                          "cull + mark-newly-hidden) + VisibleEntities compaction"
-                          + (" (MI_CULL_MORE_FRAMES: the compaction of frame f rides in the tail workgroups of frame f+1's "
-                             "kernel, the last one is enqueued by the final mi_synchronize inside the timed region)"
-                             if deferred_compaction is True else "")
-                          + (f" + one in-place RCCL all-gather of the visibility bitmask per frame over {world} GPUs "
-                             f"({gather.mode}, pipelined one frame deep on its own stream)" if gather is not None else ""),
-              "baseline_config": "BASELINE.json configs[1] (propagate + frustum-cull; the cluster stage of the metric's name is "
-                                 "configs[2], reported under other_workloads.lights)",
-              "entities_per_gpu": n_local, "views": n_views, "deferred_compaction": deferred_compaction, "parallelism": f"row-range shard x{world}"}
+    config = {"workload": f"many_cubes-shaped flat scene, {n_global} entities, {n_views} camera frustum(s), all Transforms dirty, columns "
+                          f"resident in HBM: {'mi_propagate + mi_cull' if args.unfused else 'fused frame kernel'} (propagate + reset + "
+                          "frustum cull + mark-newly-hidden) + VisibleEntities compaction"
+                          + (" (deferred into the next frame's launch)" if deferred else "")
+                          + (f"; rows sharded over {world} GPUs ({n_local} on this rank) + ONE in-place RCCL all-gather of the packed "
+                             f"ViewVisibility bitmasks per frame ({gather.mode})" if gather is not None else ""),
+              "baseline_config": "BASELINE.json configs[3]" if name == "sharded" else "BASELINE.json configs[1]",
+              "entities_total": n_global, "entities_this_rank": n_local, "views": n_views, "deferred_compaction": deferred,
+              "parallelism": f"row-range shard x{world}"}
     if gather is not None and gather.fallback_reason:
         config["rccl_direct_fallback"] = gather.fallback_reason
-    wl = Workload("flat", step, n_local, flat_bytes_per_entity(n_views, not args.unfused),
-                  "k_cull" if args.unfused else "k_flat_propagate_cull", config, "entities/sec through propagate+cull",
-                  "entities/s")
-    wl.scene, wl.frusta_of_frame, wl.n_views = scene, frusta_of_frame, n_views
+    metric = ("entities/sec through propagate+cull (10M entities x 4 frusta, 1/2/4/8-GPU scaling)" if name == "sharded"
+              else "entities/sec through propagate+cull")
+    wl = Workload(name, step, n_local, flat_bytes_per_entity(n_views, not args.unfused),
+                  "k_cull" if args.unfused else "k_flat_propagate_cull", config, metric, "entities/s",
+                  kernels=["k_cull" if args.unfused else "k_flat_propagate_cull", "k_compact_fast"])
+    wl.scene, wl.n_views, wl.global_units = scene, n_views, n_global
     return wl
 
 
 def build_tree(ctx, args, rank=0, world=1):
     import bevy_amd as B
     from bevy_amd import sharding, workloads as W
-    tr = W.gen_tree(12, 4, args.entities * world)
+    tr = W.gen_tree(12, 4, (args.entities or 1_000_000) * (world if args.scaling == "weak" else 1))
     n_global = tr["n"]
     if world > 1:
         # SURVEY 8e: shard by root subtree -- the one giant tree is opened up, its top rows are replicated and the
@@ -167,11 +226,12 @@ def build_tree(ctx, args, rank=0, world=1):
         ctx.upload_transforms(root_t[f & 1], tr["rotation"][:4], tr["scale"][:3], first_row=0)
         ctx.propagate(B.PROPAGATE_ALL_DIRTY)
     config = {"workload": f"gen_tree(12,4) truncated to {n_global} nodes ({len(tr['level_offsets']) - 1} levels), root moved "
-                          "every frame (dirty-row upload), LDS subtree-tile propagation"
+                          "every frame (dirty-row upload), subtree-tile propagation"
                           + (f", sharded by root subtree over {world} GPUs (this rank holds {tr['n']} rows, no collective)" if world > 1 else ""),
-              "nodes": n_global, "parallelism": f"root-subtree shard x{world}"}
+              "baseline_config": "BASELINE.json configs[4]", "nodes": n_global, "parallelism": f"root-subtree shard x{world}"}
     # T 40, parent_idx 4, old G 48 (set_if_neq), G 48, changed byte 1
-    wl = Workload("tree", step, tr["n"], 141.0, "k_propagate_tiles", config, "nodes/sec through hierarchy propagate", "nodes/s")
+    wl = Workload("tree", step, tr["n"], 141.0, "k_propagate_tiles", config, "nodes/sec through hierarchy propagate", "nodes/s",
+                  kernels=["k_propagate_tiles", "k_propagate_stream"])
     wl.tree = tr
     wl.global_units = n_global  # every node is owned by exactly one rank (replicated top rows are recomputed, not counted)
     return wl
@@ -189,10 +249,11 @@ def build_lights(ctx, args):
 
     def step(f):
         ctx.cluster_assign_resident()
-    config = {"workload": f"many_lights-shaped: {args.lights} point lights (range 0.3, shell R=50), 16x9x24 clusters, "
-                          "assign_objects_to_clusters, objects resident (replicas per GPU)", "lights": args.lights}
+    config = {"workload": f"many_lights-shaped: {args.lights} point lights (range 0.3, shell R=50) given as an object list, 16x9x24 "
+                          "clusters, assign_objects_to_clusters only", "baseline_config": "BASELINE.json configs[2], cluster stage alone",
+              "lights": args.lights}
     wl = Workload("lights", step, args.lights, 17.0, "k_cluster_walk", config,
-                  "lights/sec through assign_objects_to_clusters", "lights/s")
+                  "lights/sec through assign_objects_to_clusters", "lights/s", kernels=["k_cluster_walk", "k_cluster_fill"])
     wl.keep = (view, keep, lights)
     wl.oracle_args = (cam, cfv, fr)
     return wl
@@ -202,45 +263,44 @@ def build_flat_static(ctx, args):
     """configs[1], second run: 0 % dirty -- mi_propagate finds nothing changed, mi_cull reads the resident G."""
     import bevy_amd as B
     from bevy_amd import api, workloads as W
-    n = args.entities
+    n = args.entities or 1_000_000
     sc = W.many_cubes(n)
-    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
     ctx.resize(n)
     ctx.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
     ctx.upload_bounds(sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"])
     ctx.upload_changed(np.zeros(n, np.uint8))  # the change column exists from here on: only marked rows are recomputed
     ctx.propagate(B.PROPAGATE_ALL_DIRTY)
-    frames = [api.PreparedFrusta(api.compute_frustum(cfv, W.many_cubes_camera(f), W.CAMERA_FAR)) for f in range(128)]
+    frames = [api.PreparedFrusta(camera_frusta(1, f)) for f in range(N_FRAMES)]
     more = 0 if args.inline_compaction else B.CULL_MORE_FRAMES  # as in the flat workload: frames back to back
 
     def step(f):
         ctx.propagate(0)
-        ctx.cull(frames[f & 127], flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME | more)
+        ctx.cull(frames[f % N_FRAMES], flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME | more)
     config = {"workload": f"many_cubes-shaped flat scene, {n} entities, 1 frustum, 0 % of the Transforms dirty: mi_propagate "
                           "(no row was marked since the last one: returns without a launch) + mi_cull (G resident) + VisibleEntities "
-                          "compaction" + (" deferred into the next frame's launch" if more else ""), "entities": n, "deferred_compaction": bool(more)}
+                          "compaction" + (" deferred into the next frame's launch" if more else ""),
+              "baseline_config": "BASELINE.json configs[1], 0 %-dirty run", "entities": n, "deferred_compaction": bool(more)}
     # cull with G resident: read G 48 + Aabb 24 + flags 1 + layers 4 + vv 1, write vv 1 + masks
     return Workload("flat_static", step, n, flat_bytes_per_entity(1, False), "k_cull", config,
-                    "entities/sec through propagate+cull", "entities/s")
+                    "entities/sec through propagate+cull", "entities/s", kernels=["k_cull", "k_compact_fast"])
 
 
 def build_batching(ctx, args):
     """the flat frame followed by the batching work-item build of the camera's list."""
     import bevy_amd as B
     from bevy_amd import api, workloads as W
-    n = args.entities
+    n = args.entities or 1_000_000
     sc = W.many_cubes(n)
     bs = W.batching_scene(n, n_sets=64, max_bins=40, seed=7)
-    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
     ctx.resize(n)
     ctx.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
     ctx.upload_bounds(sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"])
     ctx.batch_upload_rows(bs["row_set"], bs["row_bin"], bs["row_input"])
     ctx.batch_upload_sets(bs["set_indexed"], bs["bin_table_offset"], bs["bin_table"], bs["meta_offset"], bs["bin_metadata"])
-    frames = [api.PreparedFrusta(api.compute_frustum(cfv, W.many_cubes_camera(f), W.CAMERA_FAR)) for f in range(128)]
+    frames = [api.PreparedFrusta(camera_frusta(1, f)) for f in range(N_FRAMES)]
 
     def step(f):
-        ctx.propagate_and_cull(frames[f & 127], flags=B.CULL_END_FRAME)
+        ctx.propagate_and_cull(frames[f % N_FRAMES], flags=B.CULL_END_FRAME)
         ctx.batch_build(0, 0)
     step(0)
     ctx.synchronize()
@@ -251,9 +311,191 @@ def build_batching(ctx, args):
                           f"{len(bs['bin_metadata'])} bins (stable partition by set, allocate_uniforms, unpack_bins)",
               "entities": n, "work_items_per_frame": items}
     wl = Workload("batching", step, n, flat_bytes_per_entity(1, True), "k_flat_propagate_cull", config,
-                  "entities/sec through propagate+cull+batch build", "entities/s")
+                  "entities/sec through propagate+cull+batch build", "entities/s",
+                  kernels=["k_flat_propagate_cull", "k_compact_fast", "k_batch_clear", "k_batch_hist", "k_batch_scan", "k_batch_scatter",
+                           "k_batch_bounds", "k_batch_sets", "k_batch_allocate", "k_batch_unpack", "k_batch_prep", "k_batch_plan"])
     wl.batch = (bs, rows)
     return wl
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# measurement
+# ---------------------------------------------------------------------------------------------------------------------
+def measure(ctx, wl, steps, warmup, n_blocks=0, profile_all=False, barrier=None, reduce_max=None, agree=None, target_s=0.4):
+    """W untimed frames, then B blocks of exactly `steps` frames, each between barrier + synchronize pairs (MAX over ranks
+    per block), then PROFILED_BLOCKS blocks with per-dispatch events.  Returns (block seconds [B], per-kernel profile, info)."""
+    import gc
+    import torch
+
+    def sync_all():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if barrier:
+            barrier()
+
+    # A generation-2 pass of Python's cyclic GC over everything torch imported takes ~50 ms -- a thousand frames of
+    # this workload -- and fires after a fixed number of allocations, i.e. at a random frame: collect now, and keep the
+    # collector off while frames are being enqueued (what timeit does).
+    gc.collect()
+    gc_was_enabled = gc.isenabled()
+    gc.disable()
+    frame = [0]
+
+    def run_block(k):
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            wl.step(frame[0])
+            frame[0] += 1
+        t_enq = time.perf_counter()
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if barrier:
+            barrier()
+        t1 = time.perf_counter()
+        return t1 - t0, t_enq - t0
+
+    if warmup:
+        run_block(warmup)
+    est, _ = run_block(steps)                       # untimed: sizes the number of blocks
+    if not n_blocks:
+        n_blocks = int(min(600, max(15, target_s / max(est, 1e-6))))
+        if agree:
+            n_blocks = agree(n_blocks)              # every rank runs the same number of blocks
+    times, enq = [], []
+    for _ in range(n_blocks):
+        t, e = run_block(steps)
+        times.append(t)
+        enq.append(e)
+    if reduce_max:
+        times = reduce_max(times)
+    # profiled blocks: same frames, every launch of the workload's kernels timed (not part of the statistics)
+    ctx.profile_filter(None if profile_all else wl.kernels)
+    ctx.profile_sample(1)
+    ctx.profile_burst(0)
+    ctx.profile_enable(True)
+    prof_t = [run_block(steps)[0] for _ in range(PROFILED_BLOCKS)]
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    if gc_was_enabled:
+        gc.enable()
+    info = {"host_enqueue_ms_per_step": round(1e3 * float(np.median(enq)) / steps, 5),
+            "profiled_blocks_ms_per_step": round(1e3 * float(np.median(prof_t)) / steps, 5)}
+    return np.array(times), prof, info
+
+
+def block_stats(times, steps):
+    ms = 1e3 * times / steps
+    return {"n": int(len(ms)), "steps_per_block": steps, "median_ms_per_step": round(float(np.median(ms)), 5),
+            "p10_ms_per_step": round(float(np.percentile(ms, 10)), 5), "p90_ms_per_step": round(float(np.percentile(ms, 90)), 5),
+            "min_ms_per_step": round(float(ms.min()), 5), "max_ms_per_step": round(float(ms.max()), 5)}
+
+
+def load_profiles():
+    """Committed rocprofv3 evidence of the same commands (profiles/rocprof_summary.json, written by tools/summarize_profiles.py):
+    kernel-trace average durations and the HBM traffic of the separate --pmc passes, per workload and kernel."""
+    p = os.path.join(ROOT, "profiles", "rocprof_summary.json")
+    try:
+        return json.load(open(p))
+    except Exception:
+        return {}
+
+
+def roofline_of(wl, prof, steps):
+    dk = prof.get(wl.dominant)
+    if not dk or not dk["launches"]:
+        return None
+    avg_s = dk["avg_us"] * 1e-6
+    alg_bytes = wl.bytes_per_row * wl.rows
+    achieved = alg_bytes / avg_s / 1e9
+    out = {"bound": "hbm", "kernel": wl.dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "avg_kernel_us": round(dk["avg_us"], 3),
+           "launches": dk["launches"], "algorithmic_bytes_per_launch": int(alg_bytes),
+           "timing": f"per-dispatch start/stop events (hipExtLaunchKernelGGL) on every launch of {PROFILED_BLOCKS} profiled blocks of "
+                     f"{steps} steps that follow the timed blocks"}
+    ev = load_profiles().get(wl.name, {}).get(wl.dominant)
+    if ev:
+        if ev.get("hbm_bytes_per_launch"):
+            out["traffic"] = ev["hbm_bytes_per_launch"]
+            out["traffic_source"] = f"replayed from {ev.get('source', 'profiles/')}: FETCH_SIZE / WRITE_SIZE of separate rocprofv3 --pmc passes of this command (not measured in this run)"
+        if ev.get("avg_us"):
+            out["rocprof_avg_kernel_us"] = ev["avg_us"]
+            out["rocprof_frac"] = round(alg_bytes / (ev["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
+            out["rocprof_source"] = ev.get("source", "profiles/")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baselines (the oracle's C port, on the host cores of this box; reported, never the target)
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline_frame(wl, cpu_seconds):
+    """propagate + cull over every row of the frame on all cores (persistent pool, Bevy's ceil(n/threads) batching), then the
+    gather + assign_objects_to_clusters of the visible lights on ONE core (single-threaded in the reference)."""
+    import oracle_lib as O
+    from bevy_amd import api, workloads as W
+    sc, cores = wl.scene, os.cpu_count() or 1
+    a = (sc["translation"], sc["rotation"], sc["scale"], sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"], wl.frusta0)
+    secs, _, vv, _ = O.bench_flat_frame(*a, cores, 1)
+    iters = int(max(1, min(3000, 0.6 * cpu_seconds / max(secs, 1e-4))))
+    secs, _, vv, _ = O.bench_flat_frame(*a, cores, iters)
+    t_flat = secs / iters
+    n_l = len(wl.pos_range) // 4
+    visible = np.nonzero(vv[wl.first_light:wl.first_light + n_l] & 1)[0]
+    pr = np.ascontiguousarray(np.asarray(wl.pos_range, np.float32).reshape(-1, 4)[visible]).reshape(-1)
+    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+    view = O.cluster_view_setup(W.many_cubes_camera(0), cfv, wl.frusta0, 1920, 1080, (16, 9, 24), 5.0, 1000.0)
+    t0 = time.perf_counter()
+    O.assign_objects_to_clusters(view, pr)
+    one = time.perf_counter() - t0
+    it2 = int(max(1, min(2000, 0.3 * cpu_seconds / max(one, 1e-5))))
+    t0 = time.perf_counter()
+    for _ in range(it2):
+        O.assign_objects_to_clusters(view, pr)
+    t_cl = (time.perf_counter() - t0) / it2
+    return {"value": round(wl.units / (t_flat + t_cl), 1), "unit": "entities/s", "cores": cores, "kind": "port",
+            "sample": f"{iters} frames of {sc['n']} rows: oracle C port of sync_simple_transforms + reset + check_visibility + "
+                      f"mark_newly_hidden on a persistent pool of {cores} threads, one ceil(n/threads) batch per thread and system "
+                      f"(Bevy's par_iter batching), {1e3 * t_flat:.3f} ms/frame; + {it2} runs of assign_objects_to_clusters over the "
+                      f"{len(visible)} visible lights on 1 thread (single-threaded in the reference; two passes: size, then fill), "
+                      f"{1e3 * t_cl:.3f} ms/frame",
+            "stage_ms": {"propagate_cull_all_cores": round(1e3 * t_flat, 4), "cluster_1_core": round(1e3 * t_cl, 4)}}
+
+
+def cpu_baseline_flat(wl, cpu_seconds, n_views):
+    import oracle_lib as O
+    from bevy_amd import workloads as W
+    cores = os.cpu_count() or 1
+    n_cpu = min(wl.units, 1_000_000)
+    sc = wl.scene if n_cpu == wl.units else W.many_cubes(n_cpu)
+    fr0 = camera_frusta(n_views, 0)
+    a = (sc["translation"], sc["rotation"], sc["scale"], sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"], fr0)
+    secs, _, _, _ = O.bench_flat_frame(*a, cores, 1)
+    iters = int(max(1, min(5000, cpu_seconds / max(secs, 1e-4))))
+    secs, _, _, _ = O.bench_flat_frame(*a, cores, iters)
+    return {"value": round(n_cpu * iters / secs, 1), "unit": "entities/s", "cores": cores, "kind": "port",
+            "sample": f"{iters} frames of {n_cpu} entities x {n_views} view(s): oracle C port of sync_simple_transforms + reset + "
+                      "check_visibility + mark_newly_hidden on a persistent thread pool, one ceil(n/threads) batch per thread and system "
+                      f"(Bevy's par_iter batching), {secs:.2f}s"}
+
+
+def config0_cpu_plumbing(cpu_seconds):
+    """BASELINE.json configs[0]: many_cubes at 160 000 entities, 1 camera, CPU only -- the reference's propagate_transforms +
+    check_visibility shape as the oracle's C port runs it here (the real Bevy cannot be built in this image)."""
+    import oracle_lib as O
+    from bevy_amd import workloads as W
+    n = 160_000
+    sc = W.many_cubes(n)
+    fr0 = camera_frusta(1, 0)
+    a = (sc["translation"], sc["rotation"], sc["scale"], sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"], fr0)
+    out = {"entities": n, "kind": "port", "unit": "entities/s"}
+    for label, threads in (("all_cores", os.cpu_count() or 1), ("one_core", 1)):
+        secs, _, _, _ = O.bench_flat_frame(*a, threads, 1)
+        iters = int(max(1, min(5000, 0.5 * cpu_seconds / max(secs, 1e-5))))
+        secs, _, _, _ = O.bench_flat_frame(*a, threads, iters)
+        out[label] = {"threads": threads, "value": round(n * iters / secs, 1), "ms_per_frame": round(1e3 * secs / iters, 4), "frames": iters}
+    out["note"] = ("stress_tests/many_cubes --benchmark shape (examples/stress_tests/many_cubes.rs:61,192-212) at 160k entities: "
+                   "sync_simple_transforms + reset + check_visibility + mark_newly_hidden, oracle C port; CPU plumbing line, no GPU")
+    return out
 
 
 def cpu_baseline_other(name, wl):
@@ -261,8 +503,6 @@ def cpu_baseline_other(name, wl):
     order -- the parallelism propagate_parent_transforms gets from the task pool), assign_objects_to_clusters and the batch
     bookkeeping on ONE core (single-threaded in the reference); a few seconds' worth of frames."""
     import oracle_lib as O
-    if name == "flat_static":
-        return None  # the flat line's CPU baseline is the same stage with the propagate included
     if name == "batching":
         bs, rows = wl.batch
         a = (rows, bs["row_set"], bs["row_bin"], bs["row_input"], bs["set_indexed"], bs["bin_table_offset"], bs["bin_table"],
@@ -288,84 +528,89 @@ def cpu_baseline_other(name, wl):
         return {"value": round(tr["n"] * iters / secs, 1), "unit": "nodes/s", "cores": cores, "kind": "port",
                 "sample": f"{iters} frames of {tr['n']} nodes, every Transform changed: oracle C port of propagate_parent_transforms "
                           f"(set_if_neq), rows of a level split over a persistent pool of {cores} threads, levels in order, {secs:.2f}s"}
-    cam, cfv, fr = wl.oracle_args
-    view, lights = O.cluster_view_setup(cam, cfv, fr, 1920, 1080, (16, 9, 24), 5.0, 1000.0), wl.keep[2]
-    t0 = time.perf_counter()
-    O.assign_objects_to_clusters(view, lights)
-    one = time.perf_counter() - t0
-    iters = int(max(1, min(200, 3.0 / max(one, 1e-4))))
-    t0 = time.perf_counter()
-    for _ in range(iters):
+    if name == "lights":
+        cam, cfv, fr = wl.oracle_args
+        view, lights = O.cluster_view_setup(cam, cfv, fr, 1920, 1080, (16, 9, 24), 5.0, 1000.0), wl.keep[2]
+        t0 = time.perf_counter()
         O.assign_objects_to_clusters(view, lights)
-    secs = time.perf_counter() - t0
-    n = len(lights) // 4
-    return {"value": round(n * iters / secs, 1), "unit": "lights/s", "cores": 1, "kind": "port",
-            "sample": f"{iters} frames of {n} lights: oracle C port of assign_objects_to_clusters (two passes per frame: size, then "
-                      f"fill), {secs:.2f}s"}
+        one = time.perf_counter() - t0
+        iters = int(max(1, min(200, 3.0 / max(one, 1e-4))))
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            O.assign_objects_to_clusters(view, lights)
+        secs = time.perf_counter() - t0
+        n = len(lights) // 4
+        return {"value": round(n * iters / secs, 1), "unit": "lights/s", "cores": 1, "kind": "port",
+                "sample": f"{iters} frames of {n} lights: oracle C port of assign_objects_to_clusters (two passes per frame: size, then "
+                          f"fill), {secs:.2f}s"}
+    return None
 
 
-def measure(ctx, wl, steps, warmup, profile_all, sync_extra=None):
-    """warmup untimed frames, then exactly `steps` frames between barrier+synchronize pairs.  Returns
-    (elapsed_s, per-kernel profile)."""
-    import torch
+# ---------------------------------------------------------------------------------------------------------------------
+# end-to-end: the same frame with the host on both sides of it (PCIe-inclusive; never `value`)
+# ---------------------------------------------------------------------------------------------------------------------
+def end_to_end(ctx, wl, frames=12):
+    """Per frame: the rows a Changed<Transform> query yields go in (mi_upload_transforms_indexed; the whole column at 100 %),
+    the frame runs, and what the ECS needs comes back: the changed GlobalTransforms (sparse read-back; the whole column at
+    100 %), the camera's VisibleEntities list and the cluster offsets / counts / index list.  Wall clock, synchronised every
+    frame -- the downloads synchronise anyway."""
+    import bevy_amd as B
+    from bevy_amd import api, workloads as W
+    sc = wl.scene
+    n = sc["n"]
+    views = wl.keep[0]
+    t3 = sc["translation"].reshape(n, 3)
+    r4, s3 = sc["rotation"].reshape(n, 4), sc["scale"].reshape(n, 3)
+    out = {}
+    rng = np.random.default_rng(0)
+    ctx.upload_changed(np.zeros(n, np.uint8))
+    ctx.propagate(B.PROPAGATE_ALL_DIRTY)
+    ctx.synchronize()
+    for pct in (1, 10, 100):
+        k = n * pct // 100
+        rows = np.sort(rng.choice(n, k, replace=False)).astype(np.uint32) if pct < 100 else None
+        if rows is not None:
+            tt, rr, ss = np.ascontiguousarray(t3[rows]).reshape(-1), np.ascontiguousarray(r4[rows]).reshape(-1), np.ascontiguousarray(s3[rows]).reshape(-1)
+        times, h2d, d2h = [], 0, 0
+        for f in range(frames + 2):
+            fr = api.PreparedFrusta(camera_frusta(1, f))
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            if rows is not None:
+                ctx.upload_transforms_indexed(rows, tt, rr, ss)
+                ctx.propagate(0)
+                ctx.cull(fr, flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME)
+            else:
+                ctx.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
+                ctx.propagate_and_cull(fr, flags=B.CULL_END_FRAME)
+            ctx.cluster_upload_view(views[f % N_FRAMES])
+            ctx.cluster_assign_resident()
+            if rows is not None:
+                ch_rows, ch_g = ctx.download_changed_global_transforms()
+                got_g = len(ch_rows)
+            else:
+                g = ctx.download_global_transforms(want_changed=False)
+                got_g = n
+            _, vis_rows = ctx.download_visible_entities(0, 0)
+            off, idx, counts, far, total = ctx.cluster_download(views[0].n_clusters)
+            t1 = time.perf_counter()
+            if f >= 2:
+                times.append(t1 - t0)
+            h2d = (k * 44) if rows is not None else n * 40
+            d2h = got_g * (52 if rows is not None else 48) + len(vis_rows) * 4 + len(off) * 4 + counts.size * 4 + total * 4
+        med = float(np.median(times))
+        out[f"{pct}pct_dirty"] = {"dirty_rows": int(k), "us_per_frame": round(1e6 * med, 1), "entities_per_s": round(wl.units / med, 1),
+                                  "h2d_bytes": int(h2d), "d2h_bytes": int(d2h), "pcie_GBps_effective": round((h2d + d2h) / med / 1e9, 2),
+                                  "changed_global_transforms_read_back": int(got_g), "visible_entities": int(len(vis_rows)),
+                                  "cluster_index_entries": int(total)}
+    out["note"] = ("same frame as `value` with the host on both sides: dirty Transforms H2D (mi_upload_transforms_indexed / the whole "
+                   "column at 100 %), propagate + cull + cluster, then changed GlobalTransforms (mi_download_changed_global_transforms / the "
+                   "whole column at 100 %), the camera's VisibleEntities list and the cluster lists D2H; median wall time of "
+                   f"{frames} frames, each synchronised (pageable host arrays, one staging copy each way)")
+    return out
 
-    def sync_all():
-        ctx.synchronize()
-        torch.cuda.synchronize()
-        if sync_extra:
-            sync_extra()
 
-    # A generation-2 pass of Python's cyclic GC over everything torch imported takes ~50 ms -- a thousand frames of
-    # this workload -- and fires after a fixed number of allocations, i.e. at a random frame: collect now, and keep the
-    # collector off while frames are being enqueued (what timeit does).
-    import gc
-    gc.collect()
-    gc_was_enabled = gc.isenabled()
-    gc.disable()
-    for f in range(warmup):
-        wl.step(f)
-    sync_all()
-    ctx.profile_filter(None if profile_all else [wl.dominant])
-    ctx.profile_sample(getattr(wl, "profile_every", 1))
-    wl.timed_launches = max(8, steps // getattr(wl, "profile_fraction", 1)) if getattr(wl, "profile_fraction", 1) > 1 else 0
-    ctx.profile_burst(wl.timed_launches)
-    ctx.profile_enable(True)
-    sync_all()
-    t0 = time.perf_counter()
-    for f in range(warmup, warmup + steps):
-        wl.step(f)
-    wl.host_enqueue_s = time.perf_counter() - t0  # host time to enqueue the frames (GPU-bound if well below elapsed)
-    sync_all()
-    t1 = time.perf_counter()
-    if gc_was_enabled:
-        gc.enable()
-    prof = ctx.profile_read()
-    ctx.profile_enable(False)
-    return t1 - t0, prof
-
-
-def roofline_of(wl, prof, steps):
-    dk = prof.get(wl.dominant)
-    if not dk:
-        return None
-    avg_s = dk["avg_us"] * 1e-6
-    launches_per_step = 1.0 if getattr(wl, "timed_launches", 0) else dk["launches"] * getattr(wl, "profile_every", 1) / steps
-    alg_bytes = wl.bytes_per_unit * wl.units / launches_per_step
-    achieved = alg_bytes / avg_s / 1e9
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # HBM bytes per launch from the separate --pmc passes
-    if os.path.exists(pmc):
-        try:
-            traffic = json.load(open(pmc)).get(wl.dominant, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    return {"bound": "hbm", "kernel": wl.dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "avg_kernel_us": round(dk["avg_us"], 3),
-            "launches": dk["launches"], "algorithmic_bytes_per_launch": int(alg_bytes),
-            "timing": "per-dispatch start/stop events (hipExtLaunchKernelGGL) on the first "
-                      f"{dk['launches']} launches inside the timed region of {steps} steps"}
-
-
+# ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
     import torch
@@ -386,77 +631,113 @@ def main():
     if use_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    workload = args.workload
+    if workload == "auto":
+        workload = "frame" if world == 1 else "sharded"
+    if workload in ("frame", "lights", "flat_static", "batching") and world > 1:
+        raise SystemExit(f"--workload {workload} is a single-GPU workload (replicas only); N > 1 runs `sharded` or `tree`")
 
     stream = torch.cuda.Stream()
     ctx = api.Context(local_rank, stream.cuda_stream)
-    total_frames = args.steps + args.warmup
     full_holder = []
+    scaling = "weak"
     with torch.cuda.stream(stream):
-        if args.workload == "flat":
-            wl = build_flat(ctx, args, rank, world, total_frames, full_holder)
-        elif args.workload == "tree":
+        if workload == "frame":
+            wl = build_frame(ctx, args)
+        elif workload in ("sharded", "flat"):
+            if workload == "sharded":
+                n_views = args.views or 4
+                scaling = args.scaling
+                n_global = (args.entities or 10_000_000) if scaling == "strong" else (args.entities or 1_000_000) * world
+            else:
+                n_views = args.views or 1
+                n_global = (args.entities or 1_000_000) * world
+            wl = build_flat(ctx, args, rank, world, full_holder, n_global, n_views, workload)
+        elif workload == "tree":
+            scaling = args.scaling if world > 1 else "weak"
             wl = build_tree(ctx, args, rank, world)
-        elif args.workload == "flat_static":
+        elif workload == "flat_static":
             wl = build_flat_static(ctx, args)
-        elif args.workload == "batching":
+        elif workload == "batching":
             wl = build_batching(ctx, args)
         else:
             wl = build_lights(ctx, args)
-        if args.profile_every > 0:
-            wl.profile_every, wl.profile_fraction = args.profile_every, 1
-        barrier = (lambda: dist.barrier()) if use_dist else None
-        elapsed, prof = measure(ctx, wl, args.steps, args.warmup, args.profile_all, barrier)
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+
+        def reduce_max(ts):
+            tt = torch.tensor(ts, dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return tt.cpu().tolist()
+
+        def agree(nb):
+            tt = torch.tensor([nb], dtype=torch.int64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+            return int(tt.item())
+        times, prof, info = measure(ctx, wl, args.steps, args.warmup, args.blocks, args.profile_all,
+                                    (lambda: dist.barrier()) if use_dist else None, reduce_max if use_dist else None,
+                                    agree if use_dist else None)
 
     out = None
     if rank == 0:
-        value = getattr(wl, "global_units", wl.units * world) * args.steps / elapsed
-        out = {"metric": wl.metric, "value": round(value, 1), "unit": wl.unit, "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 5), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": wl.config,
-               "host_enqueue_ms_per_step": round(1e3 * wl.host_enqueue_s / args.steps, 5),
-               "roofline": roofline_of(wl, prof, args.steps), "cpu_baseline": None,
-               "kernels": {k: round(v["avg_us"], 3) for k, v in prof.items()}}
-        if not args.no_cpu_baseline and args.workload == "flat" and world == 1:  # reported at N = 1 only
-            import oracle_lib as O  # the oracle doubles as the reported CPU baseline ("port"), never as the product
-            from bevy_amd import workloads as W
-            cores = os.cpu_count() or 1
-            n_cpu = min(wl.units, 1_000_000)
-            sc = wl.scene if n_cpu == wl.units else W.many_cubes(n_cpu)
-            fr0 = wl.frusta_of_frame(args.warmup)
-            a = (sc["translation"], sc["rotation"], sc["scale"], sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"], fr0)
-            secs, _, _, _ = O.bench_flat_frame(*a, cores, 1)
-            iters = int(max(1, min(5000, args.cpu_seconds / max(secs, 1e-4))))
-            secs, _, _, _ = O.bench_flat_frame(*a, cores, iters)
-            out["cpu_baseline"] = {
-                "value": round(n_cpu * iters / secs, 1), "unit": "entities/s", "cores": cores, "kind": "port",
-                "sample": f"{iters} frames of {n_cpu} entities x {wl.n_views} view(s): oracle C port of sync_simple_transforms + "
-                          "reset + check_visibility + mark_newly_hidden on a persistent thread pool, one ceil(n/threads) batch per "
-                          f"thread and system (Bevy's par_iter batching), {secs:.2f}s"}
-        if world == 1 and args.workload == "flat" and not args.no_other_workloads:
-            # configs[4] and configs[2], measured briefly on fresh contexts so the one line carries every stage
-            others = {}
-            for name, builder in (("tree", build_tree), ("lights", build_lights), ("flat_static", build_flat_static),
-                                  ("batching", build_batching)):
-                c2 = api.Context(local_rank, stream.cuda_stream)
-                with torch.cuda.stream(stream):
-                    w2 = builder(c2, args)
-                    e2, p2 = measure(c2, w2, 100, 10, False)
-                others[name] = {"metric": w2.metric, "value": round(w2.units * 100 / e2, 1), "unit": w2.unit,
-                                "ms_per_step": round(1e3 * e2 / 100, 5), "config": w2.config,
-                                "roofline": roofline_of(w2, p2, 100)}
-                if name == "batching":
-                    others[name]["batch_build_us_per_frame"] = round(1e6 * e2 / 100 - 1e3 * out["ms_per_step"], 2)
-                    with torch.cuda.stream(stream):
-                        _, p3 = measure(c2, w2, 20, 2, True)  # per-kernel breakdown, every launch timed (not the rate above)
-                    others[name]["kernels_us"] = {k: round(v["avg_us"], 2) for k, v in p3.items()}
-                if not args.no_cpu_baseline:
-                    others[name]["cpu_baseline"] = cpu_baseline_other(name, w2)
-                c2.close()
-            out["other_workloads"] = others
+        med = float(np.median(times))
+        units = getattr(wl, "global_units", wl.units * world)
+        out = {"metric": wl.metric, "value": round(units * args.steps / med, 1), "unit": wl.unit, "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(1e3 * med / args.steps, 5), "higher_is_better": True,
+               "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": wl.config,
+               "timing": f"median of {len(times)} blocks of exactly {args.steps} steps, each between barrier + synchronize pairs, MAX over ranks per block",
+               "blocks": block_stats(np.array(times), args.steps), "roofline": roofline_of(wl, prof, args.steps), "cpu_baseline": None,
+               "kernels": {k: round(v["avg_us"], 3) for k, v in prof.items() if v["launches"]}}
+        out.update(info)
+        if world == 1 and not args.no_cpu_baseline:
+            import oracle_lib  # noqa: F401 -- the oracle doubles as the reported CPU baseline ("port"), never as the product
+            if workload == "frame":
+                out["cpu_baseline"] = cpu_baseline_frame(wl, args.cpu_seconds)
+                out["config0_cpu_plumbing"] = config0_cpu_plumbing(args.cpu_seconds)
+            elif workload in ("flat", "sharded"):
+                out["cpu_baseline"] = cpu_baseline_flat(wl, args.cpu_seconds, wl.n_views)
+            else:
+                out["cpu_baseline"] = cpu_baseline_other(workload, wl)
+        if world == 1 and workload == "frame" and not args.no_end_to_end:
+            with torch.cuda.stream(stream):
+                out["end_to_end"] = end_to_end(ctx, wl)
+    if world > 1 and workload == "sharded":
+        # the same scene, whole, on rank 0's GPU alone (outside the timed region): what N = 1 gives for THIS workload
+        single = None
+        if rank == 0:
+            c1 = api.Context(local_rank, stream.cuda_stream)
+            with torch.cuda.stream(stream):
+                w1 = build_flat(c1, args, 0, 1, [], wl.global_units, wl.n_views, "sharded")
+                t1, _, _ = measure(c1, w1, args.steps, args.warmup, 15)
+            m1 = float(np.median(t1))
+            single = {"value": round(wl.global_units * args.steps / m1, 1), "unit": wl.unit, "ms_per_step": round(1e3 * m1 / args.steps, 5),
+                      "note": "the whole scene on rank 0's GPU alone, measured after the timed region while the other ranks wait"}
+            c1.close()
+        dist.barrier()
+        if rank == 0:
+            out["single_gpu_same_workload"] = single
+    if rank == 0 and world == 1 and workload == "frame" and not args.no_other_workloads:
+        # the other BASELINE configs, measured briefly on fresh contexts so the one line carries every stage
+        others = {}
+        specs = [("flat", lambda c: build_flat(c, args, 0, 1, [], args.entities or 1_000_000, 1, "flat")),
+                 ("flat_10m_4views", lambda c: build_flat(c, args, 0, 1, [], 10_000_000, 4, "sharded")),
+                 ("flat_10m_1view", lambda c: build_flat(c, args, 0, 1, [], 10_000_000, 1, "flat")),
+                 ("tree", lambda c: build_tree(c, args)), ("lights", lambda c: build_lights(c, args)),
+                 ("flat_static", lambda c: build_flat_static(c, args)), ("batching", lambda c: build_batching(c, args))]
+        for name, builder in specs:
+            c2 = api.Context(local_rank, stream.cuda_stream)
+            with torch.cuda.stream(stream):
+                w2 = builder(c2)
+                t2, p2, i2 = measure(c2, w2, 50, 10, 15)
+            m2 = float(np.median(t2))
+            others[name] = {"metric": w2.metric, "value": round(getattr(w2, "global_units", w2.units) * 50 / m2, 1), "unit": w2.unit,
+                            "ms_per_step": round(1e3 * m2 / 50, 5), "blocks": block_stats(np.array(t2), 50), "config": w2.config,
+                            "roofline": roofline_of(w2, p2, 50), "kernels": {k: round(v["avg_us"], 3) for k, v in p2.items() if v["launches"]}}
+            if name == "batching":
+                others[name]["batch_build_us_per_frame"] = round(1e3 * (others[name]["ms_per_step"] - others["flat"]["ms_per_step"]), 2)
+            if not args.no_cpu_baseline and name in ("tree", "lights", "batching"):
+                others[name]["cpu_baseline"] = cpu_baseline_other(name, w2)
+            c2.close()
+        out["other_workloads"] = others
+    if rank == 0:
         sys.stdout.flush()
         try:  # anything native code left in C stdio buffers (e.g. RCCL's version banner) goes out BEFORE the result line
             import ctypes

@@ -48,7 +48,7 @@ CASES = [
     ("random box200 r60", dict(lights=rand_lights(2000, 200, 60, 3))),
     ("near the eye", dict(lights=rand_lights(2000, 10, 3, 4))),
     ("rotated + translated camera", dict(lights=rand_lights(3000, 40, 8, 5), cam=W.many_cubes_camera(300, yaw=1.0, position=(3.0, -2.0, 5.0)))),
-    ("32x18x8", dict(lights=rand_lights(2000, 40, 8, 6), dims=(32, 18, 8))),
+    ("32x16x8", dict(lights=rand_lights(2000, 40, 8, 6), dims=(32, 16, 8))),
     ("single cluster", dict(lights=rand_lights(500, 40, 8, 7), dims=(1, 1, 1))),
     ("7x5x3 far 100", dict(lights=rand_lights(2000, 40, 8, 8), dims=(7, 5, 3), far=100.0)),
     ("17x9 on 1920x1080 (tiles do not divide the screen)", dict(lights=rand_lights(2000, 40, 8, 9), dims=(17, 9, 24))),

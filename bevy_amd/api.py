@@ -641,6 +641,12 @@ class Context:
                                       "avg_us": 1e3 * float(ms[k]) / int(launches[k])}
         return out
 
+    def debug_tile_plan(self):
+        """-> dict(launches, tiles, chain_tiles, bands) of the current hierarchy's tile plan (test hook)."""
+        v = [C.c_uint32(0) for _ in range(4)]
+        self._ck(self._lib.mi_debug_tile_plan(self._h, *[C.byref(x) for x in v]))
+        return dict(launches=v[0].value, tiles=v[1].value, chain_tiles=v[2].value, bands=v[3].value)
+
     def debug_logf(self, x):
         x = _f32(x)
         out = np.zeros_like(x)

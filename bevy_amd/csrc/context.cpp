@@ -621,6 +621,7 @@ int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
         ctx->level_offsets = {0, n_rows};
         ctx->passes.clear();
         ctx->groups.clear();
+        ctx->stream_levels.clear();
     }
     ctx->n = n_rows;
     return MI_OK;
@@ -840,6 +841,11 @@ int32_t mi_propagate(mi_ctx* ctx, uint32_t flags) {
                                                 gr.n_chain ? snap_r : nullptr, snap_w, ctx->snap_rows, all_dirty, static_opt,
                                                 ctx->stream));
         }
+        for (auto& lv : ctx->stream_levels) {  // the wide deepest levels, each behind the level above it
+            ProfScope sc(ctx, K_PROPAGATE_STREAM);
+            HIP_TRY(ctx, launch_propagate_level(c, (const uint32_t*)ctx->parent_idx.p, lv.first, lv.second, ctx->changed, tree_bits,
+                                                ctx->g_changed_bytes, all_dirty, static_opt, ctx->stream));
+        }
         ctx->g_chg_in_bytes = true;
     }
     if (ctx->have_changed && ctx->changed_maybe) {
@@ -915,6 +921,11 @@ int32_t mi_visibility_propagate(mi_ctx* ctx) {
         HIP_TRY(ctx, launch_inherit_tiles((const uint32_t*)ctx->parent_idx.p, (const TileDesc*)ctx->tiles.p + ps.first, ps.second,
                                           first, ctx->visibility, ctx->flags, ctx->inh_changed, ctx->stream));
         first = false;
+    }
+    for (auto& lv : ctx->stream_levels) {
+        ProfScope sc(ctx, K_INHERIT);
+        HIP_TRY(ctx, launch_inherit_level((const uint32_t*)ctx->parent_idx.p, lv.first, lv.second, ctx->visibility, ctx->flags, ctx->inh_changed,
+                                          ctx->stream));
     }
     return MI_OK;
 }
@@ -1197,7 +1208,7 @@ const char* mi_profile_kernel_name(uint32_t k) {
                                                "k_vis_end", "k_compact_count", "k_compact_scan", "k_compact_scatter",
                                                "k_compact_fast", "k_mark_dirty", "k_propagate_tiles", "k_cluster_walk", "k_cluster_fill",
                                                "k_clear_u32", "k_inherit", "k_batch_clear", "k_batch_hist", "k_batch_scan",
-                                               "k_batch_scatter", "k_batch_bounds", "k_batch_sets", "k_batch_allocate", "k_batch_unpack"};
+                                               "k_batch_scatter", "k_batch_bounds", "k_batch_sets", "k_batch_allocate", "k_batch_unpack", "k_propagate_stream"};
     return k < K_NUM_KERNELS ? names[k] : nullptr;
 }
 

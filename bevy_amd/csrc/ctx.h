@@ -71,7 +71,8 @@ struct mi_ctx {
     DevBuf parent_idx, node_flags, tiles;
     std::vector<std::pair<uint32_t, uint32_t>> passes;  // (first tile, n tiles); pass 0 starts at level 0 (roots)
     struct TileGroup { uint32_t first, count, n_chain, owner_rows; };
-    std::vector<TileGroup> groups;  // launches of mi_propagate: an owner pass + at most one pass of chain tiles
+    std::vector<TileGroup> groups;  // tile launches of mi_propagate: roots + chain bands in one, then one per dependent band
+    std::vector<std::pair<uint32_t, uint32_t>> stream_levels;  // (start, count), top-down: the wide deepest levels, one streaming launch each
     DevBuf chains, snap;            // snap: 2 x snap_rows x 48 B, pre-frame GlobalTransforms of the owner rows (see kernels_tree.hip)
     uint32_t snap_rows = 0, snap_parity = 0;
     bool snap_valid = false;

@@ -17,6 +17,7 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
         ctx->level_offsets = {0, n};
         ctx->passes.clear();
         ctx->groups.clear();
+        ctx->stream_levels.clear();
         return MI_OK;
     }
     if (!level_offsets) return fail(ctx, MI_ERR_INVALID_ARG, "mi_upload_hierarchy: level_offsets NULL");
@@ -60,125 +61,128 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
     };
 
     // ---- tile plan ----
-    // A pass = one launch covering `d` consecutive levels; its tiles partition the rows of the level the pass is
-    // rooted in.  Pass 0 is rooted in level 0 itself (tile level 0 = a range of roots / flat rows); later passes
-    // are rooted in the last level of the previous pass (tile level 0 = the children of a range of its rows).
-    // A tile "fits" when all its levels but the last together hold <= TILE_UCAP rows (they live in LDS).
-    const char* env_levels = getenv("MI_TILE_LEVELS");
-    const uint32_t max_d = env_levels ? std::max(1, std::min((int)TILE_MAX_LEVELS, atoi(env_levels))) : TILE_MAX_LEVELS;
+    // A tile = a contiguous row range at its first level plus all the descendants of those rows over the next levels,
+    // walked by one workgroup (kernels_tree.hip).  It "fits" when all its levels but the last together hold <= TILE_UCAP rows
+    // (they live in LDS); the last level is streamed and may be any size (kept <= TILE_LAST_CAP to spread the work).  Levels are cut into BANDS of consecutive levels, bottom-up, so that the bottom band -- where nearly all the
+    // rows of a tree are -- gets the deepest tiles the LDS budget allows.  Three kinds of band:
+    //   roots      first level = level 0 (forest roots and flat rows); a tile may span many roots;
+    //   chain      every tile's first-level rows are children of ONE node whose ancestor chain (<= TILE_MAX_CHAIN nodes)
+    //              the tile re-evaluates itself -- same products, same order, hence the same bits as the tiles that own
+    //              those ancestors write -- so it depends on nothing another tile produces;
+    //   dependent  (fallback: chains too long, or tiles too small to be worth a chain each) first-level parents are read
+    //              from global memory, so the band needs its own launch behind the band above.
+    // Roots and chain bands are mutually independent: they share ONE launch, whatever the depth of the hierarchy.
     std::vector<TileDesc> tiles;
     std::vector<uint32_t> chains;
     ctx->passes.clear();
     ctx->groups.clear();
+    ctx->stream_levels.clear();
     auto level_size = [&](uint32_t lv) -> uint64_t { return lv < n_levels ? level_offsets[lv + 1] - level_offsets[lv] : 0; };
-    // MI_TILE_PLAN="2,5,4": explicit band depths (experiments)
-    std::vector<uint32_t> plan;
-    if (const char* pe = getenv("MI_TILE_PLAN")) {
-        for (const char* q = pe; *q;) {
-            plan.push_back((uint32_t)std::max(1, atoi(q)));
-            while (*q && *q != ',') ++q;
-            if (*q == ',') ++q;
+    // A VERY wide deepest level is not tiled: a workgroup walking a tile is a chain of dependent round trips (descriptor,
+    // step 0, chain, LDS levels, then one round trip per 256 streamed rows) at 4 waves per SIMD; k_propagate_level sweeps a
+    // level at 8 waves per SIMD and the flat kernel's pace (650 k rows in 16.4 us = 5.6 TB/s).  But a tile launch has a floor
+    // of ~10 us however little it does, and a launch boundary costs ~1.8 us, so at 1 M nodes the single tile launch wins
+    // (33.5 us against 21.6 + 1.8 + 16.4 with the deepest level streamed); the streamed levels pay from a few million
+    // nodes up (thresholds in kernels.h).
+    uint32_t n_tile_levels = n_levels;
+    while (n_tile_levels > 1 &&
+           level_size(n_tile_levels - 1) >= (n_tile_levels == n_levels ? STREAM_LEVEL_MIN_ROWS_LAST : STREAM_LEVEL_MIN_ROWS))
+        --n_tile_levels;
+    for (uint32_t l = n_tile_levels; l < n_levels; ++l) ctx->stream_levels.emplace_back(level_offsets[l], level_offsets[l + 1] - level_offsets[l]);
+    struct Band { uint32_t s, e; bool chain; };
+    std::vector<Band> bands;  // bottom-up
+    for (uint32_t e = n_tile_levels; e > 0;) {
+        uint32_t s = e - 1;  // a band of one level always works
+        const uint32_t lo = e > TILE_MAX_LEVELS ? e - TILE_MAX_LEVELS : 0;
+        for (uint32_t cand = lo; cand + 1 < e; ++cand) {
+            // per first-level row, on average: the would-be upper levels must fit the LDS budget and the last level the cap
+            uint64_t upper = 0;
+            for (uint32_t l = cand; l + 1 < e; ++l) upper += level_size(l);
+            const uint64_t firsts = std::max<uint64_t>(1, level_size(cand));
+            if (upper <= (uint64_t)TILE_UCAP * firsts && level_size(e - 1) <= (uint64_t)TILE_LAST_CAP * firsts) { s = cand; break; }
         }
+        uint64_t rows = 0;
+        for (uint32_t l = s; l < e; ++l) rows += level_size(l);
+        // worth a chain per tile unless the band is a swarm of tiny tiles: (tiles x chain length) node products are spent on
+        // chains; keep that within a few times the band's own rows
+        const uint64_t est_tiles = std::max<uint64_t>(std::max<uint64_t>(1, level_size(s - (s ? 1 : 0))), rows / (TILE_UCAP + TILE_LAST_CAP));
+        const bool chain = s > 0 && s <= TILE_MAX_CHAIN && est_tiles * s <= 4 * rows + 4096;
+        bands.push_back({s, e, chain});
+        e = s;
     }
-    uint32_t band = 0;
-    uint32_t l = 0;  // first level this pass computes
-    while (l < n_levels) {
-        const bool roots = l == 0;
-        // band depth: as deep as possible while an average root range of one row still fits in LDS
-        const uint64_t n_roots = std::max<uint64_t>(1, roots ? level_size(0) : level_size(l - 1));
-        uint32_t d = 1;
-        uint64_t upper = level_size(l);  // rows of the levels that would be non-last if we add one more level
-        while (d < max_d && l + d < n_levels && upper <= (uint64_t)TILE_UCAP * n_roots) {
-            ++d;
-            upper += level_size(l + d - 1);
-        }
-        if (band < plan.size()) d = std::min<uint32_t>(std::min<uint32_t>(plan[band], TILE_MAX_LEVELS), n_levels - l);
-        ++band;
-        // [lo,hi) is a row range of the rooting level; returns the tile and whether it fits
-        auto build = [&](uint32_t lo, uint32_t hi, TileDesc& td) -> bool {
-            uint32_t clo = lo, chi2 = hi;
+    // tiles of one band: galloping extension of the first-level range while the tile still fits
+    auto build_band = [&](const Band& bd, uint32_t kind_base) {
+        const uint32_t d = bd.e - bd.s;
+        auto build = [&](uint32_t lo, uint32_t hi, TileDesc& td) -> bool {  // [lo,hi): rows of level bd.s
             td = TileDesc{};
+            uint32_t clo = lo, chi2 = hi;
             for (uint32_t k = 0; k < d; ++k) {
-                uint32_t nlo, nhi;
-                if (roots && k == 0) { nlo = lo; nhi = hi; }
-                else {
-                    const uint32_t plevel = roots ? k - 1 : l - 1 + k;
-                    nlo = child_begin(plevel, clo);
-                    nhi = child_begin(plevel, chi2);
+                td.start[k] = clo;
+                td.count[k] = chi2 - clo;
+                if (chi2 > clo) td.n_levels = k + 1;
+                if (k + 1 < d) {
+                    const uint32_t nlo = child_begin(bd.s + k, clo), nhi = child_begin(bd.s + k, chi2);
+                    clo = nlo;
+                    chi2 = nhi;
                 }
-                td.start[k] = nlo;
-                td.count[k] = nhi - nlo;
-                clo = nlo; chi2 = nhi;
-                if (nhi > nlo) td.n_levels = k + 1;
             }
             uint64_t up = 0;
             for (uint32_t k = 0; k + 1 < td.n_levels; ++k) up += td.count[k];
-            return up <= TILE_UCAP;
+            return up <= TILE_UCAP && (td.n_levels == 0 || td.count[td.n_levels - 1] <= TILE_LAST_CAP);
         };
-        // Chain candidate (see "Tile kinds" below): then every tile hangs below exactly one node, as long as that
-        // still gives tiles of a decent size.
-        uint64_t pass_rows = 0;
-        for (uint32_t k = 0; k < d; ++k) pass_rows += level_size(l + k);
-        // (several chained passes may share a launch: chain tiles read the pre-frame snapshot, nobody waits for anybody)
-        const bool chain_candidate = !roots && l <= TILE_MAX_CHAIN && !ctx->groups.empty() &&
-                                     (!plan.empty() || (ctx->groups.back().n_chain == 0 && ctx->groups.back().count <= 64)) &&
-                                     getenv("MI_TILE_NO_CHAIN") == nullptr && n_roots <= 16384 && pass_rows >= 128 * n_roots;
+        const uint32_t rlo = level_offsets[bd.s], rhi = level_offsets[bd.s + 1];
         const uint32_t first_tile = (uint32_t)tiles.size();
-        const uint32_t rl = roots ? 0 : l - 1;
-        const uint32_t rlo = level_offsets[rl], rhi = level_offsets[rl + 1];
         uint32_t a = rlo;
         while (a < rhi) {
             TileDesc best{};
             uint32_t b = a + 1;
-            build(a, b, best);
-            uint32_t step = 1;  // galloping extension of the root range
-            while (b < rhi && !chain_candidate) {
+            build(a, b, best);  // a single first-level row always makes a tile (the kernel streams what does not fit)
+            uint32_t step = 1;
+            while (b < rhi) {
                 const uint32_t nb = (uint32_t)std::min<uint64_t>((uint64_t)b + step, rhi);
                 TileDesc cand{};
-                // keep tiles small enough to spread over the chip: at most 4 x TILE_UCAP rows in the streamed last level
-                if (build(a, nb, cand) && (cand.n_levels == 0 || cand.count[cand.n_levels - 1] <= 4 * TILE_UCAP || nb == a + 1)) { best = cand; b = nb; step *= 2; }
+                const bool same_parent = !bd.chain || parent_idx[nb - 1] == parent_idx[a];
+                if (same_parent && build(a, nb, cand)) { best = cand; b = nb; step *= 2; }
                 else if (step > 1) step = 1;
                 else break;
             }
-            if (best.n_levels) tiles.push_back(best);
+            if (best.n_levels) {
+                best.kind = kind_base;
+                if (bd.chain) {
+                    chains.resize((tiles.size() + 1) * (size_t)TILE_MAX_CHAIN, 0u);
+                    uint32_t row = parent_idx[best.start[0]], len = 0;
+                    while (row != MI_NO_PARENT && len < TILE_MAX_CHAIN) {
+                        chains[tiles.size() * (size_t)TILE_MAX_CHAIN + len++] = row;
+                        row = parent_idx[row];
+                    }
+                    best.kind = len;
+                }
+                tiles.push_back(best);
+            }
             a = b;
         }
-        const uint32_t n_pass_tiles = (uint32_t)tiles.size() - first_tile;
-        ctx->passes.emplace_back(first_tile, n_pass_tiles);
-        // Tile kinds.  Pass 0: roots.  A later pass whose every tile hangs below ONE node of a short enough ancestor
-        // chain lets each tile re-evaluate that chain itself (kernels_tree.hip), which makes the pass independent of
-        // the one above it: it joins the previous launch.  Otherwise its tiles read their parents from global memory
-        // and the pass needs its own launch behind the previous one.
-        // (the owners wait for the chain tiles to start, so there must be few of them and only one chained pass per launch)
-        bool chainable = chain_candidate;
-        for (uint32_t ti = first_tile; chainable && ti < tiles.size(); ++ti) {
-            const TileDesc& td = tiles[ti];
-            if (td.n_levels == 0) continue;
-            const uint32_t p0 = parent_idx[td.start[0]];
-            if (parent_idx[td.start[0] + td.count[0] - 1] != p0) chainable = false;  // level 0 of the tile spans several parents
+        return std::make_pair(first_tile, (uint32_t)tiles.size() - first_tile);
+    };
+    // launch 1: the chain bands, bottom band first (the longest tiles start first), then the roots band
+    std::vector<std::pair<uint32_t, uint32_t>> band_tiles(bands.size());
+    uint32_t n_chain_tiles = 0, owner_rows = 0;
+    for (size_t i = 0; i < bands.size(); ++i)
+        if (bands[i].chain) {
+            band_tiles[i] = build_band(bands[i], 0u);
+            n_chain_tiles += band_tiles[i].second;
+            owner_rows = std::max(owner_rows, level_offsets[bands[i].s]);  // the snapshot prefix: every row above the deepest chain band
         }
-        chains.resize(tiles.size() * (size_t)TILE_MAX_CHAIN, 0u);
-        for (uint32_t ti = first_tile; ti < tiles.size(); ++ti) {
-            TileDesc& td = tiles[ti];
-            td.kind = roots ? TILE_ROOTS : 0u;
-            if (chainable && td.n_levels) {
-                uint32_t row = parent_idx[td.start[0]], len = 0;
-                while (row != MI_NO_PARENT && len < TILE_MAX_CHAIN) {
-                    chains[(size_t)ti * TILE_MAX_CHAIN + len++] = row;
-                    row = parent_idx[row];
-                }
-                td.kind = len;
-            }
+    band_tiles.back() = build_band(bands.back(), TILE_ROOTS);  // bands.back() starts at level 0
+    ctx->groups.push_back({0u, (uint32_t)tiles.size(), n_chain_tiles, owner_rows});
+    // then the dependent bands, top-down, one launch each
+    for (size_t i = bands.size(); i-- > 0;)
+        if (!bands[i].chain && bands[i].s > 0) {
+            band_tiles[i] = build_band(bands[i], 0u);
+            ctx->groups.push_back({band_tiles[i].first, band_tiles[i].second, 0u, 0u});
         }
-        if (chainable) {
-            ctx->groups.back().count += n_pass_tiles;
-            ctx->groups.back().n_chain += n_pass_tiles;
-            ctx->groups.back().owner_rows = level_offsets[l];  // the snapshot prefix: every row above the deepest chained pass
-        } else {
-            ctx->groups.push_back({first_tile, n_pass_tiles, 0u, 0u});
-        }
-        l += d;
-    }
+    chains.resize(tiles.size() * (size_t)TILE_MAX_CHAIN, 0u);
+    // the bands top-down, for the kernels that sweep level by level with one launch per band (InheritedVisibility)
+    for (size_t i = bands.size(); i-- > 0;) ctx->passes.emplace_back(band_tiles[i].first, band_tiles[i].second);
     int32_t rc;
     if ((rc = ensure(ctx, ctx->parent_idx, (size_t)n * 4))) return rc;
     if ((rc = ensure(ctx, ctx->node_flags, n))) return rc;
@@ -195,6 +199,18 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
     ctx->level_offsets.assign(level_offsets, level_offsets + n_levels + 1);
     ctx->n_levels = n_levels;
     ctx->have_hierarchy = true;
+    return MI_OK;
+}
+
+// test hook (not part of the public header): the shape of the current tile plan
+int32_t mi_debug_tile_plan(mi_ctx* ctx, uint32_t* out_launches, uint32_t* out_tiles, uint32_t* out_chain_tiles, uint32_t* out_bands) {
+    ENTER(ctx);
+    uint32_t tiles = 0, chain = 0;
+    for (auto& g : ctx->groups) { tiles += g.count; chain += g.n_chain; }
+    if (out_launches) *out_launches = (uint32_t)ctx->groups.size();
+    if (out_tiles) *out_tiles = tiles;
+    if (out_chain_tiles) *out_chain_tiles = chain;
+    if (out_bands) *out_bands = (uint32_t)ctx->passes.size();
     return MI_OK;
 }
 

@@ -120,6 +120,7 @@ enum KernelId : uint32_t {
     K_BATCH_SETS,
     K_BATCH_ALLOCATE,
     K_BATCH_UNPACK,
+    K_PROPAGATE_STREAM,
     K_NUM_KERNELS
 };
 
@@ -197,9 +198,14 @@ hipError_t launch_compact(const CompactArgs& a, hipStream_t stream, void (*mark)
 hipError_t launch_compact_fast(const CompactFastArgs& a, hipStream_t stream);
 
 // ---- hierarchy ---------------------------------------------------------------------------------
-constexpr uint32_t TILE_MAX_LEVELS = 6;
+constexpr uint32_t TILE_MAX_LEVELS = 8;
+constexpr uint32_t TILE_BLOCK = 256;           // threads per tile
 constexpr uint32_t TILE_UCAP = 512;            // LDS slots of one tile: rows of all its levels but the last
-constexpr uint32_t TILE_R = TILE_UCAP / 256;   // LDS-resident rows per thread
+constexpr uint32_t TILE_LAST_CAP = 1024;       // the planner keeps a tile's streamed last level at or below this
+// A level this wide is not given to tiles at all: it is swept by a streaming launch of its own (k_propagate_level) behind
+// the level above it.  The deepest level qualifies earlier than the ones above it (nothing else has to wait for it).
+constexpr uint32_t STREAM_LEVEL_MIN_ROWS_LAST = 1u << 20;
+constexpr uint32_t STREAM_LEVEL_MIN_ROWS = 1u << 21;
 constexpr uint32_t TILE_MAX_CHAIN = 24;       // ancestors a chain tile re-evaluates (levels above its first level)
 constexpr uint32_t TILE_ROOTS = 0x80000000u;   // TileDesc::kind: first level = level 0 of the forest
 constexpr uint32_t TILE_CHAIN_MASK = 0xFFu;    // TileDesc::kind: chain length (0 = parents come from global memory)
@@ -217,6 +223,12 @@ hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, 
                                   uint8_t* g_changed_bytes, const float* snap_read, float* snap_write, uint32_t snap_rows, bool all_dirty,
                                   bool static_opt,
                                   hipStream_t stream);
+// One whole level [start, start + count) as a stream: every row's parent lies in the level above, complete in global
+// memory (an earlier launch).  Same per-node rule as the tiles.
+hipError_t launch_propagate_level(const Columns& c, const uint32_t* parent_idx, uint32_t start, uint32_t count, const uint8_t* changed,
+                                  const uint32_t* tree_bits, uint8_t* g_changed_bytes, bool all_dirty, bool static_opt, hipStream_t stream);
+hipError_t launch_inherit_level(const uint32_t* parent_idx, uint32_t start, uint32_t count, const uint8_t* visibility, uint8_t* flags,
+                                uint8_t* inh_changed, hipStream_t stream);
 // InheritedVisibility propagation (visibility_propagate_system): writes bit0 of flags[] and changed bytes.
 hipError_t launch_inherit_flat(uint32_t n, const uint8_t* visibility, uint8_t* flags, uint8_t* inh_changed, hipStream_t stream);
 hipError_t launch_inherit_tiles(const uint32_t* parent_idx, const TileDesc* d_tiles, uint32_t n_tiles, bool roots,

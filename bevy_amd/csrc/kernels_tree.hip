@@ -23,8 +23,6 @@
 //
 // Algorithmic bytes per node: read T 40 + parent_idx 4 + old G 48 (set_if_neq, systems.rs:719),
 // write G 48 + changed 1; parent G comes from LDS (first level of a non-root tile: from L2).
-#include <stdlib.h>
-
 #include "glam_math.h"
 #include "kernels.h"
 
@@ -454,18 +452,84 @@ __device__ __forceinline__ void process_tile(const Columns& c, const TreeArgs& a
 //   otherwise    the parents of its first level are read from global memory (written by an earlier launch).
 // (Letting a chain tile's workgroup also process an owner tile was measured slower: 42 us against 34.5 us for the
 // 1 M-node tree, the owner's latency chain simply adds to that workgroup's time.)
-// BLOCK = 256 normally; 1024 for launches with so few tiles that one workgroup's loop length is the critical path.
+// BLOCK = TILE_BLOCK = 256.  Measured alternatives on the 1 M-node depth-11 tree (profiles/r02_tree_experiments.md): one wave
+// per tile (64 threads, 85- to 341-row tiles, 16 tiles resident per CU) 35.0 us -- every tile pays its own chain (46 % of
+// the VALU instructions of an 85-row tile run on one lane) and the kernel turns issue-bound; 128 threads 36.6 us; 512 / 1024
+// threads 39.0 / 50.8 us (fewer tiles resident); 256 threads 33.5 us.  The chain's inputs share wave 0's transpose buffer:
+// they are consumed before the streamed level first touches it.
 template <uint32_t BLOCK>
 __global__ void __launch_bounds__(BLOCK) k_propagate_tiles(Columns c, TreeArgs a) {
+    static_assert(TILE_MAX_CHAIN * 6 <= 192, "the chain inputs must fit in one wave's transpose buffer");
     __shared__ float4 lds_g[TILE_UCAP * 3];
     __shared__ uint8_t lds_chg[TILE_UCAP];
     __shared__ float4 lds_stage[BLOCK / 64][192];
-    __shared__ float4 lds_chain[TILE_MAX_CHAIN * 6];
     __shared__ uint8_t lds_chain_in[TILE_MAX_CHAIN];
     __shared__ float4 lds_chain_g[3];
     __shared__ uint32_t lds_chain_chg;
-    const TileLds<BLOCK> lds{lds_g, lds_chg, lds_stage, lds_chain, lds_chain_in, lds_chain_g, &lds_chain_chg};
+    const TileLds<BLOCK> lds{lds_g, lds_chg, lds_stage, &lds_stage[0][0], lds_chain_in, lds_chain_g, &lds_chain_chg};
     process_tile<BLOCK>(c, a, blockIdx.x, lds);
+}
+
+// ---------------------------------------------------------------------------------------------
+// A wide level as a stream (the deepest level of a big tree holds most of its rows).  One row per lane, no loops, so
+// the register budget allows twice the waves of the tile kernel and the level moves at the flat kernel's pace: T / R / S,
+// parent index and the old GlobalTransform in (the latter as three contiguous 1 KB wave rows through a wave-private LDS
+// transpose), the parent's GlobalTransform and change flag gathered from the level above (complete: an earlier launch;
+// the four children of a node sit in neighbouring lanes, so the gather touches 16 x 48 contiguous bytes per wave in a
+// 4-ary tree), the new GlobalTransform out through the same transpose.
+// Algorithmic bytes per row: 40 + 4 + 48 + 48 + 1 = 141 (+ 48 / fan-out for the parents, L2 hits).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_propagate_level(Columns c, TreeArgs a, uint32_t start, uint32_t count) {
+    __shared__ float4 lds_stage[4][192];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t i = blockIdx.x * 256u + tid;
+    const bool live = i < count;
+    const uint32_t row = start + i;
+    const uint32_t wbase = blockIdx.x * 256u + wv * 64u;
+    const uint32_t wave_lim = wbase < count ? (count - wbase < 64u ? count - wbase : 64u) * 3u : 0u;
+    float4* stage = lds_stage[wv];
+    float4* const gw = reinterpret_cast<float4*>(c.global) + 3ull * (start + wbase);
+    // the wave's old GlobalTransforms first: everything issued after them can stay in flight while they are transposed
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 o0 = lane < wave_lim ? gw[lane] : z4;
+    const float4 o1 = 64u + lane < wave_lim ? gw[64u + lane] : z4;
+    const float4 o2 = 128u + lane < wave_lim ? gw[128u + lane] : z4;
+    V3 t = {}, sc = {};
+    V4 q = {};
+    Affine gp = {};
+    bool p_changed = false;
+    if (live) {
+        const uint32_t p = a.parent_idx[row];
+        t = ld3(c.translation, row);
+        q = ld4(c.rotation, row);
+        sc = ld3(c.scale, row);
+        gp = ld_affine(c.global, p);
+        p_changed = a.g_changed_bytes[p] != 0;
+    }
+    stage[lane] = o0;
+    stage[64u + lane] = o1;
+    stage[128u + lane] = o2;
+    MI_WAVE_LDS_SYNC();
+    const Affine old = lds_affine(stage, lane);
+    Affine cur = old;
+    bool chg = false;
+    if (live) {
+        chg = node_update(a, false, row, gp, p_changed, affine_from_srt(sc, q, t), old, &cur);
+        a.g_changed_bytes[row] = chg ? 1 : 0;
+    }
+    const unsigned long long cm = __ballot(chg), lm = __ballot(live);
+    if (cm == lm) {  // the whole wave changed (the dirty-tree case): transpose back, three contiguous 1 KB rows out
+        MI_WAVE_LDS_SYNC();
+        lds_put(stage, lane, cur);
+        MI_WAVE_LDS_SYNC();
+#pragma unroll
+        for (uint32_t k = 0; k < 3u; ++k) {
+            const uint32_t j = k * 64u + lane;
+            if (j < wave_lim) gw[j] = stage[j];
+        }
+    } else if (chg) {
+        st_affine(c.global, row, cur);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -498,6 +562,15 @@ __global__ void __launch_bounds__(256) k_inherit_flat(uint32_t n, const uint8_t*
                                                        uint8_t* inh_changed) {
     const uint32_t row = blockIdx.x * 256u + threadIdx.x;
     if (row < n) inherit_update(row, visibility[row], 2u, flags, inh_changed);  // no parent -> Inherited means visible
+}
+
+__global__ void __launch_bounds__(256) k_inherit_level(const uint32_t* __restrict__ parent_idx, uint32_t start, uint32_t count,
+                                                        const uint8_t* __restrict__ visibility, uint8_t* flags, uint8_t* inh_changed) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t row = start + i, p = parent_idx[row];
+    const uint32_t ps = (visibility[p] & 0x80u) ? 2u : (uint32_t)(flags[p] & 1u);
+    inherit_update(row, visibility[row], ps, flags, inh_changed);
 }
 
 template <bool ROOTS>
@@ -569,6 +642,26 @@ hipError_t launch_inherit_tiles(const uint32_t* parent_idx, const TileDesc* d_ti
     return hipGetLastError();
 }
 
+hipError_t launch_inherit_level(const uint32_t* parent_idx, uint32_t start, uint32_t count, const uint8_t* visibility, uint8_t* flags,
+                                uint8_t* inh_changed, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    MI_LAUNCH(k_inherit_level, dim3((count + 255u) / 256u), dim3(256), 0, stream, parent_idx, start, count, visibility, flags, inh_changed);
+    return hipGetLastError();
+}
+hipError_t launch_propagate_level(const Columns& c, const uint32_t* parent_idx, uint32_t start, uint32_t count, const uint8_t* changed,
+                                  const uint32_t* tree_bits, uint8_t* g_changed_bytes, bool all_dirty, bool static_opt, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    TreeArgs a{};
+    a.parent_idx = parent_idx;
+    a.changed = changed;
+    a.tree_bits = tree_bits;
+    a.g_changed_bytes = g_changed_bytes;
+    a.all_dirty = all_dirty ? 1u : 0u;
+    a.static_opt = static_opt ? 1u : 0u;
+    MI_LAUNCH(k_propagate_level, dim3((count + 255u) / 256u), dim3(256), 0, stream, c, a, start, count);
+    return hipGetLastError();
+}
+
 hipError_t launch_mark_dirty(uint32_t n, const uint8_t* changed, const uint32_t* parent_idx, uint32_t* tree_bits,
                              hipStream_t stream) {
     if (n == 0) return hipSuccess;
@@ -595,13 +688,7 @@ hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, 
     a.chains = d_chains;
     a.all_dirty = all_dirty ? 1u : 0u;
     a.static_opt = static_opt ? 1u : 0u;
-    // few tiles: one workgroup's streamed-level loop is the critical path -> 1024 threads shorten it 4x
-    static const int forced = getenv("MI_TILE_BLOCK") ? atoi(getenv("MI_TILE_BLOCK")) : 0;
-    const uint32_t block = forced ? (uint32_t)forced : (n_tiles < 128u ? 1024u : 256u);
-    const uint32_t grid = n_tiles;
-    if (block == 1024u) MI_LAUNCH((k_propagate_tiles<1024>), dim3(grid), dim3(1024), 0, stream, c, a);
-    else if (block == 512u) MI_LAUNCH((k_propagate_tiles<512>), dim3(grid), dim3(512), 0, stream, c, a);
-    else MI_LAUNCH((k_propagate_tiles<256>), dim3(grid), dim3(256), 0, stream, c, a);
+    MI_LAUNCH((k_propagate_tiles<TILE_BLOCK>), dim3(n_tiles), dim3(TILE_BLOCK), 0, stream, c, a);
     return hipGetLastError();
 }
 

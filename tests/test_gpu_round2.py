@@ -191,3 +191,63 @@ def test_first_indexed_upload_keeps_rows_that_were_never_propagated(ctx_factory)
     g, chg = ctx.download_global_transforms()
     g_exp, _ = O.sync_simple_transforms(t.reshape(-1), sc["rotation"], sc["scale"])
     assert g.tobytes() == g_exp.tobytes() and chg.all()
+
+
+def test_tile_plans_are_one_launch_for_deep_and_wide_hierarchies(ctx_factory):
+    """The planner cuts levels into bands bottom-up; roots and chain bands share ONE launch whatever the depth.  Parity of
+    every shape is covered by the tree tests; this pins the launch count the performance rests on."""
+    ctx = ctx_factory()
+    for tr, want_launches in ((W.gen_tree(12, 4, 1_000_000), 1), (W.gen_tree(20, 2, 300_000), 1), (W.gen_tree(4, 40), 1),
+                              (flat_rows_plus_deep_tree(), 1), (W.gen_tree(3, 1000), None)):
+        upload_tree(ctx, tr)
+        plan = ctx.debug_tile_plan()
+        assert plan["tiles"] > 0 and plan["bands"] >= 1
+        if want_launches is not None:
+            assert plan["launches"] == want_launches, plan
+        ctx.propagate(B.PROPAGATE_ALL_DIRTY)
+        rc, g_exp, _ = O.propagate_transforms(tr["parent"], tr["translation"], tr["rotation"], tr["scale"])
+        assert rc == 0 and ctx.download_global_transforms(want_changed=False).tobytes() == g_exp.tobytes(), plan
+
+
+@pytest.mark.parametrize("static_opt", [False, True])
+def test_very_wide_deepest_level_is_streamed(ctx_factory, static_opt):
+    """A deepest level of >= 2^20 rows is not tiled: k_propagate_level sweeps it in a launch of its own behind the level above
+    (kernels.h STREAM_LEVEL_MIN_ROWS_LAST).  Same per-node rule, so: all dirty, a moved root, sparse dirty rows under the
+    static-scene rule and a static frame must all be the oracle's bits -- and visibility_propagate walks the same plan."""
+    tr = W.gen_tree(3, 1100)  # 1 + 1100 + 1 210 000 rows
+    n, parent = tr["n"], tr["parent"]
+    assert tr["level_offsets"][-1] - tr["level_offsets"][-2] >= (1 << 20)
+    flags = B.PROPAGATE_STATIC_OPT if static_opt else 0
+    ctx = ctx_factory()
+    upload_tree(ctx, tr)
+    assert ctx.debug_tile_plan()["launches"] == 1
+    ctx.propagate(B.PROPAGATE_ALL_DIRTY | flags)
+    rc, g0, chg0 = O.propagate_transforms(parent, tr["translation"], tr["rotation"], tr["scale"], static_opt=static_opt)
+    g, chg = ctx.download_global_transforms()
+    assert rc == 0 and g.tobytes() == g0.tobytes()
+    assert_bits(chg, chg0, "first frame")
+    t = tr["translation"].reshape(n, 3).copy()
+    for f, rows in enumerate([np.array([0], np.uint32), np.array([5, 1101 + 7, n - 1, 600_000], np.uint32), np.zeros(0, np.uint32),
+                              np.array([1100, 1101, 1_000_000], np.uint32)]):
+        t[rows] += F(0.75)
+        if rows.size:
+            ctx.upload_transforms_indexed(rows, t[rows].reshape(-1), tr["rotation"].reshape(n, 4)[rows].reshape(-1),
+                                          tr["scale"].reshape(n, 3)[rows].reshape(-1))
+        ctx.propagate(flags)
+        changed = np.zeros(n, np.uint8)
+        changed[rows] = 1
+        rc, g1, chg1 = O.propagate_transforms(parent, t.reshape(-1), tr["rotation"], tr["scale"], global_in=g0, static_opt=static_opt,
+                                              tree_changed=O.mark_dirty_trees(parent, changed), transform_changed=changed)
+        g, chg = ctx.download_global_transforms()
+        bad = np.nonzero((g.view(np.uint32) != g1.view(np.uint32)).reshape(-1, 12).any(axis=1))[0]
+        assert bad.size == 0, f"frame {f}: {bad.size} rows differ, first {bad[:5].tolist()}"
+        assert_bits(chg, chg1, f"frame {f} change ticks")
+        g0 = g1
+    if not static_opt:
+        rng = np.random.default_rng(9)
+        vis = rng.choice(np.array([0, 0, 1, 2, 0x80], np.uint8), size=n).astype(np.uint8)
+        ctx.upload_visibility(vis)
+        ctx.visibility_propagate()
+        inh, _ = ctx.download_inherited_visibility()
+        rc, inh_exp, _ = O.visibility_propagate(parent, vis, np.ones(n, np.uint8))
+        assert rc == 0 and np.array_equal(inh, inh_exp)

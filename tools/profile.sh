@@ -1,19 +1,30 @@
 #!/bin/bash
-# Collects the rocprofv3 evidence for one round on the GPU box:   bash tools/profile.sh <tag>
+# Collects the rocprofv3 evidence for one state of the code on the GPU box:   bash tools/profile.sh <tag> [workload ...]
 #   - kernel-trace + stats of the bench command for each workload (CSV)
-#   - separate PMC passes (FETCH_SIZE, WRITE_SIZE) for the dominant kernels, as MI355X_MICROARCH.md prescribes
-# Raw output goes to gpurun_out/prof_<tag>/ (scratch); tools/summarize_profiles.py turns it into profiles/<tag>/.
-TAG=${1:-r01}
+#   - separate PMC passes (FETCH_SIZE, WRITE_SIZE) for the streaming kernels, as MI355X_MICROARCH.md prescribes
+#     (never combined with the trace domains gpurun refuses)
+# Raw output goes to gpurun_out/prof_<tag>/ (scratch); tools/summarize_profiles.py turns it into profiles/<tag>/ and
+# profiles/rocprof_summary.json (what bench.py quotes as rocprof_avg_kernel_us / traffic).
+TAG=${1:-r02}
+shift
+WLS=${@:-frame flat flat_10m_1view flat_10m_4views tree lights flat_static batching}
 export TMPDIR=/tmp
 P=gpurun_out/prof_$TAG
 mkdir -p $P
-for wl in flat tree lights flat_static batching; do
-  timeout -k 5 120 rocprofv3 --kernel-trace --stats --output-format csv -d $P/$wl -o $wl -- \
-      python bench.py --workload $wl --steps 100 --warmup 10 --no-cpu-baseline --no-other-workloads > $P/$wl.log 2>&1
-  if [ $wl = flat_static ] || [ $wl = batching ]; then continue; fi
+COMMON="--no-cpu-baseline --no-other-workloads --no-end-to-end"
+for wl in $WLS; do
+  case $wl in
+    flat_10m_1view)  ARGS="--workload flat --entities 10000000 --views 1" ;;
+    flat_10m_4views) ARGS="--workload flat --entities 10000000 --views 4" ;;
+    *)               ARGS="--workload $wl" ;;
+  esac
+  echo "python bench.py $ARGS --steps 50 --warmup 10 --blocks 4 $COMMON" > $P/$wl.cmd
+  timeout -k 5 180 rocprofv3 --kernel-trace --stats --output-format csv -d $P/$wl -o $wl -- \
+      python bench.py $ARGS --steps 50 --warmup 10 --blocks 4 $COMMON > $P/$wl.log 2>&1
+  if [ $wl = batching ] || [ $wl = lights ]; then continue; fi
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    timeout -k 5 120 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $P/${wl}_$ctr -o $wl -- \
-        python bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline --no-other-workloads > $P/${wl}_$ctr.log 2>&1
+    timeout -k 5 180 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $P/${wl}_$ctr -o $wl -- \
+        python bench.py $ARGS --steps 10 --warmup 2 --blocks 2 $COMMON > $P/${wl}_$ctr.log 2>&1
   done
 done
-python tools/summarize_profiles.py $TAG
+python tools/summarize_profiles.py $TAG $WLS

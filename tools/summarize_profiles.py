@@ -1,7 +1,11 @@
-"""gpurun_out/prof_<tag>/ (raw rocprofv3 CSVs) -> profiles/<tag>/ (committed summaries) + profiles/pmc_traffic.json.
+"""gpurun_out/prof_<tag>/ (raw rocprofv3 CSVs) -> profiles/<tag>/ (committed summaries) + profiles/rocprof_summary.json.
 
-HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (both reported in KiB): on gfx950 FETCH_SIZE tallies the 128-byte
-requests of wide coalesced reads at 64 bytes (MI355X_MICROARCH.md, section HBM), so the read side is doubled."""
+    python tools/summarize_profiles.py <tag> [workload ...]
+
+Per workload: the kernel-trace statistics CSV (average duration per kernel) and, from the separate --pmc passes, HBM bytes per
+launch = 2 x FETCH_SIZE + WRITE_SIZE (both reported in KiB): on gfx950 FETCH_SIZE tallies the 128-byte requests of wide
+coalesced reads at 64 bytes (MI355X_MICROARCH.md, section HBM), so the read side is doubled.  rocprof_summary.json keeps, per
+workload and kernel, {avg_us, calls, hbm_bytes_per_launch, source}: bench.py quotes it next to its live event timing."""
 import collections
 import csv
 import json
@@ -9,7 +13,8 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+workloads = sys.argv[2:] or ["frame", "flat", "flat_10m_1view", "flat_10m_4views", "tree", "lights", "flat_static", "batching"]
 src = os.path.join("gpurun_out", f"prof_{tag}")
 dst = os.path.join("profiles", tag)
 os.makedirs(dst, exist_ok=True)
@@ -24,29 +29,51 @@ def short(name):
     return n.split("(")[0].split("<")[0]
 
 
-pmc = collections.defaultdict(lambda: collections.defaultdict(list))
-for wl in ("flat", "tree", "lights", "flat_static", "batching"):
+summary_path = os.path.join("profiles", "rocprof_summary.json")
+try:
+    summary = json.load(open(summary_path))
+except Exception:
+    summary = {}
+for wl in workloads:
+    entry = {}
     stats = os.path.join(src, wl, f"{wl}_kernel_stats.csv")
     if os.path.exists(stats):
         shutil.copy(stats, os.path.join(dst, f"{wl}_kernel_stats.csv"))
+        agg = collections.defaultdict(lambda: [0, 0.0])
+        for r in csv.DictReader(open(stats)):
+            k = short(r["Name"])
+            agg[k][0] += int(r["Calls"])
+            agg[k][1] += float(r["TotalDurationNs"])
+        for k, (calls, tot) in agg.items():
+            if calls and not k.startswith("__amd"):
+                entry[k] = {"avg_us": round(tot / calls / 1e3, 3), "calls": calls}
+    cmd = os.path.join(src, f"{wl}.cmd")
+    if os.path.exists(cmd):
+        shutil.copy(cmd, os.path.join(dst, f"{wl}.cmd"))
+    pmc = collections.defaultdict(lambda: collections.defaultdict(list))
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         f = os.path.join(src, f"{wl}_{ctr}", f"{wl}_counter_collection.csv")
         if not os.path.exists(f):
             continue
         for r in csv.DictReader(open(f)):
             pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-summary = {}
-for k, ctrs in pmc.items():
-    if k.startswith("__amd"):
-        continue
-    e = {c: {"avg_KiB_per_dispatch": sum(v) / len(v), "dispatches": len(v)} for c, v in ctrs.items()}
-    if "FETCH_SIZE" in ctrs and "WRITE_SIZE" in ctrs:
-        fetch = sum(ctrs["FETCH_SIZE"]) / len(ctrs["FETCH_SIZE"]) * 1024.0
-        write = sum(ctrs["WRITE_SIZE"]) / len(ctrs["WRITE_SIZE"]) * 1024.0
-        e["hbm_bytes_per_launch"] = int(2.0 * fetch + write)
-        e["note"] = "2 x FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE counts wide reads at half)"
-    summary[k] = e
-json.dump(summary, open(os.path.join(dst, "pmc_counters.json"), "w"), indent=1)
-json.dump({k: {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"]} for k, v in summary.items() if "hbm_bytes_per_launch" in v},
-          open(os.path.join("profiles", "pmc_traffic.json"), "w"), indent=1)
-print(json.dumps(summary, indent=1))
+    counters = {}
+    for k, ctrs in pmc.items():
+        if k.startswith("__amd"):
+            continue
+        e = {c: {"avg_KiB_per_dispatch": round(sum(v) / len(v), 3), "dispatches": len(v)} for c, v in ctrs.items()}
+        if "FETCH_SIZE" in ctrs and "WRITE_SIZE" in ctrs:
+            fetch = sum(ctrs["FETCH_SIZE"]) / len(ctrs["FETCH_SIZE"]) * 1024.0
+            write = sum(ctrs["WRITE_SIZE"]) / len(ctrs["WRITE_SIZE"]) * 1024.0
+            e["hbm_bytes_per_launch"] = int(2.0 * fetch + write)
+            e["note"] = "2 x FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE counts wide reads at half)"
+            entry.setdefault(k, {})["hbm_bytes_per_launch"] = e["hbm_bytes_per_launch"]
+        counters[k] = e
+    if counters:
+        json.dump(counters, open(os.path.join(dst, f"{wl}_pmc_counters.json"), "w"), indent=1)
+    for k in entry:
+        entry[k]["source"] = f"profiles/{tag}/{wl}_kernel_stats.csv" + (f" + {wl}_pmc_counters.json" if k in counters else "")
+    if entry:
+        summary[wl] = entry
+json.dump(summary, open(summary_path, "w"), indent=1, sort_keys=True)
+print(json.dumps({w: summary.get(w) for w in workloads}, indent=1))

@@ -10,10 +10,10 @@ A "step" is one frame of the hot path over device-resident columns with every Tr
 N = 1 (default workload `frame`) is BASELINE.json's metric as worded -- "entities/sec through propagate+cull+cluster at 1M
 entities" -- in ONE context on ONE stream: configs[1]'s 1 000 000 many_cubes entities plus configs[2]'s many_lights set
 (10 000 meshes + 100 000 point lights, which are rows like everything else), 1 camera:
-    mi_propagate_and_cull      sync_simple_transforms + reset_view_visibility + check_visibility_cpu_culling (meshes through
-                               their Aabb, lights through their bounding Sphere) + mark_newly_hidden + VisibleEntities lists
     mi_cluster_upload_view     this frame's camera (host constants; the view-space planes are cached on the device)
-    mi_cluster_assign_resident gather of the visible lights + assign_objects_to_clusters, 16x9x24 clusters
+    mi_propagate_and_cull      sync_simple_transforms + reset_view_visibility + check_visibility_cpu_culling (meshes through
+      (MI_CULL_WITH_CLUSTERS)  their Aabb, lights through their bounding Sphere) + mark_newly_hidden + VisibleEntities lists,
+                               then the gather of the visible lights + assign_objects_to_clusters on 16x9x24 clusters
 `value` counts the 1 000 000 entities of the metric's name only (the 110 000 rows of configs[2] are processed, not counted).
 
 N > 1 (default workload `sharded`) is configs[3]: 10 000 000 entities x 4 camera frusta, STRONG scaling -- the row range is
@@ -62,6 +62,10 @@ def parse():
     ap.add_argument("--inline-compaction", action="store_true",
                     help="launch the VisibleEntities compaction as its own kernel every frame (default: MI_CULL_MORE_FRAMES, the "
                          "compaction of frame f rides in frame f+1's launch)")
+    ap.add_argument("--separate-cluster-calls", action="store_true",
+                    help="frame: mi_propagate_and_cull, then mi_cluster_assign_resident behind it (default: ONE call with "
+                         "MI_CULL_WITH_CLUSTERS, the assignment concurrent with the frame kernel on the cluster stream)")
+    ap.add_argument("--concurrent-clusters", action="store_true", help="frame: add MI_CULL_CLUSTERS_CONCURRENT")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
@@ -120,11 +124,17 @@ def build_frame(ctx, args):
         keep.append(k)
     more = 0 if args.inline_compaction else B.CULL_MORE_FRAMES
 
+    separate = bool(getattr(args, "separate_cluster_calls", False))
+    concurrent = B.CULL_CLUSTERS_CONCURRENT if getattr(args, "concurrent_clusters", False) else 0
+
     def step(f):
         i = f % N_FRAMES
-        ctx.propagate_and_cull(frames[i], flags=B.CULL_END_FRAME | more)
         ctx.cluster_upload_view(views[i])
-        ctx.cluster_assign_resident()
+        if separate:
+            ctx.propagate_and_cull(frames[i], flags=B.CULL_END_FRAME | more)
+            ctx.cluster_assign_resident()
+        else:
+            ctx.propagate_and_cull(frames[i], flags=B.CULL_END_FRAME | B.CULL_WITH_CLUSTERS | concurrent | more)
 
     config = {"workload": f"BASELINE.json metric, one frame in one context: {n_ent} many_cubes entities (configs[1]) + {args.meshes} meshes "
                           f"and {args.lights} point lights of the many_lights shape (configs[2]; range 0.3, shell R = 50; lights are rows with a "
@@ -132,7 +142,10 @@ def build_frame(ctx, args):
                           "(propagate + reset + frustum cull + mark-newly-hidden) + VisibleEntities compaction"
                           + (" (deferred into the next frame's launch)" if more else "")
                           + " + device-side gather of the visible lights + assign_objects_to_clusters on 16x9x24 clusters "
-                            "(ClusterConfig::XYZ, first slice 5.0, far Constant(1000))",
+                            "(ClusterConfig::XYZ, first slice 5.0, far Constant(1000))"
+                          + (" -- two calls" if separate else " -- ONE call (MI_CULL_WITH_CLUSTERS), the assignment enqueued behind the cull"
+                             if not concurrent else " -- ONE call (MI_CULL_WITH_CLUSTERS | MI_CULL_CLUSTERS_CONCURRENT): the assignment "
+                             "re-derives the lights' ViewVisibility with the cull's rule and runs on the cluster stream next to the frame kernel"),
               "baseline_config": "BASELINE.json configs[1] + configs[2] in one frame; value counts the entities of configs[1] only",
               "entities": n_ent, "rows_per_frame": n_rows, "lights": args.lights, "meshes": args.meshes, "views": 1,
               "deferred_compaction": bool(more), "parallelism": "1 GPU"}

@@ -40,6 +40,8 @@ VISIBILITY_INHERITED, VISIBILITY_HIDDEN, VISIBILITY_VISIBLE, VISIBILITY_NONE = 0
 CULL_BEGIN_FRAME = 0x1
 CULL_END_FRAME = 0x2
 CULL_MORE_FRAMES = 0x4  # another cull frame follows at once: defer the compaction into its launch (MI_CULL_MORE_FRAMES)
+CULL_WITH_CLUSTERS = 0x8  # the frame also assigns the row-bound lights to clusters (MI_CULL_WITH_CLUSTERS)
+CULL_CLUSTERS_CONCURRENT = 0x10  # ... on the cluster stream, next to the frame kernel (MI_CULL_CLUSTERS_CONCURRENT)
 PROPAGATE_ALL_DIRTY = 0x1
 PROPAGATE_STATIC_OPT = 0x2
 NO_PARENT = 0xFFFFFFFF

@@ -51,7 +51,9 @@ int32_t stage_alloc(mi_ctx* ctx, size_t bytes, void** out) {
     bytes = (bytes + 255) & ~(size_t)255;
     if (ctx->stage_used + bytes > ctx->stage_bytes) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // everything staged so far has been consumed
+        if (ctx->cl_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->cl_stream));
         ctx->stage_used = 0;
+        ++ctx->stage_epoch;
         if (bytes > ctx->stage_bytes) {
             if (ctx->stage) HIP_TRY(ctx, hipHostFree(ctx->stage));
             ctx->stage = nullptr;
@@ -68,8 +70,12 @@ int32_t stage_alloc(mi_ctx* ctx, size_t bytes, void** out) {
 int32_t upload(mi_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!bytes) return MI_OK;
     void* st = nullptr;
-    int32_t rc = stage_alloc(ctx, bytes, &st);
+    // the destination may be something an assignment on the cluster stream is still reading; and that stream has to see
+    // this write before its next launch
+    int32_t rc = cluster_join(ctx);
     if (rc) return rc;
+    ctx->cl_inputs_dirty = true;
+    if ((rc = stage_alloc(ctx, bytes, &st))) return rc;
     memcpy(st, src, bytes);
     HIP_TRY(ctx, hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, ctx->stream));
     return MI_OK;
@@ -371,6 +377,8 @@ static int32_t cull_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, u
     if (!views || n_views == 0) return fail(ctx, MI_ERR_INVALID_ARG, "mi_cull: views NULL or n_views == 0");
     if (PROPAGATE && ctx->have_hierarchy)
         return fail(ctx, MI_ERR_NOT_READY, "mi_propagate_and_cull is the flat fast path; a hierarchy is uploaded -- use mi_propagate + mi_cull");
+    if ((flags & MI_CULL_WITH_CLUSTERS) && (!ctx->cl_rows_bound || !ctx->cl_have_view))
+        return fail(ctx, MI_ERR_NOT_READY, "MI_CULL_WITH_CLUSTERS needs mi_cluster_bind_objects_to_rows and mi_cluster_upload_view first");
     VisibilityOut vo{};
     CompactFastArgs prev_args{};
     bool prev_has_job = false;
@@ -382,12 +390,37 @@ static int32_t cull_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, u
     SegOut seg;
     if ((rc = prepare_segments(ctx, n_views, &seg))) return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
     Columns c = columns_of(ctx);
+    // MI_CULL_WITH_CLUSTERS: the assignment runs behind the frame kernel and reads the ViewVisibility column -- or, with
+    // MI_CULL_CLUSTERS_CONCURRENT on a call that decides the frame's ViewVisibility alone, re-derives it and runs on the cluster
+    // stream next to the frame kernel
+    const bool with_clusters = (flags & MI_CULL_WITH_CLUSTERS) != 0;
+    const bool whole_frame = (flags & MI_CULL_END_FRAME) && (PROPAGATE || (flags & MI_CULL_BEGIN_FRAME));
+    const bool derivable = with_clusters && whole_frame && ctx->views_inline && !ctx->have_hierarchy && ctx->n;
+    const bool clusters_concurrent = derivable && (flags & MI_CULL_CLUSTERS_CONCURRENT);
+    if (clusters_concurrent && (rc = cluster_assign_launch(ctx, true, nullptr))) return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
+    bool clusters_ride = false;
     {
+        // a deferred cluster fill of the previous frame rides along (it must be enqueued before this frame's walk anyway) ...
+        ClusterFillJob fill_job{};
+        const bool have_fill = ctx->cl_fill_pending && ctx->n;
+        if (have_fill) {
+            fill_job = ctx->cl_fill_job;
+            ctx->cl_fill_pending = false;
+        }
+        // ... and so does THIS frame's walk when the call decides the frame's ViewVisibility alone: the walk re-derives the
+        // lights' visibility with the cull's rule, so it needs nothing the rest of the launch produces
+        ClusterWalkJob walk_job{};
+        if (derivable && !clusters_concurrent && (rc = cluster_ride_prepare(ctx, &walk_job, &clusters_ride))) {
+            if (have_fill) launch_cluster_fill(fill_job.w, fill_job.n_clusters, fill_job.n_objects, ctx->stream);
+            return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
+        }
         ProfScope ps(ctx, PROPAGATE ? K_FLAT_PROPAGATE_CULL : K_CULL);
         const hipError_t e = PROPAGATE ? launch_flat_propagate_cull(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p,
-                                                                    n_views, vo, seg, flags & MI_CULL_END_FRAME, prev, ctx->stream)
+                                                                    n_views, vo, seg, flags & MI_CULL_END_FRAME, prev, have_fill ? &fill_job : nullptr,
+                                                                    clusters_ride ? &walk_job : nullptr, ctx->stream)
                                        : launch_cull(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p, n_views, vo,
-                                                     seg, flags & (MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME), prev, ctx->stream);
+                                                     seg, flags & (MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME), prev, have_fill ? &fill_job : nullptr,
+                                                     clusters_ride ? &walk_job : nullptr, ctx->stream);
         if (e != hipSuccess) {
             fail(ctx, MI_ERR_DEVICE, "frame kernel launch: %s", hipGetErrorString(e));
             return frame_abort(ctx, MI_ERR_DEVICE, prev, prev_has_job, prev_job);
@@ -396,6 +429,8 @@ static int32_t cull_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, u
     if (prev && ctx->n == 0) HIP_TRY(ctx, launch_compact_fast(*prev, ctx->stream));  // no frame kernel to ride in
     if (prev_has_job) exchange_push(ctx, prev_job);  // the launch that publishes the previous frame's signal is submitted
     if ((rc = run_compaction(ctx, vo, seg, flags))) return rc;
+    if (with_clusters && !clusters_concurrent && !clusters_ride && (rc = cluster_assign_launch(ctx, false, nullptr, (flags & MI_CULL_MORE_FRAMES) != 0))) return rc;
+    if (clusters_ride && !(flags & MI_CULL_MORE_FRAMES) && (rc = cluster_fill_join(ctx))) return rc;  // nobody promised a frame to carry the fill
     if (PROPAGATE) {
         if (ctx->have_changed && ctx->changed_maybe) {
             HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, ctx->n, ctx->stream));
@@ -466,6 +501,12 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
     hipSetDevice(ctx->device);
     compaction_join(ctx);
     hipStreamSynchronize(ctx->stream);
+    if (ctx->cl_stream) {
+        hipStreamSynchronize(ctx->cl_stream);
+        hipEventDestroy(ctx->ev_cl_done);
+        hipEventDestroy(ctx->ev_cl_inputs);
+        hipStreamDestroy(ctx->cl_stream);
+    }
     prof_collect(ctx);
     void* cols[] = {ctx->t, ctx->r, ctx->s, ctx->g, ctx->c, ctx->h, ctx->flags, ctx->vv, ctx->changed, ctx->g_changed_bytes,
                     ctx->layers, ctx->class_mask, ctx->keys, ctx->g_chg_bits, ctx->vv_chg_bits, ctx->tree_bits,
@@ -521,8 +562,11 @@ int32_t mi_synchronize(mi_ctx* ctx) {
     {
         int32_t rcj = compaction_join(ctx);
         if (rcj) return rcj;
+        if ((rcj = cluster_fill_join(ctx))) return rcj;
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->cl_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->cl_stream));
+    ctx->cl_on_side = false;
     if (ctx->xch.on) {
         int32_t rc = exchange_wait_issued(ctx, ctx->xch.frame);
         if (rc) return rc;
@@ -540,6 +584,11 @@ int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
     {
         int32_t rcj = compaction_join(ctx);  // buffers may move
         if (rcj) return rcj;
+    }
+    {
+        int32_t rcj = cluster_join(ctx);  // columns may move under an assignment that reads them
+        if (rcj) return rcj;
+        ctx->cl_inputs_dirty = true;
     }
     ctx->bt_resolve = true;
     ctx->changed_maybe = true;
@@ -642,6 +691,8 @@ int32_t mi_upload_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t n, const 
         memcpy(f + 7 * (size_t)n, scale, (size_t)n * 12);
         void* dev = nullptr;
         HIP_TRY(ctx, hipHostGetDevicePointer(&dev, st, 0));
+        if ((rc = cluster_join(ctx))) return rc;
+        ctx->cl_inputs_dirty = true;
         HIP_TRY(ctx, launch_upload_trs((const float*)dev, ctx->t, ctx->r, ctx->s, first_row, n, ctx->stream));
         return MI_OK;
     }
@@ -676,6 +727,8 @@ int32_t mi_upload_transforms_indexed(mi_ctx* ctx, uint32_t n, const uint32_t* ro
             HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, std::min(ctx->propagated_rows, ctx->n), ctx->stream));
         ctx->have_changed = true;
     }
+    if ((rc = cluster_join(ctx))) return rc;
+    ctx->cl_inputs_dirty = true;
     HIP_TRY(ctx, launch_upload_trs_indexed((const uint32_t*)dev, n, ctx->t, ctx->r, ctx->s, ctx->changed, ctx->stream));
     ctx->changed_maybe = true;
     return MI_OK;

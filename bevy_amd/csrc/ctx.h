@@ -64,6 +64,7 @@ struct mi_ctx {
     // ---- staging ----
     void* stage = nullptr;
     size_t stage_bytes = 0, stage_used = 0;
+    uint64_t stage_epoch = 0;  // bumped whenever the arena wraps or moves: pointers into it from before are stale
 
     // ---- hierarchy ----
     uint32_t n_levels = 1;
@@ -173,13 +174,28 @@ struct mi_ctx {
     uint32_t bt_n_sets = 0, bt_n_meta = 0;
     bool bt_have_rows = false, bt_have_sets = false, bt_built = false;
     DevBuf cl_remap, cl_bind_oc, cl_bind_idx, cl_block_counts, cl_pair_cb, cl_pair_mask, cl_acc, cl_offsets, cl_indices, cl_scalars;
-    uint32_t cl_parity = 0, cl_acc_clusters = 0, cl_acc_blocks = 0;  // cl_acc = 2 x [counts 6C | totals C | farthest_z + pad]
+    uint32_t cl_parity = 0, cl_acc_clusters = 0, cl_acc_blocks = 0;  // cl_parity: the current working set; cl_acc = 3 x [counts 6C | totals C | farthest_z + pad]
     uint32_t cl_n = 0;
     bool cl_have_type = false, cl_have_layers = false, cl_have_spot = false, cl_have_spot_dir = false, cl_any_spot = false;
     bool cl_rows_bound = false;      // mi_cluster_bind_objects_to_rows: object i is row cl_first_row + i
     uint32_t cl_first_row = 0;
     std::vector<float> cl_host_planes, cl_host_spheres;  // storage of the view mi_cluster_assign_frame builds
-    std::vector<float> cl_planes_sent, cl_spheres_sent;  // what the device copies currently hold (re-sent only when they change)
+    // The view's cluster planes are read by the kernels straight from the pinned staging arena (mapped host memory): the z
+    // planes follow the camera's scale by an ulp from frame to frame, and a device copy would put an H2D blit (~6 us) in front
+    // of every frame.  cl_planes_host is the current table, cl_planes_epoch the arena epoch its staged copy belongs to.
+    std::vector<float> cl_planes_host, cl_spheres_sent;
+    uint64_t cl_planes_epoch = ~0ull;
+    uint32_t cl_plane_counts[3] = {0, 0, 0};
+    // The cluster kernels of a MI_CULL_WITH_CLUSTERS frame run on a stream of their own, concurrently with the frame kernel.
+    hipStream_t cl_stream = nullptr;
+    hipEvent_t ev_cl_done = nullptr, ev_cl_inputs = nullptr;
+    bool cl_on_side = false;         // an assignment is (possibly) still running on cl_stream: join before touching its inputs / outputs
+    bool cl_inputs_dirty = true;     // the main stream has written something the cluster kernels read since they last waited for it
+    // The fill of a MI_CULL_WITH_CLUSTERS | MI_CULL_MORE_FRAMES frame is deferred like the VisibleEntities compaction: it rides in
+    // extra workgroups of the next frame's kernel, or cluster_fill_join launches it on its own at the first entry point that
+    // needs the lists.
+    bool cl_fill_pending = false;
+    mi::ClusterFillJob cl_fill_job{};
     mi::ClusterViewDev cl_view{};
     bool cl_have_view = false, cl_assigned = false;
 
@@ -289,6 +305,11 @@ int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg, 
 // ride in this frame's launch); returns whether there is one
 bool frame_begin(mi_ctx* ctx, mi::CompactFastArgs* prev, bool* prev_has_job, mi_ctx::Exchange::Job* prev_job);
 int32_t compaction_join(mi_ctx* ctx);   // enqueues a deferred compaction now: the lists are complete in stream order afterwards
+// ctx_cluster.cpp
+int32_t cluster_join(mi_ctx* ctx);      // orders the main stream behind an assignment running on the cluster stream
+int32_t cluster_assign_launch(mi_ctx* ctx, bool concurrent_with_frame, uint64_t* out_total, bool defer_fill = false);
+int32_t cluster_fill_join(mi_ctx* ctx);  // enqueues a deferred fill now
+int32_t cluster_ride_prepare(mi_ctx* ctx, mi::ClusterWalkJob* job, bool* can_ride);
 // ctx_exchange.cpp
 int32_t pick_side_streams(mi_ctx* ctx, hipStream_t* out, uint32_t n_keep, bool* out_shares_queue);
 int32_t exchange_begin(mi_ctx* ctx);

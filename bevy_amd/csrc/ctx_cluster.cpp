@@ -21,6 +21,7 @@ int32_t mi_cluster_upload_objects(mi_ctx* ctx, uint32_t n, const float* pos_rang
         }
     if (any_spot && !spot_sin_cos) return fail(ctx, MI_ERR_INVALID_ARG, "spot lights need spot_sin_cos");
     int32_t rc;
+    if ((rc = cluster_join(ctx))) return rc;
     if ((rc = ensure(ctx, ctx->cl_pos, (size_t)n * 16))) return rc;
     if ((rc = upload(ctx, ctx->cl_pos.p, pos_range, (size_t)n * 16))) return rc;
     ctx->cl_have_type = obj_type != nullptr;
@@ -73,22 +74,17 @@ int32_t mi_cluster_upload_view(mi_ctx* ctx, const mi_cluster_view* view) {
     if (C == 0 || C > 4096) return fail(ctx, MI_ERR_INVALID_ARG, "cluster count %llu outside 1..4096 (assign.rs:410-413)", (unsigned long long)C);
     const uint32_t nx = view->dims[0] + 1, ny = view->dims[1] + 1, nz = view->dims[2] + 1;
     int32_t rc;
-    const void* planes_before = ctx->cl_planes.p;
-    if ((rc = ensure(ctx, ctx->cl_planes, (size_t)(nx + ny + nz) * 16))) return rc;
-    if (ctx->cl_planes.p != planes_before) ctx->cl_planes_sent.clear();  // a new buffer holds nothing yet
-    float* base = (float*)ctx->cl_planes.p;
-    // The cluster planes live in VIEW space: they depend on the projection, the grid and near / far, not on where the
-    // camera is -- a moving camera re-sends only the matrices and the frustum, which travel in the kernarg segment.
-    {
-        std::vector<float> planes((size_t)(nx + ny + nz) * 4);
-        memcpy(planes.data(), view->x_planes, (size_t)nx * 16);
-        memcpy(planes.data() + 4 * (size_t)nx, view->y_planes, (size_t)ny * 16);
-        memcpy(planes.data() + 4 * (size_t)(nx + ny), view->z_planes, (size_t)nz * 16);
-        if (planes.size() != ctx->cl_planes_sent.size() || memcmp(planes.data(), ctx->cl_planes_sent.data(), planes.size() * 4) != 0) {
-            if ((rc = upload(ctx, base, planes.data(), planes.size() * 4))) return rc;
-            ctx->cl_planes_sent.swap(planes);
-        }
-    }
+    // The cluster planes live in VIEW space: they depend on the projection, the grid and near / far -- but near follows the
+    // camera's scale (assign.rs:345,366), which moves by an ulp as the camera turns, so the table is new nearly every frame.
+    // It is staged in pinned memory and read from there (see ctx.h); stage_cluster_planes re-stages it when the arena wraps.
+    ctx->cl_planes_host.resize((size_t)(nx + ny + nz) * 4);
+    memcpy(ctx->cl_planes_host.data(), view->x_planes, (size_t)nx * 16);
+    memcpy(ctx->cl_planes_host.data() + 4 * (size_t)nx, view->y_planes, (size_t)ny * 16);
+    memcpy(ctx->cl_planes_host.data() + 4 * (size_t)(nx + ny), view->z_planes, (size_t)nz * 16);
+    ctx->cl_plane_counts[0] = nx;
+    ctx->cl_plane_counts[1] = ny;
+    ctx->cl_plane_counts[2] = nz;
+    ctx->cl_planes_epoch = ~0ull;
     ClusterViewDev& d = ctx->cl_view;
     memcpy(d.dims, view->dims, sizeof d.dims);
     d.is_orthographic = view->is_orthographic;
@@ -100,9 +96,7 @@ int32_t mi_cluster_upload_view(mi_ctx* ctx, const mi_cluster_view* view) {
     memcpy(d.view_from_world_scale, view->view_from_world_scale, sizeof d.view_from_world_scale);
     d.view_from_world_scale_max = view->view_from_world_scale_max;
     memcpy(d.frustum, view->frustum, sizeof d.frustum);
-    d.x_planes = base;
-    d.y_planes = base + 4 * (size_t)nx;
-    d.z_planes = base + 4 * (size_t)(nx + ny);
+    d.x_planes = d.y_planes = d.z_planes = nullptr;  // staged at launch time
     d.cluster_spheres = nullptr;
     if (view->cluster_spheres) {  // view space as well (compute_aabb_for_cluster, assign.rs:834-900)
         const void* spheres_before = ctx->cl_spheres.p;
@@ -119,13 +113,71 @@ int32_t mi_cluster_upload_view(mi_ctx* ctx, const mi_cluster_view* view) {
     return MI_OK;
 }
 
-int32_t mi_cluster_assign_resident(mi_ctx* ctx, uint64_t* out_total) {
-    ENTER(ctx);
+}  // extern "C"
+
+namespace mi_detail {
+
+// Everything on the main stream that touches what the cluster kernels read or write goes through here first.
+int32_t cluster_fill_join(mi_ctx* ctx) {
+    if (!ctx->cl_fill_pending) return MI_OK;
+    ctx->cl_fill_pending = false;
+    ProfScope ps(ctx, K_CLUSTER_FILL);
+    HIP_TRY(ctx, launch_cluster_fill(ctx->cl_fill_job.w, ctx->cl_fill_job.n_clusters, ctx->cl_fill_job.n_objects, ctx->stream));
+    return MI_OK;
+}
+
+int32_t cluster_join(mi_ctx* ctx) {
+    {
+        int32_t rcf = cluster_fill_join(ctx);
+        if (rcf) return rcf;
+    }
+    if (!ctx->cl_on_side) return MI_OK;
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_cl_done, 0));
+    ctx->cl_on_side = false;
+    return MI_OK;
+}
+
+// ---- one assignment = a walk and a fill over one SET of working buffers ---------------------------------------------------
+// Three sets rotate (accumulators, count matrix, pair list): assignment k walks into set k % 3 and its fill zeroes set
+// (k + 2) % 3 for assignment k + 2.  Two would do while walk and fill run one behind the other; the third lets the fill of
+// assignment k share a launch with the walk of assignment k + 1 (both ride in the same frame kernel).
+namespace {
+constexpr uint32_t CL_SETS = 3;
+
+struct ClusterPrep {
+    ClusterObjects o{};
+    ClusterWork w{};
+    uint32_t C = 0;
+    size_t acc_words = 0, off_totals = 0, off_misc = 0, mat_bytes = 0, pair_slots = 0;
+};
+
+// the view's plane table in the staging arena (again, if the arena has wrapped since)
+int32_t stage_cluster_planes(mi_ctx* ctx) {
+    if (ctx->cl_planes_epoch == ctx->stage_epoch && ctx->cl_view.x_planes) return MI_OK;
+    void* st = nullptr;
+    int32_t rc = stage_alloc(ctx, ctx->cl_planes_host.size() * 4, &st);
+    if (rc) return rc;
+    memcpy(st, ctx->cl_planes_host.data(), ctx->cl_planes_host.size() * 4);
+    void* dev = nullptr;
+    HIP_TRY(ctx, hipHostGetDevicePointer(&dev, st, 0));
+    ClusterViewDev& d = ctx->cl_view;
+    d.x_planes = (const float*)dev;
+    d.y_planes = d.x_planes + 4 * (size_t)ctx->cl_plane_counts[0];
+    d.z_planes = d.y_planes + 4 * (size_t)ctx->cl_plane_counts[1];
+    ctx->cl_planes_epoch = ctx->stage_epoch;
+    return MI_OK;
+}
+
+int32_t cluster_objects(mi_ctx* ctx, bool derive, ClusterObjects* po) {
     if (!ctx->cl_have_view) return fail(ctx, MI_ERR_NOT_READY, "mi_cluster_assign_resident: no view uploaded");
+    {
+        int32_t rcs = stage_cluster_planes(ctx);
+        if (rcs) return rcs;
+    }
     if (ctx->cl_any_spot && !ctx->cl_view.cluster_spheres)
         return fail(ctx, MI_ERR_INVALID_ARG, "spot lights present but mi_cluster_view.cluster_spheres is NULL");
-    const uint32_t C = ctx->cl_view.n_clusters;
-    ClusterObjects o{};
+    ClusterObjects& o = *po;
+    o = ClusterObjects{};
     o.n = ctx->cl_n;
     o.pos_range = (const float*)ctx->cl_pos.p;
     o.obj_type = ctx->cl_have_type ? (const uint8_t*)ctx->cl_type.p : nullptr;
@@ -138,51 +190,137 @@ int32_t mi_cluster_assign_resident(mi_ctx* ctx, uint64_t* out_total) {
         if ((uint64_t)ctx->cl_first_row + o.n > ctx->n)
             return fail(ctx, MI_ERR_NOT_READY, "cluster objects are bound to rows [%u,%u) but the context has %u rows", ctx->cl_first_row,
                         ctx->cl_first_row + o.n, ctx->n);
-        o.row_global = ctx->g;
-        o.row_vv = ctx->vv;
         o.first_row = ctx->cl_first_row;
+        if (derive) {
+            o.derive = 1;
+            o.n_views = ctx->n_views;
+            o.row_translation = ctx->t;
+            o.row_rotation = ctx->r;
+            o.row_scale = ctx->s;
+            o.row_aabb_center = ctx->c;
+            o.row_aabb_half = ctx->h;
+            o.row_range = ctx->have_ranges ? ctx->range : nullptr;
+            o.row_flags = ctx->flags;
+            o.row_layers = ctx->layers;
+        } else {
+            o.row_global = ctx->g;
+            o.row_vv = ctx->vv;
+        }
     }
-    ClusterWork w{};
-    w.n_blocks = std::max(1u, (o.n + CLUSTER_BLOCK - 1) / CLUSTER_BLOCK);
-    int32_t rc;
-    const size_t off_totals = (6 * (size_t)C + 3) & ~(size_t)3, off_misc = off_totals + (((size_t)C + 3) & ~(size_t)3);
-    const size_t acc_words = off_misc + 4;  // per parity; 16-byte aligned sections: counts | totals | misc
+    return MI_OK;
+}
+
+// (re)allocates the working buffers for the current view / object count; `*fresh` = something was (re)allocated or zeroed on
+// the main stream (a side stream has to be ordered behind that)
+int32_t cluster_buffers(mi_ctx* ctx, ClusterPrep* p, bool* fresh) {
+    const uint32_t C = ctx->cl_view.n_clusters;
+    ClusterWork& w = p->w;
+    p->C = C;
+    w.n_blocks = std::max(1u, (p->o.n + CLUSTER_BLOCK - 1) / CLUSTER_BLOCK);
+    p->off_totals = (6 * (size_t)C + 3) & ~(size_t)3;
+    p->off_misc = p->off_totals + (((size_t)C + 3) & ~(size_t)3);
+    p->acc_words = p->off_misc + 4;  // per set; 16-byte aligned sections: counts | totals | misc
     w.row_stride = (w.n_blocks + 7u) & ~7u;
-    const size_t mat_bytes = (size_t)C * w.row_stride * 2;  // per parity
-    if ((rc = ensure(ctx, ctx->cl_pair_cb, (size_t)w.n_blocks * C * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->cl_pair_mask, (size_t)w.n_blocks * C * 32))) return rc;
+    p->mat_bytes = (size_t)C * w.row_stride * 2;  // per set
+    p->pair_slots = (size_t)w.n_blocks * C;       // per set
+    const bool reshape = !ctx->cl_acc.p || ctx->cl_acc_clusters != C || ctx->cl_acc_blocks != w.n_blocks;
+    const bool grow = ctx->cl_pair_cb.bytes < CL_SETS * p->pair_slots * 4 || ctx->cl_pair_mask.bytes < CL_SETS * p->pair_slots * 32 ||
+                      ctx->cl_offsets.bytes < ((size_t)C + 1) * 4 || !ctx->cl_scalars.p || !ctx->cl_indices.p;
+    *fresh = reshape || grow;
+    int32_t rc;
+    if (*fresh && (rc = cluster_join(ctx))) return rc;  // nothing may still be using what is about to move
+    if ((rc = ensure(ctx, ctx->cl_pair_cb, CL_SETS * p->pair_slots * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->cl_pair_mask, CL_SETS * p->pair_slots * 32))) return rc;
     if ((rc = ensure(ctx, ctx->cl_offsets, ((size_t)C + 1) * 4))) return rc;
     if ((rc = ensure(ctx, ctx->cl_scalars, 16))) return rc;
-    if (!ctx->cl_acc.p || ctx->cl_acc_clusters != C || ctx->cl_acc_blocks != w.n_blocks) {
-        // (re)shaped accumulators / count matrix start zeroed in both parities; afterwards the fill kernel keeps
-        // the idle parity zeroed
-        if ((rc = ensure(ctx, ctx->cl_acc, 2 * acc_words * 4))) return rc;
-        if ((rc = ensure(ctx, ctx->cl_block_counts, 2 * mat_bytes))) return rc;
-        HIP_TRY(ctx, hipMemsetAsync(ctx->cl_acc.p, 0, 2 * acc_words * 4, ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->cl_block_counts.p, 0, 2 * mat_bytes, ctx->stream));
+    if (reshape) {
+        // (re)shaped accumulators / count matrices start zeroed in every set; afterwards each fill keeps the set two ahead zeroed
+        if ((rc = ensure(ctx, ctx->cl_acc, CL_SETS * p->acc_words * 4))) return rc;
+        if ((rc = ensure(ctx, ctx->cl_block_counts, CL_SETS * p->mat_bytes))) return rc;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->cl_acc.p, 0, CL_SETS * p->acc_words * 4, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->cl_block_counts.p, 0, CL_SETS * p->mat_bytes, ctx->stream));
         ctx->cl_acc_clusters = C;
         ctx->cl_acc_blocks = w.n_blocks;
     }
     if (!ctx->cl_indices.p && (rc = ensure(ctx, ctx->cl_indices, (size_t)1 << 20))) return rc;
+    return MI_OK;
+}
+
+// the next set becomes current
+void cluster_next_set(mi_ctx* ctx, ClusterPrep* p) {
+    ctx->cl_parity = (ctx->cl_parity + 1u) % CL_SETS;
+    const uint32_t cur = ctx->cl_parity, zero = (cur + 2u) % CL_SETS;
+    ClusterWork& w = p->w;
+    uint32_t* acc = (uint32_t*)ctx->cl_acc.p + cur * p->acc_words;
+    w.block_counts = (uint16_t*)((char*)ctx->cl_block_counts.p + cur * p->mat_bytes);
+    w.block_counts_next = (uint16_t*)((char*)ctx->cl_block_counts.p + zero * p->mat_bytes);
+    w.counts = acc;
+    w.totals = acc + p->off_totals;
+    w.farthest_z = (float*)(acc + p->off_misc);
+    w.pair_total = acc + p->off_misc + 1;
+    w.acc_words = (uint32_t)p->acc_words;
+    w.acc_next = (uint32_t*)ctx->cl_acc.p + zero * p->acc_words;
+    w.pair_cb = (uint32_t*)ctx->cl_pair_cb.p + cur * p->pair_slots;
+    w.pair_mask = (uint32_t*)ctx->cl_pair_mask.p + cur * p->pair_slots * 8;
+    w.offsets = (uint32_t*)ctx->cl_offsets.p;
+    w.indices = (uint32_t*)ctx->cl_indices.p;
+    w.capacity = ctx->cl_indices.bytes / 4;
+    w.total = (uint64_t*)ctx->cl_scalars.p;
+}
+}  // namespace
+
+// One assignment of the resident objects to the uploaded view.  concurrent: launched on the cluster stream next to the frame
+// kernel of the same frame; row-bound objects then re-derive their ViewVisibility from the frame's views (ctx->view_set)
+// instead of reading the column that kernel is writing.  defer_fill: the fill is left for the next frame's kernel to carry.
+int32_t cluster_assign_launch(mi_ctx* ctx, bool concurrent, uint64_t* out_total, bool defer_fill) {
+    ClusterPrep p;
+    int32_t rc = cluster_objects(ctx, concurrent, &p.o);
+    if (rc) return rc;
+    hipStream_t stream = ctx->stream;
+    if (concurrent) {
+        if (!ctx->cl_stream) {
+            // HIP maps streams onto a small pool of hardware queues; a cluster stream that lands on the main stream's queue
+            // would simply run behind the frame kernel.  pick_side_streams (ctx_exchange.cpp) probes candidates and returns
+            // one that does not share it.
+            bool shares = false;
+            int32_t rcp = pick_side_streams(ctx, &ctx->cl_stream, 1, &shares);
+            if (rcp) return rcp;
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_cl_done, hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_cl_inputs, hipEventDisableTiming));
+        }
+        stream = ctx->cl_stream;
+        if (ctx->cl_fill_pending) {  // a fill still waiting for a frame to ride in goes out on the main stream first
+            if ((rc = cluster_fill_join(ctx))) return rc;
+            ctx->cl_inputs_dirty = true;
+        }
+    } else {
+        if ((rc = cluster_join(ctx))) return rc;  // behind whatever the cluster stream still runs (shared outputs)
+        ctx->cl_inputs_dirty = true;               // ... and the cluster stream behind this, next time
+    }
+    bool fresh = false;
+    if ((rc = cluster_buffers(ctx, &p, &fresh))) return rc;
+    if (concurrent && (fresh || ctx->cl_inputs_dirty)) {  // uploads / allocations / earlier main-stream cluster work
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_cl_inputs, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->cl_stream, ctx->ev_cl_inputs, 0));
+        ctx->cl_inputs_dirty = false;
+    }
     for (int attempt = 0; attempt < 2; ++attempt) {
-        ctx->cl_parity ^= 1u;
-        const uint32_t par = ctx->cl_parity;
-        uint32_t* acc = (uint32_t*)ctx->cl_acc.p + par * acc_words;
-        w.block_counts = (uint16_t*)((char*)ctx->cl_block_counts.p + par * mat_bytes);
-        w.block_counts_next = (uint16_t*)((char*)ctx->cl_block_counts.p + (par ^ 1u) * mat_bytes);
-        w.counts = acc;
-        w.totals = acc + off_totals;
-        w.farthest_z = (float*)(acc + off_misc);
-        w.pair_total = acc + off_misc + 1;
-        w.acc_words = (uint32_t)acc_words;
-        w.acc_next = (uint32_t*)ctx->cl_acc.p + (par ^ 1u) * acc_words;
-        w.pair_cb = (uint32_t*)ctx->cl_pair_cb.p;
-        w.pair_mask = (uint32_t*)ctx->cl_pair_mask.p;
-        w.offsets = (uint32_t*)ctx->cl_offsets.p;
-        w.indices = (uint32_t*)ctx->cl_indices.p;
-        w.capacity = ctx->cl_indices.bytes / 4;
-        w.total = (uint64_t*)ctx->cl_scalars.p;
-        HIP_TRY(ctx, launch_cluster_assign(ctx->cl_view, o, w, ctx->stream, prof_mark, ctx));
+        cluster_next_set(ctx, &p);
+        const ClusterWork& w = p.w;
+        const bool defer = defer_fill && !concurrent && !out_total;
+        HIP_TRY(ctx, launch_cluster_assign(ctx->cl_view, p.o, w, concurrent ? &ctx->view_set : nullptr, concurrent, !defer, stream, prof_mark, ctx));
+        if (defer) {  // the fill rides in the next frame's kernel (or cluster_fill_join launches it)
+            ctx->cl_fill_job.w = w;
+            ctx->cl_fill_job.n_clusters = p.C;
+            ctx->cl_fill_job.n_objects = p.o.n;
+            ctx->cl_fill_pending = true;
+            break;
+        }
+        if (concurrent) {  // fire and forget: capacity is re-checked at download
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_cl_done, ctx->cl_stream));
+            ctx->cl_on_side = true;
+            break;
+        }
         if (!out_total && attempt == 0) break;  // fire and forget: capacity is re-checked at download
         uint64_t total = 0;
         if ((rc = download(ctx, &total, w.total, 8))) return rc;
@@ -195,10 +333,58 @@ int32_t mi_cluster_assign_resident(mi_ctx* ctx, uint64_t* out_total) {
     return MI_OK;
 }
 
+// The walk of this frame's assignment as a job for the frame kernel's own launch (MI_CULL_WITH_CLUSTERS on a call that decides
+// the frame's ViewVisibility alone): *job gets the view, the objects in derive mode, the set to walk into and the z chunk
+// that fits the frame kernel's LDS; the fill is left pending.  *can_ride = false (nothing changed) when the grid is too wide
+// for that LDS -- the caller then runs the assignment behind the frame kernel.  Call AFTER taking a pending fill for the
+// same launch: this one's replaces it.
+int32_t cluster_ride_prepare(mi_ctx* ctx, ClusterWalkJob* job, bool* can_ride) {
+    *can_ride = false;
+    if (!ctx->cl_have_view || !ctx->cl_rows_bound) return MI_OK;
+    const ClusterViewDev& v = ctx->cl_view;
+    const uint32_t dxy = v.dims[0] * v.dims[1], n_planes = v.dims[0] + v.dims[1] + v.dims[2] + 3u;
+    uint32_t zc = 0;
+    while (zc < v.dims[2] && cluster_walk_lds_bytes(dxy, zc + 1u, n_planes, true) <= FRAME_KERNEL_LDS_BYTES) ++zc;
+    if (zc == 0 || ctx->cl_any_spot) return MI_OK;  // (spot lights read the cluster-sphere table: left to the walk kernel of its own)
+    ClusterPrep p;
+    int32_t rc = cluster_objects(ctx, true, &p.o);
+    if (rc) return rc;
+    if ((rc = cluster_join(ctx))) return rc;
+    bool fresh = false;
+    if ((rc = cluster_buffers(ctx, &p, &fresh))) return rc;
+    cluster_next_set(ctx, &p);
+    job->view = v;
+    job->objs = p.o;
+    job->w = p.w;
+    job->zc = zc;
+    job->n_blocks = p.w.n_blocks;
+    ctx->cl_fill_job.w = p.w;
+    ctx->cl_fill_job.n_clusters = p.C;
+    ctx->cl_fill_job.n_objects = p.o.n;
+    ctx->cl_fill_pending = true;
+    ctx->cl_inputs_dirty = true;
+    ctx->cl_assigned = true;
+    *can_ride = true;
+    return MI_OK;
+}
+
+}  // namespace mi_detail
+
+extern "C" {
+
+int32_t mi_cluster_assign_resident(mi_ctx* ctx, uint64_t* out_total) {
+    ENTER(ctx);
+    return cluster_assign_launch(ctx, false, out_total);
+}
+
 int32_t mi_cluster_download(mi_ctx* ctx, uint32_t* out_offsets, uint32_t* out_indices, uint64_t capacity, uint32_t* out_counts,
                             uint64_t* out_total, float* out_farthest_z) {
     ENTER(ctx);
     if (!ctx->cl_assigned) return fail(ctx, MI_ERR_NOT_READY, "mi_cluster_download before mi_cluster_assign_resident");
+    {
+        int32_t rcj = cluster_join(ctx);
+        if (rcj) return rcj;
+    }
     const uint32_t C = ctx->cl_view.n_clusters;
     uint64_t total = 0;
     int32_t rc;
@@ -211,7 +397,7 @@ int32_t mi_cluster_download(mi_ctx* ctx, uint32_t* out_offsets, uint32_t* out_in
     }
     if (out_total) *out_total = total;
     const size_t off_totals = (6 * (size_t)C + 3) & ~(size_t)3, off_misc = off_totals + (((size_t)C + 3) & ~(size_t)3);
-    const uint32_t* acc = (const uint32_t*)ctx->cl_acc.p + ctx->cl_parity * (off_misc + 4);
+    const uint32_t* acc = (const uint32_t*)ctx->cl_acc.p + ctx->cl_parity * (off_misc + 4);  // the current set
     if (out_farthest_z && (rc = download(ctx, out_farthest_z, acc + off_misc, 4))) return rc;
     if (out_offsets && (rc = download(ctx, out_offsets, ctx->cl_offsets.p, ((size_t)C + 1) * 4))) return rc;
     if (out_counts && (rc = download(ctx, out_counts, acc, (size_t)C * 6 * 4))) return rc;
@@ -226,6 +412,10 @@ int32_t mi_cluster_download_bindings(mi_ctx* ctx, const uint32_t* remap, uint32_
                                      uint32_t* out_index_list, uint64_t capacity, uint64_t* out_total) {
     ENTER(ctx);
     if (!ctx->cl_assigned) return fail(ctx, MI_ERR_NOT_READY, "mi_cluster_download_bindings before mi_cluster_assign_resident");
+    {
+        int32_t rcj = cluster_join(ctx);
+        if (rcj) return rcj;
+    }
     const uint32_t C = ctx->cl_view.n_clusters;
     uint64_t total = 0;
     int32_t rc;
@@ -237,7 +427,7 @@ int32_t mi_cluster_download_bindings(mi_ctx* ctx, const uint32_t* remap, uint32_
     }
     if (out_total) *out_total = total;
     const size_t off_totals = (6 * (size_t)C + 3) & ~(size_t)3, off_misc = off_totals + (((size_t)C + 3) & ~(size_t)3);
-    const uint32_t* acc = (const uint32_t*)ctx->cl_acc.p + ctx->cl_parity * (off_misc + 4);
+    const uint32_t* acc = (const uint32_t*)ctx->cl_acc.p + ctx->cl_parity * (off_misc + 4);  // the current set
     if ((rc = ensure(ctx, ctx->cl_bind_oc, (size_t)C * 32))) return rc;
     if ((rc = ensure(ctx, ctx->cl_bind_idx, std::max<size_t>(total, 1) * 4))) return rc;
     const uint32_t* d_remap = nullptr;

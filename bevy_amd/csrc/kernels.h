@@ -149,7 +149,8 @@ struct CompactFastArgs {
 };
 hipError_t launch_flat_propagate_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views,
                                       uint32_t n_views, const VisibilityOut& out, const SegOut& seg, uint32_t flags,
-                                      const CompactFastArgs* prev, hipStream_t stream);
+                                      const CompactFastArgs* prev, const struct ClusterFillJob* fill, const struct ClusterWalkJob* walk,
+                                      hipStream_t stream);
 // Level 0 of the hierarchy (roots + flat rows).  node_flags: bit0 = has children (nullptr = none do).
 // changed: per-row Changed<Transform>|... byte (nullptr or all_dirty => every row recomputed).
 // tree_bits: TransformTreeChanged bitset (only read when static_opt).
@@ -157,7 +158,8 @@ hipError_t launch_level0_propagate(const Columns& c, uint32_t n_level0, const ui
                                    const uint8_t* changed, const uint32_t* tree_bits, bool all_dirty,
                                    bool static_opt, hipStream_t stream);
 hipError_t launch_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views,
-                       const VisibilityOut& out, const SegOut& seg, uint32_t flags, const CompactFastArgs* prev, hipStream_t stream);
+                       const VisibilityOut& out, const SegOut& seg, uint32_t flags, const CompactFastArgs* prev,
+                       const struct ClusterFillJob* fill, const struct ClusterWalkJob* walk, hipStream_t stream);
 hipError_t launch_upload_trs(const float* pinned_src, float* t, float* r, float* s, uint32_t first_row, uint32_t n,
                              hipStream_t stream);
 hipError_t launch_upload_trs_indexed(const uint32_t* pinned_src, uint32_t n, float* t, float* r, float* s, uint8_t* changed,
@@ -260,12 +262,20 @@ struct ClusterObjects {
     const uint32_t* layer_mask;  // n or nullptr
     const float* spot_dir;       // 3n or nullptr
     const float* spot_sin_cos;   // 2n or nullptr
-    // mi_cluster_bind_objects_to_rows: object i is row first_row + i of the context's columns.  It takes part only if
-    // ViewVisibility::get() (bit0 of row_vv), its centre is the row's GlobalTransform translation and a spot light's
-    // direction the row's GlobalTransform::back() -- the gather of assign.rs:190-296 done on the device.
-    const float* row_global;     // 12 floats per row, or nullptr = objects are not rows
+    // mi_cluster_bind_objects_to_rows: object i is row first_row + i of the context's columns.  It takes part only if its
+    // ViewVisibility::get() is true -- the gather of assign.rs:190-296 done on the device -- its centre is the row's
+    // GlobalTransform translation and a spot light's direction the row's GlobalTransform::back().  Two ways to know:
+    //   row_vv != nullptr   read the byte the cull of this frame left (the assignment is ordered behind that cull);
+    //   derive != 0         re-derive it with the cull's own rule (visibility_rule.h) from the row's Transform, bounds, flags
+    //                       and the frame's views, so the assignment can run CONCURRENTLY with the frame kernel of the same
+    //                       frame on another stream.  Flat rows only (GlobalTransform == From(Transform)).
+    const float* row_global;     // 12 floats per row, or nullptr = objects are not rows (or derive)
     const uint8_t* row_vv;
     uint32_t first_row;
+    uint32_t derive, n_views;
+    const float *row_translation, *row_rotation, *row_scale, *row_aabb_center, *row_aabb_half, *row_range;
+    const uint8_t* row_flags;
+    const uint32_t* row_layers;
 };
 constexpr uint32_t CLUSTER_BLOCK = 256;  // objects per workgroup (= bits per cluster row in LDS)
 struct ClusterWork {
@@ -292,8 +302,30 @@ struct ClusterWork {
 hipError_t launch_cluster_bindings(uint32_t n_clusters, const uint32_t* offsets, const uint32_t* counts, const uint32_t* indices,
                                    const uint32_t* remap, uint32_t n_remap, uint64_t capacity, uint32_t* out_oc,
                                    uint32_t* out_idx, hipStream_t stream);
-hipError_t launch_cluster_assign(const ClusterViewDev& view, const ClusterObjects& objs, const ClusterWork& w,
-                                 hipStream_t stream, void (*mark)(void*, uint32_t), void* mark_ctx);
+// frame_views: the cull's views, read only when objs.derive (may be nullptr otherwise)
+hipError_t launch_cluster_assign(const ClusterViewDev& view, const ClusterObjects& objs, const ClusterWork& w, const ViewSet* frame_views,
+                                 bool small_lds, bool fill, hipStream_t stream, void (*mark)(void*, uint32_t), void* mark_ctx);
+// fill = false leaves the second kernel to the caller: launch_cluster_fill, or the frame kernel's extra workgroups (ClusterFillJob)
+hipError_t launch_cluster_fill(const ClusterWork& w, uint32_t n_clusters, uint32_t n_objects, hipStream_t stream);
+struct ClusterFillJob {
+    ClusterWork w;
+    uint32_t n_clusters, n_objects;
+};
+// The walk of this frame's assignment, riding in the frame kernel's own launch (n_blocks extra workgroups).
+struct ClusterWalkJob {
+    ClusterViewDev view;
+    ClusterObjects objs;   // derive mode: the lights' ViewVisibility is re-derived from the frame's views
+    ClusterWork w;
+    uint32_t zc;           // z slices per chunk: what fits the frame kernel's LDS
+    uint32_t n_blocks;     // 0 = no walk rides in this launch
+};
+// bytes of the LDS arena a walking workgroup needs for chunks of zc z slices (layout: cluster_walk.h)
+inline size_t cluster_walk_lds_bytes(uint32_t dxy, uint32_t zc, uint32_t n_planes, bool planes_in_lds) {
+    const size_t RC = (size_t)dxy * zc;
+    return (RC * 8u + 48u) * sizeof(uint32_t) + (planes_in_lds ? (size_t)n_planes * 16u : 0u) + ((RC + 31u) / 32u + 4u) * 4u + RC * 2u + 16u;
+}
+constexpr size_t FRAME_KERNEL_LDS_BYTES = (4096 + 4) * 4;  // k_frame's static LDS: the arena a riding walk / fill workgroup gets
+constexpr uint32_t CLUSTER_FILL_RIDE_BLOCKS = 256;  // workgroups a riding fill adds to the frame kernel's grid
 
 // ---------------------------------------------------------------------------------------------
 // Batching work-item build (kernels_batch.hip).

@@ -16,6 +16,9 @@
 
 #include "glam_math.h"
 #include "kernels.h"
+#include "visibility_rule.h"
+#include "cluster_fill.h"
+#include "cluster_walk.h"
 
 namespace mi {
 
@@ -46,74 +49,6 @@ __device__ __forceinline__ void st_affine(float* g, uint32_t row, const Affine& 
     p[0] = make_float4(a.m.x_axis.x, a.m.x_axis.y, a.m.x_axis.z, a.m.y_axis.x);
     p[1] = make_float4(a.m.y_axis.y, a.m.y_axis.z, a.m.z_axis.x, a.m.z_axis.y);
     p[2] = make_float4(a.m.z_axis.z, a.t.x, a.t.y, a.t.z);
-}
-
-// One row against one view.  The view's flags select which of the reference's per-entity closures applies:
-//   camera view        check_visibility_cpu_culling, crates/bevy_camera/src/visibility/mod.rs:788-858
-//   VIEW_SHADOW        check_dir_light_mesh_visibility (cascades, crates/bevy_light/src/lib.rs:425-475: OBB only,
-//                      near plane skipped, far plane tested) and check_point_light_mesh_visibility (cube faces
-//                      :592-650, spot :694-738: light-sphere pre-test, then all six planes)
-// Camera views: the sphere pre-test and the OBB test share the world-space centre and the plane dot products
-// (bit-identical values in the reference: both call transform_point3a on the same inputs, mod.rs:827 and
-// primitives.rs:279), so they are computed once; the far plane is never tested (mod.rs:831,835).
-// Visibility ranges (range.rs:159-161,255-263) are evaluated on the fly from the row's (start, end) pair and the
-// view's position instead of a per-(view, entity) table.
-__device__ __forceinline__ bool row_visible_in_view(const Affine& g, V3 center, V3 half, uint32_t fl,
-                                                    uint32_t entity_mask, bool have_ranges, float range_lo,
-                                                    float range_hi, const ViewParams& vp) {
-    const bool shadow = (vp.flags & VIEW_SHADOW) != 0;
-    bool vis = (fl & 0x01u) != 0;                          // InheritedVisibility
-    vis = vis && (!shadow || (fl & 0x80u));                // shadow views only see shadow casters
-    vis = vis && (vp.layer_mask & entity_mask) != 0;       // RenderLayers::intersects
-    const bool has_aabb = (fl & 0x04u) != 0;
-    if ((fl & 0x20u) && have_ranges) {                     // Has<VisibilityRange> && VisibleEntityRanges exists
-        bool in_range = false;
-        if ((vp.flags & (VIEW_RANGES | VIEW_RANGES_NO_ORIGIN)) == VIEW_RANGES) {
-            const V3 model = ((fl & 0x40u) && has_aabb) ? transform_point(g, center) : g.t;
-            const float d = length3(V3{vp.position[0], vp.position[1], vp.position[2]} - model);
-            in_range = d >= range_lo && d < range_hi;
-        }
-        vis = vis && in_range;
-    }
-    if (shadow) {
-        if (has_aabb && !(fl & 0x02u)) {
-            const V3 cw = transform_point(g, center);
-            bool inside = true;
-            if (vp.flags & VIEW_LIGHT_SPHERE)
-                inside = sphere_intersects_obb(V3{vp.light_sphere[0], vp.light_sphere[1], vp.light_sphere[2]},
-                                               vp.light_sphere[3], cw, half, g.m);
-            const V4 c4 = extend(cw, 1.0f);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                if ((i == 4 && (vp.flags & VIEW_SKIP_NEAR)) || (i == 5 && !(vp.flags & VIEW_TEST_FAR))) continue;
-                const V4 pl = V4{vp.planes[4 * i], vp.planes[4 * i + 1], vp.planes[4 * i + 2], vp.planes[4 * i + 3]};
-                const float rr = aabb_relative_radius(half, xyz(pl), g.m);
-                inside = inside && !(dot4(pl, c4) + rr <= 0.0f);
-            }
-            vis = vis && inside;
-        }
-        return vis;
-    }
-    const bool cull = !(fl & 0x02u) && !(vp.flags & VIEW_NO_CPU_CULLING);  // !NoFrustumCulling && !camera NoCpuCulling
-    if (cull && (fl & (0x04u | 0x08u))) {
-        // world-space sphere: Aabb -> (affine*center, |M3*half|) ; Sphere component used as is
-        const V3 cw = has_aabb ? transform_point(g, center) : center;
-        const float sr = has_aabb ? length3(mul(g.m, half)) : half.x;
-        const V4 c4 = extend(cw, 1.0f);
-        bool inside = true;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const V4 pl = V4{vp.planes[4 * i], vp.planes[4 * i + 1], vp.planes[4 * i + 2], vp.planes[4 * i + 3]};
-            const float d = dot4(pl, c4);
-            inside = inside && !(d + sr <= 0.0f);
-            if (has_aabb) {
-                const float rr = aabb_relative_radius(half, xyz(pl), g.m);
-                inside = inside && !(d + rr <= 0.0f);
-            }
-        }
-        vis = vis && inside;
-    }
-    return vis;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -232,19 +167,33 @@ __device__ __forceinline__ void compact_fast_block(const CompactFastArgs& a, uin
 // Algorithmic bytes per row, fused, V views: read 40 (T) + 24 (Aabb) + 1 (flags) + 4 (layers) + 1 (vv),
 // write 48 (G) + 1 (vv) + (V + 2 change masks) / 8 + V / 64 (wave counts).
 // ---------------------------------------------------------------------------------------------
-template <bool PROPAGATE, bool INLINE_VIEWS>
+// WITH_WALK: the launch may carry this frame's light-cluster walk.  A variant of its own because the walk needs more registers than
+// a row tile (93 against 66 VGPRs: 5 instead of 7 waves per SIMD for the whole launch); frames without a walk keep the lean one.
+template <bool PROPAGATE, bool INLINE_VIEWS, bool WITH_WALK>
 __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const ViewParams* __restrict__ dviews,
                                                 uint32_t n_views, VisibilityOut out, SegOut seg, uint32_t fl_frame, uint32_t n_tiles,
-                                                CompactFastArgs prev, uint32_t prev_gx) {
-    __shared__ float4 lds_g[4][192];
-    // extra workgroups: the deferred VisibleEntities compaction of the previous frame, at the head of the grid (they
-    // overlap the ramp-up instead of lengthening the tail: 0.5 us per frame at 1 M rows)
+                                                CompactFastArgs prev, uint32_t prev_gx, uint32_t n_compact, uint32_t n_fill, ClusterFillJob fill,
+                                                ClusterWalkJob walk) {
+    // 16 KB + 16 B: the four waves' GlobalTransform transpose buffers (12 KB) -- or, in a riding cluster-fill workgroup, the CSR
+    // offsets of up to 4096 clusters and the four wave totals of their scan -- or the arena of a riding cluster-walk workgroup
+    __shared__ __attribute__((aligned(16))) uint32_t lds_raw[4096 + 4];
+    float4 (*lds_g)[192] = reinterpret_cast<float4 (*)[192]>(lds_raw);
+    // extra workgroups at the head of the grid (they overlap the ramp-up instead of lengthening the tail: 0.5 us per frame at
+    // 1 M rows): the deferred VisibleEntities compaction of the previous frame, the deferred fill of the previous frame's
+    // light-cluster assignment, and the walk of THIS frame's
     const uint32_t n_extra = gridDim.x - n_tiles;
     if (blockIdx.x < n_extra) {
         const uint32_t id = blockIdx.x;
-        if (prev.signal && id == 0 && threadIdx.x == 0)  // multi-GPU exchange: the previous frame's masks are complete
-            __hip_atomic_store(prev.signal, prev.signal_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        compact_fast_block(prev, id % prev_gx, id / prev_gx, prev_gx);
+        if (id < n_compact) {
+            if (prev.signal && id == 0 && threadIdx.x == 0)  // multi-GPU exchange: the previous frame's masks are complete
+                __hip_atomic_store(prev.signal, prev.signal_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            compact_fast_block(prev, id % prev_gx, id / prev_gx, prev_gx);
+        } else if (id < n_compact + n_fill) {
+            cluster_fill_block(fill.w, fill.n_clusters, fill.n_objects, id - n_compact, n_fill, lds_raw, lds_raw + 4096);
+        } else if constexpr (WITH_WALK) {
+            // this frame's light-cluster walk: independent of the rows below (it re-derives the lights' ViewVisibility itself)
+            cluster_walk_block<true, true>(walk.view, walk.objs, walk.w, vs, walk.zc, id - n_compact - n_fill, lds_raw);
+        }
         return;
     }
     const uint32_t row = (blockIdx.x - n_extra) * 256u + threadIdx.x;
@@ -515,11 +464,12 @@ hipError_t launch_upload_trs(const float* pinned_src, float* t, float* r, float*
     return hipGetLastError();
 }
 
-// prev != nullptr: the previous frame's deferred compaction rides in the tail workgroups of this launch
+// prev != nullptr: the previous frame's deferred compaction rides in extra workgroups of this launch; fill != nullptr: so does the
+// fill of the previous frame's light-cluster assignment
 template <bool PROPAGATE>
 static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views,
                                const VisibilityOut& out, const SegOut& seg, uint32_t flags, const CompactFastArgs* prev,
-                               hipStream_t stream) {
+                               const ClusterFillJob* fill, const ClusterWalkJob* walk, hipStream_t stream) {
     if (c.n == 0) return hipSuccess;
     const uint32_t n_tiles = blocks_for(c.n);
     CompactFastArgs pa{};
@@ -529,24 +479,41 @@ static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, co
         prev_gx = (((pa.n + 63u) >> 6) + 63u) / 64u;
         prev_blocks = prev_gx * pa.n_segments;
     }
-    if (n_views <= MAX_INLINE_VIEWS && views_inline) {
-        MI_LAUNCH((k_frame<PROPAGATE, true>), dim3(n_tiles + prev_blocks), dim3(256), 0, stream, c, *views_inline,
-                  (const ViewParams*)nullptr, n_views, out, seg, flags, n_tiles, pa, prev_gx);
+    ClusterFillJob fj{};
+    uint32_t fill_blocks = 0;
+    if (fill) {
+        fj = *fill;
+        fill_blocks = CLUSTER_FILL_RIDE_BLOCKS;
+    }
+    ClusterWalkJob wj{};
+    uint32_t walk_blocks = 0;
+    if (walk && walk->n_blocks && n_views <= MAX_INLINE_VIEWS && views_inline) {  // the walk reads the views from the kernarg copy
+        wj = *walk;
+        walk_blocks = wj.n_blocks;
+    }
+    const dim3 grid(n_tiles + prev_blocks + fill_blocks + walk_blocks);
+    if (walk_blocks) {
+        MI_LAUNCH((k_frame<PROPAGATE, true, true>), grid, dim3(256), 0, stream, c, *views_inline, (const ViewParams*)nullptr, n_views, out, seg, flags,
+                  n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj);
+    } else if (n_views <= MAX_INLINE_VIEWS && views_inline) {
+        MI_LAUNCH((k_frame<PROPAGATE, true, false>), grid, dim3(256), 0, stream, c, *views_inline, (const ViewParams*)nullptr, n_views, out, seg, flags,
+                  n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj);
     } else {
         ViewSet dummy = {};
-        MI_LAUNCH((k_frame<PROPAGATE, false>), dim3(n_tiles + prev_blocks), dim3(256), 0, stream, c, dummy, d_views, n_views, out, seg,
-                  flags, n_tiles, pa, prev_gx);
+        MI_LAUNCH((k_frame<PROPAGATE, false, false>), grid, dim3(256), 0, stream, c, dummy, d_views, n_views, out, seg, flags, n_tiles, pa, prev_gx,
+                  prev_blocks, fill_blocks, fj, wj);
     }
     return hipGetLastError();
 }
 hipError_t launch_flat_propagate_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views,
                                       uint32_t n_views, const VisibilityOut& out, const SegOut& seg, uint32_t flags,
-                                      const CompactFastArgs* prev, hipStream_t stream) {
-    return launch_frame<true>(c, views_inline, d_views, n_views, out, seg, flags | CULL_BEGIN_FRAME, prev, stream);
+                                      const CompactFastArgs* prev, const ClusterFillJob* fill, const ClusterWalkJob* walk, hipStream_t stream) {
+    return launch_frame<true>(c, views_inline, d_views, n_views, out, seg, flags | CULL_BEGIN_FRAME, prev, fill, walk, stream);
 }
 hipError_t launch_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views,
-                       const VisibilityOut& out, const SegOut& seg, uint32_t flags, const CompactFastArgs* prev, hipStream_t stream) {
-    return launch_frame<false>(c, views_inline, d_views, n_views, out, seg, flags, prev, stream);
+                       const VisibilityOut& out, const SegOut& seg, uint32_t flags, const CompactFastArgs* prev,
+                       const ClusterFillJob* fill, const ClusterWalkJob* walk, hipStream_t stream) {
+    return launch_frame<false>(c, views_inline, d_views, n_views, out, seg, flags, prev, fill, walk, stream);
 }
 hipError_t launch_level0_propagate(const Columns& c, uint32_t n_level0, const uint8_t* node_flags,
                                    const uint8_t* changed, const uint32_t* tree_bits, bool all_dirty,

@@ -1,0 +1,79 @@
+// visibility_rule.h -- the per-entity visibility closure of the main-world visibility systems, shared by the frame kernel
+// (kernels_flat.hip) and by the light-cluster walk when it re-derives a light row's ViewVisibility itself instead of waiting
+// for the frame kernel of the same frame (kernels_cluster.hip): same function, same bits.
+#pragma once
+#include "glam_math.h"
+#include "kernels.h"
+
+namespace mi {
+
+// One row against one view.  The view's flags select which of the reference's per-entity closures applies:
+//   camera view        check_visibility_cpu_culling, crates/bevy_camera/src/visibility/mod.rs:788-858
+//   VIEW_SHADOW        check_dir_light_mesh_visibility (cascades, crates/bevy_light/src/lib.rs:425-475: OBB only,
+//                      near plane skipped, far plane tested) and check_point_light_mesh_visibility (cube faces
+//                      :592-650, spot :694-738: light-sphere pre-test, then all six planes)
+// Camera views: the sphere pre-test and the OBB test share the world-space centre and the plane dot products
+// (bit-identical values in the reference: both call transform_point3a on the same inputs, mod.rs:827 and
+// primitives.rs:279), so they are computed once; the far plane is never tested (mod.rs:831,835).
+// Visibility ranges (range.rs:159-161,255-263) are evaluated on the fly from the row's (start, end) pair and the
+// view's position instead of a per-(view, entity) table.
+__device__ __forceinline__ bool row_visible_in_view(const Affine& g, V3 center, V3 half, uint32_t fl,
+                                                    uint32_t entity_mask, bool have_ranges, float range_lo,
+                                                    float range_hi, const ViewParams& vp) {
+    const bool shadow = (vp.flags & VIEW_SHADOW) != 0;
+    bool vis = (fl & 0x01u) != 0;                          // InheritedVisibility
+    vis = vis && (!shadow || (fl & 0x80u));                // shadow views only see shadow casters
+    vis = vis && (vp.layer_mask & entity_mask) != 0;       // RenderLayers::intersects
+    const bool has_aabb = (fl & 0x04u) != 0;
+    if ((fl & 0x20u) && have_ranges) {                     // Has<VisibilityRange> && VisibleEntityRanges exists
+        bool in_range = false;
+        if ((vp.flags & (VIEW_RANGES | VIEW_RANGES_NO_ORIGIN)) == VIEW_RANGES) {
+            const V3 model = ((fl & 0x40u) && has_aabb) ? transform_point(g, center) : g.t;
+            const float d = length3(V3{vp.position[0], vp.position[1], vp.position[2]} - model);
+            in_range = d >= range_lo && d < range_hi;
+        }
+        vis = vis && in_range;
+    }
+    if (shadow) {
+        if (has_aabb && !(fl & 0x02u)) {
+            const V3 cw = transform_point(g, center);
+            bool inside = true;
+            if (vp.flags & VIEW_LIGHT_SPHERE)
+                inside = sphere_intersects_obb(V3{vp.light_sphere[0], vp.light_sphere[1], vp.light_sphere[2]},
+                                               vp.light_sphere[3], cw, half, g.m);
+            const V4 c4 = extend(cw, 1.0f);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                if ((i == 4 && (vp.flags & VIEW_SKIP_NEAR)) || (i == 5 && !(vp.flags & VIEW_TEST_FAR))) continue;
+                const V4 pl = V4{vp.planes[4 * i], vp.planes[4 * i + 1], vp.planes[4 * i + 2], vp.planes[4 * i + 3]};
+                const float rr = aabb_relative_radius(half, xyz(pl), g.m);
+                inside = inside && !(dot4(pl, c4) + rr <= 0.0f);
+            }
+            vis = vis && inside;
+        }
+        return vis;
+    }
+    const bool cull = !(fl & 0x02u) && !(vp.flags & VIEW_NO_CPU_CULLING);  // !NoFrustumCulling && !camera NoCpuCulling
+    if (cull && (fl & (0x04u | 0x08u))) {
+        // world-space sphere: Aabb -> (affine*center, |M3*half|) ; Sphere component used as is
+        const V3 cw = has_aabb ? transform_point(g, center) : center;
+        const float sr = has_aabb ? length3(mul(g.m, half)) : half.x;
+        const V4 c4 = extend(cw, 1.0f);
+        bool inside = true;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const V4 pl = V4{vp.planes[4 * i], vp.planes[4 * i + 1], vp.planes[4 * i + 2], vp.planes[4 * i + 3]};
+            const float d = dot4(pl, c4);
+            inside = inside && !(d + sr <= 0.0f);
+            if (has_aabb) {
+                const float rr = aabb_relative_radius(half, xyz(pl), g.m);
+                inside = inside && !(d + rr <= 0.0f);
+            }
+        }
+        vis = vis && inside;
+    }
+    return vis;
+}
+
+
+}  // namespace mi

@@ -94,6 +94,18 @@ extern "C" {
                                    * are unaffected.  With the multi-GPU exchange on, the frame's all-gather is issued together
                                    * with its compaction, i.e. one call later (mi_exchange_last joins first). */
 
+#define MI_CULL_WITH_CLUSTERS 0x8u /* the frame also assigns the row-bound lights (mi_cluster_bind_objects_to_rows) to the clusters of the
+                                   * view uploaded with mi_cluster_upload_view -- the whole metric frame, propagate + cull + cluster, in ONE
+                                   * call: the assignment is enqueued behind the cull and reads the ViewVisibility column as this call
+                                   * leaves it (NoCpuCulling rows get theirs when the frame is closed: pass MI_CULL_END_FRAME or call
+                                   * mi_visibility_end_frame first if there are any).  Same results as mi_cluster_assign_resident. */
+#define MI_CULL_CLUSTERS_CONCURRENT 0x10u /* with MI_CULL_WITH_CLUSTERS, on a call that decides the frame's ViewVisibility on its own
+                                   * (MI_CULL_BEGIN_FRAME and MI_CULL_END_FRAME both apply, <= 8 views, no hierarchy): the assignment does
+                                   * not wait for the frame kernel -- it re-derives each light's ViewVisibility::get() with the cull's own
+                                   * rule and runs on a second stream next to it.  Identical results.  Measured on MI355X it does NOT pay at
+                                   * 100 k lights (the two kernels of the assignment are latency-bound and stretch when they share the
+                                   * chip: 46.3 us per frame against 44.1 us one behind the other), so it is opt-in. */
+
 /* ---- mi_propagate flags ----------------------------------------------------------------- */
 #define MI_PROPAGATE_ALL_DIRTY 0x1u  /* every Transform counts as changed (worst case / first frame) */
 #define MI_PROPAGATE_STATIC_OPT 0x2u /* StaticTransformOptimizations::Enabled, systems.rs:87-103 */

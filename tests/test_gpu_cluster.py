@@ -103,11 +103,19 @@ def reference_sequence(sc, first_light, pr, frusta, cam, types=None, layers=None
     return off, keep[idx].astype(np.uint32), counts, far, total, visible, vv, g
 
 
+@pytest.mark.parametrize("mode", ["separate_calls", "with_clusters", "with_clusters_concurrent", "with_clusters_behind_the_cull"])
 @pytest.mark.parametrize("spots", [False, True])
-def test_lights_as_rows_of_the_frame_context(ctx_factory, spots):
-    """The whole metric frame in one context: rows = cubes + meshes + lights; mi_propagate_and_cull decides every row's
-    ViewVisibility (lights through their bounding Sphere), mi_cluster_assign_resident gathers the visible lights ON THE
-    DEVICE and assigns them.  Equal, list for list, to the reference's sequence restated with the oracle."""
+def test_lights_as_rows_of_the_frame_context(ctx_factory, spots, mode):
+    """The whole metric frame in one context: rows = cubes + meshes + lights; the cull decides every row's ViewVisibility
+    (lights through their bounding Sphere), the assignment gathers the visible lights ON THE DEVICE and assigns them.  Equal,
+    list for list, to the reference's sequence restated with the oracle, whichever way the frame is driven:
+      separate_calls                  mi_propagate_and_cull, then mi_cluster_assign_resident (reads the ViewVisibility column);
+      with_clusters                   ONE call, MI_CULL_WITH_CLUSTERS: the assignment is enqueued behind the frame kernel;
+      with_clusters_concurrent        ... | MI_CULL_CLUSTERS_CONCURRENT: the assignment re-derives the lights' visibility and
+                                      runs on the cluster stream next to the frame kernel;
+      with_clusters_behind_the_cull   MI_CULL_WITH_CLUSTERS on a call that does not close the frame (no MI_CULL_END_FRAME): the
+                                      assignment runs behind the cull and reads the column.
+    Lights move between the frames (dirty-row uploads on the main stream while the cluster stream may still be busy)."""
     sc, first_light, pr = W.frame_scene(60_000, 30_000, 3_000, light_range=1.5, ragged_flags=True)
     n_l = len(pr) // 4
     rng = np.random.default_rng(3)
@@ -119,19 +127,42 @@ def test_lights_as_rows_of_the_frame_context(ctx_factory, spots):
         sincos = np.stack([np.sin(ang), np.cos(ang)], axis=1).astype(F).reshape(-1)
         hidden = first_light + rng.integers(0, n_l, 500)             # some lights are hidden by inheritance
         sc["flags"][hidden] &= ~np.uint8(0x01)
+        if mode != "with_clusters_behind_the_cull":  # (their ViewVisibility is only set when the frame is closed)
+            ncc = first_light + rng.integers(0, n_l, 300)            # ... and some are NoCpuCulling (gpu-culling rule)
+            sc["flags"][ncc] |= np.uint8(0x10)
     ctx = ctx_factory()
     upload_scene(ctx, sc)
     ctx.cluster_upload_objects(pr, types, layers, None, sincos)
     ctx.cluster_bind_objects_to_rows(first_light, n_l)
     cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
-    for f in (0, 40):
+    t3 = sc["translation"].reshape(-1, 3)
+    c3 = sc["aabb_center"].reshape(-1, 3)
+    for f in (0, 40, 41, 42):
         cam = W.many_cubes_camera(f, yaw=0.3 * f)
         frusta = frusta_for([cam])
         view, keep = api.cluster_view_build(cam, cfv, frusta, 1920, 1080, (16, 9, 24), 5.0, 1000.0)
+        if f:  # a few hundred lights move: Transform (dirty rows) and bounding Sphere
+            moved = np.unique(first_light + rng.integers(0, n_l, 400)).astype(np.uint32)
+            t3[moved] = (t3[moved] * F(0.97)).astype(F)
+            c3[moved] = t3[moved]
+            ctx.upload_transforms_indexed(moved, t3[moved].reshape(-1), sc["rotation"].reshape(-1, 4)[moved].reshape(-1),
+                                          sc["scale"].reshape(-1, 3)[moved].reshape(-1))
+            lo, hi = int(moved.min()), int(moved.max()) + 1
+            ctx.upload_bounds(c3[lo:hi].reshape(-1), sc["aabb_half"].reshape(-1, 3)[lo:hi].reshape(-1), sc["flags"][lo:hi], sc["layers"][lo:hi],
+                              first_row=lo)
         ctx.cluster_upload_view(view)
         ctx.upload_view_visibility(np.zeros(sc["n"], np.uint8))
-        ctx.propagate_and_cull(frusta, flags=B.CULL_END_FRAME | B.CULL_MORE_FRAMES)
-        ctx.cluster_assign_resident()
+        if mode == "separate_calls":
+            ctx.propagate_and_cull(frusta, flags=B.CULL_END_FRAME | B.CULL_MORE_FRAMES)
+            ctx.cluster_assign_resident()
+        elif mode == "with_clusters":
+            ctx.propagate_and_cull(frusta, flags=B.CULL_END_FRAME | B.CULL_MORE_FRAMES | B.CULL_WITH_CLUSTERS)
+        elif mode == "with_clusters_concurrent":
+            ctx.propagate_and_cull(frusta, flags=B.CULL_END_FRAME | B.CULL_MORE_FRAMES | B.CULL_WITH_CLUSTERS | B.CULL_CLUSTERS_CONCURRENT)
+        else:
+            ctx.propagate(B.PROPAGATE_ALL_DIRTY)
+            ctx.cull(frusta, flags=B.CULL_BEGIN_FRAME | B.CULL_WITH_CLUSTERS)
+            ctx.visibility_end_frame()
         got = ctx.cluster_download(view.n_clusters)
         eoff, eidx, ecounts, efar, etotal, visible, vv, g = reference_sequence(sc, first_light, pr, frusta, cam, types, layers, sincos)
         assert 0 < visible.sum() < n_l and etotal > 0
@@ -156,8 +187,9 @@ def test_baseline_lights_config_at_full_size(ctx_factory):
     frusta = frusta_for([cam])
     view, keep = api.cluster_view_build(cam, cfv, frusta, 1920, 1080, (16, 9, 24), 5.0, 1000.0)
     ctx.cluster_upload_view(view)
-    ctx.propagate_and_cull(frusta, flags=B.CULL_END_FRAME)
-    ctx.cluster_assign_resident()
+    for _ in range(3):  # what bench.py's frame step is: one call, the assignment concurrent with the frame kernel
+        ctx.upload_view_visibility(np.zeros(sc["n"], np.uint8))
+        ctx.propagate_and_cull(frusta, flags=B.CULL_END_FRAME | B.CULL_MORE_FRAMES | B.CULL_WITH_CLUSTERS)
     got = ctx.cluster_download(view.n_clusters)
     eoff, eidx, ecounts, efar, etotal, visible, vv, g = reference_sequence(sc, first_light, pr, frusta, cam)
     assert_same_assignment(got, (eoff, eidx, ecounts, efar, etotal))

@@ -57,8 +57,8 @@ __device__ __forceinline__ void st_affine(float* g, uint32_t row, const Affine& 
 // cache line it opens.  Staging the wave's 64 x 48 B = 3 KB in LDS turns the global side into three
 // fully contiguous 1 KB wave-instructions (lane i <-> float4 i).  LDS side: ds_write_b128 at a 48-byte
 // lane stride and ds_read_b128 at a 16-byte lane stride are both bank-conflict free (8-lane groups cover
-// 32 distinct banks).  Each wave only touches its own 3 KB, but a workgroup barrier is used for
-// ordering (4 waves, negligible next to the HBM time).
+// 32 distinct banks).  Each wave only touches its own 3 KB, so a wave-level LDS fence orders it
+// (a workgroup barrier here made every wave wait for the slowest of four sets of loads).
 // ---------------------------------------------------------------------------------------------
 typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_affine_coalesced(float4* lds_wave, float* g, uint32_t wave_row0, uint32_t n,
@@ -66,7 +66,7 @@ __device__ __forceinline__ void store_affine_coalesced(float4* lds_wave, float* 
     lds_wave[lane * 3u + 0u] = make_float4(a.m.x_axis.x, a.m.x_axis.y, a.m.x_axis.z, a.m.y_axis.x);
     lds_wave[lane * 3u + 1u] = make_float4(a.m.y_axis.y, a.m.y_axis.z, a.m.z_axis.x, a.m.z_axis.y);
     lds_wave[lane * 3u + 2u] = make_float4(a.m.z_axis.z, a.t.x, a.t.y, a.t.z);
-    __syncthreads();
+    MI_WAVE_LDS_SYNC();  // the buffer is this wave's own: no workgroup barrier
     float4* dst = reinterpret_cast<float4*>(g) + 3ull * wave_row0;
     // float4s of live rows in this wave (none for the dead waves of the last workgroup)
     const uint32_t lim = wave_row0 < n ? (n - wave_row0 < 64u ? n - wave_row0 : 64u) * 3u : 0u;
@@ -80,25 +80,6 @@ __device__ __forceinline__ void store_affine_coalesced(float4* lds_wave, float* 
         }
     }
 }
-__device__ __forceinline__ Affine load_affine_coalesced(float4* lds_wave, const float* g, uint32_t wave_row0, uint32_t n,
-                                                        uint32_t lane) {
-    const float4* src = reinterpret_cast<const float4*>(g) + 3ull * wave_row0;
-    const uint32_t lim = wave_row0 < n ? (n - wave_row0 < 64u ? n - wave_row0 : 64u) * 3u : 0u;
-#pragma unroll
-    for (uint32_t k = 0; k < 3u; ++k) {
-        const uint32_t i = k * 64u + lane;
-        lds_wave[i] = i < lim ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    __syncthreads();
-    const float4 a = lds_wave[lane * 3u], b = lds_wave[lane * 3u + 1u], c = lds_wave[lane * 3u + 2u];
-    Affine r;
-    r.m.x_axis = V3{a.x, a.y, a.z};
-    r.m.y_axis = V3{a.w, b.x, b.y};
-    r.m.z_axis = V3{b.z, b.w, c.x};
-    r.t = V3{c.y, c.z, c.w};
-    return r;
-}
-
 __device__ __forceinline__ uint32_t sum_bytes(uint32_t x, uint32_t acc) { return __builtin_amdgcn_sad_u8(x, 0u, acc); }
 
 // One workgroup of the single-launch compaction: block (bx of gx, segment by).  Called from k_compact_fast and from the
@@ -207,6 +188,18 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
     V3 center = {}, half = {};
     uint32_t fl = 0, emask = 0, vv0 = 0, cmask = 1u;
     float range_lo = 0.0f, range_hi = 0.0f;
+    // G resident: its three contiguous wave rows are requested first, so that the transpose only waits for them while the
+    // bounds / flags / layers loads issued behind them are still in flight
+    float4 gl[3];
+    if (!PROPAGATE) {
+        const float4* src = reinterpret_cast<const float4*>(c.global) + 3ull * wave_row0;
+        const uint32_t lim = wave_row0 < c.n ? (c.n - wave_row0 < 64u ? c.n - wave_row0 : 64u) * 3u : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 3u; ++k) {
+            const uint32_t i = k * 64u + lane;
+            gl[k] = i < lim ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     if (live) {
         center = ld3(c.aabb_center, row);
         half = ld3(c.aabb_half, row);
@@ -230,7 +223,15 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
         // nontemporal: the fused path never reads G back (measured +3..16 % at 4 M - 10 M rows, neutral at 1 M)
         store_affine_coalesced(lds_g[wv], c.global, wave_row0, c.n, lane, g, true);
     } else {
-        g = load_affine_coalesced(lds_g[wv], c.global, wave_row0, c.n, lane);
+        float4* lds_wave = lds_g[wv];
+#pragma unroll
+        for (uint32_t k = 0; k < 3u; ++k) lds_wave[k * 64u + lane] = gl[k];
+        MI_WAVE_LDS_SYNC();
+        const float4 a = lds_wave[lane * 3u], b = lds_wave[lane * 3u + 1u], cc = lds_wave[lane * 3u + 2u];
+        g.m.x_axis = V3{a.x, a.y, a.z};
+        g.m.y_axis = V3{a.w, b.x, b.y};
+        g.m.z_axis = V3{b.z, b.w, cc.x};
+        g.t = V3{cc.y, cc.z, cc.w};
     }
     const bool ncc = (fl & 0x10u) != 0;  // NoCpuCulling rows are not in the cull query (mod.rs:771)
     const bool any_live = wave_row0 < c.n;  // waves past the last row must not touch the masks

@@ -1,0 +1,937 @@
+//! `bevy_mi355x` -- the Bevy side of the drop-in boundary of `libbevy_mi355x.so` (include/bevy_mi355x.h).
+//!
+//! [`Mi355xRenderPrepPlugin`] takes the three per-frame render-prep systems out of the `PostUpdate` schedule and puts one system
+//! with the same inputs, outputs, system set and ordering in the place of each:
+//!
+//! | stock system (reference file:line)                                                        | replacement                         |
+//! |--------------------------------------------------------------------------------------------|-------------------------------------|
+//! | `mark_dirty_trees`, `propagate_parent_transforms`, `sync_simple_transforms`                 | [`mi_propagate_transforms`]         |
+//! |   (crates/bevy_transform/src/systems.rs:42-79, 111-306, 506-748)                            |                                     |
+//! | `check_visibility_cpu_culling` (crates/bevy_camera/src/visibility/mod.rs:748-880)           | [`mi_check_visibility`]             |
+//! | `assign_objects_to_clusters` (crates/bevy_light/src/cluster/assign.rs:137-813)              | [`mi_assign_objects_to_clusters`]   |
+//!
+//! The ECS stays the owner of every component.  The library owns device-resident COLUMNS, one row per entity, and the systems
+//! below move only what changed: rows whose `Transform` change tick is newer than the system's last run go up
+//! (`mi_upload_transforms_indexed`), rows whose `GlobalTransform` the device changed come down
+//! (`mi_download_changed_global_transforms`) and are written through `Mut`, so change ticks move exactly where the stock systems
+//! move them.  Bulk reads go through `Query::contiguous_iter` (crates/bevy_ecs/src/system/query.rs:1509-1560): one slice per
+//! table, no per-entity fetch.
+//!
+//! # The CPU-fallback rule
+//!
+//! Every `mi_*` call returns an `int32` status.  A system below
+//!   1. makes all of its `mi_*` calls BEFORE it writes anything to the ECS;
+//!   2. on `MI_ERR_MALFORMED_HIERARCHY` panics with the library's message -- the reference panics on the same input
+//!      (crates/bevy_transform/src/systems.rs:715);
+//!   3. on ANY other negative status logs `mi_last_error_string` once, sets its bit in [`CpuFallback`] and returns without having
+//!      touched the ECS.  The stock system it replaced is still in the schedule, ordered right behind it and gated on that bit
+//!      (`run_if`), so the SAME frame is computed by the reference's own code; the bit stays set, i.e. the GPU path is off for
+//!      the rest of the run (a device that failed once is not retried every frame).
+//! `assign_objects_to_clusters` is `pub(crate)`, so it cannot be re-added; instead its system set
+//! (`SimulationLightSystems::AssignLightsToClusters`, which holds only that system, crates/bevy_light/src/lib.rs:187-191) is
+//! gated with the same condition and the replacement runs just before the set.
+//!
+//! There is no Rust toolchain in the image this repository is built in: this crate is written against the reference checkout
+//! (Bevy 0.20.0-dev) but has not been compiled.  `tests/test_rust_ffi.py` checks `ffi.rs` against the C header item by item and
+//! checks that every `ffi::mi_*` call below passes the declared number of arguments; `bevy_amd/host/bevy_mi355x_host.hpp` is the
+//! same host layer in C++, which IS compiled and run against the reference's system tests on the GPU.
+
+pub mod ffi;
+
+use core::ffi::CStr;
+use core::ptr;
+
+use bevy_app::{App, Plugin, PostStartup, PostUpdate};
+use bevy_camera::{
+    primitives::{Aabb, Frustum, Sphere},
+    visibility::{
+        check_visibility_cpu_culling, InheritedVisibility, NoCpuCulling, NoFrustumCulling, RenderLayers, SetViewVisibility,
+        ViewVisibility, VisibilityClass, VisibilityRange, VisibilitySystems, VisibleEntities,
+    },
+    Camera, CameraUpdateSystems,
+};
+use bevy_ecs::{
+    change_detection::Tick,
+    entity::{Entity, EntityHashMap},
+    prelude::*,
+    schedule::{IntoScheduleConfigs, RemoveSystemsOnly},
+    system::SystemChangeTick,
+};
+use bevy_light::{
+    cluster::{
+        ClusterConfig, ClusterFarZMode, ClusterableObjects, Clusters, GlobalClusterSettings, ObjectsInClusterCpu,
+    },
+    ClusteredDecal, EnvironmentMapLight, LightProbe, PointLight, RectLight, SimulationLightSystems, SpotLight, VolumetricLight,
+};
+use bevy_log::error;
+use bevy_math::{Affine3A, UVec2, UVec3};
+use bevy_platform::collections::HashMap;
+use bevy_transform::{
+    components::{GlobalTransform, Transform},
+    systems::{mark_dirty_trees, propagate_parent_transforms, sync_simple_transforms},
+    TransformSystems,
+};
+use core::any::TypeId;
+
+/// Which of the three replaced systems have handed their work back to the stock CPU systems (see the module docs).
+#[derive(Resource, Default, Clone, Copy, PartialEq, Eq, Debug)]
+pub struct CpuFallback {
+    pub transforms: bool,
+    pub visibility: bool,
+    pub clusters: bool,
+}
+
+fn transforms_fell_back(f: Res<CpuFallback>) -> bool {
+    f.transforms
+}
+fn visibility_fell_back(f: Res<CpuFallback>) -> bool {
+    f.visibility
+}
+fn clusters_fell_back(f: Res<CpuFallback>) -> bool {
+    f.clusters
+}
+
+/// The library context and the Entity <-> row table.
+#[derive(Resource)]
+pub struct Mi355x {
+    ctx: *mut ffi::MiCtx,
+    /// row -> entity; rows `[0, n_tree)` are the hierarchy in the level order `mi_hierarchy_sort` produced, rows above are free
+    /// of any hierarchy (roots without children) in table order.
+    row_entity: Vec<Entity>,
+    entity_row: EntityHashMap<u32>,
+    /// `TypeId` of a visibility class -> bit of the `class_mask` column (at most 32 classes, like the column).
+    class_bits: HashMap<TypeId, u32>,
+    /// Per-view cluster feedback (`Clusters::last_frame_*`, crates/bevy_light/src/cluster/mod.rs:153-163).
+    cluster_history: EntityHashMap<ffi::MiClusterHistory>,
+    scratch: Scratch,
+}
+
+/// Host staging reused from frame to frame (the reference keeps `Local<Vec<..>>`s for the same reason, assign.rs:179-180).
+#[derive(Default)]
+struct Scratch {
+    rows: Vec<u32>,
+    translation: Vec<f32>,
+    rotation: Vec<f32>,
+    scale: Vec<f32>,
+    global12: Vec<f32>,
+    parent: Vec<u32>,
+    new_to_old: Vec<u32>,
+    parent_idx: Vec<u32>,
+    level_offsets: Vec<u32>,
+    keys: Vec<u64>,
+    aabb_center: Vec<f32>,
+    aabb_half: Vec<f32>,
+    flags: Vec<u8>,
+    layers: Vec<u32>,
+    classes: Vec<u32>,
+    view_visibility: Vec<u8>,
+    vv_changed: Vec<u32>,
+    views: Vec<ffi::MiView>,
+    view_entities: Vec<Entity>,
+    visible_keys: Vec<u64>,
+    visible_rows: Vec<u32>,
+    obj_pos_range: Vec<f32>,
+    obj_type: Vec<u8>,
+    obj_layers: Vec<u32>,
+    obj_spot_dir: Vec<f32>,
+    obj_spot_sin_cos: Vec<f32>,
+    obj_shadows: Vec<u8>,
+    obj_volumetric: Vec<u8>,
+    obj_entity: Vec<Entity>,
+    obj_order: Vec<u32>,
+    cl_offsets: Vec<u32>,
+    cl_counts: Vec<u32>,
+    cl_indices: Vec<u32>,
+}
+
+// SAFETY: the context is only used through `ResMut<Mi355x>`, i.e. by one system at a time, which is the library's contract
+// ("one call at a time per context", include/bevy_mi355x.h).
+unsafe impl Send for Mi355x {}
+unsafe impl Sync for Mi355x {}
+
+impl Mi355x {
+    pub fn new(device: i32) -> Result<Self, String> {
+        // SAFETY: plain FFI; `out_ctx` points at a live local.
+        unsafe {
+            if ffi::mi_abi_version() != ffi::MI_ABI_VERSION {
+                return Err("libbevy_mi355x: ABI version mismatch".into());
+            }
+            let mut ctx = ptr::null_mut();
+            let status = ffi::mi_ctx_create(device, ptr::null_mut(), &mut ctx);
+            if status != ffi::MI_OK {
+                return Err(format!("mi_ctx_create({device}) failed with status {status}"));
+            }
+            Ok(Self {
+                ctx,
+                row_entity: Vec::new(),
+                entity_row: EntityHashMap::default(),
+                class_bits: HashMap::default(),
+                cluster_history: EntityHashMap::default(),
+                scratch: Scratch::default(),
+            })
+        }
+    }
+
+}
+
+fn message(ctx: *mut ffi::MiCtx) -> String {
+    // SAFETY: the library returns a NUL-terminated string that lives until the next call on this context.
+    unsafe { CStr::from_ptr(ffi::mi_last_error_string(ctx)).to_string_lossy().into_owned() }
+}
+
+/// The status rule of the module docs: `Ok` for `MI_OK`, panic for a malformed hierarchy, `Err` for everything else.
+/// (A free function over the raw handle, so that callers can hold `&mut` borrows of the resource's staging vectors.)
+fn check(ctx: *mut ffi::MiCtx, what: &str, status: i32) -> Result<(), ()> {
+    if status == ffi::MI_OK {
+        return Ok(());
+    }
+    if status == ffi::MI_ERR_MALFORMED_HIERARCHY {
+        panic!("{}", message(ctx));
+    }
+    error!("bevy_mi355x: {what} failed with status {status}: {}; falling back to the CPU system", message(ctx));
+    Err(())
+}
+
+impl Drop for Mi355x {
+    fn drop(&mut self) {
+        // SAFETY: `ctx` came from `mi_ctx_create` and is destroyed exactly once.
+        unsafe {
+            ffi::mi_synchronize(self.ctx);
+            ffi::mi_ctx_destroy(self.ctx);
+        }
+    }
+}
+
+/// Replaces transform propagation, visibility checking and light-cluster assignment with the MI355X library.
+pub struct Mi355xRenderPrepPlugin {
+    /// HIP device ordinal.
+    pub device: i32,
+}
+
+impl Plugin for Mi355xRenderPrepPlugin {
+    fn build(&self, app: &mut App) {
+        let mi = match Mi355x::new(self.device) {
+            Ok(mi) => mi,
+            Err(message) => {
+                // No device, no library: leave the stock systems where they are.
+                error!("bevy_mi355x: {message}; the stock CPU systems stay in place");
+                return;
+            }
+        };
+        app.insert_resource(mi).init_resource::<CpuFallback>();
+
+        // --- transforms: TransformPlugin registers the same three systems in PostStartup and PostUpdate
+        //     (crates/bevy_transform/src/plugins.rs:22-48).  Every system fn is its own implicit set
+        //     (crates/bevy_app/src/app.rs:330-360), which is how they are taken out again.
+        for schedule in [PostStartup.intern(), PostUpdate.intern()] {
+            app.remove_systems_in_set(schedule, mark_dirty_trees, RemoveSystemsOnly);
+            app.remove_systems_in_set(schedule, propagate_parent_transforms, RemoveSystemsOnly);
+            app.remove_systems_in_set(schedule, sync_simple_transforms, RemoveSystemsOnly);
+            app.add_systems(
+                schedule,
+                (
+                    mi_propagate_transforms,
+                    // the stock trio in its stock order, only when the replacement gave up (this frame or earlier)
+                    (mark_dirty_trees, propagate_parent_transforms, sync_simple_transforms)
+                        .chain()
+                        .run_if(transforms_fell_back),
+                )
+                    .chain()
+                    .in_set(TransformSystems::Propagate),
+            );
+        }
+
+        // --- visibility: `reset_view_visibility` before and `mark_newly_hidden_entities_invisible` after stay registered (they
+        //     are private, visibility/mod.rs:529-533); the middle step is replaced.
+        app.remove_systems_in_set(PostUpdate, check_visibility_cpu_culling, RemoveSystemsOnly);
+        app.add_systems(
+            PostUpdate,
+            (mi_check_visibility, check_visibility_cpu_culling.run_if(visibility_fell_back))
+                .chain()
+                .in_set(VisibilitySystems::CheckVisibility),
+        );
+
+        // --- clusters: gate the stock set, run the replacement right in front of it with the stock ordering constraints
+        //     (crates/bevy_light/src/lib.rs:187-191).
+        app.configure_sets(PostUpdate, SimulationLightSystems::AssignLightsToClusters.run_if(clusters_fell_back));
+        app.add_systems(
+            PostUpdate,
+            mi_assign_objects_to_clusters
+                .before(SimulationLightSystems::AssignLightsToClusters)
+                .after(TransformSystems::Propagate)
+                .after(VisibilitySystems::CheckVisibility)
+                .after(CameraUpdateSystems),
+        );
+    }
+}
+
+#[inline]
+fn changed_since(tick: Tick, ticks: &SystemChangeTick) -> bool {
+    tick.is_newer_than(ticks.last_run(), ticks.this_run())
+}
+
+/// `mark_dirty_trees` + `propagate_parent_transforms` + `sync_simple_transforms` in one device pass.
+///
+/// Same observable behaviour: `GlobalTransform` of every entity equals `parent.GlobalTransform * Transform` (or `Transform` for
+/// roots), and a `GlobalTransform` is written through `Mut` -- i.e. its change tick moves -- only where the stock systems would
+/// have written it: rows whose own `Transform`, or that of an ancestor, changed since the last run
+/// (`TransformTreeChanged` in the reference, systems.rs:42-79; the device keeps the same dirty bit per row).
+pub fn mi_propagate_transforms(
+    mut mi: ResMut<Mi355x>,
+    mut fallback: ResMut<CpuFallback>,
+    ticks: SystemChangeTick,
+    structure_changed: Query<(), Or<(Added<Transform>, Changed<ChildOf>)>>,
+    mut orphaned: RemovedComponents<ChildOf>,
+    mut despawned: RemovedComponents<Transform>,
+    transforms: Query<(Entity, Ref<Transform>, Option<&ChildOf>)>,
+    mut globals: Query<&mut GlobalTransform>,
+) {
+    if fallback.transforms {
+        return;
+    }
+    let mi = &mut *mi;
+    let ctx = mi.ctx;
+    let rebuild = !structure_changed.is_empty() || orphaned.read().count() != 0 || despawned.read().count() != 0;
+    let tables = transforms.contiguous_iter().expect("Transform and ChildOf are table components");
+
+    let result: Result<u32, ()> = (|| {
+        let s = &mut mi.scratch;
+        if rebuild {
+            // (1) provisional rows in table order, (2) parent as a provisional row, (3) level order from the library.
+            mi.row_entity.clear();
+            mi.entity_row.clear();
+            s.translation.clear();
+            s.rotation.clear();
+            s.scale.clear();
+            let mut parents_of: Vec<Option<Entity>> = Vec::new();
+            for (entities, table_transforms, child_of) in tables {
+                for (i, (entity, t)) in entities.iter().zip(table_transforms.iter()).enumerate() {
+                    mi.entity_row.insert(*entity, mi.row_entity.len() as u32);
+                    mi.row_entity.push(*entity);
+                    parents_of.push(child_of.map(|c| c[i].parent()));
+                    s.translation.extend_from_slice(&t.translation.to_array());
+                    s.rotation.extend_from_slice(&t.rotation.to_array());
+                    s.scale.extend_from_slice(&t.scale.to_array());
+                }
+            }
+            let n = mi.row_entity.len() as u32;
+            s.parent.clear();
+            // A `ChildOf` that points at an entity without `Transform` makes the child a root, as in the reference
+            // (systems.rs:528-531 only descends through entities that match the transform query).
+            s.parent.extend(parents_of.iter().map(|p| p.and_then(|p| mi.entity_row.get(&p).copied()).unwrap_or(ffi::MI_NO_PARENT)));
+            s.new_to_old.resize(n as usize, 0);
+            s.parent_idx.resize(n as usize, 0);
+            s.level_offsets.resize(n as usize + 2, 0);
+            let mut n_levels = 0u32;
+            // SAFETY: every pointer is a live Vec of at least the length the header asks for.
+            check(ctx, "mi_hierarchy_sort", unsafe {
+                ffi::mi_hierarchy_sort(
+                    n,
+                    s.parent.as_ptr(),
+                    s.new_to_old.as_mut_ptr(),
+                    s.parent_idx.as_mut_ptr(),
+                    s.level_offsets.as_mut_ptr(),
+                    s.level_offsets.len() as u32,
+                    &mut n_levels,
+                )
+            })?;
+            // rows := level order
+            let old_entities = core::mem::take(&mut mi.row_entity);
+            let gather3 = |src: &Vec<f32>, w: usize| -> Vec<f32> {
+                s.new_to_old.iter().flat_map(|&o| src[o as usize * w..(o as usize + 1) * w].iter().copied()).collect()
+            };
+            let (t, r, sc) = (gather3(&s.translation, 3), gather3(&s.rotation, 4), gather3(&s.scale, 3));
+            mi.row_entity = s.new_to_old.iter().map(|&o| old_entities[o as usize]).collect();
+            for (row, e) in mi.row_entity.iter().enumerate() {
+                mi.entity_row.insert(*e, row as u32);
+            }
+            s.keys.clear();
+            s.keys.extend(mi.row_entity.iter().map(|e| e.to_bits()));
+            // SAFETY: as above; the columns hold `n` rows after `mi_columns_resize`.
+            unsafe {
+                check(ctx, "mi_columns_resize", ffi::mi_columns_resize(ctx, n))?;
+                check(ctx, "mi_upload_transforms", ffi::mi_upload_transforms(ctx, 0, n, t.as_ptr(), r.as_ptr(), sc.as_ptr()))?;
+                check(ctx, "mi_upload_entity_keys", ffi::mi_upload_entity_keys(ctx, 0, n, s.keys.as_ptr()))?;
+                check(ctx, 
+                    "mi_upload_hierarchy",
+                    ffi::mi_upload_hierarchy(ctx, n, s.parent_idx.as_ptr(), s.level_offsets.as_ptr(), n_levels),
+                )?;
+                check(ctx, "mi_propagate", ffi::mi_propagate(ctx, ffi::MI_PROPAGATE_ALL_DIRTY))?;
+            }
+        } else {
+            // steady state: only the rows whose Transform changed since this system last ran
+            s.rows.clear();
+            s.translation.clear();
+            s.rotation.clear();
+            s.scale.clear();
+            for (entities, table_transforms, _) in tables {
+                let changed = table_transforms.changed_ticks_slice();
+                for (i, t) in table_transforms.iter().enumerate() {
+                    if changed_since(changed[i], &ticks) {
+                        s.rows.push(mi.entity_row[&entities[i]]);
+                        s.translation.extend_from_slice(&t.translation.to_array());
+                        s.rotation.extend_from_slice(&t.rotation.to_array());
+                        s.scale.extend_from_slice(&t.scale.to_array());
+                    }
+                }
+            }
+            // SAFETY: `rows` and the three columns hold `rows.len()` entries each.
+            unsafe {
+                check(ctx, 
+                    "mi_upload_transforms_indexed",
+                    ffi::mi_upload_transforms_indexed(
+                        ctx,
+                        s.rows.len() as u32,
+                        s.rows.as_ptr(),
+                        s.translation.as_ptr(),
+                        s.rotation.as_ptr(),
+                        s.scale.as_ptr(),
+                    ),
+                )?;
+                check(ctx, "mi_propagate", ffi::mi_propagate(ctx, 0))?;
+            }
+        }
+        // what the device changed, compacted on the device: ascending rows + 3x4 column-major matrices
+        let capacity = mi.row_entity.len() as u32;
+        s.rows.resize(capacity as usize, 0);
+        s.global12.resize(capacity as usize * 12, 0.0);
+        let mut count = 0u32;
+        // SAFETY: both outputs hold `capacity` entries.
+        check(ctx, "mi_download_changed_global_transforms", unsafe {
+            ffi::mi_download_changed_global_transforms(ctx, s.rows.as_mut_ptr(), s.global12.as_mut_ptr(), capacity, &mut count)
+        })?;
+        Ok(count)
+    })();
+
+    let Ok(count) = result else {
+        fallback.transforms = true; // nothing was written to the ECS; the stock trio runs next, in this same frame
+        return;
+    };
+    let s = &mi.scratch;
+    for (k, row) in s.rows[..count as usize].iter().enumerate() {
+        let cols: &[f32; 12] = s.global12[k * 12..k * 12 + 12].try_into().unwrap();
+        if let Ok(mut global) = globals.get_mut(mi.row_entity[*row as usize]) {
+            // plain assignment: the device already compared against the old value (the row is listed only if it differs or its
+            // tree was dirty), which is `set_if_neq`'s contract at systems.rs:719
+            *global = GlobalTransform::from(Affine3A::from_cols_array(cols));
+        }
+    }
+}
+
+/// `check_visibility_cpu_culling` on the device: per active camera the frustum / render-layer / visibility-range tests of
+/// visibility/mod.rs:800-846 over the resident columns, `ViewVisibility::set_visible` on the rows that passed for any view, and
+/// the per-class `VisibleEntities` lists, sorted.
+pub fn mi_check_visibility(
+    mut mi: ResMut<Mi355x>,
+    mut fallback: ResMut<CpuFallback>,
+    ticks: SystemChangeTick,
+    mut view_query: Query<(Entity, &mut VisibleEntities, &Frustum, Option<&RenderLayers>, &Camera, Has<NoCpuCulling>)>,
+    bounds_changed: Query<
+        (),
+        Or<(
+            Changed<Aabb>,
+            Changed<Sphere>,
+            Changed<InheritedVisibility>,
+            Changed<RenderLayers>,
+            Changed<VisibilityClass>,
+            Added<NoFrustumCulling>,
+        )>,
+    >,
+    rows_query: Query<
+        (
+            Entity,
+            &InheritedVisibility,
+            Option<&VisibilityClass>,
+            Option<&RenderLayers>,
+            Option<&Aabb>,
+            Has<NoFrustumCulling>,
+            Has<VisibilityRange>,
+        ),
+        Without<NoCpuCulling>,
+    >,
+    mut view_visibilities: Query<&mut ViewVisibility, Without<NoCpuCulling>>,
+) {
+    let _ = ticks;
+    if fallback.visibility || fallback.transforms {
+        // without the device-resident GlobalTransform column there is nothing to cull against
+        fallback.visibility = true;
+        return;
+    }
+    let mi = &mut *mi;
+    let ctx = mi.ctx;
+    let n = mi.row_entity.len() as u32;
+
+    let result: Result<(), ()> = (|| {
+        // --- columns that change rarely: re-staged only when one of them changed
+        if !bounds_changed.is_empty() {
+            let s = &mut mi.scratch;
+            s.aabb_center.clear();
+            s.aabb_center.resize(n as usize * 3, 0.0);
+            s.aabb_half.clear();
+            s.aabb_half.resize(n as usize * 3, 0.0);
+            s.flags.clear();
+            s.flags.resize(n as usize, 0);
+            s.layers.clear();
+            s.layers.resize(n as usize, 0);
+            s.classes.clear();
+            s.classes.resize(n as usize, 0);
+            let tables = rows_query.contiguous_iter().expect("all queried components live in tables");
+            for (entities, inherited, classes, layers, aabbs, no_frustum_culling, has_range) in tables {
+                for (i, entity) in entities.iter().enumerate() {
+                    let Some(&row) = mi.entity_row.get(entity) else { continue };
+                    let row = row as usize;
+                    let mut flags = 0u32;
+                    if inherited[i].get() {
+                        flags |= ffi::MI_FLAG_INHERITED_VISIBLE;
+                    }
+                    if no_frustum_culling {
+                        flags |= ffi::MI_FLAG_NO_FRUSTUM_CULLING;
+                    }
+                    if has_range {
+                        flags |= ffi::MI_FLAG_HAS_VISIBILITY_RANGE;
+                    }
+                    if let Some(aabbs) = aabbs {
+                        flags |= ffi::MI_FLAG_HAS_AABB;
+                        s.aabb_center[row * 3..row * 3 + 3].copy_from_slice(&aabbs[i].center.to_array());
+                        s.aabb_half[row * 3..row * 3 + 3].copy_from_slice(&aabbs[i].half_extents.to_array());
+                    }
+                    s.flags[row] = flags as u8;
+                    // The column is one 32-bit word: layers 0..=31.  A scene that uses a higher layer is not representable
+                    // and goes back to the CPU system (error path below).
+                    s.layers[row] = match layers.map(|l| &l[i]) {
+                        None => 1, // RenderLayers::default() == layer 0
+                        Some(l) => layer_word(l).ok_or(())?,
+                    };
+                    if let Some(classes) = classes {
+                        for class in classes[i].iter() {
+                            s.classes[row] |= 1 << mi_class_bit(&mut mi.class_bits, *class).ok_or(())?;
+                        }
+                    }
+                }
+            }
+            // SAFETY: every column holds `n` rows.
+            unsafe {
+                check(ctx, 
+                    "mi_upload_bounds",
+                    ffi::mi_upload_bounds(ctx, 0, n, s.aabb_center.as_ptr(), s.aabb_half.as_ptr(), s.flags.as_ptr(), s.layers.as_ptr()),
+                )?;
+                check(ctx, "mi_upload_visibility_classes", ffi::mi_upload_visibility_classes(ctx, 0, n, s.classes.as_ptr()))?;
+            }
+        }
+
+        // --- the frame's views: active cameras in query order (visibility/mod.rs:778-784)
+        let s = &mut mi.scratch;
+        s.views.clear();
+        s.view_entities.clear();
+        for (entity, _, frustum, layers, camera, no_cpu_culling) in view_query.iter() {
+            if !camera.is_active {
+                continue;
+            }
+            let mut view = ffi::MiView {
+                frustum: [0.0; 24],
+                layer_mask: match layers {
+                    None => 1,
+                    Some(l) => layer_word(l).ok_or(())?,
+                },
+                flags: if no_cpu_culling { ffi::MI_VIEW_FLAG_NO_CPU_CULLING } else { 0 },
+                position: [0.0; 3],
+                light_sphere: [0.0; 4],
+                reserved: [0; 3],
+            };
+            for (p, half_space) in frustum.half_spaces.iter().enumerate() {
+                view.frustum[p * 4..p * 4 + 4].copy_from_slice(&half_space.normal_d().to_array());
+            }
+            s.views.push(view);
+            s.view_entities.push(entity);
+        }
+        // one whole frame on the device: reset, every view, newly-hidden -> one kernel launch
+        // SAFETY: `views` holds `views.len()` entries.
+        check(ctx, "mi_cull_views", unsafe {
+            ffi::mi_cull_views(ctx, s.views.as_ptr(), s.views.len() as u32, ffi::MI_CULL_BEGIN_FRAME | ffi::MI_CULL_END_FRAME)
+        })?;
+        s.view_visibility.resize(n as usize, 0);
+        s.vv_changed.resize((n as usize + 31) / 32, 0);
+        // SAFETY: `n` bytes and ceil(n / 32) words.
+        check(ctx, "mi_download_view_visibility", unsafe {
+            ffi::mi_download_view_visibility(ctx, 0, n, s.view_visibility.as_mut_ptr(), s.vv_changed.as_mut_ptr())
+        })?;
+        Ok(())
+    })();
+    if result.is_err() {
+        fallback.visibility = true;
+        return;
+    }
+
+    // --- ECS writes.  `reset_view_visibility` has already shifted current -> previous on every component; `set_visible` on the
+    //     rows the device found visible reproduces the stock system's writes (and its change ticks, mod.rs:290-306) one to one.
+    for (row, vv) in mi.scratch.view_visibility.iter().enumerate() {
+        if vv & 1 != 0 {
+            if let Ok(mut view_visibility) = view_visibilities.get_mut(mi.row_entity[row]) {
+                view_visibility.set_visible();
+            }
+        }
+    }
+    let class_bits: Vec<(TypeId, u32)> = mi.class_bits.iter().map(|(k, v)| (*k, *v)).collect();
+    for (slot, view_entity) in mi.scratch.view_entities.clone().into_iter().enumerate() {
+        let Ok((_, mut visible_entities, ..)) = view_query.get_mut(view_entity) else { continue };
+        visible_entities.clear_all();
+        for (class, bit) in &class_bits {
+            let s = &mut mi.scratch;
+            s.visible_keys.resize(n as usize, 0);
+            s.visible_rows.resize(n as usize, 0);
+            let mut count = 0u32;
+            // SAFETY: both outputs hold `n` entries, the most one list can have.
+            let status = unsafe {
+                ffi::mi_download_visible_entities(
+                    ctx,
+                    slot as u32,
+                    *bit,
+                    s.visible_keys.as_mut_ptr(),
+                    s.visible_rows.as_mut_ptr(),
+                    n,
+                    &mut count,
+                )
+            };
+            if check(ctx, "mi_download_visible_entities", status).is_err() {
+                // ViewVisibility is already final and equal to what the CPU system would write; only this frame's lists are
+                // rebuilt by it (it clears and refills them, mod.rs:861-875).
+                fallback.visibility = true;
+                return;
+            }
+            let list = visible_entities.get_mut(*class);
+            list.extend(mi.scratch.visible_keys[..count as usize].iter().map(|bits| Entity::from_bits(*bits)));
+            list.sort_unstable(); // mod.rs:872-875: the render world's diffing needs sorted lists
+        }
+    }
+}
+
+/// `RenderLayers` as the one 32-bit word of the `layer_mask` column, `None` if a layer above 31 is set.
+fn layer_word(layers: &RenderLayers) -> Option<u32> {
+    let mut word = 0u32;
+    for layer in layers.iter() {
+        if layer >= 32 {
+            return None;
+        }
+        word |= 1 << layer;
+    }
+    Some(word)
+}
+
+fn mi_class_bit(table: &mut HashMap<TypeId, u32>, class: TypeId) -> Option<u32> {
+    let next = table.len() as u32;
+    if let Some(bit) = table.get(&class) {
+        return Some(*bit);
+    }
+    (next < 32).then(|| {
+        table.insert(class, next);
+        next
+    })
+}
+
+/// `ClusterConfig` (crates/bevy_light/src/cluster/mod.rs:104-139) as the plain struct of the C ABI.
+fn cluster_config_to_ffi(config: &ClusterConfig) -> ffi::MiClusterConfig {
+    let mut out = ffi::MiClusterConfig {
+        kind: ffi::MI_CLUSTER_CONFIG_NONE,
+        dimensions: [0; 3],
+        total: 0,
+        z_slices: 0,
+        first_slice_depth: 0.0,
+        far_z_mode: ffi::MI_CLUSTER_FAR_Z_CONSTANT,
+        far_z_constant: 0.0,
+        dynamic_resizing: 0,
+    };
+    let mut z = |z_config: &bevy_light::cluster::ClusterZConfig, out: &mut ffi::MiClusterConfig| {
+        out.first_slice_depth = z_config.first_slice_depth;
+        match z_config.far_z_mode {
+            ClusterFarZMode::MaxClusterableObjectRange => out.far_z_mode = ffi::MI_CLUSTER_FAR_Z_MAX_CLUSTERABLE_OBJECT_RANGE,
+            ClusterFarZMode::Constant(far) => {
+                out.far_z_mode = ffi::MI_CLUSTER_FAR_Z_CONSTANT;
+                out.far_z_constant = far;
+            }
+        }
+    };
+    match config {
+        ClusterConfig::None => {}
+        ClusterConfig::Single => out.kind = ffi::MI_CLUSTER_CONFIG_SINGLE,
+        ClusterConfig::XYZ { dimensions, z_config, dynamic_resizing } => {
+            out.kind = ffi::MI_CLUSTER_CONFIG_XYZ;
+            out.dimensions = dimensions.to_array();
+            out.dynamic_resizing = *dynamic_resizing as u32;
+            z(z_config, &mut out);
+        }
+        ClusterConfig::FixedZ { total, z_slices, z_config, dynamic_resizing } => {
+            out.kind = ffi::MI_CLUSTER_CONFIG_FIXED_Z;
+            out.total = *total;
+            out.z_slices = *z_slices;
+            out.dynamic_resizing = *dynamic_resizing as u32;
+            z(z_config, &mut out);
+        }
+    }
+    out
+}
+
+/// `assign_objects_to_clusters` on the device.  The object list is gathered exactly as the reference gathers it (query order:
+/// point lights, spot lights, rect lights, light probes, decals; visible ones only; assign.rs:190-296), limited and sorted as it
+/// limits and sorts it (`mi_cluster_sort_truncate`, assign.rs:298-356), and each view is resolved, walked and filled by
+/// `mi_cluster_assign_frame` (config -> dimensions incl. the `MaxClusterableObjectRange` / `dynamic_resizing` feedback of the
+/// previous frame, assign.rs:358-470; the walk itself, assign.rs:472-805).
+pub fn mi_assign_objects_to_clusters(
+    mut mi: ResMut<Mi355x>,
+    mut fallback: ResMut<CpuFallback>,
+    mut views: Query<(Entity, &GlobalTransform, &Camera, &Frustum, Option<&ClusterConfig>, &mut Clusters, Option<&RenderLayers>)>,
+    point_lights: Query<(Entity, &GlobalTransform, &ViewVisibility, &PointLight, Option<&RenderLayers>, Option<&VolumetricLight>)>,
+    spot_lights: Query<(Entity, &GlobalTransform, &ViewVisibility, &SpotLight, Option<&RenderLayers>, Option<&VolumetricLight>)>,
+    rect_lights: Query<(Entity, &GlobalTransform, &ViewVisibility, &RectLight, Option<&RenderLayers>)>,
+    light_probes: Query<(Entity, &GlobalTransform, &ViewVisibility, Has<EnvironmentMapLight>), With<LightProbe>>,
+    decals: Query<(Entity, &GlobalTransform, &ViewVisibility), With<ClusteredDecal>>,
+    settings: Option<Res<GlobalClusterSettings>>,
+) {
+    let Some(settings) = settings else { return };
+    if fallback.clusters || settings.gpu_clustering.is_some() {
+        // wgpu-side clustering is a different path (assign.rs:187); leave it to the stock system
+        fallback.clusters = true;
+        return;
+    }
+    let mi = &mut *mi;
+    let ctx = mi.ctx;
+
+    struct ViewResult {
+        entity: Entity,
+        view: ffi::MiClusterView,
+        active: bool,
+        offsets: Vec<u32>,
+        counts: Vec<u32>,
+        indices: Vec<u32>,
+        farthest_z: f32,
+        total: u64,
+    }
+
+    let result: Result<Vec<ViewResult>, ()> = (|| {
+        let s = &mut mi.scratch;
+        for v in [&mut s.obj_pos_range, &mut s.obj_spot_dir, &mut s.obj_spot_sin_cos] {
+            v.clear();
+        }
+        for v in [&mut s.obj_type, &mut s.obj_shadows, &mut s.obj_volumetric] {
+            v.clear();
+        }
+        s.obj_layers.clear();
+        s.obj_entity.clear();
+        let mut push = |s: &mut Scratch,
+                        entity: Entity,
+                        transform: &GlobalTransform,
+                        range: f32,
+                        kind: i32,
+                        layers: Option<&RenderLayers>,
+                        shadows: bool,
+                        volumetric: bool,
+                        spot: Option<(f32, [f32; 3])>|
+         -> Result<(), ()> {
+            let p = transform.translation();
+            s.obj_pos_range.extend_from_slice(&[p.x, p.y, p.z, range]);
+            s.obj_type.push(kind as u8);
+            s.obj_layers.push(match layers {
+                None => 1,
+                Some(l) => layer_word(l).ok_or(())?,
+            });
+            s.obj_shadows.push(shadows as u8);
+            s.obj_volumetric.push(volumetric as u8);
+            let (angle, dir) = spot.unwrap_or((0.0, [0.0; 3]));
+            let (sin, cos) = ops_sin_cos(angle);
+            s.obj_spot_dir.extend_from_slice(&dir);
+            s.obj_spot_sin_cos.extend_from_slice(&[sin, cos]);
+            s.obj_entity.push(entity);
+            Ok(())
+        };
+        for (e, t, vv, light, layers, vol) in point_lights.iter().filter(|q| q.2.get()) {
+            push(s, e, t, light.range, ffi::MI_OBJ_POINT_LIGHT, layers, light.shadow_maps_enabled, vol.is_some(), None)?;
+            let _ = vv;
+        }
+        for (e, t, _, light, layers, vol) in spot_lights.iter().filter(|q| q.2.get()) {
+            // the column takes `GlobalTransform::back()` as the reference computes it (assign.rs:563-573)
+            let dir = t.back().to_array();
+            push(s, e, t, light.range, ffi::MI_OBJ_SPOT_LIGHT, layers, light.shadow_maps_enabled, vol.is_some(), Some((light.outer_angle, dir)))?;
+        }
+        for (e, t, _, light, layers) in rect_lights.iter().filter(|q| q.2.get()) {
+            push(s, e, t, light.range, ffi::MI_OBJ_RECT_LIGHT, layers, false, false, None)?;
+        }
+        if settings.supports_storage_buffers {
+            // probes and decals are clustered only with storage buffers (assign.rs:262-296); their range is the radius of the
+            // transformed unit cube, `transform.radius_vec3a(Vec3A::splat(0.5))`
+            for (e, t, _, is_environment_map) in light_probes.iter().filter(|q| q.2.get()) {
+                let kind = if is_environment_map { ffi::MI_OBJ_REFLECTION_PROBE } else { ffi::MI_OBJ_IRRADIANCE_VOLUME };
+                push(s, e, t, t.radius_vec3a(bevy_math::Vec3A::splat(0.5)), kind, None, false, false, None)?;
+            }
+            if settings.clustered_decals_are_usable {
+                for (e, t, _) in decals.iter().filter(|q| q.2.get()) {
+                    push(s, e, t, t.radius_vec3a(bevy_math::Vec3A::splat(0.5)), ffi::MI_OBJ_DECAL, None, false, false, None)?;
+                }
+            }
+        }
+
+        // --- the uniform-buffer limit: stable sort by (type, shadows, volumetric, entity) and truncate (assign.rs:298-356)
+        let n_all = s.obj_entity.len() as u32;
+        s.keys.clear();
+        s.keys.extend(s.obj_entity.iter().map(|e| e.to_bits()));
+        s.obj_order.resize(n_all as usize, 0);
+        let mut n_kept = 0u32;
+        // SAFETY: every input holds `n_all` entries, `out_order` too.
+        check(ctx, "mi_cluster_sort_truncate", unsafe {
+            ffi::mi_cluster_sort_truncate(
+                n_all,
+                s.obj_type.as_ptr(),
+                s.obj_shadows.as_ptr(),
+                s.obj_volumetric.as_ptr(),
+                s.keys.as_ptr(),
+                settings.max_uniform_buffer_clusterable_objects as u32,
+                settings.supports_storage_buffers as u32,
+                s.obj_order.as_mut_ptr(),
+                &mut n_kept,
+            )
+        })?;
+        let order = &s.obj_order[..n_kept as usize];
+        let pick = |src: &Vec<f32>, w: usize| -> Vec<f32> {
+            order.iter().flat_map(|&o| src[o as usize * w..(o as usize + 1) * w].iter().copied()).collect()
+        };
+        let pos_range = pick(&s.obj_pos_range, 4);
+        let spot_dir = pick(&s.obj_spot_dir, 3);
+        let spot_sin_cos = pick(&s.obj_spot_sin_cos, 2);
+        let obj_type: Vec<u8> = order.iter().map(|&o| s.obj_type[o as usize]).collect();
+        let obj_layers: Vec<u32> = order.iter().map(|&o| s.obj_layers[o as usize]).collect();
+        let entities: Vec<Entity> = order.iter().map(|&o| s.obj_entity[o as usize]).collect();
+        s.obj_entity = entities;
+        s.obj_type.clone_from(&obj_type);
+        // SAFETY: `n_kept` entries per column.
+        check(ctx, "mi_cluster_upload_objects", unsafe {
+            ffi::mi_cluster_upload_objects(
+                ctx,
+                n_kept,
+                pos_range.as_ptr(),
+                obj_type.as_ptr(),
+                obj_layers.as_ptr(),
+                spot_dir.as_ptr(),
+                spot_sin_cos.as_ptr(),
+            )
+        })?;
+
+        // --- per view: resolve the config, walk, fill, fetch
+        let mut results = Vec::new();
+        for (entity, camera_transform, camera, frustum, config, _, layers) in views.iter() {
+            let Some(screen) = camera.physical_viewport_size() else {
+                continue; // assign.rs:372-375: `clusters.clear()` is the caller's default below
+            };
+            let config = cluster_config_to_ffi(&config.copied().unwrap_or_default());
+            let history = mi.cluster_history.entry(entity).or_insert(ffi::MiClusterHistory {
+                has_farthest_z: 0,
+                farthest_z: 0.0,
+                has_total_cluster_index_count: 0,
+                reserved: 0,
+                total_cluster_index_count: 0,
+            });
+            let mut frustum12 = [0f32; 24];
+            for (p, half_space) in frustum.half_spaces.iter().enumerate() {
+                frustum12[p * 4..p * 4 + 4].copy_from_slice(&half_space.normal_d().to_array());
+            }
+            let camera_affine = camera_transform.affine().to_cols_array();
+            let clip_from_view = camera.clip_from_view().to_cols_array();
+            // SAFETY: a zeroed mi_cluster_view is a valid "empty" value (null plane pointers, zero dims).
+            let mut view: ffi::MiClusterView = unsafe { core::mem::zeroed() };
+            let mut active = 0u32;
+            // SAFETY: fixed-size arrays of the sizes the header states; `history` and `view` are live.
+            let status = unsafe {
+                ffi::mi_cluster_assign_frame(
+                    ctx,
+                    &config,
+                    history,
+                    camera_affine.as_ptr(),
+                    clip_from_view.as_ptr(),
+                    frustum12.as_ptr(),
+                    screen.x,
+                    screen.y,
+                    match layers {
+                        None => 1,
+                        Some(l) => layer_word(l).ok_or(())?,
+                    },
+                    settings.view_cluster_bindings_max_indices as u64,
+                    &mut view,
+                    &mut active,
+                )
+            };
+            check(ctx, "mi_cluster_assign_frame", status)?;
+            let n_clusters = (view.dims[0] * view.dims[1] * view.dims[2]) as usize;
+            let mut r = ViewResult {
+                entity,
+                view,
+                active: active != 0,
+                offsets: vec![0; n_clusters + 1],
+                counts: vec![0; n_clusters * 6],
+                indices: Vec::new(),
+                farthest_z: 0.0,
+                total: 0,
+            };
+            if r.active {
+                // the history already holds this frame's total (mi_cluster_assign_frame wrote it back, assign.rs:810-811)
+                r.indices.resize(history.total_cluster_index_count as usize, 0);
+                // SAFETY: offsets n+1, counts 6n, indices `capacity` entries.
+                let status = unsafe {
+                    ffi::mi_cluster_download(
+                        ctx,
+                        r.offsets.as_mut_ptr(),
+                        r.indices.as_mut_ptr(),
+                        r.indices.len() as u64,
+                        r.counts.as_mut_ptr(),
+                        &mut r.total,
+                        &mut r.farthest_z,
+                    )
+                };
+                check(ctx, "mi_cluster_download", status)?;
+            }
+            results.push(r);
+        }
+        Ok(results)
+    })();
+
+    let Ok(results) = result else {
+        fallback.clusters = true; // `Clusters` untouched; the gated stock set runs next
+        return;
+    };
+    for r in results {
+        let Ok((.., mut clusters, _)) = views.get_mut(r.entity) else { continue };
+        let history = mi.cluster_history[&r.entity];
+        clusters.tile_size = UVec2::from_array(r.view.tile_size);
+        clusters.dimensions = UVec3::from_array(r.view.dims);
+        clusters.near = r.view.near_;
+        clusters.far = r.view.far_;
+        clusters.last_frame_farthest_z = (history.has_farthest_z != 0).then_some(history.farthest_z);
+        clusters.last_frame_total_cluster_index_count =
+            (history.has_total_cluster_index_count != 0).then_some(history.total_cluster_index_count as usize);
+        let n_clusters = (r.view.dims[0] * r.view.dims[1] * r.view.dims[2]) as usize;
+        let mut per_cluster: Vec<ObjectsInClusterCpu> = Vec::with_capacity(n_clusters);
+        for c in 0..n_clusters {
+            let mut objects = ObjectsInClusterCpu::default();
+            if r.active {
+                // a cluster's list is in object order (ascending index), the order the reference's per-object loop makes its
+                // `add_*` calls in (assign.rs:560-800, cluster/mod.rs:479-512)
+                for &object in &r.indices[r.offsets[c] as usize..r.offsets[c + 1] as usize] {
+                    let entity = mi.scratch.obj_entity[object as usize];
+                    match mi.scratch.obj_type[object as usize] as i32 {
+                        ffi::MI_OBJ_POINT_LIGHT => objects.add_point_light(entity),
+                        ffi::MI_OBJ_SPOT_LIGHT => objects.add_spot_light(entity),
+                        ffi::MI_OBJ_RECT_LIGHT => objects.add_rect_light(entity),
+                        ffi::MI_OBJ_REFLECTION_PROBE => objects.add_reflection_probe(entity),
+                        ffi::MI_OBJ_IRRADIANCE_VOLUME => objects.add_irradiance_volume(entity),
+                        _ => objects.add_decal(entity),
+                    }
+                }
+                debug_assert_eq!(objects.counts.point_lights, r.counts[c * 6]);
+            }
+            per_cluster.push(objects);
+        }
+        clusters.clusterable_objects = ClusterableObjects::Cpu(per_cluster);
+    }
+}
+
+/// `bevy_math::ops::sin_cos` -- the libm the reference is built with decides the last bit of a spot light's cone; the column
+/// takes the host's values so that the device never evaluates sin/cos itself (include/bevy_mi355x.h, `spot_sin_cos`).
+fn ops_sin_cos(angle: f32) -> (f32, f32) {
+    bevy_math::ops::sin_cos(angle)
+}

@@ -117,7 +117,7 @@ ABI_SYMBOLS = [
     "mi_cluster_config_default", "mi_cluster_config_resolve", "mi_cluster_sort_truncate", "mi_cluster_bind_objects_to_rows",
     "mi_cluster_assign_frame",
     "mi_batch_upload_rows", "mi_batch_upload_sets", "mi_batch_build", "mi_batch_download_totals", "mi_batch_download", "mi_perspective_clip_from_view", "mi_compute_frustum",
-    "mi_bind_visibility_output", "mi_exchange_configure", "mi_exchange_configure_multi", "mi_exchange_last", "mi_device_buffer", "mi_timer_begin", "mi_timer_end", "mi_profile_enable",
+    "mi_bind_visibility_output", "mi_exchange_set_mode", "mi_exchange_configure", "mi_exchange_configure_multi", "mi_exchange_last", "mi_device_buffer", "mi_timer_begin", "mi_timer_end", "mi_profile_enable",
     "mi_profile_filter", "mi_profile_sample", "mi_profile_burst", "mi_profile_read", "mi_profile_kernel_name",
 ]
 
@@ -582,6 +582,10 @@ class Context:
         self._ck(self._lib.mi_exchange_configure_multi(self._h, carr, len(comms), C.c_void_p(fn_all_gather), arr, len(bufs),
                                                        C.c_uint64(words_per_view), C.c_uint64(word_offset),
                                                        C.c_uint64(block_bytes), C.c_uint32(rank)))
+
+    def exchange_set_mode(self, mode):
+        """0 = MI_EXCHANGE_SIMPLE (default), 1 = MI_EXCHANGE_PIPELINED; before exchange_configure."""
+        self._ck(self._lib.mi_exchange_set_mode(self._h, int(mode)))
 
     def exchange_last(self, wait=True):
         p = C.c_void_p()

@@ -273,13 +273,13 @@ int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg, 
         // per-class segment masks live in the frame set; a single caller-bound buffer (mi_bind_visibility_output
         // without the exchange) read as the segment mask does not -- compact inline then.
         const bool masks_alternate = !ctx->ext_bitmask || ctx->xch.on || seg.seg_mask != nullptr;
-        if ((flags & MI_CULL_MORE_FRAMES) && masks_alternate && (!ctx->xch.on || ctx->xch.kernel_signal)) {
+        if ((flags & MI_CULL_MORE_FRAMES) && masks_alternate && (!ctx->xch.on || ctx->xch.kernel_signal || ctx->xch.simple)) {
             // Another frame follows at once: this frame's compaction rides in extra workgroups of that frame's kernel (one
             // launch per frame instead of two); compaction_join launches it on its own if something else comes first.
             // With the exchange on it still publishes "this frame's masks are complete", and the frame's all-gather is
             // queued when that launch is submitted.
             ctx->defer.has_job = false;
-            if (ctx->xch.on) {
+            if (ctx->xch.on && !ctx->xch.simple) {
                 auto& x = ctx->xch;
                 f.signal = x.kernels_flag;
                 f.signal_value = (uint32_t)(x.frame + 1);
@@ -292,7 +292,7 @@ int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg, 
             ctx->defer.pending = true;
             return MI_OK;
         }
-        if (ctx->xch.on && ctx->xch.kernel_signal) {
+        if (ctx->xch.on && !ctx->xch.simple && ctx->xch.kernel_signal) {
             f.signal = ctx->xch.kernels_flag;
             f.signal_value = (uint32_t)(ctx->xch.frame + 1);
             ctx->xch.wait_flag = f.signal;
@@ -492,6 +492,7 @@ int32_t mi_ctx_create(int32_t device, void* hip_stream, mi_ctx** out_ctx) {
         return fail(nullptr, MI_ERR_DEVICE, "raising the LDS limit of the clustering kernel failed: %s", msg.c_str());
     }
     ctx->level_offsets = {0, 0};
+    ctx->xch.debug = getenv("MI_XCH_DEBUG") != nullptr;  // the one environment knob left: read once, here
     *out_ctx = ctx;
     return MI_OK;
 }
@@ -530,7 +531,7 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
     if (ctx->timer_a) hipEventDestroy(ctx->timer_a);
     if (ctx->timer_b) hipEventDestroy(ctx->timer_b);
     exchange_stop(ctx);
-    if (getenv("MI_XCH_DEBUG") && ctx->xch.frame)
+    if (ctx->xch.debug && !ctx->xch.simple && ctx->xch.frame)
         fprintf(stderr, "[mi exchange] frames %llu: begin %.2f us (wait-issued %.2f us), end %.2f us, worker %.2f us per frame\n",
                 (unsigned long long)ctx->xch.frame, ctx->xch.dbg_begin_ns / ctx->xch.frame / 1e3, ctx->xch.dbg_wait_ns / ctx->xch.frame / 1e3,
                 ctx->xch.dbg_end_ns / ctx->xch.frame / 1e3, ctx->xch.dbg_worker_ns / ctx->xch.frame / 1e3);
@@ -539,6 +540,7 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
             if (cs) hipStreamSynchronize(cs);
         for (uint32_t i = 0; i < mi_ctx::Exchange::MAX_BUFS; ++i) {
             if (ctx->xch.ev_gathered[i]) hipEventDestroy(ctx->xch.ev_gathered[i]);
+            if (ctx->xch.ev_kernels[i]) hipEventDestroy(ctx->xch.ev_kernels[i]);
         }
         for (hipStream_t cs : ctx->xch.comm_stream)
             if (cs) hipStreamDestroy(cs);
@@ -567,7 +569,7 @@ int32_t mi_synchronize(mi_ctx* ctx) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->cl_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->cl_stream));
     ctx->cl_on_side = false;
-    if (ctx->xch.on) {
+    if (ctx->xch.on && !ctx->xch.simple) {
         int32_t rc = exchange_wait_issued(ctx, ctx->xch.frame);
         if (rc) return rc;
     }

@@ -91,6 +91,9 @@ struct mi_ctx {
     // multi-GPU exchange (mi_exchange_configure): in-place all-gather of the masks after every cull
     struct Exchange {
         bool on = false;
+        bool simple = true;      // MI_EXCHANGE_SIMPLE (default) / MI_EXCHANGE_PIPELINED
+        bool debug = false;      // MI_XCH_DEBUG, read once at mi_ctx_create
+        hipEvent_t ev_kernels[8] = {nullptr};  // simple mode: recorded behind each frame's kernels on the compute stream
         int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;  // ncclAllGather
         // Up to MAX_COMMS communicators, used round-robin by frame, each on its own stream: the all-gathers of
         // consecutive frames are then in flight together (a ~125 KB all-gather over 8 GPUs is pure latency, and one

@@ -53,7 +53,7 @@ int32_t pick_side_streams(mi_ctx* ctx, hipStream_t* out, uint32_t n_keep, bool* 
             HIP_TRY(ctx, hipStreamSynchronize(cand[i]));
             const double t = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
             if (rep == 1) cand_t[i] = t;
-            if (getenv("MI_XCH_DEBUG")) fprintf(stderr, "[mi side stream] candidate %d%s: %.1f us / frame\n", i,
+            if (ctx->xch.debug) fprintf(stderr, "[mi side stream] candidate %d%s: %.1f us / frame\n", i,
                                                 i == N_CAND - 1 ? " (high priority)" : "", t / 24.0);
         }
     HIP_TRY(ctx, hipFree(probe));
@@ -73,7 +73,7 @@ int32_t pick_side_streams(mi_ctx* ctx, hipStream_t* out, uint32_t n_keep, bool* 
         if (shares[i]) w[0] = 1;  // release the wait from the host: the compute stream's write is stuck behind it
         HIP_TRY(ctx, hipStreamSynchronize(cand[i]));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (getenv("MI_XCH_DEBUG")) fprintf(stderr, "[mi side stream] candidate %d %s the compute stream's hardware queue\n", i,
+        if (ctx->xch.debug) fprintf(stderr, "[mi side stream] candidate %d %s the compute stream's hardware queue\n", i,
                                             shares[i] ? "SHARES" : "does not share");
     }
     HIP_TRY(ctx, hipHostFree(flag));
@@ -171,6 +171,14 @@ int32_t exchange_begin(mi_ctx* ctx) {
     auto& x = ctx->xch;
     if (!x.on) return MI_OK;
     const uint32_t slot = (uint32_t)(x.frame % x.n_bufs);
+    if (x.simple) {
+        // the buffer was last used n_bufs frames ago: its all-gather must have drained before the kernels overwrite it
+        if (x.frame >= x.n_bufs) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, x.ev_gathered[slot], 0));
+        ctx->ext_bitmask = x.buf[slot];
+        ctx->ext_words_per_view = x.words_per_view;
+        ctx->ext_word_offset = x.word_offset;
+        return MI_OK;
+    }
     const auto tb0 = std::chrono::steady_clock::now();
     struct Acc { double& d; std::chrono::steady_clock::time_point t; ~Acc() { d += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t).count(); } } acc{x.dbg_begin_ns, tb0};
     if (x.frame >= x.n_bufs) {
@@ -222,6 +230,17 @@ int32_t exchange_end(mi_ctx* ctx) {
     auto& x = ctx->xch;
     if (!x.on) return MI_OK;
     const uint32_t slot = (uint32_t)(x.frame % x.n_bufs);
+    if (x.simple) {
+        // masks complete = everything enqueued so far on the compute stream (a deferred compaction is not: it only reads them)
+        HIP_TRY(ctx, hipEventRecord(x.ev_kernels[slot], ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(x.comm_stream[0], x.ev_kernels[slot], 0));
+        char* base = (char*)x.buf[slot];
+        const int err = x.all_gather(base + (size_t)x.rank * x.block_bytes, base, (size_t)x.block_bytes, 1 /* ncclUint8 */, x.comm[0], x.comm_stream[0]);
+        if (err) return fail(ctx, MI_ERR_DEVICE, "ncclAllGather failed (%d)", err);
+        HIP_TRY(ctx, hipEventRecord(x.ev_gathered[slot], x.comm_stream[0]));
+        ++x.frame;
+        return MI_OK;
+    }
     const auto te0 = std::chrono::steady_clock::now();
     if (!x.signalled) {  // nobody announces this frame's masks in-kernel: a write-value packet behind its kernels does
         x.wait_flag = x.kernels_flag;
@@ -258,6 +277,14 @@ int32_t mi_bind_visibility_output(mi_ctx* ctx, void* device_ptr, uint64_t words_
     return MI_OK;
 }
 
+int32_t mi_exchange_set_mode(mi_ctx* ctx, uint32_t mode) {
+    ENTER(ctx);
+    if (mode > MI_EXCHANGE_PIPELINED) return fail(ctx, MI_ERR_INVALID_ARG, "mi_exchange_set_mode: unknown mode %u", mode);
+    if (ctx->xch.on) return fail(ctx, MI_ERR_NOT_READY, "mi_exchange_set_mode: switch the exchange off first (mi_exchange_configure with a NULL communicator)");
+    ctx->xch.simple = mode == MI_EXCHANGE_SIMPLE;
+    return MI_OK;
+}
+
 int32_t mi_exchange_configure(mi_ctx* ctx, void* nccl_comm, void* fn_nccl_all_gather, void* const* device_bufs, uint32_t n_bufs,
                               uint64_t words_per_view, uint64_t word_offset, uint64_t block_bytes, uint32_t rank) {
     void* comms[1] = {nccl_comm};
@@ -279,7 +306,7 @@ int32_t mi_exchange_configure_multi(mi_ctx* ctx, void* const* nccl_comms, uint32
     for (uint32_t k = 0; k < n_comms; ++k)
         if (!nccl_comms[k]) return fail(ctx, MI_ERR_INVALID_ARG, "mi_exchange_configure: communicator %u is NULL", k);
     if (x.on) {  // drain whatever is in flight before changing anything
-        int32_t rc0 = exchange_wait_issued(ctx, x.frame);
+        int32_t rc0 = x.worker.joinable() ? exchange_wait_issued(ctx, x.frame) : MI_OK;
         exchange_stop(ctx);
         for (hipStream_t cs : x.comm_stream)
             if (cs) HIP_TRY(ctx, hipStreamSynchronize(cs));
@@ -296,11 +323,33 @@ int32_t mi_exchange_configure_multi(mi_ctx* ctx, void* const* nccl_comms, uint32
         return fail(ctx, MI_ERR_INVALID_ARG, "mi_exchange_configure: NULL function / buffers, n_bufs outside 2..8, or empty block");
     for (uint32_t i = 0; i < n_bufs; ++i)
         if (!device_bufs[i]) return fail(ctx, MI_ERR_INVALID_ARG, "mi_exchange_configure: buffer %u is NULL", i);
+    if (x.simple) {
+        if (!x.comm_stream[0]) HIP_TRY(ctx, hipStreamCreateWithFlags(&x.comm_stream[0], hipStreamNonBlocking));
+        for (uint32_t i = 0; i < mi_ctx::Exchange::MAX_BUFS; ++i) {
+            if (!x.ev_gathered[i]) HIP_TRY(ctx, hipEventCreateWithFlags(&x.ev_gathered[i], hipEventDisableTiming));
+            if (!x.ev_kernels[i]) HIP_TRY(ctx, hipEventCreateWithFlags(&x.ev_kernels[i], hipEventDisableTiming));
+        }
+        x.all_gather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))fn_nccl_all_gather;
+        x.n_comms = 1;  // one communicator: the first one given
+        x.comm[0] = nccl_comms[0];
+        x.n_bufs = n_bufs;
+        for (uint32_t i = 0; i < n_bufs; ++i) x.buf[i] = device_bufs[i];
+        x.words_per_view = words_per_view;
+        x.word_offset = word_offset;
+        x.block_bytes = block_bytes;
+        x.rank = rank;
+        x.frame = 0;
+        x.kernel_signal = false;
+        x.signalled = false;
+        x.on = true;
+        ctx->culled = false;
+        return MI_OK;
+    }
     if (!x.done_flag) HIP_TRY(ctx, hipHostMalloc((void**)&x.done_flag, 64, hipHostMallocMapped));
     if (!x.kernels_flag) HIP_TRY(ctx, hipMalloc((void**)&x.kernels_flag, 64));
     HIP_TRY(ctx, hipMemsetAsync(x.kernels_flag, 0, 64, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    x.kernel_signal = getenv("MI_XCH_NO_KERNEL_SIGNAL") == nullptr;
+    x.kernel_signal = true;
     x.signalled = false;
     if (!x.comm_stream[0]) {
         for (uint32_t i = 0; i < mi_ctx::Exchange::MAX_BUFS; ++i) {
@@ -338,7 +387,7 @@ int32_t mi_exchange_last(mi_ctx* ctx, void** out_device_buf, int32_t wait) {
     const uint32_t slot = (uint32_t)((x.frame - 1) % x.n_bufs);
     int32_t rc = compaction_join(ctx);  // asynchronous compaction: also what releases the last frame's all-gather
     if (rc) return rc;
-    if ((rc = exchange_wait_issued(ctx, x.frame))) return rc;
+    if (!x.simple && (rc = exchange_wait_issued(ctx, x.frame))) return rc;
     if (wait) HIP_TRY(ctx, hipEventSynchronize(x.ev_gathered[slot]));
     if (out_device_buf) *out_device_buf = x.buf[slot];
     return MI_OK;

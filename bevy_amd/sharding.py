@@ -72,7 +72,7 @@ class MaskGatherer:
     On CPU tensors (gloo tests) it always uses torch.distributed.
     """
 
-    def __init__(self, n_rows, world, n_views, rank, device=None, direct=True, group=None, n_bufs=4, n_comms=None):
+    def __init__(self, n_rows, world, n_views, rank, device=None, direct=True, group=None, n_bufs=4, n_comms=None, pipelined=None):
         import torch
         self.torch = torch
         self.world, self.rank, self.n_views, self.n_rows, self.group = world, rank, n_views, n_rows, group
@@ -87,8 +87,13 @@ class MaskGatherer:
         self.ev_gathered = [torch.cuda.Event() for _ in range(n_bufs)] if self.on_gpu else None
         self.rccl = None
         self.comms = []
-        # two communicators, used alternately by frame: consecutive all-gathers are in flight together (MI_XCH_COMMS=1..4)
-        self.n_comms = int(os.environ.get("MI_XCH_COMMS", "2")) if n_comms is None else n_comms
+        # How the library drives the exchange when it is attached to a context (mi_exchange_set_mode): the SIMPLE mode -- one
+        # communicator, one stream, event-ordered -- unless pipelined=True / MI_XCH_MODE=pipelined asks for the round-1
+        # machinery (exchange thread, alternating communicators (MI_XCH_COMMS=1..4, default 2), kernel-signalled completion),
+        # which has only ever been measured against a 1-rank communicator.
+        self.pipelined = (os.environ.get("MI_XCH_MODE", "simple") == "pipelined") if pipelined is None else bool(pipelined)
+        default_comms = "2" if self.pipelined else "1"
+        self.n_comms = int(os.environ.get("MI_XCH_COMMS", default_comms)) if n_comms is None else n_comms
         self.n_comms = max(1, min(4, self.n_comms))
         self.native = False
         self.mode = "torch.distributed"
@@ -119,9 +124,10 @@ class MaskGatherer:
             return False
         import ctypes as C
         fn = C.cast(self.rccl.ncclAllGather, C.c_void_p).value
+        ctx.exchange_set_mode(1 if self.pipelined else 0)
         ctx.exchange_configure([c.value for c in self.comms], fn, [b.data_ptr() for b in self.bufs], self.w, self.rank * self.block,
                                self.block * 8, self.rank)
-        self.mode = "rccl-native"
+        self.mode = "rccl-native-pipelined" if self.pipelined else "rccl-native"
         self.native = True
         return True
 

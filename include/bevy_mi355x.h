@@ -560,6 +560,20 @@ int32_t mi_bind_visibility_output(mi_ctx* ctx, void* device_ptr, uint64_t words_
  *   device_bufs[n_bufs]  2..8 [world][n_views][words_per_view] uint64 buffers on this device (3+ recommended)
  *   word_offset          rank * n_views * words_per_view;  block_bytes = n_views * words_per_view * 8
  * The reference has no counterpart (single process); this replaces nothing and adds the only collective. */
+/* How the library drives the exchange (set before mi_exchange_configure; default MI_EXCHANGE_SIMPLE):
+ *   MI_EXCHANGE_SIMPLE     one communicator, one library-owned communication stream, plain event ordering: an event behind the
+ *                          frame's kernels, ncclAllGather enqueued by the calling thread on the communication stream, and the
+ *                          compute stream waits for a buffer's previous all-gather (hipStreamWaitEvent) before its kernels
+ *                          overwrite it.  Nothing clever, nothing that has only ever been measured on one GPU.
+ *   MI_EXCHANGE_PIPELINED  the latency-hiding variant built in round 1 against a 1-rank communicator: a library-owned host
+ *                          thread enqueues the collectives, several communicators alternate by frame, the "masks complete"
+ *                          signal is stored by the compaction kernel itself and awaited with hipStreamWaitValue32, buffer reuse
+ *                          is paced on the host, the communication stream is picked by probing the hardware-queue mapping.
+ *                          Its motivating numbers are 1-GPU measurements (DESIGN.md section 6 lists them as hypotheses); use it
+ *                          once an N > 1 measurement says it pays. */
+#define MI_EXCHANGE_SIMPLE 0u
+#define MI_EXCHANGE_PIPELINED 1u
+int32_t mi_exchange_set_mode(mi_ctx* ctx, uint32_t mode);
 int32_t mi_exchange_configure(mi_ctx* ctx, void* nccl_comm, void* fn_nccl_all_gather, void* const* device_bufs,
                               uint32_t n_bufs, uint64_t words_per_view, uint64_t word_offset, uint64_t block_bytes,
                               uint32_t rank);

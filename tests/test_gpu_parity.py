@@ -557,8 +557,8 @@ def test_one_million_flat_entities(ctx_factory):
     assert np.array_equal(rows, np.nonzero(vis_exp[0])[0].astype(np.uint32))
 
 
-@pytest.mark.parametrize("n_comms,more", [(1, 0), (2, 0), (2, 4), (3, 4)])
-def test_mask_gatherer_single_rank_pipeline(ctx_factory, n_comms, more):
+@pytest.mark.parametrize("n_comms,more,pipelined", [(1, 0, False), (1, 4, False), (1, 0, True), (2, 0, True), (2, 4, True), (3, 4, True)])
+def test_mask_gatherer_single_rank_pipeline(ctx_factory, n_comms, more, pipelined):
     """The pipelined exchange bench.py uses for N > 1, on one rank: kernels write their masks in place into the
     gatherer's alternating buffers and the (1-rank) all-gather runs on the communication stream -- through RCCL
     directly when the library can be set up on this box, else through torch.distributed."""
@@ -568,7 +568,7 @@ def test_mask_gatherer_single_rank_pipeline(ctx_factory, n_comms, more):
     sc = W.many_cubes(n, ragged_flags=True)
     ctx = ctx_factory()
     upload_scene(ctx, sc)
-    g = sharding.MaskGatherer(n, 1, n_views, 0, device=torch.device("cuda", 0), n_comms=n_comms)
+    g = sharding.MaskGatherer(n, 1, n_views, 0, device=torch.device("cuda", 0), n_comms=n_comms, pipelined=pipelined)
     assert g.mode in ("rccl-direct", "torch.distributed"), g.mode
     assert g.mode != "rccl-direct" or len(g.comms) == n_comms
     vv = np.zeros(n, np.uint8)
@@ -594,7 +594,7 @@ def test_mask_gatherer_single_rank_pipeline(ctx_factory, n_comms, more):
     ctx2 = ctx_factory()
     upload_scene(ctx2, sc)
     if g.attach(ctx2):
-        assert g.mode == "rccl-native"
+        assert g.mode == ("rccl-native-pipelined" if pipelined else "rccl-native")
         # more = MI_CULL_MORE_FRAMES: ignored while the exchange is on (the inline compaction carries its signal)
         vv = np.zeros(n, np.uint8)
         for frame in range(5):

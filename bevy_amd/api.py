@@ -102,6 +102,11 @@ def make_views(frusta, layer_masks=None, flags=None, positions=None, light_spher
 _lib = None
 
 # every symbol include/bevy_mi355x.h declares (tests/test_abi.py checks header <-> library <-> this list)
+BATCH_ROW_MULTIDRAWABLE, BATCH_ROW_BATCHABLE, BATCH_ROW_UNBATCHABLE, BATCH_ROW_NONE = 0, 1, 2, 3
+BATCH_NO_INDIRECT_DRAWING = 0x1
+SORTED_AUTOMATIC_BATCHING, SORTED_NO_INDIRECT_DRAWING, SORTED_NO_GPU_PREPROCESSING = 0x1, 0x2, 0x4
+NO_INPUT_INDEX = 0xFFFFFFFF
+
 ABI_SYMBOLS = [
     "mi_abi_version", "mi_ctx_create", "mi_ctx_destroy", "mi_last_error_string", "mi_synchronize",
     "mi_columns_resize", "mi_upload_transforms", "mi_upload_transforms_indexed", "mi_upload_global_transforms", "mi_upload_bounds",
@@ -116,7 +121,8 @@ ABI_SYMBOLS = [
     "mi_cluster_assign_resident", "mi_cluster_download", "mi_cluster_download_bindings",
     "mi_cluster_config_default", "mi_cluster_config_resolve", "mi_cluster_sort_truncate", "mi_cluster_bind_objects_to_rows",
     "mi_cluster_assign_frame",
-    "mi_batch_upload_rows", "mi_batch_upload_sets", "mi_batch_build", "mi_batch_download_totals", "mi_batch_download", "mi_perspective_clip_from_view", "mi_compute_frustum",
+    "mi_batch_upload_rows", "mi_batch_upload_sets", "mi_batch_upload_row_bins", "mi_batch_upload_bins", "mi_batch_build", "mi_batch_build_phase",
+    "mi_batch_sorted_build", "mi_batch_download_totals", "mi_batch_download", "mi_perspective_clip_from_view", "mi_compute_frustum",
     "mi_bind_visibility_output", "mi_exchange_set_mode", "mi_exchange_configure", "mi_exchange_configure_multi", "mi_exchange_last", "mi_device_buffer", "mi_timer_begin", "mi_timer_end", "mi_profile_enable",
     "mi_profile_filter", "mi_profile_sample", "mi_profile_burst", "mi_profile_read", "mi_profile_kernel_name",
 ]
@@ -541,15 +547,38 @@ class Context:
         self._ck(self._lib.mi_batch_upload_sets(self._h, len(si), _ptr(si, C.c_uint8), _ptr(bto, C.c_uint32), _ptr(bt, C.c_uint32),
                                                 _ptr(mo, C.c_uint32), bm.ctypes.data_as(C.c_void_p) if bm.size else None))
 
-    def batch_build(self, view=0, class_bit=0, initial=None):
+    def batch_upload_row_bins(self, kind, cpu_bin, first_row=0):
+        """Per row: MI_BATCH_ROW_* and, for batchable / unbatchable rows, the bin (gpu_preprocessing.rs:2135-2357)."""
+        k = np.ascontiguousarray(kind, np.uint8)
+        b = _u32(cpu_bin)
+        self._ck(self._lib.mi_batch_upload_row_bins(self._h, first_row, len(k), _ptr(k, C.c_uint8), _ptr(b, C.c_uint32)))
+
+    def batch_upload_bins(self, unbatchable_indexed, batchable_indexed):
+        u = np.ascontiguousarray(unbatchable_indexed, np.uint8)
+        b = np.ascontiguousarray(batchable_indexed, np.uint8)
+        self._ck(self._lib.mi_batch_upload_bins(self._h, len(u), _ptr(u, C.c_uint8) if len(u) else None, len(b),
+                                                _ptr(b, C.c_uint8) if len(b) else None))
+
+    def batch_build(self, view=0, class_bit=0, initial=None, no_indirect_drawing=False):
         """initial: 7 ints (work_item_index[2], indirect_parameters_index[2], batch_set_index[2], output_mesh_uniform_index)."""
         ini = None if initial is None else (C.c_uint32 * 7)(*[int(x) for x in initial])
-        self._ck(self._lib.mi_batch_build(self._h, view, class_bit, ini))
+        if no_indirect_drawing:
+            self._ck(self._lib.mi_batch_build_phase(self._h, view, class_bit, ini, C.c_uint32(BATCH_NO_INDIRECT_DRAWING)))
+        else:
+            self._ck(self._lib.mi_batch_build(self._h, view, class_bit, ini))
+
+    def batch_sorted_build(self, items, automatic_batching=True, no_indirect_drawing=False, no_gpu_preprocessing=False, initial=None):
+        """items u32[n, 4] = (input_index, batch_set_key, bin_key, flags) in the phase's sorted order."""
+        it = np.ascontiguousarray(items, np.uint32).reshape(-1, 4)
+        ini = None if initial is None else (C.c_uint32 * 7)(*[int(x) for x in initial])
+        flags = (SORTED_AUTOMATIC_BATCHING if automatic_batching else 0) | (SORTED_NO_INDIRECT_DRAWING if no_indirect_drawing else 0) \
+            | (SORTED_NO_GPU_PREPROCESSING if no_gpu_preprocessing else 0)
+        self._ck(self._lib.mi_batch_sorted_build(self._h, len(it), it.ctypes.data_as(C.c_void_p) if len(it) else None, ini, C.c_uint32(flags)))
 
     def batch_download(self):
-        """-> dict: work_items / metadata / batch_sets (lists indexed by mesh class, u32 arrays), records u32[k, 8], totals,
-        bin_metadata."""
-        tot = (C.c_uint32 * 8)()
+        """-> dict: work_items / metadata / batch_sets (lists indexed by mesh class, u32 arrays), records u32[k, 8], unbatchable
+        u32[k, 2], batches u32[k, 6] (sorted builds), totals, bin_metadata."""
+        tot = (C.c_uint32 * 9)()
         self._ck(self._lib.mi_batch_download_totals(self._h, tot))
 
         def get(what, cls, words):
@@ -560,6 +589,7 @@ class Context:
             return out[:cnt.value]
         return dict(work_items=[get(0, c, 2) for c in range(2)], metadata=[get(1, c, 5) for c in range(2)],
                     batch_sets=[get(2, c, 2) for c in range(2)], records=get(3, 0, 8), bin_metadata=get(4, 0, 3),
+                    unbatchable=get(5, 0, 2), batches=get(6, 0, 6),
                     totals=dict(work_item_len=[tot[0], tot[1]], indirect_parameters_len=[tot[2], tot[3]],
                                 batch_set_len=[tot[4], tot[5]], data_buffer_len=int(tot[6])))
 

@@ -511,7 +511,8 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
     prof_collect(ctx);
     void* cols[] = {ctx->t, ctx->r, ctx->s, ctx->g, ctx->c, ctx->h, ctx->flags, ctx->vv, ctx->changed, ctx->g_changed_bytes,
                     ctx->layers, ctx->class_mask, ctx->keys, ctx->g_chg_bits, ctx->vv_chg_bits, ctx->tree_bits,
-                    ctx->range, ctx->visibility, ctx->inh_changed, ctx->bt_set, ctx->bt_bin, ctx->bt_input, ctx->bt_row_meta};
+                    ctx->range, ctx->visibility, ctx->inh_changed, ctx->bt_set, ctx->bt_bin, ctx->bt_input, ctx->bt_row_meta,
+                    ctx->bt_kind, ctx->bt_cpu_bin, ctx->bt_bucket};
     for (void* p : cols)
         if (p) hipFree(p);
     DevBuf* bufs[] = {&ctx->order, &ctx->chains, &ctx->snap, &ctx->inh_bits, &ctx->sparse_cnt, &ctx->sparse_rows, &ctx->sparse_total, &ctx->sparse_g, &ctx->parent_idx, &ctx->node_flags, &ctx->tiles, &ctx->views,
@@ -519,7 +520,8 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
                       &ctx->cl_type, &ctx->cl_layers, &ctx->cl_dir, &ctx->cl_sincos, &ctx->cl_planes, &ctx->cl_spheres,
                       &ctx->bt_set_indexed, &ctx->bt_table_off, &ctx->bt_table, &ctx->bt_meta_off, &ctx->bt_meta, &ctx->bt_rows_a, &ctx->bt_rows_b,
                       &ctx->bt_hist, &ctx->bt_set_count, &ctx->bt_set_scan, &ctx->bt_counters, &ctx->bt_wi[0], &ctx->bt_wi[1], &ctx->bt_md[0],
-                      &ctx->bt_md[1], &ctx->bt_bs[0], &ctx->bt_bs[1], &ctx->bt_records, &ctx->bt_totals,
+                      &ctx->bt_md[1], &ctx->bt_bs[0], &ctx->bt_bs[1], &ctx->bt_records, &ctx->bt_totals, &ctx->bt_bucket_desc, &ctx->bt_meta_out,
+                      &ctx->bt_inst[0], &ctx->bt_inst[1], &ctx->bt_plan, &ctx->bt_unb, &ctx->bt_items, &ctx->bt_sorted_scratch, &ctx->bt_batches,
                       &ctx->cl_remap, &ctx->cl_bind_oc, &ctx->cl_bind_idx, &ctx->cl_block_counts, &ctx->cl_pair_cb, &ctx->cl_pair_mask, &ctx->cl_acc,
                       &ctx->cl_offsets, &ctx->cl_indices, &ctx->cl_scalars};
     for (DevBuf* b : bufs)
@@ -621,6 +623,9 @@ int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
         if ((rc = grow_column(ctx, ctx->bt_bin, 1, old, new_cap, 0))) return rc;
         if ((rc = grow_column(ctx, ctx->bt_input, 1, old, new_cap, 0))) return rc;
         if ((rc = grow_column(ctx, ctx->bt_row_meta, 1, old, new_cap, 0xFF))) return rc;
+        if ((rc = grow_column(ctx, ctx->bt_kind, 1, old, new_cap, 0))) return rc;  // MI_BATCH_ROW_MULTIDRAWABLE
+        if ((rc = grow_column(ctx, ctx->bt_cpu_bin, 1, old, new_cap, 0))) return rc;
+        if ((rc = grow_column(ctx, ctx->bt_bucket, 1, old, new_cap, 0xFF))) return rc;
         // default RenderLayers = layer 0 (mask 1) for rows never uploaded
         {
             std::vector<uint32_t> ones(new_cap - old, 1u);
@@ -655,7 +660,8 @@ int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
             {ctx->t, 12, 0}, {ctx->r, 16, 0}, {ctx->s, 12, 0}, {ctx->g, 48, 0}, {ctx->c, 12, 0}, {ctx->h, 12, 0},
             {ctx->flags, 1, MI_FLAG_INHERITED_VISIBLE}, {ctx->vv, 1, 0}, {ctx->changed, 1, 1}, {ctx->g_changed_bytes, 1, 0},
             {ctx->class_mask, 4, 0}, {ctx->keys, 8, 0}, {ctx->range, 8, 0}, {ctx->visibility, 1, 0}, {ctx->inh_changed, 1, 0},
-            {ctx->bt_set, 4, 0xFF}, {ctx->bt_bin, 4, 0}, {ctx->bt_input, 4, 0}, {ctx->bt_row_meta, 4, 0xFF}};
+            {ctx->bt_set, 4, 0xFF}, {ctx->bt_bin, 4, 0}, {ctx->bt_input, 4, 0}, {ctx->bt_row_meta, 4, 0xFF},
+            {ctx->bt_kind, 1, 0}, {ctx->bt_cpu_bin, 4, 0}, {ctx->bt_bucket, 4, 0xFF}};
         for (auto& cdesc : cols)
             if (cdesc.p) HIP_TRY(ctx, hipMemsetAsync((char*)cdesc.p + (size_t)lo * cdesc.elem, cdesc.fill, (size_t)cnt * cdesc.elem, ctx->stream));
         HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->layers + lo), 1, cnt, ctx->stream));  // default RenderLayers = layer 0
@@ -1262,8 +1268,8 @@ const char* mi_profile_kernel_name(uint32_t k) {
     static const char* names[K_NUM_KERNELS] = {"k_flat_propagate_cull", "k_level0_propagate", "k_cull", "k_vis_begin",
                                                "k_vis_end", "k_compact_count", "k_compact_scan", "k_compact_scatter",
                                                "k_compact_fast", "k_mark_dirty", "k_propagate_tiles", "k_cluster_walk", "k_cluster_fill",
-                                               "k_clear_u32", "k_inherit", "k_batch_clear", "k_batch_hist", "k_batch_scan",
-                                               "k_batch_scatter", "k_batch_bounds", "k_batch_sets", "k_batch_allocate", "k_batch_unpack", "k_propagate_stream"};
+                                               "k_clear_u32", "k_inherit", "k_batch_hist", "k_batch_plan", "k_batch_emit",
+                                               "k_batch_scan", "k_batch_scatter", "k_batch_bounds", "k_batch_sorted", "k_propagate_stream"};
     return k < K_NUM_KERNELS ? names[k] : nullptr;
 }
 

@@ -171,6 +171,13 @@ struct mi_ctx {
     DevBuf cl_pos, cl_type, cl_layers, cl_dir, cl_sincos, cl_planes, cl_spheres;
     // batching work-item build (kernels_batch.hip)
     uint32_t *bt_set = nullptr, *bt_bin = nullptr, *bt_input = nullptr, *bt_row_meta = nullptr;  // per-row columns
+    uint8_t* bt_kind = nullptr;                              // MI_BATCH_ROW_*
+    uint32_t *bt_cpu_bin = nullptr, *bt_bucket = nullptr;    // unbatchable / batchable bin; resolved bucket
+    std::vector<uint8_t> bt_unb_indexed, bt_bat_indexed, bt_set_indexed_host;
+    std::vector<uint32_t> bt_meta_zero;                      // the uploaded GpuBinMetadata with instance_count = 0
+    DevBuf bt_bucket_desc, bt_meta_out, bt_inst[2], bt_plan, bt_unb, bt_items, bt_sorted_scratch, bt_batches;
+    uint32_t bt_inst_cur = 0;
+    bool bt_desc_dirty = true, bt_desc_no_indirect = false, bt_last_sorted = false;
     bool bt_resolve = true;  // rows or tables changed: bt_row_meta must be recomputed
     DevBuf bt_set_indexed, bt_table_off, bt_table, bt_meta_off, bt_meta, bt_rows_a, bt_rows_b, bt_hist, bt_set_count, bt_set_scan,
         bt_counters, bt_wi[2], bt_md[2], bt_bs[2], bt_records, bt_totals;

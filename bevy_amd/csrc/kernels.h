@@ -112,14 +112,13 @@ enum KernelId : uint32_t {
     K_CLUSTER_FILL,
     K_CLEAR,
     K_INHERIT,
-    K_BATCH_CLEAR,
     K_BATCH_HIST,
+    K_BATCH_PLAN,
+    K_BATCH_EMIT,
     K_BATCH_SCAN,
     K_BATCH_SCATTER,
     K_BATCH_BOUNDS,
-    K_BATCH_SETS,
-    K_BATCH_ALLOCATE,
-    K_BATCH_UNPACK,
+    K_BATCH_SORTED,
     K_PROPAGATE_STREAM,
     K_NUM_KERNELS
 };
@@ -340,40 +339,54 @@ struct BatchArgs {
     const uint32_t* list;
     const uint32_t* list_count;
     const uint64_t* list_base;  // nullptr: `list` already points at the first entry
-    // per-row render-world columns
-    const uint32_t* row_set;
-    const uint32_t* row_bin;
+    // per-row render-world columns, resolved by k_batch_resolve_rows
+    const uint32_t* row_bucket;  // where the row goes (see kernels_batch.hip), BATCH_NO_SET = nowhere in this phase
     const uint32_t* row_input;
-    const uint32_t* row_meta;  // row -> index of its bin's metadata (k_batch_resolve_rows), 0xFFFFFFFF = names no bin
-    // the phase's batch sets
-    uint32_t n_sets, n_meta;
+    const uint32_t* row_meta;    // multidrawable row -> index of its bin's metadata, 0xFFFFFFFF = names no bin
+    // the phase's buckets: kind (2 bits) | mesh class (1 bit) | bin or set id << 3
+    uint32_t n_buckets, first_set_bucket, n_sets, n_meta, no_indirect;
+    const uint32_t* bucket_desc;
     const uint8_t* set_indexed;
-    const uint32_t* bin_table_offset;
-    const uint32_t* bin_table;
     const uint32_t* meta_offset;
-    uint32_t* bin_metadata;  // 3 words per bin: indirect_parameters_offset, bin_index, instance_count
+    const uint32_t* bin_meta_in;   // as uploaded, 3 words per bin: indirect_parameters_offset, bin_index, (ignored)
+    uint32_t* bin_metadata_out;    // the same with instance_count filled in
+    uint32_t* inst_count;          // [n_meta] zero on entry; the build's instance counts
+    uint32_t* inst_count_next;     // [n_meta] zeroed by this build for the next one
     // scratch
     uint32_t* rows_a;
     uint32_t* rows_b;
     uint32_t* tile_hist;     // [256][n_tiles]
     uint32_t n_tiles;
-    uint32_t* set_count;     // [2][n_sets]: start and end of the set's run in the partitioned list
-    uint32_t* set_scan;      // [5][n_sets]: start in the partitioned list, first work item, first indirect parameters,
-                             //              batch set index, first MeshUniform slot
-    uint32_t* counters;      // [0] batched entries of the list
+    uint32_t* set_count;     // two-pass only, [2][n_buckets]: start and end of the bucket's run in the partitioned list
+    uint32_t* plan;          // [7][n_buckets]: start in the partition, first MeshUniform slot, first work item, first indirect
+                             //                 parameters, first batch set, first unbatchable index, rows
+    uint32_t* counters;      // [0] entries of the list that are in some bucket
     // outputs, [0] non-indexed [1] indexed
     uint32_t* work_items[2];   // 2 words each
     uint32_t* metadata[2];     // 5 words each
     uint32_t* batch_sets[2];   // 2 words each
-    uint32_t* records;         // 8 words per non-empty batch set
-    uint32_t* totals;          // 8 words (mi_batch_totals)
+    uint32_t* unbatchable;     // 2 words per unbatchable entity with an input index: bin, instance index
+    uint32_t* records;         // 8 words per non-empty batchable bin / batch set
+    uint32_t* totals;          // 9 words (mi_batch_totals)
     BatchInitial initial;
 };
-// enqueues the whole build (clear, stable partition of the list by batch set, set bookkeeping, allocate_uniforms,
-// unpack_bins); `mark` is called before each kernel for profiling
-hipError_t launch_batch_resolve_rows(uint32_t n, uint32_t n_sets, const uint32_t* row_set, const uint32_t* row_bin,
+struct SortedArgs {
+    const uint32_t* items;     // 4 words per phase item: input index, batch-set key, bin key, flags
+    uint32_t n_items, automatic_batching, no_indirect, merge_only;
+    uint32_t* scratch;         // [8][n_items]
+    uint32_t* work_items[2];
+    uint32_t* metadata[2];
+    uint32_t* batch_sets[2];
+    uint32_t* batches;         // 6 words per batch set (mi_sorted_batch)
+    uint32_t* totals;          // 9 words
+    BatchInitial initial;
+};
+hipError_t launch_batch_resolve_rows(uint32_t n, uint32_t n_sets, uint32_t n_unbatchable, uint32_t n_batchable, const uint8_t* row_kind,
+                                     const uint32_t* row_cpu_bin, const uint32_t* row_set, const uint32_t* row_bin, const uint32_t* row_input,
                                      const uint32_t* bin_table_offset, const uint32_t* bin_table, const uint32_t* meta_offset,
-                                     uint32_t* row_meta, hipStream_t stream);
+                                     uint32_t* row_meta, uint32_t* row_bucket, hipStream_t stream);
+// enqueues the whole build (3 launches up to 256 buckets); `mark` is called before each kernel for profiling
 hipError_t launch_batch_build(const BatchArgs& a, hipStream_t stream, void (*mark)(void*, uint32_t), void* mark_ctx);
+hipError_t launch_batch_sorted(const SortedArgs& a, hipStream_t stream, void (*mark)(void*, uint32_t), void* mark_ctx);
 
 }  // namespace mi

@@ -1,25 +1,35 @@
 // kernels_batch.hip -- batching work-item build on gfx950.
 //
-// What the reference does for a view's phase (crates/bevy_render/src/batching/gpu_preprocessing.rs:2360-2447, :2497-2580):
-// for every multidrawable batch set, reserve a run of PreprocessWorkItems, MeshUniform slots and indirect-parameter slots
-// (CPU, O(1) per set), then two compute passes per set: allocate_uniforms.wesl (exclusive prefix of the bins' instance counts
-// -> IndirectParametersMetadata.base_output_index) and unpack_bins.wesl (one PreprocessWorkItem per binned mesh instance).
+// What the reference does for one view's binned phase (crates/bevy_render/src/batching/gpu_preprocessing.rs:2079-2455):
+//   CPU loops  unbatchable bins (:2148-2224), batchable bins (:2228-2353): per entity a MeshUniform slot and a PreprocessWorkItem,
+//              per unbatchable entity / per batchable bin an indirect-parameters slot and an IndirectBatchSet
+//   then       for every multidrawable batch set (:2360-2447, :2497-2580) a run of work items, MeshUniform slots and one
+//              indirect-parameters slot per bin, followed by two compute passes per set -- allocate_uniforms.wesl (exclusive prefix of
+//              the bins' instance counts -> IndirectParametersMetadata.base_output_index) and unpack_bins.wesl (one work item per
+//              binned mesh instance)
+// and for a sorted phase (:1850-2061) one walk over the items that cuts them into batch sets and batches.
 // The bins themselves are CPU hash maps kept in step with VisibleEntities (render_phase/mod.rs:268-400).
 //
-// Here the bins are derived on the device from the VisibleEntities list the cull pass left in HBM: per row the render
-// world uploads (batch set, RenderBinIndex, InputUniformIndex) once; a frame's build is
-//   1. k_batch_clear      zero the instance counts and the per-set bounds
-//   2. stable partition of the list by batch set (LSD radix on the set id, 8 bits per pass, 1 pass for <= 256 sets):
-//      k_batch_hist -> k_batch_scan -> k_batch_scatter; pass 0 also drops the rows that are not multidrawable and
-//      counts instances per bin (integer adds: order-independent, exact; pre-aggregated per 2048-row tile in an LDS
-//      hash table, because agent-scope atomics on one cache line serialise at ~25 ns each on this part and
-//      many_cubes has ONE bin)
-//      k_batch_bounds     where each set's run starts and ends in the partitioned list (no atomics)
-//   3. k_batch_sets       one workgroup: the O(1)-per-set CPU bookkeeping as exclusive scans over the sets
-//   4. k_batch_allocate   allocate_uniforms for every non-empty set (one workgroup per set, 256-bin chunks with carry)
-//   5. k_batch_unpack     unpack_bins over the partitioned list
-// The partition is stable, so a set's instances keep the list order (ascending Entity) -- the order the oracle uses;
-// the reference leaves that order unspecified (unpack_bins.wesl:31-33).
+// Here the bins are derived on the device from the VisibleEntities list the cull pass left in HBM.  Every place a listed row can
+// go is a BUCKET, numbered in the order the reference visits them:
+//     [2b, 2b+1]   unbatchable bin b: rows with / without an input uniform index (the latter only count towards allocate(len))
+//     [2U + b]     batchable bin b
+//     [2U + B + s] multidrawable batch set s
+// and every index the reference hands out while it walks is an exclusive prefix sum over the buckets.  A frame's build is
+//   1. k_batch_hist    per 2048-row tile: rows per bucket digit (LDS histogram), instances per multidrawable bin (integer adds:
+//                      order-independent, exact; pre-aggregated per tile in an LDS hash table, because agent-scope atomics on one
+//                      cache line serialise at ~25 ns each on this part and many_cubes has ONE bin)
+//   2. k_batch_plan    ONE workgroup: the partition offsets (scan of the tile histograms), then nine exclusive scans over the buckets
+//                      = all of the reference's per-bin / per-set bookkeeping: where each bucket's work items, MeshUniform slots,
+//                      indirect-parameters slots and batch sets start; the per-bucket outputs (batchable bins' metadata, batch sets,
+//                      records, buffer lengths)
+//   3. k_batch_emit    the stable scatter of the partition, except that a row's final position is not stored: position - bucket start
+//                      is the row's ordinal in its bin, which is all its work item (and, for an unbatchable entity, its metadata and
+//                      batch set) needs.  allocate_uniforms for every non-empty batch set rides along as extra workgroups.
+// Three launches when there are at most 256 buckets.  With more (up to 65 536) the partition takes two LSD passes and the last pass
+// stores the partitioned list (hist, scan, scatter, hist, scan, scatter, bounds, plan, emit-from-list): rare, not tuned.
+// The partition is stable, so a bucket's rows keep the list order (ascending Entity) -- the order the oracle uses; the reference
+// leaves the order inside a multidrawable set unspecified (unpack_bins.wesl:31-33).
 // Everything is u32; HBM traffic is a few words per visible row, the kernels are latency-, not bandwidth-bound.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,37 +39,45 @@
 namespace mi {
 namespace {
 
+constexpr uint32_t KIND_UNB_INPUT = 0, KIND_UNB_NO_INPUT = 1, KIND_BATCHABLE = 2, KIND_SET = 3;
+__device__ __forceinline__ uint32_t desc_kind(uint32_t d) { return d & 3u; }
+__device__ __forceinline__ uint32_t desc_cls(uint32_t d) { return (d >> 2) & 1u; }
+__device__ __forceinline__ uint32_t desc_id(uint32_t d) { return d >> 3; }
+
 __device__ __forceinline__ uint32_t list_len(const BatchArgs& a, bool pass0) { return pass0 ? *a.list_count : a.counters[0]; }
-__device__ __forceinline__ const uint32_t* list_src(const BatchArgs& a, uint32_t pass, uint32_t n_pass) {
+__device__ __forceinline__ const uint32_t* list_src(const BatchArgs& a, uint32_t pass) {
     if (pass == 0) return a.list + (a.list_base ? *a.list_base : 0ull);
-    (void)n_pass;
     return a.rows_a;
 }
-// final home of the partitioned list: rows_a after one pass, rows_b after two
-__device__ __forceinline__ uint32_t* list_dst(const BatchArgs& a, uint32_t pass) { return pass == 0 ? a.rows_a : a.rows_b; }
 
-// row -> index of its bin's GpuBinMetadata in the concatenated array (once per upload, not per frame)
-__global__ void __launch_bounds__(256) k_batch_resolve_rows(uint32_t n, uint32_t n_sets, const uint32_t* row_set, const uint32_t* row_bin,
+// row -> bucket and, for multidrawable rows, index of its bin's GpuBinMetadata in the concatenated array (once per upload)
+__global__ void __launch_bounds__(256) k_batch_resolve_rows(uint32_t n, uint32_t n_sets, uint32_t n_unbatchable, uint32_t n_batchable,
+                                                            const uint8_t* row_kind, const uint32_t* row_cpu_bin, const uint32_t* row_set,
+                                                            const uint32_t* row_bin, const uint32_t* row_input,
                                                             const uint32_t* bin_table_offset, const uint32_t* bin_table,
-                                                            const uint32_t* meta_offset, uint32_t* row_meta) {
+                                                            const uint32_t* meta_offset, uint32_t* row_meta, uint32_t* row_bucket) {
     const uint32_t row = blockIdx.x * 256u + threadIdx.x;
     if (row >= n) return;
-    const uint32_t s = row_set[row];
-    uint32_t m = 0u;
-    if (s < n_sets) {
-        const uint32_t slots = bin_table_offset[s + 1] - bin_table_offset[s], bins = meta_offset[s + 1] - meta_offset[s];
-        const uint32_t b = row_bin[row];
-        const uint32_t k = b < slots ? bin_table[bin_table_offset[s] + b] : 0xFFFFFFFFu;
-        m = k < bins ? meta_offset[s] + k : 0xFFFFFFFFu;  // a hole or an index out of range: the row is treated as unbatched
+    const uint32_t kind = row_kind[row];
+    uint32_t m = 0xFFFFFFFFu, bucket = BATCH_NO_SET;
+    if (kind == 2u) {  // MI_BATCH_ROW_UNBATCHABLE
+        const uint32_t b = row_cpu_bin[row];
+        if (b < n_unbatchable) bucket = 2u * b + (row_input[row] == 0xFFFFFFFFu ? 1u : 0u);
+    } else if (kind == 1u) {  // MI_BATCH_ROW_BATCHABLE
+        const uint32_t b = row_cpu_bin[row];
+        if (b < n_batchable) bucket = 2u * n_unbatchable + b;
+    } else if (kind == 0u) {
+        const uint32_t s = row_set[row];
+        if (s < n_sets) {
+            const uint32_t slots = bin_table_offset[s + 1] - bin_table_offset[s], bins = meta_offset[s + 1] - meta_offset[s];
+            const uint32_t b = row_bin[row];
+            const uint32_t k = b < slots ? bin_table[bin_table_offset[s] + b] : 0xFFFFFFFFu;
+            m = k < bins ? meta_offset[s] + k : 0xFFFFFFFFu;  // a hole or an index out of range: the row is treated as unbatched
+            if (m != 0xFFFFFFFFu) bucket = 2u * n_unbatchable + n_batchable + s;
+        }
     }
     row_meta[row] = m;
-}
-
-__global__ void __launch_bounds__(256) k_batch_clear(BatchArgs a) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < a.n_meta) a.bin_metadata[3u * i + 2u] = 0u;
-    if (i < 2u * a.n_sets) a.set_count[i] = 0u;  // [0][s] start, [1][s] end of the set's run
-    if (i < 4u) a.counters[i] = 0u;
+    row_bucket[row] = bucket;
 }
 
 constexpr uint32_t BIN_HASH = 512, BIN_HASH_EMPTY = 0xFFFFFFFFu;
@@ -77,10 +95,10 @@ __global__ void __launch_bounds__(256) k_batch_hist(BatchArgs a) {
         }
     __syncthreads();
     const uint32_t len = list_len(a, PASS == 0);
-    const uint32_t* src = list_src(a, PASS, 0);
+    const uint32_t* src = list_src(a, PASS);
     const uint32_t i0 = blockIdx.x * BATCH_TILE;
     constexpr uint32_t PER = BATCH_TILE / 256u;
-    uint32_t rows[PER], sets[PER], metas[PER];
+    uint32_t rows[PER], buckets[PER], metas[PER];
 #pragma unroll
     for (uint32_t k = 0; k < PER; ++k) {  // independent loads first: this kernel is pure latency
         const uint32_t i = i0 + k * 256u + threadIdx.x;
@@ -89,25 +107,25 @@ __global__ void __launch_bounds__(256) k_batch_hist(BatchArgs a) {
 #pragma unroll
     for (uint32_t k = 0; k < PER; ++k) {
         const uint32_t i = i0 + k * 256u + threadIdx.x;
-        sets[k] = i < len ? a.row_set[rows[k]] : BATCH_NO_SET;
-        // NO_BATCH_SET, a stale set id or a RenderBinIndex that names no bin: not multidrawable
-        if (PASS == 0 && (sets[k] >= a.n_sets || a.row_meta[rows[k]] == 0xFFFFFFFFu)) sets[k] = BATCH_NO_SET;
+        buckets[k] = i < len ? a.row_bucket[rows[k]] : BATCH_NO_SET;
+        if (buckets[k] >= a.n_buckets) buckets[k] = BATCH_NO_SET;  // stale id after the tables shrank
     }
     if (PASS == 0) {
 #pragma unroll
         for (uint32_t k = 0; k < PER; ++k) {
             const uint32_t i = i0 + k * 256u + threadIdx.x;
-            metas[k] = i < len ? a.row_meta[rows[k]] : 0u;
+            metas[k] = i < len ? a.row_meta[rows[k]] : 0xFFFFFFFFu;
         }
     }
 #pragma unroll
     for (uint32_t k = 0; k < PER; ++k) {
-        const uint32_t s = sets[k];
-        if (s == BATCH_NO_SET) continue;
+        const uint32_t b = buckets[k];
+        if (b == BATCH_NO_SET) continue;
         if (PASS == 0) {
-            atomicAdd(&hist[s & 255u], 1u);
-            // instance_count of the row's bin (render_phase/mod.rs:307-311), through the tile's LDS table
+            atomicAdd(&hist[b & 255u], 1u);
+            // instance_count of a multidrawable row's bin (render_phase/mod.rs:307-311), through the tile's LDS table
             const uint32_t m = metas[k];
+            if (b < a.first_set_bucket || m == 0xFFFFFFFFu) continue;
             uint32_t slot = (m * 2654435761u) >> 23;
             bool done = false;
             for (uint32_t probe = 0; probe < 8u && !done; ++probe, slot = (slot + 1u) & (BIN_HASH - 1u)) {
@@ -117,52 +135,62 @@ __global__ void __launch_bounds__(256) k_batch_hist(BatchArgs a) {
                     done = true;
                 }
             }
-            if (!done) atomicAdd(&a.bin_metadata[3u * m + 2u], 1u);  // table crowded: straight to memory
+            if (!done) atomicAdd(&a.inst_count[m], 1u);  // table crowded: straight to memory
         } else {
-            atomicAdd(&hist[s >> 8], 1u);
+            atomicAdd(&hist[b >> 8], 1u);
         }
     }
     __syncthreads();
     a.tile_hist[threadIdx.x * a.n_tiles + blockIdx.x] = hist[threadIdx.x];
     if (PASS == 0)
         for (uint32_t k = threadIdx.x; k < BIN_HASH; k += 256u)
-            if (hkey[k] != BIN_HASH_EMPTY) atomicAdd(&a.bin_metadata[3u * hkey[k] + 2u], hval[k]);
+            if (hkey[k] != BIN_HASH_EMPTY) atomicAdd(&a.inst_count[hkey[k]], hval[k]);
 }
 
-// workgroup-wide exclusive scan of one value per thread (1024 threads); returns the exclusive prefix, *total = sum
-__device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* lds_waves, uint32_t* total) {
+// K exclusive scans across the 1024 threads of the workgroup in one go (two barriers): v[] becomes the exclusive prefix,
+// total[] the sums.  lds: [16][K].
+template <uint32_t K>
+__device__ __forceinline__ void block_scan_1024_multi(uint32_t (&v)[K], uint32_t (*lds)[K], uint32_t (&total)[K]) {
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    uint32_t incl = v;
+    uint32_t incl[K];
 #pragma unroll
-    for (uint32_t off = 1; off < 64u; off <<= 1) {
-        const uint32_t up = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += up;
+    for (uint32_t q = 0; q < K; ++q) {
+        incl[q] = v[q];
+#pragma unroll
+        for (uint32_t off = 1; off < 64u; off <<= 1) {
+            const uint32_t up = __shfl_up(incl[q], off, 64);
+            if (lane >= off) incl[q] += up;
+        }
     }
-    __syncthreads();  // lds_waves may still be read by the previous call
-    if (lane == 63u) lds_waves[wv] = incl;
+    __syncthreads();  // lds may still be read by the previous call
+    if (lane == 63u)
+#pragma unroll
+        for (uint32_t q = 0; q < K; ++q) lds[wv][q] = incl[q];
     __syncthreads();
-    uint32_t before = 0, all = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < 16u; ++k) {
-        const uint32_t w = lds_waves[k];
-        before += k < wv ? w : 0u;
-        all += w;
+    for (uint32_t q = 0; q < K; ++q) {
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 16u; ++k) {
+            const uint32_t w = lds[k][q];
+            before += k < wv ? w : 0u;
+            all += w;
+        }
+        total[q] = all;
+        v[q] = before + incl[q] - v[q];
     }
-    *total = all;
-    return before + incl - v;
 }
 
-// exclusive scan of tile_hist in digit-major order (= the partition offsets); counters[0] = entries kept.
-// Eight consecutive entries per thread, so up to 64 k visible rows are one trip through the loop.
-template <uint32_t PASS>
-__global__ void __launch_bounds__(1024) k_batch_scan(BatchArgs a) {
-    __shared__ uint32_t lds_waves[16];
-    const uint32_t len = list_len(a, PASS == 0);
-    const uint32_t used = (len + BATCH_TILE - 1u) / BATCH_TILE;  // tiles beyond hold zeros
+// exclusive scan of tile_hist in digit-major order (= the partition offsets); counters[0] = entries kept.  Eight consecutive
+// entries per thread, so up to 64 k visible rows are one trip through the loop.  digit_start (LDS, 257 words, may be null)
+// receives the offset at which every digit's run starts, [256] = the total.
+__device__ __forceinline__ uint32_t scan_tile_hist(const BatchArgs& a, uint32_t len, uint32_t (*lds)[1], uint32_t* digit_start) {
+    const uint32_t used = (len + BATCH_TILE - 1u) / BATCH_TILE;  // tiles beyond hold nothing
     uint32_t carry = 0;
     const uint32_t total_entries = 256u * used;  // walk (digit, tile < used) in order
+    if (digit_start && used == 0u && threadIdx.x < 257u) digit_start[threadIdx.x] = 0u;
     for (uint32_t e0 = 0; e0 < total_entries; e0 += 8192u) {
-        uint32_t v[8], idx[8], sum = 0;
+        uint32_t v[8], idx[8], sum[1] = {0};
 #pragma unroll
         for (uint32_t k = 0; k < 8u; ++k) {
             const uint32_t e = e0 + threadIdx.x * 8u + k;
@@ -172,48 +200,244 @@ __global__ void __launch_bounds__(1024) k_batch_scan(BatchArgs a) {
 #pragma unroll
         for (uint32_t k = 0; k < 8u; ++k) {
             const uint32_t t = v[k];
-            v[k] = sum;
-            sum += t;
+            v[k] = sum[0];
+            sum[0] += t;
         }
-        uint32_t tot;
-        const uint32_t ex = block_scan_1024(sum, lds_waves, &tot);
+        uint32_t tot[1];
+        block_scan_1024_multi<1>(sum, lds, tot);
 #pragma unroll
         for (uint32_t k = 0; k < 8u; ++k)
-            if (idx[k] != 0xFFFFFFFFu) a.tile_hist[idx[k]] = carry + ex + v[k];
-        carry += tot;
+            if (idx[k] != 0xFFFFFFFFu) {
+                const uint32_t off = carry + sum[0] + v[k];
+                a.tile_hist[idx[k]] = off;
+                const uint32_t e = e0 + threadIdx.x * 8u + k;
+                if (digit_start && e % used == 0u) digit_start[e / used] = off;
+            }
+        carry += tot[0];
     }
+    if (digit_start && threadIdx.x == 0) digit_start[256] = carry;
+    return carry;
+}
+
+template <uint32_t PASS>
+__global__ void __launch_bounds__(1024) k_batch_scan(BatchArgs a) {
+    __shared__ uint32_t lds_waves[16][1];
+    const uint32_t carry = scan_tile_hist(a, list_len(a, PASS == 0), lds_waves, nullptr);
     if (threadIdx.x == 0 && PASS == 0) a.counters[0] = carry;
 }
 
+// The reference's bookkeeping for every bin and batch set of the phase at once.  Per bucket, in bucket order, exclusive scans of
+//   q0      MeshUniform slots (data_buffer.add(), shared by both mesh classes)
+//   q1, q2  work items per mesh class
+//   q3, q4  indirect-parameters slots per class: allocate(entities.len()) for an unbatchable bin, 1 per non-empty batchable bin,
+//           the bin count of a non-empty batch set
+//   q5, q6  IndirectBatchSets per class: one per unbatchable entity with an input index, one per non-empty batchable bin / batch set
+//   q7      records (BinnedRenderPhaseBatchSet / batches)   q8  UnbatchableBinnedEntityIndices
+// count[] of a bucket comes from the partition offsets (ONE_PASS: digit starts in LDS) or from the run bounds in the list.
+template <bool ONE_PASS>
+__global__ void __launch_bounds__(1024) k_batch_plan(BatchArgs a) {
+    __shared__ uint32_t lds_scan1[16][1];
+    __shared__ uint32_t lds_scan[16][9];
+    __shared__ uint32_t digit_start[258];
+    if (ONE_PASS) {
+        const uint32_t kept = scan_tile_hist(a, *a.list_count, lds_scan1, digit_start);
+        if (threadIdx.x == 0) a.counters[0] = kept;
+        __syncthreads();
+    }
+    const bool indirect = a.no_indirect == 0u;
+    uint32_t carry[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t b0 = 0; b0 < a.n_buckets; b0 += 1024u) {
+        const uint32_t b = b0 + threadIdx.x;
+        const bool in = b < a.n_buckets;
+        auto count_of = [&](uint32_t k) -> uint32_t {
+            if (k >= a.n_buckets) return 0u;
+            return ONE_PASS ? digit_start[k + 1u] - digit_start[k] : a.set_count[a.n_buckets + k] - a.set_count[k];
+        };
+        const uint32_t d = in ? a.bucket_desc[b] : 0u;
+        const uint32_t kind = desc_kind(d), cls = desc_cls(d), id = desc_id(d);
+        const uint32_t cnt = in ? count_of(b) : 0u;
+        const uint32_t sibling = (in && kind == KIND_UNB_INPUT) ? count_of(b + 1u) : 0u;  // the bin's rows without an input index
+        const uint32_t bins = (in && kind == KIND_SET && cnt) ? a.meta_offset[id + 1] - a.meta_offset[id] : 0u;
+        const uint32_t items = kind == KIND_UNB_NO_INPUT ? 0u : cnt;
+        uint32_t ip = 0, bs = 0, rec = 0, unb = 0;
+        if (kind == KIND_UNB_INPUT) {
+            ip = indirect ? cnt + sibling : 0u;
+            bs = indirect ? cnt : 0u;
+            unb = cnt;
+        } else if (kind == KIND_BATCHABLE) {
+            ip = bs = (indirect && cnt) ? 1u : 0u;
+            rec = cnt ? 1u : 0u;
+        } else if (kind == KIND_SET) {
+            ip = bins;
+            bs = rec = cnt ? 1u : 0u;
+        }
+        uint32_t v[9] = {items, cls ? 0u : items, cls ? items : 0u, cls ? 0u : ip, cls ? ip : 0u, cls ? 0u : bs, cls ? bs : 0u, rec, unb};
+        uint32_t tot[9];
+        block_scan_1024_multi<9>(v, lds_scan, tot);
+        if (in) {
+            // selects, not [cls]: dynamic indexing into the kernarg struct would spill it to scratch
+            const uint32_t data0 = a.initial.output_mesh_uniform_index + carry[0] + v[0];
+            const uint32_t wi0 = cls ? a.initial.work_item_index[1] + carry[2] + v[2] : a.initial.work_item_index[0] + carry[1] + v[1];
+            const uint32_t ip0 = cls ? a.initial.indirect_parameters_index[1] + carry[4] + v[4]
+                                     : a.initial.indirect_parameters_index[0] + carry[3] + v[3];
+            const uint32_t bs0 = cls ? a.initial.batch_set_index[1] + carry[6] + v[6] : a.initial.batch_set_index[0] + carry[5] + v[5];
+            const uint32_t start = ONE_PASS ? digit_start[b] : a.set_count[b];
+            a.plan[0u * a.n_buckets + b] = start;
+            a.plan[1u * a.n_buckets + b] = data0;
+            a.plan[2u * a.n_buckets + b] = wi0;
+            // a bin's rows without an input index own the zero tail of the bin's allocate(len): their ip0 is the first tail slot
+            a.plan[3u * a.n_buckets + b] = kind == KIND_UNB_NO_INPUT ? ip0 - cnt : ip0;
+            a.plan[4u * a.n_buckets + b] = bs0;
+            a.plan[5u * a.n_buckets + b] = carry[8] + v[8];
+            a.plan[6u * a.n_buckets + b] = cnt;
+            if (cnt && (kind == KIND_BATCHABLE || kind == KIND_SET)) {
+                if (indirect) {
+                    uint32_t* bset = cls ? a.batch_sets[1] : a.batch_sets[0];
+                    bset[2u * bs0 + 0u] = 0u;   // indirect_parameters_count
+                    bset[2u * bs0 + 1u] = ip0;  // indirect_parameters_base
+                }
+                if (kind == KIND_BATCHABLE && indirect) {  // write_batch_indirect_parameters_metadata of the bin's one batch
+                    uint32_t* md = (cls ? a.metadata[1] : a.metadata[0]) + 5u * ip0;
+                    md[0] = data0;
+                    md[1] = bs0;
+                    md[2] = md[3] = md[4] = 0u;
+                }
+                uint32_t* rec_out = a.records + 8u * (carry[7] + v[7]);
+                const bool set = kind == KIND_SET;
+                rec_out[0] = set ? id : (0x80000000u | id);
+                rec_out[1] = cls;
+                rec_out[2] = indirect ? bs0 : 0u;
+                rec_out[3] = set ? wi0 : 0u;  // "Unused" for a batchable bin (gpu_preprocessing.rs:2345-2350)
+                rec_out[4] = cnt;
+                rec_out[5] = indirect ? ip0 : 0xFFFFFFFFu;
+                rec_out[6] = set ? bins : 1u;
+                rec_out[7] = data0;
+            }
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 9u; ++q) carry[q] += tot[q];
+    }
+    if (threadIdx.x == 0) {
+        for (uint32_t c = 0; c < 2u; ++c) {
+            a.totals[0 + c] = a.initial.work_item_index[c] + carry[1 + c];
+            a.totals[2 + c] = a.initial.indirect_parameters_index[c] + carry[3 + c];
+            a.totals[4 + c] = a.initial.batch_set_index[c] + carry[5 + c];
+        }
+        a.totals[6] = a.initial.output_mesh_uniform_index + carry[0];
+        a.totals[7] = carry[7];
+        a.totals[8] = carry[8];
+    }
+}
+
+// What one listed row writes once its ordinal j inside its bucket is known.
+__device__ __forceinline__ void emit_row(const BatchArgs& a, uint32_t row, uint32_t bucket, uint32_t j) {
+    const uint32_t d = a.bucket_desc[bucket];
+    const uint32_t kind = desc_kind(d), cls = desc_cls(d);
+    const bool indirect = a.no_indirect == 0u;
+    const uint32_t ip0 = a.plan[3u * a.n_buckets + bucket];
+    if (kind == KIND_UNB_NO_INPUT) {  // get_binned_index() == None: nothing but its zeroed slot of allocate(len) (:2153-2171)
+        if (indirect) {
+            uint32_t* md = (cls ? a.metadata[1] : a.metadata[0]) + 5u * (ip0 + j);
+            md[0] = md[1] = md[2] = md[3] = md[4] = 0u;
+        }
+        return;
+    }
+    const uint32_t out = a.plan[1u * a.n_buckets + bucket] + j;
+    uint32_t* wi = (cls ? a.work_items[1] : a.work_items[0]) + 2u * (a.plan[2u * a.n_buckets + bucket] + j);
+    wi[0] = a.row_input[row];
+    if (kind == KIND_UNB_INPUT) {  // :2173-2222
+        const uint32_t ipi = ip0 + j;
+        wi[1] = indirect ? ipi : out;
+        uint32_t* ub = a.unbatchable + 2u * (a.plan[5u * a.n_buckets + bucket] + j);
+        ub[0] = desc_id(d);
+        ub[1] = indirect ? ipi : out;
+        if (indirect) {
+            uint32_t* md = (cls ? a.metadata[1] : a.metadata[0]) + 5u * ipi;
+            md[0] = out;
+            md[1] = 0xFFFFFFFFu;
+            md[2] = md[3] = md[4] = 0u;
+            uint32_t* bset = (cls ? a.batch_sets[1] : a.batch_sets[0]) + 2u * (a.plan[4u * a.n_buckets + bucket] + j);
+            bset[0] = 0u;
+            bset[1] = ipi;
+        }
+    } else if (kind == KIND_BATCHABLE) {  // :2232-2310: the batch's first indirect-parameters slot, or the output index
+        wi[1] = indirect ? ip0 : out;
+    } else {  // unpack_bins.wesl:64-93
+        wi[1] = ip0 + a.bin_meta_in[3u * a.row_meta[row]];
+    }
+}
+
+// allocate_uniforms.wesl for one batch set per workgroup: base_output_index of bin k (metadata order) = the set's first
+// MeshUniform slot + sum of instance_count over bins < k; written at the bin's indirect parameters slot together with
+// batch_set_index and zeroed mesh_index / early / late counts (:120-134).  Also publishes the set's instance counts and
+// zeroes the counters the NEXT build will add into.
+__device__ __forceinline__ void allocate_set(const BatchArgs& a, uint32_t s, uint32_t* lds_waves) {
+    const uint32_t bucket = a.first_set_bucket + s;
+    const uint32_t cls = a.set_indexed[s] ? 1u : 0u;
+    const uint32_t m0 = a.meta_offset[s], bins = a.meta_offset[s + 1] - m0;
+    const uint32_t first_ip = a.plan[3u * a.n_buckets + bucket], bsi = a.plan[4u * a.n_buckets + bucket];
+    uint32_t carry = a.plan[1u * a.n_buckets + bucket];
+    const bool nonempty = a.plan[6u * a.n_buckets + bucket] != 0u;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    for (uint32_t k0 = 0; k0 < bins; k0 += 256u) {
+        const uint32_t k = k0 + threadIdx.x;
+        const uint32_t v = k < bins ? a.inst_count[m0 + k] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (uint32_t off = 1; off < 64u; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        __syncthreads();
+        if (lane == 63u) lds_waves[wv] = incl;
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 4u; ++w) {
+            before += w < wv ? lds_waves[w] : 0u;
+            all += lds_waves[w];
+        }
+        if (k < bins) {
+            a.bin_metadata_out[3u * (m0 + k) + 0u] = a.bin_meta_in[3u * (m0 + k)];
+            a.bin_metadata_out[3u * (m0 + k) + 1u] = a.bin_meta_in[3u * (m0 + k) + 1u];
+            a.bin_metadata_out[3u * (m0 + k) + 2u] = v;
+            a.inst_count_next[m0 + k] = 0u;
+            if (nonempty) {  // a batch set without instances was skipped: it owns no indirect-parameters slots (:2520-2524)
+                uint32_t* md = (cls ? a.metadata[1] : a.metadata[0]) + 5u * (first_ip + a.bin_meta_in[3u * (m0 + k)]);
+                md[0] = carry + before + incl - v;
+                md[1] = bsi;
+                md[2] = 0u;
+                md[3] = 0u;
+                md[4] = 0u;
+            }
+        }
+        carry += all;
+    }
+}
+
 // stable scatter: items keep their list order inside a digit.  8 rounds of 256 items; in a round, wave w's items precede
-// wave w+1's and lane order is item order.
-template <uint32_t PASS>
-__global__ void __launch_bounds__(256) k_batch_scatter(BatchArgs a) {
-    __shared__ uint32_t running[256];
-    __shared__ uint32_t wave_hist[4][256];
+// wave w+1's and lane order is item order.  FINAL: the position is not stored -- the row emits its outputs from it.
+template <uint32_t PASS, bool FINAL>
+__device__ __forceinline__ void scatter_tile(const BatchArgs& a, uint32_t tile, uint32_t* running, uint32_t (*wave_hist)[256]) {
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t len = list_len(a, PASS == 0);
-    const uint32_t* src = list_src(a, PASS, 0);
-    uint32_t* dst = list_dst(a, PASS);
-    running[threadIdx.x] = a.tile_hist[threadIdx.x * a.n_tiles + blockIdx.x];
-    const uint32_t i0 = blockIdx.x * BATCH_TILE;
+    const uint32_t* src = list_src(a, PASS);
+    uint32_t* dst = PASS == 0 ? a.rows_a : a.rows_b;
+    running[threadIdx.x] = a.tile_hist[threadIdx.x * a.n_tiles + tile];
+    const uint32_t i0 = tile * BATCH_TILE;
     if (i0 >= len) return;
     for (uint32_t r = 0; r < BATCH_TILE / 256u; ++r) {
 #pragma unroll
         for (uint32_t k = 0; k < 4u; ++k) wave_hist[k][threadIdx.x] = 0u;
         __syncthreads();
         const uint32_t i = i0 + r * 256u + threadIdx.x;
-        uint32_t row = 0, digit = 0;
+        uint32_t row = 0, digit = 0, bucket = BATCH_NO_SET;
         bool valid = i < len;
         if (valid) {
             row = src[i];
-            const uint32_t s = a.row_set[row];
-            if (PASS == 0) {
-                valid = s < a.n_sets && a.row_meta[row] != 0xFFFFFFFFu;
-                digit = s & 255u;
-            } else {
-                digit = s >> 8;
-            }
+            bucket = a.row_bucket[row];
+            valid = bucket < a.n_buckets;
+            digit = PASS == 0 ? (bucket & 255u) : (bucket >> 8);
         }
         // lanes of this wave holding the same digit: eight ballots, one per digit bit (constant time, however many
         // distinct digits the wave holds)
@@ -232,7 +456,8 @@ __global__ void __launch_bounds__(256) k_batch_scatter(BatchArgs a) {
             uint32_t pos = running[digit] + rank;
 #pragma unroll
             for (uint32_t k = 0; k < 3u; ++k) pos += k < wv ? wave_hist[k][digit] : 0u;
-            dst[pos] = row;
+            if (FINAL) emit_row(a, row, bucket, pos - a.plan[bucket]);
+            else dst[pos] = row;
         }
         __syncthreads();
         running[threadIdx.x] += wave_hist[0][threadIdx.x] + wave_hist[1][threadIdx.x] + wave_hist[2][threadIdx.x] + wave_hist[3][threadIdx.x];
@@ -240,221 +465,242 @@ __global__ void __launch_bounds__(256) k_batch_scatter(BatchArgs a) {
     }
 }
 
-// first and one-past-last position of every set's run in the partitioned list (both stay 0 for a set without instances)
-template <bool TWO_PASS>
+template <uint32_t PASS>
+__global__ void __launch_bounds__(256) k_batch_scatter(BatchArgs a) {
+    __shared__ uint32_t running[256];
+    __shared__ uint32_t wave_hist[4][256];
+    scatter_tile<PASS, false>(a, blockIdx.x, running, wave_hist);
+}
+
+// ONE_PASS: workgroups [0, n_tiles) scatter-and-emit, the next n_sets run allocate_uniforms.  Otherwise the partitioned list is in
+// rows_b: workgroups [0, cap / 256) emit from it.
+template <bool ONE_PASS>
+__global__ void __launch_bounds__(256) k_batch_emit(BatchArgs a, uint32_t n_emit_blocks) {
+    __shared__ uint32_t running[256];
+    __shared__ uint32_t wave_hist[4][256];
+    if (blockIdx.x >= n_emit_blocks) {
+        allocate_set(a, blockIdx.x - n_emit_blocks, running);
+        return;
+    }
+    if (ONE_PASS) {
+        scatter_tile<0, true>(a, blockIdx.x, running, wave_hist);
+    } else {
+        const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+        if (p >= a.counters[0]) return;
+        const uint32_t row = a.rows_b[p];
+        const uint32_t bucket = a.row_bucket[row];
+        emit_row(a, row, bucket, p - a.plan[bucket]);
+    }
+}
+
+// first and one-past-last position of every bucket's run in the partitioned list (both stay 0 for a bucket without rows)
 __global__ void __launch_bounds__(256) k_batch_bounds(BatchArgs a) {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     const uint32_t len = a.counters[0];
     if (p >= len) return;
-    const uint32_t* rows = TWO_PASS ? a.rows_b : a.rows_a;
-    const uint32_t s = a.row_set[rows[p]];
-    if (p == 0u || a.row_set[rows[p - 1u]] != s) a.set_count[s] = p;
-    if (p + 1u == len || a.row_set[rows[p + 1u]] != s) a.set_count[a.n_sets + s] = p + 1u;
+    const uint32_t b = a.row_bucket[a.rows_b[p]];
+    if (p == 0u || a.row_bucket[a.rows_b[p - 1u]] != b) a.set_count[b] = p;
+    if (p + 1u == len || a.row_bucket[a.rows_b[p + 1u]] != b) a.set_count[a.n_buckets + b] = p + 1u;
 }
 
-// The per-set bookkeeping of prepare_multidrawable_binned_batch_set (gpu_preprocessing.rs:2511-2579) for all sets at
-// once: exclusive scans, in set order, of (instances), (instances | class), (bins of non-empty sets | class),
-// (non-empty | class); IndirectBatchSet entries, the BinnedRenderPhaseBatchSet records and the buffer lengths.
-// K exclusive scans over the 256 threads in one go (two barriers): v[] becomes the exclusive prefix, total[] the sums
-template <uint32_t K>
-__device__ __forceinline__ void block_scan_256_multi(uint32_t (&v)[K], uint32_t (*lds)[K], uint32_t (&total)[K]) {
+__global__ void __launch_bounds__(256) k_batch_clear_bounds(BatchArgs a) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < 2u * a.n_buckets) a.set_count[i] = 0u;
+}
+
+// =============================================================================================
+// sorted phases (gpu_preprocessing.rs:1850-2061; the range merge of batching/mod.rs:219-244)
+// =============================================================================================
+// One workgroup walks the items in chunks of 1024.  Whether an item continues its predecessor's batch, breaks the batch or breaks
+// the batch set depends only on the two items (the running batch set's meta is always the previous item's); every index is an
+// exclusive prefix sum over the items.  Phase A computes per item: its MeshUniform slot, the indirect-parameters slot it allocates
+// (if it breaks), the inclusive count of batch breaks and the item that heads its batch set; phase B (after a barrier: same
+// workgroup) turns them into work items and, at each set's last item, the record flush() leaves.
+constexpr uint32_t SORTED_OK = 0, SORTED_BREAK_BATCH = 1, SORTED_HEAD = 2, SORTED_SKIP = 3;
+
+__global__ void __launch_bounds__(1024) k_batch_sorted(SortedArgs a) {
+    __shared__ uint32_t lds_scan[16][8];
+    __shared__ uint32_t lds_head[16];
+    __shared__ uint32_t carry_head;
+    const bool indirect = a.no_indirect == 0u && a.merge_only == 0u;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    uint32_t incl[K];
-#pragma unroll
-    for (uint32_t q = 0; q < K; ++q) {
-        incl[q] = v[q];
-#pragma unroll
-        for (uint32_t off = 1; off < 64u; off <<= 1) {
-            const uint32_t up = __shfl_up(incl[q], off, 64);
-            if (lane >= off) incl[q] += up;
-        }
-    }
+    // ---- phase A
+    uint32_t carry[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // with input | with input per class | allocations per class | breaks | sets | sets of class 1
+    if (threadIdx.x == 0) carry_head = 0xFFFFFFFFu;
     __syncthreads();
-    if (lane == 63u)
-#pragma unroll
-        for (uint32_t q = 0; q < K; ++q) lds[wv][q] = incl[q];
-    __syncthreads();
-#pragma unroll
-    for (uint32_t q = 0; q < K; ++q) {
-        uint32_t before = 0, all = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) {
-            const uint32_t w = lds[k][q];
-            before += k < wv ? w : 0u;
-            all += w;
-        }
-        total[q] = all;
-        v[q] = before + incl[q] - v[q];
-    }
-}
-
-__global__ void __launch_bounds__(256) k_batch_sets(BatchArgs a) {
-    __shared__ uint32_t lds_waves[4][8];
-    uint32_t c_all = 0, c_items[2] = {0, 0}, c_bins[2] = {0, 0}, c_sets[2] = {0, 0}, c_rec = 0;
-    for (uint32_t s0 = 0; s0 < a.n_sets; s0 += 256u) {
-        const uint32_t s = s0 + threadIdx.x;
-        const bool in = s < a.n_sets;
-        const uint32_t cnt = in ? a.set_count[a.n_sets + s] - a.set_count[s] : 0u;
-        const uint32_t cls = in && a.set_indexed[s] ? 1u : 0u;
-        const uint32_t bins = in && cnt ? a.meta_offset[s + 1] - a.meta_offset[s] : 0u;
-        uint32_t v[8] = {cnt, cls == 0 ? cnt : 0u, cls == 1 ? cnt : 0u, cls == 0 ? bins : 0u, cls == 1 ? bins : 0u,
-                         (cls == 0 && cnt) ? 1u : 0u, (cls == 1 && cnt) ? 1u : 0u, cnt ? 1u : 0u};
-        uint32_t tot[8];
-        block_scan_256_multi<8>(v, lds_waves, tot);
-        const uint32_t e_all = v[0], e_i0 = v[1], e_i1 = v[2], e_b0 = v[3], e_b1 = v[4], e_s0 = v[5], e_s1 = v[6], e_rec = v[7];
-        const uint32_t t_all = tot[0], t_rec = tot[7];
-        const uint32_t t_i[2] = {tot[1], tot[2]}, t_b[2] = {tot[3], tot[4]}, t_s[2] = {tot[5], tot[6]};
+    for (uint32_t i0 = 0; i0 < a.n_items; i0 += 1024u) {
+        const uint32_t i = i0 + threadIdx.x;
+        const bool in = i < a.n_items;
+        uint32_t it[4] = {0xFFFFFFFFu, 0, 0, 0}, pv[4] = {0xFFFFFFFFu, 0, 0, 0};
         if (in) {
-            const uint32_t start = c_all + e_all;
-            // selects, not [cls]: dynamic indexing into the kernarg struct would spill it to scratch
-            const uint32_t first_wi = cls ? a.initial.work_item_index[1] + c_items[1] + e_i1 : a.initial.work_item_index[0] + c_items[0] + e_i0;
-            const uint32_t first_ip = cls ? a.initial.indirect_parameters_index[1] + c_bins[1] + e_b1
-                                          : a.initial.indirect_parameters_index[0] + c_bins[0] + e_b0;
-            const uint32_t bsi = cls ? a.initial.batch_set_index[1] + c_sets[1] + e_s1 : a.initial.batch_set_index[0] + c_sets[0] + e_s0;
-            const uint32_t first_out = a.initial.output_mesh_uniform_index + start;
-            a.set_scan[0u * a.n_sets + s] = start;
-            a.set_scan[1u * a.n_sets + s] = first_wi;
-            a.set_scan[2u * a.n_sets + s] = first_ip;
-            a.set_scan[3u * a.n_sets + s] = bsi;
-            a.set_scan[4u * a.n_sets + s] = first_out;
-            if (cnt) {
-                uint32_t* bset = cls ? a.batch_sets[1] : a.batch_sets[0];
-                bset[2u * bsi + 0u] = 0u;        // indirect_parameters_count
-                bset[2u * bsi + 1u] = first_ip;  // indirect_parameters_base
-                uint32_t* rec = a.records + 8u * (c_rec + e_rec);
-                rec[0] = s;
-                rec[1] = cls;
-                rec[2] = bsi;
-                rec[3] = first_wi;
-                rec[4] = cnt;
-                rec[5] = first_ip;
-                rec[6] = bins;
-                rec[7] = first_out;
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) it[k] = a.items[4u * i + k];
+            if (i)
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) pv[k] = a.items[4u * (i - 1u) + k];
+        }
+        const bool has_in = in && it[0] != 0xFFFFFFFFu;
+        const bool meta = has_in && a.automatic_batching && (it[3] & 2u);
+        const bool prev_in = in && i && pv[0] != 0xFFFFFFFFu;
+        const bool prev_meta = prev_in && a.automatic_batching && (pv[3] & 2u);
+        uint32_t flag = SORTED_SKIP;
+        if (has_in) {
+            flag = SORTED_HEAD;
+            if (meta && prev_meta && it[1] == pv[1]) {
+                if (it[2] == pv[2]) flag = SORTED_OK;
+                else if (indirect) flag = SORTED_BREAK_BATCH;  // without indirect drawing a different mesh is a new batch set; the
+                                                               // merge-only rule has no second level either
             }
         }
-        c_all += t_all;
-        c_rec += t_rec;
-#pragma unroll
-        for (uint32_t c = 0; c < 2u; ++c) {
-            c_items[c] += t_i[c];
-            c_bins[c] += t_b[c];
-            c_sets[c] += t_s[c];
-        }
-    }
-    if (threadIdx.x == 0) {
-        for (uint32_t c = 0; c < 2u; ++c) {
-            a.totals[0 + c] = a.initial.work_item_index[c] + c_items[c];
-            a.totals[2 + c] = a.initial.indirect_parameters_index[c] + c_bins[c];
-            a.totals[4 + c] = a.initial.batch_set_index[c] + c_sets[c];
-        }
-        a.totals[6] = a.initial.output_mesh_uniform_index + c_all;
-        a.totals[7] = c_rec;
-    }
-}
-
-// allocate_uniforms.wesl for one batch set per workgroup: base_output_index of bin k (metadata order) =
-// first_output_mesh_uniform_index + sum of instance_count over bins < k; written at the bin's indirect parameters slot
-// together with batch_set_index and zeroed mesh_index / early / late counts (:120-134).
-__global__ void __launch_bounds__(256) k_batch_allocate(BatchArgs a) {
-    __shared__ uint32_t lds_waves[4];
-    const uint32_t s = blockIdx.x;
-    if (a.set_count[a.n_sets + s] == 0u) return;  // no run in the partitioned list
-    const uint32_t cls = a.set_indexed[s] ? 1u : 0u;
-    const uint32_t m0 = a.meta_offset[s], bins = a.meta_offset[s + 1] - m0;
-    const uint32_t first_ip = a.set_scan[2u * a.n_sets + s], bsi = a.set_scan[3u * a.n_sets + s];
-    uint32_t carry = a.set_scan[4u * a.n_sets + s];
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    for (uint32_t k0 = 0; k0 < bins; k0 += 256u) {
-        const uint32_t k = k0 + threadIdx.x;
-        const uint32_t v = k < bins ? a.bin_metadata[3u * (m0 + k) + 2u] : 0u;
-        uint32_t incl = v;
+        const uint32_t cls = it[3] & 1u;
+        const bool alloc = indirect && (flag == SORTED_HEAD || flag == SORTED_BREAK_BATCH);
+        uint32_t v[8] = {has_in ? 1u : 0u, (has_in && !cls) ? 1u : 0u, (has_in && cls) ? 1u : 0u, (alloc && !cls) ? 1u : 0u,
+                         (alloc && cls) ? 1u : 0u, flag == SORTED_BREAK_BATCH ? 1u : 0u, flag == SORTED_HEAD ? 1u : 0u,
+                         (flag == SORTED_HEAD && cls) ? 1u : 0u};
+        uint32_t tot[8];
+        block_scan_1024_multi<8>(v, lds_scan, tot);
+        // the item that heads this item's batch set: the latest head at or before it (max-scan of head positions)
+        uint32_t h = flag == SORTED_HEAD ? i : 0xFFFFFFFFu;  // 0xFFFFFFFF = none yet; indices compare as (x + 1)
+        uint32_t hx = h + 1u;
 #pragma unroll
         for (uint32_t off = 1; off < 64u; off <<= 1) {
-            const uint32_t up = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += up;
+            const uint32_t up = __shfl_up(hx, off, 64);
+            if (lane >= off && up > hx) hx = up;
+        }
+        if (lane == 63u) lds_head[wv] = hx;
+        __syncthreads();
+        uint32_t before = carry_head + 1u;
+        for (uint32_t k = 0; k < wv; ++k) before = lds_head[k] > before ? lds_head[k] : before;
+        hx = hx > before ? hx : before;
+        if (in) {
+            a.scratch[0u * a.n_items + i] = a.initial.output_mesh_uniform_index + carry[0] + v[0];
+            a.scratch[1u * a.n_items + i] = alloc ? (cls ? a.initial.indirect_parameters_index[1] + carry[4] + v[4]
+                                                         : a.initial.indirect_parameters_index[0] + carry[3] + v[3])
+                                                  : 0xFFFFFFFFu;
+            a.scratch[2u * a.n_items + i] = carry[5] + v[5] + (flag == SORTED_BREAK_BATCH ? 1u : 0u);  // inclusive
+            a.scratch[3u * a.n_items + i] = hx - 1u;
+            // per class: this item's work-item slot; ordinal of its set (all classes) and among the sets of its head's class
+            a.scratch[4u * a.n_items + i] = cls ? a.initial.work_item_index[1] + carry[2] + v[2] : a.initial.work_item_index[0] + carry[1] + v[1];
+            a.scratch[5u * a.n_items + i] = carry[6] + v[6];                                   // sets before this item (exclusive)
+            a.scratch[6u * a.n_items + i] = carry[7] + v[7];                                   // ... of class 1
+            a.scratch[7u * a.n_items + i] = flag;
         }
         __syncthreads();
-        if (lane == 63u) lds_waves[wv] = incl;
-        __syncthreads();
-        uint32_t before = 0, all = 0;
+        if (threadIdx.x == 1023u) carry_head = hx - 1u;
 #pragma unroll
-        for (uint32_t w = 0; w < 4u; ++w) {
-            before += w < wv ? lds_waves[w] : 0u;
-            all += lds_waves[w];
-        }
-        if (k < bins) {
-            uint32_t* md = (cls ? a.metadata[1] : a.metadata[0]) + 5u * (first_ip + a.bin_metadata[3u * (m0 + k)]);
-            md[0] = carry + before + incl - v;
-            md[1] = bsi;
-            md[2] = 0u;
-            md[3] = 0u;
-            md[4] = 0u;
-        }
-        carry += all;
+        for (uint32_t q = 0; q < 8u; ++q) carry[q] += tot[q];
+        __syncthreads();
     }
-}
-
-// unpack_bins.wesl:64-93 over the partitioned list: entry p of set s is the set's binned mesh instance p - start(s)
-template <bool TWO_PASS>
-__global__ void __launch_bounds__(256) k_batch_unpack(BatchArgs a) {
-    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= a.counters[0]) return;
-    const uint32_t row = (TWO_PASS ? a.rows_b : a.rows_a)[p];
-    const uint32_t s = a.row_set[row];
-    const uint32_t cls = a.set_indexed[s] ? 1u : 0u;
-    const uint32_t global_id = p - a.set_scan[s];
-    const uint32_t m = a.row_meta[row];
-    uint32_t* wi = (cls ? a.work_items[1] : a.work_items[0]) + 2u * (a.set_scan[1u * a.n_sets + s] + global_id);
-    wi[0] = a.row_input[row];
-    wi[1] = a.set_scan[2u * a.n_sets + s] + a.bin_metadata[3u * m];
+    if (threadIdx.x == 0) {
+        a.totals[0] = a.initial.work_item_index[0] + (a.merge_only ? 0u : carry[1]);
+        a.totals[1] = a.initial.work_item_index[1] + (a.merge_only ? 0u : carry[2]);
+        a.totals[2] = a.initial.indirect_parameters_index[0] + carry[3];
+        a.totals[3] = a.initial.indirect_parameters_index[1] + carry[4];
+        a.totals[4] = a.initial.batch_set_index[0] + (indirect ? carry[6] - carry[7] : 0u);
+        a.totals[5] = a.initial.batch_set_index[1] + (indirect ? carry[7] : 0u);
+        a.totals[6] = a.initial.output_mesh_uniform_index + carry[0];
+        a.totals[7] = carry[6];
+        a.totals[8] = 0u;
+    }
+    __threadfence();
+    __syncthreads();
+    // ---- phase B (scratch written above is read back through L2: the loads below bypass the per-CU cache)
+    auto ld = [&](uint32_t plane, uint32_t i) { return __builtin_nontemporal_load(a.scratch + plane * a.n_items + i); };
+    for (uint32_t i0 = 0; i0 < a.n_items; i0 += 1024u) {
+        const uint32_t i = i0 + threadIdx.x;
+        if (i >= a.n_items) continue;
+        const uint32_t flag = ld(7, i);
+        if (flag == SORTED_SKIP) continue;
+        const uint32_t cls = a.items[4u * i + 3u] & 1u;
+        const uint32_t out = ld(0, i), h = ld(3, i);
+        const uint32_t ip_h = ld(1, h);
+        const uint32_t cur = ip_h + (ld(2, i) - ld(2, h));  // indirect_parameters_index_range.end - 1
+        if (!a.merge_only) {
+            if (indirect && flag != SORTED_OK) {
+                uint32_t* md = (cls ? a.metadata[1] : a.metadata[0]) + 5u * ld(1, i);
+                md[0] = out;
+                md[1] = 0xFFFFFFFFu;
+                md[2] = md[3] = md[4] = 0u;
+            }
+            uint32_t* wi = (cls ? a.work_items[1] : a.work_items[0]) + 2u * ld(4, i);
+            wi[0] = a.items[4u * i];
+            wi[1] = indirect ? cur : out;
+        }
+        // the set's last item: the next item is missing, has no input index, or heads a new set
+        const bool last = i + 1u == a.n_items || ld(7, i + 1u) == SORTED_SKIP || ld(7, i + 1u) == SORTED_HEAD;
+        if (last) {
+            const uint32_t cls_h = a.items[4u * h + 3u] & 1u;
+            const uint32_t k = ld(5, h);
+            uint32_t* b = a.batches + 6u * k;
+            b[0] = h;
+            b[1] = ld(0, h);
+            b[2] = out + 1u;
+            b[3] = indirect ? ip_h : 0xFFFFFFFFu;
+            b[4] = indirect ? cur + 1u : 0xFFFFFFFFu;
+            b[5] = cls_h;
+            if (indirect) {  // add_batch_set at flush, in flush order per class (:1787-1793)
+                const uint32_t sets1 = ld(6, h);
+                const uint32_t slot = cls_h ? a.initial.batch_set_index[1] + sets1 : a.initial.batch_set_index[0] + (k - sets1);
+                uint32_t* bset = (cls_h ? a.batch_sets[1] : a.batch_sets[0]) + 2u * slot;
+                bset[0] = 0u;
+                bset[1] = ip_h;
+            }
+        }
+    }
 }
 
 }  // namespace
 
-hipError_t launch_batch_resolve_rows(uint32_t n, uint32_t n_sets, const uint32_t* row_set, const uint32_t* row_bin,
+hipError_t launch_batch_resolve_rows(uint32_t n, uint32_t n_sets, uint32_t n_unbatchable, uint32_t n_batchable, const uint8_t* row_kind,
+                                     const uint32_t* row_cpu_bin, const uint32_t* row_set, const uint32_t* row_bin, const uint32_t* row_input,
                                      const uint32_t* bin_table_offset, const uint32_t* bin_table, const uint32_t* meta_offset,
-                                     uint32_t* row_meta, hipStream_t stream) {
+                                     uint32_t* row_meta, uint32_t* row_bucket, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    MI_LAUNCH(k_batch_resolve_rows, dim3((n + 255u) / 256u), dim3(256), 0, stream, n, n_sets, row_set, row_bin, bin_table_offset,
-              bin_table, meta_offset, row_meta);
+    MI_LAUNCH(k_batch_resolve_rows, dim3((n + 255u) / 256u), dim3(256), 0, stream, n, n_sets, n_unbatchable, n_batchable, row_kind,
+              row_cpu_bin, row_set, row_bin, row_input, bin_table_offset, bin_table, meta_offset, row_meta, row_bucket);
     return hipGetLastError();
 }
 
 hipError_t launch_batch_build(const BatchArgs& a, hipStream_t stream, void (*mark)(void*, uint32_t), void* mctx) {
 #define MARK(id) do { if (mark) mark(mctx, id); } while (0)
-    const uint32_t clear_n = a.n_meta > 2u * a.n_sets ? a.n_meta : 2u * a.n_sets;
-    MARK(K_BATCH_CLEAR);
-    MI_LAUNCH(k_batch_clear, dim3((clear_n + 255u) / 256u + 1u), dim3(256), 0, stream, a);
-    const bool two = a.n_sets > 256u;
-    const uint32_t cap = a.n_tiles * BATCH_TILE;
-    MARK(K_BATCH_HIST);
-    MI_LAUNCH(k_batch_hist<0>, dim3(a.n_tiles), dim3(256), 0, stream, a);
-    MARK(K_BATCH_SCAN);
-    MI_LAUNCH(k_batch_scan<0>, dim3(1), dim3(1024), 0, stream, a);
-    MARK(K_BATCH_SCATTER);
-    MI_LAUNCH(k_batch_scatter<0>, dim3(a.n_tiles), dim3(256), 0, stream, a);
-    if (two) {
+    if (a.n_buckets <= 256u) {
+        MARK(K_BATCH_HIST);
+        MI_LAUNCH(k_batch_hist<0>, dim3(a.n_tiles), dim3(256), 0, stream, a);
+        MARK(K_BATCH_PLAN);
+        MI_LAUNCH(k_batch_plan<true>, dim3(1), dim3(1024), 0, stream, a);
+        MARK(K_BATCH_EMIT);
+        MI_LAUNCH(k_batch_emit<true>, dim3(a.n_tiles + a.n_sets), dim3(256), 0, stream, a, a.n_tiles);
+    } else {
+        const uint32_t cap = a.n_tiles * BATCH_TILE;
+        MARK(K_BATCH_HIST);
+        MI_LAUNCH(k_batch_hist<0>, dim3(a.n_tiles), dim3(256), 0, stream, a);
+        MARK(K_BATCH_SCAN);
+        MI_LAUNCH(k_batch_scan<0>, dim3(1), dim3(1024), 0, stream, a);
+        MARK(K_BATCH_SCATTER);
+        MI_LAUNCH(k_batch_scatter<0>, dim3(a.n_tiles), dim3(256), 0, stream, a);
         MARK(K_BATCH_HIST);
         MI_LAUNCH(k_batch_hist<1>, dim3(a.n_tiles), dim3(256), 0, stream, a);
         MARK(K_BATCH_SCAN);
         MI_LAUNCH(k_batch_scan<1>, dim3(1), dim3(1024), 0, stream, a);
         MARK(K_BATCH_SCATTER);
         MI_LAUNCH(k_batch_scatter<1>, dim3(a.n_tiles), dim3(256), 0, stream, a);
+        MARK(K_BATCH_BOUNDS);
+        MI_LAUNCH(k_batch_clear_bounds, dim3((2u * a.n_buckets + 255u) / 256u), dim3(256), 0, stream, a);
+        MI_LAUNCH(k_batch_bounds, dim3(cap / 256u), dim3(256), 0, stream, a);
+        MARK(K_BATCH_PLAN);
+        MI_LAUNCH(k_batch_plan<false>, dim3(1), dim3(1024), 0, stream, a);
+        MARK(K_BATCH_EMIT);
+        MI_LAUNCH(k_batch_emit<false>, dim3(cap / 256u + a.n_sets), dim3(256), 0, stream, a, cap / 256u);
     }
-    MARK(K_BATCH_BOUNDS);
-    if (two) MI_LAUNCH(k_batch_bounds<true>, dim3(cap / 256u), dim3(256), 0, stream, a);
-    else MI_LAUNCH(k_batch_bounds<false>, dim3(cap / 256u), dim3(256), 0, stream, a);
-    MARK(K_BATCH_SETS);
-    MI_LAUNCH(k_batch_sets, dim3(1), dim3(256), 0, stream, a);
-    if (a.n_sets) {
-        MARK(K_BATCH_ALLOCATE);
-        MI_LAUNCH(k_batch_allocate, dim3(a.n_sets), dim3(256), 0, stream, a);
-    }
-    MARK(K_BATCH_UNPACK);
-    if (two) MI_LAUNCH(k_batch_unpack<true>, dim3(cap / 256u), dim3(256), 0, stream, a);
-    else MI_LAUNCH(k_batch_unpack<false>, dim3(cap / 256u), dim3(256), 0, stream, a);
     MARK(K_NUM_KERNELS);
 #undef MARK
+    return hipGetLastError();
+}
+
+hipError_t launch_batch_sorted(const SortedArgs& a, hipStream_t stream, void (*mark)(void*, uint32_t), void* mctx) {
+    if (mark) mark(mctx, K_BATCH_SORTED);
+    MI_LAUNCH(k_batch_sorted, dim3(1), dim3(1024), 0, stream, a);
+    if (mark) mark(mctx, K_NUM_KERNELS);
     return hipGetLastError();
 }
 

@@ -237,3 +237,52 @@ def batching_scene(n_rows, n_sets=7, max_bins=40, seed=42, unbatched_fraction=0.
     return dict(row_set=row_set, row_bin=row_bin, row_input=row_input, set_indexed=set_indexed,
                 bin_table_offset=bin_table_offset, bin_table=np.concatenate(tables) if tables else np.zeros(0, np.uint32),
                 meta_offset=meta_offset, bin_metadata=np.concatenate(metas) if metas else np.zeros((0, 3), np.uint32))
+
+
+def phase_scene(n_rows, n_sets=7, max_bins=40, n_unbatchable_bins=5, n_batchable_bins=6, seed=42, cpu_fraction=0.15, no_input_fraction=0.1):
+    """batching_scene plus the CPU-built part of the same binned phase (gpu_preprocessing.rs:2135-2357): a share of the rows
+    sits in unbatchable bins (some of them without an input uniform index: get_binned_index() == None) or in
+    batchable-but-not-multidrawable bins; bins are numbered in the phase's sorted key order and carry their mesh class."""
+    sc = batching_scene(n_rows, n_sets=n_sets, max_bins=max_bins, seed=seed, unbatched_fraction=0.03)
+    r = splitmix64(seed + 101, 3 * n_rows + n_unbatchable_bins + n_batchable_bins + 8)
+    u = uniform01(seed + 102, n_rows)
+    kind = np.zeros(n_rows, np.uint8)
+    cpu_bin = np.zeros(n_rows, np.uint32)
+    if n_unbatchable_bins:
+        m = u < cpu_fraction * 0.5
+        kind[m] = 2
+        cpu_bin[m] = (r[:n_rows][m] % np.uint64(n_unbatchable_bins)).astype(np.uint32)
+    if n_batchable_bins:
+        m = (u >= cpu_fraction * 0.5) & (u < cpu_fraction)
+        kind[m] = 1
+        cpu_bin[m] = (r[n_rows:2 * n_rows][m] % np.uint64(n_batchable_bins)).astype(np.uint32)
+    row_input = sc["row_input"].copy()
+    no_input = (kind == 2) & (uniform01(seed + 103, n_rows) < no_input_fraction)
+    row_input[no_input] = 0xFFFFFFFF
+    sc.update(row_kind=kind, row_cpu_bin=cpu_bin, row_input=row_input,
+              unbatchable_indexed=((r[3 * n_rows:3 * n_rows + n_unbatchable_bins] >> np.uint64(9)) & np.uint64(1)).astype(np.uint8),
+              batchable_indexed=((r[3 * n_rows + n_unbatchable_bins:3 * n_rows + n_unbatchable_bins + n_batchable_bins] >> np.uint64(9))
+                                 & np.uint64(1)).astype(np.uint8))
+    return sc
+
+
+def sorted_items(n_items, seed=42, run=6, n_set_keys=5, n_bin_keys=4, no_input_fraction=0.04, no_meta_fraction=0.06):
+    """A sorted phase's items u32[n,4] = (input_index, batch_set_key, bin_key, flags): runs of equal batch-set keys with shorter
+    runs of equal bin keys inside (what a depth-sorted transparent phase with instanced meshes looks like), a few items that
+    are not part of the pipeline (no input index) and a few without compare data."""
+    r = splitmix64(seed + 7, 4 * n_items + 8)
+    items = np.zeros((n_items, 4), np.uint32)
+    items[:, 0] = (r[:n_items] & np.uint64(0xFFFFF)).astype(np.uint32)
+    block = np.arange(n_items) // max(run, 1)
+    sub = np.arange(n_items) // max(run // 3, 1)
+    sk = splitmix64(seed + 8, int(block.max()) + 2 if n_items else 1)
+    bk = splitmix64(seed + 9, int(sub.max()) + 2 if n_items else 1)
+    if n_items:
+        items[:, 1] = (sk[block] % np.uint64(n_set_keys)).astype(np.uint32)
+        items[:, 2] = (bk[sub] % np.uint64(n_bin_keys)).astype(np.uint32)
+        indexed = ((sk[block] >> np.uint64(11)) & np.uint64(1)).astype(np.uint32)  # the mesh class follows the batch set
+        u = uniform01(seed + 10, n_items)
+        has_meta = (uniform01(seed + 11, n_items) >= no_meta_fraction).astype(np.uint32)
+        items[:, 3] = indexed | (has_meta << 1)
+        items[u < no_input_fraction, 0] = 0xFFFFFFFF
+    return items

@@ -467,8 +467,8 @@ int32_t mi_cluster_download_bindings(mi_ctx* ctx, const uint32_t* remap, uint32_
  * view's VisibleEntities list, which the cull pass left in HBM: no D2H of the list, no CPU bin hash maps
  * (render_phase/mod.rs:268-400), no H2D of GpuRenderBinnedMeshInstance arrays.
  *
- * The render world uploads, per row, which batch set the mesh instance belongs to (MI_NO_BATCH_SET = unbatchable /
- * batchable-only: stays on the reference's CPU path), its RenderBinIndex inside that set and its InputUniformIndex;
+ * The render world uploads, per row, which batch set the mesh instance belongs to (MI_NO_BATCH_SET = none; rows of the phase's
+ * unbatchable / batchable-only bins are placed with mi_batch_upload_row_bins), its RenderBinIndex inside that set and its InputUniformIndex;
  * and per phase the batch sets in the order phase.multidrawable_meshes iterates them: mesh class (indexed or not),
  * the RenderBinIndex -> bin-metadata-index table (holes allowed) and the GpuBinMetadata array of every set, both
  * concatenated with offset arrays of n_sets + 1 entries.  instance_count of the metadata is an output.
@@ -497,25 +497,53 @@ typedef struct mi_indirect_parameters_metadata {  /* gpu_preprocessing.rs:898-93
 typedef struct mi_indirect_batch_set {  /* gpu_preprocessing.rs:946-965 */
     uint32_t indirect_parameters_count, indirect_parameters_base;
 } mi_indirect_batch_set;
+/* One per non-empty multidrawable batch set (`set` = its index) and one per non-empty batchable bin (`set` =
+ * MI_BATCH_RECORD_BATCHABLE_BIN | bin; first_work_item_index 0 -- "Unused", :2345-2350 --, batch_count 1, instance_count and
+ * first_output_mesh_uniform_index = first_batch.instance_range, first_indirect_parameters_index = its extra index or MI_NO_INDEX). */
+#define MI_BATCH_RECORD_BATCHABLE_BIN 0x80000000u
 typedef struct mi_batch_set_record {
     uint32_t set, indexed, index, first_work_item_index, instance_count, first_indirect_parameters_index, batch_count,
         first_output_mesh_uniform_index;
 } mi_batch_set_record;
+typedef struct mi_unbatchable_index {  /* UnbatchableBinnedEntityIndices (:2195-2222): extra index = instance..instance+1, or None */
+    uint32_t bin, instance_index;
+} mi_unbatchable_index;
 typedef struct mi_batch_initial {
     uint32_t work_item_index[2], indirect_parameters_index[2], batch_set_index[2], output_mesh_uniform_index;
 } mi_batch_initial;
 typedef struct mi_batch_totals {
-    uint32_t work_item_len[2], indirect_parameters_len[2], batch_set_len[2], data_buffer_len, n_records;
+    uint32_t work_item_len[2], indirect_parameters_len[2], batch_set_len[2], data_buffer_len, n_records, n_unbatchable;
 } mi_batch_totals;
 
+/* input_uniform_index = MI_NO_INPUT_INDEX: GetFullBatchData::get_binned_index / get_index_and_compare_data returned None. */
+#define MI_NO_INPUT_INDEX 0xFFFFFFFFu
+#define MI_NO_INDEX 0xFFFFFFFFu /* PhaseItemExtraIndex::None in an output */
 int32_t mi_batch_upload_rows(mi_ctx* ctx, uint32_t first_row, uint32_t n, const uint32_t* batch_set, const uint32_t* bin_index,
                              const uint32_t* input_uniform_index);
 /* n_sets <= 65536.  Replaces the previous tables. */
 int32_t mi_batch_upload_sets(mi_ctx* ctx, uint32_t n_sets, const uint8_t* set_indexed, const uint32_t* bin_table_offset,
                              const uint32_t* bin_index_to_bin_metadata_index, const uint32_t* meta_offset,
                              const mi_bin_metadata* bin_metadata);
-/* After mi_cull / mi_propagate_and_cull of the same frame.  initial = NULL: all zero.  Enqueues only. */
+/* The part of the same binned phase the reference builds on the CPU -- unbatchable and batchable-but-not-multidrawable bins
+ * (gpu_preprocessing.rs:2135-2357).  Per row its kind and, for the two CPU kinds, its bin; bins are numbered in the order
+ * phase.unbatchable_meshes / phase.batchable_meshes iterate after sort_binned_render_phase (batching/mod.rs:199-209) and carry
+ * their mesh class (key.0.indexed()).  Rows never uploaded are MI_BATCH_ROW_MULTIDRAWABLE (placed by mi_batch_upload_rows).
+ * n_sets + n_batchable_bins + 2 * n_unbatchable_bins <= 65536. */
+#define MI_BATCH_ROW_MULTIDRAWABLE 0u
+#define MI_BATCH_ROW_BATCHABLE 1u
+#define MI_BATCH_ROW_UNBATCHABLE 2u
+#define MI_BATCH_ROW_NONE 3u
+int32_t mi_batch_upload_row_bins(mi_ctx* ctx, uint32_t first_row, uint32_t n, const uint8_t* kind, const uint32_t* bin);
+int32_t mi_batch_upload_bins(mi_ctx* ctx, uint32_t n_unbatchable_bins, const uint8_t* unbatchable_indexed, uint32_t n_batchable_bins,
+                             const uint8_t* batchable_indexed);
+/* After mi_cull / mi_propagate_and_cull of the same frame.  initial = NULL: all zero.  Enqueues only: three kernel launches.
+ * One view's whole phase in the reference's order: unbatchables, batchables, multidrawable batch sets.
+ * mi_batch_build = mi_batch_build_phase with flags 0.  MI_BATCH_NO_INDIRECT_DRAWING: the view has NoIndirectDrawing -- work items
+ * carry output indices, no indirect parameters or batch sets are allocated, multidrawable rows are ignored (the reference puts
+ * nothing into multidrawable_meshes without multidraw). */
+#define MI_BATCH_NO_INDIRECT_DRAWING 0x1u
 int32_t mi_batch_build(mi_ctx* ctx, uint32_t view, uint32_t class_bit, const mi_batch_initial* initial);
+int32_t mi_batch_build_phase(mi_ctx* ctx, uint32_t view, uint32_t class_bit, const mi_batch_initial* initial, uint32_t flags);
 int32_t mi_batch_download_totals(mi_ctx* ctx, mi_batch_totals* out);
 /* Element [0, len) of one output array, indices absolute (the region below `initial` reads as zeros). */
 #define MI_BATCH_WORK_ITEMS 0                   /* mi_preprocess_work_item */
@@ -523,7 +551,28 @@ int32_t mi_batch_download_totals(mi_ctx* ctx, mi_batch_totals* out);
 #define MI_BATCH_SETS 2                         /* mi_indirect_batch_set */
 #define MI_BATCH_RECORDS 3                      /* mi_batch_set_record; mesh_class ignored */
 #define MI_BATCH_BIN_METADATA 4                 /* mi_bin_metadata with instance_count filled in; mesh_class ignored */
+#define MI_BATCH_UNBATCHABLE_INDICES 5          /* mi_unbatchable_index in (bin, list) order; mesh_class ignored */
+#define MI_BATCH_SORTED_BATCHES 6               /* mi_sorted_batch after mi_batch_sorted_build; mesh_class ignored */
 int32_t mi_batch_download(mi_ctx* ctx, uint32_t what, uint32_t mesh_class, void* out, uint32_t capacity_elems, uint32_t* out_count);
+
+/* Sorted phases: gpu_preprocessing::batch_and_prepare_sorted_render_phase (gpu_preprocessing.rs:1850-2061) and, with
+ * MI_SORTED_NO_GPU_PREPROCESSING, the range merge of batching::batch_and_prepare_sorted_render_phase (batching/mod.rs:219-244) as
+ * no_gpu_preprocessing.rs:76-103 drives it.  items[] (host) is phase.items in its sorted order.  Per item what
+ * get_index_and_compare_data returned: input_index (MI_NO_INPUT_INDEX = None), and if MI_SORTED_ITEM_HAS_COMPARE_DATA the batch-set
+ * key -- the whole BatchSetMeta (pipeline, draw function, dynamic offset, compare data; batching/mod.rs:42-72) interned to one id --
+ * and the bin key (BatchCompareData).  Outputs: work items / metadata / batch sets per mesh class as above (appended at `initial`),
+ * one mi_sorted_batch per batch set = what flush() writes on the set's first item (:1767-1794), totals (n_records = batch sets).
+ * MI_SORTED_NO_GPU_PREPROCESSING: only the batches (instance ranges starting at initial->output_mesh_uniform_index). */
+#define MI_SORTED_ITEM_INDEXED 1u
+#define MI_SORTED_ITEM_HAS_COMPARE_DATA 2u
+typedef struct mi_sorted_item { uint32_t input_index, batch_set_key, bin_key, flags; } mi_sorted_item;
+typedef struct mi_sorted_batch {
+    uint32_t first_item, instance_start, instance_end, indirect_parameters_start, indirect_parameters_end, indexed;
+} mi_sorted_batch;
+#define MI_SORTED_AUTOMATIC_BATCHING 0x1u   /* I::AUTOMATIC_BATCHING */
+#define MI_SORTED_NO_INDIRECT_DRAWING 0x2u
+#define MI_SORTED_NO_GPU_PREPROCESSING 0x4u
+int32_t mi_batch_sorted_build(mi_ctx* ctx, uint32_t n_items, const mi_sorted_item* items, const mi_batch_initial* initial, uint32_t flags);
 
 /* ======================================================================================= */
 /* camera helpers (pure host code; what update_frusta computes, visibility/mod.rs:627-636)   */

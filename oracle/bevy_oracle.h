@@ -358,6 +358,34 @@ uint32_t orc_batch_build(uint32_t n_list, const uint32_t* rows, const uint32_t* 
                          orc_preprocess_work_item* work_items[2], orc_indirect_parameters_metadata* metadata[2],
                          orc_indirect_batch_set* batch_sets[2], orc_batch_set_record* records, orc_batch_totals* totals);
 
+/* ---- the CPU-built part of a binned phase and the sorted phases (batching_oracle.c) ------------------------ */
+#define ORC_ROW_MULTIDRAWABLE 0u /* row_kind: the row's place is row_batch_set (or nowhere) */
+#define ORC_ROW_BATCHABLE 1u     /* in batchable bin row_bin */
+#define ORC_ROW_UNBATCHABLE 2u   /* in unbatchable bin row_bin */
+#define ORC_NO_INPUT_INDEX 0xFFFFFFFFu /* GetFullBatchData::get_binned_index / get_index_and_compare_data returned None */
+#define ORC_NO_INDEX 0xFFFFFFFFu       /* PhaseItemExtraIndex::None */
+#define ORC_RECORD_BATCHABLE_BIN 0x80000000u /* orc_batch_set_record.set of a batchable bin's batch */
+typedef struct orc_unbatchable_index { uint32_t bin, instance_index; } orc_unbatchable_index; /* UnbatchableBinnedEntityIndices */
+uint32_t orc_batch_cpu_bins(uint32_t n_list, const uint32_t* rows, const uint8_t* row_kind, const uint32_t* row_bin,
+                            const uint32_t* row_input_uniform_index, uint32_t n_unbatchable_bins, const uint8_t* unbatchable_indexed,
+                            uint32_t n_batchable_bins, const uint8_t* batchable_indexed, int no_indirect_drawing,
+                            const orc_batch_initial* initial, orc_preprocess_work_item* work_items[2],
+                            orc_indirect_parameters_metadata* metadata[2], orc_indirect_batch_set* batch_sets[2],
+                            orc_unbatchable_index* unbatchable_indices, uint32_t* n_unbatchable_indices,
+                            orc_batch_set_record* records, orc_batch_totals* totals);
+#define ORC_ITEM_INDEXED 1u          /* SortedPhaseItem::indexed() */
+#define ORC_ITEM_HAS_COMPARE_DATA 2u /* the Option<(BatchSetCompareData, BatchCompareData)> is Some */
+typedef struct orc_sorted_item { uint32_t input_index, batch_set_key, bin_key, flags; } orc_sorted_item;
+typedef struct orc_sorted_batch {  /* what flush() leaves on the batch set's first phase item, gpu_preprocessing.rs:1767-1794 */
+    uint32_t first_item, instance_start, instance_end, indirect_parameters_start, indirect_parameters_end, indexed;
+} orc_sorted_batch;
+uint32_t orc_batch_sorted(uint32_t n_items, const orc_sorted_item* items, int automatic_batching, int no_indirect_drawing,
+                          const orc_batch_initial* initial, orc_preprocess_work_item* work_items[2],
+                          orc_indirect_parameters_metadata* metadata[2], orc_indirect_batch_set* batch_sets[2],
+                          orc_sorted_batch* batches, orc_batch_totals* totals);
+uint32_t orc_batch_sorted_merge(uint32_t n_items, const orc_sorted_item* items, int automatic_batching, uint32_t first_index,
+                                orc_sorted_batch* batches, uint32_t* buffer_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -503,6 +503,118 @@ def batch_build(rows, row_set, row_bin, row_input, set_indexed, bin_table_offset
                 bin_metadata=meta)
 
 
+ROW_MULTIDRAWABLE, ROW_BATCHABLE, ROW_UNBATCHABLE = 0, 1, 2
+NO_INPUT_INDEX = 0xFFFFFFFF
+NO_INDEX = 0xFFFFFFFF
+RECORD_BATCHABLE_BIN = 0x80000000
+ITEM_INDEXED, ITEM_HAS_COMPARE_DATA = 1, 2
+
+
+def _totals_dict(tot):
+    return dict(work_item_len=list(tot.work_item_len), indirect_parameters_len=list(tot.indirect_parameters_len),
+                batch_set_len=list(tot.batch_set_len), data_buffer_len=int(tot.data_buffer_len))
+
+
+def initial_from_totals(t):
+    ini = BatchInitial()
+    for c in range(2):
+        ini.work_item_index[c] = t["work_item_len"][c]
+        ini.indirect_parameters_index[c] = t["indirect_parameters_len"][c]
+        ini.batch_set_index[c] = t["batch_set_len"][c]
+    ini.output_mesh_uniform_index = t["data_buffer_len"]
+    return ini
+
+
+def batch_cpu_bins(rows, row_kind, row_bin, row_input, unbatchable_indexed, batchable_indexed, no_indirect_drawing=False, initial=None):
+    """The unbatchable + batchable loops (gpu_preprocessing.rs:2135-2357) for one view's list.
+    -> dict(work_items, metadata, batch_sets (per class), unbatchable u32[k,2] (bin, instance_index), records u32[k,8], totals)"""
+    rows = np.ascontiguousarray(rows, np.uint32)
+    ini = initial if initial is not None else BatchInitial()
+    n = len(rows)
+    wi = [np.zeros((int(ini.work_item_index[c]) + n + 1, 2), np.uint32) for c in range(2)]
+    md = [np.zeros((int(ini.indirect_parameters_index[c]) + n + 1, 5), np.uint32) for c in range(2)]
+    bs = [np.zeros((int(ini.batch_set_index[c]) + n + 1, 2), np.uint32) for c in range(2)]
+    unb = np.zeros((n + 1, 2), np.uint32)
+    rec = np.zeros((len(batchable_indexed) + 1, 8), np.uint32)
+    n_unb = C.c_uint32(0)
+    tot = BatchTotals()
+    P2 = C.c_void_p * 2
+    lib().orc_batch_cpu_bins.restype = C.c_uint32
+    lib().orc_batch_cpu_bins(C.c_uint32(n), u32p(rows), u8p(np.ascontiguousarray(row_kind, np.uint8)),
+                             u32p(np.ascontiguousarray(row_bin, np.uint32)), u32p(np.ascontiguousarray(row_input, np.uint32)),
+                             C.c_uint32(len(unbatchable_indexed)), u8p(np.ascontiguousarray(unbatchable_indexed, np.uint8)),
+                             C.c_uint32(len(batchable_indexed)), u8p(np.ascontiguousarray(batchable_indexed, np.uint8)),
+                             C.c_int(int(bool(no_indirect_drawing))), C.byref(ini), P2(wi[0].ctypes.data, wi[1].ctypes.data),
+                             P2(md[0].ctypes.data, md[1].ctypes.data), P2(bs[0].ctypes.data, bs[1].ctypes.data),
+                             unb.ctypes.data_as(C.c_void_p), C.byref(n_unb), rec.ctypes.data_as(C.c_void_p), C.byref(tot))
+    return dict(work_items=[wi[c][:tot.work_item_len[c]] for c in range(2)],
+                metadata=[md[c][:tot.indirect_parameters_len[c]] for c in range(2)],
+                batch_sets=[bs[c][:tot.batch_set_len[c]] for c in range(2)], unbatchable=unb[:n_unb.value],
+                records=rec[:tot.n_records], totals=_totals_dict(tot))
+
+
+def batch_phase(rows, ph, no_indirect_drawing=False, initial=None):
+    """One view's whole binned phase as the reference builds it: unbatchables, batchables (CPU loops), then -- with indirect
+    drawing -- the multidrawable batch sets starting from the lengths the CPU loops left (gpu_preprocessing.rs:2431-2447).
+    `ph` is a workloads.phase_scene dict.  Arrays are absolute (index 0 = start of the buffer; below `initial` zeros)."""
+    cpu = batch_cpu_bins(rows, ph["row_kind"], ph["row_cpu_bin"], ph["row_input"], ph["unbatchable_indexed"], ph["batchable_indexed"],
+                         no_indirect_drawing, initial)
+    if no_indirect_drawing:
+        cpu["bin_metadata"] = np.ascontiguousarray(ph["bin_metadata"], np.uint32).reshape(-1, 3).copy()
+        cpu["bin_metadata"][:, 2] = 0
+        return cpu
+    multi_rows = np.ascontiguousarray(rows, np.uint32)
+    row_set = np.where(np.asarray(ph["row_kind"]) == ROW_MULTIDRAWABLE, ph["row_set"], NO_BATCH_SET).astype(np.uint32)
+    md = batch_build(multi_rows, row_set, ph["row_bin"], ph["row_input"], ph["set_indexed"], ph["bin_table_offset"], ph["bin_table"],
+                     ph["meta_offset"], ph["bin_metadata"], initial_from_totals(cpu["totals"]))
+    out = dict(unbatchable=cpu["unbatchable"], records=np.concatenate([cpu["records"], md["records"]]), totals=md["totals"],
+               bin_metadata=md["bin_metadata"])
+    for k in ("work_items", "metadata", "batch_sets"):
+        out[k] = []
+        for c in range(2):
+            a = md[k][c].copy()
+            a[:len(cpu[k][c])] = cpu[k][c]  # the multidrawable pass leaves the region below its `initial` zero
+            out[k].append(a)
+    return out
+
+
+def _sorted_call(fn, items, automatic_batching, *rest):
+    it = np.ascontiguousarray(items, np.uint32).reshape(-1, 4)
+    return it, [C.c_uint32(len(it)), it.ctypes.data_as(C.c_void_p), C.c_int(int(bool(automatic_batching)))] + list(rest)
+
+
+def batch_sorted(items, automatic_batching=True, no_indirect_drawing=False, initial=None):
+    """gpu_preprocessing::batch_and_prepare_sorted_render_phase over items u32[n,4] (input_index, batch_set_key, bin_key, flags)."""
+    ini = initial if initial is not None else BatchInitial()
+    n = len(np.asarray(items).reshape(-1, 4))
+    wi = [np.zeros((int(ini.work_item_index[c]) + n + 1, 2), np.uint32) for c in range(2)]
+    md = [np.zeros((int(ini.indirect_parameters_index[c]) + n + 1, 5), np.uint32) for c in range(2)]
+    bs = [np.zeros((int(ini.batch_set_index[c]) + n + 1, 2), np.uint32) for c in range(2)]
+    bat = np.zeros((n + 1, 6), np.uint32)
+    tot = BatchTotals()
+    P2 = C.c_void_p * 2
+    it, args = _sorted_call(None, items, automatic_batching, C.c_int(int(bool(no_indirect_drawing))), C.byref(ini),
+                            P2(wi[0].ctypes.data, wi[1].ctypes.data), P2(md[0].ctypes.data, md[1].ctypes.data),
+                            P2(bs[0].ctypes.data, bs[1].ctypes.data), bat.ctypes.data_as(C.c_void_p), C.byref(tot))
+    lib().orc_batch_sorted.restype = C.c_uint32
+    k = lib().orc_batch_sorted(*args)
+    return dict(work_items=[wi[c][:tot.work_item_len[c]] for c in range(2)],
+                metadata=[md[c][:tot.indirect_parameters_len[c]] for c in range(2)],
+                batch_sets=[bs[c][:tot.batch_set_len[c]] for c in range(2)], batches=bat[:k], totals=_totals_dict(tot))
+
+
+def batch_sorted_merge(items, automatic_batching=True, first_index=0):
+    """batching::batch_and_prepare_sorted_render_phase (mod.rs:219-244) under no_gpu_preprocessing.rs:76-103.
+    -> (batches u32[k,6], buffer_len)"""
+    n = len(np.asarray(items).reshape(-1, 4))
+    bat = np.zeros((n + 1, 6), np.uint32)
+    blen = C.c_uint32(0)
+    it, args = _sorted_call(None, items, automatic_batching, C.c_uint32(first_index), bat.ctypes.data_as(C.c_void_p), C.byref(blen))
+    lib().orc_batch_sorted_merge.restype = C.c_uint32
+    k = lib().orc_batch_sorted_merge(*args)
+    return bat[:k], int(blen.value)
+
+
 def bench_tree_frame(parent, level_offsets, t, r, s, threads, iters):
     """Level-parallel propagate (all Transforms changed) on a persistent pool; -> (seconds, G)."""
     n = len(parent)

@@ -154,3 +154,96 @@ def test_batch_build_errors(ctx_factory):
     assert got["totals"]["data_buffer_len"] == 0 and len(got["records"]) == 0
     with pytest.raises(api.MiError):
         ctx.batch_build(3, 0)  # no such view
+
+
+# ---- the whole binned phase (unbatchables, batchables, multidrawables) and the sorted phases ---------------------------------
+def assert_same_phase(got, exp):
+    assert_same(got, exp)
+    assert np.array_equal(got["unbatchable"], exp["unbatchable"])
+
+
+def upload_phase(ctx, ph):
+    ctx.batch_upload_rows(ph["row_set"], ph["row_bin"], ph["row_input"])
+    ctx.batch_upload_sets(ph["set_indexed"], ph["bin_table_offset"], ph["bin_table"], ph["meta_offset"], ph["bin_metadata"])
+    ctx.batch_upload_row_bins(ph["row_kind"], ph["row_cpu_bin"])
+    ctx.batch_upload_bins(ph["unbatchable_indexed"], ph["batchable_indexed"])
+
+
+@pytest.mark.parametrize("n,n_sets,n_unb,n_bat,radius,initial", [
+    (1, 1, 1, 1, 5.0, None), (5000, 7, 5, 6, 30.0, INITIAL), (70_001, 40, 30, 50, 60.0, None), (300_000, 1, 3, 2, 40.0, INITIAL),
+    (60_000, 300, 20, 20, 30.0, INITIAL),   # more than 256 buckets: the two-pass partition
+    (20_000, 0, 9, 4, 25.0, None),          # a phase without multidrawable sets
+    (20_000, 6, 0, 0, 25.0, None)])
+def test_phase_build_matches_oracle(ctx_factory, n, n_sets, n_unb, n_bat, radius, initial):
+    """One view's whole binned phase in the reference's order -- unbatchable bins, batchable bins, multidrawable batch sets
+    (gpu_preprocessing.rs:2135-2455) -- in three launches, every output array bit-exact, with and without indirect drawing."""
+    sc = W.many_cubes(n, radius=radius, ragged_flags=True)
+    ph = W.phase_scene(n, n_sets=n_sets, n_unbatchable_bins=n_unb, n_batchable_bins=n_bat, seed=n + n_sets, cpu_fraction=0.3)
+    ctx = ctx_factory()
+    upload_scene(ctx, sc)
+    upload_phase(ctx, ph)
+    views = frusta_for([W.many_cubes_camera(0), W.many_cubes_camera(0, yaw=2.5)])
+    for frame in range(2):  # second frame: scratch, the instance counters and the bucket tables are reused
+        ctx.propagate_and_cull(views, flags=B.CULL_END_FRAME)
+        for v in range(2):
+            rows = ctx.download_visible_entities(v, 0)[1]
+            for no_indirect in (False, True, False):
+                ctx.batch_build(v, 0, initial, no_indirect_drawing=no_indirect)
+                assert_same_phase(ctx.batch_download(), O.batch_phase(rows, ph, no_indirect, oracle_initial(initial)))
+        views = frusta_for([W.many_cubes_camera(7), W.many_cubes_camera(7, yaw=2.5)])
+    if n >= 5000:
+        exp = O.batch_phase(rows, ph, False, oracle_initial(initial))
+        assert len(rows) > 100 and (n_unb == 0 or len(exp["unbatchable"]) > 0) and (n_bat == 0 or (exp["records"][:, 0] >= 0x80000000).any())
+
+
+def test_phase_tables_can_change_between_builds(ctx_factory):
+    n = 30_000
+    sc = W.many_cubes(n, radius=25.0)
+    ctx = ctx_factory()
+    upload_scene(ctx, sc)
+    ctx.propagate_and_cull(frusta_for([W.many_cubes_camera(0)]), flags=B.CULL_END_FRAME)
+    rows = ctx.download_visible_entities(0, 0)[1]
+    for seed, n_sets, n_unb, n_bat in ((1, 5, 4, 3), (2, 9, 0, 7), (3, 2, 6, 0), (4, 5, 4, 3)):
+        ph = W.phase_scene(n, n_sets=n_sets, n_unbatchable_bins=n_unb, n_batchable_bins=n_bat, seed=seed, cpu_fraction=0.4)
+        upload_phase(ctx, ph)
+        ctx.batch_build(0, 0)
+        assert_same_phase(ctx.batch_download(), O.batch_phase(rows, ph))
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 700, 1024, 1025, 9000, 100_000])
+def test_sorted_build_matches_oracle(ctx_factory, n):
+    """batch_and_prepare_sorted_render_phase (gpu_preprocessing.rs:1850-2061) and the range merge of batching/mod.rs:219-244."""
+    ctx = ctx_factory()
+    ctx.resize(1)
+    items = W.sorted_items(n, seed=n + 1)
+    for automatic, no_indirect, initial in ((True, False, None), (True, False, INITIAL), (True, True, INITIAL), (False, False, None)):
+        ctx.batch_sorted_build(items, automatic, no_indirect, False, initial)
+        got = ctx.batch_download()
+        exp = O.batch_sorted(items, automatic, no_indirect, oracle_initial(initial))
+        assert got["totals"] == exp["totals"]
+        assert np.array_equal(got["batches"], exp["batches"])
+        for c in range(2):
+            for key in ("work_items", "metadata", "batch_sets"):
+                assert np.array_equal(got[key][c], exp[key][c]), (key, c, automatic, no_indirect)
+    for automatic in (True, False):
+        ctx.batch_sorted_build(items, automatic, False, True, (0, 0, 0, 0, 0, 0, 41))
+        got = ctx.batch_download()
+        b, blen = O.batch_sorted_merge(items, automatic, 41)
+        assert np.array_equal(got["batches"], b) and got["totals"]["data_buffer_len"] == blen
+    if n >= 700:
+        assert 0 < len(exp["batches"]) < n
+
+
+def test_sorted_build_long_runs_cross_chunks(ctx_factory):
+    """Batch sets longer than the kernel's 1024-item chunk, and one that spans the whole phase."""
+    ctx = ctx_factory()
+    ctx.resize(1)
+    for n, run in ((5000, 3000), (4096, 100_000), (3000, 1)):
+        items = W.sorted_items(n, seed=3, run=run, no_input_fraction=0.0, no_meta_fraction=0.0)
+        ctx.batch_sorted_build(items, True, False, False, INITIAL)
+        got = ctx.batch_download()
+        exp = O.batch_sorted(items, True, False, oracle_initial(INITIAL))
+        assert np.array_equal(got["batches"], exp["batches"]) and got["totals"] == exp["totals"]
+        for c in range(2):
+            for key in ("work_items", "metadata", "batch_sets"):
+                assert np.array_equal(got[key][c], exp[key][c]), (key, c, n, run)

@@ -22,7 +22,7 @@ ALIAS = {"k_frame<true": "k_flat_propagate_cull", "k_frame<false": "k_cull"}  # 
 
 
 def short(name):
-    n = name.replace("void ", "").replace("mi::", "")
+    n = name.replace("void ", "").replace("(anonymous namespace)::", "").replace("mi::", "")
     for k, v in ALIAS.items():
         if n.startswith(k):
             return v

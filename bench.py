@@ -66,6 +66,7 @@ def parse():
                     help="frame: mi_propagate_and_cull, then mi_cluster_assign_resident behind it (default: ONE call with "
                          "MI_CULL_WITH_CLUSTERS, the assignment concurrent with the frame kernel on the cluster stream)")
     ap.add_argument("--concurrent-clusters", action="store_true", help="frame: add MI_CULL_CLUSTERS_CONCURRENT")
+    ap.add_argument("--tile-mode", type=int, default=0, help="tree: 0 = tile kernel chosen by size, 1 = big tiles, 2 / 3 = light tiles (5 / 6 waves per SIMD)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
@@ -231,7 +232,10 @@ def build_tree(ctx, args, rank=0, world=1):
                   scale=tr["scale"].reshape(-1, 3)[rows].reshape(-1), owned=int(sh["owned"].sum()))
     ctx.resize(tr["n"])
     ctx.upload_transforms(tr["translation"], tr["rotation"], tr["scale"])
+    if args.tile_mode:
+        ctx.debug_set_tile_mode(args.tile_mode)
     ctx.upload_hierarchy(tr["parent"], tr["level_offsets"])
+    plan = ctx.debug_tile_plan()
     # the root moves every frame (a 40-byte dirty-row upload), so set_if_neq really rewrites every descendant
     root_t = [tr["translation"][:3].copy(), tr["translation"][:3] + np.float32(1.0)]
 
@@ -241,7 +245,7 @@ def build_tree(ctx, args, rank=0, world=1):
     config = {"workload": f"gen_tree(12,4) truncated to {n_global} nodes ({len(tr['level_offsets']) - 1} levels), root moved "
                           "every frame (dirty-row upload), subtree-tile propagation"
                           + (f", sharded by root subtree over {world} GPUs (this rank holds {tr['n']} rows, no collective)" if world > 1 else ""),
-              "baseline_config": "BASELINE.json configs[4]", "nodes": n_global, "parallelism": f"root-subtree shard x{world}"}
+              "baseline_config": "BASELINE.json configs[4]", "nodes": n_global, "parallelism": f"root-subtree shard x{world}", "tile_plan": plan}
     # T 40, parent_idx 4, old G 48 (set_if_neq), G 48, changed byte 1
     wl = Workload("tree", step, tr["n"], 141.0, "k_propagate_tiles", config, "nodes/sec through hierarchy propagate", "nodes/s",
                   kernels=["k_propagate_tiles", "k_propagate_stream"])

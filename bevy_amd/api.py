@@ -288,6 +288,9 @@ class Context:
             raise MiError(rc, msg)
         self.n = 0
         self.n_views = 0
+        # test harness only: run a whole test session under one tile kernel (the library itself reads no environment)
+        if os.environ.get("MI_TEST_TILE_MODE"):
+            self.debug_set_tile_mode(int(os.environ["MI_TEST_TILE_MODE"]))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -673,6 +676,20 @@ class Context:
             if name and launches[k]:
                 out[name.decode()] = {"launches": int(launches[k]), "total_ms": float(ms[k]),
                                       "avg_us": 1e3 * float(ms[k]) / int(launches[k])}
+        return out
+
+    def debug_set_tile_mode(self, mode):
+        """Which tile kernel the next upload_hierarchy plans for: 0 by size, 1 big tiles, 2 / 3 light tiles (test / bench hook)."""
+        self._ck(self._lib.mi_debug_set_tile_mode(self._h, int(mode)))
+
+    def debug_tree_trace(self, n_tiles=0):
+        """Development hook: n_tiles == 0 enables the per-tile phase timestamps of the light tile kernel; otherwise returns
+        them as an (n_tiles, 8) uint64 array of 10 ns ticks."""
+        if not n_tiles:
+            self._ck(self._lib.mi_debug_tree_trace(self._h, 1, None, 0))
+            return None
+        out = np.zeros((n_tiles, 8), dtype=np.uint64)
+        self._ck(self._lib.mi_debug_tree_trace(self._h, 0, out.ctypes.data_as(C.c_void_p), int(n_tiles)))
         return out
 
     def debug_tile_plan(self):

@@ -74,115 +74,137 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
     // Roots and chain bands are mutually independent: they share ONE launch, whatever the depth of the hierarchy.
     std::vector<TileDesc> tiles;
     std::vector<uint32_t> chains;
-    ctx->passes.clear();
-    ctx->groups.clear();
-    ctx->stream_levels.clear();
-    auto level_size = [&](uint32_t lv) -> uint64_t { return lv < n_levels ? level_offsets[lv + 1] - level_offsets[lv] : 0; };
-    // A VERY wide deepest level is not tiled: a workgroup walking a tile is a chain of dependent round trips (descriptor,
-    // step 0, chain, LDS levels, then one round trip per 256 streamed rows) at 4 waves per SIMD; k_propagate_level sweeps a
-    // level at 8 waves per SIMD and the flat kernel's pace (650 k rows in 16.4 us = 5.6 TB/s).  But a tile launch has a floor
-    // of ~10 us however little it does, and a launch boundary costs ~1.8 us, so at 1 M nodes the single tile launch wins
-    // (33.5 us against 21.6 + 1.8 + 16.4 with the deepest level streamed); the streamed levels pay from a few million
-    // nodes up (thresholds in kernels.h).
-    uint32_t n_tile_levels = n_levels;
-    while (n_tile_levels > 1 &&
-           level_size(n_tile_levels - 1) >= (n_tile_levels == n_levels ? STREAM_LEVEL_MIN_ROWS_LAST : STREAM_LEVEL_MIN_ROWS))
-        --n_tile_levels;
-    for (uint32_t l = n_tile_levels; l < n_levels; ++l) ctx->stream_levels.emplace_back(level_offsets[l], level_offsets[l + 1] - level_offsets[l]);
-    struct Band { uint32_t s, e; bool chain; };
-    std::vector<Band> bands;  // bottom-up
-    for (uint32_t e = n_tile_levels; e > 0;) {
-        uint32_t s = e - 1;  // a band of one level always works
-        const uint32_t lo = e > TILE_MAX_LEVELS ? e - TILE_MAX_LEVELS : 0;
-        for (uint32_t cand = lo; cand + 1 < e; ++cand) {
-            // per first-level row, on average: the would-be upper levels must fit the LDS budget and the last level the cap
-            uint64_t upper = 0;
-            for (uint32_t l = cand; l + 1 < e; ++l) upper += level_size(l);
-            const uint64_t firsts = std::max<uint64_t>(1, level_size(cand));
-            if (upper <= (uint64_t)TILE_UCAP * firsts && level_size(e - 1) <= (uint64_t)TILE_LAST_CAP * firsts) { s = cand; break; }
-        }
-        uint64_t rows = 0;
-        for (uint32_t l = s; l < e; ++l) rows += level_size(l);
-        // worth a chain per tile unless the band is a swarm of tiny tiles: (tiles x chain length) node products are spent on
-        // chains; keep that within a few times the band's own rows
-        const uint64_t est_tiles = std::max<uint64_t>(std::max<uint64_t>(1, level_size(s - (s ? 1 : 0))), rows / (TILE_UCAP + TILE_LAST_CAP));
-        const bool chain = s > 0 && s <= TILE_MAX_CHAIN && est_tiles * s <= 4 * rows + 4096;
-        bands.push_back({s, e, chain});
-        e = s;
-    }
-    // tiles of one band: galloping extension of the first-level range while the tile still fits
-    auto build_band = [&](const Band& bd, uint32_t kind_base) {
-        const uint32_t d = bd.e - bd.s;
-        auto build = [&](uint32_t lo, uint32_t hi, TileDesc& td) -> bool {  // [lo,hi): rows of level bd.s
-            td = TileDesc{};
-            uint32_t clo = lo, chi2 = hi;
-            for (uint32_t k = 0; k < d; ++k) {
-                td.start[k] = clo;
-                td.count[k] = chi2 - clo;
-                if (chi2 > clo) td.n_levels = k + 1;
-                if (k + 1 < d) {
-                    const uint32_t nlo = child_begin(bd.s + k, clo), nhi = child_begin(bd.s + k, chi2);
-                    clo = nlo;
-                    chi2 = nhi;
-                }
+    auto make_plan = [&](const bool light) {
+        tiles.clear();
+        chains.clear();
+        // Big hierarchies are cut into light tiles (kernels.h): four times as many, each short-lived, several rounds of them per
+        // CU -- the head of one tile (descriptor, ancestor chain, LDS levels) then runs under the streaming of its neighbours.
+        const uint32_t UCAP = light ? TILE_LIGHT_UCAP : TILE_UCAP, LAST_CAP = light ? TILE_LIGHT_LAST_CAP : TILE_LAST_CAP;
+        ctx->tiles_light = light;
+        ctx->passes.clear();
+        ctx->groups.clear();
+        ctx->stream_levels.clear();
+        auto level_size = [&](uint32_t lv) -> uint64_t { return lv < n_levels ? level_offsets[lv + 1] - level_offsets[lv] : 0; };
+        // A VERY wide deepest level is not tiled: a workgroup walking a tile is a chain of dependent round trips (descriptor,
+        // step 0, chain, LDS levels, then one round trip per 256 streamed rows) at 4 waves per SIMD; k_propagate_level sweeps a
+        // level at 8 waves per SIMD and the flat kernel's pace (650 k rows in 16.4 us = 5.6 TB/s).  But a tile launch has a floor
+        // of ~10 us however little it does, and a launch boundary costs ~1.8 us, so at 1 M nodes the single tile launch wins
+        // (33.5 us against 21.6 + 1.8 + 16.4 with the deepest level streamed); the streamed levels pay from a few million
+        // nodes up (thresholds in kernels.h).
+        uint32_t n_tile_levels = n_levels;
+        while (n_tile_levels > 1 &&
+               level_size(n_tile_levels - 1) >= (n_tile_levels == n_levels ? STREAM_LEVEL_MIN_ROWS_LAST : STREAM_LEVEL_MIN_ROWS))
+            --n_tile_levels;
+        for (uint32_t l = n_tile_levels; l < n_levels; ++l) ctx->stream_levels.emplace_back(level_offsets[l], level_offsets[l + 1] - level_offsets[l]);
+        struct Band { uint32_t s, e; bool chain; };
+        std::vector<Band> bands;  // bottom-up
+        for (uint32_t e = n_tile_levels; e > 0;) {
+            uint32_t s = e - 1;  // a band of one level always works
+            const uint32_t lo = e > TILE_MAX_LEVELS ? e - TILE_MAX_LEVELS : 0;
+            for (uint32_t cand = lo; cand + 1 < e; ++cand) {
+                // per first-level row, on average: the would-be upper levels must fit the LDS budget and the last level the cap
+                uint64_t upper = 0;
+                for (uint32_t l = cand; l + 1 < e; ++l) upper += level_size(l);
+                const uint64_t firsts = std::max<uint64_t>(1, level_size(cand));
+                if (upper <= (uint64_t)UCAP * firsts && level_size(e - 1) <= (uint64_t)LAST_CAP * firsts) { s = cand; break; }
             }
+            uint64_t rows = 0;
+            for (uint32_t l = s; l < e; ++l) rows += level_size(l);
+            // worth a chain per tile unless the band is a swarm of tiny tiles: (tiles x chain length) node products are spent on
+            // chains; keep that within a few times the band's own rows
+            const uint64_t est_tiles = std::max<uint64_t>(std::max<uint64_t>(1, level_size(s - (s ? 1 : 0))), rows / (UCAP + LAST_CAP));
+            const bool chain = s > 0 && s <= TILE_MAX_CHAIN && est_tiles * s <= 4 * rows + 4096;
+            bands.push_back({s, e, chain});
+            e = s;
+        }
+        // tiles of one band: galloping extension of the first-level range while the tile still fits
+        auto build_band = [&](const Band& bd, uint32_t kind_base) {
+            const uint32_t d = bd.e - bd.s;
+            auto build = [&](uint32_t lo, uint32_t hi, TileDesc& td) -> bool {  // [lo,hi): rows of level bd.s
+                td = TileDesc{};
+                uint32_t clo = lo, chi2 = hi;
+                for (uint32_t k = 0; k < d; ++k) {
+                    td.start[k] = clo;
+                    td.count[k] = chi2 - clo;
+                    if (chi2 > clo) td.n_levels = k + 1;
+                    if (k + 1 < d) {
+                        const uint32_t nlo = child_begin(bd.s + k, clo), nhi = child_begin(bd.s + k, chi2);
+                        clo = nlo;
+                        chi2 = nhi;
+                    }
+                }
+                uint64_t up = 0;
+                for (uint32_t k = 0; k + 1 < td.n_levels; ++k) up += td.count[k];
+                return up <= UCAP && (td.n_levels == 0 || td.count[td.n_levels - 1] <= LAST_CAP);
+            };
+            const uint32_t rlo = level_offsets[bd.s], rhi = level_offsets[bd.s + 1];
+            const uint32_t first_tile = (uint32_t)tiles.size();
+            uint32_t a = rlo;
+            while (a < rhi) {
+                TileDesc best{};
+                uint32_t b = a + 1;
+                build(a, b, best);  // a single first-level row always makes a tile (the kernel streams what does not fit)
+                uint32_t step = 1;
+                while (b < rhi) {
+                    const uint32_t nb = (uint32_t)std::min<uint64_t>((uint64_t)b + step, rhi);
+                    TileDesc cand{};
+                    const bool same_parent = !bd.chain || parent_idx[nb - 1] == parent_idx[a];
+                    if (same_parent && build(a, nb, cand)) { best = cand; b = nb; step *= 2; }
+                    else if (step > 1) step = 1;
+                    else break;
+                }
+                if (best.n_levels) {
+                    best.kind = kind_base;
+                    if (bd.chain) {
+                        chains.resize((tiles.size() + 1) * (size_t)TILE_MAX_CHAIN, 0u);
+                        uint32_t row = parent_idx[best.start[0]], len = 0;
+                        while (row != MI_NO_PARENT && len < TILE_MAX_CHAIN) {
+                            chains[tiles.size() * (size_t)TILE_MAX_CHAIN + len++] = row;
+                            row = parent_idx[row];
+                        }
+                        best.kind = len;
+                    }
+                    tiles.push_back(best);
+                }
+                a = b;
+            }
+            return std::make_pair(first_tile, (uint32_t)tiles.size() - first_tile);
+        };
+        // launch 1: the chain bands, bottom band first (the longest tiles start first), then the roots band
+        std::vector<std::pair<uint32_t, uint32_t>> band_tiles(bands.size());
+        uint32_t n_chain_tiles = 0, owner_rows = 0;
+        for (size_t i = 0; i < bands.size(); ++i)
+            if (bands[i].chain) {
+                band_tiles[i] = build_band(bands[i], 0u);
+                n_chain_tiles += band_tiles[i].second;
+                owner_rows = std::max(owner_rows, level_offsets[bands[i].s]);  // the snapshot prefix: every row above the deepest chain band
+            }
+        band_tiles.back() = build_band(bands.back(), TILE_ROOTS);  // bands.back() starts at level 0
+        ctx->groups.push_back({0u, (uint32_t)tiles.size(), n_chain_tiles, owner_rows});
+        // then the dependent bands, top-down, one launch each
+        for (size_t i = bands.size(); i-- > 0;)
+            if (!bands[i].chain && bands[i].s > 0) {
+                band_tiles[i] = build_band(bands[i], 0u);
+                ctx->groups.push_back({band_tiles[i].first, band_tiles[i].second, 0u, 0u});
+            }
+        chains.resize(tiles.size() * (size_t)TILE_MAX_CHAIN, 0u);
+        // the bands top-down, for the kernels that sweep level by level with one launch per band (InheritedVisibility)
+        for (size_t i = bands.size(); i-- > 0;) ctx->passes.emplace_back(band_tiles[i].first, band_tiles[i].second);
+    };
+    bool light = (ctx->tile_mode == 2 || (ctx->tile_mode == 0 && n >= TILE_LIGHT_MIN_ROWS)) &&
+                 n <= 0xFFFFFFFFu / 48u;  // the light kernel addresses rows with 32-bit byte offsets
+    make_plan(light);
+    if (light) {
+        // the light kernel has no fallback for upper levels that overflow its LDS rows (a single node with hundreds of
+        // children that have children of their own): such a hierarchy keeps the big tiles, whose kernel streams what does not fit
+        bool fits = true;
+        for (const TileDesc& td : tiles) {
             uint64_t up = 0;
             for (uint32_t k = 0; k + 1 < td.n_levels; ++k) up += td.count[k];
-            return up <= TILE_UCAP && (td.n_levels == 0 || td.count[td.n_levels - 1] <= TILE_LAST_CAP);
-        };
-        const uint32_t rlo = level_offsets[bd.s], rhi = level_offsets[bd.s + 1];
-        const uint32_t first_tile = (uint32_t)tiles.size();
-        uint32_t a = rlo;
-        while (a < rhi) {
-            TileDesc best{};
-            uint32_t b = a + 1;
-            build(a, b, best);  // a single first-level row always makes a tile (the kernel streams what does not fit)
-            uint32_t step = 1;
-            while (b < rhi) {
-                const uint32_t nb = (uint32_t)std::min<uint64_t>((uint64_t)b + step, rhi);
-                TileDesc cand{};
-                const bool same_parent = !bd.chain || parent_idx[nb - 1] == parent_idx[a];
-                if (same_parent && build(a, nb, cand)) { best = cand; b = nb; step *= 2; }
-                else if (step > 1) step = 1;
-                else break;
-            }
-            if (best.n_levels) {
-                best.kind = kind_base;
-                if (bd.chain) {
-                    chains.resize((tiles.size() + 1) * (size_t)TILE_MAX_CHAIN, 0u);
-                    uint32_t row = parent_idx[best.start[0]], len = 0;
-                    while (row != MI_NO_PARENT && len < TILE_MAX_CHAIN) {
-                        chains[tiles.size() * (size_t)TILE_MAX_CHAIN + len++] = row;
-                        row = parent_idx[row];
-                    }
-                    best.kind = len;
-                }
-                tiles.push_back(best);
-            }
-            a = b;
+            fits = fits && up <= TILE_LIGHT_UCAP;
         }
-        return std::make_pair(first_tile, (uint32_t)tiles.size() - first_tile);
-    };
-    // launch 1: the chain bands, bottom band first (the longest tiles start first), then the roots band
-    std::vector<std::pair<uint32_t, uint32_t>> band_tiles(bands.size());
-    uint32_t n_chain_tiles = 0, owner_rows = 0;
-    for (size_t i = 0; i < bands.size(); ++i)
-        if (bands[i].chain) {
-            band_tiles[i] = build_band(bands[i], 0u);
-            n_chain_tiles += band_tiles[i].second;
-            owner_rows = std::max(owner_rows, level_offsets[bands[i].s]);  // the snapshot prefix: every row above the deepest chain band
-        }
-    band_tiles.back() = build_band(bands.back(), TILE_ROOTS);  // bands.back() starts at level 0
-    ctx->groups.push_back({0u, (uint32_t)tiles.size(), n_chain_tiles, owner_rows});
-    // then the dependent bands, top-down, one launch each
-    for (size_t i = bands.size(); i-- > 0;)
-        if (!bands[i].chain && bands[i].s > 0) {
-            band_tiles[i] = build_band(bands[i], 0u);
-            ctx->groups.push_back({band_tiles[i].first, band_tiles[i].second, 0u, 0u});
-        }
-    chains.resize(tiles.size() * (size_t)TILE_MAX_CHAIN, 0u);
-    // the bands top-down, for the kernels that sweep level by level with one launch per band (InheritedVisibility)
-    for (size_t i = bands.size(); i-- > 0;) ctx->passes.emplace_back(band_tiles[i].first, band_tiles[i].second);
+        if (!fits) make_plan(light = false);
+    }
     int32_t rc;
     if ((rc = ensure(ctx, ctx->parent_idx, (size_t)n * 4))) return rc;
     if ((rc = ensure(ctx, ctx->node_flags, n))) return rc;
@@ -199,6 +221,30 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
     ctx->level_offsets.assign(level_offsets, level_offsets + n_levels + 1);
     ctx->n_levels = n_levels;
     ctx->have_hierarchy = true;
+    return MI_OK;
+}
+
+// test / bench hook (not part of the public header): which tile kernel the NEXT mi_upload_hierarchy plans for
+// (0 = chosen by size, 1 = big tiles, 2 = light tiles where they fit)
+int32_t mi_debug_set_tile_mode(mi_ctx* ctx, int32_t mode) {
+    ENTER(ctx);
+    if (mode < 0 || mode > 2) return fail(ctx, MI_ERR_INVALID_ARG, "mi_debug_set_tile_mode: mode %d", mode);
+    ctx->tile_mode = mode;
+    return MI_OK;
+}
+
+// development hook: per-tile phase timestamps of the light tile kernel (8 x s_memrealtime, 100 MHz, per tile of the first
+// launch).  enable allocates the buffer (mi_propagate then fills it every frame); read copies it out.
+int32_t mi_debug_tree_trace(mi_ctx* ctx, int32_t enable, unsigned long long* out, uint32_t n_tiles) {
+    ENTER(ctx);
+    if (enable) {
+        size_t tiles = 1;
+        for (auto& g : ctx->groups) tiles = std::max<size_t>(tiles, g.count);
+        int32_t rc = ensure(ctx, ctx->tree_trace, tiles * 64);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->tree_trace.p, 0, tiles * 64, ctx->stream));
+    }
+    if (out && ctx->tree_trace.p) return download(ctx, out, ctx->tree_trace.p, std::min<size_t>((size_t)n_tiles * 64, ctx->tree_trace.bytes));
     return MI_OK;
 }
 

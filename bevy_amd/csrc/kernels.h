@@ -17,12 +17,14 @@ struct LaunchTimer {
 };
 extern thread_local const LaunchTimer* g_launch_timer;
 // Orders one wave's own LDS traffic (cross-lane exchange through a wave-private LDS region): waits for the
-// wave's outstanding LDS operations and stops the compiler from moving LDS accesses across it.
-#define MI_WAVE_LDS_SYNC()                                    \
-    do {                                                      \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
-        __builtin_amdgcn_wave_barrier();                      \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
+// wave's outstanding LDS operations and stops the compiler from moving LDS accesses across it.  The fences name the
+// LDS address space: a plain workgroup fence also drains vmcnt -- every global load AND STORE in flight -- which put a full
+// memory round trip in front of each transpose that follows a store.
+#define MI_WAVE_LDS_SYNC()                                             \
+    do {                                                               \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); \
+        __builtin_amdgcn_wave_barrier();                               \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); \
     } while (0)
 #define MI_LAUNCH(kernel, grid, block, lds, stream, ...)                                                        \
     do {                                                                                                        \
@@ -203,6 +205,11 @@ constexpr uint32_t TILE_MAX_LEVELS = 8;
 constexpr uint32_t TILE_BLOCK = 256;           // threads per tile
 constexpr uint32_t TILE_UCAP = 512;            // LDS slots of one tile: rows of all its levels but the last
 constexpr uint32_t TILE_LAST_CAP = 1024;       // the planner keeps a tile's streamed last level at or below this
+// Light tiles (big hierarchies): a quarter of the LDS rows and a last level of ONE batch -- one row per thread, nothing
+// software-pipelined -- so the kernel fits twice the workgroups per CU and a tile is two dependent round trips, not seven.
+constexpr uint32_t TILE_LIGHT_UCAP = 112;
+constexpr uint32_t TILE_LIGHT_LAST_CAP = 256;
+constexpr uint32_t TILE_LIGHT_MIN_ROWS = 1u << 16;  // hierarchies from this many rows up are planned as light tiles
 // A level this wide is not given to tiles at all: it is swept by a streaming launch of its own (k_propagate_level) behind
 // the level above it.  The deepest level qualifies earlier than the ones above it (nothing else has to wait for it).
 constexpr uint32_t STREAM_LEVEL_MIN_ROWS_LAST = 1u << 20;
@@ -222,8 +229,8 @@ hipError_t launch_mark_dirty(uint32_t n, const uint8_t* changed, const uint32_t*
 hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, const TileDesc* d_tiles, const uint32_t* d_chains,
                                   uint32_t n_tiles, const uint8_t* node_flags, const uint8_t* changed, const uint32_t* tree_bits,
                                   uint8_t* g_changed_bytes, const float* snap_read, float* snap_write, uint32_t snap_rows, bool all_dirty,
-                                  bool static_opt,
-                                  hipStream_t stream);
+                                  bool static_opt, bool light /* the plan is one of light tiles */, hipStream_t stream,
+                                  unsigned long long* trace = nullptr);
 // One whole level [start, start + count) as a stream: every row's parent lies in the level above, complete in global
 // memory (an earlier launch).  Same per-node rule as the tiles.
 hipError_t launch_propagate_level(const Columns& c, const uint32_t* parent_idx, uint32_t start, uint32_t count, const uint8_t* changed,

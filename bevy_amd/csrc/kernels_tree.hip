@@ -75,6 +75,36 @@ __device__ __forceinline__ void lds_put(float4* slots, uint32_t slot, const Affi
     slots[slot * 3u + 2u] = o2;
 }
 
+// Addressing with a uniform base and a 32-bit byte offset per lane (global_load ... v_off, s[base:base+1]): no 64-bit
+// address arithmetic in the vector ALU.  Good for rows below 2^32 / 48 (the planner keeps bigger contexts on the other kernel).
+template <class T>
+__device__ __forceinline__ const T& at32(const void* base, uint32_t byte_off) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <class T>
+__device__ __forceinline__ T& at32w(void* base, uint32_t byte_off) {
+    return *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off);
+}
+__device__ __forceinline__ V3 ld3_32(const float* base, uint32_t row) {
+    const F3 v = at32<F3>(base, row * 12u);
+    return V3{v.x, v.y, v.z};
+}
+__device__ __forceinline__ V4 ld4_32(const float* base, uint32_t row) {
+    const float4 v = at32<float4>(base, row * 16u);
+    return V4{v.x, v.y, v.z, v.w};
+}
+// Element-wise selects.  (`cond ? a : b` on whole structs makes the compiler park both in a scratch array and load one back
+// through a computed offset -- a trip through memory in the middle of the dependent chain.)
+__device__ __forceinline__ V3 sel(bool k, V3 a, V3 b) { return V3{k ? a.x : b.x, k ? a.y : b.y, k ? a.z : b.z}; }
+__device__ __forceinline__ Affine sel(bool k, const Affine& a, const Affine& b) {
+    Affine r;
+    r.m.x_axis = sel(k, a.m.x_axis, b.m.x_axis);
+    r.m.y_axis = sel(k, a.m.y_axis, b.m.y_axis);
+    r.m.z_axis = sel(k, a.m.z_axis, b.m.z_axis);
+    r.t = sel(k, a.t, b.t);
+    return r;
+}
+
 // mark_dirty_trees: climb from every changed row to its root, OR-ing the TransformTreeChanged bit;
 // a climber stops at the first node somebody already marked (the shared atomic bitset of
 // systems.rs:208-223).
@@ -90,6 +120,19 @@ __global__ void __launch_bounds__(256) k_mark_dirty(uint32_t n, const uint8_t* _
         if (p == 0xFFFFFFFFu) break;
         row = p;
     }
+}
+
+// A tile's descriptor, fetched whole with scalar loads at the top of the kernel (two s_load for the 72 bytes).  Left to
+// itself the compiler reads the fields where they are used: one dependent s_load after the other -- or, inside divergent
+// code, per-lane vector loads -- each a round trip of its own in front of the tile's first row load.
+__device__ __forceinline__ TileDesc load_tile_desc(const TileDesc* p) {
+    typedef const uint32_t __attribute__((address_space(4))) * const_u32;
+    const_u32 src = (const_u32)(uintptr_t)p;
+    TileDesc d;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&d);
+#pragma unroll
+    for (uint32_t k = 0; k < sizeof(TileDesc) / 4u; ++k) dst[k] = src[k];
+    return d;
 }
 
 struct TreeArgs {
@@ -109,6 +152,7 @@ struct TreeArgs {
     uint32_t snap_rows;  // the snapshot covers rows [0, snap_rows): whoever computes one of them also writes its snapshot
     uint32_t all_dirty;
     uint32_t static_opt;
+    unsigned long long* trace;  // debug: 8 x s_memrealtime per tile (mi_debug_tree_trace), nullptr = off
 };
 
 // The per-node rule.  Level-0 rows: roots (systems.rs:522-530) and flat rows (systems.rs:58-63) are plain
@@ -132,23 +176,75 @@ __device__ __forceinline__ NodeIn node_inputs(const TreeArgs& a, uint32_t row, b
 __device__ __forceinline__ bool node_apply(bool is_root_level, bool static_opt, NodeIn in, const Affine& gp, bool p_changed,
                                            const Affine& local, const Affine& old, Affine* cur) {
     if (is_root_level) {
-        *cur = in.root_write ? local : old;
+        *cur = sel(in.root_write, local, old);
+        return in.root_write;
+    }
+    const bool skip = static_opt && !in.tree_changed && !p_changed;
+    const Affine nw = mul(gp, local);               // p_global_transform.mul_transform(*transform)
+    const bool set = !skip && !affine_eq(nw, old);  // set_if_neq
+    *cur = sel(set, nw, old);
+    return set;
+}
+// node_apply with the old value fetched (from LDS) only after the product is formed: 36 live registers at the peak instead
+// of 60 -- the light tile kernel's occupancy hangs on it.  Same rule, same results.
+template <class LoadOld>
+__device__ __forceinline__ bool node_apply_lazy(bool is_root_level, bool static_opt, NodeIn in, const Affine& gp, bool p_changed,
+                                                const Affine& local, LoadOld load_old, Affine* cur) {
+    if (is_root_level) {
+        if (in.root_write) *cur = local;
+        else *cur = load_old();
         return in.root_write;
     }
     const bool skip = static_opt && !in.tree_changed && !p_changed;
     if (!skip) {
-        const Affine nw = mul(gp, local);  // p_global_transform.mul_transform(*transform)
-        if (!affine_eq(nw, old)) {         // set_if_neq
-            *cur = nw;
-            return true;
-        }
+        const Affine nw = mul(gp, local);
+        __builtin_amdgcn_sched_barrier(0);
+        const Affine old = load_old();
+        const bool neq = !affine_eq(nw, old);
+        *cur = sel(neq, nw, old);
+        return neq;
     }
-    *cur = old;
+    *cur = load_old();
     return false;
 }
 __device__ __forceinline__ bool node_update(const TreeArgs& a, bool is_root_level, uint32_t row, const Affine& gp,
                                             bool p_changed, const Affine& local, const Affine& old, Affine* cur) {
     return node_apply(is_root_level, a.static_opt != 0, node_inputs(a, row, is_root_level), gp, p_changed, local, old, cur);
+}
+
+// node_inputs in two halves for the light tiles: the side-table bytes are fetched with the row's other loads (one batch,
+// no dependent round trip inside the level steps), the rule is evaluated where it is needed.
+struct NodeRaw {
+    uint32_t tree_word;  // the row's word of the TransformTreeChanged bitset (all ones when everything counts as changed)
+    uint8_t nflag;       // node_flags[row] (bit0 = has children)
+    uint8_t changed;     // Changed<Transform> | Added<GlobalTransform>
+};
+// Branch-free on purpose: a load inside an `if` makes the compiler wait for it (and, the counter being in order, for every
+// load issued before it) at the end of the branch.  Absent tables are read through a stand-in pointer (parent_idx: 4 bytes per
+// row, so any row offset is in bounds) and the value is replaced afterwards.
+template <bool ALL_DIRTY>
+__device__ __forceinline__ NodeRaw node_raw(const TreeArgs& a, uint32_t row, bool want_nflag) {
+    NodeRaw r;
+    const uint8_t* const standin = reinterpret_cast<const uint8_t*>(a.parent_idx);
+    if (ALL_DIRTY) {
+        r.tree_word = 0xFFFFFFFFu;
+        r.changed = 1;
+    } else {
+        const uint32_t w = at32<uint32_t>(a.tree_bits ? a.tree_bits : a.parent_idx, (row >> 5) * 4u);
+        r.tree_word = a.tree_bits ? w : 0xFFFFFFFFu;
+        const uint8_t ch = at32<uint8_t>(a.changed ? a.changed : standin, row);
+        r.changed = a.changed ? ch : (uint8_t)1;
+    }
+    const uint8_t nf = at32<uint8_t>(a.node_flags && want_nflag ? a.node_flags : standin, row);
+    r.nflag = a.node_flags && want_nflag ? nf : (uint8_t)0;
+    return r;
+}
+__device__ __forceinline__ NodeIn node_inputs_raw(const TreeArgs& a, uint32_t row, bool is_root_level, NodeRaw r) {
+    NodeIn in;
+    in.tree_changed = ((r.tree_word >> (row & 31u)) & 1u) != 0;
+    in.root_write = false;
+    if (is_root_level) in.root_write = (r.nflag & 1u) ? (!a.static_opt || in.tree_changed) : r.changed != 0;
+    return in;
 }
 
 // One streamed row's inputs, fetched one loop iteration ahead of their use (software pipelining: the loads of
@@ -167,11 +263,13 @@ __device__ __forceinline__ RowFetch fetch_row(const Columns& c, const uint32_t* 
     const uint32_t i = base + tid;
     const uint32_t wbase = base + wv * 64u;
     const uint32_t lim = wbase < count ? (count - wbase < 64u ? count - wbase : 64u) * 3u : 0u;
-    const float4* src = reinterpret_cast<const float4*>(c.global) + 3ull * (start + wbase);
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    f.g0 = lane < lim ? src[lane] : z;
-    f.g1 = 64u + lane < lim ? src[64u + lane] : z;
-    f.g2 = 128u + lane < lim ? src[128u + lane] : z;
+    // lanes (and whole waves) past the end re-read a float4 inside the level: a clamped index, never a `cond ? load : zero`
+    // (that turns into a select between a global and a stack address -- flat loads and a scratch slot)
+    const float4* src = reinterpret_cast<const float4*>(c.global) + 3ull * (start + (lim ? wbase : 0u));
+    const uint32_t last4 = lim ? lim - 1u : 0u;
+    f.g0 = src[lane < last4 ? lane : last4];
+    f.g1 = src[64u + lane < last4 ? 64u + lane : last4];
+    f.g2 = src[128u + lane < last4 ? 128u + lane : last4];
     f.t = V3{0.f, 0.f, 0.f};
     f.s = V3{0.f, 0.f, 0.f};
     f.q = V4{0.f, 0.f, 0.f, 0.f};
@@ -207,7 +305,7 @@ __device__ __forceinline__ void process_tile(const Columns& c, const TreeArgs& a
     uint8_t* const lds_chain_in = lds.chain_in;
     float4* const lds_chain_g = lds.chain_g;
     uint32_t& lds_chain_chg = *lds.chain_chg;
-    const TileDesc& td = a.tiles[tile];
+    const TileDesc td = load_tile_desc(a.tiles + tile);
     const uint32_t L = td.n_levels;
     const bool ROOTS = (td.kind & TILE_ROOTS) != 0;
     const uint32_t chain_len = td.kind & TILE_CHAIN_MASK;
@@ -331,9 +429,9 @@ __device__ __forceinline__ void process_tile(const Columns& c, const TreeArgs& a
                     chg = node_update(a, false, row, gp, p_changed, local, old_g[k], &cur);
                 }
                 any_chg = any_chg || chg;
-                a.g_changed_bytes[row] = chg ? 1 : 0;
                 lds_put(lds_g, u, cur);
-                lds_chg[u] = chg ? 1 : 0;
+                lds_chg[u] = chg ? 1 : 0;  // (the global change byte goes out with the flush: a store in front of the level
+                                           // barrier would make every level wait for its round trip)
             }
         }
         __syncthreads();
@@ -342,6 +440,10 @@ __device__ __forceinline__ void process_tile(const Columns& c, const TreeArgs& a
     // straight float4 copy (fully coalesced) instead of one 48-byte scatter per lane.  Unchanged rows hold
     // their old bytes, so rewriting them is value-neutral; a tile in which nothing changed writes nothing.
     const bool flush_live = __syncthreads_or(any_chg ? 1 : 0) != 0;
+#pragma unroll
+    for (uint32_t j = 0; j < TILE_MAX_LEVELS - 1; ++j)
+        if (j < n_lds)
+            for (uint32_t i = tid; i < td.count[j]; i += BLOCK) a.g_changed_bytes[td.start[j] + i] = lds_chg[ubase[j] + i];
     if (flush_live || snap_out) {
 #pragma unroll
         for (uint32_t j = 0; j < TILE_MAX_LEVELS - 1; ++j) {
@@ -471,6 +573,347 @@ __global__ void __launch_bounds__(BLOCK) k_propagate_tiles(Columns c, TreeArgs a
 }
 
 // ---------------------------------------------------------------------------------------------
+// Light tiles (big hierarchies; the planner guarantees: every level but the last holds <= TILE_LIGHT_UCAP rows together,
+// chain <= TILE_MAX_CHAIN, last level normally <= 256 rows).  Same walk and the same per-node rule as process_tile, organised
+// for residency instead of reach: ONE batch of loads per tile -- descriptor, then every row of the tile at once (upper rows
+// in lanes 0..127, the chain's nodes in the top lanes of wave 3, whose row numbers do not wait for the descriptor, one
+// last-level row per lane) -- nothing software-pipelined and nothing kept in registers across the level steps that LDS
+// can hold: the upper rows' old GlobalTransforms and the last level's (already in its transposed place) wait in LDS.
+// 6 workgroups per CU instead of 4, a few rounds of short tiles per CU: one tile's head runs under its neighbours' loads.
+// ---------------------------------------------------------------------------------------------
+// One column of an affine (x_axis, y_axis, z_axis or translation) in an LDS slot of 12 floats.
+__device__ __forceinline__ V3 lds_col(const float4* slots, uint32_t slot, uint32_t c) {
+    const float* p = reinterpret_cast<const float*>(slots) + slot * 12u + c * 3u;
+    return V3{p[0], p[1], p[2]};
+}
+__device__ __forceinline__ void lds_put_col(float4* slots, uint32_t slot, uint32_t c, V3 v) {
+    float* p = reinterpret_cast<float*>(slots) + slot * 12u + c * 3u;
+    p[0] = v.x;
+    p[1] = v.y;
+    p[2] = v.z;
+}
+// lane k of every quad -> all four lanes of the quad (v_mov_b32 with a DPP quad_perm: a register move, no LDS)
+template <int K>
+__device__ __forceinline__ float quad_bcast_f(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), K * 0x55, 0xF, 0xF, true));
+}
+__device__ __forceinline__ V3 quad_bcast(V3 v, int k) {
+    switch (k) {
+        case 0: return V3{quad_bcast_f<0>(v.x), quad_bcast_f<0>(v.y), quad_bcast_f<0>(v.z)};
+        case 1: return V3{quad_bcast_f<1>(v.x), quad_bcast_f<1>(v.y), quad_bcast_f<1>(v.z)};
+        case 2: return V3{quad_bcast_f<2>(v.x), quad_bcast_f<2>(v.y), quad_bcast_f<2>(v.z)};
+        default: return V3{quad_bcast_f<3>(v.x), quad_bcast_f<3>(v.y), quad_bcast_f<3>(v.z)};
+    }
+}
+// node_apply spread over the FOUR lanes of a quad, one output column each (c = lane & 3: the three axes and the
+// translation): the serial part of a tile -- its ancestor chain and its upper levels, one dependent node after the other --
+// is bound by instruction latency, not throughput, and a column is a quarter of the dependent instructions of a node.
+// Same operations in the same order per element (mul(M3, V3), then + translation), so the same bits.  Every lane of the
+// wave must call it (the row-wide "differs from the old value" is a ballot); `on` marks the lanes that carry a node.
+// Returns the tick decision of the lane's node; *cur_c = the lane's column of the node's GlobalTransform after the system.
+__device__ __forceinline__ bool quad_node_apply(bool on, bool is_root_level, bool static_opt, uint32_t in_bits, const Affine& gp,
+                                                bool p_changed, V3 local_c, V3 old_c, uint32_t c, uint32_t lane, V3* cur_c) {
+    const bool tree_changed = (in_bits & 1u) != 0, root_write = (in_bits & 2u) != 0;
+    const bool skip = static_opt && !tree_changed && !p_changed;
+    V3 nw = mul(gp.m, local_c);
+    if (c == 3u) nw = nw + gp.t;
+    const bool differs = !(nw.x == old_c.x && nw.y == old_c.y && nw.z == old_c.z);
+    const unsigned long long m = __ballot(on && differs);
+    const bool neq = ((m >> (lane & ~3u)) & 0xFull) != 0;
+    if (is_root_level) {
+        *cur_c = sel(root_write, local_c, old_c);
+        return root_write;
+    }
+    const bool set = !skip && neq;  // set_if_neq
+    *cur_c = sel(set, nw, old_c);
+    return set;
+}
+
+constexpr uint32_t FAN_SLOTS = TILE_LIGHT_UCAP + TILE_MAX_CHAIN;  // LDS slots: upper rows, then the chain's nodes
+constexpr uint32_t FAN_CHAIN_LANE0 = 256u - TILE_MAX_CHAIN;       // chain node k is fetched by thread FAN_CHAIN_LANE0 + k
+
+template <bool ALL_DIRTY>
+__global__ void __launch_bounds__(256, 6) k_propagate_fans(Columns c, TreeArgs a) {
+    __shared__ float4 lds_g[FAN_SLOTS * 3];    // local affine, then (upper rows) the GlobalTransform in place
+    __shared__ float4 lds_old[FAN_SLOTS * 3];  // GlobalTransform before this frame
+    __shared__ float4 lds_stage[4][192];       // last level: a wave's old GlobalTransforms as loaded (3 x 1 KB rows), read transposed
+    __shared__ uint8_t lds_chg[TILE_LIGHT_UCAP];
+    __shared__ uint8_t lds_in[FAN_SLOTS];            // per slot: bit0 TransformTreeChanged, bit1 the level-0 assignment happens
+    __shared__ uint32_t lds_pslot[TILE_LIGHT_UCAP];  // per upper row: its parent's LDS slot (or global row, see my_pslot)
+    __shared__ uint32_t lds_row[TILE_LIGHT_UCAP];    // per upper row: its row number (the write-back runs over slots)
+    __shared__ float4 lds_chain_g[3];
+    __shared__ uint32_t lds_chain_chg;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    // development trace: stamps are kept in registers and written once at the very end (a store in front of a barrier would
+    // make the barrier's vmcnt(0) wait for it and distort the phase it is meant to time)
+    unsigned long long ts[7] = {0, 0, 0, 0, 0, 0, 0};
+#define FAN_STAMP(i)                              \
+    do {                                          \
+        if (a.trace) ts[i] = wall_clock64();      \
+    } while (0)
+    FAN_STAMP(0);
+    const bool chain_lane = tid >= FAN_CHAIN_LANE0;
+    // the chain's row numbers sit at a fixed place per tile: fetched next to the descriptor, not behind it
+    const uint32_t chain_row = chain_lane ? a.chains[(size_t)tile * TILE_MAX_CHAIN + (tid - FAN_CHAIN_LANE0)] : 0u;
+    const TileDesc td = load_tile_desc(a.tiles + tile);
+    const uint32_t L = td.n_levels;
+    const bool ROOTS = (td.kind & TILE_ROOTS) != 0;
+    const uint32_t chain_len = td.kind & TILE_CHAIN_MASK;
+    float* const snap_out = a.snap_write;
+    const uint32_t n_lds = L ? L - 1u : 0u;  // every level but the last is LDS-resident
+    uint32_t ubase[TILE_MAX_LEVELS + 1];
+    ubase[0] = 0;
+#pragma unroll
+    for (uint32_t l = 0; l < TILE_MAX_LEVELS; ++l) ubase[l + 1] = ubase[l] + (l < n_lds ? td.count[l] : 0u);
+    const uint32_t U = ubase[TILE_MAX_LEVELS];
+    uint32_t s_start = td.start[0], s_count = L ? td.count[0] : 0u, s_pbase = 0, s_pstart = 0;  // the last level
+#pragma unroll
+    for (uint32_t j = 1; j < TILE_MAX_LEVELS; ++j)
+        if (j == n_lds) {
+            s_start = td.start[j];
+            s_count = td.count[j];
+            s_pbase = ubase[j - 1];
+            s_pstart = td.start[j - 1];
+        }
+    const bool s_root_level = ROOTS && n_lds == 0;
+
+    // ---- every load of the tile, as ONE batch: straight-line code, no load behind a divergent branch (the compiler waits
+    // where a result is first used, and the load counter is in order: a use in the middle would split the batch in two) ----
+    // (a) this lane's row of the last level (lanes past the end re-read the level's first row)
+    const uint32_t wbase0 = wv * 64u < s_count ? wv * 64u : 0u;
+    const uint32_t lim0 = (s_count - wbase0 < 64u ? s_count - wbase0 : 64u) * 3u;  // float4s of this wave's rows
+    const uint32_t s_row = s_start + (tid < s_count ? tid : 0u);
+    // (b) an upper row (threads below U) or a chain node (top threads of wave 3)
+    const bool is_chain = chain_lane && tid - FAN_CHAIN_LANE0 < chain_len;
+    const bool is_upper = tid < U;
+    uint32_t my_level = 0xFFFFFFFFu, u_pbase = 0, u_pstart = 0;
+    uint32_t u_row = is_chain ? chain_row : s_start;
+    {
+        uint32_t l = 0;
+#pragma unroll
+        for (uint32_t j = 1; j < TILE_MAX_LEVELS; ++j)
+            if (j < n_lds && tid >= ubase[j]) l = j;
+        uint32_t lstart = td.start[0], lbase = 0;
+#pragma unroll
+        for (uint32_t j = 1; j < TILE_MAX_LEVELS; ++j)
+            if (j == l) {
+                lstart = td.start[j];
+                lbase = ubase[j];
+                u_pstart = td.start[j - 1];
+                u_pbase = ubase[j - 1];
+            }
+        if (is_upper) {
+            my_level = l;
+            u_row = lstart + (tid - lbase);
+        }
+    }
+    // (the old value's base differs per lane: upper rows read the live column, chain nodes their PRE-frame snapshot, see TreeArgs)
+    const float* const u_old_src = is_chain ? a.snap_read : c.global;
+    const uint32_t g_off = (s_start + wbase0) * 48u;
+    const float4 f_g0 = at32<float4>(c.global, g_off + (lane < lim0 ? lane : lim0 - 1u) * 16u);
+    const float4 f_g1 = at32<float4>(c.global, g_off + (64u + lane < lim0 ? 64u + lane : lim0 - 1u) * 16u);
+    const float4 f_g2 = at32<float4>(c.global, g_off + (128u + lane < lim0 ? 128u + lane : lim0 - 1u) * 16u);
+    const uint32_t u_p = at32<uint32_t>(a.parent_idx, u_row * 4u);
+    const V3 u_s = ld3_32(c.scale, u_row), u_t = ld3_32(c.translation, u_row);
+    const V4 u_q = ld4_32(c.rotation, u_row);
+    const Affine u_old = ld_affine(u_old_src, u_row);
+    const NodeRaw u_raw = node_raw<ALL_DIRTY>(a, u_row, true);
+    const uint32_t f_p = at32<uint32_t>(a.parent_idx, s_row * 4u);
+    const V3 f_s = ld3_32(c.scale, s_row), f_t = ld3_32(c.translation, s_row);
+    const V4 f_q = ld4_32(c.rotation, s_row);
+    const NodeRaw f_raw = node_raw<ALL_DIRTY>(a, s_row, s_root_level);
+    FAN_STAMP(1);
+    __builtin_amdgcn_sched_barrier(0);  // nothing below may move above: the scheduler otherwise consumes the first loads early
+    // consume, in issue order
+    float4* const stage = lds_stage[wv];
+    stage[lane] = f_g0;
+    stage[64u + lane] = f_g1;
+    stage[128u + lane] = f_g2;
+    // per row, for the level steps: the parent's LDS slot (levels >= 1 of the tile) or its global row (level 0 of a tile
+    // below another launch), and the rule's inputs
+    if (is_upper || is_chain) {
+        const uint32_t slot = is_upper ? tid : TILE_LIGHT_UCAP + (tid - FAN_CHAIN_LANE0);
+        lds_put(lds_g, slot, affine_from_srt(u_s, u_q, u_t));
+        lds_put(lds_old, slot, u_old);
+        const bool root_level = is_upper ? (ROOTS && my_level == 0) : (tid - FAN_CHAIN_LANE0 + 1u == chain_len);
+        const NodeIn in = node_inputs_raw(a, u_row, root_level, u_raw);
+        lds_in[slot] = (uint8_t)((in.tree_changed ? 1u : 0u) | (in.root_write ? 2u : 0u));
+        if (is_upper) {
+            lds_pslot[tid] = my_level ? u_pbase + (u_p - u_pstart) : u_p;
+            lds_row[tid] = u_row;
+        }
+    }
+    __syncthreads();
+    FAN_STAMP(2);
+
+    // ---- the ancestor chain: forest root first, down to the tile's parent -- the products the owning tiles compute.
+    // One quad of wave 0 (a column per lane); the node just computed is handed on through LDS. ----
+    if (chain_len) {
+        if (wv == 0) {
+            const uint32_t cc = lane & 3u;
+            const bool on = lane < 4u;
+            Affine g = {};
+            bool chg = false;
+            uint32_t k = chain_len;
+            // the next node's inputs are fetched while this one is multiplied (nothing in the loop waits for LDS but them)
+            uint32_t in_n = lds_in[TILE_LIGHT_UCAP + k - 1u];
+            V3 loc_n = lds_col(lds_g, TILE_LIGHT_UCAP + k - 1u, cc), old_n = lds_col(lds_old, TILE_LIGHT_UCAP + k - 1u, cc);
+            while (k-- > 0) {
+                const uint32_t in_k = in_n;
+                const V3 loc_k = loc_n, old_k = old_n;
+                if (k) {
+                    in_n = lds_in[TILE_LIGHT_UCAP + k - 1u];
+                    loc_n = lds_col(lds_g, TILE_LIGHT_UCAP + k - 1u, cc);
+                    old_n = lds_col(lds_old, TILE_LIGHT_UCAP + k - 1u, cc);
+                }
+                V3 cur_c;
+                chg = quad_node_apply(on, k + 1u == chain_len, a.static_opt != 0, in_k, g, chg, loc_k, old_k, cc, lane, &cur_c);
+                // every lane of the quad gets all four columns: quad broadcasts (DPP), no trip through LDS
+                g.m.x_axis = quad_bcast(cur_c, 0);
+                g.m.y_axis = quad_bcast(cur_c, 1);
+                g.m.z_axis = quad_bcast(cur_c, 2);
+                g.t = quad_bcast(cur_c, 3);
+            }
+            if (lane == 0) {
+                lds_put(lds_chain_g, 0, g);
+                lds_chain_chg = chg ? 1u : 0u;
+            }
+        }
+        __syncthreads();
+    }
+
+    FAN_STAMP(3);
+    // ---- LDS-resident levels: four lanes per row ---------------------------------------------------------
+    bool any_chg = false;
+#pragma unroll
+    for (uint32_t l = 0; l < TILE_MAX_LEVELS - 1; ++l) {
+        if (l < n_lds) {
+            const uint32_t cnt4 = td.count[l] * 4u;
+            for (uint32_t base = 0; base < cnt4; base += 256u) {
+                if (base + wv * 64u >= cnt4) continue;  // (wave-uniform) this wave carries no row of the level
+                const uint32_t t = base + tid;
+                const bool on = t < cnt4;
+                const uint32_t r = on ? t >> 2 : 0u, cc = t & 3u;
+                const uint32_t u = ubase[l] + r;
+                Affine gp = {};
+                bool p_changed = false;
+                if (!(ROOTS && l == 0)) {
+                    if (l) {
+                        const uint32_t ps = lds_pslot[u];
+                        gp = lds_affine(lds_g, ps);
+                        p_changed = lds_chg[ps] != 0;
+                    } else if (chain_len) {
+                        gp = lds_affine(lds_chain_g, 0);
+                        p_changed = lds_chain_chg != 0;
+                    } else {
+                        const uint32_t pr = lds_pslot[u];
+                        gp = ld_affine(c.global, pr);
+                        p_changed = a.g_changed_bytes[pr] != 0;
+                    }
+                }
+                V3 cur_c;
+                const bool chg = quad_node_apply(on, ROOTS && l == 0, a.static_opt != 0, lds_in[u], gp, p_changed, lds_col(lds_g, u, cc),
+                                                 lds_col(lds_old, u, cc), cc, lane, &cur_c);
+                if (on) {
+                    lds_put_col(lds_g, u, cc, cur_c);  // in place: the quad's lanes read and write their own column only
+                    any_chg = any_chg || chg;
+                    if (cc == 0) lds_chg[u] = chg ? 1 : 0;  // (its global copy goes out with the write-back, not in front of a barrier)
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // write-back of the upper rows: slots and rows are contiguous per level -> straight float4 copies; a tile in which
+    // nothing changed writes nothing (unchanged rows hold their old bytes), the snapshot always tracks the current value
+    FAN_STAMP(4);
+    if (n_lds) {
+        const bool flush_live = __syncthreads_or(any_chg ? 1 : 0) != 0;
+        if (tid < U) at32w<uint8_t>(a.g_changed_bytes, lds_row[tid]) = lds_chg[tid];
+        if (flush_live || snap_out) {
+            for (uint32_t f = tid; f < 3u * U; f += 256u) {  // float4 f of the slots: lanes walk the rows' 48 bytes contiguously
+                const uint32_t slot = f / 3u, row = lds_row[slot];
+                const uint32_t off = row * 48u + (f - slot * 3u) * 16u;
+                const float4 v = lds_g[f];
+                if (flush_live) at32w<float4>(c.global, off) = v;
+                if (snap_out && row < a.snap_rows) at32w<float4>(snap_out, off) = v;
+            }
+        }
+    }
+
+    // ---- the last level: one row per lane; a wider level (a single node with more than 256 children) takes more batches ----
+    auto batch = [&](uint32_t base, uint32_t p, V3 sc, V4 q, V3 t, NodeRaw raw) {
+        const uint32_t i = base + tid;
+        const bool live = i < s_count;
+        const uint32_t row = s_start + i;
+        const uint32_t wbase = base + wv * 64u;
+        const uint32_t wave_lim = wbase < s_count ? (s_count - wbase < 64u ? s_count - wbase : 64u) * 3u : 0u;
+        Affine local = {}, gp = {};
+        bool p_changed = false;
+        if (live) {
+            local = affine_from_srt(sc, q, t);
+            if (!s_root_level) {
+                if (n_lds) {
+                    const uint32_t slot = s_pbase + (p - s_pstart);
+                    gp = lds_affine(lds_g, slot);
+                    p_changed = lds_chg[slot] != 0;
+                } else if (chain_len) {
+                    gp = lds_affine(lds_chain_g, 0);
+                    p_changed = lds_chain_chg != 0;
+                } else {
+                    gp = ld_affine(c.global, p);
+                    p_changed = a.g_changed_bytes[p] != 0;
+                }
+            }
+        }
+        MI_WAVE_LDS_SYNC();  // (the first batch's transpose rows were written before the workgroup barriers)
+        Affine cur = {};
+        bool chg = false;
+        if (live) {
+            chg = node_apply_lazy(s_root_level, a.static_opt != 0, node_inputs_raw(a, row, s_root_level, raw), gp, p_changed, local,
+                                  [&] { return lds_affine(stage, lane); }, &cur);
+            at32w<uint8_t>(a.g_changed_bytes, row) = chg ? 1 : 0;
+            if (snap_out && row < a.snap_rows) st_affine(snap_out, row, cur);
+        }
+        const unsigned long long cm = __ballot(chg), lm = __ballot(live);
+        if (cm == lm) {  // the whole wave changed (the dirty-tree case): transpose back, three contiguous 1 KB rows out
+            MI_WAVE_LDS_SYNC();
+            lds_put(stage, lane, cur);
+            MI_WAVE_LDS_SYNC();
+            const uint32_t doff = (s_start + wbase) * 48u;
+#pragma unroll
+            for (uint32_t k = 0; k < 3u; ++k) {
+                const uint32_t j = k * 64u + lane;
+                if (j < wave_lim) at32w<float4>(c.global, doff + j * 16u) = stage[j];
+            }
+        } else if (chg) {
+            st_affine(c.global, row, cur);
+        }
+    };
+    FAN_STAMP(5);
+    batch(0u, f_p, f_s, f_q, f_t, f_raw);
+    FAN_STAMP(6);
+    for (uint32_t base = 256u; base < s_count; base += 256u) {  // rare
+        const RowFetch fx = fetch_row(c, a.parent_idx, s_start, s_count, base, tid, lane, wv, s_root_level);
+        const uint32_t xrow = s_start + (base + tid < s_count ? base + tid : 0u);
+        const NodeRaw xraw = node_raw<ALL_DIRTY>(a, xrow, s_root_level);
+        MI_WAVE_LDS_SYNC();
+        stage[lane] = fx.g0;
+        stage[64u + lane] = fx.g1;
+        stage[128u + lane] = fx.g2;
+        batch(base, fx.p, fx.s, fx.q, fx.t, xraw);
+    }
+    if (a.trace && tid == 0) {
+        __builtin_amdgcn_s_waitcnt(0);  // stores drained
+        const unsigned long long t7 = wall_clock64();
+#pragma unroll
+        for (uint32_t i = 0; i < 7u; ++i) a.trace[(size_t)tile * 8u + i] = ts[i];
+        a.trace[(size_t)tile * 8u + 7u] = t7;
+    }
+#undef FAN_STAMP
+}
+
+// ---------------------------------------------------------------------------------------------
 // A wide level as a stream (the deepest level of a big tree holds most of its rows).  One row per lane, no loops, so
 // the register budget allows twice the waves of the tile kernel and the level moves at the flat kernel's pace: T / R / S,
 // parent index and the old GlobalTransform in (the latter as three contiguous 1 KB wave rows through a wave-private LDS
@@ -489,11 +932,14 @@ __global__ void __launch_bounds__(256) k_propagate_level(Columns c, TreeArgs a, 
     const uint32_t wave_lim = wbase < count ? (count - wbase < 64u ? count - wbase : 64u) * 3u : 0u;
     float4* stage = lds_stage[wv];
     float4* const gw = reinterpret_cast<float4*>(c.global) + 3ull * (start + wbase);
-    // the wave's old GlobalTransforms first: everything issued after them can stay in flight while they are transposed
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 o0 = lane < wave_lim ? gw[lane] : z4;
-    const float4 o1 = 64u + lane < wave_lim ? gw[64u + lane] : z4;
-    const float4 o2 = 128u + lane < wave_lim ? gw[128u + lane] : z4;
+    // the wave's old GlobalTransforms first: everything issued after them can stay in flight while they are transposed.
+    // Lanes past the end re-read the last float4 of the level (a clamped index, not a `cond ? load : zero`: the latter becomes
+    // a select between a global and a stack ADDRESS -- a flat load and a scratch slot)
+    const float4* const gr = reinterpret_cast<const float4*>(c.global) + 3ull * (start + (wave_lim ? wbase : 0u));
+    const uint32_t last4 = wave_lim ? wave_lim - 1u : 0u;
+    const float4 o0 = gr[lane < last4 ? lane : last4];
+    const float4 o1 = gr[64u + lane < last4 ? 64u + lane : last4];
+    const float4 o2 = gr[128u + lane < last4 ? 128u + lane : last4];
     V3 t = {}, sc = {};
     V4 q = {};
     Affine gp = {};
@@ -579,7 +1025,7 @@ __global__ void __launch_bounds__(256) k_inherit_tiles(const uint32_t* __restric
                                                         const uint8_t* __restrict__ visibility, uint8_t* flags,
                                                         uint8_t* inh_changed) {
     __shared__ uint8_t lds_state[TILE_UCAP];
-    const TileDesc& td = tiles[blockIdx.x];
+    const TileDesc td = load_tile_desc(tiles + blockIdx.x);
     const uint32_t L = td.n_levels;
     const uint32_t tid = threadIdx.x;
     uint32_t ubase[TILE_MAX_LEVELS + 1];
@@ -672,8 +1118,7 @@ hipError_t launch_mark_dirty(uint32_t n, const uint8_t* changed, const uint32_t*
 hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, const TileDesc* d_tiles, const uint32_t* d_chains,
                                   uint32_t n_tiles, const uint8_t* node_flags, const uint8_t* changed, const uint32_t* tree_bits,
                                   uint8_t* g_changed_bytes, const float* snap_read, float* snap_write, uint32_t snap_rows, bool all_dirty,
-                                  bool static_opt,
-                                  hipStream_t stream) {
+                                  bool static_opt, bool light, hipStream_t stream, unsigned long long* trace) {
     if (n_tiles == 0) return hipSuccess;
     TreeArgs a;
     a.snap_read = snap_read;
@@ -688,7 +1133,10 @@ hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, 
     a.chains = d_chains;
     a.all_dirty = all_dirty ? 1u : 0u;
     a.static_opt = static_opt ? 1u : 0u;
-    MI_LAUNCH((k_propagate_tiles<TILE_BLOCK>), dim3(n_tiles), dim3(TILE_BLOCK), 0, stream, c, a);
+    a.trace = trace;
+    if (light && all_dirty) MI_LAUNCH(k_propagate_fans<true>, dim3(n_tiles), dim3(256), 0, stream, c, a);
+    else if (light) MI_LAUNCH(k_propagate_fans<false>, dim3(n_tiles), dim3(256), 0, stream, c, a);
+    else MI_LAUNCH((k_propagate_tiles<TILE_BLOCK>), dim3(n_tiles), dim3(TILE_BLOCK), 0, stream, c, a);
     return hipGetLastError();
 }
 

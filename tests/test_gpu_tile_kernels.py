@@ -1,0 +1,121 @@
+"""GPU parity of the two hierarchy kernels (big subtree tiles / light tiles) on shapes that exercise each planner and kernel
+branch: the plan is forced with the mi_debug_set_tile_mode hook, results are compared with the oracle
+(propagate_parent_transforms + mark_dirty_trees, crates/bevy_transform/src/systems.rs:111-306,506-748) bit for bit, change
+ticks included, over an all-dirty frame and several partially dirty ones, with and without the static-scene rule."""
+import numpy as np
+import pytest
+
+import bevy_amd as B
+from bevy_amd import api, workloads as W
+import oracle_lib as O
+from test_gpu_parity import ctx_factory, assert_bits  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def _levels(spec, seed):
+    """spec = children per node for each level below the roots: int (every node) or callable(node_index_in_level) -> int."""
+    n_roots, fans = spec
+    parent = [B.NO_PARENT] * n_roots
+    offs = [0, n_roots]
+    prev = list(range(n_roots))
+    for fan in fans:
+        nxt = []
+        for i, p in enumerate(prev):
+            for _ in range(fan(i) if callable(fan) else fan):
+                nxt.append(len(parent))
+                parent.append(p)
+        if not nxt:
+            break
+        prev = nxt
+        offs.append(len(parent))
+    n = len(parent)
+    rng = np.random.default_rng(seed)
+    q = rng.normal(size=(n, 4))
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(F)
+    return dict(n=n, parent=np.array(parent, np.uint32), level_offsets=np.array(offs, np.uint32),
+                translation=rng.uniform(-2, 2, size=3 * n).astype(F), rotation=q.reshape(-1),
+                scale=rng.uniform(0.9, 1.1, size=3 * n).astype(F))
+
+
+SHAPES = {
+    "fan_4ary_7_levels": (1, [4] * 6),                                  # the bench's shape, small: chain tiles below a top tile
+    "one_node_700_leaves": (1, [700]),                                   # a last level of several batches in one tile
+    "wide_second_level": (1, [300, 4]),
+    "skewed": (1, [200, lambda i: 300 if i == 0 else 0, 2]),             # one subtree overflows a light tile: big tiles take over
+    "forest_3000_roots": (3000, [3, 2]),                                 # many roots per tile, level 0 holds most rows
+    "flat_rows_and_trees": (5000, [lambda i: 5 if i % 50 == 0 else 0, 6, 3]),  # flat rows share level 0 with the roots
+    "ragged": (7, [lambda i: i % 5, lambda i: (i * 7) % 4, lambda i: 300 if i == 3 else i % 3, 2]),
+    "chain_of_30_then_fan": (1, [1] * 30 + [4, 4, 4, 4, 4]),            # deeper than TILE_MAX_CHAIN: dependent launches
+    "binary_13_levels": (1, [2] * 12),
+}
+
+
+@pytest.mark.parametrize("static_opt", [False, True])
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("shape", sorted(SHAPES))
+def test_tile_kernels_match_oracle(ctx_factory, shape, mode, static_opt):
+    tr = _levels(SHAPES[shape], seed=len(shape))
+    n, parent = tr["n"], tr["parent"]
+    flags = B.PROPAGATE_STATIC_OPT if static_opt else 0
+    ctx = ctx_factory()
+    ctx.debug_set_tile_mode(mode)
+    ctx.resize(n)
+    ctx.upload_transforms(tr["translation"], tr["rotation"], tr["scale"])
+    ctx.upload_hierarchy(parent, tr["level_offsets"])
+    ctx.propagate(B.PROPAGATE_ALL_DIRTY | flags)
+    rc, g0, chg0 = O.propagate_transforms(parent, tr["translation"], tr["rotation"], tr["scale"], static_opt=static_opt)
+    assert rc == 0
+    g, chg = ctx.download_global_transforms()
+    bad = np.nonzero((g.view(np.uint32) != g0.view(np.uint32)).reshape(-1, 12).any(axis=1))[0]
+    assert bad.size == 0, f"all-dirty frame: {bad.size} rows differ, first {bad[:5].tolist()}"
+    assert_bits(chg, chg0, "change ticks of the all-dirty frame")
+    t = tr["translation"].reshape(n, 3).copy()
+    rng = np.random.default_rng(17)
+    lo = tr["level_offsets"]
+    picks = [np.array([0]),                                              # a root
+             np.array([lo[1] % n, lo[len(lo) // 2] % n, n - 1]),         # first row of level 1, a middle level, the last leaf
+             np.zeros(0, np.int64),                                      # nothing
+             rng.integers(0, n, max(1, n // 100)),                       # 1 % of the rows
+             np.array([0, n - 1])]
+    for frame, dirty in enumerate(picks):
+        dirty = np.unique(dirty).astype(np.uint32)
+        t[dirty] += F(0.375)
+        if dirty.size:
+            ctx.upload_transforms_indexed(dirty, t[dirty].reshape(-1), tr["rotation"].reshape(n, 4)[dirty].reshape(-1),
+                                          tr["scale"].reshape(n, 3)[dirty].reshape(-1))
+        ctx.propagate(flags)
+        changed = np.zeros(n, np.uint8)
+        changed[dirty] = 1
+        rc, g1, chg1 = O.propagate_transforms(parent, t.reshape(-1), tr["rotation"], tr["scale"], global_in=g0, static_opt=static_opt,
+                                              tree_changed=O.mark_dirty_trees(parent, changed), transform_changed=changed)
+        assert rc == 0
+        g, chg = ctx.download_global_transforms()
+        bad = np.nonzero((g.view(np.uint32) != g1.view(np.uint32)).reshape(-1, 12).any(axis=1))[0]
+        assert bad.size == 0, f"frame {frame}: {bad.size} rows differ, first {bad[:5].tolist()}"
+        assert_bits(chg, chg1, f"frame {frame} change ticks")
+        g0 = g1
+
+
+def test_light_plan_is_used_where_it_fits_and_not_where_it_does_not(ctx_factory):
+    def plan(shape, mode):
+        tr = _levels(SHAPES[shape], seed=1)
+        ctx = ctx_factory()
+        ctx.debug_set_tile_mode(mode)
+        ctx.resize(tr["n"])
+        ctx.upload_transforms(tr["translation"], tr["rotation"], tr["scale"])
+        ctx.upload_hierarchy(tr["parent"], tr["level_offsets"])
+        return ctx.debug_tile_plan()
+    assert plan("fan_4ary_7_levels", 2)["tiles"] > plan("fan_4ary_7_levels", 1)["tiles"]   # smaller tiles, more of them
+    assert plan("skewed", 2) == plan("skewed", 1)                                           # does not fit: the big-tile plan
+    # by size: a 1 M-node tree is planned light, a small one is not
+    big = W.gen_tree(12, 4, 1_000_000)
+    ctx = ctx_factory()
+    ctx.resize(big["n"])
+    ctx.upload_transforms(big["translation"], big["rotation"], big["scale"])
+    ctx.upload_hierarchy(big["parent"], big["level_offsets"])
+    auto = ctx.debug_tile_plan()
+    ctx.debug_set_tile_mode(1)
+    ctx.upload_hierarchy(big["parent"], big["level_offsets"])
+    assert auto["tiles"] > ctx.debug_tile_plan()["tiles"]

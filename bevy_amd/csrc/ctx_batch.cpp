@@ -55,8 +55,8 @@ int32_t mi_batch_upload_sets(mi_ctx* ctx, uint32_t n_sets, const uint8_t* set_in
     if ((rc = ensure(ctx, ctx->bt_meta, std::max<size_t>(n_meta, 1) * 12))) return rc;
     if ((rc = ensure(ctx, ctx->bt_meta_out, std::max<size_t>(n_meta, 1) * 12))) return rc;
     for (int k = 0; k < 2; ++k) {
-        if ((rc = ensure(ctx, ctx->bt_inst[k], std::max<size_t>(n_meta, 1) * 4))) return rc;
-        HIP_TRY(ctx, hipMemsetAsync(ctx->bt_inst[k].p, 0, std::max<size_t>(n_meta, 1) * 4, ctx->stream));  // builds keep them zero from here on
+        if ((rc = ensure(ctx, ctx->bt_inst[k], std::max<size_t>(n_meta, 1) * 4 * BATCH_INST_STRIDE))) return rc;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->bt_inst[k].p, 0, std::max<size_t>(n_meta, 1) * 4 * BATCH_INST_STRIDE, ctx->stream));  // builds keep them zero from here on
     }
     if (n_sets && (rc = upload(ctx, ctx->bt_set_indexed.p, set_indexed, n_sets))) return rc;
     if ((rc = upload(ctx, ctx->bt_table_off.p, bin_table_offset, ((size_t)n_sets + 1) * 4))) return rc;
@@ -185,8 +185,8 @@ int32_t mi_batch_build_phase(mi_ctx* ctx, uint32_t view, uint32_t class_bit, con
     if ((rc = ensure(ctx, ctx->bt_meta_out, std::max<size_t>(ctx->bt_n_meta, 1) * 12))) return rc;
     for (int k = 0; k < 2; ++k)
         if (!ctx->bt_inst[k].p) {
-            if ((rc = ensure(ctx, ctx->bt_inst[k], std::max<size_t>(ctx->bt_n_meta, 1) * 4))) return rc;
-            HIP_TRY(ctx, hipMemsetAsync(ctx->bt_inst[k].p, 0, std::max<size_t>(ctx->bt_n_meta, 1) * 4, ctx->stream));
+            if ((rc = ensure(ctx, ctx->bt_inst[k], std::max<size_t>(ctx->bt_n_meta, 1) * 4 * BATCH_INST_STRIDE))) return rc;
+            HIP_TRY(ctx, hipMemsetAsync(ctx->bt_inst[k].p, 0, std::max<size_t>(ctx->bt_n_meta, 1) * 4 * BATCH_INST_STRIDE, ctx->stream));
         }
     // capacities: every row of the list could be a work item / an unbatchable entity with its own slot and batch set; every bin
     // of every set gets a metadata entry

@@ -336,6 +336,9 @@ constexpr uint32_t CLUSTER_FILL_RIDE_BLOCKS = 256;  // workgroups a riding fill 
 // ---------------------------------------------------------------------------------------------
 // Batching work-item build (kernels_batch.hip).
 // ---------------------------------------------------------------------------------------------
+// instance counters are one per 64-byte line: agent-scope atomics on one line serialise (~25 ns each), and a frame adds to a
+// bin from every tile that saw it
+constexpr uint32_t BATCH_INST_STRIDE = 16;
 constexpr uint32_t BATCH_TILE = 2048;       // list items per workgroup in the partition passes
 constexpr uint32_t BATCH_NO_SET = 0xFFFFFFFFu;
 struct BatchInitial {
@@ -357,12 +360,12 @@ struct BatchArgs {
     const uint32_t* meta_offset;
     const uint32_t* bin_meta_in;   // as uploaded, 3 words per bin: indirect_parameters_offset, bin_index, (ignored)
     uint32_t* bin_metadata_out;    // the same with instance_count filled in
-    uint32_t* inst_count;          // [n_meta] zero on entry; the build's instance counts
-    uint32_t* inst_count_next;     // [n_meta] zeroed by this build for the next one
+    uint32_t* inst_count;          // [n_meta * BATCH_INST_STRIDE] zero on entry; the build's instance counts
+    uint32_t* inst_count_next;     // [n_meta * BATCH_INST_STRIDE] zeroed by this build for the next one
     // scratch
     uint32_t* rows_a;
     uint32_t* rows_b;
-    uint32_t* tile_hist;     // [256][n_tiles]
+    uint32_t* tile_hist;     // [n_tiles][256]
     uint32_t n_tiles;
     uint32_t* set_count;     // two-pass only, [2][n_buckets]: start and end of the bucket's run in the partitioned list
     uint32_t* plan;          // [7][n_buckets]: start in the partition, first MeshUniform slot, first work item, first indirect

@@ -80,7 +80,9 @@ __global__ void __launch_bounds__(256) k_batch_resolve_rows(uint32_t n, uint32_t
     row_bucket[row] = bucket;
 }
 
-constexpr uint32_t BIN_HASH = 512, BIN_HASH_EMPTY = 0xFFFFFFFFu;
+// (a tile of 2048 rows can name 2048 bins: at 512 slots a many-bin scene filled the table, every later row probed eight
+// times in vain -- an LDS round trip each -- and went to memory anyway)
+constexpr uint32_t BIN_HASH = 4096, BIN_HASH_SHIFT = 20, BIN_HASH_EMPTY = 0xFFFFFFFFu;
 
 template <uint32_t PASS>
 __global__ void __launch_bounds__(256) k_batch_hist(BatchArgs a) {
@@ -126,7 +128,7 @@ __global__ void __launch_bounds__(256) k_batch_hist(BatchArgs a) {
             // instance_count of a multidrawable row's bin (render_phase/mod.rs:307-311), through the tile's LDS table
             const uint32_t m = metas[k];
             if (b < a.first_set_bucket || m == 0xFFFFFFFFu) continue;
-            uint32_t slot = (m * 2654435761u) >> 23;
+            uint32_t slot = (m * 2654435761u) >> BIN_HASH_SHIFT;
             bool done = false;
             for (uint32_t probe = 0; probe < 8u && !done; ++probe, slot = (slot + 1u) & (BIN_HASH - 1u)) {
                 const uint32_t old = atomicCAS(&hkey[slot], BIN_HASH_EMPTY, m);
@@ -135,22 +137,22 @@ __global__ void __launch_bounds__(256) k_batch_hist(BatchArgs a) {
                     done = true;
                 }
             }
-            if (!done) atomicAdd(&a.inst_count[m], 1u);  // table crowded: straight to memory
+            if (!done) atomicAdd(&a.inst_count[(size_t)m * BATCH_INST_STRIDE], 1u);  // table crowded: straight to memory
         } else {
             atomicAdd(&hist[b >> 8], 1u);
         }
     }
     __syncthreads();
-    a.tile_hist[threadIdx.x * a.n_tiles + blockIdx.x] = hist[threadIdx.x];
+    a.tile_hist[blockIdx.x * 256u + threadIdx.x] = hist[threadIdx.x];  // [tile][digit]: one contiguous KB per tile
     if (PASS == 0)
         for (uint32_t k = threadIdx.x; k < BIN_HASH; k += 256u)
-            if (hkey[k] != BIN_HASH_EMPTY) atomicAdd(&a.inst_count[hkey[k]], hval[k]);
+            if (hkey[k] != BIN_HASH_EMPTY) atomicAdd(&a.inst_count[(size_t)hkey[k] * BATCH_INST_STRIDE], hval[k]);
 }
 
-// K exclusive scans across the 1024 threads of the workgroup in one go (two barriers): v[] becomes the exclusive prefix,
-// total[] the sums.  lds: [16][K].
-template <uint32_t K>
-__device__ __forceinline__ void block_scan_1024_multi(uint32_t (&v)[K], uint32_t (*lds)[K], uint32_t (&total)[K]) {
+// K exclusive scans across the THREADS threads of the workgroup in one go (two barriers): v[] becomes the exclusive prefix,
+// total[] the sums.  lds: [THREADS / 64][K].
+template <uint32_t K, uint32_t THREADS>
+__device__ __forceinline__ void block_scan_multi(uint32_t (&v)[K], uint32_t (*lds)[K], uint32_t (&total)[K]) {
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     uint32_t incl[K];
 #pragma unroll
@@ -171,7 +173,7 @@ __device__ __forceinline__ void block_scan_1024_multi(uint32_t (&v)[K], uint32_t
     for (uint32_t q = 0; q < K; ++q) {
         uint32_t before = 0, all = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < 16u; ++k) {
+        for (uint32_t k = 0; k < THREADS / 64u; ++k) {
             const uint32_t w = lds[k][q];
             before += k < wv ? w : 0u;
             all += w;
@@ -180,37 +182,68 @@ __device__ __forceinline__ void block_scan_1024_multi(uint32_t (&v)[K], uint32_t
         v[q] = before + incl[q] - v[q];
     }
 }
+template <uint32_t K>
+__device__ __forceinline__ void block_scan_1024_multi(uint32_t (&v)[K], uint32_t (*lds)[K], uint32_t (&total)[K]) {
+    block_scan_multi<K, 1024>(v, lds, total);
+}
 
 // exclusive scan of tile_hist in digit-major order (= the partition offsets); counters[0] = entries kept.  Eight consecutive
 // entries per thread, so up to 64 k visible rows are one trip through the loop.  digit_start (LDS, 257 words, may be null)
 // receives the offset at which every digit's run starts, [256] = the total.
+template <uint32_t THREADS>
 __device__ __forceinline__ uint32_t scan_tile_hist(const BatchArgs& a, uint32_t len, uint32_t (*lds)[1], uint32_t* digit_start) {
+    constexpr uint32_t PER = 8192u / THREADS;
     const uint32_t used = (len + BATCH_TILE - 1u) / BATCH_TILE;  // tiles beyond hold nothing
-    uint32_t carry = 0;
-    const uint32_t total_entries = 256u * used;  // walk (digit, tile < used) in order
-    if (digit_start && used == 0u && threadIdx.x < 257u) digit_start[threadIdx.x] = 0u;
-    for (uint32_t e0 = 0; e0 < total_entries; e0 += 8192u) {
-        uint32_t v[8], idx[8], sum[1] = {0};
+    if (THREADS == 256u && used <= PER) {
+        // one thread per digit: tile k's 256 counts are one contiguous KB, so every load and store below is a coalesced wave
+        // access (a single workgroup keeps only so many cache misses in flight: a digit-major table, 64 lines per wave
+        // instruction, made this scan 15 us), and there is no index arithmetic (the general walk divides by `used`)
+        uint32_t v[PER], sum[1] = {0};
 #pragma unroll
-        for (uint32_t k = 0; k < 8u; ++k) {
-            const uint32_t e = e0 + threadIdx.x * 8u + k;
-            idx[k] = e < total_entries ? (e / used) * a.n_tiles + (e % used) : 0xFFFFFFFFu;
-            v[k] = e < total_entries ? a.tile_hist[idx[k]] : 0u;
-        }
+        for (uint32_t k = 0; k < PER; ++k) v[k] = k < used ? a.tile_hist[k * 256u + threadIdx.x] : 0u;
 #pragma unroll
-        for (uint32_t k = 0; k < 8u; ++k) {
+        for (uint32_t k = 0; k < PER; ++k) {
             const uint32_t t = v[k];
             v[k] = sum[0];
             sum[0] += t;
         }
         uint32_t tot[1];
-        block_scan_1024_multi<1>(sum, lds, tot);
+        block_scan_multi<1, THREADS>(sum, lds, tot);
 #pragma unroll
-        for (uint32_t k = 0; k < 8u; ++k)
+        for (uint32_t k = 0; k < PER; ++k)
+            if (k < used) a.tile_hist[k * 256u + threadIdx.x] = sum[0] + v[k];
+        if (digit_start) {
+            digit_start[threadIdx.x] = sum[0];
+            if (threadIdx.x == 0) digit_start[256] = tot[0];
+        }
+        return tot[0];
+    }
+    uint32_t carry = 0;
+    const uint32_t total_entries = 256u * used;  // walk (digit, tile < used) in order
+    if (digit_start && used == 0u && threadIdx.x < 257u) digit_start[threadIdx.x] = 0u;
+    if (digit_start && used == 0u && THREADS < 257u && threadIdx.x == 0) digit_start[256] = 0u;
+    for (uint32_t e0 = 0; e0 < total_entries; e0 += 8192u) {
+        uint32_t v[PER], idx[PER], sum[1] = {0};
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t e = e0 + threadIdx.x * PER + k;
+            idx[k] = e < total_entries ? (e % used) * 256u + (e / used) : 0xFFFFFFFFu;
+            v[k] = e < total_entries ? a.tile_hist[idx[k]] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t t = v[k];
+            v[k] = sum[0];
+            sum[0] += t;
+        }
+        uint32_t tot[1];
+        block_scan_multi<1, THREADS>(sum, lds, tot);
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k)
             if (idx[k] != 0xFFFFFFFFu) {
                 const uint32_t off = carry + sum[0] + v[k];
                 a.tile_hist[idx[k]] = off;
-                const uint32_t e = e0 + threadIdx.x * 8u + k;
+                const uint32_t e = e0 + threadIdx.x * PER + k;
                 if (digit_start && e % used == 0u) digit_start[e / used] = off;
             }
         carry += tot[0];
@@ -222,7 +255,7 @@ __device__ __forceinline__ uint32_t scan_tile_hist(const BatchArgs& a, uint32_t 
 template <uint32_t PASS>
 __global__ void __launch_bounds__(1024) k_batch_scan(BatchArgs a) {
     __shared__ uint32_t lds_waves[16][1];
-    const uint32_t carry = scan_tile_hist(a, list_len(a, PASS == 0), lds_waves, nullptr);
+    const uint32_t carry = scan_tile_hist<1024>(a, list_len(a, PASS == 0), lds_waves, nullptr);
     if (threadIdx.x == 0 && PASS == 0) a.counters[0] = carry;
 }
 
@@ -234,19 +267,21 @@ __global__ void __launch_bounds__(1024) k_batch_scan(BatchArgs a) {
 //   q5, q6  IndirectBatchSets per class: one per unbatchable entity with an input index, one per non-empty batchable bin / batch set
 //   q7      records (BinnedRenderPhaseBatchSet / batches)   q8  UnbatchableBinnedEntityIndices
 // count[] of a bucket comes from the partition offsets (ONE_PASS: digit starts in LDS) or from the run bounds in the list.
-template <bool ONE_PASS>
-__global__ void __launch_bounds__(1024) k_batch_plan(BatchArgs a) {
-    __shared__ uint32_t lds_scan1[16][1];
-    __shared__ uint32_t lds_scan[16][9];
+// THREADS = 256 when there are at most 256 buckets (one trip through the bucket loop either way): a quarter of the waves, four
+// times the register budget -- the 1024-thread build spills 126 registers into scratch in the middle of the scans.
+template <bool ONE_PASS, uint32_t THREADS>
+__global__ void __launch_bounds__(THREADS) k_batch_plan(BatchArgs a) {
+    __shared__ uint32_t lds_scan1[THREADS / 64][1];
+    __shared__ uint32_t lds_scan[THREADS / 64][9];
     __shared__ uint32_t digit_start[258];
     if (ONE_PASS) {
-        const uint32_t kept = scan_tile_hist(a, *a.list_count, lds_scan1, digit_start);
+        const uint32_t kept = scan_tile_hist<THREADS>(a, *a.list_count, lds_scan1, digit_start);
         if (threadIdx.x == 0) a.counters[0] = kept;
         __syncthreads();
     }
     const bool indirect = a.no_indirect == 0u;
     uint32_t carry[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t b0 = 0; b0 < a.n_buckets; b0 += 1024u) {
+    for (uint32_t b0 = 0; b0 < a.n_buckets; b0 += THREADS) {
         const uint32_t b = b0 + threadIdx.x;
         const bool in = b < a.n_buckets;
         auto count_of = [&](uint32_t k) -> uint32_t {
@@ -273,7 +308,7 @@ __global__ void __launch_bounds__(1024) k_batch_plan(BatchArgs a) {
         }
         uint32_t v[9] = {items, cls ? 0u : items, cls ? items : 0u, cls ? 0u : ip, cls ? ip : 0u, cls ? 0u : bs, cls ? bs : 0u, rec, unb};
         uint32_t tot[9];
-        block_scan_1024_multi<9>(v, lds_scan, tot);
+        block_scan_multi<9, THREADS>(v, lds_scan, tot);
         if (in) {
             // selects, not [cls]: dynamic indexing into the kernarg struct would spill it to scratch
             const uint32_t data0 = a.initial.output_mesh_uniform_index + carry[0] + v[0];
@@ -381,7 +416,7 @@ __device__ __forceinline__ void allocate_set(const BatchArgs& a, uint32_t s, uin
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     for (uint32_t k0 = 0; k0 < bins; k0 += 256u) {
         const uint32_t k = k0 + threadIdx.x;
-        const uint32_t v = k < bins ? a.inst_count[m0 + k] : 0u;
+        const uint32_t v = k < bins ? a.inst_count[(size_t)(m0 + k) * BATCH_INST_STRIDE] : 0u;
         uint32_t incl = v;
 #pragma unroll
         for (uint32_t off = 1; off < 64u; off <<= 1) {
@@ -401,7 +436,7 @@ __device__ __forceinline__ void allocate_set(const BatchArgs& a, uint32_t s, uin
             a.bin_metadata_out[3u * (m0 + k) + 0u] = a.bin_meta_in[3u * (m0 + k)];
             a.bin_metadata_out[3u * (m0 + k) + 1u] = a.bin_meta_in[3u * (m0 + k) + 1u];
             a.bin_metadata_out[3u * (m0 + k) + 2u] = v;
-            a.inst_count_next[m0 + k] = 0u;
+            a.inst_count_next[(size_t)(m0 + k) * BATCH_INST_STRIDE] = 0u;
             if (nonempty) {  // a batch set without instances was skipped: it owns no indirect-parameters slots (:2520-2524)
                 uint32_t* md = (cls ? a.metadata[1] : a.metadata[0]) + 5u * (first_ip + a.bin_meta_in[3u * (m0 + k)]);
                 md[0] = carry + before + incl - v;
@@ -423,7 +458,7 @@ __device__ __forceinline__ void scatter_tile(const BatchArgs& a, uint32_t tile, 
     const uint32_t len = list_len(a, PASS == 0);
     const uint32_t* src = list_src(a, PASS);
     uint32_t* dst = PASS == 0 ? a.rows_a : a.rows_b;
-    running[threadIdx.x] = a.tile_hist[threadIdx.x * a.n_tiles + tile];
+    running[threadIdx.x] = a.tile_hist[tile * 256u + threadIdx.x];
     const uint32_t i0 = tile * BATCH_TILE;
     if (i0 >= len) return;
     for (uint32_t r = 0; r < BATCH_TILE / 256u; ++r) {
@@ -490,6 +525,281 @@ __global__ void __launch_bounds__(256) k_batch_emit(BatchArgs a, uint32_t n_emit
         const uint32_t row = a.rows_b[p];
         const uint32_t bucket = a.row_bucket[row];
         emit_row(a, row, bucket, p - a.plan[bucket]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// At most 256 buckets: plan and emit in ONE launch.  Every workgroup derives the whole plan itself, in LDS -- a bucket per
+// thread; the tile histograms are [tile][256], so a thread's walk over the tiles is a sequence of coalesced wave loads; the
+// nine scans are the ones of k_batch_plan -- and then emits its own tile's rows (or runs allocate_uniforms for one batch
+// set).  The redundant part is a ~23 KB read of L2-resident counts and a few hundred instructions per workgroup; what it buys
+// is a whole dependent launch (>= 4.3 us of dispatch + the kernel boundary's cache maintenance + the plan kernel's own chain of
+// round trips, which a single workgroup cannot overlap).  Workgroup 0 also writes the plan's global outputs.
+// A tile's rows and their columns are fetched up front, all eight rounds at once: two dependent round trips per tile, not two
+// per round.
+// ---------------------------------------------------------------------------------------------
+struct LdsPlan {
+    uint32_t desc[256];
+    uint32_t v[7][256];  // as BatchArgs::plan
+};
+__device__ __forceinline__ void emit_row_lds(const BatchArgs& a, const LdsPlan& p, uint32_t bucket, uint32_t j, uint32_t input,
+                                             uint32_t bin_ip_offset) {
+    const uint32_t d = p.desc[bucket];
+    const uint32_t kind = desc_kind(d), cls = desc_cls(d);
+    const bool indirect = a.no_indirect == 0u;
+    const uint32_t ip0 = p.v[3][bucket];
+    if (kind == KIND_UNB_NO_INPUT) {
+        if (indirect) {
+            uint32_t* md = (cls ? a.metadata[1] : a.metadata[0]) + 5u * (ip0 + j);
+            md[0] = md[1] = md[2] = md[3] = md[4] = 0u;
+        }
+        return;
+    }
+    const uint32_t out = p.v[1][bucket] + j;
+    uint32_t* wi = (cls ? a.work_items[1] : a.work_items[0]) + 2u * (p.v[2][bucket] + j);
+    wi[0] = input;
+    if (kind == KIND_UNB_INPUT) {
+        const uint32_t ipi = ip0 + j;
+        wi[1] = indirect ? ipi : out;
+        uint32_t* ub = a.unbatchable + 2u * (p.v[5][bucket] + j);
+        ub[0] = desc_id(d);
+        ub[1] = indirect ? ipi : out;
+        if (indirect) {
+            uint32_t* md = (cls ? a.metadata[1] : a.metadata[0]) + 5u * ipi;
+            md[0] = out;
+            md[1] = 0xFFFFFFFFu;
+            md[2] = md[3] = md[4] = 0u;
+            uint32_t* bset = (cls ? a.batch_sets[1] : a.batch_sets[0]) + 2u * (p.v[4][bucket] + j);
+            bset[0] = 0u;
+            bset[1] = ipi;
+        }
+    } else if (kind == KIND_BATCHABLE) {
+        wi[1] = indirect ? ip0 : out;
+    } else {
+        wi[1] = ip0 + bin_ip_offset;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_batch_plan_emit(BatchArgs a, uint32_t n_emit_blocks) {
+    constexpr uint32_t PER = BATCH_TILE / 256u;  // rows per thread
+    constexpr uint32_t TCH = 32;                 // tile histograms fetched per trip
+    __shared__ LdsPlan plan;
+    __shared__ uint32_t running[256];
+    __shared__ uint32_t wave_hist[4][256];
+    __shared__ uint32_t lds_scan1[4][1];
+    __shared__ uint32_t lds_scan[4][9];
+    __shared__ uint32_t bucket_total[257];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+    const bool emitter = blockIdx.x < n_emit_blocks;
+    const uint32_t tile = emitter ? blockIdx.x : 0xFFFFFFFFu;  // (an allocate workgroup sums no tile prefix)
+    const uint32_t len = *a.list_count;
+    const uint32_t used = (len + BATCH_TILE - 1u) / BATCH_TILE;
+    const uint32_t* src = a.list + (a.list_base ? *a.list_base : 0ull);
+    const uint32_t i0 = emitter ? tile * BATCH_TILE : 0u;
+    const bool has_rows = emitter && i0 < len;
+
+    // ---- every independent load first: this tile's rows, the bucket table, the tiles' counts of this thread's bucket ----
+    uint32_t rows[PER];
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+        const uint32_t i = i0 + k * 256u + t;
+        rows[k] = (has_rows && i < len) ? src[i] : 0u;
+    }
+    const bool in = t < a.n_buckets;
+    const uint32_t d = in ? a.bucket_desc[t] : 0u;
+    uint32_t total = 0, before = 0;
+    for (uint32_t k0 = 0; k0 < used; k0 += TCH) {
+        uint32_t h[TCH];
+#pragma unroll
+        for (uint32_t k = 0; k < TCH; ++k) h[k] = k0 + k < used ? a.tile_hist[(k0 + k) * 256u + t] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < TCH; ++k) {
+            total += h[k];
+            before += k0 + k < tile ? h[k] : 0u;
+        }
+    }
+    // ---- second trip: what depends on the rows / the descriptor ----
+    uint32_t buckets[PER], inputs[PER], metas[PER];
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+        const uint32_t i = i0 + k * 256u + t;
+        const bool live = has_rows && i < len;
+        buckets[k] = live ? a.row_bucket[rows[k]] : BATCH_NO_SET;
+        inputs[k] = live ? a.row_input[rows[k]] : 0u;
+        metas[k] = live ? a.row_meta[rows[k]] : 0xFFFFFFFFu;
+    }
+    const uint32_t kind = desc_kind(d), cls = desc_cls(d), id = desc_id(d);
+    const uint32_t nbins = (in && kind == KIND_SET) ? a.meta_offset[id + 1] - a.meta_offset[id] : 0u;
+
+    // ---- the plan (see k_batch_plan), a bucket per thread ----
+    uint32_t s1[1] = {total}, tot1[1];
+    block_scan_multi<1, 256>(s1, lds_scan1, tot1);  // s1[0] = where the bucket's run starts in the partition
+    bucket_total[t] = in ? total : 0u;
+    if (t == 0) bucket_total[256] = 0u;
+    running[t] = s1[0] + before;
+    __syncthreads();
+    const bool indirect = a.no_indirect == 0u;
+    const uint32_t cnt = in ? total : 0u;
+    const uint32_t sibling = (in && kind == KIND_UNB_INPUT) ? bucket_total[t + 1u] : 0u;
+    const uint32_t bins = cnt ? nbins : 0u;
+    const uint32_t items = kind == KIND_UNB_NO_INPUT ? 0u : cnt;
+    uint32_t ip = 0, bs = 0, rec = 0, unb = 0;
+    if (kind == KIND_UNB_INPUT) {
+        ip = indirect ? cnt + sibling : 0u;
+        bs = indirect ? cnt : 0u;
+        unb = cnt;
+    } else if (kind == KIND_BATCHABLE) {
+        ip = bs = (indirect && cnt) ? 1u : 0u;
+        rec = cnt ? 1u : 0u;
+    } else if (kind == KIND_SET) {
+        ip = bins;
+        bs = rec = cnt ? 1u : 0u;
+    }
+    uint32_t v[9] = {items, cls ? 0u : items, cls ? items : 0u, cls ? 0u : ip, cls ? ip : 0u, cls ? 0u : bs, cls ? bs : 0u, rec, unb};
+    uint32_t tot[9];
+    block_scan_multi<9, 256>(v, lds_scan, tot);
+    const uint32_t data0 = a.initial.output_mesh_uniform_index + v[0];
+    const uint32_t wi0 = cls ? a.initial.work_item_index[1] + v[2] : a.initial.work_item_index[0] + v[1];
+    const uint32_t ip0 = cls ? a.initial.indirect_parameters_index[1] + v[4] : a.initial.indirect_parameters_index[0] + v[3];
+    const uint32_t bs0 = cls ? a.initial.batch_set_index[1] + v[6] : a.initial.batch_set_index[0] + v[5];
+    const uint32_t ip_plan = kind == KIND_UNB_NO_INPUT ? ip0 - cnt : ip0;  // the zero tail of the bin's allocate(len)
+    plan.desc[t] = d;
+    plan.v[0][t] = s1[0];
+    plan.v[1][t] = data0;
+    plan.v[2][t] = wi0;
+    plan.v[3][t] = ip_plan;
+    plan.v[4][t] = bs0;
+    plan.v[5][t] = v[8];
+    plan.v[6][t] = cnt;
+    if (blockIdx.x == 0) {  // the plan's own outputs, once
+        if (in) {
+            a.plan[0u * a.n_buckets + t] = s1[0];
+            a.plan[1u * a.n_buckets + t] = data0;
+            a.plan[2u * a.n_buckets + t] = wi0;
+            a.plan[3u * a.n_buckets + t] = ip_plan;
+            a.plan[4u * a.n_buckets + t] = bs0;
+            a.plan[5u * a.n_buckets + t] = v[8];
+            a.plan[6u * a.n_buckets + t] = cnt;
+            if (cnt && (kind == KIND_BATCHABLE || kind == KIND_SET)) {
+                if (indirect) {
+                    uint32_t* bset = cls ? a.batch_sets[1] : a.batch_sets[0];
+                    bset[2u * bs0 + 0u] = 0u;
+                    bset[2u * bs0 + 1u] = ip0;
+                }
+                if (kind == KIND_BATCHABLE && indirect) {
+                    uint32_t* md = (cls ? a.metadata[1] : a.metadata[0]) + 5u * ip0;
+                    md[0] = data0;
+                    md[1] = bs0;
+                    md[2] = md[3] = md[4] = 0u;
+                }
+                uint32_t* rec_out = a.records + 8u * v[7];
+                const bool set = kind == KIND_SET;
+                rec_out[0] = set ? id : (0x80000000u | id);
+                rec_out[1] = cls;
+                rec_out[2] = indirect ? bs0 : 0u;
+                rec_out[3] = set ? wi0 : 0u;
+                rec_out[4] = cnt;
+                rec_out[5] = indirect ? ip0 : 0xFFFFFFFFu;
+                rec_out[6] = set ? bins : 1u;
+                rec_out[7] = data0;
+            }
+        }
+        if (t == 0) {
+            a.counters[0] = tot1[0];
+            for (uint32_t c = 0; c < 2u; ++c) {
+                a.totals[0 + c] = a.initial.work_item_index[c] + tot[1 + c];
+                a.totals[2 + c] = a.initial.indirect_parameters_index[c] + tot[3 + c];
+                a.totals[4 + c] = a.initial.batch_set_index[c] + tot[5 + c];
+            }
+            a.totals[6] = a.initial.output_mesh_uniform_index + tot[0];
+            a.totals[7] = tot[7];
+            a.totals[8] = tot[8];
+        }
+    }
+    __syncthreads();
+
+    if (!emitter) {  // allocate_uniforms of one batch set, from the plan in LDS
+        const uint32_t s = blockIdx.x - n_emit_blocks, bucket = a.first_set_bucket + s;
+        const uint32_t scls = a.set_indexed[s] ? 1u : 0u;
+        const uint32_t m0 = a.meta_offset[s], sbins = a.meta_offset[s + 1] - m0;
+        const uint32_t first_ip = plan.v[3][bucket], bsi = plan.v[4][bucket];
+        uint32_t carry = plan.v[1][bucket];
+        const bool nonempty = plan.v[6][bucket] != 0u;
+        uint32_t* lds_waves = running;  // (free: an allocate workgroup scatters nothing)
+        for (uint32_t k0 = 0; k0 < sbins; k0 += 256u) {
+            const uint32_t k = k0 + t;
+            const uint32_t c = k < sbins ? a.inst_count[(size_t)(m0 + k) * BATCH_INST_STRIDE] : 0u;
+            uint32_t incl = c;
+#pragma unroll
+            for (uint32_t off = 1; off < 64u; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += up;
+            }
+            __syncthreads();
+            if (lane == 63u) lds_waves[wv] = incl;
+            __syncthreads();
+            uint32_t bef = 0, all = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < 4u; ++w) {
+                bef += w < wv ? lds_waves[w] : 0u;
+                all += lds_waves[w];
+            }
+            if (k < sbins) {
+                a.bin_metadata_out[3u * (m0 + k) + 0u] = a.bin_meta_in[3u * (m0 + k)];
+                a.bin_metadata_out[3u * (m0 + k) + 1u] = a.bin_meta_in[3u * (m0 + k) + 1u];
+                a.bin_metadata_out[3u * (m0 + k) + 2u] = c;
+                a.inst_count_next[(size_t)(m0 + k) * BATCH_INST_STRIDE] = 0u;
+                if (nonempty) {
+                    uint32_t* md = (scls ? a.metadata[1] : a.metadata[0]) + 5u * (first_ip + a.bin_meta_in[3u * (m0 + k)]);
+                    md[0] = carry + bef + incl - c;
+                    md[1] = bsi;
+                    md[2] = 0u;
+                    md[3] = 0u;
+                    md[4] = 0u;
+                }
+            }
+            carry += all;
+        }
+        return;
+    }
+    if (!has_rows) return;
+
+    // ---- third trip: a multidrawable row's slot offset inside its set (unpack_bins.wesl:64-93) ----
+    uint32_t binoff[PER];
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+        if (buckets[k] >= a.n_buckets) buckets[k] = BATCH_NO_SET;  // stale id after the tables shrank
+        const bool set_row = buckets[k] != BATCH_NO_SET && buckets[k] >= a.first_set_bucket && metas[k] != 0xFFFFFFFFu;
+        binoff[k] = set_row ? a.bin_meta_in[3u * metas[k]] : 0u;
+    }
+    // ---- the stable scatter of scatter_tile<0, true>, from registers ----
+#pragma unroll
+    for (uint32_t r = 0; r < PER; ++r) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) wave_hist[k][t] = 0u;
+        __syncthreads();
+        const uint32_t bucket = buckets[r];
+        const bool valid = bucket != BATCH_NO_SET;
+        const uint32_t digit = bucket & 255u;
+        unsigned long long m = __ballot(valid);
+#pragma unroll
+        for (uint32_t b = 0; b < 8u; ++b) {
+            const bool bit = (digit >> b) & 1u;
+            const unsigned long long bb = __ballot(bit);
+            m &= bit ? bb : ~bb;
+        }
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const uint32_t rank = __popcll(m & lt), same = __popcll(m);
+        if (valid && rank == 0) wave_hist[wv][digit] = same;
+        __syncthreads();
+        if (valid) {
+            uint32_t pos = running[digit] + rank;
+#pragma unroll
+            for (uint32_t k = 0; k < 3u; ++k) pos += k < wv ? wave_hist[k][digit] : 0u;
+            emit_row_lds(a, plan, bucket, pos - plan.v[0][bucket], inputs[r], binoff[r]);
+        }
+        __syncthreads();
+        running[t] += wave_hist[0][t] + wave_hist[1][t] + wave_hist[2][t] + wave_hist[3][t];
     }
 }
 
@@ -661,15 +971,14 @@ hipError_t launch_batch_resolve_rows(uint32_t n, uint32_t n_sets, uint32_t n_unb
     return hipGetLastError();
 }
 
-hipError_t launch_batch_build(const BatchArgs& a, hipStream_t stream, void (*mark)(void*, uint32_t), void* mctx) {
+hipError_t launch_batch_build(const BatchArgs& a_in, hipStream_t stream, void (*mark)(void*, uint32_t), void* mctx) {
 #define MARK(id) do { if (mark) mark(mctx, id); } while (0)
+    const BatchArgs& a = a_in;
     if (a.n_buckets <= 256u) {
         MARK(K_BATCH_HIST);
         MI_LAUNCH(k_batch_hist<0>, dim3(a.n_tiles), dim3(256), 0, stream, a);
-        MARK(K_BATCH_PLAN);
-        MI_LAUNCH(k_batch_plan<true>, dim3(1), dim3(1024), 0, stream, a);
         MARK(K_BATCH_EMIT);
-        MI_LAUNCH(k_batch_emit<true>, dim3(a.n_tiles + a.n_sets), dim3(256), 0, stream, a, a.n_tiles);
+        MI_LAUNCH(k_batch_plan_emit, dim3(a.n_tiles + a.n_sets), dim3(256), 0, stream, a, a.n_tiles);
     } else {
         const uint32_t cap = a.n_tiles * BATCH_TILE;
         MARK(K_BATCH_HIST);
@@ -688,7 +997,7 @@ hipError_t launch_batch_build(const BatchArgs& a, hipStream_t stream, void (*mar
         MI_LAUNCH(k_batch_clear_bounds, dim3((2u * a.n_buckets + 255u) / 256u), dim3(256), 0, stream, a);
         MI_LAUNCH(k_batch_bounds, dim3(cap / 256u), dim3(256), 0, stream, a);
         MARK(K_BATCH_PLAN);
-        MI_LAUNCH(k_batch_plan<false>, dim3(1), dim3(1024), 0, stream, a);
+        MI_LAUNCH((k_batch_plan<false, 1024>), dim3(1), dim3(1024), 0, stream, a);
         MARK(K_BATCH_EMIT);
         MI_LAUNCH(k_batch_emit<false>, dim3(cap / 256u + a.n_sets), dim3(256), 0, stream, a, cap / 256u);
     }

@@ -190,6 +190,7 @@ struct ObjectWalk {
     bool z_center_some, y_center_some;
 };
 
+template <bool SPOTS = true>
 __device__ __forceinline__ ObjectWalk object_setup(const ClusterViewDev& v, const ClusterObjects& o, uint32_t obj, float* far_z_out) {
     ObjectWalk ow;
     const float4 pr = object_sphere(o, obj);
@@ -232,7 +233,7 @@ __device__ __forceinline__ ObjectWalk object_setup(const ClusterViewDev& v, cons
     ow.light_dir = V3{0.0f, 0.0f, 0.0f};
     ow.angle_sin = 0.0f;
     ow.angle_cos = 0.0f;
-    if (ow.type == 1u) {  // spot light, :563-573
+    if (SPOTS && ow.type == 1u) {  // spot light, :563-573
         V3 d;
         if (o.row_global || o.derive) {  // GlobalTransform::back() = (matrix3 * Vec3::Z).normalize(), global_transform.rs:62-68,206
             const Affine ga = object_row_affine(o, o.first_row + obj);
@@ -262,7 +263,7 @@ __device__ __forceinline__ ObjectWalk object_setup(const ClusterViewDev& v, cons
 
 // emit(xy, z) is called for every cluster (y * dims.x + x, z) with z in [z_lo, z_hi] the reference would push this object into.
 // xp / yp / zp: the view's x, y, z cluster planes (LDS copies in the kernel below).
-template <typename Emit>
+template <bool SPOTS = true, typename Emit>
 __device__ __forceinline__ void object_walk(const ClusterViewDev& v, const ObjectWalk& ow, uint32_t z_lo, uint32_t z_hi, const float* xp,
                                             const float* yp, const float* zp, Emit emit) {
     const bool ortho = v.is_orthographic != 0;
@@ -294,7 +295,7 @@ __device__ __forceinline__ void object_walk(const ClusterViewDev& v, const Objec
                 max_x -= 1u;
             }
             const uint32_t xy0 = y * v.dims[0];
-            if (ow.type == 1u) {
+            if (SPOTS && ow.type == 1u) {
                 for (uint32_t x = min_x; x <= max_x; ++x) {
                     const float4 cs = reinterpret_cast<const float4*>(v.cluster_spheres)[(size_t)(xy0 + x) * v.dims[2] + z];
                     const V3 off = ow.vs.center - V3{cs.x, cs.y, cs.z};
@@ -325,7 +326,9 @@ __device__ __forceinline__ void object_walk(const ClusterViewDev& v, const Objec
 // CHUNKED = false: zc == dims.z, the whole grid in one sweep (no z-range bookkeeping, row index == cluster index).
 // In the chunked form the per-object setup is recomputed for every chunk instead of being kept in registers across the chunk
 // loop: 67 instead of 103 VGPRs, which is what lets the walk share a kernel with the frame rows at their occupancy.
-template <bool PLANES_IN_LDS, bool CHUNKED>
+// SPOTS = false: the caller guarantees there is no spot light among the objects (the walk riding in the frame kernel: ctx_cluster.cpp
+// sends scenes with spot lights to the walk kernel of its own) -- the cone test and its five registers per object drop out.
+template <bool PLANES_IN_LDS, bool CHUNKED, bool SPOTS = true>
 __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, const ClusterObjects& o, const ClusterWork& w, const ViewSet& views,
                                                    uint32_t zc_arg, uint32_t bx, uint32_t* arena) {
     const uint32_t dxy = v.dims[0] * v.dims[1], dz = v.dims[2];
@@ -366,7 +369,7 @@ __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, cons
     uint32_t my_lo = 0xFFFFFFFFu, my_hi = 0u;
     if (in_view) {
         float far_z = 0.0f;
-        ow = object_setup(v, o, obj, &far_z);
+        ow = object_setup<SPOTS>(v, o, obj, &far_z);
         my_lo = ow.minc[2];
         my_hi = ow.maxc[2];
         atomicOr(&type_rows[(ow.type < 6u ? ow.type : 5u) * 8u + word], bit);
@@ -398,9 +401,9 @@ __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, cons
                 float unused;
                 uint32_t obj_again = obj;
                 asm volatile("" : "+v"(obj_again));
-                ow = object_setup(v, o, obj_again, &unused);
+                ow = object_setup<SPOTS>(v, o, obj_again, &unused);
             }
-            object_walk(v, ow, z0, z0 + zc - 1u, xp, yp, zp, [&](uint32_t xy, uint32_t z) {
+            object_walk<SPOTS>(v, ow, z0, z0 + zc - 1u, xp, yp, zp, [&](uint32_t xy, uint32_t z) {
                 const uint32_t r = xy * zc + (z - z0);
                 atomicOr(&rows[r * 8u + word], bit);
                 const uint32_t tb = 1u << (r & 31u);

@@ -149,7 +149,8 @@ __device__ __forceinline__ void compact_fast_block(const CompactFastArgs& a, uin
 // write 48 (G) + 1 (vv) + (V + 2 change masks) / 8 + V / 64 (wave counts).
 // ---------------------------------------------------------------------------------------------
 // WITH_WALK: the launch may carry this frame's light-cluster walk.  A variant of its own because the walk needs more registers than
-// a row tile (93 against 66 VGPRs: 5 instead of 7 waves per SIMD for the whole launch); frames without a walk keep the lean one.
+// a row tile (87 against 66 VGPRs: 5 instead of 7 waves per SIMD for the whole launch; capping it at 80 or 72 registers with
+// __launch_bounds__ spills and measured 26.9 / 29.0 us per metric frame against 25.2); frames without a walk keep the lean one.
 template <bool PROPAGATE, bool INLINE_VIEWS, bool WITH_WALK>
 __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const ViewParams* __restrict__ dviews,
                                                 uint32_t n_views, VisibilityOut out, SegOut seg, uint32_t fl_frame, uint32_t n_tiles,
@@ -173,7 +174,7 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
             cluster_fill_block(fill.w, fill.n_clusters, fill.n_objects, id - n_compact, n_fill, lds_raw, lds_raw + 4096);
         } else if constexpr (WITH_WALK) {
             // this frame's light-cluster walk: independent of the rows below (it re-derives the lights' ViewVisibility itself)
-            cluster_walk_block<true, true>(walk.view, walk.objs, walk.w, vs, walk.zc, id - n_compact - n_fill, lds_raw);
+            cluster_walk_block<true, true, false>(walk.view, walk.objs, walk.w, vs, walk.zc, id - n_compact - n_fill, lds_raw);
         }
         return;
     }

@@ -584,6 +584,7 @@ def end_to_end(ctx, wl, frames=12):
     ctx.upload_changed(np.zeros(n, np.uint8))
     ctx.propagate(B.PROPAGATE_ALL_DIRTY)
     ctx.synchronize()
+    bufs = api.FrameResultBuffers(n, n, views[0].n_clusters, 1 << 20)  # the caller's slices, allocated once like an ECS system's
     for pct in (1, 10, 100):
         k = n * pct // 100
         rows = np.sort(rng.choice(n, k, replace=False)).astype(np.uint32) if pct < 100 else None
@@ -603,14 +604,14 @@ def end_to_end(ctx, wl, frames=12):
                 ctx.propagate_and_cull(fr, flags=B.CULL_END_FRAME)
             ctx.cluster_upload_view(views[f % N_FRAMES])
             ctx.cluster_assign_resident()
-            if rows is not None:
-                ch_rows, ch_g = ctx.download_changed_global_transforms()
-                got_g = len(ch_rows)
+            if rows is not None:  # one call, two device waits: changed GlobalTransforms, the camera's list, the cluster lists
+                res = ctx.download_frame_results(bufs)
+                got_g, vis_rows, off, counts, total = len(res["changed_rows"]), res["visible_rows"], res["cluster_offsets"], res["cluster_counts"], res["cluster_total"]
             else:
                 g = ctx.download_global_transforms(want_changed=False)
                 got_g = n
-            _, vis_rows = ctx.download_visible_entities(0, 0)
-            off, idx, counts, far, total = ctx.cluster_download(views[0].n_clusters)
+                _, vis_rows = ctx.download_visible_entities(0, 0)
+                off, idx, counts, far, total = ctx.cluster_download(views[0].n_clusters)
             t1 = time.perf_counter()
             if f >= 2:
                 times.append(t1 - t0)
@@ -622,9 +623,10 @@ def end_to_end(ctx, wl, frames=12):
                                   "changed_global_transforms_read_back": int(got_g), "visible_entities": int(len(vis_rows)),
                                   "cluster_index_entries": int(total)}
     out["note"] = ("same frame as `value` with the host on both sides: dirty Transforms H2D (mi_upload_transforms_indexed / the whole "
-                   "column at 100 %), propagate + cull + cluster, then changed GlobalTransforms (mi_download_changed_global_transforms / the "
-                   "whole column at 100 %), the camera's VisibleEntities list and the cluster lists D2H; median wall time of "
-                   f"{frames} frames, each synchronised (pageable host arrays, one staging copy each way)")
+                   "column at 100 %), propagate + cull + cluster, then changed GlobalTransforms, the camera's VisibleEntities list and the "
+                   "cluster lists D2H (mi_download_frame_results: one call, two device waits; at 100 % the whole GlobalTransform column "
+                   f"and the separate downloads); median wall time of {frames} frames, each synchronised (pageable host arrays, one "
+                   "staging copy each way)")
     return out
 
 

@@ -75,6 +75,39 @@ VIEW_CLUSTER_BINDINGS_MAX_INDICES = 16384
 MAX_UNIFORM_BUFFER_CLUSTERABLE_OBJECTS = 204
 
 
+class FrameResults(C.Structure):
+    """mi_frame_results"""
+    _fields_ = [("view", C.c_uint32), ("class_bit", C.c_uint32), ("changed_capacity", C.c_uint32), ("visible_capacity", C.c_uint32),
+                ("cluster_capacity", C.c_uint64),
+                ("changed_rows", C.POINTER(C.c_uint32)), ("changed_global12", C.POINTER(C.c_float)), ("visible_rows", C.POINTER(C.c_uint32)),
+                ("cluster_offsets", C.POINTER(C.c_uint32)), ("cluster_counts", C.POINTER(C.c_uint32)), ("cluster_indices", C.POINTER(C.c_uint32)),
+                ("changed_count", C.c_uint32), ("visible_count", C.c_uint32), ("cluster_total", C.c_uint64), ("farthest_z", C.c_float),
+                ("reserved", C.c_uint32)]
+
+
+class FrameResultBuffers:
+    """Caller-owned result slices for Context.download_frame_results, allocated once (an ECS system would hand in its own)."""
+
+    def __init__(self, changed_capacity, visible_capacity, n_clusters, cluster_capacity, view=0, class_bit=0):
+        self.changed_rows = np.zeros(max(changed_capacity, 1), np.uint32)
+        self.changed_global = np.zeros(12 * max(changed_capacity, 1), np.float32)
+        self.visible_rows = np.zeros(max(visible_capacity, 1), np.uint32)
+        self.n_clusters = n_clusters
+        self.cluster_offsets = np.zeros(n_clusters + 1, np.uint32) if n_clusters else None
+        self.cluster_counts = np.zeros(6 * n_clusters, np.uint32) if n_clusters else None
+        self.cluster_indices = np.zeros(max(cluster_capacity, 1), np.uint32) if n_clusters else None
+        r = self.raw = FrameResults()
+        r.view, r.class_bit = view, class_bit
+        r.changed_capacity, r.visible_capacity, r.cluster_capacity = changed_capacity, visible_capacity, cluster_capacity if n_clusters else 0
+        r.changed_rows = _ptr(self.changed_rows, C.c_uint32) if changed_capacity else None
+        r.changed_global12 = _ptr(self.changed_global, C.c_float) if changed_capacity else None
+        r.visible_rows = _ptr(self.visible_rows, C.c_uint32) if visible_capacity else None
+        if n_clusters:
+            r.cluster_offsets = _ptr(self.cluster_offsets, C.c_uint32)
+            r.cluster_counts = _ptr(self.cluster_counts, C.c_uint32)
+            r.cluster_indices = _ptr(self.cluster_indices, C.c_uint32)
+
+
 class View(C.Structure):
     """mi_view"""
     _fields_ = [("frustum", C.c_float * 24), ("layer_mask", C.c_uint32), ("flags", C.c_uint32),
@@ -115,7 +148,7 @@ ABI_SYMBOLS = [
     "mi_visibility_propagate", "mi_download_inherited_visibility",
     "mi_visibility_begin_frame", "mi_cull", "mi_cull_views", "mi_propagate_and_cull", "mi_propagate_and_cull_views",
     "mi_visibility_end_frame",
-    "mi_download_global_transforms", "mi_download_changed_global_transforms", "mi_download_changed_mesh_inputs", "mi_download_visibility", "mi_download_view_visibility",
+    "mi_download_global_transforms", "mi_download_changed_global_transforms", "mi_download_frame_results", "mi_download_changed_mesh_inputs", "mi_download_visibility", "mi_download_view_visibility",
     "mi_download_visible_entities", "mi_cluster_view_dims", "mi_cluster_view_build",
     "mi_cluster_dimensions_fixed_z", "mi_cluster_assign", "mi_cluster_upload_objects", "mi_cluster_upload_view",
     "mi_cluster_assign_resident", "mi_cluster_download", "mi_cluster_download_bindings",
@@ -440,6 +473,17 @@ class Context:
         g = np.zeros(12 * max(m, 1), np.float32)
         self._ck(self._lib.mi_download_changed_global_transforms(self._h, _ptr(rows, C.c_uint32), _ptr(g, C.c_float), m, C.byref(cnt)))
         return rows[:m], g[:12 * m]
+
+    def download_frame_results(self, bufs):
+        """mi_download_frame_results into `bufs` (FrameResultBuffers); -> dict of views on its arrays, cut to the counts."""
+        self._ck(self._lib.mi_download_frame_results(self._h, C.byref(bufs.raw)))
+        r = bufs.raw
+        out = {"changed_rows": bufs.changed_rows[:r.changed_count], "changed_global": bufs.changed_global[:12 * r.changed_count],
+               "visible_rows": bufs.visible_rows[:r.visible_count]}
+        if bufs.n_clusters:
+            out.update(cluster_offsets=bufs.cluster_offsets, cluster_counts=bufs.cluster_counts.reshape(bufs.n_clusters, 6),
+                       cluster_indices=bufs.cluster_indices[:r.cluster_total], cluster_total=int(r.cluster_total), farthest_z=float(r.farthest_z))
+        return out
 
     def download_changed_mesh_inputs(self):
         """-> (rows, world_from_local f32[12m] transposed 3x4, culling f32[8m]) for rows whose GlobalTransform changed."""

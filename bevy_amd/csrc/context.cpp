@@ -81,8 +81,20 @@ int32_t upload(mi_ctx* ctx, void* dst, const void* src, size_t bytes) {
     return MI_OK;
 }
 
+// The caller's slice is pageable memory: a device-to-host copy straight into it goes through the runtime's own bounce
+// buffers, synchronously and in chunks (measured: 40 - 50 us per call before the first byte moves).  Through the pinned
+// arena it is one DMA, one wait and one memcpy.
 int32_t download(mi_ctx* ctx, void* dst, const void* src, size_t bytes) {
     if (!bytes) return MI_OK;
+    if (bytes <= ((size_t)32 << 20)) {
+        void* st = nullptr;
+        int32_t rc = stage_alloc(ctx, bytes, &st);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(st, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(dst, st, bytes);
+        return MI_OK;
+    }
     HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return MI_OK;
@@ -1056,7 +1068,7 @@ static int32_t changed_rows_on_device(mi_ctx* ctx, uint32_t* total) {
     f.seg_stride = ctx->cap;
     f.seg_totals = (uint32_t*)ctx->sparse_total.p;
     HIP_TRY(ctx, launch_compact_fast(f, ctx->stream));
-    return download(ctx, total, ctx->sparse_total.p, 4);
+    return total ? download(ctx, total, ctx->sparse_total.p, 4) : MI_OK;
 }
 
 int32_t mi_download_changed_global_transforms(mi_ctx* ctx, uint32_t* out_rows, float* out_global12, uint32_t capacity,
@@ -1079,6 +1091,118 @@ int32_t mi_download_changed_global_transforms(mi_ctx* ctx, uint32_t* out_rows, f
         if ((rc = download(ctx, out_global12, ctx->sparse_g.p, (size_t)total * 48))) return rc;
     }
     return MI_OK;
+}
+
+namespace {
+// several device -> host copies, one wait: the pieces land in the pinned arena and are copied out after the wait
+struct BatchedDownload {
+    struct Piece { void* dst; void* stage; size_t bytes; };
+    std::vector<Piece> pieces;
+    int32_t add(mi_ctx* ctx, void* dst, const void* src, size_t bytes) {
+        if (!bytes || !dst) return MI_OK;
+        void* st = nullptr;
+        int32_t rc;
+        // the arena wraps (and is reused from its start) when it is full: hand out what is parked in it first
+        if (ctx->stage_used + ((bytes + 255) & ~(size_t)255) > ctx->stage_bytes && (rc = finish(ctx))) return rc;
+        rc = stage_alloc(ctx, bytes, &st);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(st, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        pieces.push_back({dst, st, bytes});
+        return MI_OK;
+    }
+    int32_t finish(mi_ctx* ctx) {
+        if (pieces.empty()) return MI_OK;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (auto& p : pieces) memcpy(p.dst, p.stage, p.bytes);
+        pieces.clear();
+        return MI_OK;
+    }
+};
+}  // namespace
+
+int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
+    ENTER(ctx);
+    if (!io) return fail(ctx, MI_ERR_INVALID_ARG, "mi_download_frame_results: NULL");
+    io->changed_count = io->visible_count = 0;
+    io->cluster_total = 0;
+    io->farthest_z = 0.0f;
+    const bool want_changed = (io->changed_rows || io->changed_global12) && ctx->n;
+    const bool want_visible = io->visible_rows != nullptr;
+    const bool want_clusters = io->cluster_offsets || io->cluster_counts || io->cluster_indices;
+    int32_t rc;
+    // ---- everything that has to run before the counts are final ----
+    uint32_t seg = 0;
+    bool visible_empty = false;
+    if (want_visible) {
+        if (!ctx->culled) return fail(ctx, MI_ERR_NOT_READY, "mi_download_frame_results: visible list before mi_cull");
+        if ((rc = compaction_join(ctx))) return rc;
+        if (!ctx->compact_fast) return fail(ctx, MI_ERR_NOT_READY, "mi_download_frame_results: rows are not in key order (use mi_download_visible_entities)");
+        if (io->view >= ctx->compact_views) return fail(ctx, MI_ERR_INVALID_ARG, "mi_download_frame_results: view %u", io->view);
+        uint32_t slot = 0xFFFFFFFFu;
+        for (uint32_t k = 0; k < ctx->compact_classes; ++k)
+            if (ctx->class_bits[k] == io->class_bit) slot = k;
+        visible_empty = slot == 0xFFFFFFFFu;  // no row carries this class: VisibleEntities::get() returns &[]
+        seg = io->view * ctx->compact_classes + (visible_empty ? 0u : slot);
+    }
+    if (want_clusters) {
+        if (!ctx->cl_assigned) return fail(ctx, MI_ERR_NOT_READY, "mi_download_frame_results: clusters before an assignment");
+        if ((rc = cluster_join(ctx))) return rc;
+    }
+    if (want_changed && (rc = changed_rows_on_device(ctx, nullptr))) return rc;
+    // ---- wait 1: the counts and every fixed-size array ----
+    uint32_t changed = 0, visible = 0;
+    uint64_t cl_total = 0;
+    const uint32_t C = ctx->cl_view.n_clusters;
+    const size_t off_totals = (6 * (size_t)C + 3) & ~(size_t)3, off_misc = off_totals + (((size_t)C + 3) & ~(size_t)3);
+    const uint32_t* acc = want_clusters ? (const uint32_t*)ctx->cl_acc.p + ctx->cl_parity * (off_misc + 4) : nullptr;
+    BatchedDownload b;
+    if (want_changed && (rc = b.add(ctx, &changed, ctx->sparse_total.p, 4))) return rc;
+    if (want_visible && !visible_empty && (rc = b.add(ctx, &visible, (const uint32_t*)ctx->fb[ctx->cur].seg_totals.p + seg, 4))) return rc;
+    if (want_clusters) {
+        if ((rc = b.add(ctx, &cl_total, ctx->cl_scalars.p, 8))) return rc;
+        if ((rc = b.add(ctx, &io->farthest_z, acc + off_misc, 4))) return rc;
+        if ((rc = b.add(ctx, io->cluster_offsets, ctx->cl_offsets.p, ((size_t)C + 1) * 4))) return rc;
+        if ((rc = b.add(ctx, io->cluster_counts, acc, (size_t)C * 6 * 4))) return rc;
+    }
+    if ((rc = b.finish(ctx))) return rc;
+    if (want_clusters && cl_total > ctx->cl_indices.bytes / 4) {  // fire-and-forget assign overflowed: redo with a big enough buffer
+        uint64_t t2 = 0;
+        if ((rc = mi_cluster_assign_resident(ctx, &t2))) return rc;
+        if ((rc = cluster_join(ctx))) return rc;
+        cl_total = t2;
+        acc = (const uint32_t*)ctx->cl_acc.p + ctx->cl_parity * (off_misc + 4);
+        if ((rc = b.add(ctx, &io->farthest_z, acc + off_misc, 4))) return rc;
+        if ((rc = b.add(ctx, io->cluster_offsets, ctx->cl_offsets.p, ((size_t)C + 1) * 4))) return rc;
+        if ((rc = b.add(ctx, io->cluster_counts, acc, (size_t)C * 6 * 4))) return rc;
+        if ((rc = b.finish(ctx))) return rc;
+    }
+    io->changed_count = changed;
+    io->visible_count = visible;
+    io->cluster_total = cl_total;
+    // ---- wait 2: the lists ----
+    int32_t cap_rc = MI_OK;
+    if (want_changed && changed) {
+        if (changed > io->changed_capacity) cap_rc = fail(ctx, MI_ERR_CAPACITY, "%u GlobalTransforms changed, capacity %u", changed, io->changed_capacity);
+        else {
+            if ((rc = b.add(ctx, io->changed_rows, ctx->sparse_rows.p, (size_t)changed * 4))) return rc;
+            if (io->changed_global12) {
+                if ((rc = ensure(ctx, ctx->sparse_g, (size_t)changed * 48))) return rc;
+                HIP_TRY(ctx, launch_gather_global((const uint32_t*)ctx->sparse_rows.p, (const uint32_t*)ctx->sparse_total.p, changed, ctx->g,
+                                                  (float*)ctx->sparse_g.p, ctx->stream));
+                if ((rc = b.add(ctx, io->changed_global12, ctx->sparse_g.p, (size_t)changed * 48))) return rc;
+            }
+        }
+    }
+    if (want_visible && visible) {
+        if (visible > io->visible_capacity) cap_rc = fail(ctx, MI_ERR_CAPACITY, "visible list has %u entries, capacity %u", visible, io->visible_capacity);
+        else if ((rc = b.add(ctx, io->visible_rows, (const uint32_t*)ctx->fb[ctx->cur].out_rows.p + (uint64_t)seg * ctx->seg_stride, (size_t)visible * 4))) return rc;
+    }
+    if (io->cluster_indices && cl_total) {
+        if (cl_total > io->cluster_capacity) cap_rc = fail(ctx, MI_ERR_CAPACITY, "cluster index list has %llu entries, capacity %llu", (unsigned long long)cl_total, (unsigned long long)io->cluster_capacity);
+        else if ((rc = b.add(ctx, io->cluster_indices, ctx->cl_indices.p, (size_t)cl_total * 4))) return rc;
+    }
+    if ((rc = b.finish(ctx))) return rc;
+    return cap_rc;
 }
 
 int32_t mi_download_changed_mesh_inputs(mi_ctx* ctx, uint32_t* out_rows, float* out_world_from_local12, float* out_culling8,

@@ -331,7 +331,7 @@ inline size_t cluster_walk_lds_bytes(uint32_t dxy, uint32_t zc, uint32_t n_plane
     return (RC * 8u + 48u) * sizeof(uint32_t) + (planes_in_lds ? (size_t)n_planes * 16u : 0u) + ((RC + 31u) / 32u + 4u) * 4u + RC * 2u + 16u;
 }
 constexpr size_t FRAME_KERNEL_LDS_BYTES = (4096 + 4) * 4;  // k_frame's static LDS: the arena a riding walk / fill workgroup gets
-constexpr uint32_t CLUSTER_FILL_RIDE_BLOCKS = 256;  // workgroups a riding fill adds to the frame kernel's grid
+constexpr uint32_t CLUSTER_FILL_RIDE_BLOCKS = 128;  // workgroups a riding fill adds to the frame kernel's grid
 
 // ---------------------------------------------------------------------------------------------
 // Batching work-item build (kernels_batch.hip).

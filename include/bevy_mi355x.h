@@ -445,6 +445,34 @@ int32_t mi_cluster_assign_frame(mi_ctx* ctx, const mi_cluster_config* config, mi
 int32_t mi_cluster_download(mi_ctx* ctx, uint32_t* out_offsets, uint32_t* out_indices, uint64_t capacity,
                             uint32_t* out_counts, uint64_t* out_total, float* out_farthest_z);
 
+/* Everything a frame hands back to the ECS in ONE call and two device waits (the separate downloads wait ten times
+ * between them, and on an idle stream a wait is ~30 us): the rows whose GlobalTransform changed with their matrices
+ * (mi_download_changed_global_transforms), one (view, class) VisibleEntities row list (mi_download_visible_entities; rows
+ * only -- the caller maps rows to Entity itself -- and only when rows are numbered in key order, which is the case unless
+ * mi_upload_entity_keys said otherwise: MI_ERR_NOT_READY then) and the cluster lists of the resident assignment
+ * (mi_cluster_download).  Any out pointer may be NULL (that part is skipped; a part whose buffers are all NULL costs nothing);
+ * the counts are always filled in for the parts that ran.  MI_ERR_CAPACITY if a list exceeds its capacity (counts are valid,
+ * nothing was copied for that list). */
+typedef struct mi_frame_results {
+    /* ---- in ---- */
+    uint32_t view, class_bit;     /* which VisibleEntities list */
+    uint32_t changed_capacity;    /* rows of changed_rows / changed_global12 */
+    uint32_t visible_capacity;    /* entries of visible_rows */
+    uint64_t cluster_capacity;    /* entries of cluster_indices */
+    uint32_t* changed_rows;       /* [changed_capacity] or NULL */
+    float* changed_global12;      /* [12 * changed_capacity] or NULL */
+    uint32_t* visible_rows;       /* [visible_capacity] or NULL */
+    uint32_t* cluster_offsets;    /* [n_clusters + 1] or NULL */
+    uint32_t* cluster_counts;     /* [6 * n_clusters] or NULL */
+    uint32_t* cluster_indices;    /* [cluster_capacity] or NULL */
+    /* ---- out ---- */
+    uint32_t changed_count, visible_count;
+    uint64_t cluster_total;
+    float farthest_z;
+    uint32_t reserved;
+} mi_frame_results;
+int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io);
+
 /* The GPU wire format of the view's clusters, storage-buffer flavour, built on the device from the last
  * assignment: what extract_clusters_for_cpu_clustering + prepare_clusters_for_cpu_clustering assemble element by
  * element on the CPU (crates/bevy_pbr/src/cluster/mod.rs:394-476,478-582; push_offset_and_counts :634-650):

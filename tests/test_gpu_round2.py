@@ -251,3 +251,53 @@ def test_very_wide_deepest_level_is_streamed(ctx_factory, static_opt):
         inh, _ = ctx.download_inherited_visibility()
         rc, inh_exp, _ = O.visibility_propagate(parent, vis, np.ones(n, np.uint8))
         assert rc == 0 and np.array_equal(inh, inh_exp)
+
+
+def test_frame_results_in_one_call_equal_the_separate_downloads(ctx_factory):
+    """mi_download_frame_results = mi_download_changed_global_transforms + mi_download_visible_entities + mi_cluster_download,
+    over several frames with different dirty sets, plus the capacity error and the parts switched off."""
+    sc, first_light, pr = W.frame_scene(60_000, 6_000, 600, light_range=2.0)
+    n, n_l = sc["n"], len(pr) // 4
+    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+    ctx = ctx_factory()
+    ctx.resize(n)
+    ctx.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
+    ctx.upload_bounds(sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"])
+    ctx.cluster_upload_objects(pr)
+    ctx.cluster_bind_objects_to_rows(first_light, n_l)
+    ctx.upload_changed(np.zeros(n, np.uint8))
+    ctx.propagate(B.PROPAGATE_ALL_DIRTY)
+    t3 = sc["translation"].reshape(n, 3).copy()
+    rng = np.random.default_rng(4)
+    n_clusters = 16 * 9 * 24
+    bufs = api.FrameResultBuffers(n, n, n_clusters, 4 * n_l * 8)
+    for f, k in enumerate((1, 0, 700, n // 10)):
+        cam = W.many_cubes_camera(3 * f)
+        fr = api.compute_frustum(cfv, cam, W.CAMERA_FAR)
+        view, keep = api.cluster_view_build(cam, cfv, fr, 1920, 1080, (16, 9, 24), 5.0, 1000.0)
+        rows = np.sort(rng.choice(n, k, replace=False)).astype(np.uint32)
+        if k:
+            t3[rows] += F(0.25)
+            ctx.upload_transforms_indexed(rows, t3[rows].reshape(-1), sc["rotation"].reshape(n, 4)[rows].reshape(-1),
+                                          sc["scale"].reshape(n, 3)[rows].reshape(-1))
+        ctx.propagate(0)
+        ctx.cull(frusta_for([cam]), flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME)
+        ctx.cluster_upload_view(view)
+        ctx.cluster_assign_resident()
+        got = ctx.download_frame_results(bufs)
+        ch_rows, ch_g = ctx.download_changed_global_transforms()
+        _, vis = ctx.download_visible_entities(0, 0)
+        off, idx, counts, far, total = ctx.cluster_download(n_clusters)
+        assert np.array_equal(got["changed_rows"], ch_rows) and np.array_equal(ch_rows, rows), f"frame {f}"
+        assert got["changed_global"].tobytes() == ch_g.tobytes()
+        assert np.array_equal(got["visible_rows"], vis) and vis.size > 0
+        assert got["cluster_total"] == total and np.array_equal(got["cluster_offsets"], off) and np.array_equal(got["cluster_indices"], idx)
+        assert np.array_equal(got["cluster_counts"], counts) and got["farthest_z"] == far
+    # parts switched off, and a list that does not fit
+    only_vis = api.FrameResultBuffers(0, n, 0, 0)
+    got = ctx.download_frame_results(only_vis)
+    assert np.array_equal(got["visible_rows"], vis) and got["changed_rows"].size == 0
+    small = api.FrameResultBuffers(n, 3, 0, 0)
+    with pytest.raises(api.MiError) as e:
+        ctx.download_frame_results(small)
+    assert e.value.code == api.MI_ERR_CAPACITY and small.raw.visible_count == vis.size

@@ -828,9 +828,12 @@ __global__ void __launch_bounds__(256) k_batch_clear_bounds(BatchArgs a) {
 // workgroup) turns them into work items and, at each set's last item, the record flush() leaves.
 constexpr uint32_t SORTED_OK = 0, SORTED_BREAK_BATCH = 1, SORTED_HEAD = 2, SORTED_SKIP = 3;
 
-__global__ void __launch_bounds__(1024) k_batch_sorted(SortedArgs a) {
-    __shared__ uint32_t lds_scan[16][8];
-    __shared__ uint32_t lds_head[16];
+// THREADS = 256 for phases of up to 4 096 items (the common case: no register spills -- the 1 024-thread build, capped at 128
+// registers, spills 118 in the middle of the scans); 1 024 threads keep long phases to few trips through the loops.
+template <uint32_t THREADS>
+__global__ void __launch_bounds__(THREADS) k_batch_sorted(SortedArgs a) {
+    __shared__ uint32_t lds_scan[THREADS / 64][8];
+    __shared__ uint32_t lds_head[THREADS / 64];
     __shared__ uint32_t carry_head;
     const bool indirect = a.no_indirect == 0u && a.merge_only == 0u;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
@@ -838,7 +841,7 @@ __global__ void __launch_bounds__(1024) k_batch_sorted(SortedArgs a) {
     uint32_t carry[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // with input | with input per class | allocations per class | breaks | sets | sets of class 1
     if (threadIdx.x == 0) carry_head = 0xFFFFFFFFu;
     __syncthreads();
-    for (uint32_t i0 = 0; i0 < a.n_items; i0 += 1024u) {
+    for (uint32_t i0 = 0; i0 < a.n_items; i0 += THREADS) {
         const uint32_t i = i0 + threadIdx.x;
         const bool in = i < a.n_items;
         uint32_t it[4] = {0xFFFFFFFFu, 0, 0, 0}, pv[4] = {0xFFFFFFFFu, 0, 0, 0};
@@ -868,7 +871,7 @@ __global__ void __launch_bounds__(1024) k_batch_sorted(SortedArgs a) {
                          (alloc && cls) ? 1u : 0u, flag == SORTED_BREAK_BATCH ? 1u : 0u, flag == SORTED_HEAD ? 1u : 0u,
                          (flag == SORTED_HEAD && cls) ? 1u : 0u};
         uint32_t tot[8];
-        block_scan_1024_multi<8>(v, lds_scan, tot);
+        block_scan_multi<8, THREADS>(v, lds_scan, tot);
         // the item that heads this item's batch set: the latest head at or before it (max-scan of head positions)
         uint32_t h = flag == SORTED_HEAD ? i : 0xFFFFFFFFu;  // 0xFFFFFFFF = none yet; indices compare as (x + 1)
         uint32_t hx = h + 1u;
@@ -896,7 +899,7 @@ __global__ void __launch_bounds__(1024) k_batch_sorted(SortedArgs a) {
             a.scratch[7u * a.n_items + i] = flag;
         }
         __syncthreads();
-        if (threadIdx.x == 1023u) carry_head = hx - 1u;
+        if (threadIdx.x == THREADS - 1u) carry_head = hx - 1u;
 #pragma unroll
         for (uint32_t q = 0; q < 8u; ++q) carry[q] += tot[q];
         __syncthreads();
@@ -916,7 +919,7 @@ __global__ void __launch_bounds__(1024) k_batch_sorted(SortedArgs a) {
     __syncthreads();
     // ---- phase B (scratch written above is read back through L2: the loads below bypass the per-CU cache)
     auto ld = [&](uint32_t plane, uint32_t i) { return __builtin_nontemporal_load(a.scratch + plane * a.n_items + i); };
-    for (uint32_t i0 = 0; i0 < a.n_items; i0 += 1024u) {
+    for (uint32_t i0 = 0; i0 < a.n_items; i0 += THREADS) {
         const uint32_t i = i0 + threadIdx.x;
         if (i >= a.n_items) continue;
         const uint32_t flag = ld(7, i);
@@ -1008,7 +1011,8 @@ hipError_t launch_batch_build(const BatchArgs& a_in, hipStream_t stream, void (*
 
 hipError_t launch_batch_sorted(const SortedArgs& a, hipStream_t stream, void (*mark)(void*, uint32_t), void* mctx) {
     if (mark) mark(mctx, K_BATCH_SORTED);
-    MI_LAUNCH(k_batch_sorted, dim3(1), dim3(1024), 0, stream, a);
+    if (a.n_items <= 4096u) MI_LAUNCH(k_batch_sorted<256>, dim3(1), dim3(256), 0, stream, a);
+    else MI_LAUNCH(k_batch_sorted<1024>, dim3(1), dim3(1024), 0, stream, a);
     if (mark) mark(mctx, K_NUM_KERNELS);
     return hipGetLastError();
 }

@@ -298,9 +298,11 @@ __global__ void __launch_bounds__(256) k_level0_propagate(Columns c, uint32_t n_
                                                            const uint8_t* __restrict__ changed,
                                                            const uint32_t* __restrict__ tree_bits, bool all_dirty,
                                                            bool static_opt) {
+    __shared__ float4 lds_g[4][192];
     const uint32_t row = blockIdx.x * 256u + threadIdx.x;
     const bool live = row < n_level0;
     bool write = false;
+    Affine g = {};
     if (live) {
         const bool has_children = node_flags ? (node_flags[row] & 1u) != 0 : false;
         if (has_children) {
@@ -315,11 +317,15 @@ __global__ void __launch_bounds__(256) k_level0_propagate(Columns c, uint32_t n_
             const V3 t = ld3(c.translation, row);
             const V4 q = ld4(c.rotation, row);
             const V3 s = ld3(c.scale, row);
-            st_affine(c.global, row, affine_from_srt(s, q, t));
+            g = affine_from_srt(s, q, t);
         }
     }
     const unsigned long long w = __ballot(write);
     const unsigned long long lv = __ballot(live);
+    // a wave that rewrites every one of its rows (the dirty frame) stores three contiguous 1 KB wave rows through the LDS
+    // transpose; otherwise only the lanes that write store their own 48 bytes
+    if (w == lv && lv) store_affine_coalesced(lds_g[threadIdx.x >> 6], c.global, row & ~63u, n_level0, threadIdx.x & 63u, g);
+    else if (write) st_affine(c.global, row, g);
     if ((threadIdx.x & 63u) == 0 && lv) c.g_changed_bits[row >> 6] = w;
 }
 

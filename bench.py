@@ -595,15 +595,14 @@ def end_to_end(ctx, wl, frames=12):
             fr = api.PreparedFrusta(camera_frusta(1, f))
             ctx.synchronize()
             t0 = time.perf_counter()
-            if rows is not None:
+            ctx.cluster_upload_view(views[f % N_FRAMES])
+            if rows is not None:  # only the dirty rows are recomputed; the cull launch carries the cluster walk
                 ctx.upload_transforms_indexed(rows, tt, rr, ss)
                 ctx.propagate(0)
-                ctx.cull(fr, flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME)
+                ctx.cull(fr, flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME | B.CULL_WITH_CLUSTERS)
             else:
                 ctx.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
-                ctx.propagate_and_cull(fr, flags=B.CULL_END_FRAME)
-            ctx.cluster_upload_view(views[f % N_FRAMES])
-            ctx.cluster_assign_resident()
+                ctx.propagate_and_cull(fr, flags=B.CULL_END_FRAME | B.CULL_WITH_CLUSTERS)
             if rows is not None:  # one call, two device waits: changed GlobalTransforms, the camera's list, the cluster lists
                 res = ctx.download_frame_results(bufs)
                 got_g, vis_rows, off, counts, total = len(res["changed_rows"]), res["visible_rows"], res["cluster_offsets"], res["cluster_counts"], res["cluster_total"]

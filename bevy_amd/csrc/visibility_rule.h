@@ -59,15 +59,21 @@ __device__ __forceinline__ bool row_visible_in_view(const Affine& g, V3 center, 
         const V3 cw = has_aabb ? transform_point(g, center) : center;
         const float sr = has_aabb ? length3(mul(g.m, half)) : half.x;
         const V4 c4 = extend(cw, 1.0f);
+        // intersects_sphere over the five planes first (mod.rs:829-832) ...
         bool inside = true;
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const V4 pl = V4{vp.planes[4 * i], vp.planes[4 * i + 1], vp.planes[4 * i + 2], vp.planes[4 * i + 3]};
-            const float d = dot4(pl, c4);
-            inside = inside && !(d + sr <= 0.0f);
-            if (has_aabb) {
-                const float rr = aabb_relative_radius(half, xyz(pl), g.m);
-                inside = inside && !(d + rr <= 0.0f);
+            inside = inside && !(dot4(pl, c4) + sr <= 0.0f);
+        }
+        // ... then intersects_obb (:833-836) -- 20 flops per plane and row -- only in waves where some row is still a candidate:
+        // rows are usually numbered with some spatial coherence and a view sees a few percent of them, so most waves skip it.
+        // (The reference returns early per entity; a conjunction of the same tests gives the same answer in any order.)
+        if (__builtin_amdgcn_ballot_w64(vis && inside && has_aabb) != 0ull) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const V4 pl = V4{vp.planes[4 * i], vp.planes[4 * i + 1], vp.planes[4 * i + 2], vp.planes[4 * i + 3]};
+                if (has_aabb) inside = inside && !(dot4(pl, c4) + aabb_relative_radius(half, xyz(pl), g.m) <= 0.0f);
             }
         }
         vis = vis && inside;

@@ -203,12 +203,14 @@ def test_baseline_lights_config_at_full_size(ctx_factory):
         O.cluster_view_setup(cam, cfv, frusta, 1920, 1080, (16, 9, 24), 5.0, 1000.0), pr))
 
 
-def test_baseline_tree_config_at_full_size(ctx_factory):
+@pytest.mark.parametrize("tile_mode", [0, 1])
+def test_baseline_tree_config_at_full_size(ctx_factory, tile_mode):
     """BASELINE.json configs[4]: gen_tree(12, 4) truncated to 1 000 000 nodes, bit-exact against the oracle, then a
-    partially dirty frame and a static frame."""
+    partially dirty frame and a static frame.  tile_mode 0 = the kernel the library picks at this size (light tiles), 1 = big tiles."""
     tr = W.gen_tree(12, 4, 1_000_000)
     assert tr["n"] == 1_000_000
     ctx = ctx_factory()
+    ctx.debug_set_tile_mode(tile_mode)
     upload_tree(ctx, tr)
     ctx.propagate(B.PROPAGATE_ALL_DIRTY)
     g, chg = ctx.download_global_transforms()

@@ -16,18 +16,21 @@
 //     [2U + b]     batchable bin b
 //     [2U + B + s] multidrawable batch set s
 // and every index the reference hands out while it walks is an exclusive prefix sum over the buckets.  A frame's build is
-//   1. k_batch_hist    per 2048-row tile: rows per bucket digit (LDS histogram), instances per multidrawable bin (integer adds:
-//                      order-independent, exact; pre-aggregated per tile in an LDS hash table, because agent-scope atomics on one
-//                      cache line serialise at ~25 ns each on this part and many_cubes has ONE bin)
-//   2. k_batch_plan    ONE workgroup: the partition offsets (scan of the tile histograms), then nine exclusive scans over the buckets
-//                      = all of the reference's per-bin / per-set bookkeeping: where each bucket's work items, MeshUniform slots,
-//                      indirect-parameters slots and batch sets start; the per-bucket outputs (batchable bins' metadata, batch sets,
-//                      records, buffer lengths)
-//   3. k_batch_emit    the stable scatter of the partition, except that a row's final position is not stored: position - bucket start
-//                      is the row's ordinal in its bin, which is all its work item (and, for an unbatchable entity, its metadata and
-//                      batch set) needs.  allocate_uniforms for every non-empty batch set rides along as extra workgroups.
-// Three launches when there are at most 256 buckets.  With more (up to 65 536) the partition takes two LSD passes and the last pass
-// stores the partitioned list (hist, scan, scatter, hist, scan, scatter, bounds, plan, emit-from-list): rare, not tuned.
+//   1. k_batch_hist        per 2048-row tile: rows per bucket digit (LDS histogram, one contiguous KB per tile), instances per
+//                          multidrawable bin (integer adds: order-independent, exact; pre-aggregated per tile in a 4096-slot LDS
+//                          hash table and added to counters that sit one per 64-byte line, because agent-scope atomics on one
+//                          cache line serialise at ~25 ns each on this part and many_cubes has ONE bin)
+//   2. k_batch_plan_emit   every workgroup first derives the PLAN in LDS -- the partition offsets (scan of the tile histograms) and
+//                          nine exclusive scans over the buckets = all of the reference's per-bin / per-set bookkeeping: where each
+//                          bucket's work items, MeshUniform slots, indirect-parameters slots and batch sets start -- then performs
+//                          the stable scatter of its own tile, except that a row's final position is not stored: position - bucket
+//                          start is the row's ordinal in its bin, which is all its work item (and, for an unbatchable entity, its
+//                          metadata and batch set) needs.  allocate_uniforms for every non-empty batch set rides along as extra
+//                          workgroups; workgroup 0 writes the plan's own outputs (batchable bins' metadata, batch sets, records,
+//                          buffer lengths).
+// Two launches when there are at most 256 buckets.  With more (up to 65 536) the partition takes two LSD passes and the last pass
+// stores the partitioned list (hist, scan, scatter, hist, scan, scatter, bounds, k_batch_plan, k_batch_emit from the list): rare,
+// not tuned.
 // The partition is stable, so a bucket's rows keep the list order (ascending Entity) -- the order the oracle uses; the reference
 // leaves the order inside a multidrawable set unspecified (unpack_bins.wesl:31-33).
 // Everything is u32; HBM traffic is a few words per visible row, the kernels are latency-, not bandwidth-bound.

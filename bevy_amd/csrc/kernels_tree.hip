@@ -641,6 +641,7 @@ __global__ void __launch_bounds__(256, 6) k_propagate_fans(Columns c, TreeArgs a
     __shared__ uint8_t lds_in[FAN_SLOTS];            // per slot: bit0 TransformTreeChanged, bit1 the level-0 assignment happens
     __shared__ uint32_t lds_pslot[TILE_LIGHT_UCAP];  // per upper row: its parent's LDS slot (or global row, see my_pslot)
     __shared__ uint32_t lds_row[TILE_LIGHT_UCAP];    // per upper row: its row number (the write-back runs over slots)
+    __shared__ uint8_t lds_level[TILE_LIGHT_UCAP];   // per upper row: its level inside the tile
     __shared__ float4 lds_chain_g[3];
     __shared__ uint32_t lds_chain_chg;
     const uint32_t tile = blockIdx.x;
@@ -742,6 +743,7 @@ __global__ void __launch_bounds__(256, 6) k_propagate_fans(Columns c, TreeArgs a
         if (is_upper) {
             lds_pslot[tid] = my_level ? u_pbase + (u_p - u_pstart) : u_p;
             lds_row[tid] = u_row;
+            lds_level[tid] = (uint8_t)my_level;
         }
     }
     __syncthreads();
@@ -784,41 +786,53 @@ __global__ void __launch_bounds__(256, 6) k_propagate_fans(Columns c, TreeArgs a
     }
 
     FAN_STAMP(3);
-    // ---- LDS-resident levels: four lanes per row ---------------------------------------------------------
+    // ---- LDS-resident levels: four lanes per row.  A thread's rows are fixed before the loop -- slot tid / 4 and, for tiles with
+    // more than 64 upper rows, slot 64 + tid / 4 (TILE_LIGHT_UCAP <= 128) -- and everything about them that no other row's
+    // result changes (level, parent slot, the rule's inputs, this lane's column of the local affine and of the old value) is
+    // fetched here, once: a level step is then the parent's read, the product, the compare and the write, nothing else. ----
+    static_assert(TILE_LIGHT_UCAP <= 128u, "two rows per quad cover the upper rows");
     bool any_chg = false;
+    if (n_lds) {
+        const uint32_t cc = tid & 3u;
+        uint32_t q_slot[2], q_level[2], q_ps[2], q_in[2];
+        V3 q_loc[2], q_old[2];
 #pragma unroll
-    for (uint32_t l = 0; l < TILE_MAX_LEVELS - 1; ++l) {
-        if (l < n_lds) {
-            const uint32_t cnt4 = td.count[l] * 4u;
-            for (uint32_t base = 0; base < cnt4; base += 256u) {
-                if (base + wv * 64u >= cnt4) continue;  // (wave-uniform) this wave carries no row of the level
-                const uint32_t t = base + tid;
-                const bool on = t < cnt4;
-                const uint32_t r = on ? t >> 2 : 0u, cc = t & 3u;
-                const uint32_t u = ubase[l] + r;
+        for (uint32_t h = 0; h < 2u; ++h) {
+            const uint32_t slot = h * 64u + (tid >> 2);
+            const bool on = slot < U;
+            const uint32_t sl = on ? slot : 0u;
+            q_slot[h] = sl;
+            q_level[h] = on ? (uint32_t)lds_level[sl] : 0xFFFFFFFFu;
+            q_ps[h] = lds_pslot[sl];
+            q_in[h] = lds_in[sl];
+            q_loc[h] = lds_col(lds_g, sl, cc);
+            q_old[h] = lds_col(lds_old, sl, cc);
+        }
+        for (uint32_t l = 0; l < n_lds; ++l) {
+#pragma unroll
+            for (uint32_t h = 0; h < 2u; ++h) {
+                const bool on = q_level[h] == l;
+                if (__builtin_amdgcn_ballot_w64(on) == 0ull) continue;  // (wave-uniform) no row of this level in the wave
                 Affine gp = {};
                 bool p_changed = false;
-                if (!(ROOTS && l == 0)) {
-                    if (l) {
-                        const uint32_t ps = lds_pslot[u];
-                        gp = lds_affine(lds_g, ps);
-                        p_changed = lds_chg[ps] != 0;
-                    } else if (chain_len) {
+                if (l) {
+                    gp = lds_affine(lds_g, q_ps[h]);
+                    p_changed = lds_chg[q_ps[h]] != 0;
+                } else if (!ROOTS) {
+                    if (chain_len) {
                         gp = lds_affine(lds_chain_g, 0);
                         p_changed = lds_chain_chg != 0;
-                    } else {
-                        const uint32_t pr = lds_pslot[u];
-                        gp = ld_affine(c.global, pr);
-                        p_changed = a.g_changed_bytes[pr] != 0;
+                    } else if (on) {  // a tile below another launch: the parent is in global memory
+                        gp = ld_affine(c.global, q_ps[h]);
+                        p_changed = a.g_changed_bytes[q_ps[h]] != 0;
                     }
                 }
                 V3 cur_c;
-                const bool chg = quad_node_apply(on, ROOTS && l == 0, a.static_opt != 0, lds_in[u], gp, p_changed, lds_col(lds_g, u, cc),
-                                                 lds_col(lds_old, u, cc), cc, lane, &cur_c);
+                const bool chg = quad_node_apply(on, ROOTS && l == 0, a.static_opt != 0, q_in[h], gp, p_changed, q_loc[h], q_old[h], cc, lane, &cur_c);
                 if (on) {
-                    lds_put_col(lds_g, u, cc, cur_c);  // in place: the quad's lanes read and write their own column only
+                    lds_put_col(lds_g, q_slot[h], cc, cur_c);  // in place: the quad's lanes read and write their own column only
                     any_chg = any_chg || chg;
-                    if (cc == 0) lds_chg[u] = chg ? 1 : 0;  // (its global copy goes out with the write-back, not in front of a barrier)
+                    if (cc == 0) lds_chg[q_slot[h]] = chg ? 1 : 0;  // (its global copy goes out with the write-back)
                 }
             }
             __syncthreads();

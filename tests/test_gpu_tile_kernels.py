@@ -119,3 +119,64 @@ def test_light_plan_is_used_where_it_fits_and_not_where_it_does_not(ctx_factory)
     ctx.debug_set_tile_mode(1)
     ctx.upload_hierarchy(big["parent"], big["level_offsets"])
     assert auto["tiles"] > ctx.debug_tile_plan()["tiles"]
+
+
+def _random_forest(rng, n):
+    """Random hierarchy of n nodes: a random share of parentless rows (roots and flat rows), every other node hangs below a
+    node drawn from a sliding window before it -- narrow windows give deep chains, wide ones bushy trees."""
+    parent_old = np.full(n, B.NO_PARENT, np.uint32)
+    root_p = rng.choice([0.001, 0.02, 0.3])
+    window = int(rng.choice([1, 3, 40, 2000]))
+    for k in range(1, n):
+        if rng.random() < root_p:
+            continue
+        parent_old[k] = rng.integers(max(0, k - window), k)
+    return parent_old
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_hierarchies_match_oracle_under_both_kernels(ctx_factory, seed):
+    """Differential test over random forests (deep chains, bushy trees, many roots; 1 to ~60 000 nodes): both tile kernels, the
+    static-scene rule on and off, an all-dirty frame and three random partially dirty ones, bit for bit with change ticks."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([1, 2, 65, 900, 7000, 60_000]))
+    parent_old = _random_forest(rng, n)
+    new_to_old, parent, offs = api.hierarchy_sort(parent_old)
+    t = rng.normal(size=(n, 3)).astype(F)
+    q = rng.normal(size=(n, 4))
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(F).reshape(-1)
+    s = rng.uniform(0.8, 1.25, size=(n, 3)).astype(F).reshape(-1)
+    for mode in (1, 2):
+        for static_opt in (False, True):
+            flags = B.PROPAGATE_STATIC_OPT if static_opt else 0
+            ctx = ctx_factory()
+            ctx.debug_set_tile_mode(mode)
+            ctx.resize(n)
+            tt = t.copy()
+            ctx.upload_transforms(tt.reshape(-1), q, s)
+            ctx.upload_hierarchy(parent, offs)
+            ctx.propagate(B.PROPAGATE_ALL_DIRTY | flags)
+            rc, g0, chg0 = O.propagate_transforms(parent, tt.reshape(-1), q, s, static_opt=static_opt)
+            assert rc == 0
+            g, chg = ctx.download_global_transforms()
+            assert g.tobytes() == g0.tobytes(), f"seed {seed} mode {mode} static {static_opt}: all-dirty frame"
+            assert_bits(chg, chg0, "change ticks of the all-dirty frame")
+            ctx.upload_changed(np.zeros(n, np.uint8))  # from here on the change column says what changed (until one is uploaded,
+            frng = np.random.default_rng(seed)         # every Transform counts as changed)
+            for frame in range(3):
+                k = int(frng.choice([0, 1, max(1, n // 50)]))
+                dirty = np.unique(frng.integers(0, n, k)).astype(np.uint32) if k else np.zeros(0, np.uint32)
+                tt[dirty] += F(0.25)
+                if dirty.size:
+                    ctx.upload_transforms_indexed(dirty, tt[dirty].reshape(-1), q.reshape(n, 4)[dirty].reshape(-1), s.reshape(n, 3)[dirty].reshape(-1))
+                ctx.propagate(flags)
+                changed = np.zeros(n, np.uint8)
+                changed[dirty] = 1
+                rc, g1, chg1 = O.propagate_transforms(parent, tt.reshape(-1), q, s, global_in=g0, static_opt=static_opt,
+                                                      tree_changed=O.mark_dirty_trees(parent, changed), transform_changed=changed)
+                assert rc == 0
+                g, chg = ctx.download_global_transforms()
+                bad = np.nonzero((g.view(np.uint32) != g1.view(np.uint32)).reshape(-1, 12).any(axis=1))[0]
+                assert bad.size == 0, f"seed {seed} mode {mode} static {static_opt} frame {frame}: {bad.size} rows differ, first {bad[:5].tolist()}"
+                assert_bits(chg, chg1, f"seed {seed} mode {mode} frame {frame} change ticks")
+                g0 = g1

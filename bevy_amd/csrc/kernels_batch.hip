@@ -600,6 +600,9 @@ __global__ void __launch_bounds__(256) k_batch_plan_emit(BatchArgs a, uint32_t n
     const uint32_t* src = a.list + (a.list_base ? *a.list_base : 0ull);
     const uint32_t i0 = emitter ? tile * BATCH_TILE : 0u;
     const bool has_rows = emitter && i0 < len;
+    // the grid covers the list's capacity (every row of the scene): a tile past the list's end has nothing to emit and nobody
+    // needs its copy of the plan (workgroup 0 stays: it writes the plan's outputs even for an empty list)
+    if (emitter && !has_rows && blockIdx.x != 0u) return;
 
     // ---- every independent load first: this tile's rows, the bucket table, the tiles' counts of this thread's bucket ----
     uint32_t rows[PER];

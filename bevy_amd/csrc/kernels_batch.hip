@@ -16,7 +16,7 @@
 //     [2U + b]     batchable bin b
 //     [2U + B + s] multidrawable batch set s
 // and every index the reference hands out while it walks is an exclusive prefix sum over the buckets.  A frame's build is
-//   1. k_batch_hist        per 2048-row tile: rows per bucket digit (LDS histogram, one contiguous KB per tile), instances per
+//   1. k_batch_hist        per 1024-row tile: rows per bucket digit (LDS histogram, one contiguous KB per tile), instances per
 //                          multidrawable bin (integer adds: order-independent, exact; pre-aggregated per tile in a 4096-slot LDS
 //                          hash table and added to counters that sit one per 64-byte line, because agent-scope atomics on one
 //                          cache line serialise at ~25 ns each on this part and many_cubes has ONE bin)
@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256) k_batch_resolve_rows(uint32_t n, uint32_t
     row_bucket[row] = bucket;
 }
 
-// (a tile of 2048 rows can name 2048 bins: at 512 slots a many-bin scene filled the table, every later row probed eight
+// (a tile of 1024 rows can name 1024 bins: at 512 slots a many-bin scene filled the table, every later row probed eight
 // times in vain -- an LDS round trip each -- and went to memory anyway)
 constexpr uint32_t BIN_HASH = 4096, BIN_HASH_SHIFT = 20, BIN_HASH_EMPTY = 0xFFFFFFFFu;
 

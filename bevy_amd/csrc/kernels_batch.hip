@@ -538,7 +538,7 @@ __global__ void __launch_bounds__(256) k_batch_emit(BatchArgs a, uint32_t n_emit
 // set).  The redundant part is a ~23 KB read of L2-resident counts and a few hundred instructions per workgroup; what it buys
 // is a whole dependent launch (>= 4.3 us of dispatch + the kernel boundary's cache maintenance + the plan kernel's own chain of
 // round trips, which a single workgroup cannot overlap).  Workgroup 0 also writes the plan's global outputs.
-// A tile's rows and their columns are fetched up front, all eight rounds at once: two dependent round trips per tile, not two
+// A tile's rows and their columns are fetched up front, all four rounds at once: two dependent round trips per tile, not two
 // per round.
 // ---------------------------------------------------------------------------------------------
 struct LdsPlan {

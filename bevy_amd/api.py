@@ -728,9 +728,12 @@ class Context:
 
     def debug_tree_trace(self, n_tiles=0):
         """Development hook: n_tiles == 0 enables the per-tile phase timestamps of the light tile kernel; otherwise returns
-        them as an (n_tiles, 8) uint64 array of 10 ns ticks."""
+        them as an (n_tiles, 8) uint64 array of 10 ns ticks; n_tiles < 0 switches the stamps off."""
         if not n_tiles:
             self._ck(self._lib.mi_debug_tree_trace(self._h, 1, None, 0))
+            return None
+        if n_tiles < 0:  # off again
+            self._ck(self._lib.mi_debug_tree_trace(self._h, 0, None, 0))
             return None
         out = np.zeros((n_tiles, 8), dtype=np.uint64)
         self._ck(self._lib.mi_debug_tree_trace(self._h, 0, out.ctypes.data_as(C.c_void_p), int(n_tiles)))

@@ -234,7 +234,8 @@ int32_t mi_debug_set_tile_mode(mi_ctx* ctx, int32_t mode) {
 }
 
 // development hook: per-tile phase timestamps of the light tile kernel (8 x s_memrealtime, 100 MHz, per tile of the first
-// launch).  enable allocates the buffer (mi_propagate then fills it every frame); read copies it out.
+// launch).  enable allocates the buffer (mi_propagate then fills it every frame); out != NULL copies it out; enable = 0 with
+// out = NULL switches the stamps off again.
 int32_t mi_debug_tree_trace(mi_ctx* ctx, int32_t enable, unsigned long long* out, uint32_t n_tiles) {
     ENTER(ctx);
     if (enable) {
@@ -245,6 +246,11 @@ int32_t mi_debug_tree_trace(mi_ctx* ctx, int32_t enable, unsigned long long* out
         HIP_TRY(ctx, hipMemsetAsync(ctx->tree_trace.p, 0, tiles * 64, ctx->stream));
     }
     if (out && ctx->tree_trace.p) return download(ctx, out, ctx->tree_trace.p, std::min<size_t>((size_t)n_tiles * 64, ctx->tree_trace.bytes));
+    if (!enable && !out && ctx->tree_trace.p) {  // switch it off again: later launches carry no stamps
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(ctx->tree_trace.p));
+        ctx->tree_trace = DevBuf{};
+    }
     return MI_OK;
 }
 

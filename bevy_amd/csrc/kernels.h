@@ -209,7 +209,7 @@ constexpr uint32_t TILE_LAST_CAP = 1024;       // the planner keeps a tile's str
 // software-pipelined -- so the kernel fits twice the workgroups per CU and a tile is two dependent round trips, not seven.
 constexpr uint32_t TILE_LIGHT_UCAP = 112;
 constexpr uint32_t TILE_LIGHT_LAST_CAP = 256;
-constexpr uint32_t TILE_LIGHT_MIN_ROWS = 1u << 16;  // hierarchies from this many rows up are planned as light tiles
+constexpr uint32_t TILE_LIGHT_MIN_ROWS = 0;  // light tiles whenever they fit: measured faster from 341 to 1 M nodes
 // A level this wide is not given to tiles at all: it is swept by a streaming launch of its own (k_propagate_level) behind
 // the level above it.  The deepest level qualifies earlier than the ones above it (nothing else has to wait for it).
 constexpr uint32_t STREAM_LEVEL_MIN_ROWS_LAST = 1u << 20;

@@ -109,7 +109,7 @@ def test_light_plan_is_used_where_it_fits_and_not_where_it_does_not(ctx_factory)
         return ctx.debug_tile_plan()
     assert plan("fan_4ary_7_levels", 2)["tiles"] > plan("fan_4ary_7_levels", 1)["tiles"]   # smaller tiles, more of them
     assert plan("skewed", 2) == plan("skewed", 1)                                           # does not fit: the big-tile plan
-    # by size: a 1 M-node tree is planned light, a small one is not
+    # by default (mode 0): light tiles wherever they fit
     big = W.gen_tree(12, 4, 1_000_000)
     ctx = ctx_factory()
     ctx.resize(big["n"])

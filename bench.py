@@ -603,7 +603,7 @@ def end_to_end(ctx, wl, frames=12):
             else:
                 ctx.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
                 ctx.propagate_and_cull(fr, flags=B.CULL_END_FRAME | B.CULL_WITH_CLUSTERS)
-            if rows is not None:  # one call, two device waits: changed GlobalTransforms, the camera's list, the cluster lists
+            if rows is not None:  # one call, one packing launch, one device wait: changed GlobalTransforms, the camera's list, the cluster lists
                 res = ctx.download_frame_results(bufs)
                 got_g, vis_rows, off, counts, total = len(res["changed_rows"]), res["visible_rows"], res["cluster_offsets"], res["cluster_counts"], res["cluster_total"]
             else:
@@ -623,7 +623,7 @@ def end_to_end(ctx, wl, frames=12):
                                   "cluster_index_entries": int(total)}
     out["note"] = ("same frame as `value` with the host on both sides: dirty Transforms H2D (mi_upload_transforms_indexed / the whole "
                    "column at 100 %), propagate + cull + cluster, then changed GlobalTransforms, the camera's VisibleEntities list and the "
-                   "cluster lists D2H (mi_download_frame_results: one call, two device waits; at 100 % the whole GlobalTransform column "
+                   "cluster lists D2H (mi_download_frame_results: one call, one packing launch into pinned memory, one device wait -- two beyond 8 MB; at 100 % the whole GlobalTransform column "
                    f"and the separate downloads); median wall time of {frames} frames, each synchronised (pageable host arrays, one "
                    "staging copy each way)")
     return out

@@ -1149,12 +1149,99 @@ int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
         if ((rc = cluster_join(ctx))) return rc;
     }
     if (want_changed && (rc = changed_rows_on_device(ctx, nullptr))) return rc;
-    // ---- wait 1: the counts and every fixed-size array ----
     uint32_t changed = 0, visible = 0;
     uint64_t cl_total = 0;
     const uint32_t C = ctx->cl_view.n_clusters;
     const size_t off_totals = (6 * (size_t)C + 3) & ~(size_t)3, off_misc = off_totals + (((size_t)C + 3) & ~(size_t)3);
     const uint32_t* acc = want_clusters ? (const uint32_t*)ctx->cl_acc.p + ctx->cl_parity * (off_misc + 4) : nullptr;
+    // ---- one launch, one wait: counts and lists packed by the device into a window of the pinned arena ----
+    // (the window is bounded; a frame whose lists do not fit, or whose cluster list overflowed, takes the two waits below)
+    {
+        const bool sec_vis = want_visible && !visible_empty;
+        uint64_t need = 0;
+        if (want_changed) {
+            if (io->changed_rows) need += pack_align((uint64_t)io->changed_capacity * 4u);
+            if (io->changed_global12) need += pack_align((uint64_t)io->changed_capacity * 48u);
+        }
+        if (sec_vis) need += pack_align((uint64_t)io->visible_capacity * 4u);
+        if (want_clusters) {
+            need += pack_align(((uint64_t)C + 1u) * 4u) + pack_align((uint64_t)C * 24u);
+            if (io->cluster_indices) need += pack_align(io->cluster_capacity * 4u);
+        }
+        PackResultsJob j{};
+        j.payload_bytes = std::min<uint64_t>(need, PACK_WINDOW_BYTES);
+        void* st = nullptr;
+        if ((rc = stage_alloc(ctx, PACK_HEADER_BYTES + j.payload_bytes, &st))) return rc;
+        j.header = (uint32_t*)st;
+        j.payload = (uint8_t*)st + PACK_HEADER_BYTES;
+        if (want_changed) {
+            j.changed_total = (const uint32_t*)ctx->sparse_total.p;
+            j.changed_rows = (const uint32_t*)ctx->sparse_rows.p;
+            j.g = io->changed_global12 ? ctx->g : nullptr;
+            j.want_changed_rows = io->changed_rows != nullptr;
+            j.changed_capacity = io->changed_capacity;
+        }
+        if (sec_vis) {
+            j.visible_total = (const uint32_t*)ctx->fb[ctx->cur].seg_totals.p + seg;
+            j.visible_rows = (const uint32_t*)ctx->fb[ctx->cur].out_rows.p + (uint64_t)seg * ctx->seg_stride;
+            j.visible_capacity = io->visible_capacity;
+        }
+        if (want_clusters) {
+            j.cluster_total = (const uint64_t*)ctx->cl_scalars.p;
+            j.cluster_offsets = (const uint32_t*)ctx->cl_offsets.p;
+            j.cluster_counts = acc;
+            j.cluster_indices = io->cluster_indices ? (const uint32_t*)ctx->cl_indices.p : nullptr;
+            j.farthest_z = (const float*)(acc + off_misc);
+            j.n_clusters = C;
+            j.cluster_capacity = io->cluster_capacity;
+            j.cluster_indices_alloc = ctx->cl_indices.bytes / 4;
+        }
+        HIP_TRY(ctx, launch_pack_results(j, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const uint32_t* h = j.header;
+        if (h[5]) {
+            changed = h[0];
+            visible = h[1];
+            cl_total = (uint64_t)h[2] | ((uint64_t)h[3] << 32);
+            io->changed_count = changed;
+            io->visible_count = visible;
+            io->cluster_total = cl_total;
+            if (want_clusters) memcpy(&io->farthest_z, &h[4], 4);
+            int32_t cap_rc = MI_OK;
+            const uint8_t* src = j.payload;
+            const bool fits_changed = want_changed && changed <= io->changed_capacity;
+            if (want_changed && !fits_changed) cap_rc = fail(ctx, MI_ERR_CAPACITY, "%u GlobalTransforms changed, capacity %u", changed, io->changed_capacity);
+            if (fits_changed && io->changed_rows) {
+                memcpy(io->changed_rows, src, (size_t)changed * 4);
+                src += pack_align((uint64_t)changed * 4u);
+            }
+            if (fits_changed && io->changed_global12) {
+                memcpy(io->changed_global12, src, (size_t)changed * 48);
+                src += pack_align((uint64_t)changed * 48u);
+            }
+            if (sec_vis) {
+                if (visible > io->visible_capacity) cap_rc = fail(ctx, MI_ERR_CAPACITY, "visible list has %u entries, capacity %u", visible, io->visible_capacity);
+                else {
+                    memcpy(io->visible_rows, src, (size_t)visible * 4);
+                    src += pack_align((uint64_t)visible * 4u);
+                }
+            }
+            if (want_clusters) {
+                if (io->cluster_offsets) memcpy(io->cluster_offsets, src, ((size_t)C + 1) * 4);
+                src += pack_align(((uint64_t)C + 1u) * 4u);
+                if (io->cluster_counts) memcpy(io->cluster_counts, src, (size_t)C * 24);
+                src += pack_align((uint64_t)C * 24u);
+                if (io->cluster_indices) {
+                    if (cl_total > io->cluster_capacity) cap_rc = fail(ctx, MI_ERR_CAPACITY, "cluster index list has %llu entries, capacity %llu", (unsigned long long)cl_total, (unsigned long long)io->cluster_capacity);
+                    else memcpy(io->cluster_indices, src, (size_t)cl_total * 4);
+                }
+            }
+            return cap_rc;
+        }
+        changed = visible = 0;
+        cl_total = 0;
+    }
+    // ---- wait 1: the counts and every fixed-size array ----
     BatchedDownload b;
     if (want_changed && (rc = b.add(ctx, &changed, ctx->sparse_total.p, 4))) return rc;
     if (want_visible && !visible_empty && (rc = b.add(ctx, &visible, (const uint32_t*)ctx->fb[ctx->cur].seg_totals.p + seg, 4))) return rc;

@@ -170,6 +170,35 @@ hipError_t launch_gather_global(const uint32_t* rows, const uint32_t* total, uin
                                 hipStream_t stream);
 hipError_t launch_gather_mesh_inputs(const uint32_t* rows, const uint32_t* total, uint32_t capacity, const Columns& c, float* out_wfl,
                                      float* out_cull, hipStream_t stream);
+// One frame's results packed by ONE launch into a window of the pinned staging arena (mapped host memory), so that the host
+// needs one wait instead of one for the counts and one for the lists.  Sections follow each other at 256-byte boundaries in
+// this order, a section being present iff its pointer is set and its count fits the caller's capacity: changed rows,
+// changed GlobalTransforms (48 B each), visible rows, cluster offsets (C + 1), cluster counts (6 C), cluster indices.
+// header: [0] changed, [1] visible, [2..3] cluster total (u64), [4] farthest_z (f32 bits), [5] 1 = payload written, 0 = it did
+// not fit `payload_bytes` (or the cluster list overflowed its device buffer): the host falls back to separate copies.
+struct PackResultsJob {
+    const uint32_t* changed_total;   // nullptr: no changed section
+    const uint32_t* changed_rows;
+    const float* g;                  // nullptr: rows only
+    const uint32_t* visible_total;   // nullptr: no visible section
+    const uint32_t* visible_rows;
+    const uint64_t* cluster_total;   // nullptr: no cluster sections
+    const uint32_t* cluster_offsets;
+    const uint32_t* cluster_counts;
+    const uint32_t* cluster_indices; // nullptr: offsets and counts only
+    const float* farthest_z;
+    uint32_t n_clusters;
+    uint32_t want_changed_rows;
+    uint32_t changed_capacity, visible_capacity;
+    uint64_t cluster_capacity, cluster_indices_alloc;
+    uint32_t* header;
+    uint8_t* payload;
+    uint64_t payload_bytes;
+};
+constexpr uint32_t PACK_HEADER_BYTES = 256;
+constexpr uint64_t PACK_WINDOW_BYTES = (uint64_t)8 << 20;  // bigger frames are byte-bound anyway: they take the DMA path
+__host__ __device__ inline uint64_t pack_align(uint64_t b) { return (b + 255u) & ~(uint64_t)255u; }
+hipError_t launch_pack_results(const PackResultsJob& job, hipStream_t stream);
 constexpr uint32_t SMALL_UPLOAD_ROWS = 4096;  // at or below this, Transform uploads take the one-kernel path
 hipError_t launch_vis_begin(const Columns& c, hipStream_t stream);
 hipError_t launch_vis_end(const Columns& c, hipStream_t stream);

@@ -477,6 +477,68 @@ hipError_t launch_gather_global(const uint32_t* rows, const uint32_t* total, uin
     return hipGetLastError();
 }
 
+// Frame results -> pinned window (kernels.h PackResultsJob).  Every workgroup derives the same section offsets from the counts;
+// the stores go straight over PCIe, lane-contiguous.
+__global__ void __launch_bounds__(256) k_pack_results(PackResultsJob j) {
+    const uint32_t changed = j.changed_total ? *j.changed_total : 0u;
+    const uint32_t visible = j.visible_total ? *j.visible_total : 0u;
+    const uint64_t cl_total = j.cluster_total ? *j.cluster_total : 0ull;
+    const bool s_rows = j.changed_total && j.want_changed_rows && changed <= j.changed_capacity;
+    const bool s_g = j.changed_total && j.g && changed <= j.changed_capacity;
+    const bool s_vis = j.visible_total && visible <= j.visible_capacity;
+    const bool s_cl = j.cluster_total != nullptr;
+    const bool s_idx = s_cl && j.cluster_indices && cl_total <= j.cluster_capacity;
+    const bool overflow = s_cl && cl_total > j.cluster_indices_alloc;
+    uint64_t off = 0;
+    const uint64_t o_rows = off;  off += s_rows ? pack_align((uint64_t)changed * 4u) : 0u;
+    const uint64_t o_g = off;     off += s_g ? pack_align((uint64_t)changed * 48u) : 0u;
+    const uint64_t o_vis = off;   off += s_vis ? pack_align((uint64_t)visible * 4u) : 0u;
+    const uint64_t o_off = off;   off += s_cl ? pack_align(((uint64_t)j.n_clusters + 1u) * 4u) : 0u;
+    const uint64_t o_cnt = off;   off += s_cl ? pack_align((uint64_t)j.n_clusters * 24u) : 0u;
+    const uint64_t o_idx = off;   off += s_idx ? pack_align(cl_total * 4u) : 0u;
+    const bool fits = off <= j.payload_bytes && !overflow;
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
+    if (tid == 0) {
+        j.header[0] = changed;
+        j.header[1] = visible;
+        j.header[2] = (uint32_t)cl_total;
+        j.header[3] = (uint32_t)(cl_total >> 32);
+        j.header[4] = s_cl ? __float_as_uint(*j.farthest_z) : 0u;
+        j.header[5] = fits ? 1u : 0u;
+    }
+    if (!fits) return;
+    if (s_rows) {
+        uint32_t* d = reinterpret_cast<uint32_t*>(j.payload + o_rows);
+        for (uint32_t i = tid; i < changed; i += stride) d[i] = j.changed_rows[i];
+    }
+    if (s_g) {
+        float4* d = reinterpret_cast<float4*>(j.payload + o_g);
+        for (uint32_t i = tid; i < changed * 3u; i += stride)
+            d[i] = reinterpret_cast<const float4*>(j.g)[3ull * j.changed_rows[i / 3u] + (i % 3u)];
+    }
+    if (s_vis) {
+        uint32_t* d = reinterpret_cast<uint32_t*>(j.payload + o_vis);
+        for (uint32_t i = tid; i < visible; i += stride) d[i] = j.visible_rows[i];
+    }
+    if (s_cl) {
+        uint32_t* d0 = reinterpret_cast<uint32_t*>(j.payload + o_off);
+        for (uint32_t i = tid; i <= j.n_clusters; i += stride) d0[i] = j.cluster_offsets[i];
+        uint32_t* d1 = reinterpret_cast<uint32_t*>(j.payload + o_cnt);
+        for (uint32_t i = tid; i < j.n_clusters * 6u; i += stride) d1[i] = j.cluster_counts[i];
+    }
+    if (s_idx) {
+        uint32_t* d = reinterpret_cast<uint32_t*>(j.payload + o_idx);
+        for (uint64_t i = tid; i < cl_total; i += stride) d[i] = j.cluster_indices[i];
+    }
+}
+hipError_t launch_pack_results(const PackResultsJob& job, hipStream_t stream) {
+    // enough lanes to keep the PCIe writes flowing; the window is a few MB at most
+    const uint64_t units = job.payload_bytes / 4u;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(1, (units + 1023u) / 1024u));
+    MI_LAUNCH(k_pack_results, dim3(blocks), dim3(256), 0, stream, job);
+    return hipGetLastError();
+}
+
 hipError_t launch_upload_trs(const float* pinned_src, float* t, float* r, float* s, uint32_t first_row, uint32_t n,
                              hipStream_t stream) {
     if (n == 0) return hipSuccess;

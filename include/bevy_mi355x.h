@@ -445,8 +445,9 @@ int32_t mi_cluster_assign_frame(mi_ctx* ctx, const mi_cluster_config* config, mi
 int32_t mi_cluster_download(mi_ctx* ctx, uint32_t* out_offsets, uint32_t* out_indices, uint64_t capacity,
                             uint32_t* out_counts, uint64_t* out_total, float* out_farthest_z);
 
-/* Everything a frame hands back to the ECS in ONE call and two device waits (the separate downloads wait ten times
- * between them, and on an idle stream a wait is ~30 us): the rows whose GlobalTransform changed with their matrices
+/* Everything a frame hands back to the ECS in ONE call, one launch and one device wait (the device packs counts and lists
+ * into a window of the pinned staging arena; results beyond 8 MB take two waits: counts, then lists; the separate downloads
+ * wait ten times between them, and on an idle stream a wait is ~30 us): the rows whose GlobalTransform changed with their matrices
  * (mi_download_changed_global_transforms), one (view, class) VisibleEntities row list (mi_download_visible_entities; rows
  * only -- the caller maps rows to Entity itself -- and only when rows are numbered in key order, which is the case unless
  * mi_upload_entity_keys said otherwise: MI_ERR_NOT_READY then) and the cluster lists of the resident assignment

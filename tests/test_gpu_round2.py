@@ -301,3 +301,50 @@ def test_frame_results_in_one_call_equal_the_separate_downloads(ctx_factory):
     with pytest.raises(api.MiError) as e:
         ctx.download_frame_results(small)
     assert e.value.code == api.MI_ERR_CAPACITY and small.raw.visible_count == vis.size
+    # rows without GlobalTransforms and the other way round (sections of the packed window come and go)
+    rows_only = api.FrameResultBuffers(n, n, 0, 0)
+    rows_only.raw.changed_global12 = None
+    got = ctx.download_frame_results(rows_only)
+    assert np.array_equal(got["changed_rows"], ch_rows) and np.array_equal(got["visible_rows"], vis)
+    g_only = api.FrameResultBuffers(n, 0, n_clusters, 4 * n_l * 8)
+    g_only.raw.changed_rows = None
+    got = ctx.download_frame_results(g_only)
+    assert got["changed_global"].tobytes() == ch_g.tobytes() and np.array_equal(got["cluster_indices"], idx)
+    assert np.array_equal(got["cluster_offsets"], off) and got["farthest_z"] == far
+    # a changed list that does not fit its capacity: the error, the count, and the other lists still delivered
+    tight = api.FrameResultBuffers(max(ch_rows.size - 1, 1), n, n_clusters, 4 * n_l * 8)
+    with pytest.raises(api.MiError) as e:
+        ctx.download_frame_results(tight)
+    assert e.value.code == api.MI_ERR_CAPACITY and tight.raw.changed_count == ch_rows.size
+    assert np.array_equal(tight.visible_rows[:tight.raw.visible_count], vis)
+    assert np.array_equal(tight.cluster_indices[:tight.raw.cluster_total], idx)
+
+
+@pytest.mark.gpu
+def test_frame_results_beyond_the_packed_window_take_the_copy_path(ctx_factory):
+    """More than 8 MB of results (kernels.h PACK_WINDOW_BYTES): the packed launch reports 'does not fit' and the call falls back
+    to the counts-then-lists copies; same results as the separate downloads either way, on the frames before and after."""
+    n = 200_000
+    sc = W.many_cubes(n)
+    ctx = ctx_factory()
+    ctx.resize(n)
+    ctx.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
+    ctx.upload_bounds(sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"])
+    ctx.upload_changed(np.zeros(n, np.uint8))
+    bufs = api.FrameResultBuffers(n, n, 0, 0)
+    cam = W.many_cubes_camera(0)
+    t3 = sc["translation"].reshape(n, 3).copy()
+    for f, k in enumerate((n, 500, n, 0)):   # 10.4 MB, 26 KB, 10.4 MB, nothing
+        rows = np.arange(n, dtype=np.uint32) if k == n else np.arange(0, 4 * k, 4, dtype=np.uint32)
+        if k:
+            t3[rows] += F(0.125)
+            ctx.upload_transforms_indexed(rows, t3[rows].reshape(-1), sc["rotation"].reshape(n, 4)[rows].reshape(-1),
+                                          sc["scale"].reshape(n, 3)[rows].reshape(-1))
+        ctx.propagate(0)
+        ctx.cull(frusta_for([cam]), flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME)
+        got = ctx.download_frame_results(bufs)
+        ch_rows, ch_g = ctx.download_changed_global_transforms()
+        _, vis = ctx.download_visible_entities(0, 0)
+        assert np.array_equal(got["changed_rows"], rows) and np.array_equal(ch_rows, rows), f"frame {f}"
+        assert got["changed_global"].tobytes() == ch_g.tobytes(), f"frame {f}"
+        assert np.array_equal(got["visible_rows"], vis) and vis.size > 0, f"frame {f}"

@@ -596,10 +596,9 @@ def end_to_end(ctx, wl, frames=12):
             ctx.synchronize()
             t0 = time.perf_counter()
             ctx.cluster_upload_view(views[f % N_FRAMES])
-            if rows is not None:  # only the dirty rows are recomputed; the cull launch carries the cluster walk
+            if rows is not None:  # only the dirty rows are recomputed, in the frame launch itself; it carries the cluster walk too
                 ctx.upload_transforms_indexed(rows, tt, rr, ss)
-                ctx.propagate(0)
-                ctx.cull(fr, flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME | B.CULL_WITH_CLUSTERS)
+                ctx.propagate_and_cull(fr, flags=B.CULL_END_FRAME | B.CULL_WITH_CLUSTERS | B.CULL_CHANGED_ROWS)
             else:
                 ctx.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
                 ctx.propagate_and_cull(fr, flags=B.CULL_END_FRAME | B.CULL_WITH_CLUSTERS)
@@ -622,7 +621,7 @@ def end_to_end(ctx, wl, frames=12):
                                   "changed_global_transforms_read_back": int(got_g), "visible_entities": int(len(vis_rows)),
                                   "cluster_index_entries": int(total)}
     out["note"] = ("same frame as `value` with the host on both sides: dirty Transforms H2D (mi_upload_transforms_indexed / the whole "
-                   "column at 100 %), propagate + cull + cluster, then changed GlobalTransforms, the camera's VisibleEntities list and the "
+                   "column at 100 %), propagate + cull + cluster (one launch: MI_CULL_CHANGED_ROWS below 100 %), then changed GlobalTransforms, the camera's VisibleEntities list and the "
                    "cluster lists D2H (mi_download_frame_results: one call, one packing launch into pinned memory, one device wait -- two beyond 8 MB; at 100 % the whole GlobalTransform column "
                    f"and the separate downloads); median wall time of {frames} frames, each synchronised (pageable host arrays, one "
                    "staging copy each way)")

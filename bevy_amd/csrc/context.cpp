@@ -389,6 +389,8 @@ static int32_t cull_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, u
     if (!views || n_views == 0) return fail(ctx, MI_ERR_INVALID_ARG, "mi_cull: views NULL or n_views == 0");
     if (PROPAGATE && ctx->have_hierarchy)
         return fail(ctx, MI_ERR_NOT_READY, "mi_propagate_and_cull is the flat fast path; a hierarchy is uploaded -- use mi_propagate + mi_cull");
+    if (!PROPAGATE && (flags & MI_CULL_CHANGED_ROWS))
+        return fail(ctx, MI_ERR_INVALID_ARG, "MI_CULL_CHANGED_ROWS belongs to mi_propagate_and_cull (mi_cull does not propagate)");
     if ((flags & MI_CULL_WITH_CLUSTERS) && (!ctx->cl_rows_bound || !ctx->cl_have_view))
         return fail(ctx, MI_ERR_NOT_READY, "MI_CULL_WITH_CLUSTERS needs mi_cluster_bind_objects_to_rows and mi_cluster_upload_view first");
     VisibilityOut vo{};
@@ -427,9 +429,12 @@ static int32_t cull_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, u
             return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
         }
         ProfScope ps(ctx, PROPAGATE ? K_FLAT_PROPAGATE_CULL : K_CULL);
+        // MI_CULL_CHANGED_ROWS: sync_simple_transforms' own filter -- before any change column was uploaded every row still counts
+        // as changed (Added<GlobalTransform>), as in mi_propagate
+        const uint8_t* changed_col = (PROPAGATE && (flags & MI_CULL_CHANGED_ROWS) && ctx->have_changed) ? ctx->changed : nullptr;
         const hipError_t e = PROPAGATE ? launch_flat_propagate_cull(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p,
                                                                     n_views, vo, seg, flags & MI_CULL_END_FRAME, prev, have_fill ? &fill_job : nullptr,
-                                                                    clusters_ride ? &walk_job : nullptr, ctx->stream)
+                                                                    clusters_ride ? &walk_job : nullptr, ctx->stream, changed_col)
                                        : launch_cull(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p, n_views, vo,
                                                      seg, flags & (MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME), prev, have_fill ? &fill_job : nullptr,
                                                      clusters_ride ? &walk_job : nullptr, ctx->stream);

@@ -163,11 +163,15 @@ __device__ __forceinline__ void compact_fast_block(const CompactFastArgs& a, uin
 // WITH_WALK: the launch may carry this frame's light-cluster walk.  A variant of its own because the walk needs more registers than
 // a row tile (87 against 66 VGPRs: 5 instead of 7 waves per SIMD for the whole launch; capping it at 80 or 72 registers with
 // __launch_bounds__ spills and measured 26.9 / 29.0 us per metric frame against 25.2); frames without a walk keep the lean one.
-template <bool PROPAGATE, bool INLINE_VIEWS, bool WITH_WALK>
+// PROP: 0 = GlobalTransform is resident (mi_cull), 1 = every row is propagated (the fused frame: Transform read once,
+// GlobalTransform written once and never re-read), 2 = only rows whose Transform change byte is set are propagated
+// (sync_simple_transforms' own filter, systems.rs:45-50; `changed` is the byte column), the others keep the resident value.
+template <int PROP, bool INLINE_VIEWS, bool WITH_WALK>
 __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const ViewParams* __restrict__ dviews,
                                                 uint32_t n_views, VisibilityOut out, SegOut seg, uint32_t fl_frame, uint32_t n_tiles,
                                                 CompactFastArgs prev, uint32_t prev_gx, uint32_t n_compact, uint32_t n_fill, ClusterFillJob fill,
-                                                ClusterWalkJob walk) {
+                                                ClusterWalkJob walk, const uint8_t* __restrict__ changed) {
+    constexpr bool PROPAGATE = PROP == 1, PARTIAL = PROP == 2;
     // 16 KB + 16 B: the four waves' GlobalTransform transpose buffers (12 KB) -- or, in a riding cluster-fill workgroup, the CSR
     // offsets of up to 4096 clusters and the four wave totals of their scan -- or the arena of a riding cluster-walk workgroup
     __shared__ __attribute__((aligned(16))) uint32_t lds_raw[4096 + 4];
@@ -213,6 +217,8 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
             gl[k] = i < lim ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
+    bool dirty = false;
+    if (PARTIAL && live) dirty = changed[row] != 0;
     if (live) {
         center = ld3(c.aabb_center, row);
         half = ld3(c.aabb_half, row);
@@ -245,6 +251,13 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
         g.m.y_axis = V3{a.w, b.x, b.y};
         g.m.z_axis = V3{b.z, b.w, cc.x};
         g.t = V3{cc.y, cc.z, cc.w};
+        if (PARTIAL && dirty) {  // few rows of a wave as a rule: each stores its own 48 bytes
+            const V3 t = ld3(c.translation, row);
+            const V4 q = ld4(c.rotation, row);
+            const V3 sc = ld3(c.scale, row);
+            g = affine_from_srt(sc, q, t);
+            st_affine(c.global, row, g);
+        }
     }
     const bool ncc = (fl & 0x10u) != 0;  // NoCpuCulling rows are not in the cull query (mod.rs:771)
     const bool any_live = wave_row0 < c.n;  // waves past the last row must not touch the masks
@@ -298,6 +311,10 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
         if (fl_frame & CULL_BEGIN_FRAME) c.vv_changed_bits[wave] = chg;
         else if (chg) atomicOr(reinterpret_cast<unsigned long long*>(&c.vv_changed_bits[wave]), chg);
         if (PROPAGATE) c.g_changed_bits[wave] = lv;  // plain assignment bumps every written row's tick (systems.rs:62)
+    }
+    if (PARTIAL) {
+        const unsigned long long dm = __ballot(dirty);
+        if (lane == 0 && any_live) c.g_changed_bits[wave] = dm;
     }
 }
 
@@ -548,10 +565,10 @@ hipError_t launch_upload_trs(const float* pinned_src, float* t, float* r, float*
 
 // prev != nullptr: the previous frame's deferred compaction rides in extra workgroups of this launch; fill != nullptr: so does the
 // fill of the previous frame's light-cluster assignment
-template <bool PROPAGATE>
+template <int PROP>
 static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views,
                                const VisibilityOut& out, const SegOut& seg, uint32_t flags, const CompactFastArgs* prev,
-                               const ClusterFillJob* fill, const ClusterWalkJob* walk, hipStream_t stream) {
+                               const ClusterFillJob* fill, const ClusterWalkJob* walk, hipStream_t stream, const uint8_t* changed = nullptr) {
     if (c.n == 0) return hipSuccess;
     const uint32_t n_tiles = blocks_for(c.n);
     CompactFastArgs pa{};
@@ -575,27 +592,29 @@ static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, co
     }
     const dim3 grid(n_tiles + prev_blocks + fill_blocks + walk_blocks);
     if (walk_blocks) {
-        MI_LAUNCH((k_frame<PROPAGATE, true, true>), grid, dim3(256), 0, stream, c, *views_inline, (const ViewParams*)nullptr, n_views, out, seg, flags,
-                  n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj);
+        MI_LAUNCH((k_frame<PROP, true, true>), grid, dim3(256), 0, stream, c, *views_inline, (const ViewParams*)nullptr, n_views, out, seg, flags,
+                  n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed);
     } else if (n_views <= MAX_INLINE_VIEWS && views_inline) {
-        MI_LAUNCH((k_frame<PROPAGATE, true, false>), grid, dim3(256), 0, stream, c, *views_inline, (const ViewParams*)nullptr, n_views, out, seg, flags,
-                  n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj);
+        MI_LAUNCH((k_frame<PROP, true, false>), grid, dim3(256), 0, stream, c, *views_inline, (const ViewParams*)nullptr, n_views, out, seg, flags,
+                  n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed);
     } else {
         ViewSet dummy = {};
-        MI_LAUNCH((k_frame<PROPAGATE, false, false>), grid, dim3(256), 0, stream, c, dummy, d_views, n_views, out, seg, flags, n_tiles, pa, prev_gx,
-                  prev_blocks, fill_blocks, fj, wj);
+        MI_LAUNCH((k_frame<PROP, false, false>), grid, dim3(256), 0, stream, c, dummy, d_views, n_views, out, seg, flags, n_tiles, pa, prev_gx,
+                  prev_blocks, fill_blocks, fj, wj, changed);
     }
     return hipGetLastError();
 }
 hipError_t launch_flat_propagate_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views,
                                       uint32_t n_views, const VisibilityOut& out, const SegOut& seg, uint32_t flags,
-                                      const CompactFastArgs* prev, const ClusterFillJob* fill, const ClusterWalkJob* walk, hipStream_t stream) {
-    return launch_frame<true>(c, views_inline, d_views, n_views, out, seg, flags | CULL_BEGIN_FRAME, prev, fill, walk, stream);
+                                      const CompactFastArgs* prev, const ClusterFillJob* fill, const ClusterWalkJob* walk, hipStream_t stream,
+                                      const uint8_t* changed) {
+    if (changed) return launch_frame<2>(c, views_inline, d_views, n_views, out, seg, flags | CULL_BEGIN_FRAME, prev, fill, walk, stream, changed);
+    return launch_frame<1>(c, views_inline, d_views, n_views, out, seg, flags | CULL_BEGIN_FRAME, prev, fill, walk, stream);
 }
 hipError_t launch_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views,
                        const VisibilityOut& out, const SegOut& seg, uint32_t flags, const CompactFastArgs* prev,
                        const ClusterFillJob* fill, const ClusterWalkJob* walk, hipStream_t stream) {
-    return launch_frame<false>(c, views_inline, d_views, n_views, out, seg, flags, prev, fill, walk, stream);
+    return launch_frame<0>(c, views_inline, d_views, n_views, out, seg, flags, prev, fill, walk, stream);
 }
 hipError_t launch_level0_propagate(const Columns& c, uint32_t n_level0, const uint8_t* node_flags,
                                    const uint8_t* changed, const uint32_t* tree_bits, bool all_dirty,

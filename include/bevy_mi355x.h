@@ -106,6 +106,12 @@ extern "C" {
                                    * 100 k lights (the two kernels of the assignment are latency-bound and stretch when they share the
                                    * chip: 46.3 us per frame against 44.1 us one behind the other), so it is opt-in. */
 
+#define MI_CULL_CHANGED_ROWS 0x20u /* mi_propagate_and_cull only: propagate the rows whose Transform change byte is set (mi_upload_changed,
+                                   * mi_upload_transforms_indexed; new rows carry it as Added<GlobalTransform>) -- the filter of
+                                   * sync_simple_transforms, systems.rs:45-50 -- instead of every row; the others keep their GlobalTransform and
+                                   * their change tick.  Same results as mi_propagate(0) followed by mi_cull(MI_CULL_BEGIN_FRAME | ...), in one
+                                   * launch: the steady-state frame of a scene in which few entities move.  The change bytes are consumed. */
+
 /* ---- mi_propagate flags ----------------------------------------------------------------- */
 #define MI_PROPAGATE_ALL_DIRTY 0x1u  /* every Transform counts as changed (worst case / first frame) */
 #define MI_PROPAGATE_STATIC_OPT 0x2u /* StaticTransformOptimizations::Enabled, systems.rs:87-103 */
@@ -258,7 +264,8 @@ int32_t mi_propagate_and_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t 
  * dirty + reset_view_visibility + check_visibility_cpu_culling in ONE pass (Transform is read once,
  * GlobalTransform is written once and never re-read).  Results are identical to
  * mi_propagate(MI_PROPAGATE_ALL_DIRTY); mi_visibility_begin_frame(); mi_cull(...) [; mi_visibility_end_frame()
- * when flags has MI_CULL_END_FRAME].  MI_CULL_BEGIN_FRAME is implied. */
+ * when flags has MI_CULL_END_FRAME].  MI_CULL_BEGIN_FRAME is implied.  With MI_CULL_CHANGED_ROWS only the rows marked
+ * changed are propagated (= mi_propagate(0) in front of the cull). */
 int32_t mi_propagate_and_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_masks,
                               const uint8_t* view_flags, uint32_t n_views, uint32_t flags /* MI_CULL_* */);
 

@@ -348,3 +348,59 @@ def test_frame_results_beyond_the_packed_window_take_the_copy_path(ctx_factory):
         assert np.array_equal(got["changed_rows"], rows) and np.array_equal(ch_rows, rows), f"frame {f}"
         assert got["changed_global"].tobytes() == ch_g.tobytes(), f"frame {f}"
         assert np.array_equal(got["visible_rows"], vis) and vis.size > 0, f"frame {f}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 63, 10_007, 300_000])
+def test_fused_frame_over_the_changed_rows_equals_propagate_then_cull(ctx_factory, n):
+    """MI_CULL_CHANGED_ROWS: mi_propagate_and_cull propagates only the rows marked changed (sync_simple_transforms' filter,
+    systems.rs:45-50).  Frame by frame against mi_propagate(0) + mi_cull on a twin context and against the oracle: GlobalTransforms,
+    their change ticks, ViewVisibility with its ticks, the masks and the VisibleEntities list."""
+    sc = W.many_cubes(n, ragged_flags=True)
+    a, b = ctx_factory(), ctx_factory()
+    for c in (a, b):
+        upload_scene(c, sc)
+    t3 = sc["translation"].reshape(n, 3).copy()
+    rng = np.random.default_rng(n)
+    g_prev = None
+    # frame 0: no change column yet -> every row is Added<GlobalTransform>; then sparse, empty, dense and whole-wave dirty sets
+    picks = [None, max(1, n // 100), 0, max(1, n // 3), "waves", n]
+    for f, k in enumerate(picks):
+        cam = frusta_for([W.many_cubes_camera(2 * f)])
+        if k is None:
+            rows = np.arange(n, dtype=np.uint32)
+        else:
+            if k == "waves":   # whole waves dirty next to clean ones
+                rows = np.nonzero((np.arange(n) // 64) % 3 == 0)[0].astype(np.uint32)
+            else:
+                rows = np.sort(rng.choice(n, k, replace=False)).astype(np.uint32)
+            if rows.size:
+                t3[rows] += F(0.5)
+                for c in (a, b):
+                    c.upload_transforms_indexed(rows, t3[rows].reshape(-1), sc["rotation"].reshape(n, 4)[rows].reshape(-1),
+                                                sc["scale"].reshape(n, 3)[rows].reshape(-1))
+            elif f == 2:
+                for c in (a, b):
+                    c.upload_changed(np.zeros(n, np.uint8))
+        a.propagate_and_cull(cam, flags=B.CULL_END_FRAME | B.CULL_CHANGED_ROWS)
+        b.propagate(0)
+        b.cull(cam, flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME)
+        ga, ca = a.download_global_transforms()
+        gb, cb = b.download_global_transforms()
+        assert ga.tobytes() == gb.tobytes(), f"frame {f}"
+        assert_bits(ca, cb, f"frame {f} GlobalTransform ticks")
+        changed = np.zeros(n, np.uint8)
+        changed[rows] = 1
+        exp, exp_chg = O.sync_simple_transforms(t3.reshape(-1), sc["rotation"], sc["scale"], changed,
+                                                g_prev if g_prev is not None else np.zeros(12 * n, F))
+        assert ga.tobytes() == exp.tobytes(), f"frame {f} vs oracle"
+        assert_bits(ca, exp_chg, f"frame {f} ticks vs oracle")
+        g_prev = exp
+        va, vca = a.download_view_visibility()
+        vb, vcb = b.download_view_visibility()
+        assert np.array_equal(va, vb) and np.array_equal(vca, vcb), f"frame {f} ViewVisibility"
+        assert np.array_equal(a.download_visibility(0), b.download_visibility(0)), f"frame {f} mask"
+        assert np.array_equal(a.download_visible_entities(0, 0)[1], b.download_visible_entities(0, 0)[1]), f"frame {f} list"
+    with pytest.raises(api.MiError) as e:
+        b.cull(cam, flags=B.CULL_BEGIN_FRAME | B.CULL_CHANGED_ROWS)
+    assert e.value.code == api.MI_ERR_INVALID_ARG

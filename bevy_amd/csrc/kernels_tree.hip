@@ -559,6 +559,16 @@ __device__ __forceinline__ void process_tile(const Columns& c, const TreeArgs& a
 // the VALU instructions of an 85-row tile run on one lane) and the kernel turns issue-bound; 128 threads 36.6 us; 512 / 1024
 // threads 39.0 / 50.8 us (fewer tiles resident); 256 threads 33.5 us.  The chain's inputs share wave 0's transpose buffer:
 // they are consumed before the streamed level first touches it.
+// blockIdx -> tile for the tile kernels.  Workgroups go round the eight XCDs (blockIdx % 8), each with an L2 of its own: XCD x
+// takes a CONTIGUOUS eighth of the tiles, so that neighbouring tiles -- whose short upper-level segments share cache lines
+// (one row of a level is 12 - 48 bytes of a 128-byte line) and whose chains share ancestors -- meet in one L2 instead of
+// fetching the same lines eight times (1 M-node tree: 31.0 -> 30.0 us per launch).  Tiles of a launch do not depend on each
+// other, so any bijection is correct.
+__device__ __forceinline__ uint32_t xcd_contiguous_tile() {
+    const uint32_t nt = gridDim.x, x = blockIdx.x & 7u, q = nt >> 3, r = nt & 7u;
+    return x * q + (x < r ? x : r) + (blockIdx.x >> 3);
+}
+
 template <uint32_t BLOCK>
 __global__ void __launch_bounds__(BLOCK) k_propagate_tiles(Columns c, TreeArgs a) {
     static_assert(TILE_MAX_CHAIN * 6 <= 192, "the chain inputs must fit in one wave's transpose buffer");
@@ -569,7 +579,7 @@ __global__ void __launch_bounds__(BLOCK) k_propagate_tiles(Columns c, TreeArgs a
     __shared__ float4 lds_chain_g[3];
     __shared__ uint32_t lds_chain_chg;
     const TileLds<BLOCK> lds{lds_g, lds_chg, lds_stage, &lds_stage[0][0], lds_chain_in, lds_chain_g, &lds_chain_chg};
-    process_tile<BLOCK>(c, a, blockIdx.x, lds);
+    process_tile<BLOCK>(c, a, xcd_contiguous_tile(), lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -644,7 +654,10 @@ __global__ void __launch_bounds__(256, 6) k_propagate_fans(Columns c, TreeArgs a
     __shared__ uint8_t lds_level[TILE_LIGHT_UCAP];   // per upper row: its level inside the tile
     __shared__ float4 lds_chain_g[3];
     __shared__ uint32_t lds_chain_chg;
-    const uint32_t tile = blockIdx.x;
+    // Workgroups go round the eight XCDs (blockIdx % 8), each with an L2 of its own: XCD x takes a CONTIGUOUS eighth of the tiles,
+    // so that neighbouring tiles -- whose short upper-level segments share cache lines and whose chains share ancestors --
+    // meet in one L2 instead of fetching the same lines eight times.
+    const uint32_t tile = xcd_contiguous_tile();
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     // development trace: stamps are kept in registers and written once at the very end (a store in front of a barrier would
     // make the barrier's vmcnt(0) wait for it and distort the phase it is meant to time)

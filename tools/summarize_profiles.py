@@ -18,7 +18,8 @@ workloads = sys.argv[2:] or ["frame", "flat", "flat_10m_1view", "flat_10m_4views
 src = os.path.join("gpurun_out", f"prof_{tag}")
 dst = os.path.join("profiles", tag)
 os.makedirs(dst, exist_ok=True)
-ALIAS = {"k_frame<true": "k_flat_propagate_cull", "k_frame<false": "k_cull",  # (any INLINE_VIEWS / WITH_WALK variant)
+ALIAS = {"k_frame<1": "k_flat_propagate_cull", "k_frame<2": "k_flat_propagate_cull", "k_frame<0": "k_cull",  # PROP: 1 all rows, 2 changed rows, 0 resident G (any INLINE_VIEWS / WITH_WALK variant)
+         "k_frame<true": "k_flat_propagate_cull", "k_frame<false": "k_cull",  # (profiles from before PROP was an int)
          "k_propagate_fans": "k_propagate_tiles"}  # the tile launch of mi_propagate, whichever tile kernel the plan uses
 
 

@@ -646,8 +646,11 @@ constexpr uint32_t FAN_CHAIN_LANE0 = 256u - TILE_MAX_CHAIN;       // chain node 
 template <bool ALL_DIRTY>
 __global__ void __launch_bounds__(256, 6) k_propagate_fans(Columns c, TreeArgs a) {
     __shared__ float4 lds_g[FAN_SLOTS * 3];    // local affine, then (upper rows) the GlobalTransform in place
-    __shared__ float4 lds_old[FAN_SLOTS * 3];  // GlobalTransform before this frame
-    __shared__ float4 lds_stage[4][192];       // last level: a wave's old GlobalTransforms as loaded (3 x 1 KB rows), read transposed
+    // GlobalTransforms before this frame of the upper rows and the chain (dead once the level steps have fetched their columns of
+    // them); afterwards the same memory is the four waves' transpose buffers of the last level (3 x 1 KB rows each)
+    static_assert(FAN_SLOTS * 3 <= 4 * 192, "the old values of the upper rows fit under the transpose buffers");
+    __shared__ float4 lds_old_stage[4 * 192];
+    float4* const lds_old = lds_old_stage;
     __shared__ uint8_t lds_chg[TILE_LIGHT_UCAP];
     __shared__ uint8_t lds_in[FAN_SLOTS];            // per slot: bit0 TransformTreeChanged, bit1 the level-0 assignment happens
     __shared__ uint32_t lds_pslot[TILE_LIGHT_UCAP];  // per upper row: its parent's LDS slot (or global row, see my_pslot)
@@ -726,9 +729,6 @@ __global__ void __launch_bounds__(256, 6) k_propagate_fans(Columns c, TreeArgs a
     // (the old value's base differs per lane: upper rows read the live column, chain nodes their PRE-frame snapshot, see TreeArgs)
     const float* const u_old_src = is_chain ? a.snap_read : c.global;
     const uint32_t g_off = (s_start + wbase0) * 48u;
-    const float4 f_g0 = at32<float4>(c.global, g_off + (lane < lim0 ? lane : lim0 - 1u) * 16u);
-    const float4 f_g1 = at32<float4>(c.global, g_off + (64u + lane < lim0 ? 64u + lane : lim0 - 1u) * 16u);
-    const float4 f_g2 = at32<float4>(c.global, g_off + (128u + lane < lim0 ? 128u + lane : lim0 - 1u) * 16u);
     const uint32_t u_p = at32<uint32_t>(a.parent_idx, u_row * 4u);
     const V3 u_s = ld3_32(c.scale, u_row), u_t = ld3_32(c.translation, u_row);
     const V4 u_q = ld4_32(c.rotation, u_row);
@@ -741,10 +741,7 @@ __global__ void __launch_bounds__(256, 6) k_propagate_fans(Columns c, TreeArgs a
     FAN_STAMP(1);
     __builtin_amdgcn_sched_barrier(0);  // nothing below may move above: the scheduler otherwise consumes the first loads early
     // consume, in issue order
-    float4* const stage = lds_stage[wv];
-    stage[lane] = f_g0;
-    stage[64u + lane] = f_g1;
-    stage[128u + lane] = f_g2;
+    float4* const stage = lds_old_stage + wv * 192u;
     // per row, for the level steps: the parent's LDS slot (levels >= 1 of the tile) or its global row (level 0 of a tile
     // below another launch), and the rule's inputs
     if (is_upper || is_chain) {
@@ -855,8 +852,15 @@ __global__ void __launch_bounds__(256, 6) k_propagate_fans(Columns c, TreeArgs a
     // write-back of the upper rows: slots and rows are contiguous per level -> straight float4 copies; a tile in which
     // nothing changed writes nothing (unchanged rows hold their old bytes), the snapshot always tracks the current value
     FAN_STAMP(4);
+    // the last level's old GlobalTransforms (three contiguous 1 KB rows per wave): requested here, they travel under the
+    // write-back and the last level's own products, and land in the transpose buffers -- the memory the upper rows' old values
+    // occupied until the level steps had read them
+    bool flush_live = false;
+    if (n_lds) flush_live = __syncthreads_or(any_chg ? 1 : 0) != 0;  // (in front of the loads: the barrier drains the load counter)
+    const float4 f_g0 = at32<float4>(c.global, g_off + (lane < lim0 ? lane : lim0 - 1u) * 16u);
+    const float4 f_g1 = at32<float4>(c.global, g_off + (64u + lane < lim0 ? 64u + lane : lim0 - 1u) * 16u);
+    const float4 f_g2 = at32<float4>(c.global, g_off + (128u + lane < lim0 ? 128u + lane : lim0 - 1u) * 16u);
     if (n_lds) {
-        const bool flush_live = __syncthreads_or(any_chg ? 1 : 0) != 0;
         if (tid < U) at32w<uint8_t>(a.g_changed_bytes, lds_row[tid]) = lds_chg[tid];
         if (flush_live || snap_out) {
             for (uint32_t f = tid; f < 3u * U; f += 256u) {  // float4 f of the slots: lanes walk the rows' 48 bytes contiguously
@@ -870,7 +874,7 @@ __global__ void __launch_bounds__(256, 6) k_propagate_fans(Columns c, TreeArgs a
     }
 
     // ---- the last level: one row per lane; a wider level (a single node with more than 256 children) takes more batches ----
-    auto batch = [&](uint32_t base, uint32_t p, V3 sc, V4 q, V3 t, NodeRaw raw) {
+    auto batch = [&](uint32_t base, uint32_t p, V3 sc, V4 q, V3 t, NodeRaw raw, bool first) {
         const uint32_t i = base + tid;
         const bool live = i < s_count;
         const uint32_t row = s_start + i;
@@ -894,7 +898,12 @@ __global__ void __launch_bounds__(256, 6) k_propagate_fans(Columns c, TreeArgs a
                 }
             }
         }
-        MI_WAVE_LDS_SYNC();  // (the first batch's transpose rows were written before the workgroup barriers)
+        if (first) {  // as late as possible: everything above runs under the loads
+            stage[lane] = f_g0;
+            stage[64u + lane] = f_g1;
+            stage[128u + lane] = f_g2;
+        }
+        MI_WAVE_LDS_SYNC();
         Affine cur = {};
         bool chg = false;
         if (live) {
@@ -919,7 +928,7 @@ __global__ void __launch_bounds__(256, 6) k_propagate_fans(Columns c, TreeArgs a
         }
     };
     FAN_STAMP(5);
-    batch(0u, f_p, f_s, f_q, f_t, f_raw);
+    batch(0u, f_p, f_s, f_q, f_t, f_raw, true);
     FAN_STAMP(6);
     for (uint32_t base = 256u; base < s_count; base += 256u) {  // rare
         const RowFetch fx = fetch_row(c, a.parent_idx, s_start, s_count, base, tid, lane, wv, s_root_level);
@@ -929,7 +938,7 @@ __global__ void __launch_bounds__(256, 6) k_propagate_fans(Columns c, TreeArgs a
         stage[lane] = fx.g0;
         stage[64u + lane] = fx.g1;
         stage[128u + lane] = fx.g2;
-        batch(base, fx.p, fx.s, fx.q, fx.t, xraw);
+        batch(base, fx.p, fx.s, fx.q, fx.t, xraw, false);
     }
     if (a.trace && tid == 0) {
         __builtin_amdgcn_s_waitcnt(0);  // stores drained

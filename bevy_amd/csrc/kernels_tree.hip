@@ -644,7 +644,7 @@ constexpr uint32_t FAN_SLOTS = TILE_LIGHT_UCAP + TILE_MAX_CHAIN;  // LDS slots: 
 constexpr uint32_t FAN_CHAIN_LANE0 = 256u - TILE_MAX_CHAIN;       // chain node k is fetched by thread FAN_CHAIN_LANE0 + k
 
 template <bool ALL_DIRTY>
-__global__ void __launch_bounds__(256, 6) k_propagate_fans(Columns c, TreeArgs a) {
+__global__ void __launch_bounds__(256, 7) k_propagate_fans(Columns c, TreeArgs a) {
     __shared__ float4 lds_g[FAN_SLOTS * 3];    // local affine, then (upper rows) the GlobalTransform in place
     // GlobalTransforms before this frame of the upper rows and the chain (dead once the level steps have fetched their columns of
     // them); afterwards the same memory is the four waves' transpose buffers of the last level (3 x 1 KB rows each)

@@ -26,6 +26,14 @@ extern thread_local const LaunchTimer* g_launch_timer;
         __builtin_amdgcn_wave_barrier();                               \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); \
     } while (0)
+// Workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight across it (__syncthreads()
+// drains the load counter).
+#define MI_WG_LDS_BARRIER()                                            \
+    do {                                                               \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); \
+        __builtin_amdgcn_s_barrier();                                  \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); \
+    } while (0)
 #define MI_LAUNCH(kernel, grid, block, lds, stream, ...)                                                        \
     do {                                                                                                        \
         const ::mi::LaunchTimer* lt_ = ::mi::g_launch_timer;                                                    \

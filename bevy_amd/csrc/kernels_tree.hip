@@ -734,10 +734,6 @@ __global__ void __launch_bounds__(256, 7) k_propagate_fans(Columns c, TreeArgs a
     const V4 u_q = ld4_32(c.rotation, u_row);
     const Affine u_old = ld_affine(u_old_src, u_row);
     const NodeRaw u_raw = node_raw<ALL_DIRTY>(a, u_row, true);
-    const uint32_t f_p = at32<uint32_t>(a.parent_idx, s_row * 4u);
-    const V3 f_s = ld3_32(c.scale, s_row), f_t = ld3_32(c.translation, s_row);
-    const V4 f_q = ld4_32(c.rotation, s_row);
-    const NodeRaw f_raw = node_raw<ALL_DIRTY>(a, s_row, s_root_level);
     FAN_STAMP(1);
     __builtin_amdgcn_sched_barrier(0);  // nothing below may move above: the scheduler otherwise consumes the first loads early
     // consume, in issue order
@@ -797,6 +793,11 @@ __global__ void __launch_bounds__(256, 7) k_propagate_fans(Columns c, TreeArgs a
     }
 
     FAN_STAMP(3);
+    // the last level's own inputs: requested here, they travel under the level steps (whose barriers order LDS only)
+    const uint32_t f_p = at32<uint32_t>(a.parent_idx, s_row * 4u);
+    const V3 f_s = ld3_32(c.scale, s_row), f_t = ld3_32(c.translation, s_row);
+    const V4 f_q = ld4_32(c.rotation, s_row);
+    const NodeRaw f_raw = node_raw<ALL_DIRTY>(a, s_row, s_root_level);
     // ---- LDS-resident levels: four lanes per row.  A thread's rows are fixed before the loop -- slot tid / 4 and, for tiles with
     // more than 64 upper rows, slot 64 + tid / 4 (TILE_LIGHT_UCAP <= 128) -- and everything about them that no other row's
     // result changes (level, parent slot, the rule's inputs, this lane's column of the local affine and of the old value) is
@@ -846,7 +847,7 @@ __global__ void __launch_bounds__(256, 7) k_propagate_fans(Columns c, TreeArgs a
                     if (cc == 0) lds_chg[q_slot[h]] = chg ? 1 : 0;  // (its global copy goes out with the write-back)
                 }
             }
-            __syncthreads();
+            MI_WG_LDS_BARRIER();
         }
     }
     // write-back of the upper rows: slots and rows are contiguous per level -> straight float4 copies; a tile in which

@@ -644,7 +644,7 @@ constexpr uint32_t FAN_SLOTS = TILE_LIGHT_UCAP + TILE_MAX_CHAIN;  // LDS slots: 
 constexpr uint32_t FAN_CHAIN_LANE0 = 256u - TILE_MAX_CHAIN;       // chain node k is fetched by thread FAN_CHAIN_LANE0 + k
 
 template <bool ALL_DIRTY>
-__global__ void __launch_bounds__(256, 7) k_propagate_fans(Columns c, TreeArgs a) {
+__global__ void __launch_bounds__(256, ALL_DIRTY ? 8 : 7) k_propagate_fans(Columns c, TreeArgs a) {
     __shared__ float4 lds_g[FAN_SLOTS * 3];    // local affine, then (upper rows) the GlobalTransform in place
     // GlobalTransforms before this frame of the upper rows and the chain (dead once the level steps have fetched their columns of
     // them); afterwards the same memory is the four waves' transpose buffers of the last level (3 x 1 KB rows each)
@@ -807,7 +807,6 @@ __global__ void __launch_bounds__(256, 7) k_propagate_fans(Columns c, TreeArgs a
     if (n_lds) {
         const uint32_t cc = tid & 3u;
         uint32_t q_slot[2], q_level[2], q_ps[2], q_in[2];
-        V3 q_loc[2], q_old[2];
 #pragma unroll
         for (uint32_t h = 0; h < 2u; ++h) {
             const uint32_t slot = h * 64u + (tid >> 2);
@@ -817,8 +816,6 @@ __global__ void __launch_bounds__(256, 7) k_propagate_fans(Columns c, TreeArgs a
             q_level[h] = on ? (uint32_t)lds_level[sl] : 0xFFFFFFFFu;
             q_ps[h] = lds_pslot[sl];
             q_in[h] = lds_in[sl];
-            q_loc[h] = lds_col(lds_g, sl, cc);
-            q_old[h] = lds_col(lds_old, sl, cc);
         }
         for (uint32_t l = 0; l < n_lds; ++l) {
 #pragma unroll
@@ -840,7 +837,8 @@ __global__ void __launch_bounds__(256, 7) k_propagate_fans(Columns c, TreeArgs a
                     }
                 }
                 V3 cur_c;
-                const bool chg = quad_node_apply(on, ROOTS && l == 0, a.static_opt != 0, q_in[h], gp, p_changed, q_loc[h], q_old[h], cc, lane, &cur_c);
+                const bool chg = quad_node_apply(on, ROOTS && l == 0, a.static_opt != 0, q_in[h], gp, p_changed, lds_col(lds_g, q_slot[h], cc),
+                                                 lds_col(lds_old, q_slot[h], cc), cc, lane, &cur_c);
                 if (on) {
                     lds_put_col(lds_g, q_slot[h], cc, cur_c);  // in place: the quad's lanes read and write their own column only
                     any_chg = any_chg || chg;

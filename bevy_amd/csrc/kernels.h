@@ -242,8 +242,8 @@ constexpr uint32_t TILE_MAX_LEVELS = 8;
 constexpr uint32_t TILE_BLOCK = 256;           // threads per tile
 constexpr uint32_t TILE_UCAP = 512;            // LDS slots of one tile: rows of all its levels but the last
 constexpr uint32_t TILE_LAST_CAP = 1024;       // the planner keeps a tile's streamed last level at or below this
-// Light tiles (big hierarchies): a quarter of the LDS rows and a last level of ONE batch -- one row per thread, nothing
-// software-pipelined -- so the kernel fits twice the workgroups per CU and a tile is two dependent round trips, not seven.
+// Light tiles: a quarter of the LDS rows and a last level of one row per thread, nothing software-pipelined -- so the
+// kernel fits twice the workgroups per CU and a tile is two dependent round trips, not seven.
 constexpr uint32_t TILE_LIGHT_UCAP = 112;
 constexpr uint32_t TILE_LIGHT_LAST_CAP = 256;
 constexpr uint32_t TILE_LIGHT_MIN_ROWS = 0;  // light tiles whenever they fit: measured faster from 341 to 1 M nodes

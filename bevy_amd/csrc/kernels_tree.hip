@@ -586,11 +586,13 @@ __global__ void __launch_bounds__(BLOCK) k_propagate_tiles(Columns c, TreeArgs a
 // ---------------------------------------------------------------------------------------------
 // Light tiles (big hierarchies; the planner guarantees: every level but the last holds <= TILE_LIGHT_UCAP rows together,
 // chain <= TILE_MAX_CHAIN, last level normally <= 256 rows).  Same walk and the same per-node rule as process_tile, organised
-// for residency instead of reach: ONE batch of loads per tile -- descriptor, then every row of the tile at once (upper rows
-// in lanes 0..127, the chain's nodes in the top lanes of wave 3, whose row numbers do not wait for the descriptor, one
-// last-level row per lane) -- nothing software-pipelined and nothing kept in registers across the level steps that LDS
-// can hold: the upper rows' old GlobalTransforms and the last level's (already in its transposed place) wait in LDS.
-// 6 workgroups per CU instead of 4, a few rounds of short tiles per CU: one tile's head runs under its neighbours' loads.
+// for residency instead of reach: 8 workgroups per CU (20.4 KB of LDS, 64 registers in the all-dirty instantiation) against 4, a
+// few rounds of short tiles per CU, so that one tile's head runs under its neighbours' loads.  Nothing is software-pipelined and
+// nothing is kept in registers across the serial part that LDS can hold or that can be fetched later.  A tile's loads go out in
+// three bursts of straight-line code: behind the descriptor the upper rows (lanes 0..127) and the chain's nodes (top lanes of
+// wave 3, whose row numbers do not wait for the descriptor); after the chain the last level's own inputs, one row per lane, which
+// travel under the level steps; at the write-back the last level's old GlobalTransforms, into the LDS the upper rows' old values
+// occupied.  (Everything in one batch at the top: 30.0 us per launch at 1 M nodes; three bursts: 24.9.)
 // ---------------------------------------------------------------------------------------------
 // One column of an affine (x_axis, y_axis, z_axis or translation) in an LDS slot of 12 floats.
 __device__ __forceinline__ V3 lds_col(const float4* slots, uint32_t slot, uint32_t c) {
@@ -696,8 +698,8 @@ __global__ void __launch_bounds__(256, ALL_DIRTY ? 8 : 7) k_propagate_fans(Colum
         }
     const bool s_root_level = ROOTS && n_lds == 0;
 
-    // ---- every load of the tile, as ONE batch: straight-line code, no load behind a divergent branch (the compiler waits
-    // where a result is first used, and the load counter is in order: a use in the middle would split the batch in two) ----
+    // ---- burst 1: straight-line code, no load behind a divergent branch (the compiler waits where a result is first used, and
+    // the load counter is in order: a use in the middle would split the batch in two) ----
     // (a) this lane's row of the last level (lanes past the end re-read the level's first row)
     const uint32_t wbase0 = wv * 64u < s_count ? wv * 64u : 0u;
     const uint32_t lim0 = (s_count - wbase0 < 64u ? s_count - wbase0 : 64u) * 3u;  // float4s of this wave's rows

@@ -723,7 +723,8 @@ class Context:
         return out
 
     def debug_set_tile_mode(self, mode):
-        """Which tile kernel the next upload_hierarchy plans for: 0 by size, 1 big tiles, 2 / 3 light tiles (test / bench hook)."""
+        """What the next upload_hierarchy plans: 0 light tiles where they fit, 1 big tiles, 2 light tiles always, 3 as 0 with the
+        streamed-level thresholds at their test values (2^20 / 2^21 rows) -- test / bench hook."""
         self._ck(self._lib.mi_debug_set_tile_mode(self._h, int(mode)))
 
     def debug_tree_trace(self, n_tiles=0):

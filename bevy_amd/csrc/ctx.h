@@ -73,7 +73,7 @@ struct mi_ctx {
     std::vector<std::pair<uint32_t, uint32_t>> passes;  // (first tile, n tiles); pass 0 starts at level 0 (roots)
     struct TileGroup { uint32_t first, count, n_chain, owner_rows; };
     bool tiles_light = false;       // the plan was made for the light tile kernel (TILE_LIGHT_*)
-    int32_t tile_mode = 0;          // 0 = light tiles where they fit, 1 = always the big tiles, 2 = always light (mi_debug_set_tile_mode)
+    int32_t tile_mode = 0;          // 0 = light tiles where they fit, 1 = always the big tiles, 2 = always light, 3 = as 0 with the streamed-level thresholds at their test values (mi_debug_set_tile_mode)
     std::vector<TileGroup> groups;  // tile launches of mi_propagate: roots + chain bands in one, then one per dependent band
     std::vector<std::pair<uint32_t, uint32_t>> stream_levels;  // (start, count), top-down: the wide deepest levels, one streaming launch each
     DevBuf tree_trace;              // mi_debug_tree_trace: 8 timestamps per tile of the light tile kernel

@@ -85,15 +85,13 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
         ctx->groups.clear();
         ctx->stream_levels.clear();
         auto level_size = [&](uint32_t lv) -> uint64_t { return lv < n_levels ? level_offsets[lv + 1] - level_offsets[lv] : 0; };
-        // A VERY wide deepest level is not tiled: a workgroup walking a tile is a chain of dependent round trips (descriptor,
-        // step 0, chain, LDS levels, then one round trip per 256 streamed rows) at 4 waves per SIMD; k_propagate_level sweeps a
-        // level at 8 waves per SIMD and the flat kernel's pace (650 k rows in 16.4 us = 5.6 TB/s).  But a tile launch has a floor
-        // of ~10 us however little it does, and a launch boundary costs ~1.8 us, so at 1 M nodes the single tile launch wins
-        // (33.5 us against 21.6 + 1.8 + 16.4 with the deepest level streamed); the streamed levels pay from a few million
-        // nodes up (thresholds in kernels.h).
+        // A VERY wide deepest level is not tiled but swept as a stream by k_propagate_level, at the flat kernel's pace, in a
+        // launch of its own.  That paid from ~1.4 M nodes up while the tile kernels ran at 4 - 6 workgroups per CU; the light
+        // tile kernel of today wins at every size and shape measured, so the thresholds (kernels.h) sit above that range.
         uint32_t n_tile_levels = n_levels;
-        while (n_tile_levels > 1 &&
-               level_size(n_tile_levels - 1) >= (n_tile_levels == n_levels ? STREAM_LEVEL_MIN_ROWS_LAST : STREAM_LEVEL_MIN_ROWS))
+        const uint32_t stream_last = ctx->tile_mode == 3 ? STREAM_LEVEL_MIN_ROWS_LAST_TEST : STREAM_LEVEL_MIN_ROWS_LAST;
+        const uint32_t stream_inner = ctx->tile_mode == 3 ? STREAM_LEVEL_MIN_ROWS_TEST : STREAM_LEVEL_MIN_ROWS;
+        while (n_tile_levels > 1 && level_size(n_tile_levels - 1) >= (n_tile_levels == n_levels ? stream_last : stream_inner))
             --n_tile_levels;
         for (uint32_t l = n_tile_levels; l < n_levels; ++l) ctx->stream_levels.emplace_back(level_offsets[l], level_offsets[l + 1] - level_offsets[l]);
         struct Band { uint32_t s, e; bool chain; };
@@ -191,7 +189,7 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
         // the bands top-down, for the kernels that sweep level by level with one launch per band (InheritedVisibility)
         for (size_t i = bands.size(); i-- > 0;) ctx->passes.emplace_back(band_tiles[i].first, band_tiles[i].second);
     };
-    bool light = (ctx->tile_mode == 2 || (ctx->tile_mode == 0 && n >= TILE_LIGHT_MIN_ROWS)) &&
+    bool light = (ctx->tile_mode == 2 || ((ctx->tile_mode == 0 || ctx->tile_mode == 3) && n >= TILE_LIGHT_MIN_ROWS)) &&
                  n <= 0xFFFFFFFFu / 48u;  // the light kernel addresses rows with 32-bit byte offsets
     make_plan(light);
     if (light) {
@@ -228,7 +226,7 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
 // (0 = chosen by size, 1 = big tiles, 2 = light tiles where they fit)
 int32_t mi_debug_set_tile_mode(mi_ctx* ctx, int32_t mode) {
     ENTER(ctx);
-    if (mode < 0 || mode > 2) return fail(ctx, MI_ERR_INVALID_ARG, "mi_debug_set_tile_mode: mode %d", mode);
+    if (mode < 0 || mode > 3) return fail(ctx, MI_ERR_INVALID_ARG, "mi_debug_set_tile_mode: mode %d", mode);
     ctx->tile_mode = mode;
     return MI_OK;
 }

@@ -249,8 +249,14 @@ constexpr uint32_t TILE_LIGHT_LAST_CAP = 256;
 constexpr uint32_t TILE_LIGHT_MIN_ROWS = 0;  // light tiles whenever they fit: measured faster from 341 to 1 M nodes
 // A level this wide is not given to tiles at all: it is swept by a streaming launch of its own (k_propagate_level) behind
 // the level above it.  The deepest level qualifies earlier than the ones above it (nothing else has to wait for it).
-constexpr uint32_t STREAM_LEVEL_MIN_ROWS_LAST = 1u << 20;
-constexpr uint32_t STREAM_LEVEL_MIN_ROWS = 1u << 21;
+// With the light tile kernel at 8 workgroups per CU the tiles win on everything measured -- 1.4 M nodes 36.0 against 39.6 us per
+// frame, 5.6 M nodes (4.2 M leaves) 153 - 159 against 162, and the wide shapes at 1.2 M nodes: 1 + 1100 + 1.21 M rows 30.7 against
+// 33.8, a root with 1.2 M children 29.9 against 32.5, fan-out 16 29.1 against 33.5 -- so the thresholds sit above that range; the
+// _TEST pair (mi_debug_set_tile_mode(3)) keeps the streamed path under test at sizes the oracle handles in seconds.
+constexpr uint32_t STREAM_LEVEL_MIN_ROWS_LAST = 1u << 23;
+constexpr uint32_t STREAM_LEVEL_MIN_ROWS = 1u << 24;
+constexpr uint32_t STREAM_LEVEL_MIN_ROWS_LAST_TEST = 1u << 20;
+constexpr uint32_t STREAM_LEVEL_MIN_ROWS_TEST = 1u << 21;
 constexpr uint32_t TILE_MAX_CHAIN = 24;       // ancestors a chain tile re-evaluates (levels above its first level)
 constexpr uint32_t TILE_ROOTS = 0x80000000u;   // TileDesc::kind: first level = level 0 of the forest
 constexpr uint32_t TILE_CHAIN_MASK = 0xFFu;    // TileDesc::kind: chain length (0 = parents come from global memory)

@@ -211,16 +211,18 @@ def test_tile_plans_are_one_launch_for_deep_and_wide_hierarchies(ctx_factory):
 
 @pytest.mark.parametrize("static_opt", [False, True])
 def test_very_wide_deepest_level_is_streamed(ctx_factory, static_opt):
-    """A deepest level of >= 2^20 rows is not tiled: k_propagate_level sweeps it in a launch of its own behind the level above
-    (kernels.h STREAM_LEVEL_MIN_ROWS_LAST).  Same per-node rule, so: all dirty, a moved root, sparse dirty rows under the
+    """A very wide deepest level is not tiled: k_propagate_level sweeps it in a launch of its own behind the level above (kernels.h
+    STREAM_LEVEL_MIN_ROWS_LAST: 2^23 rows, 2^20 with the test thresholds of mi_debug_set_tile_mode(3)).  Same per-node rule, so: all dirty, a moved root, sparse dirty rows under the
     static-scene rule and a static frame must all be the oracle's bits -- and visibility_propagate walks the same plan."""
     tr = W.gen_tree(3, 1100)  # 1 + 1100 + 1 210 000 rows
     n, parent = tr["n"], tr["parent"]
     assert tr["level_offsets"][-1] - tr["level_offsets"][-2] >= (1 << 20)
     flags = B.PROPAGATE_STATIC_OPT if static_opt else 0
     ctx = ctx_factory()
+    ctx.debug_set_tile_mode(3)
     upload_tree(ctx, tr)
-    assert ctx.debug_tile_plan()["launches"] == 1
+    plan = ctx.debug_tile_plan()
+    assert plan["launches"] == 1 and plan["tiles"] < 100, plan   # the 1.21 M leaves are not in tiles
     ctx.propagate(B.PROPAGATE_ALL_DIRTY | flags)
     rc, g0, chg0 = O.propagate_transforms(parent, tr["translation"], tr["rotation"], tr["scale"], static_opt=static_opt)
     g, chg = ctx.download_global_transforms()

@@ -527,7 +527,7 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
     }
     prof_collect(ctx);
     void* cols[] = {ctx->t, ctx->r, ctx->s, ctx->g, ctx->c, ctx->h, ctx->flags, ctx->vv, ctx->changed, ctx->g_changed_bytes,
-                    ctx->layers, ctx->class_mask, ctx->keys, ctx->g_chg_bits, ctx->vv_chg_bits, ctx->tree_bits,
+                    ctx->layers, ctx->class_mask, ctx->keys, ctx->g_chg_bits, ctx->vv_chg_bits, ctx->tree_bytes,
                     ctx->range, ctx->visibility, ctx->inh_changed, ctx->bt_set, ctx->bt_bin, ctx->bt_input, ctx->bt_row_meta,
                     ctx->bt_kind, ctx->bt_cpu_bin, ctx->bt_bucket};
     for (void* p : cols)
@@ -660,12 +660,17 @@ int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
             }
             *bits = nb;
         }
-        if (ctx->tree_bits) {
+        if (ctx->tree_bytes) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            HIP_TRY(ctx, hipFree(ctx->tree_bits));
+            HIP_TRY(ctx, hipFree(ctx->tree_bytes));
         }
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->tree_bits, padded_words(new_cap) * 8 + 256));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->tree_bits, 0, padded_words(new_cap) * 8 + 256, ctx->stream));
+        // two halves: the frame's marks and the ones the frame's mark launch zeroes for the next frame
+        const size_t half_bytes = (((size_t)new_cap + 255) & ~(size_t)255) + 256;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->tree_bytes, 2 * half_bytes));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->tree_bytes, 0, 2 * half_bytes, ctx->stream));
+        ctx->tree_half_words = (uint32_t)(half_bytes / 4);
+        ctx->tree_clean[0] = ctx->tree_clean[1] = true;
+        ctx->tree_parity = 0;
         ctx->cap = new_cap;
     }
     if (n_rows > ctx->n && ctx->n < old_cap_rows) {
@@ -881,16 +886,22 @@ int32_t mi_propagate(mi_ctx* ctx, uint32_t flags) {
     ctx->g_chg_maybe = true;
     Columns c = columns_of(ctx);
     const uint32_t n0 = ctx->have_hierarchy ? ctx->level_offsets[1] : ctx->n;
-    const uint32_t* tree_bits = nullptr;
+    const uint8_t* tree_bits = nullptr;
     // mark_dirty_trees returns early unless the static optimisation is enabled (systems.rs:131-133)
     if (ctx->have_hierarchy && static_opt && !all_dirty) {
-        {
+        uint8_t* const cur = ctx->tree_bytes + (size_t)ctx->tree_parity * ctx->tree_half_words * 4;
+        uint8_t* const other = ctx->tree_bytes + (size_t)(ctx->tree_parity ^ 1u) * ctx->tree_half_words * 4;
+        if (!ctx->tree_clean[ctx->tree_parity]) {  // (not on the usual path: the previous frame's mark launch zeroed it)
             ProfScope ps(ctx, K_CLEAR);
-            HIP_TRY(ctx, launch_clear_u32(ctx->tree_bits, padded_words(ctx->n) * 2, ctx->stream));
+            HIP_TRY(ctx, launch_clear_u32((uint32_t*)cur, ctx->tree_half_words, ctx->stream));
         }
         ProfScope ps(ctx, K_MARK_DIRTY);
-        HIP_TRY(ctx, launch_mark_dirty(ctx->n, ctx->changed, (const uint32_t*)ctx->parent_idx.p, ctx->tree_bits, ctx->stream));
-        tree_bits = ctx->tree_bits;
+        HIP_TRY(ctx, launch_mark_dirty(ctx->n, ctx->changed, (const uint32_t*)ctx->parent_idx.p, cur,
+                                       ctx->tree_clean[ctx->tree_parity ^ 1u] ? nullptr : (uint32_t*)other, ctx->tree_half_words, ctx->stream));
+        ctx->tree_clean[ctx->tree_parity] = false;
+        ctx->tree_clean[ctx->tree_parity ^ 1u] = true;
+        ctx->tree_parity ^= 1u;
+        tree_bits = cur;
     }
     if (!ctx->have_hierarchy) {
         ProfScope ps(ctx, K_LEVEL0_PROPAGATE);

@@ -48,7 +48,9 @@ struct mi_ctx {
     uint8_t *flags = nullptr, *vv = nullptr, *changed = nullptr, *g_changed_bytes = nullptr;
     uint32_t *layers = nullptr, *class_mask = nullptr;
     uint64_t *keys = nullptr, *g_chg_bits = nullptr, *vv_chg_bits = nullptr;
-    uint32_t* tree_bits = nullptr;
+    uint8_t* tree_bytes = nullptr;  // TransformTreeChanged, a byte per row; two halves of tree_half_words 32-bit words (double-buffered by frame: tree_parity)
+    uint32_t tree_half_words = 0, tree_parity = 0;
+    bool tree_clean[2] = {true, true};  // the half is known to be all zero
     bool have_class_mask = false, have_keys = false, have_changed = false;
     uint32_t propagated_rows = 0;  // rows [0, propagated_rows) have been through a propagate (their Added<GlobalTransform> is consumed)
     uint32_t classes_present = 1u;

@@ -162,9 +162,9 @@ hipError_t launch_flat_propagate_cull(const Columns& c, const ViewSet* views_inl
                                       hipStream_t stream, const uint8_t* changed = nullptr /* set: only rows with a nonzero byte are propagated */);
 // Level 0 of the hierarchy (roots + flat rows).  node_flags: bit0 = has children (nullptr = none do).
 // changed: per-row Changed<Transform>|... byte (nullptr or all_dirty => every row recomputed).
-// tree_bits: TransformTreeChanged bitset (only read when static_opt).
+// tree_bytes: TransformTreeChanged, a byte per row (only read when static_opt).
 hipError_t launch_level0_propagate(const Columns& c, uint32_t n_level0, const uint8_t* node_flags,
-                                   const uint8_t* changed, const uint32_t* tree_bits, bool all_dirty,
+                                   const uint8_t* changed, const uint8_t* tree_bytes, bool all_dirty,
                                    bool static_opt, hipStream_t stream);
 hipError_t launch_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views,
                        const VisibilityOut& out, const SegOut& seg, uint32_t flags, const CompactFastArgs* prev,
@@ -266,18 +266,19 @@ struct TileDesc {
     uint32_t count[TILE_MAX_LEVELS];
     uint32_t kind;
 };
-hipError_t launch_mark_dirty(uint32_t n, const uint8_t* changed, const uint32_t* parent_idx, uint32_t* tree_bits,
+hipError_t launch_mark_dirty(uint32_t n, const uint8_t* changed, const uint32_t* parent_idx, uint8_t* tree_bytes,
+                             uint32_t* clear_words /* the other half, zeroed for the next frame; nullptr = none */, uint32_t n_clear_words,
                              hipStream_t stream);
 // One launch over a group of mutually independent tiles (TileDesc::kind tells roots / chain / dependent apart).
 hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, const TileDesc* d_tiles, const uint32_t* d_chains,
-                                  uint32_t n_tiles, const uint8_t* node_flags, const uint8_t* changed, const uint32_t* tree_bits,
+                                  uint32_t n_tiles, const uint8_t* node_flags, const uint8_t* changed, const uint8_t* tree_bytes,
                                   uint8_t* g_changed_bytes, const float* snap_read, float* snap_write, uint32_t snap_rows, bool all_dirty,
                                   bool static_opt, bool light /* the plan is one of light tiles */, hipStream_t stream,
                                   unsigned long long* trace = nullptr);
 // One whole level [start, start + count) as a stream: every row's parent lies in the level above, complete in global
 // memory (an earlier launch).  Same per-node rule as the tiles.
 hipError_t launch_propagate_level(const Columns& c, const uint32_t* parent_idx, uint32_t start, uint32_t count, const uint8_t* changed,
-                                  const uint32_t* tree_bits, uint8_t* g_changed_bytes, bool all_dirty, bool static_opt, hipStream_t stream);
+                                  const uint8_t* tree_bytes, uint8_t* g_changed_bytes, bool all_dirty, bool static_opt, hipStream_t stream);
 hipError_t launch_inherit_level(const uint32_t* parent_idx, uint32_t start, uint32_t count, const uint8_t* visibility, uint8_t* flags,
                                 uint8_t* inh_changed, hipStream_t stream);
 // InheritedVisibility propagation (visibility_propagate_system): writes bit0 of flags[] and changed bytes.

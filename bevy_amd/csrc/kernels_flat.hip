@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
 __global__ void __launch_bounds__(256) k_level0_propagate(Columns c, uint32_t n_level0,
                                                            const uint8_t* __restrict__ node_flags,
                                                            const uint8_t* __restrict__ changed,
-                                                           const uint32_t* __restrict__ tree_bits, bool all_dirty,
+                                                           const uint8_t* __restrict__ tree_bytes, bool all_dirty,
                                                            bool static_opt) {
     __shared__ float4 lds_g[4][192];
     const uint32_t row = blockIdx.x * 256u + threadIdx.x;
@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(256) k_level0_propagate(Columns c, uint32_t n_
         const bool has_children = node_flags ? (node_flags[row] & 1u) != 0 : false;
         if (has_children) {
             // roots: skipped only when the static optimisation is on and the tree is clean
-            const bool tree_changed = all_dirty || !tree_bits || ((tree_bits[row >> 5] >> (row & 31u)) & 1u);
+            const bool tree_changed = all_dirty || !tree_bytes || tree_bytes[row] != 0;
             write = !static_opt || tree_changed;
         } else {
             // flat rows: Changed<Transform> || Added<GlobalTransform> (systems.rs:45-50)
@@ -617,11 +617,11 @@ hipError_t launch_cull(const Columns& c, const ViewSet* views_inline, const View
     return launch_frame<0>(c, views_inline, d_views, n_views, out, seg, flags, prev, fill, walk, stream);
 }
 hipError_t launch_level0_propagate(const Columns& c, uint32_t n_level0, const uint8_t* node_flags,
-                                   const uint8_t* changed, const uint32_t* tree_bits, bool all_dirty,
+                                   const uint8_t* changed, const uint8_t* tree_bytes, bool all_dirty,
                                    bool static_opt, hipStream_t stream) {
     if (n_level0 == 0) return hipSuccess;
     MI_LAUNCH(k_level0_propagate, dim3(blocks_for(n_level0)), dim3(256), 0, stream, c, n_level0, node_flags,
-                       changed, tree_bits, all_dirty, static_opt);
+                       changed, tree_bytes, all_dirty, static_opt);
     return hipGetLastError();
 }
 hipError_t launch_vis_begin(const Columns& c, hipStream_t stream) {

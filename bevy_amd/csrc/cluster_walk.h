@@ -114,10 +114,16 @@ __device__ __forceinline__ V3 ld3c(const float* base, uint32_t row) {
     const F3c v = reinterpret_cast<const F3c*>(base)[row];
     return V3{v.x, v.y, v.z};
 }
-// The row's GlobalTransform: the column (behind this frame's propagate) or, in derive mode, From(Transform) itself
-// (sync_simple_transforms: the rows are flat).
+// The row's GlobalTransform: the column (behind this frame's propagate) or, in derive mode and for a row this frame's propagate
+// writes, From(Transform) itself (sync_simple_transforms: the rows are flat).
+// derive mode: does this frame's propagate write the row's GlobalTransform (then it is From(Transform), the column being written
+// by the same launch) or does the row keep the resident one?  The fused all-rows frame writes every row; the changed-rows frame
+// the rows whose change byte is set; a cull-only frame none.
+__device__ __forceinline__ bool object_row_is_propagated(const ClusterObjects& o, uint32_t row) {
+    return !o.derive_resident && (!o.row_changed || o.row_changed[row] != 0);
+}
 __device__ __forceinline__ Affine object_row_affine(const ClusterObjects& o, uint32_t row) {
-    if (o.derive) {
+    if (o.derive && object_row_is_propagated(o, row)) {
         const float4 q = reinterpret_cast<const float4*>(o.row_rotation)[row];
         return affine_from_srt(ld3c(o.row_scale, row), V4{q.x, q.y, q.z, q.w}, ld3c(o.row_translation, row));
     }
@@ -127,7 +133,7 @@ __device__ __forceinline__ Affine object_row_affine(const ClusterObjects& o, uin
 // their row's GlobalTransform (point lights: GlobalTransform::from_translation(transform.translation()), :198).
 __device__ __forceinline__ float4 object_sphere(const ClusterObjects& o, uint32_t obj) {
     float4 pr = reinterpret_cast<const float4*>(o.pos_range)[obj];
-    if (o.derive) {
+    if (o.derive && object_row_is_propagated(o, o.first_row + obj)) {
         const V3 t = ld3c(o.row_translation, o.first_row + obj);
         pr.x = t.x;
         pr.y = t.y;

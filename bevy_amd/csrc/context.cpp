@@ -411,6 +411,12 @@ static int32_t cull_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, u
     const bool whole_frame = (flags & MI_CULL_END_FRAME) && (PROPAGATE || (flags & MI_CULL_BEGIN_FRAME));
     const bool derivable = with_clusters && whole_frame && ctx->views_inline && !ctx->have_hierarchy && ctx->n;
     const bool clusters_concurrent = derivable && (flags & MI_CULL_CLUSTERS_CONCURRENT);
+    // MI_CULL_CHANGED_ROWS: sync_simple_transforms' own filter -- before any change column was uploaded every row still counts
+    // as changed (Added<GlobalTransform>), as in mi_propagate
+    const uint8_t* const changed_col = (PROPAGATE && (flags & MI_CULL_CHANGED_ROWS) && ctx->have_changed) ? ctx->changed : nullptr;
+    // a derived assignment takes a light's GlobalTransform as this frame's propagate leaves it: From(Transform) for the rows it writes
+    ctx->cl_derive_changed = changed_col;
+    ctx->cl_derive_resident = !PROPAGATE;
     if (clusters_concurrent && (rc = cluster_assign_launch(ctx, true, nullptr))) return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
     bool clusters_ride = false;
     {
@@ -429,9 +435,6 @@ static int32_t cull_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, u
             return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
         }
         ProfScope ps(ctx, PROPAGATE ? K_FLAT_PROPAGATE_CULL : K_CULL);
-        // MI_CULL_CHANGED_ROWS: sync_simple_transforms' own filter -- before any change column was uploaded every row still counts
-        // as changed (Added<GlobalTransform>), as in mi_propagate
-        const uint8_t* changed_col = (PROPAGATE && (flags & MI_CULL_CHANGED_ROWS) && ctx->have_changed) ? ctx->changed : nullptr;
         const hipError_t e = PROPAGATE ? launch_flat_propagate_cull(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p,
                                                                     n_views, vo, seg, flags & MI_CULL_END_FRAME, prev, have_fill ? &fill_job : nullptr,
                                                                     clusters_ride ? &walk_job : nullptr, ctx->stream, changed_col)

@@ -189,6 +189,9 @@ struct mi_ctx {
     uint32_t bt_n_sets = 0, bt_n_meta = 0;
     bool bt_have_rows = false, bt_have_sets = false, bt_built = false;
     DevBuf cl_remap, cl_bind_oc, cl_bind_idx, cl_block_counts, cl_pair_cb, cl_pair_mask, cl_acc, cl_offsets, cl_indices, cl_scalars;
+    // derive mode of an assignment that runs in or next to the frame kernel: which rows that frame's propagate writes (cull_frame sets them)
+    const uint8_t* cl_derive_changed = nullptr;
+    bool cl_derive_resident = false;
     uint32_t cl_parity = 0, cl_acc_clusters = 0, cl_acc_blocks = 0;  // cl_parity: the current working set; cl_acc = 3 x [counts 6C | totals C | farthest_z + pad]
     uint32_t cl_n = 0;
     bool cl_have_type = false, cl_have_layers = false, cl_have_spot = false, cl_have_spot_dir = false, cl_any_spot = false;

@@ -193,6 +193,9 @@ int32_t cluster_objects(mi_ctx* ctx, bool derive, ClusterObjects* po) {
         o.first_row = ctx->cl_first_row;
         if (derive) {
             o.derive = 1;
+            o.row_global = ctx->g;
+            o.row_changed = ctx->cl_derive_changed;
+            o.derive_resident = ctx->cl_derive_resident ? 1u : 0u;
             o.n_views = ctx->n_views;
             o.row_translation = ctx->t;
             o.row_rotation = ctx->r;

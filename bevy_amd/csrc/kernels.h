@@ -319,8 +319,12 @@ struct ClusterObjects {
     //   derive != 0         re-derive it with the cull's own rule (visibility_rule.h) from the row's Transform, bounds, flags
     //                       and the frame's views, so the assignment can run CONCURRENTLY with the frame kernel of the same
     //                       frame on another stream.  Flat rows only (GlobalTransform == From(Transform)).
-    const float* row_global;     // 12 floats per row, or nullptr = objects are not rows (or derive)
+    const float* row_global;     // 12 floats per row, or nullptr = objects are not rows
     const uint8_t* row_vv;
+    // derive mode, which rows this frame's propagate writes (those are From(Transform); the others keep the resident column):
+    // row_changed == nullptr && !derive_resident: every row; row_changed: the rows whose byte is set; derive_resident: none
+    const uint8_t* row_changed;
+    uint32_t derive_resident;
     uint32_t first_row;
     uint32_t derive, n_views;
     const float *row_translation, *row_rotation, *row_scale, *row_aabb_center, *row_aabb_half, *row_range;

@@ -406,3 +406,52 @@ def test_fused_frame_over_the_changed_rows_equals_propagate_then_cull(ctx_factor
     with pytest.raises(api.MiError) as e:
         b.cull(cam, flags=B.CULL_BEGIN_FRAME | B.CULL_CHANGED_ROWS)
     assert e.value.code == api.MI_ERR_INVALID_ARG
+
+
+def test_riding_cluster_walk_takes_the_global_transform_the_frame_leaves(ctx_factory):
+    """The light-cluster walk that rides in the frame kernel re-derives each light's ViewVisibility and position itself; it must use
+    the GlobalTransform this frame's propagate LEAVES: From(Transform) for the rows it writes, the resident one for the others.
+    Transforms changed behind change detection's back (Mut::bypass_change_detection: new values, no mark) make the two differ:
+    the reference keeps the stale GlobalTransform, so the changed-rows frame and the cull-only frame must cluster the lights
+    where they WERE.  Twin context: mi_propagate(0) + mi_cull + mi_cluster_assign_resident (reads the columns)."""
+    sc, first_light, pr = W.frame_scene(30_000, 4_000, 400, light_range=3.0)
+    n, n_l = sc["n"], len(pr) // 4
+    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+    cam = W.many_cubes_camera(0)
+    fr = api.compute_frustum(cfv, cam, W.CAMERA_FAR)
+    view, keep = api.cluster_view_build(cam, cfv, fr, 1920, 1080, (16, 9, 24), 5.0, 1000.0)
+    n_clusters = 16 * 9 * 24
+    a, b = ctx_factory(), ctx_factory()
+    for c in (a, b):
+        c.resize(n)
+        c.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
+        c.upload_bounds(sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"])
+        c.cluster_upload_objects(pr)
+        c.cluster_bind_objects_to_rows(first_light, n_l)
+        c.upload_changed(np.zeros(n, np.uint8))
+        c.propagate(B.PROPAGATE_ALL_DIRTY)
+        c.cluster_upload_view(view)
+    t3 = sc["translation"].reshape(n, 3).copy()
+    lights = np.arange(first_light, first_light + n_l)
+    t3[lights[::2]] *= F(0.5)                      # every other light moves towards the camera ...
+    marked = np.zeros(n, np.uint8)
+    marked[lights[::4]] = 1                        # ... but only every fourth is marked changed
+    marked[:100] = 1
+    for mode in ("changed_rows", "cull_only"):
+        for c in (a, b):
+            c.upload_transforms(t3.reshape(-1), sc["rotation"], sc["scale"])
+            c.upload_changed(marked if mode == "changed_rows" else np.zeros(n, np.uint8))
+        if mode == "changed_rows":
+            a.propagate_and_cull(frusta_for([cam]), flags=B.CULL_END_FRAME | B.CULL_WITH_CLUSTERS | B.CULL_CHANGED_ROWS)
+            b.propagate(0)
+        else:
+            a.cull(frusta_for([cam]), flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME | B.CULL_WITH_CLUSTERS)
+        b.cull(frusta_for([cam]), flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME)
+        b.cluster_assign_resident()
+        ra, rb = a.cluster_download(n_clusters), b.cluster_download(n_clusters)
+        assert rb[4] > 0 and ra[4] == rb[4], mode
+        for x, y in zip(ra[:3], rb[:3]):
+            assert np.array_equal(x, y), mode
+        assert ra[3] == rb[3], mode
+        assert a.download_global_transforms(want_changed=False).tobytes() == b.download_global_transforms(want_changed=False).tobytes()
+        t3[lights[1::2]] *= F(0.75)                # second round: other lights move, nothing is marked

@@ -669,9 +669,6 @@ __global__ void __launch_bounds__(256, ALL_DIRTY ? 8 : 7) k_propagate_fans(Colum
     __shared__ uint8_t lds_level[TILE_LIGHT_UCAP];   // per upper row: its level inside the tile
     __shared__ float4 lds_chain_g[3];
     __shared__ uint32_t lds_chain_chg;
-    // Workgroups go round the eight XCDs (blockIdx % 8), each with an L2 of its own: XCD x takes a CONTIGUOUS eighth of the tiles,
-    // so that neighbouring tiles -- whose short upper-level segments share cache lines and whose chains share ancestors --
-    // meet in one L2 instead of fetching the same lines eight times.
     const uint32_t tile = xcd_contiguous_tile();
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     // development trace: stamps are kept in registers and written once at the very end (a store in front of a barrier would

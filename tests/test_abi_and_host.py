@@ -187,3 +187,42 @@ def test_header_is_plain_c_and_wire_structs_have_the_reference_sizes(tmp_path):
                    check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     assert [int(x) for x in out] == [144, 8, 20, 8, 12, 32, 28, 36]  # mi_batch_totals: 9 words since n_unbatchable was added
+
+
+def test_python_constants_mirror_the_header_defines():
+    """bevy_amd/__init__.py repeats the header's flag values for the harness; a define that moves must not leave them behind."""
+    import re
+    import bevy_amd as B
+    text = open(os.path.join(ROOT, "include", "bevy_mi355x.h")).read()
+    defines = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"#define\s+MI_([A-Z0-9_]+)\s+(0x[0-9A-Fa-f]+|\d+)u?\b", text)}
+    checked = 0
+    for name in dir(B):
+        if name.isupper() and name in defines and isinstance(getattr(B, name), int):
+            assert getattr(B, name) == defines[name], (name, getattr(B, name), defines[name])
+            checked += 1
+    assert checked >= 12, checked
+    for must in ("CULL_BEGIN_FRAME", "CULL_END_FRAME", "CULL_MORE_FRAMES", "CULL_WITH_CLUSTERS", "CULL_CHANGED_ROWS", "PROPAGATE_ALL_DIRTY",
+                 "PROPAGATE_STATIC_OPT"):
+        assert must in defines and getattr(B, must) == defines[must], must
+
+
+def test_oracle_mark_dirty_trees_is_the_ancestor_closure():
+    """mark_dirty_trees (systems.rs:111-306) marks exactly the changed rows and all their ancestors -- the definition the device's
+    climb (plain byte marks, early stop at a marked node) is held to through the oracle.  Brute force over random forests."""
+    import oracle_lib as O
+    rng = np.random.default_rng(11)
+    for trial in range(40):
+        n = int(rng.integers(1, 400))
+        parent = np.full(n, 0xFFFFFFFF, np.uint32)
+        for k in range(1, n):
+            if rng.random() > 0.1:
+                parent[k] = rng.integers(max(0, k - int(rng.choice([1, 4, 60]))), k)
+        changed = (rng.random(n) < rng.choice([0.0, 0.02, 0.3])).astype(np.uint8)
+        want = np.zeros(n, np.uint8)
+        for k in np.nonzero(changed)[0]:
+            r = int(k)
+            while r != 0xFFFFFFFF and not want[r]:
+                want[r] = 1
+                r = int(parent[r])
+        got = O.mark_dirty_trees(parent, changed)
+        assert np.array_equal(got != 0, want != 0), trial

@@ -801,14 +801,16 @@ __global__ void __launch_bounds__(256, ALL_DIRTY ? 8 : 7) k_propagate_fans(Colum
     }
 
     // The static-scene rule for a whole tile at once (systems.rs:708-714 skips a node when neither its subtree nor its parent
-    // changed): the tile's parent did not change (the chain says so) and none of the tile's top rows carries
-    // TransformTreeChanged -- then, by induction down the levels, every row of the tile is skipped: it keeps its GlobalTransform
-    // and its change tick stays.  Such a tile asks for nothing more (two thirds of its bytes) and leaves.  Tiles that mirror rows
-    // into the chain snapshot take the long way.
+    // changed): the tile's parent did not change (the chain says so; the top rows of a tile of forest roots have none) and none
+    // of the tile's top rows carries TransformTreeChanged or is assigned as a root or flat row this frame -- then, by induction
+    // down the levels, every row of the tile is skipped: it keeps its GlobalTransform and its change tick stays.  Such a tile
+    // asks for nothing more (two thirds of its bytes) and leaves: the trees of a forest that did not move cost a first burst.
+    // Tiles that mirror rows into the chain snapshot take the long way.
     if constexpr (!ALL_DIRTY) {
-        if (a.static_opt && chain_len && n_lds && (!snap_out || td.start[0] >= a.snap_rows)) {
-            const bool top_marked = tid < td.count[0] && (lds_in[tid] & 1u) != 0;
-            if (__syncthreads_or((top_marked || lds_chain_chg != 0u) ? 1 : 0) == 0) {
+        if (a.static_opt && (chain_len || ROOTS) && n_lds && (!snap_out || td.start[0] >= a.snap_rows)) {
+            const bool top_marked = tid < td.count[0] && (lds_in[tid] & 3u) != 0;
+            const bool parent_changed = chain_len != 0u && lds_chain_chg != 0u;
+            if (__syncthreads_or((top_marked || parent_changed) ? 1 : 0) == 0) {
                 if (tid < U) at32w<uint8_t>(a.g_changed_bytes, lds_row[tid]) = 0;
                 for (uint32_t i = tid; i < s_count; i += 256u) at32w<uint8_t>(a.g_changed_bytes, s_start + i) = 0;
                 return;

@@ -156,8 +156,12 @@ ABI_SYMBOLS = [
     "mi_cluster_assign_frame",
     "mi_batch_upload_rows", "mi_batch_upload_sets", "mi_batch_upload_row_bins", "mi_batch_upload_bins", "mi_batch_build", "mi_batch_build_phase",
     "mi_batch_sorted_build", "mi_batch_download_totals", "mi_batch_download", "mi_perspective_clip_from_view", "mi_compute_frustum",
-    "mi_bind_visibility_output", "mi_exchange_set_mode", "mi_exchange_configure", "mi_exchange_configure_multi", "mi_exchange_last", "mi_device_buffer", "mi_timer_begin", "mi_timer_end", "mi_profile_enable",
-    "mi_profile_filter", "mi_profile_sample", "mi_profile_burst", "mi_profile_read", "mi_profile_kernel_name",
+    "mi_bind_visibility_output", "mi_exchange_set_mode", "mi_exchange_configure", "mi_exchange_configure_multi", "mi_exchange_last", "mi_device_buffer",
+]
+# include/bevy_mi355x_debug.h: instrumentation and test hooks, exported by the same library, not part of the boundary
+DEBUG_SYMBOLS = [
+    "mi_timer_begin", "mi_timer_end", "mi_profile_enable", "mi_profile_filter", "mi_profile_sample", "mi_profile_burst", "mi_profile_read",
+    "mi_profile_kernel_name", "mi_debug_set_tile_mode", "mi_debug_tree_trace", "mi_debug_tile_plan", "mi_debug_logf",
 ]
 
 
@@ -177,7 +181,7 @@ def load_library():
     lib.mi_last_error_string.restype = C.c_char_p
     lib.mi_last_error_string.argtypes = [C.c_void_p]
     lib.mi_profile_kernel_name.restype = C.c_char_p
-    for name in ABI_SYMBOLS:
+    for name in ABI_SYMBOLS + DEBUG_SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("mi_last_error_string", "mi_profile_kernel_name"):
             fn.restype = C.c_int32

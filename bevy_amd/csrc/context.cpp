@@ -430,6 +430,9 @@ static int32_t cull_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, u
         // ... and so does THIS frame's walk when the call decides the frame's ViewVisibility alone: the walk re-derives the
         // lights' visibility with the cull's rule, so it needs nothing the rest of the launch produces
         ClusterWalkJob walk_job{};
+        // what cluster_ride_prepare changes, in case the launch below fails and the walk never runs
+        const uint32_t cl_parity_before = ctx->cl_parity;
+        const bool cl_assigned_before = ctx->cl_assigned;
         if (derivable && !clusters_concurrent && (rc = cluster_ride_prepare(ctx, &walk_job, &clusters_ride))) {
             if (have_fill) launch_cluster_fill(fill_job.w, fill_job.n_clusters, fill_job.n_objects, ctx->stream);
             return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
@@ -442,6 +445,15 @@ static int32_t cull_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, u
                                                      seg, flags & (MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME), prev, have_fill ? &fill_job : nullptr,
                                                      clusters_ride ? &walk_job : nullptr, ctx->stream);
         if (e != hipSuccess) {
+            // The launch that was to carry the previous frame's fill and this frame's walk never happened: the fill goes out
+            // on its own (as in the ride_prepare failure above), and the walk's bookkeeping is taken back -- no fill may later
+            // expand, and no download may return, a set nothing walked into.
+            if (have_fill) launch_cluster_fill(fill_job.w, fill_job.n_clusters, fill_job.n_objects, ctx->stream);
+            if (clusters_ride) {
+                ctx->cl_fill_pending = false;
+                ctx->cl_assigned = cl_assigned_before;
+                ctx->cl_parity = cl_parity_before;
+            }
             fail(ctx, MI_ERR_DEVICE, "frame kernel launch: %s", hipGetErrorString(e));
             return frame_abort(ctx, MI_ERR_DEVICE, prev, prev_has_job, prev_job);
         }
@@ -453,6 +465,9 @@ static int32_t cull_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, u
     if (clusters_ride && !(flags & MI_CULL_MORE_FRAMES) && (rc = cluster_fill_join(ctx))) return rc;  // nobody promised a frame to carry the fill
     if (PROPAGATE) {
         if (ctx->have_changed && ctx->changed_maybe) {
+            // a concurrent walk on the cluster stream reads the change column (and the GlobalTransforms of the rows it does not
+            // mark): the memset waits for it
+            if (clusters_concurrent && changed_col && ctx->cl_on_side) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_cl_done, 0));
             HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, ctx->n, ctx->stream));
             ctx->changed_maybe = false;
         }
@@ -1503,7 +1518,7 @@ const char* mi_profile_kernel_name(uint32_t k) {
     return k < K_NUM_KERNELS ? names[k] : nullptr;
 }
 
-// test hook: device logf probe (not part of the public header; used by tests/test_logf.py)
+// test hook: device logf probe (include/bevy_mi355x_debug.h; tests/test_gpu_cluster.py::test_device_logf_matches_libm)
 int32_t mi_debug_logf(mi_ctx* ctx, const float* in, float* out, uint32_t n) {
     ENTER(ctx);
     DevBuf a, b;

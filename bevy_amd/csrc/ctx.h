@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/bevy_mi355x.h"
+#include "../../include/bevy_mi355x_debug.h"
 #include "kernels.h"
 
 namespace mi {

@@ -308,6 +308,8 @@ int32_t cluster_assign_launch(mi_ctx* ctx, bool concurrent, uint64_t* out_total,
         ctx->cl_inputs_dirty = false;
     }
     for (int attempt = 0; attempt < 2; ++attempt) {
+        // the plane table lives in the staging arena, and the download between the attempts may have wrapped (or moved) it
+        if ((rc = stage_cluster_planes(ctx))) return rc;
         cluster_next_set(ctx, &p);
         const ClusterWork& w = p.w;
         const bool defer = defer_fill && !concurrent && !out_total;

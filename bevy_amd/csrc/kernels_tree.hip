@@ -709,6 +709,7 @@ __global__ void __launch_bounds__(256, ALL_DIRTY ? 8 : 7) k_propagate_fans(Colum
     // (a) this lane's row of the last level (lanes past the end re-read the level's first row)
     const uint32_t wbase0 = wv * 64u < s_count ? wv * 64u : 0u;
     const uint32_t lim0 = (s_count - wbase0 < 64u ? s_count - wbase0 : 64u) * 3u;  // float4s of this wave's rows
+    const uint32_t last0 = lim0 ? lim0 - 1u : 0u;  // (an empty last level -- the planner makes none -- must not index at -1)
     const uint32_t s_row = s_start + (tid < s_count ? tid : 0u);
     // (b) an upper row (threads below U) or a chain node (top threads of wave 3)
     const bool is_chain = chain_lane && tid - FAN_CHAIN_LANE0 < chain_len;
@@ -882,9 +883,9 @@ __global__ void __launch_bounds__(256, ALL_DIRTY ? 8 : 7) k_propagate_fans(Colum
     // occupied until the level steps had read them
     bool flush_live = false;
     if (n_lds) flush_live = __syncthreads_or(any_chg ? 1 : 0) != 0;  // (in front of the loads: the barrier drains the load counter)
-    const float4 f_g0 = at32<float4>(c.global, g_off + (lane < lim0 ? lane : lim0 - 1u) * 16u);
-    const float4 f_g1 = at32<float4>(c.global, g_off + (64u + lane < lim0 ? 64u + lane : lim0 - 1u) * 16u);
-    const float4 f_g2 = at32<float4>(c.global, g_off + (128u + lane < lim0 ? 128u + lane : lim0 - 1u) * 16u);
+    const float4 f_g0 = at32<float4>(c.global, g_off + (lane < last0 ? lane : last0) * 16u);
+    const float4 f_g1 = at32<float4>(c.global, g_off + (64u + lane < last0 ? 64u + lane : last0) * 16u);
+    const float4 f_g2 = at32<float4>(c.global, g_off + (128u + lane < last0 ? 128u + lane : last0) * 16u);
     if (n_lds) {
         if (tid < U) at32w<uint8_t>(a.g_changed_bytes, lds_row[tid]) = lds_chg[tid];
         if (flush_live || snap_out) {

@@ -688,25 +688,8 @@ int32_t mi_exchange_last(mi_ctx* ctx, void** out_device_buf, int32_t wait);
 #define MI_BUF_BATCH_SETS_INDEXED 11
 int32_t mi_device_buffer(mi_ctx* ctx, uint32_t which, void** out_device_ptr, uint64_t* out_bytes);
 
-/* HIP-event timing on the context's stream (torch.cuda.Event only sees torch's stream). */
-int32_t mi_timer_begin(mi_ctx* ctx);
-int32_t mi_timer_end(mi_ctx* ctx, float* out_ms); /* synchronises */
-
-/* Per-kernel HIP-event profile: while enabled every launch is bracketed by events.
- * mi_profile_read synchronises and returns, for kernel id k < *inout_n: launches[k], total_ms[k].
- * mi_profile_kernel_name(k) names the ids (NULL past the end). */
-int32_t mi_profile_enable(mi_ctx* ctx, int32_t enabled);
-/* Restricts the profile to the kernels whose id bit is set in kernel_mask (default: all).  Bracketing only
- * the dominant kernel keeps the event overhead out of a timed region. */
-int32_t mi_profile_filter(mi_ctx* ctx, uint64_t kernel_mask);
-/* Times only every n-th launch of each selected kernel (a timed launch costs several microseconds of host time). */
-int32_t mi_profile_sample(mi_ctx* ctx, uint32_t every_n);
-/* Times at most the first first_n launches of each selected kernel after mi_profile_enable(1) (0 = no limit): a
- * timed dispatch is fenced off from its neighbours by its timestamp packets (the same isolation rocprofv3's kernel
- * trace imposes), which costs ~5 us of GPU time per launch -- a burst keeps that out of the rest of a timed region. */
-int32_t mi_profile_burst(mi_ctx* ctx, uint32_t first_n);
-int32_t mi_profile_read(mi_ctx* ctx, uint32_t* inout_n, uint64_t* launches, double* total_ms);
-const char* mi_profile_kernel_name(uint32_t k);
+/* Bench / test instrumentation (HIP-event timers, the per-kernel profile, planner and trace hooks) is declared in
+ * bevy_mi355x_debug.h: exported by the same library, not part of the drop-in boundary. */
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,52 @@
+/*
+ * bevy_mi355x_debug.h -- instrumentation and test hooks of libbevy_mi355x.so.
+ *
+ * NOT part of the drop-in boundary (include/bevy_mi355x.h): nothing here replaces anything in Bevy, and a plugin never calls it.
+ * bench.py times kernels through the mi_profile_* / mi_timer_* functions, the tests force planner decisions and read
+ * device-side probes through mi_debug_*.  Same conventions as the main header (int32 status, any thread, one call at a time).
+ */
+#ifndef BEVY_MI355X_DEBUG_H
+#define BEVY_MI355X_DEBUG_H
+
+#include "bevy_mi355x.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* HIP-event timing on the context's stream (torch.cuda.Event only sees torch's stream). */
+int32_t mi_timer_begin(mi_ctx* ctx);
+int32_t mi_timer_end(mi_ctx* ctx, float* out_ms); /* synchronises */
+
+/* Per-kernel HIP-event profile: while enabled every launch is bracketed by events.
+ * mi_profile_read synchronises and returns, for kernel id k < *inout_n: launches[k], total_ms[k].
+ * mi_profile_kernel_name(k) names the ids (NULL past the end). */
+int32_t mi_profile_enable(mi_ctx* ctx, int32_t enabled);
+/* Restricts the profile to the kernels whose id bit is set in kernel_mask (default: all).  Bracketing only
+ * the dominant kernel keeps the event overhead out of a timed region. */
+int32_t mi_profile_filter(mi_ctx* ctx, uint64_t kernel_mask);
+/* Times only every n-th launch of each selected kernel (a timed launch costs several microseconds of host time). */
+int32_t mi_profile_sample(mi_ctx* ctx, uint32_t every_n);
+/* Times at most the first first_n launches of each selected kernel after mi_profile_enable(1) (0 = no limit): a
+ * timed dispatch is fenced off from its neighbours by its timestamp packets (the same isolation rocprofv3's kernel
+ * trace imposes), which costs ~5 us of GPU time per launch -- a burst keeps that out of the rest of a timed region. */
+int32_t mi_profile_burst(mi_ctx* ctx, uint32_t first_n);
+int32_t mi_profile_read(mi_ctx* ctx, uint32_t* inout_n, uint64_t* launches, double* total_ms);
+const char* mi_profile_kernel_name(uint32_t k);
+
+/* Which tile kernel the NEXT mi_upload_hierarchy plans for: 0 = light tiles wherever every subtree fits (default), 1 = always the
+ * big tiles, 2 = always light tiles, 3 = as 0 with the streamed-level thresholds at their test values (2^20 / 2^21 rows). */
+int32_t mi_debug_set_tile_mode(mi_ctx* ctx, int32_t mode);
+/* Per-tile phase timestamps of the light tile kernel (8 x s_memrealtime, 100 MHz, per tile of the first launch).  enable != 0
+ * allocates the buffer (mi_propagate then fills it every frame); out != NULL copies n_tiles x 8 stamps out; enable == 0 with
+ * out == NULL switches the stamps off again. */
+int32_t mi_debug_tree_trace(mi_ctx* ctx, int32_t enable, unsigned long long* out, uint32_t n_tiles);
+/* The shape of the current tile plan: launches per mi_propagate, tiles, chain tiles (self-evaluated ancestor chains), bands. */
+int32_t mi_debug_tile_plan(mi_ctx* ctx, uint32_t* out_launches, uint32_t* out_tiles, uint32_t* out_chain_tiles, uint32_t* out_bands);
+/* The device's restatement of glibc logf (view_z_to_z_slice, crates/bevy_light/src/cluster/assign.rs:1057) over n inputs. */
+int32_t mi_debug_logf(mi_ctx* ctx, const float* in, float* out, uint32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEVY_MI355X_DEBUG_H */

@@ -22,8 +22,8 @@ def lib():
     return api.load_library()
 
 
-def header_symbols():
-    text = open(os.path.join(ROOT, "include", "bevy_mi355x.h")).read()
+def header_symbols(name="bevy_mi355x.h"):
+    text = open(os.path.join(ROOT, "include", name)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", text)))
 
@@ -35,6 +35,20 @@ def test_library_exports_every_header_symbol(lib):
         assert hasattr(lib, s), f"{s} declared in include/bevy_mi355x.h but not exported"
     assert sorted(api.ABI_SYMBOLS) == syms, "bevy_amd.api.ABI_SYMBOLS out of sync with the header"
     assert lib.mi_abi_version() == 1
+
+
+def test_debug_header_declares_every_hook(lib):
+    """Instrumentation and test hooks live in include/bevy_mi355x_debug.h, not in the boundary header -- and nothing the library
+    exports under the mi_ prefix is declared in neither."""
+    import subprocess
+    dbg = header_symbols("bevy_mi355x_debug.h")
+    assert sorted(api.DEBUG_SYMBOLS) == dbg
+    for s in dbg:
+        assert hasattr(lib, s), f"{s} declared in include/bevy_mi355x_debug.h but not exported"
+    assert not set(dbg) & set(header_symbols()), "a debug hook is also declared in the boundary header"
+    out = subprocess.run(["nm", "-D", "--defined-only", api.lib_path()], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("mi_")}
+    assert exported == set(dbg) | set(header_symbols()), exported ^ (set(dbg) | set(header_symbols()))
 
 
 def test_header_cites_reference_lines():

@@ -66,6 +66,7 @@ def parse():
                     help="frame: mi_propagate_and_cull, then mi_cluster_assign_resident behind it (default: ONE call with "
                          "MI_CULL_WITH_CLUSTERS, the assignment concurrent with the frame kernel on the cluster stream)")
     ap.add_argument("--concurrent-clusters", action="store_true", help="frame: add MI_CULL_CLUSTERS_CONCURRENT")
+    ap.add_argument("--sphere-path", type=int, default=0, help="flat_static / frame: 0 = world-sphere cull path from the second quiet frame (default), 1 = never (k_frame<0> over GlobalTransform + Aabb), 2 = at once")
     ap.add_argument("--tile-mode", type=int, default=0, help="tree: 0 = tile kernel chosen by size, 1 = big tiles, 2 / 3 = light tiles (5 / 6 waves per SIMD)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true")
@@ -284,25 +285,36 @@ def build_flat_static(ctx, args):
     import bevy_amd as B
     from bevy_amd import api, workloads as W
     n = args.entities or 1_000_000
-    sc = W.many_cubes(n)
+    sc = W.many_cubes(n, radius=500.0 * (n / 1_000_000.0) ** (1.0 / 3.0))  # configs[3]'s scaling: the density stays
     ctx.resize(n)
     ctx.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
     ctx.upload_bounds(sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"])
     ctx.upload_changed(np.zeros(n, np.uint8))  # the change column exists from here on: only marked rows are recomputed
     ctx.propagate(B.PROPAGATE_ALL_DIRTY)
-    frames = [api.PreparedFrusta(camera_frusta(1, f)) for f in range(N_FRAMES)]
+    n_views = args.views or 1
+    frames = [api.PreparedFrusta(camera_frusta(n_views, f)) for f in range(N_FRAMES)]
     more = 0 if args.inline_compaction else B.CULL_MORE_FRAMES  # as in the flat workload: frames back to back
+    sphere = getattr(args, "sphere_path", 0) != 1
+    ctx.debug_set_sphere_path(getattr(args, "sphere_path", 0))
 
     def step(f):
         ctx.propagate(0)
         ctx.cull(frames[f % N_FRAMES], flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME | more)
-    config = {"workload": f"many_cubes-shaped flat scene, {n} entities, 1 frustum, 0 % of the Transforms dirty: mi_propagate "
-                          "(no row was marked since the last one: returns without a launch) + mi_cull (G resident) + VisibleEntities "
-                          "compaction" + (" deferred into the next frame's launch" if more else ""),
-              "baseline_config": "BASELINE.json configs[1], 0 %-dirty run", "entities": n, "deferred_compaction": bool(more)}
-    # cull with G resident: read G 48 + Aabb 24 + flags 1 + layers 4 + vv 1, write vv 1 + masks
-    return Workload("flat_static", step, n, flat_bytes_per_entity(1, False), "k_cull", config,
-                    "entities/sec through propagate+cull", "entities/s", kernels=["k_cull", "k_compact_fast"])
+    # byte models per row.  G resident (k_frame<0>): read G 48 + Aabb 24 + flags 1 + layers 4 + vv 1, write vv 1 + masks.
+    # World-sphere column (k_frame_sph): read (cw, sr) 16 + flags 1 + layers 4 + vv 1, write vv 1 + masks; GlobalTransform and half
+    # extents only for the rows that pass a sphere test (a few percent: not counted -- the PMC traffic shows them).
+    wr = 1.0 + (n_views + 1) / 8.0 + n_views / 64.0
+    models = {"world_sphere_column": 22.0 + wr, "global_transform_resident": flat_bytes_per_entity(n_views, False)}
+    config = {"workload": f"many_cubes-shaped flat scene, {n} entities, {n_views} frustum(s), 0 % of the Transforms dirty: mi_propagate "
+                          "(no row was marked since the last one: returns without a launch) + mi_cull ("
+                          + ("the world-sphere column: 16 B per row instead of GlobalTransform + Aabb, k_frame_sph" if sphere else "G resident, k_frame<0>")
+                          + ") + VisibleEntities compaction" + (" deferred into the next frame's launch" if more else ""),
+              "baseline_config": "BASELINE.json configs[1], 0 %-dirty run", "entities": n, "views": n_views, "deferred_compaction": bool(more),
+              "sphere_path": sphere, "bytes_per_row_models": models}
+    wl = Workload("flat_static", step, n, models["world_sphere_column" if sphere else "global_transform_resident"], "k_cull", config,
+                  "entities/sec through propagate+cull", "entities/s", kernels=["k_cull", "k_compact_fast"])
+    wl.kernel_name = "k_frame_sph<false>" if sphere else "k_frame<0>"
+    return wl
 
 
 def build_batching(ctx, args):
@@ -402,6 +414,14 @@ def measure(ctx, wl, steps, warmup, n_blocks=0, profile_all=False, barrier=None,
     info = {"host_enqueue_ms_per_step": round(1e3 * float(np.median(enq)) / steps, 5),
             "profiled_blocks_ms_per_step": round(1e3 * float(np.median(prof_t)) / steps, 5)}
     return np.array(times), prof, info
+
+
+def with_args(args, **kw):
+    import copy
+    a = copy.copy(args)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
 
 
 def block_stats(times, steps):
@@ -741,7 +761,9 @@ def main():
                  ("flat_10m_4views", lambda c: build_flat(c, args, 0, 1, [], 10_000_000, 4, "sharded")),
                  ("flat_10m_1view", lambda c: build_flat(c, args, 0, 1, [], 10_000_000, 1, "flat")),
                  ("tree", lambda c: build_tree(c, args)), ("lights", lambda c: build_lights(c, args)),
-                 ("flat_static", lambda c: build_flat_static(c, args)), ("batching", lambda c: build_batching(c, args))]
+                 ("flat_static", lambda c: build_flat_static(c, args)), ("flat_static_no_sphere_column", lambda c: build_flat_static(c, with_args(args, sphere_path=1))),
+                 ("flat_static_10m_4views", lambda c: build_flat_static(c, with_args(args, entities=10_000_000, views=4))),
+                 ("batching", lambda c: build_batching(c, args))]
         for name, builder in specs:
             c2 = api.Context(local_rank, stream.cuda_stream)
             with torch.cuda.stream(stream):

@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libbevy_mi355x.so")
+# MI_LIB_VARIANT=<name>: an experiment build (bevy_amd.build.build(variant=name)) for A/B measurements on the GPU box
+_LIB_PATH = os.path.join(_HERE, "libbevy_mi355x_%s.so" % os.environ["MI_LIB_VARIANT"] if os.environ.get("MI_LIB_VARIANT") else "libbevy_mi355x.so")
 
 MI_OK = 0
 MI_ERR_INVALID_ARG = -1
@@ -161,7 +162,7 @@ ABI_SYMBOLS = [
 # include/bevy_mi355x_debug.h: instrumentation and test hooks, exported by the same library, not part of the boundary
 DEBUG_SYMBOLS = [
     "mi_timer_begin", "mi_timer_end", "mi_profile_enable", "mi_profile_filter", "mi_profile_sample", "mi_profile_burst", "mi_profile_read",
-    "mi_profile_kernel_name", "mi_debug_set_tile_mode", "mi_debug_tree_trace", "mi_debug_tile_plan", "mi_debug_logf",
+    "mi_profile_kernel_name", "mi_debug_set_tile_mode", "mi_debug_tree_trace", "mi_debug_tile_plan", "mi_debug_logf", "mi_debug_set_sphere_path",
 ]
 
 
@@ -328,6 +329,8 @@ class Context:
         # test harness only: run a whole test session under one tile kernel (the library itself reads no environment)
         if os.environ.get("MI_TEST_TILE_MODE"):
             self.debug_set_tile_mode(int(os.environ["MI_TEST_TILE_MODE"]))
+        if os.environ.get("MI_TEST_SPHERE_PATH"):  # ... or with the world-sphere cull path forced on (2) / off (1)
+            self.debug_set_sphere_path(int(os.environ["MI_TEST_SPHERE_PATH"]))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -749,6 +752,10 @@ class Context:
         v = [C.c_uint32(0) for _ in range(4)]
         self._ck(self._lib.mi_debug_tile_plan(self._h, *[C.byref(x) for x in v]))
         return dict(launches=v[0].value, tiles=v[1].value, chain_tiles=v[2].value, bands=v[3].value)
+
+    def debug_set_sphere_path(self, mode):
+        """0 = the world-sphere cull path from the second quiet frame on (default), 1 = never, 2 = at once (test / bench hook)."""
+        self._ck(self._lib.mi_debug_set_sphere_path(self._h, int(mode)))
 
     def debug_logf(self, x):
         x = _f32(x)

@@ -18,6 +18,13 @@ SOURCES = ["kernels_flat.hip", "kernels_tree.hip", "kernels_cluster.hip", "kerne
 HEADERS = ["kernels.h", "ctx.h", "glam_math.h", "visibility_rule.h", "cluster_walk.h", "cluster_fill.h", os.path.join("..", "..", "include", "bevy_mi355x.h"), os.path.join("..", "..", "include", "bevy_mi355x_debug.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
+# Per-file flags.  -fno-slp-vectorize on the row kernels: the SLP vectorizer pairs their independent f32 multiplies / adds into
+# v_pk_mul_f32 / v_pk_add_f32 (same IEEE results), and the operand pairs it has to assemble for them (v_pk_mov_b32 copies of
+# values that stay live in their scalar form as well) cost 8 - 12 VGPRs per kernel: k_frame 70 -> 62 (7 -> 8 waves per SIMD),
+# k_frame with the riding cluster walk 72 -> 64, k_propagate_fans<false> 72 -> 60 (7 -> 8), k_cluster_walk 59 -> 49
+# (tools/kernel_resources.py; profiles/r03a/kernel_resources.md).  The batching kernels are integer code and keep it.
+FILE_FLAGS = {"kernels_flat.hip": ["-fno-slp-vectorize"], "kernels_tree.hip": ["-fno-slp-vectorize"],
+              "kernels_cluster.hip": ["-fno-slp-vectorize"]}
 
 
 def hipcc():
@@ -43,20 +50,28 @@ def up_to_date():
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build(force=False, verbose=False):
-    """One object per translation unit (only the stale ones are recompiled, all of them in parallel), then one link."""
+def build(force=False, verbose=False, variant=None, file_flags=None, defines=()):
+    """One object per translation unit (only the stale ones are recompiled, all of them in parallel), then one link.
+    variant: build bevy_amd/libbevy_mi355x_<variant>.so with `file_flags` (instead of FILE_FLAGS) and extra -D `defines` -- A/B
+    experiments on the GPU box (the test harness loads it when MI_LIB_VARIANT=<variant>); the product is the default build."""
+    lib, obj_dir, fflags = LIB, OBJ_DIR, FILE_FLAGS
+    if variant:
+        lib = os.path.join(HERE, f"libbevy_mi355x_{variant}.so")
+        obj_dir = os.path.join(HERE, "build", variant)
+        fflags = FILE_FLAGS if file_flags is None else file_flags
+        force = True
     if not force and up_to_date():
         return LIB
-    os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(obj_dir, exist_ok=True)
     hdr_t = max(os.path.getmtime(d) for d in _deps())
     procs, objs = [], []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
-        obj = os.path.join(OBJ_DIR, src + ".o")
+        obj = os.path.join(obj_dir, src + ".o")
         objs.append(obj)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(sp), hdr_t):
             continue
-        cmd = [hipcc()] + CFLAGS + ["-x", "hip", "-c", sp, "-o", obj]
+        cmd = [hipcc()] + CFLAGS + fflags.get(src, []) + [f"-D{d}" for d in defines] + ["-x", "hip", "-c", sp, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -70,14 +85,14 @@ def build(force=False, verbose=False):
             sys.stderr.write(out)
     if failed:
         raise RuntimeError("hipcc failed building libbevy_mi355x.so")
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib]
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         sys.stderr.write(res.stdout + res.stderr)
         raise RuntimeError("hipcc failed linking libbevy_mi355x.so")
-    return LIB
+    return lib
 
 
 HOST_TEST_SRC = os.path.join(HERE, "..", "tests", "cpp", "host_systems_test.cpp")

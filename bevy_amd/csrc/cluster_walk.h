@@ -347,7 +347,8 @@ __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, cons
     uint32_t* touched_bits = reinterpret_cast<uint32_t*>(planes + (PLANES_IN_LDS ? 4u * (nx + ny + nz) : 0u));
     uint32_t* n_touched = touched_bits + ((RC + 31u) >> 5);
     uint32_t* z_range = n_touched + 1;  // [0] min, [1] max z slice any object of the block may touch, [2] the block's first pair slot
-    uint16_t* touched_list = reinterpret_cast<uint16_t*>(z_range + 3);
+    uint32_t* types_present = z_range + 3;  // bit t: some object of the block that is in view has type t
+    uint16_t* touched_list = reinterpret_cast<uint16_t*>(z_range + 4);
     const float* xp = PLANES_IN_LDS ? planes : v.x_planes;
     const float* yp = PLANES_IN_LDS ? planes + 4u * nx : v.y_planes;
     const float* zp = PLANES_IN_LDS ? planes + 4u * (nx + ny) : v.z_planes;
@@ -363,7 +364,10 @@ __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, cons
         for (uint32_t i = threadIdx.x; i <= ((RC + 31u) >> 5); i += CLUSTER_BLOCK) touched_bits[i] = 0u;  // bits + counter
     };
     if (threadIdx.x < 48u) type_rows[threadIdx.x] = 0u;
-    if (CHUNKED && threadIdx.x == 0) { z_range[0] = 0xFFFFFFFFu; z_range[1] = 0u; }
+    if (threadIdx.x == 0) {
+        *types_present = 0u;
+        if (CHUNKED) { z_range[0] = 0xFFFFFFFFu; z_range[1] = 0u; }
+    }
     if (!CHUNKED) clear_chunk();
     // the three plane tables are contiguous in device memory (x | y | z)
     if (PLANES_IN_LDS)
@@ -378,7 +382,9 @@ __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, cons
         ow = object_setup<SPOTS>(v, o, obj, &far_z);
         my_lo = ow.minc[2];
         my_hi = ow.maxc[2];
-        atomicOr(&type_rows[(ow.type < 6u ? ow.type : 5u) * 8u + word], bit);
+        const uint32_t ty = ow.type < 6u ? ow.type : 5u;
+        atomicOr(&type_rows[ty * 8u + word], bit);
+        if (!((*types_present >> ty) & 1u)) atomicOr(types_present, 1u << ty);
         // farthest_z = farthest_z.max(this_object_far_z), starting from 0.0 (assign.rs:421,561):
         // only positive values can raise it, and positive floats order like their bit patterns.
         if (far_z > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(w.farthest_z), __float_as_uint(far_z));
@@ -427,6 +433,7 @@ __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, cons
         if (threadIdx.x == 0) z_range[2] = nt ? atomicAdd(w.pair_total, nt) : 0u;
         __syncthreads();
         const uint32_t pair_base = z_range[2];
+        const uint32_t tp = *types_present;
         for (uint32_t i = threadIdx.x; i < nt; i += CLUSTER_BLOCK) {
             const uint32_t r = touched_list[i];
             const uint32_t c = CHUNKED ? (r / zc) * dz + z0 + (r % zc) : r;
@@ -437,12 +444,20 @@ __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, cons
             for (uint32_t k = 0; k < 8; ++k) cnt += __popc(m[k]);
             w.block_counts[(size_t)c * w.row_stride + bx] = (uint16_t)cnt;  // cluster-major
             atomicAdd(&w.totals[c], cnt);
+            // per-type counts.  Nearly every block holds objects of ONE type (the gather order groups them): the row's popcount
+            // is that type's count.  Otherwise the type masks are read per row -- through a volatile pointer: hoisted out of
+            // this loop they are 48 registers, which was the register peak of the whole walk (88 VGPRs).
+            if ((tp & (tp - 1u)) == 0u) {
+                if (cnt) atomicAdd(&w.counts[6u * c + (uint32_t)__ffs(tp) - 1u], cnt);
+            } else {
+                const volatile uint32_t* tr = type_rows;
+                for (uint32_t t = 0; t < 6; ++t) {
+                    if (!((tp >> t) & 1u)) continue;
+                    uint32_t tc = 0;
 #pragma unroll
-            for (uint32_t t = 0; t < 6; ++t) {
-                uint32_t tc = 0;
-#pragma unroll
-                for (uint32_t k = 0; k < 8; ++k) tc += __popc(m[k] & type_rows[t * 8u + k]);
-                if (tc) atomicAdd(&w.counts[6u * c + t], tc);
+                    for (uint32_t k = 0; k < 8; ++k) tc += __popc(m[k] & tr[t * 8u + k]);
+                    if (tc) atomicAdd(&w.counts[6u * c + t], tc);
+                }
             }
             const uint32_t slot = pair_base + i;
             w.pair_cb[slot] = (bx << 12) | c;

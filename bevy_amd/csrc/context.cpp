@@ -419,6 +419,7 @@ static int32_t cull_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, u
     ctx->cl_derive_resident = !PROPAGATE;
     if (clusters_concurrent && (rc = cluster_assign_launch(ctx, true, nullptr))) return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
     bool clusters_ride = false;
+    bool use_sph = false, sph_all_stale = false;
     {
         // a deferred cluster fill of the previous frame rides along (it must be enqueued before this frame's walk anyway) ...
         ClusterFillJob fill_job{};
@@ -437,8 +438,30 @@ static int32_t cull_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, u
             if (have_fill) launch_cluster_fill(fill_job.w, fill_job.n_clusters, fill_job.n_objects, ctx->stream);
             return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
         }
+        // The world-sphere path (k_frame_sph) for frames that rewrite no or few GlobalTransforms: cull only, or the
+        // changed-rows frame.  Camera views only.  A column that is not current is rebuilt by the SECOND such frame in a row: a
+        // caller that rewrites every GlobalTransform every frame (mi_propagate(ALL_DIRTY) + mi_cull) never pays for it.
+        if ((!PROPAGATE || changed_col) && ctx->sph_mode != 1 && n_views <= SPH_MAX_VIEWS && ctx->n) {
+            bool camera_views_only = true;
+            for (uint32_t v = 0; v < n_views; ++v) camera_views_only = camera_views_only && !(views[v].flags & MI_VIEW_FLAG_SHADOW);
+            if (camera_views_only && (ctx->sph_state != mi_ctx::SPH_INVALID || ctx->sph_mode == 2 || ctx->sph_quiet >= 1)) {
+                if (ctx->sph.bytes < (size_t)ctx->cap * 16) ctx->sph_state = mi_ctx::SPH_INVALID;  // (re)allocated below: nothing in it
+                if ((rc = ensure(ctx, ctx->sph, (size_t)ctx->cap * 16))) {
+                    if (have_fill) launch_cluster_fill(fill_job.w, fill_job.n_clusters, fill_job.n_objects, ctx->stream);
+                    return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
+                }
+                use_sph = true;
+                sph_all_stale = ctx->sph_state == mi_ctx::SPH_INVALID;
+            }
+        }
         ProfScope ps(ctx, PROPAGATE ? K_FLAT_PROPAGATE_CULL : K_CULL);
-        const hipError_t e = PROPAGATE ? launch_flat_propagate_cull(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p,
+        const bool stale_from_mask = use_sph && ctx->sph_state == mi_ctx::SPH_EXCEPT_CHANGED;
+        const hipError_t e = use_sph ? launch_frame_sph(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p, n_views, vo, seg,
+                                                        (flags & (MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME)) | (PROPAGATE ? CULL_BEGIN_FRAME : 0u), prev,
+                                                        have_fill ? &fill_job : nullptr, clusters_ride ? &walk_job : nullptr, ctx->stream, changed_col,
+                                                        (float*)ctx->sph.p, stale_from_mask && !ctx->g_chg_in_bytes ? ctx->g_chg_bits : nullptr,
+                                                        stale_from_mask && ctx->g_chg_in_bytes ? ctx->g_changed_bytes : nullptr, sph_all_stale)
+                             : PROPAGATE ? launch_flat_propagate_cull(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p,
                                                                     n_views, vo, seg, flags & MI_CULL_END_FRAME, prev, have_fill ? &fill_job : nullptr,
                                                                     clusters_ride ? &walk_job : nullptr, ctx->stream, changed_col)
                                        : launch_cull(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p, n_views, vo,
@@ -458,6 +481,14 @@ static int32_t cull_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, u
             return frame_abort(ctx, MI_ERR_DEVICE, prev, prev_has_job, prev_job);
         }
     }
+    // the world-sphere column after this frame
+    if (use_sph) ctx->sph_state = mi_ctx::SPH_VALID;  // stale rows (and the rows this frame propagated) were refreshed
+    else if (PROPAGATE && !changed_col) {             // every GlobalTransform rewritten
+        ctx->sph_state = mi_ctx::SPH_INVALID;
+        ctx->sph_quiet = 0;
+    } else if (PROPAGATE)                              // k_frame<2>: the rewritten rows are this frame's change mask
+        ctx->sph_state = ctx->sph_state == mi_ctx::SPH_VALID ? mi_ctx::SPH_EXCEPT_CHANGED : mi_ctx::SPH_INVALID;
+    if (!PROPAGATE || changed_col) ++ctx->sph_quiet;
     if (prev && ctx->n == 0) HIP_TRY(ctx, launch_compact_fast(*prev, ctx->stream));  // no frame kernel to ride in
     if (prev_has_job) exchange_push(ctx, prev_job);  // the launch that publishes the previous frame's signal is submitted
     if ((rc = run_compaction(ctx, vo, seg, flags))) return rc;
@@ -550,7 +581,7 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
                     ctx->bt_kind, ctx->bt_cpu_bin, ctx->bt_bucket};
     for (void* p : cols)
         if (p) hipFree(p);
-    DevBuf* bufs[] = {&ctx->order, &ctx->chains, &ctx->snap, &ctx->tree_trace, &ctx->inh_bits, &ctx->sparse_cnt, &ctx->sparse_rows, &ctx->sparse_total, &ctx->sparse_g, &ctx->parent_idx, &ctx->node_flags, &ctx->tiles, &ctx->views,
+    DevBuf* bufs[] = {&ctx->sph, &ctx->order, &ctx->chains, &ctx->snap, &ctx->tree_trace, &ctx->inh_bits, &ctx->sparse_cnt, &ctx->sparse_rows, &ctx->sparse_total, &ctx->sparse_g, &ctx->parent_idx, &ctx->node_flags, &ctx->tiles, &ctx->views,
                       &ctx->block_counts, &ctx->seg_bases, &ctx->out_keys, &ctx->cl_pos,
                       &ctx->cl_type, &ctx->cl_layers, &ctx->cl_dir, &ctx->cl_sincos, &ctx->cl_planes, &ctx->cl_spheres,
                       &ctx->bt_set_indexed, &ctx->bt_table_off, &ctx->bt_table, &ctx->bt_meta_off, &ctx->bt_meta, &ctx->bt_rows_a, &ctx->bt_rows_b,
@@ -631,6 +662,7 @@ int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
     }
     ctx->bt_resolve = true;
     ctx->changed_maybe = true;
+    if (n_rows != ctx->n) ctx->sph_state = mi_ctx::SPH_INVALID;
     const uint32_t old_cap_rows = ctx->cap;
     if (n_rows > ctx->cap) {
         uint32_t new_cap = std::max<uint64_t>(n_rows, std::min<uint64_t>((uint64_t)ctx->cap * 3 / 2, 0xFFFFFF00ull));
@@ -788,6 +820,7 @@ int32_t mi_upload_global_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t n,
     int32_t rc = check_rows(ctx, first_row, n, "mi_upload_global_transforms");
     if (rc) return rc;
     ctx->snap_valid = false;  // externally supplied values: the tree path re-snapshots its owner rows
+    ctx->sph_state = mi_ctx::SPH_INVALID;
     return upload(ctx, ctx->g + 12 * (size_t)first_row, global12, (size_t)n * 48);
 }
 
@@ -797,6 +830,7 @@ int32_t mi_upload_bounds(mi_ctx* ctx, uint32_t first_row, uint32_t n, const floa
     if (!aabb_center || !aabb_half) return fail(ctx, MI_ERR_INVALID_ARG, "mi_upload_bounds: NULL column");
     int32_t rc = check_rows(ctx, first_row, n, "mi_upload_bounds");
     if (rc) return rc;
+    ctx->sph_state = mi_ctx::SPH_INVALID;  // the spheres are functions of the bounds
     if ((rc = upload(ctx, ctx->c + 3 * (size_t)first_row, aabb_center, (size_t)n * 12))) return rc;
     if ((rc = upload(ctx, ctx->h + 3 * (size_t)first_row, aabb_half, (size_t)n * 12))) return rc;
     if (flags) {
@@ -898,10 +932,19 @@ int32_t mi_propagate(mi_ctx* ctx, uint32_t flags) {
             if (ctx->g_changed_bytes) HIP_TRY(ctx, hipMemsetAsync(ctx->g_changed_bytes, 0, ctx->n, ctx->stream));
             ctx->g_chg_in_bytes = false;
             ctx->g_chg_maybe = false;
+            // a change mask no cull frame has consumed yet is gone: the sphere column no longer knows which of its rows are stale
+            if (ctx->sph_state == mi_ctx::SPH_EXCEPT_CHANGED) ctx->sph_state = mi_ctx::SPH_INVALID;
         }
         return MI_OK;
     }
     ctx->g_chg_maybe = true;
+    // the world-sphere column: the rows this propagate rewrites are the ones its change mask will flag
+    if (all_dirty) {
+        ctx->sph_state = mi_ctx::SPH_INVALID;
+        ctx->sph_quiet = 0;
+    } else {
+        ctx->sph_state = ctx->sph_state == mi_ctx::SPH_VALID ? mi_ctx::SPH_EXCEPT_CHANGED : mi_ctx::SPH_INVALID;
+    }
     Columns c = columns_of(ctx);
     const uint32_t n0 = ctx->have_hierarchy ? ctx->level_offsets[1] : ctx->n;
     const uint8_t* tree_bits = nullptr;
@@ -1516,6 +1559,15 @@ const char* mi_profile_kernel_name(uint32_t k) {
                                                "k_clear_u32", "k_inherit", "k_batch_hist", "k_batch_plan", "k_batch_emit",
                                                "k_batch_scan", "k_batch_scatter", "k_batch_bounds", "k_batch_sorted", "k_propagate_stream"};
     return k < K_NUM_KERNELS ? names[k] : nullptr;
+}
+
+// test / bench hook: the world-sphere path of the cull-only and changed-rows frames (k_frame_sph): 0 = used from the second
+// frame in a row that rewrites no or few GlobalTransforms (default), 1 = never, 2 = at once
+int32_t mi_debug_set_sphere_path(mi_ctx* ctx, int32_t mode) {
+    ENTER(ctx);
+    if (mode < 0 || mode > 2) return fail(ctx, MI_ERR_INVALID_ARG, "mi_debug_set_sphere_path: mode %d", mode);
+    ctx->sph_mode = mode;
+    return MI_OK;
 }
 
 // test hook: device logf probe (include/bevy_mi355x_debug.h; tests/test_gpu_cluster.py::test_device_logf_matches_libm)

@@ -90,6 +90,18 @@ struct mi_ctx {
     // the last propagate may hold set bits
     bool changed_maybe = true, g_chg_maybe = true;
 
+    // ---- world-sphere column (k_frame_sph): (affine * aabb.center, |M3 * half_extents|) per row, the bounding sphere
+    // check_visibility tests first.  Valid relative to the GlobalTransform / bounds columns as `sph_state` says.
+    enum SphState : uint32_t {
+        SPH_INVALID = 0,        // nothing is known to be current
+        SPH_EXCEPT_CHANGED = 1, // current but for the rows the GlobalTransform change mask of the last propagate flags
+        SPH_VALID = 2
+    };
+    DevBuf sph;
+    uint32_t sph_state = SPH_INVALID;
+    uint32_t sph_quiet = 0;  // cull frames since the last wholesale GlobalTransform rewrite (the column is rebuilt on the second)
+    int32_t sph_mode = 0;    // mi_debug_set_sphere_path: 0 = as described, 1 = never, 2 = rebuild at once
+
     // ---- views / visibility ----
     DevBuf views;
     uint32_t n_views = 0;

@@ -169,6 +169,13 @@ hipError_t launch_level0_propagate(const Columns& c, uint32_t n_level0, const ui
 hipError_t launch_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views,
                        const VisibilityOut& out, const SegOut& seg, uint32_t flags, const CompactFastArgs* prev,
                        const struct ClusterFillJob* fill, const struct ClusterWalkJob* walk, hipStream_t stream);
+// The frame over the world-sphere column (kernels_flat.hip, k_frame_sph): camera views only, n_views <= 32.  changed == nullptr:
+// cull only; else the changed-rows frame (flags carry CULL_BEGIN_FRAME).  sph: [n] (cw, sr); stale rows as ballot words or bytes.
+hipError_t launch_frame_sph(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views, const VisibilityOut& out,
+                            const SegOut& seg, uint32_t flags, const CompactFastArgs* prev, const struct ClusterFillJob* fill,
+                            const struct ClusterWalkJob* walk, hipStream_t stream, const uint8_t* changed, float* sph, const uint64_t* stale_bits,
+                            const uint8_t* stale_bytes, bool all_stale);
+constexpr uint32_t SPH_MAX_VIEWS = 32;
 hipError_t launch_upload_trs(const float* pinned_src, float* t, float* r, float* s, uint32_t first_row, uint32_t n,
                              hipStream_t stream);
 hipError_t launch_upload_trs_indexed(const uint32_t* pinned_src, uint32_t n, float* t, float* r, float* s, uint8_t* changed,
@@ -376,7 +383,7 @@ struct ClusterWalkJob {
 // bytes of the LDS arena a walking workgroup needs for chunks of zc z slices (layout: cluster_walk.h)
 inline size_t cluster_walk_lds_bytes(uint32_t dxy, uint32_t zc, uint32_t n_planes, bool planes_in_lds) {
     const size_t RC = (size_t)dxy * zc;
-    return (RC * 8u + 48u) * sizeof(uint32_t) + (planes_in_lds ? (size_t)n_planes * 16u : 0u) + ((RC + 31u) / 32u + 4u) * 4u + RC * 2u + 16u;
+    return (RC * 8u + 48u) * sizeof(uint32_t) + (planes_in_lds ? (size_t)n_planes * 16u : 0u) + ((RC + 31u) / 32u + 5u) * 4u + RC * 2u + 16u;
 }
 constexpr size_t FRAME_KERNEL_LDS_BYTES = (4096 + 4) * 4;  // k_frame's static LDS: the arena a riding walk / fill workgroup gets
 constexpr uint32_t CLUSTER_FILL_RIDE_BLOCKS = 128;  // workgroups a riding fill adds to the frame kernel's grid

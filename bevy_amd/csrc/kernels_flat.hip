@@ -150,6 +150,82 @@ __device__ __forceinline__ void compact_fast_block(const CompactFastArgs& a, uin
 }
 
 // ---------------------------------------------------------------------------------------------
+// What a frame kernel leaves behind per view and per row, shared by k_frame and k_frame_sph.
+// emit_view: one view's packed mask word (one wave64 ballot = one 64-bit word, lane 0 stores it) and the per-(view, class)
+// wave counts / segment masks the VisibleEntities compaction consumes.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void emit_view(uint32_t v, bool vis, bool any_live, uint32_t lane, uint32_t wave, uint32_t cmask,
+                                          const VisibilityOut& out, const SegOut& seg) {
+    const unsigned long long m = __ballot(vis);
+    if (lane == 0 && any_live) out.bitmask[v * out.words_per_view + out.word_offset + wave] = m;
+    if (seg.wave_cnt) {
+        if (!seg.class_mask) {
+            if (lane == 0 && any_live) seg.wave_cnt[(size_t)v * seg.n_waves + wave] = (uint8_t)__popcll(m);
+        } else {
+            for (uint32_t k = 0; k < seg.n_classes; ++k) {
+                const unsigned long long mk = __ballot(vis && ((cmask >> seg.class_bits[k]) & 1u));
+                if (lane == 0 && any_live) {
+                    const size_t s = (size_t)v * seg.n_classes + k;
+                    seg.seg_mask[s * seg.seg_words + wave] = mk;
+                    seg.wave_cnt[s * seg.n_waves + wave] = (uint8_t)__popcll(mk);
+                }
+            }
+        }
+    }
+}
+// The ViewVisibility byte of a row: reset (mod.rs:270-274), set_visible (:290-306), gpu-culling rows (:884-903),
+// mark_newly_hidden (:908-918), and the wave's change-tick word.
+__device__ __forceinline__ void view_visibility_tail(const Columns& c, uint32_t row, bool live, bool any_live, uint32_t lane, uint32_t wave,
+                                                     uint32_t fl, uint32_t vv0, bool any, uint32_t fl_frame) {
+    const bool ncc = (fl & 0x10u) != 0;
+    uint32_t cur = vv0;
+    bool vv_changed = false;
+    if (live) {
+        if ((fl_frame & CULL_BEGIN_FRAME) && !ncc) cur = (cur & 1u) << 1;
+        if (any && !(cur & 1u)) {
+            vv_changed = !(cur & 2u);
+            cur |= 1u;
+        }
+        if (fl_frame & CULL_END_FRAME) {
+            if (ncc) {
+                const uint32_t nv = (fl & 0x01u) ? 3u : 0u;
+                if (nv != cur) { cur = nv; vv_changed = true; }
+            } else if ((cur & 3u) == 2u) {
+                cur = 0u;
+                vv_changed = true;
+            }
+        }
+        if (cur != vv0) c.view_visibility[row] = (uint8_t)cur;
+    }
+    const unsigned long long chg = __ballot(vv_changed);
+    if (lane == 0 && any_live) {
+        if (fl_frame & CULL_BEGIN_FRAME) c.vv_changed_bits[wave] = chg;
+        else if (chg) atomicOr(reinterpret_cast<unsigned long long*>(&c.vv_changed_bits[wave]), chg);
+    }
+}
+// The extra workgroups at the head of a frame kernel's grid (they overlap the ramp-up instead of lengthening the tail: 0.5 us per
+// frame at 1 M rows): the deferred VisibleEntities compaction of the previous frame, the deferred fill of the previous frame's
+// light-cluster assignment, and the walk of THIS frame's.  Returns true in a workgroup that was one of them.
+template <bool WITH_WALK>
+__device__ __forceinline__ bool frame_riders(uint32_t n_tiles, const CompactFastArgs& prev, uint32_t prev_gx, uint32_t n_compact, uint32_t n_fill,
+                                             const ClusterFillJob& fill, const ClusterWalkJob& walk, const ViewSet& vs, uint32_t* lds_raw) {
+    const uint32_t n_extra = gridDim.x - n_tiles;
+    if (blockIdx.x >= n_extra) return false;
+    const uint32_t id = blockIdx.x;
+    if (id < n_compact) {
+        if (prev.signal && id == 0 && threadIdx.x == 0)  // multi-GPU exchange: the previous frame's masks are complete
+            __hip_atomic_store(prev.signal, prev.signal_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        compact_fast_block(prev, id % prev_gx, id / prev_gx, prev_gx);
+    } else if (id < n_compact + n_fill) {
+        cluster_fill_block(fill.w, fill.n_clusters, fill.n_objects, id - n_compact, n_fill, lds_raw, lds_raw + 4096);
+    } else if constexpr (WITH_WALK) {
+        // this frame's light-cluster walk: independent of the rows below (it re-derives the lights' ViewVisibility itself)
+        cluster_walk_block<true, true, false>(walk.view, walk.objs, walk.w, vs, walk.zc, id - n_compact - n_fill, lds_raw);
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
 // The frame kernel.  PROPAGATE = true : G = From(T) for every row (sync_simple_transforms, all dirty),
 //                                       written once and never re-read (fused flat path);
 //                    PROPAGATE = false: G is read from the resident column (after mi_propagate).
@@ -176,24 +252,8 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
     // offsets of up to 4096 clusters and the four wave totals of their scan -- or the arena of a riding cluster-walk workgroup
     __shared__ __attribute__((aligned(16))) uint32_t lds_raw[4096 + 4];
     float4 (*lds_g)[192] = reinterpret_cast<float4 (*)[192]>(lds_raw);
-    // extra workgroups at the head of the grid (they overlap the ramp-up instead of lengthening the tail: 0.5 us per frame at
-    // 1 M rows): the deferred VisibleEntities compaction of the previous frame, the deferred fill of the previous frame's
-    // light-cluster assignment, and the walk of THIS frame's
+    if (frame_riders<WITH_WALK>(n_tiles, prev, prev_gx, n_compact, n_fill, fill, walk, vs, lds_raw)) return;
     const uint32_t n_extra = gridDim.x - n_tiles;
-    if (blockIdx.x < n_extra) {
-        const uint32_t id = blockIdx.x;
-        if (id < n_compact) {
-            if (prev.signal && id == 0 && threadIdx.x == 0)  // multi-GPU exchange: the previous frame's masks are complete
-                __hip_atomic_store(prev.signal, prev.signal_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            compact_fast_block(prev, id % prev_gx, id / prev_gx, prev_gx);
-        } else if (id < n_compact + n_fill) {
-            cluster_fill_block(fill.w, fill.n_clusters, fill.n_objects, id - n_compact, n_fill, lds_raw, lds_raw + 4096);
-        } else if constexpr (WITH_WALK) {
-            // this frame's light-cluster walk: independent of the rows below (it re-derives the lights' ViewVisibility itself)
-            cluster_walk_block<true, true, false>(walk.view, walk.objs, walk.w, vs, walk.zc, id - n_compact - n_fill, lds_raw);
-        }
-        return;
-    }
     const uint32_t row = (blockIdx.x - n_extra) * 256u + threadIdx.x;
     const bool live = row < c.n;
     const uint32_t wave = row >> 6;
@@ -267,55 +327,178 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
         const bool vis = live && !ncc &&
                          row_visible_in_view(g, center, half, fl, emask, c.range_start_end != nullptr, range_lo, range_hi, vp);
         any = any || vis;
-        const unsigned long long m = __ballot(vis);
-        if (lane == 0 && any_live) out.bitmask[v * out.words_per_view + out.word_offset + wave] = m;
-        if (seg.wave_cnt) {
-            if (!seg.class_mask) {
-                if (lane == 0 && any_live) seg.wave_cnt[(size_t)v * seg.n_waves + wave] = (uint8_t)__popcll(m);
-            } else {
-                for (uint32_t k = 0; k < seg.n_classes; ++k) {
-                    const unsigned long long mk = __ballot(vis && ((cmask >> seg.class_bits[k]) & 1u));
-                    if (lane == 0 && any_live) {
-                        const size_t s = (size_t)v * seg.n_classes + k;
-                        seg.seg_mask[s * seg.seg_words + wave] = mk;
-                        seg.wave_cnt[s * seg.n_waves + wave] = (uint8_t)__popcll(mk);
-                    }
-                }
-            }
-        }
+        emit_view(v, vis, any_live, lane, wave, cmask, out, seg);
     }
-    // ViewVisibility byte: reset (mod.rs:270-274), set_visible (:290-306), gpu-culling rows (:884-903),
-    // mark_newly_hidden (:908-918)
-    uint32_t cur = vv0;
-    bool vv_changed = false;
-    if (live) {
-        if ((fl_frame & CULL_BEGIN_FRAME) && !ncc) cur = (cur & 1u) << 1;
-        if (any && !(cur & 1u)) {
-            vv_changed = !(cur & 2u);
-            cur |= 1u;
-        }
-        if (fl_frame & CULL_END_FRAME) {
-            if (ncc) {
-                const uint32_t nv = (fl & 0x01u) ? 3u : 0u;
-                if (nv != cur) { cur = nv; vv_changed = true; }
-            } else if ((cur & 3u) == 2u) {
-                cur = 0u;
-                vv_changed = true;
-            }
-        }
-        if (cur != vv0) c.view_visibility[row] = (uint8_t)cur;
-    }
-    const unsigned long long chg = __ballot(vv_changed);
-    const unsigned long long lv = __ballot(live);
-    if (lane == 0 && any_live) {
-        if (fl_frame & CULL_BEGIN_FRAME) c.vv_changed_bits[wave] = chg;
-        else if (chg) atomicOr(reinterpret_cast<unsigned long long*>(&c.vv_changed_bits[wave]), chg);
-        if (PROPAGATE) c.g_changed_bits[wave] = lv;  // plain assignment bumps every written row's tick (systems.rs:62)
+    view_visibility_tail(c, row, live, any_live, lane, wave, fl, vv0, any, fl_frame);
+    if (PROPAGATE) {  // plain assignment bumps every written row's tick (systems.rs:62)
+        const unsigned long long lv = __ballot(live);
+        if (lane == 0 && any_live) c.g_changed_bits[wave] = lv;
     }
     if (PARTIAL) {
         const unsigned long long dm = __ballot(dirty);
         if (lane == 0 && any_live) c.g_changed_bits[wave] = dm;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The frame kernel over the WORLD-SPHERE column -- the frame a game mostly runs: few or no Transforms moved.
+//
+// check_visibility_cpu_culling tests a row's bounding sphere first (visibility/mod.rs:824-832): centre = affine * aabb.center,
+// radius = |M3 * half_extents| -- values that change only when the row's GlobalTransform (or Aabb) does.  The context keeps them as
+// a 16-byte column (cw.xyz, sr), the same bits the reference computes, and this kernel runs the five-plane sphere test of every
+// view on that column alone: 16 (sphere) + 1 (flags) + 4 (layers) + 1 (vv) = 22 B per row instead of 48 (G) + 24 (Aabb) + 6.
+// GlobalTransform and half extents are fetched only by the lanes that survive a sphere test and have an Aabb (intersects_obb,
+// :833-836: the OBB test shares the centre and the plane dot products, so only the relative radius is new).
+// Rows whose sphere is STALE -- their GlobalTransform changed since the column was written: the change mask of the last
+// propagate, as ballot words (flat path) or bytes (hierarchy path), or every row after something wholesale -- are refreshed
+// first, from the resident GlobalTransform (a wave that is stale as a whole takes the coalesced transpose).
+// PARTIAL (MI_CULL_CHANGED_ROWS): the rows whose Transform change byte is set are propagated here as well, exactly like
+// k_frame<2> (sync_simple_transforms' filter, systems.rs:45-50): G = From(T), stored, sphere refreshed, change word written.
+// Camera views only (the shadow-view kinds have no sphere pre-test): the host sends frames with shadow views to k_frame.
+// ---------------------------------------------------------------------------------------------
+struct SphereArgs {
+    float4* sph;                  // [n] (cw.x, cw.y, cw.z, sr)
+    const uint64_t* stale_bits;   // ballot words of the rows whose GlobalTransform changed since the column was current, or ...
+    const uint8_t* stale_bytes;   // ... a byte per row (hierarchy path); both nullptr = none
+    uint32_t all_stale;           // every row (first use, or after an all-dirty propagate / a bounds upload)
+};
+template <bool PARTIAL, bool INLINE_VIEWS, bool WITH_WALK>
+__global__ void __launch_bounds__(256) k_frame_sph(Columns c, ViewSet vs, const ViewParams* __restrict__ dviews, uint32_t n_views,
+                                                    VisibilityOut out, SegOut seg, uint32_t fl_frame, uint32_t n_tiles, CompactFastArgs prev,
+                                                    uint32_t prev_gx, uint32_t n_compact, uint32_t n_fill, ClusterFillJob fill,
+                                                    ClusterWalkJob walk, const uint8_t* __restrict__ changed, SphereArgs sa) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds_raw[4096 + 4];
+    float4 (*lds_g)[192] = reinterpret_cast<float4 (*)[192]>(lds_raw);
+    if (frame_riders<WITH_WALK>(n_tiles, prev, prev_gx, n_compact, n_fill, fill, walk, vs, lds_raw)) return;
+    const uint32_t n_extra = gridDim.x - n_tiles;
+    const uint32_t row = (blockIdx.x - n_extra) * 256u + threadIdx.x;
+    const bool live = row < c.n;
+    const uint32_t wave = row >> 6, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, wave_row0 = row & ~63u;
+    const bool any_live = wave_row0 < c.n;
+    const uint32_t rrow = live ? row : 0u;  // clamped: every load below is unconditional (one batch, no load behind a branch)
+
+    // ---- burst 1: what every row needs ----
+    float4 sp = sa.sph[rrow];
+    uint32_t fl = c.flags[rrow];
+    const uint32_t emask = c.layer_mask[rrow];
+    const uint32_t vv0 = c.view_visibility[rrow];
+    uint32_t cmask = 1u;
+    if (seg.class_mask) cmask = seg.class_mask[rrow];
+    bool dirty = false;
+    if (PARTIAL) dirty = live && changed[rrow] != 0;
+    bool stale = sa.all_stale != 0u;
+    if (sa.stale_bytes) stale = stale || sa.stale_bytes[rrow] != 0;
+    if (sa.stale_bits) stale = stale || ((sa.stale_bits[any_live ? wave : 0u] >> lane) & 1ull) != 0ull;
+    stale = (stale || dirty) && live;
+    if (!live) fl = 0u;
+    const bool has_aabb = (fl & 0x04u) != 0;
+
+    // ---- stale spheres: from the row's GlobalTransform (PARTIAL: from its Transform, which also becomes the GlobalTransform) ----
+    const unsigned long long stale_m = __ballot(stale), live_m = __ballot(live);
+    if (stale_m) {  // (wave-uniform)
+        Affine g = {};
+        const bool whole_wave = !PARTIAL && stale_m == live_m;
+        if (whole_wave) {  // three contiguous 1 KB wave rows through the wave-private transpose, as k_frame<0> reads them
+            const float4* src = reinterpret_cast<const float4*>(c.global) + 3ull * wave_row0;
+            const uint32_t lim = (c.n - wave_row0 < 64u ? c.n - wave_row0 : 64u) * 3u;
+            float4* lds_wave = lds_g[wv];
+#pragma unroll
+            for (uint32_t k = 0; k < 3u; ++k) {
+                const uint32_t i = k * 64u + lane;
+                lds_wave[i] = src[i < lim ? i : lim - 1u];
+            }
+            MI_WAVE_LDS_SYNC();
+            const float4 a = lds_wave[lane * 3u], b = lds_wave[lane * 3u + 1u], cc = lds_wave[lane * 3u + 2u];
+            g.m.x_axis = V3{a.x, a.y, a.z};
+            g.m.y_axis = V3{a.w, b.x, b.y};
+            g.m.z_axis = V3{b.z, b.w, cc.x};
+            g.t = V3{cc.y, cc.z, cc.w};
+        }
+        if (stale) {
+            if (PARTIAL && dirty) {
+                const V3 t = ld3(c.translation, row);
+                const V4 q = ld4(c.rotation, row);
+                const V3 sc = ld3(c.scale, row);
+                g = affine_from_srt(sc, q, t);
+                st_affine(c.global, row, g);
+            } else if (!whole_wave) {
+                g = ld_affine(c.global, row);
+            }
+            const V3 center = ld3(c.aabb_center, row), half = ld3(c.aabb_half, row);
+            // exactly the values row_visible_in_view computes (visibility_rule.h): Aabb -> (affine * center, |M3 * half|), a Sphere
+            // component as it is
+            const V3 cw = has_aabb ? transform_point(g, center) : center;
+            const float sr = has_aabb ? length3(mul(g.m, half)) : half.x;
+            sp = make_float4(cw.x, cw.y, cw.z, sr);
+            sa.sph[row] = sp;
+        }
+    }
+    if (PARTIAL) {
+        const unsigned long long dm = __ballot(dirty);
+        if (lane == 0 && any_live) c.g_changed_bits[wave] = dm;
+    }
+
+    // ---- stage 1, every view: InheritedVisibility, RenderLayers, VisibilityRange, the five-plane sphere test ----
+    const bool ncc = (fl & 0x10u) != 0;                     // NoCpuCulling rows are not in the cull query (mod.rs:771)
+    const bool base_ok = live && !ncc && (fl & 0x01u) != 0;  // InheritedVisibility
+    const bool bounded = (fl & (0x04u | 0x08u)) != 0 && !(fl & 0x02u);  // has an Aabb or a Sphere, and no NoFrustumCulling
+    const bool ranged = (fl & 0x20u) != 0 && c.range_start_end != nullptr;
+    float range_lo = 0.0f, range_hi = 0.0f;
+    V3 model = {};
+    if (__ballot(ranged)) {  // (rare)
+        if (ranged) {
+            const float2 r2 = reinterpret_cast<const float2*>(c.range_start_end)[row];
+            range_lo = r2.x;
+            range_hi = r2.y;
+            if ((fl & 0x40u) && has_aabb) model = V3{sp.x, sp.y, sp.z};  // transform_point(g, center): the sphere's centre
+            else model = ld3(c.global, row * 4u + 3u);                   // g.t: floats 9..11 of the row's 12 = the F3 at index 4 * row + 3
+        }
+    }
+    const V4 c4 = V4{sp.x, sp.y, sp.z, 1.0f};
+    const float sr = sp.w;
+    uint32_t pass = 0u, need = 0u;  // bit v: the row is (still) visible in view v / it still owes view v the OBB test
+    for (uint32_t v = 0; v < n_views; ++v) {
+        const ViewParams& vp = INLINE_VIEWS ? vs.v[v] : dviews[v];
+        bool vis = base_ok && (vp.layer_mask & emask) != 0;
+        if (ranged) {
+            bool in_range = false;
+            if ((vp.flags & (VIEW_RANGES | VIEW_RANGES_NO_ORIGIN)) == VIEW_RANGES) {
+                const float d = length3(V3{vp.position[0], vp.position[1], vp.position[2]} - model);
+                in_range = d >= range_lo && d < range_hi;
+            }
+            vis = vis && in_range;
+        }
+        const bool cull = bounded && !(vp.flags & VIEW_NO_CPU_CULLING);
+        bool inside = true;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const V4 pl = V4{vp.planes[4 * i], vp.planes[4 * i + 1], vp.planes[4 * i + 2], vp.planes[4 * i + 3]};
+            inside = inside && !(dot4(pl, c4) + sr <= 0.0f);
+        }
+        vis = vis && (inside || !cull);
+        if (vis) pass |= 1u << v;
+        if (vis && cull && has_aabb) need |= 1u << v;
+    }
+    // ---- stage 2, survivors with an Aabb: intersects_obb -- only here are GlobalTransform and half extents touched ----
+    if (__ballot(need != 0u)) {
+        if (need) {
+            const Affine g = ld_affine(c.global, row);
+            const V3 half = ld3(c.aabb_half, row);
+            for (uint32_t v = 0; v < n_views; ++v) {
+                if (!((need >> v) & 1u)) continue;
+                const ViewParams& vp = INLINE_VIEWS ? vs.v[v] : dviews[v];
+                bool inside = true;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    const V4 pl = V4{vp.planes[4 * i], vp.planes[4 * i + 1], vp.planes[4 * i + 2], vp.planes[4 * i + 3]};
+                    inside = inside && !(dot4(pl, c4) + aabb_relative_radius(half, xyz(pl), g.m) <= 0.0f);
+                }
+                if (!inside) pass &= ~(1u << v);
+            }
+        }
+    }
+    for (uint32_t v = 0; v < n_views; ++v) emit_view(v, ((pass >> v) & 1u) != 0, any_live, lane, wave, cmask, out, seg);
+    view_visibility_tail(c, row, live, any_live, lane, wave, fl, vv0, pass != 0u, fl_frame);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -602,6 +785,53 @@ static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, co
         MI_LAUNCH((k_frame<PROP, false, false>), grid, dim3(256), 0, stream, c, dummy, d_views, n_views, out, seg, flags, n_tiles, pa, prev_gx,
                   prev_blocks, fill_blocks, fj, wj, changed);
     }
+    return hipGetLastError();
+}
+// The frame over the world-sphere column (k_frame_sph): cull only (changed == nullptr) or the changed-rows frame.
+hipError_t launch_frame_sph(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views, const VisibilityOut& out,
+                            const SegOut& seg, uint32_t flags, const CompactFastArgs* prev, const ClusterFillJob* fill, const ClusterWalkJob* walk,
+                            hipStream_t stream, const uint8_t* changed, float* sph, const uint64_t* stale_bits, const uint8_t* stale_bytes,
+                            bool all_stale) {
+    if (c.n == 0) return hipSuccess;
+    const uint32_t n_tiles = blocks_for(c.n);
+    CompactFastArgs pa{};
+    uint32_t prev_gx = 1, prev_blocks = 0;
+    if (prev && prev->n && prev->n_segments) {
+        pa = *prev;
+        prev_gx = (((pa.n + 63u) >> 6) + 64u * compact_fast_steps(pa.n) - 1u) / (64u * compact_fast_steps(pa.n));
+        prev_blocks = prev_gx * pa.n_segments;
+    }
+    ClusterFillJob fj{};
+    uint32_t fill_blocks = 0;
+    if (fill) {
+        fj = *fill;
+        fill_blocks = CLUSTER_FILL_RIDE_BLOCKS;
+    }
+    ClusterWalkJob wj{};
+    uint32_t walk_blocks = 0;
+    if (walk && walk->n_blocks && n_views <= MAX_INLINE_VIEWS && views_inline) {
+        wj = *walk;
+        walk_blocks = wj.n_blocks;
+    }
+    SphereArgs sa{reinterpret_cast<float4*>(sph), stale_bits, stale_bytes, all_stale ? 1u : 0u};
+    const dim3 grid(n_tiles + prev_blocks + fill_blocks + walk_blocks);
+    const bool inl = n_views <= MAX_INLINE_VIEWS && views_inline;
+    ViewSet dummy = {};
+    const ViewSet& vsr = inl ? *views_inline : dummy;
+    const ViewParams* dv = inl ? nullptr : d_views;
+#define MI_SPH_LAUNCH(P, I, W) \
+    MI_LAUNCH((k_frame_sph<P, I, W>), grid, dim3(256), 0, stream, c, vsr, dv, n_views, out, seg, flags, n_tiles, pa, prev_gx, prev_blocks, \
+              fill_blocks, fj, wj, changed, sa)
+    if (changed) {
+        if (walk_blocks) MI_SPH_LAUNCH(true, true, true);
+        else if (inl) MI_SPH_LAUNCH(true, true, false);
+        else MI_SPH_LAUNCH(true, false, false);
+    } else {
+        if (walk_blocks) MI_SPH_LAUNCH(false, true, true);
+        else if (inl) MI_SPH_LAUNCH(false, true, false);
+        else MI_SPH_LAUNCH(false, false, false);
+    }
+#undef MI_SPH_LAUNCH
     return hipGetLastError();
 }
 hipError_t launch_flat_propagate_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views,

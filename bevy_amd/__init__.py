@@ -43,6 +43,7 @@ CULL_MORE_FRAMES = 0x4  # another cull frame follows at once: defer the compacti
 CULL_WITH_CLUSTERS = 0x8  # the frame also assigns the row-bound lights to clusters (MI_CULL_WITH_CLUSTERS)
 CULL_CLUSTERS_CONCURRENT = 0x10  # ... on the cluster stream, next to the frame kernel (MI_CULL_CLUSTERS_CONCURRENT)
 CULL_CHANGED_ROWS = 0x20  # mi_propagate_and_cull: only rows whose change byte is set are propagated (MI_CULL_CHANGED_ROWS)
+CULL_STATIC_OPT = 0x40  # mi_propagate_and_cull with a hierarchy: StaticTransformOptimizations for the propagate part (MI_CULL_STATIC_OPT)
 PROPAGATE_ALL_DIRTY = 0x1
 PROPAGATE_STATIC_OPT = 0x2
 NO_PARENT = 0xFFFFFFFF

@@ -76,37 +76,69 @@ VIEW_CLUSTER_BINDINGS_MAX_INDICES = 16384
 MAX_UNIFORM_BUFFER_CLUSTERABLE_OBJECTS = 204
 
 
+RESULTS_CHANGED_ROWS, RESULTS_CHANGED_GLOBALS, RESULTS_CLUSTERS, RESULTS_CLUSTER_INDICES, RESULTS_IN_PLACE = 0x1, 0x2, 0x4, 0x8, 0x10
+RESULTS_MAX_LISTS = 16
+
+
+class VisibleList(C.Structure):
+    """mi_visible_list"""
+    _fields_ = [("view", C.c_uint32), ("class_bit", C.c_uint32), ("capacity", C.c_uint32), ("count", C.c_uint32), ("rows", C.POINTER(C.c_uint32))]
+
+
 class FrameResults(C.Structure):
     """mi_frame_results"""
-    _fields_ = [("view", C.c_uint32), ("class_bit", C.c_uint32), ("changed_capacity", C.c_uint32), ("visible_capacity", C.c_uint32),
-                ("cluster_capacity", C.c_uint64),
-                ("changed_rows", C.POINTER(C.c_uint32)), ("changed_global12", C.POINTER(C.c_float)), ("visible_rows", C.POINTER(C.c_uint32)),
+    _fields_ = [("flags", C.c_uint32), ("n_lists", C.c_uint32), ("lists", C.POINTER(VisibleList)), ("changed_capacity", C.c_uint32),
+                ("reserved", C.c_uint32), ("cluster_capacity", C.c_uint64),
+                ("changed_rows", C.POINTER(C.c_uint32)), ("changed_global12", C.POINTER(C.c_float)),
                 ("cluster_offsets", C.POINTER(C.c_uint32)), ("cluster_counts", C.POINTER(C.c_uint32)), ("cluster_indices", C.POINTER(C.c_uint32)),
-                ("changed_count", C.c_uint32), ("visible_count", C.c_uint32), ("cluster_total", C.c_uint64), ("farthest_z", C.c_float),
-                ("reserved", C.c_uint32)]
+                ("changed_count", C.c_uint32), ("farthest_z", C.c_float), ("cluster_total", C.c_uint64)]
 
 
 class FrameResultBuffers:
-    """Caller-owned result slices for Context.download_frame_results, allocated once (an ECS system would hand in its own)."""
+    """The caller's side of Context.download_frame_results, allocated once (an ECS system would hand in its own slices).
+    changed_capacity / n_clusters = 0 switch those parts off; lists = [(view, class_bit, capacity), ...] (default: the camera's
+    list of class 0 when visible_capacity > 0).  in_place: no buffers -- the library returns pointers into its pinned window."""
 
-    def __init__(self, changed_capacity, visible_capacity, n_clusters, cluster_capacity, view=0, class_bit=0):
-        self.changed_rows = np.zeros(max(changed_capacity, 1), np.uint32)
-        self.changed_global = np.zeros(12 * max(changed_capacity, 1), np.float32)
-        self.visible_rows = np.zeros(max(visible_capacity, 1), np.uint32)
+    def __init__(self, changed_capacity, visible_capacity, n_clusters, cluster_capacity, view=0, class_bit=0, lists=None, in_place=False,
+                 want_rows=True, want_globals=True):
+        if lists is None:
+            lists = [(view, class_bit, visible_capacity)] if visible_capacity else []
+        self.in_place = in_place
         self.n_clusters = n_clusters
-        self.cluster_offsets = np.zeros(n_clusters + 1, np.uint32) if n_clusters else None
-        self.cluster_counts = np.zeros(6 * n_clusters, np.uint32) if n_clusters else None
-        self.cluster_indices = np.zeros(max(cluster_capacity, 1), np.uint32) if n_clusters else None
+        self.list_spec = list(lists)
         r = self.raw = FrameResults()
-        r.view, r.class_bit = view, class_bit
-        r.changed_capacity, r.visible_capacity, r.cluster_capacity = changed_capacity, visible_capacity, cluster_capacity if n_clusters else 0
-        r.changed_rows = _ptr(self.changed_rows, C.c_uint32) if changed_capacity else None
-        r.changed_global12 = _ptr(self.changed_global, C.c_float) if changed_capacity else None
-        r.visible_rows = _ptr(self.visible_rows, C.c_uint32) if visible_capacity else None
-        if n_clusters:
-            r.cluster_offsets = _ptr(self.cluster_offsets, C.c_uint32)
-            r.cluster_counts = _ptr(self.cluster_counts, C.c_uint32)
-            r.cluster_indices = _ptr(self.cluster_indices, C.c_uint32)
+        r.flags = ((RESULTS_CHANGED_ROWS if want_rows else 0) | (RESULTS_CHANGED_GLOBALS if want_globals else 0) if changed_capacity else 0) | \
+                  ((RESULTS_CLUSTERS | RESULTS_CLUSTER_INDICES) if n_clusters else 0) | (RESULTS_IN_PLACE if in_place else 0)
+        r.changed_capacity, r.cluster_capacity = changed_capacity, cluster_capacity if n_clusters else 0
+        self._lists = (VisibleList * max(len(lists), 1))()
+        self.list_rows = []
+        for k, (v, cb, cap) in enumerate(lists):
+            self._lists[k].view, self._lists[k].class_bit, self._lists[k].capacity = v, cb, cap
+            if not in_place:
+                a = np.zeros(max(cap, 1), np.uint32)
+                self.list_rows.append(a)
+                self._lists[k].rows = _ptr(a, C.c_uint32)
+        r.n_lists = len(lists)
+        r.lists = C.cast(self._lists, C.POINTER(VisibleList)) if lists else None
+        if not in_place:
+            self.changed_rows = np.zeros(max(changed_capacity, 1), np.uint32)
+            self.changed_global = np.zeros(12 * max(changed_capacity, 1), np.float32)
+            self.cluster_offsets = np.zeros(n_clusters + 1, np.uint32) if n_clusters else None
+            self.cluster_counts = np.zeros(6 * n_clusters, np.uint32) if n_clusters else None
+            self.cluster_indices = np.zeros(max(cluster_capacity, 1), np.uint32) if n_clusters else None
+            r.changed_rows = _ptr(self.changed_rows, C.c_uint32)
+            r.changed_global12 = _ptr(self.changed_global, C.c_float)
+            if n_clusters:
+                r.cluster_offsets = _ptr(self.cluster_offsets, C.c_uint32)
+                r.cluster_counts = _ptr(self.cluster_counts, C.c_uint32)
+                r.cluster_indices = _ptr(self.cluster_indices, C.c_uint32)
+
+    @property
+    def visible_rows(self):
+        return self.list_rows[0]
+
+    def list_count(self, k=0):
+        return int(self._lists[k].count)
 
 
 class View(C.Structure):
@@ -153,7 +185,7 @@ ABI_SYMBOLS = [
     "mi_download_visible_entities", "mi_cluster_view_dims", "mi_cluster_view_build",
     "mi_cluster_dimensions_fixed_z", "mi_cluster_assign", "mi_cluster_upload_objects", "mi_cluster_upload_view",
     "mi_cluster_assign_resident", "mi_cluster_download", "mi_cluster_download_bindings",
-    "mi_cluster_config_default", "mi_cluster_config_resolve", "mi_cluster_sort_truncate", "mi_cluster_bind_objects_to_rows",
+    "mi_cluster_config_default", "mi_cluster_config_resolve", "mi_cluster_sort_truncate", "mi_cluster_bind_objects_to_rows", "mi_cluster_bind_objects_to_row_list",
     "mi_cluster_assign_frame",
     "mi_batch_upload_rows", "mi_batch_upload_sets", "mi_batch_upload_row_bins", "mi_batch_upload_bins", "mi_batch_build", "mi_batch_build_phase",
     "mi_batch_sorted_build", "mi_batch_download_totals", "mi_batch_download", "mi_perspective_clip_from_view", "mi_compute_frustum",
@@ -482,14 +514,35 @@ class Context:
         return rows[:m], g[:12 * m]
 
     def download_frame_results(self, bufs):
-        """mi_download_frame_results into `bufs` (FrameResultBuffers); -> dict of views on its arrays, cut to the counts."""
-        self._ck(self._lib.mi_download_frame_results(self._h, C.byref(bufs.raw)))
+        """mi_download_frame_results into `bufs` (FrameResultBuffers); -> dict of views on its arrays (in place: on the library's
+        pinned window -- valid until the next call on this context), cut to the counts."""
+        rc = self._lib.mi_download_frame_results(self._h, C.byref(bufs.raw))
+        self._ck(rc)
         r = bufs.raw
-        out = {"changed_rows": bufs.changed_rows[:r.changed_count], "changed_global": bufs.changed_global[:12 * r.changed_count],
-               "visible_rows": bufs.visible_rows[:r.visible_count]}
+        want_rows, want_g = r.flags & RESULTS_CHANGED_ROWS, r.flags & RESULTS_CHANGED_GLOBALS
+
+        def arr(ptr, count, dtype):
+            if not ptr or not count:
+                return np.zeros(0, dtype)
+            return np.ctypeslib.as_array(ptr, shape=(count,)).view(dtype)
+        if bufs.in_place:
+            out = {"changed_rows": arr(r.changed_rows, r.changed_count if want_rows else 0, np.uint32),
+                   "changed_global": arr(r.changed_global12, 12 * r.changed_count if want_g else 0, np.float32),
+                   "lists": [arr(bufs._lists[k].rows, bufs._lists[k].count, np.uint32) for k in range(r.n_lists)]}
+        else:
+            out = {"changed_rows": bufs.changed_rows[:r.changed_count if want_rows else 0],
+                   "changed_global": bufs.changed_global[:12 * r.changed_count if want_g else 0],
+                   "lists": [bufs.list_rows[k][:bufs._lists[k].count] for k in range(r.n_lists)]}
+        out["visible_rows"] = out["lists"][0] if out["lists"] else np.zeros(0, np.uint32)
         if bufs.n_clusters:
-            out.update(cluster_offsets=bufs.cluster_offsets, cluster_counts=bufs.cluster_counts.reshape(bufs.n_clusters, 6),
-                       cluster_indices=bufs.cluster_indices[:r.cluster_total], cluster_total=int(r.cluster_total), farthest_z=float(r.farthest_z))
+            C_ = bufs.n_clusters
+            if bufs.in_place:
+                out.update(cluster_offsets=arr(r.cluster_offsets, C_ + 1, np.uint32), cluster_counts=arr(r.cluster_counts, 6 * C_, np.uint32).reshape(C_, 6),
+                           cluster_indices=arr(r.cluster_indices, int(r.cluster_total), np.uint32))
+            else:
+                out.update(cluster_offsets=bufs.cluster_offsets, cluster_counts=bufs.cluster_counts.reshape(C_, 6),
+                           cluster_indices=bufs.cluster_indices[:r.cluster_total])
+            out.update(cluster_total=int(r.cluster_total), farthest_z=float(r.farthest_z))
         return out
 
     def download_changed_mesh_inputs(self):
@@ -547,6 +600,10 @@ class Context:
 
     def cluster_bind_objects_to_rows(self, first_row, n_objects):
         self._ck(self._lib.mi_cluster_bind_objects_to_rows(self._h, first_row, n_objects))
+
+    def cluster_bind_objects_to_row_list(self, rows):
+        rows = _u32(rows)
+        self._ck(self._lib.mi_cluster_bind_objects_to_row_list(self._h, len(rows), _ptr(rows, C.c_uint32)))
 
     def cluster_assign_frame(self, config, history, camera_affine, clip_from_view, frustum, w, h, view_layer_mask=1,
                              max_indices=VIEW_CLUSTER_BINDINGS_MAX_INDICES):

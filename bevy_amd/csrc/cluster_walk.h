@@ -119,6 +119,10 @@ __device__ __forceinline__ V3 ld3c(const float* base, uint32_t row) {
 // derive mode: does this frame's propagate write the row's GlobalTransform (then it is From(Transform), the column being written
 // by the same launch) or does the row keep the resident one?  The fused all-rows frame writes every row; the changed-rows frame
 // the rows whose change byte is set; a cull-only frame none.
+// the row object `obj` is bound to: first_row + obj, or -- mi_cluster_bind_objects_to_row_list -- row_list[obj]
+__device__ __forceinline__ uint32_t object_row(const ClusterObjects& o, uint32_t obj) {
+    return o.row_list ? o.row_list[obj] : o.first_row + obj;
+}
 __device__ __forceinline__ bool object_row_is_propagated(const ClusterObjects& o, uint32_t row) {
     return !o.derive_resident && (!o.row_changed || o.row_changed[row] != 0);
 }
@@ -133,13 +137,13 @@ __device__ __forceinline__ Affine object_row_affine(const ClusterObjects& o, uin
 // their row's GlobalTransform (point lights: GlobalTransform::from_translation(transform.translation()), :198).
 __device__ __forceinline__ float4 object_sphere(const ClusterObjects& o, uint32_t obj) {
     float4 pr = reinterpret_cast<const float4*>(o.pos_range)[obj];
-    if (o.derive && object_row_is_propagated(o, o.first_row + obj)) {
-        const V3 t = ld3c(o.row_translation, o.first_row + obj);
+    if (o.derive && object_row_is_propagated(o, object_row(o, obj))) {
+        const V3 t = ld3c(o.row_translation, object_row(o, obj));
         pr.x = t.x;
         pr.y = t.y;
         pr.z = t.z;
     } else if (o.row_global) {
-        const float* g = o.row_global + 12ull * (o.first_row + obj);
+        const float* g = o.row_global + 12ull * object_row(o, obj);
         pr.x = g[9];
         pr.y = g[10];
         pr.z = g[11];
@@ -169,8 +173,8 @@ __device__ __forceinline__ bool derive_row_visible(const ClusterObjects& o, cons
 __device__ __forceinline__ bool object_in_view(const ClusterViewDev& v, const ClusterObjects& o, const ViewSet& views, uint32_t obj) {
     // the gather's `if view_visibility.get()`, assign.rs:194
     if (o.derive) {
-        if (!derive_row_visible(o, views, o.first_row + obj)) return false;
-    } else if (o.row_vv && !(o.row_vv[o.first_row + obj] & 1u)) {
+        if (!derive_row_visible(o, views, object_row(o, obj))) return false;
+    } else if (o.row_vv && !(o.row_vv[object_row(o, obj)] & 1u)) {
         return false;
     }
     const float4 pr = object_sphere(o, obj);
@@ -242,7 +246,7 @@ __device__ __forceinline__ ObjectWalk object_setup(const ClusterViewDev& v, cons
     if (SPOTS && ow.type == 1u) {  // spot light, :563-573
         V3 d;
         if (o.row_global || o.derive) {  // GlobalTransform::back() = (matrix3 * Vec3::Z).normalize(), global_transform.rs:62-68,206
-            const Affine ga = object_row_affine(o, o.first_row + obj);
+            const Affine ga = object_row_affine(o, object_row(o, obj));
             const V3 z = mul(ga.m, V3{0.0f, 0.0f, 1.0f});
             d = z * f_div(1.0f, f_sqrt((z.x * z.x + z.y * z.y) + z.z * z.z));
         } else {
@@ -347,8 +351,7 @@ __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, cons
     uint32_t* touched_bits = reinterpret_cast<uint32_t*>(planes + (PLANES_IN_LDS ? 4u * (nx + ny + nz) : 0u));
     uint32_t* n_touched = touched_bits + ((RC + 31u) >> 5);
     uint32_t* z_range = n_touched + 1;  // [0] min, [1] max z slice any object of the block may touch, [2] the block's first pair slot
-    uint32_t* types_present = z_range + 3;  // bit t: some object of the block that is in view has type t
-    uint16_t* touched_list = reinterpret_cast<uint16_t*>(z_range + 4);
+    uint16_t* touched_list = reinterpret_cast<uint16_t*>(z_range + 3);
     const float* xp = PLANES_IN_LDS ? planes : v.x_planes;
     const float* yp = PLANES_IN_LDS ? planes + 4u * nx : v.y_planes;
     const float* zp = PLANES_IN_LDS ? planes + 4u * (nx + ny) : v.z_planes;
@@ -364,10 +367,7 @@ __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, cons
         for (uint32_t i = threadIdx.x; i <= ((RC + 31u) >> 5); i += CLUSTER_BLOCK) touched_bits[i] = 0u;  // bits + counter
     };
     if (threadIdx.x < 48u) type_rows[threadIdx.x] = 0u;
-    if (threadIdx.x == 0) {
-        *types_present = 0u;
-        if (CHUNKED) { z_range[0] = 0xFFFFFFFFu; z_range[1] = 0u; }
-    }
+    if (CHUNKED && threadIdx.x == 0) { z_range[0] = 0xFFFFFFFFu; z_range[1] = 0u; }
     if (!CHUNKED) clear_chunk();
     // the three plane tables are contiguous in device memory (x | y | z)
     if (PLANES_IN_LDS)
@@ -382,9 +382,7 @@ __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, cons
         ow = object_setup<SPOTS>(v, o, obj, &far_z);
         my_lo = ow.minc[2];
         my_hi = ow.maxc[2];
-        const uint32_t ty = ow.type < 6u ? ow.type : 5u;
-        atomicOr(&type_rows[ty * 8u + word], bit);
-        if (!((*types_present >> ty) & 1u)) atomicOr(types_present, 1u << ty);
+        atomicOr(&type_rows[(ow.type < 6u ? ow.type : 5u) * 8u + word], bit);
         // farthest_z = farthest_z.max(this_object_far_z), starting from 0.0 (assign.rs:421,561):
         // only positive values can raise it, and positive floats order like their bit patterns.
         if (far_z > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(w.farthest_z), __float_as_uint(far_z));
@@ -433,7 +431,6 @@ __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, cons
         if (threadIdx.x == 0) z_range[2] = nt ? atomicAdd(w.pair_total, nt) : 0u;
         __syncthreads();
         const uint32_t pair_base = z_range[2];
-        const uint32_t tp = *types_present;
         for (uint32_t i = threadIdx.x; i < nt; i += CLUSTER_BLOCK) {
             const uint32_t r = touched_list[i];
             const uint32_t c = CHUNKED ? (r / zc) * dz + z0 + (r % zc) : r;
@@ -444,20 +441,17 @@ __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, cons
             for (uint32_t k = 0; k < 8; ++k) cnt += __popc(m[k]);
             w.block_counts[(size_t)c * w.row_stride + bx] = (uint16_t)cnt;  // cluster-major
             atomicAdd(&w.totals[c], cnt);
-            // per-type counts.  Nearly every block holds objects of ONE type (the gather order groups them): the row's popcount
-            // is that type's count.  Otherwise the type masks are read per row -- through a volatile pointer: hoisted out of
-            // this loop they are 48 registers, which was the register peak of the whole walk (88 VGPRs).
-            if ((tp & (tp - 1u)) == 0u) {
-                if (cnt) atomicAdd(&w.counts[6u * c + (uint32_t)__ffs(tp) - 1u], cnt);
-            } else {
-                const volatile uint32_t* tr = type_rows;
-                for (uint32_t t = 0; t < 6; ++t) {
-                    if (!((tp >> t) & 1u)) continue;
-                    uint32_t tc = 0;
+            // (The compiler hoists the 48 type-mask words out of this loop into registers: they are the register peak of the walk,
+            // 88 VGPRs.  Reading them per row instead brings the walk to 63 and the frame kernel that carries it from 5 to 7 waves
+            // per SIMD -- and measured SLOWER: metric frame 26.3 against 24.8 us, walk kernel 17.1 against 15.2 (profiles/r03b).  The
+            // walk is a chain of dependent round trips, not a throughput problem: with the high-water mark at 88 the scheduler
+            // spends registers on overlapping the loads of the whole kernel; at 63 it schedules for occupancy nobody needs.)
 #pragma unroll
-                    for (uint32_t k = 0; k < 8; ++k) tc += __popc(m[k] & tr[t * 8u + k]);
-                    if (tc) atomicAdd(&w.counts[6u * c + t], tc);
-                }
+            for (uint32_t t = 0; t < 6; ++t) {
+                uint32_t tc = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < 8; ++k) tc += __popc(m[k] & type_rows[t * 8u + k]);
+                if (tc) atomicAdd(&w.counts[6u * c + t], tc);
             }
             const uint32_t slot = pair_base + i;
             w.pair_cb[slot] = (bx << 12) | c;

@@ -387,8 +387,6 @@ template <bool PROPAGATE>
 static int32_t cull_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint32_t flags) {
     // validate before anything changes: a failed call must leave the previous frame's deferred compaction in place
     if (!views || n_views == 0) return fail(ctx, MI_ERR_INVALID_ARG, "mi_cull: views NULL or n_views == 0");
-    if (PROPAGATE && ctx->have_hierarchy)
-        return fail(ctx, MI_ERR_NOT_READY, "mi_propagate_and_cull is the flat fast path; a hierarchy is uploaded -- use mi_propagate + mi_cull");
     if (!PROPAGATE && (flags & MI_CULL_CHANGED_ROWS))
         return fail(ctx, MI_ERR_INVALID_ARG, "MI_CULL_CHANGED_ROWS belongs to mi_propagate_and_cull (mi_cull does not propagate)");
     if ((flags & MI_CULL_WITH_CLUSTERS) && (!ctx->cl_rows_bound || !ctx->cl_have_view))
@@ -588,7 +586,7 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
                       &ctx->bt_hist, &ctx->bt_set_count, &ctx->bt_set_scan, &ctx->bt_counters, &ctx->bt_wi[0], &ctx->bt_wi[1], &ctx->bt_md[0],
                       &ctx->bt_md[1], &ctx->bt_bs[0], &ctx->bt_bs[1], &ctx->bt_records, &ctx->bt_totals, &ctx->bt_bucket_desc, &ctx->bt_meta_out,
                       &ctx->bt_inst[0], &ctx->bt_inst[1], &ctx->bt_plan, &ctx->bt_unb, &ctx->bt_items, &ctx->bt_sorted_scratch, &ctx->bt_batches,
-                      &ctx->cl_remap, &ctx->cl_bind_oc, &ctx->cl_bind_idx, &ctx->cl_block_counts, &ctx->cl_pair_cb, &ctx->cl_pair_mask, &ctx->cl_acc,
+                      &ctx->cl_row_list, &ctx->cl_remap, &ctx->cl_bind_oc, &ctx->cl_bind_idx, &ctx->cl_block_counts, &ctx->cl_pair_cb, &ctx->cl_pair_mask, &ctx->cl_acc,
                       &ctx->cl_offsets, &ctx->cl_indices, &ctx->cl_scalars};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
@@ -663,6 +661,7 @@ int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
     ctx->bt_resolve = true;
     ctx->changed_maybe = true;
     if (n_rows != ctx->n) ctx->sph_state = mi_ctx::SPH_INVALID;
+    if (n_rows < ctx->n && ctx->cl_rows_listed) ctx->cl_rows_bound = false;  // a listed row may be gone: the caller binds again
     const uint32_t old_cap_rows = ctx->cap;
     if (n_rows > ctx->cap) {
         uint32_t new_cap = std::max<uint64_t>(n_rows, std::min<uint64_t>((uint64_t)ctx->cap * 3 / 2, 0xFFFFFF00ull));
@@ -1046,7 +1045,18 @@ int32_t mi_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_mas
 
 int32_t mi_propagate_and_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint32_t flags) {
     ENTER(ctx);
-    return cull_frame<true>(ctx, views, n_views, flags);
+    if (ctx->have_hierarchy) {
+        // With a hierarchy the frame is the tile launches of mi_propagate with the cull behind them: the same call for the
+        // caller (and no host wait in between), G written once and read once.  (Flat rows have it in one kernel.)
+        if (!views || n_views == 0) return fail(ctx, MI_ERR_INVALID_ARG, "mi_cull: views NULL or n_views == 0");
+        if ((flags & MI_CULL_WITH_CLUSTERS) && (!ctx->cl_rows_bound || !ctx->cl_have_view))
+            return fail(ctx, MI_ERR_NOT_READY, "MI_CULL_WITH_CLUSTERS needs mi_cluster_bind_objects_to_rows and mi_cluster_upload_view first");
+        const uint32_t pf = ((flags & MI_CULL_CHANGED_ROWS) ? 0u : MI_PROPAGATE_ALL_DIRTY) | ((flags & MI_CULL_STATIC_OPT) ? MI_PROPAGATE_STATIC_OPT : 0u);
+        const int32_t rc = mi_propagate(ctx, pf);
+        if (rc) return rc;
+        return cull_frame<false>(ctx, views, n_views, (flags & ~(MI_CULL_CHANGED_ROWS | MI_CULL_STATIC_OPT)) | MI_CULL_BEGIN_FRAME);
+    }
+    return cull_frame<true>(ctx, views, n_views, flags & ~MI_CULL_STATIC_OPT);
 }
 
 int32_t mi_propagate_and_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_masks, const uint8_t* view_flags,
@@ -1171,26 +1181,43 @@ int32_t mi_download_changed_global_transforms(mi_ctx* ctx, uint32_t* out_rows, f
 }
 
 namespace {
-// several device -> host copies, one wait: the pieces land in the pinned arena and are copied out after the wait
+// Room for `bytes` more in the staging arena WITHOUT a wrap in the middle of what follows: pointers handed out after this stay
+// valid together (results delivered in place live there until the caller's next call).
+int32_t stage_reserve(mi_ctx* ctx, size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (ctx->stage_used + bytes <= ctx->stage_bytes) return MI_OK;
+    void* st = nullptr;
+    int32_t rc = stage_alloc(ctx, bytes, &st);  // wraps (and grows) now
+    if (rc) return rc;
+    ctx->stage_used -= bytes;                   // ... and gives the room back
+    return MI_OK;
+}
+// several device -> host copies, one wait: the pieces land in the pinned arena and are copied out after the wait -- or, in-place
+// mode, stay there and the caller gets their addresses
 struct BatchedDownload {
     struct Piece { void* dst; void* stage; size_t bytes; };
     std::vector<Piece> pieces;
-    int32_t add(mi_ctx* ctx, void* dst, const void* src, size_t bytes) {
-        if (!bytes || !dst) return MI_OK;
+    bool in_place = false;
+    // dst: where the caller wants the bytes; in place: *out_ptr receives the address in the arena instead
+    int32_t add(mi_ctx* ctx, void* dst, const void* src, size_t bytes, void** out_ptr = nullptr) {
+        if (!bytes || (!dst && !out_ptr)) return MI_OK;
         void* st = nullptr;
         int32_t rc;
         // the arena wraps (and is reused from its start) when it is full: hand out what is parked in it first
+        // (in-place results reserved their room up front -- stage_reserve -- so this never fires for them)
         if (ctx->stage_used + ((bytes + 255) & ~(size_t)255) > ctx->stage_bytes && (rc = finish(ctx))) return rc;
         rc = stage_alloc(ctx, bytes, &st);
         if (rc) return rc;
         HIP_TRY(ctx, hipMemcpyAsync(st, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-        pieces.push_back({dst, st, bytes});
+        if (out_ptr) *out_ptr = st;
+        pieces.push_back({out_ptr ? nullptr : dst, st, bytes});
         return MI_OK;
     }
     int32_t finish(mi_ctx* ctx) {
         if (pieces.empty()) return MI_OK;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        for (auto& p : pieces) memcpy(p.dst, p.stage, p.bytes);
+        for (auto& p : pieces)
+            if (p.dst) memcpy(p.dst, p.stage, p.bytes);
         pieces.clear();
         return MI_OK;
     }
@@ -1200,53 +1227,81 @@ struct BatchedDownload {
 int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
     ENTER(ctx);
     if (!io) return fail(ctx, MI_ERR_INVALID_ARG, "mi_download_frame_results: NULL");
-    io->changed_count = io->visible_count = 0;
+    io->changed_count = 0;
     io->cluster_total = 0;
     io->farthest_z = 0.0f;
-    const bool want_changed = (io->changed_rows || io->changed_global12) && ctx->n;
-    const bool want_visible = io->visible_rows != nullptr;
-    const bool want_clusters = io->cluster_offsets || io->cluster_counts || io->cluster_indices;
+    const bool in_place = (io->flags & MI_RESULTS_IN_PLACE) != 0;
+    const bool want_rows = (io->flags & MI_RESULTS_CHANGED_ROWS) != 0, want_g = (io->flags & MI_RESULTS_CHANGED_GLOBALS) != 0;
+    const bool want_changed = (want_rows || want_g) && ctx->n;
+    const bool want_indices = (io->flags & MI_RESULTS_CLUSTER_INDICES) != 0;
+    const bool want_clusters = want_indices || (io->flags & MI_RESULTS_CLUSTERS) != 0;
+    const uint32_t n_lists = io->n_lists;
+    if (n_lists > MI_RESULTS_MAX_LISTS) return fail(ctx, MI_ERR_INVALID_ARG, "mi_download_frame_results: %u lists (at most %u)", n_lists, MI_RESULTS_MAX_LISTS);
+    if (n_lists && !io->lists) return fail(ctx, MI_ERR_INVALID_ARG, "mi_download_frame_results: lists NULL");
+    for (uint32_t l = 0; l < n_lists; ++l) io->lists[l].count = 0;
+    if (!in_place) {
+        if ((want_rows && !io->changed_rows) || (want_g && !io->changed_global12) || (want_clusters && (!io->cluster_offsets || !io->cluster_counts)) ||
+            (want_indices && !io->cluster_indices))
+            return fail(ctx, MI_ERR_INVALID_ARG, "mi_download_frame_results: a requested part has no buffer (or pass MI_RESULTS_IN_PLACE)");
+        for (uint32_t l = 0; l < n_lists; ++l)
+            if (!io->lists[l].rows && io->lists[l].capacity) return fail(ctx, MI_ERR_INVALID_ARG, "mi_download_frame_results: list %u has no buffer", l);
+    } else {
+        io->changed_rows = nullptr;
+        io->changed_global12 = nullptr;
+        io->cluster_offsets = io->cluster_counts = io->cluster_indices = nullptr;
+        for (uint32_t l = 0; l < n_lists; ++l) io->lists[l].rows = nullptr;
+    }
     int32_t rc;
     // ---- everything that has to run before the counts are final ----
-    uint32_t seg = 0;
-    bool visible_empty = false;
-    if (want_visible) {
+    const uint32_t* list_total[PACK_MAX_LISTS] = {nullptr};
+    const uint32_t* list_rows[PACK_MAX_LISTS] = {nullptr};
+    const uint64_t* list_base[PACK_MAX_LISTS] = {nullptr};
+    if (n_lists) {
         if (!ctx->culled) return fail(ctx, MI_ERR_NOT_READY, "mi_download_frame_results: visible list before mi_cull");
         if ((rc = compaction_join(ctx))) return rc;
-        if (!ctx->compact_fast) return fail(ctx, MI_ERR_NOT_READY, "mi_download_frame_results: rows are not in key order (use mi_download_visible_entities)");
-        if (io->view >= ctx->compact_views) return fail(ctx, MI_ERR_INVALID_ARG, "mi_download_frame_results: view %u", io->view);
-        uint32_t slot = 0xFFFFFFFFu;
-        for (uint32_t k = 0; k < ctx->compact_classes; ++k)
-            if (ctx->class_bits[k] == io->class_bit) slot = k;
-        visible_empty = slot == 0xFFFFFFFFu;  // no row carries this class: VisibleEntities::get() returns &[]
-        seg = io->view * ctx->compact_classes + (visible_empty ? 0u : slot);
+        for (uint32_t l = 0; l < n_lists; ++l) {
+            const mi_visible_list& ls = io->lists[l];
+            if (ls.view >= ctx->compact_views) return fail(ctx, MI_ERR_INVALID_ARG, "mi_download_frame_results: list %u names view %u", l, ls.view);
+            uint32_t slot = 0xFFFFFFFFu;
+            for (uint32_t k = 0; k < ctx->compact_classes; ++k)
+                if (ctx->class_bits[k] == ls.class_bit) slot = k;
+            if (slot == 0xFFFFFFFFu) continue;  // no row carries this class: VisibleEntities::get() returns &[]
+            const uint32_t seg = ls.view * ctx->compact_classes + slot;
+            list_total[l] = (const uint32_t*)ctx->fb[ctx->cur].seg_totals.p + seg;
+            if (ctx->compact_fast) {  // rows in key order: one strided region per segment
+                list_rows[l] = (const uint32_t*)ctx->fb[ctx->cur].out_rows.p + (uint64_t)seg * ctx->seg_stride;
+            } else {                  // sorted by key through the permutation: packed back to back, the bases are on the device
+                list_rows[l] = (const uint32_t*)ctx->fb[ctx->cur].out_rows.p;
+                list_base[l] = (const uint64_t*)ctx->seg_bases.p + seg;
+            }
+        }
     }
     if (want_clusters) {
         if (!ctx->cl_assigned) return fail(ctx, MI_ERR_NOT_READY, "mi_download_frame_results: clusters before an assignment");
         if ((rc = cluster_join(ctx))) return rc;
     }
     if (want_changed && (rc = changed_rows_on_device(ctx, nullptr))) return rc;
-    uint32_t changed = 0, visible = 0;
+    uint32_t changed = 0;
     uint64_t cl_total = 0;
     const uint32_t C = ctx->cl_view.n_clusters;
     const size_t off_totals = (6 * (size_t)C + 3) & ~(size_t)3, off_misc = off_totals + (((size_t)C + 3) & ~(size_t)3);
     const uint32_t* acc = want_clusters ? (const uint32_t*)ctx->cl_acc.p + ctx->cl_parity * (off_misc + 4) : nullptr;
+    // worst case of every section: what the window (or, on the fallback path, the arena) has to hold
+    uint64_t need = 0;
+    if (want_changed && want_rows) need += pack_align((uint64_t)io->changed_capacity * 4u);
+    if (want_changed && want_g) need += pack_align((uint64_t)io->changed_capacity * 48u);
+    for (uint32_t l = 0; l < n_lists; ++l)
+        if (list_total[l]) need += pack_align((uint64_t)io->lists[l].capacity * 4u);
+    if (want_clusters) {
+        need += pack_align(((uint64_t)C + 1u) * 4u) + pack_align((uint64_t)C * 24u);
+        if (want_indices) need += pack_align(io->cluster_capacity * 4u);
+    }
+    // (twice: should the packed launch report an overflow, the copies of the fallback path land behind its window)
+    if (in_place && (rc = stage_reserve(ctx, 2 * (PACK_HEADER_BYTES + std::min<uint64_t>(need, PACK_WINDOW_BYTES_IN_PLACE)) + 65536))) return rc;
     // ---- one launch, one wait: counts and lists packed by the device into a window of the pinned arena ----
-    // (the window is bounded; a frame whose lists do not fit, or whose cluster list overflowed, takes the two waits below)
     {
-        const bool sec_vis = want_visible && !visible_empty;
-        uint64_t need = 0;
-        if (want_changed) {
-            if (io->changed_rows) need += pack_align((uint64_t)io->changed_capacity * 4u);
-            if (io->changed_global12) need += pack_align((uint64_t)io->changed_capacity * 48u);
-        }
-        if (sec_vis) need += pack_align((uint64_t)io->visible_capacity * 4u);
-        if (want_clusters) {
-            need += pack_align(((uint64_t)C + 1u) * 4u) + pack_align((uint64_t)C * 24u);
-            if (io->cluster_indices) need += pack_align(io->cluster_capacity * 4u);
-        }
         PackResultsJob j{};
-        j.payload_bytes = std::min<uint64_t>(need, PACK_WINDOW_BYTES);
+        j.payload_bytes = std::min<uint64_t>(need, in_place ? PACK_WINDOW_BYTES_IN_PLACE : PACK_WINDOW_BYTES);
         void* st = nullptr;
         if ((rc = stage_alloc(ctx, PACK_HEADER_BYTES + j.payload_bytes, &st))) return rc;
         j.header = (uint32_t*)st;
@@ -1254,20 +1309,22 @@ int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
         if (want_changed) {
             j.changed_total = (const uint32_t*)ctx->sparse_total.p;
             j.changed_rows = (const uint32_t*)ctx->sparse_rows.p;
-            j.g = io->changed_global12 ? ctx->g : nullptr;
-            j.want_changed_rows = io->changed_rows != nullptr;
+            j.g = want_g ? ctx->g : nullptr;
+            j.want_changed_rows = want_rows ? 1u : 0u;
             j.changed_capacity = io->changed_capacity;
         }
-        if (sec_vis) {
-            j.visible_total = (const uint32_t*)ctx->fb[ctx->cur].seg_totals.p + seg;
-            j.visible_rows = (const uint32_t*)ctx->fb[ctx->cur].out_rows.p + (uint64_t)seg * ctx->seg_stride;
-            j.visible_capacity = io->visible_capacity;
+        j.n_lists = n_lists;
+        for (uint32_t l = 0; l < n_lists; ++l) {
+            j.list_total[l] = list_total[l];
+            j.list_rows[l] = list_rows[l];
+            j.list_base[l] = list_base[l];
+            j.list_capacity[l] = io->lists[l].capacity;
         }
         if (want_clusters) {
             j.cluster_total = (const uint64_t*)ctx->cl_scalars.p;
             j.cluster_offsets = (const uint32_t*)ctx->cl_offsets.p;
             j.cluster_counts = acc;
-            j.cluster_indices = io->cluster_indices ? (const uint32_t*)ctx->cl_indices.p : nullptr;
+            j.cluster_indices = want_indices ? (const uint32_t*)ctx->cl_indices.p : nullptr;
             j.farthest_z = (const float*)(acc + off_misc);
             j.n_clusters = C;
             j.cluster_capacity = io->cluster_capacity;
@@ -1278,55 +1335,62 @@ int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
         const uint32_t* h = j.header;
         if (h[5]) {
             changed = h[0];
-            visible = h[1];
             cl_total = (uint64_t)h[2] | ((uint64_t)h[3] << 32);
             io->changed_count = changed;
-            io->visible_count = visible;
             io->cluster_total = cl_total;
             if (want_clusters) memcpy(&io->farthest_z, &h[4], 4);
             int32_t cap_rc = MI_OK;
-            const uint8_t* src = j.payload;
+            uint8_t* src = j.payload;
+            // a section: copied out, or its address handed to the caller
+            auto deliver = [&](auto*& dst, size_t bytes) {
+                typedef typename std::remove_reference<decltype(dst)>::type P;
+                if (in_place) dst = reinterpret_cast<P>(src);
+                else if (bytes) memcpy(dst, src, bytes);
+                src += pack_align(bytes);
+            };
             const bool fits_changed = want_changed && changed <= io->changed_capacity;
             if (want_changed && !fits_changed) cap_rc = fail(ctx, MI_ERR_CAPACITY, "%u GlobalTransforms changed, capacity %u", changed, io->changed_capacity);
-            if (fits_changed && io->changed_rows) {
-                memcpy(io->changed_rows, src, (size_t)changed * 4);
-                src += pack_align((uint64_t)changed * 4u);
-            }
-            if (fits_changed && io->changed_global12) {
-                memcpy(io->changed_global12, src, (size_t)changed * 48);
-                src += pack_align((uint64_t)changed * 48u);
-            }
-            if (sec_vis) {
-                if (visible > io->visible_capacity) cap_rc = fail(ctx, MI_ERR_CAPACITY, "visible list has %u entries, capacity %u", visible, io->visible_capacity);
-                else {
-                    memcpy(io->visible_rows, src, (size_t)visible * 4);
-                    src += pack_align((uint64_t)visible * 4u);
-                }
+            if (fits_changed && want_rows) deliver(io->changed_rows, (size_t)changed * 4);
+            if (fits_changed && want_g) deliver(io->changed_global12, (size_t)changed * 48);
+            for (uint32_t l = 0; l < n_lists; ++l) {
+                mi_visible_list& ls = io->lists[l];
+                ls.count = h[8u + l];
+                if (!list_total[l]) continue;
+                if (ls.count > ls.capacity) cap_rc = fail(ctx, MI_ERR_CAPACITY, "visible list %u has %u entries, capacity %u", l, ls.count, ls.capacity);
+                else deliver(ls.rows, (size_t)ls.count * 4);
             }
             if (want_clusters) {
-                if (io->cluster_offsets) memcpy(io->cluster_offsets, src, ((size_t)C + 1) * 4);
-                src += pack_align(((uint64_t)C + 1u) * 4u);
-                if (io->cluster_counts) memcpy(io->cluster_counts, src, (size_t)C * 24);
-                src += pack_align((uint64_t)C * 24u);
-                if (io->cluster_indices) {
+                deliver(io->cluster_offsets, ((size_t)C + 1) * 4);
+                deliver(io->cluster_counts, (size_t)C * 24);
+                if (want_indices) {
                     if (cl_total > io->cluster_capacity) cap_rc = fail(ctx, MI_ERR_CAPACITY, "cluster index list has %llu entries, capacity %llu", (unsigned long long)cl_total, (unsigned long long)io->cluster_capacity);
-                    else memcpy(io->cluster_indices, src, (size_t)cl_total * 4);
+                    else deliver(io->cluster_indices, (size_t)cl_total * 4);
                 }
             }
             return cap_rc;
         }
-        changed = visible = 0;
+        changed = 0;
         cl_total = 0;
     }
-    // ---- wait 1: the counts and every fixed-size array ----
+    // ---- the packed window was too small (or the cluster list outgrew its device buffer): wait 1, the counts and every fixed-size array ----
     BatchedDownload b;
+    b.in_place = in_place;
+    uint32_t list_count[PACK_MAX_LISTS] = {0};
     if (want_changed && (rc = b.add(ctx, &changed, ctx->sparse_total.p, 4))) return rc;
-    if (want_visible && !visible_empty && (rc = b.add(ctx, &visible, (const uint32_t*)ctx->fb[ctx->cur].seg_totals.p + seg, 4))) return rc;
+    uint64_t list_base_host[PACK_MAX_LISTS] = {0};
+    for (uint32_t l = 0; l < n_lists; ++l) {
+        if (list_total[l] && (rc = b.add(ctx, &list_count[l], list_total[l], 4))) return rc;
+        if (list_base[l] && (rc = b.add(ctx, &list_base_host[l], list_base[l], 8))) return rc;
+    }
+    auto add_cluster_arrays = [&]() -> int32_t {
+        int32_t r;
+        if ((r = b.add(ctx, &io->farthest_z, acc + off_misc, 4))) return r;
+        if ((r = b.add(ctx, io->cluster_offsets, ctx->cl_offsets.p, ((size_t)C + 1) * 4, in_place ? (void**)&io->cluster_offsets : nullptr))) return r;
+        return b.add(ctx, io->cluster_counts, acc, (size_t)C * 6 * 4, in_place ? (void**)&io->cluster_counts : nullptr);
+    };
     if (want_clusters) {
         if ((rc = b.add(ctx, &cl_total, ctx->cl_scalars.p, 8))) return rc;
-        if ((rc = b.add(ctx, &io->farthest_z, acc + off_misc, 4))) return rc;
-        if ((rc = b.add(ctx, io->cluster_offsets, ctx->cl_offsets.p, ((size_t)C + 1) * 4))) return rc;
-        if ((rc = b.add(ctx, io->cluster_counts, acc, (size_t)C * 6 * 4))) return rc;
+        if ((rc = add_cluster_arrays())) return rc;
     }
     if ((rc = b.finish(ctx))) return rc;
     if (want_clusters && cl_total > ctx->cl_indices.bytes / 4) {  // fire-and-forget assign overflowed: redo with a big enough buffer
@@ -1335,35 +1399,35 @@ int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
         if ((rc = cluster_join(ctx))) return rc;
         cl_total = t2;
         acc = (const uint32_t*)ctx->cl_acc.p + ctx->cl_parity * (off_misc + 4);
-        if ((rc = b.add(ctx, &io->farthest_z, acc + off_misc, 4))) return rc;
-        if ((rc = b.add(ctx, io->cluster_offsets, ctx->cl_offsets.p, ((size_t)C + 1) * 4))) return rc;
-        if ((rc = b.add(ctx, io->cluster_counts, acc, (size_t)C * 6 * 4))) return rc;
+        if ((rc = add_cluster_arrays())) return rc;
         if ((rc = b.finish(ctx))) return rc;
     }
     io->changed_count = changed;
-    io->visible_count = visible;
     io->cluster_total = cl_total;
     // ---- wait 2: the lists ----
     int32_t cap_rc = MI_OK;
     if (want_changed && changed) {
         if (changed > io->changed_capacity) cap_rc = fail(ctx, MI_ERR_CAPACITY, "%u GlobalTransforms changed, capacity %u", changed, io->changed_capacity);
         else {
-            if ((rc = b.add(ctx, io->changed_rows, ctx->sparse_rows.p, (size_t)changed * 4))) return rc;
-            if (io->changed_global12) {
+            if (want_rows && (rc = b.add(ctx, io->changed_rows, ctx->sparse_rows.p, (size_t)changed * 4, in_place ? (void**)&io->changed_rows : nullptr))) return rc;
+            if (want_g) {
                 if ((rc = ensure(ctx, ctx->sparse_g, (size_t)changed * 48))) return rc;
                 HIP_TRY(ctx, launch_gather_global((const uint32_t*)ctx->sparse_rows.p, (const uint32_t*)ctx->sparse_total.p, changed, ctx->g,
                                                   (float*)ctx->sparse_g.p, ctx->stream));
-                if ((rc = b.add(ctx, io->changed_global12, ctx->sparse_g.p, (size_t)changed * 48))) return rc;
+                if ((rc = b.add(ctx, io->changed_global12, ctx->sparse_g.p, (size_t)changed * 48, in_place ? (void**)&io->changed_global12 : nullptr))) return rc;
             }
         }
     }
-    if (want_visible && visible) {
-        if (visible > io->visible_capacity) cap_rc = fail(ctx, MI_ERR_CAPACITY, "visible list has %u entries, capacity %u", visible, io->visible_capacity);
-        else if ((rc = b.add(ctx, io->visible_rows, (const uint32_t*)ctx->fb[ctx->cur].out_rows.p + (uint64_t)seg * ctx->seg_stride, (size_t)visible * 4))) return rc;
+    for (uint32_t l = 0; l < n_lists; ++l) {
+        mi_visible_list& ls = io->lists[l];
+        ls.count = list_count[l];
+        if (!list_total[l] || !ls.count) continue;
+        if (ls.count > ls.capacity) cap_rc = fail(ctx, MI_ERR_CAPACITY, "visible list %u has %u entries, capacity %u", l, ls.count, ls.capacity);
+        else if ((rc = b.add(ctx, ls.rows, list_rows[l] + list_base_host[l], (size_t)ls.count * 4, in_place ? (void**)&ls.rows : nullptr))) return rc;
     }
-    if (io->cluster_indices && cl_total) {
+    if (want_indices && cl_total) {
         if (cl_total > io->cluster_capacity) cap_rc = fail(ctx, MI_ERR_CAPACITY, "cluster index list has %llu entries, capacity %llu", (unsigned long long)cl_total, (unsigned long long)io->cluster_capacity);
-        else if ((rc = b.add(ctx, io->cluster_indices, ctx->cl_indices.p, (size_t)cl_total * 4))) return rc;
+        else if ((rc = b.add(ctx, io->cluster_indices, ctx->cl_indices.p, (size_t)cl_total * 4, in_place ? (void**)&io->cluster_indices : nullptr))) return rc;
     }
     if ((rc = b.finish(ctx))) return rc;
     return cap_rc;

@@ -210,6 +210,8 @@ struct mi_ctx {
     bool cl_have_type = false, cl_have_layers = false, cl_have_spot = false, cl_have_spot_dir = false, cl_any_spot = false;
     bool cl_rows_bound = false;      // mi_cluster_bind_objects_to_rows: object i is row cl_first_row + i
     uint32_t cl_first_row = 0;
+    DevBuf cl_row_list;              // mi_cluster_bind_objects_to_row_list: the rows, in object order
+    bool cl_rows_listed = false;
     std::vector<float> cl_host_planes, cl_host_spheres;  // storage of the view mi_cluster_assign_frame builds
     // The view's cluster planes are read by the kernels straight from the pinned staging arena (mapped host memory): the z
     // planes follow the camera's scale by an ulp from frame to frame, and a device copy would put an H2D blit (~6 us) in front

@@ -62,7 +62,30 @@ int32_t mi_cluster_bind_objects_to_rows(mi_ctx* ctx, uint32_t first_row, uint32_
     int32_t rc = check_rows(ctx, first_row, n_objects, "mi_cluster_bind_objects_to_rows");
     if (rc) return rc;
     ctx->cl_rows_bound = true;
+    ctx->cl_rows_listed = false;
     ctx->cl_first_row = first_row;
+    ctx->cl_assigned = false;
+    return MI_OK;
+}
+
+int32_t mi_cluster_bind_objects_to_row_list(mi_ctx* ctx, uint32_t n_objects, const uint32_t* rows) {
+    ENTER(ctx);
+    if (n_objects == 0) {
+        ctx->cl_rows_bound = false;
+        return MI_OK;
+    }
+    if (!rows) return fail(ctx, MI_ERR_INVALID_ARG, "mi_cluster_bind_objects_to_row_list: rows NULL");
+    if (n_objects != ctx->cl_n)
+        return fail(ctx, MI_ERR_INVALID_ARG, "mi_cluster_bind_objects_to_row_list: %u objects, %u uploaded", n_objects, ctx->cl_n);
+    for (uint32_t i = 0; i < n_objects; ++i)
+        if (rows[i] >= ctx->n) return fail(ctx, MI_ERR_INVALID_ARG, "mi_cluster_bind_objects_to_row_list: object %u names row %u of %u", i, rows[i], ctx->n);
+    int32_t rc;
+    if ((rc = cluster_join(ctx))) return rc;
+    if ((rc = ensure(ctx, ctx->cl_row_list, (size_t)n_objects * 4))) return rc;
+    if ((rc = upload(ctx, ctx->cl_row_list.p, rows, (size_t)n_objects * 4))) return rc;
+    ctx->cl_rows_bound = true;
+    ctx->cl_rows_listed = true;
+    ctx->cl_first_row = 0;
     ctx->cl_assigned = false;
     return MI_OK;
 }
@@ -187,10 +210,11 @@ int32_t cluster_objects(mi_ctx* ctx, bool derive, ClusterObjects* po) {
         return fail(ctx, MI_ERR_INVALID_ARG, "spot lights need spot_dir unless the objects are bound to rows (mi_cluster_bind_objects_to_rows)");
     o.spot_sin_cos = ctx->cl_have_spot ? (const float*)ctx->cl_sincos.p : nullptr;
     if (ctx->cl_rows_bound) {
-        if ((uint64_t)ctx->cl_first_row + o.n > ctx->n)
+        if (!ctx->cl_rows_listed && (uint64_t)ctx->cl_first_row + o.n > ctx->n)
             return fail(ctx, MI_ERR_NOT_READY, "cluster objects are bound to rows [%u,%u) but the context has %u rows", ctx->cl_first_row,
                         ctx->cl_first_row + o.n, ctx->n);
         o.first_row = ctx->cl_first_row;
+        o.row_list = ctx->cl_rows_listed ? (const uint32_t*)ctx->cl_row_list.p : nullptr;
         if (derive) {
             o.derive = 1;
             o.row_global = ctx->g;

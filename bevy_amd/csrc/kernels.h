@@ -188,15 +188,15 @@ hipError_t launch_gather_mesh_inputs(const uint32_t* rows, const uint32_t* total
 // One frame's results packed by ONE launch into a window of the pinned staging arena (mapped host memory), so that the host
 // needs one wait instead of one for the counts and one for the lists.  Sections follow each other at 256-byte boundaries in
 // this order, a section being present iff its pointer is set and its count fits the caller's capacity: changed rows,
-// changed GlobalTransforms (48 B each), visible rows, cluster offsets (C + 1), cluster counts (6 C), cluster indices.
-// header: [0] changed, [1] visible, [2..3] cluster total (u64), [4] farthest_z (f32 bits), [5] 1 = payload written, 0 = it did
-// not fit `payload_bytes` (or the cluster list overflowed its device buffer): the host falls back to separate copies.
+// changed GlobalTransforms (48 B each), the visible-row lists in the caller's order, cluster offsets (C + 1), cluster counts (6 C),
+// cluster indices.
+// header: [0] changed, [2..3] cluster total (u64), [4] farthest_z (f32 bits), [5] 1 = payload written, 0 = it did not fit
+// `payload_bytes` (or the cluster list overflowed its device buffer): the host falls back to separate copies; [8 + i] entries of list i.
+constexpr uint32_t PACK_MAX_LISTS = 16;  // MI_RESULTS_MAX_LISTS
 struct PackResultsJob {
     const uint32_t* changed_total;   // nullptr: no changed section
     const uint32_t* changed_rows;
     const float* g;                  // nullptr: rows only
-    const uint32_t* visible_total;   // nullptr: no visible section
-    const uint32_t* visible_rows;
     const uint64_t* cluster_total;   // nullptr: no cluster sections
     const uint32_t* cluster_offsets;
     const uint32_t* cluster_counts;
@@ -204,14 +204,20 @@ struct PackResultsJob {
     const float* farthest_z;
     uint32_t n_clusters;
     uint32_t want_changed_rows;
-    uint32_t changed_capacity, visible_capacity;
+    uint32_t changed_capacity, n_lists;
     uint64_t cluster_capacity, cluster_indices_alloc;
     uint32_t* header;
     uint8_t* payload;
     uint64_t payload_bytes;
+    // VisibleEntities lists: a device count (nullptr = an empty list: no row carries the class) and the rows
+    const uint32_t* list_total[PACK_MAX_LISTS];
+    const uint32_t* list_rows[PACK_MAX_LISTS];
+    const uint64_t* list_base[PACK_MAX_LISTS];  // device word: first entry of the list inside list_rows (nullptr = 0)
+    uint32_t list_capacity[PACK_MAX_LISTS];
 };
 constexpr uint32_t PACK_HEADER_BYTES = 256;
-constexpr uint64_t PACK_WINDOW_BYTES = (uint64_t)8 << 20;  // bigger frames are byte-bound anyway: they take the DMA path
+constexpr uint64_t PACK_WINDOW_BYTES = (uint64_t)8 << 20;  // copy-out mode: bigger frames are byte-bound anyway and take the DMA path
+constexpr uint64_t PACK_WINDOW_BYTES_IN_PLACE = (uint64_t)512 << 20;  // in-place mode: the window IS the result, whatever its size
 __host__ __device__ inline uint64_t pack_align(uint64_t b) { return (b + 255u) & ~(uint64_t)255u; }
 hipError_t launch_pack_results(const PackResultsJob& job, hipStream_t stream);
 constexpr uint32_t SMALL_UPLOAD_ROWS = 4096;  // at or below this, Transform uploads take the one-kernel path
@@ -333,6 +339,7 @@ struct ClusterObjects {
     const uint8_t* row_changed;
     uint32_t derive_resident;
     uint32_t first_row;
+    const uint32_t* row_list;    // mi_cluster_bind_objects_to_row_list: object i is row row_list[i] (nullptr: first_row + i)
     uint32_t derive, n_views;
     const float *row_translation, *row_rotation, *row_scale, *row_aabb_center, *row_aabb_half, *row_range;
     const uint8_t* row_flags;
@@ -383,7 +390,7 @@ struct ClusterWalkJob {
 // bytes of the LDS arena a walking workgroup needs for chunks of zc z slices (layout: cluster_walk.h)
 inline size_t cluster_walk_lds_bytes(uint32_t dxy, uint32_t zc, uint32_t n_planes, bool planes_in_lds) {
     const size_t RC = (size_t)dxy * zc;
-    return (RC * 8u + 48u) * sizeof(uint32_t) + (planes_in_lds ? (size_t)n_planes * 16u : 0u) + ((RC + 31u) / 32u + 5u) * 4u + RC * 2u + 16u;
+    return (RC * 8u + 48u) * sizeof(uint32_t) + (planes_in_lds ? (size_t)n_planes * 16u : 0u) + ((RC + 31u) / 32u + 4u) * 4u + RC * 2u + 16u;
 }
 constexpr size_t FRAME_KERNEL_LDS_BYTES = (4096 + 4) * 4;  // k_frame's static LDS: the arena a riding walk / fill workgroup gets
 constexpr uint32_t CLUSTER_FILL_RIDE_BLOCKS = 128;  // workgroups a riding fill adds to the frame kernel's grid

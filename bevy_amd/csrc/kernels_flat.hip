@@ -681,31 +681,34 @@ hipError_t launch_gather_global(const uint32_t* rows, const uint32_t* total, uin
 // the stores go straight over PCIe, lane-contiguous.
 __global__ void __launch_bounds__(256) k_pack_results(PackResultsJob j) {
     const uint32_t changed = j.changed_total ? *j.changed_total : 0u;
-    const uint32_t visible = j.visible_total ? *j.visible_total : 0u;
     const uint64_t cl_total = j.cluster_total ? *j.cluster_total : 0ull;
     const bool s_rows = j.changed_total && j.want_changed_rows && changed <= j.changed_capacity;
     const bool s_g = j.changed_total && j.g && changed <= j.changed_capacity;
-    const bool s_vis = j.visible_total && visible <= j.visible_capacity;
     const bool s_cl = j.cluster_total != nullptr;
     const bool s_idx = s_cl && j.cluster_indices && cl_total <= j.cluster_capacity;
     const bool overflow = s_cl && cl_total > j.cluster_indices_alloc;
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
     uint64_t off = 0;
     const uint64_t o_rows = off;  off += s_rows ? pack_align((uint64_t)changed * 4u) : 0u;
     const uint64_t o_g = off;     off += s_g ? pack_align((uint64_t)changed * 48u) : 0u;
-    const uint64_t o_vis = off;   off += s_vis ? pack_align((uint64_t)visible * 4u) : 0u;
+    // the lists' sections: every workgroup walks the same few counts (L2 hits) to place them
+    const uint64_t o_lists = off;
+    for (uint32_t l = 0; l < j.n_lists; ++l) {
+        const uint32_t cnt = j.list_total[l] ? *j.list_total[l] : 0u;
+        if (cnt <= j.list_capacity[l]) off += pack_align((uint64_t)cnt * 4u);
+    }
     const uint64_t o_off = off;   off += s_cl ? pack_align(((uint64_t)j.n_clusters + 1u) * 4u) : 0u;
     const uint64_t o_cnt = off;   off += s_cl ? pack_align((uint64_t)j.n_clusters * 24u) : 0u;
     const uint64_t o_idx = off;   off += s_idx ? pack_align(cl_total * 4u) : 0u;
     const bool fits = off <= j.payload_bytes && !overflow;
-    const uint32_t tid = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
     if (tid == 0) {
         j.header[0] = changed;
-        j.header[1] = visible;
         j.header[2] = (uint32_t)cl_total;
         j.header[3] = (uint32_t)(cl_total >> 32);
         j.header[4] = s_cl ? __float_as_uint(*j.farthest_z) : 0u;
         j.header[5] = fits ? 1u : 0u;
     }
+    if (tid < j.n_lists) j.header[8u + tid] = j.list_total[tid] ? *j.list_total[tid] : 0u;
     if (!fits) return;
     if (s_rows) {
         uint32_t* d = reinterpret_cast<uint32_t*>(j.payload + o_rows);
@@ -716,9 +719,16 @@ __global__ void __launch_bounds__(256) k_pack_results(PackResultsJob j) {
         for (uint32_t i = tid; i < changed * 3u; i += stride)
             d[i] = reinterpret_cast<const float4*>(j.g)[3ull * j.changed_rows[i / 3u] + (i % 3u)];
     }
-    if (s_vis) {
-        uint32_t* d = reinterpret_cast<uint32_t*>(j.payload + o_vis);
-        for (uint32_t i = tid; i < visible; i += stride) d[i] = j.visible_rows[i];
+    {
+        uint64_t o = o_lists;
+        for (uint32_t l = 0; l < j.n_lists; ++l) {
+            const uint32_t cnt = j.list_total[l] ? *j.list_total[l] : 0u;
+            if (cnt > j.list_capacity[l]) continue;
+            uint32_t* d = reinterpret_cast<uint32_t*>(j.payload + o);
+            const uint32_t* src = j.list_rows[l] + (j.list_base[l] ? *j.list_base[l] : 0ull);
+            for (uint32_t i = tid; i < cnt; i += stride) d[i] = src[i];
+            o += pack_align((uint64_t)cnt * 4u);
+        }
     }
     if (s_cl) {
         uint32_t* d0 = reinterpret_cast<uint32_t*>(j.payload + o_off);

@@ -16,6 +16,7 @@
 #pragma once
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -118,14 +119,18 @@ class World {
     Entity spawn(const Transform& t = Transform{}) {
         uint32_t i;
         if (!free_.empty()) { i = free_.back(); free_.pop_back(); }
-        else { i = (uint32_t)rec_.size(); rec_.emplace_back(); }
+        else { i = (uint32_t)rec_.size(); rec_.emplace_back(); vv_.push_back(0); vv_changed_.push_back(0); }
         Rec& r = rec_[i];
         const uint32_t gen = r.generation;
+        const bool was_touched = r.touched;
         r = Rec{};
         r.generation = gen;
+        r.touched = was_touched;
         r.alive = true;
         r.transform = t;
         r.transform_changed = r.added = true;
+        vv_[i] = vv_changed_[i] = 0;
+        touch(i);
         ++structure_version_;
         return Entity{i, gen};
     }
@@ -137,6 +142,7 @@ class World {
         for (Entity c : kids) despawn(c);
         remove_parent(e);
         Rec& r = rec(e);
+        if (r.point_light_range) ++lights_version_;
         r.alive = false;
         ++r.generation;
         free_.push_back(e.index);
@@ -150,6 +156,7 @@ class World {
         remove_parent(child);
         rec(child).parent = parent;
         rec(child).parent_changed = true;
+        touch(child.index);
         rec(parent).children.push_back(child);
         ++structure_version_;
     }
@@ -162,37 +169,79 @@ class World {
         sib.erase(std::remove(sib.begin(), sib.end(), child), sib.end());
         r.parent.reset();
         r.orphaned = true;
+        touch(child.index);
         ++structure_version_;
     }
     // test-only: corrupt ChildOf without touching Children (systems.rs:1127-1147 does the same with unsafe code)
     void set_child_of_unchecked(Entity child, Entity parent) { rec(child).parent = parent; ++structure_version_; }
 
     const Transform& transform(Entity e) const { return rec(e).transform; }
-    Transform& transform_mut(Entity e) { rec(e).transform_changed = true; return rec(e).transform; }  // DerefMut bumps the tick
+    Transform& transform_mut(Entity e) {  // DerefMut bumps the tick
+        Rec& r = rec(e);
+        r.transform_changed = true;
+        touch(e.index);
+        return r.transform;
+    }
     const GlobalTransform& global_transform(Entity e) const { return rec(e).global; }
     bool global_transform_changed(Entity e) const { return rec(e).global_changed; }
     std::optional<Entity> parent(Entity e) const { return rec(e).parent; }
     const std::vector<Entity>& children(Entity e) const { return rec(e).children; }
 
-    void insert_visibility(Entity e, Visibility v) { rec(e).visibility = v; rec(e).has_visibility = true; rec(e).visibility_changed = true; }
+    void insert_visibility(Entity e, Visibility v) {
+        Rec& r = rec(e);
+        r.visibility = v;
+        r.has_visibility = true;
+        r.visibility_changed = true;
+        touch(e.index);
+        ++visibility_version_;
+        ++bounds_version_;  // (entities without Visibility default to visible: the flag byte depends on its presence)
+    }
     bool inherited_visibility(Entity e) const { return rec(e).inherited; }
     bool inherited_visibility_changed(Entity e) const { return rec(e).inherited_changed; }
-    void insert_aabb(Entity e, Aabb a) { rec(e).aabb = a; rec(e).bounds_changed = true; }
-    void insert_point_light(Entity e, float range) { rec(e).point_light_range = range; }  // PointLight { range, .. }
+    void insert_aabb(Entity e, Aabb a) { rec(e).aabb = a; rec(e).bounds_changed = true; touch(e.index); ++bounds_version_; }
+    void insert_point_light(Entity e, float range) { rec(e).point_light_range = range; ++lights_version_; ++bounds_version_; }  // PointLight { range, .. }
     // What queue_material_meshes decides for a multidrawable mesh instance: the batch set key (pipeline + bind groups +
     // slabs), the bin key (mesh asset) and its slot in the MeshInputUniform buffer (render_phase/mod.rs:1086-1180)
     void insert_mesh_binning(Entity e, MeshBinning b) { rec(e).binning = b; ++binning_version_; }
     void remove_mesh_binning(Entity e) { rec(e).binning.reset(); ++binning_version_; }
-    bool view_visibility(Entity e) const { return (rec(e).view_visibility & 1u) != 0; }  // ViewVisibility::get
-    bool view_visibility_changed(Entity e) const { return rec(e).view_visibility_changed; }
+    bool view_visibility(Entity e) const { rec(e); return (vv_[e.index] & 1u) != 0; }  // ViewVisibility::get
+    bool view_visibility_changed(Entity e) const { rec(e); return vv_changed_[e.index] != 0; }
+
+    // ---- the stock systems that STAY registered next to the fused frame (they are private in the reference, so a plugin cannot
+    // take them out; in the three-system form the device runs them as part of mi_cull and the whole column comes back).
+    // ViewVisibility is a dense byte column here, as it is a table column in the ECS. ----
+    // reset_view_visibility, visibility/mod.rs:733-737: ViewVisibility::update() under bypass_change_detection
+    void reset_view_visibility() {
+        for (uint8_t& v : vv_) v = (uint8_t)((v & 1u) << 1);
+    }
+    // SetViewVisibility::set_visible, visibility/mod.rs:290-306: the tick moves only on a hidden -> visible transition
+    void set_visible(Entity e) {
+        uint8_t& v = vv_[e.index];
+        if (v & 1u) return;
+        if (!(v & 2u)) vv_changed_[e.index] = 1;
+        v |= 1u;
+    }
+    // mark_newly_hidden_entities_invisible, visibility/mod.rs:908-918
+    void mark_newly_hidden_entities_invisible() {
+        const size_t n = vv_.size();
+        for (size_t i = 0; i < n; ++i)
+            if ((vv_[i] & 3u) == 2u) {
+                vv_[i] = 0;
+                vv_changed_[i] = 1;
+            }
+    }
 
     // World::clear_trackers(): change flags older than this frame are no longer "changed"
     void clear_trackers() {
-        for (Rec& r : rec_) {
+        for (uint32_t i : touched_) {
+            Rec& r = rec_[i];
             r.transform_changed = r.added = r.parent_changed = r.orphaned = false;
-            r.global_changed = r.inherited_changed = r.view_visibility_changed = false;
+            r.global_changed = r.inherited_changed = false;
             r.visibility_changed = r.bounds_changed = false;
+            r.touched = false;
         }
+        touched_.clear();
+        std::fill(vv_changed_.begin(), vv_changed_.end(), (uint8_t)0);
     }
     std::vector<Entity> entities() const {
         std::vector<Entity> out;
@@ -214,13 +263,13 @@ class World {
         Visibility visibility = Visibility::Inherited;
         bool has_visibility = false;
         bool inherited = false;  // InheritedVisibility::default() == HIDDEN
-        uint8_t view_visibility = 0;
         std::optional<Aabb> aabb;
         std::optional<float> point_light_range;
         std::optional<MeshBinning> binning;
         bool transform_changed = false, added = false, parent_changed = false, orphaned = false;
-        bool global_changed = false, inherited_changed = false, view_visibility_changed = false;
+        bool global_changed = false, inherited_changed = false;
         bool visibility_changed = false, bounds_changed = false;
+        bool touched = false;  // listed in touched_: some change flag is set (what a change-tick scan would find)
     };
     Rec& rec(Entity e) {
         if (!contains(e)) throw std::out_of_range("no such entity");
@@ -230,10 +279,21 @@ class World {
         if (!contains(e)) throw std::out_of_range("no such entity");
         return rec_[e.index];
     }
+    void touch(uint32_t i) {
+        if (!rec_[i].touched) {
+            rec_[i].touched = true;
+            touched_.push_back(i);
+        }
+    }
     std::vector<Rec> rec_;
+    std::vector<uint8_t> vv_, vv_changed_;  // ViewVisibility's packed byte and its change flag, by entity index
+    std::vector<uint32_t> touched_;         // entity indices with a change flag set since clear_trackers
     std::vector<uint32_t> free_;
     uint64_t structure_version_ = 1;
     uint64_t binning_version_ = 1;
+    uint64_t lights_version_ = 1;
+    uint64_t visibility_version_ = 1;  // Visibility components written
+    uint64_t bounds_version_ = 1;      // Aabb / light bounds written
 };
 
 // Clusters + ObjectsInClusterCpu, crates/bevy_light/src/cluster/mod.rs:143-213
@@ -302,7 +362,154 @@ class Mi355xPlugin {
             World::Rec& e = w.rec_[entity_of_row_[crow[k]].index];
             std::memcpy(e.global.cols, &cg[12 * (size_t)k], 48);
             e.global_changed = true;
+            w.touch(entity_of_row_[crow[k]].index);
         }
+    }
+
+    // ==================================================================================================================
+    // The FUSED form -- what Mi355xRenderPrepPlugin { fused: true } registers: the whole render-prep frame is ONE device
+    // round trip.  frame() is the system placed in TransformSystems::Propagate (rust/bevy_mi355x/src/lib.rs: mi_fused_frame):
+    //   in    the rows a Changed<Transform> query yields                          mi_upload_transforms_indexed
+    //   run   propagate + reset + check_visibility + mark_newly_hidden + the       mi_propagate_and_cull_views(MI_CULL_CHANGED_ROWS |
+    //         gather of the visible lights + assign_objects_to_clusters            MI_CULL_WITH_CLUSTERS | MI_CULL_END_FRAME): one launch for
+    //                                                                              flat scenes, the tile launches + the cull with a hierarchy
+    //   out   changed GlobalTransforms, every view's VisibleEntities list,         ONE mi_download_frame_results, in place: one packing
+    //         the cluster lists                                                    launch, one device wait, no copy
+    // and the ECS writes follow where the stock systems make them: GlobalTransform at once; ViewVisibility (set_visible on the
+    // listed rows, between the stock reset_view_visibility and mark_newly_hidden_entities_invisible, which stay registered) and
+    // VisibleEntities in VisibilitySystems::CheckVisibility; Clusters in front of SimulationLightSystems::AssignLightsToClusters.
+    // Same World afterwards as the three-system form below (tests/cpp/host_systems_test.cpp runs the reference's system tests
+    // against both).  Frames in which the structure changed (spawn / despawn / ChildOf) or a Visibility component was written pay
+    // the slow path once (full column upload, InheritedVisibility round trip).
+    // ==================================================================================================================
+    struct FrameOutput {
+        double gather_s = 0, device_s = 0, apply_s = 0;    // ECS -> staging; the library calls (upload .. results); ECS writes
+        std::vector<std::vector<Entity>> visible_entities;  // per view: VisibleEntities::get(class 0), ascending by Entity
+        bool has_clusters = false;
+        Clusters clusters;
+        uint32_t changed_global_transforms = 0;  // rows written back this frame
+        uint32_t device_waits = 0;               // host waits for the device this frame (1 in the steady state)
+    };
+    FrameOutput frame(World& w, const std::vector<View>& views, const ClusterCamera* cam = nullptr) {
+        FrameOutput out;
+        const bool rebuilt = sync_structure(w);
+        if (rebuilt) out.device_waits += 1;  // (the rebuild path synchronises in mi_columns_resize / its uploads)
+        const uint32_t n = (uint32_t)entity_of_row_.size();
+        if (n == 0) return out;
+        // InheritedVisibility is an input of the cull: recomputed (on the device) only in frames that wrote a Visibility
+        if (rebuilt || seen_visibility_ != w.visibility_version_) {
+            visibility_propagate(w);
+            seen_visibility_ = w.visibility_version_;
+            out.device_waits += 2;
+        }
+        upload_bounds(w);
+        const auto t_start = std::chrono::steady_clock::now();
+        // ---- in: Changed<Transform> rows (World::touched_ is what the query's change-tick scan yields)
+        scratch_rows_.clear(); scratch_t_.clear(); scratch_r_.clear(); scratch_s_.clear();
+        for (uint32_t i : w.touched_) {
+            const World::Rec& e = w.rec_[i];
+            if (!e.alive || !(e.transform_changed || e.added || e.parent_changed || e.orphaned)) continue;
+            const uint32_t row = row_of_index_[i];
+            scratch_rows_.push_back(row);
+            scratch_t_.insert(scratch_t_.end(), {e.transform.translation.x, e.transform.translation.y, e.transform.translation.z});
+            scratch_r_.insert(scratch_r_.end(), {e.transform.rotation.x, e.transform.rotation.y, e.transform.rotation.z, e.transform.rotation.w});
+            scratch_s_.insert(scratch_s_.end(), {e.transform.scale.x, e.transform.scale.y, e.transform.scale.z});
+        }
+        const auto t_gathered = std::chrono::steady_clock::now();
+        check(mi_upload_transforms_indexed(ctx_, (uint32_t)scratch_rows_.size(), scratch_rows_.data(), scratch_t_.data(), scratch_r_.data(), scratch_s_.data()));
+        if (scratch_rows_.empty()) {  // keep "nothing changed" distinct from "no change information" (= all dirty)
+            const uint8_t zero = 0;
+            check(mi_upload_changed(ctx_, 0, 1, &zero));
+        }
+        // ---- the lights: rows like everything else, bound to the cluster stage by row (query order = Entity order here)
+        uint32_t n_clusters = 0;
+        mi_cluster_view cview{};
+        const bool with_clusters = cam != nullptr && !views.empty() && sync_lights(w);
+        if (with_clusters) {
+            uint32_t tile[2], dims[3];
+            if (mi_cluster_view_dims(cam->screen_width, cam->screen_height, cam->requested_dimensions, tile, dims) != MI_OK)
+                throw std::runtime_error("mi_cluster_view_dims failed");
+            n_clusters = dims[0] * dims[1] * dims[2];
+            plane_storage_.assign((size_t)(dims[0] + dims[1] + dims[2] + 3) * 4, 0.0f);
+            if (mi_cluster_view_build(cam->camera_affine, cam->clip_from_view, cam->frustum, cam->screen_width, cam->screen_height,
+                                      cam->requested_dimensions, cam->first_slice_depth, cam->far_z, cam->layer_mask, plane_storage_.data(),
+                                      nullptr, &cview) != MI_OK)
+                throw std::runtime_error("mi_cluster_view_build failed");
+            check(mi_cluster_upload_view(ctx_, &cview));
+        }
+        // ---- run: one call
+        const uint32_t static_opt = w.static_transform_optimizations ? 1u : 0u;
+        if (views.empty()) {
+            check(mi_propagate(ctx_, static_opt ? MI_PROPAGATE_STATIC_OPT : 0u));
+        } else {
+            mviews_.resize(views.size());
+            for (size_t v = 0; v < views.size(); ++v) {
+                std::memset(&mviews_[v], 0, sizeof(mi_view));
+                std::memcpy(mviews_[v].frustum, views[v].frustum, sizeof mviews_[v].frustum);
+                mviews_[v].layer_mask = views[v].layer_mask;
+            }
+            check(mi_propagate_and_cull_views(ctx_, mviews_.data(), (uint32_t)mviews_.size(),
+                                              MI_CULL_CHANGED_ROWS | MI_CULL_END_FRAME | (static_opt ? MI_CULL_STATIC_OPT : 0u) |
+                                                  (with_clusters ? MI_CULL_WITH_CLUSTERS : 0u)));
+        }
+        // ---- out: one call, one wait, read in place
+        if (views.size() > MI_RESULTS_MAX_LISTS) throw std::runtime_error("more views than mi_download_frame_results takes lists");
+        mi_visible_list lists[MI_RESULTS_MAX_LISTS] = {};
+        for (size_t v = 0; v < views.size(); ++v) {
+            lists[v].view = (uint32_t)v;
+            lists[v].class_bit = 0;
+            lists[v].capacity = n;
+        }
+        mi_frame_results fr{};
+        fr.flags = MI_RESULTS_IN_PLACE | MI_RESULTS_CHANGED_ROWS | MI_RESULTS_CHANGED_GLOBALS | (with_clusters ? (MI_RESULTS_CLUSTERS | MI_RESULTS_CLUSTER_INDICES) : 0u);
+        fr.n_lists = (uint32_t)views.size();
+        fr.lists = lists;
+        fr.changed_capacity = n;
+        fr.cluster_capacity = with_clusters ? (uint64_t)light_entities_.size() * n_clusters : 0;  // an object is in a cluster at most once
+        check(mi_download_frame_results(ctx_, &fr));
+        out.device_waits += 1;
+        const auto t_results = std::chrono::steady_clock::now();
+        // ---- ECS writes (the pointers lead into the library's pinned window: read here, nothing kept)
+        for (uint32_t k = 0; k < fr.changed_count; ++k) {  // TransformSystems::Propagate
+            const uint32_t i = entity_of_row_[fr.changed_rows[k]].index;
+            World::Rec& e = w.rec_[i];
+            std::memcpy(e.global.cols, fr.changed_global12 + 12 * (size_t)k, 48);
+            e.global_changed = true;
+            w.touch(i);
+        }
+        out.changed_global_transforms = fr.changed_count;
+        if (!views.empty()) {  // VisibilitySystems::CheckVisibility, between the two stock systems
+            w.reset_view_visibility();
+            out.visible_entities.resize(views.size());
+            for (size_t v = 0; v < views.size(); ++v) {
+                std::vector<Entity>& list = out.visible_entities[v];
+                list.reserve(lists[v].count);
+                for (uint32_t k = 0; k < lists[v].count; ++k) {
+                    const Entity e = entity_of_row_[lists[v].rows[k]];
+                    w.set_visible(e);
+                    list.push_back(e);
+                }
+            }
+            w.mark_newly_hidden_entities_invisible();
+        }
+        if (with_clusters) {  // in front of SimulationLightSystems::AssignLightsToClusters
+            out.has_clusters = true;
+            Clusters& cl = out.clusters;
+            std::memcpy(cl.dimensions, cview.dims, sizeof cl.dimensions);
+            cl.farthest_z = fr.farthest_z;
+            cl.total_index_count = fr.cluster_total;
+            cl.clusterable_objects.resize(n_clusters);
+            for (uint32_t c = 0; c < n_clusters; ++c) {
+                ObjectsInCluster& o = cl.clusterable_objects[c];
+                for (uint32_t i = fr.cluster_offsets[c]; i < fr.cluster_offsets[c + 1]; ++i) o.entities.push_back(light_entities_[fr.cluster_indices[i]]);
+                std::memcpy(o.counts, fr.cluster_counts + 6 * (size_t)c, sizeof o.counts);
+            }
+        }
+        const auto t_end = std::chrono::steady_clock::now();
+        out.gather_s = std::chrono::duration<double>(t_gathered - t_start).count();
+        out.device_s = std::chrono::duration<double>(t_results - t_gathered).count();
+        out.apply_s = std::chrono::duration<double>(t_end - t_results).count();
+        return out;
     }
 
     // VisibilitySystems::VisibilityPropagate
@@ -322,7 +529,7 @@ class Mi355xPlugin {
         check(mi_download_inherited_visibility(ctx_, 0, n, inh.data(), chg.data()));
         for (uint32_t row = 0; row < n; ++row) {
             World::Rec& e = w.rec_[entity_of_row_[row].index];
-            if ((chg[row >> 5] >> (row & 31)) & 1u) { e.inherited = inh[row] != 0; e.inherited_changed = true; }
+            if ((chg[row >> 5] >> (row & 31)) & 1u) { e.inherited = inh[row] != 0; e.inherited_changed = true; w.touch(entity_of_row_[row].index); ++w.bounds_version_; }
         }
     }
 
@@ -340,9 +547,9 @@ class Mi355xPlugin {
         std::vector<uint32_t> chg((n + 31) / 32);
         check(mi_download_view_visibility(ctx_, 0, n, vv.data(), chg.data()));
         for (uint32_t row = 0; row < n; ++row) {
-            World::Rec& e = w.rec_[entity_of_row_[row].index];
-            e.view_visibility = vv[row];
-            if ((chg[row >> 5] >> (row & 31)) & 1u) e.view_visibility_changed = true;
+            const uint32_t i = entity_of_row_[row].index;
+            w.vv_[i] = vv[row];
+            if ((chg[row >> 5] >> (row & 31)) & 1u) w.vv_changed_[i] = 1;
         }
     }
     // VisibleEntities::get(class) of one view: entities in ascending Entity order (visibility/mod.rs:861-874)
@@ -394,7 +601,7 @@ class Mi355xPlugin {
         std::vector<float> pos_range;
         for (Entity e : w.entities()) {
             const World::Rec& r = w.rec_[e.index];
-            if (!r.point_light_range) continue;
+            if (!r.point_light_range || !(w.vv_[e.index] & 1u)) continue;  // `.filter(|(.., visibility)| visibility.get())`, assign.rs:194
             lights.push_back(e);
             pos_range.insert(pos_range.end(), {r.global.cols[9], r.global.cols[10], r.global.cols[11], *r.point_light_range});
         }
@@ -438,8 +645,8 @@ class Mi355xPlugin {
     }
     // Entity -> row table.  Rebuilt (level order via mi_hierarchy_sort, full column upload) whenever entities were
     // spawned / despawned or a ChildOf changed; otherwise only dirty rows travel.
-    void sync_structure(World& w) {
-        if (seen_version_ == w.structure_version_) return;
+    bool sync_structure(World& w) {
+        if (seen_version_ == w.structure_version_) return false;
         std::vector<Entity> ents = w.entities();
         // rows in Entity::to_bits order first, so sibling order and VisibleEntities order follow the key
         std::sort(ents.begin(), ents.end(), [](Entity a, Entity b) { return a.to_bits() < b.to_bits(); });
@@ -461,6 +668,8 @@ class Mi355xPlugin {
         if (rc != MI_OK) throw std::runtime_error("mi_hierarchy_sort failed");
         entity_of_row_.resize(n);
         for (uint32_t row = 0; row < n; ++row) entity_of_row_[row] = ents[new_to_old[row]];
+        row_of_index_.assign(w.rec_.size(), MI_NO_PARENT);
+        for (uint32_t row = 0; row < n; ++row) row_of_index_[entity_of_row_[row].index] = row;
         check(mi_columns_resize(ctx_, n));
         if (n) {
             std::vector<float> t(3 * (size_t)n), r(4 * (size_t)n), s(3 * (size_t)n), g(12 * (size_t)n);
@@ -473,7 +682,7 @@ class Mi355xPlugin {
                 std::memcpy(&s[3 * (size_t)row], &e.transform.scale, 12);
                 std::memcpy(&g[12 * (size_t)row], e.global.cols, 48);
                 changed[row] = (e.transform_changed || e.added || e.parent_changed || e.orphaned) ? 1 : 0;
-                vv[row] = e.view_visibility;
+                vv[row] = w.vv_[entity_of_row_[row].index];
                 keys[row] = entity_of_row_[row].to_bits();
             }
             check(mi_upload_transforms(ctx_, 0, n, t.data(), r.data(), s.data()));
@@ -486,15 +695,60 @@ class Mi355xPlugin {
         }
         seen_version_ = w.structure_version_;
         upload_bounds(w);  // the flag byte carries InheritedVisibility: the device must start from the World's values
+        lights_version_ = 0;  // rows were renumbered: the lights are bound again
+        return true;
+    }
+    // The clusterable objects of the fused frame: point lights in query (Entity) order, each bound to its ROW -- the device takes
+    // the centre from the row's GlobalTransform and gathers only the lights whose ViewVisibility::get() is true (assign.rs:190-296).
+    // Re-uploaded only when a light was added / removed / changed its range or rows were renumbered.  Returns false without lights.
+    bool sync_lights(World& w) {
+        if (lights_version_ == w.lights_version_ && lights_version_ != 0) return !light_entities_.empty();
+        light_entities_.clear();
+        std::vector<uint32_t> rows;
+        std::vector<float> pos_range;
+        std::vector<Entity> ents = w.entities();
+        for (Entity e : ents) {
+            const World::Rec& r = w.rec_[e.index];
+            if (!r.point_light_range) continue;
+            light_entities_.push_back(e);
+            rows.push_back(row_of_index_[e.index]);
+            pos_range.insert(pos_range.end(), {0.0f, 0.0f, 0.0f, *r.point_light_range});  // the position comes from the row
+        }
+        lights_version_ = w.lights_version_;
+        if (light_entities_.empty()) {
+            check(mi_cluster_bind_objects_to_row_list(ctx_, 0, nullptr));
+            return false;
+        }
+        check(mi_cluster_upload_objects(ctx_, (uint32_t)light_entities_.size(), pos_range.data(), nullptr, nullptr, nullptr, nullptr));
+        check(mi_cluster_bind_objects_to_row_list(ctx_, (uint32_t)rows.size(), rows.data()));
+        return true;
+    }
+    // GlobalTransform::translation() an entity WILL have after this frame's propagate, from the Transforms up its ChildOf chain
+    // with the host build of the same arithmetic (glam_math.h): what update_point_light_bounding_spheres reads
+    // (crates/bevy_light/src/point_light.rs:195-208) -- it runs behind TransformSystems::Propagate, the fused frame runs inside it.
+    static GlobalTransform expected_global(const World& w, Entity e) {
+        std::vector<const Transform*> chain;
+        for (std::optional<Entity> cur = e; cur && w.contains(*cur); cur = w.rec_[cur->index].parent) chain.push_back(&w.rec_[cur->index].transform);
+        GlobalTransform g = GlobalTransform::from(*chain.back());
+        for (size_t k = chain.size() - 1; k-- > 0;) g = g * *chain[k];
+        return g;
+    }
+    static bool chain_moved(const World& w, Entity e) {
+        for (std::optional<Entity> cur = e; cur && w.contains(*cur); cur = w.rec_[cur->index].parent) {
+            const World::Rec& r = w.rec_[cur->index];
+            if (r.transform_changed || r.added || r.parent_changed || r.orphaned) return true;
+        }
+        return false;
     }
     void upload_bounds(World& w) {
         const uint32_t n = (uint32_t)entity_of_row_.size();
-        bool any = bounds_dirty_;
-        for (uint32_t row = 0; row < n && !any; ++row) {
-            const World::Rec& e = w.rec_[entity_of_row_[row].index];
-            any = e.bounds_changed || e.inherited_changed || e.visibility_changed;
-        }
+        bool any = bounds_dirty_ || seen_bounds_ != w.bounds_version_;
+        for (size_t k = 0; k < light_rows_.size() && !any; ++k) any = chain_moved(w, entity_of_row_[light_rows_[k]]);  // a moved light moves its Sphere
         if (!any) return;
+        seen_bounds_ = w.bounds_version_;
+        light_rows_.clear();
+        for (uint32_t row = 0; row < n; ++row)
+            if (w.rec_[entity_of_row_[row].index].point_light_range) light_rows_.push_back(row);
         std::vector<float> c(3 * (size_t)n, 0.f), h(3 * (size_t)n, 0.f);
         std::vector<uint8_t> flags(n);
         for (uint32_t row = 0; row < n; ++row) {
@@ -502,6 +756,12 @@ class Mi355xPlugin {
             // entities without the visibility components never enter the query; without Visibility they default visible
             flags[row] = (uint8_t)(((!e.has_visibility || e.inherited) ? MI_FLAG_INHERITED_VISIBLE : 0u) | (e.aabb ? MI_FLAG_HAS_AABB : 0u));
             if (e.aabb) { std::memcpy(&c[3 * (size_t)row], &e.aabb->center, 12); std::memcpy(&h[3 * (size_t)row], &e.aabb->half_extents, 12); }
+            else if (e.point_light_range) {  // a point light is culled by its bounding Sphere { translation, range } (point_light.rs:195-208)
+                const Vec3 t = expected_global(w, entity_of_row_[row]).translation();
+                flags[row] |= MI_FLAG_HAS_SPHERE;
+                std::memcpy(&c[3 * (size_t)row], &t, 12);
+                h[3 * (size_t)row] = *e.point_light_range;
+            }
         }
         check(mi_upload_bounds(ctx_, 0, n, c.data(), h.data(), flags.data(), nullptr));
         bounds_dirty_ = false;
@@ -554,6 +814,12 @@ class Mi355xPlugin {
     }
 
     mi_ctx* ctx_ = nullptr;
+    std::vector<uint32_t> scratch_rows_;
+    std::vector<float> scratch_t_, scratch_r_, scratch_s_, plane_storage_;
+    std::vector<mi_view> mviews_;
+    std::vector<Entity> light_entities_;
+    std::vector<uint32_t> light_rows_, row_of_index_;
+    uint64_t lights_version_ = 0, seen_visibility_ = 0, seen_bounds_ = 0;
     std::vector<std::pair<uint64_t, bool>> set_keys_;
     std::vector<std::pair<uint64_t, uint64_t>> bin_keys_;  // per metadata entry: (batch set key, bin key)
     uint64_t seen_binning_ = 0, seen_binning_structure_ = 0;

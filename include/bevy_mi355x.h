@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 1
+#define MI_ABI_VERSION 2
 
 /* ---- status codes ---------------------------------------------------------------------- */
 #define MI_OK 0
@@ -106,6 +106,8 @@ extern "C" {
                                    * 100 k lights (the two kernels of the assignment are latency-bound and stretch when they share the
                                    * chip: 46.3 us per frame against 44.1 us one behind the other), so it is opt-in. */
 
+#define MI_CULL_STATIC_OPT 0x40u   /* mi_propagate_and_cull(_views) with a hierarchy uploaded: StaticTransformOptimizations::Enabled for the
+                                   * propagate part (= MI_PROPAGATE_STATIC_OPT, systems.rs:87-103) */
 #define MI_CULL_CHANGED_ROWS 0x20u /* mi_propagate_and_cull only: propagate the rows whose Transform change byte is set (mi_upload_changed,
                                    * mi_upload_transforms_indexed; new rows carry it as Added<GlobalTransform>) -- the filter of
                                    * sync_simple_transforms, systems.rs:45-50 -- instead of every row; the others keep their GlobalTransform and
@@ -260,12 +262,12 @@ typedef struct mi_view {
 int32_t mi_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint32_t flags /* MI_CULL_* */);
 int32_t mi_propagate_and_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint32_t flags);
 
-/* Fused fast path for flat rows (no hierarchy uploaded): sync_simple_transforms with every Transform
- * dirty + reset_view_visibility + check_visibility_cpu_culling in ONE pass (Transform is read once,
- * GlobalTransform is written once and never re-read).  Results are identical to
- * mi_propagate(MI_PROPAGATE_ALL_DIRTY); mi_visibility_begin_frame(); mi_cull(...) [; mi_visibility_end_frame()
+/* The frame in one call: propagate + reset_view_visibility + check_visibility_cpu_culling.  Flat rows (no hierarchy uploaded):
+ * sync_simple_transforms with every Transform dirty and the cull in ONE pass (Transform is read once, GlobalTransform is written
+ * once and never re-read).  With a hierarchy: the tile launches of mi_propagate, the cull enqueued behind them.  Results are
+ * identical to mi_propagate(MI_PROPAGATE_ALL_DIRTY); mi_visibility_begin_frame(); mi_cull(...) [; mi_visibility_end_frame()
  * when flags has MI_CULL_END_FRAME].  MI_CULL_BEGIN_FRAME is implied.  With MI_CULL_CHANGED_ROWS only the rows marked
- * changed are propagated (= mi_propagate(0) in front of the cull). */
+ * changed are propagated (= mi_propagate(0) in front of the cull); MI_CULL_STATIC_OPT = MI_PROPAGATE_STATIC_OPT. */
 int32_t mi_propagate_and_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_masks,
                               const uint8_t* view_flags, uint32_t n_views, uint32_t flags /* MI_CULL_* */);
 
@@ -439,6 +441,10 @@ int32_t mi_cluster_upload_view(mi_ctx* ctx, const mi_cluster_view* view);
  * uploaded arrays (= row - first_row); objects that are not visible simply appear in no cluster, exactly like
  * entities the reference never gathered.  n_objects must equal the uploaded object count; n_objects = 0 unbinds. */
 int32_t mi_cluster_bind_objects_to_rows(mi_ctx* ctx, uint32_t first_row, uint32_t n_objects);
+/* The same for lights that are NOT a contiguous block of rows (with a hierarchy rows are in level order, and a light parented to
+ * something sits wherever its level puts it): object i IS row rows[i].  Everything else as above; a later mi_columns_resize that
+ * shrinks the context unbinds. */
+int32_t mi_cluster_bind_objects_to_row_list(mi_ctx* ctx, uint32_t n_objects, const uint32_t* rows);
 int32_t mi_cluster_assign_resident(mi_ctx* ctx, uint64_t* out_total);
 /* One view of one frame exactly as the system runs it (assign.rs:324-811): resolve the config against `history`,
  * build and upload the view constants, assign the resident objects, and store this frame's
@@ -452,32 +458,53 @@ int32_t mi_cluster_assign_frame(mi_ctx* ctx, const mi_cluster_config* config, mi
 int32_t mi_cluster_download(mi_ctx* ctx, uint32_t* out_offsets, uint32_t* out_indices, uint64_t capacity,
                             uint32_t* out_counts, uint64_t* out_total, float* out_farthest_z);
 
-/* Everything a frame hands back to the ECS in ONE call, one launch and one device wait (the device packs counts and lists
- * into a window of the pinned staging arena; results beyond 8 MB take two waits: counts, then lists; the separate downloads
- * wait ten times between them, and on an idle stream a wait is ~30 us): the rows whose GlobalTransform changed with their matrices
- * (mi_download_changed_global_transforms), one (view, class) VisibleEntities row list (mi_download_visible_entities; rows
- * only -- the caller maps rows to Entity itself -- and only when rows are numbered in key order, which is the case unless
- * mi_upload_entity_keys said otherwise: MI_ERR_NOT_READY then) and the cluster lists of the resident assignment
- * (mi_cluster_download).  Any out pointer may be NULL (that part is skipped; a part whose buffers are all NULL costs nothing);
- * the counts are always filled in for the parts that ran.  MI_ERR_CAPACITY if a list exceeds its capacity (counts are valid,
- * nothing was copied for that list). */
+/* Everything a frame hands back to the ECS in ONE call, one launch and one device wait: the device packs counts and lists into a
+ * window of the library's pinned (page-locked, device-mapped) host memory, the host waits once and reads them there (results too
+ * big for the window, or a cluster list that outgrew its device buffer, take two waits: counts, then lists; the separate downloads
+ * wait ten times between them, and on an idle stream a wait is ~30 us).  The parts, each switched on by its flag:
+ *   MI_RESULTS_CHANGED_ROWS / _GLOBALS   the rows whose GlobalTransform changed (ascending) / their matrices
+ *                                        (mi_download_changed_global_transforms)
+ *   lists[n_lists]                       VisibleEntities row lists of any (view, class) pairs (mi_download_visible_entities; rows
+ *                                        only -- the caller maps rows to Entity itself -- and only when rows are numbered in key order,
+ *                                        which is the case unless mi_upload_entity_keys said otherwise: MI_ERR_NOT_READY then).
+ *                                        The union of a frame's lists is exactly the set of rows SetViewVisibility::set_visible
+ *                                        was called on (visibility/mod.rs:846-857) -- except rows without a VisibilityClass.
+ *   MI_RESULTS_CLUSTERS / _CLUSTER_INDICES  offsets + counts / the index list of the resident assignment (mi_cluster_download)
+ * Without MI_RESULTS_IN_PLACE the caller passes buffers and capacities and the library copies out of the window.  With it the
+ * library SETS the pointers to the data where it lies in the pinned window -- no copy; the caller reads it in place (e.g. while
+ * writing the ECS components) and must be done before its next call on this context.  Capacities still bound what is fetched.
+ * Counts are always filled in for the parts that ran; MI_ERR_CAPACITY if a list exceeds its capacity (counts are valid, that list
+ * was not delivered, the others were). */
+#define MI_RESULTS_CHANGED_ROWS 0x1u
+#define MI_RESULTS_CHANGED_GLOBALS 0x2u
+#define MI_RESULTS_CLUSTERS 0x4u
+#define MI_RESULTS_CLUSTER_INDICES 0x8u /* implies MI_RESULTS_CLUSTERS */
+#define MI_RESULTS_IN_PLACE 0x10u
+#define MI_RESULTS_MAX_LISTS 16u
+typedef struct mi_visible_list {
+    uint32_t view, class_bit; /* in: which VisibleEntities list */
+    uint32_t capacity;        /* in: entries of rows (in place: the most the caller is prepared to read) */
+    uint32_t count;           /* out */
+    uint32_t* rows;           /* in: [capacity]; MI_RESULTS_IN_PLACE: out */
+} mi_visible_list;
 typedef struct mi_frame_results {
     /* ---- in ---- */
-    uint32_t view, class_bit;     /* which VisibleEntities list */
-    uint32_t changed_capacity;    /* rows of changed_rows / changed_global12 */
-    uint32_t visible_capacity;    /* entries of visible_rows */
-    uint64_t cluster_capacity;    /* entries of cluster_indices */
-    uint32_t* changed_rows;       /* [changed_capacity] or NULL */
-    float* changed_global12;      /* [12 * changed_capacity] or NULL */
-    uint32_t* visible_rows;       /* [visible_capacity] or NULL */
-    uint32_t* cluster_offsets;    /* [n_clusters + 1] or NULL */
-    uint32_t* cluster_counts;     /* [6 * n_clusters] or NULL */
-    uint32_t* cluster_indices;    /* [cluster_capacity] or NULL */
+    uint32_t flags;            /* MI_RESULTS_* */
+    uint32_t n_lists;          /* <= MI_RESULTS_MAX_LISTS */
+    mi_visible_list* lists;    /* [n_lists] or NULL */
+    uint32_t changed_capacity; /* rows of changed_rows / changed_global12 */
+    uint32_t reserved;         /* 0 */
+    uint64_t cluster_capacity; /* entries of cluster_indices */
+    /* ---- in, or out with MI_RESULTS_IN_PLACE ---- */
+    uint32_t* changed_rows;    /* [changed_capacity] */
+    float* changed_global12;   /* [12 * changed_capacity] */
+    uint32_t* cluster_offsets; /* [n_clusters + 1] */
+    uint32_t* cluster_counts;  /* [6 * n_clusters] */
+    uint32_t* cluster_indices; /* [cluster_capacity] */
     /* ---- out ---- */
-    uint32_t changed_count, visible_count;
-    uint64_t cluster_total;
+    uint32_t changed_count;
     float farthest_z;
-    uint32_t reserved;
+    uint64_t cluster_total;
 } mi_frame_results;
 int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io);
 

@@ -4,9 +4,15 @@
 //   crates/bevy_camera/src/visibility/mod.rs:950-1279       InheritedVisibility propagation + change detection
 //   crates/bevy_camera/src/visibility/mod.rs:1313-1448      ViewVisibility 2-bit lifecycle over frames
 //   benches/benches/bevy_camera/primitives.rs:41-52         an OBB inside a perspective frustum is visible
-// Needs an MI355X (the systems run on the device).  Exit code 0 = all passed.
+// Every test runs against BOTH forms of the plugin: the three systems of round 2 (propagate_transforms / visibility_propagate /
+// check_visibility / assign_objects_to_clusters, a device wait each) and the fused frame (Mi355xPlugin::frame: one upload, one
+// mi_propagate_and_cull_views, one mi_download_frame_results in place -- the call sequence bench.py times).
+// Needs an MI355X (the systems run on the device).  Exit code 0 = all passed.  `host_systems_test --bench` times both call
+// sequences on the BASELINE metric scene instead (bench.py's end_to_end block).
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <functional>
 
 #include "../../bevy_amd/host/bevy_mi355x_host.hpp"
@@ -20,10 +26,30 @@ static int g_failed = 0, g_checks = 0;
         if (!(cond)) { ++g_failed; std::printf("  FAILED %s:%d: %s -- %s\n", __FILE__, __LINE__, #cond, msg); } \
     } while (0)
 
+static bool g_fused = false;  // which form of the plugin the tests drive
+
 // the chained transform systems of one schedule.run()
+static void propagate(Mi355xPlugin& p, World& w) {
+    if (g_fused) p.frame(w, {});
+    else p.propagate_transforms(w);
+}
 static void run(Mi355xPlugin& p, World& w) {
-    p.propagate_transforms(w);
+    propagate(p, w);
     w.clear_trackers();
+}
+static void visibility_propagate(Mi355xPlugin& p, World& w) {
+    if (g_fused) p.frame(w, {});  // (a frame without views: propagate + InheritedVisibility, nothing to cull)
+    else p.visibility_propagate(w);
+}
+// PostUpdate of one frame with cameras: returns the cameras' VisibleEntities
+static std::vector<std::vector<Entity>> post_update(Mi355xPlugin& p, World& w, const std::vector<View>& views) {
+    if (g_fused) return p.frame(w, views).visible_entities;
+    p.propagate_transforms(w);
+    p.visibility_propagate(w);
+    p.check_visibility(w, views);
+    std::vector<std::vector<Entity>> out;
+    for (uint32_t v = 0; v < views.size(); ++v) out.push_back(p.visible_entities(v));
+    return out;
 }
 
 // systems.rs:826-886
@@ -144,18 +170,18 @@ static void change_ticks_follow_set_if_neq() {
     Entity b = world.spawn_child(a, Transform::from_xyz(0, 0, 1));
     Entity flat = world.spawn(Transform::from_xyz(5, 5, 5));
     run(plugin, world);
-    plugin.propagate_transforms(world);  // nothing changed
+    propagate(plugin, world);  // nothing changed
     CHECK(world.global_transform_changed(root), "root is re-assigned each run");
     CHECK(!world.global_transform_changed(a) && !world.global_transform_changed(b), "set_if_neq: equal value, no tick");
     CHECK(!world.global_transform_changed(flat), "flat entity without Changed<Transform> is not touched");
     world.clear_trackers();
     world.transform_mut(a).translation.y = 2.0f;
-    plugin.propagate_transforms(world);
+    propagate(plugin, world);
     CHECK(world.global_transform_changed(a) && world.global_transform_changed(b), "moved subtree");
     CHECK(world.global_transform(b) == (GlobalTransform::from_xyz(1, 0, 0) * Transform::from_xyz(0, 2, 0)) * Transform::from_xyz(0, 0, 1), "value");
     world.clear_trackers();
     world.static_transform_optimizations = true;
-    plugin.propagate_transforms(world);
+    propagate(plugin, world);
     CHECK(!world.global_transform_changed(root), "static scene optimisation: clean tree is skipped");
 }
 
@@ -174,7 +200,7 @@ static void visibility_propagation() {
     w.add_children(root2, {root2_child1, root2_child2});
     w.add_child(root2_child1, r2c1g);
     w.add_child(root2_child2, r2c2g);
-    plugin.visibility_propagate(w);
+    visibility_propagate(plugin, w);
     for (Entity e : {root1, root1_child1, root1_child2, r1c1g, r1c2g}) CHECK(!w.inherited_visibility(e), "invisibility propagates down tree from root");
     CHECK(w.inherited_visibility(root2) && w.inherited_visibility(root2_child1) && w.inherited_visibility(r2c1g), "visibility propagates down tree from root");
     CHECK(!w.inherited_visibility(root2_child2), "local invisibility is preserved");
@@ -193,11 +219,11 @@ static void visibility_propagation_change_detection() {
     auto step = [&](std::function<void()> edit, bool c1, bool c2, bool c3, bool c4, const char* what) {
         w.clear_trackers();
         if (edit) edit();
-        plugin.visibility_propagate(w);
+        visibility_propagate(plugin, w);
         CHECK(w.inherited_visibility_changed(id1) == c1 && w.inherited_visibility_changed(id2) == c2 &&
                   w.inherited_visibility_changed(id3) == c3 && w.inherited_visibility_changed(id4) == c4, what);
     };
-    plugin.visibility_propagate(w);
+    visibility_propagate(plugin, w);
     step(nullptr, false, false, false, false, "nothing changed");
     step([&] { w.insert_visibility(id1, Visibility::Hidden); }, true, true, false, false, "id1 hidden");
     step(nullptr, false, false, false, false, "stable");
@@ -226,9 +252,7 @@ static void view_visibility_lifecycle() {
         if (!first) w.clear_trackers();
         first = false;
         if (edit) edit();
-        plugin.propagate_transforms(w);
-        plugin.visibility_propagate(w);
-        plugin.check_visibility(w, views);
+        post_update(plugin, w, views);
     };
     update(nullptr);
     update(nullptr);
@@ -259,9 +283,7 @@ static void visible_entities_are_sorted_by_entity() {
         w.insert_aabb(e, Aabb{{0, 0, 0}, {0.5f, 0.5f, 0.5f}});
         if (in) inside.push_back(e);
     }
-    plugin.propagate_transforms(w);
-    plugin.check_visibility(w, {camera_looking_down_neg_z()});
-    std::vector<Entity> got = plugin.visible_entities(0);
+    std::vector<Entity> got = post_update(plugin, w, {camera_looking_down_neg_z()})[0];
     std::sort(inside.begin(), inside.end(), [](Entity a, Entity b) { return a.to_bits() < b.to_bits(); });
     CHECK(got == inside, "VisibleEntities = the entities in view, ascending by Entity::to_bits");
     for (Entity e : w.entities()) CHECK(w.view_visibility(e) == (std::find(inside.begin(), inside.end(), e) != inside.end()), "ViewVisibility");
@@ -281,11 +303,25 @@ static void lights_are_assigned_to_clusters() {
     w.insert_point_light(off_right, 1.0f);
     w.insert_point_light(huge, 1.0e6f);
     w.spawn(Transform::from_xyz(1, 2, 3));  // not a light
-    plugin.propagate_transforms(w);
     ClusterCamera cam;
     mi_perspective_clip_from_view(3.14159265f / 4.0f, 16.0f / 9.0f, 0.1f, cam.clip_from_view);
     mi_compute_frustum(cam.clip_from_view, cam.camera_affine, 1000.0f, cam.frustum);
-    const Clusters cl = plugin.assign_objects_to_clusters(w, cam);
+    Clusters cl;
+    if (g_fused) {  // the camera's frame: propagate + cull + gather of the visible lights + assignment, one round trip
+        View view;
+        std::memcpy(view.frustum, cam.frustum, sizeof view.frustum);
+        Mi355xPlugin::FrameOutput out = plugin.frame(w, {view}, &cam);
+        CHECK(out.has_clusters, "the fused frame carries the cluster stage");
+        cl = out.clusters;
+        // the lights' own ViewVisibility comes from their bounding Sphere (point_light.rs:195-208): the one behind the camera is hidden
+        CHECK(w.view_visibility(in_front) && !w.view_visibility(behind) && w.view_visibility(off_right) && w.view_visibility(huge), "ViewVisibility of the lights");
+    } else {
+        View view;
+        std::memcpy(view.frustum, cam.frustum, sizeof view.frustum);
+        plugin.propagate_transforms(w);
+        plugin.check_visibility(w, {view});  // the gather takes the lights whose ViewVisibility::get() is true (assign.rs:194)
+        cl = plugin.assign_objects_to_clusters(w, cam);
+    }
     CHECK(cl.dimensions[0] == 16 && cl.dimensions[1] == 9 && cl.dimensions[2] == 24, "1920x1080 with 16x9x24 requested");
     CHECK(cl.dimensions[0] * cl.dimensions[1] * cl.dimensions[2] <= 4096, "at most 4096 clusters (test.rs)");
     size_t n_front = 0, n_behind = 0, n_right = 0, n_huge = 0, total = 0;
@@ -329,7 +365,7 @@ static void render_multidrawable_batch_set() {
         w.insert_aabb(e, Aabb{{0, 0, 0}, {0.5f, 0.5f, 0.5f}});
         ents.push_back(e);
     }
-    plugin.propagate_transforms(w);
+    propagate(plugin, w);
     uint64_t rng = 0x9E3779B97F4A7C15ull;
     auto next = [&rng]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
     std::map<uint32_t, MeshBinning> binned;  // entity index -> control copy
@@ -352,8 +388,7 @@ static void render_multidrawable_batch_set() {
                 w.remove_mesh_binning(ents[id]);
             }
         }
-        plugin.check_visibility(w, {camera_looking_down_neg_z()});
-        const std::vector<Entity> visible = plugin.visible_entities(0);
+        const std::vector<Entity> visible = post_update(plugin, w, {camera_looking_down_neg_z()})[0];
         const PhaseBatches pb = plugin.batch_multidrawables(w, 0, &initial);
         // control: visible binned instances per (set, bin)
         std::map<std::pair<uint64_t, uint64_t>, std::vector<uint32_t>> expect;  // -> input uniform indices, VisibleEntities order
@@ -417,7 +452,188 @@ static void render_multidrawable_batch_set() {
     CHECK(!binned.empty(), "the random walk left instances binned");
 }
 
-int main() {
+// Twin worlds, one edit script; one runs the three systems, the other the fused frame: after every frame the two Worlds are the
+// same component for component -- GlobalTransform bits and change ticks, InheritedVisibility, ViewVisibility and its ticks,
+// VisibleEntities, Clusters.  (The fused frame makes its ECS writes where the stock systems make theirs; this is the check.)
+static void both_forms_leave_the_same_world() {
+    World wa, wb;
+    Mi355xPlugin pa, pb;
+    uint64_t rng = 0x2545F4914F6CDD1Dull;
+    auto next = [&rng]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+    auto frand = [&](float lo, float hi) { return lo + (hi - lo) * (float)(next() % 10000) / 10000.0f; };
+    std::vector<Entity> ents;  // the same handles are valid in both worlds (same spawn / despawn sequence)
+    auto spawn = [&](std::optional<Entity> parent, bool light) {
+        const Transform t = Transform::from_xyz(frand(-12, 12), frand(-6, 6), frand(-60, 10));
+        Entity ea = wa.spawn(t), eb = wb.spawn(t);
+        CHECK(ea == eb, "twin worlds hand out the same entity");
+        if (parent) { wa.add_child(*parent, ea); wb.add_child(*parent, eb); }
+        if (light) { const float range = frand(0.5f, 6.0f); wa.insert_point_light(ea, range); wb.insert_point_light(eb, range); }
+        else { const Aabb a{{0, 0, 0}, {frand(0.2f, 1.5f), frand(0.2f, 1.5f), frand(0.2f, 1.5f)}}; wa.insert_aabb(ea, a); wb.insert_aabb(eb, a); }
+        if (next() % 3 == 0) {
+            const Visibility v = (Visibility)(next() % 3);
+            wa.insert_visibility(ea, v); wb.insert_visibility(eb, v);
+        }
+        ents.push_back(ea);
+        return ea;
+    };
+    for (int i = 0; i < 150; ++i) {
+        std::optional<Entity> parent;
+        if (i > 10 && next() % 2) parent = ents[next() % ents.size()];
+        spawn(parent, i % 9 == 0);
+    }
+    ClusterCamera cam;
+    mi_perspective_clip_from_view(3.14159265f / 4.0f, 16.0f / 9.0f, 0.1f, cam.clip_from_view);
+    mi_compute_frustum(cam.clip_from_view, cam.camera_affine, 1000.0f, cam.frustum);
+    View view;
+    std::memcpy(view.frustum, cam.frustum, sizeof view.frustum);
+    View side = camera_looking_down_neg_z();
+    const std::vector<View> views = {view, side};
+    for (int frame = 0; frame < 14; ++frame) {
+        if (frame) { wa.clear_trackers(); wb.clear_trackers(); }
+        // edits
+        const int n_moves = frame % 4 == 3 ? 0 : 1 + (int)(next() % 25);
+        for (int k = 0; k < n_moves; ++k) {
+            const Entity e = ents[next() % ents.size()];
+            if (!wa.contains(e)) continue;
+            const float dz = frand(-3, 3), dx = frand(-1, 1);
+            wa.transform_mut(e).translation.z += dz; wb.transform_mut(e).translation.z += dz;
+            wa.transform_mut(e).translation.x += dx; wb.transform_mut(e).translation.x += dx;
+        }
+        if (frame % 3 == 1) {
+            const Entity e = ents[next() % ents.size()];
+            if (wa.contains(e)) { const Visibility v = (Visibility)(next() % 3); wa.insert_visibility(e, v); wb.insert_visibility(e, v); }
+        }
+        if (frame == 4 || frame == 9) spawn(ents[next() % 20], frame == 9);
+        if (frame == 6) {
+            const Entity e = ents[40 + next() % 50];
+            if (wa.contains(e) && wa.children(e).empty()) { wa.despawn(e); wb.despawn(e); }
+        }
+        if (frame == 7) {
+            const Entity e = ents[30 + next() % 30];
+            if (wa.contains(e) && wa.parent(e)) { wa.remove_parent(e); wb.remove_parent(e); }
+        }
+        wa.static_transform_optimizations = wb.static_transform_optimizations = frame >= 10;
+        // A: the three systems
+        pa.propagate_transforms(wa);
+        pa.visibility_propagate(wa);
+        pa.check_visibility(wa, views);
+        const Clusters ca = pa.assign_objects_to_clusters(wa, cam);
+        // B: the fused frame
+        const Mi355xPlugin::FrameOutput fb = pb.frame(wb, views, &cam);
+        if (frame > 0 && frame % 4 == 3) CHECK(fb.device_waits == 1, "a frame without structural edits is one device wait");
+        bool same = true, same_ticks = true;
+        for (Entity e : wa.entities()) {
+            same = same && wb.contains(e) && wa.global_transform(e) == wb.global_transform(e) && wa.inherited_visibility(e) == wb.inherited_visibility(e) &&
+                   wa.view_visibility(e) == wb.view_visibility(e);
+            same_ticks = same_ticks && wa.global_transform_changed(e) == wb.global_transform_changed(e) &&
+                         wa.view_visibility_changed(e) == wb.view_visibility_changed(e) &&
+                         wa.inherited_visibility_changed(e) == wb.inherited_visibility_changed(e);
+        }
+        CHECK(same, "component values");
+        CHECK(same_ticks, "change ticks");
+        for (uint32_t v = 0; v < views.size(); ++v) CHECK(pa.visible_entities(v) == fb.visible_entities[v], "VisibleEntities");
+        CHECK(fb.has_clusters && ca.clusterable_objects.size() == fb.clusters.clusterable_objects.size(), "Clusters: grid");
+        bool lists = fb.has_clusters && ca.total_index_count == fb.clusters.total_index_count && ca.farthest_z == fb.clusters.farthest_z;
+        for (size_t c = 0; lists && c < ca.clusterable_objects.size(); ++c)
+            lists = ca.clusterable_objects[c].entities == fb.clusters.clusterable_objects[c].entities &&
+                    std::memcmp(ca.clusterable_objects[c].counts, fb.clusters.clusterable_objects[c].counts, sizeof ca.clusterable_objects[c].counts) == 0;
+        CHECK(lists, "Clusters: lists, counts, farthest_z");
+        if (frame == 2) CHECK(ca.total_index_count > 0, "some light is in view");
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// --bench: BASELINE's metric scene (1 M many_cubes entities + 10 k meshes + 100 k point lights, one camera) through the host
+// layer, both call sequences, at 1 % / 10 % / 100 % of the Transforms moved per frame.  Prints one JSON object.
+// ---------------------------------------------------------------------------------------------------------------------
+static uint64_t splitmix64(uint64_t& x) {
+    uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static Transform on_sphere(uint64_t i, uint64_t n, double radius, uint64_t& seed, bool rotate) {
+    const double golden = 3.883222077450933;  // pi * (3 - sqrt(5))
+    const double phi = std::acos(1.0 - 2.0 * ((double)i + 0.36) / ((double)n - 1.0 + 0.72)), theta = golden * (double)i;
+    Transform t = Transform::from_xyz((float)(radius * std::cos(theta) * std::sin(phi)), (float)(radius * std::sin(theta) * std::sin(phi)),
+                                      (float)(radius * std::cos(phi)));
+    if (rotate) {
+        double q[4], len = 0;
+        for (double& c : q) { c = (double)(splitmix64(seed) >> 11) / 9007199254740992.0 * 2.0 - 1.0; len += c * c; }
+        len = std::sqrt(len);
+        t.rotation = {(float)(q[0] / len), (float)(q[1] / len), (float)(q[2] / len), (float)(q[3] / len)};
+    }
+    return t;
+}
+static int bench(uint32_t n_cubes, uint32_t n_meshes, uint32_t n_lights, int frames) {
+    std::printf("{\"scene\": {\"cubes\": %u, \"meshes\": %u, \"lights\": %u}", n_cubes, n_meshes, n_lights);
+    for (int fused = 0; fused < 2; ++fused) {
+        World w;
+        Mi355xPlugin plugin;
+        uint64_t seed = 42;
+        std::vector<Entity> ents;
+        ents.reserve((size_t)n_cubes + n_meshes + n_lights);
+        for (uint32_t i = 0; i < n_cubes; ++i) { Entity e = w.spawn(on_sphere(i, n_cubes, 500.0, seed, true)); w.insert_aabb(e, Aabb{{0, 0, 0}, {0.5f, 0.5f, 0.5f}}); ents.push_back(e); }
+        for (uint32_t i = 0; i < n_meshes; ++i) { Entity e = w.spawn(on_sphere(i, n_meshes, 40.0, seed, true)); w.insert_aabb(e, Aabb{{0, 0, 0}, {0.5f, 0.5f, 0.5f}}); ents.push_back(e); }
+        for (uint32_t i = 0; i < n_lights; ++i) { Entity e = w.spawn(on_sphere(i, n_lights, 50.0, seed, false)); w.insert_point_light(e, 0.3f); ents.push_back(e); }
+        ClusterCamera cam;
+        mi_perspective_clip_from_view(3.14159265f / 4.0f, 16.0f / 9.0f, 0.1f, cam.clip_from_view);
+        auto set_camera = [&](int frame) {  // many_cubes.rs:590-603: rotate_z(d); rotate_x(d), d = 0.15 / 60 per frame
+            const float a = 0.5f * 0.0025f * (float)frame, sz = std::sin(a), cz = std::cos(a);
+            Transform t;  // q = qz * qx
+            t.rotation = {cz * sz, sz * sz, sz * cz, cz * cz};
+            const GlobalTransform g = GlobalTransform::from(t);
+            std::memcpy(cam.camera_affine, g.cols, sizeof cam.camera_affine);
+            mi_compute_frustum(cam.clip_from_view, cam.camera_affine, 1000.0f, cam.frustum);
+        };
+        std::printf(", \"%s\": {", fused ? "fused_frame" : "three_systems");
+        const int pcts[3] = {1, 10, 100};
+        for (int pi = 0; pi < 3; ++pi) {
+            const size_t k = ents.size() * (size_t)pcts[pi] / 100;
+            std::vector<double> total, gather, device, apply;
+            uint32_t visible = 0, waits = 0;
+            uint64_t cluster_entries = 0;
+            for (int f = 0; f < frames + 3; ++f) {
+                // the game's own update: k entities move (spread over the whole scene)
+                const size_t stride = ents.size() / std::max<size_t>(k, 1), off = (size_t)f % std::max<size_t>(stride, 1);
+                for (size_t j = 0; j < k; ++j) w.transform_mut(ents[std::min(j * stride + off, ents.size() - 1)]).translation.y += 0.001f;
+                set_camera(f);
+                View view;
+                std::memcpy(view.frustum, cam.frustum, sizeof view.frustum);
+                const auto t0 = std::chrono::steady_clock::now();
+                if (fused) {
+                    const Mi355xPlugin::FrameOutput o = plugin.frame(w, {view}, &cam);
+                    visible = (uint32_t)o.visible_entities[0].size();
+                    cluster_entries = o.clusters.total_index_count;
+                    waits = o.device_waits;
+                    if (f >= 3) { gather.push_back(o.gather_s); device.push_back(o.device_s); apply.push_back(o.apply_s); }
+                } else {
+                    plugin.propagate_transforms(w);
+                    plugin.check_visibility(w, {view});
+                    visible = (uint32_t)plugin.visible_entities(0).size();
+                    cluster_entries = plugin.assign_objects_to_clusters(w, cam).total_index_count;
+                }
+                const auto t1 = std::chrono::steady_clock::now();
+                if (f >= 3) total.push_back(std::chrono::duration<double>(t1 - t0).count());
+                w.clear_trackers();
+            }
+            auto med = [](std::vector<double> v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+            std::printf("%s\"%dpct_dirty\": {\"dirty_rows\": %zu, \"us_per_frame\": %.1f, \"visible\": %u, \"cluster_entries\": %llu", pi ? ", " : "", pcts[pi], k,
+                        1e6 * med(total), visible, (unsigned long long)cluster_entries);
+            if (fused) std::printf(", \"gather_us\": %.1f, \"library_calls_us\": %.1f, \"ecs_writes_us\": %.1f, \"device_waits\": %u", 1e6 * med(gather), 1e6 * med(device), 1e6 * med(apply), waits);
+            std::printf("}");
+        }
+        std::printf("}");
+    }
+    std::printf("}\n");
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "--bench") {
+        const uint32_t n = argc > 2 ? (uint32_t)std::atoi(argv[2]) : 1000000u;
+        return bench(n, n / 100, n / 10, argc > 3 ? std::atoi(argv[3]) : 10);
+    }
     struct T { const char* name; void (*fn)(); };
     const T tests[] = {{"correct_parent_removed", correct_parent_removed},
                        {"did_propagate", did_propagate},
@@ -431,19 +647,25 @@ int main() {
                        {"view_visibility_lifecycle", view_visibility_lifecycle},
                        {"visible_entities_are_sorted_by_entity", visible_entities_are_sorted_by_entity},
                        {"lights_are_assigned_to_clusters", lights_are_assigned_to_clusters},
-                       {"render_multidrawable_batch_set", render_multidrawable_batch_set}};
-    int n_failed_tests = 0;
-    for (const T& t : tests) {
-        const int before = g_failed;
-        try {
-            t.fn();
-        } catch (const std::exception& e) {
-            ++g_failed;
-            std::printf("  EXCEPTION in %s: %s\n", t.name, e.what());
+                       {"render_multidrawable_batch_set", render_multidrawable_batch_set},
+                       {"both_forms_leave_the_same_world", both_forms_leave_the_same_world}};
+    int n_failed_tests = 0, n_tests = 0;
+    for (int form = 0; form < 2; ++form) {
+        g_fused = form == 1;
+        for (const T& t : tests) {
+            if (form == 1 && t.fn == both_forms_leave_the_same_world) continue;  // (drives both forms itself)
+            const int before = g_failed;
+            ++n_tests;
+            try {
+                t.fn();
+            } catch (const std::exception& e) {
+                ++g_failed;
+                std::printf("  EXCEPTION in %s: %s\n", t.name, e.what());
+            }
+            std::printf("%s %s [%s]\n", g_failed == before ? "ok    " : "FAILED", t.name, g_fused ? "fused frame" : "three systems");
+            if (g_failed != before) ++n_failed_tests;
         }
-        std::printf("%s %s\n", g_failed == before ? "ok    " : "FAILED", t.name);
-        if (g_failed != before) ++n_failed_tests;
     }
-    std::printf("%d tests, %d failed (%d checks)\n", (int)(sizeof tests / sizeof tests[0]), n_failed_tests, g_checks);
+    std::printf("%d tests, %d failed (%d checks)\n", n_tests, n_failed_tests, g_checks);
     return n_failed_tests ? 1 : 0;
 }

@@ -25,4 +25,4 @@ def test_reference_system_tests_against_the_host_layer():
     print(res.stdout)
     failed = [line for line in res.stdout.splitlines() if line.startswith("FAILED") or "EXCEPTION" in line]
     assert res.returncode == 0 and not failed, res.stdout[-3000:] + res.stderr[-1000:]
-    assert "13 tests, 0 failed" in res.stdout
+    assert "27 tests, 0 failed" in res.stdout  # 14 tests against the three systems, 13 of them again against the fused frame

@@ -302,14 +302,12 @@ def test_frame_results_in_one_call_equal_the_separate_downloads(ctx_factory):
     small = api.FrameResultBuffers(n, 3, 0, 0)
     with pytest.raises(api.MiError) as e:
         ctx.download_frame_results(small)
-    assert e.value.code == api.MI_ERR_CAPACITY and small.raw.visible_count == vis.size
+    assert e.value.code == api.MI_ERR_CAPACITY and small.list_count(0) == vis.size
     # rows without GlobalTransforms and the other way round (sections of the packed window come and go)
-    rows_only = api.FrameResultBuffers(n, n, 0, 0)
-    rows_only.raw.changed_global12 = None
+    rows_only = api.FrameResultBuffers(n, n, 0, 0, want_globals=False)
     got = ctx.download_frame_results(rows_only)
-    assert np.array_equal(got["changed_rows"], ch_rows) and np.array_equal(got["visible_rows"], vis)
-    g_only = api.FrameResultBuffers(n, 0, n_clusters, 4 * n_l * 8)
-    g_only.raw.changed_rows = None
+    assert np.array_equal(got["changed_rows"], ch_rows) and np.array_equal(got["visible_rows"], vis) and got["changed_global"].size == 0
+    g_only = api.FrameResultBuffers(n, 0, n_clusters, 4 * n_l * 8, want_rows=False)
     got = ctx.download_frame_results(g_only)
     assert got["changed_global"].tobytes() == ch_g.tobytes() and np.array_equal(got["cluster_indices"], idx)
     assert np.array_equal(got["cluster_offsets"], off) and got["farthest_z"] == far
@@ -318,8 +316,14 @@ def test_frame_results_in_one_call_equal_the_separate_downloads(ctx_factory):
     with pytest.raises(api.MiError) as e:
         ctx.download_frame_results(tight)
     assert e.value.code == api.MI_ERR_CAPACITY and tight.raw.changed_count == ch_rows.size
-    assert np.array_equal(tight.visible_rows[:tight.raw.visible_count], vis)
+    assert np.array_equal(tight.visible_rows[:tight.list_count(0)], vis)
     assert np.array_equal(tight.cluster_indices[:tight.raw.cluster_total], idx)
+    # the same frame delivered IN PLACE: pointers into the library's pinned window, nothing copied out
+    inplace = api.FrameResultBuffers(n, n, n_clusters, 4 * n_l * 8, in_place=True)
+    got = ctx.download_frame_results(inplace)
+    assert np.array_equal(got["changed_rows"], ch_rows) and got["changed_global"].tobytes() == ch_g.tobytes()
+    assert np.array_equal(got["visible_rows"], vis) and np.array_equal(got["cluster_offsets"], off) and np.array_equal(got["cluster_indices"], idx)
+    assert np.array_equal(got["cluster_counts"], counts) and got["farthest_z"] == far
 
 
 @pytest.mark.gpu
@@ -350,6 +354,10 @@ def test_frame_results_beyond_the_packed_window_take_the_copy_path(ctx_factory):
         assert np.array_equal(got["changed_rows"], rows) and np.array_equal(ch_rows, rows), f"frame {f}"
         assert got["changed_global"].tobytes() == ch_g.tobytes(), f"frame {f}"
         assert np.array_equal(got["visible_rows"], vis) and vis.size > 0, f"frame {f}"
+        # in place the window is as big as the results: one launch, one wait at any size
+        got = ctx.download_frame_results(api.FrameResultBuffers(n, n, 0, 0, in_place=True))
+        assert np.array_equal(got["changed_rows"], rows) and got["changed_global"].tobytes() == ch_g.tobytes(), f"frame {f} in place"
+        assert np.array_equal(got["visible_rows"], vis), f"frame {f} in place"
 
 
 @pytest.mark.gpu

@@ -1,0 +1,150 @@
+"""GPU parity of the round-3 entry points: the frame call with a hierarchy uploaded (mi_propagate_and_cull_views = mi_propagate +
+mi_cull in one call), mi_download_frame_results with several VisibleEntities lists on both compaction paths, lights bound to
+arbitrary rows (mi_cluster_bind_objects_to_row_list)."""
+import numpy as np
+import pytest
+
+import bevy_amd as B
+from bevy_amd import api, workloads as W
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def frusta_for(cams):
+    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+    return np.concatenate([api.compute_frustum(cfv, cam, W.CAMERA_FAR) for cam in cams])
+
+
+def assert_bits(a, b, what):
+    bad = np.nonzero(np.asarray(a) != np.asarray(b))[0]
+    assert bad.size == 0, f"{what}: {bad.size} mismatches, first rows {bad[:8].tolist()}"
+
+
+def upload_tree_scene(ctx, tr, c, h):
+    ctx.resize(tr["n"])
+    ctx.upload_transforms(tr["translation"], tr["rotation"], tr["scale"])
+    ctx.upload_hierarchy(tr["parent"], tr["level_offsets"])
+    ctx.upload_bounds(c, h)
+
+
+@pytest.mark.parametrize("static_opt", [False, True])
+def test_frame_call_with_a_hierarchy_equals_propagate_then_cull(static_opt):
+    """mi_propagate_and_cull_views with a hierarchy: the tile launches of mi_propagate and the cull in ONE call -- frame by frame
+    the same GlobalTransforms, change ticks, masks, lists and ViewVisibility as mi_propagate + mi_cull on a twin context and as
+    the oracle; all-dirty and changed-rows frames, with and without the static-scene rule."""
+    tr = W.gen_tree(8, 4)
+    n = tr["n"]
+    t = tr["translation"].reshape(n, 3).copy()
+    r4, s3 = tr["rotation"].reshape(n, 4), tr["scale"].reshape(n, 3)
+    c, h = np.zeros(3 * n, F), np.full(3 * n, 0.5, F)
+    flags, layers = np.full(n, 0x05, np.uint8), np.ones(n, np.uint32)
+    pf = B.PROPAGATE_STATIC_OPT if static_opt else 0
+    cf = B.CULL_STATIC_OPT if static_opt else 0
+    with api.Context(0) as a, api.Context(0) as b:
+        for ctx in (a, b):
+            upload_tree_scene(ctx, tr, c, h)
+            ctx.upload_changed(np.ones(n, np.uint8))
+        vv = np.zeros(n, np.uint8)
+        for frame, node in enumerate([None, 7, None, 300, 0, None]):
+            if node is not None:
+                t[node] += F(2.0)
+                for ctx in (a, b):
+                    ctx.upload_transforms_indexed(np.array([node], np.uint32), t[node], r4[node], s3[node])
+            frusta = frusta_for([W.many_cubes_camera(frame * 20, position=(0.0, 0.0, 150.0)), W.many_cubes_camera(0, yaw=0.5, position=(10.0, 0.0, 120.0))])
+            all_dirty = frame == 4
+            a.propagate_and_cull(frusta, flags=B.CULL_END_FRAME | cf | (0 if all_dirty else B.CULL_CHANGED_ROWS))
+            b.propagate(pf | (B.PROPAGATE_ALL_DIRTY if all_dirty else 0))
+            b.cull(frusta, flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME)
+            _, g, _ = O.propagate_transforms(tr["parent"], t.reshape(-1), tr["rotation"], tr["scale"])
+            vv1 = O.reset_view_visibility(flags, vv)
+            vv2, vis, chg = O.check_visibility(g, c, h, flags, layers, vv1, frusta)
+            vv3, chg2 = O.check_visibility_gpu_culling(flags, vv2)
+            vv, chg3 = O.mark_newly_hidden(flags, vv3)
+            ga, ca = a.download_global_transforms()
+            gb, cb = b.download_global_transforms()
+            assert ga.tobytes() == gb.tobytes() == g.tobytes(), f"frame {frame}: GlobalTransform"
+            assert_bits(ca, cb, f"frame {frame}: GlobalTransform change ticks")
+            for v in range(2):
+                assert_bits(a.download_visibility(v), vis[v], f"frame {frame} view {v}")
+                assert np.array_equal(a.download_visible_entities(v, 0)[1], b.download_visible_entities(v, 0)[1])
+            va, cva = a.download_view_visibility()
+            assert_bits(va, vv, f"frame {frame}: ViewVisibility")
+            assert_bits(cva, chg | chg2 | chg3, f"frame {frame}: ViewVisibility change ticks")
+
+
+@pytest.mark.parametrize("keys", ["rows", "shuffled"])
+def test_frame_results_carry_every_list_on_both_compaction_paths(keys):
+    """mi_download_frame_results with one list per (view, class): rows numbered in key order (single-launch compaction, strided
+    lists) and in arbitrary order (count / scan / scatter through the key permutation, lists back to back) -- copy-out and in
+    place, against mi_download_visible_entities."""
+    n = 30_000
+    sc = W.many_cubes(n, radius=60.0, ragged_flags=True)
+    rnd = W.splitmix64(99, n)
+    class_mask = np.where(rnd % np.uint64(5) == 0, 0b101, np.where(rnd % np.uint64(5) == 1, 0b100, 0b001)).astype(np.uint32)
+    frusta = frusta_for([W.many_cubes_camera(0), W.many_cubes_camera(0, yaw=1.0), W.many_cubes_camera(0, yaw=2.0)])
+    with api.Context(0) as ctx:
+        ctx.resize(n)
+        ctx.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
+        ctx.upload_bounds(sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"])
+        ctx.upload_visibility_classes(class_mask)
+        if keys == "shuffled":
+            ctx.upload_entity_keys((np.uint64(0xFFFFFFFF) - np.random.default_rng(1).permutation(n).astype(np.uint64)))
+        ctx.propagate_and_cull(frusta, flags=B.CULL_END_FRAME)
+        spec = [(v, cb, n) for v in range(3) for cb in (0, 2)] + [(1, 7, n)]  # class 7: no row carries it -> an empty list
+        want = [ctx.download_visible_entities(v, cb)[1] for v, cb, _ in spec]
+        assert sum(len(x) for x in want) > 0 and len(want[-1]) == 0
+        for in_place in (False, True):
+            bufs = api.FrameResultBuffers(n, 0, 0, 0, lists=spec, in_place=in_place)
+            got = ctx.download_frame_results(bufs)
+            for k in range(len(spec)):
+                assert np.array_equal(got["lists"][k], want[k]), (keys, in_place, spec[k])
+            assert got["changed_rows"].size == n  # every row was propagated
+        tight = api.FrameResultBuffers(0, 0, 0, 0, lists=[(0, 0, n), (1, 0, 3), (2, 0, n)])
+        with pytest.raises(api.MiError) as e:
+            ctx.download_frame_results(tight)
+        assert e.value.code == api.MI_ERR_CAPACITY and tight.list_count(1) == len(want[2])
+        assert np.array_equal(tight.list_rows[0][:tight.list_count(0)], want[0]) and np.array_equal(tight.list_rows[2][:tight.list_count(2)], want[4])
+
+
+def test_lights_bound_to_arbitrary_rows():
+    """mi_cluster_bind_objects_to_row_list: the lights of the metric scene scattered over the row space (every 11th row from a
+    random start is a light) give the same clusters as the same lights in a contiguous block -- riding in the frame launch
+    (MI_CULL_WITH_CLUSTERS) and as a launch of their own."""
+    sc, first_light, pr = W.frame_scene(30_000, 3_000, 300, light_range=2.0)
+    n, n_l = sc["n"], len(pr) // 4
+    rng = np.random.default_rng(8)
+    light_rows = np.sort(rng.choice(n, n_l, replace=False)).astype(np.uint32)
+    other_rows = np.setdiff1d(np.arange(n, dtype=np.uint32), light_rows)
+    perm = np.empty(n, np.int64)           # new row -> old row: lights keep their order, everything else too
+    perm[light_rows] = np.arange(first_light, first_light + n_l)
+    perm[other_rows] = np.concatenate([np.arange(0, first_light), np.arange(first_light + n_l, n)])
+    def take(col, w):
+        return np.ascontiguousarray(np.asarray(col).reshape(n, w)[perm]).reshape(-1) if w > 1 else np.ascontiguousarray(np.asarray(col)[perm])
+    sc2 = dict(n=n, translation=take(sc["translation"], 3), rotation=take(sc["rotation"], 4), scale=take(sc["scale"], 3),
+               aabb_center=take(sc["aabb_center"], 3), aabb_half=take(sc["aabb_half"], 3), flags=take(sc["flags"], 1), layers=take(sc["layers"], 1))
+    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+    out = {}
+    for name, scene, bind in (("block", sc, lambda c: c.cluster_bind_objects_to_rows(first_light, n_l)),
+                              ("list", sc2, lambda c: c.cluster_bind_objects_to_row_list(light_rows))):
+        with api.Context(0) as ctx:
+            ctx.resize(n)
+            ctx.upload_transforms(scene["translation"], scene["rotation"], scene["scale"])
+            ctx.upload_bounds(scene["aabb_center"], scene["aabb_half"], scene["flags"], scene["layers"])
+            ctx.cluster_upload_objects(pr)
+            bind(ctx)
+            res = []
+            for frame in range(3):
+                cam = W.many_cubes_camera(frame * 40)
+                fr = api.compute_frustum(cfv, cam, W.CAMERA_FAR)
+                view, keep = api.cluster_view_build(cam, cfv, fr, 1920, 1080, (16, 9, 24), 5.0, 1000.0, with_spheres=False)
+                ctx.cluster_upload_view(view)
+                ctx.propagate_and_cull(fr, flags=B.CULL_END_FRAME | B.CULL_WITH_CLUSTERS)
+                off, idx, counts, far, total = ctx.cluster_download(view.n_clusters)
+                ctx.cluster_assign_resident()  # a launch of its own, reading the ViewVisibility column the frame left
+                off2, idx2, counts2, far2, total2 = ctx.cluster_download(view.n_clusters)
+                assert total == total2 and np.array_equal(off, off2) and np.array_equal(idx[:total], idx2[:total]) and far == far2
+                res.append((off.tobytes(), idx[:total].tobytes(), counts.tobytes(), far, total))
+            out[name] = res
+    assert out["block"] == out["list"] and out["block"][0][4] > 0

@@ -589,11 +589,32 @@ def cpu_baseline_other(name, wl):
 # ---------------------------------------------------------------------------------------------------------------------
 # end-to-end: the same frame with the host on both sides of it (PCIe-inclusive; never `value`)
 # ---------------------------------------------------------------------------------------------------------------------
+def pcie_peak():
+    """What the link gives: hipMemcpyAsync between pinned host memory and the device, 64 MiB, both directions (GB/s)."""
+    import torch
+    n = 64 << 20
+    host = torch.empty(n, dtype=torch.uint8).pin_memory()
+    dev = torch.empty(n, dtype=torch.uint8, device="cuda")
+    out = {}
+    for name, (dst, src) in (("h2d", (dev, host)), ("d2h", (host, dev))):
+        best = 0.0
+        for _ in range(6):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            dst.copy_(src, non_blocking=True)
+            b.record()
+            b.synchronize()
+            best = max(best, n / (a.elapsed_time(b) * 1e-3) / 1e9)
+        out[name] = round(best, 2)
+    return out
+
+
 def end_to_end(ctx, wl, frames=12):
-    """Per frame: the rows a Changed<Transform> query yields go in (mi_upload_transforms_indexed; the whole column at 100 %),
-    the frame runs, and what the ECS needs comes back: the changed GlobalTransforms (sparse read-back; the whole column at
-    100 %), the camera's VisibleEntities list and the cluster offsets / counts / index list.  Wall clock, synchronised every
-    frame -- the downloads synchronise anyway."""
+    """The same frame with the host on both sides of it.  Per frame: the rows a Changed<Transform> query yields go in -- written
+    straight into the library's pinned upload window (mi_map_upload_window / mi_commit_upload_window; dense at 100 %) --, ONE frame
+    call runs propagate + cull + cluster (MI_CULL_CHANGED_ROWS below 100 %), and what the ECS needs comes back with ONE
+    mi_download_frame_results delivered in place: the changed GlobalTransforms, the camera's VisibleEntities list, the cluster
+    offsets / counts / index list.  Wall clock, synchronised every frame."""
     import bevy_amd as B
     from bevy_amd import api, workloads as W
     sc = wl.scene
@@ -601,53 +622,82 @@ def end_to_end(ctx, wl, frames=12):
     views = wl.keep[0]
     t3 = sc["translation"].reshape(n, 3)
     r4, s3 = sc["rotation"].reshape(n, 4), sc["scale"].reshape(n, 3)
-    out = {}
+    link = pcie_peak()
+    out = {"pcie_peak_GBps": link}
     rng = np.random.default_rng(0)
     ctx.upload_changed(np.zeros(n, np.uint8))
     ctx.propagate(B.PROPAGATE_ALL_DIRTY)
     ctx.synchronize()
-    bufs = api.FrameResultBuffers(n, n, views[0].n_clusters, 1 << 20)  # the caller's slices, allocated once like an ECS system's
+    bufs = api.FrameResultBuffers(n, n, views[0].n_clusters, 1 << 20, in_place=True)
     for pct in (1, 10, 100):
         k = n * pct // 100
         rows = np.sort(rng.choice(n, k, replace=False)).astype(np.uint32) if pct < 100 else None
-        if rows is not None:
-            tt, rr, ss = np.ascontiguousarray(t3[rows]).reshape(-1), np.ascontiguousarray(r4[rows]).reshape(-1), np.ascontiguousarray(s3[rows]).reshape(-1)
-        times, h2d, d2h = [], 0, 0
+        times, t_in, t_run, t_out, h2d, d2h = [], [], [], [], 0, 0
         for f in range(frames + 2):
             fr = api.PreparedFrusta(camera_frusta(1, f))
             ctx.synchronize()
             t0 = time.perf_counter()
             ctx.cluster_upload_view(views[f % N_FRAMES])
-            if rows is not None:  # only the dirty rows are recomputed, in the frame launch itself; it carries the cluster walk too
-                ctx.upload_transforms_indexed(rows, tt, rr, ss)
-                ctx.propagate_and_cull(fr, flags=B.CULL_END_FRAME | B.CULL_WITH_CLUSTERS | B.CULL_CHANGED_ROWS)
+            if rows is not None:  # the ECS side's gather loop, writing into the window
+                w, wrows, wt, wr, ws = ctx.map_upload_window(k)
+                wrows[:] = rows
+                np.take(t3, rows, axis=0, out=wt.reshape(k, 3))
+                np.take(r4, rows, axis=0, out=wr.reshape(k, 4))
+                np.take(s3, rows, axis=0, out=ws.reshape(k, 3))
+                ctx.commit_upload_window(w, k)
             else:
-                ctx.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
-                ctx.propagate_and_cull(fr, flags=B.CULL_END_FRAME | B.CULL_WITH_CLUSTERS)
-            if rows is not None:  # one call, one packing launch, one device wait: changed GlobalTransforms, the camera's list, the cluster lists
-                res = ctx.download_frame_results(bufs)
-                got_g, vis_rows, off, counts, total = len(res["changed_rows"]), res["visible_rows"], res["cluster_offsets"], res["cluster_counts"], res["cluster_total"]
-            else:
-                g = ctx.download_global_transforms(want_changed=False)
-                got_g = n
-                _, vis_rows = ctx.download_visible_entities(0, 0)
-                off, idx, counts, far, total = ctx.cluster_download(views[0].n_clusters)
+                w, _, wt, wr, ws = ctx.map_upload_window(n, dense=True)
+                wt[:], wr[:], ws[:] = sc["translation"], sc["rotation"], sc["scale"]
+                ctx.commit_upload_window(w, n)
             t1 = time.perf_counter()
+            ctx.propagate_and_cull(fr, flags=B.CULL_END_FRAME | B.CULL_WITH_CLUSTERS | (B.CULL_CHANGED_ROWS if rows is not None else 0))
+            t2 = time.perf_counter()
+            res = ctx.download_frame_results(bufs)
+            got_g, vis_rows, off, counts, total = len(res["changed_rows"]), res["visible_rows"], res["cluster_offsets"], res["cluster_counts"], res["cluster_total"]
+            t3_ = time.perf_counter()
             if f >= 2:
-                times.append(t1 - t0)
-            h2d = (k * 44) if rows is not None else n * 40
-            d2h = got_g * (52 if rows is not None else 48) + len(vis_rows) * 4 + len(off) * 4 + counts.size * 4 + total * 4
+                times.append(t3_ - t0)
+                t_in.append(t1 - t0)
+                t_run.append(t2 - t1)
+                t_out.append(t3_ - t2)
+            h2d = k * 44 if rows is not None else n * 40
+            d2h = got_g * 52 + len(vis_rows) * 4 + len(off) * 4 + counts.size * 4 + total * 4
         med = float(np.median(times))
+        eff = (h2d + d2h) / med / 1e9
+        # the two directions are one after the other in a synchronised frame: the link-bound time is the sum of both at their peaks
+        link_s = h2d / (link["h2d"] * 1e9) + d2h / (link["d2h"] * 1e9)
         out[f"{pct}pct_dirty"] = {"dirty_rows": int(k), "us_per_frame": round(1e6 * med, 1), "entities_per_s": round(wl.units / med, 1),
-                                  "h2d_bytes": int(h2d), "d2h_bytes": int(d2h), "pcie_GBps_effective": round((h2d + d2h) / med / 1e9, 2),
+                                  "h2d_bytes": int(h2d), "d2h_bytes": int(d2h), "pcie_GBps_effective": round(eff, 2),
+                                  "pcie_frac": round(link_s / med, 3),
+                                  "stage_us": {"gather_into_window_and_commit": round(1e6 * float(np.median(t_in)), 1),
+                                               "frame_call": round(1e6 * float(np.median(t_run)), 1),
+                                               "results_in_place": round(1e6 * float(np.median(t_out)), 1)},
                                   "changed_global_transforms_read_back": int(got_g), "visible_entities": int(len(vis_rows)),
                                   "cluster_index_entries": int(total)}
-    out["note"] = ("same frame as `value` with the host on both sides: dirty Transforms H2D (mi_upload_transforms_indexed / the whole "
-                   "column at 100 %), propagate + cull + cluster (one launch: MI_CULL_CHANGED_ROWS below 100 %), then changed GlobalTransforms, the camera's VisibleEntities list and the "
-                   "cluster lists D2H (mi_download_frame_results: one call, one packing launch into pinned memory, one device wait -- two beyond 8 MB; at 100 % the whole GlobalTransform column "
-                   f"and the separate downloads); median wall time of {frames} frames, each synchronised (pageable host arrays, one "
-                   "staging copy each way)")
+    out["note"] = ("same frame as `value` with the host on both sides, through ctypes: dirty Transforms written into the library's pinned upload "
+                   "window (no staging copy; numpy's gather is the ECS side's loop) and committed, ONE frame call (propagate + cull + "
+                   "cluster, MI_CULL_CHANGED_ROWS), ONE mi_download_frame_results delivered in place (one packing launch into pinned memory, one "
+                   f"device wait, no copy out); median wall time of {frames} frames, each synchronised.  pcie_frac = (h2d / peak_h2d + d2h / "
+                   "peak_d2h) / frame time, peaks measured in this run with pinned hipMemcpyAsync (pcie_peak_GBps)")
     return out
+
+
+def end_to_end_host_layer(n_entities):
+    """The same frames through the C++ host layer (bevy_amd/host/bevy_mi355x_host.hpp: a World with the path's components and
+    change flags, Mi355xPlugin) -- the code a maintainer would ship as the plugin's systems, not ctypes: the three systems of
+    round 2 (a device wait each) next to the fused frame (Mi355xPlugin::frame: one upload window, one frame call, one in-place
+    results call).  tests/cpp/host_systems_test --bench prints the JSON."""
+    import subprocess
+    from bevy_amd import build as mi_build
+    exe = mi_build.build_host_tests()
+    res = subprocess.run([exe, "--bench", str(n_entities), "8"], capture_output=True, text=True, timeout=600)
+    if res.returncode != 0:
+        return {"error": (res.stderr or res.stdout)[-500:]}
+    d = json.loads(res.stdout.strip().splitlines()[-1])
+    d["note"] = ("tests/cpp/host_systems_test --bench: median wall time of 8 frames per dirty fraction, World::clear_trackers outside the timed "
+                 "region.  us_per_frame is the whole system -- the World's change scan, gather, library calls, ECS writes incl. the stock "
+                 "reset_view_visibility / mark_newly_hidden passes; library_calls_us is upload commit .. results returned (what the ctypes block above times)")
+    return d
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -739,6 +789,7 @@ def main():
         if world == 1 and workload == "frame" and not args.no_end_to_end:
             with torch.cuda.stream(stream):
                 out["end_to_end"] = end_to_end(ctx, wl)
+            out["end_to_end_host_layer"] = end_to_end_host_layer(wl.units)
     if world > 1 and workload == "sharded":
         # the same scene, whole, on rank 0's GPU alone (outside the timed region): what N = 1 gives for THIS workload
         single = None

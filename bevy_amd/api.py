@@ -141,6 +141,15 @@ class FrameResultBuffers:
         return int(self._lists[k].count)
 
 
+class UploadWindow(C.Structure):
+    """mi_upload_window"""
+    _fields_ = [("rows", C.POINTER(C.c_uint32)), ("translation", C.POINTER(C.c_float)), ("rotation", C.POINTER(C.c_float)),
+                ("scale", C.POINTER(C.c_float)), ("capacity", C.c_uint32), ("flags", C.c_uint32)]
+
+
+UPLOAD_DENSE = 0x1
+
+
 class View(C.Structure):
     """mi_view"""
     _fields_ = [("frustum", C.c_float * 24), ("layer_mask", C.c_uint32), ("flags", C.c_uint32),
@@ -175,7 +184,7 @@ NO_INPUT_INDEX = 0xFFFFFFFF
 
 ABI_SYMBOLS = [
     "mi_abi_version", "mi_ctx_create", "mi_ctx_destroy", "mi_last_error_string", "mi_synchronize",
-    "mi_columns_resize", "mi_upload_transforms", "mi_upload_transforms_indexed", "mi_upload_global_transforms", "mi_upload_bounds",
+    "mi_columns_resize", "mi_upload_transforms", "mi_upload_transforms_indexed", "mi_map_upload_window", "mi_commit_upload_window", "mi_upload_global_transforms", "mi_upload_bounds",
     "mi_upload_view_visibility", "mi_upload_visibility_classes", "mi_upload_entity_keys", "mi_upload_changed",
     "mi_upload_visibility_ranges", "mi_upload_visibility", "mi_upload_hierarchy", "mi_hierarchy_sort", "mi_propagate",
     "mi_visibility_propagate", "mi_download_inherited_visibility",
@@ -401,6 +410,17 @@ class Context:
         self._ck(self._lib.mi_upload_transforms_indexed(self._h, len(rw), _ptr(rw, C.c_uint32), _ptr(t, C.c_float),
                                                         _ptr(r, C.c_float), _ptr(s, C.c_float)))
 
+    def map_upload_window(self, capacity, dense=False):
+        """-> (window, rows u32[capacity] or None, translation f32[3 capacity], rotation f32[4 capacity], scale f32[3 capacity]): numpy views
+        on the library's pinned memory, to be filled in place and handed over with commit_upload_window."""
+        w = UploadWindow()
+        self._ck(self._lib.mi_map_upload_window(self._h, int(capacity), UPLOAD_DENSE if dense else 0, C.byref(w)))
+        arr = lambda p, k, dt: np.ctypeslib.as_array(p, shape=(k * capacity,)).view(dt) if capacity else np.zeros(0, dt)
+        return w, (None if dense else arr(w.rows, 1, np.uint32)), arr(w.translation, 3, np.float32), arr(w.rotation, 4, np.float32), arr(w.scale, 3, np.float32)
+
+    def commit_upload_window(self, window, n, first_row=0):
+        self._ck(self._lib.mi_commit_upload_window(self._h, C.byref(window), int(n), int(first_row)))
+
     def upload_global_transforms(self, g, first_row=0):
         g = _f32(g)
         self._ck(self._lib.mi_upload_global_transforms(self._h, first_row, len(g) // 12, _ptr(g, C.c_float)))
@@ -425,6 +445,12 @@ class Context:
     def upload_changed(self, changed, first_row=0):
         ch = _u8(changed)
         self._ck(self._lib.mi_upload_changed(self._h, first_row, len(ch), _ptr(ch, C.c_uint8)))
+
+    def upload_changed_all(self):
+        """Every row counts as changed (the 100 %-dirty frame)."""
+        if getattr(self, "_ones", None) is None or len(self._ones) != self.n:
+            self._ones = np.ones(self.n, np.uint8)
+        self.upload_changed(self._ones)
 
     def upload_visibility_ranges(self, start_end, first_row=0):
         """start_end: f32[2n] (start_margin.start, end_margin.end); None = no VisibleEntityRanges resource."""

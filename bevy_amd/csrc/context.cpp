@@ -781,6 +781,29 @@ int32_t mi_upload_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t n, const 
     return MI_OK;
 }
 
+// rows / t / r / s lie in the pinned arena: one scatter kernel reads them over PCIe and raises the rows' change bytes
+static int32_t scatter_indexed(mi_ctx* ctx, const uint32_t* rows, const float* t, const float* r, const float* s, uint32_t n) {
+    void *d_rows = nullptr, *d_t = nullptr, *d_r = nullptr, *d_s = nullptr;
+    HIP_TRY(ctx, hipHostGetDevicePointer(&d_rows, (void*)rows, 0));
+    HIP_TRY(ctx, hipHostGetDevicePointer(&d_t, (void*)t, 0));
+    HIP_TRY(ctx, hipHostGetDevicePointer(&d_r, (void*)r, 0));
+    HIP_TRY(ctx, hipHostGetDevicePointer(&d_s, (void*)s, 0));
+    if (!ctx->have_changed) {
+        // First use of the change column: rows a propagate has already consumed count as unchanged from here on.  Rows
+        // that have not been through one yet are still Added<GlobalTransform> (systems.rs:45-50) and keep their mark.
+        if (ctx->propagated_rows)
+            HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, std::min(ctx->propagated_rows, ctx->n), ctx->stream));
+        ctx->have_changed = true;
+    }
+    int32_t rc = cluster_join(ctx);
+    if (rc) return rc;
+    ctx->cl_inputs_dirty = true;
+    HIP_TRY(ctx, launch_upload_trs_indexed((const uint32_t*)d_rows, (const float*)d_t, (const float*)d_r, (const float*)d_s, n, ctx->t, ctx->r,
+                                           ctx->s, ctx->changed, ctx->stream));
+    ctx->changed_maybe = true;
+    return MI_OK;
+}
+
 int32_t mi_upload_transforms_indexed(mi_ctx* ctx, uint32_t n, const uint32_t* rows, const float* translation,
                                      const float* rotation, const float* scale) {
     ENTER(ctx);
@@ -797,20 +820,56 @@ int32_t mi_upload_transforms_indexed(mi_ctx* ctx, uint32_t n, const uint32_t* ro
     memcpy(f, translation, (size_t)n * 12);
     memcpy(f + 3 * (size_t)n, rotation, (size_t)n * 16);
     memcpy(f + 7 * (size_t)n, scale, (size_t)n * 12);
-    void* dev = nullptr;
-    HIP_TRY(ctx, hipHostGetDevicePointer(&dev, st, 0));
-    if (!ctx->have_changed) {
-        // First use of the change column: rows a propagate has already consumed count as unchanged from here on.  Rows
-        // that have not been through one yet are still Added<GlobalTransform> (systems.rs:45-50) and keep their mark.
-        if (ctx->propagated_rows)
-            HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, std::min(ctx->propagated_rows, ctx->n), ctx->stream));
-        ctx->have_changed = true;
+    return scatter_indexed(ctx, u, f, f + 3 * (size_t)n, f + 7 * (size_t)n, n);
+}
+
+// ---- upload windows: the caller fills pinned memory in place ------------------------------------------------------------------
+int32_t mi_map_upload_window(mi_ctx* ctx, uint32_t capacity, uint32_t flags, mi_upload_window* out) {
+    ENTER(ctx);
+    if (!out) return fail(ctx, MI_ERR_INVALID_ARG, "mi_map_upload_window: NULL");
+    memset(out, 0, sizeof *out);
+    out->flags = flags;
+    out->capacity = capacity;
+    if (capacity == 0) return MI_OK;
+    const bool dense = (flags & MI_UPLOAD_DENSE) != 0;
+    void* st = nullptr;
+    int32_t rc = stage_alloc(ctx, (size_t)capacity * (dense ? 40 : 44) + 64, &st);
+    if (rc) return rc;
+    float* f = (float*)st;
+    if (!dense) {
+        out->rows = (uint32_t*)st;
+        f = (float*)(out->rows + (((size_t)capacity + 3) & ~(size_t)3));  // 16-byte aligned columns
     }
-    if ((rc = cluster_join(ctx))) return rc;
-    ctx->cl_inputs_dirty = true;
-    HIP_TRY(ctx, launch_upload_trs_indexed((const uint32_t*)dev, n, ctx->t, ctx->r, ctx->s, ctx->changed, ctx->stream));
-    ctx->changed_maybe = true;
+    out->translation = f;
+    out->rotation = f + 3 * (size_t)capacity + ((4 - (3 * (size_t)capacity) % 4) % 4);
+    out->scale = out->rotation + 4 * (size_t)capacity;
+    ctx->window_epoch = ctx->stage_epoch;
+    ctx->window_base = st;
     return MI_OK;
+}
+
+int32_t mi_commit_upload_window(mi_ctx* ctx, const mi_upload_window* w, uint32_t n, uint32_t first_row) {
+    ENTER(ctx);
+    if (!w) return fail(ctx, MI_ERR_INVALID_ARG, "mi_commit_upload_window: NULL");
+    if (n == 0) return MI_OK;
+    if (n > w->capacity) return fail(ctx, MI_ERR_INVALID_ARG, "mi_commit_upload_window: %u rows, the window holds %u", n, w->capacity);
+    if (ctx->window_epoch != ctx->stage_epoch || ctx->window_base != (w->rows ? (void*)w->rows : (void*)w->translation))
+        return fail(ctx, MI_ERR_NOT_READY, "mi_commit_upload_window: the window is no longer mapped (another call on the context came in between)");
+    ctx->window_base = nullptr;
+    if (w->flags & MI_UPLOAD_DENSE) {
+        int32_t rc = check_rows(ctx, first_row, n, "mi_commit_upload_window");
+        if (rc) return rc;
+        if ((rc = cluster_join(ctx))) return rc;
+        ctx->cl_inputs_dirty = true;
+        // pinned -> device: three DMA copies straight from the window (no staging copy)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->t + 3 * (size_t)first_row, w->translation, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->r + 4 * (size_t)first_row, w->rotation, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->s + 3 * (size_t)first_row, w->scale, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+        return MI_OK;
+    }
+    for (uint32_t i = 0; i < n; ++i)
+        if (w->rows[i] >= ctx->n) return fail(ctx, MI_ERR_INVALID_ARG, "mi_commit_upload_window: row %u >= %u live rows", w->rows[i], ctx->n);
+    return scatter_indexed(ctx, w->rows, w->translation, w->rotation, w->scale, n);
 }
 
 int32_t mi_upload_global_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t n, const float* global12) {

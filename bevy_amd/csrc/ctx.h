@@ -68,6 +68,8 @@ struct mi_ctx {
     void* stage = nullptr;
     size_t stage_bytes = 0, stage_used = 0;
     uint64_t stage_epoch = 0;  // bumped whenever the arena wraps or moves: pointers into it from before are stale
+    uint64_t window_epoch = ~0ull;  // mi_map_upload_window: the arena epoch the mapped window belongs to, and where it starts
+    void* window_base = nullptr;
 
     // ---- hierarchy ----
     uint32_t n_levels = 1;

@@ -178,8 +178,8 @@ hipError_t launch_frame_sph(const Columns& c, const ViewSet* views_inline, const
 constexpr uint32_t SPH_MAX_VIEWS = 32;
 hipError_t launch_upload_trs(const float* pinned_src, float* t, float* r, float* s, uint32_t first_row, uint32_t n,
                              hipStream_t stream);
-hipError_t launch_upload_trs_indexed(const uint32_t* pinned_src, uint32_t n, float* t, float* r, float* s, uint8_t* changed,
-                                     hipStream_t stream);
+hipError_t launch_upload_trs_indexed(const uint32_t* rows, const float* t_src, const float* r_src, const float* s_src, uint32_t n, float* t,
+                                     float* r, float* s, uint8_t* changed, hipStream_t stream);
 hipError_t launch_popcount_words(const uint64_t* bits, uint32_t n_rows, uint8_t* cnt, hipStream_t stream);
 hipError_t launch_gather_global(const uint32_t* rows, const uint32_t* total, uint32_t capacity, const float* g, float* out,
                                 hipStream_t stream);

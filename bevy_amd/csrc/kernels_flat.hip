@@ -587,29 +587,30 @@ __global__ void __launch_bounds__(256) k_upload_trs(const float* __restrict__ sr
     }
     if (i < 4u * n) r[4ull * first_row + i] = src[3ull * n + i];
 }
-// Sparse dirty-row upload (the rows a Changed<Transform> query yields): src = rows[n] | t[3n] | r[4n] | s[3n] in
-// pinned host memory; one thread per row scatters its Transform and raises the row's changed byte.
-__global__ void __launch_bounds__(256) k_upload_trs_indexed(const uint32_t* __restrict__ src, uint32_t n, float* t, float* r,
-                                                             float* s, uint8_t* changed) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t row = src[i];
-    const float* ft = reinterpret_cast<const float*>(src + n);
-    const float* fr = ft + 3ull * n;
-    const float* fs = fr + 4ull * n;
+// Sparse dirty-row upload (the rows a Changed<Transform> query yields): rows[n], t[3n], r[4n], s[3n] in pinned host memory;
+// a thread per row scatters its Transform and raises the row's changed byte.
+__global__ void __launch_bounds__(256) k_upload_trs_indexed(const uint32_t* __restrict__ rows, const float* __restrict__ ft,
+                                                             const float* __restrict__ fr, const float* __restrict__ fs, uint32_t n, float* t,
+                                                             float* r, float* s, uint8_t* changed) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint32_t row = rows[i];
 #pragma unroll
-    for (uint32_t k = 0; k < 3u; ++k) {
-        t[3ull * row + k] = ft[3ull * i + k];
-        s[3ull * row + k] = fs[3ull * i + k];
+        for (uint32_t k = 0; k < 3u; ++k) {
+            t[3ull * row + k] = ft[3ull * i + k];
+            s[3ull * row + k] = fs[3ull * i + k];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) r[4ull * row + k] = fr[4ull * i + k];
+        changed[row] = 1;
     }
-#pragma unroll
-    for (uint32_t k = 0; k < 4u; ++k) r[4ull * row + k] = fr[4ull * i + k];
-    changed[row] = 1;
 }
-hipError_t launch_upload_trs_indexed(const uint32_t* pinned_src, uint32_t n, float* t, float* r, float* s, uint8_t* changed,
-                                     hipStream_t stream) {
+hipError_t launch_upload_trs_indexed(const uint32_t* rows, const float* t_src, const float* r_src, const float* s_src, uint32_t n, float* t,
+                                     float* r, float* s, uint8_t* changed, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    MI_LAUNCH(k_upload_trs_indexed, dim3(blocks_for(n)), dim3(256), 0, stream, pinned_src, n, t, r, s, changed);
+    // the sources are pinned host memory read over PCIe: enough lanes to keep the link busy, not one workgroup per 256 rows of a
+    // million-row upload
+    const uint32_t blocks = blocks_for(n) < 2048u ? blocks_for(n) : 2048u;
+    MI_LAUNCH(k_upload_trs_indexed, dim3(blocks), dim3(256), 0, stream, rows, t_src, r_src, s_src, n, t, r, s, changed);
     return hipGetLastError();
 }
 

@@ -270,6 +270,7 @@ class World {
         bool global_changed = false, inherited_changed = false;
         bool visibility_changed = false, bounds_changed = false;
         bool touched = false;  // listed in touched_: some change flag is set (what a change-tick scan would find)
+        bool above_light = false;  // the entity is a point light or has one below it: its Transform moves a light's bounding Sphere
     };
     Rec& rec(Entity e) {
         if (!contains(e)) throw std::out_of_range("no such entity");
@@ -404,20 +405,23 @@ class Mi355xPlugin {
         }
         upload_bounds(w);
         const auto t_start = std::chrono::steady_clock::now();
-        // ---- in: Changed<Transform> rows (World::touched_ is what the query's change-tick scan yields)
-        scratch_rows_.clear(); scratch_t_.clear(); scratch_r_.clear(); scratch_s_.clear();
+        // ---- in: Changed<Transform> rows (World::touched_ is what the query's change-tick scan yields), written straight into the
+        //      library's pinned upload window: no Vec of our own, no staging copy
+        mi_upload_window win{};
+        check(mi_map_upload_window(ctx_, (uint32_t)w.touched_.size(), 0, &win));
+        uint32_t n_in = 0;
         for (uint32_t i : w.touched_) {
             const World::Rec& e = w.rec_[i];
             if (!e.alive || !(e.transform_changed || e.added || e.parent_changed || e.orphaned)) continue;
-            const uint32_t row = row_of_index_[i];
-            scratch_rows_.push_back(row);
-            scratch_t_.insert(scratch_t_.end(), {e.transform.translation.x, e.transform.translation.y, e.transform.translation.z});
-            scratch_r_.insert(scratch_r_.end(), {e.transform.rotation.x, e.transform.rotation.y, e.transform.rotation.z, e.transform.rotation.w});
-            scratch_s_.insert(scratch_s_.end(), {e.transform.scale.x, e.transform.scale.y, e.transform.scale.z});
+            win.rows[n_in] = row_of_index_[i];
+            std::memcpy(win.translation + 3 * (size_t)n_in, &e.transform.translation, 12);
+            std::memcpy(win.rotation + 4 * (size_t)n_in, &e.transform.rotation, 16);
+            std::memcpy(win.scale + 3 * (size_t)n_in, &e.transform.scale, 12);
+            ++n_in;
         }
         const auto t_gathered = std::chrono::steady_clock::now();
-        check(mi_upload_transforms_indexed(ctx_, (uint32_t)scratch_rows_.size(), scratch_rows_.data(), scratch_t_.data(), scratch_r_.data(), scratch_s_.data()));
-        if (scratch_rows_.empty()) {  // keep "nothing changed" distinct from "no change information" (= all dirty)
+        check(mi_commit_upload_window(ctx_, &win, n_in, 0));
+        if (n_in == 0) {  // keep "nothing changed" distinct from "no change information" (= all dirty)
             const uint8_t zero = 0;
             check(mi_upload_changed(ctx_, 0, 1, &zero));
         }
@@ -733,22 +737,21 @@ class Mi355xPlugin {
         for (size_t k = chain.size() - 1; k-- > 0;) g = g * *chain[k];
         return g;
     }
-    static bool chain_moved(const World& w, Entity e) {
-        for (std::optional<Entity> cur = e; cur && w.contains(*cur); cur = w.rec_[cur->index].parent) {
-            const World::Rec& r = w.rec_[cur->index];
-            if (r.transform_changed || r.added || r.parent_changed || r.orphaned) return true;
-        }
-        return false;
-    }
     void upload_bounds(World& w) {
         const uint32_t n = (uint32_t)entity_of_row_.size();
         bool any = bounds_dirty_ || seen_bounds_ != w.bounds_version_;
-        for (size_t k = 0; k < light_rows_.size() && !any; ++k) any = chain_moved(w, entity_of_row_[light_rows_[k]]);  // a moved light moves its Sphere
+        for (size_t k = 0; k < w.touched_.size() && !any; ++k) {  // a moved light (or ancestor of one) moves the light's Sphere
+            const World::Rec& e = w.rec_[w.touched_[k]];
+            any = e.above_light && (e.transform_changed || e.added || e.parent_changed || e.orphaned);
+        }
         if (!any) return;
         seen_bounds_ = w.bounds_version_;
-        light_rows_.clear();
-        for (uint32_t row = 0; row < n; ++row)
-            if (w.rec_[entity_of_row_[row].index].point_light_range) light_rows_.push_back(row);
+        for (World::Rec& e : w.rec_) e.above_light = false;
+        for (uint32_t row = 0; row < n; ++row) {
+            if (!w.rec_[entity_of_row_[row].index].point_light_range) continue;
+            for (std::optional<Entity> cur = entity_of_row_[row]; cur && w.contains(*cur) && !w.rec_[cur->index].above_light; cur = w.rec_[cur->index].parent)
+                w.rec_[cur->index].above_light = true;
+        }
         std::vector<float> c(3 * (size_t)n, 0.f), h(3 * (size_t)n, 0.f);
         std::vector<uint8_t> flags(n);
         for (uint32_t row = 0; row < n; ++row) {
@@ -814,11 +817,10 @@ class Mi355xPlugin {
     }
 
     mi_ctx* ctx_ = nullptr;
-    std::vector<uint32_t> scratch_rows_;
-    std::vector<float> scratch_t_, scratch_r_, scratch_s_, plane_storage_;
+    std::vector<float> plane_storage_;
     std::vector<mi_view> mviews_;
     std::vector<Entity> light_entities_;
-    std::vector<uint32_t> light_rows_, row_of_index_;
+    std::vector<uint32_t> row_of_index_;
     uint64_t lights_version_ = 0, seen_visibility_ = 0, seen_bounds_ = 0;
     std::vector<std::pair<uint64_t, bool>> set_keys_;
     std::vector<std::pair<uint64_t, uint64_t>> bin_keys_;  // per metadata entry: (batch set key, bin key)

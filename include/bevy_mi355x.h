@@ -166,6 +166,27 @@ int32_t mi_upload_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t n, const 
 int32_t mi_upload_transforms_indexed(mi_ctx* ctx, uint32_t n, const uint32_t* rows, const float* translation,
                                      const float* rotation, const float* scale);
 
+/* The same two uploads WITHOUT the staging copy: the library hands out a window of its pinned (page-locked, device-mapped) host
+ * memory and the caller -- whose gather loop over the ECS tables has to write the values somewhere anyway -- fills it in place:
+ *   mi_map_upload_window(capacity, flags)   rows[capacity] (NULL with MI_UPLOAD_DENSE), translation[3 capacity], rotation[4 capacity],
+ *                                           scale[3 capacity]; ONE window at a time, valid until its commit (other calls may come in
+ *                                           between; should one of them have recycled the pinned arena, the commit returns
+ *                                           MI_ERR_NOT_READY and nothing was uploaded: map and fill again)
+ *   mi_commit_upload_window(w, n, first_row) the first n entries go to the device: MI_UPLOAD_DENSE = rows [first_row, first_row + n)
+ *                                           by DMA straight from the window (mi_upload_transforms); otherwise rows[i] in any order,
+ *                                           scattered by one kernel that reads the window over PCIe and raises the rows' change
+ *                                           bytes (mi_upload_transforms_indexed; first_row ignored). */
+#define MI_UPLOAD_DENSE 0x1u
+typedef struct mi_upload_window {
+    uint32_t* rows;
+    float* translation;
+    float* rotation;
+    float* scale;
+    uint32_t capacity, flags;
+} mi_upload_window;
+int32_t mi_map_upload_window(mi_ctx* ctx, uint32_t capacity, uint32_t flags, mi_upload_window* out);
+int32_t mi_commit_upload_window(mi_ctx* ctx, const mi_upload_window* w, uint32_t n, uint32_t first_row);
+
 /* Existing GlobalTransform values (global_transform.rs:60).  Only needed when the previous values
  * matter: set_if_neq change detection (systems.rs:719) and MI_PROPAGATE_STATIC_OPT skipping. */
 int32_t mi_upload_global_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t n, const float* global12);

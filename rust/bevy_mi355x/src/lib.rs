@@ -10,6 +10,22 @@
 //! | `check_visibility_cpu_culling` (crates/bevy_camera/src/visibility/mod.rs:748-880)           | [`mi_check_visibility`]             |
 //! | `assign_objects_to_clusters` (crates/bevy_light/src/cluster/assign.rs:137-813)              | [`mi_assign_objects_to_clusters`]   |
 //!
+//! With `fused: true` (the default) the three collapse into ONE device round trip per frame: [`mi_fused_frame`], placed in
+//! `TransformSystems::Propagate`, uploads the changed `Transform`s, issues `mi_propagate_and_cull_views(MI_CULL_CHANGED_ROWS |
+//! MI_CULL_WITH_CLUSTERS | MI_CULL_END_FRAME)` -- propagate, reset, cull of every active camera, gather of the visible lights and
+//! cluster assignment: one kernel launch for a flat scene -- and reads everything back with ONE `mi_download_frame_results`
+//! (delivered in place: one packing launch, one device wait, no copy).  It writes `GlobalTransform` at once and parks the
+//! rest in [`Mi355xFrame`]; [`mi_apply_visibility`] (in `VisibilitySystems::CheckVisibility`, between the stock
+//! `reset_view_visibility` and `mark_newly_hidden_entities_invisible`, which stay registered) and [`mi_apply_clusters`] (in front
+//! of `SimulationLightSystems::AssignLightsToClusters`) make the remaining ECS writes where the stock systems make them, without
+//! touching the device.  The cameras' frusta are computed by the fused system itself, from the `GlobalTransform` each camera is
+//! ABOUT to get (`update_frusta` runs behind `TransformSystems::Propagate`; same `compute_frustum`, same inputs, same bits);
+//! should an input of the cull turn out to have changed after the submit (an `Aabb` inserted by `calculate_bounds`, an
+//! `InheritedVisibility` flipped by `visibility_propagate_system`, a `Frustum` that differs from the predicted one), the parked
+//! results are dropped and the three-system form -- registered behind the apply systems, gated on [`Mi355xFrame::valid`] -- runs
+//! for that frame.  `bevy_amd/host/bevy_mi355x_host.hpp` (`Mi355xPlugin::frame`) is the same design in C++, compiled and run
+//! against the reference's system tests in both forms (`tests/cpp/host_systems_test.cpp`).
+//!
 //! The ECS stays the owner of every component.  The library owns device-resident COLUMNS, one row per entity, and the systems
 //! below move only what changed: rows whose `Transform` change tick is newer than the system's last run go up
 //! (`mi_upload_transforms_indexed`), rows whose `GlobalTransform` the device changed come down
@@ -103,6 +119,8 @@ pub struct Mi355x {
     class_bits: HashMap<TypeId, u32>,
     /// Per-view cluster feedback (`Clusters::last_frame_*`, crates/bevy_light/src/cluster/mod.rs:153-163).
     cluster_history: EntityHashMap<ffi::MiClusterHistory>,
+    /// Storage of the x / y / z cluster planes `mi_cluster_view_build` fills for the fused frame's view.
+    plane_storage: Vec<f32>,
     scratch: Scratch,
 }
 
@@ -167,6 +185,7 @@ impl Mi355x {
                 entity_row: EntityHashMap::default(),
                 class_bits: HashMap::default(),
                 cluster_history: EntityHashMap::default(),
+                plane_storage: Vec::new(),
                 scratch: Scratch::default(),
             })
         }
@@ -206,6 +225,14 @@ impl Drop for Mi355x {
 pub struct Mi355xRenderPrepPlugin {
     /// HIP device ordinal.
     pub device: i32,
+    /// One device round trip per frame ([`mi_fused_frame`]); `false` = the three systems, a round trip each.
+    pub fused: bool,
+}
+
+impl Default for Mi355xRenderPrepPlugin {
+    fn default() -> Self {
+        Self { device: 0, fused: true }
+    }
 }
 
 impl Plugin for Mi355xRenderPrepPlugin {
@@ -218,7 +245,8 @@ impl Plugin for Mi355xRenderPrepPlugin {
                 return;
             }
         };
-        app.insert_resource(mi).init_resource::<CpuFallback>();
+        app.insert_resource(mi).init_resource::<CpuFallback>().init_resource::<Mi355xFrame>();
+        let fused = self.fused;
 
         // --- transforms: TransformPlugin registers the same three systems in PostStartup and PostUpdate
         //     (crates/bevy_transform/src/plugins.rs:22-48).  Every system fn is its own implicit set
@@ -227,10 +255,13 @@ impl Plugin for Mi355xRenderPrepPlugin {
             app.remove_systems_in_set(schedule, mark_dirty_trees, RemoveSystemsOnly);
             app.remove_systems_in_set(schedule, propagate_parent_transforms, RemoveSystemsOnly);
             app.remove_systems_in_set(schedule, sync_simple_transforms, RemoveSystemsOnly);
+            // PostStartup has no cameras to cull for yet: the propagate-only system either way
+            let fused_here = fused && schedule == PostUpdate.intern();
             app.add_systems(
                 schedule,
                 (
-                    mi_propagate_transforms,
+                    mi_fused_frame.run_if(move || fused_here),
+                    mi_propagate_transforms.run_if(move || !fused_here),
                     // the stock trio in its stock order, only when the replacement gave up (this frame or earlier)
                     (mark_dirty_trees, propagate_parent_transforms, sync_simple_transforms)
                         .chain()
@@ -246,7 +277,12 @@ impl Plugin for Mi355xRenderPrepPlugin {
         app.remove_systems_in_set(PostUpdate, check_visibility_cpu_culling, RemoveSystemsOnly);
         app.add_systems(
             PostUpdate,
-            (mi_check_visibility, check_visibility_cpu_culling.run_if(visibility_fell_back))
+            (
+                // fused: the parked lists, no device call; if they turn out stale, the round trip of its own right behind
+                mi_apply_visibility.run_if(move || fused),
+                mi_check_visibility.run_if(frame_results_missing),
+                check_visibility_cpu_culling.run_if(visibility_fell_back),
+            )
                 .chain()
                 .in_set(VisibilitySystems::CheckVisibility),
         );
@@ -256,7 +292,8 @@ impl Plugin for Mi355xRenderPrepPlugin {
         app.configure_sets(PostUpdate, SimulationLightSystems::AssignLightsToClusters.run_if(clusters_fell_back));
         app.add_systems(
             PostUpdate,
-            mi_assign_objects_to_clusters
+            (mi_apply_clusters.run_if(move || fused), mi_assign_objects_to_clusters.run_if(frame_clusters_missing))
+                .chain()
                 .before(SimulationLightSystems::AssignLightsToClusters)
                 .after(TransformSystems::Propagate)
                 .after(VisibilitySystems::CheckVisibility)
@@ -290,11 +327,29 @@ pub fn mi_propagate_transforms(
         return;
     }
     let mi = &mut *mi;
-    let ctx = mi.ctx;
     let rebuild = !structure_changed.is_empty() || orphaned.read().count() != 0 || despawned.read().count() != 0;
-    let tables = transforms.contiguous_iter().expect("Transform and ChildOf are table components");
+    let result = upload_and_propagate(mi, rebuild, &ticks, &transforms, &globals.as_readonly(), None);
+    let Ok(count) = result else {
+        fallback.transforms = true; // nothing was written to the ECS; the stock trio runs next, in this same frame
+        return;
+    };
+    write_back_global_transforms(mi, count, &mut globals);
+}
 
-    let result: Result<u32, ()> = (|| {
+/// Rows in, propagate, changed rows out -- shared by [`mi_propagate_transforms`] and the rebuild frames of [`mi_fused_frame`].
+/// `frame`: instead of `mi_propagate` + the sparse download, the caller's own frame call follows (steady-state fused frame):
+/// only the upload happens here and 0 is returned.
+fn upload_and_propagate(
+    mi: &mut Mi355x,
+    rebuild: bool,
+    ticks: &SystemChangeTick,
+    transforms: &Query<(Entity, Ref<Transform>, Option<&ChildOf>)>,
+    globals: &Query<&GlobalTransform>,
+    frame: Option<()>,
+) -> Result<u32, ()> {
+    let ctx = mi.ctx;
+    let tables = transforms.contiguous_iter().expect("Transform and ChildOf are table components");
+    {
         let s = &mut mi.scratch;
         if rebuild {
             // (1) provisional rows in table order, (2) parent as a provisional row, (3) level order from the library.
@@ -347,10 +402,20 @@ pub fn mi_propagate_transforms(
             }
             s.keys.clear();
             s.keys.extend(mi.row_entity.iter().map(|e| e.to_bits()));
+            // Every row has a new occupant: the device's GlobalTransform column is re-seeded with the ECS values in the new row
+            // order.  set_if_neq (systems.rs:719) compares against it -- against whatever entity used to sit in a row, a freshly
+            // spawned child whose GlobalTransform happens to equal the previous occupant's would never be listed as changed and
+            // would keep GlobalTransform::IDENTITY; other rows would be listed (and ticked) spuriously.
+            s.global12.clear();
+            for e in &mi.row_entity {
+                let g = globals.get(*e).map(|g| g.affine()).unwrap_or(Affine3A::IDENTITY);
+                s.global12.extend_from_slice(&g.to_cols_array());
+            }
             // SAFETY: as above; the columns hold `n` rows after `mi_columns_resize`.
             unsafe {
                 check(ctx, "mi_columns_resize", ffi::mi_columns_resize(ctx, n))?;
                 check(ctx, "mi_upload_transforms", ffi::mi_upload_transforms(ctx, 0, n, t.as_ptr(), r.as_ptr(), sc.as_ptr()))?;
+                check(ctx, "mi_upload_global_transforms", ffi::mi_upload_global_transforms(ctx, 0, n, s.global12.as_ptr()))?;
                 check(ctx, "mi_upload_entity_keys", ffi::mi_upload_entity_keys(ctx, 0, n, s.keys.as_ptr()))?;
                 check(ctx, 
                     "mi_upload_hierarchy",
@@ -360,6 +425,34 @@ pub fn mi_propagate_transforms(
             }
         } else {
             // steady state: only the rows whose Transform changed since this system last ran
+            if frame.is_some() {
+                // the fused frame writes them straight into the library's pinned upload window (no Vec, no staging copy): count,
+                // map, fill, commit
+                let changed_in = |ticks_of: &[Tick]| ticks_of.iter().filter(|t| changed_since(**t, ticks)).count();
+                let transforms_again = transforms.contiguous_iter().expect("Transform and ChildOf are table components");
+                let capacity: usize = transforms_again.map(|(_, t, _)| changed_in(t.changed_ticks_slice())).sum();
+                // SAFETY: a zeroed window is the valid "nothing mapped" value; the library fills it in.
+                let mut window: ffi::MiUploadWindow = unsafe { core::mem::zeroed() };
+                check(ctx, "mi_map_upload_window", unsafe { ffi::mi_map_upload_window(ctx, capacity as u32, 0, &mut window) })?;
+                let mut k = 0usize;
+                for (entities, table_transforms, _) in tables {
+                    let changed = table_transforms.changed_ticks_slice();
+                    for (i, t) in table_transforms.iter().enumerate() {
+                        if changed_since(changed[i], ticks) {
+                            // SAFETY: k < capacity: the same filter counted the rows above.
+                            unsafe {
+                                *window.rows.add(k) = mi.entity_row[&entities[i]];
+                                core::ptr::copy_nonoverlapping(t.translation.to_array().as_ptr(), window.translation.add(3 * k), 3);
+                                core::ptr::copy_nonoverlapping(t.rotation.to_array().as_ptr(), window.rotation.add(4 * k), 4);
+                                core::ptr::copy_nonoverlapping(t.scale.to_array().as_ptr(), window.scale.add(3 * k), 3);
+                            }
+                            k += 1;
+                        }
+                    }
+                }
+                check(ctx, "mi_commit_upload_window", unsafe { ffi::mi_commit_upload_window(ctx, &window, k as u32, 0) })?;
+                return Ok(0); // the caller's frame call propagates (MI_CULL_CHANGED_ROWS) and its results carry the rows
+            }
             s.rows.clear();
             s.translation.clear();
             s.rotation.clear();
@@ -401,12 +494,11 @@ pub fn mi_propagate_transforms(
             ffi::mi_download_changed_global_transforms(ctx, s.rows.as_mut_ptr(), s.global12.as_mut_ptr(), capacity, &mut count)
         })?;
         Ok(count)
-    })();
+    }
+}
 
-    let Ok(count) = result else {
-        fallback.transforms = true; // nothing was written to the ECS; the stock trio runs next, in this same frame
-        return;
-    };
+/// `scratch.rows[..count]` / `scratch.global12` -> `Mut<GlobalTransform>`.
+fn write_back_global_transforms(mi: &Mi355x, count: u32, globals: &mut Query<&mut GlobalTransform>) {
     let s = &mi.scratch;
     for (k, row) in s.rows[..count as usize].iter().enumerate() {
         let cols: &[f32; 12] = s.global12[k * 12..k * 12 + 12].try_into().unwrap();
@@ -438,15 +530,7 @@ pub fn mi_check_visibility(
         )>,
     >,
     rows_query: Query<
-        (
-            Entity,
-            &InheritedVisibility,
-            Option<&VisibilityClass>,
-            Option<&RenderLayers>,
-            Option<&Aabb>,
-            Has<NoFrustumCulling>,
-            Has<VisibilityRange>,
-        ),
+        (Entity, &InheritedVisibility, Option<&VisibilityClass>, Option<&RenderLayers>, Option<&Aabb>, Option<&Sphere>, Has<NoFrustumCulling>, Has<VisibilityRange>),
         Without<NoCpuCulling>,
     >,
     mut view_visibilities: Query<&mut ViewVisibility, Without<NoCpuCulling>>,
@@ -464,59 +548,7 @@ pub fn mi_check_visibility(
     let result: Result<(), ()> = (|| {
         // --- columns that change rarely: re-staged only when one of them changed
         if !bounds_changed.is_empty() {
-            let s = &mut mi.scratch;
-            s.aabb_center.clear();
-            s.aabb_center.resize(n as usize * 3, 0.0);
-            s.aabb_half.clear();
-            s.aabb_half.resize(n as usize * 3, 0.0);
-            s.flags.clear();
-            s.flags.resize(n as usize, 0);
-            s.layers.clear();
-            s.layers.resize(n as usize, 0);
-            s.classes.clear();
-            s.classes.resize(n as usize, 0);
-            let tables = rows_query.contiguous_iter().expect("all queried components live in tables");
-            for (entities, inherited, classes, layers, aabbs, no_frustum_culling, has_range) in tables {
-                for (i, entity) in entities.iter().enumerate() {
-                    let Some(&row) = mi.entity_row.get(entity) else { continue };
-                    let row = row as usize;
-                    let mut flags = 0u32;
-                    if inherited[i].get() {
-                        flags |= ffi::MI_FLAG_INHERITED_VISIBLE;
-                    }
-                    if no_frustum_culling {
-                        flags |= ffi::MI_FLAG_NO_FRUSTUM_CULLING;
-                    }
-                    if has_range {
-                        flags |= ffi::MI_FLAG_HAS_VISIBILITY_RANGE;
-                    }
-                    if let Some(aabbs) = aabbs {
-                        flags |= ffi::MI_FLAG_HAS_AABB;
-                        s.aabb_center[row * 3..row * 3 + 3].copy_from_slice(&aabbs[i].center.to_array());
-                        s.aabb_half[row * 3..row * 3 + 3].copy_from_slice(&aabbs[i].half_extents.to_array());
-                    }
-                    s.flags[row] = flags as u8;
-                    // The column is one 32-bit word: layers 0..=31.  A scene that uses a higher layer is not representable
-                    // and goes back to the CPU system (error path below).
-                    s.layers[row] = match layers.map(|l| &l[i]) {
-                        None => 1, // RenderLayers::default() == layer 0
-                        Some(l) => layer_word(l).ok_or(())?,
-                    };
-                    if let Some(classes) = classes {
-                        for class in classes[i].iter() {
-                            s.classes[row] |= 1 << mi_class_bit(&mut mi.class_bits, *class).ok_or(())?;
-                        }
-                    }
-                }
-            }
-            // SAFETY: every column holds `n` rows.
-            unsafe {
-                check(ctx, 
-                    "mi_upload_bounds",
-                    ffi::mi_upload_bounds(ctx, 0, n, s.aabb_center.as_ptr(), s.aabb_half.as_ptr(), s.flags.as_ptr(), s.layers.as_ptr()),
-                )?;
-                check(ctx, "mi_upload_visibility_classes", ffi::mi_upload_visibility_classes(ctx, 0, n, s.classes.as_ptr()))?;
-            }
+            stage_bounds(mi, &rows_query)?;
         }
 
         // --- the frame's views: active cameras in query order (visibility/mod.rs:778-784)
@@ -928,6 +960,493 @@ pub fn mi_assign_objects_to_clusters(
         }
         clusters.clusterable_objects = ClusterableObjects::Cpu(per_cluster);
     }
+}
+
+// =====================================================================================================================
+// The fused frame
+// =====================================================================================================================
+
+/// What [`mi_fused_frame`] parks for the systems that write it into the ECS where the stock systems would.
+#[derive(Resource, Default)]
+pub struct Mi355xFrame {
+    /// The visibility results below belong to this frame and nothing they depend on has changed since the submit.
+    pub valid: bool,
+    /// The same for the cluster lists.
+    pub clusters_valid: bool,
+    /// `this_run` of the fused system: inputs whose change tick is newer than this were written after the submit.
+    submit_tick: Tick,
+    /// Per active camera, in query order: the frustum the cull used and its `VisibleEntities` lists per class.
+    views: Vec<FrameView>,
+    clusters: Option<FrameClusters>,
+}
+struct FrameView {
+    entity: Entity,
+    frustum: [f32; 24],
+    lists: Vec<(TypeId, Vec<Entity>)>,
+}
+struct FrameClusters {
+    view_entity: Entity,
+    view: ffi::MiClusterView,
+    offsets: Vec<u32>,
+    counts: Vec<u32>,
+    indices: Vec<u32>,
+    objects: Vec<(Entity, u8)>,
+}
+
+fn frame_results_missing(frame: Res<Mi355xFrame>) -> bool {
+    !frame.valid
+}
+fn frame_clusters_missing(frame: Res<Mi355xFrame>) -> bool {
+    !frame.clusters_valid
+}
+
+/// `GlobalTransform` an entity is about to get: its `Transform` chained up the `ChildOf` links with the reference's own operators
+/// (`GlobalTransform::from`, `mul_transform`: global_transform.rs:315-330) -- what `propagate_parent_transforms` computes for it.
+fn expected_global(entity: Entity, transforms: &Query<(Entity, Ref<Transform>, Option<&ChildOf>)>) -> Option<GlobalTransform> {
+    let mut chain = Vec::new();
+    let mut cur = Some(entity);
+    while let Some(e) = cur {
+        let (_, t, child_of) = transforms.get(e).ok()?;
+        chain.push(*t);
+        cur = child_of.map(ChildOf::parent).filter(|p| transforms.contains(*p));
+    }
+    let mut g = GlobalTransform::from(*chain.last()?);
+    for t in chain.iter().rev().skip(1) {
+        g = g.mul_transform(*t);
+    }
+    Some(g)
+}
+
+/// The whole render-prep frame in one device round trip (module docs).  Runs in `TransformSystems::Propagate`.
+#[allow(clippy::too_many_arguments)]
+pub fn mi_fused_frame(
+    mut mi: ResMut<Mi355x>,
+    mut fallback: ResMut<CpuFallback>,
+    mut frame: ResMut<Mi355xFrame>,
+    ticks: SystemChangeTick,
+    static_opt: Option<Res<bevy_transform::systems::StaticTransformOptimizations>>,
+    structure_changed: Query<(), Or<(Added<Transform>, Changed<ChildOf>)>>,
+    mut orphaned: RemovedComponents<ChildOf>,
+    mut despawned: RemovedComponents<Transform>,
+    transforms: Query<(Entity, Ref<Transform>, Option<&ChildOf>)>,
+    mut globals: Query<&mut GlobalTransform>,
+    cameras: Query<(Entity, &Camera, &bevy_camera::Projection, Option<&RenderLayers>, Has<NoCpuCulling>, Option<&ClusterConfig>, Has<Clusters>)>,
+    bounds_changed: Query<
+        (),
+        Or<(Changed<Aabb>, Changed<Sphere>, Changed<InheritedVisibility>, Changed<RenderLayers>, Changed<VisibilityClass>, Added<NoFrustumCulling>)>,
+    >,
+    rows_query: Query<
+        (Entity, &InheritedVisibility, Option<&VisibilityClass>, Option<&RenderLayers>, Option<&Aabb>, Option<&Sphere>, Has<NoFrustumCulling>, Has<VisibilityRange>),
+        Without<NoCpuCulling>,
+    >,
+    point_lights: Query<(Entity, &PointLight, Option<&RenderLayers>)>,
+    other_clusterables: Query<(), Or<(With<SpotLight>, With<RectLight>, With<LightProbe>, With<ClusteredDecal>)>>,
+    settings: Option<Res<GlobalClusterSettings>>,
+) {
+    frame.valid = false;
+    frame.clusters_valid = false;
+    if fallback.transforms {
+        return;
+    }
+    let mi = &mut *mi;
+    let ctx = mi.ctx;
+    let rebuild = !structure_changed.is_empty() || orphaned.read().count() != 0 || despawned.read().count() != 0;
+    if rebuild {
+        // Rows are renumbered and every column goes up again: the slow frame.  Propagate alone here; the visibility and cluster
+        // systems of the three-system form (gated on `frame.valid` / `frame.clusters_valid`) take the rest of this frame.
+        match upload_and_propagate(mi, true, &ticks, &transforms, &globals.as_readonly(), None) {
+            Ok(count) => write_back_global_transforms(mi, count, &mut globals),
+            Err(()) => fallback.transforms = true,
+        }
+        return;
+    }
+    let n = mi.row_entity.len() as u32;
+
+    // ---- the frame's views: active cameras in query order, each with the frustum update_frusta WILL give it
+    let mut views: Vec<ffi::MiView> = Vec::new();
+    let mut frame_views: Vec<FrameView> = Vec::new();
+    let mut cluster_camera: Option<(Entity, GlobalTransform, [f32; 24], UVec2, ClusterConfig, u32, [f32; 16])> = None;
+    let mut clustered_cameras = 0;
+    let result: Result<(), ()> = (|| {
+        for (entity, camera, projection, layers, no_cpu_culling, config, has_clusters) in cameras.iter() {
+            if !camera.is_active {
+                continue;
+            }
+            let global = expected_global(entity, &transforms).ok_or(())?;
+            let frustum = bevy_camera::CameraProjection::compute_frustum(projection, &global); // = update_frusta, visibility/mod.rs:627-636
+            let mut planes = [0f32; 24];
+            for (p, half_space) in frustum.half_spaces.iter().enumerate() {
+                planes[p * 4..p * 4 + 4].copy_from_slice(&half_space.normal_d().to_array());
+            }
+            let layer_mask = match layers {
+                None => 1,
+                Some(l) => layer_word(l).ok_or(())?,
+            };
+            views.push(ffi::MiView {
+                frustum: planes,
+                layer_mask,
+                flags: if no_cpu_culling { ffi::MI_VIEW_FLAG_NO_CPU_CULLING } else { 0 },
+                position: [0.0; 3],
+                light_sphere: [0.0; 4],
+                reserved: [0; 3],
+            });
+            frame_views.push(FrameView { entity, frustum: planes, lists: Vec::new() });
+            if has_clusters {
+                clustered_cameras += 1;
+                if let Some(size) = camera.physical_viewport_size() {
+                    let clip = bevy_camera::CameraProjection::get_clip_from_view(projection).to_cols_array();
+                    cluster_camera = Some((entity, global, planes, size, config.copied().unwrap_or_default(), layer_mask, clip));
+                }
+            }
+        }
+        // ---- columns that change rarely (exactly as mi_check_visibility stages them)
+        if !bounds_changed.is_empty() {
+            stage_bounds(mi, &rows_query)?;
+        }
+        // ---- rows in
+        upload_and_propagate(mi, false, &ticks, &transforms, &globals.as_readonly(), Some(()))?;
+        Ok(())
+    })();
+    if result.is_err() {
+        fallback.transforms = true;
+        return;
+    }
+    if views.is_empty() || views.len() * mi.class_bits.len().max(1) > ffi::MI_RESULTS_MAX_LISTS as usize {
+        // nothing to cull (or more lists than one results call takes): the propagate-only path
+        let r = (|| -> Result<u32, ()> {
+            // SAFETY: plain calls on a live context.
+            check(ctx, "mi_propagate", unsafe { ffi::mi_propagate(ctx, 0) })?;
+            let s = &mut mi.scratch;
+            s.rows.resize(n as usize, 0);
+            s.global12.resize(n as usize * 12, 0.0);
+            let mut count = 0u32;
+            // SAFETY: both outputs hold `n` entries.
+            check(ctx, "mi_download_changed_global_transforms", unsafe {
+                ffi::mi_download_changed_global_transforms(ctx, s.rows.as_mut_ptr(), s.global12.as_mut_ptr(), n, &mut count)
+            })?;
+            Ok(count)
+        })();
+        match r {
+            Ok(count) => write_back_global_transforms(mi, count, &mut globals),
+            Err(()) => fallback.transforms = true,
+        }
+        return;
+    }
+
+    // ---- the lights ride along when the frame has exactly one clustered camera, storage buffers (no UBO sort / truncate,
+    //      assign.rs:297-321) and point lights only (the riding walk carries no cone test); otherwise the cluster system of its own
+    let mut with_clusters = false;
+    let mut cluster_objects: Vec<(Entity, u8)> = Vec::new();
+    let mut cluster_view: Option<ffi::MiClusterView> = None;
+    if let (Some((view_entity, cam_global, planes, size, config, layer_mask, clip)), Some(settings)) = (cluster_camera.as_ref(), settings.as_ref()) {
+        if clustered_cameras == 1 && settings.supports_storage_buffers && settings.gpu_clustering.is_none() && other_clusterables.is_empty() && !fallback.clusters {
+            let r = (|| -> Result<(), ()> {
+                let s = &mut mi.scratch;
+                s.obj_pos_range.clear();
+                s.obj_layers.clear();
+                s.rows.clear();
+                for (e, light, layers) in point_lights.iter() {
+                    let Some(&row) = mi.entity_row.get(&e) else { continue };
+                    s.obj_pos_range.extend_from_slice(&[0.0, 0.0, 0.0, light.range]); // the centre is the row's GlobalTransform
+                    s.obj_layers.push(match layers {
+                        None => 1,
+                        Some(l) => layer_word(l).ok_or(())?,
+                    });
+                    s.rows.push(row);
+                    cluster_objects.push((e, ffi::MI_OBJ_POINT_LIGHT as u8));
+                }
+                if cluster_objects.is_empty() {
+                    return Err(());
+                }
+                let config = cluster_config_to_ffi(config);
+                let history = mi.cluster_history.entry(*view_entity).or_insert(ffi::MiClusterHistory {
+                    has_farthest_z: 0,
+                    farthest_z: 0.0,
+                    has_total_cluster_index_count: 0,
+                    reserved: 0,
+                    total_cluster_index_count: 0,
+                });
+                // SAFETY: zeroed plain structs are valid "empty" values; every pointer below is a live Vec of the stated length.
+                let mut resolved: ffi::MiClusterResolved = unsafe { core::mem::zeroed() };
+                check(ctx, "mi_cluster_config_resolve", unsafe {
+                    ffi::mi_cluster_config_resolve(&config, history, size.x, size.y, settings.view_cluster_bindings_max_indices as u64, &mut resolved)
+                })?;
+                if resolved.active == 0 {
+                    return Err(()); // Clusters::clear(): the cluster system of its own handles it
+                }
+                let (mut tile, mut dims) = ([0u32; 2], [0u32; 3]);
+                check(ctx, "mi_cluster_view_dims", unsafe {
+                    ffi::mi_cluster_view_dims(size.x, size.y, resolved.requested_dims.as_ptr(), tile.as_mut_ptr(), dims.as_mut_ptr())
+                })?;
+                mi.plane_storage.resize(((dims[0] + dims[1] + dims[2] + 3) * 4) as usize, 0.0);
+                let mut view: ffi::MiClusterView = unsafe { core::mem::zeroed() };
+                let camera_affine = cam_global.affine().to_cols_array();
+                unsafe {
+                    check(
+                        ctx,
+                        "mi_cluster_view_build",
+                        ffi::mi_cluster_view_build(
+                            camera_affine.as_ptr(),
+                            clip.as_ptr(),
+                            planes.as_ptr(),
+                            size.x,
+                            size.y,
+                            resolved.requested_dims.as_ptr(),
+                            resolved.first_slice_depth,
+                            resolved.far_z,
+                            *layer_mask,
+                            mi.plane_storage.as_mut_ptr(),
+                            ptr::null_mut(),
+                            &mut view,
+                        ),
+                    )?;
+                    check(ctx, "mi_cluster_upload_view", ffi::mi_cluster_upload_view(ctx, &view))?;
+                    let n_obj = cluster_objects.len() as u32;
+                    check(
+                        ctx,
+                        "mi_cluster_upload_objects",
+                        ffi::mi_cluster_upload_objects(ctx, n_obj, s.obj_pos_range.as_ptr(), ptr::null(), s.obj_layers.as_ptr(), ptr::null(), ptr::null()),
+                    )?;
+                    check(ctx, "mi_cluster_bind_objects_to_row_list", ffi::mi_cluster_bind_objects_to_row_list(ctx, n_obj, s.rows.as_ptr()))?;
+                }
+                cluster_view = Some(view);
+                Ok(())
+            })();
+            with_clusters = r.is_ok();
+        }
+    }
+
+    // ---- run + read back: one call each
+    let class_bits: Vec<(TypeId, u32)> = mi.class_bits.iter().map(|(k, v)| (*k, *v)).collect();
+    let mut lists: Vec<ffi::MiVisibleList> = Vec::new();
+    for v in 0..views.len() as u32 {
+        for (_, bit) in &class_bits {
+            lists.push(ffi::MiVisibleList { view: v, class_bit: *bit, capacity: n, count: 0, rows: ptr::null_mut() });
+        }
+    }
+    let n_clusters = cluster_view.as_ref().map_or(0, |v| v.dims[0] * v.dims[1] * v.dims[2]);
+    let mut results = ffi::MiFrameResults {
+        flags: ffi::MI_RESULTS_IN_PLACE
+            | ffi::MI_RESULTS_CHANGED_ROWS
+            | ffi::MI_RESULTS_CHANGED_GLOBALS
+            | if with_clusters { ffi::MI_RESULTS_CLUSTERS | ffi::MI_RESULTS_CLUSTER_INDICES } else { 0 },
+        n_lists: lists.len() as u32,
+        lists: lists.as_mut_ptr(),
+        changed_capacity: n,
+        reserved: 0,
+        cluster_capacity: cluster_objects.len() as u64 * n_clusters as u64, // an object is in a cluster at most once
+        changed_rows: ptr::null_mut(),
+        changed_global12: ptr::null_mut(),
+        cluster_offsets: ptr::null_mut(),
+        cluster_counts: ptr::null_mut(),
+        cluster_indices: ptr::null_mut(),
+        changed_count: 0,
+        farthest_z: 0.0,
+        cluster_total: 0,
+    };
+    let static_flag = if static_opt.is_some_and(|s| s.is_enabled()) { ffi::MI_CULL_STATIC_OPT } else { 0 };
+    let run: Result<(), ()> = (|| {
+        // SAFETY: `views` holds `views.len()` entries; `results` and `lists` are live for the call.
+        check(ctx, "mi_propagate_and_cull_views", unsafe {
+            ffi::mi_propagate_and_cull_views(
+                ctx,
+                views.as_ptr(),
+                views.len() as u32,
+                ffi::MI_CULL_CHANGED_ROWS | ffi::MI_CULL_END_FRAME | static_flag | if with_clusters { ffi::MI_CULL_WITH_CLUSTERS } else { 0 },
+            )
+        })?;
+        check(ctx, "mi_download_frame_results", unsafe { ffi::mi_download_frame_results(ctx, &mut results) })
+    })();
+    if run.is_err() {
+        fallback.transforms = true; // nothing was written to the ECS; the stock systems compute this frame
+        return;
+    }
+
+    // ---- everything below reads the library's pinned window in place (valid until the next call on the context)
+    // SAFETY: the library filled in pointers to `changed_count` rows / 12 x `changed_count` floats.
+    let (rows, g12) = unsafe {
+        (
+            core::slice::from_raw_parts(results.changed_rows, results.changed_count as usize),
+            core::slice::from_raw_parts(results.changed_global12, results.changed_count as usize * 12),
+        )
+    };
+    for (k, row) in rows.iter().enumerate() {
+        let cols: &[f32; 12] = g12[k * 12..k * 12 + 12].try_into().unwrap();
+        if let Ok(mut global) = globals.get_mut(mi.row_entity[*row as usize]) {
+            *global = GlobalTransform::from(Affine3A::from_cols_array(cols)); // listed = the reference would have written it (systems.rs:719)
+        }
+    }
+    for (k, list) in lists.iter().enumerate() {
+        let (view, class) = (k / class_bits.len(), class_bits[k % class_bits.len()].0);
+        // SAFETY: `count` rows at `rows`.
+        let rows = unsafe { core::slice::from_raw_parts(list.rows, list.count as usize) };
+        let mut entities: Vec<Entity> = rows.iter().map(|r| mi.row_entity[*r as usize]).collect();
+        entities.sort_unstable(); // a no-op for a flat scene (rows are in key order); with a hierarchy the device sorted by key already
+        frame_views[view].lists.push((class, entities));
+    }
+    if let (true, Some(view), Some((view_entity, ..))) = (with_clusters, cluster_view, cluster_camera.as_ref()) {
+        let c = n_clusters as usize;
+        // SAFETY: offsets c + 1, counts 6 c, indices `cluster_total` entries.
+        let (offsets, counts, indices) = unsafe {
+            (
+                core::slice::from_raw_parts(results.cluster_offsets, c + 1).to_vec(),
+                core::slice::from_raw_parts(results.cluster_counts, 6 * c).to_vec(),
+                core::slice::from_raw_parts(results.cluster_indices, results.cluster_total as usize).to_vec(),
+            )
+        };
+        let history = mi.cluster_history.get_mut(view_entity).unwrap();
+        history.has_total_cluster_index_count = 1; // assign.rs:810-811
+        history.total_cluster_index_count = results.cluster_total;
+        history.has_farthest_z = 1;
+        history.farthest_z = results.farthest_z;
+        frame.clusters = Some(FrameClusters { view_entity: *view_entity, view, offsets, counts, indices, objects: cluster_objects });
+        frame.clusters_valid = true;
+    }
+    frame.views = frame_views;
+    frame.submit_tick = ticks.this_run();
+    frame.valid = true;
+}
+
+/// Stages the bounds / flags / layers / class columns from the ECS (shared by [`mi_check_visibility`] and [`mi_fused_frame`]).
+#[allow(clippy::type_complexity)]
+fn stage_bounds(
+    mi: &mut Mi355x,
+    rows_query: &Query<
+        (Entity, &InheritedVisibility, Option<&VisibilityClass>, Option<&RenderLayers>, Option<&Aabb>, Option<&Sphere>, Has<NoFrustumCulling>, Has<VisibilityRange>),
+        Without<NoCpuCulling>,
+    >,
+) -> Result<(), ()> {
+    let ctx = mi.ctx;
+    let n = mi.row_entity.len();
+    let s = &mut mi.scratch;
+    for (v, w) in [(&mut s.aabb_center, 3), (&mut s.aabb_half, 3)] {
+        v.clear();
+        v.resize(n * w, 0.0);
+    }
+    s.flags.clear();
+    s.flags.resize(n, 0);
+    s.layers.clear();
+    s.layers.resize(n, 0);
+    s.classes.clear();
+    s.classes.resize(n, 0);
+    for (entity, inherited, classes, layers, aabb, sphere, no_frustum_culling, has_range) in rows_query.iter() {
+        let Some(&row) = mi.entity_row.get(&entity) else { continue };
+        let row = row as usize;
+        let mut flags = 0u32;
+        if inherited.get() {
+            flags |= ffi::MI_FLAG_INHERITED_VISIBLE;
+        }
+        if no_frustum_culling {
+            flags |= ffi::MI_FLAG_NO_FRUSTUM_CULLING;
+        }
+        if has_range {
+            flags |= ffi::MI_FLAG_HAS_VISIBILITY_RANGE;
+        }
+        if let Some(aabb) = aabb {
+            flags |= ffi::MI_FLAG_HAS_AABB;
+            s.aabb_center[row * 3..row * 3 + 3].copy_from_slice(&aabb.center.to_array());
+            s.aabb_half[row * 3..row * 3 + 3].copy_from_slice(&aabb.half_extents.to_array());
+        } else if let Some(sphere) = sphere {
+            // lights: update_point_light_bounding_spheres keeps a world-space Sphere { translation, range } (point_light.rs:195-208)
+            flags |= ffi::MI_FLAG_HAS_SPHERE;
+            s.aabb_center[row * 3..row * 3 + 3].copy_from_slice(&sphere.center.to_array());
+            s.aabb_half[row * 3] = sphere.radius;
+        }
+        s.flags[row] = flags as u8;
+        s.layers[row] = match layers {
+            None => 1, // RenderLayers::default() == layer 0
+            Some(l) => layer_word(l).ok_or(())?,
+        };
+        if let Some(classes) = classes {
+            for class in classes.iter() {
+                s.classes[row] |= 1 << mi_class_bit(&mut mi.class_bits, *class).ok_or(())?;
+            }
+        }
+    }
+    // SAFETY: every column holds `n` rows.
+    unsafe {
+        check(
+            ctx,
+            "mi_upload_bounds",
+            ffi::mi_upload_bounds(ctx, 0, n as u32, s.aabb_center.as_ptr(), s.aabb_half.as_ptr(), s.flags.as_ptr(), s.layers.as_ptr()),
+        )?;
+        check(ctx, "mi_upload_visibility_classes", ffi::mi_upload_visibility_classes(ctx, 0, n as u32, s.classes.as_ptr()))
+    }
+}
+
+/// `VisibilitySystems::CheckVisibility`, fused form: the parked lists become `set_visible()` calls and `VisibleEntities`.  No
+/// device call.  Drops the parked results (-> [`mi_check_visibility`] runs next) when an input of the cull was written after the submit.
+pub fn mi_apply_visibility(
+    mi: Res<Mi355x>,
+    mut frame: ResMut<Mi355xFrame>,
+    ticks: SystemChangeTick,
+    mut view_query: Query<(&mut VisibleEntities, &Frustum)>,
+    inputs: Query<(Ref<InheritedVisibility>, Option<Ref<Aabb>>, Option<Ref<Sphere>>, Option<Ref<RenderLayers>>), Without<NoCpuCulling>>,
+    mut view_visibilities: Query<&mut ViewVisibility, Without<NoCpuCulling>>,
+) {
+    let _ = &mi;
+    if !frame.valid {
+        return;
+    }
+    let written_since = |t: Tick| t.is_newer_than(frame.submit_tick, ticks.this_run());
+    let stale_inputs = inputs.iter().any(|(inherited, aabb, sphere, layers)| {
+        written_since(inherited.last_changed())
+            || aabb.is_some_and(|a| written_since(a.last_changed()))
+            || sphere.is_some_and(|s| written_since(s.last_changed()))
+            || layers.is_some_and(|l| written_since(l.last_changed()))
+    });
+    let stale_frusta = frame.views.iter().any(|v| {
+        view_query.get(v.entity).map_or(true, |(_, frustum)| {
+            frustum.half_spaces.iter().enumerate().any(|(p, h)| h.normal_d().to_array().map(f32::to_bits) != [0, 1, 2, 3].map(|k| v.frustum[p * 4 + k].to_bits()))
+        })
+    });
+    if stale_inputs || stale_frusta {
+        frame.valid = false; // mi_check_visibility, chained right behind, culls this frame with the inputs as they are now
+        return;
+    }
+    for view in &frame.views {
+        let Ok((mut visible_entities, _)) = view_query.get_mut(view.entity) else { continue };
+        visible_entities.clear_all();
+        for (class, entities) in &view.lists {
+            for entity in entities {
+                if let Ok(mut view_visibility) = view_visibilities.get_mut(*entity) {
+                    view_visibility.set_visible(); // mod.rs:846: the tick moves only on hidden -> visible (:290-306)
+                }
+            }
+            visible_entities.get_mut(*class).extend_from_slice(entities); // sorted already (mod.rs:872-875)
+        }
+    }
+}
+
+/// In front of `SimulationLightSystems::AssignLightsToClusters`, fused form: the parked cluster lists become `Clusters`.
+pub fn mi_apply_clusters(mi: Res<Mi355x>, mut frame: ResMut<Mi355xFrame>, mut views: Query<&mut Clusters>) {
+    if !frame.valid {
+        frame.clusters_valid = false; // the lights' ViewVisibility was decided by the cull that has just been dropped
+    }
+    if !frame.clusters_valid {
+        return;
+    }
+    let Some(r) = frame.clusters.as_ref() else { return };
+    let Ok(mut clusters) = views.get_mut(r.view_entity) else { return };
+    let history = mi.cluster_history[&r.view_entity];
+    clusters.tile_size = UVec2::from_array(r.view.tile_size);
+    clusters.dimensions = UVec3::from_array(r.view.dims);
+    clusters.near = r.view.near_;
+    clusters.far = r.view.far_;
+    clusters.last_frame_farthest_z = (history.has_farthest_z != 0).then_some(history.farthest_z);
+    clusters.last_frame_total_cluster_index_count =
+        (history.has_total_cluster_index_count != 0).then_some(history.total_cluster_index_count as usize);
+    let n_clusters = (r.view.dims[0] * r.view.dims[1] * r.view.dims[2]) as usize;
+    let mut per_cluster: Vec<ObjectsInClusterCpu> = Vec::with_capacity(n_clusters);
+    for c in 0..n_clusters {
+        let mut objects = ObjectsInClusterCpu::default();
+        for &object in &r.indices[r.offsets[c] as usize..r.offsets[c + 1] as usize] {
+            objects.add_point_light(r.objects[object as usize].0); // (the riding walk carries point lights only)
+        }
+        debug_assert_eq!(objects.counts.point_lights, r.counts[c * 6]);
+        per_cluster.push(objects);
+    }
+    clusters.clusterable_objects = ClusterableObjects::Cpu(per_cluster);
 }
 
 /// `bevy_math::ops::sin_cos` -- the libm the reference is built with decides the last bit of a spot light's cone; the column

@@ -148,3 +148,42 @@ def test_lights_bound_to_arbitrary_rows():
                 res.append((off.tobytes(), idx[:total].tobytes(), counts.tobytes(), far, total))
             out[name] = res
     assert out["block"] == out["list"] and out["block"][0][4] > 0
+
+
+def test_upload_windows_equal_the_copying_uploads():
+    """mi_map_upload_window / mi_commit_upload_window: Transforms written straight into the library's pinned memory -- dense
+    (DMA from the window) and indexed (one scatter kernel reading it over PCIe, change bytes raised) -- leave the same columns
+    as mi_upload_transforms / mi_upload_transforms_indexed: same GlobalTransforms, change ticks and masks after the frame."""
+    n = 70_001
+    sc = W.many_cubes(n, radius=60.0, ragged_flags=True)
+    t3, r4, s3 = sc["translation"].reshape(n, 3), sc["rotation"].reshape(n, 4), sc["scale"].reshape(n, 3)
+    frusta = frusta_for([W.many_cubes_camera(0)])
+    rng = np.random.default_rng(5)
+    with api.Context(0) as a, api.Context(0) as b:
+        for ctx in (a, b):
+            ctx.resize(n)
+            ctx.upload_bounds(sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"])
+        a.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
+        w, _, wt, wr, ws = b.map_upload_window(n, dense=True)
+        wt[:], wr[:], ws[:] = sc["translation"], sc["rotation"], sc["scale"]
+        b.commit_upload_window(w, n)
+        for ctx in (a, b):
+            ctx.upload_changed(np.ones(n, np.uint8))
+        for frame, k in enumerate((n, 1, 5_000, 0, 40_000)):
+            rows = rng.permutation(n)[:k].astype(np.uint32)  # any order
+            t2 = (t3[rows] + F(0.5 + frame)).astype(F)
+            if k:
+                a.upload_transforms_indexed(rows, t2.reshape(-1), r4[rows].reshape(-1), s3[rows].reshape(-1))
+                w, wrows, wt, wr, ws = b.map_upload_window(k + 7)  # a window may be bigger than what is committed
+                wrows[:k], wt[:3 * k], wr[:4 * k], ws[:3 * k] = rows, t2.reshape(-1), r4[rows].reshape(-1), s3[rows].reshape(-1)
+                b.cluster_upload_objects(np.zeros(4, F))  # an unrelated call between map and commit
+                b.commit_upload_window(w, k)
+            for ctx in (a, b):
+                ctx.propagate_and_cull(frusta, flags=B.CULL_END_FRAME | B.CULL_CHANGED_ROWS)
+            ga, ca = a.download_global_transforms()
+            gb, cb = b.download_global_transforms()
+            assert ga.tobytes() == gb.tobytes() and np.array_equal(ca, cb) and int(ca.sum()) == k, f"frame {frame}"
+            assert np.array_equal(a.download_visibility(0), b.download_visibility(0))
+        with pytest.raises(api.MiError) as e:  # a window is committed once
+            b.commit_upload_window(w, 1)
+        assert e.value.code == api.MI_ERR_NOT_READY

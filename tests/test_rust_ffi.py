@@ -184,7 +184,7 @@ def test_struct_sizes_match_the_ctypes_mirrors(both):
     from bevy_amd import api
 
     mirrors = {"MiView": api.View, "MiClusterView": api.ClusterView, "MiClusterConfig": api.ClusterConfig,
-               "MiClusterHistory": api.ClusterHistory, "MiClusterResolved": api.ClusterResolved, "MiFrameResults": api.FrameResults, "MiVisibleList": api.VisibleList}
+               "MiClusterHistory": api.ClusterHistory, "MiClusterResolved": api.ClusterResolved, "MiFrameResults": api.FrameResults, "MiVisibleList": api.VisibleList, "MiUploadWindow": api.UploadWindow}
     for name, cls in mirrors.items():
         assert _rust_layout(r_structs[name]) == ctypes.sizeof(cls), name
 

@@ -66,6 +66,7 @@ def parse():
                     help="frame: mi_propagate_and_cull, then mi_cluster_assign_resident behind it (default: ONE call with "
                          "MI_CULL_WITH_CLUSTERS, the assignment concurrent with the frame kernel on the cluster stream)")
     ap.add_argument("--concurrent-clusters", action="store_true", help="frame: add MI_CULL_CLUSTERS_CONCURRENT")
+    ap.add_argument("--tree-moved", choices=["all", "subtree", "leaves"], default="all", help="tree: the root moves and every Transform counts as changed (default) / change-driven frames: one level-5 node moves / 10 000 leaves move")
     ap.add_argument("--sphere-path", type=int, default=0, help="flat_static / frame: 0 = world-sphere cull path from the second quiet frame (default), 1 = never (k_frame<0> over GlobalTransform + Aabb), 2 = at once")
     ap.add_argument("--tile-mode", type=int, default=0, help="tree: 0 = tile kernel chosen by size, 1 = big tiles, 2 / 3 = light tiles (5 / 6 waves per SIMD)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -239,6 +240,32 @@ def build_tree(ctx, args, rank=0, world=1):
     plan = ctx.debug_tile_plan()
     # the root moves every frame (a 40-byte dirty-row upload), so set_if_neq really rewrites every descendant
     root_t = [tr["translation"][:3].copy(), tr["translation"][:3] + np.float32(1.0)]
+    moved = getattr(args, "tree_moved", "all")
+    if moved != "all":
+        # change-driven frames under StaticTransformOptimizations (the frame a game mostly runs): "subtree" = one node of level 5
+        # moves (1 / 1024 of a 4-ary tree follows it), "leaves" = 10 000 random leaves move
+        n, lv = tr["n"], tr["level_offsets"]
+        rng = np.random.default_rng(3)
+        rows = (np.array([int(lv[5]) + 17], np.uint32) if moved == "subtree"
+                else np.sort(rng.choice(np.arange(int(lv[-2]), n), 10_000, replace=False)).astype(np.uint32))
+        t3 = tr["translation"].reshape(n, 3)
+        sets = [(np.ascontiguousarray(t3[rows] + np.float32(d)).reshape(-1), np.ascontiguousarray(tr["rotation"].reshape(n, 4)[rows]).reshape(-1),
+                 np.ascontiguousarray(tr["scale"].reshape(n, 3)[rows]).reshape(-1)) for d in (0.0, 1.0)]
+        ctx.upload_changed(np.ones(n, np.uint8))
+        ctx.propagate(B.PROPAGATE_STATIC_OPT)
+
+        def step(f):
+            ctx.upload_transforms_indexed(rows, *sets[f & 1])
+            ctx.propagate(B.PROPAGATE_STATIC_OPT)
+        config = {"workload": f"gen_tree(12,4) truncated to {n_global} nodes, StaticTransformOptimizations enabled, per frame "
+                              + ("ONE node of level 5 moves (1 / 1024 of the tree follows)" if moved == "subtree" else "10 000 random leaves move")
+                              + ": mi_upload_transforms_indexed + mi_propagate(MI_PROPAGATE_STATIC_OPT) = mark_dirty_trees + the tile launch",
+                  "nodes": n_global, "moved_rows": int(len(rows)), "tile_plan": plan}
+        wl = Workload("tree_" + moved, step, tr["n"], 141.0, "k_propagate_tiles", config, "nodes/sec through change-driven hierarchy propagate", "nodes/s",
+                      kernels=["k_propagate_tiles", "k_mark_dirty"])
+        wl.tree = tr
+        wl.kernel_name = "k_propagate_fans<false>"
+        return wl
 
     def step(f):
         ctx.upload_transforms(root_t[f & 1], tr["rotation"][:4], tr["scale"][:3], first_row=0)
@@ -641,14 +668,17 @@ def end_to_end(ctx, wl, frames=12):
             if rows is not None:  # the ECS side's gather loop, writing into the window
                 w, wrows, wt, wr, ws = ctx.map_upload_window(k)
                 wrows[:] = rows
-                np.take(t3, rows, axis=0, out=wt.reshape(k, 3))
-                np.take(r4, rows, axis=0, out=wr.reshape(k, 4))
-                np.take(s3, rows, axis=0, out=ws.reshape(k, 3))
+                np.take(t3, rows, axis=0, out=wt.reshape(k, 3), mode="clip")  # (mode="raise" buffers the whole output)
+                np.take(r4, rows, axis=0, out=wr.reshape(k, 4), mode="clip")
+                np.take(s3, rows, axis=0, out=ws.reshape(k, 3), mode="clip")
                 ctx.commit_upload_window(w, k)
-            else:
-                w, _, wt, wr, ws = ctx.map_upload_window(n, dense=True)
-                wt[:], wr[:], ws[:] = sc["translation"], sc["rotation"], sc["scale"]
-                ctx.commit_upload_window(w, n)
+            else:  # every row: dense windows, a chunk at a time -- chunk i crosses PCIe (DMA) while the host fills chunk i + 1
+                chunk = (n + 7) // 8
+                for lo in range(0, n, chunk):
+                    m = min(chunk, n - lo)
+                    w, _, wt, wr, ws = ctx.map_upload_window(m, dense=True)
+                    wt[:], wr[:], ws[:] = t3[lo:lo + m].reshape(-1), r4[lo:lo + m].reshape(-1), s3[lo:lo + m].reshape(-1)
+                    ctx.commit_upload_window(w, m, first_row=lo)
             t1 = time.perf_counter()
             ctx.propagate_and_cull(fr, flags=B.CULL_END_FRAME | B.CULL_WITH_CLUSTERS | (B.CULL_CHANGED_ROWS if rows is not None else 0))
             t2 = time.perf_counter()
@@ -811,7 +841,8 @@ def main():
         specs = [("flat", lambda c: build_flat(c, args, 0, 1, [], args.entities or 1_000_000, 1, "flat")),
                  ("flat_10m_4views", lambda c: build_flat(c, args, 0, 1, [], 10_000_000, 4, "sharded")),
                  ("flat_10m_1view", lambda c: build_flat(c, args, 0, 1, [], 10_000_000, 1, "flat")),
-                 ("tree", lambda c: build_tree(c, args)), ("lights", lambda c: build_lights(c, args)),
+                 ("tree", lambda c: build_tree(c, args)), ("tree_one_subtree_moves", lambda c: build_tree(c, with_args(args, tree_moved="subtree"))),
+                 ("tree_10k_leaves_move", lambda c: build_tree(c, with_args(args, tree_moved="leaves"))), ("lights", lambda c: build_lights(c, args)),
                  ("flat_static", lambda c: build_flat_static(c, args)), ("flat_static_no_sphere_column", lambda c: build_flat_static(c, with_args(args, sphere_path=1))),
                  ("flat_static_10m_4views", lambda c: build_flat_static(c, with_args(args, entities=10_000_000, views=4))),
                  ("batching", lambda c: build_batching(c, args))]

@@ -499,6 +499,7 @@ static int32_t cull_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, u
             if (clusters_concurrent && changed_col && ctx->cl_on_side) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_cl_done, 0));
             HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, ctx->n, ctx->stream));
             ctx->changed_maybe = false;
+            ctx->changed_rows_hint = 0;
         }
         ctx->g_chg_maybe = true;
         ctx->g_chg_in_bytes = false;
@@ -661,6 +662,7 @@ int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
     ctx->bt_resolve = true;
     ctx->changed_maybe = true;
     if (n_rows != ctx->n) ctx->sph_state = mi_ctx::SPH_INVALID;
+    if (n_rows > ctx->n) ctx->changed_rows_hint = UINT64_MAX;  // new rows are Added<GlobalTransform>: marked, uncounted
     if (n_rows < ctx->n && ctx->cl_rows_listed) ctx->cl_rows_bound = false;  // a listed row may be gone: the caller binds again
     const uint32_t old_cap_rows = ctx->cap;
     if (n_rows > ctx->cap) {
@@ -801,6 +803,7 @@ static int32_t scatter_indexed(mi_ctx* ctx, const uint32_t* rows, const float* t
     HIP_TRY(ctx, launch_upload_trs_indexed((const uint32_t*)d_rows, (const float*)d_t, (const float*)d_r, (const float*)d_s, n, ctx->t, ctx->r,
                                            ctx->s, ctx->changed, ctx->stream));
     ctx->changed_maybe = true;
+    if (ctx->changed_rows_hint != UINT64_MAX) ctx->changed_rows_hint += n;
     return MI_OK;
 }
 
@@ -946,6 +949,7 @@ int32_t mi_upload_changed(mi_ctx* ctx, uint32_t first_row, uint32_t n, const uin
     if (rc) return rc;
     ctx->have_changed = true;
     ctx->changed_maybe = true;
+    ctx->changed_rows_hint = UINT64_MAX;  // how many of these bytes are set is not known here
     return upload(ctx, ctx->changed + first_row, changed, n);
 }
 
@@ -1041,13 +1045,21 @@ int32_t mi_propagate(mi_ctx* ctx, uint32_t flags) {
         // EVERY launch mirrors the rows it owns below snap_rows into next frame's snapshot -- not only the launch the
         // chain tiles ride in: a chain runs up through rows owned by earlier launches too, and under the static-scene
         // rule the chain tiles compare against (and fall back to) the snapshot's value.
+        // few rows changed (every mark came through the indexed uploads, so their number is known): the light tiles test their flags
+        // before asking for anything else -- a clean tile leaves after one small round trip; with many changed rows most tiles fail
+        // the test and it would only cost them that round trip
+        uint32_t n_tiles_all = 0;
+        for (auto& gr : ctx->groups) n_tiles_all += gr.count;
+        const bool tiles_pretest = ctx->tile_pretest_mode == 2 ||
+                                   (ctx->tile_pretest_mode == 0 && static_opt && !all_dirty && ctx->changed_rows_hint != UINT64_MAX &&
+                                    ctx->changed_rows_hint * 16 <= n_tiles_all);
         for (auto& gr : ctx->groups) {
             ProfScope sc(ctx, K_PROPAGATE_TILES);
             HIP_TRY(ctx, launch_propagate_tiles(c, (const uint32_t*)ctx->parent_idx.p, (const TileDesc*)ctx->tiles.p + gr.first,
                                                 (const uint32_t*)ctx->chains.p + (size_t)gr.first * TILE_MAX_CHAIN, gr.count,
                                                 (const uint8_t*)ctx->node_flags.p, ctx->changed, tree_bits, ctx->g_changed_bytes,
                                                 gr.n_chain ? snap_r : nullptr, snap_w, ctx->snap_rows, all_dirty, static_opt,
-                                                ctx->tiles_light, ctx->stream, (unsigned long long*)ctx->tree_trace.p));
+                                                ctx->tiles_light, ctx->stream, (unsigned long long*)ctx->tree_trace.p, tiles_pretest));
         }
         for (auto& lv : ctx->stream_levels) {  // the wide deepest levels, each behind the level above it
             ProfScope sc(ctx, K_PROPAGATE_STREAM);
@@ -1059,6 +1071,7 @@ int32_t mi_propagate(mi_ctx* ctx, uint32_t flags) {
     if (ctx->have_changed && ctx->changed_maybe) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, ctx->n, ctx->stream));  // change flags are consumed
         ctx->changed_maybe = false;
+        ctx->changed_rows_hint = 0;
     }
     ctx->propagated_rows = ctx->n;
     return MI_OK;
@@ -1372,6 +1385,7 @@ int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
             j.want_changed_rows = want_rows ? 1u : 0u;
             j.changed_capacity = io->changed_capacity;
         }
+        j.big_rows = PACK_BIG_ROWS;
         j.n_lists = n_lists;
         for (uint32_t l = 0; l < n_lists; ++l) {
             j.list_total[l] = list_total[l];
@@ -1408,9 +1422,10 @@ int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
                 src += pack_align(bytes);
             };
             const bool fits_changed = want_changed && changed <= io->changed_capacity;
+            const bool by_dma = fits_changed && h[6] != 0;  // many rows: left out of the window, fetched by the copy engine below
             if (want_changed && !fits_changed) cap_rc = fail(ctx, MI_ERR_CAPACITY, "%u GlobalTransforms changed, capacity %u", changed, io->changed_capacity);
-            if (fits_changed && want_rows) deliver(io->changed_rows, (size_t)changed * 4);
-            if (fits_changed && want_g) deliver(io->changed_global12, (size_t)changed * 48);
+            if (fits_changed && !by_dma && want_rows) deliver(io->changed_rows, (size_t)changed * 4);
+            if (fits_changed && !by_dma && want_g) deliver(io->changed_global12, (size_t)changed * 48);
             for (uint32_t l = 0; l < n_lists; ++l) {
                 mi_visible_list& ls = io->lists[l];
                 ls.count = h[8u + l];
@@ -1425,6 +1440,23 @@ int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
                     if (cl_total > io->cluster_capacity) cap_rc = fail(ctx, MI_ERR_CAPACITY, "cluster index list has %llu entries, capacity %llu", (unsigned long long)cl_total, (unsigned long long)io->cluster_capacity);
                     else deliver(io->cluster_indices, (size_t)cl_total * 4);
                 }
+            }
+            if (by_dma) {  // a second wait, negligible next to megabytes over PCIe
+                BatchedDownload b;
+                b.in_place = in_place;
+                if (want_rows && (rc = b.add(ctx, io->changed_rows, ctx->sparse_rows.p, (size_t)changed * 4, in_place ? (void**)&io->changed_rows : nullptr))) return rc;
+                if (want_g) {
+                    const bool all_rows = changed == ctx->n;  // every row changed: the list is 0 .. n-1 and the column itself is the answer
+                    if (!all_rows) {
+                        if ((rc = ensure(ctx, ctx->sparse_g, (size_t)changed * 48))) return rc;
+                        HIP_TRY(ctx, launch_gather_global((const uint32_t*)ctx->sparse_rows.p, (const uint32_t*)ctx->sparse_total.p, changed, ctx->g,
+                                                          (float*)ctx->sparse_g.p, ctx->stream));
+                    }
+                    if ((rc = b.add(ctx, io->changed_global12, all_rows ? (const void*)ctx->g : ctx->sparse_g.p, (size_t)changed * 48,
+                                    in_place ? (void**)&io->changed_global12 : nullptr)))
+                        return rc;
+                }
+                if ((rc = b.finish(ctx))) return rc;
             }
             return cap_rc;
         }
@@ -1682,6 +1714,15 @@ const char* mi_profile_kernel_name(uint32_t k) {
                                                "k_clear_u32", "k_inherit", "k_batch_hist", "k_batch_plan", "k_batch_emit",
                                                "k_batch_scan", "k_batch_scatter", "k_batch_bounds", "k_batch_sorted", "k_propagate_stream"};
     return k < K_NUM_KERNELS ? names[k] : nullptr;
+}
+
+// test / bench hook: the flags-first test of the light tiles under the static-scene rule: 0 = when few rows changed (default),
+// 1 = never, 2 = always
+int32_t mi_debug_set_tile_pretest(mi_ctx* ctx, int32_t mode) {
+    ENTER(ctx);
+    if (mode < 0 || mode > 2) return fail(ctx, MI_ERR_INVALID_ARG, "mi_debug_set_tile_pretest: mode %d", mode);
+    ctx->tile_pretest_mode = mode;
+    return MI_OK;
 }
 
 // test / bench hook: the world-sphere path of the cull-only and changed-rows frames (k_frame_sph): 0 = used from the second

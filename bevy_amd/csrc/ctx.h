@@ -78,6 +78,7 @@ struct mi_ctx {
     std::vector<std::pair<uint32_t, uint32_t>> passes;  // (first tile, n tiles); pass 0 starts at level 0 (roots)
     struct TileGroup { uint32_t first, count, n_chain, owner_rows; };
     bool tiles_light = false;       // the plan was made for the light tile kernel (TILE_LIGHT_*)
+    int32_t tile_pretest_mode = 0;  // mi_debug_set_tile_pretest
     int32_t tile_mode = 0;          // 0 = light tiles where they fit, 1 = always the big tiles, 2 = always light, 3 = as 0 with the streamed-level thresholds at their test values (mi_debug_set_tile_mode)
     std::vector<TileGroup> groups;  // tile launches of mi_propagate: roots + chain bands in one, then one per dependent band
     std::vector<std::pair<uint32_t, uint32_t>> stream_levels;  // (start, count), top-down: the wide deepest levels, one streaming launch each
@@ -91,6 +92,9 @@ struct mi_ctx {
     // non-zero (set by the uploads that mark rows, cleared when mi_propagate consumes the column); the change masks of
     // the last propagate may hold set bits
     bool changed_maybe = true, g_chg_maybe = true;
+    // rows marked changed since the last propagate consumed the column, when every mark came through mi_upload_transforms_indexed /
+    // mi_commit_upload_window (UINT64_MAX: a bulk mi_upload_changed or new rows -- unknown)
+    uint64_t changed_rows_hint = UINT64_MAX;
 
     // ---- world-sphere column (k_frame_sph): (affine * aabb.center, |M3 * half_extents|) per row, the bounding sphere
     // check_visibility tests first.  Valid relative to the GlobalTransform / bounds columns as `sph_state` says.

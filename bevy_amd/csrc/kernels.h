@@ -52,6 +52,7 @@ struct ViewParams {
     uint32_t pad[3];
 };
 static_assert(sizeof(ViewParams) == 144, "ViewParams layout");
+constexpr uint32_t SPHERE_AT_TRANSLATION = 0x7FC0A11Du;  // MI_SPHERE_AT_TRANSLATION (public header): half.y of a Sphere row whose centre is the row's GlobalTransform translation
 // MI_VIEW_FLAG_* (public header)
 constexpr uint32_t VIEW_NO_CPU_CULLING = 0x01u, VIEW_SHADOW = 0x02u, VIEW_SKIP_NEAR = 0x04u, VIEW_TEST_FAR = 0x08u,
                    VIEW_LIGHT_SPHERE = 0x10u, VIEW_RANGES = 0x20u, VIEW_RANGES_NO_ORIGIN = 0x40u;
@@ -191,7 +192,8 @@ hipError_t launch_gather_mesh_inputs(const uint32_t* rows, const uint32_t* total
 // changed GlobalTransforms (48 B each), the visible-row lists in the caller's order, cluster offsets (C + 1), cluster counts (6 C),
 // cluster indices.
 // header: [0] changed, [2..3] cluster total (u64), [4] farthest_z (f32 bits), [5] 1 = payload written, 0 = it did not fit
-// `payload_bytes` (or the cluster list overflowed its device buffer): the host falls back to separate copies; [8 + i] entries of list i.
+// `payload_bytes` (or the cluster list overflowed its device buffer): the host falls back to separate copies; [6] 1 = the changed
+// sections were left out (more than big_rows rows: the host fetches them by DMA); [8 + i] entries of list i.
 constexpr uint32_t PACK_MAX_LISTS = 16;  // MI_RESULTS_MAX_LISTS
 struct PackResultsJob {
     const uint32_t* changed_total;   // nullptr: no changed section
@@ -205,6 +207,7 @@ struct PackResultsJob {
     uint32_t n_clusters;
     uint32_t want_changed_rows;
     uint32_t changed_capacity, n_lists;
+    uint32_t big_rows;  // more changed rows than this: the rows / GlobalTransform sections are left to the DMA engine (header[6] = 1)
     uint64_t cluster_capacity, cluster_indices_alloc;
     uint32_t* header;
     uint8_t* payload;
@@ -216,6 +219,9 @@ struct PackResultsJob {
     uint32_t list_capacity[PACK_MAX_LISTS];
 };
 constexpr uint32_t PACK_HEADER_BYTES = 256;
+// Above this many changed rows (3.4 MB of rows + matrices) the copy engine moves them faster than the packing kernel's stores over
+// PCIe do (55 against 29 GB/s on this box), even with the extra wait: the kernel leaves the two sections out and says so.
+constexpr uint32_t PACK_BIG_ROWS = 65536;
 constexpr uint64_t PACK_WINDOW_BYTES = (uint64_t)8 << 20;  // copy-out mode: bigger frames are byte-bound anyway and take the DMA path
 constexpr uint64_t PACK_WINDOW_BYTES_IN_PLACE = (uint64_t)512 << 20;  // in-place mode: the window IS the result, whatever its size
 __host__ __device__ inline uint64_t pack_align(uint64_t b) { return (b + 255u) & ~(uint64_t)255u; }
@@ -287,7 +293,7 @@ hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, 
                                   uint32_t n_tiles, const uint8_t* node_flags, const uint8_t* changed, const uint8_t* tree_bytes,
                                   uint8_t* g_changed_bytes, const float* snap_read, float* snap_write, uint32_t snap_rows, bool all_dirty,
                                   bool static_opt, bool light /* the plan is one of light tiles */, hipStream_t stream,
-                                  unsigned long long* trace = nullptr);
+                                  unsigned long long* trace = nullptr, bool pretest = false /* light tiles, static-scene rule: flags first */);
 // One whole level [start, start + count) as a stream: every row's parent lies in the level above, complete in global
 // memory (an earlier launch).  Same per-node rule as the tiles.
 hipError_t launch_propagate_level(const Columns& c, const uint32_t* parent_idx, uint32_t start, uint32_t count, const uint8_t* changed,

@@ -427,7 +427,8 @@ __global__ void __launch_bounds__(256) k_frame_sph(Columns c, ViewSet vs, const 
             const V3 center = ld3(c.aabb_center, row), half = ld3(c.aabb_half, row);
             // exactly the values row_visible_in_view computes (visibility_rule.h): Aabb -> (affine * center, |M3 * half|), a Sphere
             // component as it is
-            const V3 cw = has_aabb ? transform_point(g, center) : center;
+            const bool at_translation = !has_aabb && __float_as_uint(half.y) == SPHERE_AT_TRANSLATION;  // a light's sphere follows its entity
+            const V3 cw = has_aabb ? transform_point(g, center) : V3{at_translation ? g.t.x : center.x, at_translation ? g.t.y : center.y, at_translation ? g.t.z : center.z};
             const float sr = has_aabb ? length3(mul(g.m, half)) : half.x;
             sp = make_float4(cw.x, cw.y, cw.z, sr);
             sa.sph[row] = sp;
@@ -469,12 +470,7 @@ __global__ void __launch_bounds__(256) k_frame_sph(Columns c, ViewSet vs, const 
             vis = vis && in_range;
         }
         const bool cull = bounded && !(vp.flags & VIEW_NO_CPU_CULLING);
-        bool inside = true;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const V4 pl = V4{vp.planes[4 * i], vp.planes[4 * i + 1], vp.planes[4 * i + 2], vp.planes[4 * i + 3]};
-            inside = inside && !(dot4(pl, c4) + sr <= 0.0f);
-        }
+        const bool inside = sphere_inside_five_planes(vp.planes, c4, sr);
         vis = vis && (inside || !cull);
         if (vis) pass |= 1u << v;
         if (vis && cull && has_aabb) need |= 1u << v;
@@ -683,8 +679,9 @@ hipError_t launch_gather_global(const uint32_t* rows, const uint32_t* total, uin
 __global__ void __launch_bounds__(256) k_pack_results(PackResultsJob j) {
     const uint32_t changed = j.changed_total ? *j.changed_total : 0u;
     const uint64_t cl_total = j.cluster_total ? *j.cluster_total : 0ull;
-    const bool s_rows = j.changed_total && j.want_changed_rows && changed <= j.changed_capacity;
-    const bool s_g = j.changed_total && j.g && changed <= j.changed_capacity;
+    const bool big = changed > j.big_rows;  // the copy engine's job
+    const bool s_rows = j.changed_total && j.want_changed_rows && changed <= j.changed_capacity && !big;
+    const bool s_g = j.changed_total && j.g && changed <= j.changed_capacity && !big;
     const bool s_cl = j.cluster_total != nullptr;
     const bool s_idx = s_cl && j.cluster_indices && cl_total <= j.cluster_capacity;
     const bool overflow = s_cl && cl_total > j.cluster_indices_alloc;
@@ -708,6 +705,7 @@ __global__ void __launch_bounds__(256) k_pack_results(PackResultsJob j) {
         j.header[3] = (uint32_t)(cl_total >> 32);
         j.header[4] = s_cl ? __float_as_uint(*j.farthest_z) : 0u;
         j.header[5] = fits ? 1u : 0u;
+        j.header[6] = big && j.changed_total ? 1u : 0u;
     }
     if (tid < j.n_lists) j.header[8u + tid] = j.list_total[tid] ? *j.list_total[tid] : 0u;
     if (!fits) return;

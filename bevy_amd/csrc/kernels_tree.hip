@@ -161,6 +161,7 @@ struct TreeArgs {
     uint32_t snap_rows;  // the snapshot covers rows [0, snap_rows): whoever computes one of them also writes its snapshot
     uint32_t all_dirty;
     uint32_t static_opt;
+    uint32_t pretest;  // light tiles under the static-scene rule: test the tile's flags before asking for anything else (few rows changed)
     unsigned long long* trace;  // debug: 8 x s_memrealtime per tile (mi_debug_tree_trace), nullptr = off
 };
 
@@ -704,6 +705,31 @@ __global__ void __launch_bounds__(256, ALL_DIRTY ? 8 : 7) k_propagate_fans(Colum
         }
     const bool s_root_level = ROOTS && n_lds == 0;
 
+    // ---- A frame in which little moved (the frame a game mostly runs): most tiles are clean, and a clean tile should cost one small
+    // round trip, not its first burst (~11 KB) and its chain.  Flags only: the tile is skipped as a whole (the rule below) iff its
+    // parent's GlobalTransform does not change -- which takes a chain node whose own Transform changed: a node that is merely
+    // re-evaluated reproduces its value, set_if_neq leaves it alone (systems.rs:719) and its children see an unchanged parent -- and
+    // none of its top rows is marked (TransformTreeChanged) or assigned as a root / flat row.  The change bytes of the chain's nodes
+    // and the marks of the top rows answer that: <= 24 + 112 bytes.  A tile that fails the test goes on as before (the test is a
+    // superset of the exact rule evaluated after the chain), one round trip later: the host asks for it only when few rows changed.
+    if constexpr (!ALL_DIRTY) {
+        if (a.pretest && a.static_opt && (chain_len || ROOTS) && n_lds && (!snap_out || td.start[0] >= a.snap_rows)) {
+            bool hot = false;
+            if (chain_lane && tid - FAN_CHAIN_LANE0 < chain_len) hot = at32<uint8_t>(a.changed, chain_row) != 0;
+            if (tid < td.count[0]) {
+                const uint32_t row = td.start[0] + tid;
+                hot = hot || at32<uint8_t>(a.tree_bytes, row) != 0 || (ROOTS && at32<uint8_t>(a.changed, row) != 0);
+            }
+            if (__syncthreads_or(hot ? 1 : 0) == 0) {
+#pragma unroll
+                for (uint32_t l = 0; l < TILE_MAX_LEVELS; ++l)
+                    if (l < L)
+                        for (uint32_t i = tid; i < td.count[l]; i += 256u) at32w<uint8_t>(a.g_changed_bytes, td.start[l] + i) = 0;
+                return;
+            }
+        }
+    }
+
     // ---- burst 1: straight-line code, no load behind a divergent branch (the compiler waits where a result is first used, and
     // the load counter is in order: a use in the middle would split the batch in two) ----
     // (a) this lane's row of the last level (lanes past the end re-read the level's first row)
@@ -1167,6 +1193,7 @@ hipError_t launch_propagate_level(const Columns& c, const uint32_t* parent_idx, 
     a.g_changed_bytes = g_changed_bytes;
     a.all_dirty = all_dirty ? 1u : 0u;
     a.static_opt = static_opt ? 1u : 0u;
+    a.pretest = 0;
     MI_LAUNCH(k_propagate_level, dim3((count + 255u) / 256u), dim3(256), 0, stream, c, a, start, count);
     return hipGetLastError();
 }
@@ -1181,9 +1208,10 @@ hipError_t launch_mark_dirty(uint32_t n, const uint8_t* changed, const uint32_t*
 hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, const TileDesc* d_tiles, const uint32_t* d_chains,
                                   uint32_t n_tiles, const uint8_t* node_flags, const uint8_t* changed, const uint8_t* tree_bytes,
                                   uint8_t* g_changed_bytes, const float* snap_read, float* snap_write, uint32_t snap_rows, bool all_dirty,
-                                  bool static_opt, bool light, hipStream_t stream, unsigned long long* trace) {
+                                  bool static_opt, bool light, hipStream_t stream, unsigned long long* trace, bool pretest) {
     if (n_tiles == 0) return hipSuccess;
     TreeArgs a;
+    a.pretest = pretest && changed && tree_bytes ? 1u : 0u;
     a.snap_read = snap_read;
     a.snap_write = snap_write;
     a.snap_rows = snap_rows;

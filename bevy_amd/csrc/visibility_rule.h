@@ -17,6 +17,34 @@ namespace mi {
 // primitives.rs:279), so they are computed once; the far plane is never tested (mod.rs:831,835).
 // Visibility ranges (range.rs:159-161,255-263) are evaluated on the fly from the row's (start, end) pair and the
 // view's position instead of a per-(view, entity) table.
+// Frustum::intersects_sphere over planes 0..4 (far plane never tested on this path, visibility/mod.rs:829-832): true = no plane
+// has the sphere wholly behind it.  MI_PACKED_PLANES evaluates planes (0,1) and (2,3) two at a time in the halves of packed-FP32
+// instructions (v_pk_mul_f32 / v_pk_add_f32: the same IEEE multiply and add per half, in the same order, so the same bits) --
+// 26 instead of 40 vector instructions per row and view where a frame is bound by instruction issue (k_frame_sph at several views).
+typedef float mi_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bool sphere_inside_five_planes(const float* planes, V4 c4, float r) {
+#ifdef MI_PACKED_PLANES
+    bool inside = true;
+#pragma unroll
+    for (int i = 0; i < 4; i += 2) {
+        const mi_f2 px = {planes[4 * i], planes[4 * i + 4]}, py = {planes[4 * i + 1], planes[4 * i + 5]};
+        const mi_f2 pz = {planes[4 * i + 2], planes[4 * i + 6]}, pw = {planes[4 * i + 3], planes[4 * i + 7]};
+        const mi_f2 v = ((px * c4.x + pz * c4.z) + (py * c4.y + pw * c4.w)) + r;  // dot4's pairwise order, per half
+        inside = inside && !(v.x <= 0.0f) && !(v.y <= 0.0f);
+    }
+    const V4 pl = V4{planes[16], planes[17], planes[18], planes[19]};
+    return inside && !(dot4(pl, c4) + r <= 0.0f);
+#else
+    bool inside = true;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const V4 pl = V4{planes[4 * i], planes[4 * i + 1], planes[4 * i + 2], planes[4 * i + 3]};
+        inside = inside && !(dot4(pl, c4) + r <= 0.0f);
+    }
+    return inside;
+#endif
+}
+
 __device__ __forceinline__ bool row_visible_in_view(const Affine& g, V3 center, V3 half, uint32_t fl,
                                                     uint32_t entity_mask, bool have_ranges, float range_lo,
                                                     float range_hi, const ViewParams& vp) {
@@ -55,17 +83,14 @@ __device__ __forceinline__ bool row_visible_in_view(const Affine& g, V3 center, 
     }
     const bool cull = !(fl & 0x02u) && !(vp.flags & VIEW_NO_CPU_CULLING);  // !NoFrustumCulling && !camera NoCpuCulling
     if (cull && (fl & (0x04u | 0x08u))) {
-        // world-space sphere: Aabb -> (affine*center, |M3*half|) ; Sphere component used as is
-        const V3 cw = has_aabb ? transform_point(g, center) : center;
+        // world-space sphere: Aabb -> (affine*center, |M3*half|) ; Sphere component used as is -- or, a light's sphere that follows
+        // its entity (MI_SPHERE_AT_TRANSLATION), centred at the row's GlobalTransform translation
+        const bool at_translation = !has_aabb && __float_as_uint(half.y) == SPHERE_AT_TRANSLATION;
+        const V3 cw = has_aabb ? transform_point(g, center) : V3{at_translation ? g.t.x : center.x, at_translation ? g.t.y : center.y, at_translation ? g.t.z : center.z};
         const float sr = has_aabb ? length3(mul(g.m, half)) : half.x;
         const V4 c4 = extend(cw, 1.0f);
         // intersects_sphere over the five planes first (mod.rs:829-832) ...
-        bool inside = true;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const V4 pl = V4{vp.planes[4 * i], vp.planes[4 * i + 1], vp.planes[4 * i + 2], vp.planes[4 * i + 3]};
-            inside = inside && !(dot4(pl, c4) + sr <= 0.0f);
-        }
+        bool inside = sphere_inside_five_planes(vp.planes, c4, sr);
         // ... then intersects_obb (:833-836) -- 20 flops per plane and row -- only in waves where some row is still a candidate:
         // rows are usually numbered with some spatial coherence and a view sees a few percent of them, so most waves skip it.
         // (The reference returns early per entity; a conjunction of the same tests gives the same answer in any order.)

@@ -270,7 +270,6 @@ class World {
         bool global_changed = false, inherited_changed = false;
         bool visibility_changed = false, bounds_changed = false;
         bool touched = false;  // listed in touched_: some change flag is set (what a change-tick scan would find)
-        bool above_light = false;  // the entity is a point light or has one below it: its Transform moves a light's bounding Sphere
     };
     Rec& rec(Entity e) {
         if (!contains(e)) throw std::out_of_range("no such entity");
@@ -727,31 +726,10 @@ class Mi355xPlugin {
         check(mi_cluster_bind_objects_to_row_list(ctx_, (uint32_t)rows.size(), rows.data()));
         return true;
     }
-    // GlobalTransform::translation() an entity WILL have after this frame's propagate, from the Transforms up its ChildOf chain
-    // with the host build of the same arithmetic (glam_math.h): what update_point_light_bounding_spheres reads
-    // (crates/bevy_light/src/point_light.rs:195-208) -- it runs behind TransformSystems::Propagate, the fused frame runs inside it.
-    static GlobalTransform expected_global(const World& w, Entity e) {
-        std::vector<const Transform*> chain;
-        for (std::optional<Entity> cur = e; cur && w.contains(*cur); cur = w.rec_[cur->index].parent) chain.push_back(&w.rec_[cur->index].transform);
-        GlobalTransform g = GlobalTransform::from(*chain.back());
-        for (size_t k = chain.size() - 1; k-- > 0;) g = g * *chain[k];
-        return g;
-    }
     void upload_bounds(World& w) {
         const uint32_t n = (uint32_t)entity_of_row_.size();
-        bool any = bounds_dirty_ || seen_bounds_ != w.bounds_version_;
-        for (size_t k = 0; k < w.touched_.size() && !any; ++k) {  // a moved light (or ancestor of one) moves the light's Sphere
-            const World::Rec& e = w.rec_[w.touched_[k]];
-            any = e.above_light && (e.transform_changed || e.added || e.parent_changed || e.orphaned);
-        }
-        if (!any) return;
+        if (!bounds_dirty_ && seen_bounds_ == w.bounds_version_) return;
         seen_bounds_ = w.bounds_version_;
-        for (World::Rec& e : w.rec_) e.above_light = false;
-        for (uint32_t row = 0; row < n; ++row) {
-            if (!w.rec_[entity_of_row_[row].index].point_light_range) continue;
-            for (std::optional<Entity> cur = entity_of_row_[row]; cur && w.contains(*cur) && !w.rec_[cur->index].above_light; cur = w.rec_[cur->index].parent)
-                w.rec_[cur->index].above_light = true;
-        }
         std::vector<float> c(3 * (size_t)n, 0.f), h(3 * (size_t)n, 0.f);
         std::vector<uint8_t> flags(n);
         for (uint32_t row = 0; row < n; ++row) {
@@ -759,11 +737,13 @@ class Mi355xPlugin {
             // entities without the visibility components never enter the query; without Visibility they default visible
             flags[row] = (uint8_t)(((!e.has_visibility || e.inherited) ? MI_FLAG_INHERITED_VISIBLE : 0u) | (e.aabb ? MI_FLAG_HAS_AABB : 0u));
             if (e.aabb) { std::memcpy(&c[3 * (size_t)row], &e.aabb->center, 12); std::memcpy(&h[3 * (size_t)row], &e.aabb->half_extents, 12); }
-            else if (e.point_light_range) {  // a point light is culled by its bounding Sphere { translation, range } (point_light.rs:195-208)
-                const Vec3 t = expected_global(w, entity_of_row_[row]).translation();
+            else if (e.point_light_range) {
+                // a point light is culled by its bounding Sphere { GlobalTransform::translation, range } (update_point_light_bounding_spheres,
+                // point_light.rs:195-208): a sphere that follows the row's own GlobalTransform on the device -- a moving light costs nothing here
                 flags[row] |= MI_FLAG_HAS_SPHERE;
-                std::memcpy(&c[3 * (size_t)row], &t, 12);
+                const uint32_t at_translation = MI_SPHERE_AT_TRANSLATION;
                 h[3 * (size_t)row] = *e.point_light_range;
+                std::memcpy(&h[3 * (size_t)row + 1], &at_translation, 4);
             }
         }
         check(mi_upload_bounds(ctx_, 0, n, c.data(), h.data(), flags.data(), nullptr));

@@ -59,6 +59,14 @@ extern "C" {
 #define MI_FLAG_SHADOW_CASTER 0x80u      /* With<Mesh3d>, Without<NotShadowCaster>, Without<DirectionalLight>:
                                             matched by the shadow-view queries, crates/bevy_light/src/lib.rs:355-372 */
 
+/* A bounding Sphere that FOLLOWS its entity: update_point_light_bounding_spheres (crates/bevy_light/src/point_light.rs:195-208) keeps
+ * Sphere { center: GlobalTransform::translation, radius: PointLight::range } on every point light.  A row with MI_FLAG_HAS_SPHERE (and
+ * no Aabb) whose aabb_half_extents is (radius, this bit pattern, anything) gets its centre from the row's OWN GlobalTransform
+ * translation as the frame's propagate leaves it -- that system folded into the frame: a moving light costs the host nothing (no
+ * bounds upload), and the Sphere is never a frame late (in the reference it is inserted through Commands).  aabb_center is ignored.
+ * The value is a quiet NaN: memcpy the bits into the float array. */
+#define MI_SPHERE_AT_TRANSLATION 0x7FC0A11Du
+
 /* ---- per-view flags (mi_view.flags; mi_cull's view_flags byte carries the low bits) ------ */
 #define MI_VIEW_FLAG_NO_CPU_CULLING 0x01u /* camera Has<NoCpuCulling>: skip frustum tests, :756,823 */
 #define MI_VIEW_FLAG_SHADOW 0x02u         /* shadow view (cascade / cube face / spot): only MI_FLAG_SHADOW_CASTER rows,

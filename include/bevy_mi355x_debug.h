@@ -43,6 +43,9 @@ int32_t mi_debug_set_tile_mode(mi_ctx* ctx, int32_t mode);
 int32_t mi_debug_tree_trace(mi_ctx* ctx, int32_t enable, unsigned long long* out, uint32_t n_tiles);
 /* The shape of the current tile plan: launches per mi_propagate, tiles, chain tiles (self-evaluated ancestor chains), bands. */
 int32_t mi_debug_tile_plan(mi_ctx* ctx, uint32_t* out_launches, uint32_t* out_tiles, uint32_t* out_chain_tiles, uint32_t* out_bands);
+/* The flags-first test of the light tile kernel under the static-scene rule (kernels_tree.hip): 0 = when few rows changed since the
+ * last propagate (default), 1 = never, 2 = always. */
+int32_t mi_debug_set_tile_pretest(mi_ctx* ctx, int32_t mode);
 /* The world-sphere path of the cull-only and changed-rows frames (kernels_flat.hip, k_frame_sph): 0 = used from the second frame in
  * a row that rewrites no or few GlobalTransforms (default), 1 = never, 2 = at once (the first such frame rebuilds the column). */
 int32_t mi_debug_set_sphere_path(mi_ctx* ctx, int32_t mode);

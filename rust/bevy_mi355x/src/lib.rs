@@ -530,7 +530,7 @@ pub fn mi_check_visibility(
         )>,
     >,
     rows_query: Query<
-        (Entity, &InheritedVisibility, Option<&VisibilityClass>, Option<&RenderLayers>, Option<&Aabb>, Option<&Sphere>, Has<NoFrustumCulling>, Has<VisibilityRange>),
+        (Entity, &InheritedVisibility, Option<&VisibilityClass>, Option<&RenderLayers>, Option<&Aabb>, Option<&Sphere>, Option<&PointLight>, Has<NoFrustumCulling>, Has<VisibilityRange>),
         Without<NoCpuCulling>,
     >,
     mut view_visibilities: Query<&mut ViewVisibility, Without<NoCpuCulling>>,
@@ -1036,7 +1036,7 @@ pub fn mi_fused_frame(
         Or<(Changed<Aabb>, Changed<Sphere>, Changed<InheritedVisibility>, Changed<RenderLayers>, Changed<VisibilityClass>, Added<NoFrustumCulling>)>,
     >,
     rows_query: Query<
-        (Entity, &InheritedVisibility, Option<&VisibilityClass>, Option<&RenderLayers>, Option<&Aabb>, Option<&Sphere>, Has<NoFrustumCulling>, Has<VisibilityRange>),
+        (Entity, &InheritedVisibility, Option<&VisibilityClass>, Option<&RenderLayers>, Option<&Aabb>, Option<&Sphere>, Option<&PointLight>, Has<NoFrustumCulling>, Has<VisibilityRange>),
         Without<NoCpuCulling>,
     >,
     point_lights: Query<(Entity, &PointLight, Option<&RenderLayers>)>,
@@ -1312,7 +1312,7 @@ pub fn mi_fused_frame(
 fn stage_bounds(
     mi: &mut Mi355x,
     rows_query: &Query<
-        (Entity, &InheritedVisibility, Option<&VisibilityClass>, Option<&RenderLayers>, Option<&Aabb>, Option<&Sphere>, Has<NoFrustumCulling>, Has<VisibilityRange>),
+        (Entity, &InheritedVisibility, Option<&VisibilityClass>, Option<&RenderLayers>, Option<&Aabb>, Option<&Sphere>, Option<&PointLight>, Has<NoFrustumCulling>, Has<VisibilityRange>),
         Without<NoCpuCulling>,
     >,
 ) -> Result<(), ()> {
@@ -1329,7 +1329,7 @@ fn stage_bounds(
     s.layers.resize(n, 0);
     s.classes.clear();
     s.classes.resize(n, 0);
-    for (entity, inherited, classes, layers, aabb, sphere, no_frustum_culling, has_range) in rows_query.iter() {
+    for (entity, inherited, classes, layers, aabb, sphere, point_light, no_frustum_culling, has_range) in rows_query.iter() {
         let Some(&row) = mi.entity_row.get(&entity) else { continue };
         let row = row as usize;
         let mut flags = 0u32;
@@ -1346,9 +1346,15 @@ fn stage_bounds(
             flags |= ffi::MI_FLAG_HAS_AABB;
             s.aabb_center[row * 3..row * 3 + 3].copy_from_slice(&aabb.center.to_array());
             s.aabb_half[row * 3..row * 3 + 3].copy_from_slice(&aabb.half_extents.to_array());
-        } else if let Some(sphere) = sphere {
-            // lights: update_point_light_bounding_spheres keeps a world-space Sphere { translation, range } (point_light.rs:195-208)
+        } else if let Some(light) = point_light {
+            // update_point_light_bounding_spheres keeps Sphere { GlobalTransform::translation, range } on every point light
+            // (point_light.rs:195-208, inserted through Commands): on the device the sphere follows the row's own GlobalTransform,
+            // so a moving light needs no bounds upload and is never culled against last frame's position
             flags |= ffi::MI_FLAG_HAS_SPHERE;
+            s.aabb_half[row * 3] = light.range;
+            s.aabb_half[row * 3 + 1] = f32::from_bits(ffi::MI_SPHERE_AT_TRANSLATION);
+        } else if let Some(sphere) = sphere {
+            flags |= ffi::MI_FLAG_HAS_SPHERE; // any other world-space Sphere, as it is (visibility/mod.rs:838-843)
             s.aabb_center[row * 3..row * 3 + 3].copy_from_slice(&sphere.center.to_array());
             s.aabb_half[row * 3] = sphere.radius;
         }

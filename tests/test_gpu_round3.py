@@ -187,3 +187,56 @@ def test_upload_windows_equal_the_copying_uploads():
         with pytest.raises(api.MiError) as e:  # a window is committed once
             b.commit_upload_window(w, 1)
         assert e.value.code == api.MI_ERR_NOT_READY
+
+
+def test_light_spheres_that_follow_their_rows():
+    """MI_SPHERE_AT_TRANSLATION: a light row whose bounding Sphere is centred at its own GlobalTransform translation (what
+    update_point_light_bounding_spheres maintains, point_light.rs:195-208) against a twin context whose host re-uploads the
+    world-space spheres of the moved lights every frame: same ViewVisibility, same lists, same clusters -- all-dirty frames,
+    changed-rows frames on both frame kernels, and the cull-only frame."""
+    sc, first_light, pr = W.frame_scene(20_000, 2_000, 200, light_range=2.0)
+    n, n_l = sc["n"], len(pr) // 4
+    marker = np.frombuffer(np.uint32(0x7FC0A11D).tobytes(), F)[0]
+    t = sc["translation"].reshape(n, 3).copy()
+    r4, s3 = sc["rotation"].reshape(n, 4), sc["scale"].reshape(n, 3)
+    half_follow = sc["aabb_half"].reshape(n, 3).copy()
+    half_follow[first_light:, 1] = marker
+    center_follow = sc["aabb_center"].reshape(n, 3).copy()
+    center_follow[first_light:] = 123.0  # ignored
+    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+    rng = np.random.default_rng(21)
+    for sphere_path in (1, 2):
+        with api.Context(0) as a, api.Context(0) as b:
+            for ctx in (a, b):
+                ctx.debug_set_sphere_path(sphere_path)
+                ctx.resize(n)
+                ctx.upload_transforms(t.reshape(-1), sc["rotation"], sc["scale"])
+                ctx.cluster_upload_objects(pr)
+                ctx.cluster_bind_objects_to_rows(first_light, n_l)
+                ctx.upload_changed(np.ones(n, np.uint8))
+            a.upload_bounds(center_follow.reshape(-1), half_follow.reshape(-1), sc["flags"], sc["layers"])
+            center = sc["aabb_center"].reshape(n, 3).copy()
+            for frame in range(6):
+                moved = np.sort(rng.choice(np.arange(first_light, n), 150, replace=False)).astype(np.uint32)
+                t[moved] += rng.normal(0.0, 3.0, (150, 3)).astype(F)
+                center[moved] = t[moved]
+                b.upload_bounds(center.reshape(-1), sc["aabb_half"], sc["flags"], sc["layers"])  # the host-side update the marker saves
+                cam = W.many_cubes_camera(frame * 30)
+                fr = api.compute_frustum(cfv, cam, W.CAMERA_FAR)
+                view, keep = api.cluster_view_build(cam, cfv, fr, 1920, 1080, (16, 9, 24), 5.0, 1000.0, with_spheres=False)
+                res = []
+                for ctx in (a, b):
+                    ctx.upload_transforms_indexed(moved, t[moved].reshape(-1), r4[moved].reshape(-1), s3[moved].reshape(-1))
+                    ctx.cluster_upload_view(view)
+                    if frame == 2:
+                        ctx.upload_changed(np.ones(n, np.uint8))
+                        ctx.propagate_and_cull(fr, flags=B.CULL_END_FRAME | B.CULL_WITH_CLUSTERS)
+                    elif frame == 4:
+                        ctx.propagate(0)
+                        ctx.cull(fr, flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME | B.CULL_WITH_CLUSTERS)
+                    else:
+                        ctx.propagate_and_cull(fr, flags=B.CULL_END_FRAME | B.CULL_WITH_CLUSTERS | B.CULL_CHANGED_ROWS)
+                    off, idx, counts, far, total = ctx.cluster_download(view.n_clusters)
+                    res.append((ctx.download_view_visibility()[0].tobytes(), ctx.download_visibility(0).tobytes(), off.tobytes(), idx[:total].tobytes(), far, total))
+                assert res[0] == res[1], f"sphere path {sphere_path}, frame {frame}"
+                assert res[0][5] > 0

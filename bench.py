@@ -502,10 +502,21 @@ def cpu_baseline_frame(wl, cpu_seconds):
     from bevy_amd import api, workloads as W
     sc, cores = wl.scene, os.cpu_count() or 1
     a = (sc["translation"], sc["rotation"], sc["scale"], sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"], wl.frusta0)
-    secs, _, vv, _ = O.bench_flat_frame(*a, cores, 1)
-    iters = int(max(1, min(3000, 0.6 * cpu_seconds / max(secs, 1e-4))))
-    secs, _, vv, _ = O.bench_flat_frame(*a, cores, iters)
-    t_flat = secs / iters
+    # The pool's hand-offs (a join per system) cost more than the work when every core takes part: sweep the thread count, both
+    # with the reference's system structure (reset / check / mark as separate systems) and with the three visibility systems fused
+    # into one pass per batch, and quote the BEST -- the baseline should be as strong as the port can be made.
+    sweep, best = {}, None
+    budget = 0.6 * cpu_seconds / 14.0
+    for fused_vis in (False, True):
+        for th in sorted({min(cores, x) for x in (8, 16, 32, 64, 128, 256, cores)}):
+            secs, _, vv, _ = O.bench_flat_frame(*a, th, 2, fused_vis)
+            iters = int(max(3, min(3000, budget / max(secs / 2, 1e-4))))
+            secs, _, vv, _ = O.bench_flat_frame(*a, th, iters, fused_vis)
+            ms = 1e3 * secs / iters
+            sweep[f"{th} threads" + (", fused visibility" if fused_vis else "")] = round(ms, 4)
+            if best is None or ms < best[0]:
+                best = (ms, th, fused_vis, iters)
+    t_flat, cores_used, fused_used, iters = best[0] * 1e-3, best[1], best[2], best[3]
     n_l = len(wl.pos_range) // 4
     visible = np.nonzero(vv[wl.first_light:wl.first_light + n_l] & 1)[0]
     pr = np.ascontiguousarray(np.asarray(wl.pos_range, np.float32).reshape(-1, 4)[visible]).reshape(-1)
@@ -519,13 +530,15 @@ def cpu_baseline_frame(wl, cpu_seconds):
     for _ in range(it2):
         O.assign_objects_to_clusters(view, pr)
     t_cl = (time.perf_counter() - t0) / it2
-    return {"value": round(wl.units / (t_flat + t_cl), 1), "unit": "entities/s", "cores": cores, "kind": "port",
+    return {"value": round(wl.units / (t_flat + t_cl), 1), "unit": "entities/s", "cores": cores_used, "kind": "port",
             "sample": f"{iters} frames of {sc['n']} rows: oracle C port of sync_simple_transforms + reset + check_visibility + "
-                      f"mark_newly_hidden on a persistent pool of {cores} threads, one ceil(n/threads) batch per thread and system "
-                      f"(Bevy's par_iter batching), {1e3 * t_flat:.3f} ms/frame; + {it2} runs of assign_objects_to_clusters over the "
+                      f"mark_newly_hidden on a persistent pool -- best of a sweep over thread counts and system structure: {cores_used} threads"
+                      + (", the three visibility systems fused into one pass per batch" if fused_used else ", one ceil(n/threads) batch per thread and system (Bevy's par_iter batching)")
+                      + f", {1e3 * t_flat:.3f} ms/frame; + {it2} runs of assign_objects_to_clusters over the "
                       f"{len(visible)} visible lights on 1 thread (single-threaded in the reference; two passes: size, then fill), "
                       f"{1e3 * t_cl:.3f} ms/frame",
-            "stage_ms": {"propagate_cull_all_cores": round(1e3 * t_flat, 4), "cluster_1_core": round(1e3 * t_cl, 4)}}
+            "host_cores": cores, "thread_sweep_ms_per_frame": sweep,
+            "stage_ms": {"propagate_cull_best": round(1e3 * t_flat, 4), "cluster_1_core": round(1e3 * t_cl, 4)}}
 
 
 def cpu_baseline_flat(wl, cpu_seconds, n_views):
@@ -656,6 +669,8 @@ def end_to_end(ctx, wl, frames=12):
     ctx.propagate(B.PROPAGATE_ALL_DIRTY)
     ctx.synchronize()
     bufs = api.FrameResultBuffers(n, n, views[0].n_clusters, 1 << 20, in_place=True)
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(4)
     for pct in (1, 10, 100):
         k = n * pct // 100
         rows = np.sort(rng.choice(n, k, replace=False)).astype(np.uint32) if pct < 100 else None
@@ -672,12 +687,16 @@ def end_to_end(ctx, wl, frames=12):
                 np.take(r4, rows, axis=0, out=wr.reshape(k, 4), mode="clip")
                 np.take(s3, rows, axis=0, out=ws.reshape(k, 3), mode="clip")
                 ctx.commit_upload_window(w, k)
-            else:  # every row: dense windows, a chunk at a time -- chunk i crosses PCIe (DMA) while the host fills chunk i + 1
+            else:  # every row: dense windows, a chunk each, filled by a few host threads (the ECS side's par_iter); chunk i crosses
+                   # PCIe (DMA straight from the window) while the others are still being filled
                 chunk = (n + 7) // 8
-                for lo in range(0, n, chunk):
-                    m = min(chunk, n - lo)
-                    w, _, wt, wr, ws = ctx.map_upload_window(m, dense=True)
+                wins = [(lo, min(chunk, n - lo)) + ctx.map_upload_window(min(chunk, n - lo), dense=True) for lo in range(0, n, chunk)]
+
+                def fill(win):
+                    lo, m, w, _, wt, wr, ws = win
                     wt[:], wr[:], ws[:] = t3[lo:lo + m].reshape(-1), r4[lo:lo + m].reshape(-1), s3[lo:lo + m].reshape(-1)
+                    return win
+                for lo, m, w, *_ in pool.map(fill, wins):
                     ctx.commit_upload_window(w, m, first_row=lo)
             t1 = time.perf_counter()
             ctx.propagate_and_cull(fr, flags=B.CULL_END_FRAME | B.CULL_WITH_CLUSTERS | (B.CULL_CHANGED_ROWS if rows is not None else 0))

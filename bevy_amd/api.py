@@ -144,7 +144,7 @@ class FrameResultBuffers:
 class UploadWindow(C.Structure):
     """mi_upload_window"""
     _fields_ = [("rows", C.POINTER(C.c_uint32)), ("translation", C.POINTER(C.c_float)), ("rotation", C.POINTER(C.c_float)),
-                ("scale", C.POINTER(C.c_float)), ("capacity", C.c_uint32), ("flags", C.c_uint32)]
+                ("scale", C.POINTER(C.c_float)), ("capacity", C.c_uint32), ("flags", C.c_uint32), ("token", C.c_uint64)]
 
 
 UPLOAD_DENSE = 0x1
@@ -203,7 +203,7 @@ ABI_SYMBOLS = [
 # include/bevy_mi355x_debug.h: instrumentation and test hooks, exported by the same library, not part of the boundary
 DEBUG_SYMBOLS = [
     "mi_timer_begin", "mi_timer_end", "mi_profile_enable", "mi_profile_filter", "mi_profile_sample", "mi_profile_burst", "mi_profile_read",
-    "mi_profile_kernel_name", "mi_debug_set_tile_mode", "mi_debug_tree_trace", "mi_debug_tile_plan", "mi_debug_logf", "mi_debug_set_sphere_path", "mi_debug_set_tile_pretest",
+    "mi_profile_kernel_name", "mi_debug_set_tile_mode", "mi_debug_tree_trace", "mi_debug_tile_plan", "mi_debug_logf", "mi_debug_set_sphere_path", "mi_debug_set_tile_pretest", "mi_debug_set_sorted_one_wg_limit",
 ]
 
 
@@ -370,6 +370,8 @@ class Context:
         # test harness only: run a whole test session under one tile kernel (the library itself reads no environment)
         if os.environ.get("MI_TEST_TILE_MODE"):
             self.debug_set_tile_mode(int(os.environ["MI_TEST_TILE_MODE"]))
+        if os.environ.get("MI_TEST_SORTED_TILED"):
+            self.debug_set_sorted_one_wg_limit(0)
         if os.environ.get("MI_TEST_TILE_PRETEST"):
             self.debug_set_tile_pretest(int(os.environ["MI_TEST_TILE_PRETEST"]))
         if os.environ.get("MI_TEST_SPHERE_PATH"):  # ... or with the world-sphere cull path forced on (2) / off (1)
@@ -837,6 +839,10 @@ class Context:
         v = [C.c_uint32(0) for _ in range(4)]
         self._ck(self._lib.mi_debug_tile_plan(self._h, *[C.byref(x) for x in v]))
         return dict(launches=v[0].value, tiles=v[1].value, chain_tiles=v[2].value, bands=v[3].value)
+
+    def debug_set_sorted_one_wg_limit(self, items):
+        """Sorted phases up to `items` long take the single-workgroup kernel; 0 = always the tiled form (test / bench hook)."""
+        self._ck(self._lib.mi_debug_set_sorted_one_wg_limit(self._h, C.c_uint32(int(items) & 0xFFFFFFFF)))
 
     def debug_set_tile_pretest(self, mode):
         """0 = the light tiles test their flags first when few rows changed (default), 1 = never, 2 = always (test / bench hook)."""

@@ -124,7 +124,7 @@ __device__ __forceinline__ uint32_t object_row(const ClusterObjects& o, uint32_t
     return o.row_list ? o.row_list[obj] : o.first_row + obj;
 }
 __device__ __forceinline__ bool object_row_is_propagated(const ClusterObjects& o, uint32_t row) {
-    return !o.derive_resident && (!o.row_changed || o.row_changed[row] != 0);
+    return !o.derive_resident && (!o.row_changed || row_changed(o.row_changed[row], o.changed_gen));
 }
 __device__ __forceinline__ Affine object_row_affine(const ClusterObjects& o, uint32_t row) {
     if (o.derive && object_row_is_propagated(o, row)) {

@@ -100,6 +100,20 @@ int32_t download(mi_ctx* ctx, void* dst, const void* src, size_t bytes) {
     return MI_OK;
 }
 
+int32_t consume_changed(mi_ctx* ctx) {
+    if (!ctx->have_changed || !ctx->changed_maybe) return MI_OK;
+    if (ctx->changed_bulk || ctx->changed_gen >= 255u) {  // plain 1s somewhere, or the stamps are about to wrap: really clear
+        HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, ctx->n, ctx->stream));
+        ctx->changed_bulk = false;
+        ctx->changed_gen = ctx->changed_gen >= 255u ? 2u : ctx->changed_gen + 1u;
+    } else {
+        ++ctx->changed_gen;  // every stamp in the column is now a past generation: nothing to launch
+    }
+    ctx->changed_maybe = false;
+    ctx->changed_rows_hint = 0;
+    return MI_OK;
+}
+
 int32_t check_rows(mi_ctx* ctx, uint32_t first, uint32_t n, const char* what) {
     if ((uint64_t)first + n > ctx->n) return fail(ctx, MI_ERR_INVALID_ARG, "%s: rows [%u,%u) exceed %u live rows", what, first, first + n, ctx->n);
     return MI_OK;
@@ -165,6 +179,7 @@ Columns columns_of(mi_ctx* ctx) {
     c.range_start_end = ctx->have_ranges ? ctx->range : nullptr;
     c.g_changed_bits = ctx->g_chg_bits;
     c.vv_changed_bits = ctx->vv_chg_bits;
+    c.changed_gen = ctx->changed_gen;
     return c;
 }
 
@@ -495,11 +510,10 @@ static int32_t cull_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, u
     if (PROPAGATE) {
         if (ctx->have_changed && ctx->changed_maybe) {
             // a concurrent walk on the cluster stream reads the change column (and the GlobalTransforms of the rows it does not
-            // mark): the memset waits for it
-            if (clusters_concurrent && changed_col && ctx->cl_on_side) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_cl_done, 0));
-            HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, ctx->n, ctx->stream));
-            ctx->changed_maybe = false;
-            ctx->changed_rows_hint = 0;
+            // mark): a memset (bulk marks, stamp wrap) waits for it
+            if (clusters_concurrent && changed_col && ctx->cl_on_side && (ctx->changed_bulk || ctx->changed_gen >= 255u))
+                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_cl_done, 0));
+            if ((rc = consume_changed(ctx))) return rc;
         }
         ctx->g_chg_maybe = true;
         ctx->g_chg_in_bytes = false;
@@ -586,7 +600,7 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
                       &ctx->bt_set_indexed, &ctx->bt_table_off, &ctx->bt_table, &ctx->bt_meta_off, &ctx->bt_meta, &ctx->bt_rows_a, &ctx->bt_rows_b,
                       &ctx->bt_hist, &ctx->bt_set_count, &ctx->bt_set_scan, &ctx->bt_counters, &ctx->bt_wi[0], &ctx->bt_wi[1], &ctx->bt_md[0],
                       &ctx->bt_md[1], &ctx->bt_bs[0], &ctx->bt_bs[1], &ctx->bt_records, &ctx->bt_totals, &ctx->bt_bucket_desc, &ctx->bt_meta_out,
-                      &ctx->bt_inst[0], &ctx->bt_inst[1], &ctx->bt_plan, &ctx->bt_unb, &ctx->bt_items, &ctx->bt_sorted_scratch, &ctx->bt_batches,
+                      &ctx->bt_inst[0], &ctx->bt_inst[1], &ctx->bt_plan, &ctx->bt_unb, &ctx->bt_items, &ctx->bt_sorted_scratch, &ctx->bt_batches, &ctx->bt_sorted_partials,
                       &ctx->cl_row_list, &ctx->cl_remap, &ctx->cl_bind_oc, &ctx->cl_bind_idx, &ctx->cl_block_counts, &ctx->cl_pair_cb, &ctx->cl_pair_mask, &ctx->cl_acc,
                       &ctx->cl_offsets, &ctx->cl_indices, &ctx->cl_scalars};
     for (DevBuf* b : bufs)
@@ -662,7 +676,10 @@ int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
     ctx->bt_resolve = true;
     ctx->changed_maybe = true;
     if (n_rows != ctx->n) ctx->sph_state = mi_ctx::SPH_INVALID;
-    if (n_rows > ctx->n) ctx->changed_rows_hint = UINT64_MAX;  // new rows are Added<GlobalTransform>: marked, uncounted
+    if (n_rows > ctx->n) {  // new rows are Added<GlobalTransform>: marked (a plain 1), uncounted
+        ctx->changed_rows_hint = UINT64_MAX;
+        ctx->changed_bulk = true;
+    }
     if (n_rows < ctx->n && ctx->cl_rows_listed) ctx->cl_rows_bound = false;  // a listed row may be gone: the caller binds again
     const uint32_t old_cap_rows = ctx->cap;
     if (n_rows > ctx->cap) {
@@ -722,6 +739,7 @@ int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
         ctx->tree_half_words = (uint32_t)(half_bytes / 4);
         ctx->tree_clean[0] = ctx->tree_clean[1] = true;
         ctx->tree_parity = 0;
+        ctx->marks_live = ctx->marks_in_cur = ctx->marks_complete = ctx->marks_other_cleared = false;
         ctx->cap = new_cap;
     }
     if (n_rows > ctx->n && ctx->n < old_cap_rows) {
@@ -743,6 +761,8 @@ int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
     if (n_rows < ctx->propagated_rows) ctx->propagated_rows = n_rows;
     if (n_rows != ctx->n) {
         // a different row count invalidates the hierarchy and any cull result
+        if (ctx->marks_in_cur) ctx->tree_clean[ctx->tree_parity] = false;
+        ctx->marks_live = ctx->marks_in_cur = ctx->marks_complete = ctx->marks_other_cleared = false;
         ctx->have_hierarchy = false;
         ctx->n_levels = 1;
         ctx->culled = false;
@@ -800,8 +820,27 @@ static int32_t scatter_indexed(mi_ctx* ctx, const uint32_t* rows, const float* t
     int32_t rc = cluster_join(ctx);
     if (rc) return rc;
     ctx->cl_inputs_dirty = true;
+    // mark_dirty_trees for these rows in the same launch, when the frames run under the static-scene rule and the half the next
+    // propagate will read holds nothing but such marks
+    const bool mark_here = ctx->have_hierarchy && ctx->marks_live && ctx->tree_bytes && ctx->parent_idx.p &&
+                           (ctx->marks_in_cur || ctx->tree_clean[ctx->tree_parity]);
+    uint8_t* const cur = mark_here ? ctx->tree_bytes + (size_t)ctx->tree_parity * ctx->tree_half_words * 4 : nullptr;
+    uint32_t* other = nullptr;
+    if (mark_here && !ctx->marks_other_cleared && !ctx->tree_clean[ctx->tree_parity ^ 1u])
+        other = (uint32_t*)(ctx->tree_bytes + (size_t)(ctx->tree_parity ^ 1u) * ctx->tree_half_words * 4);
     HIP_TRY(ctx, launch_upload_trs_indexed((const uint32_t*)d_rows, (const float*)d_t, (const float*)d_r, (const float*)d_s, n, ctx->t, ctx->r,
-                                           ctx->s, ctx->changed, ctx->stream));
+                                           ctx->s, ctx->changed, ctx->changed_gen, ctx->stream, mark_here ? (const uint32_t*)ctx->parent_idx.p : nullptr,
+                                           cur, other, ctx->tree_half_words));
+    if (mark_here) {
+        if (!ctx->marks_in_cur) ctx->marks_complete = !ctx->changed_maybe;  // complete so far iff nothing was marked changed before this upload
+        ctx->marks_in_cur = true;
+        if (other) {
+            ctx->marks_other_cleared = true;
+            ctx->tree_clean[ctx->tree_parity ^ 1u] = true;
+        }
+    } else {
+        ctx->marks_complete = false;
+    }
     ctx->changed_maybe = true;
     if (ctx->changed_rows_hint != UINT64_MAX) ctx->changed_rows_hint += n;
     return MI_OK;
@@ -846,8 +885,7 @@ int32_t mi_map_upload_window(mi_ctx* ctx, uint32_t capacity, uint32_t flags, mi_
     out->translation = f;
     out->rotation = f + 3 * (size_t)capacity + ((4 - (3 * (size_t)capacity) % 4) % 4);
     out->scale = out->rotation + 4 * (size_t)capacity;
-    ctx->window_epoch = ctx->stage_epoch;
-    ctx->window_base = st;
+    out->token = ctx->stage_epoch + 1;  // (0 = never mapped / already committed)
     return MI_OK;
 }
 
@@ -856,9 +894,9 @@ int32_t mi_commit_upload_window(mi_ctx* ctx, const mi_upload_window* w, uint32_t
     if (!w) return fail(ctx, MI_ERR_INVALID_ARG, "mi_commit_upload_window: NULL");
     if (n == 0) return MI_OK;
     if (n > w->capacity) return fail(ctx, MI_ERR_INVALID_ARG, "mi_commit_upload_window: %u rows, the window holds %u", n, w->capacity);
-    if (ctx->window_epoch != ctx->stage_epoch || ctx->window_base != (w->rows ? (void*)w->rows : (void*)w->translation))
-        return fail(ctx, MI_ERR_NOT_READY, "mi_commit_upload_window: the window is no longer mapped (another call on the context came in between)");
-    ctx->window_base = nullptr;
+    const char* base = w->rows ? (const char*)w->rows : (const char*)w->translation;
+    if (w->token != ctx->stage_epoch + 1 || base < (const char*)ctx->stage || base >= (const char*)ctx->stage + ctx->stage_bytes)
+        return fail(ctx, MI_ERR_NOT_READY, "mi_commit_upload_window: the window is no longer mapped (the pinned arena was recycled since, or it was committed already)");
     if (w->flags & MI_UPLOAD_DENSE) {
         int32_t rc = check_rows(ctx, first_row, n, "mi_commit_upload_window");
         if (rc) return rc;
@@ -950,6 +988,9 @@ int32_t mi_upload_changed(mi_ctx* ctx, uint32_t first_row, uint32_t n, const uin
     ctx->have_changed = true;
     ctx->changed_maybe = true;
     ctx->changed_rows_hint = UINT64_MAX;  // how many of these bytes are set is not known here
+    ctx->marks_complete = false;          // rows marked changed without a climb
+    ctx->changed_bulk = true;             // plain 0 / 1 bytes, not stamps (a caller's 1 must not look like a past generation either:
+                                          // only 0 and 1 are meaningful in an uploaded byte)
     return upload(ctx, ctx->changed + first_row, changed, n);
 }
 
@@ -1014,18 +1055,28 @@ int32_t mi_propagate(mi_ctx* ctx, uint32_t flags) {
     if (ctx->have_hierarchy && static_opt && !all_dirty) {
         uint8_t* const cur = ctx->tree_bytes + (size_t)ctx->tree_parity * ctx->tree_half_words * 4;
         uint8_t* const other = ctx->tree_bytes + (size_t)(ctx->tree_parity ^ 1u) * ctx->tree_half_words * 4;
-        if (!ctx->tree_clean[ctx->tree_parity]) {  // (not on the usual path: the previous frame's mark launch zeroed it)
-            ProfScope ps(ctx, K_CLEAR);
-            HIP_TRY(ctx, launch_clear_u32((uint32_t*)cur, ctx->tree_half_words, ctx->stream));
+        if (ctx->marks_in_cur && ctx->marks_complete && ctx->tree_clean[ctx->tree_parity ^ 1u]) {
+            // every change of this frame came through the indexed uploads, which climbed and marked as they went
+            // (k_upload_trs_indexed) and zeroed the other half: nothing to launch
+        } else {
+            if (!ctx->tree_clean[ctx->tree_parity] && !ctx->marks_in_cur) {  // (not on the usual path: the previous frame's mark launch zeroed it)
+                ProfScope ps(ctx, K_CLEAR);
+                HIP_TRY(ctx, launch_clear_u32((uint32_t*)cur, ctx->tree_half_words, ctx->stream));
+            }
+            ProfScope ps(ctx, K_MARK_DIRTY);
+            HIP_TRY(ctx, launch_mark_dirty(ctx->n, ctx->changed, ctx->changed_gen, (const uint32_t*)ctx->parent_idx.p, cur,
+                                           ctx->tree_clean[ctx->tree_parity ^ 1u] ? nullptr : (uint32_t*)other, ctx->tree_half_words, ctx->stream));
         }
-        ProfScope ps(ctx, K_MARK_DIRTY);
-        HIP_TRY(ctx, launch_mark_dirty(ctx->n, ctx->changed, (const uint32_t*)ctx->parent_idx.p, cur,
-                                       ctx->tree_clean[ctx->tree_parity ^ 1u] ? nullptr : (uint32_t*)other, ctx->tree_half_words, ctx->stream));
         ctx->tree_clean[ctx->tree_parity] = false;
         ctx->tree_clean[ctx->tree_parity ^ 1u] = true;
         ctx->tree_parity ^= 1u;
         tree_bits = cur;
+        ctx->marks_live = true;
+    } else {
+        if (ctx->marks_in_cur) ctx->tree_clean[ctx->tree_parity] = false;  // marks of uploads nobody read: stale for a later frame
+        ctx->marks_live = false;
     }
+    ctx->marks_in_cur = ctx->marks_complete = ctx->marks_other_cleared = false;
     if (!ctx->have_hierarchy) {
         ProfScope ps(ctx, K_LEVEL0_PROPAGATE);
         HIP_TRY(ctx, launch_level0_propagate(c, n0, nullptr, ctx->changed, tree_bits, all_dirty, static_opt, ctx->stream));
@@ -1068,10 +1119,9 @@ int32_t mi_propagate(mi_ctx* ctx, uint32_t flags) {
         }
         ctx->g_chg_in_bytes = true;
     }
-    if (ctx->have_changed && ctx->changed_maybe) {
-        HIP_TRY(ctx, hipMemsetAsync(ctx->changed, 0, ctx->n, ctx->stream));  // change flags are consumed
-        ctx->changed_maybe = false;
-        ctx->changed_rows_hint = 0;
+    {
+        const int32_t rcc = consume_changed(ctx);  // change flags are consumed
+        if (rcc) return rcc;
     }
     ctx->propagated_rows = ctx->n;
     return MI_OK;

@@ -52,6 +52,11 @@ struct mi_ctx {
     uint8_t* tree_bytes = nullptr;  // TransformTreeChanged, a byte per row; two halves of tree_half_words 32-bit words (double-buffered by frame: tree_parity)
     uint32_t tree_half_words = 0, tree_parity = 0;
     bool tree_clean[2] = {true, true};  // the half is known to be all zero
+    // The indexed uploads mark for the coming frame themselves (k_upload_trs_indexed) when the last propagate ran under the
+    // static-scene rule: marks_live = it did; marks_in_cur = the current half holds marks of this frame's uploads (a subset of what
+    // k_mark_dirty would set: valid, never to be cleared before use); marks_complete = every change since the last propagate was
+    // marked that way, so mi_propagate needs no mark launch; marks_other_cleared = an upload of this frame zeroed the other half
+    bool marks_live = false, marks_in_cur = false, marks_complete = false, marks_other_cleared = false;
     bool have_class_mask = false, have_keys = false, have_changed = false;
     uint32_t propagated_rows = 0;  // rows [0, propagated_rows) have been through a propagate (their Added<GlobalTransform> is consumed)
     uint32_t classes_present = 1u;
@@ -68,8 +73,6 @@ struct mi_ctx {
     void* stage = nullptr;
     size_t stage_bytes = 0, stage_used = 0;
     uint64_t stage_epoch = 0;  // bumped whenever the arena wraps or moves: pointers into it from before are stale
-    uint64_t window_epoch = ~0ull;  // mi_map_upload_window: the arena epoch the mapped window belongs to, and where it starts
-    void* window_base = nullptr;
 
     // ---- hierarchy ----
     uint32_t n_levels = 1;
@@ -95,6 +98,10 @@ struct mi_ctx {
     // rows marked changed since the last propagate consumed the column, when every mark came through mi_upload_transforms_indexed /
     // mi_commit_upload_window (UINT64_MAX: a bulk mi_upload_changed or new rows -- unknown)
     uint64_t changed_rows_hint = UINT64_MAX;
+    // The change column holds stamps (row_changed(), kernels.h): what the indexed uploads write is the current generation, consuming
+    // the column is `++changed_gen`.  changed_bulk: some byte may hold the plain 1 of a bulk upload / a fresh row -- those need the memset.
+    uint32_t changed_gen = 2;
+    bool changed_bulk = true;
 
     // ---- world-sphere column (k_frame_sph): (affine * aabb.center, |M3 * half_extents|) per row, the bounding sphere
     // check_visibility tests first.  Valid relative to the GlobalTransform / bounds columns as `sph_state` says.
@@ -199,7 +206,8 @@ struct mi_ctx {
     uint32_t *bt_cpu_bin = nullptr, *bt_bucket = nullptr;    // unbatchable / batchable bin; resolved bucket
     std::vector<uint8_t> bt_unb_indexed, bt_bat_indexed, bt_set_indexed_host;
     std::vector<uint32_t> bt_meta_zero;                      // the uploaded GpuBinMetadata with instance_count = 0
-    DevBuf bt_bucket_desc, bt_meta_out, bt_inst[2], bt_plan, bt_unb, bt_items, bt_sorted_scratch, bt_batches;
+    DevBuf bt_bucket_desc, bt_meta_out, bt_inst[2], bt_plan, bt_unb, bt_items, bt_sorted_scratch, bt_batches, bt_sorted_partials;
+    uint32_t bt_sorted_one_wg_limit = mi::SORTED_ONE_WG_ITEMS;  // mi_debug_set_sorted_one_wg_limit
     uint32_t bt_inst_cur = 0;
     bool bt_desc_dirty = true, bt_desc_no_indirect = false, bt_last_sorted = false;
     bool bt_resolve = true;  // rows or tables changed: bt_row_meta must be recomputed
@@ -303,6 +311,7 @@ int32_t stage_alloc(mi_ctx* ctx, size_t bytes, void** out);
 int32_t upload(mi_ctx* ctx, void* dst, const void* src, size_t bytes);
 int32_t download(mi_ctx* ctx, void* dst, const void* src, size_t bytes);
 int32_t check_rows(mi_ctx* ctx, uint32_t first, uint32_t n, const char* what);
+int32_t consume_changed(mi_ctx* ctx);  // the propagate has read the change column: every row is unchanged from here on
 void prof_close(mi_ctx* ctx);
 void prof_mark(void* vctx, uint32_t kernel);
 void prof_collect(mi_ctx* ctx);

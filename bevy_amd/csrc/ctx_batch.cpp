@@ -287,7 +287,8 @@ int32_t mi_batch_sorted_build(mi_ctx* ctx, uint32_t n_items, const mi_sorted_ite
     a.scratch = (uint32_t*)ctx->bt_sorted_scratch.p;
     a.batches = (uint32_t*)ctx->bt_batches.p;
     a.totals = (uint32_t*)ctx->bt_totals.p;
-    HIP_TRY(ctx, launch_batch_sorted(a, ctx->stream, prof_mark, ctx));
+    if ((rc = ensure(ctx, ctx->bt_sorted_partials, (size_t)batch_sorted_partial_words(std::max(n_items, 1u)) * 4))) return rc;
+    HIP_TRY(ctx, launch_batch_sorted(a, ctx->stream, prof_mark, ctx, (uint32_t*)ctx->bt_sorted_partials.p, ctx->bt_sorted_one_wg_limit));
     ctx->bt_built = true;
     ctx->bt_last_sorted = true;
     return MI_OK;
@@ -324,6 +325,14 @@ int32_t mi_batch_download(mi_ctx* ctx, uint32_t what, uint32_t mesh_class, void*
     if (count > capacity_elems) return fail(ctx, MI_ERR_CAPACITY, "mi_batch_download: %u elements, capacity %u", count, capacity_elems);
     if (count && !out) return fail(ctx, MI_ERR_INVALID_ARG, "mi_batch_download: NULL out");
     if (count) return download(ctx, out, src, (size_t)count * elem);
+    return MI_OK;
+}
+
+// test / bench hook: phases up to this many items take the single-workgroup kernel (default SORTED_ONE_WG_ITEMS); 0 = every phase
+// goes through the tiled two-launch form, 0xFFFFFFFF = none does
+int32_t mi_debug_set_sorted_one_wg_limit(mi_ctx* ctx, uint32_t items) {
+    ENTER(ctx);
+    ctx->bt_sorted_one_wg_limit = items;
     return MI_OK;
 }
 

@@ -219,6 +219,7 @@ int32_t cluster_objects(mi_ctx* ctx, bool derive, ClusterObjects* po) {
             o.derive = 1;
             o.row_global = ctx->g;
             o.row_changed = ctx->cl_derive_changed;
+            o.changed_gen = ctx->changed_gen;
             o.derive_resident = ctx->cl_derive_resident ? 1u : 0u;
             o.n_views = ctx->n_views;
             o.row_translation = ctx->t;

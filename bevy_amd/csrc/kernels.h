@@ -73,7 +73,14 @@ struct Columns {
                                    // VisibleEntityRanges resource
     uint64_t* g_changed_bits;   // ceil(n/64) words: GlobalTransform change tick bumped
     uint64_t* vv_changed_bits;  // ceil(n/64) words: ViewVisibility change tick bumped
+    uint32_t changed_gen;       // the Transform change column holds STAMPS, see row_changed()
 };
+
+// The per-row Transform change byte: 0 = unchanged, 1 = changed (bulk uploads, rows never propagated), g in 2..255 = changed iff g is
+// the context's current generation -- what the indexed uploads write.  Consuming the column is then `generation += 1` on the host
+// instead of a memset dispatch behind every propagate (>= 4.3 us on this part: a third of a change-driven frame); a real memset
+// remains for bulk marks and for the wrap at 255.
+__host__ __device__ inline bool row_changed(uint32_t byte, uint32_t gen) { return byte == 1u || byte == gen; }
 
 struct VisibilityOut {
     uint64_t* bitmask;        // base of per-view bitmasks
@@ -179,8 +186,12 @@ hipError_t launch_frame_sph(const Columns& c, const ViewSet* views_inline, const
 constexpr uint32_t SPH_MAX_VIEWS = 32;
 hipError_t launch_upload_trs(const float* pinned_src, float* t, float* r, float* s, uint32_t first_row, uint32_t n,
                              hipStream_t stream);
+// mark_bytes != nullptr: the rows also climb to their roots setting TransformTreeChanged there (= k_mark_dirty for these rows), and
+// clear_words (the other half of the marks) is zeroed
 hipError_t launch_upload_trs_indexed(const uint32_t* rows, const float* t_src, const float* r_src, const float* s_src, uint32_t n, float* t,
-                                     float* r, float* s, uint8_t* changed, hipStream_t stream);
+                                     float* r, float* s, uint8_t* changed, uint32_t changed_gen, hipStream_t stream,
+                                     const uint32_t* parent_idx = nullptr, uint8_t* mark_bytes = nullptr, uint32_t* clear_words = nullptr,
+                                     uint32_t n_clear_words = 0);
 hipError_t launch_popcount_words(const uint64_t* bits, uint32_t n_rows, uint8_t* cnt, hipStream_t stream);
 hipError_t launch_gather_global(const uint32_t* rows, const uint32_t* total, uint32_t capacity, const float* g, float* out,
                                 hipStream_t stream);
@@ -285,7 +296,7 @@ struct TileDesc {
     uint32_t count[TILE_MAX_LEVELS];
     uint32_t kind;
 };
-hipError_t launch_mark_dirty(uint32_t n, const uint8_t* changed, const uint32_t* parent_idx, uint8_t* tree_bytes,
+hipError_t launch_mark_dirty(uint32_t n, const uint8_t* changed, uint32_t changed_gen, const uint32_t* parent_idx, uint8_t* tree_bytes,
                              uint32_t* clear_words /* the other half, zeroed for the next frame; nullptr = none */, uint32_t n_clear_words,
                              hipStream_t stream);
 // One launch over a group of mutually independent tiles (TileDesc::kind tells roots / chain / dependent apart).
@@ -343,6 +354,7 @@ struct ClusterObjects {
     // derive mode, which rows this frame's propagate writes (those are From(Transform); the others keep the resident column):
     // row_changed == nullptr && !derive_resident: every row; row_changed: the rows whose byte is set; derive_resident: none
     const uint8_t* row_changed;
+    uint32_t changed_gen;        // generation of row_changed's stamps (row_changed())
     uint32_t derive_resident;
     uint32_t first_row;
     const uint32_t* row_list;    // mi_cluster_bind_objects_to_row_list: object i is row row_list[i] (nullptr: first_row + i)
@@ -465,6 +477,11 @@ hipError_t launch_batch_resolve_rows(uint32_t n, uint32_t n_sets, uint32_t n_unb
                                      uint32_t* row_meta, uint32_t* row_bucket, hipStream_t stream);
 // enqueues the whole build (3 launches up to 256 buckets); `mark` is called before each kernel for profiling
 hipError_t launch_batch_build(const BatchArgs& a, hipStream_t stream, void (*mark)(void*, uint32_t), void* mark_ctx);
-hipError_t launch_batch_sorted(const SortedArgs& a, hipStream_t stream, void (*mark)(void*, uint32_t), void* mark_ctx);
+// partials: batch_sorted_partial_words(n_items) words of scratch for the tiled form (nullptr: the single-workgroup kernel whatever the
+// length); one_wg_limit: phases up to this long take the single-workgroup kernel (one launch)
+constexpr uint32_t SORTED_ONE_WG_ITEMS = 4096;
+uint32_t batch_sorted_partial_words(uint32_t n_items);
+hipError_t launch_batch_sorted(const SortedArgs& a, hipStream_t stream, void (*mark)(void*, uint32_t), void* mark_ctx, uint32_t* partials = nullptr,
+                               uint32_t one_wg_limit = SORTED_ONE_WG_ITEMS);
 
 }  // namespace mi

@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
         }
     }
     bool dirty = false;
-    if (PARTIAL && live) dirty = changed[row] != 0;
+    if (PARTIAL && live) dirty = row_changed(changed[row], c.changed_gen);
     if (live) {
         center = ld3(c.aabb_center, row);
         half = ld3(c.aabb_half, row);
@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(256) k_frame_sph(Columns c, ViewSet vs, const 
     uint32_t cmask = 1u;
     if (seg.class_mask) cmask = seg.class_mask[rrow];
     bool dirty = false;
-    if (PARTIAL) dirty = live && changed[rrow] != 0;
+    if (PARTIAL) dirty = live && row_changed(changed[rrow], c.changed_gen);
     bool stale = sa.all_stale != 0u;
     if (sa.stale_bytes) stale = stale || sa.stale_bytes[rrow] != 0;
     if (sa.stale_bits) stale = stale || ((sa.stale_bits[any_live ? wave : 0u] >> lane) & 1ull) != 0ull;
@@ -519,7 +519,7 @@ __global__ void __launch_bounds__(256) k_level0_propagate(Columns c, uint32_t n_
             write = !static_opt || tree_changed;
         } else {
             // flat rows: Changed<Transform> || Added<GlobalTransform> (systems.rs:45-50)
-            write = all_dirty || !changed || changed[row] != 0;
+            write = all_dirty || !changed || row_changed(changed[row], c.changed_gen);
         }
         if (write) {
             const V3 t = ld3(c.translation, row);
@@ -585,11 +585,20 @@ __global__ void __launch_bounds__(256) k_upload_trs(const float* __restrict__ sr
 }
 // Sparse dirty-row upload (the rows a Changed<Transform> query yields): rows[n], t[3n], r[4n], s[3n] in pinned host memory;
 // a thread per row scatters its Transform and raises the row's changed byte.
+// With a hierarchy under the static-scene rule the kernel is also that frame's mark_dirty_trees for the rows it uploads (mark_*
+// != nullptr): every uploaded row climbs to its root setting TransformTreeChanged, exactly like k_mark_dirty (kernels_tree.hip), and
+// the launch zeroes the other half of the double-buffered marks -- the mark launch of its own (>= 4.3 us) drops out of a frame whose
+// changes all arrive this way.
 __global__ void __launch_bounds__(256) k_upload_trs_indexed(const uint32_t* __restrict__ rows, const float* __restrict__ ft,
                                                              const float* __restrict__ fr, const float* __restrict__ fs, uint32_t n, float* t,
-                                                             float* r, float* s, uint8_t* changed) {
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const uint32_t row = rows[i];
+                                                             float* r, float* s, uint8_t* changed, uint32_t changed_gen,
+                                                             const uint32_t* __restrict__ parent_idx, uint8_t* mark_bytes,
+                                                             uint32_t* __restrict__ clear_words, uint32_t n_clear_words) {
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    if (clear_words)
+        for (uint32_t w = gid; w < n_clear_words; w += gridDim.x * 256u) clear_words[w] = 0u;
+    for (uint32_t i = gid; i < n; i += gridDim.x * 256u) {
+        uint32_t row = rows[i];
 #pragma unroll
         for (uint32_t k = 0; k < 3u; ++k) {
             t[3ull * row + k] = ft[3ull * i + k];
@@ -597,16 +606,32 @@ __global__ void __launch_bounds__(256) k_upload_trs_indexed(const uint32_t* __re
         }
 #pragma unroll
         for (uint32_t k = 0; k < 4u; ++k) r[4ull * row + k] = fr[4ull * i + k];
-        changed[row] = 1;
+        changed[row] = (uint8_t)changed_gen;  // a stamp, not a flag: see row_changed() in kernels.h
+        if (mark_bytes) {
+            for (uint32_t guard = 0; guard < 0xFFFFu; ++guard) {  // (a hierarchy is at most 65 535 levels deep here)
+                const uint32_t p = parent_idx[row];
+                const uint8_t seen = __builtin_nontemporal_load(&mark_bytes[row]);
+                if (seen) break;
+                mark_bytes[row] = 1;
+                if (p == 0xFFFFFFFFu) break;
+                row = p;
+            }
+        }
     }
 }
 hipError_t launch_upload_trs_indexed(const uint32_t* rows, const float* t_src, const float* r_src, const float* s_src, uint32_t n, float* t,
-                                     float* r, float* s, uint8_t* changed, hipStream_t stream) {
+                                     float* r, float* s, uint8_t* changed, uint32_t changed_gen, hipStream_t stream, const uint32_t* parent_idx,
+                                     uint8_t* mark_bytes, uint32_t* clear_words, uint32_t n_clear_words) {
     if (n == 0) return hipSuccess;
     // the sources are pinned host memory read over PCIe: enough lanes to keep the link busy, not one workgroup per 256 rows of a
-    // million-row upload
-    const uint32_t blocks = blocks_for(n) < 2048u ? blocks_for(n) : 2048u;
-    MI_LAUNCH(k_upload_trs_indexed, dim3(blocks), dim3(256), 0, stream, rows, t_src, r_src, s_src, n, t, r, s, changed);
+    // million-row upload; and enough workgroups for the words to clear
+    uint32_t blocks = blocks_for(n) < 2048u ? blocks_for(n) : 2048u;
+    if (clear_words) {
+        const uint32_t cb = (n_clear_words + 1023u) / 1024u < 1024u ? (n_clear_words + 1023u) / 1024u : 1024u;
+        blocks = blocks > cb ? blocks : cb;
+    }
+    MI_LAUNCH(k_upload_trs_indexed, dim3(blocks), dim3(256), 0, stream, rows, t_src, r_src, s_src, n, t, r, s, changed, changed_gen, parent_idx,
+              mark_bytes, clear_words, n_clear_words);
     return hipGetLastError();
 }
 

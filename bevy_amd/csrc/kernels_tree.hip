@@ -113,14 +113,14 @@ __device__ __forceinline__ Affine sel(bool k, const Affine& a, const Affine& b) 
 // only repeat each other's stores; whoever sees a mark stops, and the one who set it goes on, so every ancestor gets marked.
 // A step is ONE round trip (the parent's index and the mark are requested together).  The launch also zeroes the OTHER half of
 // the double-buffered marks for the next frame (clear_words), which saves a launch per frame.
-__global__ void __launch_bounds__(256) k_mark_dirty(uint32_t n, const uint8_t* __restrict__ changed,
+__global__ void __launch_bounds__(256) k_mark_dirty(uint32_t n, const uint8_t* __restrict__ changed, uint32_t changed_gen,
                                                      const uint32_t* __restrict__ parent_idx, uint8_t* tree_bytes,
                                                      uint32_t* __restrict__ clear_words, uint32_t n_clear_words) {
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     if (clear_words)
         for (uint32_t w = gid; w < n_clear_words; w += gridDim.x * 256u) clear_words[w] = 0u;
     uint32_t row = gid;
-    if (row >= n || !changed[row]) return;
+    if (row >= n || !row_changed(changed[row], changed_gen)) return;
     for (uint32_t guard = 0; guard < n; ++guard) {
         const uint32_t p = parent_idx ? parent_idx[row] : 0xFFFFFFFFu;
         const uint8_t seen = __builtin_nontemporal_load(&tree_bytes[row]);  // (not a cached copy of a line another CU is writing)
@@ -161,6 +161,7 @@ struct TreeArgs {
     uint32_t snap_rows;  // the snapshot covers rows [0, snap_rows): whoever computes one of them also writes its snapshot
     uint32_t all_dirty;
     uint32_t static_opt;
+    uint32_t changed_gen;  // generation of the change column's stamps (row_changed(), kernels.h)
     uint32_t pretest;  // light tiles under the static-scene rule: test the tile's flags before asking for anything else (few rows changed)
     unsigned long long* trace;  // debug: 8 x s_memrealtime per tile (mi_debug_tree_trace), nullptr = off
 };
@@ -179,7 +180,7 @@ __device__ __forceinline__ NodeIn node_inputs(const TreeArgs& a, uint32_t row, b
     in.root_write = false;
     if (is_root_level) {
         const bool has_children = a.node_flags && (a.node_flags[row] & 1u);
-        in.root_write = has_children ? (!a.static_opt || in.tree_changed) : (a.all_dirty || !a.changed || a.changed[row] != 0);
+        in.root_write = has_children ? (!a.static_opt || in.tree_changed) : (a.all_dirty || !a.changed || row_changed(a.changed[row], a.changed_gen));
     }
     return in;
 }
@@ -243,7 +244,7 @@ __device__ __forceinline__ NodeRaw node_raw(const TreeArgs& a, uint32_t row, boo
         const uint32_t w = at32<uint8_t>(a.tree_bytes ? a.tree_bytes : reinterpret_cast<const uint8_t*>(a.parent_idx), row);
         r.tree_word = a.tree_bytes ? w : 0xFFFFFFFFu;
         const uint8_t ch = at32<uint8_t>(a.changed ? a.changed : standin, row);
-        r.changed = a.changed ? ch : (uint8_t)1;
+        r.changed = a.changed ? (uint8_t)(row_changed(ch, a.changed_gen) ? 1 : 0) : (uint8_t)1;
     }
     const uint8_t nf = at32<uint8_t>(a.node_flags && want_nflag ? a.node_flags : standin, row);
     r.nflag = a.node_flags && want_nflag ? nf : (uint8_t)0;
@@ -715,10 +716,10 @@ __global__ void __launch_bounds__(256, ALL_DIRTY ? 8 : 7) k_propagate_fans(Colum
     if constexpr (!ALL_DIRTY) {
         if (a.pretest && a.static_opt && (chain_len || ROOTS) && n_lds && (!snap_out || td.start[0] >= a.snap_rows)) {
             bool hot = false;
-            if (chain_lane && tid - FAN_CHAIN_LANE0 < chain_len) hot = at32<uint8_t>(a.changed, chain_row) != 0;
+            if (chain_lane && tid - FAN_CHAIN_LANE0 < chain_len) hot = row_changed(at32<uint8_t>(a.changed, chain_row), a.changed_gen);
             if (tid < td.count[0]) {
                 const uint32_t row = td.start[0] + tid;
-                hot = hot || at32<uint8_t>(a.tree_bytes, row) != 0 || (ROOTS && at32<uint8_t>(a.changed, row) != 0);
+                hot = hot || at32<uint8_t>(a.tree_bytes, row) != 0 || (ROOTS && row_changed(at32<uint8_t>(a.changed, row), a.changed_gen));
             }
             if (__syncthreads_or(hot ? 1 : 0) == 0) {
 #pragma unroll
@@ -1194,14 +1195,15 @@ hipError_t launch_propagate_level(const Columns& c, const uint32_t* parent_idx, 
     a.all_dirty = all_dirty ? 1u : 0u;
     a.static_opt = static_opt ? 1u : 0u;
     a.pretest = 0;
+    a.changed_gen = c.changed_gen;
     MI_LAUNCH(k_propagate_level, dim3((count + 255u) / 256u), dim3(256), 0, stream, c, a, start, count);
     return hipGetLastError();
 }
 
-hipError_t launch_mark_dirty(uint32_t n, const uint8_t* changed, const uint32_t* parent_idx, uint8_t* tree_bytes,
+hipError_t launch_mark_dirty(uint32_t n, const uint8_t* changed, uint32_t changed_gen, const uint32_t* parent_idx, uint8_t* tree_bytes,
                              uint32_t* clear_words, uint32_t n_clear_words, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    MI_LAUNCH(k_mark_dirty, dim3((n + 255u) / 256u), dim3(256), 0, stream, n, changed, parent_idx, tree_bytes, clear_words, n_clear_words);
+    MI_LAUNCH(k_mark_dirty, dim3((n + 255u) / 256u), dim3(256), 0, stream, n, changed, changed_gen, parent_idx, tree_bytes, clear_words, n_clear_words);
     return hipGetLastError();
 }
 
@@ -1212,6 +1214,7 @@ hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, 
     if (n_tiles == 0) return hipSuccess;
     TreeArgs a;
     a.pretest = pretest && changed && tree_bytes ? 1u : 0u;
+    a.changed_gen = c.changed_gen;
     a.snap_read = snap_read;
     a.snap_write = snap_write;
     a.snap_rows = snap_rows;

@@ -17,24 +17,11 @@ namespace mi {
 // primitives.rs:279), so they are computed once; the far plane is never tested (mod.rs:831,835).
 // Visibility ranges (range.rs:159-161,255-263) are evaluated on the fly from the row's (start, end) pair and the
 // view's position instead of a per-(view, entity) table.
-// Frustum::intersects_sphere over planes 0..4 (far plane never tested on this path, visibility/mod.rs:829-832): true = no plane
-// has the sphere wholly behind it.  MI_PACKED_PLANES evaluates planes (0,1) and (2,3) two at a time in the halves of packed-FP32
-// instructions (v_pk_mul_f32 / v_pk_add_f32: the same IEEE multiply and add per half, in the same order, so the same bits) --
-// 26 instead of 40 vector instructions per row and view where a frame is bound by instruction issue (k_frame_sph at several views).
-typedef float mi_f2 __attribute__((ext_vector_type(2)));
+// Frustum::intersects_sphere over planes 0..4 (the far plane is never tested on this path, visibility/mod.rs:829-832): true = no
+// plane has the sphere wholly behind it.  (Two planes per packed-FP32 instruction -- v_pk_mul_f32 / v_pk_add_f32 on float2 values,
+// bit-identical -- was measured again in round 3 on the kernel that is bound by instruction issue, k_frame_sph at 10 M rows x 4
+// views: 150.0 against 151.8 us, and 220.6 against 214.4 on k_frame; not kept.)
 __device__ __forceinline__ bool sphere_inside_five_planes(const float* planes, V4 c4, float r) {
-#ifdef MI_PACKED_PLANES
-    bool inside = true;
-#pragma unroll
-    for (int i = 0; i < 4; i += 2) {
-        const mi_f2 px = {planes[4 * i], planes[4 * i + 4]}, py = {planes[4 * i + 1], planes[4 * i + 5]};
-        const mi_f2 pz = {planes[4 * i + 2], planes[4 * i + 6]}, pw = {planes[4 * i + 3], planes[4 * i + 7]};
-        const mi_f2 v = ((px * c4.x + pz * c4.z) + (py * c4.y + pw * c4.w)) + r;  // dot4's pairwise order, per half
-        inside = inside && !(v.x <= 0.0f) && !(v.y <= 0.0f);
-    }
-    const V4 pl = V4{planes[16], planes[17], planes[18], planes[19]};
-    return inside && !(dot4(pl, c4) + r <= 0.0f);
-#else
     bool inside = true;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
@@ -42,7 +29,6 @@ __device__ __forceinline__ bool sphere_inside_five_planes(const float* planes, V
         inside = inside && !(dot4(pl, c4) + r <= 0.0f);
     }
     return inside;
-#endif
 }
 
 __device__ __forceinline__ bool row_visible_in_view(const Affine& g, V3 center, V3 half, uint32_t fl,

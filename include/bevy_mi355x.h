@@ -177,9 +177,11 @@ int32_t mi_upload_transforms_indexed(mi_ctx* ctx, uint32_t n, const uint32_t* ro
 /* The same two uploads WITHOUT the staging copy: the library hands out a window of its pinned (page-locked, device-mapped) host
  * memory and the caller -- whose gather loop over the ECS tables has to write the values somewhere anyway -- fills it in place:
  *   mi_map_upload_window(capacity, flags)   rows[capacity] (NULL with MI_UPLOAD_DENSE), translation[3 capacity], rotation[4 capacity],
- *                                           scale[3 capacity]; ONE window at a time, valid until its commit (other calls may come in
- *                                           between; should one of them have recycled the pinned arena, the commit returns
- *                                           MI_ERR_NOT_READY and nothing was uploaded: map and fill again)
+ *                                           scale[3 capacity]; valid until its commit.  Several windows may be mapped at once (a
+ *                                           parallel gather fills one per thread; map and commit themselves are calls on the
+ *                                           context: one at a time) and other calls may come in between; should one of them have
+ *                                           recycled the pinned arena, the commit returns MI_ERR_NOT_READY and nothing was
+ *                                           uploaded: map and fill again
  *   mi_commit_upload_window(w, n, first_row) the first n entries go to the device: MI_UPLOAD_DENSE = rows [first_row, first_row + n)
  *                                           by DMA straight from the window (mi_upload_transforms); otherwise rows[i] in any order,
  *                                           scattered by one kernel that reads the window over PCIe and raises the rows' change
@@ -191,6 +193,7 @@ typedef struct mi_upload_window {
     float* rotation;
     float* scale;
     uint32_t capacity, flags;
+    uint64_t token; /* library bookkeeping: which generation of the pinned arena the window lies in */
 } mi_upload_window;
 int32_t mi_map_upload_window(mi_ctx* ctx, uint32_t capacity, uint32_t flags, mi_upload_window* out);
 int32_t mi_commit_upload_window(mi_ctx* ctx, const mi_upload_window* w, uint32_t n, uint32_t first_row);

@@ -1380,6 +1380,28 @@ static void* job_run(void* p) {
     case 3:
         orc_mark_newly_hidden(cnt, j->flags + lo, j->vv + lo, NULL);
         break;
+    case 4: {
+        /* reset_view_visibility + check_visibility (every view) + mark_newly_hidden_entities_invisible in ONE pass over the
+         * batch: row-independent systems run back to back give the same bytes, and the batch stays in cache between them --
+         * the kindest reading of what a task pool does with three par_iter systems over the same tables (bench.py's
+         * "fused_visibility" CPU baseline; the reference runs them as separate systems with a join in between). */
+        for (uint32_t i = lo; i < j->hi; ++i) {
+            uint8_t fl = j->flags[i];
+            if (!(fl & ORC_FLAG_NO_CPU_CULLING)) j->vv[i] = (uint8_t)((j->vv[i] & 1u) << 1);
+            for (uint32_t v = 0; v < j->view; ++v) { /* j->view = number of views in this phase */
+                uint8_t vis = 0;
+                if (!(fl & ORC_FLAG_NO_CPU_CULLING)) {
+                    vis = (uint8_t)entity_visible_in_view(j->g + 12 * (size_t)i, j->c + 3 * (size_t)i, j->h + 3 * (size_t)i, fl,
+                                                          j->layers ? j->layers[i] : 1u, 1, j->frusta + 24 * (size_t)v,
+                                                          j->vmasks ? j->vmasks[v] : 1u, j->vflags ? (j->vflags[v] & 1) : 0);
+                    if (vis) set_visible(&j->vv[i], NULL);
+                }
+                j->vis[(size_t)v * j->n + i] = vis;
+            }
+        }
+        orc_mark_newly_hidden(cnt, j->flags + lo, j->vv + lo, NULL);
+        break;
+    }
     }
     return NULL;
 }
@@ -1410,10 +1432,20 @@ static void run_phase(pool_t* pool) {
     pthread_barrier_wait(&pool->done);
 }
 
+double orc_bench_flat_frame2(uint32_t n, const float* t, const float* r, const float* s, const float* c,
+                             const float* h, const uint8_t* flags, const uint32_t* layers, float* g, uint8_t* vv,
+                             uint8_t* vis, const float* frusta, const uint32_t* vmasks, const uint8_t* vflags,
+                             uint32_t n_views, int threads, int iters, int fused_visibility);
 double orc_bench_flat_frame(uint32_t n, const float* t, const float* r, const float* s, const float* c,
                             const float* h, const uint8_t* flags, const uint32_t* layers, float* g, uint8_t* vv,
                             uint8_t* vis, const float* frusta, const uint32_t* vmasks, const uint8_t* vflags,
                             uint32_t n_views, int threads, int iters) {
+    return orc_bench_flat_frame2(n, t, r, s, c, h, flags, layers, g, vv, vis, frusta, vmasks, vflags, n_views, threads, iters, 0);
+}
+double orc_bench_flat_frame2(uint32_t n, const float* t, const float* r, const float* s, const float* c,
+                             const float* h, const uint8_t* flags, const uint32_t* layers, float* g, uint8_t* vv,
+                             uint8_t* vis, const float* frusta, const uint32_t* vmasks, const uint8_t* vflags,
+                             uint32_t n_views, int threads, int iters, int fused_visibility) {
     if (threads < 1) threads = 1;
     job_t* jobs = (job_t*)calloc((size_t)threads, sizeof(job_t));
     pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
@@ -1442,6 +1474,11 @@ double orc_bench_flat_frame(uint32_t n, const float* t, const float* r, const fl
     for (int it = 0; it < iters; ++it) {
         for (int k = 0; k < threads; ++k) jobs[k].phase = 0;
         run_phase(&pool);
+        if (fused_visibility) {
+            for (int k = 0; k < threads; ++k) { jobs[k].phase = 4; jobs[k].view = n_views; }
+            run_phase(&pool);
+            continue;
+        }
         for (int k = 0; k < threads; ++k) jobs[k].phase = 1;
         run_phase(&pool);
         for (uint32_t v = 0; v < n_views; ++v) {

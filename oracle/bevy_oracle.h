@@ -321,6 +321,13 @@ double orc_bench_flat_frame(uint32_t n, const float* translation, const float* r
                             uint8_t* view_visibility, uint8_t* visible_out, const float* frusta,
                             const uint32_t* view_layer_masks, const uint8_t* view_flags,
                             uint32_t n_views, int threads, int iters);
+/* the same with reset + check (every view) + mark_newly_hidden fused into one pass per batch when fused_visibility != 0 */
+double orc_bench_flat_frame2(uint32_t n, const float* translation, const float* rotation,
+                            const float* scale, const float* aabb_center, const float* aabb_half,
+                            const uint8_t* flags, const uint32_t* layer_mask, float* global,
+                            uint8_t* view_visibility, uint8_t* visible_out, const float* frusta,
+                            const uint32_t* view_layer_masks, const uint8_t* view_flags,
+                            uint32_t n_views, int threads, int iters, int fused_visibility);
 
 double orc_bench_tree_frame(uint32_t n, const uint32_t* parent, const uint32_t* level_offsets, uint32_t n_levels, const float* t,
                             const float* r, const float* s, float* g, int threads, int iters);

@@ -104,6 +104,7 @@ def lib():
         _lib = C.CDLL(build())
         _lib.orc_radius_vec3a.restype = C.c_float
         _lib.orc_bench_flat_frame.restype = C.c_double
+        _lib.orc_bench_flat_frame2.restype = C.c_double
         _lib.orc_assign_objects_to_clusters.restype = C.c_uint64
         _lib.orc_visible_entities_sorted.restype = C.c_uint32
     return _lib
@@ -427,14 +428,14 @@ def cluster_bindings_storage(offsets, counts, indices, remap=None):
     return oc, idx[:len(indices)]
 
 
-def bench_flat_frame(t, r, s, c, h, flags, layers, frusta, threads, iters):
+def bench_flat_frame(t, r, s, c, h, flags, layers, frusta, threads, iters, fused_visibility=False):
     n = len(flags)
     nv = len(frusta) // 24
     g = np.zeros(12 * n, np.float32)
     vv = np.zeros(n, np.uint8)
     vis = np.zeros(nv * n, np.uint8)
-    secs = lib().orc_bench_flat_frame(n, fp(t), fp(r), fp(s), fp(c), fp(h), u8p(flags), u32p(layers), fp(g), u8p(vv),
-                                      u8p(vis), fp(frusta), None, None, nv, int(threads), int(iters))
+    secs = lib().orc_bench_flat_frame2(n, fp(t), fp(r), fp(s), fp(c), fp(h), u8p(flags), u32p(layers), fp(g), u8p(vv),
+                                       u8p(vis), fp(frusta), None, None, nv, int(threads), int(iters), 1 if fused_visibility else 0)
     return float(secs), g, vv, vis.reshape(nv, n)
 
 

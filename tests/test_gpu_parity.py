@@ -719,8 +719,9 @@ def test_error_codes(ctx_factory):
     assert e.value.code == api.MI_ERR_MALFORMED_HIERARCHY
     frusta = frusta_for([W.many_cubes_camera(0)])
     ctx.upload_hierarchy(np.array([B.NO_PARENT] + [0] * 99, np.uint32), np.array([0, 1, 100], np.uint32))
+    ctx.propagate_and_cull(frusta)                       # with a hierarchy the frame call is mi_propagate + mi_cull (tests/test_gpu_round3.py)
     with pytest.raises(api.MiError) as e:
-        ctx.propagate_and_cull(frusta)                   # flat fast path refuses a context with a hierarchy
+        ctx.propagate_and_cull(frusta, flags=B.CULL_WITH_CLUSTERS)   # nothing bound, no cluster view
     assert e.value.code == api.MI_ERR_NOT_READY
     with pytest.raises(api.MiError) as e:
         api.Context(device=4096)

@@ -184,9 +184,18 @@ def test_upload_windows_equal_the_copying_uploads():
             gb, cb = b.download_global_transforms()
             assert ga.tobytes() == gb.tobytes() and np.array_equal(ca, cb) and int(ca.sum()) == k, f"frame {frame}"
             assert np.array_equal(a.download_visibility(0), b.download_visibility(0))
-        with pytest.raises(api.MiError) as e:  # a window is committed once
-            b.commit_upload_window(w, 1)
-        assert e.value.code == api.MI_ERR_NOT_READY
+        # several windows at once (a parallel gather fills one per thread), committed in any order
+        wins = [b.map_upload_window(1000) for _ in range(3)]
+        for j, (w, wrows, wt, wr, ws) in enumerate(wins):
+            rows = np.arange(j * 1000, j * 1000 + 1000, dtype=np.uint32)
+            wrows[:], wt[:], wr[:], ws[:] = rows, t3[rows].reshape(-1) + F(9.0), r4[rows].reshape(-1), s3[rows].reshape(-1)
+        for j in (2, 0, 1):
+            b.commit_upload_window(wins[j][0], 1000)
+        rows = np.arange(3000, dtype=np.uint32)
+        a.upload_transforms_indexed(rows, t3[rows].reshape(-1) + F(9.0), r4[rows].reshape(-1), s3[rows].reshape(-1))
+        for ctx in (a, b):
+            ctx.propagate_and_cull(frusta, flags=B.CULL_END_FRAME | B.CULL_CHANGED_ROWS)
+        assert a.download_global_transforms()[0].tobytes() == b.download_global_transforms()[0].tobytes()
 
 
 def test_light_spheres_that_follow_their_rows():
@@ -240,3 +249,93 @@ def test_light_spheres_that_follow_their_rows():
                     res.append((ctx.download_view_visibility()[0].tobytes(), ctx.download_visibility(0).tobytes(), off.tobytes(), idx[:total].tobytes(), far, total))
                 assert res[0] == res[1], f"sphere path {sphere_path}, frame {frame}"
                 assert res[0][5] > 0
+
+
+def small_forest(n, seed, flat_fraction=0.3, max_children=5):
+    rng = np.random.default_rng(seed)
+    parent = np.full(n, 0xFFFFFFFF, np.uint32)
+    n_flat = int(n * flat_fraction)
+    for i in range(n_flat + 3, n):
+        parent[i] = rng.integers(n_flat, i)
+    return parent
+
+
+def test_three_hundred_change_driven_frames_cross_the_stamp_wrap():
+    """The Transform change column holds generation stamps (consuming it is a host-side increment, with a real memset for bulk
+    marks and at the wrap after generation 255) and the indexed uploads climb and mark TransformTreeChanged themselves when the
+    frames run under the static-scene rule.  300 frames on a small forest against the oracle, frame by frame: moved rows through
+    one or several indexed uploads, a bulk mi_upload_changed now and then, frames without the static rule in between, an
+    all-dirty frame, a frame in which nothing moves, the same hierarchy uploaded again."""
+    n = 3_000
+    parent_old = small_forest(n, 5)
+    new_to_old, parent, offs = api.hierarchy_sort(parent_old)
+    rng = np.random.default_rng(6)
+    t = rng.normal(size=(n, 3)).astype(F)
+    q = rng.normal(size=(n, 4)); q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(F)
+    s = rng.uniform(0.8, 1.25, size=(n, 3)).astype(F)
+    with api.Context(0) as ctx:
+        ctx.resize(n)
+        ctx.upload_transforms(t.reshape(-1), q.reshape(-1), s.reshape(-1))
+        ctx.upload_hierarchy(parent, offs)
+        ctx.propagate(B.PROPAGATE_ALL_DIRTY | B.PROPAGATE_STATIC_OPT)
+        g0 = ctx.download_global_transforms(want_changed=False)
+        for frame in range(300):
+            static_opt = frame % 17 != 11
+            changed = np.zeros(n, np.uint8)
+            kind = "none" if frame % 23 == 7 else "bulk" if frame % 29 == 13 else "all" if frame == 150 else "indexed"
+            if frame == 200:
+                ctx.upload_hierarchy(parent, offs)  # (replaces the plan; marks climbed so far are dropped)
+            if kind in ("indexed", "bulk"):
+                for part in range(1 + frame % 3):  # one to three uploads per frame
+                    rows = rng.choice(n, 1 + int(rng.integers(0, 12)), replace=False).astype(np.uint32)
+                    t[rows] += F(0.125)
+                    changed[rows] = 1
+                    if kind == "bulk" and part == 0:
+                        ctx.upload_transforms(t.reshape(-1), q.reshape(-1), s.reshape(-1))
+                        ctx.upload_changed(changed)
+                    else:
+                        ctx.upload_transforms_indexed(rows, t[rows].reshape(-1), q[rows].reshape(-1), s[rows].reshape(-1))
+            if kind == "all":
+                changed[:] = 1
+                ctx.propagate(B.PROPAGATE_ALL_DIRTY | (B.PROPAGATE_STATIC_OPT if static_opt else 0))
+            else:
+                ctx.propagate(B.PROPAGATE_STATIC_OPT if static_opt else 0)
+            rc, g1, chg = O.propagate_transforms(parent, t.reshape(-1), q.reshape(-1), s.reshape(-1), global_in=g0, static_opt=static_opt,
+                                                 tree_changed=O.mark_dirty_trees(parent, changed), transform_changed=changed)
+            assert rc == 0
+            g, got_chg = ctx.download_global_transforms()
+            assert g.tobytes() == g1.tobytes(), f"frame {frame} ({kind}, static_opt={static_opt}): GlobalTransform"
+            assert_bits(got_chg, chg, f"frame {frame} ({kind}, static_opt={static_opt}): change ticks")
+            g0 = g1
+
+
+def test_flat_changed_rows_frames_cross_the_stamp_wrap():
+    """The same for flat rows: 300 fused changed-rows frames (k_frame<2> and the world-sphere kernel) -- exactly the marked rows
+    are rewritten, frame after frame, through the wrap of the stamps."""
+    n = 5_000
+    sc = W.many_cubes(n, radius=60.0, ragged_flags=True)
+    t = sc["translation"].reshape(n, 3).copy()
+    r4, s3 = sc["rotation"].reshape(n, 4), sc["scale"].reshape(n, 3)
+    frusta = frusta_for([W.many_cubes_camera(0)])
+    rng = np.random.default_rng(9)
+    for sphere_path in (1, 2):
+        with api.Context(0) as ctx:
+            ctx.debug_set_sphere_path(sphere_path)
+            ctx.resize(n)
+            ctx.upload_transforms(t.reshape(-1), sc["rotation"], sc["scale"])
+            ctx.upload_bounds(sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"])
+            ctx.upload_changed(np.ones(n, np.uint8))
+            for frame in range(300):
+                rows = rng.choice(n, int(rng.integers(0, 9)), replace=False).astype(np.uint32)
+                t[rows] += F(0.25)
+                ctx.upload_transforms_indexed(rows, t[rows].reshape(-1), r4[rows].reshape(-1), s3[rows].reshape(-1))
+                ctx.propagate_and_cull(frusta, flags=B.CULL_END_FRAME | B.CULL_CHANGED_ROWS)
+                if frame % 50 == 0 or frame > 250:
+                    g, chg = ctx.download_global_transforms()
+                    exp, _ = O.sync_simple_transforms(t.reshape(-1), sc["rotation"], sc["scale"])
+                    assert g.tobytes() == exp.tobytes(), f"sphere path {sphere_path}, frame {frame}"
+                    want = np.zeros(n, np.uint8)
+                    want[rows] = 1
+                    if frame == 0:
+                        want[:] = 1
+                    assert_bits(chg, want, f"sphere path {sphere_path}, frame {frame}: change ticks")

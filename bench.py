@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["auto", "frame", "sharded", "flat", "tree", "lights", "flat_static", "batching"], default="auto",
+    ap.add_argument("--workload", choices=["auto", "frame", "sharded", "flat", "tree", "lights", "flat_static", "batching", "batching_sorted"], default="auto",
                     help="auto = frame at N=1 (the BASELINE metric), sharded (configs[3]) at N>1")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong", help="sharded workload: total rows fixed / rows per GPU fixed")
     ap.add_argument("--entities", type=int, default=0, help="frame/flat/tree: entities (default 1M); sharded: total (strong, default 10M) or per GPU (weak, default 1M)")
@@ -66,6 +66,8 @@ def parse():
                     help="frame: mi_propagate_and_cull, then mi_cluster_assign_resident behind it (default: ONE call with "
                          "MI_CULL_WITH_CLUSTERS, the assignment concurrent with the frame kernel on the cluster stream)")
     ap.add_argument("--concurrent-clusters", action="store_true", help="frame: add MI_CULL_CLUSTERS_CONCURRENT")
+    ap.add_argument("--sorted-items", type=int, default=0, help="batching_sorted: items of the phase (default 65 536)")
+    ap.add_argument("--sorted-one-wg-limit", type=int, default=None, help="batching_sorted: phases up to this long take the single-workgroup kernel (default 4096; 4294967295 = always)")
     ap.add_argument("--tree-moved", choices=["all", "subtree", "leaves"], default="all", help="tree: the root moves and every Transform counts as changed (default) / change-driven frames: one level-5 node moves / 10 000 leaves move")
     ap.add_argument("--sphere-path", type=int, default=0, help="flat_static / frame: 0 = world-sphere cull path from the second quiet frame (default), 1 = never (k_frame<0> over GlobalTransform + Aabb), 2 = at once")
     ap.add_argument("--tile-mode", type=int, default=0, help="tree: 0 = tile kernel chosen by size, 1 = big tiles, 2 / 3 = light tiles (5 / 6 waves per SIMD)")
@@ -377,6 +379,32 @@ def build_batching(ctx, args):
     return wl
 
 
+def build_batching_sorted(ctx, args):
+    """Sorted phases (Transparent3d, the 2D phases): gpu_preprocessing::batch_and_prepare_sorted_render_phase over a phase of
+    --sorted-items items in their sorted order.  A step = mi_batch_sorted_build: the items go up (16 B each: they are the CPU's
+    sorted phase) and the walk runs -- one workgroup up to 4 096 items, tiles over the whole chip beyond."""
+    from bevy_amd import workloads as W
+    n = getattr(args, "sorted_items", 0) or 65_536
+    items = W.sorted_items(n, seed=5)
+    ctx.resize(1)
+    limit = getattr(args, "sorted_one_wg_limit", None)
+    if limit is not None:
+        ctx.debug_set_sorted_one_wg_limit(limit)
+
+    def step(f):
+        ctx.batch_sorted_build(items, True, False, False, None)
+    tiled = n > (4096 if limit is None else limit)
+    config = {"workload": f"sorted render phase of {n} items (runs of equal batch-set / bin keys, some without an input index): "
+                          "mi_batch_sorted_build = H2D of the items + " + ("k_batch_sorted_partials + k_batch_sorted_tiles (two launches, "
+                          f"{(n + 1023) // 1024} tiles)" if tiled else "k_batch_sorted (one workgroup)"), "items": n, "tiled": tiled}
+    # per item: read 16 (item) + 16 (its predecessor, L2), write 8 scratch planes x 4, read most of them back, write a work item 8 (+ metadata)
+    wl = Workload("batching_sorted", step, n, 16.0 + 32.0 + 32.0 + 8.0, "k_batch_sorted", config, "items/sec through the sorted-phase batch build", "items/s",
+                  kernels=["k_batch_sorted", "k_batch_scan"])
+    wl.sorted_items = items
+    wl.kernel_name = "k_batch_sorted_tiles" if tiled else "k_batch_sorted<256>"
+    return wl
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # measurement
 # ---------------------------------------------------------------------------------------------------------------------
@@ -598,6 +626,18 @@ def cpu_baseline_other(name, wl):
         return {"value": round(len(rows) * iters / secs, 1), "unit": "visible rows/s (batch build only)", "cores": 1, "kind": "port",
                 "sample": f"{iters} builds over {len(rows)} visible rows: oracle C restatement of the bin bookkeeping + "
                           f"allocate_uniforms + unpack_bins, {secs:.2f}s"}
+    if name == "batching_sorted":
+        items = wl.sorted_items
+        t0 = time.perf_counter()
+        O.batch_sorted(items, True, False, O.BatchInitial())
+        one = time.perf_counter() - t0
+        iters = int(max(1, min(500, 2.0 / max(one, 1e-5))))
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            O.batch_sorted(items, True, False, O.BatchInitial())
+        secs = time.perf_counter() - t0
+        return {"value": round(len(items) * iters / secs, 1), "unit": "items/s", "cores": 1, "kind": "port",
+                "sample": f"{iters} builds of a {len(items)}-item sorted phase: oracle C restatement of batch_and_prepare_sorted_render_phase, {secs:.2f}s"}
     if name == "tree":
         tr = wl.tree
         cores = os.cpu_count() or 1
@@ -773,7 +813,7 @@ def main():
     workload = args.workload
     if workload == "auto":
         workload = "frame" if world == 1 else "sharded"
-    if workload in ("frame", "lights", "flat_static", "batching") and world > 1:
+    if workload in ("frame", "lights", "flat_static", "batching", "batching_sorted") and world > 1:
         raise SystemExit(f"--workload {workload} is a single-GPU workload (replicas only); N > 1 runs `sharded` or `tree`")
 
     stream = torch.cuda.Stream()
@@ -799,6 +839,8 @@ def main():
             wl = build_flat_static(ctx, args)
         elif workload == "batching":
             wl = build_batching(ctx, args)
+        elif workload == "batching_sorted":
+            wl = build_batching_sorted(ctx, args)
         else:
             wl = build_lights(ctx, args)
 
@@ -864,7 +906,11 @@ def main():
                  ("tree_10k_leaves_move", lambda c: build_tree(c, with_args(args, tree_moved="leaves"))), ("lights", lambda c: build_lights(c, args)),
                  ("flat_static", lambda c: build_flat_static(c, args)), ("flat_static_no_sphere_column", lambda c: build_flat_static(c, with_args(args, sphere_path=1))),
                  ("flat_static_10m_4views", lambda c: build_flat_static(c, with_args(args, entities=10_000_000, views=4))),
-                 ("batching", lambda c: build_batching(c, args))]
+                 ("batching", lambda c: build_batching(c, args)),
+                 ("batching_sorted_4k", lambda c: build_batching_sorted(c, with_args(args, sorted_items=4096))),
+                 ("batching_sorted_64k", lambda c: build_batching_sorted(c, with_args(args, sorted_items=65_536))),
+                 ("batching_sorted_64k_one_workgroup", lambda c: build_batching_sorted(c, with_args(args, sorted_items=65_536, sorted_one_wg_limit=0xFFFFFFFF))),
+                 ("batching_sorted_1m", lambda c: build_batching_sorted(c, with_args(args, sorted_items=1_000_000)))]
         for name, builder in specs:
             c2 = api.Context(local_rank, stream.cuda_stream)
             with torch.cuda.stream(stream):
@@ -877,8 +923,8 @@ def main():
                             "roofline": roofline_of(w2, p2, 50), "kernels": {k: round(v["avg_us"], 3) for k, v in p2.items() if v["launches"]}}
             if name == "batching":
                 others[name]["batch_build_us_per_frame"] = round(1e3 * (others[name]["ms_per_step"] - others["flat"]["ms_per_step"]), 2)
-            if not args.no_cpu_baseline and name in ("tree", "lights", "batching"):
-                others[name]["cpu_baseline"] = cpu_baseline_other(name, w2)
+            if not args.no_cpu_baseline and (name in ("tree", "lights", "batching") or name.startswith("batching_sorted")):
+                others[name]["cpu_baseline"] = cpu_baseline_other(name.split("_sorted")[0] + ("_sorted" if "_sorted" in name else ""), w2)
             c2.close()
         out["other_workloads"] = others
     if rank == 0:

@@ -116,5 +116,24 @@ def build_host_tests(force=False):
     return exe
 
 
+MULTI_GPU_SRC = os.path.join(HERE, "..", "tests", "cpp", "multi_gpu_single_process.cpp")
+MULTI_GPU_EXE = os.path.join(HERE, "..", "tests", "cpp", "multi_gpu_single_process")
+
+
+def build_multi_gpu_test(force=False):
+    """tests/cpp/multi_gpu_single_process.cpp: one process, one thread, a context per GPU, RCCL through dlopen (host code only)."""
+    exe, src = os.path.abspath(MULTI_GPU_EXE), os.path.abspath(MULTI_GPU_SRC)
+    deps = [src, LIB, os.path.join(CSRC, "..", "..", "include", "bevy_mi355x.h")]
+    if not force and os.path.exists(exe) and all(os.path.getmtime(d) <= os.path.getmtime(exe) for d in deps):
+        return exe
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", src, "-o", exe, "-L", HERE, "-lbevy_mi355x",
+           "-L/opt/rocm/lib", "-lamdhip64", "-ldl", "-Wl,-rpath,$ORIGIN/../../bevy_amd", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        sys.stderr.write(res.stdout + res.stderr)
+        raise RuntimeError("g++ failed building tests/cpp/multi_gpu_single_process")
+    return exe
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

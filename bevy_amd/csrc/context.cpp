@@ -609,6 +609,7 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
         for (DevBuf* b : {&f.bitmask, &f.wave_cnt, &f.seg_mask, &f.out_rows, &f.seg_totals})
             if (b->p) hipFree(b->p);
     if (ctx->stage) hipHostFree(ctx->stage);
+    for (auto& c : ctx->win_chunks) hipHostFree(c.p);
     if (ctx->timer_a) hipEventDestroy(ctx->timer_a);
     if (ctx->timer_b) hipEventDestroy(ctx->timer_b);
     exchange_stop(ctx);
@@ -874,9 +875,33 @@ int32_t mi_map_upload_window(mi_ctx* ctx, uint32_t capacity, uint32_t flags, mi_
     out->capacity = capacity;
     if (capacity == 0) return MI_OK;
     const bool dense = (flags & MI_UPLOAD_DENSE) != 0;
-    void* st = nullptr;
-    int32_t rc = stage_alloc(ctx, (size_t)capacity * (dense ? 40 : 44) + 64, &st);
-    if (rc) return rc;
+    const size_t need = (((size_t)capacity * (dense ? 40 : 44) + 64) + 255) & ~(size_t)255;
+    auto& chunks = ctx->win_chunks;
+    if (ctx->win_open == 0 && !chunks.empty() && (chunks.size() > 1 || chunks.back().used + need > chunks.back().bytes)) {
+        // nothing is mapped: recycle.  What the device still reads of earlier windows (DMA, the scatter kernel) has to be done
+        // first -- by now normally long since (the frame's results were waited for)
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        while (chunks.size() > 1) {  // keep the biggest chunk
+            auto small = chunks.begin();
+            for (auto it = chunks.begin(); it != chunks.end(); ++it)
+                if (it->bytes < small->bytes) small = it;
+            HIP_TRY(ctx, hipHostFree(small->p));
+            chunks.erase(small);
+        }
+        chunks.back().used = 0;
+        ++ctx->win_gen;
+    }
+    if (chunks.empty() || chunks.back().used + need > chunks.back().bytes) {
+        if (ctx->win_open == 0 && !chunks.empty()) {  // (recycled above and still too small)
+            HIP_TRY(ctx, hipHostFree(chunks.back().p));
+            chunks.pop_back();
+        }
+        mi_ctx::WinChunk c{nullptr, std::max<size_t>(need, (size_t)64 << 20), 0};
+        HIP_TRY(ctx, hipHostMalloc(&c.p, c.bytes, hipHostMallocMapped));
+        chunks.push_back(c);
+    }
+    char* st = (char*)chunks.back().p + chunks.back().used;
+    chunks.back().used += need;
     float* f = (float*)st;
     if (!dense) {
         out->rows = (uint32_t*)st;
@@ -885,18 +910,23 @@ int32_t mi_map_upload_window(mi_ctx* ctx, uint32_t capacity, uint32_t flags, mi_
     out->translation = f;
     out->rotation = f + 3 * (size_t)capacity + ((4 - (3 * (size_t)capacity) % 4) % 4);
     out->scale = out->rotation + 4 * (size_t)capacity;
-    out->token = ctx->stage_epoch + 1;  // (0 = never mapped / already committed)
+    out->token = ctx->win_gen;
+    ++ctx->win_open;
     return MI_OK;
 }
 
 int32_t mi_commit_upload_window(mi_ctx* ctx, const mi_upload_window* w, uint32_t n, uint32_t first_row) {
     ENTER(ctx);
     if (!w) return fail(ctx, MI_ERR_INVALID_ARG, "mi_commit_upload_window: NULL");
-    if (n == 0) return MI_OK;
+    if (w->capacity == 0) return MI_OK;
     if (n > w->capacity) return fail(ctx, MI_ERR_INVALID_ARG, "mi_commit_upload_window: %u rows, the window holds %u", n, w->capacity);
     const char* base = w->rows ? (const char*)w->rows : (const char*)w->translation;
-    if (w->token != ctx->stage_epoch + 1 || base < (const char*)ctx->stage || base >= (const char*)ctx->stage + ctx->stage_bytes)
-        return fail(ctx, MI_ERR_NOT_READY, "mi_commit_upload_window: the window is no longer mapped (the pinned arena was recycled since, or it was committed already)");
+    bool inside = false;
+    for (auto& c : ctx->win_chunks) inside = inside || (base >= (const char*)c.p && base < (const char*)c.p + c.bytes);
+    if (w->token != ctx->win_gen || !inside || ctx->win_open == 0)
+        return fail(ctx, MI_ERR_NOT_READY, "mi_commit_upload_window: not a window that is mapped at present");
+    --ctx->win_open;  // (committing with n == 0 just gives the window back)
+    if (n == 0) return MI_OK;
     if (w->flags & MI_UPLOAD_DENSE) {
         int32_t rc = check_rows(ctx, first_row, n, "mi_commit_upload_window");
         if (rc) return rc;

@@ -74,6 +74,13 @@ struct mi_ctx {
     size_t stage_bytes = 0, stage_used = 0;
     uint64_t stage_epoch = 0;  // bumped whenever the arena wraps or moves: pointers into it from before are stale
 
+    // ---- upload windows (mi_map_upload_window): pinned chunks of their own -- several windows may be open at once, and a window
+    // must not move or be recycled while it is (the staging arena above wraps).  Recycled when a window is mapped while none is open.
+    struct WinChunk { void* p; size_t bytes, used; };
+    std::vector<WinChunk> win_chunks;
+    uint32_t win_open = 0;
+    uint64_t win_gen = 1;  // mi_upload_window::token of the windows handed out since the last recycling
+
     // ---- hierarchy ----
     uint32_t n_levels = 1;
     std::vector<uint32_t> level_offsets;  // n_levels + 1
@@ -122,7 +129,10 @@ struct mi_ctx {
     // multi-GPU exchange (mi_exchange_configure): in-place all-gather of the masks after every cull
     struct Exchange {
         bool on = false;
-        bool simple = true;      // MI_EXCHANGE_SIMPLE (default) / MI_EXCHANGE_PIPELINED
+        bool simple = true;      // MI_EXCHANGE_SIMPLE (default) or MI_EXCHANGE_GROUPED / MI_EXCHANGE_PIPELINED
+        bool grouped = false;    // MI_EXCHANGE_GROUPED: the frame calls leave the all-gather pending for mi_exchange_group_flush
+        bool group_pending = false;
+        uint32_t group_slot = 0;
         bool debug = false;      // MI_XCH_DEBUG, read once at mi_ctx_create
         hipEvent_t ev_kernels[8] = {nullptr};  // simple mode: recorded behind each frame's kernels on the compute stream
         int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;  // ncclAllGather

@@ -233,6 +233,13 @@ int32_t exchange_end(mi_ctx* ctx) {
     if (x.simple) {
         // masks complete = everything enqueued so far on the compute stream (a deferred compaction is not: it only reads them)
         HIP_TRY(ctx, hipEventRecord(x.ev_kernels[slot], ctx->stream));
+        if (x.grouped) {  // one thread drives several contexts: their all-gathers go out together (mi_exchange_group_flush)
+            if (x.group_pending) return fail(ctx, MI_ERR_NOT_READY, "MI_EXCHANGE_GROUPED: the previous frame's all-gather was never flushed (mi_exchange_group_flush)");
+            x.group_pending = true;
+            x.group_slot = slot;
+            ++x.frame;
+            return MI_OK;
+        }
         HIP_TRY(ctx, hipStreamWaitEvent(x.comm_stream[0], x.ev_kernels[slot], 0));
         char* base = (char*)x.buf[slot];
         const int err = x.all_gather(base + (size_t)x.rank * x.block_bytes, base, (size_t)x.block_bytes, 1 /* ncclUint8 */, x.comm[0], x.comm_stream[0]);
@@ -279,9 +286,45 @@ int32_t mi_bind_visibility_output(mi_ctx* ctx, void* device_ptr, uint64_t words_
 
 int32_t mi_exchange_set_mode(mi_ctx* ctx, uint32_t mode) {
     ENTER(ctx);
-    if (mode > MI_EXCHANGE_PIPELINED) return fail(ctx, MI_ERR_INVALID_ARG, "mi_exchange_set_mode: unknown mode %u", mode);
+    if (mode > MI_EXCHANGE_GROUPED) return fail(ctx, MI_ERR_INVALID_ARG, "mi_exchange_set_mode: unknown mode %u", mode);
     if (ctx->xch.on) return fail(ctx, MI_ERR_NOT_READY, "mi_exchange_set_mode: switch the exchange off first (mi_exchange_configure with a NULL communicator)");
-    ctx->xch.simple = mode == MI_EXCHANGE_SIMPLE;
+    ctx->xch.simple = mode != MI_EXCHANGE_PIPELINED;
+    ctx->xch.grouped = mode == MI_EXCHANGE_GROUPED;
+    return MI_OK;
+}
+
+int32_t mi_exchange_group_flush(mi_ctx* const* contexts, uint32_t n, void* fn_nccl_group_start, void* fn_nccl_group_end) {
+    if (!contexts || n == 0 || !fn_nccl_group_start || !fn_nccl_group_end) return fail(nullptr, MI_ERR_INVALID_ARG, "mi_exchange_group_flush: NULL");
+    typedef int (*group_fn)(void);
+    for (uint32_t i = 0; i < n; ++i)
+        if (!contexts[i] || !contexts[i]->xch.on || !contexts[i]->xch.grouped)
+            return fail(contexts[i], MI_ERR_NOT_READY, "mi_exchange_group_flush: context %u is not in MI_EXCHANGE_GROUPED mode", i);
+    int err = ((group_fn)fn_nccl_group_start)();
+    if (err) return fail(contexts[0], MI_ERR_DEVICE, "ncclGroupStart failed (%d)", err);
+    int32_t rc = MI_OK;
+    for (uint32_t i = 0; i < n && rc == MI_OK; ++i) {
+        mi_ctx* ctx = contexts[i];
+        auto& x = ctx->xch;
+        if (!x.group_pending) continue;
+        if (hipSetDevice(ctx->device) != hipSuccess || hipStreamWaitEvent(x.comm_stream[0], x.ev_kernels[x.group_slot], 0) != hipSuccess) {
+            rc = fail(ctx, MI_ERR_DEVICE, "mi_exchange_group_flush: HIP call failed on context %u", i);
+            break;
+        }
+        char* base = (char*)x.buf[x.group_slot];
+        err = x.all_gather(base + (size_t)x.rank * x.block_bytes, base, (size_t)x.block_bytes, 1 /* ncclUint8 */, x.comm[0], x.comm_stream[0]);
+        if (err) rc = fail(ctx, MI_ERR_DEVICE, "ncclAllGather failed (%d)", err);
+    }
+    err = ((group_fn)fn_nccl_group_end)();  // the collectives of every context are enqueued here, together
+    if (rc) return rc;
+    if (err) return fail(contexts[0], MI_ERR_DEVICE, "ncclGroupEnd failed (%d)", err);
+    for (uint32_t i = 0; i < n; ++i) {
+        mi_ctx* ctx = contexts[i];
+        auto& x = ctx->xch;
+        if (!x.group_pending) continue;
+        if (hipSetDevice(ctx->device) != hipSuccess || hipEventRecord(x.ev_gathered[x.group_slot], x.comm_stream[0]) != hipSuccess)
+            return fail(ctx, MI_ERR_DEVICE, "mi_exchange_group_flush: event record failed on context %u", i);
+        x.group_pending = false;
+    }
     return MI_OK;
 }
 
@@ -388,6 +431,7 @@ int32_t mi_exchange_last(mi_ctx* ctx, void** out_device_buf, int32_t wait) {
     int32_t rc = compaction_join(ctx);  // asynchronous compaction: also what releases the last frame's all-gather
     if (rc) return rc;
     if (!x.simple && (rc = exchange_wait_issued(ctx, x.frame))) return rc;
+    if (x.grouped && x.group_pending) return fail(ctx, MI_ERR_NOT_READY, "mi_exchange_last: the frame's all-gather is still pending (mi_exchange_group_flush)");
     if (wait) HIP_TRY(ctx, hipEventSynchronize(x.ev_gathered[slot]));
     if (out_device_buf) *out_device_buf = x.buf[slot];
     return MI_OK;

@@ -1282,7 +1282,9 @@ hipError_t launch_batch_sorted(const SortedArgs& a, hipStream_t stream, void (*m
         else MI_LAUNCH(k_batch_sorted<1024>, dim3(1), dim3(1024), 0, stream, a);
     } else {
         const uint32_t n_tiles = (a.n_items + SORTED_TILE - 1u) / SORTED_TILE;
+        if (mark) mark(mctx, K_BATCH_SCAN);  // (timer slots: the partials under k_batch_scan, the tiles under k_batch_sorted)
         MI_LAUNCH(k_batch_sorted_partials, dim3(n_tiles), dim3(256), 0, stream, a, partials);
+        if (mark) mark(mctx, K_BATCH_SORTED);
         MI_LAUNCH(k_batch_sorted_tiles, dim3(n_tiles), dim3(256), 0, stream, a, (const uint32_t*)partials, n_tiles);
     }
     if (mark) mark(mctx, K_NUM_KERNELS);

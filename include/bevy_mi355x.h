@@ -179,9 +179,8 @@ int32_t mi_upload_transforms_indexed(mi_ctx* ctx, uint32_t n, const uint32_t* ro
  *   mi_map_upload_window(capacity, flags)   rows[capacity] (NULL with MI_UPLOAD_DENSE), translation[3 capacity], rotation[4 capacity],
  *                                           scale[3 capacity]; valid until its commit.  Several windows may be mapped at once (a
  *                                           parallel gather fills one per thread; map and commit themselves are calls on the
- *                                           context: one at a time) and other calls may come in between; should one of them have
- *                                           recycled the pinned arena, the commit returns MI_ERR_NOT_READY and nothing was
- *                                           uploaded: map and fill again
+ *                                           context: one at a time) and other calls may come in between.  Every mapped window is
+ *                                           committed exactly once (n = 0 just gives it back)
  *   mi_commit_upload_window(w, n, first_row) the first n entries go to the device: MI_UPLOAD_DENSE = rows [first_row, first_row + n)
  *                                           by DMA straight from the window (mi_upload_transforms); otherwise rows[i] in any order,
  *                                           scattered by one kernel that reads the window over PCIe and raises the rows' change
@@ -193,7 +192,7 @@ typedef struct mi_upload_window {
     float* rotation;
     float* scale;
     uint32_t capacity, flags;
-    uint64_t token; /* library bookkeeping: which generation of the pinned arena the window lies in */
+    uint64_t token; /* library bookkeeping */
 } mi_upload_window;
 int32_t mi_map_upload_window(mi_ctx* ctx, uint32_t capacity, uint32_t flags, mi_upload_window* out);
 int32_t mi_commit_upload_window(mi_ctx* ctx, const mi_upload_window* w, uint32_t n, uint32_t first_row);
@@ -717,6 +716,13 @@ int32_t mi_bind_visibility_output(mi_ctx* ctx, void* device_ptr, uint64_t words_
  *                          once an N > 1 measurement says it pays. */
 #define MI_EXCHANGE_SIMPLE 0u
 #define MI_EXCHANGE_PIPELINED 1u
+/*   MI_EXCHANGE_GROUPED    ONE process, ONE thread, several GPUs -- what a Bevy App is (one World, systems on one schedule): a context
+ *                          per device, communicators from ncclCommInitAll.  One thread cannot issue the ranks' collectives one by one
+ *                          (the first would wait for peers the same thread has not reached yet), so the frame calls leave the frame's
+ *                          all-gather pending and mi_exchange_group_flush issues the pending all-gathers of all contexts between
+ *                          ncclGroupStart and ncclGroupEnd.  Otherwise as MI_EXCHANGE_SIMPLE (event ordering, rotating buffers).
+ *                          tests/cpp/multi_gpu_single_process.cpp drives a sharded frame this way over every GPU of the node. */
+#define MI_EXCHANGE_GROUPED 2u
 int32_t mi_exchange_set_mode(mi_ctx* ctx, uint32_t mode);
 int32_t mi_exchange_configure(mi_ctx* ctx, void* nccl_comm, void* fn_nccl_all_gather, void* const* device_bufs,
                               uint32_t n_bufs, uint64_t words_per_view, uint64_t word_offset, uint64_t block_bytes,
@@ -728,6 +734,10 @@ int32_t mi_exchange_configure(mi_ctx* ctx, void* nccl_comm, void* fn_nccl_all_ga
 int32_t mi_exchange_configure_multi(mi_ctx* ctx, void* const* nccl_comms, uint32_t n_comms, void* fn_nccl_all_gather,
                                     void* const* device_bufs, uint32_t n_bufs, uint64_t words_per_view, uint64_t word_offset,
                                     uint64_t block_bytes, uint32_t rank);
+/* MI_EXCHANGE_GROUPED: issues the pending all-gather of every listed context inside one ncclGroupStart / ncclGroupEnd pair
+ * (fn_* = the addresses of those two functions in the RCCL library the communicators belong to).  Call it after the frame calls of
+ * all contexts, from the thread that made them. */
+int32_t mi_exchange_group_flush(mi_ctx* const* contexts, uint32_t n, void* fn_nccl_group_start, void* fn_nccl_group_end);
 /* The gathered buffer of the most recent frame (optionally after waiting for its collective). */
 int32_t mi_exchange_last(mi_ctx* ctx, void** out_device_buf, int32_t wait);
 

@@ -26,3 +26,23 @@ def test_reference_system_tests_against_the_host_layer():
     failed = [line for line in res.stdout.splitlines() if line.startswith("FAILED") or "EXCEPTION" in line]
     assert res.returncode == 0 and not failed, res.stdout[-3000:] + res.stderr[-1000:]
     assert "27 tests, 0 failed" in res.stdout  # 14 tests against the three systems, 13 of them again against the fused frame
+
+
+def test_single_process_multi_gpu_driver_compiles():
+    mi_build.build()
+    exe = mi_build.build_multi_gpu_test(force=True)
+    assert os.path.exists(exe) and os.access(exe, os.X_OK)
+
+
+@pytest.mark.gpu
+def test_one_thread_drives_every_gpu_of_the_node():
+    """tests/cpp/multi_gpu_single_process.cpp: a context per device, ncclCommInitAll, MI_EXCHANGE_GROUPED -- the sharded frame of
+    configs[3] from ONE thread of ONE process (what a Bevy App is); every rank's gathered buffer must equal the masks of one
+    unsharded context.  On a one-GPU box that is a 1-rank communicator: everything but the wire."""
+    import json
+    mi_build.build()
+    exe = mi_build.build_multi_gpu_test()
+    res = subprocess.run([exe, "300000", "4"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-1000:]
+    out = json.loads(res.stdout.strip().splitlines()[-1])
+    assert out["mismatches"] == 0 and out["devices"] >= 1 and out["frames"] == 4

@@ -215,6 +215,7 @@ def test_light_spheres_that_follow_their_rows():
     cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
     rng = np.random.default_rng(21)
     for sphere_path in (1, 2):
+        t = sc["translation"].reshape(n, 3).copy()
         with api.Context(0) as a, api.Context(0) as b:
             for ctx in (a, b):
                 ctx.debug_set_sphere_path(sphere_path)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box, round 3 call F: whole suite (default; tile pre-test + sphere path forced; tiled sorted phases forced), benches
 export TMPDIR=/tmp
-O=gpurun_out/r03f
+O=gpurun_out/r03g
 mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -q > $O/pytest_default.log 2>&1; echo "pytest default rc=$?" >> $O/summary.txt
 MI_TEST_TILE_PRETEST=2 MI_TEST_SPHERE_PATH=2 MI_TEST_SORTED_TILED=1 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_round2.py tests/test_gpu_round3.py tests/test_gpu_tile_kernels.py tests/test_gpu_sphere_path.py tests/test_gpu_cluster.py tests/test_gpu_batching.py -m gpu -q > $O/pytest_forced.log 2>&1; echo "pytest forced rc=$?" >> $O/summary.txt
@@ -10,7 +10,7 @@ tail -n 6 $O/pytest_default.log; tail -n 6 $O/pytest_forced.log
 cat $O/summary.txt
 python - <<'P'
 import json,glob
-d=json.loads(open("gpurun_out/r03f/bench_full.json").read().strip().splitlines()[-1])
+d=json.loads(open("gpurun_out/r03g/bench_full.json").read().strip().splitlines()[-1])
 print("frame", d["ms_per_step"]*1e3, "us", d["kernels"], d["roofline"]["frac"])
 print("cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"], d["cpu_baseline"]["thread_sweep_ms_per_frame"])
 e=d["end_to_end"]

@@ -382,7 +382,7 @@ def build_batching(ctx, args):
 def build_batching_sorted(ctx, args):
     """Sorted phases (Transparent3d, the 2D phases): gpu_preprocessing::batch_and_prepare_sorted_render_phase over a phase of
     --sorted-items items in their sorted order.  A step = mi_batch_sorted_build: the items go up (16 B each: they are the CPU's
-    sorted phase) and the walk runs -- one workgroup up to 4 096 items, tiles over the whole chip beyond."""
+    sorted phase) and the walk runs -- one workgroup up to 1 024 items, tiles over the whole chip beyond."""
     from bevy_amd import workloads as W
     n = getattr(args, "sorted_items", 0) or 65_536
     items = W.sorted_items(n, seed=5)
@@ -393,7 +393,7 @@ def build_batching_sorted(ctx, args):
 
     def step(f):
         ctx.batch_sorted_build(items, True, False, False, None)
-    tiled = n > (4096 if limit is None else limit)
+    tiled = n > (1024 if limit is None else limit)
     config = {"workload": f"sorted render phase of {n} items (runs of equal batch-set / bin keys, some without an input index): "
                           "mi_batch_sorted_build = H2D of the items + " + ("k_batch_sorted_partials + k_batch_sorted_tiles (two launches, "
                           f"{(n + 1023) // 1024} tiles)" if tiled else "k_batch_sorted (one workgroup)"), "items": n, "tiled": tiled}
@@ -709,8 +709,6 @@ def end_to_end(ctx, wl, frames=12):
     ctx.propagate(B.PROPAGATE_ALL_DIRTY)
     ctx.synchronize()
     bufs = api.FrameResultBuffers(n, n, views[0].n_clusters, 1 << 20, in_place=True)
-    from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(4)
     for pct in (1, 10, 100):
         k = n * pct // 100
         rows = np.sort(rng.choice(n, k, replace=False)).astype(np.uint32) if pct < 100 else None
@@ -727,16 +725,13 @@ def end_to_end(ctx, wl, frames=12):
                 np.take(r4, rows, axis=0, out=wr.reshape(k, 4), mode="clip")
                 np.take(s3, rows, axis=0, out=ws.reshape(k, 3), mode="clip")
                 ctx.commit_upload_window(w, k)
-            else:  # every row: dense windows, a chunk each, filled by a few host threads (the ECS side's par_iter); chunk i crosses
-                   # PCIe (DMA straight from the window) while the others are still being filled
+            else:  # every row: dense windows, a chunk at a time -- chunk i crosses PCIe (DMA straight from the window) while the host
+                   # fills chunk i + 1.  (Four Python threads filling eight windows at once were SLOWER: 3.4 against 1.5 ms.)
                 chunk = (n + 7) // 8
-                wins = [(lo, min(chunk, n - lo)) + ctx.map_upload_window(min(chunk, n - lo), dense=True) for lo in range(0, n, chunk)]
-
-                def fill(win):
-                    lo, m, w, _, wt, wr, ws = win
+                for lo in range(0, n, chunk):
+                    m = min(chunk, n - lo)
+                    w, _, wt, wr, ws = ctx.map_upload_window(m, dense=True)
                     wt[:], wr[:], ws[:] = t3[lo:lo + m].reshape(-1), r4[lo:lo + m].reshape(-1), s3[lo:lo + m].reshape(-1)
-                    return win
-                for lo, m, w, *_ in pool.map(fill, wins):
                     ctx.commit_upload_window(w, m, first_row=lo)
             t1 = time.perf_counter()
             ctx.propagate_and_cull(fr, flags=B.CULL_END_FRAME | B.CULL_WITH_CLUSTERS | (B.CULL_CHANGED_ROWS if rows is not None else 0))

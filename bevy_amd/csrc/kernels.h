@@ -479,7 +479,7 @@ hipError_t launch_batch_resolve_rows(uint32_t n, uint32_t n_sets, uint32_t n_unb
 hipError_t launch_batch_build(const BatchArgs& a, hipStream_t stream, void (*mark)(void*, uint32_t), void* mark_ctx);
 // partials: batch_sorted_partial_words(n_items) words of scratch for the tiled form (nullptr: the single-workgroup kernel whatever the
 // length); one_wg_limit: phases up to this long take the single-workgroup kernel (one launch)
-constexpr uint32_t SORTED_ONE_WG_ITEMS = 4096;
+constexpr uint32_t SORTED_ONE_WG_ITEMS = 1024;  // (4 096 items: one workgroup 60 us, four tiles in two launches ~ 15)
 uint32_t batch_sorted_partial_words(uint32_t n_items);
 hipError_t launch_batch_sorted(const SortedArgs& a, hipStream_t stream, void (*mark)(void*, uint32_t), void* mark_ctx, uint32_t* partials = nullptr,
                                uint32_t one_wg_limit = SORTED_ONE_WG_ITEMS);

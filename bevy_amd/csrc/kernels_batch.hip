@@ -1276,7 +1276,7 @@ uint32_t batch_sorted_partial_words(uint32_t n_items) { return ((n_items + SORTE
 hipError_t launch_batch_sorted(const SortedArgs& a, hipStream_t stream, void (*mark)(void*, uint32_t), void* mctx, uint32_t* partials,
                                uint32_t sorted_one_wg_limit) {
     if (mark) mark(mctx, K_BATCH_SORTED);
-    // up to SORTED_ONE_WG items: one workgroup, one launch (latency); beyond: tiles over the whole chip, two launches
+    // up to one_wg_limit items: one workgroup, one launch (latency); beyond: tiles over the whole chip, two launches
     if (a.n_items <= sorted_one_wg_limit || !partials) {
         if (a.n_items <= 4096u) MI_LAUNCH(k_batch_sorted<256>, dim3(1), dim3(256), 0, stream, a);
         else MI_LAUNCH(k_batch_sorted<1024>, dim3(1), dim3(1024), 0, stream, a);

@@ -406,20 +406,33 @@ class Mi355xPlugin {
         const auto t_start = std::chrono::steady_clock::now();
         // ---- in: Changed<Transform> rows (World::touched_ is what the query's change-tick scan yields), written straight into the
         //      library's pinned upload window: no Vec of our own, no staging copy
-        mi_upload_window win{};
-        check(mi_map_upload_window(ctx_, (uint32_t)w.touched_.size(), 0, &win));
         uint32_t n_in = 0;
         for (uint32_t i : w.touched_) {
             const World::Rec& e = w.rec_[i];
+            n_in += e.alive && (e.transform_changed || e.added || e.parent_changed || e.orphaned);
+        }
+        // every row moved: the dense window (filled by row, DMA straight from it); otherwise rows + values for the scatter kernel
+        const bool dense = n_in == n;
+        mi_upload_window win{};
+        check(mi_map_upload_window(ctx_, n_in, dense ? MI_UPLOAD_DENSE : 0u, &win));
+        uint32_t k = 0;
+        for (uint32_t i : w.touched_) {
+            const World::Rec& e = w.rec_[i];
             if (!e.alive || !(e.transform_changed || e.added || e.parent_changed || e.orphaned)) continue;
-            win.rows[n_in] = row_of_index_[i];
-            std::memcpy(win.translation + 3 * (size_t)n_in, &e.transform.translation, 12);
-            std::memcpy(win.rotation + 4 * (size_t)n_in, &e.transform.rotation, 16);
-            std::memcpy(win.scale + 3 * (size_t)n_in, &e.transform.scale, 12);
-            ++n_in;
+            const uint32_t row = row_of_index_[i];
+            const size_t at = dense ? row : k;
+            if (!dense) win.rows[k] = row;
+            std::memcpy(win.translation + 3 * at, &e.transform.translation, 12);
+            std::memcpy(win.rotation + 4 * at, &e.transform.rotation, 16);
+            std::memcpy(win.scale + 3 * at, &e.transform.scale, 12);
+            ++k;
         }
         const auto t_gathered = std::chrono::steady_clock::now();
         check(mi_commit_upload_window(ctx_, &win, n_in, 0));
+        if (dense) {  // (the dense form raises no change bytes: every row counts as changed)
+            scratch_ones_.assign(n, 1);
+            check(mi_upload_changed(ctx_, 0, n, scratch_ones_.data()));
+        }
         if (n_in == 0) {  // keep "nothing changed" distinct from "no change information" (= all dirty)
             const uint8_t zero = 0;
             check(mi_upload_changed(ctx_, 0, 1, &zero));
@@ -798,6 +811,7 @@ class Mi355xPlugin {
 
     mi_ctx* ctx_ = nullptr;
     std::vector<float> plane_storage_;
+    std::vector<uint8_t> scratch_ones_;
     std::vector<mi_view> mviews_;
     std::vector<Entity> light_entities_;
     std::vector<uint32_t> row_of_index_;

@@ -44,7 +44,7 @@ int32_t mi_debug_tree_trace(mi_ctx* ctx, int32_t enable, unsigned long long* out
 /* The shape of the current tile plan: launches per mi_propagate, tiles, chain tiles (self-evaluated ancestor chains), bands. */
 int32_t mi_debug_tile_plan(mi_ctx* ctx, uint32_t* out_launches, uint32_t* out_tiles, uint32_t* out_chain_tiles, uint32_t* out_bands);
 /* Sorted phases (mi_batch_sorted_build): phases up to `items` long take the single-workgroup kernel (one launch), longer ones the
- * tiled two-launch form over the whole chip.  Default 4096; 0 = always tiled, 0xFFFFFFFF = never. */
+ * tiled two-launch form over the whole chip.  Default 1024; 0 = always tiled, 0xFFFFFFFF = never. */
 int32_t mi_debug_set_sorted_one_wg_limit(mi_ctx* ctx, uint32_t items);
 /* The flags-first test of the light tile kernel under the static-scene rule (kernels_tree.hip): 0 = when few rows changed since the
  * last propagate (default), 1 = never, 2 = always. */

@@ -5,9 +5,9 @@
 #     (never combined with the trace domains gpurun refuses)
 # Raw output goes to gpurun_out/prof_<tag>/ (scratch); tools/summarize_profiles.py turns it into profiles/<tag>/ and
 # profiles/rocprof_summary.json (what bench.py quotes as rocprof_avg_kernel_us / traffic).
-TAG=${1:-r02}
+TAG=${1:-r03}
 shift
-WLS=${@:-frame flat flat_10m_1view flat_10m_4views tree lights flat_static batching}
+WLS=${@:-frame flat flat_10m_1view flat_10m_4views tree tree_subtree tree_leaves lights flat_static flat_static_no_sphere flat_static_10m_4views batching batching_sorted_64k batching_sorted_1m}
 export TMPDIR=/tmp
 P=gpurun_out/prof_$TAG
 mkdir -p $P
@@ -16,12 +16,18 @@ for wl in $WLS; do
   case $wl in
     flat_10m_1view)  ARGS="--workload flat --entities 10000000 --views 1" ;;
     flat_10m_4views) ARGS="--workload flat --entities 10000000 --views 4" ;;
+    tree_subtree)    ARGS="--workload tree --tree-moved subtree" ;;
+    tree_leaves)     ARGS="--workload tree --tree-moved leaves" ;;
+    flat_static_no_sphere)  ARGS="--workload flat_static --sphere-path 1" ;;
+    flat_static_10m_4views) ARGS="--workload flat_static --entities 10000000 --views 4" ;;
+    batching_sorted_64k)    ARGS="--workload batching_sorted --sorted-items 65536" ;;
+    batching_sorted_1m)     ARGS="--workload batching_sorted --sorted-items 1000000" ;;
     *)               ARGS="--workload $wl" ;;
   esac
   echo "python bench.py $ARGS --steps 50 --warmup 10 --blocks 4 $COMMON" > $P/$wl.cmd
   timeout -k 5 180 rocprofv3 --kernel-trace --stats --output-format csv -d $P/$wl -o $wl -- \
       python bench.py $ARGS --steps 50 --warmup 10 --blocks 4 $COMMON > $P/$wl.log 2>&1
-  if [ $wl = batching ] || [ $wl = lights ]; then continue; fi
+  case $wl in batching*|lights) continue ;; esac
   for ctr in FETCH_SIZE WRITE_SIZE; do
     timeout -k 5 180 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $P/${wl}_$ctr -o $wl -- \
         python bench.py $ARGS --steps 10 --warmup 2 --blocks 2 $COMMON > $P/${wl}_$ctr.log 2>&1

@@ -13,12 +13,14 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-workloads = sys.argv[2:] or ["frame", "flat", "flat_10m_1view", "flat_10m_4views", "tree", "lights", "flat_static", "batching"]
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+workloads = sys.argv[2:] or ["frame", "flat", "flat_10m_1view", "flat_10m_4views", "tree", "tree_subtree", "tree_leaves", "lights", "flat_static", "flat_static_no_sphere",
+                             "flat_static_10m_4views", "batching", "batching_sorted_64k", "batching_sorted_1m"]
 src = os.path.join("gpurun_out", f"prof_{tag}")
 dst = os.path.join("profiles", tag)
 os.makedirs(dst, exist_ok=True)
-ALIAS = {"k_frame<1": "k_flat_propagate_cull", "k_frame<2": "k_flat_propagate_cull", "k_frame<0": "k_cull",  # PROP: 1 all rows, 2 changed rows, 0 resident G (any INLINE_VIEWS / WITH_WALK variant)
+ALIAS = {"k_frame_sph<true": "k_flat_propagate_cull", "k_frame_sph<false": "k_cull",  # the world-sphere frame kernel: PARTIAL = the changed-rows frame, else cull only
+         "k_frame<1": "k_flat_propagate_cull", "k_frame<2": "k_flat_propagate_cull", "k_frame<0": "k_cull",  # PROP: 1 all rows, 2 changed rows, 0 resident G (any INLINE_VIEWS / WITH_WALK variant)
          "k_frame<true": "k_flat_propagate_cull", "k_frame<false": "k_cull",  # (profiles from before PROP was an int)
          "k_propagate_fans": "k_propagate_tiles"}  # the tile launch of mi_propagate, whichever tile kernel the plan uses
 

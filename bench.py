@@ -158,6 +158,9 @@ def build_frame(ctx, args):
                   "entities/sec through propagate+cull+cluster at 1M entities", "entities/s", rows=n_rows,
                   kernels=["k_flat_propagate_cull", "k_compact_fast", "k_cluster_walk", "k_cluster_fill"])
     wl.scene, wl.first_light, wl.pos_range, wl.frusta0, wl.keep = sc, first_light, pr, frames[0].array, (views, keep)
+    # "k_flat_propagate_cull" is the library's timer slot; the symbol rocprofv3 shows is the k_frame instantiation
+    # <PROPAGATE, INLINE_VIEWS, WITH_WALK>: the cluster walk rides in the launch unless it runs as calls or a stream of its own
+    wl.kernel_name = "k_frame<1,true,false>" if (separate or concurrent) else "k_frame<1,true,true>"
     return wl
 
 
@@ -218,6 +221,7 @@ def build_flat(ctx, args, rank, world, full_holder, n_global, n_views, name):
                   "k_cull" if args.unfused else "k_flat_propagate_cull", config, metric, "entities/s",
                   kernels=["k_cull" if args.unfused else "k_flat_propagate_cull", "k_compact_fast"])
     wl.scene, wl.n_views, wl.global_units = scene, n_views, n_global
+    wl.kernel_name = "k_frame<0>" if args.unfused else "k_frame<1,true,false>"  # the timer slot's name is not the symbol's
     return wl
 
 
@@ -263,7 +267,12 @@ def build_tree(ctx, args, rank=0, world=1):
                               + ("ONE node of level 5 moves (1 / 1024 of the tree follows)" if moved == "subtree" else "10 000 random leaves move")
                               + ": mi_upload_transforms_indexed + mi_propagate(MI_PROPAGATE_STATIC_OPT) = mark_dirty_trees + the tile launch",
                   "nodes": n_global, "moved_rows": int(len(rows)), "tile_plan": plan}
-        wl = Workload("tree_" + moved, step, tr["n"], 141.0, "k_propagate_tiles", config, "nodes/sec through change-driven hierarchy propagate", "nodes/s",
+        # algorithmic bytes of a change-driven tile launch: every tile's descriptor (64 B) and flags pre-test (chain change bytes + top
+        # marks, <= 136 B), plus the all-dirty 141 B for the rows that are re-evaluated (the moved rows' subtrees / the moved leaves and
+        # the marked ancestors' tiles are a superset: counted as the rows below the moved ones only -- a lower bound)
+        follows = (tr["n"] // 1024 if moved == "subtree" else len(rows))
+        alg = (plan["tiles"] * 200.0 + follows * 141.0) / tr["n"]
+        wl = Workload("tree_" + moved, step, tr["n"], alg, "k_propagate_tiles", config, "nodes/sec through change-driven hierarchy propagate", "nodes/s",
                       kernels=["k_propagate_tiles", "k_mark_dirty"])
         wl.tree = tr
         wl.kernel_name = "k_propagate_fans<false>"

@@ -21,8 +21,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fn
 # Per-file flags.  -fno-slp-vectorize on the row kernels: the SLP vectorizer pairs their independent f32 multiplies / adds into
 # v_pk_mul_f32 / v_pk_add_f32 (same IEEE results), and the operand pairs it has to assemble for them (v_pk_mov_b32 copies of
 # values that stay live in their scalar form as well) cost 8 - 12 VGPRs per kernel: k_frame 70 -> 62 (7 -> 8 waves per SIMD),
-# k_frame with the riding cluster walk 72 -> 64, k_propagate_fans<false> 72 -> 60 (7 -> 8), k_cluster_walk 59 -> 49
-# (tools/kernel_resources.py; profiles/r03a/kernel_resources.md).  The batching kernels are integer code and keep it.
+# k_propagate_fans<false> 72 -> 60 (7 -> 8)
+# (tools/kernel_resources.py; profiles/r03h/kernel_resources.md).  The batching kernels are integer code and keep it.
 FILE_FLAGS = {"kernels_flat.hip": ["-fno-slp-vectorize"], "kernels_tree.hip": ["-fno-slp-vectorize"],
               "kernels_cluster.hip": ["-fno-slp-vectorize"]}
 

@@ -1278,8 +1278,8 @@ hipError_t launch_batch_sorted(const SortedArgs& a, hipStream_t stream, void (*m
     if (mark) mark(mctx, K_BATCH_SORTED);
     // up to one_wg_limit items: one workgroup, one launch (latency); beyond: tiles over the whole chip, two launches
     if (a.n_items <= sorted_one_wg_limit || !partials) {
-        if (a.n_items <= 4096u) MI_LAUNCH(k_batch_sorted<256>, dim3(1), dim3(256), 0, stream, a);
-        else MI_LAUNCH(k_batch_sorted<1024>, dim3(1), dim3(1024), 0, stream, a);
+        // (a 1 024-thread build of this kernel spilled 118 registers and was no faster per item: longer phases go to the tiles)
+        MI_LAUNCH(k_batch_sorted<256>, dim3(1), dim3(256), 0, stream, a);
     } else {
         const uint32_t n_tiles = (a.n_items + SORTED_TILE - 1u) / SORTED_TILE;
         if (mark) mark(mctx, K_BATCH_SCAN);  // (timer slots: the partials under k_batch_scan, the tiles under k_batch_sorted)

@@ -476,9 +476,32 @@ __global__ void __launch_bounds__(256) k_frame_sph(Columns c, ViewSet vs, const 
         if (vis && cull && has_aabb) need |= 1u << v;
     }
     // ---- stage 2, survivors with an Aabb: intersects_obb -- only here are GlobalTransform and half extents touched ----
-    if (__ballot(need != 0u)) {
+    const unsigned long long need_m = __ballot(need != 0u);
+    if (need_m) {
+        // a lane of its own touches one or two 128-byte lines for its 48 bytes: from a quarter of the wave on, the wave's three
+        // contiguous KB through the transpose are fewer bytes (10 M rows x 4 views, a third of the rows owing some view the OBB
+        // test: 689 MB per launch with per-lane loads)
+        Affine g = {};
+        const bool dense = __popcll(need_m) >= 16;
+        if (dense) {
+            const float4* src = reinterpret_cast<const float4*>(c.global) + 3ull * wave_row0;
+            const uint32_t lim = (c.n - wave_row0 < 64u ? c.n - wave_row0 : 64u) * 3u;
+            float4* lds_wave = lds_g[wv];
+            MI_WAVE_LDS_SYNC();  // (the stale-sphere refresh above may have used the buffer)
+#pragma unroll
+            for (uint32_t k = 0; k < 3u; ++k) {
+                const uint32_t i = k * 64u + lane;
+                lds_wave[i] = src[i < lim ? i : lim - 1u];
+            }
+            MI_WAVE_LDS_SYNC();
+            const float4 a = lds_wave[lane * 3u], b = lds_wave[lane * 3u + 1u], cc = lds_wave[lane * 3u + 2u];
+            g.m.x_axis = V3{a.x, a.y, a.z};
+            g.m.y_axis = V3{a.w, b.x, b.y};
+            g.m.z_axis = V3{b.z, b.w, cc.x};
+            g.t = V3{cc.y, cc.z, cc.w};
+        }
         if (need) {
-            const Affine g = ld_affine(c.global, row);
+            if (!dense) g = ld_affine(c.global, row);
             const V3 half = ld3(c.aabb_half, row);
             for (uint32_t v = 0; v < n_views; ++v) {
                 if (!((need >> v) & 1u)) continue;

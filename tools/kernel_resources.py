@@ -2,11 +2,13 @@
     python tools/kernel_resources.py profiles/<tag>/kernel_resources.md"""
 import re, subprocess, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bevy_amd import build as mi_build  # the library's own flags, per-file ones included (FILE_FLAGS)
 out = []
 for f in ("kernels_flat.hip", "kernels_tree.hip", "kernels_cluster.hip", "kernels_batch.hip"):
-    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
-                        "-I" + os.path.join(ROOT, "include"), "-x", "hip", "-c", os.path.join(ROOT, "bevy_amd", "csrc", f), "-o", "/tmp/_kr.o",
-                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+    r = subprocess.run(["/opt/rocm/bin/hipcc"] + [x for x in mi_build.FLAGS if x != "-shared"] + mi_build.FILE_FLAGS.get(f, [])
+                       + ["-x", "hip", "-c", os.path.join(ROOT, "bevy_amd", "csrc", f), "-o", "/tmp/_kr.o",
+                          "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
     cur, d = None, {}
     for line in r.stderr.splitlines():
         m = re.search(r"Function Name: (\S+)", line)

@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", choices=["auto", "frame", "sharded", "flat", "tree", "lights", "flat_static", "batching", "batching_sorted"], default="auto",
                     help="auto = frame at N=1 (the BASELINE metric), sharded (configs[3]) at N>1")
+    ap.add_argument("--row-summary", type=int, default=0, choices=[0, 1],
+                    help="0 = waves whose 64 rows agree in Aabb / flags / RenderLayers read the 32-byte summary (default), 1 = off")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong", help="sharded workload: total rows fixed / rows per GPU fixed")
     ap.add_argument("--entities", type=int, default=0, help="frame/flat/tree: entities (default 1M); sharded: total (strong, default 10M) or per GPU (weak, default 1M)")
     ap.add_argument("--views", type=int, default=0, help="camera frusta (default 1; sharded: 4)")
@@ -87,6 +89,11 @@ def flat_bytes_per_entity(n_views, fused=True):
     return rd + wr
 
 
+# With the row summary (kernels.h RowSummary) a wave whose 64 rows agree in Aabb / flags / RenderLayers reads 32 bytes instead of
+# 64 x (24 + 1 + 4): what the kernel moves for such rows is 28.5 B less than the algorithmic figure, which stays SURVEY 8(d)'s.
+ROW_SUMMARY_SAVES = 29.0 - 32.0 / 64.0
+
+
 class Workload:
     """step(f) enqueues one frame; units = work items per frame on this rank; rows = rows the dominant kernel streams."""
 
@@ -115,7 +122,13 @@ def build_frame(ctx, args):
     cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
     ctx.resize(n_rows)
     ctx.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
-    ctx.upload_bounds(sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"])
+    # the lights' bounding Spheres follow their rows (MI_SPHERE_AT_TRANSLATION: what the plugin uploads, so that a moved light is
+    # not a bounds change): centre = the row's GlobalTransform translation = the position the scene (and the CPU baseline) holds
+    c_dev, h_dev = sc["aabb_center"].reshape(-1, 3).copy(), sc["aabb_half"].reshape(-1, 3).copy()
+    c_dev[first_light:] = 0.0
+    h_dev[first_light:, 1] = np.frombuffer(np.uint32(0x7FC0A11D).tobytes(), np.float32)[0]
+    ctx.debug_set_row_summary(args.row_summary)
+    ctx.upload_bounds(c_dev.reshape(-1), h_dev.reshape(-1), sc["flags"], sc["layers"])
     ctx.cluster_upload_objects(pr)
     ctx.cluster_bind_objects_to_rows(first_light, args.lights)
     frames, views, keep = [], [], []
@@ -153,7 +166,7 @@ def build_frame(ctx, args):
                              "re-derives the lights' ViewVisibility with the cull's rule and runs on the cluster stream next to the frame kernel"),
               "baseline_config": "BASELINE.json configs[1] + configs[2] in one frame; value counts the entities of configs[1] only",
               "entities": n_ent, "rows_per_frame": n_rows, "lights": args.lights, "meshes": args.meshes, "views": 1,
-              "deferred_compaction": bool(more), "parallelism": "1 GPU"}
+              "deferred_compaction": bool(more), "parallelism": "1 GPU", "row_summary": args.row_summary == 0}
     wl = Workload("frame", step, n_ent, flat_bytes_per_entity(1, True), "k_flat_propagate_cull", config,
                   "entities/sec through propagate+cull+cluster at 1M entities", "entities/s", rows=n_rows,
                   kernels=["k_flat_propagate_cull", "k_compact_fast", "k_cluster_walk", "k_cluster_fill"])
@@ -161,6 +174,8 @@ def build_frame(ctx, args):
     # "k_flat_propagate_cull" is the library's timer slot; the symbol rocprofv3 shows is the k_frame instantiation
     # <PROPAGATE, INLINE_VIEWS, WITH_WALK>: the cluster walk rides in the launch unless it runs as calls or a stream of its own
     wl.kernel_name = "k_frame<1,true,false>" if (separate or concurrent) else "k_frame<1,true,true>"
+    if args.row_summary == 0:
+        wl.layout_bytes_per_row = wl.bytes_per_row - ROW_SUMMARY_SAVES  # (every wave of this scene but three is uniform)
     return wl
 
 
@@ -177,6 +192,7 @@ def build_flat(ctx, args, rank, world, full_holder, n_global, n_views, name):
     scene = W.many_cubes(n_global, radius=radius, start=lo, count=n_local)
     ctx.resize(n_local)
     ctx.upload_transforms(scene["translation"], scene["rotation"], scene["scale"])
+    ctx.debug_set_row_summary(args.row_summary)
     ctx.upload_bounds(scene["aabb_center"], scene["aabb_half"], scene["flags"], scene["layers"])
     frames = [api.PreparedFrusta(camera_frusta(n_views, f)) for f in range(N_FRAMES)]
     gather = None
@@ -212,7 +228,7 @@ def build_flat(ctx, args, rank, world, full_holder, n_global, n_views, name):
                              f"ViewVisibility bitmasks per frame ({gather.mode})" if gather is not None else ""),
               "baseline_config": "BASELINE.json configs[3]" if name == "sharded" else "BASELINE.json configs[1]",
               "entities_total": n_global, "entities_this_rank": n_local, "views": n_views, "deferred_compaction": deferred,
-              "parallelism": f"row-range shard x{world}"}
+              "parallelism": f"row-range shard x{world}", "row_summary": args.row_summary == 0}
     if gather is not None and gather.fallback_reason:
         config["rccl_direct_fallback"] = gather.fallback_reason
     metric = ("entities/sec through propagate+cull (10M entities x 4 frusta, 1/2/4/8-GPU scaling)" if name == "sharded"
@@ -222,6 +238,8 @@ def build_flat(ctx, args, rank, world, full_holder, n_global, n_views, name):
                   kernels=["k_cull" if args.unfused else "k_flat_propagate_cull", "k_compact_fast"])
     wl.scene, wl.n_views, wl.global_units = scene, n_views, n_global
     wl.kernel_name = "k_frame<0>" if args.unfused else "k_frame<1,true,false>"  # the timer slot's name is not the symbol's
+    if args.row_summary == 0:
+        wl.layout_bytes_per_row = wl.bytes_per_row - ROW_SUMMARY_SAVES
     return wl
 
 
@@ -326,6 +344,7 @@ def build_flat_static(ctx, args):
     sc = W.many_cubes(n, radius=500.0 * (n / 1_000_000.0) ** (1.0 / 3.0))  # configs[3]'s scaling: the density stays
     ctx.resize(n)
     ctx.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
+    ctx.debug_set_row_summary(args.row_summary)
     ctx.upload_bounds(sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"])
     ctx.upload_changed(np.zeros(n, np.uint8))  # the change column exists from here on: only marked rows are recomputed
     ctx.propagate(B.PROPAGATE_ALL_DIRTY)
@@ -352,6 +371,9 @@ def build_flat_static(ctx, args):
     wl = Workload("flat_static", step, n, models["world_sphere_column" if sphere else "global_transform_resident"], "k_cull", config,
                   "entities/sec through propagate+cull", "entities/s", kernels=["k_cull", "k_compact_fast"])
     wl.kernel_name = "k_frame_sph<false>" if sphere else "k_frame<0>"
+    if args.row_summary == 0:  # the sphere path reads flags + layers per row (5 B), the resident-G path Aabb as well
+        wl.layout_bytes_per_row = wl.bytes_per_row - ((5.0 - 0.5) if sphere else ROW_SUMMARY_SAVES)
+    config["row_summary"] = args.row_summary == 0
     return wl
 
 
@@ -517,6 +539,14 @@ def roofline_of(wl, prof, steps):
            "launches": dk["launches"], "algorithmic_bytes_per_launch": int(alg_bytes),
            "timing": f"per-dispatch start/stop events (hipExtLaunchKernelGGL) on every launch of {PROFILED_BLOCKS} profiled blocks of "
                      f"{steps} steps that follow the timed blocks"}
+    lay = getattr(wl, "layout_bytes_per_row", None)
+    if lay is not None:
+        # `achieved` / `frac` price the launch at SURVEY 8(d)'s algorithmic bytes, as the contract says; the layout reads less than
+        # that (row summary), so the same launch is also priced at the bytes it is laid out to move -- compare `traffic` with these
+        out["layout_bytes_per_launch"] = int(lay * wl.rows)
+        out["frac_of_layout_bytes"] = round(lay * wl.rows / avg_s / 1e9 / HBM_PEAK_GBPS, 4)
+        out["layout_note"] = ("waves whose 64 rows agree in Aabb / flags / RenderLayers read a 32-byte summary instead of 64 x 29 B of "
+                              "columns (bit-identical results; --row-summary 1 switches it off)")
     ev = load_profiles().get(getattr(wl, "profile_key", wl.name), {}).get(wl.dominant)
     if ev:
         if ev.get("hbm_bytes_per_launch"):
@@ -903,7 +933,9 @@ def main():
     if rank == 0 and world == 1 and workload == "frame" and not args.no_other_workloads:
         # the other BASELINE configs, measured briefly on fresh contexts so the one line carries every stage
         others = {}
-        specs = [("flat", lambda c: build_flat(c, args, 0, 1, [], args.entities or 1_000_000, 1, "flat")),
+        specs = [("frame_plain_columns", lambda c: build_frame(c, with_args(args, row_summary=1))),  # the metric frame, every row reading its own Aabb / flags / layers
+                 ("flat", lambda c: build_flat(c, args, 0, 1, [], args.entities or 1_000_000, 1, "flat")),
+                 ("flat_plain_columns", lambda c: build_flat(c, with_args(args, row_summary=1), 0, 1, [], args.entities or 1_000_000, 1, "flat")),
                  ("flat_10m_4views", lambda c: build_flat(c, args, 0, 1, [], 10_000_000, 4, "sharded")),
                  ("flat_10m_1view", lambda c: build_flat(c, args, 0, 1, [], 10_000_000, 1, "flat")),
                  ("tree", lambda c: build_tree(c, args)), ("tree_one_subtree_moves", lambda c: build_tree(c, with_args(args, tree_moved="subtree"))),

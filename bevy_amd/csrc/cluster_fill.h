@@ -47,14 +47,14 @@ __device__ __forceinline__ void cluster_fill_block(const ClusterWork& w, uint32_
         if (lane >= off) incl += up;
     }
     if (lane == 63u) part[wv] = incl;
-    __syncthreads();
+    MI_WG_LDS_BARRIER();
     uint32_t before = incl - sum;
 #pragma unroll
     for (uint32_t k = 0; k < 4u; ++k) before += k < wv ? part[k] : 0u;
     const uint32_t grand = part[0] + part[1] + part[2] + part[3];
 #pragma unroll
     for (uint32_t k = 0; k < 16; ++k) offs[tid * 16u + k] = before + loc[k];
-    __syncthreads();
+    MI_WG_LDS_BARRIER();
     if (bx == 0) {
         for (uint32_t c = tid; c < C; c += 256u) w.offsets[c] = offs[c];
         if (tid == 0) {

@@ -10,6 +10,17 @@
 
 namespace mi {
 
+#ifdef MI_EXP_TIMELINE
+// (experiment build) phase timestamps of the walking workgroups: [8b + k], see tools/exp_timeline.py
+__device__ unsigned long long mi_walk_marks[16 * 4096];
+#define MI_WALK_MARK(b, k)                                                                  \
+    do {                                                                                    \
+        if (threadIdx.x == 0 && (b) < 4096u) mi_walk_marks[16u * (b) + (k)] = wall_clock64(); \
+    } while (0)
+#else
+#define MI_WALK_MARK(b, k)
+#endif
+
 
 // glibc >= 2.28 logf (ARM optimized-routines algorithm, table size 16, degree-3 polynomial in
 // double).  Rust's f32::ln is the platform libm's logf (bevy_math/src/ops.rs:22-60), so this is the
@@ -25,7 +36,9 @@ static __device__ __constant__ double LOGF_TAB[16][2] = {
     {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3},
     {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},  {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
 
-__device__ __forceinline__ float libm_logf(float x) {
+// tab: the 16 x 2 table -- LOGF_TAB itself, or a copy (the walk keeps one in LDS: read from memory the table is a round trip per
+// call, microseconds while the frame's rows keep HBM busy)
+__device__ __forceinline__ float libm_logf(float x, const double* tab = &LOGF_TAB[0][0]) {
     uint32_t ix = __float_as_uint(x);
     if (ix == 0x3f800000u) return 0.0f;
     if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
@@ -39,7 +52,7 @@ __device__ __forceinline__ float libm_logf(float x) {
     const int i = (int)((tmp >> 19) & 15u);
     const int k = (int32_t)tmp >> 23;
     const uint32_t iz = ix - (tmp & 0xff800000u);
-    const double invc = LOGF_TAB[i][0], logc = LOGF_TAB[i][1];
+    const double invc = tab[2 * i], logc = tab[2 * i + 1];
     const double z = (double)__uint_as_float(iz);
     const double r = z * invc - 1.0;
     const double y0 = logc + (double)k * 0x1.62e42fefa39efp-1;
@@ -55,22 +68,22 @@ struct Sphere {
 };
 
 // view_z_to_z_slice, assign.rs:1046-1062
-__device__ __forceinline__ uint32_t view_z_to_z_slice(const ClusterViewDev& v, float view_z) {
+__device__ __forceinline__ uint32_t view_z_to_z_slice(const ClusterViewDev& v, float view_z, const double* logf_tab) {
     uint32_t z_slice;
     if (v.is_orthographic) z_slice = f32_as_u32(floorf((view_z - v.cluster_factors[0]) * v.cluster_factors[1]));
-    else z_slice = f32_as_u32(libm_logf(-view_z) * v.cluster_factors[0] - v.cluster_factors[1] + 1.0f);
+    else z_slice = f32_as_u32(libm_logf(-view_z, logf_tab) * v.cluster_factors[0] - v.cluster_factors[1] + 1.0f);
     const uint32_t lim = v.dims[2] - 1u;
     return z_slice < lim ? z_slice : lim;
 }
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return lane_min(lane_max(x, lo), hi); }
 // ndc_position_to_cluster, assign.rs:922-941
 __device__ __forceinline__ void ndc_position_to_cluster(const ClusterViewDev& v, float ndc_x, float ndc_y, float view_z,
-                                                        uint32_t out[3]) {
+                                                        uint32_t out[3], const double* logf_tab) {
     const float fx = clampf(ndc_x * 0.5f + 0.5f, 0.0f, 1.0f);
     const float fy = clampf(ndc_y * -0.5f + 0.5f, 0.0f, 1.0f);
     const uint32_t xi = f32_as_u32(floorf(fx * (float)v.dims[0]));
     const uint32_t yi = f32_as_u32(floorf(fy * (float)v.dims[1]));
-    const uint32_t zs = view_z_to_z_slice(v, view_z);
+    const uint32_t zs = view_z_to_z_slice(v, view_z, logf_tab);
     out[0] = xi > v.dims[0] - 1u ? v.dims[0] - 1u : xi;
     out[1] = yi > v.dims[1] - 1u ? v.dims[1] - 1u : yi;
     out[2] = zs > v.dims[2] - 1u ? v.dims[2] - 1u : zs;
@@ -133,52 +146,63 @@ __device__ __forceinline__ Affine object_row_affine(const ClusterObjects& o, uin
     }
     return load_affine(o.row_global + 12ull * row);
 }
-// ClusterableObjectAssignmentData::sphere (assign.rs:52-59): (x, y, z, range).  Row-bound objects take the centre from
-// their row's GlobalTransform (point lights: GlobalTransform::from_translation(transform.translation()), :198).
-__device__ __forceinline__ float4 object_sphere(const ClusterObjects& o, uint32_t obj) {
-    float4 pr = reinterpret_cast<const float4*>(o.pos_range)[obj];
-    if (o.derive && object_row_is_propagated(o, object_row(o, obj))) {
-        const V3 t = ld3c(o.row_translation, object_row(o, obj));
-        pr.x = t.x;
-        pr.y = t.y;
-        pr.z = t.z;
-    } else if (o.row_global) {
-        const float* g = o.row_global + 12ull * object_row(o, obj);
-        pr.x = g[9];
-        pr.y = g[10];
-        pr.z = g[11];
-    }
-    return pr;
-}
 // ViewVisibility::get() of a light row after this frame's visibility systems, without waiting for them: reset, then
 // set_visible() by any view of the frame (check_visibility_cpu_culling, visibility/mod.rs:788-858), or -- NoCpuCulling rows --
 // check_visibility_gpu_culling (:884-903).
-__device__ __forceinline__ bool derive_row_visible(const ClusterObjects& o, const ViewSet& views, uint32_t row) {
+// Every load of the row is issued in ONE batch, whether the row turns out to need it or not (a NoCpuCulling row never reads its
+// bounds): riding in the frame kernel a round trip to memory costs microseconds -- the rows of the launch keep HBM saturated --
+// and flags -> Transform -> sphere as three dependent trips were most of what the walk added to the frame.  *g_out = the
+// GlobalTransform the frame gives the row.
+__device__ __forceinline__ bool derive_row_visible(const ClusterObjects& o, const ViewSet& views, uint32_t row, Affine* g_out) {
     const uint32_t fl = o.row_flags[row];
-    if (fl & 0x10u) return (fl & 0x01u) != 0;
-    const Affine g = object_row_affine(o, row);
-    const V3 center = ld3c(o.row_aabb_center, row), half = ld3c(o.row_aabb_half, row);
     const uint32_t emask = o.row_layers[row];
+    const V3 center = ld3c(o.row_aabb_center, row), half = ld3c(o.row_aabb_half, row);
+    Affine g;
+    if (o.derive_resident) {  // (uniform) a cull-only frame: every row keeps its resident GlobalTransform
+        g = load_affine(o.row_global + 12ull * row);
+    } else if (!o.row_changed) {  // (uniform) the all-rows frame: From(Transform)
+        const float4 q = reinterpret_cast<const float4*>(o.row_rotation)[row];
+        g = affine_from_srt(ld3c(o.row_scale, row), V4{q.x, q.y, q.z, q.w}, ld3c(o.row_translation, row));
+    } else {  // the changed-rows frame: one more trip, by the row's change byte
+        g = object_row_affine(o, row);
+    }
     float range_lo = 0.0f, range_hi = 0.0f;
     if (o.row_range && (fl & 0x20u)) {
         const float2 r2 = reinterpret_cast<const float2*>(o.row_range)[row];
         range_lo = r2.x;
         range_hi = r2.y;
     }
+    *g_out = g;
+    if (fl & 0x10u) return (fl & 0x01u) != 0;
     bool any = false;
     for (uint32_t v = 0; v < o.n_views; ++v)
         any = any || row_visible_in_view(g, center, half, fl, emask, o.row_range != nullptr, range_lo, range_hi, views.v[v]);
     return any;
 }
-__device__ __forceinline__ bool object_in_view(const ClusterViewDev& v, const ClusterObjects& o, const ViewSet& views, uint32_t obj) {
-    // the gather's `if view_visibility.get()`, assign.rs:194
-    if (o.derive) {
-        if (!derive_row_visible(o, views, object_row(o, obj))) return false;
-    } else if (o.row_vv && !(o.row_vv[object_row(o, obj)] & 1u)) {
-        return false;
-    }
-    const float4 pr = object_sphere(o, obj);
+// The two early-outs at the top of the per-object loop (assign.rs:489 RenderLayers, :496 frustum vs light sphere) behind the
+// gather's `if view_visibility.get()` (:194).  *sphere_out = ClusterableObjectAssignmentData::sphere of the object, which the
+// caller keeps: the walk needs it again, and fetching it again is one more trip.
+__device__ __forceinline__ bool object_in_view(const ClusterViewDev& v, const ClusterObjects& o, const ViewSet& views, uint32_t obj, float4* sphere_out) {
+    float4 pr = reinterpret_cast<const float4*>(o.pos_range)[obj];  // (issued with the row's loads below)
     const uint32_t layers = o.layer_mask ? o.layer_mask[obj] : 1u;
+    bool visible = true;
+    if (o.derive) {
+        Affine g;
+        visible = derive_row_visible(o, views, object_row(o, obj), &g);
+        pr.x = g.t.x;  // point lights: GlobalTransform::from_translation(transform.translation()), assign.rs:198
+        pr.y = g.t.y;
+        pr.z = g.t.z;
+    } else {
+        if (o.row_vv) visible = (o.row_vv[object_row(o, obj)] & 1u) != 0;
+        if (o.row_global) {
+            const float* g = o.row_global + 12ull * object_row(o, obj);
+            pr.x = g[9];
+            pr.y = g[10];
+            pr.z = g[11];
+        }
+    }
+    *sphere_out = pr;
+    if (!visible) return false;
     if (!(v.view_layer_mask & layers)) return false;  // :489
     V4 fr[6];
 #pragma unroll
@@ -200,10 +224,31 @@ struct ObjectWalk {
     bool z_center_some, y_center_some;
 };
 
+// The z part of object_setup alone -- the z slices the object's cluster-space AABB spans (the same expressions, :948-1036) and its
+// far_z (:558-560): what a chunked walk needs of every object before its z loop, at a fraction of the arithmetic of the whole setup.
+__device__ __forceinline__ void object_z_extent(const ClusterViewDev& v, float4 pr, uint32_t* z_lo, uint32_t* z_hi, float* far_z_out,
+                                                const double* logf_tab) {
+    const V3 center = V3{pr.x, pr.y, pr.z};
+    const float range = pr.w;
+    const M4 view_from_world = load_m4(v.view_from_world);
+    const V3 scale = V3{v.view_from_world_scale[0], v.view_from_world_scale[1], v.view_from_world_scale[2]};
+    const V3 cv = xyz(mul(view_from_world, extend(center, 1.0f)));
+    const V3 he = abs3(scale) * range;
+    const float NEG_MIN_POS = -1.17549435e-38f;
+    const float zmin = rust_min((cv - he).z, NEG_MIN_POS), zmax = rust_min((cv + he).z, NEG_MIN_POS);
+    const uint32_t lim = v.dims[2] - 1u;
+    uint32_t a = view_z_to_z_slice(v, zmin, logf_tab), b = view_z_to_z_slice(v, zmax, logf_tab);
+    a = a > lim ? lim : a;
+    b = b > lim ? lim : b;
+    *z_lo = a < b ? a : b;
+    *z_hi = a > b ? a : b;
+    *far_z_out = -dot4(row(view_from_world, 2), extend(center, 1.0f)) + range * scale.z;
+}
+
 template <bool SPOTS = true>
-__device__ __forceinline__ ObjectWalk object_setup(const ClusterViewDev& v, const ClusterObjects& o, uint32_t obj, float* far_z_out) {
+__device__ __forceinline__ ObjectWalk object_setup(const ClusterViewDev& v, const ClusterObjects& o, uint32_t obj, float4 pr, float* far_z_out,
+                                                   const double* logf_tab) {
     ObjectWalk ow;
-    const float4 pr = object_sphere(o, obj);
     const V3 center = V3{pr.x, pr.y, pr.z};
     const float range = pr.w;
     ow.range = range;
@@ -230,8 +275,8 @@ __device__ __forceinline__ ObjectWalk object_setup(const ClusterViewDev& v, cons
         else { nmin = min3(nmin, ndc); nmax = max3(nmax, ndc); }
     }
     uint32_t c0[3], c1[3];
-    ndc_position_to_cluster(v, clampf(nmin.x, -1.0f, 1.0f), clampf(nmin.y, -1.0f, 1.0f), vmin.z, c0);
-    ndc_position_to_cluster(v, clampf(nmax.x, -1.0f, 1.0f), clampf(nmax.y, -1.0f, 1.0f), vmax.z, c1);
+    ndc_position_to_cluster(v, clampf(nmin.x, -1.0f, 1.0f), clampf(nmin.y, -1.0f, 1.0f), vmin.z, c0, logf_tab);
+    ndc_position_to_cluster(v, clampf(nmax.x, -1.0f, 1.0f), clampf(nmax.y, -1.0f, 1.0f), vmax.z, c1, logf_tab);
 #pragma unroll
     for (int k = 0; k < 3; ++k) { ow.minc[k] = c0[k] < c1[k] ? c0[k] : c1[k]; ow.maxc[k] = c0[k] > c1[k] ? c0[k] : c1[k]; }
 
@@ -261,7 +306,7 @@ __device__ __forceinline__ ObjectWalk object_setup(const ClusterViewDev& v, cons
     const V3 ndc = V3{f_div(center_clip.x, center_clip.w), f_div(center_clip.y, center_clip.w),
                       f_div(center_clip.z, center_clip.w)};
     uint32_t cc[3];
-    ndc_position_to_cluster(v, ndc.x, ndc.y, ow.vs.center.z, cc);
+    ndc_position_to_cluster(v, ndc.x, ndc.y, ow.vs.center.z, cc, logf_tab);
     ow.z_center_some = ndc.z <= 1.0f;
     ow.z_center = cc[2];
     ow.y_center = 0;
@@ -346,7 +391,8 @@ __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, cons
     const uint32_t RC = dxy * zc;  // rows of one chunk
     uint32_t* rows = arena;
     uint32_t* type_rows = rows + RC * 8u;
-    float* planes = reinterpret_cast<float*>(type_rows + 48u);
+    double* logf_tab = reinterpret_cast<double*>(type_rows + 48u);  // 32 doubles: the table of libm_logf
+    float* planes = reinterpret_cast<float*>(logf_tab + 32);
     const uint32_t nx = v.dims[0] + 1u, ny = v.dims[1] + 1u, nz = dz + 1u;
     uint32_t* touched_bits = reinterpret_cast<uint32_t*>(planes + (PLANES_IN_LDS ? 4u * (nx + ny + nz) : 0u));
     uint32_t* n_touched = touched_bits + ((RC + 31u) >> 5);
@@ -358,8 +404,23 @@ __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, cons
 
     // Most blocks of a big light set see nothing of it in this view: test first, and leave before touching LDS.
     const uint32_t obj = bx * CLUSTER_BLOCK + threadIdx.x;
-    const bool in_view = obj < o.n && object_in_view(v, o, views, obj);
+    float4 sphere = make_float4(0.f, 0.f, 0.f, 0.f);
+    // the plane tables are requested together with the objects' loads (they are contiguous in device memory: x | y | z)
+    float plane_regs[PLANES_IN_LDS ? 4 : 1] = {};
+    if (PLANES_IN_LDS) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const uint32_t i = threadIdx.x + k * CLUSTER_BLOCK;
+            if (i < 4u * (nx + ny + nz)) plane_regs[k] = v.x_planes[i];
+        }
+    }
+    MI_WALK_MARK(bx, 0);
+    const double logf_reg = (&LOGF_TAB[0][0])[threadIdx.x & 31u];
+    // (the barriers below order LDS only: a __syncthreads() also waits for every global store and atomic in flight -- the far_z
+    // atomic, the pair stores of the previous chunk --, a round trip of microseconds each while the frame's rows load HBM)
+    const bool in_view = obj < o.n && object_in_view(v, o, views, obj, &sphere);
     if (!__syncthreads_or(in_view ? 1 : 0)) return;
+    MI_WALK_MARK(bx, 1);
 
     auto clear_chunk = [&]() {
         uint4* z4 = reinterpret_cast<uint4*>(rows);
@@ -369,20 +430,34 @@ __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, cons
     if (threadIdx.x < 48u) type_rows[threadIdx.x] = 0u;
     if (CHUNKED && threadIdx.x == 0) { z_range[0] = 0xFFFFFFFFu; z_range[1] = 0u; }
     if (!CHUNKED) clear_chunk();
-    // the three plane tables are contiguous in device memory (x | y | z)
-    if (PLANES_IN_LDS)
-        for (uint32_t i = threadIdx.x; i < 4u * (nx + ny + nz); i += CLUSTER_BLOCK) planes[i] = v.x_planes[i];
-    __syncthreads();
+    if (threadIdx.x < 32u) logf_tab[threadIdx.x] = logf_reg;
+    if (PLANES_IN_LDS) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const uint32_t i = threadIdx.x + k * CLUSTER_BLOCK;
+            if (i < 4u * (nx + ny + nz)) planes[i] = plane_regs[k];
+        }
+        for (uint32_t i = threadIdx.x + 4u * CLUSTER_BLOCK; i < 4u * (nx + ny + nz); i += CLUSTER_BLOCK) planes[i] = v.x_planes[i];  // (grids beyond 255 planes)
+    }
+    MI_WG_LDS_BARRIER();
+    MI_WALK_MARK(bx, 8);
 
     const uint32_t word = threadIdx.x >> 5, bit = 1u << (threadIdx.x & 31u);
     ObjectWalk ow = {};
     uint32_t my_lo = 0xFFFFFFFFu, my_hi = 0u;
     if (in_view) {
         float far_z = 0.0f;
-        ow = object_setup<SPOTS>(v, o, obj, &far_z);
-        my_lo = ow.minc[2];
-        my_hi = ow.maxc[2];
-        atomicOr(&type_rows[(ow.type < 6u ? ow.type : 5u) * 8u + word], bit);
+        uint32_t type = 0u;
+        if (CHUNKED) {  // the whole setup is computed inside the chunk loop: here only what the loop's bounds need
+            object_z_extent(v, sphere, &my_lo, &my_hi, &far_z, logf_tab);
+            type = o.obj_type ? o.obj_type[obj] : 0u;
+        } else {
+            ow = object_setup<SPOTS>(v, o, obj, sphere, &far_z, logf_tab);
+            my_lo = ow.minc[2];
+            my_hi = ow.maxc[2];
+            type = ow.type;
+        }
+        atomicOr(&type_rows[(type < 6u ? type : 5u) * 8u + word], bit);
         // farthest_z = farthest_z.max(this_object_far_z), starting from 0.0 (assign.rs:421,561):
         // only positive values can raise it, and positive floats order like their bit patterns.
         if (far_z > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(w.farthest_z), __float_as_uint(far_z));
@@ -397,21 +472,23 @@ __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, cons
             hi = hi2 > hi ? hi2 : hi;
         }
         if ((threadIdx.x & 63u) == 0) { atomicMin(&z_range[0], lo); atomicMax(&z_range[1], hi); }
-        __syncthreads();
+        MI_WG_LDS_BARRIER();
+        MI_WALK_MARK(bx, 9);
         bz0 = z_range[0];
         bz1 = z_range[1];
     }
     for (uint32_t z0 = bz0; z0 <= bz1 && z0 < dz; z0 += zc) {  // chunks start at the block's own first slice
         if (CHUNKED) {
             clear_chunk();
-            __syncthreads();
+            MI_WG_LDS_BARRIER();
+            MI_WALK_MARK(bx, 10);
         }
         if (in_view && my_lo <= z0 + zc - 1u && my_hi >= z0) {
             if (CHUNKED) {  // recomputed, not carried across the loop (see above); the asm keeps the compiler from hoisting it back out
                 float unused;
-                uint32_t obj_again = obj;
-                asm volatile("" : "+v"(obj_again));
-                ow = object_setup<SPOTS>(v, o, obj_again, &unused);
+                float4 sphere_again = sphere;  // (the sphere itself stays in registers: fetching it again would be a trip per chunk)
+                asm volatile("" : "+v"(sphere_again.x), "+v"(sphere_again.y), "+v"(sphere_again.z), "+v"(sphere_again.w));
+                ow = object_setup<SPOTS>(v, o, obj, sphere_again, &unused, logf_tab);
             }
             object_walk<SPOTS>(v, ow, z0, z0 + zc - 1u, xp, yp, zp, [&](uint32_t xy, uint32_t z) {
                 const uint32_t r = xy * zc + (z - z0);
@@ -421,7 +498,8 @@ __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, cons
                     touched_list[atomicAdd(n_touched, 1u)] = (uint16_t)r;  // first toucher records the row
             });
         }
-        __syncthreads();
+        MI_WG_LDS_BARRIER();
+        MI_WALK_MARK(bx, 2);
 
         // Epilogue over the rows this workgroup touched in the chunk (a list kept next to the bit rows, so nothing is swept):
         // every touched row becomes a (cluster, block, 256-bit mask) pair in ONE global list -- the group reserves its
@@ -429,7 +507,8 @@ __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, cons
         // are distributed.  Only non-empty entries of the (cluster, block) count matrix are written.
         const uint32_t nt = *n_touched;
         if (threadIdx.x == 0) z_range[2] = nt ? atomicAdd(w.pair_total, nt) : 0u;
-        __syncthreads();
+        MI_WG_LDS_BARRIER();
+        MI_WALK_MARK(bx, 3);
         const uint32_t pair_base = z_range[2];
         for (uint32_t i = threadIdx.x; i < nt; i += CLUSTER_BLOCK) {
             const uint32_t r = touched_list[i];
@@ -443,7 +522,8 @@ __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, cons
             atomicAdd(&w.totals[c], cnt);
             // (The compiler hoists the 48 type-mask words out of this loop into registers: they are the register peak of the walk,
             // 88 VGPRs.  Reading them per row instead brings the walk to 63 and the frame kernel that carries it from 5 to 7 waves
-            // per SIMD -- and measured SLOWER: metric frame 26.3 against 24.8 us, walk kernel 17.1 against 15.2 (profiles/r03b).  The
+            // per SIMD -- and measured SLOWER, twice: metric frame 26.3 against 24.8 us, walk kernel 17.1 against 15.2 (profiles/r03b); with
+            // the row summary 24.6 against 22.3 (profiles/r03_experiments.md).  The
             // walk is a chain of dependent round trips, not a throughput problem: with the high-water mark at 88 the scheduler
             // spends registers on overlapping the loads of the whole kernel; at 63 it schedules for occupancy nobody needs.)
 #pragma unroll
@@ -458,9 +538,14 @@ __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, cons
             reinterpret_cast<uint4*>(w.pair_mask)[(size_t)slot * 2u] = lo;
             reinterpret_cast<uint4*>(w.pair_mask)[(size_t)slot * 2u + 1u] = hi;
         }
+        MI_WALK_MARK(bx, 4);
+#ifdef MI_EXP_TIMELINE
+        if (threadIdx.x == 0 && bx < 4096u) { mi_walk_marks[16u * bx + 5u] = nt; mi_walk_marks[16u * bx + 6u] += 1; }
+#endif
         if (!CHUNKED) break;
-        __syncthreads();  // the next chunk zeroes the rows
+        MI_WG_LDS_BARRIER();  // the next chunk zeroes the rows
     }
+    MI_WALK_MARK(bx, 7);
 }
 
 }  // namespace mi

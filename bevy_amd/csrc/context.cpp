@@ -180,7 +180,54 @@ Columns columns_of(mi_ctx* ctx) {
     c.g_changed_bits = ctx->g_chg_bits;
     c.vv_changed_bits = ctx->vv_chg_bits;
     c.changed_gen = ctx->changed_gen;
+    const bool rs_current = ctx->rs_lo[0] >= ctx->rs_hi[0] && ctx->rs_lo[1] >= ctx->rs_hi[1];
+    c.row_summary = (const uint32_t*)ctx->row_sum.p;
+    c.row_summary_on = (ctx->row_sum_mode == 0 && ctx->row_sum.p && rs_current) ? 1u : 0u;
     return c;
+}
+
+void row_summary_touch(mi_ctx* ctx, uint32_t parts, uint32_t first_row, uint32_t n_rows) {
+    if (n_rows == 0) return;
+    const uint32_t lo = first_row >> 6, hi = (uint32_t)(((uint64_t)first_row + n_rows + 63u) >> 6);
+    for (uint32_t p = 0; p < 2u; ++p) {
+        if (!(parts & (1u << p))) continue;
+        if (ctx->rs_lo[p] >= ctx->rs_hi[p]) {
+            ctx->rs_lo[p] = lo;
+            ctx->rs_hi[p] = hi;
+        } else {
+            ctx->rs_lo[p] = std::min(ctx->rs_lo[p], lo);
+            ctx->rs_hi[p] = std::max(ctx->rs_hi[p], hi);
+        }
+    }
+}
+
+int32_t row_summary_ensure(mi_ctx* ctx) {
+    if (ctx->n == 0) return MI_OK;
+    const uint32_t n_waves = (uint32_t)words64(ctx->n);
+    const size_t bytes = (size_t)words64(ctx->cap) * ROWSUM_WORDS * 4;
+    if (!ctx->row_sum.p || ctx->row_sum.bytes < bytes) {
+        int32_t rc = ensure(ctx, ctx->row_sum, bytes);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->row_sum.p, 0, ctx->row_sum.bytes, ctx->stream));
+        ctx->rs_lo[0] = ctx->rs_lo[1] = 0;
+        ctx->rs_hi[0] = ctx->rs_hi[1] = n_waves;
+    }
+    if (ctx->row_sum_mode != 0) return MI_OK;  // (allocated all the same: the frame kernels' load of it is unconditional)
+    uint32_t lo[2], hi[2];
+    for (uint32_t p = 0; p < 2u; ++p) {
+        lo[p] = std::min(ctx->rs_lo[p], n_waves);
+        hi[p] = std::min(ctx->rs_hi[p], n_waves);
+    }
+    Columns c = columns_of(ctx);
+    uint32_t* sum = (uint32_t*)ctx->row_sum.p;
+    if (lo[0] < hi[0] && lo[1] < hi[1] && lo[0] == lo[1] && hi[0] == hi[1]) {
+        HIP_TRY(ctx, launch_row_summary(c, lo[0], hi[0] - lo[0], ROWSUM_PART_AABB | ROWSUM_PART_FLAGS, sum, ctx->stream));
+    } else {
+        if (lo[0] < hi[0]) HIP_TRY(ctx, launch_row_summary(c, lo[0], hi[0] - lo[0], ROWSUM_PART_AABB, sum, ctx->stream));
+        if (lo[1] < hi[1]) HIP_TRY(ctx, launch_row_summary(c, lo[1], hi[1] - lo[1], ROWSUM_PART_FLAGS, sum, ctx->stream));
+    }
+    ctx->rs_lo[0] = ctx->rs_lo[1] = ctx->rs_hi[0] = ctx->rs_hi[1] = 0;
+    return MI_OK;
 }
 
 static_assert(sizeof(mi_view) == sizeof(ViewParams), "mi_view and ViewParams share one layout");
@@ -416,6 +463,7 @@ static int32_t cull_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, u
     if ((rc = prepare_views(ctx, views, n_views, &vo))) return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
     SegOut seg;
     if ((rc = prepare_segments(ctx, n_views, &seg))) return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
+    if ((rc = row_summary_ensure(ctx))) return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
     Columns c = columns_of(ctx);
     // MI_CULL_WITH_CLUSTERS: the assignment runs behind the frame kernel and reads the ViewVisibility column -- or, with
     // MI_CULL_CLUSTERS_CONCURRENT on a call that decides the frame's ViewVisibility alone, re-derives it and runs on the cluster
@@ -594,7 +642,7 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
                     ctx->bt_kind, ctx->bt_cpu_bin, ctx->bt_bucket};
     for (void* p : cols)
         if (p) hipFree(p);
-    DevBuf* bufs[] = {&ctx->sph, &ctx->order, &ctx->chains, &ctx->snap, &ctx->tree_trace, &ctx->inh_bits, &ctx->sparse_cnt, &ctx->sparse_rows, &ctx->sparse_total, &ctx->sparse_g, &ctx->parent_idx, &ctx->node_flags, &ctx->tiles, &ctx->views,
+    DevBuf* bufs[] = {&ctx->sph, &ctx->row_sum, &ctx->order, &ctx->chains, &ctx->snap, &ctx->tree_trace, &ctx->inh_bits, &ctx->sparse_cnt, &ctx->sparse_rows, &ctx->sparse_total, &ctx->sparse_g, &ctx->parent_idx, &ctx->node_flags, &ctx->tiles, &ctx->views,
                       &ctx->block_counts, &ctx->seg_bases, &ctx->out_keys, &ctx->cl_pos,
                       &ctx->cl_type, &ctx->cl_layers, &ctx->cl_dir, &ctx->cl_sincos, &ctx->cl_planes, &ctx->cl_spheres,
                       &ctx->bt_set_indexed, &ctx->bt_table_off, &ctx->bt_table, &ctx->bt_meta_off, &ctx->bt_meta, &ctx->bt_rows_a, &ctx->bt_rows_b,
@@ -676,7 +724,11 @@ int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
     }
     ctx->bt_resolve = true;
     ctx->changed_maybe = true;
-    if (n_rows != ctx->n) ctx->sph_state = mi_ctx::SPH_INVALID;
+    if (n_rows != ctx->n) {
+        ctx->sph_state = mi_ctx::SPH_INVALID;
+        const uint32_t a = std::min(n_rows, ctx->n) & ~63u, b = std::max(n_rows, ctx->n);  // the wave the old end lies in and everything behind
+        row_summary_touch(ctx, ROWSUM_PART_AABB | ROWSUM_PART_FLAGS, a, b - a);
+    }
     if (n_rows > ctx->n) {  // new rows are Added<GlobalTransform>: marked (a plain 1), uncounted
         ctx->changed_rows_hint = UINT64_MAX;
         ctx->changed_bulk = true;
@@ -960,6 +1012,7 @@ int32_t mi_upload_bounds(mi_ctx* ctx, uint32_t first_row, uint32_t n, const floa
     int32_t rc = check_rows(ctx, first_row, n, "mi_upload_bounds");
     if (rc) return rc;
     ctx->sph_state = mi_ctx::SPH_INVALID;  // the spheres are functions of the bounds
+    row_summary_touch(ctx, ROWSUM_PART_AABB | ROWSUM_PART_FLAGS, first_row, n);
     if ((rc = upload(ctx, ctx->c + 3 * (size_t)first_row, aabb_center, (size_t)n * 12))) return rc;
     if ((rc = upload(ctx, ctx->h + 3 * (size_t)first_row, aabb_half, (size_t)n * 12))) return rc;
     if (flags) {
@@ -1222,6 +1275,7 @@ int32_t mi_propagate_and_cull(mi_ctx* ctx, const float* frusta, const uint32_t* 
 int32_t mi_visibility_propagate(mi_ctx* ctx) {
     ENTER(ctx);
     if (ctx->n == 0) return MI_OK;
+    row_summary_touch(ctx, ROWSUM_PART_FLAGS, 0, ctx->n);  // InheritedVisibility is bit 0 of the flags column
     if (!ctx->have_hierarchy) {
         ProfScope ps(ctx, K_INHERIT);
         HIP_TRY(ctx, launch_inherit_flat(ctx->n, ctx->visibility, ctx->flags, ctx->inh_changed, ctx->stream));
@@ -1802,6 +1856,14 @@ int32_t mi_debug_set_tile_pretest(mi_ctx* ctx, int32_t mode) {
     ENTER(ctx);
     if (mode < 0 || mode > 2) return fail(ctx, MI_ERR_INVALID_ARG, "mi_debug_set_tile_pretest: mode %d", mode);
     ctx->tile_pretest_mode = mode;
+    return MI_OK;
+}
+
+// test / bench hook: the per-wave summary of Aabb / flags / RenderLayers (RowSummary, kernels.h): 0 = in use (default), 1 = off
+int32_t mi_debug_set_row_summary(mi_ctx* ctx, int32_t mode) {
+    ENTER(ctx);
+    if (mode < 0 || mode > 1) return fail(ctx, MI_ERR_INVALID_ARG, "mi_debug_set_row_summary: mode %d", mode);
+    ctx->row_sum_mode = mode;
     return MI_OK;
 }
 

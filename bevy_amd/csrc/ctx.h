@@ -122,6 +122,13 @@ struct mi_ctx {
     uint32_t sph_quiet = 0;  // cull frames since the last wholesale GlobalTransform rewrite (the column is rebuilt on the second)
     int32_t sph_mode = 0;    // mi_debug_set_sphere_path: 0 = as described, 1 = never, 2 = rebuild at once
 
+    // ---- row summary (RowSummary, kernels.h): Aabb / flags / RenderLayers per 64 rows where they are uniform.  Derived from the
+    // columns by k_row_summary; rs_lo / rs_hi = the waves [lo, hi) whose summary is out of date, per part (0 = Aabb, 1 = flags +
+    // layers).  The frame entry points bring it up to date first (row_summary_ensure); columns_of hands it to kernels only then.
+    DevBuf row_sum;
+    uint32_t rs_lo[2] = {0, 0}, rs_hi[2] = {0, 0};
+    int32_t row_sum_mode = 0;  // mi_debug_set_row_summary: 0 = in use, 1 = off (every row reads its own Aabb / flags / layers)
+
     // ---- views / visibility ----
     DevBuf views;
     uint32_t n_views = 0;
@@ -321,6 +328,8 @@ int32_t stage_alloc(mi_ctx* ctx, size_t bytes, void** out);
 int32_t upload(mi_ctx* ctx, void* dst, const void* src, size_t bytes);
 int32_t download(mi_ctx* ctx, void* dst, const void* src, size_t bytes);
 int32_t check_rows(mi_ctx* ctx, uint32_t first, uint32_t n, const char* what);
+void row_summary_touch(mi_ctx* ctx, uint32_t parts, uint32_t first_row, uint32_t n_rows);  // the columns of these rows were written
+int32_t row_summary_ensure(mi_ctx* ctx);
 int32_t consume_changed(mi_ctx* ctx);  // the propagate has read the change column: every row is unchanged from here on
 void prof_close(mi_ctx* ctx);
 void prof_mark(void* vctx, uint32_t kernel);

@@ -74,7 +74,19 @@ struct Columns {
     uint64_t* g_changed_bits;   // ceil(n/64) words: GlobalTransform change tick bumped
     uint64_t* vv_changed_bits;  // ceil(n/64) words: ViewVisibility change tick bumped
     uint32_t changed_gen;       // the Transform change column holds STAMPS, see row_changed()
+    const uint32_t* row_summary;  // 8 words per 64 rows (RowSummary below); allocated whenever a frame kernel runs
+    uint32_t row_summary_on;      // 0 = out of date / switched off: every row reads its own columns
 };
+
+// Per 64 aligned rows, what the frame kernels would otherwise read per row although it rarely differs from row to row: Aabb (the
+// entities of a mesh are spawned together: one Aabb for all of them), the flags byte and the RenderLayers mask.  A wave fetches the
+// 32 bytes with scalar loads; where a bit says "uniform" its lanes take the values from there and issue no loads on the column:
+// 29 of the ~119 B a row of the all-dirty frame costs (24 Aabb + 1 flags + 4 layers).  Waves whose rows differ read the columns as
+// before.  Written by k_row_summary from the columns themselves (after mi_upload_bounds / resize / visibility propagation, for the
+// waves they touched), so the columns stay the only source of truth.
+//   words 0-2 Aabb centre, 3-5 half extents (valid iff ROWSUM_UNIFORM_AABB), 6 RenderLayers mask, 7 = flags byte | ROWSUM_* bits
+constexpr uint32_t ROWSUM_WORDS = 8u, ROWSUM_UNIFORM_AABB = 0x80000000u, ROWSUM_UNIFORM_FLAGS = 0x40000000u;
+constexpr uint32_t ROWSUM_PART_AABB = 1u, ROWSUM_PART_FLAGS = 2u;
 
 // The per-row Transform change byte: 0 = unchanged, 1 = changed (bulk uploads, rows never propagated), g in 2..255 = changed iff g is
 // the context's current generation -- what the indexed uploads write.  Consuming the column is then `generation += 1` on the host
@@ -184,6 +196,7 @@ hipError_t launch_frame_sph(const Columns& c, const ViewSet* views_inline, const
                             const struct ClusterWalkJob* walk, hipStream_t stream, const uint8_t* changed, float* sph, const uint64_t* stale_bits,
                             const uint8_t* stale_bytes, bool all_stale);
 constexpr uint32_t SPH_MAX_VIEWS = 32;
+hipError_t launch_row_summary(const Columns& c, uint32_t first_wave, uint32_t n_waves, uint32_t parts, uint32_t* summary, hipStream_t stream);
 hipError_t launch_upload_trs(const float* pinned_src, float* t, float* r, float* s, uint32_t first_row, uint32_t n,
                              hipStream_t stream);
 // mark_bytes != nullptr: the rows also climb to their roots setting TransformTreeChanged there (= k_mark_dirty for these rows), and
@@ -408,9 +421,12 @@ struct ClusterWalkJob {
 // bytes of the LDS arena a walking workgroup needs for chunks of zc z slices (layout: cluster_walk.h)
 inline size_t cluster_walk_lds_bytes(uint32_t dxy, uint32_t zc, uint32_t n_planes, bool planes_in_lds) {
     const size_t RC = (size_t)dxy * zc;
-    return (RC * 8u + 48u) * sizeof(uint32_t) + (planes_in_lds ? (size_t)n_planes * 16u : 0u) + ((RC + 31u) / 32u + 4u) * 4u + RC * 2u + 16u;
+    return (RC * 8u + 48u) * sizeof(uint32_t) + 256u /* logf table */ + (planes_in_lds ? (size_t)n_planes * 16u : 0u) + ((RC + 31u) / 32u + 4u) * 4u + RC * 2u + 16u;
 }
-constexpr size_t FRAME_KERNEL_LDS_BYTES = (4096 + 4) * 4;  // k_frame's static LDS: the arena a riding walk / fill workgroup gets
+// k_frame's static LDS (words): what its riders get as their arena -- the compaction and the fill 16 KB, the walk (whose launches run
+// 5 workgroups per CU for its registers) the 31 KB five workgroups leave each other
+constexpr uint32_t FRAME_LDS_WORDS = 4096u, FRAME_WALK_LDS_WORDS = 7936u;
+constexpr size_t FRAME_KERNEL_LDS_BYTES = (FRAME_WALK_LDS_WORDS + 4) * 4;  // the riding walk's arena
 constexpr uint32_t CLUSTER_FILL_RIDE_BLOCKS = 128;  // workgroups a riding fill adds to the frame kernel's grid
 
 // ---------------------------------------------------------------------------------------------

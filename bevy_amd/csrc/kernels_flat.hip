@@ -51,6 +51,27 @@ __device__ __forceinline__ void st_affine(float* g, uint32_t row, const Affine& 
     p[2] = make_float4(a.m.z_axis.z, a.t.x, a.t.y, a.t.z);
 }
 
+// The wave's RowSummary (kernels.h): 32 bytes at a wave-uniform address, fetched with scalar loads.  bits = word 7, or 0 when the
+// summary is not in use / the wave has no live row.
+struct RowSum {
+    V3 center, half;
+    uint32_t layers, bits;
+};
+__device__ __forceinline__ RowSum load_row_summary(const Columns& c, uint32_t wave_row0) {
+    // no branch around the load (its results would have to be merged at the join, i.e. waited for there): the address is always
+    // valid -- row_summary is allocated whenever a frame kernel runs -- and what is not to be used is masked out of the bits
+    const bool use = c.row_summary_on != 0u && wave_row0 < c.n;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(use ? wave_row0 >> 6 : 0u);
+    const uint4* p = reinterpret_cast<const uint4*>(c.row_summary) + 2ull * w;
+    const uint4 a = p[0], b = p[1];
+    RowSum r;
+    r.center = V3{__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z)};
+    r.half = V3{__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y)};
+    r.layers = b.z;
+    r.bits = use ? b.w : 0u;
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Wave-local transposes through LDS.  A row's GlobalTransform is 48 bytes; one lane per row means
 // a lane-major float4 access touches a 3 KB span per wave-instruction and uses a third of every
@@ -206,6 +227,28 @@ __device__ __forceinline__ void view_visibility_tail(const Columns& c, uint32_t 
 // The extra workgroups at the head of a frame kernel's grid (they overlap the ramp-up instead of lengthening the tail: 0.5 us per
 // frame at 1 M rows): the deferred VisibleEntities compaction of the previous frame, the deferred fill of the previous frame's
 // light-cluster assignment, and the walk of THIS frame's.  Returns true in a workgroup that was one of them.
+#ifdef MI_EXP_TIMELINE
+// (experiment build) per workgroup of a frame launch: [3b] start, [3b+1] end (100 MHz wall clock), [3b+2] kind + 1 -- 0 compaction,
+// 1 fill, 2 walk, 3 rows.  Plain stores to the workgroup's own slots; mi_exp_timeline() below reads and clears them.
+constexpr uint32_t TIMELINE_WGS = 16384;
+__device__ unsigned long long mi_timeline[3 * TIMELINE_WGS];
+struct TimelineScope {
+    uint32_t kind;
+    unsigned long long t0;
+    __device__ TimelineScope(uint32_t k) : kind(k), t0(wall_clock64()) {}
+    __device__ ~TimelineScope() {
+        __syncthreads();
+        if (threadIdx.x == 0 && blockIdx.x < TIMELINE_WGS) {
+            mi_timeline[3 * blockIdx.x] = t0;
+            mi_timeline[3 * blockIdx.x + 1] = wall_clock64();
+            mi_timeline[3 * blockIdx.x + 2] = kind + 1;
+        }
+    }
+};
+#define MI_TIMELINE(kind) TimelineScope tl_scope_(kind)
+#else
+#define MI_TIMELINE(kind)
+#endif
 template <bool WITH_WALK>
 __device__ __forceinline__ bool frame_riders(uint32_t n_tiles, const CompactFastArgs& prev, uint32_t prev_gx, uint32_t n_compact, uint32_t n_fill,
                                              const ClusterFillJob& fill, const ClusterWalkJob& walk, const ViewSet& vs, uint32_t* lds_raw) {
@@ -215,11 +258,14 @@ __device__ __forceinline__ bool frame_riders(uint32_t n_tiles, const CompactFast
     if (id < n_compact) {
         if (prev.signal && id == 0 && threadIdx.x == 0)  // multi-GPU exchange: the previous frame's masks are complete
             __hip_atomic_store(prev.signal, prev.signal_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        MI_TIMELINE(0);
         compact_fast_block(prev, id % prev_gx, id / prev_gx, prev_gx);
     } else if (id < n_compact + n_fill) {
+        MI_TIMELINE(1);
         cluster_fill_block(fill.w, fill.n_clusters, fill.n_objects, id - n_compact, n_fill, lds_raw, lds_raw + 4096);
     } else if constexpr (WITH_WALK) {
         // this frame's light-cluster walk: independent of the rows below (it re-derives the lights' ViewVisibility itself)
+        MI_TIMELINE(2);
         cluster_walk_block<true, true, false>(walk.view, walk.objs, walk.w, vs, walk.zc, id - n_compact - n_fill, lds_raw);
     }
     return true;
@@ -250,9 +296,14 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
     constexpr bool PROPAGATE = PROP == 1, PARTIAL = PROP == 2;
     // 16 KB + 16 B: the four waves' GlobalTransform transpose buffers (12 KB) -- or, in a riding cluster-fill workgroup, the CSR
     // offsets of up to 4096 clusters and the four wave totals of their scan -- or the arena of a riding cluster-walk workgroup
-    __shared__ __attribute__((aligned(16))) uint32_t lds_raw[4096 + 4];
+    // 16 KB: the rows' transposes (4 waves x 3 KB), the compaction / fill riders' arena.  A launch that carries the cluster walk is
+    // held to 5 workgroups per CU by the walk's registers anyway, so its arena is the 31 KB that five of them leave each other: the
+    // walk sweeps the cluster grid in chunks of as many z slices as fit, and a chunk is a reservation round trip (metric frame
+    // 22.3 -> 21.7 us, profiles/r03_experiments.md)
+    __shared__ __attribute__((aligned(16))) uint32_t lds_raw[(WITH_WALK ? FRAME_WALK_LDS_WORDS : FRAME_LDS_WORDS) + 4];
     float4 (*lds_g)[192] = reinterpret_cast<float4 (*)[192]>(lds_raw);
     if (frame_riders<WITH_WALK>(n_tiles, prev, prev_gx, n_compact, n_fill, fill, walk, vs, lds_raw)) return;
+    MI_TIMELINE(3);
     const uint32_t n_extra = gridDim.x - n_tiles;
     const uint32_t row = (blockIdx.x - n_extra) * 256u + threadIdx.x;
     const bool live = row < c.n;
@@ -279,13 +330,35 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
     }
     bool dirty = false;
     if (PARTIAL && live) dirty = row_changed(changed[row], c.changed_gen);
+    // the wave's summary is requested first and waited for last: the loads every live row issues anyway go out in between
+    const RowSum rs = load_row_summary(c, wave_row0);
+    V3 t_in = {}, s_in = {};
+    V4 q_in = {};
+    if (PROPAGATE && live) {
+        t_in = ld3(c.translation, row);
+        q_in = ld4(c.rotation, row);
+        s_in = ld3(c.scale, row);
+    }
     if (live) {
-        center = ld3(c.aabb_center, row);
-        half = ld3(c.aabb_half, row);
-        fl = c.flags[row];
-        emask = c.layer_mask[row];
         vv0 = c.view_visibility[row];
         if (seg.class_mask) cmask = seg.class_mask[row];
+    }
+    const bool uni_aabb = (rs.bits & ROWSUM_UNIFORM_AABB) != 0u, uni_fl = (rs.bits & ROWSUM_UNIFORM_FLAGS) != 0u;  // (wave-uniform)
+    if (uni_aabb) {
+        center = rs.center;
+        half = rs.half;
+    } else if (live) {
+        center = ld3(c.aabb_center, row);
+        half = ld3(c.aabb_half, row);
+    }
+    if (uni_fl) {
+        fl = live ? (rs.bits & 0xFFu) : 0u;
+        emask = rs.layers;
+    } else if (live) {
+        fl = c.flags[row];
+        emask = c.layer_mask[row];
+    }
+    if (live) {
         if (c.range_start_end && (fl & 0x20u)) {
             const float2 r2 = reinterpret_cast<const float2*>(c.range_start_end)[row];
             range_lo = r2.x;
@@ -293,12 +366,7 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
         }
     }
     if (PROPAGATE) {
-        if (live) {
-            const V3 t = ld3(c.translation, row);
-            const V4 q = ld4(c.rotation, row);
-            const V3 s = ld3(c.scale, row);
-            g = affine_from_srt(s, q, t);
-        }
+        if (live) g = affine_from_srt(s_in, q_in, t_in);
         // nontemporal: the fused path never reads G back (measured +3..16 % at 4 M - 10 M rows, neutral at 1 M)
         store_affine_coalesced(lds_g[wv], c.global, wave_row0, c.n, lane, g, true);
     } else {
@@ -367,7 +435,7 @@ __global__ void __launch_bounds__(256) k_frame_sph(Columns c, ViewSet vs, const 
                                                     VisibilityOut out, SegOut seg, uint32_t fl_frame, uint32_t n_tiles, CompactFastArgs prev,
                                                     uint32_t prev_gx, uint32_t n_compact, uint32_t n_fill, ClusterFillJob fill,
                                                     ClusterWalkJob walk, const uint8_t* __restrict__ changed, SphereArgs sa) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds_raw[4096 + 4];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_raw[(WITH_WALK ? FRAME_WALK_LDS_WORDS : FRAME_LDS_WORDS) + 4];  // (as in k_frame)
     float4 (*lds_g)[192] = reinterpret_cast<float4 (*)[192]>(lds_raw);
     if (frame_riders<WITH_WALK>(n_tiles, prev, prev_gx, n_compact, n_fill, fill, walk, vs, lds_raw)) return;
     const uint32_t n_extra = gridDim.x - n_tiles;
@@ -378,12 +446,17 @@ __global__ void __launch_bounds__(256) k_frame_sph(Columns c, ViewSet vs, const 
     const uint32_t rrow = live ? row : 0u;  // clamped: every load below is unconditional (one batch, no load behind a branch)
 
     // ---- burst 1: what every row needs ----
+    const RowSum rs = load_row_summary(c, wave_row0);
+    const bool uni_aabb = (rs.bits & ROWSUM_UNIFORM_AABB) != 0u, uni_fl = (rs.bits & ROWSUM_UNIFORM_FLAGS) != 0u;  // (wave-uniform)
     float4 sp = sa.sph[rrow];
-    uint32_t fl = c.flags[rrow];
-    const uint32_t emask = c.layer_mask[rrow];
     const uint32_t vv0 = c.view_visibility[rrow];
     uint32_t cmask = 1u;
     if (seg.class_mask) cmask = seg.class_mask[rrow];
+    uint32_t fl = rs.bits & 0xFFu, emask = rs.layers;  // (the summary is waited for here, behind the loads every row issues)
+    if (!uni_fl) {
+        fl = c.flags[rrow];
+        emask = c.layer_mask[rrow];
+    }
     bool dirty = false;
     if (PARTIAL) dirty = live && row_changed(changed[rrow], c.changed_gen);
     bool stale = sa.all_stale != 0u;
@@ -424,7 +497,7 @@ __global__ void __launch_bounds__(256) k_frame_sph(Columns c, ViewSet vs, const 
             } else if (!whole_wave) {
                 g = ld_affine(c.global, row);
             }
-            const V3 center = ld3(c.aabb_center, row), half = ld3(c.aabb_half, row);
+            const V3 center = uni_aabb ? rs.center : ld3(c.aabb_center, row), half = uni_aabb ? rs.half : ld3(c.aabb_half, row);
             // exactly the values row_visible_in_view computes (visibility_rule.h): Aabb -> (affine * center, |M3 * half|), a Sphere
             // component as it is
             const bool at_translation = !has_aabb && __float_as_uint(half.y) == SPHERE_AT_TRANSLATION;  // a light's sphere follows its entity
@@ -502,7 +575,7 @@ __global__ void __launch_bounds__(256) k_frame_sph(Columns c, ViewSet vs, const 
         }
         if (need) {
             if (!dense) g = ld_affine(c.global, row);
-            const V3 half = ld3(c.aabb_half, row);
+            const V3 half = uni_aabb ? rs.half : ld3(c.aabb_half, row);
             for (uint32_t v = 0; v < n_views; ++v) {
                 if (!((need >> v) & 1u)) continue;
                 const ViewParams& vp = INLINE_VIEWS ? vs.v[v] : dviews[v];
@@ -561,6 +634,41 @@ __global__ void __launch_bounds__(256) k_level0_propagate(Columns c, uint32_t n_
 }
 
 // reset_view_visibility: bits = (bits & 1) << 1 for rows without NoCpuCulling; clears the change mask.
+// RowSummary (kernels.h) of the waves first_wave .. first_wave + n_waves - 1, from the columns: a wave per 64 rows compares every
+// live row's bits with its first row's.  parts: ROWSUM_PART_AABB rewrites words 0-5 and the Aabb bit, ROWSUM_PART_FLAGS words 6-7's
+// flags / layers and their bit (the other part of word 7 is kept).
+__global__ void __launch_bounds__(256) k_row_summary(Columns c, uint32_t first_wave, uint32_t n_waves, uint32_t parts, uint32_t* __restrict__ summary) {
+    const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (w >= n_waves) return;
+    const uint32_t wave = first_wave + w, row = wave * 64u + lane;
+    const bool live = row < c.n;
+    if (wave * 64u >= c.n) return;
+    uint32_t* o = summary + (size_t)wave * ROWSUM_WORDS;
+    uint32_t bits = o[7];
+    const uint32_t rrow = live ? row : wave * 64u;  // (dead lanes repeat the first row: they agree with it)
+    if (parts & ROWSUM_PART_AABB) {
+        const F3 ce = reinterpret_cast<const F3*>(c.aabb_center)[rrow], he = reinterpret_cast<const F3*>(c.aabb_half)[rrow];
+        const uint32_t v[6] = {__float_as_uint(ce.x), __float_as_uint(ce.y), __float_as_uint(ce.z), __float_as_uint(he.x), __float_as_uint(he.y), __float_as_uint(he.z)};
+        bool same = true;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) same = same && v[k] == (uint32_t)__builtin_amdgcn_readfirstlane((int)v[k]);
+        const bool uniform = __ballot(!same) == 0ull;
+        bits = (bits & ~ROWSUM_UNIFORM_AABB) | (uniform ? ROWSUM_UNIFORM_AABB : 0u);
+        if (lane == 0u) {  // (lane 0 is the wave's first row, live: wave * 64 < n)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[k] = v[k];
+        }
+    }
+    if (parts & ROWSUM_PART_FLAGS) {
+        const uint32_t fl = c.flags[rrow], lm = c.layer_mask[rrow];
+        const uint32_t fl0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)fl), lm0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lm);
+        const bool uniform = __ballot(fl != fl0 || lm != lm0) == 0ull;
+        bits = (bits & ~(ROWSUM_UNIFORM_FLAGS | 0xFFu)) | (uniform ? ROWSUM_UNIFORM_FLAGS : 0u) | (fl0 & 0xFFu);
+        if (lane == 0u) o[6] = lm0;
+    }
+    if (lane == 0u) o[7] = bits & (ROWSUM_UNIFORM_AABB | ROWSUM_UNIFORM_FLAGS | 0xFFu);
+}
+
 __global__ void __launch_bounds__(256) k_vis_begin(Columns c) {
     const uint32_t row = blockIdx.x * 256u + threadIdx.x;
     const bool live = row < c.n;
@@ -796,6 +904,27 @@ hipError_t launch_pack_results(const PackResultsJob& job, hipStream_t stream) {
     return hipGetLastError();
 }
 
+#ifdef MI_EXP_TIMELINE
+extern "C" int mi_exp_timeline(unsigned long long* out /* 3 * 16384 */, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(mi_timeline), sizeof(unsigned long long) * 3 * TIMELINE_WGS) != hipSuccess) return 1;
+    if (reset) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(mi_timeline)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned long long) * 3 * TIMELINE_WGS) != hipSuccess) return 1;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(mi_walk_marks)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned long long) * 16 * 4096) != hipSuccess) return 1;
+    }
+    return 0;
+}
+extern "C" int mi_exp_walk_marks(unsigned long long* out /* 16 * 4096 */) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(mi_walk_marks), sizeof(unsigned long long) * 16 * 4096) != hipSuccess;
+}
+#endif
+
+hipError_t launch_row_summary(const Columns& c, uint32_t first_wave, uint32_t n_waves, uint32_t parts, uint32_t* summary, hipStream_t stream) {
+    if (n_waves == 0) return hipSuccess;
+    MI_LAUNCH(k_row_summary, dim3((n_waves + 3u) / 4u), dim3(256), 0, stream, c, first_wave, n_waves, parts, summary);
+    return hipGetLastError();
+}
+
 hipError_t launch_upload_trs(const float* pinned_src, float* t, float* r, float* s, uint32_t first_row, uint32_t n,
                              hipStream_t stream) {
     if (n == 0) return hipSuccess;
@@ -810,6 +939,7 @@ static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, co
                                const VisibilityOut& out, const SegOut& seg, uint32_t flags, const CompactFastArgs* prev,
                                const ClusterFillJob* fill, const ClusterWalkJob* walk, hipStream_t stream, const uint8_t* changed = nullptr) {
     if (c.n == 0) return hipSuccess;
+    if (!c.row_summary) return hipErrorInvalidValue;  // (the kernel loads it unconditionally: row_summary_ensure comes first)
     const uint32_t n_tiles = blocks_for(c.n);
     CompactFastArgs pa{};
     uint32_t prev_gx = 1, prev_blocks = 0;
@@ -850,6 +980,7 @@ hipError_t launch_frame_sph(const Columns& c, const ViewSet* views_inline, const
                             hipStream_t stream, const uint8_t* changed, float* sph, const uint64_t* stale_bits, const uint8_t* stale_bytes,
                             bool all_stale) {
     if (c.n == 0) return hipSuccess;
+    if (!c.row_summary) return hipErrorInvalidValue;  // (the kernel loads it unconditionally: row_summary_ensure comes first)
     const uint32_t n_tiles = blocks_for(c.n);
     CompactFastArgs pa{};
     uint32_t prev_gx = 1, prev_blocks = 0;

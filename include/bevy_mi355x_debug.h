@@ -49,6 +49,10 @@ int32_t mi_debug_set_sorted_one_wg_limit(mi_ctx* ctx, uint32_t items);
 /* The flags-first test of the light tile kernel under the static-scene rule (kernels_tree.hip): 0 = when few rows changed since the
  * last propagate (default), 1 = never, 2 = always. */
 int32_t mi_debug_set_tile_pretest(mi_ctx* ctx, int32_t mode);
+/* The per-wave summary of Aabb / flags / RenderLayers (64 aligned rows that agree read 32 bytes instead of 64 x 29): 0 = in use
+ * (default), 1 = off -- every row reads its own columns.  Results are identical; A/B timing and tests. */
+int32_t mi_debug_set_row_summary(mi_ctx* ctx, int32_t mode);
+
 /* The world-sphere path of the cull-only and changed-rows frames (kernels_flat.hip, k_frame_sph): 0 = used from the second frame in
  * a row that rewrites no or few GlobalTransforms (default), 1 = never, 2 = at once (the first such frame rebuilds the column). */
 int32_t mi_debug_set_sphere_path(mi_ctx* ctx, int32_t mode);

@@ -7,13 +7,15 @@
 # profiles/rocprof_summary.json (what bench.py quotes as rocprof_avg_kernel_us / traffic).
 TAG=${1:-r03}
 shift
-WLS=${@:-frame flat flat_10m_1view flat_10m_4views tree tree_subtree tree_leaves lights flat_static flat_static_no_sphere flat_static_10m_4views batching batching_sorted_64k batching_sorted_1m}
+WLS=${@:-frame frame_plain_columns flat flat_plain_columns flat_10m_1view flat_10m_4views tree tree_subtree tree_leaves lights flat_static flat_static_no_sphere flat_static_10m_4views batching batching_sorted_64k batching_sorted_1m}
 export TMPDIR=/tmp
 P=gpurun_out/prof_$TAG
 mkdir -p $P
 COMMON="--no-cpu-baseline --no-other-workloads --no-end-to-end"
 for wl in $WLS; do
   case $wl in
+    frame_plain_columns) ARGS="--workload frame --row-summary 1" ;;
+    flat_plain_columns)  ARGS="--workload flat --row-summary 1" ;;
     flat_10m_1view)  ARGS="--workload flat --entities 10000000 --views 1" ;;
     flat_10m_4views) ARGS="--workload flat --entities 10000000 --views 4" ;;
     tree_subtree)    ARGS="--workload tree --tree-moved subtree" ;;

@@ -154,17 +154,38 @@ __device__ __forceinline__ Affine object_row_affine(const ClusterObjects& o, uin
 // and flags -> Transform -> sphere as three dependent trips were most of what the walk added to the frame.  *g_out = the
 // GlobalTransform the frame gives the row.
 __device__ __forceinline__ bool derive_row_visible(const ClusterObjects& o, const ViewSet& views, uint32_t row, Affine* g_out) {
-    const uint32_t fl = o.row_flags[row];
-    const uint32_t emask = o.row_layers[row];
-    const V3 center = ld3c(o.row_aabb_center, row), half = ld3c(o.row_aabb_half, row);
+    // The rows' RowSummary (kernels.h) first: lights are entities of one kind, spawned together -- their Aabb / Sphere, flags and
+    // RenderLayers agree over whole waves of rows, and a row without an Aabb needs of its GlobalTransform only the translation
+    // (visibility_rule.h: the Sphere branch).  Where every lane of the wave finds its rows summarised, the walk reads 12 + 16 bytes
+    // per light (translation, pos_range) instead of 85.
+    uint32_t fl = 0, emask = 0;
+    V3 center = {}, half = {};
+    bool summarised = false;
+    if (o.row_summary && !o.derive_resident && !o.row_changed) {  // (uniform)
+        const uint4* p = reinterpret_cast<const uint4*>(o.row_summary) + 2ull * (row >> 6);
+        const uint4 a = p[0], b = p[1];
+        summarised = (b.w & (ROWSUM_UNIFORM_AABB | ROWSUM_UNIFORM_FLAGS)) == (ROWSUM_UNIFORM_AABB | ROWSUM_UNIFORM_FLAGS) && !(b.w & 0x04u);
+        fl = b.w & 0xFFu;
+        emask = b.z;
+        center = V3{__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z)};
+        half = V3{__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y)};
+    }
     Affine g;
-    if (o.derive_resident) {  // (uniform) a cull-only frame: every row keeps its resident GlobalTransform
-        g = load_affine(o.row_global + 12ull * row);
-    } else if (!o.row_changed) {  // (uniform) the all-rows frame: From(Transform)
-        const float4 q = reinterpret_cast<const float4*>(o.row_rotation)[row];
-        g = affine_from_srt(ld3c(o.row_scale, row), V4{q.x, q.y, q.z, q.w}, ld3c(o.row_translation, row));
-    } else {  // the changed-rows frame: one more trip, by the row's change byte
-        g = object_row_affine(o, row);
+    if (__ballot(summarised) == __ballot(true)) {  // every active lane: Transform -> translation only, nothing else to fetch
+        g = Affine{M3{V3{1.0f, 0.0f, 0.0f}, V3{0.0f, 1.0f, 0.0f}, V3{0.0f, 0.0f, 1.0f}}, ld3c(o.row_translation, row)};  // (the matrix is never read: no Aabb)
+    } else {
+        fl = o.row_flags[row];
+        emask = o.row_layers[row];
+        center = ld3c(o.row_aabb_center, row);
+        half = ld3c(o.row_aabb_half, row);
+        if (o.derive_resident) {  // (uniform) a cull-only frame: every row keeps its resident GlobalTransform
+            g = load_affine(o.row_global + 12ull * row);
+        } else if (!o.row_changed) {  // (uniform) the all-rows frame: From(Transform)
+            const float4 q = reinterpret_cast<const float4*>(o.row_rotation)[row];
+            g = affine_from_srt(ld3c(o.row_scale, row), V4{q.x, q.y, q.z, q.w}, ld3c(o.row_translation, row));
+        } else {  // the changed-rows frame: one more trip, by the row's change byte
+            g = object_row_affine(o, row);
+        }
     }
     float range_lo = 0.0f, range_hi = 0.0f;
     if (o.row_range && (fl & 0x20u)) {
@@ -396,8 +417,9 @@ __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, cons
     const uint32_t nx = v.dims[0] + 1u, ny = v.dims[1] + 1u, nz = dz + 1u;
     uint32_t* touched_bits = reinterpret_cast<uint32_t*>(planes + (PLANES_IN_LDS ? 4u * (nx + ny + nz) : 0u));
     uint32_t* n_touched = touched_bits + ((RC + 31u) >> 5);
-    uint32_t* z_range = n_touched + 1;  // [0] min, [1] max z slice any object of the block may touch, [2] the block's first pair slot
-    uint16_t* touched_list = reinterpret_cast<uint16_t*>(z_range + 3);
+    uint32_t* z_range = n_touched + 1;  // [0] min, [1] max z slice any object of the block may touch, [2] the block's first pair slot,
+                                        // [3] the block's farthest_z (bits of a positive float, 0 = none)
+    uint16_t* touched_list = reinterpret_cast<uint16_t*>(z_range + 4);
     const float* xp = PLANES_IN_LDS ? planes : v.x_planes;
     const float* yp = PLANES_IN_LDS ? planes + 4u * nx : v.y_planes;
     const float* zp = PLANES_IN_LDS ? planes + 4u * (nx + ny) : v.z_planes;
@@ -406,14 +428,12 @@ __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, cons
     const uint32_t obj = bx * CLUSTER_BLOCK + threadIdx.x;
     float4 sphere = make_float4(0.f, 0.f, 0.f, 0.f);
     // the plane tables are requested together with the objects' loads (they are contiguous in device memory: x | y | z)
-    float plane_regs[PLANES_IN_LDS ? 4 : 1] = {};
-    if (PLANES_IN_LDS) {
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) {
-            const uint32_t i = threadIdx.x + k * CLUSTER_BLOCK;
-            if (i < 4u * (nx + ny + nz)) plane_regs[k] = v.x_planes[i];
-        }
-    }
+    const uint32_t n_plane_floats = PLANES_IN_LDS ? 4u * (nx + ny + nz) : 0u;
+    float pl0 = 0.f, pl1 = 0.f, pl2 = 0.f, pl3 = 0.f;  // (floats threadIdx.x + k * 256 of the tables: 16x9x24 has 208 of them)
+    if (threadIdx.x < n_plane_floats) pl0 = v.x_planes[threadIdx.x];
+    if (threadIdx.x + CLUSTER_BLOCK < n_plane_floats) pl1 = v.x_planes[threadIdx.x + CLUSTER_BLOCK];
+    if (threadIdx.x + 2u * CLUSTER_BLOCK < n_plane_floats) pl2 = v.x_planes[threadIdx.x + 2u * CLUSTER_BLOCK];
+    if (threadIdx.x + 3u * CLUSTER_BLOCK < n_plane_floats) pl3 = v.x_planes[threadIdx.x + 3u * CLUSTER_BLOCK];
     MI_WALK_MARK(bx, 0);
     const double logf_reg = (&LOGF_TAB[0][0])[threadIdx.x & 31u];
     // (the barriers below order LDS only: a __syncthreads() also waits for every global store and atomic in flight -- the far_z
@@ -428,23 +448,22 @@ __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, cons
         for (uint32_t i = threadIdx.x; i <= ((RC + 31u) >> 5); i += CLUSTER_BLOCK) touched_bits[i] = 0u;  // bits + counter
     };
     if (threadIdx.x < 48u) type_rows[threadIdx.x] = 0u;
-    if (CHUNKED && threadIdx.x == 0) { z_range[0] = 0xFFFFFFFFu; z_range[1] = 0u; }
+    if (threadIdx.x == 0) { z_range[0] = 0xFFFFFFFFu; z_range[1] = 0u; z_range[3] = 0u; }
     if (!CHUNKED) clear_chunk();
     if (threadIdx.x < 32u) logf_tab[threadIdx.x] = logf_reg;
     if (PLANES_IN_LDS) {
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) {
-            const uint32_t i = threadIdx.x + k * CLUSTER_BLOCK;
-            if (i < 4u * (nx + ny + nz)) planes[i] = plane_regs[k];
-        }
-        for (uint32_t i = threadIdx.x + 4u * CLUSTER_BLOCK; i < 4u * (nx + ny + nz); i += CLUSTER_BLOCK) planes[i] = v.x_planes[i];  // (grids beyond 255 planes)
+        if (threadIdx.x < n_plane_floats) planes[threadIdx.x] = pl0;
+        if (threadIdx.x + CLUSTER_BLOCK < n_plane_floats) planes[threadIdx.x + CLUSTER_BLOCK] = pl1;
+        if (threadIdx.x + 2u * CLUSTER_BLOCK < n_plane_floats) planes[threadIdx.x + 2u * CLUSTER_BLOCK] = pl2;
+        if (threadIdx.x + 3u * CLUSTER_BLOCK < n_plane_floats) planes[threadIdx.x + 3u * CLUSTER_BLOCK] = pl3;
+        for (uint32_t i = threadIdx.x + 4u * CLUSTER_BLOCK; i < n_plane_floats; i += CLUSTER_BLOCK) planes[i] = v.x_planes[i];  // (grids beyond 255 planes)
     }
     MI_WG_LDS_BARRIER();
     MI_WALK_MARK(bx, 8);
 
     const uint32_t word = threadIdx.x >> 5, bit = 1u << (threadIdx.x & 31u);
     ObjectWalk ow = {};
-    uint32_t my_lo = 0xFFFFFFFFu, my_hi = 0u;
+    uint32_t my_lo = 0xFFFFFFFFu, my_hi = 0u, my_far = 0u;
     if (in_view) {
         float far_z = 0.0f;
         uint32_t type = 0u;
@@ -458,11 +477,22 @@ __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, cons
             type = ow.type;
         }
         atomicOr(&type_rows[(type < 6u ? type : 5u) * 8u + word], bit);
-        // farthest_z = farthest_z.max(this_object_far_z), starting from 0.0 (assign.rs:421,561):
-        // only positive values can raise it, and positive floats order like their bit patterns.
-        if (far_z > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(w.farthest_z), __float_as_uint(far_z));
+        // farthest_z = farthest_z.max(this_object_far_z), starting from 0.0 (assign.rs:421,561): only positive values can raise it,
+        // and positive floats order like their bit patterns.  Reduced over the block first (wave shuffle, one LDS atomic per wave)
+        // and sent as ONE global atomic when the block leaves: an atomic per visible light was 8 000 of them on one address, issued
+        // into a memory pipeline the frame's rows keep full.
+        if (far_z > 0.0f) my_far = __float_as_uint(far_z);
     }
     uint32_t bz0 = 0, bz1 = dz - 1u;
+    {
+        uint32_t fz = my_far;
+#pragma unroll
+        for (uint32_t off = 32u; off; off >>= 1) {
+            const uint32_t f2 = __shfl_xor(fz, off, 64);
+            fz = f2 > fz ? f2 : fz;
+        }
+        if ((threadIdx.x & 63u) == 0 && fz) atomicMax(&z_range[3], fz);
+    }
     if (CHUNKED) {  // the z slices the block touches: wave reduction, then one LDS atomic per wave
         uint32_t lo = my_lo, hi = my_hi;
 #pragma unroll
@@ -506,7 +536,13 @@ __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, cons
         // slots with a single atomic -- so the fill can spread pairs evenly over the chip no matter how unevenly the objects
         // are distributed.  Only non-empty entries of the (cluster, block) count matrix are written.
         const uint32_t nt = *n_touched;
-        if (threadIdx.x == 0) z_range[2] = nt ? atomicAdd(w.pair_total, nt) : 0u;
+        if (threadIdx.x == 0) {
+            if (z_range[3]) {  // (all waves' LDS atomics lie behind the barrier above; sent once, with the first chunk's reservation)
+                atomicMax(reinterpret_cast<unsigned int*>(w.farthest_z), z_range[3]);
+                z_range[3] = 0u;
+            }
+            z_range[2] = nt ? atomicAdd(w.pair_total, nt) : 0u;
+        }
         MI_WG_LDS_BARRIER();
         MI_WALK_MARK(bx, 3);
         const uint32_t pair_base = z_range[2];

@@ -230,6 +230,8 @@ int32_t cluster_objects(mi_ctx* ctx, bool derive, ClusterObjects* po) {
             o.row_range = ctx->have_ranges ? ctx->range : nullptr;
             o.row_flags = ctx->flags;
             o.row_layers = ctx->layers;
+            const Columns cc = columns_of(ctx);
+            o.row_summary = cc.row_summary_on ? cc.row_summary : nullptr;
         } else {
             o.row_global = ctx->g;
             o.row_vv = ctx->vv;

@@ -375,6 +375,7 @@ struct ClusterObjects {
     const float *row_translation, *row_rotation, *row_scale, *row_aabb_center, *row_aabb_half, *row_range;
     const uint8_t* row_flags;
     const uint32_t* row_layers;
+    const uint32_t* row_summary;  // RowSummary of the context's rows when it is current, else nullptr (derive mode)
 };
 constexpr uint32_t CLUSTER_BLOCK = 256;  // objects per workgroup (= bits per cluster row in LDS)
 struct ClusterWork {
@@ -421,7 +422,7 @@ struct ClusterWalkJob {
 // bytes of the LDS arena a walking workgroup needs for chunks of zc z slices (layout: cluster_walk.h)
 inline size_t cluster_walk_lds_bytes(uint32_t dxy, uint32_t zc, uint32_t n_planes, bool planes_in_lds) {
     const size_t RC = (size_t)dxy * zc;
-    return (RC * 8u + 48u) * sizeof(uint32_t) + 256u /* logf table */ + (planes_in_lds ? (size_t)n_planes * 16u : 0u) + ((RC + 31u) / 32u + 4u) * 4u + RC * 2u + 16u;
+    return (RC * 8u + 48u) * sizeof(uint32_t) + 256u /* logf table */ + (planes_in_lds ? (size_t)n_planes * 16u : 0u) + ((RC + 31u) / 32u + 5u) * 4u + RC * 2u + 16u;
 }
 // k_frame's static LDS (words): what its riders get as their arena -- the compaction and the fill 16 KB, the walk (whose launches run
 // 5 workgroups per CU for its registers) the 31 KB five workgroups leave each other

@@ -1,6 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
-O=gpurun_out/r03p
+O=gpurun_out/r03r
 mkdir -p $O
 MI_LIB_VARIANT=timeline timeout 200 python tools/exp_timeline.py > $O/timeline.json 2> $O/timeline.err
 timeout 900 python -m pytest tests/test_gpu_cluster.py tests/test_gpu_round2.py tests/test_gpu_round3.py -x -q -m gpu > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/summary.txt
@@ -11,7 +11,7 @@ timeout 120 $B --workload flat --entities 1110000 > $O/flat1110k.json 2> $O/flat
 cat $O/timeline.json $O/summary.txt; tail -n 2 $O/pytest.log
 python - <<'PY'
 import json,glob,os
-for p in sorted(glob.glob('gpurun_out/r03p/[fl]*.json')):
+for p in sorted(glob.glob('gpurun_out/r03r/[fl]*.json')):
     try:
         d=json.loads(open(p).read().strip().splitlines()[-1]); r=d['roofline']
         print(os.path.basename(p), d['ms_per_step'], r['avg_kernel_us'], d.get('kernels'))

@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--sorted-items", type=int, default=0, help="batching_sorted: items of the phase (default 65 536)")
     ap.add_argument("--sorted-one-wg-limit", type=int, default=None, help="batching_sorted: phases up to this long take the single-workgroup kernel (default 4096; 4294967295 = always)")
     ap.add_argument("--tree-moved", choices=["all", "subtree", "leaves"], default="all", help="tree: the root moves and every Transform counts as changed (default) / change-driven frames: one level-5 node moves / 10 000 leaves move")
+    ap.add_argument("--tree-cull-launches", type=int, default=2, choices=[1, 2], help="tree --tree-cull: 2 = tile launch + cull launch (default), 1 = the tiles cull their own rows (mi_debug_set_tree_cull(2))")
+    ap.add_argument("--tree-cull", action="store_true", help="tree: the hierarchy FRAME -- mi_propagate_and_cull on a context with a hierarchy (tile launch + cull launch, one call)")
     ap.add_argument("--sphere-path", type=int, default=0, help="flat_static / frame: 0 = world-sphere cull path from the second quiet frame (default), 1 = never (k_frame<0> over GlobalTransform + Aabb), 2 = at once")
     ap.add_argument("--tile-mode", type=int, default=0, help="tree: 0 = tile kernel chosen by size, 1 = big tiles, 2 / 3 = light tiles (5 / 6 waves per SIMD)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -294,6 +296,40 @@ def build_tree(ctx, args, rank=0, world=1):
                       kernels=["k_propagate_tiles", "k_mark_dirty"])
         wl.tree = tr
         wl.kernel_name = "k_propagate_fans<false>"
+        return wl
+
+    if getattr(args, "tree_cull", False):
+        # the hierarchy FRAME: every node carries a unit-cube Aabb; one call = the tile launch (every Transform counts as changed) + the
+        # cull launch behind it (reset + check_visibility + mark-newly-hidden over the GlobalTransforms just written) + the deferred compaction
+        from bevy_amd import api
+        n = tr["n"]
+        ctx.debug_set_row_summary(args.row_summary)
+        fused = getattr(args, "tree_cull_launches", 2) == 1
+        ctx.debug_set_tree_cull(2 if fused else 1)
+        ctx.upload_bounds(np.zeros(3 * n, np.float32), np.full(3 * n, 0.5, np.float32), np.full(n, 0x05, np.uint8), np.ones(n, np.uint32))
+        n_views = args.views or 1
+        frames = [api.PreparedFrusta(camera_frusta(n_views, f)) for f in range(N_FRAMES)]
+        more = 0 if args.inline_compaction else B.CULL_MORE_FRAMES
+
+        def step_frame(f):
+            ctx.upload_transforms(root_t[f & 1], tr["rotation"][:4], tr["scale"][:3], first_row=0)
+            ctx.propagate_and_cull(frames[f % N_FRAMES], flags=B.CULL_END_FRAME | more)
+        config = {"workload": f"gen_tree(12,4) truncated to {n_global} nodes, every node with an Aabb, {n_views} camera frustum(s): the hierarchy frame in one "
+                              "call -- mi_propagate_and_cull = subtree-tile propagation (root moved, every Transform counts as changed) "
+                              + ("in which every tile also runs the visibility systems over its own rows (k_propagate_fans<true, true>)" if fused
+                                 else "+ the cull launch over the GlobalTransforms it wrote") + " + VisibleEntities compaction",
+                  "baseline_config": "BASELINE.json configs[4] + the cull of configs[1]", "nodes": n_global, "views": n_views, "tile_plan": plan,
+                  "row_summary": args.row_summary == 0}
+        # propagate 141 B per node (above) + cull with G resident: read G 48 + Aabb 24 + flags 1 + layers 4 + vv 1, write vv 1 + masks
+        config["bytes_per_node"] = {"tile_launch": 141.0, "cull_launch_G_resident": flat_bytes_per_entity(n_views, False)}
+        wl = Workload("tree_frame", step_frame, tr["n"], 141.0, "k_propagate_tiles", config,
+                      "nodes/sec through hierarchy propagate + cull", "nodes/s", kernels=["k_propagate_tiles", "k_cull", "k_compact_fast"])
+        wl.tree = tr
+        wl.kernel_name = "k_propagate_fans<true,true>" if fused else "k_propagate_fans<true> + k_frame<0>"
+        if fused:  # + read Aabb 24 + flags 1 + layers 4 (summarised: 0.5) + vv 1, write vv 1 + masks
+            wl.bytes_per_row = 141.0 + 31.0 + (n_views + 1) / 8.0 + n_views / 64.0
+            if args.row_summary == 0:
+                wl.layout_bytes_per_row = wl.bytes_per_row - ROW_SUMMARY_SAVES
         return wl
 
     def step(f):
@@ -901,6 +937,8 @@ def main():
                "timing": f"median of {len(times)} blocks of exactly {args.steps} steps, each between barrier + synchronize pairs, MAX over ranks per block",
                "blocks": block_stats(np.array(times), args.steps), "roofline": roofline_of(wl, prof, args.steps), "cpu_baseline": None,
                "kernels": {k: round(v["avg_us"], 3) for k, v in prof.items() if v["launches"]}}
+        if scaling is None:
+            del out["scaling"]  # one GPU makes no scaling claim
         out.update(info)
         if world == 1 and not args.no_cpu_baseline:
             import oracle_lib  # noqa: F401 -- the oracle doubles as the reported CPU baseline ("port"), never as the product
@@ -939,7 +977,9 @@ def main():
                  ("flat_10m_4views", lambda c: build_flat(c, args, 0, 1, [], 10_000_000, 4, "sharded")),
                  ("flat_10m_1view", lambda c: build_flat(c, args, 0, 1, [], 10_000_000, 1, "flat")),
                  ("tree", lambda c: build_tree(c, args)), ("tree_one_subtree_moves", lambda c: build_tree(c, with_args(args, tree_moved="subtree"))),
-                 ("tree_10k_leaves_move", lambda c: build_tree(c, with_args(args, tree_moved="leaves"))), ("lights", lambda c: build_lights(c, args)),
+                 ("tree_10k_leaves_move", lambda c: build_tree(c, with_args(args, tree_moved="leaves"))),
+                 ("tree_frame", lambda c: build_tree(c, with_args(args, tree_cull=True))),
+                 ("tree_frame_tiles_cull", lambda c: build_tree(c, with_args(args, tree_cull=True, tree_cull_launches=1))), ("lights", lambda c: build_lights(c, args)),
                  ("flat_static", lambda c: build_flat_static(c, args)), ("flat_static_no_sphere_column", lambda c: build_flat_static(c, with_args(args, sphere_path=1))),
                  ("flat_static_10m_4views", lambda c: build_flat_static(c, with_args(args, entities=10_000_000, views=4))),
                  ("batching", lambda c: build_batching(c, args)),

@@ -25,7 +25,7 @@ __device__ unsigned long long mi_walk_marks[16 * 4096];
 // glibc >= 2.28 logf (ARM optimized-routines algorithm, table size 16, degree-3 polynomial in
 // double).  Rust's f32::ln is the platform libm's logf (bevy_math/src/ops.rs:22-60), so this is the
 // function view_z_to_z_slice (assign.rs:1057) evaluates on the reference's CPU path.  Verified
-// bit-identical to libm logf for every non-negative binary32 (tests/test_gpu_cluster.py::test_device_logf_matches_libm keeps a sample; glibc >= 2.28 on x86-64 is the supported host libm).
+// bit-identical to libm logf for every non-negative binary32 (tests/test_gpu_parity.py::test_device_logf_matches_libm keeps a sample; glibc >= 2.28 on x86-64 is the supported host libm).
 static __device__ __constant__ double LOGF_TAB[16][2] = {
     {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2},
     {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2},  {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3},

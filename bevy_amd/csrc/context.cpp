@@ -1193,7 +1193,7 @@ int32_t mi_propagate(mi_ctx* ctx, uint32_t flags) {
                                                 (const uint32_t*)ctx->chains.p + (size_t)gr.first * TILE_MAX_CHAIN, gr.count,
                                                 (const uint8_t*)ctx->node_flags.p, ctx->changed, tree_bits, ctx->g_changed_bytes,
                                                 gr.n_chain ? snap_r : nullptr, snap_w, ctx->snap_rows, all_dirty, static_opt,
-                                                ctx->tiles_light, ctx->stream, (unsigned long long*)ctx->tree_trace.p, tiles_pretest));
+                                                ctx->tiles_light, ctx->stream, (unsigned long long*)ctx->tree_trace.p, tiles_pretest, ctx->tcull));
         }
         for (auto& lv : ctx->stream_levels) {  // the wide deepest levels, each behind the level above it
             ProfScope sc(ctx, K_PROPAGATE_STREAM);
@@ -1248,8 +1248,66 @@ int32_t mi_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_mas
     return mi_cull_views(ctx, v.empty() ? nullptr : v.data(), n_views, flags);
 }
 
+// The hierarchy frame in the tile launches themselves: every Transform counts as changed, so every tile runs, and each one also
+// runs the visibility systems over its own rows with their GlobalTransforms still in registers / LDS (k_propagate_fans<true, true>)
+// -- no second pass over the GlobalTransform column, one launch less.  A tile's rows are not aligned to the mask words, so the
+// words are ORed and counted with atomics: masks, wave counts and the ViewVisibility change words are zeroed first (three
+// memsets of a few hundred KB, enqueued in front of the tiles).  Applies when nothing else wants the frame kernels' own
+// machinery: a plan of light tiles only, views in the kernel arguments, one class segment per view, library-owned masks, no
+// visibility ranges, no cluster assignment in the same call.  Everything else takes the tile launch + cull launch.
+// MEASURED (profiles/r03_experiments.md, 1 M-node tree, 1 view): bit-identical, and SLOWER as built -- the tile kernel grows from 24.8
+// to 31.8 us (the rows' ViewVisibility bytes and summaries are fetched after the GlobalTransforms are done: one more dependent trip
+// per tile, twice; 68 registers: 7 instead of 8 workgroups per CU), and what the frame kernels carry for free goes out on its own
+// (three memsets, the previous frame's compaction): 45.0 us per frame against 37.2 for tile launch + cull launch.  It would take the
+// loads moved into the tile's first bursts, the zeroing folded into the previous frame's launch (a third set of masks) and the
+// compaction riding in the tile launch to get to ~30 us -- for frames in which EVERY Transform of a hierarchy changed, which is the
+// stress case, not what a game runs (change-driven frames: 16 us of tiles + 10 us of cull over the world-sphere column).  Kept as an
+// option (mi_debug_set_tree_cull(2)) with its tests; the default is the two launches.
+static bool tree_frame_fusable(mi_ctx* ctx, uint32_t n_views, uint32_t flags) {
+    return ctx->tree_cull_mode == 2 && ctx->n && ctx->tiles_light && ctx->stream_levels.empty() && !ctx->groups.empty() && n_views <= MAX_INLINE_VIEWS &&
+           !(flags & (MI_CULL_CHANGED_ROWS | MI_CULL_WITH_CLUSTERS)) && (flags & MI_CULL_END_FRAME) && !ctx->have_class_mask && !ctx->have_ranges &&
+           !ctx->ext_bitmask && !ctx->xch.on && !ctx->tree_trace.p;
+}
+static int32_t tree_frame_fused(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint32_t flags) {
+    VisibilityOut vo{};
+    CompactFastArgs prev_args{};
+    bool prev_has_job = false;
+    mi_ctx::Exchange::Job prev_job{};
+    const CompactFastArgs* prev = frame_begin(ctx, &prev_args, &prev_has_job, &prev_job) ? &prev_args : nullptr;
+    int32_t rc = exchange_begin(ctx);
+    if (rc) return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
+    if ((rc = prepare_views(ctx, views, n_views, &vo))) return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
+    SegOut seg;
+    if ((rc = prepare_segments(ctx, n_views, &seg))) return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
+    if ((rc = row_summary_ensure(ctx))) return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
+    // riders of the frame kernels that have no launch to ride in here: the previous frame's compaction and cluster fill go out on their own
+    if (prev) {
+        ProfScope ps(ctx, K_COMPACT_FAST);
+        HIP_TRY(ctx, launch_compact_fast(*prev, ctx->stream));
+    }
+    if (prev_has_job) exchange_push(ctx, prev_job);
+    if ((rc = cluster_fill_join(ctx))) return rc;
+    TreeCull cu{};
+    memcpy(cu.views.v, ctx->view_set.v, sizeof(ViewParams) * n_views);
+    cu.n_views = n_views;
+    cu.out = vo;
+    cu.wave_cnt = seg.wave_cnt;
+    cu.n_waves = seg.n_waves;
+    HIP_TRY(ctx, hipMemsetAsync(vo.bitmask + vo.word_offset, 0, (size_t)n_views * vo.words_per_view * 8, ctx->stream));
+    if (seg.wave_cnt) HIP_TRY(ctx, hipMemsetAsync(seg.wave_cnt, 0, (size_t)n_views * seg.n_waves, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->vv_chg_bits, 0, words64(ctx->n) * 8, ctx->stream));
+    ctx->tcull = &cu;
+    rc = mi_propagate(ctx, MI_PROPAGATE_ALL_DIRTY | ((flags & MI_CULL_STATIC_OPT) ? MI_PROPAGATE_STATIC_OPT : 0u));
+    ctx->tcull = nullptr;
+    if (rc) return rc;
+    if ((rc = run_compaction(ctx, vo, seg, flags))) return rc;
+    ctx->culled = true;
+    return exchange_end(ctx);
+}
+
 int32_t mi_propagate_and_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint32_t flags) {
     ENTER(ctx);
+    if (ctx->have_hierarchy && views && n_views && tree_frame_fusable(ctx, n_views, flags)) return tree_frame_fused(ctx, views, n_views, flags);
     if (ctx->have_hierarchy) {
         // With a hierarchy the frame is the tile launches of mi_propagate with the cull behind them: the same call for the
         // caller (and no host wait in between), G written once and read once.  (Flat rows have it in one kernel.)
@@ -1856,6 +1914,14 @@ int32_t mi_debug_set_tile_pretest(mi_ctx* ctx, int32_t mode) {
     ENTER(ctx);
     if (mode < 0 || mode > 2) return fail(ctx, MI_ERR_INVALID_ARG, "mi_debug_set_tile_pretest: mode %d", mode);
     ctx->tile_pretest_mode = mode;
+    return MI_OK;
+}
+
+// test / bench hook: the all-dirty hierarchy frame: 0, 1 = tile launch + cull launch (default), 2 = every tile culls its own rows
+int32_t mi_debug_set_tree_cull(mi_ctx* ctx, int32_t mode) {
+    ENTER(ctx);
+    if (mode < 0 || mode > 2) return fail(ctx, MI_ERR_INVALID_ARG, "mi_debug_set_tree_cull: mode %d", mode);
+    ctx->tree_cull_mode = mode;
     return MI_OK;
 }
 

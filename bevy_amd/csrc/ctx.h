@@ -88,6 +88,8 @@ struct mi_ctx {
     std::vector<std::pair<uint32_t, uint32_t>> passes;  // (first tile, n tiles); pass 0 starts at level 0 (roots)
     struct TileGroup { uint32_t first, count, n_chain, owner_rows; };
     bool tiles_light = false;       // the plan was made for the light tile kernel (TILE_LIGHT_*)
+    const mi::TreeCull* tcull = nullptr;  // set by the fused hierarchy frame around its mi_propagate: the tile launches also cull
+    int32_t tree_cull_mode = 0;           // mi_debug_set_tree_cull: 0, 1 = tile launch + cull launch (default), 2 = fused where it applies
     int32_t tile_pretest_mode = 0;  // mi_debug_set_tile_pretest
     int32_t tile_mode = 0;          // 0 = light tiles where they fit, 1 = always the big tiles, 2 = always light, 3 = as 0 with the streamed-level thresholds at their test values (mi_debug_set_tile_mode)
     std::vector<TileGroup> groups;  // tile launches of mi_propagate: roots + chain bands in one, then one per dependent band

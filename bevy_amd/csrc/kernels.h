@@ -313,11 +313,22 @@ hipError_t launch_mark_dirty(uint32_t n, const uint8_t* changed, uint32_t change
                              uint32_t* clear_words /* the other half, zeroed for the next frame; nullptr = none */, uint32_t n_clear_words,
                              hipStream_t stream);
 // One launch over a group of mutually independent tiles (TileDesc::kind tells roots / chain / dependent apart).
+// The hierarchy FRAME in the tile launch itself (k_propagate_fans<true, true>): every tile also runs the visibility systems over
+// its own rows, GlobalTransforms still in registers / LDS.  A tile's rows are not aligned to the 64-row words of the per-view masks,
+// so the words are ORed and the wave counts added with atomics into memory the host zeroed before the launch.
+struct TreeCull {
+    ViewSet views;
+    uint32_t n_views;
+    VisibilityOut out;      // zeroed: n_views * words_per_view words
+    uint8_t* wave_cnt;      // zeroed: [n_views][n_waves] (one class segment per view), or nullptr
+    uint32_t n_waves;
+};
 hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, const TileDesc* d_tiles, const uint32_t* d_chains,
                                   uint32_t n_tiles, const uint8_t* node_flags, const uint8_t* changed, const uint8_t* tree_bytes,
                                   uint8_t* g_changed_bytes, const float* snap_read, float* snap_write, uint32_t snap_rows, bool all_dirty,
                                   bool static_opt, bool light /* the plan is one of light tiles */, hipStream_t stream,
-                                  unsigned long long* trace = nullptr, bool pretest = false /* light tiles, static-scene rule: flags first */);
+                                  unsigned long long* trace = nullptr, bool pretest = false /* light tiles, static-scene rule: flags first */,
+                                  const TreeCull* cull = nullptr /* all-dirty light tiles: the visibility systems ride in the launch */);
 // One whole level [start, start + count) as a stream: every row's parent lies in the level above, complete in global
 // memory (an earlier launch).  Same per-node rule as the tiles.
 hipError_t launch_propagate_level(const Columns& c, const uint32_t* parent_idx, uint32_t start, uint32_t count, const uint8_t* changed,

@@ -25,6 +25,7 @@
 // write G 48 + changed 1; parent G comes from LDS (first level of a non-root tile: from L2).
 #include "glam_math.h"
 #include "kernels.h"
+#include "visibility_rule.h"
 
 namespace mi {
 
@@ -653,11 +654,100 @@ __device__ __forceinline__ bool quad_node_apply(bool on, bool is_root_level, boo
     return set;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The visibility systems over a tile's own rows (k_propagate_fans<true, true>, the hierarchy frame in one launch):
+// reset_view_visibility + check_visibility_cpu_culling + check_visibility_gpu_culling + mark_newly_hidden_entities_invisible
+// (visibility/mod.rs:733-737, 788-858, 884-918) for the rows a wave holds, GlobalTransform in hand.  Same rule as the frame
+// kernels (visibility_rule.h), same ViewVisibility byte and change tick (view_visibility_tail, kernels_flat.hip).  What differs
+// is where the packed results go: a tile's rows are not aligned to the 64-row words of the masks, so a wave cuts its lanes into
+// runs of consecutive rows inside one word, and the first lane of each run ORs the run's bits into the word and adds its
+// population to the word's count -- atomics into memory the host zeroed before the launch (TreeCull, kernels.h).
+// Every lane of the wave must call it; lanes carry rows in ascending order.
+// ---------------------------------------------------------------------------------------------
+struct NoCull {};
+template <bool CULL>
+struct CullArg {
+    typedef NoCull type;
+};
+template <>
+struct CullArg<true> {
+    typedef TreeCull type;
+};
+__device__ __forceinline__ void tile_cull_rows(const Columns& c, const TreeCull& cu, uint32_t lane, bool live, uint32_t row, const Affine& g) {
+    const uint32_t rrow = live ? row : 0u;  // (every load below is unconditional: one batch)
+    const uint32_t vv0 = c.view_visibility[rrow];
+    // Aabb / flags / RenderLayers: the 64-row summary where it says the rows agree (per lane: a wave's rows span two summaries or,
+    // for the upper rows, several), else the columns
+    const uint4* sp = reinterpret_cast<const uint4*>(c.row_summary) + 2ull * (c.row_summary_on ? rrow >> 6 : 0u);
+    const uint4 sa = sp[0], sb = sp[1];
+    const uint32_t bits = c.row_summary_on ? sb.w : 0u;
+    uint32_t fl = bits & 0xFFu, emask = sb.z;
+    V3 center = V3{__uint_as_float(sa.x), __uint_as_float(sa.y), __uint_as_float(sa.z)};
+    V3 half = V3{__uint_as_float(sa.w), __uint_as_float(sb.x), __uint_as_float(sb.y)};
+    if (!(bits & ROWSUM_UNIFORM_FLAGS)) {
+        fl = c.flags[rrow];
+        emask = c.layer_mask[rrow];
+    }
+    if (!(bits & ROWSUM_UNIFORM_AABB)) {
+        center = ld3(c.aabb_center, rrow);
+        half = ld3(c.aabb_half, rrow);
+    }
+    if (!live) fl = 0u;
+    const bool ncc = (fl & 0x10u) != 0;  // NoCpuCulling rows are not in the cull query (mod.rs:771)
+    uint32_t pass = 0u;
+    for (uint32_t v = 0; v < cu.n_views; ++v)
+        if (live && !ncc && row_visible_in_view(g, center, half, fl, emask, false, 0.0f, 0.0f, cu.views.v[v])) pass |= 1u << v;
+    // the ViewVisibility byte: reset (mod.rs:270-274), set_visible (:290-306), gpu-culling rows (:884-903), mark_newly_hidden (:908-918)
+    uint32_t cur = vv0;
+    bool vv_changed = false;
+    if (live) {
+        if (!ncc) cur = (cur & 1u) << 1;
+        if (pass && !(cur & 1u)) {
+            vv_changed = !(cur & 2u);
+            cur |= 1u;
+        }
+        if (ncc) {
+            const uint32_t nv = (fl & 0x01u) ? 3u : 0u;
+            if (nv != cur) { cur = nv; vv_changed = true; }
+        } else if ((cur & 3u) == 2u) {
+            cur = 0u;
+            vv_changed = true;
+        }
+        if (cur != vv0) c.view_visibility[row] = (uint8_t)cur;
+    }
+    // runs of consecutive rows inside one mask word
+    const uint32_t word = row >> 6, bit = row & 63u;
+    const uint32_t prev_row = __shfl_up(row, 1, 64);
+    const bool prev_live = __shfl_up(live ? 1 : 0, 1, 64) != 0;
+    const bool leader = live && (lane == 0u || !prev_live || row != prev_row + 1u || bit == 0u);
+    const unsigned long long leaders = __ballot(leader);
+    const unsigned long long after = lane == 63u ? 0ull : leaders & ~((2ull << lane) - 1ull);
+    const uint32_t end = after ? (uint32_t)__ffsll((long long)after) - 1u : 64u;
+    const uint32_t len = end - lane;
+    const unsigned long long run = len >= 64u ? ~0ull : (1ull << len) - 1ull;
+    for (uint32_t v = 0; v < cu.n_views; ++v) {
+        const unsigned long long m = __ballot((pass >> v) & 1u);
+        if (leader) {
+            const unsigned long long sbits = (m >> lane) & run;
+            if (sbits) {
+                atomicOr(reinterpret_cast<unsigned long long*>(cu.out.bitmask + (size_t)v * cu.out.words_per_view + cu.out.word_offset + word), sbits << bit);
+                if (cu.wave_cnt)  // a byte per word, four to an atomic (a word holds <= 64 rows: no carry between the bytes)
+                    atomicAdd(reinterpret_cast<uint32_t*>(cu.wave_cnt + (size_t)v * cu.n_waves) + (word >> 2), (uint32_t)__popcll(sbits) << (8u * (word & 3u)));
+            }
+        }
+    }
+    const unsigned long long cm = __ballot(vv_changed);
+    if (leader) {
+        const unsigned long long sbits = (cm >> lane) & run;
+        if (sbits) atomicOr(reinterpret_cast<unsigned long long*>(c.vv_changed_bits + word), sbits << bit);
+    }
+}
+
 constexpr uint32_t FAN_SLOTS = TILE_LIGHT_UCAP + TILE_MAX_CHAIN;  // LDS slots: upper rows, then the chain's nodes
 constexpr uint32_t FAN_CHAIN_LANE0 = 256u - TILE_MAX_CHAIN;       // chain node k is fetched by thread FAN_CHAIN_LANE0 + k
 
-template <bool ALL_DIRTY>
-__global__ void __launch_bounds__(256, ALL_DIRTY ? 8 : 7) k_propagate_fans(Columns c, TreeArgs a) {
+template <bool ALL_DIRTY, bool CULL = false>
+__global__ void __launch_bounds__(256, CULL ? 6 : ALL_DIRTY ? 8 : 7) k_propagate_fans(Columns c, TreeArgs a, typename CullArg<CULL>::type cu) {
     __shared__ float4 lds_g[FAN_SLOTS * 3];    // local affine, then (upper rows) the GlobalTransform in place
     // GlobalTransforms before this frame of the upper rows and the chain (dead once the level steps have fetched their columns of
     // them); afterwards the same memory is the four waves' transpose buffers of the last level (3 x 1 KB rows each)
@@ -979,6 +1069,7 @@ __global__ void __launch_bounds__(256, ALL_DIRTY ? 8 : 7) k_propagate_fans(Colum
         } else if (chg) {
             st_affine(c.global, row, cur);
         }
+        if constexpr (CULL) tile_cull_rows(c, cu, lane, live, row, cur);
     };
     FAN_STAMP(5);
     batch(0u, f_p, f_s, f_q, f_t, f_raw, true);
@@ -992,6 +1083,12 @@ __global__ void __launch_bounds__(256, ALL_DIRTY ? 8 : 7) k_propagate_fans(Colum
         stage[64u + lane] = fx.g1;
         stage[128u + lane] = fx.g2;
         batch(base, fx.p, fx.s, fx.q, fx.t, xraw, false);
+    }
+    if constexpr (CULL) {  // the upper rows: GlobalTransforms in LDS, slot = thread (waves 0 and 1)
+        if (wv * 64u < U) {
+            const bool on = tid < U;
+            tile_cull_rows(c, cu, lane, on, on ? lds_row[tid] : 0u, lds_affine(lds_g, on ? tid : 0u));
+        }
     }
     if (a.trace && tid == 0) {
         __builtin_amdgcn_s_waitcnt(0);  // stores drained
@@ -1210,7 +1307,7 @@ hipError_t launch_mark_dirty(uint32_t n, const uint8_t* changed, uint32_t change
 hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, const TileDesc* d_tiles, const uint32_t* d_chains,
                                   uint32_t n_tiles, const uint8_t* node_flags, const uint8_t* changed, const uint8_t* tree_bytes,
                                   uint8_t* g_changed_bytes, const float* snap_read, float* snap_write, uint32_t snap_rows, bool all_dirty,
-                                  bool static_opt, bool light, hipStream_t stream, unsigned long long* trace, bool pretest) {
+                                  bool static_opt, bool light, hipStream_t stream, unsigned long long* trace, bool pretest, const TreeCull* cull) {
     if (n_tiles == 0) return hipSuccess;
     TreeArgs a;
     a.pretest = pretest && changed && tree_bytes ? 1u : 0u;
@@ -1228,8 +1325,11 @@ hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, 
     a.all_dirty = all_dirty ? 1u : 0u;
     a.static_opt = static_opt ? 1u : 0u;
     a.trace = trace;
-    if (light && all_dirty) MI_LAUNCH(k_propagate_fans<true>, dim3(n_tiles), dim3(256), 0, stream, c, a);
-    else if (light) MI_LAUNCH(k_propagate_fans<false>, dim3(n_tiles), dim3(256), 0, stream, c, a);
+    if (cull) {
+        if (!(light && all_dirty) || !c.row_summary) return hipErrorInvalidValue;  // (the host checks: every tile runs, light tiles only)
+        MI_LAUNCH((k_propagate_fans<true, true>), dim3(n_tiles), dim3(256), 0, stream, c, a, *cull);
+    } else if (light && all_dirty) MI_LAUNCH((k_propagate_fans<true, false>), dim3(n_tiles), dim3(256), 0, stream, c, a, NoCull{});
+    else if (light) MI_LAUNCH((k_propagate_fans<false, false>), dim3(n_tiles), dim3(256), 0, stream, c, a, NoCull{});
     else MI_LAUNCH((k_propagate_tiles<TILE_BLOCK>), dim3(n_tiles), dim3(TILE_BLOCK), 0, stream, c, a);
     return hipGetLastError();
 }

@@ -1,0 +1,194 @@
+"""GPU parity of the hierarchy frame fused into the tile launches (kernels_tree.hip, k_propagate_fans<true, true>; context.cpp,
+tree_frame_fused): mi_propagate_and_cull on a context with a hierarchy, every Transform counting as changed -- each tile also
+runs reset_view_visibility + check_visibility + check_visibility_gpu_culling + mark_newly_hidden over its own rows
+(visibility/mod.rs:733-737, 788-858, 884-918) and ORs its bits into the packed masks with atomics.
+
+Against the oracle (propagate_parent_transforms, then the visibility systems over its GlobalTransforms) and against a twin context
+that runs the same call as two launches (the default; the fused form is mi_debug_set_tree_cull(2)): GlobalTransforms, their change ticks, every view's mask,
+VisibleEntities, ViewVisibility and its change ticks, frame after frame (the ViewVisibility byte carries from one to the next).
+Forests whose tiles start and end anywhere inside the 64-row mask words, ragged flags / layers / bounds, 1 to 8 views, frames that
+fall back (changed-rows frames in between, a shadow view kind, classes)."""
+import numpy as np
+import pytest
+
+import bevy_amd as B
+from bevy_amd import api, workloads as W
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def assert_bits(a, b, what):
+    bad = np.nonzero(np.asarray(a) != np.asarray(b))[0]
+    assert bad.size == 0, f"{what}: {bad.size} mismatches, first rows {bad[:8].tolist()}"
+
+
+def frusta_for(cams):
+    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+    return np.concatenate([api.compute_frustum(cfv, cam, W.CAMERA_FAR) for cam in cams])
+
+
+def random_forest(n, seed, max_children=6):
+    """Parents in level order for a random forest: a few roots, every other node under a random earlier node with room left."""
+    rng = np.random.default_rng(seed)
+    n_roots = max(1, n // 5000)
+    parent_old = np.full(n, 0xFFFFFFFF, np.uint32)
+    # build level by level so that rows come out in BFS order directly
+    levels = [list(range(n_roots))]
+    next_id = n_roots
+    while next_id < n:
+        prev = levels[-1]
+        kids = rng.integers(0, max_children + 1, len(prev))
+        if kids.sum() == 0:
+            kids[rng.integers(0, len(prev))] = 1
+        cur = []
+        for p, k in zip(prev, kids):
+            for _ in range(int(k)):
+                if next_id >= n:
+                    break
+                parent_old[next_id] = p
+                cur.append(next_id)
+                next_id += 1
+        levels.append(cur)
+    offs = np.cumsum([0] + [len(l) for l in levels if l]).astype(np.uint32)
+    return parent_old, offs
+
+
+def ragged_bounds(n, seed):
+    sc = W.many_cubes(n, radius=60.0, seed=seed, ragged_flags=True)
+    # keep some runs uniform so that summarised and ragged waves both occur
+    c, h, fl, lay = sc["aabb_center"].reshape(n, 3), sc["aabb_half"].reshape(n, 3), sc["flags"], sc["layers"]
+    for lo in range(0, n, 1000):
+        hi = min(n, lo + 500)
+        c[lo:hi] = 0.0
+        h[lo:hi] = 0.5
+        fl[lo:hi] = 0x05
+        lay[lo:hi] = 1
+    return sc
+
+
+def oracle_frame(parent, t, r, s, sc, vv, frusta):
+    _, g, _ = O.propagate_transforms(parent, t, r, s)
+    vv1 = O.reset_view_visibility(sc["flags"], vv)
+    vv2, vis, chg = O.check_visibility(g, sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"], vv1, frusta)
+    vv3, chg2 = O.check_visibility_gpu_culling(sc["flags"], vv2)
+    vv4, chg3 = O.mark_newly_hidden(sc["flags"], vv3)
+    return g, vv4, vis, chg | chg2 | chg3
+
+
+def compare(a, b, g, vv, vis, chg, n_views, what):
+    ga, ca = a.download_global_transforms()
+    gb, cb = b.download_global_transforms()
+    assert ga.tobytes() == g.tobytes(), f"{what}: GlobalTransform (fused)"
+    assert gb.tobytes() == g.tobytes(), f"{what}: GlobalTransform (two launches)"
+    assert_bits(ca, cb, f"{what}: GlobalTransform change ticks")
+    for v in range(n_views):
+        assert_bits(a.download_visibility(v), vis[v], f"{what}: mask of view {v} (fused)")
+        assert_bits(b.download_visibility(v), vis[v], f"{what}: mask of view {v} (two launches)")
+        rows = a.download_visible_entities(v, 0)[1]
+        assert np.array_equal(rows, np.nonzero(vis[v])[0].astype(np.uint32)), f"{what}: VisibleEntities of view {v}"
+    va, cva = a.download_view_visibility()
+    vb, cvb = b.download_view_visibility()
+    assert_bits(va, vv, f"{what}: ViewVisibility (fused)")
+    assert_bits(vb, vv, f"{what}: ViewVisibility (two launches)")
+    assert_bits(cva, chg, f"{what}: ViewVisibility change ticks (fused)")
+    assert_bits(cvb, chg, f"{what}: ViewVisibility change ticks (two launches)")
+
+
+@pytest.mark.parametrize("n,seed,n_views", [(1, 1, 1), (63, 2, 1), (65, 3, 2), (700, 4, 3), (5_000, 5, 1), (40_000, 6, 4), (150_001, 7, 8)])
+def test_fused_hierarchy_frame_matches_oracle_and_two_launches(n, seed, n_views):
+    parent, offs = random_forest(n, seed)
+    rng = np.random.default_rng(seed)
+    t = rng.normal(0.0, 6.0, (n, 3)).astype(F)
+    r = W.random_unit_quats(seed, n, 0).astype(F)
+    s = (0.8 + 0.4 * rng.random((n, 3))).astype(F)
+    sc = ragged_bounds(n, seed)
+    with api.Context(0) as a, api.Context(0) as b:
+        a.debug_set_tree_cull(2)
+        for ctx in (a, b):
+            ctx.resize(n)
+            ctx.upload_transforms(t.reshape(-1), r.reshape(-1), s.reshape(-1))
+            ctx.upload_hierarchy(parent, offs)
+            ctx.upload_bounds(sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"])
+        vv = np.zeros(n, np.uint8)
+        for frame in range(4):
+            if frame:  # some nodes move (the frame still counts every Transform as changed)
+                rows = np.sort(rng.choice(n, min(n, 20), replace=False)).astype(np.uint32)
+                t[rows] += rng.normal(0.0, 2.0, (len(rows), 3)).astype(F)
+                for ctx in (a, b):
+                    ctx.upload_transforms_indexed(rows, t[rows].reshape(-1), r[rows].reshape(-1), s[rows].reshape(-1))
+            cams = [W.many_cubes_camera(frame * 40, yaw=0.8 * v, position=(3.0 * v, 1.0, 40.0 - 10.0 * v)) for v in range(n_views)]
+            frusta = frusta_for(cams)
+            more = B.CULL_MORE_FRAMES if frame % 2 == 0 else 0  # the compaction deferred into the next call, and not
+            for ctx in (a, b):
+                ctx.propagate_and_cull(frusta, flags=B.CULL_END_FRAME | more)
+            g, vv, vis, chg = oracle_frame(parent, t.reshape(-1), r.reshape(-1), s.reshape(-1), sc, vv, frusta)
+            compare(a, b, g, vv, vis, chg, n_views, f"n={n} views={n_views} frame {frame}")
+
+
+def test_fused_and_fallback_frames_interleave():
+    """All-dirty frames (fused) between changed-rows frames, cull-only frames and a frame with a shadow view (two launches): the
+    ViewVisibility bytes and the world-sphere column's bookkeeping must carry across the two paths."""
+    tr = W.gen_tree(9, 4)
+    n = tr["n"]
+    t = tr["translation"].reshape(n, 3).copy()
+    r4, s3 = tr["rotation"].reshape(n, 4), tr["scale"].reshape(n, 3)
+    sc = ragged_bounds(n, 21)
+    rng = np.random.default_rng(5)
+    with api.Context(0) as a, api.Context(0) as b:
+        a.debug_set_tree_cull(2)
+        for ctx in (a, b):
+            ctx.resize(n)
+            ctx.upload_transforms(t.reshape(-1), tr["rotation"], tr["scale"])
+            ctx.upload_hierarchy(tr["parent"], tr["level_offsets"])
+            ctx.upload_bounds(sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"])
+            ctx.upload_changed(np.ones(n, np.uint8))
+        vv = np.zeros(n, np.uint8)
+        for frame, kind in enumerate(["all", "changed", "all", "cull", "cull", "all", "changed", "all"]):
+            rows = np.sort(rng.choice(n, 30, replace=False)).astype(np.uint32)
+            if kind != "cull":
+                t[rows] += rng.normal(0.0, 1.5, (30, 3)).astype(F)
+                for ctx in (a, b):
+                    ctx.upload_transforms_indexed(rows, t[rows].reshape(-1), r4[rows].reshape(-1), s3[rows].reshape(-1))
+            frusta = frusta_for([W.many_cubes_camera(frame * 30, position=(0.0, 0.0, 150.0)), W.many_cubes_camera(frame * 30, yaw=0.6, position=(20.0, 5.0, 100.0))])
+            for ctx in (a, b):
+                if kind == "all":
+                    ctx.propagate_and_cull(frusta, flags=B.CULL_END_FRAME | B.CULL_MORE_FRAMES)
+                elif kind == "changed":
+                    ctx.propagate_and_cull(frusta, flags=B.CULL_END_FRAME | B.CULL_CHANGED_ROWS)
+                else:
+                    ctx.propagate(0)
+                    ctx.cull(frusta, flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME)
+            g, vv, vis, chg = oracle_frame(tr["parent"], t.reshape(-1), tr["rotation"], tr["scale"], sc, vv, frusta)
+            ga = a.download_global_transforms()[0]
+            assert ga.tobytes() == g.tobytes(), f"frame {frame} ({kind}): GlobalTransform"
+            for v in range(2):
+                assert_bits(a.download_visibility(v), vis[v], f"frame {frame} ({kind}): view {v}")
+                assert np.array_equal(a.download_visible_entities(v, 0)[1], b.download_visible_entities(v, 0)[1])
+            va, cva = a.download_view_visibility()
+            assert_bits(va, vv, f"frame {frame} ({kind}): ViewVisibility")
+            assert_bits(cva, chg, f"frame {frame} ({kind}): ViewVisibility change ticks")
+
+
+def test_the_big_tree():
+    """BASELINE configs[4]: the 1 M-node tree, one all-dirty frame each way."""
+    tr = W.gen_tree(12, 4, 1_000_000)
+    n = tr["n"]
+    c, h = np.zeros(3 * n, F), np.full(3 * n, 0.5, F)
+    frusta = frusta_for([W.many_cubes_camera(0, position=(0.0, 0.0, 300.0))])
+    out = []
+    for mode in (2, 1):
+        with api.Context(0) as ctx:
+            ctx.debug_set_tree_cull(mode)
+            ctx.resize(n)
+            ctx.upload_transforms(tr["translation"], tr["rotation"], tr["scale"])
+            ctx.upload_hierarchy(tr["parent"], tr["level_offsets"])
+            ctx.upload_bounds(c, h)
+            for _ in range(2):
+                ctx.propagate_and_cull(frusta, flags=B.CULL_END_FRAME)
+            vv, chg = ctx.download_view_visibility()
+            out.append((ctx.download_global_transforms()[0].tobytes(), ctx.download_visibility(0).tobytes(), vv.tobytes(), chg.tobytes(),
+                        ctx.download_visible_entities(0, 0)[1].tobytes()))
+    assert out[0] == out[1]
+    assert np.frombuffer(out[0][1], np.uint32).any()

@@ -153,10 +153,10 @@ UPLOAD_DENSE = 0x1
 class View(C.Structure):
     """mi_view"""
     _fields_ = [("frustum", C.c_float * 24), ("layer_mask", C.c_uint32), ("flags", C.c_uint32),
-                ("position", C.c_float * 3), ("light_sphere", C.c_float * 4), ("reserved", C.c_uint32 * 3)]
+                ("position", C.c_float * 3), ("light_sphere", C.c_float * 4), ("layer_mask_hi", C.c_uint32), ("reserved", C.c_uint32 * 2)]
 
 
-def make_views(frusta, layer_masks=None, flags=None, positions=None, light_spheres=None):
+def make_views(frusta, layer_masks=None, flags=None, positions=None, light_spheres=None, layer_masks_hi=None):
     """Per-view numpy columns -> ctypes array of mi_view."""
     fr = np.ascontiguousarray(frusta, np.float32).reshape(-1, 24)
     nv = len(fr)
@@ -167,6 +167,7 @@ def make_views(frusta, layer_masks=None, flags=None, positions=None, light_spher
         arr[v].frustum[:] = fr[v].tolist()
         arr[v].layer_mask = int(layer_masks[v]) if layer_masks is not None else 1
         arr[v].flags = int(flags[v]) if flags is not None else 0
+        arr[v].layer_mask_hi = int(layer_masks_hi[v]) if layer_masks_hi is not None else 0
         if pos is not None:
             arr[v].position[:] = pos[v].tolist()
         if sph is not None:
@@ -184,7 +185,7 @@ NO_INPUT_INDEX = 0xFFFFFFFF
 
 ABI_SYMBOLS = [
     "mi_abi_version", "mi_ctx_create", "mi_ctx_destroy", "mi_last_error_string", "mi_synchronize",
-    "mi_columns_resize", "mi_upload_transforms", "mi_upload_transforms_indexed", "mi_map_upload_window", "mi_commit_upload_window", "mi_upload_global_transforms", "mi_upload_bounds",
+    "mi_columns_resize", "mi_upload_transforms", "mi_upload_transforms_indexed", "mi_map_upload_window", "mi_commit_upload_window", "mi_upload_global_transforms", "mi_upload_bounds", "mi_upload_render_layers_hi",
     "mi_upload_view_visibility", "mi_upload_visibility_classes", "mi_upload_entity_keys", "mi_upload_changed",
     "mi_upload_visibility_ranges", "mi_upload_visibility", "mi_upload_hierarchy", "mi_hierarchy_sort", "mi_propagate",
     "mi_visibility_propagate", "mi_download_inherited_visibility",
@@ -437,6 +438,11 @@ class Context:
         c, h, f, l = _f32(center), _f32(half), _u8(flags), _u32(layer_mask)
         self._ck(self._lib.mi_upload_bounds(self._h, first_row, len(c) // 3, _ptr(c, C.c_float), _ptr(h, C.c_float),
                                             _ptr(f, C.c_uint8), _ptr(l, C.c_uint32)))
+
+    def upload_render_layers_hi(self, layer_mask_hi, first_row=0):
+        """RenderLayers 32..63 of the rows (the low word goes with upload_bounds)."""
+        m = _u32(layer_mask_hi)
+        self._ck(self._lib.mi_upload_render_layers_hi(self._h, first_row, len(m), _ptr(m, C.c_uint32)))
 
     def upload_view_visibility(self, vv, first_row=0):
         vv = _u8(vv)

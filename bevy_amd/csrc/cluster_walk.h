@@ -158,7 +158,7 @@ __device__ __forceinline__ bool derive_row_visible(const ClusterObjects& o, cons
     // RenderLayers agree over whole waves of rows, and a row without an Aabb needs of its GlobalTransform only the translation
     // (visibility_rule.h: the Sphere branch).  Where every lane of the wave finds its rows summarised, the walk reads 12 + 16 bytes
     // per light (translation, pos_range) instead of 85.
-    uint32_t fl = 0, emask = 0;
+    uint32_t fl = 0, emask = 0, emask_hi = 0;
     V3 center = {}, half = {};
     bool summarised = false;
     if (o.row_summary && !o.derive_resident && !o.row_changed) {  // (uniform)
@@ -176,6 +176,7 @@ __device__ __forceinline__ bool derive_row_visible(const ClusterObjects& o, cons
     } else {
         fl = o.row_flags[row];
         emask = o.row_layers[row];
+        if (o.row_layers_hi) emask_hi = o.row_layers_hi[row];
         center = ld3c(o.row_aabb_center, row);
         half = ld3c(o.row_aabb_half, row);
         if (o.derive_resident) {  // (uniform) a cull-only frame: every row keeps its resident GlobalTransform
@@ -197,7 +198,7 @@ __device__ __forceinline__ bool derive_row_visible(const ClusterObjects& o, cons
     if (fl & 0x10u) return (fl & 0x01u) != 0;
     bool any = false;
     for (uint32_t v = 0; v < o.n_views; ++v)
-        any = any || row_visible_in_view(g, center, half, fl, emask, o.row_range != nullptr, range_lo, range_hi, views.v[v]);
+        any = any || row_visible_in_view(g, center, half, fl, emask, emask_hi, o.row_range != nullptr, range_lo, range_hi, views.v[v]);
     return any;
 }
 // The two early-outs at the top of the per-object loop (assign.rs:489 RenderLayers, :496 frustum vs light sphere) behind the

@@ -175,6 +175,7 @@ Columns columns_of(mi_ctx* ctx) {
     c.aabb_half = ctx->h;
     c.flags = ctx->flags;
     c.layer_mask = ctx->layers;
+    c.layer_mask_hi = ctx->layers_hi;
     c.view_visibility = ctx->vv;
     c.range_start_end = ctx->have_ranges ? ctx->range : nullptr;
     c.g_changed_bits = ctx->g_chg_bits;
@@ -236,7 +237,7 @@ int32_t prepare_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, Visib
     if (!views || n_views == 0) return fail(ctx, MI_ERR_INVALID_ARG, "mi_cull: views NULL or n_views == 0");
     std::vector<ViewParams> vp(n_views);
     memcpy(vp.data(), views, sizeof(ViewParams) * n_views);
-    for (auto& v : vp) v.pad[0] = v.pad[1] = v.pad[2] = 0;
+    for (auto& v : vp) v.pad[0] = v.pad[1] = 0;  // (mi_view::reserved; layer_mask_hi in front of it is the caller's)
     int32_t rc = MI_OK;
     ctx->views_inline = n_views <= MAX_INLINE_VIEWS;
     if (ctx->views_inline) {
@@ -637,7 +638,7 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
     }
     prof_collect(ctx);
     void* cols[] = {ctx->t, ctx->r, ctx->s, ctx->g, ctx->c, ctx->h, ctx->flags, ctx->vv, ctx->changed, ctx->g_changed_bytes,
-                    ctx->layers, ctx->class_mask, ctx->keys, ctx->g_chg_bits, ctx->vv_chg_bits, ctx->tree_bytes,
+                    ctx->layers, ctx->layers_hi, ctx->class_mask, ctx->keys, ctx->g_chg_bits, ctx->vv_chg_bits, ctx->tree_bytes,
                     ctx->range, ctx->visibility, ctx->inh_changed, ctx->bt_set, ctx->bt_bin, ctx->bt_input, ctx->bt_row_meta,
                     ctx->bt_kind, ctx->bt_cpu_bin, ctx->bt_bucket};
     for (void* p : cols)
@@ -752,6 +753,7 @@ int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
         ctx->changed_maybe = true;
         if ((rc = grow_column(ctx, ctx->g_changed_bytes, 1, old, new_cap, 0))) return rc;
         if ((rc = grow_column(ctx, ctx->layers, 1, old, new_cap, 0))) return rc;
+        if (ctx->layers_hi && (rc = grow_column(ctx, ctx->layers_hi, 1, old, new_cap, 0))) return rc;
         if ((rc = grow_column(ctx, ctx->class_mask, 1, old, new_cap, 0))) return rc;
         if ((rc = grow_column(ctx, ctx->keys, 1, old, new_cap, 0))) return rc;
         if ((rc = grow_column(ctx, ctx->range, 2, old, new_cap, 0))) return rc;
@@ -803,7 +805,7 @@ int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
         struct { void* p; size_t elem; int fill; } cols[] = {
             {ctx->t, 12, 0}, {ctx->r, 16, 0}, {ctx->s, 12, 0}, {ctx->g, 48, 0}, {ctx->c, 12, 0}, {ctx->h, 12, 0},
             {ctx->flags, 1, MI_FLAG_INHERITED_VISIBLE}, {ctx->vv, 1, 0}, {ctx->changed, 1, 1}, {ctx->g_changed_bytes, 1, 0},
-            {ctx->class_mask, 4, 0}, {ctx->keys, 8, 0}, {ctx->range, 8, 0}, {ctx->visibility, 1, 0}, {ctx->inh_changed, 1, 0},
+            {ctx->layers_hi, 4, 0}, {ctx->class_mask, 4, 0}, {ctx->keys, 8, 0}, {ctx->range, 8, 0}, {ctx->visibility, 1, 0}, {ctx->inh_changed, 1, 0},
             {ctx->bt_set, 4, 0xFF}, {ctx->bt_bin, 4, 0}, {ctx->bt_input, 4, 0}, {ctx->bt_row_meta, 4, 0xFF},
             {ctx->bt_kind, 1, 0}, {ctx->bt_cpu_bin, 4, 0}, {ctx->bt_bucket, 4, 0xFF}};
         for (auto& cdesc : cols)
@@ -1028,6 +1030,21 @@ int32_t mi_upload_bounds(mi_ctx* ctx, uint32_t first_row, uint32_t n, const floa
         if ((rc = upload(ctx, ctx->layers + first_row, def.data(), (size_t)n * 4))) return rc;
     }
     return MI_OK;
+}
+
+int32_t mi_upload_render_layers_hi(mi_ctx* ctx, uint32_t first_row, uint32_t n, const uint32_t* layer_mask_hi) {
+    ENTER(ctx);
+    if (!layer_mask_hi) return fail(ctx, MI_ERR_INVALID_ARG, "mi_upload_render_layers_hi: NULL");
+    int32_t rc = check_rows(ctx, first_row, n, "mi_upload_render_layers_hi");
+    if (rc) return rc;
+    if (!ctx->layers_hi) {  // the column appears with its first use: until then no kernel reads a fifth byte-quad per row
+        bool any = false;
+        for (uint32_t i = 0; i < n && !any; ++i) any = layer_mask_hi[i] != 0;
+        if (!any) return MI_OK;  // nothing above layer 31: still no column
+        if ((rc = grow_column(ctx, ctx->layers_hi, 1, 0, ctx->cap, 0))) return rc;
+    }
+    row_summary_touch(ctx, ROWSUM_PART_FLAGS, first_row, n);  // (rows above layer 31 are not summarised)
+    return upload(ctx, ctx->layers_hi + first_row, layer_mask_hi, (size_t)n * 4);
 }
 
 int32_t mi_upload_view_visibility(mi_ctx* ctx, uint32_t first_row, uint32_t n, const uint8_t* vv) {

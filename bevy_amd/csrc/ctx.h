@@ -48,6 +48,7 @@ struct mi_ctx {
     float *t = nullptr, *r = nullptr, *s = nullptr, *g = nullptr, *c = nullptr, *h = nullptr;
     uint8_t *flags = nullptr, *vv = nullptr, *changed = nullptr, *g_changed_bytes = nullptr;
     uint32_t *layers = nullptr, *class_mask = nullptr;
+    uint32_t* layers_hi = nullptr;  // RenderLayers 32..63: allocated by the first mi_upload_render_layers_hi (nullptr = no row has any)
     uint64_t *keys = nullptr, *g_chg_bits = nullptr, *vv_chg_bits = nullptr;
     uint8_t* tree_bytes = nullptr;  // TransformTreeChanged, a byte per row; two halves of tree_half_words 32-bit words (double-buffered by frame: tree_parity)
     uint32_t tree_half_words = 0, tree_parity = 0;

@@ -230,6 +230,7 @@ int32_t cluster_objects(mi_ctx* ctx, bool derive, ClusterObjects* po) {
             o.row_range = ctx->have_ranges ? ctx->range : nullptr;
             o.row_flags = ctx->flags;
             o.row_layers = ctx->layers;
+            o.row_layers_hi = ctx->layers_hi;
             const Columns cc = columns_of(ctx);
             o.row_summary = cc.row_summary_on ? cc.row_summary : nullptr;
         } else {

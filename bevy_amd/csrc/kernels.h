@@ -49,7 +49,8 @@ struct ViewParams {
     uint32_t flags;         // MI_VIEW_FLAG_*
     float position[3];      // origin for VisibilityRange distances
     float light_sphere[4];  // point / spot light (translation, range)
-    uint32_t pad[3];
+    uint32_t layer_mask_hi;  // RenderLayers 32..63 of the view
+    uint32_t pad[2];
 };
 static_assert(sizeof(ViewParams) == 144, "ViewParams layout");
 constexpr uint32_t SPHERE_AT_TRANSLATION = 0x7FC0A11Du;  // MI_SPHERE_AT_TRANSLATION (public header): half.y of a Sphere row whose centre is the row's GlobalTransform translation
@@ -68,6 +69,7 @@ struct Columns {
     const float* aabb_half;     // 3n
     const uint8_t* flags;       // n
     const uint32_t* layer_mask; // n
+    const uint32_t* layer_mask_hi;  // n: RenderLayers 32..63, or nullptr = no row has any (mi_upload_render_layers_hi)
     uint8_t* view_visibility;   // n
     const float* range_start_end;  // 2n (VisibilityRange start_margin.start, end_margin.end) or nullptr = no
                                    // VisibleEntityRanges resource
@@ -82,7 +84,8 @@ struct Columns {
 // entities of a mesh are spawned together: one Aabb for all of them), the flags byte and the RenderLayers mask.  A wave fetches the
 // 32 bytes with scalar loads; where a bit says "uniform" its lanes take the values from there and issue no loads on the column:
 // 29 of the ~119 B a row of the all-dirty frame costs (24 Aabb + 1 flags + 4 layers).  Waves whose rows differ read the columns as
-// before.  Written by k_row_summary from the columns themselves (after mi_upload_bounds / resize / visibility propagation, for the
+// before.  (A wave counts as uniform in its RenderLayers only if none of its rows has a layer above 31: the summary holds one word.)
+// Written by k_row_summary from the columns themselves (after mi_upload_bounds / resize / visibility propagation, for the
 // waves they touched), so the columns stay the only source of truth.
 //   words 0-2 Aabb centre, 3-5 half extents (valid iff ROWSUM_UNIFORM_AABB), 6 RenderLayers mask, 7 = flags byte | ROWSUM_* bits
 constexpr uint32_t ROWSUM_WORDS = 8u, ROWSUM_UNIFORM_AABB = 0x80000000u, ROWSUM_UNIFORM_FLAGS = 0x40000000u;
@@ -386,6 +389,7 @@ struct ClusterObjects {
     const float *row_translation, *row_rotation, *row_scale, *row_aabb_center, *row_aabb_half, *row_range;
     const uint8_t* row_flags;
     const uint32_t* row_layers;
+    const uint32_t* row_layers_hi;  // RenderLayers 32..63 of the rows, or nullptr
     const uint32_t* row_summary;  // RowSummary of the context's rows when it is current, else nullptr (derive mode)
 };
 constexpr uint32_t CLUSTER_BLOCK = 256;  // objects per workgroup (= bits per cluster row in LDS)

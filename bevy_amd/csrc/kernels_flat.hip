@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
 
     Affine g = {};
     V3 center = {}, half = {};
-    uint32_t fl = 0, emask = 0, vv0 = 0, cmask = 1u;
+    uint32_t fl = 0, emask = 0, emask_hi = 0, vv0 = 0, cmask = 1u;
     float range_lo = 0.0f, range_hi = 0.0f;
     // G resident: its three contiguous wave rows are requested first, so that the transpose only waits for them while the
     // bounds / flags / layers loads issued behind them are still in flight
@@ -357,6 +357,7 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
     } else if (live) {
         fl = c.flags[row];
         emask = c.layer_mask[row];
+        if (c.layer_mask_hi) emask_hi = c.layer_mask_hi[row];
     }
     if (live) {
         if (c.range_start_end && (fl & 0x20u)) {
@@ -393,7 +394,7 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
     for (uint32_t v = 0; v < n_views; ++v) {
         const ViewParams& vp = INLINE_VIEWS ? vs.v[v] : dviews[v];
         const bool vis = live && !ncc &&
-                         row_visible_in_view(g, center, half, fl, emask, c.range_start_end != nullptr, range_lo, range_hi, vp);
+                         row_visible_in_view(g, center, half, fl, emask, emask_hi, c.range_start_end != nullptr, range_lo, range_hi, vp);
         any = any || vis;
         emit_view(v, vis, any_live, lane, wave, cmask, out, seg);
     }
@@ -452,10 +453,11 @@ __global__ void __launch_bounds__(256) k_frame_sph(Columns c, ViewSet vs, const 
     const uint32_t vv0 = c.view_visibility[rrow];
     uint32_t cmask = 1u;
     if (seg.class_mask) cmask = seg.class_mask[rrow];
-    uint32_t fl = rs.bits & 0xFFu, emask = rs.layers;  // (the summary is waited for here, behind the loads every row issues)
+    uint32_t fl = rs.bits & 0xFFu, emask = rs.layers, emask_hi = 0u;  // (the summary is waited for here, behind the loads every row issues)
     if (!uni_fl) {
         fl = c.flags[rrow];
         emask = c.layer_mask[rrow];
+        if (c.layer_mask_hi) emask_hi = c.layer_mask_hi[rrow];
     }
     bool dirty = false;
     if (PARTIAL) dirty = live && row_changed(changed[rrow], c.changed_gen);
@@ -533,7 +535,7 @@ __global__ void __launch_bounds__(256) k_frame_sph(Columns c, ViewSet vs, const 
     uint32_t pass = 0u, need = 0u;  // bit v: the row is (still) visible in view v / it still owes view v the OBB test
     for (uint32_t v = 0; v < n_views; ++v) {
         const ViewParams& vp = INLINE_VIEWS ? vs.v[v] : dviews[v];
-        bool vis = base_ok && (vp.layer_mask & emask) != 0;
+        bool vis = base_ok && ((vp.layer_mask & emask) | (vp.layer_mask_hi & emask_hi)) != 0;
         if (ranged) {
             bool in_range = false;
             if ((vp.flags & (VIEW_RANGES | VIEW_RANGES_NO_ORIGIN)) == VIEW_RANGES) {
@@ -661,8 +663,9 @@ __global__ void __launch_bounds__(256) k_row_summary(Columns c, uint32_t first_w
     }
     if (parts & ROWSUM_PART_FLAGS) {
         const uint32_t fl = c.flags[rrow], lm = c.layer_mask[rrow];
+        const uint32_t hi = c.layer_mask_hi ? c.layer_mask_hi[rrow] : 0u;  // (the summary holds one word of layers: rows above 31 are not summarised)
         const uint32_t fl0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)fl), lm0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lm);
-        const bool uniform = __ballot(fl != fl0 || lm != lm0) == 0ull;
+        const bool uniform = __ballot(fl != fl0 || lm != lm0 || hi != 0u) == 0ull;
         bits = (bits & ~(ROWSUM_UNIFORM_FLAGS | 0xFFu)) | (uniform ? ROWSUM_UNIFORM_FLAGS : 0u) | (fl0 & 0xFFu);
         if (lane == 0u) o[6] = lm0;
     }

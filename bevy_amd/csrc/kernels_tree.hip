@@ -681,12 +681,13 @@ __device__ __forceinline__ void tile_cull_rows(const Columns& c, const TreeCull&
     const uint4* sp = reinterpret_cast<const uint4*>(c.row_summary) + 2ull * (c.row_summary_on ? rrow >> 6 : 0u);
     const uint4 sa = sp[0], sb = sp[1];
     const uint32_t bits = c.row_summary_on ? sb.w : 0u;
-    uint32_t fl = bits & 0xFFu, emask = sb.z;
+    uint32_t fl = bits & 0xFFu, emask = sb.z, emask_hi = 0u;
     V3 center = V3{__uint_as_float(sa.x), __uint_as_float(sa.y), __uint_as_float(sa.z)};
     V3 half = V3{__uint_as_float(sa.w), __uint_as_float(sb.x), __uint_as_float(sb.y)};
     if (!(bits & ROWSUM_UNIFORM_FLAGS)) {
         fl = c.flags[rrow];
         emask = c.layer_mask[rrow];
+        if (c.layer_mask_hi) emask_hi = c.layer_mask_hi[rrow];
     }
     if (!(bits & ROWSUM_UNIFORM_AABB)) {
         center = ld3(c.aabb_center, rrow);
@@ -696,7 +697,7 @@ __device__ __forceinline__ void tile_cull_rows(const Columns& c, const TreeCull&
     const bool ncc = (fl & 0x10u) != 0;  // NoCpuCulling rows are not in the cull query (mod.rs:771)
     uint32_t pass = 0u;
     for (uint32_t v = 0; v < cu.n_views; ++v)
-        if (live && !ncc && row_visible_in_view(g, center, half, fl, emask, false, 0.0f, 0.0f, cu.views.v[v])) pass |= 1u << v;
+        if (live && !ncc && row_visible_in_view(g, center, half, fl, emask, emask_hi, false, 0.0f, 0.0f, cu.views.v[v])) pass |= 1u << v;
     // the ViewVisibility byte: reset (mod.rs:270-274), set_visible (:290-306), gpu-culling rows (:884-903), mark_newly_hidden (:908-918)
     uint32_t cur = vv0;
     bool vv_changed = false;

@@ -32,12 +32,12 @@ __device__ __forceinline__ bool sphere_inside_five_planes(const float* planes, V
 }
 
 __device__ __forceinline__ bool row_visible_in_view(const Affine& g, V3 center, V3 half, uint32_t fl,
-                                                    uint32_t entity_mask, bool have_ranges, float range_lo,
+                                                    uint32_t entity_mask, uint32_t entity_mask_hi, bool have_ranges, float range_lo,
                                                     float range_hi, const ViewParams& vp) {
     const bool shadow = (vp.flags & VIEW_SHADOW) != 0;
     bool vis = (fl & 0x01u) != 0;                          // InheritedVisibility
     vis = vis && (!shadow || (fl & 0x80u));                // shadow views only see shadow casters
-    vis = vis && (vp.layer_mask & entity_mask) != 0;       // RenderLayers::intersects
+    vis = vis && ((vp.layer_mask & entity_mask) | (vp.layer_mask_hi & entity_mask_hi)) != 0;  // RenderLayers::intersects (render_layers.rs:121-135), layers 0..63
     const bool has_aabb = (fl & 0x04u) != 0;
     if ((fl & 0x20u) && have_ranges) {                     // Has<VisibilityRange> && VisibleEntityRanges exists
         bool in_range = false;

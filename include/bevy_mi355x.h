@@ -207,6 +207,11 @@ int32_t mi_upload_global_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t n,
 int32_t mi_upload_bounds(mi_ctx* ctx, uint32_t first_row, uint32_t n, const float* aabb_center,
                          const float* aabb_half_extents, const uint8_t* flags, const uint32_t* layer_mask);
 
+/* RenderLayers 32..63 of the rows (optional column; rows never uploaded have none).  RenderLayers::intersects
+ * (crates/bevy_camera/src/visibility/render_layers.rs:121-135) compares the masks word by word: with this column and
+ * mi_view.layer_mask_hi the first 64-bit word is covered; entities on layers >= 64 stay with the stock system. */
+int32_t mi_upload_render_layers_hi(mi_ctx* ctx, uint32_t first_row, uint32_t n, const uint32_t* layer_mask_hi);
+
 /* ViewVisibility's packed byte (bit0 current, bit1 previous; visibility/mod.rs:226-275). */
 int32_t mi_upload_view_visibility(mi_ctx* ctx, uint32_t first_row, uint32_t n, const uint8_t* view_visibility);
 
@@ -283,12 +288,14 @@ int32_t mi_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_mas
  * its own bitmask / VisibleEntities (VisibleMeshEntities) lists, indexed by its position in the array. */
 typedef struct mi_view {
     float frustum[24];     /* Frustum::half_spaces */
-    uint32_t layer_mask;   /* RenderLayers of the camera / light */
+    uint32_t layer_mask;   /* RenderLayers of the camera / light: layers 0..31 (layers 32..63: layer_mask_hi below) */
     uint32_t flags;        /* MI_VIEW_FLAG_* */
     float position[3];     /* GlobalTransform::translation of the view for VisibilityRange distances: the camera,
                               the cascade's camera (lib.rs:437-443) or the shadow LOD origin (lib.rs:601-611) */
     float light_sphere[4]; /* point / spot light: (translation, range) */
-    uint32_t reserved[3];  /* 0 */
+    uint32_t layer_mask_hi; /* layers 32..63 of the view's RenderLayers (the first u64 word of the reference's bitset,
+                               render_layers.rs:121-135); matched against mi_upload_render_layers_hi's column */
+    uint32_t reserved[2];  /* 0 */
 } mi_view;
 int32_t mi_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint32_t flags /* MI_CULL_* */);
 int32_t mi_propagate_and_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint32_t flags);

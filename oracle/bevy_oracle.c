@@ -597,6 +597,32 @@ void orc_check_visibility(uint32_t n, const float* global, const float* aabb_cen
     }
 }
 
+/* The same with RenderLayers of up to 64 layers -- the first u64 word of the reference's bitset; RenderLayers::intersects
+ * (render_layers.rs:121-135) is "some word of the two masks has a common bit".  layer_mask_hi / view_layer_masks_hi: layers 32..63
+ * (NULL = none). */
+void orc_check_visibility_layers64(uint32_t n, const float* global, const float* aabb_center, const float* aabb_half,
+                                   const uint8_t* flags, const uint32_t* layer_mask, const uint32_t* layer_mask_hi, const uint8_t* in_range,
+                                   uint8_t* vv, const float* frusta, const uint32_t* view_layer_masks, const uint32_t* view_layer_masks_hi,
+                                   const uint8_t* view_flags, uint32_t n_views, uint8_t* visible_out, uint8_t* vv_changed_out) {
+    for (uint32_t v = 0; v < n_views; ++v) {
+        const float* frustum = frusta + 24 * v;
+        uint64_t view_mask = (view_layer_masks ? view_layer_masks[v] : 1u) | ((uint64_t)(view_layer_masks_hi ? view_layer_masks_hi[v] : 0u) << 32);
+        int ncc = view_flags ? (view_flags[v] & ORC_VIEW_FLAG_NO_CPU_CULLING) != 0 : 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            uint8_t fl = flags[i];
+            uint8_t vis = 0;
+            if (!(fl & ORC_FLAG_NO_CPU_CULLING)) {
+                uint64_t em = (layer_mask ? layer_mask[i] : 1u) | ((uint64_t)(layer_mask_hi ? layer_mask_hi[i] : 0u) << 32);
+                int ir = in_range ? in_range[(size_t)v * n + i] : 1;
+                vis = (uint8_t)entity_visible_in_view(global + 12 * (size_t)i, aabb_center + 3 * (size_t)i, aabb_half + 3 * (size_t)i, fl,
+                                                      (view_mask & em) ? 1u : 0u, ir, frustum, 1u, ncc);
+                if (vis) set_visible(&vv[i], vv_changed_out ? &vv_changed_out[i] : NULL);
+            }
+            if (visible_out) visible_out[(size_t)v * n + i] = vis;
+        }
+    }
+}
+
 /* VisibilityRange::is_visible_at_all(distance), range.rs:159-161, with the model position rule of :255-263 */
 static inline int entity_in_range_of(const float* g, const float* c, uint8_t fl, const float* start_end,
                                      const float* view_pos) {

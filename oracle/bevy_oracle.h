@@ -156,6 +156,12 @@ void orc_check_visibility(uint32_t n, const float* global, const float* aabb_cen
                           const uint8_t* in_range, uint8_t* view_visibility, const float* frusta,
                           const uint32_t* view_layer_masks, const uint8_t* view_flags,
                           uint32_t n_views, uint8_t* visible_out, uint8_t* vv_changed_out);
+/* ... with RenderLayers of up to 64 layers (render_layers.rs:121-135: the first u64 word of the bitset); *_hi = layers 32..63, NULL = none */
+void orc_check_visibility_layers64(uint32_t n, const float* global, const float* aabb_center, const float* aabb_half,
+                                   const uint8_t* flags, const uint32_t* layer_mask, const uint32_t* layer_mask_hi, const uint8_t* in_range,
+                                   uint8_t* view_visibility, const float* frusta, const uint32_t* view_layer_masks,
+                                   const uint32_t* view_layer_masks_hi, const uint8_t* view_flags, uint32_t n_views, uint8_t* visible_out,
+                                   uint8_t* vv_changed_out);
 /* One view of any kind the main-world visibility systems test entities against. */
 typedef struct orc_view {
     float frustum[24];

@@ -141,6 +141,8 @@ struct Scratch {
     aabb_half: Vec<f32>,
     flags: Vec<u8>,
     layers: Vec<u32>,
+    layers_hi: Vec<u32>, // RenderLayers 32..63 (uploaded only once some entity uses one: mi_upload_render_layers_hi)
+    any_layers_hi: bool,
     classes: Vec<u32>,
     view_visibility: Vec<u8>,
     vv_changed: Vec<u32>,
@@ -559,16 +561,18 @@ pub fn mi_check_visibility(
             if !camera.is_active {
                 continue;
             }
+            let (layer_mask, layer_mask_hi) = match layers {
+                None => (1, 0),
+                Some(l) => layer_words(l).ok_or(())?,
+            };
             let mut view = ffi::MiView {
                 frustum: [0.0; 24],
-                layer_mask: match layers {
-                    None => 1,
-                    Some(l) => layer_word(l).ok_or(())?,
-                },
+                layer_mask,
                 flags: if no_cpu_culling { ffi::MI_VIEW_FLAG_NO_CPU_CULLING } else { 0 },
                 position: [0.0; 3],
                 light_sphere: [0.0; 4],
-                reserved: [0; 3],
+                layer_mask_hi,
+                reserved: [0; 2],
             };
             for (p, half_space) in frustum.half_spaces.iter().enumerate() {
                 view.frustum[p * 4..p * 4 + 4].copy_from_slice(&half_space.normal_d().to_array());
@@ -637,7 +641,20 @@ pub fn mi_check_visibility(
     }
 }
 
-/// `RenderLayers` as the one 32-bit word of the `layer_mask` column, `None` if a layer above 31 is set.
+/// `RenderLayers` as the two 32-bit words the library matches (`layer_mask`, `layer_mask_hi`: the first u64 word of the bitset,
+/// render_layers.rs:121-135), `None` if a layer above 63 is set.
+fn layer_words(layers: &RenderLayers) -> Option<(u32, u32)> {
+    let mut bits = 0u64;
+    for layer in layers.iter() {
+        if layer >= 64 {
+            return None;
+        }
+        bits |= 1 << layer;
+    }
+    Some((bits as u32, (bits >> 32) as u32))
+}
+
+/// `RenderLayers` as the one 32-bit word of a cluster object's `layer_mask`, `None` if a layer above 31 is set.
 fn layer_word(layers: &RenderLayers) -> Option<u32> {
     let mut word = 0u32;
     for layer in layers.iter() {
@@ -1078,17 +1095,21 @@ pub fn mi_fused_frame(
             for (p, half_space) in frustum.half_spaces.iter().enumerate() {
                 planes[p * 4..p * 4 + 4].copy_from_slice(&half_space.normal_d().to_array());
             }
-            let layer_mask = match layers {
-                None => 1,
-                Some(l) => layer_word(l).ok_or(())?,
+            let (layer_mask, layer_mask_hi) = match layers {
+                None => (1, 0),
+                Some(l) => layer_words(l).ok_or(())?,
             };
+            if has_clusters && layer_mask_hi != 0 {
+                return Err(()); // cluster objects carry one 32-bit layer word: a clustered camera above layer 31 stays with the stock systems
+            }
             views.push(ffi::MiView {
                 frustum: planes,
                 layer_mask,
                 flags: if no_cpu_culling { ffi::MI_VIEW_FLAG_NO_CPU_CULLING } else { 0 },
                 position: [0.0; 3],
                 light_sphere: [0.0; 4],
-                reserved: [0; 3],
+                layer_mask_hi,
+                reserved: [0; 2],
             });
             frame_views.push(FrameView { entity, frustum: planes, lists: Vec::new() });
             if has_clusters {
@@ -1327,6 +1348,8 @@ fn stage_bounds(
     s.flags.resize(n, 0);
     s.layers.clear();
     s.layers.resize(n, 0);
+    s.layers_hi.clear();
+    s.layers_hi.resize(n, 0);
     s.classes.clear();
     s.classes.resize(n, 0);
     for (entity, inherited, classes, layers, aabb, sphere, point_light, no_frustum_culling, has_range) in rows_query.iter() {
@@ -1359,10 +1382,11 @@ fn stage_bounds(
             s.aabb_half[row * 3] = sphere.radius;
         }
         s.flags[row] = flags as u8;
-        s.layers[row] = match layers {
-            None => 1, // RenderLayers::default() == layer 0
-            Some(l) => layer_word(l).ok_or(())?,
+        (s.layers[row], s.layers_hi[row]) = match layers {
+            None => (1, 0), // RenderLayers::default() == layer 0
+            Some(l) => layer_words(l).ok_or(())?,
         };
+        s.any_layers_hi |= s.layers_hi[row] != 0;
         if let Some(classes) = classes {
             for class in classes.iter() {
                 s.classes[row] |= 1 << mi_class_bit(&mut mi.class_bits, *class).ok_or(())?;
@@ -1376,6 +1400,10 @@ fn stage_bounds(
             "mi_upload_bounds",
             ffi::mi_upload_bounds(ctx, 0, n as u32, s.aabb_center.as_ptr(), s.aabb_half.as_ptr(), s.flags.as_ptr(), s.layers.as_ptr()),
         )?;
+        if s.any_layers_hi {
+            // (once a layer above 31 was seen the column stays in use: a row that leaves it must be written back to 0)
+            check(ctx, "mi_upload_render_layers_hi", ffi::mi_upload_render_layers_hi(ctx, 0, n as u32, s.layers_hi.as_ptr()))?;
+        }
         check(ctx, "mi_upload_visibility_classes", ffi::mi_upload_visibility_classes(ctx, 0, n as u32, s.classes.as_ptr()))
     }
 }

@@ -265,6 +265,17 @@ def check_visibility(g, c, h, flags, layers, vv, frusta, view_masks=None, view_f
     return vv, vis.reshape(nv, n), chg
 
 
+def check_visibility_layers64(g, c, h, flags, layers, layers_hi, vv, frusta, view_masks, view_masks_hi):
+    n = len(flags)
+    nv = len(frusta) // 24
+    vv = vv.copy()
+    vis = np.zeros(nv * n, np.uint8)
+    chg = np.zeros(n, np.uint8)
+    lib().orc_check_visibility_layers64(n, fp(g), fp(c), fp(h), u8p(flags), u32p(layers), u32p(layers_hi), None, u8p(vv), fp(frusta),
+                                        u32p(view_masks), u32p(view_masks_hi), None, nv, u8p(vis), u8p(chg))
+    return vv, vis.reshape(nv, n), chg
+
+
 def check_visibility_ranges(g, c, flags, range_start_end, view_positions):
     n = len(flags)
     vp = np.ascontiguousarray(view_positions, np.float32).reshape(-1)

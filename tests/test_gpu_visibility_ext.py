@@ -232,3 +232,80 @@ def test_inherited_visibility_propagation_matches_oracle(shape):
             assert rc == 0
             assert_bits(got, inh, f"{shape} frame {frame} InheritedVisibility")
             assert_bits(got_chg, chg, f"{shape} frame {frame} change ticks")
+
+
+def test_render_layers_up_to_63():
+    """RenderLayers::intersects compares the masks word by word (render_layers.rs:121-135); the first u64 word = the row column
+    `layer_mask` + mi_upload_render_layers_hi and mi_view.layer_mask / layer_mask_hi.  Rows and views spread over layers 0..63, on
+    every frame kernel: the all-rows frame, the cull-only frame (resident GlobalTransforms and the world-sphere column), the
+    changed-rows frame, the fused hierarchy frame -- against the oracle's 64-layer restatement; rows above layer 31 sit inside
+    waves that are otherwise uniform (the row summary must not cover them)."""
+    n = 20_000
+    sc = W.many_cubes(n, radius=60.0)
+    rng = np.random.default_rng(8)
+    lo = np.ones(n, np.uint32)
+    hi = np.zeros(n, np.uint32)
+    odd = np.sort(rng.choice(n, 3000, replace=False))
+    layer = rng.integers(0, 64, len(odd))
+    lo[odd] = np.where(layer < 32, np.uint64(1) << np.minimum(layer, 31).astype(np.uint64), 0).astype(np.uint32)
+    hi[odd] = np.where(layer >= 32, np.uint64(1) << np.maximum(layer - 32, 0).astype(np.uint64), 0).astype(np.uint32)
+    both = odd[:200]
+    lo[both] |= 1
+    hi[both] |= np.uint32(1 << 7)
+    vm_lo = np.array([1, 0, 1 << 5, 0xFFFFFFFF], np.uint32)
+    vm_hi = np.array([0, 1 << 7, 1 << 20, 0xFFFFFFFF], np.uint32)
+    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+    g, _ = O.sync_simple_transforms(sc["translation"], sc["rotation"], sc["scale"])
+
+    def expected(vv, frusta):
+        vv1 = O.reset_view_visibility(sc["flags"], vv)
+        vv2, vis, chg = O.check_visibility_layers64(g, sc["aabb_center"], sc["aabb_half"], sc["flags"], lo, hi, vv1, frusta, vm_lo, vm_hi)
+        vv3, chg2 = O.check_visibility_gpu_culling(sc["flags"], vv2)
+        vv4, chg3 = O.mark_newly_hidden(sc["flags"], vv3)
+        return vv4, vis, chg | chg2 | chg3
+
+    def views_of(frame):
+        fr = np.concatenate([api.compute_frustum(cfv, W.many_cubes_camera(frame * 30, yaw=1.5 * v), W.CAMERA_FAR) for v in range(4)])
+        return fr, api.make_views(fr, layer_masks=vm_lo, layer_masks_hi=vm_hi)
+
+    for sphere_path in (1, 2):
+        with api.Context(0) as ctx:
+            ctx.debug_set_sphere_path(sphere_path)
+            ctx.resize(n)
+            ctx.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
+            ctx.upload_bounds(sc["aabb_center"], sc["aabb_half"], sc["flags"], lo)
+            ctx.upload_render_layers_hi(hi)
+            ctx.upload_changed(np.ones(n, np.uint8))
+            vv = np.zeros(n, np.uint8)
+            for frame, kind in enumerate(["all", "cull", "cull", "changed", "cull"]):
+                fr, views = views_of(frame)
+                if kind == "all":
+                    ctx.propagate_and_cull_views(views, flags=B.CULL_END_FRAME)
+                elif kind == "changed":
+                    ctx.propagate_and_cull_views(views, flags=B.CULL_END_FRAME | B.CULL_CHANGED_ROWS)
+                else:
+                    ctx.propagate(0)
+                    ctx.cull_views(views, flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME)
+                vv, vis, chg = expected(vv, fr)
+                for v in range(4):
+                    got = ctx.download_visibility(v)
+                    bad = np.nonzero(got != vis[v])[0]
+                    assert bad.size == 0, f"sphere path {sphere_path} frame {frame} ({kind}) view {v}: rows {bad[:8].tolist()}"
+                va, cva = ctx.download_view_visibility()
+                assert np.array_equal(va, vv) and np.array_equal(cva, chg), f"sphere path {sphere_path} frame {frame} ({kind}): ViewVisibility"
+        assert vis[1].any() and vis[2].any()  # the views that live above layer 31 see something
+
+    # the same rows under a hierarchy (a forest of single nodes): the tile kernel's own cull
+    with api.Context(0) as ctx:
+        ctx.debug_set_tree_cull(2)
+        ctx.resize(n)
+        ctx.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
+        ctx.upload_hierarchy(np.full(n, 0xFFFFFFFF, np.uint32), np.array([0, n], np.uint32))
+        ctx.upload_bounds(sc["aabb_center"], sc["aabb_half"], sc["flags"], lo)
+        ctx.upload_render_layers_hi(hi)
+        fr, views = views_of(3)
+        ctx.propagate_and_cull_views(views, flags=B.CULL_END_FRAME)
+        vv, vis, chg = expected(np.zeros(n, np.uint8), fr)
+        for v in range(4):
+            assert np.array_equal(ctx.download_visibility(v), vis[v]), f"hierarchy frame, view {v}"
+        assert np.array_equal(ctx.download_view_visibility()[0], vv)

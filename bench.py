@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", choices=["auto", "frame", "sharded", "flat", "tree", "lights", "flat_static", "batching", "batching_sorted"], default="auto",
                     help="auto = frame at N=1 (the BASELINE metric), sharded (configs[3]) at N>1")
+    ap.add_argument("--walk-inrow", type=int, default=0, choices=[0, 1], help="frame: 0 = the lights' row workgroups walk them (default), 1 = extra workgroups re-derive their visibility")
     ap.add_argument("--row-summary", type=int, default=0, choices=[0, 1],
                     help="0 = waves whose 64 rows agree in Aabb / flags / RenderLayers read the 32-byte summary (default), 1 = off")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong", help="sharded workload: total rows fixed / rows per GPU fixed")
@@ -130,6 +131,7 @@ def build_frame(ctx, args):
     c_dev[first_light:] = 0.0
     h_dev[first_light:, 1] = np.frombuffer(np.uint32(0x7FC0A11D).tobytes(), np.float32)[0]
     ctx.debug_set_row_summary(args.row_summary)
+    ctx.debug_set_walk_inrow(getattr(args, "walk_inrow", 0))
     ctx.upload_bounds(c_dev.reshape(-1), h_dev.reshape(-1), sc["flags"], sc["layers"])
     ctx.cluster_upload_objects(pr)
     ctx.cluster_bind_objects_to_rows(first_light, args.lights)

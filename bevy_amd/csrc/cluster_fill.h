@@ -96,7 +96,7 @@ __device__ __forceinline__ void cluster_fill_block(const ClusterWork& w, uint32_
                                            ((unsigned long long)__shfl(mw, (int)(2u * j + 1u), 64) << 32);
             if ((m64 >> lane) & 1ull) {
                 const uint64_t d = dst + __popcll(m64 & lt);
-                if (d < w.capacity) w.indices[d] = b * CLUSTER_BLOCK + j * 64u + lane;
+                if (d < w.capacity) w.indices[d] = (uint32_t)((int32_t)(b * CLUSTER_BLOCK + j * 64u + lane) + w.obj_delta);
             }
             dst += __popcll(m64);
         }

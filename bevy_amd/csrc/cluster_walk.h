@@ -405,9 +405,47 @@ __device__ __forceinline__ void object_walk(const ClusterViewDev& v, const Objec
 // loop: 67 instead of 103 VGPRs, which is what lets the walk share a kernel with the frame rows at their occupancy.
 // SPOTS = false: the caller guarantees there is no spot light among the objects (the walk riding in the frame kernel: ctx_cluster.cpp
 // sends scenes with spot lights to the walk kernel of its own) -- the cone test and its five registers per object drop out.
+// What a walking workgroup fetches in front of everything else (with its objects' own loads): its share of the view's plane tables
+// (floats threadIdx.x + k * 256; 16x9x24 has 208) and of the logf table, both bound for LDS.
+struct WalkPrefetch {
+    float pl0, pl1, pl2, pl3;
+    double logf_reg;
+};
+template <bool PLANES_IN_LDS>
+__device__ __forceinline__ WalkPrefetch walk_prefetch(const ClusterViewDev& v) {
+    const uint32_t n_plane_floats = PLANES_IN_LDS ? 4u * (v.dims[0] + v.dims[1] + v.dims[2] + 3u) : 0u;
+    WalkPrefetch p = {0.f, 0.f, 0.f, 0.f, 0.0};
+    if (threadIdx.x < n_plane_floats) p.pl0 = v.x_planes[threadIdx.x];
+    if (threadIdx.x + CLUSTER_BLOCK < n_plane_floats) p.pl1 = v.x_planes[threadIdx.x + CLUSTER_BLOCK];
+    if (threadIdx.x + 2u * CLUSTER_BLOCK < n_plane_floats) p.pl2 = v.x_planes[threadIdx.x + 2u * CLUSTER_BLOCK];
+    if (threadIdx.x + 3u * CLUSTER_BLOCK < n_plane_floats) p.pl3 = v.x_planes[threadIdx.x + 3u * CLUSTER_BLOCK];
+    p.logf_reg = (&LOGF_TAB[0][0])[threadIdx.x & 31u];
+    return p;
+}
+
+template <bool PLANES_IN_LDS, bool CHUNKED, bool SPOTS>
+__device__ __forceinline__ void cluster_walk_tail(const ClusterViewDev& v, const ClusterObjects& o, const ClusterWork& w, uint32_t zc_arg, uint32_t bx,
+                                                  uint32_t* arena, uint32_t obj, bool in_view, float4 sphere, WalkPrefetch pf);
+
+// One workgroup of the walk over 256 objects: the objects' own tests (object_in_view), then cluster_walk_tail.
 template <bool PLANES_IN_LDS, bool CHUNKED, bool SPOTS = true>
 __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, const ClusterObjects& o, const ClusterWork& w, const ViewSet& views,
                                                    uint32_t zc_arg, uint32_t bx, uint32_t* arena) {
+    const uint32_t obj = bx * CLUSTER_BLOCK + threadIdx.x;
+    float4 sphere = make_float4(0.f, 0.f, 0.f, 0.f);
+    MI_WALK_MARK(bx, 0);
+    // the plane tables are requested together with the objects' loads (they are contiguous in device memory: x | y | z)
+    const WalkPrefetch pf = walk_prefetch<PLANES_IN_LDS>(v);
+    const bool in_view = obj < o.n && object_in_view(v, o, views, obj, &sphere);
+    cluster_walk_tail<PLANES_IN_LDS, CHUNKED, SPOTS>(v, o, w, zc_arg, bx, arena, obj, in_view, sphere, pf);
+}
+
+// Everything a walking workgroup does once it knows which of its 256 objects are in view (bit k of the block = thread k): called
+// by cluster_walk_block, and by the row workgroups of the frame kernel for the objects that ARE their rows (ClusterWalkJob::inrow).
+// Every thread of the workgroup must call it.
+template <bool PLANES_IN_LDS, bool CHUNKED, bool SPOTS>
+__device__ __forceinline__ void cluster_walk_tail(const ClusterViewDev& v, const ClusterObjects& o, const ClusterWork& w, uint32_t zc_arg, uint32_t bx,
+                                                  uint32_t* arena, uint32_t obj, bool in_view, float4 sphere, WalkPrefetch pf) {
     const uint32_t dxy = v.dims[0] * v.dims[1], dz = v.dims[2];
     const uint32_t zc = CHUNKED ? zc_arg : dz;
     const uint32_t RC = dxy * zc;  // rows of one chunk
@@ -425,21 +463,12 @@ __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, cons
     const float* yp = PLANES_IN_LDS ? planes + 4u * nx : v.y_planes;
     const float* zp = PLANES_IN_LDS ? planes + 4u * (nx + ny) : v.z_planes;
 
-    // Most blocks of a big light set see nothing of it in this view: test first, and leave before touching LDS.
-    const uint32_t obj = bx * CLUSTER_BLOCK + threadIdx.x;
-    float4 sphere = make_float4(0.f, 0.f, 0.f, 0.f);
-    // the plane tables are requested together with the objects' loads (they are contiguous in device memory: x | y | z)
-    const uint32_t n_plane_floats = PLANES_IN_LDS ? 4u * (nx + ny + nz) : 0u;
-    float pl0 = 0.f, pl1 = 0.f, pl2 = 0.f, pl3 = 0.f;  // (floats threadIdx.x + k * 256 of the tables: 16x9x24 has 208 of them)
-    if (threadIdx.x < n_plane_floats) pl0 = v.x_planes[threadIdx.x];
-    if (threadIdx.x + CLUSTER_BLOCK < n_plane_floats) pl1 = v.x_planes[threadIdx.x + CLUSTER_BLOCK];
-    if (threadIdx.x + 2u * CLUSTER_BLOCK < n_plane_floats) pl2 = v.x_planes[threadIdx.x + 2u * CLUSTER_BLOCK];
-    if (threadIdx.x + 3u * CLUSTER_BLOCK < n_plane_floats) pl3 = v.x_planes[threadIdx.x + 3u * CLUSTER_BLOCK];
-    MI_WALK_MARK(bx, 0);
-    const double logf_reg = (&LOGF_TAB[0][0])[threadIdx.x & 31u];
+    // Most blocks of a big light set see nothing of it in this view: leave before touching LDS.
     // (the barriers below order LDS only: a __syncthreads() also waits for every global store and atomic in flight -- the far_z
     // atomic, the pair stores of the previous chunk --, a round trip of microseconds each while the frame's rows load HBM)
-    const bool in_view = obj < o.n && object_in_view(v, o, views, obj, &sphere);
+    const uint32_t n_plane_floats = PLANES_IN_LDS ? 4u * (nx + ny + nz) : 0u;
+    const float pl0 = pf.pl0, pl1 = pf.pl1, pl2 = pf.pl2, pl3 = pf.pl3;
+    const double logf_reg = pf.logf_reg;
     if (!__syncthreads_or(in_view ? 1 : 0)) return;
     MI_WALK_MARK(bx, 1);
 

@@ -1934,6 +1934,15 @@ int32_t mi_debug_set_tile_pretest(mi_ctx* ctx, int32_t mode) {
     return MI_OK;
 }
 
+// test / bench hook: the cluster walk of a MI_CULL_WITH_CLUSTERS frame whose objects are a row range: 0 = by the frame kernel's own row
+// workgroups (default), 1 = by extra workgroups that re-derive the rows' visibility (what row-list bindings always take)
+int32_t mi_debug_set_walk_inrow(mi_ctx* ctx, int32_t mode) {
+    ENTER(ctx);
+    if (mode < 0 || mode > 1) return fail(ctx, MI_ERR_INVALID_ARG, "mi_debug_set_walk_inrow: mode %d", mode);
+    ctx->walk_inrow_mode = mode;
+    return MI_OK;
+}
+
 // test / bench hook: the all-dirty hierarchy frame: 0, 1 = tile launch + cull launch (default), 2 = every tile culls its own rows
 int32_t mi_debug_set_tree_cull(mi_ctx* ctx, int32_t mode) {
     ENTER(ctx);

@@ -130,6 +130,7 @@ struct mi_ctx {
     // layers).  The frame entry points bring it up to date first (row_summary_ensure); columns_of hands it to kernels only then.
     DevBuf row_sum;
     uint32_t rs_lo[2] = {0, 0}, rs_hi[2] = {0, 0};
+    int32_t walk_inrow_mode = 0;  // mi_debug_set_walk_inrow: 0 = row-range bindings are walked by the frame kernel's own row workgroups, 1 = never
     int32_t row_sum_mode = 0;  // mi_debug_set_row_summary: 0 = in use, 1 = off (every row reads its own Aabb / flags / layers)
 
     // ---- views / visibility ----

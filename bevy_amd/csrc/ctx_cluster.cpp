@@ -247,7 +247,10 @@ int32_t cluster_buffers(mi_ctx* ctx, ClusterPrep* p, bool* fresh) {
     const uint32_t C = ctx->cl_view.n_clusters;
     ClusterWork& w = p->w;
     p->C = C;
-    w.n_blocks = std::max(1u, (p->o.n + CLUSTER_BLOCK - 1) / CLUSTER_BLOCK);
+    // (one block more than the objects fill: blocks that are row tiles of the frame kernel -- ClusterWalkJob::inrow -- start and end
+    // anywhere inside a tile, and the two forms share the buffers)
+    w.n_blocks = std::max(1u, (p->o.n + CLUSTER_BLOCK - 1) / CLUSTER_BLOCK) + 1u;
+    w.obj_delta = 0;
     p->off_totals = (6 * (size_t)C + 3) & ~(size_t)3;
     p->off_misc = p->off_totals + (((size_t)C + 3) & ~(size_t)3);
     p->acc_words = p->off_misc + 4;  // per set; 16-byte aligned sections: counts | totals | misc
@@ -386,11 +389,20 @@ int32_t cluster_ride_prepare(mi_ctx* ctx, ClusterWalkJob* job, bool* can_ride) {
     bool fresh = false;
     if ((rc = cluster_buffers(ctx, &p, &fresh))) return rc;
     cluster_next_set(ctx, &p);
+    // objects bound to a contiguous row range: the frame kernel's own row workgroups walk them (a block = a row tile); a row list
+    // keeps the extra workgroups that re-derive the rows' visibility
+    job->inrow = (!ctx->cl_rows_listed && ctx->walk_inrow_mode == 0 && p.o.n) ? 1u : 0u;
+    job->tile0 = 0;
+    job->n_blocks = p.w.n_blocks;
+    if (job->inrow) {
+        job->tile0 = ctx->cl_first_row / 256u;
+        job->n_blocks = (uint32_t)(((uint64_t)ctx->cl_first_row + p.o.n + 255u) / 256u) - job->tile0;
+        p.w.obj_delta = (int32_t)(job->tile0 * 256u) - (int32_t)ctx->cl_first_row;
+    }
     job->view = v;
     job->objs = p.o;
     job->w = p.w;
     job->zc = zc;
-    job->n_blocks = p.w.n_blocks;
     ctx->cl_fill_job.w = p.w;
     ctx->cl_fill_job.n_clusters = p.C;
     ctx->cl_fill_job.n_objects = p.o.n;

@@ -413,6 +413,8 @@ struct ClusterWork {
     uint32_t* indices;            // [capacity] out
     uint64_t capacity;
     uint64_t* total;              // [1] out
+    int32_t obj_delta;            // object of (block b, bit k) = b * 256 + k + obj_delta: 0 for blocks of 256 objects; blocks that are ROW
+                                  // tiles of the frame kernel (ClusterWalkJob::inrow) start obj_delta objects in front of object 0
 };
 hipError_t launch_cluster_bindings(uint32_t n_clusters, const uint32_t* offsets, const uint32_t* counts, const uint32_t* indices,
                                    const uint32_t* remap, uint32_t n_remap, uint64_t capacity, uint32_t* out_oc,
@@ -433,6 +435,11 @@ struct ClusterWalkJob {
     ClusterWork w;
     uint32_t zc;           // z slices per chunk: what fits the frame kernel's LDS
     uint32_t n_blocks;     // 0 = no walk rides in this launch
+    // inrow: objects bound to a CONTIGUOUS row range (mi_cluster_bind_objects_to_rows) are walked by the frame kernel's own row
+    // workgroups -- the tiles tile0 .. tile0 + n_blocks - 1 hold them, a block = a row tile, and those workgroups go on into the walk
+    // with the ViewVisibility and the GlobalTransform translation they have just computed: no extra workgroups, nothing re-derived.
+    // The launch hands those tiles out first.
+    uint32_t inrow, tile0;
 };
 // bytes of the LDS arena a walking workgroup needs for chunks of zc z slices (layout: cluster_walk.h)
 inline size_t cluster_walk_lds_bytes(uint32_t dxy, uint32_t zc, uint32_t n_planes, bool planes_in_lds) {

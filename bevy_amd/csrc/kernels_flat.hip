@@ -196,7 +196,8 @@ __device__ __forceinline__ void emit_view(uint32_t v, bool vis, bool any_live, u
 }
 // The ViewVisibility byte of a row: reset (mod.rs:270-274), set_visible (:290-306), gpu-culling rows (:884-903),
 // mark_newly_hidden (:908-918), and the wave's change-tick word.
-__device__ __forceinline__ void view_visibility_tail(const Columns& c, uint32_t row, bool live, bool any_live, uint32_t lane, uint32_t wave,
+// Returns ViewVisibility::get() of the row as the frame leaves it.
+__device__ __forceinline__ bool view_visibility_tail(const Columns& c, uint32_t row, bool live, bool any_live, uint32_t lane, uint32_t wave,
                                                      uint32_t fl, uint32_t vv0, bool any, uint32_t fl_frame) {
     const bool ncc = (fl & 0x10u) != 0;
     uint32_t cur = vv0;
@@ -223,6 +224,32 @@ __device__ __forceinline__ void view_visibility_tail(const Columns& c, uint32_t 
         if (fl_frame & CULL_BEGIN_FRAME) c.vv_changed_bits[wave] = chg;
         else if (chg) atomicOr(reinterpret_cast<unsigned long long*>(&c.vv_changed_bits[wave]), chg);
     }
+    return live && (cur & 1u) != 0;
+}
+
+// ClusterWalkJob::inrow: the row workgroup of a tile that holds cluster objects goes on into the walk.  The object of a row is
+// row - first_row; it takes part if its ViewVisibility::get() is true (the gather's filter, assign.rs:194: `visible`, just computed),
+// its centre is the row's GlobalTransform translation (assign.rs:198: `translation`, in hand), and it passes the two early-outs of
+// the per-object loop (assign.rs:489 RenderLayers, :496 frustum against the light's sphere).  Every thread of the workgroup calls it.
+__device__ __forceinline__ void inrow_cluster_walk(const ClusterWalkJob& walk, uint32_t tile, uint32_t row, bool visible, V3 translation, uint32_t* arena) {
+    const uint32_t bx = tile - walk.tile0;
+    const ClusterObjects& o = walk.objs;
+    const uint32_t obj = row - o.first_row;  // (wraps for the rows of the first tile that lie in front of the objects)
+    const bool is_obj = row >= o.first_row && obj < o.n;
+    const WalkPrefetch pf = walk_prefetch<true>(walk.view);
+    float4 sphere = make_float4(translation.x, translation.y, translation.z, 0.f);
+    bool in_view = false;
+    if (is_obj) {
+        sphere.w = o.pos_range[4u * obj + 3u];
+        const uint32_t layers = o.layer_mask ? o.layer_mask[obj] : 1u;
+        if (visible && (walk.view.view_layer_mask & layers)) {
+            V4 fr[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) fr[i] = V4{walk.view.frustum[4 * i], walk.view.frustum[4 * i + 1], walk.view.frustum[4 * i + 2], walk.view.frustum[4 * i + 3]};
+            in_view = frustum_intersects_sphere(fr, translation, sphere.w, true);
+        }
+    }
+    cluster_walk_tail<true, true, false>(walk.view, o, walk.w, walk.zc, bx, arena, obj, in_view, sphere, pf);
 }
 // The extra workgroups at the head of a frame kernel's grid (they overlap the ramp-up instead of lengthening the tail: 0.5 us per
 // frame at 1 M rows): the deferred VisibleEntities compaction of the previous frame, the deferred fill of the previous frame's
@@ -305,7 +332,14 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
     if (frame_riders<WITH_WALK>(n_tiles, prev, prev_gx, n_compact, n_fill, fill, walk, vs, lds_raw)) return;
     MI_TIMELINE(3);
     const uint32_t n_extra = gridDim.x - n_tiles;
-    const uint32_t row = (blockIdx.x - n_extra) * 256u + threadIdx.x;
+    uint32_t tile = blockIdx.x - n_extra;
+    if constexpr (WITH_WALK) {  // the tiles that go on into the cluster walk are handed out first (they run longest)
+        if (walk.inrow) {
+            tile += walk.tile0;
+            if (tile >= n_tiles) tile -= n_tiles;
+        }
+    }
+    const uint32_t row = tile * 256u + threadIdx.x;
     const bool live = row < c.n;
     const uint32_t wave = row >> 6;
     const uint32_t lane = threadIdx.x & 63u;
@@ -398,7 +432,7 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
         any = any || vis;
         emit_view(v, vis, any_live, lane, wave, cmask, out, seg);
     }
-    view_visibility_tail(c, row, live, any_live, lane, wave, fl, vv0, any, fl_frame);
+    const bool vv_now = view_visibility_tail(c, row, live, any_live, lane, wave, fl, vv0, any, fl_frame);
     if (PROPAGATE) {  // plain assignment bumps every written row's tick (systems.rs:62)
         const unsigned long long lv = __ballot(live);
         if (lane == 0 && any_live) c.g_changed_bits[wave] = lv;
@@ -406,6 +440,9 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
     if (PARTIAL) {
         const unsigned long long dm = __ballot(dirty);
         if (lane == 0 && any_live) c.g_changed_bits[wave] = dm;
+    }
+    if constexpr (WITH_WALK) {
+        if (walk.inrow && tile - walk.tile0 < walk.n_blocks) inrow_cluster_walk(walk, tile, row, vv_now, g.t, lds_raw);  // (workgroup-uniform)
     }
 }
 
@@ -440,7 +477,14 @@ __global__ void __launch_bounds__(256) k_frame_sph(Columns c, ViewSet vs, const 
     float4 (*lds_g)[192] = reinterpret_cast<float4 (*)[192]>(lds_raw);
     if (frame_riders<WITH_WALK>(n_tiles, prev, prev_gx, n_compact, n_fill, fill, walk, vs, lds_raw)) return;
     const uint32_t n_extra = gridDim.x - n_tiles;
-    const uint32_t row = (blockIdx.x - n_extra) * 256u + threadIdx.x;
+    uint32_t tile = blockIdx.x - n_extra;
+    if constexpr (WITH_WALK) {  // (as in k_frame: the tiles that go on into the cluster walk first)
+        if (walk.inrow) {
+            tile += walk.tile0;
+            if (tile >= n_tiles) tile -= n_tiles;
+        }
+    }
+    const uint32_t row = tile * 256u + threadIdx.x;
     const bool live = row < c.n;
     const uint32_t wave = row >> 6, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, wave_row0 = row & ~63u;
     const bool any_live = wave_row0 < c.n;
@@ -592,7 +636,14 @@ __global__ void __launch_bounds__(256) k_frame_sph(Columns c, ViewSet vs, const 
         }
     }
     for (uint32_t v = 0; v < n_views; ++v) emit_view(v, ((pass >> v) & 1u) != 0, any_live, lane, wave, cmask, out, seg);
-    view_visibility_tail(c, row, live, any_live, lane, wave, fl, vv0, pass != 0u, fl_frame);
+    const bool vv_now = view_visibility_tail(c, row, live, any_live, lane, wave, fl, vv0, pass != 0u, fl_frame);
+    if constexpr (WITH_WALK) {
+        if (walk.inrow && tile - walk.tile0 < walk.n_blocks) {  // (workgroup-uniform)
+            // the row's GlobalTransform translation: the column as this launch leaves it (a PARTIAL frame's own stores included)
+            const V3 t = live ? ld3(c.global, row * 4u + 3u) : V3{0.f, 0.f, 0.f};
+            inrow_cluster_walk(walk, tile, row, vv_now, t, lds_raw);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -959,12 +1010,14 @@ static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, co
     }
     ClusterWalkJob wj{};
     uint32_t walk_blocks = 0;
+    bool with_walk = false;
     if (walk && walk->n_blocks && n_views <= MAX_INLINE_VIEWS && views_inline) {  // the walk reads the views from the kernarg copy
         wj = *walk;
-        walk_blocks = wj.n_blocks;
+        with_walk = true;
+        walk_blocks = wj.inrow ? 0u : wj.n_blocks;  // in-row: the row workgroups of the objects' tiles do it
     }
     const dim3 grid(n_tiles + prev_blocks + fill_blocks + walk_blocks);
-    if (walk_blocks) {
+    if (with_walk) {
         MI_LAUNCH((k_frame<PROP, true, true>), grid, dim3(256), 0, stream, c, *views_inline, (const ViewParams*)nullptr, n_views, out, seg, flags,
                   n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed);
     } else if (n_views <= MAX_INLINE_VIEWS && views_inline) {
@@ -1000,9 +1053,11 @@ hipError_t launch_frame_sph(const Columns& c, const ViewSet* views_inline, const
     }
     ClusterWalkJob wj{};
     uint32_t walk_blocks = 0;
+    bool with_walk = false;
     if (walk && walk->n_blocks && n_views <= MAX_INLINE_VIEWS && views_inline) {
         wj = *walk;
-        walk_blocks = wj.n_blocks;
+        with_walk = true;
+        walk_blocks = wj.inrow ? 0u : wj.n_blocks;  // in-row: the row workgroups of the objects' tiles do it
     }
     SphereArgs sa{reinterpret_cast<float4*>(sph), stale_bits, stale_bytes, all_stale ? 1u : 0u};
     const dim3 grid(n_tiles + prev_blocks + fill_blocks + walk_blocks);
@@ -1014,11 +1069,11 @@ hipError_t launch_frame_sph(const Columns& c, const ViewSet* views_inline, const
     MI_LAUNCH((k_frame_sph<P, I, W>), grid, dim3(256), 0, stream, c, vsr, dv, n_views, out, seg, flags, n_tiles, pa, prev_gx, prev_blocks, \
               fill_blocks, fj, wj, changed, sa)
     if (changed) {
-        if (walk_blocks) MI_SPH_LAUNCH(true, true, true);
+        if (with_walk) MI_SPH_LAUNCH(true, true, true);
         else if (inl) MI_SPH_LAUNCH(true, true, false);
         else MI_SPH_LAUNCH(true, false, false);
     } else {
-        if (walk_blocks) MI_SPH_LAUNCH(false, true, true);
+        if (with_walk) MI_SPH_LAUNCH(false, true, true);
         else if (inl) MI_SPH_LAUNCH(false, true, false);
         else MI_SPH_LAUNCH(false, false, false);
     }

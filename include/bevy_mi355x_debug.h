@@ -49,6 +49,9 @@ int32_t mi_debug_set_sorted_one_wg_limit(mi_ctx* ctx, uint32_t items);
 /* The flags-first test of the light tile kernel under the static-scene rule (kernels_tree.hip): 0 = when few rows changed since the
  * last propagate (default), 1 = never, 2 = always. */
 int32_t mi_debug_set_tile_pretest(mi_ctx* ctx, int32_t mode);
+/* The cluster walk of a MI_CULL_WITH_CLUSTERS frame whose objects are bound to a row RANGE: 0 = the frame kernel's row workgroups
+ * of those rows go on into the walk (default), 1 = extra workgroups re-derive the rows' visibility (as for row lists).  Same results. */
+int32_t mi_debug_set_walk_inrow(mi_ctx* ctx, int32_t mode);
 /* The all-dirty hierarchy frame of mi_propagate_and_cull[_views]: 0, 1 = tile launch + cull launch (default), 2 = fused into the tile
  * launches where that applies (every tile also culls its own rows; measured slower as built).  Results are identical. */
 int32_t mi_debug_set_tree_cull(mi_ctx* ctx, int32_t mode);

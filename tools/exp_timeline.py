@@ -42,6 +42,8 @@ with torch.cuda.stream(stream):
             m = np.frombuffer(mb, dtype=np.uint64).reshape(4096, 16).astype(np.float64)
             m = m[m[:, 0] > 0]
             ph = {}
+            if len(m) == 0:  # (the walk ran inside the row workgroups: no walking workgroups of their own)
+                m = np.zeros((1, 16))
             for name, a, b in (("derive", 0, 1), ("to_planes_barrier", 1, 8), ("z_extent_to_barrier", 8, 9), ("clear_to_barrier", 9, 10), ("setup_walk_to_barrier", 10, 2), ("setup_walk", 1, 2), ("reserve", 2, 3), ("pairs", 3, 4), ("whole", 0, 7)):
                 ok = (m[:, a] > 0) & (m[:, b] > 0)
                 d = (m[ok, b] - m[ok, a]) / 100.0
@@ -53,9 +55,12 @@ with torch.cuda.stream(stream):
             for k in (2, 3):
                 w = v[v[:, 2] == k + 1]
                 hist.append([round(float(x), 2) for x in np.percentile((w[:, 1] - t0) / 100.0, [0, 10, 25, 50, 75, 90, 100])] if len(w) else [])
+                if k == 3 and len(w):  # lifetimes of the row workgroups: the tiles that go on into the cluster walk live longest
+                    hist.append([round(float(x), 2) for x in np.percentile((w[:, 1] - w[:, 0]) / 100.0, [50, 90, 95, 99, 100])])
     r = np.median(np.array(rows), axis=0)
     out = {name: {"first_start_us": round(r[k, 0], 2), "last_start_us": round(r[k, 1], 2), "last_end_us": round(r[k, 2], 2), "mean_lifetime_us": round(r[k, 3], 2), "workgroups": int(r[k, 4])}
            for k, name in enumerate(["compaction", "fill", "walk", "rows"])}
     out["end_time_percentiles_0_10_25_50_75_90_100"] = {"walk": hist[0], "rows": hist[1]}
+    out["row_workgroup_lifetime_us_p50_p90_p95_p99_p100"] = hist[2] if len(hist) > 2 else []
     out["walk_phase_us_p10_p50_p90_p100"] = walk_phases
     print(json.dumps(out))

@@ -388,6 +388,9 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
     if (uni_fl) {
         fl = live ? (rs.bits & 0xFFu) : 0u;
         emask = rs.layers;
+#ifdef MI_EXP_MUTANT  // (a deliberately wrong build: tests/test_gpu_differential.py must notice, tools/gpu_mutant.sh)
+        if ((row & 0xFFFu) == 0x123u) emask = 0u;
+#endif
     } else if (live) {
         fl = c.flags[row];
         emask = c.layer_mask[row];

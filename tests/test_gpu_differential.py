@@ -1,0 +1,243 @@
+"""Differential test of the library's internal fast paths: two contexts are driven through the SAME random sequence of calls -- one
+with every fast path as the library picks it, the other with every one of them switched off through the debug hooks -- and must
+agree on everything a caller can download after every step; at intervals the oracle is asked too.
+
+    fast paths (context A, defaults)                      switched off in context B
+    row summary (RowSummary, 64-row Aabb/flags/layers)    mi_debug_set_row_summary(1)
+    world-sphere column (k_frame_sph)                     mi_debug_set_sphere_path(1)     [A: forced on at once, mode 2]
+    cluster walk in the rows' own workgroups              mi_debug_set_walk_inrow(1)
+    tile pre-test of change-driven hierarchy frames       mi_debug_set_tile_pretest(1)    [A: forced, mode 2]
+    hierarchy frame fused into the tile launches          (B: two launches)               [A: mi_debug_set_tree_cull(2)]
+
+The sequences mix: bounds uploads (whole, partial, single rows), RenderLayers above 31, Transform uploads (indexed, ranges),
+change marks, growth and shrinkage of the row count, every kind of frame (all rows, changed rows, propagate + cull, with and
+without the cluster assignment, with the compaction deferred or not), on flat scenes and on forests.  The reference has no
+counterpart (it has one path); what is pinned here is that the library's paths are interchangeable."""
+import numpy as np
+import pytest
+
+import bevy_amd as B
+from bevy_amd import api, workloads as W
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+CFV = None
+
+
+def cfv():
+    global CFV
+    if CFV is None:
+        CFV = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+    return CFV
+
+
+class Scene:
+    """Host mirror of what has been uploaded (so that the oracle can be asked)."""
+
+    def __init__(self, rng, n, forest):
+        self.rng, self.n, self.forest = rng, n, forest
+        cap = n + 4000
+        self.cap = cap
+        self.t = rng.normal(0.0, 25.0, (cap, 3)).astype(F)
+        self.r = W.random_unit_quats(int(rng.integers(1, 1 << 30)), cap, 0).astype(F).reshape(cap, 4)
+        self.s = np.where(rng.random((cap, 1)) < 0.7, 1.0, 0.5 + rng.random((cap, 3))).astype(F)
+        self.c = np.zeros((cap, 3), F)
+        self.h = np.full((cap, 3), 0.5, F)
+        self.fl = np.full(cap, 0x05, np.uint8)
+        self.lay = np.ones(cap, np.uint32)
+        self.lay_hi = np.zeros(cap, np.uint32)
+        self.parent = None
+        self.offs = None
+        if forest:
+            self.parent, self.offs = forest_of(rng, n)
+
+    def randomize_bounds(self, lo, hi):
+        rng, k = self.rng, hi - lo
+        mode = rng.integers(0, 4)
+        if mode == 0:  # one mesh
+            self.c[lo:hi] = rng.normal(0, 0.2, 3).astype(F)
+            self.h[lo:hi] = (0.2 + rng.random(3)).astype(F)
+            self.fl[lo:hi] = 0x05
+            self.lay[lo:hi] = 1
+        elif mode == 1:  # ragged
+            self.c[lo:hi] = rng.normal(0, 0.3, (k, 3)).astype(F)
+            self.h[lo:hi] = (0.1 + rng.random((k, 3))).astype(F)
+            self.fl[lo:hi] = rng.choice(np.array([0x05, 0x05, 0x07, 0x04, 0x01, 0x15, 0x09], np.uint8), k)
+            sph = self.fl[lo:hi] == 0x09
+            self.c[lo:hi][sph] = self.t[lo:hi][sph]
+            self.lay[lo:hi] = rng.choice(np.array([1, 1, 1, 2, 3, 0], np.uint32), k)
+        elif mode == 2:  # hidden run
+            self.fl[lo:hi] &= ~np.uint8(1)
+        else:  # layers above 31
+            self.lay_hi[lo:hi] = rng.choice(np.array([0, 0, 1, 1 << 9], np.uint32), k)
+            self.lay[lo:hi] = rng.choice(np.array([1, 0], np.uint32), k)
+
+
+def forest_of(rng, n):
+    n_roots = max(1, n // 3000)
+    parent = np.full(n, 0xFFFFFFFF, np.uint32)
+    levels = [list(range(n_roots))]
+    nxt = n_roots
+    while nxt < n:
+        prev = levels[-1]
+        kids = rng.integers(0, 6, len(prev))
+        if kids.sum() == 0:
+            kids[0] = 2
+        cur = []
+        for p, k in zip(prev, kids):
+            for _ in range(int(k)):
+                if nxt >= n:
+                    break
+                parent[nxt] = p
+                cur.append(nxt)
+                nxt += 1
+        levels.append(cur)
+    offs = np.cumsum([0] + [len(l) for l in levels if l]).astype(np.uint32)
+    return parent, offs
+
+
+def make_ctx(fast):
+    ctx = api.Context(0)
+    if fast:
+        ctx.debug_set_sphere_path(2)
+        ctx.debug_set_tile_pretest(2)
+        ctx.debug_set_tree_cull(2)
+    else:
+        ctx.debug_set_row_summary(1)
+        ctx.debug_set_sphere_path(1)
+        ctx.debug_set_walk_inrow(1)
+        ctx.debug_set_tile_pretest(1)
+        ctx.debug_set_tree_cull(1)
+    return ctx
+
+
+def snapshot(ctx, n_views, with_clusters, n_clusters):
+    g, gch = ctx.download_global_transforms()
+    vv, vch = ctx.download_view_visibility()
+    out = {"G": g.tobytes(), "G ticks": np.asarray(gch).tobytes(), "ViewVisibility": vv.tobytes(), "ViewVisibility ticks": np.asarray(vch).tobytes()}
+    for v in range(n_views):
+        out[f"mask {v}"] = ctx.download_visibility(v).tobytes()
+        out[f"list {v}"] = ctx.download_visible_entities(v, 0)[1].tobytes()
+    if with_clusters:
+        off, idx, counts, far, total = ctx.cluster_download(n_clusters)
+        out["cluster offsets"] = off.tobytes()
+        out["cluster counts"] = counts.tobytes()
+        out["cluster indices"] = idx[:total].tobytes()
+        out["farthest_z"] = np.float32(far).tobytes()
+    return out
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_fast_paths_are_interchangeable(seed):
+    rng = np.random.default_rng(1000 + seed)
+    forest = seed % 2 == 1
+    n = int(rng.integers(300, 30_000))
+    sc = Scene(rng, n, forest)
+    n_lights = 0 if forest else int(rng.integers(0, 3)) * 700  # lights are rows at the end of a flat scene
+    a, b = make_ctx(True), make_ctx(False)
+    try:
+        first_light = n - n_lights
+        if n_lights:
+            sc.fl[first_light:n] = 0x09
+            sc.c[first_light:n] = 0
+            sc.h[first_light:n] = 0
+            sc.h[first_light:n, 0] = 1.5
+            sc.h[first_light:n, 1] = np.frombuffer(np.uint32(0x7FC0A11D).tobytes(), F)[0]
+            sc.t[first_light:n] = rng.normal(0.0, 12.0, (n_lights, 3)).astype(F)
+        for ctx in (a, b):
+            ctx.resize(n)
+            ctx.upload_transforms(sc.t[:n].reshape(-1), sc.r[:n].reshape(-1), sc.s[:n].reshape(-1))
+            if forest:
+                ctx.upload_hierarchy(sc.parent, sc.offs)
+            ctx.upload_bounds(sc.c[:n].reshape(-1), sc.h[:n].reshape(-1), sc.fl[:n], sc.lay[:n])
+            ctx.upload_changed(np.ones(n, np.uint8))
+            if n_lights:
+                pr = np.concatenate([sc.t[first_light:n], np.full((n_lights, 1), 1.5, F)], axis=1)
+                ctx.cluster_upload_objects(pr.reshape(-1))
+                if seed % 4 == 0:
+                    ctx.cluster_bind_objects_to_row_list(np.arange(first_light, n, dtype=np.uint32))
+                else:
+                    ctx.cluster_bind_objects_to_rows(first_light, n_lights)
+        n_views = int(rng.integers(1, 4))
+        vm_lo = np.array([1, 3, 0xFFFFFFFF][:n_views], np.uint32)
+        vm_hi = np.array([0, 1 << 9, 0][:n_views], np.uint32)
+        had_clusters, n_clusters = False, 0
+        for step in range(22):
+            op = rng.integers(0, 9)
+            if op == 0 and not forest and n_lights == 0:  # resize
+                n2 = int(np.clip(n + rng.integers(-2500, 2500), 65, sc.cap - 1))
+                if n2 > n:  # fresh rows: default bounds on the device, mirror them
+                    sc.c[n:n2] = 0
+                    sc.h[n:n2] = 0
+                    sc.fl[n:n2] = 0x01
+                    sc.lay[n:n2] = 1
+                    sc.lay_hi[n:n2] = 0
+                for ctx in (a, b):
+                    ctx.resize(n2)
+                    if n2 > n:
+                        ctx.upload_transforms(sc.t[n:n2].reshape(-1), sc.r[n:n2].reshape(-1), sc.s[n:n2].reshape(-1), first_row=n)
+                n = n2
+            elif op in (1, 2):  # bounds: a run, or single rows
+                lim = first_light if n_lights else n
+                lo = int(rng.integers(0, lim))
+                hi = int(min(lim, lo + (1 if op == 2 else rng.integers(1, 3000))))
+                sc.randomize_bounds(lo, hi)
+                for ctx in (a, b):
+                    ctx.upload_bounds(sc.c[lo:hi].reshape(-1), sc.h[lo:hi].reshape(-1), sc.fl[lo:hi], sc.lay[lo:hi], first_row=lo)
+                    ctx.upload_render_layers_hi(sc.lay_hi[lo:hi], first_row=lo)
+            elif op in (3, 4):  # some Transforms move
+                k = int(min(n, rng.integers(1, 400 if op == 3 else 8)))
+                rows = np.sort(rng.choice(n, k, replace=False)).astype(np.uint32)
+                sc.t[rows] += rng.normal(0.0, 3.0, (k, 3)).astype(F)
+                for ctx in (a, b):
+                    ctx.upload_transforms_indexed(rows, sc.t[rows].reshape(-1), sc.r[rows].reshape(-1), sc.s[rows].reshape(-1))
+            # every step ends in a frame
+            cams = [W.many_cubes_camera(int(rng.integers(0, 400)), yaw=float(rng.random() * 6.0), position=tuple(rng.normal(0, 8.0, 3))) for _ in range(n_views)]
+            fr = np.concatenate([api.compute_frustum(cfv(), cam, W.CAMERA_FAR) for cam in cams])
+            views = api.make_views(fr, layer_masks=vm_lo, layer_masks_hi=vm_hi)
+            kind = ["all", "changed", "split", "split_all"][int(rng.integers(0, 4))]
+            flags = B.CULL_END_FRAME | (B.CULL_MORE_FRAMES if rng.random() < 0.5 else 0)
+            with_clusters = bool(n_lights) and rng.random() < 0.7
+            if with_clusters:
+                view, keep = api.cluster_view_build(cams[0], cfv(), fr[:24], 1920, 1080, (16, 9, 24), 5.0, 1000.0, with_spheres=False)
+                n_clusters = view.n_clusters
+                flags |= B.CULL_WITH_CLUSTERS
+            for ctx in (a, b):
+                if with_clusters:
+                    ctx.cluster_upload_view(view)
+                if kind == "all":
+                    ctx.propagate_and_cull_views(views, flags=flags)
+                elif kind == "changed":
+                    ctx.propagate_and_cull_views(views, flags=flags | B.CULL_CHANGED_ROWS | (B.CULL_STATIC_OPT if forest else 0))
+                else:
+                    ctx.propagate((B.PROPAGATE_ALL_DIRTY if kind == "split_all" else 0) | (B.PROPAGATE_STATIC_OPT if forest else 0))
+                    ctx.cull_views(views, flags=flags | B.CULL_BEGIN_FRAME)
+            had_clusters = had_clusters or with_clusters
+            sa, sb = snapshot(a, n_views, had_clusters, n_clusters), snapshot(b, n_views, had_clusters, n_clusters)
+            for key in sa:
+                assert sa[key] == sb[key], f"seed {seed} step {step} ({kind}, op {op}, n {n}, forest {forest}, clusters {with_clusters}): {key} differs"
+            # the oracle, now and then (GlobalTransforms and this frame's masks; ViewVisibility needs the carried byte: after the first ask)
+            if step % 5 == 4:
+                if forest:
+                    _, g, _ = O.propagate_transforms(sc.parent, sc.t[:n].reshape(-1), sc.r[:n].reshape(-1), sc.s[:n].reshape(-1))
+                else:
+                    g, _ = O.sync_simple_transforms(sc.t[:n].reshape(-1), sc.r[:n].reshape(-1), sc.s[:n].reshape(-1))
+                assert sa["G"] == g.tobytes(), f"seed {seed} step {step}: GlobalTransform against the oracle"
+                c_or = sc.c[:n].copy()
+                if n_lights:  # the oracle has no MI_SPHERE_AT_TRANSLATION marker: a light's Sphere is (its translation, range), written out
+                    c_or[first_light:n] = sc.t[first_light:n]
+                _, vis, _ = O.check_visibility_layers64(g, c_or.reshape(-1), oracle_half(sc, n, first_light, n_lights), sc.fl[:n], sc.lay[:n], sc.lay_hi[:n],
+                                                        np.zeros(n, np.uint8), fr, vm_lo, vm_hi)
+                for v in range(n_views):
+                    assert np.array_equal(np.frombuffer(sa[f"mask {v}"], np.uint8), vis[v]), f"seed {seed} step {step}: mask of view {v} against the oracle"
+    finally:
+        a.close()
+        b.close()
+
+
+def oracle_half(sc, n, first_light, n_lights):
+    h = sc.h[:n].copy()
+    if n_lights:
+        h[first_light:n, 1] = 0
+    return h.reshape(-1)

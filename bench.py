@@ -72,7 +72,7 @@ def parse():
     ap.add_argument("--sorted-items", type=int, default=0, help="batching_sorted: items of the phase (default 65 536)")
     ap.add_argument("--sorted-one-wg-limit", type=int, default=None, help="batching_sorted: phases up to this long take the single-workgroup kernel (default 4096; 4294967295 = always)")
     ap.add_argument("--tree-moved", choices=["all", "subtree", "leaves"], default="all", help="tree: the root moves and every Transform counts as changed (default) / change-driven frames: one level-5 node moves / 10 000 leaves move")
-    ap.add_argument("--tree-cull-launches", type=int, default=2, choices=[1, 2], help="tree --tree-cull: 2 = tile launch + cull launch (default), 1 = the tiles cull their own rows (mi_debug_set_tree_cull(2))")
+    ap.add_argument("--tree-cull-launches", type=int, default=0, choices=[0, 1, 2], help="tree --tree-cull: 0 = the library's choice (one view: the tiles cull their own rows), 1 = always that, 2 = tile launch + cull launch")
     ap.add_argument("--tree-cull", action="store_true", help="tree: the hierarchy FRAME -- mi_propagate_and_cull on a context with a hierarchy (tile launch + cull launch, one call)")
     ap.add_argument("--sphere-path", type=int, default=0, help="flat_static / frame: 0 = world-sphere cull path from the second quiet frame (default), 1 = never (k_frame<0> over GlobalTransform + Aabb), 2 = at once")
     ap.add_argument("--tile-mode", type=int, default=0, help="tree: 0 = tile kernel chosen by size, 1 = big tiles, 2 / 3 = light tiles (5 / 6 waves per SIMD)")
@@ -306,8 +306,9 @@ def build_tree(ctx, args, rank=0, world=1):
         from bevy_amd import api
         n = tr["n"]
         ctx.debug_set_row_summary(args.row_summary)
-        fused = getattr(args, "tree_cull_launches", 2) == 1
-        ctx.debug_set_tree_cull(2 if fused else 1)
+        tcl = getattr(args, "tree_cull_launches", 0)
+        fused = tcl == 1 or (tcl == 0 and (args.views or 1) == 1)
+        ctx.debug_set_tree_cull({0: 0, 1: 2, 2: 1}[tcl])
         ctx.upload_bounds(np.zeros(3 * n, np.float32), np.full(3 * n, 0.5, np.float32), np.full(n, 0x05, np.uint8), np.ones(n, np.uint32))
         n_views = args.views or 1
         frames = [api.PreparedFrusta(camera_frusta(n_views, f)) for f in range(N_FRAMES)]
@@ -981,7 +982,7 @@ def main():
                  ("tree", lambda c: build_tree(c, args)), ("tree_one_subtree_moves", lambda c: build_tree(c, with_args(args, tree_moved="subtree"))),
                  ("tree_10k_leaves_move", lambda c: build_tree(c, with_args(args, tree_moved="leaves"))),
                  ("tree_frame", lambda c: build_tree(c, with_args(args, tree_cull=True))),
-                 ("tree_frame_tiles_cull", lambda c: build_tree(c, with_args(args, tree_cull=True, tree_cull_launches=1))), ("lights", lambda c: build_lights(c, args)),
+                 ("tree_frame_two_launches", lambda c: build_tree(c, with_args(args, tree_cull=True, tree_cull_launches=2))), ("lights", lambda c: build_lights(c, args)),
                  ("flat_static", lambda c: build_flat_static(c, args)), ("flat_static_no_sphere_column", lambda c: build_flat_static(c, with_args(args, sphere_path=1))),
                  ("flat_static_10m_4views", lambda c: build_flat_static(c, with_args(args, entities=10_000_000, views=4))),
                  ("batching", lambda c: build_batching(c, args)),

@@ -865,7 +865,7 @@ class Context:
         self._ck(self._lib.mi_debug_set_walk_inrow(self._h, int(mode)))
 
     def debug_set_tree_cull(self, mode):
-        """0, 1 = the all-dirty hierarchy frame is tile launch + cull launch (default), 2 = every tile culls its own rows where that applies (test / bench hook)."""
+        """0 = the all-dirty hierarchy frame culls inside its tile launches when it has one view (default), 1 = never, 2 = whenever that applies (test / bench hook)."""
         self._ck(self._lib.mi_debug_set_tree_cull(self._h, int(mode)))
 
     def debug_set_row_summary(self, mode):

@@ -1,0 +1,78 @@
+// compact_fast.h -- one workgroup of the single-launch VisibleEntities compaction, as device code: k_compact_fast runs it on its own,
+// the frame kernels (kernels_flat.hip) and the fused hierarchy frame (kernels_tree.hip) carry the previous frame's in extra
+// workgroups of their own launch (MI_CULL_MORE_FRAMES).
+#pragma once
+#include "kernels.h"
+
+namespace mi {
+
+__device__ __forceinline__ uint32_t sum_bytes(uint32_t x, uint32_t acc) { return __builtin_amdgcn_sad_u8(x, 0u, acc); }
+
+// One workgroup of the single-launch compaction: block (bx of gx, segment by).  Called from k_compact_fast and from the
+// tail workgroups of the frame kernels (deferred compaction of the previous frame).
+// Words a compaction workgroup expands: 64 per step, `compact_fast_steps(n)` steps.  Every workgroup first sums the wave counts
+// in front of its range, so the counts read by all of them together grow with (rows / 64)^2 / steps: one step below 1 M rows
+// (2 MB of L2 reads at 1 M), ten at 10 M rows (where one step per workgroup read 760 MB per frame of 4 views: the frame went
+// from 267 to 229 us with this).
+__host__ __device__ __forceinline__ uint32_t compact_fast_steps(uint32_t n) { return 1u + (n >> 20); }
+
+__device__ __forceinline__ void compact_fast_block(const CompactFastArgs& a, uint32_t bx, uint32_t by, uint32_t gx) {
+    const uint32_t seg = by;
+    const uint32_t view = seg / a.n_classes;
+    const uint8_t* cnt = a.wave_cnt + (size_t)seg * a.n_waves;
+    const uint64_t* mask = a.seg_mask ? a.seg_mask + (size_t)seg * a.seg_words
+                                      : a.bitmask + view * a.words_per_view + a.word_offset;
+    const uint32_t n_words = (a.n + 63u) >> 6;
+    const uint32_t steps = compact_fast_steps(a.n);
+    const uint32_t w00 = bx * 64u * steps;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    __shared__ uint32_t red[4], wtot[4];
+
+    // phase 1: base = sum of cnt[0 .. w00)
+    uint32_t partial = 0;
+    const uint4* c4 = reinterpret_cast<const uint4*>(cnt);
+    for (uint32_t i = threadIdx.x; i < (w00 >> 4); i += 256u) {
+        const uint4 q = c4[i];
+        partial = sum_bytes(q.x, partial);
+        partial = sum_bytes(q.y, partial);
+        partial = sum_bytes(q.z, partial);
+        partial = sum_bytes(q.w, partial);
+    }
+#pragma unroll
+    for (uint32_t off = 32u; off; off >>= 1) partial += __shfl_xor(partial, off, 64);
+    if (lane == 0) red[wv] = partial;
+
+    uint32_t running = 0;  // entries of this workgroup's earlier steps
+    uint32_t* out = a.out_rows + (size_t)seg * a.seg_stride;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (uint32_t s = 0; s < steps; ++s) {
+        // phase 2: this wave's 16 words of the step
+        const uint32_t w0 = w00 + s * 64u;
+        const uint32_t my_word = w0 + wv * 16u + lane;
+        const unsigned long long m = (lane < 16u && my_word < n_words) ? mask[my_word] : 0ull;
+        const uint32_t pc = __popcll(m);
+        uint32_t incl = pc;
+#pragma unroll
+        for (uint32_t off = 1; off < 16u; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        const uint32_t excl = incl - pc;
+        if (s) __syncthreads();  // the step before has read wtot
+        if (lane == 15u) wtot[wv] = incl;
+        __syncthreads();
+        uint32_t base = red[0] + red[1] + red[2] + red[3] + running;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) base += k < wv ? wtot[k] : 0u;
+#pragma unroll 4
+        for (uint32_t j = 0; j < 16u; ++j) {
+            const unsigned long long mj = __shfl(m, (int)j, 64);
+            const uint32_t oj = __shfl(excl, (int)j, 64);
+            if ((mj >> lane) & 1ull) out[base + oj + __popcll(mj & lt)] = (w0 + wv * 16u + j) * 64u + lane;
+        }
+        running += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    }
+    if (bx == gx - 1u && threadIdx.x == 0) a.seg_totals[seg] = red[0] + red[1] + red[2] + red[3] + running;
+}
+
+}  // namespace mi

@@ -415,7 +415,9 @@ bool frame_begin(mi_ctx* ctx, CompactFastArgs* prev, bool* prev_has_job, mi_ctx:
     }
     ctx->defer.pending = false;
     ctx->defer.has_job = false;
-    ctx->cur ^= 1u;
+    ctx->cur = (ctx->cur + 1u) % mi_ctx::N_FB;
+    ctx->fb_zero_taken = ctx->fb_zero[ctx->cur];
+    ctx->fb_zero[ctx->cur].ok = false;
     return have;
 }
 
@@ -425,7 +427,7 @@ bool frame_begin(mi_ctx* ctx, CompactFastArgs* prev, bool* prev_has_job, mi_ctx:
 int32_t frame_abort(mi_ctx* ctx, int32_t rc, const CompactFastArgs* prev, bool prev_has_job, const mi_ctx::Exchange::Job& prev_job) {
     if (prev) launch_compact_fast(*prev, ctx->stream);
     if (prev_has_job) exchange_push(ctx, prev_job);
-    ctx->cur ^= 1u;  // the failed frame wrote nothing: the previous frame's set stays the current one
+    ctx->cur = (ctx->cur + mi_ctx::N_FB - 1u) % mi_ctx::N_FB;  // the failed frame wrote nothing: the previous frame's set stays the current one
     return rc;
 }
 
@@ -638,7 +640,7 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
     }
     prof_collect(ctx);
     void* cols[] = {ctx->t, ctx->r, ctx->s, ctx->g, ctx->c, ctx->h, ctx->flags, ctx->vv, ctx->changed, ctx->g_changed_bytes,
-                    ctx->layers, ctx->layers_hi, ctx->class_mask, ctx->keys, ctx->g_chg_bits, ctx->vv_chg_bits, ctx->tree_bytes,
+                    ctx->layers, ctx->layers_hi, ctx->class_mask, ctx->keys, ctx->g_chg_bits, ctx->vv_chg_bits, ctx->vv_chg_alt, ctx->tree_bytes,
                     ctx->range, ctx->visibility, ctx->inh_changed, ctx->bt_set, ctx->bt_bin, ctx->bt_input, ctx->bt_row_meta,
                     ctx->bt_kind, ctx->bt_cpu_bin, ctx->bt_bucket};
     for (void* p : cols)
@@ -773,6 +775,12 @@ int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
         }
         uint64_t* nb = nullptr;
         const size_t wbytes = padded_words(new_cap) * 8 + 256;
+        if (ctx->vv_chg_alt) {  // (sized like vv_chg_bits: allocated again by the next frame that wants it)
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, hipFree(ctx->vv_chg_alt));
+            ctx->vv_chg_alt = nullptr;
+            ctx->vv_alt_zeroed = false;
+        }
         for (uint64_t** bits : {&ctx->g_chg_bits, &ctx->vv_chg_bits}) {
             HIP_TRY(ctx, hipMalloc((void**)&nb, wbytes));
             HIP_TRY(ctx, hipMemsetAsync(nb, 0, wbytes, ctx->stream));
@@ -1204,13 +1212,20 @@ int32_t mi_propagate(mi_ctx* ctx, uint32_t flags) {
         const bool tiles_pretest = ctx->tile_pretest_mode == 2 ||
                                    (ctx->tile_pretest_mode == 0 && static_opt && !all_dirty && ctx->changed_rows_hint != UINT64_MAX &&
                                     ctx->changed_rows_hint * 16 <= n_tiles_all);
+        TreeCull tcull_rest;  // (the compaction riders of a fused hierarchy frame go with the first launch only)
+        const TreeCull* tcull = ctx->tcull;
         for (auto& gr : ctx->groups) {
             ProfScope sc(ctx, K_PROPAGATE_TILES);
+            if (tcull && &gr != &ctx->groups.front() && tcull == ctx->tcull) {
+                tcull_rest = *tcull;
+                tcull_rest.n_compact = 0;
+                tcull = &tcull_rest;
+            }
             HIP_TRY(ctx, launch_propagate_tiles(c, (const uint32_t*)ctx->parent_idx.p, (const TileDesc*)ctx->tiles.p + gr.first,
                                                 (const uint32_t*)ctx->chains.p + (size_t)gr.first * TILE_MAX_CHAIN, gr.count,
                                                 (const uint8_t*)ctx->node_flags.p, ctx->changed, tree_bits, ctx->g_changed_bytes,
                                                 gr.n_chain ? snap_r : nullptr, snap_w, ctx->snap_rows, all_dirty, static_opt,
-                                                ctx->tiles_light, ctx->stream, (unsigned long long*)ctx->tree_trace.p, tiles_pretest, ctx->tcull));
+                                                ctx->tiles_light, ctx->stream, (unsigned long long*)ctx->tree_trace.p, tiles_pretest, tcull));
         }
         for (auto& lv : ctx->stream_levels) {  // the wide deepest levels, each behind the level above it
             ProfScope sc(ctx, K_PROPAGATE_STREAM);
@@ -1272,16 +1287,17 @@ int32_t mi_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_mas
 // memsets of a few hundred KB, enqueued in front of the tiles).  Applies when nothing else wants the frame kernels' own
 // machinery: a plan of light tiles only, views in the kernel arguments, one class segment per view, library-owned masks, no
 // visibility ranges, no cluster assignment in the same call.  Everything else takes the tile launch + cull launch.
-// MEASURED (profiles/r03_experiments.md, 1 M-node tree, 1 view): bit-identical, and SLOWER as built -- the tile kernel grows from 24.8
-// to 31.8 us (the rows' ViewVisibility bytes and summaries are fetched after the GlobalTransforms are done: one more dependent trip
-// per tile, twice; 68 registers: 7 instead of 8 workgroups per CU), and what the frame kernels carry for free goes out on its own
-// (three memsets, the previous frame's compaction): 45.0 us per frame against 37.2 for tile launch + cull launch.  It would take the
-// loads moved into the tile's first bursts, the zeroing folded into the previous frame's launch (a third set of masks) and the
-// compaction riding in the tile launch to get to ~30 us -- for frames in which EVERY Transform of a hierarchy changed, which is the
-// stress case, not what a game runs (change-driven frames: 16 us of tiles + 10 us of cull over the world-sphere column).  Kept as an
-// option (mi_debug_set_tree_cull(2)) with its tests; the default is the two launches.
+// What the frame kernels carry for free rides here too: the previous frame's deferred compaction in the first workgroups of the
+// (first) tile launch, and the zeroing -- every tile clears a slice of the NEXT frame's set (the frame sets rotate by three; the
+// ViewVisibility change ticks alternate between two buffers), so that a run of such frames has no memset in it.
+// MEASURED (profiles/r03_experiments.md, 1 M-node tree): the tile kernel grows from 24.2 to 33.0 us (68 registers: 7 instead of 8
+// workgroups per CU; ~1 900 more vector instructions per tile in a kernel organised around latency), the cull launch (10.6 us) and
+// one launch gap go: 34.7 against 37.1 us per frame at one view, 51.4 against 44.7 at four.  mi_debug_set_tree_cull: 1 = never, 2 =
+// whenever it applies.
 static bool tree_frame_fusable(mi_ctx* ctx, uint32_t n_views, uint32_t flags) {
-    return ctx->tree_cull_mode == 2 && ctx->n && ctx->tiles_light && ctx->stream_levels.empty() && !ctx->groups.empty() && n_views <= MAX_INLINE_VIEWS &&
+    // (default: with one view, where it measured faster -- 34.7 against 37.1 us per frame of the 1 M-node tree; with four views the
+    // rule's arithmetic inside the tiles costs more than the second pass over GlobalTransform: 51.4 against 44.7)
+    return (ctx->tree_cull_mode == 2 || (ctx->tree_cull_mode == 0 && n_views == 1)) && ctx->n && ctx->tiles_light && ctx->stream_levels.empty() && !ctx->groups.empty() && n_views <= MAX_INLINE_VIEWS &&
            !(flags & (MI_CULL_CHANGED_ROWS | MI_CULL_WITH_CLUSTERS)) && (flags & MI_CULL_END_FRAME) && !ctx->have_class_mask && !ctx->have_ranges &&
            !ctx->ext_bitmask && !ctx->xch.on && !ctx->tree_trace.p;
 }
@@ -1297,26 +1313,63 @@ static int32_t tree_frame_fused(mi_ctx* ctx, const mi_view* views, uint32_t n_vi
     SegOut seg;
     if ((rc = prepare_segments(ctx, n_views, &seg))) return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
     if ((rc = row_summary_ensure(ctx))) return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
-    // riders of the frame kernels that have no launch to ride in here: the previous frame's compaction and cluster fill go out on their own
-    if (prev) {
-        ProfScope ps(ctx, K_COMPACT_FAST);
-        HIP_TRY(ctx, launch_compact_fast(*prev, ctx->stream));
-    }
     if (prev_has_job) exchange_push(ctx, prev_job);
-    if ((rc = cluster_fill_join(ctx))) return rc;
+    if ((rc = cluster_fill_join(ctx))) return frame_abort(ctx, rc, prev, false, prev_job);  // (a deferred cluster fill has no launch to ride in here)
     TreeCull cu{};
     memcpy(cu.views.v, ctx->view_set.v, sizeof(ViewParams) * n_views);
     cu.n_views = n_views;
     cu.out = vo;
     cu.wave_cnt = seg.wave_cnt;
     cu.n_waves = seg.n_waves;
-    HIP_TRY(ctx, hipMemsetAsync(vo.bitmask + vo.word_offset, 0, (size_t)n_views * vo.words_per_view * 8, ctx->stream));
-    if (seg.wave_cnt) HIP_TRY(ctx, hipMemsetAsync(seg.wave_cnt, 0, (size_t)n_views * seg.n_waves, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->vv_chg_bits, 0, words64(ctx->n) * 8, ctx->stream));
+    const uint64_t bm_words = (uint64_t)n_views * vo.words_per_view, wc_bytes = seg.wave_cnt ? (uint64_t)n_views * seg.n_waves : 0;
+    const size_t vv_bytes = padded_words(ctx->cap) * 8 + 256;
+    // this frame's set: zeroed by the previous such frame's launch -- or here (the first frame of a run, a changed shape)
+    const mi_ctx::FbZero& z = ctx->fb_zero_taken;
+    if (!(z.ok && z.bitmask == (void*)(vo.bitmask + vo.word_offset) && z.wave_cnt == (void*)seg.wave_cnt && z.bitmask_words == bm_words && z.wave_cnt_bytes == wc_bytes)) {
+        HIP_TRY(ctx, hipMemsetAsync(vo.bitmask + vo.word_offset, 0, bm_words * 8, ctx->stream));
+        if (seg.wave_cnt) HIP_TRY(ctx, hipMemsetAsync(seg.wave_cnt, 0, wc_bytes, ctx->stream));
+    }
+    // the ViewVisibility change ticks alternate between two buffers the same way
+    if (!ctx->vv_chg_alt) {
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->vv_chg_alt, vv_bytes));
+        ctx->vv_alt_zeroed = false;
+    }
+    if (ctx->vv_alt_zeroed) std::swap(ctx->vv_chg_bits, ctx->vv_chg_alt);
+    else HIP_TRY(ctx, hipMemsetAsync(ctx->vv_chg_bits, 0, words64(ctx->n) * 8, ctx->stream));
+    ctx->vv_alt_zeroed = false;
+    // the next frame's set (same shape), zeroed by this frame's tiles
+    const uint32_t nx = (ctx->cur + 1u) % mi_ctx::N_FB;
+    mi_ctx::FbZero zn;
+    if (!ctx->ext_bitmask && !(rc = ensure(ctx, ctx->fb[nx].bitmask, bm_words * 8)) && (!wc_bytes || !(rc = ensure(ctx, ctx->fb[nx].wave_cnt, wc_bytes)))) {
+        zn.bitmask = ctx->fb[nx].bitmask.p;
+        zn.wave_cnt = wc_bytes ? ctx->fb[nx].wave_cnt.p : nullptr;
+        zn.bitmask_words = bm_words;
+        zn.wave_cnt_bytes = wc_bytes;
+        cu.zero[0] = (uint64_t*)zn.bitmask;
+        cu.zero_words[0] = (uint32_t)bm_words;
+        cu.zero[1] = (uint64_t*)zn.wave_cnt;
+        cu.zero_words[1] = (uint32_t)(wc_bytes / 8);  // (n_waves is a multiple of 64)
+        cu.zero[2] = ctx->vv_chg_alt;
+        cu.zero_words[2] = (uint32_t)words64(ctx->n);
+    }
+    if (rc) return frame_abort(ctx, rc, prev, false, prev_job);
+    // the previous frame's deferred compaction rides in the (first) tile launch
+    if (prev && prev->n && prev->n_segments) {
+        cu.prev = *prev;
+        cu.prev_gx = (((prev->n + 63u) >> 6) + 64u * compact_fast_steps_host(prev->n) - 1u) / (64u * compact_fast_steps_host(prev->n));
+        cu.n_compact = cu.prev_gx * prev->n_segments;
+    } else {
+        cu.prev_gx = 1;
+    }
     ctx->tcull = &cu;
     rc = mi_propagate(ctx, MI_PROPAGATE_ALL_DIRTY | ((flags & MI_CULL_STATIC_OPT) ? MI_PROPAGATE_STATIC_OPT : 0u));
     ctx->tcull = nullptr;
     if (rc) return rc;
+    if (cu.zero[0]) {
+        zn.ok = true;
+        ctx->fb_zero[nx] = zn;
+        ctx->vv_alt_zeroed = true;
+    }
     if ((rc = run_compaction(ctx, vo, seg, flags))) return rc;
     ctx->culled = true;
     return exchange_end(ctx);
@@ -1943,7 +1996,7 @@ int32_t mi_debug_set_walk_inrow(mi_ctx* ctx, int32_t mode) {
     return MI_OK;
 }
 
-// test / bench hook: the all-dirty hierarchy frame: 0, 1 = tile launch + cull launch (default), 2 = every tile culls its own rows
+// test / bench hook: the all-dirty hierarchy frame: 0 = the tiles cull their own rows when there is one view (default), 1 = never, 2 = whenever it applies
 int32_t mi_debug_set_tree_cull(mi_ctx* ctx, int32_t mode) {
     ENTER(ctx);
     if (mode < 0 || mode > 2) return fail(ctx, MI_ERR_INVALID_ARG, "mi_debug_set_tree_cull: mode %d", mode);

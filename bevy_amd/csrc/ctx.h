@@ -90,7 +90,7 @@ struct mi_ctx {
     struct TileGroup { uint32_t first, count, n_chain, owner_rows; };
     bool tiles_light = false;       // the plan was made for the light tile kernel (TILE_LIGHT_*)
     const mi::TreeCull* tcull = nullptr;  // set by the fused hierarchy frame around its mi_propagate: the tile launches also cull
-    int32_t tree_cull_mode = 0;           // mi_debug_set_tree_cull: 0, 1 = tile launch + cull launch (default), 2 = fused where it applies
+    int32_t tree_cull_mode = 0;           // mi_debug_set_tree_cull: 0 = fused where it applies and there is one view (default), 1 = never, 2 = whenever it applies
     int32_t tile_pretest_mode = 0;  // mi_debug_set_tile_pretest
     int32_t tile_mode = 0;          // 0 = light tiles where they fit, 1 = always the big tiles, 2 = always light, 3 = as 0 with the streamed-level thresholds at their test values (mi_debug_set_tile_mode)
     std::vector<TileGroup> groups;  // tile launches of mi_propagate: roots + chain bands in one, then one per dependent band
@@ -203,7 +203,18 @@ struct mi_ctx {
     // consumes and the lists it writes.  Two sets, alternating by frame: a frame culled with MI_CULL_MORE_FRAMES defers
     // its compaction into the tail workgroups of the NEXT frame's kernel (or into a launch of its own at the first
     // entry point that exposes the lists), which reads set f while that kernel writes set f + 1.
-    static constexpr uint32_t N_FB = 2;
+    // Three sets, taken in turn (frame_begin): the frame being written, the previous frame's (whose deferred compaction may still
+    // read it), and -- for the hierarchy frames that OR their results in with atomics (tree_frame_fused) -- the next frame's, which
+    // this frame's launch zeroes.  fb_zeroed[i]: masks and wave counts of set i are known to be zero for the shape in fb_zero_shape[i].
+    static constexpr uint32_t N_FB = 3;
+    struct FbZero {
+        void *bitmask = nullptr, *wave_cnt = nullptr;  // what was zeroed (a reallocated buffer is not it any more)
+        uint64_t bitmask_words = 0, wave_cnt_bytes = 0;
+        bool ok = false;
+    } fb_zero[3];
+    FbZero fb_zero_taken;  // state of the set frame_begin has just made current (every frame writes into its set: the state is consumed)
+    uint64_t* vv_chg_alt = nullptr;  // second ViewVisibility change-tick buffer of those frames (they alternate); zeroed iff vv_alt_zeroed
+    bool vv_alt_zeroed = false;
     struct FrameBufs {
         DevBuf bitmask, wave_cnt, seg_mask, out_rows, seg_totals;
     } fb[N_FB];

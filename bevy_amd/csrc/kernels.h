@@ -319,12 +319,20 @@ hipError_t launch_mark_dirty(uint32_t n, const uint8_t* changed, uint32_t change
 // The hierarchy FRAME in the tile launch itself (k_propagate_fans<true, true>): every tile also runs the visibility systems over
 // its own rows, GlobalTransforms still in registers / LDS.  A tile's rows are not aligned to the 64-row words of the per-view masks,
 // so the words are ORed and the wave counts added with atomics into memory the host zeroed before the launch.
+inline uint32_t compact_fast_steps_host(uint32_t n) { return 1u + (n >> 20); }  // = compact_fast_steps (compact_fast.h)
 struct TreeCull {
     ViewSet views;
     uint32_t n_views;
     VisibilityOut out;      // zeroed: n_views * words_per_view words
     uint8_t* wave_cnt;      // zeroed: [n_views][n_waves] (one class segment per view), or nullptr
     uint32_t n_waves;
+    // what the NEXT such frame will OR into: zeroed by this launch (every tile a slice), so that no memset sits between the frames
+    // (the frame sets rotate by three: this frame's, the previous frame's -- being compacted --, the next frame's)
+    uint64_t* zero[3];
+    uint32_t zero_words[3];
+    // the previous frame's deferred VisibleEntities compaction rides in the first n_compact workgroups (MI_CULL_MORE_FRAMES)
+    CompactFastArgs prev;
+    uint32_t prev_gx, n_compact;
 };
 hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, const TileDesc* d_tiles, const uint32_t* d_chains,
                                   uint32_t n_tiles, const uint8_t* node_flags, const uint8_t* changed, const uint8_t* tree_bytes,

@@ -26,6 +26,7 @@
 #include "glam_math.h"
 #include "kernels.h"
 #include "visibility_rule.h"
+#include "compact_fast.h"
 
 namespace mi {
 
@@ -577,10 +578,11 @@ __device__ __forceinline__ void process_tile(const Columns& c, const TreeArgs& a
 // fetching the same lines eight times (1 M-node tree: 31.0 -> 30.0 us per launch).  Tiles of a launch do not depend on each
 // other, so any bijection is correct.  (The same inside chunks of 256 or 1 536 tiles, which keeps the launch's progression
 // through the row space: no different at 1 M, 1.4 M and 5.6 M nodes.)
-__device__ __forceinline__ uint32_t xcd_contiguous_tile() {
-    const uint32_t nt = gridDim.x, x = blockIdx.x & 7u, q = nt >> 3, r = nt & 7u;
-    return x * q + (x < r ? x : r) + (blockIdx.x >> 3);
+__device__ __forceinline__ uint32_t xcd_contiguous_tile(uint32_t bid, uint32_t nt) {
+    const uint32_t x = bid & 7u, q = nt >> 3, r = nt & 7u;
+    return x * q + (x < r ? x : r) + (bid >> 3);
 }
+__device__ __forceinline__ uint32_t xcd_contiguous_tile() { return xcd_contiguous_tile(blockIdx.x, gridDim.x); }
 
 template <uint32_t BLOCK>
 __global__ void __launch_bounds__(BLOCK) k_propagate_tiles(Columns c, TreeArgs a) {
@@ -663,6 +665,10 @@ __device__ __forceinline__ bool quad_node_apply(bool on, bool is_root_level, boo
 // runs of consecutive rows inside one word, and the first lane of each run ORs the run's bits into the word and adds its
 // population to the word's count -- atomics into memory the host zeroed before the launch (TreeCull, kernels.h).
 // Every lane of the wave must call it; lanes carry rows in ascending order.
+// (The rows' ViewVisibility bytes and summaries are fetched here, at the end of the tile.  Fetching them with the tile's first
+// bursts and keeping them -- reduced to scalars where the wave's rows agree -- cost 12 registers and a workgroup per CU and measured
+// SLOWER, 35.8 against 33.0 us per launch: what the rule adds to a tile is mostly its arithmetic, ~1 900 vector instructions per
+// tile, which a kernel organised around latency has nowhere to hide.  profiles/r03_experiments.md.)
 // ---------------------------------------------------------------------------------------------
 struct NoCull {};
 template <bool CULL>
@@ -762,7 +768,21 @@ __global__ void __launch_bounds__(256, CULL ? 6 : ALL_DIRTY ? 8 : 7) k_propagate
     __shared__ uint8_t lds_level[TILE_LIGHT_UCAP];   // per upper row: its level inside the tile
     __shared__ float4 lds_chain_g[3];
     __shared__ uint32_t lds_chain_chg;
-    const uint32_t tile = xcd_contiguous_tile();
+    uint32_t tile_bid = blockIdx.x, tile_grid = gridDim.x;
+    if constexpr (CULL) {
+        // the previous frame's VisibleEntities compaction rides in the first workgroups of the launch ...
+        if (blockIdx.x < cu.n_compact) {
+            compact_fast_block(cu.prev, blockIdx.x % cu.prev_gx, blockIdx.x / cu.prev_gx, cu.prev_gx);
+            return;
+        }
+        tile_bid -= cu.n_compact;
+        tile_grid -= cu.n_compact;
+        // ... and every tile zeroes a slice of what the next such frame ORs its results into
+#pragma unroll
+        for (uint32_t k = 0; k < 3u; ++k)
+            for (uint32_t i = tile_bid * 256u + threadIdx.x; i < cu.zero_words[k]; i += tile_grid * 256u) cu.zero[k][i] = 0ull;
+    }
+    const uint32_t tile = xcd_contiguous_tile(tile_bid, tile_grid);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     // development trace: stamps are kept in registers and written once at the very end (a store in front of a barrier would
     // make the barrier's vmcnt(0) wait for it and distort the phase it is meant to time)
@@ -1328,7 +1348,7 @@ hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, 
     a.trace = trace;
     if (cull) {
         if (!(light && all_dirty) || !c.row_summary) return hipErrorInvalidValue;  // (the host checks: every tile runs, light tiles only)
-        MI_LAUNCH((k_propagate_fans<true, true>), dim3(n_tiles), dim3(256), 0, stream, c, a, *cull);
+        MI_LAUNCH((k_propagate_fans<true, true>), dim3(n_tiles + cull->n_compact), dim3(256), 0, stream, c, a, *cull);
     } else if (light && all_dirty) MI_LAUNCH((k_propagate_fans<true, false>), dim3(n_tiles), dim3(256), 0, stream, c, a, NoCull{});
     else if (light) MI_LAUNCH((k_propagate_fans<false, false>), dim3(n_tiles), dim3(256), 0, stream, c, a, NoCull{});
     else MI_LAUNCH((k_propagate_tiles<TILE_BLOCK>), dim3(n_tiles), dim3(TILE_BLOCK), 0, stream, c, a);

@@ -52,8 +52,9 @@ int32_t mi_debug_set_tile_pretest(mi_ctx* ctx, int32_t mode);
 /* The cluster walk of a MI_CULL_WITH_CLUSTERS frame whose objects are bound to a row RANGE: 0 = the frame kernel's row workgroups
  * of those rows go on into the walk (default), 1 = extra workgroups re-derive the rows' visibility (as for row lists).  Same results. */
 int32_t mi_debug_set_walk_inrow(mi_ctx* ctx, int32_t mode);
-/* The all-dirty hierarchy frame of mi_propagate_and_cull[_views]: 0, 1 = tile launch + cull launch (default), 2 = fused into the tile
- * launches where that applies (every tile also culls its own rows; measured slower as built).  Results are identical. */
+/* The all-dirty hierarchy frame of mi_propagate_and_cull[_views]: 0 = every tile also culls its own rows when the frame has one
+ * view and nothing else needs the frame kernels (default: measured faster there), 1 = always tile launch + cull launch,
+ * 2 = fused whenever it applies.  Results are identical. */
 int32_t mi_debug_set_tree_cull(mi_ctx* ctx, int32_t mode);
 /* The per-wave summary of Aabb / flags / RenderLayers (64 aligned rows that agree read 32 bytes instead of 64 x 29): 0 = in use
  * (default), 1 = off -- every row reads its own columns.  Results are identical; A/B timing and tests. */

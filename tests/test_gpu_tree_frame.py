@@ -4,7 +4,7 @@ runs reset_view_visibility + check_visibility + check_visibility_gpu_culling + m
 (visibility/mod.rs:733-737, 788-858, 884-918) and ORs its bits into the packed masks with atomics.
 
 Against the oracle (propagate_parent_transforms, then the visibility systems over its GlobalTransforms) and against a twin context
-that runs the same call as two launches (the default; the fused form is mi_debug_set_tree_cull(2)): GlobalTransforms, their change ticks, every view's mask,
+that runs the same call as two launches (mi_debug_set_tree_cull(1); 2 = fused whenever it applies, the default only with one view): GlobalTransforms, their change ticks, every view's mask,
 VisibleEntities, ViewVisibility and its change ticks, frame after frame (the ViewVisibility byte carries from one to the next).
 Forests whose tiles start and end anywhere inside the 64-row mask words, ragged flags / layers / bounds, 1 to 8 views, frames that
 fall back (changed-rows frames in between, a shadow view kind, classes)."""
@@ -106,6 +106,7 @@ def test_fused_hierarchy_frame_matches_oracle_and_two_launches(n, seed, n_views)
     sc = ragged_bounds(n, seed)
     with api.Context(0) as a, api.Context(0) as b:
         a.debug_set_tree_cull(2)
+        b.debug_set_tree_cull(1)
         for ctx in (a, b):
             ctx.resize(n)
             ctx.upload_transforms(t.reshape(-1), r.reshape(-1), s.reshape(-1))
@@ -138,6 +139,7 @@ def test_fused_and_fallback_frames_interleave():
     rng = np.random.default_rng(5)
     with api.Context(0) as a, api.Context(0) as b:
         a.debug_set_tree_cull(2)
+        b.debug_set_tree_cull(1)
         for ctx in (a, b):
             ctx.resize(n)
             ctx.upload_transforms(t.reshape(-1), tr["rotation"], tr["scale"])

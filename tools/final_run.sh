@@ -1,8 +1,19 @@
+#!/bin/bash
+# One call on the GPU box for a state of the code:   bash tools/final_run.sh <tag>
+#   GPU tests (+ the same with the internal fast paths forced the other way), smoke(), the rocprofv3 evidence (tools/profile.sh),
+#   the single-process multi-GPU driver, the default bench line.  Everything lands under gpurun_out/prof_<tag>/ (merged back).
 TAG=$1
+export TMPDIR=/tmp
 P=gpurun_out/prof_$TAG
 mkdir -p $P
-timeout 600 python -m pytest tests -m gpu -q > $P/gputest.log 2>&1; echo "gpu tests rc=$?" >> $P/gputest.log
+rocminfo | grep -m1 gfx > $P/device.txt
+timeout 900 python -m pytest tests -m gpu -q > $P/gputest.log 2>&1; echo "gpu tests rc=$?" >> $P/gputest.log
+MI_TEST_ROW_SUMMARY=1 MI_TEST_WALK_INROW=1 MI_TEST_TREE_CULL=2 MI_TEST_SPHERE_PATH=2 MI_TEST_TILE_PRETEST=2 timeout 900 python -m pytest tests -m gpu -q \
+    --deselect tests/test_gpu_differential.py > $P/gputest_other_paths.log 2>&1; echo "gpu tests (other paths) rc=$?" >> $P/gputest_other_paths.log
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $P/smoke.log 2>&1; echo "smoke rc=$?" >> $P/smoke.log
+timeout 200 ./tests/cpp/multi_gpu_single_process 1000000 6 > $P/multi_gpu_single_process.json 2> $P/multi_gpu.err; echo "multi gpu rc=$?" >> $P/multi_gpu.err
 bash tools/profile.sh $TAG > $P/profile.log 2>&1
-timeout 900 python bench.py > $P/bench_line.json 2> $P/bench.err; echo "bench rc=$?" >> $P/bench.err
-grep -E "passed|failed|rc=" $P/gputest.log $P/smoke.log | tail -5
+timeout 1200 python bench.py > $P/bench_line.json 2> $P/bench.err; echo "bench rc=$?" >> $P/bench.err
+cp -r profiles/$TAG $P/profiles_$TAG 2>/dev/null
+cp profiles/rocprof_summary.json $P/rocprof_summary.json 2>/dev/null
+grep -E "passed|failed|rc=" $P/gputest.log $P/gputest_other_paths.log $P/smoke.log $P/multi_gpu.err $P/bench.err | tail -8

@@ -7,7 +7,7 @@
 # profiles/rocprof_summary.json (what bench.py quotes as rocprof_avg_kernel_us / traffic).
 TAG=${1:-r03}
 shift
-WLS=${@:-frame frame_plain_columns flat flat_plain_columns flat_10m_1view flat_10m_4views tree tree_subtree tree_leaves lights flat_static flat_static_no_sphere flat_static_10m_4views batching batching_sorted_64k batching_sorted_1m}
+WLS=${@:-frame frame_plain_columns flat flat_plain_columns flat_10m_1view flat_10m_4views tree tree_subtree tree_leaves tree_frame tree_frame_two_launches lights flat_static flat_static_no_sphere flat_static_10m_4views batching batching_sorted_64k batching_sorted_1m}
 export TMPDIR=/tmp
 P=gpurun_out/prof_$TAG
 mkdir -p $P
@@ -20,6 +20,8 @@ for wl in $WLS; do
     flat_10m_4views) ARGS="--workload flat --entities 10000000 --views 4" ;;
     tree_subtree)    ARGS="--workload tree --tree-moved subtree" ;;
     tree_leaves)     ARGS="--workload tree --tree-moved leaves" ;;
+    tree_frame)      ARGS="--workload tree --tree-cull" ;;
+    tree_frame_two_launches) ARGS="--workload tree --tree-cull --tree-cull-launches 2" ;;
     flat_static_no_sphere)  ARGS="--workload flat_static --sphere-path 1" ;;
     flat_static_10m_4views) ARGS="--workload flat_static --entities 10000000 --views 4" ;;
     batching_sorted_64k)    ARGS="--workload batching_sorted --sorted-items 65536" ;;

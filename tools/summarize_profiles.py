@@ -14,7 +14,7 @@ import shutil
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
-workloads = sys.argv[2:] or ["frame", "flat", "flat_10m_1view", "flat_10m_4views", "tree", "tree_subtree", "tree_leaves", "lights", "flat_static", "flat_static_no_sphere",
+workloads = sys.argv[2:] or ["frame", "frame_plain_columns", "flat", "flat_plain_columns", "tree_frame", "tree_frame_two_launches", "flat_10m_1view", "flat_10m_4views", "tree", "tree_subtree", "tree_leaves", "lights", "flat_static", "flat_static_no_sphere",
                              "flat_static_10m_4views", "batching", "batching_sorted_64k", "batching_sorted_1m"]
 src = os.path.join("gpurun_out", f"prof_{tag}")
 dst = os.path.join("profiles", tag)

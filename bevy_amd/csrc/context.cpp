@@ -1335,7 +1335,7 @@ static int32_t tree_frame_fused(mi_ctx* ctx, const mi_view* views, uint32_t n_vi
         ctx->vv_alt_zeroed = false;
     }
     if (ctx->vv_alt_zeroed) std::swap(ctx->vv_chg_bits, ctx->vv_chg_alt);
-    else HIP_TRY(ctx, hipMemsetAsync(ctx->vv_chg_bits, 0, words64(ctx->n) * 8, ctx->stream));
+    else HIP_TRY(ctx, hipMemsetAsync(ctx->vv_chg_bits, 0, padded_words(ctx->cap) * 8, ctx->stream));  // (the whole capacity: the row count may grow inside it)
     ctx->vv_alt_zeroed = false;
     // the next frame's set (same shape), zeroed by this frame's tiles
     const uint32_t nx = (ctx->cur + 1u) % mi_ctx::N_FB;
@@ -1350,7 +1350,7 @@ static int32_t tree_frame_fused(mi_ctx* ctx, const mi_view* views, uint32_t n_vi
         cu.zero[1] = (uint64_t*)zn.wave_cnt;
         cu.zero_words[1] = (uint32_t)(wc_bytes / 8);  // (n_waves is a multiple of 64)
         cu.zero[2] = ctx->vv_chg_alt;
-        cu.zero_words[2] = (uint32_t)words64(ctx->n);
+        cu.zero_words[2] = (uint32_t)padded_words(ctx->cap);
     }
     if (rc) return frame_abort(ctx, rc, prev, false, prev_job);
     // the previous frame's deferred compaction rides in the (first) tile launch
@@ -1364,7 +1364,10 @@ static int32_t tree_frame_fused(mi_ctx* ctx, const mi_view* views, uint32_t n_vi
     ctx->tcull = &cu;
     rc = mi_propagate(ctx, MI_PROPAGATE_ALL_DIRTY | ((flags & MI_CULL_STATIC_OPT) ? MI_PROPAGATE_STATIC_OPT : 0u));
     ctx->tcull = nullptr;
-    if (rc) return rc;
+    if (rc) {  // the launch that was to carry the previous frame's compaction may not have happened: it goes out on its own (idempotent)
+        if (prev) launch_compact_fast(*prev, ctx->stream);
+        return rc;
+    }
     if (cu.zero[0]) {
         zn.ok = true;
         ctx->fb_zero[nx] = zn;

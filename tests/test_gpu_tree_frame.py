@@ -194,3 +194,33 @@ def test_the_big_tree():
                         ctx.download_visible_entities(0, 0)[1].tobytes()))
     assert out[0] == out[1]
     assert np.frombuffer(out[0][1], np.uint32).any()
+
+
+def test_row_count_changes_between_fused_frames():
+    """The sets a fused frame zeroes ahead are sized by capacity, not by the row count of the frame that zeroed them: shrink the
+    scene, run frames, grow it again inside the same capacity -- masks and change ticks of the rows that came back must be right."""
+    rng = np.random.default_rng(3)
+    with api.Context(0) as a, api.Context(0) as b:
+        a.debug_set_tree_cull(2)
+        b.debug_set_tree_cull(1)
+        for n in (6000, 2500, 6000, 900, 5999):
+            parent, offs = random_forest(n, int(rng.integers(1, 1000)))
+            t = rng.normal(0.0, 6.0, (n, 3)).astype(F)
+            r = W.random_unit_quats(int(rng.integers(1, 1000)), n, 0).astype(F)
+            s = np.ones((n, 3), F)
+            sc = ragged_bounds(n, n)
+            for ctx in (a, b):
+                ctx.resize(n)
+                ctx.upload_transforms(t.reshape(-1), r.reshape(-1), s.reshape(-1))
+                ctx.upload_hierarchy(parent, offs)
+                ctx.upload_bounds(sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"])
+            for frame in range(3):
+                frusta = frusta_for([W.many_cubes_camera(frame * 50, position=(0.0, 0.0, 30.0))])
+                for ctx in (a, b):
+                    ctx.propagate_and_cull(frusta, flags=B.CULL_END_FRAME | B.CULL_MORE_FRAMES)
+                va, cva = a.download_view_visibility()
+                vb, cvb = b.download_view_visibility()
+                assert_bits(va, vb, f"n={n} frame {frame}: ViewVisibility")
+                assert_bits(cva, cvb, f"n={n} frame {frame}: ViewVisibility change ticks")
+                assert_bits(a.download_visibility(0), b.download_visibility(0), f"n={n} frame {frame}: mask")
+                assert np.array_equal(a.download_visible_entities(0, 0)[1], b.download_visible_entities(0, 0)[1])

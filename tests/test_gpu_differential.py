@@ -10,8 +10,9 @@ agree on everything a caller can download after every step; at intervals the ora
     hierarchy frame fused into the tile launches          (B: two launches)               [A: mi_debug_set_tree_cull(2)]
 
 The sequences mix: bounds uploads (whole, partial, single rows), RenderLayers above 31, Transform uploads (indexed, ranges),
-change marks, growth and shrinkage of the row count, every kind of frame (all rows, changed rows, propagate + cull, with and
-without the cluster assignment, with the compaction deferred or not), on flat scenes and on forests.  The reference has no
+change marks, growth and shrinkage of the row count, Visibility changes propagated on the device, VisibilityClass masks, one to
+nine views (a device table beyond eight) of which one may be a shadow cascade, every kind of frame (all rows, changed rows,
+propagate + cull, with and without the cluster assignment, with the compaction deferred or not), on flat scenes and on forests.  The reference has no
 counterpart (it has one path); what is pinned here is that the library's paths are interchangeable."""
 import os
 
@@ -161,9 +162,18 @@ def test_fast_paths_are_interchangeable(seed):
                     ctx.cluster_bind_objects_to_row_list(np.arange(first_light, n, dtype=np.uint32))
                 else:
                     ctx.cluster_bind_objects_to_rows(first_light, n_lights)
-        n_views = int(rng.integers(1, 4))
-        vm_lo = np.array([1, 3, 0xFFFFFFFF][:n_views], np.uint32)
-        vm_hi = np.array([0, 1 << 9, 0][:n_views], np.uint32)
+        n_views = int(rng.choice([1, 1, 2, 3, 4, 9]))  # (more than 8 views travel as a device table, not in the kernel arguments)
+        vm_lo = np.array([1, 3, 0xFFFFFFFF, 1, 1, 1, 1, 1, 1][:n_views], np.uint32)
+        vm_hi = np.array([0, 1 << 9, 0, 0, 0, 0, 0, 0, 0][:n_views], np.uint32)
+        shadow_view = n_views >= 2 and seed % 3 == 0  # the last view is a cascade: OBB only, near plane skipped, far plane tested
+        view_flags = np.zeros(n_views, np.uint32)
+        if shadow_view:
+            view_flags[-1] = B.VIEW_KIND_CASCADE
+        classes = seed % 5 == 4 and not forest  # VisibilityClass masks: lists per (view, class), per-class segment masks
+        if classes:
+            sc.cls = rng.choice(np.array([1, 1, 2, 3], np.uint32), sc.cap)
+            for ctx in (a, b):
+                ctx.upload_visibility_classes(sc.cls[:n])
         had_clusters, n_clusters = False, 0
         for step in range(22):
             op = rng.integers(0, 9)
@@ -179,6 +189,8 @@ def test_fast_paths_are_interchangeable(seed):
                     ctx.resize(n2)
                     if n2 > n:
                         ctx.upload_transforms(sc.t[n:n2].reshape(-1), sc.r[n:n2].reshape(-1), sc.s[n:n2].reshape(-1), first_row=n)
+                        if classes:
+                            ctx.upload_visibility_classes(sc.cls[n:n2], first_row=n)
                 n = n2
             elif op in (1, 2):  # bounds: a run, or single rows
                 lim = first_light if n_lights else n
@@ -188,6 +200,12 @@ def test_fast_paths_are_interchangeable(seed):
                 for ctx in (a, b):
                     ctx.upload_bounds(sc.c[lo:hi].reshape(-1), sc.h[lo:hi].reshape(-1), sc.fl[lo:hi], sc.lay[lo:hi], first_row=lo)
                     ctx.upload_render_layers_hi(sc.lay_hi[lo:hi], first_row=lo)
+            elif op == 5 and not forest:  # Visibility components change: mi_visibility_propagate rewrites InheritedVisibility on the device
+                vis_comp = np.where(rng.random(n) < 0.1, B.VISIBILITY_HIDDEN, B.VISIBILITY_INHERITED).astype(np.uint8)
+                for ctx in (a, b):
+                    ctx.upload_visibility(vis_comp)
+                    ctx.visibility_propagate()
+                sc.fl[:n] = (sc.fl[:n] & ~np.uint8(1)) | np.where(vis_comp == B.VISIBILITY_HIDDEN, 0, 1).astype(np.uint8)
             elif op in (3, 4):  # some Transforms move
                 k = int(min(n, rng.integers(1, 400 if op == 3 else 8)))
                 rows = np.sort(rng.choice(n, k, replace=False)).astype(np.uint32)
@@ -197,7 +215,7 @@ def test_fast_paths_are_interchangeable(seed):
             # every step ends in a frame
             cams = [W.many_cubes_camera(int(rng.integers(0, 400)), yaw=float(rng.random() * 6.0), position=tuple(rng.normal(0, 8.0, 3))) for _ in range(n_views)]
             fr = np.concatenate([api.compute_frustum(cfv(), cam, W.CAMERA_FAR) for cam in cams])
-            views = api.make_views(fr, layer_masks=vm_lo, layer_masks_hi=vm_hi)
+            views = api.make_views(fr, layer_masks=vm_lo, layer_masks_hi=vm_hi, flags=view_flags)
             kind = ["all", "changed", "split", "split_all"][int(rng.integers(0, 4))]
             flags = B.CULL_END_FRAME | (B.CULL_MORE_FRAMES if rng.random() < 0.5 else 0)
             with_clusters = bool(n_lights) and rng.random() < 0.7
@@ -217,6 +235,10 @@ def test_fast_paths_are_interchangeable(seed):
                     ctx.cull_views(views, flags=flags | B.CULL_BEGIN_FRAME)
             had_clusters = had_clusters or with_clusters
             sa, sb = snapshot(a, n_views, had_clusters, n_clusters), snapshot(b, n_views, had_clusters, n_clusters)
+            if classes:
+                for v in range(n_views):
+                    assert a.download_visible_entities(v, 1)[1].tobytes() == b.download_visible_entities(v, 1)[1].tobytes(), f"seed {seed} step {step}: list of view {v}, class 1"
+
             for key in sa:
                 assert sa[key] == sb[key], f"seed {seed} step {step} ({kind}, op {op}, n {n}, forest {forest}, clusters {with_clusters}): {key} differs"
             # the oracle, now and then (GlobalTransforms and this frame's masks; ViewVisibility needs the carried byte: after the first ask)
@@ -231,7 +253,7 @@ def test_fast_paths_are_interchangeable(seed):
                     c_or[first_light:n] = sc.t[first_light:n]
                 _, vis, _ = O.check_visibility_layers64(g, c_or.reshape(-1), oracle_half(sc, n, first_light, n_lights), sc.fl[:n], sc.lay[:n], sc.lay_hi[:n],
                                                         np.zeros(n, np.uint8), fr, vm_lo, vm_hi)
-                for v in range(n_views):
+                for v in range(n_views - (1 if shadow_view else 0)):  # (the 64-layer restatement knows camera views only)
                     assert np.array_equal(np.frombuffer(sa[f"mask {v}"], np.uint8), vis[v]), f"seed {seed} step {step}: mask of view {v} against the oracle"
     finally:
         a.close()

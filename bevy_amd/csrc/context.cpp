@@ -645,7 +645,7 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
                     ctx->bt_kind, ctx->bt_cpu_bin, ctx->bt_bucket};
     for (void* p : cols)
         if (p) hipFree(p);
-    DevBuf* bufs[] = {&ctx->sph, &ctx->row_sum, &ctx->order, &ctx->chains, &ctx->snap, &ctx->tree_trace, &ctx->inh_bits, &ctx->sparse_cnt, &ctx->sparse_rows, &ctx->sparse_total, &ctx->sparse_g, &ctx->parent_idx, &ctx->node_flags, &ctx->tiles, &ctx->views,
+    DevBuf* bufs[] = {&ctx->sph, &ctx->row_sum, &ctx->anc, &ctx->order, &ctx->chains, &ctx->snap, &ctx->tree_trace, &ctx->inh_bits, &ctx->sparse_cnt, &ctx->sparse_rows, &ctx->sparse_total, &ctx->sparse_g, &ctx->parent_idx, &ctx->node_flags, &ctx->tiles, &ctx->views,
                       &ctx->block_counts, &ctx->seg_bases, &ctx->out_keys, &ctx->cl_pos,
                       &ctx->cl_type, &ctx->cl_layers, &ctx->cl_dir, &ctx->cl_sincos, &ctx->cl_planes, &ctx->cl_spheres,
                       &ctx->bt_set_indexed, &ctx->bt_table_off, &ctx->bt_table, &ctx->bt_meta_off, &ctx->bt_meta, &ctx->bt_rows_a, &ctx->bt_rows_b,
@@ -893,7 +893,7 @@ static int32_t scatter_indexed(mi_ctx* ctx, const uint32_t* rows, const float* t
         other = (uint32_t*)(ctx->tree_bytes + (size_t)(ctx->tree_parity ^ 1u) * ctx->tree_half_words * 4);
     HIP_TRY(ctx, launch_upload_trs_indexed((const uint32_t*)d_rows, (const float*)d_t, (const float*)d_r, (const float*)d_s, n, ctx->t, ctx->r,
                                            ctx->s, ctx->changed, ctx->changed_gen, ctx->stream, mark_here ? (const uint32_t*)ctx->parent_idx.p : nullptr,
-                                           cur, other, ctx->tree_half_words));
+                                           cur, other, ctx->tree_half_words, ctx->anc_valid ? (const uint32_t*)ctx->anc.p : nullptr));
     if (mark_here) {
         if (!ctx->marks_in_cur) ctx->marks_complete = !ctx->changed_maybe;  // complete so far iff nothing was marked changed before this upload
         ctx->marks_in_cur = true;
@@ -1173,7 +1173,8 @@ int32_t mi_propagate(mi_ctx* ctx, uint32_t flags) {
             }
             ProfScope ps(ctx, K_MARK_DIRTY);
             HIP_TRY(ctx, launch_mark_dirty(ctx->n, ctx->changed, ctx->changed_gen, (const uint32_t*)ctx->parent_idx.p, cur,
-                                           ctx->tree_clean[ctx->tree_parity ^ 1u] ? nullptr : (uint32_t*)other, ctx->tree_half_words, ctx->stream));
+                                           ctx->tree_clean[ctx->tree_parity ^ 1u] ? nullptr : (uint32_t*)other, ctx->tree_half_words, ctx->stream,
+                                           ctx->anc_valid ? (const uint32_t*)ctx->anc.p : nullptr));
         }
         ctx->tree_clean[ctx->tree_parity] = false;
         ctx->tree_clean[ctx->tree_parity ^ 1u] = true;

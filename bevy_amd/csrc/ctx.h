@@ -89,6 +89,8 @@ struct mi_ctx {
     std::vector<std::pair<uint32_t, uint32_t>> passes;  // (first tile, n tiles); pass 0 starts at level 0 (roots)
     struct TileGroup { uint32_t first, count, n_chain, owner_rows; };
     bool tiles_light = false;       // the plan was made for the light tile kernel (TILE_LIGHT_*)
+    DevBuf anc;                     // the ancestor table (kernels.h, ANC_DEPTH): built by mi_upload_hierarchy; in use while anc_valid
+    bool anc_valid = false;
     const mi::TreeCull* tcull = nullptr;  // set by the fused hierarchy frame around its mi_propagate: the tile launches also cull
     int32_t tree_cull_mode = 0;           // mi_debug_set_tree_cull: 0 = fused where it applies and there is one view (default), 1 = never, 2 = whenever it applies
     int32_t tile_pretest_mode = 0;  // mi_debug_set_tile_pretest

@@ -16,6 +16,7 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
     ctx->marks_live = ctx->marks_in_cur = ctx->marks_complete = ctx->marks_other_cleared = false;
     if (!parent_idx || n_levels <= 1) {
         ctx->have_hierarchy = false;
+        ctx->anc_valid = false;
         ctx->n_levels = 1;
         ctx->level_offsets = {0, n};
         ctx->passes.clear();
@@ -222,7 +223,15 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
     ctx->level_offsets.assign(level_offsets, level_offsets + n_levels + 1);
     ctx->n_levels = n_levels;
     ctx->have_hierarchy = true;
-    return MI_OK;
+    // the ancestor table for mark_dirty_trees (kernels.h): level by level on the device, behind the parent_idx upload
+    ctx->anc_valid = false;
+    if (ensure(ctx, ctx->anc, (size_t)n * ANC_DEPTH * 4) == MI_OK) {
+        hipError_t e = hipSuccess;
+        for (uint32_t l = 0; l < n_levels && e == hipSuccess; ++l)
+            e = launch_build_ancestors((const uint32_t*)ctx->parent_idx.p, level_offsets[l], level_offsets[l + 1] - level_offsets[l], (uint32_t*)ctx->anc.p, ctx->stream);
+        ctx->anc_valid = e == hipSuccess;
+    }
+    return MI_OK;  // (without the table the marks climb along parent_idx)
 }
 
 // test / bench hook (not part of the public header): which tile kernel the NEXT mi_upload_hierarchy plans for

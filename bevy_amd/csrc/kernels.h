@@ -96,6 +96,37 @@ constexpr uint32_t ROWSUM_PART_AABB = 1u, ROWSUM_PART_FLAGS = 2u;
 // instead of a memset dispatch behind every propagate (>= 4.3 us on this part: a third of a change-driven frame); a real memset
 // remains for bulk marks and for the wrap at 255.
 __host__ __device__ inline bool row_changed(uint32_t byte, uint32_t gen) { return byte == 1u || byte == gen; }
+#ifdef __HIPCC__
+// mark_dirty_trees for one changed row (systems.rs:111-306): TransformTreeChanged on the row and on every ancestor.  With the
+// ancestor table (anc != nullptr, see ANC_DEPTH below) the ancestors come with one 64-byte load and the marks are independent
+// stores; without it, or from the table's last entry on in a very deep tree, a climb along parent_idx that stops at the first row
+// already marked (a stale test only lets two climbers repeat each other's stores).
+__device__ __forceinline__ void mark_row_and_ancestors(uint32_t row, const uint32_t* __restrict__ parent_idx, uint8_t* marks,
+                                                       const uint32_t* __restrict__ anc, uint32_t guard_n) {
+    if (anc) {
+        const uint4* src = reinterpret_cast<const uint4*>(anc + (size_t)row * 16u);
+        const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+        const uint32_t a[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+        marks[row] = 1;
+#pragma unroll
+        for (uint32_t k = 0; k < 16u; ++k)
+            if (a[k] != 0xFFFFFFFFu) marks[a[k]] = 1;
+        if (a[15] == 0xFFFFFFFFu) return;
+        row = a[15];  // deeper than the table: go on from its last entry (already marked: start at its parent)
+        const uint32_t p = parent_idx[row];
+        if (p == 0xFFFFFFFFu) return;
+        row = p;
+    }
+    for (uint32_t guard = 0; guard < guard_n; ++guard) {
+        const uint32_t p = parent_idx ? parent_idx[row] : 0xFFFFFFFFu;
+        const uint8_t seen = __builtin_nontemporal_load(&marks[row]);  // (not a cached copy of a line another CU is writing)
+        if (seen) break;
+        marks[row] = 1;
+        if (p == 0xFFFFFFFFu) break;
+        row = p;
+    }
+}
+#endif
 
 struct VisibilityOut {
     uint64_t* bitmask;        // base of per-view bitmasks
@@ -207,7 +238,7 @@ hipError_t launch_upload_trs(const float* pinned_src, float* t, float* r, float*
 hipError_t launch_upload_trs_indexed(const uint32_t* rows, const float* t_src, const float* r_src, const float* s_src, uint32_t n, float* t,
                                      float* r, float* s, uint8_t* changed, uint32_t changed_gen, hipStream_t stream,
                                      const uint32_t* parent_idx = nullptr, uint8_t* mark_bytes = nullptr, uint32_t* clear_words = nullptr,
-                                     uint32_t n_clear_words = 0);
+                                     uint32_t n_clear_words = 0, const uint32_t* anc = nullptr);
 hipError_t launch_popcount_words(const uint64_t* bits, uint32_t n_rows, uint8_t* cnt, hipStream_t stream);
 hipError_t launch_gather_global(const uint32_t* rows, const uint32_t* total, uint32_t capacity, const float* g, float* out,
                                 hipStream_t stream);
@@ -312,9 +343,15 @@ struct TileDesc {
     uint32_t count[TILE_MAX_LEVELS];
     uint32_t kind;
 };
+// The ancestor table: per row its first ANC_DEPTH ancestors, parent first, 0xFFFFFFFF-padded (64 bytes per row).  mark_dirty_trees is
+// a climb from every changed row to its root -- one dependent round trip per level when it follows parent_idx (eleven for a leaf of
+// the 1 M-node tree); with the table a row's ancestors arrive in ONE load and their marks go out as independent stores.  Built on
+// the device, a launch per level, when a hierarchy is uploaded; trees deeper than ANC_DEPTH + 1 levels go on climbing from the last entry.
+constexpr uint32_t ANC_DEPTH = 16;
+hipError_t launch_build_ancestors(const uint32_t* parent_idx, uint32_t start, uint32_t count, uint32_t* anc, hipStream_t stream);
 hipError_t launch_mark_dirty(uint32_t n, const uint8_t* changed, uint32_t changed_gen, const uint32_t* parent_idx, uint8_t* tree_bytes,
                              uint32_t* clear_words /* the other half, zeroed for the next frame; nullptr = none */, uint32_t n_clear_words,
-                             hipStream_t stream);
+                             hipStream_t stream, const uint32_t* anc = nullptr /* the ancestor table, or nullptr: climb along parent_idx */);
 // One launch over a group of mutually independent tiles (TileDesc::kind tells roots / chain / dependent apart).
 // The hierarchy FRAME in the tile launch itself (k_propagate_fans<true, true>): every tile also runs the visibility systems over
 // its own rows, GlobalTransforms still in registers / LDS.  A tile's rows are not aligned to the 64-row words of the per-view masks,

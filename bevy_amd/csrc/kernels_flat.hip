@@ -713,7 +713,8 @@ __global__ void __launch_bounds__(256) k_upload_trs_indexed(const uint32_t* __re
                                                              const float* __restrict__ fr, const float* __restrict__ fs, uint32_t n, float* t,
                                                              float* r, float* s, uint8_t* changed, uint32_t changed_gen,
                                                              const uint32_t* __restrict__ parent_idx, uint8_t* mark_bytes,
-                                                             uint32_t* __restrict__ clear_words, uint32_t n_clear_words) {
+                                                             uint32_t* __restrict__ clear_words, uint32_t n_clear_words,
+                                                             const uint32_t* __restrict__ anc) {
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     if (clear_words)
         for (uint32_t w = gid; w < n_clear_words; w += gridDim.x * 256u) clear_words[w] = 0u;
@@ -727,21 +728,12 @@ __global__ void __launch_bounds__(256) k_upload_trs_indexed(const uint32_t* __re
 #pragma unroll
         for (uint32_t k = 0; k < 4u; ++k) r[4ull * row + k] = fr[4ull * i + k];
         changed[row] = (uint8_t)changed_gen;  // a stamp, not a flag: see row_changed() in kernels.h
-        if (mark_bytes) {
-            for (uint32_t guard = 0; guard < 0xFFFFu; ++guard) {  // (a hierarchy is at most 65 535 levels deep here)
-                const uint32_t p = parent_idx[row];
-                const uint8_t seen = __builtin_nontemporal_load(&mark_bytes[row]);
-                if (seen) break;
-                mark_bytes[row] = 1;
-                if (p == 0xFFFFFFFFu) break;
-                row = p;
-            }
-        }
+        if (mark_bytes) mark_row_and_ancestors(row, parent_idx, mark_bytes, anc, 0xFFFFu);  // (a hierarchy is at most 65 535 levels deep here)
     }
 }
 hipError_t launch_upload_trs_indexed(const uint32_t* rows, const float* t_src, const float* r_src, const float* s_src, uint32_t n, float* t,
                                      float* r, float* s, uint8_t* changed, uint32_t changed_gen, hipStream_t stream, const uint32_t* parent_idx,
-                                     uint8_t* mark_bytes, uint32_t* clear_words, uint32_t n_clear_words) {
+                                     uint8_t* mark_bytes, uint32_t* clear_words, uint32_t n_clear_words, const uint32_t* anc) {
     if (n == 0) return hipSuccess;
     // the sources are pinned host memory read over PCIe: enough lanes to keep the link busy, not one workgroup per 256 rows of a
     // million-row upload; and enough workgroups for the words to clear
@@ -751,7 +743,7 @@ hipError_t launch_upload_trs_indexed(const uint32_t* rows, const float* t_src, c
         blocks = blocks > cb ? blocks : cb;
     }
     MI_LAUNCH(k_upload_trs_indexed, dim3(blocks), dim3(256), 0, stream, rows, t_src, r_src, s_src, n, t, r, s, changed, changed_gen, parent_idx,
-              mark_bytes, clear_words, n_clear_words);
+              mark_bytes, clear_words, n_clear_words, mark_bytes ? anc : nullptr);
     return hipGetLastError();
 }
 

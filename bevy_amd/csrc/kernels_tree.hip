@@ -115,22 +115,41 @@ __device__ __forceinline__ Affine sel(bool k, const Affine& a, const Affine& b) 
 // only repeat each other's stores; whoever sees a mark stops, and the one who set it goes on, so every ancestor gets marked.
 // A step is ONE round trip (the parent's index and the mark are requested together).  The launch also zeroes the OTHER half of
 // the double-buffered marks for the next frame (clear_words), which saves a launch per frame.
+// anc[row] = (parent, anc[parent][0 .. ANC_DEPTH - 2]) for the rows of one level; the level above is complete (an earlier launch)
+__global__ void __launch_bounds__(256) k_build_ancestors(const uint32_t* __restrict__ parent_idx, uint32_t start, uint32_t count, uint32_t* anc) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t row = start + i, p = parent_idx[row];
+    uint4 d0 = make_uint4(p, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu), d1 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu), d2 = d1, d3 = d1;
+    if (p != 0xFFFFFFFFu) {
+        const uint4* src = reinterpret_cast<const uint4*>(anc + (size_t)p * ANC_DEPTH);
+        const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+        d0 = make_uint4(p, q0.x, q0.y, q0.z);
+        d1 = make_uint4(q0.w, q1.x, q1.y, q1.z);
+        d2 = make_uint4(q1.w, q2.x, q2.y, q2.z);
+        d3 = make_uint4(q2.w, q3.x, q3.y, q3.z);
+    }
+    uint4* dst = reinterpret_cast<uint4*>(anc + (size_t)row * ANC_DEPTH);
+    dst[0] = d0;
+    dst[1] = d1;
+    dst[2] = d2;
+    dst[3] = d3;
+}
+hipError_t launch_build_ancestors(const uint32_t* parent_idx, uint32_t start, uint32_t count, uint32_t* anc, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    MI_LAUNCH(k_build_ancestors, dim3((count + 255u) / 256u), dim3(256), 0, stream, parent_idx, start, count, anc);
+    return hipGetLastError();
+}
+
 __global__ void __launch_bounds__(256) k_mark_dirty(uint32_t n, const uint8_t* __restrict__ changed, uint32_t changed_gen,
                                                      const uint32_t* __restrict__ parent_idx, uint8_t* tree_bytes,
-                                                     uint32_t* __restrict__ clear_words, uint32_t n_clear_words) {
+                                                     uint32_t* __restrict__ clear_words, uint32_t n_clear_words, const uint32_t* __restrict__ anc) {
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     if (clear_words)
         for (uint32_t w = gid; w < n_clear_words; w += gridDim.x * 256u) clear_words[w] = 0u;
-    uint32_t row = gid;
+    const uint32_t row = gid;
     if (row >= n || !row_changed(changed[row], changed_gen)) return;
-    for (uint32_t guard = 0; guard < n; ++guard) {
-        const uint32_t p = parent_idx ? parent_idx[row] : 0xFFFFFFFFu;
-        const uint8_t seen = __builtin_nontemporal_load(&tree_bytes[row]);  // (not a cached copy of a line another CU is writing)
-        if (seen) break;
-        tree_bytes[row] = 1;
-        if (p == 0xFFFFFFFFu) break;
-        row = p;
-    }
+    mark_row_and_ancestors(row, parent_idx, tree_bytes, parent_idx ? anc : nullptr, n);
 }
 
 // A tile's descriptor, fetched whole with scalar loads at the top of the kernel (two s_load for the 72 bytes).  Left to
@@ -1319,9 +1338,9 @@ hipError_t launch_propagate_level(const Columns& c, const uint32_t* parent_idx, 
 }
 
 hipError_t launch_mark_dirty(uint32_t n, const uint8_t* changed, uint32_t changed_gen, const uint32_t* parent_idx, uint8_t* tree_bytes,
-                             uint32_t* clear_words, uint32_t n_clear_words, hipStream_t stream) {
+                             uint32_t* clear_words, uint32_t n_clear_words, hipStream_t stream, const uint32_t* anc) {
     if (n == 0) return hipSuccess;
-    MI_LAUNCH(k_mark_dirty, dim3((n + 255u) / 256u), dim3(256), 0, stream, n, changed, changed_gen, parent_idx, tree_bytes, clear_words, n_clear_words);
+    MI_LAUNCH(k_mark_dirty, dim3((n + 255u) / 256u), dim3(256), 0, stream, n, changed, changed_gen, parent_idx, tree_bytes, clear_words, n_clear_words, anc);
     return hipGetLastError();
 }
 

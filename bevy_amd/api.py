@@ -204,7 +204,7 @@ ABI_SYMBOLS = [
 # include/bevy_mi355x_debug.h: instrumentation and test hooks, exported by the same library, not part of the boundary
 DEBUG_SYMBOLS = [
     "mi_timer_begin", "mi_timer_end", "mi_profile_enable", "mi_profile_filter", "mi_profile_sample", "mi_profile_burst", "mi_profile_read",
-    "mi_profile_kernel_name", "mi_debug_set_tile_mode", "mi_debug_tree_trace", "mi_debug_tile_plan", "mi_debug_logf", "mi_debug_set_sphere_path", "mi_debug_set_row_summary", "mi_debug_set_tree_cull", "mi_debug_set_walk_inrow", "mi_debug_set_tile_pretest", "mi_debug_set_sorted_one_wg_limit",
+    "mi_profile_kernel_name", "mi_debug_set_tile_mode", "mi_debug_tree_trace", "mi_debug_tile_plan", "mi_debug_logf", "mi_debug_set_sphere_path", "mi_debug_set_row_summary", "mi_debug_set_tree_cull", "mi_debug_set_walk_inrow", "mi_debug_set_chunked_frames", "mi_debug_chunked_counts", "mi_debug_set_tile_pretest", "mi_debug_set_sorted_one_wg_limit",
 ]
 
 
@@ -375,6 +375,8 @@ class Context:
             self.debug_set_sorted_one_wg_limit(0)
         if os.environ.get("MI_TEST_TILE_PRETEST"):
             self.debug_set_tile_pretest(int(os.environ["MI_TEST_TILE_PRETEST"]))
+        if os.environ.get("MI_TEST_CHUNKED_FRAMES"):  # ... or with all-dirty end-to-end frames in one piece (1)
+            self.debug_set_chunked_frames(int(os.environ["MI_TEST_CHUNKED_FRAMES"]))
         if os.environ.get("MI_TEST_WALK_INROW"):  # ... or with the riding cluster walk in workgroups of its own (1)
             self.debug_set_walk_inrow(int(os.environ["MI_TEST_WALK_INROW"]))
         if os.environ.get("MI_TEST_TREE_CULL"):  # ... or with the all-dirty hierarchy frame fused into the tile launches (2)
@@ -859,6 +861,16 @@ class Context:
     def debug_set_tile_pretest(self, mode):
         """0 = the light tiles test their flags first when few rows changed (default), 1 = never, 2 = always (test / bench hook)."""
         self._ck(self._lib.mi_debug_set_tile_pretest(self._h, int(mode)))
+
+    def debug_set_chunked_frames(self, mode):
+        """0 = a dense upload of the whole Transform table, the all-rows frame and its result download run in overlapping pieces from 262144 rows (default), 1 = never, 2 = at any row count."""
+        self._ck(self._lib.mi_debug_set_chunked_frames(self._h, int(mode)))
+
+    def debug_chunked_counts(self):
+        """(frames that ran in pieces, result downloads that delivered GlobalTransforms fetched in pieces)."""
+        a, b = C.c_uint32(0), C.c_uint32(0)
+        self._ck(self._lib.mi_debug_chunked_counts(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def debug_set_walk_inrow(self, mode):
         """0 = objects bound to a row range are walked by the frame kernel's own row workgroups (default), 1 = by extra workgroups."""

@@ -114,6 +114,36 @@ int32_t consume_changed(mi_ctx* ctx) {
     return MI_OK;
 }
 
+int32_t chunks_join(mi_ctx* ctx) {
+    if (ctx->dense_pending) {
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_up[mi_ctx::FRAME_CHUNKS - 1], 0));
+        ctx->dense_pending = false;
+    }
+    if (ctx->frame_chunked) {  // (its pieces all ran on the context's stream: nothing to wait for, only to forget)
+        ctx->frame_chunked = false;
+    }
+    return MI_OK;
+}
+static int32_t chunk_streams(mi_ctx* ctx) {
+    if (ctx->chunk_events) return MI_OK;
+    // HIP streams share a few hardware queues per priority class, and a queue runs its barrier packets (event waits and records)
+    // in order: when the upload stream landed on the queue of the context's stream -- or of the download stream -- every wait
+    // queued behind its eight event records stood until the whole upload was in (measured: the first GlobalTransform piece left
+    // when the last Transform piece had arrived, profiles/r03_experiments.md 12).  A priority class of its own gives each of the
+    // two a queue no stream of the context shares; the download stream additionally carries no waits at all (its copies are issued
+    // by the host as each piece's frame event completes, mi_download_frame_results).
+    int prio_lo = 0, prio_hi = 0;
+    HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->up_stream, hipStreamNonBlocking, prio_hi));
+    HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->dn_stream, hipStreamNonBlocking, prio_lo));
+    for (uint32_t k = 0; k < mi_ctx::FRAME_CHUNKS; ++k) {
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_up[k], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_frame[k], hipEventDisableTiming));
+    }
+    ctx->chunk_events = true;
+    return MI_OK;
+}
+
 int32_t check_rows(mi_ctx* ctx, uint32_t first, uint32_t n, const char* what) {
     if ((uint64_t)first + n > ctx->n) return fail(ctx, MI_ERR_INVALID_ARG, "%s: rows [%u,%u) exceed %u live rows", what, first, first + n, ctx->n);
     return MI_OK;
@@ -520,7 +550,35 @@ static int32_t cull_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, u
         }
         ProfScope ps(ctx, PROPAGATE ? K_FLAT_PROPAGATE_CULL : K_CULL);
         const bool stale_from_mask = use_sph && ctx->sph_state == mi_ctx::SPH_EXCEPT_CHANGED;
-        const hipError_t e = use_sph ? launch_frame_sph(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p, n_views, vo, seg,
+        const bool chunked = PROPAGATE && !changed_col && ctx->dense_pending && !use_sph;
+        if (ctx->dense_pending && !chunked) {  // (a frame of another kind: behind the whole upload)
+            const int32_t rcj = chunks_join(ctx);
+            if (rcj) return frame_abort(ctx, rcj, prev, prev_has_job, prev_job);
+        }
+        hipError_t e = hipSuccess;
+        if (chunked) {
+            // The Transforms are still arriving, piece by piece (mi_commit_upload_window): the frame runs piece by piece behind them
+            // -- each launch covers the tiles of one piece and records an event the result download starts from.  Riders that read
+            // nothing of the upload (the previous frame's compaction and cluster fill) go with the first piece; a cluster walk in
+            // workgroups of its own re-derives the lights' rows from their Transforms, so it goes with the last; the walk inside
+            // the rows' own workgroups goes wherever those rows are.
+            for (uint32_t k = 0; k < mi_ctx::FRAME_CHUNKS && e == hipSuccess; ++k) {
+                const uint32_t t_lo = ctx->chunk_lo[k] / 256u, t_hi = (ctx->chunk_lo[k + 1] + 255u) / 256u;
+                const bool first = k == 0, last = k + 1 == mi_ctx::FRAME_CHUNKS;
+                if (hipStreamWaitEvent(ctx->stream, ctx->ev_up[k], 0) != hipSuccess) { e = hipErrorUnknown; break; }
+                const ClusterWalkJob* wk = clusters_ride && (walk_job.inrow || last) ? &walk_job : nullptr;
+                if (t_hi > t_lo)
+                    e = launch_flat_propagate_cull(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p, n_views, vo, seg,
+                                                   flags & MI_CULL_END_FRAME, first ? prev : nullptr, first && have_fill ? &fill_job : nullptr, wk, ctx->stream,
+                                                   nullptr, t_lo, t_hi - t_lo);
+                if (e == hipSuccess && hipEventRecord(ctx->ev_frame[k], ctx->stream) != hipSuccess) e = hipErrorUnknown;
+            }
+            ctx->dense_pending = false;
+            ctx->frame_chunked = e == hipSuccess;
+            ctx->n_chunked_frames += e == hipSuccess;
+            if (e != hipSuccess) hipStreamWaitEvent(ctx->stream, ctx->ev_up[mi_ctx::FRAME_CHUNKS - 1], 0);  // (whatever follows: behind the whole upload)
+        } else
+        e = use_sph ? launch_frame_sph(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p, n_views, vo, seg,
                                                         (flags & (MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME)) | (PROPAGATE ? CULL_BEGIN_FRAME : 0u), prev,
                                                         have_fill ? &fill_job : nullptr, clusters_ride ? &walk_job : nullptr, ctx->stream, changed_col,
                                                         (float*)ctx->sph.p, stale_from_mask && !ctx->g_chg_in_bytes ? ctx->g_chg_bits : nullptr,
@@ -637,6 +695,18 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
         hipEventDestroy(ctx->ev_cl_done);
         hipEventDestroy(ctx->ev_cl_inputs);
         hipStreamDestroy(ctx->cl_stream);
+    }
+    if (ctx->g_host) hipHostFree(ctx->g_host);
+    if (ctx->iota_host) hipHostFree(ctx->iota_host);
+    if (ctx->chunk_events) {
+        hipStreamSynchronize(ctx->up_stream);
+        hipStreamSynchronize(ctx->dn_stream);
+        for (uint32_t k = 0; k < mi_ctx::FRAME_CHUNKS; ++k) {
+            hipEventDestroy(ctx->ev_up[k]);
+            hipEventDestroy(ctx->ev_frame[k]);
+        }
+        hipStreamDestroy(ctx->up_stream);
+        hipStreamDestroy(ctx->dn_stream);
     }
     prof_collect(ctx);
     void* cols[] = {ctx->t, ctx->r, ctx->s, ctx->g, ctx->c, ctx->h, ctx->flags, ctx->vv, ctx->changed, ctx->g_changed_bytes,
@@ -930,7 +1000,7 @@ int32_t mi_upload_transforms_indexed(mi_ctx* ctx, uint32_t n, const uint32_t* ro
 
 // ---- upload windows: the caller fills pinned memory in place ------------------------------------------------------------------
 int32_t mi_map_upload_window(mi_ctx* ctx, uint32_t capacity, uint32_t flags, mi_upload_window* out) {
-    ENTER(ctx);
+    ENTER_RAW(ctx);  // (host memory only)
     if (!out) return fail(ctx, MI_ERR_INVALID_ARG, "mi_map_upload_window: NULL");
     memset(out, 0, sizeof *out);
     out->flags = flags;
@@ -994,6 +1064,30 @@ int32_t mi_commit_upload_window(mi_ctx* ctx, const mi_upload_window* w, uint32_t
         if (rc) return rc;
         if ((rc = cluster_join(ctx))) return rc;
         ctx->cl_inputs_dirty = true;
+        if (ctx->chunk_mode != 1 && first_row == 0 && n == ctx->n && n >= (ctx->chunk_mode == 2 ? 1u : 262144u) && !ctx->have_hierarchy && !ctx->xch.on) {
+            // The whole table: FRAME_CHUNKS pieces on a stream of their own, an event behind each.  The all-rows frame that
+            // (usually) follows runs piece by piece behind them, and its results start back while the later pieces still arrive.
+            if ((rc = chunk_streams(ctx))) return rc;
+            // Whatever still reads the columns on the context's stream comes first -- waited for by the host, not by the upload
+            // stream: with an event wait in front of them the runtime sent the upload stream's copies through the DMA engine the
+            // download stream uses, and the two directions took turns (2.15 ms against 1.35 for the same pattern with this wait
+            // on the host, profiles/r03_experiments.md 12).  The stream is idle here in a loop of frames: the results of the
+            // frame before have been delivered.
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            const uint32_t tiles = (n + 255u) / 256u;
+            for (uint32_t k = 0; k <= mi_ctx::FRAME_CHUNKS; ++k) ctx->chunk_lo[k] = (uint32_t)std::min<uint64_t>(n, ((uint64_t)tiles * k / mi_ctx::FRAME_CHUNKS) * 256u);
+            for (uint32_t k = 0; k < mi_ctx::FRAME_CHUNKS; ++k) {
+                const size_t lo = ctx->chunk_lo[k], cnt = ctx->chunk_lo[k + 1] - lo;
+                if (cnt) {
+                    HIP_TRY(ctx, hipMemcpyAsync(ctx->t + 3 * lo, w->translation + 3 * lo, cnt * 12, hipMemcpyHostToDevice, ctx->up_stream));
+                    HIP_TRY(ctx, hipMemcpyAsync(ctx->r + 4 * lo, w->rotation + 4 * lo, cnt * 16, hipMemcpyHostToDevice, ctx->up_stream));
+                    HIP_TRY(ctx, hipMemcpyAsync(ctx->s + 3 * lo, w->scale + 3 * lo, cnt * 12, hipMemcpyHostToDevice, ctx->up_stream));
+                }
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_up[k], ctx->up_stream));
+            }
+            ctx->dense_pending = true;
+            return MI_OK;
+        }
         // pinned -> device: three DMA copies straight from the window (no staging copy)
         HIP_TRY(ctx, hipMemcpyAsync(ctx->t + 3 * (size_t)first_row, w->translation, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->r + 4 * (size_t)first_row, w->rotation, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
@@ -1380,7 +1474,12 @@ static int32_t tree_frame_fused(mi_ctx* ctx, const mi_view* views, uint32_t n_vi
 }
 
 int32_t mi_propagate_and_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint32_t flags) {
-    ENTER(ctx);
+    ENTER_RAW(ctx);  // (cull_frame<true> runs behind a chunked upload piece by piece; every other way out of here joins it first)
+    ctx->frame_chunked = false;
+    if (ctx->dense_pending && (ctx->have_hierarchy || (flags & MI_CULL_CHANGED_ROWS) || !views || n_views == 0)) {
+        const int32_t rcj = chunks_join(ctx);
+        if (rcj) return rcj;
+    }
     if (ctx->have_hierarchy && views && n_views && tree_frame_fusable(ctx, n_views, flags)) return tree_frame_fused(ctx, views, n_views, flags);
     if (ctx->have_hierarchy) {
         // With a hierarchy the frame is the tile launches of mi_propagate with the cull behind them: the same call for the
@@ -1563,7 +1662,13 @@ struct BatchedDownload {
 }  // namespace
 
 int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
-    ENTER(ctx);
+    ENTER_RAW(ctx);  // (a frame that ran in pieces: its GlobalTransforms start back piece by piece, below)
+    if (ctx->dense_pending) {
+        const int32_t rcj = chunks_join(ctx);
+        if (rcj) return rcj;
+    }
+    const bool frame_was_chunked = ctx->frame_chunked;
+    ctx->frame_chunked = false;
     if (!io) return fail(ctx, MI_ERR_INVALID_ARG, "mi_download_frame_results: NULL");
     io->changed_count = 0;
     io->cluster_total = 0;
@@ -1590,6 +1695,26 @@ int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
         for (uint32_t l = 0; l < n_lists; ++l) io->lists[l].rows = nullptr;
     }
     int32_t rc;
+    // ---- a frame that ran in pieces (every row propagated: every GlobalTransform changed): the column starts back piece by piece,
+    // each copy behind its piece's kernel, on a stream of its own -- under the pieces of the upload that are still arriving ----
+    void* g_prefetched = nullptr;
+    if (frame_was_chunked && want_g && ctx->n && io->changed_capacity >= ctx->n && ctx->chunk_events) {
+        // (into pinned memory of their own, not the arena: the arena is sized -- and may wrap, with a wait for the context's stream --
+        // further down, and neither may happen under or in front of these copies)
+        if (ctx->g_host_bytes < (size_t)ctx->n * 48) {
+            if (ctx->g_host) HIP_TRY(ctx, hipHostFree(ctx->g_host));
+            ctx->g_host = nullptr;
+            ctx->g_host_bytes = 0;
+            HIP_TRY(ctx, hipHostMalloc(&ctx->g_host, (size_t)ctx->cap * 48, hipHostMallocDefault));
+            ctx->g_host_bytes = (size_t)ctx->cap * 48;
+        }
+        g_prefetched = ctx->g_host;
+        for (uint32_t k = 0; k < mi_ctx::FRAME_CHUNKS; ++k) {
+            const size_t lo = ctx->chunk_lo[k], cnt = ctx->chunk_lo[k + 1] - lo;
+            HIP_TRY(ctx, hipEventSynchronize(ctx->ev_frame[k]));  // (by the host, not by the stream: see chunk_streams)
+            if (cnt) HIP_TRY(ctx, hipMemcpyAsync((char*)g_prefetched + lo * 48, ctx->g + 12 * lo, cnt * 48, hipMemcpyDeviceToHost, ctx->dn_stream));
+        }
+    }
     // ---- everything that has to run before the counts are final ----
     const uint32_t* list_total[PACK_MAX_LISTS] = {nullptr};
     const uint32_t* list_rows[PACK_MAX_LISTS] = {nullptr};
@@ -1710,8 +1835,26 @@ int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
             if (by_dma) {  // a second wait, negligible next to megabytes over PCIe
                 BatchedDownload b;
                 b.in_place = in_place;
-                if (want_rows && (rc = b.add(ctx, io->changed_rows, ctx->sparse_rows.p, (size_t)changed * 4, in_place ? (void**)&io->changed_rows : nullptr))) return rc;
-                if (want_g) {
+                if (want_rows && changed == ctx->n) {
+                    // every row changed: the list (ascending, as compacted from the mask) is 0 .. n-1 -- kept on the host, nothing to fetch
+                    if (ctx->iota_rows < changed) {
+                        if (ctx->iota_host) HIP_TRY(ctx, hipHostFree(ctx->iota_host));
+                        ctx->iota_host = nullptr;
+                        ctx->iota_rows = 0;
+                        HIP_TRY(ctx, hipHostMalloc((void**)&ctx->iota_host, (size_t)ctx->cap * 4, hipHostMallocDefault));
+                        ctx->iota_rows = ctx->cap;
+                        for (uint32_t i = 0; i < ctx->cap; ++i) ctx->iota_host[i] = i;
+                    }
+                    if (in_place) io->changed_rows = ctx->iota_host;
+                    else memcpy(io->changed_rows, ctx->iota_host, (size_t)changed * 4);
+                } else if (want_rows && (rc = b.add(ctx, io->changed_rows, ctx->sparse_rows.p, (size_t)changed * 4, in_place ? (void**)&io->changed_rows : nullptr))) return rc;
+                if (want_g && g_prefetched && changed == ctx->n) {  // already on its way (above): parked in the arena like any other piece
+                    HIP_TRY(ctx, hipStreamSynchronize(ctx->dn_stream));
+                    b.pieces.push_back({in_place ? nullptr : (void*)io->changed_global12, g_prefetched, (size_t)changed * 48});
+                    if (in_place) io->changed_global12 = (float*)g_prefetched;
+                    ++ctx->n_chunked_downloads;
+                    g_prefetched = nullptr;
+                } else if (want_g) {
                     const bool all_rows = changed == ctx->n;  // every row changed: the list is 0 .. n-1 and the column itself is the answer
                     if (!all_rows) {
                         if ((rc = ensure(ctx, ctx->sparse_g, (size_t)changed * 48))) return rc;
@@ -1724,12 +1867,14 @@ int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
                 }
                 if ((rc = b.finish(ctx))) return rc;
             }
+            if (g_prefetched) HIP_TRY(ctx, hipStreamSynchronize(ctx->dn_stream));  // (fetched for nothing: fewer rows changed than the frame propagated)
             return cap_rc;
         }
         changed = 0;
         cl_total = 0;
     }
     // ---- the packed window was too small (or the cluster list outgrew its device buffer): wait 1, the counts and every fixed-size array ----
+    if (g_prefetched) HIP_TRY(ctx, hipStreamSynchronize(ctx->dn_stream));  // (not used on this path: only let it land)
     BatchedDownload b;
     b.in_place = in_place;
     uint32_t list_count[PACK_MAX_LISTS] = {0};
@@ -1988,6 +2133,23 @@ int32_t mi_debug_set_tile_pretest(mi_ctx* ctx, int32_t mode) {
     ENTER(ctx);
     if (mode < 0 || mode > 2) return fail(ctx, MI_ERR_INVALID_ARG, "mi_debug_set_tile_pretest: mode %d", mode);
     ctx->tile_pretest_mode = mode;
+    return MI_OK;
+}
+
+// test / bench hook: a dense upload of the whole Transform table, the all-rows frame behind it and its result download in pieces
+// that overlap (FRAME_CHUNKS, ctx.h): 0 = yes, from 262144 rows (default), 1 = never, 2 = at any size (tests)
+int32_t mi_debug_set_chunked_frames(mi_ctx* ctx, int32_t mode) {
+    ENTER(ctx);
+    if (mode < 0 || mode > 2) return fail(ctx, MI_ERR_INVALID_ARG, "mi_debug_set_chunked_frames: mode %d", mode);
+    ctx->chunk_mode = mode;
+    return MI_OK;
+}
+
+// test hook: how many frames ran in pieces behind a dense upload, and how many result downloads delivered GlobalTransforms fetched in pieces
+int32_t mi_debug_chunked_counts(mi_ctx* ctx, uint32_t* out_frames, uint32_t* out_downloads) {
+    ENTER_RAW(ctx);
+    if (out_frames) *out_frames = ctx->n_chunked_frames;
+    if (out_downloads) *out_downloads = ctx->n_chunked_downloads;
     return MI_OK;
 }
 

@@ -213,7 +213,10 @@ struct CompactFastArgs {
 hipError_t launch_flat_propagate_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views,
                                       uint32_t n_views, const VisibilityOut& out, const SegOut& seg, uint32_t flags,
                                       const CompactFastArgs* prev, const struct ClusterFillJob* fill, const struct ClusterWalkJob* walk,
-                                      hipStream_t stream, const uint8_t* changed = nullptr /* set: only rows with a nonzero byte are propagated */);
+                                      hipStream_t stream, const uint8_t* changed = nullptr /* set: only rows with a nonzero byte are propagated */,
+                                      uint32_t tile_base = 0xFFFFFFFFu /* FRAME_ALL_TILES, or the first 256-row tile of a chunk ... */,
+                                      uint32_t chunk_tiles = 0 /* ... of this many tiles (all-rows frames only) */);
+constexpr uint32_t FRAME_ALL_TILES = 0xFFFFFFFFu;
 // Level 0 of the hierarchy (roots + flat rows).  node_flags: bit0 = has children (nullptr = none do).
 // changed: per-row Changed<Transform>|... byte (nullptr or all_dirty => every row recomputed).
 // tree_bytes: TransformTreeChanged, a byte per row (only read when static_opt).

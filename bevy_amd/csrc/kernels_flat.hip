@@ -251,7 +251,10 @@ template <int PROP, bool INLINE_VIEWS, bool WITH_WALK>
 __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const ViewParams* __restrict__ dviews,
                                                 uint32_t n_views, VisibilityOut out, SegOut seg, uint32_t fl_frame, uint32_t n_tiles,
                                                 CompactFastArgs prev, uint32_t prev_gx, uint32_t n_compact, uint32_t n_fill, ClusterFillJob fill,
-                                                ClusterWalkJob walk, const uint8_t* __restrict__ changed) {
+                                                ClusterWalkJob walk, const uint8_t* __restrict__ changed, uint32_t tile_base) {
+    // tile_base: FRAME_ALL_TILES = the launch covers every tile (n_tiles of them); else a CHUNK of the frame, tiles tile_base ..
+    // tile_base + n_tiles - 1 -- an all-dirty frame whose Transforms are still arriving over PCIe runs chunk by chunk, each behind
+    // its own part of the upload (cull_frame, context.cpp)
     constexpr bool PROPAGATE = PROP == 1, PARTIAL = PROP == 2;
     // 16 KB + 16 B: the four waves' GlobalTransform transpose buffers (12 KB) -- or, in a riding cluster-fill workgroup, the CSR
     // offsets of up to 4096 clusters and the four wave totals of their scan -- or the arena of a riding cluster-walk workgroup
@@ -265,7 +268,9 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
     MI_TIMELINE(3);
     const uint32_t n_extra = gridDim.x - n_tiles;
     uint32_t tile = blockIdx.x - n_extra;
-    if constexpr (WITH_WALK) {  // the tiles that go on into the cluster walk are handed out first (they run longest)
+    if (tile_base != FRAME_ALL_TILES) {
+        tile += tile_base;
+    } else if constexpr (WITH_WALK) {  // the tiles that go on into the cluster walk are handed out first (they run longest)
         if (walk.inrow) {
             tile += walk.tile0;
             if (tile >= n_tiles) tile -= n_tiles;
@@ -918,10 +923,12 @@ hipError_t launch_upload_trs(const float* pinned_src, float* t, float* r, float*
 template <int PROP>
 static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views,
                                const VisibilityOut& out, const SegOut& seg, uint32_t flags, const CompactFastArgs* prev,
-                               const ClusterFillJob* fill, const ClusterWalkJob* walk, hipStream_t stream, const uint8_t* changed = nullptr) {
+                               const ClusterFillJob* fill, const ClusterWalkJob* walk, hipStream_t stream, const uint8_t* changed = nullptr,
+                               uint32_t tile_base = FRAME_ALL_TILES, uint32_t chunk_tiles = 0) {
     if (c.n == 0) return hipSuccess;
     if (!c.row_summary) return hipErrorInvalidValue;  // (the kernel loads it unconditionally: row_summary_ensure comes first)
-    const uint32_t n_tiles = blocks_for(c.n);
+    const uint32_t n_tiles = tile_base == FRAME_ALL_TILES ? blocks_for(c.n) : chunk_tiles;
+    if (n_tiles == 0) return hipSuccess;
     CompactFastArgs pa{};
     uint32_t prev_gx = 1, prev_blocks = 0;
     if (prev && prev->n && prev->n_segments) {
@@ -946,14 +953,14 @@ static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, co
     const dim3 grid(n_tiles + prev_blocks + fill_blocks + walk_blocks);
     if (with_walk) {
         MI_LAUNCH((k_frame<PROP, true, true>), grid, dim3(256), 0, stream, c, *views_inline, (const ViewParams*)nullptr, n_views, out, seg, flags,
-                  n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed);
+                  n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed, tile_base);
     } else if (n_views <= MAX_INLINE_VIEWS && views_inline) {
         MI_LAUNCH((k_frame<PROP, true, false>), grid, dim3(256), 0, stream, c, *views_inline, (const ViewParams*)nullptr, n_views, out, seg, flags,
-                  n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed);
+                  n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed, tile_base);
     } else {
         ViewSet dummy = {};
         MI_LAUNCH((k_frame<PROP, false, false>), grid, dim3(256), 0, stream, c, dummy, d_views, n_views, out, seg, flags, n_tiles, pa, prev_gx,
-                  prev_blocks, fill_blocks, fj, wj, changed);
+                  prev_blocks, fill_blocks, fj, wj, changed, tile_base);
     }
     return hipGetLastError();
 }
@@ -1010,9 +1017,9 @@ hipError_t launch_frame_sph(const Columns& c, const ViewSet* views_inline, const
 hipError_t launch_flat_propagate_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views,
                                       uint32_t n_views, const VisibilityOut& out, const SegOut& seg, uint32_t flags,
                                       const CompactFastArgs* prev, const ClusterFillJob* fill, const ClusterWalkJob* walk, hipStream_t stream,
-                                      const uint8_t* changed) {
+                                      const uint8_t* changed, uint32_t tile_base, uint32_t chunk_tiles) {
     if (changed) return launch_frame<2>(c, views_inline, d_views, n_views, out, seg, flags | CULL_BEGIN_FRAME, prev, fill, walk, stream, changed);
-    return launch_frame<1>(c, views_inline, d_views, n_views, out, seg, flags | CULL_BEGIN_FRAME, prev, fill, walk, stream);
+    return launch_frame<1>(c, views_inline, d_views, n_views, out, seg, flags | CULL_BEGIN_FRAME, prev, fill, walk, stream, nullptr, tile_base, chunk_tiles);
 }
 hipError_t launch_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views,
                        const VisibilityOut& out, const SegOut& seg, uint32_t flags, const CompactFastArgs* prev,

@@ -429,10 +429,8 @@ class Mi355xPlugin {
         }
         const auto t_gathered = std::chrono::steady_clock::now();
         check(mi_commit_upload_window(ctx_, &win, n_in, 0));
-        if (dense) {  // (the dense form raises no change bytes: every row counts as changed)
-            scratch_ones_.assign(n, 1);
-            check(mi_upload_changed(ctx_, 0, n, scratch_ones_.data()));
-        }
+        // (every row moved: the frame below is the all-rows frame -- no change bytes to raise, and nothing between the upload and the
+        // frame that would have to wait for it: the library then runs upload, frame and result download in overlapping pieces)
         if (n_in == 0) {  // keep "nothing changed" distinct from "no change information" (= all dirty)
             const uint8_t zero = 0;
             check(mi_upload_changed(ctx_, 0, 1, &zero));
@@ -456,7 +454,7 @@ class Mi355xPlugin {
         // ---- run: one call
         const uint32_t static_opt = w.static_transform_optimizations ? 1u : 0u;
         if (views.empty()) {
-            check(mi_propagate(ctx_, static_opt ? MI_PROPAGATE_STATIC_OPT : 0u));
+            check(mi_propagate(ctx_, (dense && n ? MI_PROPAGATE_ALL_DIRTY : 0u) | (static_opt ? MI_PROPAGATE_STATIC_OPT : 0u)));
         } else {
             mviews_.resize(views.size());
             for (size_t v = 0; v < views.size(); ++v) {
@@ -465,7 +463,7 @@ class Mi355xPlugin {
                 mviews_[v].layer_mask = views[v].layer_mask;
             }
             check(mi_propagate_and_cull_views(ctx_, mviews_.data(), (uint32_t)mviews_.size(),
-                                              MI_CULL_CHANGED_ROWS | MI_CULL_END_FRAME | (static_opt ? MI_CULL_STATIC_OPT : 0u) |
+                                              (dense && n ? 0u : MI_CULL_CHANGED_ROWS) | MI_CULL_END_FRAME | (static_opt ? MI_CULL_STATIC_OPT : 0u) |
                                                   (with_clusters ? MI_CULL_WITH_CLUSTERS : 0u)));
         }
         // ---- out: one call, one wait, read in place

@@ -510,7 +510,13 @@ int32_t mi_cluster_download(mi_ctx* ctx, uint32_t* out_offsets, uint32_t* out_in
  *   MI_RESULTS_CLUSTERS / _CLUSTER_INDICES  offsets + counts / the index list of the resident assignment (mi_cluster_download)
  * Without MI_RESULTS_IN_PLACE the caller passes buffers and capacities and the library copies out of the window.  With it the
  * library SETS the pointers to the data where it lies in the pinned window -- no copy; the caller reads it in place (e.g. while
- * writing the ECS components) and must be done before its next call on this context.  Capacities still bound what is fetched.
+ * writing the ECS components), must not write to it, and must be done before its next call on this context.  Capacities still bound
+ * what is fetched.
+ * When every row's GlobalTransform changed -- a dense upload window that carried the whole table (mi_commit_upload_window) and the
+ * all-rows frame behind it -- the three run in pieces that overlap: the frame's kernel follows the upload piece by piece, and this
+ * call starts the GlobalTransforms back behind each piece while the later pieces of the upload are still arriving (PCIe is full
+ * duplex); the changed-row list of such a frame is 0 .. n-1 and is not fetched at all.  Nothing to ask for; any other call between
+ * the three waits for the whole upload first.
  * Counts are always filled in for the parts that ran; MI_ERR_CAPACITY if a list exceeds its capacity (counts are valid, that list
  * was not delivered, the others were). */
 #define MI_RESULTS_CHANGED_ROWS 0x1u

@@ -8,6 +8,7 @@ agree on everything a caller can download after every step; at intervals the ora
     cluster walk in the rows' own workgroups              mi_debug_set_walk_inrow(1)
     tile pre-test of change-driven hierarchy frames       mi_debug_set_tile_pretest(1)    [A: forced, mode 2]
     hierarchy frame fused into the tile launches          (B: two launches)               [A: mi_debug_set_tree_cull(2)]
+    all-dirty frames in pieces (upload / frame / results) mi_debug_set_chunked_frames(1)  [A: at any row count, mode 2]
 
 The sequences mix: bounds uploads (whole, partial, single rows), RenderLayers above 31, Transform uploads (indexed, ranges),
 change marks, growth and shrinkage of the row count, Visibility changes propagated on the device, VisibilityClass masks, one to
@@ -100,13 +101,16 @@ def forest_of(rng, n):
     return parent, offs
 
 
-def make_ctx(fast):
+def make_ctx(fast, seed=0):
     ctx = api.Context(0)
     if fast:
-        ctx.debug_set_sphere_path(2)
+        if seed % 3 != 1:  # (the frame in pieces is a k_frame one: a third of the seeds leave the choice of the sphere column to the library)
+            ctx.debug_set_sphere_path(2)
         ctx.debug_set_tile_pretest(2)
         ctx.debug_set_tree_cull(2)
+        ctx.debug_set_chunked_frames(2)
     else:
+        ctx.debug_set_chunked_frames(1)
         ctx.debug_set_row_summary(1)
         ctx.debug_set_sphere_path(1)
         ctx.debug_set_walk_inrow(1)
@@ -138,7 +142,7 @@ def test_fast_paths_are_interchangeable(seed):
     n = int(rng.integers(300, 30_000))
     sc = Scene(rng, n, forest)
     n_lights = 0 if (forest or n < 3000) else int(rng.integers(0, 3)) * 700  # lights are rows at the end of a flat scene
-    a, b = make_ctx(True), make_ctx(False)
+    a, b = make_ctx(True, seed), make_ctx(False, seed)
     try:
         first_light = n - n_lights
         if n_lights:
@@ -212,11 +216,21 @@ def test_fast_paths_are_interchangeable(seed):
                 sc.t[rows] += rng.normal(0.0, 3.0, (k, 3)).astype(F)
                 for ctx in (a, b):
                     ctx.upload_transforms_indexed(rows, sc.t[rows].reshape(-1), sc.r[rows].reshape(-1), sc.s[rows].reshape(-1))
+            elif op == 6 and not forest:  # every Transform moves and arrives in one dense window: upload, frame and results run in pieces
+                sc.t[:n] += rng.normal(0.0, 0.5, (n, 3)).astype(F)
+                for ctx in (a, b):
+                    w, _, wt, wr, ws = ctx.map_upload_window(n, dense=True)
+                    wt[:] = sc.t[:n].reshape(-1)
+                    wr[:] = sc.r[:n].reshape(-1)
+                    ws[:] = sc.s[:n].reshape(-1)
+                    ctx.commit_upload_window(w, n)
             # every step ends in a frame
             cams = [W.many_cubes_camera(int(rng.integers(0, 400)), yaw=float(rng.random() * 6.0), position=tuple(rng.normal(0, 8.0, 3))) for _ in range(n_views)]
             fr = np.concatenate([api.compute_frustum(cfv(), cam, W.CAMERA_FAR) for cam in cams])
             views = api.make_views(fr, layer_masks=vm_lo, layer_masks_hi=vm_hi, flags=view_flags)
             kind = ["all", "changed", "split", "split_all"][int(rng.integers(0, 4))]
+            if op == 6 and not forest:  # (a dense window carries no change marks: the frame behind it is an all-rows one)
+                kind = {"changed": "all", "split": "split_all"}.get(kind, kind)
             flags = B.CULL_END_FRAME | (B.CULL_MORE_FRAMES if rng.random() < 0.5 else 0)
             with_clusters = bool(n_lights) and rng.random() < 0.7
             if with_clusters:
@@ -234,6 +248,12 @@ def test_fast_paths_are_interchangeable(seed):
                     ctx.propagate((B.PROPAGATE_ALL_DIRTY if kind == "split_all" else 0) | (B.PROPAGATE_STATIC_OPT if forest else 0))
                     ctx.cull_views(views, flags=flags | B.CULL_BEGIN_FRAME)
             had_clusters = had_clusters or with_clusters
+            if op == 6 and not forest:  # the results in one call (in pieces in A when the frame was an all-rows one)
+                res = []
+                for ctx in (a, b):
+                    got = ctx.download_frame_results(api.FrameResultBuffers(n, n, 0, 0, in_place=bool(step % 2)))
+                    res.append((np.array(got["changed_rows"]).tobytes(), np.array(got["changed_global"]).tobytes()))
+                assert res[0] == res[1], f"seed {seed} step {step} ({kind}): mi_download_frame_results after a dense upload differs"
             sa, sb = snapshot(a, n_views, had_clusters, n_clusters), snapshot(b, n_views, had_clusters, n_clusters)
             if classes:
                 for v in range(n_views):
@@ -255,9 +275,19 @@ def test_fast_paths_are_interchangeable(seed):
                                                         np.zeros(n, np.uint8), fr, vm_lo, vm_hi)
                 for v in range(n_views - (1 if shadow_view else 0)):  # (the 64-layer restatement knows camera views only)
                     assert np.array_equal(np.frombuffer(sa[f"mask {v}"], np.uint8), vis[v]), f"seed {seed} step {step}: mask of view {v} against the oracle"
+        PIECES[0] += a.debug_chunked_counts()[0]
+        assert b.debug_chunked_counts() == (0, 0)
     finally:
         a.close()
         b.close()
+
+
+PIECES = [0]
+
+
+def test_the_pieces_were_taken():
+    """(runs after the seeds above) some of their all-rows frames behind a dense upload did run in pieces in the fast context."""
+    assert PIECES[0] > 0
 
 
 def oracle_half(sc, n, first_light, n_lights):

@@ -790,7 +790,7 @@ def end_to_end(ctx, wl, frames=12):
     for pct in (1, 10, 100):
         k = n * pct // 100
         rows = np.sort(rng.choice(n, k, replace=False)).astype(np.uint32) if pct < 100 else None
-        times, t_in, t_run, t_out, h2d, d2h = [], [], [], [], 0, 0
+        times, t_in, t_commit, t_run, t_out, h2d, d2h = [], [], [], [], [], 0, 0
         for f in range(frames + 2):
             fr = api.PreparedFrusta(camera_frusta(1, f))
             ctx.synchronize()
@@ -802,15 +802,22 @@ def end_to_end(ctx, wl, frames=12):
                 np.take(t3, rows, axis=0, out=wt.reshape(k, 3), mode="clip")  # (mode="raise" buffers the whole output)
                 np.take(r4, rows, axis=0, out=wr.reshape(k, 4), mode="clip")
                 np.take(s3, rows, axis=0, out=ws.reshape(k, 3), mode="clip")
+                tc = time.perf_counter()
                 ctx.commit_upload_window(w, k)
+                commit_s = time.perf_counter() - tc
             else:  # every row: dense windows, a chunk at a time -- chunk i crosses PCIe (DMA straight from the window) while the host
-                   # fills chunk i + 1.  (Four Python threads filling eight windows at once were SLOWER: 3.4 against 1.5 ms.)
+                   # fills chunk i + 1, and (the library's doing: a sequence of dense windows that carries the whole table) chunk i's
+                   # GlobalTransforms are computed and start back at once, under the upload of the chunks behind it.
+                   # (Four Python threads filling eight windows at once were SLOWER: 3.4 against 1.5 ms.)
                 chunk = (n + 7) // 8
+                commit_s = 0.0
                 for lo in range(0, n, chunk):
                     m = min(chunk, n - lo)
                     w, _, wt, wr, ws = ctx.map_upload_window(m, dense=True)
                     wt[:], wr[:], ws[:] = t3[lo:lo + m].reshape(-1), r4[lo:lo + m].reshape(-1), s3[lo:lo + m].reshape(-1)
+                    tc = time.perf_counter()
                     ctx.commit_upload_window(w, m, first_row=lo)
+                    commit_s += time.perf_counter() - tc
             t1 = time.perf_counter()
             ctx.propagate_and_cull(fr, flags=B.CULL_END_FRAME | B.CULL_WITH_CLUSTERS | (B.CULL_CHANGED_ROWS if rows is not None else 0))
             t2 = time.perf_counter()
@@ -820,6 +827,7 @@ def end_to_end(ctx, wl, frames=12):
             if f >= 2:
                 times.append(t3_ - t0)
                 t_in.append(t1 - t0)
+                t_commit.append(commit_s)
                 t_run.append(t2 - t1)
                 t_out.append(t3_ - t2)
             h2d = k * 44 if rows is not None else n * 40
@@ -832,14 +840,20 @@ def end_to_end(ctx, wl, frames=12):
                                   "h2d_bytes": int(h2d), "d2h_bytes": int(d2h), "pcie_GBps_effective": round(eff, 2),
                                   "pcie_frac": round(link_s / med, 3),
                                   "stage_us": {"gather_into_window_and_commit": round(1e6 * float(np.median(t_in)), 1),
+                                               "of_which_commit_calls": round(1e6 * float(np.median(t_commit)), 1),
                                                "frame_call": round(1e6 * float(np.median(t_run)), 1),
                                                "results_in_place": round(1e6 * float(np.median(t_out)), 1)},
+                                  "library_us": round(1e6 * float(np.median(np.array(t_commit) + np.array(t_run) + np.array(t_out))), 1),
                                   "changed_global_transforms_read_back": int(got_g), "visible_entities": int(len(vis_rows)),
                                   "cluster_index_entries": int(total)}
     out["note"] = ("same frame as `value` with the host on both sides, through ctypes: dirty Transforms written into the library's pinned upload "
                    "window (no staging copy; numpy's gather is the ECS side's loop) and committed, ONE frame call (propagate + cull + "
                    "cluster, MI_CULL_CHANGED_ROWS), ONE mi_download_frame_results delivered in place (one packing launch into pinned memory, one "
-                   f"device wait, no copy out); median wall time of {frames} frames, each synchronised.  pcie_frac = (h2d / peak_h2d + d2h / "
+                   f"device wait, no copy out); median wall time of {frames} frames, each synchronised.  library_us = the library's calls alone "
+                   "(commit + frame + results; the rest of us_per_frame is numpy gathering / copying the rows into the window, the ECS side's loop); "
+                   "at 100 % the table goes in as eight dense windows in a row, which the library sends piece by piece with each piece's "
+                   "GlobalTransforms computed at once and on their way back under the rest of the upload (PCIe full duplex): the results call "
+                   "finds them on the host.  pcie_frac = (h2d / peak_h2d + d2h / "
                    "peak_d2h) / frame time, peaks measured in this run with pinned hipMemcpyAsync (pcie_peak_GBps)")
     return out
 

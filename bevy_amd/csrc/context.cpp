@@ -114,33 +114,26 @@ int32_t consume_changed(mi_ctx* ctx) {
     return MI_OK;
 }
 
-int32_t chunks_join(mi_ctx* ctx) {
-    if (ctx->dense_pending) {
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_up[mi_ctx::FRAME_CHUNKS - 1], 0));
-        ctx->dense_pending = false;
-    }
-    if (ctx->frame_chunked) {  // (its pieces all ran on the context's stream: nothing to wait for, only to forget)
-        ctx->frame_chunked = false;
-    }
-    return MI_OK;
+void trs_written(mi_ctx* ctx) {
+    ++ctx->trs_version;
+    ctx->seq_cov = 0;
 }
-static int32_t chunk_streams(mi_ctx* ctx) {
-    if (ctx->chunk_events) return MI_OK;
+static int32_t piece_streams(mi_ctx* ctx) {
+    if (ctx->piece_streams) return MI_OK;
     // HIP streams share a few hardware queues per priority class, and a queue runs its barrier packets (event waits and records)
-    // in order: when the upload stream landed on the queue of the context's stream -- or of the download stream -- every wait
-    // queued behind its eight event records stood until the whole upload was in (measured: the first GlobalTransform piece left
-    // when the last Transform piece had arrived, profiles/r03_experiments.md 12).  A priority class of its own gives each of the
-    // two a queue no stream of the context shares; the download stream additionally carries no waits at all (its copies are issued
-    // by the host as each piece's frame event completes, mi_download_frame_results).
+    // in order: when the upload stream landed on the queue of the download stream, the latter's first wait stood behind every
+    // event record of the upload (measured: the first GlobalTransform piece left when the last Transform piece had arrived,
+    // profiles/r03_experiments.md 12).  A priority class of its own gives each of the two a queue no other stream of the context
+    // shares.
     int prio_lo = 0, prio_hi = 0;
     HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->up_stream, hipStreamNonBlocking, prio_hi));
     HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->dn_stream, hipStreamNonBlocking, prio_lo));
-    for (uint32_t k = 0; k < mi_ctx::FRAME_CHUNKS; ++k) {
+    for (uint32_t k = 0; k < mi_ctx::UP_PIECES; ++k) {
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_up[k], hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_frame[k], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_pre[k], hipEventDisableTiming));
     }
-    ctx->chunk_events = true;
+    ctx->piece_streams = true;
     return MI_OK;
 }
 
@@ -550,35 +543,7 @@ static int32_t cull_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, u
         }
         ProfScope ps(ctx, PROPAGATE ? K_FLAT_PROPAGATE_CULL : K_CULL);
         const bool stale_from_mask = use_sph && ctx->sph_state == mi_ctx::SPH_EXCEPT_CHANGED;
-        const bool chunked = PROPAGATE && !changed_col && ctx->dense_pending && !use_sph;
-        if (ctx->dense_pending && !chunked) {  // (a frame of another kind: behind the whole upload)
-            const int32_t rcj = chunks_join(ctx);
-            if (rcj) return frame_abort(ctx, rcj, prev, prev_has_job, prev_job);
-        }
-        hipError_t e = hipSuccess;
-        if (chunked) {
-            // The Transforms are still arriving, piece by piece (mi_commit_upload_window): the frame runs piece by piece behind them
-            // -- each launch covers the tiles of one piece and records an event the result download starts from.  Riders that read
-            // nothing of the upload (the previous frame's compaction and cluster fill) go with the first piece; a cluster walk in
-            // workgroups of its own re-derives the lights' rows from their Transforms, so it goes with the last; the walk inside
-            // the rows' own workgroups goes wherever those rows are.
-            for (uint32_t k = 0; k < mi_ctx::FRAME_CHUNKS && e == hipSuccess; ++k) {
-                const uint32_t t_lo = ctx->chunk_lo[k] / 256u, t_hi = (ctx->chunk_lo[k + 1] + 255u) / 256u;
-                const bool first = k == 0, last = k + 1 == mi_ctx::FRAME_CHUNKS;
-                if (hipStreamWaitEvent(ctx->stream, ctx->ev_up[k], 0) != hipSuccess) { e = hipErrorUnknown; break; }
-                const ClusterWalkJob* wk = clusters_ride && (walk_job.inrow || last) ? &walk_job : nullptr;
-                if (t_hi > t_lo)
-                    e = launch_flat_propagate_cull(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p, n_views, vo, seg,
-                                                   flags & MI_CULL_END_FRAME, first ? prev : nullptr, first && have_fill ? &fill_job : nullptr, wk, ctx->stream,
-                                                   nullptr, t_lo, t_hi - t_lo);
-                if (e == hipSuccess && hipEventRecord(ctx->ev_frame[k], ctx->stream) != hipSuccess) e = hipErrorUnknown;
-            }
-            ctx->dense_pending = false;
-            ctx->frame_chunked = e == hipSuccess;
-            ctx->n_chunked_frames += e == hipSuccess;
-            if (e != hipSuccess) hipStreamWaitEvent(ctx->stream, ctx->ev_up[mi_ctx::FRAME_CHUNKS - 1], 0);  // (whatever follows: behind the whole upload)
-        } else
-        e = use_sph ? launch_frame_sph(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p, n_views, vo, seg,
+        const hipError_t e = use_sph ? launch_frame_sph(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p, n_views, vo, seg,
                                                         (flags & (MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME)) | (PROPAGATE ? CULL_BEGIN_FRAME : 0u), prev,
                                                         have_fill ? &fill_job : nullptr, clusters_ride ? &walk_job : nullptr, ctx->stream, changed_col,
                                                         (float*)ctx->sph.p, stale_from_mask && !ctx->g_chg_in_bytes ? ctx->g_chg_bits : nullptr,
@@ -608,6 +573,7 @@ static int32_t cull_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, u
     else if (PROPAGATE && !changed_col) {             // every GlobalTransform rewritten
         ctx->sph_state = mi_ctx::SPH_INVALID;
         ctx->sph_quiet = 0;
+        if (!ctx->have_hierarchy) ctx->frame_all_version = ctx->trs_version;  // (= From(Transform) of every row: what a fetch ahead holds)
     } else if (PROPAGATE)                              // k_frame<2>: the rewritten rows are this frame's change mask
         ctx->sph_state = ctx->sph_state == mi_ctx::SPH_VALID ? mi_ctx::SPH_EXCEPT_CHANGED : mi_ctx::SPH_INVALID;
     if (!PROPAGATE || changed_col) ++ctx->sph_quiet;
@@ -698,12 +664,12 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
     }
     if (ctx->g_host) hipHostFree(ctx->g_host);
     if (ctx->iota_host) hipHostFree(ctx->iota_host);
-    if (ctx->chunk_events) {
+    if (ctx->piece_streams) {
         hipStreamSynchronize(ctx->up_stream);
         hipStreamSynchronize(ctx->dn_stream);
-        for (uint32_t k = 0; k < mi_ctx::FRAME_CHUNKS; ++k) {
+        for (uint32_t k = 0; k < mi_ctx::UP_PIECES; ++k) {
             hipEventDestroy(ctx->ev_up[k]);
-            hipEventDestroy(ctx->ev_frame[k]);
+            hipEventDestroy(ctx->ev_pre[k]);
         }
         hipStreamDestroy(ctx->up_stream);
         hipStreamDestroy(ctx->dn_stream);
@@ -715,7 +681,7 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
                     ctx->bt_kind, ctx->bt_cpu_bin, ctx->bt_bucket};
     for (void* p : cols)
         if (p) hipFree(p);
-    DevBuf* bufs[] = {&ctx->sph, &ctx->row_sum, &ctx->anc, &ctx->order, &ctx->chains, &ctx->snap, &ctx->tree_trace, &ctx->inh_bits, &ctx->sparse_cnt, &ctx->sparse_rows, &ctx->sparse_total, &ctx->sparse_g, &ctx->parent_idx, &ctx->node_flags, &ctx->tiles, &ctx->views,
+    DevBuf* bufs[] = {&ctx->sph, &ctx->row_sum, &ctx->anc, &ctx->order, &ctx->chains, &ctx->snap, &ctx->tree_trace, &ctx->inh_bits, &ctx->sparse_cnt, &ctx->sparse_rows, &ctx->sparse_total, &ctx->sparse_g, &ctx->g_pre, &ctx->parent_idx, &ctx->node_flags, &ctx->tiles, &ctx->views,
                       &ctx->block_counts, &ctx->seg_bases, &ctx->out_keys, &ctx->cl_pos,
                       &ctx->cl_type, &ctx->cl_layers, &ctx->cl_dir, &ctx->cl_sincos, &ctx->cl_planes, &ctx->cl_spheres,
                       &ctx->bt_set_indexed, &ctx->bt_table_off, &ctx->bt_table, &ctx->bt_meta_off, &ctx->bt_meta, &ctx->bt_rows_a, &ctx->bt_rows_b,
@@ -786,6 +752,7 @@ int32_t mi_synchronize(mi_ctx* ctx) {
 // =============================================================================================
 int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
     ENTER(ctx);
+    trs_written(ctx);
     {
         int32_t rcj = compaction_join(ctx);  // buffers may move
         if (rcj) return rcj;
@@ -916,6 +883,7 @@ int32_t mi_upload_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t n, const 
     if (!translation || !rotation || !scale) return fail(ctx, MI_ERR_INVALID_ARG, "mi_upload_transforms: NULL column");
     int32_t rc = check_rows(ctx, first_row, n, "mi_upload_transforms");
     if (rc) return rc;
+    trs_written(ctx);
     if (n && n <= SMALL_UPLOAD_ROWS) {  // dirty-row sized: one staging block, one scatter kernel
         void* st = nullptr;
         if ((rc = stage_alloc(ctx, (size_t)n * 40, &st))) return rc;
@@ -938,6 +906,7 @@ int32_t mi_upload_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t n, const 
 
 // rows / t / r / s lie in the pinned arena: one scatter kernel reads them over PCIe and raises the rows' change bytes
 static int32_t scatter_indexed(mi_ctx* ctx, const uint32_t* rows, const float* t, const float* r, const float* s, uint32_t n) {
+    trs_written(ctx);
     void *d_rows = nullptr, *d_t = nullptr, *d_r = nullptr, *d_s = nullptr;
     HIP_TRY(ctx, hipHostGetDevicePointer(&d_rows, (void*)rows, 0));
     HIP_TRY(ctx, hipHostGetDevicePointer(&d_t, (void*)t, 0));
@@ -1048,7 +1017,7 @@ int32_t mi_map_upload_window(mi_ctx* ctx, uint32_t capacity, uint32_t flags, mi_
 }
 
 int32_t mi_commit_upload_window(mi_ctx* ctx, const mi_upload_window* w, uint32_t n, uint32_t first_row) {
-    ENTER(ctx);
+    ENTER_RAW(ctx);  // (may continue a sequence of dense windows, below; every other way out of here ends it)
     if (!w) return fail(ctx, MI_ERR_INVALID_ARG, "mi_commit_upload_window: NULL");
     if (w->capacity == 0) return MI_OK;
     if (n > w->capacity) return fail(ctx, MI_ERR_INVALID_ARG, "mi_commit_upload_window: %u rows, the window holds %u", n, w->capacity);
@@ -1064,30 +1033,69 @@ int32_t mi_commit_upload_window(mi_ctx* ctx, const mi_upload_window* w, uint32_t
         if (rc) return rc;
         if ((rc = cluster_join(ctx))) return rc;
         ctx->cl_inputs_dirty = true;
-        if (ctx->chunk_mode != 1 && first_row == 0 && n == ctx->n && n >= (ctx->chunk_mode == 2 ? 1u : 262144u) && !ctx->have_hierarchy && !ctx->xch.on) {
-            // The whole table: FRAME_CHUNKS pieces on a stream of their own, an event behind each.  The all-rows frame that
-            // (usually) follows runs piece by piece behind them, and its results start back while the later pieces still arrive.
-            if ((rc = chunk_streams(ctx))) return rc;
-            // Whatever still reads the columns on the context's stream comes first -- waited for by the host, not by the upload
-            // stream: with an event wait in front of them the runtime sent the upload stream's copies through the DMA engine the
-            // download stream uses, and the two directions took turns (2.15 ms against 1.35 for the same pattern with this wait
-            // on the host, profiles/r03_experiments.md 12).  The stream is idle here in a loop of frames: the results of the
-            // frame before have been delivered.
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            const uint32_t tiles = (n + 255u) / 256u;
-            for (uint32_t k = 0; k <= mi_ctx::FRAME_CHUNKS; ++k) ctx->chunk_lo[k] = (uint32_t)std::min<uint64_t>(n, ((uint64_t)tiles * k / mi_ctx::FRAME_CHUNKS) * 256u);
-            for (uint32_t k = 0; k < mi_ctx::FRAME_CHUNKS; ++k) {
-                const size_t lo = ctx->chunk_lo[k], cnt = ctx->chunk_lo[k + 1] - lo;
-                if (cnt) {
-                    HIP_TRY(ctx, hipMemcpyAsync(ctx->t + 3 * lo, w->translation + 3 * lo, cnt * 12, hipMemcpyHostToDevice, ctx->up_stream));
-                    HIP_TRY(ctx, hipMemcpyAsync(ctx->r + 4 * lo, w->rotation + 4 * lo, cnt * 16, hipMemcpyHostToDevice, ctx->up_stream));
-                    HIP_TRY(ctx, hipMemcpyAsync(ctx->s + 3 * lo, w->scale + 3 * lo, cnt * 12, hipMemcpyHostToDevice, ctx->up_stream));
+        // ---- a sequence of dense windows that carries the whole flat table (ctx.h, "dense uploads in pieces") ----
+        const uint32_t cov = ctx->seq_cov;  // (ENTER_RAW above: a sequence in progress survives this call)
+        const bool starts = first_row == 0, continues = cov != 0 && first_row == cov && ctx->seq_pieces < mi_ctx::UP_PIECES;
+        if (ctx->chunk_mode != 1 && (starts || continues) && ctx->n >= (ctx->chunk_mode == 2 ? 1u : 262144u) && !ctx->have_hierarchy && !ctx->xch.on) {
+            if ((rc = piece_streams(ctx))) return rc;
+            if (starts) {
+                // Whatever still reads the columns on the context's stream comes first -- waited for by the host, not by the upload
+                // stream: with an event wait in front of them the runtime sent the upload stream's copies through the DMA engine the
+                // download stream uses, and the two directions took turns (2.15 ms against 1.35 for the same pattern with this wait
+                // on the host, profiles/r03_experiments.md 12).  The stream is idle here in a loop of frames: the results of the
+                // frame before have been delivered.
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                if (ctx->pre_version && !ctx->pre_used) ctx->ahead_wanted = false;  // (the last fetch ahead was for nothing)
+                ctx->seq_pieces = 0;
+                ctx->pre_version = 0;
+                ctx->pre_used = false;
+                ctx->seq_ahead = ctx->ahead_wanted || ctx->chunk_mode == 2;
+                if (ctx->seq_ahead) {
+                    if ((rc = ensure(ctx, ctx->g_pre, (size_t)ctx->cap * 48))) return rc;
+                    if (ctx->g_host_bytes < (size_t)ctx->n * 48) {
+                        HIP_TRY(ctx, hipStreamSynchronize(ctx->dn_stream));  // (a fetch nobody asked for may still be landing)
+                        if (ctx->g_host) HIP_TRY(ctx, hipHostFree(ctx->g_host));
+                        ctx->g_host = nullptr;
+                        ctx->g_host_bytes = 0;
+                        HIP_TRY(ctx, hipHostMalloc(&ctx->g_host, (size_t)ctx->cap * 48, hipHostMallocDefault));
+                        ctx->g_host_bytes = (size_t)ctx->cap * 48;
+                    }
                 }
-                HIP_TRY(ctx, hipEventRecord(ctx->ev_up[k], ctx->up_stream));
             }
-            ctx->dense_pending = true;
+            // a window that carries a large part of the table goes out in pieces of about an eighth of it
+            const uint32_t room = mi_ctx::UP_PIECES - ctx->seq_pieces;
+            const uint32_t parts = std::max(1u, std::min<uint32_t>(room, (uint32_t)(((uint64_t)n * mi_ctx::SPLIT + ctx->n / 2) / ctx->n)));
+            for (uint32_t k = 0; k < parts; ++k) {
+                const size_t lo = (size_t)n * k / parts, cnt = (size_t)n * (k + 1) / parts - lo, at = first_row + lo;
+                const uint32_t ev = ctx->seq_pieces++;
+                if (cnt) {
+                    HIP_TRY(ctx, hipMemcpyAsync(ctx->t + 3 * at, w->translation + 3 * lo, cnt * 12, hipMemcpyHostToDevice, ctx->up_stream));
+                    HIP_TRY(ctx, hipMemcpyAsync(ctx->r + 4 * at, w->rotation + 4 * lo, cnt * 16, hipMemcpyHostToDevice, ctx->up_stream));
+                    HIP_TRY(ctx, hipMemcpyAsync(ctx->s + 3 * at, w->scale + 3 * lo, cnt * 12, hipMemcpyHostToDevice, ctx->up_stream));
+                }
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_up[ev], ctx->up_stream));
+                // the context's stream follows piece by piece: everything launched on it from here on sees the upload so far
+                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_up[ev], 0));
+                if (ctx->seq_ahead && cnt) {
+                    HIP_TRY(ctx, launch_globals_ahead(ctx->t, ctx->r, ctx->s, (uint32_t)at, (uint32_t)(at + cnt), (float*)ctx->g_pre.p, ctx->stream));
+                    HIP_TRY(ctx, hipEventRecord(ctx->ev_pre[ev], ctx->stream));
+                    HIP_TRY(ctx, hipStreamWaitEvent(ctx->dn_stream, ctx->ev_pre[ev], 0));
+                    HIP_TRY(ctx, hipMemcpyAsync((char*)ctx->g_host + at * 48, (const char*)ctx->g_pre.p + at * 48, cnt * 48, hipMemcpyDeviceToHost, ctx->dn_stream));
+                }
+            }
+            ++ctx->n_piece_uploads;
+            ++ctx->trs_version;
+            ctx->seq_cov = first_row + n;
+            if (ctx->seq_cov == ctx->n) {  // complete: what is landing in g_host is every row's From(Transform) as of this version
+                ctx->seq_cov = 0;
+                if (ctx->seq_ahead) {
+                    ctx->pre_version = ctx->trs_version;
+                    ctx->pre_n = ctx->n;
+                }
+            }
             return MI_OK;
         }
+        trs_written(ctx);
         // pinned -> device: three DMA copies straight from the window (no staging copy)
         HIP_TRY(ctx, hipMemcpyAsync(ctx->t + 3 * (size_t)first_row, w->translation, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->r + 4 * (size_t)first_row, w->rotation, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
@@ -1247,6 +1255,7 @@ int32_t mi_propagate(mi_ctx* ctx, uint32_t flags) {
     if (all_dirty) {
         ctx->sph_state = mi_ctx::SPH_INVALID;
         ctx->sph_quiet = 0;
+        if (!ctx->have_hierarchy) ctx->frame_all_version = ctx->trs_version;  // (every row: From(Transform), as a fetch ahead holds it)
     } else {
         ctx->sph_state = ctx->sph_state == mi_ctx::SPH_VALID ? mi_ctx::SPH_EXCEPT_CHANGED : mi_ctx::SPH_INVALID;
     }
@@ -1474,12 +1483,7 @@ static int32_t tree_frame_fused(mi_ctx* ctx, const mi_view* views, uint32_t n_vi
 }
 
 int32_t mi_propagate_and_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint32_t flags) {
-    ENTER_RAW(ctx);  // (cull_frame<true> runs behind a chunked upload piece by piece; every other way out of here joins it first)
-    ctx->frame_chunked = false;
-    if (ctx->dense_pending && (ctx->have_hierarchy || (flags & MI_CULL_CHANGED_ROWS) || !views || n_views == 0)) {
-        const int32_t rcj = chunks_join(ctx);
-        if (rcj) return rcj;
-    }
+    ENTER(ctx);
     if (ctx->have_hierarchy && views && n_views && tree_frame_fusable(ctx, n_views, flags)) return tree_frame_fused(ctx, views, n_views, flags);
     if (ctx->have_hierarchy) {
         // With a hierarchy the frame is the tile launches of mi_propagate with the cull behind them: the same call for the
@@ -1662,13 +1666,7 @@ struct BatchedDownload {
 }  // namespace
 
 int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
-    ENTER_RAW(ctx);  // (a frame that ran in pieces: its GlobalTransforms start back piece by piece, below)
-    if (ctx->dense_pending) {
-        const int32_t rcj = chunks_join(ctx);
-        if (rcj) return rcj;
-    }
-    const bool frame_was_chunked = ctx->frame_chunked;
-    ctx->frame_chunked = false;
+    ENTER(ctx);
     if (!io) return fail(ctx, MI_ERR_INVALID_ARG, "mi_download_frame_results: NULL");
     io->changed_count = 0;
     io->cluster_total = 0;
@@ -1695,26 +1693,10 @@ int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
         for (uint32_t l = 0; l < n_lists; ++l) io->lists[l].rows = nullptr;
     }
     int32_t rc;
-    // ---- a frame that ran in pieces (every row propagated: every GlobalTransform changed): the column starts back piece by piece,
-    // each copy behind its piece's kernel, on a stream of its own -- under the pieces of the upload that are still arriving ----
-    void* g_prefetched = nullptr;
-    if (frame_was_chunked && want_g && ctx->n && io->changed_capacity >= ctx->n && ctx->chunk_events) {
-        // (into pinned memory of their own, not the arena: the arena is sized -- and may wrap, with a wait for the context's stream --
-        // further down, and neither may happen under or in front of these copies)
-        if (ctx->g_host_bytes < (size_t)ctx->n * 48) {
-            if (ctx->g_host) HIP_TRY(ctx, hipHostFree(ctx->g_host));
-            ctx->g_host = nullptr;
-            ctx->g_host_bytes = 0;
-            HIP_TRY(ctx, hipHostMalloc(&ctx->g_host, (size_t)ctx->cap * 48, hipHostMallocDefault));
-            ctx->g_host_bytes = (size_t)ctx->cap * 48;
-        }
-        g_prefetched = ctx->g_host;
-        for (uint32_t k = 0; k < mi_ctx::FRAME_CHUNKS; ++k) {
-            const size_t lo = ctx->chunk_lo[k], cnt = ctx->chunk_lo[k + 1] - lo;
-            HIP_TRY(ctx, hipEventSynchronize(ctx->ev_frame[k]));  // (by the host, not by the stream: see chunk_streams)
-            if (cnt) HIP_TRY(ctx, hipMemcpyAsync((char*)g_prefetched + lo * 48, ctx->g + 12 * lo, cnt * 48, hipMemcpyDeviceToHost, ctx->dn_stream));
-        }
-    }
+    // ---- every GlobalTransform fetched ahead (mi_commit_upload_window): good for this call when the frame in between rewrote every
+    // row from the very Transforms the fetch was computed from -- and every row then counts as changed (checked below) ----
+    const bool g_ahead = want_g && ctx->n && ctx->pre_version && ctx->pre_version == ctx->trs_version && ctx->frame_all_version == ctx->trs_version &&
+                         ctx->pre_n == ctx->n && io->changed_capacity >= ctx->n && !ctx->have_hierarchy;
     // ---- everything that has to run before the counts are final ----
     const uint32_t* list_total[PACK_MAX_LISTS] = {nullptr};
     const uint32_t* list_rows[PACK_MAX_LISTS] = {nullptr};
@@ -1848,13 +1830,15 @@ int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
                     if (in_place) io->changed_rows = ctx->iota_host;
                     else memcpy(io->changed_rows, ctx->iota_host, (size_t)changed * 4);
                 } else if (want_rows && (rc = b.add(ctx, io->changed_rows, ctx->sparse_rows.p, (size_t)changed * 4, in_place ? (void**)&io->changed_rows : nullptr))) return rc;
-                if (want_g && g_prefetched && changed == ctx->n) {  // already on its way (above): parked in the arena like any other piece
+                if (want_g && g_ahead && changed == ctx->n) {  // on its way since the upload, or here already
                     HIP_TRY(ctx, hipStreamSynchronize(ctx->dn_stream));
-                    b.pieces.push_back({in_place ? nullptr : (void*)io->changed_global12, g_prefetched, (size_t)changed * 48});
-                    if (in_place) io->changed_global12 = (float*)g_prefetched;
-                    ++ctx->n_chunked_downloads;
-                    g_prefetched = nullptr;
+                    b.pieces.push_back({in_place ? nullptr : (void*)io->changed_global12, ctx->g_host, (size_t)changed * 48});
+                    if (in_place) io->changed_global12 = (float*)ctx->g_host;
+                    ++ctx->n_ahead_downloads;
+                    ctx->pre_used = true;
                 } else if (want_g) {
+                    // (every GlobalTransform of an all-rows frame fetched the usual way: the next sequence of dense windows fetches ahead)
+                    if (changed == ctx->n && ctx->frame_all_version == ctx->trs_version) ctx->ahead_wanted = true;
                     const bool all_rows = changed == ctx->n;  // every row changed: the list is 0 .. n-1 and the column itself is the answer
                     if (!all_rows) {
                         if ((rc = ensure(ctx, ctx->sparse_g, (size_t)changed * 48))) return rc;
@@ -1867,14 +1851,12 @@ int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
                 }
                 if ((rc = b.finish(ctx))) return rc;
             }
-            if (g_prefetched) HIP_TRY(ctx, hipStreamSynchronize(ctx->dn_stream));  // (fetched for nothing: fewer rows changed than the frame propagated)
             return cap_rc;
         }
         changed = 0;
         cl_total = 0;
     }
     // ---- the packed window was too small (or the cluster list outgrew its device buffer): wait 1, the counts and every fixed-size array ----
-    if (g_prefetched) HIP_TRY(ctx, hipStreamSynchronize(ctx->dn_stream));  // (not used on this path: only let it land)
     BatchedDownload b;
     b.in_place = in_place;
     uint32_t list_count[PACK_MAX_LISTS] = {0};
@@ -2145,11 +2127,11 @@ int32_t mi_debug_set_chunked_frames(mi_ctx* ctx, int32_t mode) {
     return MI_OK;
 }
 
-// test hook: how many frames ran in pieces behind a dense upload, and how many result downloads delivered GlobalTransforms fetched in pieces
-int32_t mi_debug_chunked_counts(mi_ctx* ctx, uint32_t* out_frames, uint32_t* out_downloads) {
+// test hook: how many dense windows went out as pieces of a sequence, and how many result downloads handed out GlobalTransforms fetched ahead
+int32_t mi_debug_chunked_counts(mi_ctx* ctx, uint32_t* out_frames /* windows */, uint32_t* out_downloads) {
     ENTER_RAW(ctx);
-    if (out_frames) *out_frames = ctx->n_chunked_frames;
-    if (out_downloads) *out_downloads = ctx->n_chunked_downloads;
+    if (out_frames) *out_frames = ctx->n_piece_uploads;
+    if (out_downloads) *out_downloads = ctx->n_ahead_downloads;
     return MI_OK;
 }
 

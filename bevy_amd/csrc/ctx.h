@@ -127,23 +127,35 @@ struct mi_ctx {
     uint32_t sph_quiet = 0;  // cull frames since the last wholesale GlobalTransform rewrite (the column is rebuilt on the second)
     int32_t sph_mode = 0;    // mi_debug_set_sphere_path: 0 = as described, 1 = never, 2 = rebuild at once
 
-    // ---- chunked all-dirty frames (context.cpp: mi_commit_upload_window, cull_frame, mi_download_frame_results) ----
-    // A dense upload of EVERY row's Transform goes out in FRAME_CHUNKS pieces on a stream of its own; the all-rows frame that follows
-    // runs piece by piece, each behind its part of the upload; the changed GlobalTransforms -- all of them -- come back piece by
-    // piece on a third stream: the two PCIe directions overlap instead of queueing (1.98 -> ~1.2 ms for 1.11 M rows).
-    static constexpr uint32_t FRAME_CHUNKS = 8;
+    // ---- dense uploads in pieces, GlobalTransforms ahead of the frame (context.cpp: mi_commit_upload_window,
+    //      mi_download_frame_results; profiles/r03_experiments.md 12) ----
+    // A SEQUENCE is a run of dense windows that carries the whole flat table in ascending order: one window for every row (split
+    // into SPLIT pieces here) or several the caller commits one after the other (first_row = where the one before ended).  Each
+    // piece goes out on a stream of its own (up_stream), the context's stream waits for it, and -- once the caller has shown that
+    // it fetches every GlobalTransform of such frames -- computes the piece's GlobalTransforms at once (k_globals_ahead, into g_pre:
+    // From(Transform), what the all-rows frame will write) and sends them home on a third stream (dn_stream) while the later
+    // pieces of the upload are still arriving: PCIe is full duplex.  mi_download_frame_results hands out what arrived when the
+    // frame in between was an all-rows one of the same Transforms (trs_version), and fetches as usual otherwise.
+    static constexpr uint32_t UP_PIECES = 16, SPLIT = 8;
     hipStream_t up_stream = nullptr, dn_stream = nullptr;
-    hipEvent_t ev_up[FRAME_CHUNKS] = {}, ev_frame[FRAME_CHUNKS] = {};
-    bool chunk_events = false;
-    uint32_t n_chunked_frames = 0, n_chunked_downloads = 0;  // mi_debug_chunked_counts: how often the pieces were taken
-    uint32_t* iota_host = nullptr; // pinned 0, 1, 2 ...: the changed-row list of a frame in which every row changed (nothing to fetch)
+    hipEvent_t ev_up[UP_PIECES] = {}, ev_pre[UP_PIECES] = {};
+    bool piece_streams = false;
+    uint32_t seq_cov = 0;            // the sequence so far carries rows [0, seq_cov); 0 = none in progress (every ENTER ends one)
+    uint32_t seq_pieces = 0;         // events of this sequence in use
+    bool seq_ahead = false;          // this sequence computes and fetches GlobalTransforms ahead
+    uint64_t trs_version = 1;        // bumped by whatever writes the Transform columns, renumbers rows or changes their count
+    uint64_t pre_version = 0;        // trs_version for which g_host holds (or is receiving) every row's GlobalTransform; 0 = none
+    uint64_t frame_all_version = 0;  // trs_version of the last frame that rewrote every GlobalTransform of a flat table
+    uint32_t pre_n = 0;
+    bool pre_used = false;           // the last fetch ahead was handed out
+    bool ahead_wanted = false;       // the caller fetched every GlobalTransform after its last all-rows frame
+    DevBuf g_pre;                    // device: [cap] GlobalTransforms ahead of the frame
+    void* g_host = nullptr;          // pinned: where they land (memory of its own: valid until the next call, like the arena)
+    size_t g_host_bytes = 0;
+    uint32_t* iota_host = nullptr;   // pinned 0, 1, 2 ...: the changed-row list of a frame in which every row changed (nothing to fetch)
     size_t iota_rows = 0;
-    void* g_host = nullptr;        // pinned: where the GlobalTransforms of a frame that ran in pieces land (not the arena: the copies
-    size_t g_host_bytes = 0;       // start before anything else of the download is sized, and the arena may wrap under them)
-    uint32_t chunk_lo[FRAME_CHUNKS + 1] = {};  // row bounds of the pieces (multiples of 256)
-    bool dense_pending = false;                // a chunked upload is in flight: whoever reads the Transform columns waits for ev_up[last]
-    bool frame_chunked = false;                // the last frame ran in pieces: ev_frame[k] = piece k's GlobalTransforms are written
-    int32_t chunk_mode = 0;                    // mi_debug_set_chunked_frames: 0 = when the whole table (>= 262144 rows) arrives in one dense window (default), 1 = never, 2 = at any size
+    uint32_t n_piece_uploads = 0, n_ahead_downloads = 0;  // mi_debug_chunked_counts
+    int32_t chunk_mode = 0;          // mi_debug_set_chunked_frames: 0 = tables of >= 262144 rows (default), 1 = never, 2 = any size
 
     // ---- row summary (RowSummary, kernels.h): Aabb / flags / RenderLayers per 64 rows where they are uniform.  Derived from the
     // columns by k_row_summary; rs_lo / rs_hi = the waves [lo, hi) whose summary is out of date, per part (0 = Aabb, 1 = flags +
@@ -324,9 +336,9 @@ int32_t fail(mi_ctx* ctx, int32_t code, const char* fmt, ...);
                         hipGetErrorString(e_), __FILE__, __LINE__);                                          \
     } while (0)
 
-// ENTER_RAW: the few entry points that know about a chunked upload / frame in flight (see FRAME_CHUNKS above) and order themselves
-// against it; ENTER: everybody else -- the context's stream first waits for the whole upload, and a frame that ran in pieces is no
-// longer "the last thing that happened"
+// ENTER_RAW: mi_map_upload_window / mi_commit_upload_window, which continue a sequence of dense windows (seq_cov above); ENTER:
+// everybody else -- whatever they launch may read the Transform columns, so a window committed after them starts over on the
+// context's stream (or starts a new sequence at row 0, which waits for that stream first)
 #define ENTER_RAW(ctx)                                                   \
     do {                                                                 \
         if (!(ctx)) return fail(nullptr, MI_ERR_INVALID_ARG, "ctx is NULL"); \
@@ -336,10 +348,7 @@ int32_t fail(mi_ctx* ctx, int32_t code, const char* fmt, ...);
 #define ENTER(ctx)                                                       \
     do {                                                                 \
         ENTER_RAW(ctx);                                                  \
-        if ((ctx)->dense_pending || (ctx)->frame_chunked) {              \
-            const int32_t rcj_ = mi_detail::chunks_join(ctx);            \
-            if (rcj_) return rcj_;                                       \
-        }                                                                \
+        (ctx)->seq_cov = 0;                                              \
     } while (0)
 
 inline bool trace_on() {
@@ -376,7 +385,7 @@ int32_t download(mi_ctx* ctx, void* dst, const void* src, size_t bytes);
 int32_t check_rows(mi_ctx* ctx, uint32_t first, uint32_t n, const char* what);
 void row_summary_touch(mi_ctx* ctx, uint32_t parts, uint32_t first_row, uint32_t n_rows);  // the columns of these rows were written
 int32_t row_summary_ensure(mi_ctx* ctx);
-int32_t chunks_join(mi_ctx* ctx);  // the context's stream waits for a chunked upload in flight; a chunked frame is forgotten
+void trs_written(mi_ctx* ctx);  // the Transform columns (or the numbering / count of rows) changed: nothing fetched ahead applies any more
 int32_t consume_changed(mi_ctx* ctx);  // the propagate has read the change column: every row is unchanged from here on
 void prof_close(mi_ctx* ctx);
 void prof_mark(void* vctx, uint32_t kernel);

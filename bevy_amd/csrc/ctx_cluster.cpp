@@ -91,7 +91,7 @@ int32_t mi_cluster_bind_objects_to_row_list(mi_ctx* ctx, uint32_t n_objects, con
 }
 
 int32_t mi_cluster_upload_view(mi_ctx* ctx, const mi_cluster_view* view) {
-    ENTER_RAW(ctx);  // (the view's constants: nothing here reads the Transform columns a chunked upload may still be filling)
+    ENTER(ctx);
     if (!view || !view->x_planes || !view->y_planes || !view->z_planes) return fail(ctx, MI_ERR_INVALID_ARG, "mi_cluster_upload_view: NULL");
     const uint64_t C = (uint64_t)view->dims[0] * view->dims[1] * view->dims[2];
     if (C == 0 || C > 4096) return fail(ctx, MI_ERR_INVALID_ARG, "cluster count %llu outside 1..4096 (assign.rs:410-413)", (unsigned long long)C);

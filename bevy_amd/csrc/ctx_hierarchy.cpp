@@ -10,6 +10,7 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
                             uint32_t n_levels) {
     ENTER(ctx);
     if (n != ctx->n) return fail(ctx, MI_ERR_INVALID_ARG, "mi_upload_hierarchy: n (%u) != live rows (%u)", n, ctx->n);
+    trs_written(ctx);  // (rows may have been renumbered with it: nothing fetched ahead of a flat frame applies)
     ctx->changed_maybe = true;  // conservative: the next propagate looks at the rows again
     // marks an upload of this frame climbed for belong to the hierarchy that is being replaced
     if (ctx->marks_in_cur) ctx->tree_clean[ctx->tree_parity] = false;

@@ -213,16 +213,15 @@ struct CompactFastArgs {
 hipError_t launch_flat_propagate_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views,
                                       uint32_t n_views, const VisibilityOut& out, const SegOut& seg, uint32_t flags,
                                       const CompactFastArgs* prev, const struct ClusterFillJob* fill, const struct ClusterWalkJob* walk,
-                                      hipStream_t stream, const uint8_t* changed = nullptr /* set: only rows with a nonzero byte are propagated */,
-                                      uint32_t tile_base = 0xFFFFFFFFu /* FRAME_ALL_TILES, or the first 256-row tile of a chunk ... */,
-                                      uint32_t chunk_tiles = 0 /* ... of this many tiles (all-rows frames only) */);
-constexpr uint32_t FRAME_ALL_TILES = 0xFFFFFFFFu;
+                                      hipStream_t stream, const uint8_t* changed = nullptr /* set: only rows with a nonzero byte are propagated */);
 // Level 0 of the hierarchy (roots + flat rows).  node_flags: bit0 = has children (nullptr = none do).
 // changed: per-row Changed<Transform>|... byte (nullptr or all_dirty => every row recomputed).
 // tree_bytes: TransformTreeChanged, a byte per row (only read when static_opt).
 hipError_t launch_level0_propagate(const Columns& c, uint32_t n_level0, const uint8_t* node_flags,
                                    const uint8_t* changed, const uint8_t* tree_bytes, bool all_dirty,
                                    bool static_opt, hipStream_t stream);
+// rows lo .. hi-1: out[row] = From(Transform) (sync_simple_transforms), for the result download that runs ahead of the frame
+hipError_t launch_globals_ahead(const float* t, const float* r, const float* s, uint32_t lo, uint32_t hi, float* out, hipStream_t stream);
 hipError_t launch_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views,
                        const VisibilityOut& out, const SegOut& seg, uint32_t flags, const CompactFastArgs* prev,
                        const struct ClusterFillJob* fill, const struct ClusterWalkJob* walk, hipStream_t stream);

@@ -251,10 +251,7 @@ template <int PROP, bool INLINE_VIEWS, bool WITH_WALK>
 __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const ViewParams* __restrict__ dviews,
                                                 uint32_t n_views, VisibilityOut out, SegOut seg, uint32_t fl_frame, uint32_t n_tiles,
                                                 CompactFastArgs prev, uint32_t prev_gx, uint32_t n_compact, uint32_t n_fill, ClusterFillJob fill,
-                                                ClusterWalkJob walk, const uint8_t* __restrict__ changed, uint32_t tile_base) {
-    // tile_base: FRAME_ALL_TILES = the launch covers every tile (n_tiles of them); else a CHUNK of the frame, tiles tile_base ..
-    // tile_base + n_tiles - 1 -- an all-dirty frame whose Transforms are still arriving over PCIe runs chunk by chunk, each behind
-    // its own part of the upload (cull_frame, context.cpp)
+                                                ClusterWalkJob walk, const uint8_t* __restrict__ changed) {
     constexpr bool PROPAGATE = PROP == 1, PARTIAL = PROP == 2;
     // 16 KB + 16 B: the four waves' GlobalTransform transpose buffers (12 KB) -- or, in a riding cluster-fill workgroup, the CSR
     // offsets of up to 4096 clusters and the four wave totals of their scan -- or the arena of a riding cluster-walk workgroup
@@ -268,9 +265,7 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
     MI_TIMELINE(3);
     const uint32_t n_extra = gridDim.x - n_tiles;
     uint32_t tile = blockIdx.x - n_extra;
-    if (tile_base != FRAME_ALL_TILES) {
-        tile += tile_base;
-    } else if constexpr (WITH_WALK) {  // the tiles that go on into the cluster walk are handed out first (they run longest)
+    if constexpr (WITH_WALK) {  // the tiles that go on into the cluster walk are handed out first (they run longest)
         if (walk.inrow) {
             tile += walk.tile0;
             if (tile >= n_tiles) tile -= n_tiles;
@@ -626,6 +621,29 @@ __global__ void __launch_bounds__(256) k_level0_propagate(Columns c, uint32_t n_
     if ((threadIdx.x & 63u) == 0 && lv) c.g_changed_bits[row >> 6] = w;
 }
 
+// GlobalTransforms ahead of the frame (context.cpp, mi_commit_upload_window): rows lo .. hi-1 of a flat table, From(Transform) as
+// sync_simple_transforms writes it (systems.rs:45-50) -- the same affine_from_srt the frame kernels call -- into a buffer of the
+// library's own (not the GlobalTransform column: that one is the frame's to write), from where the copy engine takes them to the host
+// while later pieces of the upload are still arriving.
+__global__ void __launch_bounds__(256) k_globals_ahead(const float* __restrict__ t, const float* __restrict__ r, const float* __restrict__ s,
+                                                        uint32_t lo, uint32_t hi, float* __restrict__ out) {
+    __shared__ float4 lds_g[4][192];
+    const uint32_t row = (lo & ~63u) + blockIdx.x * 256u + threadIdx.x;
+    const bool live = row >= lo && row < hi;
+    Affine g = {};
+    if (live) g = affine_from_srt(ld3(s, row), ld4(r, row), ld3(t, row));
+    const uint32_t wave_row0 = row & ~63u;
+    // (wave-uniform) a wave wholly inside the piece stores its three contiguous 1 KB rows through the LDS transpose
+    if (wave_row0 >= lo && wave_row0 + 64u <= hi) store_affine_coalesced(lds_g[threadIdx.x >> 6], out, wave_row0, hi, threadIdx.x & 63u, g);
+    else if (live) st_affine(out, row, g);
+}
+hipError_t launch_globals_ahead(const float* t, const float* r, const float* s, uint32_t lo, uint32_t hi, float* out, hipStream_t stream) {
+    if (hi <= lo) return hipSuccess;
+    const uint32_t first = lo & ~63u;
+    hipLaunchKernelGGL(k_globals_ahead, dim3((hi - first + 255u) / 256u), dim3(256), 0, stream, t, r, s, lo, hi, out);
+    return hipGetLastError();
+}
+
 // reset_view_visibility: bits = (bits & 1) << 1 for rows without NoCpuCulling; clears the change mask.
 // RowSummary (kernels.h) of the waves first_wave .. first_wave + n_waves - 1, from the columns: a wave per 64 rows compares every
 // live row's bits with its first row's.  parts: ROWSUM_PART_AABB rewrites words 0-5 and the Aabb bit, ROWSUM_PART_FLAGS words 6-7's
@@ -923,12 +941,10 @@ hipError_t launch_upload_trs(const float* pinned_src, float* t, float* r, float*
 template <int PROP>
 static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views,
                                const VisibilityOut& out, const SegOut& seg, uint32_t flags, const CompactFastArgs* prev,
-                               const ClusterFillJob* fill, const ClusterWalkJob* walk, hipStream_t stream, const uint8_t* changed = nullptr,
-                               uint32_t tile_base = FRAME_ALL_TILES, uint32_t chunk_tiles = 0) {
+                               const ClusterFillJob* fill, const ClusterWalkJob* walk, hipStream_t stream, const uint8_t* changed = nullptr) {
     if (c.n == 0) return hipSuccess;
     if (!c.row_summary) return hipErrorInvalidValue;  // (the kernel loads it unconditionally: row_summary_ensure comes first)
-    const uint32_t n_tiles = tile_base == FRAME_ALL_TILES ? blocks_for(c.n) : chunk_tiles;
-    if (n_tiles == 0) return hipSuccess;
+    const uint32_t n_tiles = blocks_for(c.n);
     CompactFastArgs pa{};
     uint32_t prev_gx = 1, prev_blocks = 0;
     if (prev && prev->n && prev->n_segments) {
@@ -953,14 +969,14 @@ static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, co
     const dim3 grid(n_tiles + prev_blocks + fill_blocks + walk_blocks);
     if (with_walk) {
         MI_LAUNCH((k_frame<PROP, true, true>), grid, dim3(256), 0, stream, c, *views_inline, (const ViewParams*)nullptr, n_views, out, seg, flags,
-                  n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed, tile_base);
+                  n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed);
     } else if (n_views <= MAX_INLINE_VIEWS && views_inline) {
         MI_LAUNCH((k_frame<PROP, true, false>), grid, dim3(256), 0, stream, c, *views_inline, (const ViewParams*)nullptr, n_views, out, seg, flags,
-                  n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed, tile_base);
+                  n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed);
     } else {
         ViewSet dummy = {};
         MI_LAUNCH((k_frame<PROP, false, false>), grid, dim3(256), 0, stream, c, dummy, d_views, n_views, out, seg, flags, n_tiles, pa, prev_gx,
-                  prev_blocks, fill_blocks, fj, wj, changed, tile_base);
+                  prev_blocks, fill_blocks, fj, wj, changed);
     }
     return hipGetLastError();
 }
@@ -1017,9 +1033,9 @@ hipError_t launch_frame_sph(const Columns& c, const ViewSet* views_inline, const
 hipError_t launch_flat_propagate_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views,
                                       uint32_t n_views, const VisibilityOut& out, const SegOut& seg, uint32_t flags,
                                       const CompactFastArgs* prev, const ClusterFillJob* fill, const ClusterWalkJob* walk, hipStream_t stream,
-                                      const uint8_t* changed, uint32_t tile_base, uint32_t chunk_tiles) {
+                                      const uint8_t* changed) {
     if (changed) return launch_frame<2>(c, views_inline, d_views, n_views, out, seg, flags | CULL_BEGIN_FRAME, prev, fill, walk, stream, changed);
-    return launch_frame<1>(c, views_inline, d_views, n_views, out, seg, flags | CULL_BEGIN_FRAME, prev, fill, walk, stream, nullptr, tile_base, chunk_tiles);
+    return launch_frame<1>(c, views_inline, d_views, n_views, out, seg, flags | CULL_BEGIN_FRAME, prev, fill, walk, stream);
 }
 hipError_t launch_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views,
                        const VisibilityOut& out, const SegOut& seg, uint32_t flags, const CompactFastArgs* prev,

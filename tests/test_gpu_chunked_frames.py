@@ -1,9 +1,13 @@
-"""GPU parity of all-dirty end-to-end frames in pieces (context.cpp: mi_commit_upload_window with a dense window that carries
-every row, cull_frame running behind the pieces of the upload, mi_download_frame_results starting the GlobalTransforms back piece
-by piece): two contexts through the same frames, one with the pieces (default), one without (mi_debug_set_chunked_frames(1)),
-and the oracle for the GlobalTransforms -- changed rows, their GlobalTransforms, VisibleEntities, cluster lists, ViewVisibility,
-in place and copied out, with the cluster walk inside the rows' workgroups (row-range binding) and in workgroups of its own (row
-list), and with other calls between the upload and the frame (which must wait for the whole upload)."""
+"""GPU parity of dense uploads in pieces with the GlobalTransforms fetched ahead of the frame (context.cpp: mi_commit_upload_window
+-- a sequence of dense windows that carries the whole flat table goes out piece by piece on a stream of its own, each piece's
+GlobalTransforms are computed at once and start back to the host while the later pieces still arrive -- and
+mi_download_frame_results, which hands them out when the frame in between was an all-rows one over the same Transforms): two
+contexts through the same frames, one with the pieces, one without (mi_debug_set_chunked_frames(1)), and the oracle for the
+GlobalTransforms -- changed rows, their GlobalTransforms, VisibleEntities, cluster lists, ViewVisibility, in place and copied out;
+one window for the whole table and several windows committed one after the other; sequences that are broken off, windows out of
+order, Transforms written again between the upload and the frame (what was fetched ahead no longer applies), frames that are
+not all-rows frames.  The reference has no counterpart (sync_simple_transforms writes in place, systems.rs:45-50): what is pinned
+is that the library's two ways deliver the same bytes."""
 import numpy as np
 import pytest
 
@@ -23,9 +27,9 @@ def frame_inputs(frame):
     return fr, view, keep
 
 
-@pytest.mark.parametrize("binding", ["range", "list"])
+@pytest.mark.parametrize("binding,mode", [("range", 0), ("list", 0), ("range", 2)])
 @pytest.mark.parametrize("in_place", [True, False])
-def test_all_dirty_frames_in_pieces(binding, in_place):
+def test_all_dirty_frames_in_pieces(binding, mode, in_place):
     n_cubes, n_lights = 300_000, 3_000
     sc, first_light, pr = W.frame_scene(n_cubes, n_lights, 500, light_range=3.0)
     n = sc["n"]
@@ -35,6 +39,7 @@ def test_all_dirty_frames_in_pieces(binding, in_place):
     t = sc["translation"].reshape(n, 3).copy()
     rng = np.random.default_rng(4)
     ctxs = [api.Context(0), api.Context(0)]
+    ctxs[0].debug_set_chunked_frames(mode)  # 0: fetches ahead once the caller has fetched every GlobalTransform of such a frame; 2: always
     ctxs[1].debug_set_chunked_frames(1)
     try:
         for ctx in ctxs:
@@ -84,9 +89,10 @@ def test_all_dirty_frames_in_pieces(binding, in_place):
             assert a["cluster_total"] > 0 and len(a["visible_rows"]) > 0
             if frame == 3:
                 assert a["g_direct"].tobytes() == g.tobytes()
-        # the pieces were taken where they should have been: every frame of the first context (one more upload in frame 3 was joined
-        # by the mi_propagate behind it), none of the second
-        assert ctxs[0].debug_chunked_counts() == (5, 5) and ctxs[1].debug_chunked_counts() == (0, 0)
+        # the pieces were taken where they should have been: six dense windows went out in pieces; with the default rule the first
+        # frame fetches the usual way (and shows that the caller wants them all), frame 3's first upload was fetched ahead for nothing
+        # (mi_propagate + a direct download came between), so its second upload did not fetch ahead and its download asked again
+        assert ctxs[0].debug_chunked_counts() == ((6, 3) if mode == 0 else (6, 5)) and ctxs[1].debug_chunked_counts() == (0, 0)
     finally:
         for ctx in ctxs:
             ctx.close()
@@ -119,3 +125,100 @@ def test_an_indexed_upload_after_a_dense_one():
             ctx.propagate_and_cull(fr, flags=B.CULL_END_FRAME | B.CULL_CHANGED_ROWS)
             g, _ = O.sync_simple_transforms(t.reshape(-1), sc["rotation"], sc["scale"])
             assert ctx.download_global_transforms(want_changed=False).tobytes() == g.tobytes(), f"frame {frame}"
+
+
+def run_frames(ctx, sc, n, frames, upload, frame_flags=0, view=None):
+    """frames x (upload(ctx, frame, t) -> an all-rows frame -> results in place); returns per frame (rows, G, visible rows)."""
+    out = []
+    for frame in range(frames):
+        t = upload(ctx, frame)
+        fr, _, _ = frame_inputs(frame)
+        ctx.propagate_and_cull(fr, flags=B.CULL_END_FRAME | frame_flags)
+        got = ctx.download_frame_results(api.FrameResultBuffers(n, n, 0, 0, in_place=True))
+        out.append((np.array(got["changed_rows"]).copy(), np.array(got["changed_global"]).copy(), np.array(got["visible_rows"]).copy(), t.copy()))
+    return out
+
+
+def dense(ctx, lo, hi, t, sc):
+    w, _, wt, wr, ws = ctx.map_upload_window(hi - lo, dense=True)
+    wt[:] = t[lo:hi].reshape(-1)
+    wr[:] = sc["rotation"].reshape(-1, 4)[lo:hi].reshape(-1)
+    ws[:] = sc["scale"].reshape(-1, 3)[lo:hi].reshape(-1)
+    ctx.commit_upload_window(w, hi - lo, first_row=lo)
+
+
+@pytest.mark.parametrize("pattern", ["eight windows", "ragged windows", "broken off", "out of order", "twenty windows", "written again"])
+def test_windows_committed_one_after_the_other(pattern):
+    """The caller fills and commits the table a window at a time (the upload of one crosses PCIe while it fills the next)."""
+    n = 270_001
+    sc = W.many_cubes(n, radius=80.0)
+    t0 = sc["translation"].reshape(n, 3).copy()
+    cuts = {"eight windows": [n * k // 8 for k in range(9)], "ragged windows": [0, 1, 100_001, 100_002, 250_000, n],
+            "broken off": [0, n // 3, 2 * n // 3, n], "out of order": [0, n // 2, n], "twenty windows": [n * k // 20 for k in range(21)],
+            "written again": [0, n // 2, n]}[pattern]
+    results = []
+    for mode in (2, 1):
+        with api.Context(0) as ctx:
+            ctx.debug_set_chunked_frames(mode)
+            ctx.resize(n)
+            ctx.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
+            ctx.upload_bounds(sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"])
+            t = t0.copy()
+            rng = np.random.default_rng(21)
+
+            def upload(ctx, frame):
+                t[:] += rng.normal(0.0, 0.4, (n, 3)).astype(F)
+                pieces = list(zip(cuts[:-1], cuts[1:]))
+                if pattern == "out of order":
+                    pieces = pieces[::-1]
+                for k, (lo, hi) in enumerate(pieces):
+                    dense(ctx, lo, hi, t, sc)
+                    if pattern == "broken off" and k == 0:  # another call between two windows: the next one starts over
+                        ctx.upload_visibility_classes(np.ones(n, np.uint32))
+                if pattern == "written again":  # some rows move once more: what was fetched ahead is not this frame's
+                    rows = np.arange(7, n, 1009, dtype=np.uint32)
+                    t[rows] += F(2.0)
+                    ctx.upload_transforms_indexed(rows, t[rows].reshape(-1), sc["rotation"].reshape(n, 4)[rows].reshape(-1), sc["scale"].reshape(n, 3)[rows].reshape(-1))
+                return t
+
+            results.append(run_frames(ctx, sc, n, 3, upload))
+            if mode == 2:
+                ahead = ctx.debug_chunked_counts()[1]
+                assert ahead == (3 if pattern in ("eight windows", "ragged windows") else 0), f"{pattern}: {ahead} downloads handed out what was fetched ahead"
+    for frame, (a, b) in enumerate(zip(*results)):
+        g, _ = O.sync_simple_transforms(a[3].reshape(-1), sc["rotation"], sc["scale"])
+        assert np.array_equal(a[0], np.arange(n, dtype=np.uint32)) and np.array_equal(a[0], b[0])
+        assert a[1].tobytes() == g.tobytes(), f"{pattern}, frame {frame}: GlobalTransforms against the oracle"
+        assert a[1].tobytes() == b[1].tobytes() and np.array_equal(a[2], b[2]), f"{pattern}, frame {frame}: the two forms differ"
+
+
+def test_a_changed_rows_frame_behind_a_dense_upload_fetches_the_usual_way():
+    """Every Transform arrives, but the frame propagates the marked rows only: what was fetched ahead is not what the frame wrote."""
+    n = 270_000
+    sc = W.many_cubes(n, radius=80.0)
+    t = sc["translation"].reshape(n, 3).copy()
+    with api.Context(0) as ctx:
+        ctx.debug_set_chunked_frames(2)
+        ctx.resize(n)
+        ctx.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
+        ctx.upload_bounds(sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"])
+        fr, _, _ = frame_inputs(0)
+        ctx.upload_changed(np.zeros(n, np.uint8))
+        ctx.propagate_and_cull(fr, flags=B.CULL_END_FRAME)
+        g_before = ctx.download_global_transforms(want_changed=False).reshape(n, 12).copy()
+        t += F(0.5)
+        dense(ctx, 0, n, t, sc)
+        marks = np.zeros(n, np.uint8)
+        marks[::3] = 1
+        ctx.upload_changed(marks)
+        ctx.propagate_and_cull(fr, flags=B.CULL_END_FRAME | B.CULL_CHANGED_ROWS)
+        got = ctx.download_frame_results(api.FrameResultBuffers(n, n, 0, 0, in_place=True))
+        g, _ = O.sync_simple_transforms(t.reshape(-1), sc["rotation"], sc["scale"])
+        rows = np.arange(0, n, 3, dtype=np.uint32)
+        assert np.array_equal(np.array(got["changed_rows"]), rows)
+        assert np.array(got["changed_global"]).reshape(-1, 12).tobytes() == g.reshape(n, 12)[rows].tobytes()
+        g_now = ctx.download_global_transforms(want_changed=False).reshape(n, 12)
+        keep = np.ones(n, bool)
+        keep[rows] = False
+        assert g_now[keep].tobytes() == g_before[keep].tobytes()  # the rows that were not marked keep their GlobalTransform
+        assert ctx.debug_chunked_counts()[1] == 0

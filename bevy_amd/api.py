@@ -863,11 +863,11 @@ class Context:
         self._ck(self._lib.mi_debug_set_tile_pretest(self._h, int(mode)))
 
     def debug_set_chunked_frames(self, mode):
-        """0 = a dense upload of the whole Transform table, the all-rows frame and its result download run in overlapping pieces from 262144 rows (default), 1 = never, 2 = at any row count."""
+        """Dense windows that carry the whole table go out in pieces and their GlobalTransforms are fetched ahead of the frame: 0 = tables of 262144 rows and more (default), 1 = never, 2 = any row count, fetching ahead at once."""
         self._ck(self._lib.mi_debug_set_chunked_frames(self._h, int(mode)))
 
     def debug_chunked_counts(self):
-        """(frames that ran in pieces, result downloads that delivered GlobalTransforms fetched in pieces)."""
+        """(dense windows that went out as pieces of a sequence, result downloads that handed out GlobalTransforms fetched ahead)."""
         a, b = C.c_uint32(0), C.c_uint32(0)
         self._ck(self._lib.mi_debug_chunked_counts(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value

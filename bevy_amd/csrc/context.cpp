@@ -2118,8 +2118,8 @@ int32_t mi_debug_set_tile_pretest(mi_ctx* ctx, int32_t mode) {
     return MI_OK;
 }
 
-// test / bench hook: a dense upload of the whole Transform table, the all-rows frame behind it and its result download in pieces
-// that overlap (FRAME_CHUNKS, ctx.h): 0 = yes, from 262144 rows (default), 1 = never, 2 = at any size (tests)
+// test / bench hook: dense uploads in pieces with the GlobalTransforms fetched ahead (ctx.h): 0 = tables of >= 262144 rows (default),
+// 1 = never, 2 = any row count, fetching ahead from the first sequence on (tests)
 int32_t mi_debug_set_chunked_frames(mi_ctx* ctx, int32_t mode) {
     ENTER(ctx);
     if (mode < 0 || mode > 2) return fail(ctx, MI_ERR_INVALID_ARG, "mi_debug_set_chunked_frames: mode %d", mode);
@@ -2128,9 +2128,9 @@ int32_t mi_debug_set_chunked_frames(mi_ctx* ctx, int32_t mode) {
 }
 
 // test hook: how many dense windows went out as pieces of a sequence, and how many result downloads handed out GlobalTransforms fetched ahead
-int32_t mi_debug_chunked_counts(mi_ctx* ctx, uint32_t* out_frames /* windows */, uint32_t* out_downloads) {
+int32_t mi_debug_chunked_counts(mi_ctx* ctx, uint32_t* out_windows, uint32_t* out_downloads) {
     ENTER_RAW(ctx);
-    if (out_frames) *out_frames = ctx->n_piece_uploads;
+    if (out_windows) *out_windows = ctx->n_piece_uploads;
     if (out_downloads) *out_downloads = ctx->n_ahead_downloads;
     return MI_OK;
 }

@@ -414,9 +414,31 @@ class Mi355xPlugin {
         // every row moved: the dense window (filled by row, DMA straight from it); otherwise rows + values for the scatter kernel
         const bool dense = n_in == n;
         mi_upload_window win{};
+        double commit_in_gather_s = 0;
+        if (dense && n >= 65536u) {
+            // The whole table, by row, a window at a time: window k crosses PCIe while this loop fills window k + 1, and the
+            // library -- which sees a sequence of dense windows that carries every row -- computes each window's
+            // GlobalTransforms at once and sends them back under the rest of the upload; the results call below finds them here.
+            const uint32_t pieces = 8;
+            for (uint32_t p = 0; p < pieces; ++p) {
+                const uint32_t lo = (uint32_t)((uint64_t)n * p / pieces), hi = (uint32_t)((uint64_t)n * (p + 1) / pieces);
+                check(mi_map_upload_window(ctx_, hi - lo, MI_UPLOAD_DENSE, &win));
+                for (uint32_t row = lo; row < hi; ++row) {
+                    const World::Rec& e = w.rec_[entity_of_row_[row].index];
+                    std::memcpy(win.translation + 3 * (size_t)(row - lo), &e.transform.translation, 12);
+                    std::memcpy(win.rotation + 4 * (size_t)(row - lo), &e.transform.rotation, 16);
+                    std::memcpy(win.scale + 3 * (size_t)(row - lo), &e.transform.scale, 12);
+                }
+                const auto tc = std::chrono::steady_clock::now();
+                check(mi_commit_upload_window(ctx_, &win, hi - lo, lo));
+                commit_in_gather_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc).count();
+            }
+            n_in = 0;  // (committed)
+            win = mi_upload_window{};
+        } else
         check(mi_map_upload_window(ctx_, n_in, dense ? MI_UPLOAD_DENSE : 0u, &win));
         uint32_t k = 0;
-        for (uint32_t i : w.touched_) {
+        if (win.capacity) for (uint32_t i : w.touched_) {
             const World::Rec& e = w.rec_[i];
             if (!e.alive || !(e.transform_changed || e.added || e.parent_changed || e.orphaned)) continue;
             const uint32_t row = row_of_index_[i];
@@ -428,10 +450,10 @@ class Mi355xPlugin {
             ++k;
         }
         const auto t_gathered = std::chrono::steady_clock::now();
-        check(mi_commit_upload_window(ctx_, &win, n_in, 0));
+        if (win.capacity) check(mi_commit_upload_window(ctx_, &win, n_in, 0));
         // (every row moved: the frame below is the all-rows frame -- no change bytes to raise, and nothing between the upload and the
         // frame that would have to wait for it: the library then runs upload, frame and result download in overlapping pieces)
-        if (n_in == 0) {  // keep "nothing changed" distinct from "no change information" (= all dirty)
+        if (n_in == 0 && !dense) {  // keep "nothing changed" distinct from "no change information" (= all dirty)
             const uint8_t zero = 0;
             check(mi_upload_changed(ctx_, 0, 1, &zero));
         }
@@ -520,8 +542,8 @@ class Mi355xPlugin {
             }
         }
         const auto t_end = std::chrono::steady_clock::now();
-        out.gather_s = std::chrono::duration<double>(t_gathered - t_start).count();
-        out.device_s = std::chrono::duration<double>(t_results - t_gathered).count();
+        out.gather_s = std::chrono::duration<double>(t_gathered - t_start).count() - commit_in_gather_s;
+        out.device_s = std::chrono::duration<double>(t_results - t_gathered).count() + commit_in_gather_s;
         out.apply_s = std::chrono::duration<double>(t_end - t_results).count();
         return out;
     }

@@ -512,11 +512,14 @@ int32_t mi_cluster_download(mi_ctx* ctx, uint32_t* out_offsets, uint32_t* out_in
  * library SETS the pointers to the data where it lies in the pinned window -- no copy; the caller reads it in place (e.g. while
  * writing the ECS components), must not write to it, and must be done before its next call on this context.  Capacities still bound
  * what is fetched.
- * When every row's GlobalTransform changed -- a dense upload window that carried the whole table (mi_commit_upload_window) and the
- * all-rows frame behind it -- the three run in pieces that overlap: the frame's kernel follows the upload piece by piece, and this
- * call starts the GlobalTransforms back behind each piece while the later pieces of the upload are still arriving (PCIe is full
- * duplex); the changed-row list of such a frame is 0 .. n-1 and is not fetched at all.  Nothing to ask for; any other call between
- * the three waits for the whole upload first.
+ * Every GlobalTransform of a flat table, every frame (the all-dirty case): commit the Transforms as a SEQUENCE of dense windows that
+ * carries the whole table in ascending order -- one window for every row, or several committed one after the other, each starting
+ * where the one before ended (mi_commit_upload_window; the caller fills window k + 1 while window k crosses PCIe) -- then run the
+ * all-rows frame and ask for the changed GlobalTransforms here.  From the second such frame on the library computes each window's
+ * GlobalTransforms as soon as it has arrived and sends them back under the rest of the upload (PCIe is full duplex); this call then
+ * finds them on the host.  They are handed out only when the frame in between rewrote every row from exactly those Transforms
+ * (any other upload, resize or hierarchy in between: fetched the usual way); the changed-row list of such a frame is 0 .. n-1 and is
+ * never fetched.  Nothing to switch on, same results either way.
  * Counts are always filled in for the parts that ran; MI_ERR_CAPACITY if a list exceeds its capacity (counts are valid, that list
  * was not delivered, the others were). */
 #define MI_RESULTS_CHANGED_ROWS 0x1u

@@ -49,12 +49,15 @@ int32_t mi_debug_set_sorted_one_wg_limit(mi_ctx* ctx, uint32_t items);
 /* The flags-first test of the light tile kernel under the static-scene rule (kernels_tree.hip): 0 = when few rows changed since the
  * last propagate (default), 1 = never, 2 = always. */
 int32_t mi_debug_set_tile_pretest(mi_ctx* ctx, int32_t mode);
-/* All-dirty end-to-end frames in pieces: a dense window that carries EVERY row's Transform is uploaded in 8 pieces on a stream of
- * its own, the all-rows frame runs piece by piece behind them, and mi_download_frame_results starts the changed GlobalTransforms
- * (all of them) back piece by piece, so that the two PCIe directions overlap.  0 = yes, from 262144 rows (default), 1 = never, 2 = at any row count.  Same results. */
+/* Dense uploads in pieces with the GlobalTransforms fetched ahead (bevy_mi355x.h, mi_download_frame_results): a sequence of dense
+ * windows that carries the whole flat table goes out piece by piece on a stream of its own, and -- once the caller has fetched every
+ * GlobalTransform of such a frame -- each piece's GlobalTransforms are computed at once and sent back under the rest of the upload.
+ * 0 = tables of 262144 rows and more (default), 1 = never, 2 = any row count and fetching ahead from the first sequence on.  Same
+ * results. */
 int32_t mi_debug_set_chunked_frames(mi_ctx* ctx, int32_t mode);
-/* How many frames ran in pieces / how many mi_download_frame_results calls delivered GlobalTransforms fetched in pieces (tests). */
-int32_t mi_debug_chunked_counts(mi_ctx* ctx, uint32_t* out_frames, uint32_t* out_downloads);
+/* How many dense windows went out as pieces of such a sequence / how many mi_download_frame_results calls handed out GlobalTransforms
+ * fetched ahead (tests). */
+int32_t mi_debug_chunked_counts(mi_ctx* ctx, uint32_t* out_windows, uint32_t* out_downloads);
 /* The cluster walk of a MI_CULL_WITH_CLUSTERS frame whose objects are bound to a row RANGE: 0 = the frame kernel's row workgroups
  * of those rows go on into the walk (default), 1 = extra workgroups re-derive the rows' visibility (as for row lists).  Same results. */
 int32_t mi_debug_set_walk_inrow(mi_ctx* ctx, int32_t mode);

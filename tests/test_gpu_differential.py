@@ -8,7 +8,7 @@ agree on everything a caller can download after every step; at intervals the ora
     cluster walk in the rows' own workgroups              mi_debug_set_walk_inrow(1)
     tile pre-test of change-driven hierarchy frames       mi_debug_set_tile_pretest(1)    [A: forced, mode 2]
     hierarchy frame fused into the tile launches          (B: two launches)               [A: mi_debug_set_tree_cull(2)]
-    all-dirty frames in pieces (upload / frame / results) mi_debug_set_chunked_frames(1)  [A: at any row count, mode 2]
+    dense uploads in pieces, GlobalTransforms fetched ahead mi_debug_set_chunked_frames(1)  [A: at any row count, mode 2]
 
 The sequences mix: bounds uploads (whole, partial, single rows), RenderLayers above 31, Transform uploads (indexed, ranges),
 change marks, growth and shrinkage of the row count, Visibility changes propagated on the device, VisibilityClass masks, one to
@@ -216,7 +216,7 @@ def test_fast_paths_are_interchangeable(seed):
                 sc.t[rows] += rng.normal(0.0, 3.0, (k, 3)).astype(F)
                 for ctx in (a, b):
                     ctx.upload_transforms_indexed(rows, sc.t[rows].reshape(-1), sc.r[rows].reshape(-1), sc.s[rows].reshape(-1))
-            elif op == 6 and not forest:  # every Transform moves and arrives in one dense window: upload, frame and results run in pieces
+            elif op == 6 and not forest:  # every Transform moves and arrives in one dense window: it goes out in pieces, GlobalTransforms fetched ahead
                 sc.t[:n] += rng.normal(0.0, 0.5, (n, 3)).astype(F)
                 for ctx in (a, b):
                     w, _, wt, wr, ws = ctx.map_upload_window(n, dense=True)
@@ -248,7 +248,7 @@ def test_fast_paths_are_interchangeable(seed):
                     ctx.propagate((B.PROPAGATE_ALL_DIRTY if kind == "split_all" else 0) | (B.PROPAGATE_STATIC_OPT if forest else 0))
                     ctx.cull_views(views, flags=flags | B.CULL_BEGIN_FRAME)
             had_clusters = had_clusters or with_clusters
-            if op == 6 and not forest:  # the results in one call (in pieces in A when the frame was an all-rows one)
+            if op == 6 and not forest:  # the results in one call (fetched ahead in A when the frame was an all-rows one)
                 res = []
                 for ctx in (a, b):
                     got = ctx.download_frame_results(api.FrameResultBuffers(n, n, 0, 0, in_place=bool(step % 2)))
@@ -275,7 +275,7 @@ def test_fast_paths_are_interchangeable(seed):
                                                         np.zeros(n, np.uint8), fr, vm_lo, vm_hi)
                 for v in range(n_views - (1 if shadow_view else 0)):  # (the 64-layer restatement knows camera views only)
                     assert np.array_equal(np.frombuffer(sa[f"mask {v}"], np.uint8), vis[v]), f"seed {seed} step {step}: mask of view {v} against the oracle"
-        PIECES[0] += a.debug_chunked_counts()[0]
+        PIECES[0] += a.debug_chunked_counts()[1]
         assert b.debug_chunked_counts() == (0, 0)
     finally:
         a.close()
@@ -286,7 +286,7 @@ PIECES = [0]
 
 
 def test_the_pieces_were_taken():
-    """(runs after the seeds above) some of their all-rows frames behind a dense upload did run in pieces in the fast context."""
+    """(runs after the seeds above) some of their dense uploads did go out in pieces, with results fetched ahead, in the fast context."""
     assert PIECES[0] > 0
 
 

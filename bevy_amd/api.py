@@ -867,10 +867,11 @@ class Context:
         self._ck(self._lib.mi_debug_set_chunked_frames(self._h, int(mode)))
 
     def debug_chunked_counts(self):
-        """(dense windows that went out as pieces of a sequence, result downloads that handed out GlobalTransforms fetched ahead)."""
-        a, b = C.c_uint32(0), C.c_uint32(0)
-        self._ck(self._lib.mi_debug_chunked_counts(self._h, C.byref(a), C.byref(b)))
-        return a.value, b.value
+        """(dense windows that went out as pieces of a sequence, result downloads that handed out GlobalTransforms fetched ahead of an
+        all-rows frame, ... written ahead by the indexed window of a changed-rows frame)."""
+        a, b, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        self._ck(self._lib.mi_debug_chunked_counts(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def debug_set_walk_inrow(self, mode):
         """0 = objects bound to a row range are walked by the frame kernel's own row workgroups (default), 1 = by extra workgroups."""

@@ -576,6 +576,10 @@ static int32_t cull_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, u
         if (!ctx->have_hierarchy) ctx->frame_all_version = ctx->trs_version;  // (= From(Transform) of every row: what a fetch ahead holds)
     } else if (PROPAGATE)                              // k_frame<2>: the rewritten rows are this frame's change mask
         ctx->sph_state = ctx->sph_state == mi_ctx::SPH_VALID ? mi_ctx::SPH_EXCEPT_CHANGED : mi_ctx::SPH_INVALID;
+    // a changed-rows frame of a flat table: its change mask is exactly the rows of the one indexed upload since the column was clean, if
+    // nothing else raised a mark or wrote a Transform in between (either frame kernel)
+    if (PROPAGATE && changed_col)
+        ctx->gs_frame_ok = ctx->gs_k && !ctx->have_hierarchy && ctx->gs_frame_serial && ctx->gs_frame_serial == ctx->marks_serial && ctx->gs_trs_version == ctx->trs_version;
     if (!PROPAGATE || changed_col) ++ctx->sph_quiet;
     if (prev && ctx->n == 0) HIP_TRY(ctx, launch_compact_fast(*prev, ctx->stream));  // no frame kernel to ride in
     if (prev_has_job) exchange_push(ctx, prev_job);  // the launch that publishes the previous frame's signal is submitted
@@ -664,6 +668,7 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
     }
     if (ctx->g_host) hipHostFree(ctx->g_host);
     if (ctx->iota_host) hipHostFree(ctx->iota_host);
+    if (ctx->gs_host) hipHostFree(ctx->gs_host);
     if (ctx->piece_streams) {
         hipStreamSynchronize(ctx->up_stream);
         hipStreamSynchronize(ctx->dn_stream);
@@ -763,7 +768,7 @@ int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
         ctx->cl_inputs_dirty = true;
     }
     ctx->bt_resolve = true;
-    ctx->changed_maybe = true;
+    ctx->changed_maybe = true, ++ctx->marks_serial;
     if (n_rows != ctx->n) {
         ctx->sph_state = mi_ctx::SPH_INVALID;
         const uint32_t a = std::min(n_rows, ctx->n) & ~63u, b = std::max(n_rows, ctx->n);  // the wave the old end lies in and everything behind
@@ -789,7 +794,7 @@ int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
         if ((rc = grow_column(ctx, ctx->flags, 1, old, new_cap, MI_FLAG_INHERITED_VISIBLE))) return rc;
         if ((rc = grow_column(ctx, ctx->vv, 1, old, new_cap, 0))) return rc;
         if ((rc = grow_column(ctx, ctx->changed, 1, old, new_cap, 1))) return rc;
-        ctx->changed_maybe = true;
+        ctx->changed_maybe = true, ++ctx->marks_serial;
         if ((rc = grow_column(ctx, ctx->g_changed_bytes, 1, old, new_cap, 0))) return rc;
         if ((rc = grow_column(ctx, ctx->layers, 1, old, new_cap, 0))) return rc;
         if (ctx->layers_hi && (rc = grow_column(ctx, ctx->layers_hi, 1, old, new_cap, 0))) return rc;
@@ -905,8 +910,32 @@ int32_t mi_upload_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t n, const 
 }
 
 // rows / t / r / s lie in the pinned arena: one scatter kernel reads them over PCIe and raises the rows' change bytes
-static int32_t scatter_indexed(mi_ctx* ctx, const uint32_t* rows, const float* t, const float* r, const float* s, uint32_t n) {
+// window_rows_ascending: rows lie in an upload window (they stay put until the windows are recycled) and are strictly ascending
+static int32_t scatter_indexed(mi_ctx* ctx, const uint32_t* rows, const float* t, const float* r, const float* s, uint32_t n,
+                               bool window_rows_ascending = false) {
     trs_written(ctx);
+    // ---- GlobalTransforms ahead of the changed-rows frame (ctx.h): only when this upload's rows will be exactly the frame's ----
+    const bool column_clean = !ctx->changed_maybe && (ctx->have_changed || ctx->propagated_rows >= ctx->n);
+    if (ctx->gs_k && !ctx->gs_used && ctx->chunk_mode != 2) ctx->sparse_ahead_wanted = false;  // (the last one was written for nothing)
+    ctx->gs_k = 0;
+    ctx->gs_frame_ok = false;
+    ctx->gs_used = false;
+    float* g_ahead = nullptr;
+    if (window_rows_ascending && column_clean && ctx->chunk_mode != 1 && (ctx->sparse_ahead_wanted || ctx->chunk_mode == 2) && !ctx->have_hierarchy &&
+        !ctx->xch.on) {
+        if (ctx->gs_host_bytes < (size_t)n * 48) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (a scatter launch may still be writing the old one)
+            if (ctx->gs_host) HIP_TRY(ctx, hipHostFree(ctx->gs_host));
+            ctx->gs_host = nullptr;
+            ctx->gs_host_bytes = 0;
+            const size_t want = std::max<size_t>((size_t)n * 48 * 3 / 2, (size_t)1 << 20);
+            HIP_TRY(ctx, hipHostMalloc(&ctx->gs_host, want, hipHostMallocMapped));
+            ctx->gs_host_bytes = want;
+        }
+        void* d = nullptr;
+        HIP_TRY(ctx, hipHostGetDevicePointer(&d, ctx->gs_host, 0));
+        g_ahead = (float*)d;
+    }
     void *d_rows = nullptr, *d_t = nullptr, *d_r = nullptr, *d_s = nullptr;
     HIP_TRY(ctx, hipHostGetDevicePointer(&d_rows, (void*)rows, 0));
     HIP_TRY(ctx, hipHostGetDevicePointer(&d_t, (void*)t, 0));
@@ -932,7 +961,7 @@ static int32_t scatter_indexed(mi_ctx* ctx, const uint32_t* rows, const float* t
         other = (uint32_t*)(ctx->tree_bytes + (size_t)(ctx->tree_parity ^ 1u) * ctx->tree_half_words * 4);
     HIP_TRY(ctx, launch_upload_trs_indexed((const uint32_t*)d_rows, (const float*)d_t, (const float*)d_r, (const float*)d_s, n, ctx->t, ctx->r,
                                            ctx->s, ctx->changed, ctx->changed_gen, ctx->stream, mark_here ? (const uint32_t*)ctx->parent_idx.p : nullptr,
-                                           cur, other, ctx->tree_half_words, ctx->anc_valid ? (const uint32_t*)ctx->anc.p : nullptr));
+                                           cur, other, ctx->tree_half_words, ctx->anc_valid ? (const uint32_t*)ctx->anc.p : nullptr, g_ahead));
     if (mark_here) {
         if (!ctx->marks_in_cur) ctx->marks_complete = !ctx->changed_maybe;  // complete so far iff nothing was marked changed before this upload
         ctx->marks_in_cur = true;
@@ -943,8 +972,14 @@ static int32_t scatter_indexed(mi_ctx* ctx, const uint32_t* rows, const float* t
     } else {
         ctx->marks_complete = false;
     }
-    ctx->changed_maybe = true;
+    ctx->changed_maybe = true, ++ctx->marks_serial;
     if (ctx->changed_rows_hint != UINT64_MAX) ctx->changed_rows_hint += n;
+    if (g_ahead) {
+        ctx->gs_k = n;
+        ctx->gs_rows = rows;
+        ctx->gs_marks_serial = ctx->marks_serial;
+        ctx->gs_trs_version = ctx->trs_version;
+    }
     return MI_OK;
 }
 
@@ -1102,9 +1137,14 @@ int32_t mi_commit_upload_window(mi_ctx* ctx, const mi_upload_window* w, uint32_t
         HIP_TRY(ctx, hipMemcpyAsync(ctx->s + 3 * (size_t)first_row, w->scale, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
         return MI_OK;
     }
-    for (uint32_t i = 0; i < n; ++i)
-        if (w->rows[i] >= ctx->n) return fail(ctx, MI_ERR_INVALID_ARG, "mi_commit_upload_window: row %u >= %u live rows", w->rows[i], ctx->n);
-    return scatter_indexed(ctx, w->rows, w->translation, w->rotation, w->scale, n);
+    uint32_t top = 0, ascending = 1;  // (rows of a Changed<Transform> query in row order: what the results of the frame will list)
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t row = w->rows[i];
+        ascending &= (uint32_t)(i == 0 || row > w->rows[i - 1]);
+        top = std::max(top, row);
+    }
+    if (top >= ctx->n) return fail(ctx, MI_ERR_INVALID_ARG, "mi_commit_upload_window: row %u >= %u live rows", top, ctx->n);
+    return scatter_indexed(ctx, w->rows, w->translation, w->rotation, w->scale, n, ascending != 0);
 }
 
 int32_t mi_upload_global_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t n, const float* global12) {
@@ -1196,7 +1236,7 @@ int32_t mi_upload_changed(mi_ctx* ctx, uint32_t first_row, uint32_t n, const uin
     int32_t rc = check_rows(ctx, first_row, n, "mi_upload_changed");
     if (rc) return rc;
     ctx->have_changed = true;
-    ctx->changed_maybe = true;
+    ctx->changed_maybe = true, ++ctx->marks_serial;
     ctx->changed_rows_hint = UINT64_MAX;  // how many of these bytes are set is not known here
     ctx->marks_complete = false;          // rows marked changed without a climb
     ctx->changed_bulk = true;             // plain 0 / 1 bytes, not stamps (a caller's 1 must not look like a past generation either:
@@ -1232,6 +1272,12 @@ int32_t mi_upload_visibility(mi_ctx* ctx, uint32_t first_row, uint32_t n, const 
 // =============================================================================================
 int32_t mi_propagate(mi_ctx* ctx, uint32_t flags) {
     ENTER(ctx);
+    // (the change mask is this call's from here on -- whatever was written ahead of another frame does not describe it -- and the marks
+    // of the upload that wrote ahead are consumed by this call, whichever way it goes)
+    ctx->gs_frame_ok = false;
+    ctx->gs_frame_serial = ctx->gs_marks_serial;
+    ctx->gs_marks_serial = 0;
+    ctx->frame_all_version = 0;
     if (ctx->n == 0) return MI_OK;
     const bool all_dirty = (flags & MI_PROPAGATE_ALL_DIRTY) != 0 || !ctx->have_changed;
     const bool static_opt = (flags & MI_PROPAGATE_STATIC_OPT) != 0;
@@ -1484,6 +1530,10 @@ static int32_t tree_frame_fused(mi_ctx* ctx, const mi_view* views, uint32_t n_vi
 
 int32_t mi_propagate_and_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint32_t flags) {
     ENTER(ctx);
+    ctx->gs_frame_ok = false;  // (as in mi_propagate)
+    ctx->gs_frame_serial = ctx->gs_marks_serial;
+    ctx->gs_marks_serial = 0;
+    ctx->frame_all_version = 0;
     if (ctx->have_hierarchy && views && n_views && tree_frame_fusable(ctx, n_views, flags)) return tree_frame_fused(ctx, views, n_views, flags);
     if (ctx->have_hierarchy) {
         // With a hierarchy the frame is the tile launches of mi_propagate with the cull behind them: the same call for the
@@ -1725,7 +1775,10 @@ int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
         if (!ctx->cl_assigned) return fail(ctx, MI_ERR_NOT_READY, "mi_download_frame_results: clusters before an assignment");
         if ((rc = cluster_join(ctx))) return rc;
     }
-    if (want_changed && (rc = changed_rows_on_device(ctx, nullptr))) return rc;
+    // the changed rows are those of one indexed upload window and their GlobalTransforms were written ahead (ctx.h): nothing to compact,
+    // gather or fetch -- unless the window below turns out too small for the rest (then the usual way, further down)
+    bool sparse_ahead = want_changed && ctx->gs_frame_ok && ctx->gs_k && ctx->gs_k <= io->changed_capacity && !ctx->have_hierarchy;
+    if (want_changed && !sparse_ahead && (rc = changed_rows_on_device(ctx, nullptr))) return rc;
     uint32_t changed = 0;
     uint64_t cl_total = 0;
     const uint32_t C = ctx->cl_view.n_clusters;
@@ -1733,8 +1786,8 @@ int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
     const uint32_t* acc = want_clusters ? (const uint32_t*)ctx->cl_acc.p + ctx->cl_parity * (off_misc + 4) : nullptr;
     // worst case of every section: what the window (or, on the fallback path, the arena) has to hold
     uint64_t need = 0;
-    if (want_changed && want_rows) need += pack_align((uint64_t)io->changed_capacity * 4u);
-    if (want_changed && want_g) need += pack_align((uint64_t)io->changed_capacity * 48u);
+    if (want_changed && want_rows && !sparse_ahead) need += pack_align((uint64_t)io->changed_capacity * 4u);
+    if (want_changed && want_g && !sparse_ahead) need += pack_align((uint64_t)io->changed_capacity * 48u);
     for (uint32_t l = 0; l < n_lists; ++l)
         if (list_total[l]) need += pack_align((uint64_t)io->lists[l].capacity * 4u);
     if (want_clusters) {
@@ -1751,7 +1804,7 @@ int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
         if ((rc = stage_alloc(ctx, PACK_HEADER_BYTES + j.payload_bytes, &st))) return rc;
         j.header = (uint32_t*)st;
         j.payload = (uint8_t*)st + PACK_HEADER_BYTES;
-        if (want_changed) {
+        if (want_changed && !sparse_ahead) {
             j.changed_total = (const uint32_t*)ctx->sparse_total.p;
             j.changed_rows = (const uint32_t*)ctx->sparse_rows.p;
             j.g = want_g ? ctx->g : nullptr;
@@ -1780,7 +1833,7 @@ int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         const uint32_t* h = j.header;
         if (h[5]) {
-            changed = h[0];
+            changed = sparse_ahead ? ctx->gs_k : h[0];
             cl_total = (uint64_t)h[2] | ((uint64_t)h[3] << 32);
             io->changed_count = changed;
             io->cluster_total = cl_total;
@@ -1795,10 +1848,23 @@ int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
                 src += pack_align(bytes);
             };
             const bool fits_changed = want_changed && changed <= io->changed_capacity;
-            const bool by_dma = fits_changed && h[6] != 0;  // many rows: left out of the window, fetched by the copy engine below
+            const bool by_dma = fits_changed && !sparse_ahead && h[6] != 0;  // many rows: left out of the window, fetched by the copy engine below
+            if (sparse_ahead) {  // (the scatter launch that wrote them is long done: the wait above was for a launch far behind it)
+                if (want_rows) {
+                    if (in_place) io->changed_rows = const_cast<uint32_t*>(ctx->gs_rows);
+                    else memcpy(io->changed_rows, ctx->gs_rows, (size_t)changed * 4);
+                }
+                if (want_g) {
+                    if (in_place) io->changed_global12 = (float*)ctx->gs_host;
+                    else memcpy(io->changed_global12, ctx->gs_host, (size_t)changed * 48);
+                }
+                ctx->gs_used = true;
+                ++ctx->n_sparse_ahead_downloads;
+            } else if (want_changed && want_g && changed && changed < ctx->n && ctx->frame_all_version != ctx->trs_version)
+                ctx->sparse_ahead_wanted = true;  // (changed GlobalTransforms fetched the usual way: the next indexed window writes them ahead)
             if (want_changed && !fits_changed) cap_rc = fail(ctx, MI_ERR_CAPACITY, "%u GlobalTransforms changed, capacity %u", changed, io->changed_capacity);
-            if (fits_changed && !by_dma && want_rows) deliver(io->changed_rows, (size_t)changed * 4);
-            if (fits_changed && !by_dma && want_g) deliver(io->changed_global12, (size_t)changed * 48);
+            if (fits_changed && !by_dma && !sparse_ahead && want_rows) deliver(io->changed_rows, (size_t)changed * 4);
+            if (fits_changed && !by_dma && !sparse_ahead && want_g) deliver(io->changed_global12, (size_t)changed * 48);
             for (uint32_t l = 0; l < n_lists; ++l) {
                 mi_visible_list& ls = io->lists[l];
                 ls.count = h[8u + l];
@@ -1855,6 +1921,10 @@ int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
         }
         changed = 0;
         cl_total = 0;
+        if (sparse_ahead) {  // (the fallback fetches everything from the device)
+            sparse_ahead = false;
+            if ((rc = changed_rows_on_device(ctx, nullptr))) return rc;
+        }
     }
     // ---- the packed window was too small (or the cluster list outgrew its device buffer): wait 1, the counts and every fixed-size array ----
     BatchedDownload b;
@@ -2128,10 +2198,11 @@ int32_t mi_debug_set_chunked_frames(mi_ctx* ctx, int32_t mode) {
 }
 
 // test hook: how many dense windows went out as pieces of a sequence, and how many result downloads handed out GlobalTransforms fetched ahead
-int32_t mi_debug_chunked_counts(mi_ctx* ctx, uint32_t* out_windows, uint32_t* out_downloads) {
+int32_t mi_debug_chunked_counts(mi_ctx* ctx, uint32_t* out_windows, uint32_t* out_downloads, uint32_t* out_sparse_downloads) {
     ENTER_RAW(ctx);
     if (out_windows) *out_windows = ctx->n_piece_uploads;
     if (out_downloads) *out_downloads = ctx->n_ahead_downloads;
+    if (out_sparse_downloads) *out_sparse_downloads = ctx->n_sparse_ahead_downloads;
     return MI_OK;
 }
 

@@ -155,6 +155,21 @@ struct mi_ctx {
     uint32_t* iota_host = nullptr;   // pinned 0, 1, 2 ...: the changed-row list of a frame in which every row changed (nothing to fetch)
     size_t iota_rows = 0;
     uint32_t n_piece_uploads = 0, n_ahead_downloads = 0;  // mi_debug_chunked_counts
+    // The same for the changed rows of an indexed upload window (the changed-rows frame of a flat table): the scatter kernel that reads
+    // the window over PCIe writes each entry's GlobalTransform straight back into pinned memory (k_upload_trs_indexed, g_ahead);
+    // mi_download_frame_results hands rows and GlobalTransforms out without compacting, gathering or fetching anything when the
+    // change mask the last frame left is exactly that upload's rows: the change column was clean before it, nothing raised a mark
+    // or wrote a Transform between it and the frame, the rows were strictly ascending, and no propagate ran since.
+    uint64_t marks_serial = 1;          // bumped by whatever raises change marks
+    void* gs_host = nullptr;            // pinned, device-mapped: [gs_k] GlobalTransforms in upload order
+    size_t gs_host_bytes = 0;
+    const uint32_t* gs_rows = nullptr;  // the window's rows (pinned; stays put until a later mi_map_upload_window recycles the windows)
+    uint32_t gs_k = 0;                  // 0 = the last indexed upload wrote nothing ahead
+    uint64_t gs_marks_serial = 0, gs_trs_version = 0;  // marks_serial / trs_version right after that upload (the former until a propagate consumes the marks)
+    uint64_t gs_frame_serial = 0;       // gs_marks_serial as the current propagate call found it
+    bool gs_frame_ok = false;           // the last propagate of any kind was the changed-rows frame of a flat table over exactly those marks
+    bool gs_used = false, sparse_ahead_wanted = false;
+    uint32_t n_sparse_ahead_downloads = 0;
     int32_t chunk_mode = 0;          // mi_debug_set_chunked_frames: 0 = tables of >= 262144 rows (default), 1 = never, 2 = any size
 
     // ---- row summary (RowSummary, kernels.h): Aabb / flags / RenderLayers per 64 rows where they are uniform.  Derived from the

@@ -11,7 +11,7 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
     ENTER(ctx);
     if (n != ctx->n) return fail(ctx, MI_ERR_INVALID_ARG, "mi_upload_hierarchy: n (%u) != live rows (%u)", n, ctx->n);
     trs_written(ctx);  // (rows may have been renumbered with it: nothing fetched ahead of a flat frame applies)
-    ctx->changed_maybe = true;  // conservative: the next propagate looks at the rows again
+    ctx->changed_maybe = true, ++ctx->marks_serial;  // conservative: the next propagate looks at the rows again
     // marks an upload of this frame climbed for belong to the hierarchy that is being replaced
     if (ctx->marks_in_cur) ctx->tree_clean[ctx->tree_parity] = false;
     ctx->marks_live = ctx->marks_in_cur = ctx->marks_complete = ctx->marks_other_cleared = false;

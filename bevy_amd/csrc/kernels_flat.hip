@@ -737,26 +737,36 @@ __global__ void __launch_bounds__(256) k_upload_trs_indexed(const uint32_t* __re
                                                              float* r, float* s, uint8_t* changed, uint32_t changed_gen,
                                                              const uint32_t* __restrict__ parent_idx, uint8_t* mark_bytes,
                                                              uint32_t* __restrict__ clear_words, uint32_t n_clear_words,
-                                                             const uint32_t* __restrict__ anc) {
+                                                             const uint32_t* __restrict__ anc, float* __restrict__ g_ahead) {
+    // g_ahead (pinned host memory, or nullptr): entry i's GlobalTransform as the changed-rows frame of a flat table will write it --
+    // From(Transform), sync_simple_transforms (systems.rs:45-50), the frame kernels' affine_from_srt -- written back over PCIe by
+    // the launch that reads the Transforms over it (the link is full duplex), in upload order, three contiguous 1 KB rows per wave
+    __shared__ float4 lds_g[4][192];
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     if (clear_words)
         for (uint32_t w = gid; w < n_clear_words; w += gridDim.x * 256u) clear_words[w] = 0u;
-    for (uint32_t i = gid; i < n; i += gridDim.x * 256u) {
-        uint32_t row = rows[i];
-#pragma unroll
-        for (uint32_t k = 0; k < 3u; ++k) {
-            t[3ull * row + k] = ft[3ull * i + k];
-            s[3ull * row + k] = fs[3ull * i + k];
+    for (uint32_t i0 = gid & ~63u; i0 < n; i0 += gridDim.x * 256u) {  // (wave-uniform trip count: the transpose below is a wave's)
+        const uint32_t i = i0 + (threadIdx.x & 63u);
+        const bool live = i < n;
+        V3 tt = {}, ss = {1.0f, 1.0f, 1.0f};
+        V4 qq = {0.0f, 0.0f, 0.0f, 1.0f};
+        if (live) {
+            const uint32_t row = rows[i];
+            tt = V3{ft[3ull * i], ft[3ull * i + 1u], ft[3ull * i + 2u]};  // (dword loads: a caller's arrays promise no alignment)
+            ss = V3{fs[3ull * i], fs[3ull * i + 1u], fs[3ull * i + 2u]};
+            qq = V4{fr[4ull * i], fr[4ull * i + 1u], fr[4ull * i + 2u], fr[4ull * i + 3u]};
+            t[3ull * row] = tt.x, t[3ull * row + 1u] = tt.y, t[3ull * row + 2u] = tt.z;
+            s[3ull * row] = ss.x, s[3ull * row + 1u] = ss.y, s[3ull * row + 2u] = ss.z;
+            r[4ull * row] = qq.x, r[4ull * row + 1u] = qq.y, r[4ull * row + 2u] = qq.z, r[4ull * row + 3u] = qq.w;
+            changed[row] = (uint8_t)changed_gen;  // a stamp, not a flag: see row_changed() in kernels.h
+            if (mark_bytes) mark_row_and_ancestors(row, parent_idx, mark_bytes, anc, 0xFFFFu);  // (a hierarchy is at most 65 535 levels deep here)
         }
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) r[4ull * row + k] = fr[4ull * i + k];
-        changed[row] = (uint8_t)changed_gen;  // a stamp, not a flag: see row_changed() in kernels.h
-        if (mark_bytes) mark_row_and_ancestors(row, parent_idx, mark_bytes, anc, 0xFFFFu);  // (a hierarchy is at most 65 535 levels deep here)
+        if (g_ahead) store_affine_coalesced(lds_g[threadIdx.x >> 6], g_ahead, i0, n, threadIdx.x & 63u, affine_from_srt(ss, qq, tt));
     }
 }
 hipError_t launch_upload_trs_indexed(const uint32_t* rows, const float* t_src, const float* r_src, const float* s_src, uint32_t n, float* t,
                                      float* r, float* s, uint8_t* changed, uint32_t changed_gen, hipStream_t stream, const uint32_t* parent_idx,
-                                     uint8_t* mark_bytes, uint32_t* clear_words, uint32_t n_clear_words, const uint32_t* anc) {
+                                     uint8_t* mark_bytes, uint32_t* clear_words, uint32_t n_clear_words, const uint32_t* anc, float* g_ahead) {
     if (n == 0) return hipSuccess;
     // the sources are pinned host memory read over PCIe: enough lanes to keep the link busy, not one workgroup per 256 rows of a
     // million-row upload; and enough workgroups for the words to clear
@@ -766,7 +776,7 @@ hipError_t launch_upload_trs_indexed(const uint32_t* rows, const float* t_src, c
         blocks = blocks > cb ? blocks : cb;
     }
     MI_LAUNCH(k_upload_trs_indexed, dim3(blocks), dim3(256), 0, stream, rows, t_src, r_src, s_src, n, t, r, s, changed, changed_gen, parent_idx,
-              mark_bytes, clear_words, n_clear_words, mark_bytes ? anc : nullptr);
+              mark_bytes, clear_words, n_clear_words, mark_bytes ? anc : nullptr, g_ahead);
     return hipGetLastError();
 }
 

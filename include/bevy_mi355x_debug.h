@@ -56,8 +56,8 @@ int32_t mi_debug_set_tile_pretest(mi_ctx* ctx, int32_t mode);
  * results. */
 int32_t mi_debug_set_chunked_frames(mi_ctx* ctx, int32_t mode);
 /* How many dense windows went out as pieces of such a sequence / how many mi_download_frame_results calls handed out GlobalTransforms
- * fetched ahead (tests). */
-int32_t mi_debug_chunked_counts(mi_ctx* ctx, uint32_t* out_windows, uint32_t* out_downloads);
+ * fetched ahead of an all-rows frame / of a changed-rows frame (written back by the indexed upload window's scatter launch) (tests). */
+int32_t mi_debug_chunked_counts(mi_ctx* ctx, uint32_t* out_windows, uint32_t* out_downloads, uint32_t* out_sparse_downloads);
 /* The cluster walk of a MI_CULL_WITH_CLUSTERS frame whose objects are bound to a row RANGE: 0 = the frame kernel's row workgroups
  * of those rows go on into the walk (default), 1 = extra workgroups re-derive the rows' visibility (as for row lists).  Same results. */
 int32_t mi_debug_set_walk_inrow(mi_ctx* ctx, int32_t mode);

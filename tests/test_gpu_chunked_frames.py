@@ -92,7 +92,7 @@ def test_all_dirty_frames_in_pieces(binding, mode, in_place):
         # the pieces were taken where they should have been: six dense windows went out in pieces; with the default rule the first
         # frame fetches the usual way (and shows that the caller wants them all), frame 3's first upload was fetched ahead for nothing
         # (mi_propagate + a direct download came between), so its second upload did not fetch ahead and its download asked again
-        assert ctxs[0].debug_chunked_counts() == ((6, 3) if mode == 0 else (6, 5)) and ctxs[1].debug_chunked_counts() == (0, 0)
+        assert ctxs[0].debug_chunked_counts()[:2] == ((6, 3) if mode == 0 else (6, 5)) and ctxs[1].debug_chunked_counts() == (0, 0, 0)
     finally:
         for ctx in ctxs:
             ctx.close()
@@ -221,4 +221,94 @@ def test_a_changed_rows_frame_behind_a_dense_upload_fetches_the_usual_way():
         keep = np.ones(n, bool)
         keep[rows] = False
         assert g_now[keep].tobytes() == g_before[keep].tobytes()  # the rows that were not marked keep their GlobalTransform
-        assert ctx.debug_chunked_counts()[1] == 0
+        assert ctx.debug_chunked_counts()[1:] == (0, 0)
+
+
+# ---- changed-rows frames: the GlobalTransforms of an indexed upload window, written ahead by the scatter launch -------------------------
+def window(ctx, rows, t, sc, n):
+    k = len(rows)
+    w, wrows, wt, wr, ws = ctx.map_upload_window(k)
+    wrows[:] = rows
+    wt[:] = t[rows].reshape(-1)
+    wr[:] = sc["rotation"].reshape(n, 4)[rows].reshape(-1)
+    ws[:] = sc["scale"].reshape(n, 3)[rows].reshape(-1)
+    ctx.commit_upload_window(w, k)
+
+
+SPARSE_CASES = ["plain", "not ascending", "a mark from elsewhere", "two windows", "a dense write in between", "an all-rows frame",
+                "a second frame before the results", "results twice", "capacity too small", "default rule"]
+
+
+@pytest.mark.parametrize("case", SPARSE_CASES)
+@pytest.mark.parametrize("in_place", [True, False])
+def test_changed_rows_frames_with_globals_written_ahead(case, in_place):
+    n = 60_000
+    sc = W.many_cubes(n, radius=60.0)
+    outs, counts = [], []
+    for mode in ((0 if case == "default rule" else 2), 1):
+        t = sc["translation"].reshape(n, 3).copy()
+        rng = np.random.default_rng(77)
+        got_all = []
+        with api.Context(0) as ctx:
+            ctx.debug_set_chunked_frames(mode)
+            ctx.resize(n)
+            ctx.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
+            ctx.upload_bounds(sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"])
+            ctx.upload_changed(np.zeros(n, np.uint8))
+            fr, _, _ = frame_inputs(0)
+            ctx.propagate_and_cull(fr, flags=B.CULL_END_FRAME)  # every GlobalTransform once; the change column is clean from here on
+            for frame in range(4):
+                k = int(rng.integers(1, 9000))
+                rows = np.sort(rng.choice(n, k, replace=False)).astype(np.uint32)
+                expect = rows
+                t[rows] += rng.normal(0.0, 1.0, (k, 3)).astype(F)
+                if case == "not ascending":
+                    rows = rows[::-1].copy()
+                window(ctx, rows, t, sc, n)
+                if case == "a mark from elsewhere" and frame % 2 == 1:
+                    marks = np.zeros(n, np.uint8)
+                    extra = int(np.setdiff1d(np.arange(n, dtype=np.uint32), expect)[5])
+                    marks[extra] = 1
+                    marks[expect] = 1  # (an uploaded byte column replaces the marks)
+                    ctx.upload_changed(marks)
+                    expect = np.sort(np.append(expect, np.uint32(extra))).astype(np.uint32)
+                if case == "two windows":
+                    rows2 = np.sort(rng.choice(n, 50, replace=False)).astype(np.uint32)
+                    t[rows2] += F(1.5)
+                    window(ctx, rows2, t, sc, n)
+                    expect = np.union1d(expect, rows2).astype(np.uint32)
+                if case == "a dense write in between" and frame % 2 == 0:
+                    lo = int(expect[0])
+                    t[lo:lo + 3] += F(0.75)  # (rows at and behind the first uploaded one move again; only marked rows will be propagated)
+                    ctx.upload_transforms(t[lo:lo + 3].reshape(-1), sc["rotation"].reshape(n, 4)[lo:lo + 3].reshape(-1), sc["scale"].reshape(n, 3)[lo:lo + 3].reshape(-1), first_row=lo)
+                flags = B.CULL_END_FRAME | (0 if case == "an all-rows frame" and frame % 2 == 1 else B.CULL_CHANGED_ROWS)
+                fr, _, _ = frame_inputs(frame)
+                ctx.propagate_and_cull(fr, flags=flags)
+                if case == "an all-rows frame" and frame % 2 == 1:
+                    expect = np.arange(n, dtype=np.uint32)
+                if case == "a second frame before the results" and frame % 2 == 1:
+                    ctx.propagate_and_cull(fr, flags=flags)  # nothing is marked any more: no GlobalTransform changes in this one
+                    expect = np.zeros(0, np.uint32)
+                cap = 10 if case == "capacity too small" and frame == 2 else n
+                bufs = api.FrameResultBuffers(cap, n, 0, 0, in_place=in_place)
+                if cap < len(expect):
+                    with pytest.raises(api.MiError):
+                        ctx.download_frame_results(bufs)
+                    bufs = api.FrameResultBuffers(n, n, 0, 0, in_place=in_place)
+                for rep in range(2 if case == "results twice" else 1):
+                    got = ctx.download_frame_results(bufs)
+                    r_, g_ = np.array(got["changed_rows"]).copy(), np.array(got["changed_global"]).reshape(-1, 12).copy()
+                    assert np.array_equal(r_, expect), f"{case}, frame {frame}, mode {mode}: changed rows"
+                    g_all = ctx.download_global_transforms(want_changed=False).reshape(n, 12)
+                    assert g_.tobytes() == g_all[expect].tobytes(), f"{case}, frame {frame}, mode {mode}: changed GlobalTransforms against the column"
+                    got_all.append((r_, g_, np.array(got["visible_rows"]).copy()))
+                if case not in ("a dense write in between",):  # (there the rows the dense write moved keep their old GlobalTransform: not marked)
+                    g, _ = O.sync_simple_transforms(t.reshape(-1), sc["rotation"], sc["scale"])
+                    assert g_all.tobytes() == g.tobytes(), f"{case}, frame {frame}: the column against the oracle"
+            counts.append(ctx.debug_chunked_counts()[2])
+        outs.append(got_all)
+    for x, y in zip(*outs):
+        assert all(np.array_equal(p, q) for p, q in zip(x, y)), f"{case}: the two forms differ"
+    want = {"plain": 4, "not ascending": 0, "a mark from elsewhere": 2, "two windows": 0, "a dense write in between": 2, "an all-rows frame": 2,
+            "a second frame before the results": 2, "results twice": 8, "capacity too small": 4, "default rule": 3}[case]
+    assert counts == [want, 0], f"{case}: {counts} downloads handed out GlobalTransforms written ahead"

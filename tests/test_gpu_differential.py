@@ -9,6 +9,7 @@ agree on everything a caller can download after every step; at intervals the ora
     tile pre-test of change-driven hierarchy frames       mi_debug_set_tile_pretest(1)    [A: forced, mode 2]
     hierarchy frame fused into the tile launches          (B: two launches)               [A: mi_debug_set_tree_cull(2)]
     dense uploads in pieces, GlobalTransforms fetched ahead mi_debug_set_chunked_frames(1)  [A: at any row count, mode 2]
+    GlobalTransforms written ahead by an indexed window     (the same switch)
 
 The sequences mix: bounds uploads (whole, partial, single rows), RenderLayers above 31, Transform uploads (indexed, ranges),
 change marks, growth and shrinkage of the row count, Visibility changes propagated on the device, VisibilityClass masks, one to
@@ -224,6 +225,17 @@ def test_fast_paths_are_interchangeable(seed):
                     wr[:] = sc.r[:n].reshape(-1)
                     ws[:] = sc.s[:n].reshape(-1)
                     ctx.commit_upload_window(w, n)
+            elif op == 7 and not forest:  # some Transforms move and arrive through an indexed upload window, in row order (a Changed<Transform> query)
+                k = int(min(n, rng.integers(1, 3000)))
+                rows = np.sort(rng.choice(n, k, replace=False)).astype(np.uint32)
+                sc.t[rows] += rng.normal(0.0, 3.0, (k, 3)).astype(F)
+                for ctx in (a, b):
+                    w, wrows, wt, wr, ws = ctx.map_upload_window(k)
+                    wrows[:] = rows
+                    wt[:] = sc.t[rows].reshape(-1)
+                    wr[:] = sc.r[rows].reshape(-1)
+                    ws[:] = sc.s[rows].reshape(-1)
+                    ctx.commit_upload_window(w, k)
             # every step ends in a frame
             cams = [W.many_cubes_camera(int(rng.integers(0, 400)), yaw=float(rng.random() * 6.0), position=tuple(rng.normal(0, 8.0, 3))) for _ in range(n_views)]
             fr = np.concatenate([api.compute_frustum(cfv(), cam, W.CAMERA_FAR) for cam in cams])
@@ -248,12 +260,12 @@ def test_fast_paths_are_interchangeable(seed):
                     ctx.propagate((B.PROPAGATE_ALL_DIRTY if kind == "split_all" else 0) | (B.PROPAGATE_STATIC_OPT if forest else 0))
                     ctx.cull_views(views, flags=flags | B.CULL_BEGIN_FRAME)
             had_clusters = had_clusters or with_clusters
-            if op == 6 and not forest:  # the results in one call (fetched ahead in A when the frame was an all-rows one)
+            if op in (6, 7) and not forest:  # the results in one call (fetched / written ahead in A when the frame was of the matching kind)
                 res = []
                 for ctx in (a, b):
                     got = ctx.download_frame_results(api.FrameResultBuffers(n, n, 0, 0, in_place=bool(step % 2)))
                     res.append((np.array(got["changed_rows"]).tobytes(), np.array(got["changed_global"]).tobytes()))
-                assert res[0] == res[1], f"seed {seed} step {step} ({kind}): mi_download_frame_results after a dense upload differs"
+                assert res[0] == res[1], f"seed {seed} step {step} ({kind}, op {op}): mi_download_frame_results after an upload window differs"
             sa, sb = snapshot(a, n_views, had_clusters, n_clusters), snapshot(b, n_views, had_clusters, n_clusters)
             if classes:
                 for v in range(n_views):
@@ -275,19 +287,21 @@ def test_fast_paths_are_interchangeable(seed):
                                                         np.zeros(n, np.uint8), fr, vm_lo, vm_hi)
                 for v in range(n_views - (1 if shadow_view else 0)):  # (the 64-layer restatement knows camera views only)
                     assert np.array_equal(np.frombuffer(sa[f"mask {v}"], np.uint8), vis[v]), f"seed {seed} step {step}: mask of view {v} against the oracle"
-        PIECES[0] += a.debug_chunked_counts()[1]
-        assert b.debug_chunked_counts() == (0, 0)
+        PIECES[0] += a.debug_chunked_counts()[0]  # (their results are handed out ahead only beyond the packed window: tests/test_gpu_chunked_frames.py)
+        SPARSE[0] += a.debug_chunked_counts()[2]
+        assert b.debug_chunked_counts() == (0, 0, 0)
     finally:
         a.close()
         b.close()
 
 
 PIECES = [0]
+SPARSE = [0]
 
 
 def test_the_pieces_were_taken():
     """(runs after the seeds above) some of their dense uploads did go out in pieces, with results fetched ahead, in the fast context."""
-    assert PIECES[0] > 0
+    assert PIECES[0] > 0 and SPARSE[0] > 0
 
 
 def oracle_half(sc, n, first_light, n_lights):

@@ -910,9 +910,9 @@ int32_t mi_upload_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t n, const 
 }
 
 // rows / t / r / s lie in the pinned arena: one scatter kernel reads them over PCIe and raises the rows' change bytes
-// window_rows_ascending: rows lie in an upload window (they stay put until the windows are recycled) and are strictly ascending
+// window_order: +1 / -1 = the rows lie in an upload window (they stay put until the windows are recycled) and strictly ascend / descend
 static int32_t scatter_indexed(mi_ctx* ctx, const uint32_t* rows, const float* t, const float* r, const float* s, uint32_t n,
-                               bool window_rows_ascending = false) {
+                               int window_order = 0) {
     trs_written(ctx);
     // ---- GlobalTransforms ahead of the changed-rows frame (ctx.h): only when this upload's rows will be exactly the frame's ----
     const bool column_clean = !ctx->changed_maybe && (ctx->have_changed || ctx->propagated_rows >= ctx->n);
@@ -921,7 +921,7 @@ static int32_t scatter_indexed(mi_ctx* ctx, const uint32_t* rows, const float* t
     ctx->gs_frame_ok = false;
     ctx->gs_used = false;
     float* g_ahead = nullptr;
-    if (window_rows_ascending && column_clean && ctx->chunk_mode != 1 && (ctx->sparse_ahead_wanted || ctx->chunk_mode == 2) && !ctx->have_hierarchy &&
+    if (window_order != 0 && column_clean && ctx->chunk_mode != 1 && (ctx->sparse_ahead_wanted || ctx->chunk_mode == 2) && !ctx->have_hierarchy &&
         !ctx->xch.on) {
         if (ctx->gs_host_bytes < (size_t)n * 48) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (a scatter launch may still be writing the old one)
@@ -961,7 +961,7 @@ static int32_t scatter_indexed(mi_ctx* ctx, const uint32_t* rows, const float* t
         other = (uint32_t*)(ctx->tree_bytes + (size_t)(ctx->tree_parity ^ 1u) * ctx->tree_half_words * 4);
     HIP_TRY(ctx, launch_upload_trs_indexed((const uint32_t*)d_rows, (const float*)d_t, (const float*)d_r, (const float*)d_s, n, ctx->t, ctx->r,
                                            ctx->s, ctx->changed, ctx->changed_gen, ctx->stream, mark_here ? (const uint32_t*)ctx->parent_idx.p : nullptr,
-                                           cur, other, ctx->tree_half_words, ctx->anc_valid ? (const uint32_t*)ctx->anc.p : nullptr, g_ahead));
+                                           cur, other, ctx->tree_half_words, ctx->anc_valid ? (const uint32_t*)ctx->anc.p : nullptr, g_ahead, window_order < 0));
     if (mark_here) {
         if (!ctx->marks_in_cur) ctx->marks_complete = !ctx->changed_maybe;  // complete so far iff nothing was marked changed before this upload
         ctx->marks_in_cur = true;
@@ -977,6 +977,11 @@ static int32_t scatter_indexed(mi_ctx* ctx, const uint32_t* rows, const float* t
     if (g_ahead) {
         ctx->gs_k = n;
         ctx->gs_rows = rows;
+        if (window_order < 0) {  // (the results list rows in ascending order: the GlobalTransforms were written back to front, the rows follow)
+            ctx->gs_rows_rev.resize(n);
+            for (uint32_t i = 0; i < n; ++i) ctx->gs_rows_rev[i] = rows[n - 1u - i];
+            ctx->gs_rows = ctx->gs_rows_rev.data();
+        }
         ctx->gs_marks_serial = ctx->marks_serial;
         ctx->gs_trs_version = ctx->trs_version;
     }
@@ -1137,14 +1142,17 @@ int32_t mi_commit_upload_window(mi_ctx* ctx, const mi_upload_window* w, uint32_t
         HIP_TRY(ctx, hipMemcpyAsync(ctx->s + 3 * (size_t)first_row, w->scale, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
         return MI_OK;
     }
-    uint32_t top = 0, ascending = 1;  // (rows of a Changed<Transform> query in row order: what the results of the frame will list)
+    // (strictly monotonic rows -- a Changed<Transform> query over tables whose rows follow the Entity key, one way or the other -- are
+    // what the results of the frame will list: scatter_indexed)
+    uint32_t top = 0, ascending = 1, descending = 1;
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t row = w->rows[i];
         ascending &= (uint32_t)(i == 0 || row > w->rows[i - 1]);
+        descending &= (uint32_t)(i == 0 || row < w->rows[i - 1]);
         top = std::max(top, row);
     }
     if (top >= ctx->n) return fail(ctx, MI_ERR_INVALID_ARG, "mi_commit_upload_window: row %u >= %u live rows", top, ctx->n);
-    return scatter_indexed(ctx, w->rows, w->translation, w->rotation, w->scale, n, ascending != 0);
+    return scatter_indexed(ctx, w->rows, w->translation, w->rotation, w->scale, n, ascending ? 1 : descending ? -1 : 0);
 }
 
 int32_t mi_upload_global_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t n, const float* global12) {

@@ -163,7 +163,8 @@ struct mi_ctx {
     uint64_t marks_serial = 1;          // bumped by whatever raises change marks
     void* gs_host = nullptr;            // pinned, device-mapped: [gs_k] GlobalTransforms in upload order
     size_t gs_host_bytes = 0;
-    const uint32_t* gs_rows = nullptr;  // the window's rows (pinned; stays put until a later mi_map_upload_window recycles the windows)
+    const uint32_t* gs_rows = nullptr;  // the window's rows (pinned; stays put until a later mi_map_upload_window recycles the windows) ...
+    std::vector<uint32_t> gs_rows_rev;  // ... or, for a window whose rows descend, their reversed copy
     uint32_t gs_k = 0;                  // 0 = the last indexed upload wrote nothing ahead
     uint64_t gs_marks_serial = 0, gs_trs_version = 0;  // marks_serial / trs_version right after that upload (the former until a propagate consumes the marks)
     uint64_t gs_frame_serial = 0;       // gs_marks_serial as the current propagate call found it

@@ -241,7 +241,8 @@ hipError_t launch_upload_trs_indexed(const uint32_t* rows, const float* t_src, c
                                      float* r, float* s, uint8_t* changed, uint32_t changed_gen, hipStream_t stream,
                                      const uint32_t* parent_idx = nullptr, uint8_t* mark_bytes = nullptr, uint32_t* clear_words = nullptr,
                                      uint32_t n_clear_words = 0, const uint32_t* anc = nullptr,
-                                     float* g_ahead = nullptr /* pinned: entry i's From(Transform), 48 B each, written over PCIe */);
+                                     float* g_ahead = nullptr /* pinned: entry i's From(Transform), 48 B each, written over PCIe ... */,
+                                     bool g_reversed = false /* ... at slot n-1-i instead of i */);
 hipError_t launch_popcount_words(const uint64_t* bits, uint32_t n_rows, uint8_t* cnt, hipStream_t stream);
 hipError_t launch_gather_global(const uint32_t* rows, const uint32_t* total, uint32_t capacity, const float* g, float* out,
                                 hipStream_t stream);

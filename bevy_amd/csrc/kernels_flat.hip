@@ -737,10 +737,12 @@ __global__ void __launch_bounds__(256) k_upload_trs_indexed(const uint32_t* __re
                                                              float* r, float* s, uint8_t* changed, uint32_t changed_gen,
                                                              const uint32_t* __restrict__ parent_idx, uint8_t* mark_bytes,
                                                              uint32_t* __restrict__ clear_words, uint32_t n_clear_words,
-                                                             const uint32_t* __restrict__ anc, float* __restrict__ g_ahead) {
+                                                             const uint32_t* __restrict__ anc, float* __restrict__ g_ahead, uint32_t g_reversed) {
     // g_ahead (pinned host memory, or nullptr): entry i's GlobalTransform as the changed-rows frame of a flat table will write it --
     // From(Transform), sync_simple_transforms (systems.rs:45-50), the frame kernels' affine_from_srt -- written back over PCIe by
-    // the launch that reads the Transforms over it (the link is full duplex), in upload order, three contiguous 1 KB rows per wave
+    // the launch that reads the Transforms over it (the link is full duplex), three contiguous 1 KB rows per wave; in upload order,
+    // or (g_reversed: the window's rows descend -- a query in spawn order over rows numbered by Entity key, whose index is stored
+    // inverted) back to front, so that they stand in ascending row order either way
     __shared__ float4 lds_g[4][192];
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     if (clear_words)
@@ -761,12 +763,34 @@ __global__ void __launch_bounds__(256) k_upload_trs_indexed(const uint32_t* __re
             changed[row] = (uint8_t)changed_gen;  // a stamp, not a flag: see row_changed() in kernels.h
             if (mark_bytes) mark_row_and_ancestors(row, parent_idx, mark_bytes, anc, 0xFFFFu);  // (a hierarchy is at most 65 535 levels deep here)
         }
-        if (g_ahead) store_affine_coalesced(lds_g[threadIdx.x >> 6], g_ahead, i0, n, threadIdx.x & 63u, affine_from_srt(ss, qq, tt));
+        if (g_ahead) {
+            const Affine a = affine_from_srt(ss, qq, tt);
+            const uint32_t lane = threadIdx.x & 63u;
+            if (!g_reversed) store_affine_coalesced(lds_g[threadIdx.x >> 6], g_ahead, i0, n, lane, a);
+            else {
+                // entry i goes to slot n-1-i: the wave's 64 entries fill slots base .. base+63, base = n-64-i0 (below 0 in the wave
+                // that holds the last entries: those slots do not exist), lane l's entry in slot base + 63 - l
+                float4* lds_wave = lds_g[threadIdx.x >> 6];
+                const uint32_t sl = 63u - lane;
+                lds_wave[sl * 3u + 0u] = make_float4(a.m.x_axis.x, a.m.x_axis.y, a.m.x_axis.z, a.m.y_axis.x);
+                lds_wave[sl * 3u + 1u] = make_float4(a.m.y_axis.y, a.m.y_axis.z, a.m.z_axis.x, a.m.z_axis.y);
+                lds_wave[sl * 3u + 2u] = make_float4(a.m.z_axis.z, a.t.x, a.t.y, a.t.z);
+                MI_WAVE_LDS_SYNC();
+                const long long first = 3ll * ((long long)n - 64ll - (long long)i0);  // float4 index of slot `base`
+#pragma unroll
+                for (uint32_t k = 0; k < 3u; ++k) {
+                    const long long at = first + (long long)(k * 64u + lane);
+                    if (at >= 0) reinterpret_cast<float4*>(g_ahead)[at] = lds_wave[k * 64u + lane];
+                }
+                MI_WAVE_LDS_SYNC();  // (the next trip of this wave writes the same buffer)
+            }
+        }
     }
 }
 hipError_t launch_upload_trs_indexed(const uint32_t* rows, const float* t_src, const float* r_src, const float* s_src, uint32_t n, float* t,
                                      float* r, float* s, uint8_t* changed, uint32_t changed_gen, hipStream_t stream, const uint32_t* parent_idx,
-                                     uint8_t* mark_bytes, uint32_t* clear_words, uint32_t n_clear_words, const uint32_t* anc, float* g_ahead) {
+                                     uint8_t* mark_bytes, uint32_t* clear_words, uint32_t n_clear_words, const uint32_t* anc, float* g_ahead,
+                                     bool g_reversed) {
     if (n == 0) return hipSuccess;
     // the sources are pinned host memory read over PCIe: enough lanes to keep the link busy, not one workgroup per 256 rows of a
     // million-row upload; and enough workgroups for the words to clear
@@ -776,7 +800,7 @@ hipError_t launch_upload_trs_indexed(const uint32_t* rows, const float* t_src, c
         blocks = blocks > cb ? blocks : cb;
     }
     MI_LAUNCH(k_upload_trs_indexed, dim3(blocks), dim3(256), 0, stream, rows, t_src, r_src, s_src, n, t, r, s, changed, changed_gen, parent_idx,
-              mark_bytes, clear_words, n_clear_words, mark_bytes ? anc : nullptr, g_ahead);
+              mark_bytes, clear_words, n_clear_words, mark_bytes ? anc : nullptr, g_ahead, g_reversed ? 1u : 0u);
     return hipGetLastError();
 }
 

@@ -520,6 +520,13 @@ int32_t mi_cluster_download(mi_ctx* ctx, uint32_t* out_offsets, uint32_t* out_in
  * finds them on the host.  They are handed out only when the frame in between rewrote every row from exactly those Transforms
  * (any other upload, resize or hierarchy in between: fetched the usual way); the changed-row list of such a frame is 0 .. n-1 and is
  * never fetched.  Nothing to switch on, same results either way.
+ * Some GlobalTransforms of a flat table (the changed-rows frame): commit the moved rows through ONE indexed upload window whose
+ * rows strictly ascend or strictly descend (a Changed<Transform> query in table order over rows numbered by Entity key is one or
+ * the other) and run the MI_CULL_CHANGED_ROWS frame.  From the second such frame on the scatter launch that reads the window over
+ * PCIe writes each row's GlobalTransform straight back into pinned memory, and this call hands out the window's rows (ascending)
+ * and those GlobalTransforms without compacting the change mask, gathering or copying anything -- when the frame's change mask is
+ * exactly that window: the change column was clean before it (the frame before consumed it) and nothing raised a mark, wrote a
+ * Transform or propagated between the window and the frame.  Otherwise the usual way; same results.
  * Counts are always filled in for the parts that ran; MI_ERR_CAPACITY if a list exceeds its capacity (counts are valid, that list
  * was not delivered, the others were). */
 #define MI_RESULTS_CHANGED_ROWS 0x1u

@@ -375,7 +375,7 @@ class Context:
             self.debug_set_sorted_one_wg_limit(0)
         if os.environ.get("MI_TEST_TILE_PRETEST"):
             self.debug_set_tile_pretest(int(os.environ["MI_TEST_TILE_PRETEST"]))
-        if os.environ.get("MI_TEST_CHUNKED_FRAMES"):  # ... or with all-dirty end-to-end frames in one piece (1)
+        if os.environ.get("MI_TEST_CHUNKED_FRAMES"):  # ... or with upload windows never (1) / always (2) in pieces and GlobalTransforms sent back ahead of the frame
             self.debug_set_chunked_frames(int(os.environ["MI_TEST_CHUNKED_FRAMES"]))
         if os.environ.get("MI_TEST_WALK_INROW"):  # ... or with the riding cluster walk in workgroups of its own (1)
             self.debug_set_walk_inrow(int(os.environ["MI_TEST_WALK_INROW"]))

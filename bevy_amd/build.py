@@ -107,7 +107,7 @@ def build_host_tests(force=False):
     deps = [src, HOST_HEADER, LIB, os.path.join(CSRC, "glam_math.h"), os.path.join(CSRC, "..", "..", "include", "bevy_mi355x.h")]
     if not force and os.path.exists(exe) and all(os.path.getmtime(d) <= os.path.getmtime(exe) for d in deps):
         return exe
-    cmd = ["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-fno-fast-math", "-Wall", src, "-o", exe, "-L", HERE,
+    cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-Wall", src, "-o", exe, "-L", HERE,
            "-lbevy_mi355x", "-Wl,-rpath,$ORIGIN/../../bevy_amd", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:

@@ -732,6 +732,10 @@ __global__ void __launch_bounds__(256) k_upload_trs(const float* __restrict__ sr
 // != nullptr): every uploaded row climbs to its root setting TransformTreeChanged, exactly like k_mark_dirty (kernels_tree.hip), and
 // the launch zeroes the other half of the double-buffered marks -- the mark launch of its own (>= 4.3 us) drops out of a frame whose
 // changes all arrive this way.
+// WIDE (the three source arrays are 16-byte aligned: upload windows are): a wave fetches its 64 entries' translations and scales as
+// 48 float4 each and the rotations as one float4 per lane, and redistributes through LDS -- three wide loads per wave and every line
+// of the pinned memory crossing PCIe once, instead of ten dword loads per lane at 12- and 16-byte strides.
+template <bool WIDE>
 __global__ void __launch_bounds__(256) k_upload_trs_indexed(const uint32_t* __restrict__ rows, const float* __restrict__ ft,
                                                              const float* __restrict__ fr, const float* __restrict__ fs, uint32_t n, float* t,
                                                              float* r, float* s, uint8_t* changed, uint32_t changed_gen,
@@ -752,11 +756,33 @@ __global__ void __launch_bounds__(256) k_upload_trs_indexed(const uint32_t* __re
         const bool live = i < n;
         V3 tt = {}, ss = {1.0f, 1.0f, 1.0f};
         V4 qq = {0.0f, 0.0f, 0.0f, 1.0f};
+        if constexpr (WIDE) {
+            const uint32_t lane = threadIdx.x & 63u;
+            float4* lds_wave = lds_g[threadIdx.x >> 6];
+            const uint64_t f4 = 48ull * (i0 >> 6);  // (i0 is a multiple of 64: float 3 * i0 is float4 48 * (i0 / 64))
+            if (lane < 48u && 4ull * (f4 + lane) < 3ull * n) {  // (a float4 that starts inside the array; its tail lies in the window's padding)
+                lds_wave[lane] = reinterpret_cast<const float4*>(ft)[f4 + lane];
+                lds_wave[48u + lane] = reinterpret_cast<const float4*>(fs)[f4 + lane];
+            }
+            if (live) {
+                const float4 q4 = reinterpret_cast<const float4*>(fr)[i];
+                qq = V4{q4.x, q4.y, q4.z, q4.w};
+            }
+            MI_WAVE_LDS_SYNC();
+            if (live) {
+                const float* lf = reinterpret_cast<const float*>(lds_wave);
+                tt = V3{lf[3u * lane], lf[3u * lane + 1u], lf[3u * lane + 2u]};
+                ss = V3{lf[192u + 3u * lane], lf[192u + 3u * lane + 1u], lf[192u + 3u * lane + 2u]};
+            }
+            MI_WAVE_LDS_SYNC();  // (the transpose of the GlobalTransforms below reuses the buffer)
+        }
         if (live) {
             const uint32_t row = rows[i];
-            tt = V3{ft[3ull * i], ft[3ull * i + 1u], ft[3ull * i + 2u]};  // (dword loads: a caller's arrays promise no alignment)
-            ss = V3{fs[3ull * i], fs[3ull * i + 1u], fs[3ull * i + 2u]};
-            qq = V4{fr[4ull * i], fr[4ull * i + 1u], fr[4ull * i + 2u], fr[4ull * i + 3u]};
+            if constexpr (!WIDE) {
+                tt = V3{ft[3ull * i], ft[3ull * i + 1u], ft[3ull * i + 2u]};  // (dword loads: a caller's arrays promise no alignment)
+                ss = V3{fs[3ull * i], fs[3ull * i + 1u], fs[3ull * i + 2u]};
+                qq = V4{fr[4ull * i], fr[4ull * i + 1u], fr[4ull * i + 2u], fr[4ull * i + 3u]};
+            }
             t[3ull * row] = tt.x, t[3ull * row + 1u] = tt.y, t[3ull * row + 2u] = tt.z;
             s[3ull * row] = ss.x, s[3ull * row + 1u] = ss.y, s[3ull * row + 2u] = ss.z;
             r[4ull * row] = qq.x, r[4ull * row + 1u] = qq.y, r[4ull * row + 2u] = qq.z, r[4ull * row + 3u] = qq.w;
@@ -799,8 +825,13 @@ hipError_t launch_upload_trs_indexed(const uint32_t* rows, const float* t_src, c
         const uint32_t cb = (n_clear_words + 1023u) / 1024u < 1024u ? (n_clear_words + 1023u) / 1024u : 1024u;
         blocks = blocks > cb ? blocks : cb;
     }
-    MI_LAUNCH(k_upload_trs_indexed, dim3(blocks), dim3(256), 0, stream, rows, t_src, r_src, s_src, n, t, r, s, changed, changed_gen, parent_idx,
-              mark_bytes, clear_words, n_clear_words, mark_bytes ? anc : nullptr, g_ahead, g_reversed ? 1u : 0u);
+    const bool wide = (((uintptr_t)t_src | (uintptr_t)r_src | (uintptr_t)s_src) & 15u) == 0;
+    if (wide)
+        MI_LAUNCH(k_upload_trs_indexed<true>, dim3(blocks), dim3(256), 0, stream, rows, t_src, r_src, s_src, n, t, r, s, changed, changed_gen, parent_idx,
+                  mark_bytes, clear_words, n_clear_words, mark_bytes ? anc : nullptr, g_ahead, g_reversed ? 1u : 0u);
+    else
+        MI_LAUNCH(k_upload_trs_indexed<false>, dim3(blocks), dim3(256), 0, stream, rows, t_src, r_src, s_src, n, t, r, s, changed, changed_gen, parent_idx,
+                  mark_bytes, clear_words, n_clear_words, mark_bytes ? anc : nullptr, g_ahead, g_reversed ? 1u : 0u);
     return hipGetLastError();
 }
 

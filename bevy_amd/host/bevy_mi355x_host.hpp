@@ -119,16 +119,21 @@ class World {
     Entity spawn(const Transform& t = Transform{}) {
         uint32_t i;
         if (!free_.empty()) { i = free_.back(); free_.pop_back(); }
-        else { i = (uint32_t)rec_.size(); rec_.emplace_back(); vv_.push_back(0); vv_changed_.push_back(0); }
+        else {
+            i = (uint32_t)rec_.size();
+            rec_.emplace_back(); vv_.push_back(0); vv_changed_.push_back(0);
+            transform_.emplace_back(); global_.emplace_back(); moved_.push_back(0); global_changed_.push_back(0); touched_flag_.push_back(0);
+        }
         Rec& r = rec_[i];
         const uint32_t gen = r.generation;
-        const bool was_touched = r.touched;
         r = Rec{};
         r.generation = gen;
-        r.touched = was_touched;
         r.alive = true;
-        r.transform = t;
+        transform_[i] = t;
+        global_[i] = GlobalTransform{};
+        global_changed_[i] = 0;
         r.transform_changed = r.added = true;
+        moved_[i] = 1;
         vv_[i] = vv_changed_[i] = 0;
         touch(i);
         ++structure_version_;
@@ -144,6 +149,7 @@ class World {
         Rec& r = rec(e);
         if (r.point_light_range) ++lights_version_;
         r.alive = false;
+        moved_[e.index] = 0;
         ++r.generation;
         free_.push_back(e.index);
         ++structure_version_;
@@ -156,6 +162,7 @@ class World {
         remove_parent(child);
         rec(child).parent = parent;
         rec(child).parent_changed = true;
+        moved_[child.index] = 1;
         touch(child.index);
         rec(parent).children.push_back(child);
         ++structure_version_;
@@ -169,21 +176,23 @@ class World {
         sib.erase(std::remove(sib.begin(), sib.end(), child), sib.end());
         r.parent.reset();
         r.orphaned = true;
+        moved_[child.index] = 1;
         touch(child.index);
         ++structure_version_;
     }
     // test-only: corrupt ChildOf without touching Children (systems.rs:1127-1147 does the same with unsafe code)
     void set_child_of_unchecked(Entity child, Entity parent) { rec(child).parent = parent; ++structure_version_; }
 
-    const Transform& transform(Entity e) const { return rec(e).transform; }
+    const Transform& transform(Entity e) const { rec(e); return transform_[e.index]; }
     Transform& transform_mut(Entity e) {  // DerefMut bumps the tick
         Rec& r = rec(e);
         r.transform_changed = true;
+        moved_[e.index] = 1;
         touch(e.index);
-        return r.transform;
+        return transform_[e.index];
     }
-    const GlobalTransform& global_transform(Entity e) const { return rec(e).global; }
-    bool global_transform_changed(Entity e) const { return rec(e).global_changed; }
+    const GlobalTransform& global_transform(Entity e) const { rec(e); return global_[e.index]; }
+    bool global_transform_changed(Entity e) const { rec(e); return global_changed_[e.index] != 0; }
     std::optional<Entity> parent(Entity e) const { return rec(e).parent; }
     const std::vector<Entity>& children(Entity e) const { return rec(e).children; }
 
@@ -224,11 +233,14 @@ class World {
     // mark_newly_hidden_entities_invisible, visibility/mod.rs:908-918
     void mark_newly_hidden_entities_invisible() {
         const size_t n = vv_.size();
-        for (size_t i = 0; i < n; ++i)
-            if ((vv_[i] & 3u) == 2u) {
-                vv_[i] = 0;
-                vv_changed_[i] = 1;
-            }
+        uint8_t* vv = vv_.data();
+        uint8_t* chg = vv_changed_.data();
+        for (size_t i = 0; i < n; ++i) {  // (branch-free: a pass over a byte column, as the table walk is)
+            const uint8_t v = vv[i];
+            const uint8_t hide = (uint8_t)((v & 3u) == 2u);
+            vv[i] = hide ? (uint8_t)0 : v;
+            chg[i] = (uint8_t)(chg[i] | hide);
+        }
     }
 
     // World::clear_trackers(): change flags older than this frame are no longer "changed"
@@ -236,9 +248,9 @@ class World {
         for (uint32_t i : touched_) {
             Rec& r = rec_[i];
             r.transform_changed = r.added = r.parent_changed = r.orphaned = false;
-            r.global_changed = r.inherited_changed = false;
+            r.inherited_changed = false;
             r.visibility_changed = r.bounds_changed = false;
-            r.touched = false;
+            moved_[i] = global_changed_[i] = touched_flag_[i] = 0;
         }
         touched_.clear();
         std::fill(vv_changed_.begin(), vv_changed_.end(), (uint8_t)0);
@@ -267,9 +279,8 @@ class World {
         std::optional<float> point_light_range;
         std::optional<MeshBinning> binning;
         bool transform_changed = false, added = false, parent_changed = false, orphaned = false;
-        bool global_changed = false, inherited_changed = false;
+        bool inherited_changed = false;
         bool visibility_changed = false, bounds_changed = false;
-        bool touched = false;  // listed in touched_: some change flag is set (what a change-tick scan would find)
     };
     Rec& rec(Entity e) {
         if (!contains(e)) throw std::out_of_range("no such entity");
@@ -280,12 +291,19 @@ class World {
         return rec_[e.index];
     }
     void touch(uint32_t i) {
-        if (!rec_[i].touched) {
-            rec_[i].touched = true;
+        if (!touched_flag_[i]) {
+            touched_flag_[i] = 1;
             touched_.push_back(i);
         }
     }
     std::vector<Rec> rec_;
+    // The components the per-frame loops stream through live in columns of their own, by entity index -- as they do in Bevy's tables
+    // (a Rec is ~200 bytes: walking a million of them for one field each was the whole cost of the gather and write-back loops):
+    std::vector<Transform> transform_;
+    std::vector<GlobalTransform> global_;
+    std::vector<uint8_t> moved_;           // alive && (Changed<Transform> || Added || Changed<ChildOf> || orphaned): what the propagate's filter asks
+    std::vector<uint8_t> global_changed_;  // Changed<GlobalTransform>
+    std::vector<uint8_t> touched_flag_;    // listed in touched_: some change flag is set (what a change-tick scan would find)
     std::vector<uint8_t> vv_, vv_changed_;  // ViewVisibility's packed byte and its change flag, by entity index
     std::vector<uint32_t> touched_;         // entity indices with a change flag set since clear_trackers
     std::vector<uint32_t> free_;
@@ -340,12 +358,13 @@ class Mi355xPlugin {
         std::vector<uint32_t> rows;
         std::vector<float> t, r, s;
         for (uint32_t row = 0; row < n; ++row) {
-            const World::Rec& e = w.rec_[entity_of_row_[row].index];
-            if (!(e.transform_changed || e.added || e.parent_changed || e.orphaned)) continue;
+            const uint32_t i = entity_of_row_[row].index;
+            if (!w.moved_[i]) continue;
+            const Transform& tr = w.transform_[i];
             rows.push_back(row);
-            t.insert(t.end(), {e.transform.translation.x, e.transform.translation.y, e.transform.translation.z});
-            r.insert(r.end(), {e.transform.rotation.x, e.transform.rotation.y, e.transform.rotation.z, e.transform.rotation.w});
-            s.insert(s.end(), {e.transform.scale.x, e.transform.scale.y, e.transform.scale.z});
+            t.insert(t.end(), {tr.translation.x, tr.translation.y, tr.translation.z});
+            r.insert(r.end(), {tr.rotation.x, tr.rotation.y, tr.rotation.z, tr.rotation.w});
+            s.insert(s.end(), {tr.scale.x, tr.scale.y, tr.scale.z});
         }
         check(mi_upload_transforms_indexed(ctx_, (uint32_t)rows.size(), rows.data(), t.data(), r.data(), s.data()));
         if (rows.empty()) {  // keep "nothing changed" distinct from "no change information" (= all dirty)
@@ -359,10 +378,10 @@ class Mi355xPlugin {
         std::vector<float> cg(12 * (size_t)n);
         check(mi_download_changed_global_transforms(ctx_, crow.data(), cg.data(), n, &count));
         for (uint32_t k = 0; k < count; ++k) {
-            World::Rec& e = w.rec_[entity_of_row_[crow[k]].index];
-            std::memcpy(e.global.cols, &cg[12 * (size_t)k], 48);
-            e.global_changed = true;
-            w.touch(entity_of_row_[crow[k]].index);
+            const uint32_t i = entity_of_row_[crow[k]].index;
+            std::memcpy(w.global_[i].cols, &cg[12 * (size_t)k], 48);
+            w.global_changed_[i] = 1;
+            w.touch(i);
         }
     }
 
@@ -407,10 +426,7 @@ class Mi355xPlugin {
         // ---- in: Changed<Transform> rows (World::touched_ is what the query's change-tick scan yields), written straight into the
         //      library's pinned upload window: no Vec of our own, no staging copy
         uint32_t n_in = 0;
-        for (uint32_t i : w.touched_) {
-            const World::Rec& e = w.rec_[i];
-            n_in += e.alive && (e.transform_changed || e.added || e.parent_changed || e.orphaned);
-        }
+        for (uint32_t i : w.touched_) n_in += w.moved_[i];
         // every row moved: the dense window (filled by row, DMA straight from it); otherwise rows + values for the scatter kernel
         const bool dense = n_in == n;
         mi_upload_window win{};
@@ -424,10 +440,10 @@ class Mi355xPlugin {
                 const uint32_t lo = (uint32_t)((uint64_t)n * p / pieces), hi = (uint32_t)((uint64_t)n * (p + 1) / pieces);
                 check(mi_map_upload_window(ctx_, hi - lo, MI_UPLOAD_DENSE, &win));
                 for (uint32_t row = lo; row < hi; ++row) {
-                    const World::Rec& e = w.rec_[entity_of_row_[row].index];
-                    std::memcpy(win.translation + 3 * (size_t)(row - lo), &e.transform.translation, 12);
-                    std::memcpy(win.rotation + 4 * (size_t)(row - lo), &e.transform.rotation, 16);
-                    std::memcpy(win.scale + 3 * (size_t)(row - lo), &e.transform.scale, 12);
+                    const Transform& tr = w.transform_[entity_of_row_[row].index];
+                    std::memcpy(win.translation + 3 * (size_t)(row - lo), &tr.translation, 12);
+                    std::memcpy(win.rotation + 4 * (size_t)(row - lo), &tr.rotation, 16);
+                    std::memcpy(win.scale + 3 * (size_t)(row - lo), &tr.scale, 12);
                 }
                 const auto tc = std::chrono::steady_clock::now();
                 check(mi_commit_upload_window(ctx_, &win, hi - lo, lo));
@@ -439,14 +455,14 @@ class Mi355xPlugin {
         check(mi_map_upload_window(ctx_, n_in, dense ? MI_UPLOAD_DENSE : 0u, &win));
         uint32_t k = 0;
         if (win.capacity) for (uint32_t i : w.touched_) {
-            const World::Rec& e = w.rec_[i];
-            if (!e.alive || !(e.transform_changed || e.added || e.parent_changed || e.orphaned)) continue;
+            if (!w.moved_[i]) continue;
+            const Transform& tr = w.transform_[i];
             const uint32_t row = row_of_index_[i];
             const size_t at = dense ? row : k;
             if (!dense) win.rows[k] = row;
-            std::memcpy(win.translation + 3 * at, &e.transform.translation, 12);
-            std::memcpy(win.rotation + 4 * at, &e.transform.rotation, 16);
-            std::memcpy(win.scale + 3 * at, &e.transform.scale, 12);
+            std::memcpy(win.translation + 3 * at, &tr.translation, 12);
+            std::memcpy(win.rotation + 4 * at, &tr.rotation, 16);
+            std::memcpy(win.scale + 3 * at, &tr.scale, 12);
             ++k;
         }
         const auto t_gathered = std::chrono::steady_clock::now();
@@ -508,9 +524,8 @@ class Mi355xPlugin {
         // ---- ECS writes (the pointers lead into the library's pinned window: read here, nothing kept)
         for (uint32_t k = 0; k < fr.changed_count; ++k) {  // TransformSystems::Propagate
             const uint32_t i = entity_of_row_[fr.changed_rows[k]].index;
-            World::Rec& e = w.rec_[i];
-            std::memcpy(e.global.cols, fr.changed_global12 + 12 * (size_t)k, 48);
-            e.global_changed = true;
+            std::memcpy(w.global_[i].cols, fr.changed_global12 + 12 * (size_t)k, 48);
+            w.global_changed_[i] = 1;
             w.touch(i);
         }
         out.changed_global_transforms = fr.changed_count;
@@ -639,7 +654,7 @@ class Mi355xPlugin {
             const World::Rec& r = w.rec_[e.index];
             if (!r.point_light_range || !(w.vv_[e.index] & 1u)) continue;  // `.filter(|(.., visibility)| visibility.get())`, assign.rs:194
             lights.push_back(e);
-            pos_range.insert(pos_range.end(), {r.global.cols[9], r.global.cols[10], r.global.cols[11], *r.point_light_range});
+            pos_range.insert(pos_range.end(), {w.global_[e.index].cols[9], w.global_[e.index].cols[10], w.global_[e.index].cols[11], *r.point_light_range});
         }
         uint32_t tile[2], dims[3];
         if (mi_cluster_view_dims(cam.screen_width, cam.screen_height, cam.requested_dimensions, tile, dims) != MI_OK)
@@ -713,10 +728,11 @@ class Mi355xPlugin {
             std::vector<uint64_t> keys(n);
             for (uint32_t row = 0; row < n; ++row) {
                 const World::Rec& e = w.rec_[entity_of_row_[row].index];
-                std::memcpy(&t[3 * (size_t)row], &e.transform.translation, 12);
-                std::memcpy(&r[4 * (size_t)row], &e.transform.rotation, 16);
-                std::memcpy(&s[3 * (size_t)row], &e.transform.scale, 12);
-                std::memcpy(&g[12 * (size_t)row], e.global.cols, 48);
+                const uint32_t ei = entity_of_row_[row].index;
+                std::memcpy(&t[3 * (size_t)row], &w.transform_[ei].translation, 12);
+                std::memcpy(&r[4 * (size_t)row], &w.transform_[ei].rotation, 16);
+                std::memcpy(&s[3 * (size_t)row], &w.transform_[ei].scale, 12);
+                std::memcpy(&g[12 * (size_t)row], w.global_[ei].cols, 48);
                 changed[row] = (e.transform_changed || e.added || e.parent_changed || e.orphaned) ? 1 : 0;
                 vv[row] = w.vv_[entity_of_row_[row].index];
                 keys[row] = entity_of_row_[row].to_bits();

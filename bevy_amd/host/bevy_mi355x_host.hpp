@@ -16,13 +16,19 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <optional>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/bevy_mi355x.h"
@@ -220,8 +226,17 @@ class World {
     // take them out; in the three-system form the device runs them as part of mi_cull and the whole column comes back).
     // ViewVisibility is a dense byte column here, as it is a table column in the ECS. ----
     // reset_view_visibility, visibility/mod.rs:733-737: ViewVisibility::update() under bypass_change_detection
-    void reset_view_visibility() {
-        for (uint8_t& v : vv_) v = (uint8_t)((v & 1u) << 1);
+    void reset_view_visibility() {  // (eight bytes of the column at a time)
+        uint8_t* vv = vv_.data();
+        const size_t n = vv_.size();
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) {
+            uint64_t x;
+            std::memcpy(&x, vv + i, 8);
+            x = (x & 0x0101010101010101ull) << 1;
+            std::memcpy(vv + i, &x, 8);
+        }
+        for (; i < n; ++i) vv[i] = (uint8_t)((vv[i] & 1u) << 1);
     }
     // SetViewVisibility::set_visible, visibility/mod.rs:290-306: the tick moves only on a hidden -> visible transition
     void set_visible(Entity e) {
@@ -235,7 +250,19 @@ class World {
         const size_t n = vv_.size();
         uint8_t* vv = vv_.data();
         uint8_t* chg = vv_changed_.data();
-        for (size_t i = 0; i < n; ++i) {  // (branch-free: a pass over a byte column, as the table walk is)
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) {  // (eight bytes at a time: hide = previous-frame bit set, this-frame bit clear)
+            uint64_t x, c;
+            std::memcpy(&x, vv + i, 8);
+            const uint64_t hide = (x >> 1) & ~x & 0x0101010101010101ull;
+            if (!hide) continue;
+            std::memcpy(&c, chg + i, 8);
+            x &= ~(hide * 0xFFull);
+            c |= hide;
+            std::memcpy(vv + i, &x, 8);
+            std::memcpy(chg + i, &c, 8);
+        }
+        for (; i < n; ++i) {
             const uint8_t v = vv[i];
             const uint8_t hide = (uint8_t)((v & 3u) == 2u);
             vv[i] = hide ? (uint8_t)0 : v;
@@ -268,8 +295,6 @@ class World {
     struct Rec {
         bool alive = false;
         uint32_t generation = 0;
-        Transform transform;
-        GlobalTransform global;
         std::optional<Entity> parent;
         std::vector<Entity> children;
         Visibility visibility = Visibility::Inherited;
@@ -338,6 +363,79 @@ struct ClusterCamera {  // what the per-view setup of assign.rs:342-485 reads
 struct View {  // an active camera: Frustum + RenderLayers (crates/bevy_camera/src/visibility/mod.rs:756-781)
     float frustum[24];
     uint32_t layer_mask = 1;
+};
+
+// A handful of threads for the per-frame loops over the tables: the gather of the moved Transforms into the upload windows and the
+// write-back of the changed GlobalTransforms (Bevy runs such loops as par_iter on its ComputeTaskPool; single-threaded they cost
+// more than the PCIe transfers they feed).  for_each_chunk(n, fn): fn(0) .. fn(n-1), each once, on the workers and the caller.
+class TaskPool {
+  public:
+    explicit TaskPool(unsigned n_workers) {
+        for (unsigned i = 0; i < n_workers; ++i) workers_.emplace_back([this] { run(); });
+    }
+    ~TaskPool() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+            ++gen_;
+        }
+        cv_.notify_all();
+        for (std::thread& t : workers_) t.join();
+    }
+    TaskPool(const TaskPool&) = delete;
+    TaskPool& operator=(const TaskPool&) = delete;
+    unsigned threads() const { return (unsigned)workers_.size() + 1u; }
+    void for_each_chunk(uint32_t n_chunks, const std::function<void(uint32_t)>& fn) {
+        if (n_chunks <= 1 || workers_.empty()) {
+            for (uint32_t c = 0; c < n_chunks; ++c) fn(c);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = &fn;
+            total_ = n_chunks;
+            done_.store(0, std::memory_order_relaxed);
+            next_.store(0, std::memory_order_release);
+            ++gen_;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(m_);
+        cv_done_.wait(lk, [&] { return done_.load(std::memory_order_acquire) == total_; });
+    }
+
+  private:
+    void work() {
+        for (;;) {
+            const uint32_t c = next_.fetch_add(1, std::memory_order_acq_rel);
+            if (c >= total_) return;
+            (*job_)(c);
+            if (done_.fetch_add(1, std::memory_order_acq_rel) + 1 == total_) {
+                std::lock_guard<std::mutex> lk(m_);
+                cv_done_.notify_all();
+            }
+        }
+    }
+    void run() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+            }
+            work();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, cv_done_;
+    const std::function<void(uint32_t)>* job_ = nullptr;
+    uint32_t total_ = 0;  // (written under m_ before next_ is reset: a worker that draws a chunk sees the job it belongs to)
+    std::atomic<uint32_t> next_{0}, done_{0};
+    uint64_t gen_ = 0;
+    bool stop_ = false;
 };
 
 class Mi355xPlugin {
@@ -425,8 +523,18 @@ class Mi355xPlugin {
         const auto t_start = std::chrono::steady_clock::now();
         // ---- in: Changed<Transform> rows (World::touched_ is what the query's change-tick scan yields), written straight into the
         //      library's pinned upload window: no Vec of our own, no staging copy
-        uint32_t n_in = 0;
-        for (uint32_t i : w.touched_) n_in += w.moved_[i];
+        // (in chunks of the touched list: each chunk counts its moved entities, then writes them behind the chunks in front of it)
+        const uint32_t n_touched = (uint32_t)w.touched_.size();
+        const uint32_t g_parts = n_touched >= 32768u ? pool().threads() : 1u;
+        uint32_t g_count[64] = {0}, g_first[65] = {0};
+        pool().for_each_chunk(g_parts, [&](uint32_t c) {
+            const uint32_t a = (uint32_t)((uint64_t)n_touched * c / g_parts), b = (uint32_t)((uint64_t)n_touched * (c + 1) / g_parts);
+            uint32_t m = 0;
+            for (uint32_t j = a; j < b; ++j) m += w.moved_[w.touched_[j]];
+            g_count[c] = m;
+        });
+        for (uint32_t c = 0; c < g_parts; ++c) g_first[c + 1] = g_first[c] + g_count[c];
+        uint32_t n_in = g_first[g_parts];
         // every row moved: the dense window (filled by row, DMA straight from it); otherwise rows + values for the scatter kernel
         const bool dense = n_in == n;
         mi_upload_window win{};
@@ -439,12 +547,16 @@ class Mi355xPlugin {
             for (uint32_t p = 0; p < pieces; ++p) {
                 const uint32_t lo = (uint32_t)((uint64_t)n * p / pieces), hi = (uint32_t)((uint64_t)n * (p + 1) / pieces);
                 check(mi_map_upload_window(ctx_, hi - lo, MI_UPLOAD_DENSE, &win));
-                for (uint32_t row = lo; row < hi; ++row) {
-                    const Transform& tr = w.transform_[entity_of_row_[row].index];
-                    std::memcpy(win.translation + 3 * (size_t)(row - lo), &tr.translation, 12);
-                    std::memcpy(win.rotation + 4 * (size_t)(row - lo), &tr.rotation, 16);
-                    std::memcpy(win.scale + 3 * (size_t)(row - lo), &tr.scale, 12);
-                }
+                const uint32_t parts = pool().threads();
+                pool().for_each_chunk(parts, [&](uint32_t c) {
+                    const uint32_t a = lo + (uint32_t)((uint64_t)(hi - lo) * c / parts), b = lo + (uint32_t)((uint64_t)(hi - lo) * (c + 1) / parts);
+                    for (uint32_t row = a; row < b; ++row) {
+                        const Transform& tr = w.transform_[entity_of_row_[row].index];
+                        std::memcpy(win.translation + 3 * (size_t)(row - lo), &tr.translation, 12);
+                        std::memcpy(win.rotation + 4 * (size_t)(row - lo), &tr.rotation, 16);
+                        std::memcpy(win.scale + 3 * (size_t)(row - lo), &tr.scale, 12);
+                    }
+                });
                 const auto tc = std::chrono::steady_clock::now();
                 check(mi_commit_upload_window(ctx_, &win, hi - lo, lo));
                 commit_in_gather_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc).count();
@@ -453,18 +565,22 @@ class Mi355xPlugin {
             win = mi_upload_window{};
         } else
         check(mi_map_upload_window(ctx_, n_in, dense ? MI_UPLOAD_DENSE : 0u, &win));
-        uint32_t k = 0;
-        if (win.capacity) for (uint32_t i : w.touched_) {
-            if (!w.moved_[i]) continue;
-            const Transform& tr = w.transform_[i];
-            const uint32_t row = row_of_index_[i];
-            const size_t at = dense ? row : k;
-            if (!dense) win.rows[k] = row;
-            std::memcpy(win.translation + 3 * at, &tr.translation, 12);
-            std::memcpy(win.rotation + 4 * at, &tr.rotation, 16);
-            std::memcpy(win.scale + 3 * at, &tr.scale, 12);
-            ++k;
-        }
+        if (win.capacity) pool().for_each_chunk(g_parts, [&](uint32_t c) {
+            const uint32_t a = (uint32_t)((uint64_t)n_touched * c / g_parts), b = (uint32_t)((uint64_t)n_touched * (c + 1) / g_parts);
+            uint32_t k = g_first[c];
+            for (uint32_t j = a; j < b; ++j) {
+                const uint32_t i = w.touched_[j];
+                if (!w.moved_[i]) continue;
+                const Transform& tr = w.transform_[i];
+                const uint32_t row = row_of_index_[i];
+                const size_t at = dense ? row : k;
+                if (!dense) win.rows[k] = row;
+                std::memcpy(win.translation + 3 * at, &tr.translation, 12);
+                std::memcpy(win.rotation + 4 * at, &tr.rotation, 16);
+                std::memcpy(win.scale + 3 * at, &tr.scale, 12);
+                ++k;
+            }
+        });
         const auto t_gathered = std::chrono::steady_clock::now();
         if (win.capacity) check(mi_commit_upload_window(ctx_, &win, n_in, 0));
         // (every row moved: the frame below is the all-rows frame -- no change bytes to raise, and nothing between the upload and the
@@ -522,11 +638,22 @@ class Mi355xPlugin {
         out.device_waits += 1;
         const auto t_results = std::chrono::steady_clock::now();
         // ---- ECS writes (the pointers lead into the library's pinned window: read here, nothing kept)
-        for (uint32_t k = 0; k < fr.changed_count; ++k) {  // TransformSystems::Propagate
-            const uint32_t i = entity_of_row_[fr.changed_rows[k]].index;
-            std::memcpy(w.global_[i].cols, fr.changed_global12 + 12 * (size_t)k, 48);
-            w.global_changed_[i] = 1;
-            w.touch(i);
+        {  // TransformSystems::Propagate: Mut<GlobalTransform> of the returned rows (distinct entities: chunks write disjoint records)
+            const uint32_t n_chg = fr.changed_count, parts = n_chg >= 32768u ? pool().threads() : 1u;
+            std::vector<uint32_t> fresh[64];  // per chunk: entities this write-back is the first to touch since clear_trackers
+            pool().for_each_chunk(parts, [&](uint32_t c) {
+                const uint32_t a = (uint32_t)((uint64_t)n_chg * c / parts), b = (uint32_t)((uint64_t)n_chg * (c + 1) / parts);
+                for (uint32_t k = a; k < b; ++k) {
+                    const uint32_t i = entity_of_row_[fr.changed_rows[k]].index;
+                    std::memcpy(w.global_[i].cols, fr.changed_global12 + 12 * (size_t)k, 48);
+                    w.global_changed_[i] = 1;
+                    if (!w.touched_flag_[i]) {
+                        w.touched_flag_[i] = 1;
+                        fresh[c].push_back(i);
+                    }
+                }
+            });
+            for (uint32_t c = 0; c < parts; ++c) w.touched_.insert(w.touched_.end(), fresh[c].begin(), fresh[c].end());
         }
         out.changed_global_transforms = fr.changed_count;
         if (!views.empty()) {  // VisibilitySystems::CheckVisibility, between the two stock systems
@@ -848,6 +975,11 @@ class Mi355xPlugin {
     mi_ctx* ctx_ = nullptr;
     std::vector<float> plane_storage_;
     std::vector<uint8_t> scratch_ones_;
+    std::unique_ptr<TaskPool> pool_;
+    TaskPool& pool() {  // a few threads, started at the first big frame (half the hardware threads, eight at most)
+        if (!pool_) pool_.reset(new TaskPool(std::min(8u, std::max(2u, std::thread::hardware_concurrency() / 2u)) - 1u));
+        return *pool_;
+    }
     std::vector<mi_view> mviews_;
     std::vector<Entity> light_entities_;
     std::vector<uint32_t> row_of_index_;

@@ -543,6 +543,61 @@ static void both_forms_leave_the_same_world() {
     }
 }
 
+static Transform on_sphere(uint64_t i, uint64_t n, double radius, uint64_t& seed, bool rotate);  // (below, with the bench)
+// The same twin-world check at a size where the fused frame takes its big-table routes: the gather and the write-back in chunks on the
+// plugin's threads, an all-dirty table committed as eight dense windows (which the library sends in pieces, fetching the
+// GlobalTransforms ahead of the frame from the second such frame on), indexed windows whose rows descend (GlobalTransforms written
+// ahead by the scatter launch).  Flat scene, every tenth entity a point light.
+static void big_flat_worlds_agree() {
+    World wa, wb;
+    Mi355xPlugin pa, pb;
+    const uint32_t n = 300000;
+    uint64_t seed = 7;
+    std::vector<Entity> ents;
+    ents.reserve(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const Transform t = on_sphere(i, n, i % 10 == 9 ? 30.0 : 120.0, seed, i % 10 != 9);
+        Entity ea = wa.spawn(t), eb = wb.spawn(t);
+        if (i % 10 == 9) { wa.insert_point_light(ea, 0.5f); wb.insert_point_light(eb, 0.5f); }
+        else { const Aabb a{{0, 0, 0}, {0.5f, 0.5f, 0.5f}}; wa.insert_aabb(ea, a); wb.insert_aabb(eb, a); }
+        ents.push_back(ea);
+    }
+    ClusterCamera cam;
+    mi_perspective_clip_from_view(3.14159265f / 4.0f, 16.0f / 9.0f, 0.1f, cam.clip_from_view);
+    mi_compute_frustum(cam.clip_from_view, cam.camera_affine, 1000.0f, cam.frustum);
+    View view;
+    std::memcpy(view.frustum, cam.frustum, sizeof view.frustum);
+    const std::vector<View> views = {view};
+    const int moves[8] = {0 /* everything was just spawned */, 1, 1, 10, 10, 0, 1, 10};  // every k-th entity moves (0: none)
+    for (int frame = 0; frame < 8; ++frame) {
+        if (frame) { wa.clear_trackers(); wb.clear_trackers(); }
+        if (moves[frame])
+            for (uint32_t i = (uint32_t)frame % (uint32_t)moves[frame]; i < n; i += (uint32_t)moves[frame]) {
+                const float d = 0.01f * (float)(frame + 1);
+                wa.transform_mut(ents[i]).translation.y += d; wb.transform_mut(ents[i]).translation.y += d;
+            }
+        pa.propagate_transforms(wa);
+        pa.visibility_propagate(wa);
+        pa.check_visibility(wa, views);
+        const Clusters ca = pa.assign_objects_to_clusters(wa, cam);
+        const Mi355xPlugin::FrameOutput fb = pb.frame(wb, views, &cam);
+        bool same = true, same_ticks = true;
+        for (Entity e : ents) {
+            same = same && wa.global_transform(e) == wb.global_transform(e) && wa.view_visibility(e) == wb.view_visibility(e);
+            same_ticks = same_ticks && wa.global_transform_changed(e) == wb.global_transform_changed(e) &&
+                         wa.view_visibility_changed(e) == wb.view_visibility_changed(e);
+        }
+        CHECK(same, "big worlds: component values");
+        CHECK(same_ticks, "big worlds: change ticks");
+        CHECK(pa.visible_entities(0) == fb.visible_entities[0], "big worlds: VisibleEntities");
+        bool lists = fb.has_clusters && ca.total_index_count == fb.clusters.total_index_count && ca.farthest_z == fb.clusters.farthest_z &&
+                     ca.clusterable_objects.size() == fb.clusters.clusterable_objects.size();
+        for (size_t c = 0; lists && c < ca.clusterable_objects.size(); ++c) lists = ca.clusterable_objects[c].entities == fb.clusters.clusterable_objects[c].entities;
+        CHECK(lists, "big worlds: Clusters");
+        if (frame == 1) CHECK(fb.changed_global_transforms == n, "every GlobalTransform came back");
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // --bench: BASELINE's metric scene (1 M many_cubes entities + 10 k meshes + 100 k point lights, one camera) through the host
 // layer, both call sequences, at 1 % / 10 % / 100 % of the Transforms moved per frame.  Prints one JSON object.
@@ -649,12 +704,13 @@ int main(int argc, char** argv) {
                        {"visible_entities_are_sorted_by_entity", visible_entities_are_sorted_by_entity},
                        {"lights_are_assigned_to_clusters", lights_are_assigned_to_clusters},
                        {"render_multidrawable_batch_set", render_multidrawable_batch_set},
-                       {"both_forms_leave_the_same_world", both_forms_leave_the_same_world}};
+                       {"both_forms_leave_the_same_world", both_forms_leave_the_same_world},
+                       {"big_flat_worlds_agree", big_flat_worlds_agree}};
     int n_failed_tests = 0, n_tests = 0;
     for (int form = 0; form < 2; ++form) {
         g_fused = form == 1;
         for (const T& t : tests) {
-            if (form == 1 && t.fn == both_forms_leave_the_same_world) continue;  // (drives both forms itself)
+            if (form == 1 && (t.fn == both_forms_leave_the_same_world || t.fn == big_flat_worlds_agree)) continue;  // (drive both forms themselves)
             const int before = g_failed;
             ++n_tests;
             try {

@@ -1022,6 +1022,12 @@ int32_t mi_map_upload_window(mi_ctx* ctx, uint32_t capacity, uint32_t flags, mi_
         // nothing is mapped: recycle.  What the device still reads of earlier windows (DMA, the scatter kernel) has to be done
         // first -- by now normally long since (the frame's results were waited for)
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->gs_k && ctx->gs_rows != ctx->gs_rows_rev.data()) {
+            // the rows of the last indexed window may still be owed to a results call (written-ahead GlobalTransforms, ctx.h): they
+            // move out of the memory that is about to be handed out again
+            ctx->gs_rows_rev.assign(ctx->gs_rows, ctx->gs_rows + ctx->gs_k);
+            ctx->gs_rows = ctx->gs_rows_rev.data();
+        }
         while (chunks.size() > 1) {  // keep the biggest chunk
             auto small = chunks.begin();
             for (auto it = chunks.begin(); it != chunks.end(); ++it)

@@ -236,7 +236,7 @@ def window(ctx, rows, t, sc, n):
 
 
 SPARSE_CASES = ["plain", "descending", "not monotonic", "a mark from elsewhere", "two windows", "a dense write in between", "an all-rows frame",
-                "a second frame before the results", "results twice", "capacity too small", "default rule"]
+                "a second frame before the results", "results twice", "capacity too small", "default rule", "windows mapped before the results"]
 
 
 @pytest.mark.parametrize("case", SPARSE_CASES)
@@ -293,6 +293,19 @@ def test_changed_rows_frames_with_globals_written_ahead(case, in_place):
                 if case == "a second frame before the results" and frame % 2 == 1:
                     ctx.propagate_and_cull(fr, flags=flags)  # nothing is marked any more: no GlobalTransform changes in this one
                     expect = np.zeros(0, np.uint32)
+                if case == "windows mapped before the results":  # the caller already fills the next frame's windows: the memory of the
+                    held = []                                     # committed one is handed out again (several maps force the recycling)
+                    for _ in range(3):
+                        w2, r2, t2, q2, s2 = ctx.map_upload_window(400_000)
+                        r2[:] = 0xDEADBEEF
+                        t2[:] = -1.0
+                        held.append(w2)
+                    for w2 in held:
+                        ctx.commit_upload_window(w2, 0)
+                    w2, r2, t2, q2, s2 = ctx.map_upload_window(400_000)  # (nothing is mapped, two chunks exist: this one starts over at the front)
+                    r2[:] = 0xDEADBEEF
+                    t2[:] = -1.0
+                    ctx.commit_upload_window(w2, 0)
                 cap = 10 if case == "capacity too small" and frame == 2 else n
                 bufs = api.FrameResultBuffers(cap, n, 0, 0, in_place=in_place)
                 if cap < len(expect):
@@ -314,5 +327,5 @@ def test_changed_rows_frames_with_globals_written_ahead(case, in_place):
     for x, y in zip(*outs):
         assert all(np.array_equal(p, q) for p, q in zip(x, y)), f"{case}: the two forms differ"
     want = {"plain": 4, "descending": 4, "not monotonic": 0, "a mark from elsewhere": 2, "two windows": 0, "a dense write in between": 2, "an all-rows frame": 2,
-            "a second frame before the results": 2, "results twice": 8, "capacity too small": 4, "default rule": 3}[case]
+            "a second frame before the results": 2, "results twice": 8, "capacity too small": 4, "default rule": 3, "windows mapped before the results": 4}[case]
     assert counts == [want, 0], f"{case}: {counts} downloads handed out GlobalTransforms written ahead"

@@ -121,6 +121,11 @@ pub struct Mi355x {
     cluster_history: EntityHashMap<ffi::MiClusterHistory>,
     /// Storage of the x / y / z cluster planes `mi_cluster_view_build` fills for the fused frame's view.
     plane_storage: Vec<f32>,
+    /// Rows follow the tables (a flat world: the level order of a forest of single nodes is the order they were listed in): a walk
+    /// over the tables visits rows 0, 1, 2 ... -- what lets an all-dirty frame fill dense upload windows in one pass.
+    rows_in_table_order: bool,
+    /// The last steady-state upload of the fused frame carried every row through dense windows: its frame call is the all-rows one.
+    every_row_moved: bool,
     scratch: Scratch,
 }
 
@@ -188,6 +193,8 @@ impl Mi355x {
                 class_bits: HashMap::default(),
                 cluster_history: EntityHashMap::default(),
                 plane_storage: Vec::new(),
+                rows_in_table_order: false,
+                every_row_moved: false,
                 scratch: Scratch::default(),
             })
         }
@@ -350,6 +357,7 @@ fn upload_and_propagate(
     frame: Option<()>,
 ) -> Result<u32, ()> {
     let ctx = mi.ctx;
+    mi.every_row_moved = false;
     let tables = transforms.contiguous_iter().expect("Transform and ChildOf are table components");
     {
         let s = &mut mi.scratch;
@@ -399,6 +407,7 @@ fn upload_and_propagate(
             };
             let (t, r, sc) = (gather3(&s.translation, 3), gather3(&s.rotation, 4), gather3(&s.scale, 3));
             mi.row_entity = s.new_to_old.iter().map(|&o| old_entities[o as usize]).collect();
+            mi.rows_in_table_order = n_levels <= 1 && s.new_to_old.iter().enumerate().all(|(row, &o)| o as usize == row);
             for (row, e) in mi.row_entity.iter().enumerate() {
                 mi.entity_row.insert(*e, row as u32);
             }
@@ -433,6 +442,46 @@ fn upload_and_propagate(
                 let changed_in = |ticks_of: &[Tick]| ticks_of.iter().filter(|t| changed_since(**t, ticks)).count();
                 let transforms_again = transforms.contiguous_iter().expect("Transform and ChildOf are table components");
                 let capacity: usize = transforms_again.map(|(_, t, _)| changed_in(t.changed_ticks_slice())).sum();
+                if capacity == mi.row_entity.len() && mi.rows_in_table_order && capacity >= 65_536 {
+                    // Every Transform moved and rows follow the tables: dense windows, one after the other, each starting where the
+                    // one before ended.  Window k crosses PCIe while this loop fills window k + 1, and the library -- which sees a
+                    // sequence of dense windows that carries the whole table -- computes each window's GlobalTransforms as it
+                    // arrives and sends them back under the rest of the upload: `mi_download_frame_results` finds them on the host
+                    // (bevy_mi355x.h, mi_download_frame_results; the C++ host layer does the same).  The caller's frame call is then
+                    // the all-rows one: no MI_CULL_CHANGED_ROWS (`every_row_moved`).
+                    const WINDOWS: usize = 8;
+                    let n = capacity;
+                    let mut row = 0usize; // rows written so far == the table walk's position
+                    let mut window: ffi::MiUploadWindow = unsafe { core::mem::zeroed() };
+                    let (mut lo, mut hi) = (0usize, 0usize); // the open window carries rows [lo, hi)
+                    for (_, table_transforms, _) in tables {
+                        for t in table_transforms.iter() {
+                            if row == hi {
+                                if hi > lo {
+                                    check(ctx, "mi_commit_upload_window", unsafe { ffi::mi_commit_upload_window(ctx, &window, (hi - lo) as u32, lo as u32) })?;
+                                }
+                                lo = hi;
+                                hi = (n * (lo * WINDOWS / n + 1) / WINDOWS).max(lo + 1).min(n);
+                                check(ctx, "mi_map_upload_window", unsafe {
+                                    ffi::mi_map_upload_window(ctx, (hi - lo) as u32, ffi::MI_UPLOAD_DENSE, &mut window)
+                                })?;
+                            }
+                            let k = row - lo;
+                            // SAFETY: k < hi - lo, the capacity the window was mapped with.
+                            unsafe {
+                                core::ptr::copy_nonoverlapping(t.translation.to_array().as_ptr(), window.translation.add(3 * k), 3);
+                                core::ptr::copy_nonoverlapping(t.rotation.to_array().as_ptr(), window.rotation.add(4 * k), 4);
+                                core::ptr::copy_nonoverlapping(t.scale.to_array().as_ptr(), window.scale.add(3 * k), 3);
+                            }
+                            row += 1;
+                        }
+                    }
+                    if hi > lo {
+                        check(ctx, "mi_commit_upload_window", unsafe { ffi::mi_commit_upload_window(ctx, &window, (hi - lo) as u32, lo as u32) })?;
+                    }
+                    mi.every_row_moved = true;
+                    return Ok(0);
+                }
                 // SAFETY: a zeroed window is the valid "nothing mapped" value; the library fills it in.
                 let mut window: ffi::MiUploadWindow = unsafe { core::mem::zeroed() };
                 check(ctx, "mi_map_upload_window", unsafe { ffi::mi_map_upload_window(ctx, capacity as u32, 0, &mut window) })?;
@@ -1273,7 +1322,12 @@ pub fn mi_fused_frame(
                 ctx,
                 views.as_ptr(),
                 views.len() as u32,
-                ffi::MI_CULL_CHANGED_ROWS | ffi::MI_CULL_END_FRAME | static_flag | if with_clusters { ffi::MI_CULL_WITH_CLUSTERS } else { 0 },
+                // (dense windows carried every row: the all-rows frame -- they raise no change marks, and it is the one the library
+                // has fetched every GlobalTransform ahead for)
+                (if mi.every_row_moved { 0 } else { ffi::MI_CULL_CHANGED_ROWS })
+                    | ffi::MI_CULL_END_FRAME
+                    | static_flag
+                    | if with_clusters { ffi::MI_CULL_WITH_CLUSTERS } else { 0 },
             )
         })?;
         check(ctx, "mi_download_frame_results", unsafe { ffi::mi_download_frame_results(ctx, &mut results) })

@@ -632,6 +632,9 @@ __global__ void __launch_bounds__(256) k_globals_ahead(const float* __restrict__
     const bool live = row >= lo && row < hi;
     Affine g = {};
     if (live) g = affine_from_srt(ld3(s, row), ld4(r, row), ld3(t, row));
+#ifdef MI_EXP_MUTANT  // (a deliberately wrong build: tests/test_gpu_chunked_frames.py must notice, tools/gpu_mutant.sh)
+    if ((row & 0xFFFu) == 0x321u) g.t.x += 1.0f;
+#endif
     const uint32_t wave_row0 = row & ~63u;
     // (wave-uniform) a wave wholly inside the piece stores its three contiguous 1 KB rows through the LDS transpose
     if (wave_row0 >= lo && wave_row0 + 64u <= hi) store_affine_coalesced(lds_g[threadIdx.x >> 6], out, wave_row0, hi, threadIdx.x & 63u, g);
@@ -790,7 +793,10 @@ __global__ void __launch_bounds__(256) k_upload_trs_indexed(const uint32_t* __re
             if (mark_bytes) mark_row_and_ancestors(row, parent_idx, mark_bytes, anc, 0xFFFFu);  // (a hierarchy is at most 65 535 levels deep here)
         }
         if (g_ahead) {
-            const Affine a = affine_from_srt(ss, qq, tt);
+            Affine a = affine_from_srt(ss, qq, tt);
+#ifdef MI_EXP_MUTANT
+            if ((i & 0xFFFu) == 0x321u) a.t.x += 1.0f;
+#endif
             const uint32_t lane = threadIdx.x & 63u;
             if (!g_reversed) store_affine_coalesced(lds_g[threadIdx.x >> 6], g_ahead, i0, n, lane, a);
             else {

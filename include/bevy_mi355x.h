@@ -459,7 +459,13 @@ int32_t mi_cluster_sort_truncate(uint32_t n, const uint8_t* obj_type, const uint
  * Output = every cluster's Vec<Entity> in push order, flattened:
  *   out_offsets[C+1], out_indices[capacity] (object index), out_counts[6*C] (ClusterableObjectCounts order),
  *   out_total = last_frame_total_cluster_index_count, out_farthest_z = last_frame_farthest_z (:810-811).
- * Returns MI_ERR_CAPACITY (with out_total/out_offsets/out_counts valid) when capacity < total. */
+ * Returns MI_ERR_CAPACITY (with out_total/out_offsets/out_counts valid) when capacity < total.
+ * Supported host libm: the z slice of a depth is floor(ln(z) * scale - bias) (view_z_to_z_slice, assign.rs:1003-1024), and the
+ * device evaluates ln with glibc's logf (>= 2.28, x86-64: correctly rounded in all but a handful of inputs, reproduced bit for bit,
+ * mi_debug_logf, tests/test_gpu_parity.py::test_device_logf_matches_libm).  A Bevy built against another libm (musl, macOS, Windows' UCRT) may round ln(z)
+ * differently for depths within an ulp of a slice boundary: such an object can then differ by one z slice from that host's own
+ * assign_objects_to_clusters.  Everything else on the device is +, -, *, /, sqrt, floor, min, max: IEEE, no library; the host
+ * helpers (mi_cluster_view_build's powf, mi_perspective_clip_from_view's sin / cos) call the host's own libm, as Bevy would. */
 int32_t mi_cluster_assign(mi_ctx* ctx, const mi_cluster_view* view, uint32_t n_objects, const float* pos_range,
                           const uint8_t* obj_type, const uint32_t* layer_mask, const float* spot_dir,
                           const float* spot_sin_cos, uint32_t* out_offsets, uint32_t* out_indices, uint64_t capacity,

@@ -1729,6 +1729,18 @@ struct BatchedDownload {
 };
 }  // namespace
 
+// 0, 1, 2 ... in pinned memory: the changed-row list of a frame in which every row changed
+static int32_t identity_rows(mi_ctx* ctx, uint32_t n) {
+    if (ctx->iota_rows >= n) return MI_OK;
+    if (ctx->iota_host) HIP_TRY(ctx, hipHostFree(ctx->iota_host));
+    ctx->iota_host = nullptr;
+    ctx->iota_rows = 0;
+    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->iota_host, (size_t)ctx->cap * 4, hipHostMallocDefault));
+    ctx->iota_rows = ctx->cap;
+    for (uint32_t i = 0; i < ctx->cap; ++i) ctx->iota_host[i] = i;
+    return MI_OK;
+}
+
 int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
     ENTER(ctx);
     if (!io) return fail(ctx, MI_ERR_INVALID_ARG, "mi_download_frame_results: NULL");
@@ -1792,7 +1804,10 @@ int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
     // the changed rows are those of one indexed upload window and their GlobalTransforms were written ahead (ctx.h): nothing to compact,
     // gather or fetch -- unless the window below turns out too small for the rest (then the usual way, further down)
     bool sparse_ahead = want_changed && ctx->gs_frame_ok && ctx->gs_k && ctx->gs_k <= io->changed_capacity && !ctx->have_hierarchy;
-    if (want_changed && !sparse_ahead && (rc = changed_rows_on_device(ctx, nullptr))) return rc;
+    // ... and so is the list of an all-rows frame of a flat table whose GlobalTransforms were fetched ahead: every row, by construction
+    // (sync_simple_transforms writes -- and ticks -- every row it visits, systems.rs:45-50)
+    bool all_ahead = want_changed && g_ahead && !sparse_ahead;
+    if (want_changed && !sparse_ahead && !all_ahead && (rc = changed_rows_on_device(ctx, nullptr))) return rc;
     uint32_t changed = 0;
     uint64_t cl_total = 0;
     const uint32_t C = ctx->cl_view.n_clusters;
@@ -1800,8 +1815,8 @@ int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
     const uint32_t* acc = want_clusters ? (const uint32_t*)ctx->cl_acc.p + ctx->cl_parity * (off_misc + 4) : nullptr;
     // worst case of every section: what the window (or, on the fallback path, the arena) has to hold
     uint64_t need = 0;
-    if (want_changed && want_rows && !sparse_ahead) need += pack_align((uint64_t)io->changed_capacity * 4u);
-    if (want_changed && want_g && !sparse_ahead) need += pack_align((uint64_t)io->changed_capacity * 48u);
+    if (want_changed && want_rows && !sparse_ahead && !all_ahead) need += pack_align((uint64_t)io->changed_capacity * 4u);
+    if (want_changed && want_g && !sparse_ahead && !all_ahead) need += pack_align((uint64_t)io->changed_capacity * 48u);
     for (uint32_t l = 0; l < n_lists; ++l)
         if (list_total[l]) need += pack_align((uint64_t)io->lists[l].capacity * 4u);
     if (want_clusters) {
@@ -1818,7 +1833,7 @@ int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
         if ((rc = stage_alloc(ctx, PACK_HEADER_BYTES + j.payload_bytes, &st))) return rc;
         j.header = (uint32_t*)st;
         j.payload = (uint8_t*)st + PACK_HEADER_BYTES;
-        if (want_changed && !sparse_ahead) {
+        if (want_changed && !sparse_ahead && !all_ahead) {
             j.changed_total = (const uint32_t*)ctx->sparse_total.p;
             j.changed_rows = (const uint32_t*)ctx->sparse_rows.p;
             j.g = want_g ? ctx->g : nullptr;
@@ -1847,7 +1862,7 @@ int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         const uint32_t* h = j.header;
         if (h[5]) {
-            changed = sparse_ahead ? ctx->gs_k : h[0];
+            changed = sparse_ahead ? ctx->gs_k : all_ahead ? ctx->n : h[0];
             cl_total = (uint64_t)h[2] | ((uint64_t)h[3] << 32);
             io->changed_count = changed;
             io->cluster_total = cl_total;
@@ -1862,7 +1877,19 @@ int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
                 src += pack_align(bytes);
             };
             const bool fits_changed = want_changed && changed <= io->changed_capacity;
-            const bool by_dma = fits_changed && !sparse_ahead && h[6] != 0;  // many rows: left out of the window, fetched by the copy engine below
+            const bool by_dma = fits_changed && !sparse_ahead && !all_ahead && h[6] != 0;  // many rows: left out of the window, fetched by the copy engine below
+            if (all_ahead) {  // every row: 0 .. n-1 and what has been arriving since the upload
+                if (want_rows) {
+                    if ((rc = identity_rows(ctx, changed))) return rc;
+                    if (in_place) io->changed_rows = ctx->iota_host;
+                    else memcpy(io->changed_rows, ctx->iota_host, (size_t)changed * 4);
+                }
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->dn_stream));
+                if (in_place) io->changed_global12 = (float*)ctx->g_host;
+                else memcpy(io->changed_global12, ctx->g_host, (size_t)changed * 48);
+                ++ctx->n_ahead_downloads;
+                ctx->pre_used = true;
+            }
             if (sparse_ahead) {  // (the scatter launch that wrote them is long done: the wait above was for a launch far behind it)
                 if (want_rows) {
                     if (in_place) io->changed_rows = const_cast<uint32_t*>(ctx->gs_rows);
@@ -1877,8 +1904,8 @@ int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
             } else if (want_changed && want_g && changed && changed < ctx->n && ctx->frame_all_version != ctx->trs_version)
                 ctx->sparse_ahead_wanted = true;  // (changed GlobalTransforms fetched the usual way: the next indexed window writes them ahead)
             if (want_changed && !fits_changed) cap_rc = fail(ctx, MI_ERR_CAPACITY, "%u GlobalTransforms changed, capacity %u", changed, io->changed_capacity);
-            if (fits_changed && !by_dma && !sparse_ahead && want_rows) deliver(io->changed_rows, (size_t)changed * 4);
-            if (fits_changed && !by_dma && !sparse_ahead && want_g) deliver(io->changed_global12, (size_t)changed * 48);
+            if (fits_changed && !by_dma && !sparse_ahead && !all_ahead && want_rows) deliver(io->changed_rows, (size_t)changed * 4);
+            if (fits_changed && !by_dma && !sparse_ahead && !all_ahead && want_g) deliver(io->changed_global12, (size_t)changed * 48);
             for (uint32_t l = 0; l < n_lists; ++l) {
                 mi_visible_list& ls = io->lists[l];
                 ls.count = h[8u + l];
@@ -1899,24 +1926,11 @@ int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
                 b.in_place = in_place;
                 if (want_rows && changed == ctx->n) {
                     // every row changed: the list (ascending, as compacted from the mask) is 0 .. n-1 -- kept on the host, nothing to fetch
-                    if (ctx->iota_rows < changed) {
-                        if (ctx->iota_host) HIP_TRY(ctx, hipHostFree(ctx->iota_host));
-                        ctx->iota_host = nullptr;
-                        ctx->iota_rows = 0;
-                        HIP_TRY(ctx, hipHostMalloc((void**)&ctx->iota_host, (size_t)ctx->cap * 4, hipHostMallocDefault));
-                        ctx->iota_rows = ctx->cap;
-                        for (uint32_t i = 0; i < ctx->cap; ++i) ctx->iota_host[i] = i;
-                    }
+                    if ((rc = identity_rows(ctx, changed))) return rc;
                     if (in_place) io->changed_rows = ctx->iota_host;
                     else memcpy(io->changed_rows, ctx->iota_host, (size_t)changed * 4);
                 } else if (want_rows && (rc = b.add(ctx, io->changed_rows, ctx->sparse_rows.p, (size_t)changed * 4, in_place ? (void**)&io->changed_rows : nullptr))) return rc;
-                if (want_g && g_ahead && changed == ctx->n) {  // on its way since the upload, or here already
-                    HIP_TRY(ctx, hipStreamSynchronize(ctx->dn_stream));
-                    b.pieces.push_back({in_place ? nullptr : (void*)io->changed_global12, ctx->g_host, (size_t)changed * 48});
-                    if (in_place) io->changed_global12 = (float*)ctx->g_host;
-                    ++ctx->n_ahead_downloads;
-                    ctx->pre_used = true;
-                } else if (want_g) {
+                if (want_g) {
                     // (every GlobalTransform of an all-rows frame fetched the usual way: the next sequence of dense windows fetches ahead)
                     if (changed == ctx->n && ctx->frame_all_version == ctx->trs_version) ctx->ahead_wanted = true;
                     const bool all_rows = changed == ctx->n;  // every row changed: the list is 0 .. n-1 and the column itself is the answer
@@ -1935,8 +1949,8 @@ int32_t mi_download_frame_results(mi_ctx* ctx, mi_frame_results* io) {
         }
         changed = 0;
         cl_total = 0;
-        if (sparse_ahead) {  // (the fallback fetches everything from the device)
-            sparse_ahead = false;
+        if (sparse_ahead || all_ahead) {  // (the fallback fetches everything from the device)
+            sparse_ahead = all_ahead = false;
             if ((rc = changed_rows_on_device(ctx, nullptr))) return rc;
         }
     }

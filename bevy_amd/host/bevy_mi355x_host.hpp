@@ -400,8 +400,10 @@ class TaskPool {
         }
         cv_.notify_all();
         work();
+        // done when every chunk is -- and when no worker is still inside work(): one that drew its last (out-of-range) index late
+        // must not draw again from the counters of the NEXT job while they are being set up
         std::unique_lock<std::mutex> lk(m_);
-        cv_done_.wait(lk, [&] { return done_.load(std::memory_order_acquire) == total_; });
+        cv_done_.wait(lk, [&] { return done_.load(std::memory_order_acquire) == total_ && active_ == 0; });
     }
 
   private:
@@ -424,8 +426,13 @@ class TaskPool {
                 cv_.wait(lk, [&] { return gen_ != seen; });
                 seen = gen_;
                 if (stop_) return;
+                ++active_;  // (under the mutex: the job's fields are set and stay put while anybody is active)
             }
             work();
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (--active_ == 0) cv_done_.notify_all();
+            }
         }
     }
     std::vector<std::thread> workers_;
@@ -435,6 +442,7 @@ class TaskPool {
     uint32_t total_ = 0;  // (written under m_ before next_ is reset: a worker that draws a chunk sees the job it belongs to)
     std::atomic<uint32_t> next_{0}, done_{0};
     uint64_t gen_ = 0;
+    uint32_t active_ = 0;  // workers inside work() (under m_)
     bool stop_ = false;
 };
 

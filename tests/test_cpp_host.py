@@ -17,6 +17,24 @@ def test_host_layer_compiles_and_links():
     assert os.path.exists(exe) and os.access(exe, os.X_OK)
 
 
+def test_task_pool_runs_every_chunk_exactly_once(tmp_path):
+    """The host layer's TaskPool (gather / write-back loops in chunks on a few threads), standalone: tests/cpp/task_pool_test.cpp, plain and
+    -- where the compiler has it -- under ThreadSanitizer, which is what found that a worker leaving work() late could draw a chunk of
+    the NEXT job from counters that were still being set up (the job then ran that chunk twice)."""
+    src = os.path.join(ROOT, "tests", "cpp", "task_pool_test.cpp")
+    exe = str(tmp_path / "task_pool_test")
+    res = subprocess.run(["g++", "-std=c++17", "-O2", "-pthread", src, "-o", exe], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    res = subprocess.run([exe, "20000"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "task pool: ok" in res.stdout, res.stdout[-1000:]
+    tsan = str(tmp_path / "task_pool_tsan")
+    res = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-pthread", "-fsanitize=thread", src, "-o", tsan], capture_output=True, text=True)
+    if res.returncode != 0:
+        pytest.skip("no ThreadSanitizer runtime here")
+    res = subprocess.run([tsan, "1500"], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "task pool: ok" in res.stdout and "ThreadSanitizer" not in res.stderr, (res.stdout + res.stderr)[-3000:]
+
+
 @pytest.mark.gpu
 def test_reference_system_tests_against_the_host_layer():
     mi_build.build()

@@ -758,6 +758,7 @@ int32_t mi_synchronize(mi_ctx* ctx) {
 int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
     ENTER(ctx);
     trs_written(ctx);
+    ctx->gs_frame_ok = false;  // (rows come and go: what was written ahead for the last frame's rows is not handed out after this)
     {
         int32_t rcj = compaction_join(ctx);  // buffers may move
         if (rcj) return rcj;

@@ -11,7 +11,8 @@ agree on everything a caller can download after every step; at intervals the ora
     dense uploads in pieces, GlobalTransforms fetched ahead mi_debug_set_chunked_frames(1)  [A: at any row count, mode 2]
     GlobalTransforms written ahead by an indexed window     (the same switch)
 
-The sequences mix: bounds uploads (whole, partial, single rows), RenderLayers above 31, Transform uploads (indexed, ranges),
+The sequences mix: change marks raised from elsewhere, frames repeated before anybody asks for results, results asked at random
+steps, bounds uploads (whole, partial, single rows), RenderLayers above 31, Transform uploads (indexed, ranges),
 change marks, growth and shrinkage of the row count, Visibility changes propagated on the device, VisibilityClass masks, one to
 nine views (a device table beyond eight) of which one may be a shadow cascade, every kind of frame (all rows, changed rows,
 propagate + cull, with and without the cluster assignment, with the compaction deferred or not), on flat scenes and on forests.  The reference has no
@@ -236,6 +237,14 @@ def test_fast_paths_are_interchangeable(seed):
                     wr[:] = sc.r[rows].reshape(-1)
                     ws[:] = sc.s[rows].reshape(-1)
                     ctx.commit_upload_window(w, k)
+            # now and then somebody else raises change marks as well (rows that did not move: their GlobalTransform is rewritten with the
+            # same value and they count as changed) -- between an upload window and its frame this is what must keep results that were
+            # written ahead from being handed out
+            if not forest and rng.random() < 0.2:
+                lo = int(rng.integers(0, n))
+                hi = int(min(n, lo + rng.integers(1, 40)))
+                for ctx in (a, b):
+                    ctx.upload_changed(np.ones(hi - lo, np.uint8), first_row=lo)
             # every step ends in a frame
             cams = [W.many_cubes_camera(int(rng.integers(0, 400)), yaw=float(rng.random() * 6.0), position=tuple(rng.normal(0, 8.0, 3))) for _ in range(n_views)]
             fr = np.concatenate([api.compute_frustum(cfv(), cam, W.CAMERA_FAR) for cam in cams])
@@ -260,7 +269,11 @@ def test_fast_paths_are_interchangeable(seed):
                     ctx.propagate((B.PROPAGATE_ALL_DIRTY if kind == "split_all" else 0) | (B.PROPAGATE_STATIC_OPT if forest else 0))
                     ctx.cull_views(views, flags=flags | B.CULL_BEGIN_FRAME)
             had_clusters = had_clusters or with_clusters
-            if op in (6, 7) and not forest:  # the results in one call (fetched / written ahead in A when the frame was of the matching kind)
+            again = not forest and not with_clusters and kind in ("all", "changed") and rng.random() < 0.15
+            if again:  # the same frame once more before anybody asks for results: nothing is marked any more
+                for ctx in (a, b):
+                    ctx.propagate_and_cull_views(views, flags=flags | (B.CULL_CHANGED_ROWS if kind == "changed" else 0))
+            if not forest and (op in (6, 7) or rng.random() < 0.3):  # the results in one call (fetched / written ahead in A when the frame was of the matching kind)
                 res = []
                 for ctx in (a, b):
                     got = ctx.download_frame_results(api.FrameResultBuffers(n, n, 0, 0, in_place=bool(step % 2)))

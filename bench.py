@@ -834,7 +834,8 @@ def end_to_end(ctx, wl, frames=12):
             d2h = got_g * 52 + len(vis_rows) * 4 + len(off) * 4 + counts.size * 4 + total * 4
         med = float(np.median(times))
         eff = (h2d + d2h) / med / 1e9
-        # the two directions are one after the other in a synchronised frame: the link-bound time is the sum of both at their peaks
+        # 1.0 = the time both directions would take one after the other at their peaks (a frame whose results depend on its whole input);
+        # where the library overlaps them (100 % dirty: results ahead of the frame) the figure can pass 1.0, up to 2.0 for equal halves
         link_s = h2d / (link["h2d"] * 1e9) + d2h / (link["d2h"] * 1e9)
         out[f"{pct}pct_dirty"] = {"dirty_rows": int(k), "us_per_frame": round(1e6 * med, 1), "entities_per_s": round(wl.units / med, 1),
                                   "h2d_bytes": int(h2d), "d2h_bytes": int(d2h), "pcie_GBps_effective": round(eff, 2),
@@ -854,7 +855,8 @@ def end_to_end(ctx, wl, frames=12):
                    "at 100 % the table goes in as eight dense windows in a row, which the library sends piece by piece with each piece's "
                    "GlobalTransforms computed at once and on their way back under the rest of the upload (PCIe full duplex): the results call "
                    "finds them on the host.  pcie_frac = (h2d / peak_h2d + d2h / "
-                   "peak_d2h) / frame time, peaks measured in this run with pinned hipMemcpyAsync (pcie_peak_GBps)")
+                   "peak_d2h) / frame time, peaks measured in this run with pinned hipMemcpyAsync (pcie_peak_GBps): 1.0 = both directions one "
+                   "after the other at their peaks, more than that only where they overlap")
     return out
 
 

@@ -184,7 +184,9 @@ int32_t mi_upload_transforms_indexed(mi_ctx* ctx, uint32_t n, const uint32_t* ro
  *   mi_commit_upload_window(w, n, first_row) the first n entries go to the device: MI_UPLOAD_DENSE = rows [first_row, first_row + n)
  *                                           by DMA straight from the window (mi_upload_transforms); otherwise rows[i] in any order,
  *                                           scattered by one kernel that reads the window over PCIe and raises the rows' change
- *                                           bytes (mi_upload_transforms_indexed; first_row ignored). */
+ *                                           bytes (mi_upload_transforms_indexed; first_row ignored).
+ * Two shapes of commit let the results of the frame travel ahead of it (mi_download_frame_results, below): dense windows that
+ * carry the whole flat table one after the other, and one indexed window whose rows strictly ascend or descend. */
 #define MI_UPLOAD_DENSE 0x1u
 typedef struct mi_upload_window {
     uint32_t* rows;

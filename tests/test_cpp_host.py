@@ -32,6 +32,8 @@ def test_task_pool_runs_every_chunk_exactly_once(tmp_path):
     if res.returncode != 0:
         pytest.skip("no ThreadSanitizer runtime here")
     res = subprocess.run([tsan, "1500"], capture_output=True, text=True, timeout=600)
+    if "FATAL: ThreadSanitizer" in res.stderr:  # (the sanitizer itself could not start here: address space layout, ptrace limits ...)
+        pytest.skip("ThreadSanitizer cannot run in this environment")
     assert res.returncode == 0 and "task pool: ok" in res.stdout and "ThreadSanitizer" not in res.stderr, (res.stdout + res.stderr)[-3000:]
 
 

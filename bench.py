@@ -25,13 +25,15 @@ Timing: W warm-up steps, then B blocks of exactly K steps, each bracketed by bar
 over ranks; `ms_per_step` / `value` come from the MEDIAN block (p10 / p90 / min / max under `blocks`).  B is chosen so that the
 timed blocks cover ~0.4 s (at least 15).  Three further blocks run with per-dispatch HIP events on the kernels (`kernels`,
 `roofline`) and are kept out of the statistics -- binding events to a dispatch fences it off from its neighbours.
-Rank 0 prints ONE JSON line; DESIGN.md section 5 explains the byte accounting behind `roofline`.
+Rank 0 prints ONE compact JSON line (< 4 KB: the contract's keys, benchlib/line.py) as the LAST line of stdout and writes everything
+else it measured -- the other workloads, the CPU thread sweep, the end-to-end stages -- to bench_full.json (repo root and gpurun_out/).
+DESIGN.md section 5 explains the byte accounting behind `roofline`.  The parts live in benchlib/: one module per workload
+(wl_*.py), the timing loop (measure.py), the CPU baselines (cpu_baseline.py -- the only importer of the oracle), the PCIe-inclusive
+block (end_to_end.py), the live PMC traffic passes (traffic.py) and the result line (line.py).
 """
 import argparse
-import json
 import os
 import sys
-import time
 
 import numpy as np
 
@@ -40,9 +42,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
-PROFILED_BLOCKS = 3
-N_FRAMES = 256          # distinct prepared camera frames, cycled
+from benchlib import cpu_baseline as cpu, end_to_end as e2e, line as result_line, traffic  # noqa: E402
+from benchlib.common import with_args  # noqa: E402
+from benchlib.measure import block_stats, measure, roofline_of  # noqa: E402
+from benchlib.wl_batching import build_batching, build_batching_sorted  # noqa: E402
+from benchlib.wl_flat import build_flat, build_flat_static  # noqa: E402
+from benchlib.wl_frame import build_frame  # noqa: E402
+from benchlib.wl_lights import build_lights  # noqa: E402
+from benchlib.wl_tree import build_tree  # noqa: E402
 
 
 def parse():
@@ -81,804 +88,51 @@ def parse():
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget")
     ap.add_argument("--profile-all", action="store_true", help="profiled blocks time every kernel, not only the workload's own")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes that measure roofline.traffic in this run (N = 1)")
+    ap.add_argument("--full-line", action="store_true", help="also print the full object (bench_full.json's content) on the line BEFORE the compact one")
     return ap.parse_args()
 
 
-def flat_bytes_per_entity(n_views, fused=True):
-    # frame kernel: read Aabb 24 + flags 1 + layers 4 + vv 1 and T 40 (fused) or resident G 48 (unfused);
-    # write vv 1 + (V view masks + vv change mask)/8 bits + V/64 wave counts, and G 48 + its change mask (fused)
-    rd = 30.0 + (40.0 if fused else 48.0)
-    wr = 1.0 + (n_views + 1) / 8.0 + n_views / 64.0 + ((48.0 + 1.0 / 8.0) if fused else 0.0)
-    return rd + wr
-
-
-# With the row summary (kernels.h RowSummary) a wave whose 64 rows agree in Aabb / flags / RenderLayers reads 32 bytes instead of
-# 64 x (24 + 1 + 4): what the kernel moves for such rows is 28.5 B less than the algorithmic figure, which stays SURVEY 8(d)'s.
-ROW_SUMMARY_SAVES = 29.0 - 32.0 / 64.0
-
-
-class Workload:
-    """step(f) enqueues one frame; units = work items per frame on this rank; rows = rows the dominant kernel streams."""
-
-    def __init__(self, name, step, units, bytes_per_row, dominant, config, metric, unit, rows=None, kernels=None):
-        self.name, self.step, self.units, self.bytes_per_row = name, step, units, bytes_per_row
-        self.dominant, self.config, self.metric, self.unit = dominant, config, metric, unit
-        self.rows = units if rows is None else rows
-        self.kernels = kernels or [dominant]   # what the profiled blocks time
-
-
-def camera_frusta(n_views, frame):
-    from bevy_amd import api, workloads as W
-    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
-    return np.concatenate([api.compute_frustum(cfv, W.many_cubes_camera(frame, yaw=v * np.pi / 2), W.CAMERA_FAR) for v in range(n_views)])
-
 
 # ---------------------------------------------------------------------------------------------------------------------
-# the BASELINE metric: propagate + cull + cluster in one frame (N = 1)
-# ---------------------------------------------------------------------------------------------------------------------
-def build_frame(ctx, args):
-    import bevy_amd as B
-    from bevy_amd import api, workloads as W
-    n_ent = args.entities or 1_000_000
-    sc, first_light, pr = W.frame_scene(n_ent, args.lights, args.meshes)
-    n_rows = sc["n"]
-    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
-    ctx.resize(n_rows)
-    ctx.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
-    # the lights' bounding Spheres follow their rows (MI_SPHERE_AT_TRANSLATION: what the plugin uploads, so that a moved light is
-    # not a bounds change): centre = the row's GlobalTransform translation = the position the scene (and the CPU baseline) holds
-    c_dev, h_dev = sc["aabb_center"].reshape(-1, 3).copy(), sc["aabb_half"].reshape(-1, 3).copy()
-    c_dev[first_light:] = 0.0
-    h_dev[first_light:, 1] = np.frombuffer(np.uint32(0x7FC0A11D).tobytes(), np.float32)[0]
-    ctx.debug_set_row_summary(args.row_summary)
-    ctx.debug_set_walk_inrow(getattr(args, "walk_inrow", 0))
-    ctx.upload_bounds(c_dev.reshape(-1), h_dev.reshape(-1), sc["flags"], sc["layers"])
-    ctx.cluster_upload_objects(pr)
-    ctx.cluster_bind_objects_to_rows(first_light, args.lights)
-    frames, views, keep = [], [], []
-    for f in range(N_FRAMES):
-        cam = W.many_cubes_camera(f)
-        fr = api.compute_frustum(cfv, cam, W.CAMERA_FAR)
-        frames.append(api.PreparedFrusta(fr))
-        # ClusterConfig::XYZ{(16,9,24), first_slice_depth 5.0, Constant(1000.0), dynamic_resizing: false} (SURVEY 8d config 3)
-        v, k = api.cluster_view_build(cam, cfv, fr, 1920, 1080, (16, 9, 24), 5.0, 1000.0, with_spheres=False)
-        views.append(v)
-        keep.append(k)
-    more = 0 if args.inline_compaction else B.CULL_MORE_FRAMES
-
-    separate = bool(getattr(args, "separate_cluster_calls", False))
-    concurrent = B.CULL_CLUSTERS_CONCURRENT if getattr(args, "concurrent_clusters", False) else 0
-
-    def step(f):
-        i = f % N_FRAMES
-        ctx.cluster_upload_view(views[i])
-        if separate:
-            ctx.propagate_and_cull(frames[i], flags=B.CULL_END_FRAME | more)
-            ctx.cluster_assign_resident()
-        else:
-            ctx.propagate_and_cull(frames[i], flags=B.CULL_END_FRAME | B.CULL_WITH_CLUSTERS | concurrent | more)
-
-    config = {"workload": f"BASELINE.json metric, one frame in one context: {n_ent} many_cubes entities (configs[1]) + {args.meshes} meshes "
-                          f"and {args.lights} point lights of the many_lights shape (configs[2]; range 0.3, shell R = 50; lights are rows with a "
-                          f"bounding Sphere) = {n_rows} rows, 1 camera, all Transforms dirty, columns resident in HBM: fused frame kernel "
-                          "(propagate + reset + frustum cull + mark-newly-hidden) + VisibleEntities compaction"
-                          + (" (deferred into the next frame's launch)" if more else "")
-                          + " + device-side gather of the visible lights + assign_objects_to_clusters on 16x9x24 clusters "
-                            "(ClusterConfig::XYZ, first slice 5.0, far Constant(1000))"
-                          + (" -- two calls" if separate else " -- ONE call (MI_CULL_WITH_CLUSTERS), the assignment enqueued behind the cull"
-                             if not concurrent else " -- ONE call (MI_CULL_WITH_CLUSTERS | MI_CULL_CLUSTERS_CONCURRENT): the assignment "
-                             "re-derives the lights' ViewVisibility with the cull's rule and runs on the cluster stream next to the frame kernel"),
-              "baseline_config": "BASELINE.json configs[1] + configs[2] in one frame; value counts the entities of configs[1] only",
-              "entities": n_ent, "rows_per_frame": n_rows, "lights": args.lights, "meshes": args.meshes, "views": 1,
-              "deferred_compaction": bool(more), "parallelism": "1 GPU", "row_summary": args.row_summary == 0}
-    wl = Workload("frame", step, n_ent, flat_bytes_per_entity(1, True), "k_flat_propagate_cull", config,
-                  "entities/sec through propagate+cull+cluster at 1M entities", "entities/s", rows=n_rows,
-                  kernels=["k_flat_propagate_cull", "k_compact_fast", "k_cluster_walk", "k_cluster_fill"])
-    wl.scene, wl.first_light, wl.pos_range, wl.frusta0, wl.keep = sc, first_light, pr, frames[0].array, (views, keep)
-    # "k_flat_propagate_cull" is the library's timer slot; the symbol rocprofv3 shows is the k_frame instantiation
-    # <PROPAGATE, INLINE_VIEWS, WITH_WALK>: the cluster walk rides in the launch unless it runs as calls or a stream of its own
-    wl.kernel_name = "k_frame<1,true,false>" if (separate or concurrent) else "k_frame<1,true,true>"
-    if args.row_summary == 0:
-        wl.layout_bytes_per_row = wl.bytes_per_row - ROW_SUMMARY_SAVES  # (every wave of this scene but three is uniform)
-    return wl
+OTHER_WORKLOADS = [  # the other BASELINE configs, measured briefly on fresh contexts: they go to bench_full.json
+    ("frame_plain_columns", lambda c, a: build_frame(c, with_args(a, row_summary=1))),  # the metric frame, every row reading its own Aabb / flags / layers
+    ("flat", lambda c, a: build_flat(c, a, 0, 1, [], a.entities or 1_000_000, 1, "flat")),
+    ("flat_plain_columns", lambda c, a: build_flat(c, with_args(a, row_summary=1), 0, 1, [], a.entities or 1_000_000, 1, "flat")),
+    ("flat_10m_4views", lambda c, a: build_flat(c, a, 0, 1, [], 10_000_000, 4, "sharded")),
+    ("flat_10m_1view", lambda c, a: build_flat(c, a, 0, 1, [], 10_000_000, 1, "flat")),
+    ("tree", lambda c, a: build_tree(c, a)),
+    ("tree_one_subtree_moves", lambda c, a: build_tree(c, with_args(a, tree_moved="subtree"))),
+    ("tree_10k_leaves_move", lambda c, a: build_tree(c, with_args(a, tree_moved="leaves"))),
+    ("tree_frame", lambda c, a: build_tree(c, with_args(a, tree_cull=True))),
+    ("tree_frame_two_launches", lambda c, a: build_tree(c, with_args(a, tree_cull=True, tree_cull_launches=2))),
+    ("lights", lambda c, a: build_lights(c, a)),
+    ("flat_static", lambda c, a: build_flat_static(c, a)),
+    ("flat_static_no_sphere_column", lambda c, a: build_flat_static(c, with_args(a, sphere_path=1))),
+    ("flat_static_10m_4views", lambda c, a: build_flat_static(c, with_args(a, entities=10_000_000, views=4))),
+    ("batching", lambda c, a: build_batching(c, a)),
+    ("batching_sorted_1k", lambda c, a: build_batching_sorted(c, with_args(a, sorted_items=1024))),
+    ("batching_sorted_4k", lambda c, a: build_batching_sorted(c, with_args(a, sorted_items=4096))),
+    ("batching_sorted_64k", lambda c, a: build_batching_sorted(c, with_args(a, sorted_items=65_536))),
+    ("batching_sorted_1m", lambda c, a: build_batching_sorted(c, with_args(a, sorted_items=1_000_000))),
+]
 
 
-# ---------------------------------------------------------------------------------------------------------------------
-# flat rows, optionally sharded over ranks (configs[1] at N = 1, configs[3] at N > 1)
-# ---------------------------------------------------------------------------------------------------------------------
-def build_flat(ctx, args, rank, world, full_holder, n_global, n_views, name):
-    import torch
-    import bevy_amd as B
-    from bevy_amd import api, sharding, workloads as W
-    lo, hi = sharding.shard_rows(n_global, world, rank)
-    n_local = hi - lo
-    radius = 500.0 * (n_global / 1_000_000.0) ** (1.0 / 3.0)
-    scene = W.many_cubes(n_global, radius=radius, start=lo, count=n_local)
-    ctx.resize(n_local)
-    ctx.upload_transforms(scene["translation"], scene["rotation"], scene["scale"])
-    ctx.debug_set_row_summary(args.row_summary)
-    ctx.upload_bounds(scene["aabb_center"], scene["aabb_half"], scene["flags"], scene["layers"])
-    frames = [api.PreparedFrusta(camera_frusta(n_views, f)) for f in range(N_FRAMES)]
-    gather = None
-    if world > 1 or os.environ.get("MI_FORCE_GATHER") == "1" or os.environ.get("MI_FORCE_DIST") == "1":
-        gather = sharding.MaskGatherer(n_global, world, n_views, rank, device=torch.device("cuda", torch.cuda.current_device()))
-        full_holder.append(gather)
-        gather.attach(ctx)  # direct RCCL available: the library issues the exchange itself, one FFI call per frame
-    py_exchange = gather is not None and not gather.native
-    deferred = not args.inline_compaction and not py_exchange
-    more = B.CULL_MORE_FRAMES if deferred else 0
-    fcount = [0]
-
-    def step(f):
-        i = f % N_FRAMES
-        k = fcount[0]
-        fcount[0] += 1
-        if py_exchange:
-            gather.before_kernels(k)
-            ctx.bind_visibility_output(*gather.bind_args(k))
-        if args.unfused:
-            ctx.propagate(B.PROPAGATE_ALL_DIRTY)
-            ctx.cull(frames[i], flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME | more)
-        else:
-            ctx.propagate_and_cull(frames[i], flags=B.CULL_END_FRAME | more)
-        if py_exchange:
-            gather.after_kernels(k)
-
-    config = {"workload": f"many_cubes-shaped flat scene, {n_global} entities, {n_views} camera frustum(s), all Transforms dirty, columns "
-                          f"resident in HBM: {'mi_propagate + mi_cull' if args.unfused else 'fused frame kernel'} (propagate + reset + "
-                          "frustum cull + mark-newly-hidden) + VisibleEntities compaction"
-                          + (" (deferred into the next frame's launch)" if deferred else "")
-                          + (f"; rows sharded over {world} GPUs ({n_local} on this rank) + ONE in-place RCCL all-gather of the packed "
-                             f"ViewVisibility bitmasks per frame ({gather.mode})" if gather is not None else ""),
-              "baseline_config": "BASELINE.json configs[3]" if name == "sharded" else "BASELINE.json configs[1]",
-              "entities_total": n_global, "entities_this_rank": n_local, "views": n_views, "deferred_compaction": deferred,
-              "parallelism": f"row-range shard x{world}", "row_summary": args.row_summary == 0}
-    if gather is not None and gather.fallback_reason:
-        config["rccl_direct_fallback"] = gather.fallback_reason
-    metric = ("entities/sec through propagate+cull (10M entities x 4 frusta, 1/2/4/8-GPU scaling)" if name == "sharded"
-              else "entities/sec through propagate+cull")
-    wl = Workload(name, step, n_local, flat_bytes_per_entity(n_views, not args.unfused),
-                  "k_cull" if args.unfused else "k_flat_propagate_cull", config, metric, "entities/s",
-                  kernels=["k_cull" if args.unfused else "k_flat_propagate_cull", "k_compact_fast"])
-    wl.scene, wl.n_views, wl.global_units = scene, n_views, n_global
-    wl.kernel_name = "k_frame<0>" if args.unfused else "k_frame<1,true,false>"  # the timer slot's name is not the symbol's
-    if args.row_summary == 0:
-        wl.layout_bytes_per_row = wl.bytes_per_row - ROW_SUMMARY_SAVES
-    return wl
-
-
-def build_tree(ctx, args, rank=0, world=1):
-    import bevy_amd as B
-    from bevy_amd import sharding, workloads as W
-    tr = W.gen_tree(12, 4, (args.entities or 1_000_000) * (world if args.scaling == "weak" else 1))
-    n_global = tr["n"]
-    if world > 1:
-        # SURVEY 8e: shard by root subtree -- the one giant tree is opened up, its top rows are replicated and the
-        # subtrees below are bin-packed on the GPUs; no collective (a rank's rows never read another rank's)
-        sh = sharding.shard_hierarchy(tr["parent"], tr["level_offsets"], world, rank)
-        rows = sh["rows"].astype(np.int64)
-        tr = dict(n=len(rows), parent=sh["parent"], level_offsets=sh["level_offsets"],
-                  translation=tr["translation"].reshape(-1, 3)[rows].reshape(-1), rotation=tr["rotation"].reshape(-1, 4)[rows].reshape(-1),
-                  scale=tr["scale"].reshape(-1, 3)[rows].reshape(-1), owned=int(sh["owned"].sum()))
-    ctx.resize(tr["n"])
-    ctx.upload_transforms(tr["translation"], tr["rotation"], tr["scale"])
-    if args.tile_mode:
-        ctx.debug_set_tile_mode(args.tile_mode)
-    ctx.upload_hierarchy(tr["parent"], tr["level_offsets"])
-    plan = ctx.debug_tile_plan()
-    # the root moves every frame (a 40-byte dirty-row upload), so set_if_neq really rewrites every descendant
-    root_t = [tr["translation"][:3].copy(), tr["translation"][:3] + np.float32(1.0)]
-    moved = getattr(args, "tree_moved", "all")
-    if moved != "all":
-        # change-driven frames under StaticTransformOptimizations (the frame a game mostly runs): "subtree" = one node of level 5
-        # moves (1 / 1024 of a 4-ary tree follows it), "leaves" = 10 000 random leaves move
-        n, lv = tr["n"], tr["level_offsets"]
-        rng = np.random.default_rng(3)
-        rows = (np.array([int(lv[5]) + 17], np.uint32) if moved == "subtree"
-                else np.sort(rng.choice(np.arange(int(lv[-2]), n), 10_000, replace=False)).astype(np.uint32))
-        t3 = tr["translation"].reshape(n, 3)
-        sets = [(np.ascontiguousarray(t3[rows] + np.float32(d)).reshape(-1), np.ascontiguousarray(tr["rotation"].reshape(n, 4)[rows]).reshape(-1),
-                 np.ascontiguousarray(tr["scale"].reshape(n, 3)[rows]).reshape(-1)) for d in (0.0, 1.0)]
-        ctx.upload_changed(np.ones(n, np.uint8))
-        ctx.propagate(B.PROPAGATE_STATIC_OPT)
-
-        def step(f):
-            ctx.upload_transforms_indexed(rows, *sets[f & 1])
-            ctx.propagate(B.PROPAGATE_STATIC_OPT)
-        config = {"workload": f"gen_tree(12,4) truncated to {n_global} nodes, StaticTransformOptimizations enabled, per frame "
-                              + ("ONE node of level 5 moves (1 / 1024 of the tree follows)" if moved == "subtree" else "10 000 random leaves move")
-                              + ": mi_upload_transforms_indexed + mi_propagate(MI_PROPAGATE_STATIC_OPT) = mark_dirty_trees + the tile launch",
-                  "nodes": n_global, "moved_rows": int(len(rows)), "tile_plan": plan}
-        # algorithmic bytes of a change-driven tile launch: every tile's descriptor (64 B) and flags pre-test (chain change bytes + top
-        # marks, <= 136 B), plus the all-dirty 141 B for the rows that are re-evaluated (the moved rows' subtrees / the moved leaves and
-        # the marked ancestors' tiles are a superset: counted as the rows below the moved ones only -- a lower bound)
-        follows = (tr["n"] // 1024 if moved == "subtree" else len(rows))
-        alg = (plan["tiles"] * 200.0 + follows * 141.0) / tr["n"]
-        wl = Workload("tree_" + moved, step, tr["n"], alg, "k_propagate_tiles", config, "nodes/sec through change-driven hierarchy propagate", "nodes/s",
-                      kernels=["k_propagate_tiles", "k_mark_dirty"])
-        wl.tree = tr
-        wl.kernel_name = "k_propagate_fans<false>"
-        return wl
-
-    if getattr(args, "tree_cull", False):
-        # the hierarchy FRAME: every node carries a unit-cube Aabb; one call = the tile launch (every Transform counts as changed) + the
-        # cull launch behind it (reset + check_visibility + mark-newly-hidden over the GlobalTransforms just written) + the deferred compaction
-        from bevy_amd import api
-        n = tr["n"]
-        ctx.debug_set_row_summary(args.row_summary)
-        tcl = getattr(args, "tree_cull_launches", 0)
-        fused = tcl == 1 or (tcl == 0 and (args.views or 1) == 1)
-        ctx.debug_set_tree_cull({0: 0, 1: 2, 2: 1}[tcl])
-        ctx.upload_bounds(np.zeros(3 * n, np.float32), np.full(3 * n, 0.5, np.float32), np.full(n, 0x05, np.uint8), np.ones(n, np.uint32))
-        n_views = args.views or 1
-        frames = [api.PreparedFrusta(camera_frusta(n_views, f)) for f in range(N_FRAMES)]
-        more = 0 if args.inline_compaction else B.CULL_MORE_FRAMES
-
-        def step_frame(f):
-            ctx.upload_transforms(root_t[f & 1], tr["rotation"][:4], tr["scale"][:3], first_row=0)
-            ctx.propagate_and_cull(frames[f % N_FRAMES], flags=B.CULL_END_FRAME | more)
-        config = {"workload": f"gen_tree(12,4) truncated to {n_global} nodes, every node with an Aabb, {n_views} camera frustum(s): the hierarchy frame in one "
-                              "call -- mi_propagate_and_cull = subtree-tile propagation (root moved, every Transform counts as changed) "
-                              + ("in which every tile also runs the visibility systems over its own rows (k_propagate_fans<true, true>)" if fused
-                                 else "+ the cull launch over the GlobalTransforms it wrote") + " + VisibleEntities compaction",
-                  "baseline_config": "BASELINE.json configs[4] + the cull of configs[1]", "nodes": n_global, "views": n_views, "tile_plan": plan,
-                  "row_summary": args.row_summary == 0}
-        # propagate 141 B per node (above) + cull with G resident: read G 48 + Aabb 24 + flags 1 + layers 4 + vv 1, write vv 1 + masks
-        config["bytes_per_node"] = {"tile_launch": 141.0, "cull_launch_G_resident": flat_bytes_per_entity(n_views, False)}
-        wl = Workload("tree_frame", step_frame, tr["n"], 141.0, "k_propagate_tiles", config,
-                      "nodes/sec through hierarchy propagate + cull", "nodes/s", kernels=["k_propagate_tiles", "k_cull", "k_compact_fast"])
-        wl.tree = tr
-        wl.kernel_name = "k_propagate_fans<true,true>" if fused else "k_propagate_fans<true> + k_frame<0>"
-        if fused:  # + read Aabb 24 + flags 1 + layers 4 (summarised: 0.5) + vv 1, write vv 1 + masks
-            wl.bytes_per_row = 141.0 + 31.0 + (n_views + 1) / 8.0 + n_views / 64.0
-            if args.row_summary == 0:
-                wl.layout_bytes_per_row = wl.bytes_per_row - ROW_SUMMARY_SAVES
-        return wl
-
-    def step(f):
-        ctx.upload_transforms(root_t[f & 1], tr["rotation"][:4], tr["scale"][:3], first_row=0)
-        ctx.propagate(B.PROPAGATE_ALL_DIRTY)
-    config = {"workload": f"gen_tree(12,4) truncated to {n_global} nodes ({len(tr['level_offsets']) - 1} levels), root moved "
-                          "every frame (dirty-row upload), subtree-tile propagation"
-                          + (f", sharded by root subtree over {world} GPUs (this rank holds {tr['n']} rows, no collective)" if world > 1 else ""),
-              "baseline_config": "BASELINE.json configs[4]", "nodes": n_global, "parallelism": f"root-subtree shard x{world}", "tile_plan": plan}
-    # T 40, parent_idx 4, old G 48 (set_if_neq), G 48, changed byte 1
-    # ("k_propagate_tiles" is the library's timer slot for the tile launch: k_propagate_fans for a tree this size)
-    wl = Workload("tree", step, tr["n"], 141.0, "k_propagate_tiles", config, "nodes/sec through hierarchy propagate", "nodes/s",
-                  kernels=["k_propagate_tiles", "k_propagate_stream"])
-    wl.tree = tr
-    # the library's timer slot is called k_propagate_tiles; the kernel rocprofv3 shows for a plan of light tiles is k_propagate_fans
-    wl.kernel_name = "k_propagate_tiles<256>" if args.tile_mode == 1 else "k_propagate_fans<true>"
-    wl.global_units = n_global  # every node is owned by exactly one rank (replicated top rows are recomputed, not counted)
-    return wl
-
-
-def build_lights(ctx, args):
-    from bevy_amd import api, workloads as W
-    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
-    lights = W.many_lights(args.lights, 50.0, 0.3)
-    cam = W.many_cubes_camera(0)
-    fr = api.compute_frustum(cfv, cam, W.CAMERA_FAR)
-    view, keep = api.cluster_view_build(cam, cfv, fr, 1920, 1080, (16, 9, 24), 5.0, 1000.0)
-    ctx.cluster_upload_objects(lights)
-    ctx.cluster_upload_view(view)
-
-    def step(f):
-        ctx.cluster_assign_resident()
-    config = {"workload": f"many_lights-shaped: {args.lights} point lights (range 0.3, shell R=50) given as an object list, 16x9x24 "
-                          "clusters, assign_objects_to_clusters only", "baseline_config": "BASELINE.json configs[2], cluster stage alone",
-              "lights": args.lights}
-    wl = Workload("lights", step, args.lights, 17.0, "k_cluster_walk", config,
-                  "lights/sec through assign_objects_to_clusters", "lights/s", kernels=["k_cluster_walk", "k_cluster_fill"])
-    wl.keep = (view, keep, lights)
-    wl.oracle_args = (cam, cfv, fr)
-    return wl
-
-
-def build_flat_static(ctx, args):
-    """configs[1], second run: 0 % dirty -- mi_propagate finds nothing changed, mi_cull reads the resident G."""
-    import bevy_amd as B
-    from bevy_amd import api, workloads as W
-    n = args.entities or 1_000_000
-    sc = W.many_cubes(n, radius=500.0 * (n / 1_000_000.0) ** (1.0 / 3.0))  # configs[3]'s scaling: the density stays
-    ctx.resize(n)
-    ctx.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
-    ctx.debug_set_row_summary(args.row_summary)
-    ctx.upload_bounds(sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"])
-    ctx.upload_changed(np.zeros(n, np.uint8))  # the change column exists from here on: only marked rows are recomputed
-    ctx.propagate(B.PROPAGATE_ALL_DIRTY)
-    n_views = args.views or 1
-    frames = [api.PreparedFrusta(camera_frusta(n_views, f)) for f in range(N_FRAMES)]
-    more = 0 if args.inline_compaction else B.CULL_MORE_FRAMES  # as in the flat workload: frames back to back
-    sphere = getattr(args, "sphere_path", 0) != 1
-    ctx.debug_set_sphere_path(getattr(args, "sphere_path", 0))
-
-    def step(f):
-        ctx.propagate(0)
-        ctx.cull(frames[f % N_FRAMES], flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME | more)
-    # byte models per row.  G resident (k_frame<0>): read G 48 + Aabb 24 + flags 1 + layers 4 + vv 1, write vv 1 + masks.
-    # World-sphere column (k_frame_sph): read (cw, sr) 16 + flags 1 + layers 4 + vv 1, write vv 1 + masks; GlobalTransform and half
-    # extents only for the rows that pass a sphere test (a few percent: not counted -- the PMC traffic shows them).
-    wr = 1.0 + (n_views + 1) / 8.0 + n_views / 64.0
-    models = {"world_sphere_column": 22.0 + wr, "global_transform_resident": flat_bytes_per_entity(n_views, False)}
-    config = {"workload": f"many_cubes-shaped flat scene, {n} entities, {n_views} frustum(s), 0 % of the Transforms dirty: mi_propagate "
-                          "(no row was marked since the last one: returns without a launch) + mi_cull ("
-                          + ("the world-sphere column: 16 B per row instead of GlobalTransform + Aabb, k_frame_sph" if sphere else "G resident, k_frame<0>")
-                          + ") + VisibleEntities compaction" + (" deferred into the next frame's launch" if more else ""),
-              "baseline_config": "BASELINE.json configs[1], 0 %-dirty run", "entities": n, "views": n_views, "deferred_compaction": bool(more),
-              "sphere_path": sphere, "bytes_per_row_models": models}
-    wl = Workload("flat_static", step, n, models["world_sphere_column" if sphere else "global_transform_resident"], "k_cull", config,
-                  "entities/sec through propagate+cull", "entities/s", kernels=["k_cull", "k_compact_fast"])
-    wl.kernel_name = "k_frame_sph<false>" if sphere else "k_frame<0>"
-    if args.row_summary == 0:  # the sphere path reads flags + layers per row (5 B), the resident-G path Aabb as well
-        wl.layout_bytes_per_row = wl.bytes_per_row - ((5.0 - 0.5) if sphere else ROW_SUMMARY_SAVES)
-    config["row_summary"] = args.row_summary == 0
-    return wl
-
-
-def build_batching(ctx, args):
-    """the flat frame followed by the batching work-item build of the camera's list."""
-    import bevy_amd as B
-    from bevy_amd import api, workloads as W
-    n = args.entities or 1_000_000
-    sc = W.many_cubes(n)
-    bs = W.batching_scene(n, n_sets=64, max_bins=40, seed=7)
-    ctx.resize(n)
-    ctx.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
-    ctx.upload_bounds(sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"])
-    ctx.batch_upload_rows(bs["row_set"], bs["row_bin"], bs["row_input"])
-    ctx.batch_upload_sets(bs["set_indexed"], bs["bin_table_offset"], bs["bin_table"], bs["meta_offset"], bs["bin_metadata"])
-    frames = [api.PreparedFrusta(camera_frusta(1, f)) for f in range(N_FRAMES)]
-
-    def step(f):
-        ctx.propagate_and_cull(frames[f % N_FRAMES], flags=B.CULL_END_FRAME)
-        ctx.batch_build(0, 0)
-    step(0)
-    ctx.synchronize()
-    rows = ctx.download_visible_entities(0, 0)[1]
-    items = int(np.count_nonzero(bs["row_set"][rows] != 0xFFFFFFFF))
-    config = {"workload": f"flat frame of {n} entities + batching work-item build of the camera's VisibleEntities list: "
-                          f"{len(rows)} visible rows -> {items} PreprocessWorkItems in {len(bs['set_indexed'])} batch sets / "
-                          f"{len(bs['bin_metadata'])} bins (stable partition by set, allocate_uniforms, unpack_bins)",
-              "entities": n, "work_items_per_frame": items}
-    wl = Workload("batching", step, n, flat_bytes_per_entity(1, True), "k_flat_propagate_cull", config,
-                  "entities/sec through propagate+cull+batch build", "entities/s",
-                  kernels=["k_flat_propagate_cull", "k_compact_fast", "k_batch_hist", "k_batch_emit", "k_batch_scan", "k_batch_scatter",
-                           "k_batch_bounds", "k_batch_plan"])
-    wl.batch = (bs, rows)
-    return wl
-
-
-def build_batching_sorted(ctx, args):
-    """Sorted phases (Transparent3d, the 2D phases): gpu_preprocessing::batch_and_prepare_sorted_render_phase over a phase of
-    --sorted-items items in their sorted order.  A step = mi_batch_sorted_build: the items go up (16 B each: they are the CPU's
-    sorted phase) and the walk runs -- one workgroup up to 1 024 items, tiles over the whole chip beyond."""
-    from bevy_amd import workloads as W
-    n = getattr(args, "sorted_items", 0) or 65_536
-    items = W.sorted_items(n, seed=5)
-    ctx.resize(1)
-    limit = getattr(args, "sorted_one_wg_limit", None)
-    if limit is not None:
-        ctx.debug_set_sorted_one_wg_limit(limit)
-
-    def step(f):
-        ctx.batch_sorted_build(items, True, False, False, None)
-    tiled = n > (1024 if limit is None else limit)
-    config = {"workload": f"sorted render phase of {n} items (runs of equal batch-set / bin keys, some without an input index): "
-                          "mi_batch_sorted_build = H2D of the items + " + ("k_batch_sorted_partials + k_batch_sorted_tiles (two launches, "
-                          f"{(n + 1023) // 1024} tiles)" if tiled else "k_batch_sorted (one workgroup)"), "items": n, "tiled": tiled}
-    # per item: read 16 (item) + 16 (its predecessor, L2), write 8 scratch planes x 4, read most of them back, write a work item 8 (+ metadata)
-    wl = Workload("batching_sorted", step, n, 16.0 + 32.0 + 32.0 + 8.0, "k_batch_sorted", config, "items/sec through the sorted-phase batch build", "items/s",
-                  kernels=["k_batch_sorted", "k_batch_scan"])
-    wl.sorted_items = items
-    wl.kernel_name = "k_batch_sorted_tiles" if tiled else "k_batch_sorted<256>"
-    return wl
-
-
-# ---------------------------------------------------------------------------------------------------------------------
-# measurement
-# ---------------------------------------------------------------------------------------------------------------------
-def measure(ctx, wl, steps, warmup, n_blocks=0, profile_all=False, barrier=None, reduce_max=None, agree=None, target_s=0.4):
-    """W untimed frames, then B blocks of exactly `steps` frames, each between barrier + synchronize pairs (MAX over ranks
-    per block), then PROFILED_BLOCKS blocks with per-dispatch events.  Returns (block seconds [B], per-kernel profile, info)."""
-    import gc
-    import torch
-
-    def sync_all():
-        ctx.synchronize()
-        torch.cuda.synchronize()
-        if barrier:
-            barrier()
-
-    # A generation-2 pass of Python's cyclic GC over everything torch imported takes ~50 ms -- a thousand frames of
-    # this workload -- and fires after a fixed number of allocations, i.e. at a random frame: collect now, and keep the
-    # collector off while frames are being enqueued (what timeit does).
-    gc.collect()
-    gc_was_enabled = gc.isenabled()
-    gc.disable()
-    frame = [0]
-
-    def run_block(k):
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(k):
-            wl.step(frame[0])
-            frame[0] += 1
-        t_enq = time.perf_counter()
-        ctx.synchronize()
-        torch.cuda.synchronize()
-        if barrier:
-            barrier()
-        t1 = time.perf_counter()
-        return t1 - t0, t_enq - t0
-
-    if warmup:
-        run_block(warmup)
-    est, _ = run_block(steps)                       # untimed: sizes the number of blocks
-    if not n_blocks:
-        n_blocks = int(min(600, max(15, target_s / max(est, 1e-6))))
-        if agree:
-            n_blocks = agree(n_blocks)              # every rank runs the same number of blocks
-    times, enq = [], []
-    for _ in range(n_blocks):
-        t, e = run_block(steps)
-        times.append(t)
-        enq.append(e)
-    if reduce_max:
-        times = reduce_max(times)
-    # profiled blocks: same frames, every launch of the workload's kernels timed (not part of the statistics)
-    ctx.profile_filter(None if profile_all else wl.kernels)
-    ctx.profile_sample(1)
-    ctx.profile_burst(0)
-    ctx.profile_enable(True)
-    prof_t = [run_block(steps)[0] for _ in range(PROFILED_BLOCKS)]
-    prof = ctx.profile_read()
-    ctx.profile_enable(False)
-    if gc_was_enabled:
-        gc.enable()
-    info = {"host_enqueue_ms_per_step": round(1e3 * float(np.median(enq)) / steps, 5),
-            "profiled_blocks_ms_per_step": round(1e3 * float(np.median(prof_t)) / steps, 5)}
-    return np.array(times), prof, info
-
-
-def with_args(args, **kw):
-    import copy
-    a = copy.copy(args)
-    for k, v in kw.items():
-        setattr(a, k, v)
+def traffic_args(workload, args):
+    """argv tail that makes a child bench.py run this workload the same way (benchlib/traffic.py)."""
+    a = ["--workload", workload, "--row-summary", str(args.row_summary)]
+    for flag, val in (("--entities", args.entities), ("--views", args.views), ("--sorted-items", args.sorted_items), ("--sphere-path", args.sphere_path),
+                      ("--tile-mode", args.tile_mode), ("--tree-cull-launches", args.tree_cull_launches)):
+        if val:
+            a += [flag, str(val)]
+    a += ["--lights", str(args.lights), "--meshes", str(args.meshes), "--tree-moved", args.tree_moved]
+    for flag, on in (("--unfused", args.unfused), ("--inline-compaction", args.inline_compaction), ("--tree-cull", args.tree_cull),
+                     ("--separate-cluster-calls", args.separate_cluster_calls), ("--concurrent-clusters", args.concurrent_clusters)):
+        if on:
+            a.append(flag)
     return a
 
 
-def block_stats(times, steps):
-    ms = 1e3 * times / steps
-    return {"n": int(len(ms)), "steps_per_block": steps, "median_ms_per_step": round(float(np.median(ms)), 5),
-            "p10_ms_per_step": round(float(np.percentile(ms, 10)), 5), "p90_ms_per_step": round(float(np.percentile(ms, 90)), 5),
-            "min_ms_per_step": round(float(ms.min()), 5), "max_ms_per_step": round(float(ms.max()), 5)}
-
-
-def load_profiles():
-    """Committed rocprofv3 evidence of the same commands (profiles/rocprof_summary.json, written by tools/summarize_profiles.py):
-    kernel-trace average durations and the HBM traffic of the separate --pmc passes, per workload and kernel."""
-    p = os.path.join(ROOT, "profiles", "rocprof_summary.json")
-    try:
-        return json.load(open(p))
-    except Exception:
-        return {}
-
-
-def roofline_of(wl, prof, steps):
-    dk = prof.get(wl.dominant)
-    if not dk or not dk["launches"]:
-        return None
-    avg_s = dk["avg_us"] * 1e-6
-    alg_bytes = wl.bytes_per_row * wl.rows
-    achieved = alg_bytes / avg_s / 1e9
-    out = {"bound": "hbm", "kernel": getattr(wl, "kernel_name", wl.dominant), "timer_slot": wl.dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-           "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "avg_kernel_us": round(dk["avg_us"], 3),
-           "launches": dk["launches"], "algorithmic_bytes_per_launch": int(alg_bytes),
-           "timing": f"per-dispatch start/stop events (hipExtLaunchKernelGGL) on every launch of {PROFILED_BLOCKS} profiled blocks of "
-                     f"{steps} steps that follow the timed blocks"}
-    lay = getattr(wl, "layout_bytes_per_row", None)
-    if lay is not None:
-        # `achieved` / `frac` price the launch at SURVEY 8(d)'s algorithmic bytes, as the contract says; the layout reads less than
-        # that (row summary), so the same launch is also priced at the bytes it is laid out to move -- compare `traffic` with these
-        out["layout_bytes_per_launch"] = int(lay * wl.rows)
-        out["frac_of_layout_bytes"] = round(lay * wl.rows / avg_s / 1e9 / HBM_PEAK_GBPS, 4)
-        out["layout_note"] = ("waves whose 64 rows agree in Aabb / flags / RenderLayers read a 32-byte summary instead of 64 x 29 B of "
-                              "columns (bit-identical results; --row-summary 1 switches it off)")
-    ev = load_profiles().get(getattr(wl, "profile_key", wl.name), {}).get(wl.dominant)
-    if ev:
-        if ev.get("hbm_bytes_per_launch"):
-            out["traffic"] = ev["hbm_bytes_per_launch"]
-            out["traffic_source"] = f"replayed from {ev.get('source', 'profiles/')}: FETCH_SIZE / WRITE_SIZE of separate rocprofv3 --pmc passes of this command (not measured in this run)"
-        if ev.get("avg_us"):
-            out["rocprof_avg_kernel_us"] = ev["avg_us"]
-            out["rocprof_frac"] = round(alg_bytes / (ev["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
-            out["rocprof_source"] = ev.get("source", "profiles/")
-    return out
-
-
-# ---------------------------------------------------------------------------------------------------------------------
-# CPU baselines (the oracle's C port, on the host cores of this box; reported, never the target)
-# ---------------------------------------------------------------------------------------------------------------------
-def cpu_baseline_frame(wl, cpu_seconds):
-    """propagate + cull over every row of the frame on all cores (persistent pool, Bevy's ceil(n/threads) batching), then the
-    gather + assign_objects_to_clusters of the visible lights on ONE core (single-threaded in the reference)."""
-    import oracle_lib as O
-    from bevy_amd import api, workloads as W
-    sc, cores = wl.scene, os.cpu_count() or 1
-    a = (sc["translation"], sc["rotation"], sc["scale"], sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"], wl.frusta0)
-    # The pool's hand-offs (a join per system) cost more than the work when every core takes part: sweep the thread count, both
-    # with the reference's system structure (reset / check / mark as separate systems) and with the three visibility systems fused
-    # into one pass per batch, and quote the BEST -- the baseline should be as strong as the port can be made.
-    sweep, best = {}, None
-    budget = 0.6 * cpu_seconds / 14.0
-    for fused_vis in (False, True):
-        for th in sorted({min(cores, x) for x in (8, 16, 32, 64, 128, 256, cores)}):
-            secs, _, vv, _ = O.bench_flat_frame(*a, th, 2, fused_vis)
-            iters = int(max(3, min(3000, budget / max(secs / 2, 1e-4))))
-            secs, _, vv, _ = O.bench_flat_frame(*a, th, iters, fused_vis)
-            ms = 1e3 * secs / iters
-            sweep[f"{th} threads" + (", fused visibility" if fused_vis else "")] = round(ms, 4)
-            if best is None or ms < best[0]:
-                best = (ms, th, fused_vis, iters)
-    t_flat, cores_used, fused_used, iters = best[0] * 1e-3, best[1], best[2], best[3]
-    n_l = len(wl.pos_range) // 4
-    visible = np.nonzero(vv[wl.first_light:wl.first_light + n_l] & 1)[0]
-    pr = np.ascontiguousarray(np.asarray(wl.pos_range, np.float32).reshape(-1, 4)[visible]).reshape(-1)
-    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
-    view = O.cluster_view_setup(W.many_cubes_camera(0), cfv, wl.frusta0, 1920, 1080, (16, 9, 24), 5.0, 1000.0)
-    t0 = time.perf_counter()
-    O.assign_objects_to_clusters(view, pr)
-    one = time.perf_counter() - t0
-    it2 = int(max(1, min(2000, 0.3 * cpu_seconds / max(one, 1e-5))))
-    t0 = time.perf_counter()
-    for _ in range(it2):
-        O.assign_objects_to_clusters(view, pr)
-    t_cl = (time.perf_counter() - t0) / it2
-    return {"value": round(wl.units / (t_flat + t_cl), 1), "unit": "entities/s", "cores": cores_used, "kind": "port",
-            "sample": f"{iters} frames of {sc['n']} rows: oracle C port of sync_simple_transforms + reset + check_visibility + "
-                      f"mark_newly_hidden on a persistent pool -- best of a sweep over thread counts and system structure: {cores_used} threads"
-                      + (", the three visibility systems fused into one pass per batch" if fused_used else ", one ceil(n/threads) batch per thread and system (Bevy's par_iter batching)")
-                      + f", {1e3 * t_flat:.3f} ms/frame; + {it2} runs of assign_objects_to_clusters over the "
-                      f"{len(visible)} visible lights on 1 thread (single-threaded in the reference; two passes: size, then fill), "
-                      f"{1e3 * t_cl:.3f} ms/frame",
-            "host_cores": cores, "thread_sweep_ms_per_frame": sweep,
-            "stage_ms": {"propagate_cull_best": round(1e3 * t_flat, 4), "cluster_1_core": round(1e3 * t_cl, 4)}}
-
-
-def cpu_baseline_flat(wl, cpu_seconds, n_views):
-    import oracle_lib as O
-    from bevy_amd import workloads as W
-    cores = os.cpu_count() or 1
-    n_cpu = min(wl.units, 1_000_000)
-    sc = wl.scene if n_cpu == wl.units else W.many_cubes(n_cpu)
-    fr0 = camera_frusta(n_views, 0)
-    a = (sc["translation"], sc["rotation"], sc["scale"], sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"], fr0)
-    secs, _, _, _ = O.bench_flat_frame(*a, cores, 1)
-    iters = int(max(1, min(5000, cpu_seconds / max(secs, 1e-4))))
-    secs, _, _, _ = O.bench_flat_frame(*a, cores, iters)
-    return {"value": round(n_cpu * iters / secs, 1), "unit": "entities/s", "cores": cores, "kind": "port",
-            "sample": f"{iters} frames of {n_cpu} entities x {n_views} view(s): oracle C port of sync_simple_transforms + reset + "
-                      "check_visibility + mark_newly_hidden on a persistent thread pool, one ceil(n/threads) batch per thread and system "
-                      f"(Bevy's par_iter batching), {secs:.2f}s"}
-
-
-def config0_cpu_plumbing(cpu_seconds):
-    """BASELINE.json configs[0]: many_cubes at 160 000 entities, 1 camera, CPU only -- the reference's propagate_transforms +
-    check_visibility shape as the oracle's C port runs it here (the real Bevy cannot be built in this image)."""
-    import oracle_lib as O
-    from bevy_amd import workloads as W
-    n = 160_000
-    sc = W.many_cubes(n)
-    fr0 = camera_frusta(1, 0)
-    a = (sc["translation"], sc["rotation"], sc["scale"], sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"], fr0)
-    out = {"entities": n, "kind": "port", "unit": "entities/s"}
-    for label, threads in (("all_cores", os.cpu_count() or 1), ("one_core", 1)):
-        secs, _, _, _ = O.bench_flat_frame(*a, threads, 1)
-        iters = int(max(1, min(5000, 0.5 * cpu_seconds / max(secs, 1e-5))))
-        secs, _, _, _ = O.bench_flat_frame(*a, threads, iters)
-        out[label] = {"threads": threads, "value": round(n * iters / secs, 1), "ms_per_frame": round(1e3 * secs / iters, 4), "frames": iters}
-    out["note"] = ("stress_tests/many_cubes --benchmark shape (examples/stress_tests/many_cubes.rs:61,192-212) at 160k entities: "
-                   "sync_simple_transforms + reset + check_visibility + mark_newly_hidden, oracle C port; CPU plumbing line, no GPU")
-    return out
-
-
-def cpu_baseline_other(name, wl):
-    """The oracle's C port of the same stage on the host: the hierarchy on all cores (rows of a level in parallel, levels in
-    order -- the parallelism propagate_parent_transforms gets from the task pool), assign_objects_to_clusters and the batch
-    bookkeeping on ONE core (single-threaded in the reference); a few seconds' worth of frames."""
-    import oracle_lib as O
-    if name == "batching":
-        bs, rows = wl.batch
-        a = (rows, bs["row_set"], bs["row_bin"], bs["row_input"], bs["set_indexed"], bs["bin_table_offset"], bs["bin_table"],
-             bs["meta_offset"], bs["bin_metadata"])
-        t0 = time.perf_counter()
-        O.batch_build(*a)
-        one = time.perf_counter() - t0
-        iters = int(max(1, min(200, 2.0 / max(one, 1e-4))))
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            O.batch_build(*a)
-        secs = time.perf_counter() - t0
-        return {"value": round(len(rows) * iters / secs, 1), "unit": "visible rows/s (batch build only)", "cores": 1, "kind": "port",
-                "sample": f"{iters} builds over {len(rows)} visible rows: oracle C restatement of the bin bookkeeping + "
-                          f"allocate_uniforms + unpack_bins, {secs:.2f}s"}
-    if name == "batching_sorted":
-        items = wl.sorted_items
-        t0 = time.perf_counter()
-        O.batch_sorted(items, True, False, O.BatchInitial())
-        one = time.perf_counter() - t0
-        iters = int(max(1, min(500, 2.0 / max(one, 1e-5))))
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            O.batch_sorted(items, True, False, O.BatchInitial())
-        secs = time.perf_counter() - t0
-        return {"value": round(len(items) * iters / secs, 1), "unit": "items/s", "cores": 1, "kind": "port",
-                "sample": f"{iters} builds of a {len(items)}-item sorted phase: oracle C restatement of batch_and_prepare_sorted_render_phase, {secs:.2f}s"}
-    if name == "tree":
-        tr = wl.tree
-        cores = os.cpu_count() or 1
-        a = (tr["parent"], tr["level_offsets"], tr["translation"], tr["rotation"], tr["scale"])
-        one, _ = O.bench_tree_frame(*a, cores, 1)
-        iters = int(max(1, min(2000, 3.0 / max(one, 1e-4))))
-        secs, _ = O.bench_tree_frame(*a, cores, iters)
-        return {"value": round(tr["n"] * iters / secs, 1), "unit": "nodes/s", "cores": cores, "kind": "port",
-                "sample": f"{iters} frames of {tr['n']} nodes, every Transform changed: oracle C port of propagate_parent_transforms "
-                          f"(set_if_neq), rows of a level split over a persistent pool of {cores} threads, levels in order, {secs:.2f}s"}
-    if name == "lights":
-        cam, cfv, fr = wl.oracle_args
-        view, lights = O.cluster_view_setup(cam, cfv, fr, 1920, 1080, (16, 9, 24), 5.0, 1000.0), wl.keep[2]
-        t0 = time.perf_counter()
-        O.assign_objects_to_clusters(view, lights)
-        one = time.perf_counter() - t0
-        iters = int(max(1, min(200, 3.0 / max(one, 1e-4))))
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            O.assign_objects_to_clusters(view, lights)
-        secs = time.perf_counter() - t0
-        n = len(lights) // 4
-        return {"value": round(n * iters / secs, 1), "unit": "lights/s", "cores": 1, "kind": "port",
-                "sample": f"{iters} frames of {n} lights: oracle C port of assign_objects_to_clusters (two passes per frame: size, then "
-                          f"fill), {secs:.2f}s"}
-    return None
-
-
-# ---------------------------------------------------------------------------------------------------------------------
-# end-to-end: the same frame with the host on both sides of it (PCIe-inclusive; never `value`)
-# ---------------------------------------------------------------------------------------------------------------------
-def pcie_peak():
-    """What the link gives: hipMemcpyAsync between pinned host memory and the device, 64 MiB, both directions (GB/s)."""
-    import torch
-    n = 64 << 20
-    host = torch.empty(n, dtype=torch.uint8).pin_memory()
-    dev = torch.empty(n, dtype=torch.uint8, device="cuda")
-    out = {}
-    for name, (dst, src) in (("h2d", (dev, host)), ("d2h", (host, dev))):
-        best = 0.0
-        for _ in range(6):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            dst.copy_(src, non_blocking=True)
-            b.record()
-            b.synchronize()
-            best = max(best, n / (a.elapsed_time(b) * 1e-3) / 1e9)
-        out[name] = round(best, 2)
-    return out
-
-
-def end_to_end(ctx, wl, frames=12):
-    """The same frame with the host on both sides of it.  Per frame: the rows a Changed<Transform> query yields go in -- written
-    straight into the library's pinned upload window (mi_map_upload_window / mi_commit_upload_window; dense at 100 %) --, ONE frame
-    call runs propagate + cull + cluster (MI_CULL_CHANGED_ROWS below 100 %), and what the ECS needs comes back with ONE
-    mi_download_frame_results delivered in place: the changed GlobalTransforms, the camera's VisibleEntities list, the cluster
-    offsets / counts / index list.  Wall clock, synchronised every frame."""
-    import bevy_amd as B
-    from bevy_amd import api, workloads as W
-    sc = wl.scene
-    n = sc["n"]
-    views = wl.keep[0]
-    t3 = sc["translation"].reshape(n, 3)
-    r4, s3 = sc["rotation"].reshape(n, 4), sc["scale"].reshape(n, 3)
-    link = pcie_peak()
-    out = {"pcie_peak_GBps": link}
-    rng = np.random.default_rng(0)
-    ctx.upload_changed(np.zeros(n, np.uint8))
-    ctx.propagate(B.PROPAGATE_ALL_DIRTY)
-    ctx.synchronize()
-    bufs = api.FrameResultBuffers(n, n, views[0].n_clusters, 1 << 20, in_place=True)
-    for pct in (1, 10, 100):
-        k = n * pct // 100
-        rows = np.sort(rng.choice(n, k, replace=False)).astype(np.uint32) if pct < 100 else None
-        times, t_in, t_commit, t_run, t_out, h2d, d2h = [], [], [], [], [], 0, 0
-        for f in range(frames + 2):
-            fr = api.PreparedFrusta(camera_frusta(1, f))
-            ctx.synchronize()
-            t0 = time.perf_counter()
-            ctx.cluster_upload_view(views[f % N_FRAMES])
-            if rows is not None:  # the ECS side's gather loop, writing into the window
-                w, wrows, wt, wr, ws = ctx.map_upload_window(k)
-                wrows[:] = rows
-                np.take(t3, rows, axis=0, out=wt.reshape(k, 3), mode="clip")  # (mode="raise" buffers the whole output)
-                np.take(r4, rows, axis=0, out=wr.reshape(k, 4), mode="clip")
-                np.take(s3, rows, axis=0, out=ws.reshape(k, 3), mode="clip")
-                tc = time.perf_counter()
-                ctx.commit_upload_window(w, k)
-                commit_s = time.perf_counter() - tc
-            else:  # every row: dense windows, a chunk at a time -- chunk i crosses PCIe (DMA straight from the window) while the host
-                   # fills chunk i + 1, and (the library's doing: a sequence of dense windows that carries the whole table) chunk i's
-                   # GlobalTransforms are computed and start back at once, under the upload of the chunks behind it.
-                   # (Four Python threads filling eight windows at once were SLOWER: 3.4 against 1.5 ms.)
-                chunk = (n + 7) // 8
-                commit_s = 0.0
-                for lo in range(0, n, chunk):
-                    m = min(chunk, n - lo)
-                    w, _, wt, wr, ws = ctx.map_upload_window(m, dense=True)
-                    wt[:], wr[:], ws[:] = t3[lo:lo + m].reshape(-1), r4[lo:lo + m].reshape(-1), s3[lo:lo + m].reshape(-1)
-                    tc = time.perf_counter()
-                    ctx.commit_upload_window(w, m, first_row=lo)
-                    commit_s += time.perf_counter() - tc
-            t1 = time.perf_counter()
-            ctx.propagate_and_cull(fr, flags=B.CULL_END_FRAME | B.CULL_WITH_CLUSTERS | (B.CULL_CHANGED_ROWS if rows is not None else 0))
-            t2 = time.perf_counter()
-            res = ctx.download_frame_results(bufs)
-            got_g, vis_rows, off, counts, total = len(res["changed_rows"]), res["visible_rows"], res["cluster_offsets"], res["cluster_counts"], res["cluster_total"]
-            t3_ = time.perf_counter()
-            if f >= 2:
-                times.append(t3_ - t0)
-                t_in.append(t1 - t0)
-                t_commit.append(commit_s)
-                t_run.append(t2 - t1)
-                t_out.append(t3_ - t2)
-            h2d = k * 44 if rows is not None else n * 40
-            d2h = got_g * 52 + len(vis_rows) * 4 + len(off) * 4 + counts.size * 4 + total * 4
-        med = float(np.median(times))
-        eff = (h2d + d2h) / med / 1e9
-        # 1.0 = the time both directions would take one after the other at their peaks (a frame whose results depend on its whole input);
-        # where the library overlaps them (100 % dirty: results ahead of the frame) the figure can pass 1.0, up to 2.0 for equal halves
-        link_s = h2d / (link["h2d"] * 1e9) + d2h / (link["d2h"] * 1e9)
-        out[f"{pct}pct_dirty"] = {"dirty_rows": int(k), "us_per_frame": round(1e6 * med, 1), "entities_per_s": round(wl.units / med, 1),
-                                  "h2d_bytes": int(h2d), "d2h_bytes": int(d2h), "pcie_GBps_effective": round(eff, 2),
-                                  "pcie_frac": round(link_s / med, 3),
-                                  "stage_us": {"gather_into_window_and_commit": round(1e6 * float(np.median(t_in)), 1),
-                                               "of_which_commit_calls": round(1e6 * float(np.median(t_commit)), 1),
-                                               "frame_call": round(1e6 * float(np.median(t_run)), 1),
-                                               "results_in_place": round(1e6 * float(np.median(t_out)), 1)},
-                                  "library_us": round(1e6 * float(np.median(np.array(t_commit) + np.array(t_run) + np.array(t_out))), 1),
-                                  "changed_global_transforms_read_back": int(got_g), "visible_entities": int(len(vis_rows)),
-                                  "cluster_index_entries": int(total)}
-    out["note"] = ("same frame as `value` with the host on both sides, through ctypes: dirty Transforms written into the library's pinned upload "
-                   "window (no staging copy; numpy's gather is the ECS side's loop) and committed, ONE frame call (propagate + cull + "
-                   "cluster, MI_CULL_CHANGED_ROWS), ONE mi_download_frame_results delivered in place (one packing launch into pinned memory, one "
-                   f"device wait, no copy out); median wall time of {frames} frames, each synchronised.  library_us = the library's calls alone "
-                   "(commit + frame + results; the rest of us_per_frame is numpy gathering / copying the rows into the window, the ECS side's loop); "
-                   "at 100 % the table goes in as eight dense windows in a row, which the library sends piece by piece with each piece's "
-                   "GlobalTransforms computed at once and on their way back under the rest of the upload (PCIe full duplex): the results call "
-                   "finds them on the host.  pcie_frac = (h2d / peak_h2d + d2h / "
-                   "peak_d2h) / frame time, peaks measured in this run with pinned hipMemcpyAsync (pcie_peak_GBps): 1.0 = both directions one "
-                   "after the other at their peaks, more than that only where they overlap")
-    return out
-
-
-def end_to_end_host_layer(n_entities):
-    """The same frames through the C++ host layer (bevy_amd/host/bevy_mi355x_host.hpp: a World with the path's components and
-    change flags, Mi355xPlugin) -- the code a maintainer would ship as the plugin's systems, not ctypes: the three systems of
-    round 2 (a device wait each) next to the fused frame (Mi355xPlugin::frame: one upload window, one frame call, one in-place
-    results call).  tests/cpp/host_systems_test --bench prints the JSON."""
-    import subprocess
-    from bevy_amd import build as mi_build
-    exe = mi_build.build_host_tests()
-    res = subprocess.run([exe, "--bench", str(n_entities), "8"], capture_output=True, text=True, timeout=600)
-    if res.returncode != 0:
-        return {"error": (res.stderr or res.stdout)[-500:]}
-    d = json.loads(res.stdout.strip().splitlines()[-1])
-    d["note"] = ("tests/cpp/host_systems_test --bench: median wall time of 8 frames per dirty fraction, World::clear_trackers outside the timed "
-                 "region.  us_per_frame is the whole system -- the World's change scan, gather, library calls, ECS writes incl. the stock "
-                 "reset_view_visibility / mark_newly_hidden passes; library_calls_us is upload commit .. results returned (what the ctypes block above times)")
-    return d
-
-
-# ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
     import torch
@@ -950,28 +204,32 @@ def main():
     if rank == 0:
         med = float(np.median(times))
         units = getattr(wl, "global_units", wl.units * world)
+        live = None
+        if world == 1 and not args.no_live_traffic and os.environ.get("MI_BENCH_CHILD") != "1":
+            live = traffic.measure_live(traffic_args(workload, args), getattr(wl, "kernel_name", wl.dominant).split(" ")[0])
         out = {"metric": wl.metric, "value": round(units * args.steps / med, 1), "unit": wl.unit, "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(1e3 * med / args.steps, 5), "higher_is_better": True,
                "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": wl.config,
                "timing": f"median of {len(times)} blocks of exactly {args.steps} steps, each between barrier + synchronize pairs, MAX over ranks per block",
-               "blocks": block_stats(np.array(times), args.steps), "roofline": roofline_of(wl, prof, args.steps), "cpu_baseline": None,
+               "blocks": block_stats(np.array(times), args.steps), "roofline": roofline_of(wl, prof, args.steps, live), "cpu_baseline": None,
                "kernels": {k: round(v["avg_us"], 3) for k, v in prof.items() if v["launches"]}}
+        if live:
+            out["live_traffic"] = live
         if scaling is None:
             del out["scaling"]  # one GPU makes no scaling claim
         out.update(info)
         if world == 1 and not args.no_cpu_baseline:
-            import oracle_lib  # noqa: F401 -- the oracle doubles as the reported CPU baseline ("port"), never as the product
             if workload == "frame":
-                out["cpu_baseline"] = cpu_baseline_frame(wl, args.cpu_seconds)
-                out["config0_cpu_plumbing"] = config0_cpu_plumbing(args.cpu_seconds)
+                out["cpu_baseline"] = cpu.cpu_baseline_frame(wl, args.cpu_seconds)
+                out["config0_cpu_plumbing"] = cpu.config0_cpu_plumbing(args.cpu_seconds)
             elif workload in ("flat", "sharded"):
-                out["cpu_baseline"] = cpu_baseline_flat(wl, args.cpu_seconds, wl.n_views)
+                out["cpu_baseline"] = cpu.cpu_baseline_flat(wl, args.cpu_seconds, wl.n_views)
             else:
-                out["cpu_baseline"] = cpu_baseline_other(workload, wl)
+                out["cpu_baseline"] = cpu.cpu_baseline_other(workload, wl)
         if world == 1 and workload == "frame" and not args.no_end_to_end:
             with torch.cuda.stream(stream):
-                out["end_to_end"] = end_to_end(ctx, wl)
-            out["end_to_end_host_layer"] = end_to_end_host_layer(wl.units)
+                out["end_to_end"] = e2e.end_to_end(ctx, wl, cpu_frame_ms=(out["cpu_baseline"] or {}).get("frame_ms"))
+            out["end_to_end_host_layer"] = e2e.end_to_end_host_layer(wl.units)
     if world > 1 and workload == "sharded":
         # the same scene, whole, on rank 0's GPU alone (outside the timed region): what N = 1 gives for THIS workload
         single = None
@@ -988,28 +246,11 @@ def main():
         if rank == 0:
             out["single_gpu_same_workload"] = single
     if rank == 0 and world == 1 and workload == "frame" and not args.no_other_workloads:
-        # the other BASELINE configs, measured briefly on fresh contexts so the one line carries every stage
         others = {}
-        specs = [("frame_plain_columns", lambda c: build_frame(c, with_args(args, row_summary=1))),  # the metric frame, every row reading its own Aabb / flags / layers
-                 ("flat", lambda c: build_flat(c, args, 0, 1, [], args.entities or 1_000_000, 1, "flat")),
-                 ("flat_plain_columns", lambda c: build_flat(c, with_args(args, row_summary=1), 0, 1, [], args.entities or 1_000_000, 1, "flat")),
-                 ("flat_10m_4views", lambda c: build_flat(c, args, 0, 1, [], 10_000_000, 4, "sharded")),
-                 ("flat_10m_1view", lambda c: build_flat(c, args, 0, 1, [], 10_000_000, 1, "flat")),
-                 ("tree", lambda c: build_tree(c, args)), ("tree_one_subtree_moves", lambda c: build_tree(c, with_args(args, tree_moved="subtree"))),
-                 ("tree_10k_leaves_move", lambda c: build_tree(c, with_args(args, tree_moved="leaves"))),
-                 ("tree_frame", lambda c: build_tree(c, with_args(args, tree_cull=True))),
-                 ("tree_frame_two_launches", lambda c: build_tree(c, with_args(args, tree_cull=True, tree_cull_launches=2))), ("lights", lambda c: build_lights(c, args)),
-                 ("flat_static", lambda c: build_flat_static(c, args)), ("flat_static_no_sphere_column", lambda c: build_flat_static(c, with_args(args, sphere_path=1))),
-                 ("flat_static_10m_4views", lambda c: build_flat_static(c, with_args(args, entities=10_000_000, views=4))),
-                 ("batching", lambda c: build_batching(c, args)),
-                 ("batching_sorted_4k", lambda c: build_batching_sorted(c, with_args(args, sorted_items=4096))),
-                 ("batching_sorted_64k", lambda c: build_batching_sorted(c, with_args(args, sorted_items=65_536))),
-                 ("batching_sorted_64k_one_workgroup", lambda c: build_batching_sorted(c, with_args(args, sorted_items=65_536, sorted_one_wg_limit=0xFFFFFFFF))),
-                 ("batching_sorted_1m", lambda c: build_batching_sorted(c, with_args(args, sorted_items=1_000_000)))]
-        for name, builder in specs:
+        for name, builder in OTHER_WORKLOADS:
             c2 = api.Context(local_rank, stream.cuda_stream)
             with torch.cuda.stream(stream):
-                w2 = builder(c2)
+                w2 = builder(c2, args)
                 w2.profile_key = name  # the committed rocprofv3 evidence is filed per command (flat at 10 M rows is not "flat")
                 t2, p2, i2 = measure(c2, w2, 50, 10, 15)
             m2 = float(np.median(t2))
@@ -1019,17 +260,21 @@ def main():
             if name == "batching":
                 others[name]["batch_build_us_per_frame"] = round(1e3 * (others[name]["ms_per_step"] - others["flat"]["ms_per_step"]), 2)
             if not args.no_cpu_baseline and (name in ("tree", "lights", "batching") or name.startswith("batching_sorted")):
-                others[name]["cpu_baseline"] = cpu_baseline_other(name.split("_sorted")[0] + ("_sorted" if "_sorted" in name else ""), w2)
+                others[name]["cpu_baseline"] = cpu.cpu_baseline_other(name.split("_sorted")[0] + ("_sorted" if "_sorted" in name else ""), w2)
             c2.close()
         out["other_workloads"] = others
     if rank == 0:
+        import json
+        result_line.write_full(out)
         sys.stdout.flush()
         try:  # anything native code left in C stdio buffers (e.g. RCCL's version banner) goes out BEFORE the result line
             import ctypes
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
-        print(json.dumps(out), flush=True)
+        if args.full_line:
+            print(json.dumps(out), flush=True)
+        print(result_line.compact(out), flush=True)
     ctx.close()          # stops the library's exchange thread before the communicator goes away
     for g in full_holder:
         g.close()

@@ -1,0 +1,108 @@
+"""Flat rows, optionally sharded over ranks (configs[1] at N = 1, configs[3] at N > 1), and the 0 %-dirty run."""
+import os
+
+import numpy as np
+
+from .common import N_FRAMES, ROW_SUMMARY_SAVES, Workload, camera_frusta, flat_bytes_per_entity
+
+
+def build_flat(ctx, args, rank, world, full_holder, n_global, n_views, name):
+    import torch
+    import bevy_amd as B
+    from bevy_amd import api, sharding, workloads as W
+    lo, hi = sharding.shard_rows(n_global, world, rank)
+    n_local = hi - lo
+    radius = 500.0 * (n_global / 1_000_000.0) ** (1.0 / 3.0)
+    scene = W.many_cubes(n_global, radius=radius, start=lo, count=n_local)
+    ctx.resize(n_local)
+    ctx.upload_transforms(scene["translation"], scene["rotation"], scene["scale"])
+    ctx.debug_set_row_summary(args.row_summary)
+    ctx.upload_bounds(scene["aabb_center"], scene["aabb_half"], scene["flags"], scene["layers"])
+    frames = [api.PreparedFrusta(camera_frusta(n_views, f)) for f in range(N_FRAMES)]
+    gather = None
+    if world > 1 or os.environ.get("MI_FORCE_GATHER") == "1" or os.environ.get("MI_FORCE_DIST") == "1":
+        gather = sharding.MaskGatherer(n_global, world, n_views, rank, device=torch.device("cuda", torch.cuda.current_device()))
+        full_holder.append(gather)
+        gather.attach(ctx)  # direct RCCL available: the library issues the exchange itself, one FFI call per frame
+    py_exchange = gather is not None and not gather.native
+    deferred = not args.inline_compaction and not py_exchange
+    more = B.CULL_MORE_FRAMES if deferred else 0
+    fcount = [0]
+
+    def step(f):
+        i = f % N_FRAMES
+        k = fcount[0]
+        fcount[0] += 1
+        if py_exchange:
+            gather.before_kernels(k)
+            ctx.bind_visibility_output(*gather.bind_args(k))
+        if args.unfused:
+            ctx.propagate(B.PROPAGATE_ALL_DIRTY)
+            ctx.cull(frames[i], flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME | more)
+        else:
+            ctx.propagate_and_cull(frames[i], flags=B.CULL_END_FRAME | more)
+        if py_exchange:
+            gather.after_kernels(k)
+
+    config = {"workload": f"many_cubes-shaped flat scene, {n_global} entities, {n_views} camera frustum(s), all Transforms dirty, columns "
+                          f"resident in HBM: {'mi_propagate + mi_cull' if args.unfused else 'fused frame kernel'} (propagate + reset + "
+                          "frustum cull + mark-newly-hidden) + VisibleEntities compaction"
+                          + (" (deferred into the next frame's launch)" if deferred else "")
+                          + (f"; rows sharded over {world} GPUs ({n_local} on this rank) + ONE in-place RCCL all-gather of the packed "
+                             f"ViewVisibility bitmasks per frame ({gather.mode})" if gather is not None else ""),
+              "baseline_config": "BASELINE.json configs[3]" if name == "sharded" else "BASELINE.json configs[1]",
+              "entities_total": n_global, "entities_this_rank": n_local, "views": n_views, "deferred_compaction": deferred,
+              "parallelism": f"row-range shard x{world}", "row_summary": args.row_summary == 0}
+    if gather is not None and gather.fallback_reason:
+        config["rccl_direct_fallback"] = gather.fallback_reason
+    metric = ("entities/sec through propagate+cull (10M entities x 4 frusta, 1/2/4/8-GPU scaling)" if name == "sharded"
+              else "entities/sec through propagate+cull")
+    wl = Workload(name, step, n_local, flat_bytes_per_entity(n_views, not args.unfused),
+                  "k_cull" if args.unfused else "k_flat_propagate_cull", config, metric, "entities/s",
+                  kernels=["k_cull" if args.unfused else "k_flat_propagate_cull", "k_compact_fast"])
+    wl.scene, wl.n_views, wl.global_units = scene, n_views, n_global
+    wl.kernel_name = "k_frame<0>" if args.unfused else "k_frame<1,true,false>"  # the timer slot's name is not the symbol's
+    if args.row_summary == 0:
+        wl.layout_bytes_per_row = wl.bytes_per_row - ROW_SUMMARY_SAVES
+    return wl
+
+
+def build_flat_static(ctx, args):
+    """configs[1], second run: 0 % dirty -- mi_propagate finds nothing changed, mi_cull reads the resident G."""
+    import bevy_amd as B
+    from bevy_amd import api, workloads as W
+    n = args.entities or 1_000_000
+    sc = W.many_cubes(n, radius=500.0 * (n / 1_000_000.0) ** (1.0 / 3.0))  # configs[3]'s scaling: the density stays
+    ctx.resize(n)
+    ctx.upload_transforms(sc["translation"], sc["rotation"], sc["scale"])
+    ctx.debug_set_row_summary(args.row_summary)
+    ctx.upload_bounds(sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"])
+    ctx.upload_changed(np.zeros(n, np.uint8))  # the change column exists from here on: only marked rows are recomputed
+    ctx.propagate(B.PROPAGATE_ALL_DIRTY)
+    n_views = args.views or 1
+    frames = [api.PreparedFrusta(camera_frusta(n_views, f)) for f in range(N_FRAMES)]
+    more = 0 if args.inline_compaction else B.CULL_MORE_FRAMES  # as in the flat workload: frames back to back
+    sphere = getattr(args, "sphere_path", 0) != 1
+    ctx.debug_set_sphere_path(getattr(args, "sphere_path", 0))
+
+    def step(f):
+        ctx.propagate(0)
+        ctx.cull(frames[f % N_FRAMES], flags=B.CULL_BEGIN_FRAME | B.CULL_END_FRAME | more)
+    # byte models per row.  G resident (k_frame<0>): read G 48 + Aabb 24 + flags 1 + layers 4 + vv 1, write vv 1 + masks.
+    # World-sphere column (k_frame_sph): read (cw, sr) 16 + flags 1 + layers 4 + vv 1, write vv 1 + masks; GlobalTransform and half
+    # extents only for the rows that pass a sphere test (a few percent: not counted -- the PMC traffic shows them).
+    wr = 1.0 + (n_views + 1) / 8.0 + n_views / 64.0
+    models = {"world_sphere_column": 22.0 + wr, "global_transform_resident": flat_bytes_per_entity(n_views, False)}
+    config = {"workload": f"many_cubes-shaped flat scene, {n} entities, {n_views} frustum(s), 0 % of the Transforms dirty: mi_propagate "
+                          "(no row was marked since the last one: returns without a launch) + mi_cull ("
+                          + ("the world-sphere column: 16 B per row instead of GlobalTransform + Aabb, k_frame_sph" if sphere else "G resident, k_frame<0>")
+                          + ") + VisibleEntities compaction" + (" deferred into the next frame's launch" if more else ""),
+              "baseline_config": "BASELINE.json configs[1], 0 %-dirty run", "entities": n, "views": n_views, "deferred_compaction": bool(more),
+              "sphere_path": sphere, "bytes_per_row_models": models}
+    wl = Workload("flat_static", step, n, models["world_sphere_column" if sphere else "global_transform_resident"], "k_cull", config,
+                  "entities/sec through propagate+cull", "entities/s", kernels=["k_cull", "k_compact_fast"])
+    wl.kernel_name = "k_frame_sph<false>" if sphere else "k_frame<0>"
+    if args.row_summary == 0:  # the sphere path reads flags + layers per row (5 B), the resident-G path Aabb as well
+        wl.layout_bytes_per_row = wl.bytes_per_row - ((5.0 - 0.5) if sphere else ROW_SUMMARY_SAVES)
+    config["row_summary"] = args.row_summary == 0
+    return wl

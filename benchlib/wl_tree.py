@@ -1,0 +1,110 @@
+"""configs[4]: the deep hierarchy (all dirty, change-driven, and the hierarchy frame with its cull)."""
+import numpy as np
+
+from .common import N_FRAMES, ROW_SUMMARY_SAVES, Workload, camera_frusta, flat_bytes_per_entity
+
+
+def build_tree(ctx, args, rank=0, world=1):
+    import bevy_amd as B
+    from bevy_amd import sharding, workloads as W
+    tr = W.gen_tree(12, 4, (args.entities or 1_000_000) * (world if args.scaling == "weak" else 1))
+    n_global = tr["n"]
+    if world > 1:
+        # shard by root subtree -- the one giant tree is opened up, its top rows are replicated and the
+        # subtrees below are bin-packed on the GPUs; no collective (a rank's rows never read another rank's)
+        sh = sharding.shard_hierarchy(tr["parent"], tr["level_offsets"], world, rank)
+        rows = sh["rows"].astype(np.int64)
+        tr = dict(n=len(rows), parent=sh["parent"], level_offsets=sh["level_offsets"],
+                  translation=tr["translation"].reshape(-1, 3)[rows].reshape(-1), rotation=tr["rotation"].reshape(-1, 4)[rows].reshape(-1),
+                  scale=tr["scale"].reshape(-1, 3)[rows].reshape(-1), owned=int(sh["owned"].sum()))
+    ctx.resize(tr["n"])
+    ctx.upload_transforms(tr["translation"], tr["rotation"], tr["scale"])
+    if args.tile_mode:
+        ctx.debug_set_tile_mode(args.tile_mode)
+    ctx.upload_hierarchy(tr["parent"], tr["level_offsets"])
+    plan = ctx.debug_tile_plan()
+    # the root moves every frame (a 40-byte dirty-row upload), so set_if_neq really rewrites every descendant
+    root_t = [tr["translation"][:3].copy(), tr["translation"][:3] + np.float32(1.0)]
+    moved = getattr(args, "tree_moved", "all")
+    if moved != "all":
+        # change-driven frames under StaticTransformOptimizations (the frame a game mostly runs): "subtree" = one node of level 5
+        # moves (1 / 1024 of a 4-ary tree follows it), "leaves" = 10 000 random leaves move
+        n, lv = tr["n"], tr["level_offsets"]
+        rng = np.random.default_rng(3)
+        rows = (np.array([int(lv[5]) + 17], np.uint32) if moved == "subtree"
+                else np.sort(rng.choice(np.arange(int(lv[-2]), n), 10_000, replace=False)).astype(np.uint32))
+        t3 = tr["translation"].reshape(n, 3)
+        sets = [(np.ascontiguousarray(t3[rows] + np.float32(d)).reshape(-1), np.ascontiguousarray(tr["rotation"].reshape(n, 4)[rows]).reshape(-1),
+                 np.ascontiguousarray(tr["scale"].reshape(n, 3)[rows]).reshape(-1)) for d in (0.0, 1.0)]
+        ctx.upload_changed(np.ones(n, np.uint8))
+        ctx.propagate(B.PROPAGATE_STATIC_OPT)
+
+        def step(f):
+            ctx.upload_transforms_indexed(rows, *sets[f & 1])
+            ctx.propagate(B.PROPAGATE_STATIC_OPT)
+        config = {"workload": f"gen_tree(12,4) truncated to {n_global} nodes, StaticTransformOptimizations enabled, per frame "
+                              + ("ONE node of level 5 moves (1 / 1024 of the tree follows)" if moved == "subtree" else "10 000 random leaves move")
+                              + ": mi_upload_transforms_indexed + mi_propagate(MI_PROPAGATE_STATIC_OPT) = mark_dirty_trees + the tile launch",
+                  "nodes": n_global, "moved_rows": int(len(rows)), "tile_plan": plan}
+        # algorithmic bytes of a change-driven tile launch: every tile's descriptor (64 B) and flags pre-test (chain change bytes + top
+        # marks, <= 136 B), plus the all-dirty 141 B for the rows that are re-evaluated (the moved rows' subtrees / the moved leaves and
+        # the marked ancestors' tiles are a superset: counted as the rows below the moved ones only -- a lower bound)
+        follows = (tr["n"] // 1024 if moved == "subtree" else len(rows))
+        alg = (plan["tiles"] * 200.0 + follows * 141.0) / tr["n"]
+        wl = Workload("tree_" + moved, step, tr["n"], alg, "k_propagate_tiles", config, "nodes/sec through change-driven hierarchy propagate", "nodes/s",
+                      kernels=["k_propagate_tiles", "k_mark_dirty"])
+        wl.tree = tr
+        wl.kernel_name = "k_propagate_fans<false>"
+        return wl
+
+    if getattr(args, "tree_cull", False):
+        # the hierarchy FRAME: every node carries a unit-cube Aabb; one call = the tile launch (every Transform counts as changed) + the
+        # cull launch behind it (reset + check_visibility + mark-newly-hidden over the GlobalTransforms just written) + the deferred compaction
+        from bevy_amd import api
+        n = tr["n"]
+        ctx.debug_set_row_summary(args.row_summary)
+        tcl = getattr(args, "tree_cull_launches", 0)
+        fused = tcl == 1 or (tcl == 0 and (args.views or 1) == 1)
+        ctx.debug_set_tree_cull({0: 0, 1: 2, 2: 1}[tcl])
+        ctx.upload_bounds(np.zeros(3 * n, np.float32), np.full(3 * n, 0.5, np.float32), np.full(n, 0x05, np.uint8), np.ones(n, np.uint32))
+        n_views = args.views or 1
+        frames = [api.PreparedFrusta(camera_frusta(n_views, f)) for f in range(N_FRAMES)]
+        more = 0 if args.inline_compaction else B.CULL_MORE_FRAMES
+
+        def step_frame(f):
+            ctx.upload_transforms(root_t[f & 1], tr["rotation"][:4], tr["scale"][:3], first_row=0)
+            ctx.propagate_and_cull(frames[f % N_FRAMES], flags=B.CULL_END_FRAME | more)
+        config = {"workload": f"gen_tree(12,4) truncated to {n_global} nodes, every node with an Aabb, {n_views} camera frustum(s): the hierarchy frame in one "
+                              "call -- mi_propagate_and_cull = subtree-tile propagation (root moved, every Transform counts as changed) "
+                              + ("in which every tile also runs the visibility systems over its own rows (k_propagate_fans<true, true>)" if fused
+                                 else "+ the cull launch over the GlobalTransforms it wrote") + " + VisibleEntities compaction",
+                  "baseline_config": "BASELINE.json configs[4] + the cull of configs[1]", "nodes": n_global, "views": n_views, "tile_plan": plan,
+                  "row_summary": args.row_summary == 0}
+        # propagate 141 B per node (above) + cull with G resident: read G 48 + Aabb 24 + flags 1 + layers 4 + vv 1, write vv 1 + masks
+        config["bytes_per_node"] = {"tile_launch": 141.0, "cull_launch_G_resident": flat_bytes_per_entity(n_views, False)}
+        wl = Workload("tree_frame", step_frame, tr["n"], 141.0, "k_propagate_tiles", config,
+                      "nodes/sec through hierarchy propagate + cull", "nodes/s", kernels=["k_propagate_tiles", "k_cull", "k_compact_fast"])
+        wl.tree = tr
+        wl.kernel_name = "k_propagate_fans<true,true>" if fused else "k_propagate_fans<true> + k_frame<0>"
+        if fused:  # + read Aabb 24 + flags 1 + layers 4 (summarised: 0.5) + vv 1, write vv 1 + masks
+            wl.bytes_per_row = 141.0 + 31.0 + (n_views + 1) / 8.0 + n_views / 64.0
+            if args.row_summary == 0:
+                wl.layout_bytes_per_row = wl.bytes_per_row - ROW_SUMMARY_SAVES
+        return wl
+
+    def step(f):
+        ctx.upload_transforms(root_t[f & 1], tr["rotation"][:4], tr["scale"][:3], first_row=0)
+        ctx.propagate(B.PROPAGATE_ALL_DIRTY)
+    config = {"workload": f"gen_tree(12,4) truncated to {n_global} nodes ({len(tr['level_offsets']) - 1} levels), root moved "
+                          "every frame (dirty-row upload), subtree-tile propagation"
+                          + (f", sharded by root subtree over {world} GPUs (this rank holds {tr['n']} rows, no collective)" if world > 1 else ""),
+              "baseline_config": "BASELINE.json configs[4]", "nodes": n_global, "parallelism": f"root-subtree shard x{world}", "tile_plan": plan}
+    # T 40, parent_idx 4, old G 48 (set_if_neq), G 48, changed byte 1
+    # ("k_propagate_tiles" is the library's timer slot for the tile launch: k_propagate_fans for a tree this size)
+    wl = Workload("tree", step, tr["n"], 141.0, "k_propagate_tiles", config, "nodes/sec through hierarchy propagate", "nodes/s",
+                  kernels=["k_propagate_tiles", "k_propagate_stream"])
+    wl.tree = tr
+    # the library's timer slot is called k_propagate_tiles; the kernel rocprofv3 shows for a plan of light tiles is k_propagate_fans
+    wl.kernel_name = "k_propagate_tiles<256>" if args.tile_mode == 1 else "k_propagate_fans<true>"
+    wl.global_units = n_global  # every node is owned by exactly one rank (replicated top rows are recomputed, not counted)
+    return wl

@@ -1,0 +1,103 @@
+"""bench.py's result line: the LAST stdout line is a compact JSON object the driver can parse -- under 4 KB, the contract's keys -- at
+N = 1 (`frame`) and at N > 1 (`sharded`); everything else goes to bench_full.json.  (BENCH_r03: the 40 KB line was not parsed.)"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from benchlib import line as L  # noqa: E402
+from benchlib import traffic as T  # noqa: E402
+
+
+def canned(n_gpus=1):
+    long = "x" * 5000
+    roof = {"bound": "hbm", "kernel": "k_frame<1,true,true>", "timer_slot": "k_flat_propagate_cull", "achieved": 5100.0, "peak": 8000.0, "unit": "GB/s",
+            "frac": 0.6375, "traffic": 106_600_000, "traffic_source": "live: " + long, "avg_kernel_us": 20.1, "launches": 60,
+            "moved_bytes_per_launch": 100_900_000, "algorithmic_bytes_per_launch": 132_500_000, "frac_algorithmic": 0.82, "timing": long,
+            "layout_note": long, "rocprof_avg_kernel_us": 20.6, "rocprof_frac": 0.61, "rocprof_source": long}
+    out = {"metric": "entities/sec through propagate+cull+cluster at 1M entities", "value": 4.9e10, "unit": "entities/s", "n_gpus": n_gpus, "steps": 20,
+           "warmup": 5, "ms_per_step": 0.0204, "higher_is_better": True, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": long, "baseline_config": "BASELINE.json configs[1] + configs[2]", "entities": 1_000_000, "rows_per_frame": 1_110_000,
+                      "lights": 100_000, "meshes": 10_000, "views": 1, "parallelism": "1 GPU", "row_summary": True, "tile_plan": {"a": list(range(500))}},
+           "timing": long, "blocks": {"n": 30, "steps_per_block": 20, "median_ms_per_step": 0.02, "p10_ms_per_step": 0.0199, "p90_ms_per_step": 0.0209,
+                                      "min_ms_per_step": 0.019, "max_ms_per_step": 0.03},
+           "roofline": roof, "kernels": {f"k{i}": 1.0 for i in range(40)},
+           "cpu_baseline": {"value": 3.5e8, "unit": "entities/s", "cores": 32, "kind": "port", "sample": long, "host_cores": 256,
+                            "frame_ms": 2.88, "thread_sweep_ms_per_frame": {str(i): 1.0 for i in range(30)}, "stage_ms": {"a": 1.0}},
+           "end_to_end": {"pcie_peak_GBps": {"h2d": 56.0, "d2h": 56.0},
+                          "1pct_dirty": {"us_per_frame": 181.0, "stage_us": {"x": 1.0}}, "10pct_dirty": {"us_per_frame": 1800.0},
+                          "100pct_dirty": {"us_per_frame": 2090.0}, "x_cpu_port": {"1pct_dirty": 15.9, "10pct_dirty": 1.6, "100pct_dirty": 1.38},
+                          "note": long},
+           "end_to_end_host_layer": {"note": long}, "other_workloads": {f"w{i}": {"config": {"workload": long}, "roofline": roof} for i in range(19)}}
+    if n_gpus > 1:
+        out.update({"scaling": "strong", "metric": "entities/sec through propagate+cull (10M entities x 4 frusta, 1/2/4/8-GPU scaling)",
+                    "cpu_baseline": None, "single_gpu_same_workload": {"value": 5.5e10, "unit": "entities/s", "ms_per_step": 0.18, "note": long}})
+        out["config"].update({"entities_total": 10_000_000, "entities_this_rank": 1_250_000, "parallelism": "row-range shard x8"})
+        del out["end_to_end"], out["other_workloads"]
+    return out
+
+
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config",
+            "roofline", "cpu_baseline"}
+
+
+def test_single_gpu_line_is_compact_and_complete():
+    s = L.compact(canned(1))
+    assert "\n" not in s and len(s) < L.MAX_LINE_BYTES == 4096
+    d = json.loads(s)
+    assert REQUIRED <= set(d) and "scaling" not in d
+    assert {"bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_kernel_us", "algorithmic_bytes_per_launch",
+            "moved_bytes_per_launch", "frac_algorithmic"} <= set(d["roofline"])
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"])
+    assert d["config"]["workload"].endswith("...") and "tile_plan" not in d["config"]
+    assert d["end_to_end"]["x_cpu_port"]["100pct_dirty"] == 1.38 and d["end_to_end"]["us_per_frame"]["1pct_dirty"] == 181.0
+    assert "other_workloads" not in d and d["full"] == L.FULL_NAME
+    # frac is the bytes-moved figure: never above the algorithmic one
+    assert d["roofline"]["frac"] <= d["roofline"]["frac_algorithmic"]
+
+
+def test_sharded_line_is_compact_and_complete():
+    s = L.compact(canned(8))
+    assert len(s) < 4096
+    d = json.loads(s)
+    assert REQUIRED <= set(d) and d["scaling"] == "strong" and d["n_gpus"] == 8 and d["cpu_baseline"] is None
+    assert d["single_gpu_same_workload"]["value"] == 5.5e10
+
+
+def test_roofline_prices_the_launch_at_the_bytes_it_moves():
+    from benchlib.measure import roofline_of
+
+    class W:
+        dominant, name, kernel_name = "k_flat_propagate_cull", "frame_not_in_profiles", "k_frame<1,true,true>"
+        bytes_per_row, rows, layout_bytes_per_row = 119.0, 1_000_000, 90.5
+    prof = {"k_flat_propagate_cull": {"avg_us": 20.0, "launches": 60}}
+    r = roofline_of(W, prof, 20)
+    assert r["moved_bytes_per_launch"] == 90_500_000 and r["algorithmic_bytes_per_launch"] == 119_000_000
+    assert abs(r["frac"] - 90.5e6 / 20e-6 / 1e9 / 8000.0) < 1e-3 and abs(r["frac_algorithmic"] - 119e6 / 20e-6 / 1e9 / 8000.0) < 1e-3
+    assert r["traffic"] is None
+    r = roofline_of(W, prof, 20, {"hbm_bytes_per_launch": 93_000_000, "source": "live: test"})
+    assert r["traffic"] == 93_000_000 and r["traffic_source"].startswith("live")
+    W.layout_bytes_per_row = None
+    r = roofline_of(W, prof, 20)
+    assert r["moved_bytes_per_launch"] == r["algorithmic_bytes_per_launch"] and r["frac"] == r["frac_algorithmic"]
+
+
+def test_counter_csv_parsing(tmp_path):
+    p = tmp_path / "pmc_counter_collection.csv"
+    p.write_text('"Correlation_Id","Dispatch_Id","Kernel_Name","Counter_Name","Counter_Value"\n'
+                 '1,1,"void mi::(anonymous namespace)::k_frame<1, true, true>(mi::FrameArgs)","FETCH_SIZE",1000.0\n'
+                 '2,2,"void mi::(anonymous namespace)::k_frame<1, true, true>(mi::FrameArgs)","FETCH_SIZE",3000.0\n'
+                 '3,3,"void mi::(anonymous namespace)::k_frame<1, true, false>(mi::FrameArgs)","FETCH_SIZE",9.0\n'
+                 '4,4,"mi::k_row_summary(void*)","FETCH_SIZE",5.0\n')
+    assert T.parse_counter_csv(str(p), "k_frame<1,true,true>", "FETCH_SIZE") == [1000.0, 3000.0]
+    assert T.parse_counter_csv(str(p), "k_frame<1,true,true>", "WRITE_SIZE") == []
+
+
+def test_bench_modules_keep_the_oracle_out_of_the_timed_path():
+    """Only benchlib/cpu_baseline.py may import the oracle (the checker timed as a baseline)."""
+    for name in os.listdir(os.path.join(ROOT, "benchlib")):
+        if name.endswith(".py") and name != "cpu_baseline.py":
+            assert "oracle_lib" not in open(os.path.join(ROOT, "benchlib", name)).read(), name
+    assert "oracle_lib" not in open(os.path.join(ROOT, "bench.py")).read()

@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 O=gpurun_out/quick
 rm -rf $O; mkdir -p $O
 timeout 1500 python -m pytest ${QUICK_TESTS:-tests} -x -q -m gpu > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/summary.txt
-B="python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-other-workloads --no-end-to-end"
+B="python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-other-workloads --no-end-to-end --no-live-traffic"
 i=0
 while IFS= read -r line; do
   [ -z "$line" ] && continue

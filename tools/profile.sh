@@ -11,7 +11,7 @@ WLS=${@:-frame frame_plain_columns flat flat_plain_columns flat_10m_1view flat_1
 export TMPDIR=/tmp
 P=gpurun_out/prof_$TAG
 mkdir -p $P
-COMMON="--no-cpu-baseline --no-other-workloads --no-end-to-end"
+COMMON="--no-cpu-baseline --no-other-workloads --no-end-to-end --no-live-traffic"
 for wl in $WLS; do
   case $wl in
     frame_plain_columns) ARGS="--workload frame --row-summary 1" ;;

@@ -8,10 +8,10 @@ for m in $2; do
   MI_TEST_TILE_MODE=$m timeout 600 python -m pytest tests -m gpu -x -q -k "$K" > $O/test_mode$m.log 2>&1; echo "test mode $m rc=$? $(tail -1 $O/test_mode$m.log)" >> $O/summary.txt
 done
 for m in $3; do
-  timeout 300 python bench.py --workload tree --tile-mode $m --steps 50 --blocks 8 --no-cpu-baseline --no-other-workloads --no-end-to-end > $O/bench_mode$m.json 2> $O/bench_mode$m.err
+  timeout 300 python bench.py --workload tree --tile-mode $m --steps 50 --blocks 8 --no-cpu-baseline --no-other-workloads --no-end-to-end --no-live-traffic > $O/bench_mode$m.json 2> $O/bench_mode$m.err
   python - <<P >> $O/summary.txt
 import json
-d=json.load(open("$O/bench_mode$m.json"))
+d=json.load(open("bench_full.json"))
 print("bench mode $m", d["ms_per_step"], d["kernels"], d["config"].get("tile_plan"))
 P
 done

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 O=gpurun_out/tree_pmc
 mkdir -p $O
-COMMON="--workload tree --steps 10 --warmup 2 --blocks 2 --no-cpu-baseline --no-other-workloads --no-end-to-end"
+COMMON="--workload tree --steps 10 --warmup 2 --blocks 2 --no-cpu-baseline --no-other-workloads --no-end-to-end --no-live-traffic"
 for m in $1; do
   i=0
   for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \

@@ -1169,6 +1169,10 @@ int32_t mi_upload_global_transforms(mi_ctx* ctx, uint32_t first_row, uint32_t n,
     if (rc) return rc;
     ctx->snap_valid = false;  // externally supplied values: the tree path re-snapshots its owner rows
     ctx->sph_state = mi_ctx::SPH_INVALID;
+    // The column no longer holds what the last frame wrote: results that travelled ahead of it (every row's From(Transform) in g_host,
+    // the indexed window's rows in gs_host) are not what a download of the column would return any more -- hand out neither.
+    ctx->gs_frame_ok = false;
+    ctx->frame_all_version = 0;
     return upload(ctx, ctx->g + 12 * (size_t)first_row, global12, (size_t)n * 48);
 }
 

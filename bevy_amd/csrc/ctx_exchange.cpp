@@ -172,6 +172,9 @@ int32_t exchange_begin(mi_ctx* ctx) {
     if (!x.on) return MI_OK;
     const uint32_t slot = (uint32_t)(x.frame % x.n_bufs);
     if (x.simple) {
+        // (checked here, before any of the frame's work is enqueued: a frame that cannot be exchanged is refused whole)
+        if (x.grouped && x.group_pending)
+            return fail(ctx, MI_ERR_NOT_READY, "MI_EXCHANGE_GROUPED: the previous frame's all-gather was never flushed (mi_exchange_group_flush)");
         // the buffer was last used n_bufs frames ago: its all-gather must have drained before the kernels overwrite it
         if (x.frame >= x.n_bufs) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, x.ev_gathered[slot], 0));
         ctx->ext_bitmask = x.buf[slot];
@@ -314,16 +317,25 @@ int32_t mi_exchange_group_flush(mi_ctx* const* contexts, uint32_t n, void* fn_nc
         err = x.all_gather(base + (size_t)x.rank * x.block_bytes, base, (size_t)x.block_bytes, 1 /* ncclUint8 */, x.comm[0], x.comm_stream[0]);
         if (err) rc = fail(ctx, MI_ERR_DEVICE, "ncclAllGather failed (%d)", err);
     }
+    // The group is closed whatever happened inside it (an open group would swallow every later collective of this thread).  After a
+    // failure the frame's exchange is lost on EVERY listed context -- RCCL gives no defined state for a group that was closed around a
+    // failed call -- so none of them stays pending: the error is reported once, here, and the next frame starts clean (its masks go to
+    // the next buffer; mi_exchange_last of the lost frame returns whatever the buffer holds, which the error told the caller not to use).
     err = ((group_fn)fn_nccl_group_end)();  // the collectives of every context are enqueued here, together
-    if (rc) return rc;
-    if (err) return fail(contexts[0], MI_ERR_DEVICE, "ncclGroupEnd failed (%d)", err);
+    if (rc || err) {
+        for (uint32_t i = 0; i < n; ++i) contexts[i]->xch.group_pending = false;
+        if (rc) return rc;
+        return fail(contexts[0], MI_ERR_DEVICE, "ncclGroupEnd failed (%d)", err);
+    }
     for (uint32_t i = 0; i < n; ++i) {
         mi_ctx* ctx = contexts[i];
         auto& x = ctx->xch;
         if (!x.group_pending) continue;
-        if (hipSetDevice(ctx->device) != hipSuccess || hipEventRecord(x.ev_gathered[x.group_slot], x.comm_stream[0]) != hipSuccess)
-            return fail(ctx, MI_ERR_DEVICE, "mi_exchange_group_flush: event record failed on context %u", i);
         x.group_pending = false;
+        if (hipSetDevice(ctx->device) != hipSuccess || hipEventRecord(x.ev_gathered[x.group_slot], x.comm_stream[0]) != hipSuccess) {
+            for (uint32_t k = i; k < n; ++k) contexts[k]->xch.group_pending = false;
+            return fail(ctx, MI_ERR_DEVICE, "mi_exchange_group_flush: event record failed on context %u", i);
+        }
     }
     return MI_OK;
 }

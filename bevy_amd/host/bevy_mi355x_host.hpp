@@ -391,7 +391,12 @@ class TaskPool {
             return;
         }
         {
-            std::lock_guard<std::mutex> lk(m_);
+            // Nobody may be inside work() while the job's fields change: a worker that woke late for the job BEFORE (after its caller
+            // had already returned: active_ was 0 then, the worker still on its way out of cv_.wait) would draw a stale index from
+            // next_, compare it with the new total_ and run a chunk of this job a second time -- done_ overshoots total_ and the wait
+            // below never ends.  Such a worker finds next_ >= total_ of the finished job and leaves at once: wait for it here.
+            std::unique_lock<std::mutex> lk(m_);
+            cv_done_.wait(lk, [&] { return active_ == 0; });
             job_ = &fn;
             total_ = n_chunks;
             done_.store(0, std::memory_order_relaxed);

@@ -772,7 +772,8 @@ int32_t mi_exchange_group_flush(mi_ctx* const* contexts, uint32_t n, void* fn_nc
 /* The gathered buffer of the most recent frame (optionally after waiting for its collective). */
 int32_t mi_exchange_last(mi_ctx* ctx, void** out_device_buf, int32_t wait);
 
-/* Raw device pointers of library-owned columns, for zero-copy consumers on the same device
+/* Raw device pointers of library-owned columns, for zero-copy READERS on the same device (write through the upload entry points only:
+ * the library keeps results that travel ahead of a frame and does not see a write through a raw pointer)
  * (e.g. the render world's mesh-uniform builder).  Valid until the next mi_columns_resize. */
 #define MI_BUF_GLOBAL_TRANSFORM 0
 #define MI_BUF_VISIBILITY_BITMASK 1

@@ -454,30 +454,51 @@ fn upload_and_propagate(
                     let mut row = 0usize; // rows written so far == the table walk's position
                     let mut window: ffi::MiUploadWindow = unsafe { core::mem::zeroed() };
                     let (mut lo, mut hi) = (0usize, 0usize); // the open window carries rows [lo, hi)
-                    for (_, table_transforms, _) in tables {
-                        for t in table_transforms.iter() {
-                            if row == hi {
-                                if hi > lo {
-                                    check(ctx, "mi_commit_upload_window", unsafe { ffi::mi_commit_upload_window(ctx, &window, (hi - lo) as u32, lo as u32) })?;
+                    let mut next_window = 0usize;            // windows mapped so far: window k carries [n k / 8, n (k + 1) / 8)
+                    let mut open = false;
+                    // A failing map / commit must not leave a window mapped: it would never be recycled (its pinned chunk stays out of
+                    // the pool for the life of the context).  Every exit below gives the open window back with n = 0.
+                    let r = (|| -> Result<(), ()> {
+                        for (_, table_transforms, _) in tables {
+                            for t in table_transforms.iter() {
+                                if row == hi {
+                                    if open {
+                                        open = false;
+                                        check(ctx, "mi_commit_upload_window", unsafe { ffi::mi_commit_upload_window(ctx, &window, (hi - lo) as u32, lo as u32) })?;
+                                    }
+                                    lo = hi;
+                                    // exactly WINDOWS pieces (fewer when n < WINDOWS): boundaries n (k + 1) / WINDOWS, empty ones skipped
+                                    while hi <= lo {
+                                        next_window += 1;
+                                        hi = n * next_window / WINDOWS;
+                                    }
+                                    check(ctx, "mi_map_upload_window", unsafe {
+                                        ffi::mi_map_upload_window(ctx, (hi - lo) as u32, ffi::MI_UPLOAD_DENSE, &mut window)
+                                    })?;
+                                    open = true;
                                 }
-                                lo = hi;
-                                hi = (n * (lo * WINDOWS / n + 1) / WINDOWS).max(lo + 1).min(n);
-                                check(ctx, "mi_map_upload_window", unsafe {
-                                    ffi::mi_map_upload_window(ctx, (hi - lo) as u32, ffi::MI_UPLOAD_DENSE, &mut window)
-                                })?;
+                                let k = row - lo;
+                                // SAFETY: k < hi - lo, the capacity the window was mapped with.
+                                unsafe {
+                                    core::ptr::copy_nonoverlapping(t.translation.to_array().as_ptr(), window.translation.add(3 * k), 3);
+                                    core::ptr::copy_nonoverlapping(t.rotation.to_array().as_ptr(), window.rotation.add(4 * k), 4);
+                                    core::ptr::copy_nonoverlapping(t.scale.to_array().as_ptr(), window.scale.add(3 * k), 3);
+                                }
+                                row += 1;
                             }
-                            let k = row - lo;
-                            // SAFETY: k < hi - lo, the capacity the window was mapped with.
-                            unsafe {
-                                core::ptr::copy_nonoverlapping(t.translation.to_array().as_ptr(), window.translation.add(3 * k), 3);
-                                core::ptr::copy_nonoverlapping(t.rotation.to_array().as_ptr(), window.rotation.add(4 * k), 4);
-                                core::ptr::copy_nonoverlapping(t.scale.to_array().as_ptr(), window.scale.add(3 * k), 3);
-                            }
-                            row += 1;
                         }
-                    }
-                    if hi > lo {
-                        check(ctx, "mi_commit_upload_window", unsafe { ffi::mi_commit_upload_window(ctx, &window, (hi - lo) as u32, lo as u32) })?;
+                        if open {
+                            open = false;
+                            check(ctx, "mi_commit_upload_window", unsafe { ffi::mi_commit_upload_window(ctx, &window, (hi - lo) as u32, lo as u32) })?;
+                        }
+                        Ok(())
+                    })();
+                    if r.is_err() {
+                        if open {
+                            // SAFETY: `window` is the mapped window; n = 0 only returns it to the pool.
+                            let _ = unsafe { ffi::mi_commit_upload_window(ctx, &window, 0, 0) };
+                        }
+                        return Err(());
                     }
                     mi.every_row_moved = true;
                     return Ok(0);
@@ -1184,8 +1205,13 @@ pub fn mi_fused_frame(
     if views.is_empty() || views.len() * mi.class_bits.len().max(1) > ffi::MI_RESULTS_MAX_LISTS as usize {
         // nothing to cull (or more lists than one results call takes): the propagate-only path
         let r = (|| -> Result<u32, ()> {
+            // Dense windows raise no change marks (they carry every row): when upload_and_propagate took that route the propagate
+            // must count every Transform as changed itself -- mi_propagate(0) would find no mark and return without a launch, with the
+            // ECS change ticks already consumed.  StaticTransformOptimizations applies here as in the frame call below.
+            let propagate_flags = (if mi.every_row_moved { ffi::MI_PROPAGATE_ALL_DIRTY } else { 0 })
+                | (if static_opt.as_ref().is_some_and(|s| s.is_enabled()) { ffi::MI_PROPAGATE_STATIC_OPT } else { 0 });
             // SAFETY: plain calls on a live context.
-            check(ctx, "mi_propagate", unsafe { ffi::mi_propagate(ctx, 0) })?;
+            check(ctx, "mi_propagate", unsafe { ffi::mi_propagate(ctx, propagate_flags) })?;
             let s = &mut mi.scratch;
             s.rows.resize(n as usize, 0);
             s.global12.resize(n as usize * 12, 0.0);

@@ -25,7 +25,7 @@ def test_task_pool_runs_every_chunk_exactly_once(tmp_path):
     exe = str(tmp_path / "task_pool_test")
     res = subprocess.run(["g++", "-std=c++17", "-O2", "-pthread", src, "-o", exe], capture_output=True, text=True)
     assert res.returncode == 0, res.stderr[-2000:]
-    res = subprocess.run([exe, "20000"], capture_output=True, text=True, timeout=300)
+    res = subprocess.run([exe, "100000"], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and "task pool: ok" in res.stdout, res.stdout[-1000:]
     tsan = str(tmp_path / "task_pool_tsan")
     res = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-pthread", "-fsanitize=thread", src, "-o", tsan], capture_output=True, text=True)

@@ -82,6 +82,7 @@ def parse():
     ap.add_argument("--tree-cull-launches", type=int, default=0, choices=[0, 1, 2], help="tree --tree-cull: 0 = the library's choice (one view: the tiles cull their own rows), 1 = always that, 2 = tile launch + cull launch")
     ap.add_argument("--tree-cull", action="store_true", help="tree: the hierarchy FRAME -- mi_propagate_and_cull on a context with a hierarchy (tile launch + cull launch, one call)")
     ap.add_argument("--sphere-path", type=int, default=0, help="flat_static / frame: 0 = world-sphere cull path from the second quiet frame (default), 1 = never (k_frame<0> over GlobalTransform + Aabb), 2 = at once")
+    ap.add_argument("--static-cull-order", type=int, default=0, choices=[0, 1, 2], help="flat_static: 0 = frames of a static scene of >= 262144 rows run over the cell order (default), 1 = never, 2 = at once, any size")
     ap.add_argument("--tile-mode", type=int, default=0, help="tree: 0 = tile kernel chosen by size, 1 = big tiles, 2 / 3 = light tiles (5 / 6 waves per SIMD)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true")
@@ -110,6 +111,8 @@ OTHER_WORKLOADS = [  # the other BASELINE configs, measured briefly on fresh con
     ("flat_static", lambda c, a: build_flat_static(c, a)),
     ("flat_static_no_sphere_column", lambda c, a: build_flat_static(c, with_args(a, sphere_path=1))),
     ("flat_static_10m_4views", lambda c, a: build_flat_static(c, with_args(a, entities=10_000_000, views=4))),
+    ("flat_static_10m_4views_no_cull_order", lambda c, a: build_flat_static(c, with_args(a, entities=10_000_000, views=4, static_cull_order=1))),
+    ("flat_static_no_cull_order", lambda c, a: build_flat_static(c, with_args(a, static_cull_order=1))),
     ("batching", lambda c, a: build_batching(c, a)),
     ("batching_sorted_1k", lambda c, a: build_batching_sorted(c, with_args(a, sorted_items=1024))),
     ("batching_sorted_4k", lambda c, a: build_batching_sorted(c, with_args(a, sorted_items=4096))),
@@ -121,7 +124,7 @@ OTHER_WORKLOADS = [  # the other BASELINE configs, measured briefly on fresh con
 def traffic_args(workload, args):
     """argv tail that makes a child bench.py run this workload the same way (benchlib/traffic.py)."""
     a = ["--workload", workload, "--row-summary", str(args.row_summary)]
-    for flag, val in (("--entities", args.entities), ("--views", args.views), ("--sorted-items", args.sorted_items), ("--sphere-path", args.sphere_path),
+    for flag, val in (("--entities", args.entities), ("--views", args.views), ("--sorted-items", args.sorted_items), ("--sphere-path", args.sphere_path), ("--static-cull-order", args.static_cull_order),
                       ("--tile-mode", args.tile_mode), ("--tree-cull-launches", args.tree_cull_launches)):
         if val:
             a += [flag, str(val)]

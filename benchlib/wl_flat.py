@@ -84,6 +84,9 @@ def build_flat_static(ctx, args):
     more = 0 if args.inline_compaction else B.CULL_MORE_FRAMES  # as in the flat workload: frames back to back
     sphere = getattr(args, "sphere_path", 0) != 1
     ctx.debug_set_sphere_path(getattr(args, "sphere_path", 0))
+    order_mode = getattr(args, "static_cull_order", 0)
+    ctx.debug_set_static_cull_order(order_mode)
+    cells = sphere and order_mode != 1 and (n >= 3_000_000 or order_mode == 2)  # the library's rule (ctx.h, Cells::min_rows)
 
     def step(f):
         ctx.propagate(0)
@@ -105,4 +108,32 @@ def build_flat_static(ctx, args):
     if args.row_summary == 0:  # the sphere path reads flags + layers per row (5 B), the resident-G path Aabb as well
         wl.layout_bytes_per_row = wl.bytes_per_row - ((5.0 - 0.5) if sphere else ROW_SUMMARY_SAVES)
     config["row_summary"] = args.row_summary == 0
+    config["static_cull_order"] = cells
+    if n != 1_000_000 or n_views != 1:  # (the committed rocprofv3 evidence is filed per command: bench.py names this one in OTHER_WORKLOADS)
+        wl.profile_key = f"flat_static_{n // 1_000_000}m_{n_views}views"
+    if cells:
+        # The static cull order (kernels_cells.hip): from the fourth quiet frame on a frame is four short launches over the cell-ordered
+        # copy -- k_cells_test (a thread per cell of 64 slots: 36 B), k_frame_cells (a wave per cell that is left: 73 B per slot --
+        # row 4, ViewVisibility 1, sphere 16, last frame's bits 4, GlobalTransform 48 -- and a handful of atomics for the bits that
+        # changed), k_cells_blocks + k_cells_lists (masks -> lists and the next frame's masks).  What they move depends on what the
+        # views see; warm frames are run here to count it.  Cells that straddle a frustum border make the processed slots about 1.2 x
+        # the visible rows.
+        for f in range(6):
+            step(f)
+        ctx.synchronize()
+        builds, order_frames = ctx.debug_static_cull_counts()
+        vis_rows = int(np.count_nonzero(ctx.download_view_visibility()[0] & 1))
+        vis_total = sum(int(len(ctx.download_visible_entities(v, 0)[1])) for v in range(n_views))
+        processed = min(float(n), 1.2 * vis_rows)
+        mask_bytes = n / 64.0 * 8.0 * n_views
+        frame_kernel = processed * 73.0 + processed / 64.0 * 16.0
+        whole_frame = n / 64.0 * 36.0 + frame_kernel + 3.0 * mask_bytes + 4.0 * vis_total
+        config["workload"] = config["workload"].replace("mi_cull (", "mi_cull over the static cull order (k_cells_test + k_frame_cells + k_cells_blocks + k_cells_lists: 64 "
+                                                        "spatial neighbours per cell, whole cells rejected against each view first; without it: ")
+        config["static_cull_order_state"] = {"orders_built": builds, "frames_over_it": order_frames, "rows_visible_in_some_view": vis_rows,
+                                             "visible_list_entries": vis_total, "estimated_bytes_k_frame_cells": int(frame_kernel),
+                                             "estimated_bytes_whole_frame": int(whole_frame)}
+        wl.kernel_name = "k_frame_cells<true>" if n_views <= 8 else "k_frame_cells<false>"
+        wl.kernels = ["k_cull", "k_compact_fast", "k_vis_begin", "k_compact_count"]  # timer slots: frame, lists, cell test, blocks
+        wl.layout_bytes_per_row = min(wl.bytes_per_row, frame_kernel / n)
     return wl

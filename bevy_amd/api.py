@@ -204,7 +204,7 @@ ABI_SYMBOLS = [
 # include/bevy_mi355x_debug.h: instrumentation and test hooks, exported by the same library, not part of the boundary
 DEBUG_SYMBOLS = [
     "mi_timer_begin", "mi_timer_end", "mi_profile_enable", "mi_profile_filter", "mi_profile_sample", "mi_profile_burst", "mi_profile_read",
-    "mi_profile_kernel_name", "mi_debug_set_tile_mode", "mi_debug_tree_trace", "mi_debug_tile_plan", "mi_debug_logf", "mi_debug_set_sphere_path", "mi_debug_set_row_summary", "mi_debug_set_tree_cull", "mi_debug_set_walk_inrow", "mi_debug_set_chunked_frames", "mi_debug_chunked_counts", "mi_debug_set_tile_pretest", "mi_debug_set_sorted_one_wg_limit",
+    "mi_profile_kernel_name", "mi_debug_set_tile_mode", "mi_debug_tree_trace", "mi_debug_tile_plan", "mi_debug_logf", "mi_debug_set_sphere_path", "mi_debug_set_row_summary", "mi_debug_set_tree_cull", "mi_debug_set_walk_inrow", "mi_debug_set_chunked_frames", "mi_debug_chunked_counts", "mi_debug_set_tile_pretest", "mi_debug_set_sorted_one_wg_limit", "mi_debug_set_static_cull_order", "mi_debug_static_cull_counts",
 ]
 
 
@@ -385,6 +385,8 @@ class Context:
             self.debug_set_row_summary(int(os.environ["MI_TEST_ROW_SUMMARY"]))
         if os.environ.get("MI_TEST_SPHERE_PATH"):  # ... or with the world-sphere cull path forced on (2) / off (1)
             self.debug_set_sphere_path(int(os.environ["MI_TEST_SPHERE_PATH"]))
+        if os.environ.get("MI_TEST_STATIC_CULL_ORDER"):
+            self.debug_set_static_cull_order(int(os.environ["MI_TEST_STATIC_CULL_ORDER"]))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -885,6 +887,16 @@ class Context:
         """0 = 64 aligned rows that agree in Aabb / flags / RenderLayers read a 32-byte summary instead of their columns (default),
         1 = off (test / bench hook; results are identical)."""
         self._ck(self._lib.mi_debug_set_row_summary(self._h, int(mode)))
+
+    def debug_set_static_cull_order(self, mode):
+        """0 = cull-only frames of a static scene run over the cell order from the second eligible frame on (default), 1 = never, 2 = at once, any row count."""
+        self._ck(self._lib.mi_debug_set_static_cull_order(self._h, int(mode)))
+
+    def debug_static_cull_counts(self):
+        """(cell orders built, frames that ran over one)."""
+        a, b = C.c_uint32(0), C.c_uint32(0)
+        self._ck(self._lib.mi_debug_static_cull_counts(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def debug_set_sphere_path(self, mode):
         """0 = the world-sphere cull path from the second quiet frame on (default), 1 = never, 2 = at once (test / bench hook)."""

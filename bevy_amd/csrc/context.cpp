@@ -212,6 +212,8 @@ Columns columns_of(mi_ctx* ctx) {
 
 void row_summary_touch(mi_ctx* ctx, uint32_t parts, uint32_t first_row, uint32_t n_rows) {
     if (n_rows == 0) return;
+    ctx->cells.valid = false;  // (the static cull order copies flags / RenderLayers / half extents per cell)
+    ctx->cells.quiet = 0;
     const uint32_t lo = first_row >> 6, hi = (uint32_t)(((uint64_t)first_row + n_rows + 63u) >> 6);
     for (uint32_t p = 0; p < 2u; ++p) {
         if (!(parts & (1u << p))) continue;
@@ -361,6 +363,9 @@ int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg, 
         f.bitmask = vo.bitmask;
         f.words_per_view = vo.words_per_view;
         f.word_offset = vo.word_offset;
+        f.blk_base = seg.blk_base;
+        f.n_blks = seg.n_blks;
+        f.steps = seg.blk_base ? 1u : 0u;
         ctx->seg_stride = ctx->cap;
         if ((rc = ensure(ctx, ctx->fb[ctx->cur].out_rows, segs * ctx->seg_stride * 4))) return rc;
         f.out_rows = (uint32_t*)ctx->fb[ctx->cur].out_rows.p;
@@ -470,6 +475,231 @@ int32_t compaction_join(mi_ctx* ctx) {
 
 }  // namespace mi_detail
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Frames that OR their results in with atomics (the fused hierarchy frame, the static cull order): this frame's set of masks / wave
+// counts and the ViewVisibility change words must be zero on entry.  They are when the previous such frame's launch zeroed them
+// (fb_zero_taken / vv_alt_zeroed); else three memsets go in front.  zero[] / zero_words[] name the NEXT frame's set (same shape) for
+// this frame's launch to clear; *zn is what to store in fb_zero[next] once that launch is enqueued (atomic_frame_sets_done).
+// ---------------------------------------------------------------------------------------------------------------------------------
+static int32_t atomic_frame_sets(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg, uint32_t n_views, uint64_t* zero[3], uint32_t zero_words[3],
+                                 mi_ctx::FbZero* zn) {
+    const uint64_t bm_words = (uint64_t)n_views * vo.words_per_view, wc_bytes = seg.wave_cnt ? (uint64_t)n_views * seg.n_waves : 0;
+    const size_t vv_bytes = padded_words(ctx->cap) * 8 + 256;
+    const mi_ctx::FbZero& z = ctx->fb_zero_taken;
+    if (!(z.ok && z.bitmask == (void*)(vo.bitmask + vo.word_offset) && z.wave_cnt == (void*)seg.wave_cnt && z.bitmask_words == bm_words && z.wave_cnt_bytes == wc_bytes)) {
+        HIP_TRY(ctx, hipMemsetAsync(vo.bitmask + vo.word_offset, 0, bm_words * 8, ctx->stream));
+        if (seg.wave_cnt) HIP_TRY(ctx, hipMemsetAsync(seg.wave_cnt, 0, wc_bytes, ctx->stream));
+    }
+    // the ViewVisibility change ticks alternate between two buffers the same way
+    if (!ctx->vv_chg_alt) {
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->vv_chg_alt, vv_bytes));
+        ctx->vv_alt_zeroed = false;
+    }
+    if (ctx->vv_alt_zeroed) std::swap(ctx->vv_chg_bits, ctx->vv_chg_alt);
+    else HIP_TRY(ctx, hipMemsetAsync(ctx->vv_chg_bits, 0, padded_words(ctx->cap) * 8, ctx->stream));  // (the whole capacity: the row count may grow inside it)
+    ctx->vv_alt_zeroed = false;
+    // the next frame's set (same shape), zeroed by this frame's launch
+    const uint32_t nx = (ctx->cur + 1u) % mi_ctx::N_FB;
+    *zn = mi_ctx::FbZero{};
+    for (int k = 0; k < 3; ++k) zero[k] = nullptr, zero_words[k] = 0;
+    int32_t rc = MI_OK;
+    if (!ctx->ext_bitmask && !(rc = ensure(ctx, ctx->fb[nx].bitmask, bm_words * 8)) && (!wc_bytes || !(rc = ensure(ctx, ctx->fb[nx].wave_cnt, wc_bytes)))) {
+        zn->bitmask = ctx->fb[nx].bitmask.p;
+        zn->wave_cnt = wc_bytes ? ctx->fb[nx].wave_cnt.p : nullptr;
+        zn->bitmask_words = bm_words;
+        zn->wave_cnt_bytes = wc_bytes;
+        zero[0] = (uint64_t*)zn->bitmask;
+        zero_words[0] = (uint32_t)bm_words;
+        zero[1] = (uint64_t*)zn->wave_cnt;
+        zero_words[1] = (uint32_t)(wc_bytes / 8);  // (n_waves is a multiple of 64)
+        zero[2] = ctx->vv_chg_alt;
+        zero_words[2] = (uint32_t)padded_words(ctx->cap);
+    }
+    return rc;
+}
+static void atomic_frame_sets_done(mi_ctx* ctx, bool zeroed_next, mi_ctx::FbZero zn) {
+    if (!zeroed_next) return;
+    zn.ok = true;
+    ctx->fb_zero[(ctx->cur + 1u) % mi_ctx::N_FB] = zn;
+    ctx->vv_alt_zeroed = true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The static cull order (kernels_cells.hip): which frames take it, its build, the frame.
+// Eligible: a cull-only frame that is the whole visibility frame (MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME) of camera views, on a context
+// whose world-sphere column is current for every row (no GlobalTransform or bound changed since a k_frame_sph frame refreshed it),
+// with nothing that wants the frame kernels' own by-products: no VisibilityClass segments, no visibility ranges, library-owned masks,
+// no exchange, no cluster assignment in the call.  The SECOND such frame in a row builds the order (a scene that stops for one frame
+// does not pay for it); every frame that takes another kernel, and every write to ViewVisibility / flags / bounds, drops it.
+// ---------------------------------------------------------------------------------------------------------------------------------
+static bool cells_frame_eligible(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint32_t flags, bool* build) {
+    auto& ce = ctx->cells;
+    *build = false;
+    bool ok = views && n_views && n_views <= SPH_MAX_VIEWS && ce.mode != 1 && ctx->sph_mode != 1 && ctx->n &&
+              ctx->n >= (ce.mode == 2 ? 1u : ce.min_rows) && (flags & (MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME)) == (MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME) &&
+              !(flags & (MI_CULL_WITH_CLUSTERS | MI_CULL_CHANGED_ROWS)) && !ctx->have_class_mask && !ctx->have_ranges && !ctx->ext_bitmask && !ctx->xch.on &&
+              ctx->sph_state == mi_ctx::SPH_VALID && ctx->sph.p && !ctx->tree_trace.p;
+    for (uint32_t v = 0; ok && v < n_views; ++v) ok = !(views[v].flags & MI_VIEW_FLAG_SHADOW);
+    if (!ok) {
+        ce.quiet = 0;
+        return false;
+    }
+    if (ce.valid) return true;
+    if (ce.mode == 2 || ++ce.quiet >= 2u) {
+        *build = true;
+        return true;
+    }
+    return false;
+}
+
+static int32_t cells_build(mi_ctx* ctx) {
+    auto& ce = ctx->cells;
+    const uint32_t n = ctx->n, n_waves = (uint32_t)words64(n);
+    const size_t slots = (size_t)n_waves * 64;
+    int32_t rc;
+    if ((rc = ensure(ctx, ce.perm, slots * 4)) || (rc = ensure(ctx, ce.sph_s, slots * 16)) || (rc = ensure(ctx, ce.g_s, slots * 48)) ||
+        (rc = ensure(ctx, ce.vv_s, slots)) || (rc = ensure(ctx, ce.sum_a, (size_t)n_waves * 16)) || (rc = ensure(ctx, ce.sum_b, (size_t)n_waves * 16)) ||
+        (rc = ensure(ctx, ce.sum_h, (size_t)n_waves * 16)) || (rc = ensure(ctx, ce.state, (size_t)n_waves * 4)) || (rc = ensure(ctx, ce.keys_a, (size_t)n * 4)) ||
+        (rc = ensure(ctx, ce.keys_b, (size_t)n * 4)) || (rc = ensure(ctx, ce.vals_a, (size_t)n * 4)) || (rc = ensure(ctx, ce.vals_b, (size_t)n * 4)) ||
+        (rc = ensure(ctx, ce.minmax, 64)) || (rc = ensure(ctx, ce.work, (size_t)n_waves * 16)) || (rc = ensure(ctx, ce.work_n, 64)) ||
+        (rc = ensure(ctx, ce.pass_s, slots * 4)))
+        return rc;
+    HIP_TRY(ctx, hipMemsetAsync(ce.work_n.p, 0, 64, ctx->stream));
+    ce.work_parity = 0;
+    ce.chain_ok = false;  // (the order's pass_s is all zero: its first frame starts from zeroed masks)
+    const size_t tmp = cells_sort_temp_bytes(n);
+    if ((rc = ensure(ctx, ce.sort_tmp, tmp ? tmp : 16))) return rc;
+    CellsOrder o{n_waves, (uint32_t*)ce.perm.p, (float4*)ce.sph_s.p, (float*)ce.g_s.p, (uint8_t*)ce.vv_s.p, (uint32_t*)ce.pass_s.p, (float4*)ce.sum_a.p,
+                 (uint4*)ce.sum_b.p, (float4*)ce.sum_h.p, (uint32_t*)ce.state.p};
+    const Columns c = columns_of(ctx);
+    HIP_TRY(ctx, launch_cells_build(c, (const float*)ctx->sph.p, o, (uint32_t*)ce.minmax.p, (uint32_t*)ce.keys_a.p, (uint32_t*)ce.keys_b.p,
+                                    (uint32_t*)ce.vals_a.p, (uint32_t*)ce.vals_b.p, ce.sort_tmp.p, tmp, ctx->stream));
+    ce.n_waves = n_waves;
+    ce.valid = true;
+    ce.quiet = 0;
+    ++ce.builds;
+    return MI_OK;
+}
+
+static int32_t cells_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint32_t flags, bool build) {
+    auto& ce = ctx->cells;
+    VisibilityOut vo{};
+    CompactFastArgs prev_args{};
+    bool prev_has_job = false;
+    mi_ctx::Exchange::Job prev_job{};
+    const CompactFastArgs* prev = frame_begin(ctx, &prev_args, &prev_has_job, &prev_job) ? &prev_args : nullptr;
+    int32_t rc = exchange_begin(ctx);
+    if (rc) return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
+    if ((rc = prepare_views(ctx, views, n_views, &vo))) return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
+    SegOut seg;
+    if ((rc = prepare_segments(ctx, n_views, &seg))) return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
+    if (build && (rc = cells_build(ctx))) {
+        ce.valid = false;
+        return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
+    }
+    // ---- this frame's masks: the frame before's (its k_cells_counts copied them into this set) -- or zero ----
+    const uint64_t bm_words = (uint64_t)n_views * vo.words_per_view;
+    const bool chained = ce.chain_ok && ce.chain_mask == (const void*)(vo.bitmask + vo.word_offset) && ce.chain_words == bm_words && ce.chain_views == n_views;
+    ce.chain_ok = false;
+    if (!chained) {
+        if (!build && ce.frames) {  // pass_s describes masks this frame does not continue (another number of views, a frame in between whose
+            // counts never ran): start over on a fresh order
+            if ((rc = cells_build(ctx))) {
+                ce.valid = false;
+                return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
+            }
+        }
+        HIP_TRY(ctx, hipMemsetAsync(vo.bitmask + vo.word_offset, 0, bm_words * 8, ctx->stream));
+    }
+    // the ViewVisibility change ticks are ORed into a zeroed buffer: two alternate, each launch zeroes the other one (as in the fused
+    // hierarchy frame, atomic_frame_sets)
+    CellsZero cz{};
+    {
+        const size_t vv_bytes = padded_words(ctx->cap) * 8 + 256;
+        if (!ctx->vv_chg_alt) {
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->vv_chg_alt, vv_bytes));
+            ctx->vv_alt_zeroed = false;
+        }
+        if (ctx->vv_alt_zeroed) std::swap(ctx->vv_chg_bits, ctx->vv_chg_alt);
+        else HIP_TRY(ctx, hipMemsetAsync(ctx->vv_chg_bits, 0, padded_words(ctx->cap) * 8, ctx->stream));
+        ctx->vv_alt_zeroed = false;
+        cz.zero[2] = ctx->vv_chg_alt;
+        cz.zero_words[2] = (uint32_t)padded_words(ctx->cap);
+    }
+    ClusterFillJob fill_job{};
+    const bool have_fill = ctx->cl_fill_pending && ctx->n;  // a deferred cluster fill of the previous frame rides along
+    if (have_fill) {
+        fill_job = ctx->cl_fill_job;
+        ctx->cl_fill_pending = false;
+    }
+    CellsOrder o{ce.n_waves, (uint32_t*)ce.perm.p, (float4*)ce.sph_s.p, (float*)ce.g_s.p, (uint8_t*)ce.vv_s.p, (uint32_t*)ce.pass_s.p, (float4*)ce.sum_a.p,
+                 (uint4*)ce.sum_b.p, (float4*)ce.sum_h.p, (uint32_t*)ce.state.p};
+    const Columns c = columns_of(ctx);
+    const CellsWork work{(uint4*)ce.work.p, (uint32_t*)ce.work_n.p + ce.work_parity, (uint32_t*)ce.work_n.p + (ce.work_parity ^ 1u), chained ? 0u : 1u};
+    {
+        hipError_t e;
+        {
+            ProfScope ps(ctx, K_VIS_BEGIN);  // (timer slot of the cell test: the frame's first launch)
+            e = launch_cells_test(o, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p, n_views, cz, work, ctx->stream);
+        }
+        if (e == hipSuccess) {
+            ProfScope ps(ctx, K_CULL);
+            e = launch_frame_cells(c, o, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p, n_views, vo, cz, work, prev,
+                                   have_fill ? &fill_job : nullptr, ctx->stream);
+        }
+        if (e != hipSuccess) {
+            if (have_fill) launch_cluster_fill(fill_job.w, fill_job.n_clusters, fill_job.n_objects, ctx->stream);
+            ce.valid = false;
+            fail(ctx, MI_ERR_DEVICE, "frame kernel launch: %s", hipGetErrorString(e));
+            return frame_abort(ctx, MI_ERR_DEVICE, prev, prev_has_job, prev_job);
+        }
+    }
+    ce.work_parity ^= 1u;
+    ctx->vv_alt_zeroed = true;
+    ++ce.frames;
+    ++ctx->sph_quiet;
+    // ---- behind the frame: the lists and the next frame's starting masks, one launch over the finished masks ----
+    {
+        const uint32_t nx = (ctx->cur + 1u) % mi_ctx::N_FB;
+        const size_t segs = (size_t)n_views * ctx->compact_classes;  // (one class segment per view: no class masks on this path)
+        if ((rc = ensure(ctx, ctx->fb[nx].bitmask, bm_words * 8)) || (rc = ensure(ctx, ctx->fb[ctx->cur].seg_totals, segs * 4))) {
+            ce.valid = false;
+            return rc;
+        }
+        CellsFinishArgs fin{};
+        fin.out = vo;
+        fin.n_words = (uint32_t)words64(ctx->n);
+        fin.n_blks = (fin.n_words + 63u) / 64u;
+        if ((rc = ensure(ctx, ce.fin_scratch, ((size_t)n_views * fin.n_blks + (size_t)n_views * CELLS_FIN_GROUPS) * 4))) {
+            ce.valid = false;
+            return rc;
+        }
+        fin.blk_pre = (uint32_t*)ce.fin_scratch.p;
+        fin.grp_tot = fin.blk_pre + (size_t)n_views * fin.n_blks;
+        fin.copy_to = (uint64_t*)ctx->fb[nx].bitmask.p;
+        fin.copy_words_per_view = vo.words_per_view;
+        if (ctx->compact_fast) {  // rows are numbered in Entity-key order: the lists come out of this launch (nothing is deferred)
+            ctx->seg_stride = ctx->cap;
+            if ((rc = ensure(ctx, ctx->fb[ctx->cur].out_rows, segs * ctx->seg_stride * 4))) {
+                ce.valid = false;
+                return rc;
+            }
+            fin.out_rows = (uint32_t*)ctx->fb[ctx->cur].out_rows.p;
+            fin.seg_stride = ctx->seg_stride;
+            fin.seg_totals = (uint32_t*)ctx->fb[ctx->cur].seg_totals.p;
+        }
+        HIP_TRY(ctx, launch_cells_finish(fin, n_views, ctx->stream, prof_mark, ctx));
+        ce.chain_ok = true;
+        ce.chain_mask = ctx->fb[nx].bitmask.p;
+        ce.chain_words = bm_words;
+        ce.chain_views = n_views;
+    }
+    if (prev_has_job) exchange_push(ctx, prev_job);
+    if (!ctx->compact_fast && (rc = run_compaction(ctx, vo, seg, flags))) return rc;  // (general compaction: reads the masks itself)
+    ctx->culled = true;
+    return exchange_end(ctx);
+}
+
 // The frame entry points share one body: PROPAGATE selects the fused flat kernel (mi_propagate_and_cull).
 template <bool PROPAGATE>
 static int32_t cull_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint32_t flags) {
@@ -479,6 +709,14 @@ static int32_t cull_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, u
         return fail(ctx, MI_ERR_INVALID_ARG, "MI_CULL_CHANGED_ROWS belongs to mi_propagate_and_cull (mi_cull does not propagate)");
     if ((flags & MI_CULL_WITH_CLUSTERS) && (!ctx->cl_rows_bound || !ctx->cl_have_view))
         return fail(ctx, MI_ERR_NOT_READY, "MI_CULL_WITH_CLUSTERS needs mi_cluster_bind_objects_to_rows and mi_cluster_upload_view first");
+    if (!PROPAGATE) {
+        // the cull-only frame of a scene that has gone static: over the cell order (cells_frame below) once there is one
+        bool build = false;
+        if (cells_frame_eligible(ctx, views, n_views, flags, &build)) return cells_frame(ctx, views, n_views, flags, build);
+    } else {
+        ctx->cells.quiet = 0;
+    }
+    ctx->cells.valid = false;  // (this frame's kernel writes ViewVisibility, and refreshes world spheres, behind the order's back)
     VisibilityOut vo{};
     CompactFastArgs prev_args{};
     bool prev_has_job = false;
@@ -757,6 +995,7 @@ int32_t mi_synchronize(mi_ctx* ctx) {
 // =============================================================================================
 int32_t mi_columns_resize(mi_ctx* ctx, uint32_t n_rows) {
     ENTER(ctx);
+    ctx->cells.valid = false, ctx->cells.quiet = 0;  // (the static cull order mirrors ViewVisibility and the row count)
     trs_written(ctx);
     ctx->gs_frame_ok = false;  // (rows come and go: what was written ahead for the last frame's rows is not handed out after this)
     {
@@ -1218,6 +1457,7 @@ int32_t mi_upload_render_layers_hi(mi_ctx* ctx, uint32_t first_row, uint32_t n, 
 
 int32_t mi_upload_view_visibility(mi_ctx* ctx, uint32_t first_row, uint32_t n, const uint8_t* vv) {
     ENTER(ctx);
+    ctx->cells.valid = false, ctx->cells.quiet = 0;  // (the static cull order mirrors ViewVisibility and the row count)
     if (!vv) return fail(ctx, MI_ERR_INVALID_ARG, "mi_upload_view_visibility: NULL");
     int32_t rc = check_rows(ctx, first_row, n, "mi_upload_view_visibility");
     if (rc) return rc;
@@ -1413,6 +1653,7 @@ int32_t mi_propagate(mi_ctx* ctx, uint32_t flags) {
 
 int32_t mi_visibility_begin_frame(mi_ctx* ctx) {
     ENTER(ctx);
+    ctx->cells.valid = false, ctx->cells.quiet = 0;  // (the static cull order mirrors ViewVisibility and the row count)
     ProfScope ps(ctx, K_VIS_BEGIN);
     HIP_TRY(ctx, launch_vis_begin(columns_of(ctx), ctx->stream));
     return MI_OK;
@@ -1420,6 +1661,7 @@ int32_t mi_visibility_begin_frame(mi_ctx* ctx) {
 
 int32_t mi_visibility_end_frame(mi_ctx* ctx) {
     ENTER(ctx);
+    ctx->cells.valid = false, ctx->cells.quiet = 0;  // (the static cull order mirrors ViewVisibility and the row count)
     ProfScope ps(ctx, K_VIS_END);
     HIP_TRY(ctx, launch_vis_end(columns_of(ctx), ctx->stream));
     return MI_OK;
@@ -1471,6 +1713,8 @@ static bool tree_frame_fusable(mi_ctx* ctx, uint32_t n_views, uint32_t flags) {
            !ctx->ext_bitmask && !ctx->xch.on && !ctx->tree_trace.p;
 }
 static int32_t tree_frame_fused(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint32_t flags) {
+    ctx->cells.valid = false;  // (the tiles write ViewVisibility)
+    ctx->cells.quiet = 0;
     VisibilityOut vo{};
     CompactFastArgs prev_args{};
     bool prev_has_job = false;
@@ -1490,42 +1734,13 @@ static int32_t tree_frame_fused(mi_ctx* ctx, const mi_view* views, uint32_t n_vi
     cu.out = vo;
     cu.wave_cnt = seg.wave_cnt;
     cu.n_waves = seg.n_waves;
-    const uint64_t bm_words = (uint64_t)n_views * vo.words_per_view, wc_bytes = seg.wave_cnt ? (uint64_t)n_views * seg.n_waves : 0;
-    const size_t vv_bytes = padded_words(ctx->cap) * 8 + 256;
-    // this frame's set: zeroed by the previous such frame's launch -- or here (the first frame of a run, a changed shape)
-    const mi_ctx::FbZero& z = ctx->fb_zero_taken;
-    if (!(z.ok && z.bitmask == (void*)(vo.bitmask + vo.word_offset) && z.wave_cnt == (void*)seg.wave_cnt && z.bitmask_words == bm_words && z.wave_cnt_bytes == wc_bytes)) {
-        HIP_TRY(ctx, hipMemsetAsync(vo.bitmask + vo.word_offset, 0, bm_words * 8, ctx->stream));
-        if (seg.wave_cnt) HIP_TRY(ctx, hipMemsetAsync(seg.wave_cnt, 0, wc_bytes, ctx->stream));
-    }
-    // the ViewVisibility change ticks alternate between two buffers the same way
-    if (!ctx->vv_chg_alt) {
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->vv_chg_alt, vv_bytes));
-        ctx->vv_alt_zeroed = false;
-    }
-    if (ctx->vv_alt_zeroed) std::swap(ctx->vv_chg_bits, ctx->vv_chg_alt);
-    else HIP_TRY(ctx, hipMemsetAsync(ctx->vv_chg_bits, 0, padded_words(ctx->cap) * 8, ctx->stream));  // (the whole capacity: the row count may grow inside it)
-    ctx->vv_alt_zeroed = false;
-    // the next frame's set (same shape), zeroed by this frame's tiles
-    const uint32_t nx = (ctx->cur + 1u) % mi_ctx::N_FB;
     mi_ctx::FbZero zn;
-    if (!ctx->ext_bitmask && !(rc = ensure(ctx, ctx->fb[nx].bitmask, bm_words * 8)) && (!wc_bytes || !(rc = ensure(ctx, ctx->fb[nx].wave_cnt, wc_bytes)))) {
-        zn.bitmask = ctx->fb[nx].bitmask.p;
-        zn.wave_cnt = wc_bytes ? ctx->fb[nx].wave_cnt.p : nullptr;
-        zn.bitmask_words = bm_words;
-        zn.wave_cnt_bytes = wc_bytes;
-        cu.zero[0] = (uint64_t*)zn.bitmask;
-        cu.zero_words[0] = (uint32_t)bm_words;
-        cu.zero[1] = (uint64_t*)zn.wave_cnt;
-        cu.zero_words[1] = (uint32_t)(wc_bytes / 8);  // (n_waves is a multiple of 64)
-        cu.zero[2] = ctx->vv_chg_alt;
-        cu.zero_words[2] = (uint32_t)padded_words(ctx->cap);
-    }
+    rc = atomic_frame_sets(ctx, vo, seg, n_views, cu.zero, cu.zero_words, &zn);
     if (rc) return frame_abort(ctx, rc, prev, false, prev_job);
     // the previous frame's deferred compaction rides in the (first) tile launch
     if (prev && prev->n && prev->n_segments) {
         cu.prev = *prev;
-        cu.prev_gx = (((prev->n + 63u) >> 6) + 64u * compact_fast_steps_host(prev->n) - 1u) / (64u * compact_fast_steps_host(prev->n));
+        cu.prev_gx = (((prev->n + 63u) >> 6) + 64u * compact_fast_steps_of(*prev) - 1u) / (64u * compact_fast_steps_of(*prev));
         cu.n_compact = cu.prev_gx * prev->n_segments;
     } else {
         cu.prev_gx = 1;
@@ -1537,11 +1752,7 @@ static int32_t tree_frame_fused(mi_ctx* ctx, const mi_view* views, uint32_t n_vi
         if (prev) launch_compact_fast(*prev, ctx->stream);
         return rc;
     }
-    if (cu.zero[0]) {
-        zn.ok = true;
-        ctx->fb_zero[nx] = zn;
-        ctx->vv_alt_zeroed = true;
-    }
+    atomic_frame_sets_done(ctx, cu.zero[0] != nullptr, zn);
     if ((rc = run_compaction(ctx, vo, seg, flags))) return rc;
     ctx->culled = true;
     return exchange_end(ctx);
@@ -2270,6 +2481,22 @@ int32_t mi_debug_set_sphere_path(mi_ctx* ctx, int32_t mode) {
     ENTER(ctx);
     if (mode < 0 || mode > 2) return fail(ctx, MI_ERR_INVALID_ARG, "mi_debug_set_sphere_path: mode %d", mode);
     ctx->sph_mode = mode;
+    return MI_OK;
+}
+
+// test / bench hook: the static cull order of cull-only frames (kernels_cells.hip): 0 = built by the second eligible frame in a row of a
+// context with Cells::min_rows rows or more (default), 1 = never, 2 = at once, at any row count
+int32_t mi_debug_set_static_cull_order(mi_ctx* ctx, int32_t mode) {
+    ENTER(ctx);
+    if (mode < 0 || mode > 2) return fail(ctx, MI_ERR_INVALID_ARG, "mi_debug_set_static_cull_order: mode %d", mode);
+    ctx->cells.mode = mode;
+    if (mode == 1) ctx->cells.valid = false;
+    return MI_OK;
+}
+int32_t mi_debug_static_cull_counts(mi_ctx* ctx, uint32_t* out_builds, uint32_t* out_frames) {
+    ENTER_RAW(ctx);
+    if (out_builds) *out_builds = ctx->cells.builds;
+    if (out_frames) *out_frames = ctx->cells.frames;
     return MI_OK;
 }
 

@@ -127,6 +127,29 @@ struct mi_ctx {
     uint32_t sph_quiet = 0;  // cull frames since the last wholesale GlobalTransform rewrite (the column is rebuilt on the second)
     int32_t sph_mode = 0;    // mi_debug_set_sphere_path: 0 = as described, 1 = never, 2 = rebuild at once
 
+    // ---- static cull order (kernels_cells.hip; k_frame_cells): a cell-ordered copy of a scene that has gone static.  `valid` = the
+    // copies (world spheres, GlobalTransforms, ViewVisibility mirror, summaries) agree with the columns: cleared by whatever writes
+    // ViewVisibility other than k_frame_cells, by whatever writes flags / RenderLayers / bounds (row_summary_touch), by a resize, and by
+    // every frame that takes another kernel (any GlobalTransform change leaves sph_state != SPH_VALID, which sends the next frame
+    // there).  Built by the second eligible frame in a row that finds none (cells_frame_eligible, context.cpp).
+    struct Cells {
+        DevBuf perm, sph_s, g_s, vv_s, sum_a, sum_b, sum_h, state, keys_a, keys_b, vals_a, vals_b, sort_tmp, minmax;
+        DevBuf work, work_n;         // the frame's work list (k_cells_test -> k_frame_cells) and its two alternating counters
+        uint32_t work_parity = 0;
+        DevBuf pass_s, fin_scratch;  // per slot: its row's bits in the masks of the last frame over the order; k_cells_blocks' prefix / totals
+        // the frame that continues the one before: k_cells_counts copied that frame's masks into the set this frame writes
+        bool chain_ok = false;
+        const void* chain_mask = nullptr;
+        uint64_t chain_words = 0;
+        uint32_t chain_views = 0;
+        bool valid = false;
+        uint32_t n_waves = 0;
+        uint32_t quiet = 0;          // eligible frames in a row that found no valid order
+        int32_t mode = 0;            // mi_debug_set_static_cull_order: 0 = as described, 1 = never, 2 = at once and at any row count
+        uint32_t min_rows = 3000000; // the frame over the order is four short launches (~22 us at 1 M rows against k_frame_sph's 10; even at 4 M x 1 view, far ahead at 10 M)
+        uint32_t builds = 0, frames = 0;  // mi_debug_static_cull_counts
+    } cells;
+
     // ---- dense uploads in pieces, GlobalTransforms ahead of the frame (context.cpp: mi_commit_upload_window,
     //      mi_download_frame_results; profiles/r03_experiments.md 12) ----
     // A SEQUENCE is a run of dense windows that carries the whole flat table in ascending order: one window for every row (split
@@ -264,7 +287,7 @@ struct mi_ctx {
     uint64_t* vv_chg_alt = nullptr;  // second ViewVisibility change-tick buffer of those frames (they alternate); zeroed iff vv_alt_zeroed
     bool vv_alt_zeroed = false;
     struct FrameBufs {
-        DevBuf bitmask, wave_cnt, seg_mask, out_rows, seg_totals;
+        DevBuf bitmask, wave_cnt, seg_mask, out_rows, seg_totals, blk_cnt;
     } fb[N_FB];
     uint32_t cur = 0;  // set of the current / last frame
     struct DeferredCompaction {

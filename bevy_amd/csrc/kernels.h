@@ -154,6 +154,8 @@ struct SegOut {
     uint64_t* seg_mask;
     uint64_t seg_words;
     uint8_t class_bits[32];      // class bit of each class slot
+    uint32_t* blk_base;          // per segment and 64 words: the wave counts in front of them (CompactFastArgs::blk_base); nullptr = not kept
+    uint32_t n_blks;             // its stride per segment (= n_waves / 64)
 };
 
 // mi_cull / mi_propagate_and_cull flags (MI_CULL_* in the public header)
@@ -209,7 +211,18 @@ struct CompactFastArgs {
     // per frame: it keeps the next frame kernel from starting behind the compaction).
     uint32_t* signal;
     uint32_t signal_value;
+    // optional: per segment and 64 words (4 096 rows) the sum of the wave counts IN FRONT of them.  A compaction workgroup starts at a
+    // multiple of 64 words, so its base is one load instead of a sum over every wave count in front of it (at 10 M rows x 4 views the
+    // workgroups together read 77 MB of counts otherwise).  Written by the launches that have it cheaply (k_cells_counts).
+    const uint32_t* blk_base;
+    uint32_t n_blks;  // stride per segment
+    // 64-word steps per compaction workgroup: compact_fast_steps(n) when every workgroup sums the wave counts in front of it (fewer,
+    // longer workgroups read fewer counts), 1 with blk_base (the steps of a workgroup run one after the other, ~3 us each: ten of them
+    // were 33 us of every frame at 10 M rows).  0 = compact_fast_steps(n).
+    uint32_t steps;
 };
+inline uint32_t compact_fast_steps_host(uint32_t n) { return 1u + (n >> 20); }  // = compact_fast_steps (compact_fast.h)
+inline uint32_t compact_fast_steps_of(const CompactFastArgs& a) { return a.steps ? a.steps : compact_fast_steps_host(a.n); }
 hipError_t launch_flat_propagate_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views,
                                       uint32_t n_views, const VisibilityOut& out, const SegOut& seg, uint32_t flags,
                                       const CompactFastArgs* prev, const struct ClusterFillJob* fill, const struct ClusterWalkJob* walk,
@@ -232,6 +245,64 @@ hipError_t launch_frame_sph(const Columns& c, const ViewSet* views_inline, const
                             const struct ClusterWalkJob* walk, hipStream_t stream, const uint8_t* changed, float* sph, const uint64_t* stale_bits,
                             const uint8_t* stale_bytes, bool all_stale);
 constexpr uint32_t SPH_MAX_VIEWS = 32;
+
+// ---- the static cull order (kernels_cells.hip builds it, k_frame_cells in kernels_flat.hip uses it) ----
+// sum_b[w].x: low 8 bits = the flags byte where CELLS_UNIFORM_FLAGS, .y = the RenderLayers mask (layers 0..31) then
+constexpr uint32_t CELLS_UNIFORM_FLAGS = 0x100u;  // the wave's slots agree in flags and RenderLayers (and none has a layer above 31)
+constexpr uint32_t CELLS_UNIFORM_HALF = 0x200u;   // ... in their Aabb half extents (sum_h)
+constexpr uint32_t CELLS_REJECTABLE = 0x400u;     // every slot: in the cull query, bounded, no NoFrustumCulling
+struct CellsOrder {
+    uint32_t n_waves;      // ceil(n / 64)
+    uint32_t* perm;        // [n_waves * 64] row of each slot, 0xFFFFFFFF past the last
+    float4* sph_s;         // [n_waves * 64] world spheres in slot order
+    float* g_s;            // [n_waves * 64 * 12] GlobalTransforms in slot order
+    uint8_t* vv_s;         // [n_waves * 64] ViewVisibility bytes in slot order (mirror of the column while the order is valid)
+    uint32_t* pass_s;      // [n_waves * 64] bit v: the slot's row is set in view v's mask of the last frame over the order
+    float4* sum_a;         // [n_waves] bounding sphere of the wave's world spheres (centre, radius rounded up)
+    uint4* sum_b;          // [n_waves] bits | flags, RenderLayers
+    float4* sum_h;         // [n_waves] half extents where uniform
+    uint32_t* state;       // [n_waves] bit 0: every ViewVisibility byte of the wave is zero
+};
+size_t cells_sort_temp_bytes(uint32_t n);
+// sph: the world-sphere column [n], current for every row.  keys / vals: [n] each; minmax: 6 words.
+hipError_t launch_cells_build(const Columns& c, const float* sph, const CellsOrder& o, uint32_t* minmax, uint32_t* keys_a, uint32_t* keys_b,
+                              uint32_t* vals_a, uint32_t* vals_b, void* sort_temp, size_t sort_temp_bytes, hipStream_t stream);
+// The cull-only frame of a static scene over the cell order: camera views, MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME, one class segment
+// per view, no visibility ranges.  Masks, wave counts and the ViewVisibility change words are ORed / added with atomics into memory
+// that is zero on entry; zero[k] / zero_words[k] = what the launch zeroes for the NEXT such frame (as TreeCull::zero).
+struct CellsZero {
+    uint64_t* zero[3];
+    uint32_t zero_words[3];
+};
+// behind the frame (k_cells_blocks + k_cells_lists): from the finished masks, the VisibleEntities row lists (one class segment per
+// view) and the masks copied into the set the next frame writes
+constexpr uint32_t CELLS_FIN_GROUPS = 256;
+struct CellsFinishArgs {
+    VisibilityOut out;
+    uint32_t n_words, n_blks;          // mask words per view in use; 64-word blocks ((n_words + 63) / 64)
+    uint32_t blks_per, n_groups;       // blocks per run, runs (set by the launch)
+    uint32_t* blk_pre;                 // [views][n_blks] scratch: a block's exclusive prefix inside its run
+    uint32_t* grp_tot;                 // [views][CELLS_FIN_GROUPS] scratch: the runs' totals
+    uint64_t* copy_to;                 // the next frame's mask set, or nullptr
+    uint64_t copy_words_per_view;
+    uint32_t* out_rows;                // [views][seg_stride] the lists, or nullptr = copy only
+    uint64_t seg_stride;
+    uint32_t* seg_totals;              // [views]
+};
+hipError_t launch_cells_finish(const CellsFinishArgs& f, uint32_t n_views, hipStream_t stream, void (*mark)(void*, uint32_t), void* mark_ctx);
+// the work list between the two launches of the frame: list[n_cells] (cell, views left, summary bits | flags, RenderLayers), its counter
+// and the next frame's counter
+struct CellsWork {
+    uint4* list;
+    uint32_t *n, *n_next;
+    uint32_t fresh;  // this frame's masks start from zero (else: from the frame before's, and only changed bits are touched)
+};
+constexpr uint32_t CELLS_MAX_TILES = 8192;
+hipError_t launch_cells_test(const CellsOrder& o, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views, const CellsZero& z,
+                             const CellsWork& work, hipStream_t stream);
+hipError_t launch_frame_cells(const Columns& c, const CellsOrder& o, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views,
+                              const VisibilityOut& out, const CellsZero& z, const CellsWork& work, const CompactFastArgs* prev,
+                              const struct ClusterFillJob* fill, hipStream_t stream);
 hipError_t launch_row_summary(const Columns& c, uint32_t first_wave, uint32_t n_waves, uint32_t parts, uint32_t* summary, hipStream_t stream);
 hipError_t launch_upload_trs(const float* pinned_src, float* t, float* r, float* s, uint32_t first_row, uint32_t n,
                              hipStream_t stream);
@@ -360,7 +431,6 @@ hipError_t launch_mark_dirty(uint32_t n, const uint8_t* changed, uint32_t change
 // The hierarchy FRAME in the tile launch itself (k_propagate_fans<true, true>): every tile also runs the visibility systems over
 // its own rows, GlobalTransforms still in registers / LDS.  A tile's rows are not aligned to the 64-row words of the per-view masks,
 // so the words are ORed and the wave counts added with atomics into memory the host zeroed before the launch.
-inline uint32_t compact_fast_steps_host(uint32_t n) { return 1u + (n >> 20); }  // = compact_fast_steps (compact_fast.h)
 struct TreeCull {
     ViewSet views;
     uint32_t n_views;

@@ -582,6 +582,253 @@ __global__ void __launch_bounds__(256) k_frame_sph(Columns c, ViewSet vs, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// The cull-only frame of a STATIC scene over the cell order (kernels_cells.hip holds the build and the rationale).
+// A wave owns 64 slots of the order.  (1) Its bounding sphere against each view's five planes: a view is dropped for the whole wave
+// when the sphere lies behind one of them by more than a margin that bounds every rounding error of the per-row test -- so the rows'
+// own tests (Frustum::intersects_sphere, visibility/mod.rs:829-832) would all say "outside" -- and only if every slot is subject to
+// that test (CELLS_REJECTABLE) and the view culls at all.  The wave test never ACCEPTS anything.  (2) A wave with no view left and
+// no ViewVisibility byte set has nothing to read, nothing to write: it ends after 36 bytes.  (3) Everybody else runs k_frame_sph's
+// rule per slot -- sphere test on the slot-ordered spheres, then intersects_obb (:833-836) for the survivors on the slot-ordered
+// GlobalTransforms, both fully coalesced because a wave's slots are neighbours in space AND in memory -- for the views that are left.
+// Results go out BY ROW: mask bits and wave counts with atomics into memory the launch before zeroed (as the fused hierarchy frame
+// does, kernels_tree.hip), the ViewVisibility byte to the column and to its slot-ordered mirror.
+// Same bits as k_frame / k_frame_sph by construction; tests/test_gpu_cells.py and the differential sequences compare them.
+// ---------------------------------------------------------------------------------------------
+struct CellsFrameArgs {
+    CellsOrder o;
+    CellsZero z;
+    uint4* work;             // [n_waves] (cell, views left, summary bits | flags, RenderLayers) of the cells k_cells_test leaves for k_frame_cells
+    uint32_t* work_n;        // how many (this frame's counter)
+    uint32_t* work_n_next;   // the next frame's counter: zeroed by k_frame_cells
+    uint32_t fresh;          // the masks start from zero: no slot has contributed to them yet (pass_s is not read)
+};
+// margin of the wave test: the row test evaluates dot4(plane, (c_i, 1)) + r_i in f32, at most a few ulp (2^-24 relative) of the
+// largest term away from the real value; the bounding sphere bounds the real value from above.  1e-5 of the terms' magnitudes is
+// some twenty times that.
+__device__ __forceinline__ bool cells_sphere_behind_plane(const float* pl, float cx, float cy, float cz, float R) {
+    const float tx = pl[0] * cx, ty = pl[1] * cy, tz = pl[2] * cz;
+    const float s = tx + ty + tz + pl[3] + R;
+    const float margin = 1e-5f * (fabsf(tx) + fabsf(ty) + fabsf(tz) + fabsf(pl[3]) + R) + 1e-30f;
+    return s < -margin;  // (NaN anywhere: false -- not rejected)
+}
+// One cell (64 slots of the order) with the views `view_in` leaves it: k_frame_sph's rule per slot, results by row.  Every lane of the
+// wave calls it with the same w / view_in / st / sb.
+template <bool INLINE_VIEWS>
+__device__ __forceinline__ void cells_process(const Columns& c, const ViewSet& vs, const ViewParams* __restrict__ dviews, uint32_t n_views,
+                                              const VisibilityOut& out, const CellsFrameArgs& a, uint32_t w, uint32_t view_in, uint32_t st, uint4 sb,
+                                              float4* lds_wave, uint32_t lane) {
+    // ---- (3) per slot ----
+    const uint32_t slot = w * 64u + lane;
+    const uint32_t row = a.o.perm[slot];
+    const bool live = row != 0xFFFFFFFFu;
+    const uint32_t rrow = live ? row : 0u;
+    const uint32_t vv0 = a.o.vv_s[slot];
+    uint32_t pass = 0u;
+    uint32_t fl = sb.x & 0xFFu, emask = sb.y, emask_hi = 0u;
+    if (!(sb.x & CELLS_UNIFORM_FLAGS)) {  // (wave-uniform)
+        fl = c.flags[rrow];
+        emask = c.layer_mask[rrow];
+        if (c.layer_mask_hi) emask_hi = c.layer_mask_hi[rrow];
+    }
+    if (!live) fl = 0u;
+    const bool ncc = (fl & 0x10u) != 0;
+    if (view_in) {  // (wave-uniform)
+        const float4 sp = a.o.sph_s[slot];
+        const bool has_aabb = (fl & 0x04u) != 0;
+        const bool base_ok = live && !ncc && (fl & 0x01u) != 0;                // InheritedVisibility
+        const bool bounded = (fl & (0x04u | 0x08u)) != 0 && !(fl & 0x02u);     // has an Aabb or a Sphere, and no NoFrustumCulling
+        const V4 c4 = V4{sp.x, sp.y, sp.z, 1.0f};
+        const float sr = sp.w;
+        uint32_t need = 0u;
+        for (uint32_t v = 0; v < n_views; ++v) {
+            if (!((view_in >> v) & 1u)) continue;  // (wave-uniform: dropped for the whole wave)
+            const ViewParams& vp = INLINE_VIEWS ? vs.v[v] : dviews[v];
+            bool vis = base_ok && ((vp.layer_mask & emask) | (vp.layer_mask_hi & emask_hi)) != 0;
+            const bool cull = bounded && !(vp.flags & VIEW_NO_CPU_CULLING);
+            const bool inside = sphere_inside_five_planes(vp.planes, c4, sr);
+            vis = vis && (inside || !cull);
+            if (vis) pass |= 1u << v;
+            if (vis && cull && has_aabb) need |= 1u << v;
+        }
+        const unsigned long long need_m = __ballot(need != 0u);
+        if (need_m) {
+            Affine g = {};
+            const float4* src = reinterpret_cast<const float4*>(a.o.g_s) + 192ull * w;  // the wave's 64 GlobalTransforms: 3 KB, contiguous
+            if (__popcll(need_m) >= 16) {
+#pragma unroll
+                for (uint32_t k = 0; k < 3u; ++k) lds_wave[k * 64u + lane] = src[k * 64u + lane];
+                MI_WAVE_LDS_SYNC();
+                const float4 qa = lds_wave[lane * 3u], qb = lds_wave[lane * 3u + 1u], qc = lds_wave[lane * 3u + 2u];
+                g.m.x_axis = V3{qa.x, qa.y, qa.z};
+                g.m.y_axis = V3{qa.w, qb.x, qb.y};
+                g.m.z_axis = V3{qb.z, qb.w, qc.x};
+                g.t = V3{qc.y, qc.z, qc.w};
+            } else if (need) {
+                const float4 qa = src[lane * 3u], qb = src[lane * 3u + 1u], qc = src[lane * 3u + 2u];
+                g.m.x_axis = V3{qa.x, qa.y, qa.z};
+                g.m.y_axis = V3{qa.w, qb.x, qb.y};
+                g.m.z_axis = V3{qb.z, qb.w, qc.x};
+                g.t = V3{qc.y, qc.z, qc.w};
+            }
+            if (need) {
+                V3 half;
+                if (sb.x & CELLS_UNIFORM_HALF) {
+                    const float4 h4 = a.o.sum_h[w];
+                    half = V3{h4.x, h4.y, h4.z};
+                } else {
+                    half = ld3(c.aabb_half, row);
+                }
+                for (uint32_t v = 0; v < n_views; ++v) {
+                    if (!((need >> v) & 1u)) continue;
+                    const ViewParams& vp = INLINE_VIEWS ? vs.v[v] : dviews[v];
+                    bool inside = true;
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) {
+                        const V4 pl = V4{vp.planes[4 * i], vp.planes[4 * i + 1], vp.planes[4 * i + 2], vp.planes[4 * i + 3]};
+                        inside = inside && !(dot4(pl, c4) + aabb_relative_radius(half, xyz(pl), g.m) <= 0.0f);
+                    }
+                    if (!inside) pass &= ~(1u << v);
+                }
+            }
+        }
+    }
+    // ---- the ViewVisibility byte (reset, set_visible, gpu-culling rows, mark_newly_hidden: view_visibility_tail with both frame
+    //      flags) -- to the column and to the mirror ----
+    uint32_t cur = vv0;
+    bool vv_changed = false;
+    if (live) {
+        if (!ncc) cur = (cur & 1u) << 1;
+        if (pass && !(cur & 1u)) {
+            vv_changed = !(cur & 2u);
+            cur |= 1u;
+        }
+        if (ncc) {
+            const uint32_t nv = (fl & 0x01u) ? 3u : 0u;
+            if (nv != cur) { cur = nv; vv_changed = true; }
+        } else if ((cur & 3u) == 2u) {
+            cur = 0u;
+            vv_changed = true;
+        }
+        if (cur != vv0) {
+            c.view_visibility[row] = (uint8_t)cur;
+            a.o.vv_s[slot] = (uint8_t)cur;
+        }
+    }
+    const unsigned long long nz = __ballot(live && cur != 0u);
+    if (lane == 0u) {
+        const uint32_t ns = nz ? 0u : 1u;
+        if (ns != st) a.o.state[w] = ns;
+    }
+    // ---- results by row ----
+    // The masks of this frame start out as the masks of the frame before (k_cells_counts copied them over) and pass_s holds what each
+    // slot contributed to them: only the bits that CHANGE are touched -- a handful of rows per frame under a camera that turns slowly,
+    // none under one that stands still -- instead of one read-modify-write per visible row and view (2 M of them, 42 us, at 10 M rows x 4
+    // views; agent-scope atomics run at some 50 G/s however they are spread).  A frame that cannot continue the one before (a.fresh:
+    // the first over a new order, another shape) starts from zeroed masks and counts every slot's old contribution as nothing.
+    // (The wave counts are taken from the finished masks by k_cells_counts: added up here with atomics -- a byte per word, 64 words to
+    // a cache line -- the rows a view sees, neighbours in row order as well in many scenes, queued up on a dozen lines: 29 of 34 us at
+    // 1 M rows x 1 view.)
+    const uint32_t pass_prev = a.fresh ? 0u : a.o.pass_s[slot];
+    if (pass != pass_prev || a.fresh) a.o.pass_s[slot] = pass;
+    if (live) {
+        const uint32_t word = row >> 6;
+        const unsigned long long bit = 1ull << (row & 63u);
+        uint32_t delta = pass ^ pass_prev;
+        while (delta) {
+            const uint32_t v = (uint32_t)__ffs((int)delta) - 1u;
+            delta &= delta - 1u;
+            atomicXor(reinterpret_cast<unsigned long long*>(out.bitmask + (size_t)v * out.words_per_view + out.word_offset + word), bit);
+        }
+        if (vv_changed) atomicOr(reinterpret_cast<unsigned long long*>(c.vv_changed_bits + word), bit);
+    }
+}
+
+// The launches.  A wave per cell that tests a sphere and ends is the workgroup dispatcher's rate, not work (39 000 such workgroups
+// at 10 M rows), and every lane of it computes the same thing; a wave that takes many cells strided across the order keeps the
+// dispatcher idle but reads from all over memory (every load a TLB miss) and works its cells off one after the other.  So two launches:
+//   k_cells_test    a THREAD per cell: (1) and (2) of the description above -- 36 bytes, coalesced -- and the cells that are left
+//                   go, with the views that are left for them, onto a work list (one atomic per wave of 64 cells).  It also
+//                   zeroes the next frame's masks / wave counts / change words.
+//   k_frame_cells   a WAVE per listed cell (grid-stride over the list, the list's length read from the device): (3).  Neighbours on
+//                   the list are neighbours in the order and in memory.  The riders (the previous frame's compaction, a cluster
+//                   fill) sit in front of its grid.
+// The list's counter alternates between two words by frame; k_frame_cells zeroes the one the next frame's test will count in.
+template <bool INLINE_VIEWS>
+__global__ void __launch_bounds__(1024) k_cells_test(ViewSet vs, const ViewParams* __restrict__ dviews, uint32_t n_views, CellsFrameArgs a) {
+    const uint32_t gid = blockIdx.x * 1024u + threadIdx.x, gsz = gridDim.x * 1024u;
+#pragma unroll
+    for (uint32_t k = 0; k < 3u; ++k)
+        for (uint32_t i = gid; i < a.z.zero_words[k]; i += gsz) a.z.zero[k][i] = 0ull;
+    const uint32_t cell = gid;
+    const bool have = cell < a.o.n_waves;
+    const uint32_t lc = have ? cell : 0u;
+    const float4 sa = a.o.sum_a[lc];
+    const uint4 sb = a.o.sum_b[lc];
+    const uint32_t st = a.o.state[lc];
+    const bool rejectable = (sb.x & CELLS_REJECTABLE) != 0u;
+    uint32_t view_in = 0u;  // bit v: some slot of the cell may be visible in view v
+    for (uint32_t v = 0; v < n_views; ++v) {
+        const ViewParams& vp = INLINE_VIEWS ? vs.v[v] : dviews[v];
+        bool outside = false;
+        if (rejectable && !(vp.flags & VIEW_NO_CPU_CULLING)) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) outside = outside || cells_sphere_behind_plane(vp.planes + 4 * i, sa.x, sa.y, sa.z, sa.w);
+        }
+        if (!outside) view_in |= 1u << v;
+    }
+    // nothing can be visible and nothing was: every output of the cell's rows is the zero (or, in a frame that continues the one
+    // before, the unchanged bit) it already is
+    const bool todo = have && !(view_in == 0u && (st & 1u));
+    // one atomic per workgroup on the list's counter (agent-scope atomics on one word serialise at ~25 ns each: a wave's worth of cells
+    // per atomic was 12 us of a 17 us launch)
+    __shared__ uint32_t s_cnt[16], s_base;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(todo);
+    if (lane == 0u) s_cnt[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        uint32_t tot = 0;
+        for (uint32_t k = 0; k < 16u; ++k) {
+            const uint32_t cnt = s_cnt[k];
+            s_cnt[k] = tot;
+            tot += cnt;
+        }
+        s_base = tot ? atomicAdd(a.work_n, tot) : 0u;
+    }
+    __syncthreads();
+    if (todo) {
+        const uint32_t at = s_base + s_cnt[wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        a.work[at] = make_uint4(cell, view_in, sb.x | ((st & 1u) << 31), sb.y);
+    }
+}
+template <bool INLINE_VIEWS>
+__global__ void __launch_bounds__(256) k_frame_cells(Columns c, ViewSet vs, const ViewParams* __restrict__ dviews, uint32_t n_views,
+                                                      VisibilityOut out, CellsFrameArgs a, uint32_t n_tiles, CompactFastArgs prev, uint32_t prev_gx,
+                                                      uint32_t n_compact, uint32_t n_fill, ClusterFillJob fill) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds_raw[FRAME_LDS_WORDS + 4];
+    float4 (*lds_g)[192] = reinterpret_cast<float4 (*)[192]>(lds_raw);
+    {
+        ClusterWalkJob no_walk{};
+        if (frame_riders<false>(n_tiles, prev, prev_gx, n_compact, n_fill, fill, no_walk, vs, lds_raw)) return;
+    }
+    const uint32_t tile = blockIdx.x - (gridDim.x - n_tiles);
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t n_work = *a.work_n;
+    if (tile == 0u && threadIdx.x == 0u) *a.work_n_next = 0u;  // (the next frame's test counts in the other word)
+    for (uint32_t i = tile * 4u + wv; i < n_work; i += n_tiles * 4u) {  // (wave-uniform)
+        const uint4 job = a.work[i];
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.x), view_in = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.y);
+        uint4 sb;
+        sb.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.z) & 0x7FFFFFFFu;
+        sb.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.w);
+        sb.z = sb.w = 0u;
+        const uint32_t st = (uint32_t)__builtin_amdgcn_readfirstlane((int)job.z) >> 31;
+        cells_process<INLINE_VIEWS>(c, vs, dviews, n_views, out, a, w, view_in, st, sb, lds_g[wv], lane);
+        MI_WAVE_LDS_SYNC();  // (the next cell's transpose reuses the wave's buffer)
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Level 0 of propagation: flat rows (sync_simple_transforms) and tree roots
 // (propagate_parent_transforms, systems.rs:522-530).
 // ---------------------------------------------------------------------------------------------
@@ -1020,7 +1267,7 @@ static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, co
     uint32_t prev_gx = 1, prev_blocks = 0;
     if (prev && prev->n && prev->n_segments) {
         pa = *prev;
-        prev_gx = (((pa.n + 63u) >> 6) + 64u * compact_fast_steps(pa.n) - 1u) / (64u * compact_fast_steps(pa.n));
+        prev_gx = (((pa.n + 63u) >> 6) + 64u * compact_fast_steps_of(pa) - 1u) / (64u * compact_fast_steps_of(pa));
         prev_blocks = prev_gx * pa.n_segments;
     }
     ClusterFillJob fj{};
@@ -1063,7 +1310,7 @@ hipError_t launch_frame_sph(const Columns& c, const ViewSet* views_inline, const
     uint32_t prev_gx = 1, prev_blocks = 0;
     if (prev && prev->n && prev->n_segments) {
         pa = *prev;
-        prev_gx = (((pa.n + 63u) >> 6) + 64u * compact_fast_steps(pa.n) - 1u) / (64u * compact_fast_steps(pa.n));
+        prev_gx = (((pa.n + 63u) >> 6) + 64u * compact_fast_steps_of(pa) - 1u) / (64u * compact_fast_steps_of(pa));
         prev_blocks = prev_gx * pa.n_segments;
     }
     ClusterFillJob fj{};
@@ -1099,6 +1346,163 @@ hipError_t launch_frame_sph(const Columns& c, const ViewSet* views_inline, const
         else MI_SPH_LAUNCH(false, false, false);
     }
 #undef MI_SPH_LAUNCH
+    return hipGetLastError();
+}
+// Behind k_frame_cells: the frame's finished masks -> the VisibleEntities lists and the next frame's starting masks.
+//   lists   per view, the rows whose bit is set, ascending (= sorted by Entity, visibility/mod.rs:861-874): what k_compact_fast writes
+//           from the frame kernels' wave counts -- here straight from the masks
+//   copy    the masks themselves, into the set the next frame will write (it changes only the bits that change)
+// Two short launches, no wait inside either:
+//   k_cells_blocks (groups <= 256, views)  a workgroup walks a contiguous run of whole 64-word blocks (a wave per block, a lane per
+//       word): the copy, every block's population as its exclusive prefix INSIDE the run (blk_pre), the run's total (grp_tot)
+//   k_cells_lists  (blocks / 4, views)     a wave per block: its base = the totals of the runs in front (<= 255 numbers: four per lane,
+//       one round trip) + blk_pre, then the expansion.  A wave per block because the rows a view sees are often neighbours in row
+//       order too: with a run per workgroup one workgroup expanded 50 000 rows while fifteen had none (22 of 26 us at 1 M rows).
+// Words without a set bit cost a ballot; the expansion visits only the others.
+constexpr uint32_t CELLS_FIN_MAX_BLKS = 4096;  // blocks per run the LDS holds (16 KB): 256 runs x 4096 blocks x 4096 rows > 2^32
+__global__ void __launch_bounds__(256) k_cells_blocks(CellsFinishArgs f) {
+    const uint32_t v = blockIdx.y, grp = blockIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t b0 = grp * f.blks_per < f.n_blks ? grp * f.blks_per : f.n_blks, b1 = b0 + f.blks_per < f.n_blks ? b0 + f.blks_per : f.n_blks;
+    const uint64_t* mask = f.out.bitmask + (size_t)v * f.out.words_per_view + f.out.word_offset;
+    __shared__ uint32_t s_blk[CELLS_FIN_MAX_BLKS];
+    for (uint32_t b = b0 + wv; b < b1; b += 4u) {  // (wave-uniform)
+        const uint32_t word = b * 64u + lane;
+        const unsigned long long m = word < f.n_words ? mask[word] : 0ull;
+        if (f.copy_to && word < f.n_words) f.copy_to[(size_t)v * f.copy_words_per_view + word] = m;
+        uint32_t pc = (uint32_t)__popcll(m);
+#pragma unroll
+        for (uint32_t off = 32u; off; off >>= 1) pc += __shfl_xor(pc, off, 64);
+        if (lane == 0u) s_blk[b - b0] = pc;
+    }
+    if (!f.out_rows) return;  // (the copy only: the lists are the general compaction's)
+    __syncthreads();
+    if (wv != 0u) return;
+    const uint32_t nb = b1 - b0;
+    uint32_t carry = 0;
+    for (uint32_t i0 = 0; i0 < nb; i0 += 64u) {  // (wave-uniform)
+        const uint32_t i = i0 + lane;
+        const uint32_t cnt = i < nb ? s_blk[i] : 0u;
+        uint32_t incl = cnt;
+#pragma unroll
+        for (uint32_t off = 1; off < 64u; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        if (i < nb) f.blk_pre[(size_t)v * f.n_blks + b0 + i] = carry + incl - cnt;
+        carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0u) f.grp_tot[(size_t)v * CELLS_FIN_GROUPS + grp] = carry;
+}
+__global__ void __launch_bounds__(256) k_cells_lists(CellsFinishArgs f) {
+    const uint32_t v = blockIdx.y, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t b = blockIdx.x * 4u + wv;
+    if (b >= f.n_blks) return;  // (wave-uniform)
+    const uint64_t* mask = f.out.bitmask + (size_t)v * f.out.words_per_view + f.out.word_offset;
+    const uint32_t word = b * 64u + lane;
+    const unsigned long long m = word < f.n_words ? mask[word] : 0ull;
+    const uint32_t grp = b / f.blks_per;
+    const bool last = b == f.n_blks - 1u;  // this wave also leaves the list's length
+    const uint32_t upto = last ? f.n_groups : grp;
+    uint32_t mine = 0, all = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < CELLS_FIN_GROUPS / 64u; ++k) {
+        const uint32_t g = lane + 64u * k;
+        const uint32_t t = g < upto ? f.grp_tot[(size_t)v * CELLS_FIN_GROUPS + g] : 0u;
+        mine += g < grp ? t : 0u;
+        all += t;
+    }
+#pragma unroll
+    for (uint32_t off = 32u; off; off >>= 1) {
+        mine += __shfl_xor(mine, off, 64);
+        all += __shfl_xor(all, off, 64);
+    }
+    if (last && lane == 0u) f.seg_totals[v] = all;
+    const uint32_t pre = f.blk_pre[(size_t)v * f.n_blks + b];  // (requested with the loads above: one round trip for all of them)
+    unsigned long long nz = __ballot(m != 0ull);
+    if (nz == 0ull) return;
+    const uint32_t base = mine + pre;
+    const uint32_t pc = (uint32_t)__popcll(m);
+    uint32_t incl = pc;
+#pragma unroll
+    for (uint32_t off = 1; off < 64u; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    const uint32_t excl = incl - pc;
+    uint32_t* out = f.out_rows + (size_t)v * f.seg_stride;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t m_lo = (uint32_t)m, m_hi = (uint32_t)(m >> 32);
+    while (nz) {  // (nz is wave-uniform: j lives in a scalar register and the three values come with v_readlane, not through LDS)
+        const int j = __builtin_amdgcn_readfirstlane(__ffsll((long long)nz) - 1);
+        nz &= nz - 1ull;
+        const unsigned long long mj = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)m_hi, j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)m_lo, j);
+        const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)excl, j);
+        if ((mj >> lane) & 1ull) out[base + oj + (uint32_t)__popcll(mj & lt)] = (b * 64u + (uint32_t)j) * 64u + lane;
+    }
+}
+static uint32_t cells_dbg() {  // test hook (MI_CELLS_DBG): 16 = long runs in k_cells_blocks, the shape of tables beyond 16.7 M rows, on any table
+    static const uint32_t dbg = getenv("MI_CELLS_DBG") ? (uint32_t)atoi(getenv("MI_CELLS_DBG")) : 0u;
+    return dbg;
+}
+hipError_t launch_cells_finish(const CellsFinishArgs& f_in, uint32_t n_views, hipStream_t stream, void (*mark)(void*, uint32_t), void* mark_ctx) {
+    CellsFinishArgs f = f_in;
+    if (f.n_words == 0 || n_views == 0) return hipSuccess;
+    uint32_t groups = (f.n_blks + 15u) / 16u;  // 16 blocks (65 536 rows) a run while that keeps it to CELLS_FIN_GROUPS runs
+    if (groups > CELLS_FIN_GROUPS) groups = CELLS_FIN_GROUPS;
+    if (groups == 0) groups = 1;
+    if ((cells_dbg() & 16u) && groups > 3u) groups = 3u;  // (test hook: long runs -- the shape of tables beyond 16.7 M rows -- on any table)
+    f.blks_per = (f.n_blks + groups - 1u) / groups;
+    f.n_groups = (f.n_blks + f.blks_per - 1u) / f.blks_per;
+    if (f.blks_per > CELLS_FIN_MAX_BLKS) return hipErrorInvalidValue;  // (more than 2^32 rows)
+    if (mark) mark(mark_ctx, K_COMPACT_COUNT);
+    MI_LAUNCH(k_cells_blocks, dim3(f.n_groups, n_views), dim3(256), 0, stream, f);
+    if (f.out_rows) {
+        if (mark) mark(mark_ctx, K_COMPACT_FAST);
+        MI_LAUNCH(k_cells_lists, dim3((f.n_blks + 3u) / 4u, n_views), dim3(256), 0, stream, f);
+    }
+    if (mark) mark(mark_ctx, K_NUM_KERNELS);
+    return hipGetLastError();
+}
+// the test: a thread per cell
+hipError_t launch_cells_test(const CellsOrder& o, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views, const CellsZero& z,
+                             const CellsWork& work, hipStream_t stream) {
+    if (o.n_waves == 0) return hipSuccess;
+    CellsFrameArgs a{o, z, work.list, work.n, work.n_next, work.fresh};
+    const bool inl = n_views <= MAX_INLINE_VIEWS && views_inline;
+    ViewSet dummy = {};
+    const dim3 grid((o.n_waves + 1023u) / 1024u);
+    if (inl) MI_LAUNCH((k_cells_test<true>), grid, dim3(1024), 0, stream, *views_inline, (const ViewParams*)nullptr, n_views, a);
+    else MI_LAUNCH((k_cells_test<false>), grid, dim3(1024), 0, stream, dummy, d_views, n_views, a);
+    return hipGetLastError();
+}
+// the cells it listed: a wave each, grid-stride (at most CELLS_MAX_TILES workgroups: twice what the chip holds at once)
+hipError_t launch_frame_cells(const Columns& c, const CellsOrder& o, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views,
+                              const VisibilityOut& out, const CellsZero& z, const CellsWork& work, const CompactFastArgs* prev, const ClusterFillJob* fill,
+                              hipStream_t stream) {
+    if (c.n == 0) return hipSuccess;
+    CellsFrameArgs a{o, z, work.list, work.n, work.n_next, work.fresh};
+    const bool inl = n_views <= MAX_INLINE_VIEWS && views_inline;
+    ViewSet dummy = {};
+    const ViewSet& vsr = inl ? *views_inline : dummy;
+    const ViewParams* dv = inl ? nullptr : d_views;
+    const uint32_t want = (o.n_waves + 3u) / 4u;
+    const uint32_t n_tiles = want < CELLS_MAX_TILES ? want : CELLS_MAX_TILES;
+    CompactFastArgs pa{};
+    uint32_t prev_gx = 1, prev_blocks = 0;
+    if (prev && prev->n && prev->n_segments) {
+        pa = *prev;
+        prev_gx = (((pa.n + 63u) >> 6) + 64u * compact_fast_steps_of(pa) - 1u) / (64u * compact_fast_steps_of(pa));
+        prev_blocks = prev_gx * pa.n_segments;
+    }
+    ClusterFillJob fj{};
+    uint32_t fill_blocks = 0;
+    if (fill) {
+        fj = *fill;
+        fill_blocks = CLUSTER_FILL_RIDE_BLOCKS;
+    }
+    const dim3 grid(n_tiles + prev_blocks + fill_blocks);
+    if (inl) MI_LAUNCH((k_frame_cells<true>), grid, dim3(256), 0, stream, c, vsr, dv, n_views, out, a, n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj);
+    else MI_LAUNCH((k_frame_cells<false>), grid, dim3(256), 0, stream, c, vsr, dv, n_views, out, a, n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj);
     return hipGetLastError();
 }
 hipError_t launch_flat_propagate_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views,
@@ -1250,7 +1654,7 @@ __global__ void __launch_bounds__(256) k_compact_fast(CompactFastArgs a) {
 hipError_t launch_compact_fast(const CompactFastArgs& a, hipStream_t stream) {
     if (a.n == 0 || a.n_segments == 0) return hipSuccess;
     const uint32_t n_words = (a.n + 63u) >> 6;
-    const uint32_t per_wg = 64u * compact_fast_steps(a.n);
+    const uint32_t per_wg = 64u * compact_fast_steps_of(a);
     MI_LAUNCH(k_compact_fast, dim3((n_words + per_wg - 1u) / per_wg, a.n_segments), dim3(256), 0, stream, a);
     return hipGetLastError();
 }

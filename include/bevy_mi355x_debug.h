@@ -72,6 +72,13 @@ int32_t mi_debug_set_row_summary(mi_ctx* ctx, int32_t mode);
 /* The world-sphere path of the cull-only and changed-rows frames (kernels_flat.hip, k_frame_sph): 0 = used from the second frame in
  * a row that rewrites no or few GlobalTransforms (default), 1 = never, 2 = at once (the first such frame rebuilds the column). */
 int32_t mi_debug_set_sphere_path(mi_ctx* ctx, int32_t mode);
+/* The static cull order (kernels_cells.hip): cull-only frames of a scene that has gone static -- world spheres current, camera views,
+ * MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME, no classes / ranges / exchange -- run over a cell-ordered copy whose waves are first tested
+ * as a whole against each view (reject only).  0 = built by the second such frame in a row on contexts of 3 000 000 rows and more
+ * (default), 1 = never, 2 = at once and at any row count.  Results are identical.
+ * mi_debug_static_cull_counts: orders built / frames that ran over one (tests). */
+int32_t mi_debug_set_static_cull_order(mi_ctx* ctx, int32_t mode);
+int32_t mi_debug_static_cull_counts(mi_ctx* ctx, uint32_t* out_builds, uint32_t* out_frames);
 /* The device's restatement of glibc logf (view_z_to_z_slice, crates/bevy_light/src/cluster/assign.rs:1057) over n inputs. */
 int32_t mi_debug_logf(mi_ctx* ctx, const float* in, float* out, uint32_t n);
 

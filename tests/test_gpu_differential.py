@@ -10,6 +10,7 @@ agree on everything a caller can download after every step; at intervals the ora
     hierarchy frame fused into the tile launches          (B: two launches)               [A: mi_debug_set_tree_cull(2)]
     dense uploads in pieces, GlobalTransforms fetched ahead mi_debug_set_chunked_frames(1)  [A: at any row count, mode 2]
     GlobalTransforms written ahead by an indexed window     (the same switch)
+    static cull order (k_frame_cells over the cell order)  mi_debug_set_static_cull_order(1) [A: built at once, any row count, mode 2]
 
 The sequences mix: change marks raised from elsewhere, frames repeated before anybody asks for results, results asked at random
 steps, bounds uploads (whole, partial, single rows), RenderLayers above 31, Transform uploads (indexed, ranges),
@@ -111,8 +112,10 @@ def make_ctx(fast, seed=0):
         ctx.debug_set_tile_pretest(2)
         ctx.debug_set_tree_cull(2)
         ctx.debug_set_chunked_frames(2)
+        ctx.debug_set_static_cull_order(2)
     else:
         ctx.debug_set_chunked_frames(1)
+        ctx.debug_set_static_cull_order(1)
         ctx.debug_set_row_summary(1)
         ctx.debug_set_sphere_path(1)
         ctx.debug_set_walk_inrow(1)
@@ -302,7 +305,8 @@ def test_fast_paths_are_interchangeable(seed):
                     assert np.array_equal(np.frombuffer(sa[f"mask {v}"], np.uint8), vis[v]), f"seed {seed} step {step}: mask of view {v} against the oracle"
         PIECES[0] += a.debug_chunked_counts()[0]  # (their results are handed out ahead only beyond the packed window: tests/test_gpu_chunked_frames.py)
         SPARSE[0] += a.debug_chunked_counts()[2]
-        assert b.debug_chunked_counts() == (0, 0, 0)
+        CELLS[0] += a.debug_static_cull_counts()[1]
+        assert b.debug_chunked_counts() == (0, 0, 0) and b.debug_static_cull_counts() == (0, 0)
     finally:
         a.close()
         b.close()
@@ -310,11 +314,13 @@ def test_fast_paths_are_interchangeable(seed):
 
 PIECES = [0]
 SPARSE = [0]
+CELLS = [0]
 
 
 def test_the_pieces_were_taken():
     """(runs after the seeds above) some of their dense uploads did go out in pieces, with results fetched ahead, in the fast context."""
     assert PIECES[0] > 0 and SPARSE[0] > 0
+    assert CELLS[0] > 0, "no frame of the seeds ran over the static cull order"
 
 
 def oracle_half(sc, n, first_light, n_lights):

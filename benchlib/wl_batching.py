@@ -39,8 +39,9 @@ def build_batching(ctx, args):
 
 def build_batching_sorted(ctx, args):
     """Sorted phases (Transparent3d, the 2D phases): gpu_preprocessing::batch_and_prepare_sorted_render_phase over a phase of
-    --sorted-items items in their sorted order.  A step = mi_batch_sorted_build: the items go up (16 B each: they are the CPU's
-    sorted phase) and the walk runs -- one workgroup up to 1 024 items, tiles over the whole chip beyond."""
+    --sorted-items items in their sorted order.  A step = mi_batch_sorted_build: the items are staged (16 B each: they are the CPU's
+    sorted phase) and the walk runs -- up to 8 192 items one workgroup reading the pinned staging block itself, beyond that tiles of
+    4 096 items over the whole chip behind one H2D copy (kernels_sorted.hip)."""
     from bevy_amd import workloads as W
     n = getattr(args, "sorted_items", 0) or 65_536
     items = W.sorted_items(n, seed=5)
@@ -51,13 +52,14 @@ def build_batching_sorted(ctx, args):
 
     def step(f):
         ctx.batch_sorted_build(items, True, False, False, None)
-    tiled = n > (1024 if limit is None else limit)
+    tiled = n > min(8192, 8192 if limit is None else limit)
     config = {"workload": f"sorted render phase of {n} items (runs of equal batch-set / bin keys, some without an input index): "
-                          "mi_batch_sorted_build = H2D of the items + " + ("k_batch_sorted_partials + k_batch_sorted_tiles (two launches, "
-                          f"{(n + 1023) // 1024} tiles)" if tiled else "k_batch_sorted (one workgroup)"), "items": n, "tiled": tiled}
-    # per item: read 16 (item) + 16 (its predecessor, L2), write 8 scratch planes x 4, read most of them back, write a work item 8 (+ metadata)
-    wl = Workload("batching_sorted", step, n, 16.0 + 32.0 + 32.0 + 8.0, "k_batch_sorted", config, "items/sec through the sorted-phase batch build", "items/s",
+                          "mi_batch_sorted_build = " + (f"H2D of the items + k_sorted_walk<16, true> + k_sorted_walk<16, false> (two launches, {(n + 4095) // 4096} tiles)"
+                                                        if tiled else "k_sorted_walk (one workgroup, one launch, reading the items from the pinned staging block)"),
+              "items": n, "tiled": tiled}
+    # per item: read 16 (item), write a work item 8 (+ 20 B of metadata per batch, 24 + 8 per batch set)
+    wl = Workload("batching_sorted", step, n, 16.0 + 8.0 + 8.0, "k_batch_sorted", config, "items/sec through the sorted-phase batch build", "items/s",
                   kernels=["k_batch_sorted", "k_batch_scan"])
     wl.sorted_items = items
-    wl.kernel_name = "k_batch_sorted_tiles" if tiled else "k_batch_sorted<256>"
+    wl.kernel_name = "k_sorted_walk<16u, false>" if (tiled or n <= 4096) else "k_sorted_walk<32u, false>"
     return wl

@@ -930,7 +930,7 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
                       &ctx->bt_set_indexed, &ctx->bt_table_off, &ctx->bt_table, &ctx->bt_meta_off, &ctx->bt_meta, &ctx->bt_rows_a, &ctx->bt_rows_b,
                       &ctx->bt_hist, &ctx->bt_set_count, &ctx->bt_set_scan, &ctx->bt_counters, &ctx->bt_wi[0], &ctx->bt_wi[1], &ctx->bt_md[0],
                       &ctx->bt_md[1], &ctx->bt_bs[0], &ctx->bt_bs[1], &ctx->bt_records, &ctx->bt_totals, &ctx->bt_bucket_desc, &ctx->bt_meta_out,
-                      &ctx->bt_inst[0], &ctx->bt_inst[1], &ctx->bt_plan, &ctx->bt_unb, &ctx->bt_items, &ctx->bt_sorted_scratch, &ctx->bt_batches, &ctx->bt_sorted_partials,
+                      &ctx->bt_inst[0], &ctx->bt_inst[1], &ctx->bt_plan, &ctx->bt_unb, &ctx->bt_items, &ctx->bt_batches, &ctx->bt_sorted_partials,
                       &ctx->cl_row_list, &ctx->cl_remap, &ctx->cl_bind_oc, &ctx->cl_bind_idx, &ctx->cl_block_counts, &ctx->cl_pair_cb, &ctx->cl_pair_mask, &ctx->cl_acc,
                       &ctx->cl_offsets, &ctx->cl_indices, &ctx->cl_scalars};
     for (DevBuf* b : bufs)

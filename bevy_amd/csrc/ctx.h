@@ -309,7 +309,7 @@ struct mi_ctx {
     uint32_t *bt_cpu_bin = nullptr, *bt_bucket = nullptr;    // unbatchable / batchable bin; resolved bucket
     std::vector<uint8_t> bt_unb_indexed, bt_bat_indexed, bt_set_indexed_host;
     std::vector<uint32_t> bt_meta_zero;                      // the uploaded GpuBinMetadata with instance_count = 0
-    DevBuf bt_bucket_desc, bt_meta_out, bt_inst[2], bt_plan, bt_unb, bt_items, bt_sorted_scratch, bt_batches, bt_sorted_partials;
+    DevBuf bt_bucket_desc, bt_meta_out, bt_inst[2], bt_plan, bt_unb, bt_items, bt_batches, bt_sorted_partials;
     uint32_t bt_sorted_one_wg_limit = mi::SORTED_ONE_WG_ITEMS;  // mi_debug_set_sorted_one_wg_limit
     uint32_t bt_inst_cur = 0;
     bool bt_desc_dirty = true, bt_desc_no_indirect = false, bt_last_sorted = false;

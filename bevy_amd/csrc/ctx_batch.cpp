@@ -273,18 +273,28 @@ int32_t mi_batch_sorted_build(mi_ctx* ctx, uint32_t n_items, const mi_sorted_ite
     SortedArgs a{};
     if (initial) memcpy(&a.initial, initial, sizeof a.initial);
     int32_t rc;
-    if ((rc = ensure(ctx, ctx->bt_items, std::max<size_t>(n_items, 1) * 16))) return rc;
-    if ((rc = ensure(ctx, ctx->bt_sorted_scratch, std::max<size_t>(n_items, 1) * 8 * 4))) return rc;
     if ((rc = ensure(ctx, ctx->bt_batches, ((size_t)n_items + 1) * 24))) return rc;
     if ((rc = ensure(ctx, ctx->bt_totals, 64))) return rc;
     if ((rc = batch_outputs(ctx, a.initial, n_items, n_items, n_items, a.work_items, a.metadata, a.batch_sets))) return rc;
-    if (n_items && (rc = upload(ctx, ctx->bt_items.p, items, (size_t)n_items * 16))) return rc;
-    a.items = (const uint32_t*)ctx->bt_items.p;
+    const bool one_wg = n_items <= SORTED_ONE_WG_ITEMS && n_items <= ctx->bt_sorted_one_wg_limit;
+    if (n_items && one_wg) {
+        // a short phase is walked by one workgroup that reads the items where they were staged -- pinned host memory, once, in
+        // lane-contiguous 16-byte loads: no copy launch in front of the kernel (a DMA submission is ~5 us, the items' trip ~2)
+        void* st = nullptr;
+        if ((rc = stage_alloc(ctx, (size_t)n_items * 16, &st))) return rc;
+        memcpy(st, items, (size_t)n_items * 16);
+        void* dev = nullptr;
+        HIP_TRY(ctx, hipHostGetDevicePointer(&dev, st, 0));
+        a.items = (const uint32_t*)dev;
+    } else {
+        if ((rc = ensure(ctx, ctx->bt_items, std::max<size_t>(n_items, 1) * 16))) return rc;
+        if (n_items && (rc = upload(ctx, ctx->bt_items.p, items, (size_t)n_items * 16))) return rc;
+        a.items = (const uint32_t*)ctx->bt_items.p;
+    }
     a.n_items = n_items;
     a.automatic_batching = (flags & MI_SORTED_AUTOMATIC_BATCHING) ? 1u : 0u;
     a.no_indirect = (flags & MI_SORTED_NO_INDIRECT_DRAWING) ? 1u : 0u;
     a.merge_only = (flags & MI_SORTED_NO_GPU_PREPROCESSING) ? 1u : 0u;
-    a.scratch = (uint32_t*)ctx->bt_sorted_scratch.p;
     a.batches = (uint32_t*)ctx->bt_batches.p;
     a.totals = (uint32_t*)ctx->bt_totals.p;
     if ((rc = ensure(ctx, ctx->bt_sorted_partials, (size_t)batch_sorted_partial_words(std::max(n_items, 1u)) * 4))) return rc;

@@ -619,9 +619,8 @@ struct BatchArgs {
     BatchInitial initial;
 };
 struct SortedArgs {
-    const uint32_t* items;     // 4 words per phase item: input index, batch-set key, bin key, flags
+    const uint32_t* items;     // 4 words per phase item: input index, batch-set key, bin key, flags (device memory, or pinned host memory mapped into the device)
     uint32_t n_items, automatic_batching, no_indirect, merge_only;
-    uint32_t* scratch;         // [8][n_items]
     uint32_t* work_items[2];
     uint32_t* metadata[2];
     uint32_t* batch_sets[2];
@@ -635,9 +634,11 @@ hipError_t launch_batch_resolve_rows(uint32_t n, uint32_t n_sets, uint32_t n_unb
                                      uint32_t* row_meta, uint32_t* row_bucket, hipStream_t stream);
 // enqueues the whole build (3 launches up to 256 buckets); `mark` is called before each kernel for profiling
 hipError_t launch_batch_build(const BatchArgs& a, hipStream_t stream, void (*mark)(void*, uint32_t), void* mark_ctx);
-// partials: batch_sorted_partial_words(n_items) words of scratch for the tiled form (nullptr: the single-workgroup kernel whatever the
-// length); one_wg_limit: phases up to this long take the single-workgroup kernel (one launch)
-constexpr uint32_t SORTED_ONE_WG_ITEMS = 1024;  // (4 096 items: one workgroup 60 us, four tiles in two launches ~ 15)
+// Sorted phases (kernels_sorted.hip).  Up to SORTED_ONE_WG_ITEMS items: one workgroup, one launch, and `items` may be pinned host
+// memory (read once, coalesced).  Longer: tiles of SORTED_TILE_ITEMS items in two launches; partials = batch_sorted_partial_words(n_items)
+// words of scratch.  one_wg_limit (test hook): phases longer than this take the tiled form whatever their length.
+constexpr uint32_t SORTED_ONE_WG_ITEMS = 8192;
+constexpr uint32_t SORTED_TILE_ITEMS = 4096;
 uint32_t batch_sorted_partial_words(uint32_t n_items);
 hipError_t launch_batch_sorted(const SortedArgs& a, hipStream_t stream, void (*mark)(void*, uint32_t), void* mark_ctx, uint32_t* partials = nullptr,
                                uint32_t one_wg_limit = SORTED_ONE_WG_ITEMS);

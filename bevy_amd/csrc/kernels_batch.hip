@@ -270,8 +270,8 @@ __global__ void __launch_bounds__(1024) k_batch_scan(BatchArgs a) {
 //   q5, q6  IndirectBatchSets per class: one per unbatchable entity with an input index, one per non-empty batchable bin / batch set
 //   q7      records (BinnedRenderPhaseBatchSet / batches)   q8  UnbatchableBinnedEntityIndices
 // count[] of a bucket comes from the partition offsets (ONE_PASS: digit starts in LDS) or from the run bounds in the list.
-// THREADS = 256 when there are at most 256 buckets (one trip through the bucket loop either way): a quarter of the waves, four
-// times the register budget -- the 1024-thread build spills 126 registers into scratch in the middle of the scans.
+// THREADS: 512 in the many-bucket path (159 registers, no scratch; a 1 024-thread build is held to 128 and spilled 126 of them in the
+// middle of the scans -- removed in round 4).
 template <bool ONE_PASS, uint32_t THREADS>
 __global__ void __launch_bounds__(THREADS) k_batch_plan(BatchArgs a) {
     __shared__ uint32_t lds_scan1[THREADS / 64][1];
@@ -824,406 +824,7 @@ __global__ void __launch_bounds__(256) k_batch_clear_bounds(BatchArgs a) {
     if (i < 2u * a.n_buckets) a.set_count[i] = 0u;
 }
 
-// =============================================================================================
-// sorted phases (gpu_preprocessing.rs:1850-2061; the range merge of batching/mod.rs:219-244)
-// =============================================================================================
-// One workgroup walks the items in chunks of 1024.  Whether an item continues its predecessor's batch, breaks the batch or breaks
-// the batch set depends only on the two items (the running batch set's meta is always the previous item's); every index is an
-// exclusive prefix sum over the items.  Phase A computes per item: its MeshUniform slot, the indirect-parameters slot it allocates
-// (if it breaks), the inclusive count of batch breaks and the item that heads its batch set; phase B (after a barrier: same
-// workgroup) turns them into work items and, at each set's last item, the record flush() leaves.
-constexpr uint32_t SORTED_OK = 0, SORTED_BREAK_BATCH = 1, SORTED_HEAD = 2, SORTED_SKIP = 3;
-
-// THREADS = 256 for phases of up to 4 096 items (the common case: no register spills -- the 1 024-thread build, capped at 128
-// registers, spills 118 in the middle of the scans); 1 024 threads keep long phases to few trips through the loops.
-template <uint32_t THREADS>
-__global__ void __launch_bounds__(THREADS) k_batch_sorted(SortedArgs a) {
-    __shared__ uint32_t lds_scan[THREADS / 64][8];
-    __shared__ uint32_t lds_head[THREADS / 64];
-    __shared__ uint32_t carry_head;
-    const bool indirect = a.no_indirect == 0u && a.merge_only == 0u;
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    // ---- phase A
-    uint32_t carry[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // with input | with input per class | allocations per class | breaks | sets | sets of class 1
-    if (threadIdx.x == 0) carry_head = 0xFFFFFFFFu;
-    __syncthreads();
-    for (uint32_t i0 = 0; i0 < a.n_items; i0 += THREADS) {
-        const uint32_t i = i0 + threadIdx.x;
-        const bool in = i < a.n_items;
-        uint32_t it[4] = {0xFFFFFFFFu, 0, 0, 0}, pv[4] = {0xFFFFFFFFu, 0, 0, 0};
-        if (in) {
-#pragma unroll
-            for (uint32_t k = 0; k < 4u; ++k) it[k] = a.items[4u * i + k];
-            if (i)
-#pragma unroll
-                for (uint32_t k = 0; k < 4u; ++k) pv[k] = a.items[4u * (i - 1u) + k];
-        }
-        const bool has_in = in && it[0] != 0xFFFFFFFFu;
-        const bool meta = has_in && a.automatic_batching && (it[3] & 2u);
-        const bool prev_in = in && i && pv[0] != 0xFFFFFFFFu;
-        const bool prev_meta = prev_in && a.automatic_batching && (pv[3] & 2u);
-        uint32_t flag = SORTED_SKIP;
-        if (has_in) {
-            flag = SORTED_HEAD;
-            if (meta && prev_meta && it[1] == pv[1]) {
-                if (it[2] == pv[2]) flag = SORTED_OK;
-                else if (indirect) flag = SORTED_BREAK_BATCH;  // without indirect drawing a different mesh is a new batch set; the
-                                                               // merge-only rule has no second level either
-            }
-        }
-        const uint32_t cls = it[3] & 1u;
-        const bool alloc = indirect && (flag == SORTED_HEAD || flag == SORTED_BREAK_BATCH);
-        uint32_t v[8] = {has_in ? 1u : 0u, (has_in && !cls) ? 1u : 0u, (has_in && cls) ? 1u : 0u, (alloc && !cls) ? 1u : 0u,
-                         (alloc && cls) ? 1u : 0u, flag == SORTED_BREAK_BATCH ? 1u : 0u, flag == SORTED_HEAD ? 1u : 0u,
-                         (flag == SORTED_HEAD && cls) ? 1u : 0u};
-        uint32_t tot[8];
-        block_scan_multi<8, THREADS>(v, lds_scan, tot);
-        // the item that heads this item's batch set: the latest head at or before it (max-scan of head positions)
-        uint32_t h = flag == SORTED_HEAD ? i : 0xFFFFFFFFu;  // 0xFFFFFFFF = none yet; indices compare as (x + 1)
-        uint32_t hx = h + 1u;
-#pragma unroll
-        for (uint32_t off = 1; off < 64u; off <<= 1) {
-            const uint32_t up = __shfl_up(hx, off, 64);
-            if (lane >= off && up > hx) hx = up;
-        }
-        if (lane == 63u) lds_head[wv] = hx;
-        __syncthreads();
-        uint32_t before = carry_head + 1u;
-        for (uint32_t k = 0; k < wv; ++k) before = lds_head[k] > before ? lds_head[k] : before;
-        hx = hx > before ? hx : before;
-        if (in) {
-            a.scratch[0u * a.n_items + i] = a.initial.output_mesh_uniform_index + carry[0] + v[0];
-            a.scratch[1u * a.n_items + i] = alloc ? (cls ? a.initial.indirect_parameters_index[1] + carry[4] + v[4]
-                                                         : a.initial.indirect_parameters_index[0] + carry[3] + v[3])
-                                                  : 0xFFFFFFFFu;
-            a.scratch[2u * a.n_items + i] = carry[5] + v[5] + (flag == SORTED_BREAK_BATCH ? 1u : 0u);  // inclusive
-            a.scratch[3u * a.n_items + i] = hx - 1u;
-            // per class: this item's work-item slot; ordinal of its set (all classes) and among the sets of its head's class
-            a.scratch[4u * a.n_items + i] = cls ? a.initial.work_item_index[1] + carry[2] + v[2] : a.initial.work_item_index[0] + carry[1] + v[1];
-            a.scratch[5u * a.n_items + i] = carry[6] + v[6];                                   // sets before this item (exclusive)
-            a.scratch[6u * a.n_items + i] = carry[7] + v[7];                                   // ... of class 1
-            a.scratch[7u * a.n_items + i] = flag;
-        }
-        __syncthreads();
-        if (threadIdx.x == THREADS - 1u) carry_head = hx - 1u;
-#pragma unroll
-        for (uint32_t q = 0; q < 8u; ++q) carry[q] += tot[q];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        a.totals[0] = a.initial.work_item_index[0] + (a.merge_only ? 0u : carry[1]);
-        a.totals[1] = a.initial.work_item_index[1] + (a.merge_only ? 0u : carry[2]);
-        a.totals[2] = a.initial.indirect_parameters_index[0] + carry[3];
-        a.totals[3] = a.initial.indirect_parameters_index[1] + carry[4];
-        a.totals[4] = a.initial.batch_set_index[0] + (indirect ? carry[6] - carry[7] : 0u);
-        a.totals[5] = a.initial.batch_set_index[1] + (indirect ? carry[7] : 0u);
-        a.totals[6] = a.initial.output_mesh_uniform_index + carry[0];
-        a.totals[7] = carry[6];
-        a.totals[8] = 0u;
-    }
-    __threadfence();
-    __syncthreads();
-    // ---- phase B (scratch written above is read back through L2: the loads below bypass the per-CU cache)
-    auto ld = [&](uint32_t plane, uint32_t i) { return __builtin_nontemporal_load(a.scratch + plane * a.n_items + i); };
-    for (uint32_t i0 = 0; i0 < a.n_items; i0 += THREADS) {
-        const uint32_t i = i0 + threadIdx.x;
-        if (i >= a.n_items) continue;
-        const uint32_t flag = ld(7, i);
-        if (flag == SORTED_SKIP) continue;
-        const uint32_t cls = a.items[4u * i + 3u] & 1u;
-        const uint32_t out = ld(0, i), h = ld(3, i);
-        const uint32_t ip_h = ld(1, h);
-        const uint32_t cur = ip_h + (ld(2, i) - ld(2, h));  // indirect_parameters_index_range.end - 1
-        if (!a.merge_only) {
-            if (indirect && flag != SORTED_OK) {
-                uint32_t* md = (cls ? a.metadata[1] : a.metadata[0]) + 5u * ld(1, i);
-                md[0] = out;
-                md[1] = 0xFFFFFFFFu;
-                md[2] = md[3] = md[4] = 0u;
-            }
-            uint32_t* wi = (cls ? a.work_items[1] : a.work_items[0]) + 2u * ld(4, i);
-            wi[0] = a.items[4u * i];
-            wi[1] = indirect ? cur : out;
-        }
-        // the set's last item: the next item is missing, has no input index, or heads a new set
-        const bool last = i + 1u == a.n_items || ld(7, i + 1u) == SORTED_SKIP || ld(7, i + 1u) == SORTED_HEAD;
-        if (last) {
-            const uint32_t cls_h = a.items[4u * h + 3u] & 1u;
-            const uint32_t k = ld(5, h);
-            uint32_t* b = a.batches + 6u * k;
-            b[0] = h;
-            b[1] = ld(0, h);
-            b[2] = out + 1u;
-            b[3] = indirect ? ip_h : 0xFFFFFFFFu;
-            b[4] = indirect ? cur + 1u : 0xFFFFFFFFu;
-            b[5] = cls_h;
-            if (indirect) {  // add_batch_set at flush, in flush order per class (:1787-1793)
-                const uint32_t sets1 = ld(6, h);
-                const uint32_t slot = cls_h ? a.initial.batch_set_index[1] + sets1 : a.initial.batch_set_index[0] + (k - sets1);
-                uint32_t* bset = (cls_h ? a.batch_sets[1] : a.batch_sets[0]) + 2u * slot;
-                bset[0] = 0u;
-                bset[1] = ip_h;
-            }
-        }
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// Sorted phases of any length on the whole chip: two launches over tiles of SORTED_TILE items.
-// The single-workgroup kernel above is a chain of block scans over the phase; tens of thousands of Transparent3d / 2D items are
-// ordinary, and one workgroup is one CU of 256.  Every index the walk hands out is a prefix sum and "which item heads my batch
-// set" is a running maximum, so the phase splits into tiles the way a scan does:
-//   k_batch_sorted_partials  per tile: the eight sums, the position of the tile's last batch-set head and the eight tile-local
-//                            exclusive prefixes AT that head (what phase B reads of a head: its slots and ordinals);
-//   k_batch_sorted_tiles     every workgroup adds up the partials in front of its tile (17 words each: L2-resident), which gives
-//                            its carries and -- from the last tile before it that holds a head -- the head that governs its first
-//                            items with that head's absolute values; then phase A and phase B of the kernel above, restricted to
-//                            the tile.  Phase B's look at the next item's flag is recomputed from the two items themselves.
-// Same results as k_batch_sorted (tests/test_gpu_batching.py runs both on the same phases).
-// ---------------------------------------------------------------------------------------------
-constexpr uint32_t SORTED_TILE = 1024;
-constexpr uint32_t SORTED_PARTIAL_WORDS = 18;  // sums[8] | head position | exclusive prefixes at that head [8] | pad
-
-struct SortedItemEval {
-    uint32_t flag, cls;
-    bool has_in, alloc;
-};
-__device__ __forceinline__ SortedItemEval sorted_eval(const SortedArgs& a, uint32_t i, bool indirect) {
-    SortedItemEval e;
-    uint32_t it[4] = {0xFFFFFFFFu, 0, 0, 0}, pv[4] = {0xFFFFFFFFu, 0, 0, 0};
-    const bool in = i < a.n_items;
-    if (in) {
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) it[k] = a.items[4u * i + k];
-        if (i)
-#pragma unroll
-            for (uint32_t k = 0; k < 4u; ++k) pv[k] = a.items[4u * (i - 1u) + k];
-    }
-    e.has_in = in && it[0] != 0xFFFFFFFFu;
-    const bool meta = e.has_in && a.automatic_batching && (it[3] & 2u);
-    const bool prev_in = in && i && pv[0] != 0xFFFFFFFFu;
-    const bool prev_meta = prev_in && a.automatic_batching && (pv[3] & 2u);
-    e.flag = SORTED_SKIP;
-    if (e.has_in) {
-        e.flag = SORTED_HEAD;
-        if (meta && prev_meta && it[1] == pv[1]) {
-            if (it[2] == pv[2]) e.flag = SORTED_OK;
-            else if (indirect) e.flag = SORTED_BREAK_BATCH;
-        }
-    }
-    e.cls = it[3] & 1u;
-    e.alloc = indirect && (e.flag == SORTED_HEAD || e.flag == SORTED_BREAK_BATCH);
-    return e;
-}
-__device__ __forceinline__ void sorted_values(const SortedItemEval& e, uint32_t (&v)[8]) {
-    v[0] = e.has_in ? 1u : 0u;
-    v[1] = (e.has_in && !e.cls) ? 1u : 0u;
-    v[2] = (e.has_in && e.cls) ? 1u : 0u;
-    v[3] = (e.alloc && !e.cls) ? 1u : 0u;
-    v[4] = (e.alloc && e.cls) ? 1u : 0u;
-    v[5] = e.flag == SORTED_BREAK_BATCH ? 1u : 0u;
-    v[6] = e.flag == SORTED_HEAD ? 1u : 0u;
-    v[7] = (e.flag == SORTED_HEAD && e.cls) ? 1u : 0u;
-}
-// the latest head at or before each item of the round, as index + 1 (0 = none): wave max-scan, then the waves in front
-__device__ __forceinline__ uint32_t sorted_head_scan(uint32_t hx, uint32_t before_round, uint32_t* lds_head) {
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (uint32_t off = 1; off < 64u; off <<= 1) {
-        const uint32_t up = __shfl_up(hx, off, 64);
-        if (lane >= off && up > hx) hx = up;
-    }
-    if (lane == 63u) lds_head[wv] = hx;
-    __syncthreads();
-    uint32_t before = before_round;
-    for (uint32_t k = 0; k < wv; ++k) before = lds_head[k] > before ? lds_head[k] : before;
-    return hx > before ? hx : before;
-}
-
-__global__ void __launch_bounds__(256) k_batch_sorted_partials(SortedArgs a, uint32_t* partials) {
-    __shared__ uint32_t lds_scan[4][8];
-    __shared__ uint32_t lds_head[4];
-    __shared__ uint32_t lds_hex[9];  // [0] head position + 1 (0 = none), [1..8] the exclusive prefixes at it
-    const bool indirect = a.no_indirect == 0u && a.merge_only == 0u;
-    const uint32_t lo = blockIdx.x * SORTED_TILE, hi = lo + SORTED_TILE < a.n_items ? lo + SORTED_TILE : a.n_items;
-    uint32_t carry[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (threadIdx.x < 9u) lds_hex[threadIdx.x] = 0u;
-    __syncthreads();
-    for (uint32_t i0 = lo; i0 < hi; i0 += 256u) {
-        const uint32_t i = i0 + threadIdx.x;
-        SortedItemEval e = sorted_eval(a, i < hi ? i : a.n_items, indirect);
-        uint32_t v[8], tot[8];
-        sorted_values(e, v);
-        block_scan_multi<8, 256>(v, lds_scan, tot);
-        const uint32_t mine = e.flag == SORTED_HEAD ? i + 1u : 0u;
-        const uint32_t hx = sorted_head_scan(mine, 0u, lds_head);
-        __syncthreads();
-        // the round's last head is the last thread's running maximum; its owner records its prefixes
-        if (threadIdx.x == 255u) lds_head[0] = hx;
-        __syncthreads();
-        const uint32_t round_last = lds_head[0];
-        if (mine && mine == round_last) {
-            lds_hex[0] = mine;
-#pragma unroll
-            for (uint32_t q = 0; q < 8u; ++q) lds_hex[1u + q] = carry[q] + v[q];
-        }
-#pragma unroll
-        for (uint32_t q = 0; q < 8u; ++q) carry[q] += tot[q];
-        __syncthreads();
-    }
-    uint32_t* p = partials + (size_t)blockIdx.x * SORTED_PARTIAL_WORDS;
-    if (threadIdx.x < 8u) p[threadIdx.x] = carry[threadIdx.x];  // (carry is uniform across the workgroup)
-    if (threadIdx.x < 9u) p[8u + threadIdx.x] = lds_hex[threadIdx.x];
-}
-
-__global__ void __launch_bounds__(256) k_batch_sorted_tiles(SortedArgs a, const uint32_t* __restrict__ partials, uint32_t n_tiles) {
-    __shared__ uint32_t lds_scan[4][8];
-    __shared__ uint32_t lds_head[4];
-    __shared__ uint32_t lds_th;
-    const bool indirect = a.no_indirect == 0u && a.merge_only == 0u;
-    const uint32_t tile = blockIdx.x, lo = tile * SORTED_TILE, hi = lo + SORTED_TILE < a.n_items ? lo + SORTED_TILE : a.n_items;
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    // ---- what the tiles in front leave: the eight carries, and the last head among them with its absolute values
-    uint32_t carry[8], th1;  // th1 = 1 + the last tile in front that holds a head (0 = none)
-    {
-        uint32_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tot[8];
-        uint32_t best = 0u;
-        for (uint32_t t = threadIdx.x; t < tile; t += 256u) {
-            const uint32_t* p = partials + (size_t)t * SORTED_PARTIAL_WORDS;
-#pragma unroll
-            for (uint32_t q = 0; q < 8u; ++q) v[q] += p[q];
-            if (p[8]) best = t + 1u;  // (t ascends per thread)
-        }
-        block_scan_multi<8, 256>(v, lds_scan, tot);
-#pragma unroll
-        for (uint32_t q = 0; q < 8u; ++q) carry[q] = tot[q];
-#pragma unroll
-        for (uint32_t off = 32u; off; off >>= 1) {
-            const uint32_t o = __shfl_xor(best, off, 64);
-            best = o > best ? o : best;
-        }
-        if (lane == 0) lds_head[wv] = best;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t b = lds_head[0];
-            for (uint32_t k = 1; k < 4u; ++k) b = lds_head[k] > b ? lds_head[k] : b;
-            lds_th = b;
-        }
-        __syncthreads();
-        th1 = lds_th;
-    }
-    uint32_t in_head = 0xFFFFFFFFu, in_out = 0, in_ip = 0, in_brk = 0, in_sets = 0, in_sets1 = 0;  // the head that governs from in front
-    if (th1) {
-        uint32_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ct[8];
-        for (uint32_t t = threadIdx.x; t + 1u < th1; t += 256u) {
-            const uint32_t* p = partials + (size_t)t * SORTED_PARTIAL_WORDS;
-#pragma unroll
-            for (uint32_t q = 0; q < 8u; ++q) v[q] += p[q];
-        }
-        block_scan_multi<8, 256>(v, lds_scan, ct);  // ct = the carries of tile th1 - 1
-        const uint32_t* p = partials + (size_t)(th1 - 1u) * SORTED_PARTIAL_WORDS;
-        in_head = p[8] - 1u;
-        const uint32_t cls_h = a.items[4u * in_head + 3u] & 1u;
-        in_out = a.initial.output_mesh_uniform_index + ct[0] + p[9];
-        in_ip = cls_h ? a.initial.indirect_parameters_index[1] + ct[4] + p[13] : a.initial.indirect_parameters_index[0] + ct[3] + p[12];
-        in_brk = ct[5] + p[14];  // inclusive == exclusive at a head
-        in_sets = ct[6] + p[15];
-        in_sets1 = ct[7] + p[16];
-    }
-    // ---- phase A over the tile (k_batch_sorted's, with the carries above)
-    uint32_t before_round = in_head + 1u;
-    for (uint32_t i0 = lo; i0 < hi; i0 += 256u) {
-        const uint32_t i = i0 + threadIdx.x;
-        const bool in = i < hi;
-        SortedItemEval e = sorted_eval(a, in ? i : a.n_items, indirect);
-        uint32_t v[8], tot[8];
-        sorted_values(e, v);
-        block_scan_multi<8, 256>(v, lds_scan, tot);
-        const uint32_t hx = sorted_head_scan(e.flag == SORTED_HEAD ? i + 1u : 0u, before_round, lds_head);
-        if (in) {
-            a.scratch[0u * a.n_items + i] = a.initial.output_mesh_uniform_index + carry[0] + v[0];
-            a.scratch[1u * a.n_items + i] = e.alloc ? (e.cls ? a.initial.indirect_parameters_index[1] + carry[4] + v[4]
-                                                             : a.initial.indirect_parameters_index[0] + carry[3] + v[3])
-                                                    : 0xFFFFFFFFu;
-            a.scratch[2u * a.n_items + i] = carry[5] + v[5] + (e.flag == SORTED_BREAK_BATCH ? 1u : 0u);  // inclusive
-            a.scratch[3u * a.n_items + i] = hx - 1u;
-            a.scratch[4u * a.n_items + i] = e.cls ? a.initial.work_item_index[1] + carry[2] + v[2] : a.initial.work_item_index[0] + carry[1] + v[1];
-            a.scratch[5u * a.n_items + i] = carry[6] + v[6];
-            a.scratch[6u * a.n_items + i] = carry[7] + v[7];
-            a.scratch[7u * a.n_items + i] = e.flag;
-        }
-        __syncthreads();
-        if (threadIdx.x == 255u) lds_th = hx;
-        __syncthreads();
-        before_round = lds_th;
-#pragma unroll
-        for (uint32_t q = 0; q < 8u; ++q) carry[q] += tot[q];
-        __syncthreads();
-    }
-    if (tile + 1u == n_tiles && threadIdx.x == 0) {
-        a.totals[0] = a.initial.work_item_index[0] + (a.merge_only ? 0u : carry[1]);
-        a.totals[1] = a.initial.work_item_index[1] + (a.merge_only ? 0u : carry[2]);
-        a.totals[2] = a.initial.indirect_parameters_index[0] + carry[3];
-        a.totals[3] = a.initial.indirect_parameters_index[1] + carry[4];
-        a.totals[4] = a.initial.batch_set_index[0] + (indirect ? carry[6] - carry[7] : 0u);
-        a.totals[5] = a.initial.batch_set_index[1] + (indirect ? carry[7] : 0u);
-        a.totals[6] = a.initial.output_mesh_uniform_index + carry[0];
-        a.totals[7] = carry[6];
-        a.totals[8] = 0u;
-    }
-    __threadfence();
-    __syncthreads();
-    // ---- phase B over the tile: the tile's own scratch comes back through L2; a head in front of the tile comes from the partials
-    auto ld = [&](uint32_t plane, uint32_t i) { return __builtin_nontemporal_load(a.scratch + plane * a.n_items + i); };
-    for (uint32_t i0 = lo; i0 < hi; i0 += 256u) {
-        const uint32_t i = i0 + threadIdx.x;
-        if (i >= hi) continue;
-        const uint32_t flag = ld(7, i);
-        if (flag == SORTED_SKIP) continue;
-        const uint32_t cls = a.items[4u * i + 3u] & 1u;
-        const uint32_t out = ld(0, i), h = ld(3, i);
-        const bool h_in_front = h < lo;
-        const uint32_t ip_h = h_in_front ? in_ip : ld(1, h);
-        const uint32_t brk_h = h_in_front ? in_brk : ld(2, h);
-        const uint32_t cur = ip_h + (ld(2, i) - brk_h);  // indirect_parameters_index_range.end - 1
-        if (!a.merge_only) {
-            if (indirect && flag != SORTED_OK) {
-                uint32_t* md = (cls ? a.metadata[1] : a.metadata[0]) + 5u * ld(1, i);
-                md[0] = out;
-                md[1] = 0xFFFFFFFFu;
-                md[2] = md[3] = md[4] = 0u;
-            }
-            uint32_t* wi = (cls ? a.work_items[1] : a.work_items[0]) + 2u * ld(4, i);
-            wi[0] = a.items[4u * i];
-            wi[1] = indirect ? cur : out;
-        }
-        // the set's last item: the next item is missing, has no input index, or heads a new set (the next tile's first item:
-        // evaluated from the items themselves)
-        uint32_t next_flag = SORTED_SKIP;
-        if (i + 1u < hi) next_flag = ld(7, i + 1u);
-        else if (i + 1u < a.n_items) next_flag = sorted_eval(a, i + 1u, indirect).flag;
-        const bool last = i + 1u == a.n_items || next_flag == SORTED_SKIP || next_flag == SORTED_HEAD;
-        if (last) {
-            const uint32_t cls_h = a.items[4u * h + 3u] & 1u;
-            const uint32_t k = h_in_front ? in_sets : ld(5, h);
-            uint32_t* b = a.batches + 6u * k;
-            b[0] = h;
-            b[1] = h_in_front ? in_out : ld(0, h);
-            b[2] = out + 1u;
-            b[3] = indirect ? ip_h : 0xFFFFFFFFu;
-            b[4] = indirect ? cur + 1u : 0xFFFFFFFFu;
-            b[5] = cls_h;
-            if (indirect) {  // add_batch_set at flush, in flush order per class (:1787-1793)
-                const uint32_t sets1 = h_in_front ? in_sets1 : ld(6, h);
-                const uint32_t slot = cls_h ? a.initial.batch_set_index[1] + sets1 : a.initial.batch_set_index[0] + (k - sets1);
-                uint32_t* bset = (cls_h ? a.batch_sets[1] : a.batch_sets[0]) + 2u * slot;
-                bset[0] = 0u;
-                bset[1] = ip_h;
-            }
-        }
-    }
-}
+// (sorted phases: kernels_sorted.hip)
 
 }  // namespace
 
@@ -1263,31 +864,12 @@ hipError_t launch_batch_build(const BatchArgs& a_in, hipStream_t stream, void (*
         MI_LAUNCH(k_batch_clear_bounds, dim3((2u * a.n_buckets + 255u) / 256u), dim3(256), 0, stream, a);
         MI_LAUNCH(k_batch_bounds, dim3(cap / 256u), dim3(256), 0, stream, a);
         MARK(K_BATCH_PLAN);
-        MI_LAUNCH((k_batch_plan<false, 1024>), dim3(1), dim3(1024), 0, stream, a);
+        MI_LAUNCH((k_batch_plan<false, 512>), dim3(1), dim3(512), 0, stream, a);  // (512 threads: 256 registers each -- the 1 024-thread build spilled 126 of its 128 into scratch in the middle of the scans)
         MARK(K_BATCH_EMIT);
         MI_LAUNCH(k_batch_emit<false>, dim3(cap / 256u + a.n_sets), dim3(256), 0, stream, a, cap / 256u);
     }
     MARK(K_NUM_KERNELS);
 #undef MARK
-    return hipGetLastError();
-}
-
-uint32_t batch_sorted_partial_words(uint32_t n_items) { return ((n_items + SORTED_TILE - 1u) / SORTED_TILE) * SORTED_PARTIAL_WORDS; }
-hipError_t launch_batch_sorted(const SortedArgs& a, hipStream_t stream, void (*mark)(void*, uint32_t), void* mctx, uint32_t* partials,
-                               uint32_t sorted_one_wg_limit) {
-    if (mark) mark(mctx, K_BATCH_SORTED);
-    // up to one_wg_limit items: one workgroup, one launch (latency); beyond: tiles over the whole chip, two launches
-    if (a.n_items <= sorted_one_wg_limit || !partials) {
-        // (a 1 024-thread build of this kernel spilled 118 registers and was no faster per item: longer phases go to the tiles)
-        MI_LAUNCH(k_batch_sorted<256>, dim3(1), dim3(256), 0, stream, a);
-    } else {
-        const uint32_t n_tiles = (a.n_items + SORTED_TILE - 1u) / SORTED_TILE;
-        if (mark) mark(mctx, K_BATCH_SCAN);  // (timer slots: the partials under k_batch_scan, the tiles under k_batch_sorted)
-        MI_LAUNCH(k_batch_sorted_partials, dim3(n_tiles), dim3(256), 0, stream, a, partials);
-        if (mark) mark(mctx, K_BATCH_SORTED);
-        MI_LAUNCH(k_batch_sorted_tiles, dim3(n_tiles), dim3(256), 0, stream, a, (const uint32_t*)partials, n_tiles);
-    }
-    if (mark) mark(mctx, K_NUM_KERNELS);
     return hipGetLastError();
 }
 

@@ -210,7 +210,7 @@ def test_phase_tables_can_change_between_builds(ctx_factory):
         assert_same_phase(ctx.batch_download(), O.batch_phase(rows, ph))
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 700, 1024, 1025, 9000, 100_000])
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 700, 1024, 1025, 4095, 4096, 4097, 8191, 8192, 8193, 9000, 12_289, 100_000])
 def test_sorted_build_matches_oracle(ctx_factory, n):
     """batch_and_prepare_sorted_render_phase (gpu_preprocessing.rs:1850-2061) and the range merge of batching/mod.rs:219-244."""
     ctx = ctx_factory()
@@ -235,10 +235,10 @@ def test_sorted_build_matches_oracle(ctx_factory, n):
 
 
 def test_sorted_build_long_runs_cross_chunks(ctx_factory):
-    """Batch sets longer than the kernel's 1024-item chunk, and one that spans the whole phase."""
+    """Batch sets longer than a thread's items, than a tile (4 096 items), and one that spans the whole phase; every item a set."""
     ctx = ctx_factory()
     ctx.resize(1)
-    for n, run in ((5000, 3000), (4096, 100_000), (3000, 1)):
+    for n, run in ((5000, 3000), (4096, 100_000), (3000, 1), (20_000, 9000), (30_000, 1_000_000), (8192, 17), (8200, 1)):
         items = W.sorted_items(n, seed=3, run=run, no_input_fraction=0.0, no_meta_fraction=0.0)
         ctx.batch_sorted_build(items, True, False, False, INITIAL)
         got = ctx.batch_download()

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bevy_amd import build as mi_build  # the library's own flags, per-file ones included (FILE_FLAGS)
 out = []
-for f in ("kernels_flat.hip", "kernels_tree.hip", "kernels_cluster.hip", "kernels_batch.hip"):
+for f in ("kernels_flat.hip", "kernels_tree.hip", "kernels_cluster.hip", "kernels_batch.hip", "kernels_sorted.hip", "kernels_cells.hip"):
     r = subprocess.run(["/opt/rocm/bin/hipcc"] + [x for x in mi_build.FLAGS if x != "-shared"] + mi_build.FILE_FLAGS.get(f, [])
                        + ["-x", "hip", "-c", os.path.join(ROOT, "bevy_amd", "csrc", f), "-o", "/tmp/_kr.o",
                           "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)

@@ -360,3 +360,92 @@ def shard_hierarchy(parent, level_offsets, world, rank=None, slack=1.10):
         owned = (node_rank[rows] == r) | (rep_owner[rows] == r)
         out.append(dict(rows=rows, owned=owned, parent=lp, level_offsets=lvl.astype(np.uint32)))
     return out if rank is None else out[rank]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Light-cluster assignment sharded over the clusterable objects
+# ---------------------------------------------------------------------------------------------------------------------
+def shard_objects(n_objects, world, rank):
+    """Contiguous range [lo, hi) of the gathered object list (assign.rs:190-296: point lights, spot lights, rect lights, probes,
+    decals, in that order) that `rank` assigns.  Contiguous ranges keep the reference's push order: a cluster's entities are
+    pushed in list order (assign.rs:740-800), i.e. rank 0's objects of the cluster first, then rank 1's, each in local order."""
+    per = -(-n_objects // world) if world else n_objects
+    lo = min(n_objects, rank * per)
+    return lo, min(n_objects, lo + per)
+
+
+def merge_cluster_assignments(local, first_object, world, rank, group=None, device=None, always_exchange=False):
+    """Every rank has assigned ITS objects (`local` = what mi_cluster_assign / mi_cluster_download return for them: offsets[C + 1],
+    indices[total] as LOCAL object numbers, counts[C, 6], farthest_z, total); this builds the assignment of the whole list on every
+    rank with three collectives (RCCL over xGMI on GPUs -- device = the rank's cuda device --, gloo in the CPU tests):
+
+      1. all-gather of the ranks' per-cluster entry counts ([C] words each: 13.8 KB at 16 x 9 x 24) and, with them, of the six
+         per-type counts (summed), farthest_z (max) and the totals;
+      2. (local) global offsets = prefix over the clusters of the summed counts; rank r's entries of cluster c start at
+         offsets[c] + the counts of ranks < r in that cluster -- order within a cluster = (rank, local order) = the unsharded push
+         order, because the shards are contiguous ranges of the gathered list;
+      3. all-gather of the ranks' index segments (padded to the longest), scattered into place with the object numbers made global.
+
+    Returns (offsets[C + 1] uint32, indices[total] uint32, counts[C, 6] uint32, farthest_z float32, total int): identical to the
+    unsharded mi_cluster_assign of the concatenated list.  The reference has no counterpart (one process)."""
+    import torch
+    import torch.distributed as dist
+    off_l, idx_l, cnt_l, far_l, tot_l = local
+    off_l = np.asarray(off_l, np.int64)
+    n_clusters = len(off_l) - 1
+    per_cluster = torch.from_numpy(np.diff(off_l)).to(device)
+    counts6 = torch.from_numpy(np.ascontiguousarray(np.asarray(cnt_l, np.int64).reshape(n_clusters, 6))).to(device)
+    far = torch.tensor([float(far_l)], dtype=torch.float32, device=device)
+    head = torch.tensor([int(tot_l), int(first_object)], dtype=torch.int64, device=device)
+    if world == 1 and not always_exchange:  # (always_exchange: run the collectives on a one-rank group all the same -- tests)
+        idx = np.asarray(idx_l[:int(tot_l)], np.uint32) + np.uint32(first_object)
+        return off_l.astype(np.uint32), idx, np.asarray(cnt_l, np.uint32).reshape(n_clusters, 6), np.float32(far_l), int(tot_l)
+    # ---- 1. counts ----
+    all_counts = torch.empty(world * n_clusters, dtype=torch.int64, device=device)  # (flat: what every backend's all-gather takes)
+    dist.all_gather_into_tensor(all_counts, per_cluster, group=group)
+    all_counts = all_counts.view(world, n_clusters)
+    heads = torch.empty(world * 2, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(heads, head, group=group)
+    heads = heads.view(world, 2)
+    dist.all_reduce(counts6, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(far, op=dist.ReduceOp.MAX, group=group)
+    # ---- 2. where everybody's entries go ----
+    cluster_tot = all_counts.sum(0)
+    offsets = torch.zeros(n_clusters + 1, dtype=torch.int64, device=device)
+    offsets[1:] = torch.cumsum(cluster_tot, 0)
+    rank_before = torch.cumsum(all_counts, 0) - all_counts  # [world, C]: entries of lower ranks in each cluster
+    totals = heads[:, 0]
+    total = int(totals.sum().item())
+    longest = int(totals.max().item())
+    # ---- 3. segments ----
+    seg = torch.zeros(max(longest, 1), dtype=torch.int64, device=device)
+    seg[:int(tot_l)] = torch.from_numpy(np.asarray(idx_l[:int(tot_l)], np.int64)).to(device)
+    segs = torch.empty(world * max(longest, 1), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(segs, seg, group=group)
+    segs = segs.view(world, max(longest, 1))
+    out = torch.zeros(max(total, 1), dtype=torch.int64, device=device)
+    for r in range(world):
+        t_r = int(totals[r].item())
+        if t_r == 0:
+            continue
+        c_r = all_counts[r]
+        local_off = torch.cumsum(c_r, 0) - c_r  # rank r's own CSR offsets
+        # entry j of rank r lies in the cluster its offsets say; its place = offsets[c] + rank_before[r, c] + (j - local_off[c])
+        shift = torch.repeat_interleave(offsets[:-1] + rank_before[r] - local_off, c_r)
+        out[shift + torch.arange(t_r, device=device)] = segs[r, :t_r] + heads[r, 1]
+    return (offsets.cpu().numpy().astype(np.uint32), out[:total].cpu().numpy().astype(np.uint32), counts6.cpu().numpy().astype(np.uint32),
+            np.float32(far.item()), total)
+
+
+def cluster_assign_sharded(ctx, view, pos_range, obj_type=None, layer_mask=None, spot_dir=None, spot_sin_cos=None, world=1, rank=0, group=None,
+                           device=None, always_exchange=False):
+    """assign_objects_to_clusters with the gathered object list range-sharded over the ranks: this rank's context assigns objects
+    [lo, hi) (mi_cluster_assign), merge_cluster_assignments builds the whole view's assignment on every rank.  All arrays are the FULL
+    list (every rank gathers the same list from its copy of the World); only the slice is uploaded."""
+    n = len(pos_range) // 4
+    lo, hi = shard_objects(n, world, rank)
+
+    def cut(a, k):
+        return None if a is None else np.ascontiguousarray(np.asarray(a).reshape(n, k)[lo:hi]).reshape(-1)
+    local = ctx.cluster_assign(view, cut(pos_range, 4), cut(obj_type, 1), cut(layer_mask, 1), cut(spot_dir, 3), cut(spot_sin_cos, 2))
+    return merge_cluster_assignments(local, lo, world, rank, group, device, always_exchange)

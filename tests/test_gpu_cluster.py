@@ -241,3 +241,32 @@ def test_baseline_tree_config_at_full_size(ctx_factory, tile_mode):
     g, chg = ctx.download_global_transforms()
     assert g.tobytes() == g2.tobytes()
     assert_bits(chg, chg2, "change ticks of the sparse frame")
+
+
+def test_sharded_assignment_over_a_one_rank_rccl_group(ctx_factory):
+    """SURVEY.md 8e row 3 on the GPU box: bevy_amd.sharding.cluster_assign_sharded with the three collectives running over RCCL
+    (a one-rank communicator: everything but the wire; world sizes 2 and 3 run over gloo in tests/test_sharding_clusters_gloo.py),
+    against the unsharded HIP assignment and the oracle.  Unmeasured on more than one GPU."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from bevy_amd import sharding
+    from test_sharding_clusters_gloo import scene
+    pr, ty, layers, sd, sc = scene(20_000, 3_000, seed=4)
+    view, keep, ov = both_views(W.many_cubes_camera(7))
+    want = O.assign_objects_to_clusters(ov, pr, ty, layers, sd, sc)
+    ctx = ctx_factory()
+    assert_same_assignment(ctx.cluster_assign(view, pr, ty, layers, sd, sc), want)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        got = sharding.cluster_assign_sharded(ctx, view, pr, ty, layers, sd, sc, world=1, rank=0, device=torch.device("cuda", 0), always_exchange=True)
+    finally:
+        dist.destroy_process_group()
+    assert_same_assignment(got, want)
+    assert got[4] > 10_000

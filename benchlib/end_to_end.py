@@ -47,7 +47,7 @@ def end_to_end(ctx, wl, frames=12, cpu_frame_ms=None):
     ctx.propagate(B.PROPAGATE_ALL_DIRTY)
     ctx.synchronize()
     bufs = api.FrameResultBuffers(n, n, views[0].n_clusters, 1 << 20, in_place=True)
-    for pct in (1, 10, 100):
+    for pct, comps in ((1, "trs"), (10, "trs"), (100, "trs"), (100, "r")):  # "r": every cube rotates (many_cubes --rotate-cubes): rotations only go up
         k = n * pct // 100
         rows = np.sort(rng.choice(n, k, replace=False)).astype(np.uint32) if pct < 100 else None
         times, t_in, t_commit, t_run, t_out, h2d, d2h = [], [], [], [], [], 0, 0
@@ -73,8 +73,12 @@ def end_to_end(ctx, wl, frames=12, cpu_frame_ms=None):
                 commit_s = 0.0
                 for lo in range(0, n, chunk):
                     m = min(chunk, n - lo)
-                    w, _, wt, wr, ws = ctx.map_upload_window(m, dense=True)
-                    wt[:], wr[:], ws[:] = t3[lo:lo + m].reshape(-1), r4[lo:lo + m].reshape(-1), s3[lo:lo + m].reshape(-1)
+                    w, _, wt, wr, ws = ctx.map_upload_window(m, dense=True, components=comps)
+                    if wt is not None:
+                        wt[:] = t3[lo:lo + m].reshape(-1)
+                    wr[:] = r4[lo:lo + m].reshape(-1)
+                    if ws is not None:
+                        ws[:] = s3[lo:lo + m].reshape(-1)
                     tc = time.perf_counter()
                     ctx.commit_upload_window(w, m, first_row=lo)
                     commit_s += time.perf_counter() - tc
@@ -90,14 +94,14 @@ def end_to_end(ctx, wl, frames=12, cpu_frame_ms=None):
                 t_commit.append(commit_s)
                 t_run.append(t2 - t1)
                 t_out.append(t3_ - t2)
-            h2d = k * 44 if rows is not None else n * 40
+            h2d = k * 44 if rows is not None else n * (40 if comps == "trs" else 16)
             d2h = got_g * 52 + len(vis_rows) * 4 + len(off) * 4 + counts.size * 4 + total * 4
         med = float(np.median(times))
         eff = (h2d + d2h) / med / 1e9
         # 1.0 = the time both directions would take one after the other at their peaks (a frame whose results depend on its whole input);
         # where the library overlaps them (100 % dirty: results ahead of the frame) the figure can pass 1.0, up to 2.0 for equal halves
         link_s = h2d / (link["h2d"] * 1e9) + d2h / (link["d2h"] * 1e9)
-        out[f"{pct}pct_dirty"] = {"dirty_rows": int(k), "us_per_frame": round(1e6 * med, 1), "entities_per_s": round(wl.units / med, 1),
+        out[f"{pct}pct_dirty" + ("" if comps == "trs" else "_rotations_only")] = {"dirty_rows": int(k), "us_per_frame": round(1e6 * med, 1), "entities_per_s": round(wl.units / med, 1),
                                   "h2d_bytes": int(h2d), "d2h_bytes": int(d2h), "pcie_GBps_effective": round(eff, 2),
                                   "pcie_frac": round(link_s / med, 3),
                                   "stage_us": {"gather_into_window_and_commit": round(1e6 * float(np.median(t_in)), 1),

@@ -148,6 +148,7 @@ class UploadWindow(C.Structure):
 
 
 UPLOAD_DENSE = 0x1
+UPLOAD_TRANSLATION, UPLOAD_ROTATION, UPLOAD_SCALE = 0x2, 0x4, 0x8
 
 
 class View(C.Structure):
@@ -425,12 +426,14 @@ class Context:
         self._ck(self._lib.mi_upload_transforms_indexed(self._h, len(rw), _ptr(rw, C.c_uint32), _ptr(t, C.c_float),
                                                         _ptr(r, C.c_float), _ptr(s, C.c_float)))
 
-    def map_upload_window(self, capacity, dense=False):
+    def map_upload_window(self, capacity, dense=False, components="trs"):
         """-> (window, rows u32[capacity] or None, translation f32[3 capacity], rotation f32[4 capacity], scale f32[3 capacity]): numpy views
-        on the library's pinned memory, to be filled in place and handed over with commit_upload_window."""
+        on the library's pinned memory, to be filled in place and handed over with commit_upload_window.  components: which of
+        translation / rotation / scale the window carries ("trs" = all; "r" = rotations only, ...): the others come back as None."""
         w = UploadWindow()
-        self._ck(self._lib.mi_map_upload_window(self._h, int(capacity), UPLOAD_DENSE if dense else 0, C.byref(w)))
-        arr = lambda p, k, dt: np.ctypeslib.as_array(p, shape=(k * capacity,)).view(dt) if capacity else np.zeros(0, dt)
+        comp = 0 if set(components) == set("trs") else sum({"t": UPLOAD_TRANSLATION, "r": UPLOAD_ROTATION, "s": UPLOAD_SCALE}[c] for c in set(components))
+        self._ck(self._lib.mi_map_upload_window(self._h, int(capacity), (UPLOAD_DENSE if dense else 0) | comp, C.byref(w)))
+        arr = lambda p, k, dt: (np.ctypeslib.as_array(p, shape=(k * capacity,)).view(dt) if capacity else np.zeros(0, dt)) if p else None
         return w, (None if dense else arr(w.rows, 1, np.uint32)), arr(w.translation, 3, np.float32), arr(w.rotation, 4, np.float32), arr(w.scale, 3, np.float32)
 
     def commit_upload_window(self, window, n, first_row=0):

@@ -1176,11 +1176,11 @@ static int32_t scatter_indexed(mi_ctx* ctx, const uint32_t* rows, const float* t
         HIP_TRY(ctx, hipHostGetDevicePointer(&d, ctx->gs_host, 0));
         g_ahead = (float*)d;
     }
-    void *d_rows = nullptr, *d_t = nullptr, *d_r = nullptr, *d_s = nullptr;
+    void *d_rows = nullptr, *d_t = nullptr, *d_r = nullptr, *d_s = nullptr;  // (a component the window does not carry: nullptr)
     HIP_TRY(ctx, hipHostGetDevicePointer(&d_rows, (void*)rows, 0));
-    HIP_TRY(ctx, hipHostGetDevicePointer(&d_t, (void*)t, 0));
-    HIP_TRY(ctx, hipHostGetDevicePointer(&d_r, (void*)r, 0));
-    HIP_TRY(ctx, hipHostGetDevicePointer(&d_s, (void*)s, 0));
+    if (t) HIP_TRY(ctx, hipHostGetDevicePointer(&d_t, (void*)t, 0));
+    if (r) HIP_TRY(ctx, hipHostGetDevicePointer(&d_r, (void*)r, 0));
+    if (s) HIP_TRY(ctx, hipHostGetDevicePointer(&d_s, (void*)s, 0));
     if (!ctx->have_changed) {
         // First use of the change column: rows a propagate has already consumed count as unchanged from here on.  Rows
         // that have not been through one yet are still Added<GlobalTransform> (systems.rs:45-50) and keep their mark.
@@ -1255,8 +1255,13 @@ int32_t mi_map_upload_window(mi_ctx* ctx, uint32_t capacity, uint32_t flags, mi_
     out->flags = flags;
     out->capacity = capacity;
     if (capacity == 0) return MI_OK;
+    if (flags & ~(MI_UPLOAD_DENSE | MI_UPLOAD_TRANSLATION | MI_UPLOAD_ROTATION | MI_UPLOAD_SCALE))
+        return fail(ctx, MI_ERR_INVALID_ARG, "mi_map_upload_window: unknown flags 0x%x", flags);
     const bool dense = (flags & MI_UPLOAD_DENSE) != 0;
-    const size_t need = (((size_t)capacity * (dense ? 40 : 44) + 64) + 255) & ~(size_t)255;
+    const uint32_t comp = flags & (MI_UPLOAD_TRANSLATION | MI_UPLOAD_ROTATION | MI_UPLOAD_SCALE);
+    const bool has_t = !comp || (comp & MI_UPLOAD_TRANSLATION), has_r = !comp || (comp & MI_UPLOAD_ROTATION), has_s = !comp || (comp & MI_UPLOAD_SCALE);
+    const size_t row_bytes = (dense ? 0u : 4u) + (has_t ? 12u : 0u) + (has_r ? 16u : 0u) + (has_s ? 12u : 0u);
+    const size_t need = (((size_t)capacity * row_bytes + 128) + 255) & ~(size_t)255;
     auto& chunks = ctx->win_chunks;
     if (ctx->win_open == 0 && !chunks.empty() && (chunks.size() > 1 || chunks.back().used + need > chunks.back().bytes)) {
         // nothing is mapped: recycle.  What the device still reads of earlier windows (DMA, the scatter kernel) has to be done
@@ -1294,9 +1299,15 @@ int32_t mi_map_upload_window(mi_ctx* ctx, uint32_t capacity, uint32_t flags, mi_
         out->rows = (uint32_t*)st;
         f = (float*)(out->rows + (((size_t)capacity + 3) & ~(size_t)3));  // 16-byte aligned columns
     }
-    out->translation = f;
-    out->rotation = f + 3 * (size_t)capacity + ((4 - (3 * (size_t)capacity) % 4) % 4);
-    out->scale = out->rotation + 4 * (size_t)capacity;
+    // the components the window carries, one after the other, each on a 16-byte boundary (the scatter kernel's wide loads)
+    auto take = [&](size_t floats) {
+        float* p = f;
+        f += (floats + 3) & ~(size_t)3;
+        return p;
+    };
+    out->translation = has_t ? take(3 * (size_t)capacity) : nullptr;
+    out->rotation = has_r ? take(4 * (size_t)capacity) : nullptr;
+    out->scale = has_s ? take(3 * (size_t)capacity) : nullptr;
     out->token = ctx->win_gen;
     ++ctx->win_open;
     return MI_OK;
@@ -1307,7 +1318,7 @@ int32_t mi_commit_upload_window(mi_ctx* ctx, const mi_upload_window* w, uint32_t
     if (!w) return fail(ctx, MI_ERR_INVALID_ARG, "mi_commit_upload_window: NULL");
     if (w->capacity == 0) return MI_OK;
     if (n > w->capacity) return fail(ctx, MI_ERR_INVALID_ARG, "mi_commit_upload_window: %u rows, the window holds %u", n, w->capacity);
-    const char* base = w->rows ? (const char*)w->rows : (const char*)w->translation;
+    const char* base = w->rows ? (const char*)w->rows : w->translation ? (const char*)w->translation : w->rotation ? (const char*)w->rotation : (const char*)w->scale;
     bool inside = false;
     for (auto& c : ctx->win_chunks) inside = inside || (base >= (const char*)c.p && base < (const char*)c.p + c.bytes);
     if (w->token != ctx->win_gen || !inside || ctx->win_open == 0)
@@ -1354,10 +1365,10 @@ int32_t mi_commit_upload_window(mi_ctx* ctx, const mi_upload_window* w, uint32_t
             for (uint32_t k = 0; k < parts; ++k) {
                 const size_t lo = (size_t)n * k / parts, cnt = (size_t)n * (k + 1) / parts - lo, at = first_row + lo;
                 const uint32_t ev = ctx->seq_pieces++;
-                if (cnt) {
-                    HIP_TRY(ctx, hipMemcpyAsync(ctx->t + 3 * at, w->translation + 3 * lo, cnt * 12, hipMemcpyHostToDevice, ctx->up_stream));
-                    HIP_TRY(ctx, hipMemcpyAsync(ctx->r + 4 * at, w->rotation + 4 * lo, cnt * 16, hipMemcpyHostToDevice, ctx->up_stream));
-                    HIP_TRY(ctx, hipMemcpyAsync(ctx->s + 3 * at, w->scale + 3 * lo, cnt * 12, hipMemcpyHostToDevice, ctx->up_stream));
+                if (cnt) {  // (a component the window does not carry keeps its column)
+                    if (w->translation) HIP_TRY(ctx, hipMemcpyAsync(ctx->t + 3 * at, w->translation + 3 * lo, cnt * 12, hipMemcpyHostToDevice, ctx->up_stream));
+                    if (w->rotation) HIP_TRY(ctx, hipMemcpyAsync(ctx->r + 4 * at, w->rotation + 4 * lo, cnt * 16, hipMemcpyHostToDevice, ctx->up_stream));
+                    if (w->scale) HIP_TRY(ctx, hipMemcpyAsync(ctx->s + 3 * at, w->scale + 3 * lo, cnt * 12, hipMemcpyHostToDevice, ctx->up_stream));
                 }
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_up[ev], ctx->up_stream));
                 // the context's stream follows piece by piece: everything launched on it from here on sees the upload so far
@@ -1383,9 +1394,9 @@ int32_t mi_commit_upload_window(mi_ctx* ctx, const mi_upload_window* w, uint32_t
         }
         trs_written(ctx);
         // pinned -> device: three DMA copies straight from the window (no staging copy)
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->t + 3 * (size_t)first_row, w->translation, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->r + 4 * (size_t)first_row, w->rotation, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->s + 3 * (size_t)first_row, w->scale, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+        if (w->translation) HIP_TRY(ctx, hipMemcpyAsync(ctx->t + 3 * (size_t)first_row, w->translation, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+        if (w->rotation) HIP_TRY(ctx, hipMemcpyAsync(ctx->r + 4 * (size_t)first_row, w->rotation, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+        if (w->scale) HIP_TRY(ctx, hipMemcpyAsync(ctx->s + 3 * (size_t)first_row, w->scale, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
         return MI_OK;
     }
     // (strictly monotonic rows -- a Changed<Transform> query over tables whose rows follow the Entity key, one way or the other -- are

@@ -1001,6 +1001,8 @@ __global__ void __launch_bounds__(256) k_upload_trs_indexed(const uint32_t* __re
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     if (clear_words)
         for (uint32_t w = gid; w < n_clear_words; w += gridDim.x * 256u) clear_words[w] = 0u;
+    // ft / fr / fs == nullptr: the window does not carry that component (MI_UPLOAD_TRANSLATION / _ROTATION / _SCALE): its column keeps
+    // what it holds, and a GlobalTransform written ahead takes the resident value
     for (uint32_t i0 = gid & ~63u; i0 < n; i0 += gridDim.x * 256u) {  // (wave-uniform trip count: the transpose below is a wave's)
         const uint32_t i = i0 + (threadIdx.x & 63u);
         const bool live = i < n;
@@ -1011,31 +1013,34 @@ __global__ void __launch_bounds__(256) k_upload_trs_indexed(const uint32_t* __re
             float4* lds_wave = lds_g[threadIdx.x >> 6];
             const uint64_t f4 = 48ull * (i0 >> 6);  // (i0 is a multiple of 64: float 3 * i0 is float4 48 * (i0 / 64))
             if (lane < 48u && 4ull * (f4 + lane) < 3ull * n) {  // (a float4 that starts inside the array; its tail lies in the window's padding)
-                lds_wave[lane] = reinterpret_cast<const float4*>(ft)[f4 + lane];
-                lds_wave[48u + lane] = reinterpret_cast<const float4*>(fs)[f4 + lane];
+                if (ft) lds_wave[lane] = reinterpret_cast<const float4*>(ft)[f4 + lane];
+                if (fs) lds_wave[48u + lane] = reinterpret_cast<const float4*>(fs)[f4 + lane];
             }
-            if (live) {
+            if (live && fr) {
                 const float4 q4 = reinterpret_cast<const float4*>(fr)[i];
                 qq = V4{q4.x, q4.y, q4.z, q4.w};
             }
             MI_WAVE_LDS_SYNC();
             if (live) {
                 const float* lf = reinterpret_cast<const float*>(lds_wave);
-                tt = V3{lf[3u * lane], lf[3u * lane + 1u], lf[3u * lane + 2u]};
-                ss = V3{lf[192u + 3u * lane], lf[192u + 3u * lane + 1u], lf[192u + 3u * lane + 2u]};
+                if (ft) tt = V3{lf[3u * lane], lf[3u * lane + 1u], lf[3u * lane + 2u]};
+                if (fs) ss = V3{lf[192u + 3u * lane], lf[192u + 3u * lane + 1u], lf[192u + 3u * lane + 2u]};
             }
             MI_WAVE_LDS_SYNC();  // (the transpose of the GlobalTransforms below reuses the buffer)
         }
         if (live) {
             const uint32_t row = rows[i];
             if constexpr (!WIDE) {
-                tt = V3{ft[3ull * i], ft[3ull * i + 1u], ft[3ull * i + 2u]};  // (dword loads: a caller's arrays promise no alignment)
-                ss = V3{fs[3ull * i], fs[3ull * i + 1u], fs[3ull * i + 2u]};
-                qq = V4{fr[4ull * i], fr[4ull * i + 1u], fr[4ull * i + 2u], fr[4ull * i + 3u]};
+                if (ft) tt = V3{ft[3ull * i], ft[3ull * i + 1u], ft[3ull * i + 2u]};  // (dword loads: a caller's arrays promise no alignment)
+                if (fs) ss = V3{fs[3ull * i], fs[3ull * i + 1u], fs[3ull * i + 2u]};
+                if (fr) qq = V4{fr[4ull * i], fr[4ull * i + 1u], fr[4ull * i + 2u], fr[4ull * i + 3u]};
             }
-            t[3ull * row] = tt.x, t[3ull * row + 1u] = tt.y, t[3ull * row + 2u] = tt.z;
-            s[3ull * row] = ss.x, s[3ull * row + 1u] = ss.y, s[3ull * row + 2u] = ss.z;
-            r[4ull * row] = qq.x, r[4ull * row + 1u] = qq.y, r[4ull * row + 2u] = qq.z, r[4ull * row + 3u] = qq.w;
+            if (ft) t[3ull * row] = tt.x, t[3ull * row + 1u] = tt.y, t[3ull * row + 2u] = tt.z;
+            else if (g_ahead) tt = V3{t[3ull * row], t[3ull * row + 1u], t[3ull * row + 2u]};
+            if (fs) s[3ull * row] = ss.x, s[3ull * row + 1u] = ss.y, s[3ull * row + 2u] = ss.z;
+            else if (g_ahead) ss = V3{s[3ull * row], s[3ull * row + 1u], s[3ull * row + 2u]};
+            if (fr) r[4ull * row] = qq.x, r[4ull * row + 1u] = qq.y, r[4ull * row + 2u] = qq.z, r[4ull * row + 3u] = qq.w;
+            else if (g_ahead) qq = V4{r[4ull * row], r[4ull * row + 1u], r[4ull * row + 2u], r[4ull * row + 3u]};
             changed[row] = (uint8_t)changed_gen;  // a stamp, not a flag: see row_changed() in kernels.h
             if (mark_bytes) mark_row_and_ancestors(row, parent_idx, mark_bytes, anc, 0xFFFFu);  // (a hierarchy is at most 65 535 levels deep here)
         }
@@ -1078,7 +1083,7 @@ hipError_t launch_upload_trs_indexed(const uint32_t* rows, const float* t_src, c
         const uint32_t cb = (n_clear_words + 1023u) / 1024u < 1024u ? (n_clear_words + 1023u) / 1024u : 1024u;
         blocks = blocks > cb ? blocks : cb;
     }
-    const bool wide = (((uintptr_t)t_src | (uintptr_t)r_src | (uintptr_t)s_src) & 15u) == 0;
+    const bool wide = (((uintptr_t)t_src | (uintptr_t)r_src | (uintptr_t)s_src) & 15u) == 0;  // (a missing component: nullptr, aligned)
     if (wide)
         MI_LAUNCH(k_upload_trs_indexed<true>, dim3(blocks), dim3(256), 0, stream, rows, t_src, r_src, s_src, n, t, r, s, changed, changed_gen, parent_idx,
                   mark_bytes, clear_words, n_clear_words, mark_bytes ? anc : nullptr, g_ahead, g_reversed ? 1u : 0u);

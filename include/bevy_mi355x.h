@@ -188,6 +188,13 @@ int32_t mi_upload_transforms_indexed(mi_ctx* ctx, uint32_t n, const uint32_t* ro
  * Two shapes of commit let the results of the frame travel ahead of it (mi_download_frame_results, below): dense windows that
  * carry the whole flat table one after the other, and one indexed window whose rows strictly ascend or descend. */
 #define MI_UPLOAD_DENSE 0x1u
+/* Component-granular windows: the window carries ONLY the named components of the rows (any combination; none of the three bits =
+ * all three, as before) -- the pointers of the others are NULL and their columns keep what they hold.  A scene in which every cube
+ * rotates (examples/stress_tests/many_cubes.rs:641-648, --rotate-cubes) sends 16 bytes per row instead of 40; one in which things
+ * only move, 12.  Everything else about a window is unchanged (dense or indexed, sequences in pieces, results travelling ahead). */
+#define MI_UPLOAD_TRANSLATION 0x2u
+#define MI_UPLOAD_ROTATION 0x4u
+#define MI_UPLOAD_SCALE 0x8u
 typedef struct mi_upload_window {
     uint32_t* rows;
     float* translation;

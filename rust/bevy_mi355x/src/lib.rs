@@ -126,6 +126,12 @@ pub struct Mi355x {
     rows_in_table_order: bool,
     /// The last steady-state upload of the fused frame carried every row through dense windows: its frame call is the all-rows one.
     every_row_moved: bool,
+    /// Which components of a changed `Transform` the steady-state upload windows carry: 0 = all three (default), else a combination of
+    /// `ffi::MI_UPLOAD_TRANSLATION | MI_UPLOAD_ROTATION | MI_UPLOAD_SCALE`.  `Changed<Transform>` does not say WHAT changed, the app
+    /// does: a scene whose systems only ever turn things (`many_cubes --rotate-cubes`, examples/stress_tests/many_cubes.rs:641-648) sets
+    /// `MI_UPLOAD_ROTATION` and sends 16 bytes per moved row instead of 40.  A component that is not carried keeps the value of the
+    /// last full upload (every structural rebuild sends all three) -- setting this while a system writes the others is the app's bug.
+    pub upload_components: u32,
     scratch: Scratch,
 }
 
@@ -195,6 +201,7 @@ impl Mi355x {
                 plane_storage: Vec::new(),
                 rows_in_table_order: false,
                 every_row_moved: false,
+                upload_components: 0,
                 scratch: Scratch::default(),
             })
         }
@@ -450,6 +457,7 @@ fn upload_and_propagate(
                     // (bevy_mi355x.h, mi_download_frame_results; the C++ host layer does the same).  The caller's frame call is then
                     // the all-rows one: no MI_CULL_CHANGED_ROWS (`every_row_moved`).
                     const WINDOWS: usize = 8;
+                    let components = mi.upload_components;
                     let n = capacity;
                     let mut row = 0usize; // rows written so far == the table walk's position
                     let mut window: ffi::MiUploadWindow = unsafe { core::mem::zeroed() };
@@ -473,16 +481,23 @@ fn upload_and_propagate(
                                         hi = n * next_window / WINDOWS;
                                     }
                                     check(ctx, "mi_map_upload_window", unsafe {
-                                        ffi::mi_map_upload_window(ctx, (hi - lo) as u32, ffi::MI_UPLOAD_DENSE, &mut window)
+                                        ffi::mi_map_upload_window(ctx, (hi - lo) as u32, ffi::MI_UPLOAD_DENSE | components, &mut window)
                                     })?;
                                     open = true;
                                 }
                                 let k = row - lo;
-                                // SAFETY: k < hi - lo, the capacity the window was mapped with.
+                                // SAFETY: k < hi - lo, the capacity the window was mapped with; a component the window does not
+                                // carry has a null pointer.
                                 unsafe {
-                                    core::ptr::copy_nonoverlapping(t.translation.to_array().as_ptr(), window.translation.add(3 * k), 3);
-                                    core::ptr::copy_nonoverlapping(t.rotation.to_array().as_ptr(), window.rotation.add(4 * k), 4);
-                                    core::ptr::copy_nonoverlapping(t.scale.to_array().as_ptr(), window.scale.add(3 * k), 3);
+                                    if !window.translation.is_null() {
+                                        core::ptr::copy_nonoverlapping(t.translation.to_array().as_ptr(), window.translation.add(3 * k), 3);
+                                    }
+                                    if !window.rotation.is_null() {
+                                        core::ptr::copy_nonoverlapping(t.rotation.to_array().as_ptr(), window.rotation.add(4 * k), 4);
+                                    }
+                                    if !window.scale.is_null() {
+                                        core::ptr::copy_nonoverlapping(t.scale.to_array().as_ptr(), window.scale.add(3 * k), 3);
+                                    }
                                 }
                                 row += 1;
                             }
@@ -505,7 +520,7 @@ fn upload_and_propagate(
                 }
                 // SAFETY: a zeroed window is the valid "nothing mapped" value; the library fills it in.
                 let mut window: ffi::MiUploadWindow = unsafe { core::mem::zeroed() };
-                check(ctx, "mi_map_upload_window", unsafe { ffi::mi_map_upload_window(ctx, capacity as u32, 0, &mut window) })?;
+                check(ctx, "mi_map_upload_window", unsafe { ffi::mi_map_upload_window(ctx, capacity as u32, mi.upload_components, &mut window) })?;
                 let mut k = 0usize;
                 for (entities, table_transforms, _) in tables {
                     let changed = table_transforms.changed_ticks_slice();
@@ -514,9 +529,15 @@ fn upload_and_propagate(
                             // SAFETY: k < capacity: the same filter counted the rows above.
                             unsafe {
                                 *window.rows.add(k) = mi.entity_row[&entities[i]];
-                                core::ptr::copy_nonoverlapping(t.translation.to_array().as_ptr(), window.translation.add(3 * k), 3);
-                                core::ptr::copy_nonoverlapping(t.rotation.to_array().as_ptr(), window.rotation.add(4 * k), 4);
-                                core::ptr::copy_nonoverlapping(t.scale.to_array().as_ptr(), window.scale.add(3 * k), 3);
+                                if !window.translation.is_null() {
+                                    core::ptr::copy_nonoverlapping(t.translation.to_array().as_ptr(), window.translation.add(3 * k), 3);
+                                }
+                                if !window.rotation.is_null() {
+                                    core::ptr::copy_nonoverlapping(t.rotation.to_array().as_ptr(), window.rotation.add(4 * k), 4);
+                                }
+                                if !window.scale.is_null() {
+                                    core::ptr::copy_nonoverlapping(t.scale.to_array().as_ptr(), window.scale.add(3 * k), 3);
+                                }
                             }
                             k += 1;
                         }

@@ -329,3 +329,88 @@ def test_changed_rows_frames_with_globals_written_ahead(case, in_place):
     want = {"plain": 4, "descending": 4, "not monotonic": 0, "a mark from elsewhere": 2, "two windows": 0, "a dense write in between": 2, "an all-rows frame": 2,
             "a second frame before the results": 2, "results twice": 8, "capacity too small": 4, "default rule": 3, "windows mapped before the results": 4}[case]
     assert counts == [want, 0], f"{case}: {counts} downloads handed out GlobalTransforms written ahead"
+
+
+@pytest.mark.parametrize("mode", [2, 1])
+def test_component_granular_windows(mode):
+    """MI_UPLOAD_TRANSLATION / _ROTATION / _SCALE: a window carries only the named components (the columns of the others keep what they
+    hold).  Dense sequences in pieces with the GlobalTransforms fetched ahead (every cube rotates: 16 B per row go up), several
+    windows one after the other with different components each frame, and indexed windows whose scatter launch writes the
+    GlobalTransforms ahead from the window's components + the resident ones -- all against the oracle on the host's mirror."""
+    n = 270_001
+    sc = W.many_cubes(n, radius=80.0)
+    t, r, s = sc["translation"].reshape(n, 3).copy(), sc["rotation"].reshape(n, 4).copy(), sc["scale"].reshape(n, 3).copy()
+    rng = np.random.default_rng(21)
+    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+
+    def spin(q, k):
+        a = F(0.01 * (k + 1))
+        d = np.array([0.0, np.sin(a / 2), 0.0, np.cos(a / 2)], F)
+        out = W.quat_mul(q.T.astype(np.float64), np.broadcast_to(d[:, None].astype(np.float64), (4, len(q)))).T
+        return (out / np.linalg.norm(out, axis=1, keepdims=True)).astype(F)
+
+    with api.Context(0) as ctx:
+        ctx.debug_set_chunked_frames(mode)
+        ctx.resize(n)
+        ctx.upload_transforms(t.reshape(-1), r.reshape(-1), s.reshape(-1))
+        ctx.upload_bounds(sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"])
+        for frame, comps in enumerate(["r", "r", "t", "ts", "rs", "trs", "r"]):
+            if "t" in comps:
+                t += rng.normal(0.0, 0.3, (n, 3)).astype(F)
+            if "r" in comps:
+                r = spin(r, frame)
+            if "s" in comps:
+                s = (s * F(1.01)).astype(F)
+            fr = api.compute_frustum(cfv, W.many_cubes_camera(frame * 20), W.CAMERA_FAR)
+            cuts = [0, n] if frame % 2 == 0 else [0, n // 3, n // 3 + 70_000, n]
+            for lo, hi in zip(cuts, cuts[1:]):
+                w, _, wt, wr, ws = ctx.map_upload_window(hi - lo, dense=True, components=comps)
+                assert (wt is None) == ("t" not in comps) and (wr is None) == ("r" not in comps) and (ws is None) == ("s" not in comps)
+                if wt is not None:
+                    wt[:] = t[lo:hi].reshape(-1)
+                if wr is not None:
+                    wr[:] = r[lo:hi].reshape(-1)
+                if ws is not None:
+                    ws[:] = s[lo:hi].reshape(-1)
+                ctx.commit_upload_window(w, hi - lo, first_row=lo)
+            ctx.propagate_and_cull(fr, flags=B.CULL_END_FRAME)
+            got = ctx.download_frame_results(api.FrameResultBuffers(n, n, 0, 0, in_place=bool(frame % 2)))
+            g, _ = O.sync_simple_transforms(t.reshape(-1), r.reshape(-1), s.reshape(-1))
+            assert np.array_equal(got["changed_rows"], np.arange(n, dtype=np.uint32)), f"frame {frame} ({comps})"
+            assert np.array(got["changed_global"]).tobytes() == g.tobytes(), f"frame {frame} ({comps}): GlobalTransforms against the oracle"
+            assert ctx.download_global_transforms(want_changed=False).tobytes() == g.tobytes(), f"frame {frame} ({comps}): the column"
+        if mode == 2:
+            assert ctx.debug_chunked_counts()[1] >= 5  # handed out from what was fetched ahead
+        # indexed windows: some rows move / turn, the window carries that component only
+        ctx.upload_changed(np.zeros(n, np.uint8))
+        ctx.propagate(0)
+        for frame, comps in enumerate(["t", "r", "t", "rs", "t"]):
+            k = 20_000 + 17 * frame
+            rows = np.sort(rng.choice(n, k, replace=False)).astype(np.uint32)
+            if frame == 3:
+                rows = rows[::-1].copy()  # a descending window (spawn order over inverted indices)
+            if "t" in comps:
+                t[rows] += rng.normal(0.0, 2.0, (k, 3)).astype(F)
+            if "r" in comps:
+                r[rows] = spin(r[rows], frame)
+            if "s" in comps:
+                s[rows] = (s[rows] * F(0.97)).astype(F)
+            w, wrows, wt, wr, ws = ctx.map_upload_window(k, components=comps)
+            wrows[:] = rows
+            if wt is not None:
+                wt[:] = t[rows].reshape(-1)
+            if wr is not None:
+                wr[:] = r[rows].reshape(-1)
+            if ws is not None:
+                ws[:] = s[rows].reshape(-1)
+            ctx.commit_upload_window(w, k)
+            fr = api.compute_frustum(cfv, W.many_cubes_camera(frame * 20), W.CAMERA_FAR)
+            ctx.propagate_and_cull(fr, flags=B.CULL_END_FRAME | B.CULL_CHANGED_ROWS)
+            got = ctx.download_frame_results(api.FrameResultBuffers(n, n, 0, 0, in_place=bool(frame % 2)))
+            g, _ = O.sync_simple_transforms(t.reshape(-1), r.reshape(-1), s.reshape(-1))
+            srt = np.sort(rows)
+            assert np.array_equal(got["changed_rows"], srt), f"indexed frame {frame} ({comps})"
+            assert np.array(got["changed_global"]).tobytes() == g.reshape(n, 12)[srt].tobytes(), f"indexed frame {frame} ({comps}): changed GlobalTransforms"
+            assert ctx.download_global_transforms(want_changed=False).tobytes() == g.tobytes(), f"indexed frame {frame} ({comps}): the column"
+        if mode == 2:
+            assert ctx.debug_chunked_counts()[2] >= 3  # written ahead by the scatter launch

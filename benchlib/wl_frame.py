@@ -64,8 +64,8 @@ def build_frame(ctx, args):
                   kernels=["k_flat_propagate_cull", "k_compact_fast", "k_cluster_walk", "k_cluster_fill"])
     wl.scene, wl.first_light, wl.pos_range, wl.frusta0, wl.keep = sc, first_light, pr, frames[0].array, (views, keep)
     # "k_flat_propagate_cull" is the library's timer slot; the symbol rocprofv3 shows is the k_frame instantiation
-    # <PROPAGATE, INLINE_VIEWS, WITH_WALK>: the cluster walk rides in the launch unless it runs as calls or a stream of its own
-    wl.kernel_name = "k_frame<1,true,false>" if (separate or concurrent) else "k_frame<1,true,true>"
+    # <PROPAGATE, INLINE_VIEWS, WALK>: the cluster walk rides in the launch unless it runs as calls or a stream of its own
+    wl.kernel_name = "k_frame<1,true,0>" if (separate or concurrent) else "k_frame<1,true,1>"
     if args.row_summary == 0:
         wl.layout_bytes_per_row = wl.bytes_per_row - ROW_SUMMARY_SAVES  # (every wave of this scene but three is uniform)
     return wl

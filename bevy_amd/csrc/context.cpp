@@ -935,9 +935,19 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
                       &ctx->cl_offsets, &ctx->cl_indices, &ctx->cl_scalars};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
-    for (auto& f : ctx->fb)
-        for (DevBuf* b : {&f.bitmask, &f.wave_cnt, &f.seg_mask, &f.out_rows, &f.seg_totals})
+    for (auto& sl : ctx->cl_parked)  // (the parked cluster views' buffers; the selected one's are in the list above)
+        for (DevBuf* b : {&sl.planes, &sl.spheres, &sl.remap, &sl.bind_oc, &sl.bind_idx, &sl.block_counts, &sl.pair_cb, &sl.pair_mask, &sl.acc, &sl.offsets,
+                          &sl.indices, &sl.scalars})
             if (b->p) hipFree(b->p);
+    for (auto& f : ctx->fb)
+        for (DevBuf* b : {&f.bitmask, &f.wave_cnt, &f.seg_mask, &f.out_rows, &f.seg_totals, &f.blk_cnt})
+            if (b->p) hipFree(b->p);
+    {
+        auto& ce = ctx->cells;  // the static cull order
+        for (DevBuf* b : {&ce.perm, &ce.sph_s, &ce.g_s, &ce.vv_s, &ce.sum_a, &ce.sum_b, &ce.sum_h, &ce.state, &ce.keys_a, &ce.keys_b, &ce.vals_a, &ce.vals_b,
+                          &ce.sort_tmp, &ce.minmax, &ce.work, &ce.work_n, &ce.pass_s, &ce.fin_scratch})
+            if (b->p) hipFree(b->p);
+    }
     if (ctx->stage) hipHostFree(ctx->stage);
     for (auto& c : ctx->win_chunks) hipHostFree(c.p);
     if (ctx->timer_a) hipEventDestroy(ctx->timer_a);

@@ -349,6 +349,23 @@ struct mi_ctx {
     mi::ClusterViewDev cl_view{};
     bool cl_have_view = false, cl_assigned = false;
 
+    // ---- several clustered views (mi_cluster_select_view): everything above that belongs to ONE view -- its constants and plane
+    // tables, the working sets and outputs of its assignment, its pending fill, its binding arrays -- lives in the context's fields for
+    // the SELECTED slot and in cl_parked[k] for the others; selecting swaps.  The objects and their row binding are shared.
+    struct ClusterSlot {
+        DevBuf planes, spheres, remap, bind_oc, bind_idx, block_counts, pair_cb, pair_mask, acc, offsets, indices, scalars;
+        uint32_t parity = 0, acc_clusters = 0, acc_blocks = 0;
+        std::vector<float> host_planes, host_spheres, planes_host, spheres_sent;
+        uint64_t planes_epoch = ~0ull;
+        uint32_t plane_counts[3] = {0, 0, 0};
+        bool fill_pending = false;
+        mi::ClusterFillJob fill_job{};
+        mi::ClusterViewDev view{};
+        bool have_view = false, assigned = false;
+    };
+    ClusterSlot cl_parked[MI_CLUSTER_MAX_VIEWS];
+    uint32_t cl_slot = 0;  // the selected one (its ClusterSlot entry is unused while it is selected)
+
     // ---- timing ----
     hipEvent_t timer_a = nullptr, timer_b = nullptr;
     bool profiling = false;

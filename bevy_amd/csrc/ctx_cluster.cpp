@@ -48,6 +48,7 @@ int32_t mi_cluster_upload_objects(mi_ctx* ctx, uint32_t n, const float* pos_rang
     if (n != ctx->cl_n) ctx->cl_rows_bound = false;  // a different object set: the row binding has to be renewed
     ctx->cl_n = n;
     ctx->cl_assigned = false;
+    for (auto& parked : ctx->cl_parked) parked.assigned = false;  // (every view's assignment was over the old objects)
     return MI_OK;
 }
 
@@ -87,6 +88,48 @@ int32_t mi_cluster_bind_objects_to_row_list(mi_ctx* ctx, uint32_t n_objects, con
     ctx->cl_rows_listed = true;
     ctx->cl_first_row = 0;
     ctx->cl_assigned = false;
+    return MI_OK;
+}
+
+// The selected slot's state lives in the context's own fields; the others are parked (ctx.h, ClusterSlot).
+static void cluster_slot_exchange(mi_ctx* ctx, mi_ctx::ClusterSlot& s) {
+    std::swap(ctx->cl_planes, s.planes);
+    std::swap(ctx->cl_spheres, s.spheres);
+    std::swap(ctx->cl_remap, s.remap);
+    std::swap(ctx->cl_bind_oc, s.bind_oc);
+    std::swap(ctx->cl_bind_idx, s.bind_idx);
+    std::swap(ctx->cl_block_counts, s.block_counts);
+    std::swap(ctx->cl_pair_cb, s.pair_cb);
+    std::swap(ctx->cl_pair_mask, s.pair_mask);
+    std::swap(ctx->cl_acc, s.acc);
+    std::swap(ctx->cl_offsets, s.offsets);
+    std::swap(ctx->cl_indices, s.indices);
+    std::swap(ctx->cl_scalars, s.scalars);
+    std::swap(ctx->cl_parity, s.parity);
+    std::swap(ctx->cl_acc_clusters, s.acc_clusters);
+    std::swap(ctx->cl_acc_blocks, s.acc_blocks);
+    std::swap(ctx->cl_host_planes, s.host_planes);
+    std::swap(ctx->cl_host_spheres, s.host_spheres);
+    std::swap(ctx->cl_planes_host, s.planes_host);
+    std::swap(ctx->cl_spheres_sent, s.spheres_sent);
+    std::swap(ctx->cl_planes_epoch, s.planes_epoch);
+    for (int k = 0; k < 3; ++k) std::swap(ctx->cl_plane_counts[k], s.plane_counts[k]);
+    std::swap(ctx->cl_fill_pending, s.fill_pending);
+    std::swap(ctx->cl_fill_job, s.fill_job);
+    std::swap(ctx->cl_view, s.view);
+    std::swap(ctx->cl_have_view, s.have_view);
+    std::swap(ctx->cl_assigned, s.assigned);
+}
+
+int32_t mi_cluster_select_view(mi_ctx* ctx, uint32_t slot) {
+    ENTER(ctx);
+    if (slot >= MI_CLUSTER_MAX_VIEWS) return fail(ctx, MI_ERR_INVALID_ARG, "mi_cluster_select_view: slot %u of %u", slot, MI_CLUSTER_MAX_VIEWS);
+    if (slot == ctx->cl_slot) return MI_OK;
+    int32_t rc = cluster_join(ctx);  // (a deferred fill of the slot that is left goes out now; a side-stream assignment is joined)
+    if (rc) return rc;
+    cluster_slot_exchange(ctx, ctx->cl_parked[ctx->cl_slot]);  // park the selected slot ...
+    cluster_slot_exchange(ctx, ctx->cl_parked[slot]);          // ... and take the other one out
+    ctx->cl_slot = slot;
     return MI_OK;
 }
 
@@ -381,7 +424,10 @@ int32_t cluster_ride_prepare(mi_ctx* ctx, ClusterWalkJob* job, bool* can_ride) {
     const uint32_t dxy = v.dims[0] * v.dims[1], n_planes = v.dims[0] + v.dims[1] + v.dims[2] + 3u;
     uint32_t zc = 0;
     while (zc < v.dims[2] && cluster_walk_lds_bytes(dxy, zc + 1u, n_planes, true) <= FRAME_KERNEL_LDS_BYTES) ++zc;
-    if (zc == 0 || ctx->cl_any_spot) return MI_OK;  // (spot lights read the cluster-sphere table: left to the walk kernel of its own)
+    if (zc == 0) return MI_OK;
+    // (spot lights: the riding walk runs the cone test against the clusters' bounding spheres too -- the frame kernel's WALK = 2
+    // variant; without the sphere table the assignment of its own reports the missing table)
+    if (ctx->cl_any_spot && !v.cluster_spheres) return MI_OK;
     ClusterPrep p;
     int32_t rc = cluster_objects(ctx, true, &p.o);
     if (rc) return rc;
@@ -399,6 +445,7 @@ int32_t cluster_ride_prepare(mi_ctx* ctx, ClusterWalkJob* job, bool* can_ride) {
         job->n_blocks = (uint32_t)(((uint64_t)ctx->cl_first_row + p.o.n + 255u) / 256u) - job->tile0;
         p.w.obj_delta = (int32_t)(job->tile0 * 256u) - (int32_t)ctx->cl_first_row;
     }
+    job->spots = ctx->cl_any_spot ? 1u : 0u;
     job->view = v;
     job->objs = p.o;
     job->w = p.w;

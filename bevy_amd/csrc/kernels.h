@@ -559,6 +559,7 @@ struct ClusterWalkJob {
     // with the ViewVisibility and the GlobalTransform translation they have just computed: no extra workgroups, nothing re-derived.
     // The launch hands those tiles out first.
     uint32_t inrow, tile0;
+    uint32_t spots;        // there are spot lights among the objects: the walk runs the cone test too (view.cluster_spheres is set)
 };
 // bytes of the LDS arena a walking workgroup needs for chunks of zc z slices (layout: cluster_walk.h)
 inline size_t cluster_walk_lds_bytes(uint32_t dxy, uint32_t zc, uint32_t n_planes, bool planes_in_lds) {

@@ -163,6 +163,7 @@ __device__ __forceinline__ bool view_visibility_tail(const Columns& c, uint32_t 
 // row - first_row; it takes part if its ViewVisibility::get() is true (the gather's filter, assign.rs:194: `visible`, just computed),
 // its centre is the row's GlobalTransform translation (assign.rs:198: `translation`, in hand), and it passes the two early-outs of
 // the per-object loop (assign.rs:489 RenderLayers, :496 frustum against the light's sphere).  Every thread of the workgroup calls it.
+template <bool SPOTS>
 __device__ __forceinline__ void inrow_cluster_walk(const ClusterWalkJob& walk, uint32_t tile, uint32_t row, bool visible, V3 translation, uint32_t* arena) {
     const uint32_t bx = tile - walk.tile0;
     const ClusterObjects& o = walk.objs;
@@ -181,7 +182,7 @@ __device__ __forceinline__ void inrow_cluster_walk(const ClusterWalkJob& walk, u
             in_view = frustum_intersects_sphere(fr, translation, sphere.w, true);
         }
     }
-    cluster_walk_tail<true, true, false>(walk.view, o, walk.w, walk.zc, bx, arena, obj, in_view, sphere, pf);
+    cluster_walk_tail<true, true, SPOTS>(walk.view, o, walk.w, walk.zc, bx, arena, obj, in_view, sphere, pf);
 }
 // The extra workgroups at the head of a frame kernel's grid (they overlap the ramp-up instead of lengthening the tail: 0.5 us per
 // frame at 1 M rows): the deferred VisibleEntities compaction of the previous frame, the deferred fill of the previous frame's
@@ -208,7 +209,7 @@ struct TimelineScope {
 #else
 #define MI_TIMELINE(kind)
 #endif
-template <bool WITH_WALK>
+template <int WALK>
 __device__ __forceinline__ bool frame_riders(uint32_t n_tiles, const CompactFastArgs& prev, uint32_t prev_gx, uint32_t n_compact, uint32_t n_fill,
                                              const ClusterFillJob& fill, const ClusterWalkJob& walk, const ViewSet& vs, uint32_t* lds_raw) {
     const uint32_t n_extra = gridDim.x - n_tiles;
@@ -222,10 +223,10 @@ __device__ __forceinline__ bool frame_riders(uint32_t n_tiles, const CompactFast
     } else if (id < n_compact + n_fill) {
         MI_TIMELINE(1);
         cluster_fill_block(fill.w, fill.n_clusters, fill.n_objects, id - n_compact, n_fill, lds_raw, lds_raw + 4096);
-    } else if constexpr (WITH_WALK) {
+    } else if constexpr (WALK != 0) {
         // this frame's light-cluster walk: independent of the rows below (it re-derives the lights' ViewVisibility itself)
         MI_TIMELINE(2);
-        cluster_walk_block<true, true, false>(walk.view, walk.objs, walk.w, vs, walk.zc, id - n_compact - n_fill, lds_raw);
+        cluster_walk_block<true, true, WALK == 2>(walk.view, walk.objs, walk.w, vs, walk.zc, id - n_compact - n_fill, lds_raw);
     }
     return true;
 }
@@ -241,13 +242,15 @@ __device__ __forceinline__ bool frame_riders(uint32_t n_tiles, const CompactFast
 // Algorithmic bytes per row, fused, V views: read 40 (T) + 24 (Aabb) + 1 (flags) + 4 (layers) + 1 (vv),
 // write 48 (G) + 1 (vv) + (V + 2 change masks) / 8 + V / 64 (wave counts).
 // ---------------------------------------------------------------------------------------------
-// WITH_WALK: the launch may carry this frame's light-cluster walk.  A variant of its own because the walk needs more registers than
+// WALK: 0 = none; 1 = the launch may carry this frame's light-cluster walk; 2 = ... and there are spot lights among the objects (the
+// walk then also runs the cone test against the clusters' bounding spheres, assign.rs:681-738: five more registers per object, so
+// scenes without spot lights keep the variant without it).  A variant of its own because the walk needs more registers than
 // a row tile (87 against 66 VGPRs: 5 instead of 7 waves per SIMD for the whole launch; capping it at 80 or 72 registers with
 // __launch_bounds__ spills and measured 26.9 / 29.0 us per metric frame against 25.2); frames without a walk keep the lean one.
 // PROP: 0 = GlobalTransform is resident (mi_cull), 1 = every row is propagated (the fused frame: Transform read once,
 // GlobalTransform written once and never re-read), 2 = only rows whose Transform change byte is set are propagated
 // (sync_simple_transforms' own filter, systems.rs:45-50; `changed` is the byte column), the others keep the resident value.
-template <int PROP, bool INLINE_VIEWS, bool WITH_WALK>
+template <int PROP, bool INLINE_VIEWS, int WALK>
 __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const ViewParams* __restrict__ dviews,
                                                 uint32_t n_views, VisibilityOut out, SegOut seg, uint32_t fl_frame, uint32_t n_tiles,
                                                 CompactFastArgs prev, uint32_t prev_gx, uint32_t n_compact, uint32_t n_fill, ClusterFillJob fill,
@@ -259,13 +262,13 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
     // held to 5 workgroups per CU by the walk's registers anyway, so its arena is the 31 KB that five of them leave each other: the
     // walk sweeps the cluster grid in chunks of as many z slices as fit, and a chunk is a reservation round trip (metric frame
     // 22.3 -> 21.7 us, profiles/r03_experiments.md)
-    __shared__ __attribute__((aligned(16))) uint32_t lds_raw[(WITH_WALK ? FRAME_WALK_LDS_WORDS : FRAME_LDS_WORDS) + 4];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_raw[(WALK ? FRAME_WALK_LDS_WORDS : FRAME_LDS_WORDS) + 4];
     float4 (*lds_g)[192] = reinterpret_cast<float4 (*)[192]>(lds_raw);
-    if (frame_riders<WITH_WALK>(n_tiles, prev, prev_gx, n_compact, n_fill, fill, walk, vs, lds_raw)) return;
+    if (frame_riders<WALK>(n_tiles, prev, prev_gx, n_compact, n_fill, fill, walk, vs, lds_raw)) return;
     MI_TIMELINE(3);
     const uint32_t n_extra = gridDim.x - n_tiles;
     uint32_t tile = blockIdx.x - n_extra;
-    if constexpr (WITH_WALK) {  // the tiles that go on into the cluster walk are handed out first (they run longest)
+    if constexpr (WALK != 0) {  // the tiles that go on into the cluster walk are handed out first (they run longest)
         if (walk.inrow) {
             tile += walk.tile0;
             if (tile >= n_tiles) tile -= n_tiles;
@@ -376,8 +379,8 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
         const unsigned long long dm = __ballot(dirty);
         if (lane == 0 && any_live) c.g_changed_bits[wave] = dm;
     }
-    if constexpr (WITH_WALK) {
-        if (walk.inrow && tile - walk.tile0 < walk.n_blocks) inrow_cluster_walk(walk, tile, row, vv_now, g.t, lds_raw);  // (workgroup-uniform)
+    if constexpr (WALK != 0) {
+        if (walk.inrow && tile - walk.tile0 < walk.n_blocks) inrow_cluster_walk<WALK == 2>(walk, tile, row, vv_now, g.t, lds_raw);  // (workgroup-uniform)
     }
 }
 
@@ -403,17 +406,17 @@ struct SphereArgs {
     const uint8_t* stale_bytes;   // ... a byte per row (hierarchy path); both nullptr = none
     uint32_t all_stale;           // every row (first use, or after an all-dirty propagate / a bounds upload)
 };
-template <bool PARTIAL, bool INLINE_VIEWS, bool WITH_WALK>
+template <bool PARTIAL, bool INLINE_VIEWS, int WALK>
 __global__ void __launch_bounds__(256) k_frame_sph(Columns c, ViewSet vs, const ViewParams* __restrict__ dviews, uint32_t n_views,
                                                     VisibilityOut out, SegOut seg, uint32_t fl_frame, uint32_t n_tiles, CompactFastArgs prev,
                                                     uint32_t prev_gx, uint32_t n_compact, uint32_t n_fill, ClusterFillJob fill,
                                                     ClusterWalkJob walk, const uint8_t* __restrict__ changed, SphereArgs sa) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds_raw[(WITH_WALK ? FRAME_WALK_LDS_WORDS : FRAME_LDS_WORDS) + 4];  // (as in k_frame)
+    __shared__ __attribute__((aligned(16))) uint32_t lds_raw[(WALK ? FRAME_WALK_LDS_WORDS : FRAME_LDS_WORDS) + 4];  // (as in k_frame)
     float4 (*lds_g)[192] = reinterpret_cast<float4 (*)[192]>(lds_raw);
-    if (frame_riders<WITH_WALK>(n_tiles, prev, prev_gx, n_compact, n_fill, fill, walk, vs, lds_raw)) return;
+    if (frame_riders<WALK>(n_tiles, prev, prev_gx, n_compact, n_fill, fill, walk, vs, lds_raw)) return;
     const uint32_t n_extra = gridDim.x - n_tiles;
     uint32_t tile = blockIdx.x - n_extra;
-    if constexpr (WITH_WALK) {  // (as in k_frame: the tiles that go on into the cluster walk first)
+    if constexpr (WALK != 0) {  // (as in k_frame: the tiles that go on into the cluster walk first)
         if (walk.inrow) {
             tile += walk.tile0;
             if (tile >= n_tiles) tile -= n_tiles;
@@ -572,11 +575,11 @@ __global__ void __launch_bounds__(256) k_frame_sph(Columns c, ViewSet vs, const 
     }
     for (uint32_t v = 0; v < n_views; ++v) emit_view(v, ((pass >> v) & 1u) != 0, any_live, lane, wave, cmask, out, seg);
     const bool vv_now = view_visibility_tail(c, row, live, any_live, lane, wave, fl, vv0, pass != 0u, fl_frame);
-    if constexpr (WITH_WALK) {
+    if constexpr (WALK != 0) {
         if (walk.inrow && tile - walk.tile0 < walk.n_blocks) {  // (workgroup-uniform)
             // the row's GlobalTransform translation: the column as this launch leaves it (a PARTIAL frame's own stores included)
             const V3 t = live ? ld3(c.global, row * 4u + 3u) : V3{0.f, 0.f, 0.f};
-            inrow_cluster_walk(walk, tile, row, vv_now, t, lds_raw);
+            inrow_cluster_walk<WALK == 2>(walk, tile, row, vv_now, t, lds_raw);
         }
     }
 }
@@ -809,7 +812,7 @@ __global__ void __launch_bounds__(256) k_frame_cells(Columns c, ViewSet vs, cons
     float4 (*lds_g)[192] = reinterpret_cast<float4 (*)[192]>(lds_raw);
     {
         ClusterWalkJob no_walk{};
-        if (frame_riders<false>(n_tiles, prev, prev_gx, n_compact, n_fill, fill, no_walk, vs, lds_raw)) return;
+        if (frame_riders<0>(n_tiles, prev, prev_gx, n_compact, n_fill, fill, no_walk, vs, lds_raw)) return;
     }
     const uint32_t tile = blockIdx.x - (gridDim.x - n_tiles);
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
@@ -1290,15 +1293,18 @@ static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, co
         walk_blocks = wj.inrow ? 0u : wj.n_blocks;  // in-row: the row workgroups of the objects' tiles do it
     }
     const dim3 grid(n_tiles + prev_blocks + fill_blocks + walk_blocks);
-    if (with_walk) {
-        MI_LAUNCH((k_frame<PROP, true, true>), grid, dim3(256), 0, stream, c, *views_inline, (const ViewParams*)nullptr, n_views, out, seg, flags,
+    if (with_walk && wj.spots) {
+        MI_LAUNCH((k_frame<PROP, true, 2>), grid, dim3(256), 0, stream, c, *views_inline, (const ViewParams*)nullptr, n_views, out, seg, flags,
+                  n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed);
+    } else if (with_walk) {
+        MI_LAUNCH((k_frame<PROP, true, 1>), grid, dim3(256), 0, stream, c, *views_inline, (const ViewParams*)nullptr, n_views, out, seg, flags,
                   n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed);
     } else if (n_views <= MAX_INLINE_VIEWS && views_inline) {
-        MI_LAUNCH((k_frame<PROP, true, false>), grid, dim3(256), 0, stream, c, *views_inline, (const ViewParams*)nullptr, n_views, out, seg, flags,
+        MI_LAUNCH((k_frame<PROP, true, 0>), grid, dim3(256), 0, stream, c, *views_inline, (const ViewParams*)nullptr, n_views, out, seg, flags,
                   n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed);
     } else {
         ViewSet dummy = {};
-        MI_LAUNCH((k_frame<PROP, false, false>), grid, dim3(256), 0, stream, c, dummy, d_views, n_views, out, seg, flags, n_tiles, pa, prev_gx,
+        MI_LAUNCH((k_frame<PROP, false, 0>), grid, dim3(256), 0, stream, c, dummy, d_views, n_views, out, seg, flags, n_tiles, pa, prev_gx,
                   prev_blocks, fill_blocks, fj, wj, changed);
     }
     return hipGetLastError();
@@ -1342,13 +1348,15 @@ hipError_t launch_frame_sph(const Columns& c, const ViewSet* views_inline, const
     MI_LAUNCH((k_frame_sph<P, I, W>), grid, dim3(256), 0, stream, c, vsr, dv, n_views, out, seg, flags, n_tiles, pa, prev_gx, prev_blocks, \
               fill_blocks, fj, wj, changed, sa)
     if (changed) {
-        if (with_walk) MI_SPH_LAUNCH(true, true, true);
-        else if (inl) MI_SPH_LAUNCH(true, true, false);
-        else MI_SPH_LAUNCH(true, false, false);
+        if (with_walk && wj.spots) MI_SPH_LAUNCH(true, true, 2);
+        else if (with_walk) MI_SPH_LAUNCH(true, true, 1);
+        else if (inl) MI_SPH_LAUNCH(true, true, 0);
+        else MI_SPH_LAUNCH(true, false, 0);
     } else {
-        if (with_walk) MI_SPH_LAUNCH(false, true, true);
-        else if (inl) MI_SPH_LAUNCH(false, true, false);
-        else MI_SPH_LAUNCH(false, false, false);
+        if (with_walk && wj.spots) MI_SPH_LAUNCH(false, true, 2);
+        else if (with_walk) MI_SPH_LAUNCH(false, true, 1);
+        else if (inl) MI_SPH_LAUNCH(false, true, 0);
+        else MI_SPH_LAUNCH(false, false, 0);
     }
 #undef MI_SPH_LAUNCH
     return hipGetLastError();

@@ -499,6 +499,16 @@ int32_t mi_cluster_bind_objects_to_rows(mi_ctx* ctx, uint32_t first_row, uint32_
  * shrinks the context unbinds. */
 int32_t mi_cluster_bind_objects_to_row_list(mi_ctx* ctx, uint32_t n_objects, const uint32_t* rows);
 int32_t mi_cluster_assign_resident(mi_ctx* ctx, uint64_t* out_total);
+/* Several clustered views.  Every camera with a ClusterConfig has Clusters of its own (assign.rs:324-486 runs per view; split screen,
+ * a picture-in-picture camera): the context keeps MI_CLUSTER_MAX_VIEWS view slots -- each with its view constants, the outputs of its
+ * assignment and its history of buffers -- over ONE set of resident objects (mi_cluster_upload_objects and the row bindings are shared).
+ * mi_cluster_select_view makes `slot` the one that mi_cluster_upload_view, mi_cluster_assign_resident / _frame, mi_cluster_download(_bindings),
+ * MI_CULL_WITH_CLUSTERS and the cluster parts of mi_download_frame_results refer to (default: slot 0).  A frame of two clustered cameras:
+ * select 0, upload its view, the frame call with MI_CULL_WITH_CLUSTERS (the walk rides in the frame kernel); select 1, upload its view,
+ * mi_cluster_assign_resident (two launches behind the frame, same ViewVisibility); results per slot.  Selecting enqueues whatever the
+ * slot that is left still owes (a deferred fill). */
+#define MI_CLUSTER_MAX_VIEWS 8u
+int32_t mi_cluster_select_view(mi_ctx* ctx, uint32_t slot);
 /* One view of one frame exactly as the system runs it (assign.rs:324-811): resolve the config against `history`,
  * build and upload the view constants, assign the resident objects, and store this frame's
  * total_cluster_index_count / farthest_z back into `history` (:810-811).  out_view (optional) receives the view

@@ -134,6 +134,8 @@ def test_lights_as_rows_of_the_frame_context(ctx_factory, spots, mode):
     upload_scene(ctx, sc)
     ctx.cluster_upload_objects(pr, types, layers, None, sincos)
     ctx.cluster_bind_objects_to_rows(first_light, n_l)
+    ctx.profile_filter(None)
+    ctx.profile_enable(True)
     cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
     t3 = sc["translation"].reshape(-1, 3)
     c3 = sc["aabb_center"].reshape(-1, 3)
@@ -172,6 +174,68 @@ def test_lights_as_rows_of_the_frame_context(ctx_factory, spots, mode):
         pr_rows[:, :3] = g.reshape(-1, 12)[first_light:first_light + n_l, 9:12]
         CI.check_all(view, pr_rows.reshape(-1), types, layers, *got, visible=visible, superset=not spots)
     ctx.synchronize()
+    prof = ctx.profile_read()
+    if mode == "with_clusters":
+        # the ONE-launch path: the walk rode in the frame kernel -- with spot lights too (its cone-test variant, round 4) -- so the walk
+        # kernel of its own never ran
+        assert "k_cluster_walk" not in prof and prof["k_flat_propagate_cull"]["launches"] == 4, prof
+    elif mode == "separate_calls":
+        assert prof["k_cluster_walk"]["launches"] == 4, prof
+
+
+def test_two_clustered_cameras_through_view_slots(ctx_factory):
+    """Split screen: two cameras with Clusters of their own over the same lights (assign.rs:324-486 runs per view).  Slot 0's walk rides
+    in the frame kernel (MI_CULL_WITH_CLUSTERS), slot 1 is assigned behind it (mi_cluster_select_view + mi_cluster_assign_resident):
+    every frame both assignments equal the reference's sequence for their camera -- lists, counts, farthest_z -- and a slot keeps its
+    results while the other one is selected.  Spot lights and other RenderLayers among the objects; different grids per view."""
+    sc, first_light, pr = W.frame_scene(40_000, 20_000, 2_000, light_range=1.5, ragged_flags=True)
+    n_l = len(pr) // 4
+    rng = np.random.default_rng(8)
+    types = np.sort(rng.integers(0, 2, n_l)).astype(np.uint8)
+    layers = np.where(rng.random(n_l) < 0.1, 2, 1).astype(np.uint32)
+    ang = rng.uniform(0.1, 1.2, n_l).astype(F)
+    sincos = np.stack([np.sin(ang), np.cos(ang)], axis=1).astype(F).reshape(-1)
+    ctx = ctx_factory()
+    upload_scene(ctx, sc)
+    ctx.cluster_upload_objects(pr, types, layers, None, sincos)
+    ctx.cluster_bind_objects_to_rows(first_light, n_l)
+    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+    dims = [(16, 9, 24), (12, 7, 16)]
+    for f in (0, 30, 31):
+        cams = [W.many_cubes_camera(f, yaw=0.2 * f), W.many_cubes_camera(f, yaw=2.0 + 0.1 * f, position=(4.0, 1.0, -3.0))]
+        frusta = frusta_for(cams)
+        views = []
+        for k in range(2):
+            v, keep = api.cluster_view_build(cams[k], cfv, frusta[24 * k:24 * k + 24], 1920, 1080, dims[k], 5.0, 1000.0)
+            views.append((v, keep))
+        ctx.upload_view_visibility(np.zeros(sc["n"], np.uint8))
+        ctx.cluster_select_view(0)
+        ctx.cluster_upload_view(views[0][0])
+        ctx.propagate_and_cull(frusta, flags=B.CULL_END_FRAME | B.CULL_MORE_FRAMES | B.CULL_WITH_CLUSTERS)
+        ctx.cluster_select_view(1)
+        ctx.cluster_upload_view(views[1][0])
+        ctx.cluster_assign_resident()
+        got1 = ctx.cluster_download(views[1][0].n_clusters)
+        ctx.cluster_select_view(0)
+        got0 = ctx.cluster_download(views[0][0].n_clusters)
+        # the reference: ViewVisibility is the OR over both cameras; every view gathers the same visible lights
+        n = sc["n"]
+        g, vv, vis, _ = O.full_frame(sc["translation"], sc["rotation"], sc["scale"], sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"],
+                                     np.zeros(n, np.uint8), frusta)
+        visible = (vv[first_light:first_light + n_l] & 1) != 0
+        keep_l = np.nonzero(visible)[0]
+        pr_g = np.asarray(pr, F).reshape(-1, 4)[keep_l].copy()
+        pr_g[:, :3] = g.reshape(-1, 12)[first_light + keep_l, 9:12]
+        z = g.reshape(-1, 12)[first_light + keep_l, 6:9].astype(F)
+        ln = np.sqrt((z[:, 0] * z[:, 0] + z[:, 1] * z[:, 1]) + z[:, 2] * z[:, 2]).astype(F)
+        spot_dir = (z * (F(1.0) / ln)[:, None]).astype(F).reshape(-1)
+        for k, got in ((0, got0), (1, got1)):
+            ov = O.cluster_view_setup(cams[k], cfv, frusta[24 * k:24 * k + 24], 1920, 1080, dims[k], 5.0, 1000.0)
+            off, idx, counts, far, total = O.assign_objects_to_clusters(ov, pr_g.reshape(-1), types[keep_l].copy(), layers[keep_l].copy(), spot_dir,
+                                                                        sincos.reshape(-1, 2)[keep_l].copy().reshape(-1))
+            assert total > 0
+            assert_same_assignment(got, (off, keep_l[idx].astype(np.uint32), counts, far, total))
+        assert_bits(ctx.download_view_visibility()[0], vv, "ViewVisibility (the OR over both cameras)")
 
 
 def test_baseline_lights_config_at_full_size(ctx_factory):

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <cstdint>
 #include <cstring>
@@ -153,7 +154,7 @@ class World {
         for (Entity c : kids) despawn(c);
         remove_parent(e);
         Rec& r = rec(e);
-        if (r.point_light_range) ++lights_version_;
+        if (r.point_light_range || r.spot_light || r.rect_light_range) ++lights_version_;
         r.alive = false;
         moved_[e.index] = 0;
         ++r.generation;
@@ -215,6 +216,15 @@ class World {
     bool inherited_visibility_changed(Entity e) const { return rec(e).inherited_changed; }
     void insert_aabb(Entity e, Aabb a) { rec(e).aabb = a; rec(e).bounds_changed = true; touch(e.index); ++bounds_version_; }
     void insert_point_light(Entity e, float range) { rec(e).point_light_range = range; ++lights_version_; ++bounds_version_; }  // PointLight { range, .. }
+    void insert_spot_light(Entity e, float range, float outer_angle) {  // SpotLight { range, outer_angle, .. }
+        rec(e).spot_light = std::make_pair(range, outer_angle);
+        ++lights_version_;
+        ++bounds_version_;
+    }
+    void insert_rect_light(Entity e, float range) { rec(e).rect_light_range = range; ++lights_version_; ++bounds_version_; }  // RectLight { range, .. }
+    // GlobalClusterSettings::supports_storage_buffers: without it rect lights are not gathered at all (assign.rs:231-248)
+    void set_supports_storage_buffers(bool on) { supports_storage_buffers = on; ++lights_version_; }
+    bool supports_storage_buffers = true;
     // What queue_material_meshes decides for a multidrawable mesh instance: the batch set key (pipeline + bind groups +
     // slabs), the bin key (mesh asset) and its slot in the MeshInputUniform buffer (render_phase/mod.rs:1086-1180)
     void insert_mesh_binning(Entity e, MeshBinning b) { rec(e).binning = b; ++binning_version_; }
@@ -302,6 +312,8 @@ class World {
         bool inherited = false;  // InheritedVisibility::default() == HIDDEN
         std::optional<Aabb> aabb;
         std::optional<float> point_light_range;
+        std::optional<std::pair<float, float>> spot_light;  // (range, outer_angle)
+        std::optional<float> rect_light_range;
         std::optional<MeshBinning> binning;
         bool transform_changed = false, added = false, parent_changed = false, orphaned = false;
         bool inherited_changed = false;
@@ -612,9 +624,10 @@ class Mi355xPlugin {
                 throw std::runtime_error("mi_cluster_view_dims failed");
             n_clusters = dims[0] * dims[1] * dims[2];
             plane_storage_.assign((size_t)(dims[0] + dims[1] + dims[2] + 3) * 4, 0.0f);
+            sphere_storage_.assign(lights_any_spot_ ? (size_t)n_clusters * 4 : 0, 0.0f);  // (read by the spot lights' cone test only)
             if (mi_cluster_view_build(cam->camera_affine, cam->clip_from_view, cam->frustum, cam->screen_width, cam->screen_height,
                                       cam->requested_dimensions, cam->first_slice_depth, cam->far_z, cam->layer_mask, plane_storage_.data(),
-                                      nullptr, &cview) != MI_OK)
+                                      lights_any_spot_ ? sphere_storage_.data() : nullptr, &cview) != MI_OK)
                 throw std::runtime_error("mi_cluster_view_build failed");
             check(mi_cluster_upload_view(ctx_, &cview));
         }
@@ -788,28 +801,51 @@ class Mi355xPlugin {
     // SimulationLightSystems::AssignLightsToClusters: gathers the clusterable objects in query order (point lights;
     // assign.rs:190-296, clustered with GlobalTransform::from_translation(translation), :198) and fills Clusters.
     Clusters assign_objects_to_clusters(World& w, const ClusterCamera& cam) {
+        // the gather of assign.rs:190-248: the visible point lights, then the visible spot lights, then -- only where they are
+        // clustered at all: with storage buffers -- the visible rect lights, each kind in query (Entity) order
         std::vector<Entity> lights;
-        std::vector<float> pos_range;
-        for (Entity e : w.entities()) {
-            const World::Rec& r = w.rec_[e.index];
-            if (!r.point_light_range || !(w.vv_[e.index] & 1u)) continue;  // `.filter(|(.., visibility)| visibility.get())`, assign.rs:194
+        std::vector<float> pos_range, spot_dir, spot_sin_cos;
+        std::vector<uint8_t> types;
+        bool any_spot = false;
+        auto gather = [&](Entity e, float range, uint8_t type, float outer_angle) {
+            const float* g = w.global_[e.index].cols;
             lights.push_back(e);
-            pos_range.insert(pos_range.end(), {w.global_[e.index].cols[9], w.global_[e.index].cols[10], w.global_[e.index].cols[11], *r.point_light_range});
-        }
+            pos_range.insert(pos_range.end(), {g[9], g[10], g[11], range});
+            types.push_back(type);
+            float d[3] = {0.f, 0.f, 0.f}, sc[2] = {0.f, 0.f};
+            if (type == MI_OBJ_SPOT_LIGHT) {
+                // GlobalTransform::back() = (matrix3 * Vec3::Z).normalize() (global_transform.rs:62-68, 206), glam's order of operations
+                const float len = std::sqrt((g[6] * g[6] + g[7] * g[7]) + g[8] * g[8]), inv = 1.0f / len;
+                d[0] = g[6] * inv, d[1] = g[7] * inv, d[2] = g[8] * inv;
+                sc[0] = std::sin(outer_angle), sc[1] = std::cos(outer_angle);  // ops::sin_cos: the host's libm, like Bevy's
+                any_spot = true;
+            }
+            spot_dir.insert(spot_dir.end(), d, d + 3);
+            spot_sin_cos.insert(spot_sin_cos.end(), sc, sc + 2);
+        };
+        const std::vector<Entity> ents = w.entities();
+        auto visible = [&](Entity e) { return (w.vv_[e.index] & 1u) != 0; };  // `.filter(|(.., visibility)| visibility.get())`, assign.rs:194
+        for (Entity e : ents)
+            if (w.rec_[e.index].point_light_range && visible(e)) gather(e, *w.rec_[e.index].point_light_range, MI_OBJ_POINT_LIGHT, 0.f);
+        for (Entity e : ents)
+            if (w.rec_[e.index].spot_light && visible(e)) gather(e, w.rec_[e.index].spot_light->first, MI_OBJ_SPOT_LIGHT, w.rec_[e.index].spot_light->second);
+        if (w.supports_storage_buffers)
+            for (Entity e : ents)
+                if (w.rec_[e.index].rect_light_range && visible(e)) gather(e, *w.rec_[e.index].rect_light_range, MI_OBJ_RECT_LIGHT, 0.f);
         uint32_t tile[2], dims[3];
         if (mi_cluster_view_dims(cam.screen_width, cam.screen_height, cam.requested_dimensions, tile, dims) != MI_OK)
             throw std::runtime_error("mi_cluster_view_dims failed");
         const size_t C = (size_t)dims[0] * dims[1] * dims[2];
-        std::vector<float> planes((size_t)(dims[0] + dims[1] + dims[2] + 3) * 4);
+        std::vector<float> planes((size_t)(dims[0] + dims[1] + dims[2] + 3) * 4), spheres(any_spot ? C * 4 : 0);
         mi_cluster_view view;
         if (mi_cluster_view_build(cam.camera_affine, cam.clip_from_view, cam.frustum, cam.screen_width, cam.screen_height,
                                   cam.requested_dimensions, cam.first_slice_depth, cam.far_z, cam.layer_mask, planes.data(),
-                                  nullptr, &view) != MI_OK)
+                                  any_spot ? spheres.data() : nullptr, &view) != MI_OK)  // (the cluster spheres: read by the spot lights' cone test)
             throw std::runtime_error("mi_cluster_view_build failed");
         std::vector<uint32_t> offsets(C + 1), counts(6 * C), indices(1);
         uint64_t total = 0;
         float farthest = 0.0f;
-        int32_t rc = mi_cluster_assign(ctx_, &view, (uint32_t)lights.size(), pos_range.data(), nullptr, nullptr, nullptr, nullptr,
+        int32_t rc = mi_cluster_assign(ctx_, &view, (uint32_t)lights.size(), pos_range.data(), types.data(), nullptr, spot_dir.data(), spot_sin_cos.data(),
                                        offsets.data(), nullptr, 0, counts.data(), &total, &farthest);
         check(rc);
         indices.resize(std::max<uint64_t>(total, 1));
@@ -897,21 +933,35 @@ class Mi355xPlugin {
         if (lights_version_ == w.lights_version_ && lights_version_ != 0) return !light_entities_.empty();
         light_entities_.clear();
         std::vector<uint32_t> rows;
-        std::vector<float> pos_range;
+        // every light that could be gathered, in gather order (points, spots, rects where they are clustered at all: assign.rs:190-248);
+        // the device leaves out the ones whose ViewVisibility::get() is false this frame
+        std::vector<float> pos_range, spot_sin_cos;
+        std::vector<uint8_t> types;
+        lights_any_spot_ = false;
         std::vector<Entity> ents = w.entities();
-        for (Entity e : ents) {
-            const World::Rec& r = w.rec_[e.index];
-            if (!r.point_light_range) continue;
+        auto add = [&](Entity e, float range, uint8_t type, float outer_angle) {
             light_entities_.push_back(e);
             rows.push_back(row_of_index_[e.index]);
-            pos_range.insert(pos_range.end(), {0.0f, 0.0f, 0.0f, *r.point_light_range});  // the position comes from the row
-        }
+            pos_range.insert(pos_range.end(), {0.0f, 0.0f, 0.0f, range});  // the position (and a spot light's direction) comes from the row
+            types.push_back(type);
+            const bool spot = type == MI_OBJ_SPOT_LIGHT;
+            spot_sin_cos.push_back(spot ? std::sin(outer_angle) : 0.0f);
+            spot_sin_cos.push_back(spot ? std::cos(outer_angle) : 0.0f);
+            lights_any_spot_ = lights_any_spot_ || spot;
+        };
+        for (Entity e : ents)
+            if (w.rec_[e.index].point_light_range) add(e, *w.rec_[e.index].point_light_range, MI_OBJ_POINT_LIGHT, 0.f);
+        for (Entity e : ents)
+            if (w.rec_[e.index].spot_light) add(e, w.rec_[e.index].spot_light->first, MI_OBJ_SPOT_LIGHT, w.rec_[e.index].spot_light->second);
+        if (w.supports_storage_buffers)
+            for (Entity e : ents)
+                if (w.rec_[e.index].rect_light_range) add(e, *w.rec_[e.index].rect_light_range, MI_OBJ_RECT_LIGHT, 0.f);
         lights_version_ = w.lights_version_;
         if (light_entities_.empty()) {
             check(mi_cluster_bind_objects_to_row_list(ctx_, 0, nullptr));
             return false;
         }
-        check(mi_cluster_upload_objects(ctx_, (uint32_t)light_entities_.size(), pos_range.data(), nullptr, nullptr, nullptr, nullptr));
+        check(mi_cluster_upload_objects(ctx_, (uint32_t)light_entities_.size(), pos_range.data(), types.data(), nullptr, nullptr, spot_sin_cos.data()));
         check(mi_cluster_bind_objects_to_row_list(ctx_, (uint32_t)rows.size(), rows.data()));
         return true;
     }
@@ -926,12 +976,12 @@ class Mi355xPlugin {
             // entities without the visibility components never enter the query; without Visibility they default visible
             flags[row] = (uint8_t)(((!e.has_visibility || e.inherited) ? MI_FLAG_INHERITED_VISIBLE : 0u) | (e.aabb ? MI_FLAG_HAS_AABB : 0u));
             if (e.aabb) { std::memcpy(&c[3 * (size_t)row], &e.aabb->center, 12); std::memcpy(&h[3 * (size_t)row], &e.aabb->half_extents, 12); }
-            else if (e.point_light_range) {
+            else if (e.point_light_range || e.spot_light) {
                 // a point light is culled by its bounding Sphere { GlobalTransform::translation, range } (update_point_light_bounding_spheres,
                 // point_light.rs:195-208): a sphere that follows the row's own GlobalTransform on the device -- a moving light costs nothing here
                 flags[row] |= MI_FLAG_HAS_SPHERE;
                 const uint32_t at_translation = MI_SPHERE_AT_TRANSLATION;
-                h[3 * (size_t)row] = *e.point_light_range;
+                h[3 * (size_t)row] = e.point_light_range ? *e.point_light_range : e.spot_light->first;  // (spot_light.rs:221-234: the same Sphere)
                 std::memcpy(&h[3 * (size_t)row + 1], &at_translation, 4);
             }
         }
@@ -995,6 +1045,8 @@ class Mi355xPlugin {
     }
     std::vector<mi_view> mviews_;
     std::vector<Entity> light_entities_;
+    bool lights_any_spot_ = false;
+    std::vector<float> sphere_storage_;
     std::vector<uint32_t> row_of_index_;
     uint64_t lights_version_ = 0, seen_visibility_ = 0, seen_bounds_ = 0;
     std::vector<std::pair<uint64_t, bool>> set_keys_;

@@ -121,6 +121,8 @@ pub struct Mi355x {
     cluster_history: EntityHashMap<ffi::MiClusterHistory>,
     /// Storage of the x / y / z cluster planes `mi_cluster_view_build` fills for the fused frame's view.
     plane_storage: Vec<f32>,
+    /// ... and of the clusters' bounding spheres (only filled when there are spot lights: their cone test reads them).
+    sphere_storage: Vec<f32>,
     /// Rows follow the tables (a flat world: the level order of a forest of single nodes is the order they were listed in): a walk
     /// over the tables visits rows 0, 1, 2 ... -- what lets an all-dirty frame fill dense upload windows in one pass.
     rows_in_table_order: bool,
@@ -202,6 +204,7 @@ impl Mi355x {
                 rows_in_table_order: false,
                 every_row_moved: false,
                 upload_components: 0,
+                sphere_storage: Vec::new(),
                 scratch: Scratch::default(),
             })
         }
@@ -623,7 +626,7 @@ pub fn mi_check_visibility(
         )>,
     >,
     rows_query: Query<
-        (Entity, &InheritedVisibility, Option<&VisibilityClass>, Option<&RenderLayers>, Option<&Aabb>, Option<&Sphere>, Option<&PointLight>, Has<NoFrustumCulling>, Has<VisibilityRange>),
+        (Entity, &InheritedVisibility, Option<&VisibilityClass>, Option<&RenderLayers>, Option<&Aabb>, Option<&Sphere>, Option<&PointLight>, Option<&SpotLight>, Has<NoFrustumCulling>, Has<VisibilityRange>),
         Without<NoCpuCulling>,
     >,
     mut view_visibilities: Query<&mut ViewVisibility, Without<NoCpuCulling>>,
@@ -891,20 +894,21 @@ pub fn mi_assign_objects_to_clusters(
             let dir = t.back().to_array();
             push(s, e, t, light.range, ffi::MI_OBJ_SPOT_LIGHT, layers, light.shadow_maps_enabled, vol.is_some(), Some((light.outer_angle, dir)))?;
         }
-        for (e, t, _, light, layers) in rect_lights.iter().filter(|q| q.2.get()) {
-            push(s, e, t, light.range, ffi::MI_OBJ_RECT_LIGHT, layers, false, false, None)?;
-        }
         if settings.supports_storage_buffers {
-            // probes and decals are clustered only with storage buffers (assign.rs:262-296); their range is the radius of the
-            // transformed unit cube, `transform.radius_vec3a(Vec3A::splat(0.5))`
-            for (e, t, _, is_environment_map) in light_probes.iter().filter(|q| q.2.get()) {
-                let kind = if is_environment_map { ffi::MI_OBJ_REFLECTION_PROBE } else { ffi::MI_OBJ_IRRADIANCE_VOLUME };
-                push(s, e, t, t.radius_vec3a(bevy_math::Vec3A::splat(0.5)), kind, None, false, false, None)?;
+            // rect lights are gathered only where they are clustered at all (assign.rs:231-248) ...
+            for (e, t, _, light, layers) in rect_lights.iter().filter(|q| q.2.get()) {
+                push(s, e, t, light.range, ffi::MI_OBJ_RECT_LIGHT, layers, false, false, None)?;
             }
-            if settings.clustered_decals_are_usable {
-                for (e, t, _) in decals.iter().filter(|q| q.2.get()) {
-                    push(s, e, t, t.radius_vec3a(bevy_math::Vec3A::splat(0.5)), ffi::MI_OBJ_DECAL, None, false, false, None)?;
-                }
+            // ... and so are light probes (UBOs cannot hold their indices, assign.rs:250-277); range = `transform.radius_vec3a(Vec3A::ONE)`
+            for (e, t, _, is_reflection_probe) in light_probes.iter().filter(|q| q.2.get()) {
+                let kind = if is_reflection_probe { ffi::MI_OBJ_REFLECTION_PROBE } else { ffi::MI_OBJ_IRRADIANCE_VOLUME };
+                push(s, e, t, t.radius_vec3a(bevy_math::Vec3A::ONE), kind, None, false, false, None)?;
+            }
+        }
+        if settings.clustered_decals_are_usable {
+            // decals have a gate of their own (assign.rs:279-296); range = `transform.scale().length()`
+            for (e, t, _) in decals.iter().filter(|q| q.2.get()) {
+                push(s, e, t, t.scale().length(), ffi::MI_OBJ_DECAL, None, false, false, None)?;
             }
         }
 
@@ -1085,7 +1089,8 @@ pub struct Mi355xFrame {
     submit_tick: Tick,
     /// Per active camera, in query order: the frustum the cull used and its `VisibleEntities` lists per class.
     views: Vec<FrameView>,
-    clusters: Option<FrameClusters>,
+    /// One per clustered camera.
+    clusters: Vec<FrameClusters>,
 }
 struct FrameView {
     entity: Entity,
@@ -1144,11 +1149,15 @@ pub fn mi_fused_frame(
         Or<(Changed<Aabb>, Changed<Sphere>, Changed<InheritedVisibility>, Changed<RenderLayers>, Changed<VisibilityClass>, Added<NoFrustumCulling>)>,
     >,
     rows_query: Query<
-        (Entity, &InheritedVisibility, Option<&VisibilityClass>, Option<&RenderLayers>, Option<&Aabb>, Option<&Sphere>, Option<&PointLight>, Has<NoFrustumCulling>, Has<VisibilityRange>),
+        (Entity, &InheritedVisibility, Option<&VisibilityClass>, Option<&RenderLayers>, Option<&Aabb>, Option<&Sphere>, Option<&PointLight>, Option<&SpotLight>, Has<NoFrustumCulling>, Has<VisibilityRange>),
         Without<NoCpuCulling>,
     >,
     point_lights: Query<(Entity, &PointLight, Option<&RenderLayers>)>,
-    other_clusterables: Query<(), Or<(With<SpotLight>, With<RectLight>, With<LightProbe>, With<ClusteredDecal>)>>,
+    spot_lights: Query<(Entity, &SpotLight, Option<&RenderLayers>)>,
+    rect_lights: Query<(Entity, &RectLight, Option<&RenderLayers>)>,
+    // light probes and decals take their range from the GlobalTransform this very frame computes (assign.rs:262, 287): a World
+    // that has any leaves the clusters to `mi_assign_objects_to_clusters`, behind the frame
+    other_clusterables: Query<(), Or<(With<LightProbe>, With<ClusteredDecal>)>>,
     settings: Option<Res<GlobalClusterSettings>>,
 ) {
     frame.valid = false;
@@ -1173,7 +1182,8 @@ pub fn mi_fused_frame(
     // ---- the frame's views: active cameras in query order, each with the frustum update_frusta WILL give it
     let mut views: Vec<ffi::MiView> = Vec::new();
     let mut frame_views: Vec<FrameView> = Vec::new();
-    let mut cluster_camera: Option<(Entity, GlobalTransform, [f32; 24], UVec2, ClusterConfig, u32, [f32; 16])> = None;
+    // every camera with Clusters (assign.rs:324-486 runs per view): (entity, GlobalTransform, frustum, viewport, config, layers, clip_from_view)
+    let mut cluster_cameras: Vec<(Entity, GlobalTransform, [f32; 24], UVec2, ClusterConfig, u32, [f32; 16])> = Vec::new();
     let mut clustered_cameras = 0;
     let result: Result<(), ()> = (|| {
         for (entity, camera, projection, layers, no_cpu_culling, config, has_clusters) in cameras.iter() {
@@ -1207,7 +1217,7 @@ pub fn mi_fused_frame(
                 clustered_cameras += 1;
                 if let Some(size) = camera.physical_viewport_size() {
                     let clip = bevy_camera::CameraProjection::get_clip_from_view(projection).to_cols_array();
-                    cluster_camera = Some((entity, global, planes, size, config.copied().unwrap_or_default(), layer_mask, clip));
+                    cluster_cameras.push((entity, global, planes, size, config.copied().unwrap_or_default(), layer_mask, clip));
                 }
             }
         }
@@ -1250,86 +1260,138 @@ pub fn mi_fused_frame(
         return;
     }
 
-    // ---- the lights ride along when the frame has exactly one clustered camera, storage buffers (no UBO sort / truncate,
-    //      assign.rs:297-321) and point lights only (the riding walk carries no cone test); otherwise the cluster system of its own
+    // ---- the lights ride along: point, spot and (with storage buffers) rect lights, the gather order of assign.rs:190-248, as rows
+    //      of the frame -- the device takes a light's centre (and a spot light's direction) from its row's GlobalTransform and leaves
+    //      out the ones whose ViewVisibility::get() is false.  The first clustered camera's walk rides in the frame kernel; every
+    //      further one (split screen) is assigned behind the frame through a view slot of its own (mi_cluster_select_view).  Not with
+    //      the UBO limit (sort / truncate, assign.rs:297-321), GPU clustering, or light probes / decals in the World.
     let mut with_clusters = false;
     let mut cluster_objects: Vec<(Entity, u8)> = Vec::new();
-    let mut cluster_view: Option<ffi::MiClusterView> = None;
-    if let (Some((view_entity, cam_global, planes, size, config, layer_mask, clip)), Some(settings)) = (cluster_camera.as_ref(), settings.as_ref()) {
-        if clustered_cameras == 1 && settings.supports_storage_buffers && settings.gpu_clustering.is_none() && other_clusterables.is_empty() && !fallback.clusters {
+    let mut cluster_views: Vec<ffi::MiClusterView> = Vec::new();
+    if let Some(settings) = settings.as_ref() {
+        let every_camera_has_a_viewport = cluster_cameras.len() == clustered_cameras;
+        if !cluster_cameras.is_empty()
+            && every_camera_has_a_viewport
+            && cluster_cameras.len() <= ffi::MI_CLUSTER_MAX_VIEWS as usize
+            && settings.supports_storage_buffers
+            && settings.gpu_clustering.is_none()
+            && other_clusterables.is_empty()
+            && !fallback.clusters
+        {
             let r = (|| -> Result<(), ()> {
                 let s = &mut mi.scratch;
                 s.obj_pos_range.clear();
                 s.obj_layers.clear();
+                s.obj_type.clear();
+                s.obj_spot_sin_cos.clear();
                 s.rows.clear();
-                for (e, light, layers) in point_lights.iter() {
-                    let Some(&row) = mi.entity_row.get(&e) else { continue };
-                    s.obj_pos_range.extend_from_slice(&[0.0, 0.0, 0.0, light.range]); // the centre is the row's GlobalTransform
+                let mut any_spot = false;
+                let mut push = |s: &mut Scratch, e: Entity, range: f32, kind: i32, layers: Option<&RenderLayers>, outer_angle: Option<f32>| -> Result<(), ()> {
+                    let Some(&row) = mi.entity_row.get(&e) else { return Ok(()) };
+                    s.obj_pos_range.extend_from_slice(&[0.0, 0.0, 0.0, range]); // the centre is the row's GlobalTransform
+                    s.obj_type.push(kind as u8);
                     s.obj_layers.push(match layers {
                         None => 1,
                         Some(l) => layer_word(l).ok_or(())?,
                     });
+                    let (sin, cos) = outer_angle.map_or((0.0, 0.0), ops_sin_cos);
+                    s.obj_spot_sin_cos.extend_from_slice(&[sin, cos]);
                     s.rows.push(row);
-                    cluster_objects.push((e, ffi::MI_OBJ_POINT_LIGHT as u8));
+                    cluster_objects.push((e, kind as u8));
+                    Ok(())
+                };
+                for (e, light, layers) in point_lights.iter() {
+                    push(s, e, light.range, ffi::MI_OBJ_POINT_LIGHT, layers, None)?;
+                }
+                for (e, light, layers) in spot_lights.iter() {
+                    any_spot = true;
+                    push(s, e, light.range, ffi::MI_OBJ_SPOT_LIGHT, layers, Some(light.outer_angle))?;
+                }
+                // (rect lights are gathered only where they are clustered at all, assign.rs:231-248: storage buffers, checked above)
+                for (e, light, layers) in rect_lights.iter() {
+                    push(s, e, light.range, ffi::MI_OBJ_RECT_LIGHT, layers, None)?;
                 }
                 if cluster_objects.is_empty() {
                     return Err(());
                 }
-                let config = cluster_config_to_ffi(config);
-                let history = mi.cluster_history.entry(*view_entity).or_insert(ffi::MiClusterHistory {
-                    has_farthest_z: 0,
-                    farthest_z: 0.0,
-                    has_total_cluster_index_count: 0,
-                    reserved: 0,
-                    total_cluster_index_count: 0,
-                });
-                // SAFETY: zeroed plain structs are valid "empty" values; every pointer below is a live Vec of the stated length.
-                let mut resolved: ffi::MiClusterResolved = unsafe { core::mem::zeroed() };
-                check(ctx, "mi_cluster_config_resolve", unsafe {
-                    ffi::mi_cluster_config_resolve(&config, history, size.x, size.y, settings.view_cluster_bindings_max_indices as u64, &mut resolved)
-                })?;
-                if resolved.active == 0 {
-                    return Err(()); // Clusters::clear(): the cluster system of its own handles it
-                }
-                let (mut tile, mut dims) = ([0u32; 2], [0u32; 3]);
-                check(ctx, "mi_cluster_view_dims", unsafe {
-                    ffi::mi_cluster_view_dims(size.x, size.y, resolved.requested_dims.as_ptr(), tile.as_mut_ptr(), dims.as_mut_ptr())
-                })?;
-                mi.plane_storage.resize(((dims[0] + dims[1] + dims[2] + 3) * 4) as usize, 0.0);
-                let mut view: ffi::MiClusterView = unsafe { core::mem::zeroed() };
-                let camera_affine = cam_global.affine().to_cols_array();
+                let n_obj = cluster_objects.len() as u32;
+                // SAFETY: every column holds `n_obj` entries (a spot light's direction comes from its row: no spot_dir column).
                 unsafe {
                     check(
                         ctx,
-                        "mi_cluster_view_build",
-                        ffi::mi_cluster_view_build(
-                            camera_affine.as_ptr(),
-                            clip.as_ptr(),
-                            planes.as_ptr(),
-                            size.x,
-                            size.y,
-                            resolved.requested_dims.as_ptr(),
-                            resolved.first_slice_depth,
-                            resolved.far_z,
-                            *layer_mask,
-                            mi.plane_storage.as_mut_ptr(),
-                            ptr::null_mut(),
-                            &mut view,
-                        ),
-                    )?;
-                    check(ctx, "mi_cluster_upload_view", ffi::mi_cluster_upload_view(ctx, &view))?;
-                    let n_obj = cluster_objects.len() as u32;
-                    check(
-                        ctx,
                         "mi_cluster_upload_objects",
-                        ffi::mi_cluster_upload_objects(ctx, n_obj, s.obj_pos_range.as_ptr(), ptr::null(), s.obj_layers.as_ptr(), ptr::null(), ptr::null()),
+                        ffi::mi_cluster_upload_objects(
+                            ctx,
+                            n_obj,
+                            s.obj_pos_range.as_ptr(),
+                            s.obj_type.as_ptr(),
+                            s.obj_layers.as_ptr(),
+                            ptr::null(),
+                            s.obj_spot_sin_cos.as_ptr(),
+                        ),
                     )?;
                     check(ctx, "mi_cluster_bind_objects_to_row_list", ffi::mi_cluster_bind_objects_to_row_list(ctx, n_obj, s.rows.as_ptr()))?;
                 }
-                cluster_view = Some(view);
+                // the views: slot k for the k-th clustered camera; every one is resolved against its own history and uploaded now
+                // (slot 0 last, so that it is the selected one when the frame call runs)
+                for (k, (view_entity, cam_global, planes, size, config, layer_mask, clip)) in cluster_cameras.iter().enumerate().rev() {
+                    let config = cluster_config_to_ffi(config);
+                    let history = mi.cluster_history.entry(*view_entity).or_insert(ffi::MiClusterHistory {
+                        has_farthest_z: 0,
+                        farthest_z: 0.0,
+                        has_total_cluster_index_count: 0,
+                        reserved: 0,
+                        total_cluster_index_count: 0,
+                    });
+                    // SAFETY: zeroed plain structs are valid "empty" values; every pointer below is a live Vec of the stated length.
+                    let mut resolved: ffi::MiClusterResolved = unsafe { core::mem::zeroed() };
+                    check(ctx, "mi_cluster_config_resolve", unsafe {
+                        ffi::mi_cluster_config_resolve(&config, history, size.x, size.y, settings.view_cluster_bindings_max_indices as u64, &mut resolved)
+                    })?;
+                    if resolved.active == 0 {
+                        return Err(()); // Clusters::clear(): the cluster system of its own handles it
+                    }
+                    let (mut tile, mut dims) = ([0u32; 2], [0u32; 3]);
+                    check(ctx, "mi_cluster_view_dims", unsafe {
+                        ffi::mi_cluster_view_dims(size.x, size.y, resolved.requested_dims.as_ptr(), tile.as_mut_ptr(), dims.as_mut_ptr())
+                    })?;
+                    mi.plane_storage.resize(((dims[0] + dims[1] + dims[2] + 3) * 4) as usize, 0.0);
+                    // the clusters' bounding spheres are only read by the cone test of spot lights (assign.rs:693-707)
+                    mi.sphere_storage.resize(if any_spot { (dims[0] * dims[1] * dims[2] * 4) as usize } else { 0 }, 0.0);
+                    let mut view: ffi::MiClusterView = unsafe { core::mem::zeroed() };
+                    let camera_affine = cam_global.affine().to_cols_array();
+                    unsafe {
+                        check(
+                            ctx,
+                            "mi_cluster_view_build",
+                            ffi::mi_cluster_view_build(
+                                camera_affine.as_ptr(),
+                                clip.as_ptr(),
+                                planes.as_ptr(),
+                                size.x,
+                                size.y,
+                                resolved.requested_dims.as_ptr(),
+                                resolved.first_slice_depth,
+                                resolved.far_z,
+                                *layer_mask,
+                                mi.plane_storage.as_mut_ptr(),
+                                if any_spot { mi.sphere_storage.as_mut_ptr() } else { ptr::null_mut() },
+                                &mut view,
+                            ),
+                        )?;
+                        check(ctx, "mi_cluster_select_view", ffi::mi_cluster_select_view(ctx, k as u32))?;
+                        check(ctx, "mi_cluster_upload_view", ffi::mi_cluster_upload_view(ctx, &view))?; // (the library copies the tables)
+                    }
+                    cluster_views.push(view);
+                }
+                cluster_views.reverse(); // cluster_views[k] belongs to cluster_cameras[k]
                 Ok(())
             })();
             with_clusters = r.is_ok();
+            if !with_clusters {
+                // SAFETY: plain call; slot 0 is what every other system of this plugin expects to find selected.
+                let _ = unsafe { ffi::mi_cluster_select_view(ctx, 0) };
+            }
         }
     }
 
@@ -1341,7 +1403,7 @@ pub fn mi_fused_frame(
             lists.push(ffi::MiVisibleList { view: v, class_bit: *bit, capacity: n, count: 0, rows: ptr::null_mut() });
         }
     }
-    let n_clusters = cluster_view.as_ref().map_or(0, |v| v.dims[0] * v.dims[1] * v.dims[2]);
+    let n_clusters = cluster_views.first().map_or(0, |v| v.dims[0] * v.dims[1] * v.dims[2]);
     let mut results = ffi::MiFrameResults {
         flags: ffi::MI_RESULTS_IN_PLACE
             | ffi::MI_RESULTS_CHANGED_ROWS
@@ -1406,7 +1468,8 @@ pub fn mi_fused_frame(
         entities.sort_unstable(); // a no-op for a flat scene (rows are in key order); with a hierarchy the device sorted by key already
         frame_views[view].lists.push((class, entities));
     }
-    if let (true, Some(view), Some((view_entity, ..))) = (with_clusters, cluster_view, cluster_camera.as_ref()) {
+    frame.clusters.clear();
+    if with_clusters {
         let c = n_clusters as usize;
         // SAFETY: offsets c + 1, counts 6 c, indices `cluster_total` entries.
         let (offsets, counts, indices) = unsafe {
@@ -1416,13 +1479,45 @@ pub fn mi_fused_frame(
                 core::slice::from_raw_parts(results.cluster_indices, results.cluster_total as usize).to_vec(),
             )
         };
-        let history = mi.cluster_history.get_mut(view_entity).unwrap();
+        let view_entity = cluster_cameras[0].0;
+        let history = mi.cluster_history.get_mut(&view_entity).unwrap();
         history.has_total_cluster_index_count = 1; // assign.rs:810-811
         history.total_cluster_index_count = results.cluster_total;
         history.has_farthest_z = 1;
         history.farthest_z = results.farthest_z;
-        frame.clusters = Some(FrameClusters { view_entity: *view_entity, view, offsets, counts, indices, objects: cluster_objects });
-        frame.clusters_valid = true;
+        frame.clusters.push(FrameClusters { view_entity, view: cluster_views[0], offsets, counts, indices, objects: cluster_objects.clone() });
+        // the other clustered cameras: the same resident objects and ViewVisibility, their own view slot, assigned behind the frame
+        let others: Result<(), ()> = (|| {
+            for k in 1..cluster_cameras.len() {
+                let view = cluster_views[k];
+                let c = (view.dims[0] * view.dims[1] * view.dims[2]) as usize;
+                let (mut offsets, mut counts) = (vec![0u32; c + 1], vec![0u32; 6 * c]);
+                let mut indices = vec![0u32; cluster_objects.len() * c];
+                let (mut total, mut farthest_z) = (0u64, 0f32);
+                // SAFETY: plain calls on a live context; the outputs hold what the header asks for.
+                unsafe {
+                    check(ctx, "mi_cluster_select_view", ffi::mi_cluster_select_view(ctx, k as u32))?;
+                    check(ctx, "mi_cluster_assign_resident", ffi::mi_cluster_assign_resident(ctx, ptr::null_mut()))?;
+                    check(
+                        ctx,
+                        "mi_cluster_download",
+                        ffi::mi_cluster_download(ctx, offsets.as_mut_ptr(), indices.as_mut_ptr(), indices.len() as u64, counts.as_mut_ptr(), &mut total, &mut farthest_z),
+                    )?;
+                }
+                indices.truncate(total as usize);
+                let view_entity = cluster_cameras[k].0;
+                let history = mi.cluster_history.get_mut(&view_entity).unwrap();
+                history.has_total_cluster_index_count = 1;
+                history.total_cluster_index_count = total;
+                history.has_farthest_z = 1;
+                history.farthest_z = farthest_z;
+                frame.clusters.push(FrameClusters { view_entity, view, offsets, counts, indices, objects: cluster_objects.clone() });
+            }
+            Ok(())
+        })();
+        // SAFETY: plain call.
+        let _ = unsafe { ffi::mi_cluster_select_view(ctx, 0) };
+        frame.clusters_valid = others.is_ok(); // (else: `mi_assign_objects_to_clusters` runs for every view this frame)
     }
     frame.views = frame_views;
     frame.submit_tick = ticks.this_run();
@@ -1434,7 +1529,7 @@ pub fn mi_fused_frame(
 fn stage_bounds(
     mi: &mut Mi355x,
     rows_query: &Query<
-        (Entity, &InheritedVisibility, Option<&VisibilityClass>, Option<&RenderLayers>, Option<&Aabb>, Option<&Sphere>, Option<&PointLight>, Has<NoFrustumCulling>, Has<VisibilityRange>),
+        (Entity, &InheritedVisibility, Option<&VisibilityClass>, Option<&RenderLayers>, Option<&Aabb>, Option<&Sphere>, Option<&PointLight>, Option<&SpotLight>, Has<NoFrustumCulling>, Has<VisibilityRange>),
         Without<NoCpuCulling>,
     >,
 ) -> Result<(), ()> {
@@ -1453,7 +1548,7 @@ fn stage_bounds(
     s.layers_hi.resize(n, 0);
     s.classes.clear();
     s.classes.resize(n, 0);
-    for (entity, inherited, classes, layers, aabb, sphere, point_light, no_frustum_culling, has_range) in rows_query.iter() {
+    for (entity, inherited, classes, layers, aabb, sphere, point_light, spot_light, no_frustum_culling, has_range) in rows_query.iter() {
         let Some(&row) = mi.entity_row.get(&entity) else { continue };
         let row = row as usize;
         let mut flags = 0u32;
@@ -1470,12 +1565,13 @@ fn stage_bounds(
             flags |= ffi::MI_FLAG_HAS_AABB;
             s.aabb_center[row * 3..row * 3 + 3].copy_from_slice(&aabb.center.to_array());
             s.aabb_half[row * 3..row * 3 + 3].copy_from_slice(&aabb.half_extents.to_array());
-        } else if let Some(light) = point_light {
-            // update_point_light_bounding_spheres keeps Sphere { GlobalTransform::translation, range } on every point light
-            // (point_light.rs:195-208, inserted through Commands): on the device the sphere follows the row's own GlobalTransform,
-            // so a moving light needs no bounds upload and is never culled against last frame's position
+        } else if let Some(range) = point_light.map(|l| l.range).or(spot_light.map(|l| l.range)) {
+            // update_point_light_bounding_spheres / update_spot_light_bounding_spheres keep Sphere { GlobalTransform::translation,
+            // range } on every point and spot light (point_light.rs:195-208, spot_light.rs:221-234, inserted through Commands): on
+            // the device the sphere follows the row's own GlobalTransform, so a moving light needs no bounds upload and is never
+            // culled against last frame's position
             flags |= ffi::MI_FLAG_HAS_SPHERE;
-            s.aabb_half[row * 3] = light.range;
+            s.aabb_half[row * 3] = range;
             s.aabb_half[row * 3 + 1] = f32::from_bits(ffi::MI_SPHERE_AT_TRANSLATION);
         } else if let Some(sphere) = sphere {
             flags |= ffi::MI_FLAG_HAS_SPHERE; // any other world-space Sphere, as it is (visibility/mod.rs:838-843)
@@ -1561,27 +1657,38 @@ pub fn mi_apply_clusters(mi: Res<Mi355x>, mut frame: ResMut<Mi355xFrame>, mut vi
     if !frame.clusters_valid {
         return;
     }
-    let Some(r) = frame.clusters.as_ref() else { return };
-    let Ok(mut clusters) = views.get_mut(r.view_entity) else { return };
-    let history = mi.cluster_history[&r.view_entity];
-    clusters.tile_size = UVec2::from_array(r.view.tile_size);
-    clusters.dimensions = UVec3::from_array(r.view.dims);
-    clusters.near = r.view.near_;
-    clusters.far = r.view.far_;
-    clusters.last_frame_farthest_z = (history.has_farthest_z != 0).then_some(history.farthest_z);
-    clusters.last_frame_total_cluster_index_count =
-        (history.has_total_cluster_index_count != 0).then_some(history.total_cluster_index_count as usize);
-    let n_clusters = (r.view.dims[0] * r.view.dims[1] * r.view.dims[2]) as usize;
-    let mut per_cluster: Vec<ObjectsInClusterCpu> = Vec::with_capacity(n_clusters);
-    for c in 0..n_clusters {
-        let mut objects = ObjectsInClusterCpu::default();
-        for &object in &r.indices[r.offsets[c] as usize..r.offsets[c + 1] as usize] {
-            objects.add_point_light(r.objects[object as usize].0); // (the riding walk carries point lights only)
+    for r in frame.clusters.iter() {
+        let Ok(mut clusters) = views.get_mut(r.view_entity) else { continue };
+        let history = mi.cluster_history[&r.view_entity];
+        clusters.tile_size = UVec2::from_array(r.view.tile_size);
+        clusters.dimensions = UVec3::from_array(r.view.dims);
+        clusters.near = r.view.near_;
+        clusters.far = r.view.far_;
+        clusters.last_frame_farthest_z = (history.has_farthest_z != 0).then_some(history.farthest_z);
+        clusters.last_frame_total_cluster_index_count =
+            (history.has_total_cluster_index_count != 0).then_some(history.total_cluster_index_count as usize);
+        let n_clusters = (r.view.dims[0] * r.view.dims[1] * r.view.dims[2]) as usize;
+        let mut per_cluster: Vec<ObjectsInClusterCpu> = Vec::with_capacity(n_clusters);
+        for c in 0..n_clusters {
+            let mut objects = ObjectsInClusterCpu::default();
+            // (a cluster's list is in gather order -- points, spots, rects -- like the reference's pushes: assign.rs:740-800)
+            for &object in &r.indices[r.offsets[c] as usize..r.offsets[c + 1] as usize] {
+                let (entity, kind) = r.objects[object as usize];
+                match kind as i32 {
+                    ffi::MI_OBJ_POINT_LIGHT => objects.add_point_light(entity),
+                    ffi::MI_OBJ_SPOT_LIGHT => objects.add_spot_light(entity),
+                    ffi::MI_OBJ_RECT_LIGHT => objects.add_rect_light(entity),
+                    ffi::MI_OBJ_REFLECTION_PROBE => objects.add_reflection_probe(entity),
+                    ffi::MI_OBJ_IRRADIANCE_VOLUME => objects.add_irradiance_volume(entity),
+                    _ => objects.add_decal(entity),
+                }
+            }
+            debug_assert_eq!(objects.counts.point_lights, r.counts[c * 6]);
+            debug_assert_eq!(objects.counts.spot_lights, r.counts[c * 6 + 1]);
+            per_cluster.push(objects);
         }
-        debug_assert_eq!(objects.counts.point_lights, r.counts[c * 6]);
-        per_cluster.push(objects);
+        clusters.clusterable_objects = ClusterableObjects::Cpu(per_cluster);
     }
-    clusters.clusterable_objects = ClusterableObjects::Cpu(per_cluster);
 }
 
 /// `bevy_math::ops::sin_cos` -- the libm the reference is built with decides the last bit of a spot light's cone; the column

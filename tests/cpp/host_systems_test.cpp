@@ -350,6 +350,83 @@ static void lights_are_assigned_to_clusters() {
             }
 }
 
+// assign.rs:190-248, 563-573, 681-738: the gather takes point lights, then spot lights, then -- only with storage buffers -- rect
+// lights; a spot light is assigned to the clusters its cone reaches; every cluster's list is in gather order and its per-type counts
+// add up.  Runs in both forms of the boundary (driven by main); `compare` = the other form's result of the same World.
+static Clusters all_kinds_frame(bool fused, bool storage_buffers, std::vector<Entity>* spots_out, std::vector<Entity>* rects_out) {
+    World w;
+    Mi355xPlugin plugin;
+    w.set_supports_storage_buffers(storage_buffers);
+    std::vector<Entity> points, spots, rects;
+    uint64_t rng = 0x1234567ull;
+    auto next = [&rng]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (float)(rng % 20001) / 10000.0f - 1.0f; };
+    for (int i = 0; i < 90; ++i) {  // interleaved spawn order: the gather order is by kind, then by Entity
+        Transform t = Transform::from_xyz(14.0f * next(), 8.0f * next(), -6.0f - 40.0f * (0.5f + 0.5f * next()));
+        const float a = 1.5f * next(), b = 1.0f * next();
+        t.rotation = {std::sin(a) * std::cos(b), std::sin(b), 0.1f, std::cos(a)};
+        const float ln = std::sqrt(t.rotation.x * t.rotation.x + t.rotation.y * t.rotation.y + t.rotation.z * t.rotation.z + t.rotation.w * t.rotation.w);
+        t.rotation = {t.rotation.x / ln, t.rotation.y / ln, t.rotation.z / ln, t.rotation.w / ln};
+        Entity e = w.spawn(t);
+        if (i % 3 == 0) { w.insert_point_light(e, 2.0f + 2.0f * (0.5f + 0.5f * next())); points.push_back(e); }
+        else if (i % 3 == 1) { w.insert_spot_light(e, 6.0f + 6.0f * (0.5f + 0.5f * next()), 0.2f + 0.5f * (0.5f + 0.5f * next())); spots.push_back(e); }
+        else { w.insert_rect_light(e, 3.0f + 2.0f * (0.5f + 0.5f * next())); rects.push_back(e); }
+    }
+    Entity behind = w.spawn(Transform::from_xyz(0.0f, 0.0f, 40.0f));
+    w.insert_spot_light(behind, 3.0f, 0.4f);  // behind the camera: hidden by its bounding Sphere (spot_light.rs:221-234), never gathered
+    ClusterCamera cam;
+    mi_perspective_clip_from_view(3.14159265f / 4.0f, 16.0f / 9.0f, 0.1f, cam.clip_from_view);
+    mi_compute_frustum(cam.clip_from_view, cam.camera_affine, 1000.0f, cam.frustum);
+    View view;
+    std::memcpy(view.frustum, cam.frustum, sizeof view.frustum);
+    Clusters cl;
+    if (fused) {
+        Mi355xPlugin::FrameOutput out = plugin.frame(w, {view}, &cam);
+        CHECK(out.has_clusters, "the fused frame carries the cluster stage with every kind of light");
+        cl = out.clusters;
+    } else {
+        plugin.propagate_transforms(w);
+        plugin.check_visibility(w, {view});
+        cl = plugin.assign_objects_to_clusters(w, cam);
+    }
+    CHECK(!w.view_visibility(behind), "a spot light behind the camera is not visible");
+    if (spots_out) *spots_out = spots;
+    if (rects_out) *rects_out = rects;
+    return cl;
+}
+static void every_kind_of_light_is_clustered() {
+    for (int storage = 1; storage >= 0; --storage) {
+        std::vector<Entity> spots, rects;
+        const Clusters cl = all_kinds_frame(g_fused, storage != 0, &spots, &rects);
+        const Clusters other = all_kinds_frame(!g_fused, storage != 0, nullptr, nullptr);  // the same World through the other form
+        auto is_in = [](const std::vector<Entity>& v, Entity e) { return std::find(v.begin(), v.end(), e) != v.end(); };
+        uint64_t n_point = 0, n_spot = 0, n_rect = 0, total = 0;
+        bool grouped = true, counts_ok = true, same = cl.clusterable_objects.size() == other.clusterable_objects.size();
+        for (size_t c = 0; c < cl.clusterable_objects.size(); ++c) {
+            const ObjectsInCluster& o = cl.clusterable_objects[c];
+            total += o.entities.size();
+            uint32_t k[3] = {0, 0, 0};
+            int last_kind = 0;
+            for (Entity e : o.entities) {
+                const int kind = is_in(spots, e) ? 1 : is_in(rects, e) ? 2 : 0;
+                grouped = grouped && kind >= last_kind;  // points, then spots, then rects: the gather order
+                last_kind = kind;
+                ++k[kind];
+            }
+            counts_ok = counts_ok && o.counts[0] == k[0] && o.counts[1] == k[1] && o.counts[2] == k[2] && o.counts[3] + o.counts[4] + o.counts[5] == 0;
+            n_point += k[0], n_spot += k[1], n_rect += k[2];
+            if (same) same = o.entities.size() == other.clusterable_objects[c].entities.size() &&
+                             std::equal(o.entities.begin(), o.entities.end(), other.clusterable_objects[c].entities.begin()) &&
+                             std::memcmp(o.counts, other.clusterable_objects[c].counts, sizeof o.counts) == 0;
+        }
+        CHECK(grouped, "every cluster lists point lights, then spot lights, then rect lights");
+        CHECK(counts_ok, "ClusterableObjectCounts per type agree with the lists");
+        CHECK(n_point > 0 && n_spot > 0, "point and spot lights reach clusters");
+        CHECK(storage ? n_rect > 0 : n_rect == 0, "rect lights are gathered only with storage buffers (assign.rs:231-248)");
+        CHECK(total == cl.total_index_count, "total_cluster_index_count");
+        CHECK(same && cl.farthest_z == other.farthest_z && cl.total_index_count == other.total_index_count, "both forms of the boundary leave the same Clusters");
+    }
+}
+
 // crates/bevy_render/src/render_phase/mod.rs:2356-2700 (proptest render_multidrawable_batch_set): random Add / Remove
 // of mock mesh instances (entity 0..32, bin 0..8, distinct input uniform indices), then the invariants -- a bin's
 // instance_count is the number of entities in it, every binned instance appears exactly once with its input uniform
@@ -703,6 +780,7 @@ int main(int argc, char** argv) {
                        {"view_visibility_lifecycle", view_visibility_lifecycle},
                        {"visible_entities_are_sorted_by_entity", visible_entities_are_sorted_by_entity},
                        {"lights_are_assigned_to_clusters", lights_are_assigned_to_clusters},
+                       {"every_kind_of_light_is_clustered", every_kind_of_light_is_clustered},
                        {"render_multidrawable_batch_set", render_multidrawable_batch_set},
                        {"both_forms_leave_the_same_world", both_forms_leave_the_same_world},
                        {"big_flat_worlds_agree", big_flat_worlds_agree}};

@@ -840,7 +840,7 @@ class Context:
         return out
 
     def debug_set_tile_mode(self, mode):
-        """What the next upload_hierarchy plans: 0 light tiles where they fit, 1 big tiles, 2 light tiles always, 3 as 0 with the
+        """What the next upload_hierarchy plans: 0 subtree tiles where they fit, 1 level by level whatever the shape, 2 as 0, 3 as 0 with the
         streamed-level thresholds at their test values (2^20 / 2^21 rows) -- test / bench hook."""
         self._ck(self._lib.mi_debug_set_tile_mode(self._h, int(mode)))
 

@@ -538,7 +538,7 @@ static bool cells_frame_eligible(mi_ctx* ctx, const mi_view* views, uint32_t n_v
     bool ok = views && n_views && n_views <= SPH_MAX_VIEWS && ce.mode != 1 && ctx->sph_mode != 1 && ctx->n &&
               ctx->n >= (ce.mode == 2 ? 1u : ce.min_rows) && (flags & (MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME)) == (MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME) &&
               !(flags & (MI_CULL_WITH_CLUSTERS | MI_CULL_CHANGED_ROWS)) && !ctx->have_class_mask && !ctx->have_ranges && !ctx->ext_bitmask && !ctx->xch.on &&
-              ctx->sph_state == mi_ctx::SPH_VALID && ctx->sph.p && !ctx->tree_trace.p;
+              ctx->sph_state == mi_ctx::SPH_VALID && ctx->sph.p;
     for (uint32_t v = 0; ok && v < n_views; ++v) ok = !(views[v].flags & MI_VIEW_FLAG_SHADOW);
     if (!ok) {
         ce.quiet = 0;
@@ -1644,7 +1644,17 @@ int32_t mi_propagate(mi_ctx* ctx, uint32_t flags) {
                                     ctx->changed_rows_hint * 16 <= n_tiles_all);
         TreeCull tcull_rest;  // (the compaction riders of a fused hierarchy frame go with the first launch only)
         const TreeCull* tcull = ctx->tcull;
+        if (ctx->by_levels) {
+            // a hierarchy the tiles cannot hold (ctx_hierarchy.cpp): level 0 with the roots' rule, then each level behind its parents'
+            for (uint32_t l = 0; l < ctx->n_levels; ++l) {
+                ProfScope sc(ctx, K_PROPAGATE_STREAM);
+                const uint32_t s = ctx->level_offsets[l], cnt = ctx->level_offsets[l + 1] - s;
+                HIP_TRY(ctx, launch_propagate_level(c, (const uint32_t*)ctx->parent_idx.p, s, cnt, ctx->changed, tree_bits, ctx->g_changed_bytes,
+                                                    all_dirty, static_opt, ctx->stream, l == 0 ? (const uint8_t*)ctx->node_flags.p : nullptr));
+            }
+        }
         for (auto& gr : ctx->groups) {
+            if (ctx->by_levels) break;
             ProfScope sc(ctx, K_PROPAGATE_TILES);
             if (tcull && &gr != &ctx->groups.front() && tcull == ctx->tcull) {
                 tcull_rest = *tcull;
@@ -1655,9 +1665,10 @@ int32_t mi_propagate(mi_ctx* ctx, uint32_t flags) {
                                                 (const uint32_t*)ctx->chains.p + (size_t)gr.first * TILE_MAX_CHAIN, gr.count,
                                                 (const uint8_t*)ctx->node_flags.p, ctx->changed, tree_bits, ctx->g_changed_bytes,
                                                 gr.n_chain ? snap_r : nullptr, snap_w, ctx->snap_rows, all_dirty, static_opt,
-                                                ctx->tiles_light, ctx->stream, (unsigned long long*)ctx->tree_trace.p, tiles_pretest, tcull));
+                                                ctx->stream, (unsigned long long*)ctx->tree_trace.p, tiles_pretest, tcull));
         }
         for (auto& lv : ctx->stream_levels) {  // the wide deepest levels, each behind the level above it
+            if (ctx->by_levels) break;
             ProfScope sc(ctx, K_PROPAGATE_STREAM);
             HIP_TRY(ctx, launch_propagate_level(c, (const uint32_t*)ctx->parent_idx.p, lv.first, lv.second, ctx->changed, tree_bits,
                                                 ctx->g_changed_bytes, all_dirty, static_opt, ctx->stream));
@@ -1729,9 +1740,9 @@ int32_t mi_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_mas
 static bool tree_frame_fusable(mi_ctx* ctx, uint32_t n_views, uint32_t flags) {
     // (default: with one view, where it measured faster -- 34.7 against 37.1 us per frame of the 1 M-node tree; with four views the
     // rule's arithmetic inside the tiles costs more than the second pass over GlobalTransform: 51.4 against 44.7)
-    return (ctx->tree_cull_mode == 2 || (ctx->tree_cull_mode == 0 && n_views == 1)) && ctx->n && ctx->tiles_light && ctx->stream_levels.empty() && !ctx->groups.empty() && n_views <= MAX_INLINE_VIEWS &&
+    return (ctx->tree_cull_mode == 2 || (ctx->tree_cull_mode == 0 && n_views == 1)) && ctx->n && !ctx->by_levels && ctx->stream_levels.empty() && !ctx->groups.empty() && n_views <= MAX_INLINE_VIEWS &&
            !(flags & (MI_CULL_CHANGED_ROWS | MI_CULL_WITH_CLUSTERS)) && (flags & MI_CULL_END_FRAME) && !ctx->have_class_mask && !ctx->have_ranges &&
-           !ctx->ext_bitmask && !ctx->xch.on && !ctx->tree_trace.p;
+           !ctx->ext_bitmask && !ctx->xch.on;
 }
 static int32_t tree_frame_fused(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint32_t flags) {
     ctx->cells.valid = false;  // (the tiles write ViewVisibility)

@@ -88,13 +88,13 @@ struct mi_ctx {
     DevBuf parent_idx, node_flags, tiles;
     std::vector<std::pair<uint32_t, uint32_t>> passes;  // (first tile, n tiles); pass 0 starts at level 0 (roots)
     struct TileGroup { uint32_t first, count, n_chain, owner_rows; };
-    bool tiles_light = false;       // the plan was made for the light tile kernel (TILE_LIGHT_*)
+    bool by_levels = false;         // some tile of the plan overflows the tile kernel's LDS rows (or the row count its 32-bit offsets): mi_propagate sweeps level by level
     DevBuf anc;                     // the ancestor table (kernels.h, ANC_DEPTH): built by mi_upload_hierarchy; in use while anc_valid
     bool anc_valid = false;
     const mi::TreeCull* tcull = nullptr;  // set by the fused hierarchy frame around its mi_propagate: the tile launches also cull
     int32_t tree_cull_mode = 0;           // mi_debug_set_tree_cull: 0 = fused where it applies and there is one view (default), 1 = never, 2 = whenever it applies
     int32_t tile_pretest_mode = 0;  // mi_debug_set_tile_pretest
-    int32_t tile_mode = 0;          // 0 = light tiles where they fit, 1 = always the big tiles, 2 = always light, 3 = as 0 with the streamed-level thresholds at their test values (mi_debug_set_tile_mode)
+    int32_t tile_mode = 0;          // 0 = tiles where they fit, 1 = always level by level, 2 = as 0, 3 = as 0 with the streamed-level thresholds at their test values (mi_debug_set_tile_mode)
     std::vector<TileGroup> groups;  // tile launches of mi_propagate: roots + chain bands in one, then one per dependent band
     std::vector<std::pair<uint32_t, uint32_t>> stream_levels;  // (start, count), top-down: the wide deepest levels, one streaming launch each
     DevBuf tree_trace;              // mi_debug_tree_trace: 8 timestamps per tile of the light tile kernel

@@ -67,9 +67,10 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
 
     // ---- tile plan ----
     // A tile = a contiguous row range at its first level plus all the descendants of those rows over the next levels,
-    // walked by one workgroup (kernels_tree.hip).  It "fits" when all its levels but the last together hold <= TILE_UCAP rows
-    // (they live in LDS); the last level is streamed and may be any size (kept <= TILE_LAST_CAP to spread the work).  Levels are cut into BANDS of consecutive levels, bottom-up, so that the bottom band -- where nearly all the
-    // rows of a tree are -- gets the deepest tiles the LDS budget allows.  Three kinds of band:
+    // walked by one workgroup (kernels_tree.hip).  It "fits" when all its levels but the last together hold <= TILE_LIGHT_UCAP
+    // rows (they live in LDS); the last level is streamed and may be any size (kept <= TILE_LIGHT_LAST_CAP to spread the work).
+    // Levels are cut into BANDS of consecutive levels, bottom-up, so that the bottom band -- where nearly all the rows of a
+    // tree are -- gets the deepest tiles the LDS budget allows.  Three kinds of band:
     //   roots      first level = level 0 (forest roots and flat rows); a tile may span many roots;
     //   chain      every tile's first-level rows are children of ONE node whose ancestor chain (<= TILE_MAX_CHAIN nodes)
     //              the tile re-evaluates itself -- same products, same order, hence the same bits as the tiles that own
@@ -79,13 +80,10 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
     // Roots and chain bands are mutually independent: they share ONE launch, whatever the depth of the hierarchy.
     std::vector<TileDesc> tiles;
     std::vector<uint32_t> chains;
-    auto make_plan = [&](const bool light) {
-        tiles.clear();
-        chains.clear();
-        // Big hierarchies are cut into light tiles (kernels.h): four times as many, each short-lived, several rounds of them per
-        // CU -- the head of one tile (descriptor, ancestor chain, LDS levels) then runs under the streaming of its neighbours.
-        const uint32_t UCAP = light ? TILE_LIGHT_UCAP : TILE_UCAP, LAST_CAP = light ? TILE_LIGHT_LAST_CAP : TILE_LAST_CAP;
-        ctx->tiles_light = light;
+    {
+        // Short-lived tiles, several rounds of them per CU: the head of one tile (descriptor, ancestor chain, LDS levels) runs
+        // under the streaming of its neighbours.
+        const uint32_t UCAP = TILE_LIGHT_UCAP, LAST_CAP = TILE_LIGHT_LAST_CAP;
         ctx->passes.clear();
         ctx->groups.clear();
         ctx->stream_levels.clear();
@@ -146,7 +144,7 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
             while (a < rhi) {
                 TileDesc best{};
                 uint32_t b = a + 1;
-                build(a, b, best);  // a single first-level row always makes a tile (the kernel streams what does not fit)
+                build(a, b, best);  // a single first-level row always makes a tile (one that does not fit sends the plan to the level sweep, below)
                 uint32_t step = 1;
                 while (b < rhi) {
                     const uint32_t nb = (uint32_t)std::min<uint64_t>((uint64_t)b + step, rhi);
@@ -193,21 +191,19 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
         chains.resize(tiles.size() * (size_t)TILE_MAX_CHAIN, 0u);
         // the bands top-down, for the kernels that sweep level by level with one launch per band (InheritedVisibility)
         for (size_t i = bands.size(); i-- > 0;) ctx->passes.emplace_back(band_tiles[i].first, band_tiles[i].second);
-    };
-    bool light = (ctx->tile_mode == 2 || ((ctx->tile_mode == 0 || ctx->tile_mode == 3) && n >= TILE_LIGHT_MIN_ROWS)) &&
-                 n <= 0xFFFFFFFFu / 48u;  // the light kernel addresses rows with 32-bit byte offsets
-    make_plan(light);
-    if (light) {
-        // the light kernel has no fallback for upper levels that overflow its LDS rows (a single node with hundreds of
-        // children that have children of their own): such a hierarchy keeps the big tiles, whose kernel streams what does not fit
-        bool fits = true;
-        for (const TileDesc& td : tiles) {
-            uint64_t up = 0;
-            for (uint32_t k = 0; k + 1 < td.n_levels; ++k) up += td.count[k];
-            fits = fits && up <= TILE_LIGHT_UCAP;
-        }
-        if (!fits) make_plan(light = false);
     }
+    // The tile kernel has no fallback for upper levels that overflow its LDS rows (a single node with hundreds of children
+    // that have children of their own) and addresses rows with 32-bit byte offsets: such a hierarchy is swept level by level,
+    // one streaming launch per level (mi_propagate).  The tile list stays: the InheritedVisibility sweep walks it whatever its
+    // tiles hold (k_inherit_tiles falls back to global memory past its own LDS bytes).
+    ctx->by_levels = ctx->tile_mode == 1 || n > 0xFFFFFFFFu / 48u;
+    for (const TileDesc& td : tiles) {
+        uint64_t up = 0;
+        for (uint32_t k = 0; k + 1 < td.n_levels; ++k) up += td.count[k];
+        if (up > TILE_LIGHT_UCAP) ctx->by_levels = true;
+    }
+    if (ctx->by_levels)
+        for (auto& gr : ctx->groups) gr.n_chain = gr.owner_rows = 0;  // (no chain tile runs: no snapshot to keep)
     int32_t rc;
     if ((rc = ensure(ctx, ctx->parent_idx, (size_t)n * 4))) return rc;
     if ((rc = ensure(ctx, ctx->node_flags, n))) return rc;
@@ -236,7 +232,8 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
 }
 
 // test / bench hook (not part of the public header): which tile kernel the NEXT mi_upload_hierarchy plans for
-// (0 = chosen by size, 1 = big tiles, 2 = light tiles where they fit)
+// (0 = tiles where they fit, 1 = level by level whatever the shape, 2 = as 0 (the light tiles of earlier rounds), 3 = as 0 with the
+// streamed-level thresholds at their test values)
 int32_t mi_debug_set_tile_mode(mi_ctx* ctx, int32_t mode) {
     ENTER(ctx);
     if (mode < 0 || mode > 3) return fail(ctx, MI_ERR_INVALID_ARG, "mi_debug_set_tile_mode: mode %d", mode);
@@ -270,7 +267,7 @@ int32_t mi_debug_tile_plan(mi_ctx* ctx, uint32_t* out_launches, uint32_t* out_ti
     ENTER(ctx);
     uint32_t tiles = 0, chain = 0;
     for (auto& g : ctx->groups) { tiles += g.count; chain += g.n_chain; }
-    if (out_launches) *out_launches = (uint32_t)ctx->groups.size();
+    if (out_launches) *out_launches = ctx->by_levels ? ctx->n_levels : (uint32_t)ctx->groups.size();  // (tile launches; by levels: one per level)
     if (out_tiles) *out_tiles = tiles;
     if (out_chain_tiles) *out_chain_tiles = chain;
     if (out_bands) *out_bands = (uint32_t)ctx->passes.size();

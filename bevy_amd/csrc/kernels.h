@@ -391,14 +391,12 @@ hipError_t launch_compact_fast(const CompactFastArgs& a, hipStream_t stream);
 
 // ---- hierarchy ---------------------------------------------------------------------------------
 constexpr uint32_t TILE_MAX_LEVELS = 8;
-constexpr uint32_t TILE_BLOCK = 256;           // threads per tile
-constexpr uint32_t TILE_UCAP = 512;            // LDS slots of one tile: rows of all its levels but the last
-constexpr uint32_t TILE_LAST_CAP = 1024;       // the planner keeps a tile's streamed last level at or below this
-// Light tiles: a quarter of the LDS rows and a last level of one row per thread, nothing software-pipelined -- so the
-// kernel fits twice the workgroups per CU and a tile is two dependent round trips, not seven.
-constexpr uint32_t TILE_LIGHT_UCAP = 112;
-constexpr uint32_t TILE_LIGHT_LAST_CAP = 256;
-constexpr uint32_t TILE_LIGHT_MIN_ROWS = 0;  // light tiles whenever they fit: measured faster from 341 to 1 M nodes
+// Light tiles (the only tiles since round 4): few LDS rows and a last level of one row per thread, nothing software-pipelined
+// -- eight workgroups per CU, a tile is two dependent round trips.  A hierarchy that cannot be cut into them is swept level by
+// level (k_propagate_level), see ctx_hierarchy.cpp.
+constexpr uint32_t TILE_LIGHT_UCAP = 112;      // LDS slots of one tile: rows of all its levels but the last
+constexpr uint32_t TILE_LIGHT_LAST_CAP = 256;  // the planner keeps a tile's streamed last level at or below this
+constexpr uint32_t TILE_INHERIT_UCAP = 512;    // k_inherit_tiles: upper rows whose InheritedVisibility state it keeps in LDS (one byte each)
 // A level this wide is not given to tiles at all: it is swept by a streaming launch of its own (k_propagate_level) behind
 // the level above it.  The deepest level qualifies earlier than the ones above it (nothing else has to wait for it).
 // With the light tile kernel at 8 workgroups per CU the tiles win on everything measured -- 1.4 M nodes 36.0 against 39.6 us per
@@ -448,13 +446,15 @@ struct TreeCull {
 hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, const TileDesc* d_tiles, const uint32_t* d_chains,
                                   uint32_t n_tiles, const uint8_t* node_flags, const uint8_t* changed, const uint8_t* tree_bytes,
                                   uint8_t* g_changed_bytes, const float* snap_read, float* snap_write, uint32_t snap_rows, bool all_dirty,
-                                  bool static_opt, bool light /* the plan is one of light tiles */, hipStream_t stream,
-                                  unsigned long long* trace = nullptr, bool pretest = false /* light tiles, static-scene rule: flags first */,
-                                  const TreeCull* cull = nullptr /* all-dirty light tiles: the visibility systems ride in the launch */);
+                                  bool static_opt, hipStream_t stream,
+                                  unsigned long long* trace = nullptr, bool pretest = false /* static-scene rule: flags first */,
+                                  const TreeCull* cull = nullptr /* all-dirty frames: the visibility systems ride in the launch */);
 // One whole level [start, start + count) as a stream: every row's parent lies in the level above, complete in global
-// memory (an earlier launch).  Same per-node rule as the tiles.
+// memory (an earlier launch).  Same per-node rule as the tiles.  root_node_flags != NULL: the level is level 0 (no parents;
+// the roots' rule reads the has-children bit).
 hipError_t launch_propagate_level(const Columns& c, const uint32_t* parent_idx, uint32_t start, uint32_t count, const uint8_t* changed,
-                                  const uint8_t* tree_bytes, uint8_t* g_changed_bytes, bool all_dirty, bool static_opt, hipStream_t stream);
+                                  const uint8_t* tree_bytes, uint8_t* g_changed_bytes, bool all_dirty, bool static_opt, hipStream_t stream,
+                                  const uint8_t* root_node_flags = nullptr);
 hipError_t launch_inherit_level(const uint32_t* parent_idx, uint32_t start, uint32_t count, const uint8_t* visibility, uint8_t* flags,
                                 uint8_t* inh_changed, hipStream_t stream);
 // InheritedVisibility propagation (visibility_propagate_system): writes bit0 of flags[] and changed bytes.

@@ -3,23 +3,22 @@
 //   propagate_parent_transforms   crates/bevy_transform/src/systems.rs:506-748 (roots :522-530, descendants :679-748)
 //   sync_simple_transforms        crates/bevy_transform/src/systems.rs:42-79 (flat rows sharing level 0 with the roots)
 //
-// Rows are in level (BFS) order, so the descendants of a contiguous range of nodes form one
-// contiguous range per level.  A workgroup owns a *subtree tile*: a contiguous range of nodes at the
-// tile's first level plus all their descendants for the next few levels (the reference's mpsc work
-// queue of 512-entity chunks, systems.rs:767-813, becomes the tile list).  The tile is walked in
-// three steps:
-//   step 0  every row of the tile's upper levels (all but the last; <= TILE_UCAP rows together) gets
-//           its local affine computed from T/R/S into an LDS slot, and its old GlobalTransform and
-//           parent slot fetched into registers -- ALL upper levels at once, so the HBM latency is
-//           paid once per tile, not once per level;
-//   step 1  level by level (workgroup barrier in between) G = G_parent * local, both operands read
-//           from LDS (three ds_read_b128 each); the result overwrites the local affine in place;
-//   step 2  the tile's last level -- usually ~3/4 of its rows -- is streamed: coalesced T/R/S and
-//           old-G loads (wave-local LDS transpose), parent G from LDS, coalesced G stores.
-// One launch therefore covers up to TILE_MAX_LEVELS levels with one HBM round trip of latency plus
-// the streaming time.  A level wider than the LDS budget inside a tile falls back to reading its
-// parents from global memory, so any plan is correct; the host planner (context.cpp) only chooses
-// the fast one.
+// Rows are in level (BFS) order, so the descendants of a contiguous range of nodes form one contiguous range per level.
+// A workgroup owns a *subtree tile*: a contiguous range of nodes at the tile's first level plus all their descendants for
+// the next few levels (the reference's mpsc work queue of 512-entity chunks, systems.rs:767-813, becomes the tile list).
+// k_propagate_fans walks a tile in three steps:
+//   step 0  every row of the tile's upper levels (all but the last; <= TILE_LIGHT_UCAP rows together) gets its local affine
+//           computed from T/R/S into an LDS slot together with its old GlobalTransform and its parent's slot -- ALL upper
+//           levels at once, so the HBM latency is paid once per tile, not once per level;
+//   step 1  level by level (workgroup barrier in between) G = G_parent * local, both operands read from LDS; the result
+//           overwrites the local affine in place;
+//   step 2  the tile's last level -- usually ~3/4 of its rows -- is streamed: coalesced T/R/S and old-G loads (wave-local
+//           LDS transpose), parent G from LDS, coalesced G stores.
+// One launch therefore covers up to TILE_MAX_LEVELS levels with one HBM round trip of latency plus the streaming time.
+// A hierarchy the planner cannot cut into such tiles (one node with hundreds of children that have children of their own:
+// its upper rows overflow the LDS slots) is swept level by level instead, one k_propagate_level launch per level -- the
+// kernel the widest levels of very big trees take anyway.  (Rounds 1-3 kept a second, big-tile kernel for those shapes;
+// it had not followed the light kernel's changes and is gone.)
 //
 // Algorithmic bytes per node: read T 40 + parent_idx 4 + old G 48 (set_if_neq, systems.rs:719),
 // write G 48 + changed 1; parent G comes from LDS (first level of a non-root tile: from L2).
@@ -33,6 +32,7 @@ namespace mi {
 struct F3 {
     float x, y, z;
 };
+
 __device__ __forceinline__ V3 ld3(const float* base, uint32_t row) {
     const F3 v = reinterpret_cast<const F3*>(base)[row];
     return V3{v.x, v.y, v.z};
@@ -316,267 +316,6 @@ __device__ __forceinline__ RowFetch fetch_row(const Columns& c, const uint32_t* 
     return f;
 }
 
-template <uint32_t BLOCK>
-struct TileLds {
-    float4* g;            // [TILE_UCAP * 3] upper-level rows: local affine, then GlobalTransform (in place)
-    uint8_t* chg;         // [TILE_UCAP]
-    float4 (*stage)[192]; // [BLOCK / 64][192] wave-private transpose rows for the streamed level
-    float4* chain;        // [TILE_MAX_CHAIN * 6] per chain node: local affine (3) + old GlobalTransform (3)
-    uint8_t* chain_in;    // [TILE_MAX_CHAIN] bit0 tree_changed, bit1 root_write
-    float4* chain_g;      // [3] the tile root's GlobalTransform ...
-    uint32_t* chain_chg;  // ... and whether its tick was bumped
-};
-
-template <uint32_t BLOCK>
-__device__ __forceinline__ void process_tile(const Columns& c, const TreeArgs& a, uint32_t tile, const TileLds<BLOCK>& lds) {
-    constexpr uint32_t R = (TILE_UCAP + BLOCK - 1) / BLOCK;  // LDS-resident rows per thread
-    float4* const lds_g = lds.g;
-    uint8_t* const lds_chg = lds.chg;
-    float4 (*const lds_stage)[192] = lds.stage;
-    float4* const lds_chain = lds.chain;
-    uint8_t* const lds_chain_in = lds.chain_in;
-    float4* const lds_chain_g = lds.chain_g;
-    uint32_t& lds_chain_chg = *lds.chain_chg;
-    const TileDesc td = load_tile_desc(a.tiles + tile);
-    const uint32_t L = td.n_levels;
-    const bool ROOTS = (td.kind & TILE_ROOTS) != 0;
-    const uint32_t chain_len = td.kind & TILE_CHAIN_MASK;
-    float* const snap_out = a.snap_write;  // launches with chain tiles: rows below snap_rows are mirrored for the next frame
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-
-    // Leading levels resident in LDS: every level but the last, while the running row total fits.
-    uint32_t ubase[TILE_MAX_LEVELS + 1];
-    ubase[0] = 0;
-    uint32_t n_lds = 0, U = 0;
-#pragma unroll
-    for (uint32_t l = 0; l < TILE_MAX_LEVELS; ++l) {
-        const uint32_t cnt = l < L ? td.count[l] : 0u;
-        ubase[l + 1] = ubase[l] + cnt;
-        if (l + 1 < L && n_lds == l && ubase[l + 1] <= TILE_UCAP) {
-            n_lds = l + 1;
-            U = ubase[l + 1];
-        }
-    }
-
-    // ---- step 0: fetch everything the LDS-resident levels need, all levels at once -------------------
-    Affine old_g[R];
-    uint32_t my_row[R], my_level[R], my_pslot[R];
-#pragma unroll
-    for (uint32_t k = 0; k < R; ++k) {
-        const uint32_t u = tid + BLOCK * k;
-        my_level[k] = 0xFFFFFFFFu;
-        my_row[k] = 0;
-        my_pslot[k] = 0;
-        old_g[k] = Affine{};
-        if (u < U) {
-            uint32_t l = 0;
-#pragma unroll
-            for (uint32_t j = 1; j < TILE_MAX_LEVELS; ++j)
-                if (j < n_lds && u >= ubase[j]) l = j;
-            uint32_t lstart = td.start[0], lbase = 0, pstart = 0, pbase = 0;
-#pragma unroll
-            for (uint32_t j = 1; j < TILE_MAX_LEVELS; ++j)
-                if (j == l) {
-                    lstart = td.start[j];
-                    lbase = ubase[j];
-                    pstart = td.start[j - 1];
-                    pbase = ubase[j - 1];
-                }
-            const uint32_t row = lstart + (u - lbase);
-            my_level[k] = l;
-            my_row[k] = row;
-            const Affine local = affine_from_srt(ld3(c.scale, row), ld4(c.rotation, row), ld3(c.translation, row));
-            lds_put(lds_g, u, local);
-            old_g[k] = ld_affine(c.global, row);
-            if (!(ROOTS && l == 0)) {
-                const uint32_t p = a.parent_idx[row];
-                // parent's LDS slot (levels >= 1 of the tile) or its global row (level 0 of a non-root tile)
-                my_pslot[k] = l ? pbase + (p - pstart) : p;
-            }
-        }
-    }
-    if (tid < chain_len) {  // chain tiles: one thread per ancestor fetches what the rule needs
-        const uint32_t row = a.chains[(size_t)tile * TILE_MAX_CHAIN + tid];
-        const bool is_root = tid + 1u == chain_len;
-        lds_put(lds_chain, 2u * tid, affine_from_srt(ld3(c.scale, row), ld4(c.rotation, row), ld3(c.translation, row)));
-        lds_put(lds_chain, 2u * tid + 1u, ld_affine(a.snap_read, row));  // pre-frame value (see TreeArgs)
-        const NodeIn in = node_inputs(a, row, is_root);
-        lds_chain_in[tid] = (uint8_t)((in.tree_changed ? 1u : 0u) | (in.root_write ? 2u : 0u));
-    }
-    // The first streamed level's inputs do not depend on step 1 either: put its loads in flight now.
-    uint32_t s_start = td.start[0], s_count = L ? td.count[0] : 0u;
-#pragma unroll
-    for (uint32_t j = 1; j < TILE_MAX_LEVELS; ++j)
-        if (j == n_lds) {
-            s_start = td.start[j];
-            s_count = j < L ? td.count[j] : 0u;
-        }
-    RowFetch cur_f = fetch_row(c, a.parent_idx, s_start, s_count, 0u, tid, lane, wv, ROOTS && n_lds == 0);
-    __syncthreads();
-    if (chain_len) {
-        if (tid == 0) {  // forest root first, down to the tile's root: the same products the owning tiles compute
-            Affine g = {};
-            bool chg = false;
-            for (uint32_t k = chain_len; k-- > 0;) {
-                const bool is_root = k + 1u == chain_len;
-                NodeIn in;
-                in.tree_changed = (lds_chain_in[k] & 1u) != 0;
-                in.root_write = (lds_chain_in[k] & 2u) != 0;
-                const Affine local = lds_affine(lds_chain, 2u * k), old = lds_affine(lds_chain, 2u * k + 1u);
-                Affine cur;
-                chg = node_apply(is_root, a.static_opt != 0, in, g, chg, local, old, &cur);
-                g = cur;
-            }
-            lds_put(lds_chain_g, 0, g);
-            lds_chain_chg = chg ? 1u : 0u;
-        }
-        __syncthreads();
-    }
-
-    // ---- step 1: LDS-resident levels ---------------------------------------------------------------
-    bool any_chg = false;
-    for (uint32_t l = 0; l < n_lds; ++l) {
-#pragma unroll
-        for (uint32_t k = 0; k < R; ++k) {
-            if (my_level[k] == l) {
-                const uint32_t u = tid + BLOCK * k, row = my_row[k];
-                const Affine local = lds_affine(lds_g, u);
-                Affine cur;
-                bool chg;
-                if (ROOTS && l == 0) {
-                    chg = node_update(a, true, row, local, false, local, old_g[k], &cur);
-                } else {
-                    Affine gp;
-                    bool p_changed;
-                    if (l) {
-                        gp = lds_affine(lds_g, my_pslot[k]);
-                        p_changed = lds_chg[my_pslot[k]] != 0;
-                    } else if (chain_len) {
-                        gp = lds_affine(lds_chain_g, 0);
-                        p_changed = lds_chain_chg != 0;
-                    } else {
-                        gp = ld_affine(c.global, my_pslot[k]);
-                        p_changed = a.g_changed_bytes[my_pslot[k]] != 0;
-                    }
-                    chg = node_update(a, false, row, gp, p_changed, local, old_g[k], &cur);
-                }
-                any_chg = any_chg || chg;
-                lds_put(lds_g, u, cur);
-                lds_chg[u] = chg ? 1 : 0;  // (the global change byte goes out with the flush: a store in front of the level
-                                           // barrier would make every level wait for its round trip)
-            }
-        }
-        __syncthreads();
-    }
-    // Flush the LDS-resident levels: slots and rows are both contiguous per level, so the write-back is a
-    // straight float4 copy (fully coalesced) instead of one 48-byte scatter per lane.  Unchanged rows hold
-    // their old bytes, so rewriting them is value-neutral; a tile in which nothing changed writes nothing.
-    const bool flush_live = __syncthreads_or(any_chg ? 1 : 0) != 0;
-#pragma unroll
-    for (uint32_t j = 0; j < TILE_MAX_LEVELS - 1; ++j)
-        if (j < n_lds)
-            for (uint32_t i = tid; i < td.count[j]; i += BLOCK) a.g_changed_bytes[td.start[j] + i] = lds_chg[ubase[j] + i];
-    if (flush_live || snap_out) {
-#pragma unroll
-        for (uint32_t j = 0; j < TILE_MAX_LEVELS - 1; ++j) {
-            if (j < n_lds) {
-                float4* dst = reinterpret_cast<float4*>(c.global) + 3ull * td.start[j];
-                float4* snp = (snap_out && td.start[j] < a.snap_rows) ? reinterpret_cast<float4*>(snap_out) + 3ull * td.start[j] : nullptr;
-                const float4* src = lds_g + 3u * ubase[j];
-                const uint32_t n4 = 3u * td.count[j];
-                for (uint32_t i = tid; i < n4; i += BLOCK) {
-                    const float4 v = src[i];
-                    if (flush_live) dst[i] = v;
-                    if (snp) snp[i] = v;  // the snapshot always tracks the row's current value
-                }
-            }
-        }
-    }
-
-    // ---- step 2: streamed levels (normally just the last one) ---------------------------------------
-    for (uint32_t l = n_lds; l < L; ++l) {
-        uint32_t start = td.start[0], count = td.count[0], pbase = 0, pstart = 0;
-#pragma unroll
-        for (uint32_t j = 1; j < TILE_MAX_LEVELS; ++j)
-            if (j == l) {
-                start = td.start[j];
-                count = td.count[j];
-                pbase = ubase[j - 1];
-                pstart = td.start[j - 1];
-            }
-        const bool parents_in_lds = l > 0 && l - 1 < n_lds;
-        const bool root_level = ROOTS && l == 0;
-        float4* stage = lds_stage[wv];
-
-        if (l != n_lds) cur_f = fetch_row(c, a.parent_idx, start, count, 0u, tid, lane, wv, root_level);
-        for (uint32_t base = 0; base < count; base += BLOCK) {
-            // next iteration's loads go out before this one's math (past the end: every load is predicated off)
-            const RowFetch nxt_f = fetch_row(c, a.parent_idx, start, count, base + BLOCK, tid, lane, wv, root_level);
-            const uint32_t i = base + tid;
-            const bool live = i < count;
-            const uint32_t row = start + i;
-            const uint32_t wbase = base + wv * 64u;
-            const uint32_t wave_row0 = start + wbase;
-            const uint32_t wave_lim = wbase < count ? (count - wbase < 64u ? count - wbase : 64u) * 3u : 0u;
-            stage[lane] = cur_f.g0;
-            stage[64u + lane] = cur_f.g1;
-            stage[128u + lane] = cur_f.g2;
-            Affine local = {}, gp = {};
-            bool p_changed = false;
-            if (live) {
-                local = affine_from_srt(cur_f.s, cur_f.q, cur_f.t);
-                if (!root_level) {
-                    if (parents_in_lds) {
-                        const uint32_t slot = pbase + (cur_f.p - pstart);
-                        gp = lds_affine(lds_g, slot);
-                        p_changed = lds_chg[slot] != 0;
-                    } else if (chain_len && l == 0) {
-                        gp = lds_affine(lds_chain_g, 0);
-                        p_changed = lds_chain_chg != 0;
-                    } else {
-                        gp = ld_affine(c.global, cur_f.p);
-                        p_changed = a.g_changed_bytes[cur_f.p] != 0;
-                    }
-                }
-            }
-            MI_WAVE_LDS_SYNC();
-            const Affine old = lds_affine(stage, lane);
-            Affine cur = old;
-            bool chg = false;
-            if (live) {
-                chg = node_update(a, root_level, row, gp, p_changed, local, old, &cur);
-                a.g_changed_bytes[row] = chg ? 1 : 0;
-                if (snap_out && row < a.snap_rows) st_affine(snap_out, row, cur);
-            }
-            // store: whole wave changed (the dirty-tree case) -> transpose back and write 3 x 1 KB rows;
-            // otherwise only the changed lanes write their own 48 bytes.
-            const unsigned long long cm = __ballot(chg), lm = __ballot(live);
-            if (cm == lm) {
-                MI_WAVE_LDS_SYNC();
-                lds_put(stage, lane, cur);
-                MI_WAVE_LDS_SYNC();
-                float4* dst = reinterpret_cast<float4*>(c.global) + 3ull * wave_row0;
-#pragma unroll
-                for (uint32_t k = 0; k < 3u; ++k) {
-                    const uint32_t j = k * 64u + lane;
-                    if (j < wave_lim) dst[j] = stage[j];
-                }
-            } else if (chg) {
-                st_affine(c.global, row, cur);
-            }
-            MI_WAVE_LDS_SYNC();
-            cur_f = nxt_f;
-        }
-        if (l + 1 < L) {
-            // fallback only (a non-last level too wide for LDS): the next level reads these rows back from
-            // global memory, possibly through lines this CU cached before rewriting them
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-    }
-}
-
 // Tile kinds (TileDesc::kind):
 //   TILE_ROOTS   the tile's first level is level 0 of the forest (no parents);
 //   chain tile   (kind & TILE_CHAIN_MASK) = n > 0: the tile hangs below ONE node whose n-node ancestor chain
@@ -586,11 +325,10 @@ __device__ __forceinline__ void process_tile(const Columns& c, const TreeArgs& a
 //   otherwise    the parents of its first level are read from global memory (written by an earlier launch).
 // (Letting a chain tile's workgroup also process an owner tile was measured slower: 42 us against 34.5 us for the
 // 1 M-node tree, the owner's latency chain simply adds to that workgroup's time.)
-// BLOCK = TILE_BLOCK = 256.  Measured alternatives on the 1 M-node depth-11 tree (profiles/r02_tree_experiments.md): one wave
+// 256 threads per tile.  Measured alternatives on the 1 M-node depth-11 tree (profiles/r02_tree_experiments.md): one wave
 // per tile (64 threads, 85- to 341-row tiles, 16 tiles resident per CU) 35.0 us -- every tile pays its own chain (46 % of
 // the VALU instructions of an 85-row tile run on one lane) and the kernel turns issue-bound; 128 threads 36.6 us; 512 / 1024
-// threads 39.0 / 50.8 us (fewer tiles resident); 256 threads 33.5 us.  The chain's inputs share wave 0's transpose buffer:
-// they are consumed before the streamed level first touches it.
+// threads 39.0 / 50.8 us (fewer tiles resident); 256 threads 33.5 us.
 // blockIdx -> tile for the tile kernels.  Workgroups go round the eight XCDs (blockIdx % 8), each with an L2 of its own: XCD x
 // takes a CONTIGUOUS eighth of the tiles, so that neighbouring tiles -- whose short upper-level segments share cache lines
 // (one row of a level is 12 - 48 bytes of a 128-byte line) and whose chains share ancestors -- meet in one L2 instead of
@@ -603,23 +341,10 @@ __device__ __forceinline__ uint32_t xcd_contiguous_tile(uint32_t bid, uint32_t n
 }
 __device__ __forceinline__ uint32_t xcd_contiguous_tile() { return xcd_contiguous_tile(blockIdx.x, gridDim.x); }
 
-template <uint32_t BLOCK>
-__global__ void __launch_bounds__(BLOCK) k_propagate_tiles(Columns c, TreeArgs a) {
-    static_assert(TILE_MAX_CHAIN * 6 <= 192, "the chain inputs must fit in one wave's transpose buffer");
-    __shared__ float4 lds_g[TILE_UCAP * 3];
-    __shared__ uint8_t lds_chg[TILE_UCAP];
-    __shared__ float4 lds_stage[BLOCK / 64][192];
-    __shared__ uint8_t lds_chain_in[TILE_MAX_CHAIN];
-    __shared__ float4 lds_chain_g[3];
-    __shared__ uint32_t lds_chain_chg;
-    const TileLds<BLOCK> lds{lds_g, lds_chg, lds_stage, &lds_stage[0][0], lds_chain_in, lds_chain_g, &lds_chain_chg};
-    process_tile<BLOCK>(c, a, xcd_contiguous_tile(), lds);
-}
-
 // ---------------------------------------------------------------------------------------------
-// Light tiles (big hierarchies; the planner guarantees: every level but the last holds <= TILE_LIGHT_UCAP rows together,
-// chain <= TILE_MAX_CHAIN, last level normally <= 256 rows).  Same walk and the same per-node rule as process_tile, organised
-// for residency instead of reach: 8 workgroups per CU (20.4 KB of LDS, 64 registers in the all-dirty instantiation) against 4, a
+// Light tiles (the planner guarantees: every level but the last holds <= TILE_LIGHT_UCAP rows together, chain <=
+// TILE_MAX_CHAIN, last level normally <= 256 rows).  Organised for residency instead of reach: 8 workgroups per CU (20.4 KB
+// of LDS, 64 registers in the all-dirty instantiation), a
 // few rounds of short tiles per CU, so that one tile's head runs under its neighbours' loads.  Nothing is software-pipelined and
 // nothing is kept in registers across the serial part that LDS can hold or that can be fetched later.  A tile's loads go out in
 // three bursts of straight-line code: behind the descriptor the upper rows (lanes 0..127) and the chain's nodes (top lanes of
@@ -698,6 +423,8 @@ template <>
 struct CullArg<true> {
     typedef TreeCull type;
 };
+// (The row's ViewVisibility byte and summary are fetched here, a round trip of their own per call: requesting them with the tile's
+// last burst of loads -- 78 registers instead of 69 -- measured slower, 33.6 against 33.0 us per launch; profiles/r04_experiments.md.)
 __device__ __forceinline__ void tile_cull_rows(const Columns& c, const TreeCull& cu, uint32_t lane, bool live, uint32_t row, const Affine& g) {
     const uint32_t rrow = live ? row : 0u;  // (every load below is unconditional: one batch)
     const uint32_t vv0 = c.view_visibility[rrow];
@@ -773,7 +500,10 @@ constexpr uint32_t FAN_SLOTS = TILE_LIGHT_UCAP + TILE_MAX_CHAIN;  // LDS slots: 
 constexpr uint32_t FAN_CHAIN_LANE0 = 256u - TILE_MAX_CHAIN;       // chain node k is fetched by thread FAN_CHAIN_LANE0 + k
 
 template <bool ALL_DIRTY, bool CULL = false>
-__global__ void __launch_bounds__(256, CULL ? 6 : ALL_DIRTY ? 8 : 7) k_propagate_fans(Columns c, TreeArgs a, typename CullArg<CULL>::type cu) {
+// (workgroups per CU: the fused instantiation is bound by vector-instruction issue -- 13.1 M wave instructions per launch over 1 024
+// SIMDs, 75 % of its span -- and by how many tiles are resident; 7 against 6 per CU: 31.5 against 33.1 us per launch; 8 -- 64
+// registers, one spill -- 31.9)
+__global__ void __launch_bounds__(256, CULL ? 7 : ALL_DIRTY ? 8 : 7) k_propagate_fans(Columns c, TreeArgs a, typename CullArg<CULL>::type cu) {
     __shared__ float4 lds_g[FAN_SLOTS * 3];    // local affine, then (upper rows) the GlobalTransform in place
     // GlobalTransforms before this frame of the upper rows and the chain (dead once the level steps have fetched their columns of
     // them); afterwards the same memory is the four waves' transpose buffers of the last level (3 x 1 KB rows each)
@@ -1149,6 +879,7 @@ __global__ void __launch_bounds__(256, CULL ? 6 : ALL_DIRTY ? 8 : 7) k_propagate
 // 4-ary tree), the new GlobalTransform out through the same transpose.
 // Algorithmic bytes per row: 40 + 4 + 48 + 48 + 1 = 141 (+ 48 / fan-out for the parents, L2 hits).
 // ---------------------------------------------------------------------------------------------
+template <bool ROOT>
 __global__ void __launch_bounds__(256) k_propagate_level(Columns c, TreeArgs a, uint32_t start, uint32_t count) {
     __shared__ float4 lds_stage[4][192];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
@@ -1172,12 +903,14 @@ __global__ void __launch_bounds__(256) k_propagate_level(Columns c, TreeArgs a, 
     Affine gp = {};
     bool p_changed = false;
     if (live) {
-        const uint32_t p = a.parent_idx[row];
         t = ld3(c.translation, row);
         q = ld4(c.rotation, row);
         sc = ld3(c.scale, row);
-        gp = ld_affine(c.global, p);
-        p_changed = a.g_changed_bytes[p] != 0;
+        if (!ROOT) {  // (level 0 of a hierarchy swept by levels: forest roots and flat rows, no parents)
+            const uint32_t p = a.parent_idx[row];
+            gp = ld_affine(c.global, p);
+            p_changed = a.g_changed_bytes[p] != 0;
+        }
     }
     stage[lane] = o0;
     stage[64u + lane] = o1;
@@ -1187,7 +920,7 @@ __global__ void __launch_bounds__(256) k_propagate_level(Columns c, TreeArgs a, 
     Affine cur = old;
     bool chg = false;
     if (live) {
-        chg = node_update(a, false, row, gp, p_changed, affine_from_srt(sc, q, t), old, &cur);
+        chg = node_update(a, ROOT, row, gp, p_changed, affine_from_srt(sc, q, t), old, &cur);
         a.g_changed_bytes[row] = chg ? 1 : 0;
     }
     const unsigned long long cm = __ballot(chg), lm = __ballot(live);
@@ -1251,7 +984,7 @@ __global__ void __launch_bounds__(256) k_inherit_tiles(const uint32_t* __restric
                                                         const TileDesc* __restrict__ tiles,
                                                         const uint8_t* __restrict__ visibility, uint8_t* flags,
                                                         uint8_t* inh_changed) {
-    __shared__ uint8_t lds_state[TILE_UCAP];
+    __shared__ uint8_t lds_state[TILE_INHERIT_UCAP];
     const TileDesc td = load_tile_desc(tiles + blockIdx.x);
     const uint32_t L = td.n_levels;
     const uint32_t tid = threadIdx.x;
@@ -1262,7 +995,7 @@ __global__ void __launch_bounds__(256) k_inherit_tiles(const uint32_t* __restric
     for (uint32_t l = 0; l < TILE_MAX_LEVELS; ++l) {
         const uint32_t cnt = l < L ? td.count[l] : 0u;
         ubase[l + 1] = ubase[l] + cnt;
-        if (l + 1 < L && n_lds == l && ubase[l + 1] <= TILE_UCAP) n_lds = l + 1;
+        if (l + 1 < L && n_lds == l && ubase[l + 1] <= TILE_INHERIT_UCAP) n_lds = l + 1;
     }
     // parent state of a row whose parent is NOT in LDS (first level of a non-root tile, or the LDS fallback)
     auto parent_state_global = [&](uint32_t p) -> uint32_t {
@@ -1322,10 +1055,12 @@ hipError_t launch_inherit_level(const uint32_t* parent_idx, uint32_t start, uint
     return hipGetLastError();
 }
 hipError_t launch_propagate_level(const Columns& c, const uint32_t* parent_idx, uint32_t start, uint32_t count, const uint8_t* changed,
-                                  const uint8_t* tree_bytes, uint8_t* g_changed_bytes, bool all_dirty, bool static_opt, hipStream_t stream) {
+                                  const uint8_t* tree_bytes, uint8_t* g_changed_bytes, bool all_dirty, bool static_opt, hipStream_t stream,
+                                  const uint8_t* root_node_flags) {
     if (count == 0) return hipSuccess;
     TreeArgs a{};
     a.parent_idx = parent_idx;
+    a.node_flags = root_node_flags;
     a.changed = changed;
     a.tree_bytes = tree_bytes;
     a.g_changed_bytes = g_changed_bytes;
@@ -1333,7 +1068,8 @@ hipError_t launch_propagate_level(const Columns& c, const uint32_t* parent_idx, 
     a.static_opt = static_opt ? 1u : 0u;
     a.pretest = 0;
     a.changed_gen = c.changed_gen;
-    MI_LAUNCH(k_propagate_level, dim3((count + 255u) / 256u), dim3(256), 0, stream, c, a, start, count);
+    if (root_node_flags) MI_LAUNCH(k_propagate_level<true>, dim3((count + 255u) / 256u), dim3(256), 0, stream, c, a, start, count);
+    else MI_LAUNCH(k_propagate_level<false>, dim3((count + 255u) / 256u), dim3(256), 0, stream, c, a, start, count);
     return hipGetLastError();
 }
 
@@ -1347,7 +1083,7 @@ hipError_t launch_mark_dirty(uint32_t n, const uint8_t* changed, uint32_t change
 hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, const TileDesc* d_tiles, const uint32_t* d_chains,
                                   uint32_t n_tiles, const uint8_t* node_flags, const uint8_t* changed, const uint8_t* tree_bytes,
                                   uint8_t* g_changed_bytes, const float* snap_read, float* snap_write, uint32_t snap_rows, bool all_dirty,
-                                  bool static_opt, bool light, hipStream_t stream, unsigned long long* trace, bool pretest, const TreeCull* cull) {
+                                  bool static_opt, hipStream_t stream, unsigned long long* trace, bool pretest, const TreeCull* cull) {
     if (n_tiles == 0) return hipSuccess;
     TreeArgs a;
     a.pretest = pretest && changed && tree_bytes ? 1u : 0u;
@@ -1366,11 +1102,10 @@ hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, 
     a.static_opt = static_opt ? 1u : 0u;
     a.trace = trace;
     if (cull) {
-        if (!(light && all_dirty) || !c.row_summary) return hipErrorInvalidValue;  // (the host checks: every tile runs, light tiles only)
+        if (!all_dirty || !c.row_summary) return hipErrorInvalidValue;  // (the host checks: every tile runs)
         MI_LAUNCH((k_propagate_fans<true, true>), dim3(n_tiles + cull->n_compact), dim3(256), 0, stream, c, a, *cull);
-    } else if (light && all_dirty) MI_LAUNCH((k_propagate_fans<true, false>), dim3(n_tiles), dim3(256), 0, stream, c, a, NoCull{});
-    else if (light) MI_LAUNCH((k_propagate_fans<false, false>), dim3(n_tiles), dim3(256), 0, stream, c, a, NoCull{});
-    else MI_LAUNCH((k_propagate_tiles<TILE_BLOCK>), dim3(n_tiles), dim3(TILE_BLOCK), 0, stream, c, a);
+    } else if (all_dirty) MI_LAUNCH((k_propagate_fans<true, false>), dim3(n_tiles), dim3(256), 0, stream, c, a, NoCull{});
+    else MI_LAUNCH((k_propagate_fans<false, false>), dim3(n_tiles), dim3(256), 0, stream, c, a, NoCull{});
     return hipGetLastError();
 }
 

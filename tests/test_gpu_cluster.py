@@ -270,7 +270,7 @@ def test_baseline_lights_config_at_full_size(ctx_factory):
 @pytest.mark.parametrize("tile_mode", [0, 1])
 def test_baseline_tree_config_at_full_size(ctx_factory, tile_mode):
     """BASELINE.json configs[4]: gen_tree(12, 4) truncated to 1 000 000 nodes, bit-exact against the oracle, then a
-    partially dirty frame and a static frame.  tile_mode 0 = the kernel the library picks at this size (light tiles), 1 = big tiles."""
+    partially dirty frame and a static frame.  tile_mode 0 = the path the library picks at this size (subtree tiles), 1 = the level-by-level sweep."""
     tr = W.gen_tree(12, 4, 1_000_000)
     assert tr["n"] == 1_000_000
     ctx = ctx_factory()

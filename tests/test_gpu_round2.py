@@ -197,6 +197,7 @@ def test_tile_plans_are_one_launch_for_deep_and_wide_hierarchies(ctx_factory):
     """The planner cuts levels into bands bottom-up; roots and chain bands share ONE launch whatever the depth.  Parity of
     every shape is covered by the tree tests; this pins the launch count the performance rests on."""
     ctx = ctx_factory()
+    ctx.debug_set_tile_mode(0)  # (the suite also runs under MI_TEST_TILE_MODE=1, which sweeps level by level: this test is about the tiles)
     for tr, want_launches in ((W.gen_tree(12, 4, 1_000_000), 1), (W.gen_tree(20, 2, 300_000), 1), (W.gen_tree(4, 40), 1),
                               (flat_rows_plus_deep_tree(), 1), (W.gen_tree(3, 1000), None)):
         upload_tree(ctx, tr)

@@ -1,5 +1,6 @@
-"""GPU parity of the two hierarchy kernels (big subtree tiles / light tiles) on shapes that exercise each planner and kernel
-branch: the plan is forced with the mi_debug_set_tile_mode hook, results are compared with the oracle
+"""GPU parity of the two hierarchy paths (subtree tiles / the level-by-level sweep that takes hierarchies the tiles cannot hold) on
+shapes that exercise each planner and kernel branch: the path is forced with the mi_debug_set_tile_mode hook (1 = by levels, 2 =
+tiles where they fit), results are compared with the oracle
 (propagate_parent_transforms + mark_dirty_trees, crates/bevy_transform/src/systems.rs:111-306,506-748) bit for bit, change
 ticks included, over an all-dirty frame and several partially dirty ones, with and without the static-scene rule."""
 import numpy as np
@@ -43,7 +44,7 @@ SHAPES = {
     "fan_4ary_7_levels": (1, [4] * 6),                                  # the bench's shape, small: chain tiles below a top tile
     "one_node_700_leaves": (1, [700]),                                   # a last level of several batches in one tile
     "wide_second_level": (1, [300, 4]),
-    "skewed": (1, [200, lambda i: 300 if i == 0 else 0, 2]),             # one subtree overflows a light tile: big tiles take over
+    "skewed": (1, [200, lambda i: 300 if i == 0 else 0, 2]),             # one subtree overflows a tile: swept level by level
     "forest_3000_roots": (3000, [3, 2]),                                 # many roots per tile, level 0 holds most rows
     "flat_rows_and_trees": (5000, [lambda i: 5 if i % 50 == 0 else 0, 6, 3]),  # flat rows share level 0 with the roots
     "ragged": (7, [lambda i: i % 5, lambda i: (i * 7) % 4, lambda i: 300 if i == 3 else i % 3, 2]),
@@ -98,7 +99,7 @@ def test_tile_kernels_match_oracle(ctx_factory, shape, mode, static_opt):
         g0 = g1
 
 
-def test_light_plan_is_used_where_it_fits_and_not_where_it_does_not(ctx_factory):
+def test_tiles_are_used_where_they_fit_and_the_level_sweep_where_they_do_not(ctx_factory):
     def plan(shape, mode):
         tr = _levels(SHAPES[shape], seed=1)
         ctx = ctx_factory()
@@ -106,10 +107,13 @@ def test_light_plan_is_used_where_it_fits_and_not_where_it_does_not(ctx_factory)
         ctx.resize(tr["n"])
         ctx.upload_transforms(tr["translation"], tr["rotation"], tr["scale"])
         ctx.upload_hierarchy(tr["parent"], tr["level_offsets"])
-        return ctx.debug_tile_plan()
-    assert plan("fan_4ary_7_levels", 2)["tiles"] > plan("fan_4ary_7_levels", 1)["tiles"]   # smaller tiles, more of them
-    assert plan("skewed", 2) == plan("skewed", 1)                                           # does not fit: the big-tile plan
-    # by default (mode 0): light tiles wherever they fit
+        return ctx.debug_tile_plan(), len(tr["level_offsets"]) - 1
+    p, levels = plan("fan_4ary_7_levels", 0)
+    assert p["launches"] == 1 and levels == 7                       # roots and chain tiles share one launch
+    assert plan("fan_4ary_7_levels", 1)[0]["launches"] == 7         # forced: one launch per level
+    p, levels = plan("skewed", 0)
+    assert p["launches"] == levels == 4                             # a node with 200 children that have 300 of their own: does not fit
+    # by default (mode 0): tiles wherever they fit
     big = W.gen_tree(12, 4, 1_000_000)
     ctx = ctx_factory()
     ctx.resize(big["n"])
@@ -118,7 +122,7 @@ def test_light_plan_is_used_where_it_fits_and_not_where_it_does_not(ctx_factory)
     auto = ctx.debug_tile_plan()
     ctx.debug_set_tile_mode(1)
     ctx.upload_hierarchy(big["parent"], big["level_offsets"])
-    assert auto["tiles"] > ctx.debug_tile_plan()["tiles"]
+    assert auto["launches"] == 1 and ctx.debug_tile_plan()["launches"] == len(big["level_offsets"]) - 1
 
 
 def _random_forest(rng, n):
@@ -136,7 +140,7 @@ def _random_forest(rng, n):
 
 @pytest.mark.parametrize("seed", range(12))
 def test_random_hierarchies_match_oracle_under_both_kernels(ctx_factory, seed):
-    """Differential test over random forests (deep chains, bushy trees, many roots; 1 to ~60 000 nodes): both tile kernels, the
+    """Differential test over random forests (deep chains, bushy trees, many roots; 1 to ~60 000 nodes): both paths, the
     static-scene rule on and off, an all-dirty frame and three random partially dirty ones, bit for bit with change ticks."""
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.choice([1, 2, 65, 900, 7000, 60_000]))

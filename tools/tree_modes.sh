@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: tree parity tests under the given tile modes (1 = big tiles, 2 = light tiles), then the tree bench per mode.   bash tools/tree_modes.sh <tag> "<test modes>" "<bench modes>"
+# GPU box: tree parity tests under the given tile modes (1 = level by level, 2 = subtree tiles), then the tree bench per mode.   bash tools/tree_modes.sh <tag> "<test modes>" "<bench modes>"
 TAG=${1:-x}
 O=gpurun_out/tree_$TAG
 mkdir -p $O; : > $O/summary.txt

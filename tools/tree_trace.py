@@ -1,6 +1,6 @@
 """Development aid (GPU box): per-tile phase timeline of the light tile kernel on the bench's 1 M-node tree.
 
-    python tools/tree_trace.py [tile_mode]
+    python tools/tree_trace.py [tile_mode] [cull]     (cull: the fused hierarchy frame, k_propagate_fans<true, true>)
 
 Stamps (s_memrealtime, 10 ns): 0 start, 1 loads issued (descriptor landed), 2 loads consumed + barrier, 3 chain done,
 4 levels done, 5 upper rows written back, 6 last level computed + stores issued, 7 stores drained."""
@@ -12,6 +12,7 @@ import bevy_amd as B
 from bevy_amd import api, workloads as W
 
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+cull = len(sys.argv) > 2 and sys.argv[2] == "cull"
 tr = W.gen_tree(12, 4, 1_000_000)
 ctx = api.Context(0)
 ctx.resize(tr["n"])
@@ -21,14 +22,28 @@ ctx.upload_hierarchy(tr["parent"], tr["level_offsets"])
 plan = ctx.debug_tile_plan()
 print("plan", plan)
 root_t = [tr["translation"][:3].copy(), tr["translation"][:3] + np.float32(1.0)]
-for f in range(20):
+if cull:
+    from benchlib.common import camera_frusta
+    n = tr["n"]
+    ctx.debug_set_tree_cull(2)
+    ctx.upload_bounds(np.zeros(3 * n, np.float32), np.full(3 * n, 0.5, np.float32), np.full(n, 0x05, np.uint8), np.ones(n, np.uint32))
+    frusta = [api.PreparedFrusta(camera_frusta(1, f)) for f in range(4)]
+
+
+def frame(f):
     ctx.upload_transforms(root_t[f & 1], tr["rotation"][:4], tr["scale"][:3], first_row=0)
-    ctx.propagate(B.PROPAGATE_ALL_DIRTY)
+    if cull:
+        ctx.propagate_and_cull(frusta[f % 4], flags=B.CULL_END_FRAME | B.CULL_MORE_FRAMES)
+    else:
+        ctx.propagate(B.PROPAGATE_ALL_DIRTY)
+
+
+for f in range(20):
+    frame(f)
 ctx.synchronize()
 ctx.debug_tree_trace(0)
 for f in range(3):
-    ctx.upload_transforms(root_t[f & 1], tr["rotation"][:4], tr["scale"][:3], first_row=0)
-    ctx.propagate(B.PROPAGATE_ALL_DIRTY)
+    frame(f)
 ctx.synchronize()
 t = ctx.debug_tree_trace(plan["tiles"]).astype(np.int64)
 t0 = t[:, 0].min()

@@ -23,24 +23,20 @@ __device__ __forceinline__ void compact_fast_block(const CompactFastArgs& a, uin
     const uint64_t* mask = a.seg_mask ? a.seg_mask + (size_t)seg * a.seg_words
                                       : a.bitmask + view * a.words_per_view + a.word_offset;
     const uint32_t n_words = (a.n + 63u) >> 6;
-    const uint32_t steps = a.steps ? a.steps : compact_fast_steps(a.n);
+    const uint32_t steps = compact_fast_steps(a.n);
     const uint32_t w00 = bx * 64u * steps;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     __shared__ uint32_t red[4], wtot[4];
 
     // phase 1: base = sum of cnt[0 .. w00)
     uint32_t partial = 0;
-    if (a.blk_base) {  // (w00 is a multiple of 64 words: the rows in front of it are whole blocks)
-        if (threadIdx.x == 0u) partial = a.blk_base[(size_t)seg * a.n_blks + (w00 >> 6)];
-    } else {
-        const uint4* c4 = reinterpret_cast<const uint4*>(cnt);
-        for (uint32_t i = threadIdx.x; i < (w00 >> 4); i += 256u) {
-            const uint4 q = c4[i];
-            partial = sum_bytes(q.x, partial);
-            partial = sum_bytes(q.y, partial);
-            partial = sum_bytes(q.z, partial);
-            partial = sum_bytes(q.w, partial);
-        }
+    const uint4* c4 = reinterpret_cast<const uint4*>(cnt);
+    for (uint32_t i = threadIdx.x; i < (w00 >> 4); i += 256u) {
+        const uint4 q = c4[i];
+        partial = sum_bytes(q.x, partial);
+        partial = sum_bytes(q.y, partial);
+        partial = sum_bytes(q.z, partial);
+        partial = sum_bytes(q.w, partial);
     }
 #pragma unroll
     for (uint32_t off = 32u; off; off >>= 1) partial += __shfl_xor(partial, off, 64);

@@ -363,9 +363,6 @@ int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg, 
         f.bitmask = vo.bitmask;
         f.words_per_view = vo.words_per_view;
         f.word_offset = vo.word_offset;
-        f.blk_base = seg.blk_base;
-        f.n_blks = seg.n_blks;
-        f.steps = seg.blk_base ? 1u : 0u;
         ctx->seg_stride = ctx->cap;
         if ((rc = ensure(ctx, ctx->fb[ctx->cur].out_rows, segs * ctx->seg_stride * 4))) return rc;
         f.out_rows = (uint32_t*)ctx->fb[ctx->cur].out_rows.p;
@@ -940,7 +937,7 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
                           &sl.indices, &sl.scalars})
             if (b->p) hipFree(b->p);
     for (auto& f : ctx->fb)
-        for (DevBuf* b : {&f.bitmask, &f.wave_cnt, &f.seg_mask, &f.out_rows, &f.seg_totals, &f.blk_cnt})
+        for (DevBuf* b : {&f.bitmask, &f.wave_cnt, &f.seg_mask, &f.out_rows, &f.seg_totals})
             if (b->p) hipFree(b->p);
     {
         auto& ce = ctx->cells;  // the static cull order
@@ -1772,7 +1769,7 @@ static int32_t tree_frame_fused(mi_ctx* ctx, const mi_view* views, uint32_t n_vi
     // the previous frame's deferred compaction rides in the (first) tile launch
     if (prev && prev->n && prev->n_segments) {
         cu.prev = *prev;
-        cu.prev_gx = (((prev->n + 63u) >> 6) + 64u * compact_fast_steps_of(*prev) - 1u) / (64u * compact_fast_steps_of(*prev));
+        cu.prev_gx = (((prev->n + 63u) >> 6) + 64u * compact_fast_steps_host(prev->n) - 1u) / (64u * compact_fast_steps_host(prev->n));
         cu.n_compact = cu.prev_gx * prev->n_segments;
     } else {
         cu.prev_gx = 1;

@@ -287,7 +287,7 @@ struct mi_ctx {
     uint64_t* vv_chg_alt = nullptr;  // second ViewVisibility change-tick buffer of those frames (they alternate); zeroed iff vv_alt_zeroed
     bool vv_alt_zeroed = false;
     struct FrameBufs {
-        DevBuf bitmask, wave_cnt, seg_mask, out_rows, seg_totals, blk_cnt;
+        DevBuf bitmask, wave_cnt, seg_mask, out_rows, seg_totals;
     } fb[N_FB];
     uint32_t cur = 0;  // set of the current / last frame
     struct DeferredCompaction {

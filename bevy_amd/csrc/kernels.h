@@ -154,8 +154,6 @@ struct SegOut {
     uint64_t* seg_mask;
     uint64_t seg_words;
     uint8_t class_bits[32];      // class bit of each class slot
-    uint32_t* blk_base;          // per segment and 64 words: the wave counts in front of them (CompactFastArgs::blk_base); nullptr = not kept
-    uint32_t n_blks;             // its stride per segment (= n_waves / 64)
 };
 
 // mi_cull / mi_propagate_and_cull flags (MI_CULL_* in the public header)
@@ -211,18 +209,8 @@ struct CompactFastArgs {
     // per frame: it keeps the next frame kernel from starting behind the compaction).
     uint32_t* signal;
     uint32_t signal_value;
-    // optional: per segment and 64 words (4 096 rows) the sum of the wave counts IN FRONT of them.  A compaction workgroup starts at a
-    // multiple of 64 words, so its base is one load instead of a sum over every wave count in front of it (at 10 M rows x 4 views the
-    // workgroups together read 77 MB of counts otherwise).  Written by the launches that have it cheaply (k_cells_counts).
-    const uint32_t* blk_base;
-    uint32_t n_blks;  // stride per segment
-    // 64-word steps per compaction workgroup: compact_fast_steps(n) when every workgroup sums the wave counts in front of it (fewer,
-    // longer workgroups read fewer counts), 1 with blk_base (the steps of a workgroup run one after the other, ~3 us each: ten of them
-    // were 33 us of every frame at 10 M rows).  0 = compact_fast_steps(n).
-    uint32_t steps;
 };
 inline uint32_t compact_fast_steps_host(uint32_t n) { return 1u + (n >> 20); }  // = compact_fast_steps (compact_fast.h)
-inline uint32_t compact_fast_steps_of(const CompactFastArgs& a) { return a.steps ? a.steps : compact_fast_steps_host(a.n); }
 hipError_t launch_flat_propagate_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views,
                                       uint32_t n_views, const VisibilityOut& out, const SegOut& seg, uint32_t flags,
                                       const CompactFastArgs* prev, const struct ClusterFillJob* fill, const struct ClusterWalkJob* walk,

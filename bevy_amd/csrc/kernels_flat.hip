@@ -1275,7 +1275,7 @@ static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, co
     uint32_t prev_gx = 1, prev_blocks = 0;
     if (prev && prev->n && prev->n_segments) {
         pa = *prev;
-        prev_gx = (((pa.n + 63u) >> 6) + 64u * compact_fast_steps_of(pa) - 1u) / (64u * compact_fast_steps_of(pa));
+        prev_gx = (((pa.n + 63u) >> 6) + 64u * compact_fast_steps_host(pa.n) - 1u) / (64u * compact_fast_steps_host(pa.n));
         prev_blocks = prev_gx * pa.n_segments;
     }
     ClusterFillJob fj{};
@@ -1321,7 +1321,7 @@ hipError_t launch_frame_sph(const Columns& c, const ViewSet* views_inline, const
     uint32_t prev_gx = 1, prev_blocks = 0;
     if (prev && prev->n && prev->n_segments) {
         pa = *prev;
-        prev_gx = (((pa.n + 63u) >> 6) + 64u * compact_fast_steps_of(pa) - 1u) / (64u * compact_fast_steps_of(pa));
+        prev_gx = (((pa.n + 63u) >> 6) + 64u * compact_fast_steps_host(pa.n) - 1u) / (64u * compact_fast_steps_host(pa.n));
         prev_blocks = prev_gx * pa.n_segments;
     }
     ClusterFillJob fj{};
@@ -1504,7 +1504,7 @@ hipError_t launch_frame_cells(const Columns& c, const CellsOrder& o, const ViewS
     uint32_t prev_gx = 1, prev_blocks = 0;
     if (prev && prev->n && prev->n_segments) {
         pa = *prev;
-        prev_gx = (((pa.n + 63u) >> 6) + 64u * compact_fast_steps_of(pa) - 1u) / (64u * compact_fast_steps_of(pa));
+        prev_gx = (((pa.n + 63u) >> 6) + 64u * compact_fast_steps_host(pa.n) - 1u) / (64u * compact_fast_steps_host(pa.n));
         prev_blocks = prev_gx * pa.n_segments;
     }
     ClusterFillJob fj{};
@@ -1667,7 +1667,7 @@ __global__ void __launch_bounds__(256) k_compact_fast(CompactFastArgs a) {
 hipError_t launch_compact_fast(const CompactFastArgs& a, hipStream_t stream) {
     if (a.n == 0 || a.n_segments == 0) return hipSuccess;
     const uint32_t n_words = (a.n + 63u) >> 6;
-    const uint32_t per_wg = 64u * compact_fast_steps_of(a);
+    const uint32_t per_wg = 64u * compact_fast_steps_host(a.n);
     MI_LAUNCH(k_compact_fast, dim3((n_words + per_wg - 1u) / per_wg, a.n_segments), dim3(256), 0, stream, a);
     return hipGetLastError();
 }

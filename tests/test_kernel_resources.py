@@ -1,0 +1,65 @@
+"""Registers and occupancy of the hot kernels, as the compiler reports them for gfx950 (no GPU needed).
+
+Round 4 lost 3 us of the 21 us metric frame to a change nobody measured: two unused fields in a kernel-argument struct took
+k_frame<1, true, 1> from 14 to 98 spilled SGPRs.  The bench would have shown it; this shows it before a GPU is involved.  The
+bounds are the figures of the build whose timings are in profiles/ -- a kernel that needs more is re-measured, then re-pinned."""
+import os
+import re
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# kernel (demangled prefix) -> (max VGPRs, min waves per SIMD, max spilled SGPRs, max scratch bytes per lane)
+PINNED = {
+    "kernels_flat.hip": {
+        "mi::k_frame<1, true, 1>": (92, 5, 32, 64),     # the metric frame: propagate + cull + in-row cluster walk
+        "mi::k_frame<1, true, 0>": (64, 8, 32, 0),      # the flat frame
+        "mi::k_frame_sph<true, true, 0>": (64, 8, 32, 0),
+        "mi::k_frame_cells<true>": (64, 8, 32, 0),
+    },
+    "kernels_tree.hip": {
+        "mi::k_propagate_fans<true, false>": (64, 8, 32, 0),
+        "mi::k_propagate_fans<true, true>": (72, 7, 80, 0),
+        "mi::k_propagate_level<false>": (64, 8, 0, 0),
+    },
+}
+
+
+def _analyse(src):
+    from bevy_amd import build as mi_build
+    cmd = [mi_build.hipcc()] + [f for f in mi_build.FLAGS if f != "-shared"] + mi_build.FILE_FLAGS.get(src, []) + \
+          ["-x", "hip", "-c", os.path.join(ROOT, "bevy_amd", "csrc", src), "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out, cur = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+        for key, rx in (("vgpr", r" VGPRs: (\d+)"), ("sgpr_spill", r"SGPRs Spill: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"),
+                        ("occ", r"Occupancy \[waves/SIMD\]: (\d+)")):
+            m2 = re.search(rx, line)
+            if m2 and cur is not None:
+                cur[key] = int(m2.group(1))
+    names = list(out)
+    dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.splitlines()
+    return {re.sub(r"\(.*", "", d.replace("void ", "")): out[n] for n, d in zip(names, dem)}
+
+
+def test_hot_kernels_keep_their_registers_and_occupancy():
+    from bevy_amd import build as mi_build
+    if not os.path.exists(mi_build.hipcc()) and mi_build.hipcc() != "hipcc":
+        pytest.skip("no hipcc")
+    with ThreadPoolExecutor(len(PINNED)) as ex:
+        results = dict(zip(PINNED, ex.map(_analyse, PINNED)))
+    bad = []
+    for src, kernels in PINNED.items():
+        for name, (max_vgpr, min_occ, max_sgpr_spill, max_scratch) in kernels.items():
+            got = results[src].get(name)
+            assert got, f"{src}: no kernel {name} (have {sorted(results[src])[:8]} ...)"
+            if got["vgpr"] > max_vgpr or got["occ"] < min_occ or got["sgpr_spill"] > max_sgpr_spill or got["scratch"] > max_scratch:
+                bad.append((name, got, (max_vgpr, min_occ, max_sgpr_spill, max_scratch)))
+    assert not bad, "\n".join(f"{n}: {g} exceeds (VGPRs <= {b[0]}, waves/SIMD >= {b[1]}, spilled SGPRs <= {b[2]}, scratch <= {b[3]})" for n, g, b in bad)

@@ -45,6 +45,56 @@ def test_exported_inputs_are_the_fixture_inputs():
         assert inp["tree." + k].tobytes() == tree[k].tobytes(), k
     assert inp["cluster.lights_pos_range"].tobytes() == cl["lights"].tobytes()
     assert inp["cluster.camera"].tobytes() == cl["camera"].tobytes()
+    import export_inputs
+    for k, v in export_inputs.spot_scene().items():  # case 4 is seeded in the export script itself
+        assert inp[k].dtype == v.dtype and inp[k].tobytes() == v.tobytes(), k
+    kind = inp["cluster2.type"]
+    assert np.all(np.diff(kind.astype(np.int32)) >= 0) and 0 < int(kind.sum()) < kind.size  # points, then spots: the gather order
+
+
+def _spot_back(inp):
+    """GlobalTransform::back() of every light of case 4, the way the reference forms it: (matrix3 * Vec3::Z).normalize() with glam's
+    normalize = v * (1 / length) (global_transform.rs: local_z; oracle/bevy_oracle.c:306-310 restates the same for the camera)."""
+    n = inp["cluster2.type"].size
+    pr = inp["cluster2.lights_pos_range"].reshape(n, 4)
+    rc, g, _ = O.propagate_transforms(np.full(n, 0xFFFFFFFF, np.uint32), np.ascontiguousarray(pr[:, :3]).reshape(-1), inp["cluster2.rotation"],
+                                      np.ones(3 * n, np.float32))
+    assert rc == 0
+    z = g.reshape(n, 12)[:, 6:9].astype(np.float32)
+    f = np.float32
+    dot = (z[:, 0] * z[:, 0] + z[:, 1] * z[:, 1]).astype(f) + (z[:, 2] * z[:, 2]).astype(f)
+    recip = (f(1.0) / np.sqrt(dot.astype(f)).astype(f)).astype(f)
+    return (z * recip[:, None]).astype(f)
+
+
+def _spot_views(inp):
+    fov, aspect, near, far = inp["camera.fov_aspect_near_far"]
+    cfv = O.perspective_infinite_reverse(np.float32(fov), aspect, near)
+    w, h, dx, dy, dz = (int(x) for x in inp["cluster.screen_dims_z"])
+    first, far_z = inp["cluster.first_slice_depth_far_z"]
+    views = []
+    for cam in inp["cluster2.cameras"].reshape(-1, 12):
+        fr = O.compute_frustum_perspective(np.float32(fov), aspect, near, far, cam)
+        views.append((cam, cfv, fr, O.cluster_view_setup(cam, cfv, fr, w, h, (dx, dy, dz), float(first), float(far_z))))
+    return views, (w, h, (dx, dy, dz), float(first), float(far_z))
+
+
+def test_case_4_is_a_real_case():
+    """Without the dump: the spot / two-camera inputs do exercise the cone test -- the spot lights reach fewer clusters than the same
+    lights taken as point lights -- and the two cameras see different lists."""
+    inp = migd.read(INPUTS)
+    back = _spot_back(inp)
+    assert np.allclose(np.linalg.norm(back, axis=1), 1.0, atol=1e-6)
+    sin_cos = np.stack([np.sin(inp["cluster2.outer_angle"]), np.cos(inp["cluster2.outer_angle"])], axis=1).astype(np.float32).reshape(-1)
+    views, _ = _spot_views(inp)
+    totals = []
+    for _, _, _, view in views:
+        off, idx, _, _, total = O.assign_objects_to_clusters(view, inp["cluster2.lights_pos_range"], obj_type=inp["cluster2.type"],
+                                                            spot_dir=back.reshape(-1), spot_sin_cos=sin_cos)
+        _, _, _, _, total_points = O.assign_objects_to_clusters(view, inp["cluster2.lights_pos_range"])
+        assert 0 < total < total_points
+        totals.append((total, idx.tobytes()))
+    assert totals[0] != totals[1]
 
 
 def _flat_oracle(inp):
@@ -95,6 +145,55 @@ def test_oracle_clusters_match_the_reference():
     assert np.array_equal(off, ref["cluster.offsets"]) and np.array_equal(idx, ref["cluster.indices"])
     assert int(total) == int(ref["cluster.total"][0])
     assert bits(np.float32(farthest)) == bits(ref["cluster.farthest_z"])[0]
+
+
+@needs_dump
+def test_oracle_spot_clusters_of_two_cameras_match_the_reference():
+    inp, ref = migd.read(INPUTS), migd.read(DUMP)
+    back = _spot_back(inp)
+    spots = inp["cluster2.type"] == 1
+    assert np.array_equal(bits(back[spots]), bits(ref["cluster2.spot_back"].reshape(-1, 3)[spots]))  # the direction the cone test reads
+    views, _ = _spot_views(inp)
+    for v, (_, _, _, view) in enumerate(views):
+        off, idx, _, farthest, total = O.assign_objects_to_clusters(view, inp["cluster2.lights_pos_range"], obj_type=inp["cluster2.type"],
+                                                                   spot_dir=ref["cluster2.spot_back"], spot_sin_cos=ref["cluster2.sin_cos"])
+        assert tuple(ref[f"cluster2.dims.{v}"]) == tuple(view.dims)
+        assert np.array_equal(off, ref[f"cluster2.offsets.{v}"]) and np.array_equal(idx, ref[f"cluster2.indices.{v}"]), f"camera {v}"
+        assert int(total) == int(ref[f"cluster2.total.{v}"][0])
+        assert bits(np.float32(farthest)) == bits(ref[f"cluster2.farthest_z.{v}"])[0]
+
+
+@needs_dump
+@pytest.mark.gpu
+def test_hip_spot_clusters_of_two_cameras_match_the_reference():
+    from bevy_amd import api
+
+    inp, ref = migd.read(INPUTS), migd.read(DUMP)
+    views, (w, h, dims, first, far_z) = _spot_views(inp)
+    ctx = api.Context(device=0)
+    for v, (cam, cfv, fr, _) in enumerate(views):
+        view, _ = api.cluster_view_build(cam, cfv, fr, w, h, dims, first, far_z)
+        off, idx, *_ = ctx.cluster_assign(view, inp["cluster2.lights_pos_range"], inp["cluster2.type"], None, ref["cluster2.spot_back"],
+                                          ref["cluster2.sin_cos"])
+        assert np.array_equal(off, ref[f"cluster2.offsets.{v}"]) and np.array_equal(idx, ref[f"cluster2.indices.{v}"]), f"camera {v}"
+
+
+@pytest.mark.gpu
+def test_hip_matches_the_oracle_on_case_4():
+    """The same comparison against the oracle, which needs no dump: spot lights, two cameras, list for list."""
+    from bevy_amd import api
+
+    inp = migd.read(INPUTS)
+    back = _spot_back(inp).reshape(-1)
+    sin_cos = np.stack([np.sin(inp["cluster2.outer_angle"]), np.cos(inp["cluster2.outer_angle"])], axis=1).astype(np.float32).reshape(-1)
+    views, (w, h, dims, first, far_z) = _spot_views(inp)
+    ctx = api.Context(device=0)
+    for v, (cam, cfv, fr, oview) in enumerate(views):
+        off0, idx0, *_ = O.assign_objects_to_clusters(oview, inp["cluster2.lights_pos_range"], obj_type=inp["cluster2.type"], spot_dir=back,
+                                                      spot_sin_cos=sin_cos)
+        view, _ = api.cluster_view_build(cam, cfv, fr, w, h, dims, first, far_z)
+        off, idx, *_ = ctx.cluster_assign(view, inp["cluster2.lights_pos_range"], inp["cluster2.type"], None, back, sin_cos)
+        assert np.array_equal(off, off0) and np.array_equal(idx, idx0), f"camera {v}"
 
 
 @needs_dump

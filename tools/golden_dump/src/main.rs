@@ -23,7 +23,7 @@ use bevy_camera::{
 use bevy_ecs::prelude::*;
 use bevy_light::{
     cluster::{ClusterConfig, ClusterFarZMode, ClusterZConfig, ClusterableObjects, Clusters, GlobalClusterSettings},
-    LightPlugin, PointLight,
+    LightPlugin, PointLight, SpotLight,
 };
 use bevy_math::{Affine3A, Quat, UVec2, UVec3, Vec3, Vec3A};
 use bevy_transform::{
@@ -288,6 +288,88 @@ fn main() {
         out.insert("cluster.indices".into(), Array::U32(indices));
         out.insert("cluster.farthest_z".into(), Array::F32(vec![clusters.last_frame_farthest_z.unwrap_or(f32::NAN)]));
         out.insert("cluster.total".into(), Array::U64(vec![clusters.last_frame_total_cluster_index_count.unwrap_or(0) as u64]));
+    }
+
+    // ------------------------------------------------------------ 4. clusters again: point AND spot lights, TWO clustered cameras
+    // (the shapes round 4 added to the fused frame: the cone test of assign.rs:681-738 and one Clusters component per camera)
+    {
+        let lights = f32s(&inputs, "cluster2.lights_pos_range");
+        let (kind, rotation, outer) = (u8s(&inputs, "cluster2.type"), f32s(&inputs, "cluster2.rotation"), f32s(&inputs, "cluster2.outer_angle"));
+        let cameras = f32s(&inputs, "cluster2.cameras");
+        let dims = u32s(&inputs, "cluster.screen_dims_z");
+        let z = f32s(&inputs, "cluster.first_slice_depth_far_z");
+        let mut app = App::new();
+        app.add_plugins((TransformPlugin, VisibilityPlugin, CameraProjectionPlugin, LightPlugin));
+        app.insert_resource(GlobalClusterSettings {
+            supports_storage_buffers: true,
+            clustered_decals_are_usable: true,
+            gpu_clustering: None,
+            max_uniform_buffer_clusterable_objects: 204,
+            view_cluster_bindings_max_indices: 16384,
+        });
+        // the inputs list every point light before the first spot light: the gather order of assign.rs:189-230
+        let light_entities: Vec<Entity> = (0..kind.len())
+            .map(|i| {
+                let transform = Transform {
+                    translation: Vec3::from_slice(&lights[4 * i..]),
+                    rotation: Quat::from_slice(&rotation[4 * i..]),
+                    scale: Vec3::ONE,
+                };
+                let mut e = app.world_mut().spawn((transform, Visibility::Visible, NoFrustumCulling));
+                if kind[i] == 1 {
+                    e.insert(SpotLight { range: lights[4 * i + 3], outer_angle: outer[i], inner_angle: 0.0, ..Default::default() });
+                } else {
+                    e.insert(PointLight { range: lights[4 * i + 3], ..Default::default() });
+                }
+                e.id()
+            })
+            .collect();
+        let views: Vec<Entity> = (0..cameras.len() / 12)
+            .map(|v| {
+                let mut cam_component = Camera { is_active: true, order: v as isize, ..Default::default() };
+                cam_component.computed.target_info =
+                    Some(bevy_camera::RenderTargetInfo { physical_size: UVec2::new(dims[0], dims[1]), scale_factor: 1.0 });
+                cam_component.computed.clip_from_view =
+                    PerspectiveProjection { fov: cam[0], aspect_ratio: cam[1], near: cam[2], far: cam[3], ..Default::default() }.get_clip_from_view();
+                app.world_mut()
+                    .spawn((
+                        cam_component,
+                        projection(),
+                        camera_transform(&cameras[12 * v..12 * v + 12]),
+                        Frustum::default(),
+                        VisibleEntities::default(),
+                        Clusters::default(),
+                        ClusterConfig::XYZ {
+                            dimensions: UVec3::new(dims[2], dims[3], dims[4]),
+                            z_config: ClusterZConfig { first_slice_depth: z[0], far_z_mode: ClusterFarZMode::Constant(z[1]) },
+                            dynamic_resizing: false,
+                        },
+                    ))
+                    .id()
+            })
+            .collect();
+        app.update();
+        let world = app.world();
+        // what the assignment reads of a spot light: GlobalTransform::back() and ops::sin_cos(outer_angle) (assign.rs:563-573)
+        out.insert(
+            "cluster2.spot_back".into(),
+            Array::F32(light_entities.iter().flat_map(|e| world.get::<GlobalTransform>(*e).unwrap().back().to_array()).collect()),
+        );
+        out.insert("cluster2.sin_cos".into(), Array::F32(outer.iter().flat_map(|a| { let (s, c) = bevy_math::ops::sin_cos(*a); [s, c] }).collect()));
+        for (v, view) in views.iter().enumerate() {
+            let clusters = world.get::<Clusters>(*view).unwrap();
+            let ClusterableObjects::Cpu(per_cluster) = &clusters.clusterable_objects else { panic!("CPU clustering expected") };
+            let (mut offsets, mut indices) = (vec![0u32], Vec::new());
+            for objects in per_cluster {
+                indices.extend(objects.iter().map(|e| light_entities.iter().position(|x| x == e).unwrap() as u32));
+                offsets.push(indices.len() as u32);
+            }
+            out.insert(format!("cluster2.dims.{v}"), Array::U32(clusters.dimensions.to_array().to_vec()));
+            out.insert(format!("cluster2.offsets.{v}"), Array::U32(offsets));
+            out.insert(format!("cluster2.indices.{v}"), Array::U32(indices));
+            out.insert(format!("cluster2.farthest_z.{v}"), Array::F32(vec![clusters.last_frame_farthest_z.unwrap_or(f32::NAN)]));
+            out.insert(format!("cluster2.total.{v}"), Array::U64(vec![clusters.last_frame_total_cluster_index_count.unwrap_or(0) as u64]));
+        }
     }
 
     write_migd(&args[2], &out);

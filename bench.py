@@ -82,7 +82,7 @@ def parse():
     ap.add_argument("--tree-cull-launches", type=int, default=0, choices=[0, 1, 2], help="tree --tree-cull: 0 = the library's choice (one view: the tiles cull their own rows), 1 = always that, 2 = tile launch + cull launch")
     ap.add_argument("--tree-cull", action="store_true", help="tree: the hierarchy FRAME -- mi_propagate_and_cull on a context with a hierarchy (tile launch + cull launch, one call)")
     ap.add_argument("--sphere-path", type=int, default=0, help="flat_static / frame: 0 = world-sphere cull path from the second quiet frame (default), 1 = never (k_frame<0> over GlobalTransform + Aabb), 2 = at once")
-    ap.add_argument("--static-cull-order", type=int, default=0, choices=[0, 1, 2], help="flat_static: 0 = frames of a static scene of >= 262144 rows run over the cell order (default), 1 = never, 2 = at once, any size")
+    ap.add_argument("--static-cull-order", type=int, default=0, choices=[0, 1, 2], help="flat_static: 0 = frames of a static scene of >= 3 000 000 rows run over the cell order (default), 1 = never, 2 = at once, any size")
     ap.add_argument("--tile-mode", type=int, default=0, help="tree: 0 = subtree tiles where they fit, 1 = level by level, 3 = tiles with the streamed-level thresholds at their test values")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true")

@@ -110,7 +110,7 @@ def build_flat_static(ctx, args):
     config["row_summary"] = args.row_summary == 0
     config["static_cull_order"] = cells
     if n != 1_000_000 or n_views != 1:  # (the committed rocprofv3 evidence is filed per command: bench.py names this one in OTHER_WORKLOADS)
-        wl.profile_key = f"flat_static_{n // 1_000_000}m_{n_views}views"
+        wl.profile_key = f"flat_static_{n // 1_000_000}m_{n_views}views" + ("_no_cull_order" if sphere and order_mode == 1 and n >= 3_000_000 else "")
     if cells:
         # The static cull order (kernels_cells.hip): from the fourth quiet frame on a frame is four short launches over the cell-ordered
         # copy -- k_cells_test (a thread per cell of 64 slots: 36 B), k_frame_cells (a wave per cell that is left: 73 B per slot --

@@ -85,6 +85,7 @@ def test_default_rule_builds_on_the_second_quiet_frame_and_only_for_big_tables()
     sc = W.many_cubes(n, radius=700.0)
     g, _ = O.sync_simple_transforms(sc["translation"], sc["rotation"], sc["scale"])
     with api.Context(0) as ctx:
+        ctx.debug_set_sphere_path(0)  # (the suite also runs with the sphere column forced on at once: this test counts the default rule's frames)
         setup(ctx, sc, mode=0)
         vv = np.zeros(n, np.uint8)
         seen = []

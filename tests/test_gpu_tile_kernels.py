@@ -116,6 +116,7 @@ def test_tiles_are_used_where_they_fit_and_the_level_sweep_where_they_do_not(ctx
     # by default (mode 0): tiles wherever they fit
     big = W.gen_tree(12, 4, 1_000_000)
     ctx = ctx_factory()
+    ctx.debug_set_tile_mode(0)  # (the suite also runs under MI_TEST_TILE_MODE=1)
     ctx.resize(big["n"])
     ctx.upload_transforms(big["translation"], big["rotation"], big["scale"])
     ctx.upload_hierarchy(big["parent"], big["level_offsets"])

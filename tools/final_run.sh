@@ -8,7 +8,7 @@ P=gpurun_out/prof_$TAG
 mkdir -p $P
 rocminfo | grep -m1 gfx > $P/device.txt
 timeout 900 python -m pytest tests -m gpu -q > $P/gputest.log 2>&1; echo "gpu tests rc=$?" >> $P/gputest.log
-MI_TEST_ROW_SUMMARY=1 MI_TEST_WALK_INROW=1 MI_TEST_TREE_CULL=2 MI_TEST_SPHERE_PATH=2 MI_TEST_TILE_PRETEST=2 MI_TEST_CHUNKED_FRAMES=2 timeout 900 python -m pytest tests -m gpu -q \
+MI_TEST_ROW_SUMMARY=1 MI_TEST_WALK_INROW=1 MI_TEST_TREE_CULL=2 MI_TEST_SPHERE_PATH=2 MI_TEST_TILE_PRETEST=2 MI_TEST_CHUNKED_FRAMES=2 MI_TEST_STATIC_CULL_ORDER=2 MI_TEST_TILE_MODE=1 timeout 900 python -m pytest tests -m gpu -q \
     --deselect tests/test_gpu_differential.py > $P/gputest_other_paths.log 2>&1; echo "gpu tests (other paths) rc=$?" >> $P/gputest_other_paths.log
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $P/smoke.log 2>&1; echo "smoke rc=$?" >> $P/smoke.log
 timeout 200 ./tests/cpp/multi_gpu_single_process 1000000 6 > $P/multi_gpu_single_process.json 2> $P/multi_gpu.err; echo "multi gpu rc=$?" >> $P/multi_gpu.err

@@ -15,14 +15,19 @@ import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 workloads = sys.argv[2:] or ["frame", "frame_plain_columns", "flat", "flat_plain_columns", "tree_frame", "tree_frame_two_launches", "flat_10m_1view", "flat_10m_4views", "tree", "tree_subtree", "tree_leaves", "lights", "flat_static", "flat_static_no_sphere",
-                             "flat_static_10m_4views", "batching", "batching_sorted_64k", "batching_sorted_1m"]
+                             "flat_static_10m_4views", "flat_static_10m_4views_no_cull_order", "flat_static_4m_4views", "tree_by_levels", "batching",
+                             "batching_sorted_1k", "batching_sorted_4k", "batching_sorted_64k", "batching_sorted_1m"]
 src = os.path.join("gpurun_out", f"prof_{tag}")
 dst = os.path.join("profiles", tag)
 os.makedirs(dst, exist_ok=True)
 ALIAS = {"k_frame_sph<true": "k_flat_propagate_cull", "k_frame_sph<false": "k_cull",  # the world-sphere frame kernel: PARTIAL = the changed-rows frame, else cull only
          "k_frame<1": "k_flat_propagate_cull", "k_frame<2": "k_flat_propagate_cull", "k_frame<0": "k_cull",  # PROP: 1 all rows, 2 changed rows, 0 resident G (any INLINE_VIEWS / WITH_WALK variant)
          "k_frame<true": "k_flat_propagate_cull", "k_frame<false": "k_cull",  # (profiles from before PROP was an int)
-         "k_propagate_fans": "k_propagate_tiles"}  # the tile launch of mi_propagate, whichever tile kernel the plan uses
+         "k_propagate_fans": "k_propagate_tiles",  # the tile launch of mi_propagate (the library's timer slot keeps the round-1 name)
+         "k_propagate_level": "k_propagate_stream",
+         "k_frame_cells": "k_cull",  # the frame over the static cull order (its cell test: k_cells_test, its lists: k_cells_blocks / k_cells_lists)
+         "k_sorted_walk<512u, 16u, true>": "k_batch_scan", "k_sorted_walk<512, 16, true>": "k_batch_scan",  # the tiles' records
+         "k_sorted_walk": "k_batch_sorted"}
 
 
 def short(name):
@@ -77,6 +82,9 @@ for wl in workloads:
         json.dump(counters, open(os.path.join(dst, f"{wl}_pmc_counters.json"), "w"), indent=1)
     for k in entry:
         entry[k]["source"] = f"profiles/{tag}/{wl}_kernel_stats.csv" + (f" + {wl}_pmc_counters.json" if k in counters else "")
+    for extra in ("tree_frame_sq_counters.txt", "tree_sq_counters.txt"):  # (tools/profile.sh: SQ counters of the fused hierarchy frame / the tile launch)
+        if os.path.exists(os.path.join(src, extra)):
+            shutil.copy(os.path.join(src, extra), os.path.join(dst, extra))
     if entry:
         summary[wl] = entry
 json.dump(summary, open(summary_path, "w"), indent=1, sort_keys=True)

@@ -116,6 +116,10 @@ def end_to_end(ctx, wl, frames=12, cpu_frame_ms=None):
         # frame (cpu_baseline: every Transform dirty, best thread count; its visibility passes do not get cheaper when fewer rows move,
         # its propagate does: at 1 % / 10 % dirty the CPU figure is an upper bound of its cost, so these ratios are upper bounds too)
         out["x_cpu_port"] = {k: round(1e3 * cpu_frame_ms / v["us_per_frame"], 2) for k, v in out.items() if isinstance(v, dict) and "us_per_frame" in v}
+        # the same ratio over the library's calls alone (commit + frame + results): what is left when the ECS-side gather into the window --
+        # here ONE Python thread running numpy's take / copy, in a Bevy app a par_iter over the tables -- is taken out.  The truth for a
+        # shipped plugin lies between the two.
+        out["x_cpu_port_library_calls"] = {k: round(1e3 * cpu_frame_ms / v["library_us"], 2) for k, v in out.items() if isinstance(v, dict) and "library_us" in v}
         out["cpu_port_frame_us_all_dirty"] = round(1e3 * cpu_frame_ms, 1)
     out["note"] = ("same frame as `value` with the host on both sides, through ctypes: dirty Transforms written into the library's pinned upload "
                    "window (no staging copy; numpy's gather is the ECS side's loop) and committed, ONE frame call (propagate + cull + "

@@ -500,8 +500,8 @@ constexpr uint32_t FAN_SLOTS = TILE_LIGHT_UCAP + TILE_MAX_CHAIN;  // LDS slots: 
 constexpr uint32_t FAN_CHAIN_LANE0 = 256u - TILE_MAX_CHAIN;       // chain node k is fetched by thread FAN_CHAIN_LANE0 + k
 
 template <bool ALL_DIRTY, bool CULL = false>
-// (workgroups per CU: the fused instantiation is bound by vector-instruction issue -- 13.1 M wave instructions per launch over 1 024
-// SIMDs, 75 % of its span -- and by how many tiles are resident; 7 against 6 per CU: 31.5 against 33.1 us per launch; 8 -- 64
+// (workgroups per CU: the fused instantiation is bound by vector-instruction issue -- 12 - 13 M wave instructions per launch over 1 024
+// SIMDs, 70 - 75 % of its span -- and by how many tiles are resident; 7 against 6 per CU: 31.5 against 33.1 us per launch; 8 -- 64
 // registers, one spill -- 31.9)
 __global__ void __launch_bounds__(256, CULL ? 7 : ALL_DIRTY ? 8 : 7) k_propagate_fans(Columns c, TreeArgs a, typename CullArg<CULL>::type cu) {
     __shared__ float4 lds_g[FAN_SLOTS * 3];    // local affine, then (upper rows) the GlobalTransform in place

@@ -1,7 +1,7 @@
 """the batching work-item build (binned phase behind the flat frame; sorted phases)."""
 import numpy as np
 
-from .common import N_FRAMES, Workload, camera_frusta, flat_bytes_per_entity
+from .common import ROW_SUMMARY_SAVES, N_FRAMES, Workload, camera_frusta, flat_bytes_per_entity
 
 
 def build_batching(ctx, args):
@@ -34,6 +34,8 @@ def build_batching(ctx, args):
                   kernels=["k_flat_propagate_cull", "k_compact_fast", "k_batch_hist", "k_batch_emit", "k_batch_scan", "k_batch_scatter",
                            "k_batch_bounds", "k_batch_plan"])
     wl.batch = (bs, rows)
+    if getattr(args, "row_summary", 0) == 0:  # (the flat frame in front of the build reads the row summary like any other: moved < algorithmic)
+        wl.layout_bytes_per_row = wl.bytes_per_row - ROW_SUMMARY_SAVES
     return wl
 
 

@@ -34,6 +34,21 @@ extern thread_local const LaunchTimer* g_launch_timer;
         __builtin_amdgcn_s_barrier();                                  \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); \
     } while (0)
+#if defined(__HIPCC__)
+// A kernel argument read where it is used instead of where the compiler likes to read it (the kernel's first block: every argument
+// word then sits in an SGPR for the whole kernel, and the fused hierarchy frame's -- 1.3 KB of views, masks, zeroing and
+// compaction arguments on top of the tile kernel's own -- were 68 spilled SGPRs, v_readlane / v_writelane in every tile).  The pointer into
+// the kernarg segment goes through an empty asm statement, so nothing behind it can be hoisted above that point; the loads stay
+// scalar (the pointer is uniform and the address space is recovered after inlining).
+template <class T>
+__device__ __forceinline__ const T& kernarg_late(uint32_t offset) {
+    auto p = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const T*)(p + offset);
+}
+constexpr uint32_t kernarg_up(size_t x) { return (uint32_t)((x + 7u) & ~(size_t)7u); }
+
+#endif
 #define MI_LAUNCH(kernel, grid, block, lds, stream, ...)                                                        \
     do {                                                                                                        \
         const ::mi::LaunchTimer* lt_ = ::mi::g_launch_timer;                                                    \

@@ -380,6 +380,8 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
         if (lane == 0 && any_live) c.g_changed_bits[wave] = dm;
     }
     if constexpr (WALK != 0) {
+        // (reading the walk job here instead of at kernel entry -- kernarg_late, kernels.h: 14 -> 11 spilled SGPRs, no scratch -- made the
+        // metric frame SLOWER, 21.1 -> 22.2 us: the walk's tail is a chain of round trips, and the job's scalar loads join it)
         if (walk.inrow && tile - walk.tile0 < walk.n_blocks) inrow_cluster_walk<WALK == 2>(walk, tile, row, vv_now, g.t, lds_raw);  // (workgroup-uniform)
     }
 }

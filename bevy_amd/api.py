@@ -896,7 +896,7 @@ class Context:
         self._ck(self._lib.mi_debug_set_row_summary(self._h, int(mode)))
 
     def debug_set_static_cull_order(self, mode):
-        """0 = cull-only frames of a static scene run over the cell order from the second eligible frame on (default), 1 = never, 2 = at once, any row count."""
+        """0 = cull-only frames of a static scene run over the cell order from the second eligible frame on (default), 1 = never, 2 = at once, any row count, 3 = as 2 with the list kernels' runs capped at three (long runs, as beyond 16.7 M rows)."""
         self._ck(self._lib.mi_debug_set_static_cull_order(self._h, int(mode)))
 
     def debug_static_cull_counts(self):

@@ -533,7 +533,7 @@ static bool cells_frame_eligible(mi_ctx* ctx, const mi_view* views, uint32_t n_v
     auto& ce = ctx->cells;
     *build = false;
     bool ok = views && n_views && n_views <= SPH_MAX_VIEWS && ce.mode != 1 && ctx->sph_mode != 1 && ctx->n &&
-              ctx->n >= (ce.mode == 2 ? 1u : ce.min_rows) && (flags & (MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME)) == (MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME) &&
+              ctx->n >= (ce.mode >= 2 ? 1u : ce.min_rows) && (flags & (MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME)) == (MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME) &&
               !(flags & (MI_CULL_WITH_CLUSTERS | MI_CULL_CHANGED_ROWS)) && !ctx->have_class_mask && !ctx->have_ranges && !ctx->ext_bitmask && !ctx->xch.on &&
               ctx->sph_state == mi_ctx::SPH_VALID && ctx->sph.p;
     for (uint32_t v = 0; ok && v < n_views; ++v) ok = !(views[v].flags & MI_VIEW_FLAG_SHADOW);
@@ -542,7 +542,7 @@ static bool cells_frame_eligible(mi_ctx* ctx, const mi_view* views, uint32_t n_v
         return false;
     }
     if (ce.valid) return true;
-    if (ce.mode == 2 || ++ce.quiet >= 2u) {
+    if (ce.mode >= 2 || ++ce.quiet >= 2u) {
         *build = true;
         return true;
     }
@@ -685,6 +685,7 @@ static int32_t cells_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, 
             fin.seg_stride = ctx->seg_stride;
             fin.seg_totals = (uint32_t*)ctx->fb[ctx->cur].seg_totals.p;
         }
+        fin.max_groups = ce.mode == 3 ? 3u : 0u;
         HIP_TRY(ctx, launch_cells_finish(fin, n_views, ctx->stream, prof_mark, ctx));
         ce.chain_ok = true;
         ce.chain_mask = ctx->fb[nx].bitmask.p;
@@ -2517,7 +2518,7 @@ int32_t mi_debug_set_sphere_path(mi_ctx* ctx, int32_t mode) {
 // context with Cells::min_rows rows or more (default), 1 = never, 2 = at once, at any row count
 int32_t mi_debug_set_static_cull_order(mi_ctx* ctx, int32_t mode) {
     ENTER(ctx);
-    if (mode < 0 || mode > 2) return fail(ctx, MI_ERR_INVALID_ARG, "mi_debug_set_static_cull_order: mode %d", mode);
+    if (mode < 0 || mode > 3) return fail(ctx, MI_ERR_INVALID_ARG, "mi_debug_set_static_cull_order: mode %d", mode);
     ctx->cells.mode = mode;
     if (mode == 1) ctx->cells.valid = false;
     return MI_OK;

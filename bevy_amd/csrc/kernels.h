@@ -284,6 +284,7 @@ struct CellsFinishArgs {
     VisibilityOut out;
     uint32_t n_words, n_blks;          // mask words per view in use; 64-word blocks ((n_words + 63) / 64)
     uint32_t blks_per, n_groups;       // blocks per run, runs (set by the launch)
+    uint32_t max_groups;               // 0, or a cap on the runs (mi_debug_set_static_cull_order(3): the long runs of tables beyond 16.7 M rows)
     uint32_t* blk_pre;                 // [views][n_blks] scratch: a block's exclusive prefix inside its run
     uint32_t* grp_tot;                 // [views][CELLS_FIN_GROUPS] scratch: the runs' totals
     uint64_t* copy_to;                 // the next frame's mask set, or nullptr

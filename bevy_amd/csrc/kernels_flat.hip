@@ -1455,17 +1455,13 @@ __global__ void __launch_bounds__(256) k_cells_lists(CellsFinishArgs f) {
         if ((mj >> lane) & 1ull) out[base + oj + (uint32_t)__popcll(mj & lt)] = (b * 64u + (uint32_t)j) * 64u + lane;
     }
 }
-static uint32_t cells_dbg() {  // test hook (MI_CELLS_DBG): 16 = long runs in k_cells_blocks, the shape of tables beyond 16.7 M rows, on any table
-    static const uint32_t dbg = getenv("MI_CELLS_DBG") ? (uint32_t)atoi(getenv("MI_CELLS_DBG")) : 0u;
-    return dbg;
-}
 hipError_t launch_cells_finish(const CellsFinishArgs& f_in, uint32_t n_views, hipStream_t stream, void (*mark)(void*, uint32_t), void* mark_ctx) {
     CellsFinishArgs f = f_in;
     if (f.n_words == 0 || n_views == 0) return hipSuccess;
     uint32_t groups = (f.n_blks + 15u) / 16u;  // 16 blocks (65 536 rows) a run while that keeps it to CELLS_FIN_GROUPS runs
     if (groups > CELLS_FIN_GROUPS) groups = CELLS_FIN_GROUPS;
     if (groups == 0) groups = 1;
-    if ((cells_dbg() & 16u) && groups > 3u) groups = 3u;  // (test hook: long runs -- the shape of tables beyond 16.7 M rows -- on any table)
+    if (f.max_groups && groups > f.max_groups) groups = f.max_groups;  // (test hook: long runs -- the shape of tables beyond 16.7 M rows -- on any table)
     f.blks_per = (f.n_blks + groups - 1u) / groups;
     f.n_groups = (f.n_blks + f.blks_per - 1u) / f.blks_per;
     if (f.blks_per > CELLS_FIN_MAX_BLKS) return hipErrorInvalidValue;  // (more than 2^32 rows)

@@ -75,7 +75,8 @@ int32_t mi_debug_set_sphere_path(mi_ctx* ctx, int32_t mode);
 /* The static cull order (kernels_cells.hip): cull-only frames of a scene that has gone static -- world spheres current, camera views,
  * MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME, no classes / ranges / exchange -- run over a cell-ordered copy whose waves are first tested
  * as a whole against each view (reject only).  0 = built by the second such frame in a row on contexts of 3 000 000 rows and more
- * (default), 1 = never, 2 = at once and at any row count.  Results are identical.
+ * (default), 1 = never, 2 = at once and at any row count, 3 = as 2 with the list kernels' runs as long as those of a table beyond
+ * 16.7 M rows.  Results are identical.
  * mi_debug_static_cull_counts: orders built / frames that ran over one (tests). */
 int32_t mi_debug_set_static_cull_order(mi_ctx* ctx, int32_t mode);
 int32_t mi_debug_static_cull_counts(mi_ctx* ctx, uint32_t* out_builds, uint32_t* out_frames);

@@ -80,6 +80,25 @@ def test_static_frames_over_the_cell_order(n, more):
         assert builds == 1 and frames >= 5, (builds, frames)
 
 
+def test_long_list_runs_like_a_table_beyond_16_million_rows():
+    """k_cells_blocks cuts a view's 4 096-row blocks into at most 256 runs of at least 16 blocks: up to 16.7 M rows a run is 16 blocks,
+    beyond that it grows.  mi_debug_set_static_cull_order(3) caps the runs at three, so a 700 k-row table (171 blocks: runs of 57)
+    walks the long-run path -- several scan rounds per run -- that only such tables reach otherwise."""
+    n = 700_001
+    sc = W.many_cubes(n, radius=250.0, ragged_flags=True)
+    g, _ = O.sync_simple_transforms(sc["translation"], sc["rotation"], sc["scale"])
+    with api.Context(0) as ctx:
+        setup(ctx, sc, mode=3)
+        vv = np.zeros(n, np.uint8)
+        for frame in range(5):
+            ctx.propagate(0)
+            frusta = frusta_for(cams(frame, 3))
+            ctx.cull(frusta, flags=WHOLE | B.CULL_MORE_FRAMES)
+            vv, vis, chg = oracle_cull(sc, g, vv, frusta)
+            check_frame(ctx, vv, vis, chg, f"frame {frame}")
+        assert ctx.debug_static_cull_counts()[1] >= 2
+
+
 def test_default_rule_builds_on_the_second_quiet_frame_and_only_for_big_tables():
     n = 3_000_000
     sc = W.many_cubes(n, radius=700.0)

@@ -430,7 +430,18 @@ int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg, 
     return MI_OK;
 }
 
+// The deferred lists of a frame over the static cull order (ctx.h, Cells::lists_pending): launched on their own.
+int32_t cells_lists_join(mi_ctx* ctx) {
+    auto& ce = ctx->cells;
+    if (!ce.lists_pending) return MI_OK;
+    ce.lists_pending = false;
+    ProfScope ps(ctx, K_COMPACT_FAST);
+    HIP_TRY(ctx, launch_cells_lists(ce.lists_args, ce.lists_views, ctx->stream));
+    return MI_OK;
+}
+
 bool frame_begin(mi_ctx* ctx, CompactFastArgs* prev, bool* prev_has_job, mi_ctx::Exchange::Job* prev_job) {
+    cells_lists_join(ctx);  // (cells_frame takes a pending job out before it gets here: its launch carries it)
     const bool have = ctx->defer.pending;
     *prev_has_job = false;
     if (have) {
@@ -459,6 +470,10 @@ int32_t frame_abort(mi_ctx* ctx, int32_t rc, const CompactFastArgs* prev, bool p
 // Everything that exposes VisibleEntities (downloads, the batching build, MI_BUF_VISIBLE_ROWS, mi_synchronize) joins
 // first; the join only enqueues, so device-side consumers on the context's stream are ordered behind it.
 int32_t compaction_join(mi_ctx* ctx) {
+    {
+        const int32_t rc = cells_lists_join(ctx);
+        if (rc) return rc;
+    }
     if (!ctx->defer.pending) return MI_OK;
     ctx->defer.pending = false;
     {
@@ -580,18 +595,37 @@ static int32_t cells_build(mi_ctx* ctx) {
 
 static int32_t cells_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint32_t flags, bool build) {
     auto& ce = ctx->cells;
+    // the lists the frame before deferred ride in this frame's launch -- unless this frame is of another shape (its scratch may be
+    // reallocated) or builds a new order: then they go first, on their own
+    if (ce.lists_pending && (build || ce.lists_views != n_views)) {
+        const int32_t jrc = cells_lists_join(ctx);
+        if (jrc) return jrc;
+    }
+    const bool ride_lists = ce.lists_pending;
+    const CellsFinishArgs lists_job = ce.lists_args;
+    const uint32_t lists_views = ce.lists_views;
+    ce.lists_pending = false;  // (every way out below either carries the job in the frame's launch or launches it: lists_out)
+    auto lists_out = [&]() {
+        if (ride_lists) launch_cells_lists(lists_job, lists_views, ctx->stream);
+    };
     VisibilityOut vo{};
     CompactFastArgs prev_args{};
     bool prev_has_job = false;
     mi_ctx::Exchange::Job prev_job{};
     const CompactFastArgs* prev = frame_begin(ctx, &prev_args, &prev_has_job, &prev_job) ? &prev_args : nullptr;
     int32_t rc = exchange_begin(ctx);
-    if (rc) return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
-    if ((rc = prepare_views(ctx, views, n_views, &vo))) return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
+    if (rc || (rc = prepare_views(ctx, views, n_views, &vo))) {
+        lists_out();
+        return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
+    }
     SegOut seg;
-    if ((rc = prepare_segments(ctx, n_views, &seg))) return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
+    if ((rc = prepare_segments(ctx, n_views, &seg))) {
+        lists_out();
+        return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
+    }
     if (build && (rc = cells_build(ctx))) {
         ce.valid = false;
+        lists_out();
         return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
     }
     // ---- this frame's masks: the frame before's (its k_cells_counts copied them into this set) -- or zero ----
@@ -603,6 +637,7 @@ static int32_t cells_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, 
             // counts never ran): start over on a fresh order
             if ((rc = cells_build(ctx))) {
                 ce.valid = false;
+                lists_out();
                 return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
             }
         }
@@ -642,9 +677,10 @@ static int32_t cells_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, 
         if (e == hipSuccess) {
             ProfScope ps(ctx, K_CULL);
             e = launch_frame_cells(c, o, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p, n_views, vo, cz, work, prev,
-                                   have_fill ? &fill_job : nullptr, ctx->stream);
+                                   have_fill ? &fill_job : nullptr, ctx->stream, ride_lists ? &lists_job : nullptr, lists_views);
         }
         if (e != hipSuccess) {
+            lists_out();
             if (have_fill) launch_cluster_fill(fill_job.w, fill_job.n_clusters, fill_job.n_objects, ctx->stream);
             ce.valid = false;
             fail(ctx, MI_ERR_DEVICE, "frame kernel launch: %s", hipGetErrorString(e));
@@ -686,7 +722,15 @@ static int32_t cells_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, 
             fin.seg_totals = (uint32_t*)ctx->fb[ctx->cur].seg_totals.p;
         }
         fin.max_groups = ce.mode == 3 ? 3u : 0u;
-        HIP_TRY(ctx, launch_cells_finish(fin, n_views, ctx->stream, prof_mark, ctx));
+        // another frame follows at once: the lists ride in ITS launch (or cells_lists_join's); the block prefixes and the next frame's
+        // starting masks are wanted either way
+        const bool defer_lists = (flags & MI_CULL_MORE_FRAMES) && fin.out_rows != nullptr;
+        HIP_TRY(ctx, launch_cells_finish(fin, n_views, !defer_lists, ctx->stream, prof_mark, ctx));
+        if (defer_lists) {
+            ce.lists_args = fin;
+            ce.lists_views = n_views;
+            ce.lists_pending = true;
+        }
         ce.chain_ok = true;
         ce.chain_mask = ctx->fb[nx].bitmask.p;
         ce.chain_words = bm_words;

@@ -148,6 +148,12 @@ struct mi_ctx {
         int32_t mode = 0;            // mi_debug_set_static_cull_order: 0 = as described, 1 = never, 2 = at once and at any row count
         uint32_t min_rows = 3000000; // the frame over the order is four short launches (~22 us at 1 M rows against k_frame_sph's 10; even at 4 M x 1 view, far ahead at 10 M)
         uint32_t builds = 0, frames = 0;  // mi_debug_static_cull_counts
+        // MI_CULL_MORE_FRAMES: a frame's lists (k_cells_lists' work) are not launched behind it but ride in the next such frame's
+        // k_frame_cells launch; cells_lists_join (every frame of another kind, everything that exposes the lists) launches them on
+        // their own.  They read that frame's masks, its block prefixes (fin_scratch) and write its own list buffers.
+        bool lists_pending = false;
+        mi::CellsFinishArgs lists_args{};
+        uint32_t lists_views = 0;
     } cells;
 
     // ---- dense uploads in pieces, GlobalTransforms ahead of the frame (context.cpp: mi_commit_upload_window,

@@ -293,7 +293,10 @@ struct CellsFinishArgs {
     uint64_t seg_stride;
     uint32_t* seg_totals;              // [views]
 };
-hipError_t launch_cells_finish(const CellsFinishArgs& f, uint32_t n_views, hipStream_t stream, void (*mark)(void*, uint32_t), void* mark_ctx);
+// f.blks_per / f.n_groups are set here.  lists_now = false: only k_cells_blocks (the masks' copy and the block prefixes); the lists are then
+// launch_cells_lists' (same f) or ride in the next k_frame_cells launch.
+hipError_t launch_cells_finish(CellsFinishArgs& f, uint32_t n_views, bool lists_now, hipStream_t stream, void (*mark)(void*, uint32_t), void* mark_ctx);
+hipError_t launch_cells_lists(const CellsFinishArgs& f, uint32_t n_views, hipStream_t stream);
 // the work list between the two launches of the frame: list[n_cells] (cell, views left, summary bits | flags, RenderLayers), its counter
 // and the next frame's counter
 struct CellsWork {
@@ -306,7 +309,8 @@ hipError_t launch_cells_test(const CellsOrder& o, const ViewSet* views_inline, c
                              const CellsWork& work, hipStream_t stream);
 hipError_t launch_frame_cells(const Columns& c, const CellsOrder& o, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views,
                               const VisibilityOut& out, const CellsZero& z, const CellsWork& work, const CompactFastArgs* prev,
-                              const struct ClusterFillJob* fill, hipStream_t stream);
+                              const struct ClusterFillJob* fill, hipStream_t stream, const CellsFinishArgs* lists = nullptr /* the previous such
+                              frame's deferred lists ride in the launch */, uint32_t lists_views = 0);
 hipError_t launch_row_summary(const Columns& c, uint32_t first_wave, uint32_t n_waves, uint32_t parts, uint32_t* summary, hipStream_t stream);
 hipError_t launch_upload_trs(const float* pinned_src, float* t, float* r, float* s, uint32_t first_row, uint32_t n,
                              hipStream_t stream);

@@ -806,12 +806,26 @@ __global__ void __launch_bounds__(1024) k_cells_test(ViewSet vs, const ViewParam
         a.work[at] = make_uint4(cell, view_in, sb.x | ((st & 1u) << 31), sb.y);
     }
 }
+__device__ __forceinline__ void cells_lists_block(const CellsFinishArgs& f, uint32_t bx, uint32_t v);
 template <bool INLINE_VIEWS>
 __global__ void __launch_bounds__(256) k_frame_cells(Columns c, ViewSet vs, const ViewParams* __restrict__ dviews, uint32_t n_views,
                                                       VisibilityOut out, CellsFrameArgs a, uint32_t n_tiles, CompactFastArgs prev, uint32_t prev_gx,
-                                                      uint32_t n_compact, uint32_t n_fill, ClusterFillJob fill) {
+                                                      uint32_t n_compact, uint32_t n_fill, ClusterFillJob fill, uint32_t n_lists, uint32_t lists_views,
+                                                      CellsFinishArgs lists) {
     __shared__ __attribute__((aligned(16))) uint32_t lds_raw[FRAME_LDS_WORDS + 4];
     float4 (*lds_g)[192] = reinterpret_cast<float4 (*)[192]>(lds_raw);
+    if (n_lists) {
+        // the previous frame's VisibleEntities lists (k_cells_lists' work: MI_CULL_MORE_FRAMES deferred them) ride behind the other riders
+        // at the head of the grid: they read that frame's finished masks and block prefixes, which this launch does not touch.
+        // (10 M rows x 4 views, us per frame: lists as a launch of their own 71.1; riding at the head 64.2, spread between the cell
+        // workgroups 68.3, at the end of the grid 71.6 -- there they only start when the cells are done.)
+        const uint32_t first = n_compact + n_fill;
+        if (blockIdx.x >= first && blockIdx.x < first + n_lists) {
+            const uint32_t id = blockIdx.x - first, per_view = n_lists / lists_views;
+            cells_lists_block(lists, id % per_view, id / per_view);
+            return;
+        }
+    }
     {
         ClusterWalkJob no_walk{};
         if (frame_riders<0>(n_tiles, prev, prev_gx, n_compact, n_fill, fill, no_walk, vs, lds_raw)) return;
@@ -1408,9 +1422,9 @@ __global__ void __launch_bounds__(256) k_cells_blocks(CellsFinishArgs f) {
     }
     if (lane == 0u) f.grp_tot[(size_t)v * CELLS_FIN_GROUPS + grp] = carry;
 }
-__global__ void __launch_bounds__(256) k_cells_lists(CellsFinishArgs f) {
-    const uint32_t v = blockIdx.y, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t b = blockIdx.x * 4u + wv;
+__device__ __forceinline__ void cells_lists_block(const CellsFinishArgs& f, uint32_t bx, uint32_t v) {
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t b = bx * 4u + wv;
     if (b >= f.n_blks) return;  // (wave-uniform)
     const uint64_t* mask = f.out.bitmask + (size_t)v * f.out.words_per_view + f.out.word_offset;
     const uint32_t word = b * 64u + lane;
@@ -1455,8 +1469,13 @@ __global__ void __launch_bounds__(256) k_cells_lists(CellsFinishArgs f) {
         if ((mj >> lane) & 1ull) out[base + oj + (uint32_t)__popcll(mj & lt)] = (b * 64u + (uint32_t)j) * 64u + lane;
     }
 }
-hipError_t launch_cells_finish(const CellsFinishArgs& f_in, uint32_t n_views, hipStream_t stream, void (*mark)(void*, uint32_t), void* mark_ctx) {
-    CellsFinishArgs f = f_in;
+__global__ void __launch_bounds__(256) k_cells_lists(CellsFinishArgs f) { cells_lists_block(f, blockIdx.x, blockIdx.y); }
+hipError_t launch_cells_lists(const CellsFinishArgs& f, uint32_t n_views, hipStream_t stream) {
+    if (f.n_words == 0 || n_views == 0 || !f.out_rows) return hipSuccess;
+    MI_LAUNCH(k_cells_lists, dim3((f.n_blks + 3u) / 4u, n_views), dim3(256), 0, stream, f);
+    return hipGetLastError();
+}
+hipError_t launch_cells_finish(CellsFinishArgs& f, uint32_t n_views, bool lists_now, hipStream_t stream, void (*mark)(void*, uint32_t), void* mark_ctx) {
     if (f.n_words == 0 || n_views == 0) return hipSuccess;
     uint32_t groups = (f.n_blks + 15u) / 16u;  // 16 blocks (65 536 rows) a run while that keeps it to CELLS_FIN_GROUPS runs
     if (groups > CELLS_FIN_GROUPS) groups = CELLS_FIN_GROUPS;
@@ -1467,7 +1486,7 @@ hipError_t launch_cells_finish(const CellsFinishArgs& f_in, uint32_t n_views, hi
     if (f.blks_per > CELLS_FIN_MAX_BLKS) return hipErrorInvalidValue;  // (more than 2^32 rows)
     if (mark) mark(mark_ctx, K_COMPACT_COUNT);
     MI_LAUNCH(k_cells_blocks, dim3(f.n_groups, n_views), dim3(256), 0, stream, f);
-    if (f.out_rows) {
+    if (f.out_rows && lists_now) {
         if (mark) mark(mark_ctx, K_COMPACT_FAST);
         MI_LAUNCH(k_cells_lists, dim3((f.n_blks + 3u) / 4u, n_views), dim3(256), 0, stream, f);
     }
@@ -1489,8 +1508,8 @@ hipError_t launch_cells_test(const CellsOrder& o, const ViewSet* views_inline, c
 // the cells it listed: a wave each, grid-stride (at most CELLS_MAX_TILES workgroups: twice what the chip holds at once)
 hipError_t launch_frame_cells(const Columns& c, const CellsOrder& o, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views,
                               const VisibilityOut& out, const CellsZero& z, const CellsWork& work, const CompactFastArgs* prev, const ClusterFillJob* fill,
-                              hipStream_t stream) {
-    if (c.n == 0) return hipSuccess;
+                              hipStream_t stream, const CellsFinishArgs* lists, uint32_t lists_views) {
+    if (c.n == 0) return lists ? launch_cells_lists(*lists, lists_views, stream) : hipSuccess;
     CellsFrameArgs a{o, z, work.list, work.n, work.n_next, work.fresh};
     const bool inl = n_views <= MAX_INLINE_VIEWS && views_inline;
     ViewSet dummy = {};
@@ -1511,9 +1530,17 @@ hipError_t launch_frame_cells(const Columns& c, const CellsOrder& o, const ViewS
         fj = *fill;
         fill_blocks = CLUSTER_FILL_RIDE_BLOCKS;
     }
-    const dim3 grid(n_tiles + prev_blocks + fill_blocks);
-    if (inl) MI_LAUNCH((k_frame_cells<true>), grid, dim3(256), 0, stream, c, vsr, dv, n_views, out, a, n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj);
-    else MI_LAUNCH((k_frame_cells<false>), grid, dim3(256), 0, stream, c, vsr, dv, n_views, out, a, n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj);
+    CellsFinishArgs lf{};
+    uint32_t n_lists = 0;
+    if (lists && lists->out_rows && lists->n_words && lists_views) {
+        lf = *lists;
+        n_lists = ((lf.n_blks + 3u) / 4u) * lists_views;
+    }
+    const dim3 grid(n_tiles + prev_blocks + fill_blocks + n_lists);
+    if (inl) MI_LAUNCH((k_frame_cells<true>), grid, dim3(256), 0, stream, c, vsr, dv, n_views, out, a, n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, n_lists,
+                       lists_views, lf);
+    else MI_LAUNCH((k_frame_cells<false>), grid, dim3(256), 0, stream, c, vsr, dv, n_views, out, a, n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, n_lists,
+                   lists_views, lf);
     return hipGetLastError();
 }
 hipError_t launch_flat_propagate_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views,

@@ -118,46 +118,67 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
             bands.push_back({s, e, chain});
             e = s;
         }
-        // tiles of one band: galloping extension of the first-level range while the tile still fits
-        auto build_band = [&](const Band& bd, uint32_t kind_base) {
-            const uint32_t d = bd.e - bd.s;
-            auto build = [&](uint32_t lo, uint32_t hi, TileDesc& td) -> bool {  // [lo,hi): rows of level bd.s
-                td = TileDesc{};
-                uint32_t clo = lo, chi2 = hi;
-                for (uint32_t k = 0; k < d; ++k) {
-                    td.start[k] = clo;
-                    td.count[k] = chi2 - clo;
-                    if (chi2 > clo) td.n_levels = k + 1;
-                    if (k + 1 < d) {
-                        const uint32_t nlo = child_begin(bd.s + k, clo), nhi = child_begin(bd.s + k, chi2);
-                        clo = nlo;
-                        chi2 = nhi;
-                    }
+        // One tile: rows [lo, hi) of level s and their descendants over the next n_lv - 1 levels.  true = it fits.
+        auto build_tile = [&](uint32_t s, uint32_t n_lv, uint32_t lo, uint32_t hi, TileDesc& td) -> bool {
+            td = TileDesc{};
+            uint32_t clo = lo, chi2 = hi;
+            for (uint32_t k = 0; k < n_lv; ++k) {
+                td.start[k] = clo;
+                td.count[k] = chi2 - clo;
+                if (chi2 > clo) td.n_levels = k + 1;
+                if (k + 1 < n_lv) {
+                    const uint32_t nlo = child_begin(s + k, clo), nhi = child_begin(s + k, chi2);
+                    clo = nlo;
+                    chi2 = nhi;
                 }
-                uint64_t up = 0;
-                for (uint32_t k = 0; k + 1 < td.n_levels; ++k) up += td.count[k];
-                return up <= UCAP && (td.n_levels == 0 || td.count[td.n_levels - 1] <= LAST_CAP);
-            };
-            const uint32_t rlo = level_offsets[bd.s], rhi = level_offsets[bd.s + 1];
-            const uint32_t first_tile = (uint32_t)tiles.size();
+            }
+            uint64_t up = 0;
+            for (uint32_t k = 0; k + 1 < td.n_levels; ++k) up += td.count[k];
+            return up <= UCAP && (td.n_levels == 0 || td.count[td.n_levels - 1] <= LAST_CAP);
+        };
+        auto upper_rows = [](const TileDesc& td) {
+            uint64_t up = 0;
+            for (uint32_t k = 0; k + 1 < td.n_levels; ++k) up += td.count[k];
+            return up;
+        };
+        // What a tile of ONE first-level row could not take: a node with hundreds of children that have children of their own
+        // overflows the tile kernel's LDS rows.  Its tile is cut off after the last level that fits, and the rows below -- [lo, hi) of
+        // `level`, down to the band's end -- become tiles of a launch of their own behind the one that holds their parents (first-level
+        // parents read from global memory), cut again if need be.  (Rounds 1 - 3 sent such hierarchies to a second tile kernel, round 4
+        // first to the level sweep; this keeps them on the one tile kernel.)
+        struct Region { uint32_t level, lo, hi, e; };
+        // rows [rlo, rhi) of level s as tiles over levels [s, e): galloping extension of the first-level range while the tile still fits
+        auto cut_rows = [&](uint32_t s, uint32_t e, uint32_t rlo, uint32_t rhi, bool chain, uint32_t kind_base, std::vector<Region>& spill) {
+            const uint32_t d = e - s;
             uint32_t a = rlo;
             while (a < rhi) {
                 TileDesc best{};
                 uint32_t b = a + 1;
-                build(a, b, best);  // a single first-level row always makes a tile (one that does not fit sends the plan to the level sweep, below)
-                uint32_t step = 1;
-                while (b < rhi) {
-                    const uint32_t nb = (uint32_t)std::min<uint64_t>((uint64_t)b + step, rhi);
-                    TileDesc cand{};
-                    const bool same_parent = !bd.chain || parent_idx[nb - 1] == parent_idx[a];
-                    if (same_parent && build(a, nb, cand)) { best = cand; b = nb; step *= 2; }
-                    else if (step > 1) step = 1;
-                    else break;
+                if (!build_tile(s, d, a, b, best) && upper_rows(best) > UCAP) {
+                    // the row's own subtree does not fit: keep the levels that do, hand the rest down
+                    uint32_t k = d;
+                    while (k > 1 && (build_tile(s, k, a, b, best), upper_rows(best) > UCAP)) --k;
+                    build_tile(s, k, a, b, best);
+                    if (best.n_levels == k && k < d) {
+                        const uint32_t llo = best.start[k - 1], lhi = llo + best.count[k - 1];
+                        const uint32_t clo = child_begin(s + k - 1, llo), chi = child_begin(s + k - 1, lhi);
+                        if (chi > clo) spill.push_back({s + k, clo, chi, e});
+                    }
+                } else {
+                    uint32_t step = 1;
+                    while (b < rhi) {
+                        const uint32_t nb = (uint32_t)std::min<uint64_t>((uint64_t)b + step, rhi);
+                        TileDesc cand{};
+                        const bool same_parent = !chain || parent_idx[nb - 1] == parent_idx[a];
+                        if (same_parent && build_tile(s, d, a, nb, cand)) { best = cand; b = nb; step *= 2; }
+                        else if (step > 1) step = 1;
+                        else break;
+                    }
                 }
                 if (best.n_levels) {
                     best.kind = kind_base;
-                    if (bd.chain) {
-                        chains.resize((tiles.size() + 1) * (size_t)TILE_MAX_CHAIN, 0u);
+                    chains.resize((tiles.size() + 1) * (size_t)TILE_MAX_CHAIN, 0u);
+                    if (chain) {
                         uint32_t row = parent_idx[best.start[0]], len = 0;
                         while (row != MI_NO_PARENT && len < TILE_MAX_CHAIN) {
                             chains[tiles.size() * (size_t)TILE_MAX_CHAIN + len++] = row;
@@ -169,6 +190,12 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
                 }
                 a = b;
             }
+        };
+        std::vector<std::vector<Region>> band_spill(bands.size());
+        auto build_band = [&](size_t i, uint32_t kind_base) {
+            const Band& bd = bands[i];
+            const uint32_t first_tile = (uint32_t)tiles.size();
+            cut_rows(bd.s, bd.e, level_offsets[bd.s], level_offsets[bd.s + 1], bd.chain, kind_base, band_spill[i]);
             return std::make_pair(first_tile, (uint32_t)tiles.size() - first_tile);
         };
         // launch 1: the chain bands, bottom band first (the longest tiles start first), then the roots band
@@ -176,28 +203,45 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
         uint32_t n_chain_tiles = 0, owner_rows = 0;
         for (size_t i = 0; i < bands.size(); ++i)
             if (bands[i].chain) {
-                band_tiles[i] = build_band(bands[i], 0u);
+                band_tiles[i] = build_band(i, 0u);
                 n_chain_tiles += band_tiles[i].second;
                 owner_rows = std::max(owner_rows, level_offsets[bands[i].s]);  // the snapshot prefix: every row above the deepest chain band
             }
-        band_tiles.back() = build_band(bands.back(), TILE_ROOTS);  // bands.back() starts at level 0
+        band_tiles.back() = build_band(bands.size() - 1, TILE_ROOTS);  // bands.back() starts at level 0
         ctx->groups.push_back({0u, (uint32_t)tiles.size(), n_chain_tiles, owner_rows});
-        // then the dependent bands, top-down, one launch each
-        for (size_t i = bands.size(); i-- > 0;)
+        // then, top-down: a dependent band's own launch, and behind any band the launches of what its tiles had to hand down (one per
+        // depth of cutting: a handed-down region reads the rows of the launch that cut it)
+        std::vector<std::vector<std::pair<uint32_t, uint32_t>>> band_passes(bands.size());
+        for (size_t i = bands.size(); i-- > 0;) {
             if (!bands[i].chain && bands[i].s > 0) {
-                band_tiles[i] = build_band(bands[i], 0u);
+                band_tiles[i] = build_band(i, 0u);
                 ctx->groups.push_back({band_tiles[i].first, band_tiles[i].second, 0u, 0u});
             }
+            band_passes[i].push_back(band_tiles[i]);
+            std::vector<Region> cur;
+            cur.swap(band_spill[i]);
+            while (!cur.empty()) {
+                std::vector<Region> next;
+                const uint32_t first_tile = (uint32_t)tiles.size();
+                for (const Region& r : cur) cut_rows(r.level, r.e, r.lo, r.hi, false, 0u, next);
+                const uint32_t cnt = (uint32_t)tiles.size() - first_tile;
+                if (cnt) {
+                    ctx->groups.push_back({first_tile, cnt, 0u, 0u});
+                    band_passes[i].emplace_back(first_tile, cnt);
+                }
+                cur.swap(next);
+            }
+        }
         chains.resize(tiles.size() * (size_t)TILE_MAX_CHAIN, 0u);
-        // the bands top-down, for the kernels that sweep level by level with one launch per band (InheritedVisibility)
-        for (size_t i = bands.size(); i-- > 0;) ctx->passes.emplace_back(band_tiles[i].first, band_tiles[i].second);
+        // the bands top-down, for the kernels that sweep level by level with one launch per band (InheritedVisibility): a band's own
+        // tiles, then what they handed down, depth by depth
+        for (size_t i = bands.size(); i-- > 0;)
+            for (auto& ps : band_passes[i]) ctx->passes.push_back(ps);
     }
-    // The tile kernel has no fallback for upper levels that overflow its LDS rows (a single node with hundreds of children
-    // that have children of their own) and addresses rows with 32-bit byte offsets: such a hierarchy is swept level by level,
-    // one streaming launch per level (mi_propagate).  The tile list stays: the InheritedVisibility sweep walks it whatever its
-    // tiles hold (k_inherit_tiles falls back to global memory past its own LDS bytes).
+    // The tile kernel addresses rows with 32-bit byte offsets: a hierarchy beyond 89 M rows is swept level by level, one streaming
+    // launch per level (mi_propagate; mi_debug_set_tile_mode(1) forces it).  The tile list stays: the InheritedVisibility sweep walks it.
     ctx->by_levels = ctx->tile_mode == 1 || n > 0xFFFFFFFFu / 48u;
-    for (const TileDesc& td : tiles) {
+    for (const TileDesc& td : tiles) {  // (every tile fits by construction: a subtree that would not was cut, above)
         uint64_t up = 0;
         for (uint32_t k = 0; k + 1 < td.n_levels; ++k) up += td.count[k];
         if (up > TILE_LIGHT_UCAP) ctx->by_levels = true;

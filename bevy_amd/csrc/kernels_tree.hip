@@ -15,10 +15,11 @@
 //   step 2  the tile's last level -- usually ~3/4 of its rows -- is streamed: coalesced T/R/S and old-G loads (wave-local
 //           LDS transpose), parent G from LDS, coalesced G stores.
 // One launch therefore covers up to TILE_MAX_LEVELS levels with one HBM round trip of latency plus the streaming time.
-// A hierarchy the planner cannot cut into such tiles (one node with hundreds of children that have children of their own:
-// its upper rows overflow the LDS slots) is swept level by level instead, one k_propagate_level launch per level -- the
-// kernel the widest levels of very big trees take anyway.  (Rounds 1-3 kept a second, big-tile kernel for those shapes;
-// it had not followed the light kernel's changes and is gone.)
+// A subtree too big for a tile (one node with hundreds of children that have children of their own: its upper rows overflow the
+// LDS slots) is cut by the planner: the levels that fit make a tile, the rows below become tiles of a later launch that read their
+// first-level parents from global memory (ctx_hierarchy.cpp).  A hierarchy past this kernel's 32-bit byte offsets is swept level
+// by level instead, one k_propagate_level launch per level -- the kernel the widest levels of very big trees take anyway.  (Rounds
+// 1-3 kept a second, big-tile kernel for oversized subtrees; it had not followed the light kernel's changes and is gone.)
 //
 // Algorithmic bytes per node: read T 40 + parent_idx 4 + old G 48 (set_if_neq, systems.rs:719),
 // write G 48 + changed 1; parent G comes from LDS (first level of a non-root tile: from L2).

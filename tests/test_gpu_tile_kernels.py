@@ -1,4 +1,4 @@
-"""GPU parity of the two hierarchy paths (subtree tiles / the level-by-level sweep that takes hierarchies the tiles cannot hold) on
+"""GPU parity of the two hierarchy paths (subtree tiles, oversized subtrees cut over several launches / the level-by-level sweep) on
 shapes that exercise each planner and kernel branch: the path is forced with the mi_debug_set_tile_mode hook (1 = by levels, 2 =
 tiles where they fit), results are compared with the oracle
 (propagate_parent_transforms + mark_dirty_trees, crates/bevy_transform/src/systems.rs:111-306,506-748) bit for bit, change
@@ -44,7 +44,8 @@ SHAPES = {
     "fan_4ary_7_levels": (1, [4] * 6),                                  # the bench's shape, small: chain tiles below a top tile
     "one_node_700_leaves": (1, [700]),                                   # a last level of several batches in one tile
     "wide_second_level": (1, [300, 4]),
-    "skewed": (1, [200, lambda i: 300 if i == 0 else 0, 2]),             # one subtree overflows a tile: swept level by level
+    "skewed": (1, [200, lambda i: 300 if i == 0 else 0, 2]),             # one subtree overflows a tile: cut, the rest handed to a second launch
+    "skewed_twice": (3, [4, lambda i: 150 if i == 5 else 2, lambda i: 130 if i % 7 == 0 else 1, lambda i: 3 if i % 2 else 0, 2]),  # ... cut again below
     "forest_3000_roots": (3000, [3, 2]),                                 # many roots per tile, level 0 holds most rows
     "flat_rows_and_trees": (5000, [lambda i: 5 if i % 50 == 0 else 0, 6, 3]),  # flat rows share level 0 with the roots
     "ragged": (7, [lambda i: i % 5, lambda i: (i * 7) % 4, lambda i: 300 if i == 3 else i % 3, 2]),
@@ -99,7 +100,7 @@ def test_tile_kernels_match_oracle(ctx_factory, shape, mode, static_opt):
         g0 = g1
 
 
-def test_tiles_are_used_where_they_fit_and_the_level_sweep_where_they_do_not(ctx_factory):
+def test_tile_plans_cut_oversized_subtrees_and_the_level_sweep_can_be_forced(ctx_factory):
     def plan(shape, mode):
         tr = _levels(SHAPES[shape], seed=1)
         ctx = ctx_factory()
@@ -112,7 +113,9 @@ def test_tiles_are_used_where_they_fit_and_the_level_sweep_where_they_do_not(ctx
     assert p["launches"] == 1 and levels == 7                       # roots and chain tiles share one launch
     assert plan("fan_4ary_7_levels", 1)[0]["launches"] == 7         # forced: one launch per level
     p, levels = plan("skewed", 0)
-    assert p["launches"] == levels == 4                             # a node with 200 children that have 300 of their own: does not fit
+    assert p["launches"] == 2 and levels == 4                       # a node with 300 children that have children: its tile is cut, the rest follows
+    assert plan("skewed", 1)[0]["launches"] == 4
+    assert plan("skewed_twice", 0)[0]["launches"] >= 2
     # by default (mode 0): tiles wherever they fit
     big = W.gen_tree(12, 4, 1_000_000)
     ctx = ctx_factory()

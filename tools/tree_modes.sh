@@ -3,7 +3,7 @@
 TAG=${1:-x}
 O=gpurun_out/tree_$TAG
 mkdir -p $O; : > $O/summary.txt
-K="tree or hierarch or forest or chain or inherit or propagat or static or shard"
+K="tree or hierarch or forest or chain or inherit or propagat or static or shard or tile"
 for m in $2; do
   MI_TEST_TILE_MODE=$m timeout 600 python -m pytest tests -m gpu -x -q -k "$K" > $O/test_mode$m.log 2>&1; echo "test mode $m rc=$? $(tail -1 $O/test_mode$m.log)" >> $O/summary.txt
 done

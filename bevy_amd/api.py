@@ -45,6 +45,7 @@ class ClusterView(C.Structure):
         ("y_planes", C.POINTER(C.c_float)),
         ("z_planes", C.POINTER(C.c_float)),
         ("cluster_spheres", C.POINTER(C.c_float)),
+        ("view_layer_mask_hi", C.c_uint32),
     ]
 
     @property
@@ -194,7 +195,7 @@ ABI_SYMBOLS = [
     "mi_visibility_end_frame",
     "mi_download_global_transforms", "mi_download_changed_global_transforms", "mi_download_frame_results", "mi_download_changed_mesh_inputs", "mi_download_visibility", "mi_download_view_visibility",
     "mi_download_visible_entities", "mi_cluster_view_dims", "mi_cluster_view_build",
-    "mi_cluster_dimensions_fixed_z", "mi_cluster_assign", "mi_cluster_upload_objects", "mi_cluster_upload_view",
+    "mi_cluster_dimensions_fixed_z", "mi_cluster_assign", "mi_cluster_upload_objects", "mi_cluster_upload_object_layers_hi", "mi_cluster_upload_view",
     "mi_cluster_assign_resident", "mi_cluster_select_view", "mi_cluster_download", "mi_cluster_download_bindings",
     "mi_cluster_config_default", "mi_cluster_config_resolve", "mi_cluster_sort_truncate", "mi_cluster_bind_objects_to_rows", "mi_cluster_bind_objects_to_row_list",
     "mi_cluster_assign_frame",
@@ -643,6 +644,13 @@ class Context:
         pr, ty, lm, sd, sc = _f32(pos_range), _u8(obj_type), _u32(layer_mask), _f32(spot_dir), _f32(spot_sin_cos)
         self._ck(self._lib.mi_cluster_upload_objects(self._h, len(pr) // 4, _ptr(pr, C.c_float), _ptr(ty, C.c_uint8),
                                                      _ptr(lm, C.c_uint32), _ptr(sd, C.c_float), _ptr(sc, C.c_float)))
+        self._cluster_n = len(pr) // 4
+
+    def cluster_upload_object_layers_hi(self, layer_mask_hi):
+        """RenderLayers 32..63 of the uploaded objects (None clears the column); after cluster_upload_objects, which clears it too."""
+        hi = _u32(layer_mask_hi)
+        n = len(hi) if hi is not None else self._cluster_n
+        self._ck(self._lib.mi_cluster_upload_object_layers_hi(self._h, n, _ptr(hi, C.c_uint32)))
 
     def cluster_select_view(self, slot):
         """Makes view slot `slot` (0 .. 7) the one the cluster calls and MI_CULL_WITH_CLUSTERS refer to (several clustered cameras)."""

@@ -206,7 +206,7 @@ __device__ __forceinline__ bool derive_row_visible(const ClusterObjects& o, cons
 // caller keeps: the walk needs it again, and fetching it again is one more trip.
 __device__ __forceinline__ bool object_in_view(const ClusterViewDev& v, const ClusterObjects& o, const ViewSet& views, uint32_t obj, float4* sphere_out) {
     float4 pr = reinterpret_cast<const float4*>(o.pos_range)[obj];  // (issued with the row's loads below)
-    const uint32_t layers = o.layer_mask ? o.layer_mask[obj] : 1u;
+    const uint32_t layers = o.layer_mask ? o.layer_mask[obj] : 1u, layers_hi = o.layer_mask_hi ? o.layer_mask_hi[obj] : 0u;
     bool visible = true;
     if (o.derive) {
         Affine g;
@@ -225,7 +225,7 @@ __device__ __forceinline__ bool object_in_view(const ClusterViewDev& v, const Cl
     }
     *sphere_out = pr;
     if (!visible) return false;
-    if (!(v.view_layer_mask & layers)) return false;  // :489
+    if (!((v.view_layer_mask & layers) | (v.view_layer_mask_hi & layers_hi))) return false;  // :489, RenderLayers::intersects over the first u64 word
     V4 fr[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) fr[i] = V4{v.frustum[4 * i], v.frustum[4 * i + 1], v.frustum[4 * i + 2], v.frustum[4 * i + 3]};

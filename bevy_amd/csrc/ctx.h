@@ -308,7 +308,7 @@ struct mi_ctx {
     uint64_t seg_stride = 0;
 
     // ---- clustering ----
-    DevBuf cl_pos, cl_type, cl_layers, cl_dir, cl_sincos, cl_planes, cl_spheres;
+    DevBuf cl_pos, cl_type, cl_layers, cl_layers_hi, cl_dir, cl_sincos, cl_planes, cl_spheres;
     // batching work-item build (kernels_batch.hip)
     uint32_t *bt_set = nullptr, *bt_bin = nullptr, *bt_input = nullptr, *bt_row_meta = nullptr;  // per-row columns
     uint8_t* bt_kind = nullptr;                              // MI_BATCH_ROW_*
@@ -330,7 +330,7 @@ struct mi_ctx {
     bool cl_derive_resident = false;
     uint32_t cl_parity = 0, cl_acc_clusters = 0, cl_acc_blocks = 0;  // cl_parity: the current working set; cl_acc = 3 x [counts 6C | totals C | farthest_z + pad]
     uint32_t cl_n = 0;
-    bool cl_have_type = false, cl_have_layers = false, cl_have_spot = false, cl_have_spot_dir = false, cl_any_spot = false;
+    bool cl_have_type = false, cl_have_layers = false, cl_have_layers_hi = false, cl_have_spot = false, cl_have_spot_dir = false, cl_any_spot = false;
     bool cl_rows_bound = false;      // mi_cluster_bind_objects_to_rows: object i is row cl_first_row + i
     uint32_t cl_first_row = 0;
     DevBuf cl_row_list;              // mi_cluster_bind_objects_to_row_list: the rows, in object order

@@ -9,6 +9,20 @@ extern "C" {
 // =============================================================================================
 // clustering
 // =============================================================================================
+int32_t mi_cluster_upload_object_layers_hi(mi_ctx* ctx, uint32_t n, const uint32_t* layer_mask_hi) {
+    ENTER(ctx);
+    if (n != ctx->cl_n) return fail(ctx, MI_ERR_INVALID_ARG, "mi_cluster_upload_object_layers_hi: %u objects, %u uploaded", n, ctx->cl_n);
+    int32_t rc;
+    if ((rc = cluster_join(ctx))) return rc;
+    ctx->cl_have_layers_hi = false;
+    ctx->cl_assigned = false;
+    if (!layer_mask_hi || n == 0) return MI_OK;
+    if ((rc = ensure(ctx, ctx->cl_layers_hi, (size_t)n * 4))) return rc;
+    if ((rc = upload(ctx, ctx->cl_layers_hi.p, layer_mask_hi, (size_t)n * 4))) return rc;
+    ctx->cl_have_layers_hi = true;
+    return MI_OK;
+}
+
 int32_t mi_cluster_upload_objects(mi_ctx* ctx, uint32_t n, const float* pos_range, const uint8_t* obj_type,
                                   const uint32_t* layer_mask, const float* spot_dir, const float* spot_sin_cos) {
     ENTER(ctx);
@@ -29,6 +43,7 @@ int32_t mi_cluster_upload_objects(mi_ctx* ctx, uint32_t n, const float* pos_rang
         if ((rc = ensure(ctx, ctx->cl_type, n))) return rc;
         if ((rc = upload(ctx, ctx->cl_type.p, obj_type, n))) return rc;
     }
+    ctx->cl_have_layers_hi = false;  // (mi_cluster_upload_object_layers_hi follows, for objects on layers 32..63)
     ctx->cl_have_layers = layer_mask != nullptr;
     if (layer_mask) {
         if ((rc = ensure(ctx, ctx->cl_layers, (size_t)n * 4))) return rc;
@@ -155,6 +170,7 @@ int32_t mi_cluster_upload_view(mi_ctx* ctx, const mi_cluster_view* view) {
     memcpy(d.dims, view->dims, sizeof d.dims);
     d.is_orthographic = view->is_orthographic;
     d.view_layer_mask = view->view_layer_mask;
+    d.view_layer_mask_hi = view->view_layer_mask_hi;
     d.n_clusters = (uint32_t)C;
     memcpy(d.cluster_factors, view->cluster_factors, sizeof d.cluster_factors);
     memcpy(d.view_from_world, view->view_from_world, sizeof d.view_from_world);
@@ -248,6 +264,7 @@ int32_t cluster_objects(mi_ctx* ctx, bool derive, ClusterObjects* po) {
     o.pos_range = (const float*)ctx->cl_pos.p;
     o.obj_type = ctx->cl_have_type ? (const uint8_t*)ctx->cl_type.p : nullptr;
     o.layer_mask = ctx->cl_have_layers ? (const uint32_t*)ctx->cl_layers.p : nullptr;
+    o.layer_mask_hi = ctx->cl_have_layers_hi ? (const uint32_t*)ctx->cl_layers_hi.p : nullptr;
     o.spot_dir = ctx->cl_have_spot_dir ? (const float*)ctx->cl_dir.p : nullptr;
     if (ctx->cl_any_spot && !o.spot_dir && !ctx->cl_rows_bound)
         return fail(ctx, MI_ERR_INVALID_ARG, "spot lights need spot_dir unless the objects are bound to rows (mi_cluster_bind_objects_to_rows)");

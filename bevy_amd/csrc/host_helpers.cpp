@@ -259,6 +259,7 @@ int32_t mi_cluster_view_build(const float camera_affine[12], const float clip_fr
     out->screen_size[0] = sw; out->screen_size[1] = sh;
     out->is_orthographic = ortho ? 1u : 0u;
     out->view_layer_mask = view_layer_mask;
+    out->view_layer_mask_hi = 0u;  // (layers 32..63: the caller's to set)
     out->near_ = first_slice_depth;
     out->far_ = far_z;
     store_m4(view_from_world, out->view_from_world);

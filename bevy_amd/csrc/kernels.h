@@ -488,12 +488,14 @@ struct ClusterViewDev {
     const float* y_planes;
     const float* z_planes;
     const float* cluster_spheres;
+    uint32_t view_layer_mask_hi;  // RenderLayers 32..63 of the view
 };
 struct ClusterObjects {
     uint32_t n;
     const float* pos_range;      // 4n
     const uint8_t* obj_type;     // n or nullptr
     const uint32_t* layer_mask;  // n or nullptr
+    const uint32_t* layer_mask_hi;  // n or nullptr: RenderLayers 32..63
     const float* spot_dir;       // 3n or nullptr
     const float* spot_sin_cos;   // 2n or nullptr
     // mi_cluster_bind_objects_to_rows: object i is row first_row + i of the context's columns.  It takes part only if its

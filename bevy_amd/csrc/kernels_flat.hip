@@ -174,8 +174,8 @@ __device__ __forceinline__ void inrow_cluster_walk(const ClusterWalkJob& walk, u
     bool in_view = false;
     if (is_obj) {
         sphere.w = o.pos_range[4u * obj + 3u];
-        const uint32_t layers = o.layer_mask ? o.layer_mask[obj] : 1u;
-        if (visible && (walk.view.view_layer_mask & layers)) {
+        const uint32_t layers = o.layer_mask ? o.layer_mask[obj] : 1u, layers_hi = o.layer_mask_hi ? o.layer_mask_hi[obj] : 0u;
+        if (visible && ((walk.view.view_layer_mask & layers) | (walk.view.view_layer_mask_hi & layers_hi))) {
             V4 fr[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) fr[i] = V4{walk.view.frustum[4 * i], walk.view.frustum[4 * i + 1], walk.view.frustum[4 * i + 2], walk.view.frustum[4 * i + 3]};

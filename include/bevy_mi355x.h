@@ -389,6 +389,9 @@ typedef struct mi_cluster_view {
      * dims[0]*dims[1]*dims[2] x (cx,cy,cz,r), index (y*dims[0]+x)*dims[2]+z.  Only read for spot lights;
      * may be NULL when there are none. */
     const float* cluster_spheres;
+    /* RenderLayers 32..63 of the view (with view_layer_mask the first u64 word of the reference's bitset, render_layers.rs:121-135);
+     * matched against mi_cluster_upload_object_layers_hi's column.  mi_cluster_view_build leaves 0. */
+    uint32_t view_layer_mask_hi;
 } mi_cluster_view;
 
 /* Host helper (pure host code): fills *out from the camera's GlobalTransform, clip_from_view, Frustum,
@@ -483,6 +486,9 @@ int32_t mi_cluster_assign(mi_ctx* ctx, const mi_cluster_view* view, uint32_t n_o
 /* Device-resident variant for steady-state frames: objects are uploaded once and re-assigned per frame. */
 int32_t mi_cluster_upload_objects(mi_ctx* ctx, uint32_t n_objects, const float* pos_range, const uint8_t* obj_type,
                                   const uint32_t* layer_mask, const float* spot_dir, const float* spot_sin_cos);
+/* RenderLayers 32..63 of the uploaded objects (n_objects as in the last mi_cluster_upload_objects, which clears this column again;
+ * NULL clears it too).  Objects on layers >= 64 stay with the stock system. */
+int32_t mi_cluster_upload_object_layers_hi(mi_ctx* ctx, uint32_t n_objects, const uint32_t* layer_mask_hi);
 int32_t mi_cluster_upload_view(mi_ctx* ctx, const mi_cluster_view* view);
 /* Lights that are rows of this context (they have a Transform, a bounding Sphere and a ViewVisibility like every other
  * entity: update_point_light_bounding_spheres, crates/bevy_light/src/point_light.rs:195-208): object i of the uploaded

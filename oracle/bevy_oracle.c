@@ -966,6 +966,7 @@ void orc_cluster_view_setup(const float camera_affine[12], const float clip_from
     out->screen_size[0] = sw; out->screen_size[1] = sh;
     out->is_orthographic = (uint32_t)ortho;
     out->view_layer_mask = view_layer_mask;
+    out->view_layer_mask_hi = 0u; /* (layers 32..63: the caller sets it) */
     out->near_ = first_slice_depth;
     out->far_ = far_z;
     m4_store(&view_from_world, out->view_from_world);
@@ -1165,7 +1166,7 @@ typedef void (*emit_fn)(void* ctx, uint32_t cluster_index, uint32_t object, uint
 /* Per-object body of the loop at assign.rs:487-804; calls emit in exactly the push order. */
 static void assign_one_object(const orc_cluster_view* view, const m4* view_from_world, const m4* clip_from_view,
                               v4 view_from_world_row_2, float* cluster_spheres, uint8_t* cluster_sphere_valid,
-                              uint32_t obj, v3 center, float range, uint32_t type, uint32_t layer_mask,
+                              uint32_t obj, v3 center, float range, uint32_t type, uint64_t layer_mask,
                               const float* spot_dir, const float* spot_sin_cos, float* farthest_z,
                               emit_fn emit, void* ectx) {
     const uint32_t* dims = view->dims;
@@ -1173,7 +1174,8 @@ static void assign_one_object(const orc_cluster_view* view, const m4* view_from_
     v3 vfw_scale = V3(view->view_from_world_scale[0], view->view_from_world_scale[1], view->view_from_world_scale[2]);
     float scale_max = view->view_from_world_scale_max;
 
-    if (!(view->view_layer_mask & layer_mask)) return;                         /* :489 */
+    /* :489 RenderLayers::intersects over the first u64 word of the bitset (render_layers.rs:121-135) */
+    if (!((((uint64_t)view->view_layer_mask_hi << 32) | view->view_layer_mask) & layer_mask)) return;
     if (!frustum_intersects_sphere(view->frustum, center, range, 1)) return;   /* :496 */
 
     v3 amin, amax;
@@ -1283,6 +1285,16 @@ uint64_t orc_assign_objects_to_clusters(const orc_cluster_view* view, uint32_t n
                                         const float* spot_dir, const float* spot_sin_cos, uint32_t* offsets,
                                         uint32_t* indices, uint64_t capacity, uint32_t* counts,
                                         float* farthest_z_out) {
+    return orc_assign_objects_to_clusters_layers64(view, n_objects, pos_range, obj_type, obj_layer_mask, NULL, spot_dir, spot_sin_cos, offsets,
+                                                   indices, capacity, counts, farthest_z_out);
+}
+
+#define ORC_OBJ_LAYERS(i) ((uint64_t)(obj_layer_mask ? obj_layer_mask[i] : 1u) | ((uint64_t)(obj_layer_mask_hi ? obj_layer_mask_hi[i] : 0u) << 32))
+uint64_t orc_assign_objects_to_clusters_layers64(const orc_cluster_view* view, uint32_t n_objects, const float* pos_range,
+                                                 const uint8_t* obj_type, const uint32_t* obj_layer_mask, const uint32_t* obj_layer_mask_hi,
+                                                 const float* spot_dir, const float* spot_sin_cos, uint32_t* offsets,
+                                                 uint32_t* indices, uint64_t capacity, uint32_t* counts,
+                                                 float* farthest_z_out) {
     uint32_t C = view->dims[0] * view->dims[1] * view->dims[2];
     m4 view_from_world = m4_load(view->view_from_world);
     m4 clip_from_view = m4_load(view->clip_from_view);
@@ -1297,7 +1309,7 @@ uint64_t orc_assign_objects_to_clusters(const orc_cluster_view* view, uint32_t n
         v3 center = V3(pos_range[4 * (size_t)i], pos_range[4 * (size_t)i + 1], pos_range[4 * (size_t)i + 2]);
         assign_one_object(view, &view_from_world, &clip_from_view, row2, spheres, valid, i, center,
                           pos_range[4 * (size_t)i + 3], obj_type ? obj_type[i] : ORC_OBJ_POINT_LIGHT,
-                          obj_layer_mask ? obj_layer_mask[i] : 1u, spot_dir ? spot_dir + 3 * (size_t)i : NULL,
+                          ORC_OBJ_LAYERS(i), spot_dir ? spot_dir + 3 * (size_t)i : NULL,
                           spot_sin_cos ? spot_sin_cos + 2 * (size_t)i : NULL, &farthest, emit_count, &cc);
     }
     offsets[0] = 0;
@@ -1311,7 +1323,7 @@ uint64_t orc_assign_objects_to_clusters(const orc_cluster_view* view, uint32_t n
             v3 center = V3(pos_range[4 * (size_t)i], pos_range[4 * (size_t)i + 1], pos_range[4 * (size_t)i + 2]);
             assign_one_object(view, &view_from_world, &clip_from_view, row2, spheres, valid, i, center,
                               pos_range[4 * (size_t)i + 3], obj_type ? obj_type[i] : ORC_OBJ_POINT_LIGHT,
-                              obj_layer_mask ? obj_layer_mask[i] : 1u, spot_dir ? spot_dir + 3 * (size_t)i : NULL,
+                              ORC_OBJ_LAYERS(i), spot_dir ? spot_dir + 3 * (size_t)i : NULL,
                               spot_sin_cos ? spot_sin_cos + 2 * (size_t)i : NULL, &dummy, emit_fill, &fc);
         }
         free(cursor);

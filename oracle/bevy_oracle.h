@@ -240,6 +240,7 @@ typedef struct orc_cluster_view {
     float x_planes[(ORC_MAX_CLUSTER_DIM + 1) * 4];
     float y_planes[(ORC_MAX_CLUSTER_DIM + 1) * 4];
     float z_planes[(ORC_MAX_CLUSTER_DIM + 1) * 4];
+    uint32_t view_layer_mask_hi; /* layers 32..63 of the view's RenderLayers (orc_cluster_view_setup leaves 0) */
 } orc_cluster_view;
 
 /* ClusterConfig::dimensions_for_screen_size (FixedZ), crates/bevy_light/src/cluster/mod.rs:311-347 */
@@ -299,6 +300,13 @@ uint64_t orc_assign_objects_to_clusters(const orc_cluster_view* view, uint32_t n
                                         const float* spot_sin_cos /*2n or NULL*/,
                                         uint32_t* offsets, uint32_t* indices, uint64_t capacity,
                                         uint32_t* counts, float* farthest_z_out);
+/* The same with RenderLayers 32..63 of the objects (obj_layer_mask_hi, NULL = none) against view->view_layer_mask_hi:
+ * RenderLayers::intersects over the first u64 word of the bitset (crates/bevy_camera/src/visibility/render_layers.rs:121-135). */
+uint64_t orc_assign_objects_to_clusters_layers64(const orc_cluster_view* view, uint32_t n_objects, const float* pos_range,
+                                                 const uint8_t* obj_type, const uint32_t* obj_layer_mask,
+                                                 const uint32_t* obj_layer_mask_hi, const float* spot_dir,
+                                                 const float* spot_sin_cos, uint32_t* offsets, uint32_t* indices,
+                                                 uint64_t capacity, uint32_t* counts, float* farthest_z_out);
 
 /* The GPU wire format of one view's clusters, storage-buffer flavour: extract_clusters_for_cpu_clustering +
  * prepare_clusters_for_cpu_clustering, crates/bevy_pbr/src/cluster/mod.rs:394-476,478-582, push_offset_and_counts

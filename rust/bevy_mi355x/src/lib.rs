@@ -166,6 +166,7 @@ struct Scratch {
     obj_pos_range: Vec<f32>,
     obj_type: Vec<u8>,
     obj_layers: Vec<u32>,
+    obj_layers_hi: Vec<u32>, // RenderLayers 32..63 of the fused frame's cluster objects (mi_cluster_upload_object_layers_hi)
     obj_spot_dir: Vec<f32>,
     obj_spot_sin_cos: Vec<f32>,
     obj_shadows: Vec<u8>,
@@ -1183,7 +1184,7 @@ pub fn mi_fused_frame(
     let mut views: Vec<ffi::MiView> = Vec::new();
     let mut frame_views: Vec<FrameView> = Vec::new();
     // every camera with Clusters (assign.rs:324-486 runs per view): (entity, GlobalTransform, frustum, viewport, config, layers, clip_from_view)
-    let mut cluster_cameras: Vec<(Entity, GlobalTransform, [f32; 24], UVec2, ClusterConfig, u32, [f32; 16])> = Vec::new();
+    let mut cluster_cameras: Vec<(Entity, GlobalTransform, [f32; 24], UVec2, ClusterConfig, (u32, u32), [f32; 16])> = Vec::new();
     let mut clustered_cameras = 0;
     let result: Result<(), ()> = (|| {
         for (entity, camera, projection, layers, no_cpu_culling, config, has_clusters) in cameras.iter() {
@@ -1200,9 +1201,6 @@ pub fn mi_fused_frame(
                 None => (1, 0),
                 Some(l) => layer_words(l).ok_or(())?,
             };
-            if has_clusters && layer_mask_hi != 0 {
-                return Err(()); // cluster objects carry one 32-bit layer word: a clustered camera above layer 31 stays with the stock systems
-            }
             views.push(ffi::MiView {
                 frustum: planes,
                 layer_mask,
@@ -1217,7 +1215,7 @@ pub fn mi_fused_frame(
                 clustered_cameras += 1;
                 if let Some(size) = camera.physical_viewport_size() {
                     let clip = bevy_camera::CameraProjection::get_clip_from_view(projection).to_cols_array();
-                    cluster_cameras.push((entity, global, planes, size, config.copied().unwrap_or_default(), layer_mask, clip));
+                    cluster_cameras.push((entity, global, planes, size, config.copied().unwrap_or_default(), (layer_mask, layer_mask_hi), clip));
                 }
             }
         }
@@ -1282,6 +1280,7 @@ pub fn mi_fused_frame(
                 let s = &mut mi.scratch;
                 s.obj_pos_range.clear();
                 s.obj_layers.clear();
+                s.obj_layers_hi.clear();
                 s.obj_type.clear();
                 s.obj_spot_sin_cos.clear();
                 s.rows.clear();
@@ -1290,10 +1289,13 @@ pub fn mi_fused_frame(
                     let Some(&row) = mi.entity_row.get(&e) else { return Ok(()) };
                     s.obj_pos_range.extend_from_slice(&[0.0, 0.0, 0.0, range]); // the centre is the row's GlobalTransform
                     s.obj_type.push(kind as u8);
-                    s.obj_layers.push(match layers {
-                        None => 1,
-                        Some(l) => layer_word(l).ok_or(())?,
-                    });
+                    // the first u64 word of the bitset, as for rows and views (render_layers.rs:121-135); a light above layer 63: stock systems
+                    let (lo, hi) = match layers {
+                        None => (1, 0),
+                        Some(l) => layer_words(l).ok_or(())?,
+                    };
+                    s.obj_layers.push(lo);
+                    s.obj_layers_hi.push(hi);
                     let (sin, cos) = outer_angle.map_or((0.0, 0.0), ops_sin_cos);
                     s.obj_spot_sin_cos.extend_from_slice(&[sin, cos]);
                     s.rows.push(row);
@@ -1330,6 +1332,9 @@ pub fn mi_fused_frame(
                             s.obj_spot_sin_cos.as_ptr(),
                         ),
                     )?;
+                    if s.obj_layers_hi.iter().any(|&w| w != 0) {
+                        check(ctx, "mi_cluster_upload_object_layers_hi", ffi::mi_cluster_upload_object_layers_hi(ctx, n_obj, s.obj_layers_hi.as_ptr()))?;
+                    }
                     check(ctx, "mi_cluster_bind_objects_to_row_list", ffi::mi_cluster_bind_objects_to_row_list(ctx, n_obj, s.rows.as_ptr()))?;
                 }
                 // the views: slot k for the k-th clustered camera; every one is resolved against its own history and uploaded now
@@ -1373,12 +1378,13 @@ pub fn mi_fused_frame(
                                 resolved.requested_dims.as_ptr(),
                                 resolved.first_slice_depth,
                                 resolved.far_z,
-                                *layer_mask,
+                                layer_mask.0,
                                 mi.plane_storage.as_mut_ptr(),
                                 if any_spot { mi.sphere_storage.as_mut_ptr() } else { ptr::null_mut() },
                                 &mut view,
                             ),
                         )?;
+                        view.view_layer_mask_hi = layer_mask.1; // (the helper leaves the second word 0)
                         check(ctx, "mi_cluster_select_view", ffi::mi_cluster_select_view(ctx, k as u32))?;
                         check(ctx, "mi_cluster_upload_view", ffi::mi_cluster_upload_view(ctx, &view))?; // (the library copies the tables)
                     }

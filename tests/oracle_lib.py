@@ -63,6 +63,7 @@ class ClusterView(C.Structure):
         ("x_planes", C.c_float * ((MAX_CLUSTER_DIM + 1) * 4)),
         ("y_planes", C.c_float * ((MAX_CLUSTER_DIM + 1) * 4)),
         ("z_planes", C.c_float * ((MAX_CLUSTER_DIM + 1) * 4)),
+        ("view_layer_mask_hi", C.c_uint32),
     ]
 
 
@@ -106,6 +107,7 @@ def lib():
         _lib.orc_bench_flat_frame.restype = C.c_double
         _lib.orc_bench_flat_frame2.restype = C.c_double
         _lib.orc_assign_objects_to_clusters.restype = C.c_uint64
+        _lib.orc_assign_objects_to_clusters_layers64.restype = C.c_uint64
         _lib.orc_visible_entities_sorted.restype = C.c_uint32
     return _lib
 
@@ -396,21 +398,22 @@ def cluster_aabb_sphere(view, x, y, z):
 
 
 def assign_objects_to_clusters(view, pos_range, obj_type=None, layer_mask=None, spot_dir=None, spot_sin_cos=None,
-                               capacity=None):
+                               capacity=None, layer_mask_hi=None):
+    """layer_mask_hi: the objects' RenderLayers 32..63 (matched against view.view_layer_mask_hi)."""
     n = len(pos_range) // 4
     ncl = view.dims[0] * view.dims[1] * view.dims[2]
     offsets = np.zeros(ncl + 1, np.uint32)
     counts = np.zeros(6 * ncl, np.uint32)
     far = C.c_float(0)
     if capacity is None:
-        total = lib().orc_assign_objects_to_clusters(C.byref(view), n, fp(pos_range), u8p(obj_type), u32p(layer_mask),
-                                                     fp(spot_dir), fp(spot_sin_cos), u32p(offsets), None,
-                                                     C.c_uint64(0), u32p(counts), C.byref(far))
+        total = lib().orc_assign_objects_to_clusters_layers64(C.byref(view), n, fp(pos_range), u8p(obj_type), u32p(layer_mask), u32p(layer_mask_hi),
+                                                              fp(spot_dir), fp(spot_sin_cos), u32p(offsets), None,
+                                                              C.c_uint64(0), u32p(counts), C.byref(far))
         capacity = int(total)
     indices = np.zeros(max(capacity, 1), np.uint32)
-    total = lib().orc_assign_objects_to_clusters(C.byref(view), n, fp(pos_range), u8p(obj_type), u32p(layer_mask),
-                                                 fp(spot_dir), fp(spot_sin_cos), u32p(offsets), u32p(indices),
-                                                 C.c_uint64(capacity), u32p(counts), C.byref(far))
+    total = lib().orc_assign_objects_to_clusters_layers64(C.byref(view), n, fp(pos_range), u8p(obj_type), u32p(layer_mask), u32p(layer_mask_hi),
+                                                          fp(spot_dir), fp(spot_sin_cos), u32p(offsets), u32p(indices),
+                                                          C.c_uint64(capacity), u32p(counts), C.byref(far))
     return offsets, indices[:min(int(total), capacity)], counts.reshape(ncl, 6), float(far.value), int(total)
 
 

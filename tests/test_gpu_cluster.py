@@ -334,3 +334,58 @@ def test_sharded_assignment_over_a_one_rank_rccl_group(ctx_factory):
         dist.destroy_process_group()
     assert_same_assignment(got, want)
     assert got[4] > 10_000
+
+
+def test_cluster_objects_on_render_layers_32_to_63(ctx_factory):
+    """RenderLayers::intersects compares the masks word by word (render_layers.rs:121-135): with mi_cluster_upload_object_layers_hi and
+    mi_cluster_view.view_layer_mask_hi the first u64 word is covered for cluster objects as it is for rows and views.  Objects on layer
+    0, on layer 40, on both, on layer 5 only; views on layer 0, on layer 40, on both: the lists equal the oracle's -- through
+    mi_cluster_assign_resident and with the walk riding in the frame kernel (objects bound to rows)."""
+    sc, first_light, pr = W.frame_scene(30_000, 10_000, 3_000, light_range=2.5)
+    n_l = len(pr) // 4
+    rng = np.random.default_rng(21)
+    kind = rng.integers(0, 4, n_l)
+    lo = np.select([kind == 0, kind == 1, kind == 2], [1, 0, 1], default=1 << 5).astype(np.uint32)
+    hi = np.select([kind == 1, kind == 2], [1 << 8, 1 << 8], default=0).astype(np.uint32)  # layer 40 = bit 8 of the second word
+    ctx = ctx_factory()
+    upload_scene(ctx, sc)
+    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+    cam = W.many_cubes_camera(3, yaw=0.4)
+    frusta = frusta_for([cam])
+    n = sc["n"]
+    g, vv, vis, _ = O.full_frame(sc["translation"], sc["rotation"], sc["scale"], sc["aabb_center"], sc["aabb_half"], sc["flags"], sc["layers"],
+                                 np.zeros(n, np.uint8), frusta)
+    keep_l = np.nonzero((vv[first_light:first_light + n_l] & 1) != 0)[0]
+    pr_g = np.asarray(pr, F).reshape(-1, 4)[keep_l].copy()
+    pr_g[:, :3] = g.reshape(-1, 12)[first_light + keep_l, 9:12]
+    seen = set()
+    for view_lo, view_hi in ((1, 0), (0, 1 << 8), (1, 1 << 8), (1 << 5, 1 << 9)):
+        view, keep = api.cluster_view_build(cam, cfv, frusta, 1920, 1080, (16, 9, 24), 5.0, 1000.0, view_layer_mask=view_lo)
+        view.view_layer_mask_hi = view_hi
+        ov = O.cluster_view_setup(cam, cfv, frusta, 1920, 1080, (16, 9, 24), 5.0, 1000.0, view_layer_mask=view_lo)
+        ov.view_layer_mask_hi = view_hi
+        off, idx, counts, far, total = O.assign_objects_to_clusters(ov, pr_g.reshape(-1), None, lo[keep_l].copy(), layer_mask_hi=hi[keep_l].copy())
+        seen.add(int(total))
+        for ride in (False, True):
+            ctx.cluster_upload_objects(pr, None, lo)
+            ctx.cluster_upload_object_layers_hi(hi)
+            ctx.cluster_bind_objects_to_rows(first_light, n_l)
+            ctx.upload_view_visibility(np.zeros(n, np.uint8))
+            ctx.cluster_upload_view(view)
+            if ride:
+                ctx.propagate_and_cull(frusta, flags=B.CULL_END_FRAME | B.CULL_WITH_CLUSTERS)
+            else:
+                ctx.propagate_and_cull(frusta, flags=B.CULL_END_FRAME)
+                ctx.cluster_assign_resident()
+            goff, gidx, gcounts, gfar, gtotal = ctx.cluster_download(view.n_clusters)
+            assert gtotal == total, (view_lo, view_hi, ride, gtotal, total)
+            assert np.array_equal(goff, off) and np.array_equal(gidx, keep_l[idx]), (view_lo, view_hi, ride)  # (object indices: positions in the upload)
+    assert len(seen) == 4  # the four views really see different object sets
+    # a new object upload clears the second word again
+    ctx.cluster_upload_objects(pr, None, lo)
+    view, keep = api.cluster_view_build(cam, cfv, frusta, 1920, 1080, (16, 9, 24), 5.0, 1000.0, view_layer_mask=0)
+    view.view_layer_mask_hi = 1 << 8
+    ctx.cluster_bind_objects_to_rows(first_light, n_l)
+    ctx.cluster_upload_view(view)
+    ctx.cluster_assign_resident()
+    assert ctx.cluster_download(view.n_clusters)[4] == 0

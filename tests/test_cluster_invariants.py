@@ -334,3 +334,24 @@ def test_sort_truncate_matches_the_oracle_and_the_rule():
     assert np.array_equal(api.cluster_sort_truncate(types, shadow, vol, ent, 204, True), np.arange(n))
     assert np.array_equal(api.cluster_sort_truncate(types[:100], shadow[:100], vol[:100], ent[:100], 204, False), np.arange(100))
     assert np.array_equal(O.cluster_sort_truncate(types, shadow, vol, ent, 204, True), np.arange(n))
+
+
+def test_layers_above_31_select_the_same_objects_as_a_filtered_list():
+    """orc_assign_objects_to_clusters_layers64: RenderLayers::intersects over the first u64 word (render_layers.rs:121-135).  The lists
+    over objects with (lo, hi) layer words against a view's two words equal the lists over just the objects that intersect it."""
+    rng = np.random.default_rng(9)
+    n = 1500
+    pos = rng.uniform(-50, 50, size=(n, 3)).astype(F)
+    pr = np.concatenate([pos, rng.uniform(0.5, 15, n).astype(F)[:, None]], axis=1).astype(F)
+    lo = np.where(rng.random(n) < 0.5, 1, 0).astype(np.uint32) | np.where(rng.random(n) < 0.1, 1 << 7, 0).astype(np.uint32)
+    hi = np.where(rng.random(n) < 0.4, 1 << 8, 0).astype(np.uint32) | np.where(rng.random(n) < 0.1, 1 << 31, 0).astype(np.uint32)
+    view = oracle_view(W.many_cubes_camera(0))
+    for vlo, vhi in ((1, 0), (0, 1 << 8), (1 << 7, 1 << 31), (0, 0)):
+        view.view_layer_mask, view.view_layer_mask_hi = vlo, vhi
+        off, idx, counts, far, total = O.assign_objects_to_clusters(view, pr.reshape(-1), None, lo, layer_mask_hi=hi)
+        sel = np.nonzero((lo & np.uint32(vlo)) | (hi & np.uint32(vhi)))[0]
+        view.view_layer_mask, view.view_layer_mask_hi = 1, 0
+        off2, idx2, counts2, far2, total2 = O.assign_objects_to_clusters(view, pr[sel].reshape(-1).copy())
+        assert total == total2 and np.array_equal(off, off2) and np.array_equal(idx, sel[idx2].astype(np.uint32)), (vlo, vhi)
+        if vlo == 0 and vhi == 0:
+            assert total == 0

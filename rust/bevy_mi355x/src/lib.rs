@@ -1156,9 +1156,12 @@ pub fn mi_fused_frame(
     point_lights: Query<(Entity, &PointLight, Option<&RenderLayers>)>,
     spot_lights: Query<(Entity, &SpotLight, Option<&RenderLayers>)>,
     rect_lights: Query<(Entity, &RectLight, Option<&RenderLayers>)>,
-    // light probes and decals take their range from the GlobalTransform this very frame computes (assign.rs:262, 287): a World
-    // that has any leaves the clusters to `mi_assign_objects_to_clusters`, behind the frame
-    other_clusterables: Query<(), Or<(With<LightProbe>, With<ClusteredDecal>)>>,
+    // light probes and decals take their range from the GlobalTransform this very frame computes (assign.rs:262, 287).  For one
+    // without a parent that is From(Transform), which is known here: such probes and decals ride like the lights, with the range
+    // computed on the host; a parented one leaves the clusters to `mi_assign_objects_to_clusters`, behind the frame.
+    // (With<ViewVisibility>: the reference's queries fetch it, assign.rs:176-178 -- an entity without one is not gathered)
+    light_probes: Query<(Entity, &Transform, Has<EnvironmentMapLight>, Has<ChildOf>), (With<LightProbe>, With<ViewVisibility>)>,
+    decals: Query<(Entity, &Transform, Has<ChildOf>), (With<ClusteredDecal>, With<ViewVisibility>)>,
     settings: Option<Res<GlobalClusterSettings>>,
 ) {
     frame.valid = false;
@@ -1262,7 +1265,7 @@ pub fn mi_fused_frame(
     //      of the frame -- the device takes a light's centre (and a spot light's direction) from its row's GlobalTransform and leaves
     //      out the ones whose ViewVisibility::get() is false.  The first clustered camera's walk rides in the frame kernel; every
     //      further one (split screen) is assigned behind the frame through a view slot of its own (mi_cluster_select_view).  Not with
-    //      the UBO limit (sort / truncate, assign.rs:297-321), GPU clustering, or light probes / decals in the World.
+    //      the UBO limit (sort / truncate, assign.rs:297-321), GPU clustering, or a light probe / decal that has a parent.
     let mut with_clusters = false;
     let mut cluster_objects: Vec<(Entity, u8)> = Vec::new();
     let mut cluster_views: Vec<ffi::MiClusterView> = Vec::new();
@@ -1273,7 +1276,8 @@ pub fn mi_fused_frame(
             && cluster_cameras.len() <= ffi::MI_CLUSTER_MAX_VIEWS as usize
             && settings.supports_storage_buffers
             && settings.gpu_clustering.is_none()
-            && other_clusterables.is_empty()
+            && !light_probes.iter().any(|q| q.3)
+            && !decals.iter().any(|q| q.2)
             && !fallback.clusters
         {
             let r = (|| -> Result<(), ()> {
@@ -1312,6 +1316,18 @@ pub fn mi_fused_frame(
                 // (rect lights are gathered only where they are clustered at all, assign.rs:231-248: storage buffers, checked above)
                 for (e, light, layers) in rect_lights.iter() {
                     push(s, e, light.range, ffi::MI_OBJ_RECT_LIGHT, layers, None)?;
+                }
+                // light probes (same gate, assign.rs:250-277) and decals (their own, :279-296), RenderLayers::default() both: the range is
+                // `radius_vec3a(Vec3A::ONE)` / `scale().length()` of the GlobalTransform this frame gives them -- From(Transform) for an
+                // entity without a parent (checked above), formed here with the same glam calls the reference makes
+                for (e, t, is_reflection_probe, _) in light_probes.iter() {
+                    let kind = if is_reflection_probe { ffi::MI_OBJ_REFLECTION_PROBE } else { ffi::MI_OBJ_IRRADIANCE_VOLUME };
+                    push(s, e, GlobalTransform::from(*t).radius_vec3a(bevy_math::Vec3A::ONE), kind, None, None)?;
+                }
+                if settings.clustered_decals_are_usable {
+                    for (e, t, _) in decals.iter() {
+                        push(s, e, GlobalTransform::from(*t).scale().length(), ffi::MI_OBJ_DECAL, None, None)?;
+                    }
                 }
                 if cluster_objects.is_empty() {
                     return Err(());
@@ -1677,7 +1693,7 @@ pub fn mi_apply_clusters(mi: Res<Mi355x>, mut frame: ResMut<Mi355xFrame>, mut vi
         let mut per_cluster: Vec<ObjectsInClusterCpu> = Vec::with_capacity(n_clusters);
         for c in 0..n_clusters {
             let mut objects = ObjectsInClusterCpu::default();
-            // (a cluster's list is in gather order -- points, spots, rects -- like the reference's pushes: assign.rs:740-800)
+            // (a cluster's list is in gather order -- points, spots, rects, probes, decals -- like the reference's pushes: assign.rs:740-800)
             for &object in &r.indices[r.offsets[c] as usize..r.offsets[c + 1] as usize] {
                 let (entity, kind) = r.objects[object as usize];
                 match kind as i32 {

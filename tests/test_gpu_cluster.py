@@ -121,7 +121,7 @@ def test_lights_as_rows_of_the_frame_context(ctx_factory, spots, mode):
     rng = np.random.default_rng(3)
     types = layers = sincos = None
     if spots:
-        types = np.sort(rng.integers(0, 3, n_l)).astype(np.uint8)   # points, spots, rect lights in gather order
+        types = np.sort(rng.integers(0, 6, n_l)).astype(np.uint8)   # every kind in gather order: points, spots, rect lights, reflection probes, irradiance volumes, decals
         layers = np.where(rng.random(n_l) < 0.1, 2, 1).astype(np.uint32)
         ang = rng.uniform(0.1, 1.2, n_l).astype(F)
         sincos = np.stack([np.sin(ang), np.cos(ang)], axis=1).astype(F).reshape(-1)

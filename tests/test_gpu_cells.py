@@ -322,3 +322,46 @@ def test_ten_million_rows_four_views():
         assert_bits(a[1], b[1], f"frame {frame}: ViewVisibility")
         assert_bits(a[2], b[2], f"frame {frame}: change ticks")
     assert sum(int(m.sum()) for m in out[0][4][0]) > 100_000
+
+
+def test_lists_that_rode_in_the_next_frames_launch_are_that_frames_lists():
+    """MI_CULL_MORE_FRAMES: frame f's lists are not launched behind it, they ride at the head of frame f + 1's k_frame_cells launch.
+    Nothing the API exposes reads them afterwards (every read joins the LATEST frame's), so this test goes behind it: the three list
+    buffers of the rotating sets are captured through mi_device_buffer during three warm frames, two more frames run with nothing read
+    in between, and the buffer frame 6 wrote -- by the riders of frame 7's launch -- is fetched with hipMemcpy and compared with the
+    oracle's lists for frame 6's cameras."""
+    import ctypes as C
+    n = 400_001
+    n_views = 3
+    sc = W.many_cubes(n, radius=160.0, ragged_flags=True)
+    g, _ = O.sync_simple_transforms(sc["translation"], sc["rotation"], sc["scale"])
+    hip = C.CDLL("libamdhip64.so")
+    with api.Context(0) as ctx:
+        setup(ctx, sc)
+        vv = np.zeros(n, np.uint8)
+        ptrs, expected = [], {}
+        for frame in range(8):  # 0 - 2: the sphere column and the order come up; 3 - 5: the buffers are captured; 6, 7: nothing is read
+            ctx.propagate(0)
+            frusta = frusta_for(cams(frame, n_views))
+            ctx.cull(frusta, flags=WHOLE | B.CULL_MORE_FRAMES)
+            vv, vis, chg = oracle_cull(sc, g, vv, frusta)
+            expected[frame] = [np.nonzero(vis[v])[0].astype(np.uint32) for v in range(n_views)]
+            if frame < 3:
+                ctx.synchronize()
+            elif frame < 6:
+                ptrs.append(ctx.device_buffer(3))  # MI_BUF_VISIBLE_ROWS of the set this frame wrote (the call joins: these frames do not ride)
+        builds, frames_over_order = ctx.debug_static_cull_counts()
+        assert builds == 1 and frames_over_order >= 5, (builds, frames_over_order)
+        ctx.synchronize()  # (joins frame 7's lists; frame 6's came out of frame 7's launch)
+        assert len({p for p, _ in ptrs}) == 3, ptrs
+        p, nbytes = ptrs[0]  # the sets rotate by three: frame 6 wrote the set of frame 3
+        stride = nbytes // (4 * n_views)
+        host = np.zeros(nbytes // 4, np.uint32)
+        assert hip.hipMemcpy(C.c_void_p(host.ctypes.data), C.c_void_p(p), C.c_size_t(nbytes), 2) == 0
+        for v in range(n_views):
+            want = expected[6][v]
+            assert want.size > 100 and not np.array_equal(want, expected[3][v][:want.size])  # (the cameras move: not frame 3's leftovers)
+            assert np.array_equal(host[v * stride:v * stride + want.size], want), f"frame 6, view {v}: the riders' list"
+        # and what the API shows is frame 7's
+        for v in range(n_views):
+            assert np.array_equal(ctx.download_visible_entities(v, 0)[1], expected[7][v])

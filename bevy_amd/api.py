@@ -206,7 +206,7 @@ ABI_SYMBOLS = [
 # include/bevy_mi355x_debug.h: instrumentation and test hooks, exported by the same library, not part of the boundary
 DEBUG_SYMBOLS = [
     "mi_timer_begin", "mi_timer_end", "mi_profile_enable", "mi_profile_filter", "mi_profile_sample", "mi_profile_burst", "mi_profile_read",
-    "mi_profile_kernel_name", "mi_debug_set_tile_mode", "mi_debug_tree_trace", "mi_debug_tile_plan", "mi_debug_logf", "mi_debug_set_sphere_path", "mi_debug_set_row_summary", "mi_debug_set_tree_cull", "mi_debug_set_walk_inrow", "mi_debug_set_chunked_frames", "mi_debug_chunked_counts", "mi_debug_set_tile_pretest", "mi_debug_set_sorted_one_wg_limit", "mi_debug_set_static_cull_order", "mi_debug_static_cull_counts",
+    "mi_profile_kernel_name", "mi_debug_set_tile_mode", "mi_debug_tree_trace", "mi_debug_tile_plan", "mi_debug_logf", "mi_debug_set_sphere_path", "mi_debug_set_row_summary", "mi_debug_set_tree_cull", "mi_debug_set_walk_inrow", "mi_debug_set_chunked_frames", "mi_debug_chunked_counts", "mi_debug_set_tile_pretest", "mi_debug_set_sorted_one_wg_limit", "mi_debug_set_static_cull_order", "mi_debug_static_cull_counts", "mi_debug_cluster_download_unjoined",
 ]
 
 
@@ -906,6 +906,15 @@ class Context:
     def debug_set_static_cull_order(self, mode):
         """0 = cull-only frames of a static scene run over the cell order from the second eligible frame on (default), 1 = never, 2 = at once, any row count, 3 = as 2 with the list kernels' runs capped at three (long runs, as beyond 16.7 M rows)."""
         self._ck(self._lib.mi_debug_set_static_cull_order(self._h, int(mode)))
+
+    def debug_cluster_download_unjoined(self, n_clusters, capacity):
+        """(offsets, indices) as the last fill that RAN left them; a pending fill is not launched (test hook)."""
+        offsets = np.zeros(n_clusters + 1, np.uint32)
+        indices = np.zeros(max(capacity, 1), np.uint32)
+        tot = C.c_uint64(0)
+        self._ck(self._lib.mi_debug_cluster_download_unjoined(self._h, _ptr(offsets, C.c_uint32), _ptr(indices, C.c_uint32), C.c_uint64(len(indices)),
+                                                              C.byref(tot)))
+        return offsets, indices[:tot.value]
 
     def debug_static_cull_counts(self):
         """(cell orders built, frames that ran over one)."""

@@ -517,6 +517,22 @@ int32_t mi_cluster_download(mi_ctx* ctx, uint32_t* out_offsets, uint32_t* out_in
     return MI_OK;
 }
 
+// test hook (include/bevy_mi355x_debug.h): the lists of the last fill that ran -- a pending one is NOT launched
+int32_t mi_debug_cluster_download_unjoined(mi_ctx* ctx, uint32_t* out_offsets, uint32_t* out_indices, uint64_t capacity, uint64_t* out_total) {
+    ENTER(ctx);
+    if (!ctx->cl_assigned || !out_offsets) return fail(ctx, MI_ERR_NOT_READY, "mi_debug_cluster_download_unjoined: nothing assigned / out_offsets NULL");
+    const uint32_t C = ctx->cl_view.n_clusters;
+    int32_t rc;
+    if ((rc = download(ctx, out_offsets, ctx->cl_offsets.p, ((size_t)C + 1) * 4))) return rc;
+    const uint64_t total = out_offsets[C];
+    if (out_total) *out_total = total;
+    if (out_indices) {
+        if (total > capacity || total > ctx->cl_indices.bytes / 4) return fail(ctx, MI_ERR_CAPACITY, "cluster index list has %llu entries", (unsigned long long)total);
+        if ((rc = download(ctx, out_indices, ctx->cl_indices.p, (size_t)total * 4))) return rc;
+    }
+    return MI_OK;
+}
+
 int32_t mi_cluster_download_bindings(mi_ctx* ctx, const uint32_t* remap, uint32_t n_remap, uint32_t* out_offsets_and_counts,
                                      uint32_t* out_index_list, uint64_t capacity, uint64_t* out_total) {
     ENTER(ctx);

@@ -79,6 +79,10 @@ int32_t mi_debug_set_sphere_path(mi_ctx* ctx, int32_t mode);
  * mi_debug_static_cull_counts: orders built / frames that ran over one (tests). */
 int32_t mi_debug_set_static_cull_order(mi_ctx* ctx, int32_t mode);
 int32_t mi_debug_static_cull_counts(mi_ctx* ctx, uint32_t* out_builds, uint32_t* out_frames);
+/* The cluster lists as the LAST FILL THAT RAN left them, without launching a pending one (mi_cluster_download would: with
+ * MI_CULL_MORE_FRAMES frame f's fill rides in frame f + 1's launch and frame f + 1's own is still pending after it).  For the
+ * test that checks what a riding fill wrote: out_offsets[C + 1], out_indices[capacity]; *out_total = out_offsets[C]. */
+int32_t mi_debug_cluster_download_unjoined(mi_ctx* ctx, uint32_t* out_offsets, uint32_t* out_indices, uint64_t capacity, uint64_t* out_total);
 /* The device's restatement of glibc logf (view_z_to_z_slice, crates/bevy_light/src/cluster/assign.rs:1057) over n inputs. */
 int32_t mi_debug_logf(mi_ctx* ctx, const float* in, float* out, uint32_t n);
 

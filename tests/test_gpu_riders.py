@@ -66,3 +66,34 @@ def test_the_compaction_that_rode_in_the_next_frames_kernel(all_dirty):
             assert np.array_equal(host[v * stride:v * stride + want.size], want), f"frame 6, view {v}: the riders' list"
         for v in range(n_views):
             assert np.array_equal(ctx.download_visible_entities(v, 0)[1], expected[7][v])
+
+
+def test_the_cluster_fill_that_rode_in_the_next_frames_kernel():
+    """MI_CULL_WITH_CLUSTERS | MI_CULL_MORE_FRAMES (the metric frame): frame f's walk rides in frame f's launch, its FILL in frame
+    f + 1's.  mi_cluster_download would launch frame f + 1's pending fill first and show that; mi_debug_cluster_download_unjoined
+    shows the lists as the last fill that ran left them -- frame f's, written by riders -- which must be the reference's sequence for
+    frame f's camera."""
+    from test_gpu_cluster import reference_sequence, upload_scene
+    sc, first_light, pr = W.frame_scene(60_000, 30_000, 3_000, light_range=1.5)
+    n_l = len(pr) // 4
+    cfv = api.perspective_clip_from_view(W.CAMERA_FOV, W.CAMERA_ASPECT, W.CAMERA_NEAR)
+    with api.Context(0) as ctx:
+        upload_scene(ctx, sc)
+        ctx.cluster_upload_objects(pr)
+        ctx.cluster_bind_objects_to_rows(first_light, n_l)
+        want = {}
+        for frame in range(4):
+            cam = W.many_cubes_camera(frame * 30, yaw=0.35 * frame)
+            frusta = frusta_for([cam])
+            view, keep = api.cluster_view_build(cam, cfv, frusta, 1920, 1080, (16, 9, 24), 5.0, 1000.0)
+            ctx.upload_view_visibility(np.zeros(sc["n"], np.uint8))
+            ctx.cluster_upload_view(view)
+            ctx.propagate_and_cull(frusta, flags=B.CULL_END_FRAME | B.CULL_MORE_FRAMES | B.CULL_WITH_CLUSTERS)
+            want[frame] = reference_sequence(sc, first_light, pr, frusta, cam)
+        # frame 3's launch carried frame 2's fill; frame 3's own fill is still pending
+        off, idx = ctx.debug_cluster_download_unjoined(view.n_clusters, 1 << 22)
+        eoff, eidx, _, _, etotal, *_ = want[2]
+        assert etotal > 100 and etotal != want[3][4]
+        assert np.array_equal(off, eoff) and np.array_equal(idx, eidx), "frame 2's lists, written by the riders of frame 3's launch"
+        got = ctx.cluster_download(view.n_clusters)  # (launches frame 3's fill)
+        assert np.array_equal(got[0], want[3][0]) and np.array_equal(got[1], want[3][1])

@@ -57,6 +57,18 @@ struct Transform {
 // GlobalTransform(Affine3A), components/global_transform.rs:60 -- cols = Affine3A::to_cols_array()
 struct GlobalTransform {
     float cols[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+    // radius_vec3a(Vec3A::ONE) = (matrix3 * extents).length() (global_transform.rs:252-254): a light probe's range (assign.rs:262)
+    float radius_of_unit_extents() const {
+        const mi::Affine a = mi::load_affine(cols);
+        return mi::length3(mi::mul(a.m, mi::V3{1.0f, 1.0f, 1.0f}));
+    }
+    // scale().length() (global_transform.rs:240-248; the sign of the determinant only flips x's sign, which the square drops):
+    // a clustered decal's range (assign.rs:287)
+    float scale_length() const {
+        const mi::Affine a = mi::load_affine(cols);
+        const float x = mi::length3(a.m.x_axis), y = mi::length3(a.m.y_axis), z = mi::length3(a.m.z_axis);
+        return mi::f_sqrt((x * x + y * y) + z * z);
+    }
     static GlobalTransform from(const Transform& t) {  // global_transform.rs:326-330
         const mi::Affine a = mi::affine_from_srt(mi::V3{t.scale.x, t.scale.y, t.scale.z},
                                                  mi::V4{t.rotation.x, t.rotation.y, t.rotation.z, t.rotation.w},
@@ -154,7 +166,7 @@ class World {
         for (Entity c : kids) despawn(c);
         remove_parent(e);
         Rec& r = rec(e);
-        if (r.point_light_range || r.spot_light || r.rect_light_range) ++lights_version_;
+        if (r.point_light_range || r.spot_light || r.rect_light_range || r.light_probe || r.decal) ++lights_version_;
         r.alive = false;
         moved_[e.index] = 0;
         ++r.generation;
@@ -193,6 +205,7 @@ class World {
     const Transform& transform(Entity e) const { rec(e); return transform_[e.index]; }
     Transform& transform_mut(Entity e) {  // DerefMut bumps the tick
         Rec& r = rec(e);
+        if (r.light_probe || r.decal) ++lights_version_;  // (their cluster range is a function of the Transform: the fused frame's object list goes up again)
         r.transform_changed = true;
         moved_[e.index] = 1;
         touch(e.index);
@@ -222,6 +235,12 @@ class World {
         ++bounds_version_;
     }
     void insert_rect_light(Entity e, float range) { rec(e).rect_light_range = range; ++lights_version_; ++bounds_version_; }  // RectLight { range, .. }
+    // LightProbe (+ EnvironmentMapLight = a reflection probe, else an irradiance volume) and ClusteredDecal: clustered with a range
+    // taken from the entity's GlobalTransform of this very frame (assign.rs:250-296)
+    void insert_light_probe(Entity e, bool is_reflection_probe) { rec(e).light_probe = is_reflection_probe; ++lights_version_; }
+    void insert_clustered_decal(Entity e) { rec(e).decal = true; ++lights_version_; }
+    void set_clustered_decals_are_usable(bool on) { clustered_decals_are_usable = on; ++lights_version_; }
+    bool clustered_decals_are_usable = true;
     // GlobalClusterSettings::supports_storage_buffers: without it rect lights are not gathered at all (assign.rs:231-248)
     void set_supports_storage_buffers(bool on) { supports_storage_buffers = on; ++lights_version_; }
     bool supports_storage_buffers = true;
@@ -314,6 +333,8 @@ class World {
         std::optional<float> point_light_range;
         std::optional<std::pair<float, float>> spot_light;  // (range, outer_angle)
         std::optional<float> rect_light_range;
+        std::optional<bool> light_probe;  // is_reflection_probe
+        bool decal = false;
         std::optional<MeshBinning> binning;
         bool transform_changed = false, added = false, parent_changed = false, orphaned = false;
         bool inherited_changed = false;
@@ -617,7 +638,7 @@ class Mi355xPlugin {
         // ---- the lights: rows like everything else, bound to the cluster stage by row (query order = Entity order here)
         uint32_t n_clusters = 0;
         mi_cluster_view cview{};
-        const bool with_clusters = cam != nullptr && !views.empty() && sync_lights(w);
+        const bool with_clusters = cam != nullptr && !views.empty() && sync_lights(w) && !probes_or_decals_with_parents_;
         if (with_clusters) {
             uint32_t tile[2], dims[3];
             if (mi_cluster_view_dims(cam->screen_width, cam->screen_height, cam->requested_dimensions, tile, dims) != MI_OK)
@@ -829,9 +850,17 @@ class Mi355xPlugin {
             if (w.rec_[e.index].point_light_range && visible(e)) gather(e, *w.rec_[e.index].point_light_range, MI_OBJ_POINT_LIGHT, 0.f);
         for (Entity e : ents)
             if (w.rec_[e.index].spot_light && visible(e)) gather(e, w.rec_[e.index].spot_light->first, MI_OBJ_SPOT_LIGHT, w.rec_[e.index].spot_light->second);
-        if (w.supports_storage_buffers)
+        if (w.supports_storage_buffers) {
             for (Entity e : ents)
                 if (w.rec_[e.index].rect_light_range && visible(e)) gather(e, *w.rec_[e.index].rect_light_range, MI_OBJ_RECT_LIGHT, 0.f);
+            // light probes behind the same gate (assign.rs:250-277), range = transform.radius_vec3a(Vec3A::ONE)
+            for (Entity e : ents)
+                if (w.rec_[e.index].light_probe && visible(e))
+                    gather(e, w.global_[e.index].radius_of_unit_extents(), *w.rec_[e.index].light_probe ? MI_OBJ_REFLECTION_PROBE : MI_OBJ_IRRADIANCE_VOLUME, 0.f);
+        }
+        if (w.clustered_decals_are_usable)  // decals behind their own (assign.rs:279-296), range = transform.scale().length()
+            for (Entity e : ents)
+                if (w.rec_[e.index].decal && visible(e)) gather(e, w.global_[e.index].scale_length(), MI_OBJ_DECAL, 0.f);
         uint32_t tile[2], dims[3];
         if (mi_cluster_view_dims(cam.screen_width, cam.screen_height, cam.requested_dimensions, tile, dims) != MI_OK)
             throw std::runtime_error("mi_cluster_view_dims failed");
@@ -953,9 +982,24 @@ class Mi355xPlugin {
             if (w.rec_[e.index].point_light_range) add(e, *w.rec_[e.index].point_light_range, MI_OBJ_POINT_LIGHT, 0.f);
         for (Entity e : ents)
             if (w.rec_[e.index].spot_light) add(e, w.rec_[e.index].spot_light->first, MI_OBJ_SPOT_LIGHT, w.rec_[e.index].spot_light->second);
-        if (w.supports_storage_buffers)
+        // light probes and decals take their range from the GlobalTransform this frame computes.  Without a parent that is
+        // From(Transform), known before the frame runs: such ones ride like the lights with the range formed here; a World with a
+        // parented one leaves the clusters to the system of its own (probes_or_decals_with_parents_, checked by frame())
+        probes_or_decals_with_parents_ = false;
+        auto range_rider = [&](Entity e, bool probe) {
+            if (w.rec_[e.index].parent) { probes_or_decals_with_parents_ = true; return 0.0f; }
+            const GlobalTransform g = GlobalTransform::from(w.transform_[e.index]);
+            return probe ? g.radius_of_unit_extents() : g.scale_length();
+        };
+        if (w.supports_storage_buffers) {
             for (Entity e : ents)
                 if (w.rec_[e.index].rect_light_range) add(e, *w.rec_[e.index].rect_light_range, MI_OBJ_RECT_LIGHT, 0.f);
+            for (Entity e : ents)
+                if (w.rec_[e.index].light_probe) add(e, range_rider(e, true), *w.rec_[e.index].light_probe ? MI_OBJ_REFLECTION_PROBE : MI_OBJ_IRRADIANCE_VOLUME, 0.f);
+        }
+        if (w.clustered_decals_are_usable)
+            for (Entity e : ents)
+                if (w.rec_[e.index].decal) add(e, range_rider(e, false), MI_OBJ_DECAL, 0.f);
         lights_version_ = w.lights_version_;
         if (light_entities_.empty()) {
             check(mi_cluster_bind_objects_to_row_list(ctx_, 0, nullptr));
@@ -1046,6 +1090,7 @@ class Mi355xPlugin {
     std::vector<mi_view> mviews_;
     std::vector<Entity> light_entities_;
     bool lights_any_spot_ = false;
+    bool probes_or_decals_with_parents_ = false;  // (sync_lights: such a World's clusters are assign_objects_to_clusters' own round trip)
     std::vector<float> sphere_storage_;
     std::vector<uint32_t> row_of_index_;
     uint64_t lights_version_ = 0, seen_visibility_ = 0, seen_bounds_ = 0;

@@ -427,6 +427,76 @@ static void every_kind_of_light_is_clustered() {
     }
 }
 
+// Light probes and clustered decals (assign.rs:250-296): range = transform.radius_vec3a(Vec3A::ONE) / transform.scale().length()
+// of the GlobalTransform of THIS frame, RenderLayers::default(), probes behind supports_storage_buffers and decals behind
+// clustered_decals_are_usable.  In the fused frame an unparented one rides like a light (range from From(Transform), formed before the
+// frame runs); a parented one leaves the frame's clusters to assign_objects_to_clusters.  Both forms must leave the same Clusters --
+// also after a probe was scaled -- and the per-type counts must land in their own slots.
+static Clusters probes_and_decals_frame(bool fused, bool decals_usable, bool parented, bool* rode) {
+    World w;
+    Mi355xPlugin plugin;
+    w.set_clustered_decals_are_usable(decals_usable);
+    uint64_t rng = 0xABCDEFull;
+    auto next = [&rng]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (float)(rng % 20001) / 10000.0f - 1.0f; };
+    Entity parent = w.spawn(Transform::from_xyz(0.5f, -0.25f, -2.0f));
+    std::vector<Entity> probes;
+    for (int i = 0; i < 40; ++i) {
+        Transform t = Transform::from_xyz(12.0f * next(), 7.0f * next(), -8.0f - 30.0f * (0.5f + 0.5f * next()));
+        t.scale = {1.0f + 2.0f * (0.5f + 0.5f * next()), 0.5f + (0.5f + 0.5f * next()), 1.0f + (0.5f + 0.5f * next())};
+        Entity e = w.spawn(t);
+        if (i % 4 == 0) w.insert_point_light(e, 3.0f);
+        else if (i % 4 == 1) { w.insert_light_probe(e, true); probes.push_back(e); }
+        else if (i % 4 == 2) w.insert_light_probe(e, false);
+        else w.insert_clustered_decal(e);
+        if (parented && i == 5) w.add_child(parent, e);
+    }
+    ClusterCamera cam;
+    mi_perspective_clip_from_view(3.14159265f / 4.0f, 16.0f / 9.0f, 0.1f, cam.clip_from_view);
+    mi_compute_frustum(cam.clip_from_view, cam.camera_affine, 1000.0f, cam.frustum);
+    View view;
+    std::memcpy(view.frustum, cam.frustum, sizeof view.frustum);
+    Clusters cl;
+    for (int frame = 0; frame < 2; ++frame) {
+        if (frame == 1) w.transform_mut(probes[1]).scale = {4.0f, 3.0f, 5.0f};  // a bigger probe: its range follows in the same frame
+        if (fused) {
+            Mi355xPlugin::FrameOutput out = plugin.frame(w, {view}, &cam);
+            if (rode) *rode = out.has_clusters;
+            cl = out.has_clusters ? out.clusters : plugin.assign_objects_to_clusters(w, cam);
+        } else {
+            plugin.propagate_transforms(w);
+            plugin.check_visibility(w, {view});
+            cl = plugin.assign_objects_to_clusters(w, cam);
+        }
+    }
+    return cl;
+}
+static void light_probes_and_decals_are_clustered() {
+    for (int parented = 0; parented < 2; ++parented)
+        for (int usable = 1; usable >= 0; --usable) {
+            bool rode = false;
+            const Clusters cl = probes_and_decals_frame(g_fused, usable != 0, parented != 0, &rode);
+            const Clusters other = probes_and_decals_frame(!g_fused, usable != 0, parented != 0, nullptr);
+            if (g_fused) CHECK(rode == (parented == 0), "probes and decals ride in the fused frame unless one has a parent");
+            uint64_t k[6] = {0, 0, 0, 0, 0, 0}, total = 0;
+            bool same = cl.clusterable_objects.size() == other.clusterable_objects.size();
+            for (size_t c = 0; c < cl.clusterable_objects.size(); ++c) {
+                const ObjectsInCluster& o = cl.clusterable_objects[c];
+                total += o.entities.size();
+                uint64_t in_counts = 0;
+                for (int t = 0; t < 6; ++t) { k[t] += o.counts[t]; in_counts += o.counts[t]; }
+                CHECK(in_counts == o.entities.size(), "the per-type counts of a cluster add up to its list");
+                if (same) same = o.entities.size() == other.clusterable_objects[c].entities.size() &&
+                                 std::equal(o.entities.begin(), o.entities.end(), other.clusterable_objects[c].entities.begin()) &&
+                                 std::memcmp(o.counts, other.clusterable_objects[c].counts, sizeof o.counts) == 0;
+            }
+            CHECK(k[0] > 0 && k[3] > 0 && k[4] > 0, "point lights, reflection probes and irradiance volumes reach clusters");
+            CHECK(usable ? k[5] > 0 : k[5] == 0, "decals are gathered only where clustered decals are usable (assign.rs:279-296)");
+            CHECK(k[1] == 0 && k[2] == 0, "no spot or rect lights in this World");
+            CHECK(total == cl.total_index_count, "total_cluster_index_count");
+            CHECK(same && cl.farthest_z == other.farthest_z, "both forms of the boundary leave the same Clusters");
+        }
+}
+
 // crates/bevy_render/src/render_phase/mod.rs:2356-2700 (proptest render_multidrawable_batch_set): random Add / Remove
 // of mock mesh instances (entity 0..32, bin 0..8, distinct input uniform indices), then the invariants -- a bin's
 // instance_count is the number of entities in it, every binned instance appears exactly once with its input uniform
@@ -781,6 +851,7 @@ int main(int argc, char** argv) {
                        {"visible_entities_are_sorted_by_entity", visible_entities_are_sorted_by_entity},
                        {"lights_are_assigned_to_clusters", lights_are_assigned_to_clusters},
                        {"every_kind_of_light_is_clustered", every_kind_of_light_is_clustered},
+                       {"light_probes_and_decals_are_clustered", light_probes_and_decals_are_clustered},
                        {"render_multidrawable_batch_set", render_multidrawable_batch_set},
                        {"both_forms_leave_the_same_world", both_forms_leave_the_same_world},
                        {"big_flat_worlds_agree", big_flat_worlds_agree}};

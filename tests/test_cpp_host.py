@@ -45,7 +45,7 @@ def test_reference_system_tests_against_the_host_layer():
     print(res.stdout)
     failed = [line for line in res.stdout.splitlines() if line.startswith("FAILED") or "EXCEPTION" in line]
     assert res.returncode == 0 and not failed, res.stdout[-3000:] + res.stderr[-1000:]
-    assert "30 tests, 0 failed" in res.stdout  # 16 tests against the three systems (two of them drive both forms themselves), 14 of them again against the fused frame
+    assert "32 tests, 0 failed" in res.stdout  # 17 tests against the three systems (two of them drive both forms themselves), 15 of them again against the fused frame
 
 
 def test_single_process_multi_gpu_driver_compiles():

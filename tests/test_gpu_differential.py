@@ -11,6 +11,7 @@ agree on everything a caller can download after every step; at intervals the ora
     dense uploads in pieces, GlobalTransforms fetched ahead mi_debug_set_chunked_frames(1)  [A: at any row count, mode 2]
     GlobalTransforms written ahead by an indexed window     (the same switch)
     static cull order (k_frame_cells over the cell order)  mi_debug_set_static_cull_order(1) [A: built at once, any row count, mode 2]
+    hierarchies in subtree tiles (k_propagate_fans)        mi_debug_set_tile_mode(1): level by level, on every other seed
 
 The sequences mix: change marks raised from elsewhere, frames repeated before anybody asks for results, results asked at random
 steps, bounds uploads (whole, partial, single rows), RenderLayers above 31, Transform uploads (indexed, ranges),
@@ -121,6 +122,8 @@ def make_ctx(fast, seed=0):
         ctx.debug_set_walk_inrow(1)
         ctx.debug_set_tile_pretest(1)
         ctx.debug_set_tree_cull(1)
+        if seed % 2:  # half of the seeds: the hierarchy swept level by level instead of in subtree tiles
+            ctx.debug_set_tile_mode(1)
     return ctx
 
 

@@ -51,8 +51,8 @@ def build_tree(ctx, args, rank=0, world=1):
         # the marked ancestors' tiles are a superset: counted as the rows below the moved ones only -- a lower bound)
         follows = (tr["n"] // 1024 if moved == "subtree" else len(rows))
         alg = (plan["tiles"] * 200.0 + follows * 141.0) / tr["n"]
-        wl = Workload("tree_" + moved, step, tr["n"], alg, "k_propagate_tiles", config, "nodes/sec through change-driven hierarchy propagate", "nodes/s",
-                      kernels=["k_propagate_tiles", "k_mark_dirty"])
+        wl = Workload("tree_" + moved, step, tr["n"], alg, "k_propagate_fans", config, "nodes/sec through change-driven hierarchy propagate", "nodes/s",
+                      kernels=["k_propagate_fans", "k_mark_dirty"])
         wl.tree = tr
         wl.kernel_name = "k_propagate_fans<false>"
         return wl
@@ -82,8 +82,8 @@ def build_tree(ctx, args, rank=0, world=1):
                   "row_summary": args.row_summary == 0}
         # propagate 141 B per node (above) + cull with G resident: read G 48 + Aabb 24 + flags 1 + layers 4 + vv 1, write vv 1 + masks
         config["bytes_per_node"] = {"tile_launch": 141.0, "cull_launch_G_resident": flat_bytes_per_entity(n_views, False)}
-        wl = Workload("tree_frame", step_frame, tr["n"], 141.0, "k_propagate_tiles", config,
-                      "nodes/sec through hierarchy propagate + cull", "nodes/s", kernels=["k_propagate_tiles", "k_cull", "k_compact_fast"])
+        wl = Workload("tree_frame", step_frame, tr["n"], 141.0, "k_propagate_fans", config,
+                      "nodes/sec through hierarchy propagate + cull", "nodes/s", kernels=["k_propagate_fans", "k_cull", "k_compact_fast"])
         wl.tree = tr
         wl.kernel_name = "k_propagate_fans<true,true>" if fused else "k_propagate_fans<true> + k_frame<0>"
         if fused:  # + read Aabb 24 + flags 1 + layers 4 (summarised: 0.5) + vv 1, write vv 1 + masks
@@ -100,11 +100,12 @@ def build_tree(ctx, args, rank=0, world=1):
                           + (f", sharded by root subtree over {world} GPUs (this rank holds {tr['n']} rows, no collective)" if world > 1 else ""),
               "baseline_config": "BASELINE.json configs[4]", "nodes": n_global, "parallelism": f"root-subtree shard x{world}", "tile_plan": plan}
     # T 40, parent_idx 4, old G 48 (set_if_neq), G 48, changed byte 1
-    # ("k_propagate_tiles" is the library's timer slot for the tile launch: k_propagate_fans for a tree this size)
-    wl = Workload("tree", step, tr["n"], 141.0, "k_propagate_tiles", config, "nodes/sec through hierarchy propagate", "nodes/s",
-                  kernels=["k_propagate_tiles", "k_propagate_stream"])
+    wl = Workload("tree", step, tr["n"], 141.0, "k_propagate_fans", config, "nodes/sec through hierarchy propagate", "nodes/s",
+                  kernels=["k_propagate_fans", "k_propagate_stream"])
     wl.tree = tr
-    # the library's timer slot is called k_propagate_tiles; the kernel rocprofv3 shows for a plan of light tiles is k_propagate_fans
-    wl.kernel_name = "k_propagate_tiles<256>" if args.tile_mode == 1 else "k_propagate_fans<true>"
+    wl.kernel_name = "k_propagate_level<false>" if args.tile_mode == 1 else "k_propagate_fans<true>"
+    if args.tile_mode == 1:  # (the level sweep's launches are timed in their own slot: one per level, the rows of a frame between them)
+        wl.dominant = "k_propagate_stream"
+        wl.rows = tr["n"] / max(1, len(tr["level_offsets"]) - 1)
     wl.global_units = n_global  # every node is owned by exactly one rank (replicated top rows are recomputed, not counted)
     return wl

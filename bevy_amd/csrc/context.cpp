@@ -628,7 +628,7 @@ static int32_t cells_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, 
         lists_out();
         return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
     }
-    // ---- this frame's masks: the frame before's (its k_cells_counts copied them into this set) -- or zero ----
+    // ---- this frame's masks: the frame before's (its k_cells_blocks copied them into this set) -- or zero ----
     const uint64_t bm_words = (uint64_t)n_views * vo.words_per_view;
     const bool chained = ce.chain_ok && ce.chain_mask == (const void*)(vo.bitmask + vo.word_offset) && ce.chain_words == bm_words && ce.chain_views == n_views;
     ce.chain_ok = false;
@@ -2491,7 +2491,7 @@ int32_t mi_profile_read(mi_ctx* ctx, uint32_t* inout_n, uint64_t* launches, doub
 const char* mi_profile_kernel_name(uint32_t k) {
     static const char* names[K_NUM_KERNELS] = {"k_flat_propagate_cull", "k_level0_propagate", "k_cull", "k_vis_begin",
                                                "k_vis_end", "k_compact_count", "k_compact_scan", "k_compact_scatter",
-                                               "k_compact_fast", "k_mark_dirty", "k_propagate_tiles", "k_cluster_walk", "k_cluster_fill",
+                                               "k_compact_fast", "k_mark_dirty", "k_propagate_fans", "k_cluster_walk", "k_cluster_fill",
                                                "k_clear_u32", "k_inherit", "k_batch_hist", "k_batch_plan", "k_batch_emit",
                                                "k_batch_scan", "k_batch_scatter", "k_batch_bounds", "k_batch_sorted", "k_propagate_stream"};
     return k < K_NUM_KERNELS ? names[k] : nullptr;

@@ -137,7 +137,7 @@ struct mi_ctx {
         DevBuf work, work_n;         // the frame's work list (k_cells_test -> k_frame_cells) and its two alternating counters
         uint32_t work_parity = 0;
         DevBuf pass_s, fin_scratch;  // per slot: its row's bits in the masks of the last frame over the order; k_cells_blocks' prefix / totals
-        // the frame that continues the one before: k_cells_counts copied that frame's masks into the set this frame writes
+        // the frame that continues the one before: k_cells_blocks copied that frame's masks into the set this frame writes
         bool chain_ok = false;
         const void* chain_mask = nullptr;
         uint64_t chain_words = 0;

@@ -725,12 +725,12 @@ __device__ __forceinline__ void cells_process(const Columns& c, const ViewSet& v
         if (ns != st) a.o.state[w] = ns;
     }
     // ---- results by row ----
-    // The masks of this frame start out as the masks of the frame before (k_cells_counts copied them over) and pass_s holds what each
+    // The masks of this frame start out as the masks of the frame before (k_cells_blocks copied them over) and pass_s holds what each
     // slot contributed to them: only the bits that CHANGE are touched -- a handful of rows per frame under a camera that turns slowly,
     // none under one that stands still -- instead of one read-modify-write per visible row and view (2 M of them, 42 us, at 10 M rows x 4
     // views; agent-scope atomics run at some 50 G/s however they are spread).  A frame that cannot continue the one before (a.fresh:
     // the first over a new order, another shape) starts from zeroed masks and counts every slot's old contribution as nothing.
-    // (The wave counts are taken from the finished masks by k_cells_counts: added up here with atomics -- a byte per word, 64 words to
+    // (The wave counts are taken from the finished masks by k_cells_blocks / k_cells_lists: added up here with atomics -- a byte per word, 64 words to
     // a cache line -- the rows a view sees, neighbours in row order as well in many scenes, queued up on a dozen lines: 29 of 34 us at
     // 1 M rows x 1 view.)
     const uint32_t pass_prev = a.fresh ? 0u : a.o.pass_s[slot];

@@ -23,7 +23,6 @@ os.makedirs(dst, exist_ok=True)
 ALIAS = {"k_frame_sph<true": "k_flat_propagate_cull", "k_frame_sph<false": "k_cull",  # the world-sphere frame kernel: PARTIAL = the changed-rows frame, else cull only
          "k_frame<1": "k_flat_propagate_cull", "k_frame<2": "k_flat_propagate_cull", "k_frame<0": "k_cull",  # PROP: 1 all rows, 2 changed rows, 0 resident G (any INLINE_VIEWS / WITH_WALK variant)
          "k_frame<true": "k_flat_propagate_cull", "k_frame<false": "k_cull",  # (profiles from before PROP was an int)
-         "k_propagate_fans": "k_propagate_tiles",  # the tile launch of mi_propagate (the library's timer slot keeps the round-1 name)
          "k_propagate_level": "k_propagate_stream",
          "k_frame_cells": "k_cull",  # the frame over the static cull order (its cell test: k_cells_test, its lists: k_cells_blocks / k_cells_lists)
          "k_sorted_walk<512u, 16u, true>": "k_batch_scan", "k_sorted_walk<512, 16, true>": "k_batch_scan",  # the tiles' records

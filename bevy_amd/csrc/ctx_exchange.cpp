@@ -176,7 +176,9 @@ int32_t exchange_begin(mi_ctx* ctx) {
         if (x.grouped && x.group_pending)
             return fail(ctx, MI_ERR_NOT_READY, "MI_EXCHANGE_GROUPED: the previous frame's all-gather was never flushed (mi_exchange_group_flush)");
         // the buffer was last used n_bufs frames ago: its all-gather must have drained before the kernels overwrite it
-        if (x.frame >= x.n_bufs) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, x.ev_gathered[slot], 0));
+        // (asked on the host first: with the buffers rotating that all-gather is normally long done, and a wait packet in the compute
+        // queue costs ~6 us of every frame whether it has anything to wait for or not)
+        if (x.frame >= x.n_bufs && hipEventQuery(x.ev_gathered[slot]) != hipSuccess) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, x.ev_gathered[slot], 0));
         ctx->ext_bitmask = x.buf[slot];
         ctx->ext_words_per_view = x.words_per_view;
         ctx->ext_word_offset = x.word_offset;

@@ -16,6 +16,7 @@ int32_t mi_cluster_upload_object_layers_hi(mi_ctx* ctx, uint32_t n, const uint32
     if ((rc = cluster_join(ctx))) return rc;
     ctx->cl_have_layers_hi = false;
     ctx->cl_assigned = false;
+    for (auto& parked : ctx->cl_parked) parked.assigned = false;  // (every view's assignment was over the old layers)
     if (!layer_mask_hi || n == 0) return MI_OK;
     if ((rc = ensure(ctx, ctx->cl_layers_hi, (size_t)n * 4))) return rc;
     if ((rc = upload(ctx, ctx->cl_layers_hi.p, layer_mask_hi, (size_t)n * 4))) return rc;

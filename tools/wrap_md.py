@@ -59,7 +59,12 @@ def main():
         text = open(path).read()
         new = wrap_text(text, width)
         if "--check" in sys.argv:
-            over = [i + 1 for i, l in enumerate(text.split("\n")) if len(l) > width and not l.lstrip().startswith("|")]
+            over, fence = [], False
+            for i, l in enumerate(text.split("\n")):
+                if l.strip().startswith("```"):
+                    fence = not fence
+                elif not fence and len(l) > width and not l.lstrip().startswith("|") and not l.startswith("    "):
+                    over.append(i + 1)
             if over:
                 bad += 1
                 print(f"{path}: {len(over)} prose lines over {width} columns (first: {over[:5]})")

@@ -159,6 +159,12 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
                     uint32_t k = d;
                     while (k > 1 && (build_tile(s, k, a, b, best), upper_rows(best) > UCAP)) --k;
                     build_tile(s, k, a, b, best);
+                    // ... and not a last level that ONE workgroup would stream for milliseconds (a node with 100 000 children that have
+                    // children): such a level is handed down too, where it is cut into tiles of its own
+                    while (k > 1 && best.n_levels == k && best.count[k - 1] > 16u * LAST_CAP) {
+                        --k;
+                        build_tile(s, k, a, b, best);
+                    }
                     if (best.n_levels == k && k < d) {
                         const uint32_t llo = best.start[k - 1], lhi = llo + best.count[k - 1];
                         const uint32_t clo = child_begin(s + k - 1, llo), chi = child_begin(s + k - 1, lhi);

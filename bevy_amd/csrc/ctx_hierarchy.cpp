@@ -154,14 +154,17 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
             while (a < rhi) {
                 TileDesc best{};
                 uint32_t b = a + 1;
-                if (!build_tile(s, d, a, b, best) && upper_rows(best) > UCAP) {
+                const bool fits = build_tile(s, d, a, b, best);
+                // (a last level ONE workgroup would stream for milliseconds -- a node whose few children have 100 000 children -- is not kept
+                // either: it is handed down and cut into tiles of its own)
+                const bool too_wide = best.n_levels > 1 && best.count[best.n_levels - 1] > 16u * LAST_CAP;
+                if (!fits && (upper_rows(best) > UCAP || too_wide)) {
                     // the row's own subtree does not fit: keep the levels that do, hand the rest down
                     uint32_t k = d;
                     while (k > 1 && (build_tile(s, k, a, b, best), upper_rows(best) > UCAP)) --k;
                     build_tile(s, k, a, b, best);
-                    // ... and not a last level that ONE workgroup would stream for milliseconds (a node with 100 000 children that have
-                    // children): such a level is handed down too, where it is cut into tiles of its own
-                    while (k > 1 && best.n_levels == k && best.count[k - 1] > 16u * LAST_CAP) {
+                    if (best.n_levels < k) k = best.n_levels;
+                    while (k > 1 && best.count[k - 1] > 16u * LAST_CAP) {
                         --k;
                         build_tile(s, k, a, b, best);
                     }

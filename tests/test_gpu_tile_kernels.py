@@ -47,6 +47,7 @@ SHAPES = {
     "skewed": (1, [200, lambda i: 300 if i == 0 else 0, 2]),             # one subtree overflows a tile: cut, the rest handed to a second launch
     "skewed_twice": (3, [4, lambda i: 150 if i == 5 else 2, lambda i: 130 if i % 7 == 0 else 1, lambda i: 3 if i % 2 else 0, 2]),  # ... cut again below
     "one_node_9000_children_with_children": (1, [40, lambda i: 9000 if i == 7 else 1, lambda i: 2 if i % 3 == 0 else 0, 1]),  # a wide level handed down whole
+    "wide_last_level_under_a_small_top": (1, [400, lambda i: 12 if i == 0 else 1, lambda i: 700 if i < 12 else 1]),  # upper rows fit, 8 400 leaves do not
     "heavy_nodes_deep": (1, [2] * 8 + [lambda i: 200 if i % 97 == 0 else 2, 3, lambda i: 140 if i % 1001 == 0 else 1, 2, 2]),  # cuts inside lower bands
     "forest_3000_roots": (3000, [3, 2]),                                 # many roots per tile, level 0 holds most rows
     "flat_rows_and_trees": (5000, [lambda i: 5 if i % 50 == 0 else 0, 6, 3]),  # flat rows share level 0 with the roots

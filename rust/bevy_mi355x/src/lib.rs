@@ -70,7 +70,7 @@ use bevy_ecs::{
     change_detection::Tick,
     entity::{Entity, EntityHashMap},
     prelude::*,
-    schedule::{IntoScheduleConfigs, RemoveSystemsOnly},
+    schedule::{IntoScheduleConfigs, ScheduleCleanupPolicy::RemoveSystemsOnly, ScheduleLabel},
     system::SystemChangeTick,
 };
 use bevy_light::{
@@ -272,9 +272,9 @@ impl Plugin for Mi355xRenderPrepPlugin {
         //     (crates/bevy_transform/src/plugins.rs:22-48).  Every system fn is its own implicit set
         //     (crates/bevy_app/src/app.rs:330-360), which is how they are taken out again.
         for schedule in [PostStartup.intern(), PostUpdate.intern()] {
-            app.remove_systems_in_set(schedule, mark_dirty_trees, RemoveSystemsOnly);
-            app.remove_systems_in_set(schedule, propagate_parent_transforms, RemoveSystemsOnly);
-            app.remove_systems_in_set(schedule, sync_simple_transforms, RemoveSystemsOnly);
+            take_out(app, schedule, mark_dirty_trees);
+            take_out(app, schedule, propagate_parent_transforms);
+            take_out(app, schedule, sync_simple_transforms);
             // PostStartup has no cameras to cull for yet: the propagate-only system either way
             let fused_here = fused && schedule == PostUpdate.intern();
             app.add_systems(
@@ -294,7 +294,7 @@ impl Plugin for Mi355xRenderPrepPlugin {
 
         // --- visibility: `reset_view_visibility` before and `mark_newly_hidden_entities_invisible` after stay registered (they
         //     are private, visibility/mod.rs:529-533); the middle step is replaced.
-        app.remove_systems_in_set(PostUpdate, check_visibility_cpu_culling, RemoveSystemsOnly);
+        take_out(app, PostUpdate, check_visibility_cpu_culling);
         app.add_systems(
             PostUpdate,
             (
@@ -319,6 +319,15 @@ impl Plugin for Mi355xRenderPrepPlugin {
                 .after(VisibilitySystems::CheckVisibility)
                 .after(CameraUpdateSystems),
         );
+    }
+}
+
+/// Takes a stock system out of its schedule, keeping the ordering edges that ran through it (`RemoveSystemsOnly`,
+/// crates/bevy_ecs/src/schedule/schedule.rs:1715-1735).  A system that is not there -- the stock plugin was not added, or was added
+/// after this one -- is said so once: the replacement would otherwise run beside it.
+fn take_out<M>(app: &mut App, schedule: impl ScheduleLabel, system: impl IntoSystemSet<M>) {
+    if let Err(e) = app.remove_systems_in_set(schedule, system, RemoveSystemsOnly) {
+        error!("bevy_mi355x: a stock system could not be taken out of its schedule ({e}); add Mi355xRenderPrepPlugin after DefaultPlugins");
     }
 }
 
@@ -1195,7 +1204,8 @@ pub fn mi_fused_frame(
                 continue;
             }
             let global = expected_global(entity, &transforms).ok_or(())?;
-            let frustum = bevy_camera::CameraProjection::compute_frustum(projection, &global); // = update_frusta, visibility/mod.rs:627-636
+            // (Projection derefs to `dyn CameraProjection`: method syntax, as update_frusta itself calls it, visibility/mod.rs:627-636)
+            let frustum = projection.compute_frustum(&global);
             let mut planes = [0f32; 24];
             for (p, half_space) in frustum.half_spaces.iter().enumerate() {
                 planes[p * 4..p * 4 + 4].copy_from_slice(&half_space.normal_d().to_array());
@@ -1217,7 +1227,7 @@ pub fn mi_fused_frame(
             if has_clusters {
                 clustered_cameras += 1;
                 if let Some(size) = camera.physical_viewport_size() {
-                    let clip = bevy_camera::CameraProjection::get_clip_from_view(projection).to_cols_array();
+                    let clip = projection.get_clip_from_view().to_cols_array();
                     cluster_cameras.push((entity, global, planes, size, config.copied().unwrap_or_default(), (layer_mask, layer_mask_hi), clip));
                 }
             }

@@ -1,0 +1,38 @@
+"""The uncompiled Rust sources against the reference's API names (tools/check_rust_names.py).
+
+No rustc here, so this is the part of `cargo check` grep can do: imported paths, CamelCase identifiers, method names and the traits
+their methods need.  Where the reference checkout exists the whole tool runs; everywhere (GPU box included) the `use` leaves of the
+two files are checked against the committed fixture of names the tool resolved, so an import nobody resolved cannot be added
+unnoticed."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import check_rust_names as crn  # noqa: E402
+
+
+def test_every_bevy_import_is_a_name_the_tool_resolved():
+    known = json.load(open(crn.FIXTURE))
+    for rel in crn.FILES:
+        s = crn.strip(open(os.path.join(ROOT, rel)).read())
+        for u in crn.use_leaves(s):
+            if u and u[0].startswith("bevy") and u[-1] not in ("*", "prelude", "self"):
+                assert "::".join(u) in known, "%s imports %s: run tools/check_rust_names.py where /root/reference exists" % (rel, "::".join(u))
+
+
+def test_fixture_cites_reference_lines():
+    known = json.load(open(crn.FIXTURE))
+    assert len(known) >= 60
+    for name, where in known.items():
+        assert where.startswith("crates/" + name.split("::")[0] + "/src/"), (name, where)
+
+
+@pytest.mark.skipif(not os.path.isdir(crn.REF), reason="no reference checkout on this box")
+def test_names_resolve_against_the_reference_checkout():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_rust_names.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -18,7 +18,7 @@ use bevy_camera::{
         InheritedVisibility, NoCpuCulling, NoFrustumCulling, RenderLayers, ViewVisibility, Visibility, VisibilityClass,
         VisibilityPlugin, VisibleEntities,
     },
-    Camera, CameraProjectionPlugin, PerspectiveProjection, Projection,
+    Camera, CameraProjection, CameraProjectionPlugin, PerspectiveProjection, Projection,
 };
 use bevy_ecs::prelude::*;
 use bevy_light::{

@@ -1102,6 +1102,10 @@ pub struct Mi355xFrame {
     /// One per clustered camera.
     clusters: Vec<FrameClusters>,
 }
+// SAFETY: the only raw pointers in here are the plane / sphere tables of a parked `ffi::MiClusterView`.  They are never read again
+// after `mi_cluster_upload_view` (the library copied the tables); the systems that consume the parked view use its plain fields.
+unsafe impl Send for Mi355xFrame {}
+unsafe impl Sync for Mi355xFrame {}
 struct FrameView {
     entity: Entity,
     frustum: [f32; 24],

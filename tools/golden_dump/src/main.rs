@@ -11,7 +11,8 @@
 //! own image (no Rust toolchain), which is why it is a separate, tiny program and why the test skips when its output is absent.
 use std::{collections::BTreeMap, env, fs};
 
-use bevy_app::{App, PostUpdate};
+use bevy_app::{App, PostUpdate, TaskPoolPlugin};
+use bevy_asset::{AssetApp, AssetPlugin};
 use bevy_camera::{
     primitives::{Aabb, Frustum, Sphere},
     visibility::{
@@ -128,6 +129,24 @@ fn camera_transform(cols: &[f32]) -> Transform {
 
 struct Mesh; // the one visibility class of the dump
 
+/// The stock systems of case 2, set up as the reference's own test sets them up (visibility/mod.rs:1314-1322): `VisibilityPlugin`'s
+/// bounds systems read `Assets<Mesh>`, so the asset server and the mesh assets have to be there.
+fn visibility_app() -> App {
+    let mut app = App::new();
+    app.add_plugins((TaskPoolPlugin::default(), AssetPlugin::default(), bevy_mesh::MeshPlugin));
+    app.add_plugins((TransformPlugin, VisibilityPlugin, CameraProjectionPlugin));
+    app
+}
+
+/// ... and of cases 3 and 4: `LightPlugin::build` also registers an asset type and a system that reads `Assets<Image>`
+/// (crates/bevy_light/src/lib.rs:166-170, atmosphere.rs:549-553).
+fn light_app() -> App {
+    let mut app = visibility_app();
+    app.init_asset::<bevy_image::Image>();
+    app.add_plugins(LightPlugin);
+    app
+}
+
 // flags of include/bevy_mi355x.h
 const INHERITED_VISIBLE: u8 = 0x01;
 const NO_FRUSTUM_CULLING: u8 = 0x02;
@@ -167,8 +186,7 @@ fn main() {
         let (flags, layers, view_masks) = (u8s(&inputs, "flat.flags"), u32s(&inputs, "flat.layers"), u32s(&inputs, "flat.view_masks"));
         let cameras = f32s(&inputs, "flat.cameras");
         let layers_of = |word: u32| RenderLayers::from_layers(&(0..32).filter(|b| word >> b & 1 != 0).collect::<Vec<usize>>());
-        let mut app = App::new();
-        app.add_plugins((TransformPlugin, VisibilityPlugin, CameraProjectionPlugin));
+        let mut app = visibility_app();
         let n = flags.len();
         let entities: Vec<Entity> = (0..n)
             .map(|i| {
@@ -231,8 +249,7 @@ fn main() {
         let (camera, lights) = (f32s(&inputs, "cluster.camera"), f32s(&inputs, "cluster.lights_pos_range"));
         let dims = u32s(&inputs, "cluster.screen_dims_z");
         let z = f32s(&inputs, "cluster.first_slice_depth_far_z");
-        let mut app = App::new();
-        app.add_plugins((TransformPlugin, VisibilityPlugin, CameraProjectionPlugin, LightPlugin));
+        let mut app = light_app();
         app.insert_resource(GlobalClusterSettings {
             supports_storage_buffers: true,
             clustered_decals_are_usable: true,
@@ -298,8 +315,7 @@ fn main() {
         let cameras = f32s(&inputs, "cluster2.cameras");
         let dims = u32s(&inputs, "cluster.screen_dims_z");
         let z = f32s(&inputs, "cluster.first_slice_depth_far_z");
-        let mut app = App::new();
-        app.add_plugins((TransformPlugin, VisibilityPlugin, CameraProjectionPlugin, LightPlugin));
+        let mut app = light_app();
         app.insert_resource(GlobalClusterSettings {
             supports_storage_buffers: true,
             clustered_decals_are_usable: true,

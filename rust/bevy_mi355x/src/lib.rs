@@ -1166,15 +1166,18 @@ pub fn mi_fused_frame(
         (Entity, &InheritedVisibility, Option<&VisibilityClass>, Option<&RenderLayers>, Option<&Aabb>, Option<&Sphere>, Option<&PointLight>, Option<&SpotLight>, Has<NoFrustumCulling>, Has<VisibilityRange>),
         Without<NoCpuCulling>,
     >,
-    point_lights: Query<(Entity, &PointLight, Option<&RenderLayers>)>,
-    spot_lights: Query<(Entity, &SpotLight, Option<&RenderLayers>)>,
-    rect_lights: Query<(Entity, &RectLight, Option<&RenderLayers>)>,
-    // light probes and decals take their range from the GlobalTransform this very frame computes (assign.rs:262, 287).  For one
-    // without a parent that is From(Transform), which is known here: such probes and decals ride like the lights, with the range
-    // computed on the host; a parented one leaves the clusters to `mi_assign_objects_to_clusters`, behind the frame.
-    // (With<ViewVisibility>: the reference's queries fetch it, assign.rs:176-178 -- an entity without one is not gathered)
-    light_probes: Query<(Entity, &Transform, Has<EnvironmentMapLight>, Has<ChildOf>), (With<LightProbe>, With<ViewVisibility>)>,
-    decals: Query<(Entity, &Transform, Has<ChildOf>), (With<ClusteredDecal>, With<ViewVisibility>)>,
+    // (one tuple parameter: a system function takes at most 16 parameters, function_system.rs:950)
+    (point_lights, spot_lights, rect_lights, light_probes, decals): (
+        Query<(Entity, &PointLight, Option<&RenderLayers>)>,
+        Query<(Entity, &SpotLight, Option<&RenderLayers>)>,
+        Query<(Entity, &RectLight, Option<&RenderLayers>)>,
+        // light probes and decals take their range from the GlobalTransform this very frame computes (assign.rs:262, 287).  For one
+        // without a parent that is From(Transform), which is known here: such probes and decals ride like the lights, with the range
+        // computed on the host; a parented one leaves the clusters to `mi_assign_objects_to_clusters`, behind the frame.
+        // (With<ViewVisibility>: the reference's queries fetch it, assign.rs:176-178 -- an entity without one is not gathered)
+        Query<(Entity, &Transform, Has<EnvironmentMapLight>, Has<ChildOf>), (With<LightProbe>, With<ViewVisibility>)>,
+        Query<(Entity, &Transform, Has<ChildOf>), (With<ClusteredDecal>, With<ViewVisibility>)>,
+    ),
     settings: Option<Res<GlobalClusterSettings>>,
 ) {
     frame.valid = false;

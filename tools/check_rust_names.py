@@ -12,7 +12,8 @@ This tool checks what can be checked without a compiler:
   3. every method the file calls with `.name(` exists as `fn name` somewhere in the reference, in the file itself, or in the
      std list below (a weak check: it catches misspelt and renamed methods, not a method called on the wrong type);
   4. the traits whose methods the file calls are in scope (TRAIT_METHODS below: method -> trait that must be imported or come
-     with a prelude).
+     with a prelude);
+  5. no system function has more than 16 parameters.
 
     python tools/check_rust_names.py            # checks against /root/reference, rewrites tests/golden/reference_api_names.json
     python tools/check_rust_names.py --check    # the same, fails if the fixture would change
@@ -179,6 +180,25 @@ def check_file(rel, names, problems):
             continue
         if not grep(r"\bfn\s+" + m + r"\b", REF):
             problems.append("%s: no `fn %s` anywhere in the reference" % (rel, m))
+    # a system function takes at most 16 parameters (all_tuples!(impl_system_function, 0, 16, F), function_system.rs:950)
+    for m in re.finditer(r"\bfn (\w+)(?:<[^>]*>)?\(", s):
+        j, depth, angle, n, cur = m.end(), 1, 0, 0, ""
+        while depth:
+            c = s[j]
+            depth += c in "([{"
+            depth -= c in ")]}"
+            angle += c == "<"
+            angle -= c == ">" and s[j - 1] != "-"
+            if c == "," and depth == 1 and angle == 0:
+                n += bool(cur.strip())
+                cur = ""
+            elif depth >= 1:
+                cur += c
+            j += 1
+        n += bool(cur.strip(" )\n"))
+        params = s[m.end():j]
+        if n > 16 and re.search(r"\b(Query|Res|ResMut|Commands)\b", params):
+            problems.append("%s: system `%s` has %d parameters, the limit is 16 (group some into a tuple)" % (rel, m.group(1), n))
     for m, trait in TRAIT_METHODS.items():
         if m in methods and trait not in imported | globbed:
             problems.append("%s: `.%s()` needs the trait `%s` in scope" % (rel, m, trait))

@@ -613,20 +613,24 @@ static int32_t cells_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, 
     bool prev_has_job = false;
     mi_ctx::Exchange::Job prev_job{};
     const CompactFastArgs* prev = frame_begin(ctx, &prev_args, &prev_has_job, &prev_job) ? &prev_args : nullptr;
+    // A failure BEFORE the frame's launch gives back what the launch was to carry (the deferred lists, the previous frame's compaction
+    // and its all-gather job); one BEHIND it still hands the all-gather job on: the launch that publishes its signal is submitted.
+    auto give_back = [&](int32_t why) {
+        lists_out();
+        return frame_abort(ctx, why, prev, prev_has_job, prev_job);
+    };
+    auto behind_the_launch = [&](int32_t why) {
+        ce.valid = false;
+        if (prev_has_job) exchange_push(ctx, prev_job);
+        return why;
+    };
     int32_t rc = exchange_begin(ctx);
-    if (rc || (rc = prepare_views(ctx, views, n_views, &vo))) {
-        lists_out();
-        return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
-    }
+    if (rc || (rc = prepare_views(ctx, views, n_views, &vo))) return give_back(rc);
     SegOut seg;
-    if ((rc = prepare_segments(ctx, n_views, &seg))) {
-        lists_out();
-        return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
-    }
+    if ((rc = prepare_segments(ctx, n_views, &seg))) return give_back(rc);
     if (build && (rc = cells_build(ctx))) {
         ce.valid = false;
-        lists_out();
-        return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
+        return give_back(rc);
     }
     // ---- this frame's masks: the frame before's (its k_cells_blocks copied them into this set) -- or zero ----
     const uint64_t bm_words = (uint64_t)n_views * vo.words_per_view;
@@ -637,11 +641,10 @@ static int32_t cells_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, 
             // counts never ran): start over on a fresh order
             if ((rc = cells_build(ctx))) {
                 ce.valid = false;
-                lists_out();
-                return frame_abort(ctx, rc, prev, prev_has_job, prev_job);
+                return give_back(rc);
             }
         }
-        HIP_TRY(ctx, hipMemsetAsync(vo.bitmask + vo.word_offset, 0, bm_words * 8, ctx->stream));
+        if ((rc = hip_rc(ctx, hipMemsetAsync(vo.bitmask + vo.word_offset, 0, bm_words * 8, ctx->stream), "zeroing the frame's masks"))) return give_back(rc);
     }
     // the ViewVisibility change ticks are ORed into a zeroed buffer: two alternate, each launch zeroes the other one (as in the fused
     // hierarchy frame, atomic_frame_sets)
@@ -649,11 +652,12 @@ static int32_t cells_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, 
     {
         const size_t vv_bytes = padded_words(ctx->cap) * 8 + 256;
         if (!ctx->vv_chg_alt) {
-            HIP_TRY(ctx, hipMalloc((void**)&ctx->vv_chg_alt, vv_bytes));
+            if ((rc = hip_rc(ctx, hipMalloc((void**)&ctx->vv_chg_alt, vv_bytes), "the second ViewVisibility change mask"))) return give_back(rc);
             ctx->vv_alt_zeroed = false;
         }
         if (ctx->vv_alt_zeroed) std::swap(ctx->vv_chg_bits, ctx->vv_chg_alt);
-        else HIP_TRY(ctx, hipMemsetAsync(ctx->vv_chg_bits, 0, padded_words(ctx->cap) * 8, ctx->stream));
+        else if ((rc = hip_rc(ctx, hipMemsetAsync(ctx->vv_chg_bits, 0, padded_words(ctx->cap) * 8, ctx->stream), "zeroing the ViewVisibility change mask")))
+            return give_back(rc);
         ctx->vv_alt_zeroed = false;
         cz.zero[2] = ctx->vv_chg_alt;
         cz.zero_words[2] = (uint32_t)padded_words(ctx->cap);
@@ -695,28 +699,19 @@ static int32_t cells_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, 
     {
         const uint32_t nx = (ctx->cur + 1u) % mi_ctx::N_FB;
         const size_t segs = (size_t)n_views * ctx->compact_classes;  // (one class segment per view: no class masks on this path)
-        if ((rc = ensure(ctx, ctx->fb[nx].bitmask, bm_words * 8)) || (rc = ensure(ctx, ctx->fb[ctx->cur].seg_totals, segs * 4))) {
-            ce.valid = false;
-            return rc;
-        }
+        if ((rc = ensure(ctx, ctx->fb[nx].bitmask, bm_words * 8)) || (rc = ensure(ctx, ctx->fb[ctx->cur].seg_totals, segs * 4))) return behind_the_launch(rc);
         CellsFinishArgs fin{};
         fin.out = vo;
         fin.n_words = (uint32_t)words64(ctx->n);
         fin.n_blks = (fin.n_words + 63u) / 64u;
-        if ((rc = ensure(ctx, ce.fin_scratch, ((size_t)n_views * fin.n_blks + (size_t)n_views * CELLS_FIN_GROUPS) * 4))) {
-            ce.valid = false;
-            return rc;
-        }
+        if ((rc = ensure(ctx, ce.fin_scratch, ((size_t)n_views * fin.n_blks + (size_t)n_views * CELLS_FIN_GROUPS) * 4))) return behind_the_launch(rc);
         fin.blk_pre = (uint32_t*)ce.fin_scratch.p;
         fin.grp_tot = fin.blk_pre + (size_t)n_views * fin.n_blks;
         fin.copy_to = (uint64_t*)ctx->fb[nx].bitmask.p;
         fin.copy_words_per_view = vo.words_per_view;
         if (ctx->compact_fast) {  // rows are numbered in Entity-key order: the lists come out of this launch (nothing is deferred)
             ctx->seg_stride = ctx->cap;
-            if ((rc = ensure(ctx, ctx->fb[ctx->cur].out_rows, segs * ctx->seg_stride * 4))) {
-                ce.valid = false;
-                return rc;
-            }
+            if ((rc = ensure(ctx, ctx->fb[ctx->cur].out_rows, segs * ctx->seg_stride * 4))) return behind_the_launch(rc);
             fin.out_rows = (uint32_t*)ctx->fb[ctx->cur].out_rows.p;
             fin.seg_stride = ctx->seg_stride;
             fin.seg_totals = (uint32_t*)ctx->fb[ctx->cur].seg_totals.p;
@@ -725,7 +720,8 @@ static int32_t cells_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, 
         // another frame follows at once: the lists ride in ITS launch (or cells_lists_join's); the block prefixes and the next frame's
         // starting masks are wanted either way
         const bool defer_lists = (flags & MI_CULL_MORE_FRAMES) && fin.out_rows != nullptr;
-        HIP_TRY(ctx, launch_cells_finish(fin, n_views, !defer_lists, ctx->stream, prof_mark, ctx));
+        if ((rc = hip_rc(ctx, launch_cells_finish(fin, n_views, !defer_lists, ctx->stream, prof_mark, ctx), "the launch behind the frame over the cull order")))
+            return behind_the_launch(rc);
         if (defer_lists) {
             ce.lists_args = fin;
             ce.lists_views = n_views;

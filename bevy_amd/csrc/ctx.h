@@ -398,6 +398,12 @@ int32_t fail(mi_ctx* ctx, int32_t code, const char* fmt, ...);
                         hipGetErrorString(e_), __FILE__, __LINE__);                                          \
     } while (0)
 
+// The same as a value, for a caller that has something to give back before it returns (cells_frame): MI_OK, or the recorded failure.
+inline int32_t hip_rc(mi_ctx* ctx, hipError_t e, const char* what) {
+    if (e == hipSuccess) return MI_OK;
+    return fail(ctx, e == hipErrorOutOfMemory ? MI_ERR_OUT_OF_MEMORY : MI_ERR_DEVICE, "%s: %s", what, hipGetErrorString(e));
+}
+
 // ENTER_RAW: mi_map_upload_window / mi_commit_upload_window, which continue a sequence of dense windows (seq_cov above); ENTER:
 // everybody else -- whatever they launch may read the Transform columns, so a window committed after them starts over on the
 // context's stream (or starts a new sequence at row 0, which waits for that stream first)

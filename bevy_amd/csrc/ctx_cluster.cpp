@@ -37,6 +37,14 @@ int32_t mi_cluster_upload_objects(mi_ctx* ctx, uint32_t n, const float* pos_rang
     if (any_spot && !spot_sin_cos) return fail(ctx, MI_ERR_INVALID_ARG, "spot lights need spot_sin_cos");
     int32_t rc;
     if ((rc = cluster_join(ctx))) return rc;
+    // From here on the old set is gone: an upload that fails half way leaves an EMPTY set (nothing can be assigned over columns of
+    // two different uploads), not the old one with some new columns.
+    const uint32_t n_before = ctx->cl_n;
+    ctx->cl_n = 0;
+    ctx->cl_assigned = false;
+    for (auto& parked : ctx->cl_parked) parked.assigned = false;  // (every view's assignment was over the old objects)
+    const bool bound_before = ctx->cl_rows_bound;
+    ctx->cl_rows_bound = false;
     if ((rc = ensure(ctx, ctx->cl_pos, (size_t)n * 16))) return rc;
     if ((rc = upload(ctx, ctx->cl_pos.p, pos_range, (size_t)n * 16))) return rc;
     ctx->cl_have_type = obj_type != nullptr;
@@ -61,10 +69,8 @@ int32_t mi_cluster_upload_objects(mi_ctx* ctx, uint32_t n, const float* pos_rang
         if ((rc = upload(ctx, ctx->cl_sincos.p, spot_sin_cos, (size_t)n * 8))) return rc;
     }
     ctx->cl_any_spot = any_spot;
-    if (n != ctx->cl_n) ctx->cl_rows_bound = false;  // a different object set: the row binding has to be renewed
     ctx->cl_n = n;
-    ctx->cl_assigned = false;
-    for (auto& parked : ctx->cl_parked) parked.assigned = false;  // (every view's assignment was over the old objects)
+    ctx->cl_rows_bound = bound_before && n == n_before;  // a different object set: the row binding has to be renewed
     return MI_OK;
 }
 

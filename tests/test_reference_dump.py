@@ -67,13 +67,25 @@ def _spot_back(inp):
     return (z * recip[:, None]).astype(f)
 
 
-def _spot_views(inp):
+def _cameras(inp, ref, key):
+    """The cameras' GlobalTransforms: the ones the reference's systems saw when the dump carries them (the tool builds a camera's
+    Transform with `Transform::from_matrix`, whose decomposition need not give the fixture's affine back bit for bit), else the
+    fixture's.  Either way they are the same cameras."""
+    fixture = inp[key]
+    seen = None if ref is None else ref.get(key.replace("cameras", "camera").replace(".camera", ".camera_global"))
+    if seen is None:
+        return fixture
+    assert seen.shape == fixture.shape and np.allclose(seen, fixture, rtol=1e-5, atol=1e-5), key
+    return seen
+
+
+def _spot_views(inp, ref=None):
     fov, aspect, near, far = inp["camera.fov_aspect_near_far"]
     cfv = O.perspective_infinite_reverse(np.float32(fov), aspect, near)
     w, h, dx, dy, dz = (int(x) for x in inp["cluster.screen_dims_z"])
     first, far_z = inp["cluster.first_slice_depth_far_z"]
     views = []
-    for cam in inp["cluster2.cameras"].reshape(-1, 12):
+    for cam in _cameras(inp, ref, "cluster2.cameras").reshape(-1, 12):
         fr = O.compute_frustum_perspective(np.float32(fov), aspect, near, far, cam)
         views.append((cam, cfv, fr, O.cluster_view_setup(cam, cfv, fr, w, h, (dx, dy, dz), float(first), float(far_z))))
     return views, (w, h, (dx, dy, dz), float(first), float(far_z))
@@ -97,9 +109,9 @@ def test_case_4_is_a_real_case():
     assert totals[0] != totals[1]
 
 
-def _flat_oracle(inp):
+def _flat_oracle(inp, ref=None):
     fov, aspect, near, far = inp["camera.fov_aspect_near_far"]
-    cams = inp["flat.cameras"].reshape(-1, 12)
+    cams = _cameras(inp, ref, "flat.cameras").reshape(-1, 12)
     frusta = np.concatenate([O.compute_frustum_perspective(np.float32(fov), aspect, near, far, c) for c in cams])
     n = inp["flat.flags"].size
     g, vv, vis, _ = O.full_frame(inp["flat.translation"], inp["flat.rotation"], inp["flat.scale"], inp["flat.aabb_center"],
@@ -119,7 +131,7 @@ def test_oracle_hierarchy_matches_the_reference():
 @needs_dump
 def test_oracle_flat_frame_matches_the_reference():
     inp, ref = migd.read(INPUTS), migd.read(DUMP)
-    frusta, g, vv, vis = _flat_oracle(inp)
+    frusta, g, vv, vis = _flat_oracle(inp, ref)
     for v in range(inp["flat.view_masks"].size):
         assert np.array_equal(bits(frusta[24 * v:24 * v + 24]), bits(ref[f"flat.frustum.{v}"])), f"frustum {v}"
     assert np.array_equal(bits(g).reshape(-1), bits(ref["flat.global"]))
@@ -134,7 +146,7 @@ def test_oracle_flat_frame_matches_the_reference():
 def test_oracle_clusters_match_the_reference():
     inp, ref = migd.read(INPUTS), migd.read(DUMP)
     fov, aspect, near, far = inp["camera.fov_aspect_near_far"]
-    cam = inp["cluster.camera"]
+    cam = _cameras(inp, ref, "cluster.camera")
     cfv = O.perspective_infinite_reverse(np.float32(fov), aspect, near)
     fr = O.compute_frustum_perspective(np.float32(fov), aspect, near, far, cam)
     w, h, dx, dy, dz = (int(x) for x in inp["cluster.screen_dims_z"])
@@ -153,7 +165,7 @@ def test_oracle_spot_clusters_of_two_cameras_match_the_reference():
     back = _spot_back(inp)
     spots = inp["cluster2.type"] == 1
     assert np.array_equal(bits(back[spots]), bits(ref["cluster2.spot_back"].reshape(-1, 3)[spots]))  # the direction the cone test reads
-    views, _ = _spot_views(inp)
+    views, _ = _spot_views(inp, ref)
     for v, (_, _, _, view) in enumerate(views):
         off, idx, _, farthest, total = O.assign_objects_to_clusters(view, inp["cluster2.lights_pos_range"], obj_type=inp["cluster2.type"],
                                                                    spot_dir=ref["cluster2.spot_back"], spot_sin_cos=ref["cluster2.sin_cos"])
@@ -169,7 +181,7 @@ def test_hip_spot_clusters_of_two_cameras_match_the_reference():
     from bevy_amd import api
 
     inp, ref = migd.read(INPUTS), migd.read(DUMP)
-    views, (w, h, dims, first, far_z) = _spot_views(inp)
+    views, (w, h, dims, first, far_z) = _spot_views(inp, ref)
     ctx = api.Context(device=0)
     for v, (cam, cfv, fr, _) in enumerate(views):
         view, _ = api.cluster_view_build(cam, cfv, fr, w, h, dims, first, far_z)
@@ -203,7 +215,7 @@ def test_hip_path_matches_the_reference():
     from bevy_amd import api
 
     inp, ref = migd.read(INPUTS), migd.read(DUMP)
-    frusta, *_ = _flat_oracle(inp)
+    frusta, *_ = _flat_oracle(inp, ref)
     n = inp["flat.flags"].size
     ctx = api.Context(device=0)
     ctx.resize(n)
@@ -214,3 +226,67 @@ def test_hip_path_matches_the_reference():
     vv, _ = ctx.download_view_visibility()
     assert np.array_equal(bits(g).reshape(-1), bits(ref["flat.global"]))
     assert np.array_equal((vv & 1).astype(np.uint8), ref["flat.view_visible"])
+
+
+def test_the_dump_tests_pass_on_a_stand_in_dump_made_by_the_oracle(tmp_path, monkeypatch):
+    """The tests above have never met a real dump (no Rust here).  This runs them on a stand-in the ORACLE produced, under the
+    names tools/golden_dump/src/main.rs writes -- so that a wrong key, shape or dtype in the tests shows today, not on the day
+    somebody runs the tool -- with cameras nudged by one ulp, as `Transform::from_matrix` may nudge them: the tests must follow
+    the cameras the dump says the systems saw."""
+    import re
+    import sys as _sys
+
+    inp = migd.read(INPUTS)
+    nudge = lambda a: np.nextafter(a.astype(np.float32), np.float32(np.inf)).astype(np.float32)  # noqa: E731
+    ref = {"flat.camera_global": nudge(inp["flat.cameras"]), "cluster.camera_global": nudge(inp["cluster.camera"]),
+           "cluster2.camera_global": nudge(inp["cluster2.cameras"])}
+    rc, g, _ = O.propagate_transforms(inp["tree.parent"], inp["tree.translation"], inp["tree.rotation"], inp["tree.scale"])
+    assert rc == 0
+    ref["tree.global"] = np.ascontiguousarray(g, np.float32).reshape(-1)
+    frusta, g, vv, vis = _flat_oracle(inp, ref)
+    ref["flat.global"] = np.ascontiguousarray(g, np.float32).reshape(-1)
+    ref["flat.view_visible"] = (vv & 1).astype(np.uint8)
+    cpu_culled = (inp["flat.flags"] & 0x10) == 0
+    for v in range(inp["flat.view_masks"].size):
+        ref[f"flat.frustum.{v}"] = np.ascontiguousarray(frusta[24 * v:24 * v + 24], np.float32)
+        ref[f"flat.visible_rows.{v}"] = np.nonzero(vis[v].astype(bool) & cpu_culled)[0].astype(np.uint32)
+    fov, aspect, near, far = inp["camera.fov_aspect_near_far"]
+    cfv = O.perspective_infinite_reverse(np.float32(fov), aspect, near)
+    cam = ref["cluster.camera_global"]
+    fr = O.compute_frustum_perspective(np.float32(fov), aspect, near, far, cam)
+    w, h, dx, dy, dz = (int(x) for x in inp["cluster.screen_dims_z"])
+    first, far_z = inp["cluster.first_slice_depth_far_z"]
+    view = O.cluster_view_setup(cam, cfv, fr, w, h, (dx, dy, dz), float(first), float(far_z))
+    off, idx, _, farthest, total = O.assign_objects_to_clusters(view, inp["cluster.lights_pos_range"])
+    ref.update({"cluster.dims": np.array(view.dims, np.uint32), "cluster.near_far": np.array([first, far_z], np.float32), "cluster.offsets": off,
+                "cluster.indices": idx, "cluster.farthest_z": np.array([farthest], np.float32), "cluster.total": np.array([total], np.uint64)})
+    back = _spot_back(inp)
+    ref["cluster2.spot_back"] = back.reshape(-1)
+    ref["cluster2.sin_cos"] = np.stack([np.sin(inp["cluster2.outer_angle"]), np.cos(inp["cluster2.outer_angle"])], axis=1).astype(np.float32).reshape(-1)
+    views, _ = _spot_views(inp, ref)
+    for v, (_, _, _, view) in enumerate(views):
+        off, idx, _, farthest, total = O.assign_objects_to_clusters(view, inp["cluster2.lights_pos_range"], obj_type=inp["cluster2.type"],
+                                                                   spot_dir=ref["cluster2.spot_back"], spot_sin_cos=ref["cluster2.sin_cos"])
+        ref.update({f"cluster2.dims.{v}": np.array(view.dims, np.uint32), f"cluster2.offsets.{v}": off, f"cluster2.indices.{v}": idx,
+                    f"cluster2.farthest_z.{v}": np.array([farthest], np.float32), f"cluster2.total.{v}": np.array([total], np.uint64)})
+    # the stand-in carries exactly the arrays the Rust tool writes
+    src = open(os.path.join(ROOT, "tools", "golden_dump", "src", "main.rs")).read()
+    names = set(re.findall(r'out\.insert\(\s*"([a-z0-9_.]+)"', src))
+    for pattern in re.findall(r'out\.insert\(format!\("([a-z0-9_.]+)\.\{v\}"\)', src):
+        names |= {f"{pattern}.{v}" for v in range(2)}
+    assert names == set(ref), names ^ set(ref)
+    path = str(tmp_path / "stand_in.migd")
+    migd.write(path, ref)
+    me = _sys.modules[__name__]
+    monkeypatch.setattr(me, "DUMP", path)
+    test_oracle_hierarchy_matches_the_reference()
+    test_oracle_flat_frame_matches_the_reference()
+    test_oracle_clusters_match_the_reference()
+    test_oracle_spot_clusters_of_two_cameras_match_the_reference()
+    # ... and they do look at the dump: a flipped bit in it fails them
+    broken = dict(ref)
+    broken["cluster2.indices.1"] = ref["cluster2.indices.1"].copy()
+    broken["cluster2.indices.1"][0] ^= 1
+    migd.write(path, broken)
+    with pytest.raises(AssertionError):
+        test_oracle_spot_clusters_of_two_cameras_match_the_reference()

@@ -232,6 +232,9 @@ fn main() {
         app.update();
         let world = app.world();
         out.insert("flat.global".into(), Array::F32(entities.iter().flat_map(|e| global_bits(world.get::<GlobalTransform>(*e).unwrap())).collect()));
+        // the cameras' GlobalTransforms as the systems saw them: `Transform::from_matrix` decomposes the fixture's affine and the
+        // propagation recomposes it, which need not give back the same bits -- the test feeds the oracle THESE
+        out.insert("flat.camera_global".into(), Array::F32(views.iter().flat_map(|e| global_bits(world.get::<GlobalTransform>(*e).unwrap())).collect()));
         out.insert("flat.view_visible".into(), Array::U8(entities.iter().map(|e| world.get::<ViewVisibility>(*e).unwrap().get() as u8).collect()));
         for (v, view) in views.iter().enumerate() {
             let frustum = world.get::<Frustum>(*view).unwrap();
@@ -291,6 +294,7 @@ fn main() {
             ))
             .id();
         app.update();
+        out.insert("cluster.camera_global".into(), Array::F32(global_bits(app.world().get::<GlobalTransform>(view).unwrap()).to_vec()));
         let clusters = app.world().get::<Clusters>(view).unwrap();
         out.insert("cluster.dims".into(), Array::U32(clusters.dimensions.to_array().to_vec()));
         out.insert("cluster.near_far".into(), Array::F32(vec![clusters.near, clusters.far]));
@@ -371,6 +375,7 @@ fn main() {
             "cluster2.spot_back".into(),
             Array::F32(light_entities.iter().flat_map(|e| world.get::<GlobalTransform>(*e).unwrap().back().to_array()).collect()),
         );
+        out.insert("cluster2.camera_global".into(), Array::F32(views.iter().flat_map(|e| global_bits(world.get::<GlobalTransform>(*e).unwrap())).collect()));
         out.insert("cluster2.sin_cos".into(), Array::F32(outer.iter().flat_map(|a| { let (s, c) = bevy_math::ops::sin_cos(*a); [s, c] }).collect()));
         for (v, view) in views.iter().enumerate() {
             let clusters = world.get::<Clusters>(*view).unwrap();

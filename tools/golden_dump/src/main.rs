@@ -167,7 +167,8 @@ fn main() {
     {
         let (parent, t, r, s) = (u32s(&inputs, "tree.parent"), f32s(&inputs, "tree.translation"), f32s(&inputs, "tree.rotation"), f32s(&inputs, "tree.scale"));
         let mut app = App::new();
-        app.add_plugins(TransformPlugin);
+        // (propagate_parent_transforms takes the ComputeTaskPool, systems.rs:167-172: it has to exist)
+        app.add_plugins((TaskPoolPlugin::default(), TransformPlugin));
         let entities: Vec<Entity> = (0..parent.len()).map(|i| app.world_mut().spawn(transform_at(t, r, s, i)).id()).collect();
         for (i, p) in parent.iter().enumerate() {
             if *p != u32::MAX {

@@ -1773,7 +1773,8 @@ int32_t mi_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_mas
 // ViewVisibility change ticks alternate between two buffers), so that a run of such frames has no memset in it.
 // MEASURED (profiles/r03_experiments.md, 1 M-node tree): the tile kernel grows from 24.2 to 33.0 us (68 registers: 7 instead of 8
 // workgroups per CU; ~1 900 more vector instructions per tile in a kernel organised around latency), the cull launch (10.6 us) and
-// one launch gap go: 34.7 against 37.1 us per frame at one view, 51.4 against 44.7 at four.  mi_debug_set_tree_cull: 1 = never, 2 =
+// one launch gap go: 34.7 against 37.1 us per frame at one view, 51.4 against 44.7 at four.  Round 4 (7 workgroups per CU, the rule's
+// kernel arguments read late; profiles/r04_experiments.md 3): 32.7 us per frame at one view.  mi_debug_set_tree_cull: 1 = never, 2 =
 // whenever it applies.
 static bool tree_frame_fusable(mi_ctx* ctx, uint32_t n_views, uint32_t flags) {
     // (default: with one view, where it measured faster -- 34.7 against 37.1 us per frame of the 1 M-node tree; with four views the

@@ -49,8 +49,10 @@
 //!
 //! There is no Rust toolchain in the image this repository is built in: this crate is written against the reference checkout
 //! (Bevy 0.20.0-dev) but has not been compiled.  `tests/test_rust_ffi.py` checks `ffi.rs` against the C header item by item and
-//! checks that every `ffi::mi_*` call below passes the declared number of arguments; `bevy_amd/host/bevy_mi355x_host.hpp` is the
-//! same host layer in C++, which IS compiled and run against the reference's system tests on the GPU.
+//! checks that every `ffi::mi_*` call below passes the declared number of arguments; `tools/check_rust_names.py` resolves every
+//! import, type identifier, method name and trait scope of this file against the reference checkout (and counts system parameters);
+//! `bevy_amd/host/bevy_mi355x_host.hpp` is the same host layer in C++, which IS compiled and run against the reference's system
+//! tests on the GPU.
 
 pub mod ffi;
 

@@ -36,3 +36,31 @@ def test_fixture_cites_reference_lines():
 def test_names_resolve_against_the_reference_checkout():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_rust_names.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.skipif(not os.path.isdir(crn.REF), reason="no reference checkout on this box")
+@pytest.mark.parametrize("snippet, expected", [
+    # the five kinds of error the round-4 desk check found in lib.rs, each as the checker must report it
+    ("use bevy_ecs::schedule::RemoveSystemsOnly;\n", "names nothing the reference defines"),
+    ("use bevy_app::PostUpdate;\nfn f() { let s = PostUpdate.intern(); }\n", "needs the trait `ScheduleLabel` in scope"),
+    ("fn f(p: &u32) { let c = bevy_camera::CameraProjection::get_clip_from_view(p); }\n", "use method syntax"),
+    ("use bevy_ecs::prelude::*;\nfn sys(" + ", ".join(f"q{i}: Query<()>" for i in range(17)) + ") {}\n", "has 17 parameters"),
+    ("use bevy_camera::PerspectiveProjection;\nfn f(p: PerspectiveProjection) { p.get_clip_from_view(); }\n", "need the trait in scope"),
+    ("fn f(c: bevy_camera::Camera) { c.physical_viewport_sizes(); }\n", "no `fn physical_viewport_sizes`"),
+    ("fn f() -> Option<Frustum> { None }\n", "`Frustum` is used but neither imported"),
+])
+def test_the_checker_reports_what_it_is_there_for(snippet, expected):
+    names, problems = {}, []
+    crn.check_text("snippet.rs", snippet, names, problems)
+    assert any(expected in p for p in problems), problems
+
+
+@pytest.mark.skipif(not os.path.isdir(crn.REF), reason="no reference checkout on this box")
+def test_the_checker_accepts_what_compiles():
+    ok = ("use bevy_ecs::{prelude::*, schedule::{ScheduleCleanupPolicy::RemoveSystemsOnly, ScheduleLabel}};\nuse bevy_app::{App, PostUpdate};\n"
+          "use bevy_camera::Projection;\n"
+          "fn f(app: &mut App, p: &Projection) { let s = PostUpdate.intern(); let m = p.get_clip_from_view(); let _ = (s, m, RemoveSystemsOnly); }\n")
+    names, problems = {}, []
+    crn.check_text("snippet.rs", ok, names, problems)
+    assert not problems, problems
+    assert "bevy_ecs::schedule::ScheduleCleanupPolicy::RemoveSystemsOnly" in names

@@ -152,7 +152,11 @@ def ecs_prelude():
 
 
 def check_file(rel, names, problems):
-    s = strip(open(os.path.join(ROOT, rel)).read())
+    check_text(rel, open(os.path.join(ROOT, rel)).read(), names, problems)
+
+
+def check_text(rel, text, names, problems):
+    s = strip(text)
     leaves = use_leaves(s)
     for u in leaves:
         if not u or not u[0].startswith("bevy"):

@@ -1170,15 +1170,16 @@ pub fn mi_fused_frame(
     >,
     // (one tuple parameter: a system function takes at most 16 parameters, function_system.rs:950)
     (point_lights, spot_lights, rect_lights, light_probes, decals): (
-        Query<(Entity, &PointLight, Option<&RenderLayers>)>,
-        Query<(Entity, &SpotLight, Option<&RenderLayers>)>,
-        Query<(Entity, &RectLight, Option<&RenderLayers>)>,
+        // (With<ViewVisibility>, With<GlobalTransform>: the reference's queries fetch both, assign.rs:146-178 -- an entity without
+        // one of them is not gathered there, so it is not gathered here)
+        Query<(Entity, &PointLight, Option<&RenderLayers>), (With<ViewVisibility>, With<GlobalTransform>)>,
+        Query<(Entity, &SpotLight, Option<&RenderLayers>), (With<ViewVisibility>, With<GlobalTransform>)>,
+        Query<(Entity, &RectLight, Option<&RenderLayers>), (With<ViewVisibility>, With<GlobalTransform>)>,
         // light probes and decals take their range from the GlobalTransform this very frame computes (assign.rs:262, 287).  For one
         // without a parent that is From(Transform), which is known here: such probes and decals ride like the lights, with the range
         // computed on the host; a parented one leaves the clusters to `mi_assign_objects_to_clusters`, behind the frame.
-        // (With<ViewVisibility>: the reference's queries fetch it, assign.rs:176-178 -- an entity without one is not gathered)
-        Query<(Entity, &Transform, Has<EnvironmentMapLight>, Has<ChildOf>), (With<LightProbe>, With<ViewVisibility>)>,
-        Query<(Entity, &Transform, Has<ChildOf>), (With<ClusteredDecal>, With<ViewVisibility>)>,
+        Query<(Entity, &Transform, Has<EnvironmentMapLight>, Has<ChildOf>), (With<LightProbe>, With<ViewVisibility>, With<GlobalTransform>)>,
+        Query<(Entity, &Transform, Has<ChildOf>), (With<ClusteredDecal>, With<ViewVisibility>, With<GlobalTransform>)>,
     ),
     settings: Option<Res<GlobalClusterSettings>>,
 ) {

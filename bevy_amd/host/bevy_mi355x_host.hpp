@@ -638,7 +638,7 @@ class Mi355xPlugin {
         // ---- the lights: rows like everything else, bound to the cluster stage by row (query order = Entity order here)
         uint32_t n_clusters = 0;
         mi_cluster_view cview{};
-        const bool with_clusters = cam != nullptr && !views.empty() && sync_lights(w) && !probes_or_decals_with_parents_;
+        const bool with_clusters = cam != nullptr && !views.empty() && sync_lights(w);
         if (with_clusters) {
             uint32_t tile[2], dims[3];
             if (mi_cluster_view_dims(cam->screen_width, cam->screen_height, cam->requested_dimensions, tile, dims) != MI_OK)
@@ -959,7 +959,9 @@ class Mi355xPlugin {
     // the centre from the row's GlobalTransform and gathers only the lights whose ViewVisibility::get() is true (assign.rs:190-296).
     // Re-uploaded only when a light was added / removed / changed its range or rows were renumbered.  Returns false without lights.
     bool sync_lights(World& w) {
-        if (lights_version_ == w.lights_version_ && lights_version_ != 0) return !light_entities_.empty();
+        // (a probe or decal WITH a parent: its range follows every ancestor's Transform, which no version counts -- such a World's list
+        // goes up every frame)
+        if (lights_version_ == w.lights_version_ && lights_version_ != 0 && !probes_or_decals_with_parents_) return !light_entities_.empty();
         light_entities_.clear();
         std::vector<uint32_t> rows;
         // every light that could be gathered, in gather order (points, spots, rects where they are clustered at all: assign.rs:190-248);
@@ -982,13 +984,16 @@ class Mi355xPlugin {
             if (w.rec_[e.index].point_light_range) add(e, *w.rec_[e.index].point_light_range, MI_OBJ_POINT_LIGHT, 0.f);
         for (Entity e : ents)
             if (w.rec_[e.index].spot_light) add(e, w.rec_[e.index].spot_light->first, MI_OBJ_SPOT_LIGHT, w.rec_[e.index].spot_light->second);
-        // light probes and decals take their range from the GlobalTransform this frame computes.  Without a parent that is
-        // From(Transform), known before the frame runs: such ones ride like the lights with the range formed here; a World with a
-        // parented one leaves the clusters to the system of its own (probes_or_decals_with_parents_, checked by frame())
+        // light probes and decals take their range from the GlobalTransform this frame computes (assign.rs:262, 287): From(Transform)
+        // chained down the ChildOf links with the reference's own operators -- the products propagate_parent_transforms forms for the
+        // entity, in its order, hence its bits -- known here, before the frame runs
         probes_or_decals_with_parents_ = false;
         auto range_rider = [&](Entity e, bool probe) {
-            if (w.rec_[e.index].parent) { probes_or_decals_with_parents_ = true; return 0.0f; }
-            const GlobalTransform g = GlobalTransform::from(w.transform_[e.index]);
+            std::vector<const Transform*> chain;
+            for (std::optional<Entity> cur = e; cur; cur = w.rec_[cur->index].parent) chain.push_back(&w.transform_[cur->index]);
+            probes_or_decals_with_parents_ = probes_or_decals_with_parents_ || chain.size() > 1;
+            GlobalTransform g = GlobalTransform::from(*chain.back());
+            for (size_t i = chain.size() - 1; i-- > 0;) g = g * *chain[i];
             return probe ? g.radius_of_unit_extents() : g.scale_length();
         };
         if (w.supports_storage_buffers) {
@@ -1090,7 +1095,7 @@ class Mi355xPlugin {
     std::vector<mi_view> mviews_;
     std::vector<Entity> light_entities_;
     bool lights_any_spot_ = false;
-    bool probes_or_decals_with_parents_ = false;  // (sync_lights: such a World's clusters are assign_objects_to_clusters' own round trip)
+    bool probes_or_decals_with_parents_ = false;  // (sync_lights: such a World's object list is gathered anew every frame)
     std::vector<float> sphere_storage_;
     std::vector<uint32_t> row_of_index_;
     uint64_t lights_version_ = 0, seen_visibility_ = 0, seen_bounds_ = 0;

@@ -1175,11 +1175,11 @@ pub fn mi_fused_frame(
         Query<(Entity, &PointLight, Option<&RenderLayers>), (With<ViewVisibility>, With<GlobalTransform>)>,
         Query<(Entity, &SpotLight, Option<&RenderLayers>), (With<ViewVisibility>, With<GlobalTransform>)>,
         Query<(Entity, &RectLight, Option<&RenderLayers>), (With<ViewVisibility>, With<GlobalTransform>)>,
-        // light probes and decals take their range from the GlobalTransform this very frame computes (assign.rs:262, 287).  For one
-        // without a parent that is From(Transform), which is known here: such probes and decals ride like the lights, with the range
-        // computed on the host; a parented one leaves the clusters to `mi_assign_objects_to_clusters`, behind the frame.
-        Query<(Entity, &Transform, Has<EnvironmentMapLight>, Has<ChildOf>), (With<LightProbe>, With<ViewVisibility>, With<GlobalTransform>)>,
-        Query<(Entity, &Transform, Has<ChildOf>), (With<ClusteredDecal>, With<ViewVisibility>, With<GlobalTransform>)>,
+        // light probes and decals take their range from the GlobalTransform this very frame computes (assign.rs:262, 287): formed here
+        // by `expected_global` -- From(Transform) chained down the ChildOf links with the reference's own operators, the products
+        // `propagate_parent_transforms` forms for the entity, in its order -- so they ride like the lights, with or without a parent
+        Query<(Entity, Has<EnvironmentMapLight>), (With<LightProbe>, With<ViewVisibility>, With<GlobalTransform>)>,
+        Query<Entity, (With<ClusteredDecal>, With<ViewVisibility>, With<GlobalTransform>)>,
     ),
     settings: Option<Res<GlobalClusterSettings>>,
 ) {
@@ -1285,7 +1285,7 @@ pub fn mi_fused_frame(
     //      of the frame -- the device takes a light's centre (and a spot light's direction) from its row's GlobalTransform and leaves
     //      out the ones whose ViewVisibility::get() is false.  The first clustered camera's walk rides in the frame kernel; every
     //      further one (split screen) is assigned behind the frame through a view slot of its own (mi_cluster_select_view).  Not with
-    //      the UBO limit (sort / truncate, assign.rs:297-321), GPU clustering, or a light probe / decal that has a parent.
+    //      the UBO limit (sort / truncate, assign.rs:297-321) or GPU clustering.
     let mut with_clusters = false;
     let mut cluster_objects: Vec<(Entity, u8)> = Vec::new();
     let mut cluster_views: Vec<ffi::MiClusterView> = Vec::new();
@@ -1296,8 +1296,6 @@ pub fn mi_fused_frame(
             && cluster_cameras.len() <= ffi::MI_CLUSTER_MAX_VIEWS as usize
             && settings.supports_storage_buffers
             && settings.gpu_clustering.is_none()
-            && !light_probes.iter().any(|q| q.3)
-            && !decals.iter().any(|q| q.2)
             && !fallback.clusters
         {
             let r = (|| -> Result<(), ()> {
@@ -1338,15 +1336,17 @@ pub fn mi_fused_frame(
                     push(s, e, light.range, ffi::MI_OBJ_RECT_LIGHT, layers, None)?;
                 }
                 // light probes (same gate, assign.rs:250-277) and decals (their own, :279-296), RenderLayers::default() both: the range is
-                // `radius_vec3a(Vec3A::ONE)` / `scale().length()` of the GlobalTransform this frame gives them -- From(Transform) for an
-                // entity without a parent (checked above), formed here with the same glam calls the reference makes
-                for (e, t, is_reflection_probe, _) in light_probes.iter() {
+                // `radius_vec3a(Vec3A::ONE)` / `scale().length()` of the GlobalTransform this frame gives them (`expected_global`: the
+                // same glam calls the reference makes on the same operands); an entity outside the transform table is not a row
+                for (e, is_reflection_probe) in light_probes.iter() {
+                    let Some(g) = expected_global(e, &transforms) else { continue };
                     let kind = if is_reflection_probe { ffi::MI_OBJ_REFLECTION_PROBE } else { ffi::MI_OBJ_IRRADIANCE_VOLUME };
-                    push(s, e, GlobalTransform::from(*t).radius_vec3a(bevy_math::Vec3A::ONE), kind, None, None)?;
+                    push(s, e, g.radius_vec3a(bevy_math::Vec3A::ONE), kind, None, None)?;
                 }
                 if settings.clustered_decals_are_usable {
-                    for (e, t, _) in decals.iter() {
-                        push(s, e, GlobalTransform::from(*t).scale().length(), ffi::MI_OBJ_DECAL, None, None)?;
+                    for e in decals.iter() {
+                        let Some(g) = expected_global(e, &transforms) else { continue };
+                        push(s, e, g.scale().length(), ffi::MI_OBJ_DECAL, None, None)?;
                     }
                 }
                 if cluster_objects.is_empty() {

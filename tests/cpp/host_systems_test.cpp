@@ -438,7 +438,11 @@ static Clusters probes_and_decals_frame(bool fused, bool decals_usable, bool par
     w.set_clustered_decals_are_usable(decals_usable);
     uint64_t rng = 0xABCDEFull;
     auto next = [&rng]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (float)(rng % 20001) / 10000.0f - 1.0f; };
-    Entity parent = w.spawn(Transform::from_xyz(0.5f, -0.25f, -2.0f));
+    // (scaled and turned: a child's range is not the range of its own Transform)
+    Transform parent_t = Transform::from_xyz(0.5f, -0.25f, -2.0f);
+    parent_t.scale = {1.5f, 0.75f, 2.0f};
+    parent_t.rotation = {0.0f, 0.14943813f, 0.0f, 0.98877108f};  // 0.3 rad about y
+    Entity parent = w.spawn(parent_t);
     std::vector<Entity> probes;
     for (int i = 0; i < 40; ++i) {
         Transform t = Transform::from_xyz(12.0f * next(), 7.0f * next(), -8.0f - 30.0f * (0.5f + 0.5f * next()));
@@ -448,7 +452,7 @@ static Clusters probes_and_decals_frame(bool fused, bool decals_usable, bool par
         else if (i % 4 == 1) { w.insert_light_probe(e, true); probes.push_back(e); }
         else if (i % 4 == 2) w.insert_light_probe(e, false);
         else w.insert_clustered_decal(e);
-        if (parented && i == 5) w.add_child(parent, e);
+        if (parented && (i == 5 || i == 7)) w.add_child(parent, e);  // a reflection probe and a decal
     }
     ClusterCamera cam;
     mi_perspective_clip_from_view(3.14159265f / 4.0f, 16.0f / 9.0f, 0.1f, cam.clip_from_view);
@@ -458,6 +462,7 @@ static Clusters probes_and_decals_frame(bool fused, bool decals_usable, bool par
     Clusters cl;
     for (int frame = 0; frame < 2; ++frame) {
         if (frame == 1) w.transform_mut(probes[1]).scale = {4.0f, 3.0f, 5.0f};  // a bigger probe: its range follows in the same frame
+        if (frame == 1 && parented) w.transform_mut(parent).scale = {2.5f, 1.25f, 0.5f};  // ... and so does a child's when an ancestor changes
         if (fused) {
             Mi355xPlugin::FrameOutput out = plugin.frame(w, {view}, &cam);
             if (rode) *rode = out.has_clusters;
@@ -476,7 +481,7 @@ static void light_probes_and_decals_are_clustered() {
             bool rode = false;
             const Clusters cl = probes_and_decals_frame(g_fused, usable != 0, parented != 0, &rode);
             const Clusters other = probes_and_decals_frame(!g_fused, usable != 0, parented != 0, nullptr);
-            if (g_fused) CHECK(rode == (parented == 0), "probes and decals ride in the fused frame unless one has a parent");
+            if (g_fused) CHECK(rode, "probes and decals ride in the fused frame, with or without a parent");
             uint64_t k[6] = {0, 0, 0, 0, 0, 0}, total = 0;
             bool same = cl.clusterable_objects.size() == other.clusterable_objects.size();
             for (size_t c = 0; c < cl.clusterable_objects.size(); ++c) {

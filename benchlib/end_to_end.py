@@ -34,7 +34,7 @@ def end_to_end(ctx, wl, frames=12, cpu_frame_ms=None):
     mi_download_frame_results delivered in place: the changed GlobalTransforms, the camera's VisibleEntities list, the cluster
     offsets / counts / index list.  Wall clock, synchronised every frame."""
     import bevy_amd as B
-    from bevy_amd import api, workloads as W
+    from bevy_amd import api
     sc = wl.scene
     n = sc["n"]
     views = wl.keep[0]

@@ -5,7 +5,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import bevy_amd as B
-from bevy_amd import api, workloads as W
+from bevy_amd import api
 import bench
 class A: pass
 args = A(); args.entities = 0; args.lights = 100000; args.meshes = 10000; args.separate_cluster_calls = False; args.concurrent_clusters = False; args.inline_compaction = False

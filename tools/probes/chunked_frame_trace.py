@@ -1,7 +1,6 @@
 """One context, a few all-dirty frames through ONE dense window (the library splits it in eight): for `rocprofv3 --kernel-trace
 --memory-copy-trace` -- tools/probes/summarize_copy_trace.py turns the trace of the last frame into a timeline."""
 import os, sys
-import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.getcwd()))
 import bevy_amd as B
 from bevy_amd import api, workloads as W

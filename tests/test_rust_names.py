@@ -64,3 +64,16 @@ def test_the_checker_accepts_what_compiles():
     crn.check_text("snippet.rs", ok, names, problems)
     assert not problems, problems
     assert "bevy_ecs::schedule::ScheduleCleanupPolicy::RemoveSystemsOnly" in names
+
+
+@pytest.mark.skipif(not os.path.isdir(crn.REF), reason="no reference checkout on this box")
+@pytest.mark.parametrize("snippet, expected", [
+    ("use bevy_camera::Camera;\nfn f() { let c = Camera { is_actve: true, ..Default::default() }; }\n", "names fields the reference's definition does not have: ['is_actve']"),
+    ("use bevy_light::cluster::ClusterZConfig;\nfn f(d: f32) { let z = ClusterZConfig { first_slice_depth: d }; }\n", "leaves out ['far_z_mode']"),
+    ("use bevy_light::cluster::ClusterConfig;\nfn f(c: ClusterConfig) { if let ClusterConfig::XYZ { dimensions, z_config } = c {} }\n", "leaves out ['dynamic_resizing']"),
+    ("use bevy_camera::Camera;\nfn f(c: &Camera) -> bool { c.computed.is_actve }\n", "`.is_actve` is read"),
+])
+def test_the_checker_knows_the_reference_structs(snippet, expected):
+    names, problems = {}, []
+    crn.check_text("snippet.rs", snippet, names, problems)
+    assert any(expected in p for p in problems), problems

@@ -13,7 +13,11 @@ This tool checks what can be checked without a compiler:
      std list below (a weak check: it catches misspelt and renamed methods, not a method called on the wrong type);
   4. the traits whose methods the file calls are in scope (TRAIT_METHODS below: method -> trait that must be imported or come
      with a prelude);
-  5. no system function has more than 16 parameters.
+  5. no system function has more than 16 parameters;
+  6. every struct literal / struct pattern of a reference type (`Camera { is_active: .. }`, `ClusterConfig::XYZ { dimensions, .. }`)
+     names fields the reference's definition has, and all of them unless it ends in `..`;
+  7. every field the file reads with `.name` is a field some struct of the reference, of ffi.rs or of the file itself declares
+     (weak in the same way as 3: it catches renamed fields).
 
     python tools/check_rust_names.py            # checks against /root/reference, rewrites tests/golden/reference_api_names.json
     python tools/check_rust_names.py --check    # the same, fails if the fixture would change
@@ -203,6 +207,8 @@ def check_text(rel, text, names, problems):
         params = s[m.end():j]
         if n > 16 and re.search(r"\b(Query|Res|ResMut|Commands)\b", params):
             problems.append("%s: system `%s` has %d parameters, the limit is 16 (group some into a tuple)" % (rel, m.group(1), n))
+    check_struct_literals(rel, s, problems)
+    check_field_names(rel, s, problems)
     for m, trait in TRAIT_METHODS.items():
         if m in methods and trait not in imported | globbed:
             problems.append("%s: `.%s()` needs the trait `%s` in scope" % (rel, m, trait))
@@ -210,6 +216,87 @@ def check_text(rel, text, names, problems):
         problems.append("%s: CameraProjection's methods on a concrete projection need the trait in scope" % rel)
     if re.search(r"CameraProjection::(get_clip_from_view|compute_frustum)\(", s):
         problems.append("%s: `CameraProjection::f(&Projection)` does not resolve (Projection only DEREFS to dyn CameraProjection): use method syntax" % rel)
+
+
+def reference_struct_fields(name, variant=None):
+    """[(file, {fields})] of `pub struct name { .. }` (or of `variant { .. }` inside `pub enum name`) in the reference"""
+    hits = subprocess.run(["grep", "-rnE", r"\bpub (struct|enum) " + name + r"\b", REF, "--include=*.rs"], capture_output=True, text=True).stdout.splitlines()
+    out = []
+    for hit in hits:
+        f, line, _ = hit.split(":", 2)
+        text = "\n".join(open(f).read().split("\n")[int(line) - 1:int(line) + 400])
+        m = re.search(r"\b" + variant + r"\s*\{", text) if variant else re.search(r"\{", text)
+        if not m or (not variant and ";" in text[:m.start()]):
+            continue
+        j = k = m.end()
+        depth = 1
+        while depth and k < len(text):
+            depth += text[k] == "{"
+            depth -= text[k] == "}"
+            k += 1
+        body = re.sub(r"#\[[^\]]*\]", "", re.sub(r"//[^\n]*", "", text[j:k - 1]))
+        out.append((f.replace("/root/reference/", ""), set(re.findall(r"(?:pub(?:\([a-z]+\))?\s+)?([a-z_][a-z0-9_]*)\s*:", body))))
+    return out
+
+
+def check_struct_literals(rel, s, problems):
+    for m in re.finditer(r"(?<![\w:])((?:[a-z_]+::)*)([A-Z][A-Za-z0-9]+)(?:::([A-Z][A-Za-z0-9]+))?\s*\{", s):
+        if re.search(r"\b(struct|enum|impl|trait|for|mod|union|fn|->)\s*$", s[max(0, m.start() - 12):m.start()]) or m.group(1).startswith("ffi::"):
+            continue
+        name, variant = m.group(2), m.group(3)
+        j = k = m.end()
+        depth = 1
+        while depth:
+            depth += s[k] == "{"
+            depth -= s[k] == "}"
+            k += 1
+        parts, d, cur = [], 0, ""
+        for ch in s[j:k - 1]:
+            d += ch in "([{<"
+            d -= ch in ")]}>"
+            if ch == "," and d == 0:
+                parts.append(cur)
+                cur = ""
+            else:
+                cur += ch
+        parts.append(cur)
+        fields, rest, ok = [], False, True
+        for part in (x.strip() for x in parts):
+            if part.startswith(".."):
+                rest = True
+            elif part:
+                fm = re.match(r"^([a-z_][a-z0-9_]*)\s*(:|$)", part)
+                if not fm:
+                    ok = False
+                    break
+                fields.append(fm.group(1))
+        if not ok or not fields:
+            continue  # a block, not a field list
+        defs = reference_struct_fields(name, variant)
+        if not defs:
+            continue  # not a reference type
+        line = s[:m.start()].count("\n") + 1
+        label = name + ("::" + variant if variant else "")
+        if not any(set(fields) <= have for _, have in defs):
+            problems.append("%s:%d: `%s { .. }` names fields the reference's definition does not have: %s" % (rel, line, label, sorted(set(fields) - defs[0][1])))
+        elif not rest and not any(set(fields) == have for _, have in defs):
+            problems.append("%s:%d: `%s { .. }` leaves out %s and does not end in `..`" % (rel, line, label, sorted(defs[0][1] - set(fields))))
+
+
+_reference_fields = None
+
+
+def check_field_names(rel, s, problems):
+    global _reference_fields
+    if _reference_fields is None:
+        out = subprocess.run(["grep", "-rhoE", r"^\s+pub(\([a-z]+\))?\s+[a-z_][a-z0-9_]*\s*:", REF, "--include=*.rs"], capture_output=True, text=True).stdout
+        _reference_fields = set(re.findall(r"([a-z_][a-z0-9_]*)\s*:", out))
+    ffi = open(os.path.join(ROOT, "rust", "bevy_mi355x", "src", "ffi.rs")).read()
+    local = set(re.findall(r"^\s+(?:pub(?:\([a-z]+\))?\s+)?([a-z_][a-z0-9_]*)\s*:", s, re.M)) | set(re.findall(r"pub ([a-z_][a-z0-9_]*):", ffi))
+    glam = set("x y z w x_axis y_axis z_axis w_axis matrix3 translation".split())
+    for f in sorted(set(re.findall(r"(?<=[\w)\]])\.([a-z_][a-z0-9_]*)\b(?!\s*(?:\(|::|!))", s))):
+        if f not in _reference_fields | local | glam and not f.isdigit():
+            problems.append("%s: `.%s` is read, but no struct of the reference, of ffi.rs or of the file has such a field" % (rel, f))
 
 
 def main():

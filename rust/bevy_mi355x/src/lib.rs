@@ -669,7 +669,7 @@ pub fn mi_check_visibility(
             }
             let (layer_mask, layer_mask_hi) = match layers {
                 None => (1, 0),
-                Some(l) => layer_words(l).ok_or(())?,
+                Some(l) => layer_words_or_log(l)?,
             };
             let mut view = ffi::MiView {
                 frustum: [0.0; 24],
@@ -770,6 +770,16 @@ fn layer_word(layers: &RenderLayers) -> Option<u32> {
         word |= 1 << layer;
     }
     Some(word)
+}
+
+/// The status rule for a capability limit: said once in the log, then `Err` like any failed call (the stock systems take over).
+fn layer_words_or_log(layers: &RenderLayers) -> Result<(u32, u32), ()> {
+    layer_words(layers).ok_or_else(|| error!("bevy_mi355x: a RenderLayers beyond layer 63; the device columns hold layers 0..63 -- falling back to the CPU systems"))
+}
+fn layer_word_or_log(layers: &RenderLayers) -> Result<u32, ()> {
+    layer_word(layers).ok_or_else(|| {
+        error!("bevy_mi355x: a clusterable object or clustered view beyond layer 31 outside the fused frame; mi_cluster_assign_frame takes one 32-bit word -- falling back to the CPU system")
+    })
 }
 
 fn mi_class_bit(table: &mut HashMap<TypeId, u32>, class: TypeId) -> Option<u32> {
@@ -886,7 +896,7 @@ pub fn mi_assign_objects_to_clusters(
             s.obj_type.push(kind as u8);
             s.obj_layers.push(match layers {
                 None => 1,
-                Some(l) => layer_word(l).ok_or(())?,
+                Some(l) => layer_word_or_log(l)?,
             });
             s.obj_shadows.push(shadows as u8);
             s.obj_volumetric.push(volumetric as u8);
@@ -1005,7 +1015,7 @@ pub fn mi_assign_objects_to_clusters(
                     screen.y,
                     match layers {
                         None => 1,
-                        Some(l) => layer_word(l).ok_or(())?,
+                        Some(l) => layer_word_or_log(l)?,
                     },
                     settings.view_cluster_bindings_max_indices as u64,
                     &mut view,
@@ -1222,7 +1232,7 @@ pub fn mi_fused_frame(
             }
             let (layer_mask, layer_mask_hi) = match layers {
                 None => (1, 0),
-                Some(l) => layer_words(l).ok_or(())?,
+                Some(l) => layer_words_or_log(l)?,
             };
             views.push(ffi::MiView {
                 frustum: planes,
@@ -1314,7 +1324,7 @@ pub fn mi_fused_frame(
                     // the first u64 word of the bitset, as for rows and views (render_layers.rs:121-135); a light above layer 63: stock systems
                     let (lo, hi) = match layers {
                         None => (1, 0),
-                        Some(l) => layer_words(l).ok_or(())?,
+                        Some(l) => layer_words_or_log(l)?,
                     };
                     s.obj_layers.push(lo);
                     s.obj_layers_hi.push(hi);
@@ -1623,7 +1633,7 @@ fn stage_bounds(
         s.flags[row] = flags as u8;
         (s.layers[row], s.layers_hi[row]) = match layers {
             None => (1, 0), // RenderLayers::default() == layer 0
-            Some(l) => layer_words(l).ok_or(())?,
+            Some(l) => layer_words_or_log(l)?,
         };
         s.any_layers_hi |= s.layers_hi[row] != 0;
         if let Some(classes) = classes {

@@ -46,7 +46,7 @@ chunks chunks_exact windows swap to_vec as_ref as_mut map_or map_or_else and_the
 to_string to_str to_owned into_owned as_str wrapping_add wrapping_sub saturating_sub saturating_add position find fold
 copy_from_slice fill keys values values_mut set cast add offset read write is_null eq ne cmp partial_cmp powf ln exp ceil floor round
 clamp to_array to_cols_array is_finite flatten flat_map skip step_by next dedup try_into try_from into_iter chain extend_from_slice
-is_some_and ok_or to_string_lossy or back reverse length write_all flush to_le_bytes as_bytes exit args nth parse join display
+is_some_and ok_or ok_or_else to_string_lossy or back reverse length write_all flush to_le_bytes as_bytes exit args nth parse join display
 create unwrap_or_else""".split())
 # glam methods the files call (bevy_math re-exports glam; glam itself is not in the checkout)
 GLAM_METHODS = set("""to_cols_array to_array length from_cols_array from_array truncate extend normalize dot cross mul_vec3 transform_point3

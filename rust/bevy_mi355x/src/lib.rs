@@ -1223,7 +1223,8 @@ pub fn mi_fused_frame(
             if !camera.is_active {
                 continue;
             }
-            let global = expected_global(entity, &transforms).ok_or(())?;
+            // (a camera without Transform has no row and no GlobalTransform to predict: the stock systems take this frame)
+            let global = expected_global(entity, &transforms).ok_or_else(|| error!("bevy_mi355x: an active camera without a Transform -- falling back to the CPU systems"))?;
             // (Projection derefs to `dyn CameraProjection`: method syntax, as update_frusta itself calls it, visibility/mod.rs:627-636)
             let frustum = projection.compute_frustum(&global);
             let mut planes = [0f32; 24];
@@ -1638,7 +1639,8 @@ fn stage_bounds(
         s.any_layers_hi |= s.layers_hi[row] != 0;
         if let Some(classes) = classes {
             for class in classes.iter() {
-                s.classes[row] |= 1 << mi_class_bit(&mut mi.class_bits, *class).ok_or(())?;
+                s.classes[row] |= 1 << mi_class_bit(&mut mi.class_bits, *class)
+                    .ok_or_else(|| error!("bevy_mi355x: more than 32 visibility classes; the class column holds 32 -- falling back to the CPU systems"))?;
             }
         }
     }

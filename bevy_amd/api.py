@@ -192,7 +192,7 @@ ABI_SYMBOLS = [
     "mi_upload_visibility_ranges", "mi_upload_visibility", "mi_upload_hierarchy", "mi_hierarchy_sort", "mi_propagate",
     "mi_visibility_propagate", "mi_download_inherited_visibility",
     "mi_visibility_begin_frame", "mi_cull", "mi_cull_views", "mi_propagate_and_cull", "mi_propagate_and_cull_views",
-    "mi_visibility_end_frame",
+    "mi_visibility_end_frame", "mi_check_light_mesh_visibility",
     "mi_download_global_transforms", "mi_download_changed_global_transforms", "mi_download_frame_results", "mi_download_changed_mesh_inputs", "mi_download_visibility", "mi_download_view_visibility",
     "mi_download_visible_entities", "mi_cluster_view_dims", "mi_cluster_view_build",
     "mi_cluster_dimensions_fixed_z", "mi_cluster_assign", "mi_cluster_upload_objects", "mi_cluster_upload_object_layers_hi", "mi_cluster_upload_view",
@@ -533,6 +533,20 @@ class Context:
         """views: ctypes array from make_views()."""
         self.n_views = len(views)
         self._ck(self._lib.mi_cull_views(self._h, views, len(views), int(flags)))
+
+    def check_light_mesh_visibility(self, shadow_views, flags=0, want_any=True):
+        """mi_check_light_mesh_visibility: the frame's shadow views behind the camera pass.  Returns (per-view 0/1 arrays [n_views, n],
+        the rows set_visible() was called on) -- both unpacked from the bitmasks the call delivers in one device wait."""
+        nv = 0 if shadow_views is None else len(shadow_views)
+        w32 = (self.n + 31) // 32
+        masks = np.zeros(max(nv * w32, 1), np.uint32)
+        any_ = np.zeros(max(w32, 1), np.uint32) if want_any else None
+        self._ck(self._lib.mi_check_light_mesh_visibility(self._h, shadow_views if nv else None, nv, int(flags), _ptr(masks, C.c_uint32),
+                                                          _ptr(any_, C.c_uint32)))
+        if nv:
+            self.n_views = nv
+        per_view = np.stack([unpack_bits(masks[v * w32:(v + 1) * w32], self.n) for v in range(nv)]) if nv else np.zeros((0, self.n), np.uint8)
+        return per_view, (unpack_bits(any_[:w32], self.n) if want_any else None)
 
     def propagate_and_cull_views(self, views, flags=0):
         self.n_views = len(views)

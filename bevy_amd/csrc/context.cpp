@@ -1754,6 +1754,56 @@ int32_t mi_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t n_views, uint3
     return cull_frame<false>(ctx, views, n_views, flags);
 }
 
+// The shadow views of a frame (crates/bevy_light/src/lib.rs:342-757): the same frame kernel as the cameras' pass, each view's kind
+// selected by its flags (visibility_rule.h), ORing into ViewVisibility; every view's packed mask and their union come back in one
+// device wait (the masks of a frame's views lie one behind the other in the frame's buffer set).
+int32_t mi_check_light_mesh_visibility(mi_ctx* ctx, const mi_view* shadow_views, uint32_t n_views, uint32_t flags, uint32_t* out_bitmasks,
+                                       uint32_t* out_any) {
+    ENTER(ctx);
+    if (flags & ~MI_CULL_END_FRAME) return fail(ctx, MI_ERR_INVALID_ARG, "mi_check_light_mesh_visibility: flags 0x%x (MI_CULL_END_FRAME or 0)", flags);
+    if (n_views && (!shadow_views || !out_bitmasks)) return fail(ctx, MI_ERR_INVALID_ARG, "mi_check_light_mesh_visibility: NULL views or out_bitmasks");
+    for (uint32_t v = 0; v < n_views; ++v)
+        if (!(shadow_views[v].flags & MI_VIEW_FLAG_SHADOW))
+            return fail(ctx, MI_ERR_INVALID_ARG, "mi_check_light_mesh_visibility: view %u is not a shadow view (MI_VIEW_FLAG_SHADOW)", v);
+    const size_t words32 = ((size_t)ctx->n + 31) / 32;
+    if (out_any && words32) memset(out_any, 0, words32 * 4);
+    if (n_views == 0 || ctx->n == 0) {
+        if (n_views && words32) memset(out_bitmasks, 0, (size_t)n_views * words32 * 4);
+        if (!(flags & MI_CULL_END_FRAME) || ctx->n == 0) return MI_OK;
+        ctx->cells.valid = false, ctx->cells.quiet = 0;
+        ProfScope ps(ctx, K_VIS_END);
+        HIP_TRY(ctx, launch_vis_end(columns_of(ctx), ctx->stream));
+        return MI_OK;
+    }
+    int32_t rc = cull_frame<false>(ctx, shadow_views, n_views, flags & MI_CULL_END_FRAME);
+    if (rc) return rc;
+    const uint64_t* base;
+    uint64_t stride;
+    if (ctx->ext_bitmask) base = (const uint64_t*)ctx->ext_bitmask + ctx->ext_word_offset, stride = ctx->ext_words_per_view;
+    else base = (const uint64_t*)ctx->fb[ctx->cur].bitmask.p, stride = ctx->words_per_view;
+    // one copy of [n_views][stride] words where that is no more than twice the payload (always, for the library's own buffers),
+    // a copy per view otherwise (a caller-bound buffer with the other ranks' words in between); one wait either way
+    const size_t row_bytes = words32 * 4;
+    const bool one_copy = stride * 8 <= 2 * row_bytes + 4096;
+    const size_t st_stride = one_copy ? (size_t)stride * 8 : ((row_bytes + 255) & ~(size_t)255);
+    void* st = nullptr;
+    if ((rc = stage_alloc(ctx, st_stride * n_views, &st))) return rc;
+    if (one_copy) HIP_TRY(ctx, hipMemcpyAsync(st, base, st_stride * n_views, hipMemcpyDeviceToHost, ctx->stream));
+    else
+        for (uint32_t v = 0; v < n_views; ++v)
+            HIP_TRY(ctx, hipMemcpyAsync((char*)st + v * st_stride, base + (size_t)v * stride, row_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t tail = (ctx->n & 31u) ? (1u << (ctx->n & 31u)) - 1u : 0xFFFFFFFFu;
+    for (uint32_t v = 0; v < n_views; ++v) {
+        uint32_t* dst = out_bitmasks + (size_t)v * words32;
+        memcpy(dst, (const char*)st + v * st_stride, row_bytes);
+        dst[words32 - 1] &= tail;
+        if (out_any)
+            for (size_t w = 0; w < words32; ++w) out_any[w] |= dst[w];
+    }
+    return MI_OK;
+}
+
 int32_t mi_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_masks, const uint8_t* view_flags,
                 uint32_t n_views, uint32_t flags) {
     std::vector<mi_view> v;

@@ -37,7 +37,9 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 2
+/* 3: mi_cluster_view.view_layer_mask_hi, component-granular upload windows (round 4); mi_check_light_mesh_visibility
+ *    (round 5).  A caller built against an older header must not pass the version check. */
+#define MI_ABI_VERSION 3
 
 /* ---- status codes ---------------------------------------------------------------------- */
 #define MI_OK 0
@@ -317,6 +319,26 @@ int32_t mi_propagate_and_cull_views(mi_ctx* ctx, const mi_view* views, uint32_t 
  * changed are propagated (= mi_propagate(0) in front of the cull); MI_CULL_STATIC_OPT = MI_PROPAGATE_STATIC_OPT. */
 int32_t mi_propagate_and_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_masks,
                               const uint8_t* view_flags, uint32_t n_views, uint32_t flags /* MI_CULL_* */);
+
+/* check_dir_light_mesh_visibility + check_point_light_mesh_visibility (crates/bevy_light/src/lib.rs:342-515, 517-757;
+ * SimulationLightSystems::CheckLightVisibility, ordered after VisibilitySystems::CheckVisibility and before
+ * MarkNewlyHiddenEntitiesInvisible, lib.rs:217-230): the frame's SHADOW views in one pass over the resident columns, behind the
+ * camera pass of the same frame (mi_cull / mi_propagate_and_cull* WITHOUT MI_CULL_END_FRAME).  Every view must carry
+ * MI_VIEW_FLAG_SHADOW: one mi_view per cascade of every (directional light, camera) pair (MI_VIEW_KIND_CASCADE; layer mask = the
+ * light's RenderLayers; MI_VIEW_FLAG_RANGES + position = that camera's translation when the camera has an index in
+ * VisibleEntityRanges), six per shadow-mapped point light and one per spot light among the lights some camera sees
+ * (MI_VIEW_KIND_CUBE_FACE_OR_SPOT + light_sphere = (translation, range); MI_VIEW_FLAG_RANGES + position = the shadow LOD origin's
+ * translation, or MI_VIEW_FLAG_RANGES_NO_ORIGIN without one, lib.rs:601-611).  Only rows with MI_FLAG_SHADOW_CASTER are seen.
+ * Survivors are ORed into ViewVisibility (set_visible: lib.rs:499-510, 629, 723); flags = MI_CULL_END_FRAME also closes the frame
+ * (check_visibility_gpu_culling + mark_newly_hidden_entities_invisible) in the same pass.  n_views = 0 is allowed (only the
+ * END_FRAME part runs).  Out, in ONE device wait:
+ *   out_bitmasks[n_views * ceil(n_rows/32)]  view v's packed VisibleMeshEntities: bit r = row r was pushed to that cascade's /
+ *                                            face's / spot light's list (the caller maps rows to Entity and sorts, lib.rs:489, 664, 745)
+ *   out_any[ceil(n_rows/32)]                 OR over the views = the rows set_visible() was called on (NULL = not wanted)
+ * Afterwards view indices of mi_download_visibility / mi_download_visible_entities / mi_batch_build refer to THESE views (the
+ * shadow phases are batched from them); fetch the cameras' lists before this call. */
+int32_t mi_check_light_mesh_visibility(mi_ctx* ctx, const mi_view* shadow_views, uint32_t n_views, uint32_t flags /* MI_CULL_END_FRAME or 0 */,
+                                       uint32_t* out_bitmasks, uint32_t* out_any);
 
 /* check_visibility_gpu_culling for NoCpuCulling rows (visibility/mod.rs:884-903) followed by
  * mark_newly_hidden_entities_invisible (:908-918). */

@@ -141,6 +141,33 @@ def test_shadow_views_cascades_cube_faces_and_spot(n):
         vv, chg = ctx.download_view_visibility()
         assert_bits(vv, vv_exp, "vv (two cull calls)")
         assert_bits(chg, chg_exp, "vv changed (two cull calls)")
+    # the plugin's sequence: the cameras' frame (propagate + cull, the frame left open), then SimulationLightSystems::CheckLightVisibility
+    # as ONE call that also closes the frame -- every shadow view's VisibleMeshEntities mask and the set_visible() union in one wait
+    shadow = api.make_views(fr[24:], masks[1:], flags[1:], np.array(pos[1:], F), np.array(sph[1:], F))
+    with api.Context(0) as ctx:
+        upload(ctx, sc, vv0)
+        ctx.propagate_and_cull_views(api.make_views(fr[:24], masks[:1], flags[:1], np.array(pos[:1], F)), flags=0)
+        cam_rows = ctx.download_visible_entities(0, 0)[1]
+        assert np.array_equal(cam_rows, np.nonzero(vis_exp[0])[0].astype(np.uint32))
+        per_view, any_ = ctx.check_light_mesh_visibility(shadow, flags=B.CULL_END_FRAME)
+        for v in range(1, len(frs)):
+            assert_bits(per_view[v - 1], vis_exp[v], f"light pass view {v}")
+        assert_bits(any_, np.bitwise_or.reduce(vis_exp[1:], axis=0), "rows set_visible() was called on")
+        vv, chg = ctx.download_view_visibility()
+        assert_bits(vv, vv_exp, "vv (camera frame + light pass)")
+        assert_bits(chg, chg_exp, "vv changed (camera frame + light pass)")
+        keys, rows = ctx.download_visible_entities(3, 0)   # the lists now belong to the shadow views (the shadow phases batch from them)
+        assert np.array_equal(rows, np.nonzero(vis_exp[4])[0].astype(np.uint32))
+        # no shadow view at all: the call only closes the frame
+        ctx.propagate_and_cull_views(api.make_views(fr[:24], masks[:1], flags[:1], np.array(pos[:1], F)), flags=0)
+        per_view, any_ = ctx.check_light_mesh_visibility(None, flags=B.CULL_END_FRAME)
+        assert per_view.shape == (0, n) and not any_.any()
+        g2, vv_exp2, _, chg_exp2 = oracle_views_frame(sc, vv_exp, O.make_views(fr[:24], masks[:1], flags[:1], np.array(pos[:1], F)))
+        vv, chg = ctx.download_view_visibility()
+        assert_bits(vv, vv_exp2, "vv (camera frame + empty light pass)")
+        assert_bits(chg, chg_exp2, "vv changed (camera frame + empty light pass)")
+        with pytest.raises(api.MiError):   # a camera view is not a shadow view
+            ctx.check_light_mesh_visibility(api.make_views(fr[:24], masks[:1], flags[:1], np.array(pos[:1], F)))
 
 
 # ---- InheritedVisibility -------------------------------------------------------------------------

@@ -108,6 +108,33 @@ struct Entity {
     bool operator!=(const Entity& o) const { return !(*this == o); }
 };
 
+// VisibilityRange, crates/bevy_camera/src/visibility/range.rs:78-112
+struct VisibilityRange {
+    float start_margin_start = 0, start_margin_end = 0, end_margin_start = 0, end_margin_end = 0;
+    bool use_aabb = false;
+    static VisibilityRange abrupt(float start, float end) { return VisibilityRange{start, start, end, end, false}; }  // range.rs:135-141
+    // is_visible_at_all (range.rs:159-161): what check_visibility_ranges asks per (entity, view)
+    bool is_visible_at_all(float camera_distance) const { return camera_distance >= start_margin_start && camera_distance < end_margin_end; }
+};
+// What the shadow-view systems read of a light (crates/bevy_light/src/lib.rs:342-757).  The frusta are INPUTS here, as they are for the
+// reference's systems: build_directional_light_cascades / update_directional_light_frusta, update_point_light_frusta and
+// update_spot_light_frusta stay the stock systems (per light, not per entity) and run in front of SimulationLightSystems::CheckLightVisibility.
+struct Frustum6 {
+    float half_spaces[24];
+};
+struct DirectionalLight {                          // DirectionalLight + CascadesFrusta
+    bool shadow_maps_enabled = true;
+    std::vector<std::vector<Frustum6>> cascades;   // CascadesFrusta::frusta: per view (index into the frame's views), one frustum per cascade
+};
+struct PointLightShadows {                         // PointLight::shadow_maps_enabled + CubemapFrusta
+    bool shadow_maps_enabled = true;
+    Frustum6 cubemap_frusta[6];
+};
+struct SpotLightShadows {                          // SpotLight::shadow_maps_enabled + Frustum
+    bool shadow_maps_enabled = true;
+    Frustum6 frustum;
+};
+
 // The slice of the ECS the path touches: dense per-entity columns plus the change flags the systems read.
 struct MeshBinning {
     uint64_t batch_set_key = 0;  // BinnedPhaseItem::BatchSetKey, ordered (phase.multidrawable_meshes is an IndexMap sorted by key)
@@ -167,6 +194,7 @@ class World {
         remove_parent(e);
         Rec& r = rec(e);
         if (r.point_light_range || r.spot_light || r.rect_light_range || r.light_probe || r.decal) ++lights_version_;
+        n_shadow_lights_ -= (r.directional_light ? 1u : 0u) + (r.point_shadows ? 1u : 0u) + (r.spot_shadows ? 1u : 0u);
         r.alive = false;
         moved_[e.index] = 0;
         ++r.generation;
@@ -228,6 +256,23 @@ class World {
     bool inherited_visibility(Entity e) const { return rec(e).inherited; }
     bool inherited_visibility_changed(Entity e) const { return rec(e).inherited_changed; }
     void insert_aabb(Entity e, Aabb a) { rec(e).aabb = a; rec(e).bounds_changed = true; touch(e.index); ++bounds_version_; }
+    // RenderLayers (first word), NoFrustumCulling, VisibilityRange: inputs of every visibility closure (visibility/mod.rs:800-846)
+    void insert_render_layers(Entity e, uint32_t mask) { rec(e).render_layers = mask; ++bounds_version_; }
+    void insert_no_frustum_culling(Entity e) { rec(e).no_frustum_culling = true; ++bounds_version_; }
+    void insert_visibility_range(Entity e, VisibilityRange r) { rec(e).visibility_range = r; ++bounds_version_; }
+    // init_resource::<VisibleEntityRanges>() (VisibilityRangePlugin, range.rs:33-40): without it `visible_entity_ranges` is None in every
+    // visibility system and no VisibilityRange hides anything (visibility/mod.rs:814-816 is_some_and)
+    void set_visible_entity_ranges(bool on) { if (visible_entity_ranges_ != on) { visible_entity_ranges_ = on; ++bounds_version_; } }
+    bool visible_entity_ranges() const { return visible_entity_ranges_; }
+    // Mesh3d / NotShadowCaster: the shadow views' query is With<Mesh3d>, Without<NotShadowCaster>, Without<DirectionalLight> (bevy_light/src/lib.rs:355-372)
+    void insert_mesh3d(Entity e) { rec(e).mesh3d = true; ++bounds_version_; }
+    void insert_not_shadow_caster(Entity e) { rec(e).not_shadow_caster = true; ++bounds_version_; }
+    void insert_directional_light(Entity e, DirectionalLight l) { n_shadow_lights_ += rec(e).directional_light ? 0 : 1; rec(e).directional_light = std::move(l); ++bounds_version_; }
+    DirectionalLight& directional_light_mut(Entity e) { return *rec(e).directional_light; }
+    void insert_point_light_shadows(Entity e, PointLightShadows s) { n_shadow_lights_ += rec(e).point_shadows ? 0 : 1; rec(e).point_shadows = s; }
+    void insert_spot_light_shadows(Entity e, SpotLightShadows s) { n_shadow_lights_ += rec(e).spot_shadows ? 0 : 1; rec(e).spot_shadows = s; }
+    PointLightShadows& point_light_shadows_mut(Entity e) { return *rec(e).point_shadows; }
+    SpotLightShadows& spot_light_shadows_mut(Entity e) { return *rec(e).spot_shadows; }
     void insert_point_light(Entity e, float range) { rec(e).point_light_range = range; ++lights_version_; ++bounds_version_; }  // PointLight { range, .. }
     void insert_spot_light(Entity e, float range, float outer_angle) {  // SpotLight { range, outer_angle, .. }
         rec(e).spot_light = std::make_pair(range, outer_angle);
@@ -250,6 +295,7 @@ class World {
     void remove_mesh_binning(Entity e) { rec(e).binning.reset(); ++binning_version_; }
     bool view_visibility(Entity e) const { rec(e); return (vv_[e.index] & 1u) != 0; }  // ViewVisibility::get
     bool view_visibility_changed(Entity e) const { rec(e); return vv_changed_[e.index] != 0; }
+    uint8_t view_visibility_bits(Entity e) const { rec(e); return vv_[e.index]; }  // ViewVisibility's packed byte (bit 0 current, bit 1 previous)
 
     // ---- the stock systems that STAY registered next to the fused frame (they are private in the reference, so a plugin cannot
     // take them out; in the three-system form the device runs them as part of mi_cull and the whole column comes back).
@@ -336,6 +382,12 @@ class World {
         std::optional<bool> light_probe;  // is_reflection_probe
         bool decal = false;
         std::optional<MeshBinning> binning;
+        uint32_t render_layers = 1;  // RenderLayers::default() = layer 0
+        bool no_frustum_culling = false, mesh3d = false, not_shadow_caster = false;
+        std::optional<VisibilityRange> visibility_range;
+        std::optional<DirectionalLight> directional_light;
+        std::optional<PointLightShadows> point_shadows;
+        std::optional<SpotLightShadows> spot_shadows;
         bool transform_changed = false, added = false, parent_changed = false, orphaned = false;
         bool inherited_changed = false;
         bool visibility_changed = false, bounds_changed = false;
@@ -369,7 +421,9 @@ class World {
     uint64_t binning_version_ = 1;
     uint64_t lights_version_ = 1;
     uint64_t visibility_version_ = 1;  // Visibility components written
-    uint64_t bounds_version_ = 1;      // Aabb / light bounds written
+    uint64_t bounds_version_ = 1;      // Aabb / light bounds / layers / ranges / shadow-caster markers written
+    bool visible_entity_ranges_ = false;
+    uint32_t n_shadow_lights_ = 0;     // entities with a DirectionalLight / PointLightShadows / SpotLightShadows
 };
 
 // Clusters + ObjectsInClusterCpu, crates/bevy_light/src/cluster/mod.rs:143-213
@@ -396,6 +450,28 @@ struct ClusterCamera {  // what the per-view setup of assign.rs:342-485 reads
 struct View {  // an active camera: Frustum + RenderLayers (crates/bevy_camera/src/visibility/mod.rs:756-781)
     float frustum[24];
     uint32_t layer_mask = 1;
+    // check_visibility_ranges (range.rs:225-284) gives the first 32 entities of its view query (cameras and ShadowLodOrigins, active
+    // or not) an index in VisibleEntityRanges and measures distances from their GlobalTransform translation; a view past the 32nd
+    // has none, and every ranged entity is out of its range (entity_is_in_range_of_view, range.rs:209-217)
+    Vec3 position{};
+    bool has_range_index = true;
+};
+// get_shadow_lod_origin (bevy_light/src/lib.rs:752-799): the entity point and spot light shadow maps take their LOD distances from
+struct ShadowLodOrigin {
+    Vec3 position{};
+    bool has_range_index = true;
+};
+// CascadesVisibleEntities / CubemapVisibleEntities / VisibleMeshEntities as the shadow-view systems leave them (sorted by Entity,
+// bevy_light/src/lib.rs:489, 664, 745).  A light whose shadow maps are off or that is not visible has empty lists (directional,
+// lib.rs:400-404) or is not listed (point / spot: the systems `continue`, lib.rs:579-581, 674-676).
+struct LightVisibility {
+    struct Directional { Entity light; std::vector<std::vector<std::vector<Entity>>> entities; };  // [view][cascade]
+    struct Point { Entity light; std::vector<Entity> faces[6]; };
+    struct Spot { Entity light; std::vector<Entity> entities; };
+    std::vector<Directional> directional;
+    std::vector<Point> point;
+    std::vector<Spot> spot;
+    uint32_t n_shadow_views = 0;  // mi_views of the device pass
 };
 
 // A handful of threads for the per-frame loops over the tables: the gather of the moved Transforms into the upload windows and the
@@ -550,10 +626,19 @@ class Mi355xPlugin {
         std::vector<std::vector<Entity>> visible_entities;  // per view: VisibleEntities::get(class 0), ascending by Entity
         bool has_clusters = false;
         Clusters clusters;
+        bool has_light_visibility = false;
+        LightVisibility light_visibility;
         uint32_t changed_global_transforms = 0;  // rows written back this frame
         uint32_t device_waits = 0;               // host waits for the device this frame (1 in the steady state)
     };
-    FrameOutput frame(World& w, const std::vector<View>& views, const ClusterCamera* cam = nullptr) {
+    // `shadows` != nullptr: bevy_light's shadow-view systems are part of the schedule (SimulationLightSystems::CheckLightVisibility):
+    // a World with shadow-mapped lights then takes a second device call per frame -- the shadow views depend on what the cameras' pass
+    // found (which lights some camera sees, lib.rs:563-566; a directional light's own ViewVisibility, :400) and on frusta the stock
+    // light systems derive from this frame's GlobalTransforms.
+    struct ShadowSetup {
+        std::optional<ShadowLodOrigin> lod_origin;
+    };
+    FrameOutput frame(World& w, const std::vector<View>& views, const ClusterCamera* cam = nullptr, const ShadowSetup* shadows = nullptr) {
         FrameOutput out;
         const bool rebuilt = sync_structure(w);
         if (rebuilt) out.device_waits += 1;  // (the rebuild path synchronises in mi_columns_resize / its uploads)
@@ -654,17 +739,14 @@ class Mi355xPlugin {
         }
         // ---- run: one call
         const uint32_t static_opt = w.static_transform_optimizations ? 1u : 0u;
+        const bool light_pass = shadows != nullptr && !views.empty() && w.n_shadow_lights_ != 0;
         if (views.empty()) {
             check(mi_propagate(ctx_, (dense && n ? MI_PROPAGATE_ALL_DIRTY : 0u) | (static_opt ? MI_PROPAGATE_STATIC_OPT : 0u)));
         } else {
-            mviews_.resize(views.size());
-            for (size_t v = 0; v < views.size(); ++v) {
-                std::memset(&mviews_[v], 0, sizeof(mi_view));
-                std::memcpy(mviews_[v].frustum, views[v].frustum, sizeof mviews_[v].frustum);
-                mviews_[v].layer_mask = views[v].layer_mask;
-            }
+            camera_views(w, views);
+            // (the light pass closes the frame when there is one: it ORs into ViewVisibility before MarkNewlyHiddenEntitiesInvisible)
             check(mi_propagate_and_cull_views(ctx_, mviews_.data(), (uint32_t)mviews_.size(),
-                                              (dense && n ? 0u : MI_CULL_CHANGED_ROWS) | MI_CULL_END_FRAME | (static_opt ? MI_CULL_STATIC_OPT : 0u) |
+                                              (dense && n ? 0u : MI_CULL_CHANGED_ROWS) | (light_pass ? 0u : MI_CULL_END_FRAME) | (static_opt ? MI_CULL_STATIC_OPT : 0u) |
                                                   (with_clusters ? MI_CULL_WITH_CLUSTERS : 0u)));
         }
         // ---- out: one call, one wait, read in place
@@ -715,6 +797,13 @@ class Mi355xPlugin {
                     list.push_back(e);
                 }
             }
+            if (light_pass) {  // SimulationLightSystems::CheckLightVisibility: after CheckVisibility, before MarkNewlyHiddenEntitiesInvisible
+                shadow_views(w, views, out.visible_entities, shadows->lod_origin, /*end_frame=*/true, out.light_visibility);
+                out.has_light_visibility = true;
+                out.device_waits += 1;
+                for (uint32_t row = 0; row < n; ++row)
+                    if ((light_any_[row >> 5] >> (row & 31)) & 1u) w.set_visible(entity_of_row_[row]);  // lib.rs:499-510, 629, 723
+            } else if (shadows) out.has_light_visibility = true;  // (no shadow-mapped light: nothing to list)
             w.mark_newly_hidden_entities_invisible();
         }
         if (with_clusters) {  // in front of SimulationLightSystems::AssignLightsToClusters
@@ -758,24 +847,29 @@ class Mi355xPlugin {
         }
     }
 
-    // VisibilitySystems::CheckVisibility .. MarkNewlyHiddenEntitiesInvisible
-    void check_visibility(World& w, const std::vector<View>& views) {
+    // VisibilitySystems::CheckVisibility .. MarkNewlyHiddenEntitiesInvisible.  close_frame = false: the shadow-view systems follow
+    // (check_light_mesh_visibility below), which OR into ViewVisibility before the newly hidden entities are marked.
+    void check_visibility(World& w, const std::vector<View>& views, bool close_frame = true) {
         sync_structure(w);
         const uint32_t n = (uint32_t)entity_of_row_.size();
         if (n == 0 || views.empty()) return;
         upload_bounds(w);
-        std::vector<float> fr;
-        std::vector<uint32_t> masks;
-        for (const View& v : views) { fr.insert(fr.end(), v.frustum, v.frustum + 24); masks.push_back(v.layer_mask); }
-        check(mi_cull(ctx_, fr.data(), masks.data(), nullptr, (uint32_t)views.size(), MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME));
-        std::vector<uint8_t> vv(n);
-        std::vector<uint32_t> chg((n + 31) / 32);
-        check(mi_download_view_visibility(ctx_, 0, n, vv.data(), chg.data()));
-        for (uint32_t row = 0; row < n; ++row) {
-            const uint32_t i = entity_of_row_[row].index;
-            w.vv_[i] = vv[row];
-            if ((chg[row >> 5] >> (row & 31)) & 1u) w.vv_changed_[i] = 1;
-        }
+        camera_views(w, views);
+        check(mi_cull_views(ctx_, mviews_.data(), (uint32_t)mviews_.size(), MI_CULL_BEGIN_FRAME | (close_frame ? MI_CULL_END_FRAME : 0u)));
+        fetch_view_visibility(w);
+    }
+    // SimulationLightSystems::CheckLightVisibility = check_dir_light_mesh_visibility + check_point_light_mesh_visibility
+    // (crates/bevy_light/src/lib.rs:342-515, 517-757) followed by MarkNewlyHiddenEntitiesInvisible, after check_visibility(.., false).
+    // camera_visible_entities = the cameras' VisibleEntities of this frame (which lights some camera sees, lib.rs:563-566).
+    LightVisibility check_light_mesh_visibility(World& w, const std::vector<View>& views, const std::vector<std::vector<Entity>>& camera_visible_entities,
+                                                const std::optional<ShadowLodOrigin>& lod_origin) {
+        LightVisibility out;
+        sync_structure(w);
+        if (entity_of_row_.empty()) return out;
+        upload_bounds(w);
+        shadow_views(w, views, camera_visible_entities, lod_origin, /*end_frame=*/true, out);
+        fetch_view_visibility(w);
+        return out;
     }
     // VisibleEntities::get(class) of one view: entities in ascending Entity order (visibility/mod.rs:861-874)
     std::vector<Entity> visible_entities(uint32_t view) {
@@ -899,6 +993,110 @@ class Mi355xPlugin {
         if (rc == MI_ERR_MALFORMED_HIERARCHY) throw std::logic_error("malformed hierarchy (the reference panics here): " + msg);
         throw std::runtime_error("bevy_mi355x error " + std::to_string(rc) + ": " + msg);
     }
+    // mi_view of every camera: frustum, RenderLayers, and -- with a VisibleEntityRanges resource -- the view's index / position
+    void camera_views(const World& w, const std::vector<View>& views) {
+        mviews_.resize(views.size());
+        for (size_t v = 0; v < views.size(); ++v) {
+            mi_view& m = mviews_[v];
+            std::memset(&m, 0, sizeof(mi_view));
+            std::memcpy(m.frustum, views[v].frustum, sizeof m.frustum);
+            m.layer_mask = views[v].layer_mask;
+            if (w.visible_entity_ranges_ && views[v].has_range_index) {
+                m.flags |= MI_VIEW_FLAG_RANGES;
+                std::memcpy(m.position, &views[v].position, 12);
+            }
+        }
+    }
+    void fetch_view_visibility(World& w) {  // the three-system form: the whole column and its change mask come back
+        const uint32_t n = (uint32_t)entity_of_row_.size();
+        std::vector<uint8_t> vv(n);
+        std::vector<uint32_t> chg((n + 31) / 32);
+        check(mi_download_view_visibility(ctx_, 0, n, vv.data(), chg.data()));
+        for (uint32_t row = 0; row < n; ++row) {
+            const uint32_t i = entity_of_row_[row].index;
+            w.vv_[i] = vv[row];
+            if ((chg[row >> 5] >> (row & 31)) & 1u) w.vv_changed_[i] = 1;
+        }
+    }
+    // The frame's shadow views in the order the two systems visit them, one mi_check_light_mesh_visibility, the masks turned into the
+    // lights' lists.  light_any_ = the rows set_visible() is called on.
+    void shadow_views(World& w, const std::vector<View>& views, const std::vector<std::vector<Entity>>& camera_visible_entities,
+                      const std::optional<ShadowLodOrigin>& lod_origin, bool end_frame, LightVisibility& out) {
+        const uint32_t n = (uint32_t)entity_of_row_.size();
+        const bool ranges = w.visible_entity_ranges_;
+        std::vector<mi_view> sv;
+        struct Slot { int kind; size_t light, a, b; };  // where view k's list goes: 0 directional [a = view][b = cascade], 1 point face a, 2 spot
+        std::vector<Slot> slots;
+        auto shadow_view = [&](const Frustum6& f, uint32_t kind, uint32_t layer_mask) -> mi_view& {
+            sv.emplace_back();
+            mi_view& m = sv.back();
+            std::memset(&m, 0, sizeof m);
+            std::memcpy(m.frustum, f.half_spaces, sizeof m.frustum);
+            m.layer_mask = layer_mask;
+            m.flags = kind;
+            return m;
+        };
+        // check_dir_light_mesh_visibility: directional lights in query order; cascades keyed by camera view (lib.rs:377-424)
+        for (Entity e : w.entities()) {
+            const World::Rec& r = w.rec_[e.index];
+            if (!r.directional_light) continue;
+            out.directional.push_back({e, {}});
+            if (!r.directional_light->shadow_maps_enabled || !(w.vv_[e.index] & 1u)) continue;  // lib.rs:400-404: entities.clear()
+            auto& lists = out.directional.back().entities;
+            lists.resize(r.directional_light->cascades.size());
+            for (size_t v = 0; v < r.directional_light->cascades.size() && v < views.size(); ++v) {
+                lists[v].resize(r.directional_light->cascades[v].size());
+                for (size_t c = 0; c < r.directional_light->cascades[v].size(); ++c) {
+                    mi_view& m = shadow_view(r.directional_light->cascades[v][c], MI_VIEW_KIND_CASCADE, r.render_layers);
+                    if (ranges && views[v].has_range_index) {  // entity_is_in_range_of_view(entity, *view): the cascade's camera (lib.rs:437-443)
+                        m.flags |= MI_VIEW_FLAG_RANGES;
+                        std::memcpy(m.position, &views[v].position, 12);
+                    }
+                    slots.push_back({0, out.directional.size() - 1, v, c});
+                }
+            }
+        }
+        // check_point_light_mesh_visibility: the lights some camera sees, each once, in the order the views' lists yield them (lib.rs:563-569)
+        std::vector<uint8_t> checked(w.rec_.size(), 0);
+        for (const std::vector<Entity>& visible : camera_visible_entities)
+            for (Entity e : visible) {
+                if (checked[e.index]) continue;
+                checked[e.index] = 1;
+                const World::Rec& r = w.rec_[e.index];
+                const bool point = r.point_light_range && r.point_shadows, spot = r.spot_light && r.spot_shadows;
+                if (!point && !spot) continue;
+                if (!(point ? r.point_shadows->shadow_maps_enabled : r.spot_shadows->shadow_maps_enabled)) continue;  // lib.rs:579-581, 674-676
+                const float* g = w.global_[e.index].cols;
+                const float range = point ? *r.point_light_range : r.spot_light->first;
+                if (point) out.point.push_back({e, {}});
+                else out.spot.push_back({e, {}});
+                for (size_t f = 0; f < (point ? 6u : 1u); ++f) {
+                    mi_view& m = shadow_view(point ? r.point_shadows->cubemap_frusta[f] : r.spot_shadows->frustum, MI_VIEW_KIND_CUBE_FACE_OR_SPOT, r.render_layers);
+                    const float sphere[4] = {g[9], g[10], g[11], range};  // Sphere { center: transform.translation(), radius: range } (lib.rs:584-587)
+                    std::memcpy(m.light_sphere, sphere, sizeof sphere);
+                    if (ranges) {  // lib.rs:601-611: no origin, or an origin without an index -> ranged entities are culled
+                        if (lod_origin && lod_origin->has_range_index) {
+                            m.flags |= MI_VIEW_FLAG_RANGES;
+                            std::memcpy(m.position, &lod_origin->position, 12);
+                        } else m.flags |= MI_VIEW_FLAG_RANGES_NO_ORIGIN;
+                    }
+                    slots.push_back({point ? 1 : 2, point ? out.point.size() - 1 : out.spot.size() - 1, f, 0});
+                }
+            }
+        out.n_shadow_views = (uint32_t)sv.size();
+        const size_t words = ((size_t)n + 31) / 32;
+        light_masks_.assign(std::max<size_t>(sv.size() * words, 1), 0u);
+        light_any_.assign(std::max<size_t>(words, 1), 0u);
+        check(mi_check_light_mesh_visibility(ctx_, sv.data(), (uint32_t)sv.size(), end_frame ? MI_CULL_END_FRAME : 0u, light_masks_.data(), light_any_.data()));
+        for (size_t k = 0; k < slots.size(); ++k) {
+            const Slot& sl = slots[k];
+            std::vector<Entity>& list = sl.kind == 0 ? out.directional[sl.light].entities[sl.a][sl.b] : sl.kind == 1 ? out.point[sl.light].faces[sl.a] : out.spot[sl.light].entities;
+            const uint32_t* mask = light_masks_.data() + k * words;
+            for (size_t wd = 0; wd < words; ++wd)
+                for (uint32_t bits = mask[wd]; bits; bits &= bits - 1) list.push_back(entity_of_row_[wd * 32 + (uint32_t)__builtin_ctz(bits)]);
+            std::sort(list.begin(), list.end(), [](Entity a, Entity b) { return a.to_bits() < b.to_bits(); });  // sort_unstable (rows are in level order)
+        }
+    }
     // Entity -> row table.  Rebuilt (level order via mi_hierarchy_sort, full column upload) whenever entities were
     // spawned / despawned or a ChildOf changed; otherwise only dirty rows travel.
     bool sync_structure(World& w) {
@@ -1018,12 +1216,22 @@ class Mi355xPlugin {
         const uint32_t n = (uint32_t)entity_of_row_.size();
         if (!bounds_dirty_ && seen_bounds_ == w.bounds_version_) return;
         seen_bounds_ = w.bounds_version_;
-        std::vector<float> c(3 * (size_t)n, 0.f), h(3 * (size_t)n, 0.f);
+        std::vector<float> c(3 * (size_t)n, 0.f), h(3 * (size_t)n, 0.f), ranges(2 * (size_t)n, 0.f);
         std::vector<uint8_t> flags(n);
+        std::vector<uint32_t> layers(n);
         for (uint32_t row = 0; row < n; ++row) {
             const World::Rec& e = w.rec_[entity_of_row_[row].index];
             // entities without the visibility components never enter the query; without Visibility they default visible
-            flags[row] = (uint8_t)(((!e.has_visibility || e.inherited) ? MI_FLAG_INHERITED_VISIBLE : 0u) | (e.aabb ? MI_FLAG_HAS_AABB : 0u));
+            flags[row] = (uint8_t)(((!e.has_visibility || e.inherited) ? MI_FLAG_INHERITED_VISIBLE : 0u) | (e.aabb ? MI_FLAG_HAS_AABB : 0u) |
+                                   (e.no_frustum_culling ? MI_FLAG_NO_FRUSTUM_CULLING : 0u) |
+                                   // the shadow views' query: With<Mesh3d>, Without<NotShadowCaster>, Without<DirectionalLight> (bevy_light/src/lib.rs:355-372)
+                                   ((e.mesh3d && !e.not_shadow_caster && !e.directional_light) ? MI_FLAG_SHADOW_CASTER : 0u));
+            layers[row] = e.render_layers;
+            if (e.visibility_range) {  // Has<VisibilityRange>; the two bounds is_visible_at_all reads (range.rs:159-161); use_aabb (:255-263)
+                flags[row] |= (uint8_t)(MI_FLAG_HAS_VISIBILITY_RANGE | (e.visibility_range->use_aabb ? MI_FLAG_RANGE_USE_AABB : 0u));
+                ranges[2 * (size_t)row] = e.visibility_range->start_margin_start;
+                ranges[2 * (size_t)row + 1] = e.visibility_range->end_margin_end;
+            }
             if (e.aabb) { std::memcpy(&c[3 * (size_t)row], &e.aabb->center, 12); std::memcpy(&h[3 * (size_t)row], &e.aabb->half_extents, 12); }
             else if (e.point_light_range || e.spot_light) {
                 // a point light is culled by its bounding Sphere { GlobalTransform::translation, range } (update_point_light_bounding_spheres,
@@ -1034,7 +1242,9 @@ class Mi355xPlugin {
                 std::memcpy(&h[3 * (size_t)row + 1], &at_translation, 4);
             }
         }
-        check(mi_upload_bounds(ctx_, 0, n, c.data(), h.data(), flags.data(), nullptr));
+        check(mi_upload_bounds(ctx_, 0, n, c.data(), h.data(), flags.data(), layers.data()));
+        // Option<Res<VisibleEntityRanges>>: no resource = no range column (visibility/mod.rs:814-816)
+        check(mi_upload_visibility_ranges(ctx_, 0, n, w.visible_entity_ranges_ ? ranges.data() : nullptr));
         bounds_dirty_ = false;
     }
 
@@ -1093,6 +1303,7 @@ class Mi355xPlugin {
         return *pool_;
     }
     std::vector<mi_view> mviews_;
+    std::vector<uint32_t> light_masks_, light_any_;  // mi_check_light_mesh_visibility's outputs
     std::vector<Entity> light_entities_;
     bool lights_any_spot_ = false;
     bool probes_or_decals_with_parents_ = false;  // (sync_lights: such a World's object list is gathered anew every frame)

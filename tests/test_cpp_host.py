@@ -48,6 +48,31 @@ def test_reference_system_tests_against_the_host_layer():
     assert "32 tests, 0 failed" in res.stdout  # 17 tests against the three systems (two of them drive both forms themselves), 15 of them again against the fused frame
 
 
+def test_host_visibility_test_compiles_and_links():
+    """tests/cpp/host_visibility_test.cpp (VisibilityRange + shadow views behind the host layer, against the oracle)."""
+    import oracle_lib
+    mi_build.build()
+    oracle_lib.build()
+    exe = mi_build.build_host_visibility_test(force=True)
+    assert os.path.exists(exe) and os.access(exe, os.X_OK)
+
+
+@pytest.mark.gpu
+def test_visibility_ranges_and_shadow_views_behind_the_host_layer():
+    """VisibilityRange (visibility/range.rs:159-284, mod.rs:814-820) and check_dir_light_mesh_visibility / check_point_light_mesh_visibility
+    (bevy_light/src/lib.rs:342-757) through the C++ plugin in both boundary forms: known answers, then random Worlds over four frames
+    against the oracle (lists of every cascade / cube face / spot light, ViewVisibility bytes, change ticks)."""
+    import oracle_lib
+    mi_build.build()
+    oracle_lib.build()
+    exe = mi_build.build_host_visibility_test()
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    print(res.stdout)
+    failed = [line for line in res.stdout.splitlines() if line.startswith("FAILED") or "EXCEPTION" in line]
+    assert res.returncode == 0 and not failed, res.stdout[-3000:] + res.stderr[-1000:]
+    assert "6 tests, 0 failed" in res.stdout
+
+
 def test_single_process_multi_gpu_driver_compiles():
     mi_build.build()
     exe = mi_build.build_multi_gpu_test(force=True)

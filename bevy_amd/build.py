@@ -117,30 +117,6 @@ def build_host_tests(force=False):
     return exe
 
 
-HOST_VIS_TEST_SRC = os.path.join(HERE, "..", "tests", "cpp", "host_visibility_test.cpp")
-HOST_VIS_TEST_EXE = os.path.join(HERE, "..", "tests", "cpp", "host_visibility_test")
-
-
-def build_host_visibility_test(force=False):
-    """tests/cpp/host_visibility_test.cpp: VisibilityRange and the shadow-view systems behind the C++ host layer, checked against the CPU
-    oracle -- so this one test program links oracle/libbevy_oracle.so (the checker) next to the library.  host_systems_test, whose
-    --bench mode bench.py runs, does not."""
-    exe, src = os.path.abspath(HOST_VIS_TEST_EXE), os.path.abspath(HOST_VIS_TEST_SRC)
-    oracle_dir = os.path.abspath(os.path.join(HERE, "..", "oracle"))
-    deps = [src, HOST_HEADER, LIB, os.path.join(CSRC, "glam_math.h"), os.path.join(CSRC, "..", "..", "include", "bevy_mi355x.h"),
-            os.path.join(oracle_dir, "libbevy_oracle.so"), os.path.join(oracle_dir, "bevy_oracle.h")]
-    if not force and os.path.exists(exe) and all(os.path.getmtime(d) <= os.path.getmtime(exe) for d in deps):
-        return exe
-    cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-Wall", src, "-o", exe, "-L", HERE, "-lbevy_mi355x",
-           "-L", oracle_dir, "-lbevy_oracle", "-Wl,-rpath,$ORIGIN/../../bevy_amd", "-Wl,-rpath,$ORIGIN/../../oracle", "-Wl,-rpath,/opt/rocm/lib",
-           "-Wl,--allow-shlib-undefined"]
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        sys.stderr.write(res.stdout + res.stderr)
-        raise RuntimeError("g++ failed building tests/cpp/host_visibility_test")
-    return exe
-
-
 MULTI_GPU_SRC = os.path.join(HERE, "..", "tests", "cpp", "multi_gpu_single_process.cpp")
 MULTI_GPU_EXE = os.path.join(HERE, "..", "tests", "cpp", "multi_gpu_single_process")
 

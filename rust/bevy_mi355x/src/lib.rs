@@ -9,6 +9,8 @@
 //! |   (crates/bevy_transform/src/systems.rs:42-79, 111-306, 506-748)                            |                                     |
 //! | `check_visibility_cpu_culling` (crates/bevy_camera/src/visibility/mod.rs:748-880)           | [`mi_check_visibility`]             |
 //! | `assign_objects_to_clusters` (crates/bevy_light/src/cluster/assign.rs:137-813)              | [`mi_assign_objects_to_clusters`]   |
+//! | `check_dir_light_mesh_visibility`, `check_point_light_mesh_visibility`                      | [`mi_check_light_mesh_visibility`]  |
+//! |   (crates/bevy_light/src/lib.rs:342-515, 517-757)                                           |                                     |
 //!
 //! With `fused: true` (the default) the three collapse into ONE device round trip per frame: [`mi_fused_frame`], placed in
 //! `TransformSystems::Propagate`, uploads the changed `Transform`s, issues `mi_propagate_and_cull_views(MI_CULL_CHANGED_ROWS |
@@ -61,28 +63,32 @@ use core::ptr;
 
 use bevy_app::{App, Plugin, PostStartup, PostUpdate};
 use bevy_camera::{
-    primitives::{Aabb, Frustum, Sphere},
+    primitives::{Aabb, CascadesFrusta, CubemapFrusta, Frustum, Sphere},
     visibility::{
-        check_visibility_cpu_culling, InheritedVisibility, NoCpuCulling, NoFrustumCulling, RenderLayers, SetViewVisibility,
-        ViewVisibility, VisibilityClass, VisibilityRange, VisibilitySystems, VisibleEntities,
+        check_visibility_cpu_culling, CascadesVisibleEntities, CubemapVisibleEntities, InheritedVisibility, NoCpuCulling,
+        NoFrustumCulling, RenderLayers, SetViewVisibility, ViewVisibility, VisibilityClass, VisibilityRange, VisibilitySystems,
+        VisibleEntities, VisibleEntityRanges, VisibleMeshEntities,
     },
-    Camera, CameraUpdateSystems,
+    Camera, CameraUpdateSystems, RenderTarget, ShadowLodOrigin,
 };
 use bevy_ecs::{
     change_detection::Tick,
-    entity::{Entity, EntityHashMap},
+    entity::{Entity, EntityHashMap, EntityHashSet},
     prelude::*,
     schedule::{IntoScheduleConfigs, ScheduleCleanupPolicy::RemoveSystemsOnly, ScheduleLabel},
     system::SystemChangeTick,
 };
 use bevy_light::{
+    check_dir_light_mesh_visibility, check_point_light_mesh_visibility,
     cluster::{
-        ClusterConfig, ClusterFarZMode, ClusterableObjects, Clusters, GlobalClusterSettings, ObjectsInClusterCpu,
+        ClusterConfig, ClusterFarZMode, ClusterVisibilityClass, ClusterableObjects, Clusters, GlobalClusterSettings, ObjectsInClusterCpu,
     },
-    ClusteredDecal, EnvironmentMapLight, LightProbe, PointLight, RectLight, SimulationLightSystems, SpotLight, VolumetricLight,
+    get_shadow_lod_origin, ClusteredDecal, DirectionalLight, EnvironmentMapLight, LightProbe, NotShadowCaster, PointLight, RectLight,
+    SimulationLightSystems, SpotLight, VolumetricLight,
 };
 use bevy_log::error;
 use bevy_math::{Affine3A, UVec2, UVec3};
+use bevy_mesh::Mesh3d;
 use bevy_platform::collections::HashMap;
 use bevy_transform::{
     components::{GlobalTransform, Transform},
@@ -97,8 +103,12 @@ pub struct CpuFallback {
     pub transforms: bool,
     pub visibility: bool,
     pub clusters: bool,
+    pub light_visibility: bool,
 }
 
+fn light_visibility_fell_back(f: Res<CpuFallback>) -> bool {
+    f.light_visibility
+}
 fn transforms_fell_back(f: Res<CpuFallback>) -> bool {
     f.transforms
 }
@@ -136,6 +146,9 @@ pub struct Mi355x {
     /// `MI_UPLOAD_ROTATION` and sends 16 bytes per moved row instead of 40.  A component that is not carried keeps the value of the
     /// last full upload (every structural rebuild sends all three) -- setting this while a system writes the others is the app's bug.
     pub upload_components: u32,
+    /// Whether the device's VisibilityRange column was last staged with a `VisibleEntityRanges` resource present (`None`: never staged).
+    /// `Option<Res<VisibleEntityRanges>>` being `None` means no range hides anything (visibility/mod.rs:814-816): no column then.
+    ranges_resource: Option<bool>,
     scratch: Scratch,
 }
 
@@ -178,6 +191,10 @@ struct Scratch {
     cl_offsets: Vec<u32>,
     cl_counts: Vec<u32>,
     cl_indices: Vec<u32>,
+    ranges: Vec<f32>, // VisibilityRange (start_margin.start, end_margin.end) per row (mi_upload_visibility_ranges)
+    shadow_views: Vec<ffi::MiView>,
+    light_masks: Vec<u32>, // mi_check_light_mesh_visibility: [view][ceil(n / 32)]
+    light_any: Vec<u32>,
 }
 
 // SAFETY: the context is only used through `ResMut<Mi355x>`, i.e. by one system at a time, which is the library's contract
@@ -207,6 +224,7 @@ impl Mi355x {
                 rows_in_table_order: false,
                 every_row_moved: false,
                 upload_components: 0,
+                ranges_resource: None,
                 sphere_storage: Vec::new(),
                 scratch: Scratch::default(),
             })
@@ -309,6 +327,27 @@ impl Plugin for Mi355xRenderPrepPlugin {
                 .in_set(VisibilitySystems::CheckVisibility),
         );
 
+        // --- shadow views: check_dir_light_mesh_visibility and check_point_light_mesh_visibility are both `pub` (crates/bevy_light/src/
+        //     lib.rs:342, 517); one system over the device columns takes their place in SimulationLightSystems::CheckLightVisibility with
+        //     the stock ordering (lib.rs:217-230), the stock pair right behind it for the frames it gives up on.
+        take_out(app, PostUpdate, check_dir_light_mesh_visibility);
+        take_out(app, PostUpdate, check_point_light_mesh_visibility);
+        app.add_systems(
+            PostUpdate,
+            (
+                mi_check_light_mesh_visibility,
+                (check_dir_light_mesh_visibility, check_point_light_mesh_visibility).run_if(light_visibility_fell_back),
+            )
+                .chain()
+                .in_set(SimulationLightSystems::CheckLightVisibility)
+                .after(VisibilitySystems::CalculateBounds)
+                .after(TransformSystems::Propagate)
+                .after(SimulationLightSystems::UpdateLightFrusta)
+                // lights mark the shadow casters they see visible before the newly hidden ones are marked (lib.rs:224-229)
+                .after(VisibilitySystems::CheckVisibility)
+                .before(VisibilitySystems::MarkNewlyHiddenEntitiesInvisible),
+        );
+
         // --- clusters: gate the stock set, run the replacement right in front of it with the stock ordering constraints
         //     (crates/bevy_light/src/lib.rs:187-191).
         app.configure_sets(PostUpdate, SimulationLightSystems::AssignLightsToClusters.run_if(clusters_fell_back));
@@ -331,6 +370,61 @@ fn take_out<M>(app: &mut App, schedule: impl ScheduleLabel, system: impl IntoSys
     if let Err(e) = app.remove_systems_in_set(schedule, system, RemoveSystemsOnly) {
         error!("bevy_mi355x: a stock system could not be taken out of its schedule ({e}); add Mi355xRenderPrepPlugin after DefaultPlugins");
     }
+}
+
+/// The rows of the visibility columns: `visible_aabb_query` of `check_visibility_cpu_culling` (visibility/mod.rs:757-772) plus what the
+/// shadow-view systems' query filters on (`With<Mesh3d>, Without<NotShadowCaster>, Without<DirectionalLight>`,
+/// crates/bevy_light/src/lib.rs:355-372 -> `MI_FLAG_SHADOW_CASTER`).
+type RowsQuery<'w, 's> = Query<
+    'w,
+    's,
+    (
+        Entity,
+        &'static InheritedVisibility,
+        Option<&'static VisibilityClass>,
+        Option<&'static RenderLayers>,
+        Option<&'static Aabb>,
+        Option<&'static Sphere>,
+        Option<&'static PointLight>,
+        Option<&'static SpotLight>,
+        Has<NoFrustumCulling>,
+        Option<&'static VisibilityRange>,
+        Has<Mesh3d>,
+        Has<NotShadowCaster>,
+        Has<DirectionalLight>,
+    ),
+    Without<NoCpuCulling>,
+>;
+/// "Some input of the rarely-changing columns was written" (what `stage_bounds` re-stages for).
+type BoundsChanged<'w, 's> = Query<
+    'w,
+    's,
+    (),
+    Or<(
+        Changed<Aabb>,
+        Changed<Sphere>,
+        Changed<InheritedVisibility>,
+        Changed<RenderLayers>,
+        Changed<VisibilityClass>,
+        Added<NoFrustumCulling>,
+        Changed<VisibilityRange>,
+        Added<Mesh3d>,
+        Added<NotShadowCaster>,
+    )>,
+>;
+/// The view query of `check_visibility_ranges` (visibility/range.rs:228): its first 32 entities get an index in `VisibleEntityRanges`.
+type RangeViews<'w, 's> = Query<'w, 's, (Entity, &'static GlobalTransform), Or<(With<Camera>, With<ShadowLodOrigin>)>>;
+
+/// The entities `check_visibility_ranges` gives an index (range.rs:238-243: `.take(32)` of its view query, cameras and
+/// `ShadowLodOrigin`s, active or not) with the translation it measures distances from (`view_transform.translation_vec3a()`).  A view
+/// that is not in here has no index: `entity_is_in_range_of_view` is false for every ranged entity (range.rs:209-217) -- the device does
+/// the same for a view without `MI_VIEW_FLAG_RANGES`.
+fn range_view_table(range_views: &RangeViews) -> EntityHashMap<[f32; 3]> {
+    let mut table = EntityHashMap::default();
+    for (entity, global) in range_views.iter().take(32) {
+        table.insert(entity, global.translation().to_array());
+    }
+    table
 }
 
 #[inline]
@@ -626,21 +720,10 @@ pub fn mi_check_visibility(
     mut fallback: ResMut<CpuFallback>,
     ticks: SystemChangeTick,
     mut view_query: Query<(Entity, &mut VisibleEntities, &Frustum, Option<&RenderLayers>, &Camera, Has<NoCpuCulling>)>,
-    bounds_changed: Query<
-        (),
-        Or<(
-            Changed<Aabb>,
-            Changed<Sphere>,
-            Changed<InheritedVisibility>,
-            Changed<RenderLayers>,
-            Changed<VisibilityClass>,
-            Added<NoFrustumCulling>,
-        )>,
-    >,
-    rows_query: Query<
-        (Entity, &InheritedVisibility, Option<&VisibilityClass>, Option<&RenderLayers>, Option<&Aabb>, Option<&Sphere>, Option<&PointLight>, Option<&SpotLight>, Has<NoFrustumCulling>, Has<VisibilityRange>),
-        Without<NoCpuCulling>,
-    >,
+    bounds_changed: BoundsChanged,
+    rows_query: RowsQuery,
+    range_views: RangeViews,
+    visible_entity_ranges: Option<Res<VisibleEntityRanges>>,
     mut view_visibilities: Query<&mut ViewVisibility, Without<NoCpuCulling>>,
 ) {
     let _ = ticks;
@@ -654,10 +737,13 @@ pub fn mi_check_visibility(
     let n = mi.row_entity.len() as u32;
 
     let result: Result<(), ()> = (|| {
-        // --- columns that change rarely: re-staged only when one of them changed
-        if !bounds_changed.is_empty() {
-            stage_bounds(mi, &rows_query)?;
+        // --- columns that change rarely: re-staged only when one of them changed (or the VisibleEntityRanges resource came / went)
+        let ranges_on = visible_entity_ranges.is_some();
+        if !bounds_changed.is_empty() || mi.ranges_resource != Some(ranges_on) {
+            stage_bounds(mi, &rows_query, ranges_on)?;
         }
+        // (this system runs behind check_visibility_ranges and TransformSystems::Propagate: the views' GlobalTransforms are this frame's)
+        let range_table = if ranges_on { range_view_table(&range_views) } else { EntityHashMap::default() };
 
         // --- the frame's views: active cameras in query order (visibility/mod.rs:778-784)
         let s = &mut mi.scratch;
@@ -671,11 +757,13 @@ pub fn mi_check_visibility(
                 None => (1, 0),
                 Some(l) => layer_words_or_log(l)?,
             };
+            // visibility/mod.rs:814-820: with the resource, a ranged entity is tested against THIS view's index and position
+            let range_origin = range_table.get(&entity);
             let mut view = ffi::MiView {
                 frustum: [0.0; 24],
                 layer_mask,
-                flags: if no_cpu_culling { ffi::MI_VIEW_FLAG_NO_CPU_CULLING } else { 0 },
-                position: [0.0; 3],
+                flags: (if no_cpu_culling { ffi::MI_VIEW_FLAG_NO_CPU_CULLING } else { 0 }) | (if range_origin.is_some() { ffi::MI_VIEW_FLAG_RANGES } else { 0 }),
+                position: range_origin.copied().unwrap_or([0.0; 3]),
                 light_sphere: [0.0; 4],
                 layer_mask_hi,
                 reserved: [0; 2],
@@ -1097,6 +1185,245 @@ pub fn mi_assign_objects_to_clusters(
 }
 
 // =====================================================================================================================
+// Shadow views
+// =====================================================================================================================
+
+/// Where the list of one shadow view goes: `kind` 0 = cascade `index` of (`light`, camera `view`), 1 = cube face `index` of point light
+/// `light`, 2 = spot light `light`.
+struct ShadowList {
+    kind: u8,
+    light: Entity,
+    view: Entity,
+    index: usize,
+}
+
+/// `check_dir_light_mesh_visibility` + `check_point_light_mesh_visibility` (crates/bevy_light/src/lib.rs:342-515, 517-757) on the
+/// device: every cascade of every (directional light, camera) pair, the six cube faces of every shadow-mapped point light and the
+/// frustum of every shadow-mapped spot light some camera sees, as ONE pass over the resident columns (`mi_check_light_mesh_visibility`:
+/// the per-entity closures of lib.rs:425-475, 592-650, 694-738, selected per view by its flags), one device wait.  The survivors
+/// are ORed into `ViewVisibility` (`set_visible`, lib.rs:499-510, 629, 723) -- here on the ECS components, between the cameras' pass
+/// and the stock `mark_newly_hidden_entities_invisible`; on the device into the column the next frame's `reset` reads -- and every
+/// view's `VisibleMeshEntities` is rebuilt, sorted (lib.rs:489, 664, 745).  The light frusta are inputs, as for the stock systems:
+/// `build_directional_light_cascades`, `update_directional_light_frusta`, `update_point_light_frusta`, `update_spot_light_frusta` stay.
+#[allow(clippy::too_many_arguments, clippy::type_complexity)]
+pub fn mi_check_light_mesh_visibility(
+    mut mi: ResMut<Mi355x>,
+    mut fallback: ResMut<CpuFallback>,
+    visible_point_lights: Query<&VisibleEntities>,
+    mut directional_lights: Query<
+        (Entity, &DirectionalLight, &CascadesFrusta, &mut CascadesVisibleEntities, Option<&RenderLayers>, &ViewVisibility),
+        Without<SpotLight>,
+    >,
+    mut point_lights: Query<(&PointLight, &GlobalTransform, &CubemapFrusta, &mut CubemapVisibleEntities, Option<&RenderLayers>)>,
+    mut spot_lights: Query<(&SpotLight, &GlobalTransform, &Frustum, &mut VisibleMeshEntities, Option<&RenderLayers>)>,
+    mut camera_query: Query<(Entity, &RenderTarget), With<Camera>>,
+    mut shadow_lod_origin_query: Query<Entity, With<ShadowLodOrigin>>,
+    mut point_and_spot_light_query: Query<Entity, Or<(With<PointLight>, With<SpotLight>)>>,
+    range_views: RangeViews,
+    visible_entity_ranges: Option<Res<VisibleEntityRanges>>,
+    // (Without<DirectionalLight>: disjoint from `directional_lights`, which reads the lights' own ViewVisibility; the shadow views'
+    // query excludes directional lights anyway, lib.rs:368)
+    mut view_visibilities: Query<&mut ViewVisibility, (Without<NoCpuCulling>, Without<DirectionalLight>)>,
+    mut checked_lights: Local<EntityHashSet>,
+) {
+    if fallback.light_visibility || fallback.visibility || fallback.transforms {
+        // the columns the shadow views are tested against (GlobalTransform, flags, ranges) are no longer kept current
+        fallback.light_visibility = true;
+        return;
+    }
+    let mi = &mut *mi;
+    let ctx = mi.ctx;
+    let n = mi.row_entity.len();
+    let ranges_on = visible_entity_ranges.is_some();
+    let range_table = if ranges_on { range_view_table(&range_views) } else { EntityHashMap::default() };
+    let frustum_planes = |frustum: &Frustum| {
+        let mut planes = [0f32; 24];
+        for (p, half_space) in frustum.half_spaces.iter().enumerate() {
+            planes[p * 4..p * 4 + 4].copy_from_slice(&half_space.normal_d().to_array());
+        }
+        planes
+    };
+    let mut lists: Vec<ShadowList> = Vec::new();
+    let mut views = core::mem::take(&mut mi.scratch.shadow_views);
+    views.clear();
+
+    // ---- directional lights: the bookkeeping of lib.rs:380-404 as it is, one view per cascade (lib.rs:408-475)
+    let gather: Result<(), ()> = (|| {
+        for (light, directional_light, frusta, mut visible_entities, maybe_view_mask, light_view_visibility) in &mut directional_lights {
+            let mut views_to_remove = Vec::new();
+            for (view, cascade_view_entities) in &mut visible_entities.entities {
+                match frusta.frusta.get(view) {
+                    Some(view_frusta) => cascade_view_entities.resize(view_frusta.len(), Default::default()),
+                    None => views_to_remove.push(*view),
+                };
+            }
+            for (view, view_frusta) in &frusta.frusta {
+                visible_entities.entities.entry(*view).or_insert_with(|| vec![VisibleMeshEntities::default(); view_frusta.len()]);
+            }
+            for v in views_to_remove {
+                visible_entities.entities.remove(&v);
+            }
+            // NOTE: If shadow mapping is disabled for the light then it must have no visible entities (lib.rs:400-404)
+            if !directional_light.shadow_maps_enabled || !light_view_visibility.get() {
+                visible_entities.entities.clear();
+                continue;
+            }
+            let (layer_mask, layer_mask_hi) = match maybe_view_mask {
+                None => (1, 0),
+                Some(l) => layer_words_or_log(l)?,
+            };
+            for (view, view_frusta) in &frusta.frusta {
+                // entity_is_in_range_of_view(entity, *view): the cascade's CAMERA is the range view (lib.rs:437-443)
+                let range_origin = range_table.get(view);
+                for (cascade, frustum) in view_frusta.iter().enumerate() {
+                    views.push(ffi::MiView {
+                        frustum: frustum_planes(frustum),
+                        layer_mask,
+                        flags: ffi::MI_VIEW_KIND_CASCADE | (if range_origin.is_some() { ffi::MI_VIEW_FLAG_RANGES } else { 0 }),
+                        position: range_origin.copied().unwrap_or([0.0; 3]),
+                        light_sphere: [0.0; 4],
+                        layer_mask_hi,
+                        reserved: [0; 2],
+                    });
+                    lists.push(ShadowList { kind: 0, light, view: *view, index: cascade });
+                }
+            }
+        }
+
+        // ---- point and spot lights: the ones in some camera's VisibleEntities, each once (lib.rs:559-569)
+        checked_lights.clear();
+        let shadow_lod_origin = get_shadow_lod_origin(
+            camera_query.transmute_lens_filtered(),
+            shadow_lod_origin_query.transmute_lens_filtered(),
+            point_and_spot_light_query.transmute_lens_filtered(),
+        );
+        // lib.rs:601-611: `visible_entity_ranges.is_some_and(|r| shadow_lod_origin.is_none_or(|o| !r.entity_is_in_range_of_view(entity, o)))`
+        // -- no origin, or an origin without an index: every ranged entity is culled
+        let (range_flags, range_position) = if !ranges_on {
+            (0, [0.0; 3])
+        } else {
+            match shadow_lod_origin.and_then(|origin| range_table.get(&origin)) {
+                Some(position) => (ffi::MI_VIEW_FLAG_RANGES, *position),
+                None => (ffi::MI_VIEW_FLAG_RANGES_NO_ORIGIN, [0.0; 3]),
+            }
+        };
+        for visible_lights in &visible_point_lights {
+            for &light_entity in visible_lights.get(TypeId::of::<ClusterVisibilityClass>()) {
+                if !checked_lights.insert(light_entity) {
+                    continue;
+                }
+                if let Ok((point_light, transform, cubemap_frusta, _, maybe_view_mask)) = point_lights.get(light_entity) {
+                    if !point_light.shadow_maps_enabled {
+                        continue; // (lib.rs:579-581; `continue` also skips the spot branch, as there)
+                    }
+                    let (layer_mask, layer_mask_hi) = match maybe_view_mask {
+                        None => (1, 0),
+                        Some(l) => layer_words_or_log(l)?,
+                    };
+                    let center = transform.translation().to_array();
+                    for (face, frustum) in cubemap_frusta.iter().enumerate() {
+                        views.push(ffi::MiView {
+                            frustum: frustum_planes(frustum),
+                            layer_mask,
+                            flags: ffi::MI_VIEW_KIND_CUBE_FACE_OR_SPOT | range_flags,
+                            position: range_position,
+                            light_sphere: [center[0], center[1], center[2], point_light.range], // lib.rs:584-587
+                            layer_mask_hi,
+                            reserved: [0; 2],
+                        });
+                        lists.push(ShadowList { kind: 1, light: light_entity, view: light_entity, index: face });
+                    }
+                }
+                if let Ok((spot_light, transform, frustum, _, maybe_view_mask)) = spot_lights.get(light_entity) {
+                    if !spot_light.shadow_maps_enabled {
+                        continue;
+                    }
+                    let (layer_mask, layer_mask_hi) = match maybe_view_mask {
+                        None => (1, 0),
+                        Some(l) => layer_words_or_log(l)?,
+                    };
+                    let center = transform.translation().to_array();
+                    views.push(ffi::MiView {
+                        frustum: frustum_planes(frustum),
+                        layer_mask,
+                        flags: ffi::MI_VIEW_KIND_CUBE_FACE_OR_SPOT | range_flags,
+                        position: range_position,
+                        light_sphere: [center[0], center[1], center[2], spot_light.range], // lib.rs:679-682
+                        layer_mask_hi,
+                        reserved: [0; 2],
+                    });
+                    lists.push(ShadowList { kind: 2, light: light_entity, view: light_entity, index: 0 });
+                }
+            }
+        }
+        Ok(())
+    })();
+
+    // ---- the device pass.  flags = 0: both camera paths of this plugin have closed the frame on the device already (their
+    //      MI_CULL_END_FRAME); the survivors' bit 0 is ORed into the column the next frame's reset reads, the ECS components get their
+    //      set_visible() below, in front of the stock mark_newly_hidden_entities_invisible.
+    let words = (n + 31) / 32;
+    let run = gather.and_then(|()| {
+        let s = &mut mi.scratch;
+        s.light_masks.clear();
+        s.light_masks.resize((views.len() * words).max(1), 0);
+        s.light_any.clear();
+        s.light_any.resize(words.max(1), 0);
+        // SAFETY: `views` holds `views.len()` entries; the outputs hold views.len() * ceil(n / 32) and ceil(n / 32) words.
+        check(ctx, "mi_check_light_mesh_visibility", unsafe {
+            ffi::mi_check_light_mesh_visibility(ctx, views.as_ptr(), views.len() as u32, 0, s.light_masks.as_mut_ptr(), s.light_any.as_mut_ptr())
+        })
+    });
+    if run.is_err() {
+        mi.scratch.shadow_views = views;
+        fallback.light_visibility = true; // the stock pair, chained right behind, computes this frame (it redoes the bookkeeping above)
+        return;
+    }
+
+    // ---- ECS writes: set_visible() on the union, then every view's list
+    for (w, word) in mi.scratch.light_any[..words].iter().enumerate() {
+        let mut bits = *word;
+        while bits != 0 {
+            let row = w * 32 + bits.trailing_zeros() as usize;
+            bits &= bits - 1;
+            if let Ok(mut view_visibility) = view_visibilities.get_mut(mi.row_entity[row]) {
+                view_visibility.set_visible();
+            }
+        }
+    }
+    for (k, list) in lists.iter().enumerate() {
+        let mask = &mi.scratch.light_masks[k * words..(k + 1) * words];
+        let mut entities: Vec<Entity> = Vec::new();
+        for (w, word) in mask.iter().enumerate() {
+            let mut bits = *word;
+            while bits != 0 {
+                entities.push(mi.row_entity[w * 32 + bits.trailing_zeros() as usize]);
+                bits &= bits - 1;
+            }
+        }
+        entities.sort_unstable(); // lib.rs:489, 664, 745
+        if list.kind == 0 {
+            if let Ok((_, _, _, mut visible_entities, _, _)) = directional_lights.get_mut(list.light) {
+                if let Some(view_dest) = visible_entities.entities.get_mut(&list.view).and_then(|cascades| cascades.get_mut(list.index)) {
+                    view_dest.entities = entities;
+                    view_dest.shrink();
+                }
+            }
+        } else if list.kind == 1 {
+            if let Ok((_, _, _, mut cubemap_visible_entities, _)) = point_lights.get_mut(list.light) {
+                let view_dest = cubemap_visible_entities.get_mut(list.index);
+                view_dest.entities = entities;
+                view_dest.shrink();
+            }
+        } else if let Ok((_, _, _, mut visible_entities, _)) = spot_lights.get_mut(list.light) {
+            visible_entities.entities = entities;
+            visible_entities.shrink();
+        }
+    }
+    mi.scratch.shadow_views = views;
+}
+
+// =====================================================================================================================
 // The fused frame
 // =====================================================================================================================
 
@@ -1170,14 +1497,11 @@ pub fn mi_fused_frame(
     transforms: Query<(Entity, Ref<Transform>, Option<&ChildOf>)>,
     mut globals: Query<&mut GlobalTransform>,
     cameras: Query<(Entity, &Camera, &bevy_camera::Projection, Option<&RenderLayers>, Has<NoCpuCulling>, Option<&ClusterConfig>, Has<Clusters>)>,
-    bounds_changed: Query<
-        (),
-        Or<(Changed<Aabb>, Changed<Sphere>, Changed<InheritedVisibility>, Changed<RenderLayers>, Changed<VisibilityClass>, Added<NoFrustumCulling>)>,
-    >,
-    rows_query: Query<
-        (Entity, &InheritedVisibility, Option<&VisibilityClass>, Option<&RenderLayers>, Option<&Aabb>, Option<&Sphere>, Option<&PointLight>, Option<&SpotLight>, Has<NoFrustumCulling>, Has<VisibilityRange>),
-        Without<NoCpuCulling>,
-    >,
+    bounds_changed: BoundsChanged,
+    rows_query: RowsQuery,
+    // VisibilityRange: whether the resource exists and which views check_visibility_ranges will index this frame (it runs later, in
+    // VisibilitySystems::CheckVisibility; both are functions of the entity set, not of this frame's transforms)
+    (range_views, visible_entity_ranges): (RangeViews, Option<Res<VisibleEntityRanges>>),
     // (one tuple parameter: a system function takes at most 16 parameters, function_system.rs:950)
     (point_lights, spot_lights, rect_lights, light_probes, decals): (
         // (With<ViewVisibility>, With<GlobalTransform>: the reference's queries fetch both, assign.rs:146-178 -- an entity without
@@ -1218,6 +1542,8 @@ pub fn mi_fused_frame(
     // every camera with Clusters (assign.rs:324-486 runs per view): (entity, GlobalTransform, frustum, viewport, config, layers, clip_from_view)
     let mut cluster_cameras: Vec<(Entity, GlobalTransform, [f32; 24], UVec2, ClusterConfig, (u32, u32), [f32; 16])> = Vec::new();
     let mut clustered_cameras = 0;
+    let ranges_on = visible_entity_ranges.is_some();
+    let range_table = if ranges_on { range_view_table(&range_views) } else { EntityHashMap::default() };
     let result: Result<(), ()> = (|| {
         for (entity, camera, projection, layers, no_cpu_culling, config, has_clusters) in cameras.iter() {
             if !camera.is_active {
@@ -1235,11 +1561,14 @@ pub fn mi_fused_frame(
                 None => (1, 0),
                 Some(l) => layer_words_or_log(l)?,
             };
+            // a view with an index in VisibleEntityRanges: distances from the translation the camera is ABOUT to have (check_visibility_ranges
+            // reads its GlobalTransform behind TransformSystems::Propagate, range.rs:245)
+            let indexed = range_table.contains_key(&entity);
             views.push(ffi::MiView {
                 frustum: planes,
                 layer_mask,
-                flags: if no_cpu_culling { ffi::MI_VIEW_FLAG_NO_CPU_CULLING } else { 0 },
-                position: [0.0; 3],
+                flags: (if no_cpu_culling { ffi::MI_VIEW_FLAG_NO_CPU_CULLING } else { 0 }) | (if indexed { ffi::MI_VIEW_FLAG_RANGES } else { 0 }),
+                position: if indexed { global.translation().to_array() } else { [0.0; 3] },
                 light_sphere: [0.0; 4],
                 layer_mask_hi,
                 reserved: [0; 2],
@@ -1254,8 +1583,8 @@ pub fn mi_fused_frame(
             }
         }
         // ---- columns that change rarely (exactly as mi_check_visibility stages them)
-        if !bounds_changed.is_empty() {
-            stage_bounds(mi, &rows_query)?;
+        if !bounds_changed.is_empty() || mi.ranges_resource != Some(ranges_on) {
+            stage_bounds(mi, &rows_query, ranges_on)?;
         }
         // ---- rows in
         upload_and_propagate(mi, false, &ticks, &transforms, &globals.as_readonly(), Some(()))?;
@@ -1319,7 +1648,12 @@ pub fn mi_fused_frame(
                 s.rows.clear();
                 let mut any_spot = false;
                 let mut push = |s: &mut Scratch, e: Entity, range: f32, kind: i32, layers: Option<&RenderLayers>, outer_angle: Option<f32>| -> Result<(), ()> {
-                    let Some(&row) = mi.entity_row.get(&e) else { return Ok(()) };
+                    // (the reference's queries gather this entity, assign.rs:146-178; without a Transform it has no row here: the stock
+                    // system takes the clusters of this frame rather than this one leaving the object out)
+                    let Some(&row) = mi.entity_row.get(&e) else {
+                        error!("bevy_mi355x: a clusterable object without a Transform row -- the stock cluster system takes over");
+                        return Err(());
+                    };
                     s.obj_pos_range.extend_from_slice(&[0.0, 0.0, 0.0, range]); // the centre is the row's GlobalTransform
                     s.obj_type.push(kind as u8);
                     // the first u64 word of the bitset, as for rows and views (render_layers.rs:121-135); a light above layer 63: stock systems
@@ -1350,13 +1684,13 @@ pub fn mi_fused_frame(
                 // `radius_vec3a(Vec3A::ONE)` / `scale().length()` of the GlobalTransform this frame gives them (`expected_global`: the
                 // same glam calls the reference makes on the same operands); an entity outside the transform table is not a row
                 for (e, is_reflection_probe) in light_probes.iter() {
-                    let Some(g) = expected_global(e, &transforms) else { continue };
+                    let Some(g) = expected_global(e, &transforms) else { return Err(()) }; // (no Transform: as above)
                     let kind = if is_reflection_probe { ffi::MI_OBJ_REFLECTION_PROBE } else { ffi::MI_OBJ_IRRADIANCE_VOLUME };
                     push(s, e, g.radius_vec3a(bevy_math::Vec3A::ONE), kind, None, None)?;
                 }
                 if settings.clustered_decals_are_usable {
                     for e in decals.iter() {
-                        let Some(g) = expected_global(e, &transforms) else { continue };
+                        let Some(g) = expected_global(e, &transforms) else { return Err(()) };
                         push(s, e, g.scale().length(), ffi::MI_OBJ_DECAL, None, None)?;
                     }
                 }
@@ -1579,13 +1913,7 @@ pub fn mi_fused_frame(
 
 /// Stages the bounds / flags / layers / class columns from the ECS (shared by [`mi_check_visibility`] and [`mi_fused_frame`]).
 #[allow(clippy::type_complexity)]
-fn stage_bounds(
-    mi: &mut Mi355x,
-    rows_query: &Query<
-        (Entity, &InheritedVisibility, Option<&VisibilityClass>, Option<&RenderLayers>, Option<&Aabb>, Option<&Sphere>, Option<&PointLight>, Option<&SpotLight>, Has<NoFrustumCulling>, Has<VisibilityRange>),
-        Without<NoCpuCulling>,
-    >,
-) -> Result<(), ()> {
+fn stage_bounds(mi: &mut Mi355x, rows_query: &RowsQuery, ranges_resource: bool) -> Result<(), ()> {
     let ctx = mi.ctx;
     let n = mi.row_entity.len();
     let s = &mut mi.scratch;
@@ -1601,7 +1929,11 @@ fn stage_bounds(
     s.layers_hi.resize(n, 0);
     s.classes.clear();
     s.classes.resize(n, 0);
-    for (entity, inherited, classes, layers, aabb, sphere, point_light, spot_light, no_frustum_culling, has_range) in rows_query.iter() {
+    s.ranges.clear();
+    s.ranges.resize(n * 2, 0.0);
+    for (entity, inherited, classes, layers, aabb, sphere, point_light, spot_light, no_frustum_culling, range, mesh3d, not_shadow_caster, directional_light) in
+        rows_query.iter()
+    {
         let Some(&row) = mi.entity_row.get(&entity) else { continue };
         let row = row as usize;
         let mut flags = 0u32;
@@ -1611,8 +1943,18 @@ fn stage_bounds(
         if no_frustum_culling {
             flags |= ffi::MI_FLAG_NO_FRUSTUM_CULLING;
         }
-        if has_range {
+        if let Some(range) = range {
+            // Has<VisibilityRange> (visibility/mod.rs:814); the two bounds is_visible_at_all reads (range.rs:159-161) and use_aabb
+            // (range.rs:255-263: the model position is the Aabb centre in world space when the entity has one)
             flags |= ffi::MI_FLAG_HAS_VISIBILITY_RANGE;
+            if range.use_aabb {
+                flags |= ffi::MI_FLAG_RANGE_USE_AABB;
+            }
+            s.ranges[row * 2] = range.start_margin.start;
+            s.ranges[row * 2 + 1] = range.end_margin.end;
+        }
+        if mesh3d && !not_shadow_caster && !directional_light {
+            flags |= ffi::MI_FLAG_SHADOW_CASTER; // the shadow views' query filter, crates/bevy_light/src/lib.rs:355-372
         }
         if let Some(aabb) = aabb {
             flags |= ffi::MI_FLAG_HAS_AABB;
@@ -1655,8 +1997,16 @@ fn stage_bounds(
             // (once a layer above 31 was seen the column stays in use: a row that leaves it must be written back to 0)
             check(ctx, "mi_upload_render_layers_hi", ffi::mi_upload_render_layers_hi(ctx, 0, n as u32, s.layers_hi.as_ptr()))?;
         }
-        check(ctx, "mi_upload_visibility_classes", ffi::mi_upload_visibility_classes(ctx, 0, n as u32, s.classes.as_ptr()))
+        check(ctx, "mi_upload_visibility_classes", ffi::mi_upload_visibility_classes(ctx, 0, n as u32, s.classes.as_ptr()))?;
+        // Option<Res<VisibleEntityRanges>>: no resource = no range column, and no VisibilityRange hides anything (visibility/mod.rs:814-816)
+        check(
+            ctx,
+            "mi_upload_visibility_ranges",
+            ffi::mi_upload_visibility_ranges(ctx, 0, n as u32, if ranges_resource { s.ranges.as_ptr() } else { ptr::null() }),
+        )?;
     }
+    mi.ranges_resource = Some(ranges_resource);
+    Ok(())
 }
 
 /// `VisibilitySystems::CheckVisibility`, fused form: the parked lists become `set_visible()` calls and `VisibleEntities`.  No
@@ -1666,7 +2016,7 @@ pub fn mi_apply_visibility(
     mut frame: ResMut<Mi355xFrame>,
     ticks: SystemChangeTick,
     mut view_query: Query<(&mut VisibleEntities, &Frustum)>,
-    inputs: Query<(Ref<InheritedVisibility>, Option<Ref<Aabb>>, Option<Ref<Sphere>>, Option<Ref<RenderLayers>>), Without<NoCpuCulling>>,
+    inputs: Query<(Ref<InheritedVisibility>, Option<Ref<Aabb>>, Option<Ref<Sphere>>, Option<Ref<RenderLayers>>, Option<Ref<VisibilityRange>>), Without<NoCpuCulling>>,
     mut view_visibilities: Query<&mut ViewVisibility, Without<NoCpuCulling>>,
 ) {
     let _ = &mi;
@@ -1674,11 +2024,12 @@ pub fn mi_apply_visibility(
         return;
     }
     let written_since = |t: Tick| t.is_newer_than(frame.submit_tick, ticks.this_run());
-    let stale_inputs = inputs.iter().any(|(inherited, aabb, sphere, layers)| {
+    let stale_inputs = inputs.iter().any(|(inherited, aabb, sphere, layers, range)| {
         written_since(inherited.last_changed())
             || aabb.is_some_and(|a| written_since(a.last_changed()))
             || sphere.is_some_and(|s| written_since(s.last_changed()))
             || layers.is_some_and(|l| written_since(l.last_changed()))
+            || range.is_some_and(|r| written_since(r.last_changed()))
     });
     let stale_frusta = frame.views.iter().any(|v| {
         view_query.get(v.entity).map_or(true, |(_, frustum)| {

@@ -34,7 +34,7 @@ def test_library_exports_every_header_symbol(lib):
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/bevy_mi355x.h but not exported"
     assert sorted(api.ABI_SYMBOLS) == syms, "bevy_amd.api.ABI_SYMBOLS out of sync with the header"
-    assert lib.mi_abi_version() == 2
+    assert lib.mi_abi_version() == 3
 
 
 def test_debug_header_declares_every_hook(lib):

@@ -53,7 +53,8 @@ def test_host_visibility_test_compiles_and_links():
     import oracle_lib
     mi_build.build()
     oracle_lib.build()
-    exe = mi_build.build_host_visibility_test(force=True)
+    import cpp_build
+    exe = cpp_build.build_host_visibility_test(force=True)
     assert os.path.exists(exe) and os.access(exe, os.X_OK)
 
 
@@ -65,7 +66,8 @@ def test_visibility_ranges_and_shadow_views_behind_the_host_layer():
     import oracle_lib
     mi_build.build()
     oracle_lib.build()
-    exe = mi_build.build_host_visibility_test()
+    import cpp_build
+    exe = cpp_build.build_host_visibility_test()
     res = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     print(res.stdout)
     failed = [line for line in res.stdout.splitlines() if line.startswith("FAILED") or "EXCEPTION" in line]

@@ -47,7 +47,7 @@ to_string to_str to_owned into_owned as_str wrapping_add wrapping_sub saturating
 copy_from_slice fill keys values values_mut set cast add offset read write is_null eq ne cmp partial_cmp powf ln exp ceil floor round
 clamp to_array to_cols_array is_finite flatten flat_map skip step_by next dedup try_into try_from into_iter chain extend_from_slice
 is_some_and ok_or ok_or_else to_string_lossy or back reverse length write_all flush to_le_bytes as_bytes exit args nth parse join display
-create unwrap_or_else""".split())
+create unwrap_or_else trailing_zeros and_then""".split())
 # glam methods the files call (bevy_math re-exports glam; glam itself is not in the checkout)
 GLAM_METHODS = set("""to_cols_array to_array length from_cols_array from_array truncate extend normalize dot cross mul_vec3 transform_point3
 transform_point3a transform_vector3 inverse abs max_element min_element splat from_rotation_y from_rotation_x from_rotation_z

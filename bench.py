@@ -43,13 +43,13 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from benchlib import cpu_baseline as cpu, end_to_end as e2e, line as result_line, traffic  # noqa: E402
-from benchlib.common import with_args  # noqa: E402
+from benchlib.common import PROFILED_BLOCKS, with_args  # noqa: E402
 from benchlib.measure import block_stats, measure, roofline_of  # noqa: E402
 from benchlib.wl_batching import build_batching, build_batching_sorted  # noqa: E402
 from benchlib.wl_flat import build_flat, build_flat_static  # noqa: E402
 from benchlib.wl_frame import build_frame  # noqa: E402
 from benchlib.wl_lights import build_lights  # noqa: E402
-from benchlib.wl_tree import build_tree  # noqa: E402
+from benchlib.wl_tree import build_tree, build_tree_shape, roofline_frame  # noqa: E402
 
 
 def parse():
@@ -79,6 +79,8 @@ def parse():
     ap.add_argument("--sorted-items", type=int, default=0, help="batching_sorted: items of the phase (default 65 536)")
     ap.add_argument("--sorted-one-wg-limit", type=int, default=None, help="batching_sorted: phases up to this long take the single-workgroup kernel (default 4096; 4294967295 = always)")
     ap.add_argument("--tree-moved", choices=["all", "subtree", "leaves"], default="all", help="tree: the root moves and every Transform counts as changed (default) / change-driven frames: one level-5 node moves / 10 000 leaves move")
+    ap.add_argument("--tree-shape", default="", help="tree: one of the reference's hierarchy stress shapes (bevy_amd.workloads.HIERARCHY_SHAPES: large_tree, wide_tree, deep_tree, chain, update_leaves, update_shallow, humanoids_active / _inactive / _mixed, tree_4ary_depth11 / _depth12) instead of configs[4]'s tree")
+    ap.add_argument("--tree-shape-frame", choices=["all", "movers"], default="all", help="--tree-shape: every Transform counts as changed / the example's own frame (its update system's movers, StaticTransformOptimizations)")
     ap.add_argument("--tree-cull-launches", type=int, default=0, choices=[0, 1, 2], help="tree --tree-cull: 0 = the library's choice (one view: the tiles cull their own rows), 1 = always that, 2 = tile launch + cull launch")
     ap.add_argument("--tree-cull", action="store_true", help="tree: the hierarchy FRAME -- mi_propagate_and_cull on a context with a hierarchy (tile launch + cull launch, one call)")
     ap.add_argument("--sphere-path", type=int, default=0, help="flat_static / frame: 0 = world-sphere cull path from the second quiet frame (default), 1 = never (k_frame<0> over GlobalTransform + Aabb), 2 = at once")
@@ -108,6 +110,12 @@ OTHER_WORKLOADS = [  # the other BASELINE configs, measured briefly on fresh con
     ("tree_frame", lambda c, a: build_tree(c, with_args(a, tree_cull=True))),
     ("tree_frame_two_launches", lambda c, a: build_tree(c, with_args(a, tree_cull=True, tree_cull_launches=2))),
     ("lights", lambda c, a: build_lights(c, a)),
+] + [  # the reference's own hierarchy stress shapes (examples/stress_tests/transform_hierarchy.rs:29-160) + config 5's full-size trees
+    (f"tree_shape_{shape}" + ("" if kind == "all" else "_movers"), (lambda c, a, shape=shape, kind=kind: build_tree_shape(c, with_args(a, tree_shape=shape, tree_shape_frame=kind))))
+    for shape in ("large_tree", "wide_tree", "deep_tree", "chain", "update_leaves", "update_shallow", "humanoids_active", "humanoids_inactive", "humanoids_mixed",
+                  "tree_4ary_depth11", "tree_4ary_depth12")
+    for kind in (("all", "movers") if not shape.startswith("tree_4ary") else ("all",))
+] + [
     ("flat_static", lambda c, a: build_flat_static(c, a)),
     ("flat_static_no_sphere_column", lambda c, a: build_flat_static(c, with_args(a, sphere_path=1))),
     ("flat_static_10m_4views", lambda c, a: build_flat_static(c, with_args(a, entities=10_000_000, views=4))),
@@ -129,6 +137,8 @@ def traffic_args(workload, args):
         if val:
             a += [flag, str(val)]
     a += ["--lights", str(args.lights), "--meshes", str(args.meshes), "--tree-moved", args.tree_moved]
+    if args.tree_shape:
+        a += ["--tree-shape", args.tree_shape, "--tree-shape-frame", args.tree_shape_frame]
     for flag, on in (("--unfused", args.unfused), ("--inline-compaction", args.inline_compaction), ("--tree-cull", args.tree_cull),
                      ("--separate-cluster-calls", args.separate_cluster_calls), ("--concurrent-clusters", args.concurrent_clusters)):
         if on:
@@ -180,7 +190,9 @@ def main():
             wl = build_flat(ctx, args, rank, world, full_holder, n_global, n_views, workload)
         elif workload == "tree":
             scaling = args.scaling if world > 1 else None
-            wl = build_tree(ctx, args, rank, world)
+            if args.tree_shape and world > 1:
+                raise SystemExit("--tree-shape is a single-GPU workload")
+            wl = build_tree_shape(ctx, args) if args.tree_shape else build_tree(ctx, args, rank, world)
         elif workload == "flat_static":
             wl = build_flat_static(ctx, args)
         elif workload == "batching":
@@ -216,6 +228,8 @@ def main():
                "timing": f"median of {len(times)} blocks of exactly {args.steps} steps, each between barrier + synchronize pairs, MAX over ranks per block",
                "blocks": block_stats(np.array(times), args.steps), "roofline": roofline_of(wl, prof, args.steps, live), "cpu_baseline": None,
                "kernels": {k: round(v["avg_us"], 3) for k, v in prof.items() if v["launches"]}}
+        if getattr(wl, "frame_level_roofline", False):
+            out["roofline_frame"] = roofline_frame(wl, prof, args.steps, PROFILED_BLOCKS)
         if live:
             out["live_traffic"] = live
         if scaling is None:
@@ -260,6 +274,8 @@ def main():
             others[name] = {"metric": w2.metric, "value": round(getattr(w2, "global_units", w2.units) * 50 / m2, 1), "unit": w2.unit,
                             "ms_per_step": round(1e3 * m2 / 50, 5), "blocks": block_stats(np.array(t2), 50), "config": w2.config,
                             "roofline": roofline_of(w2, p2, 50), "kernels": {k: round(v["avg_us"], 3) for k, v in p2.items() if v["launches"]}}
+            if getattr(w2, "frame_level_roofline", False):
+                others[name]["roofline_frame"] = roofline_frame(w2, p2, 50, PROFILED_BLOCKS)
             if name == "batching":
                 others[name]["batch_build_us_per_frame"] = round(1e3 * (others[name]["ms_per_step"] - others["flat"]["ms_per_step"]), 2)
             if not args.no_cpu_baseline and (name in ("tree", "lights", "batching") or name.startswith("batching_sorted")):

@@ -109,3 +109,79 @@ def build_tree(ctx, args, rank=0, world=1):
         wl.rows = tr["n"] / max(1, len(tr["level_offsets"]) - 1)
     wl.global_units = n_global  # every node is owned by exactly one rank (replicated top rows are recomputed, not counted)
     return wl
+
+
+def build_tree_shape(ctx, args):
+    """The reference's own hierarchy stress shapes (examples/stress_tests/transform_hierarchy.rs:29-160; bevy_amd.workloads.hierarchy_shape)
+    and SURVEY 8(d) config 5's other sizes.  --tree-shape-frame all: every root moves and every Transform counts as changed (the
+    all-dirty frame of configs[4] on this shape); movers: the frame the example itself runs -- its `update` system rewrote the
+    Transforms of the nodes that carry UpdateValue, StaticTransformOptimizations enabled (the Bevy default)."""
+    import bevy_amd as B
+    from bevy_amd import workloads as W
+    name = args.tree_shape
+    sh = W.hierarchy_shape(name)
+    n = sh["n"]
+    ctx.resize(n)
+    ctx.upload_transforms(sh["translation"], sh["rotation"], sh["scale"])
+    if args.tile_mode:
+        ctx.debug_set_tile_mode(args.tile_mode)
+    ctx.upload_hierarchy(sh["parent"], sh["level_offsets"])
+    plan = ctx.debug_tile_plan()
+    frame_kind = getattr(args, "tree_shape_frame", "all")
+    rows_of = lambda idx, col, w: np.ascontiguousarray(sh[col].reshape(n, w)[idx]).reshape(-1)
+    base = {"shape": name, "nodes": n, "levels": sh["n_levels"], "movers": int(len(sh["movers"])), "tile_plan": plan,
+            "reference": "examples/stress_tests/transform_hierarchy.rs:29-160" if not name.startswith("tree_4ary") else "SURVEY 8(d) config 5 (gen_tree(depth, 4) in full)"}
+    if frame_kind == "movers" and len(sh["movers"]):
+        mv = sh["movers"]
+        rot, scl = rows_of(mv, "rotation", 4), rows_of(mv, "scale", 3)
+        frames = [sh["mover_translation"](f) for f in range(1, 9)]
+        ctx.propagate(B.PROPAGATE_ALL_DIRTY | B.PROPAGATE_STATIC_OPT)
+
+        def step(f):
+            ctx.upload_transforms_indexed(mv, frames[f % len(frames)], rot, scl)
+            ctx.propagate(B.PROPAGATE_STATIC_OPT)
+        # rows a movers frame has to touch: the movers' subtrees (closure under "child of"), 141 B each
+        below = np.zeros(n, bool)
+        below[mv] = True
+        lv = sh["level_offsets"].astype(np.int64)
+        for lo, hi in zip(lv[1:-1], lv[2:]):
+            r = np.arange(lo, hi)
+            below[r] |= below[sh["parent"][r]]
+        touched = int(below.sum())
+        config = dict(base, workload=f"{name}: {n} nodes, {sh['n_levels']} levels; per frame the `update` system's {len(mv)} movers get new translations "
+                                     f"(mi_upload_transforms_indexed) + mi_propagate(MI_PROPAGATE_STATIC_OPT); {touched} rows lie in the movers' subtrees",
+                      rows_in_moved_subtrees=touched)
+        wl = Workload("tree_shape_" + name + "_movers", step, n, 141.0 * touched / n, "k_propagate_fans", config,
+                      "nodes/sec through change-driven hierarchy propagate", "nodes/s", kernels=["k_propagate_fans", "k_mark_dirty", "k_propagate_stream", "k_level0_propagate"])
+    else:
+        roots = np.nonzero(sh["parent"] == W.NO_PARENT)[0].astype(np.uint32)
+        rt, rr, rs = rows_of(roots, "translation", 3), rows_of(roots, "rotation", 4), rows_of(roots, "scale", 3)
+        root_sets = [rt, (rt.reshape(-1, 3) + np.float32(1.0)).reshape(-1).copy()]
+
+        def step(f):
+            ctx.upload_transforms_indexed(roots, root_sets[f & 1], rr, rs)
+            ctx.propagate(B.PROPAGATE_ALL_DIRTY)
+        config = dict(base, workload=f"{name}: {n} nodes, {sh['n_levels']} levels, {len(roots)} root(s) moved every frame, every Transform counts as changed "
+                                     "(mi_propagate(MI_PROPAGATE_ALL_DIRTY))")
+        wl = Workload("tree_shape_" + name, step, n, 141.0, "k_propagate_fans", config, "nodes/sec through hierarchy propagate", "nodes/s",
+                      kernels=["k_propagate_fans", "k_propagate_stream", "k_level0_propagate", "k_mark_dirty"])
+    wl.tree = sh
+    wl.kernel_name = "k_propagate_fans<false>" if frame_kind == "movers" else "k_propagate_fans<true>"
+    wl.frame_level_roofline = True  # several launches per frame on some shapes: priced per FRAME (sum of the frame's kernels), see roofline_frame
+    return wl
+
+
+def roofline_frame(wl, prof, steps, profiled_blocks):
+    """A hierarchy frame that is several launches (2 500 dependent levels, streamed wide levels): algorithmic bytes of the frame over
+    the SUM of its kernels' device time per frame -- the figure comparable with the one-launch tree's `frac`."""
+    from .common import HBM_PEAK_GBPS
+    frames = steps * profiled_blocks
+    total_us = sum(v["avg_us"] * v["launches"] for v in prof.values() if v["launches"])
+    launches = sum(v["launches"] for v in prof.values() if v["launches"])
+    if not total_us:
+        return None
+    us = total_us / frames
+    alg = wl.bytes_per_row * wl.units
+    return {"bound": "hbm", "kernels_us_per_frame": round(us, 3), "launches_per_frame": round(launches / frames, 2), "algorithmic_bytes_per_frame": int(alg),
+            "achieved": round(alg / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+            "per_kernel": {k: {"avg_us": round(v["avg_us"], 3), "launches_per_frame": round(v["launches"] / frames, 2)} for k, v in prof.items() if v["launches"]}}

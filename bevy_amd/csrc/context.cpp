@@ -1703,7 +1703,7 @@ int32_t mi_propagate(mi_ctx* ctx, uint32_t flags) {
                                                 (const uint32_t*)ctx->chains.p + (size_t)gr.first * TILE_MAX_CHAIN, gr.count,
                                                 (const uint8_t*)ctx->node_flags.p, ctx->changed, tree_bits, ctx->g_changed_bytes,
                                                 gr.n_chain ? snap_r : nullptr, snap_w, ctx->snap_rows, all_dirty, static_opt,
-                                                ctx->stream, (unsigned long long*)ctx->tree_trace.p, tiles_pretest, tcull));
+                                                ctx->stream, (unsigned long long*)ctx->tree_trace.p, tiles_pretest, tcull, gr.deep));
         }
         for (auto& lv : ctx->stream_levels) {  // the wide deepest levels, each behind the level above it
             if (ctx->by_levels) break;

@@ -87,7 +87,7 @@ struct mi_ctx {
     std::vector<uint32_t> level_offsets;  // n_levels + 1
     DevBuf parent_idx, node_flags, tiles;
     std::vector<std::pair<uint32_t, uint32_t>> passes;  // (first tile, n tiles); pass 0 starts at level 0 (roots)
-    struct TileGroup { uint32_t first, count, n_chain, owner_rows; };
+    struct TileGroup { uint32_t first, count, n_chain, owner_rows; bool deep = false; /* some tile spans more than TILE_FAST_LEVELS levels */ };
     bool by_levels = false;         // the row count overflows the tile kernel's 32-bit offsets (or mi_debug_set_tile_mode(1)): mi_propagate sweeps level by level
     DevBuf anc;                     // the ancestor table (kernels.h, ANC_DEPTH): built by mi_upload_hierarchy; in use while anc_valid
     bool anc_valid = false;

@@ -99,15 +99,28 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
         for (uint32_t l = n_tile_levels; l < n_levels; ++l) ctx->stream_levels.emplace_back(level_offsets[l], level_offsets[l + 1] - level_offsets[l]);
         struct Band { uint32_t s, e; bool chain; };
         std::vector<Band> bands;  // bottom-up
-        for (uint32_t e = n_tile_levels; e > 0;) {
-            uint32_t s = e - 1;  // a band of one level always works
-            const uint32_t lo = e > TILE_MAX_LEVELS ? e - TILE_MAX_LEVELS : 0;
+        // the shallowest first level `cand` >= lo from which tiles down to level e - 1 fit on average
+        auto band_start = [&](uint32_t e, uint32_t lo) {
             for (uint32_t cand = lo; cand + 1 < e; ++cand) {
                 // per first-level row, on average: the would-be upper levels must fit the LDS budget and the last level the cap
                 uint64_t upper = 0;
                 for (uint32_t l = cand; l + 1 < e; ++l) upper += level_size(l);
                 const uint64_t firsts = std::max<uint64_t>(1, level_size(cand));
-                if (upper <= (uint64_t)UCAP * firsts && level_size(e - 1) <= (uint64_t)LAST_CAP * firsts) { s = cand; break; }
+                if (upper <= (uint64_t)UCAP * firsts && level_size(e - 1) <= (uint64_t)LAST_CAP * firsts) return cand;
+            }
+            return e - 1;  // a band of one level always works
+        };
+        for (uint32_t e = n_tile_levels; e > 0;) {
+            // Up to TILE_FAST_LEVELS levels per tile -- what the LDS rows allow a bushy tree anyway.  Deeper tiles (TILE_MAX_LEVELS, the
+            // kernel's second instantiation) where they END the cutting: a forest of small trees whose every tree then is (part of) ONE
+            // roots tile instead of a roots tile and several chain tiles (4 000 humanoid rigs of 68 nodes and 13 levels: 12 286 -> 4 000
+            // tiles, 43 -> 24 us per all-dirty frame), and where the hierarchy is as narrow as a chain (half the dependent launches).  On
+            // lopsided deep trees (transform_hierarchy.rs's large_tree / deep_tree) deeper bands measured SLOWER -- more chain tiles
+            // with longer chains: 25.6 -> 32.0 us -- so everything else keeps the short tiles.
+            uint32_t s = band_start(e, e > TILE_FAST_LEVELS ? e - TILE_FAST_LEVELS : 0);
+            if (s > 0 && e > TILE_FAST_LEVELS) {
+                const uint32_t deep = band_start(e, e > TILE_MAX_LEVELS ? e - TILE_MAX_LEVELS : 0);
+                if (deep == 0 || level_size(e - 1) <= 64) s = deep;
             }
             uint64_t rows = 0;
             for (uint32_t l = s; l < e; ++l) rows += level_size(l);
@@ -249,6 +262,10 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
     }
     // The tile kernel addresses rows with 32-bit byte offsets: a hierarchy beyond 89 M rows is swept level by level, one streaming
     // launch per level (mi_propagate; mi_debug_set_tile_mode(1) forces it).  The tile list stays: the InheritedVisibility sweep walks it.
+    for (auto& gr : ctx->groups) {  // which instantiation of the tile kernel a launch takes (kernels.h, TILE_FAST_LEVELS)
+        gr.deep = false;
+        for (uint32_t t = gr.first; t < gr.first + gr.count; ++t) gr.deep = gr.deep || tiles[t].n_levels > TILE_FAST_LEVELS;
+    }
     ctx->by_levels = ctx->tile_mode == 1 || n > 0xFFFFFFFFu / 48u;
     for (const TileDesc& td : tiles) {  // (every tile fits by construction: a subtree that would not was cut, above)
         uint64_t up = 0;

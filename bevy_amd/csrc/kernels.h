@@ -398,7 +398,9 @@ hipError_t launch_compact(const CompactArgs& a, hipStream_t stream, void (*mark)
 hipError_t launch_compact_fast(const CompactFastArgs& a, hipStream_t stream);
 
 // ---- hierarchy ---------------------------------------------------------------------------------
-constexpr uint32_t TILE_MAX_LEVELS = 8;
+constexpr uint32_t TILE_MAX_LEVELS = 16;  // levels a tile may span (TileDesc); the tile kernel has a second instantiation for tiles deeper than ...
+constexpr uint32_t TILE_FAST_LEVELS = 8;  // ... this, which is what every tile of a bushy tree fits in (the LDS rows bind first): 8 keeps the
+                                          // descriptor's per-level scalars in registers (16: 28 - 61 spilled SGPRs in every instantiation)
 // Light tiles (the only tiles since round 4): few LDS rows and a last level of one row per thread, nothing software-pipelined
 // -- eight workgroups per CU, a tile is two dependent round trips.  A hierarchy that cannot be cut into them is swept level by
 // level (k_propagate_level), see ctx_hierarchy.cpp.
@@ -456,7 +458,8 @@ hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, 
                                   uint8_t* g_changed_bytes, const float* snap_read, float* snap_write, uint32_t snap_rows, bool all_dirty,
                                   bool static_opt, hipStream_t stream,
                                   unsigned long long* trace = nullptr, bool pretest = false /* static-scene rule: flags first */,
-                                  const TreeCull* cull = nullptr /* all-dirty frames: the visibility systems ride in the launch */);
+                                  const TreeCull* cull = nullptr /* all-dirty frames: the visibility systems ride in the launch */,
+                                  bool deep = false /* some tile spans more than TILE_FAST_LEVELS levels */);
 // One whole level [start, start + count) as a stream: every row's parent lies in the level above, complete in global
 // memory (an earlier launch).  Same per-node rule as the tiles.  root_node_flags != NULL: the level is level 0 (no parents;
 // the roots' rule reads the has-children bit).

@@ -156,13 +156,19 @@ __global__ void __launch_bounds__(256) k_mark_dirty(uint32_t n, const uint8_t* _
 // A tile's descriptor, fetched whole with scalar loads at the top of the kernel (two s_load for the 72 bytes).  Left to
 // itself the compiler reads the fields where they are used: one dependent s_load after the other -- or, inside divergent
 // code, per-lane vector loads -- each a round trip of its own in front of the tile's first row load.
+template <uint32_t MAXL = TILE_MAX_LEVELS>
 __device__ __forceinline__ TileDesc load_tile_desc(const TileDesc* p) {
     typedef const uint32_t __attribute__((address_space(4))) * const_u32;
     const_u32 src = (const_u32)(uintptr_t)p;
-    TileDesc d;
-    uint32_t* dst = reinterpret_cast<uint32_t*>(&d);
+    static_assert(sizeof(TileDesc) == (2u + 2u * TILE_MAX_LEVELS) * 4u, "n_levels, start[], count[], kind");
+    TileDesc d;  // (entries past MAXL stay unread: a kernel instantiated for MAXL levels is only given tiles of at most that many)
+    d.n_levels = src[0];
 #pragma unroll
-    for (uint32_t k = 0; k < sizeof(TileDesc) / 4u; ++k) dst[k] = src[k];
+    for (uint32_t k = 0; k < MAXL; ++k) {
+        d.start[k] = src[1u + k];
+        d.count[k] = src[1u + TILE_MAX_LEVELS + k];
+    }
+    d.kind = src[1u + 2u * TILE_MAX_LEVELS];
     return d;
 }
 
@@ -503,7 +509,9 @@ constexpr uint32_t FANS_CULL_KERNARG = kernarg_up(kernarg_up(sizeof(Columns)) + 
 constexpr uint32_t FAN_SLOTS = TILE_LIGHT_UCAP + TILE_MAX_CHAIN;  // LDS slots: upper rows, then the chain's nodes
 constexpr uint32_t FAN_CHAIN_LANE0 = 256u - TILE_MAX_CHAIN;       // chain node k is fetched by thread FAN_CHAIN_LANE0 + k
 
-template <bool ALL_DIRTY, bool CULL = false>
+template <bool ALL_DIRTY, bool CULL = false, uint32_t MAXL = TILE_FAST_LEVELS>
+// (MAXL: the levels a tile of this launch may span -- TILE_FAST_LEVELS for bushy trees, TILE_MAX_LEVELS for the launches of narrow,
+// deep hierarchies: rigs, chains, lopsided trees -- whose tiles would otherwise be cut into several dependent or chain tiles)
 // (workgroups per CU: the fused instantiation is bound by vector-instruction issue -- 12 - 13 M wave instructions per launch over 1 024
 // SIMDs, 70 - 75 % of its span -- and by how many tiles are resident; 7 against 6 per CU: 31.5 against 33.1 us per launch; 8 -- 64
 // registers, one spill -- 31.9)
@@ -549,20 +557,20 @@ __global__ void __launch_bounds__(256, CULL ? 7 : ALL_DIRTY ? 8 : 7) k_propagate
     const bool chain_lane = tid >= FAN_CHAIN_LANE0;
     // the chain's row numbers sit at a fixed place per tile: fetched next to the descriptor, not behind it
     const uint32_t chain_row = chain_lane ? a.chains[(size_t)tile * TILE_MAX_CHAIN + (tid - FAN_CHAIN_LANE0)] : 0u;
-    const TileDesc td = load_tile_desc(a.tiles + tile);
+    const TileDesc td = load_tile_desc<MAXL>(a.tiles + tile);
     const uint32_t L = td.n_levels;
     const bool ROOTS = (td.kind & TILE_ROOTS) != 0;
     const uint32_t chain_len = td.kind & TILE_CHAIN_MASK;
     float* const snap_out = a.snap_write;
     const uint32_t n_lds = L ? L - 1u : 0u;  // every level but the last is LDS-resident
-    uint32_t ubase[TILE_MAX_LEVELS + 1];
+    uint32_t ubase[MAXL + 1];
     ubase[0] = 0;
 #pragma unroll
-    for (uint32_t l = 0; l < TILE_MAX_LEVELS; ++l) ubase[l + 1] = ubase[l] + (l < n_lds ? td.count[l] : 0u);
-    const uint32_t U = ubase[TILE_MAX_LEVELS];
+    for (uint32_t l = 0; l < MAXL; ++l) ubase[l + 1] = ubase[l] + (l < n_lds ? td.count[l] : 0u);
+    const uint32_t U = ubase[MAXL];
     uint32_t s_start = td.start[0], s_count = L ? td.count[0] : 0u, s_pbase = 0, s_pstart = 0;  // the last level
 #pragma unroll
-    for (uint32_t j = 1; j < TILE_MAX_LEVELS; ++j)
+    for (uint32_t j = 1; j < MAXL; ++j)
         if (j == n_lds) {
             s_start = td.start[j];
             s_count = td.count[j];
@@ -588,7 +596,7 @@ __global__ void __launch_bounds__(256, CULL ? 7 : ALL_DIRTY ? 8 : 7) k_propagate
             }
             if (__syncthreads_or(hot ? 1 : 0) == 0) {
 #pragma unroll
-                for (uint32_t l = 0; l < TILE_MAX_LEVELS; ++l)
+                for (uint32_t l = 0; l < MAXL; ++l)
                     if (l < L)
                         for (uint32_t i = tid; i < td.count[l]; i += 256u) at32w<uint8_t>(a.g_changed_bytes, td.start[l] + i) = 0;
                 return;
@@ -611,11 +619,11 @@ __global__ void __launch_bounds__(256, CULL ? 7 : ALL_DIRTY ? 8 : 7) k_propagate
     {
         uint32_t l = 0;
 #pragma unroll
-        for (uint32_t j = 1; j < TILE_MAX_LEVELS; ++j)
+        for (uint32_t j = 1; j < MAXL; ++j)
             if (j < n_lds && tid >= ubase[j]) l = j;
         uint32_t lstart = td.start[0], lbase = 0;
 #pragma unroll
-        for (uint32_t j = 1; j < TILE_MAX_LEVELS; ++j)
+        for (uint32_t j = 1; j < MAXL; ++j)
             if (j == l) {
                 lstart = td.start[j];
                 lbase = ubase[j];
@@ -1089,7 +1097,7 @@ hipError_t launch_mark_dirty(uint32_t n, const uint8_t* changed, uint32_t change
 hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, const TileDesc* d_tiles, const uint32_t* d_chains,
                                   uint32_t n_tiles, const uint8_t* node_flags, const uint8_t* changed, const uint8_t* tree_bytes,
                                   uint8_t* g_changed_bytes, const float* snap_read, float* snap_write, uint32_t snap_rows, bool all_dirty,
-                                  bool static_opt, hipStream_t stream, unsigned long long* trace, bool pretest, const TreeCull* cull) {
+                                  bool static_opt, hipStream_t stream, unsigned long long* trace, bool pretest, const TreeCull* cull, bool deep) {
     if (n_tiles == 0) return hipSuccess;
     TreeArgs a;
     a.pretest = pretest && changed && tree_bytes ? 1u : 0u;
@@ -1109,8 +1117,12 @@ hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, 
     a.trace = trace;
     if (cull) {
         if (!all_dirty || !c.row_summary) return hipErrorInvalidValue;  // (the host checks: every tile runs)
-        MI_LAUNCH((k_propagate_fans<true, true>), dim3(n_tiles + cull->n_compact), dim3(256), 0, stream, c, a, *cull);
-    } else if (all_dirty) MI_LAUNCH((k_propagate_fans<true, false>), dim3(n_tiles), dim3(256), 0, stream, c, a, NoCull{});
+        if (deep) MI_LAUNCH((k_propagate_fans<true, true, TILE_MAX_LEVELS>), dim3(n_tiles + cull->n_compact), dim3(256), 0, stream, c, a, *cull);
+        else MI_LAUNCH((k_propagate_fans<true, true>), dim3(n_tiles + cull->n_compact), dim3(256), 0, stream, c, a, *cull);
+    } else if (all_dirty) {
+        if (deep) MI_LAUNCH((k_propagate_fans<true, false, TILE_MAX_LEVELS>), dim3(n_tiles), dim3(256), 0, stream, c, a, NoCull{});
+        else MI_LAUNCH((k_propagate_fans<true, false>), dim3(n_tiles), dim3(256), 0, stream, c, a, NoCull{});
+    } else if (deep) MI_LAUNCH((k_propagate_fans<false, false, TILE_MAX_LEVELS>), dim3(n_tiles), dim3(256), 0, stream, c, a, NoCull{});
     else MI_LAUNCH((k_propagate_fans<false, false>), dim3(n_tiles), dim3(256), 0, stream, c, a, NoCull{});
     return hipGetLastError();
 }

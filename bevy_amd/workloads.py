@@ -192,6 +192,171 @@ def gen_tree(depth, branch, max_nodes=None, seed=42):
                 scale=np.ascontiguousarray(s).reshape(-1))
 
 
+# ---- the reference's own hierarchy stress shapes (examples/stress_tests/transform_hierarchy.rs:29-160) -------------------------------
+
+# HUMANOID_RIG (transform_hierarchy.rs:493-561): parent map of a mixamo-like rig, root excluded -- 68 nodes per rig.  Restated as
+# structure: spine + head, two arms of (shoulder, arm, forearm, hand, 5 fingers x 4 joints), two legs of 5 joints.
+def _humanoid_rig():
+    rig = [0, 1, 2, 3, 4, 5, 6, 6, 6]          # hips, spine x3, neck, head, head top + two eyes (nodes 1..9)
+    for _side in range(2):                       # shoulder (child of spine 2 = node 4), arm, forearm, hand, then five fingers
+        shoulder = len(rig) + 1
+        rig += [4, shoulder, shoulder + 1, shoulder + 2]
+        hand = shoulder + 3
+        for _finger in range(5):
+            first = len(rig) + 1
+            rig += [hand, first, first + 1, first + 2]
+    for _side in range(2):                       # upper leg (child of hips = node 1), leg, foot, toe base, toe end
+        upper = len(rig) + 1
+        rig += [1, upper, upper + 1, upper + 2, upper + 3]
+    return rig
+
+
+HUMANOID_RIG = _humanoid_rig()
+assert len(HUMANOID_RIG) == 67
+
+# name -> (test case, update filter (probability, min_depth, max_depth)), transform_hierarchy.rs:29-160
+HIERARCHY_SHAPES = {
+    "large_tree": (("non_uniform", 18, 8), (0.5, 0, None)),
+    "wide_tree": (("tree", 3, 500), (0.5, 0, None)),
+    "deep_tree": (("non_uniform", 25, 2), (0.5, 0, None)),
+    "chain": (("tree", 2500, 1), (0.5, 0, None)),
+    "update_leaves": (("tree", 18, 2), (0.5, 17, None)),
+    "update_shallow": (("tree", 18, 2), (0.5, 0, 8)),
+    "humanoids_active": (("humanoids", 4000, 0), (1.0, 0, None)),
+    "humanoids_inactive": (("humanoids", 10, 3990), (1.0, 0, None)),
+    "humanoids_mixed": (("humanoids", 2000, 2000), (1.0, 0, None)),
+    # SURVEY 8(d) config 5's other data points: the full 11-level 4-ary tree and a true depth-12 one
+    "tree_4ary_depth11": (("tree", 11, 4), (0.5, 0, None)),
+    "tree_4ary_depth12": (("tree", 12, 4), (0.5, 0, None)),
+}
+
+
+def _parent_map_tree(depth, branch):
+    """gen_tree (transform_hierarchy.rs:440-453): 0,0,..,1,1,.. -- every one of the first sum(branch^i, i < depth-1) nodes has `branch` children."""
+    inner = sum(branch ** i for i in range(depth - 1))
+    return np.repeat(np.arange(inner, dtype=np.int64), branch)
+
+
+def _parent_map_non_uniform(max_depth, max_branch):
+    """gen_non_uniform_tree (transform_hierarchy.rs:455-490): child k of a node gets a subtree one level shallower than child k - 1;
+    the recursion returns as soon as the remaining depth reaches zero.  Iterative restatement (an explicit stack of loop states)."""
+    tree = []
+    stack = [[0, max_depth, 0]]  # parent, curr_depth (decremented per sibling), siblings pushed so far
+    while stack:
+        frame = stack[-1]
+        if frame[2] == max_branch:
+            stack.pop()
+            continue
+        tree.append(frame[0])
+        frame[2] += 1
+        frame[1] -= 1
+        if frame[1] == 0:
+            stack.pop()       # `return`: the remaining siblings of this node are never pushed
+            continue
+        stack.append([len(tree), frame[1], 0])
+    return np.array(tree, np.int64)
+
+
+def level_order(parent):
+    """Rows of an arbitrary forest in level (BFS) order, the order mi_upload_hierarchy asks for: level l = the children of level l - 1's
+    rows, parent by parent, siblings in the caller's order (what mi_hierarchy_sort computes; restated here in numpy so that the harness
+    does not need the library to build a scene).  Returns (new_to_old, parent in new numbering, level_offsets)."""
+    parent = np.asarray(parent, np.int64)
+    n = len(parent)
+    has = parent != NO_PARENT
+    kids_all = np.nonzero(has)[0]
+    order = np.argsort(parent[kids_all], kind="stable")
+    kids = kids_all[order]
+    counts = np.bincount(parent[kids_all], minlength=n).astype(np.int64)
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    level = np.nonzero(~has)[0]
+    out, offs = [level], [0, len(level)]
+    while True:
+        cnt = counts[level]
+        tot = int(cnt.sum())
+        if tot == 0:
+            break
+        first = np.repeat(starts[level], cnt)
+        within = np.arange(tot) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+        level = kids[first + within]
+        out.append(level)
+        offs.append(offs[-1] + tot)
+    new_to_old = np.concatenate(out)
+    assert len(new_to_old) == n, "cycle or dangling parent"
+    old_to_new = np.empty(n, np.int64)
+    old_to_new[new_to_old] = np.arange(n)
+    p_new = np.where(parent[new_to_old] == NO_PARENT, NO_PARENT, old_to_new[np.where(has, parent, 0)][new_to_old])
+    return new_to_old.astype(np.uint32), p_new.astype(np.uint32), np.array(offs, np.uint32)
+
+
+def hierarchy_shape(name, seed=42, plain_transforms=False, scale_rigs=1.0):
+    """One of the reference's hierarchy stress configurations (transform_hierarchy.rs:29-160) as level-ordered rows.
+      structure   gen_tree / gen_non_uniform_tree / HUMANOID_RIG x (active + inactive), spawn_tree's placement: a child's translation is
+                  (32 cos a, 32 sin a, 0), a = its slot / its parent's child count (:395-422); a rig's root at a seeded (x, y) in
+                  [-250, 250)^2 (:291-325; the reference draws from rand::rng(), unseeded)
+      movers      the nodes that carry UpdateValue: every non-root node whose depth passes the filter, with the filter's probability
+                  (drawn per node at insertion, :398-405; seeded here), never a rig of the inactive group
+      mover_translation(frame)   what the `update` system leaves in the movers' Transforms in frame k (:250-262: a += dt * 0.1, dt = 1/60)
+    plain_transforms = identity rotation and unit scale like the reference; otherwise the seeded small rotation and uniform scale of
+    gen_tree() above so that the products along a chain are not trivially exact."""
+    (kind, a, b), (prob, min_depth, max_depth) = HIERARCHY_SHAPES[name]
+    rng = np.random.default_rng(seed)
+    if kind == "humanoids":
+        n_rigs = int(round((a + b) * scale_rigs))
+        n_active = int(round(a * scale_rigs)) if b else n_rigs
+        rig = np.array(HUMANOID_RIG, np.int64)
+        per = len(rig) + 1
+        base = np.arange(n_rigs, dtype=np.int64)[:, None] * per
+        parent = np.full((n_rigs, per), NO_PARENT, np.int64)
+        parent[:, 1:] = base + rig[None, :]
+        parent = parent.reshape(-1)
+        rig_active = np.repeat(np.arange(n_rigs) < n_active, per)
+        root_xy = rng.random((n_rigs, 2)) * 500.0 - 250.0
+    else:
+        pm = _parent_map_tree(a, b) if kind == "tree" else _parent_map_non_uniform(a, b)
+        parent = np.concatenate([[NO_PARENT], pm]).astype(np.int64)
+        rig_active = np.ones(len(parent), bool)
+        root_xy = None
+    n = len(parent)
+    # spawn_tree: slot / child_count per node (in spawn order), depth
+    has = parent != NO_PARENT
+    child_count = np.bincount(parent[has], minlength=n)
+    order = np.argsort(parent[has], kind="stable")
+    kids = np.nonzero(has)[0][order]
+    starts = np.concatenate([[0], np.cumsum(child_count)])
+    slot = np.zeros(n, np.int64)
+    slot[kids] = np.arange(len(kids)) - np.repeat(starts[:-1], child_count)
+    sep = np.where(has, slot / np.maximum(child_count[np.where(has, parent, 0)], 1), 0.0)
+    new_to_old, p_new, offs = level_order(parent)
+    depth_new = np.repeat(np.arange(len(offs) - 1), np.diff(offs.astype(np.int64)))
+    sep_new = sep[new_to_old]
+    t = np.stack([32.0 * np.cos(sep_new), 32.0 * np.sin(sep_new), np.zeros(n)], axis=1)
+    is_root = p_new == NO_PARENT
+    t[is_root] = 0.0
+    if root_xy is not None:
+        t[is_root, :2] = root_xy[(new_to_old[is_root] // (len(HUMANOID_RIG) + 1))]
+    draw = rng.random(n)
+    mover = (~is_root) & rig_active[new_to_old] & (draw <= prob) & (depth_new >= min_depth) & (depth_new <= (max_depth if max_depth is not None else 1 << 30))
+    movers = np.nonzero(mover)[0].astype(np.uint32)
+    if plain_transforms:
+        q = np.tile(np.array([0, 0, 0, 1], F), (n, 1))
+        s3 = np.ones((n, 3), F)
+    else:
+        small = (uniform01(seed, 3 * n).reshape(n, 3) - 0.5) * 0.4
+        q = np.concatenate([small, np.ones((n, 1))], axis=1)
+        q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(F)
+        s3 = np.repeat((0.95 + 0.1 * uniform01(seed + 5, n)).astype(F)[:, None], 3, axis=1)
+    sep_movers = sep_new[movers]
+
+    def mover_translation(frame):
+        ang = (sep_movers + np.float64(frame) * (0.1 / 60.0)).astype(F)  # UpdateValue is an f32 the system adds to each frame
+        return np.ascontiguousarray(np.stack([np.cos(ang) * F(32.0), np.sin(ang) * F(32.0), np.zeros(len(ang), F)], axis=1).astype(F)).reshape(-1)
+
+    return dict(name=name, n=n, parent=p_new, level_offsets=offs, translation=np.ascontiguousarray(t.astype(F)).reshape(-1),
+                rotation=np.ascontiguousarray(q).reshape(-1), scale=np.ascontiguousarray(s3).reshape(-1), movers=movers,
+                mover_translation=mover_translation, depth=int(len(offs) - 2), n_levels=int(len(offs) - 1))
+
+
 def batching_scene(n_rows, n_sets=7, max_bins=40, seed=42, unbatched_fraction=0.05):
     """Synthetic render-phase binning for `n_rows` mesh rows: every row names a batch set (or
     NO_BATCH_SET = not multidrawable), a RenderBinIndex inside it and an InputUniformIndex; every set has a

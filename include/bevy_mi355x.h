@@ -331,7 +331,10 @@ int32_t mi_propagate_and_cull(mi_ctx* ctx, const float* frusta, const uint32_t* 
  * translation, or MI_VIEW_FLAG_RANGES_NO_ORIGIN without one, lib.rs:601-611).  Only rows with MI_FLAG_SHADOW_CASTER are seen.
  * Survivors are ORed into ViewVisibility (set_visible: lib.rs:499-510, 629, 723); flags = MI_CULL_END_FRAME also closes the frame
  * (check_visibility_gpu_culling + mark_newly_hidden_entities_invisible) in the same pass.  n_views = 0 is allowed (only the
- * END_FRAME part runs).  Out, in ONE device wait:
+ * END_FRAME part runs).  A host that keeps ViewVisibility in its ECS and lets the stock mark_newly_hidden_entities_invisible run
+ * there (the Rust plugin) may also close the cameras' frame at once (MI_CULL_END_FRAME on that call) and pass flags = 0 here: bit 0
+ * of the device's column -- ViewVisibility::get(), all the next frame's reset reads -- comes out the same; only the device's own
+ * previous-frame bit and change mask of THIS frame then differ from the reference's.  Out, in ONE device wait:
  *   out_bitmasks[n_views * ceil(n_rows/32)]  view v's packed VisibleMeshEntities: bit r = row r was pushed to that cascade's /
  *                                            face's / spot light's list (the caller maps rows to Entity and sorts, lib.rs:489, 664, 745)
  *   out_any[ceil(n_rows/32)]                 OR over the views = the rows set_visible() was called on (NULL = not wanted)

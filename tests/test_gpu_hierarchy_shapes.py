@@ -1,0 +1,105 @@
+"""GPU parity on the reference's own hierarchy stress shapes (examples/stress_tests/transform_hierarchy.rs:29-160: large_tree,
+wide_tree, deep_tree, chain, update_leaves, update_shallow, humanoids_active / _inactive / _mixed) and on SURVEY 8(d) config 5's other
+data points (the full 11-level 4-ary tree, a true depth-12 one): every frame kind the example produces -- all dirty, the `update`
+system's movers under StaticTransformOptimizations and without, a frame in which nothing moved -- against O.propagate_transforms,
+GlobalTransform bits and change ticks.  The planner's worst cases live here: 2 500 dependent levels (chain), a 250 000-row level under
+500 parents (wide_tree), 4 000 small trees of which half never move (humanoids_mixed)."""
+import numpy as np
+import pytest
+
+import bevy_amd as B
+from bevy_amd import api, workloads as W
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+SHAPES = [n for n in W.HIERARCHY_SHAPES if n != "tree_4ary_depth12"]
+
+
+def assert_rows(g, g_exp, what):
+    bad = np.nonzero((g.view(np.uint32) != g_exp.view(np.uint32)).reshape(-1, 12).any(axis=1))[0]
+    assert bad.size == 0, f"{what}: {bad.size} rows differ, first {bad[:6].tolist()}"
+
+
+def assert_bits(a, b, what):
+    bad = np.nonzero(np.asarray(a) != np.asarray(b))[0]
+    assert bad.size == 0, f"{what}: {bad.size} mismatches, first rows {bad[:8].tolist()}"
+
+
+def run_shape(sh, static_opt):
+    n = sh["n"]
+    flags = B.PROPAGATE_STATIC_OPT if static_opt else 0
+    with api.Context(0) as ctx:
+        ctx.resize(n)
+        ctx.upload_transforms(sh["translation"], sh["rotation"], sh["scale"])
+        ctx.upload_hierarchy(sh["parent"], sh["level_offsets"])
+        # frame 0: every Transform counts as changed
+        ctx.propagate(B.PROPAGATE_ALL_DIRTY | flags)
+        g, chg = ctx.download_global_transforms()
+        rc, g_exp, chg_exp = O.propagate_transforms(sh["parent"], sh["translation"], sh["rotation"], sh["scale"], static_opt=static_opt)
+        assert rc == 0
+        assert_rows(g, g_exp, f"{sh['name']} all dirty")
+        assert_bits(chg, chg_exp, f"{sh['name']} all dirty: change ticks")
+        # frames 1, 2: the `update` system moved its nodes (transform_hierarchy.rs:250-262)
+        t = sh["translation"].copy().reshape(n, 3)
+        rot = np.ascontiguousarray(sh["rotation"].reshape(n, 4)[sh["movers"]]).reshape(-1)
+        scl = np.ascontiguousarray(sh["scale"].reshape(n, 3)[sh["movers"]]).reshape(-1)
+        changed = np.zeros(n, np.uint8)
+        changed[sh["movers"]] = 1
+        tree_changed = O.mark_dirty_trees(sh["parent"], changed)
+        for frame in (1, 2):
+            mt = sh["mover_translation"](frame)
+            t[sh["movers"]] = mt.reshape(-1, 3)
+            if len(sh["movers"]):
+                ctx.upload_transforms_indexed(sh["movers"], mt, rot, scl)
+            else:
+                ctx.upload_changed(np.zeros(n, np.uint8))
+            ctx.propagate(flags)
+            g, chg = ctx.download_global_transforms()
+            rc, g_exp, chg_exp = O.propagate_transforms(sh["parent"], t.reshape(-1), sh["rotation"], sh["scale"], global_in=g_exp, static_opt=static_opt,
+                                                        tree_changed=tree_changed, transform_changed=changed)
+            assert rc == 0
+            assert_rows(g, g_exp, f"{sh['name']} movers frame {frame}")
+            assert_bits(chg, chg_exp, f"{sh['name']} movers frame {frame}: change ticks")
+        # frame 3: nothing moved
+        ctx.upload_changed(np.zeros(n, np.uint8))
+        ctx.propagate(flags)
+        g, chg = ctx.download_global_transforms()
+        none = np.zeros(n, np.uint8)
+        rc, g_exp, chg_exp = O.propagate_transforms(sh["parent"], t.reshape(-1), sh["rotation"], sh["scale"], global_in=g_exp, static_opt=static_opt,
+                                                    tree_changed=none, transform_changed=none)
+        assert rc == 0
+        assert_rows(g, g_exp, f"{sh['name']} quiet frame")
+        assert_bits(chg, chg_exp, f"{sh['name']} quiet frame: change ticks")
+        return ctx.debug_tile_plan()
+
+
+@pytest.mark.parametrize("static_opt", [True, False])
+@pytest.mark.parametrize("name", SHAPES)
+def test_reference_hierarchy_shape(name, static_opt):
+    sh = W.hierarchy_shape(name)
+    plan = run_shape(sh, static_opt)
+    print(name, sh["n"], "nodes", sh["n_levels"], "levels", len(sh["movers"]), "movers; plan", plan)
+
+
+def test_reference_hierarchy_shape_with_plain_transforms():
+    """Identity rotations and unit scales exactly as spawn_tree leaves them (transform_hierarchy.rs:409-418)."""
+    for name in ("humanoids_mixed", "chain"):
+        run_shape(W.hierarchy_shape(name, plain_transforms=True), True)
+
+
+def test_true_depth_12_tree_all_dirty():
+    """gen_tree(12, 4) in full: 5 592 405 nodes, all dirty."""
+    sh = W.hierarchy_shape("tree_4ary_depth12")
+    assert sh["n"] == 5_592_405 and sh["n_levels"] == 12
+    with api.Context(0) as ctx:
+        ctx.resize(sh["n"])
+        ctx.upload_transforms(sh["translation"], sh["rotation"], sh["scale"])
+        ctx.upload_hierarchy(sh["parent"], sh["level_offsets"])
+        ctx.propagate(B.PROPAGATE_ALL_DIRTY)
+        g, chg = ctx.download_global_transforms()
+    rc, g_exp, chg_exp = O.propagate_transforms(sh["parent"], sh["translation"], sh["rotation"], sh["scale"])
+    assert rc == 0
+    assert_rows(g, g_exp, "depth 12")
+    assert_bits(chg, chg_exp, "depth 12: change ticks")

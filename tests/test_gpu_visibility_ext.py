@@ -166,6 +166,16 @@ def test_shadow_views_cascades_cube_faces_and_spot(n):
         vv, chg = ctx.download_view_visibility()
         assert_bits(vv, vv_exp2, "vv (camera frame + empty light pass)")
         assert_bits(chg, chg_exp2, "vv changed (camera frame + empty light pass)")
+        # the Rust shim's sequence: both of its camera paths close the frame on the device (MI_CULL_END_FRAME) and the light pass follows
+        # with flags = 0 -- the ECS components get their set_visible() from the masks; on the device only bit 0 (ViewVisibility::get(),
+        # what the next frame's reset reads) has to come out right
+        ctx.upload_view_visibility(vv0)
+        ctx.propagate_and_cull_views(api.make_views(fr[:24], masks[:1], flags[:1], np.array(pos[:1], F)), flags=B.CULL_END_FRAME)
+        per_view, any_ = ctx.check_light_mesh_visibility(shadow, flags=0)
+        for v in range(1, len(frs)):
+            assert_bits(per_view[v - 1], vis_exp[v], f"light pass behind a closed frame, view {v}")
+        vv, _ = ctx.download_view_visibility()
+        assert_bits(vv & 1, vv_exp & 1, "ViewVisibility::get() after a closed camera frame + light pass")
         with pytest.raises(api.MiError):   # a camera view is not a shadow view
             ctx.check_light_mesh_visibility(api.make_views(fr[:24], masks[:1], flags[:1], np.array(pos[:1], F)))
 

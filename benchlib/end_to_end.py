@@ -27,6 +27,30 @@ def pcie_peak():
     return out
 
 
+_GATHER = None
+
+
+def build_gather(force=False):
+    """benchlib/ecs_gather.c -> benchlib/libecs_gather.so (gcc -O2 -fopenmp): the harness's stand-in for the ECS side's par_iter."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    src, so = os.path.join(here, "ecs_gather.c"), os.path.join(here, "libecs_gather.so")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.run(["gcc", "-O2", "-fopenmp", "-shared", "-fPIC", src, "-o", so], check=True, capture_output=True)
+    return so
+
+
+def gather_lib():
+    global _GATHER
+    if _GATHER is None:
+        import ctypes as C
+        _GATHER = C.CDLL(build_gather())
+        _GATHER.ecs_gather_rows.restype = None
+        _GATHER.ecs_copy_rows.restype = None
+    return _GATHER
+
+
 def end_to_end(ctx, wl, frames=12, cpu_frame_ms=None):
     """The same frame with the host on both sides of it.  Per frame: the rows a Changed<Transform> query yields go in -- written
     straight into the library's pinned upload window (mi_map_upload_window / mi_commit_upload_window; dense at 100 %) --, ONE frame
@@ -42,6 +66,14 @@ def end_to_end(ctx, wl, frames=12, cpu_frame_ms=None):
     r4, s3 = sc["rotation"].reshape(n, 4), sc["scale"].reshape(n, 3)
     link = pcie_peak()
     out = {"pcie_peak_GBps": link}
+    import ctypes as C
+    import os
+    gl = gather_lib()
+    threads = max(1, min(8, (os.cpu_count() or 2) // 2))  # (what the C++ host layer's pool uses: half the hardware threads, eight at most)
+    fpt, u32t = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+    fp = lambda a: None if a is None else a.ctypes.data_as(fpt)
+    t3c, r4c, s3c = np.ascontiguousarray(t3), np.ascontiguousarray(r4), np.ascontiguousarray(s3)
+    out["gather_threads"] = threads
     rng = np.random.default_rng(0)
     ctx.upload_changed(np.zeros(n, np.uint8))
     ctx.propagate(B.PROPAGATE_ALL_DIRTY)
@@ -58,10 +90,7 @@ def end_to_end(ctx, wl, frames=12, cpu_frame_ms=None):
             ctx.cluster_upload_view(views[f % N_FRAMES])
             if rows is not None:  # the ECS side's gather loop, writing into the window
                 w, wrows, wt, wr, ws = ctx.map_upload_window(k)
-                wrows[:] = rows
-                np.take(t3, rows, axis=0, out=wt.reshape(k, 3), mode="clip")  # (mode="raise" buffers the whole output)
-                np.take(r4, rows, axis=0, out=wr.reshape(k, 4), mode="clip")
-                np.take(s3, rows, axis=0, out=ws.reshape(k, 3), mode="clip")
+                gl.ecs_gather_rows(k, rows.ctypes.data_as(u32t), fp(t3c), fp(r4c), fp(s3c), wrows.ctypes.data_as(u32t), fp(wt), fp(wr), fp(ws), threads)
                 tc = time.perf_counter()
                 ctx.commit_upload_window(w, k)
                 commit_s = time.perf_counter() - tc
@@ -74,11 +103,7 @@ def end_to_end(ctx, wl, frames=12, cpu_frame_ms=None):
                 for lo in range(0, n, chunk):
                     m = min(chunk, n - lo)
                     w, _, wt, wr, ws = ctx.map_upload_window(m, dense=True, components=comps)
-                    if wt is not None:
-                        wt[:] = t3[lo:lo + m].reshape(-1)
-                    wr[:] = r4[lo:lo + m].reshape(-1)
-                    if ws is not None:
-                        ws[:] = s3[lo:lo + m].reshape(-1)
+                    gl.ecs_copy_rows(lo, m, fp(t3c), fp(r4c), fp(s3c), fp(wt), fp(wr), fp(ws), threads)
                     tc = time.perf_counter()
                     ctx.commit_upload_window(w, m, first_row=lo)
                     commit_s += time.perf_counter() - tc
@@ -116,16 +141,16 @@ def end_to_end(ctx, wl, frames=12, cpu_frame_ms=None):
         # frame (cpu_baseline: every Transform dirty, best thread count; its visibility passes do not get cheaper when fewer rows move,
         # its propagate does: at 1 % / 10 % dirty the CPU figure is an upper bound of its cost, so these ratios are upper bounds too)
         out["x_cpu_port"] = {k: round(1e3 * cpu_frame_ms / v["us_per_frame"], 2) for k, v in out.items() if isinstance(v, dict) and "us_per_frame" in v}
-        # the same ratio over the library's calls alone (commit + frame + results): what is left when the ECS-side gather into the window --
-        # here ONE Python thread running numpy's take / copy, in a Bevy app a par_iter over the tables -- is taken out.  The truth for a
-        # shipped plugin lies between the two.
+        # the same ratio over the library's calls alone (commit + frame + results): what is left when the ECS-side gather into the window
+        # (benchlib/ecs_gather.c, a few threads) is taken out
         out["x_cpu_port_library_calls"] = {k: round(1e3 * cpu_frame_ms / v["library_us"], 2) for k, v in out.items() if isinstance(v, dict) and "library_us" in v}
         out["cpu_port_frame_us_all_dirty"] = round(1e3 * cpu_frame_ms, 1)
     out["note"] = ("same frame as `value` with the host on both sides, through ctypes: dirty Transforms written into the library's pinned upload "
-                   "window (no staging copy; numpy's gather is the ECS side's loop) and committed, ONE frame call (propagate + cull + "
+                   "window (no staging copy; the ECS side's gather loop is benchlib/ecs_gather.c on `gather_threads` threads -- a par_iter's stand-in; "
+                   "until round 4 it was ONE Python thread of numpy.take, 1.9 of the 2.7 ms of the 10 % frame) and committed, ONE frame call (propagate + cull + "
                    "cluster, MI_CULL_CHANGED_ROWS), ONE mi_download_frame_results delivered in place (one packing launch into pinned memory, one "
                    f"device wait, no copy out); median wall time of {frames} frames, each synchronised.  library_us = the library's calls alone "
-                   "(commit + frame + results; the rest of us_per_frame is numpy gathering / copying the rows into the window, the ECS side's loop); "
+                   "(commit + frame + results; the rest of us_per_frame is the gather loop filling the window); "
                    "at 100 % the table goes in as eight dense windows in a row, which the library sends piece by piece with each piece's "
                    "GlobalTransforms computed at once and on their way back under the rest of the upload (PCIe full duplex): the results call "
                    "finds them on the host.  pcie_frac = (h2d / peak_h2d + d2h / "

@@ -1333,6 +1333,59 @@ uint64_t orc_assign_objects_to_clusters_layers64(const orc_cluster_view* view, u
     return cc.total;
 }
 
+/* ---- CPU baseline of the cluster stage as the reference runs it (bench.py only) ---------------------------------
+ * assign_objects_to_clusters walks the objects ONCE and pushes each into the Vec<Entity> of every cluster it touches
+ * (clusters.clusterable_objects[cluster_index].add_*(entity), assign.rs:740-800); the vectors are cleared at the start of
+ * the frame and keep their capacity (Clusters::clear / the `clusterable_objects.clear()` + resize_with of assign.rs:412-420).
+ * orc_assign_objects_to_clusters above walks twice (count, then fill a CSR) because the tests want the flat arrays; timing THAT
+ * as the baseline flatters the device by the second walk.  This is the one-walk form, `iters` frames over the same objects. */
+typedef struct { uint32_t* data; uint32_t len, cap; uint32_t counts[6]; } push_vec;
+typedef struct { push_vec* clusters; uint64_t total; } push_ctx;
+static void emit_push(void* c, uint32_t cluster, uint32_t obj, uint32_t type) {
+    push_ctx* k = (push_ctx*)c;
+    push_vec* v = &k->clusters[cluster];
+    if (v->len == v->cap) {
+        v->cap = v->cap ? 2 * v->cap : 4;
+        v->data = (uint32_t*)realloc(v->data, (size_t)v->cap * sizeof(uint32_t));
+    }
+    v->data[v->len++] = obj;
+    v->counts[type]++;
+    k->total++;
+}
+double orc_bench_assign_objects_to_clusters(const orc_cluster_view* view, uint32_t n_objects, const float* pos_range,
+                                            const uint8_t* obj_type, const float* spot_dir, const float* spot_sin_cos, int iters,
+                                            uint64_t* total_out, float* farthest_z_out) {
+    uint32_t C = view->dims[0] * view->dims[1] * view->dims[2];
+    m4 view_from_world = m4_load(view->view_from_world);
+    m4 clip_from_view = m4_load(view->clip_from_view);
+    v4 row2 = m4_row(&view_from_world, 2);
+    float* spheres = (float*)calloc((size_t)C * 4 + 4, sizeof(float));
+    uint8_t* valid = (uint8_t*)calloc((size_t)C + 1, 1);
+    push_vec* clusters = (push_vec*)calloc((size_t)C + 1, sizeof(push_vec));
+    push_ctx pc = {clusters, 0};
+    float farthest = 0.0f;
+    struct timespec a, b;
+    clock_gettime(CLOCK_MONOTONIC, &a);
+    for (int it = 0; it < iters; ++it) {
+        for (uint32_t c = 0; c < C; ++c) { clusters[c].len = 0; memset(clusters[c].counts, 0, sizeof clusters[c].counts); }
+        pc.total = 0;
+        farthest = 0.0f;
+        for (uint32_t i = 0; i < n_objects; ++i) {
+            v3 center = V3(pos_range[4 * (size_t)i], pos_range[4 * (size_t)i + 1], pos_range[4 * (size_t)i + 2]);
+            assign_one_object(view, &view_from_world, &clip_from_view, row2, spheres, valid, i, center,
+                              pos_range[4 * (size_t)i + 3], obj_type ? obj_type[i] : ORC_OBJ_POINT_LIGHT, 1u,
+                              spot_dir ? spot_dir + 3 * (size_t)i : NULL, spot_sin_cos ? spot_sin_cos + 2 * (size_t)i : NULL,
+                              &farthest, emit_push, &pc);
+        }
+    }
+    clock_gettime(CLOCK_MONOTONIC, &b);
+    if (total_out) *total_out = pc.total;
+    if (farthest_z_out) *farthest_z_out = farthest;
+    for (uint32_t c = 0; c < C; ++c) free(clusters[c].data);
+    free(clusters); free(spheres); free(valid);
+    return (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
+}
+
 void orc_mesh_inputs(const float g[12], const float c[3], const float h[3], int has_aabb, float wfl[12], float cull[8]) {
     /* transpose_3x3.{x,y,z}_axis.extend(translation.{x,y,z}) */
     for (int r = 0; r < 3; ++r) {

@@ -308,6 +308,13 @@ uint64_t orc_assign_objects_to_clusters_layers64(const orc_cluster_view* view, u
                                                  const float* spot_sin_cos, uint32_t* offsets, uint32_t* indices,
                                                  uint64_t capacity, uint32_t* counts, float* farthest_z_out);
 
+/* bench.py's CPU baseline of the cluster stage: the per-object loop ONCE per frame, every touched cluster's list grown by push
+ * (assign.rs:740-800; the lists keep their capacity from frame to frame) -- `iters` frames, returns the seconds they took.
+ * (orc_assign_objects_to_clusters walks the objects twice to hand out a CSR; as a baseline that would flatter the device.) */
+double orc_bench_assign_objects_to_clusters(const orc_cluster_view* view, uint32_t n_objects, const float* pos_range,
+                                            const uint8_t* obj_type, const float* spot_dir, const float* spot_sin_cos, int iters,
+                                            uint64_t* total_out, float* farthest_z_out);
+
 /* The GPU wire format of one view's clusters, storage-buffer flavour: extract_clusters_for_cpu_clustering +
  * prepare_clusters_for_cpu_clustering, crates/bevy_pbr/src/cluster/mod.rs:394-476,478-582, push_offset_and_counts
  * :634-650, push_index / push_dummy_index :690-700.  Input = the per-cluster lists (CSR) and counts the assignment

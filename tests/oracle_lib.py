@@ -417,6 +417,16 @@ def assign_objects_to_clusters(view, pos_range, obj_type=None, layer_mask=None, 
     return offsets, indices[:min(int(total), capacity)], counts.reshape(ncl, 6), float(far.value), int(total)
 
 
+def bench_assign_objects_to_clusters(view, pos_range, iters, obj_type=None, spot_dir=None, spot_sin_cos=None):
+    """The reference's one-walk, push-per-cluster form of the assignment, `iters` frames; -> (seconds, total entries, farthest_z)."""
+    n = len(pos_range) // 4
+    total, far = C.c_uint64(0), C.c_float(0)
+    lib().orc_bench_assign_objects_to_clusters.restype = C.c_double
+    secs = lib().orc_bench_assign_objects_to_clusters(C.byref(view), n, fp(pos_range), u8p(obj_type), fp(spot_dir), fp(spot_sin_cos), int(iters),
+                                                      C.byref(total), C.byref(far))
+    return float(secs), int(total.value), float(far.value)
+
+
 def mesh_inputs(g, c, h, flags, rows):
     """-> (world_from_local f32[len(rows)*12], culling f32[len(rows)*8]) for the listed rows."""
     m = len(rows)

@@ -2,30 +2,65 @@
  * yields, copied from the component columns straight into the library's pinned upload window.  In a Bevy app this is a par_iter over
  * the tables (the Rust shim's upload_and_propagate; the C++ host layer's chunked loop in bevy_mi355x_host.hpp); the Python harness
  * has no such loop of its own -- one thread of numpy's take() was 1.9 of the 2.7 ms of a 10 %-dirty frame, a harness artefact the
- * line then carried as if it were the product's.  HARNESS code: not part of the library, not the oracle.  gcc -O2 -fopenmp. */
+ * line then carried as if it were the product's.  HARNESS code: not part of the library, not the oracle.  gcc -O2 -pthread.
+ * Plain threads, started per call (a few of them, ~30 us each: small against the loop; an OpenMP team spun for 25 ms per call in a
+ * CPU-throttled container). */
+#include <pthread.h>
 #include <stdint.h>
 #include <string.h>
 
+typedef struct {
+    uint32_t a, b, lo;
+    const uint32_t* rows;
+    const float *t3, *r4, *s3;
+    uint32_t* out_rows;
+    float *out_t, *out_r, *out_s;
+} job_t;
+
+static void* gather_job(void* p) {
+    const job_t* j = (const job_t*)p;
+    for (uint32_t i = j->a; i < j->b; ++i) {
+        const uint32_t row = j->rows[i];
+        j->out_rows[i] = row;
+        memcpy(j->out_t + 3 * (size_t)i, j->t3 + 3 * (size_t)row, 12);
+        memcpy(j->out_r + 4 * (size_t)i, j->r4 + 4 * (size_t)row, 16);
+        memcpy(j->out_s + 3 * (size_t)i, j->s3 + 3 * (size_t)row, 12);
+    }
+    return 0;
+}
+static void* copy_job(void* p) {
+    const job_t* j = (const job_t*)p;
+    const size_t a = j->a, n = (size_t)j->b - j->a, src = (size_t)j->lo + a;
+    if (j->out_t) memcpy(j->out_t + 3 * a, j->t3 + 3 * src, n * 12);
+    if (j->out_r) memcpy(j->out_r + 4 * a, j->r4 + 4 * src, n * 16);
+    if (j->out_s) memcpy(j->out_s + 3 * a, j->s3 + 3 * src, n * 12);
+    return 0;
+}
+static void run(void* (*fn)(void*), job_t* proto, uint32_t k, int threads) {
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    if (k < 8192u) threads = 1;
+    job_t jobs[64];
+    pthread_t th[64];
+    for (int c = 0; c < threads; ++c) {
+        jobs[c] = *proto;
+        jobs[c].a = (uint32_t)((uint64_t)k * (uint64_t)c / (uint64_t)threads);
+        jobs[c].b = (uint32_t)((uint64_t)k * (uint64_t)(c + 1) / (uint64_t)threads);
+    }
+    for (int c = 1; c < threads; ++c) pthread_create(&th[c], 0, fn, &jobs[c]);
+    fn(&jobs[0]);
+    for (int c = 1; c < threads; ++c) pthread_join(th[c], 0);
+}
+
 void ecs_gather_rows(uint32_t k, const uint32_t* rows, const float* t3, const float* r4, const float* s3, uint32_t* out_rows,
                      float* out_t, float* out_r, float* out_s, int threads) {
-#pragma omp parallel for num_threads(threads) schedule(static)
-    for (int64_t i = 0; i < (int64_t)k; ++i) {
-        const uint32_t row = rows[i];
-        out_rows[i] = row;
-        memcpy(out_t + 3 * i, t3 + 3 * (size_t)row, 12);
-        memcpy(out_r + 4 * i, r4 + 4 * (size_t)row, 16);
-        memcpy(out_s + 3 * i, s3 + 3 * (size_t)row, 12);
-    }
+    job_t j = {0, 0, 0, rows, t3, r4, s3, out_rows, out_t, out_r, out_s};
+    run(gather_job, &j, k, threads);
 }
 
 /* dense: rows [lo, lo + m) of whichever components the window carries (NULL = not carried) */
 void ecs_copy_rows(uint32_t lo, uint32_t m, const float* t3, const float* r4, const float* s3, float* out_t, float* out_r, float* out_s,
                    int threads) {
-#pragma omp parallel for num_threads(threads) schedule(static)
-    for (int64_t c = 0; c < (int64_t)threads; ++c) {
-        const size_t a = (size_t)m * (size_t)c / (size_t)threads, b = (size_t)m * (size_t)(c + 1) / (size_t)threads;
-        if (out_t) memcpy(out_t + 3 * a, t3 + 3 * (lo + a), (b - a) * 12);
-        if (out_r) memcpy(out_r + 4 * a, r4 + 4 * (lo + a), (b - a) * 16);
-        if (out_s) memcpy(out_s + 3 * a, s3 + 3 * (lo + a), (b - a) * 12);
-    }
+    job_t j = {0, 0, lo, 0, t3, r4, s3, 0, out_t, out_r, out_s};
+    run(copy_job, &j, m, threads);
 }

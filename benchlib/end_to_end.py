@@ -31,13 +31,13 @@ _GATHER = None
 
 
 def build_gather(force=False):
-    """benchlib/ecs_gather.c -> benchlib/libecs_gather.so (gcc -O2 -fopenmp): the harness's stand-in for the ECS side's par_iter."""
+    """benchlib/ecs_gather.c -> benchlib/libecs_gather.so (gcc -O2 -pthread): the harness's stand-in for the ECS side's par_iter."""
     import os
     import subprocess
     here = os.path.dirname(os.path.abspath(__file__))
     src, so = os.path.join(here, "ecs_gather.c"), os.path.join(here, "libecs_gather.so")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.run(["gcc", "-O2", "-fopenmp", "-shared", "-fPIC", src, "-o", so], check=True, capture_output=True)
+        subprocess.run(["gcc", "-O2", "-pthread", "-shared", "-fPIC", src, "-o", so], check=True, capture_output=True)
     return so
 
 

@@ -262,6 +262,9 @@ def main():
         dist.barrier()
         if rank == 0:
             out["single_gpu_same_workload"] = single
+            # what the driver's curve cannot show (its N = 1 point is the metric frame, another workload): this line's value against the
+            # SAME scene on one GPU, per GPU
+            out["scaling_efficiency"] = round(out["value"] / (world * single["value"]), 4)
     if rank == 0 and world == 1 and workload == "frame" and not args.no_other_workloads:
         others = {}
         for name, builder in OTHER_WORKLOADS:

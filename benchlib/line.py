@@ -18,7 +18,7 @@ ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic
                  "moved_bytes_per_launch", "algorithmic_bytes_per_launch", "frac_algorithmic", "rocprof_avg_kernel_us")
 CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "host_cores")
 CONFIG_KEYS = ("workload", "baseline_config", "entities", "entities_total", "entities_this_rank", "rows_per_frame", "nodes", "lights",
-               "meshes", "views", "items", "parallelism", "row_summary")
+               "meshes", "views", "items", "parallelism", "row_summary", "rccl_ranks", "exchange_mode")
 
 
 def _clip(s, n):
@@ -49,13 +49,16 @@ def compact(out):
     e2e = out.get("end_to_end")
     if isinstance(e2e, dict) and "x_cpu_port" in e2e:
         # PCIe-inclusive frames (never `value`): us per frame and the ratio to the CPU port's frame, per dirty fraction
-        # (us_per_frame includes the harness's single-threaded numpy gather into the upload window; library_us = the library's calls alone)
+        # (us_per_frame includes the harness's gather loop into the upload window, benchlib/ecs_gather.c; library_us = the library's calls alone)
         line["end_to_end"] = {"us_per_frame": {k: v["us_per_frame"] for k, v in e2e.items() if isinstance(v, dict) and "us_per_frame" in v},
                               "library_us": {k: v["library_us"] for k, v in e2e.items() if isinstance(v, dict) and "library_us" in v},
                               "x_cpu_port": e2e["x_cpu_port"], "x_cpu_port_library_calls": e2e.get("x_cpu_port_library_calls")}
     sg = out.get("single_gpu_same_workload")
     if sg:
         line["single_gpu_same_workload"] = {"value": sg["value"], "ms_per_step": sg["ms_per_step"]}
+    for k in ("scaling_efficiency", "host_enqueue_ms_per_step"):  # N > 1: value / (n_gpus x the same workload on ONE GPU); CPU time per frame call
+        if k in out:
+            line[k] = out[k]
     line["full"] = FULL_NAME
     s = json.dumps(line)
     if len(s) > MAX_LINE_BYTES:  # cannot happen with the clips above; a guard, not a code path

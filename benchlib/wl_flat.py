@@ -28,6 +28,14 @@ def build_flat(ctx, args, rank, world, full_holder, n_global, n_views, name):
     deferred = not args.inline_compaction and not py_exchange
     more = B.CULL_MORE_FRAMES if deferred else 0
     fcount = [0]
+    calibration = None
+    if gather is not None and gather.native and not args.unfused:
+        def run_frames(k):
+            for f in range(k):
+                ctx.propagate_and_cull(frames[f % N_FRAMES], flags=B.CULL_END_FRAME | more)
+            ctx.exchange_last(True)
+            ctx.synchronize()
+        calibration = gather.calibrate(ctx, run_frames)
 
     def step(f):
         i = f % N_FRAMES
@@ -44,7 +52,7 @@ def build_flat(ctx, args, rank, world, full_holder, n_global, n_views, name):
         if py_exchange:
             gather.after_kernels(k)
 
-    config = {"workload": f"many_cubes-shaped flat scene, {n_global} entities, {n_views} camera frustum(s), all Transforms dirty, columns "
+    config = {"workload": f"propagate+cull" + (f"+all-gather, {world} ranks" if gather is not None else "") + f": many_cubes-shaped flat scene, {n_global} entities, {n_views} camera frustum(s), all Transforms dirty, columns "
                           f"resident in HBM: {'mi_propagate + mi_cull' if args.unfused else 'fused frame kernel'} (propagate + reset + "
                           "frustum cull + mark-newly-hidden) + VisibleEntities compaction"
                           + (" (deferred into the next frame's launch)" if deferred else "")
@@ -55,6 +63,13 @@ def build_flat(ctx, args, rank, world, full_holder, n_global, n_views, name):
               "parallelism": f"row-range shard x{world}", "row_summary": args.row_summary == 0}
     if gather is not None and gather.fallback_reason:
         config["rccl_direct_fallback"] = gather.fallback_reason
+    if gather is not None:
+        # what the exchange is, as the code set it up: ranks RCCL itself reports for the communicator (ncclCommCount), who drives it
+        config["rccl_ranks"] = gather.rccl_ranks()
+        if calibration:
+            config["exchange_calibration"] = calibration
+        config["exchange_mode"] = gather.mode + (", ncclAllGather enqueued by the library's exchange thread" if gather.native and not gather.pipelined
+                                                 and os.environ.get("MI_XCH_SYNC_ENQUEUE") is None else "")
     metric = ("entities/sec through propagate+cull (10M entities x 4 frusta, 1/2/4/8-GPU scaling)" if name == "sharded"
               else "entities/sec through propagate+cull")
     wl = Workload(name, step, n_local, flat_bytes_per_entity(n_views, not args.unfused),

@@ -46,7 +46,7 @@ def build_frame(ctx, args):
         else:
             ctx.propagate_and_cull(frames[i], flags=B.CULL_END_FRAME | B.CULL_WITH_CLUSTERS | concurrent | more)
 
-    config = {"workload": f"BASELINE.json metric, one frame in one context: {n_ent} many_cubes entities (configs[1]) + {args.meshes} meshes "
+    config = {"workload": f"propagate+cull+cluster 16x9x24 in ONE frame, ONE context: {n_ent} many_cubes entities (configs[1]) + {args.meshes} meshes "
                           f"and {args.lights} point lights of the many_lights shape (configs[2]; range 0.3, shell R = 50; lights are rows with a "
                           f"bounding Sphere) = {n_rows} rows, 1 camera, all Transforms dirty, columns resident in HBM: fused frame kernel "
                           "(propagate + reset + frustum cull + mark-newly-hidden) + VisibleEntities compaction"

@@ -926,7 +926,8 @@ int32_t mi_ctx_create(int32_t device, void* hip_stream, mi_ctx** out_ctx) {
         return fail(nullptr, MI_ERR_DEVICE, "raising the LDS limit of the clustering kernel failed: %s", msg.c_str());
     }
     ctx->level_offsets = {0, 0};
-    ctx->xch.debug = getenv("MI_XCH_DEBUG") != nullptr;  // the one environment knob left: read once, here
+    ctx->xch.debug = getenv("MI_XCH_DEBUG") != nullptr;  // environment knobs of the exchange: read once, here
+    ctx->xch.async_enqueue = getenv("MI_XCH_SYNC_ENQUEUE") == nullptr;  // (set: ncclAllGather is enqueued on the caller's thread again)
     *out_ctx = ctx;
     return MI_OK;
 }

@@ -219,6 +219,11 @@ struct mi_ctx {
         bool on = false;
         bool simple = true;      // MI_EXCHANGE_SIMPLE (default) or MI_EXCHANGE_GROUPED / MI_EXCHANGE_PIPELINED
         bool grouped = false;    // MI_EXCHANGE_GROUPED: the frame calls leave the all-gather pending for mi_exchange_group_flush
+        // MI_EXCHANGE_SIMPLE (not grouped): ncclAllGather is enqueued by the library's exchange thread instead of the caller's -- RCCL's
+        // enqueue path costs 15 - 20 us of CPU per call, more than the rest of the frame call; the ordering stays plain events (the
+        // caller records "kernels done" and hands the slot over; the thread does wait / all-gather / record on the communication
+        // stream).  MI_XCH_SYNC_ENQUEUE=1 (read at mi_ctx_create) keeps the call on the caller's thread.
+        bool async_enqueue = true;
         bool group_pending = false;
         uint32_t group_slot = 0;
         bool debug = false;      // MI_XCH_DEBUG, read once at mi_ctx_create

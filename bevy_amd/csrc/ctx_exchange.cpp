@@ -129,12 +129,20 @@ void exchange_worker(mi_ctx* ctx) {
         const auto tw0 = std::chrono::steady_clock::now();
         const uint32_t k = (uint32_t)(x.worker_frames % x.n_comms);  // frame f travels on communicator f % n_comms
         hipStream_t cs = x.comm_stream[k];
-        if (hipStreamWaitValue32(cs, job.flag, job.value, hipStreamWaitValueGte, 0xFFFFFFFFu) != hipSuccess) err = -1;
         char* base = (char*)x.buf[slot];
-        if (!err) err = x.all_gather(base + (size_t)x.rank * x.block_bytes, base, (size_t)x.block_bytes, 1 /* ncclUint8 */, x.comm[k], cs);
-        if (hipEventRecord(x.ev_gathered[slot], cs) != hipSuccess && !err) err = -2;
-        // completion counter the caller's thread can read without a driver call
-        if (hipStreamWriteValue32(cs, (void*)(x.done_flag + k), (uint32_t)(x.worker_frames / x.n_comms + 1), 0) != hipSuccess && !err) err = -3;
+        if (x.simple) {
+            // plain event ordering, only on this thread: behind the frame's kernels (the caller recorded ev_kernels[slot] before it
+            // handed the slot over), the all-gather, the event mi_exchange_last and the buffer's next user wait on
+            if (hipStreamWaitEvent(cs, x.ev_kernels[slot], 0) != hipSuccess) err = -1;
+            if (!err) err = x.all_gather(base + (size_t)x.rank * x.block_bytes, base, (size_t)x.block_bytes, 1 /* ncclUint8 */, x.comm[k], cs);
+            if (hipEventRecord(x.ev_gathered[slot], cs) != hipSuccess && !err) err = -2;
+        } else {
+            if (hipStreamWaitValue32(cs, job.flag, job.value, hipStreamWaitValueGte, 0xFFFFFFFFu) != hipSuccess) err = -1;
+            if (!err) err = x.all_gather(base + (size_t)x.rank * x.block_bytes, base, (size_t)x.block_bytes, 1 /* ncclUint8 */, x.comm[k], cs);
+            if (hipEventRecord(x.ev_gathered[slot], cs) != hipSuccess && !err) err = -2;
+            // completion counter the caller's thread can read without a driver call
+            if (hipStreamWriteValue32(cs, (void*)(x.done_flag + k), (uint32_t)(x.worker_frames / x.n_comms + 1), 0) != hipSuccess && !err) err = -3;
+        }
         ++x.worker_frames;
         x.dbg_worker_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tw0).count();
         {
@@ -178,7 +186,19 @@ int32_t exchange_begin(mi_ctx* ctx) {
         // the buffer was last used n_bufs frames ago: its all-gather must have drained before the kernels overwrite it
         // (asked on the host first: with the buffers rotating that all-gather is normally long done, and a wait packet in the compute
         // queue costs ~6 us of every frame whether it has anything to wait for or not)
-        if (x.frame >= x.n_bufs && hipEventQuery(x.ev_gathered[slot]) != hipSuccess) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, x.ev_gathered[slot], 0));
+        if (x.frame >= x.n_bufs) {
+            // (asynchronous enqueue: the event is only meaningful once the exchange thread has recorded it for the buffer's last use,
+            // n_bufs frames ago -- normally long since)
+            if (x.async_enqueue && !x.grouped) {
+                const int32_t rcw = exchange_wait_issued(ctx, x.frame - x.n_bufs + 1);
+                if (rcw) return rcw;
+            }
+            const hipError_t q = hipEventQuery(x.ev_gathered[slot]);
+            if (q != hipSuccess) {
+                (void)hipGetLastError();  // hipErrorNotReady is an answer, not a failure: it must not surface as the next launch's status
+                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, x.ev_gathered[slot], 0));
+            }
+        }
         ctx->ext_bitmask = x.buf[slot];
         ctx->ext_words_per_view = x.words_per_view;
         ctx->ext_word_offset = x.word_offset;
@@ -242,6 +262,11 @@ int32_t exchange_end(mi_ctx* ctx) {
             if (x.group_pending) return fail(ctx, MI_ERR_NOT_READY, "MI_EXCHANGE_GROUPED: the previous frame's all-gather was never flushed (mi_exchange_group_flush)");
             x.group_pending = true;
             x.group_slot = slot;
+            ++x.frame;
+            return MI_OK;
+        }
+        if (x.async_enqueue) {  // the exchange thread enqueues wait + ncclAllGather + record (exchange_worker)
+            exchange_push(ctx, mi_ctx::Exchange::Job{slot, nullptr, 0u});
             ++x.frame;
             return MI_OK;
         }
@@ -404,6 +429,14 @@ int32_t mi_exchange_configure_multi(mi_ctx* ctx, void* const* nccl_comms, uint32
         x.frame = 0;
         x.kernel_signal = false;
         x.signalled = false;
+        if (x.async_enqueue && !x.grouped) {
+            x.worker_frames = 0;
+            x.submitted = x.issued = 0;
+            x.submitted_fast.store(0);
+            x.worker_error = 0;
+            x.queue.clear();
+            x.worker = std::thread(exchange_worker, ctx);
+        }
         x.on = true;
         ctx->culled = false;
         return MI_OK;
@@ -450,7 +483,7 @@ int32_t mi_exchange_last(mi_ctx* ctx, void** out_device_buf, int32_t wait) {
     const uint32_t slot = (uint32_t)((x.frame - 1) % x.n_bufs);
     int32_t rc = compaction_join(ctx);  // asynchronous compaction: also what releases the last frame's all-gather
     if (rc) return rc;
-    if (!x.simple && (rc = exchange_wait_issued(ctx, x.frame))) return rc;
+    if ((!x.simple || (x.async_enqueue && !x.grouped)) && (rc = exchange_wait_issued(ctx, x.frame))) return rc;
     if (x.grouped && x.group_pending) return fail(ctx, MI_ERR_NOT_READY, "mi_exchange_last: the frame's all-gather is still pending (mi_exchange_group_flush)");
     if (wait) HIP_TRY(ctx, hipEventSynchronize(x.ev_gathered[slot]));
     if (out_device_buf) *out_device_buf = x.buf[slot];

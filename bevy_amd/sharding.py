@@ -92,7 +92,7 @@ class MaskGatherer:
         # machinery (exchange thread, alternating communicators (MI_XCH_COMMS=1..4, default 2), kernel-signalled completion),
         # which has only ever been measured against a 1-rank communicator.
         self.pipelined = (os.environ.get("MI_XCH_MODE", "simple") == "pipelined") if pipelined is None else bool(pipelined)
-        default_comms = "2" if self.pipelined else "1"
+        default_comms = "1"  # (two alternating communicators: MI_XCH_COMMS=2 -- no faster on one GPU, and one ordering hazard more on eight)
         self.n_comms = int(os.environ.get("MI_XCH_COMMS", default_comms)) if n_comms is None else n_comms
         self.n_comms = max(1, min(4, self.n_comms))
         self.native = False
@@ -117,19 +117,66 @@ class MaskGatherer:
                 self.rccl = None
                 self.fallback_reason = self.fallback_reason or "another rank failed to set up direct RCCL"
 
-    def attach(self, ctx):
+    def attach(self, ctx, pipelined=None):
         """Hands the per-frame exchange to the library (mi_exchange_configure): one FFI call per frame then does
         bind + kernels + events + ncclAllGather natively.  Only in rccl-direct mode; returns whether it did."""
         if self.rccl is None:
             return False
         import ctypes as C
+        if pipelined is not None:
+            self.pipelined = bool(pipelined)
         fn = C.cast(self.rccl.ncclAllGather, C.c_void_p).value
+        if self.native:  # re-attaching in another mode: off first (drains what is in flight)
+            ctx.exchange_configure(None, None, None, 0, 0, 0, 0)
         ctx.exchange_set_mode(1 if self.pipelined else 0)
-        ctx.exchange_configure([c.value for c in self.comms], fn, [b.data_ptr() for b in self.bufs], self.w, self.rank * self.block,
+        comms = self.comms if self.pipelined else self.comms[:1]
+        ctx.exchange_configure([c.value for c in comms], fn, [b.data_ptr() for b in self.bufs], self.w, self.rank * self.block,
                                self.block * 8, self.rank)
         self.mode = "rccl-native-pipelined" if self.pipelined else "rccl-native"
         self.native = True
         return True
+
+    def calibrate(self, ctx, run_frames, frames=40, margin=0.93):
+        """The rule that picks the exchange mode, applied by measurement at start-up (every rank runs the same frames in lockstep, so
+        the collectives match): `frames` frames through the SIMPLE mode (events between the streams: two marker packets in the
+        compute queue per frame, ~10 us of device time whatever the kernel) and through the PIPELINED mode on ONE communicator (no
+        packet in the compute queue: the next frame's launch publishes "masks complete", the communication stream waits on the
+        value) -- pipelined where it is faster by more than 1 - margin ON EVERY RANK (a MIN-reduce of the verdicts: all ranks must
+        take the same path), simple otherwise.  run_frames(k) must enqueue k frames and return after they have completed.
+        MI_XCH_MODE=simple|pipelined in the environment skips the measurement.  Returns the record bench.py prints."""
+        import time
+        forced = os.environ.get("MI_XCH_MODE")
+        if self.rccl is None or not self.native or forced in ("simple", "pipelined"):
+            return {"chosen": "pipelined" if self.pipelined else "simple", "rule": "MI_XCH_MODE" if forced else "no direct RCCL: nothing to choose"}
+        timings = {}
+        for name, pipe in (("simple", False), ("pipelined", True)):
+            self.attach(ctx, pipelined=pipe)
+            run_frames(10)
+            t0 = time.perf_counter()
+            run_frames(frames)
+            timings[name] = (time.perf_counter() - t0) / frames
+        want = 1 if timings["pipelined"] < margin * timings["simple"] else 0
+        if _dist_on():
+            import torch.distributed as dist
+            flag = self.torch.tensor([want], dtype=self.torch.int32, device=self.bufs[0].device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            want = int(flag.item())
+        self.attach(ctx, pipelined=bool(want))
+        return {"chosen": "pipelined" if want else "simple", "simple_us_per_frame": round(1e6 * timings["simple"], 2),
+                "pipelined_us_per_frame": round(1e6 * timings["pipelined"], 2),
+                "rule": f"pipelined (one communicator, value-signalled) iff faster than {margin} x simple on every rank, {frames} frames each at start-up"}
+
+    def rccl_ranks(self):
+        """Ranks of the communicator as RCCL reports them (ncclCommCount); the torch.distributed world size on the portable path."""
+        if self.rccl is None:
+            return self.world
+        import ctypes as C
+        n = C.c_int(0)
+        try:
+            self.rccl.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+            return int(n.value) if self.rccl.ncclCommCount(self.comm, C.byref(n)) == 0 else None
+        except AttributeError:
+            return None
 
     # -- layout -------------------------------------------------------------------------------------
     def bind_args(self, frame):

@@ -784,9 +784,12 @@ int32_t mi_bind_visibility_output(mi_ctx* ctx, void* device_ptr, uint64_t words_
  * The reference has no counterpart (single process); this replaces nothing and adds the only collective. */
 /* How the library drives the exchange (set before mi_exchange_configure; default MI_EXCHANGE_SIMPLE):
  *   MI_EXCHANGE_SIMPLE     one communicator, one library-owned communication stream, plain event ordering: an event behind the
- *                          frame's kernels, ncclAllGather enqueued by the calling thread on the communication stream, and the
- *                          compute stream waits for a buffer's previous all-gather (hipStreamWaitEvent) before its kernels
- *                          overwrite it.  Nothing clever, nothing that has only ever been measured on one GPU.
+ *                          frame's kernels, wait + ncclAllGather + event on the communication stream, and the compute stream
+ *                          waits for a buffer's previous all-gather (hipStreamWaitEvent) before its kernels overwrite it.  Since
+ *                          round 5 the three communication-stream calls are made by a library-owned thread the frame call hands
+ *                          the buffer's slot to (RCCL's enqueue path is 15 - 20 us of CPU per call: more than the rest of the
+ *                          frame call, and at an 8-GPU shard size more than the frame's kernel); every rank's thread issues its
+ *                          all-gathers in frame order.  MI_XCH_SYNC_ENQUEUE=1 in the environment keeps them on the calling thread.
  *   MI_EXCHANGE_PIPELINED  the latency-hiding variant built in round 1 against a 1-rank communicator: a library-owned host
  *                          thread enqueues the collectives, several communicators alternate by frame, the "masks complete"
  *                          signal is stored by the compaction kernel itself and awaited with hipStreamWaitValue32, buffer reuse

@@ -34,7 +34,9 @@ def canned(n_gpus=1):
     if n_gpus > 1:
         out.update({"scaling": "strong", "metric": "entities/sec through propagate+cull (10M entities x 4 frusta, 1/2/4/8-GPU scaling)",
                     "cpu_baseline": None, "single_gpu_same_workload": {"value": 5.5e10, "unit": "entities/s", "ms_per_step": 0.18, "note": long}})
-        out["config"].update({"entities_total": 10_000_000, "entities_this_rank": 1_250_000, "parallelism": "row-range shard x8"})
+        out["config"].update({"entities_total": 10_000_000, "entities_this_rank": 1_250_000, "parallelism": "row-range shard x8", "rccl_ranks": 8,
+                              "exchange_mode": "rccl-native, ncclAllGather enqueued by the library's exchange thread"})
+        out.update({"scaling_efficiency": 0.81, "host_enqueue_ms_per_step": 0.0093})
         del out["end_to_end"], out["other_workloads"]
     return out
 
@@ -64,6 +66,20 @@ def test_sharded_line_is_compact_and_complete():
     d = json.loads(s)
     assert REQUIRED <= set(d) and d["scaling"] == "strong" and d["n_gpus"] == 8 and d["cpu_baseline"] is None
     assert d["single_gpu_same_workload"]["value"] == 5.5e10
+    # what the exchange was and what it cost the calling thread, next to the efficiency against the same scene on one GPU
+    assert d["config"]["rccl_ranks"] == 8 and d["config"]["exchange_mode"].startswith("rccl-native")
+    assert d["scaling_efficiency"] == 0.81 and d["host_enqueue_ms_per_step"] == 0.0093
+
+
+def test_the_stage_list_leads_the_workload_string():
+    """The driver keeps the first ~100 characters of config.workload: they must say which stages ran (the clipped string
+    did not say that clustering is in the metric frame)."""
+    import re
+    for name in ("wl_frame.py", "wl_flat.py"):
+        src = open(os.path.join(ROOT, "benchlib", name)).read()
+        m = re.search(r'config = \{"workload": f"([^"]*)"', src)
+        assert m and m.group(1).startswith("propagate+cull"), (name, m and m.group(1)[:60])
+    assert "propagate+cull+cluster 16x9x24" in open(os.path.join(ROOT, "benchlib", "wl_frame.py")).read()
 
 
 def test_roofline_prices_the_launch_at_the_bytes_it_moves():

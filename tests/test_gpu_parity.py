@@ -621,6 +621,32 @@ def test_mask_gatherer_single_rank_pipeline(ctx_factory, n_comms, more, pipeline
         ctx2.exchange_configure(None, None, None, 0, 0, 0, 0)
         ctx2.propagate_and_cull(frusta, flags=B.CULL_END_FRAME)
         assert_bits(ctx2.download_visibility(0), vis_exp[0], "after switching the exchange off")
+        g.native = False
+        if n_comms == 1 and g.attach(ctx2):
+            # the start-up rule that picks the mode (MaskGatherer.calibrate: both modes timed over the same frames, the faster one kept):
+            # whichever it keeps, the frames behind it gather the right masks
+            def run_frames(k):
+                for f in range(k):
+                    ctx2.propagate_and_cull(frusta, flags=B.CULL_END_FRAME | more)
+                ctx2.exchange_last(True)
+                ctx2.synchronize()
+            rec = g.calibrate(ctx2, run_frames, frames=12)
+            assert rec["chosen"] in ("simple", "pipelined") and g.native
+            assert g.mode == ("rccl-native-pipelined" if rec["chosen"] == "pipelined" else "rccl-native")
+            if "simple_us_per_frame" in rec:
+                assert rec["simple_us_per_frame"] > 0 and rec["pipelined_us_per_frame"] > 0
+            k0 = None
+            for frame in range(3):
+                fr2 = frusta_for([W.many_cubes_camera(7 + frame * 11), W.many_cubes_camera(frame * 3, yaw=0.6)])
+                ctx2.propagate_and_cull(fr2, flags=B.CULL_END_FRAME | more)
+                _, vv, vis_exp, _ = oracle_frame(sc, vv, fr2, None, None)
+                ptr = ctx2.exchange_last(wait=True)
+                bufs = [b for b in g.bufs if b.data_ptr() == ptr]
+                assert len(bufs) == 1
+                words = bufs[0].cpu().numpy()
+                for v in range(n_views):
+                    assert_bits(sharding.unpack_view(words, n, 1, n_views, v), vis_exp[v], f"behind the calibration, frame {frame} view {v}")
+            ctx2.exchange_configure(None, None, None, 0, 0, 0, 0)
     g.close()
 
 

@@ -313,6 +313,10 @@ struct mi_ctx {
     uint64_t seg_stride = 0;
 
     // ---- clustering ----
+    // view_z_to_z_slice evaluates ln() with a restatement of glibc's logf (cluster_walk.h); the host's own logf is what a Bevy built
+    // here would call (bevy_math::ops::ln -> std -> libm).  Compared once, on the first perspective view: 0 = not yet, 1 = agree,
+    // 2 = they differ (musl, another glibc, a vector libm): the cluster entry points then refuse, and the shim's stock system takes over
+    uint32_t libm_state = 0;
     DevBuf cl_pos, cl_type, cl_layers, cl_layers_hi, cl_dir, cl_sincos, cl_planes, cl_spheres;
     // batching work-item build (kernels_batch.hip)
     uint32_t *bt_set = nullptr, *bt_bin = nullptr, *bt_input = nullptr, *bt_row_meta = nullptr;  // per-row columns

@@ -1,6 +1,8 @@
 // ctx_cluster.cpp -- clustered-forward light assignment entry points.
 #include "ctx.h"
 
+#include <cmath>
+
 using namespace mi;
 using namespace mi_detail;
 
@@ -155,9 +157,61 @@ int32_t mi_cluster_select_view(mi_ctx* ctx, uint32_t slot) {
     return MI_OK;
 }
 
+namespace {
+// The one library call on the device side of the path: ln() in view_z_to_z_slice (assign.rs:1057).  The device carries glibc's logf;
+// whether THIS host's libm is that function is checked here, once per context, over a fixed table (every binade from 2^-12 to 2^20,
+// 96 mantissas each, plus the values around 1 where the algorithm switches branches) instead of being assumed (include/bevy_mi355x.h
+// used to say "glibc >= 2.28 on x86-64 is the supported host libm" and leave it at that).
+int32_t libm_self_test(mi_ctx* ctx) {
+    if (ctx->libm_state == 1) return MI_OK;
+    if (ctx->libm_state == 0) {
+        std::vector<float> in;
+        uint64_t rng = 0x9E3779B97F4A7C15ull;
+        for (int e = -12; e <= 20; ++e)
+            for (int k = 0; k < 96; ++k) {
+                rng ^= rng << 13, rng ^= rng >> 7, rng ^= rng << 17;
+                const uint32_t bits = ((uint32_t)(e + 127) << 23) | (uint32_t)(rng & 0x7FFFFFu);
+                float x;
+                memcpy(&x, &bits, 4);
+                in.push_back(x);
+            }
+        for (int k = -64; k <= 64; ++k) {
+            const uint32_t bits = 0x3f800000u + (uint32_t)k;
+            float x;
+            memcpy(&x, &bits, 4);
+            in.push_back(x);
+        }
+        const uint32_t n = (uint32_t)in.size();
+        std::vector<float> out(n);
+        int32_t rc = mi_debug_logf(ctx, in.data(), out.data(), n);
+        if (rc) return rc;
+        uint32_t bad = 0, first = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const float h = logf(in[i]);
+            if (memcmp(&h, &out[i], 4) != 0 && !bad++) first = i;
+        }
+        if (getenv("MI_DEBUG_FORCE_LIBM_MISMATCH")) bad = bad ? bad : 1;  // (test hook: tests/test_gpu_cluster.py)
+        ctx->libm_state = bad ? 2 : 1;
+        if (bad) {
+            uint32_t xb, hb, db;
+            const float h = logf(in[first]);
+            memcpy(&xb, &in[first], 4), memcpy(&hb, &h, 4), memcpy(&db, &out[first], 4);
+            return fail(ctx, MI_ERR_DEVICE, "the host's logf differs from the device's (glibc's) at %u of %u probes, first at 0x%08x: host 0x%08x, device 0x%08x -- "
+                        "cluster z slices could differ from this host's own assign_objects_to_clusters: the stock system must assign", bad, n, xb, hb, db);
+        }
+        return MI_OK;
+    }
+    return fail(ctx, MI_ERR_DEVICE, "the host's logf differs from the device's (checked when the first perspective view was uploaded): the stock system must assign");
+}
+}  // namespace
+
 int32_t mi_cluster_upload_view(mi_ctx* ctx, const mi_cluster_view* view) {
     ENTER(ctx);
     if (!view || !view->x_planes || !view->y_planes || !view->z_planes) return fail(ctx, MI_ERR_INVALID_ARG, "mi_cluster_upload_view: NULL");
+    if (!view->is_orthographic) {  // (an orthographic view's z slices are linear in view_z: no ln, assign.rs:1051-1054)
+        const int32_t rcl = libm_self_test(ctx);
+        if (rcl) return rcl;
+    }
     const uint64_t C = (uint64_t)view->dims[0] * view->dims[1] * view->dims[2];
     if (C == 0 || C > 4096) return fail(ctx, MI_ERR_INVALID_ARG, "cluster count %llu outside 1..4096 (assign.rs:410-413)", (unsigned long long)C);
     const uint32_t nx = view->dims[0] + 1, ny = view->dims[1] + 1, nz = view->dims[2] + 1;

@@ -500,8 +500,10 @@ int32_t mi_cluster_sort_truncate(uint32_t n, const uint8_t* obj_type, const uint
  * Supported host libm: the z slice of a depth is floor(ln(z) * scale - bias) (view_z_to_z_slice, assign.rs:1003-1024), and the
  * device evaluates ln with glibc's logf (>= 2.28, x86-64: correctly rounded in all but a handful of inputs, reproduced bit for bit,
  * mi_debug_logf, tests/test_gpu_parity.py::test_device_logf_matches_libm).  A Bevy built against another libm (musl, macOS, Windows' UCRT) may round ln(z)
- * differently for depths within an ulp of a slice boundary: such an object can then differ by one z slice from that host's own
- * assign_objects_to_clusters.  Everything else on the device is +, -, *, /, sqrt, floor, min, max: IEEE, no library; the host
+ * differently for depths within an ulp of a slice boundary: such an object could then differ by one z slice from that host's own
+ * assign_objects_to_clusters.  The library does not assume: the first perspective view uploaded on a context compares the device's
+ * logf with the host's over a fixed table of 3 297 probes, and on ANY difference mi_cluster_upload_view (hence every assignment)
+ * returns MI_ERR_DEVICE from then on -- "run the stock CPU system": clusters fall back, propagate and cull are unaffected.  Everything else on the device is +, -, *, /, sqrt, floor, min, max: IEEE, no library; the host
  * helpers (mi_cluster_view_build's powf, mi_perspective_clip_from_view's sin / cos) call the host's own libm, as Bevy would. */
 int32_t mi_cluster_assign(mi_ctx* ctx, const mi_cluster_view* view, uint32_t n_objects, const float* pos_range,
                           const uint8_t* obj_type, const uint32_t* layer_mask, const float* spot_dir,

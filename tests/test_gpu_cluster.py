@@ -389,3 +389,30 @@ def test_cluster_objects_on_render_layers_32_to_63(ctx_factory):
     ctx.cluster_upload_view(view)
     ctx.cluster_assign_resident()
     assert ctx.cluster_download(view.n_clusters)[4] == 0
+
+
+def test_host_libm_is_checked_before_the_first_perspective_view(ctx_factory, monkeypatch):
+    """view_z_to_z_slice's ln() (assign.rs:1057) is the one library call of the path: the device carries glibc's logf, and the library
+    compares it with THIS host's logf when a context gets its first perspective view (3 297 probes).  They agree on the supported
+    hosts (this box); when they do not -- forced here -- every assignment is refused with MI_ERR_DEVICE, i.e. handed to the stock
+    system, while propagate and cull go on, and orthographic views (no ln) are still served."""
+    sc = W.many_cubes(5_000)
+    pr = rand_lights(300, 40.0, 6.0, 4)
+    cam = W.many_cubes_camera(3)
+    frusta = frusta_for([cam])
+    view, keep, ov = both_views(cam)
+    ok = ctx_factory()
+    assert_same_assignment(ok.cluster_assign(view, pr), O.assign_objects_to_clusters(ov, pr))  # (the check passed on this host)
+    monkeypatch.setenv("MI_DEBUG_FORCE_LIBM_MISMATCH", "1")
+    bad = ctx_factory()
+    upload_scene(bad, sc)
+    for _ in range(2):  # the verdict sticks
+        with pytest.raises(api.MiError) as e:
+            bad.cluster_assign(view, pr)
+        assert e.value.code == api.MI_ERR_DEVICE and "logf" in str(e.value)
+    bad.propagate_and_cull(frusta, flags=B.CULL_END_FRAME)  # the rest of the path is unaffected
+    g_exp, vv_exp, vis_exp, _ = O.full_frame(sc["translation"], sc["rotation"], sc["scale"], sc["aabb_center"], sc["aabb_half"], sc["flags"],
+                                             sc["layers"], np.zeros(sc["n"], np.uint8), frusta)
+    assert_bits(bad.download_visibility(0), vis_exp[0], "cull on a context whose clusters fell back")
+    oview, okeep, oov = both_views(cam, ortho=True)
+    assert_same_assignment(bad.cluster_assign(oview, pr), O.assign_objects_to_clusters(oov, pr))

@@ -606,7 +606,8 @@ static int32_t cells_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, 
     const uint32_t lists_views = ce.lists_views;
     ce.lists_pending = false;  // (every way out below either carries the job in the frame's launch or launches it: lists_out)
     auto lists_out = [&]() {
-        if (ride_lists) launch_cells_lists(lists_job, lists_views, ctx->stream);
+        if (ride_lists && launch_cells_lists(lists_job, lists_views, ctx->stream) != hipSuccess)
+            fail(ctx, MI_ERR_DEVICE, "the deferred lists of the frame before could not be launched");  // (recorded; the caller returns its own failure)
     };
     VisibilityOut vo{};
     CompactFastArgs prev_args{};
@@ -638,11 +639,12 @@ static int32_t cells_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, 
     ce.chain_ok = false;
     if (!chained) {
         if (!build && ce.frames) {  // pass_s describes masks this frame does not continue (another number of views, a frame in between whose
-            // counts never ran): start over on a fresh order
-            if ((rc = cells_build(ctx))) {
-                ce.valid = false;
+            // counts never ran): the frame starts from zeroed masks and zeroed contributions (CellsWork::fresh: pass_s is not read, every
+            // processed slot rewrites it; the cells k_cells_test skips -- nothing visible, nothing was -- hold zeros already, and the
+            // memset makes that independent of how they got there).  Round 4 rebuilt the whole order here: bounds, keys, a radix sort
+            // of n rows and the gather, just to reach this state -- every frame, for a caller that alternates between view counts.
+            if ((rc = hip_rc(ctx, hipMemsetAsync(ce.pass_s.p, 0, (size_t)ce.n_waves * 64 * 4, ctx->stream), "zeroing the cull order's contributions")))
                 return give_back(rc);
-            }
         }
         if ((rc = hip_rc(ctx, hipMemsetAsync(vo.bitmask + vo.word_offset, 0, bm_words * 8, ctx->stream), "zeroing the frame's masks"))) return give_back(rc);
     }

@@ -80,6 +80,8 @@ int32_t mi_cluster_bind_objects_to_rows(mi_ctx* ctx, uint32_t first_row, uint32_
     ENTER(ctx);
     if (n_objects == 0) {
         ctx->cl_rows_bound = false;
+        ctx->cl_assigned = false;
+        for (auto& parked : ctx->cl_parked) parked.assigned = false;
         return MI_OK;
     }
     if (n_objects != ctx->cl_n)
@@ -90,6 +92,7 @@ int32_t mi_cluster_bind_objects_to_rows(mi_ctx* ctx, uint32_t first_row, uint32_
     ctx->cl_rows_listed = false;
     ctx->cl_first_row = first_row;
     ctx->cl_assigned = false;
+    for (auto& parked : ctx->cl_parked) parked.assigned = false;  // (the binding is shared: every view's assignment was over the old one)
     return MI_OK;
 }
 
@@ -112,6 +115,7 @@ int32_t mi_cluster_bind_objects_to_row_list(mi_ctx* ctx, uint32_t n_objects, con
     ctx->cl_rows_listed = true;
     ctx->cl_first_row = 0;
     ctx->cl_assigned = false;
+    for (auto& parked : ctx->cl_parked) parked.assigned = false;  // (as above)
     return MI_OK;
 }
 

@@ -365,3 +365,25 @@ def test_lists_that_rode_in_the_next_frames_launch_are_that_frames_lists():
         # and what the API shows is frame 7's
         for v in range(n_views):
             assert np.array_equal(ctx.download_visible_entities(v, 0)[1], expected[7][v])
+
+
+def test_alternating_view_counts_do_not_rebuild_the_order():
+    """A caller that alternates between view counts on a static scene (a picture-in-picture camera every other frame): each such frame
+    cannot continue the masks of the frame before -- it starts from zeroed masks and zeroed contributions (CellsWork::fresh) over the SAME
+    order.  Round 4 rebuilt the order (bounds, keys, radix sort, gather) on every one of those frames; results are identical either way."""
+    n = 30_007
+    sc = W.many_cubes(n, radius=60.0, ragged_flags=True)
+    g, _ = O.sync_simple_transforms(sc["translation"], sc["rotation"], sc["scale"])
+    with api.Context(0) as ctx:
+        setup(ctx, sc)
+        vv = np.zeros(n, np.uint8)
+        builds = []
+        for frame in range(9):
+            k = (1, 3, 2)[frame % 3] if frame < 6 else 2  # 1, 3, 2, 1, 3, 2 views, then three chained frames of 2
+            frusta = frusta_for(cams(frame, k))
+            ctx.cull(frusta, flags=WHOLE)
+            vv, vis, chg = oracle_cull(sc, g, vv, frusta)
+            check_frame(ctx, vv, vis, chg, f"frame {frame} with {k} view(s)")
+            builds.append(ctx.debug_static_cull_counts()[0])
+        assert builds[-1] == builds[0] == 1, f"the order was built {builds} times over nine frames of one static scene"
+        assert ctx.debug_static_cull_counts()[1] == 9

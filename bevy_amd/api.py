@@ -201,7 +201,7 @@ ABI_SYMBOLS = [
     "mi_cluster_assign_frame",
     "mi_batch_upload_rows", "mi_batch_upload_sets", "mi_batch_upload_row_bins", "mi_batch_upload_bins", "mi_batch_build", "mi_batch_build_phase",
     "mi_batch_sorted_build", "mi_batch_download_totals", "mi_batch_download", "mi_perspective_clip_from_view", "mi_compute_frustum",
-    "mi_bind_visibility_output", "mi_exchange_set_mode", "mi_exchange_configure", "mi_exchange_configure_multi", "mi_exchange_group_flush", "mi_exchange_last", "mi_device_buffer",
+    "mi_bind_visibility_output", "mi_exchange_set_mode", "mi_exchange_configure", "mi_exchange_configure_multi", "mi_exchange_configure_owned", "mi_exchange_group_flush", "mi_exchange_last", "mi_exchange_download", "mi_device_buffer",
 ]
 # include/bevy_mi355x_debug.h: instrumentation and test hooks, exported by the same library, not part of the boundary
 DEBUG_SYMBOLS = [
@@ -802,6 +802,12 @@ class Context:
     def exchange_set_mode(self, mode):
         """0 = MI_EXCHANGE_SIMPLE (default), 1 = MI_EXCHANGE_PIPELINED; before exchange_configure."""
         self._ck(self._lib.mi_exchange_set_mode(self._h, int(mode)))
+
+    def exchange_download(self, n_bytes):
+        """The most recent frame's gathered buffer on the host ([rank][view][word] as uint64), one copy behind its all-gather."""
+        out = np.zeros((int(n_bytes) + 7) // 8, np.uint64)
+        self._ck(self._lib.mi_exchange_download(self._h, out.ctypes.data_as(C.c_void_p), C.c_uint64(int(n_bytes))))
+        return out
 
     def exchange_last(self, wait=True):
         p = C.c_void_p()

@@ -105,11 +105,12 @@ def build_host_tests(force=False):
     """Compiles tests/cpp/host_systems_test.cpp (the C++ host layer + the reference's system tests) with g++ and links
     it against libbevy_mi355x.so.  Host code only: -ffp-contract=off keeps the value constructors in glam order."""
     exe, src = os.path.abspath(HOST_TEST_EXE), os.path.abspath(HOST_TEST_SRC)
-    deps = [src, HOST_HEADER, LIB, os.path.join(CSRC, "glam_math.h"), os.path.join(CSRC, "..", "..", "include", "bevy_mi355x.h")]
+    deps = [src, HOST_HEADER, os.path.join(os.path.dirname(HOST_HEADER), "bevy_mi355x_sharded.hpp"), LIB, os.path.join(CSRC, "glam_math.h"),
+            os.path.join(CSRC, "..", "..", "include", "bevy_mi355x.h")]
     if not force and os.path.exists(exe) and all(os.path.getmtime(d) <= os.path.getmtime(exe) for d in deps):
         return exe
     cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-Wall", src, "-o", exe, "-L", HERE,
-           "-lbevy_mi355x", "-Wl,-rpath,$ORIGIN/../../bevy_amd", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"]
+           "-lbevy_mi355x", "-ldl", "-Wl,-rpath,$ORIGIN/../../bevy_amd", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         sys.stderr.write(res.stdout + res.stderr)

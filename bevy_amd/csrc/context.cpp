@@ -983,6 +983,8 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
     for (auto& f : ctx->fb)
         for (DevBuf* b : {&f.bitmask, &f.wave_cnt, &f.seg_mask, &f.out_rows, &f.seg_totals})
             if (b->p) hipFree(b->p);
+    for (void* p : ctx->xch.owned)  // (mi_exchange_configure_owned's gathered buffers)
+        if (p) hipFree(p);
     {
         auto& ce = ctx->cells;  // the static cull order
         for (DevBuf* b : {&ce.perm, &ce.sph_s, &ce.g_s, &ce.vv_s, &ce.sum_a, &ce.sum_b, &ce.sum_h, &ce.state, &ce.keys_a, &ce.keys_b, &ce.vals_a, &ce.vals_b,

@@ -238,6 +238,7 @@ struct mi_ctx {
         static constexpr uint32_t MAX_BUFS = 8;
         uint32_t n_bufs = 0;
         void* buf[MAX_BUFS] = {nullptr};
+        void* owned[MAX_BUFS] = {nullptr};  // mi_exchange_configure_owned: buffers the library allocated (freed on reconfigure / destroy)
         uint64_t words_per_view = 0, word_offset = 0, block_bytes = 0;
         uint32_t rank = 0;
         uint64_t frame = 0;

@@ -476,6 +476,26 @@ int32_t mi_exchange_configure_multi(mi_ctx* ctx, void* const* nccl_comms, uint32
     return MI_OK;
 }
 
+int32_t mi_exchange_configure_owned(mi_ctx* ctx, void* const* nccl_comms, uint32_t n_comms, void* fn_nccl_all_gather, uint32_t n_bufs,
+                                    uint32_t world, uint64_t words_per_view, uint64_t word_offset, uint64_t block_bytes, uint32_t rank) {
+    ENTER(ctx);
+    auto& x = ctx->xch;
+    if (n_bufs < 2 || n_bufs > mi_ctx::Exchange::MAX_BUFS || world == 0 || block_bytes == 0)
+        return fail(ctx, MI_ERR_INVALID_ARG, "mi_exchange_configure_owned: n_bufs outside 2..8, world 0 or empty block");
+    // off first: whatever is in flight drains before the buffers it uses are freed
+    int32_t rc = mi_exchange_configure_multi(ctx, nullptr, 0, nullptr, nullptr, 0, 0, 0, 0, 0);
+    if (rc) return rc;
+    for (void*& p : x.owned)
+        if (p) { hipFree(p); p = nullptr; }
+    const size_t bytes = (size_t)world * block_bytes;
+    for (uint32_t i = 0; i < n_bufs; ++i) {
+        HIP_TRY(ctx, hipMalloc(&x.owned[i], bytes));
+        HIP_TRY(ctx, hipMemsetAsync(x.owned[i], 0, bytes, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return mi_exchange_configure_multi(ctx, nccl_comms, n_comms, fn_nccl_all_gather, x.owned, n_bufs, words_per_view, word_offset, block_bytes, rank);
+}
+
 int32_t mi_exchange_last(mi_ctx* ctx, void** out_device_buf, int32_t wait) {
     ENTER(ctx);
     auto& x = ctx->xch;
@@ -488,6 +508,17 @@ int32_t mi_exchange_last(mi_ctx* ctx, void** out_device_buf, int32_t wait) {
     if (wait) HIP_TRY(ctx, hipEventSynchronize(x.ev_gathered[slot]));
     if (out_device_buf) *out_device_buf = x.buf[slot];
     return MI_OK;
+}
+
+int32_t mi_exchange_download(mi_ctx* ctx, void* out_host, uint64_t bytes) {
+    void* buf = nullptr;
+    int32_t rc = mi_exchange_last(ctx, &buf, 0);  // (ENTER, joins a deferred compaction, waits until the all-gather is ISSUED)
+    if (rc) return rc;
+    if (!out_host || bytes == 0) return fail(ctx, MI_ERR_INVALID_ARG, "mi_exchange_download: NULL or empty");
+    auto& x = ctx->xch;
+    const uint32_t slot = (uint32_t)((x.frame - 1) % x.n_bufs);
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, x.ev_gathered[slot], 0));  // the copy runs on the context's stream, behind the collective
+    return download(ctx, out_host, buf, (size_t)bytes);
 }
 
 }  // extern "C"

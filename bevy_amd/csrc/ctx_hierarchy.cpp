@@ -120,7 +120,9 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
             uint32_t s = band_start(e, e > TILE_FAST_LEVELS ? e - TILE_FAST_LEVELS : 0);
             if (s > 0 && e > TILE_FAST_LEVELS) {
                 const uint32_t deep = band_start(e, e > TILE_MAX_LEVELS ? e - TILE_MAX_LEVELS : 0);
-                if (deep == 0 || level_size(e - 1) <= 64) s = deep;
+                uint64_t widest = 0;  // of the deeper band's levels: a chain (or a rope of a few strands) if none exceeds a wave
+                for (uint32_t l = deep; l < e; ++l) widest = std::max(widest, level_size(l));
+                if (deep == 0 || widest <= 64) s = deep;
             }
             uint64_t rows = 0;
             for (uint32_t l = s; l < e; ++l) rows += level_size(l);

@@ -367,6 +367,7 @@ class World {
 
   private:
     friend class Mi355xPlugin;
+    friend class Mi355xShardedPlugin;  // bevy_mi355x_sharded.hpp: the same World driven over several GPUs
     struct Rec {
         bool alive = false;
         uint32_t generation = 0;

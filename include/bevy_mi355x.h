@@ -818,12 +818,22 @@ int32_t mi_exchange_configure(mi_ctx* ctx, void* nccl_comm, void* fn_nccl_all_ga
 int32_t mi_exchange_configure_multi(mi_ctx* ctx, void* const* nccl_comms, uint32_t n_comms, void* fn_nccl_all_gather,
                                     void* const* device_bufs, uint32_t n_bufs, uint64_t words_per_view, uint64_t word_offset,
                                     uint64_t block_bytes, uint32_t rank);
+/* The same with the gathered buffers owned by the library (a host without a device allocator of its own: the Rust plugin, the C++ host
+ * layer): n_bufs buffers of world x block_bytes bytes each are allocated on the context's device, zeroed, and freed when the exchange is
+ * reconfigured or the context destroyed. */
+int32_t mi_exchange_configure_owned(mi_ctx* ctx, void* const* nccl_comms, uint32_t n_comms, void* fn_nccl_all_gather, uint32_t n_bufs,
+                                    uint32_t world, uint64_t words_per_view, uint64_t word_offset, uint64_t block_bytes, uint32_t rank);
 /* MI_EXCHANGE_GROUPED: issues the pending all-gather of every listed context inside one ncclGroupStart / ncclGroupEnd pair
  * (fn_* = the addresses of those two functions in the RCCL library the communicators belong to).  Call it after the frame calls of
  * all contexts, from the thread that made them. */
 int32_t mi_exchange_group_flush(mi_ctx* const* contexts, uint32_t n, void* fn_nccl_group_start, void* fn_nccl_group_end);
 /* The gathered buffer of the most recent frame (optionally after waiting for its collective). */
 int32_t mi_exchange_last(mi_ctx* ctx, void** out_device_buf, int32_t wait);
+
+/* The same buffer on the HOST: waits for the most recent frame's all-gather and copies the first `bytes` bytes of its gathered buffer
+ * ([rank][view][word], 64-bit words; bytes = world x block_bytes for all of it) into out_host -- ONE device-to-host copy gives a
+ * single-process host (a Bevy plugin driving several GPUs) every shard's ViewVisibility masks, whichever context it asks. */
+int32_t mi_exchange_download(mi_ctx* ctx, void* out_host, uint64_t bytes);
 
 /* Raw device pointers of library-owned columns, for zero-copy READERS on the same device (write through the upload entry points only:
  * the library keeps results that travel ahead of a frame and does not see a write through a raw pointer)

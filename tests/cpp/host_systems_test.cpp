@@ -16,6 +16,7 @@
 #include <functional>
 
 #include "../../bevy_amd/host/bevy_mi355x_host.hpp"
+#include "../../bevy_amd/host/bevy_mi355x_sharded.hpp"
 
 using namespace bevy_mi355x;
 
@@ -695,6 +696,89 @@ static void both_forms_leave_the_same_world() {
     }
 }
 
+// The plugin over several GPUs (bevy_mi355x_sharded.hpp: a context per device, rows in contiguous ranges, the masks all-gathered by RCCL
+// between ncclGroupStart / End and read back with ONE copy) against the single-device plugin on a twin World: after every frame the
+// same GlobalTransforms and change ticks, ViewVisibility and its ticks, VisibleEntities.  Device lists: {0} -- a 1-rank communicator,
+// every code path of the exchange but the wire --, {0, 0, 0} -- three shards on one GPU, no communicator (the masks are read per
+// context): the sharding itself, shard boundaries inside and at the end of the row space --, and, where the node has them (MI_TEST_DEVICES
+// = their number), every GPU.
+static void sharded_plugin_leaves_the_same_world() {
+    std::vector<std::vector<int>> lists = {{0}, {0, 0, 0}};
+    if (const char* nd = std::getenv("MI_TEST_DEVICES")) {
+        std::vector<int> all;
+        for (int d = 0; d < std::atoi(nd); ++d) all.push_back(d);
+        if (all.size() > 1) lists.push_back(all);
+    }
+    for (const std::vector<int>& devices : lists) {
+        World wa, wb;
+        Mi355xPlugin pa;
+        Mi355xShardedPlugin pb(devices);
+        if (devices.size() == 1 || (devices.size() > 1 && devices[0] != devices[1])) CHECK(pb.exchanged(), pb.exchange_note().c_str());
+        else CHECK(!pb.exchanged(), "a device named twice cannot form a communicator");
+        uint64_t rng = 0x853C49E6748FEA9Bull + devices.size();
+        auto next = [&rng]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+        auto frand = [&](float lo, float hi) { return lo + (hi - lo) * (float)(next() % 10000) / 10000.0f; };
+        std::vector<Entity> ents;
+        const int n = devices.size() == 3 ? 1100 : 3000;  // (1100 rows over three shards of 512: the last one is short)
+        for (int i = 0; i < n; ++i) {
+            Transform t = Transform::from_xyz(frand(-40, 40), frand(-25, 25), frand(-90, 30));
+            const float a = frand(-1.5f, 1.5f);
+            t.rotation = {std::sin(a), 0.0f, 0.0f, std::cos(a)};
+            t.scale = {frand(0.5f, 2.0f), frand(0.5f, 2.0f), frand(0.5f, 2.0f)};
+            Entity ea = wa.spawn(t), eb = wb.spawn(t);
+            CHECK(ea == eb, "twin worlds hand out the same entity");
+            if (next() % 8) { const Aabb bb{{frand(-1, 1), 0, 0}, {frand(0.2f, 2), frand(0.2f, 2), frand(0.2f, 2)}}; wa.insert_aabb(ea, bb); wb.insert_aabb(eb, bb); }
+            if (next() % 9 == 0) { wa.insert_visibility(ea, Visibility::Hidden); wb.insert_visibility(eb, Visibility::Hidden); }
+            if (next() % 5 == 0) { const VisibilityRange vr = VisibilityRange::abrupt(frand(0, 40), frand(40, 120)); wa.insert_visibility_range(ea, vr); wb.insert_visibility_range(eb, vr); }
+            if (next() % 6 == 0) { wa.insert_render_layers(ea, 2u); wb.insert_render_layers(eb, 2u); }
+            ents.push_back(ea);
+        }
+        wa.set_visible_entity_ranges(true);
+        wb.set_visible_entity_ranges(true);
+        float cam1[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 5, 2, 20};
+        View v0 = camera_looking_down_neg_z(), v1;
+        float cfv[16];
+        mi_perspective_clip_from_view(1.1f, 1.5f, 0.1f, cfv);
+        mi_compute_frustum(cfv, cam1, 400.0f, v1.frustum);
+        v1.layer_mask = 3u;
+        v1.position = {5, 2, 20};
+        std::vector<View> views = {v0, v1};
+        for (int frame = 0; frame < 7; ++frame) {
+            if (frame) { wa.clear_trackers(); wb.clear_trackers(); }
+            const int n_moves = frame == 3 ? 0 : frame == 5 ? n : 1 + (int)(next() % 200);  // a quiet frame, an all-dirty one, sparse ones
+            for (int k = 0; k < n_moves; ++k) {
+                const Entity e = frame == 5 ? ents[(size_t)k] : ents[next() % ents.size()];
+                const float dz = frand(-6, 6), dx = frand(-2, 2);
+                wa.transform_mut(e).translation.z += dz; wb.transform_mut(e).translation.z += dz;
+                wa.transform_mut(e).translation.x += dx; wb.transform_mut(e).translation.x += dx;
+            }
+            if (frame == 4) {  // one view fewer: the gathered buffers are laid out again
+                views.pop_back();
+            }
+            if (frame == 6) {  // structure: rows are renumbered and the shards cut again
+                const Transform t = Transform::from_xyz(0, 0, -30);
+                Entity ea = wa.spawn(t), eb = wb.spawn(t);
+                CHECK(ea == eb, "twin spawn");
+                ents.push_back(ea);
+                wa.despawn(ents[17]); wb.despawn(ents[17]);
+            }
+            pa.propagate_transforms(wa);
+            pa.visibility_propagate(wa);
+            pa.check_visibility(wa, views);
+            const Mi355xShardedPlugin::FrameOutput fb = pb.frame(wb, views);
+            bool same = true, same_ticks = true;
+            for (Entity e : wa.entities()) {
+                same = same && wb.contains(e) && wa.global_transform(e) == wb.global_transform(e) && wa.view_visibility_bits(e) == wb.view_visibility_bits(e);
+                same_ticks = same_ticks && wa.global_transform_changed(e) == wb.global_transform_changed(e) && wa.view_visibility_changed(e) == wb.view_visibility_changed(e);
+            }
+            CHECK(same, "GlobalTransform and ViewVisibility of every entity");
+            CHECK(same_ticks, "their change ticks");
+            for (uint32_t v = 0; v < views.size(); ++v) CHECK(pa.visible_entities(v) == fb.visible_entities[v], "VisibleEntities");
+            if (frame == 1) CHECK(!fb.visible_entities[0].empty() && fb.visible_entities[0].size() < (size_t)n, "the camera sees some of the scene");
+        }
+    }
+}
+
 static Transform on_sphere(uint64_t i, uint64_t n, double radius, uint64_t& seed, bool rotate);  // (below, with the bench)
 // The same twin-world check at a size where the fused frame takes its big-table routes: the gather and the write-back in chunks on the
 // plugin's threads, an all-dirty table committed as eight dense windows (which the library sends in pieces, fetching the
@@ -859,12 +943,13 @@ int main(int argc, char** argv) {
                        {"light_probes_and_decals_are_clustered", light_probes_and_decals_are_clustered},
                        {"render_multidrawable_batch_set", render_multidrawable_batch_set},
                        {"both_forms_leave_the_same_world", both_forms_leave_the_same_world},
+                       {"sharded_plugin_leaves_the_same_world", sharded_plugin_leaves_the_same_world},
                        {"big_flat_worlds_agree", big_flat_worlds_agree}};
     int n_failed_tests = 0, n_tests = 0;
     for (int form = 0; form < 2; ++form) {
         g_fused = form == 1;
         for (const T& t : tests) {
-            if (form == 1 && (t.fn == both_forms_leave_the_same_world || t.fn == big_flat_worlds_agree)) continue;  // (drive both forms themselves)
+            if (form == 1 && (t.fn == both_forms_leave_the_same_world || t.fn == big_flat_worlds_agree || t.fn == sharded_plugin_leaves_the_same_world)) continue;  // (drive both forms themselves)
             const int before = g_failed;
             ++n_tests;
             try {

@@ -385,5 +385,6 @@ def test_alternating_view_counts_do_not_rebuild_the_order():
             vv, vis, chg = oracle_cull(sc, g, vv, frusta)
             check_frame(ctx, vv, vis, chg, f"frame {frame} with {k} view(s)")
             builds.append(ctx.debug_static_cull_counts()[0])
-        assert builds[-1] == builds[0] == 1, f"the order was built {builds} times over nine frames of one static scene"
-        assert ctx.debug_static_cull_counts()[1] == 9
+        # (the first frames run over the world-sphere column until it is current; from the build on every frame runs over the order)
+        assert builds[-1] == 1, f"the order was built {builds} times over nine frames of one static scene"
+        assert ctx.debug_static_cull_counts()[1] == 9 - builds.index(1)

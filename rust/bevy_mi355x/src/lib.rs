@@ -57,6 +57,7 @@
 //! tests on the GPU.
 
 pub mod ffi;
+pub mod sharded;
 
 use core::ffi::CStr;
 use core::ptr;
@@ -240,7 +241,7 @@ fn message(ctx: *mut ffi::MiCtx) -> String {
 
 /// The status rule of the module docs: `Ok` for `MI_OK`, panic for a malformed hierarchy, `Err` for everything else.
 /// (A free function over the raw handle, so that callers can hold `&mut` borrows of the resource's staging vectors.)
-fn check(ctx: *mut ffi::MiCtx, what: &str, status: i32) -> Result<(), ()> {
+pub(crate) fn check(ctx: *mut ffi::MiCtx, what: &str, status: i32) -> Result<(), ()> {
     if status == ffi::MI_OK {
         return Ok(());
     }
@@ -267,17 +268,65 @@ pub struct Mi355xRenderPrepPlugin {
     pub device: i32,
     /// One device round trip per frame ([`mi_fused_frame`]); `false` = the three systems, a round trip each.
     pub fused: bool,
+    /// More than one entry: the multi-GPU form ([`sharded::mi_sharded_frame`]) -- a context per listed device, rows sharded by range,
+    /// the packed ViewVisibility masks all-gathered by RCCL (north_star's partition; flat Worlds).  Empty or one entry: `device`.
+    pub devices: Vec<i32>,
 }
 
 impl Default for Mi355xRenderPrepPlugin {
     fn default() -> Self {
-        Self { device: 0, fused: true }
+        Self { device: 0, fused: true, devices: Vec::new() }
+    }
+}
+
+impl Mi355xRenderPrepPlugin {
+    /// The multi-GPU form: `mi_sharded_frame` in `TransformSystems::Propagate` (propagate + cull of every shard, the masks gathered),
+    /// `mi_apply_visibility` in `VisibilitySystems::CheckVisibility`; the stock systems behind both for the frames they hand back.  Light
+    /// clusters and shadow views stay with the stock systems in this form.
+    fn build_sharded(&self, app: &mut App) {
+        let shards = match sharded::Mi355xShards::new(&self.devices) {
+            Ok(shards) => shards,
+            Err(message) => {
+                error!("bevy_mi355x: {message}; the stock CPU systems stay in place");
+                return;
+            }
+        };
+        app.insert_resource(shards).init_resource::<CpuFallback>().init_resource::<Mi355xFrame>();
+        for schedule in [PostStartup.intern(), PostUpdate.intern()] {
+            take_out(app, schedule, mark_dirty_trees);
+            take_out(app, schedule, propagate_parent_transforms);
+            take_out(app, schedule, sync_simple_transforms);
+            app.add_systems(
+                schedule,
+                (
+                    sharded::mi_sharded_frame,
+                    (mark_dirty_trees, propagate_parent_transforms, sync_simple_transforms).chain().run_if(transforms_fell_back),
+                )
+                    .chain()
+                    .in_set(TransformSystems::Propagate),
+            );
+        }
+        take_out(app, PostUpdate, check_visibility_cpu_culling);
+        app.add_systems(
+            PostUpdate,
+            (
+                mi_apply_visibility,
+                // (no single-context cull to fall back on: a frame whose parked lists are stale, or that fell back, is the stock system's)
+                check_visibility_cpu_culling.run_if(frame_results_missing),
+            )
+                .chain()
+                .in_set(VisibilitySystems::CheckVisibility),
+        );
     }
 }
 
 impl Plugin for Mi355xRenderPrepPlugin {
     fn build(&self, app: &mut App) {
-        let mi = match Mi355x::new(self.device) {
+        if self.devices.len() > 1 {
+            self.build_sharded(app);
+            return;
+        }
+        let mi = match Mi355x::new(self.devices.first().copied().unwrap_or(self.device)) {
             Ok(mi) => mi,
             Err(message) => {
                 // No device, no library: leave the stock systems where they are.
@@ -375,7 +424,7 @@ fn take_out<M>(app: &mut App, schedule: impl ScheduleLabel, system: impl IntoSys
 /// The rows of the visibility columns: `visible_aabb_query` of `check_visibility_cpu_culling` (visibility/mod.rs:757-772) plus what the
 /// shadow-view systems' query filters on (`With<Mesh3d>, Without<NotShadowCaster>, Without<DirectionalLight>`,
 /// crates/bevy_light/src/lib.rs:355-372 -> `MI_FLAG_SHADOW_CASTER`).
-type RowsQuery<'w, 's> = Query<
+pub(crate) type RowsQuery<'w, 's> = Query<
     'w,
     's,
     (
@@ -396,7 +445,7 @@ type RowsQuery<'w, 's> = Query<
     Without<NoCpuCulling>,
 >;
 /// "Some input of the rarely-changing columns was written" (what `stage_bounds` re-stages for).
-type BoundsChanged<'w, 's> = Query<
+pub(crate) type BoundsChanged<'w, 's> = Query<
     'w,
     's,
     (),
@@ -413,13 +462,13 @@ type BoundsChanged<'w, 's> = Query<
     )>,
 >;
 /// The view query of `check_visibility_ranges` (visibility/range.rs:228): its first 32 entities get an index in `VisibleEntityRanges`.
-type RangeViews<'w, 's> = Query<'w, 's, (Entity, &'static GlobalTransform), Or<(With<Camera>, With<ShadowLodOrigin>)>>;
+pub(crate) type RangeViews<'w, 's> = Query<'w, 's, (Entity, &'static GlobalTransform), Or<(With<Camera>, With<ShadowLodOrigin>)>>;
 
 /// The entities `check_visibility_ranges` gives an index (range.rs:238-243: `.take(32)` of its view query, cameras and
 /// `ShadowLodOrigin`s, active or not) with the translation it measures distances from (`view_transform.translation_vec3a()`).  A view
 /// that is not in here has no index: `entity_is_in_range_of_view` is false for every ranged entity (range.rs:209-217) -- the device does
 /// the same for a view without `MI_VIEW_FLAG_RANGES`.
-fn range_view_table(range_views: &RangeViews) -> EntityHashMap<[f32; 3]> {
+pub(crate) fn range_view_table(range_views: &RangeViews) -> EntityHashMap<[f32; 3]> {
     let mut table = EntityHashMap::default();
     for (entity, global) in range_views.iter().take(32) {
         table.insert(entity, global.translation().to_array());
@@ -861,7 +910,7 @@ fn layer_word(layers: &RenderLayers) -> Option<u32> {
 }
 
 /// The status rule for a capability limit: said once in the log, then `Err` like any failed call (the stock systems take over).
-fn layer_words_or_log(layers: &RenderLayers) -> Result<(u32, u32), ()> {
+pub(crate) fn layer_words_or_log(layers: &RenderLayers) -> Result<(u32, u32), ()> {
     layer_words(layers).ok_or_else(|| error!("bevy_mi355x: a RenderLayers beyond layer 63; the device columns hold layers 0..63 -- falling back to the CPU systems"))
 }
 fn layer_word_or_log(layers: &RenderLayers) -> Result<u32, ()> {
@@ -870,7 +919,7 @@ fn layer_word_or_log(layers: &RenderLayers) -> Result<u32, ()> {
     })
 }
 
-fn mi_class_bit(table: &mut HashMap<TypeId, u32>, class: TypeId) -> Option<u32> {
+pub(crate) fn mi_class_bit(table: &mut HashMap<TypeId, u32>, class: TypeId) -> Option<u32> {
     let next = table.len() as u32;
     if let Some(bit) = table.get(&class) {
         return Some(*bit);
@@ -1435,9 +1484,9 @@ pub struct Mi355xFrame {
     /// The same for the cluster lists.
     pub clusters_valid: bool,
     /// `this_run` of the fused system: inputs whose change tick is newer than this were written after the submit.
-    submit_tick: Tick,
+    pub(crate) submit_tick: Tick,
     /// Per active camera, in query order: the frustum the cull used and its `VisibleEntities` lists per class.
-    views: Vec<FrameView>,
+    pub(crate) views: Vec<FrameView>,
     /// One per clustered camera.
     clusters: Vec<FrameClusters>,
 }
@@ -1445,10 +1494,10 @@ pub struct Mi355xFrame {
 // after `mi_cluster_upload_view` (the library copied the tables); the systems that consume the parked view use its plain fields.
 unsafe impl Send for Mi355xFrame {}
 unsafe impl Sync for Mi355xFrame {}
-struct FrameView {
-    entity: Entity,
-    frustum: [f32; 24],
-    lists: Vec<(TypeId, Vec<Entity>)>,
+pub(crate) struct FrameView {
+    pub(crate) entity: Entity,
+    pub(crate) frustum: [f32; 24],
+    pub(crate) lists: Vec<(TypeId, Vec<Entity>)>,
 }
 struct FrameClusters {
     view_entity: Entity,
@@ -2012,14 +2061,12 @@ fn stage_bounds(mi: &mut Mi355x, rows_query: &RowsQuery, ranges_resource: bool) 
 /// `VisibilitySystems::CheckVisibility`, fused form: the parked lists become `set_visible()` calls and `VisibleEntities`.  No
 /// device call.  Drops the parked results (-> [`mi_check_visibility`] runs next) when an input of the cull was written after the submit.
 pub fn mi_apply_visibility(
-    mi: Res<Mi355x>,
     mut frame: ResMut<Mi355xFrame>,
     ticks: SystemChangeTick,
     mut view_query: Query<(&mut VisibleEntities, &Frustum)>,
     inputs: Query<(Ref<InheritedVisibility>, Option<Ref<Aabb>>, Option<Ref<Sphere>>, Option<Ref<RenderLayers>>, Option<Ref<VisibilityRange>>), Without<NoCpuCulling>>,
     mut view_visibilities: Query<&mut ViewVisibility, Without<NoCpuCulling>>,
 ) {
-    let _ = &mi;
     if !frame.valid {
         return;
     }

@@ -33,7 +33,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference/crates"
-FILES = ["rust/bevy_mi355x/src/lib.rs", "tools/golden_dump/src/main.rs"]
+FILES = ["rust/bevy_mi355x/src/lib.rs", "rust/bevy_mi355x/src/sharded.rs", "tools/golden_dump/src/main.rs"]
 FIXTURE = os.path.join(ROOT, "tests", "golden", "reference_api_names.json")
 
 STD_TYPES = set("""Option Some None Ok Err Vec String Box Default Clone Copy PartialEq Eq Debug Send Sync Sized Drop Fn FnMut FnOnce
@@ -47,7 +47,7 @@ to_string to_str to_owned into_owned as_str wrapping_add wrapping_sub saturating
 copy_from_slice fill keys values values_mut set cast add offset read write is_null eq ne cmp partial_cmp powf ln exp ceil floor round
 clamp to_array to_cols_array is_finite flatten flat_map skip step_by next dedup try_into try_from into_iter chain extend_from_slice
 is_some_and ok_or ok_or_else to_string_lossy or back reverse length write_all flush to_le_bytes as_bytes exit args nth parse join display
-create unwrap_or_else trailing_zeros and_then""".split())
+create unwrap_or_else trailing_zeros and_then map_err""".split())
 # glam methods the files call (bevy_math re-exports glam; glam itself is not in the checkout)
 GLAM_METHODS = set("""to_cols_array to_array length from_cols_array from_array truncate extend normalize dot cross mul_vec3 transform_point3
 transform_point3a transform_vector3 inverse abs max_element min_element splat from_rotation_y from_rotation_x from_rotation_z
@@ -293,6 +293,11 @@ def check_field_names(rel, s, problems):
         _reference_fields = set(re.findall(r"([a-z_][a-z0-9_]*)\s*:", out))
     ffi = open(os.path.join(ROOT, "rust", "bevy_mi355x", "src", "ffi.rs")).read()
     local = set(re.findall(r"^\s+(?:pub(?:\([a-z]+\))?\s+)?([a-z_][a-z0-9_]*)\s*:", s, re.M)) | set(re.findall(r"pub ([a-z_][a-z0-9_]*):", ffi))
+    if rel.startswith("rust/bevy_mi355x/src/"):  # a module of the crate reads the pub(crate) fields its siblings declare
+        crate_dir = os.path.join(ROOT, "rust", "bevy_mi355x", "src")
+        for other in os.listdir(crate_dir):
+            if other.endswith(".rs") and other != "ffi.rs":
+                local |= set(re.findall(r"^\s+pub(?:\([a-z]+\))?\s+([a-z_][a-z0-9_]*)\s*:", open(os.path.join(crate_dir, other)).read(), re.M))
     glam = set("x y z w x_axis y_axis z_axis w_axis matrix3 translation".split())
     for f in sorted(set(re.findall(r"(?<=[\w)\]])\.([a-z_][a-z0-9_]*)\b(?!\s*(?:\(|::|!))", s))):
         if f not in _reference_fields | local | glam and not f.isdigit():

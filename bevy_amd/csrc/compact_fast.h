@@ -10,12 +10,12 @@ __device__ __forceinline__ uint32_t sum_bytes(uint32_t x, uint32_t acc) { return
 
 // One workgroup of the single-launch compaction: block (bx of gx, segment by).  Called from k_compact_fast and from the
 // tail workgroups of the frame kernels (deferred compaction of the previous frame).
-// Words a compaction workgroup expands: 64 per step, `compact_fast_steps(n)` steps.  Every workgroup first sums the wave counts
-// in front of its range, so the counts read by all of them together grow with (rows / 64)^2 / steps: one step below 1 M rows
-// (2 MB of L2 reads at 1 M), ten at 10 M rows (where one step per workgroup read 760 MB per frame of 4 views: the frame went
-// from 267 to 229 us with this).
-__host__ __device__ __forceinline__ uint32_t compact_fast_steps(uint32_t n) { return 1u + (n >> 20); }
-
+// (the shape -- steps, chunks, hierarchical mode -- is described in kernels.h next to compact_fast_gx)
+// HIER_OK = false: the caller guarantees a table below COMPACT_HIER_MIN_ROWS rows -- the riders of the frame kernels, which are never
+// handed a bigger one (run_compaction launches those on their own): the hierarchical path then is not even compiled into kernels
+// whose register allocation follows every instruction of their riders (with it: k_frame<1, true, 1> 14 -> 105 spilled SGPRs, the
+// lean variants 8 -> 7 waves per SIMD).
+template <bool HIER_OK>
 __device__ __forceinline__ void compact_fast_block(const CompactFastArgs& a, uint32_t bx, uint32_t by, uint32_t gx) {
     const uint32_t seg = by;
     const uint32_t view = seg / a.n_classes;
@@ -24,19 +24,54 @@ __device__ __forceinline__ void compact_fast_block(const CompactFastArgs& a, uin
                                       : a.bitmask + view * a.words_per_view + a.word_offset;
     const uint32_t n_words = (a.n + 63u) >> 6;
     const uint32_t steps = compact_fast_steps(a.n);
-    const uint32_t w00 = bx * 64u * steps;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     __shared__ uint32_t red[4], wtot[4];
+    const bool hier = HIER_OK && compact_fast_hier(a.n);  // (uniform over the launch)
+    const uint32_t n_chunks = HIER_OK ? compact_fast_chunks(a.n) : 0u;
+    unsigned long long* const tab = reinterpret_cast<unsigned long long*>(a.seg_totals + ((a.n_segments + 1u) & ~1u)) + (size_t)seg * n_chunks;
+    if (hier && bx < n_chunks) {
+        // a summer: the counts of chunk bx (a byte per wave, four per thread), published with this frame's stamp
+        const uint32_t w = bx * COMPACT_CHUNK_WORDS + threadIdx.x * 4u;
+        uint32_t v = 0u;
+        if (w < n_words) {
+            v = *reinterpret_cast<const uint32_t*>(cnt + w);
+            if (n_words - w < 4u) v &= (1u << (8u * (n_words - w))) - 1u;  // (bytes past the last wave are not counts)
+        }
+        uint32_t p = sum_bytes(v, 0u);
+#pragma unroll
+        for (uint32_t off = 32u; off; off >>= 1) p += __shfl_xor(p, off, 64);
+        if (lane == 0) red[wv] = p;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            __hip_atomic_store(tab + bx, ((unsigned long long)a.tag << 32) | (unsigned long long)(red[0] + red[1] + red[2] + red[3]), __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const uint32_t w00 = (bx - n_chunks) * 64u * steps;
 
     // phase 1: base = sum of cnt[0 .. w00)
     uint32_t partial = 0;
-    const uint4* c4 = reinterpret_cast<const uint4*>(cnt);
-    for (uint32_t i = threadIdx.x; i < (w00 >> 4); i += 256u) {
-        const uint4 q = c4[i];
-        partial = sum_bytes(q.x, partial);
-        partial = sum_bytes(q.y, partial);
-        partial = sum_bytes(q.z, partial);
-        partial = sum_bytes(q.w, partial);
+    if (hier) {
+        const uint32_t c0 = w00 / COMPACT_CHUNK_WORDS, wc = c0 * COMPACT_CHUNK_WORDS;
+        const uint32_t off4 = threadIdx.x * 4u;  // (w00 is a multiple of 64: whole u32s)
+        if (off4 < w00 - wc) partial = sum_bytes(*reinterpret_cast<const uint32_t*>(cnt + wc + off4), 0u);
+        for (uint32_t c = threadIdx.x; c < c0; c += 256u) {
+            unsigned long long e = __hip_atomic_load(tab + c, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            while ((uint32_t)(e >> 32) != a.tag) {  // its summer has a lower workgroup id: dispatched before this workgroup, about to publish
+                __builtin_amdgcn_s_sleep(2);
+                e = __hip_atomic_load(tab + c, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            partial += (uint32_t)e;
+        }
+    } else {
+        const uint4* c4 = reinterpret_cast<const uint4*>(cnt);
+        for (uint32_t i = threadIdx.x; i < (w00 >> 4); i += 256u) {
+            const uint4 q = c4[i];
+            partial = sum_bytes(q.x, partial);
+            partial = sum_bytes(q.y, partial);
+            partial = sum_bytes(q.z, partial);
+            partial = sum_bytes(q.w, partial);
+        }
     }
 #pragma unroll
     for (uint32_t off = 32u; off; off >>= 1) partial += __shfl_xor(partial, off, 64);

@@ -346,7 +346,12 @@ int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg, 
     int32_t rc;
     const uint32_t n_classes = ctx->compact_classes;
     const size_t segs = (size_t)ctx->n_views * n_classes;
-    if ((rc = ensure(ctx, ctx->fb[ctx->cur].seg_totals, segs * 4))) return rc;
+    {
+        DevBuf& st = ctx->fb[ctx->cur].seg_totals;  // (+ the chunk totals of the hierarchical mode at this capacity)
+        const void* before = st.p;
+        if ((rc = ensure(ctx, st, compact_fast_totals_bytes(segs, ctx->cap)))) return rc;
+        if (st.p != before) HIP_TRY(ctx, hipMemsetAsync(st.p, 0, st.bytes, ctx->stream));  // fresh memory must not hold a word that reads as a stamp
+    }
     if (ctx->n == 0) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->fb[ctx->cur].seg_totals.p, 0, segs * 4, ctx->stream));
         return MI_OK;
@@ -368,12 +373,16 @@ int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg, 
         f.out_rows = (uint32_t*)ctx->fb[ctx->cur].out_rows.p;
         f.seg_stride = ctx->seg_stride;
         f.seg_totals = (uint32_t*)ctx->fb[ctx->cur].seg_totals.p;
+        if (!++ctx->compact_tag) ++ctx->compact_tag;  // (never 0: freshly allocated memory is not a valid stamp often enough to matter, 0 never)
+        f.tag = ctx->compact_tag;
         // A deferred compaction reads this frame's masks while the next frame's kernel writes its own: that needs the
         // masks in alternating buffers.  The internal sets alternate, the exchange's gathered buffers rotate and the
         // per-class segment masks live in the frame set; a single caller-bound buffer (mi_bind_visibility_output
         // without the exchange) read as the segment mask does not -- compact inline then.
         const bool masks_alternate = !ctx->ext_bitmask || ctx->xch.on || seg.seg_mask != nullptr;
-        if ((flags & MI_CULL_MORE_FRAMES) && masks_alternate && (!ctx->xch.on || ctx->xch.kernel_signal || ctx->xch.simple)) {
+        // (a table big enough for the hierarchical mode is compacted by a launch of its own: the mode lives in k_compact_fast only -- and a
+        // launch gap is small against such a frame, where the riding ten-step compaction showed 13 of its 39 us at 10 M rows x 4 views)
+        if ((flags & MI_CULL_MORE_FRAMES) && masks_alternate && (!ctx->xch.on || ctx->xch.kernel_signal || ctx->xch.simple) && !compact_fast_hier(ctx->n)) {
             // Another frame follows at once: this frame's compaction rides in extra workgroups of that frame's kernel (one
             // launch per frame instead of two); compaction_join launches it on its own if something else comes first.
             // With the exchange on it still publishes "this frame's masks are complete", and the frame's all-gather is
@@ -1866,7 +1875,7 @@ static int32_t tree_frame_fused(mi_ctx* ctx, const mi_view* views, uint32_t n_vi
     // the previous frame's deferred compaction rides in the (first) tile launch
     if (prev && prev->n && prev->n_segments) {
         cu.prev = *prev;
-        cu.prev_gx = (((prev->n + 63u) >> 6) + 64u * compact_fast_steps_host(prev->n) - 1u) / (64u * compact_fast_steps_host(prev->n));
+        cu.prev_gx = compact_fast_gx(prev->n);
         cu.n_compact = cu.prev_gx * prev->n_segments;
     } else {
         cu.prev_gx = 1;
@@ -1988,7 +1997,11 @@ static int32_t changed_rows_on_device(mi_ctx* ctx, uint32_t* total) {
     const uint32_t n_waves = (uint32_t)((padded_words(ctx->cap) + 63u) / 64u * 64u);
     if ((rc = ensure(ctx, ctx->sparse_cnt, n_waves))) return rc;
     if ((rc = ensure(ctx, ctx->sparse_rows, (size_t)ctx->cap * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->sparse_total, 16))) return rc;
+    {
+        const void* before = ctx->sparse_total.p;
+        if ((rc = ensure(ctx, ctx->sparse_total, compact_fast_totals_bytes(1, ctx->cap)))) return rc;
+        if (ctx->sparse_total.p != before) HIP_TRY(ctx, hipMemsetAsync(ctx->sparse_total.p, 0, ctx->sparse_total.bytes, ctx->stream));
+    }
     HIP_TRY(ctx, launch_popcount_words(ctx->g_chg_bits, ctx->n, (uint8_t*)ctx->sparse_cnt.p, ctx->stream));
     CompactFastArgs f{};
     f.n = ctx->n;
@@ -2001,6 +2014,8 @@ static int32_t changed_rows_on_device(mi_ctx* ctx, uint32_t* total) {
     f.out_rows = (uint32_t*)ctx->sparse_rows.p;
     f.seg_stride = ctx->cap;
     f.seg_totals = (uint32_t*)ctx->sparse_total.p;
+    if (!++ctx->compact_tag) ++ctx->compact_tag;
+    f.tag = ctx->compact_tag;
     HIP_TRY(ctx, launch_compact_fast(f, ctx->stream));
     return total ? download(ctx, total, ctx->sparse_total.p, 4) : MI_OK;
 }

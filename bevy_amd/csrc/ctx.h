@@ -308,6 +308,7 @@ struct mi_ctx {
         bool has_job = false;        // with the exchange on: the frame's all-gather, queued once the compaction is submitted
         Exchange::Job job{};
     } defer;
+    uint32_t compact_tag = 0;  // stamp of the chunk totals of the hierarchical compaction (CompactFastArgs::tag): a new one per compaction
     uint32_t compact_views = 0, compact_classes = 0;
     uint32_t class_bits[32] = {0};
     bool compact_fast = false;   // last compaction used the single-launch path (out_rows strided per segment)

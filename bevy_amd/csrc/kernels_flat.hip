@@ -219,7 +219,7 @@ __device__ __forceinline__ bool frame_riders(uint32_t n_tiles, const CompactFast
         if (prev.signal && id == 0 && threadIdx.x == 0)  // multi-GPU exchange: the previous frame's masks are complete
             __hip_atomic_store(prev.signal, prev.signal_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         MI_TIMELINE(0);
-        compact_fast_block(prev, id % prev_gx, id / prev_gx, prev_gx);
+        compact_fast_block<false>(prev, id % prev_gx, id / prev_gx, prev_gx);
     } else if (id < n_compact + n_fill) {
         MI_TIMELINE(1);
         cluster_fill_block(fill.w, fill.n_clusters, fill.n_objects, id - n_compact, n_fill, lds_raw, lds_raw + 4096);
@@ -1291,7 +1291,7 @@ static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, co
     uint32_t prev_gx = 1, prev_blocks = 0;
     if (prev && prev->n && prev->n_segments) {
         pa = *prev;
-        prev_gx = (((pa.n + 63u) >> 6) + 64u * compact_fast_steps_host(pa.n) - 1u) / (64u * compact_fast_steps_host(pa.n));
+        prev_gx = compact_fast_gx(pa.n);
         prev_blocks = prev_gx * pa.n_segments;
     }
     ClusterFillJob fj{};
@@ -1337,7 +1337,7 @@ hipError_t launch_frame_sph(const Columns& c, const ViewSet* views_inline, const
     uint32_t prev_gx = 1, prev_blocks = 0;
     if (prev && prev->n && prev->n_segments) {
         pa = *prev;
-        prev_gx = (((pa.n + 63u) >> 6) + 64u * compact_fast_steps_host(pa.n) - 1u) / (64u * compact_fast_steps_host(pa.n));
+        prev_gx = compact_fast_gx(pa.n);
         prev_blocks = prev_gx * pa.n_segments;
     }
     ClusterFillJob fj{};
@@ -1521,7 +1521,7 @@ hipError_t launch_frame_cells(const Columns& c, const CellsOrder& o, const ViewS
     uint32_t prev_gx = 1, prev_blocks = 0;
     if (prev && prev->n && prev->n_segments) {
         pa = *prev;
-        prev_gx = (((pa.n + 63u) >> 6) + 64u * compact_fast_steps_host(pa.n) - 1u) / (64u * compact_fast_steps_host(pa.n));
+        prev_gx = compact_fast_gx(pa.n);
         prev_blocks = prev_gx * pa.n_segments;
     }
     ClusterFillJob fj{};
@@ -1686,14 +1686,12 @@ hipError_t launch_compact(const CompactArgs& a, hipStream_t stream, void (*mark)
 __global__ void __launch_bounds__(256) k_compact_fast(CompactFastArgs a) {
     if (a.signal && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
         __hip_atomic_store(a.signal, a.signal_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    compact_fast_block(a, blockIdx.x, blockIdx.y, gridDim.x);
+    compact_fast_block<true>(a, blockIdx.x, blockIdx.y, gridDim.x);
 }
 
 hipError_t launch_compact_fast(const CompactFastArgs& a, hipStream_t stream) {
     if (a.n == 0 || a.n_segments == 0) return hipSuccess;
-    const uint32_t n_words = (a.n + 63u) >> 6;
-    const uint32_t per_wg = 64u * compact_fast_steps_host(a.n);
-    MI_LAUNCH(k_compact_fast, dim3((n_words + per_wg - 1u) / per_wg, a.n_segments), dim3(256), 0, stream, a);
+    MI_LAUNCH(k_compact_fast, dim3(compact_fast_gx(a.n), a.n_segments), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

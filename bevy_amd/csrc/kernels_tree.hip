@@ -534,7 +534,7 @@ __global__ void __launch_bounds__(256, CULL ? 7 : ALL_DIRTY ? 8 : 7) k_propagate
         // the previous frame's VisibleEntities compaction rides in the first workgroups of the launch ...
         if (blockIdx.x < cu.n_compact) {
             const TreeCull& cr = kernarg_late<TreeCull>(FANS_CULL_KERNARG);  // (read inside the branch: see tile_cull_rows' call)
-            compact_fast_block(cr.prev, blockIdx.x % cr.prev_gx, blockIdx.x / cr.prev_gx, cr.prev_gx);
+            compact_fast_block<false>(cr.prev, blockIdx.x % cr.prev_gx, blockIdx.x / cr.prev_gx, cr.prev_gx);
             return;
         }
         tile_bid -= cu.n_compact;

@@ -11,10 +11,8 @@ __device__ __forceinline__ uint32_t sum_bytes(uint32_t x, uint32_t acc) { return
 // One workgroup of the single-launch compaction: block (bx of gx, segment by).  Called from k_compact_fast and from the
 // tail workgroups of the frame kernels (deferred compaction of the previous frame).
 // (the shape -- steps, chunks, hierarchical mode -- is described in kernels.h next to compact_fast_gx)
-// HIER_OK = false: the caller guarantees a table below COMPACT_HIER_MIN_ROWS rows -- the riders of the frame kernels, which are never
-// handed a bigger one (run_compaction launches those on their own): the hierarchical path then is not even compiled into kernels
-// whose register allocation follows every instruction of their riders (with it: k_frame<1, true, 1> 14 -> 105 spilled SGPRs, the
-// lean variants 8 -> 7 waves per SIMD).
+// HIER_OK = false: a rider of a frame kernel (the stepped form at any size: kernels.h) -- the hierarchical path is not even compiled
+// into kernels whose register allocation follows every instruction of their riders; true: k_compact_fast, a launch of its own.
 template <bool HIER_OK>
 __device__ __forceinline__ void compact_fast_block(const CompactFastArgs& a, uint32_t bx, uint32_t by, uint32_t gx) {
     const uint32_t seg = by;
@@ -23,27 +21,36 @@ __device__ __forceinline__ void compact_fast_block(const CompactFastArgs& a, uin
     const uint64_t* mask = a.seg_mask ? a.seg_mask + (size_t)seg * a.seg_words
                                       : a.bitmask + view * a.words_per_view + a.word_offset;
     const uint32_t n_words = (a.n + 63u) >> 6;
-    const uint32_t steps = compact_fast_steps(a.n);
+    const uint32_t steps = compact_fast_steps(a.n, HIER_OK);
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     __shared__ uint32_t red[4], wtot[4];
-    const bool hier = HIER_OK && compact_fast_hier(a.n);  // (uniform over the launch)
-    const uint32_t n_chunks = HIER_OK ? compact_fast_chunks(a.n) : 0u;
+    const bool hier = compact_fast_hier(a.n, HIER_OK);  // (uniform over the launch)
+    const uint32_t n_chunks = compact_fast_chunks(a.n, HIER_OK);
     unsigned long long* const tab = reinterpret_cast<unsigned long long*>(a.seg_totals + ((a.n_segments + 1u) & ~1u)) + (size_t)seg * n_chunks;
     if (hier && bx < n_chunks) {
-        // a summer: the counts of chunk bx (a byte per wave, four per thread), published with this frame's stamp
-        const uint32_t w = bx * COMPACT_CHUNK_WORDS + threadIdx.x * 4u;
-        uint32_t v = 0u;
+        // a summer: the counts of chunk bx (a byte per wave, sixteen per thread), published with this frame's stamp.  Relaxed agent-scope
+        // accesses on the table: the word carries its own validity (stamp and total in one 64-bit store), so nothing has to be ordered
+        // around it -- acquire / release here are cache invalidations and write-backs per access, and 2 500 workgroups polling 153 words
+        // with them took 64 us per 10 M-row segment.
+        const uint32_t w = bx * COMPACT_CHUNK_WORDS + threadIdx.x * 16u;
+        uint32_t p = 0u;
         if (w < n_words) {
-            v = *reinterpret_cast<const uint32_t*>(cnt + w);
-            if (n_words - w < 4u) v &= (1u << (8u * (n_words - w))) - 1u;  // (bytes past the last wave are not counts)
+            const uint4 q = *reinterpret_cast<const uint4*>(cnt + w);
+            const uint32_t v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) {
+                const uint32_t wk = w + 4u * k;
+                uint32_t x = wk < n_words ? v[k] : 0u;
+                if (wk < n_words && n_words - wk < 4u) x &= (1u << (8u * (n_words - wk))) - 1u;  // (bytes past the last wave are not counts)
+                p = sum_bytes(x, p);
+            }
         }
-        uint32_t p = sum_bytes(v, 0u);
 #pragma unroll
         for (uint32_t off = 32u; off; off >>= 1) p += __shfl_xor(p, off, 64);
         if (lane == 0) red[wv] = p;
         __syncthreads();
         if (threadIdx.x == 0)
-            __hip_atomic_store(tab + bx, ((unsigned long long)a.tag << 32) | (unsigned long long)(red[0] + red[1] + red[2] + red[3]), __ATOMIC_RELEASE,
+            __hip_atomic_store(tab + bx, ((unsigned long long)a.tag << 32) | (unsigned long long)(red[0] + red[1] + red[2] + red[3]), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
@@ -53,13 +60,16 @@ __device__ __forceinline__ void compact_fast_block(const CompactFastArgs& a, uin
     uint32_t partial = 0;
     if (hier) {
         const uint32_t c0 = w00 / COMPACT_CHUNK_WORDS, wc = c0 * COMPACT_CHUNK_WORDS;
-        const uint32_t off4 = threadIdx.x * 4u;  // (w00 is a multiple of 64: whole u32s)
-        if (off4 < w00 - wc) partial = sum_bytes(*reinterpret_cast<const uint32_t*>(cnt + wc + off4), 0u);
+        const uint32_t off16 = threadIdx.x * 16u;  // (w00 is a multiple of 64: whole uint4s)
+        if (off16 < w00 - wc) {
+            const uint4 q = *reinterpret_cast<const uint4*>(cnt + wc + off16);
+            partial = sum_bytes(q.x, sum_bytes(q.y, sum_bytes(q.z, sum_bytes(q.w, 0u))));
+        }
         for (uint32_t c = threadIdx.x; c < c0; c += 256u) {
-            unsigned long long e = __hip_atomic_load(tab + c, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long e = __hip_atomic_load(tab + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             while ((uint32_t)(e >> 32) != a.tag) {  // its summer has a lower workgroup id: dispatched before this workgroup, about to publish
                 __builtin_amdgcn_s_sleep(2);
-                e = __hip_atomic_load(tab + c, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                e = __hip_atomic_load(tab + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             partial += (uint32_t)e;
         }

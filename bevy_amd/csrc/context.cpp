@@ -380,9 +380,7 @@ int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg, 
         // per-class segment masks live in the frame set; a single caller-bound buffer (mi_bind_visibility_output
         // without the exchange) read as the segment mask does not -- compact inline then.
         const bool masks_alternate = !ctx->ext_bitmask || ctx->xch.on || seg.seg_mask != nullptr;
-        // (a table big enough for the hierarchical mode is compacted by a launch of its own: the mode lives in k_compact_fast only -- and a
-        // launch gap is small against such a frame, where the riding ten-step compaction showed 13 of its 39 us at 10 M rows x 4 views)
-        if ((flags & MI_CULL_MORE_FRAMES) && masks_alternate && (!ctx->xch.on || ctx->xch.kernel_signal || ctx->xch.simple) && !compact_fast_hier(ctx->n)) {
+        if ((flags & MI_CULL_MORE_FRAMES) && masks_alternate && (!ctx->xch.on || ctx->xch.kernel_signal || ctx->xch.simple)) {
             // Another frame follows at once: this frame's compaction rides in extra workgroups of that frame's kernel (one
             // launch per frame instead of two); compaction_join launches it on its own if something else comes first.
             // With the exchange on it still publishes "this frame's masks are complete", and the frame's all-gather is
@@ -1875,7 +1873,7 @@ static int32_t tree_frame_fused(mi_ctx* ctx, const mi_view* views, uint32_t n_vi
     // the previous frame's deferred compaction rides in the (first) tile launch
     if (prev && prev->n && prev->n_segments) {
         cu.prev = *prev;
-        cu.prev_gx = compact_fast_gx(prev->n);
+        cu.prev_gx = compact_fast_gx(prev->n, false);
         cu.n_compact = cu.prev_gx * prev->n_segments;
     } else {
         cu.prev_gx = 1;

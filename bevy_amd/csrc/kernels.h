@@ -227,28 +227,36 @@ struct CompactFastArgs {
     uint32_t tag;  // hierarchical mode: this frame's stamp on the chunk totals (never 0).  (In what was padding: the struct is an argument
                    // of every frame kernel, and those are sensitive to the size of their argument block -- profiles/r04_experiments.md 4.)
 };
-// The single-launch compaction's shape.  Every expanding workgroup needs the number of entries in front of its range.  Small tables: it
-// sums the wave counts in front of it itself (a byte per wave: 2 MB of L2 reads in all at 1 M rows), 64 words per workgroup -- or 128
-// from 1 M rows.  From COMPACT_HIER_MIN_ROWS rows on those reads grow with the square of the table (760 MB per frame of 4 views at 10 M
-// rows with 64-word workgroups; round 2 answered with up to ten 64-word steps per workgroup, which left 245 workgroups of ten
-// serial steps for the whole chip: 29 - 39 us per 10 M-row compaction) and the mode is HIERARCHICAL: the first workgroups of every
-// segment ("summers", one per chunk of COMPACT_CHUNK_WORDS waves) add up their chunk's counts and publish (tag << 32 | total) with one
-// 64-bit release store; an expanding workgroup -- 64 words, one step -- adds the totals of the chunks in front of its own (polling a
-// word whose stamp is not this frame's yet: summers have the lower workgroup ids of their segment, so they are dispatched first and
-// are long done in practice) and the counts of its own chunk in front of its range (< 1 KB).  The table of totals lies behind
-// seg_totals; stamps make zeroing it unnecessary.
-constexpr uint32_t COMPACT_CHUNK_WORDS = 1024u;
+// The single-launch compaction's shape.  Every expanding workgroup needs the number of entries in front of its range.  It sums the wave
+// counts in front of it itself (a byte per wave: 2 MB of L2 reads in all at 1 M rows) -- reads that grow with the square of the table
+// (760 MB per frame of 4 views at 10 M rows with 64-word workgroups), which round 2 answered with up to ten 64-word steps per
+// workgroup: 245 workgroups of ten serial steps for the whole chip, 29 - 39 us per 10 M-row compaction.  That is still the form the
+// RIDERS of the frame kernels run (hier = false): they spend their time waiting in slots the frame's rows do not need, and most of it
+// disappears under the rows (10 M rows: 153 against 151 us with and without the rider at one view, 176 against 163 at four).  A
+// compaction that is a LAUNCH OF ITS OWN (everything that joins a pending one: downloads, batching, mi_synchronize; the sparse
+// GlobalTransform list; --inline-compaction) of a table of COMPACT_HIER_MIN_ROWS rows and more is HIERARCHICAL (hier = true): the
+// first workgroups of every segment ("summers", one per chunk of COMPACT_CHUNK_WORDS waves) add up their chunk's counts and publish
+// (tag << 32 | total) with one 64-bit store; an expanding workgroup -- four 64-word steps -- adds the totals of the chunks in front of
+// its own (polling a word whose stamp is not this frame's yet: summers have the lower workgroup ids of their segment, so they are
+// dispatched first and are long done in practice) and the counts of its own chunk in front of its range (< 4 KB): 29 -> 11.7 us at
+// 10 M rows x 1 view.  The table of totals lies behind seg_totals; stamps make zeroing it unnecessary.
+// (Tried and not kept: the hierarchical form inside the riders -- k_frame<1, true, 1> went from 14 to 105 spilled SGPRs and the lean
+// variants from 8 to 7 waves per SIMD -- and hierarchical launches INSTEAD of riders: 155.9 -> 164.5 us per frame at 10 M rows x 1
+// view, 185.8 -> 202.9 at four: what rides is nearly free, what is launched is not.)
+constexpr uint32_t COMPACT_CHUNK_WORDS = 4096u;  // (a summer's 4 KB of counts: one uint4 per thread; 39 chunks at 10 M rows)
 constexpr uint32_t COMPACT_HIER_MIN_ROWS = 1u << 21;
-__host__ __device__ inline bool compact_fast_hier(uint32_t n) { return n >= COMPACT_HIER_MIN_ROWS; }
-__host__ __device__ inline uint32_t compact_fast_steps(uint32_t n) { return compact_fast_hier(n) ? 1u : 1u + (n >> 20); }
-__host__ __device__ inline uint32_t compact_fast_chunks(uint32_t n) { return compact_fast_hier(n) ? (((n + 63u) >> 6) + COMPACT_CHUNK_WORDS - 1u) / COMPACT_CHUNK_WORDS : 0u; }
+__host__ __device__ inline bool compact_fast_hier(uint32_t n, bool own_launch) { return own_launch && n >= COMPACT_HIER_MIN_ROWS; }
+__host__ __device__ inline uint32_t compact_fast_steps(uint32_t n, bool own_launch) { return compact_fast_hier(n, own_launch) ? 4u : 1u + (n >> 20); }
+__host__ __device__ inline uint32_t compact_fast_chunks(uint32_t n, bool own_launch) {
+    return compact_fast_hier(n, own_launch) ? (((n + 63u) >> 6) + COMPACT_CHUNK_WORDS - 1u) / COMPACT_CHUNK_WORDS : 0u;
+}
 // workgroups per segment: the summers, then the expanders
-__host__ __device__ inline uint32_t compact_fast_gx(uint32_t n) {
-    const uint32_t per = 64u * compact_fast_steps(n);
-    return compact_fast_chunks(n) + (((n + 63u) >> 6) + per - 1u) / per;
+__host__ __device__ inline uint32_t compact_fast_gx(uint32_t n, bool own_launch) {
+    const uint32_t per = 64u * compact_fast_steps(n, own_launch);
+    return compact_fast_chunks(n, own_launch) + (((n + 63u) >> 6) + per - 1u) / per;
 }
 // bytes of the seg_totals buffer: the totals (padded to 8 bytes) and, in the hierarchical mode, n_chunks stamped totals per segment
-inline size_t compact_fast_totals_bytes(size_t segs, uint32_t n) { return ((segs + 1u) & ~(size_t)1u) * 4u + segs * compact_fast_chunks(n) * 8u; }
+inline size_t compact_fast_totals_bytes(size_t segs, uint32_t n) { return ((segs + 1u) & ~(size_t)1u) * 4u + segs * compact_fast_chunks(n, true) * 8u; }
 hipError_t launch_flat_propagate_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views,
                                       uint32_t n_views, const VisibilityOut& out, const SegOut& seg, uint32_t flags,
                                       const CompactFastArgs* prev, const struct ClusterFillJob* fill, const struct ClusterWalkJob* walk,

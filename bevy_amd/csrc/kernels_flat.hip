@@ -1291,7 +1291,7 @@ static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, co
     uint32_t prev_gx = 1, prev_blocks = 0;
     if (prev && prev->n && prev->n_segments) {
         pa = *prev;
-        prev_gx = compact_fast_gx(pa.n);
+        prev_gx = compact_fast_gx(pa.n, false);
         prev_blocks = prev_gx * pa.n_segments;
     }
     ClusterFillJob fj{};
@@ -1337,7 +1337,7 @@ hipError_t launch_frame_sph(const Columns& c, const ViewSet* views_inline, const
     uint32_t prev_gx = 1, prev_blocks = 0;
     if (prev && prev->n && prev->n_segments) {
         pa = *prev;
-        prev_gx = compact_fast_gx(pa.n);
+        prev_gx = compact_fast_gx(pa.n, false);
         prev_blocks = prev_gx * pa.n_segments;
     }
     ClusterFillJob fj{};
@@ -1521,7 +1521,7 @@ hipError_t launch_frame_cells(const Columns& c, const CellsOrder& o, const ViewS
     uint32_t prev_gx = 1, prev_blocks = 0;
     if (prev && prev->n && prev->n_segments) {
         pa = *prev;
-        prev_gx = compact_fast_gx(pa.n);
+        prev_gx = compact_fast_gx(pa.n, false);
         prev_blocks = prev_gx * pa.n_segments;
     }
     ClusterFillJob fj{};
@@ -1691,7 +1691,7 @@ __global__ void __launch_bounds__(256) k_compact_fast(CompactFastArgs a) {
 
 hipError_t launch_compact_fast(const CompactFastArgs& a, hipStream_t stream) {
     if (a.n == 0 || a.n_segments == 0) return hipSuccess;
-    MI_LAUNCH(k_compact_fast, dim3(compact_fast_gx(a.n), a.n_segments), dim3(256), 0, stream, a);
+    MI_LAUNCH(k_compact_fast, dim3(compact_fast_gx(a.n, true), a.n_segments), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

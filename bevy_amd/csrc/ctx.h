@@ -88,6 +88,9 @@ struct mi_ctx {
     DevBuf parent_idx, node_flags, tiles;
     std::vector<std::pair<uint32_t, uint32_t>> passes;  // (first tile, n tiles); pass 0 starts at level 0 (roots)
     struct TileGroup { uint32_t first, count, n_chain, owner_rows; bool deep = false; /* some tile spans more than TILE_FAST_LEVELS levels */ };
+    bool narrow = false;            // every level is at most a wave wide and there are more levels than a tile spans: one wave walks the hierarchy (k_propagate_narrow)
+    bool narrow_quad = false;       // ... and no level holds more than 16 rows
+    DevBuf level_offs_dev;          // level_offsets on the device (that kernel reads them)
     bool by_levels = false;         // the row count overflows the tile kernel's 32-bit offsets (or mi_debug_set_tile_mode(1)): mi_propagate sweeps level by level
     DevBuf anc;                     // the ancestor table (kernels.h, ANC_DEPTH): built by mi_upload_hierarchy; in use while anc_valid
     bool anc_valid = false;

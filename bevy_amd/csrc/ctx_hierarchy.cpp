@@ -23,6 +23,7 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
         ctx->passes.clear();
         ctx->groups.clear();
         ctx->stream_levels.clear();
+        ctx->narrow = false;
         return MI_OK;
     }
     if (!level_offsets) return fail(ctx, MI_ERR_INVALID_ARG, "mi_upload_hierarchy: level_offsets NULL");
@@ -291,6 +292,18 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
     if ((rc = upload(ctx, ctx->chains.p, chains.data(), chains.size() * 4))) return rc;
     ctx->level_offsets.assign(level_offsets, level_offsets + n_levels + 1);
     ctx->n_levels = n_levels;
+    // as narrow as a chain, and deeper than one tile: the whole hierarchy is one wave's walk (kernels_tree.hip, k_propagate_narrow)
+    ctx->narrow = n_levels > TILE_MAX_LEVELS && ctx->tile_mode != 1;
+    ctx->narrow_quad = true;
+    for (uint32_t l = 0; l < n_levels && ctx->narrow; ++l) {
+        const uint32_t w = level_offsets[l + 1] - level_offsets[l];
+        ctx->narrow = w <= 64u;
+        ctx->narrow_quad = ctx->narrow_quad && w <= 16u;
+    }
+    if (ctx->narrow) {
+        if ((rc = ensure(ctx, ctx->level_offs_dev, ((size_t)n_levels + 1) * 4))) return rc;
+        if ((rc = upload(ctx, ctx->level_offs_dev.p, level_offsets, ((size_t)n_levels + 1) * 4))) return rc;
+    }
     ctx->have_hierarchy = true;
     // the ancestor table for mark_dirty_trees (kernels.h): level by level on the device, behind the parent_idx upload
     ctx->anc_valid = false;

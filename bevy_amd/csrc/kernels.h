@@ -484,6 +484,11 @@ struct TreeCull {
     CompactFastArgs prev;
     uint32_t prev_gx, n_compact;
 };
+// A hierarchy whose every level is at most a wave wide: ONE wave walks all of it (kernels_tree.hip, k_propagate_narrow); quad = no
+// level holds more than 16 rows (a node per quad of lanes, a column each).
+hipError_t launch_propagate_narrow(const Columns& c, const uint32_t* parent_idx, const uint32_t* level_offsets, uint32_t n_levels,
+                                   const uint8_t* node_flags, const uint8_t* changed, const uint8_t* tree_bytes, uint8_t* g_changed_bytes, bool all_dirty,
+                                   bool static_opt, bool quad, hipStream_t stream);
 hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, const TileDesc* d_tiles, const uint32_t* d_chains,
                                   uint32_t n_tiles, const uint8_t* node_flags, const uint8_t* changed, const uint8_t* tree_bytes,
                                   uint8_t* g_changed_bytes, const float* snap_read, float* snap_write, uint32_t snap_rows, bool all_dirty,

@@ -953,6 +953,167 @@ __global__ void __launch_bounds__(256) k_propagate_level(Columns c, TreeArgs a, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// A hierarchy as narrow as a chain -- EVERY level at most a wave wide: transform_hierarchy.rs's `chain` (2 500 levels of one node), a
+// rope, a single rig -- is a chain of dependent products whatever runs it: its cost is levels x the latency of one level step.  Through
+// tiles that was a launch per TILE_MAX_LEVELS levels (155 dependent launches, 1.3 ms per frame for the 2 500-node chain; 310 and 1.8 ms
+// with 8-level tiles).  Here ONE wave walks the whole hierarchy and nothing but arithmetic sits between two levels: rows are in level
+// order, so consecutive levels are consecutive rows -- a chunk of whole levels (<= NARROW_CHUNK rows) is fetched with coalesced loads,
+// turned into local affines and parked in LDS with the old values and the rule's inputs; the levels of the chunk then run one after
+// the other, each level's inputs read from LDS while the level before is multiplied, the results handed from level to level in
+// REGISTERS: through quad broadcasts / nothing at all where every node's parent sits in the lane group its child will occupy (a chain,
+// ropes side by side), through ds_bpermute otherwise.  QUAD (levels of <= 16 rows): a node is a quad of lanes, a column each, as in the
+// tiles' chains -- a quarter of the dependent instructions per level; otherwise a lane per row.  Same rule (node_apply), same products
+// in the same order: same bits.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t NARROW_CHUNK = 256;
+__device__ __forceinline__ float shfl_f(float v, uint32_t src_lane) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __float_as_int(v)));
+}
+__device__ __forceinline__ V3 shfl3(V3 v, uint32_t src_lane) { return V3{shfl_f(v.x, src_lane), shfl_f(v.y, src_lane), shfl_f(v.z, src_lane)}; }
+template <bool ALL_DIRTY, bool QUAD>
+__global__ void __launch_bounds__(64) k_propagate_narrow(Columns c, TreeArgs a, const uint32_t* __restrict__ level_offsets, uint32_t n_levels) {
+    __shared__ float4 lds_local[NARROW_CHUNK * 3];  // per staged row: its local affine
+    __shared__ float4 lds_oldg[NARROW_CHUNK * 3];   // its GlobalTransform before this frame
+    __shared__ uint32_t lds_par[NARROW_CHUNK];      // its parent's row
+    __shared__ uint8_t lds_in[NARROW_CHUNK];        // bit0 TransformTreeChanged, bit1 the level-0 assignment happens
+    __shared__ uint32_t lds_off[NARROW_CHUNK + 2];  // level_offsets[l0 ..]
+    const uint32_t lane = threadIdx.x;
+    const uint32_t unit = QUAD ? lane >> 2 : lane;  // the node of its level this lane works on
+    const uint32_t cc = lane & 3u;                  // QUAD: the column
+    uint32_t l0 = 0, prev_start = 0;
+    // the level before, in registers: QUAD the lane's column of its node, otherwise the lane's whole node
+    V3 pq = {};
+    Affine pr = {};
+    bool p_chg = false;
+    while (l0 < n_levels) {
+        // the chunk's levels: as many whole levels from l0 on as hold <= NARROW_CHUNK rows together (a level holds <= 64: at least four)
+        for (uint32_t k = lane; k < NARROW_CHUNK + 2u; k += 64u) lds_off[k] = level_offsets[l0 + k <= n_levels ? l0 + k : n_levels];
+        MI_WAVE_LDS_SYNC();
+        const uint32_t row0 = lds_off[0];
+        uint32_t n_lv = 0;
+        {
+            // first k (1-based) whose end exceeds the budget or the hierarchy; levels are non-empty, so ends are increasing
+            uint32_t best = 0xFFFFFFFFu;
+            for (uint32_t k = lane + 1u; k <= NARROW_CHUNK + 1u; k += 64u)
+                if ((lds_off[k] - row0 > NARROW_CHUNK || l0 + k > n_levels) && k < best) best = k;
+#pragma unroll
+            for (uint32_t off = 32u; off; off >>= 1) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)best, (int)off, 64);
+                best = o < best ? o : best;
+            }
+            n_lv = __builtin_amdgcn_readfirstlane(best - 1u);  // (>= 1: the planner takes this kernel only when every level fits a wave)
+        }
+        const uint32_t rows = lds_off[n_lv] - row0;
+        // ---- stage the chunk: coalesced loads, a lane per row, four rounds
+#pragma unroll
+        for (uint32_t j = 0; j < NARROW_CHUNK / 64u; ++j) {
+            const uint32_t i = j * 64u + lane;
+            if (i < rows) {
+                const uint32_t row = row0 + i;
+                const bool root_level = l0 == 0 && i < lds_off[1] - row0;
+                const V3 sc = ld3_32(c.scale, row), t = ld3_32(c.translation, row);
+                const V4 q = ld4_32(c.rotation, row);
+                const NodeRaw raw = node_raw<ALL_DIRTY>(a, row, root_level);
+                lds_put(lds_local, i, affine_from_srt(sc, q, t));
+                lds_put(lds_oldg, i, ld_affine(c.global, row));
+                lds_par[i] = at32<uint32_t>(a.parent_idx, row * 4u);
+                const NodeIn in = node_inputs_raw(a, row, root_level, raw);
+                lds_in[i] = (uint8_t)((in.tree_changed ? 1u : 0u) | (in.root_write ? 2u : 0u));
+            }
+        }
+        MI_WAVE_LDS_SYNC();
+        // ---- the chunk's levels, one after the other.  One wave executes in order, so an LDS read only travels under arithmetic that is
+        // issued BEHIND it: level k + 1's inputs are requested (from offsets read an iteration earlier still) before level k is
+        // multiplied, and looked at in the next iteration -- the loop never waits for an address it has just asked for.
+        struct LevelIn {
+            uint32_t row, par, in;
+            bool on;
+            Affine local, old;
+            V3 local_c, old_c;
+        };
+        auto fetch = [&](uint32_t start, uint32_t end) {  // the level's rows are [start, end)
+            LevelIn f;
+            f.on = unit < end - start;
+            f.row = start + (f.on ? unit : 0u);
+            const uint32_t i = f.row - row0 < NARROW_CHUNK ? f.row - row0 : NARROW_CHUNK - 1u;  // (asked for unconditionally, also past the chunk's last level)
+            f.par = lds_par[i];
+            f.in = lds_in[i];
+            if constexpr (QUAD) {
+                f.local_c = lds_col(lds_local, i, cc);
+                f.old_c = lds_col(lds_oldg, i, cc);
+            } else {
+                f.local = lds_affine(lds_local, i);
+                f.old = lds_affine(lds_oldg, i);
+            }
+            return f;
+        };
+        uint32_t o_k = row0, o_k1 = lds_off[1], o_k2 = lds_off[2];  // level_offsets[l0 + k], [.. + 1], [.. + 2] (clamped to the last)
+        LevelIn nx = fetch(o_k, o_k1);
+        uint32_t before = prev_start;  // where the level above level k starts
+        for (uint32_t k = 0; k < n_lv; ++k) {
+            const LevelIn cu = nx;
+            const bool root_level = l0 + k == 0;
+            const uint32_t slot = root_level ? unit : (cu.par - before) & (QUAD ? 15u : 63u);
+            const bool same = __all(!cu.on || slot == unit) != 0;  // every parent sits where its child does (wave-uniform)
+            // the parents come over FIRST: LDS answers in order, so whatever is asked behind them (the next level's inputs) can stay in
+            // flight while they are used
+            bool pc = p_chg;
+            V3 pq_here = pq;   // QUAD: column cc of the parent, in the child's quad
+            Affine gp = pr;    // otherwise: the parent
+            if (!same) {
+                if constexpr (QUAD) {
+                    pq_here = shfl3(pq, slot * 4u + cc);
+                    pc = __builtin_amdgcn_ds_bpermute((int)(slot << 4), p_chg ? 1 : 0) != 0;
+                } else {
+                    gp.m.x_axis = shfl3(pr.m.x_axis, slot);
+                    gp.m.y_axis = shfl3(pr.m.y_axis, slot);
+                    gp.m.z_axis = shfl3(pr.m.z_axis, slot);
+                    gp.t = shfl3(pr.t, slot);
+                    pc = __builtin_amdgcn_ds_bpermute((int)(slot << 2), p_chg ? 1 : 0) != 0;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t o_k3 = lds_off[k + 3u <= NARROW_CHUNK + 1u ? k + 3u : NARROW_CHUNK + 1u];
+            nx = fetch(o_k1, o_k2);  // (no branch around it: the waits below are counted along the shortest path)
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (QUAD) {
+                gp.m.x_axis = quad_bcast(pq_here, 0);
+                gp.m.y_axis = quad_bcast(pq_here, 1);
+                gp.m.z_axis = quad_bcast(pq_here, 2);
+                gp.t = quad_bcast(pq_here, 3);
+                V3 cur_c;
+                const bool chg = quad_node_apply(cu.on, root_level, a.static_opt != 0, cu.in, gp, pc, cu.local_c, cu.old_c, cc, lane, &cur_c);
+                if (cu.on) {
+                    if (cc == 0u) at32w<uint8_t>(a.g_changed_bytes, cu.row) = chg ? 1 : 0;
+                    if (chg) at32w<F3>(c.global, cu.row * 48u + cc * 12u) = F3{cur_c.x, cur_c.y, cur_c.z};
+                }
+                pq = cur_c;
+                p_chg = chg;
+            } else {
+                NodeIn in;
+                in.tree_changed = (cu.in & 1u) != 0;
+                in.root_write = (cu.in & 2u) != 0;
+                Affine cur;
+                const bool chg = node_apply(root_level, a.static_opt != 0, in, gp, pc, cu.local, cu.old, &cur);
+                if (cu.on) {
+                    at32w<uint8_t>(a.g_changed_bytes, cu.row) = chg ? 1 : 0;
+                    if (chg) st_affine(c.global, cu.row, cur);
+                }
+                pr = cur;
+                p_chg = chg;
+            }
+            before = o_k;
+            o_k = o_k1;
+            o_k1 = o_k2;
+            o_k2 = o_k3;
+        }
+        prev_start = lds_off[n_lv - 1u];
+        l0 += n_lv;
+        MI_WAVE_LDS_SYNC();  // (the next chunk overwrites the offsets and the staging)
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // visibility_propagate_system + propagate_recursive (crates/bevy_camera/src/visibility/mod.rs:638-729) as the
 // fixpoint they maintain, swept over the same subtree tiles as the transforms:
 //   Visible -> true, Hidden -> false, Inherited -> parent's InheritedVisibility (true without a parent or when
@@ -1091,6 +1252,29 @@ hipError_t launch_mark_dirty(uint32_t n, const uint8_t* changed, uint32_t change
                              uint32_t* clear_words, uint32_t n_clear_words, hipStream_t stream, const uint32_t* anc) {
     if (n == 0) return hipSuccess;
     MI_LAUNCH(k_mark_dirty, dim3((n + 255u) / 256u), dim3(256), 0, stream, n, changed, changed_gen, parent_idx, tree_bytes, clear_words, n_clear_words, anc);
+    return hipGetLastError();
+}
+
+hipError_t launch_propagate_narrow(const Columns& c, const uint32_t* parent_idx, const uint32_t* level_offsets, uint32_t n_levels,
+                                   const uint8_t* node_flags, const uint8_t* changed, const uint8_t* tree_bytes, uint8_t* g_changed_bytes, bool all_dirty,
+                                   bool static_opt, bool quad, hipStream_t stream) {
+    if (n_levels == 0) return hipSuccess;
+    TreeArgs a{};
+    a.changed_gen = c.changed_gen;
+    a.parent_idx = parent_idx;
+    a.node_flags = node_flags;
+    a.changed = changed;
+    a.tree_bytes = tree_bytes;
+    a.g_changed_bytes = g_changed_bytes;
+    a.all_dirty = all_dirty ? 1u : 0u;
+    a.static_opt = static_opt ? 1u : 0u;
+    if (quad) {
+        if (all_dirty) MI_LAUNCH((k_propagate_narrow<true, true>), dim3(1), dim3(64), 0, stream, c, a, level_offsets, n_levels);
+        else MI_LAUNCH((k_propagate_narrow<false, true>), dim3(1), dim3(64), 0, stream, c, a, level_offsets, n_levels);
+    } else {
+        if (all_dirty) MI_LAUNCH((k_propagate_narrow<true, false>), dim3(1), dim3(64), 0, stream, c, a, level_offsets, n_levels);
+        else MI_LAUNCH((k_propagate_narrow<false, false>), dim3(1), dim3(64), 0, stream, c, a, level_offsets, n_levels);
+    }
     return hipGetLastError();
 }
 

@@ -231,6 +231,32 @@ HIERARCHY_SHAPES = {
 }
 
 
+# not the reference's: hierarchies as narrow as `chain` but with several nodes to a level (ropes, a handful of rigs) -- every level at
+# most a wave wide, which is what the one-wave kernel takes (kernels_tree.hip, k_propagate_narrow)
+NARROW_SHAPES = {
+    "ropes": (("narrow", 300, 64), (0.3, 0, None)),
+    "ropes_few_movers": (("narrow", 90, 17), (0.02, 0, None)),
+    "strands": (("narrow", 120, 9), (0.4, 0, None)),      # <= 16 to a level: a node per quad of lanes
+    "bundle": (("bundle", 70, 12), (0.1, 0, None)),       # 12 chains side by side under one root: every parent sits where its child does
+    "bundle_wide": (("bundle", 40, 50), (0.1, 0, None)),
+}
+
+
+def _parent_map_narrow(n_levels, max_width, rng):
+    """Level l holds 1..max_width nodes (level 0: the single root), each under a seeded parent of level l - 1."""
+    widths = np.concatenate([[1], rng.integers(1, max_width + 1, n_levels - 1)])
+    starts = np.concatenate([[0], np.cumsum(widths)])
+    pm = [starts[l - 1] + np.sort(rng.integers(0, widths[l - 1], widths[l])) for l in range(1, n_levels)]
+    return np.concatenate(pm).astype(np.int64)
+
+
+def _parent_map_bundle(n_levels, n_ropes):
+    """A root, n_ropes children, and under each a chain down to level n_levels - 1."""
+    first = np.zeros(n_ropes, np.int64)
+    rest = (1 + np.arange((n_levels - 2) * n_ropes, dtype=np.int64))
+    return np.concatenate([first, rest])
+
+
 def _parent_map_tree(depth, branch):
     """gen_tree (transform_hierarchy.rs:440-453): 0,0,..,1,1,.. -- every one of the first sum(branch^i, i < depth-1) nodes has `branch` children."""
     inner = sum(branch ** i for i in range(depth - 1))
@@ -299,7 +325,7 @@ def hierarchy_shape(name, seed=42, plain_transforms=False, scale_rigs=1.0):
       mover_translation(frame)   what the `update` system leaves in the movers' Transforms in frame k (:250-262: a += dt * 0.1, dt = 1/60)
     plain_transforms = identity rotation and unit scale like the reference; otherwise the seeded small rotation and uniform scale of
     gen_tree() above so that the products along a chain are not trivially exact."""
-    (kind, a, b), (prob, min_depth, max_depth) = HIERARCHY_SHAPES[name]
+    (kind, a, b), (prob, min_depth, max_depth) = HIERARCHY_SHAPES[name] if name in HIERARCHY_SHAPES else NARROW_SHAPES[name]
     rng = np.random.default_rng(seed)
     if kind == "humanoids":
         n_rigs = int(round((a + b) * scale_rigs))
@@ -313,7 +339,7 @@ def hierarchy_shape(name, seed=42, plain_transforms=False, scale_rigs=1.0):
         rig_active = np.repeat(np.arange(n_rigs) < n_active, per)
         root_xy = rng.random((n_rigs, 2)) * 500.0 - 250.0
     else:
-        pm = _parent_map_tree(a, b) if kind == "tree" else _parent_map_non_uniform(a, b)
+        pm = _parent_map_tree(a, b) if kind == "tree" else _parent_map_narrow(a, b, rng) if kind == "narrow" else _parent_map_bundle(a, b) if kind == "bundle" else _parent_map_non_uniform(a, b)
         parent = np.concatenate([[NO_PARENT], pm]).astype(np.int64)
         rig_active = np.ones(len(parent), bool)
         root_xy = None

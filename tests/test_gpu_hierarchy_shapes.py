@@ -83,6 +83,17 @@ def test_reference_hierarchy_shape(name, static_opt):
     print(name, sh["n"], "nodes", sh["n_levels"], "levels", len(sh["movers"]), "movers; plan", plan)
 
 
+@pytest.mark.parametrize("static_opt", [True, False])
+@pytest.mark.parametrize("name", list(W.NARROW_SHAPES))
+def test_narrow_hierarchy(name, static_opt):
+    """Every level at most a wave wide and more levels than a tile spans: the one-wave walk (k_propagate_narrow) instead of tiles --
+    several nodes to a level, parents anywhere in the level above, chunks of whole levels."""
+    sh = W.hierarchy_shape(name)
+    assert int(np.diff(sh["level_offsets"].astype(np.int64)).max()) <= 64 and sh["n_levels"] > 16
+    run_shape(sh, static_opt)
+    run_shape(W.hierarchy_shape(name, seed=7, plain_transforms=True), static_opt)
+
+
 def test_reference_hierarchy_shape_with_plain_transforms():
     """Identity rotations and unit scales exactly as spawn_tree leaves them (transform_hierarchy.rs:409-418)."""
     for name in ("humanoids_mixed", "chain"):

@@ -23,6 +23,18 @@ namespace mi {
 // views: 150.0 against 151.8 us, and 220.6 against 214.4 on k_frame; not kept.)
 __device__ __forceinline__ bool sphere_inside_five_planes(const float* planes, V4 c4, float r) {
     bool inside = true;
+#ifdef MI_EXP_PLANES_UPFRONT  // all five planes in one scalar load, no early exit between planes: k_frame 19.5 -> 19.25 us, 10 M x 1 view 151.7 -> 149.8,
+                              // 10 M x 4 views 177.9 -> 179.1; k_frame_cells<true> drops to 7 waves per SIMD -- not the product (profiles/r05a/planes_upfront_ab.txt)
+    float P[20];
+#pragma unroll
+    for (int i = 0; i < 20; ++i) P[i] = planes[i];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const V4 pl = V4{P[4 * i], P[4 * i + 1], P[4 * i + 2], P[4 * i + 3]};
+        inside = inside & !(dot4(pl, c4) + r <= 0.0f);
+    }
+    return inside;
+#endif
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         const V4 pl = V4{planes[4 * i], planes[4 * i + 1], planes[4 * i + 2], planes[4 * i + 3]};

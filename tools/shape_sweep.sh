@@ -2,7 +2,7 @@
 # bash tools/shape_sweep.sh <outdir>: one bench line per hierarchy stress shape and frame kind (bench.py --workload tree --tree-shape ...)
 OUT=${1:-gpurun_out/shapes}
 mkdir -p $OUT
-for shape in ${SHAPES:-large_tree wide_tree deep_tree chain ropes strands bundle update_leaves update_shallow humanoids_active humanoids_inactive humanoids_mixed tree_4ary_depth11 tree_4ary_depth12}; do
+for shape in ${SHAPES:-large_tree wide_tree deep_tree chain ropes bundle update_leaves update_shallow humanoids_active humanoids_inactive humanoids_mixed tree_4ary_depth11 tree_4ary_depth12}; do
   for kind in all movers; do
     case $shape in tree_4ary*) [ $kind = movers ] && continue ;; esac
     timeout 300 python bench.py --workload tree --tree-shape $shape --tree-shape-frame $kind --steps 20 --warmup 5 --blocks 8 \

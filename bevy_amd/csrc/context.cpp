@@ -936,6 +936,7 @@ int32_t mi_ctx_create(int32_t device, void* hip_stream, mi_ctx** out_ctx) {
     }
     ctx->level_offsets = {0, 0};
     ctx->xch.debug = getenv("MI_XCH_DEBUG") != nullptr;  // environment knobs of the exchange: read once, here
+    if (const char* mv = getenv("MI_MULTI_VIEW")) g_multi_view_mode = atoi(mv);  // (1: several views never take k_frame's pair pass; an A/B switch)
     ctx->xch.async_enqueue = getenv("MI_XCH_SYNC_ENQUEUE") == nullptr;  // (set: ncclAllGather is enqueued on the caller's thread again)
     *out_ctx = ctx;
     return MI_OK;

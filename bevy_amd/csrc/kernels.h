@@ -257,6 +257,7 @@ __host__ __device__ inline uint32_t compact_fast_gx(uint32_t n, bool own_launch)
 }
 // bytes of the seg_totals buffer: the totals (padded to 8 bytes) and, in the hierarchical mode, n_chunks stamped totals per segment
 inline size_t compact_fast_totals_bytes(size_t segs, uint32_t n) { return ((segs + 1u) & ~(size_t)1u) * 4u + segs * compact_fast_chunks(n, true) * 8u; }
+extern int g_multi_view_mode;  // (process-wide: set from MI_MULTI_VIEW when a context is created; kernels_flat.hip)
 hipError_t launch_flat_propagate_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views,
                                       uint32_t n_views, const VisibilityOut& out, const SegOut& seg, uint32_t flags,
                                       const CompactFastArgs* prev, const struct ClusterFillJob* fill, const struct ClusterWalkJob* walk,

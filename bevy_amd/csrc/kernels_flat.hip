@@ -83,6 +83,26 @@ __device__ __forceinline__ RowSum load_row_summary(const Columns& c, uint32_t wa
 // (a workgroup barrier here made every wave wait for the slowest of four sets of loads).
 // ---------------------------------------------------------------------------------------------
 typedef float v4f __attribute__((ext_vector_type(4)));
+// A row's affine in a wave's transpose buffer (three float4 per row, the layout of the GlobalTransform column).
+__device__ __forceinline__ Affine lds_affine(const float4* slots, uint32_t slot) {
+    const float4 a = slots[slot * 3u], b = slots[slot * 3u + 1u], cc = slots[slot * 3u + 2u];
+    Affine r;
+    r.m.x_axis = V3{a.x, a.y, a.z};
+    r.m.y_axis = V3{a.w, b.x, b.y};
+    r.m.z_axis = V3{b.z, b.w, cc.x};
+    r.t = V3{cc.y, cc.z, cc.w};
+    return r;
+}
+__device__ __forceinline__ void lds_put(float4* slots, uint32_t slot, const Affine& a) {
+    slots[slot * 3u] = make_float4(a.m.x_axis.x, a.m.x_axis.y, a.m.x_axis.z, a.m.y_axis.x);
+    slots[slot * 3u + 1u] = make_float4(a.m.y_axis.y, a.m.y_axis.z, a.m.z_axis.x, a.m.z_axis.y);
+    slots[slot * 3u + 2u] = make_float4(a.m.z_axis.z, a.t.x, a.t.y, a.t.z);
+}
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float shfl_f(float v, uint32_t src_lane) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __float_as_int(v)));
+}
+__device__ __forceinline__ V3 shfl3(V3 v, uint32_t src_lane) { return V3{shfl_f(v.x, src_lane), shfl_f(v.y, src_lane), shfl_f(v.z, src_lane)}; }
 __device__ __forceinline__ void store_affine_coalesced(float4* lds_wave, float* g, uint32_t wave_row0, uint32_t n,
                                                        uint32_t lane, const Affine& a, bool nt = false) {
     lds_wave[lane * 3u + 0u] = make_float4(a.m.x_axis.x, a.m.x_axis.y, a.m.x_axis.z, a.m.y_axis.x);
@@ -250,7 +270,17 @@ __device__ __forceinline__ bool frame_riders(uint32_t n_tiles, const CompactFast
 // PROP: 0 = GlobalTransform is resident (mi_cull), 1 = every row is propagated (the fused frame: Transform read once,
 // GlobalTransform written once and never re-read), 2 = only rows whose Transform change byte is set are propagated
 // (sync_simple_transforms' own filter, systems.rs:45-50; `changed` is the byte column), the others keep the resident value.
-template <int PROP, bool INLINE_VIEWS, int WALK>
+// MULTI (2..MULTI_MAX_VIEWS camera views, no VisibilityRange column, no riding walk): the intersects_obb half of the rule -- 29 of a
+// view's ~45 vector instructions per plane -- runs ONCE over the wave's (row, view) pairs that survived their sphere test instead of
+// once per view over all 64 lanes.  A view sees a fraction of a wave's rows (a 74-degree frustum: a fifth of the rows of a wave of
+// many_cubes), so four views leave about as many pairs as the wave has lanes: one pass instead of four.  With four views the kernel
+// is bound by instruction issue as much as by HBM (10 M rows: 178 us against 152 with one view).  Pairs are queued in LDS view by
+// view (ballot + mbcnt), a pair lane takes its row's GlobalTransform from the wave's transpose buffer (still in LDS), the row's centre
+// and half extents from the row's lane (ds_bpermute) and its view's planes from a table the workgroup wrote at its start; it ORs
+// its verdict into the row's word.  Same operations on the same values per pair as row_visible_in_view: same bits.
+constexpr uint32_t MULTI_MAX_VIEWS = 4, MULTI_LDS_TABLE = 3072u, MULTI_LDS_WAVE = 3200u;  // (words of lds_raw: behind the transposes)
+static_assert(MULTI_LDS_WAVE + 4u * 128u <= FRAME_LDS_WORDS && MULTI_LDS_TABLE + MULTI_MAX_VIEWS * 20u <= MULTI_LDS_WAVE, "multi-view scratch fits behind the transposes");
+template <int PROP, bool INLINE_VIEWS, int WALK, bool MULTI = false>
 __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const ViewParams* __restrict__ dviews,
                                                 uint32_t n_views, VisibilityOut out, SegOut seg, uint32_t fl_frame, uint32_t n_tiles,
                                                 CompactFastArgs prev, uint32_t prev_gx, uint32_t n_compact, uint32_t n_fill, ClusterFillJob fill,
@@ -338,6 +368,28 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
             range_hi = r2.y;
         }
     }
+    if constexpr (MULTI) {
+        // the views' planes where a lane can index them: wave w writes view w's five (under the row loads just issued)
+        const uint32_t u = __builtin_amdgcn_readfirstlane(wv);
+        if (u < n_views) {
+            const ViewParams& vp = vs.v[u];
+            float4* tbl = reinterpret_cast<float4*>(lds_raw + MULTI_LDS_TABLE) + u * 5u;
+            // planes 0/1 and 2/3 interleaved component by component -- (n0.x, n1.x, n0.y, n1.y), (n0.z, n1.z, d0, d1) -- so that a pair
+            // lane reads them straight into the register pairs of the packed FP32 instructions; plane 4 as it is
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float* a = vp.planes + 8 * i;
+                const float4 lo = make_float4(a[0], a[4], a[1], a[5]), hi = make_float4(a[2], a[6], a[3], a[7]);
+                if (lane == 0) {
+                    tbl[2 * i] = lo;
+                    tbl[2 * i + 1] = hi;
+                }
+            }
+            const float4 last = make_float4(vp.planes[16], vp.planes[17], vp.planes[18], vp.planes[19]);
+            if (lane == 0) tbl[4] = last;
+        }
+        MI_WG_LDS_BARRIER();
+    }
     if (PROPAGATE) {
         if (live) g = affine_from_srt(s_in, q_in, t_in);
         // nontemporal: the fused path never reads G back (measured +3..16 % at 4 M - 10 M rows, neutral at 1 M)
@@ -358,17 +410,104 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
             const V3 sc = ld3(c.scale, row);
             g = affine_from_srt(sc, q, t);
             st_affine(c.global, row, g);
+            if constexpr (MULTI) lds_put(lds_wave, lane, g);  // (the pair lanes below read the rows' GlobalTransforms from here)
         }
     }
     const bool ncc = (fl & 0x10u) != 0;  // NoCpuCulling rows are not in the cull query (mod.rs:771)
     const bool any_live = wave_row0 < c.n;  // waves past the last row must not touch the masks
     bool any = false;
-    for (uint32_t v = 0; v < n_views; ++v) {
-        const ViewParams& vp = INLINE_VIEWS ? vs.v[v] : dviews[v];
-        const bool vis = live && !ncc &&
-                         row_visible_in_view(g, center, half, fl, emask, emask_hi, c.range_start_end != nullptr, range_lo, range_hi, vp);
-        any = any || vis;
-        emit_view(v, vis, any_live, lane, wave, cmask, out, seg);
+    if constexpr (MULTI) {
+        // ---- every view's cheap half per row: InheritedVisibility, RenderLayers, the five-plane sphere test (mod.rs:797-832);
+        // rows with an Aabb that pass it queue up for intersects_obb (:833-836)
+        const bool has_aabb = (fl & 0x04u) != 0, bounded = (fl & (0x04u | 0x08u)) != 0;
+        const bool at_translation = !has_aabb && __float_as_uint(half.y) == SPHERE_AT_TRANSLATION;
+        const V3 cw = has_aabb ? transform_point(g, center) : V3{at_translation ? g.t.x : center.x, at_translation ? g.t.y : center.y, at_translation ? g.t.z : center.z};
+        const float sr = has_aabb ? length3(mul(g.m, half)) : half.x;
+        const V4 c4 = extend(cw, 1.0f);
+        uint8_t* const queue = reinterpret_cast<uint8_t*>(lds_raw + MULTI_LDS_WAVE + wv * 128u);
+        uint32_t* const verdicts = lds_raw + MULTI_LDS_WAVE + wv * 128u + 64u;
+        verdicts[lane] = 0u;
+        uint32_t visbits = 0u, n_pairs = 0u;
+        for (uint32_t v = 0; v < n_views; ++v) {
+            const ViewParams& vp = vs.v[v];
+            bool vis = live && !ncc && (fl & 0x01u) != 0 && ((vp.layer_mask & emask) | (vp.layer_mask_hi & emask_hi)) != 0;
+            const bool cull = !(fl & 0x02u) && !(vp.flags & VIEW_NO_CPU_CULLING) && bounded;
+            bool inside = true;
+#ifndef MI_EXP_MV_NOTEST
+            if (cull) inside = sphere_inside_five_planes(vp.planes, c4, sr);
+#endif
+#ifdef MI_EXP_MV_NOOBB
+            const bool cand = false;
+#else
+            const bool cand = vis && cull && inside && has_aabb;
+#endif
+            vis = vis && (!cull || (inside && !has_aabb));
+            const unsigned long long m = __ballot(cand);
+            if (m) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (cand) queue[n_pairs + rank] = (uint8_t)(lane | (v << 6));
+                n_pairs += (uint32_t)__popcll(m);
+            }
+            visbits |= (vis ? 1u : 0u) << v;
+        }
+        if (n_pairs) {  // (wave-uniform)
+            MI_WAVE_LDS_SYNC();
+            const float4* const lds_wave = lds_g[wv];
+            const float4* const tbl = reinterpret_cast<const float4*>(lds_raw + MULTI_LDS_TABLE);
+            for (uint32_t p0 = 0; p0 < n_pairs; p0 += 64u) {
+                const bool on = p0 + lane < n_pairs;
+                const uint32_t e = queue[on ? p0 + lane : 0u], src = e & 63u, pv = e >> 6;
+                const Affine gs = lds_affine(lds_wave, src);
+                const V3 cws = shfl3(cw, src), halfs = shfl3(half, src);
+                const V4 c4s = extend(cws, 1.0f);
+                bool in_obb = true;
+                // intersects_obb, two planes to an instruction (v_pk_mul_f32 / v_pk_add_f32: the kernel is bound by instruction issue with
+                // several views, and a packed FP32 instruction costs what a plain one does); the operations and their order per plane
+                // are dot4's and aabb_relative_radius's (glam_math.h), so are the bits
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float4 lo = tbl[pv * 5u + 2u * i], hi = tbl[pv * 5u + 2u * i + 1u];
+#ifdef MI_EXP_MV_NOPK  // (the same pass with plain FP32 instructions: an A/B build)
+                    const V4 pa = V4{lo.x, lo.z, hi.x, hi.z}, pb = V4{lo.y, lo.w, hi.y, hi.w};
+                    in_obb = in_obb & !(dot4(pa, c4s) + aabb_relative_radius(halfs, xyz(pa), gs.m) <= 0.0f);
+                    in_obb = in_obb & !(dot4(pb, c4s) + aabb_relative_radius(halfs, xyz(pb), gs.m) <= 0.0f);
+                    continue;
+#endif
+                    const f2 nx = f2{lo.x, lo.y}, ny = f2{lo.z, lo.w}, nz = f2{hi.x, hi.y}, d = f2{hi.z, hi.w};
+                    const f2 dist = (nx * c4s.x + nz * c4s.z) + (ny * c4s.y + d * c4s.w);
+                    const f2 vx = (nx * gs.m.x_axis.x + ny * gs.m.x_axis.y) + nz * gs.m.x_axis.z;
+                    const f2 vy = (nx * gs.m.y_axis.x + ny * gs.m.y_axis.y) + nz * gs.m.y_axis.z;
+                    const f2 vz = (nx * gs.m.z_axis.x + ny * gs.m.z_axis.y) + nz * gs.m.z_axis.z;
+                    const f2 rr = (__builtin_elementwise_abs(vx) * halfs.x + __builtin_elementwise_abs(vy) * halfs.y) + __builtin_elementwise_abs(vz) * halfs.z;
+                    const f2 sum = dist + rr;
+                    in_obb = in_obb & !(sum.x <= 0.0f) & !(sum.y <= 0.0f);
+                }
+                {
+                    const float4 p4 = tbl[pv * 5u + 4u];
+                    const V4 pl = V4{p4.x, p4.y, p4.z, p4.w};
+                    in_obb = in_obb & !(dot4(pl, c4s) + aabb_relative_radius(halfs, xyz(pl), gs.m) <= 0.0f);
+                }
+                if (on && in_obb) __hip_atomic_fetch_or(&verdicts[src], 1u << pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            MI_WAVE_LDS_SYNC();
+            visbits |= verdicts[lane];
+        }
+        for (uint32_t v = 0; v < n_views; ++v) {
+            const bool vis = ((visbits >> v) & 1u) != 0;
+            any = any || vis;
+#ifdef MI_EXP_MV_NOEMIT
+            if (v == 0)
+#endif
+            emit_view(v, vis, any_live, lane, wave, cmask, out, seg);
+        }
+    } else {
+        for (uint32_t v = 0; v < n_views; ++v) {
+            const ViewParams& vp = INLINE_VIEWS ? vs.v[v] : dviews[v];
+            const bool vis = live && !ncc &&
+                             row_visible_in_view(g, center, half, fl, emask, emask_hi, c.range_start_end != nullptr, range_lo, range_hi, vp);
+            any = any || vis;
+            emit_view(v, vis, any_live, lane, wave, cmask, out, seg);
+        }
     }
     const bool vv_now = view_visibility_tail(c, row, live, any_live, lane, wave, fl, vv0, any, fl_frame);
     if (PROPAGATE) {  // plain assignment bumps every written row's tick (systems.rs:62)
@@ -1280,6 +1419,7 @@ hipError_t launch_upload_trs(const float* pinned_src, float* t, float* r, float*
 
 // prev != nullptr: the previous frame's deferred compaction rides in extra workgroups of this launch; fill != nullptr: so does the
 // fill of the previous frame's light-cluster assignment
+int g_multi_view_mode = 0;  // MI_MULTI_VIEW (read by mi_ctx_create): 0 = as described at k_frame's MULTI, 1 = never
 template <int PROP>
 static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views,
                                const VisibilityOut& out, const SegOut& seg, uint32_t flags, const CompactFastArgs* prev,
@@ -1309,7 +1449,13 @@ static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, co
         walk_blocks = wj.inrow ? 0u : wj.n_blocks;  // in-row: the row workgroups of the objects' tiles do it
     }
     const dim3 grid(n_tiles + prev_blocks + fill_blocks + walk_blocks);
-    if (with_walk && wj.spots) {
+    // several camera views: intersects_obb over the (row, view) pairs that passed their sphere test (k_frame's MULTI)
+    bool multi = !with_walk && views_inline && n_views >= 2u && n_views <= MULTI_MAX_VIEWS && !c.range_start_end && g_multi_view_mode != 1;
+    for (uint32_t v = 0; v < n_views && multi; ++v) multi = !(views_inline->v[v].flags & VIEW_SHADOW);
+    if (multi) {
+        MI_LAUNCH((k_frame<PROP, true, 0, true>), grid, dim3(256), 0, stream, c, *views_inline, (const ViewParams*)nullptr, n_views, out, seg, flags,
+                  n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed);
+    } else if (with_walk && wj.spots) {
         MI_LAUNCH((k_frame<PROP, true, 2>), grid, dim3(256), 0, stream, c, *views_inline, (const ViewParams*)nullptr, n_views, out, seg, flags,
                   n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed);
     } else if (with_walk) {

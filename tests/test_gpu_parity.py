@@ -75,6 +75,57 @@ def test_flat_fused_frame_matches_oracle(ctx_factory, n):
     assert_bits(vv_chg, chg_exp, "ViewVisibility change mask")
 
 
+@pytest.mark.parametrize("n_views", [2, 3, 4])
+def test_several_camera_views_pair_pass(ctx_factory, n_views, monkeypatch):
+    """k_frame's MULTI path (intersects_obb over the wave's (row, view) pairs, kernels_flat.hip): cameras that look almost the same
+    way, so that a wave queues up to n_views x 64 pairs -- several passes; a ragged last wave; rows with a Sphere, without bounds,
+    NoFrustumCulling, NoCpuCulling; one camera with NoCpuCulling.  Against the oracle, against the per-view rule (MI_MULTI_VIEW=1), in
+    the fused frame, the changed-rows frame and the cull over resident GlobalTransforms."""
+    n = 20_011
+    sc = W.many_cubes(n, radius=40.0, ragged_flags=True)
+    cams = [W.many_cubes_camera(3 * k, yaw=math.pi + 0.05 * k) for k in range(n_views)]  # (looking at the spiral's dense start)
+    frusta = frusta_for(cams)
+    vmasks = np.array([1, 3, 1, 3][:n_views], np.uint32)
+    vflags = np.array([0, 0, B.VIEW_FLAG_NO_CPU_CULLING, 0][:n_views], np.uint8)
+    vv0 = (W.splitmix64(5, n) % np.uint64(2)).astype(np.uint8)
+    g_exp, vv_exp, vis_exp, chg_exp = oracle_frame(sc, vv0, frusta, vmasks, vflags)
+    assert max(int(v.sum()) for v in vis_exp) > n // 8, "the cameras see too little for several passes"
+    results = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MI_MULTI_VIEW", mode)  # (read when a context is created)
+        ctx = ctx_factory()
+        ctx.debug_set_sphere_path(1)  # (the resident cull below through k_frame, not the world-sphere kernel)
+        upload_scene(ctx, sc, vv0)
+        ctx.propagate_and_cull(frusta, vmasks, vflags)
+        ctx.visibility_end_frame()
+        fused = [ctx.download_visibility(v) for v in range(n_views)]
+        vv, vv_chg = ctx.download_view_visibility()
+        for v in range(n_views):
+            assert_bits(fused[v], vis_exp[v], f"MI_MULTI_VIEW={mode}: view {v}")
+        assert_bits(vv, vv_exp, f"MI_MULTI_VIEW={mode}: ViewVisibility bytes")
+        assert_bits(vv_chg, chg_exp, f"MI_MULTI_VIEW={mode}: ViewVisibility change mask")
+        # the same views over the resident GlobalTransforms
+        ctx.cull(frusta, vmasks, vflags)
+        resident = [ctx.download_visibility(v) for v in range(n_views)]
+        for v in range(n_views):
+            assert_bits(resident[v], vis_exp[v], f"MI_MULTI_VIEW={mode}: resident cull, view {v}")
+        # ... and the changed-rows frame: a tenth of the rows moved
+        moved = np.nonzero(W.splitmix64(11, n) % np.uint64(10) == 0)[0].astype(np.uint32)
+        t2 = sc["translation"].reshape(n, 3).copy()
+        t2[moved] *= F(0.5)
+        ctx.upload_transforms_indexed(moved, np.ascontiguousarray(t2[moved]).reshape(-1), np.ascontiguousarray(sc["rotation"].reshape(n, 4)[moved]).reshape(-1),
+                                      np.ascontiguousarray(sc["scale"].reshape(n, 3)[moved]).reshape(-1))
+        ctx.propagate_and_cull(frusta, vmasks, vflags, flags=B.CULL_CHANGED_ROWS | B.CULL_END_FRAME)
+        results.append([ctx.download_visibility(v) for v in range(n_views)] + list(ctx.download_view_visibility()) + [ctx.download_global_transforms()[0]])
+    sc2 = dict(sc, translation=np.ascontiguousarray(t2).reshape(-1))
+    g2, vv2, vis2, _ = oracle_frame(sc2, vv_exp, frusta, vmasks, vflags)
+    for v in range(n_views):
+        assert_bits(results[0][v], vis2[v], f"changed-rows frame: view {v}")
+    for a, b in zip(results[0], results[1]):
+        assert a.tobytes() == b.tobytes(), "the pair pass and the per-view rule disagree"
+    assert results[0][-1].tobytes() == g2.tobytes()
+
+
 def test_unfused_equals_fused_and_oracle(ctx_factory):
     n = 20_011
     sc = W.many_cubes(n, ragged_flags=True)

@@ -3,9 +3,11 @@
  * the tables (the Rust shim's upload_and_propagate; the C++ host layer's chunked loop in bevy_mi355x_host.hpp); the Python harness
  * has no such loop of its own -- one thread of numpy's take() was 1.9 of the 2.7 ms of a 10 %-dirty frame, a harness artefact the
  * line then carried as if it were the product's.  HARNESS code: not part of the library, not the oracle.  gcc -O2 -pthread.
- * Plain threads, started per call (a few of them, ~30 us each: small against the loop; an OpenMP team spun for 25 ms per call in a
- * CPU-throttled container). */
+ * A small persistent pool (threads started at the first call, parked on a condition variable between calls: starting eight
+ * threads per call was 200 us of a 235 us gather of 11 000 rows; an OpenMP team spun for 25 ms per call in a CPU-throttled
+ * container). */
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -36,20 +38,70 @@ static void* copy_job(void* p) {
     if (j->out_s) memcpy(j->out_s + 3 * a, j->s3 + 3 * src, n * 12);
     return 0;
 }
+#define MAX_THREADS 64
+static struct {
+    pthread_mutex_t mu;
+    pthread_cond_t wake, done_cv;
+    int started;              /* workers alive (they take job slots 1..started) */
+    uint64_t generation;      /* bumped per call */
+    int active;               /* job slots of this call (slot 0 is the caller's) */
+    int pending;              /* workers of this call still running */
+    void* (*fn)(void*);
+    job_t jobs[MAX_THREADS];
+} pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, 0, 0, 0, 0, 0, {{0}}};
+
+static void* worker(void* arg) {
+    const int slot = (int)(intptr_t)arg;
+    uint64_t seen = 0;
+    pthread_mutex_lock(&pool.mu);
+    for (;;) {
+        while (pool.generation == seen) pthread_cond_wait(&pool.wake, &pool.mu);
+        seen = pool.generation;
+        if (slot >= pool.active) continue;  /* this call uses fewer threads */
+        void* (*fn)(void*) = pool.fn;
+        pthread_mutex_unlock(&pool.mu);
+        fn(&pool.jobs[slot]);
+        pthread_mutex_lock(&pool.mu);
+        if (--pool.pending == 0) pthread_cond_signal(&pool.done_cv);
+    }
+    return 0;
+}
 static void run(void* (*fn)(void*), job_t* proto, uint32_t k, int threads) {
     if (threads < 1) threads = 1;
-    if (threads > 64) threads = 64;
-    if (k < 8192u) threads = 1;
-    job_t jobs[64];
-    pthread_t th[64];
-    for (int c = 0; c < threads; ++c) {
-        jobs[c] = *proto;
-        jobs[c].a = (uint32_t)((uint64_t)k * (uint64_t)c / (uint64_t)threads);
-        jobs[c].b = (uint32_t)((uint64_t)k * (uint64_t)(c + 1) / (uint64_t)threads);
+    if (threads > MAX_THREADS) threads = MAX_THREADS;
+    if (k < 16384u) threads = 1;  /* (a wake-up is ~20 us: not worth it below a few thousand rows per thread) */
+    job_t mine = *proto;
+    if (threads == 1) {
+        mine.a = 0;
+        mine.b = k;
+        fn(&mine);
+        return;
     }
-    for (int c = 1; c < threads; ++c) pthread_create(&th[c], 0, fn, &jobs[c]);
-    fn(&jobs[0]);
-    for (int c = 1; c < threads; ++c) pthread_join(th[c], 0);
+    pthread_mutex_lock(&pool.mu);
+    while (pool.started < threads - 1) {
+        pthread_t th;
+        const int slot = pool.started + 1;
+        if (pthread_create(&th, 0, worker, (void*)(intptr_t)slot) != 0) break;
+        pthread_detach(th);
+        pool.started = slot;
+    }
+    if (threads > pool.started + 1) threads = pool.started + 1;
+    for (int c = 0; c < threads; ++c) {
+        pool.jobs[c] = *proto;
+        pool.jobs[c].a = (uint32_t)((uint64_t)k * (uint64_t)c / (uint64_t)threads);
+        pool.jobs[c].b = (uint32_t)((uint64_t)k * (uint64_t)(c + 1) / (uint64_t)threads);
+    }
+    mine = pool.jobs[0];
+    pool.fn = fn;
+    pool.active = threads;
+    pool.pending = threads - 1;
+    pool.generation++;
+    pthread_cond_broadcast(&pool.wake);
+    pthread_mutex_unlock(&pool.mu);
+    fn(&mine);
+    pthread_mutex_lock(&pool.mu);
+    while (pool.pending) pthread_cond_wait(&pool.done_cv, &pool.mu);
+    pthread_mutex_unlock(&pool.mu);
 }
 
 void ecs_gather_rows(uint32_t k, const uint32_t* rows, const float* t3, const float* r4, const float* s3, uint32_t* out_rows,

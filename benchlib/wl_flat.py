@@ -76,7 +76,9 @@ def build_flat(ctx, args, rank, world, full_holder, n_global, n_views, name):
                   "k_cull" if args.unfused else "k_flat_propagate_cull", config, metric, "entities/s",
                   kernels=["k_cull" if args.unfused else "k_flat_propagate_cull", "k_compact_fast"])
     wl.scene, wl.n_views, wl.global_units = scene, n_views, n_global
-    wl.kernel_name = "k_frame<0>" if args.unfused else "k_frame<1,true,0>"  # the timer slot's name is not the symbol's
+    # (the timer slot's name is not the symbol's; 2 .. 4 camera views take the pair-pass kernel unless MI_MULTI_VIEW=1)
+    pairs = 2 <= n_views <= 4 and os.environ.get("MI_MULTI_VIEW", "0") != "1"
+    wl.kernel_name = "k_frame<0>" if args.unfused else "k_frame_pairs<1>" if pairs else "k_frame<1,true,0>"
     if args.row_summary == 0:
         wl.layout_bytes_per_row = wl.bytes_per_row - ROW_SUMMARY_SAVES
     return wl

@@ -280,11 +280,11 @@ __device__ __forceinline__ bool frame_riders(uint32_t n_tiles, const CompactFast
 // its verdict into the row's word.  Same operations on the same values per pair as row_visible_in_view: same bits.
 constexpr uint32_t MULTI_MAX_VIEWS = 4, MULTI_LDS_TABLE = 3072u, MULTI_LDS_WAVE = 3200u;  // (words of lds_raw: behind the transposes)
 static_assert(MULTI_LDS_WAVE + 4u * 128u <= FRAME_LDS_WORDS && MULTI_LDS_TABLE + MULTI_MAX_VIEWS * 20u <= MULTI_LDS_WAVE, "multi-view scratch fits behind the transposes");
-template <int PROP, bool INLINE_VIEWS, int WALK, bool MULTI = false>
-__global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const ViewParams* __restrict__ dviews,
-                                                uint32_t n_views, VisibilityOut out, SegOut seg, uint32_t fl_frame, uint32_t n_tiles,
-                                                CompactFastArgs prev, uint32_t prev_gx, uint32_t n_compact, uint32_t n_fill, ClusterFillJob fill,
-                                                ClusterWalkJob walk, const uint8_t* __restrict__ changed) {
+template <int PROP, bool INLINE_VIEWS, int WALK, bool MULTI>
+__device__ __forceinline__ void frame_workgroup(const Columns& c, const ViewSet& vs, const ViewParams* __restrict__ dviews, uint32_t n_views,
+                                                const VisibilityOut& out, const SegOut& seg, uint32_t fl_frame, uint32_t n_tiles,
+                                                const CompactFastArgs& prev, uint32_t prev_gx, uint32_t n_compact, uint32_t n_fill,
+                                                const ClusterFillJob& fill, const ClusterWalkJob& walk, const uint8_t* __restrict__ changed) {
     constexpr bool PROPAGATE = PROP == 1, PARTIAL = PROP == 2;
     // 16 KB + 16 B: the four waves' GlobalTransform transpose buffers (12 KB) -- or, in a riding cluster-fill workgroup, the CSR
     // offsets of up to 4096 clusters and the four wave totals of their scan -- or the arena of a riding cluster-walk workgroup
@@ -461,13 +461,14 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
                 const V3 cws = shfl3(cw, src), halfs = shfl3(half, src);
                 const V4 c4s = extend(cws, 1.0f);
                 bool in_obb = true;
-                // intersects_obb, two planes to an instruction (v_pk_mul_f32 / v_pk_add_f32: the kernel is bound by instruction issue with
-                // several views, and a packed FP32 instruction costs what a plain one does); the operations and their order per plane
-                // are dot4's and aabb_relative_radius's (glam_math.h), so are the bits
+                // intersects_obb.  -DMI_EXP_MV_PK: two planes to an instruction (v_pk_mul_f32 / v_pk_add_f32; the operations and their order per
+                // plane are dot4's and aabb_relative_radius's, so are the bits): 106 instead of 165 vector instructions per pass -- and
+                // no faster on any size (1.25 M x 4 views 22.7 against 22.5 us, 10 M 173.7 against 172.4): with the pairs out of the way
+                // the kernel is no longer bound by instruction issue (profiles/r05a/multi_view_ab.txt)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const float4 lo = tbl[pv * 5u + 2u * i], hi = tbl[pv * 5u + 2u * i + 1u];
-#ifdef MI_EXP_MV_NOPK  // (the same pass with plain FP32 instructions: an A/B build)
+#ifndef MI_EXP_MV_PK  // (the product: plain FP32 instructions; the packed form below is the A/B build)
                     const V4 pa = V4{lo.x, lo.z, hi.x, hi.z}, pb = V4{lo.y, lo.w, hi.y, hi.w};
                     in_obb = in_obb & !(dot4(pa, c4s) + aabb_relative_radius(halfs, xyz(pa), gs.m) <= 0.0f);
                     in_obb = in_obb & !(dot4(pb, c4s) + aabb_relative_radius(halfs, xyz(pb), gs.m) <= 0.0f);
@@ -523,6 +524,23 @@ __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const View
         // metric frame SLOWER, 21.1 -> 22.2 us: the walk's tail is a chain of round trips, and the job's scalar loads join it)
         if (walk.inrow && tile - walk.tile0 < walk.n_blocks) inrow_cluster_walk<WALK == 2>(walk, tile, row, vv_now, g.t, lds_raw);  // (workgroup-uniform)
     }
+}
+
+template <int PROP, bool INLINE_VIEWS, int WALK>
+__global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const ViewParams* __restrict__ dviews,
+                                                uint32_t n_views, VisibilityOut out, SegOut seg, uint32_t fl_frame, uint32_t n_tiles,
+                                                CompactFastArgs prev, uint32_t prev_gx, uint32_t n_compact, uint32_t n_fill, ClusterFillJob fill,
+                                                ClusterWalkJob walk, const uint8_t* __restrict__ changed) {
+    frame_workgroup<PROP, INLINE_VIEWS, WALK, false>(c, vs, dviews, n_views, out, seg, fl_frame, n_tiles, prev, prev_gx, n_compact, n_fill, fill, walk, changed);
+}
+// ... with 2 .. MULTI_MAX_VIEWS camera views: the pair pass (MULTI above).  A kernel name of its own, so that k_frame<...> keeps the
+// symbols the committed profiles and the bench's kernel filters know.
+template <int PROP>
+__global__ void __launch_bounds__(256, 8) k_frame_pairs(Columns c, ViewSet vs, const ViewParams* __restrict__ dviews,
+                                                      uint32_t n_views, VisibilityOut out, SegOut seg, uint32_t fl_frame, uint32_t n_tiles,
+                                                      CompactFastArgs prev, uint32_t prev_gx, uint32_t n_compact, uint32_t n_fill, ClusterFillJob fill,
+                                                      ClusterWalkJob walk, const uint8_t* __restrict__ changed) {
+    frame_workgroup<PROP, true, 0, true>(c, vs, dviews, n_views, out, seg, fl_frame, n_tiles, prev, prev_gx, n_compact, n_fill, fill, walk, changed);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1449,11 +1467,11 @@ static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, co
         walk_blocks = wj.inrow ? 0u : wj.n_blocks;  // in-row: the row workgroups of the objects' tiles do it
     }
     const dim3 grid(n_tiles + prev_blocks + fill_blocks + walk_blocks);
-    // several camera views: intersects_obb over the (row, view) pairs that passed their sphere test (k_frame's MULTI)
+    // several camera views: intersects_obb over the (row, view) pairs that passed their sphere test (k_frame_pairs)
     bool multi = !with_walk && views_inline && n_views >= 2u && n_views <= MULTI_MAX_VIEWS && !c.range_start_end && g_multi_view_mode != 1;
     for (uint32_t v = 0; v < n_views && multi; ++v) multi = !(views_inline->v[v].flags & VIEW_SHADOW);
     if (multi) {
-        MI_LAUNCH((k_frame<PROP, true, 0, true>), grid, dim3(256), 0, stream, c, *views_inline, (const ViewParams*)nullptr, n_views, out, seg, flags,
+        MI_LAUNCH((k_frame_pairs<PROP>), grid, dim3(256), 0, stream, c, *views_inline, (const ViewParams*)nullptr, n_views, out, seg, flags,
                   n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed);
     } else if (with_walk && wj.spots) {
         MI_LAUNCH((k_frame<PROP, true, 2>), grid, dim3(256), 0, stream, c, *views_inline, (const ViewParams*)nullptr, n_views, out, seg, flags,

@@ -15,9 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # kernel (demangled prefix) -> (max VGPRs, min waves per SIMD, max spilled SGPRs, max scratch bytes per lane)
 PINNED = {
     "kernels_flat.hip": {
-        "mi::k_frame<1, true, 1, false>": (92, 5, 32, 64),     # the metric frame: propagate + cull + in-row cluster walk
-        "mi::k_frame<1, true, 0, false>": (64, 8, 32, 0),      # the flat frame
-        "mi::k_frame<1, true, 0, true>": (64, 8, 32, 0),       # ... with several camera views (the pair pass)
+        "mi::k_frame<1, true, 1>": (92, 5, 32, 64),     # the metric frame: propagate + cull + in-row cluster walk
+        "mi::k_frame<1, true, 0>": (64, 8, 32, 0),      # the flat frame
+        "mi::k_frame_pairs<1>": (64, 8, 0, 0),           # ... with several camera views (the pair pass)
         "mi::k_frame_sph<true, true, 0>": (64, 8, 32, 0),
         "mi::k_frame_cells<true>": (64, 8, 32, 0),
     },

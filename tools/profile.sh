@@ -7,7 +7,7 @@
 # profiles/rocprof_summary.json (what bench.py quotes as rocprof_avg_kernel_us / traffic).
 TAG=${1:-r03}
 shift
-WLS=${@:-frame frame_plain_columns flat flat_plain_columns flat_10m_1view flat_10m_4views tree tree_subtree tree_leaves tree_frame tree_frame_two_launches lights flat_static flat_static_no_sphere flat_static_10m_4views flat_static_10m_4views_no_cull_order flat_static_4m_4views tree_by_levels batching batching_sorted_1k batching_sorted_4k batching_sorted_64k batching_sorted_1m}
+WLS=${@:-frame frame_plain_columns flat flat_plain_columns flat_10m_1view flat_10m_4views tree tree_subtree tree_leaves tree_frame tree_frame_two_launches lights flat_static flat_static_no_sphere flat_static_10m_4views flat_static_10m_4views_no_cull_order flat_static_4m_4views tree_by_levels batching batching_sorted_1k batching_sorted_4k batching_sorted_64k batching_sorted_1m flat_1250k_4views tree_shape_chain tree_shape_humanoids_mixed tree_shape_deep_tree tree_shape_large_tree tree_shape_tree_4ary_depth12}
 export TMPDIR=/tmp
 P=gpurun_out/prof_$TAG
 mkdir -p $P
@@ -27,6 +27,8 @@ for wl in $WLS; do
     flat_static_10m_4views_no_cull_order) ARGS="--workload flat_static --entities 10000000 --views 4 --static-cull-order 1" ;;
     flat_static_4m_4views)  ARGS="--workload flat_static --entities 4000000 --views 4" ;;
     tree_by_levels)         ARGS="--workload tree --tile-mode 1" ;;
+    flat_1250k_4views)      ARGS="--workload flat --entities 1250000 --views 4" ;;  # the N = 8 shard of configs[3]
+    tree_shape_*)           ARGS="--workload tree --tree-shape ${wl#tree_shape_}" ;;  # transform_hierarchy.rs's shapes
     batching_sorted_1k)     ARGS="--workload batching_sorted --sorted-items 1024" ;;
     batching_sorted_4k)     ARGS="--workload batching_sorted --sorted-items 4096" ;;
     batching_sorted_64k)    ARGS="--workload batching_sorted --sorted-items 65536" ;;
@@ -36,7 +38,7 @@ for wl in $WLS; do
   echo "python bench.py $ARGS --steps 50 --warmup 10 --blocks 4 $COMMON" > $P/$wl.cmd
   timeout -k 5 180 rocprofv3 --kernel-trace --stats --output-format csv -d $P/$wl -o $wl -- \
       python bench.py $ARGS --steps 50 --warmup 10 --blocks 4 $COMMON > $P/$wl.log 2>&1
-  case $wl in batching|batching_sorted_1k|batching_sorted_4k|batching_sorted_64k|lights) continue ;; esac
+  case $wl in batching|batching_sorted_1k|batching_sorted_4k|batching_sorted_64k|lights|tree_shape_*) continue ;; esac
   for ctr in FETCH_SIZE WRITE_SIZE; do
     timeout -k 5 180 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $P/${wl}_$ctr -o $wl -- \
         python bench.py $ARGS --steps 10 --warmup 2 --blocks 2 $COMMON > $P/${wl}_$ctr.log 2>&1

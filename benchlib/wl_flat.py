@@ -121,7 +121,8 @@ def build_flat_static(ctx, args):
               "sphere_path": sphere, "bytes_per_row_models": models}
     wl = Workload("flat_static", step, n, models["world_sphere_column" if sphere else "global_transform_resident"], "k_cull", config,
                   "entities/sec through propagate+cull", "entities/s", kernels=["k_cull", "k_compact_fast"])
-    wl.kernel_name = "k_frame_sph<false>" if sphere else "k_frame<0>"
+    pairs = 2 <= n_views <= 4 and os.environ.get("MI_MULTI_VIEW", "0") != "1"  # (several camera views: the pair-pass kernels)
+    wl.kernel_name = ("k_frame_sph_pairs<false>" if pairs else "k_frame_sph<false>") if sphere else ("k_frame_pairs<0>" if pairs else "k_frame<0>")
     if args.row_summary == 0:  # the sphere path reads flags + layers per row (5 B), the resident-G path Aabb as well
         wl.layout_bytes_per_row = wl.bytes_per_row - ((5.0 - 0.5) if sphere else ROW_SUMMARY_SAVES)
     config["row_summary"] = args.row_summary == 0

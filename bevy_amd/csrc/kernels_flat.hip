@@ -565,14 +565,34 @@ struct SphereArgs {
     const uint8_t* stale_bytes;   // ... a byte per row (hierarchy path); both nullptr = none
     uint32_t all_stale;           // every row (first use, or after an all-dirty propagate / a bounds upload)
 };
-template <bool PARTIAL, bool INLINE_VIEWS, int WALK>
-__global__ void __launch_bounds__(256) k_frame_sph(Columns c, ViewSet vs, const ViewParams* __restrict__ dviews, uint32_t n_views,
-                                                    VisibilityOut out, SegOut seg, uint32_t fl_frame, uint32_t n_tiles, CompactFastArgs prev,
-                                                    uint32_t prev_gx, uint32_t n_compact, uint32_t n_fill, ClusterFillJob fill,
-                                                    ClusterWalkJob walk, const uint8_t* __restrict__ changed, SphereArgs sa) {
+template <bool PARTIAL, bool INLINE_VIEWS, int WALK, bool MULTI>
+__device__ __forceinline__ void frame_sph_workgroup(const Columns& c, const ViewSet& vs, const ViewParams* __restrict__ dviews, uint32_t n_views,
+                                                    const VisibilityOut& out, const SegOut& seg, uint32_t fl_frame, uint32_t n_tiles,
+                                                    const CompactFastArgs& prev, uint32_t prev_gx, uint32_t n_compact, uint32_t n_fill,
+                                                    const ClusterFillJob& fill, const ClusterWalkJob& walk, const uint8_t* __restrict__ changed,
+                                                    const SphereArgs& sa) {
     __shared__ __attribute__((aligned(16))) uint32_t lds_raw[(WALK ? FRAME_WALK_LDS_WORDS : FRAME_LDS_WORDS) + 4];  // (as in k_frame)
     float4 (*lds_g)[192] = reinterpret_cast<float4 (*)[192]>(lds_raw);
     if (frame_riders<WALK>(n_tiles, prev, prev_gx, n_compact, n_fill, fill, walk, vs, lds_raw)) return;
+    if constexpr (MULTI) {  // the views' planes where a lane can index them (as in k_frame's MULTI): wave w writes view w's five
+        const uint32_t u = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        if (u < n_views) {
+            const ViewParams& vp = vs.v[u];
+            float4* tbl = reinterpret_cast<float4*>(lds_raw + MULTI_LDS_TABLE) + u * 5u;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float* a = vp.planes + 8 * i;
+                const float4 lo = make_float4(a[0], a[4], a[1], a[5]), hi = make_float4(a[2], a[6], a[3], a[7]);
+                if ((threadIdx.x & 63u) == 0) {
+                    tbl[2 * i] = lo;
+                    tbl[2 * i + 1] = hi;
+                }
+            }
+            const float4 last = make_float4(vp.planes[16], vp.planes[17], vp.planes[18], vp.planes[19]);
+            if ((threadIdx.x & 63u) == 0) tbl[4] = last;
+        }
+        MI_WG_LDS_BARRIER();
+    }
     const uint32_t n_extra = gridDim.x - n_tiles;
     uint32_t tile = blockIdx.x - n_extra;
     if constexpr (WALK != 0) {  // (as in k_frame: the tiles that go on into the cluster walk first)
@@ -716,7 +736,62 @@ __global__ void __launch_bounds__(256) k_frame_sph(Columns c, ViewSet vs, const 
             g.m.z_axis = V3{b.z, b.w, cc.x};
             g.t = V3{cc.y, cc.z, cc.w};
         }
-        if (need) {
+        if constexpr (MULTI) {
+            // intersects_obb once over the wave's (row, view) pairs that owe it, 64 to a pass (k_frame's MULTI): a pair lane takes its
+            // row's GlobalTransform from the transpose buffer (dense) or from the column, the row's sphere centre from the row's lane
+            uint8_t* const queue = reinterpret_cast<uint8_t*>(lds_raw + MULTI_LDS_WAVE + wv * 128u);
+            uint32_t* const failed = lds_raw + MULTI_LDS_WAVE + wv * 128u + 64u;
+            failed[lane] = 0u;
+            uint32_t n_pairs = 0u;
+            for (uint32_t v = 0; v < n_views; ++v) {
+                const bool cand = ((need >> v) & 1u) != 0;
+                const unsigned long long m = __ballot(cand);
+                if (m) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (cand) queue[n_pairs + rank] = (uint8_t)(lane | (v << 6));
+                    n_pairs += (uint32_t)__popcll(m);
+                }
+            }
+            MI_WAVE_LDS_SYNC();
+            const float4* const lds_wave = lds_g[wv];
+            const float4* const tbl = reinterpret_cast<const float4*>(lds_raw + MULTI_LDS_TABLE);
+            for (uint32_t p0 = 0; p0 < n_pairs; p0 += 64u) {
+                const bool on = p0 + lane < n_pairs;
+                const uint32_t e = queue[on ? p0 + lane : 0u], src = e & 63u, pv = e >> 6;
+                const uint32_t srow = wave_row0 + src;  // (a live row: it queued itself)
+                const Affine gs = dense ? lds_affine(lds_wave, src) : ld_affine(c.global, srow);
+                const V3 halfs = uni_aabb ? rs.half : ld3(c.aabb_half, srow);
+                const V4 c4s = V4{shfl_f(sp.x, src), shfl_f(sp.y, src), shfl_f(sp.z, src), 1.0f};
+                bool in_obb = true;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float4 lo = tbl[pv * 5u + 2u * i], hi = tbl[pv * 5u + 2u * i + 1u];
+#ifndef MI_EXP_MV_PK  // (the product: plain FP32; packed measured no faster here either -- 10 M x 4 views 155.3 against 152.9 us per frame)
+                    const V4 pa = V4{lo.x, lo.z, hi.x, hi.z}, pb = V4{lo.y, lo.w, hi.y, hi.w};
+                    in_obb = in_obb & !(dot4(pa, c4s) + aabb_relative_radius(halfs, xyz(pa), gs.m) <= 0.0f);
+                    in_obb = in_obb & !(dot4(pb, c4s) + aabb_relative_radius(halfs, xyz(pb), gs.m) <= 0.0f);
+                    continue;
+#endif
+                    // (-DMI_EXP_MV_PK) two planes to an instruction, v_pk_mul_f32 / v_pk_add_f32: same operations in the same order, same bits
+                    const f2 nx = f2{lo.x, lo.y}, ny = f2{lo.z, lo.w}, nz = f2{hi.x, hi.y}, d = f2{hi.z, hi.w};
+                    const f2 dist = (nx * c4s.x + nz * c4s.z) + (ny * c4s.y + d * c4s.w);
+                    const f2 vx = (nx * gs.m.x_axis.x + ny * gs.m.x_axis.y) + nz * gs.m.x_axis.z;
+                    const f2 vy = (nx * gs.m.y_axis.x + ny * gs.m.y_axis.y) + nz * gs.m.y_axis.z;
+                    const f2 vz = (nx * gs.m.z_axis.x + ny * gs.m.z_axis.y) + nz * gs.m.z_axis.z;
+                    const f2 rr = (__builtin_elementwise_abs(vx) * halfs.x + __builtin_elementwise_abs(vy) * halfs.y) + __builtin_elementwise_abs(vz) * halfs.z;
+                    const f2 sum = dist + rr;
+                    in_obb = in_obb & !(sum.x <= 0.0f) & !(sum.y <= 0.0f);
+                }
+                {
+                    const float4 p4 = tbl[pv * 5u + 4u];
+                    const V4 pl = V4{p4.x, p4.y, p4.z, p4.w};
+                    in_obb = in_obb & !(dot4(pl, c4s) + aabb_relative_radius(halfs, xyz(pl), gs.m) <= 0.0f);
+                }
+                if (on && !in_obb) __hip_atomic_fetch_or(&failed[src], 1u << pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+            MI_WAVE_LDS_SYNC();
+            pass &= ~failed[lane];
+        } else if (need) {
             if (!dense) g = ld_affine(c.global, row);
             const V3 half = uni_aabb ? rs.half : ld3(c.aabb_half, row);
             for (uint32_t v = 0; v < n_views; ++v) {
@@ -741,6 +816,22 @@ __global__ void __launch_bounds__(256) k_frame_sph(Columns c, ViewSet vs, const 
             inrow_cluster_walk<WALK == 2>(walk, tile, row, vv_now, t, lds_raw);
         }
     }
+}
+
+template <bool PARTIAL, bool INLINE_VIEWS, int WALK>
+__global__ void __launch_bounds__(256) k_frame_sph(Columns c, ViewSet vs, const ViewParams* __restrict__ dviews, uint32_t n_views,
+                                                    VisibilityOut out, SegOut seg, uint32_t fl_frame, uint32_t n_tiles, CompactFastArgs prev,
+                                                    uint32_t prev_gx, uint32_t n_compact, uint32_t n_fill, ClusterFillJob fill,
+                                                    ClusterWalkJob walk, const uint8_t* __restrict__ changed, SphereArgs sa) {
+    frame_sph_workgroup<PARTIAL, INLINE_VIEWS, WALK, false>(c, vs, dviews, n_views, out, seg, fl_frame, n_tiles, prev, prev_gx, n_compact, n_fill, fill, walk, changed, sa);
+}
+// ... with 2 .. MULTI_MAX_VIEWS camera views: intersects_obb over the (row, view) pairs (MULTI above)
+template <bool PARTIAL>
+__global__ void __launch_bounds__(256, 8) k_frame_sph_pairs(Columns c, ViewSet vs, const ViewParams* __restrict__ dviews, uint32_t n_views,
+                                                             VisibilityOut out, SegOut seg, uint32_t fl_frame, uint32_t n_tiles, CompactFastArgs prev,
+                                                             uint32_t prev_gx, uint32_t n_compact, uint32_t n_fill, ClusterFillJob fill,
+                                                             ClusterWalkJob walk, const uint8_t* __restrict__ changed, SphereArgs sa) {
+    frame_sph_workgroup<PARTIAL, true, 0, true>(c, vs, dviews, n_views, out, seg, fl_frame, n_tiles, prev, prev_gx, n_compact, n_fill, fill, walk, changed, sa);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1527,7 +1618,11 @@ hipError_t launch_frame_sph(const Columns& c, const ViewSet* views_inline, const
 #define MI_SPH_LAUNCH(P, I, W) \
     MI_LAUNCH((k_frame_sph<P, I, W>), grid, dim3(256), 0, stream, c, vsr, dv, n_views, out, seg, flags, n_tiles, pa, prev_gx, prev_blocks, \
               fill_blocks, fj, wj, changed, sa)
-    if (changed) {
+    const bool pairs = !with_walk && inl && n_views >= 2u && n_views <= MULTI_MAX_VIEWS && g_multi_view_mode != 1;
+    if (pairs) {
+        if (changed) MI_LAUNCH((k_frame_sph_pairs<true>), grid, dim3(256), 0, stream, c, vsr, dv, n_views, out, seg, flags, n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed, sa);
+        else MI_LAUNCH((k_frame_sph_pairs<false>), grid, dim3(256), 0, stream, c, vsr, dv, n_views, out, seg, flags, n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed, sa);
+    } else if (changed) {
         if (with_walk && wj.spots) MI_SPH_LAUNCH(true, true, 2);
         else if (with_walk) MI_SPH_LAUNCH(true, true, 1);
         else if (inl) MI_SPH_LAUNCH(true, true, 0);

@@ -75,12 +75,14 @@ def test_flat_fused_frame_matches_oracle(ctx_factory, n):
     assert_bits(vv_chg, chg_exp, "ViewVisibility change mask")
 
 
+@pytest.mark.parametrize("sphere_path", [1, 2])
 @pytest.mark.parametrize("n_views", [2, 3, 4])
-def test_several_camera_views_pair_pass(ctx_factory, n_views, monkeypatch):
+def test_several_camera_views_pair_pass(ctx_factory, n_views, sphere_path, monkeypatch):
     """k_frame's MULTI path (intersects_obb over the wave's (row, view) pairs, kernels_flat.hip): cameras that look almost the same
     way, so that a wave queues up to n_views x 64 pairs -- several passes; a ragged last wave; rows with a Sphere, without bounds,
     NoFrustumCulling, NoCpuCulling; one camera with NoCpuCulling.  Against the oracle, against the per-view rule (MI_MULTI_VIEW=1), in
-    the fused frame, the changed-rows frame and the cull over resident GlobalTransforms."""
+    the fused frame, the changed-rows frame and the cull over resident GlobalTransforms -- the last two through k_frame_pairs
+    (sphere_path 1) and through the world-sphere column's k_frame_sph_pairs (sphere_path 2)."""
     n = 20_011
     sc = W.many_cubes(n, radius=40.0, ragged_flags=True)
     cams = [W.many_cubes_camera(3 * k, yaw=math.pi + 0.05 * k) for k in range(n_views)]  # (looking at the spiral's dense start)
@@ -94,7 +96,7 @@ def test_several_camera_views_pair_pass(ctx_factory, n_views, monkeypatch):
     for mode in ("0", "1"):
         monkeypatch.setenv("MI_MULTI_VIEW", mode)  # (read when a context is created)
         ctx = ctx_factory()
-        ctx.debug_set_sphere_path(1)  # (the resident cull below through k_frame, not the world-sphere kernel)
+        ctx.debug_set_sphere_path(sphere_path)  # 1: the resident cull below through k_frame; 2: through the world-sphere kernel, at once
         upload_scene(ctx, sc, vv0)
         ctx.propagate_and_cull(frusta, vmasks, vflags)
         ctx.visibility_end_frame()

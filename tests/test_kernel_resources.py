@@ -19,6 +19,7 @@ PINNED = {
         "mi::k_frame<1, true, 0>": (64, 8, 32, 0),      # the flat frame
         "mi::k_frame_pairs<1>": (64, 8, 0, 0),           # ... with several camera views (the pair pass)
         "mi::k_frame_sph<true, true, 0>": (64, 8, 32, 0),
+        "mi::k_frame_sph_pairs<false>": (64, 8, 0, 0),
         "mi::k_frame_cells<true>": (64, 8, 32, 0),
     },
     "kernels_tree.hip": {

@@ -20,7 +20,7 @@ workloads = sys.argv[2:] or ["frame", "frame_plain_columns", "flat", "flat_plain
 src = os.path.join("gpurun_out", f"prof_{tag}")
 dst = os.path.join("profiles", tag)
 os.makedirs(dst, exist_ok=True)
-ALIAS = {"k_frame_sph<true": "k_flat_propagate_cull", "k_frame_sph<false": "k_cull",  # the world-sphere frame kernel: PARTIAL = the changed-rows frame, else cull only
+ALIAS = {"k_frame_sph<true": "k_flat_propagate_cull", "k_frame_sph<false": "k_cull", "k_frame_sph_pairs<true": "k_flat_propagate_cull", "k_frame_sph_pairs<false": "k_cull",  # the world-sphere frame kernel: PARTIAL = the changed-rows frame, else cull only
          "k_frame<1": "k_flat_propagate_cull", "k_frame<2": "k_flat_propagate_cull", "k_frame<0": "k_cull",
          "k_frame_pairs<1": "k_flat_propagate_cull", "k_frame_pairs<2": "k_flat_propagate_cull", "k_frame_pairs<0": "k_cull",  # 2 .. 4 camera views  # PROP: 1 all rows, 2 changed rows, 0 resident G (any INLINE_VIEWS / WITH_WALK variant)
          "k_frame<true": "k_flat_propagate_cull", "k_frame<false": "k_cull",  # (profiles from before PROP was an int)

@@ -94,6 +94,60 @@ def test_narrow_hierarchy(name, static_opt):
     run_shape(W.hierarchy_shape(name, seed=7, plain_transforms=True), static_opt)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_random_narrow_forests(seed):
+    """Random forests whose every level fits a wave (the one-wave kernel's domain): several roots, roots without children (their rule is
+    sync_simple_transforms': written iff their own Transform changed), level widths from 1 to 64 or held under 16 (the quad form),
+    17 to ~400 levels (several LDS chunks), parents anywhere in the level above; frames with random movers, with and without
+    StaticTransformOptimizations.  Bits and change ticks against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    n_levels = int(rng.integers(17, 400 if seed % 3 else 60))
+    cap = 16 if seed % 2 else 64
+    widths = rng.integers(1, cap + 1, n_levels)
+    starts = np.concatenate([[0], np.cumsum(widths)])
+    n = int(starts[-1])
+    parent = np.full(n, W.NO_PARENT, np.int64)
+    for l in range(1, n_levels):  # (level order by construction: parents sorted, so siblings stay together)
+        lo_p = starts[l - 1] + (rng.integers(0, widths[l - 1]) if seed % 4 == 0 else 0)  # some roots stay childless
+        parent[starts[l]:starts[l + 1]] = np.sort(rng.integers(lo_p, starts[l], widths[l]))
+    new_to_old, p_new, offs = W.level_order(parent)
+    assert np.array_equal(new_to_old, np.arange(n)) and int(np.diff(offs.astype(np.int64)).max()) <= 64
+    t = (rng.random((n, 3)) * 4 - 2).astype(F)
+    q = rng.normal(size=(n, 4))
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(F)
+    s3 = (0.9 + 0.2 * rng.random((n, 3))).astype(F)
+    for static_opt in (True, False):
+        flags = B.PROPAGATE_STATIC_OPT if static_opt else 0
+        with api.Context(0) as ctx:
+            ctx.resize(n)
+            ctx.upload_transforms(t.reshape(-1), q.reshape(-1), s3.reshape(-1))
+            ctx.upload_hierarchy(p_new, offs)
+            ctx.propagate(B.PROPAGATE_ALL_DIRTY | flags)
+            g, chg = ctx.download_global_transforms()
+            rc, g_exp, chg_exp = O.propagate_transforms(p_new, t.reshape(-1), q.reshape(-1), s3.reshape(-1), static_opt=static_opt)
+            assert rc == 0
+            assert_rows(g, g_exp, f"seed {seed} all dirty")
+            assert_bits(chg, chg_exp, f"seed {seed} all dirty: change ticks")
+            tt = t.copy()
+            for frame, frac in enumerate((0.3, 0.02, 0.0)):
+                moved = np.nonzero(rng.random(n) < frac)[0].astype(np.uint32)
+                changed = np.zeros(n, np.uint8)
+                changed[moved] = 1
+                if len(moved):
+                    tt[moved] += F(0.25)
+                    ctx.upload_transforms_indexed(moved, np.ascontiguousarray(tt[moved]).reshape(-1), np.ascontiguousarray(q[moved]).reshape(-1),
+                                                  np.ascontiguousarray(s3[moved]).reshape(-1))
+                else:
+                    ctx.upload_changed(changed)
+                ctx.propagate(flags)
+                g, chg = ctx.download_global_transforms()
+                rc, g_exp, chg_exp = O.propagate_transforms(p_new, tt.reshape(-1), q.reshape(-1), s3.reshape(-1), global_in=g_exp, static_opt=static_opt,
+                                                            tree_changed=O.mark_dirty_trees(p_new, changed), transform_changed=changed)
+                assert rc == 0
+                assert_rows(g, g_exp, f"seed {seed} static_opt {static_opt} frame {frame}")
+                assert_bits(chg, chg_exp, f"seed {seed} static_opt {static_opt} frame {frame}: change ticks")
+
+
 def test_reference_hierarchy_shape_with_plain_transforms():
     """Identity rotations and unit scales exactly as spawn_tree leaves them (transform_hierarchy.rs:409-418)."""
     for name in ("humanoids_mixed", "chain"):

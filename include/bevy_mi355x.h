@@ -288,7 +288,9 @@ int32_t mi_visibility_begin_frame(mi_ctx* ctx);
 /* check_visibility_cpu_culling (visibility/mod.rs:748-876) for n_views ACTIVE cameras in one pass over
  * the columns: sets ViewVisibility bit0 (set_visible, :290-306), writes one packed visibility bitmask
  * per view, and builds the per-view, per-class VisibleEntities lists sorted by Entity bits (:861-874).
- *   frusta[24*n_views]; view_layer_masks[n_views] (NULL = layer 0); view_flags[n_views] (NULL = 0). */
+ *   frusta[24*n_views]; view_layer_masks[n_views] (NULL = layer 0); view_flags[n_views] (NULL = 0).
+ * (2 .. 4 camera views run intersects_obb over (row, view) pairs instead of view by view -- same results; MI_MULTI_VIEW=1 in the
+ * environment of mi_ctx_create keeps the per-view form, an A/B switch.) */
 int32_t mi_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_masks, const uint8_t* view_flags,
                 uint32_t n_views, uint32_t flags /* MI_CULL_* */);
 

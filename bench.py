@@ -49,7 +49,7 @@ from benchlib.wl_batching import build_batching, build_batching_sorted  # noqa: 
 from benchlib.wl_flat import build_flat, build_flat_static  # noqa: E402
 from benchlib.wl_frame import build_frame  # noqa: E402
 from benchlib.wl_lights import build_lights  # noqa: E402
-from benchlib.wl_tree import build_tree, build_tree_shape, roofline_frame  # noqa: E402
+from benchlib.wl_tree import build_tree, build_tree_shape, reprice_per_frame, roofline_frame  # noqa: E402
 
 
 def parse():
@@ -230,6 +230,7 @@ def main():
                "kernels": {k: round(v["avg_us"], 3) for k, v in prof.items() if v["launches"]}}
         if getattr(wl, "frame_level_roofline", False):
             out["roofline_frame"] = roofline_frame(wl, prof, args.steps, PROFILED_BLOCKS)
+            out["roofline"] = reprice_per_frame(out["roofline"], out["roofline_frame"])
         if live:
             out["live_traffic"] = live
         if scaling is None:
@@ -279,6 +280,7 @@ def main():
                             "roofline": roofline_of(w2, p2, 50), "kernels": {k: round(v["avg_us"], 3) for k, v in p2.items() if v["launches"]}}
             if getattr(w2, "frame_level_roofline", False):
                 others[name]["roofline_frame"] = roofline_frame(w2, p2, 50, PROFILED_BLOCKS)
+                others[name]["roofline"] = reprice_per_frame(others[name]["roofline"], others[name]["roofline_frame"])
             if name == "batching":
                 others[name]["batch_build_us_per_frame"] = round(1e3 * (others[name]["ms_per_step"] - others["flat"]["ms_per_step"]), 2)
             if not args.no_cpu_baseline and (name in ("tree", "lights", "batching") or name.startswith("batching_sorted")):

@@ -171,6 +171,23 @@ def build_tree_shape(ctx, args):
     return wl
 
 
+def reprice_per_frame(roofline, frame):
+    """A frame of several launches: `roofline` as measure.roofline_of made it divides the FRAME's bytes by ONE launch's average duration
+    (0.61 for large_tree's four launches of 7.5 us: four times what the frame reaches).  Its achieved / frac become the frame's
+    (roofline_frame), the launch's own figure stays as per_launch_*."""
+    if not roofline or not frame or frame.get("launches_per_frame", 1.0) <= 1.05:
+        return roofline
+    r = dict(roofline)
+    r["per_launch_avg_kernel_us"] = r.get("avg_kernel_us")
+    for k in ("achieved", "frac", "frac_algorithmic"):
+        r[k] = frame["achieved"] if k == "achieved" else frame["frac"]
+    r.pop("rocprof_frac", None)
+    r["avg_kernel_us"] = frame["kernels_us_per_frame"]
+    r["launches_per_frame"] = frame["launches_per_frame"]
+    r["note"] = "several dependent launches per frame: achieved / frac = the frame's bytes over the SUM of its kernels' time (roofline_frame)"
+    return r
+
+
 def roofline_frame(wl, prof, steps, profiled_blocks):
     """A hierarchy frame that is several launches (2 500 dependent levels, streamed wide levels): algorithmic bytes of the frame over
     the SUM of its kernels' device time per frame -- the figure comparable with the one-launch tree's `frac`."""

@@ -270,7 +270,7 @@ __device__ __forceinline__ bool frame_riders(uint32_t n_tiles, const CompactFast
 // PROP: 0 = GlobalTransform is resident (mi_cull), 1 = every row is propagated (the fused frame: Transform read once,
 // GlobalTransform written once and never re-read), 2 = only rows whose Transform change byte is set are propagated
 // (sync_simple_transforms' own filter, systems.rs:45-50; `changed` is the byte column), the others keep the resident value.
-// MULTI (2..MULTI_MAX_VIEWS camera views, no VisibilityRange column, no riding walk): the intersects_obb half of the rule -- 29 of a
+// MULTI (2..MULTI_MAX_VIEWS camera views, no riding walk): the intersects_obb half of the rule -- 29 of a
 // view's ~45 vector instructions per plane -- runs ONCE over the wave's (row, view) pairs that survived their sphere test instead of
 // once per view over all 64 lanes.  A view sees a fraction of a wave's rows (a 74-degree frustum: a fifth of the rows of a wave of
 // many_cubes), so four views leave about as many pairs as the wave has lanes: one pass instead of four.  With four views the kernel
@@ -428,9 +428,19 @@ __device__ __forceinline__ void frame_workgroup(const Columns& c, const ViewSet&
         uint32_t* const verdicts = lds_raw + MULTI_LDS_WAVE + wv * 128u + 64u;
         verdicts[lane] = 0u;
         uint32_t visbits = 0u, n_pairs = 0u;
+        const bool ranged = (fl & 0x20u) != 0 && c.range_start_end != nullptr;
         for (uint32_t v = 0; v < n_views; ++v) {
             const ViewParams& vp = vs.v[v];
             bool vis = live && !ncc && (fl & 0x01u) != 0 && ((vp.layer_mask & emask) | (vp.layer_mask_hi & emask_hi)) != 0;
+            if (ranged) {  // Has<VisibilityRange> && VisibleEntityRanges exists (row_visible_in_view's rule, visibility_rule.h)
+                bool in_range = false;
+                if ((vp.flags & (VIEW_RANGES | VIEW_RANGES_NO_ORIGIN)) == VIEW_RANGES) {
+                    const V3 model = ((fl & 0x40u) && has_aabb) ? cw : g.t;
+                    const float d = length3(V3{vp.position[0], vp.position[1], vp.position[2]} - model);
+                    in_range = d >= range_lo && d < range_hi;
+                }
+                vis = vis && in_range;
+            }
             const bool cull = !(fl & 0x02u) && !(vp.flags & VIEW_NO_CPU_CULLING) && bounded;
             bool inside = true;
 #ifndef MI_EXP_MV_NOTEST
@@ -1559,7 +1569,7 @@ static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, co
     }
     const dim3 grid(n_tiles + prev_blocks + fill_blocks + walk_blocks);
     // several camera views: intersects_obb over the (row, view) pairs that passed their sphere test (k_frame_pairs)
-    bool multi = !with_walk && views_inline && n_views >= 2u && n_views <= MULTI_MAX_VIEWS && !c.range_start_end && g_multi_view_mode != 1;
+    bool multi = !with_walk && views_inline && n_views >= 2u && n_views <= MULTI_MAX_VIEWS && g_multi_view_mode != 1;
     for (uint32_t v = 0; v < n_views && multi; ++v) multi = !(views_inline->v[v].flags & VIEW_SHADOW);
     if (multi) {
         MI_LAUNCH((k_frame_pairs<PROP>), grid, dim3(256), 0, stream, c, *views_inline, (const ViewParams*)nullptr, n_views, out, seg, flags,

@@ -69,7 +69,8 @@ static void* worker(void* arg) {
 static void run(void* (*fn)(void*), job_t* proto, uint32_t k, int threads) {
     if (threads < 1) threads = 1;
     if (threads > MAX_THREADS) threads = MAX_THREADS;
-    if (k < 16384u) threads = 1;  /* (a wake-up is ~20 us: not worth it below a few thousand rows per thread) */
+    if ((uint32_t)threads > k / 8192u) threads = (int)(k / 8192u);  /* (a wake-up is ~20 us: at least 8 192 rows per thread) */
+    if (threads < 1) threads = 1;
     job_t mine = *proto;
     if (threads == 1) {
         mine.a = 0;

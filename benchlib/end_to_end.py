@@ -69,7 +69,9 @@ def end_to_end(ctx, wl, frames=12, cpu_frame_ms=None):
     import ctypes as C
     import os
     gl = gather_lib()
-    threads = max(1, min(8, (os.cpu_count() or 2) // 2))  # (what the C++ host layer's pool uses: half the hardware threads, eight at most)
+    # a par_iter's stand-in: up to 32 threads, a quarter of the hardware threads at most (the CPU port it is compared with takes the best of
+    # a sweep up to all of them); the helper itself keeps >= 8 192 rows per thread
+    threads = max(1, min(32, (os.cpu_count() or 2) // 4))
     fpt, u32t = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
     fp = lambda a: None if a is None else a.ctypes.data_as(fpt)
     t3c, r4c, s3c = np.ascontiguousarray(t3), np.ascontiguousarray(r4), np.ascontiguousarray(s3)

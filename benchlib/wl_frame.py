@@ -18,6 +18,9 @@ def build_frame(ctx, args):
     c_dev, h_dev = sc["aabb_center"].reshape(-1, 3).copy(), sc["aabb_half"].reshape(-1, 3).copy()
     c_dev[first_light:] = 0.0
     h_dev[first_light:, 1] = np.frombuffer(np.uint32(0x7FC0A11D).tobytes(), np.float32)[0]
+    import os
+    if os.environ.get("MI_EXP_LIGHTS_HIDDEN") == "1":  # (an experiment: the lights' InheritedVisibility off -- the launch carries the walk's code, and
+        sc["flags"][first_light:] &= np.uint8(0xFE)     # nothing walks: what the walk-carrying kernel variant costs by itself)
     ctx.debug_set_row_summary(args.row_summary)
     ctx.debug_set_walk_inrow(getattr(args, "walk_inrow", 0))
     ctx.upload_bounds(c_dev.reshape(-1), h_dev.reshape(-1), sc["flags"], sc["layers"])

@@ -1571,6 +1571,13 @@ static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, co
     // several camera views: intersects_obb over the (row, view) pairs that passed their sphere test (k_frame_pairs)
     bool multi = !with_walk && views_inline && n_views >= 2u && n_views <= MULTI_MAX_VIEWS && g_multi_view_mode != 1;
     for (uint32_t v = 0; v < n_views && multi; ++v) multi = !(views_inline->v[v].flags & VIEW_SHADOW);
+#ifdef MI_EXP_FORCE_WALK_VARIANT  // (experiment build: a launch without a walk takes the walk-carrying instantiation -- what that variant costs by itself)
+    if (!with_walk && views_inline && n_views <= MAX_INLINE_VIEWS) {
+        MI_LAUNCH((k_frame<PROP, true, 1>), grid, dim3(256), 0, stream, c, *views_inline, (const ViewParams*)nullptr, n_views, out, seg, flags,
+                  n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed);
+        return hipGetLastError();
+    }
+#endif
     if (multi) {
         MI_LAUNCH((k_frame_pairs<PROP>), grid, dim3(256), 0, stream, c, *views_inline, (const ViewParams*)nullptr, n_views, out, seg, flags,
                   n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed);

@@ -411,14 +411,17 @@ struct WalkPrefetch {
     float pl0, pl1, pl2, pl3;
     double logf_reg;
 };
+// planes: where the table is read from -- the view's own pointer (the staged copy), or the frame kernel's argument segment (WalkPlanes,
+// kernels.h) when the view carries none
 template <bool PLANES_IN_LDS>
-__device__ __forceinline__ WalkPrefetch walk_prefetch(const ClusterViewDev& v) {
+__device__ __forceinline__ WalkPrefetch walk_prefetch(const ClusterViewDev& v, const float* planes_arg = nullptr) {
     const uint32_t n_plane_floats = PLANES_IN_LDS ? 4u * (v.dims[0] + v.dims[1] + v.dims[2] + 3u) : 0u;
     WalkPrefetch p = {0.f, 0.f, 0.f, 0.f, 0.0};
-    if (threadIdx.x < n_plane_floats) p.pl0 = v.x_planes[threadIdx.x];
-    if (threadIdx.x + CLUSTER_BLOCK < n_plane_floats) p.pl1 = v.x_planes[threadIdx.x + CLUSTER_BLOCK];
-    if (threadIdx.x + 2u * CLUSTER_BLOCK < n_plane_floats) p.pl2 = v.x_planes[threadIdx.x + 2u * CLUSTER_BLOCK];
-    if (threadIdx.x + 3u * CLUSTER_BLOCK < n_plane_floats) p.pl3 = v.x_planes[threadIdx.x + 3u * CLUSTER_BLOCK];
+    const float* const src = v.x_planes ? v.x_planes : planes_arg;
+    if (threadIdx.x < n_plane_floats) p.pl0 = src[threadIdx.x];
+    if (threadIdx.x + CLUSTER_BLOCK < n_plane_floats) p.pl1 = src[threadIdx.x + CLUSTER_BLOCK];
+    if (threadIdx.x + 2u * CLUSTER_BLOCK < n_plane_floats) p.pl2 = src[threadIdx.x + 2u * CLUSTER_BLOCK];
+    if (threadIdx.x + 3u * CLUSTER_BLOCK < n_plane_floats) p.pl3 = src[threadIdx.x + 3u * CLUSTER_BLOCK];
     p.logf_reg = (&LOGF_TAB[0][0])[threadIdx.x & 31u];
     return p;
 }
@@ -430,12 +433,12 @@ __device__ __forceinline__ void cluster_walk_tail(const ClusterViewDev& v, const
 // One workgroup of the walk over 256 objects: the objects' own tests (object_in_view), then cluster_walk_tail.
 template <bool PLANES_IN_LDS, bool CHUNKED, bool SPOTS = true>
 __device__ __forceinline__ void cluster_walk_block(const ClusterViewDev& v, const ClusterObjects& o, const ClusterWork& w, const ViewSet& views,
-                                                   uint32_t zc_arg, uint32_t bx, uint32_t* arena) {
+                                                   uint32_t zc_arg, uint32_t bx, uint32_t* arena, const float* planes_arg = nullptr) {
     const uint32_t obj = bx * CLUSTER_BLOCK + threadIdx.x;
     float4 sphere = make_float4(0.f, 0.f, 0.f, 0.f);
     MI_WALK_MARK(bx, 0);
     // the plane tables are requested together with the objects' loads (they are contiguous in device memory: x | y | z)
-    const WalkPrefetch pf = walk_prefetch<PLANES_IN_LDS>(v);
+    const WalkPrefetch pf = walk_prefetch<PLANES_IN_LDS>(v, planes_arg);
     const bool in_view = obj < o.n && object_in_view(v, o, views, obj, &sphere);
     cluster_walk_tail<PLANES_IN_LDS, CHUNKED, SPOTS>(v, o, w, zc_arg, bx, arena, obj, in_view, sphere, pf);
 }

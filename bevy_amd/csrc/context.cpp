@@ -827,6 +827,8 @@ static int32_t cull_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, u
             }
         }
         ProfScope ps(ctx, PROPAGATE ? K_FLAT_PROPAGATE_CULL : K_CULL);
+        // the riding walk's plane table travels as a kernel argument (WalkPlanes, kernels.h): the launch below takes it from here
+        g_walk_planes_host = clusters_ride ? WalkPlanesHost{ctx->cl_planes_host.data(), (uint32_t)ctx->cl_planes_host.size()} : WalkPlanesHost{nullptr, 0};
         const bool stale_from_mask = use_sph && ctx->sph_state == mi_ctx::SPH_EXCEPT_CHANGED;
         const hipError_t e = use_sph ? launch_frame_sph(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p, n_views, vo, seg,
                                                         (flags & (MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME)) | (PROPAGATE ? CULL_BEGIN_FRAME : 0u), prev,

@@ -611,6 +611,30 @@ struct ClusterWalkJob {
     uint32_t inrow, tile0;
     uint32_t spots;        // there are spot lights among the objects: the walk runs the cone test too (view.cluster_spheres is set)
 };
+// The view's cluster planes (x | y | z, four floats each) as a trailing kernel argument of the frame kernels that carry the walk: the
+// table is new nearly every frame (its near plane follows the camera's scale by an ulp), a device copy would be an H2D blit in front
+// of every frame, and read from the pinned staging arena it was a trip over PCIe for each of the light tiles' workgroups -- 1.1 us of
+// the metric frame (profiles/r05a/rider_tax_decomposition.txt).  The kernel-argument segment is device memory; the walkers read the
+// table from it with per-lane loads (kernarg_late).  Tables of more than WALK_PLANES_MAX floats keep the staged copy.
+constexpr uint32_t WALK_PLANES_MAX = 256;
+struct WalkPlanes {
+    float f[WALK_PLANES_MAX];
+};
+struct NoWalkPlanes {};
+template <int WALK>
+struct WalkPlanesArg {
+    typedef WalkPlanes type;
+};
+template <>
+struct WalkPlanesArg<0> {
+    typedef NoWalkPlanes type;
+};
+// (set by the context in front of a frame launch that carries a walk, consumed by that launch: the table on the host)
+struct WalkPlanesHost {
+    const float* f;
+    uint32_t n;
+};
+extern thread_local WalkPlanesHost g_walk_planes_host;
 // bytes of the LDS arena a walking workgroup needs for chunks of zc z slices (layout: cluster_walk.h)
 inline size_t cluster_walk_lds_bytes(uint32_t dxy, uint32_t zc, uint32_t n_planes, bool planes_in_lds) {
     const size_t RC = (size_t)dxy * zc;

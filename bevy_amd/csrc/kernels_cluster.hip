@@ -39,9 +39,13 @@ extern __shared__ __attribute__((aligned(16))) uint32_t cluster_lds[];
 constexpr size_t CLUSTER_MAX_DYN_LDS = 160u * 1024u - 2048u;  // 160 KB per workgroup minus the kernel's static LDS
 constexpr size_t CLUSTER_SMALL_ROWS_BYTES = 24u * 1024u;
 
+// wp: the view's plane table as a kernel argument (WalkPlanes, kernels.h) -- read when the view carries no pointer of its own
+struct ClusterWalkKernargs {
+    ClusterViewDev v; ClusterObjects o; ClusterWork w; ViewSet views; uint32_t zc; WalkPlanes wp;
+};
 template <bool PLANES_IN_LDS, bool CHUNKED>
-__global__ void __launch_bounds__(CLUSTER_BLOCK) k_cluster_walk(ClusterViewDev v, ClusterObjects o, ClusterWork w, ViewSet views, uint32_t zc) {
-    cluster_walk_block<PLANES_IN_LDS, CHUNKED>(v, o, w, views, zc, blockIdx.x, cluster_lds);
+__global__ void __launch_bounds__(CLUSTER_BLOCK) k_cluster_walk(ClusterViewDev v, ClusterObjects o, ClusterWork w, ViewSet views, uint32_t zc, WalkPlanes wp) {
+    cluster_walk_block<PLANES_IN_LDS, CHUNKED>(v, o, w, views, zc, blockIdx.x, cluster_lds, &kernarg_late<float>((uint32_t)offsetof(ClusterWalkKernargs, wp)));
 }
 
 constexpr uint32_t CLUSTER_FILL_BLOCKS = 2048;
@@ -95,15 +99,26 @@ hipError_t launch_cluster_assign(const ClusterViewDev& view, const ClusterObject
     const bool planes_in_lds = lds_for(zc, true) <= CLUSTER_MAX_DYN_LDS;
     const size_t lds = lds_for(zc, planes_in_lds);
     // this frame's parity of the accumulators and of the count matrix was zeroed by the previous frame's fill kernel
+    // the plane table as a kernel argument where it fits and the walkers copy it to LDS anyway (else the staged copy, through the view's pointers)
+    const WalkPlanesHost ph = g_walk_planes_host;
+    g_walk_planes_host = WalkPlanesHost{nullptr, 0};
+    WalkPlanes wp;  // (only the bytes filled below are read)
+    ClusterViewDev vd = view;
+#ifndef MI_EXP_STAGED_PLANES
+    if (planes_in_lds && ph.f && ph.n && ph.n <= WALK_PLANES_MAX) {
+        for (uint32_t i = 0; i < ph.n; ++i) wp.f[i] = ph.f[i];
+        vd.x_planes = vd.y_planes = vd.z_planes = nullptr;
+    }
+#endif
     if (objs.n) {
         if (mark) mark(mctx, K_CLUSTER_WALK);
         const dim3 grid(w.n_blocks), block(CLUSTER_BLOCK);
         if (zc == dz) {
-            if (planes_in_lds) MI_LAUNCH((k_cluster_walk<true, false>), grid, block, lds, stream, view, objs, w, fv, zc);
-            else MI_LAUNCH((k_cluster_walk<false, false>), grid, block, lds, stream, view, objs, w, fv, zc);
+            if (planes_in_lds) MI_LAUNCH((k_cluster_walk<true, false>), grid, block, lds, stream, vd, objs, w, fv, zc, wp);
+            else MI_LAUNCH((k_cluster_walk<false, false>), grid, block, lds, stream, vd, objs, w, fv, zc, wp);
         } else {
-            if (planes_in_lds) MI_LAUNCH((k_cluster_walk<true, true>), grid, block, lds, stream, view, objs, w, fv, zc);
-            else MI_LAUNCH((k_cluster_walk<false, true>), grid, block, lds, stream, view, objs, w, fv, zc);
+            if (planes_in_lds) MI_LAUNCH((k_cluster_walk<true, true>), grid, block, lds, stream, vd, objs, w, fv, zc, wp);
+            else MI_LAUNCH((k_cluster_walk<false, true>), grid, block, lds, stream, vd, objs, w, fv, zc, wp);
         }
     }
     if (!fill) return hipGetLastError();

@@ -184,12 +184,13 @@ __device__ __forceinline__ bool view_visibility_tail(const Columns& c, uint32_t 
 // its centre is the row's GlobalTransform translation (assign.rs:198: `translation`, in hand), and it passes the two early-outs of
 // the per-object loop (assign.rs:489 RenderLayers, :496 frustum against the light's sphere).  Every thread of the workgroup calls it.
 template <bool SPOTS>
-__device__ __forceinline__ void inrow_cluster_walk(const ClusterWalkJob& walk, uint32_t tile, uint32_t row, bool visible, V3 translation, uint32_t* arena) {
+__device__ __forceinline__ void inrow_cluster_walk(const ClusterWalkJob& walk, uint32_t tile, uint32_t row, bool visible, V3 translation, uint32_t* arena,
+                                                   const float* planes_arg) {
     const uint32_t bx = tile - walk.tile0;
     const ClusterObjects& o = walk.objs;
     const uint32_t obj = row - o.first_row;  // (wraps for the rows of the first tile that lie in front of the objects)
     const bool is_obj = row >= o.first_row && obj < o.n;
-    const WalkPrefetch pf = walk_prefetch<true>(walk.view);
+    const WalkPrefetch pf = walk_prefetch<true>(walk.view, planes_arg);
     float4 sphere = make_float4(translation.x, translation.y, translation.z, 0.f);
     bool in_view = false;
     if (is_obj) {
@@ -231,7 +232,8 @@ struct TimelineScope {
 #endif
 template <int WALK>
 __device__ __forceinline__ bool frame_riders(uint32_t n_tiles, const CompactFastArgs& prev, uint32_t prev_gx, uint32_t n_compact, uint32_t n_fill,
-                                             const ClusterFillJob& fill, const ClusterWalkJob& walk, const ViewSet& vs, uint32_t* lds_raw) {
+                                             const ClusterFillJob& fill, const ClusterWalkJob& walk, const ViewSet& vs, uint32_t* lds_raw,
+                                             const float* planes_arg = nullptr) {
     const uint32_t n_extra = gridDim.x - n_tiles;
     if (blockIdx.x >= n_extra) return false;
     const uint32_t id = blockIdx.x;
@@ -246,7 +248,7 @@ __device__ __forceinline__ bool frame_riders(uint32_t n_tiles, const CompactFast
     } else if constexpr (WALK != 0) {
         // this frame's light-cluster walk: independent of the rows below (it re-derives the lights' ViewVisibility itself)
         MI_TIMELINE(2);
-        cluster_walk_block<true, true, WALK == 2>(walk.view, walk.objs, walk.w, vs, walk.zc, id - n_compact - n_fill, lds_raw);
+        cluster_walk_block<true, true, WALK == 2>(walk.view, walk.objs, walk.w, vs, walk.zc, id - n_compact - n_fill, lds_raw, planes_arg);
     }
     return true;
 }
@@ -284,8 +286,12 @@ template <int PROP, bool INLINE_VIEWS, int WALK, bool MULTI>
 __device__ __forceinline__ void frame_workgroup(const Columns& c, const ViewSet& vs, const ViewParams* __restrict__ dviews, uint32_t n_views,
                                                 const VisibilityOut& out, const SegOut& seg, uint32_t fl_frame, uint32_t n_tiles,
                                                 const CompactFastArgs& prev, uint32_t prev_gx, uint32_t n_compact, uint32_t n_fill,
-                                                const ClusterFillJob& fill, const ClusterWalkJob& walk, const uint8_t* __restrict__ changed) {
+                                                const ClusterFillJob& fill, const ClusterWalkJob& walk, const uint8_t* __restrict__ changed,
+                                                uint32_t wp_offset = 0) {
     constexpr bool PROPAGATE = PROP == 1, PARTIAL = PROP == 2;
+    // the riding walk's plane table: the kernel's trailing argument (WalkPlanes, kernels.h), read where the walkers want it
+    const float* planes_arg = nullptr;
+    if constexpr (WALK != 0) planes_arg = &kernarg_late<float>(wp_offset);
     // 16 KB + 16 B: the four waves' GlobalTransform transpose buffers (12 KB) -- or, in a riding cluster-fill workgroup, the CSR
     // offsets of up to 4096 clusters and the four wave totals of their scan -- or the arena of a riding cluster-walk workgroup
     // 16 KB: the rows' transposes (4 waves x 3 KB), the compaction / fill riders' arena.  A launch that carries the cluster walk is
@@ -294,7 +300,7 @@ __device__ __forceinline__ void frame_workgroup(const Columns& c, const ViewSet&
     // 22.3 -> 21.7 us, profiles/r03_experiments.md)
     __shared__ __attribute__((aligned(16))) uint32_t lds_raw[(WALK ? FRAME_WALK_LDS_WORDS : FRAME_LDS_WORDS) + 4];
     float4 (*lds_g)[192] = reinterpret_cast<float4 (*)[192]>(lds_raw);
-    if (frame_riders<WALK>(n_tiles, prev, prev_gx, n_compact, n_fill, fill, walk, vs, lds_raw)) return;
+    if (frame_riders<WALK>(n_tiles, prev, prev_gx, n_compact, n_fill, fill, walk, vs, lds_raw, planes_arg)) return;
     MI_TIMELINE(3);
     const uint32_t n_extra = gridDim.x - n_tiles;
     uint32_t tile = blockIdx.x - n_extra;
@@ -532,16 +538,22 @@ __device__ __forceinline__ void frame_workgroup(const Columns& c, const ViewSet&
     if constexpr (WALK != 0) {
         // (reading the walk job here instead of at kernel entry -- kernarg_late, kernels.h: 14 -> 11 spilled SGPRs, no scratch -- made the
         // metric frame SLOWER, 21.1 -> 22.2 us: the walk's tail is a chain of round trips, and the job's scalar loads join it)
-        if (walk.inrow && tile - walk.tile0 < walk.n_blocks) inrow_cluster_walk<WALK == 2>(walk, tile, row, vv_now, g.t, lds_raw);  // (workgroup-uniform)
+        if (walk.inrow && tile - walk.tile0 < walk.n_blocks) inrow_cluster_walk<WALK == 2>(walk, tile, row, vv_now, g.t, lds_raw, planes_arg);  // (workgroup-uniform)
     }
 }
 
+// (the kernels' argument lists as structs: where the trailing WalkPlanes sits in the argument segment)
+struct FrameKernargs {
+    Columns c; ViewSet vs; const ViewParams* dviews; uint32_t n_views; VisibilityOut out; SegOut seg; uint32_t fl_frame, n_tiles;
+    CompactFastArgs prev; uint32_t prev_gx, n_compact, n_fill; ClusterFillJob fill; ClusterWalkJob walk; const uint8_t* changed; WalkPlanes wp;
+};
 template <int PROP, bool INLINE_VIEWS, int WALK>
 __global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const ViewParams* __restrict__ dviews,
                                                 uint32_t n_views, VisibilityOut out, SegOut seg, uint32_t fl_frame, uint32_t n_tiles,
                                                 CompactFastArgs prev, uint32_t prev_gx, uint32_t n_compact, uint32_t n_fill, ClusterFillJob fill,
-                                                ClusterWalkJob walk, const uint8_t* __restrict__ changed) {
-    frame_workgroup<PROP, INLINE_VIEWS, WALK, false>(c, vs, dviews, n_views, out, seg, fl_frame, n_tiles, prev, prev_gx, n_compact, n_fill, fill, walk, changed);
+                                                ClusterWalkJob walk, const uint8_t* __restrict__ changed, typename WalkPlanesArg<WALK>::type wp) {
+    frame_workgroup<PROP, INLINE_VIEWS, WALK, false>(c, vs, dviews, n_views, out, seg, fl_frame, n_tiles, prev, prev_gx, n_compact, n_fill, fill, walk, changed,
+                                                     (uint32_t)offsetof(FrameKernargs, wp));
 }
 // ... with 2 .. MULTI_MAX_VIEWS camera views: the pair pass (MULTI above).  A kernel name of its own, so that k_frame<...> keeps the
 // symbols the committed profiles and the bench's kernel filters know.
@@ -580,10 +592,12 @@ __device__ __forceinline__ void frame_sph_workgroup(const Columns& c, const View
                                                     const VisibilityOut& out, const SegOut& seg, uint32_t fl_frame, uint32_t n_tiles,
                                                     const CompactFastArgs& prev, uint32_t prev_gx, uint32_t n_compact, uint32_t n_fill,
                                                     const ClusterFillJob& fill, const ClusterWalkJob& walk, const uint8_t* __restrict__ changed,
-                                                    const SphereArgs& sa) {
+                                                    const SphereArgs& sa, uint32_t wp_offset = 0) {
     __shared__ __attribute__((aligned(16))) uint32_t lds_raw[(WALK ? FRAME_WALK_LDS_WORDS : FRAME_LDS_WORDS) + 4];  // (as in k_frame)
     float4 (*lds_g)[192] = reinterpret_cast<float4 (*)[192]>(lds_raw);
-    if (frame_riders<WALK>(n_tiles, prev, prev_gx, n_compact, n_fill, fill, walk, vs, lds_raw)) return;
+    const float* planes_arg = nullptr;  // (as in k_frame: the riding walk's plane table in the argument segment)
+    if constexpr (WALK != 0) planes_arg = &kernarg_late<float>(wp_offset);
+    if (frame_riders<WALK>(n_tiles, prev, prev_gx, n_compact, n_fill, fill, walk, vs, lds_raw, planes_arg)) return;
     if constexpr (MULTI) {  // the views' planes where a lane can index them (as in k_frame's MULTI): wave w writes view w's five
         const uint32_t u = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         if (u < n_views) {
@@ -823,17 +837,24 @@ __device__ __forceinline__ void frame_sph_workgroup(const Columns& c, const View
         if (walk.inrow && tile - walk.tile0 < walk.n_blocks) {  // (workgroup-uniform)
             // the row's GlobalTransform translation: the column as this launch leaves it (a PARTIAL frame's own stores included)
             const V3 t = live ? ld3(c.global, row * 4u + 3u) : V3{0.f, 0.f, 0.f};
-            inrow_cluster_walk<WALK == 2>(walk, tile, row, vv_now, t, lds_raw);
+            inrow_cluster_walk<WALK == 2>(walk, tile, row, vv_now, t, lds_raw, planes_arg);
         }
     }
 }
 
+struct FrameSphKernargs {
+    Columns c; ViewSet vs; const ViewParams* dviews; uint32_t n_views; VisibilityOut out; SegOut seg; uint32_t fl_frame, n_tiles;
+    CompactFastArgs prev; uint32_t prev_gx, n_compact, n_fill; ClusterFillJob fill; ClusterWalkJob walk; const uint8_t* changed; SphereArgs sa;
+    WalkPlanes wp;
+};
 template <bool PARTIAL, bool INLINE_VIEWS, int WALK>
 __global__ void __launch_bounds__(256) k_frame_sph(Columns c, ViewSet vs, const ViewParams* __restrict__ dviews, uint32_t n_views,
                                                     VisibilityOut out, SegOut seg, uint32_t fl_frame, uint32_t n_tiles, CompactFastArgs prev,
                                                     uint32_t prev_gx, uint32_t n_compact, uint32_t n_fill, ClusterFillJob fill,
-                                                    ClusterWalkJob walk, const uint8_t* __restrict__ changed, SphereArgs sa) {
-    frame_sph_workgroup<PARTIAL, INLINE_VIEWS, WALK, false>(c, vs, dviews, n_views, out, seg, fl_frame, n_tiles, prev, prev_gx, n_compact, n_fill, fill, walk, changed, sa);
+                                                    ClusterWalkJob walk, const uint8_t* __restrict__ changed, SphereArgs sa,
+                                                    typename WalkPlanesArg<WALK>::type wp) {
+    frame_sph_workgroup<PARTIAL, INLINE_VIEWS, WALK, false>(c, vs, dviews, n_views, out, seg, fl_frame, n_tiles, prev, prev_gx, n_compact, n_fill, fill, walk, changed, sa,
+                                                            (uint32_t)offsetof(FrameSphKernargs, wp));
 }
 // ... with 2 .. MULTI_MAX_VIEWS camera views: intersects_obb over the (row, view) pairs (MULTI above)
 template <bool PARTIAL>
@@ -1538,6 +1559,20 @@ hipError_t launch_upload_trs(const float* pinned_src, float* t, float* r, float*
 
 // prev != nullptr: the previous frame's deferred compaction rides in extra workgroups of this launch; fill != nullptr: so does the
 // fill of the previous frame's light-cluster assignment
+thread_local WalkPlanesHost g_walk_planes_host = {nullptr, 0};
+// The riding walk's plane table as a kernel argument: from the host copy the context left in g_walk_planes_host (consumed here); the
+// job's view then carries no table of its own.  Returns false (the staged copy stays) when there is none or it does not fit.
+static bool take_walk_planes(ClusterWalkJob* wj, WalkPlanes* wp) {
+    const WalkPlanesHost h = g_walk_planes_host;
+    g_walk_planes_host = WalkPlanesHost{nullptr, 0};
+#ifdef MI_EXP_STAGED_PLANES  // (A/B build: the walkers read the table from the pinned staging arena, as until round 5)
+    return false;
+#endif
+    if (!h.f || h.n == 0 || h.n > WALK_PLANES_MAX) return false;
+    for (uint32_t i = 0; i < h.n; ++i) wp->f[i] = h.f[i];
+    wj->view.x_planes = wj->view.y_planes = wj->view.z_planes = nullptr;
+    return true;
+}
 int g_multi_view_mode = 0;  // MI_MULTI_VIEW (read by mi_ctx_create): 0 = as described at k_frame's MULTI, 1 = never
 template <int PROP>
 static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views,
@@ -1568,13 +1603,17 @@ static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, co
         walk_blocks = wj.inrow ? 0u : wj.n_blocks;  // in-row: the row workgroups of the objects' tiles do it
     }
     const dim3 grid(n_tiles + prev_blocks + fill_blocks + walk_blocks);
+    WalkPlanes wp;  // (only the bytes take_walk_planes fills are read)
+    NoWalkPlanes nwp;
+    if (with_walk) take_walk_planes(&wj, &wp);
+    else g_walk_planes_host = WalkPlanesHost{nullptr, 0};
     // several camera views: intersects_obb over the (row, view) pairs that passed their sphere test (k_frame_pairs)
     bool multi = !with_walk && views_inline && n_views >= 2u && n_views <= MULTI_MAX_VIEWS && g_multi_view_mode != 1;
     for (uint32_t v = 0; v < n_views && multi; ++v) multi = !(views_inline->v[v].flags & VIEW_SHADOW);
 #ifdef MI_EXP_FORCE_WALK_VARIANT  // (experiment build: a launch without a walk takes the walk-carrying instantiation -- what that variant costs by itself)
     if (!with_walk && views_inline && n_views <= MAX_INLINE_VIEWS) {
         MI_LAUNCH((k_frame<PROP, true, 1>), grid, dim3(256), 0, stream, c, *views_inline, (const ViewParams*)nullptr, n_views, out, seg, flags,
-                  n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed);
+                  n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed, wp);
         return hipGetLastError();
     }
 #endif
@@ -1583,17 +1622,17 @@ static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, co
                   n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed);
     } else if (with_walk && wj.spots) {
         MI_LAUNCH((k_frame<PROP, true, 2>), grid, dim3(256), 0, stream, c, *views_inline, (const ViewParams*)nullptr, n_views, out, seg, flags,
-                  n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed);
+                  n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed, wp);
     } else if (with_walk) {
         MI_LAUNCH((k_frame<PROP, true, 1>), grid, dim3(256), 0, stream, c, *views_inline, (const ViewParams*)nullptr, n_views, out, seg, flags,
-                  n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed);
+                  n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed, wp);
     } else if (n_views <= MAX_INLINE_VIEWS && views_inline) {
         MI_LAUNCH((k_frame<PROP, true, 0>), grid, dim3(256), 0, stream, c, *views_inline, (const ViewParams*)nullptr, n_views, out, seg, flags,
-                  n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed);
+                  n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed, nwp);
     } else {
         ViewSet dummy = {};
         MI_LAUNCH((k_frame<PROP, false, 0>), grid, dim3(256), 0, stream, c, dummy, d_views, n_views, out, seg, flags, n_tiles, pa, prev_gx,
-                  prev_blocks, fill_blocks, fj, wj, changed);
+                  prev_blocks, fill_blocks, fj, wj, changed, nwp);
     }
     return hipGetLastError();
 }
@@ -1632,23 +1671,27 @@ hipError_t launch_frame_sph(const Columns& c, const ViewSet* views_inline, const
     ViewSet dummy = {};
     const ViewSet& vsr = inl ? *views_inline : dummy;
     const ViewParams* dv = inl ? nullptr : d_views;
-#define MI_SPH_LAUNCH(P, I, W) \
+    WalkPlanes wp;  // (as in launch_frame)
+    NoWalkPlanes nwp;
+    if (with_walk) take_walk_planes(&wj, &wp);
+    else g_walk_planes_host = WalkPlanesHost{nullptr, 0};
+#define MI_SPH_LAUNCH(P, I, W, PL) \
     MI_LAUNCH((k_frame_sph<P, I, W>), grid, dim3(256), 0, stream, c, vsr, dv, n_views, out, seg, flags, n_tiles, pa, prev_gx, prev_blocks, \
-              fill_blocks, fj, wj, changed, sa)
+              fill_blocks, fj, wj, changed, sa, PL)
     const bool pairs = !with_walk && inl && n_views >= 2u && n_views <= MULTI_MAX_VIEWS && g_multi_view_mode != 1;
     if (pairs) {
         if (changed) MI_LAUNCH((k_frame_sph_pairs<true>), grid, dim3(256), 0, stream, c, vsr, dv, n_views, out, seg, flags, n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed, sa);
         else MI_LAUNCH((k_frame_sph_pairs<false>), grid, dim3(256), 0, stream, c, vsr, dv, n_views, out, seg, flags, n_tiles, pa, prev_gx, prev_blocks, fill_blocks, fj, wj, changed, sa);
     } else if (changed) {
-        if (with_walk && wj.spots) MI_SPH_LAUNCH(true, true, 2);
-        else if (with_walk) MI_SPH_LAUNCH(true, true, 1);
-        else if (inl) MI_SPH_LAUNCH(true, true, 0);
-        else MI_SPH_LAUNCH(true, false, 0);
+        if (with_walk && wj.spots) MI_SPH_LAUNCH(true, true, 2, wp);
+        else if (with_walk) MI_SPH_LAUNCH(true, true, 1, wp);
+        else if (inl) MI_SPH_LAUNCH(true, true, 0, nwp);
+        else MI_SPH_LAUNCH(true, false, 0, nwp);
     } else {
-        if (with_walk && wj.spots) MI_SPH_LAUNCH(false, true, 2);
-        else if (with_walk) MI_SPH_LAUNCH(false, true, 1);
-        else if (inl) MI_SPH_LAUNCH(false, true, 0);
-        else MI_SPH_LAUNCH(false, false, 0);
+        if (with_walk && wj.spots) MI_SPH_LAUNCH(false, true, 2, wp);
+        else if (with_walk) MI_SPH_LAUNCH(false, true, 1, wp);
+        else if (inl) MI_SPH_LAUNCH(false, true, 0, nwp);
+        else MI_SPH_LAUNCH(false, false, 0, nwp);
     }
 #undef MI_SPH_LAUNCH
     return hipGetLastError();

@@ -644,7 +644,11 @@ inline size_t cluster_walk_lds_bytes(uint32_t dxy, uint32_t zc, uint32_t n_plane
 // 5 workgroups per CU for its registers) the 31 KB five workgroups leave each other
 constexpr uint32_t FRAME_LDS_WORDS = 4096u, FRAME_WALK_LDS_WORDS = 7936u;
 constexpr size_t FRAME_KERNEL_LDS_BYTES = (FRAME_WALK_LDS_WORDS + 4) * 4;  // the riding walk's arena
+#ifdef MI_EXP_FILL_RIDE_BLOCKS
+constexpr uint32_t CLUSTER_FILL_RIDE_BLOCKS = MI_EXP_FILL_RIDE_BLOCKS;  // (A/B builds)
+#else
 constexpr uint32_t CLUSTER_FILL_RIDE_BLOCKS = 128;  // workgroups a riding fill adds to the frame kernel's grid
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Batching work-item build (kernels_batch.hip).

@@ -190,6 +190,8 @@ __device__ __forceinline__ void inrow_cluster_walk(const ClusterWalkJob& walk, u
     const ClusterObjects& o = walk.objs;
     const uint32_t obj = row - o.first_row;  // (wraps for the rows of the first tile that lie in front of the objects)
     const bool is_obj = row >= o.first_row && obj < o.n;
+    // (a tile none of whose lights is visible leaving here, in front of the table's and the objects' loads: no different, 20.30 against
+    // 20.24 us per frame -- with the table in the argument segment the prologue no longer waits for anything far away)
     const WalkPrefetch pf = walk_prefetch<true>(walk.view, planes_arg);
     float4 sphere = make_float4(translation.x, translation.y, translation.z, 0.f);
     bool in_view = false;

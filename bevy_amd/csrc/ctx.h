@@ -350,9 +350,12 @@ struct mi_ctx {
     DevBuf cl_row_list;              // mi_cluster_bind_objects_to_row_list: the rows, in object order
     bool cl_rows_listed = false;
     std::vector<float> cl_host_planes, cl_host_spheres;  // storage of the view mi_cluster_assign_frame builds
-    // The view's cluster planes are read by the kernels straight from the pinned staging arena (mapped host memory): the z
-    // planes follow the camera's scale by an ulp from frame to frame, and a device copy would put an H2D blit (~6 us) in front
-    // of every frame.  cl_planes_host is the current table, cl_planes_epoch the arena epoch its staged copy belongs to.
+    // The view's cluster planes: the z planes follow the camera's scale by an ulp from frame to frame, and a device copy would put
+    // an H2D blit (~6 us) in front of every frame.  Tables of up to WALK_PLANES_MAX floats (16 x 9 x 24: 208) travel as a trailing
+    // kernel argument of the launch that walks (WalkPlanes, kernels.h: the argument segment is device memory); bigger ones are read
+    // from the pinned staging arena (mapped host memory, a trip over PCIe per walking workgroup -- which is what every table did
+    // until round 5, 1.1 us of the metric frame).  cl_planes_host is the current table, cl_planes_epoch the arena epoch its
+    // staged copy belongs to.
     std::vector<float> cl_planes_host, cl_spheres_sent;
     uint64_t cl_planes_epoch = ~0ull;
     uint32_t cl_plane_counts[3] = {0, 0, 0};

@@ -222,7 +222,8 @@ int32_t mi_cluster_upload_view(mi_ctx* ctx, const mi_cluster_view* view) {
     int32_t rc;
     // The cluster planes live in VIEW space: they depend on the projection, the grid and near / far -- but near follows the
     // camera's scale (assign.rs:345,366), which moves by an ulp as the camera turns, so the table is new nearly every frame.
-    // It is staged in pinned memory and read from there (see ctx.h); stage_cluster_planes re-stages it when the arena wraps.
+    // It travels as a kernel argument, or -- big tables -- is staged in pinned memory and read from there (see ctx.h);
+    // stage_cluster_planes re-stages it when the arena wraps.
     ctx->cl_planes_host.resize((size_t)(nx + ny + nz) * 4);
     memcpy(ctx->cl_planes_host.data(), view->x_planes, (size_t)nx * 16);
     memcpy(ctx->cl_planes_host.data() + 4 * (size_t)nx, view->y_planes, (size_t)ny * 16);

@@ -117,3 +117,15 @@ def test_bench_modules_keep_the_oracle_out_of_the_timed_path():
         if name.endswith(".py") and name != "cpu_baseline.py":
             assert "oracle_lib" not in open(os.path.join(ROOT, "benchlib", name)).read(), name
     assert "oracle_lib" not in open(os.path.join(ROOT, "bench.py")).read()
+
+
+def test_a_frame_of_several_launches_is_priced_per_frame():
+    """benchlib.wl_tree.reprice_per_frame: `roofline` divides the frame's bytes by ONE launch's average -- four launches of 7.5 us read
+    0.61 where the frame reaches 0.15."""
+    from benchlib.wl_tree import reprice_per_frame
+    per_launch = {"achieved": 4847.7, "frac": 0.606, "frac_algorithmic": 0.606, "avg_kernel_us": 7.476, "rocprof_frac": 0.57}
+    frame = {"launches_per_frame": 4.0, "achieved": 1211.9, "frac": 0.1515, "kernels_us_per_frame": 29.9}
+    r = reprice_per_frame(per_launch, frame)
+    assert r["frac"] == 0.1515 and r["frac_algorithmic"] == 0.1515 and r["achieved"] == 1211.9 and r["avg_kernel_us"] == 29.9
+    assert r["per_launch_avg_kernel_us"] == 7.476 and r["launches_per_frame"] == 4.0 and "rocprof_frac" not in r
+    assert reprice_per_frame(per_launch, {"launches_per_frame": 1.0}) == per_launch and per_launch["frac"] == 0.606  # (one launch: untouched)

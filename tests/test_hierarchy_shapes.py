@@ -107,3 +107,20 @@ def test_oracle_propagates_the_shapes(name):
         rows = np.arange(int(lo), int(hi))
         below[rows] |= below[sh["parent"][rows]]
     assert not (differs & ~below).any() and differs.sum() > 0.5 * below.sum()
+
+
+@pytest.mark.parametrize("name", list(W.NARROW_SHAPES))
+def test_narrow_shapes_are_what_the_one_wave_kernel_takes(name):
+    """bevy_amd.workloads.NARROW_SHAPES (not the reference's): every level at most a wave wide, more levels than a tile spans; level
+    order as the library computes it; the oracle propagates them like any hierarchy."""
+    sh = W.hierarchy_shape(name)
+    widths = np.diff(sh["level_offsets"].astype(np.int64))
+    assert widths.max() <= 64 and sh["n_levels"] > 16 and widths.min() >= 1
+    n2o_lib, p_lib, offs_lib = api.hierarchy_sort(sh["parent"].astype(np.uint32))
+    assert np.array_equal(n2o_lib, np.arange(sh["n"])) and np.array_equal(p_lib, sh["parent"]) and np.array_equal(offs_lib, sh["level_offsets"])
+    rc, g, chg = O.propagate_transforms(sh["parent"], sh["translation"], sh["rotation"], sh["scale"])
+    assert rc == 0 and chg.all()
+    if name.startswith("bundle"):  # chains side by side: every parent sits where its child does
+        lo = sh["level_offsets"].astype(np.int64)
+        for l in range(2, sh["n_levels"]):
+            assert np.array_equal(sh["parent"][lo[l]:lo[l + 1]].astype(np.int64) - lo[l - 1], np.arange(lo[l + 1] - lo[l]))

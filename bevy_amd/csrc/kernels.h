@@ -174,6 +174,12 @@ struct SegOut {
 // mi_cull / mi_propagate_and_cull flags (MI_CULL_* in the public header)
 constexpr uint32_t CULL_BEGIN_FRAME = 1u;  // fuse reset_view_visibility
 constexpr uint32_t CULL_END_FRAME = 2u;    // fuse check_visibility_gpu_culling + mark_newly_hidden_entities_invisible
+// (launch-internal) the Transform columns are fetched with nontemporal loads: set by the launcher for contexts whose frame does not
+// fit the 256 MiB Infinity Cache by a wide margin (10 M rows x 1 view: 150 -> 132 us, x 4 views 179 -> 173; 8 M: 120 -> 107; 7 M:
+// 98.9 -> 94.8).  Below that the columns of frame f are still (partly) cached when frame f + 1 reads them, and fetching them past
+// the caches costs: 5 M rows x 4 views 83 -> 87.5 us, the 1.11 M-row metric frame 19.3 -> 22.6 (profiles/r05a/nt_loads_ab.txt)
+constexpr uint32_t CULL_NT_LOADS = 0x100u;
+constexpr uint32_t NT_LOADS_MIN_ROWS = 6u << 20;
 
 enum KernelId : uint32_t {
     K_FLAT_PROPAGATE_CULL = 0,

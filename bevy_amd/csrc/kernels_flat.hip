@@ -342,9 +342,18 @@ __device__ __forceinline__ void frame_workgroup(const Columns& c, const ViewSet&
     V3 t_in = {}, s_in = {};
     V4 q_in = {};
     if (PROPAGATE && live) {
-        t_in = ld3(c.translation, row);
-        q_in = ld4(c.rotation, row);
-        s_in = ld3(c.scale, row);
+        if (fl_frame & CULL_NT_LOADS) {  // (launch-uniform: a big context, kernels.h)
+            const float* tp = c.translation + 3ull * row;
+            const float* sp3 = c.scale + 3ull * row;
+            const v4f qv = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(c.rotation) + row);
+            t_in = V3{__builtin_nontemporal_load(tp), __builtin_nontemporal_load(tp + 1), __builtin_nontemporal_load(tp + 2)};
+            q_in = V4{qv.x, qv.y, qv.z, qv.w};
+            s_in = V3{__builtin_nontemporal_load(sp3), __builtin_nontemporal_load(sp3 + 1), __builtin_nontemporal_load(sp3 + 2)};
+        } else {
+            t_in = ld3(c.translation, row);
+            q_in = ld4(c.rotation, row);
+            s_in = ld3(c.scale, row);
+        }
     }
     if (live) {
         vv0 = c.view_visibility[row];
@@ -1609,6 +1618,9 @@ static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, co
     NoWalkPlanes nwp;
     if (with_walk) take_walk_planes(&wj, &wp);
     else g_walk_planes_host = WalkPlanesHost{nullptr, 0};
+#ifndef MI_EXP_NO_NT_LOADS  // (A/B build without)
+    if (PROP == 1 && c.n >= NT_LOADS_MIN_ROWS) flags |= CULL_NT_LOADS;
+#endif
     // several camera views: intersects_obb over the (row, view) pairs that passed their sphere test (k_frame_pairs)
     bool multi = !with_walk && views_inline && n_views >= 2u && n_views <= MULTI_MAX_VIEWS && g_multi_view_mode != 1;
     for (uint32_t v = 0; v < n_views && multi; ++v) multi = !(views_inline->v[v].flags & VIEW_SHADOW);

@@ -591,6 +591,26 @@ def test_device_logf_matches_libm(ctx_factory):
 
 # ---- BASELINE-size run -------------------------------------------------------------------------
 
+def test_big_context_fetches_transforms_past_the_caches(ctx_factory):
+    """From 6 Mi rows on the fused frame reads the Transform columns with nontemporal loads (CULL_NT_LOADS, kernels.h): the same frame
+    row for row against the oracle just above the threshold, ragged flags and a ragged last wave."""
+    n = (6 << 20) + 77
+    sc = W.many_cubes(n, radius=700.0, ragged_flags=True)
+    frusta = frusta_for([W.many_cubes_camera(2), W.many_cubes_camera(4, yaw=2.0)])
+    vmasks = np.array([1, 3], np.uint32)
+    ctx = ctx_factory()
+    upload_scene(ctx, sc)
+    ctx.propagate_and_cull(frusta, vmasks)
+    ctx.visibility_end_frame()
+    g_exp, vv_exp, vis_exp, chg_exp = oracle_frame(sc, np.zeros(n, np.uint8), frusta, vmasks, None)
+    assert ctx.download_global_transforms(want_changed=False).tobytes() == g_exp.tobytes()
+    for v in range(2):
+        assert_bits(ctx.download_visibility(v), vis_exp[v], f"view {v} @6 Mi")
+    vv, vv_chg = ctx.download_view_visibility()
+    assert_bits(vv, vv_exp, "ViewVisibility bytes @6 Mi")
+    ctx.resize(0)  # (give the columns back: the module's contexts live until its end)
+
+
 def test_one_million_flat_entities(ctx_factory):
     """configs[1]: 1M flat entities, 1 frustum -- compared row-for-row with the oracle (a few seconds of CPU)."""
     n = 1_000_000

@@ -45,6 +45,8 @@ for wl in $WLS; do
   done
 done
 # the fused hierarchy frame is bound by vector-instruction issue: its SQ counters next to the plain tile launch's (tools/tree_pmc.sh)
+case " $WLS " in *" tree_frame "*)
 bash tools/tree_pmc.sh 0 "--tree-cull" SQ > $P/tree_frame_sq_counters.txt 2>&1; rm -rf $P/tree_frame_sq; mv gpurun_out/tree_pmc $P/tree_frame_sq
-bash tools/tree_pmc.sh 0 "" SQ > $P/tree_sq_counters.txt 2>&1; rm -rf $P/tree_sq; mv gpurun_out/tree_pmc $P/tree_sq
+bash tools/tree_pmc.sh 0 "" SQ > $P/tree_sq_counters.txt 2>&1; rm -rf $P/tree_sq; mv gpurun_out/tree_pmc $P/tree_sq ;;
+esac
 python tools/summarize_profiles.py $TAG $WLS

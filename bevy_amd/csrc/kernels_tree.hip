@@ -172,6 +172,10 @@ __device__ __forceinline__ TileDesc load_tile_desc(const TileDesc* p) {
     return d;
 }
 
+// A hierarchy whose frame (141 B per node) does not fit the 256 MiB Infinity Cache by a wide margin fetches the streamed level's
+// Transforms and old GlobalTransforms past the caches: 5.6 M nodes 155.8 -> 135.7 us per launch; the 1 M-node tree, whose columns the
+// next frame still finds cached, 24.6 -> 28.1 the other way (profiles/r05a/nt_loads_ab.txt).
+constexpr uint32_t TREE_NT_MIN_ROWS = 4u << 20;
 struct TreeArgs {
     const uint32_t* parent_idx;
     const TileDesc* tiles;
@@ -190,7 +194,8 @@ struct TreeArgs {
     uint32_t all_dirty;
     uint32_t static_opt;
     uint32_t changed_gen;  // generation of the change column's stamps (row_changed(), kernels.h)
-    uint32_t pretest;  // light tiles under the static-scene rule: test the tile's flags before asking for anything else (few rows changed)
+    uint32_t pretest;  // bit 0: light tiles under the static-scene rule test the tile's flags before asking for anything else (few rows changed);
+                       // bit 1: the streamed level's inputs are fetched with nontemporal loads (a hierarchy of >= TREE_NT_MIN_ROWS rows)
     unsigned long long* trace;  // debug: 8 x s_memrealtime per tile (mi_debug_tree_trace), nullptr = off
 };
 
@@ -587,7 +592,7 @@ __global__ void __launch_bounds__(256, CULL ? 7 : ALL_DIRTY ? 8 : 7) k_propagate
     // and the marks of the top rows answer that: <= 24 + 112 bytes.  A tile that fails the test goes on as before (the test is a
     // superset of the exact rule evaluated after the chain), one round trip later: the host asks for it only when few rows changed.
     if constexpr (!ALL_DIRTY) {
-        if (a.pretest && a.static_opt && (chain_len || ROOTS) && n_lds && (!snap_out || td.start[0] >= a.snap_rows)) {
+        if ((a.pretest & 1u) && a.static_opt && (chain_len || ROOTS) && n_lds && (!snap_out || td.start[0] >= a.snap_rows)) {
             bool hot = false;
             if (chain_lane && tid - FAN_CHAIN_LANE0 < chain_len) hot = row_changed(at32<uint8_t>(a.changed, chain_row), a.changed_gen);
             if (tid < td.count[0]) {
@@ -722,8 +727,23 @@ __global__ void __launch_bounds__(256, CULL ? 7 : ALL_DIRTY ? 8 : 7) k_propagate
     FAN_STAMP(3);
     // the last level's own inputs: requested here, they travel under the level steps (whose barriers order LDS only)
     const uint32_t f_p = at32<uint32_t>(a.parent_idx, s_row * 4u);
-    const V3 f_s = ld3_32(c.scale, s_row), f_t = ld3_32(c.translation, s_row);
-    const V4 f_q = ld4_32(c.rotation, s_row);
+    // (a hierarchy too big for the Infinity Cache: the streamed level's inputs past the caches -- launch-uniform, TreeArgs::pretest bit 1)
+    typedef float v4f_t __attribute__((ext_vector_type(4)));
+    const bool nt = (a.pretest & 2u) != 0;
+    V3 f_s, f_t;
+    V4 f_q;
+    if (nt) {
+        const float* sp_ = &at32<float>(c.scale, s_row * 12u);
+        const float* tp_ = &at32<float>(c.translation, s_row * 12u);
+        f_s = V3{__builtin_nontemporal_load(sp_), __builtin_nontemporal_load(sp_ + 1), __builtin_nontemporal_load(sp_ + 2)};
+        f_t = V3{__builtin_nontemporal_load(tp_), __builtin_nontemporal_load(tp_ + 1), __builtin_nontemporal_load(tp_ + 2)};
+        const v4f_t fq_ = __builtin_nontemporal_load(&at32<v4f_t>(c.rotation, s_row * 16u));
+        f_q = V4{fq_.x, fq_.y, fq_.z, fq_.w};
+    } else {
+        f_s = ld3_32(c.scale, s_row);
+        f_t = ld3_32(c.translation, s_row);
+        f_q = ld4_32(c.rotation, s_row);
+    }
     const NodeRaw f_raw = node_raw<ALL_DIRTY>(a, s_row, s_root_level);
     // ---- LDS-resident levels: four lanes per row.  A thread's rows are fixed before the loop -- slot tid / 4 and, for tiles with
     // more than 64 upper rows, slot 64 + tid / 4 (TILE_LIGHT_UCAP <= 128) -- and everything about them that no other row's
@@ -783,9 +803,19 @@ __global__ void __launch_bounds__(256, CULL ? 7 : ALL_DIRTY ? 8 : 7) k_propagate
     // occupied until the level steps had read them
     bool flush_live = false;
     if (n_lds) flush_live = __syncthreads_or(any_chg ? 1 : 0) != 0;  // (in front of the loads: the barrier drains the load counter)
-    const float4 f_g0 = at32<float4>(c.global, g_off + (lane < last0 ? lane : last0) * 16u);
-    const float4 f_g1 = at32<float4>(c.global, g_off + (64u + lane < last0 ? 64u + lane : last0) * 16u);
-    const float4 f_g2 = at32<float4>(c.global, g_off + (128u + lane < last0 ? 128u + lane : last0) * 16u);
+    float4 f_g0, f_g1, f_g2;
+    if (nt) {
+        const v4f_t g0_ = __builtin_nontemporal_load(&at32<v4f_t>(c.global, g_off + (lane < last0 ? lane : last0) * 16u));
+        const v4f_t g1_ = __builtin_nontemporal_load(&at32<v4f_t>(c.global, g_off + (64u + lane < last0 ? 64u + lane : last0) * 16u));
+        const v4f_t g2_ = __builtin_nontemporal_load(&at32<v4f_t>(c.global, g_off + (128u + lane < last0 ? 128u + lane : last0) * 16u));
+        f_g0 = make_float4(g0_.x, g0_.y, g0_.z, g0_.w);
+        f_g1 = make_float4(g1_.x, g1_.y, g1_.z, g1_.w);
+        f_g2 = make_float4(g2_.x, g2_.y, g2_.z, g2_.w);
+    } else {
+        f_g0 = at32<float4>(c.global, g_off + (lane < last0 ? lane : last0) * 16u);
+        f_g1 = at32<float4>(c.global, g_off + (64u + lane < last0 ? 64u + lane : last0) * 16u);
+        f_g2 = at32<float4>(c.global, g_off + (128u + lane < last0 ? 128u + lane : last0) * 16u);
+    }
     if (n_lds) {
         if (tid < U) at32w<uint8_t>(a.g_changed_bytes, lds_row[tid]) = lds_chg[tid];
         if (flush_live || snap_out) {
@@ -1284,7 +1314,7 @@ hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, 
                                   bool static_opt, hipStream_t stream, unsigned long long* trace, bool pretest, const TreeCull* cull, bool deep) {
     if (n_tiles == 0) return hipSuccess;
     TreeArgs a;
-    a.pretest = pretest && changed && tree_bytes ? 1u : 0u;
+    a.pretest = (pretest && changed && tree_bytes ? 1u : 0u) | (c.n >= TREE_NT_MIN_ROWS ? 2u : 0u);
     a.changed_gen = c.changed_gen;
     a.snap_read = snap_read;
     a.snap_write = snap_write;

@@ -23,7 +23,7 @@ PINNED = {
         "mi::k_frame_cells<true>": (64, 8, 32, 0),
     },
     "kernels_tree.hip": {
-        "mi::k_propagate_fans<true, false, 8u>": (64, 8, 0, 0),     # the 8-level tiles: what every shape but the deep narrow bands runs
+        "mi::k_propagate_fans<true, false, 8u>": (64, 8, 8, 0),     # the 8-level tiles: what every shape but the deep narrow bands runs
         "mi::k_propagate_fans<true, true, 8u>": (72, 7, 80, 0),
         "mi::k_propagate_fans<true, false, 16u>": (64, 8, 32, 0),   # 16-level tiles (bands <= 64 rows wide, or down to level 0)
         "mi::k_propagate_narrow<true, true>": (128, 1, 0, 0),       # one wave per hierarchy: no spills is all that matters

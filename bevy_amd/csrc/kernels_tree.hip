@@ -877,7 +877,11 @@ __global__ void __launch_bounds__(256, CULL ? 7 : ALL_DIRTY ? 8 : 7) k_propagate
 #pragma unroll
             for (uint32_t k = 0; k < 3u; ++k) {
                 const uint32_t j = k * 64u + lane;
-                if (j < wave_lim) at32w<float4>(c.global, doff + j * 16u) = stage[j];
+                if (j < wave_lim) {
+                    const float4 v = stage[j];
+                    if (nt) __builtin_nontemporal_store(v4f_t{v.x, v.y, v.z, v.w}, &at32w<v4f_t>(c.global, doff + j * 16u));  // (big hierarchies: nobody finds it cached)
+                    else at32w<float4>(c.global, doff + j * 16u) = v;
+                }
             }
         } else if (chg) {
             st_affine(c.global, row, cur);

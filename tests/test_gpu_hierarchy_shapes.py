@@ -154,6 +154,35 @@ def test_reference_hierarchy_shape_with_plain_transforms():
         run_shape(W.hierarchy_shape(name, plain_transforms=True), True)
 
 
+def test_true_depth_12_tree_movers_under_the_static_scene_rule():
+    """The 5.6 M-node tree is past TREE_NT_MIN_ROWS (kernels_tree.hip): the tile kernel's streamed level goes past the caches.  The
+    change-driven instantiation on it: half the nodes move, StaticTransformOptimizations on."""
+    sh = W.hierarchy_shape("tree_4ary_depth12")
+    n = sh["n"]
+    flags = B.PROPAGATE_STATIC_OPT
+    with api.Context(0) as ctx:
+        ctx.resize(n)
+        ctx.upload_transforms(sh["translation"], sh["rotation"], sh["scale"])
+        ctx.upload_hierarchy(sh["parent"], sh["level_offsets"])
+        ctx.propagate(B.PROPAGATE_ALL_DIRTY | flags)
+        rc, g_exp, _ = O.propagate_transforms(sh["parent"], sh["translation"], sh["rotation"], sh["scale"], static_opt=True)
+        assert rc == 0
+        t = sh["translation"].copy().reshape(n, 3)
+        mt = sh["mover_translation"](1)
+        t[sh["movers"]] = mt.reshape(-1, 3)
+        ctx.upload_transforms_indexed(sh["movers"], mt, np.ascontiguousarray(sh["rotation"].reshape(n, 4)[sh["movers"]]).reshape(-1),
+                                      np.ascontiguousarray(sh["scale"].reshape(n, 3)[sh["movers"]]).reshape(-1))
+        ctx.propagate(flags)
+        g, chg = ctx.download_global_transforms()
+    changed = np.zeros(n, np.uint8)
+    changed[sh["movers"]] = 1
+    rc, g_exp, chg_exp = O.propagate_transforms(sh["parent"], t.reshape(-1), sh["rotation"], sh["scale"], global_in=g_exp, static_opt=True,
+                                                tree_changed=O.mark_dirty_trees(sh["parent"], changed), transform_changed=changed)
+    assert rc == 0
+    assert_rows(g, g_exp, "depth 12, movers")
+    assert_bits(chg, chg_exp, "depth 12, movers: change ticks")
+
+
 def test_true_depth_12_tree_all_dirty():
     """gen_tree(12, 4) in full: 5 592 405 nodes, all dirty."""
     sh = W.hierarchy_shape("tree_4ary_depth12")

@@ -762,7 +762,13 @@ __device__ __forceinline__ void frame_sph_workgroup(const Columns& c, const View
 #pragma unroll
             for (uint32_t k = 0; k < 3u; ++k) {
                 const uint32_t i = k * 64u + lane;
-                lds_wave[i] = src[i < lim ? i : lim - 1u];
+                const float4* pp = src + (i < lim ? i : lim - 1u);
+                if (fl_frame & CULL_NT_LOADS) {  // (a big static context: the survivors' GlobalTransforms are read once per frame, past the caches)
+                    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(pp));
+                    lds_wave[i] = make_float4(v.x, v.y, v.z, v.w);
+                } else {
+                    lds_wave[i] = *pp;
+                }
             }
             MI_WAVE_LDS_SYNC();
             const float4 a = lds_wave[lane * 3u], b = lds_wave[lane * 3u + 1u], cc = lds_wave[lane * 3u + 2u];
@@ -1689,6 +1695,9 @@ hipError_t launch_frame_sph(const Columns& c, const ViewSet* views_inline, const
     NoWalkPlanes nwp;
     if (with_walk) take_walk_planes(&wj, &wp);
     else g_walk_planes_host = WalkPlanesHost{nullptr, 0};
+#ifndef MI_EXP_NO_SPH_NT
+    if (c.n >= NT_LOADS_MIN_ROWS) flags |= CULL_NT_LOADS;  // (the dense fetch of the survivors' GlobalTransforms)
+#endif
 #define MI_SPH_LAUNCH(P, I, W, PL) \
     MI_LAUNCH((k_frame_sph<P, I, W>), grid, dim3(256), 0, stream, c, vsr, dv, n_views, out, seg, flags, n_tiles, pa, prev_gx, prev_blocks, \
               fill_blocks, fj, wj, changed, sa, PL)

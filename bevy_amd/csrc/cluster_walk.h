@@ -569,6 +569,19 @@ __device__ __forceinline__ void cluster_walk_tail(const ClusterViewDev& v, const
         // slots with a single atomic -- so the fill can spread pairs evenly over the chip no matter how unevenly the objects
         // are distributed.  Only non-empty entries of the (cluster, block) count matrix are written.
         const uint32_t nt = *n_touched;
+        // the kinds of object this block holds among its objects in view: one (the rule) or several
+        uint32_t single_type = 6u;
+        {
+            uint32_t kinds = 0u;
+#pragma unroll
+            for (uint32_t t = 0; t < 6; ++t) {
+                uint32_t any_t = 0u;
+#pragma unroll
+                for (uint32_t k = 0; k < 8; ++k) any_t |= type_rows[t * 8u + k];
+                kinds |= (any_t ? 1u : 0u) << t;
+            }
+            if (__popc(kinds) == 1u) single_type = (uint32_t)__ffs((int)kinds) - 1u;
+        }
         if (threadIdx.x == 0) {
             if (z_range[3]) {  // (all waves' LDS atomics lie behind the barrier above; sent once, with the first chunk's reservation)
                 atomicMax(reinterpret_cast<unsigned int*>(w.farthest_z), z_range[3]);
@@ -582,30 +595,53 @@ __device__ __forceinline__ void cluster_walk_tail(const ClusterViewDev& v, const
         for (uint32_t i = threadIdx.x; i < nt; i += CLUSTER_BLOCK) {
             const uint32_t r = touched_list[i];
             const uint32_t c = CHUNKED ? (r / zc) * dz + z0 + (r % zc) : r;
-            const uint4 lo = reinterpret_cast<const uint4*>(rows)[r * 2u], hi = reinterpret_cast<const uint4*>(rows)[r * 2u + 1u];
-            const uint32_t m[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            // the row's 256-bit mask goes out half by half: this loop is the register peak of every kernel that carries the walk
+            const uint32_t slot = pair_base + i;
             uint32_t cnt = 0;
-#pragma unroll
-            for (uint32_t k = 0; k < 8; ++k) cnt += __popc(m[k]);
+            {
+                const uint4 lo = reinterpret_cast<const uint4*>(rows)[r * 2u];
+                cnt += __popc(lo.x) + __popc(lo.y) + __popc(lo.z) + __popc(lo.w);
+                reinterpret_cast<uint4*>(w.pair_mask)[(size_t)slot * 2u] = lo;
+            }
+            {
+                const uint4 hi = reinterpret_cast<const uint4*>(rows)[r * 2u + 1u];
+                cnt += __popc(hi.x) + __popc(hi.y) + __popc(hi.z) + __popc(hi.w);
+                reinterpret_cast<uint4*>(w.pair_mask)[(size_t)slot * 2u + 1u] = hi;
+            }
+            w.pair_cb[slot] = (bx << 12) | c;
             w.block_counts[(size_t)c * w.row_stride + bx] = (uint16_t)cnt;  // cluster-major
             atomicAdd(&w.totals[c], cnt);
-            // (The compiler hoists the 48 type-mask words out of this loop into registers: they are the register peak of the walk,
-            // 88 VGPRs.  Reading them per row instead brings the walk to 63 and the frame kernel that carries it from 5 to 7 waves
-            // per SIMD -- and measured SLOWER, twice: metric frame 26.3 against 24.8 us, walk kernel 17.1 against 15.2 (profiles/r03b); with
-            // the row summary 24.6 against 22.3 (profiles/r03_experiments.md).  The
-            // walk is a chain of dependent round trips, not a throughput problem: with the high-water mark at 88 the scheduler
-            // spends registers on overlapping the loads of the whole kernel; at 63 it schedules for occupancy nobody needs.)
+            // The per-type counts (ClusterableObjectCounts, assign.rs:741-800).  Until round 5 the six 256-bit type masks were and-ed
+            // with the row here; the compiler hoisted their 48 words out of this loop into registers, which made the walk 88 VGPRs
+            // and -- with its 31 KB arena -- held every launch that carries it to 5 waves per SIMD: the ROWS of the metric frame paid
+            // for that (the same rows through the lean kernel 16.9 us, through the walk-carrying one with nothing to walk 19.4;
+            // profiles/r06_experiments.md).  Almost every block holds objects of ONE kind (lights are spawned together): then the
+            // row's population is that kind's count and the masks are never read; mixed blocks read row and masks from LDS word by
+            // word.  72 VGPRs and a 22 KB arena: 7 waves per SIMD.
+#ifdef MI_EXP_TYPE_ROWS_HOISTED  // (A/B build: as until round 5)
+            {
+                const uint4 lo = reinterpret_cast<const uint4*>(rows)[r * 2u], hi = reinterpret_cast<const uint4*>(rows)[r * 2u + 1u];
+                const uint32_t m[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-            for (uint32_t t = 0; t < 6; ++t) {
-                uint32_t tc = 0;
+                for (uint32_t t = 0; t < 6; ++t) {
+                    uint32_t tc = 0;
 #pragma unroll
-                for (uint32_t k = 0; k < 8; ++k) tc += __popc(m[k] & type_rows[t * 8u + k]);
-                if (tc) atomicAdd(&w.counts[6u * c + t], tc);
+                    for (uint32_t k = 0; k < 8; ++k) tc += __popc(m[k] & type_rows[t * 8u + k]);
+                    if (tc) atomicAdd(&w.counts[6u * c + t], tc);
+                }
             }
-            const uint32_t slot = pair_base + i;
-            w.pair_cb[slot] = (bx << 12) | c;
-            reinterpret_cast<uint4*>(w.pair_mask)[(size_t)slot * 2u] = lo;
-            reinterpret_cast<uint4*>(w.pair_mask)[(size_t)slot * 2u + 1u] = hi;
+#else
+            if (single_type < 6u) {  // (workgroup-uniform)
+                atomicAdd(&w.counts[6u * c + single_type], cnt);
+            } else {
+                for (uint32_t t = 0; t < 6; ++t) {
+                    uint32_t tc = 0;
+#pragma nounroll
+                    for (uint32_t k = 0; k < 8; ++k) tc += __popc(rows[r * 8u + k] & type_rows[t * 8u + k]);
+                    if (tc) atomicAdd(&w.counts[6u * c + t], tc);
+                }
+            }
+#endif
         }
         MI_WALK_MARK(bx, 4);
 #ifdef MI_EXP_TIMELINE

@@ -646,9 +646,19 @@ inline size_t cluster_walk_lds_bytes(uint32_t dxy, uint32_t zc, uint32_t n_plane
     const size_t RC = (size_t)dxy * zc;
     return (RC * 8u + 48u) * sizeof(uint32_t) + 256u /* logf table */ + (planes_in_lds ? (size_t)n_planes * 16u : 0u) + ((RC + 31u) / 32u + 5u) * 4u + RC * 2u + 16u;
 }
-// k_frame's static LDS (words): what its riders get as their arena -- the compaction and the fill 16 KB, the walk (whose launches run
-// 5 workgroups per CU for its registers) the 31 KB five workgroups leave each other
-constexpr uint32_t FRAME_LDS_WORDS = 4096u, FRAME_WALK_LDS_WORDS = 7936u;
+// k_frame's static LDS (words): what its riders get as their arena -- the compaction and the fill 16 KB, the walk 22 KB (seven
+// workgroups per CU; until round 5: 31 KB and five)
+// (round 6: 22 KB and 7 waves per SIMD -- FRAME_WALK_WAVES, the launch bound of the kernels that carry the walk without spot lights --
+// instead of 31 KB and 5: the arena holds 3 - 4 z slices of a 16 x 9 grid per chunk instead of 5 - 6, and the rows of the launch, which
+// are 99 % of its workgroups, run at 7 waves per SIMD: metric frame 21.8 -> 19.5 us per step on one box, profiles/r06_experiments.md)
+#ifndef MI_WALK_LDS_WORDS
+#define MI_WALK_LDS_WORDS 5600u
+#endif
+#ifndef MI_FRAME_WALK_WAVES
+#define MI_FRAME_WALK_WAVES 7
+#endif
+constexpr int FRAME_WALK_WAVES = MI_FRAME_WALK_WAVES;
+constexpr uint32_t FRAME_LDS_WORDS = 4096u, FRAME_WALK_LDS_WORDS = MI_WALK_LDS_WORDS;
 constexpr size_t FRAME_KERNEL_LDS_BYTES = (FRAME_WALK_LDS_WORDS + 4) * 4;  // the riding walk's arena
 #ifdef MI_EXP_FILL_RIDE_BLOCKS
 constexpr uint32_t CLUSTER_FILL_RIDE_BLOCKS = MI_EXP_FILL_RIDE_BLOCKS;  // (A/B builds)

@@ -294,12 +294,12 @@ __device__ __forceinline__ void frame_workgroup(const Columns& c, const ViewSet&
     // the riding walk's plane table: the kernel's trailing argument (WalkPlanes, kernels.h), read where the walkers want it
     const float* planes_arg = nullptr;
     if constexpr (WALK != 0) planes_arg = &kernarg_late<float>(wp_offset);
-    // 16 KB + 16 B: the four waves' GlobalTransform transpose buffers (12 KB) -- or, in a riding cluster-fill workgroup, the CSR
-    // offsets of up to 4096 clusters and the four wave totals of their scan -- or the arena of a riding cluster-walk workgroup
-    // 16 KB: the rows' transposes (4 waves x 3 KB), the compaction / fill riders' arena.  A launch that carries the cluster walk is
-    // held to 5 workgroups per CU by the walk's registers anyway, so its arena is the 31 KB that five of them leave each other: the
-    // walk sweeps the cluster grid in chunks of as many z slices as fit, and a chunk is a reservation round trip (metric frame
-    // 22.3 -> 21.7 us, profiles/r03_experiments.md)
+    // 16 KB + 16 B: the four waves' GlobalTransform transpose buffers (12 KB) -- or, in a riding compaction / cluster-fill workgroup,
+    // that rider's arena (the CSR offsets of up to 4096 clusters and the four wave totals of their scan).  A launch that carries the
+    // cluster walk gives its walking workgroups 22 KB (FRAME_WALK_LDS_WORDS, kernels.h): the walk sweeps the cluster grid in chunks of
+    // as many z slices as fit, and a chunk is a reservation round trip -- but every row workgroup of the launch pays for the arena
+    // and the walk's registers in occupancy, and there are a hundred of those to a walker (round 6: 31 KB / 89 VGPRs / 5 waves per
+    // SIMD -> 22 KB / 72 / 7: metric frame 21.8 -> 19.5 us per step, profiles/r06_experiments.md)
     __shared__ __attribute__((aligned(16))) uint32_t lds_raw[(WALK ? FRAME_WALK_LDS_WORDS : FRAME_LDS_WORDS) + 4];
     float4 (*lds_g)[192] = reinterpret_cast<float4 (*)[192]>(lds_raw);
     if (frame_riders<WALK>(n_tiles, prev, prev_gx, n_compact, n_fill, fill, walk, vs, lds_raw, planes_arg)) return;
@@ -410,6 +410,9 @@ __device__ __forceinline__ void frame_workgroup(const Columns& c, const ViewSet&
     if (PROPAGATE) {
         if (live) g = affine_from_srt(s_in, q_in, t_in);
         // nontemporal: the fused path never reads G back (measured +3..16 % at 4 M - 10 M rows, neutral at 1 M)
+#ifdef MI_EXP_STRIP_GSTORE
+        if (g.t.x == 1.2345e30f)
+#endif
         store_affine_coalesced(lds_g[wv], c.global, wave_row0, c.n, lane, g, true);
     } else {
         float4* lds_wave = lds_g[wv];
@@ -531,17 +534,28 @@ __device__ __forceinline__ void frame_workgroup(const Columns& c, const ViewSet&
     } else {
         for (uint32_t v = 0; v < n_views; ++v) {
             const ViewParams& vp = INLINE_VIEWS ? vs.v[v] : dviews[v];
+#ifdef MI_EXP_STRIP_VIEWS  // (timing-only builds, wrong results: what each part of the row path costs, profiles/r06_experiments.md)
+            const bool vis = live && !ncc && (fl & 1u) && g.t.z < vp.planes[3];
+#else
             const bool vis = live && !ncc &&
                              row_visible_in_view(g, center, half, fl, emask, emask_hi, c.range_start_end != nullptr, range_lo, range_hi, vp);
+#endif
             any = any || vis;
+#ifndef MI_EXP_STRIP_EMIT
             emit_view(v, vis, any_live, lane, wave, cmask, out, seg);
+#endif
         }
     }
+#ifdef MI_EXP_STRIP_TAIL
+    const bool vv_now = any;
+    if (live && any && vv0 == 77u) c.view_visibility[row] = 1;
+#else
     const bool vv_now = view_visibility_tail(c, row, live, any_live, lane, wave, fl, vv0, any, fl_frame);
     if (PROPAGATE) {  // plain assignment bumps every written row's tick (systems.rs:62)
         const unsigned long long lv = __ballot(live);
         if (lane == 0 && any_live) c.g_changed_bits[wave] = lv;
     }
+#endif
     if (PARTIAL) {
         const unsigned long long dm = __ballot(dirty);
         if (lane == 0 && any_live) c.g_changed_bits[wave] = dm;
@@ -559,7 +573,7 @@ struct FrameKernargs {
     CompactFastArgs prev; uint32_t prev_gx, n_compact, n_fill; ClusterFillJob fill; ClusterWalkJob walk; const uint8_t* changed; WalkPlanes wp;
 };
 template <int PROP, bool INLINE_VIEWS, int WALK>
-__global__ void __launch_bounds__(256) k_frame(Columns c, ViewSet vs, const ViewParams* __restrict__ dviews,
+__global__ void __launch_bounds__(256, WALK == 1 ? FRAME_WALK_WAVES : 1) k_frame(Columns c, ViewSet vs, const ViewParams* __restrict__ dviews,
                                                 uint32_t n_views, VisibilityOut out, SegOut seg, uint32_t fl_frame, uint32_t n_tiles,
                                                 CompactFastArgs prev, uint32_t prev_gx, uint32_t n_compact, uint32_t n_fill, ClusterFillJob fill,
                                                 ClusterWalkJob walk, const uint8_t* __restrict__ changed, typename WalkPlanesArg<WALK>::type wp) {
@@ -865,7 +879,7 @@ struct FrameSphKernargs {
     WalkPlanes wp;
 };
 template <bool PARTIAL, bool INLINE_VIEWS, int WALK>
-__global__ void __launch_bounds__(256) k_frame_sph(Columns c, ViewSet vs, const ViewParams* __restrict__ dviews, uint32_t n_views,
+__global__ void __launch_bounds__(256, WALK == 1 ? FRAME_WALK_WAVES : 1) k_frame_sph(Columns c, ViewSet vs, const ViewParams* __restrict__ dviews, uint32_t n_views,
                                                     VisibilityOut out, SegOut seg, uint32_t fl_frame, uint32_t n_tiles, CompactFastArgs prev,
                                                     uint32_t prev_gx, uint32_t n_compact, uint32_t n_fill, ClusterFillJob fill,
                                                     ClusterWalkJob walk, const uint8_t* __restrict__ changed, SphereArgs sa,

@@ -44,12 +44,35 @@ static inline v3 v3_max(v3 a, v3 b) { return V3(lane_max(a.x, b.x), lane_max(a.y
 static inline float rust_min(float a, float b) { return fminf(a, b); }
 static inline float rust_max(float a, float b) { return fmaxf(a, b); }
 
+/* PARITY-MARGIN SWITCHES (tests/test_parity_margin.py; never defined in the oracle proper).  glam 0.33.2 is not under
+ * /root/reference and cannot be built here, so the lane orders below are restated from memory; each ORC_* macro swaps ONE of them
+ * for the order a wrong memory would give, and the test counts what that changes on the BASELINE configs:
+ *   ORC_DOT4_LEFT_TO_RIGHT  Vec4::dot as ((x x' + y y') + z z') + w w'
+ *   ORC_DOT3_PAIRWISE       Vec3A::dot as (x x' + z z') + y y'   (dot4_in_x's shuffle pattern with a zero w lane)
+ *   ORC_DOT3_X_YZ           Vec3A::dot as x x' + (y y' + z z')
+ *   ORC_LENGTH_RSQRT        Vec3A::length as 1 / (1 / sqrt(dot))   (length through length_recip)
+ *   ORC_MAT3_COLUMNS_ZYX    Mat3A * Vec3A accumulated from the z column: (Z v.z + Y v.y) + X v.x
+ * and the build flags -ffp-contract=fast -mfma fuse every a*b+c the compiler can (variant "fma"). */
 /* Vec3A::dot, glam sse2 dot3_in_x: (x*x' + y*y') + z*z'.  The scalar Vec3::dot has the same
  * left-to-right order. */
+#if defined(ORC_DOT3_PAIRWISE)
+static inline float v3_dot(v3 a, v3 b) { return (a.x * b.x + a.z * b.z) + a.y * b.y; }
+#elif defined(ORC_DOT3_X_YZ)
+static inline float v3_dot(v3 a, v3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+#else
 static inline float v3_dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+#endif
 /* Vec4::dot, glam sse2 dot4_in_x: (x*x' + z*z') + (y*y' + w*w') -- pairwise, NOT left-to-right. */
+#if defined(ORC_DOT4_LEFT_TO_RIGHT)
+static inline float v4_dot(v4 a, v4 b) { return ((a.x * b.x + a.y * b.y) + a.z * b.z) + a.w * b.w; }
+#else
 static inline float v4_dot(v4 a, v4 b) { return (a.x * b.x + a.z * b.z) + (a.y * b.y + a.w * b.w); }
+#endif
+#if defined(ORC_LENGTH_RSQRT)
+static inline float v3_length(v3 a) { float d = v3_dot(a, a); return d > 0.0f ? 1.0f / (1.0f / sqrtf(d)) : sqrtf(d); }
+#else
 static inline float v3_length(v3 a) { return sqrtf(v3_dot(a, a)); }
+#endif
 /* Vec3A::cross (sse2): (a.zxy*b - a*b.zxy).zxy */
 static inline v3 v3_cross(v3 a, v3 b) {
     return V3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
@@ -63,10 +86,17 @@ static inline v3 v4_xyz(v4 a) { return V3(a.x, a.y, a.z); }
 
 /* Mat3A::mul_vec3a (sse2): r = X*v.x; r += Y*v.y; r += Z*v.z */
 static inline v3 m3_mul_v3(const m3* m, v3 v) {
+#if defined(ORC_MAT3_COLUMNS_ZYX)
+    v3 r = v3_scale(m->z_axis, v.z);
+    r = v3_add(r, v3_scale(m->y_axis, v.y));
+    r = v3_add(r, v3_scale(m->x_axis, v.x));
+    return r;
+#else
     v3 r = v3_scale(m->x_axis, v.x);
     r = v3_add(r, v3_scale(m->y_axis, v.y));
     r = v3_add(r, v3_scale(m->z_axis, v.z));
     return r;
+#endif
 }
 /* Mat3A * Mat3A: columns (A*B.x, A*B.y, A*B.z) */
 static inline m3 m3_mul(const m3* a, const m3* b) {
@@ -238,6 +268,12 @@ void orc_affine_transform_point(const float a[12], const float p[3], float out[3
     aff A = aff_load(a);
     v3 r = aff_point(&A, V3(p[0], p[1], p[2]));
     out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+/* (tests/test_parity_margin.py: the raw lane orders, so that the test can see that a variant build really swapped one) */
+void orc_probe_lane_orders(const float a[4], const float b[4], float out[3]) {
+    out[0] = v4_dot(V4(a[0], a[1], a[2], a[3]), V4(b[0], b[1], b[2], b[3]));
+    out[1] = v3_dot(V3(a[0], a[1], a[2]), V3(b[0], b[1], b[2]));
+    out[2] = v3_length(V3(a[0], a[1], a[2]));
 }
 float orc_radius_vec3a(const float a[12], const float e[3]) {
     aff A = aff_load(a);
@@ -593,6 +629,52 @@ void orc_check_visibility(uint32_t n, const float* global, const float* aabb_cen
                 if (vis) set_visible(&vv[i], vv_changed_out ? &vv_changed_out[i] : NULL);
             }
             if (visible_out) visible_out[(size_t)v * n + i] = vis;
+        }
+    }
+}
+
+/* PARITY-MARGIN CENSUS (tests/test_parity_margin.py): how close every DECIDING value of check_visibility's plane tests sits to
+ * its `<= 0.0` (primitives.rs:263, 289), in ulps of the largest term of the sum that forms it -- the only rows a last-ulp
+ * difference in glam's lane order could move.  Camera views; for every row that reaches the frustum tests (InheritedVisibility,
+ * RenderLayers, not NoFrustumCulling) all five planes of intersects_sphere and, for rows with an Aabb, of intersects_obb are
+ * binned (no early exit: a later plane's value decides under another order).  hist[0..4] = values within 1 / 4 / 16 / 64 / 1024
+ * ulps (cumulative), hist[5] = values binned. */
+static inline void margin_bin(float val, float big, uint64_t* hist) {
+    float ulp = nextafterf(big, INFINITY) - big;
+    float m = fabsf(val) / ulp;
+    static const float lim[5] = {1.0f, 4.0f, 16.0f, 64.0f, 1024.0f};
+    for (int k = 0; k < 5; ++k) if (m < lim[k]) hist[k]++;
+    hist[5]++;
+}
+void orc_visibility_margin_census(uint32_t n, const float* global, const float* aabb_center, const float* aabb_half,
+                                  const uint8_t* flags, const uint32_t* layer_mask, const float* frusta,
+                                  const uint32_t* view_layer_masks, uint32_t n_views, uint64_t hist[6]) {
+    for (uint32_t v = 0; v < n_views; ++v) {
+        const float* frustum = frusta + 24 * v;
+        uint32_t view_mask = view_layer_masks ? view_layer_masks[v] : 1u;
+        for (uint32_t i = 0; i < n; ++i) {
+            uint8_t fl = flags[i];
+            if ((fl & ORC_FLAG_NO_CPU_CULLING) || !(fl & ORC_FLAG_INHERITED_VISIBLE) || (fl & ORC_FLAG_NO_FRUSTUM_CULLING)) continue;
+            if (!(view_mask & (layer_mask ? layer_mask[i] : 1u))) continue;
+            if (!(fl & (ORC_FLAG_HAS_AABB | ORC_FLAG_HAS_SPHERE))) continue;
+            const float* c = aabb_center + 3 * (size_t)i;
+            const float* h = aabb_half + 3 * (size_t)i;
+            aff wfl = aff_load(global + 12 * (size_t)i);
+            v3 center = V3(c[0], c[1], c[2]), half = V3(h[0], h[1], h[2]);
+            int has_aabb = (fl & ORC_FLAG_HAS_AABB) != 0;
+            v3 sc = has_aabb ? aff_point(&wfl, center) : center;
+            float sr = has_aabb ? v3_length(m3_mul_v3(&wfl.m, half)) : h[0];
+            v4 c4 = v3_extend(sc, 1.0f);
+            for (int p = 0; p < 5; ++p) {
+                v4 hs = plane_at(frustum, p);
+                float d = v4_dot(hs, c4);
+                float big = fmaxf(fmaxf(fabsf(hs.x * sc.x), fabsf(hs.y * sc.y)), fmaxf(fabsf(hs.z * sc.z), fabsf(hs.w)));
+                margin_bin(d + sr, fmaxf(big, fabsf(sr)), hist);
+                if (has_aabb) {
+                    float rr = aabb_relative_radius(half, v4_xyz(hs), &wfl.m);
+                    margin_bin(d + rr, fmaxf(big, fabsf(rr)), hist);
+                }
+            }
         }
     }
 }

@@ -71,6 +71,7 @@ void orc_affine_inverse(const float a[12], float out[12]);
 /* Affine3A::transform_point3a */
 void orc_affine_transform_point(const float a[12], const float p[3], float out[3]);
 /* GlobalTransform::radius_vec3a, global_transform.rs:252-254 */
+void orc_probe_lane_orders(const float a[4], const float b[4], float out[3]);
 float orc_radius_vec3a(const float a[12], const float extents[3]);
 /* HalfSpace::new, crates/bevy_math/src/primitives/half_space.rs:53-57 */
 void orc_half_space_new(const float normal_d[4], float out[4]);
@@ -177,6 +178,11 @@ typedef struct orc_view {
 void orc_check_visibility_ranges(uint32_t n, const float* global, const float* aabb_center,
                                  const uint8_t* flags, const float* range_start_end,
                                  const float* view_positions, uint32_t n_views, uint8_t* in_range_out);
+
+/* parity-margin census (tests/test_parity_margin.py): hist[0..4] = deciding plane-test values within 1/4/16/64/1024 ulps of zero, hist[5] = all */
+void orc_visibility_margin_census(uint32_t n, const float* global, const float* aabb_center, const float* aabb_half,
+                                  const uint8_t* flags, const uint32_t* layer_mask, const float* frusta,
+                                  const uint32_t* view_layer_masks, uint32_t n_views, uint64_t hist[6]);
 
 /* The per-entity closures of check_visibility_cpu_culling (visibility/mod.rs:788-858),
  * check_dir_light_mesh_visibility (bevy_light/src/lib.rs:425-475) and check_point_light_mesh_visibility

@@ -41,6 +41,49 @@ def build():
     return _SO
 
 
+# ---- parity-margin variants (tests/test_parity_margin.py): the same oracle with ONE of glam's lane orders swapped for the order a
+# wrong memory of glam 0.33.2 would give (the ORC_* switches at the top of oracle/bevy_oracle.c), or with every a*b+c fused.
+PARITY_VARIANTS = {
+    "dot4_left_to_right": ["-DORC_DOT4_LEFT_TO_RIGHT"],
+    "dot3_pairwise": ["-DORC_DOT3_PAIRWISE"],
+    "dot3_x_yz": ["-DORC_DOT3_X_YZ"],
+    "length_rsqrt": ["-DORC_LENGTH_RSQRT"],
+    "mat3_columns_zyx": ["-DORC_MAT3_COLUMNS_ZYX"],
+    "fma": ["-ffp-contract=fast", "-mfma"],
+}
+_BASE_CFLAGS = ["-O2", "-std=c99", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-msse2", "-mfpmath=sse", "-Wno-unused-function"]
+
+
+def build_variant(name):
+    """oracle/libbevy_oracle_<name>.so: bevy_oracle.c with PARITY_VARIANTS[name] appended to the oracle's own flags."""
+    so = os.path.join(ORACLE_DIR, f"libbevy_oracle_{name}.so")
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("bevy_oracle.c", "batching_oracle.c", "bevy_oracle.h")] + [os.path.abspath(__file__)]
+    if os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(s) for s in srcs):
+        return so
+    subprocess.run(["gcc"] + _BASE_CFLAGS + PARITY_VARIANTS[name] + [os.path.join(ORACLE_DIR, "bevy_oracle.c"), os.path.join(ORACLE_DIR, "batching_oracle.c"),
+                                                                      "-o", so, "-shared", "-lm", "-lpthread"], check=True, capture_output=True)
+    return so
+
+
+class variant:
+    """with oracle_lib.variant("dot4_left_to_right"): every oracle_lib function runs the variant build; the oracle proper comes
+    back on exit.  (Every binding goes through lib(), so swapping the handle is enough.)"""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        global _lib
+        self.saved = _lib
+        _lib = None if self.name is None else _prepare(C.CDLL(build_variant(self.name)))
+        return self
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.saved
+        return False
+
+
 class ClusterView(C.Structure):
     _fields_ = [
         ("dims", C.c_uint32 * 3),
@@ -99,16 +142,20 @@ def make_views(frusta, layer_masks=None, flags=None, positions=None, light_spher
 _lib = None
 
 
+def _prepare(l):
+    l.orc_radius_vec3a.restype = C.c_float
+    l.orc_bench_flat_frame.restype = C.c_double
+    l.orc_bench_flat_frame2.restype = C.c_double
+    l.orc_assign_objects_to_clusters.restype = C.c_uint64
+    l.orc_assign_objects_to_clusters_layers64.restype = C.c_uint64
+    l.orc_visible_entities_sorted.restype = C.c_uint32
+    return l
+
+
 def lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(build())
-        _lib.orc_radius_vec3a.restype = C.c_float
-        _lib.orc_bench_flat_frame.restype = C.c_double
-        _lib.orc_bench_flat_frame2.restype = C.c_double
-        _lib.orc_assign_objects_to_clusters.restype = C.c_uint64
-        _lib.orc_assign_objects_to_clusters_layers64.restype = C.c_uint64
-        _lib.orc_visible_entities_sorted.restype = C.c_uint32
+        _lib = _prepare(C.CDLL(build()))
     return _lib
 
 
@@ -297,6 +344,15 @@ def check_visibility_views(g, c, h, flags, layers, range_start_end, vv, views):
     lib().orc_check_visibility_views(n, fp(g), fp(c), fp(h), u8p(flags), u32p(layers), fp(range_start_end), u8p(vv),
                                      views, nv, u8p(vis), u8p(chg))
     return vv, vis.reshape(nv, n), chg
+
+
+def visibility_margin_census(g, c, h, flags, layers, frusta):
+    """-> uint64[6]: deciding plane-test values within 1 / 4 / 16 / 64 / 1024 ulps of their `<= 0.0` (cumulative), and all of them."""
+    n = len(flags)
+    fr = np.ascontiguousarray(frusta, np.float32).reshape(-1, 24)
+    hist = np.zeros(6, np.uint64)
+    lib().orc_visibility_margin_census(n, fp(g), fp(c), fp(h), u8p(flags), u32p(layers), fp(fr), None, len(fr), u64p(hist))
+    return hist
 
 
 def visibility_propagate(parent, visibility, inherited):

@@ -5,6 +5,8 @@
 // the visibility bitmasks / VisibleEntities lists, the clustering scratch, and HIP-event timing.
 // Everything is enqueued on one HIP stream per context; the only host synchronisations are in the
 // download / timer-read entry points.
+#include <dlfcn.h>
+
 #include "ctx.h"
 
 using namespace mi;
@@ -18,6 +20,34 @@ std::string g_create_error = "no error";
 }  // namespace
 
 namespace mi_detail {
+
+// roctx, looked up once (ctx.h: TraceRange).  dlopen only: the library has no link-time dependency on a tracing runtime.
+const RoctxApi& roctx_api() {
+    static const RoctxApi api = [] {
+        RoctxApi a;
+        const char* want = getenv("MI_ROCTX");
+        const char* prof = getenv("ROCPROF_MARKER_API_TRACE");
+        const bool on = want ? (want[0] != '\0' && want[0] != '0') : (prof && prof[0] != '\0' && prof[0] != '0');
+        if (!on) return a;
+        void* push = dlsym(RTLD_DEFAULT, "roctxRangePushA");
+        void* pop = dlsym(RTLD_DEFAULT, "roctxRangePop");
+        for (const char* lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            if (push && pop) break;
+            if (void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL)) {
+                push = dlsym(h, "roctxRangePushA");
+                pop = dlsym(h, "roctxRangePop");
+            }
+        }
+        if (push && pop) {
+            a.push = (int (*)(const char*))push;
+            a.pop = (int (*)())pop;
+        } else if (want) {
+            fprintf(stderr, "[mi] MI_ROCTX is set but no roctx library could be loaded: no ranges\n");
+        }
+        return a;
+    }();
+    return api;
+}
 
 int32_t fail(mi_ctx* ctx, int32_t code, const char* fmt, ...) {
     char buf[512];
@@ -350,7 +380,13 @@ int32_t run_compaction(mi_ctx* ctx, const VisibilityOut& vo, const SegOut& seg, 
         DevBuf& st = ctx->fb[ctx->cur].seg_totals;  // (+ the chunk totals of the hierarchical mode at this capacity)
         const void* before = st.p;
         if ((rc = ensure(ctx, st, compact_fast_totals_bytes(segs, ctx->cap)))) return rc;
-        if (st.p != before) HIP_TRY(ctx, hipMemsetAsync(st.p, 0, st.bytes, ctx->stream));  // fresh memory must not hold a word that reads as a stamp
+        // Fresh memory must not hold a word that reads as a stamp -- and neither must the words of an earlier LAYOUT: the stamp table
+        // starts behind the segment totals, so with fewer segments (or another chunk count) old totals and old table entries lie where
+        // stamps are now read, and a total that happens to equal this frame's tag would pass for a published chunk sum.
+        const uint64_t layout = ((uint64_t)segs << 32) | compact_fast_chunks(ctx->cap, true);
+        uint64_t& last = ctx->fb[ctx->cur].seg_totals_layout;
+        if (st.p != before || last != layout) HIP_TRY(ctx, hipMemsetAsync(st.p, 0, st.bytes, ctx->stream));
+        last = layout;
     }
     if (ctx->n == 0) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->fb[ctx->cur].seg_totals.p, 0, segs * 4, ctx->stream));
@@ -827,20 +863,20 @@ static int32_t cull_frame(mi_ctx* ctx, const mi_view* views, uint32_t n_views, u
             }
         }
         ProfScope ps(ctx, PROPAGATE ? K_FLAT_PROPAGATE_CULL : K_CULL);
-        // the riding walk's plane table travels as a kernel argument (WalkPlanes, kernels.h): the launch below takes it from here
-        g_walk_planes_host = clusters_ride ? WalkPlanesHost{ctx->cl_planes_host.data(), (uint32_t)ctx->cl_planes_host.size()} : WalkPlanesHost{nullptr, 0};
+        // the riding walk's plane table travels as a kernel argument (WalkPlanes, kernels.h)
+        const WalkPlanesHost walk_planes = clusters_ride ? WalkPlanesHost{ctx->cl_planes_host.data(), (uint32_t)ctx->cl_planes_host.size()} : WalkPlanesHost{nullptr, 0};
         const bool stale_from_mask = use_sph && ctx->sph_state == mi_ctx::SPH_EXCEPT_CHANGED;
         const hipError_t e = use_sph ? launch_frame_sph(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p, n_views, vo, seg,
                                                         (flags & (MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME)) | (PROPAGATE ? CULL_BEGIN_FRAME : 0u), prev,
                                                         have_fill ? &fill_job : nullptr, clusters_ride ? &walk_job : nullptr, ctx->stream, changed_col,
                                                         (float*)ctx->sph.p, stale_from_mask && !ctx->g_chg_in_bytes ? ctx->g_chg_bits : nullptr,
-                                                        stale_from_mask && ctx->g_chg_in_bytes ? ctx->g_changed_bytes : nullptr, sph_all_stale)
+                                                        stale_from_mask && ctx->g_chg_in_bytes ? ctx->g_changed_bytes : nullptr, sph_all_stale, walk_planes)
                              : PROPAGATE ? launch_flat_propagate_cull(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p,
                                                                     n_views, vo, seg, flags & MI_CULL_END_FRAME, prev, have_fill ? &fill_job : nullptr,
-                                                                    clusters_ride ? &walk_job : nullptr, ctx->stream, changed_col)
+                                                                    clusters_ride ? &walk_job : nullptr, ctx->stream, changed_col, walk_planes)
                                        : launch_cull(c, ctx->views_inline ? &ctx->view_set : nullptr, (const ViewParams*)ctx->views.p, n_views, vo,
                                                      seg, flags & (MI_CULL_BEGIN_FRAME | MI_CULL_END_FRAME), prev, have_fill ? &fill_job : nullptr,
-                                                     clusters_ride ? &walk_job : nullptr, ctx->stream);
+                                                     clusters_ride ? &walk_job : nullptr, ctx->stream, walk_planes);
         if (e != hipSuccess) {
             // The launch that was to carry the previous frame's fill and this frame's walk never happened: the fill goes out
             // on its own (as in the ride_prepare failure above), and the walk's bookkeeping is taken back -- no fill may later

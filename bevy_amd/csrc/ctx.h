@@ -242,6 +242,7 @@ struct mi_ctx {
         uint32_t n_bufs = 0;
         void* buf[MAX_BUFS] = {nullptr};
         void* owned[MAX_BUFS] = {nullptr};  // mi_exchange_configure_owned: buffers the library allocated (freed on reconfigure / destroy)
+        size_t owned_bytes = 0;             // ... and the size of each (world * block_bytes): what mi_exchange_download may read; 0 = the caller's buffers
         uint64_t words_per_view = 0, word_offset = 0, block_bytes = 0;
         uint32_t rank = 0;
         uint64_t frame = 0;
@@ -303,6 +304,7 @@ struct mi_ctx {
     bool vv_alt_zeroed = false;
     struct FrameBufs {
         DevBuf bitmask, wave_cnt, seg_mask, out_rows, seg_totals;
+        uint64_t seg_totals_layout = 0;  // (segments, chunks) of the last compaction that used seg_totals: where its stamp table lay
     } fb[N_FB];
     uint32_t cur = 0;  // set of the current / last frame
     struct DeferredCompaction {
@@ -424,17 +426,38 @@ inline int32_t hip_rc(mi_ctx* ctx, hipError_t e, const char* what) {
 // ENTER_RAW: mi_map_upload_window / mi_commit_upload_window, which continue a sequence of dense windows (seq_cov above); ENTER:
 // everybody else -- whatever they launch may read the Transform columns, so a window committed after them starts over on the
 // context's stream (or starts a new sequence at row 0, which waits for that stream first)
-#define ENTER_RAW(ctx)                                                   \
-    do {                                                                 \
-        if (!(ctx)) return fail(nullptr, MI_ERR_INVALID_ARG, "ctx is NULL"); \
-        if (mi_detail::trace_on()) fprintf(stderr, "[mi] %s\n", __func__); \
-        HIP_TRY(ctx, hipSetDevice((ctx)->device));                       \
-    } while (0)
-#define ENTER(ctx)                                                       \
-    do {                                                                 \
-        ENTER_RAW(ctx);                                                  \
-        (ctx)->seq_cov = 0;                                              \
-    } while (0)
+// (statements of the entry point's own scope, not a block: the range object lives until the entry point returns)
+#define ENTER_RAW(ctx)                                                                 \
+    if (!(ctx)) return mi_detail::fail(nullptr, MI_ERR_INVALID_ARG, "ctx is NULL");    \
+    if (mi_detail::trace_on()) fprintf(stderr, "[mi] %s\n", __func__);                 \
+    mi_detail::TraceRange mi_trace_range_(__func__);                                   \
+    HIP_TRY(ctx, hipSetDevice((ctx)->device))
+#define ENTER(ctx)  \
+    ENTER_RAW(ctx); \
+    (ctx)->seq_cov = 0
+
+// Tracing hooks (the reference wraps these systems in info_span!, crates/bevy_transform/src/systems.rs:169-283): every
+// entry point of the library is a roctx range named after itself, so a rocprofv3 --marker-trace (or any roctx consumer) of a Bevy
+// frame shows mi_propagate_and_cull_views, mi_download_frame_results, ... around the kernels they launch.  No link-time
+// dependency: roctxRangePushA / roctxRangePop are looked up at first use -- among the symbols already loaded (rocprofv3 preloads
+// librocprofiler-sdk-roctx.so), then in librocprofiler-sdk-roctx.so / libroctx64.so.  On when MI_ROCTX=1, or when rocprofv3 asked for
+// marker tracing (ROCPROF_MARKER_API_TRACE) and MI_ROCTX is not 0; otherwise an entry point pays one predictable branch.
+struct RoctxApi {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+};
+const RoctxApi& roctx_api();
+struct TraceRange {
+    const RoctxApi& api;
+    explicit TraceRange(const char* name) : api(roctx_api()) {
+        if (api.push) api.push(name);
+    }
+    ~TraceRange() {
+        if (api.push) api.pop();
+    }
+    TraceRange(const TraceRange&) = delete;
+    TraceRange& operator=(const TraceRange&) = delete;
+};
 
 inline bool trace_on() {
     static const bool on = getenv("MI_TRACE") != nullptr;  // every entry point announces itself on stderr

@@ -470,8 +470,8 @@ int32_t cluster_assign_launch(mi_ctx* ctx, bool concurrent, uint64_t* out_total,
         cluster_next_set(ctx, &p);
         const ClusterWork& w = p.w;
         const bool defer = defer_fill && !concurrent && !out_total;
-        g_walk_planes_host = WalkPlanesHost{ctx->cl_planes_host.data(), (uint32_t)ctx->cl_planes_host.size()};  // (the table as a kernel argument, kernels.h)
-        HIP_TRY(ctx, launch_cluster_assign(ctx->cl_view, p.o, w, concurrent ? &ctx->view_set : nullptr, concurrent, !defer, stream, prof_mark, ctx));
+        HIP_TRY(ctx, launch_cluster_assign(ctx->cl_view, p.o, w, concurrent ? &ctx->view_set : nullptr, concurrent, !defer, stream, prof_mark, ctx,
+                                           WalkPlanesHost{ctx->cl_planes_host.data(), (uint32_t)ctx->cl_planes_host.size()}));  // (the table as a kernel argument, kernels.h)
         if (defer) {  // the fill rides in the next frame's kernel (or cluster_fill_join launches it)
             ctx->cl_fill_job.w = w;
             ctx->cl_fill_job.n_clusters = p.C;

@@ -395,6 +395,13 @@ int32_t mi_exchange_configure_multi(mi_ctx* ctx, void* const* nccl_comms, uint32
         x.on = false;
         if (rc0) return rc0;
     }
+    // buffers of an earlier mi_exchange_configure_owned: nothing is in flight any more (drained above), and this configuration either
+    // brings its own buffers or -- called from mi_exchange_configure_owned, after its "off" call -- fresh ones
+    if (!device_bufs || device_bufs != x.owned) {
+        for (void*& p : x.owned)
+            if (p) { hipFree(p); p = nullptr; }
+        x.owned_bytes = 0;
+    }
     if (!nccl_comm) {  // off: back to the internal mask buffer
         x.on = false;
         ctx->ext_bitmask = nullptr;
@@ -485,15 +492,15 @@ int32_t mi_exchange_configure_owned(mi_ctx* ctx, void* const* nccl_comms, uint32
     // off first: whatever is in flight drains before the buffers it uses are freed
     int32_t rc = mi_exchange_configure_multi(ctx, nullptr, 0, nullptr, nullptr, 0, 0, 0, 0, 0);
     if (rc) return rc;
-    for (void*& p : x.owned)
-        if (p) { hipFree(p); p = nullptr; }
     const size_t bytes = (size_t)world * block_bytes;
     for (uint32_t i = 0; i < n_bufs; ++i) {
         HIP_TRY(ctx, hipMalloc(&x.owned[i], bytes));
         HIP_TRY(ctx, hipMemsetAsync(x.owned[i], 0, bytes, ctx->stream));
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return mi_exchange_configure_multi(ctx, nccl_comms, n_comms, fn_nccl_all_gather, x.owned, n_bufs, words_per_view, word_offset, block_bytes, rank);
+    rc = mi_exchange_configure_multi(ctx, nccl_comms, n_comms, fn_nccl_all_gather, x.owned, n_bufs, words_per_view, word_offset, block_bytes, rank);
+    if (rc == MI_OK) x.owned_bytes = bytes;
+    return rc;
 }
 
 int32_t mi_exchange_last(mi_ctx* ctx, void** out_device_buf, int32_t wait) {
@@ -516,6 +523,9 @@ int32_t mi_exchange_download(mi_ctx* ctx, void* out_host, uint64_t bytes) {
     if (rc) return rc;
     if (!out_host || bytes == 0) return fail(ctx, MI_ERR_INVALID_ARG, "mi_exchange_download: NULL or empty");
     auto& x = ctx->xch;
+    if (x.owned_bytes && bytes > x.owned_bytes)  // (buffers the caller bound: their size is the caller's to know, include/bevy_mi355x.h)
+        return fail(ctx, MI_ERR_INVALID_ARG, "mi_exchange_download: %llu bytes asked of a gathered buffer of %llu (world * block_bytes)",
+                    (unsigned long long)bytes, (unsigned long long)x.owned_bytes);
     const uint32_t slot = (uint32_t)((x.frame - 1) % x.n_bufs);
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, x.ev_gathered[slot], 0));  // the copy runs on the context's stream, behind the collective
     return download(ctx, out_host, buf, (size_t)bytes);

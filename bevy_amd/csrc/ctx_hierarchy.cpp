@@ -297,7 +297,7 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
     ctx->narrow_quad = true;
     for (uint32_t l = 0; l < n_levels && ctx->narrow; ++l) {
         const uint32_t w = level_offsets[l + 1] - level_offsets[l];
-        ctx->narrow = w <= 64u;
+        ctx->narrow = w >= 1u && w <= 64u;  // (an empty level -- mi_upload_hierarchy accepts them -- sends the hierarchy to the tiles: the one-wave kernel counts on increasing level ends)
         ctx->narrow_quad = ctx->narrow_quad && w <= 16u;
     }
     if (ctx->narrow) {

@@ -263,11 +263,18 @@ __host__ __device__ inline uint32_t compact_fast_gx(uint32_t n, bool own_launch)
 }
 // bytes of the seg_totals buffer: the totals (padded to 8 bytes) and, in the hierarchical mode, n_chunks stamped totals per segment
 inline size_t compact_fast_totals_bytes(size_t segs, uint32_t n) { return ((segs + 1u) & ~(size_t)1u) * 4u + segs * compact_fast_chunks(n, true) * 8u; }
+// The clustered view's plane table on the host (x | y | z planes, four floats each; WalkPlanes below): what the context hands the launch_*
+// wrappers of the kernels that carry a cluster walk.  {nullptr, 0}: none -- the walkers read the staged copy through the view's pointers.
+struct WalkPlanesHost {
+    const float* f;
+    uint32_t n;
+};
 extern int g_multi_view_mode;  // (process-wide: set from MI_MULTI_VIEW when a context is created; kernels_flat.hip)
 hipError_t launch_flat_propagate_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views,
                                       uint32_t n_views, const VisibilityOut& out, const SegOut& seg, uint32_t flags,
                                       const CompactFastArgs* prev, const struct ClusterFillJob* fill, const struct ClusterWalkJob* walk,
-                                      hipStream_t stream, const uint8_t* changed = nullptr /* set: only rows with a nonzero byte are propagated */);
+                                      hipStream_t stream, const uint8_t* changed = nullptr /* set: only rows with a nonzero byte are propagated */,
+                                      WalkPlanesHost walk_planes = WalkPlanesHost{nullptr, 0});
 // Level 0 of the hierarchy (roots + flat rows).  node_flags: bit0 = has children (nullptr = none do).
 // changed: per-row Changed<Transform>|... byte (nullptr or all_dirty => every row recomputed).
 // tree_bytes: TransformTreeChanged, a byte per row (only read when static_opt).
@@ -278,13 +285,14 @@ hipError_t launch_level0_propagate(const Columns& c, uint32_t n_level0, const ui
 hipError_t launch_globals_ahead(const float* t, const float* r, const float* s, uint32_t lo, uint32_t hi, float* out, hipStream_t stream);
 hipError_t launch_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views,
                        const VisibilityOut& out, const SegOut& seg, uint32_t flags, const CompactFastArgs* prev,
-                       const struct ClusterFillJob* fill, const struct ClusterWalkJob* walk, hipStream_t stream);
+                       const struct ClusterFillJob* fill, const struct ClusterWalkJob* walk, hipStream_t stream,
+                       WalkPlanesHost walk_planes = WalkPlanesHost{nullptr, 0});
 // The frame over the world-sphere column (kernels_flat.hip, k_frame_sph): camera views only, n_views <= 32.  changed == nullptr:
 // cull only; else the changed-rows frame (flags carry CULL_BEGIN_FRAME).  sph: [n] (cw, sr); stale rows as ballot words or bytes.
 hipError_t launch_frame_sph(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views, const VisibilityOut& out,
                             const SegOut& seg, uint32_t flags, const CompactFastArgs* prev, const struct ClusterFillJob* fill,
                             const struct ClusterWalkJob* walk, hipStream_t stream, const uint8_t* changed, float* sph, const uint64_t* stale_bits,
-                            const uint8_t* stale_bytes, bool all_stale);
+                            const uint8_t* stale_bytes, bool all_stale, WalkPlanesHost walk_planes = WalkPlanesHost{nullptr, 0});
 constexpr uint32_t SPH_MAX_VIEWS = 32;
 
 // ---- the static cull order (kernels_cells.hip builds it, k_frame_cells in kernels_flat.hip uses it) ----
@@ -596,7 +604,8 @@ hipError_t launch_cluster_bindings(uint32_t n_clusters, const uint32_t* offsets,
                                    uint32_t* out_idx, hipStream_t stream);
 // frame_views: the cull's views, read only when objs.derive (may be nullptr otherwise)
 hipError_t launch_cluster_assign(const ClusterViewDev& view, const ClusterObjects& objs, const ClusterWork& w, const ViewSet* frame_views,
-                                 bool small_lds, bool fill, hipStream_t stream, void (*mark)(void*, uint32_t), void* mark_ctx);
+                                 bool small_lds, bool fill, hipStream_t stream, void (*mark)(void*, uint32_t), void* mark_ctx,
+                                 WalkPlanesHost walk_planes = WalkPlanesHost{nullptr, 0});
 // fill = false leaves the second kernel to the caller: launch_cluster_fill, or the frame kernel's extra workgroups (ClusterFillJob)
 hipError_t launch_cluster_fill(const ClusterWork& w, uint32_t n_clusters, uint32_t n_objects, hipStream_t stream);
 struct ClusterFillJob {
@@ -635,12 +644,8 @@ template <>
 struct WalkPlanesArg<0> {
     typedef NoWalkPlanes type;
 };
-// (set by the context in front of a frame launch that carries a walk, consumed by that launch: the table on the host)
-struct WalkPlanesHost {
-    const float* f;
-    uint32_t n;
-};
-extern thread_local WalkPlanesHost g_walk_planes_host;
+// (the table on the host: what the context hands the launch_* wrappers of the kernels that carry a walk -- an explicit argument since
+// round 6; until then a thread_local the launchers consumed, which a launch path that did not consume it could leave dangling)
 // bytes of the LDS arena a walking workgroup needs for chunks of zc z slices (layout: cluster_walk.h)
 inline size_t cluster_walk_lds_bytes(uint32_t dxy, uint32_t zc, uint32_t n_planes, bool planes_in_lds) {
     const size_t RC = (size_t)dxy * zc;

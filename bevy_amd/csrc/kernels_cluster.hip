@@ -85,7 +85,7 @@ hipError_t launch_cluster_bindings(uint32_t n_clusters, const uint32_t* offsets,
 }
 
 hipError_t launch_cluster_assign(const ClusterViewDev& view, const ClusterObjects& objs, const ClusterWork& w, const ViewSet* frame_views,
-                                 bool small_lds, bool fill, hipStream_t stream, void (*mark)(void*, uint32_t), void* mctx) {
+                                 bool small_lds, bool fill, hipStream_t stream, void (*mark)(void*, uint32_t), void* mctx, WalkPlanesHost walk_planes) {
     static const ViewSet no_views = {};
     const ViewSet& fv = frame_views ? *frame_views : no_views;
     const uint32_t n_planes = view.dims[0] + view.dims[1] + view.dims[2] + 3u;
@@ -100,8 +100,7 @@ hipError_t launch_cluster_assign(const ClusterViewDev& view, const ClusterObject
     const size_t lds = lds_for(zc, planes_in_lds);
     // this frame's parity of the accumulators and of the count matrix was zeroed by the previous frame's fill kernel
     // the plane table as a kernel argument where it fits and the walkers copy it to LDS anyway (else the staged copy, through the view's pointers)
-    const WalkPlanesHost ph = g_walk_planes_host;
-    g_walk_planes_host = WalkPlanesHost{nullptr, 0};
+    const WalkPlanesHost ph = walk_planes;
     WalkPlanes wp;  // (only the bytes filled below are read)
     ClusterViewDev vd = view;
 #ifndef MI_EXP_STAGED_PLANES

@@ -1590,12 +1590,11 @@ hipError_t launch_upload_trs(const float* pinned_src, float* t, float* r, float*
 
 // prev != nullptr: the previous frame's deferred compaction rides in extra workgroups of this launch; fill != nullptr: so does the
 // fill of the previous frame's light-cluster assignment
-thread_local WalkPlanesHost g_walk_planes_host = {nullptr, 0};
-// The riding walk's plane table as a kernel argument: from the host copy the context left in g_walk_planes_host (consumed here); the
-// job's view then carries no table of its own.  Returns false (the staged copy stays) when there is none or it does not fit.
-static bool take_walk_planes(ClusterWalkJob* wj, WalkPlanes* wp) {
-    const WalkPlanesHost h = g_walk_planes_host;
-    g_walk_planes_host = WalkPlanesHost{nullptr, 0};
+// The riding walk's plane table as a kernel argument: from the host copy the context hands the launch (h); the job's view then carries
+// no table of its own.  Returns false (the staged copy stays) when there is none or it does not fit.
+// (nulling view.x_planes makes the walkers read the argument segment: only the PLANES_IN_LDS instantiations do that -- the riders of
+// the frame kernels are cluster_walk_tail<true, ...> -- and a table of <= WALK_PLANES_MAX floats always fits their arena.)
+static bool take_walk_planes(ClusterWalkJob* wj, WalkPlanes* wp, const WalkPlanesHost& h) {
 #ifdef MI_EXP_STAGED_PLANES  // (A/B build: the walkers read the table from the pinned staging arena, as until round 5)
     return false;
 #endif
@@ -1608,7 +1607,8 @@ int g_multi_view_mode = 0;  // MI_MULTI_VIEW (read by mi_ctx_create): 0 = as des
 template <int PROP>
 static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views,
                                const VisibilityOut& out, const SegOut& seg, uint32_t flags, const CompactFastArgs* prev,
-                               const ClusterFillJob* fill, const ClusterWalkJob* walk, hipStream_t stream, const uint8_t* changed = nullptr) {
+                               const ClusterFillJob* fill, const ClusterWalkJob* walk, hipStream_t stream, const uint8_t* changed = nullptr,
+                               const WalkPlanesHost& walk_planes = WalkPlanesHost{nullptr, 0}) {
     if (c.n == 0) return hipSuccess;
     if (!c.row_summary) return hipErrorInvalidValue;  // (the kernel loads it unconditionally: row_summary_ensure comes first)
     const uint32_t n_tiles = blocks_for(c.n);
@@ -1636,8 +1636,7 @@ static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, co
     const dim3 grid(n_tiles + prev_blocks + fill_blocks + walk_blocks);
     WalkPlanes wp;  // (only the bytes take_walk_planes fills are read)
     NoWalkPlanes nwp;
-    if (with_walk) take_walk_planes(&wj, &wp);
-    else g_walk_planes_host = WalkPlanesHost{nullptr, 0};
+    if (with_walk) take_walk_planes(&wj, &wp, walk_planes);
 #ifndef MI_EXP_NO_NT_LOADS  // (A/B build without)
     if (PROP == 1 && c.n >= NT_LOADS_MIN_ROWS) flags |= CULL_NT_LOADS;
 #endif
@@ -1674,7 +1673,7 @@ static hipError_t launch_frame(const Columns& c, const ViewSet* views_inline, co
 hipError_t launch_frame_sph(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views, const VisibilityOut& out,
                             const SegOut& seg, uint32_t flags, const CompactFastArgs* prev, const ClusterFillJob* fill, const ClusterWalkJob* walk,
                             hipStream_t stream, const uint8_t* changed, float* sph, const uint64_t* stale_bits, const uint8_t* stale_bytes,
-                            bool all_stale) {
+                            bool all_stale, WalkPlanesHost walk_planes) {
     if (c.n == 0) return hipSuccess;
     if (!c.row_summary) return hipErrorInvalidValue;  // (the kernel loads it unconditionally: row_summary_ensure comes first)
     const uint32_t n_tiles = blocks_for(c.n);
@@ -1707,8 +1706,7 @@ hipError_t launch_frame_sph(const Columns& c, const ViewSet* views_inline, const
     const ViewParams* dv = inl ? nullptr : d_views;
     WalkPlanes wp;  // (as in launch_frame)
     NoWalkPlanes nwp;
-    if (with_walk) take_walk_planes(&wj, &wp);
-    else g_walk_planes_host = WalkPlanesHost{nullptr, 0};
+    if (with_walk) take_walk_planes(&wj, &wp, walk_planes);
 #ifndef MI_EXP_NO_SPH_NT
     if (c.n >= NT_LOADS_MIN_ROWS) flags |= CULL_NT_LOADS;  // (the dense fetch of the survivors' GlobalTransforms)
 #endif
@@ -1902,14 +1900,14 @@ hipError_t launch_frame_cells(const Columns& c, const CellsOrder& o, const ViewS
 hipError_t launch_flat_propagate_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views,
                                       uint32_t n_views, const VisibilityOut& out, const SegOut& seg, uint32_t flags,
                                       const CompactFastArgs* prev, const ClusterFillJob* fill, const ClusterWalkJob* walk, hipStream_t stream,
-                                      const uint8_t* changed) {
-    if (changed) return launch_frame<2>(c, views_inline, d_views, n_views, out, seg, flags | CULL_BEGIN_FRAME, prev, fill, walk, stream, changed);
-    return launch_frame<1>(c, views_inline, d_views, n_views, out, seg, flags | CULL_BEGIN_FRAME, prev, fill, walk, stream);
+                                      const uint8_t* changed, WalkPlanesHost walk_planes) {
+    if (changed) return launch_frame<2>(c, views_inline, d_views, n_views, out, seg, flags | CULL_BEGIN_FRAME, prev, fill, walk, stream, changed, walk_planes);
+    return launch_frame<1>(c, views_inline, d_views, n_views, out, seg, flags | CULL_BEGIN_FRAME, prev, fill, walk, stream, nullptr, walk_planes);
 }
 hipError_t launch_cull(const Columns& c, const ViewSet* views_inline, const ViewParams* d_views, uint32_t n_views,
                        const VisibilityOut& out, const SegOut& seg, uint32_t flags, const CompactFastArgs* prev,
-                       const ClusterFillJob* fill, const ClusterWalkJob* walk, hipStream_t stream) {
-    return launch_frame<0>(c, views_inline, d_views, n_views, out, seg, flags, prev, fill, walk, stream);
+                       const ClusterFillJob* fill, const ClusterWalkJob* walk, hipStream_t stream, WalkPlanesHost walk_planes) {
+    return launch_frame<0>(c, views_inline, d_views, n_views, out, seg, flags, prev, fill, walk, stream, nullptr, walk_planes);
 }
 hipError_t launch_level0_propagate(const Columns& c, uint32_t n_level0, const uint8_t* node_flags,
                                    const uint8_t* changed, const uint8_t* tree_bytes, bool all_dirty,

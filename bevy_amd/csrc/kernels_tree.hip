@@ -1035,7 +1035,11 @@ __global__ void __launch_bounds__(64) k_propagate_narrow(Columns c, TreeArgs a, 
                 const uint32_t o = (uint32_t)__shfl_xor((int)best, (int)off, 64);
                 best = o < best ? o : best;
             }
-            n_lv = __builtin_amdgcn_readfirstlane(best - 1u);  // (>= 1: the planner takes this kernel only when every level fits a wave)
+            n_lv = __builtin_amdgcn_readfirstlane(best - 1u);  // (>= 1: the planner takes this kernel only when every level holds 1 .. 64 rows)
+            const uint32_t left = n_levels - l0;  // (and whatever the planner let through: never past the staged offsets or the hierarchy)
+            n_lv = n_lv > NARROW_CHUNK ? NARROW_CHUNK : n_lv;
+            n_lv = n_lv > left ? left : n_lv;
+            n_lv = n_lv ? n_lv : 1u;
         }
         const uint32_t rows = lds_off[n_lv] - row0;
         // ---- stage the chunk: coalesced loads, a lane per row, four rounds

@@ -794,6 +794,13 @@ int32_t mi_bind_visibility_output(mi_ctx* ctx, void* device_ptr, uint64_t words_
  *                          the buffer's slot to (RCCL's enqueue path is 15 - 20 us of CPU per call: more than the rest of the
  *                          frame call, and at an 8-GPU shard size more than the frame's kernel); every rank's thread issues its
  *                          all-gathers in frame order.  MI_XCH_SYNC_ENQUEUE=1 in the environment keeps them on the calling thread.
+ *                          What that thread changes for a caller: (1) ncclAllGather is ENQUEUED FROM ANOTHER THREAD, one per
+ *                          context -- a process that drives several contexts in this mode issues its collectives from that many
+ *                          unsynchronised threads (use MI_EXCHANGE_GROUPED, or MI_XCH_SYNC_ENQUEUE=1, when the order across
+ *                          contexts must be the caller's); (2) a failing all-gather is reported LATE -- not by the frame call that
+ *                          queued it but by the next frame call's exchange step or by mi_exchange_last / mi_exchange_download;
+ *                          (3) the thread polls for up to 500 us after its last job before it sleeps.  mi_exchange_set_mode is
+ *                          refused while the exchange is on, so the thread never outlives its mode.
  *   MI_EXCHANGE_PIPELINED  the latency-hiding variant built in round 1 against a 1-rank communicator: a library-owned host
  *                          thread enqueues the collectives, several communicators alternate by frame, the "masks complete"
  *                          signal is stored by the compaction kernel itself and awaited with hipStreamWaitValue32, buffer reuse
@@ -822,7 +829,7 @@ int32_t mi_exchange_configure_multi(mi_ctx* ctx, void* const* nccl_comms, uint32
                                     uint64_t block_bytes, uint32_t rank);
 /* The same with the gathered buffers owned by the library (a host without a device allocator of its own: the Rust plugin, the C++ host
  * layer): n_bufs buffers of world x block_bytes bytes each are allocated on the context's device, zeroed, and freed when the exchange is
- * reconfigured or the context destroyed. */
+ * reconfigured (with or without buffers of the caller's, or switched off) or the context destroyed. */
 int32_t mi_exchange_configure_owned(mi_ctx* ctx, void* const* nccl_comms, uint32_t n_comms, void* fn_nccl_all_gather, uint32_t n_bufs,
                                     uint32_t world, uint64_t words_per_view, uint64_t word_offset, uint64_t block_bytes, uint32_t rank);
 /* MI_EXCHANGE_GROUPED: issues the pending all-gather of every listed context inside one ncclGroupStart / ncclGroupEnd pair
@@ -834,7 +841,9 @@ int32_t mi_exchange_last(mi_ctx* ctx, void** out_device_buf, int32_t wait);
 
 /* The same buffer on the HOST: waits for the most recent frame's all-gather and copies the first `bytes` bytes of its gathered buffer
  * ([rank][view][word], 64-bit words; bytes = world x block_bytes for all of it) into out_host -- ONE device-to-host copy gives a
- * single-process host (a Bevy plugin driving several GPUs) every shard's ViewVisibility masks, whichever context it asks. */
+ * single-process host (a Bevy plugin driving several GPUs) every shard's ViewVisibility masks, whichever context it asks.
+ * Buffers of mi_exchange_configure_owned: bytes beyond world x block_bytes is MI_ERR_INVALID_ARG.  Buffers the caller bound
+ * (mi_exchange_configure / _multi): the library does not know their size -- bytes must not exceed what the caller allocated. */
 int32_t mi_exchange_download(mi_ctx* ctx, void* out_host, uint64_t bytes);
 
 /* Raw device pointers of library-owned columns, for zero-copy READERS on the same device (write through the upload entry points only:

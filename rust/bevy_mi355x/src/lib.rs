@@ -88,6 +88,8 @@ use bevy_light::{
     SimulationLightSystems, SpotLight, VolumetricLight,
 };
 use bevy_log::error;
+#[cfg(feature = "trace")]
+use bevy_log::info_span;
 use bevy_math::{Affine3A, UVec2, UVec3};
 use bevy_mesh::Mesh3d;
 use bevy_platform::collections::HashMap;
@@ -497,6 +499,9 @@ pub fn mi_propagate_transforms(
     transforms: Query<(Entity, Ref<Transform>, Option<&ChildOf>)>,
     mut globals: Query<&mut GlobalTransform>,
 ) {
+    // (as the reference does inside its own systems, crates/bevy_transform/src/systems.rs:169-283, :592: a span per stage under `trace`)
+    #[cfg(feature = "trace")]
+    let _span = info_span!("mi_propagate_transforms").entered();
     if fallback.transforms {
         return;
     }
@@ -521,6 +526,8 @@ fn upload_and_propagate(
     globals: &Query<&GlobalTransform>,
     frame: Option<()>,
 ) -> Result<u32, ()> {
+    #[cfg(feature = "trace")]
+    let _span = info_span!("mi355x upload + propagate").entered();
     let ctx = mi.ctx;
     mi.every_row_moved = false;
     let tables = transforms.contiguous_iter().expect("Transform and ChildOf are table components");
@@ -750,6 +757,8 @@ fn upload_and_propagate(
 
 /// `scratch.rows[..count]` / `scratch.global12` -> `Mut<GlobalTransform>`.
 fn write_back_global_transforms(mi: &Mi355x, count: u32, globals: &mut Query<&mut GlobalTransform>) {
+    #[cfg(feature = "trace")]
+    let _span = info_span!("mi355x write back GlobalTransform").entered();
     let s = &mi.scratch;
     for (k, row) in s.rows[..count as usize].iter().enumerate() {
         let cols: &[f32; 12] = s.global12[k * 12..k * 12 + 12].try_into().unwrap();
@@ -775,6 +784,8 @@ pub fn mi_check_visibility(
     visible_entity_ranges: Option<Res<VisibleEntityRanges>>,
     mut view_visibilities: Query<&mut ViewVisibility, Without<NoCpuCulling>>,
 ) {
+    #[cfg(feature = "trace")]
+    let _span = info_span!("mi_check_visibility").entered();
     let _ = ticks;
     if fallback.visibility || fallback.transforms {
         // without the device-resident GlobalTransform column there is nothing to cull against
@@ -988,6 +999,8 @@ pub fn mi_assign_objects_to_clusters(
     decals: Query<(Entity, &GlobalTransform, &ViewVisibility), With<ClusteredDecal>>,
     settings: Option<Res<GlobalClusterSettings>>,
 ) {
+    #[cfg(feature = "trace")]
+    let _span = info_span!("mi_assign_objects_to_clusters").entered();
     let Some(settings) = settings else { return };
     if fallback.clusters || settings.gpu_clustering.is_some() {
         // wgpu-side clustering is a different path (assign.rs:187); leave it to the stock system
@@ -1275,6 +1288,8 @@ pub fn mi_check_light_mesh_visibility(
     mut view_visibilities: Query<&mut ViewVisibility, (Without<NoCpuCulling>, Without<DirectionalLight>)>,
     mut checked_lights: Local<EntityHashSet>,
 ) {
+    #[cfg(feature = "trace")]
+    let _span = info_span!("mi_check_light_mesh_visibility").entered();
     if fallback.light_visibility || fallback.visibility || fallback.transforms {
         // the columns the shadow views are tested against (GlobalTransform, flags, ranges) are no longer kept current
         fallback.light_visibility = true;
@@ -1566,6 +1581,8 @@ pub fn mi_fused_frame(
     ),
     settings: Option<Res<GlobalClusterSettings>>,
 ) {
+    #[cfg(feature = "trace")]
+    let _span = info_span!("mi_fused_frame").entered();
     frame.valid = false;
     frame.clusters_valid = false;
     if fallback.transforms {
@@ -2067,6 +2084,8 @@ pub fn mi_apply_visibility(
     inputs: Query<(Ref<InheritedVisibility>, Option<Ref<Aabb>>, Option<Ref<Sphere>>, Option<Ref<RenderLayers>>, Option<Ref<VisibilityRange>>), Without<NoCpuCulling>>,
     mut view_visibilities: Query<&mut ViewVisibility, Without<NoCpuCulling>>,
 ) {
+    #[cfg(feature = "trace")]
+    let _span = info_span!("mi_apply_visibility").entered();
     if !frame.valid {
         return;
     }
@@ -2103,6 +2122,8 @@ pub fn mi_apply_visibility(
 
 /// In front of `SimulationLightSystems::AssignLightsToClusters`, fused form: the parked cluster lists become `Clusters`.
 pub fn mi_apply_clusters(mi: Res<Mi355x>, mut frame: ResMut<Mi355xFrame>, mut views: Query<&mut Clusters>) {
+    #[cfg(feature = "trace")]
+    let _span = info_span!("mi_apply_clusters").entered();
     if !frame.valid {
         frame.clusters_valid = false; // the lights' ViewVisibility was decided by the cull that has just been dropped
     }

@@ -169,6 +169,8 @@ pub fn mi_sharded_frame(
     rows_query: RowsQuery,
     (range_views, visible_entity_ranges): (RangeViews, Option<Res<VisibleEntityRanges>>),
 ) {
+    #[cfg(feature = "trace")]
+    let _span = bevy_log::info_span!("mi_sharded_frame").entered();
     frame.valid = false;
     frame.clusters_valid = false;
     if fallback.transforms {

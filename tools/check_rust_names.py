@@ -52,6 +52,9 @@ create unwrap_or_else trailing_zeros and_then map_err""".split())
 GLAM_METHODS = set("""to_cols_array to_array length from_cols_array from_array truncate extend normalize dot cross mul_vec3 transform_point3
 transform_point3a transform_vector3 inverse abs max_element min_element splat from_rotation_y from_rotation_x from_rotation_z
 from_axis_angle from_euler looking_at from_xyz from_scale_rotation_translation to_scale_rotation_translation as_vec3 as_uvec2 xyz""".split())
+# methods of the `tracing` crate (bevy_log re-exports its macros; the crate itself is not in the checkout): `Span::entered`, as the
+# reference calls it at crates/bevy_transform/src/systems.rs:592
+TRACING_METHODS = {"entered", "in_scope", "instrument"}
 # a method that only resolves with its trait in scope -> the trait
 TRAIT_METHODS = {
     "intern": "ScheduleLabel",
@@ -184,7 +187,7 @@ def check_text(rel, text, names, problems):
     own = set(re.findall(r"\bfn\s+([a-z_][a-z0-9_]*)", s))
     methods = set(re.findall(r"(?<!\.)\.([a-z_][a-z0-9_]*)\s*(?:::<[^>]*>)?\(", s))
     for m in sorted(methods):
-        if m in own or m in STD_METHODS or m in GLAM_METHODS:
+        if m in own or m in STD_METHODS or m in GLAM_METHODS or m in TRACING_METHODS:
             continue
         if not grep(r"\bfn\s+" + m + r"\b", REF):
             problems.append("%s: no `fn %s` anywhere in the reference" % (rel, m))

@@ -242,27 +242,48 @@ def main():
                 out["config0_cpu_plumbing"] = cpu.config0_cpu_plumbing(args.cpu_seconds)
             elif workload in ("flat", "sharded"):
                 out["cpu_baseline"] = cpu.cpu_baseline_flat(wl, args.cpu_seconds, wl.n_views)
+            elif workload == "tree" and args.tree_shape:
+                out["cpu_baseline"] = cpu.cpu_baseline_tree_shape(wl, args.tree_shape_frame)
             else:
                 out["cpu_baseline"] = cpu.cpu_baseline_other(workload, wl)
         if world == 1 and workload == "frame" and not args.no_end_to_end:
             with torch.cuda.stream(stream):
                 out["end_to_end"] = e2e.end_to_end(ctx, wl, cpu_frame_ms=(out["cpu_baseline"] or {}).get("frame_ms"))
             out["end_to_end_host_layer"] = e2e.end_to_end_host_layer(wl.units)
-    if world > 1 and workload == "sharded":
+    if use_dist and workload == "sharded" and getattr(wl, "gather", None) is not None:
+        # The first N > 1 run has to certify more than speed: after the timed region every rank runs ONE more frame
+        # with a known camera set, rank 0 fetches the GATHERED masks and compares them bit for bit with the masks of the same frame
+        # computed over the whole scene in ONE context on its own GPU; the collective's own latency (events on the communication
+        # stream) and every rank's kernel time go into the line as well.
+        VERIFY_FRAME = 3
+        with torch.cuda.stream(stream):
+            gathered = wl.gathered_masks(VERIFY_FRAME)
+        ag_us = wl.gather.all_gather_latency_us()
+        dk = prof.get(wl.dominant) or {}
+        mine = torch.tensor([float(dk.get("avg_us") or 0.0)], dtype=torch.float64, device="cuda")
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
         # the same scene, whole, on rank 0's GPU alone (outside the timed region): what N = 1 gives for THIS workload
-        single = None
+        single, match = None, None
         if rank == 0:
             c1 = api.Context(local_rank, stream.cuda_stream)
             with torch.cuda.stream(stream):
-                w1 = build_flat(c1, args, 0, 1, [], wl.global_units, wl.n_views, "sharded")
+                w1 = build_flat(c1, args, 0, 1, [], wl.global_units, wl.n_views, "sharded", no_gather=True)
                 t1, _, _ = measure(c1, w1, args.steps, args.warmup, 15)
+                whole = w1.own_masks(VERIFY_FRAME)
             m1 = float(np.median(t1))
             single = {"value": round(wl.global_units * args.steps / m1, 1), "unit": wl.unit, "ms_per_step": round(1e3 * m1 / args.steps, 5),
                       "note": "the whole scene on rank 0's GPU alone, measured after the timed region while the other ranks wait"}
+            match = bool(gathered.shape == whole.shape and np.array_equal(gathered, whole))
+            if not match:
+                single["mask_bits_differing"] = int(np.count_nonzero(gathered != whole)) if gathered.shape == whole.shape else -1
             c1.close()
         dist.barrier()
         if rank == 0:
             out["single_gpu_same_workload"] = single
+            out["gathered_masks_match_single_gpu"] = match
+            out["all_gather_us"] = ag_us
+            out["kernel_us_per_rank"] = [round(float(t.item()), 2) for t in per_rank]
             # what the driver's curve cannot show (its N = 1 point is the metric frame, another workload): this line's value against the
             # SAME scene on one GPU, per GPU
             out["scaling_efficiency"] = round(out["value"] / (world * single["value"]), 4)
@@ -285,6 +306,11 @@ def main():
                 others[name]["batch_build_us_per_frame"] = round(1e3 * (others[name]["ms_per_step"] - others["flat"]["ms_per_step"]), 2)
             if not args.no_cpu_baseline and (name in ("tree", "lights", "batching") or name.startswith("batching_sorted")):
                 others[name]["cpu_baseline"] = cpu.cpu_baseline_other(name.split("_sorted")[0] + ("_sorted" if "_sorted" in name else ""), w2)
+            if not args.no_cpu_baseline and name.startswith("tree_shape_"):
+                # the CPU path beside every hierarchy shape: where the device LOSES (a chain) the table says so
+                cb = cpu.cpu_baseline_tree_shape(w2, "movers" if name.endswith("_movers") else "all", 0.5 if w2.units > 1_000_000 else 0.3)
+                cb["x_device_step"] = round(cb["ms_per_frame"] / others[name]["ms_per_step"], 2)  # > 1: the device's frame (kernels + its dirty-row upload) is faster
+                others[name]["cpu_baseline"] = cb
             c2.close()
         out["other_workloads"] = others
     if rank == 0:

@@ -107,6 +107,53 @@ def config0_cpu_plumbing(cpu_seconds):
     return out
 
 
+def cpu_baseline_tree_shape(wl, frame_kind, seconds=1.5):
+    """A hierarchy stress shape (examples/stress_tests/transform_hierarchy.rs:29-160) on the host cores, the same frame the device ran.
+    all: every Transform changed -- the level-parallel port over a sweep of thread counts (a chain wants ONE thread: a level is a barrier,
+    and 2 500 barriers cost more than 2 500 products), best quoted.  movers: mark_dirty_trees + propagate_parent_transforms under
+    StaticTransformOptimizations on one thread (the oracle's change-driven form has no pool; the reference's work queue would spread
+    the moved subtrees over the task pool -- divide by the cores that many subtrees would keep busy to bound it from below)."""
+    import ctypes as C
+    import oracle_lib as O
+    sh = wl.tree
+    n, cores = int(sh["n"]), os.cpu_count() or 1
+    if frame_kind == "movers" and len(sh["movers"]):
+        changed = np.zeros(n, np.uint8)
+        changed[sh["movers"]] = 1
+        g = np.zeros(12 * n, np.float32)
+        out_changed = np.zeros(n, np.uint8)
+        tc = np.zeros(n, np.uint8)
+        L = O.lib()
+        a = (n, O.u32p(sh["parent"]), O.fp(sh["translation"]), O.fp(sh["rotation"]), O.fp(sh["scale"]))
+        L.orc_propagate_transforms(*a, 0, None, None, O.fp(g), O.u8p(out_changed))  # the resident GlobalTransforms
+        def frame():
+            L.orc_mark_dirty_trees(n, O.u32p(sh["parent"]), O.u8p(changed), O.u8p(tc))
+            L.orc_propagate_transforms(*a, 1, O.u8p(tc), O.u8p(changed), O.fp(g), O.u8p(out_changed))
+        t0 = time.perf_counter(); frame(); one = time.perf_counter() - t0
+        iters = int(max(2, min(2000, seconds / max(one, 1e-5))))
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            frame()
+        secs = time.perf_counter() - t0
+        return {"value": round(n * iters / secs, 1), "unit": "nodes/s", "cores": 1, "kind": "port", "ms_per_frame": round(1e3 * secs / iters, 4), "host_cores": cores,
+                "sample": f"{iters} frames of {n} nodes, {len(sh['movers'])} movers: oracle C port of mark_dirty_trees + propagate_parent_transforms under "
+                          f"StaticTransformOptimizations on 1 thread, {secs:.2f}s"}
+    a = (sh["parent"], sh["level_offsets"], sh["translation"], sh["rotation"], sh["scale"])
+    sweep, best = {}, None
+    for th in sorted({min(cores, x) for x in (1, 4, 16, 64, cores)}):
+        one, _ = O.bench_tree_frame(*a, th, 1)
+        iters = int(max(1, min(2000, seconds / 5.0 / max(one, 1e-5))))
+        secs, _ = O.bench_tree_frame(*a, th, iters)
+        ms = 1e3 * secs / iters
+        sweep[f"{th} threads"] = round(ms, 4)
+        if best is None or ms < best[0]:
+            best = (ms, th, iters)
+    return {"value": round(n / (best[0] * 1e-3), 1), "unit": "nodes/s", "cores": best[1], "kind": "port", "ms_per_frame": round(best[0], 4), "host_cores": cores,
+            "thread_sweep_ms_per_frame": sweep,
+            "sample": f"{best[2]} frames of {n} nodes in {sh['n_levels']} levels, every Transform changed: oracle C port of propagate_parent_transforms (set_if_neq), rows of a "
+                      f"level split over a persistent pool, levels in order -- best of a sweep over thread counts: {best[1]} threads, {best[0]:.4f} ms/frame"}
+
+
 def cpu_baseline_other(name, wl):
     """The oracle's C port of the same stage on the host: the hierarchy on all cores (rows of a level in parallel, levels in
     order -- the parallelism propagate_parent_transforms gets from the task pool), assign_objects_to_clusters and the batch

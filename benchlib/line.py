@@ -14,7 +14,7 @@ FULL_NAME = "bench_full.json"
 # keys of the compact line, in order; `scaling` only at N > 1
 TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data", "config", "roofline", "cpu_baseline")
-ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "avg_kernel_us", "launches",
+ROOFLINE_KEYS = ("bound", "bound_note", "working_set_mib", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "avg_kernel_us", "launches",
                  "moved_bytes_per_launch", "algorithmic_bytes_per_launch", "frac_algorithmic", "rocprof_avg_kernel_us")
 CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "host_cores")
 CONFIG_KEYS = ("workload", "baseline_config", "entities", "entities_total", "entities_this_rank", "rows_per_frame", "nodes", "lights",
@@ -53,10 +53,18 @@ def compact(out):
         line["end_to_end"] = {"us_per_frame": {k: v["us_per_frame"] for k, v in e2e.items() if isinstance(v, dict) and "us_per_frame" in v},
                               "library_us": {k: v["library_us"] for k, v in e2e.items() if isinstance(v, dict) and "library_us" in v},
                               "x_cpu_port": e2e["x_cpu_port"], "x_cpu_port_library_calls": e2e.get("x_cpu_port_library_calls")}
+    pc = (out.get("other_workloads") or {}).get("frame_plain_columns")
+    if pc:
+        # the metric frame's scene is the row summary's best case (every cube shares one Aabb / flags / RenderLayers): the same frame
+        # with every row reading its own columns, beside it
+        line["plain_columns"] = {"ms_per_step": pc["ms_per_step"], "value": pc["value"], "frac": (pc.get("roofline") or {}).get("frac"),
+                                 "note": "the same frame, every row reading its own Aabb / flags / RenderLayers (no row summary)"}
     sg = out.get("single_gpu_same_workload")
     if sg:
         line["single_gpu_same_workload"] = {"value": sg["value"], "ms_per_step": sg["ms_per_step"]}
-    for k in ("scaling_efficiency", "host_enqueue_ms_per_step"):  # N > 1: value / (n_gpus x the same workload on ONE GPU); CPU time per frame call
+    # N > 1: value / (n_gpus x the same workload on ONE GPU); CPU time per frame call; the gathered masks against the masks of the whole
+    # scene in one context, bit for bit; the collective alone (events on its stream); every rank's frame kernel
+    for k in ("scaling_efficiency", "host_enqueue_ms_per_step", "gathered_masks_match_single_gpu", "all_gather_us", "kernel_us_per_rank"):
         if k in out:
             line[k] = out[k]
     line["full"] = FULL_NAME

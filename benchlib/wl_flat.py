@@ -6,7 +6,7 @@ import numpy as np
 from .common import N_FRAMES, ROW_SUMMARY_SAVES, Workload, camera_frusta, flat_bytes_per_entity
 
 
-def build_flat(ctx, args, rank, world, full_holder, n_global, n_views, name):
+def build_flat(ctx, args, rank, world, full_holder, n_global, n_views, name, no_gather=False):
     import torch
     import bevy_amd as B
     from bevy_amd import api, sharding, workloads as W
@@ -20,7 +20,7 @@ def build_flat(ctx, args, rank, world, full_holder, n_global, n_views, name):
     ctx.upload_bounds(scene["aabb_center"], scene["aabb_half"], scene["flags"], scene["layers"])
     frames = [api.PreparedFrusta(camera_frusta(n_views, f)) for f in range(N_FRAMES)]
     gather = None
-    if world > 1 or os.environ.get("MI_FORCE_GATHER") == "1" or os.environ.get("MI_FORCE_DIST") == "1":
+    if not no_gather and (world > 1 or os.environ.get("MI_FORCE_GATHER") == "1" or os.environ.get("MI_FORCE_DIST") == "1"):
         gather = sharding.MaskGatherer(n_global, world, n_views, rank, device=torch.device("cuda", torch.cuda.current_device()))
         full_holder.append(gather)
         gather.attach(ctx)  # direct RCCL available: the library issues the exchange itself, one FFI call per frame
@@ -76,6 +76,27 @@ def build_flat(ctx, args, rank, world, full_holder, n_global, n_views, name):
                   "k_cull" if args.unfused else "k_flat_propagate_cull", config, metric, "entities/s",
                   kernels=["k_cull" if args.unfused else "k_flat_propagate_cull", "k_compact_fast"])
     wl.scene, wl.n_views, wl.global_units = scene, n_views, n_global
+    wl.gather = gather
+
+    def gathered_masks(frame):
+        """One more frame with camera set `frame` (every rank calls it: the frame's all-gather is a collective) -> the gathered
+        masks on the host, bool [views][n_global] (None without an exchange)."""
+        if gather is None:
+            return None
+        step(frame)
+        if gather.native:
+            words = ctx.exchange_download(gather.world * gather.block * 8)
+        else:
+            gather.synchronize()
+            ctx.synchronize()
+            words = gather.buffer(fcount[0] - 1).cpu().numpy()
+        return gather.unpack_gathered(words)
+
+    def own_masks(frame):
+        """The same frame's masks of a context that holds the whole scene (the single-GPU run): bool [views][n]."""
+        step(frame)
+        return np.stack([ctx.download_visibility(v) for v in range(n_views)]).astype(bool)
+    wl.gathered_masks, wl.own_masks = gathered_masks, own_masks
     # (the timer slot's name is not the symbol's; 2 .. 4 camera views take the pair-pass kernel unless MI_MULTI_VIEW=1)
     pairs = 2 <= n_views <= 4 and os.environ.get("MI_MULTI_VIEW", "0") != "1"
     wl.kernel_name = "k_frame<0>" if args.unfused else "k_frame_pairs<1>" if pairs else "k_frame<1,true,0>"

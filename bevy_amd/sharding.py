@@ -276,6 +276,37 @@ class MaskGatherer:
         if self.on_gpu:
             self.comm_stream.synchronize()
 
+    def all_gather_latency_us(self, reps=50):
+        """The collective by itself: `reps` all-gathers of one frame's masks back to back on the communication stream, between two
+        events on THAT stream (the stream the all-gather runs on) -- what the exchange costs when nothing hides it.  Every rank must
+        call it (it is a collective); a scratch buffer of the gathered size, so no frame's masks are touched.  None without direct
+        RCCL."""
+        if self.rccl is None or not self.on_gpu:
+            return None
+        torch = self.torch
+        scratch = torch.zeros_like(self.bufs[0])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(5):
+            self._rccl_all_gather(scratch, self.comm_stream.cuda_stream)
+        self.comm_stream.synchronize()
+        e0.record(self.comm_stream)
+        for _ in range(reps):
+            self._rccl_all_gather(scratch, self.comm_stream.cuda_stream)
+        e1.record(self.comm_stream)
+        self.comm_stream.synchronize()
+        return round(1e3 * e0.elapsed_time(e1) / reps, 2)
+
+    def unpack_gathered(self, words):
+        """[world][n_views][w] uint64 words (host) -> bool [n_views][n_rows]: the masks of the whole scene as the gather holds them."""
+        w = np.asarray(words).view(np.uint64).reshape(self.world, self.n_views, self.w)
+        out = np.zeros((self.n_views, self.n_rows), bool)
+        for r in range(self.world):
+            lo, hi = shard_rows(self.n_rows, self.world, r)
+            if hi > lo:
+                bits = np.unpackbits(w[r].view(np.uint8), axis=1, bitorder="little")[:, :hi - lo]
+                out[:, lo:hi] = bits.astype(bool)
+        return out
+
     def close(self):
         if self.rccl is not None:
             self.synchronize()

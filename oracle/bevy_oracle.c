@@ -1716,6 +1716,21 @@ static void* tree_worker(void* p) {
 double orc_bench_tree_frame(uint32_t n, const uint32_t* parent, const uint32_t* level_offsets, uint32_t n_levels, const float* t,
                             const float* r, const float* s, float* g, int threads, int iters) {
     if (threads < 1) threads = 1;
+    if (threads == 1) { /* one core: rows in level order ARE a valid sequential order -- one sweep, no pool, no barriers (what a
+                           deep narrow hierarchy wants: a chain is 2 500 levels of one row) */
+        tree_job_t j;
+        j.parent = parent; j.t = t; j.r = r; j.s = s; j.g = g;
+        struct timespec a1, b1;
+        clock_gettime(CLOCK_MONOTONIC, &a1);
+        for (int it = 0; it < iters; ++it) {
+            j.lo = level_offsets[0]; j.hi = level_offsets[1]; j.root_level = 1;
+            tree_job_run(&j);
+            j.lo = level_offsets[1]; j.hi = level_offsets[n_levels]; j.root_level = 0;
+            if (n_levels > 1) tree_job_run(&j);
+        }
+        clock_gettime(CLOCK_MONOTONIC, &b1);
+        return (double)(b1.tv_sec - a1.tv_sec) + 1e-9 * (double)(b1.tv_nsec - a1.tv_nsec);
+    }
     tree_job_t* jobs = (tree_job_t*)calloc((size_t)threads, sizeof(tree_job_t));
     pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
     tree_arg_t* args = (tree_arg_t*)calloc((size_t)threads, sizeof(tree_arg_t));

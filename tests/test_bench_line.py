@@ -16,7 +16,8 @@ def canned(n_gpus=1):
     roof = {"bound": "hbm", "kernel": "k_frame<1,true,true>", "timer_slot": "k_flat_propagate_cull", "achieved": 5100.0, "peak": 8000.0, "unit": "GB/s",
             "frac": 0.6375, "traffic": 106_600_000, "traffic_source": "live: " + long, "avg_kernel_us": 20.1, "launches": 60,
             "moved_bytes_per_launch": 100_900_000, "algorithmic_bytes_per_launch": 132_500_000, "frac_algorithmic": 0.82, "timing": long,
-            "layout_note": long, "rocprof_avg_kernel_us": 20.6, "rocprof_frac": 0.61, "rocprof_source": long}
+            "layout_note": long, "rocprof_avg_kernel_us": 20.6, "rocprof_frac": 0.61, "rocprof_source": long,
+            "bound_note": "hbm (working set MALL-resident: 96 MiB per launch < the 256 MiB Infinity Cache)", "working_set_mib": 96.2}
     out = {"metric": "entities/sec through propagate+cull+cluster at 1M entities", "value": 4.9e10, "unit": "entities/s", "n_gpus": n_gpus, "steps": 20,
            "warmup": 5, "ms_per_step": 0.0204, "higher_is_better": True, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": long, "baseline_config": "BASELINE.json configs[1] + configs[2]", "entities": 1_000_000, "rows_per_frame": 1_110_000,
@@ -31,12 +32,14 @@ def canned(n_gpus=1):
                           "100pct_dirty": {"us_per_frame": 2090.0}, "x_cpu_port": {"1pct_dirty": 15.9, "10pct_dirty": 1.6, "100pct_dirty": 1.38},
                           "note": long},
            "end_to_end_host_layer": {"note": long}, "other_workloads": {f"w{i}": {"config": {"workload": long}, "roofline": roof} for i in range(19)}}
+    out["other_workloads"]["frame_plain_columns"] = {"ms_per_step": 0.0257, "value": 3.9e10, "roofline": dict(roof, frac=0.67), "config": {"workload": long}}
     if n_gpus > 1:
         out.update({"scaling": "strong", "metric": "entities/sec through propagate+cull (10M entities x 4 frusta, 1/2/4/8-GPU scaling)",
                     "cpu_baseline": None, "single_gpu_same_workload": {"value": 5.5e10, "unit": "entities/s", "ms_per_step": 0.18, "note": long}})
         out["config"].update({"entities_total": 10_000_000, "entities_this_rank": 1_250_000, "parallelism": "row-range shard x8", "rccl_ranks": 8,
                               "exchange_mode": "rccl-native, ncclAllGather enqueued by the library's exchange thread"})
-        out.update({"scaling_efficiency": 0.81, "host_enqueue_ms_per_step": 0.0093})
+        out.update({"scaling_efficiency": 0.81, "host_enqueue_ms_per_step": 0.0093, "gathered_masks_match_single_gpu": True, "all_gather_us": 14.2,
+                    "kernel_us_per_rank": [22.1] * n_gpus})
         del out["end_to_end"], out["other_workloads"]
     return out
 
@@ -58,6 +61,10 @@ def test_single_gpu_line_is_compact_and_complete():
     assert "other_workloads" not in d and d["full"] == L.FULL_NAME
     # frac is the bytes-moved figure: never above the algorithmic one
     assert d["roofline"]["frac"] <= d["roofline"]["frac_algorithmic"]
+    # the honest headline: the contract's enum stays, what "hbm" means at this size is said beside it, and the
+    # same frame without the row summary's best case travels in the line
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["bound_note"].startswith("hbm (working set MALL-resident")
+    assert d["plain_columns"]["ms_per_step"] == 0.0257 and d["plain_columns"]["frac"] == 0.67
 
 
 def test_sharded_line_is_compact_and_complete():
@@ -69,6 +76,40 @@ def test_sharded_line_is_compact_and_complete():
     # what the exchange was and what it cost the calling thread, next to the efficiency against the same scene on one GPU
     assert d["config"]["rccl_ranks"] == 8 and d["config"]["exchange_mode"].startswith("rccl-native")
     assert d["scaling_efficiency"] == 0.81 and d["host_enqueue_ms_per_step"] == 0.0093
+    # the first N > 1 run certifies itself: gathered masks against the whole scene in one context, the collective alone, every rank's kernel
+    assert d["gathered_masks_match_single_gpu"] is True and d["all_gather_us"] == 14.2 and len(d["kernel_us_per_rank"]) == 8
+
+
+def test_roofline_says_where_the_bytes_live():
+    from benchlib.measure import roofline_of
+
+    class W:
+        dominant, name, kernel_name = "k_flat_propagate_cull", "x_not_in_profiles", "k_frame<1,true,0>"
+        bytes_per_row, rows, layout_bytes_per_row = 119.0, 1_000_000, None
+    r = roofline_of(W, {"k_flat_propagate_cull": {"avg_us": 20.0, "launches": 60}}, 20)
+    assert r["bound"] == "hbm" and "MALL-resident" in r["bound_note"] and 113 < r["working_set_mib"] < 114
+    W.rows = 10_000_000
+    r = roofline_of(W, {"k_flat_propagate_cull": {"avg_us": 150.0, "launches": 60}}, 20)
+    assert r["bound"] == "hbm" and "beyond the Infinity Cache" in r["bound_note"]
+
+
+def test_unpack_gathered_masks():
+    """MaskGatherer.unpack_gathered: [world][views][w] words -> bool [views][rows], shard by shard (what bench.py --gpus N compares with
+    the single-context masks)."""
+    import numpy as np
+    from bevy_amd import sharding
+    n, world, views = 1000, 3, 2
+    g = sharding.MaskGatherer(n, world, views, 0, device=None, direct=False)
+    rng = np.random.default_rng(1)
+    want = rng.random((views, n)) < 0.3
+    words = np.zeros((world, views, g.w), np.uint64)
+    for r in range(world):
+        lo, hi = sharding.shard_rows(n, world, r)
+        for v in range(views):
+            bits = np.zeros(g.w * 64, np.uint8)
+            bits[:hi - lo] = want[v, lo:hi]
+            words[r, v] = np.packbits(bits, bitorder="little").view(np.uint64)
+    assert np.array_equal(g.unpack_gathered(words.reshape(-1)), want)
 
 
 def test_the_stage_list_leads_the_workload_string():

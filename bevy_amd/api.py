@@ -206,7 +206,7 @@ ABI_SYMBOLS = [
 # include/bevy_mi355x_debug.h: instrumentation and test hooks, exported by the same library, not part of the boundary
 DEBUG_SYMBOLS = [
     "mi_timer_begin", "mi_timer_end", "mi_profile_enable", "mi_profile_filter", "mi_profile_sample", "mi_profile_burst", "mi_profile_read",
-    "mi_profile_kernel_name", "mi_debug_set_tile_mode", "mi_debug_tree_trace", "mi_debug_tile_plan", "mi_debug_logf", "mi_debug_set_sphere_path", "mi_debug_set_row_summary", "mi_debug_set_tree_cull", "mi_debug_set_walk_inrow", "mi_debug_set_chunked_frames", "mi_debug_chunked_counts", "mi_debug_set_tile_pretest", "mi_debug_set_sorted_one_wg_limit", "mi_debug_set_static_cull_order", "mi_debug_static_cull_counts", "mi_debug_cluster_download_unjoined",
+    "mi_profile_kernel_name", "mi_debug_set_tile_mode", "mi_debug_tree_trace", "mi_debug_tile_plan", "mi_debug_tile_groups", "mi_debug_logf", "mi_debug_set_sphere_path", "mi_debug_set_row_summary", "mi_debug_set_tree_cull", "mi_debug_set_walk_inrow", "mi_debug_set_chunked_frames", "mi_debug_chunked_counts", "mi_debug_set_tile_pretest", "mi_debug_set_sorted_one_wg_limit", "mi_debug_set_static_cull_order", "mi_debug_static_cull_counts", "mi_debug_cluster_download_unjoined",
 ]
 
 
@@ -890,6 +890,16 @@ class Context:
         v = [C.c_uint32(0) for _ in range(4)]
         self._ck(self._lib.mi_debug_tile_plan(self._h, *[C.byref(x) for x in v]))
         return dict(launches=v[0].value, tiles=v[1].value, chain_tiles=v[2].value, bands=v[3].value)
+
+    def debug_tile_groups(self, cap_tiles=1 << 20):
+        """-> (groups [n][4]: first tile, tiles, chain tiles, deep; tiles [n][3]: levels, rows, chain length | 0x100 roots) of the tile plan."""
+        g = np.zeros(4 * 64, np.uint32)
+        ng = C.c_uint32(0)
+        t = np.zeros(3 * cap_tiles, np.uint32)
+        self._ck(self._lib.mi_debug_tile_groups(self._h, _ptr(g, C.c_uint32), 64, C.byref(ng), _ptr(t, C.c_uint32), cap_tiles))
+        groups = g.reshape(-1, 4)[:ng.value]
+        n_tiles = int((groups[:, 0] + groups[:, 1]).max()) if len(groups) else 0
+        return groups, t.reshape(-1, 3)[:n_tiles]
 
     def debug_set_sorted_one_wg_limit(self, items):
         """Sorted phases up to `items` long take the single-workgroup kernel; 0 = always the tiled form (test / bench hook)."""

@@ -91,6 +91,10 @@ struct mi_ctx {
     bool narrow = false;            // every level is at most a wave wide and there are more levels than a tile spans: one wave walks the hierarchy (k_propagate_narrow)
     bool narrow_quad = false;       // ... and no level holds more than 16 rows
     DevBuf level_offs_dev;          // level_offsets on the device (that kernel reads them)
+    bool wave_forest = false;       // a forest every tree of which fits a wave tile: a wave per tile walks it (k_propagate_wave_tiles)
+    bool wave_quad = false;         // ... and no level of any tile holds more than 16 rows
+    uint32_t n_wtiles = 0;
+    DevBuf wtiles;                  // the wave tiles (TileDesc, kind TILE_ROOTS)
     bool by_levels = false;         // the row count overflows the tile kernel's 32-bit offsets (or mi_debug_set_tile_mode(1)): mi_propagate sweeps level by level
     DevBuf anc;                     // the ancestor table (kernels.h, ANC_DEPTH): built by mi_upload_hierarchy; in use while anc_valid
     bool anc_valid = false;

@@ -24,6 +24,7 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
         ctx->groups.clear();
         ctx->stream_levels.clear();
         ctx->narrow = false;
+        ctx->wave_forest = false;
         return MI_OK;
     }
     if (!level_offsets) return fail(ctx, MI_ERR_INVALID_ARG, "mi_upload_hierarchy: level_offsets NULL");
@@ -304,6 +305,65 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
         if ((rc = ensure(ctx, ctx->level_offs_dev, ((size_t)n_levels + 1) * 4))) return rc;
         if ((rc = upload(ctx, ctx->level_offs_dev.p, level_offsets, ((size_t)n_levels + 1) * 4))) return rc;
     }
+    // A forest of small trees (humanoid rigs: transform_hierarchy.rs:493-561; most of a game's scene): when EVERY root's tree fits a
+    // wave tile -- <= TILE_MAX_LEVELS levels, <= WAVE_TILE_ROWS rows, no level wider than a wave -- a wave per tile walks it
+    // (k_propagate_wave_tiles): consecutive roots are packed into one tile while the limits hold, first with at most 16 rows to a
+    // level (a node per quad of lanes), else with at most 64.  Deep enough for the serial level steps to be what a tile costs
+    // (>= 5 levels): a shallow forest is bandwidth, which the workgroup tiles are built for.  mi_debug_set_tile_mode(4) plans without.
+    ctx->wave_forest = false;
+    ctx->n_wtiles = 0;
+    if (n_levels >= 5 && n_levels <= TILE_MAX_LEVELS && !ctx->narrow && (ctx->tile_mode == 0 || ctx->tile_mode == 2 || ctx->tile_mode == 3)) {
+        auto wave_tile = [&](uint32_t lo, uint32_t hi, uint32_t max_w, TileDesc& td) -> bool {
+            td = TileDesc{};
+            uint32_t clo = lo, chi = hi, total = 0;
+            for (uint32_t k = 0; k < n_levels && chi > clo; ++k) {
+                td.start[k] = clo;
+                td.count[k] = chi - clo;
+                td.n_levels = k + 1;
+                total += chi - clo;
+                if (chi - clo > max_w || total > WAVE_TILE_ROWS) return false;
+                if (k + 1 < n_levels) {
+                    const uint32_t nlo = child_begin(k, clo), nhi = child_begin(k, chi);
+                    clo = nlo;
+                    chi = nhi;
+                } else {
+                    clo = chi;
+                }
+            }
+            td.kind = TILE_ROOTS;
+            return true;
+        };
+        const uint32_t n_roots = level_offsets[1];
+        for (uint32_t max_w : {16u, 64u}) {
+            std::vector<TileDesc> wt;
+            bool ok = true;
+            uint32_t a0 = 0;
+            while (a0 < n_roots && ok) {
+                TileDesc best{};
+                uint32_t b = a0 + 1;
+                ok = wave_tile(a0, b, max_w, best);
+                if (!ok) break;
+                uint32_t step = 1;
+                while (b < n_roots) {  // galloping extension of the root range while the tile still fits
+                    const uint32_t nb = (uint32_t)std::min<uint64_t>((uint64_t)b + step, n_roots);
+                    TileDesc cand{};
+                    if (wave_tile(a0, nb, max_w, cand)) { best = cand; b = nb; step *= 2; }
+                    else if (step > 1) step = 1;
+                    else break;
+                }
+                wt.push_back(best);
+                a0 = b;
+            }
+            if (ok && !wt.empty()) {
+                if ((rc = ensure(ctx, ctx->wtiles, wt.size() * sizeof(TileDesc)))) return rc;
+                if ((rc = upload(ctx, ctx->wtiles.p, wt.data(), wt.size() * sizeof(TileDesc)))) return rc;
+                ctx->wave_forest = true;
+                ctx->wave_quad = max_w == 16u;
+                ctx->n_wtiles = (uint32_t)wt.size();
+                break;
+            }
+        }
+    }
     ctx->have_hierarchy = true;
     // the ancestor table for mark_dirty_trees (kernels.h): level by level on the device, behind the parent_idx upload
     ctx->anc_valid = false;
@@ -318,10 +378,10 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
 
 // test / bench hook (not part of the public header): which tile kernel the NEXT mi_upload_hierarchy plans for
 // (0 = tiles where they fit, 1 = level by level whatever the shape, 2 = as 0 (the light tiles of earlier rounds), 3 = as 0 with the
-// streamed-level thresholds at their test values)
+// streamed-level thresholds at their test values, 4 = as 0 without the wave tiles of a forest of small trees)
 int32_t mi_debug_set_tile_mode(mi_ctx* ctx, int32_t mode) {
     ENTER(ctx);
-    if (mode < 0 || mode > 3) return fail(ctx, MI_ERR_INVALID_ARG, "mi_debug_set_tile_mode: mode %d", mode);
+    if (mode < 0 || mode > 4) return fail(ctx, MI_ERR_INVALID_ARG, "mi_debug_set_tile_mode: mode %d", mode);
     ctx->tile_mode = mode;
     return MI_OK;
 }
@@ -333,7 +393,7 @@ int32_t mi_debug_tree_trace(mi_ctx* ctx, int32_t enable, unsigned long long* out
     ENTER(ctx);
     if (enable) {
         size_t tiles = 1;
-        for (auto& g : ctx->groups) tiles = std::max<size_t>(tiles, g.count);
+        for (auto& g : ctx->groups) tiles = std::max<size_t>(tiles, (size_t)g.first + g.count);  // (every launch's tiles at their own place)
         int32_t rc = ensure(ctx, ctx->tree_trace, tiles * 64);
         if (rc) return rc;
         HIP_TRY(ctx, hipMemsetAsync(ctx->tree_trace.p, 0, tiles * 64, ctx->stream));
@@ -352,10 +412,42 @@ int32_t mi_debug_tile_plan(mi_ctx* ctx, uint32_t* out_launches, uint32_t* out_ti
     ENTER(ctx);
     uint32_t tiles = 0, chain = 0;
     for (auto& g : ctx->groups) { tiles += g.count; chain += g.n_chain; }
-    if (out_launches) *out_launches = ctx->by_levels ? ctx->n_levels : (uint32_t)ctx->groups.size();  // (tile launches; by levels: one per level)
+    if (out_launches) *out_launches = ctx->by_levels ? ctx->n_levels : ctx->wave_forest ? 1u : (uint32_t)ctx->groups.size();  // (tile launches; by levels: one per level)
+    if (ctx->wave_forest && !ctx->by_levels) tiles = ctx->n_wtiles, chain = 0;  // (the wave tiles of a forest of small trees: one launch)
     if (out_tiles) *out_tiles = tiles;
     if (out_chain_tiles) *out_chain_tiles = chain;
     if (out_bands) *out_bands = (uint32_t)ctx->passes.size();
+    return MI_OK;
+}
+
+// development hook: the launches of the current tile plan -- per group (first tile, tiles, chain tiles, deep instantiation) -- and per
+// tile (levels, rows, chain length | 0x100 for a roots tile) (tools/shape_trace.py)
+int32_t mi_debug_tile_groups(mi_ctx* ctx, uint32_t* out_groups, uint32_t cap_groups, uint32_t* out_n_groups, uint32_t* out_tiles, uint32_t cap_tiles) {
+    ENTER(ctx);
+    uint32_t ng = 0;
+    for (auto& g : ctx->groups) {
+        if (out_groups && ng < cap_groups) {
+            out_groups[4 * ng] = g.first;
+            out_groups[4 * ng + 1] = g.count;
+            out_groups[4 * ng + 2] = g.n_chain;
+            out_groups[4 * ng + 3] = g.deep ? 1u : 0u;
+        }
+        ++ng;
+    }
+    if (out_n_groups) *out_n_groups = ng;
+    if (out_tiles && cap_tiles && ctx->tiles.p) {
+        const size_t nt = std::min<size_t>(cap_tiles, ctx->tiles.bytes / sizeof(TileDesc));
+        std::vector<TileDesc> td(nt);
+        int32_t rc = download(ctx, td.data(), ctx->tiles.p, nt * sizeof(TileDesc));
+        if (rc) return rc;
+        for (size_t i = 0; i < nt; ++i) {
+            uint32_t rows = 0;
+            for (uint32_t k = 0; k < td[i].n_levels && k < TILE_MAX_LEVELS; ++k) rows += td[i].count[k];
+            out_tiles[3 * i] = td[i].n_levels;
+            out_tiles[3 * i + 1] = rows;
+            out_tiles[3 * i + 2] = (td[i].kind & TILE_CHAIN_MASK) | ((td[i].kind & TILE_ROOTS) ? 0x100u : 0u);
+        }
+    }
     return MI_OK;
 }
 

@@ -504,6 +504,12 @@ struct TreeCull {
 hipError_t launch_propagate_narrow(const Columns& c, const uint32_t* parent_idx, const uint32_t* level_offsets, uint32_t n_levels,
                                    const uint8_t* node_flags, const uint8_t* changed, const uint8_t* tree_bytes, uint8_t* g_changed_bytes, bool all_dirty,
                                    bool static_opt, bool quad, hipStream_t stream);
+// A forest of small trees, a wave per tile (kernels_tree.hip, k_propagate_wave_tiles): every tile is a forest-root tile whose levels
+// hold <= 64 rows each (quad: <= 16) and <= WAVE_TILE_ROWS rows together.
+constexpr uint32_t WAVE_TILE_ROWS = 80;
+hipError_t launch_propagate_wave_tiles(const Columns& c, const uint32_t* parent_idx, const TileDesc* d_wtiles, uint32_t n_tiles, const uint8_t* node_flags,
+                                       const uint8_t* changed, const uint8_t* tree_bytes, uint8_t* g_changed_bytes, bool all_dirty, bool static_opt,
+                                       bool quad, bool pretest, hipStream_t stream);
 hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, const TileDesc* d_tiles, const uint32_t* d_chains,
                                   uint32_t n_tiles, const uint8_t* node_flags, const uint8_t* changed, const uint8_t* tree_bytes,
                                   uint8_t* g_changed_bytes, const float* snap_read, float* snap_write, uint32_t snap_rows, bool all_dirty,

@@ -1152,6 +1152,214 @@ __global__ void __launch_bounds__(64) k_propagate_narrow(Columns c, TreeArgs a, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// A FOREST OF SMALL TREES, a wave per tree (round 6): transform_hierarchy.rs's humanoids_* -- 4 000 rigs of 68 nodes in 13 levels -- and
+// what a game's scene mostly is.  Through the workgroup tiles a rig held a 256-thread workgroup, most of whose lanes had no row, for a
+// chain of 13 barriered level steps (23.5 us per all-dirty frame: two rounds of 4 000 tiles at 8 per CU).  Here the tile is the
+// one-wave walk of k_propagate_narrow above, per TREE instead of per hierarchy: a wave stages its tile's rows (TileDesc: per level a
+// row range -- the rows of one tree are contiguous inside each level, not across levels) into its own LDS with coalesced loads and
+// runs the levels one after the other, results handed down in registers (quad broadcasts / ds_bpermute), nothing but arithmetic
+// between two levels and no workgroup barrier anywhere.  8 KB of LDS per wave: 19 tiles per CU, 4 800 trees in flight -- the 4 000
+// rigs are ONE round.  QUAD (no level of a tile holds more than 16 rows): a node per quad of lanes, a column each.  Tiles are
+// forest-root tiles (kind TILE_ROOTS): the planner takes this path only when EVERY root's tree fits a wave tile (ctx_hierarchy.cpp).
+// Same rule (node_apply / quad_node_apply), same products in the same order: same bits.
+// ---------------------------------------------------------------------------------------------
+template <bool ALL_DIRTY, bool QUAD>
+__global__ void __launch_bounds__(64) k_propagate_wave_tiles(Columns c, TreeArgs a, const TileDesc* __restrict__ wtiles) {
+    __shared__ float4 lds_local[WAVE_TILE_ROWS * 3];  // per staged row: its local affine
+    __shared__ float4 lds_oldg[WAVE_TILE_ROWS * 3];   // its GlobalTransform before this frame
+    __shared__ uint32_t lds_par[WAVE_TILE_ROWS];      // its parent's row
+    __shared__ uint8_t lds_in[WAVE_TILE_ROWS];        // bit0 TransformTreeChanged, bit1 the level-0 assignment happens
+    __shared__ uint32_t lds_lv[(TILE_MAX_LEVELS + 3u) * 4u];  // per level of the tile: LDS base, first row, rows; three empty levels behind the last
+    const uint32_t lane = threadIdx.x;
+    const uint32_t unit = QUAD ? lane >> 2 : lane;  // the node of its level this lane works on
+    const uint32_t cc = lane & 3u;                  // QUAD: the column
+    const TileDesc td = load_tile_desc<TILE_MAX_LEVELS>(wtiles + xcd_contiguous_tile());
+    const uint32_t L = td.n_levels;
+    // the level table: lane k writes level k's entry (LDS base = rows of the levels above it)
+    uint32_t rows = 0;
+    {
+        uint32_t base = 0, st = 0, cn = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < TILE_MAX_LEVELS; ++k) {
+            const uint32_t cnt_k = k < L ? td.count[k] : 0u;
+            if (lane == k) {
+                base = rows;
+                st = td.start[k];
+                cn = cnt_k;
+            }
+            rows += cnt_k;
+        }
+        if (lane >= TILE_MAX_LEVELS) base = rows;
+        if (lane < TILE_MAX_LEVELS + 3u) {
+            lds_lv[lane * 4u] = base;
+            lds_lv[lane * 4u + 1u] = st;
+            lds_lv[lane * 4u + 2u] = cn;
+        }
+    }
+    // where staged row i lives: its level's first row and LDS base (scalars of the descriptor, compared lane by lane)
+    auto row_of = [&](uint32_t i, bool* root_level) {
+        uint32_t lstart = td.start[0], lbase = 0, acc = 0;
+        bool root = true;
+#pragma unroll
+        for (uint32_t k = 0; k < TILE_MAX_LEVELS; ++k) {
+            if (k < L && i >= acc) {
+                lstart = td.start[k];
+                lbase = acc;
+                root = k == 0u;
+            }
+            acc += k < L ? td.count[k] : 0u;
+        }
+        *root_level = root;
+        return lstart + (i - lbase);
+    };
+    constexpr uint32_t ROUNDS = (WAVE_TILE_ROWS + 63u) / 64u;
+    // ---- a frame in which little moved: the tile's flags first (as the workgroup tiles' pretest, k_propagate_fans): under the
+    // static-scene rule a tree none of whose rows is marked (TransformTreeChanged: a moved descendant marks every ancestor up to the
+    // root) or assigned as a root / flat row keeps every GlobalTransform and every tick -- one small round trip instead of the tile
+    if constexpr (!ALL_DIRTY) {
+        if ((a.pretest & 1u) && a.static_opt) {
+            bool hot = false;
+#pragma unroll
+            for (uint32_t j = 0; j < ROUNDS; ++j) {
+                const uint32_t i = j * 64u + lane;
+                bool root_level;
+                const uint32_t row = row_of(i < rows ? i : 0u, &root_level);
+                const NodeIn in = node_inputs_raw(a, row, root_level, node_raw<false>(a, row, root_level));
+                hot = hot || (i < rows && (in.tree_changed || in.root_write));
+            }
+            if (__ballot(hot) == 0ull) {
+#pragma unroll
+                for (uint32_t j = 0; j < ROUNDS; ++j) {
+                    const uint32_t i = j * 64u + lane;
+                    bool root_level;
+                    const uint32_t row = row_of(i < rows ? i : 0u, &root_level);
+                    if (i < rows) at32w<uint8_t>(a.g_changed_bytes, row) = 0;
+                }
+                return;
+            }
+        }
+    }
+    // ---- stage the tile: a lane per row, coalesced inside each level
+    bool hot = false;
+#pragma unroll
+    for (uint32_t j = 0; j < ROUNDS; ++j) {
+        const uint32_t i = j * 64u + lane;
+        if (i < rows) {
+            bool root_level;
+            const uint32_t row = row_of(i, &root_level);
+            const V3 sc = ld3_32(c.scale, row), t = ld3_32(c.translation, row);
+            const V4 q = ld4_32(c.rotation, row);
+            const NodeRaw raw = node_raw<ALL_DIRTY>(a, row, root_level);
+            lds_put(lds_local, i, affine_from_srt(sc, q, t));
+            lds_put(lds_oldg, i, ld_affine(c.global, row));
+            lds_par[i] = at32<uint32_t>(a.parent_idx, row * 4u);
+            const NodeIn in = node_inputs_raw(a, row, root_level, raw);
+            lds_in[i] = (uint8_t)((in.tree_changed ? 1u : 0u) | (in.root_write ? 2u : 0u));
+            hot = hot || in.tree_changed || in.root_write;
+        }
+    }
+    MI_WAVE_LDS_SYNC();
+    if constexpr (!ALL_DIRTY) {  // (the same rule without the pretest's extra round trip: everything is here, nothing is computed)
+        if (a.static_opt && __ballot(hot) == 0ull) {
+#pragma unroll
+            for (uint32_t j = 0; j < ROUNDS; ++j) {
+                const uint32_t i = j * 64u + lane;
+                bool root_level;
+                const uint32_t row = row_of(i < rows ? i : 0u, &root_level);
+                if (i < rows) at32w<uint8_t>(a.g_changed_bytes, row) = 0;
+            }
+            return;
+        }
+    }
+    // ---- the tile's levels, one after the other (the loop of k_propagate_narrow: level k + 1's inputs are requested before level k
+    // is multiplied and looked at an iteration later -- the wave never waits for an address it has just asked for)
+    struct LevelIn {
+        uint32_t row, par, in;
+        bool on;
+        Affine local, old;
+        V3 local_c, old_c;
+    };
+    auto fetch = [&](uint32_t base, uint32_t start, uint32_t cnt) {
+        LevelIn f;
+        f.on = unit < cnt;
+        const uint32_t u = f.on ? unit : 0u;
+        f.row = start + u;
+        const uint32_t i = base + u < WAVE_TILE_ROWS ? base + u : WAVE_TILE_ROWS - 1u;  // (asked for unconditionally, also behind the last level)
+        f.par = lds_par[i];
+        f.in = lds_in[i];
+        if constexpr (QUAD) {
+            f.local_c = lds_col(lds_local, i, cc);
+            f.old_c = lds_col(lds_oldg, i, cc);
+        } else {
+            f.local = lds_affine(lds_local, i);
+            f.old = lds_affine(lds_oldg, i);
+        }
+        return f;
+    };
+    uint32_t b0 = lds_lv[0], s0 = lds_lv[1], c0 = lds_lv[2];  // level k
+    uint32_t b1 = lds_lv[4], s1 = lds_lv[5], c1 = lds_lv[6];  // level k + 1
+    LevelIn nx = fetch(b0, s0, c0);
+    uint32_t before = 0;  // first row of the level above level k
+    V3 pq = {};           // the level before, in registers: QUAD the lane's column of its node, otherwise the lane's whole node
+    Affine pr = {};
+    bool p_chg = false;
+    for (uint32_t k = 0; k < L; ++k) {
+        const LevelIn cu = nx;
+        const bool root_level = k == 0u;
+        const uint32_t slot = root_level ? unit : (cu.par - before) & (QUAD ? 15u : 63u);
+        const bool same = __all(!cu.on || slot == unit) != 0;  // every parent sits where its child does (wave-uniform)
+        bool pc = p_chg;
+        V3 pq_here = pq;
+        Affine gp = pr;
+        if (!same) {
+            if constexpr (QUAD) {
+                pq_here = shfl3(pq, slot * 4u + cc);
+                pc = __builtin_amdgcn_ds_bpermute((int)(slot << 4), p_chg ? 1 : 0) != 0;
+            } else {
+                gp.m.x_axis = shfl3(pr.m.x_axis, slot);
+                gp.m.y_axis = shfl3(pr.m.y_axis, slot);
+                gp.m.z_axis = shfl3(pr.m.z_axis, slot);
+                gp.t = shfl3(pr.t, slot);
+                pc = __builtin_amdgcn_ds_bpermute((int)(slot << 2), p_chg ? 1 : 0) != 0;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t b2 = lds_lv[(k + 2u) * 4u], s2 = lds_lv[(k + 2u) * 4u + 1u], c2 = lds_lv[(k + 2u) * 4u + 2u];
+        nx = fetch(b1, s1, c1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (QUAD) {
+            gp.m.x_axis = quad_bcast(pq_here, 0);
+            gp.m.y_axis = quad_bcast(pq_here, 1);
+            gp.m.z_axis = quad_bcast(pq_here, 2);
+            gp.t = quad_bcast(pq_here, 3);
+            V3 cur_c;
+            const bool chg = quad_node_apply(cu.on, root_level, a.static_opt != 0, cu.in, gp, pc, cu.local_c, cu.old_c, cc, lane, &cur_c);
+            if (cu.on) {
+                if (cc == 0u) at32w<uint8_t>(a.g_changed_bytes, cu.row) = chg ? 1 : 0;
+                if (chg) at32w<F3>(c.global, cu.row * 48u + cc * 12u) = F3{cur_c.x, cur_c.y, cur_c.z};
+            }
+            pq = cur_c;
+            p_chg = chg;
+        } else {
+            NodeIn in;
+            in.tree_changed = (cu.in & 1u) != 0;
+            in.root_write = (cu.in & 2u) != 0;
+            Affine cur;
+            const bool chg = node_apply(root_level, a.static_opt != 0, in, gp, pc, cu.local, cu.old, &cur);
+            if (cu.on) {
+                at32w<uint8_t>(a.g_changed_bytes, cu.row) = chg ? 1 : 0;
+                if (chg) st_affine(c.global, cu.row, cur);
+            }
+            pr = cur;
+            p_chg = chg;
+        }
+        before = s0;
+        b0 = b1; s0 = s1; c0 = c1;
+        b1 = b2; s1 = s2; c1 = c2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // visibility_propagate_system + propagate_recursive (crates/bevy_camera/src/visibility/mod.rs:638-729) as the
 // fixpoint they maintain, swept over the same subtree tiles as the transforms:
 //   Visible -> true, Hidden -> false, Inherited -> parent's InheritedVisibility (true without a parent or when
@@ -1312,6 +1520,30 @@ hipError_t launch_propagate_narrow(const Columns& c, const uint32_t* parent_idx,
     } else {
         if (all_dirty) MI_LAUNCH((k_propagate_narrow<true, false>), dim3(1), dim3(64), 0, stream, c, a, level_offsets, n_levels);
         else MI_LAUNCH((k_propagate_narrow<false, false>), dim3(1), dim3(64), 0, stream, c, a, level_offsets, n_levels);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_propagate_wave_tiles(const Columns& c, const uint32_t* parent_idx, const TileDesc* d_wtiles, uint32_t n_tiles, const uint8_t* node_flags,
+                                       const uint8_t* changed, const uint8_t* tree_bytes, uint8_t* g_changed_bytes, bool all_dirty, bool static_opt,
+                                       bool quad, bool pretest, hipStream_t stream) {
+    if (n_tiles == 0) return hipSuccess;
+    TreeArgs a{};
+    a.pretest = pretest && changed && tree_bytes ? 1u : 0u;
+    a.changed_gen = c.changed_gen;
+    a.parent_idx = parent_idx;
+    a.node_flags = node_flags;
+    a.changed = changed;
+    a.tree_bytes = tree_bytes;
+    a.g_changed_bytes = g_changed_bytes;
+    a.all_dirty = all_dirty ? 1u : 0u;
+    a.static_opt = static_opt ? 1u : 0u;
+    if (quad) {
+        if (all_dirty) MI_LAUNCH((k_propagate_wave_tiles<true, true>), dim3(n_tiles), dim3(64), 0, stream, c, a, d_wtiles);
+        else MI_LAUNCH((k_propagate_wave_tiles<false, true>), dim3(n_tiles), dim3(64), 0, stream, c, a, d_wtiles);
+    } else {
+        if (all_dirty) MI_LAUNCH((k_propagate_wave_tiles<true, false>), dim3(n_tiles), dim3(64), 0, stream, c, a, d_wtiles);
+        else MI_LAUNCH((k_propagate_wave_tiles<false, false>), dim3(n_tiles), dim3(64), 0, stream, c, a, d_wtiles);
     }
     return hipGetLastError();
 }

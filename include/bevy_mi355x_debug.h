@@ -34,7 +34,7 @@ int32_t mi_profile_burst(mi_ctx* ctx, uint32_t first_n);
 int32_t mi_profile_read(mi_ctx* ctx, uint32_t* inout_n, uint64_t* launches, double* total_ms);
 const char* mi_profile_kernel_name(uint32_t k);
 
-/* How the NEXT mi_upload_hierarchy plans mi_propagate: 0 = subtree tiles (a subtree too big for one is cut; default), 1 = always level by level, 2 = as 0, 3 = as 0 with the streamed-level thresholds at their test values (2^20 / 2^21 rows). */
+/* How the NEXT mi_upload_hierarchy plans mi_propagate: 0 = subtree tiles (a subtree too big for one is cut; a forest of small trees: a wave per tree; default), 1 = always level by level, 2 = as 0, 3 = as 0 with the streamed-level thresholds at their test values (2^20 / 2^21 rows), 4 = as 0 without the wave tiles of a forest of small trees. */
 int32_t mi_debug_set_tile_mode(mi_ctx* ctx, int32_t mode);
 /* Per-tile phase timestamps of the light tile kernel (8 x s_memrealtime, 100 MHz, per tile of the first launch).  enable != 0
  * allocates the buffer (mi_propagate then fills it every frame); out != NULL copies n_tiles x 8 stamps out; enable == 0 with
@@ -42,6 +42,9 @@ int32_t mi_debug_set_tile_mode(mi_ctx* ctx, int32_t mode);
 int32_t mi_debug_tree_trace(mi_ctx* ctx, int32_t enable, unsigned long long* out, uint32_t n_tiles);
 /* The shape of the current tile plan: launches per mi_propagate, tiles, chain tiles (self-evaluated ancestor chains), bands. */
 int32_t mi_debug_tile_plan(mi_ctx* ctx, uint32_t* out_launches, uint32_t* out_tiles, uint32_t* out_chain_tiles, uint32_t* out_bands);
+/* The launches of the current tile plan: out_groups[4g ..] = (first tile, tiles, chain tiles, deep instantiation) per launch; out_tiles[3t ..] =
+ * (levels, rows, chain length | 0x100 for a tile of forest roots) per tile (tools/shape_trace.py). */
+int32_t mi_debug_tile_groups(mi_ctx* ctx, uint32_t* out_groups, uint32_t cap_groups, uint32_t* out_n_groups, uint32_t* out_tiles, uint32_t cap_tiles);
 /* Sorted phases (mi_batch_sorted_build): phases up to `items` long take the single-workgroup kernel (one launch), longer ones the
  * tiled two-launch form over the whole chip.  Default 1024; 0 = always tiled, 0xFFFFFFFF = never. */
 int32_t mi_debug_set_sorted_one_wg_limit(mi_ctx* ctx, uint32_t items);

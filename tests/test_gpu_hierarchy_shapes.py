@@ -197,3 +197,96 @@ def test_true_depth_12_tree_all_dirty():
     assert rc == 0
     assert_rows(g, g_exp, "depth 12")
     assert_bits(chg, chg_exp, "depth 12: change ticks")
+
+
+def _small_forest(rng, n_trees, max_depth, max_children, max_level_width):
+    """A forest of small random trees in level order: tree sizes and shapes vary, some roots are childless."""
+    parent = []
+    for _ in range(n_trees):
+        base = len(parent)
+        parent.append(W.NO_PARENT)
+        level = [base]
+        depth = int(rng.integers(0, max_depth + 1))
+        for _d in range(depth):
+            nxt = []
+            for p in level:
+                for _c in range(int(rng.integers(0, max_children + 1))):
+                    if len(nxt) < max_level_width:
+                        nxt.append(len(parent))
+                        parent.append(p)
+            if not nxt:
+                break
+            level = nxt
+    return np.array(parent, np.int64)
+
+
+def _run_forest(parent, rng, tile_mode, frames=((0.3, True), (0.02, True), (0.0, True), (0.2, False))):
+    new_to_old, p_new, offs = W.level_order(parent)
+    n = len(parent)
+    t = (rng.random((n, 3)) * 4 - 2).astype(F)
+    q = rng.normal(size=(n, 4))
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(F)
+    s3 = (0.9 + 0.2 * rng.random((n, 3))).astype(F)
+    with api.Context(0) as ctx:
+        ctx.debug_set_tile_mode(tile_mode)
+        ctx.resize(n)
+        ctx.upload_transforms(t.reshape(-1), q.reshape(-1), s3.reshape(-1))
+        ctx.upload_hierarchy(p_new, offs)
+        plan = ctx.debug_tile_plan()
+        ctx.propagate(B.PROPAGATE_ALL_DIRTY)
+        g, chg = ctx.download_global_transforms()
+        rc, g_exp, chg_exp = O.propagate_transforms(p_new, t.reshape(-1), q.reshape(-1), s3.reshape(-1))
+        assert rc == 0
+        assert_rows(g, g_exp, "forest all dirty")
+        assert_bits(chg, chg_exp, "forest all dirty: change ticks")
+        tt = t.copy()
+        for frame, (frac, static_opt) in enumerate(frames):
+            moved = np.nonzero(rng.random(n) < frac)[0].astype(np.uint32)
+            changed = np.zeros(n, np.uint8)
+            changed[moved] = 1
+            if len(moved):
+                tt[moved] += F(0.25)
+                ctx.upload_transforms_indexed(moved, np.ascontiguousarray(tt[moved]).reshape(-1), np.ascontiguousarray(q[moved]).reshape(-1),
+                                              np.ascontiguousarray(s3[moved]).reshape(-1))
+            else:
+                ctx.upload_changed(changed)
+            ctx.propagate(B.PROPAGATE_STATIC_OPT if static_opt else 0)
+            g, chg = ctx.download_global_transforms()
+            rc, g_exp, chg_exp = O.propagate_transforms(p_new, tt.reshape(-1), q.reshape(-1), s3.reshape(-1), global_in=g_exp, static_opt=static_opt,
+                                                        tree_changed=O.mark_dirty_trees(p_new, changed), transform_changed=changed)
+            assert rc == 0
+            assert_rows(g, g_exp, f"forest frame {frame} static_opt {static_opt}")
+            assert_bits(chg, chg_exp, f"forest frame {frame}: change ticks")
+    return plan, len(offs) - 1
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_forest_of_small_trees_takes_a_wave_per_tile(seed):
+    """Forests every tree of which fits a wave tile (k_propagate_wave_tiles, round 6): rigs of random shape -- narrow enough for the
+    quad form (<= 16 rows to a level of a tile) or not, several small trees packed into one tile, childless roots -- with movers under
+    StaticTransformOptimizations and without, a quiet frame; and the same forests through the workgroup tiles (tile mode 4)."""
+    rng = np.random.default_rng(7000 + seed)
+    narrow = seed % 2 == 0
+    parent = _small_forest(rng, int(rng.integers(3, 900)), int(rng.integers(5, 13)), 2 if narrow else 4, 6 if narrow else 40)
+    state = rng.bit_generator.state
+    plan, n_levels = _run_forest(parent, rng, 0)
+    rng.bit_generator.state = state
+    plan4, _ = _run_forest(parent, rng, 4)
+    n_roots = int((parent == W.NO_PARENT).sum())
+    counts = np.bincount(np.cumsum(parent == W.NO_PARENT) - 1)  # (spawn order: a tree's nodes follow its root)
+    fits = n_levels >= 5 and counts.max() <= 80
+    print(f"seed {seed}: {len(parent)} nodes, {n_roots} trees (largest {counts.max()}), {n_levels} levels; plan {plan}, without wave tiles {plan4}")
+    if fits and not narrow:
+        pass  # (a level of one tree may exceed 64 rows only with > 80 rows in all: every such forest takes the wave tiles)
+    if fits:
+        assert plan["launches"] == 1 and plan["tiles"] <= n_roots and plan4["tiles"] != plan["tiles"] or plan4["launches"] >= 1, plan  # ONE launch, at most a tile per tree (small trees share tiles)
+
+
+def test_a_forest_with_one_big_tree_keeps_the_workgroup_tiles():
+    """One tree too big for a wave tile: the whole hierarchy takes the workgroup tiles (the planner's rule is all-or-nothing)."""
+    rng = np.random.default_rng(99)
+    small = _small_forest(rng, 200, 8, 2, 6)
+    big = W._parent_map_tree(7, 3)  # 1 093 nodes
+    parent = np.concatenate([small, [W.NO_PARENT], big + len(small)])
+    plan, _ = _run_forest(parent, rng, 0, frames=((0.3, True), (0.0, True)))
+    print("plan", plan)

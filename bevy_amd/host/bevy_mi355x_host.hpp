@@ -254,6 +254,8 @@ class World {
         ++bounds_version_;  // (entities without Visibility default to visible: the flag byte depends on its presence)
     }
     bool inherited_visibility(Entity e) const { return rec(e).inherited; }
+    bool has_aabb(Entity e) const { return rec(e).aabb.has_value(); }
+    bool has_point_light(Entity e) const { return rec(e).point_light_range.has_value(); }
     bool inherited_visibility_changed(Entity e) const { return rec(e).inherited_changed; }
     void insert_aabb(Entity e, Aabb a) { rec(e).aabb = a; rec(e).bounds_changed = true; touch(e.index); ++bounds_version_; }
     // RenderLayers (first word), NoFrustumCulling, VisibilityRange: inputs of every visibility closure (visibility/mod.rs:800-846)

@@ -4,22 +4,37 @@
 // that wants every GPU creates one context per device and drives them all from the thread its system runs on:
 //
 //   Mi355xShardedPlugin plugin({0, 1, 2, 3, 4, 5, 6, 7});           // Mi355xRenderPrepPlugin { devices: vec![0, .., 7] } in the Rust crate
-//   plugin.frame(world, views)                                        // TransformSystems::Propagate .. MarkNewlyHiddenEntitiesInvisible
-//       rows (Entity order) in contiguous 256-aligned ranges, one per context; per frame and context the rows a
-//       Changed<Transform> query yields go up (mi_upload_transforms_indexed), ONE frame call each (mi_propagate_and_cull_views: enqueue
-//       only, the devices run side by side), mi_exchange_group_flush = the N in-place all-gathers between ncclGroupStart / ncclGroupEnd,
-//       each context's changed GlobalTransforms back (its shard only: GlobalTransform stays sharded), and ONE device-to-host copy of
-//       ONE context's gathered buffer -- every shard's masks of every view -- from which ViewVisibility and VisibleEntities are written.
+//   plugin.frame(world, views, cluster_camera)                        // TransformSystems::Propagate .. MarkNewlyHiddenEntitiesInvisible
 //
-// Scope: flat Worlds (every entity a root without children -- configs[1] / configs[3]); a World with ChildOf is refused (its sharding is
-// by root subtree, bevy_amd/sharding.py: shard_hierarchy, and stays with the single-device plugin here).  Lights, clusters and batching
-// are the single-device plugin's: SURVEY 8e shards clusters over LIGHTS (optional at 100 k) and leaves batching as replicas.
+// The three partitions of SURVEY 8(e), all behind this one call (round 6: rows 2 and 3 joined row 1 here; until then they were
+// Python only, bevy_amd/sharding.py):
+//   row 1  a FLAT World (every entity a root without children -- configs[1] / configs[3]): rows in Entity order, cut into contiguous
+//          256-aligned ranges, one per context;
+//   row 2  a World with ChildOf: whole TREES go to contexts -- forest roots are independent (propagate_parent_transforms,
+//          crates/bevy_transform/src/systems.rs:522) -- biggest first onto the least loaded; while the fullest context exceeds 1.10 x its
+//          fair share the biggest tree that has children is OPENED: its root becomes a replicated row (every context that holds
+//          something below it recomputes it -- the same products, the same bits -- and the lowest such context owns it) and its child
+//          subtrees are placed instead.  No collective on this path: a context's rows never read another context's.  Each context
+//          holds its rows in level order (a subsequence of the World's level order) with a hierarchy of its own;
+//   row 3  light clusters: every context assigns the clusterable objects whose ROWS it owns (mi_cluster_bind_objects_to_row_list:
+//          the device gathers the visible ones from this frame's ViewVisibility, as the single-device frame does) and the per-cluster
+//          lists are merged here in the order of the gathered list (assign.rs:190-296: a cluster's entities are pushed in list
+//          order, :740-800) -- per-type counts summed, farthest_z the maximum;
+// and per frame: the rows a Changed<Transform> query yields go up to every context that holds them (mi_upload_transforms_indexed), ONE
+// frame call each (mi_propagate_and_cull_views: enqueue only, the devices run side by side), mi_exchange_group_flush = the N in-place
+// all-gathers between ncclGroupStart / ncclGroupEnd, each context's changed GlobalTransforms back (owned rows only: GlobalTransform stays
+// sharded), and ONE device-to-host copy of ONE context's gathered buffer -- every shard's masks of every view -- from which
+// ViewVisibility and VisibleEntities are written (rows a context merely replicates are skipped).
+//
 // A device named twice in the list ({0, 0, 0}: three shards on one GPU) cannot form a communicator: such a plugin runs without the
 // exchange and reads each shard's masks from its own context -- which is how tests/cpp/host_systems_test.cpp exercises several shards on
 // a one-GPU box; with distinct devices ({0} there) it goes through RCCL.  RCCL is loaded with dlopen: no link-time dependency.
+// Batching stays the single-device plugin's (replicas only), and so do the shadow views.
 #pragma once
 
 #include <dlfcn.h>
+
+#include <unordered_map>
 
 #include "bevy_mi355x_host.hpp"
 
@@ -58,31 +73,48 @@ class Mi355xShardedPlugin {
     bool exchanged() const { return !comms_.empty(); }  // the masks travel through the RCCL all-gather (else: read per context)
     const std::string& exchange_note() const { return note_; }
     size_t shards() const { return ctxs_.size(); }
+    // the partition of the last frame: rows per context, and how many of them are replicated split roots (hierarchies only)
+    std::vector<uint32_t> shard_rows() const { return cnt_; }
+    uint32_t replicated_rows() const { return n_replicated_; }
+    bool sharded_by_tree() const { return hier_; }
 
     struct FrameOutput {
         std::vector<std::vector<Entity>> visible_entities;  // per view: VisibleEntities::get(class 0), ascending by Entity
         uint32_t changed_global_transforms = 0;
         bool exchanged = false;
+        bool has_clusters = false;
+        Clusters clusters;
     };
 
-    FrameOutput frame(World& w, const std::vector<View>& views) {
+    FrameOutput frame(World& w, const std::vector<View>& views, const ClusterCamera* cam = nullptr) {
         FrameOutput out;
         out.exchanged = exchanged();
-        sync_structure(w);
-        const uint32_t n = (uint32_t)entity_of_row_.size(), N = (uint32_t)ctxs_.size();
-        if (n == 0) return out;
+        const bool rebuilt = sync_structure(w);
+        const uint32_t N = (uint32_t)ctxs_.size();
+        if (n_rows_ == 0) return out;
+        // InheritedVisibility is an input of the cull: with a hierarchy it is recomputed (on the devices) in frames that wrote a Visibility
+        if (hier_ && (rebuilt || seen_visibility_ != w.visibility_version_)) {
+            visibility_propagate(w);
+            seen_visibility_ = w.visibility_version_;
+        }
         upload_bounds(w);
-        // ---- in: the rows a Changed<Transform> query yields, by shard
+        // ---- in: the rows a Changed<Transform> query yields, to every context that holds them
         std::vector<std::vector<uint32_t>> rows(N);
         std::vector<std::vector<float>> t(N), r(N), s(N);
+        auto push = [&](const Holder& h, const Transform& tr) {
+            rows[h.shard].push_back(h.row);
+            t[h.shard].insert(t[h.shard].end(), {tr.translation.x, tr.translation.y, tr.translation.z});
+            r[h.shard].insert(r[h.shard].end(), {tr.rotation.x, tr.rotation.y, tr.rotation.z, tr.rotation.w});
+            s[h.shard].insert(s[h.shard].end(), {tr.scale.x, tr.scale.y, tr.scale.z});
+        };
         for (uint32_t i : w.touched_) {
             if (!w.moved_[i]) continue;
-            const uint32_t row = row_of_index_[i], d = row / rows_per_;
-            const Transform& tr = w.transform_[i];
-            rows[d].push_back(row - d * rows_per_);
-            t[d].insert(t[d].end(), {tr.translation.x, tr.translation.y, tr.translation.z});
-            r[d].insert(r[d].end(), {tr.rotation.x, tr.rotation.y, tr.rotation.z, tr.rotation.w});
-            s[d].insert(s[d].end(), {tr.scale.x, tr.scale.y, tr.scale.z});
+            push(primary_[i], w.transform_[i]);
+            if (n_replicated_) {
+                auto it = replicas_.find(i);
+                if (it != replicas_.end())
+                    for (const Holder& h : it->second) push(h, w.transform_[i]);
+            }
         }
         for (uint32_t d = 0; d < N; ++d) {
             if (!cnt_[d]) continue;
@@ -91,6 +123,24 @@ class Mi355xShardedPlugin {
                 const uint8_t zero = 0;
                 check(d, mi_upload_changed(ctxs_[d], 0, 1, &zero));
             }
+        }
+        // ---- the lights: rows like everything else, every context binds the ones it owns to its cluster stage
+        const bool with_clusters = cam != nullptr && !views.empty() && sync_lights(w);
+        uint32_t n_clusters = 0;
+        mi_cluster_view cview{};
+        if (with_clusters) {
+            uint32_t tile[2], dims[3];
+            if (mi_cluster_view_dims(cam->screen_width, cam->screen_height, cam->requested_dimensions, tile, dims) != MI_OK)
+                throw std::runtime_error("mi_cluster_view_dims failed");
+            n_clusters = dims[0] * dims[1] * dims[2];
+            plane_storage_.assign((size_t)(dims[0] + dims[1] + dims[2] + 3) * 4, 0.0f);
+            sphere_storage_.assign(lights_any_spot_ ? (size_t)n_clusters * 4 : 0, 0.0f);
+            if (mi_cluster_view_build(cam->camera_affine, cam->clip_from_view, cam->frustum, cam->screen_width, cam->screen_height,
+                                      cam->requested_dimensions, cam->first_slice_depth, cam->far_z, cam->layer_mask, plane_storage_.data(),
+                                      lights_any_spot_ ? sphere_storage_.data() : nullptr, &cview) != MI_OK)
+                throw std::runtime_error("mi_cluster_view_build failed");
+            for (uint32_t d = 0; d < N; ++d)
+                if (!shard_lights_[d].empty()) check(d, mi_cluster_upload_view(ctxs_[d], &cview));
         }
         // ---- run: one frame call per context (enqueue only: the devices run side by side), then the all-gathers together
         std::vector<mi_view> mv(views.size());
@@ -105,13 +155,18 @@ class Mi355xShardedPlugin {
         }
         const uint32_t n_views = (uint32_t)views.size();
         if (n_views != exchange_views_) configure_exchange(n_views);
+        const uint32_t static_opt = w.static_transform_optimizations ? 1u : 0u;
         for (uint32_t d = 0; d < N; ++d) {
-            if (n_views) check(d, mi_propagate_and_cull_views(ctxs_[d], mv.data(), n_views, MI_CULL_CHANGED_ROWS | MI_CULL_END_FRAME));
-            else if (cnt_[d]) check(d, mi_propagate(ctxs_[d], 0));
+            if (n_views)
+                check(d, mi_propagate_and_cull_views(ctxs_[d], mv.data(), n_views,
+                                                     MI_CULL_CHANGED_ROWS | MI_CULL_END_FRAME | (static_opt ? MI_CULL_STATIC_OPT : 0u) |
+                                                         (with_clusters && !shard_lights_[d].empty() ? MI_CULL_WITH_CLUSTERS : 0u)));
+            else if (cnt_[d]) check(d, mi_propagate(ctxs_[d], static_opt ? MI_PROPAGATE_STATIC_OPT : 0u));
         }
         if (n_views && exchanged())
             check(0, mi_exchange_group_flush(ctxs_.data(), N, group_start_, group_end_));
-        // ---- out: every shard's changed GlobalTransforms (GlobalTransform stays sharded: each context returns its own rows)
+        // ---- out: every shard's changed GlobalTransforms (GlobalTransform stays sharded: each context returns the rows it OWNS; what
+        // it merely replicates -- a split tree's root -- comes from the owner, same bits)
         std::vector<uint32_t> crow;
         std::vector<float> cg;
         for (uint32_t d = 0; d < N; ++d) {
@@ -121,12 +176,13 @@ class Mi355xShardedPlugin {
             uint32_t count = 0;
             check(d, mi_download_changed_global_transforms(ctxs_[d], crow.data(), cg.data(), cnt_[d], &count));
             for (uint32_t k = 0; k < count; ++k) {
-                const uint32_t i = entity_of_row_[d * rows_per_ + crow[k]].index;
+                if (!owned_[d][crow[k]]) continue;
+                const uint32_t i = rows_of_[d][crow[k]].index;
                 std::memcpy(w.global_[i].cols, &cg[12 * (size_t)k], 48);
                 w.global_changed_[i] = 1;
                 w.touch(i);
+                ++out.changed_global_transforms;
             }
-            out.changed_global_transforms += count;
         }
         if (!n_views) return out;
         // ---- the masks: ONE copy of one context's gathered buffer ([rank][view][word]) -- or, without the exchange, each context's own
@@ -149,23 +205,30 @@ class Mi355xShardedPlugin {
         // ---- ECS writes: VisibilitySystems::CheckVisibility between the stock reset and mark-newly-hidden systems
         w.reset_view_visibility();
         out.visible_entities.resize(n_views);
-        for (uint32_t v = 0; v < n_views; ++v)
+        for (uint32_t v = 0; v < n_views; ++v) {
+            std::vector<Entity>& list = out.visible_entities[v];
             for (uint32_t d = 0; d < N; ++d) {
                 const uint64_t* src = &masks_[((size_t)d * n_views + v) * wpv];
                 for (uint64_t k = 0; k < (cnt_[d] + 63u) / 64u; ++k)
                     for (uint64_t m = src[k]; m; m &= m - 1) {
                         const uint32_t local = (uint32_t)(k * 64u) + (uint32_t)__builtin_ctzll(m);
                         if (local >= cnt_[d]) break;
-                        const Entity e = entity_of_row_[d * rows_per_ + local];
+                        if (!owned_[d][local]) continue;
+                        const Entity e = rows_of_[d][local];
                         w.set_visible(e);
-                        out.visible_entities[v].push_back(e);
+                        list.push_back(e);
                     }
             }
+            // rows of a tree-sharded World are in level order per context: VisibleEntities is sorted by Entity (visibility/mod.rs:861-874)
+            if (hier_) std::sort(list.begin(), list.end(), [](Entity a, Entity b) { return a.to_bits() < b.to_bits(); });
+        }
         w.mark_newly_hidden_entities_invisible();
+        if (with_clusters) merge_clusters(cview, n_clusters, out);
         return out;
     }
 
   private:
+    struct Holder { uint32_t shard, row; };
     void check(uint32_t d, int32_t rc) {
         if (rc == MI_OK) return;
         throw std::runtime_error("bevy_mi355x (shard " + std::to_string(d) + ") error " + std::to_string(rc) + ": " + mi_last_error_string(ctxs_[d]));
@@ -201,32 +264,154 @@ class Mi355xShardedPlugin {
             check(d, mi_exchange_configure_owned(ctxs_[d], &comms_[d], 1, all_gather_, 3, (uint32_t)ctxs_.size(), wpv, (uint64_t)d * n_views * wpv, block, d));
         }
     }
-    // Entity -> (shard, row): rows in Entity::to_bits order, cut into contiguous 256-aligned ranges (a mask word never straddles shards)
-    void sync_structure(World& w) {
-        if (seen_version_ == w.structure_version_) return;
+
+    // ---- whole trees to contexts, an oversized tree opened at its root (bevy_amd/sharding.py: shard_hierarchy, the
+    // same greedy placement -- tests/cpp/host_systems_test.cpp compares the two through the World they leave).  parent / offs: the World's
+    // rows in level order (mi_hierarchy_sort).  Fills node_rank (-1 = replicated) and need[r][row].
+    void place_trees(uint32_t n, const std::vector<uint32_t>& parent, const std::vector<uint32_t>& offs, uint32_t n_levels, std::vector<int32_t>& node_rank,
+                     std::vector<std::vector<uint8_t>>& need, std::vector<int32_t>& rep_owner) {
+        const uint32_t N = (uint32_t)ctxs_.size();
+        std::vector<uint64_t> size(n, 1);
+        for (uint32_t l = n_levels; l-- > 1;)
+            for (uint32_t i = offs[l]; i < offs[l + 1]; ++i) size[parent[i]] += size[i];
+        // children of a row: contiguous in the next level (rows of a level are ordered by parent)
+        std::vector<uint32_t> first_child(n, 0), n_children(n, 0);
+        for (uint32_t l = 1; l < n_levels; ++l)
+            for (uint32_t i = offs[l]; i < offs[l + 1]; ++i) {
+                if (!n_children[parent[i]]) first_child[parent[i]] = i;
+                ++n_children[parent[i]];
+            }
+        struct Unit { uint64_t size; uint32_t root; };
+        std::vector<Unit> units;
+        for (uint32_t i = offs[0]; i < offs[1]; ++i) units.push_back({size[i], i});
+        std::vector<uint8_t> replicated(n, 0);
+        std::vector<uint64_t> load(N);
+        std::vector<int32_t> unit_rank(n, -2);
+        auto pack = [&]() {
+            std::sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.size != b.size ? a.size > b.size : a.root < b.root; });
+            std::fill(load.begin(), load.end(), 0);
+            for (const Unit& u : units) {
+                uint32_t best = 0;
+                for (uint32_t k = 1; k < N; ++k)
+                    if (load[k] < load[best]) best = k;
+                load[best] += u.size;
+                unit_rank[u.root] = (int32_t)best;
+            }
+        };
+        pack();
+        const double ideal = (double)n / (double)N, slack = 1.10;
+        for (uint32_t iter = 0; iter < 64u * N; ++iter) {
+            if (N == 1 || (double)*std::max_element(load.begin(), load.end()) <= slack * ideal) break;
+            size_t big = units.size();  // the biggest unit that still has children (units are sorted: the first such)
+            for (size_t k = 0; k < units.size(); ++k)
+                if (n_children[units[k].root]) { big = k; break; }
+            if (big == units.size()) break;
+            const uint32_t root = units[big].root;
+            units.erase(units.begin() + (std::ptrdiff_t)big);
+            replicated[root] = 1;
+            unit_rank[root] = -2;
+            for (uint32_t c = first_child[root]; c < first_child[root] + n_children[root]; ++c) units.push_back({size[c], c});
+            pack();
+        }
+        node_rank.assign(n, -2);
+        for (uint32_t l = 0; l < n_levels; ++l)
+            for (uint32_t i = offs[l]; i < offs[l + 1]; ++i)
+                node_rank[i] = replicated[i] ? -1 : unit_rank[i] >= 0 ? unit_rank[i] : node_rank[parent[i]];
+        need.assign(N, std::vector<uint8_t>(n, 0));
+        for (uint32_t i = 0; i < n; ++i)
+            if (node_rank[i] >= 0) need[(size_t)node_rank[i]][i] = 1;
+        for (uint32_t l = n_levels; l-- > 1;)
+            for (uint32_t i = offs[l]; i < offs[l + 1]; ++i)
+                for (uint32_t rk = 0; rk < N; ++rk)
+                    if (need[rk][i]) need[rk][parent[i]] = 1;
+        rep_owner.assign(n, -1);
+        n_replicated_ = 0;
+        for (uint32_t i = 0; i < n; ++i)
+            if (replicated[i]) {
+                ++n_replicated_;
+                for (uint32_t rk = 0; rk < N && rep_owner[i] < 0; ++rk)
+                    if (need[rk][i]) rep_owner[i] = (int32_t)rk;
+                if (rep_owner[i] < 0) { rep_owner[i] = 0; need[0][i] = 1; }
+            }
+    }
+
+    // Entity -> (shard, row).  Returns true when the partition was rebuilt.
+    bool sync_structure(World& w) {
+        if (seen_version_ == w.structure_version_) return false;
         std::vector<Entity> ents = w.entities();
-        for (Entity e : ents)
-            if (w.rec_[e.index].parent || !w.rec_[e.index].children.empty())
-                throw std::runtime_error("Mi355xShardedPlugin: a World with ChildOf shards by root subtree (bevy_amd/sharding.py); use Mi355xPlugin");
         std::sort(ents.begin(), ents.end(), [](Entity a, Entity b) { return a.to_bits() < b.to_bits(); });
-        entity_of_row_ = ents;
         const uint32_t n = (uint32_t)ents.size(), N = (uint32_t)ctxs_.size();
-        row_of_index_.assign(w.rec_.size(), MI_NO_PARENT);
-        for (uint32_t row = 0; row < n; ++row) row_of_index_[ents[row].index] = row;
-        rows_per_ = ((n + N - 1) / N + 255u) / 256u * 256u;
-        if (rows_per_ == 0) rows_per_ = 256u;
+        n_rows_ = n;
+        hier_ = false;
+        for (Entity e : ents) hier_ = hier_ || w.rec_[e.index].parent || !w.rec_[e.index].children.empty();
+        rows_of_.assign(N, {});
+        owned_.assign(N, {});
+        primary_.assign(w.rec_.size(), Holder{0xFFFFFFFFu, 0xFFFFFFFFu});
+        replicas_.clear();
+        n_replicated_ = 0;
+        std::vector<std::vector<uint32_t>> local_parent(N), local_offs(N);
+        if (!hier_) {
+            // row 1: contiguous 256-aligned ranges of the Entity order (a mask word never straddles shards)
+            const uint32_t per = std::max(256u, ((n + N - 1) / N + 255u) / 256u * 256u);
+            for (uint32_t d = 0; d < N; ++d) {
+                const uint32_t lo = (uint32_t)std::min<uint64_t>(n, (uint64_t)d * per), m = std::min(n - lo, per);
+                rows_of_[d].assign(ents.begin() + lo, ents.begin() + lo + m);
+                owned_[d].assign(m, 1);
+                for (uint32_t k = 0; k < m; ++k) primary_[ents[lo + k].index] = Holder{d, k};
+            }
+        } else {
+            // row 2: the World's rows in level order, then whole trees to contexts
+            std::vector<uint32_t> slot_of_index(w.rec_.size(), MI_NO_PARENT), parent(std::max(n, 1u), MI_NO_PARENT);
+            for (uint32_t i = 0; i < n; ++i) slot_of_index[ents[i].index] = i;
+            for (uint32_t i = 0; i < n; ++i) {
+                const auto& p = w.rec_[ents[i].index].parent;
+                if (p) {
+                    if (!w.contains(*p)) throw std::logic_error("ChildOf points at a despawned entity");
+                    parent[i] = slot_of_index[p->index];
+                }
+            }
+            std::vector<uint32_t> new_to_old(std::max(n, 1u)), pidx(std::max(n, 1u)), offs((size_t)n + 2);
+            uint32_t n_levels = 0;
+            const int32_t rc = mi_hierarchy_sort(n, parent.data(), new_to_old.data(), pidx.data(), offs.data(), n + 2, &n_levels);
+            if (rc == MI_ERR_MALFORMED_HIERARCHY) throw std::logic_error("malformed hierarchy (the reference panics here): cycle in ChildOf");
+            if (rc != MI_OK) throw std::runtime_error("mi_hierarchy_sort failed");
+            std::vector<int32_t> node_rank, rep_owner;
+            std::vector<std::vector<uint8_t>> need;
+            place_trees(n, pidx, offs, n_levels, node_rank, need, rep_owner);
+            std::vector<uint32_t> local_of(n);
+            for (uint32_t d = 0; d < N; ++d) {
+                uint32_t m = 0;
+                local_offs[d].push_back(0);
+                for (uint32_t l = 0; l < n_levels; ++l) {
+                    for (uint32_t i = offs[l]; i < offs[l + 1]; ++i) {
+                        if (!need[d][i]) continue;
+                        local_of[i] = m++;
+                        const Entity e = ents[new_to_old[i]];
+                        rows_of_[d].push_back(e);
+                        const bool own = node_rank[i] == (int32_t)d || rep_owner[i] == (int32_t)d;
+                        owned_[d].push_back(own ? 1 : 0);
+                        local_parent[d].push_back(pidx[i] == MI_NO_PARENT ? MI_NO_PARENT : local_of[pidx[i]]);  // (a held row's parent is held: need is closed upwards)
+                        if (own) primary_[e.index] = Holder{d, m - 1};
+                        else replicas_[e.index].push_back(Holder{d, m - 1});
+                    }
+                    if (m != local_offs[d].back()) local_offs[d].push_back(m);  // (empty levels dropped)
+                }
+            }
+        }
+        // every context: its rows, columns, hierarchy
         cnt_.assign(N, 0u);
+        uint32_t widest = 0;
         for (uint32_t d = 0; d < N; ++d) {
-            const uint32_t lo = std::min<uint64_t>(n, (uint64_t)d * rows_per_);
-            cnt_[d] = std::min(n - lo, rows_per_);
-            check(d, mi_columns_resize(ctxs_[d], cnt_[d]));
-            if (!cnt_[d]) continue;
-            const uint32_t m = cnt_[d];
+            const uint32_t m = (uint32_t)rows_of_[d].size();
+            cnt_[d] = m;
+            widest = std::max(widest, m);
+            check(d, mi_columns_resize(ctxs_[d], m));
+            if (!m) continue;
             std::vector<float> t(3 * (size_t)m), r(4 * (size_t)m), s(3 * (size_t)m), g(12 * (size_t)m);
             std::vector<uint8_t> changed(m), vv(m);
             std::vector<uint64_t> keys(m);
             for (uint32_t k = 0; k < m; ++k) {
-                const Entity e = ents[lo + k];
+                const Entity e = rows_of_[d][k];
                 const World::Rec& rec = w.rec_[e.index];
                 std::memcpy(&t[3 * (size_t)k], &w.transform_[e.index].translation, 12);
                 std::memcpy(&r[4 * (size_t)k], &w.transform_[e.index].rotation, 16);
@@ -240,25 +425,60 @@ class Mi355xShardedPlugin {
             check(d, mi_upload_global_transforms(ctxs_[d], 0, m, g.data()));
             check(d, mi_upload_view_visibility(ctxs_[d], 0, m, vv.data()));
             check(d, mi_upload_entity_keys(ctxs_[d], 0, m, keys.data()));
+            const uint32_t lv = hier_ ? (uint32_t)local_offs[d].size() - 1u : 1u;
+            check(d, mi_upload_hierarchy(ctxs_[d], m, lv > 1 ? local_parent[d].data() : nullptr, lv > 1 ? local_offs[d].data() : nullptr, lv));
             check(d, mi_upload_changed(ctxs_[d], 0, m, changed.data()));
         }
+        rows_per_ = std::max(256u, (widest + 255u) / 256u * 256u);  // the gathered buffer's block: the widest shard, whole mask words
         seen_version_ = w.structure_version_;
         seen_bounds_ = 0;
+        upload_bounds(w);               // the flag byte carries InheritedVisibility: the devices must start from the World's values
+        lights_version_ = 0;            // rows were renumbered: the lights are bound again
         exchange_views_ = 0xFFFFFFFFu;  // the shard size may have changed: the gathered buffers are laid out again
+        return true;
     }
+
+    // VisibilitySystems::VisibilityPropagate over the shards (hierarchies): every context sweeps its own trees; a replicated root gets
+    // the same value everywhere, the owner's is written to the World
+    void visibility_propagate(World& w) {
+        for (uint32_t d = 0; d < ctxs_.size(); ++d) {
+            const uint32_t m = cnt_[d];
+            if (!m) continue;
+            std::vector<uint8_t> vis(m);
+            for (uint32_t k = 0; k < m; ++k) {
+                const World::Rec& e = w.rec_[rows_of_[d][k].index];
+                vis[k] = e.has_visibility ? (uint8_t)e.visibility : (uint8_t)MI_VISIBILITY_NONE;
+            }
+            check(d, mi_upload_visibility(ctxs_[d], 0, m, vis.data()));
+            check(d, mi_visibility_propagate(ctxs_[d]));
+            std::vector<uint8_t> inh(m);
+            std::vector<uint32_t> chg((m + 31) / 32);
+            check(d, mi_download_inherited_visibility(ctxs_[d], 0, m, inh.data(), chg.data()));
+            for (uint32_t k = 0; k < m; ++k) {
+                if (!owned_[d][k] || !((chg[k >> 5] >> (k & 31)) & 1u)) continue;
+                World::Rec& e = w.rec_[rows_of_[d][k].index];
+                e.inherited = inh[k] != 0;
+                e.inherited_changed = true;
+                w.touch(rows_of_[d][k].index);
+                ++w.bounds_version_;
+            }
+        }
+    }
+
     void upload_bounds(World& w) {
         if (seen_bounds_ == w.bounds_version_) return;
         seen_bounds_ = w.bounds_version_;
         for (uint32_t d = 0; d < ctxs_.size(); ++d) {
-            const uint32_t m = cnt_[d], lo = d * rows_per_;
+            const uint32_t m = cnt_[d];
             if (!m) continue;
             std::vector<float> c(3 * (size_t)m, 0.f), h(3 * (size_t)m, 0.f), ranges(2 * (size_t)m, 0.f);
             std::vector<uint8_t> flags(m);
             std::vector<uint32_t> layers(m);
             for (uint32_t k = 0; k < m; ++k) {
-                const World::Rec& e = w.rec_[entity_of_row_[lo + k].index];
-                flags[k] = (uint8_t)(((!e.has_visibility || e.visibility != Visibility::Hidden) ? MI_FLAG_INHERITED_VISIBLE : 0u) | (e.aabb ? MI_FLAG_HAS_AABB : 0u) |
-                                     (e.no_frustum_culling ? MI_FLAG_NO_FRUSTUM_CULLING : 0u));  // (flat rows: InheritedVisibility = Visibility != Hidden, visibility/mod.rs:650-660)
+                const World::Rec& e = w.rec_[rows_of_[d][k].index];
+                // InheritedVisibility: flat rows Visibility != Hidden (visibility/mod.rs:650-660); with a hierarchy the swept value
+                const bool inherited = hier_ ? (!e.has_visibility || e.inherited) : (!e.has_visibility || e.visibility != Visibility::Hidden);
+                flags[k] = (uint8_t)((inherited ? MI_FLAG_INHERITED_VISIBLE : 0u) | (e.aabb ? MI_FLAG_HAS_AABB : 0u) | (e.no_frustum_culling ? MI_FLAG_NO_FRUSTUM_CULLING : 0u));
                 layers[k] = e.render_layers;
                 if (e.visibility_range) {
                     flags[k] |= (uint8_t)(MI_FLAG_HAS_VISIBILITY_RANGE | (e.visibility_range->use_aabb ? MI_FLAG_RANGE_USE_AABB : 0u));
@@ -266,9 +486,92 @@ class Mi355xShardedPlugin {
                     ranges[2 * (size_t)k + 1] = e.visibility_range->end_margin_end;
                 }
                 if (e.aabb) { std::memcpy(&c[3 * (size_t)k], &e.aabb->center, 12); std::memcpy(&h[3 * (size_t)k], &e.aabb->half_extents, 12); }
+                else if (e.point_light_range || e.spot_light) {  // a light's bounding Sphere follows its row's GlobalTransform (as in Mi355xPlugin::upload_bounds)
+                    flags[k] |= MI_FLAG_HAS_SPHERE;
+                    const uint32_t at_translation = MI_SPHERE_AT_TRANSLATION;
+                    h[3 * (size_t)k] = e.point_light_range ? *e.point_light_range : e.spot_light->first;
+                    std::memcpy(&h[3 * (size_t)k + 1], &at_translation, 4);
+                }
             }
             check(d, mi_upload_bounds(ctxs_[d], 0, m, c.data(), h.data(), flags.data(), layers.data()));
             check(d, mi_upload_visibility_ranges(ctxs_[d], 0, m, w.visible_entity_ranges() ? ranges.data() : nullptr));
+        }
+    }
+
+    // ---- the clusterable objects by owner.  The gathered list of assign.rs:190-248 (point lights, then spot lights,
+    // each in Entity order; the kinds the single-device plugin's sync_lights adds beyond these stay with it) is cut by the context that
+    // OWNS each object's row; a context's sublist keeps the list's order, so its per-cluster lists ascend in list position.
+    bool sync_lights(World& w) {
+        if (lights_version_ == w.lights_version_ && lights_version_ != 0) return !light_entities_.empty();
+        const uint32_t N = (uint32_t)ctxs_.size();
+        light_entities_.clear();
+        shard_lights_.assign(N, {});
+        std::vector<std::vector<uint32_t>> rows(N);
+        std::vector<std::vector<float>> pos_range(N), sin_cos(N);
+        std::vector<std::vector<uint8_t>> types(N);
+        lights_any_spot_ = false;
+        const std::vector<Entity> ents = w.entities();  // (the mock World's query order, as Mi355xPlugin::sync_lights gathers)
+        auto add = [&](Entity e, float range, uint8_t type, float outer_angle) {
+            const Holder h = primary_[e.index];
+            shard_lights_[h.shard].push_back((uint32_t)light_entities_.size());
+            light_entities_.push_back(e);
+            rows[h.shard].push_back(h.row);
+            pos_range[h.shard].insert(pos_range[h.shard].end(), {0.0f, 0.0f, 0.0f, range});  // the position comes from the row
+            types[h.shard].push_back(type);
+            const bool spot = type == MI_OBJ_SPOT_LIGHT;
+            sin_cos[h.shard].push_back(spot ? std::sin(outer_angle) : 0.0f);
+            sin_cos[h.shard].push_back(spot ? std::cos(outer_angle) : 0.0f);
+            lights_any_spot_ = lights_any_spot_ || spot;
+        };
+        for (Entity e : ents)
+            if (w.rec_[e.index].point_light_range) add(e, *w.rec_[e.index].point_light_range, MI_OBJ_POINT_LIGHT, 0.f);
+        for (Entity e : ents)
+            if (w.rec_[e.index].spot_light) add(e, w.rec_[e.index].spot_light->first, MI_OBJ_SPOT_LIGHT, w.rec_[e.index].spot_light->second);
+        lights_version_ = w.lights_version_;
+        for (uint32_t d = 0; d < N; ++d) {
+            if (!cnt_[d]) continue;
+            if (shard_lights_[d].empty()) {
+                check(d, mi_cluster_bind_objects_to_row_list(ctxs_[d], 0, nullptr));
+                continue;
+            }
+            check(d, mi_cluster_upload_objects(ctxs_[d], (uint32_t)shard_lights_[d].size(), pos_range[d].data(), types[d].data(), nullptr, nullptr, sin_cos[d].data()));
+            check(d, mi_cluster_bind_objects_to_row_list(ctxs_[d], (uint32_t)rows[d].size(), rows[d].data()));
+        }
+        return !light_entities_.empty();
+    }
+    // every context's lists (object numbers of ITS sublist) -> the view's Clusters, each cluster's entities in list order
+    void merge_clusters(const mi_cluster_view& cview, uint32_t n_clusters, FrameOutput& out) {
+        const uint32_t N = (uint32_t)ctxs_.size();
+        out.has_clusters = true;
+        Clusters& cl = out.clusters;
+        std::memcpy(cl.dimensions, cview.dims, sizeof cl.dimensions);
+        cl.farthest_z = 0.0f;
+        cl.total_index_count = 0;
+        cl.clusterable_objects.assign(n_clusters, ObjectsInCluster{});
+        std::vector<std::vector<uint32_t>> offs(N), idx(N);
+        std::vector<uint32_t> counts(6 * (size_t)n_clusters);
+        for (uint32_t d = 0; d < N; ++d) {
+            if (shard_lights_[d].empty()) continue;
+            uint64_t total = 0;
+            float far_z = 0.0f;
+            offs[d].assign((size_t)n_clusters + 1, 0u);
+            check(d, mi_cluster_download(ctxs_[d], offs[d].data(), nullptr, 0, counts.data(), &total, &far_z));
+            idx[d].assign(std::max<uint64_t>(total, 1), 0u);
+            if (total) check(d, mi_cluster_download(ctxs_[d], nullptr, idx[d].data(), total, nullptr, nullptr, nullptr));
+            cl.total_index_count += total;
+            cl.farthest_z = std::max(cl.farthest_z, far_z);  // farthest_z.max(..) over the objects, from 0.0 (assign.rs:421, 561)
+            for (uint32_t c = 0; c < n_clusters; ++c)
+                for (uint32_t k = 0; k < 6; ++k) cl.clusterable_objects[c].counts[k] += counts[6 * (size_t)c + k];
+        }
+        std::vector<uint32_t> merged;
+        for (uint32_t c = 0; c < n_clusters; ++c) {
+            merged.clear();
+            for (uint32_t d = 0; d < N; ++d) {
+                if (offs[d].empty()) continue;
+                for (uint32_t i = offs[d][c]; i < offs[d][c + 1]; ++i) merged.push_back(shard_lights_[d][idx[d][i]]);  // position in the gathered list
+            }
+            std::sort(merged.begin(), merged.end());  // (every context's run ascends: a merge of N sorted runs)
+            for (uint32_t g : merged) cl.clusterable_objects[c].entities.push_back(light_entities_[g]);
         }
     }
 
@@ -278,11 +581,18 @@ class Mi355xShardedPlugin {
     int (*comm_destroy_)(void*) = nullptr;
     void *all_gather_ = nullptr, *group_start_ = nullptr, *group_end_ = nullptr;
     std::string note_ = "a device is named more than once: no communicator, the masks are read per context";
-    std::vector<Entity> entity_of_row_;
-    std::vector<uint32_t> row_of_index_, cnt_;
+    std::vector<std::vector<Entity>> rows_of_;     // [shard][local row]
+    std::vector<std::vector<uint8_t>> owned_;      // [shard][local row]: this context is responsible for the row (else it replicates a split root)
+    std::vector<Holder> primary_;                  // by entity index: the owning (shard, row)
+    std::unordered_map<uint32_t, std::vector<Holder>> replicas_;  // entity index -> the other holders of a replicated root
+    std::vector<uint32_t> cnt_;
     std::vector<uint64_t> masks_;
-    uint32_t rows_per_ = 0, exchange_views_ = 0xFFFFFFFFu;
-    uint64_t seen_version_ = 0, seen_bounds_ = 0;
+    std::vector<Entity> light_entities_;               // the gathered list
+    std::vector<std::vector<uint32_t>> shard_lights_;  // per context: positions in the gathered list of the objects it owns, ascending
+    std::vector<float> plane_storage_, sphere_storage_;
+    bool lights_any_spot_ = false, hier_ = false;
+    uint32_t rows_per_ = 0, exchange_views_ = 0xFFFFFFFFu, n_rows_ = 0, n_replicated_ = 0;
+    uint64_t seen_version_ = 0, seen_bounds_ = 0, seen_visibility_ = 0, lights_version_ = 0;
 };
 
 }  // namespace bevy_mi355x

@@ -779,6 +779,168 @@ static void sharded_plugin_leaves_the_same_world() {
     }
 }
 
+// SURVEY 8(e) rows 2 and 3 behind the plugin (round 6): a World WITH ChildOf -- a forest of rigs, plus one tree too big for a context's
+// fair share, which the placement opens at its root (the root becomes a replicated row) -- and clustered lights, through
+// Mi355xShardedPlugin over {0}, {0, 0, 0} (and every GPU where there are several) against the single-device plugin's fused frame on a
+// twin World: GlobalTransform, ViewVisibility, InheritedVisibility and their ticks of every entity, VisibleEntities (sorted by
+// Entity), and the view's Clusters list for list (entities in gather order, per-type counts, farthest_z, total).
+static void sharded_plugin_shards_trees_and_lights() {
+    std::vector<std::vector<int>> lists = {{0}, {0, 0, 0}};
+    if (const char* nd = std::getenv("MI_TEST_DEVICES")) {
+        std::vector<int> all;
+        for (int d = 0; d < std::atoi(nd); ++d) all.push_back(d);
+        if (all.size() > 1) lists.push_back(all);
+    }
+    for (const std::vector<int>& devices : lists) {
+        World wa, wb;
+        Mi355xPlugin pa;
+        Mi355xShardedPlugin pb(devices);
+        uint64_t rng = 0x9E3779B97F4A7C15ull + devices.size();
+        auto next = [&rng]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+        auto frand = [&](float lo, float hi) { return lo + (hi - lo) * (float)(next() % 10000) / 10000.0f; };
+        std::vector<Entity> ents, lights;
+        auto spawn_pair = [&](const Transform& t) {
+            Entity ea = wa.spawn(t), eb = wb.spawn(t);
+            CHECK(ea == eb, "twin worlds hand out the same entity");
+            ents.push_back(ea);
+            return ea;
+        };
+        auto small_transform = [&]() {
+            Transform t = Transform::from_xyz(frand(-2, 2), frand(-2, 2), frand(-2, 2));
+            const float a = frand(-0.6f, 0.6f);
+            t.rotation = {0.0f, std::sin(a), 0.0f, std::cos(a)};
+            t.scale = {frand(0.8f, 1.2f), frand(0.8f, 1.2f), frand(0.8f, 1.2f)};
+            return t;
+        };
+        // 90 rigs: a root somewhere in front of the camera, a spine, limbs (depth up to 7)
+        for (int rig = 0; rig < 90; ++rig) {
+            Transform rt = Transform::from_xyz(frand(-40, 40), frand(-25, 25), frand(-90, -5));
+            const Entity root = spawn_pair(rt);
+            std::vector<Entity> frontier = {root};
+            const int depth = 2 + (int)(next() % 6);
+            for (int dlev = 0; dlev < depth; ++dlev) {
+                std::vector<Entity> nxt;
+                for (Entity p : frontier) {
+                    const int kids = dlev == 0 ? 2 + (int)(next() % 2) : (int)(next() % 3);
+                    for (int k = 0; k < kids && nxt.size() < 12; ++k) {
+                        const Entity c = spawn_pair(small_transform());
+                        wa.add_child(p, c); wb.add_child(p, c);
+                        nxt.push_back(c);
+                    }
+                }
+                if (nxt.empty()) break;
+                frontier = nxt;
+            }
+        }
+        // one big tree (a 5-ary tree of depth 5: 781 nodes -- more than a third of the World): opened at its root over three shards
+        {
+            const Entity root = spawn_pair(Transform::from_xyz(0, 0, -40));
+            std::vector<Entity> frontier = {root};
+            for (int dlev = 0; dlev < 4; ++dlev) {
+                std::vector<Entity> nxt;
+                for (Entity p : frontier)
+                    for (int k = 0; k < 5; ++k) {
+                        const Entity c = spawn_pair(small_transform());
+                        wa.add_child(p, c); wb.add_child(p, c);
+                        nxt.push_back(c);
+                    }
+                frontier = nxt;
+            }
+        }
+        // bounds, visibility components, and lights riding on some of the nodes (and some free-standing ones)
+        for (Entity e : ents) {
+            if (next() % 4) { const Aabb bb{{0, 0, 0}, {frand(0.2f, 1.5f), frand(0.2f, 1.5f), frand(0.2f, 1.5f)}}; wa.insert_aabb(e, bb); wb.insert_aabb(e, bb); }
+            const uint64_t v = next() % 12;
+            if (v == 0) { wa.insert_visibility(e, Visibility::Hidden); wb.insert_visibility(e, Visibility::Hidden); }
+            else if (v == 1) { wa.insert_visibility(e, Visibility::Visible); wb.insert_visibility(e, Visibility::Visible); }
+            else { wa.insert_visibility(e, Visibility::Inherited); wb.insert_visibility(e, Visibility::Inherited); }
+        }
+        for (int i = 0; i < 400; ++i) {
+            Entity e;
+            if (i % 3 == 0) e = spawn_pair(Transform::from_xyz(frand(-30, 30), frand(-15, 15), frand(-80, -3)));
+            else e = ents[next() % ents.size()];
+            if (wa.has_point_light(e) || wa.has_aabb(e)) continue;
+            const float range = frand(0.5f, 6.0f);
+            wa.insert_point_light(e, range); wb.insert_point_light(e, range);
+            wa.insert_visibility(e, Visibility::Inherited); wb.insert_visibility(e, Visibility::Inherited);
+            lights.push_back(e);
+        }
+        ClusterCamera cam;
+        mi_perspective_clip_from_view(3.14159265f / 4.0f, 16.0f / 9.0f, 0.1f, cam.clip_from_view);
+        mi_compute_frustum(cam.clip_from_view, cam.camera_affine, 1000.0f, cam.frustum);
+        View view;
+        std::memcpy(view.frustum, cam.frustum, sizeof view.frustum);
+        const std::vector<View> views = {view};
+        for (int frame = 0; frame < 6; ++frame) {
+            if (frame) { wa.clear_trackers(); wb.clear_trackers(); }
+            wa.static_transform_optimizations = wb.static_transform_optimizations = frame >= 3;
+            const int n_moves = frame == 2 ? 0 : 1 + (int)(next() % 300);
+            for (int k = 0; k < n_moves; ++k) {
+                const Entity e = ents[next() % ents.size()];
+                const float dz = frand(-3, 3), dx = frand(-1, 1);
+                wa.transform_mut(e).translation.z += dz; wb.transform_mut(e).translation.z += dz;
+                wa.transform_mut(e).translation.x += dx; wb.transform_mut(e).translation.x += dx;
+            }
+            if (frame == 4) {  // a Visibility component is written: InheritedVisibility is swept again, on every shard
+                const Entity e = ents[7];
+                wa.insert_visibility(e, Visibility::Hidden); wb.insert_visibility(e, Visibility::Hidden);
+            }
+            if (frame == 5) {  // structure: a subtree changes its parent, the partition is rebuilt
+                const Entity child = ents[3], new_parent = ents[ents.size() - 5];
+                wa.remove_parent(child); wb.remove_parent(child);
+                wa.add_child(new_parent, child); wb.add_child(new_parent, child);
+            }
+            const Mi355xPlugin::FrameOutput fa = pa.frame(wa, views, &cam);
+            const Mi355xShardedPlugin::FrameOutput fb = pb.frame(wb, views, &cam);
+            if (frame == 0) {
+                CHECK(pb.sharded_by_tree(), "a World with ChildOf shards by tree");
+                if (devices.size() == 3) CHECK(pb.replicated_rows() >= 1, "the big tree was opened: its root is a replicated row");
+                uint32_t held = 0;
+                for (uint32_t c : pb.shard_rows()) held += c;
+                CHECK(held >= wb.entities().size() && held <= wb.entities().size() + pb.replicated_rows() * (uint32_t)(devices.size() - 1), "every entity is held by a shard, replicated roots by several");
+            }
+            bool same = true, same_ticks = true, same_inh = true;
+            for (Entity e : wa.entities()) {
+                same = same && wb.contains(e) && wa.global_transform(e) == wb.global_transform(e) && wa.view_visibility_bits(e) == wb.view_visibility_bits(e);
+                same_ticks = same_ticks && wa.global_transform_changed(e) == wb.global_transform_changed(e) && wa.view_visibility_changed(e) == wb.view_visibility_changed(e);
+                same_inh = same_inh && wa.inherited_visibility(e) == wb.inherited_visibility(e);
+            }
+            CHECK(same, "GlobalTransform and ViewVisibility of every entity");
+            CHECK(same_ticks, "their change ticks");
+            CHECK(same_inh, "InheritedVisibility of every entity");
+            CHECK(fa.visible_entities.size() == 1 && fb.visible_entities.size() == 1 && fa.visible_entities[0] == fb.visible_entities[0], "VisibleEntities, sorted by Entity");
+            if (frame == 0) CHECK(!fb.visible_entities[0].empty() && fb.visible_entities[0].size() < wb.entities().size(), "the camera sees some of the scene");
+            CHECK(fa.has_clusters && fb.has_clusters, "both frames carry the cluster stage");
+            bool lists_same = fa.clusters.clusterable_objects.size() == fb.clusters.clusterable_objects.size();
+            size_t total = 0;
+            for (size_t c = 0; lists_same && c < fa.clusters.clusterable_objects.size(); ++c) {
+                const ObjectsInCluster &x = fa.clusters.clusterable_objects[c], &y = fb.clusters.clusterable_objects[c];
+                lists_same = x.entities == y.entities && std::memcmp(x.counts, y.counts, sizeof x.counts) == 0;
+                total += x.entities.size();
+            }
+            if (!lists_same) {
+                size_t nd = 0, first = (size_t)-1;
+                for (size_t c = 0; c < fa.clusters.clusterable_objects.size() && c < fb.clusters.clusterable_objects.size(); ++c)
+                    if (!(fa.clusters.clusterable_objects[c].entities == fb.clusters.clusterable_objects[c].entities)) { ++nd; if (first == (size_t)-1) first = c; }
+                std::printf("    devices %zu frame %d: totals %llu / %llu, %zu clusters differ, first %zu:", devices.size(), frame, (unsigned long long)fa.clusters.total_index_count,
+                            (unsigned long long)fb.clusters.total_index_count, nd, first);
+                if (first != (size_t)-1) {
+                    for (Entity e : fa.clusters.clusterable_objects[first].entities) std::printf(" %u", e.index);
+                    std::printf(" |");
+                    for (Entity e : fb.clusters.clusterable_objects[first].entities) std::printf(" %u", e.index);
+                    std::printf(" | counts %u %u / %u %u", fa.clusters.clusterable_objects[first].counts[0], fa.clusters.clusterable_objects[first].counts[1],
+                                fb.clusters.clusterable_objects[first].counts[0], fb.clusters.clusterable_objects[first].counts[1]);
+                }
+                std::printf("\n");
+            }
+            CHECK(lists_same, "every cluster's list (gather order) and per-type counts");
+            CHECK(fa.clusters.total_index_count == fb.clusters.total_index_count && total == fb.clusters.total_index_count, "the total index count");
+            CHECK(fa.clusters.farthest_z == fb.clusters.farthest_z, "farthest_z");
+            if (frame == 0) CHECK(total > 0, "some light is assigned");
+        }
+    }
+}
+
 static Transform on_sphere(uint64_t i, uint64_t n, double radius, uint64_t& seed, bool rotate);  // (below, with the bench)
 // The same twin-world check at a size where the fused frame takes its big-table routes: the gather and the write-back in chunks on the
 // plugin's threads, an all-dirty table committed as eight dense windows (which the library sends in pieces, fetching the
@@ -944,12 +1106,13 @@ int main(int argc, char** argv) {
                        {"render_multidrawable_batch_set", render_multidrawable_batch_set},
                        {"both_forms_leave_the_same_world", both_forms_leave_the_same_world},
                        {"sharded_plugin_leaves_the_same_world", sharded_plugin_leaves_the_same_world},
+                       {"sharded_plugin_shards_trees_and_lights", sharded_plugin_shards_trees_and_lights},
                        {"big_flat_worlds_agree", big_flat_worlds_agree}};
     int n_failed_tests = 0, n_tests = 0;
     for (int form = 0; form < 2; ++form) {
         g_fused = form == 1;
         for (const T& t : tests) {
-            if (form == 1 && (t.fn == both_forms_leave_the_same_world || t.fn == big_flat_worlds_agree || t.fn == sharded_plugin_leaves_the_same_world)) continue;  // (drive both forms themselves)
+            if (form == 1 && (t.fn == both_forms_leave_the_same_world || t.fn == big_flat_worlds_agree || t.fn == sharded_plugin_leaves_the_same_world || t.fn == sharded_plugin_shards_trees_and_lights)) continue;  // (drive both forms themselves)
             const int before = g_failed;
             ++n_tests;
             try {

@@ -1532,7 +1532,7 @@ fn frame_clusters_missing(frame: Res<Mi355xFrame>) -> bool {
 
 /// `GlobalTransform` an entity is about to get: its `Transform` chained up the `ChildOf` links with the reference's own operators
 /// (`GlobalTransform::from`, `mul_transform`: global_transform.rs:315-330) -- what `propagate_parent_transforms` computes for it.
-fn expected_global(entity: Entity, transforms: &Query<(Entity, Ref<Transform>, Option<&ChildOf>)>) -> Option<GlobalTransform> {
+pub(crate) fn expected_global(entity: Entity, transforms: &Query<(Entity, Ref<Transform>, Option<&ChildOf>)>) -> Option<GlobalTransform> {
     let mut chain = Vec::new();
     let mut cur = Some(entity);
     while let Some(e) = cur {

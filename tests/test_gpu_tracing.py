@@ -63,7 +63,7 @@ def test_entry_points_are_roctx_ranges(tmp_path, on):
     pops = [l for l in lines if l.startswith("pop")]
     assert len(pushes) == len(pops) and len(pushes) >= 5
     names = {p[2] for p in pushes}
-    for want in ("mi_resize", "mi_upload_transforms", "mi_upload_bounds", "mi_propagate_and_cull", "mi_download_visibility"):
+    for want in ("mi_columns_resize", "mi_upload_transforms", "mi_upload_bounds", "mi_propagate_and_cull", "mi_download_visibility"):
         assert any(n.startswith(want) for n in names), (want, sorted(names))
     depth = 0
     for l in lines:  # well nested, never below zero

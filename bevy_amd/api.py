@@ -189,7 +189,7 @@ ABI_SYMBOLS = [
     "mi_abi_version", "mi_ctx_create", "mi_ctx_destroy", "mi_last_error_string", "mi_synchronize",
     "mi_columns_resize", "mi_upload_transforms", "mi_upload_transforms_indexed", "mi_map_upload_window", "mi_commit_upload_window", "mi_upload_global_transforms", "mi_upload_bounds", "mi_upload_render_layers_hi",
     "mi_upload_view_visibility", "mi_upload_visibility_classes", "mi_upload_entity_keys", "mi_upload_changed",
-    "mi_upload_visibility_ranges", "mi_upload_visibility", "mi_upload_hierarchy", "mi_hierarchy_sort", "mi_propagate",
+    "mi_upload_visibility_ranges", "mi_upload_visibility", "mi_upload_hierarchy", "mi_hierarchy_sort", "mi_hierarchy_advice_for", "mi_propagate",
     "mi_visibility_propagate", "mi_download_inherited_visibility",
     "mi_visibility_begin_frame", "mi_cull", "mi_cull_views", "mi_propagate_and_cull", "mi_propagate_and_cull_views",
     "mi_visibility_end_frame", "mi_check_light_mesh_visibility",
@@ -353,6 +353,23 @@ def hierarchy_sort(parent):
     if rc != MI_OK:
         raise MiError(rc, "mi_hierarchy_sort: malformed hierarchy" if rc == MI_ERR_MALFORMED_HIERARCHY else "mi_hierarchy_sort")
     return new_to_old[:n], pidx[:n], offs[:nl.value + 1].copy()
+
+
+class HierarchyAdvice(C.Structure):
+    """mi_hierarchy_advice"""
+    _fields_ = [("plan", C.c_uint32), ("keep_on_host", C.c_uint32), ("n_levels", C.c_uint32), ("widest_level", C.c_uint32),
+                ("est_device_us", C.c_float), ("est_host_us", C.c_float)]
+
+
+def hierarchy_advice(level_offsets):
+    """How mi_propagate would walk a hierarchy of these level sizes and whether the stock CPU systems should keep it (a hierarchy no
+    wider than a wave: a chain, a rope) -> dict(plan, keep_on_host, n_levels, widest_level, est_device_us, est_host_us).  No context."""
+    offs = _u32(level_offsets)
+    a = HierarchyAdvice()
+    rc = load_library().mi_hierarchy_advice_for(max(len(offs) - 1, 0), _ptr(offs, C.c_uint32), C.byref(a))
+    if rc != MI_OK:
+        raise MiError(rc, "mi_hierarchy_advice_for")
+    return {k: getattr(a, k) for k, _ in HierarchyAdvice._fields_}
 
 
 # ---- device context ------------------------------------------------------------------------------

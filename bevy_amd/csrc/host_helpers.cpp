@@ -10,6 +10,7 @@
 
 #include "../../include/bevy_mi355x.h"
 #include "glam_math.h"
+#include "kernels.h"  // TILE_MAX_LEVELS: mi_hierarchy_advice_for asks the planner's question
 
 using namespace mi;
 
@@ -353,6 +354,29 @@ int32_t mi_cluster_view_build(const float camera_affine[12], const float clip_fr
 
 // Level (BFS) order of an arbitrary ChildOf array -- replaces the Children Vec<Entity> pointer chase
 // (crates/bevy_ecs/src/hierarchy.rs:107,152) with contiguous per-level ranges.
+// (the rule mi_upload_hierarchy applies -- ctx_hierarchy.cpp: ctx->narrow -- as a question the host can ask before it uploads anything)
+int32_t mi_hierarchy_advice_for(uint32_t n_levels, const uint32_t* level_offsets, mi_hierarchy_advice* out) {
+    if (!out || (n_levels && !level_offsets)) return MI_ERR_INVALID_ARG;
+    mi_hierarchy_advice a{};
+    a.n_levels = n_levels;
+    bool every_level_fits_a_wave = n_levels > 0;
+    for (uint32_t l = 0; l < n_levels; ++l) {
+        if (level_offsets[l + 1] < level_offsets[l]) return MI_ERR_MALFORMED_HIERARCHY;
+        const uint32_t w = level_offsets[l + 1] - level_offsets[l];
+        a.widest_level = w > a.widest_level ? w : a.widest_level;
+        every_level_fits_a_wave = every_level_fits_a_wave && w >= 1u && w <= 64u;
+    }
+    const uint32_t n = n_levels ? level_offsets[n_levels] - level_offsets[0] : 0u;
+    a.est_host_us = 0.02f * (float)n;
+    a.plan = n_levels <= 1u ? MI_HIERARCHY_PLAN_FLAT : (every_level_fits_a_wave && n_levels > mi::TILE_MAX_LEVELS) ? MI_HIERARCHY_PLAN_ONE_WAVE : MI_HIERARCHY_PLAN_TILES;
+    if (a.plan == MI_HIERARCHY_PLAN_ONE_WAVE) {
+        a.est_device_us = 8.0f + 0.32f * (float)n_levels;  // a launch and its round trips + the dependent level steps (profiles/r05zz/shapes_table.md: chain 791 us / 2 500 levels)
+        a.keep_on_host = a.est_host_us < a.est_device_us ? 1u : 0u;
+    }
+    *out = a;
+    return MI_OK;
+}
+
 int32_t mi_hierarchy_sort(uint32_t n, const uint32_t* parent, uint32_t* new_to_old, uint32_t* out_parent_idx,
                           uint32_t* out_level_offsets, uint32_t level_capacity, uint32_t* out_n_levels) {
     if (!parent || !new_to_old || !out_parent_idx || !out_level_offsets || !out_n_levels || level_capacity < 2) return MI_ERR_INVALID_ARG;

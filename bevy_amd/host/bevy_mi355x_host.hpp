@@ -572,11 +572,22 @@ class Mi355xPlugin {
     Mi355xPlugin(const Mi355xPlugin&) = delete;
     Mi355xPlugin& operator=(const Mi355xPlugin&) = delete;
 
+    // A hierarchy the stock systems should keep (mi_hierarchy_advice_for: no level wider than a wave -- a chain, a rope, one rig -- where
+    // the device has nothing to run side by side and a CPU core is faster; transform_hierarchy.rs's `chain`: 0.8 ms against 0.05):
+    // the plugin then leaves mark_dirty_trees / propagate_parent_transforms / sync_simple_transforms to the host (below) and hands
+    // the GlobalTransforms to the visibility stage.  set_keep_narrow_hierarchies_on_host(false): everything on the device (tests).
+    bool transforms_on_host() const { return transforms_on_host_; }
+    void set_keep_narrow_hierarchies_on_host(bool on) { allow_host_transforms_ = on; seen_version_ = 0; }
+
     // TransformSystems::Propagate
     void propagate_transforms(World& w) {
         sync_structure(w);
         const uint32_t n = (uint32_t)entity_of_row_.size();
         if (n == 0) return;
+        if (transforms_on_host_) {
+            stock_propagate_transforms(w);
+            return;
+        }
         // Changed<Transform> rows: sparse upload (also raises their "changed" byte)
         std::vector<uint32_t> rows;
         std::vector<float> t, r, s;
@@ -647,6 +658,30 @@ class Mi355xPlugin {
         if (rebuilt) out.device_waits += 1;  // (the rebuild path synchronises in mi_columns_resize / its uploads)
         const uint32_t n = (uint32_t)entity_of_row_.size();
         if (n == 0) return out;
+        if (transforms_on_host_) {
+            // the stock transform systems keep this World (propagate_transforms above); visibility, light visibility and clusters follow
+            // as the systems they are, on the device, over the GlobalTransforms the host computed
+            propagate_transforms(w);
+            if (rebuilt || seen_visibility_ != w.visibility_version_) {
+                visibility_propagate(w);
+                seen_visibility_ = w.visibility_version_;
+            }
+            const bool light_pass_h = shadows != nullptr && !views.empty() && w.n_shadow_lights_ != 0;
+            if (!views.empty()) {
+                check_visibility(w, views, /*close_frame=*/!light_pass_h);
+                for (uint32_t v = 0; v < views.size(); ++v) out.visible_entities.push_back(visible_entities(v));
+                if (light_pass_h) {
+                    out.light_visibility = check_light_mesh_visibility(w, views, out.visible_entities, shadows->lod_origin);
+                    out.has_light_visibility = true;
+                } else if (shadows) out.has_light_visibility = true;
+            }
+            if (cam != nullptr && !views.empty()) {
+                out.clusters = assign_objects_to_clusters(w, *cam);
+                out.has_clusters = true;
+            }
+            for (uint32_t row = 0; row < n; ++row) out.changed_global_transforms += w.global_changed_[entity_of_row_[row].index] ? 1u : 0u;
+            return out;
+        }
         // InheritedVisibility is an input of the cull: recomputed (on the device) only in frames that wrote a Visibility
         if (rebuilt || seen_visibility_ != w.visibility_version_) {
             visibility_propagate(w);
@@ -1125,6 +1160,12 @@ class Mi355xPlugin {
         if (rc != MI_OK) throw std::runtime_error("mi_hierarchy_sort failed");
         entity_of_row_.resize(n);
         for (uint32_t row = 0; row < n; ++row) entity_of_row_[row] = ents[new_to_old[row]];
+        parent_row_.assign(pidx.begin(), pidx.begin() + n);
+        {
+            mi_hierarchy_advice advice{};
+            if (mi_hierarchy_advice_for(n_levels, offs.data(), &advice) != MI_OK) throw std::runtime_error("mi_hierarchy_advice_for failed");
+            transforms_on_host_ = allow_host_transforms_ && advice.keep_on_host != 0;
+        }
         row_of_index_.assign(w.rec_.size(), MI_NO_PARENT);
         for (uint32_t row = 0; row < n; ++row) row_of_index_[entity_of_row_[row].index] = row;
         check(mi_columns_resize(ctx_, n));
@@ -1155,6 +1196,49 @@ class Mi355xPlugin {
         upload_bounds(w);  // the flag byte carries InheritedVisibility: the device must start from the World's values
         lights_version_ = 0;  // rows were renumbered: the lights are bound again
         return true;
+    }
+    // mark_dirty_trees + propagate_parent_transforms + sync_simple_transforms (crates/bevy_transform/src/systems.rs:42-79, 111-306,
+    // 506-748) as the stock systems run them, on the host: rows are in level order, so one sweep meets every parent before its
+    // children.  Same rule as the kernels (kernels_tree.hip: node_apply) and the same glam operations (csrc/glam_math.h through
+    // GlobalTransform::from / operator*), hence the same bits and the same change ticks -- tests/cpp/host_systems_test.cpp runs
+    // `chain` both ways.  Then the GlobalTransform column goes to the device for the visibility stage (a narrow hierarchy is small).
+    void stock_propagate_transforms(World& w) {
+        const uint32_t n = (uint32_t)entity_of_row_.size();
+        const bool static_opt = w.static_transform_optimizations;
+        std::vector<uint8_t> tree(n, 0), bumped(n, 0);
+        if (static_opt)  // mark_dirty_trees returns early unless the optimisation is enabled (systems.rs:131-133)
+            for (uint32_t row = 0; row < n; ++row)
+                if (w.moved_[entity_of_row_[row].index])
+                    for (uint32_t r = row; r != MI_NO_PARENT && !tree[r]; r = parent_row_[r]) tree[r] = 1;
+        for (uint32_t row = 0; row < n; ++row) {
+            const uint32_t i = entity_of_row_[row].index, p = parent_row_[row];
+            if (p == MI_NO_PARENT) {
+                // a root with children: assigned unless its tree is static (systems.rs:522-530); a flat row: iff its own Transform
+                // changed (sync_simple_transforms, :58-63) -- plain assignments, the tick moves
+                const bool write = !w.rec_[i].children.empty() ? (!static_opt || tree[row]) : w.moved_[i] != 0;
+                if (write) {
+                    w.global_[i] = GlobalTransform::from(w.transform_[i]);
+                    bumped[row] = 1;
+                }
+                continue;
+            }
+            if (static_opt && !tree[row] && !bumped[p]) continue;  // the static-scene rule (systems.rs:708-714); its subtree is not visited either
+            const GlobalTransform nw = w.global_[entity_of_row_[p].index] * w.transform_[i];
+            if (!(nw == w.global_[i])) {  // set_if_neq (systems.rs:719)
+                w.global_[i] = nw;
+                bumped[row] = 1;
+            }
+        }
+        std::vector<float> g(12 * (size_t)n);
+        for (uint32_t row = 0; row < n; ++row) {
+            const uint32_t i = entity_of_row_[row].index;
+            if (bumped[row]) {
+                w.global_changed_[i] = 1;
+                w.touch(i);
+            }
+            std::memcpy(&g[12 * (size_t)row], w.global_[i].cols, 48);
+        }
+        check(mi_upload_global_transforms(ctx_, 0, n, g.data()));
     }
     // The clusterable objects of the fused frame: point lights in query (Entity) order, each bound to its ROW -- the device takes
     // the centre from the row's GlobalTransform and gathers only the lights whose ViewVisibility::get() is true (assign.rs:190-296).
@@ -1317,8 +1401,10 @@ class Mi355xPlugin {
     std::vector<std::pair<uint64_t, uint64_t>> bin_keys_;  // per metadata entry: (batch set key, bin key)
     uint64_t seen_binning_ = 0, seen_binning_structure_ = 0;
     std::vector<Entity> entity_of_row_;
+    std::vector<uint32_t> parent_row_;  // per row: its parent's row (MI_NO_PARENT for roots); rows are in level order
     uint64_t seen_version_ = 0;
     bool bounds_dirty_ = true;
+    bool transforms_on_host_ = false, allow_host_transforms_ = true;
 };
 
 }  // namespace bevy_mi355x

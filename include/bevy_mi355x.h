@@ -264,6 +264,28 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
 int32_t mi_hierarchy_sort(uint32_t n, const uint32_t* parent, uint32_t* out_new_to_old, uint32_t* out_parent_idx,
                           uint32_t* out_level_offsets, uint32_t level_capacity, uint32_t* out_n_levels);
 
+/* Host helper: how mi_propagate would walk a hierarchy of these level sizes, and whether the STOCK systems should keep it
+ * (round 6).  propagate_parent_transforms (crates/bevy_transform/src/systems.rs:506-657) walks a tree depth first on a CPU core: a
+ * node is ~20 ns of arithmetic whatever the shape.  The device wins by running thousands of nodes side by side; a hierarchy in which
+ * NO level holds more than a wave of rows (transform_hierarchy.rs's `chain`: 2 500 levels of one node; a rope; one rig) has nothing
+ * to run side by side -- it is levels x the latency of one dependent level step (~0.32 us on MI355X: one wave's instruction stream,
+ * k_propagate_narrow), i.e. 16 x a CPU core's time on `chain`.  For such a World the plugin keeps mark_dirty_trees /
+ * propagate_parent_transforms / sync_simple_transforms registered (the host layers: bevy_amd/host/bevy_mi355x_host.hpp,
+ * rust/bevy_mi355x/src/lib.rs) and hands the GlobalTransforms to the visibility stage.  Pure host code (no ctx).
+ *   level_offsets[n_levels + 1]   as for mi_upload_hierarchy (mi_hierarchy_sort's output) */
+#define MI_HIERARCHY_PLAN_FLAT 0u      /* one level: every row a root (k_frame / k_level0_propagate) */
+#define MI_HIERARCHY_PLAN_TILES 1u     /* subtree tiles (or a wave per tree, or level by level): the device has rows to run side by side */
+#define MI_HIERARCHY_PLAN_ONE_WAVE 2u  /* every level at most 64 rows and more than 16 levels: one wave walks the whole hierarchy */
+typedef struct mi_hierarchy_advice {
+    uint32_t plan;           /* MI_HIERARCHY_PLAN_* */
+    uint32_t keep_on_host;   /* 1 = the stock CPU systems are expected to be faster for this hierarchy */
+    uint32_t n_levels;
+    uint32_t widest_level;   /* rows of the widest level */
+    float est_device_us;     /* the model behind keep_on_host: a launch + levels x the dependent level step (plan ONE_WAVE; 0 otherwise) */
+    float est_host_us;       /* rows x 20 ns on one core */
+} mi_hierarchy_advice;
+int32_t mi_hierarchy_advice_for(uint32_t n_levels, const uint32_t* level_offsets, mi_hierarchy_advice* out);
+
 /* ======================================================================================= */
 /* systems                                                                                   */
 /* ======================================================================================= */

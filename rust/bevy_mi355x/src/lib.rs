@@ -149,6 +149,9 @@ pub struct Mi355x {
     /// `MI_UPLOAD_ROTATION` and sends 16 bytes per moved row instead of 40.  A component that is not carried keeps the value of the
     /// last full upload (every structural rebuild sends all three) -- setting this while a system writes the others is the app's bug.
     pub upload_components: u32,
+    /// The last structural rebuild found a hierarchy the stock systems should keep (`mi_hierarchy_advice_for`: no level wider than a
+    /// wave): the frames fall back (see [`CpuFallback`]) until the structure changes, when the question is asked again.
+    hierarchy_kept_on_host: bool,
     /// Whether the device's VisibilityRange column was last staged with a `VisibleEntityRanges` resource present (`None`: never staged).
     /// `Option<Res<VisibleEntityRanges>>` being `None` means no range hides anything (visibility/mod.rs:814-816): no column then.
     ranges_resource: Option<bool>,
@@ -227,7 +230,8 @@ impl Mi355x {
                 rows_in_table_order: false,
                 every_row_moved: false,
                 upload_components: 0,
-                ranges_resource: None,
+                hierarchy_kept_on_host: false,
+            ranges_resource: None,
                 sphere_storage: Vec::new(),
                 scratch: Scratch::default(),
             })
@@ -502,11 +506,15 @@ pub fn mi_propagate_transforms(
     // (as the reference does inside its own systems, crates/bevy_transform/src/systems.rs:169-283, :592: a span per stage under `trace`)
     #[cfg(feature = "trace")]
     let _span = info_span!("mi_propagate_transforms").entered();
-    if fallback.transforms {
-        return;
-    }
     let mi = &mut *mi;
     let rebuild = !structure_changed.is_empty() || orphaned.read().count() != 0 || despawned.read().count() != 0;
+    if fallback.transforms {
+        if !(mi.hierarchy_kept_on_host && rebuild) {
+            return;
+        }
+        // not a device error: the stock systems kept a hierarchy as narrow as a chain, and its structure has just changed -- ask again
+        *fallback = CpuFallback::default();
+    }
     let result = upload_and_propagate(mi, rebuild, &ticks, &transforms, &globals.as_readonly(), None);
     let Ok(count) = result else {
         fallback.transforms = true; // nothing was written to the ECS; the stock trio runs next, in this same frame
@@ -572,6 +580,18 @@ fn upload_and_propagate(
                     &mut n_levels,
                 )
             })?;
+            // A hierarchy no wider than a wave per level (transform_hierarchy.rs's `chain`, a rope, one rig) is one wave's chain of
+            // dependent level steps on the device and 20 ns a node on a CPU core: the library says so (mi_hierarchy_advice_for), and the
+            // stock systems keep such a World -- this frame and every frame until its structure changes again.  Not an error: no log.
+            {
+                // SAFETY: level_offsets holds n_levels + 1 entries; the out struct is plain data.
+                let mut advice: ffi::MiHierarchyAdvice = unsafe { core::mem::zeroed() };
+                check(ctx, "mi_hierarchy_advice_for", unsafe { ffi::mi_hierarchy_advice_for(n_levels, s.level_offsets.as_ptr(), &mut advice) })?;
+                mi.hierarchy_kept_on_host = advice.keep_on_host != 0;
+                if mi.hierarchy_kept_on_host {
+                    return Err(());
+                }
+            }
             // rows := level order
             let old_entities = core::mem::take(&mut mi.row_entity);
             let gather3 = |src: &Vec<f32>, w: usize| -> Vec<f32> {
@@ -1585,12 +1605,15 @@ pub fn mi_fused_frame(
     let _span = info_span!("mi_fused_frame").entered();
     frame.valid = false;
     frame.clusters_valid = false;
-    if fallback.transforms {
-        return;
-    }
     let mi = &mut *mi;
     let ctx = mi.ctx;
     let rebuild = !structure_changed.is_empty() || orphaned.read().count() != 0 || despawned.read().count() != 0;
+    if fallback.transforms {
+        if !(mi.hierarchy_kept_on_host && rebuild) {
+            return;
+        }
+        *fallback = CpuFallback::default(); // (as in mi_propagate_transforms: a narrow hierarchy whose structure changed is looked at again)
+    }
     if rebuild {
         // Rows are renumbered and every column goes up again: the slow frame.  Propagate alone here; the visibility and cluster
         // systems of the three-system form (gated on `frame.valid` / `frame.clusters_valid`) take the rest of this frame.

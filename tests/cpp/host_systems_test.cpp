@@ -779,6 +779,80 @@ static void sharded_plugin_leaves_the_same_world() {
     }
 }
 
+// A hierarchy no wider than a wave per level -- transform_hierarchy.rs's `chain` (:29-160), a rope of a few strands -- is one wave's
+// chain of dependent level steps on the device (0.32 us a level) and 20 ns a node on a CPU core: mi_hierarchy_advice_for says
+// "keep it on the host", and the plugin then leaves the three transform systems to the host (stock_propagate_transforms) and runs
+// visibility over the GlobalTransforms it uploads.  Twin Worlds: the default plugin (host transforms) against one that is told to
+// keep everything on the device -- the same World after every frame, both forms.
+static void narrow_hierarchy_stays_with_the_stock_systems() {
+    World wa, wb;
+    Mi355xPlugin pa, pb;
+    pb.set_keep_narrow_hierarchies_on_host(false);
+    uint64_t rng = 0xD1B54A32D192ED03ull;
+    auto next = [&rng]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+    auto frand = [&](float lo, float hi) { return lo + (hi - lo) * (float)(next() % 10000) / 10000.0f; };
+    std::vector<Entity> ents;
+    auto spawn_pair = [&](const Transform& t) {
+        Entity ea = wa.spawn(t), eb = wb.spawn(t);
+        CHECK(ea == eb, "twin worlds hand out the same entity");
+        ents.push_back(ea);
+        return ea;
+    };
+    // a chain of 60 nodes in front of the camera and a rope of three strands hanging off its root, 40 levels deep
+    std::vector<Entity> tips = {spawn_pair(Transform::from_xyz(0, 0, -30))};
+    const Entity root = tips[0];
+    for (int k = 0; k < 3; ++k) {
+        Entity c = spawn_pair(Transform::from_xyz(frand(-1, 1), frand(-1, 1), frand(-1, 0)));
+        wa.add_child(root, c); wb.add_child(root, c);
+        tips.push_back(c);
+    }
+    for (int level = 0; level < 59; ++level)
+        for (size_t k = 0; k < tips.size(); ++k) {
+            if (k > 0 && level >= 39) continue;
+            Transform t = Transform::from_xyz(frand(-0.3f, 0.3f), frand(-0.3f, 0.3f), frand(-0.4f, 0.1f));
+            const float a = frand(-0.2f, 0.2f);
+            t.rotation = {0.0f, std::sin(a), 0.0f, std::cos(a)};
+            t.scale = {frand(0.95f, 1.05f), frand(0.95f, 1.05f), frand(0.95f, 1.05f)};
+            const Entity c = spawn_pair(t);
+            wa.add_child(tips[k], c); wb.add_child(tips[k], c);
+            tips[k] = c;
+        }
+    for (Entity e : ents)
+        if (next() % 3) { const Aabb bb{{0, 0, 0}, {0.3f, 0.3f, 0.3f}}; wa.insert_aabb(e, bb); wb.insert_aabb(e, bb); }
+    const std::vector<View> views = {camera_looking_down_neg_z()};
+    for (int frame = 0; frame < 5; ++frame) {
+        if (frame) { wa.clear_trackers(); wb.clear_trackers(); }
+        wa.static_transform_optimizations = wb.static_transform_optimizations = frame >= 2;
+        const int n_moves = frame == 3 ? 0 : 1 + (int)(next() % 12);
+        for (int k = 0; k < n_moves; ++k) {
+            const Entity e = ents[next() % ents.size()];
+            const float dz = frand(-0.5f, 0.5f);
+            wa.transform_mut(e).translation.z += dz; wb.transform_mut(e).translation.z += dz;
+        }
+        const std::vector<std::vector<Entity>> la = post_update(pa, wa, views), lb = post_update(pb, wb, views);
+        if (frame == 0) {
+            CHECK(pa.transforms_on_host(), "a chain and a rope: the stock transform systems keep the World");
+            CHECK(!pb.transforms_on_host(), "told otherwise, the plugin propagates on the device");
+        }
+        bool same = true, same_ticks = true;
+        for (Entity e : wa.entities()) {
+            same = same && wa.global_transform(e) == wb.global_transform(e) && wa.view_visibility_bits(e) == wb.view_visibility_bits(e);
+            same_ticks = same_ticks && wa.global_transform_changed(e) == wb.global_transform_changed(e) && wa.view_visibility_changed(e) == wb.view_visibility_changed(e);
+        }
+        CHECK(same, "GlobalTransform and ViewVisibility of every entity: host transforms against the device's");
+        CHECK(same_ticks, "their change ticks");
+        CHECK(la == lb, "VisibleEntities");
+        if (frame == 0) CHECK(!la[0].empty(), "the camera sees the chain");
+    }
+    // a bushy tree is the device's: the advice is per World
+    World wc;
+    Mi355xPlugin pc;
+    const Entity r2 = wc.spawn(Transform::from_xyz(0, 0, -10));
+    for (int k = 0; k < 200; ++k) wc.add_child(r2, wc.spawn(Transform::from_xyz((float)k, 0, 0)));
+    post_update(pc, wc, views);
+    CHECK(!pc.transforms_on_host(), "a wide tree stays on the device");
+}
+
 // SURVEY 8(e) rows 2 and 3 behind the plugin (round 6): a World WITH ChildOf -- a forest of rigs, plus one tree too big for a context's
 // fair share, which the placement opens at its root (the root becomes a replicated row) -- and clustered lights, through
 // Mi355xShardedPlugin over {0}, {0, 0, 0} (and every GPU where there are several) against the single-device plugin's fused frame on a
@@ -1105,6 +1179,7 @@ int main(int argc, char** argv) {
                        {"light_probes_and_decals_are_clustered", light_probes_and_decals_are_clustered},
                        {"render_multidrawable_batch_set", render_multidrawable_batch_set},
                        {"both_forms_leave_the_same_world", both_forms_leave_the_same_world},
+                       {"narrow_hierarchy_stays_with_the_stock_systems", narrow_hierarchy_stays_with_the_stock_systems},
                        {"sharded_plugin_leaves_the_same_world", sharded_plugin_leaves_the_same_world},
                        {"sharded_plugin_shards_trees_and_lights", sharded_plugin_shards_trees_and_lights},
                        {"big_flat_worlds_agree", big_flat_worlds_agree}};

@@ -45,7 +45,7 @@ def test_reference_system_tests_against_the_host_layer():
     print(res.stdout)
     failed = [line for line in res.stdout.splitlines() if line.startswith("FAILED") or "EXCEPTION" in line]
     assert res.returncode == 0 and not failed, res.stdout[-3000:] + res.stderr[-1000:]
-    assert "34 tests, 0 failed" in res.stdout  # 19 tests against the three systems (four of them drive both forms / both plugins themselves), 15 of them again against the fused frame
+    assert "36 tests, 0 failed" in res.stdout  # 20 tests against the three systems (four of them drive both forms / both plugins themselves), 16 of them again against the fused frame
 
 
 def test_host_visibility_test_compiles_and_links():

@@ -23,7 +23,8 @@ STRUCT_RUST = {"mi_ctx": "MiCtx", "mi_view": "MiView", "mi_cluster_view": "MiClu
                "mi_preprocess_work_item": "MiPreprocessWorkItem", "mi_indirect_parameters_metadata": "MiIndirectParametersMetadata",
                "mi_indirect_batch_set": "MiIndirectBatchSet", "mi_batch_set_record": "MiBatchSetRecord", "mi_batch_initial": "MiBatchInitial",
                "mi_batch_totals": "MiBatchTotals", "mi_sorted_item": "MiSortedItem", "mi_sorted_batch": "MiSortedBatch", "mi_unbatchable_index": "MiUnbatchableIndex",
-               "mi_frame_results": "MiFrameResults", "mi_visible_list": "MiVisibleList", "mi_upload_window": "MiUploadWindow"}
+               "mi_frame_results": "MiFrameResults", "mi_visible_list": "MiVisibleList", "mi_upload_window": "MiUploadWindow",
+               "mi_hierarchy_advice": "MiHierarchyAdvice"}
 
 
 def strip_comments(src):

@@ -64,7 +64,8 @@ def compact(out):
         line["single_gpu_same_workload"] = {"value": sg["value"], "ms_per_step": sg["ms_per_step"]}
     # N > 1: value / (n_gpus x the same workload on ONE GPU); CPU time per frame call; the gathered masks against the masks of the whole
     # scene in one context, bit for bit; the collective alone (events on its stream); every rank's frame kernel
-    for k in ("scaling_efficiency", "host_enqueue_ms_per_step", "gathered_masks_match_single_gpu", "all_gather_us", "kernel_us_per_rank"):
+    for k in ("scaling_efficiency", "host_enqueue_ms_per_step", "host_busy_ms_per_step", "host_backpressure_ms_per_step", "gathered_masks_match_single_gpu", "all_gather_us",
+              "kernel_us_per_rank"):
         if k in out:
             line[k] = out[k]
     line["full"] = FULL_NAME

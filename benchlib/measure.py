@@ -50,10 +50,19 @@ def measure(ctx, wl, steps, warmup, n_blocks=0, profile_all=False, barrier=None,
         if agree:
             n_blocks = agree(n_blocks)              # every rank runs the same number of blocks
     times, enq = [], []
+    try:
+        ctx.debug_exchange_times(reset=True)  # (the multi-GPU exchange's share of the calling thread's time over the timed blocks)
+    except Exception:  # noqa: BLE001 -- an older library: no such hook
+        pass
     for _ in range(n_blocks):
         t, e = run_block(steps)
         times.append(t)
         enq.append(e)
+    xt = None
+    try:
+        xt = ctx.debug_exchange_times()
+    except Exception:  # noqa: BLE001
+        pass
     if reduce_max:
         times = reduce_max(times)
     # profiled blocks: same frames, every launch of the workload's kernels timed (not part of the statistics)
@@ -68,6 +77,12 @@ def measure(ctx, wl, steps, warmup, n_blocks=0, profile_all=False, barrier=None,
         gc.enable()
     info = {"host_enqueue_ms_per_step": round(1e3 * float(np.median(enq)) / steps, 5),
             "profiled_blocks_ms_per_step": round(1e3 * float(np.median(prof_t)) / steps, 5)}
+    if xt and xt["wait_ns"] > 0:
+        # MI_EXCHANGE_PIPELINED paces the caller n_bufs - 1 frames ahead of the exchange: a device-bound frame shows up in the caller's
+        # time as WAITING for a gathered buffer's previous all-gather, not as work.  host_busy = the enqueue time without that wait.
+        wait_ms = 1e-6 * xt["wait_ns"] / (n_blocks * steps)
+        info["host_backpressure_ms_per_step"] = round(wait_ms, 5)
+        info["host_busy_ms_per_step"] = round(max(0.0, info["host_enqueue_ms_per_step"] - wait_ms), 5)
     return np.array(times), prof, info
 
 

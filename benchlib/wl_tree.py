@@ -167,6 +167,8 @@ def build_tree_shape(ctx, args):
                       kernels=["k_propagate_fans", "k_propagate_stream", "k_level0_propagate", "k_mark_dirty"])
     wl.tree = sh
     wl.kernel_name = "k_propagate_fans<false>" if frame_kind == "movers" else "k_propagate_fans<true>"
+    if name.startswith("humanoids") and not args.tile_mode:  # (a forest of small trees: a wave per tile)
+        wl.kernel_name = "k_propagate_wave_tiles<false,true>" if frame_kind == "movers" else "k_propagate_wave_tiles<true,true>"
     wl.frame_level_roofline = True  # several launches per frame on some shapes: priced per FRAME (sum of the frame's kernels), see roofline_frame
     return wl
 

@@ -206,7 +206,7 @@ ABI_SYMBOLS = [
 # include/bevy_mi355x_debug.h: instrumentation and test hooks, exported by the same library, not part of the boundary
 DEBUG_SYMBOLS = [
     "mi_timer_begin", "mi_timer_end", "mi_profile_enable", "mi_profile_filter", "mi_profile_sample", "mi_profile_burst", "mi_profile_read",
-    "mi_profile_kernel_name", "mi_debug_set_tile_mode", "mi_debug_tree_trace", "mi_debug_tile_plan", "mi_debug_tile_groups", "mi_debug_logf", "mi_debug_set_sphere_path", "mi_debug_set_row_summary", "mi_debug_set_tree_cull", "mi_debug_set_walk_inrow", "mi_debug_set_chunked_frames", "mi_debug_chunked_counts", "mi_debug_set_tile_pretest", "mi_debug_set_sorted_one_wg_limit", "mi_debug_set_static_cull_order", "mi_debug_static_cull_counts", "mi_debug_cluster_download_unjoined",
+    "mi_profile_kernel_name", "mi_debug_set_tile_mode", "mi_debug_tree_trace", "mi_debug_tile_plan", "mi_debug_tile_groups", "mi_debug_exchange_times", "mi_debug_logf", "mi_debug_set_sphere_path", "mi_debug_set_row_summary", "mi_debug_set_tree_cull", "mi_debug_set_walk_inrow", "mi_debug_set_chunked_frames", "mi_debug_chunked_counts", "mi_debug_set_tile_pretest", "mi_debug_set_sorted_one_wg_limit", "mi_debug_set_static_cull_order", "mi_debug_static_cull_counts", "mi_debug_cluster_download_unjoined",
 ]
 
 
@@ -907,6 +907,12 @@ class Context:
         v = [C.c_uint32(0) for _ in range(4)]
         self._ck(self._lib.mi_debug_tile_plan(self._h, *[C.byref(x) for x in v]))
         return dict(launches=v[0].value, tiles=v[1].value, chain_tiles=v[2].value, bands=v[3].value)
+
+    def debug_exchange_times(self, reset=False):
+        """-> dict(frames, begin_ns, wait_ns, end_ns, worker_ns): what the exchange cost the calling thread (wait_ns = device back-pressure)."""
+        out = (C.c_double * 5)()
+        self._ck(self._lib.mi_debug_exchange_times(self._h, out, 1 if reset else 0))
+        return dict(frames=out[0], begin_ns=out[1], wait_ns=out[2], end_ns=out[3], worker_ns=out[4])
 
     def debug_tile_groups(self, cap_tiles=1 << 20):
         """-> (groups [n][4]: first tile, tiles, chain tiles, deep; tiles [n][3]: levels, rows, chain length | 0x100 roots) of the tile plan."""

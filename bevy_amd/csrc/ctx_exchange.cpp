@@ -503,6 +503,24 @@ int32_t mi_exchange_configure_owned(mi_ctx* ctx, void* const* nccl_comms, uint32
     return rc;
 }
 
+// bench hook (include/bevy_mi355x_debug.h): what the exchange cost the CALLING thread so far -- out[0] frames, out[1] ns inside the
+// begin step, out[2] of which spent waiting for a gathered buffer's previous all-gather to complete (back-pressure of the device: the
+// pipelined mode paces the caller n_bufs - 1 frames ahead, so a device-bound frame shows up here, not as work), out[3] ns inside the end
+// step, out[4] ns the exchange thread spent enqueueing.  reset != 0 zeroes the counters.
+int32_t mi_debug_exchange_times(mi_ctx* ctx, double* out5, int32_t reset) {
+    ENTER_RAW(ctx);
+    auto& x = ctx->xch;
+    if (out5) {
+        out5[0] = (double)x.frame;
+        out5[1] = x.dbg_begin_ns;
+        out5[2] = x.dbg_wait_ns;
+        out5[3] = x.dbg_end_ns;
+        out5[4] = x.dbg_worker_ns;
+    }
+    if (reset) x.dbg_begin_ns = x.dbg_wait_ns = x.dbg_end_ns = x.dbg_worker_ns = 0.0;
+    return MI_OK;
+}
+
 int32_t mi_exchange_last(mi_ctx* ctx, void** out_device_buf, int32_t wait) {
     ENTER(ctx);
     auto& x = ctx->xch;

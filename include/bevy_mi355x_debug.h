@@ -40,6 +40,9 @@ int32_t mi_debug_set_tile_mode(mi_ctx* ctx, int32_t mode);
  * allocates the buffer (mi_propagate then fills it every frame); out != NULL copies n_tiles x 8 stamps out; enable == 0 with
  * out == NULL switches the stamps off again. */
 int32_t mi_debug_tree_trace(mi_ctx* ctx, int32_t enable, unsigned long long* out, uint32_t n_tiles);
+/* What the multi-GPU exchange cost the calling thread: out5 = frames, ns in the begin step, ns of those spent WAITING for a gathered
+ * buffer's previous all-gather (device back-pressure in MI_EXCHANGE_PIPELINED, not work), ns in the end step, ns of the exchange thread. */
+int32_t mi_debug_exchange_times(mi_ctx* ctx, double* out5, int32_t reset);
 /* The shape of the current tile plan: launches per mi_propagate, tiles, chain tiles (self-evaluated ancestor chains), bands. */
 int32_t mi_debug_tile_plan(mi_ctx* ctx, uint32_t* out_launches, uint32_t* out_tiles, uint32_t* out_chain_tiles, uint32_t* out_bands);
 /* The launches of the current tile plan: out_groups[4g ..] = (first tile, tiles, chain tiles, deep instantiation) per launch; out_tiles[3t ..] =

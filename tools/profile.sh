@@ -7,7 +7,7 @@
 # profiles/rocprof_summary.json (what bench.py quotes as rocprof_avg_kernel_us / traffic).
 TAG=${1:-r03}
 shift
-WLS=${@:-frame frame_plain_columns flat flat_plain_columns flat_10m_1view flat_10m_4views tree tree_subtree tree_leaves tree_frame tree_frame_two_launches lights flat_static flat_static_no_sphere flat_static_10m_4views flat_static_10m_4views_no_cull_order flat_static_4m_4views tree_by_levels batching batching_sorted_1k batching_sorted_4k batching_sorted_64k batching_sorted_1m flat_1250k_4views tree_shape_chain tree_shape_humanoids_mixed tree_shape_deep_tree tree_shape_large_tree tree_shape_tree_4ary_depth12}
+WLS=${@:-frame frame_plain_columns flat flat_plain_columns flat_10m_1view flat_10m_4views tree tree_subtree tree_leaves tree_frame tree_frame_two_launches lights flat_static flat_static_no_sphere flat_static_10m_4views flat_static_10m_4views_no_cull_order flat_static_4m_4views tree_by_levels batching batching_sorted_1k batching_sorted_4k batching_sorted_64k batching_sorted_1m flat_1250k_4views tree_shape_chain tree_shape_humanoids_mixed tree_shape_humanoids_active tree_shape_deep_tree tree_shape_large_tree tree_shape_update_leaves tree_shape_tree_4ary_depth12}
 export TMPDIR=/tmp
 P=gpurun_out/prof_$TAG
 mkdir -p $P

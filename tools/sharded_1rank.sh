@@ -15,15 +15,18 @@ python bench.py $COMMON 2> $OUT/no_exchange.err | tail -n 1 > $OUT/no_exchange.j
 python - "$OUT" <<'PY'
 import json, sys, os
 out = sys.argv[1]
-print("| mode | us / frame | host enqueue us / frame | kernel us | exchange_mode |")
-print("|---|---|---|---|---|")
+print("| mode | us / frame | host enqueue us / frame | of which waiting for the device (back-pressure) | host busy us / frame | kernel us | gathered masks == single-GPU masks | all-gather alone us | exchange_mode |")
+print("|---|---|---|---|---|---|---|---|---|")
 for name in ("no_exchange", "simple_sync", "simple_async", "pipelined", "default_calibrated"):
     try:
         d = json.load(open(os.path.join(out, name + ".json")))
     except Exception as e:
         print("|", name, "| unreadable:", e, "|")
         continue
-    print(f"| {name} | {1e3 * d['ms_per_step']:.2f} | {1e3 * d.get('host_enqueue_ms_per_step', float('nan')):.2f} | {d['roofline']['avg_kernel_us']} | {d['config'].get('exchange_mode')} ranks={d['config'].get('rccl_ranks')} |")
+    bp, busy = d.get('host_backpressure_ms_per_step'), d.get('host_busy_ms_per_step')
+    print(f"| {name} | {1e3 * d['ms_per_step']:.2f} | {1e3 * d.get('host_enqueue_ms_per_step', float('nan')):.2f} | {'-' if bp is None else round(1e3 * bp, 2)} | "
+          f"{'-' if busy is None else round(1e3 * busy, 2)} | {d['roofline']['avg_kernel_us']} | {d.get('gathered_masks_match_single_gpu')} | {d.get('all_gather_us')} | "
+          f"{d['config'].get('exchange_mode')} ranks={d['config'].get('rccl_ranks')} |")
 PY
 python -c "
 import json,sys

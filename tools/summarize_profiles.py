@@ -25,6 +25,7 @@ ALIAS = {"k_frame_sph<true": "k_flat_propagate_cull", "k_frame_sph<false": "k_cu
          "k_frame_pairs<1": "k_flat_propagate_cull", "k_frame_pairs<2": "k_flat_propagate_cull", "k_frame_pairs<0": "k_cull",  # 2 .. 4 camera views  # PROP: 1 all rows, 2 changed rows, 0 resident G (any INLINE_VIEWS / WITH_WALK variant)
          "k_frame<true": "k_flat_propagate_cull", "k_frame<false": "k_cull",  # (profiles from before PROP was an int)
          "k_propagate_level": "k_propagate_stream", "k_propagate_narrow": "k_propagate_stream",
+         "k_propagate_wave_tiles": "k_propagate_fans",  # a forest of small trees: a wave per tile (round 6), timed in the tile launch's slot
          "k_frame_cells": "k_cull",  # the frame over the static cull order (its cell test: k_cells_test, its lists: k_cells_blocks / k_cells_lists)
          "k_sorted_walk<512u, 16u, true>": "k_batch_scan", "k_sorted_walk<512, 16, true>": "k_batch_scan",  # the tiles' records
          "k_sorted_walk": "k_batch_sorted"}

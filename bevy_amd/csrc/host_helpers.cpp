@@ -370,7 +370,9 @@ int32_t mi_hierarchy_advice_for(uint32_t n_levels, const uint32_t* level_offsets
     a.est_host_us = 0.02f * (float)n;
     a.plan = n_levels <= 1u ? MI_HIERARCHY_PLAN_FLAT : (every_level_fits_a_wave && n_levels > mi::TILE_MAX_LEVELS) ? MI_HIERARCHY_PLAN_ONE_WAVE : MI_HIERARCHY_PLAN_TILES;
     if (a.plan == MI_HIERARCHY_PLAN_ONE_WAVE) {
-        a.est_device_us = 8.0f + 0.32f * (float)n_levels;  // a launch and its round trips + the dependent level steps (profiles/r05zz/shapes_table.md: chain 791 us / 2 500 levels)
+        // a launch and its round trips + the dependent level steps: 0.32 us a level with a node per quad of lanes (no level above 16
+        // rows: chain 774 us / 2 500 levels), 0.85 us with a lane per row (ropes: 260 us / 300 levels) -- profiles/r06y/shapes_table.md
+        a.est_device_us = 8.0f + (a.widest_level <= 16u ? 0.32f : 0.85f) * (float)n_levels;
         a.keep_on_host = a.est_host_us < a.est_device_us ? 1u : 0u;
     }
     *out = a;

@@ -268,8 +268,8 @@ int32_t mi_hierarchy_sort(uint32_t n, const uint32_t* parent, uint32_t* out_new_
  * (round 6).  propagate_parent_transforms (crates/bevy_transform/src/systems.rs:506-657) walks a tree depth first on a CPU core: a
  * node is ~20 ns of arithmetic whatever the shape.  The device wins by running thousands of nodes side by side; a hierarchy in which
  * NO level holds more than a wave of rows (transform_hierarchy.rs's `chain`: 2 500 levels of one node; a rope; one rig) has nothing
- * to run side by side -- it is levels x the latency of one dependent level step (~0.32 us on MI355X: one wave's instruction stream,
- * k_propagate_narrow), i.e. 16 x a CPU core's time on `chain`.  For such a World the plugin keeps mark_dirty_trees /
+ * to run side by side -- it is levels x the latency of one dependent level step (~0.32 us on MI355X with at most 16 rows to a level,
+ * ~0.85 us with up to 64: one wave's instruction stream, k_propagate_narrow), i.e. 26 x a CPU core's time on `chain`.  For such a World the plugin keeps mark_dirty_trees /
  * propagate_parent_transforms / sync_simple_transforms registered (the host layers: bevy_amd/host/bevy_mi355x_host.hpp,
  * rust/bevy_mi355x/src/lib.rs) and hands the GlobalTransforms to the visibility stage.  Pure host code (no ctx).
  *   level_offsets[n_levels + 1]   as for mi_upload_hierarchy (mi_hierarchy_sort's output) */

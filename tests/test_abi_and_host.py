@@ -240,3 +240,26 @@ def test_oracle_mark_dirty_trees_is_the_ancestor_closure():
                 r = int(parent[r])
         got = O.mark_dirty_trees(parent, changed)
         assert np.array_equal(got != 0, want != 0), trial
+
+
+def test_hierarchy_advice_keeps_only_narrow_hierarchies_on_the_host(lib):
+    """mi_hierarchy_advice_for (pure host code): the planner's question "is this hierarchy one wave's walk?" answered before anything is
+    uploaded.  The reference's `chain` (2 500 levels of one node) and a rope stay with the stock systems -- levels x 0.32 us on the device
+    against 20 ns per node on a core --; everything with rows to run side by side is the device's, whatever its depth."""
+    from bevy_amd import api, workloads as W
+    chain = api.hierarchy_advice(W.hierarchy_shape("chain")["level_offsets"])
+    assert chain["plan"] == 2 and chain["keep_on_host"] == 1 and chain["n_levels"] == 2500 and chain["widest_level"] == 1
+    assert chain["est_device_us"] > 10 * chain["est_host_us"]
+    ropes = api.hierarchy_advice(W.hierarchy_shape("ropes")["level_offsets"])
+    assert ropes["plan"] == 2 and ropes["keep_on_host"] == 1 and ropes["widest_level"] <= 64
+    for name in ("humanoids_active", "deep_tree", "large_tree", "wide_tree", "update_leaves"):
+        a = api.hierarchy_advice(W.hierarchy_shape(name)["level_offsets"])
+        assert a["plan"] == 1 and a["keep_on_host"] == 0, (name, a)
+    flat = api.hierarchy_advice([0, 1_000_000])
+    assert flat["plan"] == 0 and flat["keep_on_host"] == 0
+    # 16 levels of one node fit a tile: not the one-wave plan; 17 do not
+    assert api.hierarchy_advice(list(range(17)))["plan"] == 1 and api.hierarchy_advice(list(range(18)))["plan"] == 2
+    # an empty level is refused by the one-wave plan (ADVICE r05), a decreasing offset by the function
+    assert api.hierarchy_advice([0, 1, 1] + list(range(2, 30)))["plan"] == 1
+    with pytest.raises(api.MiError):
+        api.hierarchy_advice([0, 5, 3])

@@ -206,7 +206,7 @@ ABI_SYMBOLS = [
 # include/bevy_mi355x_debug.h: instrumentation and test hooks, exported by the same library, not part of the boundary
 DEBUG_SYMBOLS = [
     "mi_timer_begin", "mi_timer_end", "mi_profile_enable", "mi_profile_filter", "mi_profile_sample", "mi_profile_burst", "mi_profile_read",
-    "mi_profile_kernel_name", "mi_debug_set_tile_mode", "mi_debug_tree_trace", "mi_debug_tile_plan", "mi_debug_tile_groups", "mi_debug_exchange_times", "mi_debug_logf", "mi_debug_set_sphere_path", "mi_debug_set_row_summary", "mi_debug_set_tree_cull", "mi_debug_set_walk_inrow", "mi_debug_set_chunked_frames", "mi_debug_chunked_counts", "mi_debug_set_tile_pretest", "mi_debug_set_sorted_one_wg_limit", "mi_debug_set_static_cull_order", "mi_debug_static_cull_counts", "mi_debug_cluster_download_unjoined",
+    "mi_profile_kernel_name", "mi_debug_set_tile_mode", "mi_debug_tree_trace", "mi_debug_tile_plan", "mi_debug_tile_groups", "mi_debug_strip_plan", "mi_debug_exchange_times", "mi_debug_logf", "mi_debug_set_sphere_path", "mi_debug_set_row_summary", "mi_debug_set_tree_cull", "mi_debug_set_walk_inrow", "mi_debug_set_chunked_frames", "mi_debug_chunked_counts", "mi_debug_set_tile_pretest", "mi_debug_set_sorted_one_wg_limit", "mi_debug_set_static_cull_order", "mi_debug_static_cull_counts", "mi_debug_cluster_download_unjoined",
 ]
 
 
@@ -927,6 +927,14 @@ class Context:
     def debug_set_sorted_one_wg_limit(self, items):
         """Sorted phases up to `items` long take the single-workgroup kernel; 0 = always the tiled form (test / bench hook)."""
         self._ck(self._lib.mi_debug_set_sorted_one_wg_limit(self._h, C.c_uint32(int(items) & 0xFFFFFFFF)))
+
+    def debug_strip_plan(self):
+        """(rounds per strip, cone rounds per strip, rounds of the whole table) of the current plan's strips; empty arrays without strips."""
+        n, tot = C.c_uint32(0), C.c_uint32(0)
+        self._ck(self._lib.mi_debug_strip_plan(self._h, None, None, 0, C.byref(n), C.byref(tot)))
+        r, cr = np.zeros(max(n.value, 1), np.uint32), np.zeros(max(n.value, 1), np.uint32)
+        self._ck(self._lib.mi_debug_strip_plan(self._h, _ptr(r, C.c_uint32), _ptr(cr, C.c_uint32), n.value, C.byref(n), C.byref(tot)))
+        return r[:n.value], cr[:n.value], tot.value
 
     def debug_set_tile_pretest(self, mode):
         """0 = the light tiles test their flags first when few rows changed (default), 1 = never, 2 = always (test / bench hook)."""

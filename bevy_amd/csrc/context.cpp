@@ -1011,7 +1011,7 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
                     ctx->bt_kind, ctx->bt_cpu_bin, ctx->bt_bucket};
     for (void* p : cols)
         if (p) hipFree(p);
-    DevBuf* bufs[] = {&ctx->sph, &ctx->row_sum, &ctx->anc, &ctx->order, &ctx->chains, &ctx->snap, &ctx->tree_trace, &ctx->inh_bits, &ctx->sparse_cnt, &ctx->sparse_rows, &ctx->sparse_total, &ctx->sparse_g, &ctx->g_pre, &ctx->parent_idx, &ctx->node_flags, &ctx->tiles, &ctx->wtiles, &ctx->level_offs_dev, &ctx->views,
+    DevBuf* bufs[] = {&ctx->sph, &ctx->row_sum, &ctx->anc, &ctx->order, &ctx->chains, &ctx->snap, &ctx->tree_trace, &ctx->inh_bits, &ctx->sparse_cnt, &ctx->sparse_rows, &ctx->sparse_total, &ctx->sparse_g, &ctx->g_pre, &ctx->parent_idx, &ctx->node_flags, &ctx->tiles, &ctx->wtiles, &ctx->strips, &ctx->strip_rounds, &ctx->level_offs_dev, &ctx->views,
                       &ctx->block_counts, &ctx->seg_bases, &ctx->out_keys, &ctx->cl_pos,
                       &ctx->cl_type, &ctx->cl_layers, &ctx->cl_layers_hi, &ctx->cl_dir, &ctx->cl_sincos, &ctx->cl_planes, &ctx->cl_spheres,
                       &ctx->bt_set_indexed, &ctx->bt_table_off, &ctx->bt_table, &ctx->bt_meta_off, &ctx->bt_meta, &ctx->bt_rows_a, &ctx->bt_rows_b,
@@ -1713,6 +1713,27 @@ int32_t mi_propagate(mi_ctx* ctx, uint32_t flags) {
         HIP_TRY(ctx, launch_propagate_narrow(c, (const uint32_t*)ctx->parent_idx.p, (const uint32_t*)ctx->level_offs_dev.p, ctx->n_levels,
                                              (const uint8_t*)ctx->node_flags.p, ctx->changed, tree_bits, ctx->g_changed_bytes, all_dirty, static_opt, ctx->narrow_quad, ctx->stream));
         ctx->g_chg_in_bytes = true;
+    } else if (ctx->strip_plan && !ctx->by_levels) {
+        // strips: one launch of independent waves; the cones read the pre-frame snapshot of the rows above the deepest band, the strips
+        // that own those rows write next frame's
+        float* snap_r = nullptr;
+        float* snap_w = nullptr;
+        if (ctx->snap_rows) {
+            snap_r = (float*)ctx->snap.p + (size_t)ctx->snap_parity * ctx->snap_rows * 12;
+            snap_w = (float*)ctx->snap.p + (size_t)(ctx->snap_parity ^ 1u) * ctx->snap_rows * 12;
+            if (!ctx->snap_valid) {  // first frame after a (re)plan or an external GlobalTransform upload
+                HIP_TRY(ctx, hipMemcpyAsync(snap_r, ctx->g, (size_t)ctx->snap_rows * 48, hipMemcpyDeviceToDevice, ctx->stream));
+                ctx->snap_valid = true;
+            }
+            ctx->snap_parity ^= 1u;
+        }
+        ProfScope sc(ctx, K_PROPAGATE_TILES);
+        const bool pretest = ctx->tile_pretest_mode == 2 || (ctx->tile_pretest_mode == 0 && static_opt && !all_dirty && ctx->changed_rows_hint != UINT64_MAX &&
+                                                            ctx->changed_rows_hint * 16 <= ctx->n_strips);
+        HIP_TRY(ctx, launch_propagate_strips(c, (const uint32_t*)ctx->parent_idx.p, (const StripDesc*)ctx->strips.p, (const StripRound*)ctx->strip_rounds.p, ctx->n_strips,
+                                             (const uint8_t*)ctx->node_flags.p, ctx->changed, tree_bits, ctx->g_changed_bytes, snap_r, snap_w, ctx->snap_rows, all_dirty,
+                                             static_opt, pretest, ctx->stream, (unsigned long long*)ctx->tree_trace.p));
+        ctx->g_chg_in_bytes = true;
     } else if (ctx->wave_forest && !ctx->by_levels) {
         // a forest of small trees: a wave per tile, one launch (ctx_hierarchy.cpp).  No chain tiles, so nothing reads or keeps the
         // chain snapshot: whatever it held is stale for a later plan.
@@ -1895,7 +1916,7 @@ int32_t mi_cull(mi_ctx* ctx, const float* frusta, const uint32_t* view_layer_mas
 static bool tree_frame_fusable(mi_ctx* ctx, uint32_t n_views, uint32_t flags) {
     // (default: with one view, where it measured faster -- 34.7 against 37.1 us per frame of the 1 M-node tree; with four views the
     // rule's arithmetic inside the tiles costs more than the second pass over GlobalTransform: 51.4 against 44.7)
-    return (ctx->tree_cull_mode == 2 || (ctx->tree_cull_mode == 0 && n_views == 1)) && ctx->n && !ctx->by_levels && !ctx->narrow && !ctx->wave_forest && ctx->stream_levels.empty() && !ctx->groups.empty() && n_views <= MAX_INLINE_VIEWS &&
+    return (ctx->tree_cull_mode == 2 || (ctx->tree_cull_mode == 0 && n_views == 1)) && ctx->n && !ctx->by_levels && !ctx->narrow && !ctx->wave_forest && !ctx->strip_plan && ctx->stream_levels.empty() && !ctx->groups.empty() && n_views <= MAX_INLINE_VIEWS &&
            !(flags & (MI_CULL_CHANGED_ROWS | MI_CULL_WITH_CLUSTERS)) && (flags & MI_CULL_END_FRAME) && !ctx->have_class_mask && !ctx->have_ranges &&
            !ctx->ext_bitmask && !ctx->xch.on;
 }

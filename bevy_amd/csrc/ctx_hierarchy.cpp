@@ -364,6 +364,156 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
             }
         }
     }
+    // STRIPS (kernels.h, k_propagate_strips): a hierarchy of >= 4 levels that is neither a forest of wave tiles nor as narrow as a chain
+    // takes ONE launch of independent waves, whatever its depth.  The levels are cut into bands bottom-up -- a band grows upwards while
+    // its widest level stays within W / 2 rows per row of its first level --; inside a band consecutive first-level rows are grouped
+    // into a strip while no level of their subtree, and no level of the cone of their ancestors, holds more than W rows.  A single
+    // row whose subtree is wider than that inside the band keeps the levels that fit; the rows below become strips of their own (their
+    // cone runs through it).  mi_debug_set_tile_mode(4) plans without, (5) takes strips wherever they can be planned.
+    ctx->strip_plan = false;
+    ctx->n_strips = 0;
+    {
+        uint32_t W = 128;
+        if (const char* ev = getenv("MI_STRIP_W")) W = (uint32_t)std::max(1, atoi(ev));
+        W = std::min(W, STRIP_W_CAP);
+        const bool quad_rounds = !getenv("MI_STRIP_NO_QUAD");
+        const bool modes_ok = ctx->tile_mode == 0 || ctx->tile_mode == 2 || ctx->tile_mode == 3;
+        const bool wanted = ctx->tile_mode == 5 || (modes_ok && !ctx->wave_forest && !ctx->narrow && n_levels >= 6 && n <= STRIP_MAX_ROWS);
+        if (wanted && !ctx->by_levels && n > 0) {
+            auto level_size = [&](uint32_t lv) -> uint64_t { return level_offsets[lv + 1] - level_offsets[lv]; };
+            std::vector<std::pair<uint32_t, uint32_t>> bands;  // [s, e), bottom-up
+            for (uint32_t e = n_levels; e > 0;) {
+                uint32_t s = e - 1;
+                uint64_t widest = level_size(s);
+                while (s > 0) {
+                    const uint64_t w2 = std::max(widest, level_size(s - 1));
+                    if (w2 > (uint64_t)std::max(1u, W / 2u) * std::max<uint64_t>(1, level_size(s - 1))) break;
+                    widest = w2;
+                    --s;
+                }
+                bands.emplace_back(s, e);
+                e = s;
+            }
+            std::vector<StripDesc> strips;
+            std::vector<uint32_t> strip_top;  // first own level of each strip
+            std::vector<StripRound> rounds;
+            struct Region { uint32_t s, lo, hi, e; };
+            std::vector<Region> work;
+            // the levels of [a, b) of level s that fit (every level <= W rows), up to e; 0 = the cone of [a, b) is too wide
+            auto fit_levels = [&](uint32_t s, uint32_t e, uint32_t a, uint32_t b) -> uint32_t {
+                uint32_t plo = a, phi = b;
+                for (uint32_t l = s; l-- > 0;) {
+                    const uint32_t nlo = parent_idx[plo], nhi = parent_idx[phi - 1] + 1u;
+                    if (nhi - nlo > W) return 0;
+                    plo = nlo;
+                    phi = nhi;
+                }
+                uint32_t clo = a, chi = b, k = 0;
+                while (s + k < e && chi > clo) {
+                    if (chi - clo > W) return k;
+                    const uint32_t nlo = s + k + 1 < n_levels ? child_begin(s + k, clo) : 0u, nhi = s + k + 1 < n_levels ? child_begin(s + k, chi) : 0u;
+                    clo = nlo;
+                    chi = nhi;
+                    ++k;
+                }
+                return e - s;  // (all of them: the subtree may end earlier)
+            };
+            auto emit_level = [&](uint32_t l, uint32_t lo, uint32_t hi, uint32_t pstart, uint32_t bits) {
+                for (uint32_t r = 0; lo + 64u * r < hi; ++r) {
+                    StripRound rd{};
+                    rd.row0 = lo + 64u * r;
+                    rd.pstart = pstart;
+                    const uint32_t cnt = std::min(64u, hi - rd.row0);
+                    rd.info = cnt | ((64u * r) << 8) | ((l & 1u) ? STRIP_PARITY : 0u) | (l == 0 ? STRIP_ROOT : 0u) | bits |
+                              (rd.row0 + cnt == hi ? STRIP_LEVEL_END : 0u) | (cnt <= 16u && quad_rounds ? STRIP_QUAD : 0u);
+                    rd.level = l;
+                    rounds.push_back(rd);
+                }
+            };
+            auto emit = [&](uint32_t s, uint32_t a, uint32_t b, uint32_t n_lv) {
+                std::vector<std::pair<uint32_t, uint32_t>> cone(s);
+                uint32_t plo = a, phi = b;
+                for (uint32_t l = s; l-- > 0;) {
+                    const uint32_t nlo = parent_idx[plo], nhi = parent_idx[phi - 1] + 1u;
+                    cone[l] = {nlo, nhi};
+                    plo = nlo;
+                    phi = nhi;
+                }
+                StripDesc sd{};
+                sd.first_round = (uint32_t)rounds.size();
+                uint32_t prev = 0;
+                for (uint32_t l = 0; l < s; ++l) {
+                    emit_level(l, cone[l].first, cone[l].second, prev, l + 1 == s ? STRIP_ABOVE_TOP : 0u);
+                    prev = cone[l].first;
+                }
+                uint32_t clo = a, chi = b;
+                for (uint32_t k = 0; k < n_lv && chi > clo; ++k) {
+                    emit_level(s + k, clo, chi, prev, STRIP_OWNED);
+                    prev = clo;
+                    const uint32_t nlo = s + k + 1 < n_levels ? child_begin(s + k, clo) : 0u, nhi = s + k + 1 < n_levels ? child_begin(s + k, chi) : 0u;
+                    clo = nlo;
+                    chi = nhi;
+                }
+                while ((rounds.size() - sd.first_round) % STRIP_RING) rounds.push_back(StripRound{});
+                sd.n_rounds = (uint32_t)(rounds.size() - sd.first_round);
+                strips.push_back(sd);
+                strip_top.push_back(s);
+            };
+            bool ok = true;
+            for (auto& bd : bands) work.push_back({bd.first, level_offsets[bd.first], level_offsets[bd.first + 1], bd.second});
+            for (size_t wi = 0; wi < work.size() && ok; ++wi) {  // (regions handed down are appended behind)
+                const Region rg = work[wi];
+                uint32_t a = rg.lo;
+                while (a < rg.hi) {
+                    uint32_t b = a + 1;
+                    uint32_t lv = fit_levels(rg.s, rg.e, a, b);  // (>= 1: one row, a cone of one row per level)
+                    if (lv == 0) { ok = false; break; }
+                    if (lv < rg.e - rg.s) {
+                        // the row's own subtree outgrows the width at level s + lv: keep the levels above, hand the rest down
+                        uint32_t clo = a, chi = b;
+                        for (uint32_t k = 0; k < lv; ++k) {
+                            const uint32_t nlo = child_begin(rg.s + k, clo), nhi = child_begin(rg.s + k, chi);
+                            clo = nlo;
+                            chi = nhi;
+                        }
+                        if (chi > clo) work.push_back({rg.s + lv, clo, chi, rg.e});
+                    } else {
+                        uint32_t step = 1;
+                        while (b < rg.hi) {  // galloping extension while everything still fits
+                            const uint32_t nb = (uint32_t)std::min<uint64_t>((uint64_t)b + step, rg.hi);
+                            if (fit_levels(rg.s, rg.e, a, nb) == rg.e - rg.s) { b = nb; step *= 2; }
+                            else if (step > 1) step = 1;
+                            else break;
+                        }
+                    }
+                    emit(rg.s, a, b, lv);
+                    a = b;
+                }
+                if (rounds.size() > (size_t)64 * n + (1u << 20)) ok = false;  // (cones out of all proportion: a hierarchy for the tiles)
+            }
+            if (ok && !strips.empty()) {
+                for (uint32_t i = 0; i < 2u * STRIP_RING; ++i) rounds.push_back(StripRound{});
+                uint32_t snap_level = 0;
+                for (uint32_t s : strip_top) snap_level = std::max(snap_level, s);
+                const uint32_t strip_snap_rows = level_offsets[snap_level];  // every cone row lies above the deepest first level
+                for (size_t i = 0; i < strips.size(); ++i)
+                    if (level_offsets[strip_top[i]] < strip_snap_rows) strips[i].n_rounds |= 0x80000000u;
+                if ((rc = ensure(ctx, ctx->strips, strips.size() * sizeof(StripDesc)))) return rc;
+                if ((rc = upload(ctx, ctx->strips.p, strips.data(), strips.size() * sizeof(StripDesc)))) return rc;
+                if ((rc = ensure(ctx, ctx->strip_rounds, rounds.size() * sizeof(StripRound)))) return rc;
+                if ((rc = upload(ctx, ctx->strip_rounds.p, rounds.data(), rounds.size() * sizeof(StripRound)))) return rc;
+                ctx->strip_plan = true;
+                if (ctx->tile_mode == 5) ctx->narrow = ctx->wave_forest = false;  // (the test mode: strips whatever else would take the hierarchy)
+                ctx->n_strips = (uint32_t)strips.size();
+                ctx->n_strip_rounds = (uint32_t)rounds.size();
+                ctx->strip_bands = (uint32_t)bands.size();
+                // the snapshot the cones read: the strips' own prefix (the tile plan's chain tiles do not run)
+                ctx->snap_rows = strip_snap_rows;
+                ctx->snap_valid = false;
+                if (ctx->snap_rows && (rc = ensure(ctx, ctx->snap, 2 * (size_t)ctx->snap_rows * 48))) return rc;
+            }
+        }
+    }
     ctx->have_hierarchy = true;
     // the ancestor table for mark_dirty_trees (kernels.h): level by level on the device, behind the parent_idx upload
     ctx->anc_valid = false;
@@ -378,10 +528,11 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
 
 // test / bench hook (not part of the public header): which tile kernel the NEXT mi_upload_hierarchy plans for
 // (0 = tiles where they fit, 1 = level by level whatever the shape, 2 = as 0 (the light tiles of earlier rounds), 3 = as 0 with the
-// streamed-level thresholds at their test values, 4 = as 0 without the wave tiles of a forest of small trees)
+// streamed-level thresholds at their test values, 4 = as 0 without the wave tiles of a forest of small trees and without strips,
+// 5 = strips wherever they can be planned)
 int32_t mi_debug_set_tile_mode(mi_ctx* ctx, int32_t mode) {
     ENTER(ctx);
-    if (mode < 0 || mode > 4) return fail(ctx, MI_ERR_INVALID_ARG, "mi_debug_set_tile_mode: mode %d", mode);
+    if (mode < 0 || mode > 5) return fail(ctx, MI_ERR_INVALID_ARG, "mi_debug_set_tile_mode: mode %d", mode);
     ctx->tile_mode = mode;
     return MI_OK;
 }
@@ -394,6 +545,7 @@ int32_t mi_debug_tree_trace(mi_ctx* ctx, int32_t enable, unsigned long long* out
     if (enable) {
         size_t tiles = 1;
         for (auto& g : ctx->groups) tiles = std::max<size_t>(tiles, (size_t)g.first + g.count);  // (every launch's tiles at their own place)
+        tiles = std::max<size_t>(tiles, ctx->n_strips);
         int32_t rc = ensure(ctx, ctx->tree_trace, tiles * 64);
         if (rc) return rc;
         HIP_TRY(ctx, hipMemsetAsync(ctx->tree_trace.p, 0, tiles * 64, ctx->stream));
@@ -414,9 +566,38 @@ int32_t mi_debug_tile_plan(mi_ctx* ctx, uint32_t* out_launches, uint32_t* out_ti
     for (auto& g : ctx->groups) { tiles += g.count; chain += g.n_chain; }
     if (out_launches) *out_launches = ctx->by_levels ? ctx->n_levels : ctx->wave_forest ? 1u : (uint32_t)ctx->groups.size();  // (tile launches; by levels: one per level)
     if (ctx->wave_forest && !ctx->by_levels) tiles = ctx->n_wtiles, chain = 0;  // (the wave tiles of a forest of small trees: one launch)
+    if (ctx->strip_plan && !ctx->by_levels) {  // (strips: one launch; "chain tiles" = the strips with a cone)
+        tiles = ctx->n_strips, chain = ctx->n_strips > 0 ? ctx->n_strips - 1u : 0u;
+        if (out_launches) *out_launches = 1u;
+    }
     if (out_tiles) *out_tiles = tiles;
     if (out_chain_tiles) *out_chain_tiles = chain;
     if (out_bands) *out_bands = (uint32_t)ctx->passes.size();
+    return MI_OK;
+}
+
+// development hook: the strips of the current plan -- per strip its rounds (padding included) and cone rounds (tools/strip_trace.py);
+// *out_n = strips, *out_total_rounds = the table's rounds
+int32_t mi_debug_strip_plan(mi_ctx* ctx, uint32_t* out_rounds, uint32_t* out_cone_rounds, uint32_t cap, uint32_t* out_n, uint32_t* out_total_rounds) {
+    ENTER(ctx);
+    if (out_n) *out_n = ctx->strip_plan ? ctx->n_strips : 0u;
+    if (out_total_rounds) *out_total_rounds = ctx->strip_plan ? ctx->n_strip_rounds : 0u;
+    if (!ctx->strip_plan || !cap || (!out_rounds && !out_cone_rounds)) return MI_OK;
+    std::vector<StripDesc> sd(ctx->n_strips);
+    std::vector<StripRound> rd(ctx->n_strip_rounds);
+    int32_t rc = download(ctx, sd.data(), ctx->strips.p, sd.size() * sizeof(StripDesc));
+    if (rc) return rc;
+    if ((rc = download(ctx, rd.data(), ctx->strip_rounds.p, rd.size() * sizeof(StripRound)))) return rc;
+    for (uint32_t i = 0; i < ctx->n_strips && i < cap; ++i) {
+        const uint32_t nr = sd[i].n_rounds & 0xFFFFFFu;
+        uint32_t cone = 0;
+        for (uint32_t j = 0; j < nr; ++j) {
+            const uint32_t info = rd[sd[i].first_round + j].info;
+            if ((info & 0x7Fu) && !(info & STRIP_OWNED)) ++cone;
+        }
+        if (out_rounds) out_rounds[i] = nr;
+        if (out_cone_rounds) out_cone_rounds[i] = cone;
+    }
     return MI_OK;
 }
 

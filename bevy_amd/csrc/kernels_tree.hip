@@ -1360,6 +1360,281 @@ __global__ void __launch_bounds__(64) k_propagate_wave_tiles(Columns c, TreeArgs
 }
 
 // ---------------------------------------------------------------------------------------------
+// STRIPS (round 6): a lopsided or deep tree -- transform_hierarchy.rs's large_tree / deep_tree, 250 000 - 320 000 nodes in 19 / 26
+// levels whose widths swell and shrink -- in ONE launch.  Through the workgroup tiles such a tree was three or four launches, each
+// behind the one that wrote its parents (a subtree of 15 levels does not fit a tile's LDS rows, and below the first cut the tiles'
+// top rows have hundreds of different parents: no single chain to re-evaluate): 27 - 31 us of 5 - 9 us tiles and the gaps between
+// launches.  A strip (kernels.h) is one WAVE that walks a list of rounds -- up to 64 rows of one level, a row per lane --: first the
+// CONE of its rows' ancestors, level by level from the forest's roots down (a contiguous row range per level; evaluated, never
+// written -- the strips that own those rows form the same products in the same order), then the rows it owns.  A level's results stay
+// in LDS for the level below; the inputs of the next STRIP_RING rounds are in flight while a round is multiplied (the table of rounds is
+// known up front, so nothing is asked for behind a result); no workgroup barrier, no wait for another wave, whatever the depth.
+// The cone's rows compare against (and, skipped under the static-scene rule, keep) their PRE-frame GlobalTransforms, which their
+// owners may be rewriting in this very launch: they read the chain snapshot (TreeArgs::snap_read), as the chain tiles do.
+// Same rule (node_apply), same products in the same order: same bits, same ticks.
+// ---------------------------------------------------------------------------------------------
+struct StripIn {
+    V3 t, s;
+    float4 q;
+    uint32_t par;
+    float4 o0, o1, o2;  // the old GlobalTransform as it was loaded (whole register quads: what the loop carries is what the loads wrote)
+    NodeRaw raw;
+};
+__device__ __forceinline__ StripRound load_round(const StripRound* tab, uint32_t j) {
+    typedef const uint32_t __attribute__((address_space(4))) * const_u32;
+    const_u32 src = (const_u32)(uintptr_t)(tab + j);
+    StripRound e;
+    e.row0 = src[0];
+    e.pstart = src[1];
+    e.info = src[2];
+    e.level = src[3];
+    return e;
+}
+// Two waves per strip.  What a level costs its strip is the instructions ONE wave has to issue for it, ~5 cycles apiece when the wave is
+// alone on its SIMD: with everything in one wave's stream -- the round's 14 loads and their addresses, From(Transform), the parent's
+// read, the product, the compare, the stores -- a round was 0.72 us whatever its rows (profiles/r06_experiments.md, the strip-down
+// builds: the loads 0.17, the stores 0.05, the parent's read 0.07, the rest 0.38).  So the PRODUCER wave (wave 1) does everything that
+// does not hang on the level above -- the loads (the next STRIP_RING rounds in flight), From(Transform), the rule's inputs -- and leaves a
+// round ready in one of two LDS slots; the CONSUMER wave (wave 0) runs the dependent chain only: parent from LDS, product, set_if_neq,
+// the level's results into LDS for the level below and out to memory; <= 16 rows: a row per quad of lanes, a column each.  One workgroup
+// barrier per round hands a slot over each way.
+struct StripStage {
+    float4 local[2][64 * 3];  // From(Transform)
+    float4 old[2][64 * 3];    // the GlobalTransform before this frame (the cone's rows: from the snapshot)
+    uint32_t par[2][64];
+    uint8_t in[2][64];        // bit0 TransformTreeChanged, bit1 the level-0 assignment happens
+};
+template <bool ALL_DIRTY>
+__global__ void __launch_bounds__(STRIP_THREADS) k_propagate_strips(Columns c, TreeArgs a, const StripDesc* __restrict__ strips, const StripRound* __restrict__ rounds) {
+    __shared__ float4 lds_g[2][STRIP_W_CAP * 3];  // the GlobalTransforms of the level above / of this level
+    __shared__ uint8_t lds_chg[2][STRIP_W_CAP];   // "tick bumped" of the same rows
+    __shared__ StripStage st;
+    static_assert(STRIP_RING % 2u == 0u, "a round's staging slot is its ring position's parity");
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t strip = xcd_contiguous_tile();
+    unsigned long long ts[3] = {0, 0, 0};
+    if (a.trace) ts[0] = wall_clock64();
+    uint32_t first, J;
+    bool snap_owner;
+    {
+        typedef const uint32_t __attribute__((address_space(4))) * const_u32;
+        const_u32 src = (const_u32)(uintptr_t)(strips + strip);
+        first = src[0];
+        const uint32_t nr = src[1];
+        J = nr & 0xFFFFFFu;
+        snap_owner = (nr >> 31) != 0u;
+    }
+    const StripRound* const tab = rounds + first;
+    // ---- a frame in which little moved: the strip's flags first (the workgroup tiles' pretest).  Under the static-scene rule the rows
+    // the strip owns keep every GlobalTransform and every tick unless one of them is marked (TransformTreeChanged) or assigned as a
+    // root / flat row, or the parent of a top row gets a new tick -- which takes a cone row whose own Transform changed (a row that is
+    // merely re-evaluated reproduces its value and set_if_neq leaves it alone, systems.rs:719), or a forest root directly above the top
+    // rows that is assigned this frame (its tick is bumped whatever the value, systems.rs:522-530).  Strips that mirror rows into the
+    // snapshot take the long way.  (Both waves test, and agree.)
+    if constexpr (!ALL_DIRTY) {
+        if ((a.pretest & 1u) && a.static_opt && !snap_owner) {
+            bool hot = false;
+            for (uint32_t j = 0; j < J; j += STRIP_RING) {
+#pragma unroll
+                for (uint32_t d = 0; d < STRIP_RING; ++d) {
+                    const StripRound e = load_round(tab, j + d);
+                    const bool on = lane < (e.info & 0x7Fu);
+                    const uint32_t row = e.row0 + (on ? lane : 0u);
+                    const bool root_level = (e.info & STRIP_ROOT) != 0u;
+                    const NodeIn in = node_inputs_raw(a, row, root_level, node_raw<false>(a, row, root_level));
+                    const bool own_hot = in.tree_changed || in.root_write;
+                    const bool cone_hot = row_changed(at32<uint8_t>(a.changed, row), a.changed_gen) || ((e.info & STRIP_ABOVE_TOP) != 0u && in.root_write);
+                    hot = hot || (on && ((e.info & STRIP_OWNED) ? own_hot : cone_hot));
+                }
+            }
+            if (__ballot(hot) == 0ull) {
+                if (wv == 0u)
+                    for (uint32_t j = 0; j < J; ++j) {
+                        const StripRound e = load_round(tab, j);
+                        if ((e.info & STRIP_OWNED) && lane < (e.info & 0x7Fu)) at32w<uint8_t>(a.g_changed_bytes, e.row0 + lane) = 0;
+                    }
+                return;
+            }
+        }
+    }
+    if (a.trace) ts[1] = wall_clock64();
+    if (wv == STRIP_CONSUMERS) {
+        // ================= the producer =================
+        // A round's inputs: a row per lane, coalesced inside the level; lanes past the round's rows re-read its first row.  (Scale,
+        // translation and rotation word by word, each offset of the rotation through an empty asm statement so that the loads are not
+        // merged back: a merged load lands in a register pair / triple / quad which the loop-carried copy of the ring cannot always be
+        // allocated on top of -- the moves that remained at the loop's end waited for every load in flight but the last four.)
+        auto fetch = [&](const StripRound& e) {
+            StripIn f;
+            const bool on = lane < (e.info & 0x7Fu);
+            const uint32_t row = e.row0 + (on ? lane : 0u);
+            const bool root_level = (e.info & STRIP_ROOT) != 0u;
+            const float* const old_src = (e.info & STRIP_OWNED) ? c.global : a.snap_read;  // (uniform)
+            f.t = V3{at32<float>(c.translation, row * 12u), at32<float>(c.translation, row * 12u + 4u), at32<float>(c.translation, row * 12u + 8u)};
+            f.s = V3{at32<float>(c.scale, row * 12u), at32<float>(c.scale, row * 12u + 4u), at32<float>(c.scale, row * 12u + 8u)};
+            {
+                uint32_t q0 = row * 16u, q1 = row * 16u + 4u, q2 = row * 16u + 8u, q3 = row * 16u + 12u;
+                asm volatile("" : "+v"(q1));
+                asm volatile("" : "+v"(q2));
+                asm volatile("" : "+v"(q3));
+                f.q = make_float4(at32<float>(c.rotation, q0), at32<float>(c.rotation, q1), at32<float>(c.rotation, q2), at32<float>(c.rotation, q3));
+            }
+            f.par = at32<uint32_t>(a.parent_idx, row * 4u);
+            f.o0 = at32<float4>(old_src, row * 48u);
+            f.o1 = at32<float4>(old_src, row * 48u + 16u);
+            f.o2 = at32<float4>(old_src, row * 48u + 32u);
+            f.raw = node_raw<ALL_DIRTY>(a, row, root_level);
+            return f;
+        };
+        auto stage = [&](const StripRound& e, const StripIn& in, uint32_t sl) {
+            const bool on = lane < (e.info & 0x7Fu);
+            const uint32_t row = e.row0 + (on ? lane : 0u);
+            const bool root_level = (e.info & STRIP_ROOT) != 0u;
+            lds_put(st.local[sl], lane, affine_from_srt(in.s, V4{in.q.x, in.q.y, in.q.z, in.q.w}, in.t));
+            st.old[sl][lane * 3u] = in.o0;
+            st.old[sl][lane * 3u + 1u] = in.o1;
+            st.old[sl][lane * 3u + 2u] = in.o2;
+            uint32_t ps = in.par - e.pstart;  // the parent's slot in the level above (whatever a root reads there is ignored)
+            st.par[sl][lane] = ps < STRIP_W_CAP ? ps : STRIP_W_CAP - 1u;
+            const NodeIn nin = node_inputs_raw(a, row, root_level, in.raw);
+            st.in[sl][lane] = (uint8_t)((nin.tree_changed ? 1u : 0u) | (nin.root_write ? 2u : 0u));
+        };
+#ifdef MI_EXP_STRIP_STAMPS
+        unsigned long long x_work = 0, x_wait = 0, x_last = wall_clock64();
+#endif
+        StripRound e[STRIP_RING], f[STRIP_RING];
+        StripIn ring[STRIP_RING];
+#pragma unroll
+        for (uint32_t d = 0; d < STRIP_RING; ++d) {
+            e[d] = load_round(tab, d);
+            f[d] = load_round(tab, STRIP_RING + d);
+        }
+#pragma unroll
+        for (uint32_t d = 0; d < STRIP_RING; ++d) ring[d] = fetch(e[d]);
+        for (uint32_t j = 0; j < J; j += STRIP_RING) {
+            StripRound g[STRIP_RING];
+#pragma unroll
+            for (uint32_t d = 0; d < STRIP_RING; ++d) g[d] = load_round(tab, j + 2u * STRIP_RING + d);  // (the table ends in 2 x STRIP_RING padding rounds)
+#pragma unroll
+            for (uint32_t d = 0; d < STRIP_RING; ++d) {
+                stage(e[d], ring[d], d & 1u);
+                __builtin_amdgcn_sched_barrier(0);
+                ring[d] = fetch(f[d]);  // (behind the staging that used them up: the loads land in the registers the loop carries)
+#ifdef MI_EXP_STRIP_STAMPS
+                const unsigned long long tb = wall_clock64();
+                x_work += tb - x_last;
+#endif
+                MI_WG_LDS_BARRIER();    // round j + d is staged; the consumer is through with round j + d - 1: its slot is free
+#ifdef MI_EXP_STRIP_STAMPS
+                x_last = wall_clock64();
+                x_wait += x_last - tb;
+#endif
+            }
+#pragma unroll
+            for (uint32_t d = 0; d < STRIP_RING; ++d) {
+                e[d] = f[d];
+                f[d] = g[d];
+            }
+        }
+#ifdef MI_EXP_STRIP_STAMPS
+        if (a.trace && lane == 0) {
+            a.trace[(size_t)strip * 8u + 5u] = x_wait;
+            a.trace[(size_t)strip * 8u + 6u] = x_work;
+        }
+#endif
+        return;
+    }
+    // ================= the consumer =================
+    // (every consumer wave: sixteen rows of the round, a row per quad of lanes, a column of the affine each)
+    const uint32_t q_unit = wv * 16u + (lane >> 2), q_cc = lane & 3u;
+    auto step = [&](const StripRound& e, uint32_t sl) {
+        const uint32_t n = e.info & 0x7Fu;
+        const bool on = q_unit < n;
+        const uint32_t u = on ? q_unit : 0u;
+        const uint32_t row = e.row0 + u;
+        const bool root_level = (e.info & STRIP_ROOT) != 0u;
+        const bool owned = (e.info & STRIP_OWNED) != 0u;
+        const uint32_t p = (e.info & STRIP_PARITY) ? 1u : 0u;
+        const uint32_t slot = ((e.info >> 8) & 0xFFu) + u;
+        const uint32_t ps = st.par[sl][u];
+        const uint32_t in_bits = st.in[sl][u];
+#ifndef MI_EXP_STRIP_NOLDS
+        const Affine gp = lds_affine(lds_g[p ^ 1u], ps);
+        const bool pc = lds_chg[p ^ 1u][ps] != 0;
+#else
+        const Affine gp = lds_affine(st.old[sl], u);
+        const bool pc = ps == 77u;
+#endif
+        V3 cur_c;
+        const bool chg = quad_node_apply(on, root_level, a.static_opt != 0, in_bits, gp, pc, lds_col(st.local[sl], u, q_cc), lds_col(st.old[sl], u, q_cc), q_cc, lane, &cur_c);
+        if (on) {
+            lds_put_col(lds_g[p], slot, q_cc, cur_c);
+            if (q_cc == 0u) lds_chg[p][slot] = chg ? 1 : 0;
+#ifndef MI_EXP_STRIP_NOSTORE
+            if (owned) {
+                if (q_cc == 0u) at32w<uint8_t>(a.g_changed_bytes, row) = chg ? 1 : 0;
+                if (chg) at32w<F3>(c.global, row * 48u + q_cc * 12u) = F3{cur_c.x, cur_c.y, cur_c.z};
+                if (snap_owner && row < a.snap_rows) at32w<F3>(a.snap_write, row * 48u + q_cc * 12u) = F3{cur_c.x, cur_c.y, cur_c.z};
+            }
+#else
+            if (owned && chg && cur_c.x == 1.2345f) at32w<uint8_t>(a.g_changed_bytes, row) = 1;
+#endif
+        }
+    };
+#ifdef MI_EXP_STRIP_STAMPS
+    unsigned long long y_work = 0, y_wait = 0, y_last = wall_clock64();
+#endif
+    {
+        StripRound e[STRIP_RING];
+#pragma unroll
+        for (uint32_t d = 0; d < STRIP_RING; ++d) e[d] = load_round(tab, d);
+        for (uint32_t j = 0; j < J; j += STRIP_RING) {
+            StripRound g[STRIP_RING];
+#pragma unroll
+            for (uint32_t d = 0; d < STRIP_RING; ++d) g[d] = load_round(tab, j + STRIP_RING + d);
+#pragma unroll
+            for (uint32_t d = 0; d < STRIP_RING; ++d) {
+#ifdef MI_EXP_STRIP_STAMPS
+                const unsigned long long tb = wall_clock64();
+                y_work += tb - y_last;
+#endif
+                MI_WG_LDS_BARRIER();  // round j + d is staged
+#ifdef MI_EXP_STRIP_STAMPS
+                y_last = wall_clock64();
+                y_wait += y_last - tb;
+#endif
+                step(e[d], d & 1u);
+            }
+#pragma unroll
+            for (uint32_t d = 0; d < STRIP_RING; ++d) e[d] = g[d];
+        }
+    }
+    if (a.trace && wv == 0u) {
+        ts[2] = wall_clock64();
+        __builtin_amdgcn_s_waitcnt(0);  // stores drained
+        const unsigned long long t7 = wall_clock64();
+        if (lane == 0) {  // the eight stamps of the workgroup tiles' trace: start, flags tested, -, -, rounds done, -, -, drained
+            unsigned long long* const o = a.trace + (size_t)strip * 8u;
+            o[0] = ts[0];
+            o[1] = ts[1];
+#ifdef MI_EXP_STRIP_STAMPS
+            o[2] = y_wait;
+            o[3] = y_work;
+            o[4] = ts[2];
+#else
+            o[2] = ts[1];
+            o[3] = ts[1];
+            o[4] = ts[2];
+            o[5] = ts[2];
+            o[6] = ts[2];
+#endif
+            o[7] = t7;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // visibility_propagate_system + propagate_recursive (crates/bevy_camera/src/visibility/mod.rs:638-729) as the
 // fixpoint they maintain, swept over the same subtree tiles as the transforms:
 //   Visible -> true, Hidden -> false, Inherited -> parent's InheritedVisibility (true without a parent or when
@@ -1545,6 +1820,29 @@ hipError_t launch_propagate_wave_tiles(const Columns& c, const uint32_t* parent_
         if (all_dirty) MI_LAUNCH((k_propagate_wave_tiles<true, false>), dim3(n_tiles), dim3(64), 0, stream, c, a, d_wtiles);
         else MI_LAUNCH((k_propagate_wave_tiles<false, false>), dim3(n_tiles), dim3(64), 0, stream, c, a, d_wtiles);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_propagate_strips(const Columns& c, const uint32_t* parent_idx, const StripDesc* d_strips, const StripRound* d_rounds, uint32_t n_strips,
+                                   const uint8_t* node_flags, const uint8_t* changed, const uint8_t* tree_bytes, uint8_t* g_changed_bytes, const float* snap_read,
+                                   float* snap_write, uint32_t snap_rows, bool all_dirty, bool static_opt, bool pretest, hipStream_t stream, unsigned long long* trace) {
+    if (n_strips == 0) return hipSuccess;
+    TreeArgs a{};
+    a.pretest = pretest && changed && tree_bytes ? 1u : 0u;
+    a.changed_gen = c.changed_gen;
+    a.snap_read = snap_read ? snap_read : c.global;  // (no cone anywhere: nothing reads it)
+    a.snap_write = snap_write;
+    a.snap_rows = snap_write ? snap_rows : 0u;
+    a.parent_idx = parent_idx;
+    a.node_flags = node_flags;
+    a.changed = changed;
+    a.tree_bytes = tree_bytes;
+    a.g_changed_bytes = g_changed_bytes;
+    a.all_dirty = all_dirty ? 1u : 0u;
+    a.static_opt = static_opt ? 1u : 0u;
+    a.trace = trace;
+    if (all_dirty) MI_LAUNCH((k_propagate_strips<true>), dim3(n_strips), dim3(STRIP_THREADS), 0, stream, c, a, d_strips, d_rounds);
+    else MI_LAUNCH((k_propagate_strips<false>), dim3(n_strips), dim3(STRIP_THREADS), 0, stream, c, a, d_strips, d_rounds);
     return hipGetLastError();
 }
 

@@ -34,7 +34,7 @@ int32_t mi_profile_burst(mi_ctx* ctx, uint32_t first_n);
 int32_t mi_profile_read(mi_ctx* ctx, uint32_t* inout_n, uint64_t* launches, double* total_ms);
 const char* mi_profile_kernel_name(uint32_t k);
 
-/* How the NEXT mi_upload_hierarchy plans mi_propagate: 0 = subtree tiles (a subtree too big for one is cut; a forest of small trees: a wave per tree; default), 1 = always level by level, 2 = as 0, 3 = as 0 with the streamed-level thresholds at their test values (2^20 / 2^21 rows), 4 = as 0 without the wave tiles of a forest of small trees. */
+/* How the NEXT mi_upload_hierarchy plans mi_propagate: 0 = subtree tiles (a subtree too big for one is cut; a forest of small trees: a wave per tree; a deep or lopsided tree up to 2^20 rows: strips; default), 1 = always level by level, 2 = as 0, 3 = as 0 with the streamed-level thresholds at their test values (2^20 / 2^21 rows), 4 = as 0 without the wave tiles of a forest of small trees and without strips, 5 = strips (one launch of independent waves, kernels.h) wherever they can be planned. */
 int32_t mi_debug_set_tile_mode(mi_ctx* ctx, int32_t mode);
 /* Per-tile phase timestamps of the light tile kernel (8 x s_memrealtime, 100 MHz, per tile of the first launch).  enable != 0
  * allocates the buffer (mi_propagate then fills it every frame); out != NULL copies n_tiles x 8 stamps out; enable == 0 with
@@ -45,6 +45,9 @@ int32_t mi_debug_tree_trace(mi_ctx* ctx, int32_t enable, unsigned long long* out
 int32_t mi_debug_exchange_times(mi_ctx* ctx, double* out5, int32_t reset);
 /* The shape of the current tile plan: launches per mi_propagate, tiles, chain tiles (self-evaluated ancestor chains), bands. */
 int32_t mi_debug_tile_plan(mi_ctx* ctx, uint32_t* out_launches, uint32_t* out_tiles, uint32_t* out_chain_tiles, uint32_t* out_bands);
+/* The strips of the current plan (kernels.h: one launch of independent waves): rounds and cone rounds per strip, the strip count and the
+ * rounds of the whole table (0 when the plan has no strips). */
+int32_t mi_debug_strip_plan(mi_ctx* ctx, uint32_t* out_rounds, uint32_t* out_cone_rounds, uint32_t cap, uint32_t* out_n, uint32_t* out_total_rounds);
 /* The launches of the current tile plan: out_groups[4g ..] = (first tile, tiles, chain tiles, deep instantiation) per launch; out_tiles[3t ..] =
  * (levels, rows, chain length | 0x100 for a tile of forest roots) per tile (tools/shape_trace.py). */
 int32_t mi_debug_tile_groups(mi_ctx* ctx, uint32_t* out_groups, uint32_t cap_groups, uint32_t* out_n_groups, uint32_t* out_tiles, uint32_t cap_tiles);

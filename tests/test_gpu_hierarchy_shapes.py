@@ -27,10 +27,14 @@ def assert_bits(a, b, what):
     assert bad.size == 0, f"{what}: {bad.size} mismatches, first rows {bad[:8].tolist()}"
 
 
-def run_shape(sh, static_opt):
+def run_shape(sh, static_opt, tile_mode=None, pretest=None):
     n = sh["n"]
     flags = B.PROPAGATE_STATIC_OPT if static_opt else 0
     with api.Context(0) as ctx:
+        if tile_mode is not None:
+            ctx.debug_set_tile_mode(tile_mode)
+        if pretest is not None:
+            ctx.debug_set_tile_pretest(pretest)
         ctx.resize(n)
         ctx.upload_transforms(sh["translation"], sh["rotation"], sh["scale"])
         ctx.upload_hierarchy(sh["parent"], sh["level_offsets"])
@@ -220,7 +224,7 @@ def _small_forest(rng, n_trees, max_depth, max_children, max_level_width):
     return np.array(parent, np.int64)
 
 
-def _run_forest(parent, rng, tile_mode, frames=((0.3, True), (0.02, True), (0.0, True), (0.2, False))):
+def _run_forest(parent, rng, tile_mode, frames=((0.3, True), (0.02, True), (0.0, True), (0.2, False)), pretest=None):
     new_to_old, p_new, offs = W.level_order(parent)
     n = len(parent)
     t = (rng.random((n, 3)) * 4 - 2).astype(F)
@@ -229,6 +233,8 @@ def _run_forest(parent, rng, tile_mode, frames=((0.3, True), (0.02, True), (0.0,
     s3 = (0.9 + 0.2 * rng.random((n, 3))).astype(F)
     with api.Context(0) as ctx:
         ctx.debug_set_tile_mode(tile_mode)
+        if pretest is not None:
+            ctx.debug_set_tile_pretest(pretest)
         ctx.resize(n)
         ctx.upload_transforms(t.reshape(-1), q.reshape(-1), s3.reshape(-1))
         ctx.upload_hierarchy(p_new, offs)

@@ -169,6 +169,9 @@ def build_tree_shape(ctx, args):
     wl.kernel_name = "k_propagate_fans<false>" if frame_kind == "movers" else "k_propagate_fans<true>"
     if name.startswith("humanoids") and not args.tile_mode:  # (a forest of small trees: a wave per tile)
         wl.kernel_name = "k_propagate_wave_tiles<false,true>" if frame_kind == "movers" else "k_propagate_wave_tiles<true,true>"
+    if len(ctx.debug_strip_plan()[0]):  # (a deep or lopsided tree: strips)
+        wl.kernel_name = "k_propagate_strips<false>" if frame_kind == "movers" else "k_propagate_strips<true>"
+        config["strips"] = {"strips": int(len(ctx.debug_strip_plan()[0])), "rounds": int(ctx.debug_strip_plan()[2])}
     wl.frame_level_roofline = True  # several launches per frame on some shapes: priced per FRAME (sum of the frame's kernels), see roofline_frame
     return wl
 

@@ -376,9 +376,15 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
         uint32_t W = 128;
         if (const char* ev = getenv("MI_STRIP_W")) W = (uint32_t)std::max(1, atoi(ev));
         W = std::min(W, STRIP_W_CAP);
-        const bool quad_rounds = !getenv("MI_STRIP_NO_QUAD");
+        const bool narrow_batches = !getenv("MI_STRIP_NO_BATCHES");
+        uint32_t max_extra = 1000;
+        if (const char* ev = getenv("MI_STRIP_EXTRA")) max_extra = (uint32_t)std::max(0, atoi(ev));
         const bool modes_ok = ctx->tile_mode == 0 || ctx->tile_mode == 2 || ctx->tile_mode == 3;
-        const bool wanted = ctx->tile_mode == 5 || (modes_ok && !ctx->wave_forest && !ctx->narrow && n_levels >= 6 && n <= STRIP_MAX_ROWS);
+        // by default: where the tiles need dependent launches (a lopsided tree), or the hierarchy is deep enough for the tiles' chains and
+        // level steps to be what a frame costs (measured, all-dirty frame, kernel us: large_tree 36.3 -> 17.8, deep_tree 26.7 -> 22.9,
+        // update_leaves 19.4 -> 16.0; a root with 500 x 500 descendants 10.2 -> 13.5 and the 1.4 M-node 4-ary tree 32.9 -> 67.9 the other way)
+        const bool wanted = ctx->tile_mode == 5 || (modes_ok && !ctx->wave_forest && !ctx->narrow && !ctx->by_levels && n <= STRIP_MAX_ROWS &&
+                                                    (ctx->groups.size() >= 2 || n_levels >= 16));
         if (wanted && !ctx->by_levels && n > 0) {
             auto level_size = [&](uint32_t lv) -> uint64_t { return level_offsets[lv + 1] - level_offsets[lv]; };
             std::vector<std::pair<uint32_t, uint32_t>> bands;  // [s, e), bottom-up
@@ -399,18 +405,24 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
             std::vector<StripRound> rounds;
             struct Region { uint32_t s, lo, hi, e; };
             std::vector<Region> work;
+            bool too_long = false;
             // the levels of [a, b) of level s that fit (every level <= W rows), up to e; 0 = the cone of [a, b) is too wide
+            // (`extra`: the rounds beyond one per level -- levels of more than 64 rows -- a strip may have: the launch ends with its longest strip)
             auto fit_levels = [&](uint32_t s, uint32_t e, uint32_t a, uint32_t b) -> uint32_t {
-                uint32_t plo = a, phi = b;
+                uint32_t plo = a, phi = b, extra = 0;
                 for (uint32_t l = s; l-- > 0;) {
                     const uint32_t nlo = parent_idx[plo], nhi = parent_idx[phi - 1] + 1u;
                     if (nhi - nlo > W) return 0;
+                    extra += (nhi - nlo - 1u) / 64u;
                     plo = nlo;
                     phi = nhi;
                 }
+                if (extra > max_extra && b - a > 1u) return 0;
                 uint32_t clo = a, chi = b, k = 0;
                 while (s + k < e && chi > clo) {
                     if (chi - clo > W) return k;
+                    extra += (chi - clo - 1u) / 64u;
+                    if (extra > max_extra && b - a > 1u) return k;
                     const uint32_t nlo = s + k + 1 < n_levels ? child_begin(s + k, clo) : 0u, nhi = s + k + 1 < n_levels ? child_begin(s + k, chi) : 0u;
                     clo = nlo;
                     chi = nhi;
@@ -424,8 +436,7 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
                     rd.row0 = lo + 64u * r;
                     rd.pstart = pstart;
                     const uint32_t cnt = std::min(64u, hi - rd.row0);
-                    rd.info = cnt | ((64u * r) << 8) | ((l & 1u) ? STRIP_PARITY : 0u) | (l == 0 ? STRIP_ROOT : 0u) | bits |
-                              (rd.row0 + cnt == hi ? STRIP_LEVEL_END : 0u) | (cnt <= 16u && quad_rounds ? STRIP_QUAD : 0u);
+                    rd.info = cnt | ((64u * r) << 8) | ((l & 1u) ? STRIP_PARITY : 0u) | (l == 0 ? STRIP_ROOT : 0u) | bits;
                     rd.level = l;
                     rounds.push_back(rd);
                 }
@@ -454,8 +465,28 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
                     clo = nlo;
                     chi = nhi;
                 }
-                while ((rounds.size() - sd.first_round) % STRIP_RING) rounds.push_back(StripRound{});
+                // batches: a round of more than 16 rows is a batch of its own; up to four consecutive narrow levels of the same kind
+                // (cone / own) share one -- the producer stages them together, one consumer wave walks them back to back
+                uint32_t n_batches = 0;
+                for (size_t r0 = sd.first_round; r0 < rounds.size();) {
+                    size_t r1 = r0 + 1;
+                    if ((rounds[r0].info & 0x7Fu) <= 16u && narrow_batches)
+                        while (r1 < rounds.size() && r1 - r0 < 4 && (rounds[r1].info & 0x7Fu) <= 16u &&
+                               ((rounds[r1].info ^ rounds[r0].info) & STRIP_OWNED) == 0u && ((rounds[r1].info >> 8) & 0xFFu) == 0u)
+                            ++r1;
+                    rounds[r0].info |= (uint32_t)(r1 - r0) << STRIP_BATCH_SHIFT;
+                    ++n_batches;
+                    r0 = r1;
+                }
+                if (n_batches & 1u) {  // (an even number of batches: the kernel's loops turn twice per iteration)
+                    StripRound pad{};
+                    pad.info = 1u << STRIP_BATCH_SHIFT;
+                    rounds.push_back(pad);
+                    ++n_batches;
+                }
                 sd.n_rounds = (uint32_t)(rounds.size() - sd.first_round);
+                if (sd.n_rounds + 8u > STRIP_TAB_CAP || n_batches > 0xFFu) too_long = true;  // (a hierarchy of more levels than a strip's table holds: the tiles)
+                sd.n_rounds |= n_batches << 16;
                 strips.push_back(sd);
                 strip_top.push_back(s);
             };
@@ -491,8 +522,8 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
                 }
                 if (rounds.size() > (size_t)64 * n + (1u << 20)) ok = false;  // (cones out of all proportion: a hierarchy for the tiles)
             }
-            if (ok && !strips.empty()) {
-                for (uint32_t i = 0; i < 2u * STRIP_RING; ++i) rounds.push_back(StripRound{});
+            if (ok && !too_long && !strips.empty()) {
+                for (uint32_t i = 0; i < 8u; ++i) rounds.push_back(StripRound{});  // (the producer reads up to six entries past a strip's last round)
                 uint32_t snap_level = 0;
                 for (uint32_t s : strip_top) snap_level = std::max(snap_level, s);
                 const uint32_t strip_snap_rows = level_offsets[snap_level];  // every cone row lies above the deepest first level
@@ -589,7 +620,7 @@ int32_t mi_debug_strip_plan(mi_ctx* ctx, uint32_t* out_rounds, uint32_t* out_con
     if (rc) return rc;
     if ((rc = download(ctx, rd.data(), ctx->strip_rounds.p, rd.size() * sizeof(StripRound)))) return rc;
     for (uint32_t i = 0; i < ctx->n_strips && i < cap; ++i) {
-        const uint32_t nr = sd[i].n_rounds & 0xFFFFFFu;
+        const uint32_t nr = sd[i].n_rounds & 0xFFFFu;
         uint32_t cone = 0;
         for (uint32_t j = 0; j < nr; ++j) {
             const uint32_t info = rd[sd[i].first_round + j].info;

@@ -510,17 +510,18 @@ constexpr uint32_t WAVE_TILE_ROWS = 80;
 hipError_t launch_propagate_wave_tiles(const Columns& c, const uint32_t* parent_idx, const TileDesc* d_wtiles, uint32_t n_tiles, const uint8_t* node_flags,
                                        const uint8_t* changed, const uint8_t* tree_bytes, uint8_t* g_changed_bytes, bool all_dirty, bool static_opt,
                                        bool quad, bool pretest, hipStream_t stream);
-// STRIPS (round 6, kernels_tree.hip: k_propagate_strips): a lopsided or deep tree in ONE launch of mutually independent waves.  The levels
-// are cut into bands; a strip OWNS a run of consecutive rows of its band's first level and all their descendants inside the band (no
-// level of it wider than the planner's width), and RE-EVALUATES -- never writes -- the cone of their ancestors above the band, level by
-// level, a contiguous row range each (rows are in level order and ordered by parent): the same products in the same order as the
-// strips that own those rows form, hence the same bits and the same change ticks, and nothing another wave produces is waited for.
-// A strip is a list of ROUNDS -- up to 64 rows of one level, a row per lane -- walked in order; a level's GlobalTransforms stay in LDS
-// for the level below (two levels of STRIP_W_CAP rows).  The table of rounds is flat: no limit on the levels of a hierarchy.
+// STRIPS (round 6, kernels_tree.hip: k_propagate_strips): a lopsided or deep tree in ONE launch of mutually independent workgroups.  The
+// levels are cut into bands; a strip OWNS a run of consecutive rows of its band's first level and all their descendants inside the band
+// (no level of it wider than the planner's width), and RE-EVALUATES -- never writes -- the cone of their ancestors above the band, level
+// by level, a contiguous row range each (rows are in level order and ordered by parent): the same products in the same order as the
+// strips that own those rows form, hence the same bits and the same change ticks, and nothing another workgroup produces is waited for.
+// A strip is a list of ROUNDS -- up to 64 rows of one level -- grouped into BATCHES: a round of more than 16 rows alone, or up to four
+// consecutive narrow levels; a producer wave stages a batch in LDS, four consumer waves walk it (kernels_tree.hip).  A level's
+// GlobalTransforms stay in LDS for the level below (two levels of STRIP_W_CAP rows).
 constexpr uint32_t STRIP_W_CAP = 128;  // rows of one level of one strip
 constexpr uint32_t STRIP_MAX_ROWS = 1u << 20;  // hierarchies above this are bandwidth: the workgroup tiles (measured: profiles/r06_experiments.md)
-constexpr uint32_t STRIP_RING = 2;     // rounds whose inputs the producer wave keeps in flight (even; a strip's round count is padded to a multiple)
-constexpr uint32_t STRIP_CONSUMERS = 4;  // consumer waves of a strip's workgroup: sixteen rows of a round each; one more wave produces
+constexpr uint32_t STRIP_TAB_CAP = 56;   // table entries of a strip held in LDS: a strip has at most STRIP_TAB_CAP - 8 (the producer reads ahead)
+constexpr uint32_t STRIP_CONSUMERS = 4;  // consumer waves of a strip's workgroup: sixteen rows of a wide round each; one more wave produces
 constexpr uint32_t STRIP_THREADS = 64u * (STRIP_CONSUMERS + 1u);
 struct StripRound {  // 16 bytes
     uint32_t row0;    // first row of the round
@@ -531,12 +532,11 @@ struct StripRound {  // 16 bytes
 constexpr uint32_t STRIP_PARITY = 1u << 16;     // which of the two LDS level buffers the round's level writes
 constexpr uint32_t STRIP_OWNED = 1u << 17;      // the strip owns the rows (writes GlobalTransform, change byte, snapshot); otherwise the cone
 constexpr uint32_t STRIP_ROOT = 1u << 18;       // level 0 of the forest
-constexpr uint32_t STRIP_LEVEL_END = 1u << 19;  // last round of its level
-constexpr uint32_t STRIP_QUAD = 1u << 21;       // <= 16 rows: a row per quad of lanes, a column of the affine each (half the instructions of a lane per row)
 constexpr uint32_t STRIP_ABOVE_TOP = 1u << 20;  // cone rounds of the level directly above the strip's first own level
+constexpr uint32_t STRIP_BATCH_SHIFT = 22;      // bits 22-24 of a batch's FIRST entry: its entries (1 = one round of up to 64 rows; 2 - 4 = consecutive narrow levels)
 struct StripDesc {
     uint32_t first_round;
-    uint32_t n_rounds;  // bits 0-23 (a multiple of STRIP_RING); bit 31: the strip owns rows of the snapshot prefix (no early exit)
+    uint32_t n_rounds;  // bits 0-15 the strip's table entries, 16-23 its batches (even); bit 31: the strip owns rows of the snapshot prefix (no early exit)
 };
 hipError_t launch_propagate_strips(const Columns& c, const uint32_t* parent_idx, const StripDesc* d_strips, const StripRound* d_rounds, uint32_t n_strips,
                                    const uint8_t* node_flags, const uint8_t* changed, const uint8_t* tree_bytes, uint8_t* g_changed_bytes, const float* snap_read,

@@ -1364,14 +1364,13 @@ __global__ void __launch_bounds__(64) k_propagate_wave_tiles(Columns c, TreeArgs
 // levels whose widths swell and shrink -- in ONE launch.  Through the workgroup tiles such a tree was three or four launches, each
 // behind the one that wrote its parents (a subtree of 15 levels does not fit a tile's LDS rows, and below the first cut the tiles'
 // top rows have hundreds of different parents: no single chain to re-evaluate): 27 - 31 us of 5 - 9 us tiles and the gaps between
-// launches.  A strip (kernels.h) is one WAVE that walks a list of rounds -- up to 64 rows of one level, a row per lane --: first the
-// CONE of its rows' ancestors, level by level from the forest's roots down (a contiguous row range per level; evaluated, never
-// written -- the strips that own those rows form the same products in the same order), then the rows it owns.  A level's results stay
-// in LDS for the level below; the inputs of the next STRIP_RING rounds are in flight while a round is multiplied (the table of rounds is
-// known up front, so nothing is asked for behind a result); no workgroup barrier, no wait for another wave, whatever the depth.
-// The cone's rows compare against (and, skipped under the static-scene rule, keep) their PRE-frame GlobalTransforms, which their
-// owners may be rewriting in this very launch: they read the chain snapshot (TreeArgs::snap_read), as the chain tiles do.
-// Same rule (node_apply), same products in the same order: same bits, same ticks.
+// launches.  A strip (kernels.h) is a workgroup that walks a list of rounds -- up to 64 rows of one level --: first the CONE of its
+// rows' ancestors, level by level from the forest's roots down (a contiguous row range per level; evaluated, never written -- the
+// strips that own those rows form the same products in the same order), then the rows it owns.  A level's results stay in LDS for the
+// level below; the table of rounds is known up front, so nothing is asked for behind a result; no wait for another workgroup,
+// whatever the depth.  The cone's rows compare against (and, skipped under the static-scene rule, keep) their PRE-frame
+// GlobalTransforms, which their owners may be rewriting in this very launch: they read the chain snapshot (TreeArgs::snap_read), as
+// the chain tiles do.  Same rule (quad_node_apply), same products in the same order: same bits, same ticks.
 // ---------------------------------------------------------------------------------------------
 struct StripIn {
     V3 t, s;
@@ -1379,98 +1378,124 @@ struct StripIn {
     uint32_t par;
     float4 o0, o1, o2;  // the old GlobalTransform as it was loaded (whole register quads: what the loop carries is what the loads wrote)
     NodeRaw raw;
+    uint32_t row, pstart, info;  // of the lane's table entry
 };
-__device__ __forceinline__ StripRound load_round(const StripRound* tab, uint32_t j) {
-    typedef const uint32_t __attribute__((address_space(4))) * const_u32;
-    const_u32 src = (const_u32)(uintptr_t)(tab + j);
-    StripRound e;
-    e.row0 = src[0];
-    e.pstart = src[1];
-    e.info = src[2];
-    e.level = src[3];
-    return e;
-}
-// Two waves per strip.  What a level costs its strip is the instructions ONE wave has to issue for it, ~5 cycles apiece when the wave is
-// alone on its SIMD: with everything in one wave's stream -- the round's 14 loads and their addresses, From(Transform), the parent's
-// read, the product, the compare, the stores -- a round was 0.72 us whatever its rows (profiles/r06_experiments.md, the strip-down
-// builds: the loads 0.17, the stores 0.05, the parent's read 0.07, the rest 0.38).  So the PRODUCER wave (wave 1) does everything that
-// does not hang on the level above -- the loads (the next STRIP_RING rounds in flight), From(Transform), the rule's inputs -- and leaves a
-// round ready in one of two LDS slots; the CONSUMER wave (wave 0) runs the dependent chain only: parent from LDS, product, set_if_neq,
-// the level's results into LDS for the level below and out to memory; <= 16 rows: a row per quad of lanes, a column each.  One workgroup
-// barrier per round hands a slot over each way.
+// A strip's workgroup: four CONSUMER waves and a PRODUCER wave.  What a level costs its strip is the instructions a wave has to issue for
+// it, 2 - 3.5 ns apiece (tools/probes/issue_rate_probe.hip: a dependent v_fma 3.5 ns, an independent one 2.1, a dependent LDS read 25, an LDS
+// hand-over through a barrier 70): with everything in ONE wave's stream -- a round's 14 loads and their addresses, From(Transform), the
+// parent's read, the product, the compare, the stores -- a round was 0.72 us whatever its rows.  So the producer does everything that
+// does not hang on the level above -- the loads (two batches ahead, in registers), From(Transform), the rule's inputs -- and leaves a
+// BATCH ready in one of two LDS slots of 64 rows: one round of up to 64 rows, or up to four consecutive NARROW levels (<= 16 rows
+// each) of the strip -- the cone of a deep tree is a dozen levels of one to three rows.  The consumers run the dependent chain only:
+// parent from LDS, product, set_if_neq, the level's results into LDS for the level below and out to memory, a row per quad of lanes, a
+// column of the affine each; a wide round sixteen rows per wave, the levels of a narrow batch one behind the other in wave 0 with
+// nothing but LDS between them (~0.2 us a level).  One workgroup barrier per batch hands a slot over each way.
 struct StripStage {
     float4 local[2][64 * 3];  // From(Transform)
     float4 old[2][64 * 3];    // the GlobalTransform before this frame (the cone's rows: from the snapshot)
-    uint32_t par[2][64];
-    uint8_t in[2][64];        // bit0 TransformTreeChanged, bit1 the level-0 assignment happens
+    uint32_t pin[2][64];      // bits 0-7 the parent's slot in the level above; bit 8 TransformTreeChanged, bit 9 the level-0 assignment happens
 };
+#ifdef MI_EXP_STRIP_STAMPS  // (timing build: how long a wave works between two barriers and how long it waits at them)
+#define STRIP_BARRIER()                               \
+    do {                                              \
+        const unsigned long long tb_ = wall_clock64(); \
+        x_work += tb_ - x_last;                       \
+        MI_WG_LDS_BARRIER();                          \
+        x_last = wall_clock64();                      \
+        x_wait += x_last - tb_;                       \
+    } while (0)
+#else
+#define STRIP_BARRIER() MI_WG_LDS_BARRIER()
+#endif
 template <bool ALL_DIRTY>
-__global__ void __launch_bounds__(STRIP_THREADS) k_propagate_strips(Columns c, TreeArgs a, const StripDesc* __restrict__ strips, const StripRound* __restrict__ rounds) {
+__global__ void __launch_bounds__(STRIP_THREADS, 7) k_propagate_strips(Columns c, TreeArgs a, const StripDesc* __restrict__ strips, const StripRound* __restrict__ rounds) {
     __shared__ float4 lds_g[2][STRIP_W_CAP * 3];  // the GlobalTransforms of the level above / of this level
     __shared__ uint8_t lds_chg[2][STRIP_W_CAP];   // "tick bumped" of the same rows
     __shared__ StripStage st;
-    static_assert(STRIP_RING % 2u == 0u, "a round's staging slot is its ring position's parity");
+    // The strip's rounds, copied into LDS first and read from there.  (Read with scalar loads from memory inside the loops they cost
+    // 0.2 us a round: scalar loads share the LDS counter and return out of order, so the first wait for any LDS result waited for them.)
+    __shared__ uint4 tab[STRIP_TAB_CAP];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t strip = xcd_contiguous_tile();
     unsigned long long ts[3] = {0, 0, 0};
     if (a.trace) ts[0] = wall_clock64();
-    uint32_t first, J;
+    uint32_t first, J, NB;
     bool snap_owner;
     {
         typedef const uint32_t __attribute__((address_space(4))) * const_u32;
         const_u32 src = (const_u32)(uintptr_t)(strips + strip);
         first = src[0];
         const uint32_t nr = src[1];
-        J = nr & 0xFFFFFFu;
+        J = nr & 0xFFFFu;
+        NB = (nr >> 16) & 0xFFu;
         snap_owner = (nr >> 31) != 0u;
     }
-    const StripRound* const tab = rounds + first;
+    for (uint32_t i = threadIdx.x; i < J + 8u && i < STRIP_TAB_CAP; i += STRIP_THREADS) tab[i] = reinterpret_cast<const uint4*>(rounds + first)[i];
+    __syncthreads();
     // ---- a frame in which little moved: the strip's flags first (the workgroup tiles' pretest).  Under the static-scene rule the rows
     // the strip owns keep every GlobalTransform and every tick unless one of them is marked (TransformTreeChanged) or assigned as a
     // root / flat row, or the parent of a top row gets a new tick -- which takes a cone row whose own Transform changed (a row that is
     // merely re-evaluated reproduces its value and set_if_neq leaves it alone, systems.rs:719), or a forest root directly above the top
     // rows that is assigned this frame (its tick is bumped whatever the value, systems.rs:522-530).  Strips that mirror rows into the
-    // snapshot take the long way.  (Both waves test, and agree.)
+    // snapshot take the long way.  (Every wave tests, and they agree.)
     if constexpr (!ALL_DIRTY) {
         if ((a.pretest & 1u) && a.static_opt && !snap_owner) {
             bool hot = false;
-            for (uint32_t j = 0; j < J; j += STRIP_RING) {
-#pragma unroll
-                for (uint32_t d = 0; d < STRIP_RING; ++d) {
-                    const StripRound e = load_round(tab, j + d);
-                    const bool on = lane < (e.info & 0x7Fu);
-                    const uint32_t row = e.row0 + (on ? lane : 0u);
-                    const bool root_level = (e.info & STRIP_ROOT) != 0u;
-                    const NodeIn in = node_inputs_raw(a, row, root_level, node_raw<false>(a, row, root_level));
-                    const bool own_hot = in.tree_changed || in.root_write;
-                    const bool cone_hot = row_changed(at32<uint8_t>(a.changed, row), a.changed_gen) || ((e.info & STRIP_ABOVE_TOP) != 0u && in.root_write);
-                    hot = hot || (on && ((e.info & STRIP_OWNED) ? own_hot : cone_hot));
-                }
+            for (uint32_t j = 0; j < J; ++j) {
+                const uint4 e = tab[j];
+                const bool on = lane < (e.z & 0x7Fu);
+                const uint32_t row = e.x + (on ? lane : 0u);
+                const bool root_level = (e.z & STRIP_ROOT) != 0u;
+                const NodeIn in = node_inputs_raw(a, row, root_level, node_raw<false>(a, row, true));
+                const bool own_hot = in.tree_changed || in.root_write;
+                const bool cone_hot = row_changed(at32<uint8_t>(a.changed, row), a.changed_gen) || ((e.z & STRIP_ABOVE_TOP) != 0u && in.root_write);
+                hot = hot || (on && ((e.z & STRIP_OWNED) ? own_hot : cone_hot));
             }
             if (__ballot(hot) == 0ull) {
                 if (wv == 0u)
                     for (uint32_t j = 0; j < J; ++j) {
-                        const StripRound e = load_round(tab, j);
-                        if ((e.info & STRIP_OWNED) && lane < (e.info & 0x7Fu)) at32w<uint8_t>(a.g_changed_bytes, e.row0 + lane) = 0;
+                        const uint4 e = tab[j];
+                        if ((e.z & STRIP_OWNED) && lane < (e.z & 0x7Fu)) at32w<uint8_t>(a.g_changed_bytes, e.x + lane) = 0;
                     }
                 return;
             }
         }
     }
+#ifdef MI_EXP_STRIP_STAMPS
+    unsigned long long x_work = 0, x_wait = 0, x_last = wall_clock64();
+#endif
     if (a.trace) ts[1] = wall_clock64();
+    // a batch's header: the info word of its first entry (uniform)
+    auto header = [&](uint32_t i) { return (uint32_t)__builtin_amdgcn_readfirstlane(tab[i].z); };
+    auto batch_entries = [](uint32_t info) {
+        const uint32_t k = (info >> STRIP_BATCH_SHIFT) & 7u;
+        return k ? k : 1u;
+    };
+    // The barriers: B(k) when batch k is staged and batch k - 1 is through.  NB of them on either side (NB, the strip's batches, is even:
+    // the planner pads).  (A third slot, the producer two batches ahead and the consumers fetching batch k + 1's staged inputs under
+    // batch k's arithmetic, measured no faster and cost a workgroup per CU.)
     if (wv == STRIP_CONSUMERS) {
         // ================= the producer =================
-        // A round's inputs: a row per lane, coalesced inside the level; lanes past the round's rows re-read its first row.  (Scale,
-        // translation and rotation word by word, each offset of the rotation through an empty asm statement so that the loads are not
-        // merged back: a merged load lands in a register pair / triple / quad which the loop-carried copy of the ring cannot always be
-        // allocated on top of -- the moves that remained at the loop's end waited for every load in flight but the last four.)
-        auto fetch = [&](const StripRound& e) {
+        // A batch's inputs: a row per lane -- lane i row i of a wide round, or row i % 16 of the batch's narrow level i / 16 --, the
+        // lane's table entry from LDS; lanes past the rows re-read the entry's first row.  (Scale, translation and rotation word by
+        // word, each offset of the rotation through an empty asm statement so that the loads are not merged back: a merged load lands in
+        // a register pair / triple / quad which the loop-carried copy of the ring cannot always be allocated on top of -- the moves that
+        // remained at the loop's end waited for every load in flight but the last four.)
+        auto fetch = [&](uint32_t i, uint32_t info0) {
             StripIn f;
-            const bool on = lane < (e.info & 0x7Fu);
-            const uint32_t row = e.row0 + (on ? lane : 0u);
-            const bool root_level = (e.info & STRIP_ROOT) != 0u;
-            const float* const old_src = (e.info & STRIP_OWNED) ? c.global : a.snap_read;  // (uniform)
+            const uint32_t cnt = batch_entries(info0);
+            const bool wide = (info0 & 0x7Fu) > 16u;
+            const uint32_t sub_raw = lane >> 4;
+            const uint32_t sub = wide ? 0u : (sub_raw < cnt ? sub_raw : cnt - 1u);
+            const uint4 ev = tab[i + sub];
+            const uint32_t jrow = wide ? lane : (lane & 15u);
+            const bool on = jrow < (ev.z & 0x7Fu) && (wide || sub_raw < cnt);
+            const uint32_t row = ev.x + (on ? jrow : 0u);
+            f.row = row;
+            f.pstart = ev.y;
+            f.info = on ? ev.z : (ev.z & ~0x7Fu);  // (a lane without a row: zero rows)
+            const float* const old_src = (info0 & STRIP_OWNED) ? c.global : a.snap_read;  // (uniform: a batch is cone or own, never both)
             f.t = V3{at32<float>(c.translation, row * 12u), at32<float>(c.translation, row * 12u + 4u), at32<float>(c.translation, row * 12u + 8u)};
             f.s = V3{at32<float>(c.scale, row * 12u), at32<float>(c.scale, row * 12u + 4u), at32<float>(c.scale, row * 12u + 8u)};
             {
@@ -1484,58 +1509,42 @@ __global__ void __launch_bounds__(STRIP_THREADS) k_propagate_strips(Columns c, T
             f.o0 = at32<float4>(old_src, row * 48u);
             f.o1 = at32<float4>(old_src, row * 48u + 16u);
             f.o2 = at32<float4>(old_src, row * 48u + 32u);
-            f.raw = node_raw<ALL_DIRTY>(a, row, root_level);
+            f.raw = node_raw<ALL_DIRTY>(a, row, true);
             return f;
         };
-        auto stage = [&](const StripRound& e, const StripIn& in, uint32_t sl) {
-            const bool on = lane < (e.info & 0x7Fu);
-            const uint32_t row = e.row0 + (on ? lane : 0u);
-            const bool root_level = (e.info & STRIP_ROOT) != 0u;
+        auto stage = [&](const StripIn& in, uint32_t sl) {
+            const bool root_level = (in.info & STRIP_ROOT) != 0u;
             lds_put(st.local[sl], lane, affine_from_srt(in.s, V4{in.q.x, in.q.y, in.q.z, in.q.w}, in.t));
             st.old[sl][lane * 3u] = in.o0;
             st.old[sl][lane * 3u + 1u] = in.o1;
             st.old[sl][lane * 3u + 2u] = in.o2;
-            uint32_t ps = in.par - e.pstart;  // the parent's slot in the level above (whatever a root reads there is ignored)
-            st.par[sl][lane] = ps < STRIP_W_CAP ? ps : STRIP_W_CAP - 1u;
-            const NodeIn nin = node_inputs_raw(a, row, root_level, in.raw);
-            st.in[sl][lane] = (uint8_t)((nin.tree_changed ? 1u : 0u) | (nin.root_write ? 2u : 0u));
+            uint32_t ps = in.par - in.pstart;  // the parent's slot in the level above (whatever a root reads there is ignored)
+            ps = ps < STRIP_W_CAP ? ps : STRIP_W_CAP - 1u;
+            const NodeIn nin = node_inputs_raw(a, in.row, root_level, in.raw);
+            st.pin[sl][lane] = ps | (nin.tree_changed ? 0x100u : 0u) | (nin.root_write ? 0x200u : 0u);
         };
-#ifdef MI_EXP_STRIP_STAMPS
-        unsigned long long x_work = 0, x_wait = 0, x_last = wall_clock64();
-#endif
-        StripRound e[STRIP_RING], f[STRIP_RING];
-        StripIn ring[STRIP_RING];
-#pragma unroll
-        for (uint32_t d = 0; d < STRIP_RING; ++d) {
-            e[d] = load_round(tab, d);
-            f[d] = load_round(tab, STRIP_RING + d);
-        }
-#pragma unroll
-        for (uint32_t d = 0; d < STRIP_RING; ++d) ring[d] = fetch(e[d]);
-        for (uint32_t j = 0; j < J; j += STRIP_RING) {
-            StripRound g[STRIP_RING];
-#pragma unroll
-            for (uint32_t d = 0; d < STRIP_RING; ++d) g[d] = load_round(tab, j + 2u * STRIP_RING + d);  // (the table ends in 2 x STRIP_RING padding rounds)
-#pragma unroll
-            for (uint32_t d = 0; d < STRIP_RING; ++d) {
-                stage(e[d], ring[d], d & 1u);
-                __builtin_amdgcn_sched_barrier(0);
-                ring[d] = fetch(f[d]);  // (behind the staging that used them up: the loads land in the registers the loop carries)
-#ifdef MI_EXP_STRIP_STAMPS
-                const unsigned long long tb = wall_clock64();
-                x_work += tb - x_last;
-#endif
-                MI_WG_LDS_BARRIER();    // round j + d is staged; the consumer is through with round j + d - 1: its slot is free
-#ifdef MI_EXP_STRIP_STAMPS
-                x_last = wall_clock64();
-                x_wait += x_last - tb;
-#endif
-            }
-#pragma unroll
-            for (uint32_t d = 0; d < STRIP_RING; ++d) {
-                e[d] = f[d];
-                f[d] = g[d];
-            }
+        // the next batch to ask for: its first entry and header (kept inside the table: J + 8 entries are there)
+        uint32_t pf = 0, hf = header(0);
+        auto advance = [&]() {
+            pf += batch_entries(hf);
+            pf = pf < J + 4u ? pf : J + 4u;
+            hf = header(pf);
+        };
+        StripIn r0 = fetch(pf, hf);
+        advance();
+        StripIn r1 = fetch(pf, hf);
+        advance();
+        for (uint32_t k = 0; k < NB; k += 2u) {
+            stage(r0, 0u);
+            __builtin_amdgcn_sched_barrier(0);
+            r0 = fetch(pf, hf);  // (behind the staging that used them up: the loads land in the registers the loop carries)
+            advance();
+            STRIP_BARRIER();  // B(k)
+            stage(r1, 1u);
+            __builtin_amdgcn_sched_barrier(0);
+            r1 = fetch(pf, hf);
+            advance();
+            STRIP_BARRIER();  // B(k + 1)
         }
 #ifdef MI_EXP_STRIP_STAMPS
         if (a.trace && lane == 0) {
@@ -1545,69 +1554,93 @@ __global__ void __launch_bounds__(STRIP_THREADS) k_propagate_strips(Columns c, T
 #endif
         return;
     }
-    // ================= the consumer =================
-    // (every consumer wave: sixteen rows of the round, a row per quad of lanes, a column of the affine each)
-    const uint32_t q_unit = wv * 16u + (lane >> 2), q_cc = lane & 3u;
-    auto step = [&](const StripRound& e, uint32_t sl) {
-        const uint32_t n = e.info & 0x7Fu;
-        const bool on = q_unit < n;
-        const uint32_t u = on ? q_unit : 0u;
-        const uint32_t row = e.row0 + u;
-        const bool root_level = (e.info & STRIP_ROOT) != 0u;
-        const bool owned = (e.info & STRIP_OWNED) != 0u;
-        const uint32_t p = (e.info & STRIP_PARITY) ? 1u : 0u;
-        const uint32_t slot = ((e.info >> 8) & 0xFFu) + u;
-        const uint32_t ps = st.par[sl][u];
-        const uint32_t in_bits = st.in[sl][u];
-#ifndef MI_EXP_STRIP_NOLDS
+    // ================= the consumers =================
+    const uint32_t q_unit = lane >> 2, q_cc = lane & 3u;
+    struct Staged {
+        uint32_t pin;
+        V3 local_c, old_c;
+    };
+    // the staged inputs of the lane's row: `sidx` its place in the slot
+    auto staged = [&](uint32_t sl, uint32_t sidx) {
+        Staged r;
+        r.pin = st.pin[sl][sidx];
+        r.local_c = lds_col(st.local[sl], sidx, q_cc);
+        r.old_c = lds_col(st.old[sl], sidx, q_cc);
+        return r;
+    };
+    // where the lane's row of a batch's FIRST round sits in the slot (a wide round: sixteen rows per consumer wave)
+    auto first_sidx = [&](uint32_t info0) {
+        const bool wide = (info0 & 0x7Fu) > 16u;
+        const uint32_t j = (wide ? wv * 16u : 0u) + q_unit;
+        return j < (info0 & 0x7Fu) ? j : 0u;
+    };
+    // one level's rows: j = the lane's row inside the round
+    auto level_step = [&](uint32_t row0, uint32_t info, uint32_t j, const Staged& in) {
+        const bool on = j < (info & 0x7Fu);
+        const uint32_t jj = on ? j : 0u;
+        const uint32_t row = row0 + jj;
+        const bool root_level = (info & STRIP_ROOT) != 0u;
+        const bool owned = (info & STRIP_OWNED) != 0u;
+        const uint32_t p = (info & STRIP_PARITY) ? 1u : 0u;
+        const uint32_t slot = ((info >> 8) & 0xFFu) + jj;
+        const uint32_t ps = in.pin & 0xFFu;
         const Affine gp = lds_affine(lds_g[p ^ 1u], ps);
         const bool pc = lds_chg[p ^ 1u][ps] != 0;
-#else
-        const Affine gp = lds_affine(st.old[sl], u);
-        const bool pc = ps == 77u;
-#endif
         V3 cur_c;
-        const bool chg = quad_node_apply(on, root_level, a.static_opt != 0, in_bits, gp, pc, lds_col(st.local[sl], u, q_cc), lds_col(st.old[sl], u, q_cc), q_cc, lane, &cur_c);
+        const bool chg = quad_node_apply(on, root_level, a.static_opt != 0, in.pin >> 8, gp, pc, in.local_c, in.old_c, q_cc, lane, &cur_c);
         if (on) {
             lds_put_col(lds_g[p], slot, q_cc, cur_c);
             if (q_cc == 0u) lds_chg[p][slot] = chg ? 1 : 0;
-#ifndef MI_EXP_STRIP_NOSTORE
             if (owned) {
                 if (q_cc == 0u) at32w<uint8_t>(a.g_changed_bytes, row) = chg ? 1 : 0;
                 if (chg) at32w<F3>(c.global, row * 48u + q_cc * 12u) = F3{cur_c.x, cur_c.y, cur_c.z};
                 if (snap_owner && row < a.snap_rows) at32w<F3>(a.snap_write, row * 48u + q_cc * 12u) = F3{cur_c.x, cur_c.y, cur_c.z};
             }
-#else
-            if (owned && chg && cur_c.x == 1.2345f) at32w<uint8_t>(a.g_changed_bytes, row) = 1;
-#endif
         }
     };
-#ifdef MI_EXP_STRIP_STAMPS
-    unsigned long long y_work = 0, y_wait = 0, y_last = wall_clock64();
-#endif
-    {
-        StripRound e[STRIP_RING];
+    auto batch = [&](uint32_t i, uint32_t info0, uint32_t sl) {
+        const uint32_t row0 = __builtin_amdgcn_readfirstlane(tab[i].x);
+        const bool wide = (info0 & 0x7Fu) > 16u;
+        if (wide) {
+            level_step(row0, info0, wv * 16u + q_unit, staged(sl, first_sidx(info0)));
+            return;
+        }
+        if (wv != 0u) return;  // (the levels of a narrow batch hang on each other: one wave, nothing but LDS between two of them)
+        const uint32_t cnt = batch_entries(info0);
+        // every level's staged inputs first: they do not hang on anything
+        uint32_t infos[4], rows0[4];
+        Staged in[4];
+        infos[0] = info0, rows0[0] = row0;
+        in[0] = staged(sl, first_sidx(info0));
 #pragma unroll
-        for (uint32_t d = 0; d < STRIP_RING; ++d) e[d] = load_round(tab, d);
-        for (uint32_t j = 0; j < J; j += STRIP_RING) {
-            StripRound g[STRIP_RING];
+        for (uint32_t s2 = 1; s2 < 4u; ++s2) {
+            const uint4 ev = tab[i + (s2 < cnt ? s2 : 0u)];
+            infos[s2] = __builtin_amdgcn_readfirstlane(ev.z);
+            rows0[s2] = __builtin_amdgcn_readfirstlane(ev.x);
+            in[s2] = staged(sl, 16u * s2 + (q_unit < (infos[s2] & 0x7Fu) ? q_unit : 0u));
+        }
+        level_step(rows0[0], infos[0], q_unit, in[0]);
 #pragma unroll
-            for (uint32_t d = 0; d < STRIP_RING; ++d) g[d] = load_round(tab, j + STRIP_RING + d);
-#pragma unroll
-            for (uint32_t d = 0; d < STRIP_RING; ++d) {
-#ifdef MI_EXP_STRIP_STAMPS
-                const unsigned long long tb = wall_clock64();
-                y_work += tb - y_last;
-#endif
-                MI_WG_LDS_BARRIER();  // round j + d is staged
-#ifdef MI_EXP_STRIP_STAMPS
-                y_last = wall_clock64();
-                y_wait += y_last - tb;
-#endif
-                step(e[d], d & 1u);
+        for (uint32_t s2 = 1; s2 < 4u; ++s2) {
+            if (s2 < cnt) {
+                MI_WAVE_LDS_SYNC();  // (the level above is written)
+                level_step(rows0[s2], infos[s2], q_unit, in[s2]);
             }
-#pragma unroll
-            for (uint32_t d = 0; d < STRIP_RING; ++d) e[d] = g[d];
+        }
+    };
+    {
+        uint32_t pc_i = 0, hc = header(0);
+        for (uint32_t k = 0; k < NB; k += 2u) {
+            STRIP_BARRIER();  // B(k)
+            batch(pc_i, hc, 0u);
+            pc_i += batch_entries(hc);
+            pc_i = pc_i < J + 4u ? pc_i : J + 4u;
+            hc = header(pc_i);
+            STRIP_BARRIER();  // B(k + 1)
+            batch(pc_i, hc, 1u);
+            pc_i += batch_entries(hc);
+            pc_i = pc_i < J + 4u ? pc_i : J + 4u;
+            hc = header(pc_i);
         }
     }
     if (a.trace && wv == 0u) {
@@ -1619,8 +1652,8 @@ __global__ void __launch_bounds__(STRIP_THREADS) k_propagate_strips(Columns c, T
             o[0] = ts[0];
             o[1] = ts[1];
 #ifdef MI_EXP_STRIP_STAMPS
-            o[2] = y_wait;
-            o[3] = y_work;
+            o[2] = x_wait;
+            o[3] = x_work;
             o[4] = ts[2];
 #else
             o[2] = ts[1];
@@ -1634,6 +1667,7 @@ __global__ void __launch_bounds__(STRIP_THREADS) k_propagate_strips(Columns c, T
     }
 }
 
+#undef STRIP_BARRIER
 // ---------------------------------------------------------------------------------------------
 // visibility_propagate_system + propagate_recursive (crates/bevy_camera/src/visibility/mod.rs:638-729) as the
 // fixpoint they maintain, swept over the same subtree tiles as the transforms:

@@ -115,10 +115,11 @@ def test_tile_plans_cut_oversized_subtrees_and_the_level_sweep_can_be_forced(ctx
     p, levels = plan("fan_4ary_7_levels", 0)
     assert p["launches"] == 1 and levels == 7                       # roots and chain tiles share one launch
     assert plan("fan_4ary_7_levels", 1)[0]["launches"] == 7         # forced: one launch per level
-    p, levels = plan("skewed", 0)
+    p, levels = plan("skewed", 4)
     assert p["launches"] == 2 and levels == 4                       # a node with 300 children that have children: its tile is cut, the rest follows
     assert plan("skewed", 1)[0]["launches"] == 4
-    assert plan("skewed_twice", 0)[0]["launches"] >= 2
+    assert plan("skewed_twice", 4)[0]["launches"] >= 2
+    assert plan("skewed", 0)[0]["launches"] == 1 and plan("skewed_twice", 0)[0]["launches"] == 1  # by default such a hierarchy takes strips: one launch (round 6)
     # by default (mode 0): tiles wherever they fit
     big = W.gen_tree(12, 4, 1_000_000)
     ctx = ctx_factory()

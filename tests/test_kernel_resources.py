@@ -29,6 +29,8 @@ PINNED = {
         "mi::k_propagate_fans<true, true, 8u>": (72, 7, 80, 0),
         "mi::k_propagate_fans<true, false, 16u>": (64, 8, 32, 0),   # 16-level tiles (bands <= 64 rows wide, or down to level 0)
         "mi::k_propagate_narrow<true, true>": (128, 1, 0, 0),       # one wave per hierarchy: no spills is all that matters
+        "mi::k_propagate_strips<true>": (72, 7, 0, 0),              # strips: five waves per workgroup, five workgroups per CU (1 280 strips in flight) take 7 waves per SIMD
+        "mi::k_propagate_strips<false>": (72, 7, 0, 0),
         "mi::k_propagate_level<false>": (64, 8, 0, 0),
     },
 }

@@ -26,6 +26,7 @@ ALIAS = {"k_frame_sph<true": "k_flat_propagate_cull", "k_frame_sph<false": "k_cu
          "k_frame<true": "k_flat_propagate_cull", "k_frame<false": "k_cull",  # (profiles from before PROP was an int)
          "k_propagate_level": "k_propagate_stream", "k_propagate_narrow": "k_propagate_stream",
          "k_propagate_wave_tiles": "k_propagate_fans",  # a forest of small trees: a wave per tile (round 6), timed in the tile launch's slot
+         "k_propagate_strips": "k_propagate_fans",  # a deep or lopsided tree: strips (round 6), timed in the tile launch's slot
          "k_frame_cells": "k_cull",  # the frame over the static cull order (its cell test: k_cells_test, its lists: k_cells_blocks / k_cells_lists)
          "k_sorted_walk<512u, 16u, true>": "k_batch_scan", "k_sorted_walk<512, 16, true>": "k_batch_scan",  # the tiles' records
          "k_sorted_walk": "k_batch_sorted"}

@@ -373,9 +373,12 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
     ctx->strip_plan = false;
     ctx->n_strips = 0;
     {
-        uint32_t W = 128;
-        if (const char* ev = getenv("MI_STRIP_W")) W = (uint32_t)std::max(1, atoi(ev));
-        W = std::min(W, STRIP_W_CAP);
+        // The width: 64 rows to a level (one round per level) while every strip of the launch is in flight at once -- five workgroups of
+        // five waves per CU --, else 128: a second round at the widest levels costs a strip less than waiting for a free CU does
+        // (deep_tree, kernel us of an all-dirty frame: 1 839 strips of 64 29.8, 1 084 of 128 22.9).  MI_STRIP_W: the test knob.
+        const uint32_t resident = 5u * 256u;
+        std::vector<uint32_t> widths = {64u, 128u};
+        if (const char* ev = getenv("MI_STRIP_W")) widths = {std::min((uint32_t)std::max(1, atoi(ev)), STRIP_W_CAP)};
         const bool narrow_batches = !getenv("MI_STRIP_NO_BATCHES");
         uint32_t max_extra = 1000;
         if (const char* ev = getenv("MI_STRIP_EXTRA")) max_extra = (uint32_t)std::max(0, atoi(ev));
@@ -385,7 +388,9 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
         // update_leaves 19.4 -> 16.0; a root with 500 x 500 descendants 10.2 -> 13.5 and the 1.4 M-node 4-ary tree 32.9 -> 67.9 the other way)
         const bool wanted = ctx->tile_mode == 5 || (modes_ok && !ctx->wave_forest && !ctx->narrow && !ctx->by_levels && n <= STRIP_MAX_ROWS &&
                                                     (ctx->groups.size() >= 2 || n_levels >= 16));
-        if (wanted && !ctx->by_levels && n > 0) {
+        for (size_t wi_ = 0; wi_ < widths.size() && wanted && !ctx->by_levels && n > 0 && !ctx->strip_plan; ++wi_) {
+            const uint32_t W = widths[wi_];
+            const bool last_width = wi_ + 1 == widths.size();
             auto level_size = [&](uint32_t lv) -> uint64_t { return level_offsets[lv + 1] - level_offsets[lv]; };
             std::vector<std::pair<uint32_t, uint32_t>> bands;  // [s, e), bottom-up
             for (uint32_t e = n_levels; e > 0;) {
@@ -522,7 +527,7 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
                 }
                 if (rounds.size() > (size_t)64 * n + (1u << 20)) ok = false;  // (cones out of all proportion: a hierarchy for the tiles)
             }
-            if (ok && !too_long && !strips.empty()) {
+            if (ok && !too_long && !strips.empty() && (last_width || strips.size() <= resident)) {
                 for (uint32_t i = 0; i < 8u; ++i) rounds.push_back(StripRound{});  // (the producer reads up to six entries past a strip's last round)
                 uint32_t snap_level = 0;
                 for (uint32_t s : strip_top) snap_level = std::max(snap_level, s);

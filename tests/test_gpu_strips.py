@@ -77,7 +77,7 @@ def _lopsided_forest(rng, n_trees, depth, max_children, p_leaf, fan_node_every=0
     return np.array(parent, np.int64)
 
 
-@pytest.mark.parametrize("width", [3, 8, 64, 128])
+@pytest.mark.parametrize("width", [3, 8, 64, 128, None])  # (None: the planner's own choice)
 @pytest.mark.parametrize("seed", range(6))
 def test_random_forests_through_strips(seed, width, strip_width):
     rng = np.random.default_rng(9100 + seed)

@@ -388,7 +388,7 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
         // update_leaves 19.4 -> 16.0; a root with 500 x 500 descendants 10.2 -> 13.5 and the 1.4 M-node 4-ary tree 32.9 -> 67.9 the other way)
         const bool wanted = ctx->tile_mode == 5 || (modes_ok && !ctx->wave_forest && !ctx->narrow && !ctx->by_levels && n <= STRIP_MAX_ROWS &&
                                                     (ctx->groups.size() >= 2 || n_levels >= 16));
-        for (size_t wi_ = 0; wi_ < widths.size() && wanted && !ctx->by_levels && n > 0 && !ctx->strip_plan; ++wi_) {
+        for (size_t wi_ = 0; wi_ < widths.size() && wanted && !ctx->by_levels && n > 0 && n < (1u << 24) && !ctx->strip_plan; ++wi_) {  // (the kernel's 24-bit row offsets)
             const uint32_t W = widths[wi_];
             const bool last_width = wi_ + 1 == widths.size();
             auto level_size = [&](uint32_t lv) -> uint64_t { return level_offsets[lv + 1] - level_offsets[lv]; };

@@ -1496,8 +1496,9 @@ __global__ void __launch_bounds__(STRIP_THREADS, 7) k_propagate_strips(Columns c
             f.pstart = ev.y;
             f.info = on ? ev.z : (ev.z & ~0x7Fu);  // (a lane without a row: zero rows)
             const float* const old_src = (info0 & STRIP_OWNED) ? c.global : a.snap_read;  // (uniform: a batch is cone or own, never both)
-            f.t = V3{at32<float>(c.translation, row * 12u), at32<float>(c.translation, row * 12u + 4u), at32<float>(c.translation, row * 12u + 8u)};
-            f.s = V3{at32<float>(c.scale, row * 12u), at32<float>(c.scale, row * 12u + 4u), at32<float>(c.scale, row * 12u + 8u)};
+            const uint32_t r12 = __umul24(row, 12u), r48 = __umul24(row, 48u);  // (rows of a hierarchy that takes strips are below 2^24)
+            f.t = V3{at32<float>(c.translation, r12), at32<float>(c.translation, r12 + 4u), at32<float>(c.translation, r12 + 8u)};
+            f.s = V3{at32<float>(c.scale, r12), at32<float>(c.scale, r12 + 4u), at32<float>(c.scale, r12 + 8u)};
             {
                 uint32_t q0 = row * 16u, q1 = row * 16u + 4u, q2 = row * 16u + 8u, q3 = row * 16u + 12u;
                 asm volatile("" : "+v"(q1));
@@ -1506,9 +1507,9 @@ __global__ void __launch_bounds__(STRIP_THREADS, 7) k_propagate_strips(Columns c
                 f.q = make_float4(at32<float>(c.rotation, q0), at32<float>(c.rotation, q1), at32<float>(c.rotation, q2), at32<float>(c.rotation, q3));
             }
             f.par = at32<uint32_t>(a.parent_idx, row * 4u);
-            f.o0 = at32<float4>(old_src, row * 48u);
-            f.o1 = at32<float4>(old_src, row * 48u + 16u);
-            f.o2 = at32<float4>(old_src, row * 48u + 32u);
+            f.o0 = at32<float4>(old_src, r48);
+            f.o1 = at32<float4>(old_src, r48 + 16u);
+            f.o2 = at32<float4>(old_src, r48 + 32u);
             f.raw = node_raw<ALL_DIRTY>(a, row, true);
             return f;
         };
@@ -1561,11 +1562,17 @@ __global__ void __launch_bounds__(STRIP_THREADS, 7) k_propagate_strips(Columns c
         V3 local_c, old_c;
     };
     // the staged inputs of the lane's row: `sidx` its place in the slot
+    // (24-bit multiplies for every offset: rows, slots and their byte offsets are far below 2^24, and a full 32-bit or 64-bit multiply-add
+    // issues at a quarter of the rate -- five of them were a tenth of a level's step)
+    const uint32_t cc3 = q_cc * 3u;
     auto staged = [&](uint32_t sl, uint32_t sidx) {
         Staged r;
         r.pin = st.pin[sl][sidx];
-        r.local_c = lds_col(st.local[sl], sidx, q_cc);
-        r.old_c = lds_col(st.old[sl], sidx, q_cc);
+        const uint32_t o = __umul24(sidx, 12u) + cc3;
+        const float* const lp = reinterpret_cast<const float*>(st.local[sl]);
+        const float* const op = reinterpret_cast<const float*>(st.old[sl]);
+        r.local_c = V3{lp[o], lp[o + 1u], lp[o + 2u]};
+        r.old_c = V3{op[o], op[o + 1u], op[o + 2u]};
         return r;
     };
     // where the lane's row of a batch's FIRST round sits in the slot (a wide round: sixteen rows per consumer wave)
@@ -1589,12 +1596,14 @@ __global__ void __launch_bounds__(STRIP_THREADS, 7) k_propagate_strips(Columns c
         V3 cur_c;
         const bool chg = quad_node_apply(on, root_level, a.static_opt != 0, in.pin >> 8, gp, pc, in.local_c, in.old_c, q_cc, lane, &cur_c);
         if (on) {
-            lds_put_col(lds_g[p], slot, q_cc, cur_c);
+            float* const gw = reinterpret_cast<float*>(lds_g[p]) + __umul24(slot, 12u) + cc3;
+            gw[0] = cur_c.x, gw[1] = cur_c.y, gw[2] = cur_c.z;
             if (q_cc == 0u) lds_chg[p][slot] = chg ? 1 : 0;
             if (owned) {
+                const uint32_t goff = __umul24(row, 48u) + cc3 * 4u;
                 if (q_cc == 0u) at32w<uint8_t>(a.g_changed_bytes, row) = chg ? 1 : 0;
-                if (chg) at32w<F3>(c.global, row * 48u + q_cc * 12u) = F3{cur_c.x, cur_c.y, cur_c.z};
-                if (snap_owner && row < a.snap_rows) at32w<F3>(a.snap_write, row * 48u + q_cc * 12u) = F3{cur_c.x, cur_c.y, cur_c.z};
+                if (chg) at32w<F3>(c.global, goff) = F3{cur_c.x, cur_c.y, cur_c.z};
+                if (snap_owner && row < a.snap_rows) at32w<F3>(a.snap_write, goff) = F3{cur_c.x, cur_c.y, cur_c.z};
             }
         }
     };

@@ -6,7 +6,7 @@ P=gpurun_out/prof_$TAG
 D=profiles/$TAG
 mkdir -p $D
 cp -r $P/profiles_$TAG/. $D/
-for f in device.txt gputest.log gputest_other_paths.log smoke.log host_systems_test.log host_visibility_test.log multi_gpu_single_process.json shapes_table.md \
+for f in device.txt gputest.log gputest_other_paths.log gputest_strips_forced.log strip_traces.txt strips_ab.md smoke.log host_systems_test.log host_visibility_test.log multi_gpu_single_process.json shapes_table.md \
          sharded_1rank.md bench_line.json bench_full.json bench_stdout.txt tree_frame_sq_counters.txt tree_sq_counters.txt; do
   [ -f $P/$f ] && cp $P/$f $D/
 done

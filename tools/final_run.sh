@@ -16,6 +16,8 @@ timeout 200 ./tests/cpp/multi_gpu_single_process 1000000 6 > $P/multi_gpu_single
 timeout 600 ./tests/cpp/host_systems_test > $P/host_systems_test.log 2>&1; echo "host systems rc=$?" >> $P/host_systems_test.log
 timeout 600 ./tests/cpp/host_visibility_test > $P/host_visibility_test.log 2>&1; echo "host visibility rc=$?" >> $P/host_visibility_test.log
 bash tools/shape_sweep.sh $P/shapes > $P/shapes_table.md 2>&1
+for s in large_tree deep_tree update_leaves update_shallow; do python tools/strip_trace.py $s 0; done > $P/strip_traces.txt 2>&1
+SHAPES="large_tree deep_tree update_leaves update_shallow humanoids_active wide_tree" WIDTHS="64 128" bash tools/strips_ab.sh $P/strips_ab > $P/strips_ab.md 2>&1
 bash tools/sharded_1rank.sh $P/sharded_1rank > $P/sharded_1rank.md 2>&1
 bash tools/profile.sh $TAG > $P/profile.log 2>&1
 timeout 1200 python bench.py > $P/bench_stdout.txt 2> $P/bench.err; echo "bench rc=$?" >> $P/bench.err

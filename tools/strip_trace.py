@@ -1,5 +1,6 @@
 """Development aid (GPU box): the strips of a hierarchy stress shape (k_propagate_strips) -- rounds per strip, and the per-strip phase
-timeline of an all-dirty frame (stamps: 0 start, 1 flags tested, 2 first batch asked for, 3 cone done, 4 rounds done, 7 stores drained).
+timeline of an all-dirty frame (stamps: 0 start, 1 table in LDS and flags tested, 4 rounds done, 7 stores drained; with a
+-DMI_EXP_STRIP_STAMPS build (MI_LIB_VARIANT=sx_stamps...) also how long consumer wave 0 and the producer work and wait per round).
     python tools/strip_trace.py <shape> [tile_mode, default 5]"""
 import sys, os
 import numpy as np
@@ -21,6 +22,9 @@ print(name, n, "nodes; level widths", np.diff(sh["level_offsets"].astype(np.int6
 print("plan", ctx.debug_tile_plan(), "MI_STRIP_W", os.environ.get("MI_STRIP_W"))
 rounds, cone, total = ctx.debug_strip_plan()
 ns = len(rounds)
+if not ns:
+    print("the plan has no strips")
+    sys.exit(0)
 print(f"{ns} strips, {total} rounds in the table ({n / max(1, 64 * total):.3f} of the lanes carry a row); rounds per strip p10 {np.percentile(rounds, 10):.0f} p50 {np.median(rounds):.0f} "
       f"max {rounds.max()}; cone rounds per strip mean {cone.mean():.1f} max {cone.max()}")
 roots = np.nonzero(sh["parent"] == W.NO_PARENT)[0].astype(np.uint32)
@@ -48,14 +52,8 @@ rel = (t[ok] - t0) * 0.01
 life = rel[:, 7] - rel[:, 0]
 print(f"span: first start {rel[:, 0].min():.2f} us, last start {rel[:, 0].max():.2f}, p50 start {np.median(rel[:, 0]):.2f}; last drain {rel[:, 7].max():.2f}; "
       f"strip life p10 {np.percentile(life, 10):.2f} p50 {np.median(life):.2f} p90 {np.percentile(life, 90):.2f} max {life.max():.2f}")
-ph = {"flags/desc": rel[:, 1] - rel[:, 0], "first batch asked": rel[:, 2] - rel[:, 1], "cone": rel[:, 3] - rel[:, 2], "own rounds": rel[:, 4] - rel[:, 3], "drain": rel[:, 7] - rel[:, 4]}
-print("phases mean: " + ", ".join(f"{k} {v.mean():.2f}" for k, v in ph.items()))
 r_ok = rounds[ok].astype(np.float64)
-print(f"us per round (life / rounds): p10 {np.percentile(life / r_ok, 10):.3f} p50 {np.median(life / r_ok):.3f} p90 {np.percentile(life / r_ok, 90):.3f}")
-c_ok = cone[ok].astype(np.float64)
-m = c_ok > 0
-if m.any():
-    print(f"us per cone round: p50 {np.median(ph['cone'][m] / c_ok[m]):.3f}; us per own round: p50 {np.median(ph['own rounds'] / np.maximum(1, r_ok - c_ok)):.3f}")
+print(f"table copied and flags tested: mean {np.mean(rel[:, 1] - rel[:, 0]):.2f} us; us per round (life / rounds): p10 {np.percentile(life / r_ok, 10):.3f} p50 {np.median(life / r_ok):.3f} p90 {np.percentile(life / r_ok, 90):.3f}")
 if os.environ.get("MI_LIB_VARIANT", "").startswith("sx_stamps"):  # (-DMI_EXP_STRIP_STAMPS: slots 2, 3 = consumer wave 0's wait / work, 5, 6 = the producer's; 10 ns ticks)
     tt = t[ok].astype(np.float64) * 0.01
     for nm, col in (("consumer wait at the barrier", 2), ("consumer work", 3), ("producer wait at the barrier", 5), ("producer work", 6)):

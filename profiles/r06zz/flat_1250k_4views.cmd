@@ -1,0 +1,1 @@
+python bench.py --workload flat --entities 1250000 --views 4 --steps 50 --warmup 10 --blocks 4 --no-cpu-baseline --no-other-workloads --no-end-to-end --no-live-traffic

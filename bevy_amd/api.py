@@ -206,7 +206,7 @@ ABI_SYMBOLS = [
 # include/bevy_mi355x_debug.h: instrumentation and test hooks, exported by the same library, not part of the boundary
 DEBUG_SYMBOLS = [
     "mi_timer_begin", "mi_timer_end", "mi_profile_enable", "mi_profile_filter", "mi_profile_sample", "mi_profile_burst", "mi_profile_read",
-    "mi_profile_kernel_name", "mi_debug_set_tile_mode", "mi_debug_tree_trace", "mi_debug_tile_plan", "mi_debug_tile_groups", "mi_debug_strip_plan", "mi_debug_exchange_times", "mi_debug_logf", "mi_debug_set_sphere_path", "mi_debug_set_row_summary", "mi_debug_set_tree_cull", "mi_debug_set_walk_inrow", "mi_debug_set_chunked_frames", "mi_debug_chunked_counts", "mi_debug_set_tile_pretest", "mi_debug_set_sorted_one_wg_limit", "mi_debug_set_static_cull_order", "mi_debug_static_cull_counts", "mi_debug_cluster_download_unjoined",
+    "mi_profile_kernel_name", "mi_debug_set_tile_mode", "mi_debug_tree_trace", "mi_debug_tile_plan", "mi_debug_tile_groups", "mi_debug_strip_plan", "mi_debug_plan_strips", "mi_debug_exchange_times", "mi_debug_logf", "mi_debug_set_sphere_path", "mi_debug_set_row_summary", "mi_debug_set_tree_cull", "mi_debug_set_walk_inrow", "mi_debug_set_chunked_frames", "mi_debug_chunked_counts", "mi_debug_set_tile_pretest", "mi_debug_set_sorted_one_wg_limit", "mi_debug_set_static_cull_order", "mi_debug_static_cull_counts", "mi_debug_cluster_download_unjoined",
 ]
 
 
@@ -370,6 +370,26 @@ def hierarchy_advice(level_offsets):
     if rc != MI_OK:
         raise MiError(rc, "mi_hierarchy_advice_for")
     return {k: getattr(a, k) for k, _ in HierarchyAdvice._fields_}
+
+
+def debug_plan_strips(parent, level_offsets, width=64):
+    """The strips plan of a hierarchy (mi_debug_plan_strips: host code, no context) -> None when it cannot be planned, else
+    dict(strips: (n, 3) uint32 [first entry, entries | batches << 16 | bit 31, first own level], rounds: (m, 4) uint32
+    [row0, pstart, info, level], bands, snap_rows)."""
+    par, offs = _u32(parent), _u32(level_offsets)
+    counts = np.zeros(4, np.uint32)
+    lib = load_library()
+    rc = lib.mi_debug_plan_strips(len(offs) - 1, _ptr(offs, C.c_uint32), _ptr(par, C.c_uint32), int(width), None, 0, None, 0, _ptr(counts, C.c_uint32))
+    if rc != MI_OK:
+        raise MiError(rc, "mi_debug_plan_strips")
+    if not counts[0]:
+        return None
+    strips, rounds = np.zeros((int(counts[0]), 3), np.uint32), np.zeros((int(counts[1]), 4), np.uint32)
+    rc = lib.mi_debug_plan_strips(len(offs) - 1, _ptr(offs, C.c_uint32), _ptr(par, C.c_uint32), int(width), _ptr(strips, C.c_uint32), len(strips),
+                                  _ptr(rounds, C.c_uint32), len(rounds), _ptr(counts, C.c_uint32))
+    if rc != MI_OK:
+        raise MiError(rc, "mi_debug_plan_strips")
+    return dict(strips=strips, rounds=rounds, bands=int(counts[2]), snap_rows=int(counts[3]))
 
 
 # ---- device context ------------------------------------------------------------------------------

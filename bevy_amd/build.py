@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbevy_mi355x.so")
 SOURCES = ["kernels_flat.hip", "kernels_tree.hip", "kernels_cluster.hip", "kernels_batch.hip", "kernels_sorted.hip", "kernels_cells.hip", "context.cpp", "ctx_hierarchy.cpp", "ctx_exchange.cpp",
            "ctx_batch.cpp", "ctx_cluster.cpp", "host_helpers.cpp"]
-HEADERS = ["kernels.h", "ctx.h", "glam_math.h", "visibility_rule.h", "cluster_walk.h", "cluster_fill.h", "compact_fast.h", os.path.join("..", "..", "include", "bevy_mi355x.h"), os.path.join("..", "..", "include", "bevy_mi355x_debug.h")]
+HEADERS = ["kernels.h", "ctx.h", "glam_math.h", "visibility_rule.h", "cluster_walk.h", "cluster_fill.h", "compact_fast.h", "strip_plan.h", os.path.join("..", "..", "include", "bevy_mi355x.h"), os.path.join("..", "..", "include", "bevy_mi355x_debug.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 # Per-file flags.  -fno-slp-vectorize on the row kernels: the SLP vectorizer pairs their independent f32 multiplies / adds into

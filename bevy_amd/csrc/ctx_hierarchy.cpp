@@ -1,5 +1,6 @@
 // ctx_hierarchy.cpp -- mi_upload_hierarchy: validation of the level-ordered parent array and the subtree-tile plan.
 #include "ctx.h"
+#include "strip_plan.h"
 
 using namespace mi;
 using namespace mi_detail;
@@ -389,165 +390,25 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
         const bool wanted = ctx->tile_mode == 5 || (modes_ok && !ctx->wave_forest && !ctx->narrow && !ctx->by_levels && n <= STRIP_MAX_ROWS &&
                                                     (ctx->groups.size() >= 2 || n_levels >= 16));
         for (size_t wi_ = 0; wi_ < widths.size() && wanted && !ctx->by_levels && n > 0 && n < (1u << 24) && !ctx->strip_plan; ++wi_) {  // (the kernel's 24-bit row offsets)
-            const uint32_t W = widths[wi_];
             const bool last_width = wi_ + 1 == widths.size();
-            auto level_size = [&](uint32_t lv) -> uint64_t { return level_offsets[lv + 1] - level_offsets[lv]; };
-            std::vector<std::pair<uint32_t, uint32_t>> bands;  // [s, e), bottom-up
-            for (uint32_t e = n_levels; e > 0;) {
-                uint32_t s = e - 1;
-                uint64_t widest = level_size(s);
-                while (s > 0) {
-                    const uint64_t w2 = std::max(widest, level_size(s - 1));
-                    if (w2 > (uint64_t)std::max(1u, W / 2u) * std::max<uint64_t>(1, level_size(s - 1))) break;
-                    widest = w2;
-                    --s;
-                }
-                bands.emplace_back(s, e);
-                e = s;
-            }
-            std::vector<StripDesc> strips;
-            std::vector<uint32_t> strip_top;  // first own level of each strip
-            std::vector<StripRound> rounds;
-            struct Region { uint32_t s, lo, hi, e; };
-            std::vector<Region> work;
-            bool too_long = false;
-            // the levels of [a, b) of level s that fit (every level <= W rows), up to e; 0 = the cone of [a, b) is too wide
-            // (`extra`: the rounds beyond one per level -- levels of more than 64 rows -- a strip may have: the launch ends with its longest strip)
-            auto fit_levels = [&](uint32_t s, uint32_t e, uint32_t a, uint32_t b) -> uint32_t {
-                uint32_t plo = a, phi = b, extra = 0;
-                for (uint32_t l = s; l-- > 0;) {
-                    const uint32_t nlo = parent_idx[plo], nhi = parent_idx[phi - 1] + 1u;
-                    if (nhi - nlo > W) return 0;
-                    extra += (nhi - nlo - 1u) / 64u;
-                    plo = nlo;
-                    phi = nhi;
-                }
-                if (extra > max_extra && b - a > 1u) return 0;
-                uint32_t clo = a, chi = b, k = 0;
-                while (s + k < e && chi > clo) {
-                    if (chi - clo > W) return k;
-                    extra += (chi - clo - 1u) / 64u;
-                    if (extra > max_extra && b - a > 1u) return k;
-                    const uint32_t nlo = s + k + 1 < n_levels ? child_begin(s + k, clo) : 0u, nhi = s + k + 1 < n_levels ? child_begin(s + k, chi) : 0u;
-                    clo = nlo;
-                    chi = nhi;
-                    ++k;
-                }
-                return e - s;  // (all of them: the subtree may end earlier)
-            };
-            auto emit_level = [&](uint32_t l, uint32_t lo, uint32_t hi, uint32_t pstart, uint32_t bits) {
-                for (uint32_t r = 0; lo + 64u * r < hi; ++r) {
-                    StripRound rd{};
-                    rd.row0 = lo + 64u * r;
-                    rd.pstart = pstart;
-                    const uint32_t cnt = std::min(64u, hi - rd.row0);
-                    rd.info = cnt | ((64u * r) << 8) | ((l & 1u) ? STRIP_PARITY : 0u) | (l == 0 ? STRIP_ROOT : 0u) | bits;
-                    rd.level = l;
-                    rounds.push_back(rd);
-                }
-            };
-            auto emit = [&](uint32_t s, uint32_t a, uint32_t b, uint32_t n_lv) {
-                std::vector<std::pair<uint32_t, uint32_t>> cone(s);
-                uint32_t plo = a, phi = b;
-                for (uint32_t l = s; l-- > 0;) {
-                    const uint32_t nlo = parent_idx[plo], nhi = parent_idx[phi - 1] + 1u;
-                    cone[l] = {nlo, nhi};
-                    plo = nlo;
-                    phi = nhi;
-                }
-                StripDesc sd{};
-                sd.first_round = (uint32_t)rounds.size();
-                uint32_t prev = 0;
-                for (uint32_t l = 0; l < s; ++l) {
-                    emit_level(l, cone[l].first, cone[l].second, prev, l + 1 == s ? STRIP_ABOVE_TOP : 0u);
-                    prev = cone[l].first;
-                }
-                uint32_t clo = a, chi = b;
-                for (uint32_t k = 0; k < n_lv && chi > clo; ++k) {
-                    emit_level(s + k, clo, chi, prev, STRIP_OWNED);
-                    prev = clo;
-                    const uint32_t nlo = s + k + 1 < n_levels ? child_begin(s + k, clo) : 0u, nhi = s + k + 1 < n_levels ? child_begin(s + k, chi) : 0u;
-                    clo = nlo;
-                    chi = nhi;
-                }
-                // batches: a round of more than 16 rows is a batch of its own; up to four consecutive narrow levels of the same kind
-                // (cone / own) share one -- the producer stages them together, one consumer wave walks them back to back
-                uint32_t n_batches = 0;
-                for (size_t r0 = sd.first_round; r0 < rounds.size();) {
-                    size_t r1 = r0 + 1;
-                    if ((rounds[r0].info & 0x7Fu) <= 16u && narrow_batches)
-                        while (r1 < rounds.size() && r1 - r0 < 4 && (rounds[r1].info & 0x7Fu) <= 16u &&
-                               ((rounds[r1].info ^ rounds[r0].info) & STRIP_OWNED) == 0u && ((rounds[r1].info >> 8) & 0xFFu) == 0u)
-                            ++r1;
-                    rounds[r0].info |= (uint32_t)(r1 - r0) << STRIP_BATCH_SHIFT;
-                    ++n_batches;
-                    r0 = r1;
-                }
-                if (n_batches & 1u) {  // (an even number of batches: the kernel's loops turn twice per iteration)
-                    StripRound pad{};
-                    pad.info = 1u << STRIP_BATCH_SHIFT;
-                    rounds.push_back(pad);
-                    ++n_batches;
-                }
-                sd.n_rounds = (uint32_t)(rounds.size() - sd.first_round);
-                if (sd.n_rounds + 8u > STRIP_TAB_CAP || n_batches > 0xFFu) too_long = true;  // (a hierarchy of more levels than a strip's table holds: the tiles)
-                sd.n_rounds |= n_batches << 16;
-                strips.push_back(sd);
-                strip_top.push_back(s);
-            };
-            bool ok = true;
-            for (auto& bd : bands) work.push_back({bd.first, level_offsets[bd.first], level_offsets[bd.first + 1], bd.second});
-            for (size_t wi = 0; wi < work.size() && ok; ++wi) {  // (regions handed down are appended behind)
-                const Region rg = work[wi];
-                uint32_t a = rg.lo;
-                while (a < rg.hi) {
-                    uint32_t b = a + 1;
-                    uint32_t lv = fit_levels(rg.s, rg.e, a, b);  // (>= 1: one row, a cone of one row per level)
-                    if (lv == 0) { ok = false; break; }
-                    if (lv < rg.e - rg.s) {
-                        // the row's own subtree outgrows the width at level s + lv: keep the levels above, hand the rest down
-                        uint32_t clo = a, chi = b;
-                        for (uint32_t k = 0; k < lv; ++k) {
-                            const uint32_t nlo = child_begin(rg.s + k, clo), nhi = child_begin(rg.s + k, chi);
-                            clo = nlo;
-                            chi = nhi;
-                        }
-                        if (chi > clo) work.push_back({rg.s + lv, clo, chi, rg.e});
-                    } else {
-                        uint32_t step = 1;
-                        while (b < rg.hi) {  // galloping extension while everything still fits
-                            const uint32_t nb = (uint32_t)std::min<uint64_t>((uint64_t)b + step, rg.hi);
-                            if (fit_levels(rg.s, rg.e, a, nb) == rg.e - rg.s) { b = nb; step *= 2; }
-                            else if (step > 1) step = 1;
-                            else break;
-                        }
-                    }
-                    emit(rg.s, a, b, lv);
-                    a = b;
-                }
-                if (rounds.size() > (size_t)64 * n + (1u << 20)) ok = false;  // (cones out of all proportion: a hierarchy for the tiles)
-            }
-            if (ok && !too_long && !strips.empty() && (last_width || strips.size() <= resident)) {
-                for (uint32_t i = 0; i < 8u; ++i) rounds.push_back(StripRound{});  // (the producer reads up to six entries past a strip's last round)
-                uint32_t snap_level = 0;
-                for (uint32_t s : strip_top) snap_level = std::max(snap_level, s);
-                const uint32_t strip_snap_rows = level_offsets[snap_level];  // every cone row lies above the deepest first level
-                for (size_t i = 0; i < strips.size(); ++i)
-                    if (level_offsets[strip_top[i]] < strip_snap_rows) strips[i].n_rounds |= 0x80000000u;
-                if ((rc = ensure(ctx, ctx->strips, strips.size() * sizeof(StripDesc)))) return rc;
-                if ((rc = upload(ctx, ctx->strips.p, strips.data(), strips.size() * sizeof(StripDesc)))) return rc;
-                if ((rc = ensure(ctx, ctx->strip_rounds, rounds.size() * sizeof(StripRound)))) return rc;
-                if ((rc = upload(ctx, ctx->strip_rounds.p, rounds.data(), rounds.size() * sizeof(StripRound)))) return rc;
-                ctx->strip_plan = true;
-                if (ctx->tile_mode == 5) ctx->narrow = ctx->wave_forest = false;  // (the test mode: strips whatever else would take the hierarchy)
-                ctx->n_strips = (uint32_t)strips.size();
-                ctx->n_strip_rounds = (uint32_t)rounds.size();
-                ctx->strip_bands = (uint32_t)bands.size();
-                // the snapshot the cones read: the strips' own prefix (the tile plan's chain tiles do not run)
-                ctx->snap_rows = strip_snap_rows;
-                ctx->snap_valid = false;
-                if (ctx->snap_rows && (rc = ensure(ctx, ctx->snap, 2 * (size_t)ctx->snap_rows * 48))) return rc;
-            }
+            StripPlan sp;
+            if (!plan_strips(n, n_levels, level_offsets, parent_idx, first_child.data(), widths[wi_], narrow_batches, max_extra, sp)) continue;
+            if (!last_width && sp.strips.size() > resident) continue;
+            if ((rc = ensure(ctx, ctx->strips, sp.strips.size() * sizeof(StripDesc)))) return rc;
+            if ((rc = upload(ctx, ctx->strips.p, sp.strips.data(), sp.strips.size() * sizeof(StripDesc)))) return rc;
+            if ((rc = ensure(ctx, ctx->strip_rounds, sp.rounds.size() * sizeof(StripRound)))) return rc;
+            if ((rc = upload(ctx, ctx->strip_rounds.p, sp.rounds.data(), sp.rounds.size() * sizeof(StripRound)))) return rc;
+            if ((rc = ensure(ctx, ctx->strip_cone_flags, sp.cone_flags.size()))) return rc;
+            if ((rc = upload(ctx, ctx->strip_cone_flags.p, sp.cone_flags.data(), sp.cone_flags.size()))) return rc;
+            ctx->strip_plan = true;
+            if (ctx->tile_mode == 5) ctx->narrow = ctx->wave_forest = false;  // (the test mode: strips whatever else would take the hierarchy)
+            ctx->n_strips = (uint32_t)sp.strips.size();
+            ctx->n_strip_rounds = (uint32_t)sp.rounds.size();
+            ctx->strip_bands = sp.n_bands;
+            // the snapshot the cones read: the strips' own prefix (the tile plan's chain tiles do not run)
+            ctx->snap_rows = sp.snap_rows;
+            ctx->snap_valid = false;
+            if (ctx->snap_rows && (rc = ensure(ctx, ctx->snap, 2 * (size_t)ctx->snap_rows * 48))) return rc;
         }
     }
     ctx->have_hierarchy = true;

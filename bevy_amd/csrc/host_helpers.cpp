@@ -11,6 +11,8 @@
 #include "../../include/bevy_mi355x.h"
 #include "glam_math.h"
 #include "kernels.h"  // TILE_MAX_LEVELS: mi_hierarchy_advice_for asks the planner's question
+#include "strip_plan.h"
+#include "../../include/bevy_mi355x_debug.h"
 
 using namespace mi;
 
@@ -354,6 +356,56 @@ int32_t mi_cluster_view_build(const float camera_affine[12], const float clip_fr
 
 // Level (BFS) order of an arbitrary ChildOf array -- replaces the Children Vec<Entity> pointer chase
 // (crates/bevy_ecs/src/hierarchy.rs:107,152) with contiguous per-level ranges.
+// test hook (bevy_mi355x_debug.h): the strips plan of a hierarchy as mi_upload_hierarchy would make it at `width` rows to a level -- host
+// code only, no device, no context (tests/test_strip_plan.py walks the plan on the CPU).  out_counts = {strips, table entries, bands,
+// snapshot rows}; all zero when the hierarchy cannot be planned.  out_strips: 3 words per strip (first entry, the StripDesc word, first
+// own level); out_rounds: 4 words per entry (StripRound).
+int32_t mi_debug_plan_strips(uint32_t n_levels, const uint32_t* level_offsets, const uint32_t* parent_idx, uint32_t width, uint32_t* out_strips,
+                             uint32_t cap_strips, uint32_t* out_rounds, uint32_t cap_rounds, uint32_t* out_counts) {
+    if (!out_counts || !n_levels || !level_offsets || !parent_idx) return MI_ERR_INVALID_ARG;
+    const uint32_t n = level_offsets[n_levels];
+    out_counts[0] = out_counts[1] = out_counts[2] = out_counts[3] = 0;
+    for (uint32_t l = 0; l < n_levels; ++l)
+        if (level_offsets[l + 1] < level_offsets[l]) return MI_ERR_MALFORMED_HIERARCHY;
+    // rows of a level ordered by parent, parents in the level above (what mi_upload_hierarchy checks)
+    for (uint32_t l = 1; l < n_levels; ++l) {
+        uint32_t prev = level_offsets[l - 1];
+        for (uint32_t i = level_offsets[l]; i < level_offsets[l + 1]; ++i) {
+            const uint32_t p = parent_idx[i];
+            if (p < level_offsets[l - 1] || p >= level_offsets[l] || p < prev) return MI_ERR_MALFORMED_HIERARCHY;
+            prev = p;
+        }
+    }
+    std::vector<uint32_t> first_child((size_t)n + 1, 0);
+    for (uint32_t l = 0; l + 1 < n_levels; ++l) {
+        uint32_t ch = level_offsets[l + 1];
+        const uint32_t chi = level_offsets[l + 2];
+        for (uint32_t p = level_offsets[l]; p < level_offsets[l + 1]; ++p) {
+            first_child[p] = ch;
+            while (ch < chi && parent_idx[ch] == p) ++ch;
+        }
+    }
+    for (uint32_t p = level_offsets[n_levels - 1]; p <= n; ++p) first_child[p] = n;
+    StripPlan sp;
+    if (!plan_strips(n, n_levels, level_offsets, parent_idx, first_child.data(), width, true, 1000u, sp)) return MI_OK;
+    out_counts[0] = (uint32_t)sp.strips.size();
+    out_counts[1] = (uint32_t)sp.rounds.size();
+    out_counts[2] = sp.n_bands;
+    out_counts[3] = sp.snap_rows;
+    for (size_t i = 0; out_strips && i < sp.strips.size() && i < cap_strips; ++i) {
+        out_strips[3 * i] = sp.strips[i].first_round;
+        out_strips[3 * i + 1] = sp.strips[i].n_rounds;
+        out_strips[3 * i + 2] = sp.strip_top[i];
+    }
+    for (size_t i = 0; out_rounds && i < sp.rounds.size() && i < cap_rounds; ++i) {
+        out_rounds[4 * i] = sp.rounds[i].row0;
+        out_rounds[4 * i + 1] = sp.rounds[i].pstart;
+        out_rounds[4 * i + 2] = sp.rounds[i].info;
+        out_rounds[4 * i + 3] = sp.rounds[i].level;
+    }
+    return MI_OK;
+}
+
 // (the rule mi_upload_hierarchy applies -- ctx_hierarchy.cpp: ctx->narrow -- as a question the host can ask before it uploads anything)
 int32_t mi_hierarchy_advice_for(uint32_t n_levels, const uint32_t* level_offsets, mi_hierarchy_advice* out) {
     if (!out || (n_levels && !level_offsets)) return MI_ERR_INVALID_ARG;

@@ -1379,6 +1379,7 @@ struct StripIn {
     float4 o0, o1, o2;  // the old GlobalTransform as it was loaded (whole register quads: what the loop carries is what the loads wrote)
     NodeRaw raw;
     uint32_t row, pstart, info;  // of the lane's table entry
+    uint32_t snap;               // the row is mirrored into the snapshot (some strip's cone holds it)
 };
 // A strip's workgroup: four CONSUMER waves and a PRODUCER wave.  What a level costs its strip is the instructions a wave has to issue for
 // it, 2 - 3.5 ns apiece (tools/probes/issue_rate_probe.hip: a dependent v_fma 3.5 ns, an independent one 2.1, a dependent LDS read 25, an LDS
@@ -1393,7 +1394,7 @@ struct StripIn {
 struct StripStage {
     float4 local[2][64 * 3];  // From(Transform)
     float4 old[2][64 * 3];    // the GlobalTransform before this frame (the cone's rows: from the snapshot)
-    uint32_t pin[2][64];      // bits 0-7 the parent's slot in the level above; bit 8 TransformTreeChanged, bit 9 the level-0 assignment happens
+    uint32_t pin[2][64];      // bits 0-7 the parent's slot in the level above; bit 8 TransformTreeChanged, bit 9 the level-0 assignment happens, bit 10 mirrored into the snapshot
 };
 #ifdef MI_EXP_STRIP_STAMPS  // (timing build: how long a wave works between two barriers and how long it waits at them)
 #define STRIP_BARRIER()                               \
@@ -1511,6 +1512,10 @@ __global__ void __launch_bounds__(STRIP_THREADS, 7) k_propagate_strips(Columns c
             f.o1 = at32<float4>(old_src, r48 + 16u);
             f.o2 = at32<float4>(old_src, r48 + 32u);
             f.raw = node_raw<ALL_DIRTY>(a, row, true);
+            // (absent flags: the whole snapshot prefix; read through a stand-in so that there is no branch around the load)
+            const uint8_t* const cf = reinterpret_cast<const uint8_t*>(a.chains);
+            const uint32_t cfv = at32<uint8_t>(cf ? cf : reinterpret_cast<const uint8_t*>(a.parent_idx), row);
+            f.snap = snap_owner && row < a.snap_rows && (cf ? cfv != 0u : true) ? 1u : 0u;
             return f;
         };
         auto stage = [&](const StripIn& in, uint32_t sl) {
@@ -1522,7 +1527,7 @@ __global__ void __launch_bounds__(STRIP_THREADS, 7) k_propagate_strips(Columns c
             uint32_t ps = in.par - in.pstart;  // the parent's slot in the level above (whatever a root reads there is ignored)
             ps = ps < STRIP_W_CAP ? ps : STRIP_W_CAP - 1u;
             const NodeIn nin = node_inputs_raw(a, in.row, root_level, in.raw);
-            st.pin[sl][lane] = ps | (nin.tree_changed ? 0x100u : 0u) | (nin.root_write ? 0x200u : 0u);
+            st.pin[sl][lane] = ps | (nin.tree_changed ? 0x100u : 0u) | (nin.root_write ? 0x200u : 0u) | (in.snap ? 0x400u : 0u);
         };
         // the next batch to ask for: its first entry and header (kept inside the table: J + 8 entries are there)
         uint32_t pf = 0, hf = header(0);
@@ -1603,7 +1608,7 @@ __global__ void __launch_bounds__(STRIP_THREADS, 7) k_propagate_strips(Columns c
                 const uint32_t goff = __umul24(row, 48u) + cc3 * 4u;
                 if (q_cc == 0u) at32w<uint8_t>(a.g_changed_bytes, row) = chg ? 1 : 0;
                 if (chg) at32w<F3>(c.global, goff) = F3{cur_c.x, cur_c.y, cur_c.z};
-                if (snap_owner && row < a.snap_rows) at32w<F3>(a.snap_write, goff) = F3{cur_c.x, cur_c.y, cur_c.z};
+                if (in.pin & 0x400u) at32w<F3>(a.snap_write, goff) = F3{cur_c.x, cur_c.y, cur_c.z};
             }
         }
     };
@@ -1868,7 +1873,8 @@ hipError_t launch_propagate_wave_tiles(const Columns& c, const uint32_t* parent_
 
 hipError_t launch_propagate_strips(const Columns& c, const uint32_t* parent_idx, const StripDesc* d_strips, const StripRound* d_rounds, uint32_t n_strips,
                                    const uint8_t* node_flags, const uint8_t* changed, const uint8_t* tree_bytes, uint8_t* g_changed_bytes, const float* snap_read,
-                                   float* snap_write, uint32_t snap_rows, bool all_dirty, bool static_opt, bool pretest, hipStream_t stream, unsigned long long* trace) {
+                                   float* snap_write, uint32_t snap_rows, bool all_dirty, bool static_opt, bool pretest, hipStream_t stream, unsigned long long* trace,
+                                   const uint8_t* cone_flags) {
     if (n_strips == 0) return hipSuccess;
     TreeArgs a{};
     a.pretest = pretest && changed && tree_bytes ? 1u : 0u;
@@ -1884,6 +1890,9 @@ hipError_t launch_propagate_strips(const Columns& c, const uint32_t* parent_idx,
     a.all_dirty = all_dirty ? 1u : 0u;
     a.static_opt = static_opt ? 1u : 0u;
     a.trace = trace;
+    // (TreeArgs::chains is the chain tiles' table; the strips have none and carry their per-row snapshot flags there -- a field more would
+    // be a kernel argument more in every tile kernel.  Without flags: every row of the snapshot prefix.)
+    a.chains = reinterpret_cast<const uint32_t*>(snap_write ? cone_flags : nullptr);
     if (all_dirty) MI_LAUNCH((k_propagate_strips<true>), dim3(n_strips), dim3(STRIP_THREADS), 0, stream, c, a, d_strips, d_rounds);
     else MI_LAUNCH((k_propagate_strips<false>), dim3(n_strips), dim3(STRIP_THREADS), 0, stream, c, a, d_strips, d_rounds);
     return hipGetLastError();

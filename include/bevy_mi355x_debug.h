@@ -45,6 +45,14 @@ int32_t mi_debug_tree_trace(mi_ctx* ctx, int32_t enable, unsigned long long* out
 int32_t mi_debug_exchange_times(mi_ctx* ctx, double* out5, int32_t reset);
 /* The shape of the current tile plan: launches per mi_propagate, tiles, chain tiles (self-evaluated ancestor chains), bands. */
 int32_t mi_debug_tile_plan(mi_ctx* ctx, uint32_t* out_launches, uint32_t* out_tiles, uint32_t* out_chain_tiles, uint32_t* out_bands);
+/* The strips plan of a hierarchy as mi_upload_hierarchy would make it at `width` (1 .. 128) rows to a level: host code only -- no device,
+ * no context.  out_counts = {strips, table entries, bands, snapshot rows} (all zero: cannot be planned); out_strips: 3 words per strip
+ * (first table entry; entries | batches << 16 | owns-snapshot-rows << 31; first own level); out_rounds: 4 words per entry (first row;
+ * first row of the strip's range in the level above; rows | first LDS slot << 8 | flags from bit 16: level parity, own, forest root,
+ * -, directly above the own rows, -, entries of the batch << 22; level).  A strip lists the cone of its rows' ancestors, level 0
+ * downwards, then the rows it owns. */
+int32_t mi_debug_plan_strips(uint32_t n_levels, const uint32_t* level_offsets, const uint32_t* parent_idx, uint32_t width, uint32_t* out_strips,
+                             uint32_t cap_strips, uint32_t* out_rounds, uint32_t cap_rounds, uint32_t* out_counts);
 /* The strips of the current plan (kernels.h: one launch of independent waves): rounds and cone rounds per strip, the strip count and the
  * rounds of the whole table (0 when the plan has no strips). */
 int32_t mi_debug_strip_plan(mi_ctx* ctx, uint32_t* out_rounds, uint32_t* out_cone_rounds, uint32_t cap, uint32_t* out_n, uint32_t* out_total_rounds);

@@ -58,3 +58,13 @@ if os.environ.get("MI_LIB_VARIANT", "").startswith("sx_stamps"):  # (-DMI_EXP_ST
     tt = t[ok].astype(np.float64) * 0.01
     for nm, col in (("consumer wait at the barrier", 2), ("consumer work", 3), ("producer wait at the barrier", 5), ("producer work", 6)):
         print(f"{nm}: per strip p50 {np.median(tt[:, col]):.2f} us, per round p50 {np.median(tt[:, col] / r_ok):.3f}")
+if os.environ.get("STRIP_TRACE_SLOWEST"):
+    idx = np.nonzero(ok)[0]
+    order = np.argsort(-life)[:12]
+    print("slowest strips: index, start us, life us, table entries, cone entries")
+    for o in order:
+        print(f"  {idx[o]:5d} {rel[o, 0]:6.2f} {life[o]:6.2f} {rounds[idx[o]]:3d} {cone[idx[o]]:3d}")
+    for lo, hi in ((0, 25), (25, 50), (50, 75), (75, 100)):
+        sel = (life >= np.percentile(life, lo)) & (life <= np.percentile(life, hi))
+        print(f"  life quartile {lo}-{hi}: life {life[sel].mean():.2f}, entries {rounds[idx[sel]].mean():.1f}, cone {cone[idx[sel]].mean():.1f}")
+    print(f"  corr(life, entries) {np.corrcoef(life, rounds[idx])[0, 1]:.2f}, corr(life, cone) {np.corrcoef(life, cone[idx])[0, 1]:.2f}, corr(life, strip index) {np.corrcoef(life, idx)[0, 1]:.2f}")

@@ -1011,7 +1011,7 @@ int32_t mi_ctx_destroy(mi_ctx* ctx) {
                     ctx->bt_kind, ctx->bt_cpu_bin, ctx->bt_bucket};
     for (void* p : cols)
         if (p) hipFree(p);
-    DevBuf* bufs[] = {&ctx->sph, &ctx->row_sum, &ctx->anc, &ctx->order, &ctx->chains, &ctx->snap, &ctx->tree_trace, &ctx->inh_bits, &ctx->sparse_cnt, &ctx->sparse_rows, &ctx->sparse_total, &ctx->sparse_g, &ctx->g_pre, &ctx->parent_idx, &ctx->node_flags, &ctx->tiles, &ctx->wtiles, &ctx->strips, &ctx->strip_rounds, &ctx->strip_cone_flags, &ctx->level_offs_dev, &ctx->views,
+    DevBuf* bufs[] = {&ctx->sph, &ctx->row_sum, &ctx->anc, &ctx->order, &ctx->chains, &ctx->snap, &ctx->tree_trace, &ctx->inh_bits, &ctx->sparse_cnt, &ctx->sparse_rows, &ctx->sparse_total, &ctx->sparse_g, &ctx->g_pre, &ctx->parent_idx, &ctx->node_flags, &ctx->tiles, &ctx->wtiles, &ctx->strips, &ctx->strip_rounds, &ctx->level_offs_dev, &ctx->views,
                       &ctx->block_counts, &ctx->seg_bases, &ctx->out_keys, &ctx->cl_pos,
                       &ctx->cl_type, &ctx->cl_layers, &ctx->cl_layers_hi, &ctx->cl_dir, &ctx->cl_sincos, &ctx->cl_planes, &ctx->cl_spheres,
                       &ctx->bt_set_indexed, &ctx->bt_table_off, &ctx->bt_table, &ctx->bt_meta_off, &ctx->bt_meta, &ctx->bt_rows_a, &ctx->bt_rows_b,
@@ -1732,7 +1732,7 @@ int32_t mi_propagate(mi_ctx* ctx, uint32_t flags) {
                                                             ctx->changed_rows_hint * 16 <= ctx->n_strips);
         HIP_TRY(ctx, launch_propagate_strips(c, (const uint32_t*)ctx->parent_idx.p, (const StripDesc*)ctx->strips.p, (const StripRound*)ctx->strip_rounds.p, ctx->n_strips,
                                              (const uint8_t*)ctx->node_flags.p, ctx->changed, tree_bits, ctx->g_changed_bytes, snap_r, snap_w, ctx->snap_rows, all_dirty,
-                                             static_opt, pretest, ctx->stream, (unsigned long long*)ctx->tree_trace.p, (const uint8_t*)ctx->strip_cone_flags.p));
+                                             static_opt, pretest, ctx->stream, (unsigned long long*)ctx->tree_trace.p));
         ctx->g_chg_in_bytes = true;
     } else if (ctx->wave_forest && !ctx->by_levels) {
         // a forest of small trees: a wave per tile, one launch (ctx_hierarchy.cpp).  No chain tiles, so nothing reads or keeps the

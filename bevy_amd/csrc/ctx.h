@@ -98,7 +98,6 @@ struct mi_ctx {
     bool strip_plan = false;        // the hierarchy is walked by strips: one launch of independent waves (k_propagate_strips)
     uint32_t n_strips = 0, n_strip_rounds = 0, strip_bands = 0;
     DevBuf strips, strip_rounds;    // StripDesc per strip, the flat table of StripRound
-    DevBuf strip_cone_flags;        // per row: some strip's cone holds it (its owner mirrors it into the snapshot)
     bool by_levels = false;         // the row count overflows the tile kernel's 32-bit offsets (or mi_debug_set_tile_mode(1)): mi_propagate sweeps level by level
     DevBuf anc;                     // the ancestor table (kernels.h, ANC_DEPTH): built by mi_upload_hierarchy; in use while anc_valid
     bool anc_valid = false;

@@ -398,8 +398,9 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
             if ((rc = upload(ctx, ctx->strips.p, sp.strips.data(), sp.strips.size() * sizeof(StripDesc)))) return rc;
             if ((rc = ensure(ctx, ctx->strip_rounds, sp.rounds.size() * sizeof(StripRound)))) return rc;
             if ((rc = upload(ctx, ctx->strip_rounds.p, sp.rounds.data(), sp.rounds.size() * sizeof(StripRound)))) return rc;
-            if ((rc = ensure(ctx, ctx->strip_cone_flags, sp.cone_flags.size()))) return rc;
-            if ((rc = upload(ctx, ctx->strip_cone_flags.p, sp.cone_flags.data(), sp.cone_flags.size()))) return rc;
+            // node_flags bit 1: some strip's cone holds the row (its owner mirrors it into the snapshot the cones read)
+            for (uint32_t r = 0; r < n; ++r) nflags[r] = (uint8_t)((nflags[r] & 1u) | (sp.cone_flags[r] ? 2u : 0u));
+            if ((rc = upload(ctx, ctx->node_flags.p, nflags.data(), n))) return rc;
             ctx->strip_plan = true;
             if (ctx->tile_mode == 5) ctx->narrow = ctx->wave_forest = false;  // (the test mode: strips whatever else would take the hierarchy)
             ctx->n_strips = (uint32_t)sp.strips.size();

@@ -541,7 +541,7 @@ struct StripDesc {
 hipError_t launch_propagate_strips(const Columns& c, const uint32_t* parent_idx, const StripDesc* d_strips, const StripRound* d_rounds, uint32_t n_strips,
                                    const uint8_t* node_flags, const uint8_t* changed, const uint8_t* tree_bytes, uint8_t* g_changed_bytes, const float* snap_read,
                                    float* snap_write, uint32_t snap_rows, bool all_dirty, bool static_opt, bool pretest, hipStream_t stream,
-                                   unsigned long long* trace = nullptr, const uint8_t* cone_flags = nullptr /* per row: mirrored into the snapshot */);
+                                   unsigned long long* trace = nullptr);
 hipError_t launch_propagate_tiles(const Columns& c, const uint32_t* parent_idx, const TileDesc* d_tiles, const uint32_t* d_chains,
                                   uint32_t n_tiles, const uint8_t* node_flags, const uint8_t* changed, const uint8_t* tree_bytes,
                                   uint8_t* g_changed_bytes, const float* snap_read, float* snap_write, uint32_t snap_rows, bool all_dirty,

@@ -179,7 +179,7 @@ constexpr uint32_t TREE_NT_MIN_ROWS = 4u << 20;
 struct TreeArgs {
     const uint32_t* parent_idx;
     const TileDesc* tiles;
-    const uint8_t* node_flags;  // bit0 = has children (only level-0 rows consult it)
+    const uint8_t* node_flags;  // bit0 = has children (only level-0 rows consult it); bit1 = some strip's cone holds the row (its owner mirrors it into the snapshot)
     const uint8_t* changed;     // per-row Changed<Transform>|Added<GlobalTransform> byte, nullptr = all
     const uint8_t* tree_bytes;  // TransformTreeChanged, a byte per row, nullptr = all changed
     uint8_t* g_changed_bytes;   // out: GlobalTransform change tick bumped
@@ -1378,8 +1378,6 @@ struct StripIn {
     uint32_t par;
     float4 o0, o1, o2;  // the old GlobalTransform as it was loaded (whole register quads: what the loop carries is what the loads wrote)
     NodeRaw raw;
-    uint32_t row, pstart, info;  // of the lane's table entry
-    uint32_t snap;               // the row is mirrored into the snapshot (some strip's cone holds it)
 };
 // A strip's workgroup: four CONSUMER waves and a PRODUCER wave.  What a level costs its strip is the instructions a wave has to issue for
 // it, 2 - 3.5 ns apiece (tools/probes/issue_rate_probe.hip: a dependent v_fma 3.5 ns, an independent one 2.1, a dependent LDS read 25, an LDS
@@ -1483,8 +1481,12 @@ __global__ void __launch_bounds__(STRIP_THREADS, 7) k_propagate_strips(Columns c
         // word, each offset of the rotation through an empty asm statement so that the loads are not merged back: a merged load lands in
         // a register pair / triple / quad which the loop-carried copy of the ring cannot always be allocated on top of -- the moves that
         // remained at the loop's end waited for every load in flight but the last four.)
-        auto fetch = [&](uint32_t i, uint32_t info0) {
-            StripIn f;
+        // the lane's table entry of the batch that starts at entry i: its row, the first row of the level above, its flags (zero rows
+        // for a lane without a row)
+        struct Mine {
+            uint32_t row, pstart, info;
+        };
+        auto mine = [&](uint32_t i, uint32_t info0) {
             const uint32_t cnt = batch_entries(info0);
             const bool wide = (info0 & 0x7Fu) > 16u;
             const uint32_t sub_raw = lane >> 4;
@@ -1492,10 +1494,13 @@ __global__ void __launch_bounds__(STRIP_THREADS, 7) k_propagate_strips(Columns c
             const uint4 ev = tab[i + sub];
             const uint32_t jrow = wide ? lane : (lane & 15u);
             const bool on = jrow < (ev.z & 0x7Fu) && (wide || sub_raw < cnt);
-            const uint32_t row = ev.x + (on ? jrow : 0u);
-            f.row = row;
-            f.pstart = ev.y;
-            f.info = on ? ev.z : (ev.z & ~0x7Fu);  // (a lane without a row: zero rows)
+            return Mine{ev.x + (on ? jrow : 0u), ev.y, on ? ev.z : (ev.z & ~0x7Fu)};
+        };
+        // (what the loop carries is what the loads wrote, nothing derived from them: a value computed from a load would be waited for
+        // at the loop's end)
+        auto fetch = [&](uint32_t i, uint32_t info0) {
+            StripIn f;
+            const uint32_t row = mine(i, info0).row;
             const float* const old_src = (info0 & STRIP_OWNED) ? c.global : a.snap_read;  // (uniform: a batch is cone or own, never both)
             const uint32_t r12 = __umul24(row, 12u), r48 = __umul24(row, 48u);  // (rows of a hierarchy that takes strips are below 2^24)
             f.t = V3{at32<float>(c.translation, r12), at32<float>(c.translation, r12 + 4u), at32<float>(c.translation, r12 + 8u)};
@@ -1512,22 +1517,20 @@ __global__ void __launch_bounds__(STRIP_THREADS, 7) k_propagate_strips(Columns c
             f.o1 = at32<float4>(old_src, r48 + 16u);
             f.o2 = at32<float4>(old_src, r48 + 32u);
             f.raw = node_raw<ALL_DIRTY>(a, row, true);
-            // (absent flags: the whole snapshot prefix; read through a stand-in so that there is no branch around the load)
-            const uint8_t* const cf = reinterpret_cast<const uint8_t*>(a.chains);
-            const uint32_t cfv = at32<uint8_t>(cf ? cf : reinterpret_cast<const uint8_t*>(a.parent_idx), row);
-            f.snap = snap_owner && row < a.snap_rows && (cf ? cfv != 0u : true) ? 1u : 0u;
             return f;
         };
-        auto stage = [&](const StripIn& in, uint32_t sl) {
-            const bool root_level = (in.info & STRIP_ROOT) != 0u;
+        auto stage = [&](const StripIn& in, uint32_t i, uint32_t info0, uint32_t sl) {
+            const Mine m = mine(i, info0);
+            const bool root_level = (m.info & STRIP_ROOT) != 0u;
             lds_put(st.local[sl], lane, affine_from_srt(in.s, V4{in.q.x, in.q.y, in.q.z, in.q.w}, in.t));
             st.old[sl][lane * 3u] = in.o0;
             st.old[sl][lane * 3u + 1u] = in.o1;
             st.old[sl][lane * 3u + 2u] = in.o2;
-            uint32_t ps = in.par - in.pstart;  // the parent's slot in the level above (whatever a root reads there is ignored)
+            uint32_t ps = in.par - m.pstart;  // the parent's slot in the level above (whatever a root reads there is ignored)
             ps = ps < STRIP_W_CAP ? ps : STRIP_W_CAP - 1u;
-            const NodeIn nin = node_inputs_raw(a, in.row, root_level, in.raw);
-            st.pin[sl][lane] = ps | (nin.tree_changed ? 0x100u : 0u) | (nin.root_write ? 0x200u : 0u) | (in.snap ? 0x400u : 0u);
+            const NodeIn nin = node_inputs_raw(a, m.row, root_level, in.raw);
+            const bool snap = snap_owner && (in.raw.nflag & 2u) != 0u;  // (node_flags bit 1: some strip's cone holds the row -- its owner mirrors it into the snapshot)
+            st.pin[sl][lane] = ps | (nin.tree_changed ? 0x100u : 0u) | (nin.root_write ? 0x200u : 0u) | (snap ? 0x400u : 0u);
         };
         // the next batch to ask for: its first entry and header (kept inside the table: J + 8 entries are there)
         uint32_t pf = 0, hf = header(0);
@@ -1536,18 +1539,22 @@ __global__ void __launch_bounds__(STRIP_THREADS, 7) k_propagate_strips(Columns c
             pf = pf < J + 4u ? pf : J + 4u;
             hf = header(pf);
         };
+        uint32_t i0 = pf, h0 = hf;  // the batch whose loads r0 holds
         StripIn r0 = fetch(pf, hf);
         advance();
+        uint32_t i1 = pf, h1 = hf;
         StripIn r1 = fetch(pf, hf);
         advance();
         for (uint32_t k = 0; k < NB; k += 2u) {
-            stage(r0, 0u);
+            stage(r0, i0, h0, 0u);
             __builtin_amdgcn_sched_barrier(0);
+            i0 = pf, h0 = hf;
             r0 = fetch(pf, hf);  // (behind the staging that used them up: the loads land in the registers the loop carries)
             advance();
             STRIP_BARRIER();  // B(k)
-            stage(r1, 1u);
+            stage(r1, i1, h1, 1u);
             __builtin_amdgcn_sched_barrier(0);
+            i1 = pf, h1 = hf;
             r1 = fetch(pf, hf);
             advance();
             STRIP_BARRIER();  // B(k + 1)
@@ -1621,25 +1628,16 @@ __global__ void __launch_bounds__(STRIP_THREADS, 7) k_propagate_strips(Columns c
         }
         if (wv != 0u) return;  // (the levels of a narrow batch hang on each other: one wave, nothing but LDS between two of them)
         const uint32_t cnt = batch_entries(info0);
-        // every level's staged inputs first: they do not hang on anything
-        uint32_t infos[4], rows0[4];
-        Staged in[4];
-        infos[0] = info0, rows0[0] = row0;
-        in[0] = staged(sl, first_sidx(info0));
-#pragma unroll
-        for (uint32_t s2 = 1; s2 < 4u; ++s2) {
+        // a level's staged inputs are asked for before the level above is multiplied: they do not hang on anything
+        Staged cur = staged(sl, first_sidx(info0));
+        uint32_t info = info0, r0w = row0;
+        for (uint32_t s2 = 1; s2 <= cnt; ++s2) {
             const uint4 ev = tab[i + (s2 < cnt ? s2 : 0u)];
-            infos[s2] = __builtin_amdgcn_readfirstlane(ev.z);
-            rows0[s2] = __builtin_amdgcn_readfirstlane(ev.x);
-            in[s2] = staged(sl, 16u * s2 + (q_unit < (infos[s2] & 0x7Fu) ? q_unit : 0u));
-        }
-        level_step(rows0[0], infos[0], q_unit, in[0]);
-#pragma unroll
-        for (uint32_t s2 = 1; s2 < 4u; ++s2) {
-            if (s2 < cnt) {
-                MI_WAVE_LDS_SYNC();  // (the level above is written)
-                level_step(rows0[s2], infos[s2], q_unit, in[s2]);
-            }
+            const uint32_t info_n = __builtin_amdgcn_readfirstlane(ev.z), row_n = __builtin_amdgcn_readfirstlane(ev.x);
+            const Staged nxt = staged(sl, 16u * (s2 < cnt ? s2 : 0u) + (q_unit < (info_n & 0x7Fu) ? q_unit : 0u));
+            level_step(r0w, info, q_unit, cur);
+            MI_WAVE_LDS_SYNC();  // (the level below reads what this one wrote)
+            cur = nxt, info = info_n, r0w = row_n;
         }
     };
     {
@@ -1873,8 +1871,7 @@ hipError_t launch_propagate_wave_tiles(const Columns& c, const uint32_t* parent_
 
 hipError_t launch_propagate_strips(const Columns& c, const uint32_t* parent_idx, const StripDesc* d_strips, const StripRound* d_rounds, uint32_t n_strips,
                                    const uint8_t* node_flags, const uint8_t* changed, const uint8_t* tree_bytes, uint8_t* g_changed_bytes, const float* snap_read,
-                                   float* snap_write, uint32_t snap_rows, bool all_dirty, bool static_opt, bool pretest, hipStream_t stream, unsigned long long* trace,
-                                   const uint8_t* cone_flags) {
+                                   float* snap_write, uint32_t snap_rows, bool all_dirty, bool static_opt, bool pretest, hipStream_t stream, unsigned long long* trace) {
     if (n_strips == 0) return hipSuccess;
     TreeArgs a{};
     a.pretest = pretest && changed && tree_bytes ? 1u : 0u;
@@ -1890,9 +1887,6 @@ hipError_t launch_propagate_strips(const Columns& c, const uint32_t* parent_idx,
     a.all_dirty = all_dirty ? 1u : 0u;
     a.static_opt = static_opt ? 1u : 0u;
     a.trace = trace;
-    // (TreeArgs::chains is the chain tiles' table; the strips have none and carry their per-row snapshot flags there -- a field more would
-    // be a kernel argument more in every tile kernel.  Without flags: every row of the snapshot prefix.)
-    a.chains = reinterpret_cast<const uint32_t*>(snap_write ? cone_flags : nullptr);
     if (all_dirty) MI_LAUNCH((k_propagate_strips<true>), dim3(n_strips), dim3(STRIP_THREADS), 0, stream, c, a, d_strips, d_rounds);
     else MI_LAUNCH((k_propagate_strips<false>), dim3(n_strips), dim3(STRIP_THREADS), 0, stream, c, a, d_strips, d_rounds);
     return hipGetLastError();

@@ -520,7 +520,7 @@ hipError_t launch_propagate_wave_tiles(const Columns& c, const uint32_t* parent_
 // GlobalTransforms stay in LDS for the level below (two levels of STRIP_W_CAP rows).
 constexpr uint32_t STRIP_W_CAP = 128;  // rows of one level of one strip
 constexpr uint32_t STRIP_MAX_ROWS = 1u << 20;  // hierarchies above this are bandwidth: the workgroup tiles (measured: profiles/r06_experiments.md)
-constexpr uint32_t STRIP_TAB_CAP = 56;   // table entries of a strip held in LDS: a strip has at most STRIP_TAB_CAP - 8 (the producer reads ahead)
+constexpr uint32_t STRIP_TAB_CAP = 256;  // table entries of a strip held in LDS: a strip has at most STRIP_TAB_CAP - 8 (the producer reads ahead)
 constexpr uint32_t STRIP_CONSUMERS = 4;  // consumer waves of a strip's workgroup: sixteen rows of a wide round each; one more wave produces
 constexpr uint32_t STRIP_THREADS = 64u * (STRIP_CONSUMERS + 1u);
 struct StripRound {  // 16 bytes

@@ -49,7 +49,7 @@ def test_reference_shapes_through_strips(name, static_opt, pretest):
     sh = W.hierarchy_shape(name)
     plan = run_shape(sh, static_opt, tile_mode=5, pretest=pretest)
     print(name, sh["n"], "nodes", sh["n_levels"], "levels; plan", plan)
-    if sh["n_levels"] <= 40:  # (a strip's rounds -- a level each at least -- live in LDS: deeper hierarchies keep the tiles / the one-wave walk)
+    if sh["n_levels"] <= 200:  # (a strip's rounds -- a level each at least -- live in LDS, 248 of them: deeper hierarchies keep the tiles / the one-wave walk)
         assert plan["launches"] == 1, plan
 
 
@@ -94,8 +94,7 @@ def test_random_forests_through_strips(seed, width, strip_width):
     state = rng.bit_generator.state
     plan, n_levels = _run_forest(parent, rng, 5, pretest=2 if seed % 2 else None)
     print(f"seed {seed} width {width}: {len(parent)} nodes, {n_levels} levels; plan {plan}")
-    if n_levels <= 24:
-        assert plan["launches"] == 1, plan
+    assert plan["launches"] == 1, plan
     rng.bit_generator.state = state
     plan4, _ = _run_forest(parent, rng, 4)  # the same frames through the workgroup tiles
 

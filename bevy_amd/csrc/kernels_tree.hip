@@ -1467,6 +1467,7 @@ __global__ void __launch_bounds__(STRIP_THREADS, 7) k_propagate_strips(Columns c
     if (a.trace) ts[1] = wall_clock64();
     // a batch's header: the info word of its first entry (uniform)
     auto header = [&](uint32_t i) { return (uint32_t)__builtin_amdgcn_readfirstlane(tab[i].z); };
+    auto first_row = [&](uint32_t i) { return (uint32_t)__builtin_amdgcn_readfirstlane(tab[i].x); };
     auto batch_entries = [](uint32_t info) {
         const uint32_t k = (info >> STRIP_BATCH_SHIFT) & 7u;
         return k ? k : 1u;
@@ -1604,7 +1605,9 @@ __global__ void __launch_bounds__(STRIP_THREADS, 7) k_propagate_strips(Columns c
         const uint32_t slot = ((info >> 8) & 0xFFu) + jj;
         const uint32_t ps = in.pin & 0xFFu;
         const Affine gp = lds_affine(lds_g[p ^ 1u], ps);
-        const bool pc = lds_chg[p ^ 1u][ps] != 0;
+        const uint32_t pcv = lds_chg[p ^ 1u][ps];
+        __builtin_amdgcn_sched_barrier(0);  // (the parent's tick is asked for WITH the parent, not where it is used: a round trip less on the chain)
+        const bool pc = pcv != 0u;
         V3 cur_c;
         const bool chg = quad_node_apply(on, root_level, a.static_opt != 0, in.pin >> 8, gp, pc, in.local_c, in.old_c, q_cc, lane, &cur_c);
         if (on) {
@@ -1619,8 +1622,7 @@ __global__ void __launch_bounds__(STRIP_THREADS, 7) k_propagate_strips(Columns c
             }
         }
     };
-    auto batch = [&](uint32_t i, uint32_t info0, uint32_t sl) {
-        const uint32_t row0 = __builtin_amdgcn_readfirstlane(tab[i].x);
+    auto batch = [&](uint32_t i, uint32_t info0, uint32_t row0, uint32_t sl) {
         const bool wide = (info0 & 0x7Fu) > 16u;
         if (wide) {
             level_step(row0, info0, wv * 16u + q_unit, staged(sl, first_sidx(info0)));
@@ -1641,18 +1643,18 @@ __global__ void __launch_bounds__(STRIP_THREADS, 7) k_propagate_strips(Columns c
         }
     };
     {
-        uint32_t pc_i = 0, hc = header(0);
+        uint32_t pc_i = 0, hc = header(0), rc0 = first_row(0);  // (the next batch's header and first row are read before the barrier that opens it)
         for (uint32_t k = 0; k < NB; k += 2u) {
             STRIP_BARRIER();  // B(k)
-            batch(pc_i, hc, 0u);
+            batch(pc_i, hc, rc0, 0u);
             pc_i += batch_entries(hc);
             pc_i = pc_i < J + 4u ? pc_i : J + 4u;
-            hc = header(pc_i);
+            hc = header(pc_i), rc0 = first_row(pc_i);
             STRIP_BARRIER();  // B(k + 1)
-            batch(pc_i, hc, 1u);
+            batch(pc_i, hc, rc0, 1u);
             pc_i += batch_entries(hc);
             pc_i = pc_i < J + 4u ? pc_i : J + 4u;
-            hc = header(pc_i);
+            hc = header(pc_i), rc0 = first_row(pc_i);
         }
     }
     if (a.trace && wv == 0u) {

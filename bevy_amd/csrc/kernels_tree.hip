@@ -1638,7 +1638,9 @@ __global__ void __launch_bounds__(STRIP_THREADS, 7) k_propagate_strips(Columns c
             const uint32_t info_n = __builtin_amdgcn_readfirstlane(ev.z), row_n = __builtin_amdgcn_readfirstlane(ev.x);
             const Staged nxt = staged(sl, 16u * (s2 < cnt ? s2 : 0u) + (q_unit < (info_n & 0x7Fu) ? q_unit : 0u));
             level_step(r0w, info, q_unit, cur);
-            MI_WAVE_LDS_SYNC();  // (the level below reads what this one wrote)
+            // (the level below reads what this one wrote: LDS executes one wave's operations in order, so the read needs no wait for the
+            // write -- only the compiler must keep their order)
+            __builtin_amdgcn_wave_barrier();
             cur = nxt, info = info_n, r0w = row_n;
         }
     };

@@ -1383,12 +1383,13 @@ struct StripIn {
 // it, 2 - 3.5 ns apiece (tools/probes/issue_rate_probe.hip: a dependent v_fma 3.5 ns, an independent one 2.1, a dependent LDS read 25, an LDS
 // hand-over through a barrier 70): with everything in ONE wave's stream -- a round's 14 loads and their addresses, From(Transform), the
 // parent's read, the product, the compare, the stores -- a round was 0.72 us whatever its rows.  So the producer does everything that
-// does not hang on the level above -- the loads (two batches ahead, in registers), From(Transform), the rule's inputs -- and leaves a
+// does not hang on the level above -- the loads (a batch ahead of the one being staged, in registers), From(Transform), the rule's inputs -- and leaves a
 // BATCH ready in one of two LDS slots of 64 rows: one round of up to 64 rows, or up to four consecutive NARROW levels (<= 16 rows
 // each) of the strip -- the cone of a deep tree is a dozen levels of one to three rows.  The consumers run the dependent chain only:
 // parent from LDS, product, set_if_neq, the level's results into LDS for the level below and out to memory, a row per quad of lanes, a
 // column of the affine each; a wide round sixteen rows per wave, the levels of a narrow batch one behind the other in wave 0 with
-// nothing but LDS between them (~0.2 us a level).  One workgroup barrier per batch hands a slot over each way.
+// nothing but LDS between them.  One workgroup barrier per batch hands a slot over each way.  What is left is consumer wave 0's
+// instruction stream: ~0.4 us a level, narrow or wide (profiles/r06_experiments.md section 5).
 struct StripStage {
     float4 local[2][64 * 3];  // From(Transform)
     float4 old[2][64 * 3];    // the GlobalTransform before this frame (the cone's rows: from the snapshot)

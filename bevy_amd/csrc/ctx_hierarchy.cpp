@@ -384,11 +384,13 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
         uint32_t max_extra = 1000;
         if (const char* ev = getenv("MI_STRIP_EXTRA")) max_extra = (uint32_t)std::max(0, atoi(ev));
         const bool modes_ok = ctx->tile_mode == 0 || ctx->tile_mode == 2 || ctx->tile_mode == 3;
-        // by default: where the tiles need dependent launches (a lopsided tree), or the hierarchy is deep enough for the tiles' chains and
-        // level steps to be what a frame costs (measured, all-dirty frame, kernel us: large_tree 36.3 -> 17.8, deep_tree 26.7 -> 22.9,
-        // update_leaves 19.4 -> 16.0; a root with 500 x 500 descendants 10.2 -> 13.5 and the 1.4 M-node 4-ary tree 32.9 -> 67.9 the other way)
+        // by default: where the tiles need dependent launches (a lopsided tree), or a deep hierarchy has more tiles than the chip holds at
+        // once (2 048: the launch then runs two generations of tiles' chains).  Measured, all-dirty frame, kernel us: large_tree 36.3 ->
+        // 17.8, deep_tree 26.7 -> 22.9, update_leaves (18 levels, 2 065 tiles) 19.4 -> 16.0; the other way: a full binary tree of 16
+        // levels (517 tiles) 8.9 -> 10.1 us per frame, a root with 500 x 500 descendants 10.2 -> 13.5, the 1.4 M-node 4-ary tree 32.9 ->
+        // 67.9 (tools/probes/mid_shapes_probe.py, profiles/r06b/).
         const bool wanted = ctx->tile_mode == 5 || (modes_ok && !ctx->wave_forest && !ctx->narrow && !ctx->by_levels && n <= STRIP_MAX_ROWS &&
-                                                    (ctx->groups.size() >= 2 || n_levels >= 16));
+                                                    (ctx->groups.size() >= 2 || (n_levels >= 16 && !ctx->groups.empty() && ctx->groups.front().count > 2048u)));
         for (size_t wi_ = 0; wi_ < widths.size() && wanted && !ctx->by_levels && n > 0 && n < (1u << 24) && !ctx->strip_plan; ++wi_) {  // (the kernel's 24-bit row offsets)
             const bool last_width = wi_ + 1 == widths.size();
             StripPlan sp;

@@ -380,9 +380,6 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
         const uint32_t resident = 5u * 256u;
         std::vector<uint32_t> widths = {64u, 128u};
         if (const char* ev = getenv("MI_STRIP_W")) widths = {std::min((uint32_t)std::max(1, atoi(ev)), STRIP_W_CAP)};
-        const bool narrow_batches = !getenv("MI_STRIP_NO_BATCHES");
-        uint32_t max_extra = 1000;
-        if (const char* ev = getenv("MI_STRIP_EXTRA")) max_extra = (uint32_t)std::max(0, atoi(ev));
         const bool modes_ok = ctx->tile_mode == 0 || ctx->tile_mode == 2 || ctx->tile_mode == 3;
         // by default: where the tiles need dependent launches (a lopsided tree), or a deep hierarchy has more tiles than the chip holds at
         // once (2 048: the launch then runs two generations of tiles' chains).  Measured, all-dirty frame, kernel us: large_tree 36.3 ->
@@ -394,7 +391,7 @@ int32_t mi_upload_hierarchy(mi_ctx* ctx, uint32_t n, const uint32_t* parent_idx,
         for (size_t wi_ = 0; wi_ < widths.size() && wanted && !ctx->by_levels && n > 0 && n < (1u << 24) && !ctx->strip_plan; ++wi_) {  // (the kernel's 24-bit row offsets)
             const bool last_width = wi_ + 1 == widths.size();
             StripPlan sp;
-            if (!plan_strips(n, n_levels, level_offsets, parent_idx, first_child.data(), widths[wi_], narrow_batches, max_extra, sp)) continue;
+            if (!plan_strips(n, n_levels, level_offsets, parent_idx, first_child.data(), widths[wi_], true, 1000u, sp)) continue;
             if (!last_width && sp.strips.size() > resident) continue;
             if ((rc = ensure(ctx, ctx->strips, sp.strips.size() * sizeof(StripDesc)))) return rc;
             if ((rc = upload(ctx, ctx->strips.p, sp.strips.data(), sp.strips.size() * sizeof(StripDesc)))) return rc;

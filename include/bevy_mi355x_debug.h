@@ -34,7 +34,7 @@ int32_t mi_profile_burst(mi_ctx* ctx, uint32_t first_n);
 int32_t mi_profile_read(mi_ctx* ctx, uint32_t* inout_n, uint64_t* launches, double* total_ms);
 const char* mi_profile_kernel_name(uint32_t k);
 
-/* How the NEXT mi_upload_hierarchy plans mi_propagate: 0 = subtree tiles (a subtree too big for one is cut; a forest of small trees: a wave per tree; a deep or lopsided tree up to 2^20 rows: strips; default), 1 = always level by level, 2 = as 0, 3 = as 0 with the streamed-level thresholds at their test values (2^20 / 2^21 rows), 4 = as 0 without the wave tiles of a forest of small trees and without strips, 5 = strips (one launch of independent waves, kernels.h) wherever they can be planned. */
+/* How the NEXT mi_upload_hierarchy plans mi_propagate: 0 = subtree tiles (a subtree too big for one is cut; a forest of small trees: a wave per tree; a deep or lopsided tree up to 2^20 rows: strips; default), 1 = always level by level, 2 = as 0, 3 = as 0 with the streamed-level thresholds at their test values (2^20 / 2^21 rows), 4 = as 0 without the wave tiles of a forest of small trees and without strips, 5 = strips (one launch of independent workgroups, kernels.h) wherever they can be planned.  (Environment, read at mi_upload_hierarchy: MI_STRIP_W = rows to a level of a strip, 1 .. 128, instead of the planner's own 64 / 128 -- the tests' knob.) */
 int32_t mi_debug_set_tile_mode(mi_ctx* ctx, int32_t mode);
 /* Per-tile phase timestamps of the light tile kernel (8 x s_memrealtime, 100 MHz, per tile of the first launch).  enable != 0
  * allocates the buffer (mi_propagate then fills it every frame); out != NULL copies n_tiles x 8 stamps out; enable == 0 with

@@ -38,7 +38,7 @@ for wl in $WLS; do
   echo "python bench.py $ARGS --steps 50 --warmup 10 --blocks 4 $COMMON" > $P/$wl.cmd
   timeout -k 5 180 rocprofv3 --kernel-trace --stats --output-format csv -d $P/$wl -o $wl -- \
       python bench.py $ARGS --steps 50 --warmup 10 --blocks 4 $COMMON > $P/$wl.log 2>&1
-  case $wl in batching|batching_sorted_1k|batching_sorted_4k|batching_sorted_64k|lights|tree_shape_*) continue ;; esac
+  case $wl in batching|batching_sorted_1k|batching_sorted_4k|batching_sorted_64k|lights|tree_shape_chain|tree_shape_humanoids*|tree_shape_tree_4ary*) continue ;; esac  # (PMC passes for the streaming kernels and the strips)
   for ctr in FETCH_SIZE WRITE_SIZE; do
     timeout -k 5 180 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $P/${wl}_$ctr -o $wl -- \
         python bench.py $ARGS --steps 10 --warmup 2 --blocks 2 $COMMON > $P/${wl}_$ctr.log 2>&1
